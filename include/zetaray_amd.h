@@ -1,0 +1,181 @@
+/*
+ * zetaray_amd.h -- C-ABI of the MI355X-native ReSTIR path-tracing core (libzetaray_amd.so).
+ *
+ * Drop-in boundary for the hot path of alipbcs/ZetaRay's render passes.  Each entry point replaces one piece of
+ * the reference's RenderPass surface (Source/ZetaRenderPass/RenderPass.h:9-80):
+ *
+ *   zr_scene_*        <- buffers a pass fetches from SharedShaderResources by name
+ *                        (Source/ZetaCore/Scene/SceneRenderer.h:17-32; RtAccelerationStructure.cpp:121-200, 318-506)
+ *   zr_gbuffer_*      <- GBufferData textures (Source/ZetaRenderer/Default/DefaultRendererImpl.h:80-130,
+ *                        Source/ZetaRenderer/Default/GBuffer.cpp:41-76)
+ *   zr_pass_create/init/resize/reset_temporal/set_params/render/get_output/destroy
+ *                     <- Pass::Pass(), Init(), OnWindowResized(), ResetTemporal(), Set*(), Render(CommandList&),
+ *                        GetOutput(SHADER_OUT_RES), Reset()
+ *                        (GBufferRT.h:27-47, PreLighting.h:28-58,97-128, IndirectLighting.h:72-108, DirectLighting.h:39-57)
+ *
+ * Conventions: plain pointers and sizes, no torch / D3D12 types.  All functions return 0 on success or a nonzero
+ * zr_status; zr_last_error() returns a thread-local message.  (The reference aborts through Check(); the C++
+ * RenderPass-shaped wrapper in zetaray_amd/host converts nonzero into that behaviour.)  zr_pass_render only
+ * enqueues work on the given hipStream_t and never synchronises the host -- the analogue of recording into a
+ * CommandList.  Distinct handles may be driven from distinct host threads; one handle is externally serialised
+ * (same contract as Source/ZetaCore/Core/RenderGraph.cpp:442-541).
+ *
+ * There is no CPU fallback: every compute entry point fails with ZR_ERR_NO_DEVICE when no HIP device is usable.
+ */
+#ifndef ZETARAY_AMD_H
+#define ZETARAY_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+#include "zr_wire.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ZR_ABI_VERSION 1
+
+typedef enum zr_status {
+    ZR_OK = 0,
+    ZR_ERR_INVALID_ARG = 1,
+    ZR_ERR_NO_DEVICE = 2,
+    ZR_ERR_HIP = 3,
+    ZR_ERR_OOM = 4,
+    ZR_ERR_UNSUPPORTED = 5,
+    ZR_ERR_NOT_INITIALIZED = 6
+} zr_status;
+
+typedef struct zr_scene   zr_scene;
+typedef struct zr_gbuffer zr_gbuffer;
+typedef struct zr_pass    zr_pass;
+
+/* pass kinds: the four hot-path RenderPass nodes of the reference */
+typedef enum zr_pass_kind {
+    ZR_PASS_GBUFFER     = 0,   /* GBufferRT          */
+    ZR_PASS_PRELIGHTING = 1,   /* PreLighting + EmissiveTriangleAliasTable */
+    ZR_PASS_DI_EMISSIVE = 2,   /* DirectLighting     */
+    ZR_PASS_DI_SKY      = 3,   /* SkyDI              */
+    ZR_PASS_INDIRECT    = 4    /* IndirectLighting   */
+} zr_pass_kind;
+
+/* IndirectLighting::INTEGRATOR, reference IndirectLighting.h:40-46 */
+typedef enum zr_integrator {
+    ZR_INTEGRATOR_PATH_TRACING = 0,
+    ZR_INTEGRATOR_RESTIR_GI    = 1,
+    ZR_INTEGRATOR_RESTIR_PT    = 2
+} zr_integrator;
+
+/* CB_IND_FLAGS, reference IndirectLighting_Common.h:38-49 */
+#define ZR_IND_TEMPORAL_RESAMPLE       (1u << 0)
+#define ZR_IND_SPATIAL_RESAMPLE        (1u << 1)
+#define ZR_IND_STOCHASTIC_MULTI_BOUNCE (1u << 2)
+#define ZR_IND_RUSSIAN_ROULETTE        (1u << 3)
+#define ZR_IND_BOILING_SUPPRESSION     (1u << 4)
+#define ZR_IND_PATH_REGULARIZATION     (1u << 5)
+#define ZR_IND_SORT_TEMPORAL           (1u << 6)
+#define ZR_IND_SORT_SPATIAL            (1u << 7)
+
+/* Pass parameters.  Defaults = the reference's (IndirectLighting.h:231-244, IndirectLighting.cpp:146-165). */
+typedef struct zr_params {
+    uint32_t flags;                 /* ZR_IND_* */
+    uint32_t max_non_tr_bounces;    /* 3 */
+    uint32_t max_glossy_tr_bounces; /* 4 */
+    uint32_t m_max_temporal;        /* 10 */
+    uint32_t m_max_spatial;         /* 8 */
+    float    alpha_min;             /* 0.175^2 */
+    uint32_t presampling;           /* SetLightPresamplingParams(bool, numSets, setSize) */
+    uint32_t num_sample_sets;       /* 128 */
+    uint32_t sample_set_size;       /* 512 */
+    uint32_t reserved[7];
+} zr_params;
+
+/* outputs, GetOutput(SHADER_OUT_RES) */
+typedef enum zr_output {
+    ZR_OUT_FINAL = 0               /* RGBA32F, linear radiance (reference: *_FINAL textures) */
+} zr_output;
+
+/* G-buffer planes (reference GBufferData::GBUFFER order and DXGI formats, DefaultRendererImpl.h:82-109) */
+typedef enum zr_gbuffer_plane {
+    ZR_GB_BASE_COLOR = 0,   /* R8G8B8A8_UNORM   4 B  (a = subsurface)                        */
+    ZR_GB_NORMAL,           /* R16G16_UNORM     4 B  octahedral                              */
+    ZR_GB_METALLIC_ROUGHNESS,/* R8G8_UNORM      2 B  x = flag byte, y = roughness            */
+    ZR_GB_MOTION_VECTOR,    /* R16G16_SNORM     4 B                                          */
+    ZR_GB_EMISSIVE_COLOR,   /* R11G11B10_FLOAT  4 B  written only when emissive              */
+    ZR_GB_IOR,              /* R8_UNORM         1 B  written only when transmissive          */
+    ZR_GB_COAT,             /* R16G16B16A16_UINT 8 B written only when coated                */
+    ZR_GB_DEPTH,            /* R32_FLOAT        4 B  view z (or t with DoF); miss = FLT_MAX  */
+    ZR_GB_TRI_DIFF_GEO_A,   /* R32G32B32A32_UINT 16 B                                        */
+    ZR_GB_TRI_DIFF_GEO_B,   /* R32G32_UINT      8 B                                          */
+    ZR_GB_COUNT
+} zr_gbuffer_plane;
+
+/* bytes per pixel of each plane */
+static const uint32_t ZR_GB_PLANE_BYTES[ZR_GB_COUNT] = {4, 4, 2, 4, 4, 1, 8, 4, 16, 8};
+
+/* host view of one frame's G-buffer (oracle input/output and zr_gbuffer_download target); row-major, tightly packed */
+typedef struct zr_gbuffer_planes {
+    uint32_t width, height;
+    void*    plane[ZR_GB_COUNT];
+} zr_gbuffer_planes;
+
+/* per-frame ray counters (unit of work = one BVH query) */
+typedef struct zr_counters {
+    uint64_t n_closest;
+    uint64_t n_shadow;
+} zr_counters;
+
+/* ---- library ---- */
+int         zr_abi_version(void);
+const char* zr_last_error(void);
+int         zr_device_count(int* count);
+
+/* ---- scene: device copies of VB/IB/MeshInstance/Material/Emissive/AliasTable + BVH ---- */
+int zr_scene_create(int device, const zr_scene_desc* desc, zr_scene** out);
+int zr_scene_destroy(zr_scene* scene);
+/* EmissiveTriangleAliasTable::Render (PreLighting.cpp:512-585): upload a host-built table ... */
+int zr_scene_set_alias_table(zr_scene* scene, const zr_alias_entry* entries, uint32_t n);
+/* ... or build it from per-triangle power exactly like PreLighting.cpp:27-158 (host side, bit-exact) */
+int zr_alias_table_build(const float* power, uint32_t n, uint32_t align_phase, zr_alias_entry* out_entries);
+int zr_scene_get_alias_table(const zr_scene* scene, zr_alias_entry* out_entries, uint32_t n);
+/* BVH introspection for tests / the CPU baseline */
+int zr_scene_bvh_info(const zr_scene* scene, uint32_t* num_nodes, uint32_t* num_tris, uint32_t* max_depth);
+
+/* ---- G-buffer ---- */
+int zr_gbuffer_create(int device, uint32_t width, uint32_t height, zr_gbuffer** out);
+int zr_gbuffer_destroy(zr_gbuffer* gb);
+int zr_gbuffer_download(const zr_gbuffer* gb, void* hip_stream, zr_gbuffer_planes* host_planes);
+int zr_gbuffer_device_plane(const zr_gbuffer* gb, int plane, void** dev_ptr);
+
+/* ---- passes ---- */
+int zr_params_default(zr_params* p);
+int zr_pass_create(int kind, int device, zr_pass** out);
+int zr_pass_init(zr_pass* pass, uint32_t width, uint32_t height, int integrator);
+int zr_pass_resize(zr_pass* pass, uint32_t width, uint32_t height);   /* OnWindowResized + ResetTemporal */
+int zr_pass_reset_temporal(zr_pass* pass);
+int zr_pass_set_params(zr_pass* pass, const zr_params* params);
+/* Render(CommandList&): enqueue only.  cb = the 544-byte cbFrameConstants of this frame (host pointer, copied). */
+int zr_pass_render(zr_pass* pass, void* hip_stream, const zr_frame_constants* cb, const zr_scene* scene,
+                   zr_gbuffer* gbuffer);
+int zr_pass_get_output(const zr_pass* pass, int which, void** dev_ptr, uint32_t* width, uint32_t* height,
+                       uint32_t* bytes_per_pixel);
+int zr_pass_download_output(const zr_pass* pass, int which, void* hip_stream, void* host_dst, size_t bytes);
+/* ray counters accumulated since the last call (device -> host copy; synchronises the stream) */
+int zr_pass_read_counters(zr_pass* pass, void* hip_stream, zr_counters* out, int reset);
+/* GpuTimer analogue (Source/ZetaCore/Core/GpuTimer.h:28-45): per-kernel hipEvent timing of the last render */
+int zr_pass_enable_timing(zr_pass* pass, int enable);
+int zr_pass_get_timings(zr_pass* pass, uint32_t max_entries, const char** names, float* ms, uint32_t* launches,
+                        uint32_t* count);
+int zr_pass_destroy(zr_pass* pass);
+
+/* ---- ray-query microbenchmark surface (bench.py roofline leg / parity tests of traversal) ---- */
+/* rays: n x 8 floats (ox,oy,oz,tmin,dx,dy,dz,tmax) device pointer; hits: n x 4 uint32 (t bits, u bits, v bits, tri) */
+int zr_trace_closest(const zr_scene* scene, void* hip_stream, const float* d_rays, uint32_t n, uint32_t mask,
+                     uint32_t* d_hits);
+int zr_trace_any(const zr_scene* scene, void* hip_stream, const float* d_rays, uint32_t n, uint32_t mask,
+                 uint32_t* d_occluded);
+
+#ifdef __cplusplus
+}
+#endif
+
+#endif /* ZETARAY_AMD_H */

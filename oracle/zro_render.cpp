@@ -1,0 +1,768 @@
+// ORACLE -- test infrastructure only.  Nothing under oracle/ is linked into, imported by, or called from the product
+// library; only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg use it, as the checker.
+//
+// PARITY STATUS: the reference (alipbcs/ZetaRay) has no executable CPU implementation of this path and no golden
+// vectors.  What IS pinned against the reference: the alias table (property tests of
+// Tests/TestAliasTable.cpp + a build of the reference's own AliasTable/Kahan sources in oracle/_ref when they
+// compile) and the octahedral round trip (Tests/TestMath.cpp:485-508).  Radiance, G-buffer and hit results are
+// "parity unpinned": this restatement follows the shaders line by line but cannot be checked against them.
+//
+// zro_render.cpp: CPU restatement of
+//   K1  Source/ZetaRenderPass/GBuffer/GBufferRT_Inline.hlsl + GBufferRT.hlsli            (primary-hit G-buffer)
+//   K2  Source/ZetaRenderPass/PreLighting/EstimateTriEmissivePower.hlsl                   (emissive power)
+//       Source/ZetaRenderPass/PreLighting/PreLighting.cpp:27-158, ZetaCore/Math/Sampling.cpp:13-50,
+//       ZetaCore/Math/Common.cpp:72-139                                                   (alias table, Kahan)
+//   K9  Source/ZetaRenderPass/IndirectLighting/PathTracer/PathTracer.hlsl,
+//       ReSTIR_GI/PathTracing.hlsli, ReSTIR_GI/ReSTIR_GI_NEE.hlsli, NEE.hlsli             (1-spp path tracer)
+// and the C entry points the tests bind with ctypes.
+#include <cstdio>
+#include <cstdlib>
+#include <chrono>
+#include "zro_scene.h"
+#include "../include/zetaray_amd.h"
+
+using namespace zro;
+
+//--------------------------------------------------------------------------------------
+// Alias table (CPU side of the reference hot path)
+//--------------------------------------------------------------------------------------
+
+// Math::KahanSum, Common.cpp:72-139.  The reference sums with 8 AVX2 lanes after a scalar head that runs until the
+// pointer is 32-byte aligned; `align_phase` = number of floats in that head (0 for the aligned allocations the
+// reference uses).  The lane structure is reproduced exactly so the rounding is identical.
+static float KahanSumRef(const float* data, int64_t N, int64_t align_phase)
+{
+    float sum = 0.0f, compensation = 0.0f;
+    int64_t start = align_phase < N ? align_phase : N;
+    for (int64_t i = 0; i < start; i++)
+    {
+        float corrected = data[i] - compensation;
+        float newSum = sum + corrected;
+        compensation = (newSum - sum) - corrected;
+        sum = newSum;
+    }
+    int64_t numToSumSIMD = N - start;
+    numToSumSIMD -= numToSumSIMD & 15;
+    float vSum[8] = {0}, vComp[8] = {0};
+    for (int64_t c = start; c < start + numToSumSIMD; c += 16)
+        for (int l = 0; l < 8; l++)
+        {
+            float vCurr = data[c + l] + data[c + 8 + l];
+            float vCorrected = vCurr - vComp[l];
+            float vNewSum = vSum[l] + vCorrected;
+            vComp[l] = (vNewSum - vSum[l]) - vCorrected;
+            vSum[l] = vNewSum;
+        }
+    for (int i = 0; i < 8; i++)
+    {
+        float corrected = vSum[i] - compensation - vComp[i];
+        float newSum = sum + corrected;
+        compensation = (newSum - sum) - corrected;
+        sum = newSum;
+    }
+    for (int64_t i = start + numToSumSIMD; i < N; i++)
+    {
+        float corrected = data[i] - compensation;
+        float newSum = sum + corrected;
+        compensation = (newSum - sum) - corrected;
+        sum = newSum;
+    }
+    return sum;
+}
+
+// BuildAliasTable, PreLighting.cpp:27-158 (Vose, LIFO index stacks)
+static void BuildAliasTableRef(std::vector<float>& probs, zr_alias_entry* table, int64_t align_phase)
+{
+    const int64_t N = (int64_t)probs.size();
+    const float oneDivN = 1.0f / (float)N;
+    // AliasTable_Normalize, Sampling.cpp:13-50
+    const float sum = KahanSumRef(probs.data(), N, align_phase);
+    const float sumRcp = (float)N / sum;
+    for (int64_t i = 0; i < N; i++) probs[i] *= sumRcp;
+
+    for (int64_t i = 0; i < N; i++) { table[i].cached_p_orig = probs[i] * oneDivN; table[i].alias = 0xffffffffu; table[i].p_curr = 0; }
+    std::vector<uint32_t> larger, smaller;
+    larger.reserve(N); smaller.reserve(N);
+    for (int64_t i = 0; i < N; i++)
+    {
+        if (probs[i] < 1.0f) smaller.push_back((uint32_t)i);
+        else larger.push_back((uint32_t)i);
+    }
+    while (!smaller.empty() && !larger.empty())
+    {
+        const uint32_t smallerIdx = smaller.back(); smaller.pop_back();
+        const float smallerProb = probs[smallerIdx];
+        const uint32_t largerIdx = larger.back();
+        float largerProb = probs[largerIdx];
+        table[smallerIdx].alias = largerIdx;
+        table[smallerIdx].p_curr = smallerProb;
+        largerProb = (smallerProb + largerProb) - 1.0f;
+        probs[largerIdx] = largerProb;
+        if (largerProb < 1.0f) { larger.pop_back(); smaller.push_back(largerIdx); }
+    }
+    while (!larger.empty()) { uint32_t idx = larger.back(); larger.pop_back(); table[idx].alias = idx; table[idx].p_curr = 1.0f; }
+    while (!smaller.empty()) { uint32_t idx = smaller.back(); smaller.pop_back(); table[idx].alias = idx; table[idx].p_curr = 1.0f; }
+    for (int64_t i = 0; i < N; i++) table[i].cached_p_alias = table[table[i].alias].cached_p_orig;
+}
+
+//--------------------------------------------------------------------------------------
+// Packing helpers for G-buffer planes (D3D format conversion rules pinned by the ABI)
+//--------------------------------------------------------------------------------------
+static inline uint32_t PackUnorm8(float f) { return Math::FloatToUNorm8(f); }
+static inline uint32_t PackUnorm16(float f) { return (uint32_t)Math::FloatToUNorm16(f); }
+static inline uint32_t PackSnorm16(float f)
+{
+    if (zr_isnan(f)) f = 0;
+    f = zr_clamp(f, -1.0f, 1.0f);
+    f = f * 32767.0f;
+    int32_t i = (int32_t)(f >= 0 ? f + 0.5f : f - 0.5f);
+    return (uint32_t)(uint16_t)(int16_t)i;
+}
+// float -> unsigned small float with `mbits` mantissa bits, 5 exponent bits (R11G11B10_FLOAT), round-to-nearest-even
+static inline uint32_t PackUFloat(float f, int mbits)
+{
+    uint32_t x = zr_asuint(f);
+    if (x & 0x80000000u) return 0;                       // negative (and -0) -> 0
+    if (x >= 0x7f800000u) return x > 0x7f800000u ? ((0x1fu << mbits) | 1u) : (0x1fu << mbits);   // nan / inf
+    const int shift = 23 - mbits;
+    if (x >= 0x47800000u) return (0x1eu << mbits) | ((1u << mbits) - 1u);   // >= 65536 -> max finite
+    if (x < 0x38800000u)
+    {
+        // denormal in the target format: value / 2^-14 * 2^mbits
+        if (x < 0x33000000u) return 0;
+        uint32_t e = x >> 23;
+        uint32_t m = (x & 0x007fffffu) | 0x00800000u;
+        uint32_t sh = (uint32_t)shift + (113u - e);
+        if (sh > 24) return 0;
+        uint32_t r = m >> sh;
+        uint32_t rem = m & ((1u << sh) - 1u);
+        uint32_t half = 1u << (sh - 1u);
+        if (rem > half || (rem == half && (r & 1u))) r++;
+        return r;
+    }
+    uint32_t r = (x - 0x38000000u) >> shift;
+    uint32_t rem = x & ((1u << shift) - 1u);
+    uint32_t half = 1u << (shift - 1);
+    if (rem > half || (rem == half && (r & 1u))) r++;
+    uint32_t maxv = (0x1eu << mbits) | ((1u << mbits) - 1u);
+    return r > maxv ? maxv : r;
+}
+static inline uint32_t PackR11G11B10F(float3 c) { return PackUFloat(c.x, 6) | (PackUFloat(c.y, 6) << 11) | (PackUFloat(c.z, 5) << 22); }
+
+// GBuffers.hlsli:52-68
+static inline float EncodeMetallic(float metalness, bool isTransmissive, float3 emissive, float trDepth, float subsurface, float coat_weight)
+{
+    bool isMetal = metalness >= MIN_METALNESS_METAL;
+    bool isEmissive = dot(emissive, emissive) > 0;
+    uint32_t ret = isTransmissive ? 1u : 0u;
+    ret |= ((uint32_t)isEmissive << 1);
+    ret |= ((uint32_t)(trDepth > 0) << 3);
+    ret |= ((uint32_t)(subsurface > 0) << 4);
+    ret |= ((uint32_t)(coat_weight > 0) << 5);
+    ret |= ((uint32_t)isMetal << 7);
+    return (float)ret / 255.0f;
+}
+static inline float EncodeIOR(float ior) { return (ior - MIN_IOR) / (MAX_IOR - MIN_IOR); }
+static inline float DecodeIOR(float enc) { return zr_fma(enc, MAX_IOR - MIN_IOR, MIN_IOR); }
+
+struct GBView
+{
+    uint32_t w, h;
+    uint32_t* baseColor; uint32_t* normal; uint16_t* mr; uint32_t* motion; uint32_t* emissive; uint8_t* ior;
+    uint16_t* coat; float* depth; uint32_t* triA; uint32_t* triB;
+    GBView(const zr_gbuffer_planes* p)
+    {
+        w = p->width; h = p->height;
+        baseColor = (uint32_t*)p->plane[ZR_GB_BASE_COLOR]; normal = (uint32_t*)p->plane[ZR_GB_NORMAL];
+        mr = (uint16_t*)p->plane[ZR_GB_METALLIC_ROUGHNESS]; motion = (uint32_t*)p->plane[ZR_GB_MOTION_VECTOR];
+        emissive = (uint32_t*)p->plane[ZR_GB_EMISSIVE_COLOR]; ior = (uint8_t*)p->plane[ZR_GB_IOR];
+        coat = (uint16_t*)p->plane[ZR_GB_COAT]; depth = (float*)p->plane[ZR_GB_DEPTH];
+        triA = (uint32_t*)p->plane[ZR_GB_TRI_DIFF_GEO_A]; triB = (uint32_t*)p->plane[ZR_GB_TRI_DIFF_GEO_B];
+    }
+};
+
+static inline float3 Row(const float* m, int r) { return f3(m[4 * r], m[4 * r + 1], m[4 * r + 2]); }
+static inline float3 Mul3x4(const float* m, float3 p)
+{
+    // mul(float3x4, float4(p, 1)): row . (p, 1), left to right
+    return f3(m[0] * p.x + m[1] * p.y + m[2] * p.z + m[3], m[4] * p.x + m[5] * p.y + m[6] * p.z + m[7],
+              m[8] * p.x + m[9] * p.y + m[10] * p.z + m[11]);
+}
+
+//--------------------------------------------------------------------------------------
+// K1: G-buffer (GBufferRT_Inline.hlsl:204-287, TracePrimaryHit :72-198, GBufferRT.hlsli:102-282)
+//--------------------------------------------------------------------------------------
+static void RenderGBuffer(const Scene& sc, const zr_frame_constants& g, GBView gb)
+{
+    BSDF::g_rho = &sc.rhoLUT;
+    const float2 renderDim = {(float)g.render_width, (float)g.render_height};
+    const float2 jitter = {g.curr_camera_jitter[0], g.curr_camera_jitter[1]};
+    const float3 vbx = Row(g.curr_view, 0), vby = Row(g.curr_view, 1), vbz = Row(g.curr_view, 2);
+
+    for (uint32_t y = 0; y < g.render_height; y++)
+    for (uint32_t x = 0; x < g.render_width; x++)
+    {
+        const size_t px = (size_t)y * g.render_width + x;
+        float2 lensSample = {0, 0};
+        float3 rayDirCS = RT::GeneratePinholeCameraRay_CS((int)x, (int)y, renderDim, g.aspect_ratio, g.tan_half_fov, jitter);
+        float3 rayOrigin = f3(g.camera_pos);
+        if (g.dof)
+        {
+            uint32_t hx = x, hy = y, hz = x; zr_pcg3d(&hx, &hy, &hz);
+            RNG rng = RNG::Init(hz, hy, g.frame_num);
+            lensSample = Sampling::UniformSampleDiskConcentric(rng.Uniform2D());
+            lensSample = lensSample * g.lens_radius;
+            rayOrigin += mad3(lensSample.x, vbx, lensSample.y * vby);
+            float3 focalPoint = g.focus_depth * rayDirCS;
+            rayDirCS = focalPoint - f3(lensSample.x, lensSample.y, 0);
+        }
+        float3 rayDir = mad3(rayDirCS.x, vbx, mad3(rayDirCS.y, vby, rayDirCS.z * vbz));
+        rayDir = normalize(rayDir);
+
+        sc.counters.n_closest++;
+        Scene::RawHit h = sc.Trace(rayOrigin, rayDir, 0.0f, ZR_FLT_MAX, ZR_SUBGROUP_ALL, false);
+
+        if (!h.hit)
+        {
+            gb.depth[px] = ZR_FLT_MAX;
+            // g_metallicRoughness[DTid].x = 4 / 255 (invalid flag); y is left untouched by the reference -> pinned to 0
+            gb.mr[px] = (uint16_t)PackUnorm8(4.0f / 255.0f);
+            float3 prevCameraPos = f3(g.prev_view_inv[3], g.prev_view_inv[7], g.prev_view_inv[11]);
+            float3 motion = f3(g.camera_pos) - prevCameraPos;
+            float2 motionNDC = motion.z > 0 ? f2(motion.x / (motion.z * g.tan_half_fov), motion.y / (motion.z * g.tan_half_fov)) : f2(0, 0);
+            motionNDC.x /= g.aspect_ratio;
+            float2 motionUV = Math::UVFromNDC(motionNDC);
+            gb.motion[px] = PackSnorm16(motionUV.x) | (PackSnorm16(motionUV.y) << 16);
+            // planes the reference does not write on a miss are pinned to 0
+            gb.baseColor[px] = 0; gb.normal[px] = 0; gb.emissive[px] = 0; gb.ior[px] = 0;
+            for (int k = 0; k < 4; k++) { gb.coat[4 * px + k] = 0; gb.triA[4 * px + k] = 0; }
+            gb.triB[2 * px] = gb.triB[2 * px + 1] = 0;
+            continue;
+        }
+
+        const WorldTri& T = sc.tris[h.tri];
+        const uint32_t meshIdx = T.mesh_idx, primIdx = T.prim_idx;
+        const float2 bary = {h.u, h.v};
+        const zr_mesh_instance& md = sc.instances[meshIdx];
+        uint32_t tri = primIdx * 3 + md.base_idx_offset;
+        const zr_vertex& V0 = sc.vertices[sc.indices[tri] + md.base_vtx_offset];
+        const zr_vertex& V1 = sc.vertices[sc.indices[tri + 1] + md.base_vtx_offset];
+        const zr_vertex& V2 = sc.vertices[sc.indices[tri + 2] + md.base_vtx_offset];
+
+        float4 q = normalize(Math::DecodeNormalized4(md.rotation));
+        const float3 scale = f3(zr_f16_to_f32(md.scale[0]), zr_f16_to_f32(md.scale[1]), zr_f16_to_f32(md.scale[2]));
+        const float3 translation = f3(md.translation);
+
+        float2 uv0 = {V0.uv[0], V0.uv[1]}, uv1 = {V1.uv[0], V1.uv[1]}, uv2 = {V2.uv[0], V2.uv[1]};
+        float2 uv = uv0 + bary.x * (uv1 - uv0) + bary.y * (uv2 - uv0);
+        (void)uv;
+
+        float3 v0_n = Math::DecodeOct32(V0.normal), v1_n = Math::DecodeOct32(V1.normal), v2_n = Math::DecodeOct32(V2.normal);
+        float3 normal = v0_n + bary.x * (v1_n - v0_n) + bary.y * (v2_n - v0_n);
+        const float3 scaleInv = f3(1.0f / scale.x, 1.0f / scale.y, 1.0f / scale.z);
+        normal *= scaleInv;
+        normal = Math::RotateVector(normal, q);
+        normal = normalize(normal);
+
+        float3 v0W = Math::TransformTRS(f3(V0.pos), translation, q, scale);
+        float3 v1W = Math::TransformTRS(f3(V1.pos), translation, q, scale);
+        float3 v2W = Math::TransformTRS(f3(V2.pos), translation, q, scale);
+        float3 n0W = normalize(Math::RotateVector(v0_n * scaleInv, q));
+        float3 n1W = normalize(Math::RotateVector(v1_n * scaleInv, q));
+        float3 n2W = normalize(Math::RotateVector(v2_n * scaleInv, q));
+        Math::TriDifferentials td = Math::TriDifferentials::Compute(v0W, v1W, v2W, n0W, n1W, n2W, uv0, uv1, uv2);
+
+        // motion vector
+        float3 hitPos = mad3(rayDir, f3(h.t), rayOrigin);   // mad(dir, t, origin)
+        float3 posL = Math::InverseTransformTRS(hitPos, translation, q, scale);
+        float3 prevTranslation = translation - f3(zr_f16_to_f32(md.d_translation[0]), zr_f16_to_f32(md.d_translation[1]), zr_f16_to_f32(md.d_translation[2]));
+        float4 q_prev = normalize(Math::DecodeNormalized4(md.prev_rotation));
+        float3 prevScale = f3(zr_f16_to_f32(md.prev_scale[0]), zr_f16_to_f32(md.prev_scale[1]), zr_f16_to_f32(md.prev_scale[2]));
+        float3 pos_prev = Math::TransformTRS(posL, prevTranslation, q_prev, prevScale);
+        float3 posV_prev = Mul3x4(g.prev_view, pos_prev);
+        float2 posNDC_prev = {posV_prev.x / (posV_prev.z * g.tan_half_fov), posV_prev.y / (posV_prev.z * g.tan_half_fov)};
+        posNDC_prev.x /= g.aspect_ratio;
+
+        float2 currUV = {((float)x + 0.5f) / renderDim.x, ((float)y + 0.5f) / renderDim.y};
+        float2 prevUV = Math::UVFromNDC(posNDC_prev) - f2(jitter.x / renderDim.x, jitter.y / renderDim.y);
+        float2 motionVec = currUV - prevUV;
+
+        float3 pos = mad3(h.t, rayDir, rayOrigin);
+        float3 posV = Mul3x4(g.curr_view, pos);
+        float z = g.dof ? h.t : posV.z;
+        float3 wo = rayOrigin - pos;
+
+        // ApplyTextureMaps (GBufferRT.hlsli:178-282), texture maps out of scope this round
+        Mat mat; mat.m = sc.materials[md.mat_idx];
+        float3 baseColor = mat.GetBaseColorFactor();
+        float3 emissiveColor = mat.GetEmissiveFactor();
+        float metallic = mat.Metallic() ? 1.0f : 0.0f;
+        float roughness = mat.GetSpecularRoughness();
+        float3 shadingNormal = normal;
+        float3 dndu = td.dndu, dndv = td.dndv;
+        if (mat.DoubleSided() && dot(wo, normal) < 0) { shadingNormal = shadingNormal * -1.0f; dndu = dndu * -1.0f; dndv = dndv * -1.0f; }
+        if (dot(wo, normal) > 0 && dot(wo, shadingNormal) < 0)
+        {
+            wo = normalize(wo);
+            shadingNormal = shadingNormal - dot(shadingNormal, wo) * wo;
+            shadingNormal = 1e-4f * wo + shadingNormal;
+            shadingNormal = normalize(shadingNormal);
+        }
+        float emissiveStrength = mat.GetEmissiveStrength();
+        emissiveColor *= emissiveStrength;
+        bool transmissive = mat.Transmissive();
+        float ior = mat.GetSpecularIOR();
+        float trDepth = transmissive ? mat.GetTransmissionDepth() : 0;
+        float subsurface = mat.ThinWalled() ? mat.GetSubsurface() : 0;
+        float coat_weight = mat.GetCoatWeight();
+        float3 coat_color = mat.GetCoatColor();
+        float coat_roughness = mat.GetCoatRoughness();
+        float coat_ior = mat.GetCoatIOR();
+        float encoded = EncodeMetallic(metallic, transmissive, emissiveColor, trDepth, subsurface, coat_weight);
+
+        // WriteToGBuffers (GBufferRT.hlsli:102-176)
+        gb.depth[px] = z;
+        float2 en = Math::EncodeUnitVector(shadingNormal);
+        gb.normal[px] = PackUnorm16(en.x) | (PackUnorm16(en.y) << 16);
+        gb.baseColor[px] = PackUnorm8(baseColor.x) | (PackUnorm8(baseColor.y) << 8) | (PackUnorm8(baseColor.z) << 16) |
+            ((subsurface > 0 ? PackUnorm8(subsurface) : 0u) << 24);
+        gb.mr[px] = (uint16_t)(PackUnorm8(encoded) | (PackUnorm8(roughness) << 8));
+        gb.emissive[px] = dot(emissiveColor, emissiveColor) > 0 ? PackR11G11B10F(max3(emissiveColor, 0.0f)) : 0u;
+        gb.ior[px] = transmissive ? (uint8_t)PackUnorm8(EncodeIOR(ior)) : (uint8_t)0;
+        if (coat_weight > 0)
+        {
+            uint32_t c = Math::Float3ToRGB8(coat_color);
+            gb.coat[4 * px + 0] = (uint16_t)(c & 0xffff);
+            gb.coat[4 * px + 1] = (uint16_t)((c >> 16) | (Math::FloatToUNorm8(coat_weight) << 8));
+            gb.coat[4 * px + 2] = (uint16_t)(Math::FloatToUNorm8(coat_roughness) | (Math::FloatToUNorm8(EncodeIOR(coat_ior)) << 8));
+            gb.coat[4 * px + 3] = 0;
+        }
+        else { for (int k = 0; k < 4; k++) gb.coat[4 * px + k] = 0; }
+        gb.motion[px] = PackSnorm16(motionVec.x) | (PackSnorm16(motionVec.y) << 16);
+        uint32_t dpdu_h[3] = {zr_f32_to_f16(td.dpdu.x), zr_f32_to_f16(td.dpdu.y), zr_f32_to_f16(td.dpdu.z)};
+        uint32_t dpdv_h[3] = {zr_f32_to_f16(td.dpdv.x), zr_f32_to_f16(td.dpdv.y), zr_f32_to_f16(td.dpdv.z)};
+        uint32_t dndu_h[3] = {zr_f32_to_f16(dndu.x), zr_f32_to_f16(dndu.y), zr_f32_to_f16(dndu.z)};
+        uint32_t dndv_h[3] = {zr_f32_to_f16(dndv.x), zr_f32_to_f16(dndv.y), zr_f32_to_f16(dndv.z)};
+        gb.triA[4 * px + 0] = dpdu_h[0] | (dpdu_h[1] << 16);
+        gb.triA[4 * px + 1] = dpdu_h[2] | (dpdv_h[0] << 16);
+        gb.triA[4 * px + 2] = dpdv_h[1] | (dpdv_h[2] << 16);
+        gb.triA[4 * px + 3] = dndu_h[0] | (dndu_h[1] << 16);
+        gb.triB[2 * px + 0] = dndu_h[2] | (dndv_h[0] << 16);
+        gb.triB[2 * px + 1] = dndv_h[1] | (dndv_h[2] << 16);
+    }
+}
+
+//--------------------------------------------------------------------------------------
+// K2: per-triangle emissive power (EstimateTriEmissivePower.hlsl:29-79, untextured branch)
+//--------------------------------------------------------------------------------------
+static void EstimatePower(const Scene& sc, float* out)
+{
+    for (size_t i = 0; i < sc.emissives.size(); i++)
+    {
+        EmTri tri; tri.t = sc.emissives[i];
+        float3 power = f3(64.0f);    // ESTIMATE_TRI_POWER_NUM_SAMPLES_PER_TRI
+        power = power * tri.GetFactor() * tri.GetStrength();
+        const float3 vtx0 = tri.Vtx0(), vtx1 = tri.V1(), vtx2 = tri.V2();
+        const float surfaceArea = 0.5f * length(cross(vtx1 - vtx0, vtx2 - vtx0));
+        const float pdf = surfaceArea > 0 ? 1.0f / surfaceArea : 0;
+        out[i] = pdf > 0 ? Math::Luminance(power) * ZR_PI / (pdf * 64.0f) : 0;
+    }
+}
+
+//--------------------------------------------------------------------------------------
+// K9: path tracer.  NEE: RGI_Util::NEE_Emissive_MIS (ReSTIR_GI_NEE.hlsli:8-118) with PathTracer/Params.hlsli
+// (MIS_ALL_BOUNCES 1, MIS_NUM_LIGHT_SAMPLES 1, MIS_NON_DIFFUSE_BSDF_SAMPLING 0, APPROXIMATE_EMISSIVE_SHADOW_RAY 0,
+//  ACCOUNT_FOR_TRANSMITTANCE 1)
+//--------------------------------------------------------------------------------------
+static float3 NEE_Emissive_MIS(const Scene& sc, int NumLightSamples, bool skipDiffuse, float3 pos, float3 normal,
+    BSDF::ShadingData surface, uint32_t numEmissives, RNG& rng)
+{
+    float3 ld = f3(0.0f);
+    const bool specular = surface.GlossSpecular() && (surface.metallic || surface.specTr) && (!surface.Coated() || surface.CoatSpecular());
+    const int numLightSamples = specular ? 0 : NumLightSamples;
+
+    // BSDF sampling
+    {
+        BSDF::BSDFSample bsdfSample = skipDiffuse ? BSDF::SampleBSDF_NoDiffuse(normal, surface, rng) : BSDF::SampleBSDF(normal, surface, rng);
+        float3 wi = bsdfSample.wi;
+        float3 f = bsdfSample.f;
+        float wiPdf = bsdfSample.pdf;
+        RtRayQuery::Hit_Emissive hitInfo = RtRayQuery::Hit_Emissive::FindClosest(sc, pos, normal, wi, surface.Transmissive());
+        if (hitInfo.HitWasEmissive())
+        {
+            EmTri emissive; emissive.t = sc.emissives[hitInfo.emissiveTriIdx];
+            float3 le = Light::Le_EmissiveTriangle(emissive, hitInfo.bary);
+            const float3 vtx0 = emissive.Vtx0(), vtx1 = emissive.V1(), vtx2 = emissive.V2();
+            float3 lightNormal = cross(vtx1 - vtx0, vtx2 - vtx0);
+            float twoArea = length(lightNormal);
+            twoArea = zr_max(twoArea, 1e-6f);
+            lightNormal = dot(lightNormal, lightNormal) == 0 ? f3(1.0f) : lightNormal / twoArea;
+            lightNormal = emissive.IsDoubleSided() && dot(-wi, lightNormal) < 0 ? -lightNormal : lightNormal;
+            const float lightSourcePdf = numLightSamples > 0 ? sc.alias[hitInfo.emissiveTriIdx].cached_p_orig : 0;
+            const float lightPdf = lightSourcePdf * (2.0f / twoArea);
+            float dwdA = hitInfo.t > 0 ? zr_saturate(dot(lightNormal, -wi)) / (hitInfo.t * hitInfo.t) : 0;
+            wiPdf *= dwdA;
+            le *= f * dwdA;
+            ld = RT::PowerHeuristic(wiPdf, lightPdf, le, 1, (float)numLightSamples);
+        }
+    }
+    // Light sampling
+    for (int s_l = 0; s_l < numLightSamples; s_l++)
+    {
+        Light::AliasTableSample entry = Light::AliasTableSample::get(sc, numEmissives, rng);
+        EmTri tri; tri.t = sc.emissives[entry.idx];
+        Light::EmissiveTriSample lightSample = Light::EmissiveTriSample::get(pos, tri, rng);
+        float3 le = Light::Le_EmissiveTriangle(tri, lightSample.bary);
+        const float lightPdf = entry.pdf * lightSample.pdf;
+        const uint32_t lightID = tri.t.id;
+        const float t = length(lightSample.pos - pos);
+        const float3 wi = (lightSample.pos - pos) / t;
+        if (dot(lightSample.normal, -wi) > 0)
+        {
+            const float dwdA = zr_saturate(dot(lightSample.normal, -wi)) / (t * t);
+            surface.SetWi(wi, normal);
+            le *= BSDF::Unified(surface).f * dwdA;
+            if (dot(le, le) > 0)
+                le *= RtRayQuery::Visibility_Segment(sc, false, pos, wi, t, normal, lightID, surface.Transmissive()) ? 1.0f : 0.0f;
+            float bsdfPdf = skipDiffuse ? BSDF::BSDFSamplerPdf_NoDiffuse(normal, surface, wi, BSDF::NoOp()) :
+                BSDF::BSDFSamplerPdf(normal, surface, wi, BSDF::NoOp(), rng);
+            bsdfPdf *= dwdA;
+            ld += RT::PowerHeuristic(lightPdf, bsdfPdf, le, (float)numLightSamples);
+        }
+    }
+    return ld;
+}
+
+// One path of the 8x8 group ("virtual wave" of 64 lanes, SURVEY.md section 7: the RR reduction runs over the explicit
+// 64-pixel block, lanes = pixels of the group in row-major order).
+struct PathState
+{
+    bool active = false;        // still inside ReSTIR_RT::PathTrace's while(true)
+    bool atRR = false;          // reached the Russian-roulette point in this iteration
+    uint32_t x, y;
+    float3 li, throughput, pos, normal;
+    float eta_curr; int bounce; bool inTranslucentMedium;
+    BSDF::BSDFSample bsdfSample; RtRayQuery::Hit hitInfo; RT::RayDifferentials rd;
+    RNG rngThread, rngGroup;
+    float3 firstBsdfOverPdf;
+    int maxNumBounces;
+    // per-iteration temporaries carried from phase A to phase B
+    BSDF::ShadingData surface; float eta_next; float3 dpdx, dpdy;
+};
+
+static const int MIN_NUM_BOUNCES_RUSSIAN_ROULETTE = 3;
+
+static void RenderPathTracer(const Scene& sc, const zr_frame_constants& g, GBView gb, const zr_params& prm, float* finalRGBA)
+{
+    BSDF::g_rho = &sc.rhoLUT;
+    const uint32_t W = g.render_width, H = g.render_height;
+    const float2 renderDim = {(float)W, (float)H};
+    const float2 jitter = {g.curr_camera_jitter[0], g.curr_camera_jitter[1]};
+    const float3 vbx = Row(g.curr_view, 0), vby = Row(g.curr_view, 1), vbz = Row(g.curr_view, 2);
+    const bool russianRoulette = prm.flags & ZR_IND_RUSSIAN_ROULETTE;
+    const bool accumulate = g.accumulate && g.camera_static;
+    const uint32_t numSampleSets = prm.presampling ? prm.num_sample_sets : 0;
+
+    const uint32_t GX = (W + 7) / 8, GY = (H + 7) / 8;
+    std::vector<PathState> lanes(64);
+    for (uint32_t gy = 0; gy < GY; gy++)
+    for (uint32_t gx = 0; gx < GX; gx++)
+    {
+        // ---- PathTracer.hlsl main :115-212 + EstimateIndirectLighting :56-109, up to the PathTrace() call ----
+        for (uint32_t l = 0; l < 64; l++)
+        {
+            PathState& P = lanes[l];
+            P = PathState();
+            const uint32_t x = gx * 8 + (l & 7), y = gy * 8 + (l >> 3);
+            P.x = x; P.y = y;
+            if (x >= W || y >= H) continue;
+            const size_t px = (size_t)y * W + x;
+            float* out = finalRGBA + 4 * px;
+
+            const uint16_t mrp = gb.mr[px];
+            const float mr_x = (float)(mrp & 0xff) / 255.0f, mr_y = (float)(mrp >> 8) / 255.0f;
+            const uint32_t fl = (uint32_t)zr_fma(mr_x, 255.0f, 0.5f);
+            const bool f_transmissive = fl & 1, f_emissive = fl & 2, f_invalid = fl & 4, f_trDepthGt0 = fl & 8, f_metallic = fl & 128;
+            if (f_invalid || f_emissive)
+            {
+                if (!accumulate) { out[0] = out[1] = out[2] = 0; }
+                continue;
+            }
+            const float z_view = gb.depth[px];
+            float2 lensSample = {0, 0};
+            float3 origin = f3(g.camera_pos);
+            if (g.dof)
+            {
+                uint32_t hx = x, hy = y, hz = x; zr_pcg3d(&hx, &hy, &hz);
+                RNG rngDoF = RNG::Init(hz, hy, g.frame_num);
+                lensSample = Sampling::UniformSampleDiskConcentric(rngDoF.Uniform2D());
+                lensSample = lensSample * g.lens_radius;
+            }
+            const float3 pos = Math::WorldPosFromScreenSpace2(f2((float)x, (float)y), renderDim, z_view, g.tan_half_fov,
+                g.aspect_ratio, jitter, vbx, vby, vbz, g.dof, lensSample, g.focus_depth, origin);
+            const uint32_t np = gb.normal[px];
+            const float3 normal = Math::DecodeUnitVector(f2((float)(np & 0xffff) / 65535.0f, (float)(np >> 16) / 65535.0f));
+            const float3 baseColor = Math::UnpackRGB8(gb.baseColor[px]);
+            float eta_curr = ETA_AIR, eta_next = DEFAULT_ETA_MAT;
+            if (f_transmissive) eta_next = DecodeIOR((float)gb.ior[px] / 255.0f);
+            const float3 wo = normalize(origin - pos);
+            BSDF::ShadingData surface = BSDF::ShadingData::Init(normal, wo, f_metallic, mr_y, baseColor, eta_curr, eta_next,
+                f_transmissive, f_trDepthGt0 ? 1.0f : 0.0f);
+
+            P.rngGroup = RNG::Init(gx ^ 61u, gy ^ 61u, g.frame_num);
+            P.rngThread = RNG::Init(x ^ 511u, y ^ 31u, g.frame_num);
+            P.maxNumBounces = f_transmissive ? (int)prm.max_glossy_tr_bounces : (int)prm.max_non_tr_bounces;
+
+            // EstimateIndirectLighting
+            const uint32_t sampleSetIdx = P.rngGroup.UniformUintBounded_Faster(numSampleSets);
+            (void)sampleSetIdx;
+            P.li = f3(0.0f);
+            BSDF::BSDFSample bsdfSample = BSDF::SampleBSDF(normal, surface, P.rngThread);
+            bool alive = bsdfSample.pdf != 0;
+            RtRayQuery::Hit hitInfo; hitInfo.hit = false;
+            if (alive)
+            {
+                hitInfo = RtRayQuery::FindClosest(sc, true, true, pos, normal, bsdfSample.wi, surface.Transmissive());
+                alive = hitInfo.hit;
+            }
+            if (alive)
+            {
+                Math::TriDifferentials triDiffs = Math::TriDifferentials::Unpack(&gb.triA[4 * px], &gb.triB[2 * px]);
+                RT::RayDifferentials rd = RT::RayDifferentials::Init((int)x, (int)y, renderDim, g.tan_half_fov, g.aspect_ratio,
+                    jitter, vbx, vby, vbz, g.dof, g.focus_depth, lensSample, origin);
+                float3 dpdx, dpdy;
+                rd.dpdx_dpdy(pos, normal, dpdx, dpdy);
+                rd.ComputeUVDifferentials(dpdx, dpdy, triDiffs.dpdu, triDiffs.dpdv);
+                rd.UpdateRays(pos, normal, bsdfSample.wi, surface.wo, triDiffs, dpdx, dpdy, dot(bsdfSample.wi, normal) < 0, surface.eta);
+
+                // ReSTIR_RT::PathTrace prologue (PathTracing.hlsli:16-21)
+                P.active = true;
+                P.throughput = f3(1.0f);
+                P.pos = pos; P.normal = normal;
+                P.eta_curr = dot(normal, bsdfSample.wi) < 0 ? eta_next : ETA_AIR;
+                P.bounce = 0;
+                P.inTranslucentMedium = dot(normal, bsdfSample.wi) < 0;
+                P.bsdfSample = bsdfSample; P.hitInfo = hitInfo; P.rd = rd;
+                P.firstBsdfOverPdf = bsdfSample.bsdfOverPdf;
+            }
+        }
+
+        // ---- ReSTIR_RT::PathTrace loop (PathTracing.hlsli:23-96), lanes in lockstep per iteration ----
+        for (;;)
+        {
+            bool any = false;
+            // phase A: up to the Russian-roulette point
+            for (uint32_t l = 0; l < 64; l++)
+            {
+                PathState& P = lanes[l];
+                P.atRR = false;
+                if (!P.active) continue;
+                any = true;
+                float3 hitPos = mad3(P.hitInfo.t, P.bsdfSample.wi, P.pos);
+                P.rd.dpdx_dpdy(hitPos, P.hitInfo.normal, P.dpdx, P.dpdy);
+                P.rd.ComputeUVDifferentials(P.dpdx, P.dpdy, P.hitInfo.triDiffs.dpdu, P.hitInfo.triDiffs.dpdv);
+                if (!RtRayQuery::GetMaterialData(sc, -P.bsdfSample.wi, P.eta_curr, P.rd.uv_grads, P.hitInfo, P.surface, P.eta_next))
+                { P.active = false; continue; }
+                // RGI_Util::NEE, NEE_EMISSIVE == 1, USE_MIS == 1, MIS_ALL_BOUNCES == 1
+                P.li += P.throughput * NEE_Emissive_MIS(sc, 1, false, hitPos, P.hitInfo.normal, P.surface, g.num_emissive_triangles, P.rngThread);
+                if (P.inTranslucentMedium && (P.surface.trDepth > 0))
+                {
+                    float3 extCoeff = -log3(P.surface.baseColor_Fr0_TrCol) / P.surface.trDepth;
+                    P.throughput *= exp3(-P.hitInfo.t * extCoeff);
+                }
+                if (P.bounce >= (P.maxNumBounces - 1)) { P.active = false; continue; }
+                P.pos = hitPos;
+                P.normal = P.hitInfo.normal;
+                P.bounce++;
+                P.atRR = russianRoulette && (P.bounce >= MIN_NUM_BOUNCES_RUSSIAN_ROULETTE);
+            }
+            if (!any) break;
+            // WaveActiveMax over the lanes that execute the RR block in this iteration
+            float waveThroughput = 0; bool anyRR = false;
+            for (uint32_t l = 0; l < 64; l++)
+                if (lanes[l].active && lanes[l].atRR)
+                {
+                    float lum = Math::Luminance(lanes[l].throughput);
+                    waveThroughput = anyRR ? zr_max(waveThroughput, lum) : lum; anyRR = true;
+                }
+            // phase B
+            for (uint32_t l = 0; l < 64; l++)
+            {
+                PathState& P = lanes[l];
+                if (!P.active) continue;
+                if (P.atRR)
+                {
+                    float p_terminate = zr_max(0.05f, 1 - waveThroughput);
+                    if (P.rngGroup.Uniform() < p_terminate) { P.active = false; continue; }
+                    P.throughput /= (1 - p_terminate);
+                }
+                P.bsdfSample = BSDF::BSDFSample::Init();
+                if (P.bounce < P.maxNumBounces) P.bsdfSample = BSDF::SampleBSDF(P.normal, P.surface, P.rngThread);
+                if (Math::Luminance(P.bsdfSample.bsdfOverPdf) == 0) { P.active = false; continue; }
+                P.hitInfo = RtRayQuery::FindClosest(sc, false, true, P.pos, P.normal, P.bsdfSample.wi, P.surface.Transmissive());
+                if (!P.hitInfo.hit) { P.active = false; continue; }
+                P.throughput *= P.bsdfSample.bsdfOverPdf;
+                bool transmitted = dot(P.normal, P.bsdfSample.wi) < 0;
+                P.eta_curr = transmitted ? (P.eta_curr == ETA_AIR ? P.eta_next : ETA_AIR) : P.eta_curr;
+                P.inTranslucentMedium = transmitted ? !P.inTranslucentMedium : P.inTranslucentMedium;
+                P.rd.UpdateRays(P.pos, P.normal, P.bsdfSample.wi, P.surface.wo, P.hitInfo.triDiffs, P.dpdx, P.dpdy, transmitted, P.surface.eta);
+            }
+        }
+
+        // ---- epilogue (PathTracer.hlsl:99-108, 199-211) ----
+        for (uint32_t l = 0; l < 64; l++)
+        {
+            PathState& P = lanes[l];
+            if (P.x >= W || P.y >= H) continue;
+            const size_t px = (size_t)P.y * W + P.x;
+            const uint32_t fl = (uint32_t)zr_fma((float)(gb.mr[px] & 0xff) / 255.0f, 255.0f, 0.5f);
+            if (fl & (2u | 4u)) continue;
+            float3 li = P.li;
+            if (dot(li, li) > 0) li *= P.firstBsdfOverPdf;
+            li = any_nan(li) ? f3(0.0f) : li;
+            float* out = finalRGBA + 4 * px;
+            if (accumulate) { out[0] += li.x; out[1] += li.y; out[2] += li.z; }
+            else { out[0] = li.x; out[1] = li.y; out[2] = li.z; }
+        }
+    }
+}
+
+//--------------------------------------------------------------------------------------
+// C entry points (ctypes)
+//--------------------------------------------------------------------------------------
+extern "C" {
+
+struct zro_scene { Scene s; };
+
+zro_scene* zro_scene_create(const zr_scene_desc* d, int force_bvh)
+{
+    zro_scene* h = new zro_scene();
+    h->s.Build(*d, force_bvh != 0);
+    return h;
+}
+void zro_scene_destroy(zro_scene* h) { delete h; }
+int zro_scene_num_tris(const zro_scene* h) { return (int)h->s.tris.size(); }
+
+int zro_kahan_sum(const float* data, uint64_t n, uint32_t align_phase, float* out)
+{ *out = KahanSumRef(data, (int64_t)n, align_phase); return 0; }
+
+int zro_alias_table_build(const float* power, uint32_t n, uint32_t align_phase, zr_alias_entry* out)
+{
+    std::vector<float> probs(power, power + n);
+    BuildAliasTableRef(probs, out, align_phase);
+    return 0;
+}
+int zro_scene_set_alias_table(zro_scene* h, const zr_alias_entry* e, uint32_t n) { h->s.alias.assign(e, e + n); return 0; }
+int zro_estimate_power(const zro_scene* h, float* out) { EstimatePower(h->s, out); return 0; }
+
+int zro_gbuffer_render(const zro_scene* h, const zr_frame_constants* cb, zr_gbuffer_planes* planes)
+{ RenderGBuffer(h->s, *cb, GBView(planes)); return 0; }
+
+int zro_pathtrace_render(const zro_scene* h, const zr_frame_constants* cb, const zr_gbuffer_planes* planes,
+    const zr_params* prm, float* final_rgba, zr_counters* counters)
+{
+    h->s.counters = Counters();
+    RenderPathTracer(h->s, *cb, GBView(planes), *prm, final_rgba);
+    if (counters) { counters->n_closest = h->s.counters.n_closest; counters->n_shadow = h->s.counters.n_shadow; }
+    return 0;
+}
+
+// rays: n x 8 floats (o, tmin, d, tmax); hits: n x 4 uint32 (t bits, u bits, v bits, tri or 0xffffffff)
+int zro_trace_closest(const zro_scene* h, const float* rays, uint32_t n, uint32_t mask, uint32_t* hits)
+{
+    for (uint32_t i = 0; i < n; i++)
+    {
+        const float* r = rays + 8 * i;
+        Scene::RawHit rh = h->s.Trace(f3(r[0], r[1], r[2]), f3(r[4], r[5], r[6]), r[3], r[7], mask, false);
+        hits[4 * i + 0] = zr_asuint(rh.hit ? rh.t : 0.0f); hits[4 * i + 1] = zr_asuint(rh.u); hits[4 * i + 2] = zr_asuint(rh.v);
+        hits[4 * i + 3] = rh.hit ? rh.tri : 0xffffffffu;
+    }
+    return 0;
+}
+int zro_trace_any(const zro_scene* h, const float* rays, uint32_t n, uint32_t mask, uint32_t* occluded)
+{
+    for (uint32_t i = 0; i < n; i++)
+    {
+        const float* r = rays + 8 * i;
+        occluded[i] = h->s.Trace(f3(r[0], r[1], r[2]), f3(r[4], r[5], r[6]), r[3], r[7], mask, true).hit ? 1u : 0u;
+    }
+    return 0;
+}
+// timed single-thread traversal for bench.py's cpu_baseline leg: returns seconds spent in the traversal loop only
+double zro_trace_closest_timed(const zro_scene* h, const float* rays, uint32_t n, uint32_t mask, uint32_t* hits)
+{
+    auto t0 = std::chrono::steady_clock::now();
+    zro_trace_closest(h, rays, n, mask, hits);
+    auto t1 = std::chrono::steady_clock::now();
+    return std::chrono::duration<double>(t1 - t0).count();
+}
+
+// ---- known-answer helpers for the math contract (tests/test_detmath.py) ----
+void zro_kat_unary(int fn, const float* x, float* y, uint32_t n)
+{
+    for (uint32_t i = 0; i < n; i++)
+        switch (fn)
+        {
+        case 0: y[i] = zr_sin(x[i]); break;
+        case 1: y[i] = zr_cos(x[i]); break;
+        case 2: y[i] = zr_exp(x[i]); break;
+        case 3: y[i] = zr_log(x[i]); break;
+        case 4: y[i] = zr_atan(x[i]); break;
+        case 5: y[i] = zr_round_f16(x[i]); break;
+        case 6: y[i] = Math::ArcCos(x[i]); break;
+        case 7: y[i] = zr_sqrt(x[i]); break;
+        default: y[i] = 0;
+        }
+}
+void zro_kat_f32_to_f16(const float* x, uint16_t* y, uint32_t n) { for (uint32_t i = 0; i < n; i++) y[i] = zr_f32_to_f16(x[i]); }
+void zro_kat_f16_to_f32(const uint16_t* x, float* y, uint32_t n) { for (uint32_t i = 0; i < n; i++) y[i] = zr_f16_to_f32(x[i]); }
+void zro_kat_pcg3d(const uint32_t* in, uint32_t* out, uint32_t n)
+{ for (uint32_t i = 0; i < n; i++) { uint32_t x = in[3 * i], y = in[3 * i + 1], z = in[3 * i + 2]; zr_pcg3d(&x, &y, &z); out[3 * i] = x; out[3 * i + 1] = y; out[3 * i + 2] = z; } }
+void zro_kat_oct_encode(const float* n3, uint16_t* out, uint32_t n)
+{ for (uint32_t i = 0; i < n; i++) Math::EncodeOct32(f3(n3 + 3 * i), out + 2 * i); }
+void zro_kat_oct_decode(const uint16_t* in, float* n3, uint32_t n)
+{ for (uint32_t i = 0; i < n; i++) { float3 v = Math::DecodeOct32(in + 2 * i); n3[3 * i] = v.x; n3[3 * i + 1] = v.y; n3[3 * i + 2] = v.z; } }
+void zro_kat_rng_stream(uint32_t px, uint32_t py, uint32_t frame, float* out, uint32_t n)
+{ RNG r = RNG::Init(px, py, frame); for (uint32_t i = 0; i < n; i++) out[i] = r.Uniform(); }
+void zro_kat_uniform_bounded(uint32_t seed, uint32_t bound, uint32_t* out, uint32_t n)
+{ RNG r = RNG::InitSeed(seed); for (uint32_t i = 0; i < n; i++) out[i] = r.UniformUintBounded(bound); }
+// alias-table draw restated from LightSource.hlsli:72-98 over a standalone table (property tests of TestAliasTable.cpp)
+void zro_kat_alias_sample(const zr_alias_entry* table, uint32_t n, uint32_t seed, uint32_t* idx, float* pdf, uint32_t draws)
+{
+    RNG r = RNG::InitSeed(seed);
+    for (uint32_t i = 0; i < draws; i++)
+    {
+        uint32_t u0 = r.UniformUintBounded(n);
+        const zr_alias_entry& s = table[u0];
+        if (r.Uniform() < s.p_curr) { idx[i] = u0; pdf[i] = s.cached_p_orig; }
+        else { idx[i] = s.alias; pdf[i] = s.cached_p_alias; }
+    }
+}
+// BSDF evaluation probe: one Unified() + SampleBSDF() at a synthetic shading point (tests compare HIP vs oracle)
+void zro_kat_bsdf(const zro_scene* h, const float* in /* n x 16 */, float* out /* n x 12 */, uint32_t n)
+{
+    BSDF::g_rho = &h->s.rhoLUT;
+    for (uint32_t i = 0; i < n; i++)
+    {
+        const float* p = in + 16 * i;
+        float3 nrm = normalize(f3(p[0], p[1], p[2]));
+        float3 wo = normalize(f3(p[3], p[4], p[5]));
+        float3 wi = normalize(f3(p[6], p[7], p[8]));
+        bool metallic = p[9] > 0.5f; float roughness = p[10]; float3 base = f3(p[11], p[12], p[13]);
+        bool specTr = p[14] > 0.5f; float coat_w = p[15];
+        BSDF::ShadingData s = BSDF::ShadingData::Init(nrm, wo, metallic, roughness, base, ETA_AIR, DEFAULT_ETA_MAT, specTr, 0, 0,
+            coat_w, f3(0.8f), 0.2f, DEFAULT_ETA_COAT);
+        s.SetWi(wi, nrm);
+        BSDF::BSDFEval e = BSDF::Unified(s);
+        RNG rng = RNG::InitSeed(12345u + i);
+        BSDF::BSDFSample bs = BSDF::SampleBSDF(nrm, s, rng);
+        float* o = out + 12 * i;
+        o[0] = e.f.x; o[1] = e.f.y; o[2] = e.f.z;
+        o[3] = bs.wi.x; o[4] = bs.wi.y; o[5] = bs.wi.z; o[6] = bs.pdf;
+        o[7] = bs.bsdfOverPdf.x; o[8] = bs.bsdfOverPdf.y; o[9] = bs.bsdfOverPdf.z; o[10] = (float)(int)bs.lobe;
+        RNG rng2 = RNG::InitSeed(777u + i);
+        o[11] = BSDF::BSDFSamplerPdf(nrm, s, wi, BSDF::NoOp(), rng2);
+    }
+}
+
+} // extern "C"

@@ -1,0 +1,38 @@
+"""Extracts the raw R16_UNORM payload of the reference's rho.dds (64x32x16 GGX dielectric reflectance LUT,
+Assets/LUT/rho.dds, MIT) into zetaray_amd/assets/rho_lut_u16.bin so it travels to the GPU box (which has no
+/root/reference), and converts the two Cornell glTF scenes (Assets/CornellBox, CC-BY-4.0, "Cornell Box- Original" by
+t-ly, https://sketchfab.com/3d-models/cornell-box-original-0d18de8d108c4c9cab1a4405698cc6b6) into wire-format
+fixtures tests/golden/cornell*.npz with zetaray_amd.scene_io.load_gltf.
+Run once in the build container:  python tools/extract_assets.py
+"""
+import os
+import shutil
+import struct
+
+REF = "/root/reference"
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def main():
+    raw = open(os.path.join(REF, "Assets/LUT/rho.dds"), "rb").read()
+    assert raw[:4] == b"DDS "
+    h = struct.unpack("<31I", raw[4:128])
+    height, width, depth = h[2], h[3], h[5]
+    assert (width, height, depth) == (64, 32, 16)
+    payload = raw[128:128 + width * height * depth * 2]
+    os.makedirs(os.path.join(ROOT, "zetaray_amd/assets"), exist_ok=True)
+    open(os.path.join(ROOT, "zetaray_amd/assets/rho_lut_u16.bin"), "wb").write(payload)
+    import sys
+    sys.path.insert(0, ROOT)
+    from zetaray_amd import scene_io
+    dst = os.path.join(ROOT, "tests/golden")
+    os.makedirs(dst, exist_ok=True)
+    for name in ("cornell", "cornell_emissive"):
+        sc = scene_io.load_gltf(os.path.join(REF, "Assets/CornellBox", name + ".gltf"))
+        scene_io.save_npz(sc, os.path.join(dst, name + ".npz"))
+        print(name, "tris", sc.num_tris, "emissives", len(sc.emissives))
+    print("ok")
+
+
+if __name__ == "__main__":
+    main()

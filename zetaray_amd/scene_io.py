@@ -1,0 +1,442 @@
+"""Scene ingestion: glTF -> wire-format arrays (caller side of the hot path).
+
+Restates, for the feature subset the Cornell assets use (float3/float2/float4 accessors, u16/u32 indices, TRS
+nodes, KHR_materials_emissive_strength / ior / transmission / clearcoat):
+  Source/ZetaCore/Model/glTF.cpp:143-268   (attribute processing: RHS->LHS flip, CW winding)
+  Source/ZetaCore/Model/glTF.cpp:523-643   (ProcessMaterials)
+  Source/ZetaCore/Model/glTF.cpp:692-767   (ProcessEmissiveSubtree)
+  Source/ZetaCore/Model/glTF.cpp:769-940   (ProcessNodeSubtree: TRS -> LHS)
+  Source/ZetaCore/RayTracing/RtAccelerationStructure.cpp:318-380 (FillMeshInstanceData: quantised TRS)
+  Source/ZetaCore/Scene/SceneCore.cpp:25-36,196-236 (emissive world transform + PCG3d ID)
+  Source/ZetaCore/Core/Material.h:66-260   (Material packing)
+This is host plumbing in Python (numpy); it produces the buffers handed to zr_scene_create and to the oracle, so it is
+not part of the oracle<->HIP parity.  Texture images are not decoded (BC7) -- materials keep their factors only.
+"""
+import json
+import os
+import struct
+
+import numpy as np
+
+from . import wire
+
+_COMP = {5120: "i1", 5121: "u1", 5122: "<i2", 5123: "<u2", 5125: "<u4", 5126: "<f4"}
+_NCOMP = {"SCALAR": 1, "VEC2": 2, "VEC3": 3, "VEC4": 4, "MAT4": 16}
+
+
+def f32_to_f16_bits(x):
+    return np.asarray(x, dtype=np.float32).astype(np.float16).view(np.uint16)
+
+
+def pcg3d(x, y, z):
+    """RNG::PCG3d, Source/ZetaRenderPass/Common/Sampling.hlsli:22-33."""
+    M = 0xFFFFFFFF
+    x = (x * 1664525 + 1013904223) & M
+    y = (y * 1664525 + 1013904223) & M
+    z = (z * 1664525 + 1013904223) & M
+    x = (x + y * z) & M
+    y = (y + z * x) & M
+    z = (z + x * y) & M
+    x ^= x >> 16
+    y ^= y >> 16
+    z ^= z >> 16
+    x = (x + y * z) & M
+    y = (y + z * x) & M
+    z = (z + x * y) & M
+    return x, y, z
+
+
+def encode_octahedral(n):
+    """Math::encode_octahedral + unorm2::FromNormalized (OctahedralVector.h:8-24, Vector.h:626-647)."""
+    n = np.asarray(n, dtype=np.float32).reshape(-1, 3)
+    denom = np.abs(n[:, 0]) + np.abs(n[:, 1]) + np.abs(n[:, 2])
+    p = n[:, :2] / denom[:, None]
+    sgn = np.where(np.signbit(p), np.float32(-1), np.float32(1)).astype(np.float32)
+    folded = (np.float32(1) - np.abs(p[:, ::-1])) * sgn
+    enc = np.where((n[:, 2] <= 0)[:, None], folded, p).astype(np.float32)
+    u = (enc * np.float32(0.5) + np.float32(0.5)) * np.float32(65535.0)
+    return np.rint(u).astype(np.uint16)
+
+
+def unorm8(f):
+    f = np.clip(np.float32(f), 0, 1)
+    return int(np.float32(f) * np.float32(255.0) + np.float32(0.5))
+
+
+def rgb8(c):
+    return unorm8(c[0]) | (unorm8(c[1]) << 8) | (unorm8(c[2]) << 16)
+
+
+def pack_material(base_color=(1, 1, 1, 1), metallic=0.0, roughness=1.0, ior=1.5, transmission=0.0, subsurface=0.0,
+                  coat_weight=0.0, coat_color=(0.8, 0.8, 0.8), coat_roughness=0.0, coat_ior=1.6,
+                  emissive_factor=(0, 0, 0), emissive_strength=1.0, normal_scale=1.0, alpha_cutoff=0.5,
+                  alpha_mode=0, double_sided=False, thin_walled=False, transmission_depth=0.0,
+                  base_color_tex=0xFFFF, normal_tex=0xFFFF, mr_tex=0xFFFF, emissive_tex=0xFFFF):
+    """Material packing, Source/ZetaCore/Core/Material.h:66-260 (setter semantics)."""
+    m = np.zeros((), dtype=wire.MATERIAL)
+    m["base_color_factor"] = rgb8(base_color) | (unorm8(base_color[3]) << 24)
+    m["base_color_tex_subsurf_coat_weight"] = base_color_tex | (unorm8(subsurface) << 16) | (unorm8(coat_weight) << 24)
+    m["normal_tex_tr_depth"] = normal_tex | (int(f32_to_f16_bits(transmission_depth)) << 16)
+    m["mr_tex_spec_roughness_coat_roughness"] = mr_tex | (unorm8(roughness) << 16) | (unorm8(coat_roughness) << 24)
+    m["emissive_factor_normal_scale"] = rgb8(emissive_factor) | (unorm8(normal_scale) << 24)
+    ior_n = (np.float32(ior) - np.float32(1.0)) / np.float32(1.5)
+    ior16 = int(np.clip(ior_n, 0, 1) * np.float32(65535.0) + np.float32(0.5))
+    m["emissive_strength_ior"] = int(f32_to_f16_bits(emissive_strength)) | (ior16 << 16)
+    cior_n = (np.float32(coat_ior) - np.float32(1.0)) / np.float32(1.5)
+    m["emissive_tex_alpha_cutoff_coat_ior"] = emissive_tex | (unorm8(alpha_cutoff) << 16) | (unorm8(cior_n) << 24)
+    flags = rgb8(coat_color)
+    if metallic >= 0.9:
+        flags |= 1 << 24
+    if double_sided:
+        flags |= 1 << 25
+    if transmission >= 0.9:
+        flags |= 1 << 26
+    flags |= (alpha_mode & 3) << 27
+    if thin_walled:
+        flags |= 1 << 29
+    m["coat_color_flags"] = flags
+    return m
+
+
+def quat_rotate(q, v):
+    """Math::RotateVector (Math.hlsli:556-565), float32."""
+    q = np.asarray(q, np.float32)
+    v = np.asarray(v, np.float32)
+    im = q[:3]
+    t = np.cross(np.float32(2) * im, v).astype(np.float32)
+    return (v + q[3] * t + np.cross(im, t)).astype(np.float32)
+
+
+def trs_matrix(t, q, s):
+    """float32 3x4 row-major object-to-world matrix for p' = R(S p) + T."""
+    cols = [quat_rotate(q, np.array(e, np.float32) * np.float32(s[i])) for i, e in
+            enumerate(((1, 0, 0), (0, 1, 0), (0, 0, 1)))]
+    M = np.zeros((3, 4), np.float32)
+    for i in range(3):
+        M[:, i] = cols[i]
+    M[:, 3] = np.asarray(t, np.float32)
+    return M
+
+
+class Scene:
+    """Wire-format scene + the ctypes desc that points into it."""
+
+    def __init__(self):
+        self.vertices = np.zeros(0, wire.VERTEX)
+        self.indices = np.zeros(0, np.uint32)
+        self.instances = np.zeros(0, wire.MESH_INSTANCE)
+        self.instance_to_world = np.zeros((0, 12), np.float32)
+        self.instance_mask = np.zeros(0, np.uint8)
+        self.instance_num_tris = np.zeros(0, np.uint32)
+        self.materials = np.zeros(0, wire.MATERIAL)
+        self.emissives = np.zeros(0, wire.EMISSIVE_TRI)
+        self.rho = None
+        self.rho_dim = (0, 0, 0)
+        self._desc = None
+
+    @property
+    def num_tris(self):
+        return int(self.instance_num_tris.sum())
+
+    def desc(self) -> wire.SceneDesc:
+        for name in ("vertices", "indices", "instances", "instance_to_world", "instance_mask", "instance_num_tris",
+                     "materials", "emissives", "rho"):
+            setattr(self, name, np.ascontiguousarray(getattr(self, name)))
+        d = wire.SceneDesc()
+        d.vertices = self.vertices.ctypes.data
+        d.num_vertices = len(self.vertices)
+        d.indices = self.indices.ctypes.data
+        d.num_indices = len(self.indices)
+        d.instances = self.instances.ctypes.data
+        d.num_instances = len(self.instances)
+        d.instance_to_world = self.instance_to_world.ctypes.data
+        d.instance_mask = self.instance_mask.ctypes.data
+        d.instance_num_tris = self.instance_num_tris.ctypes.data
+        d.materials = self.materials.ctypes.data
+        d.num_materials = len(self.materials)
+        d.emissives = self.emissives.ctypes.data if len(self.emissives) else None
+        d.num_emissives = len(self.emissives)
+        d.rho_lut = self.rho.ctypes.data
+        d.rho_dim[0], d.rho_dim[1], d.rho_dim[2] = self.rho_dim
+        self._desc = d
+        return d
+
+
+def load_rho_dds(path):
+    """Assets/LUT/rho.dds: legacy DDS header (128 B), R16_UNORM volume 64 x 32 x 16 (BSDF.hlsli:279-296)."""
+    raw = open(path, "rb").read()
+    assert raw[:4] == b"DDS "
+    h = struct.unpack("<31I", raw[4:128])
+    height, width, depth = h[2], h[3], h[5]
+    data = np.frombuffer(raw, dtype="<u2", offset=128, count=width * height * depth).copy()
+    return data, (width, height, depth)
+
+
+def default_rho_path():
+    here = os.path.dirname(os.path.abspath(__file__))
+    p = os.path.join(here, "assets", "rho_lut_u16.bin")
+    return p
+
+
+def load_rho_default():
+    """The rho LUT travels with the package as raw R16 data (zetaray_amd/assets/rho_lut_u16.bin, 64 KiB)."""
+    p = default_rho_path()
+    data = np.fromfile(p, dtype="<u2")
+    assert data.size == 64 * 32 * 16
+    return data, (64, 32, 16)
+
+
+def _accessor(g, bins, idx):
+    acc = g["accessors"][idx]
+    bv = g["bufferViews"][acc["bufferView"]]
+    buf = bins[bv["buffer"]]
+    dt = np.dtype(_COMP[acc["componentType"]])
+    nc = _NCOMP[acc["type"]]
+    off = bv.get("byteOffset", 0) + acc.get("byteOffset", 0)
+    stride = bv.get("byteStride", 0) or dt.itemsize * nc
+    count = acc["count"]
+    if stride == dt.itemsize * nc:
+        a = np.frombuffer(buf, dtype=dt, offset=off, count=count * nc).reshape(count, nc)
+    else:
+        a = np.ndarray((count, nc), dtype=dt, buffer=buf, offset=off, strides=(stride, dt.itemsize))
+    return np.array(a)
+
+
+def load_gltf(path, rho=None) -> Scene:
+    g = json.load(open(path))
+    base = os.path.dirname(path)
+    bins = [open(os.path.join(base, b["uri"]), "rb").read() for b in g["buffers"]]
+
+    sc = Scene()
+    # ---- materials (index 0 = default material, glTF materials follow: EmissiveInstance.MaterialIdx = idx + 1) ----
+    mats = [pack_material(metallic=0.0, roughness=0.3)]     # Material() defaults, Material.h:66-95
+    for m in g.get("materials", []):
+        pbr = m.get("pbrMetallicRoughness", {})
+        ext = m.get("extensions", {})
+        kw = dict(
+            base_color=pbr.get("baseColorFactor", [1, 1, 1, 1]),
+            metallic=pbr.get("metallicFactor", 1.0),
+            roughness=pbr.get("roughnessFactor", 1.0),
+            emissive_factor=m.get("emissiveFactor", [0, 0, 0]),
+            emissive_strength=ext.get("KHR_materials_emissive_strength", {}).get("emissiveStrength", 1.0),
+            ior=ext.get("KHR_materials_ior", {}).get("ior", 1.5),
+            transmission=ext.get("KHR_materials_transmission", {}).get("transmissionFactor", 0.0),
+            coat_weight=ext.get("KHR_materials_clearcoat", {}).get("clearcoatFactor", 0.0),
+            coat_roughness=ext.get("KHR_materials_clearcoat", {}).get("clearcoatRoughnessFactor", 0.0),
+            alpha_cutoff=m.get("alphaCutoff", 0.5),
+            alpha_mode={"OPAQUE": 0, "MASK": 1, "BLEND": 2}[m.get("alphaMode", "OPAQUE")],
+            double_sided=m.get("doubleSided", False),
+        )
+        mats.append(pack_material(**kw))
+    sc.materials = np.array(mats, dtype=wire.MATERIAL)
+
+    # ---- meshes: one entry per (mesh, primitive) ----
+    verts, inds, mesh_info = [], [], {}
+    vtx_off = idx_off = 0
+    for mi, mesh in enumerate(g["meshes"]):
+        for pi, prim in enumerate(mesh["primitives"]):
+            at = prim["attributes"]
+            pos = _accessor(g, bins, at["POSITION"]).astype(np.float32)
+            nrm = _accessor(g, bins, at["NORMAL"]).astype(np.float32)
+            v = np.zeros(len(pos), wire.VERTEX)
+            v["pos"] = pos * np.array([1, 1, -1], np.float32)
+            v["normal"] = encode_octahedral(nrm * np.array([1, 1, -1], np.float32))
+            if "TEXCOORD_0" in at:
+                v["uv"] = _accessor(g, bins, at["TEXCOORD_0"]).astype(np.float32)
+                if "TANGENT" in at:
+                    tan = _accessor(g, bins, at["TANGENT"]).astype(np.float32)[:, :3]
+                    v["tangent"] = encode_octahedral(tan * np.array([1, 1, -1], np.float32))
+            idx = _accessor(g, bins, prim["indices"]).astype(np.uint32).reshape(-1, 3)
+            idx = idx[:, [0, 2, 1]].reshape(-1)          # clockwise ordering
+            mesh_info[(mi, pi)] = dict(vtx=vtx_off, idx=idx_off, nidx=len(idx), mat=prim.get("material", -1))
+            verts.append(v)
+            inds.append(idx)
+            vtx_off += len(v)
+            idx_off += len(idx)
+    sc.vertices = np.concatenate(verts)
+    sc.indices = np.concatenate(inds)
+
+    # ---- instances: scene nodes in order (flat hierarchy only; children are walked depth-first) ----
+    insts, mats_w, masks, ntris, emissive_tris = [], [], [], [], []
+
+    def is_emissive(matidx):
+        if matidx < 0:
+            return False
+        m = g["materials"][matidx]
+        ef = m.get("emissiveFactor", [0, 0, 0])
+        return (ef[0] + ef[1] + ef[2]) > 0 or "emissiveTexture" in m
+
+    def walk(nidx, parent):
+        node = g["nodes"][nidx]
+        assert "matrix" not in node, "matrix nodes not supported by this loader"
+        s = np.array(node.get("scale", [1, 1, 1]), np.float32)
+        t = np.array(node.get("translation", [0, 0, 0]), np.float32) * np.array([1, 1, -1], np.float32)
+        r = np.array(node.get("rotation", [0, 0, 0, 1]), np.float32) * np.array([-1, -1, 1, 1], np.float32)
+        local = np.vstack([trs_matrix(t, r, s), [0, 0, 0, 1]]).astype(np.float32)
+        world = (parent @ local).astype(np.float32)
+        if "mesh" in node:
+            mi = node["mesh"]
+            for pi in range(len(g["meshes"][mi]["primitives"])):
+                info = mesh_info[(mi, pi)]
+                inst = np.zeros((), wire.MESH_INSTANCE)
+                inst["base_vtx_offset"] = info["vtx"]
+                inst["base_idx_offset"] = info["idx"]
+                # FillMeshInstanceData: decomposeSRT of the world matrix, then quantise.  Only un-parented TRS nodes
+                # are exact here (the Cornell scenes); general hierarchies would need a polar decomposition.
+                rq = r / np.float32(np.sqrt(np.float32(np.dot(r, r))))
+                inst["rotation"] = np.rint((rq * np.float32(0.5) + np.float32(0.5)) * np.float32(65535.0)).astype(np.uint16)
+                inst["scale"] = f32_to_f16_bits(s)
+                inst["mat_idx"] = info["mat"] + 1
+                inst["translation"] = world[:3, 3]
+                inst["prev_rotation"] = inst["rotation"]
+                inst["prev_scale"] = inst["scale"]
+                inst["d_translation"] = f32_to_f16_bits([0, 0, 0])
+                inst["base_color_tex"] = 0xFFFF
+                matp = sc.materials[info["mat"] + 1]
+                alpha = np.float32((int(matp["base_color_factor"]) >> 24) & 0xFF) / np.float32(255.0)
+                cutoff = np.float32((int(matp["emissive_tex_alpha_cutoff_coat_ior"]) >> 16) & 0xFF) / np.float32(255.0)
+                inst["alpha_factor_cutoff"] = unorm8(alpha) | (unorm8(cutoff) << 8)
+                em = is_emissive(info["mat"])
+                inst["base_emissive_tri_offset"] = 0xFFFFFFFF
+                insts.append(inst)
+                mats_w.append(world[:3, :].reshape(12))
+                masks.append(wire.SUBGROUP_EMISSIVE if em else wire.SUBGROUP_NON_EMISSIVE)
+                ntris.append(info["nidx"] // 3)
+                if em:
+                    emissive_tris.append((len(insts) - 1, info, world[:3, :]))
+        for c in node.get("children", []):
+            walk(c, world)
+
+    scene_idx = g.get("scene", 0)
+    for n in g["scenes"][scene_idx]["nodes"]:
+        walk(n, np.eye(4, dtype=np.float32))
+
+    sc.instances = np.array(insts, dtype=wire.MESH_INSTANCE)
+    sc.instance_to_world = np.array(mats_w, dtype=np.float32)
+    sc.instance_mask = np.array(masks, dtype=np.uint8)
+    sc.instance_num_tris = np.array(ntris, dtype=np.uint32)
+
+    # ---- emissive triangles (glTF.cpp:692-767 then SceneCore.cpp:196-236) ----
+    ems = []
+    for inst_idx, info, M in emissive_tris:
+        sc.instances[inst_idx]["base_emissive_tri_offset"] = len(ems)
+        matp = sc.materials[info["mat"] + 1]
+        tri_idx = sc.indices[info["idx"]:info["idx"] + info["nidx"]].reshape(-1, 3)
+        for prim, (i0, i1, i2) in enumerate(tri_idx):
+            vs = [sc.vertices[info["vtx"] + i] for i in (i0, i1, i2)]
+            pw = [(M[:, :3] @ v["pos"].astype(np.float32) + M[:, 3]).astype(np.float32) for v in vs]
+            ems.append(pack_emissive_triangle(
+                pw[0], pw[1], pw[2], [v["uv"] for v in vs],
+                factor_rgb8=int(matp["emissive_factor_normal_scale"]) & 0xFFFFFF,
+                tex=int(matp["emissive_tex_alpha_cutoff_coat_ior"]) & 0xFFFF,
+                strength_h=int(matp["emissive_strength_ior"]) & 0xFFFF,
+                tri_id=pcg3d(inst_idx, 0, prim)[0],
+                double_sided=bool(int(matp["coat_color_flags"]) & (1 << 25))))
+    sc.emissives = np.array(ems, dtype=wire.EMISSIVE_TRI) if ems else np.zeros(0, wire.EMISSIVE_TRI)
+
+    if rho is None:
+        sc.rho, sc.rho_dim = load_rho_default()
+    else:
+        sc.rho, sc.rho_dim = rho
+    return sc
+
+
+def save_npz(sc: Scene, path):
+    """Wire-format fixture (tests/golden/*.npz); the rho LUT is not stored (it ships in zetaray_amd/assets)."""
+    np.savez_compressed(path, vertices=sc.vertices, indices=sc.indices, instances=sc.instances,
+                        instance_to_world=sc.instance_to_world, instance_mask=sc.instance_mask,
+                        instance_num_tris=sc.instance_num_tris, materials=sc.materials, emissives=sc.emissives)
+
+
+def load_npz(path) -> Scene:
+    z = np.load(path)
+    sc = Scene()
+    sc.vertices = z["vertices"].astype(wire.VERTEX)
+    sc.indices = z["indices"].astype(np.uint32)
+    sc.instances = z["instances"].astype(wire.MESH_INSTANCE)
+    sc.instance_to_world = z["instance_to_world"].astype(np.float32)
+    sc.instance_mask = z["instance_mask"].astype(np.uint8)
+    sc.instance_num_tris = z["instance_num_tris"].astype(np.uint32)
+    sc.materials = z["materials"].astype(wire.MATERIAL)
+    sc.emissives = z["emissives"].astype(wire.EMISSIVE_TRI)
+    sc.rho, sc.rho_dim = load_rho_default()
+    return sc
+
+
+def pack_emissive_triangle(v0, v1, v2, uvs, factor_rgb8, tex, strength_h, tri_id, double_sided):
+    """RT::EmissiveTriangle ctor + StoreVertices (RtCommon.h:73-166): normalised edges oct-encoded as UNORM16 with
+    round-to-nearest, half edge lengths; ID patched to the PCG3d hash (SceneCore.cpp:229-235)."""
+    e = np.zeros((), wire.EMISSIVE_TRI)
+    v0, v1, v2 = (np.asarray(v, np.float32) for v in (v0, v1, v2))
+    e["vtx0"] = v0
+    e0, e1 = v1 - v0, v2 - v0
+    l0 = np.float32(np.sqrt(np.float32(np.dot(e0, e0))))
+    l1 = np.float32(np.sqrt(np.float32(np.dot(e1, e1))))
+    e["v0v1"] = encode_octahedral(e0 / l0)[0]
+    e["v0v2"] = encode_octahedral(e1 / l1)[0]
+    e["edge_lengths"] = f32_to_f16_bits([l0, l1])
+    e["id"] = tri_id
+    e["packed_a"] = (factor_rgb8 & 0xFFFFFF) | (1 << 24) | ((1 << 25) if double_sided else 0) | ((strength_h & 0xF) << 28)
+    e["packed_b"] = (tex & 0xFFFF) | (strength_h << 16)
+    e["uv0"] = f32_to_f16_bits(uvs[0])
+    e["uv1"] = f32_to_f16_bits(uvs[1])
+    e["uv2"] = f32_to_f16_bits(uvs[2])
+    return e
+
+
+def make_frame_constants(width, height, frame_num=1, cam_pos=(0.0, 1.2, -4.043), view_dir=(0, 0, 1), up=(0, 1, 0),
+                         vfov_deg=60.0, near=0.2, num_emissives=0, accumulate=0, camera_static=0,
+                         num_frames_static=0, jitter=(0.0, 0.0)):
+    """cbFrameConstants for a static pinhole camera.  Reference defaults: Win32App.cpp:1510-1511 (camera),
+    DefaultRenderer.cpp:257-308 (sun / atmosphere), Camera.cpp:63-106 (lookToLH basis)."""
+    cb = np.zeros((), wire.FRAME_CONSTANTS)
+    eye = np.array(cam_pos, np.float32)
+    z = np.array(view_dir, np.float32)
+    z = z / np.float32(np.linalg.norm(z))
+    x = np.cross(np.array(up, np.float32), z).astype(np.float32)
+    x = x / np.float32(np.linalg.norm(x))
+    y = np.cross(z, x).astype(np.float32)
+    view = np.zeros((3, 4), np.float32)
+    view[0, :3], view[1, :3], view[2, :3] = x, y, z
+    view[:, 3] = [-np.dot(x, eye), -np.dot(y, eye), -np.dot(z, eye)]
+    view_inv = np.zeros((3, 4), np.float32)
+    view_inv[:, 0], view_inv[:, 1], view_inv[:, 2], view_inv[:, 3] = x, y, z, eye
+    for k in ("curr_view", "prev_view"):
+        cb[k] = view.reshape(12)
+    for k in ("curr_view_inv", "prev_view_inv"):
+        cb[k] = view_inv.reshape(12)
+    cb["camera_pos"] = eye
+    cb["camera_near"] = near
+    cb["aspect_ratio"] = np.float32(width) / np.float32(height)
+    tan_half = np.float32(np.tan(np.float32(0.5) * np.float32(np.deg2rad(vfov_deg))))
+    cb["tan_half_fov"] = tan_half
+    cb["pixel_spread_angle"] = np.float32(np.arctan(np.float32(2) * tan_half / np.float32(height)))
+    cb["dt"] = 1.0 / 60.0
+    cb["frame_num"] = frame_num
+    cb["render_width"], cb["render_height"] = width, height
+    cb["display_width"], cb["display_height"] = width, height
+    cb["curr_camera_jitter"] = jitter
+    cb["prev_camera_jitter"] = jitter
+    cb["planet_radius"] = 6360.0
+    ang = np.float32(np.deg2rad(0.5 * 0.526))
+    cb["sun_cos_angular_radius"] = np.float32(np.cos(ang))
+    cb["sun_sin_angular_radius"] = np.float32(np.sqrt(np.float32(1) - np.float32(np.cos(ang)) ** 2))
+    sd = np.array([0.6565358, -0.0560669, 0.752208233], np.float32)
+    sd = sd / np.float32(np.linalg.norm(sd))
+    if num_emissives > 0:
+        sd = np.array([0.0, 1.0, 0.0], np.float32)   # emissive scenes move the sun below the horizon (PathTracer.cpp:112-119)
+    cb["sun_dir"] = sd
+    cb["sun_illuminance"] = 20.0
+    cb["atmosphere_altitude"] = 100.0
+    cb["g"] = 0.8
+    cb["num_frames_camera_static"] = num_frames_static
+    cb["camera_static"] = camera_static
+    cb["accumulate"] = accumulate
+    cb["camera_ray_uv_grads_scale"] = 1.0
+    cb["mip_bias"] = 0.0
+    cb["num_emissive_triangles"] = num_emissives
+    cb["one_div_num_emissive_triangles"] = (1.0 / num_emissives) if num_emissives else 0.0
+    cb["focus_depth"] = 5.0
+    cb["lens_radius"] = 0.0
+    cb["dof"] = 0
+    return cb

@@ -1,0 +1,135 @@
+"""numpy dtypes / ctypes structs mirroring include/zr_wire.h and include/zetaray_amd.h (bit-exact layouts).
+
+Host-side plumbing only: these are the buffers a ZetaRay-style caller already owns
+(reference: Source/ZetaCore/RayTracing/RtCommon.h:47-332, Source/ZetaCore/Core/Material.h:419-427,
+Source/ZetaCore/Core/Vertex.h:8-14, Source/ZetaRenderPass/Common/FrameConstants.h:10-78).
+"""
+import ctypes as C
+
+import numpy as np
+
+VERTEX = np.dtype([("pos", "<f4", 3), ("uv", "<f4", 2), ("normal", "<u2", 2), ("tangent", "<u2", 2)])
+assert VERTEX.itemsize == 28
+
+MESH_INSTANCE = np.dtype([
+    ("base_vtx_offset", "<u4"), ("base_idx_offset", "<u4"), ("rotation", "<u2", 4), ("scale", "<u2", 3),
+    ("mat_idx", "<u2"), ("base_emissive_tri_offset", "<u4"), ("translation", "<f4", 3),
+    ("prev_rotation", "<u2", 4), ("prev_scale", "<u2", 3), ("d_translation", "<u2", 3),
+    ("base_color_tex", "<u2"), ("alpha_factor_cutoff", "<u2")])
+assert MESH_INSTANCE.itemsize == 64
+
+MATERIAL = np.dtype([
+    ("base_color_factor", "<u4"), ("base_color_tex_subsurf_coat_weight", "<u4"), ("normal_tex_tr_depth", "<u4"),
+    ("mr_tex_spec_roughness_coat_roughness", "<u4"), ("emissive_factor_normal_scale", "<u4"),
+    ("emissive_strength_ior", "<u4"), ("emissive_tex_alpha_cutoff_coat_ior", "<u4"), ("coat_color_flags", "<u4")])
+assert MATERIAL.itemsize == 32
+
+EMISSIVE_TRI = np.dtype([
+    ("vtx0", "<f4", 3), ("v0v1", "<u2", 2), ("v0v2", "<u2", 2), ("edge_lengths", "<u2", 2), ("id", "<u4"),
+    ("packed_a", "<u4"), ("packed_b", "<u4"), ("uv0", "<u2", 2), ("uv1", "<u2", 2), ("uv2", "<u2", 2)])
+assert EMISSIVE_TRI.itemsize == 48
+
+ALIAS_ENTRY = np.dtype([("cached_p_orig", "<f4"), ("cached_p_alias", "<f4"), ("p_curr", "<f4"), ("alias", "<u4")])
+assert ALIAS_ENTRY.itemsize == 16
+
+FRAME_CONSTANTS = np.dtype([
+    ("curr_view", "<f4", 12), ("prev_view", "<f4", 12), ("curr_view_inv", "<f4", 12), ("prev_view_inv", "<f4", 12),
+    ("curr_view_proj", "<f4", 16), ("prev_view_proj", "<f4", 16),
+    ("camera_pos", "<f4", 3), ("camera_near", "<f4"),
+    ("aspect_ratio", "<f4"), ("pixel_spread_angle", "<f4"), ("tan_half_fov", "<f4"), ("dt", "<f4"),
+    ("frame_num", "<u4"), ("curr_gbuffer_desc_heap_offset", "<u4"), ("prev_gbuffer_desc_heap_offset", "<u4"),
+    ("base_color_maps_desc_heap_offset", "<u4"),
+    ("normal_maps_desc_heap_offset", "<u4"), ("metallic_roughness_maps_desc_heap_offset", "<u4"),
+    ("emissive_maps_desc_heap_offset", "<u4"), ("env_map_desc_heap_offset", "<u4"),
+    ("render_width", "<u4"), ("render_height", "<u4"), ("display_width", "<u4"), ("display_height", "<u4"),
+    ("curr_camera_jitter", "<f4", 2), ("prev_camera_jitter", "<f4", 2),
+    ("planet_radius", "<f4"), ("sun_cos_angular_radius", "<f4"), ("sun_sin_angular_radius", "<f4"), ("pad", "<f4"),
+    ("sun_dir", "<f4", 3), ("sun_illuminance", "<f4"),
+    ("rayleigh_sigma_s_color", "<f4", 3), ("rayleigh_sigma_s_scale", "<f4"),
+    ("ozone_sigma_a_color", "<f4", 3), ("ozone_sigma_a_scale", "<f4"),
+    ("mie_sigma_s", "<f4"), ("mie_sigma_a", "<f4"), ("atmosphere_altitude", "<f4"), ("g", "<f4"),
+    ("num_frames_camera_static", "<u4"), ("camera_static", "<u4"), ("accumulate", "<u4"), ("sun_moved", "<u4"),
+    ("camera_ray_uv_grads_scale", "<f4"), ("mip_bias", "<f4"), ("one_div_num_emissive_triangles", "<f4"),
+    ("num_emissive_triangles", "<u4"),
+    ("focus_depth", "<f4"), ("lens_radius", "<f4"), ("dof", "<u4"), ("pad2", "<u4")])
+assert FRAME_CONSTANTS.itemsize == 544
+
+SUBGROUP_EMISSIVE = 1
+SUBGROUP_NON_EMISSIVE = 2
+SUBGROUP_ALL = 3
+
+GB_PLANE_NAMES = ["base_color", "normal", "metallic_roughness", "motion_vector", "emissive_color", "ior", "coat",
+                  "depth", "tri_diff_geo_a", "tri_diff_geo_b"]
+GB_PLANE_BYTES = [4, 4, 2, 4, 4, 1, 8, 4, 16, 8]
+GB_PLANE_DTYPES = [("<u4", 1), ("<u4", 1), ("<u2", 1), ("<u4", 1), ("<u4", 1), ("u1", 1), ("<u2", 4), ("<f4", 1),
+                   ("<u4", 4), ("<u4", 2)]
+GB_COUNT = 10
+
+
+class SceneDesc(C.Structure):
+    _fields_ = [
+        ("vertices", C.c_void_p), ("num_vertices", C.c_uint32),
+        ("indices", C.c_void_p), ("num_indices", C.c_uint32),
+        ("instances", C.c_void_p), ("num_instances", C.c_uint32),
+        ("instance_to_world", C.c_void_p),
+        ("instance_mask", C.c_void_p),
+        ("instance_num_tris", C.c_void_p),
+        ("materials", C.c_void_p), ("num_materials", C.c_uint32),
+        ("emissives", C.c_void_p), ("num_emissives", C.c_uint32),
+        ("rho_lut", C.c_void_p), ("rho_dim", C.c_uint32 * 3),
+    ]
+
+
+class GBufferPlanes(C.Structure):
+    _fields_ = [("width", C.c_uint32), ("height", C.c_uint32), ("plane", C.c_void_p * GB_COUNT)]
+
+
+class Params(C.Structure):
+    _fields_ = [
+        ("flags", C.c_uint32), ("max_non_tr_bounces", C.c_uint32), ("max_glossy_tr_bounces", C.c_uint32),
+        ("m_max_temporal", C.c_uint32), ("m_max_spatial", C.c_uint32), ("alpha_min", C.c_float),
+        ("presampling", C.c_uint32), ("num_sample_sets", C.c_uint32), ("sample_set_size", C.c_uint32),
+        ("reserved", C.c_uint32 * 7)]
+
+
+class Counters(C.Structure):
+    _fields_ = [("n_closest", C.c_uint64), ("n_shadow", C.c_uint64)]
+
+
+IND_TEMPORAL_RESAMPLE = 1 << 0
+IND_SPATIAL_RESAMPLE = 1 << 1
+IND_STOCHASTIC_MULTI_BOUNCE = 1 << 2
+IND_RUSSIAN_ROULETTE = 1 << 3
+IND_BOILING_SUPPRESSION = 1 << 4
+IND_PATH_REGULARIZATION = 1 << 5
+IND_SORT_TEMPORAL = 1 << 6
+IND_SORT_SPATIAL = 1 << 7
+
+
+def default_params() -> Params:
+    """Reference defaults: IndirectLighting.h:231-244, IndirectLighting.cpp:146-165."""
+    p = Params()
+    p.flags = (IND_TEMPORAL_RESAMPLE | IND_SPATIAL_RESAMPLE | IND_RUSSIAN_ROULETTE | IND_BOILING_SUPPRESSION |
+               IND_SORT_TEMPORAL | IND_SORT_SPATIAL)
+    p.max_non_tr_bounces = 3
+    p.max_glossy_tr_bounces = 4
+    p.m_max_temporal = 10
+    p.m_max_spatial = 8
+    p.alpha_min = 0.175 * 0.175
+    p.presampling = 0
+    p.num_sample_sets = 128
+    p.sample_set_size = 512
+    return p
+
+
+def alloc_gbuffer_planes(width: int, height: int):
+    """Host planes (numpy) + the ctypes view handed to the oracle / zr_gbuffer_download."""
+    arrays = []
+    planes = GBufferPlanes()
+    planes.width, planes.height = width, height
+    for i, (dt, n) in enumerate(GB_PLANE_DTYPES):
+        shape = (height, width) if n == 1 else (height, width, n)
+        a = np.zeros(shape, dtype=dt)
+        arrays.append(a)
+        planes.plane[i] = a.ctypes.data
+    return arrays, planes
