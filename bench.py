@@ -1,0 +1,211 @@
+#!/usr/bin/env python
+"""bench.py -- one "step" = one frame of the hot path (G-buffer + indirect-lighting pass) on synthetic/fixture input.
+
+  python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run, one rank per GPU)
+
+Metric (BASELINE.json): Mrays/s (+ ms/frame) at 1920x1080, 3 non-transmissive bounces, Cornell-Box-class scene.
+A ray = one BVH query (closest-hit or any-hit), counted on the device.  Scene, BVH, G-buffer
+and all queues are resident in HBM before the timed region; the timed region is K frames bracketed by barrier +
+torch.cuda.synchronize(), max over ranks.  N > 1 shards the frame by 32-px-aligned screen tiles (scene replicated);
+the path-tracing integrator has no cross-pixel reads, so there is no data-path collective ("scaling": weak would be
+wrong here -- the total work is fixed, so this reports "strong").
+
+Extra objects on the JSON line (rank 0, N = 1): "roofline" for the dominant kernel (hipEvent timing inside the library,
+algorithmic bytes from the per-ray model of DESIGN.md section 6) and "cpu_baseline" (the CPU oracle's single-thread
+traversal of its own BVH2 over a bounded sample of the same frame's rays).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+# per-ray algorithmic bytes; split by the kernel that touches them
+BYTES_CLOSEST = 296          # 64 ray w+r, 40 hit w+r, 192 vertex/index/instance/material gathers
+BYTES_SHADOW = 72            # 64 ray w+r, 8 result w+r
+TRACE_CLOSEST = 32 + 20      # trace kernel: ray record read + hit record written
+TRACE_SHADOW = 32 + 4
+SHADE_CLOSEST = BYTES_CLOSEST - TRACE_CLOSEST
+SHADE_SHADOW = BYTES_SHADOW - TRACE_SHADOW
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: 8 TB/s
+
+
+def tile_grid(n):
+    return {1: (1, 1), 2: (2, 1), 4: (2, 2), 8: (4, 2)}[n]
+
+
+def tile_rect(w, h, n, rank):
+    gx, gy = tile_grid(n)
+    tx, ty = rank % gx, rank // gx
+
+    def split(total, parts, i):
+        # 32-px aligned boundaries
+        edges = [min(total, ((total * k // parts) + 31) // 32 * 32) for k in range(parts + 1)]
+        edges[-1] = total
+        return edges[i], edges[i + 1] - edges[i]
+    x0, tw = split(w, gx, tx)
+    y0, th = split(h, gy, ty)
+    return x0, y0, tw, th
+
+
+def cpu_baseline(scene_host, cb, max_rays=1_000_000):
+    """Single-thread CPU traversal (oracle BVH2 + ABI intersection) over primary + diffuse-bounce rays of this frame."""
+    from oracle import zro
+    o = zro.OracleScene(scene_host, force_bvh=True)
+    w, h = int(cb["render_width"]), int(cb["render_height"])
+    rng = np.random.default_rng(0x5EED)
+    n = max_rays // 2
+    # primary rays (subsampled pixel grid)
+    px = rng.integers(0, w, n)
+    py = rng.integers(0, h, n)
+    ndc_x = ((px + 0.5) / w) * 2 - 1
+    ndc_y = -(((py + 0.5) / h) * 2 - 1)
+    d = np.stack([ndc_x * float(cb["aspect_ratio"]) * float(cb["tan_half_fov"]), ndc_y * float(cb["tan_half_fov"]), np.ones(n)], 1)
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    o3 = np.tile(np.asarray(cb["camera_pos"], np.float64), (n, 1))
+    prim = np.concatenate([o3, np.zeros((n, 1)), d, np.full((n, 1), 3.0e38)], 1).astype(np.float32)
+    hits = o.trace_closest(prim)
+    ok = hits[:, 3] != 0xFFFFFFFF
+    t = hits[ok, 0].view(np.float32)
+    p = prim[ok, 0:3] + prim[ok, 4:7] * (t[:, None] * 0.999)
+    d2 = rng.normal(size=p.shape)
+    d2 /= np.linalg.norm(d2, axis=1, keepdims=True)
+    sec = np.concatenate([p, np.full((len(p), 1), 1e-4), d2, np.full((len(p), 1), 3.0e38)], 1).astype(np.float32)
+    rays = np.concatenate([prim, sec], 0)
+    _, dt = o.trace_closest(rays, timed=True)
+    return {"value": round(len(rays) / dt / 1e6, 4), "unit": "Mrays/s", "cores": 1, "kind": "port",
+            "sample": f"{len(rays)} closest-hit rays (random primary + diffuse bounce) of the same frame, oracle BVH2, "
+                      f"{dt:.2f} s, host has {os.cpu_count()} logical cores"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=64)
+    ap.add_argument("--warmup", type=int, default=8)
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--scene", default=os.path.join(ROOT, "tests", "golden", "cornell_emissive.npz"))
+    args = ap.parse_args()
+
+    import torch
+    from zetaray_amd import api, scene_io, wire
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    torch.cuda.set_device(local_rank)
+
+    W, H = args.width, args.height
+    sc = scene_io.load_npz(args.scene)
+    prm = wire.default_params()
+    x0, y0, tw, th = tile_rect(W, H, world, rank)
+    r = api.Renderer(sc, tw, th, device=local_rank, params=prm, tile_origin=(x0, y0))
+
+    def frame(i):
+        cb = scene_io.make_frame_constants(W, H, frame_num=i, num_emissives=len(sc.emissives))
+        r.render_frame(cb)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        frame(1 + i)
+    barrier()
+    r.p_gbuffer.read_counters(reset=True)
+    r.p_indirect.read_counters(reset=True)
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        frame(1 + args.warmup + i)
+    barrier()
+    dt = time.perf_counter() - t0
+
+    c1 = r.p_gbuffer.read_counters(reset=True)
+    c2 = r.p_indirect.read_counters(reset=True)
+    rays = np.array([c1[0] + c2[0], c1[1] + c2[1]], np.float64)
+    tmax = dt
+    if dist is not None:
+        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        tmax = float(tt.item())
+        rr = torch.tensor(rays, dtype=torch.float64, device="cuda")
+        dist.all_reduce(rr, op=dist.ReduceOp.SUM)
+        rays = rr.cpu().numpy()
+    n_closest, n_shadow = float(rays[0]), float(rays[1])
+    ms_per_step = tmax / args.steps * 1e3
+    mrays = (n_closest + n_shadow) / tmax / 1e6
+
+    out = {
+        "metric": "Mrays/s", "value": round(mrays, 2), "unit": "Mrays/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "strong",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"Cornell Box (cornell_emissive: 58 triangles, 2 emissive) {W}x{H}, G-buffer + 1-spp "
+                               f"path tracer (K1+K9, NEE+MIS, 3 non-transmissive bounces, static camera); ReSTIR PT "
+                               f"reuse passes not implemented yet", "parallelism": f"screen tiles {tile_grid(world)}",
+                   "rays_per_frame": round((n_closest + n_shadow) / args.steps, 1),
+                   "fps": round(1e3 / ms_per_step, 2)},
+    }
+
+    if rank == 0 and world == 1:
+        # ---- roofline of the dominant kernel: hipEvent timing inside the library over a few timed frames
+        r.p_gbuffer.enable_timing(True)
+        r.p_indirect.enable_timing(True)
+        agg = {}
+        nfr = 8
+        r.p_indirect.read_counters(reset=True)
+        for i in range(nfr):
+            frame(1000 + i)
+            torch.cuda.synchronize()
+            for name, (ms, launches) in {**r.p_gbuffer.timings(), **r.p_indirect.timings()}.items():
+                a = agg.setdefault(name, [0.0, 0])
+                a[0] += ms
+                a[1] += launches
+        cc, cs = r.p_indirect.read_counters(reset=True)
+        r.p_gbuffer.read_counters(reset=True)
+        r.p_gbuffer.enable_timing(False)
+        r.p_indirect.enable_timing(False)
+        dom = max(agg, key=lambda k: agg[k][0])
+        launches = agg[dom][1]
+        avg_ms = agg[dom][0] / launches
+        if dom == "trace":
+            bytes_launch = (TRACE_CLOSEST * cc + TRACE_SHADOW * cs) / launches
+        elif dom == "pt_shade":
+            bytes_launch = (SHADE_CLOSEST * cc + SHADE_SHADOW * cs) / launches
+        elif dom == "gbuffer":
+            bytes_launch = (BYTES_CLOSEST + 47) * W * H
+        else:
+            bytes_launch = 0.0
+        achieved = bytes_launch / (avg_ms * 1e-3) / 1e9
+        frame_bytes = (BYTES_CLOSEST * (cc / nfr + W * H) + BYTES_SHADOW * (cs / nfr) + (47 + 38 + 16) * W * H)
+        out["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
+                           "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                           "avg_launch_ms": round(avg_ms, 4), "launches_per_frame": launches / nfr,
+                           "frame_model_GBs": round(frame_bytes / (ms_per_step * 1e-3) / 1e9, 2),
+                           "kernel_ms_per_frame": {k: round(v[0] / nfr, 4) for k, v in agg.items()}}
+        if not args.no_cpu_baseline:
+            cbf = scene_io.make_frame_constants(W, H, frame_num=1, num_emissives=len(sc.emissives))
+            out["cpu_baseline"] = cpu_baseline(sc, cbf)
+    if rank == 0:
+        print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -143,6 +143,10 @@ int zr_scene_bvh_info(const zr_scene* scene, uint32_t* num_nodes, uint32_t* num_
 /* ---- G-buffer ---- */
 int zr_gbuffer_create(int device, uint32_t width, uint32_t height, zr_gbuffer** out);
 int zr_gbuffer_destroy(zr_gbuffer* gb);
+/* Multi-GPU screen-tile split: this G-buffer (and the passes rendering into it) covers the
+ * tile whose top-left pixel is (x0, y0) of the full render target described by cbFrameConstants.RenderWidth/Height.
+ * Origins are 32-pixel aligned so thread groups, RNG group ids and sort tiles coincide with the single-GPU run. */
+int zr_gbuffer_set_tile_origin(zr_gbuffer* gb, uint32_t x0, uint32_t y0);
 int zr_gbuffer_download(const zr_gbuffer* gb, void* hip_stream, zr_gbuffer_planes* host_planes);
 int zr_gbuffer_device_plane(const zr_gbuffer* gb, int plane, void** dev_ptr);
 

@@ -18,8 +18,10 @@
 
 #if defined(__HIPCC__)
 #define ZR_HD __host__ __device__ inline
+#define ZR_HDM __host__ __device__          /* member functions */
 #else
 #define ZR_HD static inline
+#define ZR_HDM
 #endif
 
 #define ZR_PI              3.141592654f

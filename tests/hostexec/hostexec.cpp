@@ -1,0 +1,162 @@
+// tests/hostexec -- TEST-ONLY serial executor for the stage functions of zetaray_amd/csrc/zr_stages.h.
+//
+// The product library (libzetaray_amd.so) only runs these functions inside HIP kernels and has no CPU path.  This
+// harness compiles the very same ZR_HD functions with g++ and drives them with plain loops (queues, slot allocation
+// and the trace stage in program order), so the `-m "not gpu"` suite can check the wavefront decomposition against
+// the oracle in a container without a GPU.  It is never linked into, or loaded by, the product.
+#include <vector>
+#include <cstring>
+#include "../../zetaray_amd/csrc/zr_stages.h"
+#include "../../zetaray_amd/csrc/zr_bvh.h"
+
+using namespace zr;
+
+struct HxScene
+{
+    std::vector<zr_vertex> vertices; std::vector<uint32_t> indices; std::vector<zr_mesh_instance> instances;
+    std::vector<zr_material> materials; std::vector<zr_emissive_triangle> emissives; std::vector<zr_alias_entry> alias;
+    std::vector<uint16_t> rho; BuiltBvh bvh; SceneView view;
+};
+
+struct HxQueue
+{
+    std::vector<U4> s0, hitC, hitM; std::vector<F4> f[8], rays[6]; std::vector<uint32_t> lightID, visS;
+    void Resize(size_t n)
+    {
+        s0.resize(n); hitC.resize(n); hitM.resize(n); lightID.resize(n); visS.resize(n);
+        for (auto& v : f) v.resize(n);
+        for (auto& v : rays) v.resize(n);
+    }
+    PathQueue View()
+    {
+        PathQueue q;
+        q.s0 = s0.data(); q.s1 = f[0].data(); q.s2 = f[1].data(); q.s3 = f[2].data(); q.s4 = f[3].data(); q.s5 = f[4].data();
+        q.s6 = f[5].data(); q.s7 = f[6].data(); q.s8 = f[7].data();
+        q.rayC_o = rays[0].data(); q.rayC_d = rays[1].data(); q.rayM_o = rays[2].data(); q.rayM_d = rays[3].data();
+        q.rayS_o = rays[4].data(); q.rayS_d = rays[5].data();
+        q.sLightID = lightID.data(); q.hitC = hitC.data(); q.hitM = hitM.data(); q.visS = visS.data();
+        return q;
+    }
+};
+
+static GBuf ViewOf(const zr_gbuffer_planes* p)
+{
+    GBuf g; g.w = p->width; g.h = p->height; g.x0 = 0; g.y0 = 0;
+    g.baseColor = (uint32_t*)p->plane[ZR_GB_BASE_COLOR]; g.normal = (uint32_t*)p->plane[ZR_GB_NORMAL];
+    g.mr = (uint16_t*)p->plane[ZR_GB_METALLIC_ROUGHNESS]; g.motion = (uint32_t*)p->plane[ZR_GB_MOTION_VECTOR];
+    g.emissive = (uint32_t*)p->plane[ZR_GB_EMISSIVE_COLOR]; g.ior = (uint8_t*)p->plane[ZR_GB_IOR];
+    g.coat = (uint16_t*)p->plane[ZR_GB_COAT]; g.depth = (float*)p->plane[ZR_GB_DEPTH];
+    g.triA = (uint32_t*)p->plane[ZR_GB_TRI_DIFF_GEO_A]; g.triB = (uint32_t*)p->plane[ZR_GB_TRI_DIFF_GEO_B];
+    return g;
+}
+
+extern "C" {
+
+HxScene* zhx_scene_create(const zr_scene_desc* d)
+{
+    HxScene* s = new HxScene();
+    s->vertices.assign(d->vertices, d->vertices + d->num_vertices);
+    s->indices.assign(d->indices, d->indices + d->num_indices);
+    s->instances.assign(d->instances, d->instances + d->num_instances);
+    s->materials.assign(d->materials, d->materials + d->num_materials);
+    if (d->num_emissives) s->emissives.assign(d->emissives, d->emissives + d->num_emissives);
+    s->rho.assign(d->rho_lut, d->rho_lut + (size_t)d->rho_dim[0] * d->rho_dim[1] * d->rho_dim[2]);
+    BvhBuilder b;
+    s->bvh = b.Build(*d);
+    SceneView& v = s->view;
+    v.vertices = s->vertices.data(); v.indices = s->indices.data(); v.instances = s->instances.data(); v.materials = s->materials.data();
+    v.emissives = s->emissives.data(); v.alias = nullptr; v.nodes = s->bvh.nodes.data(); v.tris = s->bvh.tris.data(); v.triMeta = s->bvh.meta.data();
+    v.rho.data = s->rho.data(); v.rho.dx = d->rho_dim[0]; v.rho.dy = d->rho_dim[1]; v.rho.dz = d->rho_dim[2];
+    v.numEmissives = d->num_emissives; v.numNodes = (uint32_t)s->bvh.nodes.size(); v.numTris = (uint32_t)s->bvh.tris.size();
+    return s;
+}
+void zhx_scene_destroy(HxScene* s) { delete s; }
+void zhx_scene_set_alias(HxScene* s, const zr_alias_entry* e, uint32_t n) { s->alias.assign(e, e + n); s->view.alias = s->alias.data(); }
+void zhx_bvh_info(const HxScene* s, uint32_t* nodes, uint32_t* tris, uint32_t* depth)
+{ *nodes = s->view.numNodes; *tris = s->view.numTris; *depth = s->bvh.maxDepth; }
+void zhx_estimate_power(const HxScene* s, float* out) { for (size_t i = 0; i < s->emissives.size(); i++) out[i] = EstimateTriPower(s->emissives[i]); }
+
+void zhx_gbuffer(const HxScene* s, const zr_frame_constants* cb, zr_gbuffer_planes* planes)
+{
+    GBuf gb = ViewOf(planes);
+    uint32_t stack[64];
+    for (uint32_t y = 0; y < cb->render_height; y++)
+        for (uint32_t x = 0; x < cb->render_width; x++)
+            GBufferPixel(s->view, *cb, gb, x, y, stack, nullptr);
+}
+
+void zhx_pathtrace(const HxScene* s, const zr_frame_constants* cb, const zr_gbuffer_planes* planes, const zr_params* params,
+    float* finalRGBA, zr_counters* counters)
+{
+    const uint32_t W = cb->render_width, H = cb->render_height;
+    const size_t cap = (size_t)W * H;
+    GBuf gb = ViewOf(planes);
+    PtParams prm;
+    prm.maxNonTrBounces = params->max_non_tr_bounces; prm.maxGlossyTrBounces = params->max_glossy_tr_bounces;
+    prm.russianRoulette = (params->flags & ZR_IND_RUSSIAN_ROULETTE) ? 1u : 0u;
+    prm.numSampleSets = params->presampling ? params->num_sample_sets : 0u;
+    prm.accumulate = (cb->accumulate && cb->camera_static) ? 1u : 0u;
+    HxQueue q[2]; q[0].Resize(cap); q[1].Resize(cap);
+    std::vector<F4> firstBOP(cap);
+    uint64_t nClosest = 0, nShadow = 0;
+    uint32_t stack[64];
+
+    uint32_t count = 0;
+    PathQueue q0 = q[0].View();
+    // same pixel order as the kernel: 16x16 tiles, 8x8 quadrants
+    for (uint32_t ty = 0; ty < (H + 15) / 16; ty++) for (uint32_t tx = 0; tx < (W + 15) / 16; tx++)
+    for (uint32_t t = 0; t < 256; t++)
+    {
+        uint32_t wave = t >> 6, lane = t & 63;
+        uint32_t x = tx * 16 + (wave & 1) * 8 + (lane & 7), y = ty * 16 + (wave >> 1) * 8 + (lane >> 3);
+        if (x >= W || y >= H) continue;
+        PathOut po;
+        PtInitPixel(s->view, *cb, gb, prm, x, y, finalRGBA, firstBOP.data(), po);
+        if (po.alive) WritePath(q0, count++, po);
+    }
+    const uint32_t maxB = prm.maxNonTrBounces > prm.maxGlossyTrBounces ? prm.maxNonTrBounces : prm.maxGlossyTrBounces;
+    for (uint32_t r = 0; r < maxB + 1; r++)
+    {
+        PathQueue in = q[r & 1].View(), out = q[(r + 1) & 1].View();
+        for (uint32_t i = 0; i < count; i++)
+        {
+            if (in.rayC_d[i].w >= 0) { in.hitC[i] = TraceClosestRay(s->view, in.rayC_o[i], in.rayC_d[i], ZR_SUBGROUP_ALL, stack); nClosest++; }
+            else { U4 m; m.x = m.y = m.z = 0; m.w = kInvalidTri; in.hitC[i] = m; }
+            if (in.rayM_d[i].w >= 0) { in.hitM[i] = TraceClosestRay(s->view, in.rayM_o[i], in.rayM_d[i], ZR_SUBGROUP_ALL, stack); nClosest++; }
+            if (in.rayS_d[i].w >= 0) { in.visS[i] = TraceSegmentRay(s->view, in.rayS_o[i], in.rayS_d[i], in.sLightID[i], stack); nShadow++; }
+        }
+        uint32_t outCount = 0;
+        for (uint32_t i = 0; i < count; i++)
+        {
+            PathOut po;
+            PtShadePath(s->view, *cb, prm, in, i, finalRGBA, firstBOP.data(), po);
+            if (po.alive) WritePath(out, outCount++, po);
+        }
+        count = outCount;
+    }
+    if (counters) { counters->n_closest = nClosest; counters->n_shadow = nShadow; }
+}
+
+void zhx_trace_closest(const HxScene* s, const float* rays, uint32_t n, uint32_t mask, uint32_t* hits)
+{
+    uint32_t stack[64];
+    for (uint32_t i = 0; i < n; i++)
+    {
+        F4 ro = f4(rays[8 * i], rays[8 * i + 1], rays[8 * i + 2], rays[8 * i + 3]);
+        F4 rd = f4(rays[8 * i + 4], rays[8 * i + 5], rays[8 * i + 6], rays[8 * i + 7]);
+        U4 h = TraceClosestRay(s->view, ro, rd, mask, stack);
+        hits[4 * i] = h.x; hits[4 * i + 1] = h.y; hits[4 * i + 2] = h.z; hits[4 * i + 3] = h.w;
+    }
+}
+void zhx_trace_any(const HxScene* s, const float* rays, uint32_t n, uint32_t mask, uint32_t* occ)
+{
+    uint32_t stack[64];
+    for (uint32_t i = 0; i < n; i++)
+    {
+        RawHit h = Traverse<true>(s->view, v3(rays[8 * i], rays[8 * i + 1], rays[8 * i + 2]), v3(rays[8 * i + 4], rays[8 * i + 5], rays[8 * i + 6]),
+            rays[8 * i + 3], rays[8 * i + 7], mask, stack);
+        occ[i] = h.tri != kInvalidTri ? 1u : 0u;
+    }
+}
+
+} // extern "C"

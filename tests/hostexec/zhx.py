@@ -1,0 +1,82 @@
+"""ctypes binding of tests/hostexec/libzhx.so (TEST-ONLY serial executor of the HIP stage functions)."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        subprocess.check_call(["make", "-s", "-C", _HERE, "libzhx.so"])
+        L = C.CDLL(os.path.join(_HERE, "libzhx.so"))
+        L.zhx_scene_create.restype = C.c_void_p
+        L.zhx_scene_create.argtypes = [C.c_void_p]
+        L.zhx_scene_destroy.argtypes = [C.c_void_p]
+        L.zhx_scene_set_alias.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32]
+        L.zhx_bvh_info.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.zhx_estimate_power.argtypes = [C.c_void_p, C.c_void_p]
+        L.zhx_gbuffer.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.zhx_pathtrace.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.zhx_trace_closest.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]
+        L.zhx_trace_any.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]
+        _LIB = L
+    return _LIB
+
+
+class HostExecScene:
+    def __init__(self, scene, alias=None):
+        self.scene = scene
+        self._desc = scene.desc()
+        self.h = lib().zhx_scene_create(C.addressof(self._desc))
+        if alias is not None:
+            self._alias = np.ascontiguousarray(alias)
+            lib().zhx_scene_set_alias(self.h, self._alias.ctypes.data, len(self._alias))
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib().zhx_scene_destroy(self.h)
+            self.h = None
+
+    def bvh_info(self):
+        a, b, c = C.c_uint32(), C.c_uint32(), C.c_uint32()
+        lib().zhx_bvh_info(self.h, C.byref(a), C.byref(b), C.byref(c))
+        return a.value, b.value, c.value
+
+    def estimate_power(self):
+        out = np.zeros(len(self.scene.emissives), np.float32)
+        lib().zhx_estimate_power(self.h, out.ctypes.data)
+        return out
+
+    def gbuffer(self, cb):
+        from zetaray_amd import wire
+        arrays, planes = wire.alloc_gbuffer_planes(int(cb["render_width"]), int(cb["render_height"]))
+        cbb = np.ascontiguousarray(cb)
+        lib().zhx_gbuffer(self.h, cbb.ctypes.data, C.addressof(planes))
+        return arrays, planes
+
+    def pathtrace(self, cb, planes, params, final=None):
+        from zetaray_amd import wire
+        w, h = int(cb["render_width"]), int(cb["render_height"])
+        if final is None:
+            final = np.zeros((h, w, 4), np.float32)
+        cnt = wire.Counters()
+        cbb = np.ascontiguousarray(cb)
+        lib().zhx_pathtrace(self.h, cbb.ctypes.data, C.addressof(planes), C.addressof(params), final.ctypes.data, C.addressof(cnt))
+        return final, (cnt.n_closest, cnt.n_shadow)
+
+    def trace_closest(self, rays, mask=3):
+        rays = np.ascontiguousarray(rays, np.float32)
+        hits = np.zeros((len(rays), 4), np.uint32)
+        lib().zhx_trace_closest(self.h, rays.ctypes.data, len(rays), mask, hits.ctypes.data)
+        return hits
+
+    def trace_any(self, rays, mask=3):
+        rays = np.ascontiguousarray(rays, np.float32)
+        occ = np.zeros(len(rays), np.uint32)
+        lib().zhx_trace_any(self.h, rays.ctypes.data, len(rays), mask, occ.ctypes.data)
+        return occ

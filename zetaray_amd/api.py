@@ -1,0 +1,250 @@
+"""ctypes binding of libzetaray_amd.so (the C-ABI in include/zetaray_amd.h) plus thin Python mirrors of the
+reference's pass surface (Init / OnWindowResized / ResetTemporal / Render / GetOutput).
+
+Host plumbing only: everything that computes happens inside the HIP library.  The library has no CPU path -- every
+compute entry point raises ZetaRayError (ZR_ERR_NO_DEVICE) when no MI355X is visible, and importing this module fails
+loudly if libzetaray_amd.so has not been built (python -c "import __graft_entry__ as g; g.build()").
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import wire
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libzetaray_amd.so")
+
+PASS_GBUFFER, PASS_PRELIGHTING, PASS_DI_EMISSIVE, PASS_DI_SKY, PASS_INDIRECT = range(5)
+INTEGRATOR_PATH_TRACING, INTEGRATOR_RESTIR_GI, INTEGRATOR_RESTIR_PT = range(3)
+OUT_FINAL = 0
+
+EXPORTS = [
+    "zr_abi_version", "zr_last_error", "zr_device_count", "zr_scene_create", "zr_scene_destroy",
+    "zr_scene_set_alias_table", "zr_alias_table_build", "zr_scene_get_alias_table", "zr_scene_bvh_info",
+    "zr_gbuffer_create", "zr_gbuffer_destroy", "zr_gbuffer_set_tile_origin", "zr_gbuffer_download", "zr_gbuffer_device_plane",
+    "zr_params_default", "zr_pass_create", "zr_pass_init", "zr_pass_resize", "zr_pass_reset_temporal",
+    "zr_pass_set_params", "zr_pass_render", "zr_pass_get_output", "zr_pass_download_output",
+    "zr_pass_read_counters", "zr_pass_enable_timing", "zr_pass_get_timings", "zr_pass_destroy",
+    "zr_trace_closest", "zr_trace_any",
+]
+
+
+class ZetaRayError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"zetaray_amd error {code}: {msg}")
+        self.code = code
+
+
+_LIB = None
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(f"{LIB_PATH} is missing: build the HIP extension first "
+                              f"(python -c 'import __graft_entry__ as g; g.build()'); there is no fallback path")
+        L = C.CDLL(LIB_PATH)
+        L.zr_last_error.restype = C.c_char_p
+        vp, u32, i32 = C.c_void_p, C.c_uint32, C.c_int
+        L.zr_device_count.argtypes = [vp]
+        L.zr_scene_create.argtypes = [i32, vp, vp]
+        L.zr_scene_destroy.argtypes = [vp]
+        L.zr_scene_set_alias_table.argtypes = [vp, vp, u32]
+        L.zr_alias_table_build.argtypes = [vp, u32, u32, vp]
+        L.zr_scene_get_alias_table.argtypes = [vp, vp, u32]
+        L.zr_scene_bvh_info.argtypes = [vp, vp, vp, vp]
+        L.zr_gbuffer_create.argtypes = [i32, u32, u32, vp]
+        L.zr_gbuffer_destroy.argtypes = [vp]
+        L.zr_gbuffer_set_tile_origin.argtypes = [vp, u32, u32]
+        L.zr_gbuffer_download.argtypes = [vp, vp, vp]
+        L.zr_gbuffer_device_plane.argtypes = [vp, i32, vp]
+        L.zr_params_default.argtypes = [vp]
+        L.zr_pass_create.argtypes = [i32, i32, vp]
+        L.zr_pass_init.argtypes = [vp, u32, u32, i32]
+        L.zr_pass_resize.argtypes = [vp, u32, u32]
+        L.zr_pass_reset_temporal.argtypes = [vp]
+        L.zr_pass_set_params.argtypes = [vp, vp]
+        L.zr_pass_render.argtypes = [vp, vp, vp, vp, vp]
+        L.zr_pass_get_output.argtypes = [vp, i32, vp, vp, vp, vp]
+        L.zr_pass_download_output.argtypes = [vp, i32, vp, vp, C.c_size_t]
+        L.zr_pass_read_counters.argtypes = [vp, vp, vp, i32]
+        L.zr_pass_enable_timing.argtypes = [vp, i32]
+        L.zr_pass_get_timings.argtypes = [vp, u32, vp, vp, vp, vp]
+        L.zr_pass_destroy.argtypes = [vp]
+        L.zr_trace_closest.argtypes = [vp, vp, vp, u32, u32, vp]
+        L.zr_trace_any.argtypes = [vp, vp, vp, u32, u32, vp]
+        _LIB = L
+    return _LIB
+
+
+def _check(code):
+    if code != 0:
+        raise ZetaRayError(code, lib().zr_last_error().decode())
+
+
+def device_count():
+    n = C.c_int(0)
+    _check(lib().zr_device_count(C.byref(n)))
+    return n.value
+
+
+def alias_table_build(power, align_phase=0):
+    """zr_alias_table_build: host-side Vose build of the reference (PreLighting.cpp:27-158); needs no GPU."""
+    power = np.ascontiguousarray(power, np.float32)
+    out = np.zeros(len(power), wire.ALIAS_ENTRY)
+    _check(lib().zr_alias_table_build(power.ctypes.data, len(power), align_phase, out.ctypes.data))
+    return out
+
+
+class Scene:
+    def __init__(self, scene, device=0):
+        self.host = scene
+        self._desc = scene.desc()
+        self.h = C.c_void_p()
+        _check(lib().zr_scene_create(device, C.addressof(self._desc), C.byref(self.h)))
+
+    def set_alias_table(self, entries):
+        entries = np.ascontiguousarray(entries)
+        _check(lib().zr_scene_set_alias_table(self.h, entries.ctypes.data, len(entries)))
+
+    def get_alias_table(self):
+        out = np.zeros(len(self.host.emissives), wire.ALIAS_ENTRY)
+        _check(lib().zr_scene_get_alias_table(self.h, out.ctypes.data, len(out)))
+        return out
+
+    def bvh_info(self):
+        a, b, c = C.c_uint32(), C.c_uint32(), C.c_uint32()
+        _check(lib().zr_scene_bvh_info(self.h, C.byref(a), C.byref(b), C.byref(c)))
+        return a.value, b.value, c.value
+
+    def close(self):
+        if self.h:
+            lib().zr_scene_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class GBuffer:
+    def __init__(self, width, height, device=0):
+        self.w, self.h_ = width, height
+        self.h = C.c_void_p()
+        _check(lib().zr_gbuffer_create(device, width, height, C.byref(self.h)))
+
+    def set_tile_origin(self, x0, y0):
+        _check(lib().zr_gbuffer_set_tile_origin(self.h, x0, y0))
+
+    def download(self, stream=None):
+        arrays, planes = wire.alloc_gbuffer_planes(self.w, self.h_)
+        _check(lib().zr_gbuffer_download(self.h, stream, C.addressof(planes)))
+        return arrays, planes
+
+    def close(self):
+        if self.h:
+            lib().zr_gbuffer_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Pass:
+    """One RenderPass node (GBufferRT / PreLighting / IndirectLighting) behind the C-ABI."""
+
+    def __init__(self, kind, width, height, integrator=INTEGRATOR_PATH_TRACING, device=0, params=None):
+        self.kind = kind
+        self.w, self.h_ = width, height
+        self.h = C.c_void_p()
+        _check(lib().zr_pass_create(kind, device, C.byref(self.h)))
+        _check(lib().zr_pass_init(self.h, width, height, integrator))
+        if params is not None:
+            self.set_params(params)
+
+    def set_params(self, params):
+        _check(lib().zr_pass_set_params(self.h, C.addressof(params)))
+
+    def resize(self, width, height):
+        _check(lib().zr_pass_resize(self.h, width, height))
+        self.w, self.h_ = width, height
+
+    def reset_temporal(self):
+        _check(lib().zr_pass_reset_temporal(self.h))
+
+    def render(self, cb, scene, gbuffer=None, stream=None):
+        cbb = np.ascontiguousarray(cb)
+        _check(lib().zr_pass_render(self.h, stream, cbb.ctypes.data, scene.h, gbuffer.h if gbuffer is not None else None))
+
+    def output_ptr(self, which=OUT_FINAL):
+        dev = C.c_void_p()
+        w, h, bpp = C.c_uint32(), C.c_uint32(), C.c_uint32()
+        _check(lib().zr_pass_get_output(self.h, which, C.byref(dev), C.byref(w), C.byref(h), C.byref(bpp)))
+        return dev.value, w.value, h.value, bpp.value
+
+    def download(self, which=OUT_FINAL, stream=None):
+        out = np.zeros((self.h_, self.w, 4), np.float32)
+        _check(lib().zr_pass_download_output(self.h, which, stream, out.ctypes.data, out.nbytes))
+        return out
+
+    def read_counters(self, reset=True, stream=None):
+        c = wire.Counters()
+        _check(lib().zr_pass_read_counters(self.h, stream, C.addressof(c), int(reset)))
+        return c.n_closest, c.n_shadow
+
+    def enable_timing(self, on=True):
+        _check(lib().zr_pass_enable_timing(self.h, int(on)))
+
+    def timings(self):
+        n = 64
+        names = (C.c_char_p * n)()
+        ms = (C.c_float * n)()
+        launches = (C.c_uint32 * n)()
+        cnt = C.c_uint32()
+        _check(lib().zr_pass_get_timings(self.h, n, names, ms, launches, C.byref(cnt)))
+        return {names[i].decode(): (ms[i], launches[i]) for i in range(min(cnt.value, n))}
+
+    def close(self):
+        if self.h:
+            lib().zr_pass_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Renderer:
+    """Minimal host restatement of DefaultRenderer's per-frame order for the hot path
+    (Source/ZetaRenderer/Default/PathTracer.cpp:325-563): GBuffer -> PreLighting (+ alias table) -> Indirect."""
+
+    def __init__(self, scene_host, width, height, device=0, params=None, integrator=INTEGRATOR_PATH_TRACING,
+                 tile_origin=(0, 0)):
+        """width/height = size of the tile this renderer owns; tile_origin = its top-left pixel in the full target."""
+        self.scene = Scene(scene_host, device)
+        self.gbuffer = GBuffer(width, height, device)
+        if tile_origin != (0, 0):
+            self.gbuffer.set_tile_origin(*tile_origin)
+        self.p_gbuffer = Pass(PASS_GBUFFER, width, height, device=device)
+        self.p_prelight = Pass(PASS_PRELIGHTING, width, height, device=device)
+        self.p_indirect = Pass(PASS_INDIRECT, width, height, integrator, device=device, params=params)
+        self._alias_ready = False
+
+    def render_frame(self, cb, stream=None):
+        self.p_gbuffer.render(cb, self.scene, self.gbuffer, stream)
+        if not self._alias_ready:
+            self.p_prelight.render(cb, self.scene, None, stream)
+            self._alias_ready = True
+        self.p_indirect.render(cb, self.scene, self.gbuffer, stream)
+
+    def final(self):
+        return self.p_indirect.download()

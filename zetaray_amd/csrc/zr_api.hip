@@ -1,0 +1,748 @@
+// zr_api.hip -- HIP kernels (gfx950) and the C-ABI of libzetaray_amd.so (include/zetaray_amd.h).
+//
+// Kernel wrappers around the stage functions of zr_stages.h: pixel <-> lane mapping, wave-ballot stream compaction
+// into the SoA path queues, ray counters, per-kernel hipEvent timing.  Host side: scene upload + BVH build, G-buffer
+// planes, the pass objects mirroring the reference's RenderPass surface (citations in include/zetaray_amd.h).
+// There is no CPU fallback in this library: without a usable HIP device every compute entry point fails loudly.
+#include <hip/hip_runtime.h>
+#include <immintrin.h>
+#include <string>
+#include <vector>
+#include <cstdio>
+#include <cstdarg>
+#include <cstring>
+#include <new>
+#include "zr_stages.h"
+#include "zr_bvh.h"
+
+using namespace zr;
+
+// ------------------------------------------------------------------------------------------------ errors
+static thread_local std::string g_err;
+static int Fail(int code, const char* fmt, ...)
+{
+    char buf[512];
+    va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof(buf), fmt, ap); va_end(ap);
+    g_err = buf;
+    return code;
+}
+#define HIP_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return Fail(ZR_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); } while (0)
+
+static int RequireDevice(int device)
+{
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) return Fail(ZR_ERR_NO_DEVICE, "no usable HIP device (hipGetDeviceCount: %s); libzetaray_amd has no CPU path", hipGetErrorString(e));
+    if (device < 0 || device >= n) return Fail(ZR_ERR_INVALID_ARG, "device %d out of range (0..%d)", device, n - 1);
+    HIP_TRY(hipSetDevice(device));
+    return ZR_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ device helpers
+static constexpr int kBlock = 256;
+static constexpr int kStack = 48;
+
+// one atomic per wave: lanes that `want` a slot get consecutive indices
+__device__ __forceinline__ uint32_t AllocSlotWave(uint32_t* counter, bool want)
+{
+    const uint64_t m = __ballot(want);
+    if (m == 0) return 0;
+    const uint32_t lane = __lane_id();
+    const uint32_t prefix = __popcll(m & ((1ull << lane) - 1ull));
+    const int leader = __ffsll((long long)m) - 1;
+    uint32_t base = 0;
+    if ((int)lane == leader) base = atomicAdd(counter, (uint32_t)__popcll(m));
+    base = __shfl(base, leader);
+    return base + prefix;
+}
+__device__ __forceinline__ void CountWave(unsigned long long* counter, bool pred)
+{
+    const uint64_t m = __ballot(pred);
+    if (m && __lane_id() == (uint32_t)(__ffsll((long long)m) - 1)) atomicAdd(counter, (unsigned long long)__popcll(m));
+}
+
+// pixel mapping: a 256-thread block covers a 16x16 tile; each wave64 covers one 8x8 quadrant in row-major order, so
+// a wave is exactly one 8x8 thread group of the reference (GBufferRT_Common.h:6-7, IndirectLighting_Common.h:6-7).
+__device__ __forceinline__ void PixelOfThread(uint32_t tilesX, uint32_t x0, uint32_t y0, uint32_t* x, uint32_t* y)
+{
+    const uint32_t tile = blockIdx.x;
+    const uint32_t tx = tile % tilesX, ty = tile / tilesX;
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    *x = x0 + tx * 16u + (wave & 1u) * 8u + (lane & 7u);
+    *y = y0 + ty * 16u + (wave >> 1) * 8u + (lane >> 3);
+}
+
+__global__ void __launch_bounds__(kBlock) k_gbuffer(SceneView sc, zr_frame_constants g, GBuf gb, uint32_t tilesX)
+{
+    uint32_t x, y; PixelOfThread(tilesX, gb.x0, gb.y0, &x, &y);
+    if (x >= gb.x0 + gb.w || y >= gb.y0 + gb.h) return;
+    uint32_t stack[kStack];
+    GBufferPixel(sc, g, gb, x, y, stack, nullptr);
+}
+
+__global__ void __launch_bounds__(kBlock) k_pt_init(SceneView sc, zr_frame_constants g, GBuf gb, PtParams prm, float* finalRGBA,
+    F4* firstBOP, PathQueue out, uint32_t* outCount, uint32_t tilesX)
+{
+    uint32_t x, y; PixelOfThread(tilesX, gb.x0, gb.y0, &x, &y);
+    PathOut po; po.alive = false;
+    if (x < gb.x0 + gb.w && y < gb.y0 + gb.h) PtInitPixel(sc, g, gb, prm, x, y, finalRGBA, firstBOP, po);
+    const uint32_t slot = AllocSlotWave(outCount, po.alive);
+    if (po.alive) WritePath(out, slot, po);
+}
+
+// trace stage: grid-stride over 3 * n rays (C rays, then M rays, then S rays of the n live slots)
+__global__ void __launch_bounds__(kBlock) k_trace(SceneView sc, PathQueue q, const uint32_t* count, unsigned long long* counters)
+{
+    const uint32_t n = *count;
+    const uint32_t total = 3u * n;
+    uint32_t stack[kStack];
+    for (uint32_t base = blockIdx.x * kBlock; base < total; base += gridDim.x * kBlock)
+    {
+        const uint32_t j = base + threadIdx.x;
+        bool closest = false, shadow = false;
+        if (j < total)
+        {
+            const uint32_t type = j / n, i = j - type * n;
+            if (type == 0)
+            {
+                const F4 rd = q.rayC_d[i];
+                if (rd.w >= 0) { q.hitC[i] = TraceClosestRay(sc, q.rayC_o[i], rd, ZR_SUBGROUP_ALL, stack); closest = true; }
+                else { U4 miss; miss.x = 0; miss.y = 0; miss.z = 0; miss.w = kInvalidTri; q.hitC[i] = miss; }
+            }
+            else if (type == 1)
+            {
+                const F4 rd = q.rayM_d[i];
+                if (rd.w >= 0) { q.hitM[i] = TraceClosestRay(sc, q.rayM_o[i], rd, ZR_SUBGROUP_ALL, stack); closest = true; }
+            }
+            else
+            {
+                const F4 rd = q.rayS_d[i];
+                if (rd.w >= 0) { q.visS[i] = TraceSegmentRay(sc, q.rayS_o[i], rd, q.sLightID[i], stack); shadow = true; }
+            }
+        }
+        CountWave(&counters[0], closest);
+        CountWave(&counters[1], shadow);
+    }
+}
+
+__global__ void __launch_bounds__(kBlock) k_pt_shade(SceneView sc, zr_frame_constants g, PtParams prm, PathQueue in, const uint32_t* inCount,
+    PathQueue out, uint32_t* outCount, float* finalRGBA, const F4* firstBOP)
+{
+    const uint32_t n = *inCount;
+    for (uint32_t base = blockIdx.x * kBlock; base < n; base += gridDim.x * kBlock)
+    {
+        const uint32_t i = base + threadIdx.x;
+        PathOut po; po.alive = false;
+        if (i < n) PtShadePath(sc, g, prm, in, i, finalRGBA, firstBOP, po);
+        const uint32_t slot = AllocSlotWave(outCount, po.alive);
+        if (po.alive) WritePath(out, slot, po);
+    }
+}
+
+__global__ void k_estimate_power(const zr_emissive_triangle* em, uint32_t n, float* power)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) power[i] = EstimateTriPower(em[i]);
+}
+
+// generic ray-query kernels behind zr_trace_closest / zr_trace_any
+__global__ void __launch_bounds__(kBlock) k_trace_rays(SceneView sc, const F4* rays, uint32_t n, uint32_t mask, U4* hits)
+{
+    uint32_t stack[kStack];
+    for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock)
+        hits[i] = TraceClosestRay(sc, rays[2 * i], rays[2 * i + 1], mask, stack);
+}
+__global__ void __launch_bounds__(kBlock) k_trace_rays_any(SceneView sc, const F4* rays, uint32_t n, uint32_t mask, uint32_t* occ)
+{
+    uint32_t stack[kStack];
+    for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock)
+    {
+        const F4 ro = rays[2 * i], rd = rays[2 * i + 1];
+        RawHit h = Traverse<true>(sc, xyz(ro), xyz(rd), ro.w, rd.w, mask, stack);
+        occ[i] = h.tri != kInvalidTri ? 1u : 0u;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ host objects
+template<typename T> struct DevBuf
+{
+    T* p = nullptr; size_t n = 0;
+    int Alloc(size_t count) { Free(); n = count; if (!count) return ZR_OK; hipError_t e = hipMalloc((void**)&p, count * sizeof(T)); if (e != hipSuccess) { p = nullptr; return Fail(ZR_ERR_OOM, "hipMalloc(%zu B) failed: %s", count * sizeof(T), hipGetErrorString(e)); } return ZR_OK; }
+    int Upload(const T* src, size_t count) { int r = Alloc(count); if (r) return r; if (count) HIP_TRY(hipMemcpy(p, src, count * sizeof(T), hipMemcpyHostToDevice)); return ZR_OK; }
+    void Free() { if (p) { (void)hipFree(p); p = nullptr; } n = 0; }
+    ~DevBuf() { Free(); }
+};
+
+struct zr_scene
+{
+    int device = 0;
+    DevBuf<zr_vertex> vertices; DevBuf<uint32_t> indices; DevBuf<zr_mesh_instance> instances; DevBuf<zr_material> materials;
+    DevBuf<zr_emissive_triangle> emissives; DevBuf<zr_alias_entry> alias; DevBuf<BvhNode> nodes; DevBuf<BvhTri> tris;
+    DevBuf<TriMeta> meta; DevBuf<uint16_t> rho;
+    std::vector<zr_alias_entry> aliasHost;
+    SceneView view{};
+    uint32_t maxDepth = 0;
+};
+
+struct zr_gbuffer
+{
+    int device = 0; uint32_t w = 0, h = 0, x0 = 0, y0 = 0;
+    DevBuf<uint8_t> planes[ZR_GB_COUNT];
+    GBuf View() const
+    {
+        GBuf g; g.w = w; g.h = h; g.x0 = x0; g.y0 = y0;
+        g.baseColor = (uint32_t*)planes[ZR_GB_BASE_COLOR].p; g.normal = (uint32_t*)planes[ZR_GB_NORMAL].p;
+        g.mr = (uint16_t*)planes[ZR_GB_METALLIC_ROUGHNESS].p; g.motion = (uint32_t*)planes[ZR_GB_MOTION_VECTOR].p;
+        g.emissive = (uint32_t*)planes[ZR_GB_EMISSIVE_COLOR].p; g.ior = (uint8_t*)planes[ZR_GB_IOR].p;
+        g.coat = (uint16_t*)planes[ZR_GB_COAT].p; g.depth = (float*)planes[ZR_GB_DEPTH].p;
+        g.triA = (uint32_t*)planes[ZR_GB_TRI_DIFF_GEO_A].p; g.triB = (uint32_t*)planes[ZR_GB_TRI_DIFF_GEO_B].p;
+        return g;
+    }
+};
+
+struct QueueStorage
+{
+    DevBuf<U4> s0; DevBuf<F4> f[8]; DevBuf<F4> rays[6]; DevBuf<uint32_t> lightID; DevBuf<U4> hitC, hitM; DevBuf<uint32_t> visS;
+    int Alloc(size_t cap)
+    {
+        int r;
+        if ((r = s0.Alloc(cap))) return r;
+        for (auto& b : f) if ((r = b.Alloc(cap))) return r;
+        for (auto& b : rays) if ((r = b.Alloc(cap))) return r;
+        if ((r = lightID.Alloc(cap))) return r;
+        if ((r = hitC.Alloc(cap))) return r;
+        if ((r = hitM.Alloc(cap))) return r;
+        if ((r = visS.Alloc(cap))) return r;
+        return ZR_OK;
+    }
+    PathQueue View() const
+    {
+        PathQueue q;
+        q.s0 = s0.p; q.s1 = f[0].p; q.s2 = f[1].p; q.s3 = f[2].p; q.s4 = f[3].p; q.s5 = f[4].p; q.s6 = f[5].p; q.s7 = f[6].p; q.s8 = f[7].p;
+        q.rayC_o = rays[0].p; q.rayC_d = rays[1].p; q.rayM_o = rays[2].p; q.rayM_d = rays[3].p; q.rayS_o = rays[4].p; q.rayS_d = rays[5].p;
+        q.sLightID = lightID.p; q.hitC = hitC.p; q.hitM = hitM.p; q.visS = visS.p;
+        return q;
+    }
+};
+
+static constexpr int kMaxRounds = 16;
+static constexpr int kMaxTimers = 64;
+
+struct zr_pass
+{
+    int kind = 0, device = 0, integrator = 0;
+    bool initialized = false;
+    uint32_t w = 0, h = 0;
+    zr_params params{};
+    // INDIRECT
+    QueueStorage q[2];
+    DevBuf<float> finalRGBA; DevBuf<F4> firstBOP; DevBuf<uint32_t> counts; DevBuf<unsigned long long> counters;
+    zr_counters hostCounters{0, 0};
+    // PRELIGHTING
+    DevBuf<float> power;
+    // timing
+    bool timing = false;
+    struct Timer { const char* name; hipEvent_t a, b; bool used; };
+    std::vector<Timer> timers;
+    int numTimers = 0;
+    std::vector<std::string> timerNames; std::vector<float> timerMs; std::vector<uint32_t> timerLaunches;
+};
+
+// ------------------------------------------------------------------------------------------------ timing helpers
+static void TimerBegin(zr_pass* p, hipStream_t s, const char* name)
+{
+    if (!p->timing) return;
+    if (p->numTimers >= (int)p->timers.size())
+    {
+        zr_pass::Timer t; t.name = name; t.used = false;
+        if (hipEventCreate(&t.a) != hipSuccess || hipEventCreate(&t.b) != hipSuccess) return;
+        p->timers.push_back(t);
+    }
+    zr_pass::Timer& t = p->timers[p->numTimers];
+    t.name = name; t.used = true;
+    (void)hipEventRecord(t.a, s);
+}
+static void TimerEnd(zr_pass* p, hipStream_t s)
+{
+    if (!p->timing) return;
+    if (p->numTimers >= (int)p->timers.size()) return;
+    (void)hipEventRecord(p->timers[p->numTimers].b, s);
+    p->numTimers++;
+}
+
+// ------------------------------------------------------------------------------------------------ alias table (host)
+// Math::KahanSum (Source/ZetaCore/Math/Common.cpp:72-139) with the reference's AVX2 lane structure.  `phase` floats of
+// scalar head emulate a pointer that is `phase` floats short of 32-byte alignment (0 for the reference's allocations).
+static float KahanSumAVX2(const float* data, int64_t N, int64_t phase)
+{
+    float sum = 0.0f, compensation = 0.0f;
+    const int64_t start = phase < N ? phase : N;
+    for (int64_t i = 0; i < start; i++)
+    {
+        volatile float corrected = data[i] - compensation;
+        volatile float newSum = sum + corrected;
+        compensation = (newSum - sum) - corrected;
+        sum = newSum;
+    }
+    int64_t numSimd = (N - start);
+    numSimd -= numSimd & 15;
+    __m256 vSum = _mm256_setzero_ps(), vComp = _mm256_setzero_ps();
+    for (int64_t c = start; c < start + numSimd; c += 16)
+    {
+        __m256 V1 = _mm256_loadu_ps(data + c), V2 = _mm256_loadu_ps(data + c + 8);
+        __m256 vCurr = _mm256_add_ps(V1, V2);
+        __m256 vCorrected = _mm256_sub_ps(vCurr, vComp);
+        __m256 vNewSum = _mm256_add_ps(vSum, vCorrected);
+        vComp = _mm256_sub_ps(vNewSum, vSum);
+        vComp = _mm256_sub_ps(vComp, vCorrected);
+        vSum = vNewSum;
+    }
+    alignas(32) float simdSum[8], simdComp[8];
+    _mm256_store_ps(simdSum, vSum); _mm256_store_ps(simdComp, vComp);
+    for (int i = 0; i < 8; i++)
+    {
+        volatile float corrected = simdSum[i] - compensation - simdComp[i];
+        volatile float newSum = sum + corrected;
+        compensation = (newSum - sum) - corrected;
+        sum = newSum;
+    }
+    for (int64_t i = start + numSimd; i < N; i++)
+    {
+        volatile float corrected = data[i] - compensation;
+        volatile float newSum = sum + corrected;
+        compensation = (newSum - sum) - corrected;
+        sum = newSum;
+    }
+    return sum;
+}
+
+// BuildAliasTable (Source/ZetaRenderPass/PreLighting/PreLighting.cpp:27-158): Vose's method with LIFO index stacks.
+static void BuildAliasTableHost(std::vector<float>& probs, zr_alias_entry* table, uint32_t phase)
+{
+    const int64_t N = (int64_t)probs.size();
+    const float oneDivN = 1.0f / (float)N;
+    const float sum = KahanSumAVX2(probs.data(), N, phase);
+    const float sumRcp = (float)N / sum;
+    for (int64_t i = 0; i < N; i++) probs[i] *= sumRcp;
+    for (int64_t i = 0; i < N; i++) { table[i].cached_p_orig = probs[i] * oneDivN; table[i].alias = 0xffffffffu; table[i].p_curr = 0.0f; }
+    std::vector<uint32_t> larger, smaller;
+    larger.reserve(N); smaller.reserve(N);
+    for (int64_t i = 0; i < N; i++) (probs[i] < 1.0f ? smaller : larger).push_back((uint32_t)i);
+    while (!smaller.empty() && !larger.empty())
+    {
+        const uint32_t si = smaller.back(); smaller.pop_back();
+        const float sp = probs[si];
+        const uint32_t li = larger.back();
+        float lp = probs[li];
+        table[si].alias = li; table[si].p_curr = sp;
+        lp = (sp + lp) - 1.0f;
+        probs[li] = lp;
+        if (lp < 1.0f) { larger.pop_back(); smaller.push_back(li); }
+    }
+    for (; !larger.empty(); larger.pop_back()) { table[larger.back()].alias = larger.back(); table[larger.back()].p_curr = 1.0f; }
+    for (; !smaller.empty(); smaller.pop_back()) { table[smaller.back()].alias = smaller.back(); table[smaller.back()].p_curr = 1.0f; }
+    for (int64_t i = 0; i < N; i++) table[i].cached_p_alias = table[table[i].alias].cached_p_orig;
+}
+
+// ------------------------------------------------------------------------------------------------ C-ABI
+extern "C" {
+
+int zr_abi_version(void) { return ZR_ABI_VERSION; }
+const char* zr_last_error(void) { return g_err.c_str(); }
+
+int zr_device_count(int* count)
+{
+    if (!count) return Fail(ZR_ERR_INVALID_ARG, "count is null");
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    *count = (e == hipSuccess) ? n : 0;
+    return ZR_OK;
+}
+
+int zr_params_default(zr_params* p)
+{
+    if (!p) return Fail(ZR_ERR_INVALID_ARG, "params is null");
+    memset(p, 0, sizeof(*p));
+    p->flags = ZR_IND_TEMPORAL_RESAMPLE | ZR_IND_SPATIAL_RESAMPLE | ZR_IND_RUSSIAN_ROULETTE | ZR_IND_BOILING_SUPPRESSION |
+               ZR_IND_SORT_TEMPORAL | ZR_IND_SORT_SPATIAL;
+    p->max_non_tr_bounces = 3; p->max_glossy_tr_bounces = 4; p->m_max_temporal = 10; p->m_max_spatial = 8;
+    p->alpha_min = 0.175f * 0.175f; p->presampling = 0; p->num_sample_sets = 128; p->sample_set_size = 512;
+    return ZR_OK;
+}
+
+int zr_alias_table_build(const float* power, uint32_t n, uint32_t align_phase, zr_alias_entry* out)
+{
+    if (!power || !out || n == 0) return Fail(ZR_ERR_INVALID_ARG, "zr_alias_table_build: null/empty input");
+    std::vector<float> probs(power, power + n);
+    BuildAliasTableHost(probs, out, align_phase);
+    return ZR_OK;
+}
+
+int zr_scene_create(int device, const zr_scene_desc* d, zr_scene** out)
+{
+    if (!d || !out) return Fail(ZR_ERR_INVALID_ARG, "zr_scene_create: null argument");
+    if (!d->vertices || !d->indices || !d->instances || !d->materials || !d->rho_lut || !d->instance_to_world || !d->instance_mask || !d->instance_num_tris)
+        return Fail(ZR_ERR_INVALID_ARG, "zr_scene_create: incomplete scene description");
+    int r = RequireDevice(device);
+    if (r) return r;
+    zr_scene* s = new (std::nothrow) zr_scene();
+    if (!s) return Fail(ZR_ERR_OOM, "out of host memory");
+    s->device = device;
+    BvhBuilder builder;
+    BuiltBvh bvh = builder.Build(*d);
+    if (bvh.maxDepth + 2 > (uint32_t)kStack) { delete s; return Fail(ZR_ERR_UNSUPPORTED, "BVH depth %u exceeds traversal stack", bvh.maxDepth); }
+    s->maxDepth = bvh.maxDepth;
+#define UP(buf, ptr, cnt) if ((r = s->buf.Upload(ptr, cnt))) { delete s; return r; }
+    UP(vertices, d->vertices, d->num_vertices);
+    UP(indices, d->indices, d->num_indices);
+    UP(instances, d->instances, d->num_instances);
+    UP(materials, d->materials, d->num_materials);
+    UP(emissives, d->emissives, d->num_emissives);
+    UP(nodes, bvh.nodes.data(), bvh.nodes.size());
+    UP(tris, bvh.tris.data(), bvh.tris.size());
+    UP(meta, bvh.meta.data(), bvh.meta.size());
+    UP(rho, d->rho_lut, (size_t)d->rho_dim[0] * d->rho_dim[1] * d->rho_dim[2]);
+#undef UP
+    SceneView& v = s->view;
+    v.vertices = s->vertices.p; v.indices = s->indices.p; v.instances = s->instances.p; v.materials = s->materials.p;
+    v.emissives = s->emissives.p; v.alias = nullptr; v.nodes = s->nodes.p; v.tris = s->tris.p; v.triMeta = s->meta.p;
+    v.rho.data = s->rho.p; v.rho.dx = d->rho_dim[0]; v.rho.dy = d->rho_dim[1]; v.rho.dz = d->rho_dim[2];
+    v.numEmissives = d->num_emissives; v.numNodes = (uint32_t)bvh.nodes.size(); v.numTris = (uint32_t)bvh.tris.size();
+    *out = s;
+    return ZR_OK;
+}
+
+int zr_scene_destroy(zr_scene* s) { delete s; return ZR_OK; }
+
+int zr_scene_set_alias_table(zr_scene* s, const zr_alias_entry* e, uint32_t n)
+{
+    if (!s || !e) return Fail(ZR_ERR_INVALID_ARG, "zr_scene_set_alias_table: null argument");
+    if (n != s->view.numEmissives) return Fail(ZR_ERR_INVALID_ARG, "alias table size %u != number of emissive triangles %u", n, s->view.numEmissives);
+    HIP_TRY(hipSetDevice(s->device));
+    int r = s->alias.Upload(e, n);
+    if (r) return r;
+    s->aliasHost.assign(e, e + n);
+    s->view.alias = s->alias.p;
+    return ZR_OK;
+}
+
+int zr_scene_get_alias_table(const zr_scene* s, zr_alias_entry* out, uint32_t n)
+{
+    if (!s || !out) return Fail(ZR_ERR_INVALID_ARG, "null argument");
+    if (n != s->aliasHost.size()) return Fail(ZR_ERR_INVALID_ARG, "alias table has %zu entries", s->aliasHost.size());
+    memcpy(out, s->aliasHost.data(), n * sizeof(zr_alias_entry));
+    return ZR_OK;
+}
+
+int zr_scene_bvh_info(const zr_scene* s, uint32_t* num_nodes, uint32_t* num_tris, uint32_t* max_depth)
+{
+    if (!s) return Fail(ZR_ERR_INVALID_ARG, "null scene");
+    if (num_nodes) *num_nodes = s->view.numNodes;
+    if (num_tris) *num_tris = s->view.numTris;
+    if (max_depth) *max_depth = s->maxDepth;
+    return ZR_OK;
+}
+
+int zr_gbuffer_create(int device, uint32_t w, uint32_t h, zr_gbuffer** out)
+{
+    if (!out || !w || !h) return Fail(ZR_ERR_INVALID_ARG, "zr_gbuffer_create: bad argument");
+    int r = RequireDevice(device);
+    if (r) return r;
+    zr_gbuffer* g = new (std::nothrow) zr_gbuffer();
+    if (!g) return Fail(ZR_ERR_OOM, "out of host memory");
+    g->device = device; g->w = w; g->h = h;
+    for (int i = 0; i < ZR_GB_COUNT; i++)
+    {
+        if ((r = g->planes[i].Alloc((size_t)w * h * ZR_GB_PLANE_BYTES[i]))) { delete g; return r; }
+        hipError_t e = hipMemset(g->planes[i].p, 0, g->planes[i].n);
+        if (e != hipSuccess) { delete g; return Fail(ZR_ERR_HIP, "hipMemset failed: %s", hipGetErrorString(e)); }
+    }
+    *out = g;
+    return ZR_OK;
+}
+int zr_gbuffer_destroy(zr_gbuffer* g) { delete g; return ZR_OK; }
+int zr_gbuffer_set_tile_origin(zr_gbuffer* g, uint32_t x0, uint32_t y0)
+{
+    if (!g) return Fail(ZR_ERR_INVALID_ARG, "null gbuffer");
+    if ((x0 & 31u) || (y0 & 31u)) return Fail(ZR_ERR_INVALID_ARG, "tile origin must be 32-pixel aligned");
+    g->x0 = x0; g->y0 = y0;
+    return ZR_OK;
+}
+
+int zr_gbuffer_download(const zr_gbuffer* g, void* stream, zr_gbuffer_planes* hp)
+{
+    if (!g || !hp) return Fail(ZR_ERR_INVALID_ARG, "null argument");
+    if (hp->width != g->w || hp->height != g->h) return Fail(ZR_ERR_INVALID_ARG, "plane size mismatch");
+    HIP_TRY(hipSetDevice(g->device));
+    HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+    for (int i = 0; i < ZR_GB_COUNT; i++)
+        if (hp->plane[i]) HIP_TRY(hipMemcpy(hp->plane[i], g->planes[i].p, g->planes[i].n, hipMemcpyDeviceToHost));
+    return ZR_OK;
+}
+int zr_gbuffer_device_plane(const zr_gbuffer* g, int plane, void** dev)
+{
+    if (!g || !dev || plane < 0 || plane >= ZR_GB_COUNT) return Fail(ZR_ERR_INVALID_ARG, "bad argument");
+    *dev = g->planes[plane].p;
+    return ZR_OK;
+}
+
+int zr_pass_create(int kind, int device, zr_pass** out)
+{
+    if (!out) return Fail(ZR_ERR_INVALID_ARG, "null out");
+    if (kind < ZR_PASS_GBUFFER || kind > ZR_PASS_INDIRECT) return Fail(ZR_ERR_INVALID_ARG, "unknown pass kind %d", kind);
+    if (kind == ZR_PASS_DI_EMISSIVE || kind == ZR_PASS_DI_SKY) return Fail(ZR_ERR_UNSUPPORTED, "pass kind %d (ReSTIR DI) is not implemented yet", kind);
+    int r = RequireDevice(device);
+    if (r) return r;
+    zr_pass* p = new (std::nothrow) zr_pass();
+    if (!p) return Fail(ZR_ERR_OOM, "out of host memory");
+    p->kind = kind; p->device = device;
+    zr_params_default(&p->params);
+    *out = p;
+    return ZR_OK;
+}
+
+static int AllocPass(zr_pass* p)
+{
+    int r;
+    if (p->kind == ZR_PASS_INDIRECT)
+    {
+        const size_t cap = (size_t)p->w * p->h;
+        if ((r = p->q[0].Alloc(cap))) return r;
+        if ((r = p->q[1].Alloc(cap))) return r;
+        if ((r = p->finalRGBA.Alloc(cap * 4))) return r;
+        if ((r = p->firstBOP.Alloc(cap))) return r;
+        if ((r = p->counts.Alloc(kMaxRounds + 2))) return r;
+        if ((r = p->counters.Alloc(2))) return r;
+        HIP_TRY(hipMemset(p->finalRGBA.p, 0, cap * 4 * sizeof(float)));
+        HIP_TRY(hipMemset(p->counters.p, 0, 2 * sizeof(unsigned long long)));
+    }
+    return ZR_OK;
+}
+
+int zr_pass_init(zr_pass* p, uint32_t w, uint32_t h, int integrator)
+{
+    if (!p || !w || !h) return Fail(ZR_ERR_INVALID_ARG, "zr_pass_init: bad argument");
+    if (p->kind == ZR_PASS_INDIRECT && integrator != ZR_INTEGRATOR_PATH_TRACING)
+        return Fail(ZR_ERR_UNSUPPORTED, "integrator %d is not implemented yet (PATH_TRACING only)", integrator);
+    HIP_TRY(hipSetDevice(p->device));
+    p->w = w; p->h = h; p->integrator = integrator;
+    int r = AllocPass(p);
+    if (r) return r;
+    p->initialized = true;
+    return ZR_OK;
+}
+int zr_pass_resize(zr_pass* p, uint32_t w, uint32_t h)
+{
+    if (!p) return Fail(ZR_ERR_INVALID_ARG, "null pass");
+    if (!p->initialized) return Fail(ZR_ERR_NOT_INITIALIZED, "pass not initialised");
+    return zr_pass_init(p, w, h, p->integrator);
+}
+int zr_pass_reset_temporal(zr_pass* p)
+{
+    if (!p) return Fail(ZR_ERR_INVALID_ARG, "null pass");
+    if (!p->initialized) return Fail(ZR_ERR_NOT_INITIALIZED, "pass not initialised");
+    HIP_TRY(hipSetDevice(p->device));
+    if (p->kind == ZR_PASS_INDIRECT) HIP_TRY(hipMemset(p->finalRGBA.p, 0, p->finalRGBA.n * sizeof(float)));
+    return ZR_OK;
+}
+int zr_pass_set_params(zr_pass* p, const zr_params* prm)
+{
+    if (!p || !prm) return Fail(ZR_ERR_INVALID_ARG, "null argument");
+    if (prm->max_non_tr_bounces < 1 || prm->max_non_tr_bounces > 15 || prm->max_glossy_tr_bounces < 1 || prm->max_glossy_tr_bounces > 15)
+        return Fail(ZR_ERR_INVALID_ARG, "bounce counts must be in 1..15");
+    if (prm->presampling) return Fail(ZR_ERR_UNSUPPORTED, "light presampling is not implemented yet");
+    p->params = *prm;
+    return ZR_OK;
+}
+
+static int RenderGBuffer(zr_pass* p, hipStream_t s, const zr_frame_constants* cb, const zr_scene* sc, zr_gbuffer* gb)
+{
+    if (!gb) return Fail(ZR_ERR_INVALID_ARG, "GBUFFER pass needs a gbuffer");
+    if (gb->x0 + gb->w > cb->render_width || gb->y0 + gb->h > cb->render_height) return Fail(ZR_ERR_INVALID_ARG, "gbuffer tile lies outside the render target of the frame constants");
+    const uint32_t tilesX = (gb->w + 15) / 16, tilesY = (gb->h + 15) / 16;
+    TimerBegin(p, s, "gbuffer");
+    hipLaunchKernelGGL(k_gbuffer, dim3(tilesX * tilesY), dim3(kBlock), 0, s, sc->view, *cb, gb->View(), tilesX);
+    TimerEnd(p, s);
+    HIP_TRY(hipGetLastError());
+    p->hostCounters.n_closest += (uint64_t)gb->w * gb->h;
+    return ZR_OK;
+}
+
+static int RenderPreLighting(zr_pass* p, hipStream_t s, zr_scene* sc)
+{
+    const uint32_t n = sc->view.numEmissives;
+    if (n == 0) return ZR_OK;
+    int r = p->power.Alloc(n);
+    if (r) return r;
+    TimerBegin(p, s, "estimate_power");
+    hipLaunchKernelGGL(k_estimate_power, dim3((n + 255) / 256), dim3(256), 0, s, sc->emissives.p, n, p->power.p);
+    TimerEnd(p, s);
+    HIP_TRY(hipGetLastError());
+    // EmissiveTriangleAliasTable::Render (PreLighting.cpp:512-585): read back, build on the host, upload
+    std::vector<float> power(n);
+    HIP_TRY(hipMemcpyAsync(power.data(), p->power.p, n * sizeof(float), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    std::vector<zr_alias_entry> table(n);
+    BuildAliasTableHost(power, table.data(), 0);
+    return zr_scene_set_alias_table(sc, table.data(), n);
+}
+
+static int RenderIndirect(zr_pass* p, hipStream_t s, const zr_frame_constants* cb, const zr_scene* sc, zr_gbuffer* gb)
+{
+    if (!gb) return Fail(ZR_ERR_INVALID_ARG, "INDIRECT pass needs a gbuffer");
+    if (gb->w != p->w || gb->h != p->h || gb->x0 + gb->w > cb->render_width || gb->y0 + gb->h > cb->render_height)
+        return Fail(ZR_ERR_INVALID_ARG, "frame constants / gbuffer tile / pass size mismatch");
+    if (sc->view.numEmissives == 0) return Fail(ZR_ERR_UNSUPPORTED, "scenes without emissive triangles (sun/sky NEE) are not implemented yet");
+    if (!sc->view.alias) return Fail(ZR_ERR_NOT_INITIALIZED, "emissive alias table missing: render the PRELIGHTING pass (or zr_scene_set_alias_table) first");
+    if (cb->num_emissive_triangles != sc->view.numEmissives) return Fail(ZR_ERR_INVALID_ARG, "cbFrameConstants.NumEmissiveTriangles != scene");
+    PtParams prm;
+    prm.maxNonTrBounces = p->params.max_non_tr_bounces; prm.maxGlossyTrBounces = p->params.max_glossy_tr_bounces;
+    prm.russianRoulette = (p->params.flags & ZR_IND_RUSSIAN_ROULETTE) ? 1u : 0u;
+    prm.numSampleSets = p->params.presampling ? p->params.num_sample_sets : 0u;
+    prm.accumulate = (cb->accumulate && cb->camera_static) ? 1u : 0u;
+    const uint32_t maxB = prm.maxNonTrBounces > prm.maxGlossyTrBounces ? prm.maxNonTrBounces : prm.maxGlossyTrBounces;
+    const int rounds = (int)maxB + 1;
+    if (rounds > kMaxRounds) return Fail(ZR_ERR_INVALID_ARG, "too many bounces");
+
+    HIP_TRY(hipMemsetAsync(p->counts.p, 0, (kMaxRounds + 2) * sizeof(uint32_t), s));
+    const uint32_t tilesX = (p->w + 15) / 16, tilesY = (p->h + 15) / 16;
+    const GBuf gbv = gb->View();
+    TimerBegin(p, s, "pt_init");
+    hipLaunchKernelGGL(k_pt_init, dim3(tilesX * tilesY), dim3(kBlock), 0, s, sc->view, *cb, gbv, prm, p->finalRGBA.p, p->firstBOP.p,
+        p->q[0].View(), p->counts.p + 0, tilesX);
+    TimerEnd(p, s);
+    const size_t cap = (size_t)p->w * p->h;
+    const uint32_t gridShade = (uint32_t)std::min<size_t>((cap + kBlock - 1) / kBlock, 4096);
+    const uint32_t gridTrace = (uint32_t)std::min<size_t>((3 * cap + kBlock - 1) / kBlock, 8192);
+    for (int r = 0; r < rounds; r++)
+    {
+        const PathQueue qin = p->q[r & 1].View(), qout = p->q[(r + 1) & 1].View();
+        TimerBegin(p, s, "trace");
+        hipLaunchKernelGGL(k_trace, dim3(gridTrace), dim3(kBlock), 0, s, sc->view, qin, p->counts.p + r, p->counters.p);
+        TimerEnd(p, s);
+        TimerBegin(p, s, "pt_shade");
+        hipLaunchKernelGGL(k_pt_shade, dim3(gridShade), dim3(kBlock), 0, s, sc->view, *cb, prm, qin, p->counts.p + r, qout, p->counts.p + r + 1,
+            p->finalRGBA.p, p->firstBOP.p);
+        TimerEnd(p, s);
+    }
+    HIP_TRY(hipGetLastError());
+    return ZR_OK;
+}
+
+int zr_pass_render(zr_pass* p, void* stream, const zr_frame_constants* cb, const zr_scene* sc, zr_gbuffer* gb)
+{
+    if (!p || !cb || !sc) return Fail(ZR_ERR_INVALID_ARG, "zr_pass_render: null argument");
+    if (!p->initialized) return Fail(ZR_ERR_NOT_INITIALIZED, "pass not initialised (zr_pass_init)");
+    if (sc->device != p->device || (gb && gb->device != p->device)) return Fail(ZR_ERR_INVALID_ARG, "scene / gbuffer / pass live on different devices");
+    HIP_TRY(hipSetDevice(p->device));
+    hipStream_t s = (hipStream_t)stream;
+    p->numTimers = 0;
+    switch (p->kind)
+    {
+    case ZR_PASS_GBUFFER: return RenderGBuffer(p, s, cb, sc, gb);
+    case ZR_PASS_PRELIGHTING: return RenderPreLighting(p, s, const_cast<zr_scene*>(sc));
+    case ZR_PASS_INDIRECT: return RenderIndirect(p, s, cb, sc, gb);
+    default: return Fail(ZR_ERR_UNSUPPORTED, "pass kind %d not implemented", p->kind);
+    }
+}
+
+int zr_pass_get_output(const zr_pass* p, int which, void** dev, uint32_t* w, uint32_t* h, uint32_t* bpp)
+{
+    if (!p || !dev) return Fail(ZR_ERR_INVALID_ARG, "null argument");
+    if (!p->initialized) return Fail(ZR_ERR_NOT_INITIALIZED, "pass not initialised");
+    if (p->kind != ZR_PASS_INDIRECT || which != ZR_OUT_FINAL) return Fail(ZR_ERR_INVALID_ARG, "pass has no such output");
+    *dev = p->finalRGBA.p;
+    if (w) *w = p->w;
+    if (h) *h = p->h;
+    if (bpp) *bpp = 16;
+    return ZR_OK;
+}
+int zr_pass_download_output(const zr_pass* p, int which, void* stream, void* dst, size_t bytes)
+{
+    void* dev = nullptr; uint32_t w, h, bpp;
+    int r = zr_pass_get_output(p, which, &dev, &w, &h, &bpp);
+    if (r) return r;
+    if (!dst || bytes != (size_t)w * h * bpp) return Fail(ZR_ERR_INVALID_ARG, "destination must hold %zu bytes", (size_t)w * h * bpp);
+    HIP_TRY(hipSetDevice(p->device));
+    HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+    HIP_TRY(hipMemcpy(dst, dev, bytes, hipMemcpyDeviceToHost));
+    return ZR_OK;
+}
+int zr_pass_read_counters(zr_pass* p, void* stream, zr_counters* out, int reset)
+{
+    if (!p || !out) return Fail(ZR_ERR_INVALID_ARG, "null argument");
+    HIP_TRY(hipSetDevice(p->device));
+    out->n_closest = p->hostCounters.n_closest; out->n_shadow = p->hostCounters.n_shadow;
+    if (p->kind == ZR_PASS_INDIRECT && p->initialized)
+    {
+        unsigned long long c[2];
+        HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+        HIP_TRY(hipMemcpy(c, p->counters.p, sizeof(c), hipMemcpyDeviceToHost));
+        out->n_closest += c[0]; out->n_shadow += c[1];
+        if (reset) HIP_TRY(hipMemset(p->counters.p, 0, sizeof(c)));
+    }
+    if (reset) { p->hostCounters.n_closest = 0; p->hostCounters.n_shadow = 0; }
+    return ZR_OK;
+}
+int zr_pass_enable_timing(zr_pass* p, int enable)
+{
+    if (!p) return Fail(ZR_ERR_INVALID_ARG, "null pass");
+    p->timing = enable != 0;
+    return ZR_OK;
+}
+int zr_pass_get_timings(zr_pass* p, uint32_t max_entries, const char** names, float* ms, uint32_t* launches, uint32_t* count)
+{
+    if (!p || !count) return Fail(ZR_ERR_INVALID_ARG, "null argument");
+    HIP_TRY(hipSetDevice(p->device));
+    p->timerNames.clear(); p->timerMs.clear(); p->timerLaunches.clear();
+    for (int i = 0; i < p->numTimers; i++)
+    {
+        zr_pass::Timer& t = p->timers[i];
+        HIP_TRY(hipEventSynchronize(t.b));
+        float dt = 0;
+        HIP_TRY(hipEventElapsedTime(&dt, t.a, t.b));
+        size_t k = 0;
+        for (; k < p->timerNames.size(); k++) if (p->timerNames[k] == t.name) break;
+        if (k == p->timerNames.size()) { p->timerNames.push_back(t.name); p->timerMs.push_back(0); p->timerLaunches.push_back(0); }
+        p->timerMs[k] += dt; p->timerLaunches[k]++;
+    }
+    *count = (uint32_t)p->timerNames.size();
+    for (uint32_t k = 0; k < *count && k < max_entries; k++)
+    {
+        if (names) names[k] = p->timerNames[k].c_str();
+        if (ms) ms[k] = p->timerMs[k];
+        if (launches) launches[k] = p->timerLaunches[k];
+    }
+    return ZR_OK;
+}
+int zr_pass_destroy(zr_pass* p)
+{
+    if (!p) return ZR_OK;
+    (void)hipSetDevice(p->device);
+    for (auto& t : p->timers) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); }
+    delete p;
+    return ZR_OK;
+}
+
+int zr_trace_closest(const zr_scene* sc, void* stream, const float* d_rays, uint32_t n, uint32_t mask, uint32_t* d_hits)
+{
+    if (!sc || !d_rays || !d_hits) return Fail(ZR_ERR_INVALID_ARG, "null argument");
+    if (n == 0) return ZR_OK;
+    HIP_TRY(hipSetDevice(sc->device));
+    const uint32_t grid = std::min<uint32_t>((n + kBlock - 1) / kBlock, 8192u);
+    hipLaunchKernelGGL(k_trace_rays, dim3(grid), dim3(kBlock), 0, (hipStream_t)stream, sc->view, (const F4*)d_rays, n, mask, (U4*)d_hits);
+    HIP_TRY(hipGetLastError());
+    return ZR_OK;
+}
+int zr_trace_any(const zr_scene* sc, void* stream, const float* d_rays, uint32_t n, uint32_t mask, uint32_t* d_occ)
+{
+    if (!sc || !d_rays || !d_occ) return Fail(ZR_ERR_INVALID_ARG, "null argument");
+    if (n == 0) return ZR_OK;
+    HIP_TRY(hipSetDevice(sc->device));
+    const uint32_t grid = std::min<uint32_t>((n + kBlock - 1) / kBlock, 8192u);
+    hipLaunchKernelGGL(k_trace_rays_any, dim3(grid), dim3(kBlock), 0, (hipStream_t)stream, sc->view, (const F4*)d_rays, n, mask, d_occ);
+    HIP_TRY(hipGetLastError());
+    return ZR_OK;
+}
+
+} // extern "C"

@@ -1,0 +1,188 @@
+// zr_bvh.h -- host-side BVH2 builder (binned SAH) over world-space triangles.
+//
+// Stands in for the reference's acceleration-structure build, which is a D3D12 driver call
+// (Source/ZetaCore/RayTracing/RtAccelerationStructure.cpp:121-200 StaticBLAS::Rebuild, :789 TLAS::Render): all static
+// mesh instances are flattened into one triangle soup with the instance's float 3x4 transform baked in, exactly what
+// the reference's static BLAS holds.  Indexing contract kept from the reference: a hit reports
+// meshIdx = GeometryIndex() + InstanceID() and the primitive index within that mesh (RtAccelerationStructure.cpp:393-405).
+// Runs once per scene on the host; the device only ever sees the flat node / triangle arrays (zr_dev_scene.h).
+#pragma once
+#include <vector>
+#include <algorithm>
+#include <cstring>
+#include "zr_dev_scene.h"
+
+namespace zr {
+
+struct BuiltBvh
+{
+    std::vector<BvhNode> nodes;
+    std::vector<BvhTri> tris;        // leaf order
+    std::vector<TriMeta> meta;       // global order
+    uint32_t maxDepth = 0;
+};
+
+struct BuildTri { float bmin[3], bmax[3], cent[3]; uint32_t gidx; };
+
+static inline float NextF(float f) { return zr::NextFloat32(f); }
+static inline float PrevF(float f) { return zr::PrevFloat32(f); }
+
+class BvhBuilder
+{
+public:
+    static constexpr int kBins = 16;
+    static constexpr uint32_t kMaxLeaf = 4;
+
+    BuiltBvh Build(const zr_scene_desc& d)
+    {
+        BuiltBvh out;
+        // ---- flatten instances -> world-space triangles (global order = instance order, then primitive order)
+        std::vector<BvhTri> soup;
+        for (uint32_t i = 0; i < d.num_instances; i++)
+        {
+            const zr_mesh_instance& mi = d.instances[i];
+            const float* M = d.instance_to_world + 12 * i;
+            for (uint32_t p = 0; p < d.instance_num_tris[i]; p++)
+            {
+                float w[3][3];
+                for (int k = 0; k < 3; k++)
+                {
+                    uint32_t vi = d.indices[mi.base_idx_offset + 3 * p + k] + mi.base_vtx_offset;
+                    const float* P = d.vertices[vi].pos;
+                    for (int r = 0; r < 3; r++)
+                        w[k][r] = M[4 * r + 0] * P[0] + M[4 * r + 1] * P[1] + M[4 * r + 2] * P[2] + M[4 * r + 3];
+                }
+                BvhTri t;
+                for (int r = 0; r < 3; r++) { t.v0[r] = w[0][r]; t.e1[r] = w[1][r] - w[0][r]; t.e2[r] = w[2][r] - w[0][r]; }
+                t.gidx = (uint32_t)soup.size(); t.mask = d.instance_mask[i]; t.mesh = i;
+                soup.push_back(t);
+                TriMeta m; m.mesh = i; m.prim = p;
+                out.meta.push_back(m);
+            }
+        }
+        const uint32_t N = (uint32_t)soup.size();
+        bt_.resize(N);
+        for (uint32_t i = 0; i < N; i++)
+        {
+            const BvhTri& t = soup[i];
+            for (int r = 0; r < 3; r++)
+            {
+                float a = t.v0[r], b = t.v0[r] + t.e1[r], c = t.v0[r] + t.e2[r];
+                float lo = std::min(a, std::min(b, c)), hi = std::max(a, std::max(b, c));
+                bt_[i].bmin[r] = PrevF(lo); bt_[i].bmax[r] = NextF(hi);   // one-ulp pad: v0 + e1 is a rounded v1
+                bt_[i].cent[r] = 0.5f * (lo + hi);
+            }
+            bt_[i].gidx = i;
+        }
+        if (N <= kMaxLeaf * 2)
+        {
+            // tiny scene: a single leaf, no nodes
+            out.tris = soup;
+            out.maxDepth = 0;
+            return out;
+        }
+        out.nodes.reserve(N);
+        out.tris.reserve(N);
+        soup_ = &soup; out_ = &out;
+        out.nodes.push_back(BvhNode());
+        BuildInternal(0, 0, N, 1);
+        return out;
+    }
+
+private:
+    std::vector<BuildTri> bt_;
+    const std::vector<BvhTri>* soup_ = nullptr;
+    BuiltBvh* out_ = nullptr;
+
+    static void Grow(float bmin[3], float bmax[3], const float lo[3], const float hi[3])
+    { for (int r = 0; r < 3; r++) { bmin[r] = std::min(bmin[r], lo[r]); bmax[r] = std::max(bmax[r], hi[r]); } }
+    static float Area(const float bmin[3], const float bmax[3])
+    {
+        float dx = bmax[0] - bmin[0], dy = bmax[1] - bmin[1], dz = bmax[2] - bmin[2];
+        return 2.0f * (dx * dy + dy * dz + dz * dx);
+    }
+    void Bounds(uint32_t first, uint32_t count, float bmin[3], float bmax[3]) const
+    {
+        for (int r = 0; r < 3; r++) { bmin[r] = 3.402823466e+38f; bmax[r] = -3.402823466e+38f; }
+        for (uint32_t i = first; i < first + count; i++) Grow(bmin, bmax, bt_[i].bmin, bt_[i].bmax);
+    }
+    uint32_t MakeLeaf(uint32_t first, uint32_t count)
+    {
+        uint32_t slot = (uint32_t)out_->tris.size();
+        // deterministic leaf order: ascending global index
+        std::sort(bt_.begin() + first, bt_.begin() + first + count, [](const BuildTri& a, const BuildTri& b) { return a.gidx < b.gidx; });
+        for (uint32_t i = first; i < first + count; i++) out_->tris.push_back((*soup_)[bt_[i].gidx]);
+        return kLeafBit | (slot << 3) | (count - 1);
+    }
+    // splits [first, first+count) and returns the child reference (leaf or node index)
+    uint32_t BuildChild(uint32_t first, uint32_t count, uint32_t depth)
+    {
+        if (count <= kMaxLeaf) { out_->maxDepth = std::max(out_->maxDepth, depth); return MakeLeaf(first, count); }
+        uint32_t idx = (uint32_t)out_->nodes.size();
+        out_->nodes.push_back(BvhNode());
+        BuildInternal(idx, first, count, depth + 1);
+        return idx;
+    }
+    void BuildInternal(uint32_t nodeIdx, uint32_t first, uint32_t count, uint32_t depth)
+    {
+        // centroid bounds
+        float cmin[3] = {3.402823466e+38f, 3.402823466e+38f, 3.402823466e+38f}, cmax[3] = {-3.402823466e+38f, -3.402823466e+38f, -3.402823466e+38f};
+        for (uint32_t i = first; i < first + count; i++)
+            for (int r = 0; r < 3; r++) { cmin[r] = std::min(cmin[r], bt_[i].cent[r]); cmax[r] = std::max(cmax[r], bt_[i].cent[r]); }
+        int bestAxis = -1, bestSplit = -1; float bestCost = 3.402823466e+38f;
+        for (int axis = 0; axis < 3; axis++)
+        {
+            float ext = cmax[axis] - cmin[axis];
+            if (!(ext > 0)) continue;
+            struct Bin { float bmin[3], bmax[3]; uint32_t n; } bins[kBins];
+            for (auto& b : bins) { for (int r = 0; r < 3; r++) { b.bmin[r] = 3.402823466e+38f; b.bmax[r] = -3.402823466e+38f; } b.n = 0; }
+            float scale = (float)kBins / ext;
+            for (uint32_t i = first; i < first + count; i++)
+            {
+                int b = std::min(kBins - 1, (int)((bt_[i].cent[axis] - cmin[axis]) * scale));
+                Grow(bins[b].bmin, bins[b].bmax, bt_[i].bmin, bt_[i].bmax); bins[b].n++;
+            }
+            float la[kBins], ra[kBins]; uint32_t ln[kBins], rn[kBins];
+            float lb[3] = {3.402823466e+38f, 3.402823466e+38f, 3.402823466e+38f}, ub[3] = {-3.402823466e+38f, -3.402823466e+38f, -3.402823466e+38f};
+            uint32_t n = 0;
+            for (int b = 0; b < kBins; b++) { if (bins[b].n) Grow(lb, ub, bins[b].bmin, bins[b].bmax); n += bins[b].n; la[b] = n ? Area(lb, ub) : 0; ln[b] = n; }
+            for (int r = 0; r < 3; r++) { lb[r] = 3.402823466e+38f; ub[r] = -3.402823466e+38f; }
+            n = 0;
+            for (int b = kBins - 1; b >= 0; b--) { if (bins[b].n) Grow(lb, ub, bins[b].bmin, bins[b].bmax); n += bins[b].n; ra[b] = n ? Area(lb, ub) : 0; rn[b] = n; }
+            for (int s = 0; s < kBins - 1; s++)
+            {
+                if (ln[s] == 0 || rn[s + 1] == 0) continue;
+                float cost = la[s] * (float)ln[s] + ra[s + 1] * (float)rn[s + 1];
+                if (cost < bestCost) { bestCost = cost; bestAxis = axis; bestSplit = s; }
+            }
+        }
+        uint32_t mid;
+        if (bestAxis < 0)
+        {
+            // all centroids coincide: split by index
+            mid = first + count / 2;
+            std::sort(bt_.begin() + first, bt_.begin() + first + count, [](const BuildTri& a, const BuildTri& b) { return a.gidx < b.gidx; });
+        }
+        else
+        {
+            float ext = cmax[bestAxis] - cmin[bestAxis];
+            float scale = (float)kBins / ext;
+            float c0 = cmin[bestAxis];
+            auto it = std::partition(bt_.begin() + first, bt_.begin() + first + count, [&](const BuildTri& t) {
+                int b = std::min(kBins - 1, (int)((t.cent[bestAxis] - c0) * scale));
+                return b <= bestSplit; });
+            mid = (uint32_t)(it - bt_.begin());
+            if (mid == first || mid == first + count) mid = first + count / 2;
+        }
+        float lmin[3], lmax[3], rmin[3], rmax[3];
+        Bounds(first, mid - first, lmin, lmax);
+        Bounds(mid, first + count - mid, rmin, rmax);
+        uint32_t l = BuildChild(first, mid - first, depth);
+        uint32_t r = BuildChild(mid, first + count - mid, depth);
+        BvhNode& n = out_->nodes[nodeIdx];
+        for (int k = 0; k < 3; k++) { n.lmin[k] = lmin[k]; n.lmax[k] = lmax[k]; n.rmin[k] = rmin[k]; n.rmax[k] = rmax[k]; }
+        n.left = l; n.right = r; n.pad0 = 0; n.pad1 = 0;
+    }
+};
+
+} // namespace zr

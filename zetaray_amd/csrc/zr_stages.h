@@ -1,0 +1,593 @@
+// zr_stages.h -- per-item stage functions of the G-buffer pass (K1) and the wavefront path tracer (K9).
+//
+// MI355X design: the reference runs one thread per pixel through the whole path
+// (Source/ZetaRenderPass/IndirectLighting/PathTracer/PathTracer.hlsl:115-212 -> ReSTIR_GI/PathTracing.hlsli:10-99, a
+// "megakernel" whose inner loop calls the driver's RayQuery).  Here the path is cut at every BVH query into streaming
+// stages over SoA queues in HBM:
+//
+//     gbuffer -> pt_init -> [ trace(C, M, S) -> pt_shade ] x (maxBounces + 1)
+//
+// * a path's state lives in 16-byte SoA records indexed by its *queue slot* (coalesced dwordx4 loads/stores);
+// * every shade step compacts surviving paths into the next queue (wave ballot + one atomic per wave);
+// * next-event estimation is deferred: a vertex emits its MIS BSDF ray (M) and its light-segment ray (S) together
+//   with the continuation ray (C); the *next* shade step resolves them ("pending NEE") before shading the new vertex.
+//   The RNG stream per pixel is consumed in exactly the reference's order, so results do not depend on the cut.
+//
+// Every function here is ZR_HD: the kernels in zr_kernels.hip are thin wrappers (slot allocation, LDS staging), and
+// tests/hostexec runs the same functions serially on the CPU to check them against the oracle without a GPU.
+#pragma once
+#include "zr_dev_scene.h"
+#include "../../include/zetaray_amd.h"
+
+namespace zr {
+
+struct alignas(16) F4 { float x, y, z, w; };
+struct alignas(16) U4 { uint32_t x, y, z, w; };
+ZR_HD F4 f4(V3 a, float w) { F4 r; r.x = a.x; r.y = a.y; r.z = a.z; r.w = w; return r; }
+ZR_HD F4 f4(float x, float y, float z, float w) { F4 r; r.x = x; r.y = y; r.z = z; r.w = w; return r; }
+ZR_HD V3 xyz(F4 a) { return v3(a.x, a.y, a.z); }
+
+// ---------------------------------------------------------------- G-buffer planes (device or host pointers)
+struct GBuf
+{
+    // planes cover the screen tile [x0, x0 + w) x [y0, y0 + h) of the full render target (multi-GPU tile split,
+    // SURVEY.md section 8(e)); pixel coordinates passed to the stage functions are always global.
+    uint32_t w, h, x0, y0;
+    uint32_t* baseColor; uint32_t* normal; uint16_t* mr; uint32_t* motion; uint32_t* emissive; uint8_t* ior;
+    uint16_t* coat; float* depth; uint32_t* triA; uint32_t* triB;
+};
+
+ZR_HD float EncodeMetallic(float metalness, bool tr, V3 emissive, float trDepth, float subsurface, float coat_weight)  // GBuffers.hlsli:52-68
+{
+    uint32_t r = tr ? 1u : 0u;
+    r |= ((uint32_t)(dot(emissive, emissive) > 0) << 1);
+    r |= ((uint32_t)(trDepth > 0) << 3);
+    r |= ((uint32_t)(subsurface > 0) << 4);
+    r |= ((uint32_t)(coat_weight > 0) << 5);
+    r |= ((uint32_t)(metalness >= kMinMetalnessMetal) << 7);
+    return (float)r / 255.0f;
+}
+ZR_HD float EncodeIOR(float ior) { return (ior - kMinIOR) / (kMaxIOR - kMinIOR); }   // GBuffers.hlsli:97-105
+ZR_HD float DecodeIOR(float e) { return zr_fma(e, kMaxIOR - kMinIOR, kMinIOR); }
+
+// K1: one pixel of GBufferRT_Inline.hlsl main (:204-287) + TracePrimaryHit (:72-198) + GBufferRT.hlsli:102-282.
+// Primary rays are coherent, so traversal runs inline in this kernel (no queue round trip).
+ZR_HD void GBufferPixel(const SceneView& sc, const zr_frame_constants& g, const GBuf& gb, uint32_t x, uint32_t y,
+    uint32_t* stack, uint64_t* nClosest)
+{
+    const uint32_t px = (y - gb.y0) * gb.w + (x - gb.x0);
+    const V2 renderDim = v2((float)g.render_width, (float)g.render_height);
+    const V2 jitter = v2(g.curr_camera_jitter[0], g.curr_camera_jitter[1]);
+    const V3 vbx = Row3(g.curr_view, 0), vby = Row3(g.curr_view, 1), vbz = Row3(g.curr_view, 2);
+
+    V2 lens = v2(0, 0);
+    V3 dirCS = GeneratePinholeCameraRay_CS((int)x, (int)y, renderDim, g.aspect_ratio, g.tan_half_fov, jitter);
+    V3 origin = v3p(g.camera_pos);
+    if (g.dof)
+    {
+        uint32_t hx = x, hy = y, hz = x; zr_pcg3d(&hx, &hy, &hz);
+        Rng rng = Rng::Init(hz, hy, g.frame_num);
+        lens = UniformSampleDiskConcentric(rng.Uniform2D());
+        lens = lens * g.lens_radius;
+        origin = origin + mad(lens.x, vbx, lens.y * vby);
+        dirCS = g.focus_depth * dirCS - v3(lens.x, lens.y, 0);
+    }
+    V3 dir = normalize(mad(dirCS.x, vbx, mad(dirCS.y, vby, dirCS.z * vbz)));
+
+    (void)nClosest;
+    RawHit h = Traverse<false>(sc, origin, dir, 0.0f, ZR_FLT_MAX, ZR_SUBGROUP_ALL, stack);
+
+    if (h.tri == kInvalidTri)
+    {
+        gb.depth[px] = ZR_FLT_MAX;
+        gb.mr[px] = (uint16_t)FloatToUNorm8(4.0f / 255.0f);
+        V3 prevCam = v3(g.prev_view_inv[3], g.prev_view_inv[7], g.prev_view_inv[11]);
+        V3 motion = v3p(g.camera_pos) - prevCam;
+        V2 mndc = motion.z > 0 ? v2(motion.x / (motion.z * g.tan_half_fov), motion.y / (motion.z * g.tan_half_fov)) : v2(0, 0);
+        mndc.x /= g.aspect_ratio;
+        V2 muv = UVFromNDC(mndc);
+        gb.motion[px] = PackSnorm16(muv.x) | (PackSnorm16(muv.y) << 16);
+        gb.baseColor[px] = 0; gb.normal[px] = 0; gb.emissive[px] = 0; gb.ior[px] = 0;
+        for (int k = 0; k < 4; k++) { gb.coat[4 * px + k] = 0; gb.triA[4 * px + k] = 0; }
+        gb.triB[2 * px] = 0; gb.triB[2 * px + 1] = 0;
+        return;
+    }
+
+    const TriMeta tm = sc.triMeta[h.tri];
+    const zr_mesh_instance& md = sc.instances[tm.mesh];
+    uint32_t tri = tm.prim * 3 + md.base_idx_offset;
+    const zr_vertex& V0 = sc.vertices[sc.indices[tri] + md.base_vtx_offset];
+    const zr_vertex& V1 = sc.vertices[sc.indices[tri + 1] + md.base_vtx_offset];
+    const zr_vertex& V2_ = sc.vertices[sc.indices[tri + 2] + md.base_vtx_offset];
+    V4 q = normalize(DecodeNormalized4(md.rotation));
+    const V3 scale = v3(zr_f16_to_f32(md.scale[0]), zr_f16_to_f32(md.scale[1]), zr_f16_to_f32(md.scale[2]));
+    const V3 trn = v3p(md.translation);
+    const V2 uv0 = v2(V0.uv[0], V0.uv[1]), uv1 = v2(V1.uv[0], V1.uv[1]), uv2 = v2(V2_.uv[0], V2_.uv[1]);
+
+    V3 v0_n = DecodeOct32(V0.normal), v1_n = DecodeOct32(V1.normal), v2_n = DecodeOct32(V2_.normal);
+    V3 normal = v0_n + h.u * (v1_n - v0_n) + h.v * (v2_n - v0_n);
+    const V3 scaleInv = v3(1.0f / scale.x, 1.0f / scale.y, 1.0f / scale.z);
+    normal = normalize(RotateVector(normal * scaleInv, q));
+
+    V3 v0W = TransformTRS(v3p(V0.pos), trn, q, scale);
+    V3 v1W = TransformTRS(v3p(V1.pos), trn, q, scale);
+    V3 v2W = TransformTRS(v3p(V2_.pos), trn, q, scale);
+    V3 n0W = normalize(RotateVector(v0_n * scaleInv, q));
+    V3 n1W = normalize(RotateVector(v1_n * scaleInv, q));
+    V3 n2W = normalize(RotateVector(v2_n * scaleInv, q));
+    TriDiffs td = ComputeTriDiffs(v0W, v1W, v2W, n0W, n1W, n2W, uv0, uv1, uv2);
+
+    // motion vector
+    V3 hitPos = mad(h.t, dir, origin);
+    V3 posL = InverseTransformTRS(hitPos, trn, q, scale);
+    V3 prevT = trn - v3(zr_f16_to_f32(md.d_translation[0]), zr_f16_to_f32(md.d_translation[1]), zr_f16_to_f32(md.d_translation[2]));
+    V4 qp = normalize(DecodeNormalized4(md.prev_rotation));
+    V3 ps = v3(zr_f16_to_f32(md.prev_scale[0]), zr_f16_to_f32(md.prev_scale[1]), zr_f16_to_f32(md.prev_scale[2]));
+    V3 posPrev = TransformTRS(posL, prevT, qp, ps);
+    V3 pvPrev = Mul3x4(g.prev_view, posPrev);
+    V2 ndcPrev = v2(pvPrev.x / (pvPrev.z * g.tan_half_fov), pvPrev.y / (pvPrev.z * g.tan_half_fov));
+    ndcPrev.x /= g.aspect_ratio;
+    V2 currUV = v2(((float)x + 0.5f) / renderDim.x, ((float)y + 0.5f) / renderDim.y);
+    V2 prevUV = UVFromNDC(ndcPrev) - v2(jitter.x / renderDim.x, jitter.y / renderDim.y);
+    V2 motionVec = currUV - prevUV;
+
+    V3 pos = mad(h.t, dir, origin);
+    V3 posV = Mul3x4(g.curr_view, pos);
+    float z = g.dof ? h.t : posV.z;
+    V3 wo = origin - pos;
+
+    const zr_material mat = sc.materials[md.mat_idx];
+    V3 baseColor = UnpackRGB8(mat.base_color_factor);
+    V3 emissive = UnpackRGB8(mat.emissive_factor_normal_scale);
+    float metallic = MatMetallic(mat) ? 1.0f : 0.0f;
+    float roughness = MatRoughness(mat);
+    V3 sn = normal;
+    V3 dndu = td.dndu, dndv = td.dndv;
+    if (MatDoubleSided(mat) && dot(wo, normal) < 0) { sn = sn * -1.0f; dndu = dndu * -1.0f; dndv = dndv * -1.0f; }
+    if (dot(wo, normal) > 0 && dot(wo, sn) < 0)
+    {
+        wo = normalize(wo);
+        sn = sn - dot(sn, wo) * wo;
+        sn = 1e-4f * wo + sn;
+        sn = normalize(sn);
+    }
+    emissive = emissive * MatEmissiveStrength(mat);
+    bool tr = MatTransmissive(mat);
+    float ior = MatIOR(mat);
+    float trDepth = tr ? MatTrDepth(mat) : 0;
+    float subsurface = MatThinWalled(mat) ? MatSubsurface(mat) : 0;
+    float coat_w = MatCoatWeight(mat);
+    float encoded = EncodeMetallic(metallic, tr, emissive, trDepth, subsurface, coat_w);
+
+    gb.depth[px] = z;
+    V2 en = EncodeUnitVector(sn);
+    gb.normal[px] = FloatToUNorm16(en.x) | (FloatToUNorm16(en.y) << 16);
+    gb.baseColor[px] = FloatToUNorm8(baseColor.x) | (FloatToUNorm8(baseColor.y) << 8) | (FloatToUNorm8(baseColor.z) << 16) |
+        ((subsurface > 0 ? FloatToUNorm8(subsurface) : 0u) << 24);
+    gb.mr[px] = (uint16_t)(FloatToUNorm8(encoded) | (FloatToUNorm8(roughness) << 8));
+    gb.emissive[px] = dot(emissive, emissive) > 0 ? PackR11G11B10F(vmax(emissive, 0.0f)) : 0u;
+    gb.ior[px] = tr ? (uint8_t)FloatToUNorm8(EncodeIOR(ior)) : (uint8_t)0;
+    if (coat_w > 0)
+    {
+        uint32_t c = Float3ToRGB8(UnpackRGB8(mat.coat_color_flags));
+        gb.coat[4 * px + 0] = (uint16_t)(c & 0xffff);
+        gb.coat[4 * px + 1] = (uint16_t)((c >> 16) | (FloatToUNorm8(coat_w) << 8));
+        gb.coat[4 * px + 2] = (uint16_t)(FloatToUNorm8(MatCoatRoughness(mat)) | (FloatToUNorm8(EncodeIOR(MatCoatIOR(mat))) << 8));
+        gb.coat[4 * px + 3] = 0;
+    }
+    else { for (int k = 0; k < 4; k++) gb.coat[4 * px + k] = 0; }
+    gb.motion[px] = PackSnorm16(motionVec.x) | (PackSnorm16(motionVec.y) << 16);
+    uint32_t a0 = zr_f32_to_f16(td.dpdu.x), a1 = zr_f32_to_f16(td.dpdu.y), a2 = zr_f32_to_f16(td.dpdu.z);
+    uint32_t b0 = zr_f32_to_f16(td.dpdv.x), b1 = zr_f32_to_f16(td.dpdv.y), b2 = zr_f32_to_f16(td.dpdv.z);
+    uint32_t c0 = zr_f32_to_f16(dndu.x), c1 = zr_f32_to_f16(dndu.y), c2 = zr_f32_to_f16(dndu.z);
+    uint32_t d0 = zr_f32_to_f16(dndv.x), d1 = zr_f32_to_f16(dndv.y), d2 = zr_f32_to_f16(dndv.z);
+    gb.triA[4 * px + 0] = a0 | (a1 << 16);
+    gb.triA[4 * px + 1] = a2 | (b0 << 16);
+    gb.triA[4 * px + 2] = b1 | (b2 << 16);
+    gb.triA[4 * px + 3] = c0 | (c1 << 16);
+    gb.triB[2 * px + 0] = c2 | (d0 << 16);
+    gb.triB[2 * px + 1] = d1 | (d2 << 16);
+}
+
+// ---------------------------------------------------------------- wavefront path state
+// flags word (s0.w)
+static constexpr uint32_t PF_BOUNCE_MASK = 0xfu;
+static constexpr uint32_t PF_IN_MEDIUM = 1u << 4;
+static constexpr uint32_t PF_DRAIN = 1u << 5;       // no continuation ray: resolve pending NEE, write the pixel, retire
+static constexpr uint32_t PF_PENDING = 1u << 6;     // the previous vertex left NEE contributions to resolve
+static constexpr uint32_t PF_NLS = 1u << 7;         // numLightSamples of the pending vertex (0 or 1)
+static constexpr uint32_t PF_MAXB_SHIFT = 8;        // bits 8..11 maxNumBounces
+static constexpr uint32_t PF_S_RAY = 1u << 12;      // a light-segment ray is in flight for the pending vertex
+
+struct PathQueue
+{
+    U4* s0;   // pid, rngThread, rngGroup, flags
+    F4* s1;   // li.xyz, eta_curr
+    F4* s2;   // throughput.xyz (already multiplied by the continuation's bsdfOverPdf), misPdf
+    F4* s3;   // pos.xyz (vertex the continuation ray leaves), unused
+    F4* s4;   // wi.xyz (continuation direction), unused
+    F4* s5;   // thrNEE.xyz (throughput at the pending vertex), unused
+    F4* s6;   // misF.xyz, unused
+    F4* s7;   // misWi.xyz, unused
+    F4* s8;   // ldLight.xyz (unshadowed MIS-weighted light-sample contribution), unused
+    // rays of this slot: (origin.xyz, tmin), (dir.xyz, tmax); tmax < 0 => no ray
+    F4* rayC_o; F4* rayC_d; F4* rayM_o; F4* rayM_d; F4* rayS_o; F4* rayS_d;
+    uint32_t* sLightID;   // emissive triangle ID the S ray is aimed at
+    // results written by the trace kernel
+    U4* hitC; U4* hitM;   // (t bits, u bits, v bits, global tri or kInvalidTri)
+    uint32_t* visS;       // 1 = segment unoccluded
+};
+
+struct PathOut   // what one shade/init step wants to write into the next queue
+{
+    bool alive;          // false: the path retired in this step (pixel written)
+    U4 s0; F4 s1, s2, s3, s4, s5, s6, s7, s8;
+    F4 rayC_o, rayC_d, rayM_o, rayM_d, rayS_o, rayS_d;
+    uint32_t sLightID;
+};
+
+ZR_HD void WritePath(const PathQueue& q, uint32_t slot, const PathOut& p)
+{
+    q.s0[slot] = p.s0; q.s1[slot] = p.s1; q.s2[slot] = p.s2; q.s3[slot] = p.s3; q.s4[slot] = p.s4;
+    q.s5[slot] = p.s5; q.s6[slot] = p.s6; q.s7[slot] = p.s7; q.s8[slot] = p.s8;
+    q.rayC_o[slot] = p.rayC_o; q.rayC_d[slot] = p.rayC_d;
+    q.rayM_o[slot] = p.rayM_o; q.rayM_d[slot] = p.rayM_d;
+    q.rayS_o[slot] = p.rayS_o; q.rayS_d[slot] = p.rayS_d;
+    q.sLightID[slot] = p.sLightID;
+}
+
+struct PtParams
+{
+    uint32_t maxNonTrBounces, maxGlossyTrBounces;
+    uint32_t russianRoulette;
+    uint32_t numSampleSets;      // 0 when light presampling is off
+    uint32_t accumulate;         // g.accumulate && g.camera_static
+};
+
+// closest-hit ray of Hit::FindClosest / Hit_Emissive::FindClosest (RayQuery.hlsli:26-48 / 156-174).
+// strictZero: Hit::FindClosest treats ndotwi == 0 as "no ray" and < 0 as backface; Hit_Emissive uses <= 0 as backface.
+ZR_HD bool MakeClosestRay(V3 pos, V3 normal, V3 wi, bool transmissive, bool emissiveVariant, F4* ro, F4* rd)
+{
+    float ndotwi = dot(normal, wi);
+    bool back;
+    if (emissiveVariant) back = ndotwi <= 0;
+    else { if (ndotwi == 0) return false; back = ndotwi < 0; }
+    if (back)
+    {
+        if (!transmissive) return false;
+        normal = emissiveVariant ? normal * -1.0f : -normal;
+    }
+    V3 o = OffsetRayRTG(pos, normal);
+    *ro = f4(o, back ? 5e-5f : 1e-6f);
+    *rd = f4(wi, ZR_FLT_MAX);
+    return true;
+}
+
+// Visibility_Segment with APPROXIMATE_EMISSIVE_SHADOW_RAY == 0 (RayQuery.hlsli:337-406): returns 0 = early-out
+// "occluded", 1 = ray emitted
+ZR_HD int MakeSegmentRay(V3 origin, V3 wi, float rayT, V3 normal, uint32_t triID, bool transmissive, F4* ro, F4* rd)
+{
+    if (triID == 0xffffffffu) return 0;
+    if (rayT < 1e-6f) return 0;
+    float ndotwi = dot(normal, wi);
+    if (ndotwi == 0) return 0;
+    if (ndotwi < 0)
+    {
+        if (transmissive) normal = normal * -1.0f;
+        else return 0;
+    }
+    V3 o = OffsetRayRTG(origin, normal);
+    *ro = f4(o, 3e-6f);
+    *rd = f4(wi, rayT);
+    return 1;
+}
+
+ZR_HD void WriteFinal(float* finalRGBA, uint32_t pid, V3 li, V3 firstBOP, bool accumulate)
+{
+    if (dot(li, li) > 0) li = li * firstBOP;
+    li = any_nan(li) ? v3(0.0f) : li;
+    float* o = finalRGBA + 4 * (size_t)pid;
+    if (accumulate) { o[0] += li.x; o[1] += li.y; o[2] += li.z; }
+    else { o[0] = li.x; o[1] = li.y; o[2] = li.z; }
+}
+
+// K9 prologue for one pixel: PathTracer.hlsl main (:115-198) + EstimateIndirectLighting (:56-79) up to the first
+// FindClosest.  Writes the pixel directly when no path starts.
+ZR_HD void PtInitPixel(const SceneView& sc, const zr_frame_constants& g, const GBuf& gb, const PtParams& prm, uint32_t x, uint32_t y,
+    float* finalRGBA, F4* firstBOP, PathOut& out)
+{
+    out.alive = false;
+    const uint32_t pid = (y - gb.y0) * gb.w + (x - gb.x0);
+    const uint16_t mrp = gb.mr[pid];
+    const float mr_x = (float)(mrp & 0xff) / 255.0f, mr_y = (float)(mrp >> 8) / 255.0f;
+    const uint32_t fl = (uint32_t)zr_fma(mr_x, 255.0f, 0.5f);
+    if (fl & (ZR_GBUF_INVALID | ZR_GBUF_EMISSIVE))
+    {
+        if (!prm.accumulate) { float* o = finalRGBA + 4 * (size_t)pid; o[0] = 0; o[1] = 0; o[2] = 0; }
+        return;
+    }
+    const bool f_tr = fl & ZR_GBUF_TRANSMISSIVE, f_trDepth = fl & ZR_GBUF_TRDEPTH_GT0, f_metal = fl & ZR_GBUF_METALLIC;
+    const V2 renderDim = v2((float)g.render_width, (float)g.render_height);
+    const V2 jitter = v2(g.curr_camera_jitter[0], g.curr_camera_jitter[1]);
+    const V3 vbx = Row3(g.curr_view, 0), vby = Row3(g.curr_view, 1), vbz = Row3(g.curr_view, 2);
+
+    const float z_view = gb.depth[pid];
+    V2 lens = v2(0, 0);
+    V3 origin = v3p(g.camera_pos);
+    if (g.dof)
+    {
+        uint32_t hx = x, hy = y, hz = x; zr_pcg3d(&hx, &hy, &hz);
+        Rng r = Rng::Init(hz, hy, g.frame_num);
+        lens = UniformSampleDiskConcentric(r.Uniform2D());
+        lens = lens * g.lens_radius;
+    }
+    // Math::WorldPosFromScreenSpace2, Math.hlsli:218-248
+    V3 pos;
+    {
+        V2 uv = v2(((float)x + 0.5f + jitter.x) / renderDim.x, ((float)y + 0.5f + jitter.y) / renderDim.y);
+        V2 ndc = NDCFromUV(uv);
+        V3 dir_w;
+        if (!g.dof)
+        {
+            V3 dv = v3(ndc.x * g.aspect_ratio * g.tan_half_fov * z_view, ndc.y * g.tan_half_fov * z_view, z_view);
+            dir_w = mad(dv.x, vbx, mad(dv.y, vby, dv.z * vbz));
+        }
+        else
+        {
+            V3 dv = v3(ndc.x * g.aspect_ratio * g.tan_half_fov, ndc.y * g.tan_half_fov, 1);
+            dv = g.focus_depth * dv - v3(lens.x, lens.y, 0);
+            dir_w = normalize(mad(dv.x, vbx, mad(dv.y, vby, dv.z * vbz)));
+            dir_w = dir_w * z_view;
+            origin = origin + mad(lens.x, vbx, lens.y * vby);
+        }
+        pos = origin + dir_w;
+    }
+    const V3 normal = DecodeOct32u(gb.normal[pid]);
+    const V3 baseColor = UnpackRGB8(gb.baseColor[pid]);
+    float eta_curr = kEtaAir, eta_next = kDefaultEtaMat;
+    if (f_tr) eta_next = DecodeIOR((float)gb.ior[pid] / 255.0f);
+    const V3 wo = normalize(origin - pos);
+    Surface surface = InitSurface(normal, wo, f_metal, mr_y, baseColor, eta_curr, eta_next, f_tr, f_trDepth ? 1.0f : 0.0f,
+        0.0f, 0.0f, v3(0.0f), 0.0f, kDefaultEtaCoat);
+
+    Rng rngGroup = Rng::Init((x >> 3) ^ 61u, (y >> 3) ^ 61u, g.frame_num);
+    Rng rngThread = Rng::Init(x ^ 511u, y ^ 31u, g.frame_num);
+    const uint32_t maxB = f_tr ? prm.maxGlossyTrBounces : prm.maxNonTrBounces;
+    (void)rngGroup.UniformUintBounded_Faster(prm.numSampleSets);     // sampleSetIdx (one group-RNG draw, always)
+
+    BsdfSample bs = SampleBSDF(sc.rho, normal, surface, rngThread);
+    F4 ro, rd;
+    bool ok = bs.pdf != 0;
+    if (ok) ok = MakeClosestRay(pos, normal, bs.wi, surface.Transmissive(), false, &ro, &rd);
+    if (!ok)
+    {
+        WriteFinal(finalRGBA, pid, v3(0.0f), v3(0.0f), prm.accumulate);
+        return;
+    }
+    firstBOP[pid] = f4(bs.bsdfOverPdf, 0.0f);
+    const bool tr0 = dot(normal, bs.wi) < 0;
+    out.alive = true;
+    out.s0.x = pid; out.s0.y = rngThread.s; out.s0.z = rngGroup.s;
+    out.s0.w = 0u | (tr0 ? PF_IN_MEDIUM : 0u) | (maxB << PF_MAXB_SHIFT);
+    out.s1 = f4(v3(0.0f), tr0 ? eta_next : kEtaAir);
+    out.s2 = f4(v3(1.0f), 0.0f);
+    out.s3 = f4(pos, 0.0f);
+    out.s4 = f4(bs.wi, 0.0f);
+    out.s5 = f4(v3(0.0f), 0.0f); out.s6 = out.s5; out.s7 = out.s5; out.s8 = out.s5;
+    out.rayC_o = ro; out.rayC_d = rd;
+    out.rayM_o = f4(v3(0.0f), 0.0f); out.rayM_d = f4(v3(0.0f), -1.0f);
+    out.rayS_o = out.rayM_o; out.rayS_d = out.rayM_d;
+    out.sLightID = 0xffffffffu;
+}
+
+// One shade step for the path in slot `i` of `in`:
+//   (1) resolve the pending NEE of the previous vertex (RGI_Util::NEE_Emissive_MIS tail, ReSTIR_GI_NEE.hlsli:40-64, 98-113)
+//   (2) shade the continuation hit: GetMaterialData, NEE setup, Beer-Lambert, bounce bookkeeping, SampleBSDF
+//       (ReSTIR_RT::PathTrace loop body, PathTracing.hlsli:25-95)
+ZR_HD void PtShadePath(const SceneView& sc, const zr_frame_constants& g, const PtParams& prm, const PathQueue& in, uint32_t i,
+    float* finalRGBA, const F4* firstBOP, PathOut& out)
+{
+    out.alive = false;
+    const U4 s0 = in.s0[i];
+    const uint32_t pid = s0.x;
+    uint32_t flags = s0.w;
+    const F4 s1 = in.s1[i];
+    V3 li = xyz(s1);
+    float eta_curr = s1.w;
+
+    // ---- (1) pending NEE
+    if (flags & PF_PENDING)
+    {
+        const float nls = (flags & PF_NLS) ? 1.0f : 0.0f;
+        V3 ld = v3(0.0f);
+        const U4 hm = in.hitM[i];
+        if (in.rayM_d[i].w >= 0 && hm.w != kInvalidTri)
+        {
+            const TriMeta tm = sc.triMeta[hm.w];
+            const uint32_t base = sc.instances[tm.mesh].base_emissive_tri_offset;
+            if (base != 0xffffffffu)
+            {
+                const uint32_t eidx = base + tm.prim;
+                const zr_emissive_triangle em = sc.emissives[eidx];
+                V3 le = EmLe(em);
+                const V3 vtx0 = v3p(em.vtx0), vtx1 = EmV1(em), vtx2 = EmV2(em);
+                V3 ln = cross(vtx1 - vtx0, vtx2 - vtx0);
+                float twoArea = length(ln);
+                twoArea = zr_max(twoArea, 1e-6f);
+                ln = dot(ln, ln) == 0 ? v3(1.0f) : ln / twoArea;
+                const V3 wi = xyz(in.s7[i]);
+                ln = EmDoubleSided(em) && dot(-wi, ln) < 0 ? -ln : ln;
+                const float lightSourcePdf = nls > 0 ? sc.alias[eidx].cached_p_orig : 0;
+                const float lightPdf = lightSourcePdf * (2.0f / twoArea);
+                const float t = zr_asfloat(hm.x);
+                float dwdA = t > 0 ? zr_saturate(dot(ln, -wi)) / (t * t) : 0;
+                float wiPdf = in.s2[i].w;
+                wiPdf *= dwdA;
+                le = le * (xyz(in.s6[i]) * dwdA);
+                ld = PowerHeuristic(wiPdf, lightPdf, le, 1.0f, nls);
+            }
+        }
+        bool addLight = true;
+        if (flags & PF_S_RAY) addLight = in.visS[i] != 0;
+        if (addLight) ld = ld + xyz(in.s8[i]);
+        li = li + xyz(in.s5[i]) * ld;
+    }
+
+    const V3 fb = xyz(firstBOP[pid]);
+    if (flags & PF_DRAIN) { WriteFinal(finalRGBA, pid, li, fb, prm.accumulate); return; }
+
+    // ---- (2) continuation hit
+    const U4 hc = in.hitC[i];
+    if (hc.w == kInvalidTri) { WriteFinal(finalRGBA, pid, li, fb, prm.accumulate); return; }
+    const V3 pos0 = xyz(in.s3[i]);
+    const V3 wiC = xyz(in.s4[i]);
+    V3 thr = xyz(in.s2[i]);
+    const float t = zr_asfloat(hc.x);
+    const V3 hitPos = mad(t, wiC, pos0);
+    const TriMeta tm = sc.triMeta[hc.w];
+    HitInfo hit;
+    hit.t = t;
+    FillHit<false>(sc, tm.mesh, tm.prim, zr_asfloat(hc.y), zr_asfloat(hc.z), false, hit);
+    Surface surface; float eta_mat;
+    if (!GetMaterialData(sc, -wiC, eta_curr, hit, surface, eta_mat)) { WriteFinal(finalRGBA, pid, li, fb, prm.accumulate); return; }
+    const float eta_next = eta_curr == kEtaAir ? eta_mat : kEtaAir;    // as computed inside GetMaterialData
+
+    Rng rngT = Rng::Seed(s0.y);
+    Rng rngG = Rng::Seed(s0.z);
+    uint32_t bounce = flags & PF_BOUNCE_MASK;
+    const uint32_t maxB = (flags >> PF_MAXB_SHIFT) & 0xfu;
+    bool inMedium = flags & PF_IN_MEDIUM;
+
+    out.s5 = f4(thr, 0.0f);                                          // thrNEE: throughput before Beer-Lambert
+    out.rayM_o = f4(v3(0.0f), 0.0f); out.rayM_d = f4(v3(0.0f), -1.0f);
+    out.rayS_o = out.rayM_o; out.rayS_d = out.rayM_d;
+    out.sLightID = 0xffffffffu;
+    uint32_t nflags = PF_PENDING;
+
+    // NEE_Emissive_MIS<1, false> (ReSTIR_GI_NEE.hlsli:8-118), everything that does not need a trace result
+    const V3 n = hit.normal;
+    const bool specular = surface.GlossSpecular() && (surface.metallic || surface.specTr) && (!surface.Coated() || surface.CoatSpecular());
+    const int numLightSamples = specular ? 0 : 1;
+    if (numLightSamples) nflags |= PF_NLS;
+    {
+        BsdfSample bs = SampleBSDF(sc.rho, n, surface, rngT);
+        out.s6 = f4(bs.f, 0.0f);
+        out.s7 = f4(bs.wi, 0.0f);
+        float misPdf = bs.pdf;
+        F4 ro, rd;
+        if (MakeClosestRay(hitPos, n, bs.wi, surface.Transmissive(), true, &ro, &rd)) { out.rayM_o = ro; out.rayM_d = rd; }
+        out.s2.w = misPdf;
+    }
+    V3 ldLight = v3(0.0f);
+    for (int s_l = 0; s_l < numLightSamples; s_l++)
+    {
+        // Light::AliasTableSample::get, LightSource.hlsli:72-98
+        uint32_t u0 = rngT.UniformUintBounded(g.num_emissive_triangles);
+        const zr_alias_entry ae = sc.alias[u0];
+        uint32_t lidx; float lpdfSrc;
+        if (rngT.Uniform() < ae.p_curr) { lpdfSrc = ae.cached_p_orig; lidx = u0; }
+        else { lpdfSrc = ae.cached_p_alias; lidx = ae.alias; }
+        const zr_emissive_triangle em = sc.emissives[lidx];
+        // Light::EmissiveTriSample::get, LightSource.hlsli:109-137
+        V2 u = rngT.Uniform2D();
+        V2 bary = UniformSampleTriangle(u);
+        const V3 vtx0 = v3p(em.vtx0), vtx1 = EmV1(em), vtx2 = EmV2(em);
+        V3 lpos = (1.0f - bary.x - bary.y) * vtx0 + bary.x * vtx1 + bary.y * vtx2;
+        V3 ln = cross(vtx1 - vtx0, vtx2 - vtx0);
+        bool normalIs0 = dot(ln, ln) == 0;
+        float twoArea = length(ln);
+        float lpdfPos = normalIs0 ? 0.0f : 2.0f / twoArea;
+        ln = normalIs0 ? ln : ln / twoArea;
+        ln = EmDoubleSided(em) && dot(hitPos - lpos, ln) < 0 ? -ln : ln;
+
+        V3 le = EmLe(em);
+        const float lightPdf = lpdfSrc * lpdfPos;
+        const float tl = length(lpos - hitPos);
+        const V3 wi = (lpos - hitPos) / tl;
+        if (dot(ln, -wi) > 0)
+        {
+            const float dwdA = zr_saturate(dot(ln, -wi)) / (tl * tl);
+            surface.SetWi(wi, n);
+            le = le * (Unified(sc.rho, surface).f * dwdA);
+            bool occludedEarly = false;
+            if (dot(le, le) > 0)
+            {
+                F4 ro, rd;
+                if (MakeSegmentRay(hitPos, wi, tl, n, em.id, surface.Transmissive(), &ro, &rd))
+                { out.rayS_o = ro; out.rayS_d = rd; out.sLightID = em.id; nflags |= PF_S_RAY; }
+                else occludedEarly = true;
+            }
+            float bsdfPdf = BSDFSamplerPdf(sc.rho, n, surface, wi, rngT);
+            bsdfPdf *= dwdA;
+            if (occludedEarly) le = le * 0.0f;
+            ldLight = ldLight + PowerHeuristic(lightPdf, bsdfPdf, le, (float)numLightSamples, 1.0f);
+        }
+    }
+    out.s8 = f4(ldLight, 0.0f);
+
+    // Beer-Lambert (ACCOUNT_FOR_TRANSMITTANCE == 1, PathTracing.hlsli:43-50)
+    if (inMedium && (surface.trDepth > 0))
+    {
+        V3 ext = -vlog(surface.base) / surface.trDepth;
+        thr = thr * vexp(-t * ext);
+    }
+
+    bool cont = !(bounce >= (maxB - 1));
+    BsdfSample bs2 = InitBsdfSample();
+    F4 cro = f4(v3(0.0f), 0.0f), crd = f4(v3(0.0f), -1.0f);
+    if (cont)
+    {
+        bounce++;
+        // Russian roulette (PathTracing.hlsli:62-72) is resolved by the RR stage when it can trigger; see zr_kernels.hip
+        if (bounce < maxB) bs2 = SampleBSDF(sc.rho, n, surface, rngT);
+        if (Luminance(bs2.bsdfOverPdf) == 0) cont = false;
+    }
+    if (cont) cont = MakeClosestRay(hitPos, n, bs2.wi, surface.Transmissive(), false, &cro, &crd);
+    if (cont)
+    {
+        thr = thr * bs2.bsdfOverPdf;
+        bool transmitted = dot(n, bs2.wi) < 0;
+        eta_curr = transmitted ? (eta_curr == kEtaAir ? eta_next : kEtaAir) : eta_curr;
+        inMedium = transmitted ? !inMedium : inMedium;
+    }
+    else nflags |= PF_DRAIN;
+
+    out.alive = true;
+    out.s0.x = pid; out.s0.y = rngT.s; out.s0.z = rngG.s;
+    out.s0.w = nflags | (bounce & PF_BOUNCE_MASK) | (inMedium ? PF_IN_MEDIUM : 0u) | (maxB << PF_MAXB_SHIFT);
+    out.s1 = f4(li, eta_curr);
+    out.s2 = f4(thr, out.s2.w);
+    out.s3 = f4(hitPos, 0.0f);
+    out.s4 = f4(bs2.wi, 0.0f);
+    out.rayC_o = cro; out.rayC_d = crd;
+}
+
+// trace stage for one ray of a queue slot
+ZR_HD U4 TraceClosestRay(const SceneView& sc, F4 ro, F4 rd, uint32_t mask, uint32_t* stack)
+{
+    RawHit h = Traverse<false>(sc, xyz(ro), xyz(rd), ro.w, rd.w, mask, stack);
+    U4 r; r.x = zr_asuint(h.tri == kInvalidTri ? 0.0f : h.t); r.y = zr_asuint(h.u); r.z = zr_asuint(h.v); r.w = h.tri;
+    return r;
+}
+// Visibility_Segment tail (RayQuery.hlsli:392-405): closest hit over NON_EMISSIVE geometry, visible iff no hit or the
+// hit's hashed ID equals the light's
+ZR_HD uint32_t TraceSegmentRay(const SceneView& sc, F4 ro, F4 rd, uint32_t lightID, uint32_t* stack)
+{
+    RawHit h = Traverse<false>(sc, xyz(ro), xyz(rd), ro.w, rd.w, ZR_SUBGROUP_NON_EMISSIVE, stack);
+    if (h.tri == kInvalidTri) return 1u;
+    const TriMeta tm = sc.triMeta[h.tri];
+    return TriID(tm.mesh, tm.prim) == lightID ? 1u : 0u;
+}
+
+// K2: EstimateTriEmissivePower.hlsl:29-79 (untextured branch)
+ZR_HD float EstimateTriPower(const zr_emissive_triangle& em)
+{
+    V3 power = v3(64.0f);
+    power = power * UnpackRGB8(em.packed_a) * zr_f16_to_f32((uint16_t)(em.packed_b >> 16));
+    const V3 vtx0 = v3p(em.vtx0), vtx1 = EmV1(em), vtx2 = EmV2(em);
+    const float area = 0.5f * length(cross(vtx1 - vtx0, vtx2 - vtx0));
+    const float pdf = area > 0 ? 1.0f / area : 0;
+    return pdf > 0 ? Luminance(power) * ZR_PI / (pdf * 64.0f) : 0;
+}
+
+} // namespace zr
