@@ -1,0 +1,201 @@
+"""CPU-side (`-m "not gpu"`) checks: the math contract, the wavefront stage functions of the HIP path executed by
+the test-only serial host executor (tests/hostexec) against the oracle, BVH vs brute force, the C-ABI surface, and the
+committed golden renders."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from oracle import zro
+from tests.hostexec import zhx
+from zetaray_amd import scene_io, wire
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+# ------------------------------------------------------------------ arithmetic contract (include/zr_detmath.h)
+def _ulp_diff(a, b):
+    ai = a.view(np.int32).astype(np.int64)
+    bi = b.view(np.int32).astype(np.int64)
+    ai = np.where(ai < 0, -(ai & 0x7FFFFFFF), ai)
+    bi = np.where(bi < 0, -(bi & 0x7FFFFFFF), bi)
+    return np.abs(ai - bi)
+
+
+def test_detmath_accuracy():
+    rng = np.random.default_rng(0)
+    x = rng.uniform(-20, 20, 200000).astype(np.float32)
+    assert np.abs(zro.kat_unary(0, x) - np.sin(x.astype(np.float64))).max() < 3e-7
+    assert np.abs(zro.kat_unary(1, x) - np.cos(x.astype(np.float64))).max() < 3e-7
+    xe = rng.uniform(-80, 80, 200000).astype(np.float32)
+    e = zro.kat_unary(2, xe)
+    assert (np.abs(e - np.exp(xe.astype(np.float64))) / np.exp(xe.astype(np.float64))).max() < 3e-7
+    xl = (10.0 ** rng.uniform(-30, 30, 200000)).astype(np.float32)
+    assert np.abs(zro.kat_unary(3, xl) - np.log(xl.astype(np.float64))).max() < 1e-5
+    assert (_ulp_diff(zro.kat_unary(3, xl), np.log(xl.astype(np.float64)).astype(np.float32)) <= 2).all()
+    xa = rng.uniform(-50, 50, 200000).astype(np.float32)
+    assert np.abs(zro.kat_unary(4, xa) - np.arctan(xa.astype(np.float64))).max() < 3e-7
+    assert zro.kat_unary(2, np.array([0.0], np.float32))[0] == 1.0
+    assert zro.kat_unary(3, np.array([1.0], np.float32))[0] == 0.0
+    assert np.isneginf(zro.kat_unary(3, np.array([0.0], np.float32))[0])
+
+
+def test_half_roundtrip_all_halves():
+    h = np.arange(65536, dtype=np.uint16)
+    f = np.zeros(65536, np.float32)
+    zro.lib().zro_kat_f16_to_f32(h.ctypes.data, f.ctypes.data, len(h))
+    want = h.view(np.float16).astype(np.float32)
+    nan = np.isnan(want)
+    assert np.array_equal(f[~nan].view(np.uint32), want[~nan].view(np.uint32)) and np.isnan(f[nan]).all()
+    back = np.zeros(65536, np.uint16)
+    zro.lib().zro_kat_f32_to_f16(f.ctypes.data, back.ctypes.data, len(f))
+    assert np.array_equal(back[~nan], h[~nan])
+
+
+def test_pcg3d_known_answers():
+    v = np.array([[0, 0, 0], [1, 2, 3], [4, 0, 57], [0xFFFFFFFF, 7, 9]], np.uint32)
+    out = np.zeros_like(v)
+    zro.lib().zro_kat_pcg3d(v.ctypes.data, out.ctypes.data, len(v))
+    for row, got in zip(v, out):
+        assert tuple(int(g) for g in got) == scene_io.pcg3d(int(row[0]), int(row[1]), int(row[2]))
+
+
+def test_uniform_bounded_is_in_range_and_uniform():
+    out = np.zeros(60000, np.uint32)
+    zro.lib().zro_kat_uniform_bounded(123, 7, out.ctypes.data, len(out))
+    assert out.max() < 7
+    counts = np.bincount(out, minlength=7)
+    assert np.abs(counts / len(out) - 1 / 7).max() < 0.01
+
+
+# ------------------------------------------------------------------ stage functions (host executor) vs oracle
+@pytest.fixture(scope="module")
+def hx_emissive(cornell_emissive, oracle_emissive):
+    return zhx.HostExecScene(cornell_emissive, oracle_emissive.alias)
+
+
+def test_power_estimate_bit_exact(hx_emissive, oracle_emissive):
+    assert np.array_equal(hx_emissive.estimate_power().view(np.uint32), oracle_emissive.power.view(np.uint32))
+
+
+@pytest.mark.parametrize("w,h,frame", [(64, 64, 1), (100, 56, 5)])
+def test_gbuffer_and_path_tracer_bit_exact(hx_emissive, oracle_emissive, cornell_emissive, w, h, frame):
+    cb = scene_io.make_frame_constants(w, h, frame_num=frame, num_emissives=len(cornell_emissive.emissives))
+    ga, gp = oracle_emissive.gbuffer(cb)
+    ha, hp = hx_emissive.gbuffer(cb)
+    for name, a, b in zip(wire.GB_PLANE_NAMES, ga, ha):
+        assert np.array_equal(a.view(np.uint8), b.view(np.uint8)), name
+    prm = wire.default_params()
+    fo, co = oracle_emissive.pathtrace(cb, gp, prm)
+    fh, ch = hx_emissive.pathtrace(cb, hp, prm)
+    assert co == ch
+    assert np.array_equal(fo.view(np.uint32), fh.view(np.uint32))
+    assert fo[..., :3].sum() > 0
+
+
+def test_dof_and_jitter_paths(hx_emissive, oracle_emissive, cornell_emissive):
+    cb = scene_io.make_frame_constants(48, 48, frame_num=3, num_emissives=len(cornell_emissive.emissives), jitter=(0.25, -0.125))
+    cb["dof"] = 1
+    cb["lens_radius"] = 0.05
+    cb["focus_depth"] = 4.0
+    ga, gp = oracle_emissive.gbuffer(cb)
+    ha, hp = hx_emissive.gbuffer(cb)
+    for name, a, b in zip(wire.GB_PLANE_NAMES, ga, ha):
+        assert np.array_equal(a.view(np.uint8), b.view(np.uint8)), name
+    prm = wire.default_params()
+    fo, _ = oracle_emissive.pathtrace(cb, gp, prm)
+    fh, _ = hx_emissive.pathtrace(cb, hp, prm)
+    assert np.array_equal(fo.view(np.uint32), fh.view(np.uint32))
+
+
+def _random_rays(n, seed, lo=(-1.2, 0.0, -1.2), hi=(1.2, 2.1, 1.2)):
+    rng = np.random.default_rng(seed)
+    o = rng.uniform(lo, hi, (n, 3))
+    d = rng.normal(size=(n, 3))
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    tmax = np.where(rng.uniform(size=(n, 1)) < 0.5, 3.0e38, rng.uniform(0.1, 3.0, (n, 1)))
+    return np.concatenate([o, np.full((n, 1), 1e-5), d, tmax], 1).astype(np.float32)
+
+
+def test_traversal_bvh_vs_bruteforce(hx_emissive, oracle_emissive, cornell_emissive):
+    """Closest hit with the ABI tie-break and any-hit do not depend on the acceleration structure: oracle brute force
+    == oracle BVH2 == product SAH BVH (host-executed)."""
+    rays = _random_rays(40000, 11)
+    brute = oracle_emissive.trace_closest(rays)
+    obvh = zro.OracleScene(cornell_emissive, force_bvh=True)
+    assert np.array_equal(brute, obvh.trace_closest(rays))
+    assert np.array_equal(brute, hx_emissive.trace_closest(rays))
+    for mask in (1, 2):
+        assert np.array_equal(oracle_emissive.trace_closest(rays, mask), hx_emissive.trace_closest(rays, mask))
+        assert np.array_equal(oracle_emissive.trace_any(rays, mask), hx_emissive.trace_any(rays, mask))
+    assert np.array_equal(oracle_emissive.trace_any(rays), hx_emissive.trace_any(rays))
+
+
+def test_traversal_synthetic_scene():
+    """A few thousand random + axis-aligned coplanar triangles (ties on t): brute force vs both BVHs."""
+    sc = scene_io.make_synthetic_scene(num_tris=3000, num_emissive=64, seed=3)
+    o = zro.OracleScene(sc)                      # <= 256 tris -> brute force, otherwise BVH: force both
+    ob = zro.OracleScene(sc, force_bvh=True)
+    hx = zhx.HostExecScene(sc, o.alias)
+    nodes, tris, depth = hx.bvh_info()
+    assert tris == sc.num_tris and nodes > 100 and depth < 40
+    rays = _random_rays(20000, 5, lo=(-4, -4, -4), hi=(4, 4, 4))
+    a = ob.trace_closest(rays)
+    assert np.array_equal(a, hx.trace_closest(rays))
+    assert (a[:, 3] != 0xFFFFFFFF).mean() > 0.2
+
+
+def test_empty_and_degenerate_inputs(hx_emissive, oracle_emissive):
+    rays = np.zeros((0, 8), np.float32)
+    assert oracle_emissive.trace_closest(rays).shape == (0, 4)
+    # zero-length direction, tmax <= tmin, NaN origin: all must miss identically
+    bad = np.array([[0, 1, 0, 0, 0, 0, 0, 1e30], [0, 1, 0, 1.0, 0, 0, 1, 0.5], [np.nan, 1, 0, 0, 0, 0, 1, 1e30]], np.float32)
+    assert np.array_equal(oracle_emissive.trace_closest(bad), hx_emissive.trace_closest(bad))
+    assert (oracle_emissive.trace_closest(bad)[:, 3] == 0xFFFFFFFF).all()
+
+
+# ------------------------------------------------------------------ golden fixtures (regression pin of the oracle)
+def test_golden_render(oracle_emissive, cornell_emissive):
+    g = np.load(os.path.join(ROOT, "tests", "golden", "render_emissive_64.npz"))
+    cb = scene_io.make_frame_constants(64, 64, frame_num=1, num_emissives=len(cornell_emissive.emissives))
+    arrays, planes = oracle_emissive.gbuffer(cb)
+    for name, a in zip(wire.GB_PLANE_NAMES, arrays):
+        assert np.array_equal(a, g["gb_" + name]), name
+    final, cnt = oracle_emissive.pathtrace(cb, planes, wire.default_params())
+    assert np.array_equal(final.view(np.uint32), g["final"].view(np.uint32))
+    assert tuple(cnt) == tuple(g["counters"])
+
+
+# ------------------------------------------------------------------ C-ABI surface
+def test_abi_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "zetaray_amd.h")).read()
+    declared = set(re.findall(r"^\s*(?:int|const char\*)\s+(zr_\w+)\s*\(", hdr, flags=re.M))
+    assert len(declared) >= 28
+    from zetaray_amd import api
+    L = api.lib()
+    for name in declared:
+        assert hasattr(L, name), f"libzetaray_amd.so does not export {name}"
+    assert declared == set(api.EXPORTS)
+    assert L.zr_abi_version() == 1
+
+
+def test_no_device_is_a_loud_error(cornell_emissive):
+    """This container has no GPU: compute entry points must fail with ZR_ERR_NO_DEVICE, never fall back."""
+    from zetaray_amd import api
+    if api.device_count() > 0:
+        pytest.skip("a HIP device is visible")
+    with pytest.raises(api.ZetaRayError) as e:
+        api.Scene(cornell_emissive)
+    assert e.value.code == 2
+    with pytest.raises(api.ZetaRayError):
+        api.GBuffer(64, 64)
+    with pytest.raises(api.ZetaRayError):
+        api.Pass(api.PASS_INDIRECT, 64, 64)
+
+
+def test_wire_struct_sizes():
+    assert wire.VERTEX.itemsize == 28 and wire.MESH_INSTANCE.itemsize == 64 and wire.MATERIAL.itemsize == 32
+    assert wire.EMISSIVE_TRI.itemsize == 48 and wire.ALIAS_ENTRY.itemsize == 16 and wire.FRAME_CONSTANTS.itemsize == 544
+    assert C.sizeof(wire.Params) == 64

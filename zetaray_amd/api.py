@@ -45,6 +45,14 @@ def lib():
         if not os.path.exists(LIB_PATH):
             raise ImportError(f"{LIB_PATH} is missing: build the HIP extension first "
                               f"(python -c 'import __graft_entry__ as g; g.build()'); there is no fallback path")
+        # One HIP runtime per process: the PyTorch-ROCm wheel bundles its own libamdhip64 (same SONAME as the system
+        # one this library links).  Whichever is loaded first serves both, and torch only finds its GPUs through its
+        # own copy -- so torch goes first; libzetaray_amd.so then binds to the already-loaded runtime, which also makes
+        # torch.cuda.synchronize() / torch streams and this library's launches share one device context.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         L = C.CDLL(LIB_PATH)
         L.zr_last_error.restype = C.c_char_p
         vp, u32, i32 = C.c_void_p, C.c_uint32, C.c_int

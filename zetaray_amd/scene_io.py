@@ -440,3 +440,130 @@ def make_frame_constants(width, height, frame_num=1, cam_pos=(0.0, 1.2, -4.043),
     cb["lens_radius"] = 0.0
     cb["dof"] = 0
     return cb
+
+
+def make_synthetic_scene(num_tris=262144, num_emissive=100000, seed=0x5EED, room=4.0, with_special_materials=True) -> Scene:
+    """Procedural Sponza-class stand-in for BASELINE config 4 (not in the reference):
+    a box room, `num_tris` clutter triangles in 8 instances with different materials (diffuse, rough metal, coated,
+    glossy; plus a few axis-aligned coplanar sheets that produce exact t ties) and `num_emissive` small double-sided
+    emissive triangles with strengths log-uniform in [0.5, 50].  Deterministic in `seed` (numpy PCG64)."""
+    rng = np.random.default_rng(seed)
+    sc = Scene()
+    mats = [pack_material(metallic=0.0, roughness=0.3),
+            pack_material(base_color=(0.7, 0.7, 0.7, 1), metallic=0, roughness=1.0, double_sided=True)]
+    palette = [dict(base_color=(0.63, 0.065, 0.05, 1), roughness=1.0), dict(base_color=(0.14, 0.45, 0.09, 1), roughness=0.8),
+               dict(base_color=(0.2, 0.3, 0.8, 1), roughness=0.5), dict(base_color=(0.9, 0.8, 0.3, 1), roughness=0.35, metallic=1.0),
+               dict(base_color=(0.8, 0.8, 0.8, 1), roughness=0.25), dict(base_color=(0.5, 0.2, 0.6, 1), roughness=0.6),
+               dict(base_color=(0.7, 0.1, 0.1, 1), roughness=0.4, coat_weight=1.0, coat_roughness=0.1) if with_special_materials
+               else dict(base_color=(0.7, 0.1, 0.1, 1), roughness=0.4),
+               dict(base_color=(0.3, 0.6, 0.6, 1), roughness=0.15)]
+    for p in palette:
+        mats.append(pack_material(double_sided=True, **p))
+    em_mat_idx = len(mats)
+    mats.append(pack_material(base_color=(0.8, 0.8, 0.8, 1), roughness=1.0, double_sided=True, emissive_factor=(1.0, 0.85, 0.7),
+                              emissive_strength=5.0))
+    sc.materials = np.array(mats, dtype=wire.MATERIAL)
+
+    verts, inds, insts, xforms, masks, ntris = [], [], [], [], [], []
+    ident_q = np.rint((np.array([0, 0, 0, 1], np.float32) * np.float32(0.5) + np.float32(0.5)) * np.float32(65535.0)).astype(np.uint16)
+
+    def add_instance(P, N, mat, mask):
+        """P: (T, 3, 3) triangle vertices, N: (T, 3) face normals."""
+        T = len(P)
+        v = np.zeros(T * 3, wire.VERTEX)
+        v["pos"] = P.reshape(-1, 3).astype(np.float32)
+        v["normal"] = encode_octahedral(np.repeat(N, 3, axis=0))
+        v["uv"] = np.tile(np.array([[0, 0], [1, 0], [0, 1]], np.float32), (T, 1))
+        inst = np.zeros((), wire.MESH_INSTANCE)
+        inst["base_vtx_offset"] = sum(len(x) for x in verts)
+        inst["base_idx_offset"] = sum(len(x) for x in inds)
+        inst["rotation"] = ident_q
+        inst["prev_rotation"] = ident_q
+        inst["scale"] = f32_to_f16_bits([1, 1, 1])
+        inst["prev_scale"] = inst["scale"]
+        inst["mat_idx"] = mat
+        inst["base_emissive_tri_offset"] = 0xFFFFFFFF
+        inst["base_color_tex"] = 0xFFFF
+        inst["alpha_factor_cutoff"] = 255 | (128 << 8)
+        verts.append(v)
+        inds.append(np.arange(T * 3, dtype=np.uint32))
+        insts.append(inst)
+        xforms.append(np.array([1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0], np.float32))
+        masks.append(mask)
+        ntris.append(T)
+        return len(insts) - 1
+
+    def face_normals(P):
+        n = np.cross(P[:, 1] - P[:, 0], P[:, 2] - P[:, 0])
+        ln = np.linalg.norm(n, axis=1, keepdims=True)
+        return (n / np.maximum(ln, 1e-20)).astype(np.float32)
+
+    # room: inward-facing box [-room, room]^3 (floor at -room)
+    r = room
+    c = np.array([[-r, -r, -r], [r, -r, -r], [r, r, -r], [-r, r, -r], [-r, -r, r], [r, -r, r], [r, r, r], [-r, r, r]], np.float32)
+    quads = [(0, 1, 2, 3), (5, 4, 7, 6), (4, 0, 3, 7), (1, 5, 6, 2), (3, 2, 6, 7), (4, 5, 1, 0)]
+    P = np.array([[c[a], c[b], c[d]] for (a, b, cc, d) in quads] + [[c[b], c[cc], c[d]] for (a, b, cc, d) in quads], np.float32)
+    add_instance(P, face_normals(P), 1, wire.SUBGROUP_NON_EMISSIVE)
+
+    # clutter
+    per = max(1, num_tris // 8)
+    size = np.float32(2.0 * room / max(2.0, (num_tris ** (1.0 / 3.0))))
+    for k in range(8):
+        ctr = rng.uniform(-0.9 * room, 0.9 * room, (per, 1, 3)).astype(np.float32)
+        P = ctr + rng.normal(size=(per, 3, 3)).astype(np.float32) * size
+        if k == 0 and per >= 16:
+            # coplanar, overlapping, axis-aligned sheets -> exact ties on t for axis-parallel rays
+            m = min(per // 2, 64)
+            zs = np.float32(0.5)
+            for j in range(m):
+                P[j] = np.array([[-1, -1, zs], [1, -1, zs], [-1, 1, zs]], np.float32) * np.float32(0.5 + 0.01 * (j % 4))
+        add_instance(P, face_normals(P), 2 + k, wire.SUBGROUP_NON_EMISSIVE)
+
+    # emissive triangles
+    if num_emissive > 0:
+        ctr = rng.uniform(-0.85 * room, 0.85 * room, (num_emissive, 1, 3)).astype(np.float32)
+        P = ctr + rng.normal(size=(num_emissive, 3, 3)).astype(np.float32) * (size * np.float32(0.5))
+        ei = add_instance(P, face_normals(P), em_mat_idx, wire.SUBGROUP_EMISSIVE)
+        insts[ei]["base_emissive_tri_offset"] = 0
+        strengths = np.exp(rng.uniform(np.log(0.5), np.log(50.0), num_emissive)).astype(np.float32)
+        sh = f32_to_f16_bits(strengths)
+        matp = sc.materials[em_mat_idx]
+        ems = np.zeros(num_emissive, wire.EMISSIVE_TRI)
+        e0, e1 = P[:, 1] - P[:, 0], P[:, 2] - P[:, 0]
+        l0 = np.sqrt((e0 * e0).sum(1, dtype=np.float32)).astype(np.float32)
+        l1 = np.sqrt((e1 * e1).sum(1, dtype=np.float32)).astype(np.float32)
+        ems["vtx0"] = P[:, 0]
+        ems["v0v1"] = encode_octahedral(e0 / l0[:, None])
+        ems["v0v2"] = encode_octahedral(e1 / l1[:, None])
+        ems["edge_lengths"] = np.stack([f32_to_f16_bits(l0), f32_to_f16_bits(l1)], 1)
+        M = 0xFFFFFFFF
+        # vectorised PCG3d(geometryIndex = instance index, instanceID = 0, primIdx)
+        x = np.full(num_emissive, ei, np.uint64)
+        y = np.zeros(num_emissive, np.uint64)
+        z = np.arange(num_emissive, dtype=np.uint64)
+        x = (x * 1664525 + 1013904223) & M
+        y = (y * 1664525 + 1013904223) & M
+        z = (z * 1664525 + 1013904223) & M
+        x = (x + y * z) & M
+        y = (y + z * x) & M
+        z = (z + x * y) & M
+        x ^= x >> np.uint64(16)
+        y ^= y >> np.uint64(16)
+        z ^= z >> np.uint64(16)
+        x = (x + y * z) & M
+        ems["id"] = x.astype(np.uint32)
+        fac = int(matp["emissive_factor_normal_scale"]) & 0xFFFFFF
+        ems["packed_a"] = (fac | (1 << 24) | (1 << 25)) | ((sh.astype(np.uint32) & 0xF) << 28)
+        ems["packed_b"] = 0xFFFF | (sh.astype(np.uint32) << 16)
+        uvh = f32_to_f16_bits(np.array([[0, 0], [1, 0], [0, 1]], np.float32))
+        ems["uv0"], ems["uv1"], ems["uv2"] = uvh[0], uvh[1], uvh[2]
+        sc.emissives = ems
+
+    sc.vertices = np.concatenate(verts)
+    sc.indices = np.concatenate(inds)
+    sc.instances = np.array(insts, dtype=wire.MESH_INSTANCE)
+    sc.instance_to_world = np.array(xforms, np.float32)
+    sc.instance_mask = np.array(masks, np.uint8)
+    sc.instance_num_tris = np.array(ntris, np.uint32)
+    sc.rho, sc.rho_dim = load_rho_default()
+    return sc
