@@ -108,9 +108,9 @@ def test_full_resolution_properties(api, cornell_emissive):
 
 def test_errors_are_loud(api, cornell_emissive):
     r = api.Renderer(cornell_emissive, 32, 32)
-    cb = _frame(cornell_emissive, 64, 64)
+    cb = _frame(cornell_emissive, 16, 16)
     with pytest.raises(api.ZetaRayError):
-        r.p_gbuffer.render(cb, r.scene, r.gbuffer)         # size mismatch
+        r.p_gbuffer.render(cb, r.scene, r.gbuffer)         # G-buffer tile larger than the render target
     p = wire.default_params()
     p.presampling = 1
     with pytest.raises(api.ZetaRayError):
