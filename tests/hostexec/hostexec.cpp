@@ -76,21 +76,27 @@ void zhx_bvh_info(const HxScene* s, uint32_t* nodes, uint32_t* tris, uint32_t* d
 { *nodes = s->view.numNodes; *tris = s->view.numTris; *depth = s->bvh.maxDepth; }
 void zhx_estimate_power(const HxScene* s, float* out) { for (size_t i = 0; i < s->emissives.size(); i++) out[i] = EstimateTriPower(s->emissives[i]); }
 
+static uint32_t g_tile_x0 = 0, g_tile_y0 = 0;
+// screen-tile origin for the next zhx_gbuffer / zhx_pathtrace calls (planes then have the tile's size)
+void zhx_set_tile_origin(uint32_t x0, uint32_t y0) { g_tile_x0 = x0; g_tile_y0 = y0; }
+
 void zhx_gbuffer(const HxScene* s, const zr_frame_constants* cb, zr_gbuffer_planes* planes)
 {
     GBuf gb = ViewOf(planes);
+    gb.x0 = g_tile_x0; gb.y0 = g_tile_y0;
     uint32_t stack[64];
-    for (uint32_t y = 0; y < cb->render_height; y++)
-        for (uint32_t x = 0; x < cb->render_width; x++)
+    for (uint32_t y = gb.y0; y < gb.y0 + gb.h; y++)
+        for (uint32_t x = gb.x0; x < gb.x0 + gb.w; x++)
             GBufferPixel(s->view, *cb, gb, x, y, stack, nullptr);
 }
 
 void zhx_pathtrace(const HxScene* s, const zr_frame_constants* cb, const zr_gbuffer_planes* planes, const zr_params* params,
     float* finalRGBA, zr_counters* counters)
 {
-    const uint32_t W = cb->render_width, H = cb->render_height;
-    const size_t cap = (size_t)W * H;
     GBuf gb = ViewOf(planes);
+    gb.x0 = g_tile_x0; gb.y0 = g_tile_y0;
+    const uint32_t W = gb.w, H = gb.h;
+    const size_t cap = (size_t)W * H;
     PtParams prm;
     prm.maxNonTrBounces = params->max_non_tr_bounces; prm.maxGlossyTrBounces = params->max_glossy_tr_bounces;
     prm.russianRoulette = (params->flags & ZR_IND_RUSSIAN_ROULETTE) ? 1u : 0u;
@@ -108,8 +114,8 @@ void zhx_pathtrace(const HxScene* s, const zr_frame_constants* cb, const zr_gbuf
     for (uint32_t t = 0; t < 256; t++)
     {
         uint32_t wave = t >> 6, lane = t & 63;
-        uint32_t x = tx * 16 + (wave & 1) * 8 + (lane & 7), y = ty * 16 + (wave >> 1) * 8 + (lane >> 3);
-        if (x >= W || y >= H) continue;
+        uint32_t x = gb.x0 + tx * 16 + (wave & 1) * 8 + (lane & 7), y = gb.y0 + ty * 16 + (wave >> 1) * 8 + (lane >> 3);
+        if (x >= gb.x0 + W || y >= gb.y0 + H) continue;
         PathOut po;
         PtInitPixel(s->view, *cb, gb, prm, x, y, finalRGBA, firstBOP.data(), po);
         if (po.alive) WritePath(q0, count++, po);

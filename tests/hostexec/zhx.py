@@ -23,6 +23,7 @@ def lib():
         L.zhx_gbuffer.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.zhx_pathtrace.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.zhx_trace_closest.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]
+        L.zhx_set_tile_origin.argtypes = [C.c_uint32, C.c_uint32]
         L.zhx_trace_any.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]
         _LIB = L
     return _LIB
@@ -52,16 +53,28 @@ class HostExecScene:
         lib().zhx_estimate_power(self.h, out.ctypes.data)
         return out
 
-    def gbuffer(self, cb):
+    def gbuffer(self, cb, tile=None):
+        """tile = (x0, y0, w, h) renders only that screen tile (planes have the tile's size)."""
         from zetaray_amd import wire
-        arrays, planes = wire.alloc_gbuffer_planes(int(cb["render_width"]), int(cb["render_height"]))
+        x0, y0, w, h = tile if tile else (0, 0, int(cb["render_width"]), int(cb["render_height"]))
+        arrays, planes = wire.alloc_gbuffer_planes(w, h)
         cbb = np.ascontiguousarray(cb)
+        lib().zhx_set_tile_origin(x0, y0)
         lib().zhx_gbuffer(self.h, cbb.ctypes.data, C.addressof(planes))
+        lib().zhx_set_tile_origin(0, 0)
         return arrays, planes
 
-    def pathtrace(self, cb, planes, params, final=None):
+    def pathtrace(self, cb, planes, params, final=None, tile=None):
         from zetaray_amd import wire
-        w, h = int(cb["render_width"]), int(cb["render_height"])
+        x0, y0, w, h = tile if tile else (0, 0, int(cb["render_width"]), int(cb["render_height"]))
+        lib().zhx_set_tile_origin(x0, y0)
+        try:
+            return self._pathtrace(cb, planes, params, final, w, h)
+        finally:
+            lib().zhx_set_tile_origin(0, 0)
+
+    def _pathtrace(self, cb, planes, params, final, w, h):
+        from zetaray_amd import wire
         if final is None:
             final = np.zeros((h, w, 4), np.float32)
         cnt = wire.Counters()

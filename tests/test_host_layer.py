@@ -1,0 +1,55 @@
+"""C++ RenderPass / RenderGraph mirror (zetaray_amd/host): graph ordering on the CPU, a full frame on the GPU."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+from zetaray_amd import scene_io, wire
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _lib():
+    from zetaray_amd import api
+    api.lib()                                                    # torch + libzetaray_amd first (one HIP runtime)
+    L = C.CDLL(os.path.join(ROOT, "zetaray_amd", "libzetaray_host.so"))
+    L.zrh_graph_selftest.argtypes = [C.c_char_p, C.c_int]
+    L.zrh_render_frame.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]
+    return L
+
+
+def test_render_graph_orders_the_reference_node_set():
+    """The reference's hot-path nodes with its resource dependencies (PathTracer.cpp:325-563): RT_AS_Build -> GBuffer,
+    PreLighting -> EmissiveAliasTable -> {DirectLighting || Indirect} -> Compositing; every delegate runs once and
+    never before its producers."""
+    buf = C.create_string_buffer(1024)
+    n = _lib().zrh_graph_selftest(buf, 1024)
+    batches, log = buf.value.decode().split("#")
+    assert n == 8
+    b = [set(x.split(",")) for x in batches.split("|")]
+    assert b[0] == {"RT_AS_Build", "Sky", "PreLighting"}
+    assert b[1] == {"GBuffer", "EmissiveAliasTable"}
+    assert b[2] == {"DirectLighting", "Indirect"}            # same batch: may record concurrently
+    assert b[3] == {"Compositing"}
+    order = log.split(",")
+    pos = {name: i for i, name in enumerate(order)}
+    assert len(pos) == 8
+    for before, after in [("RT_AS_Build", "GBuffer"), ("PreLighting", "EmissiveAliasTable"), ("GBuffer", "Indirect"),
+                          ("EmissiveAliasTable", "DirectLighting"), ("Sky", "Indirect"), ("Indirect", "Compositing"),
+                          ("DirectLighting", "Compositing")]:
+        assert pos[before] < pos[after]
+
+
+@pytest.mark.gpu
+def test_cpp_passes_render_a_frame(cornell_emissive, oracle_emissive):
+    w, h = 80, 48
+    cb = scene_io.make_frame_constants(w, h, frame_num=2, num_emissives=len(cornell_emissive.emissives))
+    desc = cornell_emissive.desc()
+    out = np.zeros((h, w, 4), np.float32)
+    cbb = np.ascontiguousarray(cb)
+    rc = _lib().zrh_render_frame(C.addressof(desc), cbb.ctypes.data, w, h, out.ctypes.data)
+    assert rc == 0
+    _, planes = oracle_emissive.gbuffer(cb)
+    want, _ = oracle_emissive.pathtrace(cb, planes, wire.default_params())
+    assert np.array_equal(out.view(np.uint32), want.view(np.uint32))

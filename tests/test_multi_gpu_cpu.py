@@ -1,0 +1,82 @@
+"""N > 1 path on the CPU: world-size-2 gloo job.  Each rank renders its 32-px-aligned screen tile with the host
+executor (same stage functions as the HIP kernels, global pixel coordinates for RNG seeds / group ids); the tiles are
+gathered with torch.distributed and must stitch to the bit-identical single-process image."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _worker(rank, world, port, w, h, out_path):
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from bench import tile_rect
+    from oracle import zro
+    from tests.hostexec import zhx
+    from zetaray_amd import scene_io, wire
+    sc = scene_io.load_npz(os.path.join(ROOT, "tests", "golden", "cornell_emissive.npz"))
+    o = zro.OracleScene(sc)
+    hx = zhx.HostExecScene(sc, o.alias)
+    cb = scene_io.make_frame_constants(w, h, frame_num=4, num_emissives=len(sc.emissives))
+    tile = tile_rect(w, h, world, rank)
+    _, planes = hx.gbuffer(cb, tile=tile)
+    final, cnt = hx.pathtrace(cb, planes, wire.default_params(), tile=tile)
+    # gather tiles (padded to a common shape) and ray counters on rank 0
+    pad = torch.zeros((h, w, 4), dtype=torch.float32)
+    pad[:tile[3], :tile[2]] = torch.from_numpy(final)
+    meta = torch.tensor(list(tile) + [cnt[0], cnt[1]], dtype=torch.int64)
+    tiles = [torch.zeros_like(pad) for _ in range(world)] if rank == 0 else None
+    metas = [torch.zeros_like(meta) for _ in range(world)] if rank == 0 else None
+    dist.gather(pad, tiles, dst=0)
+    dist.gather(meta, metas, dst=0)
+    if rank == 0:
+        img = np.zeros((h, w, 4), np.float32)
+        rays = np.zeros(2, np.int64)
+        for t, m in zip(tiles, metas):
+            x0, y0, tw, th, nc, ns = [int(v) for v in m]
+            img[y0:y0 + th, x0:x0 + tw] = t.numpy()[:th, :tw]
+            rays += [nc, ns]
+        np.savez(out_path, img=img, rays=rays)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_tile_split_is_bit_identical(tmp_path):
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    w, h = 160, 96
+    out = str(tmp_path / "stitched.npz")
+    mp.spawn(_worker, args=(2, port, w, h, out), nprocs=2, join=True)
+    got = np.load(out)
+    sys.path.insert(0, ROOT)
+    from oracle import zro
+    from zetaray_amd import scene_io, wire
+    sc = scene_io.load_npz(os.path.join(ROOT, "tests", "golden", "cornell_emissive.npz"))
+    o = zro.OracleScene(sc)
+    cb = scene_io.make_frame_constants(w, h, frame_num=4, num_emissives=len(sc.emissives))
+    _, planes = o.gbuffer(cb)
+    want, cnt = o.pathtrace(cb, planes, wire.default_params())
+    assert np.array_equal(got["img"].view(np.uint32), want.view(np.uint32))
+    assert tuple(got["rays"]) == tuple(cnt)
+
+
+def test_tile_rects_cover_the_frame():
+    from bench import tile_rect
+    for n in (1, 2, 4, 8):
+        cover = np.zeros((1080, 1920), np.int32)
+        for r in range(n):
+            x0, y0, tw, th = tile_rect(1920, 1080, n, r)
+            assert x0 % 32 == 0 and y0 % 32 == 0 and tw > 0 and th > 0
+            cover[y0:y0 + th, x0:x0 + tw] += 1
+        assert (cover == 1).all()

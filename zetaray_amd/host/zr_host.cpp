@@ -1,0 +1,333 @@
+// zr_host.cpp -- implementation of the RenderPass / RenderGraph mirror (see zr_host.h).  Plain C++ (g++), links
+// libzetaray_amd.so for the passes and libamdhip64 for streams/events (runtime API only; no kernels here).
+#include "zr_host.h"
+#include <algorithm>
+#include <cstring>
+#include <future>
+#include <mutex>
+#include <thread>
+#include <hip/hip_runtime_api.h>
+
+namespace ZetaRayAMD {
+
+// ------------------------------------------------------------------------------------------------ TaskSet
+Support::TaskSet::TaskHandle Support::TaskSet::EmplaceTask(const char* name, std::function<void()> f)
+{
+    if ((int)m_tasks.size() >= MAX_NUM_TASKS) { std::fprintf(stderr, "TaskSet: too many tasks\n"); std::abort(); }
+    Task t; t.name = name; t.fn = std::move(f);
+    m_tasks.push_back(std::move(t));
+    return (int)m_tasks.size() - 1;
+}
+void Support::TaskSet::AddOutgoingEdge(TaskHandle a, TaskHandle b) { m_tasks[a].out.push_back(b); m_tasks[b].indeg++; }
+void Support::TaskSet::Sort()
+{
+    // longest-path levels (same ordering rule the reference uses for render nodes, RenderGraph.cpp:561-642)
+    std::vector<int> indeg(m_tasks.size());
+    for (size_t i = 0; i < m_tasks.size(); i++) { indeg[i] = m_tasks[i].indeg; m_tasks[i].level = 0; }
+    std::vector<int> q;
+    for (size_t i = 0; i < m_tasks.size(); i++) if (!indeg[i]) q.push_back((int)i);
+    size_t done = 0;
+    while (done < q.size())
+    {
+        int u = q[done++];
+        for (int v : m_tasks[u].out)
+        {
+            m_tasks[v].level = std::max(m_tasks[v].level, m_tasks[u].level + 1);
+            if (--indeg[v] == 0) q.push_back(v);
+        }
+    }
+    if (done != m_tasks.size()) { std::fprintf(stderr, "TaskSet: cycle detected\n"); std::abort(); }
+    int maxL = 0;
+    for (auto& t : m_tasks) maxL = std::max(maxL, t.level);
+    m_levels.assign(maxL + 1, {});
+    for (size_t i = 0; i < m_tasks.size(); i++) m_levels[m_tasks[i].level].push_back((int)i);
+}
+void Support::TaskSet::Run(bool parallel)
+{
+    if (m_levels.empty()) Sort();
+    for (auto& level : m_levels)
+    {
+        if (!parallel || level.size() == 1) { for (int i : level) m_tasks[i].fn(); continue; }
+        std::vector<std::future<void>> fs;
+        for (int i : level) fs.push_back(std::async(std::launch::async, m_tasks[i].fn));
+        for (auto& f : fs) f.get();
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ RenderGraph
+namespace Core {
+
+RenderGraph::RenderGraph()
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) == hipSuccess && n > 0)
+    {
+        m_hasDevice = true;
+        for (auto& s : m_streams) { hipStream_t st; if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) { std::fprintf(stderr, "hipStreamCreate failed\n"); std::abort(); } s = st; }
+    }
+}
+RenderGraph::~RenderGraph()
+{
+    if (!m_hasDevice) return;
+    for (void* e : m_eventPool) (void)hipEventDestroy((hipEvent_t)e);
+    for (auto& s : m_streams) if (s) (void)hipStreamDestroy((hipStream_t)s);
+}
+void RenderGraph::Reset() { m_nodes.clear(); m_resources.clear(); m_inPostRegister = false; }
+void RenderGraph::BeginFrame() { m_nodes.clear(); m_inPostRegister = false; m_eventsUsed = 0; }
+
+RenderNodeHandle RenderGraph::RegisterRenderPass(const char* name, RENDER_NODE_TYPE t, Delegate1<CommandList&> dlg, bool)
+{
+    if (m_inPostRegister) { std::fprintf(stderr, "RegisterRenderPass after MoveToPostRegister\n"); std::abort(); }
+    if ((int)m_nodes.size() >= MAX_NUM_RENDER_PASSES) { std::fprintf(stderr, "too many render passes\n"); std::abort(); }
+    Node n; n.name = name; n.type = t; n.dlg = std::move(dlg);
+    m_nodes.push_back(std::move(n));
+    return RenderNodeHandle((int)m_nodes.size() - 1);
+}
+void RenderGraph::RegisterResource(const void*, uint64_t path, uint32_t, bool)
+{
+    if (m_inPostRegister) { std::fprintf(stderr, "RegisterResource after MoveToPostRegister\n"); std::abort(); }
+    if (std::find(m_resources.begin(), m_resources.end(), path) == m_resources.end())
+    {
+        if ((int)m_resources.size() >= MAX_NUM_RESOURCES) { std::fprintf(stderr, "too many resources\n"); std::abort(); }
+        m_resources.push_back(path);
+    }
+}
+void RenderGraph::RemoveResource(uint64_t path) { m_resources.erase(std::remove(m_resources.begin(), m_resources.end(), path), m_resources.end()); }
+void RenderGraph::MoveToPostRegister() { m_inPostRegister = true; }
+void RenderGraph::AddInput(RenderNodeHandle h, uint64_t path, uint32_t)
+{
+    if (!m_inPostRegister || !h.IsValid()) { std::fprintf(stderr, "AddInput: invalid call order\n"); std::abort(); }
+    if (std::find(m_resources.begin(), m_resources.end(), path) == m_resources.end()) { std::fprintf(stderr, "AddInput: resource %llu was not registered\n", (unsigned long long)path); std::abort(); }
+    m_nodes[h.Val].inputs.push_back(path);
+}
+void RenderGraph::AddOutput(RenderNodeHandle h, uint64_t path, uint32_t)
+{
+    if (!m_inPostRegister || !h.IsValid()) { std::fprintf(stderr, "AddOutput: invalid call order\n"); std::abort(); }
+    if (std::find(m_resources.begin(), m_resources.end(), path) == m_resources.end()) { std::fprintf(stderr, "AddOutput: resource %llu was not registered\n", (unsigned long long)path); std::abort(); }
+    m_nodes[h.Val].outputs.push_back(path);
+}
+void* RenderGraph::AcquireEvent()
+{
+    if (!m_hasDevice) return nullptr;
+    if (m_eventsUsed == m_eventPool.size())
+    {
+        hipEvent_t e;
+        if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { std::fprintf(stderr, "hipEventCreate failed\n"); std::abort(); }
+        m_eventPool.push_back(e);
+    }
+    return m_eventPool[m_eventsUsed++];
+}
+
+void RenderGraph::Build(Support::TaskSet& ts)
+{
+    const int N = (int)m_nodes.size();
+    // producer -> consumer edges (a node depends on every earlier-registered node that outputs one of its inputs,
+    // and on earlier writers/readers of its outputs: RAW, WAW, WAR), registration order breaks ties like the reference
+    for (int i = 0; i < N; i++)
+    {
+        m_nodes[i].deps.clear();
+        for (int j = 0; j < i; j++)
+        {
+            bool dep = false;
+            for (uint64_t in : m_nodes[i].inputs) if (std::find(m_nodes[j].outputs.begin(), m_nodes[j].outputs.end(), in) != m_nodes[j].outputs.end()) dep = true;
+            for (uint64_t out : m_nodes[i].outputs)
+            {
+                if (std::find(m_nodes[j].outputs.begin(), m_nodes[j].outputs.end(), out) != m_nodes[j].outputs.end()) dep = true;
+                if (std::find(m_nodes[j].inputs.begin(), m_nodes[j].inputs.end(), out) != m_nodes[j].inputs.end()) dep = true;
+            }
+            if (dep) m_nodes[i].deps.push_back(j);
+        }
+    }
+    // batch index = longest path from a root (RenderGraph.cpp:561-642)
+    int maxBatch = 0;
+    for (int i = 0; i < N; i++)
+    {
+        int b = 0;
+        for (int j : m_nodes[i].deps) b = std::max(b, m_nodes[j].batch + 1);
+        m_nodes[i].batch = b; maxBatch = std::max(maxBatch, b);
+        m_nodes[i].doneEvent = AcquireEvent();
+    }
+    m_batchNames.assign(N ? maxBatch + 1 : 0, {});
+    for (int i = 0; i < N; i++) m_batchNames[m_nodes[i].batch].push_back(m_nodes[i].name);
+
+    // one task per node; task edges mirror the node edges so recording order == dependency order, while the GPU-side
+    // order is enforced with events (the reference's barriers + cross-queue fences, RenderGraph.cpp:442-541)
+    std::vector<int> handles(N);
+    for (int i = 0; i < N; i++)
+    {
+        handles[i] = ts.EmplaceTask(m_nodes[i].name.c_str(), [this, i]()
+        {
+            Node& n = m_nodes[i];
+            void* stream = m_streams[n.type == RENDER_NODE_TYPE::ASYNC_COMPUTE ? 1 : 0];
+            if (m_hasDevice)
+                for (int j : n.deps)
+                {
+                    void* depStream = m_streams[m_nodes[j].type == RENDER_NODE_TYPE::ASYNC_COMPUTE ? 1 : 0];
+                    if (depStream != stream) (void)hipStreamWaitEvent((hipStream_t)stream, (hipEvent_t)m_nodes[j].doneEvent, 0);
+                }
+            CommandList cl(stream);
+            n.dlg(cl);
+            if (m_hasDevice) (void)hipEventRecord((hipEvent_t)n.doneEvent, (hipStream_t)stream);
+        });
+    }
+    for (int i = 0; i < N; i++) for (int j : m_nodes[i].deps) ts.AddOutgoingEdge(handles[j], handles[i]);
+    ts.Sort();
+    ts.Finalize();
+}
+void RenderGraph::WaitForFrame()
+{
+    if (!m_hasDevice) return;
+    for (auto& s : m_streams) (void)hipStreamSynchronize((hipStream_t)s);
+}
+
+} // namespace Core
+
+// ------------------------------------------------------------------------------------------------ passes
+namespace RenderPass {
+
+RenderPassBase::~RenderPassBase() { if (m_pass) zr_pass_destroy(m_pass); }
+void RenderPassBase::Reset(bool waitForGPU)
+{
+    if (!m_pass) return;
+    if (waitForGPU) (void)hipDeviceSynchronize();
+    zr_pass_destroy(m_pass);
+    m_pass = nullptr; m_initialized = false;
+}
+void RenderPassBase::InitRenderPass(int kind, FrameContext* ctx, int integrator)
+{
+    if (m_pass) { std::fprintf(stderr, "Attempting to double-init.\n"); std::abort(); }
+    m_ctx = ctx; m_integrator = integrator;
+    ZR_CHECK(zr_pass_create(kind, ctx->device, &m_pass));
+    ZR_CHECK(zr_pass_init(m_pass, ctx->renderWidth, ctx->renderHeight, integrator));
+    m_initialized = true;
+}
+
+void GBufferRT::Init(FrameContext* ctx) { InitRenderPass(ZR_PASS_GBUFFER, ctx, 0); }
+void GBufferRT::OnWindowResized() { ZR_CHECK(zr_pass_resize(m_pass, m_ctx->renderWidth, m_ctx->renderHeight)); }
+void GBufferRT::Render(Core::CommandList& cl) { ZR_CHECK(zr_pass_render(m_pass, cl.Stream(), &m_ctx->frameConstants, m_ctx->scene, m_ctx->gbuffer)); }
+
+void PreLighting::Init(FrameContext* ctx) { InitRenderPass(ZR_PASS_PRELIGHTING, ctx, 0); }
+void PreLighting::Render(Core::CommandList& cl)
+{
+    // the alias table only changes when the emissive set changes (EmissiveTriangleAliasTable::Update, PreLighting.cpp:455-510)
+    if (m_aliasReady) return;
+    ZR_CHECK(zr_pass_render(m_pass, cl.Stream(), &m_ctx->frameConstants, m_ctx->scene, nullptr));
+    m_aliasReady = true;
+}
+
+void IndirectLighting::Init(FrameContext* ctx, INTEGRATOR method)
+{
+    zr_params_default(&m_params);
+    InitRenderPass(ZR_PASS_INDIRECT, ctx, (int)method);
+}
+void IndirectLighting::OnWindowResized() { ZR_CHECK(zr_pass_resize(m_pass, m_ctx->renderWidth, m_ctx->renderHeight)); }
+void IndirectLighting::ResetTemporal() { ZR_CHECK(zr_pass_reset_temporal(m_pass)); }
+void IndirectLighting::SetMethod(INTEGRATOR method)
+{
+    m_integrator = (int)method;
+    ZR_CHECK(zr_pass_init(m_pass, m_ctx->renderWidth, m_ctx->renderHeight, m_integrator));
+    ZR_CHECK(zr_pass_set_params(m_pass, &m_params));
+}
+void IndirectLighting::SetLightPresamplingParams(bool enable, int numSampleSets, int sampleSetSize)
+{
+    m_params.presampling = enable ? 1u : 0u; m_params.num_sample_sets = (uint32_t)numSampleSets; m_params.sample_set_size = (uint32_t)sampleSetSize;
+    ZR_CHECK(zr_pass_set_params(m_pass, &m_params));
+}
+void IndirectLighting::SetMaxBounces(int nonTr, int glossyTr)
+{
+    m_params.max_non_tr_bounces = (uint32_t)nonTr; m_params.max_glossy_tr_bounces = (uint32_t)glossyTr;
+    ZR_CHECK(zr_pass_set_params(m_pass, &m_params));
+}
+void* IndirectLighting::GetOutput(SHADER_OUT_RES i) const
+{
+    if (i != SHADER_OUT_RES::FINAL) { std::fprintf(stderr, "Invalid shader output.\n"); std::abort(); }
+    void* dev = nullptr; uint32_t w, h, bpp;
+    ZR_CHECK(zr_pass_get_output(m_pass, ZR_OUT_FINAL, &dev, &w, &h, &bpp));
+    return dev;
+}
+void IndirectLighting::Render(Core::CommandList& cl) { ZR_CHECK(zr_pass_render(m_pass, cl.Stream(), &m_ctx->frameConstants, m_ctx->scene, m_ctx->gbuffer)); }
+
+} // namespace RenderPass
+} // namespace ZetaRayAMD
+
+// ------------------------------------------------------------------------------------------------ C test hooks
+// Small extern "C" surface so the Python test-suite can exercise the C++ layer (graph ordering without a GPU; a full
+// frame through GBufferRT -> PreLighting -> IndirectLighting on the GPU box).
+using namespace ZetaRayAMD;
+
+extern "C" {
+
+// Registers the reference's hot-path node set with the reference's resource dependencies (ZR/PathTracer.cpp:325-563,
+// ZR/GBuffer.cpp) using dummy delegates and returns the batch layout as a string "a,b|c|d,e".
+int zrh_graph_selftest(char* out, int outLen)
+{
+    Core::RenderGraph g;
+    struct Dummy { std::vector<std::string>* log; std::string name; std::mutex* m; void Render(Core::CommandList&) { std::lock_guard<std::mutex> l(*m); log->push_back(name); } };
+    std::vector<std::string> log; std::mutex mtx;
+    Dummy as{&log, "RT_AS_Build", &mtx}, gb{&log, "GBuffer", &mtx}, sky{&log, "Sky", &mtx}, pre{&log, "PreLighting", &mtx}, alias{&log, "EmissiveAliasTable", &mtx},
+        di{&log, "DirectLighting", &mtx}, ind{&log, "Indirect", &mtx}, comp{&log, "Compositing", &mtx};
+    enum : uint64_t { R_BVH = 100, R_GBUF, R_SKYLUT, R_POWER, R_ALIAS, R_DI, R_IND, R_HDR };
+    g.BeginFrame();
+    auto hAS = g.RegisterRenderPass("RT_AS_Build", Core::RENDER_NODE_TYPE::COMPUTE, Core::MakeDelegate(&as, &Dummy::Render));
+    auto hGB = g.RegisterRenderPass("GBuffer", Core::RENDER_NODE_TYPE::COMPUTE, Core::MakeDelegate(&gb, &Dummy::Render));
+    auto hSky = g.RegisterRenderPass("Sky", Core::RENDER_NODE_TYPE::ASYNC_COMPUTE, Core::MakeDelegate(&sky, &Dummy::Render));
+    auto hPre = g.RegisterRenderPass("PreLighting", Core::RENDER_NODE_TYPE::COMPUTE, Core::MakeDelegate(&pre, &Dummy::Render));
+    auto hAl = g.RegisterRenderPass("EmissiveAliasTable", Core::RENDER_NODE_TYPE::COMPUTE, Core::MakeDelegate(&alias, &Dummy::Render));
+    auto hDI = g.RegisterRenderPass("DirectLighting", Core::RENDER_NODE_TYPE::COMPUTE, Core::MakeDelegate(&di, &Dummy::Render));
+    auto hInd = g.RegisterRenderPass("Indirect", Core::RENDER_NODE_TYPE::ASYNC_COMPUTE, Core::MakeDelegate(&ind, &Dummy::Render));
+    auto hC = g.RegisterRenderPass("Compositing", Core::RENDER_NODE_TYPE::COMPUTE, Core::MakeDelegate(&comp, &Dummy::Render));
+    for (uint64_t r = R_BVH; r <= R_HDR; r++) g.RegisterResource(nullptr, r);
+    g.MoveToPostRegister();
+    g.AddOutput(hAS, R_BVH, Core::STATE_UNORDERED_ACCESS);
+    g.AddInput(hGB, R_BVH, Core::STATE_SHADER_READ); g.AddOutput(hGB, R_GBUF, Core::STATE_UNORDERED_ACCESS);
+    g.AddOutput(hSky, R_SKYLUT, Core::STATE_UNORDERED_ACCESS);
+    g.AddOutput(hPre, R_POWER, Core::STATE_UNORDERED_ACCESS);
+    g.AddInput(hAl, R_POWER, Core::STATE_SHADER_READ); g.AddOutput(hAl, R_ALIAS, Core::STATE_UNORDERED_ACCESS);
+    g.AddInput(hDI, R_GBUF, Core::STATE_SHADER_READ); g.AddInput(hDI, R_ALIAS, Core::STATE_SHADER_READ); g.AddInput(hDI, R_BVH, Core::STATE_SHADER_READ); g.AddOutput(hDI, R_DI, Core::STATE_UNORDERED_ACCESS);
+    g.AddInput(hInd, R_GBUF, Core::STATE_SHADER_READ); g.AddInput(hInd, R_ALIAS, Core::STATE_SHADER_READ); g.AddInput(hInd, R_BVH, Core::STATE_SHADER_READ); g.AddInput(hInd, R_SKYLUT, Core::STATE_SHADER_READ); g.AddOutput(hInd, R_IND, Core::STATE_UNORDERED_ACCESS);
+    g.AddInput(hC, R_DI, Core::STATE_SHADER_READ); g.AddInput(hC, R_IND, Core::STATE_SHADER_READ); g.AddOutput(hC, R_HDR, Core::STATE_UNORDERED_ACCESS);
+    Support::TaskSet ts;
+    g.Build(ts);
+    ts.Run(true);
+    g.WaitForFrame();
+    std::string s;
+    for (size_t b = 0; b < g.Batches().size(); b++) { if (b) s += "|"; for (size_t i = 0; i < g.Batches()[b].size(); i++) { if (i) s += ","; s += g.Batches()[b][i]; } }
+    s += "#";
+    for (size_t i = 0; i < log.size(); i++) { if (i) s += ","; s += log[i]; }
+    std::snprintf(out, outLen, "%s", s.c_str());
+    return (int)log.size();
+}
+
+// One frame through the C++ pass objects scheduled by the graph; copies FINAL (w*h*4 floats) to `finalOut`.
+int zrh_render_frame(const zr_scene_desc* desc, const zr_frame_constants* cb, uint32_t w, uint32_t h, float* finalOut)
+{
+    RenderPass::FrameContext ctx;
+    ctx.device = 0; ctx.renderWidth = w; ctx.renderHeight = h; ctx.frameConstants = *cb;
+    ZR_CHECK(zr_scene_create(0, desc, &ctx.scene));
+    ZR_CHECK(zr_gbuffer_create(0, w, h, &ctx.gbuffer));
+    {
+        RenderPass::GBufferRT gb; RenderPass::PreLighting pre; RenderPass::IndirectLighting ind;
+        gb.Init(&ctx); pre.Init(&ctx); ind.Init(&ctx, RenderPass::IndirectLighting::INTEGRATOR::PATH_TRACING);
+        Core::RenderGraph g;
+        enum : uint64_t { R_GBUF = 1, R_ALIAS, R_IND };
+        g.BeginFrame();
+        auto hGB = g.RegisterRenderPass("GBuffer", Core::RENDER_NODE_TYPE::COMPUTE, Core::MakeDelegate(&gb, &RenderPass::GBufferRT::Render));
+        auto hPre = g.RegisterRenderPass("PreLighting", Core::RENDER_NODE_TYPE::ASYNC_COMPUTE, Core::MakeDelegate(&pre, &RenderPass::PreLighting::Render));
+        auto hInd = g.RegisterRenderPass("Indirect", Core::RENDER_NODE_TYPE::COMPUTE, Core::MakeDelegate(&ind, &RenderPass::IndirectLighting::Render));
+        g.RegisterResource(nullptr, R_GBUF); g.RegisterResource(nullptr, R_ALIAS); g.RegisterResource(ind.GetOutput(RenderPass::IndirectLighting::SHADER_OUT_RES::FINAL), R_IND);
+        g.MoveToPostRegister();
+        g.AddOutput(hGB, R_GBUF, Core::STATE_UNORDERED_ACCESS);
+        g.AddOutput(hPre, R_ALIAS, Core::STATE_UNORDERED_ACCESS);
+        g.AddInput(hInd, R_GBUF, Core::STATE_SHADER_READ); g.AddInput(hInd, R_ALIAS, Core::STATE_SHADER_READ); g.AddOutput(hInd, R_IND, Core::STATE_UNORDERED_ACCESS);
+        Support::TaskSet ts;
+        g.Build(ts);
+        ts.Run(true);
+        g.WaitForFrame();
+        if (hipMemcpy(finalOut, ind.GetOutput(RenderPass::IndirectLighting::SHADER_OUT_RES::FINAL), (size_t)w * h * 16, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    }
+    zr_gbuffer_destroy(ctx.gbuffer);
+    zr_scene_destroy(ctx.scene);
+    return 0;
+}
+
+} // extern "C"

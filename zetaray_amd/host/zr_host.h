@@ -1,0 +1,198 @@
+// zr_host.h -- C++ host-side mirror of the reference's RenderPass / RenderGraph node API over the C-ABI.
+//
+// Keeps the surface a ZetaRay-style renderer (Source/ZetaRenderer/Default/PathTracer.cpp:287-294, 474-552) programs
+// against, re-implemented over HIP streams and events instead of D3D12 command lists and resource barriers:
+//
+//   reference                                                     here
+//   ------------------------------------------------------------  ---------------------------------------------------
+//   Core::CommandList (ZC/Core/CommandList.h)                     Core::CommandList  = one hipStream_t
+//   fastdelegate::FastDelegate1<CommandList&> + MakeDelegate      Core::Delegate1<CommandList&> + MakeDelegate
+//   Core::RenderGraph (ZC/Core/RenderGraph.h:56-118)              Core::RenderGraph  (same method names/order of use)
+//     BeginFrame / RegisterRenderPass / RegisterResource /          resource states -> producer/consumer edges;
+//     MoveToPostRegister / AddInput / AddOutput / Build(TaskSet&)   barriers -> hipEventRecord / hipStreamWaitEvent
+//   Support::TaskSet (ZC/Support/Task.h:89-149)                   Support::TaskSet   (<= 16 tasks, edges, Run())
+//   RenderPass::GBufferRT / PreLighting / IndirectLighting        RenderPass::* : Init / OnWindowResized / ResetTemporal /
+//     (RP/GBuffer/GBufferRT.h:27-47, RP/PreLighting/PreLighting.h:28-58,  Set* / GetOutput / Render(CommandList&)
+//      RP/IndirectLighting/IndirectLighting.h:72-108)
+//   Check(expr, fmt...) aborts (ZC/Utility/Error.h:68-81)         ZR_CHECK: nonzero zr_status -> message + abort
+//
+// Threading contract is the reference's: Build() runs one task per render node (nodes of one dependency level may
+// record concurrently from worker threads, each into its own stream); a pass object is never entered re-entrantly.
+#pragma once
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <functional>
+#include <string>
+#include <vector>
+#include "../../include/zetaray_amd.h"
+
+#define ZR_CHECK(expr) do { int zr_rc_ = (expr); if (zr_rc_ != 0) { std::fprintf(stderr, "Check failed: %s -> %d: %s (%s:%d)\n", #expr, zr_rc_, zr_last_error(), __FILE__, __LINE__); std::abort(); } } while (0)
+
+namespace ZetaRayAMD {
+
+namespace Support {
+    // Minimal stand-in for ZetaRay's TaskSet: tasks + edges, executed level by level (tasks of one level concurrently).
+    struct TaskSet
+    {
+        static constexpr int MAX_NUM_TASKS = 16;
+        using TaskHandle = int;
+        TaskHandle EmplaceTask(const char* name, std::function<void()> f);
+        void AddOutgoingEdge(TaskHandle a, TaskHandle b);
+        void Sort();
+        void Finalize() {}
+        void Run(bool parallel = true);          // App::Submit(ZetaMove(ts)) + wait
+        int GetSize() const { return (int)m_tasks.size(); }
+        struct Task { std::string name; std::function<void()> fn; std::vector<int> out; int indeg = 0; int level = 0; };
+        std::vector<Task> m_tasks;
+        std::vector<std::vector<int>> m_levels;
+    };
+}
+
+namespace Core {
+    class CommandList
+    {
+    public:
+        explicit CommandList(void* hipStream = nullptr) : m_stream(hipStream) {}
+        void* Stream() const { return m_stream; }
+    private:
+        void* m_stream;
+    };
+    using ComputeCmdList = CommandList;
+
+    // FastDelegate1<CommandList&>-shaped callable
+    template<typename Arg> struct Delegate1
+    {
+        std::function<void(Arg)> fn;
+        void operator()(Arg a) const { fn(a); }
+        explicit operator bool() const { return (bool)fn; }
+    };
+    template<typename T, typename Arg>
+    Delegate1<Arg> MakeDelegate(T* obj, void (T::*method)(Arg)) { Delegate1<Arg> d; d.fn = [obj, method](Arg a) { (obj->*method)(a); }; return d; }
+
+    enum class RENDER_NODE_TYPE : uint8_t { RENDER, COMPUTE, ASYNC_COMPUTE };
+    // stand-ins for D3D12_RESOURCE_STATES: only read vs write matters for ordering
+    enum RESOURCE_STATE : uint32_t { STATE_COMMON = 0, STATE_SHADER_READ = 1, STATE_UNORDERED_ACCESS = 2 };
+
+    struct RenderNodeHandle
+    {
+        static constexpr int INVALID_HANDLE = -1;
+        RenderNodeHandle() = default;
+        explicit RenderNodeHandle(int u) : Val(u) {}
+        bool IsValid() const { return Val != INVALID_HANDLE; }
+        int Val = INVALID_HANDLE;
+    };
+
+    class RenderGraph
+    {
+    public:
+        static constexpr int MAX_NUM_RENDER_PASSES = 32;
+        static constexpr int MAX_NUM_RESOURCES = 64;
+        RenderGraph();
+        ~RenderGraph();
+        RenderGraph(const RenderGraph&) = delete;
+        RenderGraph& operator=(const RenderGraph&) = delete;
+
+        void Reset();
+        void BeginFrame();
+        RenderNodeHandle RegisterRenderPass(const char* name, RENDER_NODE_TYPE t, Delegate1<CommandList&> dlg, bool forceSeparateCmdList = false);
+        void RegisterResource(const void* res, uint64_t path, uint32_t initState = STATE_COMMON, bool isWindowSizeDependent = true);
+        void RemoveResource(uint64_t path);
+        void MoveToPostRegister();
+        void AddInput(RenderNodeHandle h, uint64_t path, uint32_t expectedState);
+        void AddOutput(RenderNodeHandle h, uint64_t path, uint32_t expectedState);
+        // Builds the DAG from the declared producers/consumers, orders nodes by longest path, turns cross-stream
+        // dependencies into events, and emits one task per node into `ts`.
+        void Build(Support::TaskSet& ts);
+        // Host wait for everything submitted by the last Build (the reference's frame completion fence).
+        void WaitForFrame();
+        // introspection for tests: execution order (node names by batch) of the last Build
+        const std::vector<std::vector<std::string>>& Batches() const { return m_batchNames; }
+        void* GraphicsStream() const { return m_streams[0]; }
+        void* AsyncComputeStream() const { return m_streams[1]; }
+        // without a HIP device the graph still builds/orders/executes delegates (streams are null): used by CPU tests
+        bool HasDevice() const { return m_hasDevice; }
+
+    private:
+        struct Node
+        {
+            std::string name; RENDER_NODE_TYPE type; Delegate1<CommandList&> dlg;
+            std::vector<uint64_t> inputs, outputs; std::vector<int> deps; int batch = 0; void* doneEvent = nullptr;
+        };
+        std::vector<Node> m_nodes;
+        std::vector<uint64_t> m_resources;
+        bool m_inPostRegister = false;
+        void* m_streams[2] = {nullptr, nullptr};
+        bool m_hasDevice = false;
+        std::vector<void*> m_eventPool;
+        size_t m_eventsUsed = 0;
+        std::vector<std::vector<std::string>> m_batchNames;
+        void* AcquireEvent();
+    };
+}
+
+namespace RenderPass {
+    // Shared scene + G-buffer objects the passes fetch "by name" in the reference (SharedShaderResources); here they are
+    // explicit members of a small context owned by the renderer.
+    struct FrameContext
+    {
+        zr_scene* scene = nullptr;
+        zr_gbuffer* gbuffer = nullptr;
+        zr_frame_constants frameConstants{};
+        uint32_t renderWidth = 0, renderHeight = 0;
+        int device = 0;
+    };
+
+    struct RenderPassBase
+    {
+        bool IsInitialized() const { return m_pass != nullptr && m_initialized; }
+        void Reset(bool waitForGPU);
+        RenderPassBase() = default;
+        RenderPassBase(RenderPassBase&&) = delete;
+        RenderPassBase& operator=(RenderPassBase&&) = delete;
+        ~RenderPassBase();
+    protected:
+        void InitRenderPass(int kind, FrameContext* ctx, int integrator);
+        zr_pass* m_pass = nullptr;
+        FrameContext* m_ctx = nullptr;
+        bool m_initialized = false;
+        int m_integrator = 0;
+    };
+
+    struct GBufferRT final : public RenderPassBase
+    {
+        void Init(FrameContext* ctx);
+        void OnWindowResized();
+        void Render(Core::CommandList& cmdList);
+    };
+
+    struct PreLighting final : public RenderPassBase
+    {
+        void Init(FrameContext* ctx);
+        void OnWindowResized() {}
+        void SetLightPresamplingParams(int minToEnable, int numSampleSets, int sampleSetSize) { m_minPresample = minToEnable; m_numSets = numSampleSets; m_setSize = sampleSetSize; }
+        void Render(Core::CommandList& cmdList);
+    private:
+        int m_minPresample = 0, m_numSets = 0, m_setSize = 0;
+        bool m_aliasReady = false;
+    };
+
+    struct IndirectLighting final : public RenderPassBase
+    {
+        enum class SHADER_OUT_RES { FINAL, COUNT };
+        enum class INTEGRATOR : uint8_t { PATH_TRACING, ReSTIR_GI, ReSTIR_PT, COUNT };
+        void Init(FrameContext* ctx, INTEGRATOR method);
+        void OnWindowResized();
+        void ResetTemporal();
+        void SetMethod(INTEGRATOR method);
+        void SetLightPresamplingParams(bool enable, int numSampleSets, int sampleSetSize);
+        void SetMaxBounces(int nonTr, int glossyTr);
+        // device pointer of the FINAL plane (RGBA32F)
+        void* GetOutput(SHADER_OUT_RES i) const;
+        void Render(Core::CommandList& cmdList);
+    private:
+        zr_params m_params{};
+    };
+}
+
+} // namespace ZetaRayAMD
