@@ -102,6 +102,8 @@ void zhx_pathtrace(const HxScene* s, const zr_frame_constants* cb, const zr_gbuf
     prm.russianRoulette = (params->flags & ZR_IND_RUSSIAN_ROULETTE) ? 1u : 0u;
     prm.numSampleSets = params->presampling ? params->num_sample_sets : 0u;
     prm.accumulate = (cb->accumulate && cb->camera_static) ? 1u : 0u;
+    prm.tileW = W; prm.groupsX = (W + 7) / 8;
+    std::vector<uint32_t> groupMax((size_t)prm.groupsX * ((H + 7) / 8));
     HxQueue q[2]; q[0].Resize(cap); q[1].Resize(cap);
     std::vector<F4> firstBOP(cap);
     uint64_t nClosest = 0, nShadow = 0;
@@ -132,13 +134,15 @@ void zhx_pathtrace(const HxScene* s, const zr_frame_constants* cb, const zr_gbuf
             if (in.rayS_d[i].w >= 0) { in.visS[i] = TraceSegmentRay(s->view, in.rayS_o[i], in.rayS_d[i], in.sLightID[i], stack); nShadow++; }
         }
         uint32_t outCount = 0;
+        std::fill(groupMax.begin(), groupMax.end(), 0u);
         for (uint32_t i = 0; i < count; i++)
         {
             PathOut po;
-            PtShadePath(s->view, *cb, prm, in, i, finalRGBA, firstBOP.data(), po);
+            PtShadePath(s->view, *cb, prm, in, i, finalRGBA, firstBOP.data(), groupMax.data(), po);
             if (po.alive) WritePath(out, outCount++, po);
         }
         count = outCount;
+        for (uint32_t i = 0; i < count; i++) PtRussianRoulette(s->view, prm, out, i, groupMax.data());
     }
     if (counters) { counters->n_closest = nClosest; counters->n_shadow = nShadow; }
 }

@@ -126,17 +126,25 @@ __global__ void __launch_bounds__(kBlock) k_trace(SceneView sc, PathQueue q, con
 }
 
 __global__ void __launch_bounds__(kBlock) k_pt_shade(SceneView sc, zr_frame_constants g, PtParams prm, PathQueue in, const uint32_t* inCount,
-    PathQueue out, uint32_t* outCount, float* finalRGBA, const F4* firstBOP)
+    PathQueue out, uint32_t* outCount, float* finalRGBA, const F4* firstBOP, uint32_t* groupMax)
 {
     const uint32_t n = *inCount;
     for (uint32_t base = blockIdx.x * kBlock; base < n; base += gridDim.x * kBlock)
     {
         const uint32_t i = base + threadIdx.x;
         PathOut po; po.alive = false;
-        if (i < n) PtShadePath(sc, g, prm, in, i, finalRGBA, firstBOP, po);
+        if (i < n) PtShadePath(sc, g, prm, in, i, finalRGBA, firstBOP, groupMax, po);
         const uint32_t slot = AllocSlotWave(outCount, po.alive);
         if (po.alive) WritePath(out, slot, po);
     }
+}
+
+// Russian-roulette stage: finishes the vertices PtShadePath parked (only launched for rounds in which RR can trigger)
+__global__ void __launch_bounds__(kBlock) k_pt_rr(SceneView sc, PtParams prm, PathQueue q, const uint32_t* count, const uint32_t* groupMax)
+{
+    const uint32_t n = *count;
+    for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock)
+        PtRussianRoulette(sc, prm, q, i, groupMax);
 }
 
 __global__ void k_estimate_power(const zr_emissive_triangle* em, uint32_t n, float* power)
@@ -237,6 +245,7 @@ struct zr_pass
     // INDIRECT
     QueueStorage q[2];
     DevBuf<float> finalRGBA; DevBuf<F4> firstBOP; DevBuf<uint32_t> counts; DevBuf<unsigned long long> counters;
+    DevBuf<uint32_t> groupMax;      // kMaxRounds x (8x8 groups of the tile): RR reduction keys
     zr_counters hostCounters{0, 0};
     // PRELIGHTING
     DevBuf<float> power;
@@ -513,6 +522,7 @@ static int AllocPass(zr_pass* p)
         if ((r = p->firstBOP.Alloc(cap))) return r;
         if ((r = p->counts.Alloc(kMaxRounds + 2))) return r;
         if ((r = p->counters.Alloc(2))) return r;
+        if ((r = p->groupMax.Alloc((size_t)kMaxRounds * ((p->w + 7) / 8) * ((p->h + 7) / 8)))) return r;
         HIP_TRY(hipMemset(p->finalRGBA.p, 0, cap * 4 * sizeof(float)));
         HIP_TRY(hipMemset(p->counters.p, 0, 2 * sizeof(unsigned long long)));
     }
@@ -600,11 +610,16 @@ static int RenderIndirect(zr_pass* p, hipStream_t s, const zr_frame_constants* c
     prm.russianRoulette = (p->params.flags & ZR_IND_RUSSIAN_ROULETTE) ? 1u : 0u;
     prm.numSampleSets = p->params.presampling ? p->params.num_sample_sets : 0u;
     prm.accumulate = (cb->accumulate && cb->camera_static) ? 1u : 0u;
+    prm.tileW = p->w; prm.groupsX = (p->w + 7) / 8;
+    const uint32_t numGroups = prm.groupsX * ((p->h + 7) / 8);
     const uint32_t maxB = prm.maxNonTrBounces > prm.maxGlossyTrBounces ? prm.maxNonTrBounces : prm.maxGlossyTrBounces;
     const int rounds = (int)maxB + 1;
     if (rounds > kMaxRounds) return Fail(ZR_ERR_INVALID_ARG, "too many bounces");
 
     HIP_TRY(hipMemsetAsync(p->counts.p, 0, (kMaxRounds + 2) * sizeof(uint32_t), s));
+    // Russian roulette can only trigger once bounce >= 3, i.e. from round 2 on and only if some path may take >= 4 bounces
+    const bool rrPossible = prm.russianRoulette && maxB >= 4;
+    if (rrPossible) HIP_TRY(hipMemsetAsync(p->groupMax.p, 0, (size_t)rounds * numGroups * sizeof(uint32_t), s));
     const uint32_t tilesX = (p->w + 15) / 16, tilesY = (p->h + 15) / 16;
     const GBuf gbv = gb->View();
     TimerBegin(p, s, "pt_init");
@@ -622,8 +637,14 @@ static int RenderIndirect(zr_pass* p, hipStream_t s, const zr_frame_constants* c
         TimerEnd(p, s);
         TimerBegin(p, s, "pt_shade");
         hipLaunchKernelGGL(k_pt_shade, dim3(gridShade), dim3(kBlock), 0, s, sc->view, *cb, prm, qin, p->counts.p + r, qout, p->counts.p + r + 1,
-            p->finalRGBA.p, p->firstBOP.p);
+            p->finalRGBA.p, p->firstBOP.p, p->groupMax.p + (size_t)r * numGroups);
         TimerEnd(p, s);
+        if (rrPossible && r >= 2)
+        {
+            TimerBegin(p, s, "pt_rr");
+            hipLaunchKernelGGL(k_pt_rr, dim3(gridShade), dim3(kBlock), 0, s, sc->view, prm, qout, p->counts.p + r + 1, p->groupMax.p + (size_t)r * numGroups);
+            TimerEnd(p, s);
+        }
     }
     HIP_TRY(hipGetLastError());
     return ZR_OK;

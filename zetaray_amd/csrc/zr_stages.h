@@ -198,6 +198,7 @@ static constexpr uint32_t PF_PENDING = 1u << 6;     // the previous vertex left 
 static constexpr uint32_t PF_NLS = 1u << 7;         // numLightSamples of the pending vertex (0 or 1)
 static constexpr uint32_t PF_MAXB_SHIFT = 8;        // bits 8..11 maxNumBounces
 static constexpr uint32_t PF_S_RAY = 1u << 12;      // a light-segment ray is in flight for the pending vertex
+static constexpr uint32_t PF_PARKED = 1u << 13;     // waiting for the Russian-roulette stage (group max not known yet)
 
 struct PathQueue
 {
@@ -242,6 +243,7 @@ struct PtParams
     uint32_t russianRoulette;
     uint32_t numSampleSets;      // 0 when light presampling is off
     uint32_t accumulate;         // g.accumulate && g.camera_static
+    uint32_t tileW, groupsX;     // tile width in pixels / in 8x8 groups (group key of the RR reduction)
 };
 
 // closest-hit ray of Hit::FindClosest / Hit_Emissive::FindClosest (RayQuery.hlsli:26-48 / 156-174).
@@ -380,12 +382,49 @@ ZR_HD void PtInitPixel(const SceneView& sc, const zr_frame_constants& g, const G
     out.sLightID = 0xffffffffu;
 }
 
+ZR_HD void zr_atomic_max_u32(uint32_t* p, uint32_t v)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    atomicMax(p, v);
+#else
+    if (v > *p) *p = v;
+#endif
+}
+
+// Tail of the PathTrace loop body (PathTracing.hlsli:74-95): sample the continuation direction, emit the C ray,
+// update throughput / medium bookkeeping speculatively (they only matter if the ray hits).
+ZR_HD void PtContinue(const SceneView& sc, V3 n, const Surface& surface, V3 hitPos, float eta_curr, float eta_next, bool inMedium,
+    V3 thr, uint32_t bounce, uint32_t maxB, uint32_t nflags, uint32_t pid, Rng& rngT, Rng& rngG, V3 li, PathOut& out)
+{
+    BsdfSample bs2 = InitBsdfSample();
+    F4 cro = f4(v3(0.0f), 0.0f), crd = f4(v3(0.0f), -1.0f);
+    if (bounce < maxB) bs2 = SampleBSDF(sc.rho, n, surface, rngT);
+    bool cont = !(Luminance(bs2.bsdfOverPdf) == 0);
+    if (cont) cont = MakeClosestRay(hitPos, n, bs2.wi, surface.Transmissive(), false, &cro, &crd);
+    if (cont)
+    {
+        thr = thr * bs2.bsdfOverPdf;
+        bool transmitted = dot(n, bs2.wi) < 0;
+        eta_curr = transmitted ? (eta_curr == kEtaAir ? eta_next : kEtaAir) : eta_curr;
+        inMedium = transmitted ? !inMedium : inMedium;
+    }
+    else nflags |= PF_DRAIN;
+    out.alive = true;
+    out.s0.x = pid; out.s0.y = rngT.s; out.s0.z = rngG.s;
+    out.s0.w = nflags | (bounce & PF_BOUNCE_MASK) | (inMedium ? PF_IN_MEDIUM : 0u) | (maxB << PF_MAXB_SHIFT);
+    out.s1 = f4(li, eta_curr);
+    out.s2 = f4(thr, out.s2.w);
+    out.s3 = f4(hitPos, 0.0f);
+    out.s4 = f4(bs2.wi, 0.0f);
+    out.rayC_o = cro; out.rayC_d = crd;
+}
+
 // One shade step for the path in slot `i` of `in`:
 //   (1) resolve the pending NEE of the previous vertex (RGI_Util::NEE_Emissive_MIS tail, ReSTIR_GI_NEE.hlsli:40-64, 98-113)
 //   (2) shade the continuation hit: GetMaterialData, NEE setup, Beer-Lambert, bounce bookkeeping, SampleBSDF
 //       (ReSTIR_RT::PathTrace loop body, PathTracing.hlsli:25-95)
 ZR_HD void PtShadePath(const SceneView& sc, const zr_frame_constants& g, const PtParams& prm, const PathQueue& in, uint32_t i,
-    float* finalRGBA, const F4* firstBOP, PathOut& out)
+    float* finalRGBA, const F4* firstBOP, uint32_t* groupMax, PathOut& out)
 {
     out.alive = false;
     const U4 s0 = in.s0[i];
@@ -532,34 +571,76 @@ ZR_HD void PtShadePath(const SceneView& sc, const zr_frame_constants& g, const P
         thr = thr * vexp(-t * ext);
     }
 
-    bool cont = !(bounce >= (maxB - 1));
-    BsdfSample bs2 = InitBsdfSample();
-    F4 cro = f4(v3(0.0f), 0.0f), crd = f4(v3(0.0f), -1.0f);
-    if (cont)
-    {
-        bounce++;
-        // Russian roulette (PathTracing.hlsli:62-72) is resolved by the RR stage when it can trigger; see zr_kernels.hip
-        if (bounce < maxB) bs2 = SampleBSDF(sc.rho, n, surface, rngT);
-        if (Luminance(bs2.bsdfOverPdf) == 0) cont = false;
-    }
-    if (cont) cont = MakeClosestRay(hitPos, n, bs2.wi, surface.Transmissive(), false, &cro, &crd);
-    if (cont)
-    {
-        thr = thr * bs2.bsdfOverPdf;
-        bool transmitted = dot(n, bs2.wi) < 0;
-        eta_curr = transmitted ? (eta_curr == kEtaAir ? eta_next : kEtaAir) : eta_curr;
-        inMedium = transmitted ? !inMedium : inMedium;
-    }
-    else nflags |= PF_DRAIN;
-
     out.alive = true;
-    out.s0.x = pid; out.s0.y = rngT.s; out.s0.z = rngG.s;
-    out.s0.w = nflags | (bounce & PF_BOUNCE_MASK) | (inMedium ? PF_IN_MEDIUM : 0u) | (maxB << PF_MAXB_SHIFT);
     out.s1 = f4(li, eta_curr);
-    out.s2 = f4(thr, out.s2.w);
     out.s3 = f4(hitPos, 0.0f);
-    out.s4 = f4(bs2.wi, 0.0f);
-    out.rayC_o = cro; out.rayC_d = crd;
+    if (bounce >= (maxB - 1))
+    {
+        // PathTracing.hlsli:53-54: the path ends here; one more round drains the pending NEE of this vertex
+        out.s0.x = pid; out.s0.y = rngT.s; out.s0.z = rngG.s;
+        out.s0.w = nflags | PF_DRAIN | (bounce & PF_BOUNCE_MASK) | (inMedium ? PF_IN_MEDIUM : 0u) | (maxB << PF_MAXB_SHIFT);
+        out.s2 = f4(thr, out.s2.w);
+        out.s4 = f4(v3(0.0f), 0.0f);
+        out.rayC_o = f4(v3(0.0f), 0.0f); out.rayC_d = f4(v3(0.0f), -1.0f);
+        return;
+    }
+    bounce++;
+    if (prm.russianRoulette && bounce >= 3u)
+    {
+        // Russian roulette (PathTracing.hlsli:62-72) needs WaveActiveMax(luminance(throughput)) over the 8x8 group:
+        // publish this lane's value, park the path; PtRussianRoulette (next kernel) finishes the vertex.
+        const uint32_t lx = pid % prm.tileW, ly = pid / prm.tileW;
+        zr_atomic_max_u32(&groupMax[(ly >> 3) * prm.groupsX + (lx >> 3)], zr_asuint(Luminance(thr)));
+        out.s0.x = pid; out.s0.y = rngT.s; out.s0.z = rngG.s;
+        out.s0.w = nflags | PF_PARKED | (bounce & PF_BOUNCE_MASK) | (inMedium ? PF_IN_MEDIUM : 0u) | (maxB << PF_MAXB_SHIFT);
+        out.s2 = f4(thr, out.s2.w);
+        out.s4 = f4(wiC, 0.0f);                                            // incoming direction, needed to rebuild the surface
+        out.rayC_o = f4(zr_asfloat(hc.y), zr_asfloat(hc.z), zr_asfloat(hc.w), t);   // hit record (bary, triangle, t)
+        out.rayC_d = f4(v3(0.0f), -1.0f);
+        return;
+    }
+    PtContinue(sc, n, surface, hitPos, eta_curr, eta_next, inMedium, thr, bounce, maxB, nflags, pid, rngT, rngG, li, out);
+}
+
+// Russian-roulette stage for the parked path in slot `i` of `q` (in place): PathTracing.hlsli:62-72, then the loop tail.
+// `groupMax` holds, per 8x8 group, the max luminance(throughput) over the lanes that reached the RR block this round
+// (the reference's WaveActiveMax; lanes = pixels of the 8x8 thread group).
+ZR_HD void PtRussianRoulette(const SceneView& sc, const PtParams& prm, const PathQueue& q, uint32_t i, const uint32_t* groupMax)
+{
+    const U4 s0 = q.s0[i];
+    if (!(s0.w & PF_PARKED)) return;
+    const uint32_t pid = s0.x;
+    const uint32_t lx = pid % prm.tileW, ly = pid / prm.tileW;
+    const float waveThroughput = zr_asfloat(groupMax[(ly >> 3) * prm.groupsX + (lx >> 3)]);
+    Rng rngT = Rng::Seed(s0.y), rngG = Rng::Seed(s0.z);
+    uint32_t flags = s0.w & ~PF_PARKED;
+    const uint32_t bounce = flags & PF_BOUNCE_MASK, maxB = (flags >> PF_MAXB_SHIFT) & 0xfu;
+    const bool inMedium = flags & PF_IN_MEDIUM;
+    const uint32_t nflags = flags & (PF_PENDING | PF_NLS | PF_S_RAY);
+    const float p_terminate = zr_max(0.05f, 1 - waveThroughput);
+    if (rngG.Uniform() < p_terminate)
+    {
+        U4 o = s0; o.z = rngG.s; o.w = flags | PF_DRAIN;
+        q.s0[i] = o;
+        q.rayC_d[i] = f4(v3(0.0f), -1.0f);
+        return;
+    }
+    const F4 s2 = q.s2[i];
+    V3 thr = xyz(s2) / (1 - p_terminate);
+    const F4 s1 = q.s1[i];
+    const float eta_curr = s1.w;
+    const V3 hitPos = xyz(q.s3[i]), wiC = xyz(q.s4[i]);
+    const F4 rec = q.rayC_o[i];
+    const uint32_t tri = zr_asuint(rec.z);
+    const TriMeta tm = sc.triMeta[tri];
+    HitInfo hit; hit.t = rec.w;
+    FillHit<false>(sc, tm.mesh, tm.prim, rec.x, rec.y, false, hit);
+    Surface surface; float eta_mat;
+    GetMaterialData(sc, -wiC, eta_curr, hit, surface, eta_mat);        // succeeded once already in PtShadePath
+    const float eta_next = eta_curr == kEtaAir ? eta_mat : kEtaAir;
+    PathOut po; po.s2.w = s2.w;
+    PtContinue(sc, hit.normal, surface, hitPos, eta_curr, eta_next, inMedium, thr, bounce, maxB, nflags, pid, rngT, rngG, xyz(s1), po);
+    q.s0[i] = po.s0; q.s1[i] = po.s1; q.s2[i] = po.s2; q.s4[i] = po.s4; q.rayC_o[i] = po.rayC_o; q.rayC_d[i] = po.rayC_d;
 }
 
 // trace stage for one ray of a queue slot

@@ -456,7 +456,11 @@ def make_synthetic_scene(num_tris=262144, num_emissive=100000, seed=0x5EED, room
                dict(base_color=(0.8, 0.8, 0.8, 1), roughness=0.25), dict(base_color=(0.5, 0.2, 0.6, 1), roughness=0.6),
                dict(base_color=(0.7, 0.1, 0.1, 1), roughness=0.4, coat_weight=1.0, coat_roughness=0.1) if with_special_materials
                else dict(base_color=(0.7, 0.1, 0.1, 1), roughness=0.4),
-               dict(base_color=(0.3, 0.6, 0.6, 1), roughness=0.15)]
+               dict(base_color=(0.3, 0.6, 0.6, 1), roughness=0.15) if not with_special_materials
+               else dict(base_color=(0.6, 0.9, 0.7, 1), roughness=0.2, transmission=1.0, ior=1.45, transmission_depth=0.75)]
+    if with_special_materials:
+        palette[2] = dict(base_color=(0.95, 0.95, 0.95, 1), roughness=0.0, transmission=1.0, ior=1.5)       # clear specular glass
+        palette[5] = dict(base_color=(0.5, 0.2, 0.6, 1), roughness=0.6, subsurface=0.5, thin_walled=True)   # thin-walled diffuse transmission
     for p in palette:
         mats.append(pack_material(double_sided=True, **p))
     em_mat_idx = len(mats)
