@@ -627,6 +627,8 @@ static void RenderPathTracer(const Scene& sc, const zr_frame_constants& g, GBVie
     }
 }
 
+#include "zro_rpt.h"
+
 //--------------------------------------------------------------------------------------
 // C entry points (ctypes)
 //--------------------------------------------------------------------------------------
@@ -665,6 +667,41 @@ int zro_pathtrace_render(const zro_scene* h, const zr_frame_constants* cb, const
     RenderPathTracer(h->s, *cb, GBView(planes), *prm, final_rgba);
     if (counters) { counters->n_closest = h->s.counters.n_closest; counters->n_shadow = h->s.counters.n_shadow; }
     return 0;
+}
+
+// ReSTIR PT (zro_rpt.h): stateful (two reservoir sets + r-buffers); prev may be null on the first frame
+struct zro_rpt { RPT::State st; };
+zro_rpt* zro_rpt_create(uint32_t w, uint32_t h, const uint16_t* sample_set_half2_512)
+{
+    zro_rpt* r = new zro_rpt(); r->st.Resize(w, h);
+    r->st.sampleSet.assign(sample_set_half2_512, sample_set_half2_512 + 1024);
+    return r;
+}
+void zro_rpt_destroy(zro_rpt* r) { delete r; }
+void zro_rpt_reset_temporal(zro_rpt* r) { r->st.temporalValid = false; }
+int zro_rpt_render(const zro_scene* h, zro_rpt* r, const zr_frame_constants* cb, const zr_gbuffer_planes* curr,
+    const zr_gbuffer_planes* prev, const zr_params* prm, float* final_rgba)
+{ RPT::Render(h->s, *cb, curr, prev, *prm, r->st, final_rgba); return 0; }
+int zro_rpt_self_shift(const zro_scene* h, zro_rpt* r, const zr_frame_constants* cb, const zr_gbuffer_planes* curr, const zr_params* prm, int which, float* out)
+{ RPT::SelfShift(h->s, *cb, curr, *prm, r->st, which, out); return 0; }
+// which: 0 = reservoirs the next frame will read as "previous", 1 = the other set.  plane: 0..6 = A..G, 7 = target, 8 = neighbor
+int zro_rpt_read_plane(const zro_rpt* r, int which, int plane, void* out)
+{
+    const RPT::ReservoirPlanes& p = r->st.reservoirs[which == 0 ? 1 - r->st.currIdx : r->st.currIdx];
+    auto cp = [&](const void* src, size_t bytes) { std::memcpy(out, src, bytes); return 0; };
+    switch (plane)
+    {
+    case 0: return cp(p.A.data(), p.A.size() * 4);
+    case 1: return cp(p.B.data(), p.B.size() * 4);
+    case 2: return cp(p.C.data(), p.C.size() * 4);
+    case 3: return cp(p.D.data(), p.D.size() * 4);
+    case 4: return cp(p.E.data(), p.E.size() * 2);
+    case 5: return cp(p.F.data(), p.F.size() * 4);
+    case 6: return cp(p.G.data(), p.G.size() * 4);
+    case 7: return cp(r->st.target.data(), r->st.target.size() * 4);
+    case 8: return cp(r->st.neighbor.data(), r->st.neighbor.size());
+    }
+    return 1;
 }
 
 // rays: n x 8 floats (o, tmin, d, tmax); hits: n x 4 uint32 (t bits, u bits, v bits, tri or 0xffffffff)

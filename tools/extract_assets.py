@@ -22,6 +22,15 @@ def main():
     payload = raw[128:128 + width * height * depth * 2]
     os.makedirs(os.path.join(ROOT, "zetaray_amd/assets"), exist_ok=True)
     open(os.path.join(ROOT, "zetaray_amd/assets/rho_lut_u16.bin"), "wb").write(payload)
+    # 512-point spatial-search sample set (RP/IndirectLighting/ReSTIR_PT/SampleSet.hlsli: `static const half2 k_samples[512]`),
+    # stored as 512 x 2 IEEE binary16 values; a data table, shipped like the LUT above
+    import re
+    import numpy as np
+    txt = open(os.path.join(REF, "Source/ZetaRenderPass/IndirectLighting/ReSTIR_PT/SampleSet.hlsli")).read()
+    pts = re.findall(r"half2\(([-0-9.e]+),\s*([-0-9.e]+)\)", txt)
+    assert len(pts) == 512, len(pts)
+    arr = np.array(pts, dtype=np.float64).astype(np.float32).astype(np.float16)
+    arr.tofile(os.path.join(ROOT, "zetaray_amd/assets/rpt_sample_set_f16.bin"))
     import sys
     sys.path.insert(0, ROOT)
     from zetaray_amd import scene_io

@@ -186,6 +186,14 @@ def load_rho_default():
     return data, (64, 32, 16)
 
 
+def load_rpt_sample_set():
+    """512 x half2 spatial-search points of ReSTIR PT (reference: ReSTIR_PT/SampleSet.hlsli), raw binary16 pairs."""
+    p = os.path.join(os.path.dirname(default_rho_path()), "rpt_sample_set_f16.bin")
+    data = np.fromfile(p, dtype="<u2")
+    assert data.size == 1024
+    return data
+
+
 def _accessor(g, bins, idx):
     acc = g["accessors"][idx]
     bv = g["bufferViews"][acc["bufferView"]]
