@@ -397,6 +397,20 @@ struct Reservoir
     }
 };
 
+// canonical 64-lane wave sum of the ABI: xor butterfly with strides 1, 2, ..., 32; lanes that
+// do not take part contribute +0.0f
+static inline float WaveSum64(const float* in)
+{
+    float v[64], t[64];
+    for (int i = 0; i < 64; i++) v[i] = in[i];
+    for (int s = 1; s < 64; s <<= 1)
+    {
+        for (int i = 0; i < 64; i++) t[i] = v[i] + v[i ^ s];
+        for (int i = 0; i < 64; i++) v[i] = t[i];
+    }
+    return v[0];
+}
+
 struct Globals { const Scene* sc; uint32_t numEmissives; int maxNumBounces; float alpha_min; };
 
 // ---- ReSTIR_PT_NEE.hlsli:134-207
@@ -1093,10 +1107,16 @@ static void PathTracePass(const Scene& sc, const zr_frame_constants& g, const GB
             bool any = false;
             for (uint32_t l = 0; l < 64; l++) { if (lanes[l].active) any = true; PT_PhaseA(gl[l], lanes[l], rr); }
             if (!any) break;
-            float waveThroughput = 0; bool anyRR = false;
+            // WaveActiveMax pinned to an integer max over the luminance bit patterns (NaN / negative -> 0)
+            uint32_t bits = 0;
             for (uint32_t l = 0; l < 64; l++)
                 if (lanes[l].active && lanes[l].atRR)
-                { float lum = Math::Luminance(lanes[l].throughput); waveThroughput = anyRR ? zr_max(waveThroughput, lum) : lum; anyRR = true; }
+                {
+                    float lum = Math::Luminance(lanes[l].throughput);
+                    uint32_t b = (zr_isnan(lum) || lum < 0) ? 0u : zr_asuint(lum);
+                    bits = b > bits ? b : bits;
+                }
+            const float waveThroughput = zr_asfloat(bits);
             for (uint32_t l = 0; l < 64; l++) PT_PhaseB(gl[l], lanes[l], waveThroughput);
         }
         for (uint32_t l = 0; l < 64; l++)
@@ -1504,7 +1524,8 @@ static void SpatialPass(const Scene& sc, const zr_frame_constants& g, const GBuf
     for (uint32_t gy = 0; gy < (H + 7) / 8; gy++) for (uint32_t gx = 0; gx < (W + 7) / 8; gx++)
     {
         // WaveActiveSum #1 / #2: lanes that passed the invalid/emissive early-out
-        float sum1 = 0, sum2 = 0;
+        float v1[64], v2[64], v3[64], v4[64];
+        for (uint32_t l = 0; l < 64; l++) v1[l] = v2[l] = v3[l] = v4[l] = 0.0f;
         for (uint32_t l = 0; l < 64; l++)
         {
             Lane& a = L[l]; a.valid = a.hasN = a.spatialEmpty = a.resample = false;
@@ -1521,11 +1542,11 @@ static void SpatialPass(const Scene& sc, const zr_frame_constants& g, const GBuf
             int sx, sy;
             a.hasN = neighborOf(x, y, sx, sy);
             if (a.hasN) a.sp = (size_t)sy * W + sx;
-            sum1 += a.r_curr.w_sum;
-            sum2 += a.r_curr.w_sum * (a.hasN ? 0.0f : 1.0f);
+            v1[l] = a.r_curr.w_sum;
+            v2[l] = a.r_curr.w_sum * (a.hasN ? 0.0f : 1.0f);
         }
+        const float sum1 = WaveSum64(v1), sum2 = WaveSum64(v2);
         // lanes without a neighbour finish; the rest load the spatial reservoir and join WaveActiveSum #3
-        float sum3 = 0;
         for (uint32_t l = 0; l < 64; l++)
         {
             Lane& a = L[l];
@@ -1544,9 +1565,9 @@ static void SpatialPass(const Scene& sc, const zr_frame_constants& g, const GBuf
             if ((a.r_curr.w_sum != 0) && (a.r_spatial.M > 0) && !a.r_curr.rc.Empty()) a.r_curr.w_sum = out.B[2 * a.px];
             a.M_new = (uint16_t)(a.r_curr.M + a.r_spatial.M);
             a.spatialEmpty = a.r_spatial.rc.Empty();
-            sum3 += a.r_curr.w_sum * (a.spatialEmpty ? 1.0f : 0.0f);
+            v3[l] = a.r_curr.w_sum * (a.spatialEmpty ? 1.0f : 0.0f);
         }
-        float sum4 = 0;
+        const float sum3 = WaveSum64(v3);
         for (uint32_t l = 0; l < 64; l++)
         {
             Lane& a = L[l];
@@ -1590,8 +1611,9 @@ static void SpatialPass(const Scene& sc, const zr_frame_constants& g, const GBuf
             a.r_curr.M = a.M_new;
             a.spatialEmpty = changed;                    // reuse the flag to carry `changed`
             a.M_max = (changed && shift.surfKMin1Tramsmissive) ? std::min<uint32_t>(a.M_max, M_MAX_X_K_TRANSMISSIVE) : a.M_max;
-            sum4 += a.r_curr.w_sum;
+            v4[l] = a.r_curr.w_sum;
         }
+        const float sum4 = WaveSum64(v4);
         for (uint32_t l = 0; l < 64; l++)
         {
             Lane& a = L[l];

@@ -25,6 +25,12 @@ def lib():
         L.zhx_trace_closest.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]
         L.zhx_set_tile_origin.argtypes = [C.c_uint32, C.c_uint32]
         L.zhx_trace_any.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]
+        L.zhx_rpt_create.restype = C.c_void_p
+        L.zhx_rpt_create.argtypes = [C.c_uint32, C.c_uint32]
+        L.zhx_rpt_destroy.argtypes = [C.c_void_p]
+        L.zhx_rpt_reset_temporal.argtypes = [C.c_void_p]
+        L.zhx_rpt_render.argtypes = [C.c_void_p] * 7
+        L.zhx_rpt_read_plane.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
         _LIB = L
     return _LIB
 
@@ -93,3 +99,39 @@ class HostExecScene:
         occ = np.zeros(len(rays), np.uint32)
         lib().zhx_trace_any(self.h, rays.ctypes.data, len(rays), mask, occ.ctypes.data)
         return occ
+
+
+class HostExecRPT:
+    """ReSTIR PT through the HIP stage functions, serially (mirror of oracle.zro.OracleRPT)."""
+    PLANES = {"A": (0, np.uint32, 1), "B": (1, np.float32, 2), "C": (2, np.uint32, 4), "D": (3, np.uint32, 4),
+              "E": (4, np.uint16, 1), "F": (5, np.float32, 2), "G": (6, np.uint32, 2), "target": (7, np.float32, 4),
+              "neighbor": (8, np.uint8, 2)}
+
+    def __init__(self, hxscene, w, h):
+        self.hx, self.w, self.h = hxscene, w, h
+        self.r = lib().zhx_rpt_create(w, h)
+        self.prev = None
+        self.final = np.zeros((h, w, 4), np.float32)
+
+    def __del__(self):
+        if getattr(self, "r", None):
+            lib().zhx_rpt_destroy(self.r)
+            self.r = None
+
+    def reset_temporal(self):
+        lib().zhx_rpt_reset_temporal(self.r)
+
+    def render(self, cb, params, gb=None):
+        if gb is None:
+            gb = self.hx.gbuffer(cb)
+        cbb = np.ascontiguousarray(cb)
+        prev = C.addressof(self.prev[1]) if self.prev is not None else None
+        lib().zhx_rpt_render(self.hx.h, self.r, cbb.ctypes.data, C.addressof(gb[1]), prev, C.addressof(params), self.final.ctypes.data)
+        self.prev = gb
+        return self.final
+
+    def plane(self, name, which=0):
+        idx, dt, ch = self.PLANES[name]
+        out = np.zeros((self.h, self.w, ch), dt)
+        lib().zhx_rpt_read_plane(self.r, which, idx, out.ctypes.data)
+        return out

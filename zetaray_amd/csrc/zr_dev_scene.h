@@ -128,7 +128,7 @@ ZR_HD float MatEmissiveStrength(const zr_material& m) { return zr_f16_to_f32((ui
 struct HitInfo { float t; V3 normal; uint32_t ID; uint32_t meshIdx; uint32_t matIdx; V3 dndu, dndv, dpdu, dpdv; V2 uv; };
 
 template<bool WantDiffs>
-ZR_HD void FillHit(const SceneView& sc, uint32_t meshIdx, uint32_t primIdx, float bu, float bv, bool wantID, HitInfo& ret)
+ZR_HD void FillHit(const SceneView& sc, uint32_t meshIdx, uint32_t primIdx, float bu, float bv, bool wantID, HitInfo& ret, bool currFrame = true)
 {
     const zr_mesh_instance& md = sc.instances[meshIdx];
     ret.matIdx = md.mat_idx;
@@ -138,8 +138,10 @@ ZR_HD void FillHit(const SceneView& sc, uint32_t meshIdx, uint32_t primIdx, floa
     const zr_vertex& V1 = sc.vertices[sc.indices[tri + 1] + md.base_vtx_offset];
     const zr_vertex& V2_ = sc.vertices[sc.indices[tri + 2] + md.base_vtx_offset];
 
-    V4 q = normalize(DecodeNormalized4(md.rotation));
-    V3 s = v3(zr_f16_to_f32(md.scale[0]), zr_f16_to_f32(md.scale[1]), zr_f16_to_f32(md.scale[2]));
+    // InCurrFrame == false: previous frame's instance transform (RayQuery.hlsli:75-90)
+    V4 q = normalize(DecodeNormalized4(currFrame ? md.rotation : md.prev_rotation));
+    const uint16_t* sh = currFrame ? md.scale : md.prev_scale;
+    V3 s = v3(zr_f16_to_f32(sh[0]), zr_f16_to_f32(sh[1]), zr_f16_to_f32(sh[2]));
 
     float tmp = 1 - bu - bv;
     V2 uv = v2(zr_fma(bv, V2_.uv[0], tmp * V0.uv[0]), zr_fma(bv, V2_.uv[1], tmp * V0.uv[1]));
@@ -156,6 +158,7 @@ ZR_HD void FillHit(const SceneView& sc, uint32_t meshIdx, uint32_t primIdx, floa
     if (WantDiffs)
     {
         V3 trn = v3p(md.translation);
+        if (!currFrame) trn = trn - v3(zr_f16_to_f32(md.d_translation[0]), zr_f16_to_f32(md.d_translation[1]), zr_f16_to_f32(md.d_translation[2]));
         V3 v0W = TransformTRS(v3p(V0.pos), trn, q, s);
         V3 v1W = TransformTRS(v3p(V1.pos), trn, q, s);
         V3 v2W = TransformTRS(v3p(V2_.pos), trn, q, s);
