@@ -33,6 +33,21 @@ TRACE_SHADOW = 32 + 4
 SHADE_CLOSEST = BYTES_CLOSEST - TRACE_CLOSEST
 SHADE_SHADOW = BYTES_SHADOW - TRACE_SHADOW
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: 8 TB/s
+# ReSTIR PT: algorithmic per-pixel bytes of each pass besides its rays: G-buffer planes read
+# (38 B: base colour 4, normal 4, mr 2, depth 4, ior 1, coat 8 (rare), tri diffs 0 -- not carried, motion 4, ...) and
+# reservoir (62 B per set), r-buffer (42 B), target (16 B), final (16 B) planes read / written
+RPT_PIXEL_BYTES = {
+    "rpt_pathtrace": 23 + 62 + 16,                 # G-buffer in, reservoir + target (or final) out
+    "rpt_replay_ctt": 2 * 27 + 4 + 62 + 42,        # curr + prev G-buffer, motion, reservoir in, r-buffer out
+    "rpt_replay_ttc": 2 * 27 + 4 + 62 + 42,
+    "rpt_reconnect_ctt": 2 * 27 + 4 + 62 + 4 + 42 + 4,
+    "rpt_reconnect_ttc": 2 * 27 + 4 + 2 * 62 + 16 + 42 + 62 + 16,
+    "rpt_spatial_search": 4 * 14 + 2,              # own + 3 candidates x (mr, depth, normal), neighbour out
+    "rpt_replay_cts": 2 + 27 + 62 + 42,
+    "rpt_replay_stc": 2 + 27 + 62 + 42,
+    "rpt_reconnect_cts": 2 + 27 + 62 + 4 + 42 + 4,
+    "rpt_reconnect_stc": 2 + 27 + 2 * 62 + 16 + 42 + 62 + 16,
+}
 
 
 def tile_grid(n):
@@ -92,6 +107,8 @@ def main():
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--scene", default=os.path.join(ROOT, "tests", "golden", "cornell_emissive.npz"))
+    ap.add_argument("--integrator", choices=["restir_pt", "pt"], default="restir_pt",
+                    help="restir_pt = K11-K16 (BASELINE metric); pt = K9 unidirectional path tracer")
     args = ap.parse_args()
 
     import torch
@@ -113,7 +130,14 @@ def main():
     sc = scene_io.load_npz(args.scene)
     prm = wire.default_params()
     x0, y0, tw, th = tile_rect(W, H, world, rank)
-    r = api.Renderer(sc, tw, th, device=local_rank, params=prm, tile_origin=(x0, y0))
+    rpt = args.integrator == "restir_pt"
+    if rpt and world > 1:
+        # spatio-temporal reuse reads neighbouring pixels' reservoirs: sharding the frame needs the halo exchange of
+        # SURVEY.md section 8(e), which is not implemented yet -> every rank renders the whole frame (replicas), and the
+        # line says so.  Use --integrator pt for the tile-sharded path tracer.
+        x0, y0, tw, th = 0, 0, W, H
+    r = api.Renderer(sc, tw, th, device=local_rank, params=prm, tile_origin=(x0, y0),
+                     integrator=api.INTEGRATOR_RESTIR_PT if rpt else api.INTEGRATOR_PATH_TRACING)
 
     def frame(i):
         cb = scene_io.make_frame_constants(W, H, frame_num=i, num_emissives=len(sc.emissives))
@@ -150,14 +174,21 @@ def main():
     n_closest, n_shadow = float(rays[0]), float(rays[1])
     ms_per_step = tmax / args.steps * 1e3
     mrays = (n_closest + n_shadow) / tmax / 1e6
+    replicas = rpt and world > 1
 
     out = {
         "metric": "Mrays/s", "value": round(mrays, 2), "unit": "Mrays/s", "n_gpus": world, "steps": args.steps,
-        "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "strong",
+        "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
+        "scaling": "weak" if replicas else "strong",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": f"Cornell Box (cornell_emissive: 58 triangles, 2 emissive) {W}x{H}, G-buffer + 1-spp "
-                               f"path tracer (K1+K9, NEE+MIS, 3 non-transmissive bounces, static camera); ReSTIR PT "
-                               f"reuse passes not implemented yet", "parallelism": f"screen tiles {tile_grid(world)}",
+        "config": {"workload": (f"Cornell Box (cornell_emissive: 58 triangles, 2 emissive) {W}x{H}, G-buffer + ReSTIR PT "
+                                f"(K1 + K11-K16: initial candidates, temporal + spatial reconnection reuse, boiling "
+                                f"suppression; 3 non-transmissive / 4 glossy-transmissive bounces, static camera)") if rpt else
+                               (f"Cornell Box (cornell_emissive: 58 triangles, 2 emissive) {W}x{H}, G-buffer + 1-spp "
+                                f"path tracer (K1+K9, NEE+MIS, 3 non-transmissive bounces, static camera)"),
+                   "integrator": args.integrator,
+                   "parallelism": (f"{world} full-frame replicas (halo exchange for the screen-tile split not implemented)"
+                                   if replicas else f"screen tiles {tile_grid(world)}"),
                    "rays_per_frame": round((n_closest + n_shadow) / args.steps, 1),
                    "fps": round(1e3 / ms_per_step, 2)},
     }
@@ -176,6 +207,7 @@ def main():
                 a = agg.setdefault(name, [0.0, 0])
                 a[0] += ms
                 a[1] += launches
+        kern_rays = r.p_indirect.kernel_counters()
         cc, cs = r.p_indirect.read_counters(reset=True)
         r.p_gbuffer.read_counters(reset=True)
         r.p_gbuffer.enable_timing(False)
@@ -183,7 +215,12 @@ def main():
         dom = max(agg, key=lambda k: agg[k][0])
         launches = agg[dom][1]
         avg_ms = agg[dom][0] / launches
-        if dom == "trace":
+        if dom.startswith("rpt_"):
+            # per-ray model of SURVEY.md section 8(d) on the rays this kernel issued + the per-pixel reservoir / G-buffer
+            # bytes it must touch
+            kcc, kcs = kern_rays.get(dom, (0, 0))
+            bytes_launch = (BYTES_CLOSEST * kcc + BYTES_SHADOW * kcs) / launches + RPT_PIXEL_BYTES.get(dom, 0) * W * H
+        elif dom == "trace":
             bytes_launch = (TRACE_CLOSEST * cc + TRACE_SHADOW * cs) / launches
         elif dom == "pt_shade":
             bytes_launch = (SHADE_CLOSEST * cc + SHADE_SHADOW * cs) / launches

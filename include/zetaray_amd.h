@@ -91,7 +91,23 @@ typedef struct zr_params {
 
 /* outputs, GetOutput(SHADER_OUT_RES) */
 typedef enum zr_output {
-    ZR_OUT_FINAL = 0               /* RGBA32F, linear radiance (reference: *_FINAL textures) */
+    ZR_OUT_FINAL = 0,              /* RGBA32F, linear radiance (reference: *_FINAL textures) */
+    /* ReSTIR PT persistent state, in the reference's texture formats (IndirectLighting.h:128-144, Reservoir.hlsli:267-456):
+       the reservoir set the NEXT frame reads as "previous".  Exposed for parity tests and for a renderer that wants to
+       checkpoint / migrate temporal history. */
+    ZR_OUT_RPT_RESERVOIR_A = 1,    /* RGBA8_UINT   4 B: k | M << 4, lobes | lt_k << 6, lt_k+1 | motion << 2            */
+    ZR_OUT_RPT_RESERVOIR_B = 2,    /* RG32F        8 B: w_sum, W                                                      */
+    ZR_OUT_RPT_RESERVOIR_C = 3,    /* RGBA32_UINT 16 B                                                               */
+    ZR_OUT_RPT_RESERVOIR_D = 4,    /* RGBA32_UINT 16 B                                                               */
+    ZR_OUT_RPT_RESERVOIR_E = 5,    /* R16F         2 B                                                               */
+    ZR_OUT_RPT_RESERVOIR_F = 6,    /* RG32F        8 B                                                               */
+    ZR_OUT_RPT_RESERVOIR_G = 7,    /* RG32_UINT    8 B                                                               */
+    ZR_OUT_RPT_TARGET      = 8,    /* RGBA32F     16 B (xyz)                                                         */
+    ZR_OUT_RPT_NEIGHBOR    = 9,    /* RG8_UINT     2 B: spatial neighbour offset + 32, 255 = none                    */
+    /* replay buffers of the last frame (scratch between K13 and K14/K16; Shift.hlsli:191-358): current-to-neighbour
+       and neighbour-to-current, planes A (RGBA16F 8 B), B (RGBA32_UINT), C (RGBA32_UINT), D (R16_UINT) */
+    ZR_OUT_RPT_RBUF_CTN_A  = 10, ZR_OUT_RPT_RBUF_CTN_B = 11, ZR_OUT_RPT_RBUF_CTN_C = 12, ZR_OUT_RPT_RBUF_CTN_D = 13,
+    ZR_OUT_RPT_RBUF_NTC_A  = 14, ZR_OUT_RPT_RBUF_NTC_B = 15, ZR_OUT_RPT_RBUF_NTC_C = 16, ZR_OUT_RPT_RBUF_NTC_D = 17
 } zr_output;
 
 /* G-buffer planes (reference GBufferData::GBUFFER order and DXGI formats, DefaultRendererImpl.h:82-109) */
@@ -165,6 +181,9 @@ int zr_pass_get_output(const zr_pass* pass, int which, void** dev_ptr, uint32_t*
 int zr_pass_download_output(const zr_pass* pass, int which, void* hip_stream, void* host_dst, size_t bytes);
 /* ray counters accumulated since the last call (device -> host copy; synchronises the stream) */
 int zr_pass_read_counters(zr_pass* pass, void* hip_stream, zr_counters* out, int reset);
+/* the same counters split by the kernel that issued the queries (not reset; roofline bookkeeping of bench.py) */
+int zr_pass_read_kernel_counters(zr_pass* pass, void* hip_stream, uint32_t max_entries, const char** names,
+                                 uint64_t* n_closest, uint64_t* n_shadow, uint32_t* count);
 /* GpuTimer analogue (Source/ZetaCore/Core/GpuTimer.h:28-45): per-kernel hipEvent timing of the last render */
 int zr_pass_enable_timing(zr_pass* pass, int enable);
 int zr_pass_get_timings(zr_pass* pass, uint32_t max_entries, const char** names, float* ms, uint32_t* launches,

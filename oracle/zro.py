@@ -39,7 +39,7 @@ def lib():
         L.zro_rpt_create.argtypes = [C.c_uint32, C.c_uint32, C.c_void_p]
         L.zro_rpt_destroy.argtypes = [C.c_void_p]
         L.zro_rpt_reset_temporal.argtypes = [C.c_void_p]
-        L.zro_rpt_render.argtypes = [C.c_void_p] * 7
+        L.zro_rpt_render.argtypes = [C.c_void_p] * 8
         L.zro_rpt_self_shift.argtypes = [C.c_void_p] * 5 + [C.c_int, C.c_void_p]
         L.zro_rpt_read_plane.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
         L.zro_kat_unary.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_uint32]
@@ -143,8 +143,11 @@ class OracleRPT:
             gb = self.osc.gbuffer(cb)
         cbb = np.ascontiguousarray(cb)
         prev = C.addressof(self.prev[1]) if self.prev is not None else None
+        from zetaray_amd import wire
+        cnt = wire.Counters()
         lib().zro_rpt_render(self.osc.h, self.r, cbb.ctypes.data, C.addressof(gb[1]), prev, C.addressof(params),
-                             self.final.ctypes.data)
+                             self.final.ctypes.data, C.addressof(cnt))
+        self.counters = (cnt.n_closest, cnt.n_shadow)
         self.prev = gb
         return self.final
 

@@ -680,8 +680,13 @@ zro_rpt* zro_rpt_create(uint32_t w, uint32_t h, const uint16_t* sample_set_half2
 void zro_rpt_destroy(zro_rpt* r) { delete r; }
 void zro_rpt_reset_temporal(zro_rpt* r) { r->st.temporalValid = false; }
 int zro_rpt_render(const zro_scene* h, zro_rpt* r, const zr_frame_constants* cb, const zr_gbuffer_planes* curr,
-    const zr_gbuffer_planes* prev, const zr_params* prm, float* final_rgba)
-{ RPT::Render(h->s, *cb, curr, prev, *prm, r->st, final_rgba); return 0; }
+    const zr_gbuffer_planes* prev, const zr_params* prm, float* final_rgba, zr_counters* counters)
+{
+    h->s.counters = Counters();
+    RPT::Render(h->s, *cb, curr, prev, *prm, r->st, final_rgba);
+    if (counters) { counters->n_closest = h->s.counters.n_closest; counters->n_shadow = h->s.counters.n_shadow; }
+    return 0;
+}
 int zro_rpt_self_shift(const zro_scene* h, zro_rpt* r, const zr_frame_constants* cb, const zr_gbuffer_planes* curr, const zr_params* prm, int which, float* out)
 { RPT::SelfShift(h->s, *cb, curr, *prm, r->st, which, out); return 0; }
 // which: 0 = reservoirs the next frame will read as "previous", 1 = the other set.  plane: 0..6 = A..G, 7 = target, 8 = neighbor

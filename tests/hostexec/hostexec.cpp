@@ -200,9 +200,11 @@ void zhx_rpt_destroy(HxRpt* r) { delete r; }
 void zhx_rpt_reset_temporal(HxRpt* r) { r->temporalValid = false; }
 
 void zhx_rpt_render(const HxScene* s, HxRpt* R, const zr_frame_constants* cb, const zr_gbuffer_planes* curr, const zr_gbuffer_planes* prev,
-    const zr_params* params, float* finalRGBA)
+    const zr_params* params, float* finalRGBA, zr_counters* counters)
 {
     using namespace rpt;
+    uint32_t cnt[2] = {0, 0}; uint64_t total[2] = {0, 0};
+    auto flush = [&]() { total[0] += cnt[0]; total[1] += cnt[1]; cnt[0] = cnt[1] = 0; };
     const zr_frame_constants& g = *cb;
     const uint32_t W = g.render_width, H = g.render_height;
     RptFrame F;
@@ -226,30 +228,31 @@ void zhx_rpt_render(const HxScene* s, HxRpt* R, const zr_frame_constants* cb, co
     std::vector<PTLane> lanes(64);
     for (uint32_t by = 0; by < (H + 3) / 4; by++) for (uint32_t bx = 0; bx < (W + 15) / 16; bx++)
     {
-        for (uint32_t l = 0; l < 64; l++) PtInitLane(F.sc, g, F.gb, prm, bx * 16 + (l & 15), by * 4 + (l >> 4), finalRGBA, stack, lanes[l]);
+        for (uint32_t l = 0; l < 64; l++) PtInitLane(F.sc, g, F.gb, prm, bx * 16 + (l & 15), by * 4 + (l >> 4), finalRGBA, stack, cnt, lanes[l]);
         for (;;)
         {
             bool any = false;
-            for (uint32_t l = 0; l < 64; l++) { if (lanes[l].active) any = true; PtPhaseA(F.sc, g, prm, stack, lanes[l]); }
+            for (uint32_t l = 0; l < 64; l++) { if (lanes[l].active) any = true; PtPhaseA(F.sc, g, prm, stack, cnt, lanes[l]); }
             if (!any) break;
             uint32_t bits = 0;
             for (uint32_t l = 0; l < 64; l++) { uint32_t b = PtRRKey(lanes[l]); bits = b > bits ? b : bits; }
             for (uint32_t l = 0; l < 64; l++) PtPhaseB(prm, lanes[l], bits);
         }
         for (uint32_t l = 0; l < 64; l++) PtFinishLane(F.gb, prm, F.cur, F.tex, finalRGBA, lanes[l]);
+        flush();
     }
     if (prm.doTemporal)
     {
-        for (int v = 0; v < 2; v++) for (uint32_t y = 0; y < H; y++) for (uint32_t x = 0; x < W; x++) ReplayTemporalPixel(F, g, v, x, y, stack);
-        for (uint32_t y = 0; y < H; y++) for (uint32_t x = 0; x < W; x++) ReconnectCtTPixel(F, g, x, y, stack);
-        for (uint32_t y = 0; y < H; y++) for (uint32_t x = 0; x < W; x++) ReconnectTtCPixel(F, g, x, y, stack);
+        for (int v = 0; v < 2; v++) for (uint32_t y = 0; y < H; y++) for (uint32_t x = 0; x < W; x++) { ReplayTemporalPixel(F, g, v, x, y, stack, cnt); flush(); }
+        for (uint32_t y = 0; y < H; y++) for (uint32_t x = 0; x < W; x++) { ReconnectCtTPixel(F, g, x, y, stack, cnt); flush(); }
+        for (uint32_t y = 0; y < H; y++) for (uint32_t x = 0; x < W; x++) { ReconnectTtCPixel(F, g, x, y, stack, cnt); flush(); }
     }
     if (prm.doSpatial)
     {
         for (uint32_t y = 0; y < H; y++) for (uint32_t x = 0; x < W; x++) SpatialSearchPixel(F, g, x, y);
         R->currIdx = 1 - R->currIdx;          // IndirectLighting.cpp:609-612, 682-685
-        for (int v = 0; v < 2; v++) for (uint32_t y = 0; y < H; y++) for (uint32_t x = 0; x < W; x++) ReplaySpatialPixel(F, g, v, x, y, stack);
-        for (uint32_t y = 0; y < H; y++) for (uint32_t x = 0; x < W; x++) ReconnectCtSPixel(F, g, x, y, stack);
+        for (int v = 0; v < 2; v++) for (uint32_t y = 0; y < H; y++) for (uint32_t x = 0; x < W; x++) { ReplaySpatialPixel(F, g, v, x, y, stack, cnt); flush(); }
+        for (uint32_t y = 0; y < H; y++) for (uint32_t x = 0; x < W; x++) { ReconnectCtSPixel(F, g, x, y, stack, cnt); flush(); }
         std::vector<StcLane> L(64);
         float v1[64], v2[64], v3[64], v4[64];
         for (uint32_t gy = 0; gy < (H + 7) / 8; gy++) for (uint32_t gx = 0; gx < (W + 7) / 8; gx++)
@@ -258,11 +261,13 @@ void zhx_rpt_render(const HxScene* s, HxRpt* R, const zr_frame_constants* cb, co
             const float sum1 = ButterflySum64(v1), sum2 = ButterflySum64(v2);
             for (uint32_t l = 0; l < 64; l++) StcPhase1(F, g, L[l], sum1, v3[l]);
             const float sum3 = ButterflySum64(v3);
-            for (uint32_t l = 0; l < 64; l++) StcPhase2(F, g, L[l], sum1, stack, v4[l]);
+            for (uint32_t l = 0; l < 64; l++) StcPhase2(F, g, L[l], sum1, stack, cnt, v4[l]);
             const float sum4 = ButterflySum64(v4);
             for (uint32_t l = 0; l < 64; l++) StcPhase3(F, g, L[l], sum2 + sum3 + sum4);
         }
     }
+    flush();
+    if (counters) { counters->n_closest = total[0]; counters->n_shadow = total[1]; }
     R->temporalValid = true;
     R->currIdx = 1 - R->currIdx;
 }
@@ -283,6 +288,17 @@ int zhx_rpt_read_plane(const HxRpt* R, int which, int plane, void* out)
     case 6: return cp(p.G.data(), p.G.size() * 4);
     case 7: return cp(R->target.data(), R->target.size() * 16);
     case 8: return cp(R->neighbor.data(), R->neighbor.size());
+    }
+    if (plane >= 10 && plane <= 17)
+    {
+        const HxRpt::RB& b = R->rb[(plane - 10) / 4];
+        switch ((plane - 10) % 4)
+        {
+        case 0: return cp(b.A.data(), b.A.size() * 2);
+        case 1: return cp(b.B.data(), b.B.size() * 16);
+        case 2: return cp(b.C.data(), b.C.size() * 16);
+        default: return cp(b.D.data(), b.D.size() * 2);
+        }
     }
     return 1;
 }

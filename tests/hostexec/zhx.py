@@ -29,7 +29,7 @@ def lib():
         L.zhx_rpt_create.argtypes = [C.c_uint32, C.c_uint32]
         L.zhx_rpt_destroy.argtypes = [C.c_void_p]
         L.zhx_rpt_reset_temporal.argtypes = [C.c_void_p]
-        L.zhx_rpt_render.argtypes = [C.c_void_p] * 7
+        L.zhx_rpt_render.argtypes = [C.c_void_p] * 8
         L.zhx_rpt_read_plane.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
         _LIB = L
     return _LIB
@@ -105,7 +105,9 @@ class HostExecRPT:
     """ReSTIR PT through the HIP stage functions, serially (mirror of oracle.zro.OracleRPT)."""
     PLANES = {"A": (0, np.uint32, 1), "B": (1, np.float32, 2), "C": (2, np.uint32, 4), "D": (3, np.uint32, 4),
               "E": (4, np.uint16, 1), "F": (5, np.float32, 2), "G": (6, np.uint32, 2), "target": (7, np.float32, 4),
-              "neighbor": (8, np.uint8, 2)}
+              "neighbor": (8, np.uint8, 2),
+              "ctn_A": (10, np.uint16, 4), "ctn_B": (11, np.uint32, 4), "ctn_C": (12, np.uint32, 4), "ctn_D": (13, np.uint16, 1),
+              "ntc_A": (14, np.uint16, 4), "ntc_B": (15, np.uint32, 4), "ntc_C": (16, np.uint32, 4), "ntc_D": (17, np.uint16, 1)}
 
     def __init__(self, hxscene, w, h):
         self.hx, self.w, self.h = hxscene, w, h
@@ -126,7 +128,11 @@ class HostExecRPT:
             gb = self.hx.gbuffer(cb)
         cbb = np.ascontiguousarray(cb)
         prev = C.addressof(self.prev[1]) if self.prev is not None else None
-        lib().zhx_rpt_render(self.hx.h, self.r, cbb.ctypes.data, C.addressof(gb[1]), prev, C.addressof(params), self.final.ctypes.data)
+        from zetaray_amd import wire
+        cnt = wire.Counters()
+        lib().zhx_rpt_render(self.hx.h, self.r, cbb.ctypes.data, C.addressof(gb[1]), prev, C.addressof(params), self.final.ctypes.data,
+                             C.addressof(cnt))
+        self.counters = (cnt.n_closest, cnt.n_shadow)
         self.prev = gb
         return self.final
 

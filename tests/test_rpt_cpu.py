@@ -1,0 +1,145 @@
+"""ReSTIR PT (K11-K16) on CPU: the HIP stage functions (zr_rpt.h, run serially by tests/hostexec) against the oracle
+(oracle/zro_rpt.h) -- bit-exact radiance AND bit-exact persistent state (all 7 reservoir planes) over several frames --
+plus properties that pin the oracle itself: the no-reuse estimator agrees with the K9 path tracer in expectation, and
+shifting a reservoir's path onto its own pixel reproduces its target with Jacobian 1."""
+import numpy as np
+import pytest
+
+from oracle import zro
+from tests.hostexec import zhx
+from zetaray_amd import scene_io, wire
+
+PLANES = ("A", "B", "C", "D", "E", "F", "G", "neighbor")
+
+
+def _cb(sc, w, h, f, **kw):
+    return scene_io.make_frame_constants(w, h, frame_num=f, num_emissives=len(sc.emissives), **kw)
+
+
+def _assert_same_state(o, h, frame):
+    for nm in PLANES:
+        pa, pb = o.plane(nm), h.plane(nm)
+        if nm == "A":      # RGBA8: the w channel is never written
+            pa, pb = pa & 0xffffff, pb & 0xffffff
+        assert np.array_equal(pa.view(np.uint8), pb.view(np.uint8)), f"frame {frame}: reservoir plane {nm} differs"
+
+
+@pytest.fixture(scope="module")
+def hx_emissive(cornell_emissive, oracle_emissive):
+    return zhx.HostExecScene(cornell_emissive, oracle_emissive.alias)
+
+
+@pytest.mark.parametrize("mode", ["full", "temporal", "none", "no_boiling"])
+def test_rpt_cornell_bit_exact(cornell_emissive, oracle_emissive, hx_emissive, mode):
+    w, h = 64, 48
+    prm = wire.default_params()
+    if mode == "temporal":
+        prm.flags &= ~wire.IND_SPATIAL_RESAMPLE
+    if mode == "none":
+        prm.flags &= ~(wire.IND_SPATIAL_RESAMPLE | wire.IND_TEMPORAL_RESAMPLE)
+    if mode == "no_boiling":
+        prm.flags &= ~wire.IND_BOILING_SUPPRESSION
+    o, x = zro.OracleRPT(oracle_emissive, w, h), zhx.HostExecRPT(hx_emissive, w, h)
+    for f in range(1, 5):
+        cb = _cb(cornell_emissive, w, h, f)
+        a, b = o.render(cb, prm), x.render(cb, prm)
+        assert not np.isnan(a).any()
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), f"frame {f}: radiance differs"
+        _assert_same_state(o, x, f)
+        assert o.counters == x.counters and o.counters[0] > 0
+    assert a[..., :3].max() > 0
+
+
+def test_rpt_moving_camera_and_reset(cornell_emissive, oracle_emissive, hx_emissive):
+    """Camera translation between frames (motion vectors -> prevPixel != pixel, disocclusion at the borders), camera
+    jitter, then ResetTemporal."""
+    w, h = 72, 40
+    prm = wire.default_params()
+    o, x = zro.OracleRPT(oracle_emissive, w, h), zhx.HostExecRPT(hx_emissive, w, h)
+    prev_cb = None
+    for f in range(1, 6):
+        cam = (0.05 * f, 1.2 + 0.02 * f, -4.043 + 0.03 * f)
+        cb = _cb(cornell_emissive, w, h, f, cam_pos=cam, jitter=(0.25 * (f % 2), -0.125))
+        if prev_cb is not None:
+            for k in ("prev_view", "prev_view_inv", "prev_camera_jitter"):
+                cb[k] = prev_cb[k.replace("prev_", "curr_")] if k != "prev_camera_jitter" else prev_cb["curr_camera_jitter"]
+        prev_cb = cb.copy()
+        if f == 4:
+            o.reset_temporal(); x.reset_temporal()
+        a, b = o.render(cb, prm), x.render(cb, prm)
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), f"frame {f}"
+        _assert_same_state(o, x, f)
+    mv = o.prev[0][wire.GB_PLANE_NAMES.index("motion_vector")] if hasattr(wire, "GB_PLANE_NAMES") else None
+    assert mv is None or np.any(mv != 0)
+
+
+@pytest.fixture(scope="module")
+def synthetic_small():
+    sc = scene_io.make_synthetic_scene(num_tris=3000, num_emissive=1500, seed=11)
+    o = zro.OracleScene(sc, force_bvh=True)
+    return sc, o, zhx.HostExecScene(sc, o.alias)
+
+
+@pytest.mark.parametrize("nb,gb", [(3, 4), (6, 8)])
+def test_rpt_all_material_classes(synthetic_small, nb, gb):
+    """Metal, coat, specular / rough glass (GLOSSY_T reconnection limits, k > 2 replays, case 3 light reconnections),
+    thin-walled transmission; (6, 8) bounces make Russian roulette and the 16x4-wave max trigger."""
+    sc, osc, hx = synthetic_small
+    w, h = 64, 48
+    prm = wire.default_params()
+    prm.max_non_tr_bounces, prm.max_glossy_tr_bounces = nb, gb
+    o, x = zro.OracleRPT(osc, w, h), zhx.HostExecRPT(hx, w, h)
+    ks = set()
+    for f in range(1, 5):
+        cb = _cb(sc, w, h, f, cam_pos=(0, 0, -3.5))
+        a, b = o.render(cb, prm), x.render(cb, prm)
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), f"frame {f}"
+        _assert_same_state(o, x, f)
+        A = o.plane("A")[..., 0]
+        k = A & 0xf
+        lt_k = (A >> 14) & 3
+        lt_k1 = (A >> 16) & 3
+        for kk, c3, c2 in zip(k.ravel(), lt_k.ravel(), lt_k1.ravel()):
+            if kk != 15:
+                ks.add((int(kk) + 2, 3 if c3 else (2 if c2 else 1)))
+    # the scene must exercise reconnections beyond the first indirect vertex and all three cases
+    assert any(k > 2 for k, _ in ks) and {c for _, c in ks} == {1, 2, 3}, ks
+
+
+def test_rpt_initial_candidates_unbiased_vs_k9(cornell_emissive, oracle_emissive):
+    """Without reuse K11 is a path tracer with a different RNG layout: its mean converges to K9's (pins the oracle's
+    NEE / MIS / throughput bookkeeping against the independently pinned K9 restatement)."""
+    w, h, n = 48, 32, 160
+    prm = wire.default_params()
+    p2 = wire.default_params()
+    p2.flags &= ~(wire.IND_SPATIAL_RESAMPLE | wire.IND_TEMPORAL_RESAMPLE)
+    acc9, accp = np.zeros((h, w, 4), np.float64), np.zeros((h, w, 4), np.float64)
+    rpt = zro.OracleRPT(oracle_emissive, w, h)
+    for f in range(1, n + 1):
+        cb = _cb(cornell_emissive, w, h, f)
+        gb = oracle_emissive.gbuffer(cb)
+        acc9 += oracle_emissive.pathtrace(cb, gb[1], prm)[0]
+        accp += rpt.render(cb, p2, gb)
+    m9, mp = acc9[..., :3].mean(axis=(0, 1)) / n, accp[..., :3].mean(axis=(0, 1)) / n
+    assert np.all(np.abs(mp / m9 - 1) < 0.06), (m9, mp)
+
+
+def test_rpt_self_shift_identity(synthetic_small):
+    """Reconnection shift of a path onto its own pixel, k == 2 (no replay): target ~= stored target (L is fp16, w_k is
+    oct32), Jacobian ~= 1, for case 1 and case 2.  (k > 2 goes through the r-buffer, whose context Load() resets the
+    replay RNG -- Shift.hlsli:196-204, 700-713 -- so the reference's own shift is not an identity there.)"""
+    sc, osc, _ = synthetic_small
+    w, h = 64, 48
+    prm = wire.default_params()
+    prm.max_non_tr_bounces, prm.max_glossy_tr_bounces = 5, 6
+    rpt = zro.OracleRPT(osc, w, h)
+    cb = _cb(sc, w, h, 3, cam_pos=(0, 0, -3.5))
+    rpt.render(cb, prm)
+    o = rpt.self_shift(cb, prm).reshape(-1, 6)
+    o = o[(o[:, 4] == 2) & (o[:, 1] > 0)]
+    assert len(o) > 400 and set(o[:, 5].astype(int)) == {1, 2}
+    ok = o[:, 0] > 0
+    assert ok.mean() > 0.97
+    tr, jr = o[ok, 0] / o[ok, 1], o[ok, 2] / o[ok, 3]
+    assert np.median(np.abs(tr - 1)) < 2e-3 and np.quantile(np.abs(tr - 1), 0.85) < 0.03
+    assert np.median(np.abs(jr - 1)) < 1e-3 and np.quantile(np.abs(jr - 1), 0.85) < 0.03

@@ -18,6 +18,12 @@ LIB_PATH = os.path.join(_HERE, "libzetaray_amd.so")
 PASS_GBUFFER, PASS_PRELIGHTING, PASS_DI_EMISSIVE, PASS_DI_SKY, PASS_INDIRECT = range(5)
 INTEGRATOR_PATH_TRACING, INTEGRATOR_RESTIR_GI, INTEGRATOR_RESTIR_PT = range(3)
 OUT_FINAL = 0
+# ReSTIR PT persistent state (zr_output): name -> (id, dtype, channels)
+RPT_OUTPUTS = {"A": (1, np.uint32, 1), "B": (2, np.float32, 2), "C": (3, np.uint32, 4), "D": (4, np.uint32, 4),
+               "E": (5, np.uint16, 1), "F": (6, np.float32, 2), "G": (7, np.uint32, 2), "target": (8, np.float32, 4),
+               "neighbor": (9, np.uint8, 2),
+               "ctn_A": (10, np.uint16, 4), "ctn_B": (11, np.uint32, 4), "ctn_C": (12, np.uint32, 4), "ctn_D": (13, np.uint16, 1),
+               "ntc_A": (14, np.uint16, 4), "ntc_B": (15, np.uint32, 4), "ntc_C": (16, np.uint32, 4), "ntc_D": (17, np.uint16, 1)}
 
 EXPORTS = [
     "zr_abi_version", "zr_last_error", "zr_device_count", "zr_scene_create", "zr_scene_destroy",
@@ -25,7 +31,7 @@ EXPORTS = [
     "zr_gbuffer_create", "zr_gbuffer_destroy", "zr_gbuffer_set_tile_origin", "zr_gbuffer_download", "zr_gbuffer_device_plane",
     "zr_params_default", "zr_pass_create", "zr_pass_init", "zr_pass_resize", "zr_pass_reset_temporal",
     "zr_pass_set_params", "zr_pass_render", "zr_pass_get_output", "zr_pass_download_output",
-    "zr_pass_read_counters", "zr_pass_enable_timing", "zr_pass_get_timings", "zr_pass_destroy",
+    "zr_pass_read_counters", "zr_pass_read_kernel_counters", "zr_pass_enable_timing", "zr_pass_get_timings", "zr_pass_destroy",
     "zr_trace_closest", "zr_trace_any",
 ]
 
@@ -78,6 +84,7 @@ def lib():
         L.zr_pass_get_output.argtypes = [vp, i32, vp, vp, vp, vp]
         L.zr_pass_download_output.argtypes = [vp, i32, vp, vp, C.c_size_t]
         L.zr_pass_read_counters.argtypes = [vp, vp, vp, i32]
+        L.zr_pass_read_kernel_counters.argtypes = [vp, vp, u32, vp, vp, vp, vp]
         L.zr_pass_enable_timing.argtypes = [vp, i32]
         L.zr_pass_get_timings.argtypes = [vp, u32, vp, vp, vp, vp]
         L.zr_pass_destroy.argtypes = [vp]
@@ -202,10 +209,27 @@ class Pass:
         _check(lib().zr_pass_download_output(self.h, which, stream, out.ctypes.data, out.nbytes))
         return out
 
+    def download_plane(self, name, stream=None):
+        """ReSTIR PT reservoir / target / neighbour planes (see RPT_OUTPUTS)."""
+        which, dt, ch = RPT_OUTPUTS[name]
+        out = np.zeros((self.h_, self.w, ch), dt)
+        _check(lib().zr_pass_download_output(self.h, which, stream, out.ctypes.data, out.nbytes))
+        return out
+
     def read_counters(self, reset=True, stream=None):
         c = wire.Counters()
         _check(lib().zr_pass_read_counters(self.h, stream, C.addressof(c), int(reset)))
         return c.n_closest, c.n_shadow
+
+    def kernel_counters(self, stream=None):
+        """{kernel name: (closest-hit queries, shadow queries)} accumulated since the last read_counters(reset=True)."""
+        n = 16
+        names = (C.c_char_p * n)()
+        a = (C.c_uint64 * n)()
+        b = (C.c_uint64 * n)()
+        cnt = C.c_uint32()
+        _check(lib().zr_pass_read_kernel_counters(self.h, stream, n, names, a, b, C.byref(cnt)))
+        return {names[i].decode(): (a[i], b[i]) for i in range(cnt.value)}
 
     def enable_timing(self, on=True):
         _check(lib().zr_pass_enable_timing(self.h, int(on)))

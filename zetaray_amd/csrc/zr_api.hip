@@ -13,7 +13,13 @@
 #include <cstring>
 #include <new>
 #include "zr_stages.h"
+#include "zr_rpt.h"
 #include "zr_bvh.h"
+
+// 512 x half2 spatial-search points (generated from zetaray_amd/assets/rpt_sample_set_f16.bin by the Makefile)
+static const uint16_t kRptSampleSet[1024] = {
+#include "zr_rpt_sample_set.inc"
+};
 
 using namespace zr;
 
@@ -171,6 +177,93 @@ __global__ void __launch_bounds__(kBlock) k_trace_rays_any(SceneView sc, const F
     }
 }
 
+// ------------------------------------------------------------------------------------------------ ReSTIR PT kernels
+// per-lane ray counters -> one atomic pair per wave (all 64 lanes must call this)
+__device__ __forceinline__ void FlushRayCounters(unsigned long long* counters, const uint32_t* cnt)
+{
+    uint32_t a = cnt[0], b = cnt[1];
+    for (int s = 1; s < 64; s <<= 1) { a += __shfl_xor(a, s); b += __shfl_xor(b, s); }
+    if (__lane_id() == 0)
+    {
+        if (a) atomicAdd(counters + 0, (unsigned long long)a);
+        if (b) atomicAdd(counters + 1, (unsigned long long)b);
+    }
+}
+
+// K11: block = 16x16 pixels, wave w = rows 4w..4w+3 (a 16x4 block: the RR "wave" of the ABI, zr_rpt.h header)
+__global__ void __launch_bounds__(kBlock) k_rpt_pathtrace(rpt::RptFrame F, zr_frame_constants g, uint32_t tilesX, unsigned long long* counters)
+{
+    const uint32_t tile = blockIdx.x, tx = tile % tilesX, ty = tile / tilesX;
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    const uint32_t x = tx * 16u + (lane & 15u), y = ty * 16u + wave * 4u + (lane >> 4);
+    uint32_t stack[kStack];
+    uint32_t cnt[2] = {0u, 0u};
+    rpt::PTLane P;
+    rpt::PtInitLane(F.sc, g, F.gb, F.prm, x, y, F.finalRGBA, stack, cnt, P);
+    for (;;)
+    {
+        const bool any = __ballot(P.active) != 0;
+        rpt::PtPhaseA(F.sc, g, F.prm, stack, cnt, P);
+        if (!any) break;
+        uint32_t key = rpt::PtRRKey(P);
+        if (__ballot(key != 0) != 0)
+        {
+            for (int s = 1; s < 64; s <<= 1) { uint32_t o = __shfl_xor(key, s); key = o > key ? o : key; }
+        }
+        rpt::PtPhaseB(F.prm, P, key);
+    }
+    rpt::PtFinishLane(F.gb, F.prm, F.cur, F.tex, F.finalRGBA, P);
+    FlushRayCounters(counters, cnt);
+}
+
+enum RptPixelPass { RPT_REPLAY_CTT = 0, RPT_REPLAY_TTC, RPT_RECONNECT_CTT, RPT_RECONNECT_TTC, RPT_SPATIAL_SEARCH, RPT_REPLAY_CTS,
+    RPT_REPLAY_STC, RPT_RECONNECT_CTS };
+
+template<int PASS>
+__global__ void __launch_bounds__(kBlock) k_rpt_pixel(rpt::RptFrame F, zr_frame_constants g, uint32_t tilesX, unsigned long long* counters)
+{
+    uint32_t x, y; PixelOfThread(tilesX, 0, 0, &x, &y);
+    uint32_t stack[kStack];
+    uint32_t cnt[2] = {0u, 0u};
+    if (x < F.gb.w && y < F.gb.h)
+    {
+        if (PASS == RPT_REPLAY_CTT) rpt::ReplayTemporalPixel(F, g, 0, x, y, stack, cnt);
+        else if (PASS == RPT_REPLAY_TTC) rpt::ReplayTemporalPixel(F, g, 1, x, y, stack, cnt);
+        else if (PASS == RPT_RECONNECT_CTT) rpt::ReconnectCtTPixel(F, g, x, y, stack, cnt);
+        else if (PASS == RPT_RECONNECT_TTC) rpt::ReconnectTtCPixel(F, g, x, y, stack, cnt);
+        else if (PASS == RPT_SPATIAL_SEARCH) rpt::SpatialSearchPixel(F, g, x, y);
+        else if (PASS == RPT_REPLAY_CTS) rpt::ReplaySpatialPixel(F, g, 0, x, y, stack, cnt);
+        else if (PASS == RPT_REPLAY_STC) rpt::ReplaySpatialPixel(F, g, 1, x, y, stack, cnt);
+        else if (PASS == RPT_RECONNECT_CTS) rpt::ReconnectCtSPixel(F, g, x, y, stack, cnt);
+    }
+    if (PASS != RPT_SPATIAL_SEARCH) FlushRayCounters(counters, cnt);
+}
+
+// canonical wave sum of the ABI: xor butterfly, strides 1..32 (zr_rpt.h ButterflySum64 is the host statement of it)
+__device__ __forceinline__ float WaveSumButterfly(float v)
+{
+    for (int s = 1; s < 64; s <<= 1) v = v + __shfl_xor(v, s);
+    return v;
+}
+
+// K16 StC: wave = 8x8 pixel group; every lane of the wave walks all four phases (absent lanes contribute 0)
+__global__ void __launch_bounds__(kBlock) k_rpt_stc(rpt::RptFrame F, zr_frame_constants g, uint32_t tilesX, unsigned long long* counters)
+{
+    uint32_t x, y; PixelOfThread(tilesX, 0, 0, &x, &y);
+    uint32_t stack[kStack];
+    uint32_t cnt[2] = {0u, 0u};
+    rpt::StcLane a;
+    float v1, v2, v3, v4;
+    rpt::StcPhase0(F, g, x, y, a, v1, v2);
+    const float sum1 = WaveSumButterfly(v1), sum2 = WaveSumButterfly(v2);
+    rpt::StcPhase1(F, g, a, sum1, v3);
+    const float sum3 = WaveSumButterfly(v3);
+    rpt::StcPhase2(F, g, a, sum1, stack, cnt, v4);
+    const float sum4 = WaveSumButterfly(v4);
+    rpt::StcPhase3(F, g, a, sum2 + sum3 + sum4);
+    FlushRayCounters(counters, cnt);
+}
+
 // ------------------------------------------------------------------------------------------------ host objects
 template<typename T> struct DevBuf
 {
@@ -195,9 +288,17 @@ struct zr_scene
 struct zr_gbuffer
 {
     int device = 0; uint32_t w = 0, h = 0, x0 = 0, y0 = 0;
-    DevBuf<uint8_t> planes[ZR_GB_COUNT];
-    GBuf View() const
+    // double-buffered like the reference's GBufferData (DefaultRendererImpl.h:80-130): every GBUFFER pass render flips
+    // `cur`; the other set is the previous frame's G-buffer that the temporal passes of ReSTIR read
+    DevBuf<uint8_t> planeSets[2][ZR_GB_COUNT];
+    int cur = 0; uint64_t numRendered = 0;
+    DevBuf<uint8_t>* Planes() { return planeSets[cur]; }
+    const DevBuf<uint8_t>* Planes() const { return planeSets[cur]; }
+    GBuf View() const { return ViewOf(cur); }
+    GBuf PrevView() const { return ViewOf(cur ^ 1); }
+    GBuf ViewOf(int which) const
     {
+        const DevBuf<uint8_t>* planes = planeSets[which];
         GBuf g; g.w = w; g.h = h; g.x0 = x0; g.y0 = y0;
         g.baseColor = (uint32_t*)planes[ZR_GB_BASE_COLOR].p; g.normal = (uint32_t*)planes[ZR_GB_NORMAL].p;
         g.mr = (uint16_t*)planes[ZR_GB_METALLIC_ROUGHNESS].p; g.motion = (uint32_t*)planes[ZR_GB_MOTION_VECTOR].p;
@@ -235,6 +336,10 @@ struct QueueStorage
 
 static constexpr int kMaxRounds = 16;
 static constexpr int kMaxTimers = 64;
+// ray-counter slots (pairs of u64 on the device): 0 = wavefront path tracer, 1.. = ReSTIR PT kernels in launch order
+static constexpr int kCounterSlots = 16;
+static const char* const kCounterNames[kCounterSlots] = {"trace", "rpt_pathtrace", "rpt_replay_ctt", "rpt_replay_ttc", "rpt_reconnect_ctt",
+    "rpt_reconnect_ttc", "rpt_spatial_search", "rpt_replay_cts", "rpt_replay_stc", "rpt_reconnect_cts", "rpt_reconnect_stc", "", "", "", "", ""};
 
 struct zr_pass
 {
@@ -247,6 +352,26 @@ struct zr_pass
     DevBuf<float> finalRGBA; DevBuf<F4> firstBOP; DevBuf<uint32_t> counts; DevBuf<unsigned long long> counters;
     DevBuf<uint32_t> groupMax;      // kMaxRounds x (8x8 groups of the tile): RR reduction keys
     zr_counters hostCounters{0, 0};
+    // INDIRECT / ReSTIR PT: two reservoir sets (7 planes each), two r-buffers, target, spatial neighbour, sample set
+    struct ResStorage
+    {
+        DevBuf<uint32_t> A, G; DevBuf<float> B, F; DevBuf<U4> C, D; DevBuf<uint16_t> E;
+        int Alloc(size_t n)
+        {
+            int r;
+            if ((r = A.Alloc(n)) || (r = B.Alloc(2 * n)) || (r = C.Alloc(n)) || (r = D.Alloc(n)) || (r = E.Alloc(n)) || (r = F.Alloc(2 * n)) || (r = G.Alloc(2 * n))) return r;
+            return ZR_OK;
+        }
+        rpt::ResPlanes View() const { rpt::ResPlanes v; v.A = A.p; v.B = B.p; v.C = C.p; v.D = D.p; v.E = E.p; v.F = F.p; v.G = G.p; return v; }
+    } res[2];
+    struct RBufStorage
+    {
+        DevBuf<uint16_t> A, D; DevBuf<U4> B, C;
+        int Alloc(size_t n) { int r; if ((r = A.Alloc(4 * n)) || (r = B.Alloc(n)) || (r = C.Alloc(n)) || (r = D.Alloc(n))) return r; return ZR_OK; }
+        rpt::RBuf View() const { rpt::RBuf v; v.A = A.p; v.B = B.p; v.C = C.p; v.D = D.p; return v; }
+    } rb[2];
+    DevBuf<F4> rptTarget; DevBuf<uint8_t> rptNeighbor; DevBuf<uint16_t> rptSampleSet;
+    bool temporalValid = false; int currIdx = 0;
     // PRELIGHTING
     DevBuf<float> power;
     // timing
@@ -460,10 +585,11 @@ int zr_gbuffer_create(int device, uint32_t w, uint32_t h, zr_gbuffer** out)
     zr_gbuffer* g = new (std::nothrow) zr_gbuffer();
     if (!g) return Fail(ZR_ERR_OOM, "out of host memory");
     g->device = device; g->w = w; g->h = h;
+    for (int k = 0; k < 2; k++)
     for (int i = 0; i < ZR_GB_COUNT; i++)
     {
-        if ((r = g->planes[i].Alloc((size_t)w * h * ZR_GB_PLANE_BYTES[i]))) { delete g; return r; }
-        hipError_t e = hipMemset(g->planes[i].p, 0, g->planes[i].n);
+        if ((r = g->planeSets[k][i].Alloc((size_t)w * h * ZR_GB_PLANE_BYTES[i]))) { delete g; return r; }
+        hipError_t e = hipMemset(g->planeSets[k][i].p, 0, g->planeSets[k][i].n);
         if (e != hipSuccess) { delete g; return Fail(ZR_ERR_HIP, "hipMemset failed: %s", hipGetErrorString(e)); }
     }
     *out = g;
@@ -485,13 +611,13 @@ int zr_gbuffer_download(const zr_gbuffer* g, void* stream, zr_gbuffer_planes* hp
     HIP_TRY(hipSetDevice(g->device));
     HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
     for (int i = 0; i < ZR_GB_COUNT; i++)
-        if (hp->plane[i]) HIP_TRY(hipMemcpy(hp->plane[i], g->planes[i].p, g->planes[i].n, hipMemcpyDeviceToHost));
+        if (hp->plane[i]) HIP_TRY(hipMemcpy(hp->plane[i], g->Planes()[i].p, g->Planes()[i].n, hipMemcpyDeviceToHost));
     return ZR_OK;
 }
 int zr_gbuffer_device_plane(const zr_gbuffer* g, int plane, void** dev)
 {
     if (!g || !dev || plane < 0 || plane >= ZR_GB_COUNT) return Fail(ZR_ERR_INVALID_ARG, "bad argument");
-    *dev = g->planes[plane].p;
+    *dev = g->Planes()[plane].p;
     return ZR_OK;
 }
 
@@ -521,10 +647,29 @@ static int AllocPass(zr_pass* p)
         if ((r = p->finalRGBA.Alloc(cap * 4))) return r;
         if ((r = p->firstBOP.Alloc(cap))) return r;
         if ((r = p->counts.Alloc(kMaxRounds + 2))) return r;
-        if ((r = p->counters.Alloc(2))) return r;
+        if ((r = p->counters.Alloc(2 * kCounterSlots))) return r;
         if ((r = p->groupMax.Alloc((size_t)kMaxRounds * ((p->w + 7) / 8) * ((p->h + 7) / 8)))) return r;
         HIP_TRY(hipMemset(p->finalRGBA.p, 0, cap * 4 * sizeof(float)));
-        HIP_TRY(hipMemset(p->counters.p, 0, 2 * sizeof(unsigned long long)));
+        HIP_TRY(hipMemset(p->counters.p, 0, 2 * kCounterSlots * sizeof(unsigned long long)));
+        if (p->integrator == ZR_INTEGRATOR_RESTIR_PT)
+        {
+            for (int k = 0; k < 2; k++)
+            {
+                if ((r = p->res[k].Alloc(cap))) return r;
+                if ((r = p->rb[k].Alloc(cap))) return r;
+                zr_pass::ResStorage& R = p->res[k];
+                HIP_TRY(hipMemset(R.A.p, 0, cap * 4)); HIP_TRY(hipMemset(R.B.p, 0, cap * 8)); HIP_TRY(hipMemset(R.C.p, 0, cap * 16));
+                HIP_TRY(hipMemset(R.D.p, 0, cap * 16)); HIP_TRY(hipMemset(R.E.p, 0, cap * 2)); HIP_TRY(hipMemset(R.F.p, 0, cap * 8));
+                HIP_TRY(hipMemset(R.G.p, 0, cap * 8));
+                zr_pass::RBufStorage& B = p->rb[k];
+                HIP_TRY(hipMemset(B.A.p, 0, cap * 8)); HIP_TRY(hipMemset(B.B.p, 0, cap * 16)); HIP_TRY(hipMemset(B.C.p, 0, cap * 16)); HIP_TRY(hipMemset(B.D.p, 0, cap * 2));
+            }
+            if ((r = p->rptTarget.Alloc(cap))) return r;
+            if ((r = p->rptNeighbor.Alloc(2 * cap))) return r;
+            HIP_TRY(hipMemset(p->rptTarget.p, 0, cap * 16)); HIP_TRY(hipMemset(p->rptNeighbor.p, 0, cap * 2));
+            if ((r = p->rptSampleSet.Upload(kRptSampleSet, 1024))) return r;
+            p->temporalValid = false; p->currIdx = 0;
+        }
     }
     return ZR_OK;
 }
@@ -532,8 +677,8 @@ static int AllocPass(zr_pass* p)
 int zr_pass_init(zr_pass* p, uint32_t w, uint32_t h, int integrator)
 {
     if (!p || !w || !h) return Fail(ZR_ERR_INVALID_ARG, "zr_pass_init: bad argument");
-    if (p->kind == ZR_PASS_INDIRECT && integrator != ZR_INTEGRATOR_PATH_TRACING)
-        return Fail(ZR_ERR_UNSUPPORTED, "integrator %d is not implemented yet (PATH_TRACING only)", integrator);
+    if (p->kind == ZR_PASS_INDIRECT && integrator != ZR_INTEGRATOR_PATH_TRACING && integrator != ZR_INTEGRATOR_RESTIR_PT)
+        return Fail(ZR_ERR_UNSUPPORTED, "integrator %d is not implemented yet (PATH_TRACING and RESTIR_PT only)", integrator);
     HIP_TRY(hipSetDevice(p->device));
     p->w = w; p->h = h; p->integrator = integrator;
     int r = AllocPass(p);
@@ -553,6 +698,7 @@ int zr_pass_reset_temporal(zr_pass* p)
     if (!p->initialized) return Fail(ZR_ERR_NOT_INITIALIZED, "pass not initialised");
     HIP_TRY(hipSetDevice(p->device));
     if (p->kind == ZR_PASS_INDIRECT) HIP_TRY(hipMemset(p->finalRGBA.p, 0, p->finalRGBA.n * sizeof(float)));
+    p->temporalValid = false;       // IndirectLighting::ResetTemporal -> RESET_TEMPORAL_TEXTURES next frame
     return ZR_OK;
 }
 int zr_pass_set_params(zr_pass* p, const zr_params* prm)
@@ -570,6 +716,7 @@ static int RenderGBuffer(zr_pass* p, hipStream_t s, const zr_frame_constants* cb
     if (!gb) return Fail(ZR_ERR_INVALID_ARG, "GBUFFER pass needs a gbuffer");
     if (gb->x0 + gb->w > cb->render_width || gb->y0 + gb->h > cb->render_height) return Fail(ZR_ERR_INVALID_ARG, "gbuffer tile lies outside the render target of the frame constants");
     const uint32_t tilesX = (gb->w + 15) / 16, tilesY = (gb->h + 15) / 16;
+    gb->cur ^= 1; gb->numRendered++;
     TimerBegin(p, s, "gbuffer");
     hipLaunchKernelGGL(k_gbuffer, dim3(tilesX * tilesY), dim3(kBlock), 0, s, sc->view, *cb, gb->View(), tilesX);
     TimerEnd(p, s);
@@ -597,6 +744,59 @@ static int RenderPreLighting(zr_pass* p, hipStream_t s, zr_scene* sc)
     return zr_scene_set_alias_table(sc, table.data(), n);
 }
 
+// IndirectLighting::RenderReSTIR_PT (IndirectLighting.cpp:877-1004) + the Render() tail (:1006-1025)
+static int RenderReSTIR_PT(zr_pass* p, hipStream_t s, const zr_frame_constants* cb, const zr_scene* sc, zr_gbuffer* gb)
+{
+    using namespace rpt;
+    if (gb->x0 || gb->y0 || gb->w != cb->render_width || gb->h != cb->render_height)
+        return Fail(ZR_ERR_UNSUPPORTED, "RESTIR_PT needs the whole frame on one device (screen-tile split needs the halo exchange, not implemented yet)");
+    RptFrame F;
+    F.sc = sc->view; F.gb = gb->View(); F.gbPrev = gb->PrevView();
+    F.rbCtN = p->rb[0].View(); F.rbNtC = p->rb[1].View(); F.tex.target = p->rptTarget.p; F.tex.neighbor = p->rptNeighbor.p;
+    F.finalRGBA = p->finalRGBA.p; F.sampleSet = p->rptSampleSet.p;
+    RptParams& prm = F.prm;
+    const zr_params& ip = p->params;
+    const bool havePrevGBuffer = gb->numRendered >= 2;
+    prm.maxNonTrBounces = ip.max_non_tr_bounces; prm.maxGlossyTrBounces = ip.max_glossy_tr_bounces;
+    prm.russianRoulette = (ip.flags & ZR_IND_RUSSIAN_ROULETTE) ? 1u : 0u;
+    prm.numSampleSets = ip.presampling ? ip.num_sample_sets : 0u;
+    prm.accumulate = (cb->accumulate && cb->camera_static) ? 1u : 0u;
+    prm.boiling = (ip.flags & ZR_IND_BOILING_SUPPRESSION) ? 1u : 0u;
+    prm.M_max_temporal = ip.m_max_temporal & 0xf; prm.M_max_spatial = ip.m_max_spatial & 0xf; prm.alpha_min = ip.alpha_min;
+    prm.doTemporal = ((ip.flags & ZR_IND_TEMPORAL_RESAMPLE) && p->temporalValid && havePrevGBuffer) ? 1u : 0u;
+    prm.doSpatial = ((ip.flags & ZR_IND_SPATIAL_RESAMPLE) && prm.doTemporal) ? 1u : 0u;
+    prm.writeReservoirs = (prm.doTemporal || !p->temporalValid) ? 1u : 0u;
+    F.cur = p->res[p->currIdx].View(); F.prev = p->res[1 - p->currIdx].View();
+    const uint32_t tilesX = (p->w + 15) / 16, tilesY = (p->h + 15) / 16;
+    const dim3 grid(tilesX * tilesY), block(kBlock);
+    int slot = 1;
+#define RPT_LAUNCH(name, kernel) do { TimerBegin(p, s, name); hipLaunchKernelGGL(kernel, grid, block, 0, s, F, *cb, tilesX, p->counters.p + 2 * slot); TimerEnd(p, s); slot++; } while (0)
+    RPT_LAUNCH("rpt_pathtrace", k_rpt_pathtrace);
+    if (prm.doTemporal)
+    {
+        RPT_LAUNCH("rpt_replay_ctt", k_rpt_pixel<RPT_REPLAY_CTT>);
+        RPT_LAUNCH("rpt_replay_ttc", k_rpt_pixel<RPT_REPLAY_TTC>);
+        RPT_LAUNCH("rpt_reconnect_ctt", k_rpt_pixel<RPT_RECONNECT_CTT>);
+        RPT_LAUNCH("rpt_reconnect_ttc", k_rpt_pixel<RPT_RECONNECT_TTC>);
+    }
+    if (prm.doSpatial)
+    {
+        slot = 6;
+        RPT_LAUNCH("rpt_spatial_search", k_rpt_pixel<RPT_SPATIAL_SEARCH>);
+        // spatial reads this frame's reservoirs and writes the other set, which becomes "current" (IndirectLighting.cpp:609-612, 682-685)
+        p->currIdx = 1 - p->currIdx;
+        RPT_LAUNCH("rpt_replay_cts", k_rpt_pixel<RPT_REPLAY_CTS>);
+        RPT_LAUNCH("rpt_replay_stc", k_rpt_pixel<RPT_REPLAY_STC>);
+        RPT_LAUNCH("rpt_reconnect_cts", k_rpt_pixel<RPT_RECONNECT_CTS>);
+        RPT_LAUNCH("rpt_reconnect_stc", k_rpt_stc);
+    }
+#undef RPT_LAUNCH
+    HIP_TRY(hipGetLastError());
+    p->temporalValid = true;
+    p->currIdx = 1 - p->currIdx;
+    return ZR_OK;
+}
+
 static int RenderIndirect(zr_pass* p, hipStream_t s, const zr_frame_constants* cb, const zr_scene* sc, zr_gbuffer* gb)
 {
     if (!gb) return Fail(ZR_ERR_INVALID_ARG, "INDIRECT pass needs a gbuffer");
@@ -605,6 +805,7 @@ static int RenderIndirect(zr_pass* p, hipStream_t s, const zr_frame_constants* c
     if (sc->view.numEmissives == 0) return Fail(ZR_ERR_UNSUPPORTED, "scenes without emissive triangles (sun/sky NEE) are not implemented yet");
     if (!sc->view.alias) return Fail(ZR_ERR_NOT_INITIALIZED, "emissive alias table missing: render the PRELIGHTING pass (or zr_scene_set_alias_table) first");
     if (cb->num_emissive_triangles != sc->view.numEmissives) return Fail(ZR_ERR_INVALID_ARG, "cbFrameConstants.NumEmissiveTriangles != scene");
+    if (p->integrator == ZR_INTEGRATOR_RESTIR_PT) return RenderReSTIR_PT(p, s, cb, sc, gb);
     PtParams prm;
     prm.maxNonTrBounces = p->params.max_non_tr_bounces; prm.maxGlossyTrBounces = p->params.max_glossy_tr_bounces;
     prm.russianRoulette = (p->params.flags & ZR_IND_RUSSIAN_ROULETTE) ? 1u : 0u;
@@ -671,11 +872,40 @@ int zr_pass_get_output(const zr_pass* p, int which, void** dev, uint32_t* w, uin
 {
     if (!p || !dev) return Fail(ZR_ERR_INVALID_ARG, "null argument");
     if (!p->initialized) return Fail(ZR_ERR_NOT_INITIALIZED, "pass not initialised");
-    if (p->kind != ZR_PASS_INDIRECT || which != ZR_OUT_FINAL) return Fail(ZR_ERR_INVALID_ARG, "pass has no such output");
-    *dev = p->finalRGBA.p;
+    if (p->kind != ZR_PASS_INDIRECT) return Fail(ZR_ERR_INVALID_ARG, "pass has no such output");
+    uint32_t bytes = 16;
+    if (which == ZR_OUT_FINAL) *dev = p->finalRGBA.p;
+    else if (which >= ZR_OUT_RPT_RBUF_CTN_A && which <= ZR_OUT_RPT_RBUF_NTC_D && p->integrator == ZR_INTEGRATOR_RESTIR_PT)
+    {
+        const zr_pass::RBufStorage& B = p->rb[(which - ZR_OUT_RPT_RBUF_CTN_A) / 4];
+        switch ((which - ZR_OUT_RPT_RBUF_CTN_A) % 4)
+        {
+        case 0: *dev = B.A.p; bytes = 8; break;
+        case 1: *dev = B.B.p; bytes = 16; break;
+        case 2: *dev = B.C.p; bytes = 16; break;
+        default: *dev = B.D.p; bytes = 2; break;
+        }
+    }
+    else if (which >= ZR_OUT_RPT_RESERVOIR_A && which <= ZR_OUT_RPT_NEIGHBOR && p->integrator == ZR_INTEGRATOR_RESTIR_PT)
+    {
+        const zr_pass::ResStorage& R = p->res[1 - p->currIdx];      // the set the next frame reads as "previous"
+        switch (which)
+        {
+        case ZR_OUT_RPT_RESERVOIR_A: *dev = R.A.p; bytes = 4; break;
+        case ZR_OUT_RPT_RESERVOIR_B: *dev = R.B.p; bytes = 8; break;
+        case ZR_OUT_RPT_RESERVOIR_C: *dev = R.C.p; bytes = 16; break;
+        case ZR_OUT_RPT_RESERVOIR_D: *dev = R.D.p; bytes = 16; break;
+        case ZR_OUT_RPT_RESERVOIR_E: *dev = R.E.p; bytes = 2; break;
+        case ZR_OUT_RPT_RESERVOIR_F: *dev = R.F.p; bytes = 8; break;
+        case ZR_OUT_RPT_RESERVOIR_G: *dev = R.G.p; bytes = 8; break;
+        case ZR_OUT_RPT_TARGET: *dev = p->rptTarget.p; bytes = 16; break;
+        default: *dev = p->rptNeighbor.p; bytes = 2; break;
+        }
+    }
+    else return Fail(ZR_ERR_INVALID_ARG, "pass has no such output");
     if (w) *w = p->w;
     if (h) *h = p->h;
-    if (bpp) *bpp = 16;
+    if (bpp) *bpp = bytes;
     return ZR_OK;
 }
 int zr_pass_download_output(const zr_pass* p, int which, void* stream, void* dst, size_t bytes)
@@ -696,13 +926,31 @@ int zr_pass_read_counters(zr_pass* p, void* stream, zr_counters* out, int reset)
     out->n_closest = p->hostCounters.n_closest; out->n_shadow = p->hostCounters.n_shadow;
     if (p->kind == ZR_PASS_INDIRECT && p->initialized)
     {
-        unsigned long long c[2];
+        unsigned long long c[2 * kCounterSlots];
         HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
         HIP_TRY(hipMemcpy(c, p->counters.p, sizeof(c), hipMemcpyDeviceToHost));
-        out->n_closest += c[0]; out->n_shadow += c[1];
+        for (int i = 0; i < kCounterSlots; i++) { out->n_closest += c[2 * i]; out->n_shadow += c[2 * i + 1]; }
         if (reset) HIP_TRY(hipMemset(p->counters.p, 0, sizeof(c)));
     }
     if (reset) { p->hostCounters.n_closest = 0; p->hostCounters.n_shadow = 0; }
+    return ZR_OK;
+}
+int zr_pass_read_kernel_counters(zr_pass* p, void* stream, uint32_t max_entries, const char** names, uint64_t* closest, uint64_t* shadow,
+    uint32_t* count)
+{
+    if (!p || !names || !closest || !shadow || !count) return Fail(ZR_ERR_INVALID_ARG, "null argument");
+    if (p->kind != ZR_PASS_INDIRECT || !p->initialized) return Fail(ZR_ERR_NOT_INITIALIZED, "INDIRECT pass not initialised");
+    HIP_TRY(hipSetDevice(p->device));
+    unsigned long long c[2 * kCounterSlots];
+    HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+    HIP_TRY(hipMemcpy(c, p->counters.p, sizeof(c), hipMemcpyDeviceToHost));
+    uint32_t n = 0;
+    for (int i = 0; i < kCounterSlots && n < max_entries; i++)
+    {
+        if (!kCounterNames[i][0] || (c[2 * i] == 0 && c[2 * i + 1] == 0)) continue;
+        names[n] = kCounterNames[i]; closest[n] = c[2 * i]; shadow[n] = c[2 * i + 1]; n++;
+    }
+    *count = n;
     return ZR_OK;
 }
 int zr_pass_enable_timing(zr_pass* p, int enable)

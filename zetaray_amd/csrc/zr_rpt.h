@@ -366,7 +366,8 @@ ZR_HD Reservoir Load_Metadata(const ResPlanes& p, size_t i) { Reservoir r = Init
 ZR_HD Reservoir Load_NonReconnection(const ResPlanes& p, size_t i)
 { Reservoir r = InitReservoir(); r.UnpackMetadata(p.A[i]); r.w_sum = p.B[2 * i]; r.W = p.B[2 * i + 1]; return r; }
 
-struct Globals { const SceneView* sc; uint32_t numEmissives; int maxNumBounces; float alpha_min; uint32_t* stack; };
+// cnt: this lane's ray counters {closest-hit queries, shadow / visibility queries} (never null)
+struct Globals { const SceneView* sc; uint32_t numEmissives; int maxNumBounces; float alpha_min; uint32_t* stack; uint32_t* cnt; };
 
 // ---- ray queries (inline traversal)
 struct HitEm { bool hit; float t; uint32_t mesh, prim, emissiveTriIdx; float bu, bv; };
@@ -376,6 +377,7 @@ ZR_HD HitEm FindClosestEm(const Globals& g, V3 pos, V3 normal, V3 wi, bool trans
     HitEm r; r.hit = false; r.emissiveTriIdx = 0xffffffffu; r.t = 0; r.mesh = 0; r.prim = 0; r.bu = 0; r.bv = 0;
     F4 ro, rd;
     if (!MakeClosestRay(pos, normal, wi, transmissive, true, &ro, &rd)) return r;
+    g.cnt[0]++;
     RawHit h = Traverse<false>(*g.sc, xyz(ro), xyz(rd), ro.w, rd.w, ZR_SUBGROUP_ALL, g.stack);
     if (h.tri == kInvalidTri) return r;
     const TriMeta tm = g.sc->triMeta[h.tri];
@@ -389,6 +391,7 @@ ZR_HD bool FindClosestID(const Globals& g, bool currFrame, V3 pos, V3 normal, V3
 {
     F4 ro, rd;
     if (!MakeClosestRay(pos, normal, wi, transmissive, false, &ro, &rd)) return false;
+    g.cnt[0]++;
     RawHit h = Traverse<false>(*g.sc, xyz(ro), xyz(rd), ro.w, rd.w, ZR_SUBGROUP_ALL, g.stack);
     if (h.tri == kInvalidTri) return false;
     const TriMeta tm = g.sc->triMeta[h.tri];
@@ -411,6 +414,7 @@ ZR_HD bool VisibilitySegmentApprox(const Globals& g, V3 origin, V3 wi, float ray
     const V3 o = OffsetRayRTG(origin, normal);
     const float tminv = 3e-6f;
     const float tmax = PrevFloat32(rayT * 0.999f - NextFloat32(tminv));
+    g.cnt[1]++;
     RawHit h = Traverse<true>(*g.sc, o, wi, tminv, tmax, ZR_SUBGROUP_NON_EMISSIVE, g.stack);
     if (h.tri == kInvalidTri) return true;
     const TriMeta tm = g.sc->triMeta[h.tri];
@@ -721,7 +725,7 @@ struct RptParams
 
 // main() prologue + RIS_InitialCandidates up to the first FindClosest (ReSTIR_PT_PathTrace.hlsl:360-530, 194-236)
 ZR_HD void PtInitLane(const SceneView& sc, const zr_frame_constants& g, const GBuf& gb, const RptParams& prm, uint32_t x, uint32_t y,
-    float* finalRGBA, uint32_t* stack, PTLane& P)
+    float* finalRGBA, uint32_t* stack, uint32_t* cnt, PTLane& P)
 {
     P.active = false; P.atRR = false; P.valid = false; P.x = x; P.y = y;
     if (x >= g.render_width || y >= g.render_height) return;
@@ -750,16 +754,16 @@ ZR_HD void PtInitLane(const SceneView& sc, const zr_frame_constants& g, const GB
     P.throughput_k = v3(1.0f);
     P.inMedium = P.eta_curr != kEtaAir;
     P.pos = ps.pos; P.normal = ps.normal; P.surface = ps.surface; P.bs = bs; P.eta_next = ps.eta_next;
-    Globals gl; gl.sc = &sc; gl.numEmissives = g.num_emissive_triangles; gl.maxNumBounces = P.maxNumBounces; gl.alpha_min = prm.alpha_min; gl.stack = stack;
+    Globals gl; gl.sc = &sc; gl.numEmissives = g.num_emissive_triangles; gl.maxNumBounces = P.maxNumBounces; gl.alpha_min = prm.alpha_min; gl.stack = stack; gl.cnt = cnt;
     P.nextHit = FindClosestEm(gl, ps.pos, ps.normal, bs.wi, ps.surface.Transmissive());
     P.active = true;
 }
 
-ZR_HD void PtPhaseA(const SceneView& sc, const zr_frame_constants& g, const RptParams& prm, uint32_t* stack, PTLane& P)
+ZR_HD void PtPhaseA(const SceneView& sc, const zr_frame_constants& g, const RptParams& prm, uint32_t* stack, uint32_t* cnt, PTLane& P)
 {
     P.atRR = false;
     if (!P.active) return;
-    Globals gl; gl.sc = &sc; gl.numEmissives = g.num_emissive_triangles; gl.maxNumBounces = P.maxNumBounces; gl.alpha_min = prm.alpha_min; gl.stack = stack;
+    Globals gl; gl.sc = &sc; gl.numEmissives = g.num_emissive_triangles; gl.maxNumBounces = P.maxNumBounces; gl.alpha_min = prm.alpha_min; gl.stack = stack; gl.cnt = cnt;
     P.pathVertex = P.bounce + 2;
     if (!P.nextHit.hit) { P.active = false; return; }
     P.hit.t = P.nextHit.t;
@@ -948,6 +952,7 @@ ZR_HD void Replay(const Globals& g, bool currFrame, int numBounces, BsdfSample b
         {
             F4 ro, rd;
             if (!MakeClosestRay(ctx.pos, ctx.normal, bs.wi, ctx.surface.Transmissive(), false, &ro, &rd)) { ctx.throughput = v3(0.0f); return; }
+            g.cnt[0]++;
             RawHit h = Traverse<false>(sc, xyz(ro), xyz(rd), ro.w, rd.w, ZR_SUBGROUP_ALL, g.stack);
             if (h.tri == kInvalidTri) { ctx.throughput = v3(0.0f); return; }
             const TriMeta tm = sc.triMeta[h.tri];
@@ -1089,9 +1094,9 @@ struct RptFrame
     RBuf rbCtN, rbNtC; RptTex tex; float* finalRGBA; const uint16_t* sampleSet; RptParams prm;
 };
 
-ZR_HD Globals MakeGlobals(const RptFrame& F, const zr_frame_constants& g, bool transmissive, uint32_t* stack)
+ZR_HD Globals MakeGlobals(const RptFrame& F, const zr_frame_constants& g, bool transmissive, uint32_t* stack, uint32_t* cnt)
 {
-    Globals gl; gl.sc = &F.sc; gl.numEmissives = g.num_emissive_triangles; gl.alpha_min = F.prm.alpha_min; gl.stack = stack;
+    Globals gl; gl.sc = &F.sc; gl.numEmissives = g.num_emissive_triangles; gl.alpha_min = F.prm.alpha_min; gl.stack = stack; gl.cnt = cnt;
     gl.maxNumBounces = transmissive ? (int)F.prm.maxGlossyTrBounces : (int)F.prm.maxNonTrBounces;
     return gl;
 }
@@ -1121,7 +1126,7 @@ ZR_HD TemporalPixel FindTemporal(const RptFrame& F, const zr_frame_constants& g,
 }
 
 // K13 Replay_CtT / Replay_TtC (ReSTIR_PT_Replay.hlsl:289-534)
-ZR_HD void ReplayTemporalPixel(const RptFrame& F, const zr_frame_constants& g, int variant, uint32_t x, uint32_t y, uint32_t* stack)
+ZR_HD void ReplayTemporalPixel(const RptFrame& F, const zr_frame_constants& g, int variant, uint32_t x, uint32_t y, uint32_t* stack, uint32_t* cnt)
 {
     const size_t px = (size_t)y * F.gb.w + x;
     GFlags flags = DecodeFlags(F.gb.mr[px]);
@@ -1130,7 +1135,7 @@ ZR_HD void ReplayTemporalPixel(const RptFrame& F, const zr_frame_constants& g, i
     PixelSurface ps = LoadPixelSurface(F.gb, cam, x, y, g.frame_num, px);
     TemporalPixel tp = FindTemporal(F, g, x, y, ps, 0.01f, false);
     if (!tp.ok) return;
-    Globals gl = MakeGlobals(F, g, flags.transmissive, stack);
+    Globals gl = MakeGlobals(F, g, flags.transmissive, stack, cnt);
     const size_t pp = (size_t)tp.py * F.gb.w + tp.px;
     if (variant == 0)
     {
@@ -1177,7 +1182,7 @@ ZR_HD void MoveXk(const SceneView& sc, Reconnection& rc, bool currToPrev, bool s
 }
 
 // K14 Reconnect_CtT (ReSTIR_PT_Reconnect_CtT.hlsl:130-292)
-ZR_HD void ReconnectCtTPixel(const RptFrame& F, const zr_frame_constants& g, uint32_t x, uint32_t y, uint32_t* stack)
+ZR_HD void ReconnectCtTPixel(const RptFrame& F, const zr_frame_constants& g, uint32_t x, uint32_t y, uint32_t* stack, uint32_t* cnt)
 {
     const size_t px = (size_t)y * F.gb.w + x;
     GFlags flags = DecodeFlags(F.gb.mr[px]);
@@ -1193,7 +1198,7 @@ ZR_HD void ReconnectCtTPixel(const RptFrame& F, const zr_frame_constants& g, uin
     {
         r_curr.Load_Reconnection(F.cur, px);
         if (r_curr.rc.IsCase1() || r_curr.rc.IsCase2()) MoveXk(F.sc, r_curr.rc, true, false);
-        Globals gl = MakeGlobals(F, g, flags.transmissive, stack);
+        Globals gl = MakeGlobals(F, g, flags.transmissive, stack, cnt);
         OffsetPath shift = Shift2(gl, false, px, tp.prev.pos, tp.prev.normal, tp.prev.eta_next, tp.prev.surface, r_curr.rc, F.rbCtN);
         float target_prev = Luminance(shift.target);
         if (target_prev > 0)
@@ -1208,7 +1213,7 @@ ZR_HD void ReconnectCtTPixel(const RptFrame& F, const zr_frame_constants& g, uin
 }
 
 // K14 Reconnect_TtC (ReSTIR_PT_Reconnect_TtC.hlsl:124-390)
-ZR_HD void ReconnectTtCPixel(const RptFrame& F, const zr_frame_constants& g, uint32_t x, uint32_t y, uint32_t* stack)
+ZR_HD void ReconnectTtCPixel(const RptFrame& F, const zr_frame_constants& g, uint32_t x, uint32_t y, uint32_t* stack, uint32_t* cnt)
 {
     const size_t px = (size_t)y * F.gb.w + x;
     GFlags flags = DecodeFlags(F.gb.mr[px]);
@@ -1239,7 +1244,7 @@ ZR_HD void ReconnectTtCPixel(const RptFrame& F, const zr_frame_constants& g, uin
     }
     r_prev.Load_Reconnection(F.prev, pp);
     if (r_prev.rc.IsCase1() || r_prev.rc.IsCase2()) MoveXk(F.sc, r_prev.rc, false, true);
-    Globals gl = MakeGlobals(F, g, flags.transmissive, stack);
+    Globals gl = MakeGlobals(F, g, flags.transmissive, stack, cnt);
     OffsetPath shift = Shift2(gl, true, px, ps.pos, ps.normal, ps.eta_next, ps.surface, r_prev.rc, F.rbNtC);
     float targetLum_curr = Luminance(shift.target);
     float jacobian = r_prev.rc.partialJacobian > 0 ? shift.partialJacobian / r_prev.rc.partialJacobian : 0;
@@ -1337,12 +1342,12 @@ ZR_HD bool NeighborOf(const RptFrame& F, uint32_t x, uint32_t y, int& sx, int& s
 
 // In the spatial passes F.cur = the temporal pass's output ("in"), F.prev = the set written for the next frame ("out")
 // K13 Replay_CtS / Replay_StC
-ZR_HD void ReplaySpatialPixel(const RptFrame& F, const zr_frame_constants& g, int variant, uint32_t x, uint32_t y, uint32_t* stack)
+ZR_HD void ReplaySpatialPixel(const RptFrame& F, const zr_frame_constants& g, int variant, uint32_t x, uint32_t y, uint32_t* stack, uint32_t* cnt)
 {
     const size_t px = (size_t)y * F.gb.w + x;
     GFlags flags = DecodeFlags(F.gb.mr[px]);
     if (flags.invalid || flags.emissive) return;
-    Globals gl = MakeGlobals(F, g, flags.transmissive, stack);
+    Globals gl = MakeGlobals(F, g, flags.transmissive, stack, cnt);
     const Camera cam = CurrCamera(g);
     int sx, sy;
     if (variant == 0)
@@ -1374,7 +1379,7 @@ ZR_HD void ReplaySpatialPixel(const RptFrame& F, const zr_frame_constants& g, in
 }
 
 // K16 Reconnect_CtS (ReSTIR_PT_Reconnect_CtS.hlsl:149-230)
-ZR_HD void ReconnectCtSPixel(const RptFrame& F, const zr_frame_constants& g, uint32_t x, uint32_t y, uint32_t* stack)
+ZR_HD void ReconnectCtSPixel(const RptFrame& F, const zr_frame_constants& g, uint32_t x, uint32_t y, uint32_t* stack, uint32_t* cnt)
 {
     const size_t px = (size_t)y * F.gb.w + x;
     int sx, sy;
@@ -1387,7 +1392,7 @@ ZR_HD void ReconnectCtSPixel(const RptFrame& F, const zr_frame_constants& g, uin
     if ((r_curr.w_sum != 0) && !r_curr.rc.Empty())
     {
         r_curr.Load_Reconnection(F.cur, px);
-        Globals gl = MakeGlobals(F, g, flags.transmissive, stack);
+        Globals gl = MakeGlobals(F, g, flags.transmissive, stack, cnt);
         const Camera cam = CurrCamera(g);
         PixelSurface pn = LoadPixelSurface(F.gb, cam, (uint32_t)sx, (uint32_t)sy, g.frame_num, px);
         OffsetPath shift = Shift2(gl, true, px, pn.pos, pn.normal, pn.eta_next, pn.surface, r_curr.rc, F.rbCtN);
@@ -1461,7 +1466,7 @@ ZR_HD void StcPhase1(const RptFrame& F, const zr_frame_constants& g, StcLane& a,
     s3 = a.r_curr.w_sum * (a.spatialEmpty ? 1.0f : 0.0f);
 }
 // phase 2: lanes whose neighbour is empty finish; the others shift + resample; contributes sum4
-ZR_HD void StcPhase2(const RptFrame& F, const zr_frame_constants& g, StcLane& a, float sum1, uint32_t* stack, float& s4)
+ZR_HD void StcPhase2(const RptFrame& F, const zr_frame_constants& g, StcLane& a, float sum1, uint32_t* stack, uint32_t* cnt, float& s4)
 {
     s4 = 0;
     if (!a.valid || !a.hasN) return;
@@ -1480,7 +1485,7 @@ ZR_HD void StcPhase2(const RptFrame& F, const zr_frame_constants& g, StcLane& a,
     a.M_max = a.r_spatial.rc.x_k_in_motion ? umin(a.M_max, kMmaxXkInMotion) : a.M_max;
     a.r_spatial.rc.x_k_in_motion = false;
     a.r_spatial.Load_Reconnection(F.cur, a.sp);
-    Globals gl = MakeGlobals(F, g, a.flags.transmissive, stack);
+    Globals gl = MakeGlobals(F, g, a.flags.transmissive, stack, cnt);
     OffsetPath shift = Shift2(gl, true, a.px, a.ps.pos, a.ps.normal, a.ps.eta_next, a.ps.surface, a.r_spatial.rc, F.rbNtC);
     float targetLum_curr = Luminance(shift.target);
     float targetLum_spatial = a.r_spatial.W > 0 ? a.r_spatial.w_sum / a.r_spatial.W : 0;
