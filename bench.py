@@ -37,16 +37,11 @@ HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: 8 TB/s
 # (38 B: base colour 4, normal 4, mr 2, depth 4, ior 1, coat 8 (rare), tri diffs 0 -- not carried, motion 4, ...) and
 # reservoir (62 B per set), r-buffer (42 B), target (16 B), final (16 B) planes read / written
 RPT_PIXEL_BYTES = {
-    "rpt_pathtrace": 23 + 62 + 16,                 # G-buffer in, reservoir + target (or final) out
-    "rpt_replay_ctt": 2 * 27 + 4 + 62 + 42,        # curr + prev G-buffer, motion, reservoir in, r-buffer out
-    "rpt_replay_ttc": 2 * 27 + 4 + 62 + 42,
-    "rpt_reconnect_ctt": 2 * 27 + 4 + 62 + 4 + 42 + 4,
-    "rpt_reconnect_ttc": 2 * 27 + 4 + 2 * 62 + 16 + 42 + 62 + 16,
-    "rpt_spatial_search": 4 * 14 + 2,              # own + 3 candidates x (mr, depth, normal), neighbour out
-    "rpt_replay_cts": 2 + 27 + 62 + 42,
-    "rpt_replay_stc": 2 + 27 + 62 + 42,
-    "rpt_reconnect_cts": 2 + 27 + 62 + 4 + 42 + 4,
-    "rpt_reconnect_stc": 2 + 27 + 2 * 62 + 16 + 42 + 62 + 16,
+    "rpt_pathtrace": 23 + 62 + 16,                       # G-buffer in, reservoir + target (or final) out
+    "rpt_reconnect_temporal": 2 * 27 + 4 + 2 * 62 + 16 + 2 * 42 + 62 + 16,   # CtT + TtC fused
+    "rpt_reconnect_spatial": 2 + 2 * 27 + 3 * 62 + 16 + 2 * 42 + 62 + 16,   # CtS + StC fused
+    "rpt_spatial_search": 4 * 14 + 2 + 8,
+    "rpt_classify_temporal": 2 + 4 + 8,
 }
 
 

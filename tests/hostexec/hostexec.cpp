@@ -244,20 +244,22 @@ void zhx_rpt_render(const HxScene* s, HxRpt* R, const zr_frame_constants* cb, co
     if (prm.doTemporal)
     {
         for (int v = 0; v < 2; v++) for (uint32_t y = 0; y < H; y++) for (uint32_t x = 0; x < W; x++) { ReplayTemporalPixel(F, g, v, x, y, stack, cnt); flush(); }
-        for (uint32_t y = 0; y < H; y++) for (uint32_t x = 0; x < W; x++) { ReconnectCtTPixel(F, g, x, y, stack, cnt); flush(); }
-        for (uint32_t y = 0; y < H; y++) for (uint32_t x = 0; x < W; x++) { ReconnectTtCPixel(F, g, x, y, stack, cnt); flush(); }
+        for (uint32_t y = 0; y < H; y++) for (uint32_t x = 0; x < W; x++) { ReconnectTemporalPixel(F, g, x, y, stack, cnt); flush(); }
     }
     if (prm.doSpatial)
     {
         for (uint32_t y = 0; y < H; y++) for (uint32_t x = 0; x < W; x++) SpatialSearchPixel(F, g, x, y);
         R->currIdx = 1 - R->currIdx;          // IndirectLighting.cpp:609-612, 682-685
         for (int v = 0; v < 2; v++) for (uint32_t y = 0; y < H; y++) for (uint32_t x = 0; x < W; x++) { ReplaySpatialPixel(F, g, v, x, y, stack, cnt); flush(); }
-        for (uint32_t y = 0; y < H; y++) for (uint32_t x = 0; x < W; x++) { ReconnectCtSPixel(F, g, x, y, stack, cnt); flush(); }
         std::vector<StcLane> L(64);
         float v1[64], v2[64], v3[64], v4[64];
         for (uint32_t gy = 0; gy < (H + 7) / 8; gy++) for (uint32_t gx = 0; gx < (W + 7) / 8; gx++)
         {
-            for (uint32_t l = 0; l < 64; l++) StcPhase0(F, g, gx * 8 + (l & 7), gy * 8 + (l >> 3), L[l], v1[l], v2[l]);
+            for (uint32_t l = 0; l < 64; l++)
+            {
+                StcPhase0(F, g, gx * 8 + (l & 7), gy * 8 + (l >> 3), L[l], v1[l], v2[l]);
+                if (L[l].valid && L[l].hasN) ReconnectCtSPixel(F, g, L[l].x, L[l].y, stack, cnt);
+            }
             const float sum1 = ButterflySum64(v1), sum2 = ButterflySum64(v2);
             for (uint32_t l = 0; l < 64; l++) StcPhase1(F, g, L[l], sum1, v3[l]);
             const float sum3 = ButterflySum64(v3);

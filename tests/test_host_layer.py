@@ -53,3 +53,22 @@ def test_cpp_passes_render_a_frame(cornell_emissive, oracle_emissive):
     _, planes = oracle_emissive.gbuffer(cb)
     want, _ = oracle_emissive.pathtrace(cb, planes, wire.default_params())
     assert np.array_equal(out.view(np.uint32), want.view(np.uint32))
+
+
+@pytest.mark.gpu
+def test_cpp_passes_render_restir_pt_sequence(cornell_emissive, oracle_emissive):
+    """IndirectLighting::Init(INTEGRATOR::ReSTIR_PT) driven by the C++ RenderGraph for 3 frames == oracle frame 3."""
+    from oracle import zro
+    w, h, n = 80, 48, 3
+    cbs = np.stack([scene_io.make_frame_constants(w, h, frame_num=f, num_emissives=len(cornell_emissive.emissives)) for f in range(1, n + 1)])
+    cbs = np.ascontiguousarray(cbs)
+    desc = cornell_emissive.desc()
+    out = np.zeros((h, w, 4), np.float32)
+    L = _lib()
+    L.zrh_render_sequence.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.c_void_p]
+    assert L.zrh_render_sequence(C.addressof(desc), cbs.ctypes.data, n, w, h, 2, out.ctypes.data) == 0
+    o = zro.OracleRPT(oracle_emissive, w, h)
+    prm = wire.default_params()
+    for f in range(n):
+        want = o.render(cbs[f], prm)
+    assert np.array_equal(out.view(np.uint32), want.view(np.uint32))

@@ -216,27 +216,57 @@ __global__ void __launch_bounds__(kBlock) k_rpt_pathtrace(rpt::RptFrame F, zr_fr
     FlushRayCounters(counters, cnt);
 }
 
-enum RptPixelPass { RPT_REPLAY_CTT = 0, RPT_REPLAY_TTC, RPT_RECONNECT_CTT, RPT_RECONNECT_TTC, RPT_SPATIAL_SEARCH, RPT_REPLAY_CTS,
-    RPT_REPLAY_STC, RPT_RECONNECT_CTS };
+enum RptPixelPass { RPT_REPLAY_CTT = 0, RPT_REPLAY_TTC, RPT_RECONNECT_TEMPORAL, RPT_SPATIAL_SEARCH, RPT_REPLAY_CTS, RPT_REPLAY_STC };
 
+// light per-pixel kernels (no traversal, no scratch)
 template<int PASS>
-__global__ void __launch_bounds__(kBlock) k_rpt_pixel(rpt::RptFrame F, zr_frame_constants g, uint32_t tilesX, unsigned long long* counters)
+__global__ void __launch_bounds__(kBlock) k_rpt_light(rpt::RptFrame F, zr_frame_constants g, uint32_t tilesX, uint32_t* listA, uint32_t* listB, uint32_t* counts)
+{
+    uint32_t x, y; PixelOfThread(tilesX, 0, 0, &x, &y);
+    const bool in = x < F.gb.w && y < F.gb.h;
+    bool a = false, b = false;
+    if (PASS == 0)          // temporal work lists: pixels whose current / temporal reservoir needs a replay (k > 2)
+    {
+        if (in) { a = rpt::NeedsReplayCtT(F, x, y); b = rpt::NeedsReplayTtC(F, g, x, y); }
+    }
+    else                    // K15 spatial search, then the spatial work lists
+    {
+        if (in) { rpt::SpatialSearchPixel(F, g, x, y); a = rpt::NeedsReplayCtS(F, x, y); b = rpt::NeedsReplayStC(F, x, y); }
+    }
+    const uint32_t pid = y * F.gb.w + x;
+    const uint32_t sa = AllocSlotWave(counts + 0, a);
+    if (a) listA[sa] = pid;
+    const uint32_t sb = AllocSlotWave(counts + 1, b);
+    if (b) listB[sb] = pid;
+}
+
+// K13 replays over a work list (device-side count, fixed grid, grid-stride): only pixels with k > 2 pay for the heavy kernel
+template<int PASS>
+__global__ void __launch_bounds__(kBlock) k_rpt_replay(rpt::RptFrame F, zr_frame_constants g, const uint32_t* list, const uint32_t* count,
+    unsigned long long* counters)
+{
+    uint32_t stack[kStack];
+    uint32_t cnt[2] = {0u, 0u};
+    const uint32_t n = *count;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
+    {
+        const uint32_t pid = list[i], x = pid % F.gb.w, y = pid / F.gb.w;
+        if (PASS == RPT_REPLAY_CTT) rpt::ReplayTemporalPixel(F, g, 0, x, y, stack, cnt);
+        else if (PASS == RPT_REPLAY_TTC) rpt::ReplayTemporalPixel(F, g, 1, x, y, stack, cnt);
+        else if (PASS == RPT_REPLAY_CTS) rpt::ReplaySpatialPixel(F, g, 0, x, y, stack, cnt);
+        else rpt::ReplaySpatialPixel(F, g, 1, x, y, stack, cnt);
+    }
+    if (n) FlushRayCounters(counters, cnt);
+}
+
+// K14: CtT + TtC fused per pixel (zr_rpt.h ReconnectTemporalPixel)
+__global__ void __launch_bounds__(kBlock) k_rpt_temporal(rpt::RptFrame F, zr_frame_constants g, uint32_t tilesX, unsigned long long* counters)
 {
     uint32_t x, y; PixelOfThread(tilesX, 0, 0, &x, &y);
     uint32_t stack[kStack];
     uint32_t cnt[2] = {0u, 0u};
-    if (x < F.gb.w && y < F.gb.h)
-    {
-        if (PASS == RPT_REPLAY_CTT) rpt::ReplayTemporalPixel(F, g, 0, x, y, stack, cnt);
-        else if (PASS == RPT_REPLAY_TTC) rpt::ReplayTemporalPixel(F, g, 1, x, y, stack, cnt);
-        else if (PASS == RPT_RECONNECT_CTT) rpt::ReconnectCtTPixel(F, g, x, y, stack, cnt);
-        else if (PASS == RPT_RECONNECT_TTC) rpt::ReconnectTtCPixel(F, g, x, y, stack, cnt);
-        else if (PASS == RPT_SPATIAL_SEARCH) rpt::SpatialSearchPixel(F, g, x, y);
-        else if (PASS == RPT_REPLAY_CTS) rpt::ReplaySpatialPixel(F, g, 0, x, y, stack, cnt);
-        else if (PASS == RPT_REPLAY_STC) rpt::ReplaySpatialPixel(F, g, 1, x, y, stack, cnt);
-        else if (PASS == RPT_RECONNECT_CTS) rpt::ReconnectCtSPixel(F, g, x, y, stack, cnt);
-    }
-    if (PASS != RPT_SPATIAL_SEARCH) FlushRayCounters(counters, cnt);
+    if (x < F.gb.w && y < F.gb.h) rpt::ReconnectTemporalPixel(F, g, x, y, stack, cnt);
+    FlushRayCounters(counters, cnt);
 }
 
 // canonical wave sum of the ABI: xor butterfly, strides 1..32 (zr_rpt.h ButterflySum64 is the host statement of it)
@@ -246,7 +276,7 @@ __device__ __forceinline__ float WaveSumButterfly(float v)
     return v;
 }
 
-// K16 StC: wave = 8x8 pixel group; every lane of the wave walks all four phases (absent lanes contribute 0)
+// K16 CtS + StC: wave = 8x8 pixel group; every lane of the wave walks all four phases (absent lanes contribute 0)
 __global__ void __launch_bounds__(kBlock) k_rpt_stc(rpt::RptFrame F, zr_frame_constants g, uint32_t tilesX, unsigned long long* counters)
 {
     uint32_t x, y; PixelOfThread(tilesX, 0, 0, &x, &y);
@@ -255,6 +285,7 @@ __global__ void __launch_bounds__(kBlock) k_rpt_stc(rpt::RptFrame F, zr_frame_co
     rpt::StcLane a;
     float v1, v2, v3, v4;
     rpt::StcPhase0(F, g, x, y, a, v1, v2);
+    if (a.valid && a.hasN) rpt::ReconnectCtSPixel(F, g, x, y, stack, cnt);       // K16 CtS of this pixel (see zr_rpt.h)
     const float sum1 = WaveSumButterfly(v1), sum2 = WaveSumButterfly(v2);
     rpt::StcPhase1(F, g, a, sum1, v3);
     const float sum3 = WaveSumButterfly(v3);
@@ -338,8 +369,8 @@ static constexpr int kMaxRounds = 16;
 static constexpr int kMaxTimers = 64;
 // ray-counter slots (pairs of u64 on the device): 0 = wavefront path tracer, 1.. = ReSTIR PT kernels in launch order
 static constexpr int kCounterSlots = 16;
-static const char* const kCounterNames[kCounterSlots] = {"trace", "rpt_pathtrace", "rpt_replay_ctt", "rpt_replay_ttc", "rpt_reconnect_ctt",
-    "rpt_reconnect_ttc", "rpt_spatial_search", "rpt_replay_cts", "rpt_replay_stc", "rpt_reconnect_cts", "rpt_reconnect_stc", "", "", "", "", ""};
+static const char* const kCounterNames[kCounterSlots] = {"trace", "rpt_pathtrace", "rpt_replay_ctt", "rpt_replay_ttc", "rpt_reconnect_temporal",
+    "rpt_replay_cts", "rpt_replay_stc", "rpt_reconnect_spatial", "", "", "", "", "", "", "", ""};
 
 struct zr_pass
 {
@@ -371,6 +402,7 @@ struct zr_pass
         rpt::RBuf View() const { rpt::RBuf v; v.A = A.p; v.B = B.p; v.C = C.p; v.D = D.p; return v; }
     } rb[2];
     DevBuf<F4> rptTarget; DevBuf<uint8_t> rptNeighbor; DevBuf<uint16_t> rptSampleSet;
+    DevBuf<uint32_t> rptLists, rptListCounts;      // 4 replay work lists (pixel ids) + their device-side counts
     bool temporalValid = false; int currIdx = 0;
     // PRELIGHTING
     DevBuf<float> power;
@@ -668,6 +700,8 @@ static int AllocPass(zr_pass* p)
             if ((r = p->rptNeighbor.Alloc(2 * cap))) return r;
             HIP_TRY(hipMemset(p->rptTarget.p, 0, cap * 16)); HIP_TRY(hipMemset(p->rptNeighbor.p, 0, cap * 2));
             if ((r = p->rptSampleSet.Upload(kRptSampleSet, 1024))) return r;
+            if ((r = p->rptLists.Alloc(4 * cap))) return r;
+            if ((r = p->rptListCounts.Alloc(4))) return r;
             p->temporalValid = false; p->currIdx = 0;
         }
     }
@@ -769,28 +803,32 @@ static int RenderReSTIR_PT(zr_pass* p, hipStream_t s, const zr_frame_constants* 
     F.cur = p->res[p->currIdx].View(); F.prev = p->res[1 - p->currIdx].View();
     const uint32_t tilesX = (p->w + 15) / 16, tilesY = (p->h + 15) / 16;
     const dim3 grid(tilesX * tilesY), block(kBlock);
-    int slot = 1;
-#define RPT_LAUNCH(name, kernel) do { TimerBegin(p, s, name); hipLaunchKernelGGL(kernel, grid, block, 0, s, F, *cb, tilesX, p->counters.p + 2 * slot); TimerEnd(p, s); slot++; } while (0)
-    RPT_LAUNCH("rpt_pathtrace", k_rpt_pathtrace);
+    // work lists for the replay passes: [0] CtT, [1] TtC, [2] CtS, [3] StC; counts live in p->counts[kMaxRounds + 2 ...]
+    uint32_t* listCnt = p->rptListCounts.p;
+    HIP_TRY(hipMemsetAsync(listCnt, 0, 4 * sizeof(uint32_t), s));
+    const size_t cap = (size_t)p->w * p->h;
+    uint32_t* lists[4] = {p->rptLists.p, p->rptLists.p + cap, p->rptLists.p + 2 * cap, p->rptLists.p + 3 * cap};
+    const dim3 gridList((uint32_t)std::min<size_t>((cap + kBlock - 1) / kBlock, 2048));
+    unsigned long long* ctr = p->counters.p;
+#define RPT_TIMED(name, launch) do { TimerBegin(p, s, name); launch; TimerEnd(p, s); } while (0)
+    RPT_TIMED("rpt_pathtrace", hipLaunchKernelGGL(k_rpt_pathtrace, grid, block, 0, s, F, *cb, tilesX, ctr + 2 * 1));
     if (prm.doTemporal)
     {
-        RPT_LAUNCH("rpt_replay_ctt", k_rpt_pixel<RPT_REPLAY_CTT>);
-        RPT_LAUNCH("rpt_replay_ttc", k_rpt_pixel<RPT_REPLAY_TTC>);
-        RPT_LAUNCH("rpt_reconnect_ctt", k_rpt_pixel<RPT_RECONNECT_CTT>);
-        RPT_LAUNCH("rpt_reconnect_ttc", k_rpt_pixel<RPT_RECONNECT_TTC>);
+        RPT_TIMED("rpt_classify_temporal", hipLaunchKernelGGL(k_rpt_light<0>, grid, block, 0, s, F, *cb, tilesX, lists[0], lists[1], listCnt + 0));
+        RPT_TIMED("rpt_replay_ctt", hipLaunchKernelGGL(k_rpt_replay<RPT_REPLAY_CTT>, gridList, block, 0, s, F, *cb, lists[0], listCnt + 0, ctr + 2 * 2));
+        RPT_TIMED("rpt_replay_ttc", hipLaunchKernelGGL(k_rpt_replay<RPT_REPLAY_TTC>, gridList, block, 0, s, F, *cb, lists[1], listCnt + 1, ctr + 2 * 3));
+        RPT_TIMED("rpt_reconnect_temporal", hipLaunchKernelGGL(k_rpt_temporal, grid, block, 0, s, F, *cb, tilesX, ctr + 2 * 4));
     }
     if (prm.doSpatial)
     {
-        slot = 6;
-        RPT_LAUNCH("rpt_spatial_search", k_rpt_pixel<RPT_SPATIAL_SEARCH>);
+        RPT_TIMED("rpt_spatial_search", hipLaunchKernelGGL(k_rpt_light<1>, grid, block, 0, s, F, *cb, tilesX, lists[2], lists[3], listCnt + 2));
         // spatial reads this frame's reservoirs and writes the other set, which becomes "current" (IndirectLighting.cpp:609-612, 682-685)
         p->currIdx = 1 - p->currIdx;
-        RPT_LAUNCH("rpt_replay_cts", k_rpt_pixel<RPT_REPLAY_CTS>);
-        RPT_LAUNCH("rpt_replay_stc", k_rpt_pixel<RPT_REPLAY_STC>);
-        RPT_LAUNCH("rpt_reconnect_cts", k_rpt_pixel<RPT_RECONNECT_CTS>);
-        RPT_LAUNCH("rpt_reconnect_stc", k_rpt_stc);
+        RPT_TIMED("rpt_replay_cts", hipLaunchKernelGGL(k_rpt_replay<RPT_REPLAY_CTS>, gridList, block, 0, s, F, *cb, lists[2], listCnt + 2, ctr + 2 * 5));
+        RPT_TIMED("rpt_replay_stc", hipLaunchKernelGGL(k_rpt_replay<RPT_REPLAY_STC>, gridList, block, 0, s, F, *cb, lists[3], listCnt + 3, ctr + 2 * 6));
+        RPT_TIMED("rpt_reconnect_spatial", hipLaunchKernelGGL(k_rpt_stc, grid, block, 0, s, F, *cb, tilesX, ctr + 2 * 7));
     }
-#undef RPT_LAUNCH
+#undef RPT_TIMED
     HIP_TRY(hipGetLastError());
     p->temporalValid = true;
     p->currIdx = 1 - p->currIdx;

@@ -1181,55 +1181,53 @@ ZR_HD void MoveXk(const SceneView& sc, Reconnection& rc, bool currToPrev, bool s
     }
 }
 
-// K14 Reconnect_CtT (ReSTIR_PT_Reconnect_CtT.hlsl:130-292)
-ZR_HD void ReconnectCtTPixel(const RptFrame& F, const zr_frame_constants& g, uint32_t x, uint32_t y, uint32_t* stack, uint32_t* cnt)
-{
-    const size_t px = (size_t)y * F.gb.w + x;
-    GFlags flags = DecodeFlags(F.gb.mr[px]);
-    if (flags.invalid || flags.emissive) return;
-    const Camera cam = CurrCamera(g);
-    PixelSurface ps = LoadPixelSurface(F.gb, cam, x, y, g.frame_num, px);
-    TemporalPixel tp = FindTemporal(F, g, x, y, ps, kMaxPlaneDistReuse, true);
-    if (!tp.ok) return;
-    const size_t pp = (size_t)tp.py * F.gb.w + tp.px;
-    Reservoir r_curr = Load_NonReconnection(F.cur, px);
-    Reservoir r_prev = Load_Metadata(F.prev, pp);
-    if (r_curr.w_sum != 0 && r_prev.M > 0 && !r_curr.rc.Empty())
-    {
-        r_curr.Load_Reconnection(F.cur, px);
-        if (r_curr.rc.IsCase1() || r_curr.rc.IsCase2()) MoveXk(F.sc, r_curr.rc, true, false);
-        Globals gl = MakeGlobals(F, g, flags.transmissive, stack, cnt);
-        OffsetPath shift = Shift2(gl, false, px, tp.prev.pos, tp.prev.normal, tp.prev.eta_next, tp.prev.surface, r_curr.rc, F.rbCtN);
-        float target_prev = Luminance(shift.target);
-        if (target_prev > 0)
-        {
-            float targetLum_curr = r_curr.W > 0 ? r_curr.w_sum / r_curr.W : 0;
-            float jacobian = r_curr.rc.partialJacobian > 0 ? shift.partialJacobian / r_curr.rc.partialJacobian : 0;
-            float m_curr = targetLum_curr / (targetLum_curr + (float)r_prev.M * target_prev * jacobian);
-            r_curr.w_sum *= m_curr;
-            F.cur.B[2 * px] = r_curr.w_sum;
-        }
-    }
-}
-
-// K14 Reconnect_TtC (ReSTIR_PT_Reconnect_TtC.hlsl:124-390)
-ZR_HD void ReconnectTtCPixel(const RptFrame& F, const zr_frame_constants& g, uint32_t x, uint32_t y, uint32_t* stack, uint32_t* cnt)
+// K14 Reconnect_CtT (ReSTIR_PT_Reconnect_CtT.hlsl:130-292) followed by Reconnect_TtC (ReSTIR_PT_Reconnect_TtC.hlsl:124-390)
+// for one pixel.  The reference runs them as two dispatches; both only read/write this pixel's current reservoir (CtT
+// writes w_sum, TtC reads it back) and read the previous frame's set, so running them back to back per pixel gives the
+// same result and shares the G-buffer reconstruction and the temporal-pixel search.
+ZR_HD void ReconnectTemporalPixel(const RptFrame& F, const zr_frame_constants& g, uint32_t x, uint32_t y, uint32_t* stack, uint32_t* cnt)
 {
     const size_t px = (size_t)y * F.gb.w + x;
     GFlags flags = DecodeFlags(F.gb.mr[px]);
     if (flags.invalid || flags.emissive) return;
     const bool doSpatial = F.prm.doSpatial;
-    Reservoir r_curr = Load_NonReconnection(F.cur, px);
-    r_curr.target = xyz(F.tex.target[px]);
     const Camera cam = CurrCamera(g);
     PixelSurface ps = LoadPixelSurface(F.gb, cam, x, y, g.frame_num, px);
-    TemporalPixel tp = FindTemporal(F, g, x, y, ps, kMaxPlaneDistReuse, false);
+    // CtT reads the previous G-buffer's coat plane at DTid (ReSTIR_PT_Reconnect_CtT.hlsl:80), TtC at prevPixel
+    TemporalPixel tp = FindTemporal(F, g, x, y, ps, kMaxPlaneDistReuse, true);
+    Globals gl = MakeGlobals(F, g, flags.transmissive, stack, cnt);
+    const size_t pp = (size_t)tp.py * F.gb.w + tp.px;
+
+    // ---- current -> temporal: MIS weight of the current sample
+    if (tp.ok)
+    {
+        Reservoir r_curr = Load_NonReconnection(F.cur, px);
+        Reservoir r_prev = Load_Metadata(F.prev, pp);
+        if (r_curr.w_sum != 0 && r_prev.M > 0 && !r_curr.rc.Empty())
+        {
+            r_curr.Load_Reconnection(F.cur, px);
+            if (r_curr.rc.IsCase1() || r_curr.rc.IsCase2()) MoveXk(F.sc, r_curr.rc, true, false);
+            OffsetPath shift = Shift2(gl, false, px, tp.prev.pos, tp.prev.normal, tp.prev.eta_next, tp.prev.surface, r_curr.rc, F.rbCtN);
+            float target_prev = Luminance(shift.target);
+            if (target_prev > 0)
+            {
+                float targetLum_curr = r_curr.W > 0 ? r_curr.w_sum / r_curr.W : 0;
+                float jacobian = r_curr.rc.partialJacobian > 0 ? shift.partialJacobian / r_curr.rc.partialJacobian : 0;
+                float m_curr = targetLum_curr / (targetLum_curr + (float)r_prev.M * target_prev * jacobian);
+                r_curr.w_sum *= m_curr;
+                F.cur.B[2 * px] = r_curr.w_sum;
+            }
+        }
+    }
+
+    // ---- temporal -> current: resample
+    Reservoir r_curr = Load_NonReconnection(F.cur, px);
+    r_curr.target = xyz(F.tex.target[px]);
     if (!tp.ok)
     {
         if (!doSpatial) WriteOutputColor(g, F.finalRGBA, px, r_curr.target * r_curr.W);
         return;
     }
-    const size_t pp = (size_t)tp.py * F.gb.w + tp.px;
     Reservoir r_prev = Load_NonReconnection(F.prev, pp);
     const uint32_t M_max = F.prm.M_max_temporal;
     const uint32_t M_new = (r_curr.M + r_prev.M) & 0xffffu;
@@ -1244,7 +1242,6 @@ ZR_HD void ReconnectTtCPixel(const RptFrame& F, const zr_frame_constants& g, uin
     }
     r_prev.Load_Reconnection(F.prev, pp);
     if (r_prev.rc.IsCase1() || r_prev.rc.IsCase2()) MoveXk(F.sc, r_prev.rc, false, true);
-    Globals gl = MakeGlobals(F, g, flags.transmissive, stack, cnt);
     OffsetPath shift = Shift2(gl, true, px, ps.pos, ps.normal, ps.eta_next, ps.surface, r_prev.rc, F.rbNtC);
     float targetLum_curr = Luminance(shift.target);
     float jacobian = r_prev.rc.partialJacobian > 0 ? shift.partialJacobian / r_prev.rc.partialJacobian : 0;
@@ -1269,6 +1266,30 @@ ZR_HD void ReconnectTtCPixel(const RptFrame& F, const zr_frame_constants& g, uin
     }
     else r_curr.WriteReservoirData(F.cur, px, M_max);
     if (!doSpatial) WriteOutputColor(g, F.finalRGBA, px, r_curr.target * r_curr.W);
+}
+
+// cheap predicates for the replay work lists (supersets of the pixels the replay passes act on; the passes re-check)
+ZR_HD bool NeedsReplayCtT(const RptFrame& F, uint32_t x, uint32_t y)
+{
+    const size_t px = (size_t)y * F.gb.w + x;
+    GFlags flags = DecodeFlags(F.gb.mr[px]);
+    if (flags.invalid || flags.emissive) return false;
+    const uint32_t k = F.cur.A[px] & 0xf;
+    return k != Reconnection::EMPTY && k > 0;           // stored k - 2 > 0
+}
+ZR_HD bool NeedsReplayTtC(const RptFrame& F, const zr_frame_constants& g, uint32_t x, uint32_t y)
+{
+    const size_t px = (size_t)y * F.gb.w + x;
+    GFlags flags = DecodeFlags(F.gb.mr[px]);
+    if (flags.invalid || flags.emissive) return false;
+    const V2 renderDim = v2((float)g.render_width, (float)g.render_height);
+    const V2 motionVec = DecodeMotion(F.gb.motion[px]);
+    const V2 prevUV = v2(((float)x + 0.5f) / renderDim.x, ((float)y + 0.5f) / renderDim.y) - motionVec;
+    if (prevUV.x < 0 || prevUV.y < 0 || prevUV.x > 1 || prevUV.y > 1) return false;
+    const int ppx = (int)(prevUV.x * renderDim.x), ppy = (int)(prevUV.y * renderDim.y);
+    if (ppx >= (int)F.gb.w || ppy >= (int)F.gb.h) return false;
+    const uint32_t k = F.prev.A[(size_t)ppy * F.gb.w + ppx] & 0xf;
+    return k != Reconnection::EMPTY && k > 0;
 }
 
 // Math::WorldPosFromScreenSpace, Math.hlsli:205-216
@@ -1378,7 +1399,28 @@ ZR_HD void ReplaySpatialPixel(const RptFrame& F, const zr_frame_constants& g, in
     }
 }
 
-// K16 Reconnect_CtS (ReSTIR_PT_Reconnect_CtS.hlsl:149-230)
+ZR_HD bool NeedsReplayCtS(const RptFrame& F, uint32_t x, uint32_t y)
+{
+    const size_t px = (size_t)y * F.gb.w + x;
+    GFlags flags = DecodeFlags(F.gb.mr[px]);
+    if (flags.invalid || flags.emissive) return false;
+    if (F.tex.neighbor[2 * px] == 255) return false;
+    const uint32_t k = F.cur.A[px] & 0xf;
+    return k != Reconnection::EMPTY && k > 0;
+}
+ZR_HD bool NeedsReplayStC(const RptFrame& F, uint32_t x, uint32_t y)
+{
+    const size_t px = (size_t)y * F.gb.w + x;
+    GFlags flags = DecodeFlags(F.gb.mr[px]);
+    if (flags.invalid || flags.emissive) return false;
+    int sx, sy;
+    if (!NeighborOf(F, x, y, sx, sy)) return false;
+    const uint32_t k = F.cur.A[(size_t)sy * F.gb.w + sx] & 0xf;
+    return k != Reconnection::EMPTY && k > 0;
+}
+
+// K16 Reconnect_CtS (ReSTIR_PT_Reconnect_CtS.hlsl:149-230).  Like CtT/TtC it only touches this pixel's entries (reads the
+// "in" set, writes w_sum of the "out" set that StC reads back), so the StC kernel runs it per lane before its phase 1.
 ZR_HD void ReconnectCtSPixel(const RptFrame& F, const zr_frame_constants& g, uint32_t x, uint32_t y, uint32_t* stack, uint32_t* cnt)
 {
     const size_t px = (size_t)y * F.gb.w + x;

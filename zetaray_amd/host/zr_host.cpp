@@ -299,35 +299,45 @@ int zrh_graph_selftest(char* out, int outLen)
 }
 
 // One frame through the C++ pass objects scheduled by the graph; copies FINAL (w*h*4 floats) to `finalOut`.
-int zrh_render_frame(const zr_scene_desc* desc, const zr_frame_constants* cb, uint32_t w, uint32_t h, float* finalOut)
+// Renders `n` consecutive frames (cbs[i] = cbFrameConstants of frame i) through the graph exactly as the reference's
+// frame loop does (PathTracer.cpp:474-552: register passes / resources, declare inputs / outputs, Build, submit, fence)
+// and copies the FINAL plane of the last frame.  integrator: 0 = PATH_TRACING, 2 = ReSTIR_PT.
+int zrh_render_sequence(const zr_scene_desc* desc, const zr_frame_constants* cbs, uint32_t n, uint32_t w, uint32_t h, int integrator, float* finalOut)
 {
     RenderPass::FrameContext ctx;
-    ctx.device = 0; ctx.renderWidth = w; ctx.renderHeight = h; ctx.frameConstants = *cb;
+    ctx.device = 0; ctx.renderWidth = w; ctx.renderHeight = h;
     ZR_CHECK(zr_scene_create(0, desc, &ctx.scene));
     ZR_CHECK(zr_gbuffer_create(0, w, h, &ctx.gbuffer));
     {
         RenderPass::GBufferRT gb; RenderPass::PreLighting pre; RenderPass::IndirectLighting ind;
-        gb.Init(&ctx); pre.Init(&ctx); ind.Init(&ctx, RenderPass::IndirectLighting::INTEGRATOR::PATH_TRACING);
+        gb.Init(&ctx); pre.Init(&ctx); ind.Init(&ctx, (RenderPass::IndirectLighting::INTEGRATOR)integrator);
         Core::RenderGraph g;
         enum : uint64_t { R_GBUF = 1, R_ALIAS, R_IND };
-        g.BeginFrame();
-        auto hGB = g.RegisterRenderPass("GBuffer", Core::RENDER_NODE_TYPE::COMPUTE, Core::MakeDelegate(&gb, &RenderPass::GBufferRT::Render));
-        auto hPre = g.RegisterRenderPass("PreLighting", Core::RENDER_NODE_TYPE::ASYNC_COMPUTE, Core::MakeDelegate(&pre, &RenderPass::PreLighting::Render));
-        auto hInd = g.RegisterRenderPass("Indirect", Core::RENDER_NODE_TYPE::COMPUTE, Core::MakeDelegate(&ind, &RenderPass::IndirectLighting::Render));
-        g.RegisterResource(nullptr, R_GBUF); g.RegisterResource(nullptr, R_ALIAS); g.RegisterResource(ind.GetOutput(RenderPass::IndirectLighting::SHADER_OUT_RES::FINAL), R_IND);
-        g.MoveToPostRegister();
-        g.AddOutput(hGB, R_GBUF, Core::STATE_UNORDERED_ACCESS);
-        g.AddOutput(hPre, R_ALIAS, Core::STATE_UNORDERED_ACCESS);
-        g.AddInput(hInd, R_GBUF, Core::STATE_SHADER_READ); g.AddInput(hInd, R_ALIAS, Core::STATE_SHADER_READ); g.AddOutput(hInd, R_IND, Core::STATE_UNORDERED_ACCESS);
-        Support::TaskSet ts;
-        g.Build(ts);
-        ts.Run(true);
-        g.WaitForFrame();
+        for (uint32_t f = 0; f < n; f++)
+        {
+            ctx.frameConstants = cbs[f];
+            g.BeginFrame();
+            auto hGB = g.RegisterRenderPass("GBuffer", Core::RENDER_NODE_TYPE::COMPUTE, Core::MakeDelegate(&gb, &RenderPass::GBufferRT::Render));
+            auto hPre = g.RegisterRenderPass("PreLighting", Core::RENDER_NODE_TYPE::ASYNC_COMPUTE, Core::MakeDelegate(&pre, &RenderPass::PreLighting::Render));
+            auto hInd = g.RegisterRenderPass("Indirect", Core::RENDER_NODE_TYPE::COMPUTE, Core::MakeDelegate(&ind, &RenderPass::IndirectLighting::Render));
+            g.RegisterResource(nullptr, R_GBUF); g.RegisterResource(nullptr, R_ALIAS); g.RegisterResource(ind.GetOutput(RenderPass::IndirectLighting::SHADER_OUT_RES::FINAL), R_IND);
+            g.MoveToPostRegister();
+            g.AddOutput(hGB, R_GBUF, Core::STATE_UNORDERED_ACCESS);
+            g.AddOutput(hPre, R_ALIAS, Core::STATE_UNORDERED_ACCESS);
+            g.AddInput(hInd, R_GBUF, Core::STATE_SHADER_READ); g.AddInput(hInd, R_ALIAS, Core::STATE_SHADER_READ); g.AddOutput(hInd, R_IND, Core::STATE_UNORDERED_ACCESS);
+            Support::TaskSet ts;
+            g.Build(ts);
+            ts.Run(true);
+            g.WaitForFrame();
+        }
         if (hipMemcpy(finalOut, ind.GetOutput(RenderPass::IndirectLighting::SHADER_OUT_RES::FINAL), (size_t)w * h * 16, hipMemcpyDeviceToHost) != hipSuccess) return -1;
     }
     zr_gbuffer_destroy(ctx.gbuffer);
     zr_scene_destroy(ctx.scene);
     return 0;
 }
+
+int zrh_render_frame(const zr_scene_desc* desc, const zr_frame_constants* cb, uint32_t w, uint32_t h, float* finalOut)
+{ return zrh_render_sequence(desc, cb, 1, w, h, 0, finalOut); }
 
 } // extern "C"
