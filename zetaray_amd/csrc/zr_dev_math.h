@@ -48,8 +48,8 @@ ZR_HD V4 normalize(V4 a) { float inv = 1.0f / zr_sqrt(dot(a, a)); return v4(a.x 
 ZR_HD V3 mad(float s, V3 a, V3 b) { return v3(zr_fma(s, a.x, b.x), zr_fma(s, a.y, b.y), zr_fma(s, a.z, b.z)); }
 ZR_HD V3 saturate(V3 a) { return v3(zr_saturate(a.x), zr_saturate(a.y), zr_saturate(a.z)); }
 ZR_HD V3 vmax(V3 a, float s) { return v3(zr_max(a.x, s), zr_max(a.y, s), zr_max(a.z, s)); }
-ZR_HD V3 vexp(V3 a) { return v3(zr_exp(a.x), zr_exp(a.y), zr_exp(a.z)); }
-ZR_HD V3 vlog(V3 a) { return v3(zr_log(a.x), zr_log(a.y), zr_log(a.z)); }
+ZR_HD_FLAT V3 vexp(V3 a) { return v3(zr_exp(a.x), zr_exp(a.y), zr_exp(a.z)); }
+ZR_HD_FLAT V3 vlog(V3 a) { return v3(zr_log(a.x), zr_log(a.y), zr_log(a.z)); }
 ZR_HD bool any_nan(V3 a) { return zr_isnan(a.x) || zr_isnan(a.y) || zr_isnan(a.z); }
 ZR_HD V3 reflect(V3 i, V3 n) { return i - 2.0f * dot(n, i) * n; }
 ZR_HD V3 refract(V3 i, V3 n, float eta)

@@ -936,7 +936,7 @@ ZR_HD void WriteOffsetCtx(const OffsetCtx& ctx, const RBuf& rb, size_t i, bool i
 }
 
 // Shift.hlsli:377-474
-ZR_HD void Replay(const Globals& g, bool currFrame, int numBounces, BsdfSample bs, OffsetCtx& ctx)
+ZR_HD_FLAT void Replay(const Globals& g, bool currFrame, int numBounces, BsdfSample bs, OffsetCtx& ctx)
 {
     const SceneView& sc = *g.sc;
     ctx.throughput = bs.bsdfOverPdf;
@@ -984,7 +984,7 @@ ZR_HD void Replay(const Globals& g, bool currFrame, int numBounces, BsdfSample b
 }
 
 // Shift.hlsli:818-859
-ZR_HD OffsetCtx Replay_kGt2(const Globals& g, bool currFrame, V3 pos, V3 normal, float ior, const Surface& surface, const Reconnection& rc)
+ZR_HD_FLAT OffsetCtx Replay_kGt2(const Globals& g, bool currFrame, V3 pos, V3 normal, float ior, const Surface& surface, const Reconnection& rc)
 {
     OffsetCtx ctx = InitOffsetCtx();
     ctx.pos = pos; ctx.normal = normal; ctx.surface = surface; ctx.rngReplay = Rng::Seed(rc.seed_replay);
@@ -997,7 +997,7 @@ ZR_HD OffsetCtx Replay_kGt2(const Globals& g, bool currFrame, V3 pos, V3 normal,
 }
 
 // Shift.hlsli:476-546
-ZR_HD float StepPath(const Globals& g, bool currFrame, OffsetCtx& ctx, const Reconnection& rc)
+ZR_HD_FLAT float StepPath(const Globals& g, bool currFrame, OffsetCtx& ctx, const Reconnection& rc)
 {
     const SceneView& sc = *g.sc;
     if (!IsLobeValid(ctx.surface, rc.lobe_k_min_1)) return 0;
@@ -1031,7 +1031,7 @@ ZR_HD float StepPath(const Globals& g, bool currFrame, OffsetCtx& ctx, const Rec
 struct OffsetPath { V3 target; float partialJacobian; bool surfKMin1Transmissive; };
 
 // Shift2<Emissive = true>, Shift.hlsli:662-816
-ZR_HD OffsetPath Shift2(const Globals& g, bool currFrame, size_t DTidIdx, V3 pos, V3 normal, float ior, const Surface& surface,
+ZR_HD_FLAT OffsetPath Shift2(const Globals& g, bool currFrame, size_t DTidIdx, V3 pos, V3 normal, float ior, const Surface& surface,
     const Reconnection& rc, const RBuf& rbuffer)
 {
     OffsetCtx ctx = InitOffsetCtx();
@@ -1126,7 +1126,7 @@ ZR_HD TemporalPixel FindTemporal(const RptFrame& F, const zr_frame_constants& g,
 }
 
 // K13 Replay_CtT / Replay_TtC (ReSTIR_PT_Replay.hlsl:289-534)
-ZR_HD void ReplayTemporalPixel(const RptFrame& F, const zr_frame_constants& g, int variant, uint32_t x, uint32_t y, uint32_t* stack, uint32_t* cnt)
+ZR_HD_FLAT void ReplayTemporalPixel(const RptFrame& F, const zr_frame_constants& g, int variant, uint32_t x, uint32_t y, uint32_t* stack, uint32_t* cnt)
 {
     const size_t px = (size_t)y * F.gb.w + x;
     GFlags flags = DecodeFlags(F.gb.mr[px]);
@@ -1363,7 +1363,7 @@ ZR_HD bool NeighborOf(const RptFrame& F, uint32_t x, uint32_t y, int& sx, int& s
 
 // In the spatial passes F.cur = the temporal pass's output ("in"), F.prev = the set written for the next frame ("out")
 // K13 Replay_CtS / Replay_StC
-ZR_HD void ReplaySpatialPixel(const RptFrame& F, const zr_frame_constants& g, int variant, uint32_t x, uint32_t y, uint32_t* stack, uint32_t* cnt)
+ZR_HD_FLAT void ReplaySpatialPixel(const RptFrame& F, const zr_frame_constants& g, int variant, uint32_t x, uint32_t y, uint32_t* stack, uint32_t* cnt)
 {
     const size_t px = (size_t)y * F.gb.w + x;
     GFlags flags = DecodeFlags(F.gb.mr[px]);
