@@ -45,22 +45,7 @@ RPT_PIXEL_BYTES = {
 }
 
 
-def tile_grid(n):
-    return {1: (1, 1), 2: (2, 1), 4: (2, 2), 8: (4, 2)}[n]
-
-
-def tile_rect(w, h, n, rank):
-    gx, gy = tile_grid(n)
-    tx, ty = rank % gx, rank // gx
-
-    def split(total, parts, i):
-        # 32-px aligned boundaries
-        edges = [min(total, ((total * k // parts) + 31) // 32 * 32) for k in range(parts + 1)]
-        edges[-1] = total
-        return edges[i], edges[i + 1] - edges[i]
-    x0, tw = split(w, gx, tx)
-    y0, th = split(h, gy, ty)
-    return x0, y0, tw, th
+from zetaray_amd.tiling import tile_grid, tile_rect  # noqa: E402  (shared with the tests and the tiled renderer)
 
 
 def cpu_baseline(scene_host, cb, max_rays=1_000_000):
@@ -102,6 +87,8 @@ def main():
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--scene", default=os.path.join(ROOT, "tests", "golden", "cornell_emissive.npz"))
+    ap.add_argument("--no-final-halo", action="store_true",
+                    help="skip the post-frame halo exchange (exact for a static camera, which this bench uses)")
     ap.add_argument("--integrator", choices=["restir_pt", "pt"], default="restir_pt",
                     help="restir_pt = K11-K16 (BASELINE metric); pt = K9 unidirectional path tracer")
     args = ap.parse_args()
@@ -126,17 +113,23 @@ def main():
     prm = wire.default_params()
     x0, y0, tw, th = tile_rect(W, H, world, rank)
     rpt = args.integrator == "restir_pt"
-    if rpt and world > 1:
-        # spatio-temporal reuse reads neighbouring pixels' reservoirs: sharding the frame needs the halo exchange of
-        # SURVEY.md section 8(e), which is not implemented yet -> every rank renders the whole frame (replicas), and the
-        # line says so.  Use --integrator pt for the tile-sharded path tracer.
-        x0, y0, tw, th = 0, 0, W, H
-    r = api.Renderer(sc, tw, th, device=local_rank, params=prm, tile_origin=(x0, y0),
-                     integrator=api.INTEGRATOR_RESTIR_PT if rpt else api.INTEGRATOR_PATH_TRACING)
+    tiled = None
+    if rpt:
+        # ReSTIR PT reads neighbouring pixels' reservoirs: each rank owns a 32-px-aligned tile, renders the G-buffer of the
+        # tile + a 32-px apron, and exchanges reservoir halos point-to-point over RCCL before the spatial stage and after
+        # the frame (zetaray_amd/tiling.py); N = 1 degenerates to the plain renderer
+        from zetaray_amd import tiling
+        tiled = tiling.TiledRestirPT(sc, W, H, world, rank, device=local_rank, params=prm, dist=dist)
+        r = tiled.r
+    else:
+        r = api.Renderer(sc, tw, th, device=local_rank, params=prm, tile_origin=(x0, y0), integrator=api.INTEGRATOR_PATH_TRACING)
 
     def frame(i):
         cb = scene_io.make_frame_constants(W, H, frame_num=i, num_emissives=len(sc.emissives))
-        r.render_frame(cb)
+        if tiled is not None:
+            tiled.render_frame(cb, exchange_final=not args.no_final_halo)
+        else:
+            r.render_frame(cb)
 
     def barrier():
         if dist is not None:
@@ -169,12 +162,11 @@ def main():
     n_closest, n_shadow = float(rays[0]), float(rays[1])
     ms_per_step = tmax / args.steps * 1e3
     mrays = (n_closest + n_shadow) / tmax / 1e6
-    replicas = rpt and world > 1
 
     out = {
         "metric": "Mrays/s", "value": round(mrays, 2), "unit": "Mrays/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
-        "scaling": "weak" if replicas else "strong",
+        "scaling": "strong",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": (f"Cornell Box (cornell_emissive: 58 triangles, 2 emissive) {W}x{H}, G-buffer + ReSTIR PT "
                                 f"(K1 + K11-K16: initial candidates, temporal + spatial reconnection reuse, boiling "
@@ -182,8 +174,9 @@ def main():
                                (f"Cornell Box (cornell_emissive: 58 triangles, 2 emissive) {W}x{H}, G-buffer + 1-spp "
                                 f"path tracer (K1+K9, NEE+MIS, 3 non-transmissive bounces, static camera)"),
                    "integrator": args.integrator,
-                   "parallelism": (f"{world} full-frame replicas (halo exchange for the screen-tile split not implemented)"
-                                   if replicas else f"screen tiles {tile_grid(world)}"),
+                   "parallelism": f"screen tiles {tile_grid(world)}" + (
+                       f", 32-px apron, RCCL p2p halo exchange of reservoir planes (62 B/px): {tiled.halo_bytes} B sent per "
+                       f"rank per exchange, {1 if args.no_final_halo else 2} exchanges per frame" if (rpt and world > 1) else ""),
                    "rays_per_frame": round((n_closest + n_shadow) / args.steps, 1),
                    "fps": round(1e3 / ms_per_step, 2)},
     }

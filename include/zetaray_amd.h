@@ -176,6 +176,27 @@ int zr_pass_set_params(zr_pass* pass, const zr_params* params);
 /* Render(CommandList&): enqueue only.  cb = the 544-byte cbFrameConstants of this frame (host pointer, copied). */
 int zr_pass_render(zr_pass* pass, void* hip_stream, const zr_frame_constants* cb, const zr_scene* scene,
                    zr_gbuffer* gbuffer);
+/* ---- multi-GPU screen-tile split of a pass with cross-pixel reuse ----
+   The G-buffer (and so every plane of the pass) covers this device's tile plus an apron; `owned` is the part this device
+   shades.  Apron G-buffer pixels are rendered locally (geometry is replicated); apron reservoirs arrive through
+   zr_pass_halo_unpack.  Frame order on every device:
+     GBUFFER render -> INDIRECT stage TEMPORAL -> exchange ZR_HALO_POST_TEMPORAL -> INDIRECT stage SPATIAL ->
+     exchange ZR_HALO_FINAL (only needed when reprojection can cross tiles, i.e. a moving camera).
+   Reference: the two stages are IndirectLighting::ReSTIR_PT_Temporal / ReSTIR_PT_Spatial (IndirectLighting.cpp:370-596, 598-875),
+   a renderer registers them as two graph nodes with the exchange between them. */
+#define ZR_STAGE_TEMPORAL 1
+#define ZR_STAGE_SPATIAL  2
+#define ZR_STAGE_ALL      3
+#define ZR_HALO_POST_TEMPORAL 0   /* valid between the two stages of a frame */
+#define ZR_HALO_FINAL         1   /* valid after the frame: the set the next frame reads as "previous" */
+#define ZR_HALO_BYTES_PER_PIXEL 62  /* planes A..G back to back: 4 + 8 + 16 + 16 + 2 + 8 + 8, each row-major over the rect */
+int zr_pass_set_owned_rect(zr_pass* pass, uint32_t x0, uint32_t y0, uint32_t width, uint32_t height);   /* global pixels; width 0 = whole tile */
+int zr_pass_render_stage(zr_pass* pass, void* hip_stream, const zr_frame_constants* cb, const zr_scene* scene,
+                         zr_gbuffer* gbuffer, int stages);
+int zr_pass_halo_pack(zr_pass* pass, void* hip_stream, const zr_gbuffer* gbuffer, int which, uint32_t x0, uint32_t y0,
+                      uint32_t width, uint32_t height, void* dev_dst, size_t bytes);
+int zr_pass_halo_unpack(zr_pass* pass, void* hip_stream, const zr_gbuffer* gbuffer, int which, uint32_t x0, uint32_t y0,
+                        uint32_t width, uint32_t height, const void* dev_src, size_t bytes);
 int zr_pass_get_output(const zr_pass* pass, int which, void** dev_ptr, uint32_t* width, uint32_t* height,
                        uint32_t* bytes_per_pixel);
 int zr_pass_download_output(const zr_pass* pass, int which, void* hip_stream, void* host_dst, size_t bytes);

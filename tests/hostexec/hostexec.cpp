@@ -178,7 +178,7 @@ void zhx_trace_any(const HxScene* s, const float* rays, uint32_t n, uint32_t mas
 // ---------------------------------------------------------------- ReSTIR PT (zr_rpt.h) in program order
 struct HxRpt
 {
-    uint32_t w = 0, h = 0; bool temporalValid = false; int currIdx = 0;
+    uint32_t w = 0, h = 0; bool temporalValid = false, doTemporal = false, doSpatial = false; int currIdx = 0;
     struct Planes { std::vector<uint32_t> A, G; std::vector<float> B, F; std::vector<U4> C, D; std::vector<uint16_t> E;
         void Resize(size_t n) { A.assign(n, 0); B.assign(2 * n, 0); C.assign(n, U4{0, 0, 0, 0}); D.assign(n, U4{0, 0, 0, 0}); E.assign(n, 0); F.assign(2 * n, 0); G.assign(2 * n, 0); }
         rpt::ResPlanes View() { rpt::ResPlanes p; p.A = A.data(); p.B = B.data(); p.C = C.data(); p.D = D.data(); p.E = E.data(); p.F = F.data(); p.G = G.data(); return p; } } res[2];
@@ -199,16 +199,25 @@ HxRpt* zhx_rpt_create(uint32_t w, uint32_t h)
 void zhx_rpt_destroy(HxRpt* r) { delete r; }
 void zhx_rpt_reset_temporal(HxRpt* r) { r->temporalValid = false; }
 
-void zhx_rpt_render(const HxScene* s, HxRpt* R, const zr_frame_constants* cb, const zr_gbuffer_planes* curr, const zr_gbuffer_planes* prev,
-    const zr_params* params, float* finalRGBA, zr_counters* counters)
+// owned rect (global pixel coordinates) for the screen-tile split; w == 0 -> the whole plane rect
+static uint32_t g_own[4] = {0, 0, 0, 0};
+void zhx_rpt_set_owned_rect(uint32_t x0, uint32_t y0, uint32_t w, uint32_t h) { g_own[0] = x0; g_own[1] = y0; g_own[2] = w; g_own[3] = h; }
+
+// stages: 1 = K11 + temporal passes, 2 = spatial passes + end-of-frame bookkeeping, 3 = whole frame.
+// The planes (`curr`, `prev`, reservoirs, finalRGBA) cover the extended tile whose origin zhx_set_tile_origin gave.
+void zhx_rpt_render_stage(const HxScene* s, HxRpt* R, const zr_frame_constants* cb, const zr_gbuffer_planes* curr, const zr_gbuffer_planes* prev,
+    const zr_params* params, float* finalRGBA, zr_counters* counters, int stages)
 {
     using namespace rpt;
     uint32_t cnt[2] = {0, 0}; uint64_t total[2] = {0, 0};
     auto flush = [&]() { total[0] += cnt[0]; total[1] += cnt[1]; cnt[0] = cnt[1] = 0; };
     const zr_frame_constants& g = *cb;
-    const uint32_t W = g.render_width, H = g.render_height;
     RptFrame F;
-    F.sc = s->view; F.gb = ViewOf(curr); F.gbPrev = prev ? ViewOf(prev) : F.gb;
+    F.sc = s->view; F.gb = ViewOf(curr); F.gb.x0 = g_tile_x0; F.gb.y0 = g_tile_y0;
+    F.gbPrev = prev ? ViewOf(prev) : F.gb; F.gbPrev.x0 = g_tile_x0; F.gbPrev.y0 = g_tile_y0;
+    F.ox0 = g_own[2] ? g_own[0] : F.gb.x0; F.oy0 = g_own[2] ? g_own[1] : F.gb.y0;
+    F.ow = g_own[2] ? g_own[2] : F.gb.w; F.oh = g_own[2] ? g_own[3] : F.gb.h;
+    const uint32_t X0 = F.ox0, Y0 = F.oy0, X1 = F.ox0 + F.ow, Y1 = F.oy0 + F.oh;
     F.rbCtN = R->rb[0].View(); F.rbNtC = R->rb[1].View(); F.tex.target = R->target.data(); F.tex.neighbor = R->neighbor.data();
     F.finalRGBA = finalRGBA; F.sampleSet = kRptSampleSet;
     RptParams& prm = F.prm;
@@ -218,42 +227,53 @@ void zhx_rpt_render(const HxScene* s, HxRpt* R, const zr_frame_constants* cb, co
     prm.accumulate = (g.accumulate && g.camera_static) ? 1u : 0u;
     prm.boiling = (params->flags & ZR_IND_BOILING_SUPPRESSION) ? 1u : 0u;
     prm.M_max_temporal = params->m_max_temporal & 0xf; prm.M_max_spatial = params->m_max_spatial & 0xf; prm.alpha_min = params->alpha_min;
-    prm.doTemporal = ((params->flags & ZR_IND_TEMPORAL_RESAMPLE) && R->temporalValid && prev) ? 1u : 0u;
-    prm.doSpatial = ((params->flags & ZR_IND_SPATIAL_RESAMPLE) && prm.doTemporal) ? 1u : 0u;
+    if (stages & 1)
+    {
+        R->doTemporal = (params->flags & ZR_IND_TEMPORAL_RESAMPLE) && R->temporalValid && prev;
+        R->doSpatial = (params->flags & ZR_IND_SPATIAL_RESAMPLE) && R->doTemporal;
+    }
+    prm.doTemporal = R->doTemporal ? 1u : 0u;
+    prm.doSpatial = R->doSpatial ? 1u : 0u;
     prm.writeReservoirs = (prm.doTemporal || !R->temporalValid) ? 1u : 0u;
     F.cur = R->res[R->currIdx].View(); F.prev = R->res[1 - R->currIdx].View();
     uint32_t stack[64];
 
-    // K11: waves = 16x4 pixel blocks
-    std::vector<PTLane> lanes(64);
-    for (uint32_t by = 0; by < (H + 3) / 4; by++) for (uint32_t bx = 0; bx < (W + 15) / 16; bx++)
+    if (stages & 1)
     {
-        for (uint32_t l = 0; l < 64; l++) PtInitLane(F.sc, g, F.gb, prm, bx * 16 + (l & 15), by * 4 + (l >> 4), finalRGBA, stack, cnt, lanes[l]);
-        for (;;)
+        // K11: waves = 16x4 pixel blocks of the global grid
+        std::vector<PTLane> lanes(64);
+        for (uint32_t by = Y0 / 4; by < (Y1 + 3) / 4; by++) for (uint32_t bx = X0 / 16; bx < (X1 + 15) / 16; bx++)
         {
-            bool any = false;
-            for (uint32_t l = 0; l < 64; l++) { if (lanes[l].active) any = true; PtPhaseA(F.sc, g, prm, stack, cnt, lanes[l]); }
-            if (!any) break;
-            uint32_t bits = 0;
-            for (uint32_t l = 0; l < 64; l++) { uint32_t b = PtRRKey(lanes[l]); bits = b > bits ? b : bits; }
-            for (uint32_t l = 0; l < 64; l++) PtPhaseB(prm, lanes[l], bits);
+            for (uint32_t l = 0; l < 64; l++)
+            {
+                const uint32_t x = bx * 16 + (l & 15), y = by * 4 + (l >> 4);
+                PtInitLane(F.sc, g, F.gb, prm, F.Owns(x, y), x, y, finalRGBA, stack, cnt, lanes[l]);
+            }
+            for (;;)
+            {
+                bool any = false;
+                for (uint32_t l = 0; l < 64; l++) { if (lanes[l].active) any = true; PtPhaseA(F.sc, g, prm, stack, cnt, lanes[l]); }
+                if (!any) break;
+                uint32_t bits = 0;
+                for (uint32_t l = 0; l < 64; l++) { uint32_t b = PtRRKey(lanes[l]); bits = b > bits ? b : bits; }
+                for (uint32_t l = 0; l < 64; l++) PtPhaseB(prm, lanes[l], bits);
+            }
+            for (uint32_t l = 0; l < 64; l++) PtFinishLane(F.gb, prm, F.cur, F.tex, finalRGBA, lanes[l]);
+            flush();
         }
-        for (uint32_t l = 0; l < 64; l++) PtFinishLane(F.gb, prm, F.cur, F.tex, finalRGBA, lanes[l]);
-        flush();
+        if (prm.doTemporal)
+        {
+            for (int v = 0; v < 2; v++) for (uint32_t y = Y0; y < Y1; y++) for (uint32_t x = X0; x < X1; x++) { ReplayTemporalPixel(F, g, v, x, y, stack, cnt); flush(); }
+            for (uint32_t y = Y0; y < Y1; y++) for (uint32_t x = X0; x < X1; x++) { ReconnectTemporalPixel(F, g, x, y, stack, cnt); flush(); }
+        }
     }
-    if (prm.doTemporal)
+    if ((stages & 2) && prm.doSpatial)
     {
-        for (int v = 0; v < 2; v++) for (uint32_t y = 0; y < H; y++) for (uint32_t x = 0; x < W; x++) { ReplayTemporalPixel(F, g, v, x, y, stack, cnt); flush(); }
-        for (uint32_t y = 0; y < H; y++) for (uint32_t x = 0; x < W; x++) { ReconnectTemporalPixel(F, g, x, y, stack, cnt); flush(); }
-    }
-    if (prm.doSpatial)
-    {
-        for (uint32_t y = 0; y < H; y++) for (uint32_t x = 0; x < W; x++) SpatialSearchPixel(F, g, x, y);
-        R->currIdx = 1 - R->currIdx;          // IndirectLighting.cpp:609-612, 682-685
-        for (int v = 0; v < 2; v++) for (uint32_t y = 0; y < H; y++) for (uint32_t x = 0; x < W; x++) { ReplaySpatialPixel(F, g, v, x, y, stack, cnt); flush(); }
+        for (uint32_t y = Y0; y < Y1; y++) for (uint32_t x = X0; x < X1; x++) SpatialSearchPixel(F, g, x, y);
+        for (int v = 0; v < 2; v++) for (uint32_t y = Y0; y < Y1; y++) for (uint32_t x = X0; x < X1; x++) { ReplaySpatialPixel(F, g, v, x, y, stack, cnt); flush(); }
         std::vector<StcLane> L(64);
         float v1[64], v2[64], v3[64], v4[64];
-        for (uint32_t gy = 0; gy < (H + 7) / 8; gy++) for (uint32_t gx = 0; gx < (W + 7) / 8; gx++)
+        for (uint32_t gy = Y0 / 8; gy < (Y1 + 7) / 8; gy++) for (uint32_t gx = X0 / 8; gx < (X1 + 7) / 8; gx++)
         {
             for (uint32_t l = 0; l < 64; l++)
             {
@@ -270,9 +290,17 @@ void zhx_rpt_render(const HxScene* s, HxRpt* R, const zr_frame_constants* cb, co
     }
     flush();
     if (counters) { counters->n_closest = total[0]; counters->n_shadow = total[1]; }
-    R->temporalValid = true;
-    R->currIdx = 1 - R->currIdx;
+    if (stages & 2)
+    {
+        // spatial wrote the other set, which becomes "current" (IndirectLighting.cpp:609-612, 682-685); Render() flips again
+        if (prm.doSpatial) R->currIdx = 1 - R->currIdx;
+        R->temporalValid = true;
+        R->currIdx = 1 - R->currIdx;
+    }
 }
+void zhx_rpt_render(const HxScene* s, HxRpt* R, const zr_frame_constants* cb, const zr_gbuffer_planes* curr, const zr_gbuffer_planes* prev,
+    const zr_params* params, float* finalRGBA, zr_counters* counters)
+{ zhx_rpt_render_stage(s, R, cb, curr, prev, params, finalRGBA, counters, 3); }
 
 // which: 0 = the set the next frame reads as "previous", 1 = the other.  plane: 0..6 = A..G, 7 = target, 8 = neighbor
 int zhx_rpt_read_plane(const HxRpt* R, int which, int plane, void* out)
@@ -303,6 +331,27 @@ int zhx_rpt_read_plane(const HxRpt* R, int which, int plane, void* out)
         }
     }
     return 1;
+}
+
+// overwrite the rows [y0, y0 + h) x columns [x0, x0 + w) (plane-local coordinates) of a reservoir plane from a full-size host array
+int zhx_rpt_write_plane_rect(HxRpt* R, int which, int plane, const void* src, uint32_t x0, uint32_t y0, uint32_t w, uint32_t h)
+{
+    HxRpt::Planes& p = R->res[which == 0 ? 1 - R->currIdx : R->currIdx];
+    void* base; size_t bpp;
+    switch (plane)
+    {
+    case 0: base = p.A.data(); bpp = 4; break;
+    case 1: base = p.B.data(); bpp = 8; break;
+    case 2: base = p.C.data(); bpp = 16; break;
+    case 3: base = p.D.data(); bpp = 16; break;
+    case 4: base = p.E.data(); bpp = 2; break;
+    case 5: base = p.F.data(); bpp = 8; break;
+    case 6: base = p.G.data(); bpp = 8; break;
+    default: return 1;
+    }
+    for (uint32_t y = y0; y < y0 + h; y++)
+        std::memcpy((char*)base + ((size_t)y * R->w + x0) * bpp, (const char*)src + ((size_t)y * R->w + x0) * bpp, (size_t)w * bpp);
+    return 0;
 }
 
 } // extern "C"

@@ -30,6 +30,9 @@ def lib():
         L.zhx_rpt_destroy.argtypes = [C.c_void_p]
         L.zhx_rpt_reset_temporal.argtypes = [C.c_void_p]
         L.zhx_rpt_render.argtypes = [C.c_void_p] * 8
+        L.zhx_rpt_render_stage.argtypes = [C.c_void_p] * 8 + [C.c_int]
+        L.zhx_rpt_set_owned_rect.argtypes = [C.c_uint32] * 4
+        L.zhx_rpt_write_plane_rect.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p] + [C.c_uint32] * 4
         L.zhx_rpt_read_plane.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
         _LIB = L
     return _LIB
@@ -109,8 +112,10 @@ class HostExecRPT:
               "ctn_A": (10, np.uint16, 4), "ctn_B": (11, np.uint32, 4), "ctn_C": (12, np.uint32, 4), "ctn_D": (13, np.uint16, 1),
               "ntc_A": (14, np.uint16, 4), "ntc_B": (15, np.uint32, 4), "ntc_C": (16, np.uint32, 4), "ntc_D": (17, np.uint16, 1)}
 
-    def __init__(self, hxscene, w, h):
+    def __init__(self, hxscene, w, h, ext=None, owned=None):
+        """w, h = plane size (the extended tile's size when ext is given)"""
         self.hx, self.w, self.h = hxscene, w, h
+        self.ext, self.owned = ext, owned
         self.r = lib().zhx_rpt_create(w, h)
         self.prev = None
         self.final = np.zeros((h, w, 4), np.float32)
@@ -124,17 +129,41 @@ class HostExecRPT:
         lib().zhx_rpt_reset_temporal(self.r)
 
     def render(self, cb, params, gb=None):
-        if gb is None:
-            gb = self.hx.gbuffer(cb)
+        return self.render_stage(cb, params, 3, gb)
+
+    def render_stage(self, cb, params, stages, gb=None):
+        """stages: 1 = K11 + temporal, 2 = spatial + end of frame, 3 = both.  With ext=(x0, y0, w, h) the planes cover that
+        extended tile and `owned` is the rect this instance shades (multi-device split)."""
+        from zetaray_amd import wire
+        if stages & 1:
+            if gb is None:
+                gb = self.hx.gbuffer(cb, tile=self.ext)
+            self._gb = gb
+        gb = self._gb
         cbb = np.ascontiguousarray(cb)
         prev = C.addressof(self.prev[1]) if self.prev is not None else None
-        from zetaray_amd import wire
         cnt = wire.Counters()
-        lib().zhx_rpt_render(self.hx.h, self.r, cbb.ctypes.data, C.addressof(gb[1]), prev, C.addressof(params), self.final.ctypes.data,
-                             C.addressof(cnt))
-        self.counters = (cnt.n_closest, cnt.n_shadow)
-        self.prev = gb
+        L = lib()
+        if self.ext is not None:
+            L.zhx_set_tile_origin(self.ext[0], self.ext[1])
+            L.zhx_rpt_set_owned_rect(*self.owned)
+        try:
+            L.zhx_rpt_render_stage(self.hx.h, self.r, cbb.ctypes.data, C.addressof(gb[1]), prev, C.addressof(params),
+                                   self.final.ctypes.data, C.addressof(cnt), stages)
+        finally:
+            L.zhx_set_tile_origin(0, 0)
+            L.zhx_rpt_set_owned_rect(0, 0, 0, 0)
+        c = getattr(self, "counters", (0, 0)) if not (stages & 1) else (0, 0)
+        self.counters = (c[0] + cnt.n_closest, c[1] + cnt.n_shadow)
+        if stages & 2:
+            self.prev = gb
         return self.final
+
+    def write_plane_rect(self, name, which, full, rect_local):
+        """copy rect_local = (x0, y0, w, h) (plane-local coordinates) of the full-size array `full` into the plane"""
+        idx, dt, ch = self.PLANES[name]
+        full = np.ascontiguousarray(full, dt)
+        lib().zhx_rpt_write_plane_rect(self.r, which, idx, full.ctypes.data, *rect_local)
 
     def plane(self, name, which=0):
         idx, dt, ch = self.PLANES[name]

@@ -224,3 +224,33 @@ def test_restir_pt_full_resolution_properties(api, cornell_emissive):
         l = lum(a)
         return np.abs(l[:, 1:] - l[:, :-1]).mean()
     assert hf(imgs[0]) < 0.8 * hf(base)
+
+
+def test_restir_pt_tile_split_with_halo_exchange_on_gpu(api, cornell_emissive, oracle_emissive):
+    """4 tiles (2x2) of one frame sequence on one device: each tile object renders its tile + apron, halos move through
+    zr_pass_halo_pack / unpack (the buffers RCCL would carry); stitched radiance == the full-frame oracle, moving camera."""
+    from oracle import zro
+    from zetaray_amd import tiling
+    w, h, world = 192, 128, 4
+    prm = wire.default_params()
+    ranks = [tiling.TiledRestirPT(cornell_emissive, w, h, world, r, params=prm) for r in range(world)]
+    o = zro.OracleRPT(oracle_emissive, w, h)
+    prev = None
+    for f in range(1, 5):
+        cb = _frame(cornell_emissive, w, h, f, cam_pos=(0.05 * f, 1.2, -4.043 + 0.02 * f))
+        if prev is not None:
+            cb["prev_view"], cb["prev_view_inv"], cb["prev_camera_jitter"] = prev["curr_view"], prev["curr_view_inv"], prev["curr_camera_jitter"]
+        prev = cb.copy()
+        for r in ranks:
+            r.stage_temporal(cb)
+        tiling.exchange_in_process(ranks, api.HALO_POST_TEMPORAL)
+        for r in ranks:
+            r.stage_spatial(cb)
+        tiling.exchange_in_process(ranks, api.HALO_FINAL)
+        want = o.render(cb, prm)
+        img = np.zeros_like(want)
+        for r in ranks:
+            (x0, y0, tw, th), t = r.final_tile()
+            img[y0:y0 + th, x0:x0 + tw] = t
+        mism = int((img.view(np.uint32) != want.view(np.uint32)).any(axis=2).sum())
+        assert mism == 0, f"frame {f}: {mism} pixels differ"

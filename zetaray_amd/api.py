@@ -33,7 +33,11 @@ EXPORTS = [
     "zr_pass_set_params", "zr_pass_render", "zr_pass_get_output", "zr_pass_download_output",
     "zr_pass_read_counters", "zr_pass_read_kernel_counters", "zr_pass_enable_timing", "zr_pass_get_timings", "zr_pass_destroy",
     "zr_trace_closest", "zr_trace_any",
+    "zr_pass_set_owned_rect", "zr_pass_render_stage", "zr_pass_halo_pack", "zr_pass_halo_unpack",
 ]
+STAGE_TEMPORAL, STAGE_SPATIAL, STAGE_ALL = 1, 2, 3
+HALO_POST_TEMPORAL, HALO_FINAL = 0, 1
+HALO_BYTES_PER_PIXEL = 62
 
 
 class ZetaRayError(RuntimeError):
@@ -85,6 +89,10 @@ def lib():
         L.zr_pass_download_output.argtypes = [vp, i32, vp, vp, C.c_size_t]
         L.zr_pass_read_counters.argtypes = [vp, vp, vp, i32]
         L.zr_pass_read_kernel_counters.argtypes = [vp, vp, u32, vp, vp, vp, vp]
+        L.zr_pass_set_owned_rect.argtypes = [vp, u32, u32, u32, u32]
+        L.zr_pass_render_stage.argtypes = [vp, vp, vp, vp, vp, i32]
+        L.zr_pass_halo_pack.argtypes = [vp, vp, vp, i32, u32, u32, u32, u32, vp, C.c_size_t]
+        L.zr_pass_halo_unpack.argtypes = [vp, vp, vp, i32, u32, u32, u32, u32, vp, C.c_size_t]
         L.zr_pass_enable_timing.argtypes = [vp, i32]
         L.zr_pass_get_timings.argtypes = [vp, u32, vp, vp, vp, vp]
         L.zr_pass_destroy.argtypes = [vp]
@@ -197,6 +205,19 @@ class Pass:
     def render(self, cb, scene, gbuffer=None, stream=None):
         cbb = np.ascontiguousarray(cb)
         _check(lib().zr_pass_render(self.h, stream, cbb.ctypes.data, scene.h, gbuffer.h if gbuffer is not None else None))
+
+    def render_stage(self, cb, scene, gbuffer, stages, stream=None):
+        cbb = np.ascontiguousarray(cb)
+        _check(lib().zr_pass_render_stage(self.h, stream, cbb.ctypes.data, scene.h, gbuffer.h if gbuffer is not None else None, stages))
+
+    def set_owned_rect(self, x0, y0, w, h):
+        _check(lib().zr_pass_set_owned_rect(self.h, x0, y0, w, h))
+
+    def halo_pack(self, gbuffer, which, rect, dev_ptr, nbytes, stream=None):
+        _check(lib().zr_pass_halo_pack(self.h, stream, gbuffer.h, which, rect[0], rect[1], rect[2], rect[3], dev_ptr, nbytes))
+
+    def halo_unpack(self, gbuffer, which, rect, dev_ptr, nbytes, stream=None):
+        _check(lib().zr_pass_halo_unpack(self.h, stream, gbuffer.h, which, rect[0], rect[1], rect[2], rect[3], dev_ptr, nbytes))
 
     def output_ptr(self, which=OUT_FINAL):
         dev = C.c_void_p()

@@ -195,11 +195,11 @@ __global__ void __launch_bounds__(kBlock) k_rpt_pathtrace(rpt::RptFrame F, zr_fr
 {
     const uint32_t tile = blockIdx.x, tx = tile % tilesX, ty = tile / tilesX;
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
-    const uint32_t x = tx * 16u + (lane & 15u), y = ty * 16u + wave * 4u + (lane >> 4);
+    const uint32_t x = F.ox0 + tx * 16u + (lane & 15u), y = F.oy0 + ty * 16u + wave * 4u + (lane >> 4);
     uint32_t stack[kStack];
     uint32_t cnt[2] = {0u, 0u};
     rpt::PTLane P;
-    rpt::PtInitLane(F.sc, g, F.gb, F.prm, x, y, F.finalRGBA, stack, cnt, P);
+    rpt::PtInitLane(F.sc, g, F.gb, F.prm, F.Owns(x, y), x, y, F.finalRGBA, stack, cnt, P);
     for (;;)
     {
         const bool any = __ballot(P.active) != 0;
@@ -222,8 +222,8 @@ enum RptPixelPass { RPT_REPLAY_CTT = 0, RPT_REPLAY_TTC, RPT_RECONNECT_TEMPORAL, 
 template<int PASS>
 __global__ void __launch_bounds__(kBlock) k_rpt_light(rpt::RptFrame F, zr_frame_constants g, uint32_t tilesX, uint32_t* listA, uint32_t* listB, uint32_t* counts)
 {
-    uint32_t x, y; PixelOfThread(tilesX, 0, 0, &x, &y);
-    const bool in = x < F.gb.w && y < F.gb.h;
+    uint32_t x, y; PixelOfThread(tilesX, F.ox0, F.oy0, &x, &y);
+    const bool in = F.Owns(x, y);
     bool a = false, b = false;
     if (PASS == 0)          // temporal work lists: pixels whose current / temporal reservoir needs a replay (k > 2)
     {
@@ -233,7 +233,7 @@ __global__ void __launch_bounds__(kBlock) k_rpt_light(rpt::RptFrame F, zr_frame_
     {
         if (in) { rpt::SpatialSearchPixel(F, g, x, y); a = rpt::NeedsReplayCtS(F, x, y); b = rpt::NeedsReplayStC(F, x, y); }
     }
-    const uint32_t pid = y * F.gb.w + x;
+    const uint32_t pid = in ? (uint32_t)rpt::Pix(F.gb, x, y) : 0u;
     const uint32_t sa = AllocSlotWave(counts + 0, a);
     if (a) listA[sa] = pid;
     const uint32_t sb = AllocSlotWave(counts + 1, b);
@@ -250,7 +250,7 @@ __global__ void __launch_bounds__(kBlock) k_rpt_replay(rpt::RptFrame F, zr_frame
     const uint32_t n = *count;
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
     {
-        const uint32_t pid = list[i], x = pid % F.gb.w, y = pid / F.gb.w;
+        const uint32_t pid = list[i], x = F.gb.x0 + pid % F.gb.w, y = F.gb.y0 + pid / F.gb.w;
         if (PASS == RPT_REPLAY_CTT) rpt::ReplayTemporalPixel(F, g, 0, x, y, stack, cnt);
         else if (PASS == RPT_REPLAY_TTC) rpt::ReplayTemporalPixel(F, g, 1, x, y, stack, cnt);
         else if (PASS == RPT_REPLAY_CTS) rpt::ReplaySpatialPixel(F, g, 0, x, y, stack, cnt);
@@ -262,10 +262,10 @@ __global__ void __launch_bounds__(kBlock) k_rpt_replay(rpt::RptFrame F, zr_frame
 // K14: CtT + TtC fused per pixel (zr_rpt.h ReconnectTemporalPixel)
 __global__ void __launch_bounds__(kBlock) k_rpt_temporal(rpt::RptFrame F, zr_frame_constants g, uint32_t tilesX, unsigned long long* counters)
 {
-    uint32_t x, y; PixelOfThread(tilesX, 0, 0, &x, &y);
+    uint32_t x, y; PixelOfThread(tilesX, F.ox0, F.oy0, &x, &y);
     uint32_t stack[kStack];
     uint32_t cnt[2] = {0u, 0u};
-    if (x < F.gb.w && y < F.gb.h) rpt::ReconnectTemporalPixel(F, g, x, y, stack, cnt);
+    if (F.Owns(x, y)) rpt::ReconnectTemporalPixel(F, g, x, y, stack, cnt);
     FlushRayCounters(counters, cnt);
 }
 
@@ -279,7 +279,7 @@ __device__ __forceinline__ float WaveSumButterfly(float v)
 // K16 CtS + StC: wave = 8x8 pixel group; every lane of the wave walks all four phases (absent lanes contribute 0)
 __global__ void __launch_bounds__(kBlock) k_rpt_stc(rpt::RptFrame F, zr_frame_constants g, uint32_t tilesX, unsigned long long* counters)
 {
-    uint32_t x, y; PixelOfThread(tilesX, 0, 0, &x, &y);
+    uint32_t x, y; PixelOfThread(tilesX, F.ox0, F.oy0, &x, &y);
     uint32_t stack[kStack];
     uint32_t cnt[2] = {0u, 0u};
     rpt::StcLane a;
@@ -403,7 +403,8 @@ struct zr_pass
     } rb[2];
     DevBuf<F4> rptTarget; DevBuf<uint8_t> rptNeighbor; DevBuf<uint16_t> rptSampleSet;
     DevBuf<uint32_t> rptLists, rptListCounts;      // 4 replay work lists (pixel ids) + their device-side counts
-    bool temporalValid = false; int currIdx = 0;
+    bool temporalValid = false, doTemporal = false, doSpatial = false; int currIdx = 0;
+    uint32_t own[4] = {0, 0, 0, 0};                // owned rect (global pixels); w == 0 -> the whole G-buffer rect
     // PRELIGHTING
     DevBuf<float> power;
     // timing
@@ -778,14 +779,29 @@ static int RenderPreLighting(zr_pass* p, hipStream_t s, zr_scene* sc)
     return zr_scene_set_alias_table(sc, table.data(), n);
 }
 
-// IndirectLighting::RenderReSTIR_PT (IndirectLighting.cpp:877-1004) + the Render() tail (:1006-1025)
-static int RenderReSTIR_PT(zr_pass* p, hipStream_t s, const zr_frame_constants* cb, const zr_scene* sc, zr_gbuffer* gb)
+// IndirectLighting::RenderReSTIR_PT (IndirectLighting.cpp:877-1004) + the Render() tail (:1006-1025).
+// stages: ZR_STAGE_TEMPORAL = K11 + temporal passes, ZR_STAGE_SPATIAL = spatial passes + end-of-frame bookkeeping; a
+// multi-GPU host exchanges reservoir halos between the two (and after the second).
+static int RenderReSTIR_PT(zr_pass* p, hipStream_t s, const zr_frame_constants* cb, const zr_scene* sc, zr_gbuffer* gb, int stages)
 {
     using namespace rpt;
-    if (gb->x0 || gb->y0 || gb->w != cb->render_width || gb->h != cb->render_height)
-        return Fail(ZR_ERR_UNSUPPORTED, "RESTIR_PT needs the whole frame on one device (screen-tile split needs the halo exchange, not implemented yet)");
     RptFrame F;
     F.sc = sc->view; F.gb = gb->View(); F.gbPrev = gb->PrevView();
+    F.ox0 = p->own[2] ? p->own[0] : gb->x0; F.oy0 = p->own[2] ? p->own[1] : gb->y0;
+    F.ow = p->own[2] ? p->own[2] : gb->w; F.oh = p->own[2] ? p->own[3] : gb->h;
+    if (F.ox0 < gb->x0 || F.oy0 < gb->y0 || F.ox0 + F.ow > gb->x0 + gb->w || F.oy0 + F.oh > gb->y0 + gb->h)
+        return Fail(ZR_ERR_INVALID_ARG, "owned rect lies outside the G-buffer tile");
+    if ((F.ox0 & 31u) || (F.oy0 & 31u)) return Fail(ZR_ERR_INVALID_ARG, "owned rect origin must be 32-pixel aligned");
+    const bool wholeFrame = F.ox0 == 0 && F.oy0 == 0 && F.ow == cb->render_width && F.oh == cb->render_height;
+    if (!wholeFrame)
+    {
+        // neighbours within the spatial search radius must be readable: the G-buffer tile must extend the owned rect by
+        // >= 16 px wherever the frame continues
+        auto apronOk = [&](uint32_t lo, uint32_t olo, uint32_t hi, uint32_t ohi, uint32_t frame) {
+            return (olo == 0 || olo - lo >= 16) && (ohi == frame || hi - ohi >= 16); };
+        if (!apronOk(gb->x0, F.ox0, gb->x0 + gb->w, F.ox0 + F.ow, cb->render_width) || !apronOk(gb->y0, F.oy0, gb->y0 + gb->h, F.oy0 + F.oh, cb->render_height))
+            return Fail(ZR_ERR_INVALID_ARG, "RESTIR_PT on a screen tile needs a G-buffer apron of >= 16 px around the owned rect (zr_pass_set_owned_rect)");
+    }
     F.rbCtN = p->rb[0].View(); F.rbNtC = p->rb[1].View(); F.tex.target = p->rptTarget.p; F.tex.neighbor = p->rptNeighbor.p;
     F.finalRGBA = p->finalRGBA.p; F.sampleSet = p->rptSampleSet.p;
     RptParams& prm = F.prm;
@@ -797,45 +813,57 @@ static int RenderReSTIR_PT(zr_pass* p, hipStream_t s, const zr_frame_constants* 
     prm.accumulate = (cb->accumulate && cb->camera_static) ? 1u : 0u;
     prm.boiling = (ip.flags & ZR_IND_BOILING_SUPPRESSION) ? 1u : 0u;
     prm.M_max_temporal = ip.m_max_temporal & 0xf; prm.M_max_spatial = ip.m_max_spatial & 0xf; prm.alpha_min = ip.alpha_min;
-    prm.doTemporal = ((ip.flags & ZR_IND_TEMPORAL_RESAMPLE) && p->temporalValid && havePrevGBuffer) ? 1u : 0u;
-    prm.doSpatial = ((ip.flags & ZR_IND_SPATIAL_RESAMPLE) && prm.doTemporal) ? 1u : 0u;
+    if (stages & ZR_STAGE_TEMPORAL)
+    {
+        p->doTemporal = (ip.flags & ZR_IND_TEMPORAL_RESAMPLE) && p->temporalValid && havePrevGBuffer;
+        p->doSpatial = (ip.flags & ZR_IND_SPATIAL_RESAMPLE) && p->doTemporal;
+    }
+    prm.doTemporal = p->doTemporal ? 1u : 0u;
+    prm.doSpatial = p->doSpatial ? 1u : 0u;
     prm.writeReservoirs = (prm.doTemporal || !p->temporalValid) ? 1u : 0u;
     F.cur = p->res[p->currIdx].View(); F.prev = p->res[1 - p->currIdx].View();
-    const uint32_t tilesX = (p->w + 15) / 16, tilesY = (p->h + 15) / 16;
+    const uint32_t tilesX = (F.ow + 15) / 16, tilesY = (F.oh + 15) / 16;
     const dim3 grid(tilesX * tilesY), block(kBlock);
-    // work lists for the replay passes: [0] CtT, [1] TtC, [2] CtS, [3] StC; counts live in p->counts[kMaxRounds + 2 ...]
+    // work lists for the replay passes: [0] CtT, [1] TtC, [2] CtS, [3] StC (plane-local pixel ids, device-side counts)
     uint32_t* listCnt = p->rptListCounts.p;
-    HIP_TRY(hipMemsetAsync(listCnt, 0, 4 * sizeof(uint32_t), s));
     const size_t cap = (size_t)p->w * p->h;
     uint32_t* lists[4] = {p->rptLists.p, p->rptLists.p + cap, p->rptLists.p + 2 * cap, p->rptLists.p + 3 * cap};
-    const dim3 gridList((uint32_t)std::min<size_t>((cap + kBlock - 1) / kBlock, 2048));
+    const dim3 gridList((uint32_t)std::min<size_t>((cap + kBlock - 1) / kBlock, 1024));
     unsigned long long* ctr = p->counters.p;
 #define RPT_TIMED(name, launch) do { TimerBegin(p, s, name); launch; TimerEnd(p, s); } while (0)
-    RPT_TIMED("rpt_pathtrace", hipLaunchKernelGGL(k_rpt_pathtrace, grid, block, 0, s, F, *cb, tilesX, ctr + 2 * 1));
-    if (prm.doTemporal)
+    if (stages & ZR_STAGE_TEMPORAL)
     {
-        RPT_TIMED("rpt_classify_temporal", hipLaunchKernelGGL(k_rpt_light<0>, grid, block, 0, s, F, *cb, tilesX, lists[0], lists[1], listCnt + 0));
-        RPT_TIMED("rpt_replay_ctt", hipLaunchKernelGGL(k_rpt_replay<RPT_REPLAY_CTT>, gridList, block, 0, s, F, *cb, lists[0], listCnt + 0, ctr + 2 * 2));
-        RPT_TIMED("rpt_replay_ttc", hipLaunchKernelGGL(k_rpt_replay<RPT_REPLAY_TTC>, gridList, block, 0, s, F, *cb, lists[1], listCnt + 1, ctr + 2 * 3));
-        RPT_TIMED("rpt_reconnect_temporal", hipLaunchKernelGGL(k_rpt_temporal, grid, block, 0, s, F, *cb, tilesX, ctr + 2 * 4));
+        HIP_TRY(hipMemsetAsync(listCnt, 0, 4 * sizeof(uint32_t), s));
+        RPT_TIMED("rpt_pathtrace", hipLaunchKernelGGL(k_rpt_pathtrace, grid, block, 0, s, F, *cb, tilesX, ctr + 2 * 1));
+        if (prm.doTemporal)
+        {
+            RPT_TIMED("rpt_classify_temporal", hipLaunchKernelGGL(k_rpt_light<0>, grid, block, 0, s, F, *cb, tilesX, lists[0], lists[1], listCnt + 0));
+            RPT_TIMED("rpt_replay_ctt", hipLaunchKernelGGL(k_rpt_replay<RPT_REPLAY_CTT>, gridList, block, 0, s, F, *cb, lists[0], listCnt + 0, ctr + 2 * 2));
+            RPT_TIMED("rpt_replay_ttc", hipLaunchKernelGGL(k_rpt_replay<RPT_REPLAY_TTC>, gridList, block, 0, s, F, *cb, lists[1], listCnt + 1, ctr + 2 * 3));
+            RPT_TIMED("rpt_reconnect_temporal", hipLaunchKernelGGL(k_rpt_temporal, grid, block, 0, s, F, *cb, tilesX, ctr + 2 * 4));
+        }
     }
-    if (prm.doSpatial)
+    if ((stages & ZR_STAGE_SPATIAL) && prm.doSpatial)
     {
         RPT_TIMED("rpt_spatial_search", hipLaunchKernelGGL(k_rpt_light<1>, grid, block, 0, s, F, *cb, tilesX, lists[2], lists[3], listCnt + 2));
-        // spatial reads this frame's reservoirs and writes the other set, which becomes "current" (IndirectLighting.cpp:609-612, 682-685)
-        p->currIdx = 1 - p->currIdx;
         RPT_TIMED("rpt_replay_cts", hipLaunchKernelGGL(k_rpt_replay<RPT_REPLAY_CTS>, gridList, block, 0, s, F, *cb, lists[2], listCnt + 2, ctr + 2 * 5));
         RPT_TIMED("rpt_replay_stc", hipLaunchKernelGGL(k_rpt_replay<RPT_REPLAY_STC>, gridList, block, 0, s, F, *cb, lists[3], listCnt + 3, ctr + 2 * 6));
         RPT_TIMED("rpt_reconnect_spatial", hipLaunchKernelGGL(k_rpt_stc, grid, block, 0, s, F, *cb, tilesX, ctr + 2 * 7));
     }
 #undef RPT_TIMED
     HIP_TRY(hipGetLastError());
-    p->temporalValid = true;
-    p->currIdx = 1 - p->currIdx;
+    if (stages & ZR_STAGE_SPATIAL)
+    {
+        // spatial read this frame's reservoirs and wrote the other set, which becomes "current"
+        // (IndirectLighting.cpp:609-612, 682-685); Render() flips once more (:1018-1024)
+        if (prm.doSpatial) p->currIdx = 1 - p->currIdx;
+        p->temporalValid = true;
+        p->currIdx = 1 - p->currIdx;
+    }
     return ZR_OK;
 }
 
-static int RenderIndirect(zr_pass* p, hipStream_t s, const zr_frame_constants* cb, const zr_scene* sc, zr_gbuffer* gb)
+static int RenderIndirect(zr_pass* p, hipStream_t s, const zr_frame_constants* cb, const zr_scene* sc, zr_gbuffer* gb, int stages)
 {
     if (!gb) return Fail(ZR_ERR_INVALID_ARG, "INDIRECT pass needs a gbuffer");
     if (gb->w != p->w || gb->h != p->h || gb->x0 + gb->w > cb->render_width || gb->y0 + gb->h > cb->render_height)
@@ -843,7 +871,8 @@ static int RenderIndirect(zr_pass* p, hipStream_t s, const zr_frame_constants* c
     if (sc->view.numEmissives == 0) return Fail(ZR_ERR_UNSUPPORTED, "scenes without emissive triangles (sun/sky NEE) are not implemented yet");
     if (!sc->view.alias) return Fail(ZR_ERR_NOT_INITIALIZED, "emissive alias table missing: render the PRELIGHTING pass (or zr_scene_set_alias_table) first");
     if (cb->num_emissive_triangles != sc->view.numEmissives) return Fail(ZR_ERR_INVALID_ARG, "cbFrameConstants.NumEmissiveTriangles != scene");
-    if (p->integrator == ZR_INTEGRATOR_RESTIR_PT) return RenderReSTIR_PT(p, s, cb, sc, gb);
+    if (p->integrator == ZR_INTEGRATOR_RESTIR_PT) return RenderReSTIR_PT(p, s, cb, sc, gb, stages);
+    if (!(stages & ZR_STAGE_TEMPORAL)) return ZR_OK;      // single-stage integrators render in the first stage
     PtParams prm;
     prm.maxNonTrBounces = p->params.max_non_tr_bounces; prm.maxGlossyTrBounces = p->params.max_glossy_tr_bounces;
     prm.russianRoulette = (p->params.flags & ZR_IND_RUSSIAN_ROULETTE) ? 1u : 0u;
@@ -890,8 +919,53 @@ static int RenderIndirect(zr_pass* p, hipStream_t s, const zr_frame_constants* c
 }
 
 int zr_pass_render(zr_pass* p, void* stream, const zr_frame_constants* cb, const zr_scene* sc, zr_gbuffer* gb)
+{ return zr_pass_render_stage(p, stream, cb, sc, gb, ZR_STAGE_ALL); }
+
+int zr_pass_set_owned_rect(zr_pass* p, uint32_t x0, uint32_t y0, uint32_t w, uint32_t h)
+{
+    if (!p) return Fail(ZR_ERR_INVALID_ARG, "null pass");
+    p->own[0] = x0; p->own[1] = y0; p->own[2] = w; p->own[3] = h;
+    return ZR_OK;
+}
+
+// which reservoir set a halo transfer addresses (zr_halo_set)
+static zr_pass::ResStorage* HaloSet(zr_pass* p, int which)
+{
+    // between the stages of a frame the post-temporal reservoirs are res[currIdx]; after the frame the set the next
+    // frame reads as "previous" is res[1 - currIdx]
+    return &p->res[which == ZR_HALO_POST_TEMPORAL ? p->currIdx : 1 - p->currIdx];
+}
+static int HaloCopy(zr_pass* p, hipStream_t s, const zr_gbuffer* gb, int which, uint32_t x0, uint32_t y0, uint32_t w, uint32_t h, void* packed, size_t bytes, bool pack)
+{
+    if (!p || !gb || !packed) return Fail(ZR_ERR_INVALID_ARG, "null argument");
+    if (p->kind != ZR_PASS_INDIRECT || p->integrator != ZR_INTEGRATOR_RESTIR_PT || !p->initialized) return Fail(ZR_ERR_NOT_INITIALIZED, "not an initialised RESTIR_PT pass");
+    if (x0 < gb->x0 || y0 < gb->y0 || x0 + w > gb->x0 + gb->w || y0 + h > gb->y0 + gb->h) return Fail(ZR_ERR_INVALID_ARG, "halo rect lies outside this device's planes");
+    const size_t n = (size_t)w * h;
+    if (bytes != n * ZR_HALO_BYTES_PER_PIXEL) return Fail(ZR_ERR_INVALID_ARG, "halo buffer must hold %zu bytes", n * ZR_HALO_BYTES_PER_PIXEL);
+    if (!n) return ZR_OK;
+    HIP_TRY(hipSetDevice(p->device));
+    zr_pass::ResStorage* R = HaloSet(p, which);
+    struct { void* base; size_t bpp; } planes[7] = {{R->A.p, 4}, {R->B.p, 8}, {R->C.p, 16}, {R->D.p, 16}, {R->E.p, 2}, {R->F.p, 8}, {R->G.p, 8}};
+    char* cursor = (char*)packed;
+    const size_t first = (size_t)(y0 - gb->y0) * gb->w + (x0 - gb->x0);
+    for (auto& pl : planes)
+    {
+        char* tile = (char*)pl.base + first * pl.bpp;
+        if (pack) HIP_TRY(hipMemcpy2DAsync(cursor, w * pl.bpp, tile, gb->w * pl.bpp, w * pl.bpp, h, hipMemcpyDeviceToDevice, s));
+        else HIP_TRY(hipMemcpy2DAsync(tile, gb->w * pl.bpp, cursor, w * pl.bpp, w * pl.bpp, h, hipMemcpyDeviceToDevice, s));
+        cursor += n * pl.bpp;
+    }
+    return ZR_OK;
+}
+int zr_pass_halo_pack(zr_pass* p, void* stream, const zr_gbuffer* gb, int which, uint32_t x0, uint32_t y0, uint32_t w, uint32_t h, void* dev_dst, size_t bytes)
+{ return HaloCopy(p, (hipStream_t)stream, gb, which, x0, y0, w, h, dev_dst, bytes, true); }
+int zr_pass_halo_unpack(zr_pass* p, void* stream, const zr_gbuffer* gb, int which, uint32_t x0, uint32_t y0, uint32_t w, uint32_t h, const void* dev_src, size_t bytes)
+{ return HaloCopy(p, (hipStream_t)stream, gb, which, x0, y0, w, h, const_cast<void*>(dev_src), bytes, false); }
+
+int zr_pass_render_stage(zr_pass* p, void* stream, const zr_frame_constants* cb, const zr_scene* sc, zr_gbuffer* gb, int stages)
 {
     if (!p || !cb || !sc) return Fail(ZR_ERR_INVALID_ARG, "zr_pass_render: null argument");
+    if (!(stages & ZR_STAGE_ALL)) return Fail(ZR_ERR_INVALID_ARG, "no stage selected");
     if (!p->initialized) return Fail(ZR_ERR_NOT_INITIALIZED, "pass not initialised (zr_pass_init)");
     if (sc->device != p->device || (gb && gb->device != p->device)) return Fail(ZR_ERR_INVALID_ARG, "scene / gbuffer / pass live on different devices");
     HIP_TRY(hipSetDevice(p->device));
@@ -899,9 +973,9 @@ int zr_pass_render(zr_pass* p, void* stream, const zr_frame_constants* cb, const
     p->numTimers = 0;
     switch (p->kind)
     {
-    case ZR_PASS_GBUFFER: return RenderGBuffer(p, s, cb, sc, gb);
-    case ZR_PASS_PRELIGHTING: return RenderPreLighting(p, s, const_cast<zr_scene*>(sc));
-    case ZR_PASS_INDIRECT: return RenderIndirect(p, s, cb, sc, gb);
+    case ZR_PASS_GBUFFER: return (stages & ZR_STAGE_TEMPORAL) ? RenderGBuffer(p, s, cb, sc, gb) : ZR_OK;
+    case ZR_PASS_PRELIGHTING: return (stages & ZR_STAGE_TEMPORAL) ? RenderPreLighting(p, s, const_cast<zr_scene*>(sc)) : ZR_OK;
+    case ZR_PASS_INDIRECT: return RenderIndirect(p, s, cb, sc, gb, stages);
     default: return Fail(ZR_ERR_UNSUPPORTED, "pass kind %d not implemented", p->kind);
     }
 }

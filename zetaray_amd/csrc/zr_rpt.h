@@ -624,6 +624,10 @@ ZR_HD V2 DecodeMotion(uint32_t m)
     return v2(fx < -1.0f ? -1.0f : fx, fy < -1.0f ? -1.0f : fy);
 }
 
+// plane index of the global pixel (x, y): planes cover the extended tile [gb.x0, gb.x0 + gb.w) x [gb.y0, gb.y0 + gb.h)
+ZR_HD size_t Pix(const GBuf& gb, uint32_t x, uint32_t y) { return (size_t)(y - gb.y0) * gb.w + (x - gb.x0); }
+ZR_HD bool InPlanes(const GBuf& gb, int x, int y) { return x >= (int)gb.x0 && y >= (int)gb.y0 && x < (int)(gb.x0 + gb.w) && y < (int)(gb.y0 + gb.h); }
+
 struct Camera { V2 renderDim, jitter; V3 vbx, vby, vbz, origin; float tanHalfFOV, aspect; bool dof; float focusDepth, lensRadius; };
 ZR_HD Camera CurrCamera(const zr_frame_constants& g)
 {
@@ -668,7 +672,7 @@ struct PixelSurface { V3 pos, normal; float eta_next; Surface surface; GFlags fl
 ZR_HD PixelSurface LoadPixelSurface(const GBuf& gb, const Camera& cam, uint32_t x, uint32_t y, uint32_t frameForLens, size_t coatPixel)
 {
     PixelSurface ps;
-    const size_t px = (size_t)y * gb.w + x;
+    const size_t px = Pix(gb, x, y);
     const uint16_t mrp = gb.mr[px];
     ps.flags = DecodeFlags(mrp); ps.roughness = RoughnessOf(mrp); ps.z = gb.depth[px];
     V2 lens = v2(0, 0);
@@ -724,12 +728,12 @@ struct RptParams
 };
 
 // main() prologue + RIS_InitialCandidates up to the first FindClosest (ReSTIR_PT_PathTrace.hlsl:360-530, 194-236)
-ZR_HD void PtInitLane(const SceneView& sc, const zr_frame_constants& g, const GBuf& gb, const RptParams& prm, uint32_t x, uint32_t y,
+ZR_HD void PtInitLane(const SceneView& sc, const zr_frame_constants& g, const GBuf& gb, const RptParams& prm, bool owned, uint32_t x, uint32_t y,
     float* finalRGBA, uint32_t* stack, uint32_t* cnt, PTLane& P)
 {
     P.active = false; P.atRR = false; P.valid = false; P.x = x; P.y = y;
-    if (x >= g.render_width || y >= g.render_height) return;
-    const size_t px = (size_t)y * gb.w + x;
+    if (!owned) return;
+    const size_t px = Pix(gb, x, y);
     GFlags flags = DecodeFlags(gb.mr[px]);
     if (flags.invalid || flags.emissive)
     {
@@ -834,7 +838,7 @@ struct RptTex   // per-pass auxiliary planes
 ZR_HD void PtFinishLane(const GBuf& gb, const RptParams& prm, const ResPlanes& out, const RptTex& tex, float* finalRGBA, PTLane& P)
 {
     if (!P.valid) return;
-    const size_t px = (size_t)P.y * gb.w + P.x;
+    const size_t px = Pix(gb, P.x, P.y);
     Reservoir& r = P.r;
     r.rc.seed_replay = P.seed_replay;
     float targetLum = Luminance(r.target);
@@ -1092,6 +1096,10 @@ struct RptFrame
 {
     SceneView sc; GBuf gb, gbPrev; ResPlanes cur, prev;    // cur = this frame's reservoirs, prev = the other set
     RBuf rbCtN, rbNtC; RptTex tex; float* finalRGBA; const uint16_t* sampleSet; RptParams prm;
+    // pixels this device is responsible for (global coordinates); the planes also hold an apron of neighbouring tiles'
+    // pixels: G-buffer rendered locally, reservoirs received through the halo exchange
+    uint32_t ox0, oy0, ow, oh;
+    ZR_HDM bool Owns(uint32_t x, uint32_t y) const { return x >= ox0 && y >= oy0 && x < ox0 + ow && y < oy0 + oh; }
 };
 
 ZR_HD Globals MakeGlobals(const RptFrame& F, const zr_frame_constants& g, bool transmissive, uint32_t* stack, uint32_t* cnt)
@@ -1107,14 +1115,15 @@ ZR_HD TemporalPixel FindTemporal(const RptFrame& F, const zr_frame_constants& g,
 {
     TemporalPixel t; t.ok = false; t.px = 0; t.py = 0;
     const V2 renderDim = v2((float)g.render_width, (float)g.render_height);
-    const size_t px = (size_t)y * F.gb.w + x;
+    const size_t px = Pix(F.gb, x, y);
     const V2 motionVec = DecodeMotion(F.gb.motion[px]);
     const V2 currUV = v2(((float)x + 0.5f) / renderDim.x, ((float)y + 0.5f) / renderDim.y);
     const V2 prevUV = currUV - motionVec;
     int ppx = (int)(prevUV.x * renderDim.x), ppy = (int)(prevUV.y * renderDim.y);
     if (prevUV.x < 0 || prevUV.y < 0 || prevUV.x > 1 || prevUV.y > 1) return t;
-    if (ppx >= (int)F.gb.w || ppy >= (int)F.gb.h) return t;      // prevUV == 1: out of bounds, pinned to "no history"
-    const size_t pp = (size_t)ppy * F.gb.w + ppx;
+    if (ppx >= (int)g.render_width || ppy >= (int)g.render_height) return t;      // prevUV == 1: out of bounds, pinned to "no history"
+    if (!InPlanes(F.gb, ppx, ppy)) return t;      // screen-tile split: reprojection beyond the apron = no history (SURVEY 8(e) caveat)
+    const size_t pp = Pix(F.gb, (uint32_t)ppx, (uint32_t)ppy);
     if (F.gbPrev.depth[pp] == ZR_FLT_MAX) return t;
     const Camera pcam = PrevCamera(g);
     t.prev = LoadPixelSurface(F.gbPrev, pcam, (uint32_t)ppx, (uint32_t)ppy, g.frame_num - 1, coatAtDTid ? px : pp);
@@ -1128,7 +1137,7 @@ ZR_HD TemporalPixel FindTemporal(const RptFrame& F, const zr_frame_constants& g,
 // K13 Replay_CtT / Replay_TtC (ReSTIR_PT_Replay.hlsl:289-534)
 ZR_HD_FLAT void ReplayTemporalPixel(const RptFrame& F, const zr_frame_constants& g, int variant, uint32_t x, uint32_t y, uint32_t* stack, uint32_t* cnt)
 {
-    const size_t px = (size_t)y * F.gb.w + x;
+    const size_t px = Pix(F.gb, x, y);
     GFlags flags = DecodeFlags(F.gb.mr[px]);
     if (flags.invalid || flags.emissive) return;
     const Camera cam = CurrCamera(g);
@@ -1136,7 +1145,7 @@ ZR_HD_FLAT void ReplayTemporalPixel(const RptFrame& F, const zr_frame_constants&
     TemporalPixel tp = FindTemporal(F, g, x, y, ps, 0.01f, false);
     if (!tp.ok) return;
     Globals gl = MakeGlobals(F, g, flags.transmissive, stack, cnt);
-    const size_t pp = (size_t)tp.py * F.gb.w + tp.px;
+    const size_t pp = Pix(F.gb, (uint32_t)tp.px, (uint32_t)tp.py);
     if (variant == 0)
     {
         Reservoir r = Load_Metadata(F.cur, px);
@@ -1187,7 +1196,7 @@ ZR_HD void MoveXk(const SceneView& sc, Reconnection& rc, bool currToPrev, bool s
 // same result and shares the G-buffer reconstruction and the temporal-pixel search.
 ZR_HD void ReconnectTemporalPixel(const RptFrame& F, const zr_frame_constants& g, uint32_t x, uint32_t y, uint32_t* stack, uint32_t* cnt)
 {
-    const size_t px = (size_t)y * F.gb.w + x;
+    const size_t px = Pix(F.gb, x, y);
     GFlags flags = DecodeFlags(F.gb.mr[px]);
     if (flags.invalid || flags.emissive) return;
     const bool doSpatial = F.prm.doSpatial;
@@ -1196,7 +1205,7 @@ ZR_HD void ReconnectTemporalPixel(const RptFrame& F, const zr_frame_constants& g
     // CtT reads the previous G-buffer's coat plane at DTid (ReSTIR_PT_Reconnect_CtT.hlsl:80), TtC at prevPixel
     TemporalPixel tp = FindTemporal(F, g, x, y, ps, kMaxPlaneDistReuse, true);
     Globals gl = MakeGlobals(F, g, flags.transmissive, stack, cnt);
-    const size_t pp = (size_t)tp.py * F.gb.w + tp.px;
+    const size_t pp = Pix(F.gb, (uint32_t)tp.px, (uint32_t)tp.py);
 
     // ---- current -> temporal: MIS weight of the current sample
     if (tp.ok)
@@ -1271,7 +1280,7 @@ ZR_HD void ReconnectTemporalPixel(const RptFrame& F, const zr_frame_constants& g
 // cheap predicates for the replay work lists (supersets of the pixels the replay passes act on; the passes re-check)
 ZR_HD bool NeedsReplayCtT(const RptFrame& F, uint32_t x, uint32_t y)
 {
-    const size_t px = (size_t)y * F.gb.w + x;
+    const size_t px = Pix(F.gb, x, y);
     GFlags flags = DecodeFlags(F.gb.mr[px]);
     if (flags.invalid || flags.emissive) return false;
     const uint32_t k = F.cur.A[px] & 0xf;
@@ -1279,7 +1288,7 @@ ZR_HD bool NeedsReplayCtT(const RptFrame& F, uint32_t x, uint32_t y)
 }
 ZR_HD bool NeedsReplayTtC(const RptFrame& F, const zr_frame_constants& g, uint32_t x, uint32_t y)
 {
-    const size_t px = (size_t)y * F.gb.w + x;
+    const size_t px = Pix(F.gb, x, y);
     GFlags flags = DecodeFlags(F.gb.mr[px]);
     if (flags.invalid || flags.emissive) return false;
     const V2 renderDim = v2((float)g.render_width, (float)g.render_height);
@@ -1287,8 +1296,8 @@ ZR_HD bool NeedsReplayTtC(const RptFrame& F, const zr_frame_constants& g, uint32
     const V2 prevUV = v2(((float)x + 0.5f) / renderDim.x, ((float)y + 0.5f) / renderDim.y) - motionVec;
     if (prevUV.x < 0 || prevUV.y < 0 || prevUV.x > 1 || prevUV.y > 1) return false;
     const int ppx = (int)(prevUV.x * renderDim.x), ppy = (int)(prevUV.y * renderDim.y);
-    if (ppx >= (int)F.gb.w || ppy >= (int)F.gb.h) return false;
-    const uint32_t k = F.prev.A[(size_t)ppy * F.gb.w + ppx] & 0xf;
+    if (ppx >= (int)g.render_width || ppy >= (int)g.render_height || !InPlanes(F.gb, ppx, ppy)) return false;
+    const uint32_t k = F.prev.A[Pix(F.gb, (uint32_t)ppx, (uint32_t)ppy)] & 0xf;
     return k != Reconnection::EMPTY && k > 0;
 }
 
@@ -1307,8 +1316,8 @@ ZR_HD V3 WorldPosSS(float px, float py, V2 renderDim, float z_view, float tanHal
 ZR_HD void SpatialSearchPixel(const RptFrame& F, const zr_frame_constants& g, uint32_t x, uint32_t y)
 {
     const GBuf& gb = F.gb;
-    const uint32_t W = gb.w, H = gb.h;
-    const size_t px = (size_t)y * W + x;
+    const uint32_t W = g.render_width, H = g.render_height;
+    const size_t px = Pix(gb, x, y);
     const uint16_t mrp = gb.mr[px];
     GFlags flags = DecodeFlags(mrp);
     if (flags.invalid || flags.emissive) return;
@@ -1334,7 +1343,8 @@ ZR_HD void SpatialSearchPixel(const RptFrame& F, const zr_frame_constants& g, ui
         const int sxp = (int)__builtin_rintf((float)x + rx), syp = (int)__builtin_rintf((float)y + ry);
         if (sxp < 0 || syp < 0 || sxp >= (int)W || syp >= (int)H) continue;
         if (sxp == (int)x && syp == (int)y) continue;
-        const size_t sp = (size_t)syp * W + sxp;
+        if (!InPlanes(gb, sxp, syp)) continue;      // cannot happen with an apron >= the search radius
+        const size_t sp = Pix(gb, (uint32_t)sxp, (uint32_t)syp);
         const uint16_t smr = gb.mr[sp];
         GFlags sf = DecodeFlags(smr);
         if (sf.invalid || sf.emissive) continue;
@@ -1355,7 +1365,7 @@ ZR_HD void SpatialSearchPixel(const RptFrame& F, const zr_frame_constants& g, ui
 
 ZR_HD bool NeighborOf(const RptFrame& F, uint32_t x, uint32_t y, int& sx, int& sy)
 {
-    const size_t px = (size_t)y * F.gb.w + x;
+    const size_t px = Pix(F.gb, x, y);
     if (F.tex.neighbor[2 * px] == 255) return false;
     sx = (int)F.tex.neighbor[2 * px] - kNeighborOffset + (int)x; sy = (int)F.tex.neighbor[2 * px + 1] - kNeighborOffset + (int)y;
     return true;
@@ -1365,7 +1375,7 @@ ZR_HD bool NeighborOf(const RptFrame& F, uint32_t x, uint32_t y, int& sx, int& s
 // K13 Replay_CtS / Replay_StC
 ZR_HD_FLAT void ReplaySpatialPixel(const RptFrame& F, const zr_frame_constants& g, int variant, uint32_t x, uint32_t y, uint32_t* stack, uint32_t* cnt)
 {
-    const size_t px = (size_t)y * F.gb.w + x;
+    const size_t px = Pix(F.gb, x, y);
     GFlags flags = DecodeFlags(F.gb.mr[px]);
     if (flags.invalid || flags.emissive) return;
     Globals gl = MakeGlobals(F, g, flags.transmissive, stack, cnt);
@@ -1378,7 +1388,7 @@ ZR_HD_FLAT void ReplaySpatialPixel(const RptFrame& F, const zr_frame_constants& 
         {
             r.Load_Reconnection(F.cur, px);
             if (!NeighborOf(F, x, y, sx, sy)) return;
-            const size_t sp = (size_t)sy * F.gb.w + sx;
+            const size_t sp = Pix(F.gb, (uint32_t)sx, (uint32_t)sy);
             PixelSurface pn = LoadPixelSurface(F.gb, cam, (uint32_t)sx, (uint32_t)sy, g.frame_num, sp);
             OffsetCtx ctx = Replay_kGt2(gl, true, pn.pos, pn.normal, pn.eta_next, pn.surface, r.rc);
             WriteOffsetCtx(ctx, F.rbCtN, px, r.rc.IsCase3());
@@ -1387,7 +1397,7 @@ ZR_HD_FLAT void ReplaySpatialPixel(const RptFrame& F, const zr_frame_constants& 
     else
     {
         if (!NeighborOf(F, x, y, sx, sy)) return;
-        const size_t sp = (size_t)sy * F.gb.w + sx;
+        const size_t sp = Pix(F.gb, (uint32_t)sx, (uint32_t)sy);
         Reservoir r = Load_Metadata(F.cur, sp);
         if (!r.rc.Empty() && (r.rc.k > 2))
         {
@@ -1401,7 +1411,7 @@ ZR_HD_FLAT void ReplaySpatialPixel(const RptFrame& F, const zr_frame_constants& 
 
 ZR_HD bool NeedsReplayCtS(const RptFrame& F, uint32_t x, uint32_t y)
 {
-    const size_t px = (size_t)y * F.gb.w + x;
+    const size_t px = Pix(F.gb, x, y);
     GFlags flags = DecodeFlags(F.gb.mr[px]);
     if (flags.invalid || flags.emissive) return false;
     if (F.tex.neighbor[2 * px] == 255) return false;
@@ -1410,12 +1420,12 @@ ZR_HD bool NeedsReplayCtS(const RptFrame& F, uint32_t x, uint32_t y)
 }
 ZR_HD bool NeedsReplayStC(const RptFrame& F, uint32_t x, uint32_t y)
 {
-    const size_t px = (size_t)y * F.gb.w + x;
+    const size_t px = Pix(F.gb, x, y);
     GFlags flags = DecodeFlags(F.gb.mr[px]);
     if (flags.invalid || flags.emissive) return false;
     int sx, sy;
     if (!NeighborOf(F, x, y, sx, sy)) return false;
-    const uint32_t k = F.cur.A[(size_t)sy * F.gb.w + sx] & 0xf;
+    const uint32_t k = F.cur.A[Pix(F.gb, (uint32_t)sx, (uint32_t)sy)] & 0xf;
     return k != Reconnection::EMPTY && k > 0;
 }
 
@@ -1423,12 +1433,12 @@ ZR_HD bool NeedsReplayStC(const RptFrame& F, uint32_t x, uint32_t y)
 // "in" set, writes w_sum of the "out" set that StC reads back), so the StC kernel runs it per lane before its phase 1.
 ZR_HD void ReconnectCtSPixel(const RptFrame& F, const zr_frame_constants& g, uint32_t x, uint32_t y, uint32_t* stack, uint32_t* cnt)
 {
-    const size_t px = (size_t)y * F.gb.w + x;
+    const size_t px = Pix(F.gb, x, y);
     int sx, sy;
     if (!NeighborOf(F, x, y, sx, sy)) return;
     GFlags flags = DecodeFlags(F.gb.mr[px]);
     if (flags.invalid || flags.emissive) return;
-    const size_t sp = (size_t)sy * F.gb.w + sx;
+    const size_t sp = Pix(F.gb, (uint32_t)sx, (uint32_t)sy);
     Reservoir r_curr = Load_NonReconnection(F.cur, px);
     Reservoir r_spatial = Load_Metadata(F.cur, sp);
     if ((r_curr.w_sum != 0) && !r_curr.rc.Empty())
@@ -1470,8 +1480,8 @@ ZR_HD void StcSuppress(float waveAvgExclusive, Reservoir& r)
 ZR_HD void StcPhase0(const RptFrame& F, const zr_frame_constants& g, uint32_t x, uint32_t y, StcLane& a, float& s1, float& s2)
 {
     a.valid = a.hasN = a.spatialEmpty = a.resample = a.changed = false; a.x = x; a.y = y; s1 = 0; s2 = 0;
-    if (x >= F.gb.w || y >= F.gb.h) return;
-    a.px = (size_t)y * F.gb.w + x;
+    if (!F.Owns(x, y)) return;
+    a.px = Pix(F.gb, x, y);
     a.flags = DecodeFlags(F.gb.mr[a.px]);
     if (a.flags.invalid || a.flags.emissive) return;
     a.valid = true;
@@ -1482,7 +1492,7 @@ ZR_HD void StcPhase0(const RptFrame& F, const zr_frame_constants& g, uint32_t x,
     a.r_curr.target = xyz(F.tex.target[a.px]);
     int sx, sy;
     a.hasN = NeighborOf(F, x, y, sx, sy);
-    if (a.hasN) a.sp = (size_t)sy * F.gb.w + sx;
+    if (a.hasN) a.sp = Pix(F.gb, (uint32_t)sx, (uint32_t)sy);
     s1 = a.r_curr.w_sum;
     s2 = a.r_curr.w_sum * (a.hasN ? 0.0f : 1.0f);
 }

@@ -1,0 +1,158 @@
+"""Screen-tile split of a frame over N devices and the reservoir halo exchange of the ReSTIR passes (SURVEY.md section
+8(e)): host-side logic shared by bench.py, the GPU path (RCCL through torch.distributed) and the CPU tests (gloo + the
+test-only host executor).
+
+Tiles are 32-px aligned so thread groups, wave-reduction groups and RNG group ids are those of the single-device run; every
+device renders the G-buffer of its tile plus a 32-px apron locally (geometry is replicated) and owns the reservoirs of its
+tile; apron reservoirs come from the neighbours: post-temporal reservoirs before the spatial stage (the spatial passes
+read a neighbour within 15 px) and final reservoirs after it (the next frame's temporal passes read the motion-shifted
+pixel).  Point-to-point only: nothing is reduced, so a ring collective would only add per-link latency on xGMI.
+"""
+import numpy as np
+
+APRON = 32
+
+
+def tile_grid(n):
+    return {1: (1, 1), 2: (2, 1), 4: (2, 2), 8: (4, 2)}[n]
+
+
+def tile_rect(w, h, n, rank):
+    """(x0, y0, tw, th) of rank's tile: 32-px aligned boundaries."""
+    gx, gy = tile_grid(n)
+    tx, ty = rank % gx, rank // gx
+
+    def split(total, parts, i):
+        edges = [min(total, ((total * k // parts) + 31) // 32 * 32) for k in range(parts + 1)]
+        edges[-1] = total
+        return edges[i], edges[i + 1] - edges[i]
+    x0, tw = split(w, gx, tx)
+    y0, th = split(h, gy, ty)
+    return x0, y0, tw, th
+
+
+def extended_rect(w, h, rect, apron=APRON):
+    x0, y0, tw, th = rect
+    ex0, ey0 = max(0, x0 - apron), max(0, y0 - apron)
+    ex1, ey1 = min(w, x0 + tw + apron), min(h, y0 + th + apron)
+    return ex0, ey0, ex1 - ex0, ey1 - ey0
+
+
+def intersect(a, b):
+    x0, y0 = max(a[0], b[0]), max(a[1], b[1])
+    x1, y1 = min(a[0] + a[2], b[0] + b[2]), min(a[1] + a[3], b[1] + b[3])
+    if x1 <= x0 or y1 <= y0:
+        return None
+    return x0, y0, x1 - x0, y1 - y0
+
+
+def halo_plan(w, h, n, rank, apron=APRON):
+    """[(peer, send_rect, recv_rect)]: send = my tile inside the peer's extended rect, recv = the peer's tile inside mine
+    (global pixel coordinates).  Symmetric by construction, so both sides agree on sizes without a handshake."""
+    mine = tile_rect(w, h, n, rank)
+    mine_ext = extended_rect(w, h, mine, apron)
+    plan = []
+    for peer in range(n):
+        if peer == rank:
+            continue
+        theirs = tile_rect(w, h, n, peer)
+        send = intersect(mine, extended_rect(w, h, theirs, apron))
+        recv = intersect(theirs, mine_ext)
+        if send is not None or recv is not None:
+            plan.append((peer, send, recv))
+    return plan
+
+
+class TiledRestirPT:
+    """One rank of the tile-split ReSTIR PT renderer on a GPU: G-buffer + PreLighting + Indirect (two stages) with the halo
+    exchange in between, through torch.distributed P2P (backend nccl == RCCL over xGMI on ROCm)."""
+
+    def __init__(self, scene_host, width, height, world, rank, device=0, params=None, dist=None):
+        import torch
+        from . import api
+        self.api, self.torch, self.dist = api, torch, dist
+        self.W, self.H, self.world, self.rank = width, height, world, rank
+        self.tile = tile_rect(width, height, world, rank)
+        self.ext = extended_rect(width, height, self.tile) if world > 1 else self.tile
+        self.plan = halo_plan(width, height, world, rank) if world > 1 else []
+        ex0, ey0, ew, eh = self.ext
+        self.r = api.Renderer(scene_host, ew, eh, device=device, params=params, integrator=api.INTEGRATOR_RESTIR_PT,
+                              tile_origin=(ex0, ey0))
+        if world > 1:
+            self.r.p_indirect.set_owned_rect(*self.tile)
+        self.device = torch.device("cuda", device)
+        self.bufs = {}
+        for peer, send, recv in self.plan:
+            sb = torch.empty(send[2] * send[3] * api.HALO_BYTES_PER_PIXEL, dtype=torch.uint8, device=self.device) if send else None
+            rb = torch.empty(recv[2] * recv[3] * api.HALO_BYTES_PER_PIXEL, dtype=torch.uint8, device=self.device) if recv else None
+            self.bufs[peer] = (sb, rb)
+        self.halo_bytes = sum((sb.numel() if sb is not None else 0) for sb, _ in self.bufs.values())
+
+    def pack(self, which):
+        """stage 1 of an exchange: copy my border strips into the per-peer send buffers (device-to-device, on the stream)"""
+        for peer, send, recv in self.plan:
+            if send:
+                sb = self.bufs[peer][0]
+                self.r.p_indirect.halo_pack(self.r.gbuffer, which, send, sb.data_ptr(), sb.numel())
+
+    def unpack(self, which):
+        """stage 3: scatter the received strips into my apron"""
+        for peer, send, recv in self.plan:
+            if recv:
+                rb = self.bufs[peer][1]
+                self.r.p_indirect.halo_unpack(self.r.gbuffer, which, recv, rb.data_ptr(), rb.numel())
+
+    def exchange(self, which):
+        if not self.plan:
+            return
+        dist = self.dist
+        self.pack(which)
+        ops = []
+        for peer, send, recv in self.plan:
+            sb, rb = self.bufs[peer]
+            if send:
+                ops.append(dist.P2POp(dist.isend, sb, peer))
+            if recv:
+                ops.append(dist.P2POp(dist.irecv, rb, peer))
+        for req in dist.batch_isend_irecv(ops):
+            req.wait()
+        self.unpack(which)
+
+    def stage_temporal(self, cb):
+        api, r = self.api, self.r
+        r.p_gbuffer.render(cb, r.scene, r.gbuffer)
+        if not r._alias_ready:
+            r.p_prelight.render(cb, r.scene, None)
+            r._alias_ready = True
+        r.p_indirect.render_stage(cb, r.scene, r.gbuffer, api.STAGE_TEMPORAL)
+
+    def stage_spatial(self, cb):
+        self.r.p_indirect.render_stage(cb, self.r.scene, self.r.gbuffer, self.api.STAGE_SPATIAL)
+
+    def render_frame(self, cb, exchange_final=True):
+        """exchange_final=False skips the post-frame exchange: valid for a static camera (reprojection stays in the tile)"""
+        self.stage_temporal(cb)
+        self.exchange(self.api.HALO_POST_TEMPORAL)
+        self.stage_spatial(cb)
+        if exchange_final:
+            self.exchange(self.api.HALO_FINAL)
+
+    def final_tile(self):
+        """(tile rect, RGBA32F array of the owned tile)"""
+        full = self.r.final()
+        x0, y0, tw, th = self.tile
+        ex0, ey0 = self.ext[0], self.ext[1]
+        return self.tile, full[y0 - ey0:y0 - ey0 + th, x0 - ex0:x0 - ex0 + tw].copy()
+
+
+def exchange_in_process(ranks, which):
+    """Halo exchange between TiledRestirPT objects living in ONE process (all tiles on one device): used by the GPU test
+    on a single-GPU box; the data path (pack -> buffer -> unpack) is the one RCCL sees."""
+    for r in ranks:
+        r.pack(which)
+    for r in ranks:
+        for peer, send, recv in r.plan:
+            if recv:
+                r.bufs[peer][1].copy_(ranks[peer].bufs[r.rank][0])
+    for r in ranks:
+        r.unpack(which)
