@@ -35,6 +35,7 @@ def lib():
         L.zro_trace_any.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]
         L.zro_trace_closest_timed.restype = C.c_double
         L.zro_trace_closest_timed.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]
+        L.zro_presample.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p]
         L.zro_rpt_create.restype = C.c_void_p
         L.zro_rpt_create.argtypes = [C.c_uint32, C.c_uint32, C.c_void_p]
         L.zro_rpt_destroy.argtypes = [C.c_void_p]
@@ -78,6 +79,13 @@ class OracleScene:
     def estimate_power(self):
         out = np.zeros(len(self.scene.emissives), np.float32)
         lib().zro_estimate_power(self.h, out.ctypes.data)
+        return out
+
+    def presample(self, frame_num, num_sets, set_size):
+        """K3: (re)generate the presampled light sets for this frame; returns them (wire.PRESAMPLED_TRI records)"""
+        from zetaray_amd import wire
+        out = np.zeros(num_sets * set_size, wire.PRESAMPLED_TRI)
+        lib().zro_presample(self.h, frame_num, num_sets, set_size, out.ctypes.data)
         return out
 
     def gbuffer(self, cb):

@@ -375,7 +375,7 @@ static void EstimatePower(const Scene& sc, float* out)
 //  ACCOUNT_FOR_TRANSMITTANCE 1)
 //--------------------------------------------------------------------------------------
 static float3 NEE_Emissive_MIS(const Scene& sc, int NumLightSamples, bool skipDiffuse, float3 pos, float3 normal,
-    BSDF::ShadingData surface, uint32_t numEmissives, RNG& rng)
+    BSDF::ShadingData surface, uint32_t numEmissives, RNG& rng, bool presampled = false, uint32_t sampleSetIdx = 0)
 {
     float3 ld = f3(0.0f);
     const bool specular = surface.GlossSpecular() && (surface.metallic || surface.specTr) && (!surface.Coated() || surface.CoatSpecular());
@@ -409,12 +409,21 @@ static float3 NEE_Emissive_MIS(const Scene& sc, int NumLightSamples, bool skipDi
     // Light sampling
     for (int s_l = 0; s_l < numLightSamples; s_l++)
     {
-        Light::AliasTableSample entry = Light::AliasTableSample::get(sc, numEmissives, rng);
-        EmTri tri; tri.t = sc.emissives[entry.idx];
-        Light::EmissiveTriSample lightSample = Light::EmissiveTriSample::get(pos, tri, rng);
-        float3 le = Light::Le_EmissiveTriangle(tri, lightSample.bary);
-        const float lightPdf = entry.pdf * lightSample.pdf;
-        const uint32_t lightID = tri.t.id;
+        Light::EmissiveTriSample lightSample; float3 le; float lightPdf; uint32_t lightID;
+        if (presampled)     // USE_PRESAMPLED_SETS (ReSTIR_GI_NEE.hlsli:68-85)
+        {
+            Light::PresampledLight pl = Light::SamplePresampledSet(sc, sampleSetIdx, pos, rng);
+            lightSample.pos = pl.pos; lightSample.normal = pl.normal; le = pl.le; lightPdf = pl.pdf; lightID = pl.ID;
+        }
+        else
+        {
+            Light::AliasTableSample entry = Light::AliasTableSample::get(sc, numEmissives, rng);
+            EmTri tri; tri.t = sc.emissives[entry.idx];
+            lightSample = Light::EmissiveTriSample::get(pos, tri, rng);
+            le = Light::Le_EmissiveTriangle(tri, lightSample.bary);
+            lightPdf = entry.pdf * lightSample.pdf;
+            lightID = tri.t.id;
+        }
         const float t = length(lightSample.pos - pos);
         const float3 wi = (lightSample.pos - pos) / t;
         if (dot(lightSample.normal, -wi) > 0)
@@ -445,7 +454,7 @@ struct PathState
     BSDF::BSDFSample bsdfSample; RtRayQuery::Hit hitInfo; RT::RayDifferentials rd;
     RNG rngThread, rngGroup;
     float3 firstBsdfOverPdf;
-    int maxNumBounces;
+    int maxNumBounces; uint32_t sampleSetIdx = 0;
     // per-iteration temporaries carried from phase A to phase B
     BSDF::ShadingData surface; float eta_next; float3 dpdx, dpdy;
 };
@@ -515,7 +524,7 @@ static void RenderPathTracer(const Scene& sc, const zr_frame_constants& g, GBVie
 
             // EstimateIndirectLighting
             const uint32_t sampleSetIdx = P.rngGroup.UniformUintBounded_Faster(numSampleSets);
-            (void)sampleSetIdx;
+            P.sampleSetIdx = sampleSetIdx;
             P.li = f3(0.0f);
             BSDF::BSDFSample bsdfSample = BSDF::SampleBSDF(normal, surface, P.rngThread);
             bool alive = bsdfSample.pdf != 0;
@@ -564,7 +573,8 @@ static void RenderPathTracer(const Scene& sc, const zr_frame_constants& g, GBVie
                 if (!RtRayQuery::GetMaterialData(sc, -P.bsdfSample.wi, P.eta_curr, P.rd.uv_grads, P.hitInfo, P.surface, P.eta_next))
                 { P.active = false; continue; }
                 // RGI_Util::NEE, NEE_EMISSIVE == 1, USE_MIS == 1, MIS_ALL_BOUNCES == 1
-                P.li += P.throughput * NEE_Emissive_MIS(sc, 1, false, hitPos, P.hitInfo.normal, P.surface, g.num_emissive_triangles, P.rngThread);
+                P.li += P.throughput * NEE_Emissive_MIS(sc, 1, false, hitPos, P.hitInfo.normal, P.surface, g.num_emissive_triangles, P.rngThread,
+                    prm.presampling != 0, P.sampleSetIdx);
                 if (P.inTranslucentMedium && (P.surface.trDepth > 0))
                 {
                     float3 extCoeff = -log3(P.surface.baseColor_Fr0_TrCol) / P.surface.trDepth;
@@ -666,6 +676,32 @@ int zro_pathtrace_render(const zro_scene* h, const zr_frame_constants* cb, const
     h->s.counters = Counters();
     RenderPathTracer(h->s, *cb, GBView(planes), *prm, final_rgba);
     if (counters) { counters->n_closest = h->s.counters.n_closest; counters->n_shadow = h->s.counters.n_shadow; }
+    return 0;
+}
+
+// K3 PresampleEmissives.hlsl:20-44: numSets * setSize samples, thread i seeds RNG::Init(i, frame)
+int zro_presample(zro_scene* h, uint32_t frame_num, uint32_t num_sets, uint32_t set_size, zr_presampled_tri* out)
+{
+    Scene& sc = h->s;
+    const uint32_t total = num_sets * set_size;
+    sc.sampleSets.resize(total); sc.sampleSetSize = set_size;
+    for (uint32_t i = 0; i < total; i++)
+    {
+        RNG rng = RNG::InitIdx(i, frame_num);
+        Light::AliasTableSample entry = Light::AliasTableSample::get(sc, (uint32_t)sc.emissives.size(), rng);
+        EmTri tri; tri.t = sc.emissives[entry.idx];
+        Light::EmissiveTriSample ls = Light::EmissiveTriSample::get(f3(0.0f), tri, rng, false);
+        float3 le = Light::Le_EmissiveTriangle(tri, ls.bary);
+        zr_presampled_tri& s = sc.sampleSets[i];
+        s.pos[0] = ls.pos.x; s.pos[1] = ls.pos.y; s.pos[2] = ls.pos.z;
+        Math::EncodeOct32(ls.normal, s.normal);
+        s.le[0] = zr_f32_to_f16(le.x); s.le[1] = zr_f32_to_f16(le.y); s.le[2] = zr_f32_to_f16(le.z);
+        s.bary[0] = Math::FloatToUNorm16(ls.bary.x); s.bary[1] = Math::FloatToUNorm16(ls.bary.y);
+        s.two_sided = tri.IsDoubleSided() ? 1 : 0;
+        s.idx = entry.idx; s.id = tri.t.id;
+        s.pdf = entry.pdf * ls.pdf;
+    }
+    if (out) std::memcpy(out, sc.sampleSets.data(), (size_t)total * sizeof(zr_presampled_tri));
     return 0;
 }
 

@@ -411,7 +411,7 @@ static inline float WaveSum64(const float* in)
     return v[0];
 }
 
-struct Globals { const Scene* sc; uint32_t numEmissives; int maxNumBounces; float alpha_min; };
+struct Globals { const Scene* sc; uint32_t numEmissives; int maxNumBounces; float alpha_min; bool presampled = false; uint32_t sampleSetIdx = 0; };
 
 // ---- ReSTIR_PT_NEE.hlsli:134-207
 static DirectLightingEstimate NEE_Bsdf(const Globals& g, float3 pos, float3 normal, const BSDF::ShadingData& surface, int nextBounce,
@@ -459,13 +459,23 @@ static DirectLightingEstimate NEE_Emissive(const Globals& g, float3 pos, float3 
 {
     DirectLightingEstimate ret = DirectLightingEstimate::Init();
     ret.lt = TYPE::EMISSIVE; ret.lobe = LOBE::ALL;
-    Light::AliasTableSample entry = Light::AliasTableSample::get(*g.sc, g.numEmissives, rng);
-    EmTri tri; tri.t = g.sc->emissives[entry.idx];
-    Light::EmissiveTriSample lightSample = Light::EmissiveTriSample::get(pos, tri, rng);
-    float3 le = Light::Le_EmissiveTriangle(tri, lightSample.bary);
-    const float lightPdf = entry.pdf * lightSample.pdf;
-    const uint32_t lightID = tri.t.id;
-    const bool twoSided = tri.IsDoubleSided();
+    Light::EmissiveTriSample lightSample; float3 le; float lightPdf; uint32_t lightID; bool twoSided;
+    if (g.presampled)       // USE_PRESAMPLED_SETS, ReSTIR_PT_NEE.hlsli:217-236
+    {
+        Light::PresampledLight pl = Light::SamplePresampledSet(*g.sc, g.sampleSetIdx, pos, rng);
+        lightSample.pos = pl.pos; lightSample.normal = pl.normal; le = pl.le; lightPdf = pl.pdf; lightID = pl.ID; twoSided = pl.twoSided;
+        rng.Uniform3D();    // "deterministic RNG state regardless of USE_PRESAMPLED_SETS"
+    }
+    else
+    {
+        Light::AliasTableSample entry = Light::AliasTableSample::get(*g.sc, g.numEmissives, rng);
+        EmTri tri; tri.t = g.sc->emissives[entry.idx];
+        lightSample = Light::EmissiveTriSample::get(pos, tri, rng);
+        le = Light::Le_EmissiveTriangle(tri, lightSample.bary);
+        lightPdf = entry.pdf * lightSample.pdf;
+        lightID = tri.t.id;
+        twoSided = tri.IsDoubleSided();
+    }
     const float t = length(lightSample.pos - pos);
     const float3 wi = (lightSample.pos - pos) / t;
     if ((dot(lightSample.normal, -wi) > 0) && (t > 0))
@@ -1090,7 +1100,8 @@ static void PathTracePass(const Scene& sc, const zr_frame_constants& g, const GB
             rd.ComputeUVDifferentials(dpdx, dpdy, triDiffs.dpdu, triDiffs.dpdv);
             rd.UpdateRays(ps.pos, ps.normal, bsdfSample.wi, ps.surface.wo, triDiffs, dpdx, dpdy, dot(bsdfSample.wi, ps.normal) < 0, ps.surface.eta);
             const uint32_t numSets = prm.presampling ? prm.num_sample_sets : 0;
-            (void)P.rngGroup.UniformUintBounded_Faster(numSets);
+            gl[l].presampled = prm.presampling != 0;
+            gl[l].sampleSetIdx = P.rngGroup.UniformUintBounded_Faster(numSets);
             // PathTrace prologue
             P.reconnection = Reconnection::Init();
             P.bounce = 0; P.throughput = bsdfSample.bsdfOverPdf;

@@ -76,6 +76,8 @@ struct Scene
     std::vector<zr_material> materials;
     std::vector<zr_emissive_triangle> emissives;
     std::vector<zr_alias_entry> alias;
+    std::vector<zr_presampled_tri> sampleSets;   // K3 output (PresampleEmissives.hlsl), numSets x setSize
+    uint32_t sampleSetSize = 0;
     std::vector<uint16_t> rho;
     RhoLUT rhoLUT;
     std::vector<WorldTri> tris;          // global triangle order = instance order, then primitive order
@@ -492,6 +494,20 @@ struct EmissiveTriSample
         return ret;
     }
 };
+
+// LightSource.hlsli:99-106 + the decode every USE_PRESAMPLED_SETS branch repeats (ReSTIR_GI_NEE.hlsli:68-85, ReSTIR_PT_NEE.hlsli:217-236)
+struct PresampledLight { float3 pos, normal, le; float pdf; uint32_t idx, ID; bool twoSided; };
+static inline PresampledLight SamplePresampledSet(const Scene& sc, uint32_t sampleSetIdx, float3 shadingPos, RNG& rng)
+{
+    uint32_t u = rng.UniformUintBounded_Faster(sc.sampleSetSize);
+    const zr_presampled_tri& t = sc.sampleSets[(size_t)sampleSetIdx * sc.sampleSetSize + u];
+    PresampledLight r;
+    r.pos = f3(t.pos); r.normal = Math::DecodeOct32(t.normal);
+    r.le = f3(zr_f16_to_f32(t.le[0]), zr_f16_to_f32(t.le[1]), zr_f16_to_f32(t.le[2]));
+    r.pdf = t.pdf; r.idx = t.idx; r.ID = t.id; r.twoSided = t.two_sided != 0;
+    if (r.twoSided && dot(shadingPos - r.pos, r.normal) < 0) r.normal *= -1.0f;
+    return r;
+}
 
 // LightSource.hlsli:202-223 (emissive textures: out of scope this round, factor * strength only)
 static inline float3 Le_EmissiveTriangle(const EmTri& tri, float2 bary)

@@ -20,7 +20,7 @@ struct HxScene
 {
     std::vector<zr_vertex> vertices; std::vector<uint32_t> indices; std::vector<zr_mesh_instance> instances;
     std::vector<zr_material> materials; std::vector<zr_emissive_triangle> emissives; std::vector<zr_alias_entry> alias;
-    std::vector<uint16_t> rho; BuiltBvh bvh; SceneView view;
+    std::vector<uint16_t> rho; BuiltBvh bvh; SceneView view; std::vector<zr_presampled_tri> sampleSets;
 };
 
 struct HxQueue
@@ -70,7 +70,7 @@ HxScene* zhx_scene_create(const zr_scene_desc* d)
     s->bvh = b.Build(*d);
     SceneView& v = s->view;
     v.vertices = s->vertices.data(); v.indices = s->indices.data(); v.instances = s->instances.data(); v.materials = s->materials.data();
-    v.emissives = s->emissives.data(); v.alias = nullptr; v.nodes = s->bvh.nodes.data(); v.tris = s->bvh.tris.data(); v.triMeta = s->bvh.meta.data();
+    v.emissives = s->emissives.data(); v.alias = nullptr; v.sampleSets = nullptr; v.sampleSetSize = 0; v.nodes = s->bvh.nodes.data(); v.tris = s->bvh.tris.data(); v.triMeta = s->bvh.meta.data();
     v.rho.data = s->rho.data(); v.rho.dx = d->rho_dim[0]; v.rho.dy = d->rho_dim[1]; v.rho.dz = d->rho_dim[2];
     v.numEmissives = d->num_emissives; v.numNodes = (uint32_t)s->bvh.nodes.size(); v.numTris = (uint32_t)s->bvh.tris.size();
     return s;
@@ -79,6 +79,15 @@ void zhx_scene_destroy(HxScene* s) { delete s; }
 void zhx_scene_set_alias(HxScene* s, const zr_alias_entry* e, uint32_t n) { s->alias.assign(e, e + n); s->view.alias = s->alias.data(); }
 void zhx_bvh_info(const HxScene* s, uint32_t* nodes, uint32_t* tris, uint32_t* depth)
 { *nodes = s->view.numNodes; *tris = s->view.numTris; *depth = s->bvh.maxDepth; }
+// K3 for frame `frame_num`
+void zhx_presample(HxScene* s, uint32_t frame_num, uint32_t num_sets, uint32_t set_size, zr_presampled_tri* out)
+{
+    const uint32_t total = num_sets * set_size;
+    s->sampleSets.resize(total);
+    for (uint32_t i = 0; i < total; i++) s->sampleSets[i] = PresampleEmissive(s->view, i, frame_num, s->view.numEmissives);
+    s->view.sampleSets = s->sampleSets.data(); s->view.sampleSetSize = set_size;
+    if (out) std::memcpy(out, s->sampleSets.data(), (size_t)total * sizeof(zr_presampled_tri));
+}
 void zhx_estimate_power(const HxScene* s, float* out) { for (size_t i = 0; i < s->emissives.size(); i++) out[i] = EstimateTriPower(s->emissives[i]); }
 
 static uint32_t g_tile_x0 = 0, g_tile_y0 = 0;

@@ -25,6 +25,7 @@ def lib():
         L.zhx_trace_closest.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]
         L.zhx_set_tile_origin.argtypes = [C.c_uint32, C.c_uint32]
         L.zhx_trace_any.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]
+        L.zhx_presample.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p]
         L.zhx_rpt_create.restype = C.c_void_p
         L.zhx_rpt_create.argtypes = [C.c_uint32, C.c_uint32]
         L.zhx_rpt_destroy.argtypes = [C.c_void_p]
@@ -60,6 +61,12 @@ class HostExecScene:
     def estimate_power(self):
         out = np.zeros(len(self.scene.emissives), np.float32)
         lib().zhx_estimate_power(self.h, out.ctypes.data)
+        return out
+
+    def presample(self, frame_num, num_sets, set_size):
+        from zetaray_amd import wire
+        out = np.zeros(num_sets * set_size, wire.PRESAMPLED_TRI)
+        lib().zhx_presample(self.h, frame_num, num_sets, set_size, out.ctypes.data)
         return out
 
     def gbuffer(self, cb, tile=None):

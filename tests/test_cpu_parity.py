@@ -244,3 +244,29 @@ def test_synthetic_scene_all_material_classes(synthetic_small, frame, nb, gb):
     fh, ch = hx.pathtrace(cb, gp, prm)
     assert co == ch
     assert np.array_equal(fo.view(np.uint32), fh.view(np.uint32))
+
+
+def test_presampled_light_sets(synthetic_small):
+    """K3 PresampleEmissives + the USE_PRESAMPLED_SETS NEE branches of K9 and K11: sets bit-exact, radiance bit-exact."""
+    from oracle import zro as _zro
+    from tests.hostexec import zhx as _zhx
+    sc, o, hx = synthetic_small
+    prm = wire.default_params()
+    prm.presampling, prm.num_sample_sets, prm.sample_set_size = 1, 16, 64
+    w, h = 64, 48
+    orpt, hrpt = _zro.OracleRPT(o, w, h), _zhx.HostExecRPT(hx, w, h)
+    for f in (1, 2, 3):
+        cb = scene_io.make_frame_constants(w, h, frame_num=f, num_emissives=len(sc.emissives), cam_pos=(0, 0, -3.5))
+        a, b = o.presample(f, 16, 64), hx.presample(f, 16, 64)
+        assert np.array_equal(a.view(np.uint8), b.view(np.uint8))
+        assert len(np.unique(a["idx"])) > 20 and (a["pdf"] > 0).all()
+        _, planes = o.gbuffer(cb)
+        want, cnt = o.pathtrace(cb, planes, prm)
+        got, cnt2 = hx.pathtrace(cb, planes, prm)
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32)) and cnt == cnt2
+        r1, r2 = orpt.render(cb, prm), hrpt.render(cb, prm)
+        assert np.array_equal(r1.view(np.uint32), r2.view(np.uint32)) and orpt.counters == hrpt.counters
+    # presampling changes the light draws: the image must differ from the alias-table path
+    p0 = wire.default_params()
+    want0, _ = o.pathtrace(cb, planes, p0)
+    assert not np.array_equal(want0, want)

@@ -254,3 +254,32 @@ def test_restir_pt_tile_split_with_halo_exchange_on_gpu(api, cornell_emissive, o
             img[y0:y0 + th, x0:x0 + tw] = t
         mism = int((img.view(np.uint32) != want.view(np.uint32)).any(axis=2).sum())
         assert mism == 0, f"frame {f}: {mism} pixels differ"
+
+
+def test_presampled_light_sets_on_gpu(api):
+    """K3 on the GPU + the presampled NEE branches of K9 and K11 (PreLighting regenerates the sets every frame)."""
+    from oracle import zro
+    sc = scene_io.make_synthetic_scene(num_tris=3000, num_emissive=1500, seed=11)
+    o = zro.OracleScene(sc, force_bvh=True)
+    prm = wire.default_params()
+    prm.presampling, prm.num_sample_sets, prm.sample_set_size = 1, 32, 128
+    w, h = 96, 64
+    rp = api.Renderer(sc, w, h, params=prm)
+    rr = api.Renderer(sc, w, h, params=prm, integrator=api.INTEGRATOR_RESTIR_PT)
+    orpt = zro.OracleRPT(o, w, h)
+    for f in (1, 2, 3):
+        cb = _frame(sc, w, h, f, cam_pos=(0, 0, -3.5))
+        o.presample(f, 32, 128)
+        rp.render_frame(cb)
+        _, planes = o.gbuffer(cb)
+        want, _ = o.pathtrace(cb, planes, prm)
+        assert np.array_equal(rp.final().view(np.uint32), want.view(np.uint32)), f"K9 frame {f}"
+        rr.render_frame(cb)
+        want2 = orpt.render(cb, prm)
+        assert np.array_equal(rr.final().view(np.uint32), want2.view(np.uint32)), f"ReSTIR PT frame {f}"
+    # a pass asked to use presampled sets that were never generated must fail loudly
+    r3 = api.Renderer(sc, w, h, params=wire.default_params())
+    r3.render_frame(cb)
+    r3.p_indirect.set_params(prm)
+    with pytest.raises(api.ZetaRayError):
+        r3.p_indirect.render(cb, r3.scene, r3.gbuffer)

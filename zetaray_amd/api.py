@@ -288,13 +288,14 @@ class Renderer:
         if tile_origin != (0, 0):
             self.gbuffer.set_tile_origin(*tile_origin)
         self.p_gbuffer = Pass(PASS_GBUFFER, width, height, device=device)
-        self.p_prelight = Pass(PASS_PRELIGHTING, width, height, device=device)
+        self.p_prelight = Pass(PASS_PRELIGHTING, width, height, device=device, params=params)
+        self._presampling = bool(params is not None and params.presampling)
         self.p_indirect = Pass(PASS_INDIRECT, width, height, integrator, device=device, params=params)
         self._alias_ready = False
 
     def render_frame(self, cb, stream=None):
         self.p_gbuffer.render(cb, self.scene, self.gbuffer, stream)
-        if not self._alias_ready:
+        if not self._alias_ready or self._presampling:      # presampled light sets are regenerated every frame (K3)
             self.p_prelight.render(cb, self.scene, None, stream)
             self._alias_ready = True
         self.p_indirect.render(cb, self.scene, self.gbuffer, stream)

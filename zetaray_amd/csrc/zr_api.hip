@@ -153,6 +153,12 @@ __global__ void __launch_bounds__(kBlock) k_pt_rr(SceneView sc, PtParams prm, Pa
         PtRussianRoulette(sc, prm, q, i, groupMax);
 }
 
+__global__ void k_presample(SceneView sc, uint32_t total, uint32_t frameNum, uint32_t numEmissives, zr_presampled_tri* out)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < total) out[i] = PresampleEmissive(sc, i, frameNum, numEmissives);
+}
+
 __global__ void k_estimate_power(const zr_emissive_triangle* em, uint32_t n, float* power)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -311,6 +317,7 @@ struct zr_scene
     DevBuf<zr_vertex> vertices; DevBuf<uint32_t> indices; DevBuf<zr_mesh_instance> instances; DevBuf<zr_material> materials;
     DevBuf<zr_emissive_triangle> emissives; DevBuf<zr_alias_entry> alias; DevBuf<BvhNode> nodes; DevBuf<BvhTri> tris;
     DevBuf<TriMeta> meta; DevBuf<uint16_t> rho;
+    DevBuf<zr_presampled_tri> sampleSets; uint32_t numSampleSets = 0;      // K3 output, refreshed by every PRELIGHTING render
     std::vector<zr_alias_entry> aliasHost;
     SceneView view{};
     uint32_t maxDepth = 0;
@@ -572,7 +579,7 @@ int zr_scene_create(int device, const zr_scene_desc* d, zr_scene** out)
 #undef UP
     SceneView& v = s->view;
     v.vertices = s->vertices.p; v.indices = s->indices.p; v.instances = s->instances.p; v.materials = s->materials.p;
-    v.emissives = s->emissives.p; v.alias = nullptr; v.nodes = s->nodes.p; v.tris = s->tris.p; v.triMeta = s->meta.p;
+    v.emissives = s->emissives.p; v.alias = nullptr; v.sampleSets = nullptr; v.sampleSetSize = 0; v.nodes = s->nodes.p; v.tris = s->tris.p; v.triMeta = s->meta.p;
     v.rho.data = s->rho.p; v.rho.dx = d->rho_dim[0]; v.rho.dy = d->rho_dim[1]; v.rho.dz = d->rho_dim[2];
     v.numEmissives = d->num_emissives; v.numNodes = (uint32_t)bvh.nodes.size(); v.numTris = (uint32_t)bvh.tris.size();
     *out = s;
@@ -741,7 +748,8 @@ int zr_pass_set_params(zr_pass* p, const zr_params* prm)
     if (!p || !prm) return Fail(ZR_ERR_INVALID_ARG, "null argument");
     if (prm->max_non_tr_bounces < 1 || prm->max_non_tr_bounces > 15 || prm->max_glossy_tr_bounces < 1 || prm->max_glossy_tr_bounces > 15)
         return Fail(ZR_ERR_INVALID_ARG, "bounce counts must be in 1..15");
-    if (prm->presampling) return Fail(ZR_ERR_UNSUPPORTED, "light presampling is not implemented yet");
+    if (prm->presampling && (prm->num_sample_sets == 0 || prm->sample_set_size == 0 || prm->num_sample_sets > 65535 || prm->sample_set_size > 65535))
+        return Fail(ZR_ERR_INVALID_ARG, "presampling needs 1..65535 sample sets of 1..65535 samples");
     p->params = *prm;
     return ZR_OK;
 }
@@ -760,10 +768,27 @@ static int RenderGBuffer(zr_pass* p, hipStream_t s, const zr_frame_constants* cb
     return ZR_OK;
 }
 
-static int RenderPreLighting(zr_pass* p, hipStream_t s, zr_scene* sc)
+// K3: PreLighting::Render presampling branch (PreLighting.cpp:369-411): every frame, seeded by FrameNum
+static int RenderPresample(zr_pass* p, hipStream_t s, const zr_frame_constants* cb, zr_scene* sc)
+{
+    const uint32_t total = p->params.num_sample_sets * p->params.sample_set_size;
+    if (sc->sampleSets.n != total) { int r = sc->sampleSets.Alloc(total); if (r) return r; }
+    sc->numSampleSets = p->params.num_sample_sets;
+    sc->view.sampleSets = sc->sampleSets.p; sc->view.sampleSetSize = p->params.sample_set_size;
+    TimerBegin(p, s, "presample_emissives");
+    hipLaunchKernelGGL(k_presample, dim3((total + 63) / 64), dim3(64), 0, s, sc->view, total, cb->frame_num, sc->view.numEmissives, sc->sampleSets.p);
+    TimerEnd(p, s);
+    HIP_TRY(hipGetLastError());
+    return ZR_OK;
+}
+
+static int RenderPreLighting(zr_pass* p, hipStream_t s, const zr_frame_constants* cb, zr_scene* sc)
 {
     const uint32_t n = sc->view.numEmissives;
     if (n == 0) return ZR_OK;
+    // the alias table is built once per emissive set (EmissiveTriangleAliasTable is only re-run when emissives change);
+    // zr_scene_set_alias_table(…, 0 entries) or a new scene forces a rebuild
+    if (sc->view.alias) return p->params.presampling ? RenderPresample(p, s, cb, sc) : ZR_OK;
     int r = p->power.Alloc(n);
     if (r) return r;
     TimerBegin(p, s, "estimate_power");
@@ -776,7 +801,8 @@ static int RenderPreLighting(zr_pass* p, hipStream_t s, zr_scene* sc)
     HIP_TRY(hipStreamSynchronize(s));
     std::vector<zr_alias_entry> table(n);
     BuildAliasTableHost(power, table.data(), 0);
-    return zr_scene_set_alias_table(sc, table.data(), n);
+    if ((r = zr_scene_set_alias_table(sc, table.data(), n))) return r;
+    return p->params.presampling ? RenderPresample(p, s, cb, sc) : ZR_OK;
 }
 
 // IndirectLighting::RenderReSTIR_PT (IndirectLighting.cpp:877-1004) + the Render() tail (:1006-1025).
@@ -871,6 +897,8 @@ static int RenderIndirect(zr_pass* p, hipStream_t s, const zr_frame_constants* c
     if (sc->view.numEmissives == 0) return Fail(ZR_ERR_UNSUPPORTED, "scenes without emissive triangles (sun/sky NEE) are not implemented yet");
     if (!sc->view.alias) return Fail(ZR_ERR_NOT_INITIALIZED, "emissive alias table missing: render the PRELIGHTING pass (or zr_scene_set_alias_table) first");
     if (cb->num_emissive_triangles != sc->view.numEmissives) return Fail(ZR_ERR_INVALID_ARG, "cbFrameConstants.NumEmissiveTriangles != scene");
+    if (p->params.presampling && (!sc->view.sampleSets || sc->numSampleSets != p->params.num_sample_sets || sc->view.sampleSetSize != p->params.sample_set_size))
+        return Fail(ZR_ERR_NOT_INITIALIZED, "presampled light sets missing or of another size: render the PRELIGHTING pass with the same presampling params first");
     if (p->integrator == ZR_INTEGRATOR_RESTIR_PT) return RenderReSTIR_PT(p, s, cb, sc, gb, stages);
     if (!(stages & ZR_STAGE_TEMPORAL)) return ZR_OK;      // single-stage integrators render in the first stage
     PtParams prm;
@@ -974,7 +1002,7 @@ int zr_pass_render_stage(zr_pass* p, void* stream, const zr_frame_constants* cb,
     switch (p->kind)
     {
     case ZR_PASS_GBUFFER: return (stages & ZR_STAGE_TEMPORAL) ? RenderGBuffer(p, s, cb, sc, gb) : ZR_OK;
-    case ZR_PASS_PRELIGHTING: return (stages & ZR_STAGE_TEMPORAL) ? RenderPreLighting(p, s, const_cast<zr_scene*>(sc)) : ZR_OK;
+    case ZR_PASS_PRELIGHTING: return (stages & ZR_STAGE_TEMPORAL) ? RenderPreLighting(p, s, cb, const_cast<zr_scene*>(sc)) : ZR_OK;
     case ZR_PASS_INDIRECT: return RenderIndirect(p, s, cb, sc, gb, stages);
     default: return Fail(ZR_ERR_UNSUPPORTED, "pass kind %d not implemented", p->kind);
     }

@@ -33,6 +33,8 @@ struct SceneView
     const zr_material* materials;
     const zr_emissive_triangle* emissives;
     const zr_alias_entry* alias;
+    const zr_presampled_tri* sampleSets;   // K3 output: numSampleSets x sampleSetSize (null until a PRELIGHTING pass presampled)
+    uint32_t sampleSetSize;
     const BvhNode* nodes;
     const BvhTri* tris;
     const TriMeta* triMeta;
@@ -214,6 +216,21 @@ ZR_HD V3 EmV2(const zr_emissive_triangle& t)
     V3 d = DecodeUnitVector(v2((float)t.v0v2[0] / 65535.0f, (float)t.v0v2[1] / 65535.0f));
     return mad(zr_f16_to_f32(t.edge_lengths[1]), d, v3p(t.vtx0));
 }
+// Light::SamplePresampledSet (LightSource.hlsli:99-106) + the decode of the USE_PRESAMPLED_SETS branches
+// (ReSTIR_GI_NEE.hlsli:68-85, ReSTIR_PT_NEE.hlsli:217-236)
+struct PresampledLight { V3 pos, normal, le; float pdf; uint32_t idx, ID; bool twoSided; };
+ZR_HD PresampledLight SamplePresampledSet(const SceneView& sc, uint32_t sampleSetIdx, V3 shadingPos, Rng& rng)
+{
+    uint32_t u = rng.UniformUintBounded_Faster(sc.sampleSetSize);
+    const zr_presampled_tri t = sc.sampleSets[(size_t)sampleSetIdx * sc.sampleSetSize + u];
+    PresampledLight r;
+    r.pos = v3p(t.pos); r.normal = DecodeOct32(t.normal);
+    r.le = v3(zr_f16_to_f32(t.le[0]), zr_f16_to_f32(t.le[1]), zr_f16_to_f32(t.le[2]));
+    r.pdf = t.pdf; r.idx = t.idx; r.ID = t.id; r.twoSided = t.two_sided != 0;
+    if (r.twoSided && dot(shadingPos - r.pos, r.normal) < 0) r.normal = r.normal * -1.0f;
+    return r;
+}
+
 // Le_EmissiveTriangle, LightSource.hlsli:202-223 (emissive textures not bound)
 ZR_HD V3 EmLe(const zr_emissive_triangle& t)
 {

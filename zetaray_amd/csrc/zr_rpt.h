@@ -367,7 +367,7 @@ ZR_HD Reservoir Load_NonReconnection(const ResPlanes& p, size_t i)
 { Reservoir r = InitReservoir(); r.UnpackMetadata(p.A[i]); r.w_sum = p.B[2 * i]; r.W = p.B[2 * i + 1]; return r; }
 
 // cnt: this lane's ray counters {closest-hit queries, shadow / visibility queries} (never null)
-struct Globals { const SceneView* sc; uint32_t numEmissives; int maxNumBounces; float alpha_min; uint32_t* stack; uint32_t* cnt; };
+struct Globals { const SceneView* sc; uint32_t numEmissives; int maxNumBounces; float alpha_min; uint32_t* stack; uint32_t* cnt; bool presampled; uint32_t sampleSetIdx; };
 
 // ---- ray queries (inline traversal)
 struct HitEm { bool hit; float t; uint32_t mesh, prim, emissiveTriIdx; float bu, bv; };
@@ -469,26 +469,37 @@ ZR_HD Direct NEE_Emissive(const Globals& g, V3 pos, V3 normal, Surface surface, 
     const SceneView& sc = *g.sc;
     Direct ret = InitDirect();
     ret.lt = LT_EMISSIVE; ret.lobe = LOBE_ALL;
-    // Light::AliasTableSample::get, LightSource.hlsli:72-98
-    uint32_t u0 = rng.UniformUintBounded(g.numEmissives);
-    const zr_alias_entry ae = sc.alias[u0];
-    uint32_t lidx; float lpdfSrc;
-    if (rng.Uniform() < ae.p_curr) { lpdfSrc = ae.cached_p_orig; lidx = u0; }
-    else { lpdfSrc = ae.cached_p_alias; lidx = ae.alias; }
-    const zr_emissive_triangle em = sc.emissives[lidx];
-    // Light::EmissiveTriSample::get, LightSource.hlsli:109-137
-    V2 u = rng.Uniform2D();
-    V2 bary = UniformSampleTriangle(u);
-    const V3 vtx0 = v3p(em.vtx0), vtx1 = EmV1(em), vtx2 = EmV2(em);
-    V3 lpos = (1.0f - bary.x - bary.y) * vtx0 + bary.x * vtx1 + bary.y * vtx2;
-    V3 ln = cross(vtx1 - vtx0, vtx2 - vtx0);
-    bool normalIs0 = dot(ln, ln) == 0;
-    float twoArea = length(ln);
-    float lpdfPos = normalIs0 ? 0.0f : 2.0f / twoArea;
-    ln = normalIs0 ? ln : ln / twoArea;
-    ln = EmDoubleSided(em) && dot(pos - lpos, ln) < 0 ? -ln : ln;
-    V3 le = EmLe(em);
-    const float lightPdf = lpdfSrc * lpdfPos;
+    V3 lpos, ln, le; float lightPdf; uint32_t lightID; bool twoSided;
+    if (g.presampled)       // USE_PRESAMPLED_SETS, ReSTIR_PT_NEE.hlsli:217-236
+    {
+        PresampledLight pl = SamplePresampledSet(sc, g.sampleSetIdx, pos, rng);
+        lpos = pl.pos; ln = pl.normal; le = pl.le; lightPdf = pl.pdf; lightID = pl.ID; twoSided = pl.twoSided;
+        rng.Uniform(); rng.Uniform(); rng.Uniform();       // "deterministic RNG state regardless of USE_PRESAMPLED_SETS"
+    }
+    else
+    {
+        // Light::AliasTableSample::get, LightSource.hlsli:72-98
+        uint32_t u0 = rng.UniformUintBounded(g.numEmissives);
+        const zr_alias_entry ae = sc.alias[u0];
+        uint32_t lidx; float lpdfSrc;
+        if (rng.Uniform() < ae.p_curr) { lpdfSrc = ae.cached_p_orig; lidx = u0; }
+        else { lpdfSrc = ae.cached_p_alias; lidx = ae.alias; }
+        const zr_emissive_triangle em = sc.emissives[lidx];
+        // Light::EmissiveTriSample::get, LightSource.hlsli:109-137
+        V2 u = rng.Uniform2D();
+        V2 bary = UniformSampleTriangle(u);
+        const V3 vtx0 = v3p(em.vtx0), vtx1 = EmV1(em), vtx2 = EmV2(em);
+        lpos = (1.0f - bary.x - bary.y) * vtx0 + bary.x * vtx1 + bary.y * vtx2;
+        ln = cross(vtx1 - vtx0, vtx2 - vtx0);
+        bool normalIs0 = dot(ln, ln) == 0;
+        float twoArea = length(ln);
+        float lpdfPos = normalIs0 ? 0.0f : 2.0f / twoArea;
+        ln = normalIs0 ? ln : ln / twoArea;
+        ln = EmDoubleSided(em) && dot(pos - lpos, ln) < 0 ? -ln : ln;
+        le = EmLe(em);
+        lightPdf = lpdfSrc * lpdfPos;
+        lightID = em.id; twoSided = EmDoubleSided(em);
+    }
     const float t = length(lpos - pos);
     const V3 wi = (lpos - pos) / t;
     if ((dot(ln, -wi) > 0) && (t > 0))
@@ -497,7 +508,7 @@ ZR_HD Direct NEE_Emissive(const Globals& g, V3 pos, V3 normal, Surface surface, 
         surface.SetWi(wi, normal);
         V3 ld = le * Unified(sc.rho, surface).f * dwdA;
         if (dot(ld, ld) > 0)
-            ld = ld * (VisibilitySegmentApprox(g, pos, wi, t, normal, em.id, surface.Transmissive()) ? 1.0f : 0.0f);
+            ld = ld * (VisibilitySegmentApprox(g, pos, wi, t, normal, lightID, surface.Transmissive()) ? 1.0f : 0.0f);
         float bsdfPdf = 0;
         if (dot(ld, ld) > 0)
         {
@@ -505,8 +516,8 @@ ZR_HD Direct NEE_Emissive(const Globals& g, V3 pos, V3 normal, Surface surface, 
             bsdfPdf *= dwdA;
         }
         ret.ld = PowerHeuristic(lightPdf, bsdfPdf, ld, 1.0f, 1.0f);
-        ret.le = le; ret.wi = wi; ret.pdf_solidAngle = lightPdf / dwdA; ret.dwdA = dwdA; ret.ID = em.id;
-        ret.pos = lpos; ret.normal = ln; ret.pdf_light = lightPdf; ret.twoSided = EmDoubleSided(em);
+        ret.le = le; ret.wi = wi; ret.pdf_solidAngle = lightPdf / dwdA; ret.dwdA = dwdA; ret.ID = lightID;
+        ret.pos = lpos; ret.normal = ln; ret.pdf_light = lightPdf; ret.twoSided = twoSided;
     }
     return ret;
 }
@@ -716,7 +727,7 @@ struct PTLane
     V3 pos, normal; Surface surface; BsdfSample bs;
     Rng rngReplay, rngThread, rngGroup;
     Reconnection rc; Reservoir r; V3 li, throughput, throughput_k; int bounce; PrevHit prevHit; float eta_curr, eta_next;
-    bool inMedium; HitEm nextHit; uint32_t seed_replay; int maxNumBounces;
+    bool inMedium; HitEm nextHit; uint32_t seed_replay, sampleSetIdx; int maxNumBounces;
     HitInfo hit; V3 tr; float prevPdf; uint32_t prevLobe; int pathVertex;
 };
 
@@ -750,7 +761,7 @@ ZR_HD void PtInitLane(const SceneView& sc, const zr_frame_constants& g, const GB
     P.r = InitReservoir(); P.li = v3(0.0f);
     BsdfSample bs = SampleBSDF(sc.rho, ps.normal, ps.surface, P.rngReplay);
     if (dot(bs.bsdfOverPdf, bs.bsdfOverPdf) == 0) return;
-    (void)P.rngGroup.UniformUintBounded_Faster(prm.numSampleSets);
+    P.sampleSetIdx = P.rngGroup.UniformUintBounded_Faster(prm.numSampleSets);
     P.rc = InitReconnection();
     P.bounce = 0; P.throughput = bs.bsdfOverPdf;
     P.prevHit.alpha_lobe = LobeAlpha(ps.surface, bs.lobe); P.prevHit.lobe = bs.lobe; P.prevHit.wi = bs.wi; P.prevHit.pdf = bs.pdf;
@@ -759,6 +770,7 @@ ZR_HD void PtInitLane(const SceneView& sc, const zr_frame_constants& g, const GB
     P.inMedium = P.eta_curr != kEtaAir;
     P.pos = ps.pos; P.normal = ps.normal; P.surface = ps.surface; P.bs = bs; P.eta_next = ps.eta_next;
     Globals gl; gl.sc = &sc; gl.numEmissives = g.num_emissive_triangles; gl.maxNumBounces = P.maxNumBounces; gl.alpha_min = prm.alpha_min; gl.stack = stack; gl.cnt = cnt;
+    gl.presampled = prm.numSampleSets != 0; gl.sampleSetIdx = P.sampleSetIdx;
     P.nextHit = FindClosestEm(gl, ps.pos, ps.normal, bs.wi, ps.surface.Transmissive());
     P.active = true;
 }
@@ -768,6 +780,7 @@ ZR_HD void PtPhaseA(const SceneView& sc, const zr_frame_constants& g, const RptP
     P.atRR = false;
     if (!P.active) return;
     Globals gl; gl.sc = &sc; gl.numEmissives = g.num_emissive_triangles; gl.maxNumBounces = P.maxNumBounces; gl.alpha_min = prm.alpha_min; gl.stack = stack; gl.cnt = cnt;
+    gl.presampled = prm.numSampleSets != 0; gl.sampleSetIdx = P.sampleSetIdx;
     P.pathVertex = P.bounce + 2;
     if (!P.nextHit.hit) { P.active = false; return; }
     P.hit.t = P.nextHit.t;
@@ -1104,7 +1117,7 @@ struct RptFrame
 
 ZR_HD Globals MakeGlobals(const RptFrame& F, const zr_frame_constants& g, bool transmissive, uint32_t* stack, uint32_t* cnt)
 {
-    Globals gl; gl.sc = &F.sc; gl.numEmissives = g.num_emissive_triangles; gl.alpha_min = F.prm.alpha_min; gl.stack = stack; gl.cnt = cnt;
+    Globals gl; gl.sc = &F.sc; gl.numEmissives = g.num_emissive_triangles; gl.alpha_min = F.prm.alpha_min; gl.stack = stack; gl.cnt = cnt; gl.presampled = false; gl.sampleSetIdx = 0;
     gl.maxNumBounces = transmissive ? (int)F.prm.maxGlossyTrBounces : (int)F.prm.maxNonTrBounces;
     return gl;
 }

@@ -205,7 +205,7 @@ struct PathQueue
     U4* s0;   // pid, rngThread, rngGroup, flags
     F4* s1;   // li.xyz, eta_curr
     F4* s2;   // throughput.xyz (already multiplied by the continuation's bsdfOverPdf), misPdf
-    F4* s3;   // pos.xyz (vertex the continuation ray leaves), unused
+    F4* s3;   // pos.xyz (vertex the continuation ray leaves), sampleSetIdx bits (presampled light sets)
     F4* s4;   // wi.xyz (continuation direction), unused
     F4* s5;   // thrNEE.xyz (throughput at the pending vertex), unused
     F4* s6;   // misF.xyz, unused
@@ -241,7 +241,7 @@ struct PtParams
 {
     uint32_t maxNonTrBounces, maxGlossyTrBounces;
     uint32_t russianRoulette;
-    uint32_t numSampleSets;      // 0 when light presampling is off
+    uint32_t numSampleSets;      // 0 when light presampling is off (then NEE draws from the alias table)
     uint32_t accumulate;         // g.accumulate && g.camera_static
     uint32_t tileW, groupsX;     // tile width in pixels / in 8x8 groups (group key of the RR reduction)
 };
@@ -355,7 +355,7 @@ ZR_HD void PtInitPixel(const SceneView& sc, const zr_frame_constants& g, const G
     Rng rngGroup = Rng::Init((x >> 3) ^ 61u, (y >> 3) ^ 61u, g.frame_num);
     Rng rngThread = Rng::Init(x ^ 511u, y ^ 31u, g.frame_num);
     const uint32_t maxB = f_tr ? prm.maxGlossyTrBounces : prm.maxNonTrBounces;
-    (void)rngGroup.UniformUintBounded_Faster(prm.numSampleSets);     // sampleSetIdx (one group-RNG draw, always)
+    const uint32_t sampleSetIdx = rngGroup.UniformUintBounded_Faster(prm.numSampleSets);     // one group-RNG draw, always
 
     BsdfSample bs = SampleBSDF(sc.rho, normal, surface, rngThread);
     F4 ro, rd;
@@ -373,7 +373,7 @@ ZR_HD void PtInitPixel(const SceneView& sc, const zr_frame_constants& g, const G
     out.s0.w = 0u | (tr0 ? PF_IN_MEDIUM : 0u) | (maxB << PF_MAXB_SHIFT);
     out.s1 = f4(v3(0.0f), tr0 ? eta_next : kEtaAir);
     out.s2 = f4(v3(1.0f), 0.0f);
-    out.s3 = f4(pos, 0.0f);
+    out.s3 = f4(pos, zr_asfloat(sampleSetIdx));
     out.s4 = f4(bs.wi, 0.0f);
     out.s5 = f4(v3(0.0f), 0.0f); out.s6 = out.s5; out.s7 = out.s5; out.s8 = out.s5;
     out.rayC_o = ro; out.rayC_d = rd;
@@ -394,7 +394,7 @@ ZR_HD void zr_atomic_max_u32(uint32_t* p, uint32_t v)
 // Tail of the PathTrace loop body (PathTracing.hlsli:74-95): sample the continuation direction, emit the C ray,
 // update throughput / medium bookkeeping speculatively (they only matter if the ray hits).
 ZR_HD void PtContinue(const SceneView& sc, V3 n, const Surface& surface, V3 hitPos, float eta_curr, float eta_next, bool inMedium,
-    V3 thr, uint32_t bounce, uint32_t maxB, uint32_t nflags, uint32_t pid, Rng& rngT, Rng& rngG, V3 li, PathOut& out)
+    V3 thr, uint32_t bounce, uint32_t maxB, uint32_t nflags, uint32_t pid, Rng& rngT, Rng& rngG, V3 li, float setIdxBits, PathOut& out)
 {
     BsdfSample bs2 = InitBsdfSample();
     F4 cro = f4(v3(0.0f), 0.0f), crd = f4(v3(0.0f), -1.0f);
@@ -414,7 +414,7 @@ ZR_HD void PtContinue(const SceneView& sc, V3 n, const Surface& surface, V3 hitP
     out.s0.w = nflags | (bounce & PF_BOUNCE_MASK) | (inMedium ? PF_IN_MEDIUM : 0u) | (maxB << PF_MAXB_SHIFT);
     out.s1 = f4(li, eta_curr);
     out.s2 = f4(thr, out.s2.w);
-    out.s3 = f4(hitPos, 0.0f);
+    out.s3 = f4(hitPos, setIdxBits);
     out.s4 = f4(bs2.wi, 0.0f);
     out.rayC_o = cro; out.rayC_d = crd;
 }
@@ -479,6 +479,7 @@ ZR_HD void PtShadePath(const SceneView& sc, const zr_frame_constants& g, const P
     const U4 hc = in.hitC[i];
     if (hc.w == kInvalidTri) { WriteFinal(finalRGBA, pid, li, fb, prm.accumulate); return; }
     const V3 pos0 = xyz(in.s3[i]);
+    const float setIdxBits = in.s3[i].w;
     const V3 wiC = xyz(in.s4[i]);
     V3 thr = xyz(in.s2[i]);
     const float t = zr_asfloat(hc.x);
@@ -520,27 +521,36 @@ ZR_HD void PtShadePath(const SceneView& sc, const zr_frame_constants& g, const P
     V3 ldLight = v3(0.0f);
     for (int s_l = 0; s_l < numLightSamples; s_l++)
     {
-        // Light::AliasTableSample::get, LightSource.hlsli:72-98
-        uint32_t u0 = rngT.UniformUintBounded(g.num_emissive_triangles);
-        const zr_alias_entry ae = sc.alias[u0];
-        uint32_t lidx; float lpdfSrc;
-        if (rngT.Uniform() < ae.p_curr) { lpdfSrc = ae.cached_p_orig; lidx = u0; }
-        else { lpdfSrc = ae.cached_p_alias; lidx = ae.alias; }
-        const zr_emissive_triangle em = sc.emissives[lidx];
-        // Light::EmissiveTriSample::get, LightSource.hlsli:109-137
-        V2 u = rngT.Uniform2D();
-        V2 bary = UniformSampleTriangle(u);
-        const V3 vtx0 = v3p(em.vtx0), vtx1 = EmV1(em), vtx2 = EmV2(em);
-        V3 lpos = (1.0f - bary.x - bary.y) * vtx0 + bary.x * vtx1 + bary.y * vtx2;
-        V3 ln = cross(vtx1 - vtx0, vtx2 - vtx0);
-        bool normalIs0 = dot(ln, ln) == 0;
-        float twoArea = length(ln);
-        float lpdfPos = normalIs0 ? 0.0f : 2.0f / twoArea;
-        ln = normalIs0 ? ln : ln / twoArea;
-        ln = EmDoubleSided(em) && dot(hitPos - lpos, ln) < 0 ? -ln : ln;
-
-        V3 le = EmLe(em);
-        const float lightPdf = lpdfSrc * lpdfPos;
+        V3 lpos, ln, le; float lightPdf; uint32_t lightID;
+        if (prm.numSampleSets)      // USE_PRESAMPLED_SETS (ReSTIR_GI_NEE.hlsli:68-85)
+        {
+            PresampledLight pl = SamplePresampledSet(sc, zr_asuint(setIdxBits), hitPos, rngT);
+            lpos = pl.pos; ln = pl.normal; le = pl.le; lightPdf = pl.pdf; lightID = pl.ID;
+        }
+        else
+        {
+            // Light::AliasTableSample::get, LightSource.hlsli:72-98
+            uint32_t u0 = rngT.UniformUintBounded(g.num_emissive_triangles);
+            const zr_alias_entry ae = sc.alias[u0];
+            uint32_t lidx; float lpdfSrc;
+            if (rngT.Uniform() < ae.p_curr) { lpdfSrc = ae.cached_p_orig; lidx = u0; }
+            else { lpdfSrc = ae.cached_p_alias; lidx = ae.alias; }
+            const zr_emissive_triangle em = sc.emissives[lidx];
+            // Light::EmissiveTriSample::get, LightSource.hlsli:109-137
+            V2 u = rngT.Uniform2D();
+            V2 bary = UniformSampleTriangle(u);
+            const V3 vtx0 = v3p(em.vtx0), vtx1 = EmV1(em), vtx2 = EmV2(em);
+            lpos = (1.0f - bary.x - bary.y) * vtx0 + bary.x * vtx1 + bary.y * vtx2;
+            ln = cross(vtx1 - vtx0, vtx2 - vtx0);
+            bool normalIs0 = dot(ln, ln) == 0;
+            float twoArea = length(ln);
+            float lpdfPos = normalIs0 ? 0.0f : 2.0f / twoArea;
+            ln = normalIs0 ? ln : ln / twoArea;
+            ln = EmDoubleSided(em) && dot(hitPos - lpos, ln) < 0 ? -ln : ln;
+            le = EmLe(em);
+            lightPdf = lpdfSrc * lpdfPos;
+            lightID = em.id;
+        }
         const float tl = length(lpos - hitPos);
         const V3 wi = (lpos - hitPos) / tl;
         if (dot(ln, -wi) > 0)
@@ -552,8 +562,8 @@ ZR_HD void PtShadePath(const SceneView& sc, const zr_frame_constants& g, const P
             if (dot(le, le) > 0)
             {
                 F4 ro, rd;
-                if (MakeSegmentRay(hitPos, wi, tl, n, em.id, surface.Transmissive(), &ro, &rd))
-                { out.rayS_o = ro; out.rayS_d = rd; out.sLightID = em.id; nflags |= PF_S_RAY; }
+                if (MakeSegmentRay(hitPos, wi, tl, n, lightID, surface.Transmissive(), &ro, &rd))
+                { out.rayS_o = ro; out.rayS_d = rd; out.sLightID = lightID; nflags |= PF_S_RAY; }
                 else occludedEarly = true;
             }
             float bsdfPdf = BSDFSamplerPdf(sc.rho, n, surface, wi, rngT);
@@ -573,7 +583,7 @@ ZR_HD void PtShadePath(const SceneView& sc, const zr_frame_constants& g, const P
 
     out.alive = true;
     out.s1 = f4(li, eta_curr);
-    out.s3 = f4(hitPos, 0.0f);
+    out.s3 = f4(hitPos, setIdxBits);
     if (bounce >= (maxB - 1))
     {
         // PathTracing.hlsli:53-54: the path ends here; one more round drains the pending NEE of this vertex
@@ -599,7 +609,7 @@ ZR_HD void PtShadePath(const SceneView& sc, const zr_frame_constants& g, const P
         out.rayC_d = f4(v3(0.0f), -1.0f);
         return;
     }
-    PtContinue(sc, n, surface, hitPos, eta_curr, eta_next, inMedium, thr, bounce, maxB, nflags, pid, rngT, rngG, li, out);
+    PtContinue(sc, n, surface, hitPos, eta_curr, eta_next, inMedium, thr, bounce, maxB, nflags, pid, rngT, rngG, li, setIdxBits, out);
 }
 
 // Russian-roulette stage for the parked path in slot `i` of `q` (in place): PathTracing.hlsli:62-72, then the loop tail.
@@ -630,6 +640,7 @@ ZR_HD void PtRussianRoulette(const SceneView& sc, const PtParams& prm, const Pat
     const F4 s1 = q.s1[i];
     const float eta_curr = s1.w;
     const V3 hitPos = xyz(q.s3[i]), wiC = xyz(q.s4[i]);
+    const float setIdxBits = q.s3[i].w;
     const F4 rec = q.rayC_o[i];
     const uint32_t tri = zr_asuint(rec.z);
     const TriMeta tm = sc.triMeta[tri];
@@ -639,7 +650,7 @@ ZR_HD void PtRussianRoulette(const SceneView& sc, const PtParams& prm, const Pat
     GetMaterialData(sc, -wiC, eta_curr, hit, surface, eta_mat);        // succeeded once already in PtShadePath
     const float eta_next = eta_curr == kEtaAir ? eta_mat : kEtaAir;
     PathOut po; po.s2.w = s2.w;
-    PtContinue(sc, hit.normal, surface, hitPos, eta_curr, eta_next, inMedium, thr, bounce, maxB, nflags, pid, rngT, rngG, xyz(s1), po);
+    PtContinue(sc, hit.normal, surface, hitPos, eta_curr, eta_next, inMedium, thr, bounce, maxB, nflags, pid, rngT, rngG, xyz(s1), setIdxBits, po);
     q.s0[i] = po.s0; q.s1[i] = po.s1; q.s2[i] = po.s2; q.s4[i] = po.s4; q.rayC_o[i] = po.rayC_o; q.rayC_d[i] = po.rayC_d;
 }
 
@@ -658,6 +669,37 @@ ZR_HD uint32_t TraceSegmentRay(const SceneView& sc, F4 ro, F4 rd, uint32_t light
     if (h.tri == kInvalidTri) return 1u;
     const TriMeta tm = sc.triMeta[h.tri];
     return TriID(tm.mesh, tm.prim) == lightID ? 1u : 0u;
+}
+
+// K3: PresampleEmissives.hlsl:20-44 -- sample i of numSets * setSize
+ZR_HD zr_presampled_tri PresampleEmissive(const SceneView& sc, uint32_t i, uint32_t frameNum, uint32_t numEmissives)
+{
+    Rng rng; rng.s = zr_pcg(i + zr_pcg(frameNum));                 // RNG::Init(idx, frame), Sampling.hlsli:52-60
+    uint32_t u0 = rng.UniformUintBounded(numEmissives);
+    const zr_alias_entry ae = sc.alias[u0];
+    uint32_t lidx; float lpdfSrc;
+    if (rng.Uniform() < ae.p_curr) { lpdfSrc = ae.cached_p_orig; lidx = u0; }
+    else { lpdfSrc = ae.cached_p_alias; lidx = ae.alias; }
+    const zr_emissive_triangle em = sc.emissives[lidx];
+    V2 bary = UniformSampleTriangle(rng.Uniform2D());
+    const V3 vtx0 = v3p(em.vtx0), vtx1 = EmV1(em), vtx2 = EmV2(em);
+    V3 lpos = (1.0f - bary.x - bary.y) * vtx0 + bary.x * vtx1 + bary.y * vtx2;
+    V3 ln = cross(vtx1 - vtx0, vtx2 - vtx0);
+    bool normalIs0 = dot(ln, ln) == 0;
+    float twoArea = length(ln);
+    float lpdfPos = normalIs0 ? 0.0f : 2.0f / twoArea;
+    ln = normalIs0 ? ln : ln / twoArea;                            // reverseNormalIfTwoSided == false
+    V3 le = EmLe(em);
+    zr_presampled_tri s;
+    s.pos[0] = lpos.x; s.pos[1] = lpos.y; s.pos[2] = lpos.z;
+    V2 e = EncodeUnitVector(ln);
+    s.normal[0] = (uint16_t)FloatToUNorm16(e.x); s.normal[1] = (uint16_t)FloatToUNorm16(e.y);
+    s.le[0] = zr_f32_to_f16(le.x); s.le[1] = zr_f32_to_f16(le.y); s.le[2] = zr_f32_to_f16(le.z);
+    s.bary[0] = (uint16_t)FloatToUNorm16(bary.x); s.bary[1] = (uint16_t)FloatToUNorm16(bary.y);
+    s.two_sided = EmDoubleSided(em) ? 1 : 0;
+    s.idx = lidx; s.id = em.id;
+    s.pdf = lpdfSrc * lpdfPos;
+    return s;
 }
 
 // K2: EstimateTriEmissivePower.hlsl:29-79 (untextured branch)

@@ -121,7 +121,7 @@ class TiledRestirPT:
     def stage_temporal(self, cb):
         api, r = self.api, self.r
         r.p_gbuffer.render(cb, r.scene, r.gbuffer)
-        if not r._alias_ready:
+        if not r._alias_ready or r._presampling:
             r.p_prelight.render(cb, r.scene, None)
             r._alias_ready = True
         r.p_indirect.render_stage(cb, r.scene, r.gbuffer, api.STAGE_TEMPORAL)

@@ -32,6 +32,10 @@ assert EMISSIVE_TRI.itemsize == 48
 ALIAS_ENTRY = np.dtype([("cached_p_orig", "<f4"), ("cached_p_alias", "<f4"), ("p_curr", "<f4"), ("alias", "<u4")])
 assert ALIAS_ENTRY.itemsize == 16
 
+PRESAMPLED_TRI = np.dtype([("pos", "<f4", 3), ("normal", "<u2", 2), ("pdf", "<f4"), ("id", "<u4"), ("idx", "<u4"), ("bary", "<u2", 2),
+                           ("le", "<u2", 3), ("two_sided", "<u2")])
+assert PRESAMPLED_TRI.itemsize == 40
+
 FRAME_CONSTANTS = np.dtype([
     ("curr_view", "<f4", 12), ("prev_view", "<f4", 12), ("curr_view_inv", "<f4", 12), ("prev_view_inv", "<f4", 12),
     ("curr_view_proj", "<f4", 16), ("prev_view_proj", "<f4", 16),
