@@ -112,9 +112,11 @@ def test_errors_are_loud(api, cornell_emissive):
     with pytest.raises(api.ZetaRayError):
         r.p_gbuffer.render(cb, r.scene, r.gbuffer)         # G-buffer tile larger than the render target
     p = wire.default_params()
-    p.presampling = 1
+    p.max_non_tr_bounces = 99
     with pytest.raises(api.ZetaRayError):
-        r.p_indirect.set_params(p)                          # not implemented -> explicit error, never silent
+        r.p_indirect.set_params(p)                          # invalid parameter -> explicit error, never silent
+    with pytest.raises(api.ZetaRayError):
+        api.Pass(api.PASS_INDIRECT, 32, 32, integrator=api.INTEGRATOR_RESTIR_GI)   # not implemented yet -> explicit error
 
 
 def test_russian_roulette_and_materials_on_gpu(api):
