@@ -89,6 +89,7 @@ def main():
     ap.add_argument("--scene", default=os.path.join(ROOT, "tests", "golden", "cornell_emissive.npz"))
     ap.add_argument("--no-final-halo", action="store_true",
                     help="skip the post-frame halo exchange (exact for a static camera, which this bench uses)")
+    ap.add_argument("--direct", action="store_true", help="also run the ReSTIR DI (emissive) pass every frame (N = 1)")
     ap.add_argument("--integrator", choices=["restir_pt", "pt"], default="restir_pt",
                     help="restir_pt = K11-K16 (BASELINE metric); pt = K9 unidirectional path tracer")
     args = ap.parse_args()
@@ -124,6 +125,10 @@ def main():
     else:
         r = api.Renderer(sc, tw, th, device=local_rank, params=prm, tile_origin=(x0, y0), integrator=api.INTEGRATOR_PATH_TRACING)
 
+    if args.direct:
+        assert world == 1, "--direct: the DI pass has no tile split yet"
+        r.enable_direct(wire.default_params_di(), device=local_rank)
+
     def frame(i):
         cb = scene_io.make_frame_constants(W, H, frame_num=i, num_emissives=len(sc.emissives))
         if tiled is not None:
@@ -141,6 +146,8 @@ def main():
     barrier()
     r.p_gbuffer.read_counters(reset=True)
     r.p_indirect.read_counters(reset=True)
+    if r.p_direct is not None:
+        r.p_direct.read_counters(reset=True)
     barrier()
     t0 = time.perf_counter()
     for i in range(args.steps):
@@ -150,7 +157,8 @@ def main():
 
     c1 = r.p_gbuffer.read_counters(reset=True)
     c2 = r.p_indirect.read_counters(reset=True)
-    rays = np.array([c1[0] + c2[0], c1[1] + c2[1]], np.float64)
+    c3 = r.p_direct.read_counters(reset=True) if r.p_direct is not None else (0, 0)
+    rays = np.array([c1[0] + c2[0] + c3[0], c1[1] + c2[1] + c3[1]], np.float64)
     tmax = dt
     if dist is not None:
         tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
@@ -173,7 +181,7 @@ def main():
                                 f"suppression; 3 non-transmissive / 4 glossy-transmissive bounces, static camera)") if rpt else
                                (f"Cornell Box (cornell_emissive: 58 triangles, 2 emissive) {W}x{H}, G-buffer + 1-spp "
                                 f"path tracer (K1+K9, NEE+MIS, 3 non-transmissive bounces, static camera)"),
-                   "integrator": args.integrator,
+                   "integrator": args.integrator + ("+restir_di" if args.direct else ""),
                    "parallelism": f"screen tiles {tile_grid(world)}" + (
                        f", 32-px apron, RCCL p2p halo exchange of reservoir planes (62 B/px): {tiled.halo_bytes} B sent per "
                        f"rank per exchange, {1 if args.no_final_halo else 2} exchanges per frame" if (rpt and world > 1) else ""),
@@ -185,13 +193,15 @@ def main():
         # ---- roofline of the dominant kernel: hipEvent timing inside the library over a few timed frames
         r.p_gbuffer.enable_timing(True)
         r.p_indirect.enable_timing(True)
+        if r.p_direct is not None:
+            r.p_direct.enable_timing(True)
         agg = {}
         nfr = 8
         r.p_indirect.read_counters(reset=True)
         for i in range(nfr):
             frame(1000 + i)
             torch.cuda.synchronize()
-            for name, (ms, launches) in {**r.p_gbuffer.timings(), **r.p_indirect.timings()}.items():
+            for name, (ms, launches) in {**r.p_gbuffer.timings(), **r.p_indirect.timings(), **(r.p_direct.timings() if r.p_direct is not None else {})}.items():
                 a = agg.setdefault(name, [0.0, 0])
                 a[0] += ms
                 a[1] += launches

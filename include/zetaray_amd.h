@@ -74,6 +74,9 @@ typedef enum zr_integrator {
 #define ZR_IND_PATH_REGULARIZATION     (1u << 5)
 #define ZR_IND_SORT_TEMPORAL           (1u << 6)
 #define ZR_IND_SORT_SPATIAL            (1u << 7)
+/* ReSTIR DI (ZR_PASS_DI_EMISSIVE) reads TEMPORAL_RESAMPLE / SPATIAL_RESAMPLE above plus (CB_RDI_FLAGS, DirectLighting_Common.h:13-20): */
+#define ZR_DI_STOCHASTIC_SPATIAL          (1u << 8)
+#define ZR_DI_EXTRA_DISOCCLUSION_SAMPLING (1u << 9)
 
 /* Pass parameters.  Defaults = the reference's (IndirectLighting.h:231-244, IndirectLighting.cpp:146-165). */
 typedef struct zr_params {
@@ -107,7 +110,11 @@ typedef enum zr_output {
     /* replay buffers of the last frame (scratch between K13 and K14/K16; Shift.hlsli:191-358): current-to-neighbour
        and neighbour-to-current, planes A (RGBA16F 8 B), B (RGBA32_UINT), C (RGBA32_UINT), D (R16_UINT) */
     ZR_OUT_RPT_RBUF_CTN_A  = 10, ZR_OUT_RPT_RBUF_CTN_B = 11, ZR_OUT_RPT_RBUF_CTN_C = 12, ZR_OUT_RPT_RBUF_CTN_D = 13,
-    ZR_OUT_RPT_RBUF_NTC_A  = 14, ZR_OUT_RPT_RBUF_NTC_B = 15, ZR_OUT_RPT_RBUF_NTC_C = 16, ZR_OUT_RPT_RBUF_NTC_D = 17
+    ZR_OUT_RPT_RBUF_NTC_A  = 14, ZR_OUT_RPT_RBUF_NTC_B = 15, ZR_OUT_RPT_RBUF_NTC_C = 16, ZR_OUT_RPT_RBUF_NTC_D = 17,
+    /* ReSTIR DI (ZR_PASS_DI_EMISSIVE) persistent state written by the last frame (Reservoir.hlsli:150-213) */
+    ZR_OUT_RDI_RESERVOIR_A = 20,   /* RGBA32_UINT 16 B: bary unorm2, le.xy half2, le.z half | M << 16, lightIdx */
+    ZR_OUT_RDI_RESERVOIR_B = 21,   /* RG32F        8 B: w_sum, W */
+    ZR_OUT_RDI_TARGET      = 22    /* RGBA32F     16 B (xyz; negated when the pixel was disoccluded) */
 } zr_output;
 
 /* G-buffer planes (reference GBufferData::GBUFFER order and DXGI formats, DefaultRendererImpl.h:82-109) */

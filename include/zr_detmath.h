@@ -159,6 +159,18 @@ ZR_HD float zr_atan2(float y, float x)
     return w + zr_atan(y / x);
 }
 
+/* unsigned small float (5-bit exponent, `mbits` mantissa bits: the channels of R11G11B10_FLOAT) -> fp32, exact */
+ZR_HD float zr_unpack_ufloat(uint32_t bits, int mbits)
+{
+    const uint32_t e = bits >> mbits, m = bits & ((1u << mbits) - 1u);
+    if (e == 0) return (float)m * zr_asfloat((uint32_t)(127 - 14 - mbits) << 23);
+    if (e == 31) return zr_asfloat(0x7f800000u | (m << (23 - mbits)));
+    return zr_asfloat(((e + 112u) << 23) | (m << (23 - mbits)));
+}
+/* D3D ftou / ftoi: NaN -> 0, out of range saturates (x86 cvttss2si and C++ casts do something else) */
+ZR_HD uint32_t zr_f2u_sat(float f) { if (zr_isnan(f) || f <= 0.0f) return 0u; if (f >= 4294967296.0f) return 0xffffffffu; return (uint32_t)f; }
+ZR_HD int32_t zr_f2i_sat(float f) { if (zr_isnan(f)) return 0; if (f >= 2147483648.0f) return 2147483647; if (f <= -2147483648.0f) return (-2147483647 - 1); return (int32_t)f; }
+
 /* fp32 -> fp16, round-to-nearest-even, full denormal/inf/nan handling (== v_cvt_f16_f32 / F16C) */
 ZR_HD uint16_t zr_f32_to_f16(float f)
 {

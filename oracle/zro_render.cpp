@@ -638,6 +638,7 @@ static void RenderPathTracer(const Scene& sc, const zr_frame_constants& g, GBVie
 }
 
 #include "zro_rpt.h"
+#include "zro_rdi.h"
 
 //--------------------------------------------------------------------------------------
 // C entry points (ctypes)
@@ -743,6 +744,30 @@ int zro_rpt_read_plane(const zro_rpt* r, int which, int plane, void* out)
     case 8: return cp(r->st.neighbor.data(), r->st.neighbor.size());
     }
     return 1;
+}
+
+// ReSTIR DI (zro_rdi.h)
+struct zro_rdi { RDI::State st; };
+zro_rdi* zro_rdi_create(uint32_t w, uint32_t h, const uint16_t* sample_set_half2_32)
+{ zro_rdi* r = new zro_rdi(); r->st.Resize(w, h); r->st.sampleSet.assign(sample_set_half2_32, sample_set_half2_32 + 64); return r; }
+void zro_rdi_destroy(zro_rdi* r) { delete r; }
+void zro_rdi_reset_temporal(zro_rdi* r) { r->st.temporalValid = false; r->st.currIdx = 0; }
+int zro_rdi_render(const zro_scene* h, zro_rdi* r, const zr_frame_constants* cb, const zr_gbuffer_planes* curr, const zr_gbuffer_planes* prev,
+    const zr_params* prm, float* final_rgba, zr_counters* counters)
+{
+    h->s.counters = Counters();
+    RDI::Render(h->s, *cb, curr, prev, *prm, r->st, final_rgba);
+    if (counters) { counters->n_closest = h->s.counters.n_closest; counters->n_shadow = h->s.counters.n_shadow; }
+    return 0;
+}
+// plane 0 = reservoir A (4 x u32), 1 = B (2 x f32) of the set written by the last frame, 2 = target (4 x f32)
+int zro_rdi_read_plane(const zro_rdi* r, int plane, void* out)
+{
+    const int last = 1 - r->st.currIdx;
+    if (plane == 0) std::memcpy(out, r->st.A[last].data(), r->st.A[last].size() * 4);
+    else if (plane == 1) std::memcpy(out, r->st.B[last].data(), r->st.B[last].size() * 4);
+    else std::memcpy(out, r->st.target.data(), r->st.target.size() * 4);
+    return 0;
 }
 
 // rays: n x 8 floats (o, tmin, d, tmax); hits: n x 4 uint32 (t bits, u bits, v bits, tri or 0xffffffff)

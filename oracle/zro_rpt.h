@@ -733,7 +733,7 @@ struct PixelSurface { float3 pos, normal, origin; float2 lensSample; float eta_n
 
 // coatFromPixel: the reference reads the coat plane at a different pixel than the others in two places
 // (ReSTIR_PT_Reconnect_CtT.hlsl:80 and _CtS.hlsl:99 use DTid instead of the shifted pixel); restated as is.
-static PixelSurface LoadPixelSurface(const GBufRead& gb, const Camera& cam, uint32_t x, uint32_t y, uint32_t frameForLens, size_t coatPixel)
+static PixelSurface LoadPixelSurfaceEx(const GBufRead& gb, const Camera& cam, uint32_t x, uint32_t y, uint32_t frameForLens, size_t coatPixel, bool useTrDepth)
 {
     PixelSurface ps;
     const size_t px = (size_t)y * gb.w + x;
@@ -762,9 +762,11 @@ static PixelSurface LoadPixelSurface(const GBufRead& gb, const Camera& cam, uint
     }
     const float3 wo = normalize(ps.origin - ps.pos);
     ps.surface = BSDF::ShadingData::Init(ps.normal, wo, ps.flags.metallic, ps.roughness, baseColor, ETA_AIR, ps.eta_next, ps.flags.transmissive,
-        ps.flags.trDepthGt0 ? 1.0f : 0.0f, subsurface, coat_weight, coat_color, coat_roughness, coat_ior);
+        (useTrDepth && ps.flags.trDepthGt0) ? 1.0f : 0.0f, subsurface, coat_weight, coat_color, coat_roughness, coat_ior);
     return ps;
 }
+static inline PixelSurface LoadPixelSurface(const GBufRead& gb, const Camera& cam, uint32_t x, uint32_t y, uint32_t frameForLens, size_t coatPixel)
+{ return LoadPixelSurfaceEx(gb, cam, x, y, frameForLens, coatPixel, true); }
 
 // ---- r-buffers (Shift.hlsli:191-358): OffsetPathContext
 struct RBuffer

@@ -9,9 +9,13 @@
 #include "../../zetaray_amd/csrc/zr_stages.h"
 #include "../../zetaray_amd/csrc/zr_bvh.h"
 #include "../../zetaray_amd/csrc/zr_rpt.h"
+#include "../../zetaray_amd/csrc/zr_rdi.h"
 
 static const uint16_t kRptSampleSet[1024] = {
 #include "../../zetaray_amd/csrc/zr_rpt_sample_set.inc"
+};
+static const uint16_t kRdiSampleSet[64] = {
+#include "../../zetaray_amd/csrc/zr_rdi_sample_set.inc"
 };
 
 using namespace zr;
@@ -360,6 +364,66 @@ int zhx_rpt_write_plane_rect(HxRpt* R, int which, int plane, const void* src, ui
     }
     for (uint32_t y = y0; y < y0 + h; y++)
         std::memcpy((char*)base + ((size_t)y * R->w + x0) * bpp, (const char*)src + ((size_t)y * R->w + x0) * bpp, (size_t)w * bpp);
+    return 0;
+}
+
+// ---------------------------------------------------------------- ReSTIR DI (zr_rdi.h) in program order
+struct HxRdi
+{
+    uint32_t w = 0, h = 0; bool temporalValid = false; int currIdx = 0;
+    std::vector<U4> A[2]; std::vector<float> B[2]; std::vector<F4> target;
+};
+HxRdi* zhx_rdi_create(uint32_t w, uint32_t h)
+{
+    HxRdi* r = new HxRdi(); r->w = w; r->h = h; size_t n = (size_t)w * h;
+    for (int i = 0; i < 2; i++) { r->A[i].assign(n, U4{0, 0, 0, 0}); r->B[i].assign(2 * n, 0.0f); }
+    r->target.assign(n, F4{0, 0, 0, 0});
+    return r;
+}
+void zhx_rdi_destroy(HxRdi* r) { delete r; }
+void zhx_rdi_reset_temporal(HxRdi* r) { r->temporalValid = false; r->currIdx = 0; }
+void zhx_rdi_render(const HxScene* s, HxRdi* R, const zr_frame_constants* cb, const zr_gbuffer_planes* curr, const zr_gbuffer_planes* prev,
+    const zr_params* params, float* finalRGBA, zr_counters* counters)
+{
+    using namespace rdi;
+    uint32_t cnt[2] = {0, 0};
+    const zr_frame_constants& g = *cb;
+    const uint32_t W = g.render_width, H = g.render_height;
+    DiFrame F;
+    F.sc = s->view; F.gb = ViewOf(curr); F.gbPrev = prev ? ViewOf(prev) : F.gb;
+    F.ox0 = 0; F.oy0 = 0; F.ow = W; F.oh = H;
+    F.cur.A = R->A[R->currIdx].data(); F.cur.B = R->B[R->currIdx].data();
+    F.prev.A = R->A[1 - R->currIdx].data(); F.prev.B = R->B[1 - R->currIdx].data();
+    F.target = R->target.data(); F.finalRGBA = finalRGBA; F.sampleSet = kRdiSampleSet;
+    DiParams& prm = F.prm;
+    prm.flags = params->flags; prm.M_max = params->m_max_temporal; prm.numSampleSets = params->presampling ? params->num_sample_sets : 0u;
+    prm.accumulate = (g.accumulate && g.camera_static) ? 1u : 0u;
+    prm.doTemporal = (R->temporalValid && (params->flags & ZR_IND_TEMPORAL_RESAMPLE) && prev) ? 1u : 0u;
+    prm.doSpatial = (prm.doTemporal && (params->flags & ZR_IND_SPATIAL_RESAMPLE)) ? 1u : 0u;
+    prm.writeReservoirs = (prm.doTemporal || !R->temporalValid) ? 1u : 0u;
+    uint32_t stack[64];
+    for (uint32_t y = 0; y < H; y++) for (uint32_t x = 0; x < W; x++) TemporalPixel(F, g, x, y, stack, cnt);
+    if (prm.doSpatial)
+    {
+        std::vector<SpatialLane> L(64);
+        for (uint32_t gy = 0; gy < (H + 7) / 8; gy++) for (uint32_t gx = 0; gx < (W + 7) / 8; gx++)
+        {
+            uint32_t sum = 0;
+            for (uint32_t l = 0; l < 64; l++) { SpatialPhase0(F, g, gx * 8 + (l & 7), gy * 8 + (l >> 3), L[l]); sum += L[l].disoccluded ? 1u : 0u; }
+            for (uint32_t l = 0; l < 64; l++) SpatialPhase1(F, g, L[l], sum, stack, cnt);
+        }
+    }
+    if (counters) { counters->n_closest = cnt[0]; counters->n_shadow = cnt[1]; }
+    R->temporalValid = true;
+    R->currIdx = 1 - R->currIdx;
+}
+// plane 0 = reservoir A, 1 = B of the set written by the last frame, 2 = target
+int zhx_rdi_read_plane(const HxRdi* R, int plane, void* out)
+{
+    const int last = 1 - R->currIdx;
+    if (plane == 0) std::memcpy(out, R->A[last].data(), R->A[last].size() * 16);
+    else if (plane == 1) std::memcpy(out, R->B[last].data(), R->B[last].size() * 4);
+    else std::memcpy(out, R->target.data(), R->target.size() * 16);
     return 0;
 }
 

@@ -31,6 +31,11 @@ def main():
     assert len(pts) == 512, len(pts)
     arr = np.array(pts, dtype=np.float64).astype(np.float32).astype(np.float16)
     arr.tofile(os.path.join(ROOT, "zetaray_amd/assets/rpt_sample_set_f16.bin"))
+    # 32-point spatial sample set of ReSTIR DI (DirectLighting/Emissive/Resampling.hlsli: `static const half2 k_samples[32]`)
+    txt = open(os.path.join(REF, "Source/ZetaRenderPass/DirectLighting/Emissive/Resampling.hlsli")).read()
+    pts = re.findall(r"half2\(([-0-9.e]+),\s*([-0-9.e]+)\)", txt)
+    assert len(pts) == 32, len(pts)
+    np.array(pts, dtype=np.float64).astype(np.float32).astype(np.float16).tofile(os.path.join(ROOT, "zetaray_amd/assets/rdi_sample_set_f16.bin"))
     import sys
     sys.path.insert(0, ROOT)
     from zetaray_amd import scene_io

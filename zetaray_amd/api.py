@@ -23,6 +23,7 @@ RPT_OUTPUTS = {"A": (1, np.uint32, 1), "B": (2, np.float32, 2), "C": (3, np.uint
                "E": (5, np.uint16, 1), "F": (6, np.float32, 2), "G": (7, np.uint32, 2), "target": (8, np.float32, 4),
                "neighbor": (9, np.uint8, 2),
                "ctn_A": (10, np.uint16, 4), "ctn_B": (11, np.uint32, 4), "ctn_C": (12, np.uint32, 4), "ctn_D": (13, np.uint16, 1),
+               "di_A": (20, np.uint32, 4), "di_B": (21, np.float32, 2), "di_target": (22, np.float32, 4),
                "ntc_A": (14, np.uint16, 4), "ntc_B": (15, np.uint32, 4), "ntc_C": (16, np.uint32, 4), "ntc_D": (17, np.uint16, 1)}
 
 EXPORTS = [
@@ -291,13 +292,21 @@ class Renderer:
         self.p_prelight = Pass(PASS_PRELIGHTING, width, height, device=device, params=params)
         self._presampling = bool(params is not None and params.presampling)
         self.p_indirect = Pass(PASS_INDIRECT, width, height, integrator, device=device, params=params)
+        self.p_direct = None          # ReSTIR DI (emissive): enable_direct()
         self._alias_ready = False
+
+    def enable_direct(self, params=None, device=0):
+        """add the DirectLighting (ReSTIR DI, emissive) pass; it renders after PreLighting, next to Indirect"""
+        self.p_direct = Pass(PASS_DI_EMISSIVE, self.p_indirect.w, self.p_indirect.h_, device=device, params=params)
+        return self.p_direct
 
     def render_frame(self, cb, stream=None):
         self.p_gbuffer.render(cb, self.scene, self.gbuffer, stream)
         if not self._alias_ready or self._presampling:      # presampled light sets are regenerated every frame (K3)
             self.p_prelight.render(cb, self.scene, None, stream)
             self._alias_ready = True
+        if self.p_direct is not None:
+            self.p_direct.render(cb, self.scene, self.gbuffer, stream)
         self.p_indirect.render(cb, self.scene, self.gbuffer, stream)
 
     def final(self):

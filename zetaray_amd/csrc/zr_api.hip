@@ -14,6 +14,7 @@
 #include <new>
 #include "zr_stages.h"
 #include "zr_rpt.h"
+#include "zr_rdi.h"
 #include "zr_bvh.h"
 
 // 512 x half2 spatial-search points (generated from zetaray_amd/assets/rpt_sample_set_f16.bin by the Makefile)
@@ -301,6 +302,33 @@ __global__ void __launch_bounds__(kBlock) k_rpt_stc(rpt::RptFrame F, zr_frame_co
     FlushRayCounters(counters, cnt);
 }
 
+// ------------------------------------------------------------------------------------------------ ReSTIR DI kernels
+static const uint16_t kRdiSampleSet[64] = {
+#include "zr_rdi_sample_set.inc"
+};
+
+// K5: initial candidates + temporal reuse, one thread per pixel (8x8 quadrant per wave, like the reference's thread group)
+__global__ void __launch_bounds__(kBlock) k_rdi_temporal(rdi::DiFrame F, zr_frame_constants g, uint32_t tilesX, unsigned long long* counters)
+{
+    uint32_t x, y; PixelOfThread(tilesX, F.ox0, F.oy0, &x, &y);
+    uint32_t stack[kStack];
+    uint32_t cnt[2] = {0u, 0u};
+    if (F.Owns(x, y)) rdi::TemporalPixel(F, g, x, y, stack, cnt);
+    FlushRayCounters(counters, cnt);
+}
+// K6: spatial reuse with pairwise MIS; WaveActiveSum(disoccluded) = popcount of a ballot over the 8x8 group
+__global__ void __launch_bounds__(kBlock) k_rdi_spatial(rdi::DiFrame F, zr_frame_constants g, uint32_t tilesX, unsigned long long* counters)
+{
+    uint32_t x, y; PixelOfThread(tilesX, F.ox0, F.oy0, &x, &y);
+    uint32_t stack[kStack];
+    uint32_t cnt[2] = {0u, 0u};
+    rdi::SpatialLane a;
+    rdi::SpatialPhase0(F, g, x, y, a);
+    const uint32_t waveDisoccluded = (uint32_t)__popcll(__ballot(a.disoccluded));
+    rdi::SpatialPhase1(F, g, a, waveDisoccluded, stack, cnt);
+    FlushRayCounters(counters, cnt);
+}
+
 // ------------------------------------------------------------------------------------------------ host objects
 template<typename T> struct DevBuf
 {
@@ -377,7 +405,7 @@ static constexpr int kMaxTimers = 64;
 // ray-counter slots (pairs of u64 on the device): 0 = wavefront path tracer, 1.. = ReSTIR PT kernels in launch order
 static constexpr int kCounterSlots = 16;
 static const char* const kCounterNames[kCounterSlots] = {"trace", "rpt_pathtrace", "rpt_replay_ctt", "rpt_replay_ttc", "rpt_reconnect_temporal",
-    "rpt_replay_cts", "rpt_replay_stc", "rpt_reconnect_spatial", "", "", "", "", "", "", "", ""};
+    "rpt_replay_cts", "rpt_replay_stc", "rpt_reconnect_spatial", "rdi_temporal", "rdi_spatial", "", "", "", "", "", ""};
 
 struct zr_pass
 {
@@ -410,6 +438,8 @@ struct zr_pass
     } rb[2];
     DevBuf<F4> rptTarget; DevBuf<uint8_t> rptNeighbor; DevBuf<uint16_t> rptSampleSet;
     DevBuf<uint32_t> rptLists, rptListCounts;      // 4 replay work lists (pixel ids) + their device-side counts
+    // DI_EMISSIVE: two reservoir sets (A RGBA32_UINT, B RG32F), target, sample set
+    DevBuf<U4> diA[2]; DevBuf<float> diB[2]; DevBuf<F4> diTarget; DevBuf<uint16_t> diSampleSet;
     bool temporalValid = false, doTemporal = false, doSpatial = false; int currIdx = 0;
     uint32_t own[4] = {0, 0, 0, 0};                // owned rect (global pixels); w == 0 -> the whole G-buffer rect
     // PRELIGHTING
@@ -665,13 +695,19 @@ int zr_pass_create(int kind, int device, zr_pass** out)
 {
     if (!out) return Fail(ZR_ERR_INVALID_ARG, "null out");
     if (kind < ZR_PASS_GBUFFER || kind > ZR_PASS_INDIRECT) return Fail(ZR_ERR_INVALID_ARG, "unknown pass kind %d", kind);
-    if (kind == ZR_PASS_DI_EMISSIVE || kind == ZR_PASS_DI_SKY) return Fail(ZR_ERR_UNSUPPORTED, "pass kind %d (ReSTIR DI) is not implemented yet", kind);
+    if (kind == ZR_PASS_DI_SKY) return Fail(ZR_ERR_UNSUPPORTED, "pass kind %d (sun / sky ReSTIR DI) is not implemented yet", kind);
     int r = RequireDevice(device);
     if (r) return r;
     zr_pass* p = new (std::nothrow) zr_pass();
     if (!p) return Fail(ZR_ERR_OOM, "out of host memory");
     p->kind = kind; p->device = device;
     zr_params_default(&p->params);
+    if (kind == ZR_PASS_DI_EMISSIVE)
+    {
+        // DirectLighting.cpp:100-107, DirectLighting.h:93-98
+        p->params.flags = ZR_IND_TEMPORAL_RESAMPLE | ZR_IND_SPATIAL_RESAMPLE | ZR_DI_STOCHASTIC_SPATIAL | ZR_DI_EXTRA_DISOCCLUSION_SAMPLING;
+        p->params.m_max_temporal = 20; p->params.m_max_spatial = 20; p->params.alpha_min = 0.05f * 0.05f;
+    }
     *out = p;
     return ZR_OK;
 }
@@ -679,6 +715,23 @@ int zr_pass_create(int kind, int device, zr_pass** out)
 static int AllocPass(zr_pass* p)
 {
     int r;
+    if (p->kind == ZR_PASS_DI_EMISSIVE)
+    {
+        const size_t cap = (size_t)p->w * p->h;
+        if ((r = p->finalRGBA.Alloc(cap * 4))) return r;
+        if ((r = p->counters.Alloc(2 * kCounterSlots))) return r;
+        HIP_TRY(hipMemset(p->finalRGBA.p, 0, cap * 4 * sizeof(float)));
+        HIP_TRY(hipMemset(p->counters.p, 0, 2 * kCounterSlots * sizeof(unsigned long long)));
+        for (int k = 0; k < 2; k++)
+        {
+            if ((r = p->diA[k].Alloc(cap)) || (r = p->diB[k].Alloc(2 * cap))) return r;
+            HIP_TRY(hipMemset(p->diA[k].p, 0, cap * 16)); HIP_TRY(hipMemset(p->diB[k].p, 0, cap * 8));
+        }
+        if ((r = p->diTarget.Alloc(cap))) return r;
+        HIP_TRY(hipMemset(p->diTarget.p, 0, cap * 16));
+        if ((r = p->diSampleSet.Upload(kRdiSampleSet, 64))) return r;
+        p->temporalValid = false; p->currIdx = 0;
+    }
     if (p->kind == ZR_PASS_INDIRECT)
     {
         const size_t cap = (size_t)p->w * p->h;
@@ -741,11 +794,13 @@ int zr_pass_reset_temporal(zr_pass* p)
     HIP_TRY(hipSetDevice(p->device));
     if (p->kind == ZR_PASS_INDIRECT) HIP_TRY(hipMemset(p->finalRGBA.p, 0, p->finalRGBA.n * sizeof(float)));
     p->temporalValid = false;       // IndirectLighting::ResetTemporal -> RESET_TEMPORAL_TEXTURES next frame
+    if (p->kind == ZR_PASS_DI_EMISSIVE) { HIP_TRY(hipMemset(p->finalRGBA.p, 0, p->finalRGBA.n * sizeof(float))); p->currIdx = 0; }   // DirectLighting.cpp:159-164
     return ZR_OK;
 }
 int zr_pass_set_params(zr_pass* p, const zr_params* prm)
 {
     if (!p || !prm) return Fail(ZR_ERR_INVALID_ARG, "null argument");
+    if (p->kind == ZR_PASS_DI_EMISSIVE && (prm->m_max_temporal < 1 || prm->m_max_temporal > 30)) return Fail(ZR_ERR_INVALID_ARG, "DI M_max must be in 1..30");
     if (prm->max_non_tr_bounces < 1 || prm->max_non_tr_bounces > 15 || prm->max_glossy_tr_bounces < 1 || prm->max_glossy_tr_bounces > 15)
         return Fail(ZR_ERR_INVALID_ARG, "bounce counts must be in 1..15");
     if (prm->presampling && (prm->num_sample_sets == 0 || prm->sample_set_size == 0 || prm->num_sample_sets > 65535 || prm->sample_set_size > 65535))
@@ -803,6 +858,48 @@ static int RenderPreLighting(zr_pass* p, hipStream_t s, const zr_frame_constants
     BuildAliasTableHost(power, table.data(), 0);
     if ((r = zr_scene_set_alias_table(sc, table.data(), n))) return r;
     return p->params.presampling ? RenderPresample(p, s, cb, sc) : ZR_OK;
+}
+
+// DirectLighting::Render (DirectLighting.cpp:166-296)
+static int RenderDirectEmissive(zr_pass* p, hipStream_t s, const zr_frame_constants* cb, const zr_scene* sc, zr_gbuffer* gb)
+{
+    using namespace rdi;
+    if (!gb) return Fail(ZR_ERR_INVALID_ARG, "DI_EMISSIVE pass needs a gbuffer");
+    if (gb->w != p->w || gb->h != p->h) return Fail(ZR_ERR_INVALID_ARG, "gbuffer / pass size mismatch");
+    if (gb->x0 || gb->y0 || gb->w != cb->render_width || gb->h != cb->render_height)
+        return Fail(ZR_ERR_UNSUPPORTED, "DI_EMISSIVE needs the whole frame on one device (its screen-tile halo exchange is not implemented yet)");
+    if (sc->view.numEmissives == 0) return Fail(ZR_ERR_INVALID_ARG, "DI_EMISSIVE needs emissive triangles");
+    if (!sc->view.alias) return Fail(ZR_ERR_NOT_INITIALIZED, "emissive alias table missing: render the PRELIGHTING pass first");
+    if (cb->num_emissive_triangles != sc->view.numEmissives) return Fail(ZR_ERR_INVALID_ARG, "cbFrameConstants.NumEmissiveTriangles != scene");
+    const zr_params& ip = p->params;
+    if (ip.presampling && (!sc->view.sampleSets || sc->numSampleSets != ip.num_sample_sets || sc->view.sampleSetSize != ip.sample_set_size))
+        return Fail(ZR_ERR_NOT_INITIALIZED, "presampled light sets missing or of another size: render the PRELIGHTING pass with the same presampling params first");
+    DiFrame F;
+    F.sc = sc->view; F.gb = gb->View(); F.gbPrev = gb->PrevView();
+    F.ox0 = 0; F.oy0 = 0; F.ow = gb->w; F.oh = gb->h;
+    F.cur.A = p->diA[p->currIdx].p; F.cur.B = p->diB[p->currIdx].p; F.prev.A = p->diA[1 - p->currIdx].p; F.prev.B = p->diB[1 - p->currIdx].p;
+    F.target = p->diTarget.p; F.finalRGBA = p->finalRGBA.p; F.sampleSet = p->diSampleSet.p;
+    DiParams& prm = F.prm;
+    prm.flags = ip.flags; prm.M_max = ip.m_max_temporal; prm.numSampleSets = ip.presampling ? ip.num_sample_sets : 0u;
+    prm.accumulate = (cb->accumulate && cb->camera_static) ? 1u : 0u;
+    prm.doTemporal = (p->temporalValid && (ip.flags & ZR_IND_TEMPORAL_RESAMPLE) && gb->numRendered >= 2) ? 1u : 0u;
+    prm.doSpatial = (prm.doTemporal && (ip.flags & ZR_IND_SPATIAL_RESAMPLE)) ? 1u : 0u;
+    prm.writeReservoirs = (prm.doTemporal || !p->temporalValid) ? 1u : 0u;
+    const uint32_t tilesX = (p->w + 15) / 16, tilesY = (p->h + 15) / 16;
+    const dim3 grid(tilesX * tilesY), block(kBlock);
+    TimerBegin(p, s, "rdi_temporal");
+    hipLaunchKernelGGL(k_rdi_temporal, grid, block, 0, s, F, *cb, tilesX, p->counters.p + 2 * 8);
+    TimerEnd(p, s);
+    if (prm.doSpatial)
+    {
+        TimerBegin(p, s, "rdi_spatial");
+        hipLaunchKernelGGL(k_rdi_spatial, grid, block, 0, s, F, *cb, tilesX, p->counters.p + 2 * 9);
+        TimerEnd(p, s);
+    }
+    HIP_TRY(hipGetLastError());
+    p->temporalValid = true;
+    p->currIdx = 1 - p->currIdx;
+    return ZR_OK;
 }
 
 // IndirectLighting::RenderReSTIR_PT (IndirectLighting.cpp:877-1004) + the Render() tail (:1006-1025).
@@ -1004,6 +1101,7 @@ int zr_pass_render_stage(zr_pass* p, void* stream, const zr_frame_constants* cb,
     case ZR_PASS_GBUFFER: return (stages & ZR_STAGE_TEMPORAL) ? RenderGBuffer(p, s, cb, sc, gb) : ZR_OK;
     case ZR_PASS_PRELIGHTING: return (stages & ZR_STAGE_TEMPORAL) ? RenderPreLighting(p, s, cb, const_cast<zr_scene*>(sc)) : ZR_OK;
     case ZR_PASS_INDIRECT: return RenderIndirect(p, s, cb, sc, gb, stages);
+    case ZR_PASS_DI_EMISSIVE: return (stages & ZR_STAGE_TEMPORAL) ? RenderDirectEmissive(p, s, cb, sc, gb) : ZR_OK;
     default: return Fail(ZR_ERR_UNSUPPORTED, "pass kind %d not implemented", p->kind);
     }
 }
@@ -1012,6 +1110,20 @@ int zr_pass_get_output(const zr_pass* p, int which, void** dev, uint32_t* w, uin
 {
     if (!p || !dev) return Fail(ZR_ERR_INVALID_ARG, "null argument");
     if (!p->initialized) return Fail(ZR_ERR_NOT_INITIALIZED, "pass not initialised");
+    if (p->kind == ZR_PASS_DI_EMISSIVE)
+    {
+        uint32_t b = 16;
+        const int last = 1 - p->currIdx;        // the reservoir set written by the last frame
+        if (which == ZR_OUT_FINAL) *dev = p->finalRGBA.p;
+        else if (which == ZR_OUT_RDI_RESERVOIR_A) *dev = p->diA[last].p;
+        else if (which == ZR_OUT_RDI_RESERVOIR_B) { *dev = p->diB[last].p; b = 8; }
+        else if (which == ZR_OUT_RDI_TARGET) *dev = p->diTarget.p;
+        else return Fail(ZR_ERR_INVALID_ARG, "pass has no such output");
+        if (w) *w = p->w;
+        if (h) *h = p->h;
+        if (bpp) *bpp = b;
+        return ZR_OK;
+    }
     if (p->kind != ZR_PASS_INDIRECT) return Fail(ZR_ERR_INVALID_ARG, "pass has no such output");
     uint32_t bytes = 16;
     if (which == ZR_OUT_FINAL) *dev = p->finalRGBA.p;
@@ -1064,7 +1176,7 @@ int zr_pass_read_counters(zr_pass* p, void* stream, zr_counters* out, int reset)
     if (!p || !out) return Fail(ZR_ERR_INVALID_ARG, "null argument");
     HIP_TRY(hipSetDevice(p->device));
     out->n_closest = p->hostCounters.n_closest; out->n_shadow = p->hostCounters.n_shadow;
-    if (p->kind == ZR_PASS_INDIRECT && p->initialized)
+    if ((p->kind == ZR_PASS_INDIRECT || p->kind == ZR_PASS_DI_EMISSIVE) && p->initialized)
     {
         unsigned long long c[2 * kCounterSlots];
         HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
@@ -1079,7 +1191,7 @@ int zr_pass_read_kernel_counters(zr_pass* p, void* stream, uint32_t max_entries,
     uint32_t* count)
 {
     if (!p || !names || !closest || !shadow || !count) return Fail(ZR_ERR_INVALID_ARG, "null argument");
-    if (p->kind != ZR_PASS_INDIRECT || !p->initialized) return Fail(ZR_ERR_NOT_INITIALIZED, "INDIRECT pass not initialised");
+    if ((p->kind != ZR_PASS_INDIRECT && p->kind != ZR_PASS_DI_EMISSIVE) || !p->initialized) return Fail(ZR_ERR_NOT_INITIALIZED, "pass has no ray counters or is not initialised");
     HIP_TRY(hipSetDevice(p->device));
     unsigned long long c[2 * kCounterSlots];
     HIP_TRY(hipStreamSynchronize((hipStream_t)stream));

@@ -680,7 +680,7 @@ struct PixelSurface { V3 pos, normal; float eta_next; Surface surface; GFlags fl
 
 // coatPixel: the reference reads the coat plane at DTid instead of the shifted pixel in two passes
 // (ReSTIR_PT_Reconnect_CtT.hlsl:80, _CtS.hlsl:99); restated as is.
-ZR_HD PixelSurface LoadPixelSurface(const GBuf& gb, const Camera& cam, uint32_t x, uint32_t y, uint32_t frameForLens, size_t coatPixel)
+ZR_HD PixelSurface LoadPixelSurfaceEx(const GBuf& gb, const Camera& cam, uint32_t x, uint32_t y, uint32_t frameForLens, size_t coatPixel, bool useTrDepth)
 {
     PixelSurface ps;
     const size_t px = Pix(gb, x, y);
@@ -714,9 +714,11 @@ ZR_HD PixelSurface LoadPixelSurface(const GBuf& gb, const Camera& cam, uint32_t 
     }
     const V3 wo = normalize(origin - ps.pos);
     ps.surface = InitSurface(ps.normal, wo, ps.flags.metallic, ps.roughness, baseColor, kEtaAir, ps.eta_next, ps.flags.transmissive,
-        ps.flags.trDepthGt0 ? 1.0f : 0.0f, subsurface, coat_weight, coat_color, coat_roughness, coat_ior);
+        (useTrDepth && ps.flags.trDepthGt0) ? 1.0f : 0.0f, subsurface, coat_weight, coat_color, coat_roughness, coat_ior);
     return ps;
 }
+ZR_HD PixelSurface LoadPixelSurface(const GBuf& gb, const Camera& cam, uint32_t x, uint32_t y, uint32_t frameForLens, size_t coatPixel)
+{ return LoadPixelSurfaceEx(gb, cam, x, y, frameForLens, coatPixel, true); }
 
 // ---- K11: one lane of PathTrace (ReSTIR_PT_PathTrace.hlsl:194-358), cut at the Russian-roulette point so the 64
 // lanes of a wave step in lockstep around the WaveActiveMax

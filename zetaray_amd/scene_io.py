@@ -194,6 +194,14 @@ def load_rpt_sample_set():
     return data
 
 
+def load_rdi_sample_set():
+    """32 x half2 spatial sample points of ReSTIR DI (reference: DirectLighting/Emissive/Resampling.hlsli k_samples)."""
+    p = os.path.join(os.path.dirname(default_rho_path()), "rdi_sample_set_f16.bin")
+    data = np.fromfile(p, dtype="<u2")
+    assert data.size == 64
+    return data
+
+
 def _accessor(g, bins, idx):
     acc = g["accessors"][idx]
     bv = g["bufferViews"][acc["bufferView"]]

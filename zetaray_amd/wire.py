@@ -126,6 +126,24 @@ def default_params() -> Params:
     return p
 
 
+DI_STOCHASTIC_SPATIAL = 1 << 8
+DI_EXTRA_DISOCCLUSION_SAMPLING = 1 << 9
+
+
+def default_params_di() -> Params:
+    """ReSTIR DI defaults: DirectLighting.cpp:100-107, DirectLighting.h:93-98 (M_max 20, alpha_min 0.05^2)."""
+    p = Params()
+    p.flags = IND_TEMPORAL_RESAMPLE | IND_SPATIAL_RESAMPLE | DI_STOCHASTIC_SPATIAL | DI_EXTRA_DISOCCLUSION_SAMPLING
+    p.max_non_tr_bounces, p.max_glossy_tr_bounces = 1, 1
+    p.m_max_temporal = 20
+    p.m_max_spatial = 20
+    p.alpha_min = 0.05 * 0.05
+    p.presampling = 0
+    p.num_sample_sets = 128
+    p.sample_set_size = 512
+    return p
+
+
 def alloc_gbuffer_planes(width: int, height: int):
     """Host planes (numpy) + the ctypes view handed to the oracle / zr_gbuffer_download."""
     arrays = []
