@@ -1095,7 +1095,7 @@ int zr_pass_render_stage(zr_pass* p, void* stream, const zr_frame_constants* cb,
     if (sc->device != p->device || (gb && gb->device != p->device)) return Fail(ZR_ERR_INVALID_ARG, "scene / gbuffer / pass live on different devices");
     HIP_TRY(hipSetDevice(p->device));
     hipStream_t s = (hipStream_t)stream;
-    p->numTimers = 0;
+    if (stages & ZR_STAGE_TEMPORAL) p->numTimers = 0;      // timings accumulate over the stages of one frame
     switch (p->kind)
     {
     case ZR_PASS_GBUFFER: return (stages & ZR_STAGE_TEMPORAL) ? RenderGBuffer(p, s, cb, sc, gb) : ZR_OK;

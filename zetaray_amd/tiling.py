@@ -124,6 +124,8 @@ class TiledRestirPT:
         if not r._alias_ready or r._presampling:
             r.p_prelight.render(cb, r.scene, None)
             r._alias_ready = True
+        if r.p_direct is not None:
+            r.p_direct.render(cb, r.scene, r.gbuffer)
         r.p_indirect.render_stage(cb, r.scene, r.gbuffer, api.STAGE_TEMPORAL)
 
     def stage_spatial(self, cb):
