@@ -90,7 +90,7 @@ def main():
     ap.add_argument("--no-final-halo", action="store_true",
                     help="skip the post-frame halo exchange (exact for a static camera, which this bench uses)")
     ap.add_argument("--direct", action="store_true", help="also run the ReSTIR DI (emissive) pass every frame (N = 1)")
-    ap.add_argument("--integrator", choices=["restir_pt", "pt"], default="restir_pt",
+    ap.add_argument("--integrator", choices=["restir_pt", "restir_gi", "pt"], default="restir_pt",
                     help="restir_pt = K11-K16 (BASELINE metric); pt = K9 unidirectional path tracer")
     args = ap.parse_args()
 
@@ -123,7 +123,10 @@ def main():
         tiled = tiling.TiledRestirPT(sc, W, H, world, rank, device=local_rank, params=prm, dist=dist)
         r = tiled.r
     else:
-        r = api.Renderer(sc, tw, th, device=local_rank, params=prm, tile_origin=(x0, y0), integrator=api.INTEGRATOR_PATH_TRACING)
+        if args.integrator == "restir_gi":
+            assert world == 1, "restir_gi has no tile split yet"
+        r = api.Renderer(sc, tw, th, device=local_rank, params=prm, tile_origin=(x0, y0),
+                         integrator=api.INTEGRATOR_RESTIR_GI if args.integrator == "restir_gi" else api.INTEGRATOR_PATH_TRACING)
 
     if args.direct:
         assert world == 1, "--direct: the DI pass has no tile split yet"
@@ -179,6 +182,8 @@ def main():
         "config": {"workload": (f"Cornell Box (cornell_emissive: 58 triangles, 2 emissive) {W}x{H}, G-buffer + ReSTIR PT "
                                 f"(K1 + K11-K16: initial candidates, temporal + spatial reconnection reuse, boiling "
                                 f"suppression; 3 non-transmissive / 4 glossy-transmissive bounces, static camera)") if rpt else
+                               (f"Cornell Box (cornell_emissive: 58 triangles, 2 emissive) {W}x{H}, G-buffer + ReSTIR GI (K1+K10, "
+                                f"3 bounces, temporal reuse, static camera)") if args.integrator == "restir_gi" else
                                (f"Cornell Box (cornell_emissive: 58 triangles, 2 emissive) {W}x{H}, G-buffer + 1-spp "
                                 f"path tracer (K1+K9, NEE+MIS, 3 non-transmissive bounces, static camera)"),
                    "integrator": args.integrator + ("+restir_di" if args.direct else ""),
@@ -213,7 +218,10 @@ def main():
         dom = max(agg, key=lambda k: agg[k][0])
         launches = agg[dom][1]
         avg_ms = agg[dom][0] / launches
-        if dom.startswith("rpt_"):
+        if dom == "rgi":
+            kcc, kcs = kern_rays.get(dom, (0, 0))
+            bytes_launch = (BYTES_CLOSEST * kcc + BYTES_SHADOW * kcs) / launches + (23 + 2 * 40 + 27 + 16) * W * H
+        elif dom.startswith("rpt_"):
             # per-ray model of SURVEY.md section 8(d) on the rays this kernel issued + the per-pixel reservoir / G-buffer
             # bytes it must touch
             kcc, kcs = kern_rays.get(dom, (0, 0))

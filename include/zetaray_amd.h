@@ -114,7 +114,11 @@ typedef enum zr_output {
     /* ReSTIR DI (ZR_PASS_DI_EMISSIVE) persistent state written by the last frame (Reservoir.hlsli:150-213) */
     ZR_OUT_RDI_RESERVOIR_A = 20,   /* RGBA32_UINT 16 B: bary unorm2, le.xy half2, le.z half | M << 16, lightIdx */
     ZR_OUT_RDI_RESERVOIR_B = 21,   /* RG32F        8 B: w_sum, W */
-    ZR_OUT_RDI_TARGET      = 22    /* RGBA32F     16 B (xyz; negated when the pixel was disoccluded) */
+    ZR_OUT_RDI_TARGET      = 22,   /* RGBA32F     16 B (xyz; negated when the pixel was disoccluded) */
+    /* ReSTIR GI persistent state written by the last frame (ReSTIR_GI/Reservoir.hlsli:72-131) */
+    ZR_OUT_RGI_RESERVOIR_A = 30,   /* RGBA32F 16 B: sample position, hit ID bits */
+    ZR_OUT_RGI_RESERVOIR_B = 31,   /* RGBA16F  8 B: Lo, M */
+    ZR_OUT_RGI_RESERVOIR_C = 32    /* RGBA32F 16 B: w_sum, W, oct32 normal bits, unused */
 } zr_output;
 
 /* G-buffer planes (reference GBufferData::GBUFFER order and DXGI formats, DefaultRendererImpl.h:82-109) */

@@ -375,7 +375,7 @@ static void EstimatePower(const Scene& sc, float* out)
 //  ACCOUNT_FOR_TRANSMITTANCE 1)
 //--------------------------------------------------------------------------------------
 static float3 NEE_Emissive_MIS(const Scene& sc, int NumLightSamples, bool skipDiffuse, float3 pos, float3 normal,
-    BSDF::ShadingData surface, uint32_t numEmissives, RNG& rng, bool presampled = false, uint32_t sampleSetIdx = 0)
+    BSDF::ShadingData surface, uint32_t numEmissives, RNG& rng, bool presampled = false, uint32_t sampleSetIdx = 0, bool approximateShadow = false)
 {
     float3 ld = f3(0.0f);
     const bool specular = surface.GlossSpecular() && (surface.metallic || surface.specTr) && (!surface.Coated() || surface.CoatSpecular());
@@ -432,7 +432,7 @@ static float3 NEE_Emissive_MIS(const Scene& sc, int NumLightSamples, bool skipDi
             surface.SetWi(wi, normal);
             le *= BSDF::Unified(surface).f * dwdA;
             if (dot(le, le) > 0)
-                le *= RtRayQuery::Visibility_Segment(sc, false, pos, wi, t, normal, lightID, surface.Transmissive()) ? 1.0f : 0.0f;
+                le *= RtRayQuery::Visibility_Segment(sc, approximateShadow, pos, wi, t, normal, lightID, surface.Transmissive()) ? 1.0f : 0.0f;
             float bsdfPdf = skipDiffuse ? BSDF::BSDFSamplerPdf_NoDiffuse(normal, surface, wi, BSDF::NoOp()) :
                 BSDF::BSDFSamplerPdf(normal, surface, wi, BSDF::NoOp(), rng);
             bsdfPdf *= dwdA;
@@ -639,6 +639,7 @@ static void RenderPathTracer(const Scene& sc, const zr_frame_constants& g, GBVie
 
 #include "zro_rpt.h"
 #include "zro_rdi.h"
+#include "zro_rgi.h"
 
 //--------------------------------------------------------------------------------------
 // C entry points (ctypes)
@@ -767,6 +768,29 @@ int zro_rdi_read_plane(const zro_rdi* r, int plane, void* out)
     if (plane == 0) std::memcpy(out, r->st.A[last].data(), r->st.A[last].size() * 4);
     else if (plane == 1) std::memcpy(out, r->st.B[last].data(), r->st.B[last].size() * 4);
     else std::memcpy(out, r->st.target.data(), r->st.target.size() * 4);
+    return 0;
+}
+
+// ReSTIR GI (zro_rgi.h)
+struct zro_rgi { RGI::State st; };
+zro_rgi* zro_rgi_create(uint32_t w, uint32_t h) { zro_rgi* r = new zro_rgi(); r->st.Resize(w, h); return r; }
+void zro_rgi_destroy(zro_rgi* r) { delete r; }
+void zro_rgi_reset_temporal(zro_rgi* r) { r->st.temporalValid = false; }
+int zro_rgi_render(const zro_scene* h, zro_rgi* r, const zr_frame_constants* cb, const zr_gbuffer_planes* curr, const zr_gbuffer_planes* prev,
+    const zr_params* prm, float* final_rgba, zr_counters* counters)
+{
+    h->s.counters = Counters();
+    RGI::Render(h->s, *cb, curr, prev, *prm, r->st, final_rgba);
+    if (counters) { counters->n_closest = h->s.counters.n_closest; counters->n_shadow = h->s.counters.n_shadow; }
+    return 0;
+}
+// plane 0 = A (4 x f32: pos, ID bits), 1 = B (4 x f16: Lo, M), 2 = C (4 x f32: w_sum, W, normal oct32 bits, unused) of the last frame's set
+int zro_rgi_read_plane(const zro_rgi* r, int plane, void* out)
+{
+    const int last = 1 - r->st.currIdx;
+    if (plane == 0) std::memcpy(out, r->st.A[last].data(), r->st.A[last].size() * 4);
+    else if (plane == 1) std::memcpy(out, r->st.B[last].data(), r->st.B[last].size() * 2);
+    else std::memcpy(out, r->st.C[last].data(), r->st.C[last].size() * 4);
     return 0;
 }
 

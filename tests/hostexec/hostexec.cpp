@@ -10,6 +10,7 @@
 #include "../../zetaray_amd/csrc/zr_bvh.h"
 #include "../../zetaray_amd/csrc/zr_rpt.h"
 #include "../../zetaray_amd/csrc/zr_rdi.h"
+#include "../../zetaray_amd/csrc/zr_rgi.h"
 
 static const uint16_t kRptSampleSet[1024] = {
 #include "../../zetaray_amd/csrc/zr_rpt_sample_set.inc"
@@ -424,6 +425,72 @@ int zhx_rdi_read_plane(const HxRdi* R, int plane, void* out)
     if (plane == 0) std::memcpy(out, R->A[last].data(), R->A[last].size() * 16);
     else if (plane == 1) std::memcpy(out, R->B[last].data(), R->B[last].size() * 4);
     else std::memcpy(out, R->target.data(), R->target.size() * 16);
+    return 0;
+}
+
+// ---------------------------------------------------------------- ReSTIR GI (zr_rgi.h) in program order
+struct HxRgi
+{
+    uint32_t w = 0, h = 0; bool temporalValid = false; int currIdx = 0;
+    std::vector<F4> A[2], C[2]; std::vector<uint16_t> B[2];
+};
+HxRgi* zhx_rgi_create(uint32_t w, uint32_t h)
+{
+    HxRgi* r = new HxRgi(); r->w = w; r->h = h; size_t n = (size_t)w * h;
+    for (int i = 0; i < 2; i++) { r->A[i].assign(n, F4{0, 0, 0, 0}); r->C[i].assign(n, F4{0, 0, 0, 0}); r->B[i].assign(4 * n, 0); }
+    return r;
+}
+void zhx_rgi_destroy(HxRgi* r) { delete r; }
+void zhx_rgi_reset_temporal(HxRgi* r) { r->temporalValid = false; }
+void zhx_rgi_render(const HxScene* s, HxRgi* R, const zr_frame_constants* cb, const zr_gbuffer_planes* curr, const zr_gbuffer_planes* prev,
+    const zr_params* params, float* finalRGBA, zr_counters* counters)
+{
+    using namespace rgi;
+    uint32_t cnt[2] = {0, 0};
+    const zr_frame_constants& g = *cb;
+    const uint32_t W = g.render_width, H = g.render_height;
+    GiFrame F;
+    F.sc = s->view; F.gb = ViewOf(curr); F.gbPrev = prev ? ViewOf(prev) : F.gb;
+    F.ox0 = 0; F.oy0 = 0; F.ow = W; F.oh = H;
+    F.cur.A = R->A[R->currIdx].data(); F.cur.B = R->B[R->currIdx].data(); F.cur.C = R->C[R->currIdx].data();
+    F.prev.A = R->A[1 - R->currIdx].data(); F.prev.B = R->B[1 - R->currIdx].data(); F.prev.C = R->C[1 - R->currIdx].data();
+    F.finalRGBA = finalRGBA;
+    GiParams& prm = F.prm;
+    prm.flags = params->flags; prm.maxNonTrBounces = params->max_non_tr_bounces; prm.maxGlossyTrBounces = params->max_glossy_tr_bounces;
+    prm.numSampleSets = params->presampling ? params->num_sample_sets : 0u;
+    prm.accumulate = (g.accumulate && g.camera_static) ? 1u : 0u;
+    prm.doTemporal = ((params->flags & ZR_IND_TEMPORAL_RESAMPLE) && R->temporalValid && prev) ? 1u : 0u;
+    prm.writeReservoirs = (prm.doTemporal || !R->temporalValid) ? 1u : 0u;
+    prm.M_max = (float)params->m_max_temporal;
+    uint32_t stack[64];
+    std::vector<Lane> L(64);
+    float wsum[64];
+    for (uint32_t gy = 0; gy < (H + 7) / 8; gy++) for (uint32_t gx = 0; gx < (W + 7) / 8; gx++)
+    {
+        for (uint32_t l = 0; l < 64; l++) InitLane(F, g, gx * 8 + (l & 7), gy * 8 + (l >> 3), stack, cnt, L[l]);
+        for (;;)
+        {
+            bool any = false;
+            for (uint32_t l = 0; l < 64; l++) { if (L[l].active) any = true; PhaseA(F, g, stack, cnt, L[l]); }
+            if (!any) break;
+            uint32_t bits = 0;
+            for (uint32_t l = 0; l < 64; l++) { uint32_t b = RRKey(L[l]); bits = b > bits ? b : bits; }
+            for (uint32_t l = 0; l < 64; l++) PhaseB(F, g, stack, cnt, L[l], bits);
+        }
+        for (uint32_t l = 0; l < 64; l++) wsum[l] = FinishAndResample(F, g, stack, cnt, L[l]);
+        const float waveSum = rpt::ButterflySum64(wsum);
+        for (uint32_t l = 0; l < 64; l++) SuppressAndWrite(F, L[l], waveSum);
+    }
+    if (counters) { counters->n_closest = cnt[0]; counters->n_shadow = cnt[1]; }
+    R->temporalValid = true;
+    R->currIdx = 1 - R->currIdx;
+}
+int zhx_rgi_read_plane(const HxRgi* R, int plane, void* out)
+{
+    const int last = 1 - R->currIdx;
+    if (plane == 0) std::memcpy(out, R->A[last].data(), R->A[last].size() * 16);
+    else if (plane == 1) std::memcpy(out, R->B[last].data(), R->B[last].size() * 2);
+    else std::memcpy(out, R->C[last].data(), R->C[last].size() * 16);
     return 0;
 }
 

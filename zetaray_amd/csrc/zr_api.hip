@@ -15,6 +15,7 @@
 #include "zr_stages.h"
 #include "zr_rpt.h"
 #include "zr_rdi.h"
+#include "zr_rgi.h"
 #include "zr_bvh.h"
 
 // 512 x half2 spatial-search points (generated from zetaray_amd/assets/rpt_sample_set_f16.bin by the Makefile)
@@ -329,6 +330,34 @@ __global__ void __launch_bounds__(kBlock) k_rdi_spatial(rdi::DiFrame F, zr_frame
     FlushRayCounters(counters, cnt);
 }
 
+// ------------------------------------------------------------------------------------------------ ReSTIR GI kernel
+// K10: one 8x8 pixel group per wave, bounce loop in lockstep around the Russian-roulette wave max, then temporal resampling
+// and the boiling-suppression wave sum (zr_rgi.h)
+__global__ void __launch_bounds__(kBlock) k_rgi(rgi::GiFrame F, zr_frame_constants g, uint32_t tilesX, unsigned long long* counters)
+{
+    uint32_t x, y; PixelOfThread(tilesX, F.ox0, F.oy0, &x, &y);
+    uint32_t stack[kStack];
+    uint32_t cnt[2] = {0u, 0u};
+    rgi::Lane P;
+    rgi::InitLane(F, g, x, y, stack, cnt, P);
+    for (;;)
+    {
+        const bool any = __ballot(P.active) != 0;
+        rgi::PhaseA(F, g, stack, cnt, P);
+        if (!any) break;
+        uint32_t key = rgi::RRKey(P);
+        if (__ballot(key != 0) != 0)
+        {
+            for (int s = 1; s < 64; s <<= 1) { uint32_t o = __shfl_xor(key, s); key = o > key ? o : key; }
+        }
+        rgi::PhaseB(F, g, stack, cnt, P, key);
+    }
+    const float w = rgi::FinishAndResample(F, g, stack, cnt, P);
+    const float waveSum = WaveSumButterfly(w);
+    rgi::SuppressAndWrite(F, P, waveSum);
+    FlushRayCounters(counters, cnt);
+}
+
 // ------------------------------------------------------------------------------------------------ host objects
 template<typename T> struct DevBuf
 {
@@ -405,7 +434,7 @@ static constexpr int kMaxTimers = 64;
 // ray-counter slots (pairs of u64 on the device): 0 = wavefront path tracer, 1.. = ReSTIR PT kernels in launch order
 static constexpr int kCounterSlots = 16;
 static const char* const kCounterNames[kCounterSlots] = {"trace", "rpt_pathtrace", "rpt_replay_ctt", "rpt_replay_ttc", "rpt_reconnect_temporal",
-    "rpt_replay_cts", "rpt_replay_stc", "rpt_reconnect_spatial", "rdi_temporal", "rdi_spatial", "", "", "", "", "", ""};
+    "rpt_replay_cts", "rpt_replay_stc", "rpt_reconnect_spatial", "rdi_temporal", "rdi_spatial", "rgi", "", "", "", "", ""};
 
 struct zr_pass
 {
@@ -440,6 +469,8 @@ struct zr_pass
     DevBuf<uint32_t> rptLists, rptListCounts;      // 4 replay work lists (pixel ids) + their device-side counts
     // DI_EMISSIVE: two reservoir sets (A RGBA32_UINT, B RG32F), target, sample set
     DevBuf<U4> diA[2]; DevBuf<float> diB[2]; DevBuf<F4> diTarget; DevBuf<uint16_t> diSampleSet;
+    // INDIRECT / ReSTIR GI: two reservoir sets (A RGBA32F, B RGBA16F, C RGBA32F)
+    DevBuf<F4> giA[2], giC[2]; DevBuf<uint16_t> giB[2];
     bool temporalValid = false, doTemporal = false, doSpatial = false; int currIdx = 0;
     uint32_t own[4] = {0, 0, 0, 0};                // owned rect (global pixels); w == 0 -> the whole G-buffer rect
     // PRELIGHTING
@@ -744,6 +775,15 @@ static int AllocPass(zr_pass* p)
         if ((r = p->groupMax.Alloc((size_t)kMaxRounds * ((p->w + 7) / 8) * ((p->h + 7) / 8)))) return r;
         HIP_TRY(hipMemset(p->finalRGBA.p, 0, cap * 4 * sizeof(float)));
         HIP_TRY(hipMemset(p->counters.p, 0, 2 * kCounterSlots * sizeof(unsigned long long)));
+        if (p->integrator == ZR_INTEGRATOR_RESTIR_GI)
+        {
+            for (int k = 0; k < 2; k++)
+            {
+                if ((r = p->giA[k].Alloc(cap)) || (r = p->giB[k].Alloc(4 * cap)) || (r = p->giC[k].Alloc(cap))) return r;
+                HIP_TRY(hipMemset(p->giA[k].p, 0, cap * 16)); HIP_TRY(hipMemset(p->giB[k].p, 0, cap * 8)); HIP_TRY(hipMemset(p->giC[k].p, 0, cap * 16));
+            }
+            p->temporalValid = false; p->currIdx = 0;
+        }
         if (p->integrator == ZR_INTEGRATOR_RESTIR_PT)
         {
             for (int k = 0; k < 2; k++)
@@ -772,8 +812,8 @@ static int AllocPass(zr_pass* p)
 int zr_pass_init(zr_pass* p, uint32_t w, uint32_t h, int integrator)
 {
     if (!p || !w || !h) return Fail(ZR_ERR_INVALID_ARG, "zr_pass_init: bad argument");
-    if (p->kind == ZR_PASS_INDIRECT && integrator != ZR_INTEGRATOR_PATH_TRACING && integrator != ZR_INTEGRATOR_RESTIR_PT)
-        return Fail(ZR_ERR_UNSUPPORTED, "integrator %d is not implemented yet (PATH_TRACING and RESTIR_PT only)", integrator);
+    if (p->kind == ZR_PASS_INDIRECT && (integrator < ZR_INTEGRATOR_PATH_TRACING || integrator > ZR_INTEGRATOR_RESTIR_PT))
+        return Fail(ZR_ERR_INVALID_ARG, "unknown integrator %d", integrator);
     HIP_TRY(hipSetDevice(p->device));
     p->w = w; p->h = h; p->integrator = integrator;
     int r = AllocPass(p);
@@ -902,6 +942,36 @@ static int RenderDirectEmissive(zr_pass* p, hipStream_t s, const zr_frame_consta
     return ZR_OK;
 }
 
+// IndirectLighting::RenderReSTIR_GI (IndirectLighting.cpp:277-368) + the Render() tail (:1006-1025)
+static int RenderReSTIR_GI(zr_pass* p, hipStream_t s, const zr_frame_constants* cb, const zr_scene* sc, zr_gbuffer* gb)
+{
+    using namespace rgi;
+    if (gb->x0 || gb->y0 || gb->w != cb->render_width || gb->h != cb->render_height)
+        return Fail(ZR_ERR_UNSUPPORTED, "RESTIR_GI needs the whole frame on one device (its screen-tile halo exchange is not implemented yet)");
+    const zr_params& ip = p->params;
+    GiFrame F;
+    F.sc = sc->view; F.gb = gb->View(); F.gbPrev = gb->PrevView();
+    F.ox0 = 0; F.oy0 = 0; F.ow = gb->w; F.oh = gb->h;
+    F.cur.A = p->giA[p->currIdx].p; F.cur.B = p->giB[p->currIdx].p; F.cur.C = p->giC[p->currIdx].p;
+    F.prev.A = p->giA[1 - p->currIdx].p; F.prev.B = p->giB[1 - p->currIdx].p; F.prev.C = p->giC[1 - p->currIdx].p;
+    F.finalRGBA = p->finalRGBA.p;
+    GiParams& prm = F.prm;
+    prm.flags = ip.flags; prm.maxNonTrBounces = ip.max_non_tr_bounces; prm.maxGlossyTrBounces = ip.max_glossy_tr_bounces;
+    prm.numSampleSets = ip.presampling ? ip.num_sample_sets : 0u;
+    prm.accumulate = (cb->accumulate && cb->camera_static) ? 1u : 0u;
+    prm.doTemporal = ((ip.flags & ZR_IND_TEMPORAL_RESAMPLE) && p->temporalValid && gb->numRendered >= 2) ? 1u : 0u;
+    prm.writeReservoirs = (prm.doTemporal || !p->temporalValid) ? 1u : 0u;
+    prm.M_max = (float)ip.m_max_temporal;
+    const uint32_t tilesX = (p->w + 15) / 16, tilesY = (p->h + 15) / 16;
+    TimerBegin(p, s, "rgi");
+    hipLaunchKernelGGL(k_rgi, dim3(tilesX * tilesY), dim3(kBlock), 0, s, F, *cb, tilesX, p->counters.p + 2 * 10);
+    TimerEnd(p, s);
+    HIP_TRY(hipGetLastError());
+    p->temporalValid = true;
+    p->currIdx = 1 - p->currIdx;
+    return ZR_OK;
+}
+
 // IndirectLighting::RenderReSTIR_PT (IndirectLighting.cpp:877-1004) + the Render() tail (:1006-1025).
 // stages: ZR_STAGE_TEMPORAL = K11 + temporal passes, ZR_STAGE_SPATIAL = spatial passes + end-of-frame bookkeeping; a
 // multi-GPU host exchanges reservoir halos between the two (and after the second).
@@ -997,7 +1067,8 @@ static int RenderIndirect(zr_pass* p, hipStream_t s, const zr_frame_constants* c
     if (p->params.presampling && (!sc->view.sampleSets || sc->numSampleSets != p->params.num_sample_sets || sc->view.sampleSetSize != p->params.sample_set_size))
         return Fail(ZR_ERR_NOT_INITIALIZED, "presampled light sets missing or of another size: render the PRELIGHTING pass with the same presampling params first");
     if (p->integrator == ZR_INTEGRATOR_RESTIR_PT) return RenderReSTIR_PT(p, s, cb, sc, gb, stages);
-    if (!(stages & ZR_STAGE_TEMPORAL)) return ZR_OK;      // single-stage integrators render in the first stage
+    if (!(stages & ZR_STAGE_TEMPORAL)) return ZR_OK;
+    if (p->integrator == ZR_INTEGRATOR_RESTIR_GI) return RenderReSTIR_GI(p, s, cb, sc, gb);      // single-stage integrators render in the first stage
     PtParams prm;
     prm.maxNonTrBounces = p->params.max_non_tr_bounces; prm.maxGlossyTrBounces = p->params.max_glossy_tr_bounces;
     prm.russianRoulette = (p->params.flags & ZR_IND_RUSSIAN_ROULETTE) ? 1u : 0u;
@@ -1127,6 +1198,13 @@ int zr_pass_get_output(const zr_pass* p, int which, void** dev, uint32_t* w, uin
     if (p->kind != ZR_PASS_INDIRECT) return Fail(ZR_ERR_INVALID_ARG, "pass has no such output");
     uint32_t bytes = 16;
     if (which == ZR_OUT_FINAL) *dev = p->finalRGBA.p;
+    else if (which >= ZR_OUT_RGI_RESERVOIR_A && which <= ZR_OUT_RGI_RESERVOIR_C && p->integrator == ZR_INTEGRATOR_RESTIR_GI)
+    {
+        const int last = 1 - p->currIdx;
+        if (which == ZR_OUT_RGI_RESERVOIR_A) *dev = p->giA[last].p;
+        else if (which == ZR_OUT_RGI_RESERVOIR_B) { *dev = p->giB[last].p; bytes = 8; }
+        else *dev = p->giC[last].p;
+    }
     else if (which >= ZR_OUT_RPT_RBUF_CTN_A && which <= ZR_OUT_RPT_RBUF_NTC_D && p->integrator == ZR_INTEGRATOR_RESTIR_PT)
     {
         const zr_pass::RBufStorage& B = p->rb[(which - ZR_OUT_RPT_RBUF_CTN_A) / 4];
