@@ -182,10 +182,11 @@ struct Scene
 
     // One candidate test.  zr_ray_tri applies the ray's own (tmin, tmax); the closest-hit rule on top of it is:
     // smaller t wins, equal t goes to the smaller global triangle index (ABI tie-break, include/zr_intersect.h).
-    inline void TestTri(uint32_t ti, float3 o, float3 d, float tmin, float rayTmax, uint32_t mask, RawHit& best) const
+    inline void TestTri(uint32_t ti, float3 o, float3 d, float tmin, float rayTmax, uint32_t mask, RawHit& best, bool filterID = false, uint32_t ignoreID = 0) const
     {
         const WorldTri& T = tris[ti];
         if (!(T.mask & mask)) return;
+        if (filterID) { uint32_t kx = T.mesh_idx, ky = 0, kz = T.prim_idx; zr_pcg3d(&kx, &ky, &kz); if (kx == ignoreID) return; }
         float t, u, v;
         if (zr_ray_tri(o.x, o.y, o.z, d.x, d.y, d.z, T.v0[0], T.v0[1], T.v0[2], T.e1[0], T.e1[1], T.e1[2],
                 T.e2[0], T.e2[1], T.e2[2], tmin, rayTmax, &t, &u, &v))
@@ -197,14 +198,15 @@ struct Scene
 
     // closest hit (anyHit=false) or first accepted hit (anyHit=true) with tmin < t < tmax over triangles whose
     // instance mask intersects `mask`
-    RawHit Trace(float3 o, float3 d, float tmin, float tmax, uint32_t mask, bool anyHit) const
+    // filterID: triangles whose hashed ID equals ignoreID are not candidates (approximate shadow segments, see Visibility_Segment)
+    RawHit Trace(float3 o, float3 d, float tmin, float tmax, uint32_t mask, bool anyHit, bool filterID = false, uint32_t ignoreID = 0) const
     {
         RawHit best; best.hit = false; best.t = tmax; best.u = best.v = 0; best.tri = 0xffffffffu;
         if (bruteForce)
         {
             for (uint32_t i = 0; i < tris.size(); i++)
             {
-                TestTri(i, o, d, tmin, tmax, mask, best);
+                TestTri(i, o, d, tmin, tmax, mask, best, filterID, ignoreID);
                 if (anyHit && best.hit) return best;
             }
             return best;
@@ -222,7 +224,7 @@ struct Scene
             {
                 for (uint32_t i = n.first; i < n.first + n.count; i++)
                 {
-                    TestTri(triOrder[i], o, d, tmin, tmax, mask, best);
+                    TestTri(triOrder[i], o, d, tmin, tmax, mask, best, filterID, ignoreID);
                     if (anyHit && best.hit) return best;
                 }
             }
@@ -402,8 +404,12 @@ static inline bool Visibility_Segment(const Scene& sc, bool approximate, float3 
     Scene::RawHit h;
     if (approximate)
     {
+        // RAY_FLAG_ACCEPT_FIRST_HIT_AND_END_SEARCH + "hit ID == light ID -> visible" (RayQuery.hlsli:372-405) depends on which
+        // hit the driver finds first.  Pinned order-independently: triangles carrying the target's ID are not occluders,
+        // any other hit inside the shortened segment occludes.
         float tmax = Math::PrevFloat32(rayT * 0.999f - Math::NextFloat32(tminv));
-        h = sc.Trace(adjustedOrigin, wi, tminv, tmax, ZR_SUBGROUP_NON_EMISSIVE, true);
+        h = sc.Trace(adjustedOrigin, wi, tminv, tmax, ZR_SUBGROUP_NON_EMISSIVE, true, true, triID);
+        return !h.hit;
     }
     else
         h = sc.Trace(adjustedOrigin, wi, tminv, rayT, ZR_SUBGROUP_NON_EMISSIVE, false);

@@ -46,13 +46,18 @@ struct SceneView
 
 struct RawHit { float t, u, v; uint32_t tri; };     // tri = global triangle index, kInvalidTri on miss
 
+// hashed triangle ID of the reference: PCG3d(GeometryIndex = meshIdx, InstanceID = 0, PrimitiveIndex).x
+ZR_HD uint32_t TriID(uint32_t meshIdx, uint32_t primIdx)
+{ uint32_t kx = meshIdx, ky = 0, kz = primIdx; zr_pcg3d(&kx, &ky, &kz); return kx; }
+
 ZR_HD void IntersectLeaf(const SceneView& sc, uint32_t first, uint32_t count, V3 o, V3 d, float tmin, float tmax,
-    uint32_t mask, RawHit& best)
+    uint32_t mask, RawHit& best, bool filterID = false, uint32_t ignoreID = 0)
 {
     for (uint32_t i = first; i < first + count; i++)
     {
         const BvhTri& T = sc.tris[i];
         if (!(T.mask & mask)) continue;
+        if (filterID) { const TriMeta tm = sc.triMeta[T.gidx]; if (TriID(tm.mesh, tm.prim) == ignoreID) continue; }
         float t, u, v;
         if (zr_ray_tri(o.x, o.y, o.z, d.x, d.y, d.z, T.v0[0], T.v0[1], T.v0[2], T.e1[0], T.e1[1], T.e1[2],
                 T.e2[0], T.e2[1], T.e2[2], tmin, tmax, &t, &u, &v))
@@ -67,12 +72,12 @@ ZR_HD void IntersectLeaf(const SceneView& sc, uint32_t first, uint32_t count, V3
 // Stack-based BVH2 traversal.  `stack` points at this lane's private stack (scratch on the host executor, registers /
 // scratch / LDS slice on the device -- the caller decides).  anyHit: return on the first accepted hit.
 template<bool AnyHit>
-ZR_HD RawHit Traverse(const SceneView& sc, V3 o, V3 d, float tmin, float tmax, uint32_t mask, uint32_t* stack)
+ZR_HD RawHit Traverse(const SceneView& sc, V3 o, V3 d, float tmin, float tmax, uint32_t mask, uint32_t* stack, bool filterID = false, uint32_t ignoreID = 0)
 {
     RawHit best; best.t = tmax; best.u = 0; best.v = 0; best.tri = kInvalidTri;
     if (sc.numNodes == 0)
     {
-        IntersectLeaf(sc, 0, sc.numTris, o, d, tmin, tmax, mask, best);
+        IntersectLeaf(sc, 0, sc.numTris, o, d, tmin, tmax, mask, best, filterID, ignoreID);
         return best;
     }
     const float idx = zr_safe_rcp_dir(d.x), idy = zr_safe_rcp_dir(d.y), idz = zr_safe_rcp_dir(d.z);
@@ -83,7 +88,7 @@ ZR_HD RawHit Traverse(const SceneView& sc, V3 o, V3 d, float tmin, float tmax, u
         if (cur & kLeafBit)
         {
             uint32_t first = (cur & 0x7fffffffu) >> 3, count = (cur & 7u) + 1u;
-            IntersectLeaf(sc, first, count, o, d, tmin, tmax, mask, best);
+            IntersectLeaf(sc, first, count, o, d, tmin, tmax, mask, best, filterID, ignoreID);
             if (AnyHit && best.tri != kInvalidTri) return best;
             if (sp == 0) break;
             cur = stack[--sp];
@@ -178,9 +183,6 @@ ZR_HD void FillHit(const SceneView& sc, uint32_t meshIdx, uint32_t primIdx, floa
         ret.ID = kx;
     }
 }
-
-ZR_HD uint32_t TriID(uint32_t meshIdx, uint32_t primIdx)
-{ uint32_t kx = meshIdx, ky = 0, kz = primIdx; zr_pcg3d(&kx, &ky, &kz); return kx; }
 
 // GetMaterialData, RayQuery.hlsli:452-524 (texture maps not bound: factors only)
 ZR_HD bool GetMaterialData(const SceneView& sc, V3 wo, float eta_curr, HitInfo& hit, Surface& surface, float& eta)

@@ -415,10 +415,10 @@ ZR_HD bool VisibilitySegmentApprox(const Globals& g, V3 origin, V3 wi, float ray
     const float tminv = 3e-6f;
     const float tmax = PrevFloat32(rayT * 0.999f - NextFloat32(tminv));
     g.cnt[1]++;
-    RawHit h = Traverse<true>(*g.sc, o, wi, tminv, tmax, ZR_SUBGROUP_NON_EMISSIVE, g.stack);
-    if (h.tri == kInvalidTri) return true;
-    const TriMeta tm = g.sc->triMeta[h.tri];
-    return TriID(tm.mesh, tm.prim) == triID;
+    // "first accepted hit, visible iff its ID is the target's" (RayQuery.hlsli:372-405) depends on the traversal order; pinned
+    // order-independently: triangles carrying the target's ID are not occluders, any other hit in the shortened segment is
+    RawHit h = Traverse<true>(*g.sc, o, wi, tminv, tmax, ZR_SUBGROUP_NON_EMISSIVE, g.stack, true, triID);
+    return h.tri == kInvalidTri;
 }
 
 ZR_HD bool IsSpecular(const Surface& s) { return s.GlossSpecular() && (s.metallic || s.specTr) && (!s.Coated() || s.CoatSpecular()); }
