@@ -86,7 +86,12 @@ def main():
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--scene", default=os.path.join(ROOT, "tests", "golden", "cornell_emissive.npz"))
+    ap.add_argument("--scene", default=os.path.join(ROOT, "tests", "golden", "cornell_emissive.npz"),
+                    help="wire-format .npz, or 'synthetic' = the procedural Sponza-class scene of BASELINE config 4 "
+                         "(262144 triangles + 100000 emissive triangles, presampled light sets on)")
+    ap.add_argument("--synthetic-tris", type=int, default=262144)
+    ap.add_argument("--synthetic-layout", choices=["atrium", "soup"], default="atrium")
+    ap.add_argument("--synthetic-emissives", type=int, default=100000)
     ap.add_argument("--no-final-halo", action="store_true",
                     help="skip the post-frame halo exchange (exact for a static camera, which this bench uses)")
     ap.add_argument("--direct", action="store_true", help="also run the ReSTIR DI (emissive) pass every frame (N = 1)")
@@ -110,8 +115,18 @@ def main():
     torch.cuda.set_device(local_rank)
 
     W, H = args.width, args.height
-    sc = scene_io.load_npz(args.scene)
+    cam = {}
+    if args.scene == "synthetic":
+        sc = scene_io.make_synthetic_scene(num_tris=args.synthetic_tris, num_emissive=args.synthetic_emissives, layout=args.synthetic_layout)
+        cam = dict(cam_pos=(0, 0, -3.5))
+        scene_name = f"synthetic Sponza-class {args.synthetic_layout} ({sc.num_tris} triangles, {len(sc.emissives)} emissive, alias table + presampled sets 128x512)"
+    else:
+        sc = scene_io.load_npz(args.scene)
+        scene_name = f"Cornell Box ({os.path.basename(args.scene)[:-4]}: {sc.num_tris} triangles, {len(sc.emissives)} emissive)"
     prm = wire.default_params()
+    if args.scene == "synthetic":
+        # the reference turns light presampling on above a light-count threshold (PreLighting.cpp:289-297)
+        prm.presampling, prm.num_sample_sets, prm.sample_set_size = 1, 128, 512
     x0, y0, tw, th = tile_rect(W, H, world, rank)
     rpt = args.integrator == "restir_pt"
     tiled = None
@@ -130,10 +145,12 @@ def main():
 
     if args.direct:
         assert world == 1, "--direct: the DI pass has no tile split yet"
-        r.enable_direct(wire.default_params_di(), device=local_rank)
+        dip = wire.default_params_di()
+        dip.presampling, dip.num_sample_sets, dip.sample_set_size = prm.presampling, prm.num_sample_sets, prm.sample_set_size
+        r.enable_direct(dip, device=local_rank)
 
     def frame(i):
-        cb = scene_io.make_frame_constants(W, H, frame_num=i, num_emissives=len(sc.emissives))
+        cb = scene_io.make_frame_constants(W, H, frame_num=i, num_emissives=len(sc.emissives), **cam)
         if tiled is not None:
             tiled.render_frame(cb, exchange_final=not args.no_final_halo)
         else:
@@ -179,12 +196,12 @@ def main():
         "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
         "scaling": "strong",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": (f"Cornell Box (cornell_emissive: 58 triangles, 2 emissive) {W}x{H}, G-buffer + ReSTIR PT "
+        "config": {"workload": (f"{scene_name} {W}x{H}, G-buffer + ReSTIR PT "
                                 f"(K1 + K11-K16: initial candidates, temporal + spatial reconnection reuse, boiling "
                                 f"suppression; 3 non-transmissive / 4 glossy-transmissive bounces, static camera)") if rpt else
-                               (f"Cornell Box (cornell_emissive: 58 triangles, 2 emissive) {W}x{H}, G-buffer + ReSTIR GI (K1+K10, "
+                               (f"{scene_name} {W}x{H}, G-buffer + ReSTIR GI (K1+K10, "
                                 f"3 bounces, temporal reuse, static camera)") if args.integrator == "restir_gi" else
-                               (f"Cornell Box (cornell_emissive: 58 triangles, 2 emissive) {W}x{H}, G-buffer + 1-spp "
+                               (f"{scene_name} {W}x{H}, G-buffer + 1-spp "
                                 f"path tracer (K1+K9, NEE+MIS, 3 non-transmissive bounces, static camera)"),
                    "integrator": args.integrator + ("+restir_di" if args.direct else ""),
                    "parallelism": f"screen tiles {tile_grid(world)}" + (
@@ -242,7 +259,7 @@ def main():
                            "frame_model_GBs": round(frame_bytes / (ms_per_step * 1e-3) / 1e9, 2),
                            "kernel_ms_per_frame": {k: round(v[0] / nfr, 4) for k, v in agg.items()}}
         if not args.no_cpu_baseline:
-            cbf = scene_io.make_frame_constants(W, H, frame_num=1, num_emissives=len(sc.emissives))
+            cbf = scene_io.make_frame_constants(W, H, frame_num=1, num_emissives=len(sc.emissives), **cam)
             out["cpu_baseline"] = cpu_baseline(sc, cbf)
     if rank == 0:
         print(json.dumps(out))

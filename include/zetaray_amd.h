@@ -55,7 +55,8 @@ typedef enum zr_pass_kind {
     ZR_PASS_PRELIGHTING = 1,   /* PreLighting + EmissiveTriangleAliasTable */
     ZR_PASS_DI_EMISSIVE = 2,   /* DirectLighting     */
     ZR_PASS_DI_SKY      = 3,   /* SkyDI              */
-    ZR_PASS_INDIRECT    = 4    /* IndirectLighting   */
+    ZR_PASS_INDIRECT    = 4,   /* IndirectLighting   */
+    ZR_PASS_COMPOSITING = 5    /* Compositing: (DI + indirect * !emissive) / NumFramesCameraStatic */
 } zr_pass_kind;
 
 /* IndirectLighting::INTEGRATOR, reference IndirectLighting.h:40-46 */
@@ -211,6 +212,12 @@ int zr_pass_halo_unpack(zr_pass* pass, void* hip_stream, const zr_gbuffer* gbuff
 int zr_pass_get_output(const zr_pass* pass, int which, void** dev_ptr, uint32_t* width, uint32_t* height,
                        uint32_t* bytes_per_pixel);
 int zr_pass_download_output(const zr_pass* pass, int which, void* hip_stream, void* host_dst, size_t bytes);
+/* Compositing inputs (cbCompositing::*DescHeapIdx + CB_COMPOSIT_FLAGS, RP/Compositing/Compositing_Common.h:12-37): device pointers
+   to RGBA32F planes of the pass size, or NULL to leave a term out.  Output: zr_pass_get_output(ZR_OUT_FINAL). */
+#define ZR_IN_EMISSIVE_DI 0
+#define ZR_IN_INDIRECT    1
+#define ZR_IN_SKY_DI      2
+int zr_pass_set_input(zr_pass* pass, int which, const void* dev_rgba32f);
 /* ray counters accumulated since the last call (device -> host copy; synchronises the stream) */
 int zr_pass_read_counters(zr_pass* pass, void* hip_stream, zr_counters* out, int reset);
 /* the same counters split by the kernel that issued the queries (not reset; roofline bookkeeping of bench.py) */

@@ -373,3 +373,22 @@ def test_restir_gi_materials_rr_on_gpu(api):
         r.render_frame(cb)
         want = ogi.render(cb, prm)
         assert np.array_equal(r.final().view(np.uint32), want.view(np.uint32)), f"frame {f}"
+
+
+def test_compositing(api, cornell_emissive, oracle_emissive):
+    """Compositing.hlsl: (emissive DI + indirect * !emissive) / NumFramesCameraStatic; miss pixels 0 when not accumulating."""
+    from oracle import zro
+    w, h = 96, 64
+    r = api.Renderer(cornell_emissive, w, h, params=wire.default_params(), integrator=api.INTEGRATOR_RESTIR_PT)
+    di = r.enable_direct(wire.default_params_di())
+    comp = r.enable_compositing()
+    for f in range(1, 4):
+        cb = _frame(cornell_emissive, w, h, f, accumulate=1, camera_static=1, num_frames_static=f)
+        r.render_frame(cb)
+    ind, d, out = r.final(), di.download(), comp.download()
+    gb, _ = r.gbuffer.download()
+    mr = gb[wire.GB_PLANE_NAMES.index("metallic_roughness")]
+    emissive = ((mr & 0xff) & 2) != 0
+    want = (d[..., :3] + ind[..., :3] * (~emissive)[..., None]) / np.float32(3)
+    assert np.array_equal(out[..., :3].view(np.uint32), want.astype(np.float32).view(np.uint32))
+    assert out[..., :3].max() > 0

@@ -72,3 +72,22 @@ def test_cpp_passes_render_restir_pt_sequence(cornell_emissive, oracle_emissive)
     for f in range(n):
         want = o.render(cbs[f], prm)
     assert np.array_equal(out.view(np.uint32), want.view(np.uint32))
+
+
+@pytest.mark.gpu
+def test_cpp_passes_render_gi_and_di_sequence(cornell_emissive, oracle_emissive):
+    """C++ RenderGraph with GBuffer -> PreLighting -> {DirectLighting (ReSTIR DI), Indirect (ReSTIR GI)} for 3 frames."""
+    from oracle import zro
+    w, h, n = 80, 48, 3
+    cbs = np.ascontiguousarray(np.stack([scene_io.make_frame_constants(w, h, frame_num=f, num_emissives=len(cornell_emissive.emissives)) for f in range(1, n + 1)]))
+    desc = cornell_emissive.desc()
+    out, dout = np.zeros((h, w, 4), np.float32), np.zeros((h, w, 4), np.float32)
+    L = _lib()
+    L.zrh_render_sequence2.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.c_void_p, C.c_void_p]
+    assert L.zrh_render_sequence2(C.addressof(desc), cbs.ctypes.data, n, w, h, 1, out.ctypes.data, dout.ctypes.data) == 0
+    ogi, odi = zro.OracleRGI(oracle_emissive, w, h), zro.OracleRDI(oracle_emissive, w, h)
+    for f in range(n):
+        want = ogi.render(cbs[f], wire.default_params())
+        dwant = odi.render(cbs[f], wire.default_params_di())
+    assert np.array_equal(out.view(np.uint32), want.view(np.uint32))
+    assert np.array_equal(dout.view(np.uint32), dwant.view(np.uint32))

@@ -15,7 +15,8 @@ from . import wire
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libzetaray_amd.so")
 
-PASS_GBUFFER, PASS_PRELIGHTING, PASS_DI_EMISSIVE, PASS_DI_SKY, PASS_INDIRECT = range(5)
+PASS_GBUFFER, PASS_PRELIGHTING, PASS_DI_EMISSIVE, PASS_DI_SKY, PASS_INDIRECT, PASS_COMPOSITING = range(6)
+IN_EMISSIVE_DI, IN_INDIRECT, IN_SKY_DI = range(3)
 INTEGRATOR_PATH_TRACING, INTEGRATOR_RESTIR_GI, INTEGRATOR_RESTIR_PT = range(3)
 OUT_FINAL = 0
 # ReSTIR PT persistent state (zr_output): name -> (id, dtype, channels)
@@ -35,7 +36,7 @@ EXPORTS = [
     "zr_pass_set_params", "zr_pass_render", "zr_pass_get_output", "zr_pass_download_output",
     "zr_pass_read_counters", "zr_pass_read_kernel_counters", "zr_pass_enable_timing", "zr_pass_get_timings", "zr_pass_destroy",
     "zr_trace_closest", "zr_trace_any",
-    "zr_pass_set_owned_rect", "zr_pass_render_stage", "zr_pass_halo_pack", "zr_pass_halo_unpack",
+    "zr_pass_set_owned_rect", "zr_pass_render_stage", "zr_pass_halo_pack", "zr_pass_halo_unpack", "zr_pass_set_input",
 ]
 STAGE_TEMPORAL, STAGE_SPATIAL, STAGE_ALL = 1, 2, 3
 HALO_POST_TEMPORAL, HALO_FINAL = 0, 1
@@ -91,6 +92,7 @@ def lib():
         L.zr_pass_download_output.argtypes = [vp, i32, vp, vp, C.c_size_t]
         L.zr_pass_read_counters.argtypes = [vp, vp, vp, i32]
         L.zr_pass_read_kernel_counters.argtypes = [vp, vp, u32, vp, vp, vp, vp]
+        L.zr_pass_set_input.argtypes = [vp, i32, vp]
         L.zr_pass_set_owned_rect.argtypes = [vp, u32, u32, u32, u32]
         L.zr_pass_render_stage.argtypes = [vp, vp, vp, vp, vp, i32]
         L.zr_pass_halo_pack.argtypes = [vp, vp, vp, i32, u32, u32, u32, u32, vp, C.c_size_t]
@@ -212,6 +214,9 @@ class Pass:
         cbb = np.ascontiguousarray(cb)
         _check(lib().zr_pass_render_stage(self.h, stream, cbb.ctypes.data, scene.h, gbuffer.h if gbuffer is not None else None, stages))
 
+    def set_input(self, which, dev_ptr):
+        _check(lib().zr_pass_set_input(self.h, which, dev_ptr))
+
     def set_owned_rect(self, x0, y0, w, h):
         _check(lib().zr_pass_set_owned_rect(self.h, x0, y0, w, h))
 
@@ -294,7 +299,16 @@ class Renderer:
         self._presampling = bool(params is not None and params.presampling)
         self.p_indirect = Pass(PASS_INDIRECT, width, height, integrator, device=device, params=params)
         self.p_direct = None          # ReSTIR DI (emissive): enable_direct()
+        self.p_composit = None        # Compositing: enable_compositing()
         self._alias_ready = False
+
+    def enable_compositing(self, device=0):
+        """add the Compositing pass: (DI + indirect * !emissive) / NumFramesCameraStatic"""
+        self.p_composit = Pass(PASS_COMPOSITING, self.p_indirect.w, self.p_indirect.h_, device=device)
+        self.p_composit.set_input(IN_INDIRECT, self.p_indirect.output_ptr()[0])
+        if self.p_direct is not None:
+            self.p_composit.set_input(IN_EMISSIVE_DI, self.p_direct.output_ptr()[0])
+        return self.p_composit
 
     def enable_direct(self, params=None, device=0):
         """add the DirectLighting (ReSTIR DI, emissive) pass; it renders after PreLighting, next to Indirect"""
@@ -309,6 +323,8 @@ class Renderer:
         if self.p_direct is not None:
             self.p_direct.render(cb, self.scene, self.gbuffer, stream)
         self.p_indirect.render(cb, self.scene, self.gbuffer, stream)
+        if self.p_composit is not None:
+            self.p_composit.render(cb, self.scene, self.gbuffer, stream)
 
     def final(self):
         return self.p_indirect.download()

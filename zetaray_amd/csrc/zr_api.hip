@@ -155,6 +155,13 @@ __global__ void __launch_bounds__(kBlock) k_pt_rr(SceneView sc, PtParams prm, Pa
         PtRussianRoulette(sc, prm, q, i, groupMax);
 }
 
+// Compositing: pure streaming kernel (2 + 16 + 16 B read, 16 B written per pixel)
+__global__ void __launch_bounds__(256) k_composite(zr_frame_constants g, const uint16_t* mr, const F4* skyDI, const F4* emissiveDI, const F4* indirect, F4* out, uint32_t n)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = CompositePixel(g, mr[i], skyDI, emissiveDI, indirect, i, out[i]);
+}
+
 __global__ void k_presample(SceneView sc, uint32_t total, uint32_t frameNum, uint32_t numEmissives, zr_presampled_tri* out)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -472,6 +479,7 @@ struct zr_pass
     // INDIRECT / ReSTIR GI: two reservoir sets (A RGBA32F, B RGBA16F, C RGBA32F)
     DevBuf<F4> giA[2], giC[2]; DevBuf<uint16_t> giB[2];
     bool temporalValid = false, doTemporal = false, doSpatial = false; int currIdx = 0;
+    const F4* compIn[3] = {nullptr, nullptr, nullptr};     // COMPOSITING inputs (emissive DI, indirect, sky DI)
     uint32_t own[4] = {0, 0, 0, 0};                // owned rect (global pixels); w == 0 -> the whole G-buffer rect
     // PRELIGHTING
     DevBuf<float> power;
@@ -725,7 +733,7 @@ int zr_gbuffer_device_plane(const zr_gbuffer* g, int plane, void** dev)
 int zr_pass_create(int kind, int device, zr_pass** out)
 {
     if (!out) return Fail(ZR_ERR_INVALID_ARG, "null out");
-    if (kind < ZR_PASS_GBUFFER || kind > ZR_PASS_INDIRECT) return Fail(ZR_ERR_INVALID_ARG, "unknown pass kind %d", kind);
+    if (kind < ZR_PASS_GBUFFER || kind > ZR_PASS_COMPOSITING) return Fail(ZR_ERR_INVALID_ARG, "unknown pass kind %d", kind);
     if (kind == ZR_PASS_DI_SKY) return Fail(ZR_ERR_UNSUPPORTED, "pass kind %d (sun / sky ReSTIR DI) is not implemented yet", kind);
     int r = RequireDevice(device);
     if (r) return r;
@@ -746,6 +754,12 @@ int zr_pass_create(int kind, int device, zr_pass** out)
 static int AllocPass(zr_pass* p)
 {
     int r;
+    if (p->kind == ZR_PASS_COMPOSITING)
+    {
+        const size_t cap = (size_t)p->w * p->h;
+        if ((r = p->finalRGBA.Alloc(cap * 4))) return r;
+        HIP_TRY(hipMemset(p->finalRGBA.p, 0, cap * 4 * sizeof(float)));
+    }
     if (p->kind == ZR_PASS_DI_EMISSIVE)
     {
         const size_t cap = (size_t)p->w * p->h;
@@ -1117,6 +1131,24 @@ static int RenderIndirect(zr_pass* p, hipStream_t s, const zr_frame_constants* c
 int zr_pass_render(zr_pass* p, void* stream, const zr_frame_constants* cb, const zr_scene* sc, zr_gbuffer* gb)
 { return zr_pass_render_stage(p, stream, cb, sc, gb, ZR_STAGE_ALL); }
 
+int zr_pass_set_input(zr_pass* p, int which, const void* dev)
+{
+    if (!p || p->kind != ZR_PASS_COMPOSITING || which < 0 || which > 2) return Fail(ZR_ERR_INVALID_ARG, "zr_pass_set_input: not a COMPOSITING pass or bad input id");
+    p->compIn[which] = (const F4*)dev;
+    return ZR_OK;
+}
+static int RenderCompositing(zr_pass* p, hipStream_t s, const zr_frame_constants* cb, zr_gbuffer* gb)
+{
+    if (!gb || gb->w != p->w || gb->h != p->h) return Fail(ZR_ERR_INVALID_ARG, "COMPOSITING needs a gbuffer of the pass size");
+    const uint32_t n = p->w * p->h;
+    TimerBegin(p, s, "compositing");
+    hipLaunchKernelGGL(k_composite, dim3((n + 255) / 256), dim3(256), 0, s, *cb, (const uint16_t*)gb->Planes()[ZR_GB_METALLIC_ROUGHNESS].p, p->compIn[ZR_IN_SKY_DI],
+        p->compIn[ZR_IN_EMISSIVE_DI], p->compIn[ZR_IN_INDIRECT], (F4*)p->finalRGBA.p, n);
+    TimerEnd(p, s);
+    HIP_TRY(hipGetLastError());
+    return ZR_OK;
+}
+
 int zr_pass_set_owned_rect(zr_pass* p, uint32_t x0, uint32_t y0, uint32_t w, uint32_t h)
 {
     if (!p) return Fail(ZR_ERR_INVALID_ARG, "null pass");
@@ -1173,6 +1205,7 @@ int zr_pass_render_stage(zr_pass* p, void* stream, const zr_frame_constants* cb,
     case ZR_PASS_PRELIGHTING: return (stages & ZR_STAGE_TEMPORAL) ? RenderPreLighting(p, s, cb, const_cast<zr_scene*>(sc)) : ZR_OK;
     case ZR_PASS_INDIRECT: return RenderIndirect(p, s, cb, sc, gb, stages);
     case ZR_PASS_DI_EMISSIVE: return (stages & ZR_STAGE_TEMPORAL) ? RenderDirectEmissive(p, s, cb, sc, gb) : ZR_OK;
+    case ZR_PASS_COMPOSITING: return (stages & ZR_STAGE_SPATIAL) ? RenderCompositing(p, s, cb, gb) : ZR_OK;
     default: return Fail(ZR_ERR_UNSUPPORTED, "pass kind %d not implemented", p->kind);
     }
 }
@@ -1181,6 +1214,15 @@ int zr_pass_get_output(const zr_pass* p, int which, void** dev, uint32_t* w, uin
 {
     if (!p || !dev) return Fail(ZR_ERR_INVALID_ARG, "null argument");
     if (!p->initialized) return Fail(ZR_ERR_NOT_INITIALIZED, "pass not initialised");
+    if (p->kind == ZR_PASS_COMPOSITING)
+    {
+        if (which != ZR_OUT_FINAL) return Fail(ZR_ERR_INVALID_ARG, "pass has no such output");
+        *dev = p->finalRGBA.p;
+        if (w) *w = p->w;
+        if (h) *h = p->h;
+        if (bpp) *bpp = 16;
+        return ZR_OK;
+    }
     if (p->kind == ZR_PASS_DI_EMISSIVE)
     {
         uint32_t b = 16;

@@ -702,6 +702,21 @@ ZR_HD zr_presampled_tri PresampleEmissive(const SceneView& sc, uint32_t i, uint3
     return s;
 }
 
+// Compositing.hlsl:30-125 for one pixel (in-scattering off; Le_SkyWithSunDisk of miss pixels pinned to 0: no sky model bound)
+ZR_HD F4 CompositePixel(const zr_frame_constants& g, uint16_t mrp, const F4* skyDI, const F4* emissiveDI, const F4* indirect, size_t px, F4 prevOut)
+{
+    const uint32_t fl = (uint32_t)zr_fma((float)(mrp & 0xff) / 255.0f, 255.0f, 0.5f);
+    const bool accumulate = g.accumulate && g.camera_static;
+    if ((fl & ZR_GBUF_INVALID) && !accumulate) return f4(v3(0.0f), prevOut.w);
+    const uint32_t numFramesAccumulated = accumulate ? g.num_frames_camera_static : 1u;
+    V3 color = v3(0.0f);
+    if (skyDI) color = xyz(skyDI[px]);
+    else if (emissiveDI) color = color + xyz(emissiveDI[px]);
+    if (indirect && !(fl & ZR_GBUF_EMISSIVE)) color = color + xyz(indirect[px]);
+    color = color / (float)numFramesAccumulated;
+    return f4(color, prevOut.w);
+}
+
 // K2: EstimateTriEmissivePower.hlsl:29-79 (untextured branch)
 ZR_HD float EstimateTriPower(const zr_emissive_triangle& em)
 {

@@ -215,6 +215,30 @@ void PreLighting::Render(Core::CommandList& cl)
     m_aliasReady = true;
 }
 
+void DirectLighting::Init(FrameContext* ctx)
+{
+    InitRenderPass(ZR_PASS_DI_EMISSIVE, ctx, 0);
+    // the library installs the reference defaults for this pass kind (DirectLighting.cpp:100-107); keep a copy to edit
+    zr_params_default(&m_params);
+    m_params.flags = ZR_IND_TEMPORAL_RESAMPLE | ZR_IND_SPATIAL_RESAMPLE | ZR_DI_STOCHASTIC_SPATIAL | ZR_DI_EXTRA_DISOCCLUSION_SAMPLING;
+    m_params.m_max_temporal = 20; m_params.m_max_spatial = 20; m_params.alpha_min = 0.05f * 0.05f;
+}
+void DirectLighting::OnWindowResized() { ZR_CHECK(zr_pass_resize(m_pass, m_ctx->renderWidth, m_ctx->renderHeight)); }
+void DirectLighting::ResetTemporal() { ZR_CHECK(zr_pass_reset_temporal(m_pass)); }
+void DirectLighting::SetLightPresamplingParams(bool enable, int numSampleSets, int sampleSetSize)
+{
+    m_params.presampling = enable ? 1u : 0u; m_params.num_sample_sets = (uint32_t)numSampleSets; m_params.sample_set_size = (uint32_t)sampleSetSize;
+    ZR_CHECK(zr_pass_set_params(m_pass, &m_params));
+}
+void* DirectLighting::GetOutput(SHADER_OUT_RES i) const
+{
+    if (i != SHADER_OUT_RES::FINAL) { std::fprintf(stderr, "Invalid shader output.\n"); std::abort(); }
+    void* dev = nullptr; uint32_t w, h, bpp;
+    ZR_CHECK(zr_pass_get_output(m_pass, ZR_OUT_FINAL, &dev, &w, &h, &bpp));
+    return dev;
+}
+void DirectLighting::Render(Core::CommandList& cl) { ZR_CHECK(zr_pass_render(m_pass, cl.Stream(), &m_ctx->frameConstants, m_ctx->scene, m_ctx->gbuffer)); }
+
 void IndirectLighting::Init(FrameContext* ctx, INTEGRATOR method)
 {
     zr_params_default(&m_params);
@@ -302,17 +326,18 @@ int zrh_graph_selftest(char* out, int outLen)
 // Renders `n` consecutive frames (cbs[i] = cbFrameConstants of frame i) through the graph exactly as the reference's
 // frame loop does (PathTracer.cpp:474-552: register passes / resources, declare inputs / outputs, Build, submit, fence)
 // and copies the FINAL plane of the last frame.  integrator: 0 = PATH_TRACING, 2 = ReSTIR_PT.
-int zrh_render_sequence(const zr_scene_desc* desc, const zr_frame_constants* cbs, uint32_t n, uint32_t w, uint32_t h, int integrator, float* finalOut)
+int zrh_render_sequence2(const zr_scene_desc* desc, const zr_frame_constants* cbs, uint32_t n, uint32_t w, uint32_t h, int integrator, float* finalOut, float* directOut)
 {
     RenderPass::FrameContext ctx;
     ctx.device = 0; ctx.renderWidth = w; ctx.renderHeight = h;
     ZR_CHECK(zr_scene_create(0, desc, &ctx.scene));
     ZR_CHECK(zr_gbuffer_create(0, w, h, &ctx.gbuffer));
     {
-        RenderPass::GBufferRT gb; RenderPass::PreLighting pre; RenderPass::IndirectLighting ind;
+        RenderPass::GBufferRT gb; RenderPass::PreLighting pre; RenderPass::IndirectLighting ind; RenderPass::DirectLighting di;
         gb.Init(&ctx); pre.Init(&ctx); ind.Init(&ctx, (RenderPass::IndirectLighting::INTEGRATOR)integrator);
+        if (directOut) di.Init(&ctx);
         Core::RenderGraph g;
-        enum : uint64_t { R_GBUF = 1, R_ALIAS, R_IND };
+        enum : uint64_t { R_GBUF = 1, R_ALIAS, R_IND, R_DI };
         for (uint32_t f = 0; f < n; f++)
         {
             ctx.frameConstants = cbs[f];
@@ -320,10 +345,15 @@ int zrh_render_sequence(const zr_scene_desc* desc, const zr_frame_constants* cbs
             auto hGB = g.RegisterRenderPass("GBuffer", Core::RENDER_NODE_TYPE::COMPUTE, Core::MakeDelegate(&gb, &RenderPass::GBufferRT::Render));
             auto hPre = g.RegisterRenderPass("PreLighting", Core::RENDER_NODE_TYPE::ASYNC_COMPUTE, Core::MakeDelegate(&pre, &RenderPass::PreLighting::Render));
             auto hInd = g.RegisterRenderPass("Indirect", Core::RENDER_NODE_TYPE::COMPUTE, Core::MakeDelegate(&ind, &RenderPass::IndirectLighting::Render));
+            // DirectLighting sits in the same dependency level as Indirect (PathTracer.cpp:474-552): both read the G-buffer + alias table
+            Core::RenderNodeHandle hDI;
+            if (directOut) hDI = g.RegisterRenderPass("DirectLighting", Core::RENDER_NODE_TYPE::COMPUTE, Core::MakeDelegate(&di, &RenderPass::DirectLighting::Render));
             g.RegisterResource(nullptr, R_GBUF); g.RegisterResource(nullptr, R_ALIAS); g.RegisterResource(ind.GetOutput(RenderPass::IndirectLighting::SHADER_OUT_RES::FINAL), R_IND);
+            if (directOut) g.RegisterResource(di.GetOutput(RenderPass::DirectLighting::SHADER_OUT_RES::FINAL), R_DI);
             g.MoveToPostRegister();
             g.AddOutput(hGB, R_GBUF, Core::STATE_UNORDERED_ACCESS);
             g.AddOutput(hPre, R_ALIAS, Core::STATE_UNORDERED_ACCESS);
+            if (directOut) { g.AddInput(hDI, R_GBUF, Core::STATE_SHADER_READ); g.AddInput(hDI, R_ALIAS, Core::STATE_SHADER_READ); g.AddOutput(hDI, R_DI, Core::STATE_UNORDERED_ACCESS); }
             g.AddInput(hInd, R_GBUF, Core::STATE_SHADER_READ); g.AddInput(hInd, R_ALIAS, Core::STATE_SHADER_READ); g.AddOutput(hInd, R_IND, Core::STATE_UNORDERED_ACCESS);
             Support::TaskSet ts;
             g.Build(ts);
@@ -331,11 +361,15 @@ int zrh_render_sequence(const zr_scene_desc* desc, const zr_frame_constants* cbs
             g.WaitForFrame();
         }
         if (hipMemcpy(finalOut, ind.GetOutput(RenderPass::IndirectLighting::SHADER_OUT_RES::FINAL), (size_t)w * h * 16, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+        if (directOut && hipMemcpy(directOut, di.GetOutput(RenderPass::DirectLighting::SHADER_OUT_RES::FINAL), (size_t)w * h * 16, hipMemcpyDeviceToHost) != hipSuccess) return -1;
     }
     zr_gbuffer_destroy(ctx.gbuffer);
     zr_scene_destroy(ctx.scene);
     return 0;
 }
+
+int zrh_render_sequence(const zr_scene_desc* desc, const zr_frame_constants* cbs, uint32_t n, uint32_t w, uint32_t h, int integrator, float* finalOut)
+{ return zrh_render_sequence2(desc, cbs, n, w, h, integrator, finalOut, nullptr); }
 
 int zrh_render_frame(const zr_scene_desc* desc, const zr_frame_constants* cb, uint32_t w, uint32_t h, float* finalOut)
 { return zrh_render_sequence(desc, cb, 1, w, h, 0, finalOut); }

@@ -177,6 +177,20 @@ namespace RenderPass {
         bool m_aliasReady = false;
     };
 
+    // RP/DirectLighting/Emissive/DirectLighting.h:19-60: ReSTIR DI for emissive lights
+    struct DirectLighting final : public RenderPassBase
+    {
+        enum class SHADER_OUT_RES { FINAL, COUNT };
+        void Init(FrameContext* ctx);
+        void OnWindowResized();
+        void ResetTemporal();
+        void SetLightPresamplingParams(bool enable, int numSampleSets, int sampleSetSize);
+        void* GetOutput(SHADER_OUT_RES i) const;
+        void Render(Core::CommandList& cmdList);
+    private:
+        zr_params m_params{};
+    };
+
     struct IndirectLighting final : public RenderPassBase
     {
         enum class SHADER_OUT_RES { FINAL, COUNT };

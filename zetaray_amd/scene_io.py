@@ -458,11 +458,75 @@ def make_frame_constants(width, height, frame_num=1, cam_pos=(0.0, 1.2, -4.043),
     return cb
 
 
-def make_synthetic_scene(num_tris=262144, num_emissive=100000, seed=0x5EED, room=4.0, with_special_materials=True) -> Scene:
+def _grid_tris(fn, nu, nv):
+    """Tessellate the parametric surface fn(u, v) -> (..., 3), u, v in [0, 1], into 2 * nu * nv triangles (T, 3, 3)."""
+    u, v = np.meshgrid(np.linspace(0, 1, nu + 1, dtype=np.float32), np.linspace(0, 1, nv + 1, dtype=np.float32), indexing="ij")
+    Pg = fn(u, v).astype(np.float32)
+    a, b, c, d = Pg[:-1, :-1], Pg[1:, :-1], Pg[1:, 1:], Pg[:-1, 1:]
+    t1 = np.stack([a, b, d], axis=2).reshape(-1, 3, 3)
+    t2 = np.stack([b, c, d], axis=2).reshape(-1, 3, 3)
+    return np.concatenate([t1, t2]).astype(np.float32)
+
+
+def _atrium_geometry(num_tris, num_emissive, room, rng):
+    """Structured ("Sponza-class") content for make_synthetic_scene(layout="atrium"): displaced floor and wall, two rows of
+    columns joined by arches, wavy curtains, statues -- coherent surfaces a SAH BVH handles like real architecture -- and
+    `num_emissive` triangles in small spherical lanterns.  Returns ([8 arrays (T, 3, 3)], emissive (E, 3, 3))."""
+    r = np.float32(room)
+    budget = max(num_tris, 2048)
+    s = (budget / 262144.0) ** 0.5            # linear tessellation scale
+
+    def n(k):
+        return max(2, int(round(k * s)))
+    two_pi = np.float32(2 * np.pi)
+    floor = _grid_tris(lambda u, v: np.stack([(2 * u - 1) * r * 0.98, -r + 0.03 + 0.02 * np.sin(40 * u) * np.cos(36 * v), (2 * v - 1) * r * 0.98], -1), n(160), n(160))
+    wall = _grid_tris(lambda u, v: np.stack([(2 * u - 1) * r * 0.98, (2 * v - 1) * r * 0.98, r - 0.03 - 0.04 * np.cos(24 * u) * np.cos(24 * v)], -1), n(128), n(128))
+    cols, arches = [], []
+    zs = [-1.0, 0.5, 2.0, 3.5]
+    for x0 in (-2.0, 2.0):
+        for z0 in zs:
+            cols.append(_grid_tris(lambda u, v, x0=x0, z0=z0: np.stack([x0 * r / 4 + (0.22 + 0.03 * np.cos(8 * two_pi * u)) * np.cos(two_pi * u) * r / 4,
+                                                                  (2 * v - 1) * r * 0.97, z0 * r / 4 + (0.22 + 0.03 * np.cos(8 * two_pi * u)) * np.sin(two_pi * u) * r / 4], -1), n(48), n(96)))
+        for za, zb in zip(zs[:-1], zs[1:]):
+            zc, rad = 0.5 * (za + zb) * r / 4, 0.5 * (zb - za) * r / 4
+            arches.append(_grid_tris(lambda u, v, x0=x0, zc=zc, rad=rad: np.stack([x0 * r / 4 + 0.08 * r / 4 * np.cos(two_pi * u),
+                                                                            0.45 * r + (rad + 0.08 * r / 4 * np.sin(two_pi * u)) * np.sin(np.pi * v),
+                                                                            zc - (rad + 0.08 * r / 4 * np.sin(two_pi * u)) * np.cos(np.pi * v)], -1), n(32), n(64)))
+    curtains = []
+    for x0, z0 in ((-3.2, -0.5), (-3.2, 2.2), (3.2, -0.5), (3.2, 2.2)):
+        curtains.append(_grid_tris(lambda u, v, x0=x0, z0=z0: np.stack([x0 * r / 4 + 0.08 * np.sin(30 * u + 3 * v), (0.9 - 1.5 * v) * r * 0.9,
+                                                                 z0 * r / 4 + (u - 0.5) * 2.2 * r / 4], -1), n(96), n(96)))
+    statues = []
+    for cx, cz, rad in ((-0.9, 1.2, 0.45), (0.9, 2.4, 0.35), (0.0, 3.0, 0.55)):
+        def statue(u, v, cx=cx, cz=cz, rad=rad):
+            w = np.float32(np.pi) * (0.02 + 0.96 * v)          # keep away from the poles: no degenerate triangles
+            rr = rad * r / 4 * (1 + 0.15 * np.sin(12 * w)) * np.sin(w)
+            return np.stack([cx * r / 4 + rr * np.cos(two_pi * u), -r + rad * r / 4 * (1.05 - np.cos(w)), cz * r / 4 + rr * np.sin(two_pi * u)], -1)
+        statues.append(_grid_tris(statue, n(64), n(64)))
+    groups = [floor, wall, np.concatenate(cols[:4]), np.concatenate(cols[4:]), np.concatenate(arches), np.concatenate(curtains[:2]),
+              np.concatenate(curtains[2:]), np.concatenate(statues)]
+    # lanterns: small lat-long spheres, 2 * a * b triangles each, on a jittered lattice in the upper part of the hall
+    em = np.zeros((0, 3, 3), np.float32)
+    if num_emissive > 0:
+        a_, b_ = 10, 10
+        per = 2 * a_ * b_
+        count = max(1, (num_emissive + per - 1) // per)
+        ctr = np.stack([rng.uniform(-0.85 * r, 0.85 * r, count), rng.uniform(-0.2 * r, 0.85 * r, count), rng.uniform(-0.6 * r, 0.9 * r, count)], 1).astype(np.float32)
+        rad = rng.uniform(0.03, 0.07, count).astype(np.float32) * r / 4
+        unit = _grid_tris(lambda u, v: np.stack([np.sin(np.pi * (0.02 + 0.96 * v)) * np.cos(two_pi * u), np.cos(np.pi * (0.02 + 0.96 * v)),
+                                                 np.sin(np.pi * (0.02 + 0.96 * v)) * np.sin(two_pi * u)], -1), a_, b_)
+        em = (ctr[:, None, None, :] + unit[None] * rad[:, None, None, None]).reshape(-1, 3, 3)[:num_emissive].astype(np.float32)
+    return groups, em
+
+
+def make_synthetic_scene(num_tris=262144, num_emissive=100000, seed=0x5EED, room=4.0, with_special_materials=True, layout="soup") -> Scene:
     """Procedural Sponza-class stand-in for BASELINE config 4 (not in the reference):
     a box room, `num_tris` clutter triangles in 8 instances with different materials (diffuse, rough metal, coated,
     glossy; plus a few axis-aligned coplanar sheets that produce exact t ties) and `num_emissive` small double-sided
-    emissive triangles with strengths log-uniform in [0.5, 50].  Deterministic in `seed` (numpy PCG64)."""
+    emissive triangles with strengths log-uniform in [0.5, 50].  Deterministic in `seed` (numpy PCG64).
+    layout="soup": uniformly random triangles (worst case for any BVH; used by the parity tests for its exact-t ties and
+    material coverage).  layout="atrium": the same room, materials and light model, but structured geometry (displaced
+    floor / wall, columns, arches, curtains, statues, lantern lights) -- what bench.py uses for BASELINE config 4."""
     rng = np.random.default_rng(seed)
     sc = Scene()
     mats = [pack_material(metallic=0.0, roughness=0.3),
@@ -525,10 +589,16 @@ def make_synthetic_scene(num_tris=262144, num_emissive=100000, seed=0x5EED, room
     P = np.array([[c[a], c[b], c[d]] for (a, b, cc, d) in quads] + [[c[b], c[cc], c[d]] for (a, b, cc, d) in quads], np.float32)
     add_instance(P, face_normals(P), 1, wire.SUBGROUP_NON_EMISSIVE)
 
+    atrium_em = None
+    if layout == "atrium":
+        groups, atrium_em = _atrium_geometry(num_tris, num_emissive, room, rng)
+        for k, P in enumerate(groups):
+            add_instance(P, face_normals(P), 2 + k, wire.SUBGROUP_NON_EMISSIVE)
+        num_emissive = len(atrium_em)
     # clutter
     per = max(1, num_tris // 8)
     size = np.float32(2.0 * room / max(2.0, (num_tris ** (1.0 / 3.0))))
-    for k in range(8):
+    for k in range(8 if layout == "soup" else 0):
         ctr = rng.uniform(-0.9 * room, 0.9 * room, (per, 1, 3)).astype(np.float32)
         P = ctr + rng.normal(size=(per, 3, 3)).astype(np.float32) * size
         if k == 0 and per >= 16:
@@ -543,6 +613,8 @@ def make_synthetic_scene(num_tris=262144, num_emissive=100000, seed=0x5EED, room
     if num_emissive > 0:
         ctr = rng.uniform(-0.85 * room, 0.85 * room, (num_emissive, 1, 3)).astype(np.float32)
         P = ctr + rng.normal(size=(num_emissive, 3, 3)).astype(np.float32) * (size * np.float32(0.5))
+        if atrium_em is not None:
+            P = atrium_em
         ei = add_instance(P, face_normals(P), em_mat_idx, wire.SUBGROUP_EMISSIVE)
         insts[ei]["base_emissive_tri_offset"] = 0
         strengths = np.exp(rng.uniform(np.log(0.5), np.log(50.0), num_emissive)).astype(np.float32)
