@@ -76,4 +76,24 @@ ZR_HD int zr_ray_box(float ox, float oy, float oz, float idx, float idy, float i
     return tn <= tf;
 }
 
+/*
+ * The same test with the machine's own min / max (v_min_f32 / v_max_f32 on gfx950, which fuse to the three-operand
+ * forms): what BVH traversal uses.  A box test only selects candidates -- closest hit with the index tie-break and any
+ * hit do not depend on which conservative test produced them -- so unlike zr_ray_tri its arithmetic is not part of the
+ * parity contract; it only has to never reject a box whose triangle zr_ray_tri would accept (same widening as above).
+ */
+ZR_HD int zr_ray_box_native(float ox, float oy, float oz, float idx, float idy, float idz,
+                            float bminx, float bminy, float bminz, float bmaxx, float bmaxy, float bmaxz,
+                            float tmin, float tmax, float* t_entry)
+{
+    float t0x = (bminx - ox) * idx, t1x = (bmaxx - ox) * idx;
+    float t0y = (bminy - oy) * idy, t1y = (bmaxy - oy) * idy;
+    float t0z = (bminz - oz) * idz, t1z = (bmaxz - oz) * idz;
+    float tn = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(t0x, t1x), __builtin_fminf(t0y, t1y)), __builtin_fmaxf(__builtin_fminf(t0z, t1z), tmin));
+    float tf = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(t0x, t1x), __builtin_fmaxf(t0y, t1y)), __builtin_fminf(__builtin_fmaxf(t0z, t1z), tmax));
+    tf *= 1.0000003576278687f;
+    *t_entry = tn;
+    return tn <= tf;
+}
+
 #endif /* ZR_INTERSECT_H */

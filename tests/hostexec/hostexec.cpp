@@ -75,9 +75,9 @@ HxScene* zhx_scene_create(const zr_scene_desc* d)
     s->bvh = b.Build(*d);
     SceneView& v = s->view;
     v.vertices = s->vertices.data(); v.indices = s->indices.data(); v.instances = s->instances.data(); v.materials = s->materials.data();
-    v.emissives = s->emissives.data(); v.alias = nullptr; v.sampleSets = nullptr; v.sampleSetSize = 0; v.nodes = s->bvh.nodes.data(); v.tris = s->bvh.tris.data(); v.triMeta = s->bvh.meta.data();
+    v.emissives = s->emissives.data(); v.alias = nullptr; v.sampleSets = nullptr; v.sampleSetSize = 0; v.nodes = s->bvh.nodes4.data(); v.tris = s->bvh.tris.data(); v.triMeta = s->bvh.meta.data();
     v.rho.data = s->rho.data(); v.rho.dx = d->rho_dim[0]; v.rho.dy = d->rho_dim[1]; v.rho.dz = d->rho_dim[2];
-    v.numEmissives = d->num_emissives; v.numNodes = (uint32_t)s->bvh.nodes.size(); v.numTris = (uint32_t)s->bvh.tris.size();
+    v.numEmissives = d->num_emissives; v.numNodes = (uint32_t)s->bvh.nodes4.size(); v.numTris = (uint32_t)s->bvh.tris.size();
     return s;
 }
 void zhx_scene_destroy(HxScene* s) { delete s; }
@@ -103,7 +103,7 @@ void zhx_gbuffer(const HxScene* s, const zr_frame_constants* cb, zr_gbuffer_plan
 {
     GBuf gb = ViewOf(planes);
     gb.x0 = g_tile_x0; gb.y0 = g_tile_y0;
-    uint32_t stack[64];
+    zr::StackEntry stackMem[zr::kTravStack]; zr::TravStack stack; stack.lds = nullptr; stack.stride = 0; stack.mem = stackMem;
     for (uint32_t y = gb.y0; y < gb.y0 + gb.h; y++)
         for (uint32_t x = gb.x0; x < gb.x0 + gb.w; x++)
             GBufferPixel(s->view, *cb, gb, x, y, stack, nullptr);
@@ -126,7 +126,7 @@ void zhx_pathtrace(const HxScene* s, const zr_frame_constants* cb, const zr_gbuf
     HxQueue q[2]; q[0].Resize(cap); q[1].Resize(cap);
     std::vector<F4> firstBOP(cap);
     uint64_t nClosest = 0, nShadow = 0;
-    uint32_t stack[64];
+    zr::StackEntry stackMem[zr::kTravStack]; zr::TravStack stack; stack.lds = nullptr; stack.stride = 0; stack.mem = stackMem;
 
     uint32_t count = 0;
     PathQueue q0 = q[0].View();
@@ -168,7 +168,7 @@ void zhx_pathtrace(const HxScene* s, const zr_frame_constants* cb, const zr_gbuf
 
 void zhx_trace_closest(const HxScene* s, const float* rays, uint32_t n, uint32_t mask, uint32_t* hits)
 {
-    uint32_t stack[64];
+    zr::StackEntry stackMem[zr::kTravStack]; zr::TravStack stack; stack.lds = nullptr; stack.stride = 0; stack.mem = stackMem;
     for (uint32_t i = 0; i < n; i++)
     {
         F4 ro = f4(rays[8 * i], rays[8 * i + 1], rays[8 * i + 2], rays[8 * i + 3]);
@@ -179,7 +179,7 @@ void zhx_trace_closest(const HxScene* s, const float* rays, uint32_t n, uint32_t
 }
 void zhx_trace_any(const HxScene* s, const float* rays, uint32_t n, uint32_t mask, uint32_t* occ)
 {
-    uint32_t stack[64];
+    zr::StackEntry stackMem[zr::kTravStack]; zr::TravStack stack; stack.lds = nullptr; stack.stride = 0; stack.mem = stackMem;
     for (uint32_t i = 0; i < n; i++)
     {
         RawHit h = Traverse<true>(s->view, v3(rays[8 * i], rays[8 * i + 1], rays[8 * i + 2]), v3(rays[8 * i + 4], rays[8 * i + 5], rays[8 * i + 6]),
@@ -250,7 +250,7 @@ void zhx_rpt_render_stage(const HxScene* s, HxRpt* R, const zr_frame_constants* 
     prm.doSpatial = R->doSpatial ? 1u : 0u;
     prm.writeReservoirs = (prm.doTemporal || !R->temporalValid) ? 1u : 0u;
     F.cur = R->res[R->currIdx].View(); F.prev = R->res[1 - R->currIdx].View();
-    uint32_t stack[64];
+    zr::StackEntry stackMem[zr::kTravStack]; zr::TravStack stack; stack.lds = nullptr; stack.stride = 0; stack.mem = stackMem;
 
     if (stages & 1)
     {
@@ -402,7 +402,7 @@ void zhx_rdi_render(const HxScene* s, HxRdi* R, const zr_frame_constants* cb, co
     prm.doTemporal = (R->temporalValid && (params->flags & ZR_IND_TEMPORAL_RESAMPLE) && prev) ? 1u : 0u;
     prm.doSpatial = (prm.doTemporal && (params->flags & ZR_IND_SPATIAL_RESAMPLE)) ? 1u : 0u;
     prm.writeReservoirs = (prm.doTemporal || !R->temporalValid) ? 1u : 0u;
-    uint32_t stack[64];
+    zr::StackEntry stackMem[zr::kTravStack]; zr::TravStack stack; stack.lds = nullptr; stack.stride = 0; stack.mem = stackMem;
     for (uint32_t y = 0; y < H; y++) for (uint32_t x = 0; x < W; x++) TemporalPixel(F, g, x, y, stack, cnt);
     if (prm.doSpatial)
     {
@@ -462,7 +462,7 @@ void zhx_rgi_render(const HxScene* s, HxRgi* R, const zr_frame_constants* cb, co
     prm.doTemporal = ((params->flags & ZR_IND_TEMPORAL_RESAMPLE) && R->temporalValid && prev) ? 1u : 0u;
     prm.writeReservoirs = (prm.doTemporal || !R->temporalValid) ? 1u : 0u;
     prm.M_max = (float)params->m_max_temporal;
-    uint32_t stack[64];
+    zr::StackEntry stackMem[zr::kTravStack]; zr::TravStack stack; stack.lds = nullptr; stack.stride = 0; stack.mem = stackMem;
     std::vector<Lane> L(64);
     float wsum[64];
     for (uint32_t gy = 0; gy < (H + 7) / 8; gy++) for (uint32_t gx = 0; gx < (W + 7) / 8; gx++)

@@ -48,7 +48,10 @@ static int RequireDevice(int device)
 
 // ------------------------------------------------------------------------------------------------ device helpers
 static constexpr int kBlock = 256;
-static constexpr int kStack = 48;
+// this lane's traversal stack: kTravLdsEntries entries in LDS (16 KB per 256-lane block at 8 entries), the rest in scratch
+#define ZR_TRAV_STACK(name) \
+    __shared__ StackEntry name##Lds[kTravLdsEntries * kBlock]; StackEntry name##Mem[kTravStack - kTravLdsEntries]; \
+    TravStack name; name.lds = (ZR_LDS_AS StackEntry*)name##Lds + threadIdx.x; name.stride = kBlock; name.mem = (ZR_PRIVATE_AS StackEntry*)name##Mem
 
 // one atomic per wave: lanes that `want` a slot get consecutive indices
 __device__ __forceinline__ uint32_t AllocSlotWave(uint32_t* counter, bool want)
@@ -84,7 +87,7 @@ __global__ void __launch_bounds__(kBlock) k_gbuffer(SceneView sc, zr_frame_const
 {
     uint32_t x, y; PixelOfThread(tilesX, gb.x0, gb.y0, &x, &y);
     if (x >= gb.x0 + gb.w || y >= gb.y0 + gb.h) return;
-    uint32_t stack[kStack];
+    ZR_TRAV_STACK(stack);
     GBufferPixel(sc, g, gb, x, y, stack, nullptr);
 }
 
@@ -98,12 +101,12 @@ __global__ void __launch_bounds__(kBlock) k_pt_init(SceneView sc, zr_frame_const
     if (po.alive) WritePath(out, slot, po);
 }
 
-// trace stage: grid-stride over 3 * n rays (C rays, then M rays, then S rays of the n live slots)
-__global__ void __launch_bounds__(kBlock) k_trace(SceneView sc, PathQueue q, const uint32_t* count, unsigned long long* counters)
+// trace stage, run-to-completion variant (ZR_TRACE_MODE=0): grid-stride over the 3 * n ray slots
+__global__ void __launch_bounds__(kBlock) k_trace_simple(SceneView sc, PathQueue q, const uint32_t* count, unsigned long long* counters)
 {
     const uint32_t n = *count;
     const uint32_t total = 3u * n;
-    uint32_t stack[kStack];
+    ZR_TRAV_STACK(stack);
     for (uint32_t base = blockIdx.x * kBlock; base < total; base += gridDim.x * kBlock)
     {
         const uint32_t j = base + threadIdx.x;
@@ -131,6 +134,84 @@ __global__ void __launch_bounds__(kBlock) k_trace(SceneView sc, PathQueue q, con
         CountWave(&counters[0], closest);
         CountWave(&counters[1], shadow);
     }
+}
+
+// trace stage over the 3 * n ray slots of the n live paths (C rays, then M rays, then S rays; a slot with d.w < 0 holds
+// no ray).  Persistent waves: every lane owns one ray at a time and advances it one BVH step (an inner node or a leaf)
+// per iteration; lanes whose ray finished -- or whose slot was empty -- take the next slot from the wave's chunk, and
+// the wave takes chunks of kTraceChunk slots from a global cursor.  A wave therefore never waits for its slowest ray
+// with 63 idle lanes, and empty slots cost one load instead of a lane.  Which lane traces which ray has no effect on
+// the results.
+static constexpr uint32_t kTraceChunk = 256;
+static constexpr uint32_t kTraceRefillAt = 8;       // refill once this many lanes are idle (or nothing is left to step)
+__global__ void __launch_bounds__(kBlock) k_trace(SceneView sc, PathQueue q, const uint32_t* count, uint32_t* cursor, unsigned long long* counters)
+{
+    const uint32_t n = *count;
+    const uint32_t total = 3u * n;
+    ZR_TRAV_STACK(stack);
+    const uint32_t lane = __lane_id();
+    TravState st;
+    bool active = false;
+    uint32_t slot = 0;                              // this lane's ray: type * n + i
+    uint32_t nClosest = 0, nShadow = 0;
+    uint32_t chunkPos = 0, chunkEnd = 0;            // wave-uniform
+    bool exhausted = false;                         // wave-uniform: the global cursor ran past `total`
+    for (;;)
+    {
+        const uint64_t idle = __ballot(!active);
+        const uint32_t nIdle = (uint32_t)__popcll(idle);
+        if (nIdle >= kTraceRefillAt && !(exhausted && chunkPos == chunkEnd))
+        {
+            if (chunkPos == chunkEnd)
+            {
+                uint32_t b = 0;
+                if (lane == 0) b = atomicAdd(cursor, kTraceChunk);
+                b = __builtin_amdgcn_readfirstlane(b);
+                exhausted = b >= total;
+                chunkPos = b < total ? b : total;
+                chunkEnd = b + kTraceChunk < total ? b + kTraceChunk : total;
+            }
+            const uint32_t rank = (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
+            const uint32_t j = chunkPos + rank;
+            if (!active && j < chunkEnd)
+            {
+                const uint32_t type = j / n, i = j - type * n;
+                F4 ro, rd;
+                if (type == 0) { rd = q.rayC_d[i]; ro = q.rayC_o[i]; }
+                else if (type == 1) { rd = q.rayM_d[i]; ro = q.rayM_o[i]; }
+                else { rd = q.rayS_d[i]; ro = q.rayS_o[i]; }
+                if (rd.w >= 0)
+                {
+                    active = true; slot = j;
+                    if (type == 2) { TravInit(sc, st, xyz(ro), xyz(rd), ro.w, rd.w, ZR_SUBGROUP_NON_EMISSIVE, false, 0); nShadow++; }
+                    else { TravInit(sc, st, xyz(ro), xyz(rd), ro.w, rd.w, ZR_SUBGROUP_ALL, false, 0); nClosest++; }
+                }
+                else if (type == 0) { U4 miss; miss.x = 0; miss.y = 0; miss.z = 0; miss.w = kInvalidTri; q.hitC[i] = miss; }
+            }
+            chunkPos = chunkPos + nIdle < chunkEnd ? chunkPos + nIdle : chunkEnd;
+        }
+        if (__ballot(active) == 0)
+        {
+            if (exhausted && chunkPos == chunkEnd) break;
+            continue;
+        }
+        if (active)
+        {
+            const uint32_t type = slot / n;
+            // shadow segments stop at the first hit unless the light's own triangle has to be told apart (TraceSegmentRay)
+            if (TravStep(sc, st, stack, false))
+            {
+                const uint32_t i = slot - type * n;
+                if (type == 0) q.hitC[i] = PackRawHit(st.best);
+                else if (type == 1) q.hitM[i] = PackRawHit(st.best);
+                else q.visS[i] = SegmentVisible(sc, st.best, q.sLightID[i]);
+                active = false;
+            }
+        }
+    }
+    uint32_t a = nClosest, b = nShadow;
+    for (int s = 1; s < 64; s <<= 1) { a += __shfl_xor(a, s); b += __shfl_xor(b, s); }
+    if (lane == 0) { if (a) atomicAdd(&counters[0], (unsigned long long)a); if (b) atomicAdd(&counters[1], (unsigned long long)b); }
 }
 
 __global__ void __launch_bounds__(kBlock) k_pt_shade(SceneView sc, zr_frame_constants g, PtParams prm, PathQueue in, const uint32_t* inCount,
@@ -177,13 +258,13 @@ __global__ void k_estimate_power(const zr_emissive_triangle* em, uint32_t n, flo
 // generic ray-query kernels behind zr_trace_closest / zr_trace_any
 __global__ void __launch_bounds__(kBlock) k_trace_rays(SceneView sc, const F4* rays, uint32_t n, uint32_t mask, U4* hits)
 {
-    uint32_t stack[kStack];
+    ZR_TRAV_STACK(stack);
     for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock)
         hits[i] = TraceClosestRay(sc, rays[2 * i], rays[2 * i + 1], mask, stack);
 }
 __global__ void __launch_bounds__(kBlock) k_trace_rays_any(SceneView sc, const F4* rays, uint32_t n, uint32_t mask, uint32_t* occ)
 {
-    uint32_t stack[kStack];
+    ZR_TRAV_STACK(stack);
     for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock)
     {
         const F4 ro = rays[2 * i], rd = rays[2 * i + 1];
@@ -211,7 +292,7 @@ __global__ void __launch_bounds__(kBlock) k_rpt_pathtrace(rpt::RptFrame F, zr_fr
     const uint32_t tile = blockIdx.x, tx = tile % tilesX, ty = tile / tilesX;
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
     const uint32_t x = F.ox0 + tx * 16u + (lane & 15u), y = F.oy0 + ty * 16u + wave * 4u + (lane >> 4);
-    uint32_t stack[kStack];
+    ZR_TRAV_STACK(stack);
     uint32_t cnt[2] = {0u, 0u};
     rpt::PTLane P;
     rpt::PtInitLane(F.sc, g, F.gb, F.prm, F.Owns(x, y), x, y, F.finalRGBA, stack, cnt, P);
@@ -260,7 +341,7 @@ template<int PASS>
 __global__ void __launch_bounds__(kBlock) k_rpt_replay(rpt::RptFrame F, zr_frame_constants g, const uint32_t* list, const uint32_t* count,
     unsigned long long* counters)
 {
-    uint32_t stack[kStack];
+    ZR_TRAV_STACK(stack);
     uint32_t cnt[2] = {0u, 0u};
     const uint32_t n = *count;
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
@@ -278,7 +359,7 @@ __global__ void __launch_bounds__(kBlock) k_rpt_replay(rpt::RptFrame F, zr_frame
 __global__ void __launch_bounds__(kBlock) k_rpt_temporal(rpt::RptFrame F, zr_frame_constants g, uint32_t tilesX, unsigned long long* counters)
 {
     uint32_t x, y; PixelOfThread(tilesX, F.ox0, F.oy0, &x, &y);
-    uint32_t stack[kStack];
+    ZR_TRAV_STACK(stack);
     uint32_t cnt[2] = {0u, 0u};
     if (F.Owns(x, y)) rpt::ReconnectTemporalPixel(F, g, x, y, stack, cnt);
     FlushRayCounters(counters, cnt);
@@ -295,7 +376,7 @@ __device__ __forceinline__ float WaveSumButterfly(float v)
 __global__ void __launch_bounds__(kBlock) k_rpt_stc(rpt::RptFrame F, zr_frame_constants g, uint32_t tilesX, unsigned long long* counters)
 {
     uint32_t x, y; PixelOfThread(tilesX, F.ox0, F.oy0, &x, &y);
-    uint32_t stack[kStack];
+    ZR_TRAV_STACK(stack);
     uint32_t cnt[2] = {0u, 0u};
     rpt::StcLane a;
     float v1, v2, v3, v4;
@@ -319,7 +400,7 @@ static const uint16_t kRdiSampleSet[64] = {
 __global__ void __launch_bounds__(kBlock) k_rdi_temporal(rdi::DiFrame F, zr_frame_constants g, uint32_t tilesX, unsigned long long* counters)
 {
     uint32_t x, y; PixelOfThread(tilesX, F.ox0, F.oy0, &x, &y);
-    uint32_t stack[kStack];
+    ZR_TRAV_STACK(stack);
     uint32_t cnt[2] = {0u, 0u};
     if (F.Owns(x, y)) rdi::TemporalPixel(F, g, x, y, stack, cnt);
     FlushRayCounters(counters, cnt);
@@ -328,7 +409,7 @@ __global__ void __launch_bounds__(kBlock) k_rdi_temporal(rdi::DiFrame F, zr_fram
 __global__ void __launch_bounds__(kBlock) k_rdi_spatial(rdi::DiFrame F, zr_frame_constants g, uint32_t tilesX, unsigned long long* counters)
 {
     uint32_t x, y; PixelOfThread(tilesX, F.ox0, F.oy0, &x, &y);
-    uint32_t stack[kStack];
+    ZR_TRAV_STACK(stack);
     uint32_t cnt[2] = {0u, 0u};
     rdi::SpatialLane a;
     rdi::SpatialPhase0(F, g, x, y, a);
@@ -343,7 +424,7 @@ __global__ void __launch_bounds__(kBlock) k_rdi_spatial(rdi::DiFrame F, zr_frame
 __global__ void __launch_bounds__(kBlock) k_rgi(rgi::GiFrame F, zr_frame_constants g, uint32_t tilesX, unsigned long long* counters)
 {
     uint32_t x, y; PixelOfThread(tilesX, F.ox0, F.oy0, &x, &y);
-    uint32_t stack[kStack];
+    ZR_TRAV_STACK(stack);
     uint32_t cnt[2] = {0u, 0u};
     rgi::Lane P;
     rgi::InitLane(F, g, x, y, stack, cnt, P);
@@ -379,7 +460,7 @@ struct zr_scene
 {
     int device = 0;
     DevBuf<zr_vertex> vertices; DevBuf<uint32_t> indices; DevBuf<zr_mesh_instance> instances; DevBuf<zr_material> materials;
-    DevBuf<zr_emissive_triangle> emissives; DevBuf<zr_alias_entry> alias; DevBuf<BvhNode> nodes; DevBuf<BvhTri> tris;
+    DevBuf<zr_emissive_triangle> emissives; DevBuf<zr_alias_entry> alias; DevBuf<Bvh4Node> nodes; DevBuf<BvhTri> tris;
     DevBuf<TriMeta> meta; DevBuf<uint16_t> rho;
     DevBuf<zr_presampled_tri> sampleSets; uint32_t numSampleSets = 0;      // K3 output, refreshed by every PRELIGHTING render
     std::vector<zr_alias_entry> aliasHost;
@@ -633,7 +714,7 @@ int zr_scene_create(int device, const zr_scene_desc* d, zr_scene** out)
     s->device = device;
     BvhBuilder builder;
     BuiltBvh bvh = builder.Build(*d);
-    if (bvh.maxDepth + 2 > (uint32_t)kStack) { delete s; return Fail(ZR_ERR_UNSUPPORTED, "BVH depth %u exceeds traversal stack", bvh.maxDepth); }
+    if (bvh.stackNeed + 1 > (uint32_t)kTravStack) { delete s; return Fail(ZR_ERR_UNSUPPORTED, "BVH needs %u traversal stack entries (limit %d)", bvh.stackNeed, kTravStack - 1); }
     s->maxDepth = bvh.maxDepth;
 #define UP(buf, ptr, cnt) if ((r = s->buf.Upload(ptr, cnt))) { delete s; return r; }
     UP(vertices, d->vertices, d->num_vertices);
@@ -641,7 +722,7 @@ int zr_scene_create(int device, const zr_scene_desc* d, zr_scene** out)
     UP(instances, d->instances, d->num_instances);
     UP(materials, d->materials, d->num_materials);
     UP(emissives, d->emissives, d->num_emissives);
-    UP(nodes, bvh.nodes.data(), bvh.nodes.size());
+    UP(nodes, bvh.nodes4.data(), bvh.nodes4.size());
     UP(tris, bvh.tris.data(), bvh.tris.size());
     UP(meta, bvh.meta.data(), bvh.meta.size());
     UP(rho, d->rho_lut, (size_t)d->rho_dim[0] * d->rho_dim[1] * d->rho_dim[2]);
@@ -650,7 +731,7 @@ int zr_scene_create(int device, const zr_scene_desc* d, zr_scene** out)
     v.vertices = s->vertices.p; v.indices = s->indices.p; v.instances = s->instances.p; v.materials = s->materials.p;
     v.emissives = s->emissives.p; v.alias = nullptr; v.sampleSets = nullptr; v.sampleSetSize = 0; v.nodes = s->nodes.p; v.tris = s->tris.p; v.triMeta = s->meta.p;
     v.rho.data = s->rho.p; v.rho.dx = d->rho_dim[0]; v.rho.dy = d->rho_dim[1]; v.rho.dz = d->rho_dim[2];
-    v.numEmissives = d->num_emissives; v.numNodes = (uint32_t)bvh.nodes.size(); v.numTris = (uint32_t)bvh.tris.size();
+    v.numEmissives = d->num_emissives; v.numNodes = (uint32_t)bvh.nodes4.size(); v.numTris = (uint32_t)bvh.tris.size();
     *out = s;
     return ZR_OK;
 }
@@ -784,7 +865,7 @@ static int AllocPass(zr_pass* p)
         if ((r = p->q[1].Alloc(cap))) return r;
         if ((r = p->finalRGBA.Alloc(cap * 4))) return r;
         if ((r = p->firstBOP.Alloc(cap))) return r;
-        if ((r = p->counts.Alloc(kMaxRounds + 2))) return r;
+        if ((r = p->counts.Alloc(2 * (kMaxRounds + 2)))) return r;   // queue counts, then k_trace cursors
         if ((r = p->counters.Alloc(2 * kCounterSlots))) return r;
         if ((r = p->groupMax.Alloc((size_t)kMaxRounds * ((p->w + 7) / 8) * ((p->h + 7) / 8)))) return r;
         HIP_TRY(hipMemset(p->finalRGBA.p, 0, cap * 4 * sizeof(float)));
@@ -1094,7 +1175,7 @@ static int RenderIndirect(zr_pass* p, hipStream_t s, const zr_frame_constants* c
     const int rounds = (int)maxB + 1;
     if (rounds > kMaxRounds) return Fail(ZR_ERR_INVALID_ARG, "too many bounces");
 
-    HIP_TRY(hipMemsetAsync(p->counts.p, 0, (kMaxRounds + 2) * sizeof(uint32_t), s));
+    HIP_TRY(hipMemsetAsync(p->counts.p, 0, 2 * (kMaxRounds + 2) * sizeof(uint32_t), s));
     // Russian roulette can only trigger once bounce >= 3, i.e. from round 2 on and only if some path may take >= 4 bounces
     const bool rrPossible = prm.russianRoulette && maxB >= 4;
     if (rrPossible) HIP_TRY(hipMemsetAsync(p->groupMax.p, 0, (size_t)rounds * numGroups * sizeof(uint32_t), s));
@@ -1106,12 +1187,15 @@ static int RenderIndirect(zr_pass* p, hipStream_t s, const zr_frame_constants* c
     TimerEnd(p, s);
     const size_t cap = (size_t)p->w * p->h;
     const uint32_t gridShade = (uint32_t)std::min<size_t>((cap + kBlock - 1) / kBlock, 4096);
-    const uint32_t gridTrace = (uint32_t)std::min<size_t>((3 * cap + kBlock - 1) / kBlock, 8192);
+    const uint32_t gridTrace = (uint32_t)std::min<size_t>((3 * cap + kBlock - 1) / kBlock, 2048);    // persistent: 256 CUs x 8 blocks
+    const uint32_t gridTraceSimple = (uint32_t)std::min<size_t>((3 * cap + kBlock - 1) / kBlock, 8192);
+    static const int traceMode = [] { const char* e = getenv("ZR_TRACE_MODE"); return e ? atoi(e) : 0; }();
     for (int r = 0; r < rounds; r++)
     {
         const PathQueue qin = p->q[r & 1].View(), qout = p->q[(r + 1) & 1].View();
         TimerBegin(p, s, "trace");
-        hipLaunchKernelGGL(k_trace, dim3(gridTrace), dim3(kBlock), 0, s, sc->view, qin, p->counts.p + r, p->counters.p);
+        if (traceMode == 0) hipLaunchKernelGGL(k_trace_simple, dim3(gridTraceSimple), dim3(kBlock), 0, s, sc->view, qin, p->counts.p + r, p->counters.p);
+        else hipLaunchKernelGGL(k_trace, dim3(gridTrace), dim3(kBlock), 0, s, sc->view, qin, p->counts.p + r, p->counts.p + (kMaxRounds + 2) + r, p->counters.p);
         TimerEnd(p, s);
         TimerBegin(p, s, "pt_shade");
         hipLaunchKernelGGL(k_pt_shade, dim3(gridShade), dim3(kBlock), 0, s, sc->view, *cb, prm, qin, p->counts.p + r, qout, p->counts.p + r + 1,

@@ -10,13 +10,16 @@
 #include <vector>
 #include <algorithm>
 #include <cstring>
+#include <cmath>
 #include "zr_dev_scene.h"
 
 namespace zr {
 
 struct BuiltBvh
 {
-    std::vector<BvhNode> nodes;
+    std::vector<BvhNode> nodes;      // binned-SAH BVH2 (builder intermediate)
+    std::vector<Bvh4Node> nodes4;    // what the device traverses: the BVH2 collapsed to 4-wide nodes
+    uint32_t stackNeed = 0;          // traversal stack entries the BVH4 can require (ordered traversal, <= 3 pushes per level)
     std::vector<BvhTri> tris;        // leaf order
     std::vector<TriMeta> meta;       // global order
     uint32_t maxDepth = 0;
@@ -86,10 +89,73 @@ public:
         soup_ = &soup; out_ = &out;
         out.nodes.push_back(BvhNode());
         BuildInternal(0, 0, N, 1);
+        out.nodes4.reserve(out.nodes.size() / 2 + 1);
+        Collapse(0, out.stackNeed);
         return out;
     }
 
 private:
+    // BVH2 -> BVH4: start from a node's two children and keep replacing the inner child of largest surface area by its
+    // own two children until there are four (or only leaves are left).  Returns the new node's index; `need` receives the
+    // stack entries a traversal below this node can hold at once.
+    uint32_t Collapse(uint32_t node2, uint32_t& need)
+    {
+        struct C { uint32_t ref; float lo[3], hi[3]; } c[4];
+        const BvhNode& n = out_->nodes[node2];
+        int k = 2;
+        c[0].ref = n.left; c[1].ref = n.right;
+        for (int r = 0; r < 3; r++) { c[0].lo[r] = n.lmin[r]; c[0].hi[r] = n.lmax[r]; c[1].lo[r] = n.rmin[r]; c[1].hi[r] = n.rmax[r]; }
+        while (k < 4)
+        {
+            int pick = -1; float bestA = -1.0f;
+            for (int i = 0; i < k; i++)
+                if (!(c[i].ref & kLeafBit)) { float a = Area(c[i].lo, c[i].hi); if (a > bestA) { bestA = a; pick = i; } }
+            if (pick < 0) break;
+            const BvhNode& m = out_->nodes[c[pick].ref];
+            c[pick].ref = m.left; c[k].ref = m.right;
+            for (int r = 0; r < 3; r++) { c[pick].lo[r] = m.lmin[r]; c[pick].hi[r] = m.lmax[r]; c[k].lo[r] = m.rmin[r]; c[k].hi[r] = m.rmax[r]; }
+            k++;
+        }
+        const uint32_t idx = (uint32_t)out_->nodes4.size();
+        out_->nodes4.push_back(Bvh4Node());
+        uint32_t refs[4]; uint32_t below = 0;
+        for (int i = 0; i < k; i++)
+        {
+            refs[i] = c[i].ref;
+            if (!(c[i].ref & kLeafBit)) { uint32_t nd = 0; refs[i] = Collapse(c[i].ref, nd); below = std::max(below, nd); }
+        }
+        // quantise: origin = the node's min corner, per-axis scale = the smallest power of two whose 255 steps reach the
+        // max corner; child planes rounded outwards against the device's decode expression fma(q, scale, origin)
+        float lo[3], hi[3];
+        for (int r = 0; r < 3; r++) { lo[r] = c[0].lo[r]; hi[r] = c[0].hi[r]; for (int i = 1; i < k; i++) { lo[r] = std::min(lo[r], c[i].lo[r]); hi[r] = std::max(hi[r], c[i].hi[r]); } }
+        uint32_t ex[3], qlo[3] = {0, 0, 0}, qhi[3] = {0, 0, 0};
+        for (int r = 0; r < 3; r++)
+        {
+            int e = 1;
+            const double ext = (double)hi[r] - (double)lo[r];
+            if (ext > 0) { int ee; std::frexp(ext / 255.0, &ee); e = std::max(1, std::min(254, ee + 126 - 1)); }
+            while (e < 254 && !(std::fmaf(255.0f, ScaleOf((uint32_t)e), lo[r]) >= hi[r])) e++;
+            ex[r] = (uint32_t)e;
+            const float sc = ScaleOf(ex[r]);
+            for (int i = 0; i < k; i++)
+            {
+                int a = (int)std::floor(((double)c[i].lo[r] - (double)lo[r]) / (double)sc); a = std::max(0, std::min(255, a));
+                while (a > 0 && std::fmaf((float)a, sc, lo[r]) > c[i].lo[r]) a--;
+                int b = (int)std::ceil(((double)c[i].hi[r] - (double)lo[r]) / (double)sc); b = std::max(0, std::min(255, b));
+                while (b < 255 && std::fmaf((float)b, sc, lo[r]) < c[i].hi[r]) b++;
+                qlo[r] |= (uint32_t)a << (8 * i); qhi[r] |= (uint32_t)b << (8 * i);
+            }
+        }
+        Bvh4Node& o = out_->nodes4[idx];
+        o.ox = lo[0]; o.oy = lo[1]; o.oz = lo[2]; o.exps = ex[0] | (ex[1] << 8) | (ex[2] << 16);
+        for (int i = 0; i < 4; i++) o.child[i] = i < k ? refs[i] : kEmptyChild;
+        o.qlox = qlo[0]; o.qloy = qlo[1]; o.qloz = qlo[2]; o.qhix = qhi[0]; o.qhiy = qhi[1]; o.qhiz = qhi[2]; o.pad0 = 0; o.pad1 = 0;
+        need = (uint32_t)(k - 1) + below;
+        return idx;
+    }
+
+    static float ScaleOf(uint32_t biasedExp) { uint32_t u = biasedExp << 23; float f; std::memcpy(&f, &u, 4); return f; }
+
     std::vector<BuildTri> bt_;
     const std::vector<BvhTri>* soup_ = nullptr;
     BuiltBvh* out_ = nullptr;

@@ -1,15 +1,15 @@
 // zr_dev_scene.h -- device view of the scene, BVH traversal, hit reconstruction, material fetch, light sampling.
 //
 // Replaces, for the HIP path, what the reference gets from the D3D12 driver (TLAS/BLAS + inline RayQuery,
-// Source/ZetaRenderPass/Common/RayQuery.hlsli:42-53,168-179,317-331,372-396) with an explicit BVH2 over world-space
+// Source/ZetaRenderPass/Common/RayQuery.hlsli:42-53,168-179,317-331,372-396) with an explicit BVH4 over world-space
 // triangles in HBM, and restates the shader-side code around it:
 //   RayQuery.hlsli:15-144  (Hit::FindClosest vertex fetch / TRS / tri differentials / PCG3d ID)
 //   RayQuery.hlsli:452-524 (GetMaterialData)      Material.h:268-417 (accessors)
 //   LightSource.hlsli:48-137, 202-223 (alias table draw, emissive triangle decode/sample, Le)
 //
 // HBM layout:
-//   nodes : 64 B each  = {L.min xyz, L.max xyz, R.min xyz, R.max xyz, left, right, pad, pad}; child >= 0x80000000 is a
-//           leaf: bits 0..2 = count-1, bits 3..30 = first triangle slot
+//   nodes : 128 B each = BVH4 node {lo.x[4], lo.y[4], lo.z[4], hi.x[4], hi.y[4], hi.z[4], child[4], pad[4]}; child >= 0x80000000
+//           is a leaf: bits 0..2 = count-1, bits 3..30 = first triangle slot; 0xffffffff = empty slot
 //   tris  : 48 B each in leaf order = {v0 xyz, globalTriIdx | e1 xyz, subgroup mask | e2 xyz, meshIdx}
 //   triMeta : 8 B per *global* triangle = {meshIdx, primIdx} (hit reconstruction)
 #pragma once
@@ -18,12 +18,24 @@
 
 namespace zr {
 
-struct BvhNode { float lmin[3], lmax[3], rmin[3], rmax[3]; uint32_t left, right, pad0, pad1; };
+struct BvhNode { float lmin[3], lmax[3], rmin[3], rmax[3]; uint32_t left, right, pad0, pad1; };    // builder's BVH2 (host only)
+// device node, 64 B = four 16-byte loads per lane: the child boxes are 8-bit offsets from the node's own min corner in
+// units of a per-axis power of two (plane = fma(q, 2^(e-127), origin), one rounding; the builder rounds q outwards
+// against exactly that expression, so the decoded box always contains the child).  Byte k of a q word = child k.
+struct Bvh4Node
+{
+    float ox, oy, oz; uint32_t exps;            // exps: bits 0..7 / 8..15 / 16..23 = biased exponent of the x / y / z scale
+    uint32_t child[4];
+    uint32_t qlox, qloy, qloz, qhix;
+    uint32_t qhiy, qhiz, pad0, pad1;
+};
 struct BvhTri { float v0[3]; uint32_t gidx; float e1[3]; uint32_t mask; float e2[3]; uint32_t mesh; };
 struct TriMeta { uint32_t mesh, prim; };
 
 static constexpr uint32_t kLeafBit = 0x80000000u;
 static constexpr uint32_t kInvalidTri = 0xffffffffu;
+static constexpr uint32_t kEmptyChild = 0xffffffffu;      // unused child slot of a Bvh4Node
+static constexpr uint32_t kWholeSceneLeaf = 0xfffffffeu;  // traversal root of a scene without nodes
 
 struct SceneView
 {
@@ -35,7 +47,7 @@ struct SceneView
     const zr_alias_entry* alias;
     const zr_presampled_tri* sampleSets;   // K3 output: numSampleSets x sampleSetSize (null until a PRELIGHTING pass presampled)
     uint32_t sampleSetSize;
-    const BvhNode* nodes;
+    const Bvh4Node* nodes;
     const BvhTri* tris;
     const TriMeta* triMeta;
     RhoView rho;
@@ -69,52 +81,124 @@ ZR_HD void IntersectLeaf(const SceneView& sc, uint32_t first, uint32_t count, V3
     }
 }
 
-// Stack-based BVH2 traversal.  `stack` points at this lane's private stack (scratch on the host executor, registers /
-// scratch / LDS slice on the device -- the caller decides).  anyHit: return on the first accepted hit.
-template<bool AnyHit>
-ZR_HD RawHit Traverse(const SceneView& sc, V3 o, V3 d, float tmin, float tmax, uint32_t mask, uint32_t* stack, bool filterID = false, uint32_t ignoreID = 0)
+// Stack-based BVH4 traversal, written as an explicit state machine so that a kernel can either run it to completion
+// (Traverse, used inline by the ReSTIR kernels) or advance many rays one step at a time and refill finished lanes
+// (k_trace).  `stack` is this lane's private stack of (child, entry distance) pairs.  Children
+// are visited near-to-far and a popped child whose entry distance lies beyond the current closest hit is skipped; none
+// of that changes the result (closest hit + index tie-break / any hit are order independent, zr_intersect.h).
+static constexpr int kTravStack = 64;                     // entries; the host checks the built tree against it
+static constexpr int kTravStackWords = 2 * kTravStack;
+static constexpr int kTravLdsEntries = 8;                 // device: the first entries live in LDS, deeper ones in scratch
+
+// One lane's traversal stack.  Device kernels keep the bottom kTravLdsEntries entries in LDS (entry e of lane l at
+// lds[e * stride + l]: conflict-free, and off the vector-memory path that the node / triangle fetches saturate) and the
+// rest in scratch; the host executor keeps everything in `mem`.
+struct StackEntry { uint32_t child; float t; };
+#ifdef __HIP_DEVICE_COMPILE__
+#define ZR_LDS_AS __attribute__((address_space(3)))
+#define ZR_PRIVATE_AS __attribute__((address_space(5)))
+#else
+#define ZR_LDS_AS
+#define ZR_PRIVATE_AS
+#endif
+struct TravStack { ZR_LDS_AS StackEntry* lds; uint32_t stride; ZR_PRIVATE_AS StackEntry* mem; };
+
+// (member-wise accesses: copying a whole StackEntry through an address-space-qualified pointer would go through a generic
+// pointer, and ROCm 7.2's gfx950 backend rejects the aperture check it emits for that cast)
+ZR_HD void StackWrite(const TravStack& st, int e, uint32_t c, float t)
 {
-    RawHit best; best.t = tmax; best.u = 0; best.v = 0; best.tri = kInvalidTri;
-    if (sc.numNodes == 0)
+#ifdef __HIP_DEVICE_COMPILE__
+    if (e < kTravLdsEntries) { ZR_LDS_AS StackEntry* p = st.lds + (uint32_t)e * st.stride; p->child = c; p->t = t; return; }
+    e -= kTravLdsEntries;
+#endif
+    st.mem[e].child = c; st.mem[e].t = t;
+}
+ZR_HD void StackRead(const TravStack& st, int e, uint32_t& c, float& t)
+{
+#ifdef __HIP_DEVICE_COMPILE__
+    if (e < kTravLdsEntries) { const ZR_LDS_AS StackEntry* p = st.lds + (uint32_t)e * st.stride; c = p->child; t = p->t; return; }
+    e -= kTravLdsEntries;
+#endif
+    c = st.mem[e].child; t = st.mem[e].t;
+}
+
+struct TravState
+{
+    V3 o, d; float idx, idy, idz, tmin, tmax;
+    RawHit best;
+    uint32_t cur, mask, ignoreID; int sp; bool filterID;
+};
+
+ZR_HD void TravInit(const SceneView& sc, TravState& s, V3 o, V3 d, float tmin, float tmax, uint32_t mask, bool filterID, uint32_t ignoreID)
+{
+    s.o = o; s.d = d; s.tmin = tmin; s.tmax = tmax; s.mask = mask; s.filterID = filterID; s.ignoreID = ignoreID;
+    s.best.t = tmax; s.best.u = 0; s.best.v = 0; s.best.tri = kInvalidTri;
+    s.idx = zr_safe_rcp_dir(d.x); s.idy = zr_safe_rcp_dir(d.y); s.idz = zr_safe_rcp_dir(d.z);
+    s.sp = 0;
+    // no nodes: a single leaf covering all triangles (tiny scenes)
+    s.cur = sc.numNodes ? 0u : kWholeSceneLeaf;
+}
+
+// pops the next child still worth visiting; false when the stack ran empty
+ZR_HD bool TravPop(TravState& s, const TravStack& stack)
+{
+    while (s.sp > 0)
     {
-        IntersectLeaf(sc, 0, sc.numTris, o, d, tmin, tmax, mask, best, filterID, ignoreID);
-        return best;
+        --s.sp;
+        uint32_t c; float t;
+        StackRead(stack, s.sp, c, t);
+        // same condition as re-running zr_ray_box with the current best t
+        if (t <= s.best.t * 1.0000003576278687f) { s.cur = c; return true; }
     }
-    const float idx = zr_safe_rcp_dir(d.x), idy = zr_safe_rcp_dir(d.y), idz = zr_safe_rcp_dir(d.z);
-    int sp = 0;
-    uint32_t cur = 0;
-    for (;;)
+    return false;
+}
+
+#define ZR_TRAV_CSWAP(a, b) { const bool sw = t##b < t##a; const float tt = sw ? t##a : t##b; t##a = sw ? t##b : t##a; t##b = tt; \
+    const uint32_t cc = sw ? c##a : c##b; c##a = sw ? c##b : c##a; c##b = cc; }
+
+// one step: a leaf (all its triangles) or an inner node (4 box tests).  Returns true when the ray is finished.
+ZR_HD bool TravStep(const SceneView& sc, TravState& s, const TravStack& stack, bool anyHit)
+{
+    if (s.cur & kLeafBit)
     {
-        if (cur & kLeafBit)
-        {
-            uint32_t first = (cur & 0x7fffffffu) >> 3, count = (cur & 7u) + 1u;
-            IntersectLeaf(sc, first, count, o, d, tmin, tmax, mask, best, filterID, ignoreID);
-            if (AnyHit && best.tri != kInvalidTri) return best;
-            if (sp == 0) break;
-            cur = stack[--sp];
-            continue;
-        }
-        const BvhNode& n = sc.nodes[cur];
-        float tl, tr;
-        // cull against the current best t (inclusive + widened, so equal-t candidates for the tie-break are visited)
-        bool hl = zr_ray_box(o.x, o.y, o.z, idx, idy, idz, n.lmin[0], n.lmin[1], n.lmin[2], n.lmax[0], n.lmax[1], n.lmax[2], tmin, best.t, &tl);
-        bool hr = zr_ray_box(o.x, o.y, o.z, idx, idy, idz, n.rmin[0], n.rmin[1], n.rmin[2], n.rmax[0], n.rmax[1], n.rmax[2], tmin, best.t, &tr);
-        if (hl && hr)
-        {
-            uint32_t nearC = n.left, farC = n.right;
-            if (tr < tl) { nearC = n.right; farC = n.left; }
-            stack[sp++] = farC;
-            cur = nearC;
-        }
-        else if (hl) cur = n.left;
-        else if (hr) cur = n.right;
-        else
-        {
-            if (sp == 0) break;
-            cur = stack[--sp];
-        }
+        uint32_t first = (s.cur & 0x7fffffffu) >> 3, count = (s.cur & 7u) + 1u;
+        if (s.cur == kWholeSceneLeaf) { first = 0; count = sc.numTris; }
+        IntersectLeaf(sc, first, count, s.o, s.d, s.tmin, s.tmax, s.mask, s.best, s.filterID, s.ignoreID);
+        if (anyHit && s.best.tri != kInvalidTri) return true;
+        return !TravPop(s, stack);
     }
-    return best;
+    const Bvh4Node n = sc.nodes[s.cur];
+    const float inf = zr_asfloat(0x7f800000u);
+    const float sx = zr_asfloat((n.exps & 0xffu) << 23), sy = zr_asfloat(((n.exps >> 8) & 0xffu) << 23), sz = zr_asfloat(((n.exps >> 16) & 0xffu) << 23);
+    uint32_t c0 = n.child[0], c1 = n.child[1], c2 = n.child[2], c3 = n.child[3];
+    float t0, t1, t2, t3;
+    // cull against the current best t (inclusive + widened, so equal-t candidates for the tie-break are visited)
+#define ZR_Q(w, k) ((float)(((w) >> (8 * (k))) & 0xffu))
+#define ZR_TRAV_BOX(k) if (!(c##k != kEmptyChild && zr_ray_box_native(s.o.x, s.o.y, s.o.z, s.idx, s.idy, s.idz, \
+        zr_fma(ZR_Q(n.qlox, k), sx, n.ox), zr_fma(ZR_Q(n.qloy, k), sy, n.oy), zr_fma(ZR_Q(n.qloz, k), sz, n.oz), \
+        zr_fma(ZR_Q(n.qhix, k), sx, n.ox), zr_fma(ZR_Q(n.qhiy, k), sy, n.oy), zr_fma(ZR_Q(n.qhiz, k), sz, n.oz), \
+        s.tmin, s.best.t, &t##k))) { t##k = inf; c##k = kEmptyChild; }
+    ZR_TRAV_BOX(0) ZR_TRAV_BOX(1) ZR_TRAV_BOX(2) ZR_TRAV_BOX(3)
+#undef ZR_TRAV_BOX
+#undef ZR_Q
+    // sorting network: near to far, misses (t = inf) last
+    ZR_TRAV_CSWAP(0, 1) ZR_TRAV_CSWAP(2, 3) ZR_TRAV_CSWAP(0, 2) ZR_TRAV_CSWAP(1, 3) ZR_TRAV_CSWAP(1, 2)
+    if (c0 == kEmptyChild) return !TravPop(s, stack);
+    if (c3 != kEmptyChild) StackWrite(stack, s.sp++, c3, t3);
+    if (c2 != kEmptyChild) StackWrite(stack, s.sp++, c2, t2);
+    if (c1 != kEmptyChild) StackWrite(stack, s.sp++, c1, t1);
+    s.cur = c0;
+    return false;
+}
+#undef ZR_TRAV_CSWAP
+
+template<bool AnyHit>
+ZR_HD RawHit Traverse(const SceneView& sc, V3 o, V3 d, float tmin, float tmax, uint32_t mask, const TravStack& stack, bool filterID = false, uint32_t ignoreID = 0)
+{
+    TravState s;
+    TravInit(sc, s, o, d, tmin, tmax, mask, filterID, ignoreID);
+    while (!TravStep(sc, s, stack, AnyHit)) {}
+    return s.best;
 }
 
 // ---- Material.h accessors ----

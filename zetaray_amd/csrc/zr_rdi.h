@@ -347,7 +347,7 @@ ZR_HD void WriteFinal(const zr_frame_constants& g, float* finalRGBA, size_t px, 
 ZR_HD V3 EmissiveColor(const GBuf& gb, size_t px)
 { uint32_t v = gb.emissive[px]; return v3(zr_unpack_ufloat(v & 0x7ff, 6), zr_unpack_ufloat((v >> 11) & 0x7ff, 6), zr_unpack_ufloat(v >> 22, 5)); }
 
-ZR_HD Globals MakeGlobals(const DiFrame& F, const zr_frame_constants& g, uint32_t* stack, uint32_t* cnt)
+ZR_HD Globals MakeGlobals(const DiFrame& F, const zr_frame_constants& g, TravStack stack, uint32_t* cnt)
 {
     Globals gl; gl.sc = &F.sc; gl.numEmissives = g.num_emissive_triangles; gl.alpha_min = 0; gl.stack = stack; gl.cnt = cnt; gl.maxNumBounces = 1;
     gl.presampled = false; gl.sampleSetIdx = 0;
@@ -355,7 +355,7 @@ ZR_HD Globals MakeGlobals(const DiFrame& F, const zr_frame_constants& g, uint32_
 }
 
 // K5: ReSTIR_DI_Temporal.hlsl main (:263-390) + EstimateDirectLighting (:205-257) for one pixel
-ZR_HD void TemporalPixel(const DiFrame& F, const zr_frame_constants& g, uint32_t x, uint32_t y, uint32_t* stack, uint32_t* cnt)
+ZR_HD void TemporalPixel(const DiFrame& F, const zr_frame_constants& g, uint32_t x, uint32_t y, TravStack stack, uint32_t* cnt)
 {
     const DiParams& prm = F.prm;
     const size_t px = Pix(F.gb, x, y);
@@ -503,7 +503,7 @@ ZR_HD void SpatialPhase0(const DiFrame& F, const zr_frame_constants& g, uint32_t
     }
     a.r = r;
 }
-ZR_HD void SpatialPhase1(const DiFrame& F, const zr_frame_constants& g, SpatialLane& a, uint32_t waveDisoccluded, uint32_t* stack, uint32_t* cnt)
+ZR_HD void SpatialPhase1(const DiFrame& F, const zr_frame_constants& g, SpatialLane& a, uint32_t waveDisoccluded, TravStack stack, uint32_t* cnt)
 {
     if (!a.active) return;
     const DiParams& prm = F.prm;

@@ -194,7 +194,7 @@ struct Lane
     Reservoir r;
 };
 
-ZR_HD Globals MakeGlobals(const GiFrame& F, const zr_frame_constants& g, const Lane& P, uint32_t* stack, uint32_t* cnt)
+ZR_HD Globals MakeGlobals(const GiFrame& F, const zr_frame_constants& g, const Lane& P, TravStack stack, uint32_t* cnt)
 {
     Globals gl; gl.sc = &F.sc; gl.numEmissives = g.num_emissive_triangles; gl.alpha_min = 0; gl.stack = stack; gl.cnt = cnt; gl.maxNumBounces = P.maxNumBounces;
     gl.presampled = F.prm.numSampleSets != 0; gl.sampleSetIdx = P.sampleSetIdx;
@@ -216,7 +216,7 @@ ZR_HD bool TraceContinuation(const Globals& gl, V3 pos, V3 normal, V3 wi, bool t
 }
 
 // ReSTIR_GI.hlsl main prologue + EstimateIndirectLighting / RIS_InitialCandidates up to the PathTrace call
-ZR_HD void InitLane(const GiFrame& F, const zr_frame_constants& g, uint32_t x, uint32_t y, uint32_t* stack, uint32_t* cnt, Lane& P)
+ZR_HD void InitLane(const GiFrame& F, const zr_frame_constants& g, uint32_t x, uint32_t y, TravStack stack, uint32_t* cnt, Lane& P)
 {
     const GiParams& prm = F.prm;
     P.valid = false; P.active = false; P.atRR = false; P.hasSample = false; P.x = x; P.y = y;
@@ -271,7 +271,7 @@ ZR_HD void InitLane(const GiFrame& F, const zr_frame_constants& g, uint32_t x, u
 }
 
 // PathTracing.hlsli:23-62 (GI parameters)
-ZR_HD void PhaseA(const GiFrame& F, const zr_frame_constants& g, uint32_t* stack, uint32_t* cnt, Lane& P)
+ZR_HD void PhaseA(const GiFrame& F, const zr_frame_constants& g, TravStack stack, uint32_t* cnt, Lane& P)
 {
     P.atRR = false;
     if (!P.active) return;
@@ -295,7 +295,7 @@ ZR_HD uint32_t RRKey(const Lane& P)
     return (zr_isnan(lum) || lum < 0) ? 0u : zr_asuint(lum);
 }
 // PathTracing.hlsli:62-95
-ZR_HD void PhaseB(const GiFrame& F, const zr_frame_constants& g, uint32_t* stack, uint32_t* cnt, Lane& P, uint32_t waveMaxBits)
+ZR_HD void PhaseB(const GiFrame& F, const zr_frame_constants& g, TravStack stack, uint32_t* cnt, Lane& P, uint32_t waveMaxBits)
 {
     if (!P.active) return;
     if (P.atRR)
@@ -528,7 +528,7 @@ ZR_HD void TemporalResample2(const Globals& gl, const GiFrame& F, const zr_frame
 }
 
 // tail of RIS_InitialCandidates + the temporal branch of EstimateIndirectLighting; returns the lane's w_sum for the wave sum
-ZR_HD float FinishAndResample(const GiFrame& F, const zr_frame_constants& g, uint32_t* stack, uint32_t* cnt, Lane& P)
+ZR_HD float FinishAndResample(const GiFrame& F, const zr_frame_constants& g, TravStack stack, uint32_t* cnt, Lane& P)
 {
     if (!P.valid) return 0.0f;
     if (P.hasSample)

@@ -367,7 +367,7 @@ ZR_HD Reservoir Load_NonReconnection(const ResPlanes& p, size_t i)
 { Reservoir r = InitReservoir(); r.UnpackMetadata(p.A[i]); r.w_sum = p.B[2 * i]; r.W = p.B[2 * i + 1]; return r; }
 
 // cnt: this lane's ray counters {closest-hit queries, shadow / visibility queries} (never null)
-struct Globals { const SceneView* sc; uint32_t numEmissives; int maxNumBounces; float alpha_min; uint32_t* stack; uint32_t* cnt; bool presampled; uint32_t sampleSetIdx; };
+struct Globals { const SceneView* sc; uint32_t numEmissives; int maxNumBounces; float alpha_min; TravStack stack; uint32_t* cnt; bool presampled; uint32_t sampleSetIdx; };
 
 // ---- ray queries (inline traversal)
 struct HitEm { bool hit; float t; uint32_t mesh, prim, emissiveTriIdx; float bu, bv; };
@@ -742,7 +742,7 @@ struct RptParams
 
 // main() prologue + RIS_InitialCandidates up to the first FindClosest (ReSTIR_PT_PathTrace.hlsl:360-530, 194-236)
 ZR_HD void PtInitLane(const SceneView& sc, const zr_frame_constants& g, const GBuf& gb, const RptParams& prm, bool owned, uint32_t x, uint32_t y,
-    float* finalRGBA, uint32_t* stack, uint32_t* cnt, PTLane& P)
+    float* finalRGBA, TravStack stack, uint32_t* cnt, PTLane& P)
 {
     P.active = false; P.atRR = false; P.valid = false; P.x = x; P.y = y;
     if (!owned) return;
@@ -777,7 +777,7 @@ ZR_HD void PtInitLane(const SceneView& sc, const zr_frame_constants& g, const GB
     P.active = true;
 }
 
-ZR_HD void PtPhaseA(const SceneView& sc, const zr_frame_constants& g, const RptParams& prm, uint32_t* stack, uint32_t* cnt, PTLane& P)
+ZR_HD void PtPhaseA(const SceneView& sc, const zr_frame_constants& g, const RptParams& prm, TravStack stack, uint32_t* cnt, PTLane& P)
 {
     P.atRR = false;
     if (!P.active) return;
@@ -1117,7 +1117,7 @@ struct RptFrame
     ZR_HDM bool Owns(uint32_t x, uint32_t y) const { return x >= ox0 && y >= oy0 && x < ox0 + ow && y < oy0 + oh; }
 };
 
-ZR_HD Globals MakeGlobals(const RptFrame& F, const zr_frame_constants& g, bool transmissive, uint32_t* stack, uint32_t* cnt)
+ZR_HD Globals MakeGlobals(const RptFrame& F, const zr_frame_constants& g, bool transmissive, TravStack stack, uint32_t* cnt)
 {
     Globals gl; gl.sc = &F.sc; gl.numEmissives = g.num_emissive_triangles; gl.alpha_min = F.prm.alpha_min; gl.stack = stack; gl.cnt = cnt; gl.presampled = false; gl.sampleSetIdx = 0;
     gl.maxNumBounces = transmissive ? (int)F.prm.maxGlossyTrBounces : (int)F.prm.maxNonTrBounces;
@@ -1150,7 +1150,7 @@ ZR_HD TemporalPixel FindTemporal(const RptFrame& F, const zr_frame_constants& g,
 }
 
 // K13 Replay_CtT / Replay_TtC (ReSTIR_PT_Replay.hlsl:289-534)
-ZR_HD_FLAT void ReplayTemporalPixel(const RptFrame& F, const zr_frame_constants& g, int variant, uint32_t x, uint32_t y, uint32_t* stack, uint32_t* cnt)
+ZR_HD_FLAT void ReplayTemporalPixel(const RptFrame& F, const zr_frame_constants& g, int variant, uint32_t x, uint32_t y, TravStack stack, uint32_t* cnt)
 {
     const size_t px = Pix(F.gb, x, y);
     GFlags flags = DecodeFlags(F.gb.mr[px]);
@@ -1209,7 +1209,7 @@ ZR_HD void MoveXk(const SceneView& sc, Reconnection& rc, bool currToPrev, bool s
 // for one pixel.  The reference runs them as two dispatches; both only read/write this pixel's current reservoir (CtT
 // writes w_sum, TtC reads it back) and read the previous frame's set, so running them back to back per pixel gives the
 // same result and shares the G-buffer reconstruction and the temporal-pixel search.
-ZR_HD void ReconnectTemporalPixel(const RptFrame& F, const zr_frame_constants& g, uint32_t x, uint32_t y, uint32_t* stack, uint32_t* cnt)
+ZR_HD void ReconnectTemporalPixel(const RptFrame& F, const zr_frame_constants& g, uint32_t x, uint32_t y, TravStack stack, uint32_t* cnt)
 {
     const size_t px = Pix(F.gb, x, y);
     GFlags flags = DecodeFlags(F.gb.mr[px]);
@@ -1388,7 +1388,7 @@ ZR_HD bool NeighborOf(const RptFrame& F, uint32_t x, uint32_t y, int& sx, int& s
 
 // In the spatial passes F.cur = the temporal pass's output ("in"), F.prev = the set written for the next frame ("out")
 // K13 Replay_CtS / Replay_StC
-ZR_HD_FLAT void ReplaySpatialPixel(const RptFrame& F, const zr_frame_constants& g, int variant, uint32_t x, uint32_t y, uint32_t* stack, uint32_t* cnt)
+ZR_HD_FLAT void ReplaySpatialPixel(const RptFrame& F, const zr_frame_constants& g, int variant, uint32_t x, uint32_t y, TravStack stack, uint32_t* cnt)
 {
     const size_t px = Pix(F.gb, x, y);
     GFlags flags = DecodeFlags(F.gb.mr[px]);
@@ -1446,7 +1446,7 @@ ZR_HD bool NeedsReplayStC(const RptFrame& F, uint32_t x, uint32_t y)
 
 // K16 Reconnect_CtS (ReSTIR_PT_Reconnect_CtS.hlsl:149-230).  Like CtT/TtC it only touches this pixel's entries (reads the
 // "in" set, writes w_sum of the "out" set that StC reads back), so the StC kernel runs it per lane before its phase 1.
-ZR_HD void ReconnectCtSPixel(const RptFrame& F, const zr_frame_constants& g, uint32_t x, uint32_t y, uint32_t* stack, uint32_t* cnt)
+ZR_HD void ReconnectCtSPixel(const RptFrame& F, const zr_frame_constants& g, uint32_t x, uint32_t y, TravStack stack, uint32_t* cnt)
 {
     const size_t px = Pix(F.gb, x, y);
     int sx, sy;
@@ -1533,7 +1533,7 @@ ZR_HD void StcPhase1(const RptFrame& F, const zr_frame_constants& g, StcLane& a,
     s3 = a.r_curr.w_sum * (a.spatialEmpty ? 1.0f : 0.0f);
 }
 // phase 2: lanes whose neighbour is empty finish; the others shift + resample; contributes sum4
-ZR_HD void StcPhase2(const RptFrame& F, const zr_frame_constants& g, StcLane& a, float sum1, uint32_t* stack, uint32_t* cnt, float& s4)
+ZR_HD void StcPhase2(const RptFrame& F, const zr_frame_constants& g, StcLane& a, float sum1, TravStack stack, uint32_t* cnt, float& s4)
 {
     s4 = 0;
     if (!a.valid || !a.hasN) return;

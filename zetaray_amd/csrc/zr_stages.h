@@ -53,7 +53,7 @@ ZR_HD float DecodeIOR(float e) { return zr_fma(e, kMaxIOR - kMinIOR, kMinIOR); }
 // K1: one pixel of GBufferRT_Inline.hlsl main (:204-287) + TracePrimaryHit (:72-198) + GBufferRT.hlsli:102-282.
 // Primary rays are coherent, so traversal runs inline in this kernel (no queue round trip).
 ZR_HD void GBufferPixel(const SceneView& sc, const zr_frame_constants& g, const GBuf& gb, uint32_t x, uint32_t y,
-    uint32_t* stack, uint64_t* nClosest)
+    TravStack stack, uint64_t* nClosest)
 {
     const uint32_t px = (y - gb.y0) * gb.w + (x - gb.x0);
     const V2 renderDim = v2((float)g.render_width, (float)g.render_height);
@@ -655,21 +655,20 @@ ZR_HD void PtRussianRoulette(const SceneView& sc, const PtParams& prm, const Pat
 }
 
 // trace stage for one ray of a queue slot
-ZR_HD U4 TraceClosestRay(const SceneView& sc, F4 ro, F4 rd, uint32_t mask, uint32_t* stack)
-{
-    RawHit h = Traverse<false>(sc, xyz(ro), xyz(rd), ro.w, rd.w, mask, stack);
-    U4 r; r.x = zr_asuint(h.tri == kInvalidTri ? 0.0f : h.t); r.y = zr_asuint(h.u); r.z = zr_asuint(h.v); r.w = h.tri;
-    return r;
-}
+ZR_HD U4 PackRawHit(const RawHit& h)
+{ U4 r; r.x = zr_asuint(h.tri == kInvalidTri ? 0.0f : h.t); r.y = zr_asuint(h.u); r.z = zr_asuint(h.v); r.w = h.tri; return r; }
+ZR_HD U4 TraceClosestRay(const SceneView& sc, F4 ro, F4 rd, uint32_t mask, TravStack stack)
+{ return PackRawHit(Traverse<false>(sc, xyz(ro), xyz(rd), ro.w, rd.w, mask, stack)); }
 // Visibility_Segment tail (RayQuery.hlsli:392-405): closest hit over NON_EMISSIVE geometry, visible iff no hit or the
 // hit's hashed ID equals the light's
-ZR_HD uint32_t TraceSegmentRay(const SceneView& sc, F4 ro, F4 rd, uint32_t lightID, uint32_t* stack)
+ZR_HD uint32_t SegmentVisible(const SceneView& sc, const RawHit& h, uint32_t lightID)
 {
-    RawHit h = Traverse<false>(sc, xyz(ro), xyz(rd), ro.w, rd.w, ZR_SUBGROUP_NON_EMISSIVE, stack);
     if (h.tri == kInvalidTri) return 1u;
     const TriMeta tm = sc.triMeta[h.tri];
     return TriID(tm.mesh, tm.prim) == lightID ? 1u : 0u;
 }
+ZR_HD uint32_t TraceSegmentRay(const SceneView& sc, F4 ro, F4 rd, uint32_t lightID, TravStack stack)
+{ return SegmentVisible(sc, Traverse<false>(sc, xyz(ro), xyz(rd), ro.w, rd.w, ZR_SUBGROUP_NON_EMISSIVE, stack), lightID); }
 
 // K3: PresampleEmissives.hlsl:20-44 -- sample i of numSets * setSize
 ZR_HD zr_presampled_tri PresampleEmissive(const SceneView& sc, uint32_t i, uint32_t frameNum, uint32_t numEmissives)
