@@ -136,31 +136,32 @@ __global__ void __launch_bounds__(kBlock) k_trace_simple(SceneView sc, PathQueue
     }
 }
 
-// trace stage over the 3 * n ray slots of the n live paths (C rays, then M rays, then S rays; a slot with d.w < 0 holds
-// no ray).  Persistent waves: every lane owns one ray at a time and advances it one BVH step (an inner node or a leaf)
-// per iteration; lanes whose ray finished -- or whose slot was empty -- take the next slot from the wave's chunk, and
-// the wave takes chunks of kTraceChunk slots from a global cursor.  A wave therefore never waits for its slowest ray
-// with 63 idle lanes, and empty slots cost one load instead of a lane.  Which lane traces which ray has no effect on
-// the results.
+// trace stage, persistent variant (ZR_TRACE_MODE=1).  Every lane owns one ray at a time; each iteration the wave votes
+// for one phase -- refill idle lanes from the wave's chunk of ray slots, inner-node step, or one triangle test -- and runs
+// the one most lanes are waiting for (the phases of Traverse, zr_dev_scene.h, plus the refill).  Waves take chunks of
+// kTraceChunk slots from a global cursor; an empty slot (d.w < 0) costs one load instead of a lane.  Which lane traces
+// which ray, and in which order, has no effect on the results.
 static constexpr uint32_t kTraceChunk = 256;
-static constexpr uint32_t kTraceRefillAt = 8;       // refill once this many lanes are idle (or nothing is left to step)
 __global__ void __launch_bounds__(kBlock) k_trace(SceneView sc, PathQueue q, const uint32_t* count, uint32_t* cursor, unsigned long long* counters)
 {
     const uint32_t n = *count;
     const uint32_t total = 3u * n;
     ZR_TRAV_STACK(stack);
     const uint32_t lane = __lane_id();
-    TravState st;
-    bool active = false;
+    TravState st; TravLane L; L.triCur = 0; L.triEnd = 0; L.done = true;
     uint32_t slot = 0;                              // this lane's ray: type * n + i
     uint32_t nClosest = 0, nShadow = 0;
     uint32_t chunkPos = 0, chunkEnd = 0;            // wave-uniform
     bool exhausted = false;                         // wave-uniform: the global cursor ran past `total`
     for (;;)
     {
-        const uint64_t idle = __ballot(!active);
-        const uint32_t nIdle = (uint32_t)__popcll(idle);
-        if (nIdle >= kTraceRefillAt && !(exhausted && chunkPos == chunkEnd))
+        const bool atTri = L.triCur < L.triEnd;
+        const bool atNode = !L.done && !atTri;
+        const uint64_t mIdle = __ballot(L.done);
+        const uint32_t nNode = (uint32_t)__popcll(__ballot(atNode)), nTri = (uint32_t)__popcll(__ballot(atTri)), nIdle = (uint32_t)__popcll(mIdle);
+        const bool canRefill = !(exhausted && chunkPos == chunkEnd);
+        if (nNode + nTri == 0 && !canRefill) break;
+        if (canRefill && nIdle >= (nNode > nTri ? nNode : nTri))
         {
             if (chunkPos == chunkEnd)
             {
@@ -171,9 +172,9 @@ __global__ void __launch_bounds__(kBlock) k_trace(SceneView sc, PathQueue q, con
                 chunkPos = b < total ? b : total;
                 chunkEnd = b + kTraceChunk < total ? b + kTraceChunk : total;
             }
-            const uint32_t rank = (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
+            const uint32_t rank = (uint32_t)__popcll(mIdle & ((1ull << lane) - 1ull));
             const uint32_t j = chunkPos + rank;
-            if (!active && j < chunkEnd)
+            if (L.done && j < chunkEnd)
             {
                 const uint32_t type = j / n, i = j - type * n;
                 F4 ro, rd;
@@ -182,31 +183,26 @@ __global__ void __launch_bounds__(kBlock) k_trace(SceneView sc, PathQueue q, con
                 else { rd = q.rayS_d[i]; ro = q.rayS_o[i]; }
                 if (rd.w >= 0)
                 {
-                    active = true; slot = j;
+                    slot = j; L.done = false;
                     if (type == 2) { TravInit(sc, st, xyz(ro), xyz(rd), ro.w, rd.w, ZR_SUBGROUP_NON_EMISSIVE, false, 0); nShadow++; }
                     else { TravInit(sc, st, xyz(ro), xyz(rd), ro.w, rd.w, ZR_SUBGROUP_ALL, false, 0); nClosest++; }
+                    TravEnter(sc, st, L, st.cur);
                 }
                 else if (type == 0) { U4 miss; miss.x = 0; miss.y = 0; miss.z = 0; miss.w = kInvalidTri; q.hitC[i] = miss; }
             }
             chunkPos = chunkPos + nIdle < chunkEnd ? chunkPos + nIdle : chunkEnd;
-        }
-        if (__ballot(active) == 0)
-        {
-            if (exhausted && chunkPos == chunkEnd) break;
             continue;
         }
-        if (active)
+        bool stepped = false;
+        if (nNode >= nTri) { if (atNode) { TravNodePhase(sc, st, L, stack); stepped = true; } }
+        else if (atTri) { TravTriPhase(sc, st, L, stack, false); stepped = true; }
+        if (stepped && L.done)
         {
-            const uint32_t type = slot / n;
-            // shadow segments stop at the first hit unless the light's own triangle has to be told apart (TraceSegmentRay)
-            if (TravStep(sc, st, stack, false))
-            {
-                const uint32_t i = slot - type * n;
-                if (type == 0) q.hitC[i] = PackRawHit(st.best);
-                else if (type == 1) q.hitM[i] = PackRawHit(st.best);
-                else q.visS[i] = SegmentVisible(sc, st.best, q.sLightID[i]);
-                active = false;
-            }
+            // shadow segments run to the closest hit: visible iff it is the light's own triangle (TraceSegmentRay)
+            const uint32_t type = slot / n, i = slot - type * n;
+            if (type == 0) q.hitC[i] = PackRawHit(st.best);
+            else if (type == 1) q.hitM[i] = PackRawHit(st.best);
+            else q.visS[i] = SegmentVisible(sc, st.best, q.sLightID[i]);
         }
     }
     uint32_t a = nClosest, b = nShadow;
