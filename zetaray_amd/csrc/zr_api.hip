@@ -48,6 +48,7 @@ static int RequireDevice(int device)
 
 // ------------------------------------------------------------------------------------------------ device helpers
 static constexpr int kBlock = 256;
+static constexpr uint32_t kCounterStride = 64;     // queue counters live 256 B apart: their atomics spread over L2 channels
 // this lane's traversal stack: kTravLdsEntries entries in LDS (16 KB per 256-lane block at 8 entries), the rest in scratch
 #define ZR_TRAV_STACK(name) \
     __shared__ StackEntry name##Lds[kTravLdsEntries * kBlock]; StackEntry name##Mem[kTravStack - kTravLdsEntries]; \
@@ -66,6 +67,22 @@ __device__ __forceinline__ uint32_t AllocSlotWave(uint32_t* counter, bool want)
     base = __shfl(base, leader);
     return base + prefix;
 }
+// appends this wave's new rays to the queue's compacted ray lists, one list per ray type so that the trace stage's waves
+// stay type-uniform: one atomic per wave and type (all 64 lanes must call this)
+__device__ __forceinline__ void AppendRays(uint32_t* rayList, uint32_t cap, uint32_t* rayCount, uint32_t slot, bool c, bool m, bool sh)
+{
+    const uint32_t s0 = AllocSlotWave(rayCount, c), s1 = AllocSlotWave(rayCount + kCounterStride, m), s2 = AllocSlotWave(rayCount + 2 * kCounterStride, sh);
+    if (c) rayList[s0] = slot;
+    if (m) rayList[cap + s1] = slot;
+    if (sh) rayList[2 * cap + s2] = slot;
+}
+// entry j of the concatenation (C rays, M rays, S rays) of a queue's ray lists -> type, slot
+__device__ __forceinline__ void RayOfIndex(const uint32_t* rayList, uint32_t cap, uint32_t nC, uint32_t nM, uint32_t j, uint32_t& type, uint32_t& slot)
+{
+    type = j < nC ? 0u : (j < nC + nM ? 1u : 2u);
+    slot = rayList[type * cap + (j - (type == 0 ? 0u : (type == 1 ? nC : nC + nM)))];
+}
+
 __device__ __forceinline__ void CountWave(unsigned long long* counter, bool pred)
 {
     const uint64_t m = __ballot(pred);
@@ -92,20 +109,20 @@ __global__ void __launch_bounds__(kBlock) k_gbuffer(SceneView sc, zr_frame_const
 }
 
 __global__ void __launch_bounds__(kBlock) k_pt_init(SceneView sc, zr_frame_constants g, GBuf gb, PtParams prm, float* finalRGBA,
-    F4* firstBOP, PathQueue out, uint32_t* outCount, uint32_t tilesX)
+    F4* firstBOP, PathQueue out, uint32_t* outCount, uint32_t* outRays, uint32_t cap, uint32_t tilesX)
 {
     uint32_t x, y; PixelOfThread(tilesX, gb.x0, gb.y0, &x, &y);
     PathOut po; po.alive = false;
     if (x < gb.x0 + gb.w && y < gb.y0 + gb.h) PtInitPixel(sc, g, gb, prm, x, y, finalRGBA, firstBOP, po);
     const uint32_t slot = AllocSlotWave(outCount, po.alive);
     if (po.alive) WritePath(out, slot, po);
+    AppendRays(out.rayList, cap, outRays, slot, po.alive && po.rayC_d.w >= 0, po.alive && po.rayM_d.w >= 0, po.alive && po.rayS_d.w >= 0);
 }
 
-// trace stage, run-to-completion variant (ZR_TRACE_MODE=0): grid-stride over the 3 * n ray slots
-__global__ void __launch_bounds__(kBlock) k_trace_simple(SceneView sc, PathQueue q, const uint32_t* count, unsigned long long* counters)
+// trace stage, run-to-completion variant (default): grid-stride over the queue's compacted ray list
+__global__ void __launch_bounds__(kBlock) k_trace_simple(SceneView sc, PathQueue q, const uint32_t* rayCount, uint32_t cap, unsigned long long* counters)
 {
-    const uint32_t n = *count;
-    const uint32_t total = 3u * n;
+    const uint32_t nC = rayCount[0], nM = rayCount[kCounterStride], total = nC + nM + rayCount[2 * kCounterStride];
     ZR_TRAV_STACK(stack);
     for (uint32_t base = blockIdx.x * kBlock; base < total; base += gridDim.x * kBlock)
     {
@@ -113,23 +130,18 @@ __global__ void __launch_bounds__(kBlock) k_trace_simple(SceneView sc, PathQueue
         bool closest = false, shadow = false;
         if (j < total)
         {
-            const uint32_t type = j / n, i = j - type * n;
-            if (type == 0)
-            {
-                const F4 rd = q.rayC_d[i];
-                if (rd.w >= 0) { q.hitC[i] = TraceClosestRay(sc, q.rayC_o[i], rd, ZR_SUBGROUP_ALL, stack); closest = true; }
-                else { U4 miss; miss.x = 0; miss.y = 0; miss.z = 0; miss.w = kInvalidTri; q.hitC[i] = miss; }
-            }
-            else if (type == 1)
-            {
-                const F4 rd = q.rayM_d[i];
-                if (rd.w >= 0) { q.hitM[i] = TraceClosestRay(sc, q.rayM_o[i], rd, ZR_SUBGROUP_ALL, stack); closest = true; }
-            }
-            else
-            {
-                const F4 rd = q.rayS_d[i];
-                if (rd.w >= 0) { q.visS[i] = TraceSegmentRay(sc, q.rayS_o[i], rd, q.sLightID[i], stack); shadow = true; }
-            }
+            // one Traverse call site for the three ray types: a wave holds a mix of them
+            uint32_t type, i;
+            RayOfIndex(q.rayList, cap, nC, nM, j, type, i);
+            F4 ro, rd;
+            if (type == 0) { rd = q.rayC_d[i]; ro = q.rayC_o[i]; }
+            else if (type == 1) { rd = q.rayM_d[i]; ro = q.rayM_o[i]; }
+            else { rd = q.rayS_d[i]; ro = q.rayS_o[i]; }
+            const RawHit h = Traverse<false>(sc, xyz(ro), xyz(rd), ro.w, rd.w, type == 2 ? ZR_SUBGROUP_NON_EMISSIVE : ZR_SUBGROUP_ALL, stack);
+            if (type == 0) q.hitC[i] = PackRawHit(h);
+            else if (type == 1) q.hitM[i] = PackRawHit(h);
+            else q.visS[i] = SegmentVisible(sc, h, q.sLightID[i]);
+            closest = type != 2; shadow = type == 2;
         }
         CountWave(&counters[0], closest);
         CountWave(&counters[1], shadow);
@@ -139,17 +151,17 @@ __global__ void __launch_bounds__(kBlock) k_trace_simple(SceneView sc, PathQueue
 // trace stage, persistent variant (ZR_TRACE_MODE=1).  Every lane owns one ray at a time; each iteration the wave votes
 // for one phase -- refill idle lanes from the wave's chunk of ray slots, inner-node step, or one triangle test -- and runs
 // the one most lanes are waiting for (the phases of Traverse, zr_dev_scene.h, plus the refill).  Waves take chunks of
-// kTraceChunk slots from a global cursor; an empty slot (d.w < 0) costs one load instead of a lane.  Which lane traces
-// which ray, and in which order, has no effect on the results.
+// kTraceChunk entries of the compacted ray list from a global cursor.  Which lane traces which ray, and in which order,
+// has no effect on the results.
 static constexpr uint32_t kTraceChunk = 256;
-__global__ void __launch_bounds__(kBlock) k_trace(SceneView sc, PathQueue q, const uint32_t* count, uint32_t* cursor, unsigned long long* counters)
+static constexpr uint32_t kTraceRefillAt = 16;
+__global__ void __launch_bounds__(kBlock) k_trace(SceneView sc, PathQueue q, const uint32_t* rayCount, uint32_t cap, uint32_t* cursor, unsigned long long* counters)
 {
-    const uint32_t n = *count;
-    const uint32_t total = 3u * n;
+    const uint32_t nC = rayCount[0], nM = rayCount[kCounterStride], total = nC + nM + rayCount[2 * kCounterStride];
     ZR_TRAV_STACK(stack);
     const uint32_t lane = __lane_id();
     TravState st; TravLane L; L.triCur = 0; L.triEnd = 0; L.done = true;
-    uint32_t slot = 0;                              // this lane's ray: type * n + i
+    uint32_t slot = 0;                              // this lane's ray: list entry (slot | type << 30)
     uint32_t nClosest = 0, nShadow = 0;
     uint32_t chunkPos = 0, chunkEnd = 0;            // wave-uniform
     bool exhausted = false;                         // wave-uniform: the global cursor ran past `total`
@@ -161,7 +173,7 @@ __global__ void __launch_bounds__(kBlock) k_trace(SceneView sc, PathQueue q, con
         const uint32_t nNode = (uint32_t)__popcll(__ballot(atNode)), nTri = (uint32_t)__popcll(__ballot(atTri)), nIdle = (uint32_t)__popcll(mIdle);
         const bool canRefill = !(exhausted && chunkPos == chunkEnd);
         if (nNode + nTri == 0 && !canRefill) break;
-        if (canRefill && nIdle >= (nNode > nTri ? nNode : nTri))
+        if (canRefill && (nIdle >= kTraceRefillAt || nNode + nTri == 0))
         {
             if (chunkPos == chunkEnd)
             {
@@ -176,19 +188,17 @@ __global__ void __launch_bounds__(kBlock) k_trace(SceneView sc, PathQueue q, con
             const uint32_t j = chunkPos + rank;
             if (L.done && j < chunkEnd)
             {
-                const uint32_t type = j / n, i = j - type * n;
+                uint32_t type, i;
+                RayOfIndex(q.rayList, cap, nC, nM, j, type, i);
+                slot = i | (type << 30);
                 F4 ro, rd;
                 if (type == 0) { rd = q.rayC_d[i]; ro = q.rayC_o[i]; }
                 else if (type == 1) { rd = q.rayM_d[i]; ro = q.rayM_o[i]; }
                 else { rd = q.rayS_d[i]; ro = q.rayS_o[i]; }
-                if (rd.w >= 0)
-                {
-                    slot = j; L.done = false;
-                    if (type == 2) { TravInit(sc, st, xyz(ro), xyz(rd), ro.w, rd.w, ZR_SUBGROUP_NON_EMISSIVE, false, 0); nShadow++; }
-                    else { TravInit(sc, st, xyz(ro), xyz(rd), ro.w, rd.w, ZR_SUBGROUP_ALL, false, 0); nClosest++; }
-                    TravEnter(sc, st, L, st.cur);
-                }
-                else if (type == 0) { U4 miss; miss.x = 0; miss.y = 0; miss.z = 0; miss.w = kInvalidTri; q.hitC[i] = miss; }
+                L.done = false;
+                if (type == 2) { TravInit(sc, st, xyz(ro), xyz(rd), ro.w, rd.w, ZR_SUBGROUP_NON_EMISSIVE, false, 0); nShadow++; }
+                else { TravInit(sc, st, xyz(ro), xyz(rd), ro.w, rd.w, ZR_SUBGROUP_ALL, false, 0); nClosest++; }
+                TravEnter(sc, st, L, st.cur);
             }
             chunkPos = chunkPos + nIdle < chunkEnd ? chunkPos + nIdle : chunkEnd;
             continue;
@@ -199,7 +209,7 @@ __global__ void __launch_bounds__(kBlock) k_trace(SceneView sc, PathQueue q, con
         if (stepped && L.done)
         {
             // shadow segments run to the closest hit: visible iff it is the light's own triangle (TraceSegmentRay)
-            const uint32_t type = slot / n, i = slot - type * n;
+            const uint32_t type = slot >> 30, i = slot & 0x3fffffffu;
             if (type == 0) q.hitC[i] = PackRawHit(st.best);
             else if (type == 1) q.hitM[i] = PackRawHit(st.best);
             else q.visS[i] = SegmentVisible(sc, st.best, q.sLightID[i]);
@@ -211,7 +221,7 @@ __global__ void __launch_bounds__(kBlock) k_trace(SceneView sc, PathQueue q, con
 }
 
 __global__ void __launch_bounds__(kBlock) k_pt_shade(SceneView sc, zr_frame_constants g, PtParams prm, PathQueue in, const uint32_t* inCount,
-    PathQueue out, uint32_t* outCount, float* finalRGBA, const F4* firstBOP, uint32_t* groupMax)
+    PathQueue out, uint32_t* outCount, uint32_t* outRays, uint32_t cap, float* finalRGBA, const F4* firstBOP, uint32_t* groupMax)
 {
     const uint32_t n = *inCount;
     for (uint32_t base = blockIdx.x * kBlock; base < n; base += gridDim.x * kBlock)
@@ -221,15 +231,20 @@ __global__ void __launch_bounds__(kBlock) k_pt_shade(SceneView sc, zr_frame_cons
         if (i < n) PtShadePath(sc, g, prm, in, i, finalRGBA, firstBOP, groupMax, po);
         const uint32_t slot = AllocSlotWave(outCount, po.alive);
         if (po.alive) WritePath(out, slot, po);
+        AppendRays(out.rayList, cap, outRays, slot, po.alive && po.rayC_d.w >= 0, po.alive && po.rayM_d.w >= 0, po.alive && po.rayS_d.w >= 0);
     }
 }
 
 // Russian-roulette stage: finishes the vertices PtShadePath parked (only launched for rounds in which RR can trigger)
-__global__ void __launch_bounds__(kBlock) k_pt_rr(SceneView sc, PtParams prm, PathQueue q, const uint32_t* count, const uint32_t* groupMax)
+__global__ void __launch_bounds__(kBlock) k_pt_rr(SceneView sc, PtParams prm, PathQueue q, const uint32_t* count, uint32_t* rays, uint32_t cap, const uint32_t* groupMax)
 {
     const uint32_t n = *count;
-    for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock)
-        PtRussianRoulette(sc, prm, q, i, groupMax);
+    for (uint32_t base = blockIdx.x * kBlock; base < n; base += gridDim.x * kBlock)
+    {
+        const uint32_t i = base + threadIdx.x;
+        const bool cont = i < n && PtRussianRoulette(sc, prm, q, i, groupMax);
+        AppendRays(q.rayList, cap, rays, i, cont, false, false);
+    }
 }
 
 // Compositing: pure streaming kernel (2 + 16 + 16 B read, 16 B written per pixel)
@@ -490,7 +505,7 @@ struct zr_gbuffer
 
 struct QueueStorage
 {
-    DevBuf<U4> s0; DevBuf<F4> f[8]; DevBuf<F4> rays[6]; DevBuf<uint32_t> lightID; DevBuf<U4> hitC, hitM; DevBuf<uint32_t> visS;
+    DevBuf<U4> s0; DevBuf<F4> f[8]; DevBuf<F4> rays[6]; DevBuf<uint32_t> lightID; DevBuf<U4> hitC, hitM; DevBuf<uint32_t> visS, rayList;
     int Alloc(size_t cap)
     {
         int r;
@@ -501,6 +516,7 @@ struct QueueStorage
         if ((r = hitC.Alloc(cap))) return r;
         if ((r = hitM.Alloc(cap))) return r;
         if ((r = visS.Alloc(cap))) return r;
+        if ((r = rayList.Alloc(3 * cap))) return r;
         return ZR_OK;
     }
     PathQueue View() const
@@ -508,7 +524,7 @@ struct QueueStorage
         PathQueue q;
         q.s0 = s0.p; q.s1 = f[0].p; q.s2 = f[1].p; q.s3 = f[2].p; q.s4 = f[3].p; q.s5 = f[4].p; q.s6 = f[5].p; q.s7 = f[6].p; q.s8 = f[7].p;
         q.rayC_o = rays[0].p; q.rayC_d = rays[1].p; q.rayM_o = rays[2].p; q.rayM_d = rays[3].p; q.rayS_o = rays[4].p; q.rayS_d = rays[5].p;
-        q.sLightID = lightID.p; q.hitC = hitC.p; q.hitM = hitM.p; q.visS = visS.p;
+        q.sLightID = lightID.p; q.hitC = hitC.p; q.hitM = hitM.p; q.visS = visS.p; q.rayList = rayList.p;
         return q;
     }
 };
@@ -861,7 +877,7 @@ static int AllocPass(zr_pass* p)
         if ((r = p->q[1].Alloc(cap))) return r;
         if ((r = p->finalRGBA.Alloc(cap * 4))) return r;
         if ((r = p->firstBOP.Alloc(cap))) return r;
-        if ((r = p->counts.Alloc(2 * (kMaxRounds + 2)))) return r;   // queue counts, then k_trace cursors
+        if ((r = p->counts.Alloc(5 * (kMaxRounds + 2) * kCounterStride))) return r;   // per round: live paths, k_trace cursor, 3 ray counts
         if ((r = p->counters.Alloc(2 * kCounterSlots))) return r;
         if ((r = p->groupMax.Alloc((size_t)kMaxRounds * ((p->w + 7) / 8) * ((p->h + 7) / 8)))) return r;
         HIP_TRY(hipMemset(p->finalRGBA.p, 0, cap * 4 * sizeof(float)));
@@ -1171,7 +1187,9 @@ static int RenderIndirect(zr_pass* p, hipStream_t s, const zr_frame_constants* c
     const int rounds = (int)maxB + 1;
     if (rounds > kMaxRounds) return Fail(ZR_ERR_INVALID_ARG, "too many bounces");
 
-    HIP_TRY(hipMemsetAsync(p->counts.p, 0, 2 * (kMaxRounds + 2) * sizeof(uint32_t), s));
+    HIP_TRY(hipMemsetAsync(p->counts.p, 0, 5 * (kMaxRounds + 2) * kCounterStride * sizeof(uint32_t), s));
+    // counter (kind, round): kind 0 = live paths, 1 = k_trace cursor, 2..4 = C / M / S rays
+    auto Ctr = [&](int kind, int round) { return p->counts.p + ((size_t)round * 5 + kind) * kCounterStride; };
     // Russian roulette can only trigger once bounce >= 3, i.e. from round 2 on and only if some path may take >= 4 bounces
     const bool rrPossible = prm.russianRoulette && maxB >= 4;
     if (rrPossible) HIP_TRY(hipMemsetAsync(p->groupMax.p, 0, (size_t)rounds * numGroups * sizeof(uint32_t), s));
@@ -1179,7 +1197,7 @@ static int RenderIndirect(zr_pass* p, hipStream_t s, const zr_frame_constants* c
     const GBuf gbv = gb->View();
     TimerBegin(p, s, "pt_init");
     hipLaunchKernelGGL(k_pt_init, dim3(tilesX * tilesY), dim3(kBlock), 0, s, sc->view, *cb, gbv, prm, p->finalRGBA.p, p->firstBOP.p,
-        p->q[0].View(), p->counts.p + 0, tilesX);
+        p->q[0].View(), Ctr(0, 0), Ctr(2, 0), (uint32_t)((size_t)p->w * p->h), tilesX);
     TimerEnd(p, s);
     const size_t cap = (size_t)p->w * p->h;
     const uint32_t gridShade = (uint32_t)std::min<size_t>((cap + kBlock - 1) / kBlock, 4096);
@@ -1190,17 +1208,17 @@ static int RenderIndirect(zr_pass* p, hipStream_t s, const zr_frame_constants* c
     {
         const PathQueue qin = p->q[r & 1].View(), qout = p->q[(r + 1) & 1].View();
         TimerBegin(p, s, "trace");
-        if (traceMode == 0) hipLaunchKernelGGL(k_trace_simple, dim3(gridTraceSimple), dim3(kBlock), 0, s, sc->view, qin, p->counts.p + r, p->counters.p);
-        else hipLaunchKernelGGL(k_trace, dim3(gridTrace), dim3(kBlock), 0, s, sc->view, qin, p->counts.p + r, p->counts.p + (kMaxRounds + 2) + r, p->counters.p);
+        if (traceMode == 0) hipLaunchKernelGGL(k_trace_simple, dim3(gridTraceSimple), dim3(kBlock), 0, s, sc->view, qin, Ctr(2, r), (uint32_t)cap, p->counters.p);
+        else hipLaunchKernelGGL(k_trace, dim3(gridTrace), dim3(kBlock), 0, s, sc->view, qin, Ctr(2, r), (uint32_t)cap, Ctr(1, r), p->counters.p);
         TimerEnd(p, s);
         TimerBegin(p, s, "pt_shade");
-        hipLaunchKernelGGL(k_pt_shade, dim3(gridShade), dim3(kBlock), 0, s, sc->view, *cb, prm, qin, p->counts.p + r, qout, p->counts.p + r + 1,
+        hipLaunchKernelGGL(k_pt_shade, dim3(gridShade), dim3(kBlock), 0, s, sc->view, *cb, prm, qin, Ctr(0, r), qout, Ctr(0, r + 1), Ctr(2, r + 1), (uint32_t)cap,
             p->finalRGBA.p, p->firstBOP.p, p->groupMax.p + (size_t)r * numGroups);
         TimerEnd(p, s);
         if (rrPossible && r >= 2)
         {
             TimerBegin(p, s, "pt_rr");
-            hipLaunchKernelGGL(k_pt_rr, dim3(gridShade), dim3(kBlock), 0, s, sc->view, prm, qout, p->counts.p + r + 1, p->groupMax.p + (size_t)r * numGroups);
+            hipLaunchKernelGGL(k_pt_rr, dim3(gridShade), dim3(kBlock), 0, s, sc->view, prm, qout, Ctr(0, r + 1), Ctr(2, r + 1), (uint32_t)cap, p->groupMax.p + (size_t)r * numGroups);
             TimerEnd(p, s);
         }
     }

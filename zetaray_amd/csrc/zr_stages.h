@@ -217,6 +217,8 @@ struct PathQueue
     // results written by the trace kernel
     U4* hitC; U4* hitM;   // (t bits, u bits, v bits, global tri or kInvalidTri)
     uint32_t* visS;       // 1 = segment unoccluded
+    // device only: compacted list of this queue's rays (slot | type << 30; type 0 = C, 1 = M, 2 = S), any order
+    uint32_t* rayList;
 };
 
 struct PathOut   // what one shade/init step wants to write into the next queue
@@ -235,6 +237,8 @@ ZR_HD void WritePath(const PathQueue& q, uint32_t slot, const PathOut& p)
     q.rayM_o[slot] = p.rayM_o; q.rayM_d[slot] = p.rayM_d;
     q.rayS_o[slot] = p.rayS_o; q.rayS_d[slot] = p.rayS_d;
     q.sLightID[slot] = p.sLightID;
+    // slots without a C ray read back as a miss (the trace stage only visits listed rays)
+    if (p.rayC_d.w < 0) { U4 miss; miss.x = 0; miss.y = 0; miss.z = 0; miss.w = kInvalidTri; q.hitC[slot] = miss; }
 }
 
 struct PtParams
@@ -615,10 +619,11 @@ ZR_HD void PtShadePath(const SceneView& sc, const zr_frame_constants& g, const P
 // Russian-roulette stage for the parked path in slot `i` of `q` (in place): PathTracing.hlsli:62-72, then the loop tail.
 // `groupMax` holds, per 8x8 group, the max luminance(throughput) over the lanes that reached the RR block this round
 // (the reference's WaveActiveMax; lanes = pixels of the 8x8 thread group).
-ZR_HD void PtRussianRoulette(const SceneView& sc, const PtParams& prm, const PathQueue& q, uint32_t i, const uint32_t* groupMax)
+// Returns true when the path continues, i.e. slot i now holds a C ray.
+ZR_HD bool PtRussianRoulette(const SceneView& sc, const PtParams& prm, const PathQueue& q, uint32_t i, const uint32_t* groupMax)
 {
     const U4 s0 = q.s0[i];
-    if (!(s0.w & PF_PARKED)) return;
+    if (!(s0.w & PF_PARKED)) return false;
     const uint32_t pid = s0.x;
     const uint32_t lx = pid % prm.tileW, ly = pid / prm.tileW;
     const float waveThroughput = zr_asfloat(groupMax[(ly >> 3) * prm.groupsX + (lx >> 3)]);
@@ -633,7 +638,7 @@ ZR_HD void PtRussianRoulette(const SceneView& sc, const PtParams& prm, const Pat
         U4 o = s0; o.z = rngG.s; o.w = flags | PF_DRAIN;
         q.s0[i] = o;
         q.rayC_d[i] = f4(v3(0.0f), -1.0f);
-        return;
+        return false;
     }
     const F4 s2 = q.s2[i];
     V3 thr = xyz(s2) / (1 - p_terminate);
@@ -652,6 +657,7 @@ ZR_HD void PtRussianRoulette(const SceneView& sc, const PtParams& prm, const Pat
     PathOut po; po.s2.w = s2.w;
     PtContinue(sc, hit.normal, surface, hitPos, eta_curr, eta_next, inMedium, thr, bounce, maxB, nflags, pid, rngT, rngG, xyz(s1), setIdxBits, po);
     q.s0[i] = po.s0; q.s1[i] = po.s1; q.s2[i] = po.s2; q.s4[i] = po.s4; q.rayC_o[i] = po.rayC_o; q.rayC_d[i] = po.rayC_d;
+    return po.rayC_d.w >= 0;
 }
 
 // trace stage for one ray of a queue slot
