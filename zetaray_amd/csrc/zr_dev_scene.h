@@ -168,10 +168,11 @@ ZR_HD uint32_t TravNode(const SceneView& sc, TravState& s, const TravStack& stac
     float t0, t1, t2, t3;
     // cull against the current best t (inclusive + widened, so equal-t candidates for the tie-break are visited)
 #define ZR_Q(w, k) ((float)(((w) >> (8 * (k))) & 0xffu))
-#define ZR_TRAV_BOX(k) if (!(c##k != kEmptyChild && zr_ray_box_native(s.o.x, s.o.y, s.o.z, s.idx, s.idy, s.idz, \
+    // (all four slots are tested unconditionally -- an empty slot decodes to a harmless box -- to keep the phase branch-free)
+#define ZR_TRAV_BOX(k) { const int h = zr_ray_box_native(s.o.x, s.o.y, s.o.z, s.idx, s.idy, s.idz, \
         zr_fma(ZR_Q(n.qlox, k), sx, n.ox), zr_fma(ZR_Q(n.qloy, k), sy, n.oy), zr_fma(ZR_Q(n.qloz, k), sz, n.oz), \
         zr_fma(ZR_Q(n.qhix, k), sx, n.ox), zr_fma(ZR_Q(n.qhiy, k), sy, n.oy), zr_fma(ZR_Q(n.qhiz, k), sz, n.oz), \
-        s.tmin, s.best.t, &t##k))) { t##k = inf; c##k = kEmptyChild; }
+        s.tmin, s.best.t, &t##k); const bool ok = (h != 0) & (c##k != kEmptyChild); t##k = ok ? t##k : inf; c##k = ok ? c##k : kEmptyChild; }
     ZR_TRAV_BOX(0) ZR_TRAV_BOX(1) ZR_TRAV_BOX(2) ZR_TRAV_BOX(3)
 #undef ZR_TRAV_BOX
 #undef ZR_Q
