@@ -56,7 +56,13 @@ typedef enum zr_pass_kind {
     ZR_PASS_DI_EMISSIVE = 2,   /* DirectLighting     */
     ZR_PASS_DI_SKY      = 3,   /* SkyDI              */
     ZR_PASS_INDIRECT    = 4,   /* IndirectLighting   */
-    ZR_PASS_COMPOSITING = 5    /* Compositing: (DI + indirect * !emissive) / NumFramesCameraStatic */
+    ZR_PASS_COMPOSITING = 5,   /* Compositing: (DI + indirect * !emissive) / NumFramesCameraStatic */
+    /* Sky (RP/Sky/Sky.cpp:34-66,120-164; K17 RP/Sky/SkyViewLUT.hlsl): zr_pass_init(pass, LutWidth, LutHeight, 0) (the reference
+       uses 256 x 128, DefaultRendererImpl.h:165-166); zr_pass_render writes the sky-view LUT from cbFrameConstants' sun and
+       atmosphere fields and binds it to the scene, where Le_Sky of every later pass samples it (the reference does the same
+       through EnvMapDescHeapOffset).  Pinned: R11G11B10_FLOAT store rounds to nearest even; the LUT is sampled with fp32 bilinear
+       interpolation, texel centres at (i + 0.5) / N, wrap addressing.  Inscattering voxel grid: out of scope (post stack). */
+    ZR_PASS_SKY         = 6
 } zr_pass_kind;
 
 /* IndirectLighting::INTEGRATOR, reference IndirectLighting.h:40-46 */
@@ -119,7 +125,9 @@ typedef enum zr_output {
     /* ReSTIR GI persistent state written by the last frame (ReSTIR_GI/Reservoir.hlsli:72-131) */
     ZR_OUT_RGI_RESERVOIR_A = 30,   /* RGBA32F 16 B: sample position, hit ID bits */
     ZR_OUT_RGI_RESERVOIR_B = 31,   /* RGBA16F  8 B: Lo, M */
-    ZR_OUT_RGI_RESERVOIR_C = 32    /* RGBA32F 16 B: w_sum, W, oct32 normal bits, unused */
+    ZR_OUT_RGI_RESERVOIR_C = 32,   /* RGBA32F 16 B: w_sum, W, oct32 normal bits, unused */
+    /* Sky (ZR_PASS_SKY) */
+    ZR_OUT_SKY_LUT         = 40    /* R11G11B10_FLOAT 4 B, LutWidth x LutHeight (Sky::SHADER_OUT_RES::SKY_VIEW_LUT) */
 } zr_output;
 
 /* G-buffer planes (reference GBufferData::GBUFFER order and DXGI formats, DefaultRendererImpl.h:82-109) */

@@ -34,6 +34,7 @@
 #define ZR_PI_OVER_4       0.7853981635f
 #define ZR_ONE_OVER_PI     0.318309886f
 #define ZR_ONE_OVER_2_PI   0.159154943f
+#define ZR_ONE_OVER_4_PI   0.079577472f
 #define ZR_FLT_MAX         3.402823466e+38f
 #define ZR_FLT16_MAX       65504.0f
 

@@ -287,6 +287,38 @@ namespace Math {
 }
 
 // Sampling.hlsli:12-159
+// float -> unsigned small float with `mbits` mantissa bits, 5 exponent bits (R11G11B10_FLOAT), round-to-nearest-even
+static inline uint32_t PackUFloat(float f, int mbits)
+{
+    uint32_t x = zr_asuint(f);
+    if (x & 0x80000000u) return 0;                       // negative (and -0) -> 0
+    if (x >= 0x7f800000u) return x > 0x7f800000u ? ((0x1fu << mbits) | 1u) : (0x1fu << mbits);   // nan / inf
+    const int shift = 23 - mbits;
+    if (x >= 0x47800000u) return (0x1eu << mbits) | ((1u << mbits) - 1u);   // >= 65536 -> max finite
+    if (x < 0x38800000u)
+    {
+        // denormal in the target format: value / 2^-14 * 2^mbits
+        if (x < 0x33000000u) return 0;
+        uint32_t e = x >> 23;
+        uint32_t m = (x & 0x007fffffu) | 0x00800000u;
+        uint32_t sh = (uint32_t)shift + (113u - e);
+        if (sh > 24) return 0;
+        uint32_t r = m >> sh;
+        uint32_t rem = m & ((1u << sh) - 1u);
+        uint32_t half = 1u << (sh - 1u);
+        if (rem > half || (rem == half && (r & 1u))) r++;
+        return r;
+    }
+    uint32_t r = (x - 0x38000000u) >> shift;
+    uint32_t rem = x & ((1u << shift) - 1u);
+    uint32_t half = 1u << (shift - 1);
+    if (rem > half || (rem == half && (r & 1u))) r++;
+    uint32_t maxv = (0x1eu << mbits) | ((1u << mbits) - 1u);
+    return r > maxv ? maxv : r;
+}
+static inline uint32_t PackR11G11B10F(float3 c) { return PackUFloat(c.x, 6) | (PackUFloat(c.y, 6) << 11) | (PackUFloat(c.z, 5) << 22); }
+
+
 struct RNG
 {
     uint32_t State;

@@ -118,37 +118,6 @@ static inline uint32_t PackSnorm16(float f)
     int32_t i = (int32_t)(f >= 0 ? f + 0.5f : f - 0.5f);
     return (uint32_t)(uint16_t)(int16_t)i;
 }
-// float -> unsigned small float with `mbits` mantissa bits, 5 exponent bits (R11G11B10_FLOAT), round-to-nearest-even
-static inline uint32_t PackUFloat(float f, int mbits)
-{
-    uint32_t x = zr_asuint(f);
-    if (x & 0x80000000u) return 0;                       // negative (and -0) -> 0
-    if (x >= 0x7f800000u) return x > 0x7f800000u ? ((0x1fu << mbits) | 1u) : (0x1fu << mbits);   // nan / inf
-    const int shift = 23 - mbits;
-    if (x >= 0x47800000u) return (0x1eu << mbits) | ((1u << mbits) - 1u);   // >= 65536 -> max finite
-    if (x < 0x38800000u)
-    {
-        // denormal in the target format: value / 2^-14 * 2^mbits
-        if (x < 0x33000000u) return 0;
-        uint32_t e = x >> 23;
-        uint32_t m = (x & 0x007fffffu) | 0x00800000u;
-        uint32_t sh = (uint32_t)shift + (113u - e);
-        if (sh > 24) return 0;
-        uint32_t r = m >> sh;
-        uint32_t rem = m & ((1u << sh) - 1u);
-        uint32_t half = 1u << (sh - 1u);
-        if (rem > half || (rem == half && (r & 1u))) r++;
-        return r;
-    }
-    uint32_t r = (x - 0x38000000u) >> shift;
-    uint32_t rem = x & ((1u << shift) - 1u);
-    uint32_t half = 1u << (shift - 1);
-    if (rem > half || (rem == half && (r & 1u))) r++;
-    uint32_t maxv = (0x1eu << mbits) | ((1u << mbits) - 1u);
-    return r > maxv ? maxv : r;
-}
-static inline uint32_t PackR11G11B10F(float3 c) { return PackUFloat(c.x, 6) | (PackUFloat(c.y, 6) << 11) | (PackUFloat(c.z, 5) << 22); }
-
 // GBuffers.hlsli:52-68
 static inline float EncodeMetallic(float metalness, bool isTransmissive, float3 emissive, float trDepth, float subsurface, float coat_weight)
 {
@@ -461,6 +430,44 @@ struct PathState
 
 static const int MIN_NUM_BOUNCES_RUSSIAN_ROULETTE = 3;
 
+//--------------------------------------------------------------------------------------
+// Sun / sky next-event estimation (scenes without emissive triangles, NEE_EMISSIVE == 0):
+// ReSTIR_Util::NEE_Sun<true> / NEE_Sky<true> (NEE.hlsli:86-152) chosen by RGI_Util::NEE (ReSTIR_GI_NEE.hlsli:194-226)
+// with P_SUN_VS_SKY 0.65 and SUN_DISK_SAMPLING 0 (PathTracer/Params.hlsli:8,24; ReSTIR_GI/Params.hlsli:8,28).
+//--------------------------------------------------------------------------------------
+struct SkyIncidentRadiance { const SkyLUT* lut; float3 operator()(float3 w) const { return Light::Le_Sky(w, *lut); } };
+
+static float3 NEE_Sun(const Scene& sc, const zr_frame_constants& g, float3 pos, float3 normal, BSDF::ShadingData surface)
+{
+    float3 wi = -f3(g.sun_dir);
+    surface.SetWi(wi, normal);
+    float3 bsdfxCosTheta = BSDF::Unified(surface).f;
+    if (dot(bsdfxCosTheta, bsdfxCosTheta) == 0) return f3(0.0f);
+    if (!RtRayQuery::Visibility_Ray(sc, pos, wi, normal, surface.Transmissive())) return f3(0.0f);
+    float3 le = Light::Le_Sun(pos, g);
+    return bsdfxCosTheta * le;
+}
+static float3 NEE_Sky(const Scene& sc, float3 pos, float3 normal, const BSDF::ShadingData& surface, RNG& rng)
+{
+    SkyIncidentRadiance leFunc; leFunc.lut = &sc.sky;
+    BSDF::BSDFSample bsdfSample = BSDF::SampleBSDF(normal, surface, leFunc, rng);
+    float3 ld = bsdfSample.bsdfOverPdf;
+    if (dot(ld, ld) > 0) ld = ld * (RtRayQuery::Visibility_Ray(sc, pos, bsdfSample.wi, normal, surface.Transmissive()) ? 1.0f : 0.0f);
+    return ld;
+}
+static float3 NEE_SunSky(const Scene& sc, const zr_frame_constants& g, float3 pos, float3 normal, const BSDF::ShadingData& surface, RNG& rngThread)
+{
+    const float P_SUN_VS_SKY = 0.65f;
+    float p_sun = rngThread.Uniform();
+    if (-g.sun_dir[1] > 0)
+    {
+        float q = (surface.Transmissive() ? 1.0f : (dot(-f3(g.sun_dir), normal) > 0 ? 1.0f : 0.0f)) * P_SUN_VS_SKY;
+        if (p_sun < q) return NEE_Sun(sc, g, pos, normal, surface) / q;
+        return NEE_Sky(sc, pos, normal, surface, rngThread) / (1 - q);
+    }
+    return f3(0.0f);
+}
+
 static void RenderPathTracer(const Scene& sc, const zr_frame_constants& g, GBView gb, const zr_params& prm, float* finalRGBA)
 {
     BSDF::g_rho = &sc.rhoLUT;
@@ -573,8 +580,11 @@ static void RenderPathTracer(const Scene& sc, const zr_frame_constants& g, GBVie
                 if (!RtRayQuery::GetMaterialData(sc, -P.bsdfSample.wi, P.eta_curr, P.rd.uv_grads, P.hitInfo, P.surface, P.eta_next))
                 { P.active = false; continue; }
                 // RGI_Util::NEE, NEE_EMISSIVE == 1, USE_MIS == 1, MIS_ALL_BOUNCES == 1
-                P.li += P.throughput * NEE_Emissive_MIS(sc, 1, false, hitPos, P.hitInfo.normal, P.surface, g.num_emissive_triangles, P.rngThread,
-                    prm.presampling != 0, P.sampleSetIdx);
+                if (g.num_emissive_triangles)
+                    P.li += P.throughput * NEE_Emissive_MIS(sc, 1, false, hitPos, P.hitInfo.normal, P.surface, g.num_emissive_triangles, P.rngThread,
+                        prm.presampling != 0, P.sampleSetIdx);
+                else    // NEE_EMISSIVE == 0
+                    P.li += P.throughput * NEE_SunSky(sc, g, hitPos, P.hitInfo.normal, P.surface, P.rngThread);
                 if (P.inTranslucentMedium && (P.surface.trDepth > 0))
                 {
                     float3 extCoeff = -log3(P.surface.baseColor_Fr0_TrCol) / P.surface.trDepth;
@@ -678,6 +688,28 @@ int zro_pathtrace_render(const zro_scene* h, const zr_frame_constants* cb, const
     h->s.counters = Counters();
     RenderPathTracer(h->s, *cb, GBView(planes), *prm, final_rgba);
     if (counters) { counters->n_closest = h->s.counters.n_closest; counters->n_shadow = h->s.counters.n_shadow; }
+    return 0;
+}
+
+// K17 SkyViewLUT.hlsl: w x h R11G11B10_FLOAT texels; bound to the scene (what Le_Sky samples)
+int zro_sky_lut(zro_scene* h, const zr_frame_constants* cb, uint32_t w, uint32_t ht, uint32_t* out)
+{
+    Scene& sc = h->s;
+    sc.skyData.resize((size_t)w * ht);
+    for (uint32_t y = 0; y < ht; y++) for (uint32_t x = 0; x < w; x++) sc.skyData[(size_t)y * w + x] = SkyViewLUT_Texel(*cb, x, y, w, ht);
+    sc.sky.data = sc.skyData.data(); sc.sky.w = w; sc.sky.h = ht;
+    if (out) std::memcpy(out, sc.skyData.data(), sc.skyData.size() * 4);
+    return 0;
+}
+// Le_Sky / Le_Sun probes for tests: n directions (or positions) -> n RGB triples
+int zro_le_sky(const zro_scene* h, const float* dirs, uint32_t n, float* out)
+{
+    for (uint32_t i = 0; i < n; i++) { float3 r = Light::Le_Sky(f3(dirs + 3 * i), h->s.sky); out[3 * i] = r.x; out[3 * i + 1] = r.y; out[3 * i + 2] = r.z; }
+    return 0;
+}
+int zro_le_sun(const zr_frame_constants* cb, const float* pos, uint32_t n, float* out)
+{
+    for (uint32_t i = 0; i < n; i++) { float3 r = Light::Le_Sun(f3(pos + 3 * i), *cb); out[3 * i] = r.x; out[3 * i + 1] = r.y; out[3 * i + 2] = r.z; }
     return 0;
 }
 

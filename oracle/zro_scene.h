@@ -8,6 +8,7 @@
 #include <vector>
 #include <algorithm>
 #include "zro_bsdf.h"
+#include "zro_sky.h"
 #include "../include/zr_intersect.h"
 
 namespace zro {
@@ -78,6 +79,8 @@ struct Scene
     std::vector<zr_alias_entry> alias;
     std::vector<zr_presampled_tri> sampleSets;   // K3 output (PresampleEmissives.hlsl), numSets x setSize
     uint32_t sampleSetSize = 0;
+    std::vector<uint32_t> skyData;               // K17 output (SkyViewLUT.hlsl), R11G11B10_FLOAT texels
+    SkyLUT sky;
     std::vector<uint16_t> rho;
     RhoLUT rhoLUT;
     std::vector<WorldTri> tris;          // global triangle order = instance order, then primitive order

@@ -25,7 +25,7 @@ struct HxScene
 {
     std::vector<zr_vertex> vertices; std::vector<uint32_t> indices; std::vector<zr_mesh_instance> instances;
     std::vector<zr_material> materials; std::vector<zr_emissive_triangle> emissives; std::vector<zr_alias_entry> alias;
-    std::vector<uint16_t> rho; BuiltBvh bvh; SceneView view; std::vector<zr_presampled_tri> sampleSets;
+    std::vector<uint16_t> rho; BuiltBvh bvh; SceneView view; std::vector<zr_presampled_tri> sampleSets; std::vector<uint32_t> skyLut;
 };
 
 struct HxQueue
@@ -93,6 +93,18 @@ void zhx_presample(HxScene* s, uint32_t frame_num, uint32_t num_sets, uint32_t s
     s->view.sampleSets = s->sampleSets.data(); s->view.sampleSetSize = set_size;
     if (out) std::memcpy(out, s->sampleSets.data(), (size_t)total * sizeof(zr_presampled_tri));
 }
+// K17 through the device stage function; binds the LUT to the scene like ZR_PASS_SKY does
+void zhx_sky_lut(HxScene* s, const zr_frame_constants* cb, uint32_t w, uint32_t h, uint32_t* out)
+{
+    s->skyLut.resize((size_t)w * h);
+    for (uint32_t y = 0; y < h; y++) for (uint32_t x = 0; x < w; x++) s->skyLut[(size_t)y * w + x] = SkyViewLutTexel(*cb, x, y, w, h);
+    s->view.sky.data = s->skyLut.data(); s->view.sky.w = w; s->view.sky.h = h;
+    if (out) std::memcpy(out, s->skyLut.data(), s->skyLut.size() * 4);
+}
+void zhx_le_sky(const HxScene* s, const float* dirs, uint32_t n, float* out)
+{ for (uint32_t i = 0; i < n; i++) { V3 r = Le_Sky(v3p(dirs + 3 * i), s->view.sky); out[3 * i] = r.x; out[3 * i + 1] = r.y; out[3 * i + 2] = r.z; } }
+void zhx_le_sun(const zr_frame_constants* cb, const float* pos, uint32_t n, float* out)
+{ for (uint32_t i = 0; i < n; i++) { V3 r = Le_Sun(v3p(pos + 3 * i), *cb); out[3 * i] = r.x; out[3 * i + 1] = r.y; out[3 * i + 2] = r.z; } }
 void zhx_estimate_power(const HxScene* s, float* out) { for (size_t i = 0; i < s->emissives.size(); i++) out[i] = EstimateTriPower(s->emissives[i]); }
 
 static uint32_t g_tile_x0 = 0, g_tile_y0 = 0;

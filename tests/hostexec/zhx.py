@@ -26,6 +26,9 @@ def lib():
         L.zhx_set_tile_origin.argtypes = [C.c_uint32, C.c_uint32]
         L.zhx_trace_any.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]
         L.zhx_presample.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p]
+        L.zhx_sky_lut.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]
+        L.zhx_le_sky.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]
+        L.zhx_le_sun.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]
         L.zhx_rpt_create.restype = C.c_void_p
         L.zhx_rpt_create.argtypes = [C.c_uint32, C.c_uint32]
         L.zhx_rpt_destroy.argtypes = [C.c_void_p]
@@ -79,6 +82,27 @@ class HostExecScene:
         from zetaray_amd import wire
         out = np.zeros(num_sets * set_size, wire.PRESAMPLED_TRI)
         lib().zhx_presample(self.h, frame_num, num_sets, set_size, out.ctypes.data)
+        return out
+
+    def sky_lut(self, cb, w=256, h=128):
+        """K17: generate and bind the sky-view LUT; returns the R11G11B10F texels (h, w) uint32"""
+        out = np.zeros((h, w), np.uint32)
+        cbb = np.ascontiguousarray(cb)
+        lib().zhx_sky_lut(self.h, cbb.ctypes.data, w, h, out.ctypes.data)
+        return out
+
+    def le_sky(self, dirs):
+        d = np.ascontiguousarray(dirs, np.float32).reshape(-1, 3)
+        out = np.zeros_like(d)
+        lib().zhx_le_sky(self.h, d.ctypes.data, len(d), out.ctypes.data)
+        return out
+
+    @staticmethod
+    def le_sun(cb, pos):
+        p = np.ascontiguousarray(pos, np.float32).reshape(-1, 3)
+        out = np.zeros_like(p)
+        cbb = np.ascontiguousarray(cb)
+        lib().zhx_le_sun(cbb.ctypes.data, p.ctypes.data, len(p), out.ctypes.data)
         return out
 
     def gbuffer(self, cb, tile=None):

@@ -392,3 +392,47 @@ def test_compositing(api, cornell_emissive, oracle_emissive):
     want = (d[..., :3] + ind[..., :3] * (~emissive)[..., None]) / np.float32(3)
     assert np.array_equal(out[..., :3].view(np.uint32), want.astype(np.float32).view(np.uint32))
     assert out[..., :3].max() > 0
+
+
+# ------------------------------------------------------------------ sun / sky (K17 + NEE_EMISSIVE == 0 path tracer)
+@pytest.fixture(scope="module")
+def cornell_sky():
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    return scene_io.load_npz(os.path.join(root, "tests", "golden", "cornell.npz"))
+
+
+def test_sky_view_lut_bit_exact(api, cornell_sky):
+    """K17 through ZR_PASS_SKY vs the oracle: every R11G11B10F texel of the 256 x 128 LUT, two sun positions."""
+    from oracle import zro
+    orc = zro.OracleScene(cornell_sky)
+    sc = api.Scene(cornell_sky)
+    p = api.Pass(api.PASS_SKY, 256, 128)
+    for sun in ((0.6565358, -0.0560669, 0.752208233), (0.2, -0.9, -0.3)):
+        cb = scene_io.make_frame_constants(64, 64)
+        sd = np.array(sun, np.float32)
+        cb["sun_dir"] = sd / np.float32(np.linalg.norm(sd))
+        p.render(cb, sc, None)
+        got = p.download_plane("sky_lut")[..., 0]
+        want = orc.sky_lut(cb, 256, 128)
+        assert np.array_equal(got, want), f"{int((got != want).sum())} LUT texels differ"
+
+
+@pytest.mark.parametrize("w,h,frame", [(64, 48, 1), (200, 120, 4)])
+def test_path_tracer_sun_sky_bit_exact(api, cornell_sky, w, h, frame):
+    """The reference's default Cornell box (no emissives): K17 + K1 + K9 with sun / sky NEE, radiance and counters bit-exact."""
+    from oracle import zro
+    orc = zro.OracleScene(cornell_sky)
+    cb = scene_io.make_frame_constants(w, h, frame_num=frame, num_emissives=0)
+    prm = wire.default_params()
+    r = api.Renderer(cornell_sky, w, h, params=prm)
+    r.render_frame(cb)
+    got = r.final()
+    n_closest, n_shadow = r.p_indirect.read_counters()
+    orc.sky_lut(cb, 256, 128)
+    _, planes = orc.gbuffer(cb)
+    want, cnt = orc.pathtrace(cb, planes, prm)
+    mism = int((got.view(np.uint32) != want.view(np.uint32)).sum())
+    assert mism == 0, f"{mism} radiance floats differ, max abs {np.abs(got - want).max()}"
+    assert (n_closest, n_shadow) == (cnt[0], cnt[1])
+    assert got[..., :3].sum() > 0

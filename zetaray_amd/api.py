@@ -15,11 +15,13 @@ from . import wire
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libzetaray_amd.so")
 
-PASS_GBUFFER, PASS_PRELIGHTING, PASS_DI_EMISSIVE, PASS_DI_SKY, PASS_INDIRECT, PASS_COMPOSITING = range(6)
+PASS_GBUFFER, PASS_PRELIGHTING, PASS_DI_EMISSIVE, PASS_DI_SKY, PASS_INDIRECT, PASS_COMPOSITING, PASS_SKY = range(7)
+OUT_SKY_LUT = 40
 IN_EMISSIVE_DI, IN_INDIRECT, IN_SKY_DI = range(3)
 INTEGRATOR_PATH_TRACING, INTEGRATOR_RESTIR_GI, INTEGRATOR_RESTIR_PT = range(3)
 OUT_FINAL = 0
 # ReSTIR PT persistent state (zr_output): name -> (id, dtype, channels)
+RPT_OUTPUTS_EXTRA = {"sky_lut": (40, np.uint32, 1)}
 RPT_OUTPUTS = {"A": (1, np.uint32, 1), "B": (2, np.float32, 2), "C": (3, np.uint32, 4), "D": (4, np.uint32, 4),
                "E": (5, np.uint16, 1), "F": (6, np.float32, 2), "G": (7, np.uint32, 2), "target": (8, np.float32, 4),
                "neighbor": (9, np.uint8, 2),
@@ -239,7 +241,7 @@ class Pass:
 
     def download_plane(self, name, stream=None):
         """ReSTIR PT reservoir / target / neighbour planes (see RPT_OUTPUTS)."""
-        which, dt, ch = RPT_OUTPUTS[name]
+        which, dt, ch = RPT_OUTPUTS[name] if name in RPT_OUTPUTS else RPT_OUTPUTS_EXTRA[name]
         out = np.zeros((self.h_, self.w, ch), dt)
         _check(lib().zr_pass_download_output(self.h, which, stream, out.ctypes.data, out.nbytes))
         return out
@@ -298,6 +300,8 @@ class Renderer:
         self.p_prelight = Pass(PASS_PRELIGHTING, width, height, device=device, params=params)
         self._presampling = bool(params is not None and params.presampling)
         self.p_indirect = Pass(PASS_INDIRECT, width, height, integrator, device=device, params=params)
+        # Sky pass (K17): scenes without emissive triangles light with sun + sky, which sample the sky-view LUT
+        self.p_sky = Pass(PASS_SKY, 256, 128, device=device) if len(scene_host.emissives) == 0 else None
         self.p_direct = None          # ReSTIR DI (emissive): enable_direct()
         self.p_composit = None        # Compositing: enable_compositing()
         self._alias_ready = False
@@ -316,6 +320,8 @@ class Renderer:
         return self.p_direct
 
     def render_frame(self, cb, stream=None):
+        if self.p_sky is not None:
+            self.p_sky.render(cb, self.scene, None, stream)
         self.p_gbuffer.render(cb, self.scene, self.gbuffer, stream)
         if not self._alias_ready or self._presampling:      # presampled light sets are regenerated every frame (K3)
             self.p_prelight.render(cb, self.scene, None, stream)

@@ -137,10 +137,13 @@ __global__ void __launch_bounds__(kBlock) k_trace_simple(SceneView sc, PathQueue
             if (type == 0) { rd = q.rayC_d[i]; ro = q.rayC_o[i]; }
             else if (type == 1) { rd = q.rayM_d[i]; ro = q.rayM_o[i]; }
             else { rd = q.rayS_d[i]; ro = q.rayS_o[i]; }
-            const RawHit h = Traverse<false>(sc, xyz(ro), xyz(rd), ro.w, rd.w, type == 2 ? ZR_SUBGROUP_NON_EMISSIVE : ZR_SUBGROUP_ALL, stack);
+            // S rays: segment to an emissive triangle (closest over NON_EMISSIVE) or sun / sky visibility (any hit over ALL)
+            const uint32_t lightID = type == 2 ? q.sLightID[i] : 0u;
+            const bool vis = type == 2 && lightID == kVisibilityRayID;
+            const RawHit h = TraverseDyn(sc, xyz(ro), xyz(rd), ro.w, rd.w, (type == 2 && !vis) ? ZR_SUBGROUP_NON_EMISSIVE : ZR_SUBGROUP_ALL, stack, vis);
             if (type == 0) q.hitC[i] = PackRawHit(h);
             else if (type == 1) q.hitM[i] = PackRawHit(h);
-            else q.visS[i] = SegmentVisible(sc, h, q.sLightID[i]);
+            else q.visS[i] = SegmentVisible(sc, h, lightID);
             closest = type != 2; shadow = type == 2;
         }
         CountWave(&counters[0], closest);
@@ -162,6 +165,7 @@ __global__ void __launch_bounds__(kBlock) k_trace(SceneView sc, PathQueue q, con
     const uint32_t lane = __lane_id();
     TravState st; TravLane L; L.triCur = 0; L.triEnd = 0; L.done = true;
     uint32_t slot = 0;                              // this lane's ray: list entry (slot | type << 30)
+    bool laneAnyHit = false;
     uint32_t nClosest = 0, nShadow = 0;
     uint32_t chunkPos = 0, chunkEnd = 0;            // wave-uniform
     bool exhausted = false;                         // wave-uniform: the global cursor ran past `total`
@@ -196,8 +200,12 @@ __global__ void __launch_bounds__(kBlock) k_trace(SceneView sc, PathQueue q, con
                 else if (type == 1) { rd = q.rayM_d[i]; ro = q.rayM_o[i]; }
                 else { rd = q.rayS_d[i]; ro = q.rayS_o[i]; }
                 L.done = false;
-                if (type == 2) { TravInit(sc, st, xyz(ro), xyz(rd), ro.w, rd.w, ZR_SUBGROUP_NON_EMISSIVE, false, 0); nShadow++; }
-                else { TravInit(sc, st, xyz(ro), xyz(rd), ro.w, rd.w, ZR_SUBGROUP_ALL, false, 0); nClosest++; }
+                if (type == 2)
+                {
+                    laneAnyHit = q.sLightID[i] == kVisibilityRayID;
+                    TravInit(sc, st, xyz(ro), xyz(rd), ro.w, rd.w, laneAnyHit ? ZR_SUBGROUP_ALL : ZR_SUBGROUP_NON_EMISSIVE, false, 0); nShadow++;
+                }
+                else { laneAnyHit = false; TravInit(sc, st, xyz(ro), xyz(rd), ro.w, rd.w, ZR_SUBGROUP_ALL, false, 0); nClosest++; }
                 TravEnter(sc, st, L, st.cur);
             }
             chunkPos = chunkPos + nIdle < chunkEnd ? chunkPos + nIdle : chunkEnd;
@@ -205,7 +213,7 @@ __global__ void __launch_bounds__(kBlock) k_trace(SceneView sc, PathQueue q, con
         }
         bool stepped = false;
         if (nNode >= nTri) { if (atNode) { TravNodePhase(sc, st, L, stack); stepped = true; } }
-        else if (atTri) { TravTriPhase(sc, st, L, stack, false); stepped = true; }
+        else if (atTri) { TravTriPhase(sc, st, L, stack, laneAnyHit); stepped = true; }
         if (stepped && L.done)
         {
             // shadow segments run to the closest hit: visible iff it is the light's own triangle (TraceSegmentRay)
@@ -264,6 +272,13 @@ __global__ void k_estimate_power(const zr_emissive_triangle* em, uint32_t n, flo
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) power[i] = EstimateTriPower(em[i]);
+}
+
+// K17 sky-view LUT: one thread per texel, 8 x 8 threads per group like the reference (ALU-bound: ~300 exp per texel)
+__global__ void __launch_bounds__(64) k_sky_lut(zr_frame_constants g, uint32_t w, uint32_t h, uint32_t* out)
+{
+    const uint32_t x = blockIdx.x * 8 + (threadIdx.x & 7), y = blockIdx.y * 8 + (threadIdx.x >> 3);
+    if (x < w && y < h) out[(size_t)y * w + x] = SkyViewLutTexel(g, x, y, w, h);
 }
 
 // generic ray-query kernels behind zr_trace_closest / zr_trace_any
@@ -544,6 +559,7 @@ struct zr_pass
     zr_params params{};
     // INDIRECT
     QueueStorage q[2];
+    DevBuf<uint32_t> skyLut;                       // ZR_PASS_SKY: R11G11B10F texels
     DevBuf<float> finalRGBA; DevBuf<F4> firstBOP; DevBuf<uint32_t> counts; DevBuf<unsigned long long> counters;
     DevBuf<uint32_t> groupMax;      // kMaxRounds x (8x8 groups of the tile): RR reduction keys
     zr_counters hostCounters{0, 0};
@@ -826,7 +842,7 @@ int zr_gbuffer_device_plane(const zr_gbuffer* g, int plane, void** dev)
 int zr_pass_create(int kind, int device, zr_pass** out)
 {
     if (!out) return Fail(ZR_ERR_INVALID_ARG, "null out");
-    if (kind < ZR_PASS_GBUFFER || kind > ZR_PASS_COMPOSITING) return Fail(ZR_ERR_INVALID_ARG, "unknown pass kind %d", kind);
+    if (kind < ZR_PASS_GBUFFER || kind > ZR_PASS_SKY) return Fail(ZR_ERR_INVALID_ARG, "unknown pass kind %d", kind);
     if (kind == ZR_PASS_DI_SKY) return Fail(ZR_ERR_UNSUPPORTED, "pass kind %d (sun / sky ReSTIR DI) is not implemented yet", kind);
     int r = RequireDevice(device);
     if (r) return r;
@@ -847,6 +863,7 @@ int zr_pass_create(int kind, int device, zr_pass** out)
 static int AllocPass(zr_pass* p)
 {
     int r;
+    if (p->kind == ZR_PASS_SKY) { if ((r = p->skyLut.Alloc((size_t)p->w * p->h))) return r; }
     if (p->kind == ZR_PASS_COMPOSITING)
     {
         const size_t cap = (size_t)p->w * p->h;
@@ -967,6 +984,17 @@ static int RenderGBuffer(zr_pass* p, hipStream_t s, const zr_frame_constants* cb
     TimerEnd(p, s);
     HIP_TRY(hipGetLastError());
     p->hostCounters.n_closest += (uint64_t)gb->w * gb->h;
+    return ZR_OK;
+}
+
+// Sky::Render (Sky.cpp:120-164): K17, then bind the LUT to the scene
+static int RenderSky(zr_pass* p, hipStream_t s, const zr_frame_constants* cb, zr_scene* sc)
+{
+    TimerBegin(p, s, "sky_view_lut");
+    hipLaunchKernelGGL(k_sky_lut, dim3((p->w + 7) / 8, (p->h + 7) / 8), dim3(64), 0, s, *cb, p->w, p->h, p->skyLut.p);
+    TimerEnd(p, s);
+    HIP_TRY(hipGetLastError());
+    sc->view.sky.data = p->skyLut.p; sc->view.sky.w = p->w; sc->view.sky.h = p->h;
     return ZR_OK;
 }
 
@@ -1168,8 +1196,13 @@ static int RenderIndirect(zr_pass* p, hipStream_t s, const zr_frame_constants* c
     if (!gb) return Fail(ZR_ERR_INVALID_ARG, "INDIRECT pass needs a gbuffer");
     if (gb->w != p->w || gb->h != p->h || gb->x0 + gb->w > cb->render_width || gb->y0 + gb->h > cb->render_height)
         return Fail(ZR_ERR_INVALID_ARG, "frame constants / gbuffer tile / pass size mismatch");
-    if (sc->view.numEmissives == 0) return Fail(ZR_ERR_UNSUPPORTED, "scenes without emissive triangles (sun/sky NEE) are not implemented yet");
-    if (!sc->view.alias) return Fail(ZR_ERR_NOT_INITIALIZED, "emissive alias table missing: render the PRELIGHTING pass (or zr_scene_set_alias_table) first");
+    if (sc->view.numEmissives == 0)
+    {
+        // NEE_EMISSIVE == 0 shader variants: sun + sky next-event estimation
+        if (p->integrator != ZR_INTEGRATOR_PATH_TRACING) return Fail(ZR_ERR_UNSUPPORTED, "sun/sky NEE (scenes without emissive triangles) is implemented for the path tracer only");
+        if (!sc->view.sky.data) return Fail(ZR_ERR_NOT_INITIALIZED, "sky-view LUT missing: render a ZR_PASS_SKY pass first");
+    }
+    else if (!sc->view.alias) return Fail(ZR_ERR_NOT_INITIALIZED, "emissive alias table missing: render the PRELIGHTING pass (or zr_scene_set_alias_table) first");
     if (cb->num_emissive_triangles != sc->view.numEmissives) return Fail(ZR_ERR_INVALID_ARG, "cbFrameConstants.NumEmissiveTriangles != scene");
     if (p->params.presampling && (!sc->view.sampleSets || sc->numSampleSets != p->params.num_sample_sets || sc->view.sampleSetSize != p->params.sample_set_size))
         return Fail(ZR_ERR_NOT_INITIALIZED, "presampled light sets missing or of another size: render the PRELIGHTING pass with the same presampling params first");
@@ -1304,6 +1337,7 @@ int zr_pass_render_stage(zr_pass* p, void* stream, const zr_frame_constants* cb,
     case ZR_PASS_INDIRECT: return RenderIndirect(p, s, cb, sc, gb, stages);
     case ZR_PASS_DI_EMISSIVE: return (stages & ZR_STAGE_TEMPORAL) ? RenderDirectEmissive(p, s, cb, sc, gb) : ZR_OK;
     case ZR_PASS_COMPOSITING: return (stages & ZR_STAGE_SPATIAL) ? RenderCompositing(p, s, cb, gb) : ZR_OK;
+    case ZR_PASS_SKY: return (stages & ZR_STAGE_TEMPORAL) ? RenderSky(p, s, cb, const_cast<zr_scene*>(sc)) : ZR_OK;
     default: return Fail(ZR_ERR_UNSUPPORTED, "pass kind %d not implemented", p->kind);
     }
 }
@@ -1312,6 +1346,15 @@ int zr_pass_get_output(const zr_pass* p, int which, void** dev, uint32_t* w, uin
 {
     if (!p || !dev) return Fail(ZR_ERR_INVALID_ARG, "null argument");
     if (!p->initialized) return Fail(ZR_ERR_NOT_INITIALIZED, "pass not initialised");
+    if (p->kind == ZR_PASS_SKY)
+    {
+        if (which != ZR_OUT_SKY_LUT) return Fail(ZR_ERR_INVALID_ARG, "pass has no such output");
+        *dev = p->skyLut.p;
+        if (w) *w = p->w;
+        if (h) *h = p->h;
+        if (bpp) *bpp = 4;
+        return ZR_OK;
+    }
     if (p->kind == ZR_PASS_COMPOSITING)
     {
         if (which != ZR_OUT_FINAL) return Fail(ZR_ERR_INVALID_ARG, "pass has no such output");

@@ -417,8 +417,12 @@ struct BsdfSample { V3 wi; uint32_t lobe; float pdf; V3 bsdfOverPdf; V3 f; };
 ZR_HD BsdfSample InitBsdfSample()
 { BsdfSample r; r.wi = v3(0.0f); r.lobe = LOBE_ALL; r.pdf = 0; r.bsdfOverPdf = v3(0.0f); r.f = v3(0.0f); return r; }
 
-// SampleBSDF_NoDiffuse (target functor = NoOp), BSDFSampling.hlsli:59-152
-ZR_HD BsdfSample SampleBSDF_NoDiffuse(const RhoView& rho, V3 n, Surface s, V2 u_c, V2 u_g, float u_wrs_0, float u_wrs_1)
+// target functor of the lobe RIS (BSDFSampling.hlsli:14-22 NoOp; NEE.hlsli:68-84 SkyIncidentRadiance is the other one)
+struct NoOpTarget { ZR_HDM V3 operator()(V3) const { return v3(1.0f); } };
+
+// SampleBSDF_NoDiffuse, BSDFSampling.hlsli:59-152
+template<typename Func>
+ZR_HD BsdfSample SampleBSDF_NoDiffuse(const RhoView& rho, V3 n, Surface s, V2 u_c, V2 u_g, float u_wrs_0, float u_wrs_1, Func func)
 {
     BsdfSample ret = InitBsdfSample();
     float pdf_base = 1;
@@ -432,7 +436,7 @@ ZR_HD BsdfSample SampleBSDF_NoDiffuse(const RhoView& rho, V3 n, Surface s, V2 u_
             V3 wi_c = SampleCoat(s, n, u_c);
             s.SetWi_Refl(wi_c, n);
             Eval e = Unified(rho, s);
-            ret.wi = wi_c; ret.lobe = LOBE_COAT; ret.f = e.f;
+            ret.wi = wi_c; ret.lobe = LOBE_COAT; ret.f = e.f * func(wi_c);
             ret.pdf = CoatPdf(s) * pdf_coat;
             ret.bsdfOverPdf = ret.f / ret.pdf;
             return ret;
@@ -446,13 +450,15 @@ ZR_HD BsdfSample SampleBSDF_NoDiffuse(const RhoView& rho, V3 n, Surface s, V2 u_
     ret.pdf = s.GlossSpecular() ? 1 : wh_pdf / 4.0f;
     ret.pdf *= pdf_base;
     Eval e = Unified(rho, s);
-    ret.f = e.f * v3(1.0f);
+    const V3 func_r = func(wi_r);
+    ret.f = e.f * func_r;
     ret.bsdfOverPdf = ret.f / ret.pdf;
     if (s.metallic || !s.specTr || e.tir) return ret;
 
     V3 wi_t = refract(-s.wo, wh, 1 / s.eta);
-    float p_r = e.Fr_g.x * Luminance(v3(1.0f));
-    p_r = p_r / (p_r + (1 - e.Fr_g.x) * Luminance(v3(1.0f)));
+    const V3 func_t = func(wi_t);
+    float p_r = e.Fr_g.x * Luminance(func_r);
+    p_r = p_r / (p_r + (1 - e.Fr_g.x) * Luminance(func_t));
     if (u_wrs_1 < p_r)
     {
         ret.bsdfOverPdf = ret.bsdfOverPdf / p_r;
@@ -467,16 +473,17 @@ ZR_HD BsdfSample SampleBSDF_NoDiffuse(const RhoView& rho, V3 n, Surface s, V2 u_
             ret.pdf *= wh_pdf * s.whdotwo;
             ret.pdf *= JacobianHalfVecToIncident_Tr(s.eta, s.whdotwo, s.whdotwi);
         }
-        ret.f = DielectricBaseSpecularTr(rho, s, e.Fr_g.x) * v3(1.0f);
+        ret.f = DielectricBaseSpecularTr(rho, s, e.Fr_g.x) * func_t;
         ret.bsdfOverPdf = ret.pdf > 0 ? ret.f / ret.pdf : v3(0.0f);
         ret.wi = wi_t; ret.lobe = LOBE_GLOSSY_T;
     }
     return ret;
 }
 
-// SampleBSDF_NoSpecTr (target functor = NoOp), BSDFSampling.hlsli:181-296
+// SampleBSDF_NoSpecTr, BSDFSampling.hlsli:181-296
+template<typename Func>
 ZR_HD BsdfSample SampleBSDF_NoSpecTr(const RhoView& rho, V3 n, Surface s, V2 u_coat, V2 u_g, V2 u_d, float u_wrs_g,
-    float u_wrs_dr, float u_wrs_dt)
+    float u_wrs_dr, float u_wrs_dt, Func func)
 {
     BsdfSample ret = InitBsdfSample();
     float w_sum = 0;
@@ -486,7 +493,7 @@ ZR_HD BsdfSample SampleBSDF_NoSpecTr(const RhoView& rho, V3 n, Surface s, V2 u_c
         V3 wi_c = SampleCoat(s, n, u_coat);
         s.SetWi_Refl(wi_c, n);
         Eval e = Unified(rho, s);
-        target = e.f * v3(1.0f);
+        target = e.f * func(wi_c);
         ret.wi = wi_c; ret.lobe = LOBE_COAT; ret.f = target;
         float pdf_c = CoatPdf(s), pdf_g = GlossPdf(s);
         float pdf_d = !s.metallic ? DiffusePdf(s) : 0;
@@ -496,7 +503,7 @@ ZR_HD BsdfSample SampleBSDF_NoSpecTr(const RhoView& rho, V3 n, Surface s, V2 u_c
         V3 wi_g = SampleGloss(s, n, u_g);
         s.SetWi_Refl(wi_g, n);
         Eval e = Unified(rho, s);
-        V3 target_g = e.f * v3(1.0f);
+        V3 target_g = e.f * func(wi_g);
         float pdf_g = GlossPdf(s);
         float pdf_d = !s.metallic && !e.tir ? DiffusePdf(s) : 0;
         float pdf_c = s.Coated() ? CoatPdf(s) : 0;
@@ -512,7 +519,7 @@ ZR_HD BsdfSample SampleBSDF_NoSpecTr(const RhoView& rho, V3 n, Surface s, V2 u_c
         {
             s.SetWi_Refl(wi_d, n);
             Eval e = Unified(rho, s);
-            V3 target_dr = e.f * v3(1.0f);
+            V3 target_dr = e.f * func(wi_d);
             Fr_g = e.Fr_g.x;
             float pdf_g = GlossPdf(s);
             float pdf_c = s.Coated() ? CoatPdf(s) : 0;
@@ -524,7 +531,7 @@ ZR_HD BsdfSample SampleBSDF_NoSpecTr(const RhoView& rho, V3 n, Surface s, V2 u_c
         {
             V3 wi_dt = -wi_d;
             V3 target_dt = DielectricBaseDiffuseTr(rho, s, Fr_g);
-            target_dt = target_dt * v3(1.0f);
+            target_dt = target_dt * func(wi_dt);
             float w_dt = Luminance(target_dt) / pdf_d;
             w_sum += w_dt;
             if ((w_sum > 0) && (u_wrs_dt < (w_dt / w_sum))) { target = target_dt; ret.wi = wi_dt; ret.lobe = LOBE_DIFFUSE_T; ret.f = target_dt; }
@@ -537,15 +544,19 @@ ZR_HD BsdfSample SampleBSDF_NoSpecTr(const RhoView& rho, V3 n, Surface s, V2 u_c
 }
 
 // SampleBSDF, BSDFSampling.hlsli:318-338: always consumes 9 uniforms so the RNG stream stays aligned for replay
-ZR_HD BsdfSample SampleBSDF(const RhoView& rho, V3 n, const Surface& s, Rng& rng)
+template<typename Func>
+ZR_HD BsdfSample SampleBSDF(const RhoView& rho, V3 n, const Surface& s, Func func, Rng& rng)
 {
     V2 u_c = rng.Uniform2D();
     V2 u_g = rng.Uniform2D();
     V2 u_d = rng.Uniform2D();
     float u0 = rng.Uniform(), u1 = rng.Uniform(), u2 = rng.Uniform();
-    if (!s.specTr) return SampleBSDF_NoSpecTr(rho, n, s, u_c, u_g, u_d, u0, u1, u2);
-    return SampleBSDF_NoDiffuse(rho, n, s, u_c, u_g, u0, u1);
+    if (!s.specTr) return SampleBSDF_NoSpecTr(rho, n, s, u_c, u_g, u_d, u0, u1, u2, func);
+    return SampleBSDF_NoDiffuse(rho, n, s, u_c, u_g, u0, u1, func);
 }
+ZR_HD BsdfSample SampleBSDF(const RhoView& rho, V3 n, const Surface& s, Rng& rng) { return SampleBSDF(rho, n, s, NoOpTarget(), rng); }
+ZR_HD BsdfSample SampleBSDF_NoDiffuse(const RhoView& rho, V3 n, const Surface& s, V2 u_c, V2 u_g, float u_wrs_0, float u_wrs_1)
+{ return SampleBSDF_NoDiffuse(rho, n, s, u_c, u_g, u_wrs_0, u_wrs_1, NoOpTarget()); }
 
 // BSDFSamplerPdf_NoDiffuse (NoOp target), BSDFSampling.hlsli:565-631
 ZR_HD float BSDFSamplerPdf_NoDiffuse(const RhoView& rho, V3 n, Surface s, V3 wi)

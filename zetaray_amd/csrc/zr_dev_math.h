@@ -86,6 +86,14 @@ ZR_HD float ArcCos(float x)          // Math.hlsli:103-113
     res *= zr_sqrt(1.0f - xAbs);
     return (x >= 0) ? res : ZR_PI - res;
 }
+ZR_HD V2 SphericalFromCartesian(V3 w)  // Math.hlsli:121-134: (theta, phi), phi clockwise from +x in [0, 2 pi)
+{
+    V2 thetaPhi;
+    thetaPhi.x = ArcCos(w.y);
+    thetaPhi.y = zr_atan2(-w.z, w.x);
+    thetaPhi.y = thetaPhi.y < 0 ? thetaPhi.y + ZR_TWO_PI : thetaPhi.y;
+    return thetaPhi;
+}
 ZR_HD float SignNotZero(float x) { return zr_asfloat(0x3f800000u | (0x80000000u & zr_asuint(x))); }  // :148-155
 ZR_HD V2 NDCFromUV(V2 uv) { V2 n = v2(uv.x * 2.0f - 1.0f, uv.y * 2.0f - 1.0f); n.y = -n.y; return n; } // :163-169
 ZR_HD V2 UVFromNDC(V2 ndc) { return v2(ndc.x * 0.5f + 0.5f, ndc.y * -0.5f + 0.5f); }                   // :171-174

@@ -14,6 +14,7 @@
 //   triMeta : 8 B per *global* triangle = {meshIdx, primIdx} (hit reconstruction)
 #pragma once
 #include "zr_dev_bsdf.h"
+#include "zr_sky.h"
 #include "../../include/zr_intersect.h"
 
 namespace zr {
@@ -47,6 +48,7 @@ struct SceneView
     const zr_alias_entry* alias;
     const zr_presampled_tri* sampleSets;   // K3 output: numSampleSets x sampleSetSize (null until a PRELIGHTING pass presampled)
     uint32_t sampleSetSize;
+    SkyLutView sky;                        // K17 output (null until a SKY pass rendered)
     const Bvh4Node* nodes;
     const BvhTri* tris;
     const TriMeta* triMeta;
@@ -237,8 +239,8 @@ ZR_HD void TravTriPhase(const SceneView& sc, TravState& s, TravLane& L, const Tr
     else if (L.triCur == L.triEnd) TravPopEnter(sc, s, L, stack);
 }
 
-template<bool AnyHit>
-ZR_HD RawHit Traverse(const SceneView& sc, V3 o, V3 d, float tmin, float tmax, uint32_t mask, const TravStack& stack, bool filterID = false, uint32_t ignoreID = 0)
+ZR_HD RawHit TraverseDyn(const SceneView& sc, V3 o, V3 d, float tmin, float tmax, uint32_t mask, const TravStack& stack, bool anyHit,
+    bool filterID = false, uint32_t ignoreID = 0)
 {
     TravState s;
     TravInit(sc, s, o, d, tmin, tmax, mask, filterID, ignoreID);
@@ -252,13 +254,16 @@ ZR_HD RawHit Traverse(const SceneView& sc, V3 o, V3 d, float tmin, float tmax, u
         const uint64_t mNode = __ballot(atNode), mTri = __ballot(atTri);
         if ((mNode | mTri) == 0) break;
         if (__popcll(mNode) >= __popcll(mTri)) { if (atNode) TravNodePhase(sc, s, L, stack); }
-        else { if (atTri) TravTriPhase(sc, s, L, stack, AnyHit); }
+        else { if (atTri) TravTriPhase(sc, s, L, stack, anyHit); }
     }
 #else
-    while (!TravStep(sc, s, stack, AnyHit)) {}
+    while (!TravStep(sc, s, stack, anyHit)) {}
 #endif
     return s.best;
 }
+template<bool AnyHit>
+ZR_HD RawHit Traverse(const SceneView& sc, V3 o, V3 d, float tmin, float tmax, uint32_t mask, const TravStack& stack, bool filterID = false, uint32_t ignoreID = 0)
+{ return TraverseDyn(sc, o, d, tmin, tmax, mask, stack, AnyHit, filterID, ignoreID); }
 
 // ---- Material.h accessors ----
 ZR_HD bool MatDoubleSided(const zr_material& m) { return m.coat_color_flags & (1u << ZR_MAT_DOUBLE_SIDED_BIT); }

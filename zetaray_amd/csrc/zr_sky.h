@@ -1,0 +1,152 @@
+// zr_sky.h -- the sky model on the device: atmosphere integrals, the sky-view LUT texel (K17) and the radiance lookups.
+//
+// Restates (device code; the CPU restatement used by the tests is oracle/zro_sky.h):
+//   Source/ZetaRenderPass/Common/Volumetric.hlsli:34-229   phase functions, densities, EstimateTransmittance, EstimateLs
+//   Source/ZetaRenderPass/Sky/SkyViewLUT.hlsl:19-63        K17: one thread per LUT texel, non-linear latitude, R11G11B10_FLOAT store
+//   Source/ZetaRenderPass/Common/LightSource.hlsli:139-199 Le_Sun (6-step transmittance), Le_Sky (LUT lookup), Le_SkyWithSunDisk
+// Pinned where D3D leaves it open (include/zetaray_amd.h, ZR_PASS_SKY): the store rounds to R11G11B10_FLOAT to nearest even;
+// g_samLinearWrap = fp32 bilinear, texel centres at (i + 0.5) / N, wrap addressing on both axes.
+// K17 is ALU-bound by construction: 32 x (8 + 1) exp3 evaluations per texel, 4 bytes written.
+#pragma once
+#include "zr_dev_math.h"
+#include "../../include/zr_wire.h"
+
+namespace zr {
+
+ZR_HD float RayleighPhaseFunction(float cosTheta) { return 0.0596831f * (1.0f + cosTheta * cosTheta); }
+ZR_HD float SchlickPhaseFunction(float cosTheta, float g)
+{
+    float k = 1.55f * g - 0.55f * g * g * g;
+    float denom = 1.0f - k * cosTheta;
+    return ZR_ONE_OVER_4_PI * (1.0f - k * k) / (denom * denom);
+}
+// altitude in km: (Rayleigh, Mie, ozone) densities, Volumetric.hlsli:66-88
+ZR_HD V3 AtmosphereDensity(float altitude)
+{
+    return v3(zr_exp(-zr_max(0.0f, altitude / 8.0f)), zr_exp(-zr_max(0.0f, altitude / 1.2f)),
+        zr_max(0.0f, 1 - zr_abs(altitude - 25.0f) / 15.0f));
+}
+ZR_HD float IntersectRayAtmosphere(float radius, V3 rayOrigin, V3 rayDir)     // :101-112
+{
+    float mDotdir = dot(rayDir, rayOrigin);
+    float delta = mDotdir * mDotdir - dot(rayOrigin, rayOrigin) + radius * radius;
+    delta = zr_sqrt(delta);
+    return -mDotdir + delta;
+}
+ZR_HD bool IntersectRayPlanet(float radius, V3 rayOrigin, V3 rayDir, float& t) // :114-132
+{
+    float mDotdir = dot(rayDir, rayOrigin);
+    float delta = mDotdir * mDotdir - dot(rayOrigin, rayOrigin) + radius * radius;
+    if (delta < 0.0f) { t = 0; return false; }
+    delta = zr_sqrt(delta);
+    t = zr_min(-mDotdir - delta, -mDotdir + delta);
+    return t >= 0.0f;
+}
+ZR_HD V3 EstimateTransmittance(float planetRadius, V3 rayOrigin, V3 rayDir, float t, V3 sigma_t_rayleigh, float sigma_t_mie,
+    V3 sigma_t_ozone, int numSteps)                                           // :137-170
+{
+    if (t <= 1e-5f) return v3(1.0f);
+    const float stepSize = t / (float)numSteps;
+    V3 pos = rayOrigin + 0.5f * stepSize * rayDir;
+    V3 opticalThickness = v3(0.0f);
+    for (int s = 0; s < numSteps; s++)
+    {
+        opticalThickness = opticalThickness + AtmosphereDensity(length(pos) - planetRadius);
+        pos = pos + stepSize * rayDir;
+    }
+    opticalThickness = sigma_t_rayleigh * opticalThickness.x + v3(sigma_t_mie * opticalThickness.y) + sigma_t_ozone * opticalThickness.z;
+    opticalThickness = opticalThickness * stepSize;
+    return vexp(-opticalThickness);
+}
+ZR_HD V3 EstimateLs(float planetRadius, V3 rayOrigin, V3 rayDir, V3 lightDir, float atmosphereHeight, float g,
+    V3 sigma_s_rayleigh, float sigma_s_mie, float sigma_t_mie, V3 sigma_t_ozone, int numSteps)   // :173-229
+{
+    float t = IntersectRayAtmosphere(planetRadius + atmosphereHeight, rayOrigin, rayDir);
+    float tPlanet;
+    if (IntersectRayPlanet(planetRadius, rayOrigin, rayDir, tPlanet)) t = tPlanet;
+    const float stepSize = t / (float)numSteps;
+    V3 pos = rayOrigin + 0.5f * stepSize * rayDir;
+    V3 opticalThickness = v3(0.0f), LsRayleigh = v3(0.0f), LsMie = v3(0.0f);
+    for (int s = 0; s < numSteps; s++)
+    {
+        V3 density = AtmosphereDensity(length(pos) - planetRadius);
+        opticalThickness = opticalThickness + density * stepSize;
+        V3 rayOriginToPosTr = vexp(-(sigma_s_rayleigh * opticalThickness.x + v3(sigma_t_mie * opticalThickness.y) + sigma_t_ozone * opticalThickness.z));
+        const float posToAtmosphereDist = IntersectRayAtmosphere(planetRadius + atmosphereHeight, pos, -lightDir);
+        V3 LoTranmittance = EstimateTransmittance(planetRadius, pos, -lightDir, posToAtmosphereDist, sigma_s_rayleigh, sigma_t_mie, sigma_t_ozone, 8);
+        LsRayleigh = LsRayleigh + rayOriginToPosTr * density.x * LoTranmittance;
+        LsMie = LsMie + rayOriginToPosTr * density.y * LoTranmittance;
+        pos = pos + stepSize * rayDir;
+    }
+    const float cosTheta = dot(lightDir, -rayDir);
+    V3 Ls = LsRayleigh * sigma_s_rayleigh * RayleighPhaseFunction(cosTheta);
+    Ls = Ls + LsMie * sigma_s_mie * SchlickPhaseFunction(cosTheta, g);
+    Ls = Ls * stepSize;
+    return Ls;
+}
+
+// K17: texel (x, y) of a w x h sky-view LUT, SkyViewLUT.hlsl:19-63
+ZR_HD uint32_t SkyViewLutTexel(const zr_frame_constants& g, uint32_t x, uint32_t y, uint32_t w, uint32_t h)
+{
+    float phi = ((float)x / (float)w);
+    phi *= ZR_TWO_PI;
+    float v = ((float)y / (float)h);
+    float s = v >= 0.5f ? 1.0f : -1.0f;
+    float a = v - 0.5f;
+    float theta = a * a * ZR_TWO_PI * s + ZR_PI_OVER_2;
+    float sinTheta = zr_sin(theta);
+    V3 wdir = v3(1.0f * sinTheta * zr_cos(phi), 1.0f * zr_cos(theta), -1.0f * sinTheta * zr_sin(phi));   // Math::SphericalToCartesian
+    const V3 sigma_s_rayleigh = v3p(g.rayleigh_sigma_s_color) * g.rayleigh_sigma_s_scale;
+    const float sigma_t_mie = g.mie_sigma_a + g.mie_sigma_s;
+    const V3 sigma_t_ozone = v3p(g.ozone_sigma_a_color) * g.ozone_sigma_a_scale;
+    V3 rayOrigin = v3(0.0f, g.planet_radius + 0.2f, 0.0f);
+    V3 Ls = EstimateLs(g.planet_radius, rayOrigin, wdir, v3p(g.sun_dir), g.atmosphere_altitude, g.g, sigma_s_rayleigh,
+        g.mie_sigma_s, sigma_t_mie, sigma_t_ozone, 32);
+    Ls = Ls * g.sun_illuminance;
+    return PackR11G11B10F(v3(zr_max(Ls.x, 0.0f), zr_max(Ls.y, 0.0f), zr_max(Ls.z, 0.0f)));
+}
+
+struct SkyLutView { const uint32_t* data; uint32_t w, h; };
+
+ZR_HD V3 Le_Sun(V3 pos, const zr_frame_constants& g)        // LightSource.hlsli:139-157
+{
+    const V3 sigma_t_rayleigh = v3p(g.rayleigh_sigma_s_color) * g.rayleigh_sigma_s_scale;
+    const float sigma_t_mie = g.mie_sigma_a + g.mie_sigma_s;
+    const V3 sigma_t_ozone = v3p(g.ozone_sigma_a_color) * g.ozone_sigma_a_scale;
+    V3 temp = pos;
+    temp.y += g.planet_radius;
+    const float t = IntersectRayAtmosphere(g.planet_radius + g.atmosphere_altitude, temp, -v3p(g.sun_dir));
+    const V3 tr = EstimateTransmittance(g.planet_radius, temp, -v3p(g.sun_dir), t, sigma_t_rayleigh, sigma_t_mie, sigma_t_ozone, 6);
+    return tr * g.sun_illuminance;
+}
+ZR_HD V3 SkyTexel(const SkyLutView& lut, int x, int y)
+{
+    const uint32_t v = lut.data[(size_t)y * lut.w + x];
+    return v3(zr_unpack_ufloat(v & 0x7ff, 6), zr_unpack_ufloat((v >> 11) & 0x7ff, 6), zr_unpack_ufloat(v >> 22, 5));
+}
+ZR_HD int WrapIndex(int i, int n) { int m = i % n; return m < 0 ? m + n : m; }
+ZR_HD V3 SampleSkyLut(const SkyLutView& lut, V2 uv)
+{
+    const float x = uv.x * (float)lut.w - 0.5f, y = uv.y * (float)lut.h - 0.5f;
+    const float fx = zr_floor(x), fy = zr_floor(y);
+    const float tx = x - fx, ty = y - fy;
+    const int x0 = WrapIndex((int)fx, (int)lut.w), x1 = WrapIndex((int)fx + 1, (int)lut.w);
+    const int y0 = WrapIndex((int)fy, (int)lut.h), y1 = WrapIndex((int)fy + 1, (int)lut.h);
+    const V3 a = SkyTexel(lut, x0, y0), b = SkyTexel(lut, x1, y0), c = SkyTexel(lut, x0, y1), d = SkyTexel(lut, x1, y1);
+    const V3 r0 = v3(zr_lerp(a.x, b.x, tx), zr_lerp(a.y, b.y, tx), zr_lerp(a.z, b.z, tx));
+    const V3 r1 = v3(zr_lerp(c.x, d.x, tx), zr_lerp(c.y, d.y, tx), zr_lerp(c.z, d.z, tx));
+    return v3(zr_lerp(r0.x, r1.x, ty), zr_lerp(r0.y, r1.y, ty), zr_lerp(r0.z, r1.z, ty));
+}
+ZR_HD V3 Le_Sky(V3 wi, const SkyLutView& lut)                // LightSource.hlsli:159-174
+{
+    const V2 thetaPhi = SphericalFromCartesian(wi);
+    V2 uv = v2(thetaPhi.y * ZR_ONE_OVER_2_PI, thetaPhi.x * ZR_ONE_OVER_PI);
+    const float sn = thetaPhi.x >= ZR_PI_OVER_2 ? 1.0f : -1.0f;
+    uv.y = zr_fma(0.5f, thetaPhi.x, -ZR_PI_OVER_4);
+    uv.y = 0.5f + sn * zr_sqrt(zr_abs(uv.y) * ZR_ONE_OVER_PI);
+    return SampleSkyLut(lut, uv);
+}
+// the target functor NEE_Sky hands to the lobe RIS (NEE.hlsli:68-84)
+struct SkyIncidentRadiance { SkyLutView lut; ZR_HDM V3 operator()(V3 w) const { return Le_Sky(w, lut); } };
+
+} // namespace zr

@@ -288,6 +288,22 @@ ZR_HD int MakeSegmentRay(V3 origin, V3 wi, float rayT, V3 normal, uint32_t triID
     return 1;
 }
 
+// Visibility_Ray (RayQuery.hlsli:302-334): any hit over ALL geometry to infinity.  Returns 0 = early-out "occluded",
+// 1 = ray emitted.  The trace stage recognises it by sLightID == kVisibilityRayID.
+static constexpr uint32_t kVisibilityRayID = 0xffffffffu;     // never a segment target: Visibility_Segment rejects it
+ZR_HD int MakeVisibilityRay(V3 origin, V3 wi, V3 normal, bool transmissive, F4* ro, F4* rd)
+{
+    if (dot(normal, wi) <= 0)
+    {
+        if (transmissive) normal = normal * -1.0f;
+        else return 0;
+    }
+    V3 o = OffsetRayRTG(origin, normal);
+    *ro = f4(o, Lerp(0.0f, 8e-5f, dot(normal, wi)));
+    *rd = f4(wi, ZR_FLT_MAX);
+    return 1;
+}
+
 ZR_HD void WriteFinal(float* finalRGBA, uint32_t pid, V3 li, V3 firstBOP, bool accumulate)
 {
     if (dot(li, li) > 0) li = li * firstBOP;
@@ -508,72 +524,113 @@ ZR_HD void PtShadePath(const SceneView& sc, const zr_frame_constants& g, const P
     out.sLightID = 0xffffffffu;
     uint32_t nflags = PF_PENDING;
 
-    // NEE_Emissive_MIS<1, false> (ReSTIR_GI_NEE.hlsli:8-118), everything that does not need a trace result
     const V3 n = hit.normal;
-    const bool specular = surface.GlossSpecular() && (surface.metallic || surface.specTr) && (!surface.Coated() || surface.CoatSpecular());
-    const int numLightSamples = specular ? 0 : 1;
-    if (numLightSamples) nflags |= PF_NLS;
-    {
-        BsdfSample bs = SampleBSDF(sc.rho, n, surface, rngT);
-        out.s6 = f4(bs.f, 0.0f);
-        out.s7 = f4(bs.wi, 0.0f);
-        float misPdf = bs.pdf;
-        F4 ro, rd;
-        if (MakeClosestRay(hitPos, n, bs.wi, surface.Transmissive(), true, &ro, &rd)) { out.rayM_o = ro; out.rayM_d = rd; }
-        out.s2.w = misPdf;
-    }
     V3 ldLight = v3(0.0f);
-    for (int s_l = 0; s_l < numLightSamples; s_l++)
+    if (g.num_emissive_triangles)
     {
-        V3 lpos, ln, le; float lightPdf; uint32_t lightID;
-        if (prm.numSampleSets)      // USE_PRESAMPLED_SETS (ReSTIR_GI_NEE.hlsli:68-85)
+        // NEE_Emissive_MIS<1, false> (ReSTIR_GI_NEE.hlsli:8-118), everything that does not need a trace result
+        const bool specular = surface.GlossSpecular() && (surface.metallic || surface.specTr) && (!surface.Coated() || surface.CoatSpecular());
+        const int numLightSamples = specular ? 0 : 1;
+        if (numLightSamples) nflags |= PF_NLS;
         {
-            PresampledLight pl = SamplePresampledSet(sc, zr_asuint(setIdxBits), hitPos, rngT);
-            lpos = pl.pos; ln = pl.normal; le = pl.le; lightPdf = pl.pdf; lightID = pl.ID;
+            BsdfSample bs = SampleBSDF(sc.rho, n, surface, rngT);
+            out.s6 = f4(bs.f, 0.0f);
+            out.s7 = f4(bs.wi, 0.0f);
+            float misPdf = bs.pdf;
+            F4 ro, rd;
+            if (MakeClosestRay(hitPos, n, bs.wi, surface.Transmissive(), true, &ro, &rd)) { out.rayM_o = ro; out.rayM_d = rd; }
+            out.s2.w = misPdf;
         }
-        else
+        for (int s_l = 0; s_l < numLightSamples; s_l++)
         {
-            // Light::AliasTableSample::get, LightSource.hlsli:72-98
-            uint32_t u0 = rngT.UniformUintBounded(g.num_emissive_triangles);
-            const zr_alias_entry ae = sc.alias[u0];
-            uint32_t lidx; float lpdfSrc;
-            if (rngT.Uniform() < ae.p_curr) { lpdfSrc = ae.cached_p_orig; lidx = u0; }
-            else { lpdfSrc = ae.cached_p_alias; lidx = ae.alias; }
-            const zr_emissive_triangle em = sc.emissives[lidx];
-            // Light::EmissiveTriSample::get, LightSource.hlsli:109-137
-            V2 u = rngT.Uniform2D();
-            V2 bary = UniformSampleTriangle(u);
-            const V3 vtx0 = v3p(em.vtx0), vtx1 = EmV1(em), vtx2 = EmV2(em);
-            lpos = (1.0f - bary.x - bary.y) * vtx0 + bary.x * vtx1 + bary.y * vtx2;
-            ln = cross(vtx1 - vtx0, vtx2 - vtx0);
-            bool normalIs0 = dot(ln, ln) == 0;
-            float twoArea = length(ln);
-            float lpdfPos = normalIs0 ? 0.0f : 2.0f / twoArea;
-            ln = normalIs0 ? ln : ln / twoArea;
-            ln = EmDoubleSided(em) && dot(hitPos - lpos, ln) < 0 ? -ln : ln;
-            le = EmLe(em);
-            lightPdf = lpdfSrc * lpdfPos;
-            lightID = em.id;
+            V3 lpos, ln, le; float lightPdf; uint32_t lightID;
+            if (prm.numSampleSets)      // USE_PRESAMPLED_SETS (ReSTIR_GI_NEE.hlsli:68-85)
+            {
+                PresampledLight pl = SamplePresampledSet(sc, zr_asuint(setIdxBits), hitPos, rngT);
+                lpos = pl.pos; ln = pl.normal; le = pl.le; lightPdf = pl.pdf; lightID = pl.ID;
+            }
+            else
+            {
+                // Light::AliasTableSample::get, LightSource.hlsli:72-98
+                uint32_t u0 = rngT.UniformUintBounded(g.num_emissive_triangles);
+                const zr_alias_entry ae = sc.alias[u0];
+                uint32_t lidx; float lpdfSrc;
+                if (rngT.Uniform() < ae.p_curr) { lpdfSrc = ae.cached_p_orig; lidx = u0; }
+                else { lpdfSrc = ae.cached_p_alias; lidx = ae.alias; }
+                const zr_emissive_triangle em = sc.emissives[lidx];
+                // Light::EmissiveTriSample::get, LightSource.hlsli:109-137
+                V2 u = rngT.Uniform2D();
+                V2 bary = UniformSampleTriangle(u);
+                const V3 vtx0 = v3p(em.vtx0), vtx1 = EmV1(em), vtx2 = EmV2(em);
+                lpos = (1.0f - bary.x - bary.y) * vtx0 + bary.x * vtx1 + bary.y * vtx2;
+                ln = cross(vtx1 - vtx0, vtx2 - vtx0);
+                bool normalIs0 = dot(ln, ln) == 0;
+                float twoArea = length(ln);
+                float lpdfPos = normalIs0 ? 0.0f : 2.0f / twoArea;
+                ln = normalIs0 ? ln : ln / twoArea;
+                ln = EmDoubleSided(em) && dot(hitPos - lpos, ln) < 0 ? -ln : ln;
+                le = EmLe(em);
+                lightPdf = lpdfSrc * lpdfPos;
+                lightID = em.id;
+            }
+            const float tl = length(lpos - hitPos);
+            const V3 wi = (lpos - hitPos) / tl;
+            if (dot(ln, -wi) > 0)
+            {
+                const float dwdA = zr_saturate(dot(ln, -wi)) / (tl * tl);
+                surface.SetWi(wi, n);
+                le = le * (Unified(sc.rho, surface).f * dwdA);
+                bool occludedEarly = false;
+                if (dot(le, le) > 0)
+                {
+                    F4 ro, rd;
+                    if (MakeSegmentRay(hitPos, wi, tl, n, lightID, surface.Transmissive(), &ro, &rd))
+                    { out.rayS_o = ro; out.rayS_d = rd; out.sLightID = lightID; nflags |= PF_S_RAY; }
+                    else occludedEarly = true;
+                }
+                float bsdfPdf = BSDFSamplerPdf(sc.rho, n, surface, wi, rngT);
+                bsdfPdf *= dwdA;
+                if (occludedEarly) le = le * 0.0f;
+                ldLight = ldLight + PowerHeuristic(lightPdf, bsdfPdf, le, (float)numLightSamples, 1.0f);
+            }
         }
-        const float tl = length(lpos - hitPos);
-        const V3 wi = (lpos - hitPos) / tl;
-        if (dot(ln, -wi) > 0)
+    }
+    else
+    {
+        // RGI_Util::NEE with NEE_EMISSIVE == 0 (ReSTIR_GI_NEE.hlsli:194-226): sun with probability q, else the sky through
+        // BSDF sampling with Le_Sky as the RIS target (NEE.hlsli:86-152); one visibility ray, resolved by the next step
+        out.s6 = f4(v3(0.0f), 0.0f); out.s7 = out.s6; out.s2.w = 0;
+        const float p_sun = rngT.Uniform();
+        const V3 sunDir = v3p(g.sun_dir);
+        if (-sunDir.y > 0)
         {
-            const float dwdA = zr_saturate(dot(ln, -wi)) / (tl * tl);
-            surface.SetWi(wi, n);
-            le = le * (Unified(sc.rho, surface).f * dwdA);
-            bool occludedEarly = false;
-            if (dot(le, le) > 0)
+            const float q = (surface.Transmissive() ? 1.0f : (dot(-sunDir, n) > 0 ? 1.0f : 0.0f)) * 0.65f;   // P_SUN_VS_SKY
+            V3 wi = -sunDir; bool wantRay; float invSel;
+            if (p_sun < q)
+            {
+                Surface ss = surface;
+                ss.SetWi(wi, n);
+                const V3 f = Unified(sc.rho, ss).f;
+                wantRay = !(dot(f, f) == 0);
+                ldLight = wantRay ? f * Le_Sun(hitPos, g) : v3(0.0f);
+                invSel = q;
+            }
+            else
+            {
+                SkyIncidentRadiance leFunc; leFunc.lut = sc.sky;
+                const BsdfSample bs = SampleBSDF(sc.rho, n, surface, leFunc, rngT);
+                ldLight = bs.bsdfOverPdf; wi = bs.wi;
+                wantRay = dot(ldLight, ldLight) > 0;
+                invSel = 1 - q;
+            }
+            if (wantRay)
             {
                 F4 ro, rd;
-                if (MakeSegmentRay(hitPos, wi, tl, n, lightID, surface.Transmissive(), &ro, &rd))
-                { out.rayS_o = ro; out.rayS_d = rd; out.sLightID = lightID; nflags |= PF_S_RAY; }
-                else occludedEarly = true;
+                if (MakeVisibilityRay(hitPos, wi, n, surface.Transmissive(), &ro, &rd))
+                { out.rayS_o = ro; out.rayS_d = rd; out.sLightID = kVisibilityRayID; nflags |= PF_S_RAY; }
+                else ldLight = ldLight * 0.0f;
             }
-            float bsdfPdf = BSDFSamplerPdf(sc.rho, n, surface, wi, rngT);
-            bsdfPdf *= dwdA;
-            if (occludedEarly) le = le * 0.0f;
-            ldLight = ldLight + PowerHeuristic(lightPdf, bsdfPdf, le, (float)numLightSamples, 1.0f);
+            ldLight = ldLight / invSel;
         }
     }
     out.s8 = f4(ldLight, 0.0f);
@@ -665,16 +722,21 @@ ZR_HD U4 PackRawHit(const RawHit& h)
 { U4 r; r.x = zr_asuint(h.tri == kInvalidTri ? 0.0f : h.t); r.y = zr_asuint(h.u); r.z = zr_asuint(h.v); r.w = h.tri; return r; }
 ZR_HD U4 TraceClosestRay(const SceneView& sc, F4 ro, F4 rd, uint32_t mask, TravStack stack)
 { return PackRawHit(Traverse<false>(sc, xyz(ro), xyz(rd), ro.w, rd.w, mask, stack)); }
-// Visibility_Segment tail (RayQuery.hlsli:392-405): closest hit over NON_EMISSIVE geometry, visible iff no hit or the
-// hit's hashed ID equals the light's
+// S rays.  Segment to an emissive triangle, Visibility_Segment tail (RayQuery.hlsli:392-405): closest hit over NON_EMISSIVE
+// geometry, visible iff no hit or the hit's hashed ID equals the light's.  Sun / sky, Visibility_Ray (RayQuery.hlsli:317-333,
+// lightID == kVisibilityRayID): any hit over ALL geometry, visible iff none.
 ZR_HD uint32_t SegmentVisible(const SceneView& sc, const RawHit& h, uint32_t lightID)
 {
     if (h.tri == kInvalidTri) return 1u;
+    if (lightID == kVisibilityRayID) return 0u;
     const TriMeta tm = sc.triMeta[h.tri];
     return TriID(tm.mesh, tm.prim) == lightID ? 1u : 0u;
 }
 ZR_HD uint32_t TraceSegmentRay(const SceneView& sc, F4 ro, F4 rd, uint32_t lightID, TravStack stack)
-{ return SegmentVisible(sc, Traverse<false>(sc, xyz(ro), xyz(rd), ro.w, rd.w, ZR_SUBGROUP_NON_EMISSIVE, stack), lightID); }
+{
+    const bool vis = lightID == kVisibilityRayID;
+    return SegmentVisible(sc, TraverseDyn(sc, xyz(ro), xyz(rd), ro.w, rd.w, vis ? ZR_SUBGROUP_ALL : ZR_SUBGROUP_NON_EMISSIVE, stack, vis), lightID);
+}
 
 // K3: PresampleEmissives.hlsl:20-44 -- sample i of numSets * setSize
 ZR_HD zr_presampled_tri PresampleEmissive(const SceneView& sc, uint32_t i, uint32_t frameNum, uint32_t numEmissives)

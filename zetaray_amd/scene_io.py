@@ -445,6 +445,16 @@ def make_frame_constants(width, height, frame_num=1, cam_pos=(0.0, 1.2, -4.043),
     cb["sun_illuminance"] = 20.0
     cb["atmosphere_altitude"] = 100.0
     cb["g"] = 0.8
+    # atmosphere coefficients in 1/km, stored as unit colour + scale (DefaultRendererImpl.h:29-32, DefaultRenderer.cpp:289-306)
+    def _normalize_and_store(v, ckey, skey):
+        v = np.asarray(v, np.float32) * np.float32(1e-3)
+        scale = np.float32(np.sqrt(np.float32(v[0] * v[0] + v[1] * v[1] + v[2] * v[2])))
+        cb[skey] = scale
+        cb[ckey] = v * (np.float32(1.0) / scale)
+    _normalize_and_store((5.802, 13.558, 33.1), "rayleigh_sigma_s_color", "rayleigh_sigma_s_scale")
+    _normalize_and_store((0.65, 1.881, 0.085), "ozone_sigma_a_color", "ozone_sigma_a_scale")
+    cb["mie_sigma_s"] = np.float32(3.996) * np.float32(1e-3)
+    cb["mie_sigma_a"] = np.float32(4.4) * np.float32(1e-3)
     cb["num_frames_camera_static"] = num_frames_static
     cb["camera_static"] = camera_static
     cb["accumulate"] = accumulate
