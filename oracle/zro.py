@@ -52,6 +52,12 @@ def lib():
         L.zro_rdi_reset_temporal.argtypes = [C.c_void_p]
         L.zro_rdi_render.argtypes = [C.c_void_p] * 8
         L.zro_rdi_read_plane.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        L.zro_sdi_create.restype = C.c_void_p
+        L.zro_sdi_create.argtypes = [C.c_uint32, C.c_uint32]
+        L.zro_sdi_destroy.argtypes = [C.c_void_p]
+        L.zro_sdi_reset_temporal.argtypes = [C.c_void_p]
+        L.zro_sdi_render.argtypes = [C.c_void_p] * 8
+        L.zro_sdi_read_plane.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
         L.zro_rgi_create.restype = C.c_void_p
         L.zro_rgi_create.argtypes = [C.c_uint32, C.c_uint32]
         L.zro_rgi_destroy.argtypes = [C.c_void_p]
@@ -245,6 +251,44 @@ class OracleRDI:
         idx, dt, ch = self.PLANES[name]
         out = np.zeros((self.h, self.w, ch), dt)
         lib().zro_rdi_read_plane(self.r, idx, out.ctypes.data)
+        return out
+
+
+class OracleSDI:
+    """Stateful sun + sky ReSTIR DI renderer of the oracle (zro_sdi.h).  The scene's sky LUT must be bound (sky_lut())."""
+    PLANES = {"A": (0, np.uint8, 1), "B": (1, np.uint16, 2), "C": (2, np.float32, 2), "target": (3, np.float32, 4)}
+
+    def __init__(self, oscene, w, h):
+        self.osc, self.w, self.h = oscene, w, h
+        self.r = lib().zro_sdi_create(w, h)
+        self.prev = None
+        self.final = np.zeros((h, w, 4), np.float32)
+
+    def __del__(self):
+        if getattr(self, "r", None):
+            lib().zro_sdi_destroy(self.r)
+            self.r = None
+
+    def reset_temporal(self):
+        lib().zro_sdi_reset_temporal(self.r)
+
+    def render(self, cb, params, gb=None):
+        from zetaray_amd import wire
+        if gb is None:
+            gb = self.osc.gbuffer(cb)
+        cbb = np.ascontiguousarray(cb)
+        prev = C.addressof(self.prev[1]) if self.prev is not None else None
+        cnt = wire.Counters()
+        lib().zro_sdi_render(self.osc.h, self.r, cbb.ctypes.data, C.addressof(gb[1]), prev, C.addressof(params),
+                             self.final.ctypes.data, C.addressof(cnt))
+        self.counters = (cnt.n_closest, cnt.n_shadow)
+        self.prev = gb
+        return self.final
+
+    def plane(self, name):
+        idx, dt, ch = self.PLANES[name]
+        out = np.zeros((self.h, self.w, ch), dt)
+        lib().zro_sdi_read_plane(self.r, idx, out.ctypes.data)
         return out
 
 

@@ -399,6 +399,14 @@ namespace RT {
         float2 ndc = Math::NDCFromUV(uv);
         return f3(ndc.x * aspectRatio * tanHalfFOV, ndc.y * tanHalfFOV, 1);
     }
+    // RT.hlsli:222-231
+    static inline float3 GeneratePinholeCameraRay(int px, int py, float2 renderDim, float aspectRatio, float tanHalfFOV,
+        float3 viewBasisX, float3 viewBasisY, float3 viewBasisZ, float2 jitter)
+    {
+        float3 dirV = GeneratePinholeCameraRay_CS(px, py, renderDim, aspectRatio, tanHalfFOV, jitter);
+        float3 dirW = mad3(dirV.x, viewBasisX, mad3(dirV.y, viewBasisY, dirV.z * viewBasisZ));
+        return normalize(dirW);
+    }
     // RT.hlsli:245-262 (Waechter-Binder)
     static inline float3 OffsetRayRTG(float3 pos, float3 geometricNormal)
     {

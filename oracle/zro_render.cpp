@@ -650,6 +650,7 @@ static void RenderPathTracer(const Scene& sc, const zr_frame_constants& g, GBVie
 #include "zro_rpt.h"
 #include "zro_rdi.h"
 #include "zro_rgi.h"
+#include "zro_sdi.h"
 
 //--------------------------------------------------------------------------------------
 // C entry points (ctypes)
@@ -799,6 +800,30 @@ int zro_rdi_read_plane(const zro_rdi* r, int plane, void* out)
     const int last = 1 - r->st.currIdx;
     if (plane == 0) std::memcpy(out, r->st.A[last].data(), r->st.A[last].size() * 4);
     else if (plane == 1) std::memcpy(out, r->st.B[last].data(), r->st.B[last].size() * 4);
+    else std::memcpy(out, r->st.target.data(), r->st.target.size() * 4);
+    return 0;
+}
+
+// ReSTIR DI for sun + sky (zro_sdi.h)
+struct zro_sdi { SDI::State st; };
+zro_sdi* zro_sdi_create(uint32_t w, uint32_t h) { zro_sdi* r = new zro_sdi(); r->st.Resize(w, h); return r; }
+void zro_sdi_destroy(zro_sdi* r) { delete r; }
+void zro_sdi_reset_temporal(zro_sdi* r) { r->st.temporalValid = false; r->st.currIdx = 0; }
+int zro_sdi_render(const zro_scene* h, zro_sdi* r, const zr_frame_constants* cb, const zr_gbuffer_planes* curr, const zr_gbuffer_planes* prev,
+    const zr_params* prm, float* final_rgba, zr_counters* counters)
+{
+    h->s.counters = Counters();
+    SDI::Render(h->s, *cb, curr, prev, *prm, r->st, final_rgba);
+    if (counters) { counters->n_closest = h->s.counters.n_closest; counters->n_shadow = h->s.counters.n_shadow; }
+    return 0;
+}
+// plane 0 = A (u8 metadata), 1 = B (2 x u16 oct32), 2 = C (2 x f32: w_sum, W) of the set written by the last frame, 3 = target (4 x f32)
+int zro_sdi_read_plane(const zro_sdi* r, int plane, void* out)
+{
+    const int last = 1 - r->st.currIdx;
+    if (plane == 0) std::memcpy(out, r->st.A[last].data(), r->st.A[last].size());
+    else if (plane == 1) std::memcpy(out, r->st.B[last].data(), r->st.B[last].size() * 2);
+    else if (plane == 2) std::memcpy(out, r->st.C[last].data(), r->st.C[last].size() * 4);
     else std::memcpy(out, r->st.target.data(), r->st.target.size() * 4);
     return 0;
 }

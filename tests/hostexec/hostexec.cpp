@@ -8,6 +8,7 @@
 #include <cstring>
 #include "../../zetaray_amd/csrc/zr_stages.h"
 #include "../../zetaray_amd/csrc/zr_bvh.h"
+#include "../../zetaray_amd/csrc/zr_sdi.h"
 #include "../../zetaray_amd/csrc/zr_rpt.h"
 #include "../../zetaray_amd/csrc/zr_rdi.h"
 #include "../../zetaray_amd/csrc/zr_rgi.h"
@@ -506,4 +507,55 @@ int zhx_rgi_read_plane(const HxRgi* R, int plane, void* out)
     return 0;
 }
 
+
+// ---- ReSTIR DI for sun + sky (zr_sdi.h) ----
+struct HxSdi
+{
+    uint32_t w = 0, h = 0; bool temporalValid = false; int currIdx = 0;
+    std::vector<uint8_t> A[2]; std::vector<uint16_t> B[2]; std::vector<float> C[2]; std::vector<F4> target;
+};
+HxSdi* zhx_sdi_create(uint32_t w, uint32_t h)
+{
+    HxSdi* r = new HxSdi(); r->w = w; r->h = h; size_t n = (size_t)w * h;
+    for (int i = 0; i < 2; i++) { r->A[i].assign(n, 0); r->B[i].assign(2 * n, 0); r->C[i].assign(2 * n, 0.0f); }
+    r->target.assign(n, F4{0, 0, 0, 0});
+    return r;
+}
+void zhx_sdi_destroy(HxSdi* r) { delete r; }
+void zhx_sdi_reset_temporal(HxSdi* r) { r->temporalValid = false; r->currIdx = 0; }
+void zhx_sdi_render(const HxScene* s, HxSdi* R, const zr_frame_constants* cb, const zr_gbuffer_planes* curr, const zr_gbuffer_planes* prev,
+    const zr_params* params, float* finalRGBA, zr_counters* counters)
+{
+    using namespace sdi;
+    uint32_t cnt[2] = {0, 0};
+    const zr_frame_constants& g = *cb;
+    const uint32_t W = g.render_width, H = g.render_height;
+    SkyFrame F;
+    F.sc = s->view; F.gb = ViewOf(curr); F.gbPrev = prev ? ViewOf(prev) : F.gb;
+    F.cur.A = R->A[R->currIdx].data(); F.cur.B = R->B[R->currIdx].data(); F.cur.C = R->C[R->currIdx].data();
+    F.prev.A = R->A[1 - R->currIdx].data(); F.prev.B = R->B[1 - R->currIdx].data(); F.prev.C = R->C[1 - R->currIdx].data();
+    F.target = R->target.data(); F.finalRGBA = finalRGBA;
+    SkyParams& prm = F.prm;
+    prm.M_max_sky = params->m_max_temporal; prm.M_max_sun = params->m_max_spatial; prm.alpha_min = params->alpha_min;
+    prm.accumulate = (g.accumulate && g.camera_static) ? 1u : 0u;
+    prm.doTemporal = (R->temporalValid && (params->flags & ZR_IND_TEMPORAL_RESAMPLE) && prev) ? 1u : 0u;
+    prm.doSpatial = (prm.doTemporal && (params->flags & ZR_IND_SPATIAL_RESAMPLE)) ? 1u : 0u;
+    prm.writeReservoirs = (prm.doTemporal || !R->temporalValid) ? 1u : 0u;
+    zr::StackEntry stackMem[zr::kTravStack]; zr::TravStack stack; stack.lds = nullptr; stack.stride = 0; stack.mem = stackMem;
+    for (uint32_t y = 0; y < H; y++) for (uint32_t x = 0; x < W; x++) TemporalPixel(F, g, x, y, stack, cnt);
+    if (prm.doSpatial) for (uint32_t y = 0; y < H; y++) for (uint32_t x = 0; x < W; x++) SpatialPixel(F, g, x, y, stack, cnt);
+    if (counters) { counters->n_closest = cnt[0]; counters->n_shadow = cnt[1]; }
+    R->temporalValid = true;
+    R->currIdx = 1 - R->currIdx;
+}
+// plane 0 = A, 1 = B, 2 = C of the set written by the last frame, 3 = target
+int zhx_sdi_read_plane(const HxSdi* R, int plane, void* out)
+{
+    const int last = 1 - R->currIdx;
+    if (plane == 0) std::memcpy(out, R->A[last].data(), R->A[last].size());
+    else if (plane == 1) std::memcpy(out, R->B[last].data(), R->B[last].size() * 2);
+    else if (plane == 2) std::memcpy(out, R->C[last].data(), R->C[last].size() * 4);
+    else std::memcpy(out, R->target.data(), R->target.size() * sizeof(F4));
+    return 0;
+}
 } // extern "C"

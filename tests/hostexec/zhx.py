@@ -44,6 +44,12 @@ def lib():
         L.zhx_rdi_reset_temporal.argtypes = [C.c_void_p]
         L.zhx_rdi_render.argtypes = [C.c_void_p] * 8
         L.zhx_rdi_read_plane.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        L.zhx_sdi_create.restype = C.c_void_p
+        L.zhx_sdi_create.argtypes = [C.c_uint32, C.c_uint32]
+        L.zhx_sdi_destroy.argtypes = [C.c_void_p]
+        L.zhx_sdi_reset_temporal.argtypes = [C.c_void_p]
+        L.zhx_sdi_render.argtypes = [C.c_void_p] * 8
+        L.zhx_sdi_read_plane.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
         L.zhx_rgi_create.restype = C.c_void_p
         L.zhx_rgi_create.argtypes = [C.c_uint32, C.c_uint32]
         L.zhx_rgi_destroy.argtypes = [C.c_void_p]
@@ -250,6 +256,44 @@ class HostExecRDI:
         idx, dt, ch = self.PLANES[name]
         out = np.zeros((self.h, self.w, ch), dt)
         lib().zhx_rdi_read_plane(self.r, idx, out.ctypes.data)
+        return out
+
+
+class HostExecSDI:
+    """Sun + sky ReSTIR DI through the HIP stage functions, serially (mirror of oracle.zro.OracleSDI)."""
+    PLANES = {"A": (0, np.uint8, 1), "B": (1, np.uint16, 2), "C": (2, np.float32, 2), "target": (3, np.float32, 4)}
+
+    def __init__(self, hxscene, w, h):
+        self.hx, self.w, self.h = hxscene, w, h
+        self.r = lib().zhx_sdi_create(w, h)
+        self.prev = None
+        self.final = np.zeros((h, w, 4), np.float32)
+
+    def __del__(self):
+        if getattr(self, "r", None):
+            lib().zhx_sdi_destroy(self.r)
+            self.r = None
+
+    def reset_temporal(self):
+        lib().zhx_sdi_reset_temporal(self.r)
+
+    def render(self, cb, params, gb=None):
+        from zetaray_amd import wire
+        if gb is None:
+            gb = self.hx.gbuffer(cb)
+        cbb = np.ascontiguousarray(cb)
+        prev = C.addressof(self.prev[1]) if self.prev is not None else None
+        cnt = wire.Counters()
+        lib().zhx_sdi_render(self.hx.h, self.r, cbb.ctypes.data, C.addressof(gb[1]), prev, C.addressof(params), self.final.ctypes.data,
+                             C.addressof(cnt))
+        self.counters = (cnt.n_closest, cnt.n_shadow)
+        self.prev = gb
+        return self.final
+
+    def plane(self, name):
+        idx, dt, ch = self.PLANES[name]
+        out = np.zeros((self.h, self.w, ch), dt)
+        lib().zhx_sdi_read_plane(self.r, idx, out.ctypes.data)
         return out
 
 

@@ -558,8 +558,9 @@ ZR_HD BsdfSample SampleBSDF(const RhoView& rho, V3 n, const Surface& s, Rng& rng
 ZR_HD BsdfSample SampleBSDF_NoDiffuse(const RhoView& rho, V3 n, const Surface& s, V2 u_c, V2 u_g, float u_wrs_0, float u_wrs_1)
 { return SampleBSDF_NoDiffuse(rho, n, s, u_c, u_g, u_wrs_0, u_wrs_1, NoOpTarget()); }
 
-// BSDFSamplerPdf_NoDiffuse (NoOp target), BSDFSampling.hlsli:565-631
-ZR_HD float BSDFSamplerPdf_NoDiffuse(const RhoView& rho, V3 n, Surface s, V3 wi)
+// BSDFSamplerPdf_NoDiffuse, BSDFSampling.hlsli:565-631
+template<typename Func>
+ZR_HD float BSDFSamplerPdf_NoDiffuse(const RhoView& rho, V3 n, Surface s, V3 wi, Func func)
 {
     V3 wh = s.SetWi(wi, n);
     float pdf_base = 1, pdf_c = 0;
@@ -579,8 +580,8 @@ ZR_HD float BSDFSamplerPdf_NoDiffuse(const RhoView& rho, V3 n, Surface s, V3 wi)
     }
     float pdf_g = s.GlossSpecular() ? (s.ndotwh >= kMinNdotHSpecular ? 1.0f : 0.0f) : 1;
     pdf_g *= pdf_base;
-    (void)wh;
-    float lumA = Luminance(v3(1.0f)), lumB = Luminance(v3(1.0f));
+    const V3 wi_other = !s.reflection ? reflect(-s.wo, wh) : refract(-s.wo, wh, 1 / s.eta);
+    float lumA = Luminance(func(wi)), lumB = Luminance(func(wi_other));
     float Fr_g = s.Fresnel().x;
     float pdf_r = Fr_g * (s.reflection ? lumA : lumB);
     pdf_r = pdf_r / (pdf_r + (1 - Fr_g) * (s.reflection ? lumB : lumA));
@@ -599,14 +600,15 @@ ZR_HD float BSDFSamplerPdf_NoDiffuse(const RhoView& rho, V3 n, Surface s, V3 wi)
     return pdf_g;
 }
 
-// BSDFSamplerPdf (NoOp target), BSDFSampling.hlsli:639-759
-ZR_HD float BSDFSamplerPdf(const RhoView& rho, V3 n, Surface s, V3 wi_z, Rng& rng)
+// BSDFSamplerPdf, BSDFSampling.hlsli:639-759
+template<typename Func>
+ZR_HD float BSDFSamplerPdf(const RhoView& rho, V3 n, Surface s, V3 wi_z, Func func, Rng& rng)
 {
-    if (s.specTr) return BSDFSamplerPdf_NoDiffuse(rho, n, s, wi_z);
+    if (s.specTr) return BSDFSamplerPdf_NoDiffuse(rho, n, s, wi_z, func);
     s.SetWi(wi_z, n);
     if (!s.reflection && !s.ThinWalled()) return 0;
     Eval ez = Unified(rho, s);
-    float targetLum = Luminance(ez.f * v3(1.0f));
+    float targetLum = Luminance(ez.f * func(wi_z));
     if (targetLum == 0) return 0;
 
     float w_sum_c, w_sum_g, w_sum_dr, w_sum_dt;
@@ -627,7 +629,7 @@ ZR_HD float BSDFSamplerPdf(const RhoView& rho, V3 n, Surface s, V3 wi_z, Rng& rn
         s.SetWi_Refl(wi_d, n);
         Eval e = Unified(rho, s);
         Fr_g = e.Fr_g.x;
-        float lum = Luminance(e.f * v3(1.0f));
+        float lum = Luminance(e.f * func(wi_d));
         float pdf_g = GlossPdf(s);
         float pdf_c = s.Coated() ? CoatPdf(s) : 0;
         float w = BalanceHeuristic3(pdf_d, pdf_g, pdf_c, lum);
@@ -636,14 +638,14 @@ ZR_HD float BSDFSamplerPdf(const RhoView& rho, V3 n, Surface s, V3 wi_z, Rng& rn
     if (!s.metallic && s.ThinWalled())
     {
         V3 target_dt = DielectricBaseDiffuseTr(rho, s, Fr_g);
-        float w = Luminance(target_dt * v3(1.0f)) / pdf_d;
+        float w = Luminance(target_dt * func(-wi_d)) / pdf_d;
         w_sum_g += w; w_sum_dr += w; w_sum_c += w;
     }
     {
         V3 wi_g = SampleGloss(s, n, rng.Uniform2D());
         s.SetWi_Refl(wi_g, n);
         V3 target_g = Unified(rho, s).f;
-        float lum = Luminance(target_g * v3(1.0f));
+        float lum = Luminance(target_g * func(wi_g));
         float pdf_g = GlossPdf(s);
         float pdf_dd = !s.metallic ? DiffusePdf(s) : 0;
         float pdf_c = s.Coated() ? CoatPdf(s) : 0;
@@ -655,7 +657,7 @@ ZR_HD float BSDFSamplerPdf(const RhoView& rho, V3 n, Surface s, V3 wi_z, Rng& rn
         V3 wi_c = SampleCoat(s, n, rng.Uniform2D());
         s.SetWi_Refl(wi_c, n);
         V3 target_c = Unified(rho, s).f;
-        float lum = Luminance(target_c * v3(1.0f));
+        float lum = Luminance(target_c * func(wi_c));
         float pdf_g = GlossPdf(s);
         float pdf_dd = !s.metallic ? DiffusePdf(s) : 0;
         float pdf_c = CoatPdf(s);
@@ -668,5 +670,7 @@ ZR_HD float BSDFSamplerPdf(const RhoView& rho, V3 n, Surface s, V3 wi_z, Rng& rn
     pdf += s.ThinWalled() && (w_sum_dt > 0) ? targetLum / w_sum_dt : 0;
     return pdf;
 }
+ZR_HD float BSDFSamplerPdf_NoDiffuse(const RhoView& rho, V3 n, const Surface& s, V3 wi) { return BSDFSamplerPdf_NoDiffuse(rho, n, s, wi, NoOpTarget()); }
+ZR_HD float BSDFSamplerPdf(const RhoView& rho, V3 n, const Surface& s, V3 wi_z, Rng& rng) { return BSDFSamplerPdf(rho, n, s, wi_z, NoOpTarget(), rng); }
 
 } // namespace zr

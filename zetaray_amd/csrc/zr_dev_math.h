@@ -252,6 +252,15 @@ ZR_HD V3 SampleCosineWeightedHemisphere(V2 u, float* pdf)    // Sampling.hlsli:1
     *pdf = z * ZR_ONE_OVER_PI;
     return v3(c * sinTheta, s * sinTheta, z);
 }
+ZR_HD V3 UniformSampleCone(V2 u, float cosThetaMax, float* pdf)   // Sampling.hlsli:198-212
+{
+    const float phi = ZR_TWO_PI * u.y;
+    const float cosTheta = zr_saturate((1.0f - u.x) + u.x * cosThetaMax);
+    const float sinTheta = zr_sqrt(1.0f - cosTheta * cosTheta);
+    float s, c; zr_sincos(phi, &s, &c);
+    *pdf = ZR_ONE_OVER_2_PI / (1.0f - cosThetaMax);
+    return v3(c * sinTheta, s * sinTheta, cosTheta);
+}
 ZR_HD V2 UniformSampleDiskConcentric(V2 u)     // Sampling.hlsli:222-244
 {
     float a = 2.0f * u.x - 1.0f, b = 2.0f * u.y - 1.0f;
@@ -276,6 +285,11 @@ ZR_HD V3 GeneratePinholeCameraRay_CS(int px, int py, V2 renderDim, float aspectR
     V2 uv = v2(((float)px + 0.5f + jitter.x) / renderDim.x, ((float)py + 0.5f + jitter.y) / renderDim.y);
     V2 ndc = NDCFromUV(uv);
     return v3(ndc.x * aspectRatio * tanHalfFOV, ndc.y * tanHalfFOV, 1);
+}
+ZR_HD V3 GeneratePinholeCameraRay(int px, int py, V2 renderDim, float aspectRatio, float tanHalfFOV, V3 vbx, V3 vby, V3 vbz, V2 jitter)  // :222-231
+{
+    V3 dirV = GeneratePinholeCameraRay_CS(px, py, renderDim, aspectRatio, tanHalfFOV, jitter);
+    return normalize(mad(dirV.x, vbx, mad(dirV.y, vby, dirV.z * vbz)));
 }
 ZR_HD V3 OffsetRayRTG(V3 pos, V3 gn)           // RT.hlsli:245-262 (Waechter-Binder)
 {

@@ -529,7 +529,8 @@ def _atrium_geometry(num_tris, num_emissive, room, rng):
     return groups, em
 
 
-def make_synthetic_scene(num_tris=262144, num_emissive=100000, seed=0x5EED, room=4.0, with_special_materials=True, layout="soup") -> Scene:
+def make_synthetic_scene(num_tris=262144, num_emissive=100000, seed=0x5EED, room=4.0, with_special_materials=True, layout="soup",
+                         open_top=False) -> Scene:
     """Procedural Sponza-class stand-in for BASELINE config 4 (not in the reference):
     a box room, `num_tris` clutter triangles in 8 instances with different materials (diffuse, rough metal, coated,
     glossy; plus a few axis-aligned coplanar sheets that produce exact t ties) and `num_emissive` small double-sided
@@ -596,6 +597,8 @@ def make_synthetic_scene(num_tris=262144, num_emissive=100000, seed=0x5EED, room
     r = room
     c = np.array([[-r, -r, -r], [r, -r, -r], [r, r, -r], [-r, r, -r], [-r, -r, r], [r, -r, r], [r, r, r], [-r, r, r]], np.float32)
     quads = [(0, 1, 2, 3), (5, 4, 7, 6), (4, 0, 3, 7), (1, 5, 6, 2), (3, 2, 6, 7), (4, 5, 1, 0)]
+    if open_top:        # no ceiling: sun and sky reach the clutter (sun / sky DI and NEE tests)
+        quads = [q for q in quads if q != (3, 2, 6, 7)]
     P = np.array([[c[a], c[b], c[d]] for (a, b, cc, d) in quads] + [[c[b], c[cc], c[d]] for (a, b, cc, d) in quads], np.float32)
     add_instance(P, face_normals(P), 1, wire.SUBGROUP_NON_EMISSIVE)
 

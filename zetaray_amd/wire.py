@@ -130,6 +130,16 @@ DI_STOCHASTIC_SPATIAL = 1 << 8
 DI_EXTRA_DISOCCLUSION_SAMPLING = 1 << 9
 
 
+def default_params_sky_di():
+    """SkyDI defaults (SkyDI.cpp:81-82, SkyDI.h:86-92): M_max sky 15 (m_max_temporal), M_max sun 3 (m_max_spatial), alpha_min 0.35^2"""
+    p = default_params()
+    p.flags = 0x3          # TEMPORAL_RESAMPLE | SPATIAL_RESAMPLE
+    p.m_max_temporal = 15
+    p.m_max_spatial = 3
+    p.alpha_min = float(np.float32(0.35) * np.float32(0.35))
+    return p
+
+
 def default_params_di() -> Params:
     """ReSTIR DI defaults: DirectLighting.cpp:100-107, DirectLighting.h:93-98 (M_max 20, alpha_min 0.05^2)."""
     p = Params()
