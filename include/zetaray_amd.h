@@ -54,7 +54,8 @@ typedef enum zr_pass_kind {
     ZR_PASS_GBUFFER     = 0,   /* GBufferRT          */
     ZR_PASS_PRELIGHTING = 1,   /* PreLighting + EmissiveTriangleAliasTable */
     ZR_PASS_DI_EMISSIVE = 2,   /* DirectLighting     */
-    ZR_PASS_DI_SKY      = 3,   /* SkyDI              */
+    ZR_PASS_DI_SKY      = 3,   /* SkyDI (RP/DirectLighting/Sky/SkyDI.cpp): zr_params.m_max_temporal = M_max (Sky), m_max_spatial = M_max (Sun),
+                                  alpha_min = Alpha_min; needs the scene's sky-view LUT (ZR_PASS_SKY) */
     ZR_PASS_INDIRECT    = 4,   /* IndirectLighting   */
     ZR_PASS_COMPOSITING = 5,   /* Compositing: (DI + indirect * !emissive) / NumFramesCameraStatic */
     /* Sky (RP/Sky/Sky.cpp:34-66,120-164; K17 RP/Sky/SkyViewLUT.hlsl): zr_pass_init(pass, LutWidth, LutHeight, 0) (the reference
@@ -126,6 +127,11 @@ typedef enum zr_output {
     ZR_OUT_RGI_RESERVOIR_A = 30,   /* RGBA32F 16 B: sample position, hit ID bits */
     ZR_OUT_RGI_RESERVOIR_B = 31,   /* RGBA16F  8 B: Lo, M */
     ZR_OUT_RGI_RESERVOIR_C = 32,   /* RGBA32F 16 B: w_sum, W, oct32 normal bits, unused */
+    /* sun + sky ReSTIR DI (ZR_PASS_DI_SKY) persistent state written by the last frame (DirectLighting/Sky/Reservoir.hlsli:137-164) */
+    ZR_OUT_SDI_RESERVOIR_A = 24,   /* R8_UINT    1 B: M | sky << 4 | halfVectorCopyShift << 5 | lobe is coat << 6 | (w_sum > 0) << 7 */
+    ZR_OUT_SDI_RESERVOIR_B = 25,   /* RG16_UINT  4 B: oct32 of wi (or of the tangent-frame half vector) */
+    ZR_OUT_SDI_RESERVOIR_C = 26,   /* RG32F      8 B: w_sum, W */
+    ZR_OUT_SDI_TARGET      = 27,   /* RGBA32F   16 B (xyz) */
     /* Sky (ZR_PASS_SKY) */
     ZR_OUT_SKY_LUT         = 40    /* R11G11B10_FLOAT 4 B, LutWidth x LutHeight (Sky::SHADER_OUT_RES::SKY_VIEW_LUT) */
 } zr_output;

@@ -21,7 +21,8 @@ IN_EMISSIVE_DI, IN_INDIRECT, IN_SKY_DI = range(3)
 INTEGRATOR_PATH_TRACING, INTEGRATOR_RESTIR_GI, INTEGRATOR_RESTIR_PT = range(3)
 OUT_FINAL = 0
 # ReSTIR PT persistent state (zr_output): name -> (id, dtype, channels)
-RPT_OUTPUTS_EXTRA = {"sky_lut": (40, np.uint32, 1)}
+RPT_OUTPUTS_EXTRA = {"sky_lut": (40, np.uint32, 1), "sdi_A": (24, np.uint8, 1), "sdi_B": (25, np.uint16, 2), "sdi_C": (26, np.float32, 2),
+                     "sdi_target": (27, np.float32, 4)}
 RPT_OUTPUTS = {"A": (1, np.uint32, 1), "B": (2, np.float32, 2), "C": (3, np.uint32, 4), "D": (4, np.uint32, 4),
                "E": (5, np.uint16, 1), "F": (6, np.float32, 2), "G": (7, np.uint32, 2), "target": (8, np.float32, 4),
                "neighbor": (9, np.uint8, 2),
@@ -303,6 +304,8 @@ class Renderer:
         # Sky pass (K17): scenes without emissive triangles light with sun + sky, which sample the sky-view LUT
         self.p_sky = Pass(PASS_SKY, 256, 128, device=device) if len(scene_host.emissives) == 0 else None
         self.p_direct = None          # ReSTIR DI (emissive): enable_direct()
+        self.p_sky_direct = None      # ReSTIR DI (sun + sky): enable_sky_direct()
+        self.skip_indirect = False
         self.p_composit = None        # Compositing: enable_compositing()
         self._alias_ready = False
 
@@ -313,6 +316,13 @@ class Renderer:
         if self.p_direct is not None:
             self.p_composit.set_input(IN_EMISSIVE_DI, self.p_direct.output_ptr()[0])
         return self.p_composit
+
+    def enable_sky_direct(self, params=None, device=0):
+        """add the SkyDI (sun + sky ReSTIR DI) pass; it renders after the Sky pass and the G-buffer"""
+        if self.p_sky is None:
+            self.p_sky = Pass(PASS_SKY, 256, 128, device=device)
+        self.p_sky_direct = Pass(PASS_DI_SKY, self.p_indirect.w, self.p_indirect.h_, device=device, params=params)
+        return self.p_sky_direct
 
     def enable_direct(self, params=None, device=0):
         """add the DirectLighting (ReSTIR DI, emissive) pass; it renders after PreLighting, next to Indirect"""
@@ -328,7 +338,10 @@ class Renderer:
             self._alias_ready = True
         if self.p_direct is not None:
             self.p_direct.render(cb, self.scene, self.gbuffer, stream)
-        self.p_indirect.render(cb, self.scene, self.gbuffer, stream)
+        if self.p_sky_direct is not None:
+            self.p_sky_direct.render(cb, self.scene, self.gbuffer, stream)
+        if not self.skip_indirect:
+            self.p_indirect.render(cb, self.scene, self.gbuffer, stream)
         if self.p_composit is not None:
             self.p_composit.render(cb, self.scene, self.gbuffer, stream)
 

@@ -15,6 +15,7 @@
 #include "zr_stages.h"
 #include "zr_rpt.h"
 #include "zr_rdi.h"
+#include "zr_sdi.h"
 #include "zr_rgi.h"
 #include "zr_bvh.h"
 
@@ -417,6 +418,25 @@ __global__ void __launch_bounds__(kBlock) k_rpt_stc(rpt::RptFrame F, zr_frame_co
     FlushRayCounters(counters, cnt);
 }
 
+// ------------------------------------------------------------------------------------------------ sun + sky ReSTIR DI kernels
+// K7: initial candidates (sun, cosine-sky, BSDF-sky) + temporal reuse; K8: pairwise-MIS spatial reuse.  One thread per pixel.
+__global__ void __launch_bounds__(kBlock) k_sdi_temporal(sdi::SkyFrame F, zr_frame_constants g, uint32_t tilesX, unsigned long long* counters)
+{
+    uint32_t x, y; PixelOfThread(tilesX, F.gb.x0, F.gb.y0, &x, &y);
+    ZR_TRAV_STACK(stack);
+    uint32_t cnt[2] = {0u, 0u};
+    if (x < F.gb.x0 + F.gb.w && y < F.gb.y0 + F.gb.h) sdi::TemporalPixel(F, g, x, y, stack, cnt);
+    FlushRayCounters(counters, cnt);
+}
+__global__ void __launch_bounds__(kBlock) k_sdi_spatial(sdi::SkyFrame F, zr_frame_constants g, uint32_t tilesX, unsigned long long* counters)
+{
+    uint32_t x, y; PixelOfThread(tilesX, F.gb.x0, F.gb.y0, &x, &y);
+    ZR_TRAV_STACK(stack);
+    uint32_t cnt[2] = {0u, 0u};
+    if (x < F.gb.x0 + F.gb.w && y < F.gb.y0 + F.gb.h) sdi::SpatialPixel(F, g, x, y, stack, cnt);
+    FlushRayCounters(counters, cnt);
+}
+
 // ------------------------------------------------------------------------------------------------ ReSTIR DI kernels
 static const uint16_t kRdiSampleSet[64] = {
 #include "zr_rdi_sample_set.inc"
@@ -549,7 +569,7 @@ static constexpr int kMaxTimers = 64;
 // ray-counter slots (pairs of u64 on the device): 0 = wavefront path tracer, 1.. = ReSTIR PT kernels in launch order
 static constexpr int kCounterSlots = 16;
 static const char* const kCounterNames[kCounterSlots] = {"trace", "rpt_pathtrace", "rpt_replay_ctt", "rpt_replay_ttc", "rpt_reconnect_temporal",
-    "rpt_replay_cts", "rpt_replay_stc", "rpt_reconnect_spatial", "rdi_temporal", "rdi_spatial", "rgi", "", "", "", "", ""};
+    "rpt_replay_cts", "rpt_replay_stc", "rpt_reconnect_spatial", "rdi_temporal", "rdi_spatial", "rgi", "sdi_temporal", "sdi_spatial", "", "", ""};
 
 struct zr_pass
 {
@@ -585,6 +605,7 @@ struct zr_pass
     DevBuf<uint32_t> rptLists, rptListCounts;      // 4 replay work lists (pixel ids) + their device-side counts
     // DI_EMISSIVE: two reservoir sets (A RGBA32_UINT, B RG32F), target, sample set
     DevBuf<U4> diA[2]; DevBuf<float> diB[2]; DevBuf<F4> diTarget; DevBuf<uint16_t> diSampleSet;
+    DevBuf<uint8_t> skyA[2]; DevBuf<uint16_t> skyB[2]; DevBuf<float> skyC[2];      // sun + sky DI reservoirs (R8_UINT, RG16_UINT, RG32F)
     // INDIRECT / ReSTIR GI: two reservoir sets (A RGBA32F, B RGBA16F, C RGBA32F)
     DevBuf<F4> giA[2], giC[2]; DevBuf<uint16_t> giB[2];
     bool temporalValid = false, doTemporal = false, doSpatial = false; int currIdx = 0;
@@ -843,13 +864,18 @@ int zr_pass_create(int kind, int device, zr_pass** out)
 {
     if (!out) return Fail(ZR_ERR_INVALID_ARG, "null out");
     if (kind < ZR_PASS_GBUFFER || kind > ZR_PASS_SKY) return Fail(ZR_ERR_INVALID_ARG, "unknown pass kind %d", kind);
-    if (kind == ZR_PASS_DI_SKY) return Fail(ZR_ERR_UNSUPPORTED, "pass kind %d (sun / sky ReSTIR DI) is not implemented yet", kind);
     int r = RequireDevice(device);
     if (r) return r;
     zr_pass* p = new (std::nothrow) zr_pass();
     if (!p) return Fail(ZR_ERR_OOM, "out of host memory");
     p->kind = kind; p->device = device;
     zr_params_default(&p->params);
+    if (kind == ZR_PASS_DI_SKY)
+    {
+        // SkyDI.cpp:81-82, SkyDI.h:86-92: M_max (Sky) 15 -> m_max_temporal, M_max (Sun) 3 -> m_max_spatial, Alpha_min = 0.35^2
+        p->params.flags = ZR_IND_TEMPORAL_RESAMPLE | ZR_IND_SPATIAL_RESAMPLE;
+        p->params.m_max_temporal = 15; p->params.m_max_spatial = 3; p->params.alpha_min = 0.35f * 0.35f;
+    }
     if (kind == ZR_PASS_DI_EMISSIVE)
     {
         // DirectLighting.cpp:100-107, DirectLighting.h:93-98
@@ -869,6 +895,22 @@ static int AllocPass(zr_pass* p)
         const size_t cap = (size_t)p->w * p->h;
         if ((r = p->finalRGBA.Alloc(cap * 4))) return r;
         HIP_TRY(hipMemset(p->finalRGBA.p, 0, cap * 4 * sizeof(float)));
+    }
+    if (p->kind == ZR_PASS_DI_SKY)
+    {
+        const size_t cap = (size_t)p->w * p->h;
+        if ((r = p->finalRGBA.Alloc(cap * 4))) return r;
+        if ((r = p->counters.Alloc(2 * kCounterSlots))) return r;
+        HIP_TRY(hipMemset(p->finalRGBA.p, 0, cap * 4 * sizeof(float)));
+        HIP_TRY(hipMemset(p->counters.p, 0, 2 * kCounterSlots * sizeof(unsigned long long)));
+        for (int k = 0; k < 2; k++)
+        {
+            if ((r = p->skyA[k].Alloc(cap)) || (r = p->skyB[k].Alloc(2 * cap)) || (r = p->skyC[k].Alloc(2 * cap))) return r;
+            HIP_TRY(hipMemset(p->skyA[k].p, 0, cap)); HIP_TRY(hipMemset(p->skyB[k].p, 0, cap * 4)); HIP_TRY(hipMemset(p->skyC[k].p, 0, cap * 8));
+        }
+        if ((r = p->diTarget.Alloc(cap))) return r;
+        HIP_TRY(hipMemset(p->diTarget.p, 0, cap * 16));
+        p->temporalValid = false; p->currIdx = 0;
     }
     if (p->kind == ZR_PASS_DI_EMISSIVE)
     {
@@ -958,13 +1000,15 @@ int zr_pass_reset_temporal(zr_pass* p)
     HIP_TRY(hipSetDevice(p->device));
     if (p->kind == ZR_PASS_INDIRECT) HIP_TRY(hipMemset(p->finalRGBA.p, 0, p->finalRGBA.n * sizeof(float)));
     p->temporalValid = false;       // IndirectLighting::ResetTemporal -> RESET_TEMPORAL_TEXTURES next frame
-    if (p->kind == ZR_PASS_DI_EMISSIVE) { HIP_TRY(hipMemset(p->finalRGBA.p, 0, p->finalRGBA.n * sizeof(float))); p->currIdx = 0; }   // DirectLighting.cpp:159-164
+    if (p->kind == ZR_PASS_DI_EMISSIVE || p->kind == ZR_PASS_DI_SKY) { HIP_TRY(hipMemset(p->finalRGBA.p, 0, p->finalRGBA.n * sizeof(float))); p->currIdx = 0; }   // DirectLighting.cpp:159-164, SkyDI.cpp:128-133
     return ZR_OK;
 }
 int zr_pass_set_params(zr_pass* p, const zr_params* prm)
 {
     if (!p || !prm) return Fail(ZR_ERR_INVALID_ARG, "null argument");
     if (p->kind == ZR_PASS_DI_EMISSIVE && (prm->m_max_temporal < 1 || prm->m_max_temporal > 30)) return Fail(ZR_ERR_INVALID_ARG, "DI M_max must be in 1..30");
+    if (p->kind == ZR_PASS_DI_SKY && (prm->m_max_temporal < 1 || prm->m_max_temporal > 15 || prm->m_max_spatial < 1 || prm->m_max_spatial > 15))
+        return Fail(ZR_ERR_INVALID_ARG, "sky DI M_max (sky = m_max_temporal, sun = m_max_spatial) must be in 1..15");
     if (prm->max_non_tr_bounces < 1 || prm->max_non_tr_bounces > 15 || prm->max_glossy_tr_bounces < 1 || prm->max_glossy_tr_bounces > 15)
         return Fail(ZR_ERR_INVALID_ARG, "bounce counts must be in 1..15");
     if (prm->presampling && (prm->num_sample_sets == 0 || prm->sample_set_size == 0 || prm->num_sample_sets > 65535 || prm->sample_set_size > 65535))
@@ -1069,6 +1113,44 @@ static int RenderDirectEmissive(zr_pass* p, hipStream_t s, const zr_frame_consta
     {
         TimerBegin(p, s, "rdi_spatial");
         hipLaunchKernelGGL(k_rdi_spatial, grid, block, 0, s, F, *cb, tilesX, p->counters.p + 2 * 9);
+        TimerEnd(p, s);
+    }
+    HIP_TRY(hipGetLastError());
+    p->temporalValid = true;
+    p->currIdx = 1 - p->currIdx;
+    return ZR_OK;
+}
+
+// SkyDI::Render (SkyDI.cpp:135-259)
+static int RenderDirectSky(zr_pass* p, hipStream_t s, const zr_frame_constants* cb, const zr_scene* sc, zr_gbuffer* gb)
+{
+    using namespace sdi;
+    if (!gb) return Fail(ZR_ERR_INVALID_ARG, "DI_SKY pass needs a gbuffer");
+    if (gb->w != p->w || gb->h != p->h) return Fail(ZR_ERR_INVALID_ARG, "gbuffer / pass size mismatch");
+    if (gb->x0 || gb->y0 || gb->w != cb->render_width || gb->h != cb->render_height)
+        return Fail(ZR_ERR_UNSUPPORTED, "DI_SKY needs the whole frame on one device (its screen-tile halo exchange is not implemented yet)");
+    if (!sc->view.sky.data) return Fail(ZR_ERR_NOT_INITIALIZED, "sky-view LUT missing: render a ZR_PASS_SKY pass first");
+    const zr_params& ip = p->params;
+    SkyFrame F;
+    F.sc = sc->view; F.gb = gb->View(); F.gbPrev = gb->PrevView();
+    F.cur.A = p->skyA[p->currIdx].p; F.cur.B = p->skyB[p->currIdx].p; F.cur.C = p->skyC[p->currIdx].p;
+    F.prev.A = p->skyA[1 - p->currIdx].p; F.prev.B = p->skyB[1 - p->currIdx].p; F.prev.C = p->skyC[1 - p->currIdx].p;
+    F.target = p->diTarget.p; F.finalRGBA = p->finalRGBA.p;
+    SkyParams& prm = F.prm;
+    prm.M_max_sky = ip.m_max_temporal; prm.M_max_sun = ip.m_max_spatial; prm.alpha_min = ip.alpha_min;
+    prm.accumulate = (cb->accumulate && cb->camera_static) ? 1u : 0u;
+    prm.doTemporal = (p->temporalValid && (ip.flags & ZR_IND_TEMPORAL_RESAMPLE) && gb->numRendered >= 2) ? 1u : 0u;
+    prm.doSpatial = (prm.doTemporal && (ip.flags & ZR_IND_SPATIAL_RESAMPLE)) ? 1u : 0u;
+    prm.writeReservoirs = (prm.doTemporal || !p->temporalValid) ? 1u : 0u;
+    const uint32_t tilesX = (p->w + 15) / 16, tilesY = (p->h + 15) / 16;
+    const dim3 grid(tilesX * tilesY), block(kBlock);
+    TimerBegin(p, s, "sdi_temporal");
+    hipLaunchKernelGGL(k_sdi_temporal, grid, block, 0, s, F, *cb, tilesX, p->counters.p + 2 * 11);
+    TimerEnd(p, s);
+    if (prm.doSpatial)
+    {
+        TimerBegin(p, s, "sdi_spatial");
+        hipLaunchKernelGGL(k_sdi_spatial, grid, block, 0, s, F, *cb, tilesX, p->counters.p + 2 * 12);
         TimerEnd(p, s);
     }
     HIP_TRY(hipGetLastError());
@@ -1336,6 +1418,7 @@ int zr_pass_render_stage(zr_pass* p, void* stream, const zr_frame_constants* cb,
     case ZR_PASS_PRELIGHTING: return (stages & ZR_STAGE_TEMPORAL) ? RenderPreLighting(p, s, cb, const_cast<zr_scene*>(sc)) : ZR_OK;
     case ZR_PASS_INDIRECT: return RenderIndirect(p, s, cb, sc, gb, stages);
     case ZR_PASS_DI_EMISSIVE: return (stages & ZR_STAGE_TEMPORAL) ? RenderDirectEmissive(p, s, cb, sc, gb) : ZR_OK;
+    case ZR_PASS_DI_SKY: return (stages & ZR_STAGE_TEMPORAL) ? RenderDirectSky(p, s, cb, sc, gb) : ZR_OK;
     case ZR_PASS_COMPOSITING: return (stages & ZR_STAGE_SPATIAL) ? RenderCompositing(p, s, cb, gb) : ZR_OK;
     case ZR_PASS_SKY: return (stages & ZR_STAGE_TEMPORAL) ? RenderSky(p, s, cb, const_cast<zr_scene*>(sc)) : ZR_OK;
     default: return Fail(ZR_ERR_UNSUPPORTED, "pass kind %d not implemented", p->kind);
@@ -1362,6 +1445,21 @@ int zr_pass_get_output(const zr_pass* p, int which, void** dev, uint32_t* w, uin
         if (w) *w = p->w;
         if (h) *h = p->h;
         if (bpp) *bpp = 16;
+        return ZR_OK;
+    }
+    if (p->kind == ZR_PASS_DI_SKY)
+    {
+        uint32_t b = 16;
+        const int last = 1 - p->currIdx;
+        if (which == ZR_OUT_FINAL) *dev = p->finalRGBA.p;
+        else if (which == ZR_OUT_SDI_RESERVOIR_A) { *dev = p->skyA[last].p; b = 1; }
+        else if (which == ZR_OUT_SDI_RESERVOIR_B) { *dev = p->skyB[last].p; b = 4; }
+        else if (which == ZR_OUT_SDI_RESERVOIR_C) { *dev = p->skyC[last].p; b = 8; }
+        else if (which == ZR_OUT_SDI_TARGET) *dev = p->diTarget.p;
+        else return Fail(ZR_ERR_INVALID_ARG, "pass has no such output");
+        if (w) *w = p->w;
+        if (h) *h = p->h;
+        if (bpp) *bpp = b;
         return ZR_OK;
     }
     if (p->kind == ZR_PASS_DI_EMISSIVE)
@@ -1437,7 +1535,7 @@ int zr_pass_read_counters(zr_pass* p, void* stream, zr_counters* out, int reset)
     if (!p || !out) return Fail(ZR_ERR_INVALID_ARG, "null argument");
     HIP_TRY(hipSetDevice(p->device));
     out->n_closest = p->hostCounters.n_closest; out->n_shadow = p->hostCounters.n_shadow;
-    if ((p->kind == ZR_PASS_INDIRECT || p->kind == ZR_PASS_DI_EMISSIVE) && p->initialized)
+    if ((p->kind == ZR_PASS_INDIRECT || p->kind == ZR_PASS_DI_EMISSIVE || p->kind == ZR_PASS_DI_SKY) && p->initialized)
     {
         unsigned long long c[2 * kCounterSlots];
         HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
@@ -1452,7 +1550,7 @@ int zr_pass_read_kernel_counters(zr_pass* p, void* stream, uint32_t max_entries,
     uint32_t* count)
 {
     if (!p || !names || !closest || !shadow || !count) return Fail(ZR_ERR_INVALID_ARG, "null argument");
-    if ((p->kind != ZR_PASS_INDIRECT && p->kind != ZR_PASS_DI_EMISSIVE) || !p->initialized) return Fail(ZR_ERR_NOT_INITIALIZED, "pass has no ray counters or is not initialised");
+    if ((p->kind != ZR_PASS_INDIRECT && p->kind != ZR_PASS_DI_EMISSIVE && p->kind != ZR_PASS_DI_SKY) || !p->initialized) return Fail(ZR_ERR_NOT_INITIALIZED, "pass has no ray counters or is not initialised");
     HIP_TRY(hipSetDevice(p->device));
     unsigned long long c[2 * kCounterSlots];
     HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
