@@ -95,6 +95,8 @@ def main():
     ap.add_argument("--no-final-halo", action="store_true",
                     help="skip the post-frame halo exchange (exact for a static camera, which this bench uses)")
     ap.add_argument("--direct", action="store_true", help="also run the ReSTIR DI (emissive) pass every frame (N = 1)")
+    ap.add_argument("--sky-direct", action="store_true", help="also run the sun + sky ReSTIR DI pass (K7/K8) every frame (N = 1)")
+    ap.add_argument("--di-only", action="store_true", help="skip the indirect pass: BASELINE config 1 (ReSTIR DI only)")
     ap.add_argument("--integrator", choices=["restir_pt", "restir_gi", "pt"], default="restir_pt",
                     help="restir_pt = K11-K16 (BASELINE metric); pt = K9 unidirectional path tracer")
     args = ap.parse_args()
@@ -149,6 +151,14 @@ def main():
         dip.presampling, dip.num_sample_sets, dip.sample_set_size = prm.presampling, prm.num_sample_sets, prm.sample_set_size
         r.enable_direct(dip, device=local_rank)
 
+    if args.sky_direct:
+        assert world == 1, "--sky-direct: the sky DI pass has no tile split yet"
+        r.enable_sky_direct(wire.default_params_sky_di(), device=local_rank)
+    if args.di_only:
+        assert world == 1 and not rpt and (args.direct or args.sky_direct), "--di-only needs --integrator pt and a DI pass"
+        r.skip_indirect = True
+    di_passes = [q for q in (r.p_direct, r.p_sky_direct) if q is not None]
+
     def frame(i):
         cb = scene_io.make_frame_constants(W, H, frame_num=i, num_emissives=len(sc.emissives), **cam)
         if tiled is not None:
@@ -166,8 +176,8 @@ def main():
     barrier()
     r.p_gbuffer.read_counters(reset=True)
     r.p_indirect.read_counters(reset=True)
-    if r.p_direct is not None:
-        r.p_direct.read_counters(reset=True)
+    for q in di_passes:
+        q.read_counters(reset=True)
     barrier()
     t0 = time.perf_counter()
     for i in range(args.steps):
@@ -177,7 +187,11 @@ def main():
 
     c1 = r.p_gbuffer.read_counters(reset=True)
     c2 = r.p_indirect.read_counters(reset=True)
-    c3 = r.p_direct.read_counters(reset=True) if r.p_direct is not None else (0, 0)
+    c3 = [0, 0]
+    for q in di_passes:
+        cq = q.read_counters(reset=True)
+        c3[0] += cq[0]
+        c3[1] += cq[1]
     rays = np.array([c1[0] + c2[0] + c3[0], c1[1] + c2[1] + c3[1]], np.float64)
     tmax = dt
     if dist is not None:
@@ -196,14 +210,17 @@ def main():
         "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
         "scaling": "strong",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": (f"{scene_name} {W}x{H}, G-buffer + ReSTIR PT "
+        "config": {"workload": (f"{scene_name} {W}x{H}, sky-view LUT + G-buffer + ReSTIR DI only (K17 + K1 + "
+                                f"{'K5/K6 emissive ' if args.direct else ''}{'K7/K8 sun + sky ' if args.sky_direct else ''}"
+                                f"initial candidates, temporal + pairwise-MIS spatial reuse, static camera)") if args.di_only else
+                               (f"{scene_name} {W}x{H}, G-buffer + ReSTIR PT "
                                 f"(K1 + K11-K16: initial candidates, temporal + spatial reconnection reuse, boiling "
                                 f"suppression; 3 non-transmissive / 4 glossy-transmissive bounces, static camera)") if rpt else
                                (f"{scene_name} {W}x{H}, G-buffer + ReSTIR GI (K1+K10, "
                                 f"3 bounces, temporal reuse, static camera)") if args.integrator == "restir_gi" else
                                (f"{scene_name} {W}x{H}, G-buffer + 1-spp "
                                 f"path tracer (K1+K9, NEE+MIS, 3 non-transmissive bounces, static camera)"),
-                   "integrator": args.integrator + ("+restir_di" if args.direct else ""),
+                   "integrator": ("" if args.di_only else args.integrator) + ("+restir_di" if args.direct else "") + ("+sky_di" if args.sky_direct else ""),
                    "parallelism": f"screen tiles {tile_grid(world)}" + (
                        f", 32-px apron, RCCL p2p halo exchange of reservoir planes (62 B/px): {tiled.halo_bytes} B sent per "
                        f"rank per exchange, {1 if args.no_final_halo else 2} exchanges per frame" if (rpt and world > 1) else ""),
@@ -215,15 +232,20 @@ def main():
         # ---- roofline of the dominant kernel: hipEvent timing inside the library over a few timed frames
         r.p_gbuffer.enable_timing(True)
         r.p_indirect.enable_timing(True)
-        if r.p_direct is not None:
-            r.p_direct.enable_timing(True)
+        if r.p_sky is not None:
+            r.p_sky.enable_timing(True)
+        for q in di_passes:
+            q.enable_timing(True)
         agg = {}
         nfr = 8
         r.p_indirect.read_counters(reset=True)
         for i in range(nfr):
             frame(1000 + i)
             torch.cuda.synchronize()
-            for name, (ms, launches) in {**r.p_gbuffer.timings(), **r.p_indirect.timings(), **(r.p_direct.timings() if r.p_direct is not None else {})}.items():
+            tm = {**r.p_gbuffer.timings(), **({} if args.di_only else r.p_indirect.timings())}
+            for q in di_passes + ([r.p_sky] if r.p_sky is not None else []):
+                tm.update(q.timings())
+            for name, (ms, launches) in tm.items():
                 a = agg.setdefault(name, [0.0, 0])
                 a[0] += ms
                 a[1] += launches
@@ -247,6 +269,11 @@ def main():
             bytes_launch = (TRACE_CLOSEST * cc + TRACE_SHADOW * cs) / launches
         elif dom == "pt_shade":
             bytes_launch = (SHADE_CLOSEST * cc + SHADE_SHADOW * cs) / launches
+        elif dom in ("sdi_temporal", "sdi_spatial", "rdi_temporal", "rdi_spatial"):
+            # DI: shadow / visibility rays of this kernel + the G-buffer planes (27 B) and reservoir planes it reads and writes
+            q = r.p_sky_direct if dom.startswith("sdi") else r.p_direct
+            kcc, kcs = q.kernel_counters().get(dom, (0, 0))
+            bytes_launch = (BYTES_CLOSEST * kcc + BYTES_SHADOW * kcs) / launches + (27 * 3 + 2 * 13 + 32) * W * H
         elif dom == "gbuffer":
             bytes_launch = (BYTES_CLOSEST + 47) * W * H
         else:
