@@ -438,7 +438,9 @@ static void Render(const Scene& sc, const zr_frame_constants& g, const zr_gbuffe
                 if (!RtRayQuery::GetMaterialData(sc, -P.bsdfSample.wi, P.eta_curr, P.rd.uv_grads, P.hitInfo, P.psurface, P.eta_next)) { P.active = false; continue; }
                 // RGI_Util::NEE (NEE_EMISSIVE == 1, USE_MIS == 1, MIS_ALL_BOUNCES == 0)
                 float3 ld;
-                if (P.bounce == 0)
+                if (g.num_emissive_triangles == 0)      // NEE_EMISSIVE == 0: sun + sky (ReSTIR_GI_NEE.hlsli:194-226)
+                    ld = NEE_SunSky(sc, g, hitPos, P.hitInfo.normal, P.psurface, P.rngThread);
+                else if (P.bounce == 0)
                     ld = NEE_Emissive_MIS(sc, 1, true, hitPos, P.hitInfo.normal, P.psurface, g.num_emissive_triangles, P.rngThread, presampled, P.sampleSetIdx, true);
                 else
                     ld = NEE_Emissive_Power(sc, hitPos, P.hitInfo.normal, P.psurface, g.num_emissive_triangles, presampled, P.sampleSetIdx, P.rngThread);

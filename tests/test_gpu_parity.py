@@ -475,3 +475,28 @@ def test_sky_di_bit_exact(api, cornell_sky, scene_kind, w, h):
         for nm, onm in (("sdi_A", "A"), ("sdi_B", "B"), ("sdi_C", "C"), ("sdi_target", "target")):
             assert np.array_equal(di.download_plane(nm).view(np.uint8), o.plane(onm).view(np.uint8)), f"frame {f}: sky DI plane {onm}"
     assert got[..., :3].max() > 0
+
+
+def test_restir_gi_sun_sky_bit_exact(api, cornell_sky):
+    """K10 with sun + sky NEE (no emissive triangles) through the C-ABI, 4 frames, camera moving from frame 3."""
+    from oracle import zro
+    w, h = 120, 80
+    osc = zro.OracleScene(cornell_sky)
+    prm = wire.default_params()
+    r = api.Renderer(cornell_sky, w, h, params=prm, integrator=api.INTEGRATOR_RESTIR_GI)
+    o = zro.OracleRGI(osc, w, h)
+    prev = None
+    for f in range(1, 5):
+        cb = scene_io.make_frame_constants(w, h, frame_num=f, num_emissives=0, cam_pos=(0.05 * max(0, f - 2), 1.2, -4.043))
+        if prev is not None:
+            cb["prev_view"], cb["prev_view_inv"], cb["prev_camera_jitter"] = prev["curr_view"], prev["curr_view_inv"], prev["curr_camera_jitter"]
+        prev = cb.copy()
+        r.p_indirect.read_counters(reset=True)
+        r.render_frame(cb)
+        got = r.final()
+        osc.sky_lut(cb, 256, 128)
+        want = o.render(cb, prm)
+        mism = int((got.view(np.uint32) != want.view(np.uint32)).any(axis=2).sum())
+        assert mism == 0, f"frame {f}: {mism} pixels differ"
+        assert r.p_indirect.read_counters() == o.counters
+    assert got[..., :3].max() > 0

@@ -1281,7 +1281,7 @@ static int RenderIndirect(zr_pass* p, hipStream_t s, const zr_frame_constants* c
     if (sc->view.numEmissives == 0)
     {
         // NEE_EMISSIVE == 0 shader variants: sun + sky next-event estimation
-        if (p->integrator != ZR_INTEGRATOR_PATH_TRACING) return Fail(ZR_ERR_UNSUPPORTED, "sun/sky NEE (scenes without emissive triangles) is implemented for the path tracer only");
+        if (p->integrator == ZR_INTEGRATOR_RESTIR_PT) return Fail(ZR_ERR_UNSUPPORTED, "sun/sky NEE (scenes without emissive triangles) is implemented for the path tracer and ReSTIR GI, not yet for ReSTIR PT");
         if (!sc->view.sky.data) return Fail(ZR_ERR_NOT_INITIALIZED, "sky-view LUT missing: render a ZR_PASS_SKY pass first");
     }
     else if (!sc->view.alias) return Fail(ZR_ERR_NOT_INITIALIZED, "emissive alias table missing: render the PRELIGHTING pass (or zr_scene_set_alias_table) first");

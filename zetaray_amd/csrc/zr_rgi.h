@@ -115,6 +115,41 @@ ZR_HD LightDraw DrawLight(const Globals& g, V3 shadingPos, Rng& rng)
     return d;
 }
 
+// RtRayQuery::Visibility_Ray (RayQuery.hlsli:302-334), traced in place
+ZR_HD bool VisibilityRay(const Globals& gl, V3 origin, V3 wi, V3 normal, bool transmissive)
+{
+    F4 ro, rd;
+    if (!MakeVisibilityRay(origin, wi, normal, transmissive, &ro, &rd)) return false;
+    gl.cnt[1]++;
+    RawHit h = Traverse<true>(*gl.sc, xyz(ro), xyz(rd), ro.w, rd.w, ZR_SUBGROUP_ALL, gl.stack);
+    return h.tri == kInvalidTri;
+}
+// RGI_Util::NEE with NEE_EMISSIVE == 0 (ReSTIR_GI_NEE.hlsli:194-226): ReSTIR_Util::NEE_Sun<true> with probability q,
+// else NEE_Sky<true> (NEE.hlsli:86-152); P_SUN_VS_SKY 0.65, SUN_DISK_SAMPLING 0 (ReSTIR_GI/Params.hlsli:8,28)
+ZR_HD V3 NEE_SunSky(const Globals& gl, const zr_frame_constants& g, V3 pos, V3 normal, const Surface& surface, Rng& rng)
+{
+    const SceneView& sc = *gl.sc;
+    const float p_sun = rng.Uniform();
+    const V3 sunDir = v3p(g.sun_dir);
+    if (!(-sunDir.y > 0)) return v3(0.0f);
+    const float q = (surface.Transmissive() ? 1.0f : (dot(-sunDir, normal) > 0 ? 1.0f : 0.0f)) * 0.65f;
+    if (p_sun < q)
+    {
+        const V3 wi = -sunDir;
+        Surface ss = surface;
+        ss.SetWi(wi, normal);
+        const V3 f = Unified(sc.rho, ss).f;
+        V3 ld = v3(0.0f);
+        if (!(dot(f, f) == 0) && VisibilityRay(gl, pos, wi, normal, surface.Transmissive())) ld = f * Le_Sun(pos, g);
+        return ld / q;
+    }
+    SkyIncidentRadiance leFunc; leFunc.lut = sc.sky;
+    const BsdfSample bs = SampleBSDF(sc.rho, normal, surface, leFunc, rng);
+    V3 ld = bs.bsdfOverPdf;
+    if (dot(ld, ld) > 0) ld = ld * (VisibilityRay(gl, pos, bs.wi, normal, surface.Transmissive()) ? 1.0f : 0.0f);
+    return ld / (1 - q);
+}
+
 // RGI_Util::NEE_Emissive_MIS<1, skipDiffuse = true> (ReSTIR_GI_NEE.hlsli:8-118), APPROXIMATE_EMISSIVE_SHADOW_RAY 1
 ZR_HD V3 NEE_Emissive_MIS(const Globals& g, V3 pos, V3 normal, Surface surface, Rng& rng)
 {
@@ -281,7 +316,9 @@ ZR_HD void PhaseA(const GiFrame& F, const zr_frame_constants& g, TravStack stack
     if (!GetMaterialData(F.sc, -P.bs.wi, P.eta_curr, P.hit, P.psurface, eta_mat)) { P.active = false; return; }
     P.eta_next = eta_mat;
     // RGI_Util::NEE (NEE_EMISSIVE == 1, USE_MIS == 1, MIS_ALL_BOUNCES == 0)
-    V3 ld = P.bounce == 0 ? NEE_Emissive_MIS(gl, hitPos, P.hit.normal, P.psurface, P.rngThread) : NEE_Emissive_Power(gl, hitPos, P.hit.normal, P.psurface, P.rngThread);
+    V3 ld;
+    if (g.num_emissive_triangles == 0) ld = NEE_SunSky(gl, g, hitPos, P.hit.normal, P.psurface, P.rngThread);     // NEE_EMISSIVE == 0
+    else ld = P.bounce == 0 ? NEE_Emissive_MIS(gl, hitPos, P.hit.normal, P.psurface, P.rngThread) : NEE_Emissive_Power(gl, hitPos, P.hit.normal, P.psurface, P.rngThread);
     P.li = P.li + P.throughput * ld;
     if (P.bounce >= (P.maxNumBounces - 1)) { P.active = false; return; }
     P.ppos = hitPos; P.pnormal = P.hit.normal;
