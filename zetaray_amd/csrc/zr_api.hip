@@ -49,7 +49,20 @@ static int RequireDevice(int device)
 
 // ------------------------------------------------------------------------------------------------ device helpers
 static constexpr int kBlock = 256;
-static constexpr uint32_t kCounterStride = 64;     // queue counters live 256 B apart: their atomics spread over L2 channels
+// Occupancy targets of the register-heavy shading kernels, waves per SIMD (the compiler spills a little to reach them).
+// Measured on MI355X, Cornell 1080p / 380k-triangle atrium: k_rpt_pathtrace 2 -> 4 waves: 1.45 -> 1.19 ms /
+// 14.9 -> 10.7 ms; k_rgi 2 -> 4: 2.19 -> 1.68 ms; k_rdi_* 2 -> 3: 0.72 -> 0.67, 0.39 -> 0.33 ms; k_sdi_spatial -> 4: 0.58 ->
+// 0.49 ms.  k_rpt_temporal, k_rpt_stc, k_pt_shade and k_sdi_temporal got slower with more waves and keep the default.
+#define ZR_WAVES(n) __attribute__((amdgpu_waves_per_eu(n, n)))
+#define ZR_WAVES_PATHTRACE ZR_WAVES(4)
+#define ZR_WAVES_RGI ZR_WAVES(4)
+#define ZR_WAVES_RDI_T ZR_WAVES(3)
+#define ZR_WAVES_RDI_S ZR_WAVES(3)
+#define ZR_WAVES_SDI_S ZR_WAVES(4)
+#define ZR_WAVES_SDI_T
+#define ZR_WAVES_TEMPORAL
+#define ZR_WAVES_STC
+#define ZR_WAVES_SHADE
 // this lane's traversal stack: kTravLdsEntries entries in LDS (16 KB per 256-lane block at 8 entries), the rest in scratch
 #define ZR_TRAV_STACK(name) \
     __shared__ StackEntry name##Lds[kTravLdsEntries * kBlock]; StackEntry name##Mem[kTravStack - kTravLdsEntries]; \
@@ -229,7 +242,7 @@ __global__ void __launch_bounds__(kBlock) k_trace(SceneView sc, PathQueue q, con
     if (lane == 0) { if (a) atomicAdd(&counters[0], (unsigned long long)a); if (b) atomicAdd(&counters[1], (unsigned long long)b); }
 }
 
-__global__ void __launch_bounds__(kBlock) k_pt_shade(SceneView sc, zr_frame_constants g, PtParams prm, PathQueue in, const uint32_t* inCount,
+__global__ void __launch_bounds__(kBlock) ZR_WAVES_SHADE k_pt_shade(SceneView sc, zr_frame_constants g, PtParams prm, PathQueue in, const uint32_t* inCount,
     PathQueue out, uint32_t* outCount, uint32_t* outRays, uint32_t cap, float* finalRGBA, const F4* firstBOP, uint32_t* groupMax)
 {
     const uint32_t n = *inCount;
@@ -314,7 +327,7 @@ __device__ __forceinline__ void FlushRayCounters(unsigned long long* counters, c
 }
 
 // K11: block = 16x16 pixels, wave w = rows 4w..4w+3 (a 16x4 block: the RR "wave" of the ABI, zr_rpt.h header)
-__global__ void __launch_bounds__(kBlock) k_rpt_pathtrace(rpt::RptFrame F, zr_frame_constants g, uint32_t tilesX, unsigned long long* counters)
+__global__ void __launch_bounds__(kBlock) ZR_WAVES_PATHTRACE k_rpt_pathtrace(rpt::RptFrame F, zr_frame_constants g, uint32_t tilesX, unsigned long long* counters)
 {
     const uint32_t tile = blockIdx.x, tx = tile % tilesX, ty = tile / tilesX;
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
@@ -383,7 +396,7 @@ __global__ void __launch_bounds__(kBlock) k_rpt_replay(rpt::RptFrame F, zr_frame
 }
 
 // K14: CtT + TtC fused per pixel (zr_rpt.h ReconnectTemporalPixel)
-__global__ void __launch_bounds__(kBlock) k_rpt_temporal(rpt::RptFrame F, zr_frame_constants g, uint32_t tilesX, unsigned long long* counters)
+__global__ void __launch_bounds__(kBlock) ZR_WAVES_TEMPORAL k_rpt_temporal(rpt::RptFrame F, zr_frame_constants g, uint32_t tilesX, unsigned long long* counters)
 {
     uint32_t x, y; PixelOfThread(tilesX, F.ox0, F.oy0, &x, &y);
     ZR_TRAV_STACK(stack);
@@ -400,7 +413,7 @@ __device__ __forceinline__ float WaveSumButterfly(float v)
 }
 
 // K16 CtS + StC: wave = 8x8 pixel group; every lane of the wave walks all four phases (absent lanes contribute 0)
-__global__ void __launch_bounds__(kBlock) k_rpt_stc(rpt::RptFrame F, zr_frame_constants g, uint32_t tilesX, unsigned long long* counters)
+__global__ void __launch_bounds__(kBlock) ZR_WAVES_STC k_rpt_stc(rpt::RptFrame F, zr_frame_constants g, uint32_t tilesX, unsigned long long* counters)
 {
     uint32_t x, y; PixelOfThread(tilesX, F.ox0, F.oy0, &x, &y);
     ZR_TRAV_STACK(stack);
@@ -420,7 +433,7 @@ __global__ void __launch_bounds__(kBlock) k_rpt_stc(rpt::RptFrame F, zr_frame_co
 
 // ------------------------------------------------------------------------------------------------ sun + sky ReSTIR DI kernels
 // K7: initial candidates (sun, cosine-sky, BSDF-sky) + temporal reuse; K8: pairwise-MIS spatial reuse.  One thread per pixel.
-__global__ void __launch_bounds__(kBlock) k_sdi_temporal(sdi::SkyFrame F, zr_frame_constants g, uint32_t tilesX, unsigned long long* counters)
+__global__ void __launch_bounds__(kBlock) ZR_WAVES_SDI_T k_sdi_temporal(sdi::SkyFrame F, zr_frame_constants g, uint32_t tilesX, unsigned long long* counters)
 {
     uint32_t x, y; PixelOfThread(tilesX, F.gb.x0, F.gb.y0, &x, &y);
     ZR_TRAV_STACK(stack);
@@ -428,7 +441,7 @@ __global__ void __launch_bounds__(kBlock) k_sdi_temporal(sdi::SkyFrame F, zr_fra
     if (x < F.gb.x0 + F.gb.w && y < F.gb.y0 + F.gb.h) sdi::TemporalPixel(F, g, x, y, stack, cnt);
     FlushRayCounters(counters, cnt);
 }
-__global__ void __launch_bounds__(kBlock) k_sdi_spatial(sdi::SkyFrame F, zr_frame_constants g, uint32_t tilesX, unsigned long long* counters)
+__global__ void __launch_bounds__(kBlock) ZR_WAVES_SDI_S k_sdi_spatial(sdi::SkyFrame F, zr_frame_constants g, uint32_t tilesX, unsigned long long* counters)
 {
     uint32_t x, y; PixelOfThread(tilesX, F.gb.x0, F.gb.y0, &x, &y);
     ZR_TRAV_STACK(stack);
@@ -443,7 +456,7 @@ static const uint16_t kRdiSampleSet[64] = {
 };
 
 // K5: initial candidates + temporal reuse, one thread per pixel (8x8 quadrant per wave, like the reference's thread group)
-__global__ void __launch_bounds__(kBlock) k_rdi_temporal(rdi::DiFrame F, zr_frame_constants g, uint32_t tilesX, unsigned long long* counters)
+__global__ void __launch_bounds__(kBlock) ZR_WAVES_RDI_T k_rdi_temporal(rdi::DiFrame F, zr_frame_constants g, uint32_t tilesX, unsigned long long* counters)
 {
     uint32_t x, y; PixelOfThread(tilesX, F.ox0, F.oy0, &x, &y);
     ZR_TRAV_STACK(stack);
@@ -452,7 +465,7 @@ __global__ void __launch_bounds__(kBlock) k_rdi_temporal(rdi::DiFrame F, zr_fram
     FlushRayCounters(counters, cnt);
 }
 // K6: spatial reuse with pairwise MIS; WaveActiveSum(disoccluded) = popcount of a ballot over the 8x8 group
-__global__ void __launch_bounds__(kBlock) k_rdi_spatial(rdi::DiFrame F, zr_frame_constants g, uint32_t tilesX, unsigned long long* counters)
+__global__ void __launch_bounds__(kBlock) ZR_WAVES_RDI_S k_rdi_spatial(rdi::DiFrame F, zr_frame_constants g, uint32_t tilesX, unsigned long long* counters)
 {
     uint32_t x, y; PixelOfThread(tilesX, F.ox0, F.oy0, &x, &y);
     ZR_TRAV_STACK(stack);
@@ -467,7 +480,7 @@ __global__ void __launch_bounds__(kBlock) k_rdi_spatial(rdi::DiFrame F, zr_frame
 // ------------------------------------------------------------------------------------------------ ReSTIR GI kernel
 // K10: one 8x8 pixel group per wave, bounce loop in lockstep around the Russian-roulette wave max, then temporal resampling
 // and the boiling-suppression wave sum (zr_rgi.h)
-__global__ void __launch_bounds__(kBlock) k_rgi(rgi::GiFrame F, zr_frame_constants g, uint32_t tilesX, unsigned long long* counters)
+__global__ void __launch_bounds__(kBlock) ZR_WAVES_RGI k_rgi(rgi::GiFrame F, zr_frame_constants g, uint32_t tilesX, unsigned long long* counters)
 {
     uint32_t x, y; PixelOfThread(tilesX, F.ox0, F.oy0, &x, &y);
     ZR_TRAV_STACK(stack);
