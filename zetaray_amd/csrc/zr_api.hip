@@ -63,6 +63,7 @@ static constexpr int kBlock = 256;
 #define ZR_WAVES_TEMPORAL
 #define ZR_WAVES_STC
 #define ZR_WAVES_SHADE
+static constexpr uint32_t kCounterStride = 64;     // queue counters live 256 B apart: their atomics spread over L2 channels
 // this lane's traversal stack: kTravLdsEntries entries in LDS (16 KB per 256-lane block at 8 entries), the rest in scratch
 #define ZR_TRAV_STACK(name) \
     __shared__ StackEntry name##Lds[kTravLdsEntries * kBlock]; StackEntry name##Mem[kTravStack - kTravLdsEntries]; \
