@@ -132,18 +132,15 @@ def main():
     x0, y0, tw, th = tile_rect(W, H, world, rank)
     rpt = args.integrator == "restir_pt"
     tiled = None
-    if rpt:
-        # ReSTIR PT reads neighbouring pixels' reservoirs: each rank owns a 32-px-aligned tile, renders the G-buffer of the
+    if rpt or args.integrator == "restir_gi":
+        # ReSTIR PT / GI read neighbouring pixels' reservoirs: each rank owns a 32-px-aligned tile, renders the G-buffer of the
         # tile + a 32-px apron, and exchanges reservoir halos point-to-point over RCCL before the spatial stage and after
         # the frame (zetaray_amd/tiling.py); N = 1 degenerates to the plain renderer
         from zetaray_amd import tiling
-        tiled = tiling.TiledRestirPT(sc, W, H, world, rank, device=local_rank, params=prm, dist=dist)
+        tiled = tiling.TiledRestirPT(sc, W, H, world, rank, device=local_rank, params=prm, dist=dist, kind=args.integrator)
         r = tiled.r
     else:
-        if args.integrator == "restir_gi":
-            assert world == 1, "restir_gi has no tile split yet"
-        r = api.Renderer(sc, tw, th, device=local_rank, params=prm, tile_origin=(x0, y0),
-                         integrator=api.INTEGRATOR_RESTIR_GI if args.integrator == "restir_gi" else api.INTEGRATOR_PATH_TRACING)
+        r = api.Renderer(sc, tw, th, device=local_rank, params=prm, tile_origin=(x0, y0), integrator=api.INTEGRATOR_PATH_TRACING)
 
     if args.direct:
         assert world == 1, "--direct: the DI pass has no tile split yet"
@@ -222,8 +219,9 @@ def main():
                                 f"path tracer (K1+K9, NEE+MIS, 3 non-transmissive bounces, static camera)"),
                    "integrator": ("" if args.di_only else args.integrator) + ("+restir_di" if args.direct else "") + ("+sky_di" if args.sky_direct else ""),
                    "parallelism": f"screen tiles {tile_grid(world)}" + (
-                       f", 32-px apron, RCCL p2p halo exchange of reservoir planes (62 B/px): {tiled.halo_bytes} B sent per "
-                       f"rank per exchange, {1 if args.no_final_halo else 2} exchanges per frame" if (rpt and world > 1) else ""),
+                       f", 32-px apron, RCCL p2p halo exchange of reservoir planes ({tiled.bpp} B/px): {tiled.halo_bytes} B sent per "
+                       f"rank per exchange, {(1 if args.no_final_halo else 2) if rpt else (0 if args.no_final_halo else 1)} exchanges per frame"
+                       if (tiled is not None and world > 1) else ""),
                    "rays_per_frame": round((n_closest + n_shadow) / args.steps, 1),
                    "fps": round(1e3 / ms_per_step, 2)},
     }

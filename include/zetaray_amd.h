@@ -217,6 +217,11 @@ int zr_pass_render(zr_pass* pass, void* hip_stream, const zr_frame_constants* cb
 #define ZR_HALO_FINAL         1   /* valid after the frame: the set the next frame reads as "previous" */
 #define ZR_HALO_BYTES_PER_PIXEL 62  /* planes A..G back to back: 4 + 8 + 16 + 16 + 2 + 8 + 8, each row-major over the rect */
 int zr_pass_set_owned_rect(zr_pass* pass, uint32_t x0, uint32_t y0, uint32_t width, uint32_t height);   /* global pixels; width 0 = whole tile */
+/* The same protocol for the other passes with cross-pixel reuse (SURVEY 8(e) "Collective"): bytes per pixel of a halo transfer =
+   the pass's reservoir planes back to back: ReSTIR PT 62, ReSTIR GI 40 (A, B, C), ReSTIR DI emissive 24 (A, B), sun + sky DI 13.
+   DI passes: TEMPORAL stage -> exchange ZR_HALO_POST_TEMPORAL -> SPATIAL stage (the exchanged set is also the one the next
+   frame reprojects into, so no ZR_HALO_FINAL is needed).  ReSTIR GI renders in the TEMPORAL stage and needs ZR_HALO_FINAL only. */
+int zr_pass_halo_bytes_per_pixel(zr_pass* pass, uint32_t* bytes);
 int zr_pass_render_stage(zr_pass* pass, void* hip_stream, const zr_frame_constants* cb, const zr_scene* scene,
                          zr_gbuffer* gbuffer, int stages);
 int zr_pass_halo_pack(zr_pass* pass, void* hip_stream, const zr_gbuffer* gbuffer, int which, uint32_t x0, uint32_t y0,

@@ -535,6 +535,7 @@ void zhx_sdi_render(const HxScene* s, HxSdi* R, const zr_frame_constants* cb, co
     F.cur.A = R->A[R->currIdx].data(); F.cur.B = R->B[R->currIdx].data(); F.cur.C = R->C[R->currIdx].data();
     F.prev.A = R->A[1 - R->currIdx].data(); F.prev.B = R->B[1 - R->currIdx].data(); F.prev.C = R->C[1 - R->currIdx].data();
     F.target = R->target.data(); F.finalRGBA = finalRGBA;
+    F.ox0 = 0; F.oy0 = 0; F.ow = W; F.oh = H;
     SkyParams& prm = F.prm;
     prm.M_max_sky = params->m_max_temporal; prm.M_max_sun = params->m_max_spatial; prm.alpha_min = params->alpha_min;
     prm.accumulate = (g.accumulate && g.camera_static) ? 1u : 0u;

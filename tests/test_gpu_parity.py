@@ -500,3 +500,49 @@ def test_restir_gi_sun_sky_bit_exact(api, cornell_sky):
         assert mism == 0, f"frame {f}: {mism} pixels differ"
         assert r.p_indirect.read_counters() == o.counters
     assert got[..., :3].max() > 0
+
+
+@pytest.mark.parametrize("kind", ["di", "sky_di", "restir_gi"])
+def test_tile_split_with_halo_exchange_other_passes_on_gpu(api, cornell_emissive, oracle_emissive, cornell_sky, kind):
+    """SURVEY 8(e) for the other passes with cross-pixel reuse: 4 tiles (2x2) on one device, reservoir halos through
+    zr_pass_halo_pack / unpack (ReSTIR DI 24 B/px and sun + sky DI 13 B/px between their stages, ReSTIR GI 40 B/px after the frame);
+    stitched radiance == the full-frame oracle, moving camera."""
+    from oracle import zro
+    from zetaray_amd import tiling
+    w, h, world = 192, 128, 4
+    if kind == "di":
+        sc, osc, pp = cornell_emissive, oracle_emissive, wire.default_params_di()
+        o = zro.OracleRDI(osc, w, h)
+    elif kind == "sky_di":
+        sc, pp = cornell_sky, wire.default_params_sky_di()
+        osc = zro.OracleScene(sc)
+        o = zro.OracleSDI(osc, w, h)
+    else:
+        sc, osc, pp = cornell_emissive, oracle_emissive, wire.default_params()
+        o = zro.OracleRGI(osc, w, h)
+    ranks = [tiling.TiledRestirPT(sc, w, h, world, r, params=wire.default_params(), kind=kind, pass_params=pp) for r in range(world)]
+    assert ranks[0].bpp == {"di": 24, "sky_di": 13, "restir_gi": 40}[kind]
+    post, final = ranks[0].EXCHANGES[kind]
+    prev = None
+    for f in range(1, 5):
+        cb = _frame(sc, w, h, f, cam_pos=(0.05 * f, 1.2, -4.043 + 0.02 * f))
+        if prev is not None:
+            cb["prev_view"], cb["prev_view_inv"], cb["prev_camera_jitter"] = prev["curr_view"], prev["curr_view_inv"], prev["curr_camera_jitter"]
+        prev = cb.copy()
+        for r in ranks:
+            r.stage_temporal(cb)
+        if post:
+            tiling.exchange_in_process(ranks, api.HALO_POST_TEMPORAL)
+        for r in ranks:
+            r.stage_spatial(cb)
+        if final:
+            tiling.exchange_in_process(ranks, api.HALO_FINAL)
+        if kind == "sky_di":
+            osc.sky_lut(cb, 256, 128)
+        want = o.render(cb, pp)
+        img = np.zeros_like(want)
+        for r in ranks:
+            (x0, y0, tw, th), t = r.final_tile()
+            img[y0:y0 + th, x0:x0 + tw] = t
+        mism = int((img.view(np.uint32) != want.view(np.uint32)).any(axis=2).sum())
+        assert mism == 0, f"{kind} frame {f}: {mism} pixels differ"

@@ -39,7 +39,7 @@ EXPORTS = [
     "zr_pass_set_params", "zr_pass_render", "zr_pass_get_output", "zr_pass_download_output",
     "zr_pass_read_counters", "zr_pass_read_kernel_counters", "zr_pass_enable_timing", "zr_pass_get_timings", "zr_pass_destroy",
     "zr_trace_closest", "zr_trace_any",
-    "zr_pass_set_owned_rect", "zr_pass_render_stage", "zr_pass_halo_pack", "zr_pass_halo_unpack", "zr_pass_set_input",
+    "zr_pass_set_owned_rect", "zr_pass_render_stage", "zr_pass_halo_pack", "zr_pass_halo_unpack", "zr_pass_halo_bytes_per_pixel", "zr_pass_set_input",
 ]
 STAGE_TEMPORAL, STAGE_SPATIAL, STAGE_ALL = 1, 2, 3
 HALO_POST_TEMPORAL, HALO_FINAL = 0, 1
@@ -99,6 +99,7 @@ def lib():
         L.zr_pass_set_owned_rect.argtypes = [vp, u32, u32, u32, u32]
         L.zr_pass_render_stage.argtypes = [vp, vp, vp, vp, vp, i32]
         L.zr_pass_halo_pack.argtypes = [vp, vp, vp, i32, u32, u32, u32, u32, vp, C.c_size_t]
+        L.zr_pass_halo_bytes_per_pixel.argtypes = [vp, vp]
         L.zr_pass_halo_unpack.argtypes = [vp, vp, vp, i32, u32, u32, u32, u32, vp, C.c_size_t]
         L.zr_pass_enable_timing.argtypes = [vp, i32]
         L.zr_pass_get_timings.argtypes = [vp, u32, vp, vp, vp, vp]
@@ -226,6 +227,11 @@ class Pass:
     def halo_pack(self, gbuffer, which, rect, dev_ptr, nbytes, stream=None):
         _check(lib().zr_pass_halo_pack(self.h, stream, gbuffer.h, which, rect[0], rect[1], rect[2], rect[3], dev_ptr, nbytes))
 
+    def halo_bytes_per_pixel(self):
+        b = C.c_uint32()
+        _check(lib().zr_pass_halo_bytes_per_pixel(self.h, C.byref(b)))
+        return b.value
+
     def halo_unpack(self, gbuffer, which, rect, dev_ptr, nbytes, stream=None):
         _check(lib().zr_pass_halo_unpack(self.h, stream, gbuffer.h, which, rect[0], rect[1], rect[2], rect[3], dev_ptr, nbytes))
 
@@ -294,6 +300,7 @@ class Renderer:
                  tile_origin=(0, 0)):
         """width/height = size of the tile this renderer owns; tile_origin = its top-left pixel in the full target."""
         self.scene = Scene(scene_host, device)
+        self.scene_host = scene_host
         self.gbuffer = GBuffer(width, height, device)
         if tile_origin != (0, 0):
             self.gbuffer.set_tile_origin(*tile_origin)

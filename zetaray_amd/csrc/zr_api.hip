@@ -436,18 +436,18 @@ __global__ void __launch_bounds__(kBlock) ZR_WAVES_STC k_rpt_stc(rpt::RptFrame F
 // K7: initial candidates (sun, cosine-sky, BSDF-sky) + temporal reuse; K8: pairwise-MIS spatial reuse.  One thread per pixel.
 __global__ void __launch_bounds__(kBlock) ZR_WAVES_SDI_T k_sdi_temporal(sdi::SkyFrame F, zr_frame_constants g, uint32_t tilesX, unsigned long long* counters)
 {
-    uint32_t x, y; PixelOfThread(tilesX, F.gb.x0, F.gb.y0, &x, &y);
+    uint32_t x, y; PixelOfThread(tilesX, F.ox0, F.oy0, &x, &y);
     ZR_TRAV_STACK(stack);
     uint32_t cnt[2] = {0u, 0u};
-    if (x < F.gb.x0 + F.gb.w && y < F.gb.y0 + F.gb.h) sdi::TemporalPixel(F, g, x, y, stack, cnt);
+    if (F.Owns(x, y)) sdi::TemporalPixel(F, g, x, y, stack, cnt);
     FlushRayCounters(counters, cnt);
 }
 __global__ void __launch_bounds__(kBlock) ZR_WAVES_SDI_S k_sdi_spatial(sdi::SkyFrame F, zr_frame_constants g, uint32_t tilesX, unsigned long long* counters)
 {
-    uint32_t x, y; PixelOfThread(tilesX, F.gb.x0, F.gb.y0, &x, &y);
+    uint32_t x, y; PixelOfThread(tilesX, F.ox0, F.oy0, &x, &y);
     ZR_TRAV_STACK(stack);
     uint32_t cnt[2] = {0u, 0u};
-    if (x < F.gb.x0 + F.gb.w && y < F.gb.y0 + F.gb.h) sdi::SpatialPixel(F, g, x, y, stack, cnt);
+    if (F.Owns(x, y)) sdi::SpatialPixel(F, g, x, y, stack, cnt);
     FlushRayCounters(counters, cnt);
 }
 
@@ -1094,13 +1094,12 @@ static int RenderPreLighting(zr_pass* p, hipStream_t s, const zr_frame_constants
 }
 
 // DirectLighting::Render (DirectLighting.cpp:166-296)
-static int RenderDirectEmissive(zr_pass* p, hipStream_t s, const zr_frame_constants* cb, const zr_scene* sc, zr_gbuffer* gb)
+static int RenderDirectEmissive(zr_pass* p, hipStream_t s, const zr_frame_constants* cb, const zr_scene* sc, zr_gbuffer* gb, int stages)
 {
     using namespace rdi;
     if (!gb) return Fail(ZR_ERR_INVALID_ARG, "DI_EMISSIVE pass needs a gbuffer");
     if (gb->w != p->w || gb->h != p->h) return Fail(ZR_ERR_INVALID_ARG, "gbuffer / pass size mismatch");
-    if (gb->x0 || gb->y0 || gb->w != cb->render_width || gb->h != cb->render_height)
-        return Fail(ZR_ERR_UNSUPPORTED, "DI_EMISSIVE needs the whole frame on one device (its screen-tile halo exchange is not implemented yet)");
+    if (gb->x0 + gb->w > cb->render_width || gb->y0 + gb->h > cb->render_height) return Fail(ZR_ERR_INVALID_ARG, "gbuffer tile outside the render target");
     if (sc->view.numEmissives == 0) return Fail(ZR_ERR_INVALID_ARG, "DI_EMISSIVE needs emissive triangles");
     if (!sc->view.alias) return Fail(ZR_ERR_NOT_INITIALIZED, "emissive alias table missing: render the PRELIGHTING pass first");
     if (cb->num_emissive_triangles != sc->view.numEmissives) return Fail(ZR_ERR_INVALID_ARG, "cbFrameConstants.NumEmissiveTriangles != scene");
@@ -1109,7 +1108,8 @@ static int RenderDirectEmissive(zr_pass* p, hipStream_t s, const zr_frame_consta
         return Fail(ZR_ERR_NOT_INITIALIZED, "presampled light sets missing or of another size: render the PRELIGHTING pass with the same presampling params first");
     DiFrame F;
     F.sc = sc->view; F.gb = gb->View(); F.gbPrev = gb->PrevView();
-    F.ox0 = 0; F.oy0 = 0; F.ow = gb->w; F.oh = gb->h;
+    F.ox0 = p->own[2] ? p->own[0] : gb->x0; F.oy0 = p->own[2] ? p->own[1] : gb->y0;
+    F.ow = p->own[2] ? p->own[2] : gb->w; F.oh = p->own[2] ? p->own[3] : gb->h;
     F.cur.A = p->diA[p->currIdx].p; F.cur.B = p->diB[p->currIdx].p; F.prev.A = p->diA[1 - p->currIdx].p; F.prev.B = p->diB[1 - p->currIdx].p;
     F.target = p->diTarget.p; F.finalRGBA = p->finalRGBA.p; F.sampleSet = p->diSampleSet.p;
     DiParams& prm = F.prm;
@@ -1118,11 +1118,15 @@ static int RenderDirectEmissive(zr_pass* p, hipStream_t s, const zr_frame_consta
     prm.doTemporal = (p->temporalValid && (ip.flags & ZR_IND_TEMPORAL_RESAMPLE) && gb->numRendered >= 2) ? 1u : 0u;
     prm.doSpatial = (prm.doTemporal && (ip.flags & ZR_IND_SPATIAL_RESAMPLE)) ? 1u : 0u;
     prm.writeReservoirs = (prm.doTemporal || !p->temporalValid) ? 1u : 0u;
-    const uint32_t tilesX = (p->w + 15) / 16, tilesY = (p->h + 15) / 16;
+    const uint32_t tilesX = (F.ow + 15) / 16, tilesY = (F.oh + 15) / 16;
     const dim3 grid(tilesX * tilesY), block(kBlock);
-    TimerBegin(p, s, "rdi_temporal");
-    hipLaunchKernelGGL(k_rdi_temporal, grid, block, 0, s, F, *cb, tilesX, p->counters.p + 2 * 8);
-    TimerEnd(p, s);
+    if (stages & ZR_STAGE_TEMPORAL)
+    {
+        TimerBegin(p, s, "rdi_temporal");
+        hipLaunchKernelGGL(k_rdi_temporal, grid, block, 0, s, F, *cb, tilesX, p->counters.p + 2 * 8);
+        TimerEnd(p, s);
+    }
+    if (!(stages & ZR_STAGE_SPATIAL)) { HIP_TRY(hipGetLastError()); return ZR_OK; }
     if (prm.doSpatial)
     {
         TimerBegin(p, s, "rdi_spatial");
@@ -1136,17 +1140,18 @@ static int RenderDirectEmissive(zr_pass* p, hipStream_t s, const zr_frame_consta
 }
 
 // SkyDI::Render (SkyDI.cpp:135-259)
-static int RenderDirectSky(zr_pass* p, hipStream_t s, const zr_frame_constants* cb, const zr_scene* sc, zr_gbuffer* gb)
+static int RenderDirectSky(zr_pass* p, hipStream_t s, const zr_frame_constants* cb, const zr_scene* sc, zr_gbuffer* gb, int stages)
 {
     using namespace sdi;
     if (!gb) return Fail(ZR_ERR_INVALID_ARG, "DI_SKY pass needs a gbuffer");
     if (gb->w != p->w || gb->h != p->h) return Fail(ZR_ERR_INVALID_ARG, "gbuffer / pass size mismatch");
-    if (gb->x0 || gb->y0 || gb->w != cb->render_width || gb->h != cb->render_height)
-        return Fail(ZR_ERR_UNSUPPORTED, "DI_SKY needs the whole frame on one device (its screen-tile halo exchange is not implemented yet)");
+    if (gb->x0 + gb->w > cb->render_width || gb->y0 + gb->h > cb->render_height) return Fail(ZR_ERR_INVALID_ARG, "gbuffer tile outside the render target");
     if (!sc->view.sky.data) return Fail(ZR_ERR_NOT_INITIALIZED, "sky-view LUT missing: render a ZR_PASS_SKY pass first");
     const zr_params& ip = p->params;
     SkyFrame F;
     F.sc = sc->view; F.gb = gb->View(); F.gbPrev = gb->PrevView();
+    F.ox0 = p->own[2] ? p->own[0] : gb->x0; F.oy0 = p->own[2] ? p->own[1] : gb->y0;
+    F.ow = p->own[2] ? p->own[2] : gb->w; F.oh = p->own[2] ? p->own[3] : gb->h;
     F.cur.A = p->skyA[p->currIdx].p; F.cur.B = p->skyB[p->currIdx].p; F.cur.C = p->skyC[p->currIdx].p;
     F.prev.A = p->skyA[1 - p->currIdx].p; F.prev.B = p->skyB[1 - p->currIdx].p; F.prev.C = p->skyC[1 - p->currIdx].p;
     F.target = p->diTarget.p; F.finalRGBA = p->finalRGBA.p;
@@ -1156,11 +1161,15 @@ static int RenderDirectSky(zr_pass* p, hipStream_t s, const zr_frame_constants* 
     prm.doTemporal = (p->temporalValid && (ip.flags & ZR_IND_TEMPORAL_RESAMPLE) && gb->numRendered >= 2) ? 1u : 0u;
     prm.doSpatial = (prm.doTemporal && (ip.flags & ZR_IND_SPATIAL_RESAMPLE)) ? 1u : 0u;
     prm.writeReservoirs = (prm.doTemporal || !p->temporalValid) ? 1u : 0u;
-    const uint32_t tilesX = (p->w + 15) / 16, tilesY = (p->h + 15) / 16;
+    const uint32_t tilesX = (F.ow + 15) / 16, tilesY = (F.oh + 15) / 16;
     const dim3 grid(tilesX * tilesY), block(kBlock);
-    TimerBegin(p, s, "sdi_temporal");
-    hipLaunchKernelGGL(k_sdi_temporal, grid, block, 0, s, F, *cb, tilesX, p->counters.p + 2 * 11);
-    TimerEnd(p, s);
+    if (stages & ZR_STAGE_TEMPORAL)
+    {
+        TimerBegin(p, s, "sdi_temporal");
+        hipLaunchKernelGGL(k_sdi_temporal, grid, block, 0, s, F, *cb, tilesX, p->counters.p + 2 * 11);
+        TimerEnd(p, s);
+    }
+    if (!(stages & ZR_STAGE_SPATIAL)) { HIP_TRY(hipGetLastError()); return ZR_OK; }
     if (prm.doSpatial)
     {
         TimerBegin(p, s, "sdi_spatial");
@@ -1177,12 +1186,11 @@ static int RenderDirectSky(zr_pass* p, hipStream_t s, const zr_frame_constants* 
 static int RenderReSTIR_GI(zr_pass* p, hipStream_t s, const zr_frame_constants* cb, const zr_scene* sc, zr_gbuffer* gb)
 {
     using namespace rgi;
-    if (gb->x0 || gb->y0 || gb->w != cb->render_width || gb->h != cb->render_height)
-        return Fail(ZR_ERR_UNSUPPORTED, "RESTIR_GI needs the whole frame on one device (its screen-tile halo exchange is not implemented yet)");
     const zr_params& ip = p->params;
     GiFrame F;
     F.sc = sc->view; F.gb = gb->View(); F.gbPrev = gb->PrevView();
-    F.ox0 = 0; F.oy0 = 0; F.ow = gb->w; F.oh = gb->h;
+    F.ox0 = p->own[2] ? p->own[0] : gb->x0; F.oy0 = p->own[2] ? p->own[1] : gb->y0;
+    F.ow = p->own[2] ? p->own[2] : gb->w; F.oh = p->own[2] ? p->own[3] : gb->h;
     F.cur.A = p->giA[p->currIdx].p; F.cur.B = p->giB[p->currIdx].p; F.cur.C = p->giC[p->currIdx].p;
     F.prev.A = p->giA[1 - p->currIdx].p; F.prev.B = p->giB[1 - p->currIdx].p; F.prev.C = p->giC[1 - p->currIdx].p;
     F.finalRGBA = p->finalRGBA.p;
@@ -1390,21 +1398,53 @@ static zr_pass::ResStorage* HaloSet(zr_pass* p, int which)
     // frame reads as "previous" is res[1 - currIdx]
     return &p->res[which == ZR_HALO_POST_TEMPORAL ? p->currIdx : 1 - p->currIdx];
 }
+struct HaloPlane { void* base; size_t bpp; };
+// the planes a halo transfer of this pass moves, and their bytes per pixel
+static int HaloPlanes(zr_pass* p, int which, HaloPlane* planes, size_t* bytesPerPixel)
+{
+    // between the stages of a frame the post-temporal set is [currIdx]; after the frame the set the next frame reads as
+    // "previous" is [1 - currIdx]
+    const int set = which == ZR_HALO_POST_TEMPORAL ? p->currIdx : 1 - p->currIdx;
+    int n = 0;
+    if (p->kind == ZR_PASS_INDIRECT && p->integrator == ZR_INTEGRATOR_RESTIR_PT)
+    {
+        zr_pass::ResStorage* R = &p->res[set];
+        const HaloPlane pl[7] = {{R->A.p, 4}, {R->B.p, 8}, {R->C.p, 16}, {R->D.p, 16}, {R->E.p, 2}, {R->F.p, 8}, {R->G.p, 8}};
+        for (auto& q : pl) planes[n++] = q;
+    }
+    else if (p->kind == ZR_PASS_INDIRECT && p->integrator == ZR_INTEGRATOR_RESTIR_GI)
+    { planes[n++] = {p->giA[set].p, 16}; planes[n++] = {p->giB[set].p, 8}; planes[n++] = {p->giC[set].p, 16}; }
+    else if (p->kind == ZR_PASS_DI_EMISSIVE) { planes[n++] = {p->diA[set].p, 16}; planes[n++] = {p->diB[set].p, 8}; }
+    else if (p->kind == ZR_PASS_DI_SKY) { planes[n++] = {p->skyA[set].p, 1}; planes[n++] = {p->skyB[set].p, 4}; planes[n++] = {p->skyC[set].p, 8}; }
+    size_t b = 0;
+    for (int i = 0; i < n; i++) b += planes[i].bpp;
+    *bytesPerPixel = b;
+    return n;
+}
+int zr_pass_halo_bytes_per_pixel(zr_pass* p, uint32_t* bytes)
+{
+    if (!p || !bytes) return Fail(ZR_ERR_INVALID_ARG, "null argument");
+    HaloPlane pl[8]; size_t b = 0;
+    if (!p->initialized || !HaloPlanes(p, ZR_HALO_FINAL, pl, &b)) return Fail(ZR_ERR_NOT_INITIALIZED, "pass has no reservoir planes to exchange (or is not initialised)");
+    *bytes = (uint32_t)b;
+    return ZR_OK;
+}
 static int HaloCopy(zr_pass* p, hipStream_t s, const zr_gbuffer* gb, int which, uint32_t x0, uint32_t y0, uint32_t w, uint32_t h, void* packed, size_t bytes, bool pack)
 {
     if (!p || !gb || !packed) return Fail(ZR_ERR_INVALID_ARG, "null argument");
-    if (p->kind != ZR_PASS_INDIRECT || p->integrator != ZR_INTEGRATOR_RESTIR_PT || !p->initialized) return Fail(ZR_ERR_NOT_INITIALIZED, "not an initialised RESTIR_PT pass");
+    HaloPlane planes[8]; size_t bpp = 0;
+    const int np = p->initialized ? HaloPlanes(p, which, planes, &bpp) : 0;
+    if (!np) return Fail(ZR_ERR_NOT_INITIALIZED, "pass has no reservoir planes to exchange (or is not initialised)");
     if (x0 < gb->x0 || y0 < gb->y0 || x0 + w > gb->x0 + gb->w || y0 + h > gb->y0 + gb->h) return Fail(ZR_ERR_INVALID_ARG, "halo rect lies outside this device's planes");
     const size_t n = (size_t)w * h;
-    if (bytes != n * ZR_HALO_BYTES_PER_PIXEL) return Fail(ZR_ERR_INVALID_ARG, "halo buffer must hold %zu bytes", n * ZR_HALO_BYTES_PER_PIXEL);
+    if (bytes != n * bpp) return Fail(ZR_ERR_INVALID_ARG, "halo buffer must hold %zu bytes", n * bpp);
     if (!n) return ZR_OK;
     HIP_TRY(hipSetDevice(p->device));
-    zr_pass::ResStorage* R = HaloSet(p, which);
-    struct { void* base; size_t bpp; } planes[7] = {{R->A.p, 4}, {R->B.p, 8}, {R->C.p, 16}, {R->D.p, 16}, {R->E.p, 2}, {R->F.p, 8}, {R->G.p, 8}};
     char* cursor = (char*)packed;
     const size_t first = (size_t)(y0 - gb->y0) * gb->w + (x0 - gb->x0);
-    for (auto& pl : planes)
+    for (int i = 0; i < np; i++)
     {
+        const HaloPlane& pl = planes[i];
         char* tile = (char*)pl.base + first * pl.bpp;
         if (pack) HIP_TRY(hipMemcpy2DAsync(cursor, w * pl.bpp, tile, gb->w * pl.bpp, w * pl.bpp, h, hipMemcpyDeviceToDevice, s));
         else HIP_TRY(hipMemcpy2DAsync(tile, gb->w * pl.bpp, cursor, w * pl.bpp, w * pl.bpp, h, hipMemcpyDeviceToDevice, s));
@@ -1431,8 +1471,8 @@ int zr_pass_render_stage(zr_pass* p, void* stream, const zr_frame_constants* cb,
     case ZR_PASS_GBUFFER: return (stages & ZR_STAGE_TEMPORAL) ? RenderGBuffer(p, s, cb, sc, gb) : ZR_OK;
     case ZR_PASS_PRELIGHTING: return (stages & ZR_STAGE_TEMPORAL) ? RenderPreLighting(p, s, cb, const_cast<zr_scene*>(sc)) : ZR_OK;
     case ZR_PASS_INDIRECT: return RenderIndirect(p, s, cb, sc, gb, stages);
-    case ZR_PASS_DI_EMISSIVE: return (stages & ZR_STAGE_TEMPORAL) ? RenderDirectEmissive(p, s, cb, sc, gb) : ZR_OK;
-    case ZR_PASS_DI_SKY: return (stages & ZR_STAGE_TEMPORAL) ? RenderDirectSky(p, s, cb, sc, gb) : ZR_OK;
+    case ZR_PASS_DI_EMISSIVE: return RenderDirectEmissive(p, s, cb, sc, gb, stages);
+    case ZR_PASS_DI_SKY: return RenderDirectSky(p, s, cb, sc, gb, stages);
     case ZR_PASS_COMPOSITING: return (stages & ZR_STAGE_SPATIAL) ? RenderCompositing(p, s, cb, gb) : ZR_OK;
     case ZR_PASS_SKY: return (stages & ZR_STAGE_TEMPORAL) ? RenderSky(p, s, cb, const_cast<zr_scene*>(sc)) : ZR_OK;
     default: return Fail(ZR_ERR_UNSUPPORTED, "pass kind %d not implemented", p->kind);

@@ -111,7 +111,12 @@ ZR_HD bool IsShiftInvertible(const Reservoir& r_base, const Surface& surface_off
 { return !r_base.halfVectorCopyShift || (IsLobeValid(surface_offset, r_base.lobe) && (LobeAlpha(surface_offset, r_base.lobe) <= alpha_min)); }
 
 struct SkyParams { uint32_t M_max_sky, M_max_sun, accumulate, doTemporal, doSpatial, writeReservoirs; float alpha_min; };
-struct SkyFrame { SceneView sc; GBuf gb, gbPrev; SkyPlanes cur, prev; F4* target; float* finalRGBA; SkyParams prm; };
+struct SkyFrame
+{
+    SceneView sc; GBuf gb, gbPrev; SkyPlanes cur, prev; F4* target; float* finalRGBA; SkyParams prm;
+    uint32_t ox0, oy0, ow, oh;       // owned rect (global pixels): the part of the planes this device shades (multi-GPU tile split)
+    ZR_HDM bool Owns(uint32_t x, uint32_t y) const { return x >= ox0 && y >= oy0 && x < ox0 + ow && y < oy0 + oh; }
+};
 struct Ctx { const SceneView* sc; const zr_frame_constants* g; TravStack stack; uint32_t* cnt; };
 
 // RtRayQuery::Visibility_Ray, RayQuery.hlsli:302-334

@@ -64,27 +64,41 @@ def halo_plan(w, h, n, rank, apron=APRON):
 
 
 class TiledRestirPT:
-    """One rank of the tile-split ReSTIR PT renderer on a GPU: G-buffer + PreLighting + Indirect (two stages) with the halo
-    exchange in between, through torch.distributed P2P (backend nccl == RCCL over xGMI on ROCm)."""
+    """One rank of a tile-split renderer on a GPU: G-buffer + PreLighting + the pass with cross-pixel reuse (two stages) with
+    the halo exchange in between, through torch.distributed P2P (backend nccl == RCCL over xGMI on ROCm).
 
-    def __init__(self, scene_host, width, height, world, rank, device=0, params=None, dist=None):
+    kind = "restir_pt" (default; Indirect, 62 B/px, exchanges post-temporal and final reservoirs), "restir_gi" (Indirect, 40 B/px,
+    one stage, final exchange only), "di" (ReSTIR DI emissive, 24 B/px) or "sky_di" (sun + sky ReSTIR DI, 13 B/px): the DI
+    passes exchange once, between their temporal and spatial stages."""
+
+    def __init__(self, scene_host, width, height, world, rank, device=0, params=None, dist=None, kind="restir_pt", pass_params=None):
         import torch
         from . import api
         self.api, self.torch, self.dist = api, torch, dist
+        self.kind = kind
         self.W, self.H, self.world, self.rank = width, height, world, rank
         self.tile = tile_rect(width, height, world, rank)
         self.ext = extended_rect(width, height, self.tile) if world > 1 else self.tile
         self.plan = halo_plan(width, height, world, rank) if world > 1 else []
         ex0, ey0, ew, eh = self.ext
-        self.r = api.Renderer(scene_host, ew, eh, device=device, params=params, integrator=api.INTEGRATOR_RESTIR_PT,
-                              tile_origin=(ex0, ey0))
+        integ = {"restir_pt": api.INTEGRATOR_RESTIR_PT, "restir_gi": api.INTEGRATOR_RESTIR_GI}.get(kind, api.INTEGRATOR_PATH_TRACING)
+        self.r = api.Renderer(scene_host, ew, eh, device=device, params=params, integrator=integ, tile_origin=(ex0, ey0))
+        if kind == "di":
+            self.hp = self.r.enable_direct(pass_params, device=device)
+            self.r.skip_indirect = True
+        elif kind == "sky_di":
+            self.hp = self.r.enable_sky_direct(pass_params, device=device)
+            self.r.skip_indirect = True
+        else:
+            self.hp = self.r.p_indirect          # the pass whose reservoirs cross tile borders
         if world > 1:
-            self.r.p_indirect.set_owned_rect(*self.tile)
+            self.hp.set_owned_rect(*self.tile)
         self.device = torch.device("cuda", device)
+        self.bpp = self.hp.halo_bytes_per_pixel()
         self.bufs = {}
         for peer, send, recv in self.plan:
-            sb = torch.empty(send[2] * send[3] * api.HALO_BYTES_PER_PIXEL, dtype=torch.uint8, device=self.device) if send else None
-            rb = torch.empty(recv[2] * recv[3] * api.HALO_BYTES_PER_PIXEL, dtype=torch.uint8, device=self.device) if recv else None
+            sb = torch.empty(send[2] * send[3] * self.bpp, dtype=torch.uint8, device=self.device) if send else None
+            rb = torch.empty(recv[2] * recv[3] * self.bpp, dtype=torch.uint8, device=self.device) if recv else None
             self.bufs[peer] = (sb, rb)
         self.halo_bytes = sum((sb.numel() if sb is not None else 0) for sb, _ in self.bufs.values())
 
@@ -93,14 +107,14 @@ class TiledRestirPT:
         for peer, send, recv in self.plan:
             if send:
                 sb = self.bufs[peer][0]
-                self.r.p_indirect.halo_pack(self.r.gbuffer, which, send, sb.data_ptr(), sb.numel())
+                self.hp.halo_pack(self.r.gbuffer, which, send, sb.data_ptr(), sb.numel())
 
     def unpack(self, which):
         """stage 3: scatter the received strips into my apron"""
         for peer, send, recv in self.plan:
             if recv:
                 rb = self.bufs[peer][1]
-                self.r.p_indirect.halo_unpack(self.r.gbuffer, which, recv, rb.data_ptr(), rb.numel())
+                self.hp.halo_unpack(self.r.gbuffer, which, recv, rb.data_ptr(), rb.numel())
 
     def exchange(self, which):
         if not self.plan:
@@ -120,28 +134,38 @@ class TiledRestirPT:
 
     def stage_temporal(self, cb):
         api, r = self.api, self.r
+        if r.p_sky is not None:
+            r.p_sky.render(cb, r.scene, None)
         r.p_gbuffer.render(cb, r.scene, r.gbuffer)
-        if not r._alias_ready or r._presampling:
+        if len(r.scene_host.emissives) and (not r._alias_ready or r._presampling):
             r.p_prelight.render(cb, r.scene, None)
             r._alias_ready = True
+        if self.kind in ("di", "sky_di"):
+            self.hp.render_stage(cb, r.scene, r.gbuffer, api.STAGE_TEMPORAL)
+            return
         if r.p_direct is not None:
             r.p_direct.render(cb, r.scene, r.gbuffer)
         r.p_indirect.render_stage(cb, r.scene, r.gbuffer, api.STAGE_TEMPORAL)
 
     def stage_spatial(self, cb):
-        self.r.p_indirect.render_stage(cb, self.r.scene, self.r.gbuffer, self.api.STAGE_SPATIAL)
+        self.hp.render_stage(cb, self.r.scene, self.r.gbuffer, self.api.STAGE_SPATIAL)
+
+    # which exchanges a frame of this kind needs: (post-temporal, final)
+    EXCHANGES = {"restir_pt": (True, True), "restir_gi": (False, True), "di": (True, False), "sky_di": (True, False)}
 
     def render_frame(self, cb, exchange_final=True):
         """exchange_final=False skips the post-frame exchange: valid for a static camera (reprojection stays in the tile)"""
+        post, final = self.EXCHANGES[self.kind]
         self.stage_temporal(cb)
-        self.exchange(self.api.HALO_POST_TEMPORAL)
+        if post:
+            self.exchange(self.api.HALO_POST_TEMPORAL)
         self.stage_spatial(cb)
-        if exchange_final:
+        if final and exchange_final:
             self.exchange(self.api.HALO_FINAL)
 
     def final_tile(self):
         """(tile rect, RGBA32F array of the owned tile)"""
-        full = self.r.final()
+        full = self.hp.download()
         x0, y0, tw, th = self.tile
         ex0, ey0 = self.ext[0], self.ext[1]
         return self.tile, full[y0 - ey0:y0 - ey0 + th, x0 - ex0:x0 - ex0 + tw].copy()
