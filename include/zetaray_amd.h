@@ -97,7 +97,14 @@ typedef struct zr_params {
     uint32_t presampling;           /* SetLightPresamplingParams(bool, numSets, setSize) */
     uint32_t num_sample_sets;       /* 128 */
     uint32_t sample_set_size;       /* 512 */
-    uint32_t reserved[7];
+    /* Light voxel grid (K4; PreLighting::SetLightVoxelGridParams / IndirectLighting::SetLightVoxelGridParams, off by default like
+       DefaultRendererImpl.h:73-77; needs presampling, IndirectLighting.h:93).  PRELIGHTING builds the grid every frame around the
+       camera; ReSTIR GI then samples lights from it on bounces > 0 (the ReSTIR_GI_LVG shader variant). */
+    uint32_t use_lvg;               /* 0 */
+    uint32_t lvg_grid_dim;          /* x | y << 10 | z << 20; reference default (32, 8, 40) */
+    float    lvg_extents[3];        /* voxel half extents; reference default (0.6, 0.45, 0.6) */
+    float    lvg_offset_y;          /* 0.1 */
+    uint32_t reserved[1];
 } zr_params;
 
 /* outputs, GetOutput(SHADER_OUT_RES) */
@@ -179,6 +186,8 @@ int zr_scene_set_alias_table(zr_scene* scene, const zr_alias_entry* entries, uin
 /* ... or build it from per-triangle power exactly like PreLighting.cpp:27-158 (host side, bit-exact) */
 int zr_alias_table_build(const float* power, uint32_t n, uint32_t align_phase, zr_alias_entry* out_entries);
 int zr_scene_get_alias_table(const zr_scene* scene, zr_alias_entry* out_entries, uint32_t n);
+/* K4 output (PreLighting::GetLightVoxelGrid, GlobalResource::LIGHT_VOXEL_GRID): dim.x * dim.y * dim.z * 64 samples, voxel-major */
+int zr_scene_get_light_voxel_grid(const zr_scene* scene, void* hip_stream, zr_voxel_sample* out_samples, uint32_t n);
 /* BVH introspection for tests / the CPU baseline */
 int zr_scene_bvh_info(const zr_scene* scene, uint32_t* num_nodes, uint32_t* num_tris, uint32_t* max_depth);
 

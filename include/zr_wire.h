@@ -95,6 +95,17 @@ typedef struct zr_presampled_tri {
     uint16_t two_sided;
 } zr_presampled_tri;
 
+/* reference: RtCommon.h:324-332 (32 B): one of the 64 light samples of a light-voxel-grid voxel */
+typedef struct zr_voxel_sample {
+    float    pos[3];
+    uint16_t normal[2];
+    float    pdf;
+    uint32_t id;
+    uint16_t le[3];      /* half3 */
+    uint16_t two_sided;
+} zr_voxel_sample;
+#define ZR_LVG_SAMPLES_PER_VOXEL 64u   /* NUM_SAMPLES_PER_VOXEL, PreLighting_Common.h:14 */
+
 /* reference: Source/ZetaRenderPass/Common/FrameConstants.h:10-78 (544 B).  Row-major 3x4 matrices. */
 typedef struct zr_frame_constants {
     float curr_view[12];

@@ -36,6 +36,7 @@ def lib():
         L.zro_trace_closest_timed.restype = C.c_double
         L.zro_trace_closest_timed.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]
         L.zro_presample.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p]
+        L.zro_build_lvg.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p]
         L.zro_sky_lut.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]
         L.zro_le_sky.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]
         L.zro_le_sun.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]
@@ -107,6 +108,16 @@ class OracleScene:
         from zetaray_amd import wire
         out = np.zeros(num_sets * set_size, wire.PRESAMPLED_TRI)
         lib().zro_presample(self.h, frame_num, num_sets, set_size, out.ctypes.data)
+        return out
+
+    def build_lvg(self, cb, dim, extents, offset_y):
+        """K4: build and bind the light voxel grid; returns (dz, dy, dx, 64) wire.VOXEL_SAMPLE records"""
+        from zetaray_amd import wire
+        d = np.array(dim, np.uint32)
+        e = np.array(extents, np.float32)
+        out = np.zeros((int(d[2]), int(d[1]), int(d[0]), 64), wire.VOXEL_SAMPLE)
+        cbb = np.ascontiguousarray(cb)
+        lib().zro_build_lvg(self.h, cbb.ctypes.data, d.ctypes.data, e.ctypes.data, float(offset_y), out.ctypes.data)
         return out
 
     def sky_lut(self, cb, w=256, h=128):

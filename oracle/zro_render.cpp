@@ -692,6 +692,24 @@ int zro_pathtrace_render(const zro_scene* h, const zr_frame_constants* cb, const
     return 0;
 }
 
+// K4 BuildLightVoxelGrid.hlsl: dim.x * dim.y * dim.z voxels x 64 samples, bound to the scene
+int zro_build_lvg(zro_scene* h, const zr_frame_constants* cb, const uint32_t* dim, const float* extents, float offset_y, zr_voxel_sample* out)
+{
+    Scene& sc = h->s;
+    const size_t nv = (size_t)dim[0] * dim[1] * dim[2];
+    sc.lvgData.resize(nv * 64);
+    for (int a = 0; a < 3; a++) { sc.lvgDim[a] = dim[a]; sc.lvgExtents[a] = extents[a]; }
+    sc.lvgOffsetY = offset_y;
+    const float3 e = f3(extents[0], extents[1], extents[2]);
+    for (uint32_t z = 0; z < dim[2]; z++) for (uint32_t y = 0; y < dim[1]; y++) for (uint32_t x = 0; x < dim[0]; x++)
+    {
+        const int v[3] = {(int)x, (int)y, (int)z};
+        LVG::BuildVoxel(sc, *cb, dim, e, offset_y, (int)x, (int)y, (int)z, sc.lvgData.data() + (size_t)LVG::FlattenVoxelIndex(v, dim) * 64);
+    }
+    if (out) std::memcpy(out, sc.lvgData.data(), sc.lvgData.size() * sizeof(zr_voxel_sample));
+    return 0;
+}
+
 // K17 SkyViewLUT.hlsl: w x h R11G11B10_FLOAT texels; bound to the scene (what Le_Sky samples)
 int zro_sky_lut(zro_scene* h, const zr_frame_constants* cb, uint32_t w, uint32_t ht, uint32_t* out)
 {

@@ -11,6 +11,7 @@
 // Out-of-range texel reads (negative coordinates of the temporal search) return 0, as D3D does.
 #pragma once
 #include "zro_rpt.h"
+#include "zro_lvg.h"
 
 namespace zro {
 namespace RGI {
@@ -84,6 +85,41 @@ static void WriteReservoir(State& st, int set, size_t i, const Reservoir& r, flo
     a[0] = r.pos.x; a[1] = r.pos.y; a[2] = r.pos.z; a[3] = zr_asfloat(r.ID);
     b[0] = zr_f32_to_f16(r.Lo.x); b[1] = zr_f32_to_f16(r.Lo.y); b[2] = zr_f32_to_f16(r.Lo.z); b[3] = zr_f32_to_f16(M_clamped);
     c[0] = r.w_sum; c[1] = r.W; c[2] = zr_asfloat(nu);
+}
+
+// RGI_Util::NEE_Emissive_LVG, ReSTIR_GI_NEE.hlsli:121-187 (numSamples = 1; globals.extents / offset_y are fp16, ReSTIR_GI.hlsl:51-53)
+static float3 NEE_Emissive_LVG(const Scene& sc, const zr_frame_constants& g, float3 pos, float3 normal, BSDF::ShadingData surface,
+    uint32_t sampleSetIdx, RNG& rng)
+{
+    float3 ret = f3(0.0f);
+    const float3 extents = f3(zr_round_f16(sc.lvgExtents[0]), zr_round_f16(sc.lvgExtents[1]), zr_round_f16(sc.lvgExtents[2]));
+    const float offset_y = zr_round_f16(sc.lvgOffsetY);
+    zr_voxel_sample s;
+    float3 lpos, lnormal, le; float lightPdf; uint32_t lightID;
+    if (LVG::Sample(pos, sc, 64, g.curr_view, s, rng, extents, offset_y))
+    {
+        lpos = f3(s.pos); lnormal = Math::DecodeOct32(s.normal);
+        le = f3(zr_f16_to_f32(s.le[0]), zr_f16_to_f32(s.le[1]), zr_f16_to_f32(s.le[2]));
+        lightPdf = s.pdf; lightID = s.id;
+        if (s.two_sided && dot(lnormal, pos - lpos) < 0) lnormal = lnormal * -1.0f;
+    }
+    else
+    {
+        Light::PresampledLight pl = Light::SamplePresampledSet(sc, sampleSetIdx, pos, rng);
+        lpos = pl.pos; lnormal = pl.normal; le = pl.le; lightPdf = pl.pdf; lightID = pl.ID;
+    }
+    const float t = length(lpos - pos);
+    const float3 wi = (lpos - pos) / t;
+    if (lightID != 0xffffffffu && dot(lnormal, -wi) > 0)
+    {
+        const float dwdA = zr_saturate(dot(lnormal, -wi)) / (t * t);
+        surface.SetWi(wi, normal);
+        le = le * (BSDF::Unified(surface).f * dwdA);
+        if (Math::Luminance(le) > 1e-6f)
+            le *= RtRayQuery::Visibility_Segment(sc, true, pos, wi, t, normal, lightID, surface.Transmissive()) ? 1.0f : 0.0f;
+        ret += le / zr_max(lightPdf, 1e-6f);
+    }
+    return ret;       // ld /= numSamples (1)
 }
 
 // NEE.hlsli:150-222 (NumSamples = 1)
@@ -442,6 +478,8 @@ static void Render(const Scene& sc, const zr_frame_constants& g, const zr_gbuffe
                     ld = NEE_SunSky(sc, g, hitPos, P.hitInfo.normal, P.psurface, P.rngThread);
                 else if (P.bounce == 0)
                     ld = NEE_Emissive_MIS(sc, 1, true, hitPos, P.hitInfo.normal, P.psurface, g.num_emissive_triangles, P.rngThread, presampled, P.sampleSetIdx, true);
+                else if (prm.use_lvg && presampled)      // USE_LVG && USE_PRESAMPLED_SETS (ReSTIR_GI_NEE.hlsli:240-243)
+                    ld = NEE_Emissive_LVG(sc, g, hitPos, P.hitInfo.normal, P.psurface, P.sampleSetIdx, P.rngThread);
                 else
                     ld = NEE_Emissive_Power(sc, hitPos, P.hitInfo.normal, P.psurface, g.num_emissive_triangles, presampled, P.sampleSetIdx, P.rngThread);
                 P.li += P.throughput * ld;

@@ -79,6 +79,8 @@ struct Scene
     std::vector<zr_alias_entry> alias;
     std::vector<zr_presampled_tri> sampleSets;   // K3 output (PresampleEmissives.hlsl), numSets x setSize
     uint32_t sampleSetSize = 0;
+    std::vector<zr_voxel_sample> lvgData;        // K4 output (BuildLightVoxelGrid.hlsl): 64 samples per voxel
+    uint32_t lvgDim[3] = {0, 0, 0}; float lvgExtents[3] = {0, 0, 0}; float lvgOffsetY = 0;
     std::vector<uint32_t> skyData;               // K17 output (SkyViewLUT.hlsl), R11G11B10_FLOAT texels
     SkyLUT sky;
     std::vector<uint16_t> rho;

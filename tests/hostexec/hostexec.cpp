@@ -26,7 +26,7 @@ struct HxScene
 {
     std::vector<zr_vertex> vertices; std::vector<uint32_t> indices; std::vector<zr_mesh_instance> instances;
     std::vector<zr_material> materials; std::vector<zr_emissive_triangle> emissives; std::vector<zr_alias_entry> alias;
-    std::vector<uint16_t> rho; BuiltBvh bvh; SceneView view; std::vector<zr_presampled_tri> sampleSets; std::vector<uint32_t> skyLut;
+    std::vector<uint16_t> rho; BuiltBvh bvh; SceneView view; std::vector<zr_presampled_tri> sampleSets; std::vector<uint32_t> skyLut; std::vector<zr_voxel_sample> lvg;
 };
 
 struct HxQueue
@@ -93,6 +93,25 @@ void zhx_presample(HxScene* s, uint32_t frame_num, uint32_t num_sets, uint32_t s
     for (uint32_t i = 0; i < total; i++) s->sampleSets[i] = PresampleEmissive(s->view, i, frame_num, s->view.numEmissives);
     s->view.sampleSets = s->sampleSets.data(); s->view.sampleSetSize = set_size;
     if (out) std::memcpy(out, s->sampleSets.data(), (size_t)total * sizeof(zr_presampled_tri));
+}
+// K4 through the device stage functions: the 64 threads of a voxel serially, group sums = the canonical butterfly
+void zhx_build_lvg(HxScene* s, const zr_frame_constants* cb, const uint32_t* dim, const float* extents, float offset_y, zr_voxel_sample* out)
+{
+    const size_t nv = (size_t)dim[0] * dim[1] * dim[2];
+    s->lvg.resize(nv * 64);
+    const V3 ext = v3(extents[0], extents[1], extents[2]);
+    for (uint32_t z = 0; z < dim[2]; z++) for (uint32_t y = 0; y < dim[1]; y++) for (uint32_t x = 0; x < dim[0]; x++)
+    {
+        const int v[3] = {(int)x, (int)y, (int)z};
+        zr_voxel_sample r[64]; float w[64], tz[64]; uint32_t n = 0;
+        for (uint32_t t = 0; t < 64; t++) { uint32_t nl; LvgThread(s->view, *cb, dim, ext, offset_y, v, t, r[t], w[t], tz[t], nl); n += nl; }
+        const float sum = rpt::ButterflySum64(w);
+        for (uint32_t t = 0; t < 64; t++) { LvgFinish(r[t], tz[t], sum, n); s->lvg[(size_t)LvgFlatten(v, dim) * 64 + t] = r[t]; }
+    }
+    s->view.lvg = s->lvg.data();
+    for (int a = 0; a < 3; a++) { s->view.lvgDim[a] = dim[a]; s->view.lvgExtents[a] = extents[a]; }
+    s->view.lvgOffsetY = offset_y;
+    if (out) std::memcpy(out, s->lvg.data(), s->lvg.size() * sizeof(zr_voxel_sample));
 }
 // K17 through the device stage function; binds the LUT to the scene like ZR_PASS_SKY does
 void zhx_sky_lut(HxScene* s, const zr_frame_constants* cb, uint32_t w, uint32_t h, uint32_t* out)
@@ -475,6 +494,7 @@ void zhx_rgi_render(const HxScene* s, HxRgi* R, const zr_frame_constants* cb, co
     prm.doTemporal = ((params->flags & ZR_IND_TEMPORAL_RESAMPLE) && R->temporalValid && prev) ? 1u : 0u;
     prm.writeReservoirs = (prm.doTemporal || !R->temporalValid) ? 1u : 0u;
     prm.M_max = (float)params->m_max_temporal;
+    prm.useLVG = (params->use_lvg && params->presampling) ? 1u : 0u;
     zr::StackEntry stackMem[zr::kTravStack]; zr::TravStack stack; stack.lds = nullptr; stack.stride = 0; stack.mem = stackMem;
     std::vector<Lane> L(64);
     float wsum[64];

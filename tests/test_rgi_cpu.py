@@ -115,3 +115,40 @@ def test_rgi_sun_sky_bit_exact(kind):
         assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), f"frame {f}: radiance differs"
         _same(o, x, f)
     assert a[..., :3].max() > 0
+
+
+def test_light_voxel_grid_and_rgi_lvg_bit_exact():
+    """K4 (BuildLightVoxelGrid) + the ReSTIR_GI_LVG variant: the grid's 64 samples per voxel (position, oct normal, half radiance,
+    pdf from the group-wide RIS mean, light ID) and 3 GI frames that draw their bounce > 0 lights from it, bit-exact."""
+    sc = scene_io.make_synthetic_scene(num_tris=2000, num_emissive=600, seed=3)
+    osc = zro.OracleScene(sc, force_bvh=True)
+    hx = zhx.HostExecScene(sc, osc.alias)
+    w, h = 56, 40
+    prm = wire.default_params()
+    prm.presampling, prm.num_sample_sets, prm.sample_set_size = 1, 16, 64
+    prm.use_lvg = 1
+    dim, ext, off = (8, 4, 10), (0.6, 0.45, 0.6), 0.1
+    prm.lvg_grid_dim = dim[0] | (dim[1] << 10) | (dim[2] << 20)
+    prm.lvg_extents[:] = ext
+    prm.lvg_offset_y = off
+    o, x = zro.OracleRGI(osc, w, h), zhx.HostExecRGI(hx, w, h)
+    for f in range(1, 4):
+        cb = _cb(sc, w, h, f, cam_pos=(0.0, 0.0, -3.5))
+        osc.presample(f, 16, 64)
+        hx.presample(f, 16, 64)
+        ga, gb = osc.build_lvg(cb, dim, ext, off), hx.build_lvg(cb, dim, ext, off)
+        assert np.array_equal(ga.view(np.uint8), gb.view(np.uint8)), f"frame {f}: light voxel grid differs"
+        a, b = o.render(cb, prm), x.render(cb, prm)
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), f"frame {f}: radiance differs"
+        _same(o, x, f)
+    valid = ga["id"] != 0xFFFFFFFF
+    assert valid.mean() > 0.5 and (ga["pdf"][valid] > 0).all()
+    # the LVG variant really changes the estimator's samples (same RNG stream, different light choice on bounces > 0)
+    prm2 = wire.default_params()
+    prm2.presampling, prm2.num_sample_sets, prm2.sample_set_size = 1, 16, 64
+    o2 = zro.OracleRGI(osc, w, h)
+    cb = _cb(sc, w, h, 1, cam_pos=(0.0, 0.0, -3.5))
+    osc.presample(1, 16, 64)
+    osc.build_lvg(cb, dim, ext, off)
+    o3 = zro.OracleRGI(osc, w, h)
+    assert not np.array_equal(o2.render(cb, prm2), o3.render(cb, prm))

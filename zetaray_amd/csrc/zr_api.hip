@@ -289,6 +289,22 @@ __global__ void k_estimate_power(const zr_emissive_triangle* em, uint32_t n, flo
     if (i < n) power[i] = EstimateTriPower(em[i]);
 }
 
+__device__ __forceinline__ float WaveSumButterfly(float v);
+// K4 light voxel grid: one wave64 per voxel = the reference's 64-thread group; the group sums are wave reductions
+__global__ void __launch_bounds__(64) k_build_lvg(SceneView sc, zr_frame_constants g, uint32_t dx, uint32_t dy, uint32_t dz, float ex, float ey, float ez,
+    float offset_y, zr_voxel_sample* out)
+{
+    const uint32_t dim[3] = {dx, dy, dz};
+    const int v[3] = {(int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z};
+    zr_voxel_sample r; float w_sum, target_z; uint32_t numLights;
+    LvgThread(sc, g, dim, v3(ex, ey, ez), offset_y, v, threadIdx.x, r, w_sum, target_z, numLights);
+    const float w_sum_group = WaveSumButterfly(w_sum);
+    uint32_t n = numLights;
+    for (int s = 1; s < 64; s <<= 1) n += __shfl_xor(n, s);
+    LvgFinish(r, target_z, w_sum_group, n);
+    out[(size_t)LvgFlatten(v, dim) * ZR_LVG_SAMPLES_PER_VOXEL + threadIdx.x] = r;
+}
+
 // K17 sky-view LUT: one thread per texel, 8 x 8 threads per group like the reference (ALU-bound: ~300 exp per texel)
 __global__ void __launch_bounds__(64) k_sky_lut(zr_frame_constants g, uint32_t w, uint32_t h, uint32_t* out)
 {
@@ -523,6 +539,7 @@ struct zr_scene
     DevBuf<zr_emissive_triangle> emissives; DevBuf<zr_alias_entry> alias; DevBuf<Bvh4Node> nodes; DevBuf<BvhTri> tris;
     DevBuf<TriMeta> meta; DevBuf<uint16_t> rho;
     DevBuf<zr_presampled_tri> sampleSets; uint32_t numSampleSets = 0;      // K3 output, refreshed by every PRELIGHTING render
+    DevBuf<zr_voxel_sample> lvg;                                           // K4 output, rebuilt by every PRELIGHTING render when use_lvg
     std::vector<zr_alias_entry> aliasHost;
     SceneView view{};
     uint32_t maxDepth = 0;
@@ -754,6 +771,9 @@ int zr_params_default(zr_params* p)
                ZR_IND_SORT_TEMPORAL | ZR_IND_SORT_SPATIAL;
     p->max_non_tr_bounces = 3; p->max_glossy_tr_bounces = 4; p->m_max_temporal = 10; p->m_max_spatial = 8;
     p->alpha_min = 0.175f * 0.175f; p->presampling = 0; p->num_sample_sets = 128; p->sample_set_size = 512;
+    // light voxel grid: off; VOXEL_GRID_DIM (32, 8, 40), VOXEL_EXTENTS (0.6, 0.45, 0.6), y offset 0.1 (DefaultRendererImpl.h:42-43, 73-77)
+    p->use_lvg = 0; p->lvg_grid_dim = 32u | (8u << 10) | (40u << 20);
+    p->lvg_extents[0] = 0.6f; p->lvg_extents[1] = 0.45f; p->lvg_extents[2] = 0.6f; p->lvg_offset_y = 0.1f;
     return ZR_OK;
 }
 
@@ -818,6 +838,17 @@ int zr_scene_get_alias_table(const zr_scene* s, zr_alias_entry* out, uint32_t n)
     if (!s || !out) return Fail(ZR_ERR_INVALID_ARG, "null argument");
     if (n != s->aliasHost.size()) return Fail(ZR_ERR_INVALID_ARG, "alias table has %zu entries", s->aliasHost.size());
     memcpy(out, s->aliasHost.data(), n * sizeof(zr_alias_entry));
+    return ZR_OK;
+}
+
+int zr_scene_get_light_voxel_grid(const zr_scene* s, void* stream, zr_voxel_sample* out, uint32_t n)
+{
+    if (!s || !out) return Fail(ZR_ERR_INVALID_ARG, "null argument");
+    if (!s->view.lvg) return Fail(ZR_ERR_NOT_INITIALIZED, "no light voxel grid: render the PRELIGHTING pass with use_lvg first");
+    if (n != s->lvg.n) return Fail(ZR_ERR_INVALID_ARG, "the light voxel grid has %zu samples", s->lvg.n);
+    HIP_TRY(hipSetDevice(s->device));
+    HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+    HIP_TRY(hipMemcpy(out, s->lvg.p, (size_t)n * sizeof(zr_voxel_sample), hipMemcpyDeviceToHost));
     return ZR_OK;
 }
 
@@ -1023,6 +1054,13 @@ int zr_pass_set_params(zr_pass* p, const zr_params* prm)
     if (p->kind == ZR_PASS_DI_EMISSIVE && (prm->m_max_temporal < 1 || prm->m_max_temporal > 30)) return Fail(ZR_ERR_INVALID_ARG, "DI M_max must be in 1..30");
     if (p->kind == ZR_PASS_DI_SKY && (prm->m_max_temporal < 1 || prm->m_max_temporal > 15 || prm->m_max_spatial < 1 || prm->m_max_spatial > 15))
         return Fail(ZR_ERR_INVALID_ARG, "sky DI M_max (sky = m_max_temporal, sun = m_max_spatial) must be in 1..15");
+    if (prm->use_lvg)
+    {
+        const uint32_t dx = prm->lvg_grid_dim & 1023u, dy = (prm->lvg_grid_dim >> 10) & 1023u, dz = (prm->lvg_grid_dim >> 20) & 1023u;
+        if (!prm->presampling) return Fail(ZR_ERR_INVALID_ARG, "the light voxel grid needs light presampling (IndirectLighting.h:93)");
+        if (!dx || !dy || !dz || !(prm->lvg_extents[0] > 0) || !(prm->lvg_extents[1] > 0) || !(prm->lvg_extents[2] > 0))
+            return Fail(ZR_ERR_INVALID_ARG, "light voxel grid: dimension / extents must be positive");
+    }
     if (prm->max_non_tr_bounces < 1 || prm->max_non_tr_bounces > 15 || prm->max_glossy_tr_bounces < 1 || prm->max_glossy_tr_bounces > 15)
         return Fail(ZR_ERR_INVALID_ARG, "bounce counts must be in 1..15");
     if (prm->presampling && (prm->num_sample_sets == 0 || prm->sample_set_size == 0 || prm->num_sample_sets > 65535 || prm->sample_set_size > 65535))
@@ -1070,7 +1108,32 @@ static int RenderPresample(zr_pass* p, hipStream_t s, const zr_frame_constants* 
     return ZR_OK;
 }
 
+// K4: PreLighting::Render light-voxel-grid branch (PreLighting.cpp:405-428): every frame (the grid follows the camera)
+static int RenderLVG(zr_pass* p, hipStream_t s, const zr_frame_constants* cb, zr_scene* sc)
+{
+    const zr_params& ip = p->params;
+    const uint32_t dx = ip.lvg_grid_dim & 1023u, dy = (ip.lvg_grid_dim >> 10) & 1023u, dz = (ip.lvg_grid_dim >> 20) & 1023u;
+    const size_t total = (size_t)dx * dy * dz * ZR_LVG_SAMPLES_PER_VOXEL;
+    if (sc->lvg.n != total) { int r = sc->lvg.Alloc(total); if (r) return r; }
+    TimerBegin(p, s, "build_lvg");
+    hipLaunchKernelGGL(k_build_lvg, dim3(dx, dy, dz), dim3(64), 0, s, sc->view, *cb, dx, dy, dz, ip.lvg_extents[0], ip.lvg_extents[1], ip.lvg_extents[2],
+        ip.lvg_offset_y, sc->lvg.p);
+    TimerEnd(p, s);
+    HIP_TRY(hipGetLastError());
+    sc->view.lvg = sc->lvg.p; sc->view.lvgDim[0] = dx; sc->view.lvgDim[1] = dy; sc->view.lvgDim[2] = dz;
+    for (int a = 0; a < 3; a++) sc->view.lvgExtents[a] = ip.lvg_extents[a];
+    sc->view.lvgOffsetY = ip.lvg_offset_y;
+    return ZR_OK;
+}
+
+static int RenderPreLightingInner(zr_pass* p, hipStream_t s, const zr_frame_constants* cb, zr_scene* sc);
 static int RenderPreLighting(zr_pass* p, hipStream_t s, const zr_frame_constants* cb, zr_scene* sc)
+{
+    int r = RenderPreLightingInner(p, s, cb, sc);
+    if (r || !p->params.use_lvg || sc->view.numEmissives == 0) return r;
+    return RenderLVG(p, s, cb, sc);
+}
+static int RenderPreLightingInner(zr_pass* p, hipStream_t s, const zr_frame_constants* cb, zr_scene* sc)
 {
     const uint32_t n = sc->view.numEmissives;
     if (n == 0) return ZR_OK;
@@ -1201,6 +1264,8 @@ static int RenderReSTIR_GI(zr_pass* p, hipStream_t s, const zr_frame_constants* 
     prm.doTemporal = ((ip.flags & ZR_IND_TEMPORAL_RESAMPLE) && p->temporalValid && gb->numRendered >= 2) ? 1u : 0u;
     prm.writeReservoirs = (prm.doTemporal || !p->temporalValid) ? 1u : 0u;
     prm.M_max = (float)ip.m_max_temporal;
+    prm.useLVG = (ip.use_lvg && ip.presampling) ? 1u : 0u;
+    if (prm.useLVG && !sc->view.lvg) return Fail(ZR_ERR_NOT_INITIALIZED, "light voxel grid missing: render the PRELIGHTING pass with use_lvg first");
     const uint32_t tilesX = (p->w + 15) / 16, tilesY = (p->h + 15) / 16;
     TimerBegin(p, s, "rgi");
     hipLaunchKernelGGL(k_rgi, dim3(tilesX * tilesY), dim3(kBlock), 0, s, F, *cb, tilesX, p->counters.p + 2 * 10);

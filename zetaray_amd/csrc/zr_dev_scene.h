@@ -49,6 +49,8 @@ struct SceneView
     const zr_presampled_tri* sampleSets;   // K3 output: numSampleSets x sampleSetSize (null until a PRELIGHTING pass presampled)
     uint32_t sampleSetSize;
     SkyLutView sky;                        // K17 output (null until a SKY pass rendered)
+    const zr_voxel_sample* lvg;            // K4 output: lvgDim.x * y * z voxels x 64 samples (null unless PRELIGHTING built it)
+    uint32_t lvgDim[3]; float lvgExtents[3]; float lvgOffsetY;
     const Bvh4Node* nodes;
     const BvhTri* tris;
     const TriMeta* triMeta;

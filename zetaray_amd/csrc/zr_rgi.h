@@ -11,6 +11,7 @@
 // Out-of-range texel reads of the temporal search return 0 (D3D rule).  Ray differentials are not carried (no textures).
 #pragma once
 #include "zr_rpt.h"
+#include "zr_lvg.h"
 
 namespace zr {
 namespace rgi {
@@ -38,7 +39,7 @@ struct Reservoir
 ZR_HD Reservoir InitReservoir()
 { Reservoir r; r.pos = v3(ZR_FLT_MAX); r.normal = v3(0.0f); r.Lo = v3(0.0f); r.M = 0; r.w_sum = 0; r.W = 0; r.ID = 0xffffffffu; r.target_z = v3(0.0f); return r; }
 
-struct GiParams { uint32_t flags, maxNonTrBounces, maxGlossyTrBounces, numSampleSets, accumulate, doTemporal, writeReservoirs; float M_max; };
+struct GiParams { uint32_t flags, maxNonTrBounces, maxGlossyTrBounces, numSampleSets, accumulate, doTemporal, writeReservoirs, useLVG; float M_max; };
 struct GiFrame
 {
     SceneView sc; GBuf gb, gbPrev; GiPlanes cur, prev; float* finalRGBA; GiParams prm;
@@ -113,6 +114,40 @@ ZR_HD LightDraw DrawLight(const Globals& g, V3 shadingPos, Rng& rng)
     d.pdf = lpdfSrc * lpdfPos;
     d.ID = em.id;
     return d;
+}
+
+// RGI_Util::NEE_Emissive_LVG, ReSTIR_GI_NEE.hlsli:121-187 (numSamples = 1; globals.extents / offset_y are fp16, ReSTIR_GI.hlsl:51-53)
+ZR_HD V3 NEE_Emissive_LVG(const Globals& gl, const zr_frame_constants& g, V3 pos, V3 normal, Surface surface, Rng& rng)
+{
+    const SceneView& sc = *gl.sc;
+    const V3 ext = v3(zr_round_f16(sc.lvgExtents[0]), zr_round_f16(sc.lvgExtents[1]), zr_round_f16(sc.lvgExtents[2]));
+    const float offset_y = zr_round_f16(sc.lvgOffsetY);
+    zr_voxel_sample s;
+    V3 lpos, lnormal, le; float lightPdf; uint32_t lightID;
+    if (LvgSample(sc, pos, g.curr_view, ext, offset_y, s, rng))
+    {
+        lpos = v3p(s.pos); lnormal = DecodeOct32(s.normal);
+        le = v3(zr_f16_to_f32(s.le[0]), zr_f16_to_f32(s.le[1]), zr_f16_to_f32(s.le[2]));
+        lightPdf = s.pdf; lightID = s.id;
+        if (s.two_sided && dot(lnormal, pos - lpos) < 0) lnormal = lnormal * -1.0f;
+    }
+    else
+    {
+        PresampledLight pl = SamplePresampledSet(sc, gl.sampleSetIdx, pos, rng);
+        lpos = pl.pos; lnormal = pl.normal; le = pl.le; lightPdf = pl.pdf; lightID = pl.ID;
+    }
+    V3 ret = v3(0.0f);
+    const float t = length(lpos - pos);
+    const V3 wi = (lpos - pos) / t;
+    if (lightID != 0xffffffffu && dot(lnormal, -wi) > 0)
+    {
+        const float dwdA = zr_saturate(dot(lnormal, -wi)) / (t * t);
+        surface.SetWi(wi, normal);
+        le = le * (Unified(sc.rho, surface).f * dwdA);
+        if (Luminance(le) > 1e-6f) le = le * (VisibilitySegmentApprox(gl, pos, wi, t, normal, lightID, surface.Transmissive()) ? 1.0f : 0.0f);
+        ret = ret + le / zr_max(lightPdf, 1e-6f);
+    }
+    return ret;
 }
 
 // RtRayQuery::Visibility_Ray (RayQuery.hlsli:302-334), traced in place
@@ -318,7 +353,9 @@ ZR_HD void PhaseA(const GiFrame& F, const zr_frame_constants& g, TravStack stack
     // RGI_Util::NEE (NEE_EMISSIVE == 1, USE_MIS == 1, MIS_ALL_BOUNCES == 0)
     V3 ld;
     if (g.num_emissive_triangles == 0) ld = NEE_SunSky(gl, g, hitPos, P.hit.normal, P.psurface, P.rngThread);     // NEE_EMISSIVE == 0
-    else ld = P.bounce == 0 ? NEE_Emissive_MIS(gl, hitPos, P.hit.normal, P.psurface, P.rngThread) : NEE_Emissive_Power(gl, hitPos, P.hit.normal, P.psurface, P.rngThread);
+    else if (P.bounce == 0) ld = NEE_Emissive_MIS(gl, hitPos, P.hit.normal, P.psurface, P.rngThread);
+    else if (F.prm.useLVG && gl.presampled) ld = NEE_Emissive_LVG(gl, g, hitPos, P.hit.normal, P.psurface, P.rngThread);     // USE_LVG && USE_PRESAMPLED_SETS
+    else ld = NEE_Emissive_Power(gl, hitPos, P.hit.normal, P.psurface, P.rngThread);
     P.li = P.li + P.throughput * ld;
     if (P.bounce >= (P.maxNumBounces - 1)) { P.active = false; return; }
     P.ppos = hitPos; P.pnormal = P.hit.normal;

@@ -35,6 +35,8 @@ assert ALIAS_ENTRY.itemsize == 16
 PRESAMPLED_TRI = np.dtype([("pos", "<f4", 3), ("normal", "<u2", 2), ("pdf", "<f4"), ("id", "<u4"), ("idx", "<u4"), ("bary", "<u2", 2),
                            ("le", "<u2", 3), ("two_sided", "<u2")])
 assert PRESAMPLED_TRI.itemsize == 40
+VOXEL_SAMPLE = np.dtype([("pos", "<f4", 3), ("normal", "<u2", 2), ("pdf", "<f4"), ("id", "<u4"), ("le", "<u2", 3), ("two_sided", "<u2")])
+assert VOXEL_SAMPLE.itemsize == 32
 
 FRAME_CONSTANTS = np.dtype([
     ("curr_view", "<f4", 12), ("prev_view", "<f4", 12), ("curr_view_inv", "<f4", 12), ("prev_view_inv", "<f4", 12),
@@ -93,7 +95,8 @@ class Params(C.Structure):
         ("flags", C.c_uint32), ("max_non_tr_bounces", C.c_uint32), ("max_glossy_tr_bounces", C.c_uint32),
         ("m_max_temporal", C.c_uint32), ("m_max_spatial", C.c_uint32), ("alpha_min", C.c_float),
         ("presampling", C.c_uint32), ("num_sample_sets", C.c_uint32), ("sample_set_size", C.c_uint32),
-        ("reserved", C.c_uint32 * 7)]
+        ("use_lvg", C.c_uint32), ("lvg_grid_dim", C.c_uint32), ("lvg_extents", C.c_float * 3), ("lvg_offset_y", C.c_float),
+        ("reserved", C.c_uint32 * 1)]
 
 
 class Counters(C.Structure):
@@ -123,6 +126,10 @@ def default_params() -> Params:
     p.presampling = 0
     p.num_sample_sets = 128
     p.sample_set_size = 512
+    p.use_lvg = 0
+    p.lvg_grid_dim = 32 | (8 << 10) | (40 << 20)
+    p.lvg_extents[:] = (0.6, 0.45, 0.6)
+    p.lvg_offset_y = 0.1
     return p
 
 
