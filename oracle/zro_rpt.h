@@ -118,13 +118,14 @@ static BSDF::BSDFSamplerEval EvalBSDFSampler_NoSpecTr(float3 normal, BSDF::Shadi
     return ret;
 }
 
-// BSDFSampling.hlsli:430-502 (NoOp target)
-static BSDF::BSDFSamplerEval EvalBSDFSampler_NoDiffuse(float3 normal, BSDF::ShadingData surface, float3 wi, LOBE lobe)
+// BSDFSampling.hlsli:430-502
+template<typename Func>
+static BSDF::BSDFSamplerEval EvalBSDFSampler_NoDiffuse(float3 normal, BSDF::ShadingData surface, float3 wi, LOBE lobe, Func func)
 {
     using namespace BSDF;
     float3 wh = surface.SetWi(wi, normal);
     BSDFEval eval = Unified(surface);
-    const float3 targetScale = f3(1.0f);
+    const float3 targetScale = func(wi);
     float pdf_base = 1;
     BSDFSamplerEval ret;
     ret.f = eval.f * targetScale;
@@ -145,9 +146,9 @@ static BSDF::BSDFSamplerEval EvalBSDFSampler_NoDiffuse(float3 normal, BSDF::Shad
     ret.pdf *= pdf_base;
     ret.bsdfOverPdf = ret.f / ret.pdf;
     if (surface.metallic || !surface.specTr || eval.tir) return ret;
-    (void)wh;
+    const float3 wi_other = lobe == LOBE::GLOSSY_T ? reflect(-surface.wo, wh) : refract(-surface.wo, wh, 1 / surface.eta);
     float targetScaleLum = Math::Luminance(targetScale);
-    float targetScaleOtherLum = Math::Luminance(f3(1.0f));
+    float targetScaleOtherLum = Math::Luminance(func(wi_other));
     float p_r = eval.Fr_g.x * (lobe == LOBE::GLOSSY_R ? targetScaleLum : targetScaleOtherLum);
     p_r = p_r / (p_r + (1 - eval.Fr_g.x) * (lobe == LOBE::GLOSSY_R ? targetScaleOtherLum : targetScaleLum));
     if (lobe == LOBE::GLOSSY_R)
@@ -180,7 +181,7 @@ static BSDF::BSDFSamplerEval EvalBSDFSampler(float3 normal, const BSDF::ShadingD
     float2 u_d = rng.Uniform2D();
     rng.Uniform(); rng.Uniform(); rng.Uniform();
     if (!surface.specTr) return EvalBSDFSampler_NoSpecTr(normal, surface, wi, lobe, u_c, u_g, u_d);
-    return EvalBSDFSampler_NoDiffuse(normal, surface, wi, lobe);
+    return EvalBSDFSampler_NoDiffuse(normal, surface, wi, lobe, BSDF::NoOp());
 }
 
 // NEE.hlsli:28-73
@@ -302,8 +303,8 @@ struct Reservoir
     { Reservoir r = Init(); r.UnpackMetadata(p.A[i]); return r; }
     static Reservoir Load_NonReconnection(const ReservoirPlanes& p, size_t i)
     { Reservoir r = Init(); r.UnpackMetadata(p.A[i]); r.w_sum = p.B[2 * i]; r.W = p.B[2 * i + 1]; return r; }
-    // Emissive == true variants of LoadCase1/2/3 (Reservoir.hlsli:47-139)
-    void Load_Reconnection(const ReservoirPlanes& p, size_t i)
+    // LoadCase1/2/3<Emissive> (Reservoir.hlsli:47-139)
+    void Load_Reconnection(const ReservoirPlanes& p, size_t i, bool emissive = true)
     {
         const uint32_t* inC = &p.C[4 * i]; const uint32_t* inD = &p.D[4 * i];
         auto oct = [](uint32_t e) { uint16_t v[2] = {(uint16_t)(e & 0xffff), (uint16_t)(e >> 16)}; return Math::DecodeOct32(v); };
@@ -314,6 +315,19 @@ struct Reservoir
             rc.x_k = f3(zr_asfloat(inC[3]), zr_asfloat(inD[0]), zr_asfloat(inD[1]));
             rc.meshIdx = p.G[2 * i + 1];
             rc.L = f3(zr_f16_to_f32(inD[3] & 0xffff), zr_f16_to_f32(inD[3] >> 16), zr_f16_to_f32(p.E[i]));
+        }
+        else if (rc.IsCase2() && !emissive)
+        {
+            rc.partialJacobian = zr_asfloat(inC[0]); rc.seed_replay = inC[1]; rc.ID = inC[2];
+            rc.x_k = f3(zr_asfloat(inC[3]), zr_asfloat(inD[0]), zr_asfloat(inD[1]));
+            if (rc.lt_k_plus_1 == TYPE::SKY) { rc.w_k_lightNormal_w_sky = oct(inD[2]); rc.seed_nee = inD[3]; }
+            rc.meshIdx = p.G[2 * i + 1];
+        }
+        else if (!rc.IsCase2() && !emissive)
+        {
+            rc.seed_replay = inC[1]; rc.ID = inC[2];
+            rc.partialJacobian = zr_asfloat(inC[0]);
+            if (rc.lt_k == TYPE::SKY) { rc.w_k_lightNormal_w_sky = oct(inD[2]); rc.seed_nee = inD[3]; }
         }
         else if (rc.IsCase2())
         {
@@ -335,11 +349,11 @@ struct Reservoir
             rc.w_k_lightNormal_w_sky = oct(inD[2]);
         }
     }
-    static Reservoir Load(const ReservoirPlanes& p, size_t i)
+    static Reservoir Load(const ReservoirPlanes& p, size_t i, bool emissive = true)
     {
         Reservoir r = Load_NonReconnection(p, i);
         if (r.rc.Empty()) return r;
-        r.Load_Reconnection(p, i);
+        r.Load_Reconnection(p, i, emissive);
         return r;
     }
     static uint32_t PackA_x(const Reconnection& rc, uint32_t m)
@@ -356,8 +370,8 @@ struct Reservoir
         p.A[i] = (p.A[i] & 0xffffff00u) | (PackA_x(rc, m) & 0xff);
         p.B[2 * i + 1] = W;
     }
-    // Write<Emissive = true>, Reservoir.hlsli:367-456
-    void Write(ReservoirPlanes& p, size_t i, uint32_t M_max = 0)
+    // Write<Emissive>, Reservoir.hlsli:283-330, 367-456 (the non-emissive variant writes only some components of C / D / G)
+    void Write(ReservoirPlanes& p, size_t i, uint32_t M_max = 0, bool emissive = true)
     {
         uint32_t m = M_max == 0 ? M : std::min<uint32_t>(M, M_max);
         uint32_t mx = PackA_x(rc, m) & 0xff;
@@ -377,6 +391,18 @@ struct Reservoir
             D[0] = zr_asuint(rc.x_k.y); D[1] = zr_asuint(rc.x_k.z); D[2] = w_k_encoded; D[3] = lh;
             p.E[i] = zr_f32_to_f16(rc.L.z);
             p.G[2 * i + 1] = rc.meshIdx;
+        }
+        else if (rc.IsCase2() && !emissive)
+        {
+            C[0] = zr_asuint(rc.partialJacobian); C[1] = rc.seed_replay; C[2] = rc.ID; C[3] = zr_asuint(rc.x_k.x);
+            if (rc.lt_k_plus_1 == TYPE::SKY) { D[0] = zr_asuint(rc.x_k.y); D[1] = zr_asuint(rc.x_k.z); D[2] = w_k_encoded; D[3] = rc.seed_nee; }
+            else { D[0] = zr_asuint(rc.x_k.y); D[1] = zr_asuint(rc.x_k.z); }
+            p.G[2 * i + 1] = rc.meshIdx;
+        }
+        else if (!rc.IsCase2() && !emissive)
+        {
+            C[0] = zr_asuint(rc.partialJacobian); C[1] = rc.seed_replay; C[2] = rc.ID;
+            if (rc.lt_k == TYPE::SKY) { D[2] = w_k_encoded; D[3] = rc.seed_nee; }
         }
         else if (rc.IsCase2())
         {
@@ -411,7 +437,10 @@ static inline float WaveSum64(const float* in)
     return v[0];
 }
 
-struct Globals { const Scene* sc; uint32_t numEmissives; int maxNumBounces; float alpha_min; bool presampled = false; uint32_t sampleSetIdx = 0; };
+struct Globals { const Scene* sc; uint32_t numEmissives; int maxNumBounces; float alpha_min; bool presampled = false; uint32_t sampleSetIdx = 0;
+    const zr_frame_constants* frame = nullptr; };      // numEmissives == 0 selects the NEE_EMISSIVE == 0 shader variants (sun + sky)
+
+struct SkyFunc { const SkyLUT* lut; float3 operator()(float3 w) const { return Light::Le_Sky(w, *lut); } };
 
 // ---- ReSTIR_PT_NEE.hlsli:134-207
 static DirectLightingEstimate NEE_Bsdf(const Globals& g, float3 pos, float3 normal, const BSDF::ShadingData& surface, int nextBounce,
@@ -555,6 +584,68 @@ static DirectLightingEstimate EvalDirect_Emissive_Case3(const Globals& g, float3
 }
 
 // ---- ReSTIR_PT_PathTrace.hlsl:36-192
+// RPT_Util::NEE_NonEmissive, ReSTIR_PT_NEE.hlsli:10-132 (SKY_SAMPLING_PREFER_PERFORMANCE == 1)
+static DirectLightingEstimate NEE_NonEmissive(const Globals& g, float3 pos, float3 normal, BSDF::ShadingData surface, RNG& rng)
+{
+    const Scene& sc = *g.sc; const zr_frame_constants& fr = *g.frame;
+    DirectLightingEstimate ret = DirectLightingEstimate::Init();
+    ret.dwdA = 1;
+    SkyFunc leFunc; leFunc.lut = &sc.sky;
+    const bool specular = surface.GlossSpecular() && (surface.metallic || surface.specTr) && (!surface.Coated() || surface.CoatSpecular());
+    float w_sum = 0;
+    float3 target_z = f3(0.0f);
+    const float2 u_wrs = rng.Uniform2D();
+    const float2 u_d = rng.Uniform2D();
+    const float2 u_c = rng.Uniform2D();
+    const float2 u_g = rng.Uniform2D();
+    const float u_wrs_b0 = rng.Uniform();
+    const float u_wrs_b1 = rng.Uniform();
+    {
+        const float3 wi_s = -f3(fr.sun_dir);
+        const bool visible = (wi_s.y > 0) && ((dot(wi_s, normal) > 0) || surface.Transmissive());
+        float pdf_b = 0, pdf_d = 0;
+        if (visible)
+        {
+            surface.SetWi(wi_s, normal);
+            target_z = Light::Le_Sun(pos, fr) * BSDF::Unified(surface).f;
+            float ndotWi = dot(wi_s, normal);
+            pdf_b = (ndotWi < 0) && surface.ThinWalled() ? 0 : BSDF::BSDFSamplerPdf_NoDiffuse(normal, surface, wi_s, leFunc);
+            pdf_d = (!specular ? 1.0f : 0.0f) * zr_abs(ndotWi) * ZR_ONE_OVER_PI;
+            pdf_d *= surface.ThinWalled() ? 0.5f : (ndotWi > 0 ? 1.0f : 0.0f);
+        }
+        w_sum = RT::BalanceHeuristic3(1, pdf_b, pdf_d, Math::Luminance(target_z));
+        ret.lt = TYPE::SUN; ret.lobe = LOBE::ALL; ret.wi = wi_s;
+    }
+    if (!specular)
+    {
+        float pdf_e;
+        float3 wi_e = BSDF::SampleDiffuse(normal, u_d, pdf_e);
+        if (surface.ThinWalled()) { wi_e = u_wrs_b1 > 0.5f ? -wi_e : wi_e; pdf_e *= 0.5f; }
+        surface.SetWi(wi_e, normal);
+        const float3 target = leFunc(wi_e) * BSDF::Unified(surface).f;
+        const float pdf_b = !surface.reflection && surface.ThinWalled() ? 0 : BSDF::BSDFSamplerPdf_NoDiffuse(normal, surface, wi_e, leFunc);
+        const float denom = pdf_e + pdf_b;
+        const float w_e = denom == 0 ? 0.0f : Math::Luminance(target) / denom;
+        w_sum += w_e;
+        if ((w_sum > 0) && (u_wrs.y < (w_e / w_sum))) { ret.lt = TYPE::SKY; ret.lobe = LOBE::ALL; ret.wi = wi_e; target_z = target; }
+    }
+    {
+        BSDF::BSDFSample bsdfSample = BSDF::SampleBSDF_NoDiffuse(normal, surface, u_c, u_g, u_wrs_b0, u_wrs_b1, leFunc);
+        float ndotwi = dot(bsdfSample.wi, normal);
+        float pdf_e = (!specular ? 1.0f : 0.0f) * zr_abs(ndotwi) * ZR_ONE_OVER_PI;
+        pdf_e *= surface.ThinWalled() ? 0.5f : (ndotwi > 0 ? 1.0f : 0.0f);
+        const float denom = bsdfSample.pdf + pdf_e;
+        const float w_b = denom == 0 ? 0.0f : Math::Luminance(bsdfSample.f) / denom;
+        w_sum += w_b;
+        if ((w_sum > 0) && (u_wrs.x < (w_b / w_sum))) { ret.lt = TYPE::SKY; ret.lobe = bsdfSample.lobe; ret.wi = bsdfSample.wi; target_z = bsdfSample.f; }
+    }
+    const float targetLum = Math::Luminance(target_z);
+    ret.ld = targetLum > 0 ? target_z * w_sum / targetLum : f3(0.0f);
+    ret.pdf_solidAngle = w_sum > 0 ? targetLum / w_sum : 0;
+    if (dot(ret.ld, ret.ld) > 0) ret.ld *= RtRayQuery::Visibility_Ray(sc, pos, ret.wi, normal, surface.Transmissive()) ? 1.0f : 0.0f;
+    return ret;
+}
+
 struct PrevHit { float alpha_lobe; float3 wi; float pdf; LOBE lobe; };
 
 static void MaybeSetCase2OrCase3(const Globals& g, int pathVertex, float3 pos, float3 normal, float t, uint32_t ID, uint32_t meshIdx,
@@ -572,6 +663,18 @@ static void EstimateDirectAndUpdateRC(const Globals& g, int pathVertex, float3 p
     const PrevHit& prevHit, float3 throughput, float3 throughput_k, float3& li, BSDF::BSDFSample& bsdfSample, RtRayQuery::Hit_Emissive& nextHit,
     Reconnection& rc, Reservoir& r, RNG& rngNEE, RNG& rngReplay)
 {
+    if (g.numEmissives == 0)      // EstimateDirectAndUpdateRC<false>, ReSTIR_PT_PathTrace.hlsl:172-191
+    {
+        const uint32_t seed_nee = rngNEE.State;
+        DirectLightingEstimate ls = NEE_NonEmissive(g, pos, hitInfo.normal, surface, rngNEE);
+        const float3 fOverPdf = throughput * ls.ld;
+        li += fOverPdf;
+        rc.L = RoundHalf3(ls.ld * throughput_k);
+        MaybeSetCase2OrCase3(g, pathVertex, pos, hitInfo.normal, hitInfo.t, hitInfo.ID, hitInfo.meshIdx, surface, prevHit, ls, seed_nee, rc);
+        float risWeight = Math::Luminance(fOverPdf);
+        r.Update(risWeight, fOverPdf, rc, rngNEE);
+        return;
+    }
     BSDF::BSDFSample nextBsdfSample;
     int nextBounce = pathVertex - 1;
     DirectLightingEstimate ls_b = NEE_Bsdf(g, pos, hitInfo.normal, surface, nextBounce, nextBsdfSample, nextHit, rngReplay);
@@ -620,7 +723,9 @@ static void PT_PhaseA(const Globals& gl, PTLane& P, bool russianRoulette)
     if (!P.active) return;
     const Scene& sc = *gl.sc;
     P.pathVertex = P.bounce + 2;
-    P.hitInfo = P.nextHit.ToHitInfo(sc, true);
+    // NEE_EMISSIVE == 0: Hit::FindClosest<true, true>; == 1: the BSDF ray of the previous vertex's NEE (ReSTIR_PT_PathTrace.hlsl:232-239)
+    P.hitInfo = gl.numEmissives == 0 ? RtRayQuery::FindClosest(sc, true, true, P.pos, P.normal, P.bsdfSample.wi, P.surface.Transmissive())
+                                     : P.nextHit.ToHitInfo(sc, true);
     if (!P.hitInfo.hit) { P.active = false; return; }
     float3 newPos = mad3(P.hitInfo.t, P.bsdfSample.wi, P.pos);
     P.rd.dpdx_dpdy(newPos, P.hitInfo.normal, P.dpdx, P.dpdy);
@@ -654,6 +759,11 @@ static void PT_PhaseB(const Globals& gl, PTLane& P, float waveThroughput)
         if (P.rngGroup.Uniform() < p_terminate) { P.active = false; return; }
         P.throughput /= (1 - p_terminate);
         P.throughput_k /= (P.reconnection.k <= P.bounce) ? (1 - p_terminate) : 1.0f;
+    }
+    if (gl.numEmissives == 0)     // ReSTIR_PT_PathTrace.hlsl:310-316
+    {
+        P.bsdfSample = BSDF::BSDFSample::Init();
+        if (P.bounce < gl.maxNumBounces) P.bsdfSample = BSDF::SampleBSDF(P.normal, P.surface, P.rngReplay);
     }
     if (dot(P.bsdfSample.bsdfOverPdf, P.bsdfSample.bsdfOverPdf) == 0) { P.active = false; return; }
     const float alpha_lobe = LobeAlpha(P.surface, P.bsdfSample.lobe);
@@ -946,6 +1056,75 @@ static float StepPath(const Globals& g, bool InCurrFrame, OffsetPathContext& ctx
     return partialJacobian;
 }
 
+// RPT_Util::EstimateDirect_y_k_min_1, Shift.hlsli:548-660 (SKY_SAMPLING_PREFER_PERFORMANCE == 1): re-runs the sun / sky RIS of
+// NEE_NonEmissive at the offset path's y_{k-1} with the base path's pick (lt, wd, lobe) forced; returns ld, writes its pdf
+static float3 EstimateDirect_y_k_min_1(const Globals& g, OffsetPathContext ctx, TYPE lt, float3 wd, LOBE lobe, RNG rngNEE, float& pdfOut)
+{
+    const Scene& sc = *g.sc; const zr_frame_constants& fr = *g.frame;
+    const float2 u_wrs = rngNEE.Uniform2D(); (void)u_wrs;
+    const float2 u_d = rngNEE.Uniform2D();
+    const float2 u_c = rngNEE.Uniform2D();
+    const float2 u_g = rngNEE.Uniform2D();
+    const float u_wrs_b0 = rngNEE.Uniform();
+    const float u_wrs_b1 = rngNEE.Uniform();
+    SkyFunc leFunc; leFunc.lut = &sc.sky;
+    const bool specular = ctx.surface.GlossSpecular() && (ctx.surface.metallic || ctx.surface.specTr) && (!ctx.surface.Coated() || ctx.surface.CoatSpecular());
+    float3 target_z = f3(0.0f);
+    float w_sum;
+    {
+        float3 wi_sun = -f3(fr.sun_dir);
+        float pdf_b = 0, pdf_e = 0;
+        const bool visible = (wi_sun.y > 0) && ((dot(wi_sun, ctx.normal) > 0) || ctx.surface.Transmissive());
+        if (visible)
+        {
+            ctx.surface.SetWi(wi_sun, ctx.normal);
+            target_z = Light::Le_Sun(ctx.pos, fr) * BSDF::Unified(ctx.surface).f;
+            float ndotWi = dot(wi_sun, ctx.normal);
+            pdf_b = (ndotWi < 0) && ctx.surface.ThinWalled() ? 0 : BSDF::BSDFSamplerPdf_NoDiffuse(ctx.normal, ctx.surface, wi_sun, leFunc);
+            pdf_e = (!specular ? 1.0f : 0.0f) * zr_abs(ndotWi) * ZR_ONE_OVER_PI;
+            pdf_e *= ctx.surface.ThinWalled() ? 0.5f : (ndotWi > 0 ? 1.0f : 0.0f);
+        }
+        w_sum = RT::BalanceHeuristic3(1, pdf_e, pdf_b, Math::Luminance(target_z));
+    }
+    if (!specular)
+    {
+        const bool isZ_e = lt == TYPE::SKY && lobe == LOBE::ALL;
+        float pdf_unused;
+        float3 wi_e = isZ_e ? wd : BSDF::SampleDiffuse(ctx.normal, u_d, pdf_unused);
+        float pdf_e = zr_saturate(dot(ctx.normal, wi_e)) * ZR_ONE_OVER_PI;
+        if (ctx.surface.ThinWalled()) { wi_e = u_wrs_b1 > 0.5f ? -wi_e : wi_e; pdf_e *= 0.5f; }
+        ctx.surface.SetWi(wi_e, ctx.normal);
+        float3 target = leFunc(wi_e) * BSDF::Unified(ctx.surface).f;
+        target_z = isZ_e ? target : target_z;
+        const float pdf_b = !ctx.surface.reflection && ctx.surface.ThinWalled() ? 0 : BSDF::BSDFSamplerPdf_NoDiffuse(ctx.normal, ctx.surface, wi_e, leFunc);
+        const float denom = pdf_e + pdf_b;
+        w_sum += denom == 0 ? 0.0f : Math::Luminance(target) / denom;
+    }
+    const bool isZ_b = lt == TYPE::SKY && lobe != LOBE::ALL;
+    if (isZ_b)
+    {
+        BSDF::BSDFSamplerEval eval = EvalBSDFSampler_NoDiffuse(ctx.normal, ctx.surface, wd, lobe, leFunc);
+        target_z = eval.f;
+        float ndotwi = dot(wd, ctx.normal);
+        float pdf_e = (!specular ? 1.0f : 0.0f) * zr_abs(ndotwi) * ZR_ONE_OVER_PI;
+        pdf_e *= ctx.surface.ThinWalled() ? 0.5f : (ndotwi > 0 ? 1.0f : 0.0f);
+        const float denom = eval.pdf + pdf_e;
+        w_sum += denom == 0 ? 0.0f : Math::Luminance(eval.f) / denom;
+    }
+    else
+    {
+        BSDF::BSDFSample bsdfSample = BSDF::SampleBSDF_NoDiffuse(ctx.normal, ctx.surface, u_c, u_g, u_wrs_b0, u_wrs_b1, leFunc);
+        float ndotwi = dot(bsdfSample.wi, ctx.normal);
+        float pdf_e = (!specular ? 1.0f : 0.0f) * zr_abs(ndotwi) * ZR_ONE_OVER_PI;
+        pdf_e *= ctx.surface.ThinWalled() ? 0.5f : (ndotwi > 0 ? 1.0f : 0.0f);
+        const float denom = bsdfSample.pdf + pdf_e;
+        w_sum += denom == 0 ? 0.0f : Math::Luminance(bsdfSample.f) / denom;
+    }
+    const float targetLum = Math::Luminance(target_z);
+    pdfOut = w_sum > 0 ? targetLum / w_sum : 0;
+    return targetLum > 0 ? target_z * w_sum / targetLum : f3(0.0f);
+}
+
 struct OffsetPath { float3 target; float partialJacobian; bool surfKMin1Tramsmissive; };
 
 // Shift2<Emissive = true>, Shift.hlsli:662-816
@@ -995,6 +1174,25 @@ static OffsetPath Shift2(const Globals& g, bool InCurrFrame, size_t DTidIdx, flo
         if (alpha_lobe_k_min_1 < g.alpha_min) return ret;
     }
     RNG rngNEE = RNG::InitSeed(rc.seed_nee);
+    if (g.numEmissives == 0)      // Shift2<Emissive = false>, Shift.hlsli:788-813
+    {
+        const TYPE lt = rc.IsCase2() ? rc.lt_k_plus_1 : rc.lt_k;
+        const LOBE lobe = rc.IsCase2() ? rc.lobe_k : rc.lobe_k_min_1;
+        float pdf;
+        const float3 target = EstimateDirect_y_k_min_1(g, ctx, lt, rc.w_k_lightNormal_w_sky, lobe, rngNEE, pdf);
+        ret.target = ctx.throughput * target;
+        if (rc.IsCase2()) ret.partialJacobian *= pdf;
+        else
+        {
+            ret.partialJacobian = pdf;
+            if (dot(ret.target, ret.target) > 0)
+            {
+                float3 wi = rc.lt_k == TYPE::SUN ? -f3(g.frame->sun_dir) : rc.w_k_lightNormal_w_sky;
+                ret.target *= RtRayQuery::Visibility_Ray(*g.sc, ctx.pos, wi, ctx.normal, ctx.surface.Transmissive()) ? 1.0f : 0.0f;
+            }
+        }
+        return ret;
+    }
     if (rc.IsCase2())
     {
         float3 w_k = rc.w_k_lightNormal_w_sky;
@@ -1075,7 +1273,7 @@ static void PathTracePass(const Scene& sc, const zr_frame_constants& g, const GB
             PTLane& P = lanes[l]; P = PTLane();
             const uint32_t x = bx * 16 + (l & 15), y = by * 4 + (l >> 4);
             P.x = x; P.y = y;
-            gl[l].sc = &sc; gl[l].numEmissives = g.num_emissive_triangles; gl[l].alpha_min = prm.alpha_min; gl[l].maxNumBounces = (int)prm.max_non_tr_bounces;
+            gl[l].sc = &sc; gl[l].frame = &g; gl[l].numEmissives = g.num_emissive_triangles; gl[l].alpha_min = prm.alpha_min; gl[l].maxNumBounces = (int)prm.max_non_tr_bounces;
             if (x >= W || y >= H) continue;
             P.inFrame = true;
             const size_t px = (size_t)y * W + x;
@@ -1103,7 +1301,7 @@ static void PathTracePass(const Scene& sc, const zr_frame_constants& g, const GB
             rd.UpdateRays(ps.pos, ps.normal, bsdfSample.wi, ps.surface.wo, triDiffs, dpdx, dpdy, dot(bsdfSample.wi, ps.normal) < 0, ps.surface.eta);
             const uint32_t numSets = prm.presampling ? prm.num_sample_sets : 0;
             gl[l].presampled = prm.presampling != 0;
-            gl[l].sampleSetIdx = P.rngGroup.UniformUintBounded_Faster(numSets);
+            gl[l].sampleSetIdx = g.num_emissive_triangles ? P.rngGroup.UniformUintBounded_Faster(numSets) : 0u;   // ReSTIR_PT_PathTrace.hlsl:406-408
             // PathTrace prologue
             P.reconnection = Reconnection::Init();
             P.bounce = 0; P.throughput = bsdfSample.bsdfOverPdf;
@@ -1112,7 +1310,7 @@ static void PathTracePass(const Scene& sc, const zr_frame_constants& g, const GB
             P.throughput_k = f3(1.0f);
             P.inTranslucentMedium = P.eta_curr != ETA_AIR;
             P.pos = ps.pos; P.normal = ps.normal; P.surface = ps.surface; P.bsdfSample = bsdfSample; P.rd = rd; P.eta_next = ps.eta_next;
-            P.nextHit = RtRayQuery::Hit_Emissive::FindClosest(sc, ps.pos, ps.normal, bsdfSample.wi, ps.surface.Transmissive());
+            if (g.num_emissive_triangles) P.nextHit = RtRayQuery::Hit_Emissive::FindClosest(sc, ps.pos, ps.normal, bsdfSample.wi, ps.surface.Transmissive());
             P.active = true;
         }
         for (;;)
@@ -1141,7 +1339,7 @@ static void PathTracePass(const Scene& sc, const zr_frame_constants& g, const GB
             r.rc.seed_replay = P.seed_replay;
             float targetLum = Math::Luminance(r.target);
             r.W = targetLum > 0 ? zr_max(r.w_sum / targetLum, 1.0f) : 0;
-            if (writeReservoirs) r.Write(out, px);
+            if (writeReservoirs) r.Write(out, px, 0, g.num_emissive_triangles != 0);
             if (doTemporal)
             {
                 float3 t = Sanitize3(r.target);
@@ -1223,7 +1421,7 @@ static void TemporalPass(const Scene& sc, const zr_frame_constants& g, const GBu
     const Camera cam = CurrCamera(g);
     ReservoirPlanes& cur = st.reservoirs[st.currIdx];
     const ReservoirPlanes& prev = st.reservoirs[1 - st.currIdx];
-    Globals gl; gl.sc = &sc; gl.numEmissives = g.num_emissive_triangles; gl.alpha_min = prm.alpha_min; gl.maxNumBounces = 0;
+    Globals gl; gl.sc = &sc; gl.frame = &g; gl.numEmissives = g.num_emissive_triangles; gl.alpha_min = prm.alpha_min; gl.maxNumBounces = 0;
     const uint32_t M_max = prm.m_max_temporal & 0xf;
 
     // ---- K13 Replay_CtT and Replay_TtC (ReSTIR_PT_Replay.hlsl:289-534); plane threshold 0.01 here
@@ -1243,7 +1441,7 @@ static void TemporalPass(const Scene& sc, const zr_frame_constants& g, const GBu
             Reservoir r_curr = Reservoir::Load_Metadata(cur, px);
             if (!r_curr.rc.Empty() && (r_curr.rc.k > 2))
             {
-                r_curr.Load_Reconnection(cur, px);
+                r_curr.Load_Reconnection(cur, px, g.num_emissive_triangles != 0);
                 const Camera pcam = PrevCamera(g);
                 Math::TriDifferentials triDiffs = LoadTriDiffs(gbPrev, pp);
                 RT::RayDifferentials rd = InitRD(pcam, tp.px, tp.py, tp.prev.lensSample, tp.prev.origin);
@@ -1259,7 +1457,7 @@ static void TemporalPass(const Scene& sc, const zr_frame_constants& g, const GBu
             Reservoir r_prev = Reservoir::Load_Metadata(prev, pp);
             if (!r_prev.rc.Empty() && (r_prev.rc.k > 2))
             {
-                r_prev.Load_Reconnection(prev, pp);
+                r_prev.Load_Reconnection(prev, pp, g.num_emissive_triangles != 0);
                 Math::TriDifferentials triDiffs = LoadTriDiffs(gb, px);
                 RT::RayDifferentials rd = InitRD(cam, (int)x, (int)y, ps.lensSample, ps.origin);
                 OffsetPathContext ctx = Replay_kGt2(gl, true, ps.pos, ps.normal, ps.eta_next, ps.surface, rd, triDiffs, r_prev.rc);
@@ -1283,7 +1481,7 @@ static void TemporalPass(const Scene& sc, const zr_frame_constants& g, const GBu
         Reservoir r_prev = Reservoir::Load_Metadata(prev, pp);
         if (r_curr.w_sum != 0 && r_prev.M > 0 && !r_curr.rc.Empty())
         {
-            r_curr.Load_Reconnection(cur, px);
+            r_curr.Load_Reconnection(cur, px, g.num_emissive_triangles != 0);
             if (r_curr.rc.IsCase1() || r_curr.rc.IsCase2()) MoveXk(sc, r_curr.rc, true, false);
             gl.maxNumBounces = flags.transmissive ? (int)prm.max_glossy_tr_bounces : (int)prm.max_non_tr_bounces;
             Math::TriDifferentials triDiffs; RT::RayDifferentials rd = ZeroRD();
@@ -1335,7 +1533,7 @@ static void TemporalPass(const Scene& sc, const zr_frame_constants& g, const GBu
             if (!doSpatial) WriteOutputColor(g, finalRGBA, px, r_curr.target * r_curr.W);
             continue;
         }
-        r_prev.Load_Reconnection(prev, pp);
+        r_prev.Load_Reconnection(prev, pp, g.num_emissive_triangles != 0);
         if (r_prev.rc.IsCase1() || r_prev.rc.IsCase2()) MoveXk(sc, r_prev.rc, false, true);
         Math::TriDifferentials triDiffs; RT::RayDifferentials rd = ZeroRD();
         triDiffs.dpdu = triDiffs.dpdv = triDiffs.dndu = triDiffs.dndv = f3(0.0f);
@@ -1359,7 +1557,7 @@ static void TemporalPass(const Scene& sc, const zr_frame_constants& g, const GBu
         r_curr.M = M_new;
         if (changed)
         {
-            r_curr.Write(cur, px, M_max);
+            r_curr.Write(cur, px, M_max, g.num_emissive_triangles != 0);
             if (doSpatial)
             {
                 float3 t = Sanitize3(r_curr.target);
@@ -1388,7 +1586,7 @@ static void SpatialPass(const Scene& sc, const zr_frame_constants& g, const GBuf
     const uint32_t W = g.render_width, H = g.render_height;
     const Camera cam = CurrCamera(g);
     const float2 renderDim = cam.renderDim;
-    Globals gl; gl.sc = &sc; gl.numEmissives = g.num_emissive_triangles; gl.alpha_min = prm.alpha_min; gl.maxNumBounces = 0;
+    Globals gl; gl.sc = &sc; gl.frame = &g; gl.numEmissives = g.num_emissive_triangles; gl.alpha_min = prm.alpha_min; gl.maxNumBounces = 0;
 
     // ---- K15 SpatialSearch (ReSTIR_PT_SpatialSearch.hlsl:21-146)
     for (uint32_t y = 0; y < H; y++) for (uint32_t x = 0; x < W; x++)
@@ -1463,7 +1661,7 @@ static void SpatialPass(const Scene& sc, const zr_frame_constants& g, const GBuf
             Reservoir r_curr = Reservoir::Load_Metadata(in, px);
             if (!r_curr.rc.Empty() && (r_curr.rc.k > 2))
             {
-                r_curr.Load_Reconnection(in, px);
+                r_curr.Load_Reconnection(in, px, g.num_emissive_triangles != 0);
                 if (!neighborOf(x, y, sx, sy)) continue;
                 const size_t sp = (size_t)sy * W + sx;
                 PixelSurface pn = LoadPixelSurface(gb, cam, (uint32_t)sx, (uint32_t)sy, g.frame_num, sp);
@@ -1480,7 +1678,7 @@ static void SpatialPass(const Scene& sc, const zr_frame_constants& g, const GBuf
             Reservoir r_spatial = Reservoir::Load_Metadata(in, sp);
             if (!r_spatial.rc.Empty() && (r_spatial.rc.k > 2))
             {
-                r_spatial.Load_Reconnection(in, sp);
+                r_spatial.Load_Reconnection(in, sp, g.num_emissive_triangles != 0);
                 PixelSurface ps = LoadPixelSurface(gb, cam, x, y, g.frame_num, px);
                 Math::TriDifferentials triDiffs = LoadTriDiffs(gb, px);
                 RT::RayDifferentials rd = InitRD(cam, (int)x, (int)y, ps.lensSample, ps.origin);
@@ -1503,7 +1701,7 @@ static void SpatialPass(const Scene& sc, const zr_frame_constants& g, const GBuf
         Reservoir r_spatial = Reservoir::Load_Metadata(in, sp);
         if ((r_curr.w_sum != 0) && !r_curr.rc.Empty())
         {
-            r_curr.Load_Reconnection(in, px);
+            r_curr.Load_Reconnection(in, px, g.num_emissive_triangles != 0);
             gl.maxNumBounces = flags.transmissive ? (int)prm.max_glossy_tr_bounces : (int)prm.max_non_tr_bounces;
             // coat plane read at DTid (ReSTIR_PT_Reconnect_CtS.hlsl:99)
             PixelSurface pn = LoadPixelSurface(gb, cam, (uint32_t)sx, (uint32_t)sy, g.frame_num, px);
@@ -1528,7 +1726,7 @@ static void SpatialPass(const Scene& sc, const zr_frame_constants& g, const GBuf
     // ---- K16 Reconnect_StC (ReSTIR_PT_Reconnect_StC.hlsl:112-352); wave = 8x8 pixel group
     const bool boiling = prm.flags & ZR_IND_BOILING_SUPPRESSION;
     auto copyToNextFrame = [&](size_t px, Reservoir& r, uint32_t M_max) {
-        if (!r.rc.Empty()) { r.Load_Reconnection(in, px); r.Write(out, px, M_max); }
+        if (!r.rc.Empty()) { r.Load_Reconnection(in, px, g.num_emissive_triangles != 0); r.Write(out, px, M_max, g.num_emissive_triangles != 0); }
         else r.WriteReservoirData(out, px, M_max); };
     auto suppress = [&](float waveAvgExclusive, Reservoir& r) {
         if (r.w_sum > 50 * waveAvgExclusive) { r.M = 0; r.w_sum = 0; r.W = 0; r.rc.Clear(); } };
@@ -1599,7 +1797,7 @@ static void SpatialPass(const Scene& sc, const zr_frame_constants& g, const GBuf
             a.resample = true;
             a.M_max = a.r_spatial.rc.x_k_in_motion ? std::min<uint32_t>(a.M_max, M_MAX_X_K_IN_MOTION) : a.M_max;
             a.r_spatial.rc.x_k_in_motion = false;
-            a.r_spatial.Load_Reconnection(in, a.sp);
+            a.r_spatial.Load_Reconnection(in, a.sp, g.num_emissive_triangles != 0);
             gl.maxNumBounces = a.flags.transmissive ? (int)prm.max_glossy_tr_bounces : (int)prm.max_non_tr_bounces;
             Math::TriDifferentials triDiffs; RT::RayDifferentials rd = ZeroRD();
             triDiffs.dpdu = triDiffs.dpdv = triDiffs.dndu = triDiffs.dndv = f3(0.0f);
@@ -1637,7 +1835,7 @@ static void SpatialPass(const Scene& sc, const zr_frame_constants& g, const GBuf
                 float waveAvgExclusive = (waveSum - a.r_curr.w_sum) / 64.0f;
                 suppress(waveAvgExclusive, a.r_curr);
             }
-            if (a.spatialEmpty) a.r_curr.Write(out, a.px, a.M_max);
+            if (a.spatialEmpty) a.r_curr.Write(out, a.px, a.M_max, g.num_emissive_triangles != 0);
             else copyToNextFrame(a.px, a.r_curr, a.M_max);
             WriteOutputColor(g, finalRGBA, a.px, a.r_curr.target * a.r_curr.W);
         }
@@ -1671,14 +1869,14 @@ static void SelfShift(const Scene& sc, const zr_frame_constants& g, const zr_gbu
     const Camera cam = CurrCamera(g);
     const ReservoirPlanes& in = st.reservoirs[which == 0 ? 1 - st.currIdx : st.currIdx];
     RBuffer rb; rb.Resize((size_t)W * H);
-    Globals gl; gl.sc = &sc; gl.numEmissives = g.num_emissive_triangles; gl.alpha_min = prm.alpha_min;
+    Globals gl; gl.sc = &sc; gl.frame = &g; gl.numEmissives = g.num_emissive_triangles; gl.alpha_min = prm.alpha_min;
     for (uint32_t y = 0; y < H; y++) for (uint32_t x = 0; x < W; x++)
     {
         const size_t px = (size_t)y * W + x;
         float* o = out + 6 * px; for (int i = 0; i < 6; i++) o[i] = 0;
         GFlags flags = DecodeFlags(gb.mr[px]);
         if (flags.invalid || flags.emissive) continue;
-        Reservoir r = Reservoir::Load(in, px);
+        Reservoir r = Reservoir::Load(in, px, g.num_emissive_triangles != 0);
         if (r.rc.Empty()) continue;
         gl.maxNumBounces = flags.transmissive ? (int)prm.max_glossy_tr_bounces : (int)prm.max_non_tr_bounces;
         PixelSurface ps = LoadPixelSurface(gb, cam, x, y, g.frame_num, px);

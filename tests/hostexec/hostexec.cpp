@@ -273,6 +273,7 @@ void zhx_rpt_render_stage(const HxScene* s, HxRpt* R, const zr_frame_constants* 
     prm.accumulate = (g.accumulate && g.camera_static) ? 1u : 0u;
     prm.boiling = (params->flags & ZR_IND_BOILING_SUPPRESSION) ? 1u : 0u;
     prm.M_max_temporal = params->m_max_temporal & 0xf; prm.M_max_spatial = params->m_max_spatial & 0xf; prm.alpha_min = params->alpha_min;
+    prm.emissive = g.num_emissive_triangles ? 1u : 0u;
     if (stages & 1)
     {
         R->doTemporal = (params->flags & ZR_IND_TEMPORAL_RESAMPLE) && R->temporalValid && prev;
@@ -302,7 +303,7 @@ void zhx_rpt_render_stage(const HxScene* s, HxRpt* R, const zr_frame_constants* 
                 if (!any) break;
                 uint32_t bits = 0;
                 for (uint32_t l = 0; l < 64; l++) { uint32_t b = PtRRKey(lanes[l]); bits = b > bits ? b : bits; }
-                for (uint32_t l = 0; l < 64; l++) PtPhaseB(prm, lanes[l], bits);
+                for (uint32_t l = 0; l < 64; l++) PtPhaseB(F.sc, prm, lanes[l], bits);
             }
             for (uint32_t l = 0; l < 64; l++) PtFinishLane(F.gb, prm, F.cur, F.tex, finalRGBA, lanes[l]);
             flush();

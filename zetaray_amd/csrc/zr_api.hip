@@ -363,7 +363,7 @@ __global__ void __launch_bounds__(kBlock) ZR_WAVES_PATHTRACE k_rpt_pathtrace(rpt
         {
             for (int s = 1; s < 64; s <<= 1) { uint32_t o = __shfl_xor(key, s); key = o > key ? o : key; }
         }
-        rpt::PtPhaseB(F.prm, P, key);
+        rpt::PtPhaseB(F.sc, F.prm, P, key);
     }
     rpt::PtFinishLane(F.gb, F.prm, F.cur, F.tex, F.finalRGBA, P);
     FlushRayCounters(counters, cnt);
@@ -1310,6 +1310,7 @@ static int RenderReSTIR_PT(zr_pass* p, hipStream_t s, const zr_frame_constants* 
     prm.accumulate = (cb->accumulate && cb->camera_static) ? 1u : 0u;
     prm.boiling = (ip.flags & ZR_IND_BOILING_SUPPRESSION) ? 1u : 0u;
     prm.M_max_temporal = ip.m_max_temporal & 0xf; prm.M_max_spatial = ip.m_max_spatial & 0xf; prm.alpha_min = ip.alpha_min;
+    prm.emissive = cb->num_emissive_triangles ? 1u : 0u;
     if (stages & ZR_STAGE_TEMPORAL)
     {
         p->doTemporal = (ip.flags & ZR_IND_TEMPORAL_RESAMPLE) && p->temporalValid && havePrevGBuffer;
@@ -1368,7 +1369,6 @@ static int RenderIndirect(zr_pass* p, hipStream_t s, const zr_frame_constants* c
     if (sc->view.numEmissives == 0)
     {
         // NEE_EMISSIVE == 0 shader variants: sun + sky next-event estimation
-        if (p->integrator == ZR_INTEGRATOR_RESTIR_PT) return Fail(ZR_ERR_UNSUPPORTED, "sun/sky NEE (scenes without emissive triangles) is implemented for the path tracer and ReSTIR GI, not yet for ReSTIR PT");
         if (!sc->view.sky.data) return Fail(ZR_ERR_NOT_INITIALIZED, "sky-view LUT missing: render a ZR_PASS_SKY pass first");
     }
     else if (!sc->view.alias) return Fail(ZR_ERR_NOT_INITIALIZED, "emissive alias table missing: render the PRELIGHTING pass (or zr_scene_set_alias_table) first");

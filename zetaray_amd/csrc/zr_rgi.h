@@ -150,15 +150,7 @@ ZR_HD V3 NEE_Emissive_LVG(const Globals& gl, const zr_frame_constants& g, V3 pos
     return ret;
 }
 
-// RtRayQuery::Visibility_Ray (RayQuery.hlsli:302-334), traced in place
-ZR_HD bool VisibilityRay(const Globals& gl, V3 origin, V3 wi, V3 normal, bool transmissive)
-{
-    F4 ro, rd;
-    if (!MakeVisibilityRay(origin, wi, normal, transmissive, &ro, &rd)) return false;
-    gl.cnt[1]++;
-    RawHit h = Traverse<true>(*gl.sc, xyz(ro), xyz(rd), ro.w, rd.w, ZR_SUBGROUP_ALL, gl.stack);
-    return h.tri == kInvalidTri;
-}
+using rpt::VisibilityRay;       // RtRayQuery::Visibility_Ray, traced in place (zr_rpt.h)
 // RGI_Util::NEE with NEE_EMISSIVE == 0 (ReSTIR_GI_NEE.hlsli:194-226): ReSTIR_Util::NEE_Sun<true> with probability q,
 // else NEE_Sky<true> (NEE.hlsli:86-152); P_SUN_VS_SKY 0.65, SUN_DISK_SAMPLING 0 (ReSTIR_GI/Params.hlsli:8,28)
 ZR_HD V3 NEE_SunSky(const Globals& gl, const zr_frame_constants& g, V3 pos, V3 normal, const Surface& surface, Rng& rng)

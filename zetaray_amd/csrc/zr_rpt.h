@@ -126,12 +126,13 @@ ZR_HD SamplerEval EvalBSDFSampler_NoSpecTr(const RhoView& rho, V3 n, Surface s, 
     return ret;
 }
 
-// BSDFSampling.hlsli:430-502 (NoOp target)
-ZR_HD SamplerEval EvalBSDFSampler_NoDiffuse(const RhoView& rho, V3 n, Surface s, V3 wi, uint32_t lobe)
+// BSDFSampling.hlsli:430-502
+template<typename Func>
+ZR_HD SamplerEval EvalBSDFSampler_NoDiffuse(const RhoView& rho, V3 n, Surface s, V3 wi, uint32_t lobe, Func func)
 {
-    s.SetWi(wi, n);
+    const V3 wh = s.SetWi(wi, n);
     Eval e = Unified(rho, s);
-    const V3 targetScale = v3(1.0f);
+    const V3 targetScale = func(wi);
     float pdf_base = 1;
     SamplerEval ret;
     ret.f = e.f * targetScale;
@@ -152,7 +153,8 @@ ZR_HD SamplerEval EvalBSDFSampler_NoDiffuse(const RhoView& rho, V3 n, Surface s,
     ret.pdf *= pdf_base;
     ret.bsdfOverPdf = ret.f / ret.pdf;
     if (s.metallic || !s.specTr || e.tir) return ret;
-    float lumA = Luminance(targetScale), lumB = Luminance(v3(1.0f));
+    const V3 wi_other = lobe == LOBE_GLOSSY_T ? reflect(-s.wo, wh) : refract(-s.wo, wh, 1 / s.eta);
+    float lumA = Luminance(targetScale), lumB = Luminance(func(wi_other));
     float p_r = e.Fr_g.x * (lobe == LOBE_GLOSSY_R ? lumA : lumB);
     p_r = p_r / (p_r + (1 - e.Fr_g.x) * (lobe == LOBE_GLOSSY_R ? lumB : lumA));
     if (lobe == LOBE_GLOSSY_R)
@@ -181,7 +183,7 @@ ZR_HD SamplerEval EvalBSDFSampler(const RhoView& rho, V3 n, const Surface& s, V3
     V2 u_d = rng.Uniform2D();
     rng.Uniform(); rng.Uniform(); rng.Uniform();
     if (!s.specTr) return EvalBSDFSampler_NoSpecTr(rho, n, s, wi, lobe, u_c, u_g, u_d);
-    return EvalBSDFSampler_NoDiffuse(rho, n, s, wi, lobe);
+    return EvalBSDFSampler_NoDiffuse(rho, n, s, wi, lobe, NoOpTarget());
 }
 
 // NEE.hlsli:28-73
@@ -292,10 +294,22 @@ struct Reservoir
         rc.x_k_in_motion = (mz >> 2) != 0;
         M = mx >> 4;
     }
-    // Emissive == true variants of LoadCase1/2/3 (Reservoir.hlsli:47-139)
-    ZR_HDM void Load_Reconnection(const ResPlanes& p, size_t i)
+    // LoadCase1/2/3<Emissive> (Reservoir.hlsli:47-139)
+    ZR_HDM void Load_Reconnection(const ResPlanes& p, size_t i, bool emissive)
     {
         const U4 c = p.C[i], d = p.D[i];
+        if (!emissive && !rc.IsCase1())
+        {
+            rc.seed_replay = c.y; rc.ID = c.z; rc.partialJacobian = zr_asfloat(c.x);
+            if (rc.IsCase2())
+            {
+                rc.x_k = v3(zr_asfloat(c.w), zr_asfloat(d.x), zr_asfloat(d.y));
+                if (rc.lt_k_plus_1 == LT_SKY) { rc.w = DecodeOct32u(d.z); rc.seed_nee = d.w; }
+                rc.meshIdx = p.G[2 * i + 1];
+            }
+            else if (rc.lt_k == LT_SKY) { rc.w = DecodeOct32u(d.z); rc.seed_nee = d.w; }
+            return;
+        }
         rc.seed_replay = c.y; rc.ID = c.z;
         rc.x_k = v3(zr_asfloat(c.w), zr_asfloat(d.x), zr_asfloat(d.y));
         rc.w = DecodeOct32u(d.z);
@@ -328,8 +342,8 @@ struct Reservoir
         p.A[i] = (p.A[i] & 0xffffff00u) | (PackA_x(rc, m) & 0xff);
         p.B[2 * i + 1] = W;
     }
-    // Write<Emissive = true>, Reservoir.hlsli:367-456
-    ZR_HDM void Write(const ResPlanes& p, size_t i, uint32_t M_max)
+    // Write<Emissive>, Reservoir.hlsli:283-330, 367-456 (the non-emissive variant writes only some components of C / D / G)
+    ZR_HDM void Write(const ResPlanes& p, size_t i, uint32_t M_max, bool emissive)
     {
         uint32_t m = M_max == 0 ? M : umin(M, M_max);
         uint32_t mx = PackA_x(rc, m) & 0xff;
@@ -342,6 +356,21 @@ struct Reservoir
         V2 e = EncodeUnitVector(rc.w);
         uint32_t w_enc = FloatToUNorm16(e.x) | (FloatToUNorm16(e.y) << 16);
         uint32_t lh = (uint32_t)zr_f32_to_f16(rc.L.x) | ((uint32_t)zr_f32_to_f16(rc.L.y) << 16);
+        if (!emissive && !rc.IsCase1())
+        {
+            U4 c = p.C[i], d = p.D[i];
+            c.x = zr_asuint(rc.partialJacobian); c.y = rc.seed_replay; c.z = rc.ID;
+            if (rc.IsCase2())
+            {
+                c.w = zr_asuint(rc.x_k.x);
+                d.x = zr_asuint(rc.x_k.y); d.y = zr_asuint(rc.x_k.z);
+                if (rc.lt_k_plus_1 == LT_SKY) { d.z = w_enc; d.w = rc.seed_nee; }
+                p.G[2 * i + 1] = rc.meshIdx;
+            }
+            else if (rc.lt_k == LT_SKY) { d.z = w_enc; d.w = rc.seed_nee; }
+            p.C[i] = c; p.D[i] = d;
+            return;
+        }
         U4 c, d;
         c.y = rc.seed_replay; c.z = rc.ID; c.w = zr_asuint(rc.x_k.x);
         d.x = zr_asuint(rc.x_k.y); d.y = zr_asuint(rc.x_k.z); d.z = w_enc; d.w = lh;
@@ -367,7 +396,9 @@ ZR_HD Reservoir Load_NonReconnection(const ResPlanes& p, size_t i)
 { Reservoir r = InitReservoir(); r.UnpackMetadata(p.A[i]); r.w_sum = p.B[2 * i]; r.W = p.B[2 * i + 1]; return r; }
 
 // cnt: this lane's ray counters {closest-hit queries, shadow / visibility queries} (never null)
-struct Globals { const SceneView* sc; uint32_t numEmissives; int maxNumBounces; float alpha_min; TravStack stack; uint32_t* cnt; bool presampled; uint32_t sampleSetIdx; };
+// numEmissives == 0 selects the NEE_EMISSIVE == 0 shader variants (sun + sky lighting); frame = cbFrameConstants (sun, atmosphere)
+struct Globals { const SceneView* sc; uint32_t numEmissives; int maxNumBounces; float alpha_min; TravStack stack; uint32_t* cnt; bool presampled; uint32_t sampleSetIdx;
+    const zr_frame_constants* frame; };
 
 // ---- ray queries (inline traversal)
 struct HitEm { bool hit; float t; uint32_t mesh, prim, emissiveTriIdx; float bu, bv; };
@@ -579,6 +610,79 @@ ZR_HD Direct EvalDirect_Case3(const Globals& g, V3 pos, V3 normal, Surface surfa
 }
 
 // ---- ReSTIR_PT_PathTrace.hlsl:36-192
+// RtRayQuery::Visibility_Ray (RayQuery.hlsli:302-334), traced in place
+ZR_HD bool VisibilityRay(const Globals& g, V3 origin, V3 wi, V3 normal, bool transmissive)
+{
+    F4 ro, rd;
+    if (!MakeVisibilityRay(origin, wi, normal, transmissive, &ro, &rd)) return false;
+    g.cnt[1]++;
+    RawHit h = Traverse<true>(*g.sc, xyz(ro), xyz(rd), ro.w, rd.w, ZR_SUBGROUP_ALL, g.stack);
+    return h.tri == kInvalidTri;
+}
+
+// RPT_Util::NEE_NonEmissive, ReSTIR_PT_NEE.hlsli:10-132 (SKY_SAMPLING_PREFER_PERFORMANCE == 1): one RIS over {sun, cosine sky sample,
+// BSDF (no-diffuse sampler) sky sample} with Le_Sky as the lobe-RIS target, then a single visibility ray
+ZR_HD Direct NEE_NonEmissive(const Globals& g, V3 pos, V3 normal, Surface surface, Rng& rng)
+{
+    const SceneView& sc = *g.sc; const zr_frame_constants& fr = *g.frame; const RhoView& rho = sc.rho;
+    Direct ret = InitDirect();
+    ret.dwdA = 1;
+    SkyIncidentRadiance leFunc; leFunc.lut = sc.sky;
+    const bool specular = IsSpecular(surface);
+    float w_sum = 0;
+    V3 target_z = v3(0.0f);
+    const V2 u_wrs = rng.Uniform2D();
+    const V2 u_d = rng.Uniform2D();
+    const V2 u_c = rng.Uniform2D();
+    const V2 u_g = rng.Uniform2D();
+    const float u_wrs_b0 = rng.Uniform();
+    const float u_wrs_b1 = rng.Uniform();
+    {
+        const V3 wi_s = -v3p(fr.sun_dir);
+        const bool visible = (wi_s.y > 0) && ((dot(wi_s, normal) > 0) || surface.Transmissive());
+        float pdf_b = 0, pdf_d = 0;
+        if (visible)
+        {
+            surface.SetWi(wi_s, normal);
+            target_z = Le_Sun(pos, fr) * Unified(rho, surface).f;
+            const float ndotWi = dot(wi_s, normal);
+            pdf_b = (ndotWi < 0) && surface.ThinWalled() ? 0 : BSDFSamplerPdf_NoDiffuse(rho, normal, surface, wi_s, leFunc);
+            pdf_d = (!specular ? 1.0f : 0.0f) * zr_abs(ndotWi) * ZR_ONE_OVER_PI;
+            pdf_d *= surface.ThinWalled() ? 0.5f : (ndotWi > 0 ? 1.0f : 0.0f);
+        }
+        w_sum = BalanceHeuristic3(1, pdf_b, pdf_d, Luminance(target_z));
+        ret.lt = LT_SUN; ret.lobe = LOBE_ALL; ret.wi = wi_s;
+    }
+    if (!specular)
+    {
+        float pdf_e;
+        V3 wi_e = SampleDiffuse(normal, u_d, &pdf_e);
+        if (surface.ThinWalled()) { wi_e = u_wrs_b1 > 0.5f ? -wi_e : wi_e; pdf_e *= 0.5f; }
+        surface.SetWi(wi_e, normal);
+        const V3 target = leFunc(wi_e) * Unified(rho, surface).f;
+        const float pdf_b = !surface.reflection && surface.ThinWalled() ? 0 : BSDFSamplerPdf_NoDiffuse(rho, normal, surface, wi_e, leFunc);
+        const float denom = pdf_e + pdf_b;
+        const float w_e = denom == 0 ? 0.0f : Luminance(target) / denom;
+        w_sum += w_e;
+        if ((w_sum > 0) && (u_wrs.y < (w_e / w_sum))) { ret.lt = LT_SKY; ret.lobe = LOBE_ALL; ret.wi = wi_e; target_z = target; }
+    }
+    {
+        const BsdfSample bs = SampleBSDF_NoDiffuse(rho, normal, surface, u_c, u_g, u_wrs_b0, u_wrs_b1, leFunc);
+        const float ndotwi = dot(bs.wi, normal);
+        float pdf_e = (!specular ? 1.0f : 0.0f) * zr_abs(ndotwi) * ZR_ONE_OVER_PI;
+        pdf_e *= surface.ThinWalled() ? 0.5f : (ndotwi > 0 ? 1.0f : 0.0f);
+        const float denom = bs.pdf + pdf_e;
+        const float w_b = denom == 0 ? 0.0f : Luminance(bs.f) / denom;
+        w_sum += w_b;
+        if ((w_sum > 0) && (u_wrs.x < (w_b / w_sum))) { ret.lt = LT_SKY; ret.lobe = bs.lobe; ret.wi = bs.wi; target_z = bs.f; }
+    }
+    const float targetLum = Luminance(target_z);
+    ret.ld = targetLum > 0 ? target_z * w_sum / targetLum : v3(0.0f);
+    ret.pdf_solidAngle = w_sum > 0 ? targetLum / w_sum : 0;
+    if (dot(ret.ld, ret.ld) > 0) ret.ld = ret.ld * (VisibilityRay(g, pos, ret.wi, normal, surface.Transmissive()) ? 1.0f : 0.0f);
+    return ret;
+}
+
 struct PrevHit { float alpha_lobe; V3 wi; float pdf; uint32_t lobe; };
 
 ZR_HD void MaybeSetCase2OrCase3(const Globals& g, int pathVertex, V3 pos, V3 normal, float t, uint32_t ID, uint32_t meshIdx,
@@ -595,6 +699,17 @@ ZR_HD void MaybeSetCase2OrCase3(const Globals& g, int pathVertex, V3 pos, V3 nor
 ZR_HD void EstimateDirectAndUpdateRC(const Globals& g, int pathVertex, V3 pos, const HitInfo& hit, const Surface& surface, const PrevHit& prevHit,
     V3 throughput, V3 throughput_k, V3& li, BsdfSample& bs, HitEm& nextHit, Reconnection& rc, Reservoir& r, Rng& rngNEE, Rng& rngReplay)
 {
+    if (g.numEmissives == 0)      // EstimateDirectAndUpdateRC<false>, ReSTIR_PT_PathTrace.hlsl:172-191
+    {
+        const uint32_t seed_nee = rngNEE.s;
+        Direct ls = NEE_NonEmissive(g, pos, hit.normal, surface, rngNEE);
+        const V3 fOverPdf = throughput * ls.ld;
+        li = li + fOverPdf;
+        rc.L = RoundHalf3(ls.ld * throughput_k);
+        MaybeSetCase2OrCase3(g, pathVertex, pos, hit.normal, hit.t, hit.ID, hit.meshIdx, surface, prevHit, ls, seed_nee, rc);
+        r.Update(Luminance(fOverPdf), fOverPdf, rc, rngNEE);
+        return;
+    }
     BsdfSample nbs;
     int nextBounce = pathVertex - 1;
     Direct ls_b = NEE_Bsdf(g, pos, hit.normal, surface, nextBounce, nbs, nextHit, rngReplay);
@@ -738,6 +853,7 @@ struct RptParams
     uint32_t maxNonTrBounces, maxGlossyTrBounces, russianRoulette, numSampleSets, accumulate, boiling, M_max_temporal, M_max_spatial;
     float alpha_min;
     uint32_t doTemporal, doSpatial, writeReservoirs;
+    uint32_t emissive;      // NEE_EMISSIVE: the scene has emissive triangles (else sun + sky)
 };
 
 // main() prologue + RIS_InitialCandidates up to the first FindClosest (ReSTIR_PT_PathTrace.hlsl:360-530, 194-236)
@@ -763,7 +879,7 @@ ZR_HD void PtInitLane(const SceneView& sc, const zr_frame_constants& g, const GB
     P.r = InitReservoir(); P.li = v3(0.0f);
     BsdfSample bs = SampleBSDF(sc.rho, ps.normal, ps.surface, P.rngReplay);
     if (dot(bs.bsdfOverPdf, bs.bsdfOverPdf) == 0) return;
-    P.sampleSetIdx = P.rngGroup.UniformUintBounded_Faster(prm.numSampleSets);
+    P.sampleSetIdx = prm.emissive ? P.rngGroup.UniformUintBounded_Faster(prm.numSampleSets) : 0u;      // ReSTIR_PT_PathTrace.hlsl:406-408
     P.rc = InitReconnection();
     P.bounce = 0; P.throughput = bs.bsdfOverPdf;
     P.prevHit.alpha_lobe = LobeAlpha(ps.surface, bs.lobe); P.prevHit.lobe = bs.lobe; P.prevHit.wi = bs.wi; P.prevHit.pdf = bs.pdf;
@@ -771,9 +887,9 @@ ZR_HD void PtInitLane(const SceneView& sc, const zr_frame_constants& g, const GB
     P.throughput_k = v3(1.0f);
     P.inMedium = P.eta_curr != kEtaAir;
     P.pos = ps.pos; P.normal = ps.normal; P.surface = ps.surface; P.bs = bs; P.eta_next = ps.eta_next;
-    Globals gl; gl.sc = &sc; gl.numEmissives = g.num_emissive_triangles; gl.maxNumBounces = P.maxNumBounces; gl.alpha_min = prm.alpha_min; gl.stack = stack; gl.cnt = cnt;
+    Globals gl; gl.sc = &sc; gl.frame = &g; gl.numEmissives = g.num_emissive_triangles; gl.maxNumBounces = P.maxNumBounces; gl.alpha_min = prm.alpha_min; gl.stack = stack; gl.cnt = cnt;
     gl.presampled = prm.numSampleSets != 0; gl.sampleSetIdx = P.sampleSetIdx;
-    P.nextHit = FindClosestEm(gl, ps.pos, ps.normal, bs.wi, ps.surface.Transmissive());
+    if (prm.emissive) P.nextHit = FindClosestEm(gl, ps.pos, ps.normal, bs.wi, ps.surface.Transmissive());
     P.active = true;
 }
 
@@ -781,12 +897,17 @@ ZR_HD void PtPhaseA(const SceneView& sc, const zr_frame_constants& g, const RptP
 {
     P.atRR = false;
     if (!P.active) return;
-    Globals gl; gl.sc = &sc; gl.numEmissives = g.num_emissive_triangles; gl.maxNumBounces = P.maxNumBounces; gl.alpha_min = prm.alpha_min; gl.stack = stack; gl.cnt = cnt;
+    Globals gl; gl.sc = &sc; gl.frame = &g; gl.numEmissives = g.num_emissive_triangles; gl.maxNumBounces = P.maxNumBounces; gl.alpha_min = prm.alpha_min; gl.stack = stack; gl.cnt = cnt;
     gl.presampled = prm.numSampleSets != 0; gl.sampleSetIdx = P.sampleSetIdx;
     P.pathVertex = P.bounce + 2;
-    if (!P.nextHit.hit) { P.active = false; return; }
-    P.hit.t = P.nextHit.t;
-    FillHit<false>(sc, P.nextHit.mesh, P.nextHit.prim, P.nextHit.bu, P.nextHit.bv, true, P.hit, true);
+    if (prm.emissive)
+    {
+        // the BSDF ray of the previous vertex's NEE (ReSTIR_PT_PathTrace.hlsl:235-239)
+        if (!P.nextHit.hit) { P.active = false; return; }
+        P.hit.t = P.nextHit.t;
+        FillHit<false>(sc, P.nextHit.mesh, P.nextHit.prim, P.nextHit.bu, P.nextHit.bv, true, P.hit, true);
+    }
+    else if (!FindClosestID(gl, true, P.pos, P.normal, P.bs.wi, P.surface.Transmissive(), P.hit)) { P.active = false; return; }   // Hit::FindClosest<true, true>
     V3 newPos = mad(P.hit.t, P.bs.wi, P.pos);
     float eta_mat;
     if (!GetMaterialData(sc, -P.bs.wi, P.eta_curr, P.hit, P.surface, eta_mat)) { P.active = false; return; }
@@ -817,7 +938,7 @@ ZR_HD uint32_t PtRRKey(const PTLane& P)
     return (zr_isnan(lum) || lum < 0) ? 0u : zr_asuint(lum);
 }
 
-ZR_HD void PtPhaseB(const RptParams& prm, PTLane& P, uint32_t waveMaxBits)
+ZR_HD void PtPhaseB(const SceneView& sc, const RptParams& prm, PTLane& P, uint32_t waveMaxBits)
 {
     if (!P.active) return;
     const float waveThroughput = zr_asfloat(waveMaxBits);
@@ -827,6 +948,11 @@ ZR_HD void PtPhaseB(const RptParams& prm, PTLane& P, uint32_t waveMaxBits)
         if (P.rngGroup.Uniform() < p_terminate) { P.active = false; return; }
         P.throughput = P.throughput / (1 - p_terminate);
         P.throughput_k = P.throughput_k / (((int)P.rc.k <= P.bounce) ? (1 - p_terminate) : 1.0f);
+    }
+    if (!prm.emissive)      // ReSTIR_PT_PathTrace.hlsl:310-316
+    {
+        P.bs = InitBsdfSample();
+        if (P.bounce < P.maxNumBounces) P.bs = SampleBSDF(sc.rho, P.normal, P.surface, P.rngReplay);
     }
     if (dot(P.bs.bsdfOverPdf, P.bs.bsdfOverPdf) == 0) { P.active = false; return; }
     const float alpha_lobe = LobeAlpha(P.surface, P.bs.lobe);
@@ -858,7 +984,7 @@ ZR_HD void PtFinishLane(const GBuf& gb, const RptParams& prm, const ResPlanes& o
     r.rc.seed_replay = P.seed_replay;
     float targetLum = Luminance(r.target);
     r.W = targetLum > 0 ? zr_max(r.w_sum / targetLum, 1.0f) : 0;
-    if (prm.writeReservoirs) r.Write(out, px, 0);
+    if (prm.writeReservoirs) r.Write(out, px, 0, prm.emissive != 0);
     if (prm.doTemporal) tex.target[px] = f4(Sanitize3(r.target), 0.0f);
     else
     {
@@ -1047,6 +1173,75 @@ ZR_HD_FLAT float StepPath(const Globals& g, bool currFrame, OffsetCtx& ctx, cons
     return pj;
 }
 
+// RPT_Util::EstimateDirect_y_k_min_1, Shift.hlsli:548-660 (SKY_SAMPLING_PREFER_PERFORMANCE == 1): the sun / sky RIS of NEE_NonEmissive
+// re-run at the offset path's y_{k-1} with the base path's pick (lt, wd, lobe) forced; returns ld, writes its pdf
+ZR_HD V3 EstimateDirect_y_k_min_1(const Globals& g, OffsetCtx ctx, uint32_t lt, V3 wd, uint32_t lobe, Rng rngNEE, float& pdfOut)
+{
+    const SceneView& sc = *g.sc; const zr_frame_constants& fr = *g.frame; const RhoView& rho = sc.rho;
+    rngNEE.Uniform2D();
+    const V2 u_d = rngNEE.Uniform2D();
+    const V2 u_c = rngNEE.Uniform2D();
+    const V2 u_g = rngNEE.Uniform2D();
+    const float u_wrs_b0 = rngNEE.Uniform();
+    const float u_wrs_b1 = rngNEE.Uniform();
+    SkyIncidentRadiance leFunc; leFunc.lut = sc.sky;
+    const bool specular = IsSpecular(ctx.surface);
+    V3 target_z = v3(0.0f);
+    float w_sum;
+    {
+        const V3 wi_sun = -v3p(fr.sun_dir);
+        float pdf_b = 0, pdf_e = 0;
+        const bool visible = (wi_sun.y > 0) && ((dot(wi_sun, ctx.normal) > 0) || ctx.surface.Transmissive());
+        if (visible)
+        {
+            ctx.surface.SetWi(wi_sun, ctx.normal);
+            target_z = Le_Sun(ctx.pos, fr) * Unified(rho, ctx.surface).f;
+            const float ndotWi = dot(wi_sun, ctx.normal);
+            pdf_b = (ndotWi < 0) && ctx.surface.ThinWalled() ? 0 : BSDFSamplerPdf_NoDiffuse(rho, ctx.normal, ctx.surface, wi_sun, leFunc);
+            pdf_e = (!specular ? 1.0f : 0.0f) * zr_abs(ndotWi) * ZR_ONE_OVER_PI;
+            pdf_e *= ctx.surface.ThinWalled() ? 0.5f : (ndotWi > 0 ? 1.0f : 0.0f);
+        }
+        w_sum = BalanceHeuristic3(1, pdf_e, pdf_b, Luminance(target_z));
+    }
+    if (!specular)
+    {
+        const bool isZ_e = lt == LT_SKY && lobe == LOBE_ALL;
+        float pdf_unused;
+        V3 wi_e = isZ_e ? wd : SampleDiffuse(ctx.normal, u_d, &pdf_unused);
+        float pdf_e = zr_saturate(dot(ctx.normal, wi_e)) * ZR_ONE_OVER_PI;
+        if (ctx.surface.ThinWalled()) { wi_e = u_wrs_b1 > 0.5f ? -wi_e : wi_e; pdf_e *= 0.5f; }
+        ctx.surface.SetWi(wi_e, ctx.normal);
+        const V3 target = leFunc(wi_e) * Unified(rho, ctx.surface).f;
+        target_z = isZ_e ? target : target_z;
+        const float pdf_b = !ctx.surface.reflection && ctx.surface.ThinWalled() ? 0 : BSDFSamplerPdf_NoDiffuse(rho, ctx.normal, ctx.surface, wi_e, leFunc);
+        const float denom = pdf_e + pdf_b;
+        w_sum += denom == 0 ? 0.0f : Luminance(target) / denom;
+    }
+    const bool isZ_b = lt == LT_SKY && lobe != LOBE_ALL;
+    if (isZ_b)
+    {
+        const SamplerEval e = EvalBSDFSampler_NoDiffuse(rho, ctx.normal, ctx.surface, wd, lobe, leFunc);
+        target_z = e.f;
+        const float ndotwi = dot(wd, ctx.normal);
+        float pdf_e = (!specular ? 1.0f : 0.0f) * zr_abs(ndotwi) * ZR_ONE_OVER_PI;
+        pdf_e *= ctx.surface.ThinWalled() ? 0.5f : (ndotwi > 0 ? 1.0f : 0.0f);
+        const float denom = e.pdf + pdf_e;
+        w_sum += denom == 0 ? 0.0f : Luminance(e.f) / denom;
+    }
+    else
+    {
+        const BsdfSample bs = SampleBSDF_NoDiffuse(rho, ctx.normal, ctx.surface, u_c, u_g, u_wrs_b0, u_wrs_b1, leFunc);
+        const float ndotwi = dot(bs.wi, ctx.normal);
+        float pdf_e = (!specular ? 1.0f : 0.0f) * zr_abs(ndotwi) * ZR_ONE_OVER_PI;
+        pdf_e *= ctx.surface.ThinWalled() ? 0.5f : (ndotwi > 0 ? 1.0f : 0.0f);
+        const float denom = bs.pdf + pdf_e;
+        w_sum += denom == 0 ? 0.0f : Luminance(bs.f) / denom;
+    }
+    const float targetLum = Luminance(target_z);
+    pdfOut = w_sum > 0 ? targetLum / w_sum : 0;
+    return targetLum > 0 ? target_z * w_sum / targetLum : v3(0.0f);
+}
+
 struct OffsetPath { V3 target; float partialJacobian; bool surfKMin1Transmissive; };
 
 // Shift2<Emissive = true>, Shift.hlsli:662-816
@@ -1085,6 +1280,25 @@ ZR_HD_FLAT OffsetPath Shift2(const Globals& g, bool currFrame, size_t DTidIdx, V
         if (LobeAlpha(ctx.surface, rc.lobe_k_min_1) < g.alpha_min) return ret;
     }
     Rng rngNEE = Rng::Seed(rc.seed_nee);
+    if (g.numEmissives == 0)      // Shift2<Emissive = false>, Shift.hlsli:788-813
+    {
+        const uint32_t lt = rc.IsCase2() ? rc.lt_k_plus_1 : rc.lt_k;
+        const uint32_t lobe = rc.IsCase2() ? rc.lobe_k : rc.lobe_k_min_1;
+        float pdf;
+        const V3 target = EstimateDirect_y_k_min_1(g, ctx, lt, rc.w, lobe, rngNEE, pdf);
+        ret.target = ctx.throughput * target;
+        if (rc.IsCase2()) ret.partialJacobian *= pdf;
+        else
+        {
+            ret.partialJacobian = pdf;
+            if (dot(ret.target, ret.target) > 0)
+            {
+                const V3 wi = rc.lt_k == LT_SUN ? -v3p(g.frame->sun_dir) : rc.w;
+                ret.target = ret.target * (VisibilityRay(g, ctx.pos, wi, ctx.normal, ctx.surface.Transmissive()) ? 1.0f : 0.0f);
+            }
+        }
+        return ret;
+    }
     if (rc.IsCase2())
     {
         Direct ls = EvalDirect_Case2(g, ctx.normal, ctx.surface, rc.w, rc.L, rc.dwdA, rc.lightPdf, rc.lobe_k, ctx.rngReplay, rngNEE);
@@ -1119,7 +1333,7 @@ struct RptFrame
 
 ZR_HD Globals MakeGlobals(const RptFrame& F, const zr_frame_constants& g, bool transmissive, TravStack stack, uint32_t* cnt)
 {
-    Globals gl; gl.sc = &F.sc; gl.numEmissives = g.num_emissive_triangles; gl.alpha_min = F.prm.alpha_min; gl.stack = stack; gl.cnt = cnt; gl.presampled = false; gl.sampleSetIdx = 0;
+    Globals gl; gl.sc = &F.sc; gl.frame = &g; gl.numEmissives = g.num_emissive_triangles; gl.alpha_min = F.prm.alpha_min; gl.stack = stack; gl.cnt = cnt; gl.presampled = false; gl.sampleSetIdx = 0;
     gl.maxNumBounces = transmissive ? (int)F.prm.maxGlossyTrBounces : (int)F.prm.maxNonTrBounces;
     return gl;
 }
@@ -1166,7 +1380,7 @@ ZR_HD_FLAT void ReplayTemporalPixel(const RptFrame& F, const zr_frame_constants&
         Reservoir r = Load_Metadata(F.cur, px);
         if (!r.rc.Empty() && (r.rc.k > 2))
         {
-            r.Load_Reconnection(F.cur, px);
+            r.Load_Reconnection(F.cur, px, F.prm.emissive != 0);
             OffsetCtx ctx = Replay_kGt2(gl, false, tp.prev.pos, tp.prev.normal, tp.prev.eta_next, tp.prev.surface, r.rc);
             WriteOffsetCtx(ctx, F.rbCtN, px, r.rc.IsCase3());
         }
@@ -1176,7 +1390,7 @@ ZR_HD_FLAT void ReplayTemporalPixel(const RptFrame& F, const zr_frame_constants&
         Reservoir r = Load_Metadata(F.prev, pp);
         if (!r.rc.Empty() && (r.rc.k > 2))
         {
-            r.Load_Reconnection(F.prev, pp);
+            r.Load_Reconnection(F.prev, pp, F.prm.emissive != 0);
             OffsetCtx ctx = Replay_kGt2(gl, true, ps.pos, ps.normal, ps.eta_next, ps.surface, r.rc);
             WriteOffsetCtx(ctx, F.rbNtC, px, r.rc.IsCase3());
         }
@@ -1229,7 +1443,7 @@ ZR_HD void ReconnectTemporalPixel(const RptFrame& F, const zr_frame_constants& g
         Reservoir r_prev = Load_Metadata(F.prev, pp);
         if (r_curr.w_sum != 0 && r_prev.M > 0 && !r_curr.rc.Empty())
         {
-            r_curr.Load_Reconnection(F.cur, px);
+            r_curr.Load_Reconnection(F.cur, px, F.prm.emissive != 0);
             if (r_curr.rc.IsCase1() || r_curr.rc.IsCase2()) MoveXk(F.sc, r_curr.rc, true, false);
             OffsetPath shift = Shift2(gl, false, px, tp.prev.pos, tp.prev.normal, tp.prev.eta_next, tp.prev.surface, r_curr.rc, F.rbCtN);
             float target_prev = Luminance(shift.target);
@@ -1264,7 +1478,7 @@ ZR_HD void ReconnectTemporalPixel(const RptFrame& F, const zr_frame_constants& g
         if (!doSpatial) WriteOutputColor(g, F.finalRGBA, px, r_curr.target * r_curr.W);
         return;
     }
-    r_prev.Load_Reconnection(F.prev, pp);
+    r_prev.Load_Reconnection(F.prev, pp, F.prm.emissive != 0);
     if (r_prev.rc.IsCase1() || r_prev.rc.IsCase2()) MoveXk(F.sc, r_prev.rc, false, true);
     OffsetPath shift = Shift2(gl, true, px, ps.pos, ps.normal, ps.eta_next, ps.surface, r_prev.rc, F.rbNtC);
     float targetLum_curr = Luminance(shift.target);
@@ -1285,7 +1499,7 @@ ZR_HD void ReconnectTemporalPixel(const RptFrame& F, const zr_frame_constants& g
     r_curr.M = M_new;
     if (changed)
     {
-        r_curr.Write(F.cur, px, M_max);
+        r_curr.Write(F.cur, px, M_max, F.prm.emissive != 0);
         if (doSpatial) F.tex.target[px] = f4(Sanitize3(r_curr.target), 0.0f);
     }
     else r_curr.WriteReservoirData(F.cur, px, M_max);
@@ -1401,7 +1615,7 @@ ZR_HD_FLAT void ReplaySpatialPixel(const RptFrame& F, const zr_frame_constants& 
         Reservoir r = Load_Metadata(F.cur, px);
         if (!r.rc.Empty() && (r.rc.k > 2))
         {
-            r.Load_Reconnection(F.cur, px);
+            r.Load_Reconnection(F.cur, px, F.prm.emissive != 0);
             if (!NeighborOf(F, x, y, sx, sy)) return;
             const size_t sp = Pix(F.gb, (uint32_t)sx, (uint32_t)sy);
             PixelSurface pn = LoadPixelSurface(F.gb, cam, (uint32_t)sx, (uint32_t)sy, g.frame_num, sp);
@@ -1416,7 +1630,7 @@ ZR_HD_FLAT void ReplaySpatialPixel(const RptFrame& F, const zr_frame_constants& 
         Reservoir r = Load_Metadata(F.cur, sp);
         if (!r.rc.Empty() && (r.rc.k > 2))
         {
-            r.Load_Reconnection(F.cur, sp);
+            r.Load_Reconnection(F.cur, sp, F.prm.emissive != 0);
             PixelSurface ps = LoadPixelSurface(F.gb, cam, x, y, g.frame_num, px);
             OffsetCtx ctx = Replay_kGt2(gl, true, ps.pos, ps.normal, ps.eta_next, ps.surface, r.rc);
             WriteOffsetCtx(ctx, F.rbNtC, px, r.rc.IsCase3());
@@ -1458,7 +1672,7 @@ ZR_HD void ReconnectCtSPixel(const RptFrame& F, const zr_frame_constants& g, uin
     Reservoir r_spatial = Load_Metadata(F.cur, sp);
     if ((r_curr.w_sum != 0) && !r_curr.rc.Empty())
     {
-        r_curr.Load_Reconnection(F.cur, px);
+        r_curr.Load_Reconnection(F.cur, px, F.prm.emissive != 0);
         Globals gl = MakeGlobals(F, g, flags.transmissive, stack, cnt);
         const Camera cam = CurrCamera(g);
         PixelSurface pn = LoadPixelSurface(F.gb, cam, (uint32_t)sx, (uint32_t)sy, g.frame_num, px);
@@ -1485,7 +1699,7 @@ struct StcLane
 };
 ZR_HD void StcCopyToNextFrame(const RptFrame& F, size_t px, Reservoir& r, uint32_t M_max)
 {
-    if (!r.rc.Empty()) { r.Load_Reconnection(F.cur, px); r.Write(F.prev, px, M_max); }
+    if (!r.rc.Empty()) { r.Load_Reconnection(F.cur, px, F.prm.emissive != 0); r.Write(F.prev, px, M_max, F.prm.emissive != 0); }
     else r.WriteReservoirData(F.prev, px, M_max);
 }
 ZR_HD void StcSuppress(float waveAvgExclusive, Reservoir& r)
@@ -1551,7 +1765,7 @@ ZR_HD void StcPhase2(const RptFrame& F, const zr_frame_constants& g, StcLane& a,
     a.resample = true;
     a.M_max = a.r_spatial.rc.x_k_in_motion ? umin(a.M_max, kMmaxXkInMotion) : a.M_max;
     a.r_spatial.rc.x_k_in_motion = false;
-    a.r_spatial.Load_Reconnection(F.cur, a.sp);
+    a.r_spatial.Load_Reconnection(F.cur, a.sp, F.prm.emissive != 0);
     Globals gl = MakeGlobals(F, g, a.flags.transmissive, stack, cnt);
     OffsetPath shift = Shift2(gl, true, a.px, a.ps.pos, a.ps.normal, a.ps.eta_next, a.ps.surface, a.r_spatial.rc, F.rbNtC);
     float targetLum_curr = Luminance(shift.target);
@@ -1582,7 +1796,7 @@ ZR_HD void StcPhase3(const RptFrame& F, const zr_frame_constants& g, StcLane& a,
         float waveAvgExclusive = (waveSum - a.r_curr.w_sum) / 64.0f;
         StcSuppress(waveAvgExclusive, a.r_curr);
     }
-    if (a.changed) a.r_curr.Write(F.prev, a.px, a.M_max);
+    if (a.changed) a.r_curr.Write(F.prev, a.px, a.M_max, F.prm.emissive != 0);
     else StcCopyToNextFrame(F, a.px, a.r_curr, a.M_max);
     WriteOutputColor(g, F.finalRGBA, a.px, a.r_curr.target * a.r_curr.W);
 }
