@@ -342,9 +342,20 @@ class Renderer:
         self.p_direct = Pass(PASS_DI_EMISSIVE, self.p_indirect.w, self.p_indirect.h_, device=device, params=params)
         return self.p_direct
 
-    def render_frame(self, cb, stream=None):
-        if self.p_sky is not None:
+    _SKY_FIELDS = ("sun_dir", "sun_illuminance", "planet_radius", "atmosphere_altitude", "g", "rayleigh_sigma_s_color", "rayleigh_sigma_s_scale",
+                   "ozone_sigma_a_color", "ozone_sigma_a_scale", "mie_sigma_s", "mie_sigma_a")
+
+    def render_sky(self, cb, stream=None):
+        """K17 only when its inputs (sun, atmosphere) changed: the LUT does not depend on the camera"""
+        if self.p_sky is None:
+            return
+        key = b"".join(np.asarray(cb[f]).tobytes() for f in self._SKY_FIELDS)
+        if key != getattr(self, "_sky_key", None):
             self.p_sky.render(cb, self.scene, None, stream)
+            self._sky_key = key
+
+    def render_frame(self, cb, stream=None):
+        self.render_sky(cb, stream)
         self.p_gbuffer.render(cb, self.scene, self.gbuffer, stream)
         if not self._alias_ready or self._presampling:      # presampled light sets are regenerated every frame (K3)
             self.p_prelight.render(cb, self.scene, None, stream)

@@ -134,8 +134,7 @@ class TiledRestirPT:
 
     def stage_temporal(self, cb):
         api, r = self.api, self.r
-        if r.p_sky is not None:
-            r.p_sky.render(cb, r.scene, None)
+        r.render_sky(cb)
         r.p_gbuffer.render(cb, r.scene, r.gbuffer)
         if len(r.scene_host.emissives) and (not r._alias_ready or r._presampling):
             r.p_prelight.render(cb, r.scene, None)
@@ -145,6 +144,8 @@ class TiledRestirPT:
             return
         if r.p_direct is not None:
             r.p_direct.render(cb, r.scene, r.gbuffer)
+        if r.p_sky_direct is not None:
+            r.p_sky_direct.render(cb, r.scene, r.gbuffer)
         r.p_indirect.render_stage(cb, r.scene, r.gbuffer, api.STAGE_TEMPORAL)
 
     def stage_spatial(self, cb):
