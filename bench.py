@@ -252,6 +252,16 @@ def main():
         r.p_gbuffer.read_counters(reset=True)
         r.p_gbuffer.enable_timing(False)
         r.p_indirect.enable_timing(False)
+        # per-frame wall time distribution (SURVEY 8(d) timing protocol): host clock around one frame + device sync
+        ft = []
+        for i in range(64):
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            frame(2000 + i)
+            torch.cuda.synchronize()
+            ft.append((time.perf_counter() - t1) * 1e3)
+        out["config"]["frame_ms_median"] = round(float(np.median(ft)), 4)
+        out["config"]["frame_ms_p95"] = round(float(np.percentile(ft, 95)), 4)
         dom = max(agg, key=lambda k: agg[k][0])
         launches = agg[dom][1]
         avg_ms = agg[dom][0] / launches
@@ -278,8 +288,19 @@ def main():
             bytes_launch = 0.0
         achieved = bytes_launch / (avg_ms * 1e-3) / 1e9
         frame_bytes = (BYTES_CLOSEST * (cc / nfr + W * H) + BYTES_SHADOW * (cs / nfr) + (47 + 38 + 16) * W * H)
+        # measured HBM-side bytes per launch of that kernel: PMC passes (FETCH_SIZE x 2 x 1024 + WRITE_SIZE x 1024, MI355X_MICROARCH.md) of
+        # exactly this command, collected by scripts/gpu_pmc.sh and committed under profiles/ (rocprofv3 cannot run inside the bench)
+        traffic, traffic_src = None, None
+        default_workload = (args.scene.endswith("cornell_emissive.npz") and rpt and not args.direct and not args.sky_direct and (W, H) == (1920, 1080))
+        pmc_file = os.path.join(ROOT, "profiles", "r01_pmc_traffic_rpt1080p.json")
+        if default_workload and os.path.exists(pmc_file):
+            kmap = {"rpt_pathtrace": "k_rpt_pathtrace", "rpt_reconnect_spatial": "k_rpt_stc", "rpt_reconnect_temporal": "k_rpt_temporal", "gbuffer": "k_gbuffer"}
+            rec = json.load(open(pmc_file)).get(kmap.get(dom, ""))
+            if rec:
+                traffic, traffic_src = round(rec["traffic_bytes"]), "profiles/r01_pmc_traffic_rpt1080p.json"
         out["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
-                           "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                           "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_unit": "bytes per launch",
+                           "traffic_source": traffic_src, "algorithmic_bytes_per_launch": round(bytes_launch),
                            "avg_launch_ms": round(avg_ms, 4), "launches_per_frame": launches / nfr,
                            "frame_model_GBs": round(frame_bytes / (ms_per_step * 1e-3) / 1e9, 2),
                            "kernel_ms_per_frame": {k: round(v[0] / nfr, 4) for k, v in agg.items()}}

@@ -91,3 +91,28 @@ def test_cpp_passes_render_gi_and_di_sequence(cornell_emissive, oracle_emissive)
         dwant = odi.render(cbs[f], wire.default_params_di())
     assert np.array_equal(out.view(np.uint32), want.view(np.uint32))
     assert np.array_equal(dout.view(np.uint32), dwant.view(np.uint32))
+
+
+@pytest.mark.gpu
+def test_cpp_passes_render_sun_sky_sequence():
+    """The reference's default frame through the C++ mirror: Sky (K17) -> GBuffer -> {SkyDI (K7/K8), Indirect (ReSTIR PT, sun + sky NEE)}
+    scheduled by the RenderGraph for 3 frames == the oracle's frame 3 of both."""
+    import os
+    from oracle import zro
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sc = scene_io.load_npz(os.path.join(root, "tests", "golden", "cornell.npz"))
+    osc = zro.OracleScene(sc)
+    w, h, n = 80, 48, 3
+    cbs = np.ascontiguousarray(np.stack([scene_io.make_frame_constants(w, h, frame_num=f, num_emissives=0) for f in range(1, n + 1)]))
+    desc = sc.desc()
+    out, dout = np.zeros((h, w, 4), np.float32), np.zeros((h, w, 4), np.float32)
+    L = _lib()
+    L.zrh_render_sequence_sky.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.c_void_p, C.c_void_p]
+    assert L.zrh_render_sequence_sky(C.addressof(desc), cbs.ctypes.data, n, w, h, 2, out.ctypes.data, dout.ctypes.data) == 0
+    opt, osd = zro.OracleRPT(osc, w, h), zro.OracleSDI(osc, w, h)
+    for f in range(n):
+        osc.sky_lut(cbs[f], 256, 128)
+        want = opt.render(cbs[f], wire.default_params())
+        dwant = osd.render(cbs[f], wire.default_params_sky_di())
+    assert np.array_equal(out.view(np.uint32), want.view(np.uint32))
+    assert np.array_equal(dout.view(np.uint32), dwant.view(np.uint32))

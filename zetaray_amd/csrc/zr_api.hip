@@ -50,11 +50,11 @@ static int RequireDevice(int device)
 // ------------------------------------------------------------------------------------------------ device helpers
 static constexpr int kBlock = 256;
 // Occupancy targets of the register-heavy shading kernels, waves per SIMD (the compiler spills a little to reach them).
-// Measured on MI355X, Cornell 1080p / 380k-triangle atrium: k_rpt_pathtrace 2 -> 4 waves: 1.45 -> 1.19 ms /
-// 14.9 -> 10.7 ms; k_rgi 2 -> 4: 2.19 -> 1.68 ms; k_rdi_* 2 -> 3: 0.72 -> 0.67, 0.39 -> 0.33 ms; k_sdi_spatial -> 4: 0.58 ->
+// Measured on MI355X, Cornell 1080p / 380k-triangle atrium: k_rpt_pathtrace 2 -> 3 waves: 1.45 -> 1.21 ms /
+// 14.9 -> 11.8 ms (4 waves: 1.19 / 10.7 ms, but its ~300 B/lane of spills stream 3.4 GB through L2 per launch, PMC); k_rgi 2 -> 4: 2.19 -> 1.68 ms; k_rdi_* 2 -> 3: 0.72 -> 0.67, 0.39 -> 0.33 ms; k_sdi_spatial -> 4: 0.58 ->
 // 0.49 ms.  k_rpt_temporal, k_rpt_stc, k_pt_shade and k_sdi_temporal got slower with more waves and keep the default.
 #define ZR_WAVES(n) __attribute__((amdgpu_waves_per_eu(n, n)))
-#define ZR_WAVES_PATHTRACE ZR_WAVES(4)
+#define ZR_WAVES_PATHTRACE ZR_WAVES(3)
 #define ZR_WAVES_RGI ZR_WAVES(4)
 #define ZR_WAVES_RDI_T ZR_WAVES(3)
 #define ZR_WAVES_RDI_S ZR_WAVES(3)

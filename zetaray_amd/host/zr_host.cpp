@@ -239,6 +239,35 @@ void* DirectLighting::GetOutput(SHADER_OUT_RES i) const
 }
 void DirectLighting::Render(Core::CommandList& cl) { ZR_CHECK(zr_pass_render(m_pass, cl.Stream(), &m_ctx->frameConstants, m_ctx->scene, m_ctx->gbuffer)); }
 
+void Sky::Init(FrameContext* ctx, int lutWidth, int lutHeight)
+{
+    // the LUT has its own size: InitRenderPass would use the render size
+    m_ctx = ctx;
+    ZR_CHECK(zr_pass_create(ZR_PASS_SKY, ctx->device, &m_pass));
+    ZR_CHECK(zr_pass_init(m_pass, (uint32_t)lutWidth, (uint32_t)lutHeight, 0));
+    m_initialized = true;
+}
+void* Sky::GetOutput(SHADER_OUT_RES i) const
+{
+    if (i != SHADER_OUT_RES::SKY_VIEW_LUT) { std::fprintf(stderr, "Invalid shader output.\n"); std::abort(); }
+    void* dev = nullptr; uint32_t w, h, bpp;
+    ZR_CHECK(zr_pass_get_output(m_pass, ZR_OUT_SKY_LUT, &dev, &w, &h, &bpp));
+    return dev;
+}
+void Sky::Render(Core::CommandList& cl) { ZR_CHECK(zr_pass_render(m_pass, cl.Stream(), &m_ctx->frameConstants, m_ctx->scene, nullptr)); }
+
+void SkyDI::Init(FrameContext* ctx) { InitRenderPass(ZR_PASS_DI_SKY, ctx, 0); }       // library defaults = SkyDI.cpp:81-82
+void SkyDI::OnWindowResized() { ZR_CHECK(zr_pass_resize(m_pass, m_ctx->renderWidth, m_ctx->renderHeight)); }
+void SkyDI::ResetTemporal() { ZR_CHECK(zr_pass_reset_temporal(m_pass)); }
+void* SkyDI::GetOutput(SHADER_OUT_RES i) const
+{
+    if (i != SHADER_OUT_RES::DENOISED) { std::fprintf(stderr, "Invalid shader output.\n"); std::abort(); }
+    void* dev = nullptr; uint32_t w, h, bpp;
+    ZR_CHECK(zr_pass_get_output(m_pass, ZR_OUT_FINAL, &dev, &w, &h, &bpp));
+    return dev;
+}
+void SkyDI::Render(Core::CommandList& cl) { ZR_CHECK(zr_pass_render(m_pass, cl.Stream(), &m_ctx->frameConstants, m_ctx->scene, m_ctx->gbuffer)); }
+
 void IndirectLighting::Init(FrameContext* ctx, INTEGRATOR method)
 {
     zr_params_default(&m_params);
@@ -362,6 +391,48 @@ int zrh_render_sequence2(const zr_scene_desc* desc, const zr_frame_constants* cb
         }
         if (hipMemcpy(finalOut, ind.GetOutput(RenderPass::IndirectLighting::SHADER_OUT_RES::FINAL), (size_t)w * h * 16, hipMemcpyDeviceToHost) != hipSuccess) return -1;
         if (directOut && hipMemcpy(directOut, di.GetOutput(RenderPass::DirectLighting::SHADER_OUT_RES::FINAL), (size_t)w * h * 16, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    }
+    zr_gbuffer_destroy(ctx.gbuffer);
+    zr_scene_destroy(ctx.scene);
+    return 0;
+}
+
+// The reference's default (sun + sky) frame: Sky -> GBuffer -> {SkyDI, Indirect} (PathTracer.cpp:165-181, 311-360, 474-552).
+// Copies the FINAL planes of the last frame: Indirect to `finalOut`, SkyDI to `skyDiOut`.
+int zrh_render_sequence_sky(const zr_scene_desc* desc, const zr_frame_constants* cbs, uint32_t n, uint32_t w, uint32_t h, int integrator, float* finalOut, float* skyDiOut)
+{
+    RenderPass::FrameContext ctx;
+    ctx.device = 0; ctx.renderWidth = w; ctx.renderHeight = h;
+    ZR_CHECK(zr_scene_create(0, desc, &ctx.scene));
+    ZR_CHECK(zr_gbuffer_create(0, w, h, &ctx.gbuffer));
+    {
+        RenderPass::Sky sky; RenderPass::GBufferRT gb; RenderPass::IndirectLighting ind; RenderPass::SkyDI sdi;
+        sky.Init(&ctx, 256, 128); gb.Init(&ctx); ind.Init(&ctx, (RenderPass::IndirectLighting::INTEGRATOR)integrator); sdi.Init(&ctx);
+        Core::RenderGraph g;
+        enum : uint64_t { R_LUT = 1, R_GBUF, R_IND, R_SDI };
+        for (uint32_t f = 0; f < n; f++)
+        {
+            ctx.frameConstants = cbs[f];
+            g.BeginFrame();
+            auto hSky = g.RegisterRenderPass("Sky", Core::RENDER_NODE_TYPE::COMPUTE, Core::MakeDelegate(&sky, &RenderPass::Sky::Render));
+            auto hGB = g.RegisterRenderPass("GBuffer", Core::RENDER_NODE_TYPE::COMPUTE, Core::MakeDelegate(&gb, &RenderPass::GBufferRT::Render));
+            auto hSdi = g.RegisterRenderPass("SkyDI", Core::RENDER_NODE_TYPE::COMPUTE, Core::MakeDelegate(&sdi, &RenderPass::SkyDI::Render));
+            auto hInd = g.RegisterRenderPass("Indirect", Core::RENDER_NODE_TYPE::COMPUTE, Core::MakeDelegate(&ind, &RenderPass::IndirectLighting::Render));
+            g.RegisterResource(sky.GetOutput(RenderPass::Sky::SHADER_OUT_RES::SKY_VIEW_LUT), R_LUT); g.RegisterResource(nullptr, R_GBUF);
+            g.RegisterResource(ind.GetOutput(RenderPass::IndirectLighting::SHADER_OUT_RES::FINAL), R_IND);
+            g.RegisterResource(sdi.GetOutput(RenderPass::SkyDI::SHADER_OUT_RES::DENOISED), R_SDI);
+            g.MoveToPostRegister();
+            g.AddOutput(hSky, R_LUT, Core::STATE_UNORDERED_ACCESS);
+            g.AddOutput(hGB, R_GBUF, Core::STATE_UNORDERED_ACCESS);
+            g.AddInput(hSdi, R_LUT, Core::STATE_SHADER_READ); g.AddInput(hSdi, R_GBUF, Core::STATE_SHADER_READ); g.AddOutput(hSdi, R_SDI, Core::STATE_UNORDERED_ACCESS);
+            g.AddInput(hInd, R_LUT, Core::STATE_SHADER_READ); g.AddInput(hInd, R_GBUF, Core::STATE_SHADER_READ); g.AddOutput(hInd, R_IND, Core::STATE_UNORDERED_ACCESS);
+            Support::TaskSet ts;
+            g.Build(ts);
+            ts.Run(true);
+            g.WaitForFrame();
+        }
+        if (hipMemcpy(finalOut, ind.GetOutput(RenderPass::IndirectLighting::SHADER_OUT_RES::FINAL), (size_t)w * h * 16, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+        if (skyDiOut && hipMemcpy(skyDiOut, sdi.GetOutput(RenderPass::SkyDI::SHADER_OUT_RES::DENOISED), (size_t)w * h * 16, hipMemcpyDeviceToHost) != hipSuccess) return -1;
     }
     zr_gbuffer_destroy(ctx.gbuffer);
     zr_scene_destroy(ctx.scene);

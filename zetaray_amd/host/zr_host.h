@@ -191,6 +191,26 @@ namespace RenderPass {
         zr_params m_params{};
     };
 
+    // RP/Sky/Sky.h:12-112: sky-view LUT (the in-scattering voxel grid is out of scope)
+    struct Sky final : public RenderPassBase
+    {
+        enum class SHADER_OUT_RES { SKY_VIEW_LUT, COUNT };
+        void Init(FrameContext* ctx, int lutWidth, int lutHeight);
+        void* GetOutput(SHADER_OUT_RES i) const;
+        void Render(Core::CommandList& cmdList);
+    };
+
+    // RP/DirectLighting/Sky/SkyDI.h:19-137: ReSTIR DI for sun + sky
+    struct SkyDI final : public RenderPassBase
+    {
+        enum class SHADER_OUT_RES { DENOISED, COUNT };       // the reference names its (undenoised) FINAL output DENOISED
+        void Init(FrameContext* ctx);
+        void OnWindowResized();
+        void ResetTemporal();
+        void* GetOutput(SHADER_OUT_RES i) const;
+        void Render(Core::CommandList& cmdList);
+    };
+
     struct IndirectLighting final : public RenderPassBase
     {
         enum class SHADER_OUT_RES { FINAL, COUNT };
