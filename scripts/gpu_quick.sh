@@ -1,0 +1,6 @@
+cd $GRAFT_REPO_ROOT
+P='import sys,json; d=json.loads(sys.stdin.read()); print(d["ms_per_step"], d["roofline"]["kernel_ms_per_frame"])'
+timeout 900 python -m pytest tests -x -q -m gpu 2>&1 | tail -3
+timeout 600 python bench.py --gpus 1 --steps 32 --warmup 4 --no-cpu-baseline 2>&1 | tail -1 | python -c "$P"
+timeout 600 python bench.py --gpus 1 --steps 32 --warmup 4 --scene tests/golden/cornell.npz --no-cpu-baseline 2>&1 | tail -1 | python -c "$P"
+timeout 600 python bench.py --gpus 1 --steps 8 --warmup 2 --scene synthetic --no-cpu-baseline 2>&1 | tail -1 | python -c "$P"

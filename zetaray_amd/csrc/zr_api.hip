@@ -344,8 +344,11 @@ __device__ __forceinline__ void FlushRayCounters(unsigned long long* counters, c
 }
 
 // K11: block = 16x16 pixels, wave w = rows 4w..4w+3 (a 16x4 block: the RR "wave" of the ABI, zr_rpt.h header)
+// EMISSIVE: the NEE_EMISSIVE shader permutation (emissive triangles vs sun + sky); a template constant so the other variant folds away
+template<bool EMISSIVE>
 __global__ void __launch_bounds__(kBlock) ZR_WAVES_PATHTRACE k_rpt_pathtrace(rpt::RptFrame F, zr_frame_constants g, uint32_t tilesX, unsigned long long* counters)
 {
+    F.prm.emissive = EMISSIVE ? 1u : 0u;
     const uint32_t tile = blockIdx.x, tx = tile % tilesX, ty = tile / tilesX;
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
     const uint32_t x = F.ox0 + tx * 16u + (lane & 15u), y = F.oy0 + ty * 16u + wave * 4u + (lane >> 4);
@@ -394,10 +397,11 @@ __global__ void __launch_bounds__(kBlock) k_rpt_light(rpt::RptFrame F, zr_frame_
 }
 
 // K13 replays over a work list (device-side count, fixed grid, grid-stride): only pixels with k > 2 pay for the heavy kernel
-template<int PASS>
+template<int PASS, bool EMISSIVE>
 __global__ void __launch_bounds__(kBlock) k_rpt_replay(rpt::RptFrame F, zr_frame_constants g, const uint32_t* list, const uint32_t* count,
     unsigned long long* counters)
 {
+    F.prm.emissive = EMISSIVE ? 1u : 0u;
     ZR_TRAV_STACK(stack);
     uint32_t cnt[2] = {0u, 0u};
     const uint32_t n = *count;
@@ -413,8 +417,10 @@ __global__ void __launch_bounds__(kBlock) k_rpt_replay(rpt::RptFrame F, zr_frame
 }
 
 // K14: CtT + TtC fused per pixel (zr_rpt.h ReconnectTemporalPixel)
+template<bool EMISSIVE>
 __global__ void __launch_bounds__(kBlock) ZR_WAVES_TEMPORAL k_rpt_temporal(rpt::RptFrame F, zr_frame_constants g, uint32_t tilesX, unsigned long long* counters)
 {
+    F.prm.emissive = EMISSIVE ? 1u : 0u;
     uint32_t x, y; PixelOfThread(tilesX, F.ox0, F.oy0, &x, &y);
     ZR_TRAV_STACK(stack);
     uint32_t cnt[2] = {0u, 0u};
@@ -430,8 +436,10 @@ __device__ __forceinline__ float WaveSumButterfly(float v)
 }
 
 // K16 CtS + StC: wave = 8x8 pixel group; every lane of the wave walks all four phases (absent lanes contribute 0)
+template<bool EMISSIVE>
 __global__ void __launch_bounds__(kBlock) ZR_WAVES_STC k_rpt_stc(rpt::RptFrame F, zr_frame_constants g, uint32_t tilesX, unsigned long long* counters)
 {
+    F.prm.emissive = EMISSIVE ? 1u : 0u;
     uint32_t x, y; PixelOfThread(tilesX, F.ox0, F.oy0, &x, &y);
     ZR_TRAV_STACK(stack);
     uint32_t cnt[2] = {0u, 0u};
@@ -1329,26 +1337,32 @@ static int RenderReSTIR_PT(zr_pass* p, hipStream_t s, const zr_frame_constants* 
     const dim3 gridList((uint32_t)std::min<size_t>((cap + kBlock - 1) / kBlock, 1024));
     unsigned long long* ctr = p->counters.p;
 #define RPT_TIMED(name, launch) do { TimerBegin(p, s, name); launch; TimerEnd(p, s); } while (0)
+    // the NEE_EMISSIVE permutation of a kernel (the reference compiles separate shaders, IndirectLighting.h:251-300)
+    const bool emissiveVariant = prm.emissive != 0;
+#define RPT_LAUNCH_E(kern, ...) do { if (emissiveVariant) hipLaunchKernelGGL(kern<true>, __VA_ARGS__); else hipLaunchKernelGGL(kern<false>, __VA_ARGS__); } while (0)
+#define RPT_LAUNCH_PE(kern, PASS, ...) do { if (emissiveVariant) hipLaunchKernelGGL((kern<PASS, true>), __VA_ARGS__); else hipLaunchKernelGGL((kern<PASS, false>), __VA_ARGS__); } while (0)
     if (stages & ZR_STAGE_TEMPORAL)
     {
         HIP_TRY(hipMemsetAsync(listCnt, 0, 4 * sizeof(uint32_t), s));
-        RPT_TIMED("rpt_pathtrace", hipLaunchKernelGGL(k_rpt_pathtrace, grid, block, 0, s, F, *cb, tilesX, ctr + 2 * 1));
+        RPT_TIMED("rpt_pathtrace", RPT_LAUNCH_E(k_rpt_pathtrace, grid, block, 0, s, F, *cb, tilesX, ctr + 2 * 1));
         if (prm.doTemporal)
         {
             RPT_TIMED("rpt_classify_temporal", hipLaunchKernelGGL(k_rpt_light<0>, grid, block, 0, s, F, *cb, tilesX, lists[0], lists[1], listCnt + 0));
-            RPT_TIMED("rpt_replay_ctt", hipLaunchKernelGGL(k_rpt_replay<RPT_REPLAY_CTT>, gridList, block, 0, s, F, *cb, lists[0], listCnt + 0, ctr + 2 * 2));
-            RPT_TIMED("rpt_replay_ttc", hipLaunchKernelGGL(k_rpt_replay<RPT_REPLAY_TTC>, gridList, block, 0, s, F, *cb, lists[1], listCnt + 1, ctr + 2 * 3));
-            RPT_TIMED("rpt_reconnect_temporal", hipLaunchKernelGGL(k_rpt_temporal, grid, block, 0, s, F, *cb, tilesX, ctr + 2 * 4));
+            RPT_TIMED("rpt_replay_ctt", RPT_LAUNCH_PE(k_rpt_replay, RPT_REPLAY_CTT, gridList, block, 0, s, F, *cb, lists[0], listCnt + 0, ctr + 2 * 2));
+            RPT_TIMED("rpt_replay_ttc", RPT_LAUNCH_PE(k_rpt_replay, RPT_REPLAY_TTC, gridList, block, 0, s, F, *cb, lists[1], listCnt + 1, ctr + 2 * 3));
+            RPT_TIMED("rpt_reconnect_temporal", RPT_LAUNCH_E(k_rpt_temporal, grid, block, 0, s, F, *cb, tilesX, ctr + 2 * 4));
         }
     }
     if ((stages & ZR_STAGE_SPATIAL) && prm.doSpatial)
     {
         RPT_TIMED("rpt_spatial_search", hipLaunchKernelGGL(k_rpt_light<1>, grid, block, 0, s, F, *cb, tilesX, lists[2], lists[3], listCnt + 2));
-        RPT_TIMED("rpt_replay_cts", hipLaunchKernelGGL(k_rpt_replay<RPT_REPLAY_CTS>, gridList, block, 0, s, F, *cb, lists[2], listCnt + 2, ctr + 2 * 5));
-        RPT_TIMED("rpt_replay_stc", hipLaunchKernelGGL(k_rpt_replay<RPT_REPLAY_STC>, gridList, block, 0, s, F, *cb, lists[3], listCnt + 3, ctr + 2 * 6));
-        RPT_TIMED("rpt_reconnect_spatial", hipLaunchKernelGGL(k_rpt_stc, grid, block, 0, s, F, *cb, tilesX, ctr + 2 * 7));
+        RPT_TIMED("rpt_replay_cts", RPT_LAUNCH_PE(k_rpt_replay, RPT_REPLAY_CTS, gridList, block, 0, s, F, *cb, lists[2], listCnt + 2, ctr + 2 * 5));
+        RPT_TIMED("rpt_replay_stc", RPT_LAUNCH_PE(k_rpt_replay, RPT_REPLAY_STC, gridList, block, 0, s, F, *cb, lists[3], listCnt + 3, ctr + 2 * 6));
+        RPT_TIMED("rpt_reconnect_spatial", RPT_LAUNCH_E(k_rpt_stc, grid, block, 0, s, F, *cb, tilesX, ctr + 2 * 7));
     }
 #undef RPT_TIMED
+#undef RPT_LAUNCH_E
+#undef RPT_LAUNCH_PE
     HIP_TRY(hipGetLastError());
     if (stages & ZR_STAGE_SPATIAL)
     {

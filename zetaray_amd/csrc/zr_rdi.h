@@ -349,7 +349,7 @@ ZR_HD V3 EmissiveColor(const GBuf& gb, size_t px)
 
 ZR_HD Globals MakeGlobals(const DiFrame& F, const zr_frame_constants& g, TravStack stack, uint32_t* cnt)
 {
-    Globals gl; gl.sc = &F.sc; gl.numEmissives = g.num_emissive_triangles; gl.alpha_min = 0; gl.stack = stack; gl.cnt = cnt; gl.maxNumBounces = 1;
+    Globals gl; gl.sc = &F.sc; gl.frame = &g; gl.emissive = g.num_emissive_triangles != 0; gl.numEmissives = g.num_emissive_triangles; gl.alpha_min = 0; gl.stack = stack; gl.cnt = cnt; gl.maxNumBounces = 1;
     gl.presampled = false; gl.sampleSetIdx = 0;
     return gl;
 }

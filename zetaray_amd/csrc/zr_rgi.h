@@ -258,7 +258,7 @@ struct Lane
 
 ZR_HD Globals MakeGlobals(const GiFrame& F, const zr_frame_constants& g, const Lane& P, TravStack stack, uint32_t* cnt)
 {
-    Globals gl; gl.sc = &F.sc; gl.numEmissives = g.num_emissive_triangles; gl.alpha_min = 0; gl.stack = stack; gl.cnt = cnt; gl.maxNumBounces = P.maxNumBounces;
+    Globals gl; gl.sc = &F.sc; gl.frame = &g; gl.emissive = g.num_emissive_triangles != 0; gl.numEmissives = g.num_emissive_triangles; gl.alpha_min = 0; gl.stack = stack; gl.cnt = cnt; gl.maxNumBounces = P.maxNumBounces;
     gl.presampled = F.prm.numSampleSets != 0; gl.sampleSetIdx = P.sampleSetIdx;
     return gl;
 }

@@ -396,9 +396,10 @@ ZR_HD Reservoir Load_NonReconnection(const ResPlanes& p, size_t i)
 { Reservoir r = InitReservoir(); r.UnpackMetadata(p.A[i]); r.w_sum = p.B[2 * i]; r.W = p.B[2 * i + 1]; return r; }
 
 // cnt: this lane's ray counters {closest-hit queries, shadow / visibility queries} (never null)
-// numEmissives == 0 selects the NEE_EMISSIVE == 0 shader variants (sun + sky lighting); frame = cbFrameConstants (sun, atmosphere)
+// emissive == false selects the NEE_EMISSIVE == 0 shader variants (sun + sky lighting): the kernels are instantiated per variant and set
+// it from a template constant, so the other variant's code folds away; frame = cbFrameConstants (sun, atmosphere)
 struct Globals { const SceneView* sc; uint32_t numEmissives; int maxNumBounces; float alpha_min; TravStack stack; uint32_t* cnt; bool presampled; uint32_t sampleSetIdx;
-    const zr_frame_constants* frame; };
+    const zr_frame_constants* frame; bool emissive; };
 
 // ---- ray queries (inline traversal)
 struct HitEm { bool hit; float t; uint32_t mesh, prim, emissiveTriIdx; float bu, bv; };
@@ -699,7 +700,7 @@ ZR_HD void MaybeSetCase2OrCase3(const Globals& g, int pathVertex, V3 pos, V3 nor
 ZR_HD void EstimateDirectAndUpdateRC(const Globals& g, int pathVertex, V3 pos, const HitInfo& hit, const Surface& surface, const PrevHit& prevHit,
     V3 throughput, V3 throughput_k, V3& li, BsdfSample& bs, HitEm& nextHit, Reconnection& rc, Reservoir& r, Rng& rngNEE, Rng& rngReplay)
 {
-    if (g.numEmissives == 0)      // EstimateDirectAndUpdateRC<false>, ReSTIR_PT_PathTrace.hlsl:172-191
+    if (!g.emissive)      // EstimateDirectAndUpdateRC<false>, ReSTIR_PT_PathTrace.hlsl:172-191
     {
         const uint32_t seed_nee = rngNEE.s;
         Direct ls = NEE_NonEmissive(g, pos, hit.normal, surface, rngNEE);
@@ -887,7 +888,7 @@ ZR_HD void PtInitLane(const SceneView& sc, const zr_frame_constants& g, const GB
     P.throughput_k = v3(1.0f);
     P.inMedium = P.eta_curr != kEtaAir;
     P.pos = ps.pos; P.normal = ps.normal; P.surface = ps.surface; P.bs = bs; P.eta_next = ps.eta_next;
-    Globals gl; gl.sc = &sc; gl.frame = &g; gl.numEmissives = g.num_emissive_triangles; gl.maxNumBounces = P.maxNumBounces; gl.alpha_min = prm.alpha_min; gl.stack = stack; gl.cnt = cnt;
+    Globals gl; gl.sc = &sc; gl.frame = &g; gl.emissive = prm.emissive != 0; gl.numEmissives = g.num_emissive_triangles; gl.maxNumBounces = P.maxNumBounces; gl.alpha_min = prm.alpha_min; gl.stack = stack; gl.cnt = cnt;
     gl.presampled = prm.numSampleSets != 0; gl.sampleSetIdx = P.sampleSetIdx;
     if (prm.emissive) P.nextHit = FindClosestEm(gl, ps.pos, ps.normal, bs.wi, ps.surface.Transmissive());
     P.active = true;
@@ -897,7 +898,7 @@ ZR_HD void PtPhaseA(const SceneView& sc, const zr_frame_constants& g, const RptP
 {
     P.atRR = false;
     if (!P.active) return;
-    Globals gl; gl.sc = &sc; gl.frame = &g; gl.numEmissives = g.num_emissive_triangles; gl.maxNumBounces = P.maxNumBounces; gl.alpha_min = prm.alpha_min; gl.stack = stack; gl.cnt = cnt;
+    Globals gl; gl.sc = &sc; gl.frame = &g; gl.emissive = prm.emissive != 0; gl.numEmissives = g.num_emissive_triangles; gl.maxNumBounces = P.maxNumBounces; gl.alpha_min = prm.alpha_min; gl.stack = stack; gl.cnt = cnt;
     gl.presampled = prm.numSampleSets != 0; gl.sampleSetIdx = P.sampleSetIdx;
     P.pathVertex = P.bounce + 2;
     if (prm.emissive)
@@ -1280,7 +1281,7 @@ ZR_HD_FLAT OffsetPath Shift2(const Globals& g, bool currFrame, size_t DTidIdx, V
         if (LobeAlpha(ctx.surface, rc.lobe_k_min_1) < g.alpha_min) return ret;
     }
     Rng rngNEE = Rng::Seed(rc.seed_nee);
-    if (g.numEmissives == 0)      // Shift2<Emissive = false>, Shift.hlsli:788-813
+    if (!g.emissive)      // Shift2<Emissive = false>, Shift.hlsli:788-813
     {
         const uint32_t lt = rc.IsCase2() ? rc.lt_k_plus_1 : rc.lt_k;
         const uint32_t lobe = rc.IsCase2() ? rc.lobe_k : rc.lobe_k_min_1;
@@ -1333,7 +1334,7 @@ struct RptFrame
 
 ZR_HD Globals MakeGlobals(const RptFrame& F, const zr_frame_constants& g, bool transmissive, TravStack stack, uint32_t* cnt)
 {
-    Globals gl; gl.sc = &F.sc; gl.frame = &g; gl.numEmissives = g.num_emissive_triangles; gl.alpha_min = F.prm.alpha_min; gl.stack = stack; gl.cnt = cnt; gl.presampled = false; gl.sampleSetIdx = 0;
+    Globals gl; gl.sc = &F.sc; gl.frame = &g; gl.emissive = F.prm.emissive != 0; gl.numEmissives = g.num_emissive_triangles; gl.alpha_min = F.prm.alpha_min; gl.stack = stack; gl.cnt = cnt; gl.presampled = false; gl.sampleSetIdx = 0;
     gl.maxNumBounces = transmissive ? (int)F.prm.maxGlossyTrBounces : (int)F.prm.maxNonTrBounces;
     return gl;
 }
