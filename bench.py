@@ -294,7 +294,8 @@ def main():
         default_workload = (args.scene.endswith("cornell_emissive.npz") and rpt and not args.direct and not args.sky_direct and (W, H) == (1920, 1080))
         pmc_file = os.path.join(ROOT, "profiles", "r01_pmc_traffic_rpt1080p.json")
         if default_workload and os.path.exists(pmc_file):
-            kmap = {"rpt_pathtrace": "k_rpt_pathtrace", "rpt_reconnect_spatial": "k_rpt_stc", "rpt_reconnect_temporal": "k_rpt_temporal", "gbuffer": "k_gbuffer"}
+            kmap = {"rpt_pathtrace": "k_rpt_pathtrace<true>", "rpt_reconnect_spatial": "k_rpt_stc<true>", "rpt_reconnect_temporal": "k_rpt_temporal<true>",
+                    "gbuffer": "k_gbuffer"}
             rec = json.load(open(pmc_file)).get(kmap.get(dom, ""))
             if rec:
                 traffic, traffic_src = round(rec["traffic_bytes"]), "profiles/r01_pmc_traffic_rpt1080p.json"

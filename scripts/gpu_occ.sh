@@ -3,8 +3,7 @@ P='import sys,json; d=json.loads(sys.stdin.read()); print(d["ms_per_step"], d["r
 for v in base occ; do
   echo "== $v"
   if [ $v = occ ]; then cp zetaray_amd/libzr_occ.so zetaray_amd/libzetaray_amd.so; fi
-  timeout 600 python bench.py --gpus 1 --steps 32 --warmup 4 --direct --no-cpu-baseline 2>&1 | tail -1 | python -c "$P"
-  timeout 600 python bench.py --gpus 1 --steps 32 --warmup 4 --integrator restir_gi --no-cpu-baseline 2>&1 | tail -1 | python -c "$P"
-  timeout 600 python bench.py --gpus 1 --steps 32 --warmup 4 --scene tests/golden/cornell.npz --integrator pt --sky-direct --di-only --no-cpu-baseline 2>&1 | tail -1 | python -c "$P"
+  timeout 600 python bench.py --gpus 1 --steps 32 --warmup 4 --no-cpu-baseline 2>&1 | tail -1 | python -c "$P"
+  timeout 600 python bench.py --gpus 1 --steps 32 --warmup 4 --scene tests/golden/cornell.npz --no-cpu-baseline 2>&1 | tail -1 | python -c "$P"
   timeout 600 python bench.py --gpus 1 --steps 8 --warmup 2 --scene synthetic --no-cpu-baseline 2>&1 | tail -1 | python -c "$P"
 done

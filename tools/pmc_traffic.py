@@ -2,15 +2,16 @@
 FETCH_SIZE / WRITE_SIZE are KB; on gfx950 FETCH_SIZE under-reports wide coalesced reads by 2x (MI355X_MICROARCH.md, HBM section), so
 `fetch_bytes` = 2 x 1024 x FETCH_SIZE and `write_bytes` = 1024 x WRITE_SIZE (uncalibrated for narrow / scratch accesses).
   python tools/pmc_traffic.py gpurun_out/pmc_fetch_summary.csv gpurun_out/pmc_write_summary.csv profiles/r01_pmc_traffic_rpt1080p.json"""
-import csv
 import json
 import sys
 
 
 def load(path):
     out = {}
-    for row in csv.DictReader(open(path)):
-        out[row["kernel"].replace("void ", "")] = (float(row["avg_value_per_launch"]), int(row["launches"]), float(row["avg_duration_us"]))
+    for line in open(path).read().splitlines()[1:]:
+        # kernel names may contain commas (template arguments): split from the right
+        name, _ctr, launches, val, dur = line.rsplit(",", 4)
+        out[name.replace("void ", "")] = (float(val), int(launches), float(dur))
     return out
 
 
