@@ -85,6 +85,9 @@ typedef enum zr_integrator {
 /* ReSTIR DI (ZR_PASS_DI_EMISSIVE) reads TEMPORAL_RESAMPLE / SPATIAL_RESAMPLE above plus (CB_RDI_FLAGS, DirectLighting_Common.h:13-20): */
 #define ZR_DI_STOCHASTIC_SPATIAL          (1u << 8)
 #define ZR_DI_EXTRA_DISOCCLUSION_SAMPLING (1u << 9)
+/* Compositing (ZR_PASS_COMPOSITING): run the firefly filter on the composited image (Compositing::SetFireflyFilterEnablement,
+   RP/Compositing/FireflyFilter.hlsl).  Pinned: every pixel reads the unfiltered image (the reference filters its UAV in place). */
+#define ZR_COMPOSIT_FIREFLY_FILTER        (1u << 10)
 
 /* Pass parameters.  Defaults = the reference's (IndirectLighting.h:231-244, IndirectLighting.cpp:146-165). */
 typedef struct zr_params {

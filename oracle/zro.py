@@ -36,6 +36,7 @@ def lib():
         L.zro_trace_closest_timed.restype = C.c_double
         L.zro_trace_closest_timed.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]
         L.zro_presample.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p]
+        L.zro_firefly.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32]
         L.zro_build_lvg.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p]
         L.zro_sky_lut.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]
         L.zro_le_sky.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]
@@ -77,6 +78,15 @@ def lib():
         L.zro_kat_bsdf.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32]
         _LIB = L
     return _LIB
+
+
+def firefly_filter(rgba, depth):
+    """FireflyFilter.hlsl on an (h, w, 4) float32 image with the (h, w) float32 view-depth plane (FLT_MAX = no geometry)"""
+    rgba = np.ascontiguousarray(rgba, np.float32)
+    depth = np.ascontiguousarray(depth, np.float32).reshape(rgba.shape[0], rgba.shape[1])
+    out = np.zeros_like(rgba)
+    lib().zro_firefly(rgba.ctypes.data, depth.ctypes.data, out.ctypes.data, rgba.shape[1], rgba.shape[0])
+    return out
 
 
 class OracleScene:

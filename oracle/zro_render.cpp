@@ -692,6 +692,39 @@ int zro_pathtrace_render(const zro_scene* h, const zr_frame_constants* cb, const
     return 0;
 }
 
+// FireflyFilter.hlsl:33-123 on an RGBA32F image (Jacobi reading of the in-place filter, see include/zetaray_amd.h)
+int zro_firefly(const float* in_rgba, const float* depth, float* out_rgba, uint32_t w, uint32_t h)
+{
+    for (uint32_t y = 0; y < h; y++) for (uint32_t x = 0; x < w; x++)
+    {
+        const size_t px = (size_t)y * w + x;
+        float3 color = f3(in_rgba[4 * px], in_rgba[4 * px + 1], in_rgba[4 * px + 2]);
+        out_rgba[4 * px + 3] = in_rgba[4 * px + 3];
+        if (depth[px] != ZR_FLT_MAX)
+        {
+            float minLum = ZR_FLT_MAX, maxLum = 0.0f;
+            float3 minColor = color, maxColor = f3(0.0f);
+            const float currLum = Math::Luminance(color);
+            for (int i = -1; i <= 1; i++) for (int j = -1; j <= 1; j++)
+            {
+                if (i == 0 && j == 0) continue;
+                const int ax = (int)x + j, ay = (int)y + i;
+                if (ax < 0 || ay < 0 || ax >= (int)w || ay >= (int)h) continue;
+                const size_t np_ = (size_t)ay * w + ax;
+                if (depth[np_] == ZR_FLT_MAX) continue;
+                const float3 nc = f3(in_rgba[4 * np_], in_rgba[4 * np_ + 1], in_rgba[4 * np_ + 2]);
+                const float nl = Math::Luminance(nc);
+                if (nl < minLum) { minLum = nl; minColor = nc; }
+                else if (nl > maxLum) { maxLum = nl; maxColor = nc; }
+            }
+            float3 ret = currLum < minLum ? minColor : (currLum > maxLum ? maxColor : color);
+            color = minLum <= maxLum ? ret : color;
+        }
+        out_rgba[4 * px] = color.x; out_rgba[4 * px + 1] = color.y; out_rgba[4 * px + 2] = color.z;
+    }
+    return 0;
+}
+
 // K4 BuildLightVoxelGrid.hlsl: dim.x * dim.y * dim.z voxels x 64 samples, bound to the scene
 int zro_build_lvg(zro_scene* h, const zr_frame_constants* cb, const uint32_t* dim, const float* extents, float offset_y, zr_voxel_sample* out)
 {

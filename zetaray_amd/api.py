@@ -322,9 +322,13 @@ class Renderer:
         self.p_composit = None        # Compositing: enable_compositing()
         self._alias_ready = False
 
-    def enable_compositing(self, device=0):
-        """add the Compositing pass: (DI + indirect * !emissive) / NumFramesCameraStatic"""
-        self.p_composit = Pass(PASS_COMPOSITING, self.p_indirect.w, self.p_indirect.h_, device=device)
+    def enable_compositing(self, device=0, firefly_filter=False):
+        """add the Compositing pass: (DI + indirect * !emissive) / NumFramesCameraStatic, optionally followed by the firefly filter"""
+        prm = None
+        if firefly_filter:
+            prm = wire.default_params()
+            prm.flags |= wire.COMPOSIT_FIREFLY_FILTER
+        self.p_composit = Pass(PASS_COMPOSITING, self.p_indirect.w, self.p_indirect.h_, device=device, params=prm)
         self.p_composit.set_input(IN_INDIRECT, self.p_indirect.output_ptr()[0])
         if self.p_direct is not None:
             self.p_composit.set_input(IN_EMISSIVE_DI, self.p_direct.output_ptr()[0])

@@ -277,6 +277,39 @@ __global__ void __launch_bounds__(256) k_composite(zr_frame_constants g, const u
     if (i < n) out[i] = CompositePixel(g, mr[i], skyDI, emissiveDI, indirect, i, out[i]);
 }
 
+// Firefly filter (FireflyFilter.hlsl): a 3 x 3 stencil over RGBA32F + depth.  A block filters a 64 x 16 pixel tile, 4 pixels per thread;
+// colour and depth of the tile and its 1-pixel border are staged through LDS once (66 x 18 texels x 20 B = 23.8 KB, rows of 1 KB so the
+// global loads coalesce and ~5 of them are in flight per thread), so every texel leaves HBM / L2 once per block instead of 9 times per
+// pixel: 20 B read + 16 B written per pixel, HBM-bound.
+static constexpr int kFfW = 64, kFfH = 16, kFfLW = kFfW + 2, kFfLH = kFfH + 2;
+__global__ void __launch_bounds__(256) k_firefly(const F4* in, const float* depth, F4* out, uint32_t W, uint32_t H)
+{
+    __shared__ F4 sCol[kFfLW * kFfLH];
+    __shared__ float sDep[kFfLW * kFfLH];
+    const int bx = (int)blockIdx.x * kFfW, by = (int)blockIdx.y * kFfH;
+    for (int t = threadIdx.x; t < kFfLW * kFfLH; t += 256)
+    {
+        const int lx = t % kFfLW, ly = t / kFfLW;
+        const int gx = bx + lx - 1, gy = by + ly - 1;
+        const bool inside = gx >= 0 && gy >= 0 && gx < (int)W && gy < (int)H;
+        sCol[t] = inside ? in[(size_t)gy * W + gx] : f4(v3(0.0f), 0.0f);
+        sDep[t] = inside ? depth[(size_t)gy * W + gx] : ZR_FLT_MAX;
+    }
+    __syncthreads();
+    auto col = [&](int tx, int ty) { return xyz(sCol[ty * kFfLW + tx]); };
+    auto dep = [&](int tx, int ty) { return sDep[ty * kFfLW + tx]; };
+    for (int k = 0; k < 4; k++)
+    {
+        const int lx = threadIdx.x & 63, ly = (threadIdx.x >> 6) + 4 * k;
+        const int x = bx + lx, y = by + ly;
+        if (x >= (int)W || y >= (int)H) continue;
+        const F4 c = sCol[(ly + 1) * kFfLW + lx + 1];
+        V3 color = xyz(c);
+        if (sDep[(ly + 1) * kFfLW + lx + 1] != ZR_FLT_MAX) color = FireflyClamp(col, dep, lx + 1, ly + 1, x, y, (int)W, (int)H, color);
+        out[(size_t)y * W + x] = f4(color, c.w);
+    }
+}
+
 __global__ void k_presample(SceneView sc, uint32_t total, uint32_t frameNum, uint32_t numEmissives, zr_presampled_tri* out)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -946,6 +979,8 @@ static int AllocPass(zr_pass* p)
     if (p->kind == ZR_PASS_COMPOSITING)
     {
         const size_t cap = (size_t)p->w * p->h;
+        if ((r = p->firstBOP.Alloc(cap))) return r;            // scratch plane of the firefly filter (composited, unfiltered)
+        HIP_TRY(hipMemset(p->firstBOP.p, 0, cap * sizeof(F4)));
         if ((r = p->finalRGBA.Alloc(cap * 4))) return r;
         HIP_TRY(hipMemset(p->finalRGBA.p, 0, cap * 4 * sizeof(float)));
     }
@@ -1456,9 +1491,19 @@ static int RenderCompositing(zr_pass* p, hipStream_t s, const zr_frame_constants
     if (!gb || gb->w != p->w || gb->h != p->h) return Fail(ZR_ERR_INVALID_ARG, "COMPOSITING needs a gbuffer of the pass size");
     const uint32_t n = p->w * p->h;
     TimerBegin(p, s, "compositing");
+    // with the firefly filter on (Compositing.cpp: m_filterFirefly) the composited image goes to a scratch plane and the filter writes FINAL
+    const bool firefly = (p->params.flags & ZR_COMPOSIT_FIREFLY_FILTER) != 0;
+    F4* composited = firefly ? p->firstBOP.p : (F4*)p->finalRGBA.p;
     hipLaunchKernelGGL(k_composite, dim3((n + 255) / 256), dim3(256), 0, s, *cb, (const uint16_t*)gb->Planes()[ZR_GB_METALLIC_ROUGHNESS].p, p->compIn[ZR_IN_SKY_DI],
-        p->compIn[ZR_IN_EMISSIVE_DI], p->compIn[ZR_IN_INDIRECT], (F4*)p->finalRGBA.p, n);
+        p->compIn[ZR_IN_EMISSIVE_DI], p->compIn[ZR_IN_INDIRECT], composited, n);
     TimerEnd(p, s);
+    if (firefly)
+    {
+        TimerBegin(p, s, "firefly_filter");
+        hipLaunchKernelGGL(k_firefly, dim3((p->w + kFfW - 1) / kFfW, (p->h + kFfH - 1) / kFfH), dim3(256), 0, s, composited, (const float*)gb->Planes()[ZR_GB_DEPTH].p,
+            (F4*)p->finalRGBA.p, p->w, p->h);
+        TimerEnd(p, s);
+    }
     HIP_TRY(hipGetLastError());
     return ZR_OK;
 }

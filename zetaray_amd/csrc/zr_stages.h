@@ -784,6 +784,33 @@ ZR_HD F4 CompositePixel(const zr_frame_constants& g, uint16_t mrp, const F4* sky
     return f4(color, prevOut.w);
 }
 
+// FireflyFilter.hlsl:33-85 (the ReLAX firefly clamp): the centre colour is clamped to the [min, max]-luminance colours of its 3 x 3
+// neighbours that have geometry (depth != FLT_MAX).  `lum` / `col` / `dep` address a tile with a 1-texel border: (tx, ty) = centre.
+// Pinned: the reference filters the composited UAV in place (neighbours may or may not be filtered already); here every pixel
+// reads the unfiltered image (Jacobi), which is the only order-independent reading.
+template<typename TileC, typename TileD>
+ZR_HD V3 FireflyClamp(const TileC& col, const TileD& dep, int tx, int ty, int x, int y, int W, int H, V3 currColor)
+{
+    float minLum = ZR_FLT_MAX, maxLum = 0.0f;
+    V3 minColor = currColor, maxColor = v3(0.0f);
+    const float currLum = Luminance(currColor);
+    for (int i = -1; i <= 1; i++)
+        for (int j = -1; j <= 1; j++)
+        {
+            if (i == 0 && j == 0) continue;
+            const int ax = x + j, ay = y + i;
+            if (ax < 0 || ay < 0 || ax >= W || ay >= H) continue;      // (uint compare in the reference: negative addresses fail it too)
+            if (dep(tx + j, ty + i) == ZR_FLT_MAX) continue;
+            const V3 nc = col(tx + j, ty + i);
+            const float nl = Luminance(nc);
+            if (nl < minLum) { minLum = nl; minColor = nc; }
+            else if (nl > maxLum) { maxLum = nl; maxColor = nc; }
+        }
+    V3 ret = currLum < minLum ? minColor : (currLum > maxLum ? maxColor : currColor);
+    ret = minLum <= maxLum ? ret : currColor;
+    return ret;
+}
+
 // K2: EstimateTriEmissivePower.hlsl:29-79 (untextured branch)
 ZR_HD float EstimateTriPower(const zr_emissive_triangle& em)
 {

@@ -133,6 +133,7 @@ def default_params() -> Params:
     return p
 
 
+COMPOSIT_FIREFLY_FILTER = 1 << 10
 DI_STOCHASTIC_SPATIAL = 1 << 8
 DI_EXTRA_DISOCCLUSION_SAMPLING = 1 << 9
 
