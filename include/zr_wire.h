@@ -180,6 +180,32 @@ typedef struct zr_frame_constants {
 #define ZR_SUBGROUP_EMISSIVE      0x1u
 #define ZR_SUBGROUP_NON_EMISSIVE  0x2u
 #define ZR_SUBGROUP_ALL           0x3u
+/* Extra bit of zr_scene_desc.instance_mask: the instance's BLAS geometry is built WITHOUT
+   D3D12_RAYTRACING_GEOMETRY_FLAG_OPAQUE (RtAccelerationStructure.cpp:155-158, RT_Flags::IsOpaque == false), so primary
+   rays run the alpha test of GBufferRT_Inline.hlsl:37-70 on its triangles.  All other rays force opaque
+   (RayQuery.hlsli:42,168,317-319,372-374,382-383) and ignore the bit. */
+#define ZR_INSTANCE_NON_OPAQUE    0x80u
+
+/*
+ * Material textures.  The reference binds BC-compressed DDS textures (BC7_UNORM_SRGB base colour / emissive, BC5_UNORM
+ * normal / metallic-roughness, Assets.cpp + Tools/BCnCompressglTF) through four descriptor tables and filters them in
+ * hardware.  Neither block decompression nor hardware filtering is pinned by the reference, so this ABI takes the decoded
+ * texels: every texture is a full mip chain of uncompressed texels (mip m is max(1, w >> m) x max(1, h >> m), rows
+ * top-down, mips packed back to back from `offset`, which must be a multiple of 4), and zr_texture.h defines the
+ * filtering.  Material / MeshInstance / EmissiveTriangle texture indices address `textures` exactly like the reference
+ * addresses its descriptor heap: textures[frame_constants.<kind>_maps_desc_heap_offset + tex16].
+ */
+#define ZR_TEX_RGBA8_SRGB  0u   /* 4 B/texel, RGB through the sRGB transfer function, A linear (base colour, emissive) */
+#define ZR_TEX_RGBA8       1u   /* 4 B/texel, UNORM */
+#define ZR_TEX_RG8         2u   /* 2 B/texel, UNORM (normal XY, metallic-roughness); samples return (r, g, 0, 1) */
+typedef struct zr_texture_desc {
+    uint64_t offset;     /* byte offset of mip 0 inside zr_scene_desc.texels */
+    uint16_t width;
+    uint16_t height;
+    uint8_t  num_mips;   /* >= 1 */
+    uint8_t  format;     /* ZR_TEX_* */
+    uint16_t pad;
+} zr_texture_desc;
 
 /* G-buffer flag byte, reference Source/ZetaRenderPass/Common/GBuffers.hlsli:52-87 */
 #define ZR_GBUF_TRANSMISSIVE  (1u << 0)
@@ -209,6 +235,9 @@ typedef struct zr_scene_desc {
     const zr_emissive_triangle* emissives;       uint32_t num_emissives;
     /* rho.dds payload: R16_UNORM, 64 x 32 x 16 (reference BSDF.hlsli:279-296, Assets/LUT/rho.dds) */
     const uint16_t*             rho_lut;         uint32_t rho_dim[3];
+    /* material textures (may be null / 0: every tex16 of the scene must then be ZR_INVALID_TEX) */
+    const zr_texture_desc*      textures;        uint32_t num_textures;
+    const uint8_t*              texels;          uint64_t texel_bytes;
 } zr_scene_desc;
 
 #ifdef __cplusplus

@@ -29,6 +29,8 @@ def lib():
         L.zro_kahan_sum.argtypes = [C.c_void_p, C.c_uint64, C.c_uint32, C.c_void_p]
         L.zro_scene_set_alias_table.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32]
         L.zro_estimate_power.argtypes = [C.c_void_p, C.c_void_p]
+        L.zro_scene_latch_heap_offsets.argtypes = [C.c_void_p, C.c_void_p]
+        L.zro_tex_sample.argtypes = [C.c_void_p, C.c_uint32, C.c_int, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]
         L.zro_gbuffer_render.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.zro_pathtrace_render.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.zro_trace_closest.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]
@@ -90,12 +92,15 @@ def firefly_filter(rgba, depth):
 
 
 class OracleScene:
-    def __init__(self, scene, force_bvh=False):
-        """scene: zetaray_amd.scene_io.Scene"""
+    def __init__(self, scene, force_bvh=False, cb=None):
+        """scene: zetaray_amd.scene_io.Scene.  cb: frame constants whose texture descriptor-table offsets the power
+        estimate (K2) should use; only matters for scenes with emissive textures at a non-zero table offset."""
         from zetaray_amd import wire
         self.scene = scene
         self._desc = scene.desc()
         self.h = lib().zro_scene_create(C.addressof(self._desc), int(force_bvh))
+        if cb is not None:
+            self.latch_heap_offsets(cb)
         self.alias = None
         if len(scene.emissives):
             power = self.estimate_power()
@@ -107,6 +112,19 @@ class OracleScene:
         if getattr(self, "h", None):
             lib().zro_scene_destroy(self.h)
             self.h = None
+
+    def latch_heap_offsets(self, cb):
+        cbb = np.ascontiguousarray(cb)
+        lib().zro_scene_latch_heap_offsets(self.h, cbb.ctypes.data)
+
+    def tex_sample(self, tex, mode, uv, g=None):
+        """zr_texture.h on this scene's heap: mode 0 point, 1 SampleLevel (lod = g[:, 0]), 2 SampleGrad (g = ddx.uv, ddy.uv)"""
+        uv = np.ascontiguousarray(uv, np.float32)
+        g = np.zeros((len(uv), 4), np.float32) if g is None else np.ascontiguousarray(g, np.float32)
+        out = np.zeros((len(uv), 4), np.float32)
+        lib().zro_tex_sample(self.h, C.c_uint32(tex), C.c_int(mode), uv.ctypes.data_as(C.c_void_p), g.ctypes.data_as(C.c_void_p),
+                            C.c_uint32(len(uv)), out.ctypes.data_as(C.c_void_p))
+        return out
 
     def estimate_power(self):
         out = np.zeros(len(self.scene.emissives), np.float32)

@@ -89,7 +89,7 @@ static inline void BuildVoxel(const Scene& sc, const zr_frame_constants& g, cons
             Light::AliasTableSample entry = Light::AliasTableSample::get(sc, g.num_emissive_triangles, rng);
             EmTri tri; tri.t = sc.emissives[entry.idx];
             Light::EmissiveTriSample ls = Light::EmissiveTriSample::get(voxelCenter, tri, rng, false);
-            const float3 le = Light::Le_EmissiveTriangle(tri, ls.bary);
+            const float3 le = Light::Le_EmissiveTriangle(sc, tri, ls.bary);
             // AdjustLightPos: snap lights inside the voxel to its boundary planes
             const float3 d = abs3(ls.pos - voxelCenter);
             const bool inside = d.x <= extents.x && d.y <= extents.y && d.z <= extents.z;

@@ -164,6 +164,21 @@ namespace Math {
     };
 
     // Math.hlsli:325-389
+    // Math.hlsli:263-284
+    static inline float3 TangentSpaceToWorldSpace(float2 bumpNormal2, float3 tangent, float3 normal, float scale)
+    {
+        float3 bumpNormal = f3(zr_fma(2.0f, bumpNormal2.x, -1.0f), zr_fma(2.0f, bumpNormal2.y, -1.0f), 0.0f);
+        bumpNormal.z = zr_sqrt(zr_saturate(1.0f - dot(bumpNormal, bumpNormal)));
+        float3 scaledBumpNormal = bumpNormal * f3(scale, scale, 1.0f);
+        if (dot(scaledBumpNormal, scaledBumpNormal) < 1e-6f) return normal;
+        scaledBumpNormal = normalize(scaledBumpNormal);
+        normal = normalize(normal);
+        tangent = normalize(tangent - dot(tangent, normal) * normal);
+        float3 bitangent = cross(normal, tangent);
+        // mul(row vector, float3x3(tangent, bitangent, normal)): sum over rows, left to right
+        return scaledBumpNormal.x * tangent + scaledBumpNormal.y * bitangent + scaledBumpNormal.z * normal;
+    }
+
     struct TriDifferentials
     {
         float3 dpdu, dpdv, dndu, dndv;

@@ -143,7 +143,7 @@ static Reservoir RIS_InitialCandidates(const Scene& sc, const zr_frame_constants
         if (hitInfo.hit)
         {
             EmTri emissive; emissive.t = sc.emissives[hitInfo.emissiveTriIdx];
-            le = Light::Le_EmissiveTriangle(emissive, hitInfo.bary);
+            le = Light::Le_EmissiveTriangle(sc, emissive, hitInfo.bary);
             const float3 vtx0 = emissive.Vtx0(), vtx1 = emissive.V1(), vtx2 = emissive.V2();
             lightNormal = cross(vtx1 - vtx0, vtx2 - vtx0);
             float twoArea = length(lightNormal);
@@ -186,7 +186,7 @@ static Reservoir RIS_InitialCandidates(const Scene& sc, const zr_frame_constants
             Light::AliasTableSample entry = Light::AliasTableSample::get(sc, g.num_emissive_triangles, rng);
             EmTri tri; tri.t = sc.emissives[entry.idx];
             lightSample = Light::EmissiveTriSample::get(pos, tri, rng);
-            le = Light::Le_EmissiveTriangle(tri, lightSample.bary);
+            le = Light::Le_EmissiveTriangle(sc, tri, lightSample.bary);
             pdf_light = entry.pdf * lightSample.pdf;
             emissiveIdx = entry.idx; lightID = tri.t.id; doubleSided = tri.IsDoubleSided();
         }

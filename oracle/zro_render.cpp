@@ -158,6 +158,54 @@ static inline float3 Mul3x4(const float* m, float3 p)
               m[8] * p.x + m[9] * p.y + m[10] * p.z + m[11]);
 }
 
+// GBufferRT.hlsli:11-100
+static float4 UVDifferentials(int px, int py, float3 origin, float3 dir, bool thinLens, float2 lensSample, float focusDepth,
+    float t, float3 dpdu, float3 dpdv, const zr_frame_constants& g)
+{
+    float dpduDotdpdu = dot(dpdu, dpdu);
+    float dpdvDotdpdv = dot(dpdv, dpdv);
+    float dpduDotdpdv = dot(dpdu, dpdv);
+    float det = dpduDotdpdu * dpdvDotdpdv - dpduDotdpdv * dpduDotdpdv;
+    if (zr_abs(det) < 1e-7f) return {0, 0, 0, 0};
+
+    const float2 renderDim = {(float)g.render_width, (float)g.render_height};
+    const float2 jitter = {g.curr_camera_jitter[0], g.curr_camera_jitter[1]};
+    float3 dir_cs_x = RT::GeneratePinholeCameraRay_CS(px + 1, py, renderDim, g.aspect_ratio, g.tan_half_fov, jitter);
+    float3 dir_cs_y = RT::GeneratePinholeCameraRay_CS(px, py - 1, renderDim, g.aspect_ratio, g.tan_half_fov, jitter);
+    if (thinLens)
+    {
+        dir_cs_x = focusDepth * dir_cs_x - f3(lensSample.x, lensSample.y, 0);
+        dir_cs_y = focusDepth * dir_cs_y - f3(lensSample.x, lensSample.y, 0);
+    }
+    const float3 vbx = Row(g.curr_view, 0), vby = Row(g.curr_view, 1), vbz = Row(g.curr_view, 2);
+    float3 dir_x = normalize(mad3(dir_cs_x.x, vbx, mad3(dir_cs_x.y, vby, dir_cs_x.z * vbz)));
+    float3 dir_y = normalize(mad3(dir_cs_y.x, vbx, mad3(dir_cs_y.y, vby, dir_cs_y.z * vbz)));
+
+    float3 faceNormal = normalize(cross(dpdu, dpdv));
+    float3 p = origin + t * dir;
+    float d = -dot(faceNormal, p);
+    float numerator = -dot(faceNormal, origin) - d;
+
+    float denom_x = dot(faceNormal, dir_x);
+    denom_x = (denom_x < 0 ? -1.0f : 1.0f) * zr_max(zr_abs(denom_x), 1e-8f);
+    float t_x = numerator / denom_x;
+    float3 p_x = origin + t_x * dir_x;
+
+    float denom_y = dot(faceNormal, dir_y);
+    denom_y = (denom_y < 0 ? -1.0f : 1.0f) * zr_max(zr_abs(denom_y), 1e-8f);
+    float t_y = numerator / denom_y;
+    float3 p_y = origin + t_y * dir_y;
+
+    // x_hat = (A^T A)^-1 A^T b with A = [dpdu dpdv]; mul(float2x2, float2) = row . vector, left to right
+    float3 dpdx = p_x - p;
+    float2 bx = {dot(dpdu, dpdx), dot(dpdv, dpdx)};
+    float2 grads_x = {(dpdvDotdpdv * bx.x + -dpduDotdpdv * bx.y) / det, (-dpduDotdpdv * bx.x + dpduDotdpdu * bx.y) / det};
+    float3 dpdy = p_y - p;
+    float2 by = {dot(dpdu, dpdy), dot(dpdv, dpdy)};
+    float2 grads_y = {(dpdvDotdpdv * by.x + -dpduDotdpdv * by.y) / det, (-dpduDotdpdv * by.x + dpduDotdpdu * by.y) / det};
+    return {grads_x.x, grads_x.y, grads_y.x, grads_y.y};
+}
+
 //--------------------------------------------------------------------------------------
 // K1: G-buffer (GBufferRT_Inline.hlsl:204-287, TracePrimaryHit :72-198, GBufferRT.hlsli:102-282)
 //--------------------------------------------------------------------------------------
@@ -189,7 +237,7 @@ static void RenderGBuffer(const Scene& sc, const zr_frame_constants& g, GBView g
         rayDir = normalize(rayDir);
 
         sc.counters.n_closest++;
-        Scene::RawHit h = sc.Trace(rayOrigin, rayDir, 0.0f, ZR_FLT_MAX, ZR_SUBGROUP_ALL, false);
+        Scene::RawHit h = sc.Trace(rayOrigin, rayDir, 0.0f, ZR_FLT_MAX, ZR_SUBGROUP_ALL, false, false, 0, /*alphaTest*/ true);
 
         if (!h.hit)
         {
@@ -224,7 +272,6 @@ static void RenderGBuffer(const Scene& sc, const zr_frame_constants& g, GBView g
 
         float2 uv0 = {V0.uv[0], V0.uv[1]}, uv1 = {V1.uv[0], V1.uv[1]}, uv2 = {V2.uv[0], V2.uv[1]};
         float2 uv = uv0 + bary.x * (uv1 - uv0) + bary.y * (uv2 - uv0);
-        (void)uv;
 
         float3 v0_n = Math::DecodeOct32(V0.normal), v1_n = Math::DecodeOct32(V1.normal), v2_n = Math::DecodeOct32(V2.normal);
         float3 normal = v0_n + bary.x * (v1_n - v0_n) + bary.y * (v2_n - v0_n);
@@ -232,6 +279,13 @@ static void RenderGBuffer(const Scene& sc, const zr_frame_constants& g, GBView g
         normal *= scaleInv;
         normal = Math::RotateVector(normal, q);
         normal = normalize(normal);
+
+        // tangent vector (GBufferRT_Inline.hlsl:147-155)
+        float3 v0_t = Math::DecodeOct32(V0.tangent), v1_t = Math::DecodeOct32(V1.tangent), v2_t = Math::DecodeOct32(V2.tangent);
+        float3 tangent = v0_t + bary.x * (v1_t - v0_t) + bary.y * (v2_t - v0_t);
+        tangent *= scale;
+        tangent = Math::RotateVector(tangent, q);
+        tangent = normalize(tangent);
 
         float3 v0W = Math::TransformTRS(f3(V0.pos), translation, q, scale);
         float3 v1W = Math::TransformTRS(f3(V1.pos), translation, q, scale);
@@ -261,14 +315,36 @@ static void RenderGBuffer(const Scene& sc, const zr_frame_constants& g, GBView g
         float z = g.dof ? h.t : posV.z;
         float3 wo = rayOrigin - pos;
 
-        // ApplyTextureMaps (GBufferRT.hlsli:178-282), texture maps out of scope this round
+        // ApplyTextureMaps (GBufferRT.hlsli:178-282)
         Mat mat; mat.m = sc.materials[md.mat_idx];
+        const bool anyTex = mat.GetBaseColorTex() != ZR_INVALID_TEX || mat.GetNormalTex() != ZR_INVALID_TEX ||
+            mat.GetMetallicRoughnessTex() != ZR_INVALID_TEX;
+        // (the gradients only feed SampleGrad; they are skipped for untextured materials)
+        float4 grads = {0, 0, 0, 0};
+        if (anyTex)
+            grads = UVDifferentials((int)x, (int)y, rayOrigin, rayDir, g.dof != 0, lensSample, g.focus_depth, h.t, td.dpdu, td.dpdv, g);
+        grads = {grads.x * g.camera_ray_uv_grads_scale, grads.y * g.camera_ray_uv_grads_scale,
+                 grads.z * g.camera_ray_uv_grads_scale, grads.w * g.camera_ray_uv_grads_scale};
         float3 baseColor = mat.GetBaseColorFactor();
         float3 emissiveColor = mat.GetEmissiveFactor();
+        float normalScale = mat.GetNormalScale();
         float metallic = mat.Metallic() ? 1.0f : 0.0f;
         float roughness = mat.GetSpecularRoughness();
         float3 shadingNormal = normal;
         float3 dndu = td.dndu, dndv = td.dndv;
+        if (mat.GetBaseColorTex() != ZR_INVALID_TEX)
+        {
+            float c[4];
+            zr_tex_sample_grad(&sc.tex, g.base_color_maps_desc_heap_offset + mat.GetBaseColorTex(), uv.x, uv.y, grads.x, grads.y, grads.z, grads.w, c);
+            baseColor = baseColor * f3(c[0], c[1], c[2]);
+        }
+        // avoid normal mapping if tangent = (0, 0, 0), which results in NaN
+        if (mat.GetNormalTex() != ZR_INVALID_TEX && zr_abs(dot(tangent, tangent)) > 1e-6f)
+        {
+            float c[4];
+            zr_tex_sample_grad(&sc.tex, g.normal_maps_desc_heap_offset + mat.GetNormalTex(), uv.x, uv.y, grads.x, grads.y, grads.z, grads.w, c);
+            shadingNormal = Math::TangentSpaceToWorldSpace(f2(c[0], c[1]), tangent, normal, normalScale);
+        }
         if (mat.DoubleSided() && dot(wo, normal) < 0) { shadingNormal = shadingNormal * -1.0f; dndu = dndu * -1.0f; dndv = dndv * -1.0f; }
         if (dot(wo, normal) > 0 && dot(wo, shadingNormal) < 0)
         {
@@ -277,7 +353,20 @@ static void RenderGBuffer(const Scene& sc, const zr_frame_constants& g, GBView g
             shadingNormal = 1e-4f * wo + shadingNormal;
             shadingNormal = normalize(shadingNormal);
         }
+        if (mat.GetMetallicRoughnessTex() != ZR_INVALID_TEX)
+        {
+            float c[4];
+            zr_tex_sample_grad(&sc.tex, g.metallic_roughness_maps_desc_heap_offset + mat.GetMetallicRoughnessTex(), uv.x, uv.y, grads.x, grads.y, grads.z, grads.w, c);
+            metallic *= c[0];
+            roughness *= c[1];
+        }
         float emissiveStrength = mat.GetEmissiveStrength();
+        if (mat.GetEmissiveTex() != ZR_INVALID_TEX)
+        {
+            float c[4];
+            zr_tex_sample_level(&sc.tex, g.emissive_maps_desc_heap_offset + mat.GetEmissiveTex(), uv.x, uv.y, 0.0f, c);
+            emissiveColor = emissiveColor * f3(c[0], c[1], c[2]);
+        }
         emissiveColor *= emissiveStrength;
         bool transmissive = mat.Transmissive();
         float ior = mat.GetSpecularIOR();
@@ -322,14 +411,41 @@ static void RenderGBuffer(const Scene& sc, const zr_frame_constants& g, GBView g
 }
 
 //--------------------------------------------------------------------------------------
-// K2: per-triangle emissive power (EstimateTriEmissivePower.hlsl:29-79, untextured branch)
+// K2: per-triangle emissive power (EstimateTriEmissivePower.hlsl:29-79).  Textured triangles: 32 lanes x 2 Halton(2, 3)
+// points (PreLighting.cpp:236-243, Sampling.cpp:160-174), emissive map sampled with g_samLinearWrap at mip 0; the
+// WaveActiveSum over the 32 lane partials is pinned to ascending lane order.
 //--------------------------------------------------------------------------------------
+static float Halton(int i, int b)
+{
+    float f = 1.0f, r = 0.0f, bf = (float)b;
+    while (i > 0) { f /= bf; r = r + f * (float)(i % b); i = (int)((float)i / bf); }
+    return r;
+}
 static void EstimatePower(const Scene& sc, float* out)
 {
     for (size_t i = 0; i < sc.emissives.size(); i++)
     {
         EmTri tri; tri.t = sc.emissives[i];
         float3 power = f3(64.0f);    // ESTIMATE_TRI_POWER_NUM_SAMPLES_PER_TRI
+        if (tri.GetTex() != ZR_INVALID_TEX)
+        {
+            power = f3(0.0f);
+            for (int lane = 0; lane < 32; lane++)
+            {
+                float3 lanePower = f3(0.0f);
+                for (int k = 0; k < 2; k++)
+                {
+                    const int si = lane * 2 + k;
+                    float2 u = {Halton(si + 1, 2), Halton(si + 1, 3)};
+                    float2 bary = Sampling::UniformSampleTriangle(u);
+                    float2 texUV = (1.0f - bary.x - bary.y) * tri.UV0() + bary.x * tri.UV1() + bary.y * tri.UV2();
+                    float c[4];
+                    zr_tex_sample_level(&sc.tex, sc.emissiveMapsOffset + tri.GetTex(), texUV.x, texUV.y, 0.0f, c);
+                    lanePower += f3(c[0], c[1], c[2]);
+                }
+                power += lanePower;
+            }
+        }
         power = power * tri.GetFactor() * tri.GetStrength();
         const float3 vtx0 = tri.Vtx0(), vtx1 = tri.V1(), vtx2 = tri.V2();
         const float surfaceArea = 0.5f * length(cross(vtx1 - vtx0, vtx2 - vtx0));
@@ -360,7 +476,7 @@ static float3 NEE_Emissive_MIS(const Scene& sc, int NumLightSamples, bool skipDi
         if (hitInfo.HitWasEmissive())
         {
             EmTri emissive; emissive.t = sc.emissives[hitInfo.emissiveTriIdx];
-            float3 le = Light::Le_EmissiveTriangle(emissive, hitInfo.bary);
+            float3 le = Light::Le_EmissiveTriangle(sc, emissive, hitInfo.bary);
             const float3 vtx0 = emissive.Vtx0(), vtx1 = emissive.V1(), vtx2 = emissive.V2();
             float3 lightNormal = cross(vtx1 - vtx0, vtx2 - vtx0);
             float twoArea = length(lightNormal);
@@ -389,7 +505,7 @@ static float3 NEE_Emissive_MIS(const Scene& sc, int NumLightSamples, bool skipDi
             Light::AliasTableSample entry = Light::AliasTableSample::get(sc, numEmissives, rng);
             EmTri tri; tri.t = sc.emissives[entry.idx];
             lightSample = Light::EmissiveTriSample::get(pos, tri, rng);
-            le = Light::Le_EmissiveTriangle(tri, lightSample.bary);
+            le = Light::Le_EmissiveTriangle(sc, tri, lightSample.bary);
             lightPdf = entry.pdf * lightSample.pdf;
             lightID = tri.t.id;
         }
@@ -679,14 +795,28 @@ int zro_alias_table_build(const float* power, uint32_t n, uint32_t align_phase, 
 }
 int zro_scene_set_alias_table(zro_scene* h, const zr_alias_entry* e, uint32_t n) { h->s.alias.assign(e, e + n); return 0; }
 int zro_estimate_power(const zro_scene* h, float* out) { EstimatePower(h->s, out); return 0; }
+// zr_texture.h on the scene's heap.  mode 0: point (mip 0); 1: SampleLevel, lod = g[0]; 2: SampleGrad, g = ddx.uv, ddy.uv
+int zro_tex_sample(const zro_scene* h, uint32_t tex, int mode, const float* uv, const float* g, uint32_t n, float* out)
+{
+    for (uint32_t i = 0; i < n; i++)
+    {
+        float* o = out + 4 * i;
+        if (mode == 0) zr_tex_point(&h->s.tex, tex, uv[2 * i], uv[2 * i + 1], o);
+        else if (mode == 1) zr_tex_sample_level(&h->s.tex, tex, uv[2 * i], uv[2 * i + 1], g[4 * i], o);
+        else zr_tex_sample_grad(&h->s.tex, tex, uv[2 * i], uv[2 * i + 1], g[4 * i], g[4 * i + 1], g[4 * i + 2], g[4 * i + 3], o);
+    }
+    return 0;
+}
+// latches the four texture descriptor-table offsets of the frame constants (for the entry points that take no cb)
+int zro_scene_latch_heap_offsets(const zro_scene* h, const zr_frame_constants* cb) { h->s.LatchHeapOffsets(*cb); return 0; }
 
 int zro_gbuffer_render(const zro_scene* h, const zr_frame_constants* cb, zr_gbuffer_planes* planes)
-{ RenderGBuffer(h->s, *cb, GBView(planes)); return 0; }
+{ h->s.LatchHeapOffsets(*cb); RenderGBuffer(h->s, *cb, GBView(planes)); return 0; }
 
 int zro_pathtrace_render(const zro_scene* h, const zr_frame_constants* cb, const zr_gbuffer_planes* planes,
     const zr_params* prm, float* final_rgba, zr_counters* counters)
 {
-    h->s.counters = Counters();
+    h->s.counters = Counters(); h->s.LatchHeapOffsets(*cb);
     RenderPathTracer(h->s, *cb, GBView(planes), *prm, final_rgba);
     if (counters) { counters->n_closest = h->s.counters.n_closest; counters->n_shadow = h->s.counters.n_shadow; }
     return 0;
@@ -729,6 +859,7 @@ int zro_firefly(const float* in_rgba, const float* depth, float* out_rgba, uint3
 int zro_build_lvg(zro_scene* h, const zr_frame_constants* cb, const uint32_t* dim, const float* extents, float offset_y, zr_voxel_sample* out)
 {
     Scene& sc = h->s;
+    sc.LatchHeapOffsets(*cb);
     const size_t nv = (size_t)dim[0] * dim[1] * dim[2];
     sc.lvgData.resize(nv * 64);
     for (int a = 0; a < 3; a++) { sc.lvgDim[a] = dim[a]; sc.lvgExtents[a] = extents[a]; }
@@ -777,7 +908,7 @@ int zro_presample(zro_scene* h, uint32_t frame_num, uint32_t num_sets, uint32_t 
         Light::AliasTableSample entry = Light::AliasTableSample::get(sc, (uint32_t)sc.emissives.size(), rng);
         EmTri tri; tri.t = sc.emissives[entry.idx];
         Light::EmissiveTriSample ls = Light::EmissiveTriSample::get(f3(0.0f), tri, rng, false);
-        float3 le = Light::Le_EmissiveTriangle(tri, ls.bary);
+        float3 le = Light::Le_EmissiveTriangle(sc, tri, ls.bary);
         zr_presampled_tri& s = sc.sampleSets[i];
         s.pos[0] = ls.pos.x; s.pos[1] = ls.pos.y; s.pos[2] = ls.pos.z;
         Math::EncodeOct32(ls.normal, s.normal);
@@ -804,7 +935,7 @@ void zro_rpt_reset_temporal(zro_rpt* r) { r->st.temporalValid = false; }
 int zro_rpt_render(const zro_scene* h, zro_rpt* r, const zr_frame_constants* cb, const zr_gbuffer_planes* curr,
     const zr_gbuffer_planes* prev, const zr_params* prm, float* final_rgba, zr_counters* counters)
 {
-    h->s.counters = Counters();
+    h->s.counters = Counters(); h->s.LatchHeapOffsets(*cb);
     RPT::Render(h->s, *cb, curr, prev, *prm, r->st, final_rgba);
     if (counters) { counters->n_closest = h->s.counters.n_closest; counters->n_shadow = h->s.counters.n_shadow; }
     return 0;
@@ -840,7 +971,7 @@ void zro_rdi_reset_temporal(zro_rdi* r) { r->st.temporalValid = false; r->st.cur
 int zro_rdi_render(const zro_scene* h, zro_rdi* r, const zr_frame_constants* cb, const zr_gbuffer_planes* curr, const zr_gbuffer_planes* prev,
     const zr_params* prm, float* final_rgba, zr_counters* counters)
 {
-    h->s.counters = Counters();
+    h->s.counters = Counters(); h->s.LatchHeapOffsets(*cb);
     RDI::Render(h->s, *cb, curr, prev, *prm, r->st, final_rgba);
     if (counters) { counters->n_closest = h->s.counters.n_closest; counters->n_shadow = h->s.counters.n_shadow; }
     return 0;
@@ -863,7 +994,7 @@ void zro_sdi_reset_temporal(zro_sdi* r) { r->st.temporalValid = false; r->st.cur
 int zro_sdi_render(const zro_scene* h, zro_sdi* r, const zr_frame_constants* cb, const zr_gbuffer_planes* curr, const zr_gbuffer_planes* prev,
     const zr_params* prm, float* final_rgba, zr_counters* counters)
 {
-    h->s.counters = Counters();
+    h->s.counters = Counters(); h->s.LatchHeapOffsets(*cb);
     SDI::Render(h->s, *cb, curr, prev, *prm, r->st, final_rgba);
     if (counters) { counters->n_closest = h->s.counters.n_closest; counters->n_shadow = h->s.counters.n_shadow; }
     return 0;
@@ -887,7 +1018,7 @@ void zro_rgi_reset_temporal(zro_rgi* r) { r->st.temporalValid = false; }
 int zro_rgi_render(const zro_scene* h, zro_rgi* r, const zr_frame_constants* cb, const zr_gbuffer_planes* curr, const zr_gbuffer_planes* prev,
     const zr_params* prm, float* final_rgba, zr_counters* counters)
 {
-    h->s.counters = Counters();
+    h->s.counters = Counters(); h->s.LatchHeapOffsets(*cb);
     RGI::Render(h->s, *cb, curr, prev, *prm, r->st, final_rgba);
     if (counters) { counters->n_closest = h->s.counters.n_closest; counters->n_shadow = h->s.counters.n_shadow; }
     return 0;

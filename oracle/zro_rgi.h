@@ -138,7 +138,7 @@ static float3 NEE_Emissive_Power(const Scene& sc, float3 pos, float3 normal, BSD
         Light::AliasTableSample entry = Light::AliasTableSample::get(sc, numEmissives, rng);
         EmTri tri; tri.t = sc.emissives[entry.idx];
         lightSample = Light::EmissiveTriSample::get(pos, tri, rng);
-        le = Light::Le_EmissiveTriangle(tri, lightSample.bary);
+        le = Light::Le_EmissiveTriangle(sc, tri, lightSample.bary);
         lightPdf = entry.pdf * lightSample.pdf;
         lightID = tri.t.id;
     }

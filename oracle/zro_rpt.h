@@ -459,7 +459,7 @@ static DirectLightingEstimate NEE_Bsdf(const Globals& g, float3 pos, float3 norm
     if (hitInfo.HitWasEmissive())
     {
         EmTri emissive; emissive.t = g.sc->emissives[hitInfo.emissiveTriIdx];
-        const float3 le = Light::Le_EmissiveTriangle(emissive, hitInfo.bary);
+        const float3 le = Light::Le_EmissiveTriangle(*g.sc, emissive, hitInfo.bary);
         const float3 vtx0 = emissive.Vtx0(), vtx1 = emissive.V1(), vtx2 = emissive.V2();
         float3 lightNormal = cross(vtx1 - vtx0, vtx2 - vtx0);
         float twoArea = length(lightNormal);
@@ -500,7 +500,7 @@ static DirectLightingEstimate NEE_Emissive(const Globals& g, float3 pos, float3 
         Light::AliasTableSample entry = Light::AliasTableSample::get(*g.sc, g.numEmissives, rng);
         EmTri tri; tri.t = g.sc->emissives[entry.idx];
         lightSample = Light::EmissiveTriSample::get(pos, tri, rng);
-        le = Light::Le_EmissiveTriangle(tri, lightSample.bary);
+        le = Light::Le_EmissiveTriangle(*g.sc, tri, lightSample.bary);
         lightPdf = entry.pdf * lightSample.pdf;
         lightID = tri.t.id;
         twoSided = tri.IsDoubleSided();
@@ -1043,7 +1043,7 @@ static float StepPath(const Globals& g, bool InCurrFrame, OffsetPathContext& ctx
     const bool transmitted = dot(ctx.normal, w_k_min_1) < 0;
     ctx.eta_curr = transmitted ? (ctx.eta_curr == ETA_AIR ? ctx.eta_next : ETA_AIR) : ctx.eta_curr;
     const bool inTranslucentMedium = ctx.eta_curr != ETA_AIR;
-    if (!RtRayQuery::GetMaterialData(sc, -w_k_min_1, ctx.eta_curr, ctx.rd.uv_grads, hitInfo, ctx.surface, ctx.eta_next)) return 0;
+    if (!RtRayQuery::GetMaterialData(sc, -w_k_min_1, ctx.eta_curr, ctx.rd.uv_grads, hitInfo, ctx.surface, ctx.eta_next, RtRayQuery::TexSampler::Isotropic)) return 0;
     if (inTranslucentMedium && (ctx.surface.trDepth > 0))
     {
         float3 extCoeff = -log3(ctx.surface.baseColor_Fr0_TrCol) / ctx.surface.trDepth;

@@ -9,6 +9,8 @@
 #include <algorithm>
 #include "zro_bsdf.h"
 #include "zro_sky.h"
+#include "../include/zr_texture.h"
+#include "../include/zr_srgb_table.h"
 #include "../include/zr_intersect.h"
 
 namespace zro {
@@ -49,6 +51,9 @@ struct EmTri
     float GetStrength() const { return zr_f16_to_f32((uint16_t)(t.packed_b >> 16)); }
     float3 GetFactor() const { return Math::UnpackRGB8(t.packed_a); }
     uint32_t GetTex() const { return t.packed_b & 0xffffu; }
+    float2 UV0() const { return {zr_f16_to_f32(t.uv0[0]), zr_f16_to_f32(t.uv0[1])}; }     // EMISSIVE_UV_HALF == 1
+    float2 UV1() const { return {zr_f16_to_f32(t.uv1[0]), zr_f16_to_f32(t.uv1[1])}; }
+    float2 UV2() const { return {zr_f16_to_f32(t.uv2[0]), zr_f16_to_f32(t.uv2[1])}; }
     float3 Vtx0() const { return f3(t.vtx0); }
     float3 V1() const
     {
@@ -85,6 +90,17 @@ struct Scene
     SkyLUT sky;
     std::vector<uint16_t> rho;
     RhoLUT rhoLUT;
+    // material texture heap (zr_wire.h zr_texture_desc / zr_texture.h) and the four descriptor-table offsets of the frame
+    // constants (FrameConstants.h:31-34), latched by every render entry point before it shades
+    std::vector<zr_texture_desc> texDescs;
+    std::vector<uint8_t> texels;
+    zr_tex_heap tex = {nullptr, nullptr, nullptr, 0};
+    mutable uint32_t baseColorMapsOffset = 0, normalMapsOffset = 0, mrMapsOffset = 0, emissiveMapsOffset = 0;
+    void LatchHeapOffsets(const zr_frame_constants& g) const
+    {
+        baseColorMapsOffset = g.base_color_maps_desc_heap_offset; normalMapsOffset = g.normal_maps_desc_heap_offset;
+        mrMapsOffset = g.metallic_roughness_maps_desc_heap_offset; emissiveMapsOffset = g.emissive_maps_desc_heap_offset;
+    }
     std::vector<WorldTri> tris;          // global triangle order = instance order, then primitive order
     std::vector<BVHNode> nodes;
     std::vector<uint32_t> triOrder;      // BVH leaf order -> global triangle index
@@ -101,6 +117,12 @@ struct Scene
         size_t nrho = (size_t)d.rho_dim[0] * d.rho_dim[1] * d.rho_dim[2];
         rho.assign(d.rho_lut, d.rho_lut + nrho);
         rhoLUT.data = rho.data(); rhoLUT.dim[0] = d.rho_dim[0]; rhoLUT.dim[1] = d.rho_dim[1]; rhoLUT.dim[2] = d.rho_dim[2];
+        if (d.num_textures)
+        {
+            texDescs.assign(d.textures, d.textures + d.num_textures);
+            texels.assign(d.texels, d.texels + d.texel_bytes);
+        }
+        tex.descs = texDescs.data(); tex.texels = texels.data(); tex.srgb = zr_srgb_to_linear_table; tex.count = (uint32_t)texDescs.size();
 
         tris.clear();
         for (uint32_t i = 0; i < d.num_instances; i++)
@@ -187,7 +209,33 @@ struct Scene
 
     // One candidate test.  zr_ray_tri applies the ray's own (tmin, tmax); the closest-hit rule on top of it is:
     // smaller t wins, equal t goes to the smaller global triangle index (ABI tie-break, include/zr_intersect.h).
-    inline void TestTri(uint32_t ti, float3 o, float3 d, float tmin, float rayTmax, uint32_t mask, RawHit& best, bool filterID = false, uint32_t ignoreID = 0) const
+    // GBufferRT_Inline.hlsl:37-70: the alpha test primary rays run on candidate hits of non-opaque geometry
+    // (g_samLinearWrap, mip 0).  true = the candidate is committed.
+    bool TestOpacity(uint32_t meshIdx, uint32_t primIdx, float bu, float bv) const
+    {
+        const zr_mesh_instance& md = instances[meshIdx];
+        const float alphaFactor = (float)(md.alpha_factor_cutoff & 0xffu) / 255.0f;      // Math::UnpackRG
+        const float cutoff = (float)(md.alpha_factor_cutoff >> 8) / 255.0f;
+        if (cutoff == 1.0f) return false;
+        float alpha = alphaFactor;
+        if (md.base_color_tex != 0xffffu)
+        {
+            uint32_t tri = primIdx * 3 + md.base_idx_offset;
+            const zr_vertex& V0 = vertices[indices[tri] + md.base_vtx_offset];
+            const zr_vertex& V1 = vertices[indices[tri + 1] + md.base_vtx_offset];
+            const zr_vertex& V2 = vertices[indices[tri + 2] + md.base_vtx_offset];
+            float u = V0.uv[0] + bu * (V1.uv[0] - V0.uv[0]) + bv * (V2.uv[0] - V0.uv[0]);
+            float v = V0.uv[1] + bu * (V1.uv[1] - V0.uv[1]) + bv * (V2.uv[1] - V0.uv[1]);
+            float c[4];
+            zr_tex_sample_level(&tex, baseColorMapsOffset + md.base_color_tex, u, v, 0.0f, c);
+            alpha *= c[3];
+        }
+        if (alpha < cutoff) return false;
+        return true;
+    }
+
+    inline void TestTri(uint32_t ti, float3 o, float3 d, float tmin, float rayTmax, uint32_t mask, RawHit& best, bool filterID = false, uint32_t ignoreID = 0,
+        bool alphaTest = false) const
     {
         const WorldTri& T = tris[ti];
         if (!(T.mask & mask)) return;
@@ -196,6 +244,7 @@ struct Scene
         if (zr_ray_tri(o.x, o.y, o.z, d.x, d.y, d.z, T.v0[0], T.v0[1], T.v0[2], T.e1[0], T.e1[1], T.e1[2],
                 T.e2[0], T.e2[1], T.e2[2], tmin, rayTmax, &t, &u, &v))
         {
+            if (alphaTest && (T.mask & ZR_INSTANCE_NON_OPAQUE) && !TestOpacity(T.mesh_idx, T.prim_idx, u, v)) return;
             if (!best.hit || t < best.t || (t == best.t && ti < best.tri))
             { best.hit = true; best.t = t; best.u = u; best.v = v; best.tri = ti; }
         }
@@ -204,14 +253,16 @@ struct Scene
     // closest hit (anyHit=false) or first accepted hit (anyHit=true) with tmin < t < tmax over triangles whose
     // instance mask intersects `mask`
     // filterID: triangles whose hashed ID equals ignoreID are not candidates (approximate shadow segments, see Visibility_Segment)
-    RawHit Trace(float3 o, float3 d, float tmin, float tmax, uint32_t mask, bool anyHit, bool filterID = false, uint32_t ignoreID = 0) const
+    // alphaTest: candidates on ZR_INSTANCE_NON_OPAQUE geometry must pass TestOpacity (primary rays only)
+    RawHit Trace(float3 o, float3 d, float tmin, float tmax, uint32_t mask, bool anyHit, bool filterID = false, uint32_t ignoreID = 0,
+        bool alphaTest = false) const
     {
         RawHit best; best.hit = false; best.t = tmax; best.u = best.v = 0; best.tri = 0xffffffffu;
         if (bruteForce)
         {
             for (uint32_t i = 0; i < tris.size(); i++)
             {
-                TestTri(i, o, d, tmin, tmax, mask, best, filterID, ignoreID);
+                TestTri(i, o, d, tmin, tmax, mask, best, filterID, ignoreID, alphaTest);
                 if (anyHit && best.hit) return best;
             }
             return best;
@@ -229,7 +280,7 @@ struct Scene
             {
                 for (uint32_t i = n.first; i < n.first + n.count; i++)
                 {
-                    TestTri(triOrder[i], o, d, tmin, tmax, mask, best, filterID, ignoreID);
+                    TestTri(triOrder[i], o, d, tmin, tmax, mask, best, filterID, ignoreID, alphaTest);
                     if (anyHit && best.hit) return best;
                 }
             }
@@ -428,12 +479,22 @@ static inline bool Visibility_Segment(const Scene& sc, bool approximate, float3 
     return true;
 }
 
-// RayQuery.hlsli:452-524.  Texture maps are not part of this round's scope (DESIGN.md "out of scope"): materials
-// with a base-colour / metallic-roughness texture are shaded with their factors only, on both sides of the parity.
-static inline bool GetMaterialData(const Scene& sc, float3 wo, float eta_curr, float4 uv_grads, Hit& hitInfo,
-    BSDF::ShadingData& surface, float& eta)
+// RayQuery.hlsli:408-450: the two TexSampler policies.  Anisotropic = SampleGrad(samp, uv, ddx, ddy); Isotropic =
+// SampleLevel(samp, uv, log2(max(dd.x * w, dd.y * h))) with dd = uv_grads.xy only (used by the reconnection shift,
+// Shift.hlsli:519).  Filtering itself is zr_texture.h.
+enum class TexSampler { Anisotropic, Isotropic };
+static inline void SampleMaterialTex(const Scene& sc, uint32_t tex, TexSampler ts, float2 uv, float4 g, float out[4])
 {
-    (void)uv_grads;
+    if (ts == TexSampler::Anisotropic) { zr_tex_sample_grad(&sc.tex, tex, uv.x, uv.y, g.x, g.y, g.z, g.w, out); return; }
+    const zr_texture_desc& d = sc.tex.descs[tex];
+    float mip = zr_log2(zr_max(g.x * (float)d.width, g.y * (float)d.height));
+    zr_tex_sample_level(&sc.tex, tex, uv.x, uv.y, mip, out);
+}
+
+// RayQuery.hlsli:452-524
+static inline bool GetMaterialData(const Scene& sc, float3 wo, float eta_curr, float4 uv_grads, Hit& hitInfo,
+    BSDF::ShadingData& surface, float& eta, TexSampler ts = TexSampler::Anisotropic)
+{
     Mat mat; mat.m = sc.materials[hitInfo.matIdx];
     const bool hitBackface = dot(wo, hitInfo.normal) < 0;
     eta = DEFAULT_ETA_MAT;
@@ -450,6 +511,21 @@ static inline bool GetMaterialData(const Scene& sc, float3 wo, float eta_curr, f
     bool tr = mat.Transmissive();
     eta = mat.GetSpecularIOR();
     float trDepth = tr ? mat.GetTransmissionDepth() : 0;
+    const uint32_t baseColorTex = mat.GetBaseColorTex();
+    const uint32_t metallicRoughnessTex = mat.GetMetallicRoughnessTex();
+    if ((trDepth == 0) && (baseColorTex != ZR_INVALID_TEX))
+    {
+        float c[4];
+        SampleMaterialTex(sc, sc.baseColorMapsOffset + baseColorTex, ts, hitInfo.uv, uv_grads, c);
+        baseColor = baseColor * f3(c[0], c[1], c[2]);
+    }
+    if (metallicRoughnessTex != ZR_INVALID_TEX)
+    {
+        float c[4];
+        SampleMaterialTex(sc, sc.mrMapsOffset + metallicRoughnessTex, ts, hitInfo.uv, uv_grads, c);
+        metallic *= c[0];
+        roughness *= c[1];
+    }
     float eta_next = eta_curr == ETA_AIR ? eta : ETA_AIR;
     float subsurface = mat.ThinWalled() ? zr_round_f16(mat.GetSubsurface()) : 0;
     float coat_weight = mat.GetCoatWeight();
@@ -520,14 +596,21 @@ static inline PresampledLight SamplePresampledSet(const Scene& sc, uint32_t samp
     return r;
 }
 
-// LightSource.hlsli:202-223 (emissive textures: out of scope this round, factor * strength only)
-static inline float3 Le_EmissiveTriangle(const EmTri& tri, float2 bary)
+// LightSource.hlsli:202-223 (default sampler g_samPointWrap: the mip-0 texel under texUV)
+static inline float3 Le_EmissiveTriangle(const Scene& sc, const EmTri& tri, float2 bary)
 {
-    (void)bary;
     const float3 emissiveFactor = tri.GetFactor();
     const float emissiveStrength = tri.GetStrength();
     float3 le = emissiveFactor * emissiveStrength;
     if (Math::Luminance(le) == 0) return f3(0.0f);
+    const uint32_t emissiveTex = tri.GetTex();
+    if (emissiveTex != ZR_INVALID_TEX)
+    {
+        float2 texUV = (1.0f - bary.x - bary.y) * tri.UV0() + bary.x * tri.UV1() + bary.y * tri.UV2();
+        float c[4];
+        zr_tex_point(&sc.tex, sc.emissiveMapsOffset + emissiveTex, texUV.x, texUV.y, c);
+        le = le * f3(c[0], c[1], c[2]);
+    }
     return le;
 }
 

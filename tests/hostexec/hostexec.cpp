@@ -5,6 +5,7 @@
 // and the trace stage in program order), so the `-m "not gpu"` suite can check the wavefront decomposition against
 // the oracle in a container without a GPU.  It is never linked into, or loaded by, the product.
 #include <vector>
+#include "../../include/zr_srgb_table.h"
 #include <cstring>
 #include "../../zetaray_amd/csrc/zr_stages.h"
 #include "../../zetaray_amd/csrc/zr_bvh.h"
@@ -26,8 +27,15 @@ struct HxScene
 {
     std::vector<zr_vertex> vertices; std::vector<uint32_t> indices; std::vector<zr_mesh_instance> instances;
     std::vector<zr_material> materials; std::vector<zr_emissive_triangle> emissives; std::vector<zr_alias_entry> alias;
-    std::vector<uint16_t> rho; BuiltBvh bvh; SceneView view; std::vector<zr_presampled_tri> sampleSets; std::vector<uint32_t> skyLut; std::vector<zr_voxel_sample> lvg;
+    std::vector<uint16_t> rho; BuiltBvh bvh; mutable SceneView view; std::vector<zr_texture_desc> texDescs; std::vector<uint8_t> texels; std::vector<zr_presampled_tri> sampleSets; std::vector<uint32_t> skyLut; std::vector<zr_voxel_sample> lvg;
 };
+
+// the descriptor-table offsets of the frame constants, latched into the scene view like zr_pass_render does
+static void Latch(const HxScene* s, const zr_frame_constants* cb)
+{
+    s->view.baseColorMapsOffset = cb->base_color_maps_desc_heap_offset; s->view.normalMapsOffset = cb->normal_maps_desc_heap_offset;
+    s->view.mrMapsOffset = cb->metallic_roughness_maps_desc_heap_offset; s->view.emissiveMapsOffset = cb->emissive_maps_desc_heap_offset;
+}
 
 struct HxQueue
 {
@@ -79,6 +87,8 @@ HxScene* zhx_scene_create(const zr_scene_desc* d)
     v.emissives = s->emissives.data(); v.alias = nullptr; v.sampleSets = nullptr; v.sampleSetSize = 0; v.nodes = s->bvh.nodes4.data(); v.tris = s->bvh.tris.data(); v.triMeta = s->bvh.meta.data();
     v.rho.data = s->rho.data(); v.rho.dx = d->rho_dim[0]; v.rho.dy = d->rho_dim[1]; v.rho.dz = d->rho_dim[2];
     v.numEmissives = d->num_emissives; v.numNodes = (uint32_t)s->bvh.nodes4.size(); v.numTris = (uint32_t)s->bvh.tris.size();
+    if (d->num_textures) { s->texDescs.assign(d->textures, d->textures + d->num_textures); s->texels.assign(d->texels, d->texels + d->texel_bytes); }
+    v.tex.descs = s->texDescs.data(); v.tex.texels = s->texels.data(); v.tex.srgb = zr_srgb_to_linear_table; v.tex.count = d->num_textures;
     return s;
 }
 void zhx_scene_destroy(HxScene* s) { delete s; }
@@ -96,7 +106,7 @@ void zhx_presample(HxScene* s, uint32_t frame_num, uint32_t num_sets, uint32_t s
 }
 // K4 through the device stage functions: the 64 threads of a voxel serially, group sums = the canonical butterfly
 void zhx_build_lvg(HxScene* s, const zr_frame_constants* cb, const uint32_t* dim, const float* extents, float offset_y, zr_voxel_sample* out)
-{
+{ Latch(s, cb);
     const size_t nv = (size_t)dim[0] * dim[1] * dim[2];
     s->lvg.resize(nv * 64);
     const V3 ext = v3(extents[0], extents[1], extents[2]);
@@ -125,14 +135,25 @@ void zhx_le_sky(const HxScene* s, const float* dirs, uint32_t n, float* out)
 { for (uint32_t i = 0; i < n; i++) { V3 r = Le_Sky(v3p(dirs + 3 * i), s->view.sky); out[3 * i] = r.x; out[3 * i + 1] = r.y; out[3 * i + 2] = r.z; } }
 void zhx_le_sun(const zr_frame_constants* cb, const float* pos, uint32_t n, float* out)
 { for (uint32_t i = 0; i < n; i++) { V3 r = Le_Sun(v3p(pos + 3 * i), *cb); out[3 * i] = r.x; out[3 * i + 1] = r.y; out[3 * i + 2] = r.z; } }
-void zhx_estimate_power(const HxScene* s, float* out) { for (size_t i = 0; i < s->emissives.size(); i++) out[i] = EstimateTriPower(s->emissives[i]); }
+void zhx_tex_sample(const HxScene* s, uint32_t tex, int mode, const float* uv, const float* g, uint32_t n, float* out)
+{
+    for (uint32_t i = 0; i < n; i++)
+    {
+        float* o = out + 4 * i;
+        if (mode == 0) zr_tex_point(&s->view.tex, tex, uv[2 * i], uv[2 * i + 1], o);
+        else if (mode == 1) zr_tex_sample_level(&s->view.tex, tex, uv[2 * i], uv[2 * i + 1], g[4 * i], o);
+        else zr_tex_sample_grad(&s->view.tex, tex, uv[2 * i], uv[2 * i + 1], g[4 * i], g[4 * i + 1], g[4 * i + 2], g[4 * i + 3], o);
+    }
+}
+void zhx_latch_heap_offsets(const HxScene* s, const zr_frame_constants* cb) { Latch(s, cb); }
+void zhx_estimate_power(const HxScene* s, float* out) { for (size_t i = 0; i < s->emissives.size(); i++) out[i] = EstimateTriPower(s->view, s->emissives[i]); }
 
 static uint32_t g_tile_x0 = 0, g_tile_y0 = 0;
 // screen-tile origin for the next zhx_gbuffer / zhx_pathtrace calls (planes then have the tile's size)
 void zhx_set_tile_origin(uint32_t x0, uint32_t y0) { g_tile_x0 = x0; g_tile_y0 = y0; }
 
 void zhx_gbuffer(const HxScene* s, const zr_frame_constants* cb, zr_gbuffer_planes* planes)
-{
+{ Latch(s, cb);
     GBuf gb = ViewOf(planes);
     gb.x0 = g_tile_x0; gb.y0 = g_tile_y0;
     zr::StackEntry stackMem[zr::kTravStack]; zr::TravStack stack; stack.lds = nullptr; stack.stride = 0; stack.mem = stackMem;
@@ -143,7 +164,7 @@ void zhx_gbuffer(const HxScene* s, const zr_frame_constants* cb, zr_gbuffer_plan
 
 void zhx_pathtrace(const HxScene* s, const zr_frame_constants* cb, const zr_gbuffer_planes* planes, const zr_params* params,
     float* finalRGBA, zr_counters* counters)
-{
+{ Latch(s, cb);
     GBuf gb = ViewOf(planes);
     gb.x0 = g_tile_x0; gb.y0 = g_tile_y0;
     const uint32_t W = gb.w, H = gb.h;
@@ -253,7 +274,7 @@ void zhx_rpt_set_owned_rect(uint32_t x0, uint32_t y0, uint32_t w, uint32_t h) { 
 // The planes (`curr`, `prev`, reservoirs, finalRGBA) cover the extended tile whose origin zhx_set_tile_origin gave.
 void zhx_rpt_render_stage(const HxScene* s, HxRpt* R, const zr_frame_constants* cb, const zr_gbuffer_planes* curr, const zr_gbuffer_planes* prev,
     const zr_params* params, float* finalRGBA, zr_counters* counters, int stages)
-{
+{ Latch(s, cb);
     using namespace rpt;
     uint32_t cnt[2] = {0, 0}; uint64_t total[2] = {0, 0};
     auto flush = [&]() { total[0] += cnt[0]; total[1] += cnt[1]; cnt[0] = cnt[1] = 0; };
@@ -347,7 +368,7 @@ void zhx_rpt_render_stage(const HxScene* s, HxRpt* R, const zr_frame_constants* 
 }
 void zhx_rpt_render(const HxScene* s, HxRpt* R, const zr_frame_constants* cb, const zr_gbuffer_planes* curr, const zr_gbuffer_planes* prev,
     const zr_params* params, float* finalRGBA, zr_counters* counters)
-{ zhx_rpt_render_stage(s, R, cb, curr, prev, params, finalRGBA, counters, 3); }
+{ Latch(s, cb); zhx_rpt_render_stage(s, R, cb, curr, prev, params, finalRGBA, counters, 3); }
 
 // which: 0 = the set the next frame reads as "previous", 1 = the other.  plane: 0..6 = A..G, 7 = target, 8 = neighbor
 int zhx_rpt_read_plane(const HxRpt* R, int which, int plane, void* out)
@@ -418,7 +439,7 @@ void zhx_rdi_destroy(HxRdi* r) { delete r; }
 void zhx_rdi_reset_temporal(HxRdi* r) { r->temporalValid = false; r->currIdx = 0; }
 void zhx_rdi_render(const HxScene* s, HxRdi* R, const zr_frame_constants* cb, const zr_gbuffer_planes* curr, const zr_gbuffer_planes* prev,
     const zr_params* params, float* finalRGBA, zr_counters* counters)
-{
+{ Latch(s, cb);
     using namespace rdi;
     uint32_t cnt[2] = {0, 0};
     const zr_frame_constants& g = *cb;
@@ -477,7 +498,7 @@ void zhx_rgi_destroy(HxRgi* r) { delete r; }
 void zhx_rgi_reset_temporal(HxRgi* r) { r->temporalValid = false; }
 void zhx_rgi_render(const HxScene* s, HxRgi* R, const zr_frame_constants* cb, const zr_gbuffer_planes* curr, const zr_gbuffer_planes* prev,
     const zr_params* params, float* finalRGBA, zr_counters* counters)
-{
+{ Latch(s, cb);
     using namespace rgi;
     uint32_t cnt[2] = {0, 0};
     const zr_frame_constants& g = *cb;
@@ -546,7 +567,7 @@ void zhx_sdi_destroy(HxSdi* r) { delete r; }
 void zhx_sdi_reset_temporal(HxSdi* r) { r->temporalValid = false; r->currIdx = 0; }
 void zhx_sdi_render(const HxScene* s, HxSdi* R, const zr_frame_constants* cb, const zr_gbuffer_planes* curr, const zr_gbuffer_planes* prev,
     const zr_params* params, float* finalRGBA, zr_counters* counters)
-{
+{ Latch(s, cb);
     using namespace sdi;
     uint32_t cnt[2] = {0, 0};
     const zr_frame_constants& g = *cb;

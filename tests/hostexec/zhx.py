@@ -20,6 +20,8 @@ def lib():
         L.zhx_scene_set_alias.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32]
         L.zhx_bvh_info.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.zhx_estimate_power.argtypes = [C.c_void_p, C.c_void_p]
+        L.zhx_latch_heap_offsets.argtypes = [C.c_void_p, C.c_void_p]
+        L.zhx_tex_sample.argtypes = [C.c_void_p, C.c_uint32, C.c_int, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]
         L.zhx_gbuffer.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.zhx_pathtrace.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.zhx_trace_closest.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]
@@ -79,6 +81,19 @@ class HostExecScene:
         a, b, c = C.c_uint32(), C.c_uint32(), C.c_uint32()
         lib().zhx_bvh_info(self.h, C.byref(a), C.byref(b), C.byref(c))
         return a.value, b.value, c.value
+
+    def latch_heap_offsets(self, cb):
+        cbb = np.ascontiguousarray(cb)
+        lib().zhx_latch_heap_offsets(self.h, cbb.ctypes.data)
+
+    def tex_sample(self, tex, mode, uv, g=None):
+        """zr_texture.h on this scene's heap: mode 0 point, 1 SampleLevel (lod = g[:, 0]), 2 SampleGrad (g = ddx.uv, ddy.uv)"""
+        uv = np.ascontiguousarray(uv, np.float32)
+        g = np.zeros((len(uv), 4), np.float32) if g is None else np.ascontiguousarray(g, np.float32)
+        out = np.zeros((len(uv), 4), np.float32)
+        lib().zhx_tex_sample(self.h, C.c_uint32(tex), C.c_int(mode), uv.ctypes.data_as(C.c_void_p), g.ctypes.data_as(C.c_void_p),
+                            C.c_uint32(len(uv)), out.ctypes.data_as(C.c_void_p))
+        return out
 
     def estimate_power(self):
         out = np.zeros(len(self.scene.emissives), np.float32)

@@ -18,6 +18,7 @@
 #include "zr_sdi.h"
 #include "zr_rgi.h"
 #include "zr_bvh.h"
+#include "../../include/zr_srgb_table.h"
 
 // 512 x half2 spatial-search points (generated from zetaray_amd/assets/rpt_sample_set_f16.bin by the Makefile)
 static const uint16_t kRptSampleSet[1024] = {
@@ -316,10 +317,10 @@ __global__ void k_presample(SceneView sc, uint32_t total, uint32_t frameNum, uin
     if (i < total) out[i] = PresampleEmissive(sc, i, frameNum, numEmissives);
 }
 
-__global__ void k_estimate_power(const zr_emissive_triangle* em, uint32_t n, float* power)
+__global__ void k_estimate_power(SceneView sc, uint32_t n, float* power)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) power[i] = EstimateTriPower(em[i]);
+    if (i < n) power[i] = EstimateTriPower(sc, sc.emissives[i]);
 }
 
 __device__ __forceinline__ float WaveSumButterfly(float v);
@@ -579,10 +580,14 @@ struct zr_scene
     DevBuf<zr_vertex> vertices; DevBuf<uint32_t> indices; DevBuf<zr_mesh_instance> instances; DevBuf<zr_material> materials;
     DevBuf<zr_emissive_triangle> emissives; DevBuf<zr_alias_entry> alias; DevBuf<Bvh4Node> nodes; DevBuf<BvhTri> tris;
     DevBuf<TriMeta> meta; DevBuf<uint16_t> rho;
+    DevBuf<zr_texture_desc> texDescs; DevBuf<uint8_t> texels; DevBuf<float> srgb;   // material texture heap (zr_texture.h)
     DevBuf<zr_presampled_tri> sampleSets; uint32_t numSampleSets = 0;      // K3 output, refreshed by every PRELIGHTING render
     DevBuf<zr_voxel_sample> lvg;                                           // K4 output, rebuilt by every PRELIGHTING render when use_lvg
     std::vector<zr_alias_entry> aliasHost;
-    SceneView view{};
+    // `view` is what kernels receive by value; its texture descriptor-table offsets are latched from the frame constants
+    // of each zr_pass_render call (they are per-frame data in the reference, FrameConstants.h:31-34)
+    mutable SceneView view{};
+    int64_t maxTex[4] = {-1, -1, -1, -1};     // largest tex16 used per table (base colour, normal, metallic-roughness, emissive)
     uint32_t maxDepth = 0;
 };
 
@@ -850,12 +855,41 @@ int zr_scene_create(int device, const zr_scene_desc* d, zr_scene** out)
     UP(tris, bvh.tris.data(), bvh.tris.size());
     UP(meta, bvh.meta.data(), bvh.meta.size());
     UP(rho, d->rho_lut, (size_t)d->rho_dim[0] * d->rho_dim[1] * d->rho_dim[2]);
+    if (d->num_textures)
+    {
+        if (!d->textures || !d->texels) { delete s; return Fail(ZR_ERR_INVALID_ARG, "zr_scene_create: num_textures > 0 without textures / texels"); }
+        for (uint32_t i = 0; i < d->num_textures; i++)
+        {
+            const zr_texture_desc& t = d->textures[i];
+            const zr_tex_mip last = zr_tex_mip_of(&t, t.num_mips ? t.num_mips - 1u : 0u);
+            const uint64_t end = last.offset + (uint64_t)last.w * last.h * (t.format == ZR_TEX_RG8 ? 2u : 4u);
+            if (!t.num_mips || !t.width || !t.height || t.format > ZR_TEX_RG8 || (t.offset & 3u) || end > d->texel_bytes)
+            { delete s; return Fail(ZR_ERR_INVALID_ARG, "zr_scene_create: texture %u is malformed or lies outside the texel blob", i); }
+        }
+        UP(texDescs, d->textures, d->num_textures);
+        UP(texels, d->texels, d->texel_bytes);
+    }
+    UP(srgb, zr_srgb_to_linear_table, 256);
 #undef UP
     SceneView& v = s->view;
     v.vertices = s->vertices.p; v.indices = s->indices.p; v.instances = s->instances.p; v.materials = s->materials.p;
     v.emissives = s->emissives.p; v.alias = nullptr; v.sampleSets = nullptr; v.sampleSetSize = 0; v.nodes = s->nodes.p; v.tris = s->tris.p; v.triMeta = s->meta.p;
     v.rho.data = s->rho.p; v.rho.dx = d->rho_dim[0]; v.rho.dy = d->rho_dim[1]; v.rho.dz = d->rho_dim[2];
     v.numEmissives = d->num_emissives; v.numNodes = (uint32_t)bvh.nodes4.size(); v.numTris = (uint32_t)bvh.tris.size();
+    v.tex.descs = s->texDescs.p; v.tex.texels = s->texels.p; v.tex.srgb = s->srgb.p; v.tex.count = d->num_textures;
+    // largest tex16 per descriptor table, so that zr_pass_render can reject frame constants whose table offsets would
+    // send a texture fetch outside the heap
+    for (uint32_t i = 0; i < d->num_materials; i++)
+    {
+        const zr_material& m = d->materials[i];
+        const uint32_t t[4] = { m.base_color_tex_subsurf_coat_weight & 0xffffu, m.normal_tex_tr_depth & 0xffffu,
+                                m.mr_tex_spec_roughness_coat_roughness & 0xffffu, m.emissive_tex_alpha_cutoff_coat_ior & 0xffffu };
+        for (int k = 0; k < 4; k++) if (t[k] != ZR_INVALID_TEX && (int64_t)t[k] > s->maxTex[k]) s->maxTex[k] = t[k];
+    }
+    for (uint32_t i = 0; i < d->num_instances; i++)
+        if (d->instances[i].base_color_tex != ZR_INVALID_TEX && (int64_t)d->instances[i].base_color_tex > s->maxTex[0]) s->maxTex[0] = d->instances[i].base_color_tex;
+    for (uint32_t i = 0; i < d->num_emissives; i++)
+    { const uint32_t t = d->emissives[i].packed_b & 0xffffu; if (t != ZR_INVALID_TEX && (int64_t)t > s->maxTex[3]) s->maxTex[3] = t; }
     *out = s;
     return ZR_OK;
 }
@@ -1186,7 +1220,7 @@ static int RenderPreLightingInner(zr_pass* p, hipStream_t s, const zr_frame_cons
     int r = p->power.Alloc(n);
     if (r) return r;
     TimerBegin(p, s, "estimate_power");
-    hipLaunchKernelGGL(k_estimate_power, dim3((n + 255) / 256), dim3(256), 0, s, sc->emissives.p, n, p->power.p);
+    hipLaunchKernelGGL(k_estimate_power, dim3((n + 255) / 256), dim3(256), 0, s, sc->view, n, p->power.p);
     TimerEnd(p, s);
     HIP_TRY(hipGetLastError());
     // EmissiveTriangleAliasTable::Render (PreLighting.cpp:512-585): read back, build on the host, upload
@@ -1590,6 +1624,15 @@ int zr_pass_render_stage(zr_pass* p, void* stream, const zr_frame_constants* cb,
     HIP_TRY(hipSetDevice(p->device));
     hipStream_t s = (hipStream_t)stream;
     if (stages & ZR_STAGE_TEMPORAL) p->numTimers = 0;      // timings accumulate over the stages of one frame
+    {
+        const uint32_t off[4] = { cb->base_color_maps_desc_heap_offset, cb->normal_maps_desc_heap_offset,
+                                  cb->metallic_roughness_maps_desc_heap_offset, cb->emissive_maps_desc_heap_offset };
+        for (int k = 0; k < 4; k++)
+            if (sc->maxTex[k] >= 0 && (uint64_t)off[k] + (uint64_t)sc->maxTex[k] >= sc->view.tex.count)
+                return Fail(ZR_ERR_INVALID_ARG, "texture table %d: offset %u + index %lld lies outside the scene's %u textures", k, off[k], (long long)sc->maxTex[k], sc->view.tex.count);
+    }
+    sc->view.baseColorMapsOffset = cb->base_color_maps_desc_heap_offset; sc->view.normalMapsOffset = cb->normal_maps_desc_heap_offset;
+    sc->view.mrMapsOffset = cb->metallic_roughness_maps_desc_heap_offset; sc->view.emissiveMapsOffset = cb->emissive_maps_desc_heap_offset;
     switch (p->kind)
     {
     case ZR_PASS_GBUFFER: return (stages & ZR_STAGE_TEMPORAL) ? RenderGBuffer(p, s, cb, sc, gb) : ZR_OK;

@@ -15,6 +15,7 @@
 #pragma once
 #include "zr_dev_bsdf.h"
 #include "zr_sky.h"
+#include "../../include/zr_texture.h"
 #include "../../include/zr_intersect.h"
 
 namespace zr {
@@ -55,6 +56,10 @@ struct SceneView
     const BvhTri* tris;
     const TriMeta* triMeta;
     RhoView rho;
+    // material texture heap (zr_wire.h zr_texture_desc, zr_texture.h) + the four descriptor-table offsets of the frame
+    // constants (FrameConstants.h:31-34), latched from the cb of the zr_pass_render call that launches the kernel
+    zr_tex_heap tex;
+    uint32_t baseColorMapsOffset, normalMapsOffset, mrMapsOffset, emissiveMapsOffset;
     uint32_t numEmissives;
     uint32_t numNodes;       // 0 => single leaf covering tris[0 .. numTris)
     uint32_t numTris;
@@ -66,8 +71,33 @@ struct RawHit { float t, u, v; uint32_t tri; };     // tri = global triangle ind
 ZR_HD uint32_t TriID(uint32_t meshIdx, uint32_t primIdx)
 { uint32_t kx = meshIdx, ky = 0, kz = primIdx; zr_pcg3d(&kx, &ky, &kz); return kx; }
 
+// TestOpacity, GBufferRT_Inline.hlsl:37-70: alpha test of a candidate hit on non-opaque geometry (primary rays only;
+// g_samLinearWrap at mip 0).  true = commit the candidate.
+ZR_HD bool TestOpacity(const SceneView& sc, uint32_t meshIdx, uint32_t primIdx, float bu, float bv)
+{
+    const zr_mesh_instance& md = sc.instances[meshIdx];
+    const float alphaFactor = (float)(md.alpha_factor_cutoff & 0xffu) / 255.0f;      // Math::UnpackRG
+    const float cutoff = (float)(md.alpha_factor_cutoff >> 8) / 255.0f;
+    if (cutoff == 1.0f) return false;
+    float alpha = alphaFactor;
+    if (md.base_color_tex != 0xffffu)
+    {
+        const uint32_t tri = primIdx * 3 + md.base_idx_offset;
+        const zr_vertex& V0 = sc.vertices[sc.indices[tri] + md.base_vtx_offset];
+        const zr_vertex& V1 = sc.vertices[sc.indices[tri + 1] + md.base_vtx_offset];
+        const zr_vertex& V2_ = sc.vertices[sc.indices[tri + 2] + md.base_vtx_offset];
+        const float u = V0.uv[0] + bu * (V1.uv[0] - V0.uv[0]) + bv * (V2_.uv[0] - V0.uv[0]);
+        const float v = V0.uv[1] + bu * (V1.uv[1] - V0.uv[1]) + bv * (V2_.uv[1] - V0.uv[1]);
+        float c[4];
+        zr_tex_sample_level(&sc.tex, sc.baseColorMapsOffset + md.base_color_tex, u, v, 0.0f, c);
+        alpha *= c[3];
+    }
+    if (alpha < cutoff) return false;
+    return true;
+}
+
 ZR_HD void IntersectTri(const SceneView& sc, uint32_t i, V3 o, V3 d, float tmin, float tmax,
-    uint32_t mask, RawHit& best, bool filterID = false, uint32_t ignoreID = 0)
+    uint32_t mask, RawHit& best, bool filterID = false, uint32_t ignoreID = 0, bool alphaTest = false)
 {
     const BvhTri T = sc.tris[i];
     if (!(T.mask & mask)) return;
@@ -76,15 +106,17 @@ ZR_HD void IntersectTri(const SceneView& sc, uint32_t i, V3 o, V3 d, float tmin,
     if (zr_ray_tri(o.x, o.y, o.z, d.x, d.y, d.z, T.v0[0], T.v0[1], T.v0[2], T.e1[0], T.e1[1], T.e1[2],
             T.e2[0], T.e2[1], T.e2[2], tmin, tmax, &t, &u, &v))
     {
+        if (alphaTest && (T.mask & ZR_INSTANCE_NON_OPAQUE))
+        { const TriMeta tm = sc.triMeta[T.gidx]; if (!TestOpacity(sc, tm.mesh, tm.prim, u, v)) return; }
         // closest hit; equal t goes to the smaller global triangle index (ABI tie-break)
         if (best.tri == kInvalidTri || t < best.t || (t == best.t && T.gidx < best.tri))
         { best.t = t; best.u = u; best.v = v; best.tri = T.gidx; }
     }
 }
 ZR_HD void IntersectLeaf(const SceneView& sc, uint32_t first, uint32_t count, V3 o, V3 d, float tmin, float tmax,
-    uint32_t mask, RawHit& best, bool filterID = false, uint32_t ignoreID = 0)
+    uint32_t mask, RawHit& best, bool filterID = false, uint32_t ignoreID = 0, bool alphaTest = false)
 {
-    for (uint32_t i = first; i < first + count; i++) IntersectTri(sc, i, o, d, tmin, tmax, mask, best, filterID, ignoreID);
+    for (uint32_t i = first; i < first + count; i++) IntersectTri(sc, i, o, d, tmin, tmax, mask, best, filterID, ignoreID, alphaTest);
 }
 
 // Stack-based BVH4 traversal, written as an explicit state machine so that a kernel can either run it to completion
@@ -190,13 +222,13 @@ ZR_HD uint32_t TravNode(const SceneView& sc, TravState& s, const TravStack& stac
 #undef ZR_TRAV_CSWAP
 
 // one step: a leaf (all its triangles) or an inner node (4 box tests).  Returns true when the ray is finished.
-ZR_HD bool TravStep(const SceneView& sc, TravState& s, const TravStack& stack, bool anyHit)
+ZR_HD bool TravStep(const SceneView& sc, TravState& s, const TravStack& stack, bool anyHit, bool alphaTest = false)
 {
     if (s.cur & kLeafBit)
     {
         uint32_t first = (s.cur & 0x7fffffffu) >> 3, count = (s.cur & 7u) + 1u;
         if (s.cur == kWholeSceneLeaf) { first = 0; count = sc.numTris; }
-        IntersectLeaf(sc, first, count, s.o, s.d, s.tmin, s.tmax, s.mask, s.best, s.filterID, s.ignoreID);
+        IntersectLeaf(sc, first, count, s.o, s.d, s.tmin, s.tmax, s.mask, s.best, s.filterID, s.ignoreID, alphaTest);
         if (anyHit && s.best.tri != kInvalidTri) return true;
         return !TravPop(s, stack);
     }
@@ -233,16 +265,17 @@ ZR_HD void TravNodePhase(const SceneView& sc, TravState& s, TravLane& L, const T
     if (next == kEmptyChild) TravPopEnter(sc, s, L, stack);
     else TravEnter(sc, s, L, next);
 }
-ZR_HD void TravTriPhase(const SceneView& sc, TravState& s, TravLane& L, const TravStack& stack, bool anyHit)
+ZR_HD void TravTriPhase(const SceneView& sc, TravState& s, TravLane& L, const TravStack& stack, bool anyHit, bool alphaTest = false)
 {
-    IntersectTri(sc, L.triCur, s.o, s.d, s.tmin, s.tmax, s.mask, s.best, s.filterID, s.ignoreID);
+    IntersectTri(sc, L.triCur, s.o, s.d, s.tmin, s.tmax, s.mask, s.best, s.filterID, s.ignoreID, alphaTest);
     L.triCur++;
     if (anyHit && s.best.tri != kInvalidTri) { L.done = true; L.triCur = L.triEnd; }
     else if (L.triCur == L.triEnd) TravPopEnter(sc, s, L, stack);
 }
 
+// alphaTest (primary rays): candidates on ZR_INSTANCE_NON_OPAQUE geometry must pass TestOpacity
 ZR_HD RawHit TraverseDyn(const SceneView& sc, V3 o, V3 d, float tmin, float tmax, uint32_t mask, const TravStack& stack, bool anyHit,
-    bool filterID = false, uint32_t ignoreID = 0)
+    bool filterID = false, uint32_t ignoreID = 0, bool alphaTest = false)
 {
     TravState s;
     TravInit(sc, s, o, d, tmin, tmax, mask, filterID, ignoreID);
@@ -256,10 +289,10 @@ ZR_HD RawHit TraverseDyn(const SceneView& sc, V3 o, V3 d, float tmin, float tmax
         const uint64_t mNode = __ballot(atNode), mTri = __ballot(atTri);
         if ((mNode | mTri) == 0) break;
         if (__popcll(mNode) >= __popcll(mTri)) { if (atNode) TravNodePhase(sc, s, L, stack); }
-        else { if (atTri) TravTriPhase(sc, s, L, stack, anyHit); }
+        else { if (atTri) TravTriPhase(sc, s, L, stack, anyHit, alphaTest); }
     }
 #else
-    while (!TravStep(sc, s, stack, anyHit)) {}
+    while (!TravStep(sc, s, stack, anyHit, alphaTest)) {}
 #endif
     return s.best;
 }
@@ -383,11 +416,20 @@ ZR_HD PresampledLight SamplePresampledSet(const SceneView& sc, uint32_t sampleSe
     return r;
 }
 
-// Le_EmissiveTriangle, LightSource.hlsli:202-223 (emissive textures not bound)
-ZR_HD V3 EmLe(const zr_emissive_triangle& t)
+// Le_EmissiveTriangle, LightSource.hlsli:202-223 (default sampler g_samPointWrap: the mip-0 texel under texUV)
+ZR_HD V2 EmUV(const uint16_t* h) { return v2(zr_f16_to_f32(h[0]), zr_f16_to_f32(h[1])); }
+ZR_HD V3 EmLe(const SceneView& sc, const zr_emissive_triangle& t, V2 bary)
 {
     V3 le = UnpackRGB8(t.packed_a) * zr_f16_to_f32((uint16_t)(t.packed_b >> 16));
     if (Luminance(le) == 0) return v3(0.0f);
+    const uint32_t emissiveTex = t.packed_b & 0xffffu;
+    if (emissiveTex != ZR_INVALID_TEX)
+    {
+        const V2 texUV = (1.0f - bary.x - bary.y) * EmUV(t.uv0) + bary.x * EmUV(t.uv1) + bary.y * EmUV(t.uv2);
+        float c[4];
+        zr_tex_point(&sc.tex, sc.emissiveMapsOffset + emissiveTex, texUV.x, texUV.y, c);
+        le = le * v3(c[0], c[1], c[2]);
+    }
     return le;
 }
 

@@ -89,7 +89,7 @@ ZR_HD void LvgThread(const SceneView& sc, const zr_frame_constants& g, const uin
         const float twoArea = length(ln);
         const float lpdfPos = normalIs0 ? 0.0f : 2.0f / twoArea;
         ln = normalIs0 ? ln : ln / twoArea;
-        const V3 le = EmLe(em);
+        const V3 le = EmLe(sc, em, bary);
         const V3 d = v3(zr_abs(lpos.x - voxelCenter.x), zr_abs(lpos.y - voxelCenter.y), zr_abs(lpos.z - voxelCenter.z));
         const bool inside = d.x <= ext.x && d.y <= ext.y && d.z <= ext.z;
         V3 lightPos = lpos;

@@ -156,7 +156,7 @@ ZR_HD Reservoir RIS_InitialCandidates(const Globals& gl, const zr_frame_constant
         if (hitInfo.hit)
         {
             const zr_emissive_triangle em = sc.emissives[hitInfo.emissiveTriIdx];
-            le = EmLe(em);
+            le = EmLe(sc, em, hitInfo.bary);
             const V3 vtx0 = v3p(em.vtx0), vtx1 = EmV1(em), vtx2 = EmV2(em);
             lightNormal = cross(vtx1 - vtx0, vtx2 - vtx0);
             float twoArea = length(lightNormal);
@@ -210,7 +210,7 @@ ZR_HD Reservoir RIS_InitialCandidates(const Globals& gl, const zr_frame_constant
             float lpdfPos = normalIs0 ? 0.0f : 2.0f / twoArea;
             ln = normalIs0 ? ln : ln / twoArea;
             ln = EmDoubleSided(em) && dot(pos - lpos, ln) < 0 ? -ln : ln;
-            le = EmLe(em);
+            le = EmLe(sc, em, lbary);
             pdf_light = lpdfSrc * lpdfPos;
             lightID = em.id; doubleSided = EmDoubleSided(em);
         }

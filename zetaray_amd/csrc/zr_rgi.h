@@ -110,7 +110,7 @@ ZR_HD LightDraw DrawLight(const Globals& g, V3 shadingPos, Rng& rng)
     float lpdfPos = normalIs0 ? 0.0f : 2.0f / twoArea;
     ln = normalIs0 ? ln : ln / twoArea;
     d.normal = EmDoubleSided(em) && dot(shadingPos - d.pos, ln) < 0 ? -ln : ln;
-    d.le = EmLe(em);
+    d.le = EmLe(sc, em, bary);
     d.pdf = lpdfSrc * lpdfPos;
     d.ID = em.id;
     return d;
@@ -191,7 +191,7 @@ ZR_HD V3 NEE_Emissive_MIS(const Globals& g, V3 pos, V3 normal, Surface surface, 
         if (hitInfo.emissiveTriIdx != 0xffffffffu)
         {
             const zr_emissive_triangle em = sc.emissives[hitInfo.emissiveTriIdx];
-            V3 le = EmLe(em);
+            V3 le = EmLe(sc, em, v2(hitInfo.bu, hitInfo.bv));
             const V3 vtx0 = v3p(em.vtx0), vtx1 = EmV1(em), vtx2 = EmV2(em);
             V3 ln = cross(vtx1 - vtx0, vtx2 - vtx0);
             float twoArea = length(ln);

@@ -471,7 +471,7 @@ ZR_HD Direct NEE_Bsdf(const Globals& g, V3 pos, V3 normal, const Surface& surfac
     if (hitInfo.emissiveTriIdx != 0xffffffffu)
     {
         const zr_emissive_triangle em = sc.emissives[hitInfo.emissiveTriIdx];
-        const V3 le = EmLe(em);
+        const V3 le = EmLe(sc, em, v2(hitInfo.bu, hitInfo.bv));
         const V3 vtx0 = v3p(em.vtx0), vtx1 = EmV1(em), vtx2 = EmV2(em);
         V3 ln = cross(vtx1 - vtx0, vtx2 - vtx0);
         float twoArea = length(ln);
@@ -528,7 +528,7 @@ ZR_HD Direct NEE_Emissive(const Globals& g, V3 pos, V3 normal, Surface surface, 
         float lpdfPos = normalIs0 ? 0.0f : 2.0f / twoArea;
         ln = normalIs0 ? ln : ln / twoArea;
         ln = EmDoubleSided(em) && dot(pos - lpos, ln) < 0 ? -ln : ln;
-        le = EmLe(em);
+        le = EmLe(sc, em, bary);
         lightPdf = lpdfSrc * lpdfPos;
         lightID = em.id; twoSided = EmDoubleSided(em);
     }

@@ -50,6 +50,68 @@ ZR_HD float EncodeMetallic(float metalness, bool tr, V3 emissive, float trDepth,
 ZR_HD float EncodeIOR(float ior) { return (ior - kMinIOR) / (kMaxIOR - kMinIOR); }   // GBuffers.hlsli:97-105
 ZR_HD float DecodeIOR(float e) { return zr_fma(e, kMaxIOR - kMinIOR, kMinIOR); }
 
+// GBufferRT::UVDifferentials, GBufferRT.hlsli:11-100
+ZR_HD F4 UVDifferentials(int px, int py, V3 origin, V3 dir, bool thinLens, V2 lensSample, float focusDepth, float t,
+    V3 dpdu, V3 dpdv, const zr_frame_constants& g)
+{
+    const float dpduDotdpdu = dot(dpdu, dpdu);
+    const float dpdvDotdpdv = dot(dpdv, dpdv);
+    const float dpduDotdpdv = dot(dpdu, dpdv);
+    const float det = dpduDotdpdu * dpdvDotdpdv - dpduDotdpdv * dpduDotdpdv;
+    if (zr_abs(det) < 1e-7f) return f4(0, 0, 0, 0);
+
+    const V2 renderDim = v2((float)g.render_width, (float)g.render_height);
+    const V2 jitter = v2(g.curr_camera_jitter[0], g.curr_camera_jitter[1]);
+    V3 dir_cs_x = GeneratePinholeCameraRay_CS(px + 1, py, renderDim, g.aspect_ratio, g.tan_half_fov, jitter);
+    V3 dir_cs_y = GeneratePinholeCameraRay_CS(px, py - 1, renderDim, g.aspect_ratio, g.tan_half_fov, jitter);
+    if (thinLens)
+    {
+        dir_cs_x = focusDepth * dir_cs_x - v3(lensSample.x, lensSample.y, 0);
+        dir_cs_y = focusDepth * dir_cs_y - v3(lensSample.x, lensSample.y, 0);
+    }
+    const V3 vbx = Row3(g.curr_view, 0), vby = Row3(g.curr_view, 1), vbz = Row3(g.curr_view, 2);
+    const V3 dir_x = normalize(mad(dir_cs_x.x, vbx, mad(dir_cs_x.y, vby, dir_cs_x.z * vbz)));
+    const V3 dir_y = normalize(mad(dir_cs_y.x, vbx, mad(dir_cs_y.y, vby, dir_cs_y.z * vbz)));
+
+    const V3 faceNormal = normalize(cross(dpdu, dpdv));
+    const V3 p = origin + t * dir;
+    const float d = -dot(faceNormal, p);
+    const float numerator = -dot(faceNormal, origin) - d;
+
+    float denom_x = dot(faceNormal, dir_x);
+    denom_x = (denom_x < 0 ? -1.0f : 1.0f) * zr_max(zr_abs(denom_x), 1e-8f);
+    const float t_x = numerator / denom_x;
+    const V3 p_x = origin + t_x * dir_x;
+
+    float denom_y = dot(faceNormal, dir_y);
+    denom_y = (denom_y < 0 ? -1.0f : 1.0f) * zr_max(zr_abs(denom_y), 1e-8f);
+    const float t_y = numerator / denom_y;
+    const V3 p_y = origin + t_y * dir_y;
+
+    // least-squares solution x_hat = (A^T A)^-1 A^T b, A = [dpdu dpdv]; mul(float2x2, float2) = row . vector, left to right
+    const V3 dpdx = p_x - p;
+    const V2 bx = v2(dot(dpdu, dpdx), dot(dpdv, dpdx));
+    const V3 dpdy = p_y - p;
+    const V2 by = v2(dot(dpdu, dpdy), dot(dpdv, dpdy));
+    return f4((dpdvDotdpdv * bx.x + -dpduDotdpdv * bx.y) / det, (-dpduDotdpdv * bx.x + dpduDotdpdu * bx.y) / det,
+              (dpdvDotdpdv * by.x + -dpduDotdpdv * by.y) / det, (-dpduDotdpdv * by.x + dpduDotdpdu * by.y) / det);
+}
+
+// Math::TangentSpaceToWorldSpace, Math.hlsli:263-284
+ZR_HD V3 TangentSpaceToWorldSpace(V2 bumpNormal2, V3 tangent, V3 normal, float scale)
+{
+    V3 bumpNormal = v3(zr_fma(2.0f, bumpNormal2.x, -1.0f), zr_fma(2.0f, bumpNormal2.y, -1.0f), 0.0f);
+    bumpNormal.z = zr_sqrt(zr_saturate(1.0f - dot(bumpNormal, bumpNormal)));
+    V3 scaledBumpNormal = bumpNormal * v3(scale, scale, 1.0f);
+    if (dot(scaledBumpNormal, scaledBumpNormal) < 1e-6f) return normal;
+    scaledBumpNormal = normalize(scaledBumpNormal);
+    normal = normalize(normal);
+    tangent = normalize(tangent - dot(tangent, normal) * normal);
+    const V3 bitangent = cross(normal, tangent);
+    // mul(row vector, float3x3(tangent, bitangent, normal)): sum over rows, left to right
+    return scaledBumpNormal.x * tangent + scaledBumpNormal.y * bitangent + scaledBumpNormal.z * normal;
+}
+
 // K1: one pixel of GBufferRT_Inline.hlsl main (:204-287) + TracePrimaryHit (:72-198) + GBufferRT.hlsli:102-282.
 // Primary rays are coherent, so traversal runs inline in this kernel (no queue round trip).
 ZR_HD void GBufferPixel(const SceneView& sc, const zr_frame_constants& g, const GBuf& gb, uint32_t x, uint32_t y,
@@ -75,7 +137,8 @@ ZR_HD void GBufferPixel(const SceneView& sc, const zr_frame_constants& g, const 
     V3 dir = normalize(mad(dirCS.x, vbx, mad(dirCS.y, vby, dirCS.z * vbz)));
 
     (void)nClosest;
-    RawHit h = Traverse<false>(sc, origin, dir, 0.0f, ZR_FLT_MAX, ZR_SUBGROUP_ALL, stack);
+    // TracePrimaryHit: the only ray type without RAY_FLAG_FORCE_OPAQUE -> alpha-tested candidates
+    RawHit h = TraverseDyn(sc, origin, dir, 0.0f, ZR_FLT_MAX, ZR_SUBGROUP_ALL, stack, false, false, 0, /*alphaTest*/ true);
 
     if (h.tri == kInvalidTri)
     {
@@ -109,6 +172,13 @@ ZR_HD void GBufferPixel(const SceneView& sc, const zr_frame_constants& g, const 
     const V3 scaleInv = v3(1.0f / scale.x, 1.0f / scale.y, 1.0f / scale.z);
     normal = normalize(RotateVector(normal * scaleInv, q));
 
+    const V2 uv = uv0 + h.u * (uv1 - uv0) + h.v * (uv2 - uv0);
+
+    // tangent vector (GBufferRT_Inline.hlsl:147-155)
+    const V3 v0_t = DecodeOct32(V0.tangent), v1_t = DecodeOct32(V1.tangent), v2_t = DecodeOct32(V2_.tangent);
+    V3 tangent = v0_t + h.u * (v1_t - v0_t) + h.v * (v2_t - v0_t);
+    tangent = normalize(RotateVector(tangent * scale, q));
+
     V3 v0W = TransformTRS(v3p(V0.pos), trn, q, scale);
     V3 v1W = TransformTRS(v3p(V1.pos), trn, q, scale);
     V3 v2W = TransformTRS(v3p(V2_.pos), trn, q, scale);
@@ -136,13 +206,35 @@ ZR_HD void GBufferPixel(const SceneView& sc, const zr_frame_constants& g, const 
     float z = g.dof ? h.t : posV.z;
     V3 wo = origin - pos;
 
+    // ApplyTextureMaps, GBufferRT.hlsli:178-282
     const zr_material mat = sc.materials[md.mat_idx];
+    const uint32_t baseColorTex = mat.base_color_tex_subsurf_coat_weight & 0xffffu, normalTex = mat.normal_tex_tr_depth & 0xffffu;
+    const uint32_t mrTex = mat.mr_tex_spec_roughness_coat_roughness & 0xffffu, emissiveTex = mat.emissive_tex_alpha_cutoff_coat_ior & 0xffffu;
+    // (the gradients only feed SampleGrad; untextured materials skip them)
+    F4 grads = f4(0, 0, 0, 0);
+    if (baseColorTex != ZR_INVALID_TEX || normalTex != ZR_INVALID_TEX || mrTex != ZR_INVALID_TEX)
+        grads = UVDifferentials((int)x, (int)y, origin, dir, g.dof != 0, lens, g.focus_depth, h.t, td.dpdu, td.dpdv, g);
+    grads = f4(grads.x * g.camera_ray_uv_grads_scale, grads.y * g.camera_ray_uv_grads_scale,
+               grads.z * g.camera_ray_uv_grads_scale, grads.w * g.camera_ray_uv_grads_scale);
     V3 baseColor = UnpackRGB8(mat.base_color_factor);
     V3 emissive = UnpackRGB8(mat.emissive_factor_normal_scale);
     float metallic = MatMetallic(mat) ? 1.0f : 0.0f;
     float roughness = MatRoughness(mat);
     V3 sn = normal;
     V3 dndu = td.dndu, dndv = td.dndv;
+    if (baseColorTex != ZR_INVALID_TEX)
+    {
+        float c[4];
+        zr_tex_sample_grad(&sc.tex, g.base_color_maps_desc_heap_offset + baseColorTex, uv.x, uv.y, grads.x, grads.y, grads.z, grads.w, c);
+        baseColor = baseColor * v3(c[0], c[1], c[2]);
+    }
+    // avoid normal mapping if tangent = (0, 0, 0), which results in NaN
+    if (normalTex != ZR_INVALID_TEX && zr_abs(dot(tangent, tangent)) > 1e-6f)
+    {
+        float c[4];
+        zr_tex_sample_grad(&sc.tex, g.normal_maps_desc_heap_offset + normalTex, uv.x, uv.y, grads.x, grads.y, grads.z, grads.w, c);
+        sn = TangentSpaceToWorldSpace(v2(c[0], c[1]), tangent, normal, (float)(mat.emissive_factor_normal_scale >> 24) / 255.0f);
+    }
     if (MatDoubleSided(mat) && dot(wo, normal) < 0) { sn = sn * -1.0f; dndu = dndu * -1.0f; dndv = dndv * -1.0f; }
     if (dot(wo, normal) > 0 && dot(wo, sn) < 0)
     {
@@ -150,6 +242,19 @@ ZR_HD void GBufferPixel(const SceneView& sc, const zr_frame_constants& g, const 
         sn = sn - dot(sn, wo) * wo;
         sn = 1e-4f * wo + sn;
         sn = normalize(sn);
+    }
+    if (mrTex != ZR_INVALID_TEX)
+    {
+        float c[4];
+        zr_tex_sample_grad(&sc.tex, g.metallic_roughness_maps_desc_heap_offset + mrTex, uv.x, uv.y, grads.x, grads.y, grads.z, grads.w, c);
+        metallic *= c[0];
+        roughness *= c[1];
+    }
+    if (emissiveTex != ZR_INVALID_TEX)
+    {
+        float c[4];
+        zr_tex_sample_level(&sc.tex, g.emissive_maps_desc_heap_offset + emissiveTex, uv.x, uv.y, 0.0f, c);
+        emissive = emissive * v3(c[0], c[1], c[2]);
     }
     emissive = emissive * MatEmissiveStrength(mat);
     bool tr = MatTransmissive(mat);
@@ -468,7 +573,7 @@ ZR_HD void PtShadePath(const SceneView& sc, const zr_frame_constants& g, const P
             {
                 const uint32_t eidx = base + tm.prim;
                 const zr_emissive_triangle em = sc.emissives[eidx];
-                V3 le = EmLe(em);
+                V3 le = EmLe(sc, em, v2(zr_asfloat(hm.y), zr_asfloat(hm.z)));
                 const V3 vtx0 = v3p(em.vtx0), vtx1 = EmV1(em), vtx2 = EmV2(em);
                 V3 ln = cross(vtx1 - vtx0, vtx2 - vtx0);
                 float twoArea = length(ln);
@@ -569,7 +674,7 @@ ZR_HD void PtShadePath(const SceneView& sc, const zr_frame_constants& g, const P
                 float lpdfPos = normalIs0 ? 0.0f : 2.0f / twoArea;
                 ln = normalIs0 ? ln : ln / twoArea;
                 ln = EmDoubleSided(em) && dot(hitPos - lpos, ln) < 0 ? -ln : ln;
-                le = EmLe(em);
+                le = EmLe(sc, em, bary);
                 lightPdf = lpdfSrc * lpdfPos;
                 lightID = em.id;
             }
@@ -756,7 +861,7 @@ ZR_HD zr_presampled_tri PresampleEmissive(const SceneView& sc, uint32_t i, uint3
     float twoArea = length(ln);
     float lpdfPos = normalIs0 ? 0.0f : 2.0f / twoArea;
     ln = normalIs0 ? ln : ln / twoArea;                            // reverseNormalIfTwoSided == false
-    V3 le = EmLe(em);
+    V3 le = EmLe(sc, em, bary);
     zr_presampled_tri s;
     s.pos[0] = lpos.x; s.pos[1] = lpos.y; s.pos[2] = lpos.z;
     V2 e = EncodeUnitVector(ln);
@@ -811,10 +916,37 @@ ZR_HD V3 FireflyClamp(const TileC& col, const TileD& dep, int tx, int ty, int x,
     return ret;
 }
 
-// K2: EstimateTriEmissivePower.hlsl:29-79 (untextured branch)
-ZR_HD float EstimateTriPower(const zr_emissive_triangle& em)
+// K2: EstimateTriEmissivePower.hlsl:29-79.  Textured triangles: 32 lanes x 2 Halton(2, 3) points (PreLighting.cpp:236-243,
+// Sampling.cpp:160-174), emissive map at mip 0 through g_samLinearWrap; the WaveActiveSum over the lane partials is pinned
+// to ascending lane order (one thread per triangle here).
+ZR_HD float Halton(int i, int b)
+{
+    float f = 1.0f, r = 0.0f; const float bf = (float)b;
+    while (i > 0) { f /= bf; r = r + f * (float)(i % b); i = (int)((float)i / bf); }
+    return r;
+}
+ZR_HD float EstimateTriPower(const SceneView& sc, const zr_emissive_triangle& em)
 {
     V3 power = v3(64.0f);
+    const uint32_t emissiveTex = em.packed_b & 0xffffu;
+    if (emissiveTex != ZR_INVALID_TEX)
+    {
+        power = v3(0.0f);
+        for (int lane = 0; lane < 32; lane++)
+        {
+            V3 lanePower = v3(0.0f);
+            for (int k = 0; k < 2; k++)
+            {
+                const int si = lane * 2 + k;
+                const V2 bary = UniformSampleTriangle(v2(Halton(si + 1, 2), Halton(si + 1, 3)));
+                const V2 texUV = (1.0f - bary.x - bary.y) * EmUV(em.uv0) + bary.x * EmUV(em.uv1) + bary.y * EmUV(em.uv2);
+                float c[4];
+                zr_tex_sample_level(&sc.tex, sc.emissiveMapsOffset + emissiveTex, texUV.x, texUV.y, 0.0f, c);
+                lanePower = lanePower + v3(c[0], c[1], c[2]);
+            }
+            power = power + lanePower;
+        }
+    }
     power = power * UnpackRGB8(em.packed_a) * zr_f16_to_f32((uint16_t)(em.packed_b >> 16));
     const V3 vtx0 = v3p(em.vtx0), vtx1 = EmV1(em), vtx2 = EmV2(em);
     const float area = 0.5f * length(cross(vtx1 - vtx0, vtx2 - vtx0));

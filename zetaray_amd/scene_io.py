@@ -132,7 +132,34 @@ class Scene:
         self.emissives = np.zeros(0, wire.EMISSIVE_TRI)
         self.rho = None
         self.rho_dim = (0, 0, 0)
+        self.textures = np.zeros(0, wire.TEXTURE_DESC)     # material texture heap (include/zr_wire.h zr_texture_desc)
+        self.texels = np.zeros(0, np.uint8)
         self._desc = None
+
+    def add_texture(self, image, fmt=wire.TEX_RGBA8_SRGB, mips=True):
+        """Appends one texture (H x W x C uint8, C = 4 for RGBA8 formats, 2 for RG8) with its full mip chain and returns
+        its index in the heap.  Mips are 2x2 box filtered on the stored bytes (round half up; an odd size drops its last
+        row / column -- floor convention, as the reference's offline texconv does); the reference ships them inside the
+        .dds (Tools/BCnCompressglTF), here they are the caller's data like any other texel."""
+        img = np.ascontiguousarray(image, np.uint8)
+        ch = 2 if fmt == wire.TEX_RG8 else 4
+        assert img.ndim == 3 and img.shape[2] == ch
+        chain = [img]
+        while mips and (chain[-1].shape[0] > 1 or chain[-1].shape[1] > 1):
+            a = chain[-1].astype(np.uint32)
+            h, w = a.shape[0], a.shape[1]
+            h2, w2 = max(1, h // 2), max(1, w // 2)
+            ys = (np.arange(h2) * 2, np.minimum(np.arange(h2) * 2 + 1, h - 1))
+            xs = (np.arange(w2) * 2, np.minimum(np.arange(w2) * 2 + 1, w - 1))
+            acc = sum(a[np.ix_(yy, xx)] for yy in ys for xx in xs)
+            chain.append(((acc + 2) // 4).astype(np.uint8))
+        off = (len(self.texels) + 3) // 4 * 4
+        blob = np.concatenate([m.reshape(-1) for m in chain])
+        self.texels = np.concatenate([self.texels, np.zeros(off - len(self.texels), np.uint8), blob])
+        d = np.zeros(1, wire.TEXTURE_DESC)
+        d["offset"], d["width"], d["height"], d["num_mips"], d["format"] = off, img.shape[1], img.shape[0], len(chain), fmt
+        self.textures = np.concatenate([self.textures, d])
+        return len(self.textures) - 1
 
     @property
     def num_tris(self):
@@ -140,7 +167,7 @@ class Scene:
 
     def desc(self) -> wire.SceneDesc:
         for name in ("vertices", "indices", "instances", "instance_to_world", "instance_mask", "instance_num_tris",
-                     "materials", "emissives", "rho"):
+                     "materials", "emissives", "rho", "textures", "texels"):
             setattr(self, name, np.ascontiguousarray(getattr(self, name)))
         d = wire.SceneDesc()
         d.vertices = self.vertices.ctypes.data
@@ -158,6 +185,10 @@ class Scene:
         d.num_emissives = len(self.emissives)
         d.rho_lut = self.rho.ctypes.data
         d.rho_dim[0], d.rho_dim[1], d.rho_dim[2] = self.rho_dim
+        d.textures = self.textures.ctypes.data if len(self.textures) else None
+        d.num_textures = len(self.textures)
+        d.texels = self.texels.ctypes.data if len(self.texels) else None
+        d.texel_bytes = len(self.texels)
         self._desc = d
         return d
 
@@ -672,3 +703,76 @@ def make_synthetic_scene(num_tris=262144, num_emissive=100000, seed=0x5EED, room
     sc.instance_num_tris = np.array(ntris, np.uint32)
     sc.rho, sc.rho_dim = load_rho_default()
     return sc
+
+
+def add_test_textures(sc: Scene, seed=7, non_opaque_instance=2):
+    """Binds a small procedural texture set to a synthetic scene (tests / benches; not in the reference): two sRGB base
+    colour maps (the second with a varying alpha channel), an RG8 normal map, a non-power-of-two RG8 metallic-roughness
+    map and an sRGB emissive map.  Heap order [base0, base1, normal0, mr0, emissive0]; returns the four descriptor-table
+    offsets to put into the frame constants: dict(base_color=0, normal=2, metallic_roughness=3, emissive=4).
+    Material 1 (the room) gets base0 + normal0 + mr0, every third clutter material base1, the emissive material and all
+    emissive triangles emissive0; instance `non_opaque_instance` becomes alpha tested (ZR_INSTANCE_NON_OPAQUE, cutoff 0.5)
+    against base1.  UVs are scaled so that several mip levels are exercised and per-vertex tangents are filled in."""
+    rng = np.random.default_rng(seed)
+    def smooth(h, w, c):
+        a = rng.uniform(0, 1, (h // 4 + 1, w // 4 + 1, c))
+        a = np.kron(a, np.ones((4, 4, 1)))[:h, :w]
+        a = 0.75 * a + 0.25 * rng.uniform(0, 1, (h, w, c))
+        return np.clip(np.rint(a * 255), 0, 255).astype(np.uint8)
+    base0 = smooth(32, 64, 4); base0[..., 3] = 255
+    base1 = smooth(32, 32, 4)
+    yy, xx = np.mgrid[0:32, 0:32]
+    base1[..., 3] = np.where(((xx // 4) + (yy // 4)) % 2 == 0, 255, rng.integers(0, 120, (32, 32))).astype(np.uint8)
+    nrm = np.clip(128 + rng.normal(0, 30, (32, 32, 2)), 0, 255).astype(np.uint8)
+    mr = smooth(12, 24, 2)
+    em = smooth(8, 8, 4)
+    t_base0 = sc.add_texture(base0, wire.TEX_RGBA8_SRGB)
+    t_base1 = sc.add_texture(base1, wire.TEX_RGBA8_SRGB)
+    t_nrm = sc.add_texture(nrm, wire.TEX_RG8)
+    t_mr = sc.add_texture(mr, wire.TEX_RG8)
+    t_em = sc.add_texture(em, wire.TEX_RGBA8_SRGB)
+    offs = dict(base_color=t_base0, normal=t_nrm, metallic_roughness=t_mr, emissive=t_em)
+
+    mats = sc.materials.copy()
+    def set_tex(i, field, tex):
+        mats[field][i] = (int(mats[field][i]) & 0xFFFF0000) | tex
+    set_tex(1, "base_color_tex_subsurf_coat_weight", 0)
+    set_tex(1, "normal_tex_tr_depth", 0)
+    set_tex(1, "mr_tex_spec_roughness_coat_roughness", 0)
+    mats["emissive_factor_normal_scale"][1] = (int(mats["emissive_factor_normal_scale"][1]) & 0x00FFFFFF) | (200 << 24)   # normal scale
+    for i in range(2, len(mats) - 1, 3):
+        set_tex(i, "base_color_tex_subsurf_coat_weight", 1)
+    set_tex(len(mats) - 1, "emissive_tex_alpha_cutoff_coat_ior", 0)
+    sc.materials = mats
+    if len(sc.emissives):
+        ems = sc.emissives.copy()
+        ems["packed_b"] = (ems["packed_b"] & np.uint32(0xFFFF0000)) | np.uint32(0)
+        sc.emissives = ems
+    inst = sc.instances.copy()
+    masks = sc.instance_mask.copy()
+    k = non_opaque_instance
+    if k is not None and k < len(inst):
+        inst["base_color_tex"][k] = 1
+        inst["alpha_factor_cutoff"][k] = 255 | (128 << 8)
+        masks[k] |= wire.INSTANCE_NON_OPAQUE
+    sc.instances, sc.instance_mask = inst, masks
+    # UV scale per instance + tangents (non-indexed synthetic meshes: 3 vertices per triangle)
+    v = sc.vertices.copy()
+    for i in range(len(inst)):
+        b, n = int(inst["base_vtx_offset"][i]), int(sc.instance_num_tris[i]) * 3
+        v["uv"][b:b + n] *= np.float32(6.0 if i == 0 else 1.5)
+        P = v["pos"][b:b + n].reshape(-1, 3, 3)
+        t = P[:, 1] - P[:, 0]
+        t = t / np.maximum(np.linalg.norm(t, axis=1, keepdims=True), 1e-20)
+        v["tangent"][b:b + n] = encode_octahedral(np.repeat(t.astype(np.float32), 3, axis=0))
+    sc.vertices = v
+    return offs
+
+
+def set_texture_heap_offsets(cb, offs):
+    """Writes add_test_textures' table offsets into frame constants (FrameConstants.h:31-34)."""
+    cb["base_color_maps_desc_heap_offset"] = offs["base_color"]
+    cb["normal_maps_desc_heap_offset"] = offs["normal"]
+    cb["metallic_roughness_maps_desc_heap_offset"] = offs["metallic_roughness"]
+    cb["emissive_maps_desc_heap_offset"] = offs["emissive"]
+    return cb

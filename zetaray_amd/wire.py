@@ -63,6 +63,9 @@ assert FRAME_CONSTANTS.itemsize == 544
 SUBGROUP_EMISSIVE = 1
 SUBGROUP_NON_EMISSIVE = 2
 SUBGROUP_ALL = 3
+INSTANCE_NON_OPAQUE = 0x80      # extra bit of instance_mask: geometry without the OPAQUE flag (primary-ray alpha test)
+TEX_RGBA8_SRGB, TEX_RGBA8, TEX_RG8 = 0, 1, 2
+TEXTURE_DESC = np.dtype([("offset", "<u8"), ("width", "<u2"), ("height", "<u2"), ("num_mips", "u1"), ("format", "u1"), ("pad", "<u2")])
 
 GB_PLANE_NAMES = ["base_color", "normal", "metallic_roughness", "motion_vector", "emissive_color", "ior", "coat",
                   "depth", "tri_diff_geo_a", "tri_diff_geo_b"]
@@ -83,6 +86,8 @@ class SceneDesc(C.Structure):
         ("materials", C.c_void_p), ("num_materials", C.c_uint32),
         ("emissives", C.c_void_p), ("num_emissives", C.c_uint32),
         ("rho_lut", C.c_void_p), ("rho_dim", C.c_uint32 * 3),
+        ("textures", C.c_void_p), ("num_textures", C.c_uint32),
+        ("texels", C.c_void_p), ("texel_bytes", C.c_uint64),
     ]
 
 
