@@ -39,9 +39,10 @@ static void Latch(const HxScene* s, const zr_frame_constants* cb)
 
 struct HxQueue
 {
-    std::vector<U4> s0, hitC, hitM; std::vector<F4> f[8], rays[6]; std::vector<uint32_t> lightID, visS;
+    std::vector<U4> s0, hitC, hitM; std::vector<F4> f[8], rays[6], t[8]; std::vector<uint32_t> lightID, visS;
     void Resize(size_t n)
     {
+        for (auto& v : t) v.resize(n);
         s0.resize(n); hitC.resize(n); hitM.resize(n); lightID.resize(n); visS.resize(n);
         for (auto& v : f) v.resize(n);
         for (auto& v : rays) v.resize(n);
@@ -54,6 +55,7 @@ struct HxQueue
         q.rayC_o = rays[0].data(); q.rayC_d = rays[1].data(); q.rayM_o = rays[2].data(); q.rayM_d = rays[3].data();
         q.rayS_o = rays[4].data(); q.rayS_d = rays[5].data();
         q.sLightID = lightID.data(); q.hitC = hitC.data(); q.hitM = hitM.data(); q.visS = visS.data();
+        for (int k = 0; k < 8; k++) q.t[k] = t[k].data();
         return q;
     }
 };
@@ -181,6 +183,7 @@ void zhx_pathtrace(const HxScene* s, const zr_frame_constants* cb, const zr_gbuf
     uint64_t nClosest = 0, nShadow = 0;
     zr::StackEntry stackMem[zr::kTravStack]; zr::TravStack stack; stack.lds = nullptr; stack.stride = 0; stack.mem = stackMem;
 
+    const bool tex = s->view.tex.count != 0;
     uint32_t count = 0;
     PathQueue q0 = q[0].View();
     // same pixel order as the kernel: 16x16 tiles, 8x8 quadrants
@@ -191,8 +194,8 @@ void zhx_pathtrace(const HxScene* s, const zr_frame_constants* cb, const zr_gbuf
         uint32_t x = gb.x0 + tx * 16 + (wave & 1) * 8 + (lane & 7), y = gb.y0 + ty * 16 + (wave >> 1) * 8 + (lane >> 3);
         if (x >= gb.x0 + W || y >= gb.y0 + H) continue;
         PathOut po;
-        PtInitPixel(s->view, *cb, gb, prm, x, y, finalRGBA, firstBOP.data(), po);
-        if (po.alive) WritePath(q0, count++, po);
+        PtInitPixel(s->view, *cb, gb, prm, x, y, finalRGBA, firstBOP.data(), po, tex);
+        if (po.alive) WritePath(q0, count++, po, tex);
     }
     const uint32_t maxB = prm.maxNonTrBounces > prm.maxGlossyTrBounces ? prm.maxNonTrBounces : prm.maxGlossyTrBounces;
     for (uint32_t r = 0; r < maxB + 1; r++)
@@ -210,11 +213,11 @@ void zhx_pathtrace(const HxScene* s, const zr_frame_constants* cb, const zr_gbuf
         for (uint32_t i = 0; i < count; i++)
         {
             PathOut po;
-            PtShadePath(s->view, *cb, prm, in, i, finalRGBA, firstBOP.data(), groupMax.data(), po);
-            if (po.alive) WritePath(out, outCount++, po);
+            PtShadePath(s->view, *cb, prm, in, i, finalRGBA, firstBOP.data(), groupMax.data(), po, tex);
+            if (po.alive) WritePath(out, outCount++, po, tex);
         }
         count = outCount;
-        for (uint32_t i = 0; i < count; i++) PtRussianRoulette(s->view, prm, out, i, groupMax.data());
+        for (uint32_t i = 0; i < count; i++) PtRussianRoulette(s->view, prm, out, i, groupMax.data(), tex);
     }
     if (counters) { counters->n_closest = nClosest; counters->n_shadow = nShadow; }
 }

@@ -167,3 +167,27 @@ def test_emissive_power_textured(pair, textured):
     plain = scene_io.make_synthetic_scene(num_tris=1024, num_emissive=64, seed=11)
     pp = zro.OracleScene(plain, force_bvh=True).estimate_power()
     assert (po <= pp * 1.0001).all() and (po < pp).any() and (po > 0).all()      # the map only darkens (texels <= 1)
+
+
+def _params(**kw):
+    p = wire.default_params()
+    for k, v in kw.items():
+        setattr(p, k, v)
+    return p
+
+
+def test_pathtracer_textured_bit_exact(pair, textured):
+    """K9 with ray differentials driving the base-colour / metallic-roughness LODs at every bounce, emissive-textured lights."""
+    orc, hx = pair
+    sc, offs = textured
+    cb = _cb(offs, w=32, h=24, num_emissives=len(sc.emissives))
+    planes_a, planes = orc.gbuffer(cb)
+    prm = _params(max_non_tr_bounces=4, max_glossy_tr_bounces=5)
+    fo, _ = orc.pathtrace(cb, planes, prm)
+    fh, _ = hx.pathtrace(cb, planes, prm)
+    assert np.array_equal(fo.view(np.uint32), fh.view(np.uint32))
+    assert np.isfinite(fo).all() and fo[..., :3].max() > 0
+    # and the textures matter: the same G-buffer shaded without the heap differs
+    plain = scene_io.make_synthetic_scene(num_tris=1024, num_emissive=64, seed=11)
+    fp, _ = zro.OracleScene(plain, force_bvh=True).pathtrace(cb, planes, prm)
+    assert not np.array_equal(fp, fo)

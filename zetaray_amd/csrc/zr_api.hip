@@ -124,14 +124,15 @@ __global__ void __launch_bounds__(kBlock) k_gbuffer(SceneView sc, zr_frame_const
     GBufferPixel(sc, g, gb, x, y, stack, nullptr);
 }
 
+template<bool TEX>
 __global__ void __launch_bounds__(kBlock) k_pt_init(SceneView sc, zr_frame_constants g, GBuf gb, PtParams prm, float* finalRGBA,
     F4* firstBOP, PathQueue out, uint32_t* outCount, uint32_t* outRays, uint32_t cap, uint32_t tilesX)
 {
     uint32_t x, y; PixelOfThread(tilesX, gb.x0, gb.y0, &x, &y);
     PathOut po; po.alive = false;
-    if (x < gb.x0 + gb.w && y < gb.y0 + gb.h) PtInitPixel(sc, g, gb, prm, x, y, finalRGBA, firstBOP, po);
+    if (x < gb.x0 + gb.w && y < gb.y0 + gb.h) PtInitPixel(sc, g, gb, prm, x, y, finalRGBA, firstBOP, po, TEX);
     const uint32_t slot = AllocSlotWave(outCount, po.alive);
-    if (po.alive) WritePath(out, slot, po);
+    if (po.alive) WritePath(out, slot, po, TEX);
     AppendRays(out.rayList, cap, outRays, slot, po.alive && po.rayC_d.w >= 0, po.alive && po.rayM_d.w >= 0, po.alive && po.rayS_d.w >= 0);
 }
 
@@ -244,6 +245,7 @@ __global__ void __launch_bounds__(kBlock) k_trace(SceneView sc, PathQueue q, con
     if (lane == 0) { if (a) atomicAdd(&counters[0], (unsigned long long)a); if (b) atomicAdd(&counters[1], (unsigned long long)b); }
 }
 
+template<bool TEX>
 __global__ void __launch_bounds__(kBlock) ZR_WAVES_SHADE k_pt_shade(SceneView sc, zr_frame_constants g, PtParams prm, PathQueue in, const uint32_t* inCount,
     PathQueue out, uint32_t* outCount, uint32_t* outRays, uint32_t cap, float* finalRGBA, const F4* firstBOP, uint32_t* groupMax)
 {
@@ -252,21 +254,22 @@ __global__ void __launch_bounds__(kBlock) ZR_WAVES_SHADE k_pt_shade(SceneView sc
     {
         const uint32_t i = base + threadIdx.x;
         PathOut po; po.alive = false;
-        if (i < n) PtShadePath(sc, g, prm, in, i, finalRGBA, firstBOP, groupMax, po);
+        if (i < n) PtShadePath(sc, g, prm, in, i, finalRGBA, firstBOP, groupMax, po, TEX);
         const uint32_t slot = AllocSlotWave(outCount, po.alive);
-        if (po.alive) WritePath(out, slot, po);
+        if (po.alive) WritePath(out, slot, po, TEX);
         AppendRays(out.rayList, cap, outRays, slot, po.alive && po.rayC_d.w >= 0, po.alive && po.rayM_d.w >= 0, po.alive && po.rayS_d.w >= 0);
     }
 }
 
 // Russian-roulette stage: finishes the vertices PtShadePath parked (only launched for rounds in which RR can trigger)
+template<bool TEX>
 __global__ void __launch_bounds__(kBlock) k_pt_rr(SceneView sc, PtParams prm, PathQueue q, const uint32_t* count, uint32_t* rays, uint32_t cap, const uint32_t* groupMax)
 {
     const uint32_t n = *count;
     for (uint32_t base = blockIdx.x * kBlock; base < n; base += gridDim.x * kBlock)
     {
         const uint32_t i = base + threadIdx.x;
-        const bool cont = i < n && PtRussianRoulette(sc, prm, q, i, groupMax);
+        const bool cont = i < n && PtRussianRoulette(sc, prm, q, i, groupMax, TEX);
         AppendRays(q.rayList, cap, rays, i, cont, false, false);
     }
 }
@@ -618,6 +621,13 @@ struct zr_gbuffer
 struct QueueStorage
 {
     DevBuf<U4> s0; DevBuf<F4> f[8]; DevBuf<F4> rays[6]; DevBuf<uint32_t> lightID; DevBuf<U4> hitC, hitM; DevBuf<uint32_t> visS, rayList;
+    DevBuf<F4> t[8];      // ray-differential state, allocated by the first render of a textured scene
+    int AllocTex(size_t cap)
+    {
+        int r;
+        for (auto& b : t) if (b.n != cap && (r = b.Alloc(cap))) return r;
+        return ZR_OK;
+    }
     int Alloc(size_t cap)
     {
         int r;
@@ -637,6 +647,7 @@ struct QueueStorage
         q.s0 = s0.p; q.s1 = f[0].p; q.s2 = f[1].p; q.s3 = f[2].p; q.s4 = f[3].p; q.s5 = f[4].p; q.s6 = f[5].p; q.s7 = f[6].p; q.s8 = f[7].p;
         q.rayC_o = rays[0].p; q.rayC_d = rays[1].p; q.rayM_o = rays[2].p; q.rayM_d = rays[3].p; q.rayS_o = rays[4].p; q.rayS_d = rays[5].p;
         q.sLightID = lightID.p; q.hitC = hitC.p; q.hitM = hitM.p; q.visS = visS.p; q.rayList = rayList.p;
+        for (int k = 0; k < 8; k++) q.t[k] = t[k].p;
         return q;
     }
 };
@@ -1480,8 +1491,10 @@ static int RenderIndirect(zr_pass* p, hipStream_t s, const zr_frame_constants* c
     if (rrPossible) HIP_TRY(hipMemsetAsync(p->groupMax.p, 0, (size_t)rounds * numGroups * sizeof(uint32_t), s));
     const uint32_t tilesX = (p->w + 15) / 16, tilesY = (p->h + 15) / 16;
     const GBuf gbv = gb->View();
+    const bool tex = sc->view.tex.count != 0;      // kernels carry ray differentials only when there is a texture heap
+    if (tex) { int r; if ((r = p->q[0].AllocTex((size_t)p->w * p->h)) || (r = p->q[1].AllocTex((size_t)p->w * p->h))) return r; }
     TimerBegin(p, s, "pt_init");
-    hipLaunchKernelGGL(k_pt_init, dim3(tilesX * tilesY), dim3(kBlock), 0, s, sc->view, *cb, gbv, prm, p->finalRGBA.p, p->firstBOP.p,
+    hipLaunchKernelGGL(tex ? k_pt_init<true> : k_pt_init<false>, dim3(tilesX * tilesY), dim3(kBlock), 0, s, sc->view, *cb, gbv, prm, p->finalRGBA.p, p->firstBOP.p,
         p->q[0].View(), Ctr(0, 0), Ctr(2, 0), (uint32_t)((size_t)p->w * p->h), tilesX);
     TimerEnd(p, s);
     const size_t cap = (size_t)p->w * p->h;
@@ -1497,13 +1510,13 @@ static int RenderIndirect(zr_pass* p, hipStream_t s, const zr_frame_constants* c
         else hipLaunchKernelGGL(k_trace, dim3(gridTrace), dim3(kBlock), 0, s, sc->view, qin, Ctr(2, r), (uint32_t)cap, Ctr(1, r), p->counters.p);
         TimerEnd(p, s);
         TimerBegin(p, s, "pt_shade");
-        hipLaunchKernelGGL(k_pt_shade, dim3(gridShade), dim3(kBlock), 0, s, sc->view, *cb, prm, qin, Ctr(0, r), qout, Ctr(0, r + 1), Ctr(2, r + 1), (uint32_t)cap,
+        hipLaunchKernelGGL(tex ? k_pt_shade<true> : k_pt_shade<false>, dim3(gridShade), dim3(kBlock), 0, s, sc->view, *cb, prm, qin, Ctr(0, r), qout, Ctr(0, r + 1), Ctr(2, r + 1), (uint32_t)cap,
             p->finalRGBA.p, p->firstBOP.p, p->groupMax.p + (size_t)r * numGroups);
         TimerEnd(p, s);
         if (rrPossible && r >= 2)
         {
             TimerBegin(p, s, "pt_rr");
-            hipLaunchKernelGGL(k_pt_rr, dim3(gridShade), dim3(kBlock), 0, s, sc->view, prm, qout, Ctr(0, r + 1), Ctr(2, r + 1), (uint32_t)cap, p->groupMax.p + (size_t)r * numGroups);
+            hipLaunchKernelGGL(tex ? k_pt_rr<true> : k_pt_rr<false>, dim3(gridShade), dim3(kBlock), 0, s, sc->view, prm, qout, Ctr(0, r + 1), Ctr(2, r + 1), (uint32_t)cap, p->groupMax.p + (size_t)r * numGroups);
             TimerEnd(p, s);
         }
     }

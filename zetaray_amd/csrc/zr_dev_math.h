@@ -111,6 +111,16 @@ ZR_HD ONB BuildONB(V3 n)             // Math.hlsli:289-302 (Duff et al.)
 }
 
 struct TriDiffs { V3 dpdu, dpdv, dndu, dndv; };
+// TriDifferentials::Unpack, Math.hlsli:385-402 (G-buffer planes TRI_DIFF_GEO_A / _B: 12 halfs)
+ZR_HD TriDiffs UnpackTriDiffs(const uint32_t* a, const uint32_t* b)
+{
+    TriDiffs r;
+    r.dpdu = v3(zr_f16_to_f32((uint16_t)(a[0] & 0xffff)), zr_f16_to_f32((uint16_t)(a[0] >> 16)), zr_f16_to_f32((uint16_t)(a[1] & 0xffff)));
+    r.dpdv = v3(zr_f16_to_f32((uint16_t)(a[1] >> 16)), zr_f16_to_f32((uint16_t)(a[2] & 0xffff)), zr_f16_to_f32((uint16_t)(a[2] >> 16)));
+    r.dndu = v3(zr_f16_to_f32((uint16_t)(a[3] & 0xffff)), zr_f16_to_f32((uint16_t)(a[3] >> 16)), zr_f16_to_f32((uint16_t)(b[0] & 0xffff)));
+    r.dndv = v3(zr_f16_to_f32((uint16_t)(b[0] >> 16)), zr_f16_to_f32((uint16_t)(b[1] & 0xffff)), zr_f16_to_f32((uint16_t)(b[1] >> 16)));
+    return r;
+}
 ZR_HD TriDiffs ComputeTriDiffs(V3 p0, V3 p1, V3 p2, V3 n0, V3 n1, V3 n2, V2 uv0, V2 uv1, V2 uv2)  // Math.hlsli:339-383
 {
     TriDiffs ret;
@@ -315,6 +325,101 @@ ZR_HD V3 PowerHeuristic(float p_1, float p_2, V3 f, float n_1, float n_2)  // RT
     if (denom == 0) return v3(0.0f);
     return (n_1 * n_1 * p_1 * f) / denom;
 }
+
+// RT::RayDifferentials, RT.hlsli:309-479 (Igehy).  Only texture LODs consume them: kernels carry them when the scene
+// has a texture heap and skip them otherwise.
+struct RayDiffs
+{
+    V3 origin_x, dir_x, origin_y, dir_y;
+    V4 uv_grads;
+
+    // Init (:323-353).  uv_grads is left uninitialised by the reference and pinned to 0 by the ABI.
+    static ZR_HDM RayDiffs Init(int px, int py, V2 renderDim, float tanHalfFOV, float aspectRatio, V2 jitter, V3 vbx, V3 vby, V3 vbz,
+        bool thinLens, float focusDepth, V2 lensSample, V3 origin)
+    {
+        RayDiffs ret;
+        V3 dir_cs_x = GeneratePinholeCameraRay_CS(px + 1, py, renderDim, aspectRatio, tanHalfFOV, jitter);
+        V3 dir_cs_y = GeneratePinholeCameraRay_CS(px, py - 1, renderDim, aspectRatio, tanHalfFOV, jitter);
+        if (thinLens)
+        {
+            dir_cs_x = focusDepth * dir_cs_x - v3(lensSample.x, lensSample.y, 0);
+            dir_cs_y = focusDepth * dir_cs_y - v3(lensSample.x, lensSample.y, 0);
+        }
+        ret.dir_x = normalize(mad(dir_cs_x.x, vbx, mad(dir_cs_x.y, vby, dir_cs_x.z * vbz)));
+        ret.dir_y = normalize(mad(dir_cs_y.x, vbx, mad(dir_cs_y.y, vby, dir_cs_y.z * vbz)));
+        ret.origin_x = origin; ret.origin_y = origin;
+        ret.uv_grads = v4(0, 0, 0, 0);
+        return ret;
+    }
+    static ZR_HDM RayDiffs Zero()
+    { RayDiffs r; r.origin_x = v3(0.0f); r.dir_x = v3(0.0f); r.origin_y = v3(0.0f); r.dir_y = v3(0.0f); r.uv_grads = v4(0, 0, 0, 0); return r; }
+
+    // dpdx_dpdy (:355-378)
+    ZR_HDM void dpdx_dpdy(V3 hitPoint, V3 normal, V3& dpdx, V3& dpdy) const
+    {
+        const float d = dot(normal, hitPoint);
+        const float numerator_x = d - dot(normal, origin_x);
+        const float denom_x = dot(normal, dir_x);
+        const float t_x = numerator_x / denom_x;
+        const V3 hitPoint_x = mad(t_x, dir_x, origin_x);
+        const float numerator_y = d - dot(normal, origin_y);
+        const float denom_y = dot(normal, dir_y);
+        const float t_y = numerator_y / denom_y;
+        const V3 hitPoint_y = mad(t_y, dir_y, origin_y);
+        dpdx = denom_x != 0 ? hitPoint_x - hitPoint : v3(ZR_FLT16_MAX);
+        dpdy = denom_y != 0 ? hitPoint_y - hitPoint : v3(ZR_FLT16_MAX);
+    }
+
+    // UpdateRays (:380-440)
+    ZR_HDM void UpdateRays(V3 p, V3 normal, V3 wi, V3 wo, V3 dndu, V3 dndv, V3 dpdx, V3 dpdy, bool transmitted, float eta)
+    {
+        origin_x = p + dpdx;
+        origin_y = p + dpdy;
+        const V3 dwodx = -dir_x - wo;
+        const V3 dwody = -dir_y - wo;
+        const V3 dndx = dndu * uv_grads.x + dndv * uv_grads.y;
+        const V3 dndy = dndu * uv_grads.z + dndv * uv_grads.w;
+        const float dndotWodx = dot(dndx, wo) + dot(normal, dwodx);
+        const float dndotWody = dot(dndy, wo) + dot(normal, dwody);
+        const float ndotwo = dot(normal, wo);
+        if (!transmitted)
+        {
+            dir_x = wi + mad(2.0f, mad(dndotWodx, normal, ndotwo * dndx), -dwodx);
+            dir_y = wi + mad(2.0f, mad(dndotWody, normal, ndotwo * dndy), -dwody);
+        }
+        else
+        {
+            const float eta_relative = 1.0f / eta;
+            const float ndotwi = zr_abs(dot(normal, wi));
+            const float q = zr_fma(eta_relative, ndotwo, -ndotwi);
+            const float common = zr_fma(eta_relative, -ndotwo / ndotwi, 1.0f);
+            const float dqdx = eta_relative * dndotWodx * common;
+            const float dqdy = eta_relative * dndotWody * common;
+            dir_x = mad(-eta_relative, dwodx, wi) + mad(q, dndx, dqdx * normal);
+            dir_y = mad(-eta_relative, dwody, wi) + mad(q, dndy, dqdy * normal);
+        }
+    }
+
+    // ComputeUVDifferentials (:442-478)
+    ZR_HDM void ComputeUVDifferentials(V3 dpdx, V3 dpdy, V3 dpdu, V3 dpdv)
+    {
+        const float dpduDotdpdu = dot(dpdu, dpdu);
+        const float dpdvDotdpdv = dot(dpdv, dpdv);
+        const float dpduDotdpdv = dot(dpdu, dpdv);
+        const float det = dpduDotdpdu * dpdvDotdpdv - dpduDotdpdv * dpduDotdpdv;
+        if (zr_abs(det) < 1e-7f) { uv_grads = v4(0, 0, 0, 0); return; }
+        const V2 b_x = v2(dot(dpdu, dpdx), dot(dpdv, dpdx));
+        const V2 grads_x = v2((dpdvDotdpdv * b_x.x + -dpduDotdpdv * b_x.y) / det, (-dpduDotdpdv * b_x.x + dpduDotdpdu * b_x.y) / det);
+        const V2 b_y = v2(dot(dpdu, dpdy), dot(dpdv, dpdy));
+        const V2 grads_y = v2((dpdvDotdpdv * b_y.x + -dpduDotdpdv * b_y.y) / det, (-dpduDotdpdv * b_y.x + dpduDotdpdu * b_y.y) / det);
+        const bool invalid_x = (uv_grads.x == ZR_FLT16_MAX) || (dpdx.x == ZR_FLT16_MAX);
+        const bool invalid_y = (uv_grads.z == ZR_FLT16_MAX) || (dpdy.x == ZR_FLT16_MAX);
+        uv_grads.x = invalid_x ? ZR_FLT16_MAX : grads_x.x;
+        uv_grads.y = invalid_x ? ZR_FLT16_MAX : grads_x.y;
+        uv_grads.z = invalid_y ? ZR_FLT16_MAX : grads_y.x;
+        uv_grads.w = invalid_y ? ZR_FLT16_MAX : grads_y.y;
+    }
+};
 
 ZR_HD V3 Row3(const float* m, int r) { return v3(m[4 * r], m[4 * r + 1], m[4 * r + 2]); }
 ZR_HD V3 Mul3x4(const float* m, V3 p)

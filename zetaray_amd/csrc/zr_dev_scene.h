@@ -368,20 +368,56 @@ ZR_HD void FillHit(const SceneView& sc, uint32_t meshIdx, uint32_t primIdx, floa
 }
 
 // GetMaterialData, RayQuery.hlsli:452-524 (texture maps not bound: factors only)
-ZR_HD bool GetMaterialData(const SceneView& sc, V3 wo, float eta_curr, HitInfo& hit, Surface& surface, float& eta)
+// The two TexSampler policies of RayQuery.hlsli:408-450.  Anisotropic = SampleGrad(samp, uv, ddx, ddy) with the default
+// TEXTURE_FILTER::ANISOTROPIC_4X sampler (IndirectLighting.h:243); isotropic = SampleLevel(g_samLinearWrap, uv,
+// log2(max(dd.x * w, dd.y * h))) with dd = uv_grads.xy (the reconnection shift, Shift.hlsli:519).
+ZR_HD void SampleMaterialTex(const SceneView& sc, uint32_t tex, bool isotropic, V2 uv, V4 g, float out[4])
+{
+    if (!isotropic) { zr_tex_sample_grad(&sc.tex, tex, uv.x, uv.y, g.x, g.y, g.z, g.w, out); return; }
+    const zr_texture_desc& d = sc.tex.descs[tex];
+    const float mip = zr_log2(zr_max(g.x * (float)d.width, g.y * (float)d.height));
+    zr_tex_sample_level(&sc.tex, tex, uv.x, uv.y, mip, out);
+}
+
+// `tex` is a compile-time constant at every device call site (kernels are instantiated per TEXTURED permutation): without
+// a texture heap nothing below reads uv_grads, and kernels then do not carry ray differentials at all.
+ZR_HD bool GetMaterialData(const SceneView& sc, V3 wo, float eta_curr, HitInfo& hit, Surface& surface, float& eta,
+    V4 uv_grads = v4(0, 0, 0, 0), bool tex = false, bool isotropic = false)
 {
     const zr_material mat = sc.materials[hit.matIdx];
     const bool hitBackface = dot(wo, hit.normal) < 0;
     eta = kDefaultEtaMat;
     const bool ds = MatDoubleSided(mat);
     if (!ds && hitBackface) return false;
-    if (ds && hitBackface) hit.normal = hit.normal * -1.0f;
+    if (ds && hitBackface)
+    {
+        hit.normal = hit.normal * -1.0f;
+        if (tex) { hit.dndu = hit.dndu * -1.0f; hit.dndv = hit.dndv * -1.0f; }
+    }
     V3 baseColor = UnpackRGB8(mat.base_color_factor);
     float metallic = MatMetallic(mat) ? 1.0f : 0.0f;
     float roughness = MatRoughness(mat);
     bool tr = MatTransmissive(mat);
     eta = MatIOR(mat);
     float trDepth = tr ? MatTrDepth(mat) : 0;
+    if (tex)
+    {
+        const uint32_t baseColorTex = mat.base_color_tex_subsurf_coat_weight & 0xffffu;
+        const uint32_t mrTex = mat.mr_tex_spec_roughness_coat_roughness & 0xffffu;
+        if ((trDepth == 0) && (baseColorTex != ZR_INVALID_TEX))
+        {
+            float c[4];
+            SampleMaterialTex(sc, sc.baseColorMapsOffset + baseColorTex, isotropic, hit.uv, uv_grads, c);
+            baseColor = baseColor * v3(c[0], c[1], c[2]);
+        }
+        if (mrTex != ZR_INVALID_TEX)
+        {
+            float c[4];
+            SampleMaterialTex(sc, sc.mrMapsOffset + mrTex, isotropic, hit.uv, uv_grads, c);
+            metallic *= c[0];
+            roughness *= c[1];
+        }
+    }
     float eta_next = eta_curr == kEtaAir ? eta : kEtaAir;
     float subsurface = MatThinWalled(mat) ? zr_round_f16(MatSubsurface(mat)) : 0;
     surface = InitSurface(hit.normal, wo, metallic >= kMinMetalnessMetal, roughness, baseColor, eta_curr, eta_next, tr, trDepth,

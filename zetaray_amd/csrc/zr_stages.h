@@ -304,6 +304,7 @@ static constexpr uint32_t PF_NLS = 1u << 7;         // numLightSamples of the pe
 static constexpr uint32_t PF_MAXB_SHIFT = 8;        // bits 8..11 maxNumBounces
 static constexpr uint32_t PF_S_RAY = 1u << 12;      // a light-segment ray is in flight for the pending vertex
 static constexpr uint32_t PF_PARKED = 1u << 13;     // waiting for the Russian-roulette stage (group max not known yet)
+static constexpr uint32_t PF_RD_PENDING = 1u << 14; // textured scenes: RayDifferentials::UpdateRays of the last vertex still to run
 
 struct PathQueue
 {
@@ -316,6 +317,12 @@ struct PathQueue
     F4* s6;   // misF.xyz, unused
     F4* s7;   // misWi.xyz, unused
     F4* s8;   // ldLight.xyz (unshadowed MIS-weighted light-sample contribution), unused
+    // Textured scenes only (null otherwise): ray differentials (RT.hlsli:309-479) and what their deferred UpdateRays needs.
+    // The reference calls UpdateRays after the continuation ray hit, with the NEW hit's triangle differentials
+    // (PathTracing.hlsli:90-95), so it runs at the start of the next shade step (PF_RD_PENDING).
+    //   t[0..3] = (origin_x, uv_grads.x), (dir_x, .y), (origin_y, .z), (dir_y, .w)
+    //   t[4] = (normal of the vertex the C ray leaves, its surface.eta), t[5] = its surface.wo, t[6] = dpdx, t[7] = dpdy
+    F4* t[8];
     // rays of this slot: (origin.xyz, tmin), (dir.xyz, tmax); tmax < 0 => no ray
     F4* rayC_o; F4* rayC_d; F4* rayM_o; F4* rayM_d; F4* rayS_o; F4* rayS_d;
     uint32_t* sLightID;   // emissive triangle ID the S ray is aimed at
@@ -332,10 +339,24 @@ struct PathOut   // what one shade/init step wants to write into the next queue
     U4 s0; F4 s1, s2, s3, s4, s5, s6, s7, s8;
     F4 rayC_o, rayC_d, rayM_o, rayM_d, rayS_o, rayS_d;
     uint32_t sLightID;
+    F4 t[8];             // textured scenes only
 };
 
-ZR_HD void WritePath(const PathQueue& q, uint32_t slot, const PathOut& p)
+ZR_HD void PackRayDiffs(const RayDiffs& rd, F4* t)
 {
+    t[0] = f4(rd.origin_x, rd.uv_grads.x); t[1] = f4(rd.dir_x, rd.uv_grads.y);
+    t[2] = f4(rd.origin_y, rd.uv_grads.z); t[3] = f4(rd.dir_y, rd.uv_grads.w);
+}
+ZR_HD RayDiffs UnpackRayDiffs(F4 t0, F4 t1, F4 t2, F4 t3)
+{
+    RayDiffs rd; rd.origin_x = xyz(t0); rd.dir_x = xyz(t1); rd.origin_y = xyz(t2); rd.dir_y = xyz(t3);
+    rd.uv_grads = v4(t0.w, t1.w, t2.w, t3.w);
+    return rd;
+}
+
+ZR_HD void WritePath(const PathQueue& q, uint32_t slot, const PathOut& p, bool tex = false)
+{
+    if (tex) { for (int k = 0; k < 8; k++) q.t[k][slot] = p.t[k]; }
     q.s0[slot] = p.s0; q.s1[slot] = p.s1; q.s2[slot] = p.s2; q.s3[slot] = p.s3; q.s4[slot] = p.s4;
     q.s5[slot] = p.s5; q.s6[slot] = p.s6; q.s7[slot] = p.s7; q.s8[slot] = p.s8;
     q.rayC_o[slot] = p.rayC_o; q.rayC_d[slot] = p.rayC_d;
@@ -421,7 +442,7 @@ ZR_HD void WriteFinal(float* finalRGBA, uint32_t pid, V3 li, V3 firstBOP, bool a
 // K9 prologue for one pixel: PathTracer.hlsl main (:115-198) + EstimateIndirectLighting (:56-79) up to the first
 // FindClosest.  Writes the pixel directly when no path starts.
 ZR_HD void PtInitPixel(const SceneView& sc, const zr_frame_constants& g, const GBuf& gb, const PtParams& prm, uint32_t x, uint32_t y,
-    float* finalRGBA, F4* firstBOP, PathOut& out)
+    float* finalRGBA, F4* firstBOP, PathOut& out, bool tex = false)
 {
     out.alive = false;
     const uint32_t pid = (y - gb.y0) * gb.w + (x - gb.x0);
@@ -505,6 +526,20 @@ ZR_HD void PtInitPixel(const SceneView& sc, const zr_frame_constants& g, const G
     out.rayM_o = f4(v3(0.0f), 0.0f); out.rayM_d = f4(v3(0.0f), -1.0f);
     out.rayS_o = out.rayM_o; out.rayS_d = out.rayM_d;
     out.sLightID = 0xffffffffu;
+    if (tex)
+    {
+        // PathTracer.hlsl:170-190: camera ray differentials -> uv gradients at the primary hit -> differentials of the first
+        // bounce (the reference does this only if the first bounce hits; a miss retires the path, so nothing reads them)
+        const TriDiffs td = UnpackTriDiffs(&gb.triA[4 * pid], &gb.triB[2 * pid]);
+        RayDiffs rdf = RayDiffs::Init((int)x, (int)y, renderDim, g.tan_half_fov, g.aspect_ratio, jitter, vbx, vby, vbz, g.dof != 0,
+            g.focus_depth, lens, origin);
+        V3 dpdx, dpdy;
+        rdf.dpdx_dpdy(pos, normal, dpdx, dpdy);
+        rdf.ComputeUVDifferentials(dpdx, dpdy, td.dpdu, td.dpdv);
+        rdf.UpdateRays(pos, normal, bs.wi, surface.wo, td.dndu, td.dndv, dpdx, dpdy, dot(bs.wi, normal) < 0, surface.eta);
+        PackRayDiffs(rdf, out.t);
+        out.t[4] = f4(v3(0.0f), 0.0f); out.t[5] = out.t[4]; out.t[6] = out.t[4]; out.t[7] = out.t[4];
+    }
 }
 
 ZR_HD void zr_atomic_max_u32(uint32_t* p, uint32_t v)
@@ -532,6 +567,7 @@ ZR_HD void PtContinue(const SceneView& sc, V3 n, const Surface& surface, V3 hitP
         bool transmitted = dot(n, bs2.wi) < 0;
         eta_curr = transmitted ? (eta_curr == kEtaAir ? eta_next : kEtaAir) : eta_curr;
         inMedium = transmitted ? !inMedium : inMedium;
+        nflags |= PF_RD_PENDING;        // only textured kernels look at it
     }
     else nflags |= PF_DRAIN;
     out.alive = true;
@@ -549,7 +585,7 @@ ZR_HD void PtContinue(const SceneView& sc, V3 n, const Surface& surface, V3 hitP
 //   (2) shade the continuation hit: GetMaterialData, NEE setup, Beer-Lambert, bounce bookkeeping, SampleBSDF
 //       (ReSTIR_RT::PathTrace loop body, PathTracing.hlsli:25-95)
 ZR_HD void PtShadePath(const SceneView& sc, const zr_frame_constants& g, const PtParams& prm, const PathQueue& in, uint32_t i,
-    float* finalRGBA, const F4* firstBOP, uint32_t* groupMax, PathOut& out)
+    float* finalRGBA, const F4* firstBOP, uint32_t* groupMax, PathOut& out, bool tex = false)
 {
     out.alive = false;
     const U4 s0 = in.s0[i];
@@ -612,10 +648,29 @@ ZR_HD void PtShadePath(const SceneView& sc, const zr_frame_constants& g, const P
     const TriMeta tm = sc.triMeta[hc.w];
     HitInfo hit;
     hit.t = t;
-    FillHit<false>(sc, tm.mesh, tm.prim, zr_asfloat(hc.y), zr_asfloat(hc.z), false, hit);
+    V4 uvGrads = v4(0, 0, 0, 0);
+    V3 dpdx = v3(0.0f), dpdy = v3(0.0f);
+    if (tex)
+    {
+        FillHit<true>(sc, tm.mesh, tm.prim, zr_asfloat(hc.y), zr_asfloat(hc.z), false, hit);
+        RayDiffs rdf = UnpackRayDiffs(in.t[0][i], in.t[1][i], in.t[2][i], in.t[3][i]);
+        if (flags & PF_RD_PENDING)
+        {
+            // tail of the previous loop iteration (PathTracing.hlsli:90-95), with this hit's triangle differentials
+            const F4 t4 = in.t[4][i];
+            const V3 nPrev = xyz(t4);
+            rdf.UpdateRays(pos0, nPrev, wiC, xyz(in.t[5][i]), hit.dndu, hit.dndv, xyz(in.t[6][i]), xyz(in.t[7][i]), dot(nPrev, wiC) < 0, t4.w);
+        }
+        rdf.dpdx_dpdy(hitPos, hit.normal, dpdx, dpdy);
+        rdf.ComputeUVDifferentials(dpdx, dpdy, hit.dpdu, hit.dpdv);
+        uvGrads = rdf.uv_grads;
+        PackRayDiffs(rdf, out.t);
+    }
+    else FillHit<false>(sc, tm.mesh, tm.prim, zr_asfloat(hc.y), zr_asfloat(hc.z), false, hit);
     Surface surface; float eta_mat;
-    if (!GetMaterialData(sc, -wiC, eta_curr, hit, surface, eta_mat)) { WriteFinal(finalRGBA, pid, li, fb, prm.accumulate); return; }
+    if (!GetMaterialData(sc, -wiC, eta_curr, hit, surface, eta_mat, uvGrads, tex)) { WriteFinal(finalRGBA, pid, li, fb, prm.accumulate); return; }
     const float eta_next = eta_curr == kEtaAir ? eta_mat : kEtaAir;    // as computed inside GetMaterialData
+    if (tex) { out.t[4] = f4(hit.normal, surface.eta); out.t[5] = f4(surface.wo, 0.0f); out.t[6] = f4(dpdx, 0.0f); out.t[7] = f4(dpdy, 0.0f); }
 
     Rng rngT = Rng::Seed(s0.y);
     Rng rngG = Rng::Seed(s0.z);
@@ -782,7 +837,7 @@ ZR_HD void PtShadePath(const SceneView& sc, const zr_frame_constants& g, const P
 // `groupMax` holds, per 8x8 group, the max luminance(throughput) over the lanes that reached the RR block this round
 // (the reference's WaveActiveMax; lanes = pixels of the 8x8 thread group).
 // Returns true when the path continues, i.e. slot i now holds a C ray.
-ZR_HD bool PtRussianRoulette(const SceneView& sc, const PtParams& prm, const PathQueue& q, uint32_t i, const uint32_t* groupMax)
+ZR_HD bool PtRussianRoulette(const SceneView& sc, const PtParams& prm, const PathQueue& q, uint32_t i, const uint32_t* groupMax, bool tex = false)
 {
     const U4 s0 = q.s0[i];
     if (!(s0.w & PF_PARKED)) return false;
@@ -814,7 +869,8 @@ ZR_HD bool PtRussianRoulette(const SceneView& sc, const PtParams& prm, const Pat
     HitInfo hit; hit.t = rec.w;
     FillHit<false>(sc, tm.mesh, tm.prim, rec.x, rec.y, false, hit);
     Surface surface; float eta_mat;
-    GetMaterialData(sc, -wiC, eta_curr, hit, surface, eta_mat);        // succeeded once already in PtShadePath
+    // (succeeded once already in PtShadePath; the uv gradients of this vertex are still in the slot)
+    GetMaterialData(sc, -wiC, eta_curr, hit, surface, eta_mat, tex ? v4(q.t[0][i].w, q.t[1][i].w, q.t[2][i].w, q.t[3][i].w) : v4(0, 0, 0, 0), tex);
     const float eta_next = eta_curr == kEtaAir ? eta_mat : kEtaAir;
     PathOut po; po.s2.w = s2.w;
     PtContinue(sc, hit.normal, surface, hitPos, eta_curr, eta_next, inMedium, thr, bounce, maxB, nflags, pid, rngT, rngG, xyz(s1), setIdxBits, po);
