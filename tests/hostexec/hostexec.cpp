@@ -520,6 +520,7 @@ void zhx_rgi_render(const HxScene* s, HxRgi* R, const zr_frame_constants* cb, co
     prm.writeReservoirs = (prm.doTemporal || !R->temporalValid) ? 1u : 0u;
     prm.M_max = (float)params->m_max_temporal;
     prm.useLVG = (params->use_lvg && params->presampling) ? 1u : 0u;
+    prm.textured = s->view.tex.count ? 1u : 0u;
     zr::StackEntry stackMem[zr::kTravStack]; zr::TravStack stack; stack.lds = nullptr; stack.stride = 0; stack.mem = stackMem;
     std::vector<Lane> L(64);
     float wsum[64];

@@ -191,3 +191,29 @@ def test_pathtracer_textured_bit_exact(pair, textured):
     plain = scene_io.make_synthetic_scene(num_tris=1024, num_emissive=64, seed=11)
     fp, _ = zro.OracleScene(plain, force_bvh=True).pathtrace(cb, planes, prm)
     assert not np.array_equal(fp, fo)
+
+
+def _frames(sc, offs, w, h, n):
+    prev = None
+    for f in range(1, n + 1):
+        cb = _cb(offs, w=w, h=h, frame_num=f, num_emissives=len(sc.emissives))
+        cb["camera_pos"][0] += 0.04 * max(0, f - 2)
+        if prev is not None:
+            cb["prev_view"], cb["prev_view_inv"], cb["prev_camera_jitter"] = prev["curr_view"], prev["curr_view_inv"], prev["curr_camera_jitter"]
+        prev = cb.copy()
+        yield f, cb
+
+
+def test_restir_gi_textured_bit_exact(pair, textured):
+    orc, hx = pair
+    sc, offs = textured
+    w, h = 40, 32
+    prm = _params(max_non_tr_bounces=4, max_glossy_tr_bounces=5)
+    o, x = zro.OracleRGI(orc, w, h), zhx.HostExecRGI(hx, w, h)
+    for f, cb in _frames(sc, offs, w, h, 3):
+        a, b = o.render(cb, prm), x.render(cb, prm)
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), f"frame {f}"
+        for nm in ("A", "B", "C"):
+            assert np.array_equal(o.plane(nm).view(np.uint8), x.plane(nm).view(np.uint8)), f"frame {f}: GI plane {nm}"
+        assert o.counters == x.counters
+    assert np.isfinite(a).all() and a[..., :3].max() > 0

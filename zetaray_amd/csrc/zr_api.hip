@@ -542,8 +542,10 @@ __global__ void __launch_bounds__(kBlock) ZR_WAVES_RDI_S k_rdi_spatial(rdi::DiFr
 // ------------------------------------------------------------------------------------------------ ReSTIR GI kernel
 // K10: one 8x8 pixel group per wave, bounce loop in lockstep around the Russian-roulette wave max, then temporal resampling
 // and the boiling-suppression wave sum (zr_rgi.h)
+template<bool TEX>
 __global__ void __launch_bounds__(kBlock) ZR_WAVES_RGI k_rgi(rgi::GiFrame F, zr_frame_constants g, uint32_t tilesX, unsigned long long* counters)
 {
+    F.prm.textured = TEX;
     uint32_t x, y; PixelOfThread(tilesX, F.ox0, F.oy0, &x, &y);
     ZR_TRAV_STACK(stack);
     uint32_t cnt[2] = {0u, 0u};
@@ -1353,10 +1355,11 @@ static int RenderReSTIR_GI(zr_pass* p, hipStream_t s, const zr_frame_constants* 
     prm.writeReservoirs = (prm.doTemporal || !p->temporalValid) ? 1u : 0u;
     prm.M_max = (float)ip.m_max_temporal;
     prm.useLVG = (ip.use_lvg && ip.presampling) ? 1u : 0u;
+    prm.textured = sc->view.tex.count ? 1u : 0u;
     if (prm.useLVG && !sc->view.lvg) return Fail(ZR_ERR_NOT_INITIALIZED, "light voxel grid missing: render the PRELIGHTING pass with use_lvg first");
     const uint32_t tilesX = (p->w + 15) / 16, tilesY = (p->h + 15) / 16;
     TimerBegin(p, s, "rgi");
-    hipLaunchKernelGGL(k_rgi, dim3(tilesX * tilesY), dim3(kBlock), 0, s, F, *cb, tilesX, p->counters.p + 2 * 10);
+    hipLaunchKernelGGL(sc->view.tex.count ? k_rgi<true> : k_rgi<false>, dim3(tilesX * tilesY), dim3(kBlock), 0, s, F, *cb, tilesX, p->counters.p + 2 * 10);
     TimerEnd(p, s);
     HIP_TRY(hipGetLastError());
     p->temporalValid = true;

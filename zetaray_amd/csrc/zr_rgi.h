@@ -39,7 +39,9 @@ struct Reservoir
 ZR_HD Reservoir InitReservoir()
 { Reservoir r; r.pos = v3(ZR_FLT_MAX); r.normal = v3(0.0f); r.Lo = v3(0.0f); r.M = 0; r.w_sum = 0; r.W = 0; r.ID = 0xffffffffu; r.target_z = v3(0.0f); return r; }
 
-struct GiParams { uint32_t flags, maxNonTrBounces, maxGlossyTrBounces, numSampleSets, accumulate, doTemporal, writeReservoirs, useLVG; float M_max; };
+// textured: the scene has a texture heap -> the lanes carry ray differentials (RT.hlsli:309-479) for the texture LODs.  The kernel
+// is instantiated per value and overwrites the field with its template constant, so untextured frames compile all of it away.
+struct GiParams { uint32_t flags, maxNonTrBounces, maxGlossyTrBounces, numSampleSets, accumulate, doTemporal, writeReservoirs, useLVG; float M_max; uint32_t textured; };
 struct GiFrame
 {
     SceneView sc; GBuf gb, gbPrev; GiPlanes cur, prev; float* finalRGBA; GiParams prm;
@@ -254,6 +256,7 @@ struct Lane
     V3 li, throughput, ppos, pnormal; float eta_curr, eta_next; int bounce; bool inMedium;
     BsdfSample bs; HitInfo hit; Surface psurface;
     Reservoir r;
+    RayDiffs rd; V3 dpdx, dpdy;      // textured scenes only
 };
 
 ZR_HD Globals MakeGlobals(const GiFrame& F, const zr_frame_constants& g, const Lane& P, TravStack stack, uint32_t* cnt)
@@ -264,7 +267,7 @@ ZR_HD Globals MakeGlobals(const GiFrame& F, const zr_frame_constants& g, const L
 }
 
 // Hit::FindClosest<ID, true> over this lane's continuation ray
-ZR_HD bool TraceContinuation(const Globals& gl, V3 pos, V3 normal, V3 wi, bool transmissive, bool wantID, HitInfo& hit)
+ZR_HD bool TraceContinuation(const Globals& gl, V3 pos, V3 normal, V3 wi, bool transmissive, bool wantID, HitInfo& hit, bool wantDiffs = false)
 {
     F4 ro, rd;
     if (!MakeClosestRay(pos, normal, wi, transmissive, false, &ro, &rd)) return false;
@@ -273,7 +276,8 @@ ZR_HD bool TraceContinuation(const Globals& gl, V3 pos, V3 normal, V3 wi, bool t
     if (h.tri == kInvalidTri) return false;
     const TriMeta tm = gl.sc->triMeta[h.tri];
     hit.t = h.t;
-    FillHit<false>(*gl.sc, tm.mesh, tm.prim, h.u, h.v, wantID, hit, true);
+    if (wantDiffs) FillHit<true>(*gl.sc, tm.mesh, tm.prim, h.u, h.v, wantID, hit, true);
+    else FillHit<false>(*gl.sc, tm.mesh, tm.prim, h.u, h.v, wantID, hit, true);
     return true;
 }
 
@@ -320,8 +324,19 @@ ZR_HD void InitLane(const GiFrame& F, const zr_frame_constants& g, uint32_t x, u
     P.r = InitReservoir();
     P.firstSample = SampleBSDF(F.sc.rho, P.normal, P.surface, P.rngThread);
     if (P.firstSample.pdf == 0) return;
+    if (prm.textured)
+    {
+        // Resampling.hlsli:60-75: camera ray differentials -> uv gradients at the primary hit -> differentials of the first bounce
+        const TriDiffs td = UnpackTriDiffs(&F.gb.triA[4 * P.px], &F.gb.triB[2 * P.px]);
+        P.rd = RayDiffs::Init((int)x, (int)y, cam.renderDim, cam.tanHalfFOV, cam.aspect, cam.jitter, cam.vbx, cam.vby, cam.vbz, cam.dof,
+            cam.focusDepth, lens, origin);
+        V3 dpdx, dpdy;
+        P.rd.dpdx_dpdy(P.pos, P.normal, dpdx, dpdy);
+        P.rd.ComputeUVDifferentials(dpdx, dpdy, td.dpdu, td.dpdv);
+        P.rd.UpdateRays(P.pos, P.normal, P.firstSample.wi, P.surface.wo, td.dndu, td.dndv, dpdx, dpdy, dot(P.firstSample.wi, P.normal) < 0, P.surface.eta);
+    }
     Globals gl = MakeGlobals(F, g, P, stack, cnt);
-    if (!TraceContinuation(gl, P.pos, P.normal, P.firstSample.wi, P.surface.Transmissive(), true, P.hit)) return;
+    if (!TraceContinuation(gl, P.pos, P.normal, P.firstSample.wi, P.surface.Transmissive(), true, P.hit, prm.textured)) return;
     P.hasSample = true;
     P.hitPos = P.pos + P.hit.t * P.firstSample.wi;
     P.hitNormal = P.hit.normal; P.hitID = P.hit.ID;
@@ -340,7 +355,14 @@ ZR_HD void PhaseA(const GiFrame& F, const zr_frame_constants& g, TravStack stack
     Globals gl = MakeGlobals(F, g, P, stack, cnt);
     V3 hitPos = mad(P.hit.t, P.bs.wi, P.ppos);
     float eta_mat;
-    if (!GetMaterialData(F.sc, -P.bs.wi, P.eta_curr, P.hit, P.psurface, eta_mat)) { P.active = false; return; }
+    V4 uvGrads = v4(0, 0, 0, 0);
+    if (F.prm.textured)
+    {
+        P.rd.dpdx_dpdy(hitPos, P.hit.normal, P.dpdx, P.dpdy);
+        P.rd.ComputeUVDifferentials(P.dpdx, P.dpdy, P.hit.dpdu, P.hit.dpdv);
+        uvGrads = P.rd.uv_grads;
+    }
+    if (!GetMaterialData(F.sc, -P.bs.wi, P.eta_curr, P.hit, P.psurface, eta_mat, uvGrads, F.prm.textured)) { P.active = false; return; }
     P.eta_next = eta_mat;
     // RGI_Util::NEE (NEE_EMISSIVE == 1, USE_MIS == 1, MIS_ALL_BOUNCES == 0)
     V3 ld;
@@ -374,11 +396,13 @@ ZR_HD void PhaseB(const GiFrame& F, const zr_frame_constants& g, TravStack stack
     if (P.bounce < P.maxNumBounces) P.bs = SampleBSDF(F.sc.rho, P.pnormal, P.psurface, P.rngThread);
     if (Luminance(P.bs.bsdfOverPdf) == 0) { P.active = false; return; }
     Globals gl = MakeGlobals(F, g, P, stack, cnt);
-    if (!TraceContinuation(gl, P.ppos, P.pnormal, P.bs.wi, P.psurface.Transmissive(), false, P.hit)) { P.active = false; return; }
+    if (!TraceContinuation(gl, P.ppos, P.pnormal, P.bs.wi, P.psurface.Transmissive(), false, P.hit, F.prm.textured)) { P.active = false; return; }
     P.throughput = P.throughput * P.bs.bsdfOverPdf;
     bool transmitted = dot(P.pnormal, P.bs.wi) < 0;
     P.eta_curr = transmitted ? (P.eta_curr == kEtaAir ? P.eta_next : kEtaAir) : P.eta_curr;
     P.inMedium = transmitted ? !P.inMedium : P.inMedium;
+    // with the new hit's triangle differentials, as the reference does (PathTracing.hlsli:93-94)
+    if (F.prm.textured) P.rd.UpdateRays(P.ppos, P.pnormal, P.bs.wi, P.psurface.wo, P.hit.dndu, P.hit.dndv, P.dpdx, P.dpdy, transmitted, P.psurface.eta);
 }
 
 // Resampling.hlsli:283-303
