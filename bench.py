@@ -96,6 +96,8 @@ def main():
                     help="skip the post-frame halo exchange (exact for a static camera, which this bench uses)")
     ap.add_argument("--direct", action="store_true", help="also run the ReSTIR DI (emissive) pass every frame (N = 1)")
     ap.add_argument("--sky-direct", action="store_true", help="also run the sun + sky ReSTIR DI pass (K7/K8) every frame (N = 1)")
+    ap.add_argument("--textured", action="store_true",
+                    help="bind the procedural test texture set to the synthetic scene (TEXTURED kernel permutations: ray differentials, material maps)")
     ap.add_argument("--di-only", action="store_true", help="skip the indirect pass: BASELINE config 1 (ReSTIR DI only)")
     ap.add_argument("--integrator", choices=["restir_pt", "restir_gi", "pt"], default="restir_pt",
                     help="restir_pt = K11-K16 (BASELINE metric); pt = K9 unidirectional path tracer")
@@ -118,10 +120,15 @@ def main():
 
     W, H = args.width, args.height
     cam = {}
+    tex_offsets = None
+    assert not args.textured or args.scene == "synthetic", "--textured needs --scene synthetic"
     if args.scene == "synthetic":
         sc = scene_io.make_synthetic_scene(num_tris=args.synthetic_tris, num_emissive=args.synthetic_emissives, layout=args.synthetic_layout)
         cam = dict(cam_pos=(0, 0, -3.5))
         scene_name = f"synthetic Sponza-class {args.synthetic_layout} ({sc.num_tris} triangles, {len(sc.emissives)} emissive, alias table + presampled sets 128x512)"
+        if args.textured:
+            tex_offsets = scene_io.add_test_textures(sc)
+            scene_name += ", textured (base colour / normal / metallic-roughness / emissive maps, alpha-tested instance)"
     else:
         sc = scene_io.load_npz(args.scene)
         scene_name = f"Cornell Box ({os.path.basename(args.scene)[:-4]}: {sc.num_tris} triangles, {len(sc.emissives)} emissive)"
@@ -158,6 +165,8 @@ def main():
 
     def frame(i):
         cb = scene_io.make_frame_constants(W, H, frame_num=i, num_emissives=len(sc.emissives), **cam)
+        if tex_offsets is not None:
+            scene_io.set_texture_heap_offsets(cb, tex_offsets)
         if tiled is not None:
             tiled.render_frame(cb, exchange_final=not args.no_final_halo)
         else:
@@ -307,6 +316,8 @@ def main():
                            "kernel_ms_per_frame": {k: round(v[0] / nfr, 4) for k, v in agg.items()}}
         if not args.no_cpu_baseline:
             cbf = scene_io.make_frame_constants(W, H, frame_num=1, num_emissives=len(sc.emissives), **cam)
+            if tex_offsets is not None:
+                scene_io.set_texture_heap_offsets(cbf, tex_offsets)
             out["cpu_baseline"] = cpu_baseline(sc, cbf)
     if rank == 0:
         print(json.dumps(out))

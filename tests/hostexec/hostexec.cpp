@@ -298,6 +298,7 @@ void zhx_rpt_render_stage(const HxScene* s, HxRpt* R, const zr_frame_constants* 
     prm.boiling = (params->flags & ZR_IND_BOILING_SUPPRESSION) ? 1u : 0u;
     prm.M_max_temporal = params->m_max_temporal & 0xf; prm.M_max_spatial = params->m_max_spatial & 0xf; prm.alpha_min = params->alpha_min;
     prm.emissive = g.num_emissive_triangles ? 1u : 0u;
+    prm.textured = s->view.tex.count ? 1u : 0u;
     if (stages & 1)
     {
         R->doTemporal = (params->flags & ZR_IND_TEMPORAL_RESAMPLE) && R->temporalValid && prev;

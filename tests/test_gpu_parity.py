@@ -649,3 +649,94 @@ def test_firefly_filter_on_gpu(api, cornell_emissive):
     gbs = 36.0 * W4 * H4 / (best * 1e-3) / 1e9
     print(f"firefly filter 3840x2160: {best * 1e3:.1f} us, {gbs:.0f} GB/s algorithmic ({gbs / 8000:.1%} of the 8 TB/s roofline)")
     assert gbs > 500
+
+
+# ------------------------------------------------------------------------------------------------ material textures
+def _textured_scene(num_emissive):
+    sc = scene_io.make_synthetic_scene(num_tris=3000, num_emissive=num_emissive, seed=11, open_top=(num_emissive == 0))
+    offs = scene_io.add_test_textures(sc)
+    return sc, offs
+
+
+def _textured_frames(sc, offs, w, h, n, cam0, sun=None):
+    prev = None
+    for f in range(1, n + 1):
+        cb = scene_io.make_frame_constants(w, h, frame_num=f, num_emissives=len(sc.emissives),
+                                           cam_pos=(cam0[0] + 0.05 * max(0, f - 2), cam0[1], cam0[2]))
+        scene_io.set_texture_heap_offsets(cb, offs)
+        if sun is not None:
+            sd = np.array(sun, np.float32)
+            cb["sun_dir"] = sd / np.float32(np.linalg.norm(sd))
+        if prev is not None:
+            cb["prev_view"], cb["prev_view_inv"], cb["prev_camera_jitter"] = prev["curr_view"], prev["curr_view_inv"], prev["curr_camera_jitter"]
+        prev = cb.copy()
+        yield f, cb
+
+
+@pytest.mark.parametrize("dof", [False, True])
+def test_textured_gbuffer_and_emissive_power_on_gpu(api, dof):
+    """K1 with base-colour / normal / metallic-roughness / emissive maps, UV differentials and alpha-tested primary rays, and K2 +
+    alias table over emissive-textured triangles, through the C-ABI: bit-exact vs the oracle."""
+    from oracle import zro
+    sc, offs = _textured_scene(1500)
+    w, h = 200, 120
+    _, cb = next(_textured_frames(sc, offs, w, h, 1, (0.3, 0.2, -3.6)))
+    if dof:
+        cb["dof"], cb["focus_depth"], cb["lens_radius"], cb["camera_ray_uv_grads_scale"] = 1, 3.0, 0.05, 0.75
+    orc = zro.OracleScene(sc, force_bvh=True, cb=cb)
+    r = api.Renderer(sc, w, h)
+    r.p_prelight.render(cb, r.scene)
+    assert np.array_equal(r.scene.get_alias_table().view(np.uint8), orc.alias.view(np.uint8))
+    r.p_gbuffer.render(cb, r.scene, r.gbuffer)
+    got, _ = r.gbuffer.download()
+    want, _ = orc.gbuffer(cb)
+    for name, a, b in zip(wire.GB_PLANE_NAMES, got, want):
+        assert np.array_equal(a.view(np.uint8), b.view(np.uint8)), f"G-buffer plane {name} differs"
+    # table offsets that point outside the heap are refused, not read
+    bad = cb.copy()
+    bad["emissive_maps_desc_heap_offset"] = 1000
+    with pytest.raises(api.ZetaRayError):
+        r.p_gbuffer.render(bad, r.scene, r.gbuffer)
+
+
+@pytest.mark.parametrize("integrator", ["pt", "restir_gi", "restir_pt"])
+@pytest.mark.parametrize("lights", ["emissive", "sun_sky"])
+def test_textured_integrators_on_gpu(api, integrator, lights):
+    """The TEXTURED kernel permutations (ray differentials through every bounce, replay and reconnection shift; texture LODs from
+    them) x both NEE_EMISSIVE permutations, through the C-ABI over 4 frames with a moving camera: radiance, persistent reservoir
+    planes and ray counters bit-exact vs the oracle."""
+    from oracle import zro
+    sc, offs = _textured_scene(1500 if lights == "emissive" else 0)
+    w, h = 96, 64
+    cam0, sun = ((0.3, 0.2, -3.6), None) if lights == "emissive" else ((0.0, 2.0, -3.5), (0.3, -0.8, 0.4))
+    prm = wire.default_params()
+    prm.max_non_tr_bounces, prm.max_glossy_tr_bounces = 5, 7
+    kind = {"pt": api.INTEGRATOR_PATH_TRACING, "restir_gi": api.INTEGRATOR_RESTIR_GI, "restir_pt": api.INTEGRATOR_RESTIR_PT}[integrator]
+    r = api.Renderer(sc, w, h, params=prm, integrator=kind)
+    orc = None
+    o = None
+    for f, cb in _textured_frames(sc, offs, w, h, 4, cam0, sun):
+        if orc is None:
+            orc = zro.OracleScene(sc, force_bvh=True, cb=cb)
+            o = {"pt": None, "restir_gi": zro.OracleRGI, "restir_pt": zro.OracleRPT}[integrator]
+            o = o(orc, w, h) if o else None
+        r.p_indirect.read_counters(reset=True)
+        r.render_frame(cb)
+        got = r.final()
+        if lights == "sun_sky":
+            orc.sky_lut(cb, 256, 128)
+        if o is None:
+            keep, planes = orc.gbuffer(cb)
+            want, cnt = orc.pathtrace(cb, planes, prm)
+        else:
+            want, cnt = o.render(cb, prm), o.counters
+        mism = int((got.view(np.uint32) != want.view(np.uint32)).any(axis=2).sum())
+        assert mism == 0, f"frame {f}: {mism} pixels differ"
+        assert tuple(r.p_indirect.read_counters()) == tuple(cnt)
+        if integrator == "restir_pt":
+            for nm in "ABCDEFG":
+                pa, pb = r.p_indirect.download_plane(nm), o.plane(nm)
+                if nm == "A":
+                    pa, pb = pa & 0xffffff, pb & 0xffffff
+                assert np.array_equal(pa.view(np.uint8), pb.view(np.uint8)), f"frame {f}: plane {nm}"
+    assert got[..., :3].max() > 0

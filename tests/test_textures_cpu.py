@@ -217,3 +217,67 @@ def test_restir_gi_textured_bit_exact(pair, textured):
             assert np.array_equal(o.plane(nm).view(np.uint8), x.plane(nm).view(np.uint8)), f"frame {f}: GI plane {nm}"
         assert o.counters == x.counters
     assert np.isfinite(a).all() and a[..., :3].max() > 0
+
+
+RPT_PLANES = ["A", "B", "C", "D", "E", "F", "G"]
+
+
+def _rpt_same(o, x, f):
+    for nm in RPT_PLANES:
+        pa, pb = o.plane(nm), x.plane(nm)
+        if nm == "A":      # RGBA8: the w channel is never written
+            pa, pb = pa & 0xffffff, pb & 0xffffff
+        assert np.array_equal(pa.view(np.uint8), pb.view(np.uint8)), f"frame {f}: reservoir plane {nm}"
+    assert o.counters == x.counters
+
+
+@pytest.mark.parametrize("mode", ["full", "none"])
+def test_restir_pt_textured_bit_exact(pair, textured, mode):
+    """K11-K16 with ray differentials through path tracing, replay (r-buffer uv-gradient channel) and the reconnection
+    shift's isotropic LOD; moving camera, 6 / 8 bounces so that k > 2 replays and Russian roulette occur."""
+    orc, hx = pair
+    sc, offs = textured
+    w, h = 40, 32
+    prm = _params(max_non_tr_bounces=6, max_glossy_tr_bounces=8)
+    if mode == "none":
+        prm.flags &= ~(wire.IND_SPATIAL_RESAMPLE | wire.IND_TEMPORAL_RESAMPLE)
+    o, x = zro.OracleRPT(orc, w, h), zhx.HostExecRPT(hx, w, h)
+    ks = set()
+    for f, cb in _frames(sc, offs, w, h, 4):
+        a, b = o.render(cb, prm), x.render(cb, prm)
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), f"frame {f}"
+        _rpt_same(o, x, f)
+        ks |= set((o.plane("A")[..., 0] & 0xf).ravel().tolist())
+    assert np.isfinite(a).all() and a[..., :3].max() > 0
+    assert any(k not in (0, 15) for k in ks), ks         # reconnections beyond the first indirect vertex occurred
+
+
+def test_sun_sky_textured_bit_exact():
+    """NEE_EMISSIVE == 0 x TEXTURED permutations of K9, K10 and K11-K16 (the reference's default cornell.gltf is exactly this:
+    sun + sky over a textured floor)."""
+    sc = scene_io.make_synthetic_scene(num_tris=1200, num_emissive=0, seed=5, open_top=True)
+    offs = scene_io.add_test_textures(sc)
+    orc, hx = zro.OracleScene(sc, force_bvh=True), zhx.HostExecScene(sc)
+    w, h = 40, 32
+    prm = _params()
+    sd = np.array((0.3, -0.8, 0.4), np.float32)
+    po, px_ = zro.OracleRPT(orc, w, h), zhx.HostExecRPT(hx, w, h)
+    go, gx = zro.OracleRGI(orc, w, h), zhx.HostExecRGI(hx, w, h)
+    prev = None
+    for f in range(1, 4):
+        cb = scene_io.make_frame_constants(w, h, frame_num=f, num_emissives=0, cam_pos=(0.05 * max(0, f - 2), 2.0, -3.5))
+        scene_io.set_texture_heap_offsets(cb, offs)
+        cb["sun_dir"] = sd / np.float32(np.linalg.norm(sd))
+        if prev is not None:
+            cb["prev_view"], cb["prev_view_inv"], cb["prev_camera_jitter"] = prev["curr_view"], prev["curr_view_inv"], prev["curr_camera_jitter"]
+        prev = cb.copy()
+        orc.sky_lut(cb, 256, 128); hx.sky_lut(cb, 256, 128)
+        a, b = po.render(cb, prm), px_.render(cb, prm)
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), f"RPT frame {f}"
+        _rpt_same(po, px_, f)
+        a, b = go.render(cb, prm), gx.render(cb, prm)
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), f"GI frame {f}"
+    keep, planes = orc.gbuffer(cb)          # (the ctypes plane table points into `keep`)
+    fo, _ = orc.pathtrace(cb, planes, prm)
+    fh, _ = hx.pathtrace(cb, planes, prm)
+    assert np.array_equal(fo.view(np.uint32), fh.view(np.uint32)) and fo[..., :3].max() > 0

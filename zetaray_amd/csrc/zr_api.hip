@@ -382,10 +382,11 @@ __device__ __forceinline__ void FlushRayCounters(unsigned long long* counters, c
 
 // K11: block = 16x16 pixels, wave w = rows 4w..4w+3 (a 16x4 block: the RR "wave" of the ABI, zr_rpt.h header)
 // EMISSIVE: the NEE_EMISSIVE shader permutation (emissive triangles vs sun + sky); a template constant so the other variant folds away
-template<bool EMISSIVE>
+// TEX: the scene has a texture heap (ray differentials carried, material maps sampled); likewise a template constant
+template<bool EMISSIVE, bool TEX>
 __global__ void __launch_bounds__(kBlock) ZR_WAVES_PATHTRACE k_rpt_pathtrace(rpt::RptFrame F, zr_frame_constants g, uint32_t tilesX, unsigned long long* counters)
 {
-    F.prm.emissive = EMISSIVE ? 1u : 0u;
+    F.prm.emissive = EMISSIVE ? 1u : 0u; F.prm.textured = TEX ? 1u : 0u;
     const uint32_t tile = blockIdx.x, tx = tile % tilesX, ty = tile / tilesX;
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
     const uint32_t x = F.ox0 + tx * 16u + (lane & 15u), y = F.oy0 + ty * 16u + wave * 4u + (lane >> 4);
@@ -434,11 +435,11 @@ __global__ void __launch_bounds__(kBlock) k_rpt_light(rpt::RptFrame F, zr_frame_
 }
 
 // K13 replays over a work list (device-side count, fixed grid, grid-stride): only pixels with k > 2 pay for the heavy kernel
-template<int PASS, bool EMISSIVE>
+template<int PASS, bool EMISSIVE, bool TEX>
 __global__ void __launch_bounds__(kBlock) k_rpt_replay(rpt::RptFrame F, zr_frame_constants g, const uint32_t* list, const uint32_t* count,
     unsigned long long* counters)
 {
-    F.prm.emissive = EMISSIVE ? 1u : 0u;
+    F.prm.emissive = EMISSIVE ? 1u : 0u; F.prm.textured = TEX ? 1u : 0u;
     ZR_TRAV_STACK(stack);
     uint32_t cnt[2] = {0u, 0u};
     const uint32_t n = *count;
@@ -454,10 +455,10 @@ __global__ void __launch_bounds__(kBlock) k_rpt_replay(rpt::RptFrame F, zr_frame
 }
 
 // K14: CtT + TtC fused per pixel (zr_rpt.h ReconnectTemporalPixel)
-template<bool EMISSIVE>
+template<bool EMISSIVE, bool TEX>
 __global__ void __launch_bounds__(kBlock) ZR_WAVES_TEMPORAL k_rpt_temporal(rpt::RptFrame F, zr_frame_constants g, uint32_t tilesX, unsigned long long* counters)
 {
-    F.prm.emissive = EMISSIVE ? 1u : 0u;
+    F.prm.emissive = EMISSIVE ? 1u : 0u; F.prm.textured = TEX ? 1u : 0u;
     uint32_t x, y; PixelOfThread(tilesX, F.ox0, F.oy0, &x, &y);
     ZR_TRAV_STACK(stack);
     uint32_t cnt[2] = {0u, 0u};
@@ -473,10 +474,10 @@ __device__ __forceinline__ float WaveSumButterfly(float v)
 }
 
 // K16 CtS + StC: wave = 8x8 pixel group; every lane of the wave walks all four phases (absent lanes contribute 0)
-template<bool EMISSIVE>
+template<bool EMISSIVE, bool TEX>
 __global__ void __launch_bounds__(kBlock) ZR_WAVES_STC k_rpt_stc(rpt::RptFrame F, zr_frame_constants g, uint32_t tilesX, unsigned long long* counters)
 {
-    F.prm.emissive = EMISSIVE ? 1u : 0u;
+    F.prm.emissive = EMISSIVE ? 1u : 0u; F.prm.textured = TEX ? 1u : 0u;
     uint32_t x, y; PixelOfThread(tilesX, F.ox0, F.oy0, &x, &y);
     ZR_TRAV_STACK(stack);
     uint32_t cnt[2] = {0u, 0u};
@@ -1402,6 +1403,7 @@ static int RenderReSTIR_PT(zr_pass* p, hipStream_t s, const zr_frame_constants* 
     prm.boiling = (ip.flags & ZR_IND_BOILING_SUPPRESSION) ? 1u : 0u;
     prm.M_max_temporal = ip.m_max_temporal & 0xf; prm.M_max_spatial = ip.m_max_spatial & 0xf; prm.alpha_min = ip.alpha_min;
     prm.emissive = cb->num_emissive_triangles ? 1u : 0u;
+    prm.textured = sc->view.tex.count ? 1u : 0u;
     if (stages & ZR_STAGE_TEMPORAL)
     {
         p->doTemporal = (ip.flags & ZR_IND_TEMPORAL_RESAMPLE) && p->temporalValid && havePrevGBuffer;
@@ -1422,8 +1424,14 @@ static int RenderReSTIR_PT(zr_pass* p, hipStream_t s, const zr_frame_constants* 
 #define RPT_TIMED(name, launch) do { TimerBegin(p, s, name); launch; TimerEnd(p, s); } while (0)
     // the NEE_EMISSIVE permutation of a kernel (the reference compiles separate shaders, IndirectLighting.h:251-300)
     const bool emissiveVariant = prm.emissive != 0;
-#define RPT_LAUNCH_E(kern, ...) do { if (emissiveVariant) hipLaunchKernelGGL(kern<true>, __VA_ARGS__); else hipLaunchKernelGGL(kern<false>, __VA_ARGS__); } while (0)
-#define RPT_LAUNCH_PE(kern, PASS, ...) do { if (emissiveVariant) hipLaunchKernelGGL((kern<PASS, true>), __VA_ARGS__); else hipLaunchKernelGGL((kern<PASS, false>), __VA_ARGS__); } while (0)
+    // ... and the TEXTURED permutation (this ABI's: untextured scenes carry no ray differentials)
+    const bool texVariant = prm.textured != 0;
+#define RPT_LAUNCH_E(kern, ...) do { \
+        if (emissiveVariant) { if (texVariant) hipLaunchKernelGGL((kern<true, true>), __VA_ARGS__); else hipLaunchKernelGGL((kern<true, false>), __VA_ARGS__); } \
+        else { if (texVariant) hipLaunchKernelGGL((kern<false, true>), __VA_ARGS__); else hipLaunchKernelGGL((kern<false, false>), __VA_ARGS__); } } while (0)
+#define RPT_LAUNCH_PE(kern, PASS, ...) do { \
+        if (emissiveVariant) { if (texVariant) hipLaunchKernelGGL((kern<PASS, true, true>), __VA_ARGS__); else hipLaunchKernelGGL((kern<PASS, true, false>), __VA_ARGS__); } \
+        else { if (texVariant) hipLaunchKernelGGL((kern<PASS, false, true>), __VA_ARGS__); else hipLaunchKernelGGL((kern<PASS, false, false>), __VA_ARGS__); } } while (0)
     if (stages & ZR_STAGE_TEMPORAL)
     {
         HIP_TRY(hipMemsetAsync(listCnt, 0, 4 * sizeof(uint32_t), s));

@@ -11,8 +11,9 @@
 //   * K16 StC boiling suppression: "wave" = 8x8 pixel group, sum = 64-lane xor-butterfly (strides 1..32), absent lanes 0
 //
 // Round-1 structure: one thread per pixel per pass with inline BVH traversal (same cut as the reference's passes).
-// Ray differentials only feed texture LODs (no textures bound in this round), so they are not carried; the r-buffer's
-// uv-gradient channel is written as 0.
+// Ray differentials (RT.hlsli:309-479) only feed texture LODs: the kernels are instantiated per TEXTURED permutation
+// (RptParams.textured / Globals.textured hold the template constant) and carry them only when the scene has a texture heap;
+// otherwise the r-buffer's uv-gradient channel is written as 0 and never read.
 #pragma once
 #include "zr_stages.h"
 
@@ -398,7 +399,7 @@ ZR_HD Reservoir Load_NonReconnection(const ResPlanes& p, size_t i)
 // cnt: this lane's ray counters {closest-hit queries, shadow / visibility queries} (never null)
 // emissive == false selects the NEE_EMISSIVE == 0 shader variants (sun + sky lighting): the kernels are instantiated per variant and set
 // it from a template constant, so the other variant's code folds away; frame = cbFrameConstants (sun, atmosphere)
-struct Globals { const SceneView* sc; uint32_t numEmissives; int maxNumBounces; float alpha_min; TravStack stack; uint32_t* cnt; bool presampled; uint32_t sampleSetIdx;
+struct Globals { bool textured = false; const SceneView* sc; uint32_t numEmissives; int maxNumBounces; float alpha_min; TravStack stack; uint32_t* cnt; bool presampled; uint32_t sampleSetIdx;
     const zr_frame_constants* frame; bool emissive; };
 
 // ---- ray queries (inline traversal)
@@ -419,7 +420,7 @@ ZR_HD HitEm FindClosestEm(const Globals& g, V3 pos, V3 normal, V3 wi, bool trans
     return r;
 }
 // Hit::FindClosest<ID = true>, RayQuery.hlsli:15-144
-ZR_HD bool FindClosestID(const Globals& g, bool currFrame, V3 pos, V3 normal, V3 wi, bool transmissive, HitInfo& hit)
+ZR_HD bool FindClosestID(const Globals& g, bool currFrame, V3 pos, V3 normal, V3 wi, bool transmissive, HitInfo& hit, bool wantDiffs = false)
 {
     F4 ro, rd;
     if (!MakeClosestRay(pos, normal, wi, transmissive, false, &ro, &rd)) return false;
@@ -428,7 +429,8 @@ ZR_HD bool FindClosestID(const Globals& g, bool currFrame, V3 pos, V3 normal, V3
     if (h.tri == kInvalidTri) return false;
     const TriMeta tm = g.sc->triMeta[h.tri];
     hit.t = h.t;
-    FillHit<false>(*g.sc, tm.mesh, tm.prim, h.u, h.v, true, hit, currFrame);
+    if (wantDiffs) FillHit<true>(*g.sc, tm.mesh, tm.prim, h.u, h.v, true, hit, currFrame);
+    else FillHit<false>(*g.sc, tm.mesh, tm.prim, h.u, h.v, true, hit, currFrame);
     return true;
 }
 // Visibility_Segment with APPROXIMATE_EMISSIVE_SHADOW_RAY == 1 (RayQuery.hlsli:337-406)
@@ -792,7 +794,7 @@ ZR_HD V3 WorldPosSS2(const Camera& c, float px, float py, float z_view, V2 lens,
     return origin + dir_w;
 }
 
-struct PixelSurface { V3 pos, normal; float eta_next; Surface surface; GFlags flags; float roughness, z; };
+struct PixelSurface { V3 pos, normal; float eta_next; Surface surface; GFlags flags; float roughness, z; V2 lens; V3 origin; };   // lens / origin: what RayDifferentials::Init needs
 
 // coatPixel: the reference reads the coat plane at DTid instead of the shifted pixel in two passes
 // (ReSTIR_PT_Reconnect_CtT.hlsl:80, _CtS.hlsl:99); restated as is.
@@ -831,6 +833,7 @@ ZR_HD PixelSurface LoadPixelSurfaceEx(const GBuf& gb, const Camera& cam, uint32_
     const V3 wo = normalize(origin - ps.pos);
     ps.surface = InitSurface(ps.normal, wo, ps.flags.metallic, ps.roughness, baseColor, kEtaAir, ps.eta_next, ps.flags.transmissive,
         (useTrDepth && ps.flags.trDepthGt0) ? 1.0f : 0.0f, subsurface, coat_weight, coat_color, coat_roughness, coat_ior);
+    ps.lens = lens; ps.origin = origin;
     return ps;
 }
 ZR_HD PixelSurface LoadPixelSurface(const GBuf& gb, const Camera& cam, uint32_t x, uint32_t y, uint32_t frameForLens, size_t coatPixel)
@@ -847,7 +850,22 @@ struct PTLane
     Reconnection rc; Reservoir r; V3 li, throughput, throughput_k; int bounce; PrevHit prevHit; float eta_curr, eta_next;
     bool inMedium; HitEm nextHit; uint32_t seed_replay, sampleSetIdx; int maxNumBounces;
     HitInfo hit; V3 tr; float prevPdf; uint32_t prevLobe; int pathVertex;
+    RayDiffs rd; V3 dpdx, dpdy;      // textured scenes only
 };
+
+ZR_HD RayDiffs InitRD(const Camera& c, int x, int y, V2 lens, V3 origin)
+{ return RayDiffs::Init(x, y, c.renderDim, c.tanHalfFOV, c.aspect, c.jitter, c.vbx, c.vby, c.vbz, c.dof, c.focusDepth, lens, origin); }
+ZR_HD TriDiffs LoadTriDiffs(const GBuf& gb, size_t px) { return UnpackTriDiffs(&gb.triA[4 * px], &gb.triB[2 * px]); }
+// the three calls every shift / path prologue makes at the primary hit (e.g. ReSTIR_PT_PathTrace.hlsl:380-392)
+ZR_HD RayDiffs PrimaryRayDiffs(const Camera& c, int x, int y, const PixelSurface& ps, const TriDiffs& td, V3 wi)
+{
+    RayDiffs rd = InitRD(c, x, y, ps.lens, ps.origin);
+    V3 dpdx, dpdy;
+    rd.dpdx_dpdy(ps.pos, ps.normal, dpdx, dpdy);
+    rd.ComputeUVDifferentials(dpdx, dpdy, td.dpdu, td.dpdv);
+    rd.UpdateRays(ps.pos, ps.normal, wi, ps.surface.wo, td.dndu, td.dndv, dpdx, dpdy, dot(wi, ps.normal) < 0, ps.surface.eta);
+    return rd;
+}
 
 struct RptParams
 {
@@ -855,6 +873,7 @@ struct RptParams
     float alpha_min;
     uint32_t doTemporal, doSpatial, writeReservoirs;
     uint32_t emissive;      // NEE_EMISSIVE: the scene has emissive triangles (else sun + sky)
+    uint32_t textured;      // the scene has a texture heap: carry ray differentials, sample base-colour / metallic-roughness maps
 };
 
 // main() prologue + RIS_InitialCandidates up to the first FindClosest (ReSTIR_PT_PathTrace.hlsl:360-530, 194-236)
@@ -880,6 +899,7 @@ ZR_HD void PtInitLane(const SceneView& sc, const zr_frame_constants& g, const GB
     P.r = InitReservoir(); P.li = v3(0.0f);
     BsdfSample bs = SampleBSDF(sc.rho, ps.normal, ps.surface, P.rngReplay);
     if (dot(bs.bsdfOverPdf, bs.bsdfOverPdf) == 0) return;
+    if (prm.textured) P.rd = PrimaryRayDiffs(cam, (int)x, (int)y, ps, LoadTriDiffs(gb, px), bs.wi);
     P.sampleSetIdx = prm.emissive ? P.rngGroup.UniformUintBounded_Faster(prm.numSampleSets) : 0u;      // ReSTIR_PT_PathTrace.hlsl:406-408
     P.rc = InitReconnection();
     P.bounce = 0; P.throughput = bs.bsdfOverPdf;
@@ -906,12 +926,20 @@ ZR_HD void PtPhaseA(const SceneView& sc, const zr_frame_constants& g, const RptP
         // the BSDF ray of the previous vertex's NEE (ReSTIR_PT_PathTrace.hlsl:235-239)
         if (!P.nextHit.hit) { P.active = false; return; }
         P.hit.t = P.nextHit.t;
-        FillHit<false>(sc, P.nextHit.mesh, P.nextHit.prim, P.nextHit.bu, P.nextHit.bv, true, P.hit, true);
+        if (prm.textured) FillHit<true>(sc, P.nextHit.mesh, P.nextHit.prim, P.nextHit.bu, P.nextHit.bv, true, P.hit, true);
+        else FillHit<false>(sc, P.nextHit.mesh, P.nextHit.prim, P.nextHit.bu, P.nextHit.bv, true, P.hit, true);
     }
-    else if (!FindClosestID(gl, true, P.pos, P.normal, P.bs.wi, P.surface.Transmissive(), P.hit)) { P.active = false; return; }   // Hit::FindClosest<true, true>
+    else if (!FindClosestID(gl, true, P.pos, P.normal, P.bs.wi, P.surface.Transmissive(), P.hit, prm.textured)) { P.active = false; return; }   // Hit::FindClosest<true, true>
     V3 newPos = mad(P.hit.t, P.bs.wi, P.pos);
     float eta_mat;
-    if (!GetMaterialData(sc, -P.bs.wi, P.eta_curr, P.hit, P.surface, eta_mat)) { P.active = false; return; }
+    V4 uvGrads = v4(0, 0, 0, 0);
+    if (prm.textured)
+    {
+        P.rd.dpdx_dpdy(newPos, P.hit.normal, P.dpdx, P.dpdy);
+        P.rd.ComputeUVDifferentials(P.dpdx, P.dpdy, P.hit.dpdu, P.hit.dpdv);
+        uvGrads = P.rd.uv_grads;
+    }
+    if (!GetMaterialData(sc, -P.bs.wi, P.eta_curr, P.hit, P.surface, eta_mat, uvGrads, prm.textured)) { P.active = false; return; }
     P.eta_next = eta_mat;
     P.pos = newPos;
     P.normal = P.hit.normal;
@@ -968,6 +996,7 @@ ZR_HD void PtPhaseB(const SceneView& sc, const RptParams& prm, PTLane& P, uint32
     P.eta_curr = transmitted ? (P.eta_curr == kEtaAir ? P.eta_next : kEtaAir) : P.eta_curr;
     P.inMedium = P.eta_curr != kEtaAir;
     P.prevHit.alpha_lobe = alpha_lobe; P.prevHit.lobe = P.bs.lobe; P.prevHit.wi = P.bs.wi; P.prevHit.pdf = P.bs.pdf;
+    if (prm.textured) P.rd.UpdateRays(P.pos, P.normal, P.bs.wi, P.surface.wo, P.hit.dndu, P.hit.dndv, P.dpdx, P.dpdy, transmitted, P.surface.eta);
 }
 
 struct RptTex   // per-pass auxiliary planes
@@ -1012,17 +1041,19 @@ struct RBuf
     U4* B; U4* C;  // RGBA32_UINT
     uint16_t* D;   // R16_UINT
 };
-struct OffsetCtx { V3 throughput, pos, normal; Surface surface; float eta_curr, eta_next; Rng rngReplay; };
+struct OffsetCtx { V3 throughput, pos, normal; Surface surface; float eta_curr, eta_next; Rng rngReplay; RayDiffs rd; };   // rd: textured scenes only
 ZR_HD OffsetCtx InitOffsetCtx()
 {
     OffsetCtx c; c.throughput = v3(0.0f); c.pos = v3(0.0f); c.normal = v3(0.0f);
     c.surface = InitSurface(v3(0, 0, 1), v3(0, 0, 1), false, 0, v3(0.0f), kEtaAir, kDefaultEtaMat, false, 0, 0, 0, v3(0.0f), 0, kDefaultEtaCoat);
     c.eta_curr = kEtaAir; c.eta_next = kDefaultEtaMat; c.rngReplay.s = 0;
+    c.rd = RayDiffs::Zero();
     return c;
 }
-ZR_HD OffsetCtx LoadOffsetCtx(const RBuf& rb, size_t i)
+ZR_HD OffsetCtx LoadOffsetCtx(const RBuf& rb, size_t i, bool isCase3 = false, bool tex = false)
 {
     OffsetCtx ctx = InitOffsetCtx();
+    if (tex && !isCase3) { const float inAw = zr_f16_to_f32(rb.A[4 * i + 3]); ctx.rd.uv_grads = v4(inAw, inAw, inAw, inAw); }
     ctx.throughput = v3(zr_f16_to_f32(rb.A[4 * i]), zr_f16_to_f32(rb.A[4 * i + 1]), zr_f16_to_f32(rb.A[4 * i + 2]));
     if (dot(ctx.throughput, ctx.throughput) == 0) return ctx;
     const U4 b = rb.B[i], c = rb.C[i];
@@ -1052,9 +1083,21 @@ ZR_HD OffsetCtx LoadOffsetCtx(const RBuf& rb, size_t i)
         coat_weight, coat_color, coat_roughness, coat_ior);
     return ctx;
 }
-ZR_HD void WriteOffsetCtx(const OffsetCtx& ctx, const RBuf& rb, size_t i, bool isCase3)
+ZR_HD void WriteOffsetCtx(const OffsetCtx& ctx, const RBuf& rb, size_t i, bool isCase3, bool tex = false)
 {
-    if (!isCase3) rb.A[4 * i + 3] = 0;     // max uv gradient: no textures bound, always 0
+    if (!isCase3)
+    {
+        // max uv gradient (untextured scenes: never read, written as 0)
+        uint16_t gradMax = 0;
+        if (tex)
+        {
+            const V4 uv = ctx.rd.uv_grads;
+            const float ddx_uv = zr_sqrt(uv.x * uv.x + uv.y * uv.y);
+            const float ddy_uv = zr_sqrt(uv.z * uv.z + uv.w * uv.w);
+            gradMax = zr_f32_to_f16(zr_max(ddx_uv, ddy_uv));
+        }
+        rb.A[4 * i + 3] = gradMax;
+    }
     rb.A[4 * i] = zr_f32_to_f16(ctx.throughput.x); rb.A[4 * i + 1] = zr_f32_to_f16(ctx.throughput.y); rb.A[4 * i + 2] = zr_f32_to_f16(ctx.throughput.z);
     if (dot(ctx.throughput, ctx.throughput) == 0) return;
     const Surface& s = ctx.surface;
@@ -1103,10 +1146,18 @@ ZR_HD_FLAT void Replay(const Globals& g, bool currFrame, int numBounces, BsdfSam
             if (h.tri == kInvalidTri) { ctx.throughput = v3(0.0f); return; }
             const TriMeta tm = sc.triMeta[h.tri];
             hit.t = h.t;
-            FillHit<false>(sc, tm.mesh, tm.prim, h.u, h.v, false, hit, currFrame);
+            if (g.textured) FillHit<true>(sc, tm.mesh, tm.prim, h.u, h.v, false, hit, currFrame);
+            else FillHit<false>(sc, tm.mesh, tm.prim, h.u, h.v, false, hit, currFrame);
         }
         float eta_mat;
-        if (!GetMaterialData(sc, -bs.wi, ctx.eta_curr, hit, ctx.surface, eta_mat)) { ctx.throughput = v3(0.0f); return; }
+        V3 dpdx = v3(0.0f), dpdy = v3(0.0f);
+        if (g.textured)
+        {
+            const V3 newPos = mad(hit.t, bs.wi, ctx.pos);
+            ctx.rd.dpdx_dpdy(newPos, hit.normal, dpdx, dpdy);
+            ctx.rd.ComputeUVDifferentials(dpdx, dpdy, hit.dpdu, hit.dpdv);
+        }
+        if (!GetMaterialData(sc, -bs.wi, ctx.eta_curr, hit, ctx.surface, eta_mat, ctx.rd.uv_grads, g.textured)) { ctx.throughput = v3(0.0f); return; }
         ctx.eta_next = eta_mat;
         ctx.pos = mad(hit.t, bs.wi, ctx.pos);
         ctx.normal = hit.normal;
@@ -1126,11 +1177,20 @@ ZR_HD_FLAT void Replay(const Globals& g, bool currFrame, int numBounces, BsdfSam
         ctx.throughput = ctx.throughput * bs.bsdfOverPdf;
         inMedium = ctx.eta_curr != kEtaAir;
         alpha_prev = alpha_lobe; lobe_prev = bs.lobe;
+        if (g.textured) ctx.rd.UpdateRays(ctx.pos, ctx.normal, bs.wi, ctx.surface.wo, hit.dndu, hit.dndv, dpdx, dpdy, transmitted, ctx.surface.eta);
     }
 }
 
 // Shift.hlsli:818-859
-ZR_HD_FLAT OffsetCtx Replay_kGt2(const Globals& g, bool currFrame, V3 pos, V3 normal, float ior, const Surface& surface, const Reconnection& rc)
+// What RayDifferentials::Init and the triangle differentials of a shift's primary hit are built from (textured scenes): the
+// pixel the offset path starts at, its camera, lens sample / ray origin and the G-buffer holding its triangle differentials.
+struct PrimaryDiffs { Camera cam; int x, y; V2 lens; V3 origin; const GBuf* gb; size_t px; };
+ZR_HD PrimaryDiffs MakePrimaryDiffs(const Camera& cam, int x, int y, const PixelSurface& ps, const GBuf& gb, size_t px)
+{ PrimaryDiffs d; d.cam = cam; d.x = x; d.y = y; d.lens = ps.lens; d.origin = ps.origin; d.gb = &gb; d.px = px; return d; }
+
+// preComputed: Replay_CtT evaluates dpdx_dpdy / ComputeUVDifferentials once more before the call (ReSTIR_PT_Replay.hlsl:114-117)
+ZR_HD_FLAT OffsetCtx Replay_kGt2(const Globals& g, bool currFrame, V3 pos, V3 normal, float ior, const Surface& surface, const Reconnection& rc,
+    const PrimaryDiffs& pd, bool preComputed = false)
 {
     OffsetCtx ctx = InitOffsetCtx();
     ctx.pos = pos; ctx.normal = normal; ctx.surface = surface; ctx.rngReplay = Rng::Seed(rc.seed_replay);
@@ -1138,6 +1198,16 @@ ZR_HD_FLAT OffsetCtx Replay_kGt2(const Globals& g, bool currFrame, V3 pos, V3 no
     const int numBounces = (int)rc.k - 2;
     BsdfSample bs = SampleBSDF(g.sc->rho, ctx.normal, ctx.surface, ctx.rngReplay);
     if (dot(bs.bsdfOverPdf, bs.bsdfOverPdf) == 0) { ctx.throughput = v3(0.0f); return ctx; }
+    if (g.textured)
+    {
+        const TriDiffs td = LoadTriDiffs(*pd.gb, pd.px);
+        ctx.rd = InitRD(pd.cam, pd.x, pd.y, pd.lens, pd.origin);
+        V3 dpdx, dpdy;
+        if (preComputed) { ctx.rd.dpdx_dpdy(pos, normal, dpdx, dpdy); ctx.rd.ComputeUVDifferentials(dpdx, dpdy, td.dpdu, td.dpdv); }
+        ctx.rd.dpdx_dpdy(ctx.pos, ctx.normal, dpdx, dpdy);
+        ctx.rd.ComputeUVDifferentials(dpdx, dpdy, td.dpdu, td.dpdv);
+        ctx.rd.UpdateRays(ctx.pos, ctx.normal, bs.wi, ctx.surface.wo, td.dndu, td.dndv, dpdx, dpdy, dot(bs.wi, ctx.normal) < 0, ctx.surface.eta);
+    }
     Replay(g, currFrame, numBounces, bs, ctx);
     return ctx;
 }
@@ -1160,7 +1230,9 @@ ZR_HD_FLAT float StepPath(const Globals& g, bool currFrame, OffsetCtx& ctx, cons
     ctx.eta_curr = transmitted ? (ctx.eta_curr == kEtaAir ? ctx.eta_next : kEtaAir) : ctx.eta_curr;
     const bool inMedium = ctx.eta_curr != kEtaAir;
     float eta_mat;
-    if (!GetMaterialData(sc, -w_k_min_1, ctx.eta_curr, hit, ctx.surface, eta_mat)) return 0;
+    if (g.textured) { hit.dndu = v3(0.0f); hit.dndv = v3(0.0f); }     // (not fetched here; GetMaterialData may flip them)
+    // RtRayQuery::IsotropicSampler with g_samLinearWrap (Shift.hlsli:519-521)
+    if (!GetMaterialData(sc, -w_k_min_1, ctx.eta_curr, hit, ctx.surface, eta_mat, ctx.rd.uv_grads, g.textured, true)) return 0;
     ctx.eta_next = eta_mat;
     if (inMedium && (ctx.surface.trDepth > 0))
     {
@@ -1247,16 +1319,30 @@ struct OffsetPath { V3 target; float partialJacobian; bool surfKMin1Transmissive
 
 // Shift2<Emissive = true>, Shift.hlsli:662-816
 ZR_HD_FLAT OffsetPath Shift2(const Globals& g, bool currFrame, size_t DTidIdx, V3 pos, V3 normal, float ior, const Surface& surface,
-    const Reconnection& rc, const RBuf& rbuffer)
+    const Reconnection& rc, const RBuf& rbuffer, const PrimaryDiffs& pd)
 {
     OffsetCtx ctx = InitOffsetCtx();
     ctx.pos = pos; ctx.normal = normal; ctx.surface = surface; ctx.rngReplay = Rng::Seed(rc.seed_replay);
     ctx.eta_curr = kEtaAir; ctx.eta_next = ior; ctx.throughput = v3(1.0f);
     OffsetPath ret; ret.target = v3(0.0f); ret.partialJacobian = 0; ret.surfKMin1Transmissive = false;
     const int numBounces = (int)rc.k - 2;
-    if (numBounces != 0)
+    if (numBounces == 0)
     {
-        ctx = LoadOffsetCtx(rbuffer, DTidIdx);
+        if (g.textured)
+        {
+            // Shift.hlsli:688-700: the uv gradients of the primary hit feed the isotropic LOD of the reconnection vertex
+            const TriDiffs td = LoadTriDiffs(*pd.gb, pd.px);
+            ctx.rd = InitRD(pd.cam, pd.x, pd.y, pd.lens, pd.origin);
+            V3 dpdx, dpdy;
+            ctx.rd.dpdx_dpdy(ctx.pos, ctx.normal, dpdx, dpdy);
+            ctx.rd.ComputeUVDifferentials(dpdx, dpdy, td.dpdu, td.dpdv);
+            const V3 wi = normalize(rc.x_k - ctx.pos);
+            ctx.rd.UpdateRays(ctx.pos, ctx.normal, wi, ctx.surface.wo, td.dndu, td.dndv, dpdx, dpdy, dot(wi, ctx.normal) < 0, ior);
+        }
+    }
+    else
+    {
+        ctx = LoadOffsetCtx(rbuffer, DTidIdx, rc.IsCase3(), g.textured);
         if (dot(ctx.throughput, ctx.throughput) == 0) return ret;
         // Load() leaves rngReplay at state 0; the reference then advances that state (Shift.hlsli:707-713) -- restated as is
         for (int b = 0; b < numBounces; b++) for (int k = 0; k < 9; k++) ctx.rngReplay.Uniform();
@@ -1334,7 +1420,7 @@ struct RptFrame
 
 ZR_HD Globals MakeGlobals(const RptFrame& F, const zr_frame_constants& g, bool transmissive, TravStack stack, uint32_t* cnt)
 {
-    Globals gl; gl.sc = &F.sc; gl.frame = &g; gl.emissive = F.prm.emissive != 0; gl.numEmissives = g.num_emissive_triangles; gl.alpha_min = F.prm.alpha_min; gl.stack = stack; gl.cnt = cnt; gl.presampled = false; gl.sampleSetIdx = 0;
+    Globals gl; gl.textured = F.prm.textured != 0; gl.sc = &F.sc; gl.frame = &g; gl.emissive = F.prm.emissive != 0; gl.numEmissives = g.num_emissive_triangles; gl.alpha_min = F.prm.alpha_min; gl.stack = stack; gl.cnt = cnt; gl.presampled = false; gl.sampleSetIdx = 0;
     gl.maxNumBounces = transmissive ? (int)F.prm.maxGlossyTrBounces : (int)F.prm.maxNonTrBounces;
     return gl;
 }
@@ -1382,8 +1468,9 @@ ZR_HD_FLAT void ReplayTemporalPixel(const RptFrame& F, const zr_frame_constants&
         if (!r.rc.Empty() && (r.rc.k > 2))
         {
             r.Load_Reconnection(F.cur, px, F.prm.emissive != 0);
-            OffsetCtx ctx = Replay_kGt2(gl, false, tp.prev.pos, tp.prev.normal, tp.prev.eta_next, tp.prev.surface, r.rc);
-            WriteOffsetCtx(ctx, F.rbCtN, px, r.rc.IsCase3());
+            OffsetCtx ctx = Replay_kGt2(gl, false, tp.prev.pos, tp.prev.normal, tp.prev.eta_next, tp.prev.surface, r.rc,
+                MakePrimaryDiffs(PrevCamera(g), tp.px, tp.py, tp.prev, F.gbPrev, pp), true);
+            WriteOffsetCtx(ctx, F.rbCtN, px, r.rc.IsCase3(), gl.textured);
         }
     }
     else
@@ -1392,8 +1479,8 @@ ZR_HD_FLAT void ReplayTemporalPixel(const RptFrame& F, const zr_frame_constants&
         if (!r.rc.Empty() && (r.rc.k > 2))
         {
             r.Load_Reconnection(F.prev, pp, F.prm.emissive != 0);
-            OffsetCtx ctx = Replay_kGt2(gl, true, ps.pos, ps.normal, ps.eta_next, ps.surface, r.rc);
-            WriteOffsetCtx(ctx, F.rbNtC, px, r.rc.IsCase3());
+            OffsetCtx ctx = Replay_kGt2(gl, true, ps.pos, ps.normal, ps.eta_next, ps.surface, r.rc, MakePrimaryDiffs(cam, (int)x, (int)y, ps, F.gb, px));
+            WriteOffsetCtx(ctx, F.rbNtC, px, r.rc.IsCase3(), gl.textured);
         }
     }
 }
@@ -1446,7 +1533,8 @@ ZR_HD void ReconnectTemporalPixel(const RptFrame& F, const zr_frame_constants& g
         {
             r_curr.Load_Reconnection(F.cur, px, F.prm.emissive != 0);
             if (r_curr.rc.IsCase1() || r_curr.rc.IsCase2()) MoveXk(F.sc, r_curr.rc, true, false);
-            OffsetPath shift = Shift2(gl, false, px, tp.prev.pos, tp.prev.normal, tp.prev.eta_next, tp.prev.surface, r_curr.rc, F.rbCtN);
+            OffsetPath shift = Shift2(gl, false, px, tp.prev.pos, tp.prev.normal, tp.prev.eta_next, tp.prev.surface, r_curr.rc, F.rbCtN,
+                MakePrimaryDiffs(PrevCamera(g), tp.px, tp.py, tp.prev, F.gbPrev, pp));
             float target_prev = Luminance(shift.target);
             if (target_prev > 0)
             {
@@ -1481,7 +1569,7 @@ ZR_HD void ReconnectTemporalPixel(const RptFrame& F, const zr_frame_constants& g
     }
     r_prev.Load_Reconnection(F.prev, pp, F.prm.emissive != 0);
     if (r_prev.rc.IsCase1() || r_prev.rc.IsCase2()) MoveXk(F.sc, r_prev.rc, false, true);
-    OffsetPath shift = Shift2(gl, true, px, ps.pos, ps.normal, ps.eta_next, ps.surface, r_prev.rc, F.rbNtC);
+    OffsetPath shift = Shift2(gl, true, px, ps.pos, ps.normal, ps.eta_next, ps.surface, r_prev.rc, F.rbNtC, MakePrimaryDiffs(cam, (int)x, (int)y, ps, F.gb, px));
     float targetLum_curr = Luminance(shift.target);
     float jacobian = r_prev.rc.partialJacobian > 0 ? shift.partialJacobian / r_prev.rc.partialJacobian : 0;
     bool changed = false;
@@ -1620,8 +1708,8 @@ ZR_HD_FLAT void ReplaySpatialPixel(const RptFrame& F, const zr_frame_constants& 
             if (!NeighborOf(F, x, y, sx, sy)) return;
             const size_t sp = Pix(F.gb, (uint32_t)sx, (uint32_t)sy);
             PixelSurface pn = LoadPixelSurface(F.gb, cam, (uint32_t)sx, (uint32_t)sy, g.frame_num, sp);
-            OffsetCtx ctx = Replay_kGt2(gl, true, pn.pos, pn.normal, pn.eta_next, pn.surface, r.rc);
-            WriteOffsetCtx(ctx, F.rbCtN, px, r.rc.IsCase3());
+            OffsetCtx ctx = Replay_kGt2(gl, true, pn.pos, pn.normal, pn.eta_next, pn.surface, r.rc, MakePrimaryDiffs(cam, sx, sy, pn, F.gb, sp));
+            WriteOffsetCtx(ctx, F.rbCtN, px, r.rc.IsCase3(), gl.textured);
         }
     }
     else
@@ -1633,8 +1721,8 @@ ZR_HD_FLAT void ReplaySpatialPixel(const RptFrame& F, const zr_frame_constants& 
         {
             r.Load_Reconnection(F.cur, sp, F.prm.emissive != 0);
             PixelSurface ps = LoadPixelSurface(F.gb, cam, x, y, g.frame_num, px);
-            OffsetCtx ctx = Replay_kGt2(gl, true, ps.pos, ps.normal, ps.eta_next, ps.surface, r.rc);
-            WriteOffsetCtx(ctx, F.rbNtC, px, r.rc.IsCase3());
+            OffsetCtx ctx = Replay_kGt2(gl, true, ps.pos, ps.normal, ps.eta_next, ps.surface, r.rc, MakePrimaryDiffs(cam, (int)x, (int)y, ps, F.gb, px));
+            WriteOffsetCtx(ctx, F.rbNtC, px, r.rc.IsCase3(), gl.textured);
         }
     }
 }
@@ -1677,7 +1765,7 @@ ZR_HD void ReconnectCtSPixel(const RptFrame& F, const zr_frame_constants& g, uin
         Globals gl = MakeGlobals(F, g, flags.transmissive, stack, cnt);
         const Camera cam = CurrCamera(g);
         PixelSurface pn = LoadPixelSurface(F.gb, cam, (uint32_t)sx, (uint32_t)sy, g.frame_num, px);
-        OffsetPath shift = Shift2(gl, true, px, pn.pos, pn.normal, pn.eta_next, pn.surface, r_curr.rc, F.rbCtN);
+        OffsetPath shift = Shift2(gl, true, px, pn.pos, pn.normal, pn.eta_next, pn.surface, r_curr.rc, F.rbCtN, MakePrimaryDiffs(cam, sx, sy, pn, F.gb, sp));
         float target_spatial = Luminance(shift.target);
         if (target_spatial > 0)
         {
@@ -1768,7 +1856,8 @@ ZR_HD void StcPhase2(const RptFrame& F, const zr_frame_constants& g, StcLane& a,
     a.r_spatial.rc.x_k_in_motion = false;
     a.r_spatial.Load_Reconnection(F.cur, a.sp, F.prm.emissive != 0);
     Globals gl = MakeGlobals(F, g, a.flags.transmissive, stack, cnt);
-    OffsetPath shift = Shift2(gl, true, a.px, a.ps.pos, a.ps.normal, a.ps.eta_next, a.ps.surface, a.r_spatial.rc, F.rbNtC);
+    OffsetPath shift = Shift2(gl, true, a.px, a.ps.pos, a.ps.normal, a.ps.eta_next, a.ps.surface, a.r_spatial.rc, F.rbNtC,
+        MakePrimaryDiffs(CurrCamera(g), (int)a.x, (int)a.y, a.ps, F.gb, a.px));
     float targetLum_curr = Luminance(shift.target);
     float targetLum_spatial = a.r_spatial.W > 0 ? a.r_spatial.w_sum / a.r_spatial.W : 0;
     float jacobian = a.r_spatial.rc.partialJacobian > 0 ? shift.partialJacobian / a.r_spatial.rc.partialJacobian : 0;
