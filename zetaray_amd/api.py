@@ -13,7 +13,7 @@ import numpy as np
 from . import wire
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libzetaray_amd.so")
+LIB_PATH = os.environ.get("ZETARAY_AMD_LIB", os.path.join(_HERE, "libzetaray_amd.so"))     # (override: compiler-variant experiments)
 
 PASS_GBUFFER, PASS_PRELIGHTING, PASS_DI_EMISSIVE, PASS_DI_SKY, PASS_INDIRECT, PASS_COMPOSITING, PASS_SKY = range(7)
 OUT_SKY_LUT = 40

@@ -55,7 +55,9 @@ static constexpr int kBlock = 256;
 // 14.9 -> 11.8 ms (4 waves: 1.19 / 10.7 ms, but its ~300 B/lane of spills stream 3.4 GB through L2 per launch, PMC); k_rgi 2 -> 4: 2.19 -> 1.68 ms; k_rdi_* 2 -> 3: 0.72 -> 0.67, 0.39 -> 0.33 ms; k_sdi_spatial -> 4: 0.58 ->
 // 0.49 ms.  k_rpt_temporal, k_rpt_stc, k_pt_shade and k_sdi_temporal got slower with more waves and keep the default.
 #define ZR_WAVES(n) __attribute__((amdgpu_waves_per_eu(n, n)))
+#ifndef ZR_WAVES_PATHTRACE
 #define ZR_WAVES_PATHTRACE ZR_WAVES(3)
+#endif
 #define ZR_WAVES_RGI ZR_WAVES(4)
 #define ZR_WAVES_RDI_T ZR_WAVES(3)
 #define ZR_WAVES_RDI_S ZR_WAVES(3)
@@ -384,7 +386,7 @@ __device__ __forceinline__ void FlushRayCounters(unsigned long long* counters, c
 // EMISSIVE: the NEE_EMISSIVE shader permutation (emissive triangles vs sun + sky); a template constant so the other variant folds away
 // TEX: the scene has a texture heap (ray differentials carried, material maps sampled); likewise a template constant
 template<bool EMISSIVE, bool TEX>
-__global__ void __launch_bounds__(kBlock) ZR_WAVES_PATHTRACE k_rpt_pathtrace(rpt::RptFrame F, zr_frame_constants g, uint32_t tilesX, unsigned long long* counters)
+__device__ __forceinline__ void RptPathtraceBody(rpt::RptFrame& F, const zr_frame_constants& g, uint32_t tilesX, unsigned long long* counters)
 {
     F.prm.emissive = EMISSIVE ? 1u : 0u; F.prm.textured = TEX ? 1u : 0u;
     const uint32_t tile = blockIdx.x, tx = tile % tilesX, ty = tile / tilesX;
@@ -409,6 +411,16 @@ __global__ void __launch_bounds__(kBlock) ZR_WAVES_PATHTRACE k_rpt_pathtrace(rpt
     rpt::PtFinishLane(F.gb, F.prm, F.cur, F.tex, F.finalRGBA, P);
     FlushRayCounters(counters, cnt);
 }
+template<bool EMISSIVE>
+__global__ void __launch_bounds__(kBlock) ZR_WAVES_PATHTRACE k_rpt_pathtrace(rpt::RptFrame F, zr_frame_constants g, uint32_t tilesX, unsigned long long* counters)
+{ RptPathtraceBody<EMISSIVE, false>(F, g, tilesX, counters); }
+// The TEXTURED permutation keeps the compiler's default occupancy: forced to 3 waves (amdgpu_waves_per_eu(3, 3): ~150 spilled
+// VGPRs), ROCm 7.2's clang miscompiles the <sun + sky, textured> instance -- the y / z components of the reconnection radiance
+// rc.L of case-1 samples are written as 0 in ~70 % of the pixels (-O2 and -fno-vectorize change nothing, dropping the attribute
+// does; found by tests/test_gpu_parity.py::test_textured_integrators_on_gpu).
+template<bool EMISSIVE>
+__global__ void __launch_bounds__(kBlock) k_rpt_pathtrace_tex(rpt::RptFrame F, zr_frame_constants g, uint32_t tilesX, unsigned long long* counters)
+{ RptPathtraceBody<EMISSIVE, true>(F, g, tilesX, counters); }
 
 enum RptPixelPass { RPT_REPLAY_CTT = 0, RPT_REPLAY_TTC, RPT_RECONNECT_TEMPORAL, RPT_SPATIAL_SEARCH, RPT_REPLAY_CTS, RPT_REPLAY_STC };
 
@@ -1435,7 +1447,10 @@ static int RenderReSTIR_PT(zr_pass* p, hipStream_t s, const zr_frame_constants* 
     if (stages & ZR_STAGE_TEMPORAL)
     {
         HIP_TRY(hipMemsetAsync(listCnt, 0, 4 * sizeof(uint32_t), s));
-        RPT_TIMED("rpt_pathtrace", RPT_LAUNCH_E(k_rpt_pathtrace, grid, block, 0, s, F, *cb, tilesX, ctr + 2 * 1));
+        TimerBegin(p, s, "rpt_pathtrace");
+        if (texVariant) { if (emissiveVariant) hipLaunchKernelGGL(k_rpt_pathtrace_tex<true>, grid, block, 0, s, F, *cb, tilesX, ctr + 2 * 1); else hipLaunchKernelGGL(k_rpt_pathtrace_tex<false>, grid, block, 0, s, F, *cb, tilesX, ctr + 2 * 1); }
+        else { if (emissiveVariant) hipLaunchKernelGGL(k_rpt_pathtrace<true>, grid, block, 0, s, F, *cb, tilesX, ctr + 2 * 1); else hipLaunchKernelGGL(k_rpt_pathtrace<false>, grid, block, 0, s, F, *cb, tilesX, ctr + 2 * 1); }
+        TimerEnd(p, s);
         if (prm.doTemporal)
         {
             RPT_TIMED("rpt_classify_temporal", hipLaunchKernelGGL(k_rpt_light<0>, grid, block, 0, s, F, *cb, tilesX, lists[0], lists[1], listCnt + 0));
