@@ -303,9 +303,11 @@ def main():
         default_workload = (args.scene.endswith("cornell_emissive.npz") and rpt and not args.direct and not args.sky_direct and (W, H) == (1920, 1080))
         pmc_file = os.path.join(ROOT, "profiles", "r01_pmc_traffic_rpt1080p.json")
         if default_workload and os.path.exists(pmc_file):
-            kmap = {"rpt_pathtrace": "k_rpt_pathtrace<true>", "rpt_reconnect_spatial": "k_rpt_stc<true>", "rpt_reconnect_temporal": "k_rpt_temporal<true>",
-                    "gbuffer": "k_gbuffer"}
-            rec = json.load(open(pmc_file)).get(kmap.get(dom, ""))
+            # kernel names as rocprofv3 prints them (template arguments: NEE_EMISSIVE, TEXTURED)
+            kmap = {"rpt_pathtrace": ["k_rpt_pathtrace<true>"], "rpt_reconnect_spatial": ["k_rpt_stc<true, false>", "k_rpt_stc<true>"],
+                    "rpt_reconnect_temporal": ["k_rpt_temporal<true, false>", "k_rpt_temporal<true>"], "gbuffer": ["k_gbuffer"]}
+            table = json.load(open(pmc_file))
+            rec = next((table[k] for k in kmap.get(dom, []) if k in table), None)
             if rec:
                 traffic, traffic_src = round(rec["traffic_bytes"]), "profiles/r01_pmc_traffic_rpt1080p.json"
         out["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,

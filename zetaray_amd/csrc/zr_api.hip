@@ -25,7 +25,6 @@ static const uint16_t kRptSampleSet[1024] = {
 #include "zr_rpt_sample_set.inc"
 };
 
-using namespace zr;
 
 // ------------------------------------------------------------------------------------------------ errors
 static thread_local std::string g_err;
@@ -48,75 +47,10 @@ static int RequireDevice(int device)
     return ZR_OK;
 }
 
-// ------------------------------------------------------------------------------------------------ device helpers
-static constexpr int kBlock = 256;
-// Occupancy targets of the register-heavy shading kernels, waves per SIMD (the compiler spills a little to reach them).
-// Measured on MI355X, Cornell 1080p / 380k-triangle atrium: k_rpt_pathtrace 2 -> 3 waves: 1.45 -> 1.21 ms /
-// 14.9 -> 11.8 ms (4 waves: 1.19 / 10.7 ms, but its ~300 B/lane of spills stream 3.4 GB through L2 per launch, PMC); k_rgi 2 -> 4: 2.19 -> 1.68 ms; k_rdi_* 2 -> 3: 0.72 -> 0.67, 0.39 -> 0.33 ms; k_sdi_spatial -> 4: 0.58 ->
-// 0.49 ms.  k_rpt_temporal, k_rpt_stc, k_pt_shade and k_sdi_temporal got slower with more waves and keep the default.
-#define ZR_WAVES(n) __attribute__((amdgpu_waves_per_eu(n, n)))
-#ifndef ZR_WAVES_PATHTRACE
-#define ZR_WAVES_PATHTRACE ZR_WAVES(3)
-#endif
-#define ZR_WAVES_RGI ZR_WAVES(4)
-#define ZR_WAVES_RDI_T ZR_WAVES(3)
-#define ZR_WAVES_RDI_S ZR_WAVES(3)
-#define ZR_WAVES_SDI_S ZR_WAVES(4)
-#define ZR_WAVES_SDI_T
-#define ZR_WAVES_TEMPORAL
-#define ZR_WAVES_STC
-#define ZR_WAVES_SHADE
-static constexpr uint32_t kCounterStride = 64;     // queue counters live 256 B apart: their atomics spread over L2 channels
-// this lane's traversal stack: kTravLdsEntries entries in LDS (16 KB per 256-lane block at 8 entries), the rest in scratch
-#define ZR_TRAV_STACK(name) \
-    __shared__ StackEntry name##Lds[kTravLdsEntries * kBlock]; StackEntry name##Mem[kTravStack - kTravLdsEntries]; \
-    TravStack name; name.lds = (ZR_LDS_AS StackEntry*)name##Lds + threadIdx.x; name.stride = kBlock; name.mem = (ZR_PRIVATE_AS StackEntry*)name##Mem
-
-// one atomic per wave: lanes that `want` a slot get consecutive indices
-__device__ __forceinline__ uint32_t AllocSlotWave(uint32_t* counter, bool want)
-{
-    const uint64_t m = __ballot(want);
-    if (m == 0) return 0;
-    const uint32_t lane = __lane_id();
-    const uint32_t prefix = __popcll(m & ((1ull << lane) - 1ull));
-    const int leader = __ffsll((long long)m) - 1;
-    uint32_t base = 0;
-    if ((int)lane == leader) base = atomicAdd(counter, (uint32_t)__popcll(m));
-    base = __shfl(base, leader);
-    return base + prefix;
-}
-// appends this wave's new rays to the queue's compacted ray lists, one list per ray type so that the trace stage's waves
-// stay type-uniform: one atomic per wave and type (all 64 lanes must call this)
-__device__ __forceinline__ void AppendRays(uint32_t* rayList, uint32_t cap, uint32_t* rayCount, uint32_t slot, bool c, bool m, bool sh)
-{
-    const uint32_t s0 = AllocSlotWave(rayCount, c), s1 = AllocSlotWave(rayCount + kCounterStride, m), s2 = AllocSlotWave(rayCount + 2 * kCounterStride, sh);
-    if (c) rayList[s0] = slot;
-    if (m) rayList[cap + s1] = slot;
-    if (sh) rayList[2 * cap + s2] = slot;
-}
-// entry j of the concatenation (C rays, M rays, S rays) of a queue's ray lists -> type, slot
-__device__ __forceinline__ void RayOfIndex(const uint32_t* rayList, uint32_t cap, uint32_t nC, uint32_t nM, uint32_t j, uint32_t& type, uint32_t& slot)
-{
-    type = j < nC ? 0u : (j < nC + nM ? 1u : 2u);
-    slot = rayList[type * cap + (j - (type == 0 ? 0u : (type == 1 ? nC : nC + nM)))];
-}
-
-__device__ __forceinline__ void CountWave(unsigned long long* counter, bool pred)
-{
-    const uint64_t m = __ballot(pred);
-    if (m && __lane_id() == (uint32_t)(__ffsll((long long)m) - 1)) atomicAdd(counter, (unsigned long long)__popcll(m));
-}
-
-// pixel mapping: a 256-thread block covers a 16x16 tile; each wave64 covers one 8x8 quadrant in row-major order, so
-// a wave is exactly one 8x8 thread group of the reference (GBufferRT_Common.h:6-7, IndirectLighting_Common.h:6-7).
-__device__ __forceinline__ void PixelOfThread(uint32_t tilesX, uint32_t x0, uint32_t y0, uint32_t* x, uint32_t* y)
-{
-    const uint32_t tile = blockIdx.x;
-    const uint32_t tx = tile % tilesX, ty = tile / tilesX;
-    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
-    *x = x0 + tx * 16u + (wave & 1u) * 8u + (lane & 7u);
-    *y = y0 + ty * 16u + (wave >> 1) * 8u + (lane >> 3);
-}
+#include "zr_kernels.h"
+// the ReSTIR PT kernels are compiled in zr_tu_rpt_a.hip / zr_tu_rpt_b.hip (see zr_kernels.h)
+ZR_RPT_GROUP_A(extern template)
+ZR_RPT_GROUP_B(extern template)
 
 __global__ void __launch_bounds__(kBlock) k_gbuffer(SceneView sc, zr_frame_constants g, GBuf gb, uint32_t tilesX)
 {
@@ -248,8 +182,8 @@ __global__ void __launch_bounds__(kBlock) k_trace(SceneView sc, PathQueue q, con
 }
 
 template<bool TEX>
-__global__ void __launch_bounds__(kBlock) ZR_WAVES_SHADE k_pt_shade(SceneView sc, zr_frame_constants g, PtParams prm, PathQueue in, const uint32_t* inCount,
-    PathQueue out, uint32_t* outCount, uint32_t* outRays, uint32_t cap, float* finalRGBA, const F4* firstBOP, uint32_t* groupMax)
+__device__ __forceinline__ void PtShadeBody(const SceneView& sc, const zr_frame_constants& g, const PtParams& prm, const PathQueue& in, const uint32_t* inCount,
+    const PathQueue& out, uint32_t* outCount, uint32_t* outRays, uint32_t cap, float* finalRGBA, const F4* firstBOP, uint32_t* groupMax)
 {
     const uint32_t n = *inCount;
     for (uint32_t base = blockIdx.x * kBlock; base < n; base += gridDim.x * kBlock)
@@ -262,6 +196,14 @@ __global__ void __launch_bounds__(kBlock) ZR_WAVES_SHADE k_pt_shade(SceneView sc
         AppendRays(out.rayList, cap, outRays, slot, po.alive && po.rayC_d.w >= 0, po.alive && po.rayM_d.w >= 0, po.alive && po.rayS_d.w >= 0);
     }
 }
+__global__ void __launch_bounds__(kBlock) k_pt_shade(SceneView sc, zr_frame_constants g, PtParams prm, PathQueue in, const uint32_t* inCount,
+    PathQueue out, uint32_t* outCount, uint32_t* outRays, uint32_t cap, float* finalRGBA, const F4* firstBOP, uint32_t* groupMax)
+{ PtShadeBody<false>(sc, g, prm, in, inCount, out, outCount, outRays, cap, finalRGBA, firstBOP, groupMax); }
+// textured permutation: 258 VGPRs by default = 1 wave per SIMD; asking for 2 costs 2 registers and takes the atrium's shade
+// stage from 8.6 to 5.6 ms per frame (the same request on the untextured kernel, 246 VGPRs, made it 10 % slower -- not applied)
+__global__ void __launch_bounds__(kBlock) ZR_WAVES_MIN(2) k_pt_shade_tex(SceneView sc, zr_frame_constants g, PtParams prm, PathQueue in, const uint32_t* inCount,
+    PathQueue out, uint32_t* outCount, uint32_t* outRays, uint32_t cap, float* finalRGBA, const F4* firstBOP, uint32_t* groupMax)
+{ PtShadeBody<true>(sc, g, prm, in, inCount, out, outCount, outRays, cap, finalRGBA, firstBOP, groupMax); }
 
 // Russian-roulette stage: finishes the vertices PtShadePath parked (only launched for rounds in which RR can trigger)
 template<bool TEX>
@@ -367,143 +309,6 @@ __global__ void __launch_bounds__(kBlock) k_trace_rays_any(SceneView sc, const F
         RawHit h = Traverse<true>(sc, xyz(ro), xyz(rd), ro.w, rd.w, mask, stack);
         occ[i] = h.tri != kInvalidTri ? 1u : 0u;
     }
-}
-
-// ------------------------------------------------------------------------------------------------ ReSTIR PT kernels
-// per-lane ray counters -> one atomic pair per wave (all 64 lanes must call this)
-__device__ __forceinline__ void FlushRayCounters(unsigned long long* counters, const uint32_t* cnt)
-{
-    uint32_t a = cnt[0], b = cnt[1];
-    for (int s = 1; s < 64; s <<= 1) { a += __shfl_xor(a, s); b += __shfl_xor(b, s); }
-    if (__lane_id() == 0)
-    {
-        if (a) atomicAdd(counters + 0, (unsigned long long)a);
-        if (b) atomicAdd(counters + 1, (unsigned long long)b);
-    }
-}
-
-// K11: block = 16x16 pixels, wave w = rows 4w..4w+3 (a 16x4 block: the RR "wave" of the ABI, zr_rpt.h header)
-// EMISSIVE: the NEE_EMISSIVE shader permutation (emissive triangles vs sun + sky); a template constant so the other variant folds away
-// TEX: the scene has a texture heap (ray differentials carried, material maps sampled); likewise a template constant
-template<bool EMISSIVE, bool TEX>
-__device__ __forceinline__ void RptPathtraceBody(rpt::RptFrame& F, const zr_frame_constants& g, uint32_t tilesX, unsigned long long* counters)
-{
-    F.prm.emissive = EMISSIVE ? 1u : 0u; F.prm.textured = TEX ? 1u : 0u;
-    const uint32_t tile = blockIdx.x, tx = tile % tilesX, ty = tile / tilesX;
-    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
-    const uint32_t x = F.ox0 + tx * 16u + (lane & 15u), y = F.oy0 + ty * 16u + wave * 4u + (lane >> 4);
-    ZR_TRAV_STACK(stack);
-    uint32_t cnt[2] = {0u, 0u};
-    rpt::PTLane P;
-    rpt::PtInitLane(F.sc, g, F.gb, F.prm, F.Owns(x, y), x, y, F.finalRGBA, stack, cnt, P);
-    for (;;)
-    {
-        const bool any = __ballot(P.active) != 0;
-        rpt::PtPhaseA(F.sc, g, F.prm, stack, cnt, P);
-        if (!any) break;
-        uint32_t key = rpt::PtRRKey(P);
-        if (__ballot(key != 0) != 0)
-        {
-            for (int s = 1; s < 64; s <<= 1) { uint32_t o = __shfl_xor(key, s); key = o > key ? o : key; }
-        }
-        rpt::PtPhaseB(F.sc, F.prm, P, key);
-    }
-    rpt::PtFinishLane(F.gb, F.prm, F.cur, F.tex, F.finalRGBA, P);
-    FlushRayCounters(counters, cnt);
-}
-template<bool EMISSIVE>
-__global__ void __launch_bounds__(kBlock) ZR_WAVES_PATHTRACE k_rpt_pathtrace(rpt::RptFrame F, zr_frame_constants g, uint32_t tilesX, unsigned long long* counters)
-{ RptPathtraceBody<EMISSIVE, false>(F, g, tilesX, counters); }
-// The TEXTURED permutation keeps the compiler's default occupancy: forced to 3 waves (amdgpu_waves_per_eu(3, 3): ~150 spilled
-// VGPRs), ROCm 7.2's clang miscompiles the <sun + sky, textured> instance -- the y / z components of the reconnection radiance
-// rc.L of case-1 samples are written as 0 in ~70 % of the pixels (-O2 and -fno-vectorize change nothing, dropping the attribute
-// does; found by tests/test_gpu_parity.py::test_textured_integrators_on_gpu).
-template<bool EMISSIVE>
-__global__ void __launch_bounds__(kBlock) k_rpt_pathtrace_tex(rpt::RptFrame F, zr_frame_constants g, uint32_t tilesX, unsigned long long* counters)
-{ RptPathtraceBody<EMISSIVE, true>(F, g, tilesX, counters); }
-
-enum RptPixelPass { RPT_REPLAY_CTT = 0, RPT_REPLAY_TTC, RPT_RECONNECT_TEMPORAL, RPT_SPATIAL_SEARCH, RPT_REPLAY_CTS, RPT_REPLAY_STC };
-
-// light per-pixel kernels (no traversal, no scratch)
-template<int PASS>
-__global__ void __launch_bounds__(kBlock) k_rpt_light(rpt::RptFrame F, zr_frame_constants g, uint32_t tilesX, uint32_t* listA, uint32_t* listB, uint32_t* counts)
-{
-    uint32_t x, y; PixelOfThread(tilesX, F.ox0, F.oy0, &x, &y);
-    const bool in = F.Owns(x, y);
-    bool a = false, b = false;
-    if (PASS == 0)          // temporal work lists: pixels whose current / temporal reservoir needs a replay (k > 2)
-    {
-        if (in) { a = rpt::NeedsReplayCtT(F, x, y); b = rpt::NeedsReplayTtC(F, g, x, y); }
-    }
-    else                    // K15 spatial search, then the spatial work lists
-    {
-        if (in) { rpt::SpatialSearchPixel(F, g, x, y); a = rpt::NeedsReplayCtS(F, x, y); b = rpt::NeedsReplayStC(F, x, y); }
-    }
-    const uint32_t pid = in ? (uint32_t)rpt::Pix(F.gb, x, y) : 0u;
-    const uint32_t sa = AllocSlotWave(counts + 0, a);
-    if (a) listA[sa] = pid;
-    const uint32_t sb = AllocSlotWave(counts + 1, b);
-    if (b) listB[sb] = pid;
-}
-
-// K13 replays over a work list (device-side count, fixed grid, grid-stride): only pixels with k > 2 pay for the heavy kernel
-template<int PASS, bool EMISSIVE, bool TEX>
-__global__ void __launch_bounds__(kBlock) k_rpt_replay(rpt::RptFrame F, zr_frame_constants g, const uint32_t* list, const uint32_t* count,
-    unsigned long long* counters)
-{
-    F.prm.emissive = EMISSIVE ? 1u : 0u; F.prm.textured = TEX ? 1u : 0u;
-    ZR_TRAV_STACK(stack);
-    uint32_t cnt[2] = {0u, 0u};
-    const uint32_t n = *count;
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
-    {
-        const uint32_t pid = list[i], x = F.gb.x0 + pid % F.gb.w, y = F.gb.y0 + pid / F.gb.w;
-        if (PASS == RPT_REPLAY_CTT) rpt::ReplayTemporalPixel(F, g, 0, x, y, stack, cnt);
-        else if (PASS == RPT_REPLAY_TTC) rpt::ReplayTemporalPixel(F, g, 1, x, y, stack, cnt);
-        else if (PASS == RPT_REPLAY_CTS) rpt::ReplaySpatialPixel(F, g, 0, x, y, stack, cnt);
-        else rpt::ReplaySpatialPixel(F, g, 1, x, y, stack, cnt);
-    }
-    if (n) FlushRayCounters(counters, cnt);
-}
-
-// K14: CtT + TtC fused per pixel (zr_rpt.h ReconnectTemporalPixel)
-template<bool EMISSIVE, bool TEX>
-__global__ void __launch_bounds__(kBlock) ZR_WAVES_TEMPORAL k_rpt_temporal(rpt::RptFrame F, zr_frame_constants g, uint32_t tilesX, unsigned long long* counters)
-{
-    F.prm.emissive = EMISSIVE ? 1u : 0u; F.prm.textured = TEX ? 1u : 0u;
-    uint32_t x, y; PixelOfThread(tilesX, F.ox0, F.oy0, &x, &y);
-    ZR_TRAV_STACK(stack);
-    uint32_t cnt[2] = {0u, 0u};
-    if (F.Owns(x, y)) rpt::ReconnectTemporalPixel(F, g, x, y, stack, cnt);
-    FlushRayCounters(counters, cnt);
-}
-
-// canonical wave sum of the ABI: xor butterfly, strides 1..32 (zr_rpt.h ButterflySum64 is the host statement of it)
-__device__ __forceinline__ float WaveSumButterfly(float v)
-{
-    for (int s = 1; s < 64; s <<= 1) v = v + __shfl_xor(v, s);
-    return v;
-}
-
-// K16 CtS + StC: wave = 8x8 pixel group; every lane of the wave walks all four phases (absent lanes contribute 0)
-template<bool EMISSIVE, bool TEX>
-__global__ void __launch_bounds__(kBlock) ZR_WAVES_STC k_rpt_stc(rpt::RptFrame F, zr_frame_constants g, uint32_t tilesX, unsigned long long* counters)
-{
-    F.prm.emissive = EMISSIVE ? 1u : 0u; F.prm.textured = TEX ? 1u : 0u;
-    uint32_t x, y; PixelOfThread(tilesX, F.ox0, F.oy0, &x, &y);
-    ZR_TRAV_STACK(stack);
-    uint32_t cnt[2] = {0u, 0u};
-    rpt::StcLane a;
-    float v1, v2, v3, v4;
-    rpt::StcPhase0(F, g, x, y, a, v1, v2);
-    if (a.valid && a.hasN) rpt::ReconnectCtSPixel(F, g, x, y, stack, cnt);       // K16 CtS of this pixel (see zr_rpt.h)
-    const float sum1 = WaveSumButterfly(v1), sum2 = WaveSumButterfly(v2);
-    rpt::StcPhase1(F, g, a, sum1, v3);
-    const float sum3 = WaveSumButterfly(v3);
-    rpt::StcPhase2(F, g, a, sum1, stack, cnt, v4);
-    const float sum4 = WaveSumButterfly(v4);
-    rpt::StcPhase3(F, g, a, sum2 + sum3 + sum4);
-    FlushRayCounters(counters, cnt);
 }
 
 // ------------------------------------------------------------------------------------------------ sun + sky ReSTIR DI kernels
@@ -1536,7 +1341,7 @@ static int RenderIndirect(zr_pass* p, hipStream_t s, const zr_frame_constants* c
         else hipLaunchKernelGGL(k_trace, dim3(gridTrace), dim3(kBlock), 0, s, sc->view, qin, Ctr(2, r), (uint32_t)cap, Ctr(1, r), p->counters.p);
         TimerEnd(p, s);
         TimerBegin(p, s, "pt_shade");
-        hipLaunchKernelGGL(tex ? k_pt_shade<true> : k_pt_shade<false>, dim3(gridShade), dim3(kBlock), 0, s, sc->view, *cb, prm, qin, Ctr(0, r), qout, Ctr(0, r + 1), Ctr(2, r + 1), (uint32_t)cap,
+        hipLaunchKernelGGL(tex ? k_pt_shade_tex : k_pt_shade, dim3(gridShade), dim3(kBlock), 0, s, sc->view, *cb, prm, qin, Ctr(0, r), qout, Ctr(0, r + 1), Ctr(2, r + 1), (uint32_t)cap,
             p->finalRGBA.p, p->firstBOP.p, p->groupMax.p + (size_t)r * numGroups);
         TimerEnd(p, s);
         if (rrPossible && r >= 2)
