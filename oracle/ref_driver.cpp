@@ -26,5 +26,17 @@ void zref_oct32_encode(const float* n3, uint16_t* out, uint64_t n)
 void zref_oct32_decode(const uint16_t* in, float* n3, uint64_t n)
 { for (uint64_t i = 0; i < n; i++) { Math::oct32 o; o.v.x = in[2 * i]; o.v.y = in[2 * i + 1]; Math::float3 f = o.decode(); n3[3 * i] = f.x; n3[3 * i + 1] = f.y; n3[3 * i + 2] = f.z; } }
 void zref_f32_to_f16(const float* x, uint16_t* y, uint64_t n) { for (uint64_t i = 0; i < n; i++) { Math::half h(x[i]); y[i] = h.x; } }
+// Math::Halton (Sampling.cpp:160-174): the 64 sample points of the textured branch of EstimateTriEmissivePower (K2)
+float zref_halton(int i, int b) { return Math::Halton(i, b); }
+// unorm4::FromNormalized (Vector.h:745-769): the rotation quantisation of RT::MeshInstance (RtAccelerationStructure.cpp:343-357)
+void zref_unorm4_from_normalized(const float* q4, uint16_t* out, uint64_t n)
+{
+    for (uint64_t i = 0; i < n; i++)
+    {
+        Math::float4a v(q4[4 * i], q4[4 * i + 1], q4[4 * i + 2], q4[4 * i + 3]);
+        Math::unorm4 u = Math::unorm4::FromNormalized(v);
+        out[4 * i] = u.x; out[4 * i + 1] = u.y; out[4 * i + 2] = u.z; out[4 * i + 3] = u.w;
+    }
+}
 uintptr_t zref_align_phase(const float* p) { return ((32 - (reinterpret_cast<uintptr_t>(p) & 31)) & 31) / 4; }
 }

@@ -808,6 +808,7 @@ int zro_tex_sample(const zro_scene* h, uint32_t tex, int mode, const float* uv, 
     return 0;
 }
 // latches the four texture descriptor-table offsets of the frame constants (for the entry points that take no cb)
+float zro_halton(int i, int b) { return Halton(i, b); }
 int zro_scene_latch_heap_offsets(const zro_scene* h, const zr_frame_constants* cb) { h->s.LatchHeapOffsets(*cb); return 0; }
 
 int zro_gbuffer_render(const zro_scene* h, const zr_frame_constants* cb, zr_gbuffer_planes* planes)

@@ -147,6 +147,7 @@ void zhx_tex_sample(const HxScene* s, uint32_t tex, int mode, const float* uv, c
         else zr_tex_sample_grad(&s->view.tex, tex, uv[2 * i], uv[2 * i + 1], g[4 * i], g[4 * i + 1], g[4 * i + 2], g[4 * i + 3], o);
     }
 }
+float zhx_halton(int i, int b) { return Halton(i, b); }
 void zhx_latch_heap_offsets(const HxScene* s, const zr_frame_constants* cb) { Latch(s, cb); }
 void zhx_estimate_power(const HxScene* s, float* out) { for (size_t i = 0; i < s->emissives.size(); i++) out[i] = EstimateTriPower(s->view, s->emissives[i]); }
 

@@ -74,6 +74,17 @@ def main():
     h = np.zeros(len(x), np.uint16)
     L.zref_f32_to_f16(x.ctypes.data, h.ctypes.data, len(x))
     out["half_in"], out["half_out"] = x, h
+
+    L.zref_halton.restype = C.c_float
+    L.zref_halton.argtypes = [C.c_int, C.c_int]
+    out["halton"] = np.array([[L.zref_halton(i + 1, 2), L.zref_halton(i + 1, 3)] for i in range(64)], np.float32)
+
+    L.zref_unorm4_from_normalized.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64]
+    q = rng.normal(size=(3000, 4)).astype(np.float32)
+    q = np.ascontiguousarray((q / np.linalg.norm(q, axis=1, keepdims=True)).astype(np.float32))
+    qu = np.zeros((len(q), 4), np.uint16)
+    L.zref_unorm4_from_normalized(q.ctypes.data, qu.ctypes.data, len(q))
+    out["unorm4_in"], out["unorm4_out"] = q, qu
     np.savez_compressed(os.path.join(ROOT, "tests", "golden", "ref_pins.npz"), **out)
     print("wrote", len(out), "arrays")
 
