@@ -63,7 +63,13 @@ typedef enum zr_pass_kind {
        atmosphere fields and binds it to the scene, where Le_Sky of every later pass samples it (the reference does the same
        through EnvMapDescHeapOffset).  Pinned: R11G11B10_FLOAT store rounds to nearest even; the LUT is sampled with fp32 bilinear
        interpolation, texel centres at (i + 0.5) / N, wrap addressing.  Inscattering voxel grid: out of scope (post stack). */
-    ZR_PASS_SKY         = 6
+    ZR_PASS_SKY         = 6,
+    /* TAA (RP/TAA/TAA.cpp, TAA.hlsl): temporal anti-aliasing of the composited image.  Input: an
+       RGBA32F image bound with zr_pass_set_input(ZR_IN_TAA_SIGNAL) -- e.g. the COMPOSITING pass's FINAL -- plus the depth and
+       motion-vector planes of the gbuffer passed to zr_pass_render.  Output: ZR_OUT_TAA, R16G16B16A16_FLOAT like the reference's
+       two ping-pong targets (TAA.cpp:120-146); zr_params.taa_blend_weight = cbTAA.BlendWeight (default 0.1, TAA.h:72);
+       zr_pass_reset_temporal = TemporalIsValid 0 for the next frame. */
+    ZR_PASS_TAA         = 7
 } zr_pass_kind;
 
 /* IndirectLighting::INTEGRATOR, reference IndirectLighting.h:40-46 */
@@ -107,7 +113,7 @@ typedef struct zr_params {
     uint32_t lvg_grid_dim;          /* x | y << 10 | z << 20; reference default (32, 8, 40) */
     float    lvg_extents[3];        /* voxel half extents; reference default (0.6, 0.45, 0.6) */
     float    lvg_offset_y;          /* 0.1 */
-    uint32_t reserved[1];
+    float    taa_blend_weight;      /* ZR_PASS_TAA: cbTAA.BlendWeight, 0.1 */
 } zr_params;
 
 /* outputs, GetOutput(SHADER_OUT_RES) */
@@ -143,7 +149,9 @@ typedef enum zr_output {
     ZR_OUT_SDI_RESERVOIR_C = 26,   /* RG32F      8 B: w_sum, W */
     ZR_OUT_SDI_TARGET      = 27,   /* RGBA32F   16 B (xyz) */
     /* Sky (ZR_PASS_SKY) */
-    ZR_OUT_SKY_LUT         = 40    /* R11G11B10_FLOAT 4 B, LutWidth x LutHeight (Sky::SHADER_OUT_RES::SKY_VIEW_LUT) */
+    ZR_OUT_SKY_LUT         = 40,   /* R11G11B10_FLOAT 4 B, LutWidth x LutHeight (Sky::SHADER_OUT_RES::SKY_VIEW_LUT) */
+    /* TAA (ZR_PASS_TAA) */
+    ZR_OUT_TAA             = 41    /* RGBA16F 8 B: the anti-aliased image written by the last render (TAA::SHADER_OUT_RES::OUTPUT_A / _B) */
 } zr_output;
 
 /* G-buffer planes (reference GBufferData::GBUFFER order and DXGI formats, DefaultRendererImpl.h:82-109) */
@@ -248,12 +256,18 @@ int zr_pass_download_output(const zr_pass* pass, int which, void* hip_stream, vo
 #define ZR_IN_EMISSIVE_DI 0
 #define ZR_IN_INDIRECT    1
 #define ZR_IN_SKY_DI      2
+#define ZR_IN_TAA_SIGNAL  3   /* ZR_PASS_TAA: the RGBA32F image to anti-alias (TAA::SHADER_IN_RES::SIGNAL) */
 int zr_pass_set_input(zr_pass* pass, int which, const void* dev_rgba32f);
 /* ray counters accumulated since the last call (device -> host copy; synchronises the stream) */
 int zr_pass_read_counters(zr_pass* pass, void* hip_stream, zr_counters* out, int reset);
 /* the same counters split by the kernel that issued the queries (not reset; roofline bookkeeping of bench.py) */
 int zr_pass_read_kernel_counters(zr_pass* pass, void* hip_stream, uint32_t max_entries, const char** names,
                                  uint64_t* n_closest, uint64_t* n_shadow, uint32_t* count);
+/* Device self-test of the arithmetic contract's half conversions: runs the instruction path the kernels use and the portable code of
+   zr_detmath.h side by side on the device over all 2^32 fp32 and all 2^16 fp16 bit patterns; returns the number of disagreeing
+   patterns (both must be 0). */
+int zr_selftest_half_conversions(int device, uint64_t* mismatches_f32_to_f16, uint64_t* mismatches_f16_to_f32);
+
 /* GpuTimer analogue (Source/ZetaCore/Core/GpuTimer.h:28-45): per-kernel hipEvent timing of the last render */
 int zr_pass_enable_timing(zr_pass* pass, int enable);
 int zr_pass_get_timings(zr_pass* pass, uint32_t max_entries, const char** names, float* ms, uint32_t* launches,

@@ -173,7 +173,7 @@ ZR_HD uint32_t zr_f2u_sat(float f) { if (zr_isnan(f) || f <= 0.0f) return 0u; if
 ZR_HD int32_t zr_f2i_sat(float f) { if (zr_isnan(f)) return 0; if (f >= 2147483648.0f) return 2147483647; if (f <= -2147483648.0f) return (-2147483647 - 1); return (int32_t)f; }
 
 /* fp32 -> fp16, round-to-nearest-even, full denormal/inf/nan handling (== v_cvt_f16_f32 / F16C) */
-ZR_HD uint16_t zr_f32_to_f16(float f)
+ZR_HD uint16_t zr_f32_to_f16_portable(float f)
 {
     uint32_t x = zr_asuint(f);
     uint32_t sign = (x >> 16) & 0x8000u;
@@ -198,7 +198,7 @@ ZR_HD uint16_t zr_f32_to_f16(float f)
     return (uint16_t)(sign | r);
 }
 
-ZR_HD float zr_f16_to_f32(uint16_t h)
+ZR_HD float zr_f16_to_f32_portable(uint16_t h)
 {
     uint32_t sign = ((uint32_t)h & 0x8000u) << 16;
     uint32_t e = (h >> 10) & 0x1fu;
@@ -212,6 +212,29 @@ ZR_HD float zr_f16_to_f32(uint16_t h)
     }
     if (e == 31) return zr_asfloat(sign | 0x7f800000u | (m << 13));
     return zr_asfloat(sign | ((e + 112u) << 23) | (m << 13));
+}
+/* gfx950 kernels use the conversion instructions (v_cvt_f16_f32 / v_cvt_f32_f16: round-to-nearest-even, fp16 denormals kept) for
+   everything but NaN (and Inf on the way up), where the portable code's canonical results are kept.  zr_selftest_half_conversions
+   (include/zetaray_amd.h) compares the two paths on the device for every fp32 and every fp16 bit pattern. */
+ZR_HD uint16_t zr_f32_to_f16(float f)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (f != f) return (uint16_t)(((zr_asuint(f) >> 16) & 0x8000u) | 0x7e00u);
+    union { _Float16 h; uint16_t u; } c; c.h = (_Float16)f;
+    return c.u;
+#else
+    return zr_f32_to_f16_portable(f);
+#endif
+}
+ZR_HD float zr_f16_to_f32(uint16_t h)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    if ((h & 0x7c00u) == 0x7c00u) return zr_asfloat((((uint32_t)h & 0x8000u) << 16) | 0x7f800000u | (((uint32_t)h & 0x3ffu) << 13));
+    union { _Float16 h; uint16_t u; } c; c.u = h;
+    return (float)c.h;
+#else
+    return zr_f16_to_f32_portable(h);
+#endif
 }
 /* round-trip through half, the effect of an HLSL (half) cast followed by (float) */
 ZR_HD float zr_round_f16(float f) { return zr_f16_to_f32(zr_f32_to_f16(f)); }

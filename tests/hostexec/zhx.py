@@ -359,3 +359,18 @@ class HostExecRGI:
         out = np.zeros((self.h, self.w, ch), dt)
         lib().zhx_rgi_read_plane(self.r, idx, out.ctypes.data)
         return out
+
+
+def taa(signal_rgba, depth, motion, prev_out, blend_weight=0.1, temporal_valid=True):
+    """TAA.hlsl on an RGBA32F signal (h, w, 4), depth (h, w) f32, motion (h, w) u32 (R16G16_SNORM), history (h, w, 4) f16 bits (u16);
+    returns the new RGBA16F output as u16 (alpha = the history buffer's, untouched)."""
+    sig = np.ascontiguousarray(signal_rgba, np.float32)
+    h, w = sig.shape[:2]
+    d = np.ascontiguousarray(depth, np.float32)
+    m = np.ascontiguousarray(motion, np.uint32)
+    prev = np.ascontiguousarray(prev_out, np.uint16)
+    out = np.zeros((h, w, 4), np.uint16)
+    f = lib().zhx_taa
+    f.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_float, C.c_int]
+    f(sig.ctypes.data, d.ctypes.data, m.ctypes.data, prev.ctypes.data, out.ctypes.data, w, h, float(blend_weight), int(bool(temporal_valid)))
+    return out

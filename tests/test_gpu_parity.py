@@ -740,3 +740,43 @@ def test_textured_integrators_on_gpu(api, integrator, lights):
                     pa, pb = pa & 0xffffff, pb & 0xffffff
                 assert np.array_equal(pa.view(np.uint8), pb.view(np.uint8)), f"frame {f}: plane {nm}"
     assert got[..., :3].max() > 0
+
+
+def test_taa_on_gpu(api, cornell_emissive, oracle_emissive):
+    """ZR_PASS_TAA after Compositing (ReSTIR PT, moving + jittered camera, 5 frames): the RGBA16F output == the oracle's TAA.hlsl
+    restatement run on the same composited signal and G-buffer planes, every frame; reset_temporal restarts the history."""
+    from oracle import zro
+    w, h = 200, 120
+    r = api.Renderer(cornell_emissive, w, h, params=wire.default_params(), integrator=api.INTEGRATOR_RESTIR_PT)
+    taa = r.enable_taa(0.1)
+    hist = np.zeros((h, w, 4), np.uint16)
+    prev = None
+    for f in range(1, 6):
+        cb = scene_io.make_frame_constants(w, h, frame_num=f, num_emissives=len(cornell_emissive.emissives), cam_pos=(0.05 * max(0, f - 2), 1.2, -4.043),
+                                           jitter=(0.25 * ((f * 7) % 4 - 1.5) / 2, 0.25 * ((f * 3) % 4 - 1.5) / 2))
+        if prev is not None:
+            cb["prev_view"], cb["prev_view_inv"], cb["prev_camera_jitter"] = prev["curr_view"], prev["curr_view_inv"], prev["curr_camera_jitter"]
+        prev = cb.copy()
+        if f == 4:
+            taa.reset_temporal()
+        r.render_frame(cb)
+        signal = r.p_composit.download()
+        planes, _ = r.gbuffer.download()
+        want = zro.taa(signal, planes[7].reshape(h, w), planes[3].reshape(h, w), hist, 0.1, f not in (1, 4))
+        got = taa.download_plane("taa")
+        assert np.array_equal(got[..., :3], want[..., :3]), f"frame {f}"
+        if f in (1, 4):
+            assert np.array_equal(got[..., :3], signal[..., :3].astype(np.float16).view(np.uint16))
+        hist = got
+    assert got[..., :3].view(np.float16).astype(np.float32).max() > 0
+
+
+def test_half_conversion_instructions_match_portable_code(api):
+    """The kernels' fp32 <-> fp16 conversions use v_cvt_f16_f32 / v_cvt_f32_f16; on the device they must agree with the portable
+    code (== the oracle's, pinned to the reference's half in test_ref_pins.py) for all 2^32 / 2^16 bit patterns."""
+    import ctypes as C
+    a, b = C.c_uint64(), C.c_uint64()
+    L = api.lib()
+    L.zr_selftest_half_conversions.argtypes = [C.c_int, C.c_void_p, C.c_void_p]
+    assert L.zr_selftest_half_conversions(0, C.byref(a), C.byref(b)) == 0
+    assert (a.value, b.value) == (0, 0)

@@ -15,13 +15,14 @@ from . import wire
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("ZETARAY_AMD_LIB", os.path.join(_HERE, "libzetaray_amd.so"))     # (override: compiler-variant experiments)
 
-PASS_GBUFFER, PASS_PRELIGHTING, PASS_DI_EMISSIVE, PASS_DI_SKY, PASS_INDIRECT, PASS_COMPOSITING, PASS_SKY = range(7)
+PASS_GBUFFER, PASS_PRELIGHTING, PASS_DI_EMISSIVE, PASS_DI_SKY, PASS_INDIRECT, PASS_COMPOSITING, PASS_SKY, PASS_TAA = range(8)
+IN_TAA_SIGNAL, OUT_TAA = 3, 41
 OUT_SKY_LUT = 40
 IN_EMISSIVE_DI, IN_INDIRECT, IN_SKY_DI = range(3)
 INTEGRATOR_PATH_TRACING, INTEGRATOR_RESTIR_GI, INTEGRATOR_RESTIR_PT = range(3)
 OUT_FINAL = 0
 # ReSTIR PT persistent state (zr_output): name -> (id, dtype, channels)
-RPT_OUTPUTS_EXTRA = {"sky_lut": (40, np.uint32, 1), "sdi_A": (24, np.uint8, 1), "sdi_B": (25, np.uint16, 2), "sdi_C": (26, np.float32, 2),
+RPT_OUTPUTS_EXTRA = {"taa": (41, np.uint16, 4), "sky_lut": (40, np.uint32, 1), "sdi_A": (24, np.uint8, 1), "sdi_B": (25, np.uint16, 2), "sdi_C": (26, np.float32, 2),
                      "sdi_target": (27, np.float32, 4)}
 RPT_OUTPUTS = {"A": (1, np.uint32, 1), "B": (2, np.float32, 2), "C": (3, np.uint32, 4), "D": (4, np.uint32, 4),
                "E": (5, np.uint16, 1), "F": (6, np.float32, 2), "G": (7, np.uint32, 2), "target": (8, np.float32, 4),
@@ -37,7 +38,7 @@ EXPORTS = [
     "zr_gbuffer_create", "zr_gbuffer_destroy", "zr_gbuffer_set_tile_origin", "zr_gbuffer_download", "zr_gbuffer_device_plane",
     "zr_params_default", "zr_pass_create", "zr_pass_init", "zr_pass_resize", "zr_pass_reset_temporal",
     "zr_pass_set_params", "zr_pass_render", "zr_pass_get_output", "zr_pass_download_output",
-    "zr_pass_read_counters", "zr_pass_read_kernel_counters", "zr_pass_enable_timing", "zr_pass_get_timings", "zr_pass_destroy",
+    "zr_pass_read_counters", "zr_pass_read_kernel_counters", "zr_pass_enable_timing", "zr_pass_get_timings", "zr_selftest_half_conversions", "zr_pass_destroy",
     "zr_trace_closest", "zr_trace_any",
     "zr_pass_set_owned_rect", "zr_pass_render_stage", "zr_pass_halo_pack", "zr_pass_halo_unpack", "zr_pass_halo_bytes_per_pixel", "zr_pass_set_input",
 ]
@@ -334,6 +335,17 @@ class Renderer:
             self.p_composit.set_input(IN_EMISSIVE_DI, self.p_direct.output_ptr()[0])
         return self.p_composit
 
+    def enable_taa(self, blend_weight=0.1, device=0):
+        """add the TAA pass on the composited image (adds the Compositing pass if it is not there yet); read it with
+        p_taa.download_plane("taa") (RGBA16F bits)"""
+        if self.p_composit is None:
+            self.enable_compositing(device=device)
+        prm = wire.default_params()
+        prm.taa_blend_weight = blend_weight
+        self.p_taa = Pass(PASS_TAA, self.p_indirect.w, self.p_indirect.h_, device=device, params=prm)
+        self.p_taa.set_input(IN_TAA_SIGNAL, self.p_composit.output_ptr()[0])
+        return self.p_taa
+
     def enable_sky_direct(self, params=None, device=0):
         """add the SkyDI (sun + sky ReSTIR DI) pass; it renders after the Sky pass and the G-buffer"""
         if self.p_sky is None:
@@ -372,6 +384,8 @@ class Renderer:
             self.p_indirect.render(cb, self.scene, self.gbuffer, stream)
         if self.p_composit is not None:
             self.p_composit.render(cb, self.scene, self.gbuffer, stream)
+        if getattr(self, "p_taa", None) is not None:
+            self.p_taa.render(cb, self.scene, self.gbuffer, stream)
 
     def final(self):
         return self.p_indirect.download()

@@ -18,6 +18,7 @@
 #include "zr_sdi.h"
 #include "zr_rgi.h"
 #include "zr_bvh.h"
+#include "zr_taa.h"
 #include "../../include/zr_srgb_table.h"
 
 // 512 x half2 spatial-search points (generated from zetaray_amd/assets/rpt_sample_set_f16.bin by the Makefile)
@@ -216,6 +217,30 @@ __global__ void __launch_bounds__(kBlock) k_pt_rr(SceneView sc, PtParams prm, Pa
         const bool cont = i < n && PtRussianRoulette(sc, prm, q, i, groupMax, TEX);
         AppendRays(q.rayList, cap, rays, i, cont, false, false);
     }
+}
+
+// TAA: one thread per pixel; 9 signal + 9 depth reads from a 3 x 3 neighbourhood that the L2 serves after the first touch, 9 bilinear
+// history fetches (36 half4 texels) around the reprojected position, one half4 store: HBM-bound (16 + 4 + 4 + 8 B read, 8 B written per
+// pixel algorithmically)
+__global__ void __launch_bounds__(256) k_taa(taa::TaaFrame F)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < F.w * F.h) taa::TaaPixel(F, i % F.w, i / F.w);
+}
+
+// self-test of zr_detmath.h's half conversions (instruction path vs portable path), see zr_selftest_half_conversions
+__global__ void __launch_bounds__(256) k_selftest_half(unsigned long long* bad)
+{
+    unsigned long long b0 = 0, b1 = 0;
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < (1ull << 32); i += stride)
+    {
+        const float f = zr_asfloat((uint32_t)i);
+        if (zr_f32_to_f16(f) != zr_f32_to_f16_portable(f)) b0++;
+        if (i < 65536u && zr_asuint(zr_f16_to_f32((uint16_t)i)) != zr_asuint(zr_f16_to_f32_portable((uint16_t)i))) b1++;
+    }
+    if (b0) atomicAdd(bad, b0);
+    if (b1) atomicAdd(bad + 1, b1);
 }
 
 // Compositing: pure streaming kernel (2 + 16 + 16 B read, 16 B written per pixel)
@@ -517,7 +542,8 @@ struct zr_pass
     // INDIRECT / ReSTIR GI: two reservoir sets (A RGBA32F, B RGBA16F, C RGBA32F)
     DevBuf<F4> giA[2], giC[2]; DevBuf<uint16_t> giB[2];
     bool temporalValid = false, doTemporal = false, doSpatial = false; int currIdx = 0;
-    const F4* compIn[3] = {nullptr, nullptr, nullptr};     // COMPOSITING inputs (emissive DI, indirect, sky DI)
+    const F4* compIn[4] = {nullptr, nullptr, nullptr, nullptr};     // COMPOSITING inputs (emissive DI, indirect, sky DI); [3] = TAA signal
+    DevBuf<uint16_t> taaOut[2]; int taaIdx = 0;            // TAA: ping-pong RGBA16F outputs; taaIdx = the one written last
     uint32_t own[4] = {0, 0, 0, 0};                // owned rect (global pixels); w == 0 -> the whole G-buffer rect
     // PRELIGHTING
     DevBuf<float> power;
@@ -640,6 +666,22 @@ int zr_device_count(int* count)
     return ZR_OK;
 }
 
+int zr_selftest_half_conversions(int device, uint64_t* m0, uint64_t* m1)
+{
+    if (!m0 || !m1) return Fail(ZR_ERR_INVALID_ARG, "null argument");
+    int r = RequireDevice(device);
+    if (r) return r;
+    DevBuf<unsigned long long> bad;
+    if ((r = bad.Alloc(2))) return r;
+    HIP_TRY(hipMemset(bad.p, 0, 2 * sizeof(unsigned long long)));
+    hipLaunchKernelGGL(k_selftest_half, dim3(256 * 64), dim3(256), 0, 0, bad.p);
+    HIP_TRY(hipGetLastError());
+    unsigned long long h[2];
+    HIP_TRY(hipMemcpy(h, bad.p, sizeof(h), hipMemcpyDeviceToHost));
+    *m0 = h[0]; *m1 = h[1];
+    return ZR_OK;
+}
+
 int zr_params_default(zr_params* p)
 {
     if (!p) return Fail(ZR_ERR_INVALID_ARG, "params is null");
@@ -649,6 +691,7 @@ int zr_params_default(zr_params* p)
     p->max_non_tr_bounces = 3; p->max_glossy_tr_bounces = 4; p->m_max_temporal = 10; p->m_max_spatial = 8;
     p->alpha_min = 0.175f * 0.175f; p->presampling = 0; p->num_sample_sets = 128; p->sample_set_size = 512;
     // light voxel grid: off; VOXEL_GRID_DIM (32, 8, 40), VOXEL_EXTENTS (0.6, 0.45, 0.6), y offset 0.1 (DefaultRendererImpl.h:42-43, 73-77)
+    p->taa_blend_weight = 0.1f;      // TAA.h:72
     p->use_lvg = 0; p->lvg_grid_dim = 32u | (8u << 10) | (40u << 20);
     p->lvg_extents[0] = 0.6f; p->lvg_extents[1] = 0.45f; p->lvg_extents[2] = 0.6f; p->lvg_offset_y = 0.1f;
     return ZR_OK;
@@ -814,7 +857,7 @@ int zr_gbuffer_device_plane(const zr_gbuffer* g, int plane, void** dev)
 int zr_pass_create(int kind, int device, zr_pass** out)
 {
     if (!out) return Fail(ZR_ERR_INVALID_ARG, "null out");
-    if (kind < ZR_PASS_GBUFFER || kind > ZR_PASS_SKY) return Fail(ZR_ERR_INVALID_ARG, "unknown pass kind %d", kind);
+    if (kind < ZR_PASS_GBUFFER || kind > ZR_PASS_TAA) return Fail(ZR_ERR_INVALID_ARG, "unknown pass kind %d", kind);
     int r = RequireDevice(device);
     if (r) return r;
     zr_pass* p = new (std::nothrow) zr_pass();
@@ -841,6 +884,12 @@ static int AllocPass(zr_pass* p)
 {
     int r;
     if (p->kind == ZR_PASS_SKY) { if ((r = p->skyLut.Alloc((size_t)p->w * p->h))) return r; }
+    if (p->kind == ZR_PASS_TAA)
+    {
+        const size_t n = (size_t)p->w * p->h * 4;
+        for (int k = 0; k < 2; k++) { if ((r = p->taaOut[k].Alloc(n))) return r; HIP_TRY(hipMemset(p->taaOut[k].p, 0, n * sizeof(uint16_t))); }
+        p->taaIdx = 0; p->temporalValid = false;
+    }
     if (p->kind == ZR_PASS_COMPOSITING)
     {
         const size_t cap = (size_t)p->w * p->h;
@@ -1360,10 +1409,31 @@ int zr_pass_render(zr_pass* p, void* stream, const zr_frame_constants* cb, const
 
 int zr_pass_set_input(zr_pass* p, int which, const void* dev)
 {
-    if (!p || p->kind != ZR_PASS_COMPOSITING || which < 0 || which > 2) return Fail(ZR_ERR_INVALID_ARG, "zr_pass_set_input: not a COMPOSITING pass or bad input id");
+    if (p && p->kind == ZR_PASS_TAA && which == ZR_IN_TAA_SIGNAL) { p->compIn[3] = (const F4*)dev; return ZR_OK; }
+    if (!p || p->kind != ZR_PASS_COMPOSITING || which < 0 || which > 2) return Fail(ZR_ERR_INVALID_ARG, "zr_pass_set_input: not a COMPOSITING / TAA pass or bad input id");
     p->compIn[which] = (const F4*)dev;
     return ZR_OK;
 }
+// TAA::Render (TAA.cpp:75-118): reads the other output as history, then the roles swap
+static int RenderTAA(zr_pass* p, hipStream_t s, const zr_frame_constants* cb, zr_gbuffer* gb)
+{
+    if (!gb || gb->w != p->w || gb->h != p->h) return Fail(ZR_ERR_INVALID_ARG, "TAA needs a gbuffer of the pass size");
+    if (cb->render_width != p->w || cb->render_height != p->h) return Fail(ZR_ERR_INVALID_ARG, "TAA: frame constants / pass size mismatch");
+    if (!p->compIn[3]) return Fail(ZR_ERR_NOT_INITIALIZED, "TAA: no input bound (zr_pass_set_input(ZR_IN_TAA_SIGNAL))");
+    const int curr = 1 - p->taaIdx;
+    taa::TaaFrame F;
+    F.signal = p->compIn[3]; F.depth = (const float*)gb->Planes()[ZR_GB_DEPTH].p; F.motion = (const uint32_t*)gb->Planes()[ZR_GB_MOTION_VECTOR].p;
+    F.prevOut = p->taaOut[p->taaIdx].p; F.currOut = p->taaOut[curr].p; F.w = p->w; F.h = p->h;
+    F.blendWeight = p->params.taa_blend_weight; F.temporalIsValid = p->temporalValid ? 1u : 0u;
+    const uint32_t n = p->w * p->h;
+    TimerBegin(p, s, "taa");
+    hipLaunchKernelGGL(k_taa, dim3((n + 255) / 256), dim3(256), 0, s, F);
+    TimerEnd(p, s);
+    HIP_TRY(hipGetLastError());
+    p->taaIdx = curr; p->temporalValid = true;
+    return ZR_OK;
+}
+
 static int RenderCompositing(zr_pass* p, hipStream_t s, const zr_frame_constants* cb, zr_gbuffer* gb)
 {
     if (!gb || gb->w != p->w || gb->h != p->h) return Fail(ZR_ERR_INVALID_ARG, "COMPOSITING needs a gbuffer of the pass size");
@@ -1486,6 +1556,7 @@ int zr_pass_render_stage(zr_pass* p, void* stream, const zr_frame_constants* cb,
     case ZR_PASS_DI_SKY: return RenderDirectSky(p, s, cb, sc, gb, stages);
     case ZR_PASS_COMPOSITING: return (stages & ZR_STAGE_SPATIAL) ? RenderCompositing(p, s, cb, gb) : ZR_OK;
     case ZR_PASS_SKY: return (stages & ZR_STAGE_TEMPORAL) ? RenderSky(p, s, cb, const_cast<zr_scene*>(sc)) : ZR_OK;
+    case ZR_PASS_TAA: return (stages & ZR_STAGE_SPATIAL) ? RenderTAA(p, s, cb, gb) : ZR_OK;
     default: return Fail(ZR_ERR_UNSUPPORTED, "pass kind %d not implemented", p->kind);
     }
 }
@@ -1501,6 +1572,15 @@ int zr_pass_get_output(const zr_pass* p, int which, void** dev, uint32_t* w, uin
         if (w) *w = p->w;
         if (h) *h = p->h;
         if (bpp) *bpp = 4;
+        return ZR_OK;
+    }
+    if (p->kind == ZR_PASS_TAA)
+    {
+        if (which != ZR_OUT_TAA) return Fail(ZR_ERR_INVALID_ARG, "pass has no such output");
+        *dev = p->taaOut[p->taaIdx].p;
+        if (w) *w = p->w;
+        if (h) *h = p->h;
+        if (bpp) *bpp = 8;
         return ZR_OK;
     }
     if (p->kind == ZR_PASS_COMPOSITING)

@@ -101,7 +101,7 @@ class Params(C.Structure):
         ("m_max_temporal", C.c_uint32), ("m_max_spatial", C.c_uint32), ("alpha_min", C.c_float),
         ("presampling", C.c_uint32), ("num_sample_sets", C.c_uint32), ("sample_set_size", C.c_uint32),
         ("use_lvg", C.c_uint32), ("lvg_grid_dim", C.c_uint32), ("lvg_extents", C.c_float * 3), ("lvg_offset_y", C.c_float),
-        ("reserved", C.c_uint32 * 1)]
+        ("taa_blend_weight", C.c_float)]
 
 
 class Counters(C.Structure):
@@ -135,6 +135,7 @@ def default_params() -> Params:
     p.lvg_grid_dim = 32 | (8 << 10) | (40 << 20)
     p.lvg_extents[:] = (0.6, 0.45, 0.6)
     p.lvg_offset_y = 0.1
+    p.taa_blend_weight = 0.1
     return p
 
 
