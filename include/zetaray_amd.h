@@ -265,7 +265,8 @@ int zr_pass_read_kernel_counters(zr_pass* pass, void* hip_stream, uint32_t max_e
                                  uint64_t* n_closest, uint64_t* n_shadow, uint32_t* count);
 /* Device self-test of the arithmetic contract's half conversions: runs the instruction path the kernels use and the portable code of
    zr_detmath.h side by side on the device over all 2^32 fp32 and all 2^16 fp16 bit patterns; returns the number of disagreeing
-   patterns (both must be 0). */
+   patterns (both must be 0).  The second count also covers zr_div255 / zr_div65535 (UNORM decode) against the IEEE division for
+   all 65536 integer inputs. */
 int zr_selftest_half_conversions(int device, uint64_t* mismatches_f32_to_f16, uint64_t* mismatches_f16_to_f32);
 
 /* GpuTimer analogue (Source/ZetaCore/Core/GpuTimer.h:28-45): per-kernel hipEvent timing of the last render */

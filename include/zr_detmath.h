@@ -236,6 +236,29 @@ ZR_HD float zr_f16_to_f32(uint16_t h)
     return zr_f16_to_f32_portable(h);
 #endif
 }
+/* UNORM8 / UNORM16 -> float: x / 255 and x / 65535 for integer-valued x in [0, 65535].  IEEE division costs ~10 instructions on gfx950;
+   device code uses a reciprocal multiply with one fma correction step, which returns the correctly rounded quotient for every such x
+   (checked on the device against the division for all 65536 inputs by zr_selftest_half_conversions). */
+ZR_HD float zr_div255(float x)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    const float r = 1.0f / 255.0f;
+    const float q = x * r;
+    return __builtin_fmaf(__builtin_fmaf(-q, 255.0f, x), r, q);
+#else
+    return x / 255.0f;
+#endif
+}
+ZR_HD float zr_div65535(float x)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    const float r = 1.0f / 65535.0f;
+    const float q = x * r;
+    return __builtin_fmaf(__builtin_fmaf(-q, 65535.0f, x), r, q);
+#else
+    return x / 65535.0f;
+#endif
+}
 /* round-trip through half, the effect of an HLSL (half) cast followed by (float) */
 ZR_HD float zr_round_f16(float f) { return zr_f16_to_f32(zr_f32_to_f16(f)); }
 

@@ -54,15 +54,15 @@ ZR_HD void zr_tex_texel(const zr_tex_heap* T, const zr_texture_desc* d, const zr
     if (d->format == ZR_TEX_RG8)
     {
         const uint16_t p = *(const uint16_t*)(T->texels + m->offset + idx * 2u);
-        out[0] = (float)(p & 0xffu) / 255.0f; out[1] = (float)(p >> 8) / 255.0f; out[2] = 0.0f; out[3] = 1.0f;
+        out[0] = zr_div255((float)(p & 0xffu)); out[1] = zr_div255((float)(p >> 8)); out[2] = 0.0f; out[3] = 1.0f;
         return;
     }
     const uint32_t p = *(const uint32_t*)(T->texels + m->offset + idx * 4u);
     if (d->format == ZR_TEX_RGBA8_SRGB)
     { out[0] = T->srgb[p & 0xffu]; out[1] = T->srgb[(p >> 8) & 0xffu]; out[2] = T->srgb[(p >> 16) & 0xffu]; }
     else
-    { out[0] = (float)(p & 0xffu) / 255.0f; out[1] = (float)((p >> 8) & 0xffu) / 255.0f; out[2] = (float)((p >> 16) & 0xffu) / 255.0f; }
-    out[3] = (float)(p >> 24) / 255.0f;
+    { out[0] = zr_div255((float)(p & 0xffu)); out[1] = zr_div255((float)((p >> 8) & 0xffu)); out[2] = zr_div255((float)((p >> 16) & 0xffu)); }
+    out[3] = zr_div255((float)(p >> 24));
 }
 
 /* wrap addressing: [0, 1); NaN / inf -> 0 */

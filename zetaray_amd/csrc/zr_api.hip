@@ -237,7 +237,15 @@ __global__ void __launch_bounds__(256) k_selftest_half(unsigned long long* bad)
     {
         const float f = zr_asfloat((uint32_t)i);
         if (zr_f32_to_f16(f) != zr_f32_to_f16_portable(f)) b0++;
-        if (i < 65536u && zr_asuint(zr_f16_to_f32((uint16_t)i)) != zr_asuint(zr_f16_to_f32_portable((uint16_t)i))) b1++;
+        if (i < 65536u)
+        {
+            if (zr_asuint(zr_f16_to_f32((uint16_t)i)) != zr_asuint(zr_f16_to_f32_portable((uint16_t)i))) b1++;
+            // the UNORM divisions by constant (zr_div255 / zr_div65535) against the IEEE division
+            const float x = (float)(uint32_t)i;
+            volatile float d255 = 255.0f, d65535 = 65535.0f;      // (volatile: keep real divisions)
+            if (zr_asuint(zr_div255(x)) != zr_asuint(x / d255)) b1++;
+            if (zr_asuint(zr_div65535(x)) != zr_asuint(x / d65535)) b1++;
+        }
     }
     if (b0) atomicAdd(bad, b0);
     if (b1) atomicAdd(bad + 1, b1);

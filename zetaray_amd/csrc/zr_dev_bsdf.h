@@ -34,7 +34,7 @@ ZR_HD float SampleRho(const RhoView& lut, float u, float v, float w)
     int y0 = iy < 0 ? 0 : (iy > hy ? hy : iy), y1 = iy + 1 < 0 ? 0 : (iy + 1 > hy ? hy : iy + 1);
     int z0 = iz < 0 ? 0 : (iz > hz ? hz : iz), z1 = iz + 1 < 0 ? 0 : (iz + 1 > hz ? hz : iz + 1);
     const uint32_t sy = lut.dx, sz = lut.dx * lut.dy;
-#define ZR_RHO(X, Y, Z) ((float)lut.data[(uint32_t)(Z) * sz + (uint32_t)(Y) * sy + (uint32_t)(X)] / 65535.0f)
+#define ZR_RHO(X, Y, Z) (zr_div65535((float)lut.data[(uint32_t)(Z) * sz + (uint32_t)(Y) * sy + (uint32_t)(X)]))
     float c00 = zr_lerp(ZR_RHO(x0, y0, z0), ZR_RHO(x1, y0, z0), tx);
     float c10 = zr_lerp(ZR_RHO(x0, y1, z0), ZR_RHO(x1, y1, z0), tx);
     float c01 = zr_lerp(ZR_RHO(x0, y0, z1), ZR_RHO(x1, y0, z1), tx);

@@ -165,8 +165,8 @@ ZR_HD uint32_t FloatToUNorm8(float f) { f = zr_saturate(f); return (uint32_t)zr_
 ZR_HD uint32_t FloatToUNorm16(float f) { f = zr_saturate(f); return (uint32_t)zr_fma(f, 65535.0f, 0.5f); } // :597-601
 ZR_HD V4 DecodeNormalized4(const uint16_t* u)   // Math.hlsli:629-634
 {
-    return v4(zr_fma((float)u[0] / 65535.0f, 2.0f, -1.0f), zr_fma((float)u[1] / 65535.0f, 2.0f, -1.0f),
-              zr_fma((float)u[2] / 65535.0f, 2.0f, -1.0f), zr_fma((float)u[3] / 65535.0f, 2.0f, -1.0f));
+    return v4(zr_fma(zr_div65535((float)u[0]), 2.0f, -1.0f), zr_fma(zr_div65535((float)u[1]), 2.0f, -1.0f),
+              zr_fma(zr_div65535((float)u[2]), 2.0f, -1.0f), zr_fma(zr_div65535((float)u[3]), 2.0f, -1.0f));
 }
 ZR_HD V2 EncodeUnitVector(V3 n)      // Math.hlsli:638-644
 {
@@ -184,11 +184,11 @@ ZR_HD V3 DecodeUnitVector(V2 u)      // Math.hlsli:646-658
     n.y += (n.y >= 0.0f) ? -t : t;
     return normalize(n);
 }
-ZR_HD V3 DecodeOct32(const uint16_t* e) { return DecodeUnitVector(v2((float)e[0] / 65535.0f, (float)e[1] / 65535.0f)); }
-ZR_HD V3 DecodeOct32u(uint32_t e) { return DecodeUnitVector(v2((float)(e & 0xffffu) / 65535.0f, (float)(e >> 16) / 65535.0f)); }
+ZR_HD V3 DecodeOct32(const uint16_t* e) { return DecodeUnitVector(v2(zr_div65535((float)e[0]), zr_div65535((float)e[1]))); }
+ZR_HD V3 DecodeOct32u(uint32_t e) { return DecodeUnitVector(v2(zr_div65535((float)(e & 0xffffu)), zr_div65535((float)(e >> 16)))); }
 ZR_HD float Luminance(V3 c) { return dot(v3(0.2126f, 0.7152f, 0.0722f), c); }   // Math.hlsli:693-696
 ZR_HD V3 UnpackRGB8(uint32_t rgb)    // Math.hlsli:733-741
-{ return v3((float)(rgb & 0xff) / 255.0f, (float)((rgb >> 8) & 0xff) / 255.0f, (float)((rgb >> 16) & 0xff) / 255.0f); }
+{ return v3(zr_div255((float)(rgb & 0xff)), zr_div255((float)((rgb >> 8) & 0xff)), zr_div255((float)((rgb >> 16) & 0xff))); }
 ZR_HD uint32_t Float3ToRGB8(V3 v)    // Math.hlsli:754-761
 {
     v = saturate(v);

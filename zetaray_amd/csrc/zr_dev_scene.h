@@ -76,8 +76,8 @@ ZR_HD uint32_t TriID(uint32_t meshIdx, uint32_t primIdx)
 ZR_HD bool TestOpacity(const SceneView& sc, uint32_t meshIdx, uint32_t primIdx, float bu, float bv)
 {
     const zr_mesh_instance& md = sc.instances[meshIdx];
-    const float alphaFactor = (float)(md.alpha_factor_cutoff & 0xffu) / 255.0f;      // Math::UnpackRG
-    const float cutoff = (float)(md.alpha_factor_cutoff >> 8) / 255.0f;
+    const float alphaFactor = zr_div255((float)(md.alpha_factor_cutoff & 0xffu));      // Math::UnpackRG
+    const float cutoff = zr_div255((float)(md.alpha_factor_cutoff >> 8));
     if (cutoff == 1.0f) return false;
     float alpha = alphaFactor;
     if (md.base_color_tex != 0xffffu)
@@ -305,13 +305,13 @@ ZR_HD bool MatDoubleSided(const zr_material& m) { return m.coat_color_flags & (1
 ZR_HD bool MatMetallic(const zr_material& m) { return m.coat_color_flags & (1u << ZR_MAT_METALLIC_BIT); }
 ZR_HD bool MatTransmissive(const zr_material& m) { return m.coat_color_flags & (1u << ZR_MAT_TRANSMISSIVE_BIT); }
 ZR_HD bool MatThinWalled(const zr_material& m) { return m.coat_color_flags & (1u << ZR_MAT_THIN_WALLED_BIT); }
-ZR_HD float MatRoughness(const zr_material& m) { return (float)((m.mr_tex_spec_roughness_coat_roughness >> 16) & 0xff) / 255.0f; }
-ZR_HD float MatCoatRoughness(const zr_material& m) { return (float)((m.mr_tex_spec_roughness_coat_roughness >> 24) & 0xff) / 255.0f; }
+ZR_HD float MatRoughness(const zr_material& m) { return zr_div255((float)((m.mr_tex_spec_roughness_coat_roughness >> 16) & 0xff)); }
+ZR_HD float MatCoatRoughness(const zr_material& m) { return zr_div255((float)((m.mr_tex_spec_roughness_coat_roughness >> 24) & 0xff)); }
 ZR_HD float MatIOR(const zr_material& m) { return zr_fma(1.5f / 65535.0f, (float)(m.emissive_strength_ior >> 16), kMinIOR); }
 ZR_HD float MatCoatIOR(const zr_material& m) { return zr_fma(1.5f / 255.0f, (float)((m.emissive_tex_alpha_cutoff_coat_ior >> 24) & 0xff), kMinIOR); }
 ZR_HD float MatTrDepth(const zr_material& m) { return zr_f16_to_f32((uint16_t)(m.normal_tex_tr_depth >> 16)); }
-ZR_HD float MatSubsurface(const zr_material& m) { return (float)((m.base_color_tex_subsurf_coat_weight >> 16) & 0xff) / 255.0f; }
-ZR_HD float MatCoatWeight(const zr_material& m) { return (float)((m.base_color_tex_subsurf_coat_weight >> 24) & 0xff) / 255.0f; }
+ZR_HD float MatSubsurface(const zr_material& m) { return zr_div255((float)((m.base_color_tex_subsurf_coat_weight >> 16) & 0xff)); }
+ZR_HD float MatCoatWeight(const zr_material& m) { return zr_div255((float)((m.base_color_tex_subsurf_coat_weight >> 24) & 0xff)); }
 ZR_HD float MatEmissiveStrength(const zr_material& m) { return zr_f16_to_f32((uint16_t)(m.emissive_strength_ior & 0xffff)); }
 
 // ---- hit reconstruction (RayQuery.hlsli:55-131 / 209-289) ----
@@ -429,12 +429,12 @@ ZR_HD bool GetMaterialData(const SceneView& sc, V3 wo, float eta_curr, HitInfo& 
 ZR_HD bool EmDoubleSided(const zr_emissive_triangle& t) { return t.packed_a & (1u << 25); }
 ZR_HD V3 EmV1(const zr_emissive_triangle& t)
 {
-    V3 d = DecodeUnitVector(v2((float)t.v0v1[0] / 65535.0f, (float)t.v0v1[1] / 65535.0f));
+    V3 d = DecodeUnitVector(v2(zr_div65535((float)t.v0v1[0]), zr_div65535((float)t.v0v1[1])));
     return mad(zr_f16_to_f32(t.edge_lengths[0]), d, v3p(t.vtx0));
 }
 ZR_HD V3 EmV2(const zr_emissive_triangle& t)
 {
-    V3 d = DecodeUnitVector(v2((float)t.v0v2[0] / 65535.0f, (float)t.v0v2[1] / 65535.0f));
+    V3 d = DecodeUnitVector(v2(zr_div65535((float)t.v0v2[0]), zr_div65535((float)t.v0v2[1])));
     return mad(zr_f16_to_f32(t.edge_lengths[1]), d, v3p(t.vtx0));
 }
 // Light::SamplePresampledSet (LightSource.hlsli:99-106) + the decode of the USE_PRESAMPLED_SETS branches

@@ -61,7 +61,7 @@ ZR_HD Reservoir LoadReservoir(const DiPlanes& p, size_t i)
     r.w_sum = p.B[2 * i]; r.W = p.B[2 * i + 1];
     r.le = v3(zr_f16_to_f32((uint16_t)(a.y & 0xffff)), zr_f16_to_f32((uint16_t)(a.y >> 16)), zr_f16_to_f32((uint16_t)(a.z & 0xffff)));
     r.lightIdx = a.w;
-    r.bary = v2((float)(a.x & 0xffff) / 65535.0f, (float)(a.x >> 16) / 65535.0f);
+    r.bary = v2(zr_div65535((float)(a.x & 0xffff)), zr_div65535((float)(a.x >> 16)));
     return r;
 }
 
@@ -188,7 +188,7 @@ ZR_HD Reservoir RIS_InitialCandidates(const Globals& gl, const zr_frame_constant
             uint32_t u = rng.UniformUintBounded_Faster(sc.sampleSetSize);
             const zr_presampled_tri t = sc.sampleSets[(size_t)sampleSetIdx * sc.sampleSetSize + u];
             lpos = v3p(t.pos); ln = DecodeOct32(t.normal);
-            lbary = v2((float)t.bary[0] / 65535.0f, (float)t.bary[1] / 65535.0f);
+            lbary = v2(zr_div65535((float)t.bary[0]), zr_div65535((float)t.bary[1]));
             le = v3(zr_f16_to_f32(t.le[0]), zr_f16_to_f32(t.le[1]), zr_f16_to_f32(t.le[2]));
             pdf_light = t.pdf; emissiveIdx = t.idx; lightID = t.id; doubleSided = t.two_sided != 0;
             if (doubleSided && dot(pos - lpos, ln) < 0) ln = -ln;

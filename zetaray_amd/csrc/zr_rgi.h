@@ -312,7 +312,7 @@ ZR_HD void InitLane(const GiFrame& F, const zr_frame_constants& g, uint32_t x, u
     const V3 baseColor = UnpackRGB8(F.gb.baseColor[P.px]);
     P.roughness = RoughnessOf(mrp);
     P.ior = kDefaultEtaMat;
-    if (flags.transmissive) P.ior = DecodeIOR((float)F.gb.ior[P.px] / 255.0f);
+    if (flags.transmissive) P.ior = DecodeIOR(zr_div255((float)F.gb.ior[P.px]));
     const V3 wo = normalize(origin - P.pos);
     P.surface = InitSurface(P.normal, wo, flags.metallic, P.roughness, baseColor, kEtaAir, P.ior, flags.transmissive, 0.0f, 0.0f, 0.0f, v3(0.0f), 0.0f, kDefaultEtaCoat);
     P.rngGroup = Rng::Init((x >> 3) ^ 61u, (y >> 3) ^ 61u, g.frame_num);
@@ -463,7 +463,7 @@ ZR_HD void FindTemporalCandidate(const GiFrame& F, const zr_frame_constants& g, 
         valid[curr] = dot(prevNormal, normal) > 0.1f;
         if (roughness < 0.5f) valid[curr] = valid[curr] && (zr_abs(prevRough - roughness) < 0.15f);
         float prevEta_mat = kDefaultEtaMat;
-        if (pf.transmissive) prevEta_mat = DecodeIOR((float)(sp == (size_t)-1 ? 0 : F.gbPrev.ior[sp]) / 255.0f);
+        if (pf.transmissive) prevEta_mat = DecodeIOR(zr_div255((float)(sp == (size_t)-1 ? 0 : F.gbPrev.ior[sp])));
         valid[curr] = valid[curr] && (pf.transmissive == transmissive);
         valid[curr] = g.dof ? true : valid[curr];
         if (valid[curr])

@@ -742,11 +742,11 @@ ZR_HD void EstimateDirectAndUpdateRC(const Globals& g, int pathVertex, V3 pos, c
 struct GFlags { bool metallic, transmissive, emissive, invalid, trDepthGt0, subsurface, coated; };
 ZR_HD GFlags DecodeFlags(uint16_t mrp)
 {
-    const uint32_t v = (uint32_t)zr_fma((float)(mrp & 0xff) / 255.0f, 255.0f, 0.5f);
+    const uint32_t v = (uint32_t)zr_fma(zr_div255((float)(mrp & 0xff)), 255.0f, 0.5f);
     GFlags f; f.transmissive = v & 1; f.emissive = v & 2; f.invalid = v & 4; f.trDepthGt0 = v & 8; f.subsurface = v & 16; f.coated = v & 32; f.metallic = v & 128;
     return f;
 }
-ZR_HD float RoughnessOf(uint16_t mrp) { return (float)(mrp >> 8) / 255.0f; }
+ZR_HD float RoughnessOf(uint16_t mrp) { return zr_div255((float)(mrp >> 8)); }
 ZR_HD V2 DecodeMotion(uint32_t m)
 {
     float fx = (float)(int16_t)(uint16_t)(m & 0xffff) / 32767.0f, fy = (float)(int16_t)(uint16_t)(m >> 16) / 32767.0f;
@@ -817,18 +817,18 @@ ZR_HD PixelSurface LoadPixelSurfaceEx(const GBuf& gb, const Camera& cam, uint32_
     ps.normal = DecodeOct32u(gb.normal[px]);
     const uint32_t bc = gb.baseColor[px];
     const V3 baseColor = UnpackRGB8(bc);
-    const float subsurface = ps.flags.subsurface ? (float)(bc >> 24) / 255.0f : 0.0f;
+    const float subsurface = ps.flags.subsurface ? zr_div255((float)(bc >> 24)) : 0.0f;
     ps.eta_next = kDefaultEtaMat;
-    if (ps.flags.transmissive) ps.eta_next = DecodeIOR((float)gb.ior[px] / 255.0f);
+    if (ps.flags.transmissive) ps.eta_next = DecodeIOR(zr_div255((float)gb.ior[px]));
     float coat_weight = 0, coat_roughness = 0, coat_ior = kDefaultEtaCoat; V3 coat_color = v3(0.0f);
     if (ps.flags.coated)
     {
         const uint16_t* p = &gb.coat[4 * coatPixel];     // GBuffer::UnpackCoat, GBuffers.hlsli:107-121
-        coat_weight = (float)((p[1] >> 8) & 0xff) / 255.0f;
-        coat_roughness = (float)(p[2] & 0xff) / 255.0f;
+        coat_weight = zr_div255((float)((p[1] >> 8) & 0xff));
+        coat_roughness = zr_div255((float)(p[2] & 0xff));
         uint32_t c = (uint32_t)p[0] | (((uint32_t)p[1] & 0xff) << 16);
         coat_color = UnpackRGB8(c);
-        coat_ior = DecodeIOR((float)(p[2] >> 8) / 255.0f);
+        coat_ior = DecodeIOR(zr_div255((float)(p[2] >> 8)));
     }
     const V3 wo = normalize(origin - ps.pos);
     ps.surface = InitSurface(ps.normal, wo, ps.flags.metallic, ps.roughness, baseColor, kEtaAir, ps.eta_next, ps.flags.transmissive,
@@ -1059,25 +1059,25 @@ ZR_HD OffsetCtx LoadOffsetCtx(const RBuf& rb, size_t i, bool isCase3 = false, bo
     const U4 b = rb.B[i], c = rb.C[i];
     ctx.pos = v3(zr_asfloat(b.x), zr_asfloat(b.y), zr_asfloat(b.z));
     ctx.normal = DecodeOct32u(b.w);
-    ctx.eta_curr = zr_fma((float)((c.z >> 8) & 0xff) / 255.0f, 1.5f, 1.0f);
-    ctx.eta_next = zr_fma((float)((c.z >> 16) & 0xff) / 255.0f, 1.5f, 1.0f);
+    ctx.eta_curr = zr_fma(zr_div255((float)((c.z >> 8) & 0xff)), 1.5f, 1.0f);
+    ctx.eta_next = zr_fma(zr_div255((float)((c.z >> 16) & 0xff)), 1.5f, 1.0f);
     V3 wo = DecodeOct32u(c.x);
-    float roughness = (float)(c.z & 0xff) / 255.0f;
+    float roughness = zr_div255((float)(c.z & 0xff));
     V3 baseColor = UnpackRGB8(c.y & 0xffffff);
     uint32_t flags = c.y >> 24;
     bool metallic = flags & 0x1, specTr = (flags & 0x4) == 0x4;
     float trDepth = (flags & 0x8) == 0x8 ? 1.0f : 0.0f;
     bool coated = (flags & 0x10) == 0x10;
-    float subsurface = (float)((c.z >> 24) & 0xff) / 255.0f;
+    float subsurface = zr_div255((float)((c.z >> 24) & 0xff));
     float eta_next = ctx.eta_curr == kEtaAir ? ctx.eta_next : kEtaAir;
     float coat_weight = 0, coat_roughness = 0, coat_ior = kDefaultEtaCoat; V3 coat_color = v3(0.0f);
     if (coated)
     {
         uint32_t c_w = c.w; uint32_t d_w = rb.D[i];
-        coat_weight = (float)((c_w >> 24) & 0xff) / 255.0f;
+        coat_weight = zr_div255((float)((c_w >> 24) & 0xff));
         coat_color = UnpackRGB8(c_w & 0xffffff);
-        coat_roughness = (float)(d_w & 0xff) / 255.0f;
-        coat_ior = zr_fma((float)((d_w >> 8) & 0xff) / 255.0f, 1.5f, 1.0f);
+        coat_roughness = zr_div255((float)(d_w & 0xff));
+        coat_ior = zr_fma(zr_div255((float)((d_w >> 8) & 0xff)), 1.5f, 1.0f);
     }
     ctx.surface = InitSurface(ctx.normal, wo, metallic, roughness, baseColor, ctx.eta_curr, eta_next, specTr, trDepth, zr_round_f16(subsurface),
         coat_weight, coat_color, coat_roughness, coat_ior);

@@ -45,7 +45,7 @@ ZR_HD float EncodeMetallic(float metalness, bool tr, V3 emissive, float trDepth,
     r |= ((uint32_t)(subsurface > 0) << 4);
     r |= ((uint32_t)(coat_weight > 0) << 5);
     r |= ((uint32_t)(metalness >= kMinMetalnessMetal) << 7);
-    return (float)r / 255.0f;
+    return zr_div255((float)r);
 }
 ZR_HD float EncodeIOR(float ior) { return (ior - kMinIOR) / (kMaxIOR - kMinIOR); }   // GBuffers.hlsli:97-105
 ZR_HD float DecodeIOR(float e) { return zr_fma(e, kMaxIOR - kMinIOR, kMinIOR); }
@@ -233,7 +233,7 @@ ZR_HD void GBufferPixel(const SceneView& sc, const zr_frame_constants& g, const 
     {
         float c[4];
         zr_tex_sample_grad(&sc.tex, g.normal_maps_desc_heap_offset + normalTex, uv.x, uv.y, grads.x, grads.y, grads.z, grads.w, c);
-        sn = TangentSpaceToWorldSpace(v2(c[0], c[1]), tangent, normal, (float)(mat.emissive_factor_normal_scale >> 24) / 255.0f);
+        sn = TangentSpaceToWorldSpace(v2(c[0], c[1]), tangent, normal, zr_div255((float)(mat.emissive_factor_normal_scale >> 24)));
     }
     if (MatDoubleSided(mat) && dot(wo, normal) < 0) { sn = sn * -1.0f; dndu = dndu * -1.0f; dndv = dndv * -1.0f; }
     if (dot(wo, normal) > 0 && dot(wo, sn) < 0)
@@ -447,7 +447,7 @@ ZR_HD void PtInitPixel(const SceneView& sc, const zr_frame_constants& g, const G
     out.alive = false;
     const uint32_t pid = (y - gb.y0) * gb.w + (x - gb.x0);
     const uint16_t mrp = gb.mr[pid];
-    const float mr_x = (float)(mrp & 0xff) / 255.0f, mr_y = (float)(mrp >> 8) / 255.0f;
+    const float mr_x = zr_div255((float)(mrp & 0xff)), mr_y = zr_div255((float)(mrp >> 8));
     const uint32_t fl = (uint32_t)zr_fma(mr_x, 255.0f, 0.5f);
     if (fl & (ZR_GBUF_INVALID | ZR_GBUF_EMISSIVE))
     {
@@ -493,7 +493,7 @@ ZR_HD void PtInitPixel(const SceneView& sc, const zr_frame_constants& g, const G
     const V3 normal = DecodeOct32u(gb.normal[pid]);
     const V3 baseColor = UnpackRGB8(gb.baseColor[pid]);
     float eta_curr = kEtaAir, eta_next = kDefaultEtaMat;
-    if (f_tr) eta_next = DecodeIOR((float)gb.ior[pid] / 255.0f);
+    if (f_tr) eta_next = DecodeIOR(zr_div255((float)gb.ior[pid]));
     const V3 wo = normalize(origin - pos);
     Surface surface = InitSurface(normal, wo, f_metal, mr_y, baseColor, eta_curr, eta_next, f_tr, f_trDepth ? 1.0f : 0.0f,
         0.0f, 0.0f, v3(0.0f), 0.0f, kDefaultEtaCoat);
@@ -933,7 +933,7 @@ ZR_HD zr_presampled_tri PresampleEmissive(const SceneView& sc, uint32_t i, uint3
 // Compositing.hlsl:30-125 for one pixel (in-scattering off; Le_SkyWithSunDisk of miss pixels pinned to 0: no sky model bound)
 ZR_HD F4 CompositePixel(const zr_frame_constants& g, uint16_t mrp, const F4* skyDI, const F4* emissiveDI, const F4* indirect, size_t px, F4 prevOut)
 {
-    const uint32_t fl = (uint32_t)zr_fma((float)(mrp & 0xff) / 255.0f, 255.0f, 0.5f);
+    const uint32_t fl = (uint32_t)zr_fma(zr_div255((float)(mrp & 0xff)), 255.0f, 0.5f);
     const bool accumulate = g.accumulate && g.camera_static;
     if ((fl & ZR_GBUF_INVALID) && !accumulate) return f4(v3(0.0f), prevOut.w);
     const uint32_t numFramesAccumulated = accumulate ? g.num_frames_camera_static : 1u;
