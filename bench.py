@@ -246,6 +246,8 @@ def main():
         agg = {}
         nfr = 8
         r.p_indirect.read_counters(reset=True)
+        for q in di_passes:
+            q.read_counters(reset=True)
         for i in range(nfr):
             frame(1000 + i)
             torch.cuda.synchronize()
@@ -257,6 +259,9 @@ def main():
                 a[0] += ms
                 a[1] += launches
         kern_rays = r.p_indirect.kernel_counters()
+        di_rays = {}
+        for q in di_passes:      # the DI passes' per-kernel ray counts over the same nfr frames
+            di_rays.update(q.kernel_counters())
         cc, cs = r.p_indirect.read_counters(reset=True)
         r.p_gbuffer.read_counters(reset=True)
         r.p_gbuffer.enable_timing(False)
@@ -288,8 +293,7 @@ def main():
             bytes_launch = (SHADE_CLOSEST * cc + SHADE_SHADOW * cs) / launches
         elif dom in ("sdi_temporal", "sdi_spatial", "rdi_temporal", "rdi_spatial"):
             # DI: shadow / visibility rays of this kernel + the G-buffer planes (27 B) and reservoir planes it reads and writes
-            q = r.p_sky_direct if dom.startswith("sdi") else r.p_direct
-            kcc, kcs = q.kernel_counters().get(dom, (0, 0))
+            kcc, kcs = di_rays.get(dom, (0, 0))
             bytes_launch = (BYTES_CLOSEST * kcc + BYTES_SHADOW * kcs) / launches + (27 * 3 + 2 * 13 + 32) * W * H
         elif dom == "gbuffer":
             bytes_launch = (BYTES_CLOSEST + 47) * W * H

@@ -268,6 +268,41 @@ void* SkyDI::GetOutput(SHADER_OUT_RES i) const
 }
 void SkyDI::Render(Core::CommandList& cl) { ZR_CHECK(zr_pass_render(m_pass, cl.Stream(), &m_ctx->frameConstants, m_ctx->scene, m_ctx->gbuffer)); }
 
+void Compositing::Init(FrameContext* ctx) { InitRenderPass(ZR_PASS_COMPOSITING, ctx, 0); ZR_CHECK(zr_params_default(&m_params)); }
+void Compositing::OnWindowResized() { ZR_CHECK(zr_pass_resize(m_pass, m_ctx->renderWidth, m_ctx->renderHeight)); }
+void Compositing::SetGpuDescriptor(SHADER_IN_GPU_DESC i, const void* dev)
+{
+    const int which = i == SHADER_IN_GPU_DESC::SKY_DI ? ZR_IN_SKY_DI : (i == SHADER_IN_GPU_DESC::EMISSIVE_DI ? ZR_IN_EMISSIVE_DI : ZR_IN_INDIRECT);
+    ZR_CHECK(zr_pass_set_input(m_pass, which, dev));
+}
+void Compositing::SetFireflyFilterEnablement(bool b)
+{
+    m_params.flags = b ? (m_params.flags | ZR_COMPOSIT_FIREFLY_FILTER) : (m_params.flags & ~(uint32_t)ZR_COMPOSIT_FIREFLY_FILTER);
+    ZR_CHECK(zr_pass_set_params(m_pass, &m_params));
+}
+void* Compositing::GetOutput(SHADER_OUT_RES i) const
+{
+    if (i != SHADER_OUT_RES::COMPOSITED) { std::fprintf(stderr, "Invalid shader output.\n"); std::abort(); }
+    void* dev = nullptr; uint32_t w, h, bpp;
+    ZR_CHECK(zr_pass_get_output(m_pass, ZR_OUT_FINAL, &dev, &w, &h, &bpp));
+    return dev;
+}
+void Compositing::Render(Core::CommandList& cl) { ZR_CHECK(zr_pass_render(m_pass, cl.Stream(), &m_ctx->frameConstants, m_ctx->scene, m_ctx->gbuffer)); }
+
+void TAA::Init(FrameContext* ctx) { InitRenderPass(ZR_PASS_TAA, ctx, 0); ZR_CHECK(zr_params_default(&m_params)); }
+void TAA::OnWindowResized() { ZR_CHECK(zr_pass_resize(m_pass, m_ctx->renderWidth, m_ctx->renderHeight)); }
+void TAA::SetCPUDescriptor(SHADER_IN_CPU_DESC, const void* dev) { ZR_CHECK(zr_pass_set_input(m_pass, ZR_IN_TAA_SIGNAL, dev)); }
+void TAA::SetBlendWeight(float w) { m_params.taa_blend_weight = w; ZR_CHECK(zr_pass_set_params(m_pass, &m_params)); }
+void TAA::ResetTemporal() { ZR_CHECK(zr_pass_reset_temporal(m_pass)); }
+void* TAA::GetOutput(SHADER_OUT_RES i) const
+{
+    if (i >= SHADER_OUT_RES::COUNT) { std::fprintf(stderr, "Invalid shader output.\n"); std::abort(); }
+    void* dev = nullptr; uint32_t w, h, bpp;
+    ZR_CHECK(zr_pass_get_output(m_pass, ZR_OUT_TAA, &dev, &w, &h, &bpp));
+    return dev;
+}
+void TAA::Render(Core::CommandList& cl) { ZR_CHECK(zr_pass_render(m_pass, cl.Stream(), &m_ctx->frameConstants, m_ctx->scene, m_ctx->gbuffer)); }
+
 void IndirectLighting::Init(FrameContext* ctx, INTEGRATOR method)
 {
     zr_params_default(&m_params);

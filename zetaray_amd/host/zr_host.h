@@ -211,6 +211,37 @@ namespace RenderPass {
         void Render(Core::CommandList& cmdList);
     };
 
+    // RP/Compositing/Compositing.h:19-115: (sky DI | emissive DI) + indirect, optional firefly filter
+    struct Compositing final : public RenderPassBase
+    {
+        enum class SHADER_IN_GPU_DESC { SKY_DI, EMISSIVE_DI, INDIRECT, COUNT };
+        enum class SHADER_OUT_RES { COMPOSITED, COUNT };
+        void Init(FrameContext* ctx);
+        void OnWindowResized();
+        void SetGpuDescriptor(SHADER_IN_GPU_DESC i, const void* devicePlane);       // RGBA32F FINAL plane of the producing pass
+        void SetFireflyFilterEnablement(bool b);
+        void* GetOutput(SHADER_OUT_RES i) const;
+        void Render(Core::CommandList& cmdList);
+    private:
+        zr_params m_params{};
+    };
+
+    // RP/TAA/TAA.h:20-80: temporal anti-aliasing of the composited image
+    struct TAA final : public RenderPassBase
+    {
+        enum class SHADER_IN_CPU_DESC { SIGNAL, COUNT };
+        enum class SHADER_OUT_RES { OUTPUT_A, OUTPUT_B, COUNT };
+        void Init(FrameContext* ctx);
+        void OnWindowResized();
+        void SetCPUDescriptor(SHADER_IN_CPU_DESC i, const void* devicePlane);       // RGBA32F signal
+        void SetBlendWeight(float w);                                                // param "BlendWeight", TAA.cpp:150-153
+        void ResetTemporal();
+        void* GetOutput(SHADER_OUT_RES i) const;      // the library exposes the target written last (both enumerators return it)
+        void Render(Core::CommandList& cmdList);
+    private:
+        zr_params m_params{};
+    };
+
     struct IndirectLighting final : public RenderPassBase
     {
         enum class SHADER_OUT_RES { FINAL, COUNT };
