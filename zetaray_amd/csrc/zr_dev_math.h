@@ -14,9 +14,31 @@
 
 namespace zr {
 
-struct V2 { float x, y; };
-struct V3 { float x, y, z; };
-struct V4 { float x, y, z, w; };
+struct V2      // member-wise copies: see V3
+{
+    float x, y;
+    ZR_HDM V2() = default;
+    ZR_HDM V2(const V2& o) : x(o.x), y(o.y) {}
+    ZR_HDM V2& operator=(const V2& o) { x = o.x; y = o.y; return *this; }
+};
+// V3 has user-provided (member-wise) copy operations on purpose: for a trivially copyable struct clang lowers `c ? a : b` on V3
+// lvalues to a select of the two ADDRESSES followed by a 12-byte memcpy, which SROA cannot split -- both operands and the result then
+// stay in scratch memory (32 such temporaries in k_rpt_temporal / k_rpt_stc).  With member-wise copies the select is over loaded
+// scalars and everything is promoted to registers.
+struct V3
+{
+    float x, y, z;
+    ZR_HDM V3() = default;
+    ZR_HDM V3(const V3& o) : x(o.x), y(o.y), z(o.z) {}
+    ZR_HDM V3& operator=(const V3& o) { x = o.x; y = o.y; z = o.z; return *this; }
+};
+struct V4
+{
+    float x, y, z, w;
+    ZR_HDM V4() = default;
+    ZR_HDM V4(const V4& o) : x(o.x), y(o.y), z(o.z), w(o.w) {}
+    ZR_HDM V4& operator=(const V4& o) { x = o.x; y = o.y; z = o.z; w = o.w; return *this; }
+};
 
 ZR_HD V2 v2(float x, float y) { V2 r; r.x = x; r.y = y; return r; }
 ZR_HD V3 v3(float x, float y, float z) { V3 r; r.x = x; r.y = y; r.z = z; return r; }
@@ -235,6 +257,9 @@ ZR_HD uint32_t PackR11G11B10F(V3 c) { return PackUFloat(c.x, 6) | (PackUFloat(c.
 struct Rng
 {
     uint32_t s;
+    ZR_HDM Rng() = default;
+    ZR_HDM Rng(const Rng& o) : s(o.s) {}
+    ZR_HDM Rng& operator=(const Rng& o) { s = o.s; return *this; }
     static ZR_HDM Rng Init(uint32_t px, uint32_t py, uint32_t frame) { Rng r; uint32_t x = px, y = py, z = frame; zr_pcg3d(&x, &y, &z); r.s = x; return r; }
     static ZR_HDM Rng Seed(uint32_t seed) { Rng r; r.s = seed; return r; }
     ZR_HDM uint32_t UniformUint()
