@@ -24,13 +24,19 @@ static constexpr int kBlock = 256;
 #ifndef ZR_WAVES_PATHTRACE
 #define ZR_WAVES_PATHTRACE ZR_WAVES(3)
 #endif
+#ifndef ZR_WAVES_RGI
 #define ZR_WAVES_RGI ZR_WAVES(4)
+#endif
 #define ZR_WAVES_RDI_T ZR_WAVES(3)
 #define ZR_WAVES_RDI_S ZR_WAVES(3)
 #define ZR_WAVES_SDI_S ZR_WAVES(4)
 #define ZR_WAVES_SDI_T
-#define ZR_WAVES_TEMPORAL
-#define ZR_WAVES_STC
+#ifndef ZR_WAVES_TEMPORAL
+#define ZR_WAVES_TEMPORAL 
+#endif
+#ifndef ZR_WAVES_STC
+#define ZR_WAVES_STC 
+#endif
 static constexpr uint32_t kCounterStride = 64;     // queue counters live 256 B apart: their atomics spread over L2 channels
 // this lane's traversal stack: kTravLdsEntries entries in LDS (16 KB per 256-lane block at 8 entries), the rest in scratch
 #define ZR_TRAV_STACK(name) \
