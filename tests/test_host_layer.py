@@ -116,3 +116,45 @@ def test_cpp_passes_render_sun_sky_sequence():
         dwant = osd.render(cbs[f], wire.default_params_sky_di())
     assert np.array_equal(out.view(np.uint32), want.view(np.uint32))
     assert np.array_equal(dout.view(np.uint32), dwant.view(np.uint32))
+
+
+@pytest.mark.gpu
+def test_cpp_passes_render_post_chain():
+    """... followed by the post chain through the C++ mirror: Compositing (sky DI + indirect) -> TAA, scheduled by the RenderGraph over 4
+    frames with a jittered, moving camera: the composited image and the RGBA16F TAA output == the oracle's."""
+    import os
+    from oracle import zro
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sc = scene_io.load_npz(os.path.join(root, "tests", "golden", "cornell.npz"))
+    osc = zro.OracleScene(sc)
+    w, h, n = 80, 48, 4
+    cbl, prev = [], None
+    for f in range(1, n + 1):
+        cb = scene_io.make_frame_constants(w, h, frame_num=f, num_emissives=0, cam_pos=(0.04 * max(0, f - 2), 1.2, -4.043),
+                                           jitter=(0.2 * (f % 3 - 1), 0.2 * (f % 2 - 0.5)))
+        if prev is not None:
+            cb["prev_view"], cb["prev_view_inv"], cb["prev_camera_jitter"] = prev["curr_view"], prev["curr_view_inv"], prev["curr_camera_jitter"]
+        prev = cb.copy()
+        cbl.append(cb)
+    cbs = np.ascontiguousarray(np.stack(cbl))
+    desc = sc.desc()
+    out, dout, comp = (np.zeros((h, w, 4), np.float32) for _ in range(3))
+    taa = np.zeros((h, w, 4), np.uint16)
+    L = _lib()
+    L.zrh_render_sequence_sky_post.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int] + [C.c_void_p] * 4
+    assert L.zrh_render_sequence_sky_post(C.addressof(desc), cbs.ctypes.data, n, w, h, 2, out.ctypes.data, dout.ctypes.data, comp.ctypes.data, taa.ctypes.data) == 0
+    opt, osd = zro.OracleRPT(osc, w, h), zro.OracleSDI(osc, w, h)
+    hist = np.zeros((h, w, 4), np.uint16)
+    for f in range(n):
+        osc.sky_lut(cbs[f], 256, 128)
+        ind = opt.render(cbs[f], wire.default_params())
+        sdi = osd.render(cbs[f], wire.default_params_sky_di())
+        planes, _keep = osc.gbuffer(cbs[f])
+        # Compositing.hlsl:30-125 without accumulation: sky DI + indirect * !emissive, 0 for pixels without geometry
+        fl = planes[2].reshape(h, w) & 0xff
+        signal = np.zeros((h, w, 4), np.float32)
+        signal[..., :3] = sdi[..., :3] + ind[..., :3] * ((fl & 2) == 0)[..., None]
+        signal[(fl & 4) != 0] = 0
+        hist = zro.taa(signal, planes[7].reshape(h, w), planes[3].reshape(h, w), hist, 0.1, f > 0)
+    assert np.array_equal(comp.view(np.uint32)[..., :3], signal.view(np.uint32)[..., :3])
+    assert np.array_equal(taa[..., :3], hist[..., :3])

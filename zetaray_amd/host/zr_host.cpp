@@ -434,8 +434,17 @@ int zrh_render_sequence2(const zr_scene_desc* desc, const zr_frame_constants* cb
 
 // The reference's default (sun + sky) frame: Sky -> GBuffer -> {SkyDI, Indirect} (PathTracer.cpp:165-181, 311-360, 474-552).
 // Copies the FINAL planes of the last frame: Indirect to `finalOut`, SkyDI to `skyDiOut`.
+int zrh_render_sequence_sky_post(const zr_scene_desc* desc, const zr_frame_constants* cbs, uint32_t n, uint32_t w, uint32_t h, int integrator, float* finalOut, float* skyDiOut,
+    float* compositedOut, uint16_t* taaOut);
 int zrh_render_sequence_sky(const zr_scene_desc* desc, const zr_frame_constants* cbs, uint32_t n, uint32_t w, uint32_t h, int integrator, float* finalOut, float* skyDiOut)
+{ return zrh_render_sequence_sky_post(desc, cbs, n, w, h, integrator, finalOut, skyDiOut, nullptr, nullptr); }
+
+// ... followed by Compositing -> TAA when compositedOut / taaOut are given (DefaultRenderer's post chain, Compositing.cpp / TAA.cpp):
+// compositedOut = RGBA32F of the last frame, taaOut = RGBA16F bits of the last frame
+int zrh_render_sequence_sky_post(const zr_scene_desc* desc, const zr_frame_constants* cbs, uint32_t n, uint32_t w, uint32_t h, int integrator, float* finalOut, float* skyDiOut,
+    float* compositedOut, uint16_t* taaOut)
 {
+    const bool post = compositedOut || taaOut;
     RenderPass::FrameContext ctx;
     ctx.device = 0; ctx.renderWidth = w; ctx.renderHeight = h;
     ZR_CHECK(zr_scene_create(0, desc, &ctx.scene));
@@ -443,8 +452,16 @@ int zrh_render_sequence_sky(const zr_scene_desc* desc, const zr_frame_constants*
     {
         RenderPass::Sky sky; RenderPass::GBufferRT gb; RenderPass::IndirectLighting ind; RenderPass::SkyDI sdi;
         sky.Init(&ctx, 256, 128); gb.Init(&ctx); ind.Init(&ctx, (RenderPass::IndirectLighting::INTEGRATOR)integrator); sdi.Init(&ctx);
+        RenderPass::Compositing comp; RenderPass::TAA taa;
+        if (post)
+        {
+            comp.Init(&ctx); taa.Init(&ctx);
+            comp.SetGpuDescriptor(RenderPass::Compositing::SHADER_IN_GPU_DESC::SKY_DI, sdi.GetOutput(RenderPass::SkyDI::SHADER_OUT_RES::DENOISED));
+            comp.SetGpuDescriptor(RenderPass::Compositing::SHADER_IN_GPU_DESC::INDIRECT, ind.GetOutput(RenderPass::IndirectLighting::SHADER_OUT_RES::FINAL));
+            taa.SetCPUDescriptor(RenderPass::TAA::SHADER_IN_CPU_DESC::SIGNAL, comp.GetOutput(RenderPass::Compositing::SHADER_OUT_RES::COMPOSITED));
+        }
         Core::RenderGraph g;
-        enum : uint64_t { R_LUT = 1, R_GBUF, R_IND, R_SDI };
+        enum : uint64_t { R_LUT = 1, R_GBUF, R_IND, R_SDI, R_COMP, R_TAA };
         for (uint32_t f = 0; f < n; f++)
         {
             ctx.frameConstants = cbs[f];
@@ -456,16 +473,32 @@ int zrh_render_sequence_sky(const zr_scene_desc* desc, const zr_frame_constants*
             g.RegisterResource(sky.GetOutput(RenderPass::Sky::SHADER_OUT_RES::SKY_VIEW_LUT), R_LUT); g.RegisterResource(nullptr, R_GBUF);
             g.RegisterResource(ind.GetOutput(RenderPass::IndirectLighting::SHADER_OUT_RES::FINAL), R_IND);
             g.RegisterResource(sdi.GetOutput(RenderPass::SkyDI::SHADER_OUT_RES::DENOISED), R_SDI);
+            Core::RenderNodeHandle hComp{}, hTaa{};
+            if (post)
+            {
+                hComp = g.RegisterRenderPass("Compositing", Core::RENDER_NODE_TYPE::COMPUTE, Core::MakeDelegate(&comp, &RenderPass::Compositing::Render));
+                hTaa = g.RegisterRenderPass("TAA", Core::RENDER_NODE_TYPE::COMPUTE, Core::MakeDelegate(&taa, &RenderPass::TAA::Render));
+                g.RegisterResource(comp.GetOutput(RenderPass::Compositing::SHADER_OUT_RES::COMPOSITED), R_COMP);
+                g.RegisterResource(nullptr, R_TAA);       // ping-pong target: identified by its path id, like the reference's dummy resources
+            }
             g.MoveToPostRegister();
             g.AddOutput(hSky, R_LUT, Core::STATE_UNORDERED_ACCESS);
             g.AddOutput(hGB, R_GBUF, Core::STATE_UNORDERED_ACCESS);
             g.AddInput(hSdi, R_LUT, Core::STATE_SHADER_READ); g.AddInput(hSdi, R_GBUF, Core::STATE_SHADER_READ); g.AddOutput(hSdi, R_SDI, Core::STATE_UNORDERED_ACCESS);
             g.AddInput(hInd, R_LUT, Core::STATE_SHADER_READ); g.AddInput(hInd, R_GBUF, Core::STATE_SHADER_READ); g.AddOutput(hInd, R_IND, Core::STATE_UNORDERED_ACCESS);
+            if (post)
+            {
+                g.AddInput(hComp, R_SDI, Core::STATE_SHADER_READ); g.AddInput(hComp, R_IND, Core::STATE_SHADER_READ); g.AddInput(hComp, R_GBUF, Core::STATE_SHADER_READ);
+                g.AddOutput(hComp, R_COMP, Core::STATE_UNORDERED_ACCESS);
+                g.AddInput(hTaa, R_COMP, Core::STATE_SHADER_READ); g.AddInput(hTaa, R_GBUF, Core::STATE_SHADER_READ); g.AddOutput(hTaa, R_TAA, Core::STATE_UNORDERED_ACCESS);
+            }
             Support::TaskSet ts;
             g.Build(ts);
             ts.Run(true);
             g.WaitForFrame();
         }
+        if (compositedOut && hipMemcpy(compositedOut, comp.GetOutput(RenderPass::Compositing::SHADER_OUT_RES::COMPOSITED), (size_t)w * h * 16, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+        if (taaOut && hipMemcpy(taaOut, taa.GetOutput(RenderPass::TAA::SHADER_OUT_RES::OUTPUT_A), (size_t)w * h * 8, hipMemcpyDeviceToHost) != hipSuccess) return -1;
         if (hipMemcpy(finalOut, ind.GetOutput(RenderPass::IndirectLighting::SHADER_OUT_RES::FINAL), (size_t)w * h * 16, hipMemcpyDeviceToHost) != hipSuccess) return -1;
         if (skyDiOut && hipMemcpy(skyDiOut, sdi.GetOutput(RenderPass::SkyDI::SHADER_OUT_RES::DENOISED), (size_t)w * h * 16, hipMemcpyDeviceToHost) != hipSuccess) return -1;
     }
