@@ -1,11 +1,14 @@
 """GPU parity tests proper: the HIP path through the C-ABI vs the CPU oracle, bit-exact (ABI arithmetic contract,
 include/zr_detmath.h).  Run on the GPU box with -m gpu."""
+import os
+
 import numpy as np
 import pytest
 
 from zetaray_amd import scene_io, wire
 
 pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 @pytest.fixture(scope="module")
@@ -780,3 +783,23 @@ def test_half_conversion_instructions_match_portable_code(api):
     L.zr_selftest_half_conversions.argtypes = [C.c_int, C.c_void_p, C.c_void_p]
     assert L.zr_selftest_half_conversions(0, C.byref(a), C.byref(b)) == 0
     assert (a.value, b.value) == (0, 0)
+
+
+def test_restir_pt_large_scene_kernel_build_on_gpu():
+    """K11 has a second build for scenes whose BVH exceeds the caches (4 waves per SIMD, zr_kernels.h); ZR_LARGE_SCENE_NODES=1 selects it
+    for the small test scene, in a fresh process (the threshold is read once): same bit-exact comparison as the materials / RR test."""
+    import subprocess
+    import sys
+    code = (
+        "import sys; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+        "from oracle import zro\n"
+        "from zetaray_amd import api, scene_io, wire\n"
+        "import test_gpu_parity as T\n"
+        "sc = scene_io.make_synthetic_scene(num_tris=3000, num_emissive=1500, seed=11)\n"
+        "o = zro.OracleScene(sc, force_bvh=True)\n"
+        "prm = wire.default_params(); prm.max_non_tr_bounces, prm.max_glossy_tr_bounces = 6, 8\n"
+        "T._rpt_compare(api, sc, o, 96, 64, prm, 3, cam=dict(cam_pos=(0, 0, -3.5)))\n"
+        "print('LARGE_OK')\n") % (ROOT, os.path.join(ROOT, "tests"))
+    env = dict(os.environ, ZR_LARGE_SCENE_NODES="1")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "LARGE_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]

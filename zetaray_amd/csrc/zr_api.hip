@@ -505,6 +505,7 @@ struct QueueStorage
     }
 };
 
+static constexpr uint32_t kLargeSceneNodes = 16384;     // BVH4 nodes (64 B each): 1 MB of nodes and up counts as "does not fit the caches"
 static constexpr int kMaxRounds = 16;
 static constexpr int kMaxTimers = 64;
 // ray-counter slots (pairs of u64 on the device): 0 = wavefront path tracer, 1.. = ReSTIR PT kernels in launch order
@@ -1298,6 +1299,8 @@ static int RenderReSTIR_PT(zr_pass* p, hipStream_t s, const zr_frame_constants* 
 #define RPT_TIMED(name, launch) do { TimerBegin(p, s, name); launch; TimerEnd(p, s); } while (0)
     // the NEE_EMISSIVE permutation of a kernel (the reference compiles separate shaders, IndirectLighting.h:251-300)
     const bool emissiveVariant = prm.emissive != 0;
+    // (ZR_LARGE_SCENE_NODES: test hook, lets the parity tests run the large-scene kernel build on their small scenes)
+    static const uint32_t largeSceneNodes = [] { const char* e = getenv("ZR_LARGE_SCENE_NODES"); return e ? (uint32_t)atoi(e) : kLargeSceneNodes; }();
     // ... and the TEXTURED permutation (this ABI's: untextured scenes carry no ray differentials)
     const bool texVariant = prm.textured != 0;
 #define RPT_LAUNCH_E(kern, ...) do { \
@@ -1311,6 +1314,8 @@ static int RenderReSTIR_PT(zr_pass* p, hipStream_t s, const zr_frame_constants* 
         HIP_TRY(hipMemsetAsync(listCnt, 0, 4 * sizeof(uint32_t), s));
         TimerBegin(p, s, "rpt_pathtrace");
         if (texVariant) { if (emissiveVariant) hipLaunchKernelGGL(k_rpt_pathtrace_tex<true>, grid, block, 0, s, F, *cb, tilesX, ctr + 2 * 1); else hipLaunchKernelGGL(k_rpt_pathtrace_tex<false>, grid, block, 0, s, F, *cb, tilesX, ctr + 2 * 1); }
+        else if (sc->view.numNodes >= largeSceneNodes)     // BVH beyond the caches: the 4-wave build of K11 (zr_kernels.h)
+        { if (emissiveVariant) hipLaunchKernelGGL(k_rpt_pathtrace_w4<true>, grid, block, 0, s, F, *cb, tilesX, ctr + 2 * 1); else hipLaunchKernelGGL(k_rpt_pathtrace_w4<false>, grid, block, 0, s, F, *cb, tilesX, ctr + 2 * 1); }
         else { if (emissiveVariant) hipLaunchKernelGGL(k_rpt_pathtrace<true>, grid, block, 0, s, F, *cb, tilesX, ctr + 2 * 1); else hipLaunchKernelGGL(k_rpt_pathtrace<false>, grid, block, 0, s, F, *cb, tilesX, ctr + 2 * 1); }
         TimerEnd(p, s);
         if (prm.doTemporal)

@@ -134,6 +134,12 @@ __device__ __forceinline__ void RptPathtraceBody(rpt::RptFrame& F, const zr_fram
 template<bool EMISSIVE>
 __global__ void __launch_bounds__(kBlock) ZR_WAVES_PATHTRACE k_rpt_pathtrace(rpt::RptFrame F, zr_frame_constants g, uint32_t tilesX, unsigned long long* counters)
 { RptPathtraceBody<EMISSIVE, false>(F, g, tilesX, counters); }
+// The same kernel at 4 waves per SIMD (128 VGPRs, more spills): used for scenes whose BVH does not fit the caches, where the inline
+// traversal is latency-bound and the extra wave hides more than the spills cost (380 k-triangle atrium: 11.7 -> 10.6 ms; on the
+// 58-triangle Cornell box both take 1.16 ms, and the 3-wave build moves 5x less spill traffic, so small scenes keep it).
+template<bool EMISSIVE>
+__global__ void __launch_bounds__(kBlock) ZR_WAVES(4) k_rpt_pathtrace_w4(rpt::RptFrame F, zr_frame_constants g, uint32_t tilesX, unsigned long long* counters)
+{ RptPathtraceBody<EMISSIVE, false>(F, g, tilesX, counters); }
 // The TEXTURED permutation keeps the compiler's default occupancy: forced to 3 waves (amdgpu_waves_per_eu(3, 3): ~150 spilled
 // VGPRs), ROCm 7.2's clang miscompiles the <sun + sky, textured> instance -- the y / z components of the reconnection radiance
 // rc.L of case-1 samples are written as 0 in ~70 % of the pixels (-O2 and -fno-vectorize change nothing, dropping the attribute
@@ -233,6 +239,7 @@ __global__ void __launch_bounds__(kBlock) ZR_WAVES_STC k_rpt_stc(rpt::RptFrame F
 #define ZR_RPT_ARGS_LIST (rpt::RptFrame, zr_frame_constants, const uint32_t*, const uint32_t*, unsigned long long*)
 #define ZR_RPT_GROUP_A(X) \
     X __global__ void k_rpt_pathtrace<true> ZR_RPT_ARGS_TILE; X __global__ void k_rpt_pathtrace<false> ZR_RPT_ARGS_TILE; \
+    X __global__ void k_rpt_pathtrace_w4<true> ZR_RPT_ARGS_TILE; X __global__ void k_rpt_pathtrace_w4<false> ZR_RPT_ARGS_TILE; \
     X __global__ void k_rpt_pathtrace_tex<true> ZR_RPT_ARGS_TILE; X __global__ void k_rpt_pathtrace_tex<false> ZR_RPT_ARGS_TILE; \
     X __global__ void k_rpt_temporal<true, true> ZR_RPT_ARGS_TILE; X __global__ void k_rpt_temporal<true, false> ZR_RPT_ARGS_TILE; \
     X __global__ void k_rpt_temporal<false, true> ZR_RPT_ARGS_TILE; X __global__ void k_rpt_temporal<false, false> ZR_RPT_ARGS_TILE;
