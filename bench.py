@@ -222,7 +222,11 @@ def main():
         cq = q.read_counters(reset=True)
         c3[0] += cq[0]
         c3[1] += cq[1]
-    rays = np.array([c1[0] + c2[0] + c3[0], c1[1] + c2[1] + c3[1]], np.float64)
+    # primary rays: RenderGBuffer counts every pixel of the G-buffer it renders, which in tiled mode includes the 32-px apron around
+    # the owned tile (rendered redundantly on every neighbour).  Only owned pixels are useful work: report those, and the
+    # redundant apron rays separately.
+    apron_rays = max(0, c1[0] - tw * th * args.steps) if (tiled is not None and world > 1) else 0
+    rays = np.array([c1[0] - apron_rays + c2[0] + c3[0], c1[1] + c2[1] + c3[1]], np.float64)
     tmax = dt
     if dist is not None:
         tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
@@ -231,6 +235,9 @@ def main():
         rr = torch.tensor(rays, dtype=torch.float64, device="cuda")
         dist.all_reduce(rr, op=dist.ReduceOp.SUM)
         rays = rr.cpu().numpy()
+        ar = torch.tensor([float(apron_rays)], dtype=torch.float64, device="cuda")
+        dist.all_reduce(ar, op=dist.ReduceOp.SUM)
+        apron_rays = float(ar.item())
     n_closest, n_shadow = float(rays[0]), float(rays[1])
     ms_per_step = tmax / args.steps * 1e3
     mrays = (n_closest + n_shadow) / tmax / 1e6
@@ -256,6 +263,7 @@ def main():
                        f"rank per exchange, {(1 if args.no_final_halo else 2) if rpt else (0 if args.no_final_halo else 1)} exchanges per frame"
                        if (tiled is not None and world > 1) else ""),
                    "rays_per_frame": round((n_closest + n_shadow) / args.steps, 1),
+                   "redundant_apron_primary_rays_per_frame": round(apron_rays / args.steps, 1),
                    "fps": round(1e3 / ms_per_step, 2)},
     }
 

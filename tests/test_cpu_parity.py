@@ -168,6 +168,27 @@ def test_golden_render(oracle_emissive, cornell_emissive):
     assert tuple(cnt) == tuple(g["counters"])
 
 
+@pytest.mark.parametrize("scene_name,golden", [("cornell.npz", "config1_cornell_256.npz"), ("cornell_emissive.npz", "config1_cornell_emissive_256.npz")])
+def test_golden_config1_256(scene_name, golden):
+    """BASELINE config 1 (256 x 256, K9 1 spp, frame 1, jitter off, default sun) for both Cornell scenes: the oracle
+    reproduces the committed fixtures (tools/make_goldens.py) -- G-buffer planes, sky-view LUT, FINAL, ray counters.  The GPU test
+    test_baseline_config1_goldens_on_gpu checks the HIP path against the same files."""
+    from oracle import zro
+    sc = scene_io.load_npz(os.path.join(ROOT, "tests", "golden", scene_name))
+    o = zro.OracleScene(sc)
+    g = np.load(os.path.join(ROOT, "tests", "golden", golden))
+    cb = scene_io.make_frame_constants(256, 256, frame_num=1, num_emissives=len(sc.emissives))
+    if "sky_lut" in g.files:
+        assert np.array_equal(o.sky_lut(cb, 256, 128), g["sky_lut"])
+    arrays, planes = o.gbuffer(cb)
+    for name, a in zip(wire.GB_PLANE_NAMES, arrays):
+        assert np.array_equal(a, g["gb_" + name]), name
+    final, cnt = o.pathtrace(cb, planes, wire.default_params())
+    assert np.array_equal(final.view(np.uint32), g["final"].view(np.uint32))
+    assert tuple(cnt) == tuple(g["counters"])
+    assert final[..., :3].max() > 0
+
+
 # ------------------------------------------------------------------ C-ABI surface
 def test_abi_exports_every_declared_symbol():
     hdr = open(os.path.join(ROOT, "include", "zetaray_amd.h")).read()

@@ -803,3 +803,100 @@ def test_restir_pt_large_scene_kernel_build_on_gpu():
     env = dict(os.environ, ZR_LARGE_SCENE_NODES="1")
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "LARGE_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+# ------------------------------------------------------------------ parity on the BASELINE configurations
+def test_baseline_config_cornell_1080p_restir_pt_bit_exact(api, cornell_emissive, oracle_emissive):
+    """The bench workload itself: Cornell (emissive) 1920 x 1080, ReSTIR PT defaults (3 / 4 bounces, temporal + spatial reuse, boiling
+    suppression), frames 1-3, FULL frame vs the oracle, tolerance 0: radiance, the 7 persistent reservoir planes + spatial neighbour
+    plane, and the ray counters of every frame (IndirectLighting.cpp:877-1004)."""
+    got = _rpt_compare(api, cornell_emissive, oracle_emissive, 1920, 1080, wire.default_params(), 3)
+    assert got[..., :3].max() > 0
+
+
+@pytest.fixture(scope="module")
+def atrium():
+    """BASELINE config 4's scene class (bench.py --scene synthetic): 380 588 triangles of which 100 000 emissive"""
+    from oracle import zro
+    sc = scene_io.make_synthetic_scene(num_tris=262144, num_emissive=100000, layout="atrium")
+    return sc, zro.OracleScene(sc, force_bvh=True)
+
+
+def test_baseline_config_atrium_restir_pt_bit_exact(api, atrium):
+    """The 380k-triangle / 100k-light atrium with the presampled light sets the reference would use (128 x 512, PreLighting.cpp:289-297)
+    at 480 x 270 for 3 frames, ZR_LARGE_SCENE_NODES at its default: the BVH has >= 16k nodes, so the 4-wave build of K11
+    (k_rpt_pathtrace_w4) and traversal stacks deeper than the 8 LDS entries really run.  Radiance, reservoir planes, counters: tolerance 0."""
+    sc, o = atrium
+    handle = api.Scene(sc)
+    nodes, tris, depth = handle.bvh_info()
+    handle.close()
+    assert nodes >= 16384 and tris == sc.num_tris, (nodes, tris)
+    assert int(os.environ.get("ZR_LARGE_SCENE_NODES", "16384")) == 16384, "this test must run with the default large-scene threshold"
+    prm = wire.default_params()
+    prm.presampling, prm.num_sample_sets, prm.sample_set_size = 1, 128, 512
+    w, h = 480, 270
+    from oracle import zro
+    r = api.Renderer(sc, w, h, params=prm, integrator=api.INTEGRATOR_RESTIR_PT)
+    orpt = zro.OracleRPT(o, w, h)
+    for f in (1, 2, 3):
+        cb = _frame(sc, w, h, f, cam_pos=(0, 0, -3.5))
+        o.presample(f, 128, 512)
+        r.p_indirect.read_counters(reset=True)
+        r.render_frame(cb)
+        got = r.final()
+        want = orpt.render(cb, prm)
+        assert r.p_indirect.read_counters() == orpt.counters, f"frame {f}: ray counters differ"
+        mism = int((got.view(np.uint32) != want.view(np.uint32)).any(axis=2).sum())
+        assert mism == 0, f"frame {f}: {mism} pixels differ, max abs {np.abs(got - want).max()}"
+        for nm in RPT_PLANES:
+            a, b = r.p_indirect.download_plane(nm), orpt.plane(nm)
+            if nm == "A":
+                a, b = a & 0xffffff, b & 0xffffff
+            assert np.array_equal(a.view(np.uint8), b.view(np.uint8)), f"frame {f}: reservoir plane {nm} differs"
+    assert got[..., :3].max() > 0
+    # k > 2 reconnections (replay work lists) must be live on this scene
+    k = (r.p_indirect.download_plane("A")[..., 0] & 0xf)
+    assert (k > 0).any()
+
+
+def test_baseline_config_atrium_path_tracer_and_gi_bit_exact(api, atrium):
+    """Same scene, the wavefront K9 path tracer and ReSTIR GI (K10) at 320 x 180, 2 frames each."""
+    from oracle import zro
+    sc, o = atrium
+    prm = wire.default_params()
+    prm.presampling, prm.num_sample_sets, prm.sample_set_size = 1, 128, 512
+    w, h = 320, 180
+    rp = api.Renderer(sc, w, h, params=prm)
+    rg = api.Renderer(sc, w, h, params=prm, integrator=api.INTEGRATOR_RESTIR_GI)
+    ogi = zro.OracleRGI(o, w, h)
+    for f in (1, 2):
+        cb = _frame(sc, w, h, f, cam_pos=(0, 0, -3.5))
+        o.presample(f, 128, 512)
+        rp.render_frame(cb)
+        _, planes = o.gbuffer(cb)
+        want, cnt = o.pathtrace(cb, planes, prm)
+        assert np.array_equal(rp.final().view(np.uint32), want.view(np.uint32)), f"K9 frame {f}"
+        assert rp.p_indirect.read_counters() == (cnt[0], cnt[1])
+        rg.render_frame(cb)
+        wantg = ogi.render(cb, prm)
+        assert np.array_equal(rg.final().view(np.uint32), wantg.view(np.uint32)), f"ReSTIR GI frame {f}"
+
+
+@pytest.mark.parametrize("scene_name,golden", [("cornell.npz", "config1_cornell_256.npz"), ("cornell_emissive.npz", "config1_cornell_emissive_256.npz")])
+def test_baseline_config1_goldens_on_gpu(api, scene_name, golden):
+    """BASELINE config 1 (256 x 256, K9, 1 spp, frame 1, jitter off, default sun) against the COMMITTED fixtures of tests/golden/
+    (tools/make_goldens.py): G-buffer planes, sky-view LUT, FINAL and ray counters, both Cornell scenes."""
+    sc = scene_io.load_npz(os.path.join(ROOT, "tests", "golden", scene_name))
+    g = np.load(os.path.join(ROOT, "tests", "golden", golden))
+    w = h = 256
+    cb = scene_io.make_frame_constants(w, h, frame_num=1, num_emissives=len(sc.emissives))
+    r = api.Renderer(sc, w, h, params=wire.default_params())
+    r.render_frame(cb)
+    planes, _ = r.gbuffer.download()
+    for name, a in zip(wire.GB_PLANE_NAMES, planes):
+        assert np.array_equal(a.view(np.uint8), g["gb_" + name].view(np.uint8)), f"G-buffer plane {name} differs from the golden"
+    if "sky_lut" in g.files:
+        assert np.array_equal(r.p_sky.download_plane("sky_lut")[..., 0], g["sky_lut"])
+    got = r.final()
+    assert np.array_equal(got.view(np.uint32), g["final"].view(np.uint32))
+    assert tuple(r.p_indirect.read_counters()) == tuple(int(x) for x in g["counters"])

@@ -94,6 +94,33 @@ def test_cpp_passes_render_gi_and_di_sequence(cornell_emissive, oracle_emissive)
 
 
 @pytest.mark.gpu
+def test_cpp_passes_render_with_light_presampling():
+    """PreLighting::SetLightPresamplingParams through the C++ mirror: K3 regenerates the presampled sets every frame (seeded by
+    FrameNum) and Indirect (ReSTIR PT) + DirectLighting read them; 3 frames scheduled by the RenderGraph == the oracle's frame 3."""
+    from oracle import zro
+    sc = scene_io.make_synthetic_scene(num_tris=3000, num_emissive=1500, seed=11)
+    o = zro.OracleScene(sc, force_bvh=True)
+    w, h, n = 96, 64, 3
+    cbs = np.ascontiguousarray(np.stack([scene_io.make_frame_constants(w, h, frame_num=f, num_emissives=len(sc.emissives), cam_pos=(0, 0, -3.5))
+                                         for f in range(1, n + 1)]))
+    desc = sc.desc()
+    out, dout = np.zeros((h, w, 4), np.float32), np.zeros((h, w, 4), np.float32)
+    L = _lib()
+    L.zrh_render_sequence3.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int]
+    assert L.zrh_render_sequence3(C.addressof(desc), cbs.ctypes.data, n, w, h, 2, out.ctypes.data, dout.ctypes.data, 32, 128) == 0
+    ip, dp = wire.default_params(), wire.default_params_di()
+    for q in (ip, dp):
+        q.presampling, q.num_sample_sets, q.sample_set_size = 1, 32, 128
+    opt, odi = zro.OracleRPT(o, w, h), zro.OracleRDI(o, w, h)
+    for f in range(n):
+        o.presample(f + 1, 32, 128)
+        want = opt.render(cbs[f], ip)
+        dwant = odi.render(cbs[f], dp)
+    assert np.array_equal(out.view(np.uint32), want.view(np.uint32))
+    assert np.array_equal(dout.view(np.uint32), dwant.view(np.uint32))
+
+
+@pytest.mark.gpu
 def test_cpp_passes_render_sun_sky_sequence():
     """The reference's default frame through the C++ mirror: Sky (K17) -> GBuffer -> {SkyDI (K7/K8), Indirect (ReSTIR PT, sun + sky NEE)}
     scheduled by the RenderGraph for 3 frames == the oracle's frame 3 of both."""

@@ -20,3 +20,26 @@ out["final"] = final
 out["counters"] = np.array(cnt, np.uint64)
 np.savez_compressed(os.path.join(ROOT, "tests", "golden", "render_emissive_64.npz"), **out)
 print("ok", final[..., :3].mean())
+
+
+def config1(scene_name, out_name, w=256, h=256):
+    """BASELINE config 1: the Cornell box at 256x256, camera (0, 1.2, -4.043) looking down +z, vfov 60 deg, jitter off,
+    PATH_TRACING (K9) 1 spp, FrameNum 1, Accumulate 0, the reference's default sun / atmosphere.  Stores the oracle's G-buffer planes, the
+    sky-view LUT (sun + sky scene only), FINAL and the ray counters."""
+    scn = scene_io.load_npz(os.path.join(ROOT, "tests", "golden", scene_name))
+    osc = zro.OracleScene(scn)
+    cbf = scene_io.make_frame_constants(w, h, frame_num=1, num_emissives=len(scn.emissives))
+    res = {}
+    if len(scn.emissives) == 0:
+        res["sky_lut"] = osc.sky_lut(cbf, 256, 128)
+    arr, pl = osc.gbuffer(cbf)
+    fin, c = osc.pathtrace(cbf, pl, wire.default_params())
+    res.update({"gb_" + n: a for n, a in zip(wire.GB_PLANE_NAMES, arr)})
+    res["final"] = fin
+    res["counters"] = np.array(c, np.uint64)
+    np.savez_compressed(os.path.join(ROOT, "tests", "golden", out_name), **res)
+    print(out_name, "ok", fin[..., :3].mean(), c)
+
+
+config1("cornell.npz", "config1_cornell_256.npz")
+config1("cornell_emissive.npz", "config1_cornell_emissive_256.npz")

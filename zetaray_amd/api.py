@@ -330,10 +330,20 @@ class Renderer:
             prm = wire.default_params()
             prm.flags |= wire.COMPOSIT_FIREFLY_FILTER
         self.p_composit = Pass(PASS_COMPOSITING, self.p_indirect.w, self.p_indirect.h_, device=device, params=prm)
-        self.p_composit.set_input(IN_INDIRECT, self.p_indirect.output_ptr()[0])
-        if self.p_direct is not None:
-            self.p_composit.set_input(IN_EMISSIVE_DI, self.p_direct.output_ptr()[0])
+        self._bind_post_inputs()
         return self.p_composit
+
+    def _bind_post_inputs(self):
+        """(re)bind the Compositing / TAA inputs to the current output planes of the lighting passes: called whenever a pass is
+        added and at the start of every frame (output pointers change on Pass.resize; a term whose pass is absent stays unbound,
+        which CompositePixel treats as 'term absent')"""
+        if self.p_composit is None:
+            return
+        self.p_composit.set_input(IN_INDIRECT, None if self.skip_indirect else self.p_indirect.output_ptr()[0])
+        self.p_composit.set_input(IN_EMISSIVE_DI, self.p_direct.output_ptr()[0] if self.p_direct is not None else None)
+        self.p_composit.set_input(IN_SKY_DI, self.p_sky_direct.output_ptr()[0] if self.p_sky_direct is not None else None)
+        if getattr(self, "p_taa", None) is not None:
+            self.p_taa.set_input(IN_TAA_SIGNAL, self.p_composit.output_ptr()[0])
 
     def enable_taa(self, blend_weight=0.1, device=0):
         """add the TAA pass on the composited image (adds the Compositing pass if it is not there yet); read it with
@@ -343,7 +353,7 @@ class Renderer:
         prm = wire.default_params()
         prm.taa_blend_weight = blend_weight
         self.p_taa = Pass(PASS_TAA, self.p_indirect.w, self.p_indirect.h_, device=device, params=prm)
-        self.p_taa.set_input(IN_TAA_SIGNAL, self.p_composit.output_ptr()[0])
+        self._bind_post_inputs()
         return self.p_taa
 
     def enable_sky_direct(self, params=None, device=0):
@@ -351,11 +361,13 @@ class Renderer:
         if self.p_sky is None:
             self.p_sky = Pass(PASS_SKY, 256, 128, device=device)
         self.p_sky_direct = Pass(PASS_DI_SKY, self.p_indirect.w, self.p_indirect.h_, device=device, params=params)
+        self._bind_post_inputs()
         return self.p_sky_direct
 
     def enable_direct(self, params=None, device=0):
         """add the DirectLighting (ReSTIR DI, emissive) pass; it renders after PreLighting, next to Indirect"""
         self.p_direct = Pass(PASS_DI_EMISSIVE, self.p_indirect.w, self.p_indirect.h_, device=device, params=params)
+        self._bind_post_inputs()
         return self.p_direct
 
     _SKY_FIELDS = ("sun_dir", "sun_illuminance", "planet_radius", "atmosphere_altitude", "g", "rayleigh_sigma_s_color", "rayleigh_sigma_s_scale",
@@ -371,6 +383,7 @@ class Renderer:
             self._sky_key = key
 
     def render_frame(self, cb, stream=None):
+        self._bind_post_inputs()
         self.render_sky(cb, stream)
         self.p_gbuffer.render(cb, self.scene, self.gbuffer, stream)
         if not self._alias_ready or self._presampling:      # presampled light sets are regenerated every frame (K3)

@@ -12,6 +12,7 @@
 #include <cstdarg>
 #include <cstring>
 #include <new>
+#include <mutex>
 #include "zr_stages.h"
 #include "zr_rpt.h"
 #include "zr_rdi.h"
@@ -440,12 +441,28 @@ struct zr_scene
     DevBuf<zr_presampled_tri> sampleSets; uint32_t numSampleSets = 0;      // K3 output, refreshed by every PRELIGHTING render
     DevBuf<zr_voxel_sample> lvg;                                           // K4 output, rebuilt by every PRELIGHTING render when use_lvg
     std::vector<zr_alias_entry> aliasHost;
-    // `view` is what kernels receive by value; its texture descriptor-table offsets are latched from the frame constants
-    // of each zr_pass_render call (they are per-frame data in the reference, FrameConstants.h:31-34)
-    mutable SceneView view{};
+    // `view` is what kernels receive by value.  Passes of one dependency level may record concurrently from several host threads
+    // (RenderGraph.cpp:442-541) while Sky / PreLighting publish scene-owned state (sky LUT, alias table, presampled sets, LVG):
+    // every reader takes a private copy through FrameView() and every writer updates `view` under `mtx`.
+    SceneView view{};
+    mutable std::mutex mtx;
     int64_t maxTex[4] = {-1, -1, -1, -1};     // largest tex16 used per table (base colour, normal, metallic-roughness, emissive)
     uint32_t maxDepth = 0;
 };
+
+// The scene as one launch sees it: a private copy of the scene's view with the texture descriptor-table offsets of THIS frame's
+// constants (per-frame data in the reference, FrameConstants.h:31-34) -- nothing per-frame is latched on the shared scene.
+static SceneView FrameView(const zr_scene* sc, const zr_frame_constants* cb)
+{
+    std::lock_guard<std::mutex> lock(sc->mtx);
+    SceneView v = sc->view;
+    if (cb)
+    {
+        v.baseColorMapsOffset = cb->base_color_maps_desc_heap_offset; v.normalMapsOffset = cb->normal_maps_desc_heap_offset;
+        v.mrMapsOffset = cb->metallic_roughness_maps_desc_heap_offset; v.emissiveMapsOffset = cb->emissive_maps_desc_heap_offset;
+    }
+    return v;
+}
 
 struct zr_gbuffer
 {
@@ -786,6 +803,7 @@ int zr_scene_set_alias_table(zr_scene* s, const zr_alias_entry* e, uint32_t n)
     HIP_TRY(hipSetDevice(s->device));
     int r = s->alias.Upload(e, n);
     if (r) return r;
+    std::lock_guard<std::mutex> lock(s->mtx);
     s->aliasHost.assign(e, e + n);
     s->view.alias = s->alias.p;
     return ZR_OK;
@@ -1042,7 +1060,7 @@ static int RenderGBuffer(zr_pass* p, hipStream_t s, const zr_frame_constants* cb
     const uint32_t tilesX = (gb->w + 15) / 16, tilesY = (gb->h + 15) / 16;
     gb->cur ^= 1; gb->numRendered++;
     TimerBegin(p, s, "gbuffer");
-    hipLaunchKernelGGL(k_gbuffer, dim3(tilesX * tilesY), dim3(kBlock), 0, s, sc->view, *cb, gb->View(), tilesX);
+    hipLaunchKernelGGL(k_gbuffer, dim3(tilesX * tilesY), dim3(kBlock), 0, s, FrameView(sc, cb), *cb, gb->View(), tilesX);
     TimerEnd(p, s);
     HIP_TRY(hipGetLastError());
     p->hostCounters.n_closest += (uint64_t)gb->w * gb->h;
@@ -1056,7 +1074,7 @@ static int RenderSky(zr_pass* p, hipStream_t s, const zr_frame_constants* cb, zr
     hipLaunchKernelGGL(k_sky_lut, dim3((p->w + 7) / 8, (p->h + 7) / 8), dim3(64), 0, s, *cb, p->w, p->h, p->skyLut.p);
     TimerEnd(p, s);
     HIP_TRY(hipGetLastError());
-    sc->view.sky.data = p->skyLut.p; sc->view.sky.w = p->w; sc->view.sky.h = p->h;
+    { std::lock_guard<std::mutex> lock(sc->mtx); sc->view.sky.data = p->skyLut.p; sc->view.sky.w = p->w; sc->view.sky.h = p->h; }
     return ZR_OK;
 }
 
@@ -1065,10 +1083,13 @@ static int RenderPresample(zr_pass* p, hipStream_t s, const zr_frame_constants* 
 {
     const uint32_t total = p->params.num_sample_sets * p->params.sample_set_size;
     if (sc->sampleSets.n != total) { int r = sc->sampleSets.Alloc(total); if (r) return r; }
-    sc->numSampleSets = p->params.num_sample_sets;
-    sc->view.sampleSets = sc->sampleSets.p; sc->view.sampleSetSize = p->params.sample_set_size;
+    {
+        std::lock_guard<std::mutex> lock(sc->mtx);
+        sc->numSampleSets = p->params.num_sample_sets;
+        sc->view.sampleSets = sc->sampleSets.p; sc->view.sampleSetSize = p->params.sample_set_size;
+    }
     TimerBegin(p, s, "presample_emissives");
-    hipLaunchKernelGGL(k_presample, dim3((total + 63) / 64), dim3(64), 0, s, sc->view, total, cb->frame_num, sc->view.numEmissives, sc->sampleSets.p);
+    hipLaunchKernelGGL(k_presample, dim3((total + 63) / 64), dim3(64), 0, s, FrameView(sc, cb), total, cb->frame_num, sc->view.numEmissives, sc->sampleSets.p);
     TimerEnd(p, s);
     HIP_TRY(hipGetLastError());
     return ZR_OK;
@@ -1082,10 +1103,11 @@ static int RenderLVG(zr_pass* p, hipStream_t s, const zr_frame_constants* cb, zr
     const size_t total = (size_t)dx * dy * dz * ZR_LVG_SAMPLES_PER_VOXEL;
     if (sc->lvg.n != total) { int r = sc->lvg.Alloc(total); if (r) return r; }
     TimerBegin(p, s, "build_lvg");
-    hipLaunchKernelGGL(k_build_lvg, dim3(dx, dy, dz), dim3(64), 0, s, sc->view, *cb, dx, dy, dz, ip.lvg_extents[0], ip.lvg_extents[1], ip.lvg_extents[2],
+    hipLaunchKernelGGL(k_build_lvg, dim3(dx, dy, dz), dim3(64), 0, s, FrameView(sc, cb), *cb, dx, dy, dz, ip.lvg_extents[0], ip.lvg_extents[1], ip.lvg_extents[2],
         ip.lvg_offset_y, sc->lvg.p);
     TimerEnd(p, s);
     HIP_TRY(hipGetLastError());
+    std::lock_guard<std::mutex> lock(sc->mtx);
     sc->view.lvg = sc->lvg.p; sc->view.lvgDim[0] = dx; sc->view.lvgDim[1] = dy; sc->view.lvgDim[2] = dz;
     for (int a = 0; a < 3; a++) sc->view.lvgExtents[a] = ip.lvg_extents[a];
     sc->view.lvgOffsetY = ip.lvg_offset_y;
@@ -1109,7 +1131,7 @@ static int RenderPreLightingInner(zr_pass* p, hipStream_t s, const zr_frame_cons
     int r = p->power.Alloc(n);
     if (r) return r;
     TimerBegin(p, s, "estimate_power");
-    hipLaunchKernelGGL(k_estimate_power, dim3((n + 255) / 256), dim3(256), 0, s, sc->view, n, p->power.p);
+    hipLaunchKernelGGL(k_estimate_power, dim3((n + 255) / 256), dim3(256), 0, s, FrameView(sc, cb), n, p->power.p);
     TimerEnd(p, s);
     HIP_TRY(hipGetLastError());
     // EmissiveTriangleAliasTable::Render (PreLighting.cpp:512-585): read back, build on the host, upload
@@ -1120,6 +1142,30 @@ static int RenderPreLightingInner(zr_pass* p, hipStream_t s, const zr_frame_cons
     BuildAliasTableHost(power, table.data(), 0);
     if ((r = zr_scene_set_alias_table(sc, table.data(), n))) return r;
     return p->params.presampling ? RenderPresample(p, s, cb, sc) : ZR_OK;
+}
+
+// The rect of the G-buffer tile this pass shades (zr_pass_set_owned_rect; width 0 = the whole tile), validated once for every
+// pass with cross-pixel reuse: inside the tile (planes are indexed relative to the tile origin), 32-px aligned origin (thread
+// groups / RNG group ids coincide with the single-device run) and -- on a proper sub-rect of the frame -- an apron of >= 16 px
+// wherever the frame continues (spatial / temporal-candidate search radius: 15 px ReSTIR PT, 16 px DI / sky DI / GI).
+static int ResolveOwnedRect(const zr_pass* p, const zr_gbuffer* gb, const zr_frame_constants* cb, uint32_t* ox0, uint32_t* oy0, uint32_t* ow, uint32_t* oh)
+{
+    const uint32_t x0 = p->own[2] ? p->own[0] : gb->x0, y0 = p->own[2] ? p->own[1] : gb->y0;
+    const uint32_t w = p->own[2] ? p->own[2] : gb->w, h = p->own[2] ? p->own[3] : gb->h;
+    if (w == 0 || h == 0) return Fail(ZR_ERR_INVALID_ARG, "owned rect is empty");
+    if (x0 < gb->x0 || y0 < gb->y0 || (uint64_t)x0 + w > (uint64_t)gb->x0 + gb->w || (uint64_t)y0 + h > (uint64_t)gb->y0 + gb->h)
+        return Fail(ZR_ERR_INVALID_ARG, "owned rect lies outside the G-buffer tile");
+    if ((x0 & 31u) || (y0 & 31u)) return Fail(ZR_ERR_INVALID_ARG, "owned rect origin must be 32-pixel aligned");
+    const bool wholeFrame = x0 == 0 && y0 == 0 && w == cb->render_width && h == cb->render_height;
+    if (!wholeFrame)
+    {
+        auto apronOk = [&](uint32_t lo, uint32_t olo, uint32_t hi, uint32_t ohi, uint32_t frame) {
+            return (olo == 0 || olo - lo >= 16) && (ohi == frame || hi - ohi >= 16); };
+        if (!apronOk(gb->x0, x0, gb->x0 + gb->w, x0 + w, cb->render_width) || !apronOk(gb->y0, y0, gb->y0 + gb->h, y0 + h, cb->render_height))
+            return Fail(ZR_ERR_INVALID_ARG, "a pass with cross-pixel reuse on a screen tile needs a G-buffer apron of >= 16 px around the owned rect (zr_pass_set_owned_rect)");
+    }
+    *ox0 = x0; *oy0 = y0; *ow = w; *oh = h;
+    return ZR_OK;
 }
 
 // DirectLighting::Render (DirectLighting.cpp:166-296)
@@ -1136,9 +1182,8 @@ static int RenderDirectEmissive(zr_pass* p, hipStream_t s, const zr_frame_consta
     if (ip.presampling && (!sc->view.sampleSets || sc->numSampleSets != ip.num_sample_sets || sc->view.sampleSetSize != ip.sample_set_size))
         return Fail(ZR_ERR_NOT_INITIALIZED, "presampled light sets missing or of another size: render the PRELIGHTING pass with the same presampling params first");
     DiFrame F;
-    F.sc = sc->view; F.gb = gb->View(); F.gbPrev = gb->PrevView();
-    F.ox0 = p->own[2] ? p->own[0] : gb->x0; F.oy0 = p->own[2] ? p->own[1] : gb->y0;
-    F.ow = p->own[2] ? p->own[2] : gb->w; F.oh = p->own[2] ? p->own[3] : gb->h;
+    F.sc = FrameView(sc, cb); F.gb = gb->View(); F.gbPrev = gb->PrevView();
+    if (int orc = ResolveOwnedRect(p, gb, cb, &F.ox0, &F.oy0, &F.ow, &F.oh)) return orc;
     F.cur.A = p->diA[p->currIdx].p; F.cur.B = p->diB[p->currIdx].p; F.prev.A = p->diA[1 - p->currIdx].p; F.prev.B = p->diB[1 - p->currIdx].p;
     F.target = p->diTarget.p; F.finalRGBA = p->finalRGBA.p; F.sampleSet = p->diSampleSet.p;
     DiParams& prm = F.prm;
@@ -1178,9 +1223,8 @@ static int RenderDirectSky(zr_pass* p, hipStream_t s, const zr_frame_constants* 
     if (!sc->view.sky.data) return Fail(ZR_ERR_NOT_INITIALIZED, "sky-view LUT missing: render a ZR_PASS_SKY pass first");
     const zr_params& ip = p->params;
     SkyFrame F;
-    F.sc = sc->view; F.gb = gb->View(); F.gbPrev = gb->PrevView();
-    F.ox0 = p->own[2] ? p->own[0] : gb->x0; F.oy0 = p->own[2] ? p->own[1] : gb->y0;
-    F.ow = p->own[2] ? p->own[2] : gb->w; F.oh = p->own[2] ? p->own[3] : gb->h;
+    F.sc = FrameView(sc, cb); F.gb = gb->View(); F.gbPrev = gb->PrevView();
+    if (int orc = ResolveOwnedRect(p, gb, cb, &F.ox0, &F.oy0, &F.ow, &F.oh)) return orc;
     F.cur.A = p->skyA[p->currIdx].p; F.cur.B = p->skyB[p->currIdx].p; F.cur.C = p->skyC[p->currIdx].p;
     F.prev.A = p->skyA[1 - p->currIdx].p; F.prev.B = p->skyB[1 - p->currIdx].p; F.prev.C = p->skyC[1 - p->currIdx].p;
     F.target = p->diTarget.p; F.finalRGBA = p->finalRGBA.p;
@@ -1217,9 +1261,8 @@ static int RenderReSTIR_GI(zr_pass* p, hipStream_t s, const zr_frame_constants* 
     using namespace rgi;
     const zr_params& ip = p->params;
     GiFrame F;
-    F.sc = sc->view; F.gb = gb->View(); F.gbPrev = gb->PrevView();
-    F.ox0 = p->own[2] ? p->own[0] : gb->x0; F.oy0 = p->own[2] ? p->own[1] : gb->y0;
-    F.ow = p->own[2] ? p->own[2] : gb->w; F.oh = p->own[2] ? p->own[3] : gb->h;
+    F.sc = FrameView(sc, cb); F.gb = gb->View(); F.gbPrev = gb->PrevView();
+    if (int orc = ResolveOwnedRect(p, gb, cb, &F.ox0, &F.oy0, &F.ow, &F.oh)) return orc;
     F.cur.A = p->giA[p->currIdx].p; F.cur.B = p->giB[p->currIdx].p; F.cur.C = p->giC[p->currIdx].p;
     F.prev.A = p->giA[1 - p->currIdx].p; F.prev.B = p->giB[1 - p->currIdx].p; F.prev.C = p->giC[1 - p->currIdx].p;
     F.finalRGBA = p->finalRGBA.p;
@@ -1233,7 +1276,7 @@ static int RenderReSTIR_GI(zr_pass* p, hipStream_t s, const zr_frame_constants* 
     prm.useLVG = (ip.use_lvg && ip.presampling) ? 1u : 0u;
     prm.textured = sc->view.tex.count ? 1u : 0u;
     if (prm.useLVG && !sc->view.lvg) return Fail(ZR_ERR_NOT_INITIALIZED, "light voxel grid missing: render the PRELIGHTING pass with use_lvg first");
-    const uint32_t tilesX = (p->w + 15) / 16, tilesY = (p->h + 15) / 16;
+    const uint32_t tilesX = (F.ow + 15) / 16, tilesY = (F.oh + 15) / 16;
     TimerBegin(p, s, "rgi");
     hipLaunchKernelGGL(sc->view.tex.count ? k_rgi<true> : k_rgi<false>, dim3(tilesX * tilesY), dim3(kBlock), 0, s, F, *cb, tilesX, p->counters.p + 2 * 10);
     TimerEnd(p, s);
@@ -1250,22 +1293,8 @@ static int RenderReSTIR_PT(zr_pass* p, hipStream_t s, const zr_frame_constants* 
 {
     using namespace rpt;
     RptFrame F;
-    F.sc = sc->view; F.gb = gb->View(); F.gbPrev = gb->PrevView();
-    F.ox0 = p->own[2] ? p->own[0] : gb->x0; F.oy0 = p->own[2] ? p->own[1] : gb->y0;
-    F.ow = p->own[2] ? p->own[2] : gb->w; F.oh = p->own[2] ? p->own[3] : gb->h;
-    if (F.ox0 < gb->x0 || F.oy0 < gb->y0 || F.ox0 + F.ow > gb->x0 + gb->w || F.oy0 + F.oh > gb->y0 + gb->h)
-        return Fail(ZR_ERR_INVALID_ARG, "owned rect lies outside the G-buffer tile");
-    if ((F.ox0 & 31u) || (F.oy0 & 31u)) return Fail(ZR_ERR_INVALID_ARG, "owned rect origin must be 32-pixel aligned");
-    const bool wholeFrame = F.ox0 == 0 && F.oy0 == 0 && F.ow == cb->render_width && F.oh == cb->render_height;
-    if (!wholeFrame)
-    {
-        // neighbours within the spatial search radius must be readable: the G-buffer tile must extend the owned rect by
-        // >= 16 px wherever the frame continues
-        auto apronOk = [&](uint32_t lo, uint32_t olo, uint32_t hi, uint32_t ohi, uint32_t frame) {
-            return (olo == 0 || olo - lo >= 16) && (ohi == frame || hi - ohi >= 16); };
-        if (!apronOk(gb->x0, F.ox0, gb->x0 + gb->w, F.ox0 + F.ow, cb->render_width) || !apronOk(gb->y0, F.oy0, gb->y0 + gb->h, F.oy0 + F.oh, cb->render_height))
-            return Fail(ZR_ERR_INVALID_ARG, "RESTIR_PT on a screen tile needs a G-buffer apron of >= 16 px around the owned rect (zr_pass_set_owned_rect)");
-    }
+    F.sc = FrameView(sc, cb); F.gb = gb->View(); F.gbPrev = gb->PrevView();
+    if (int orc = ResolveOwnedRect(p, gb, cb, &F.ox0, &F.oy0, &F.ow, &F.oh)) return orc;
     F.rbCtN = p->rb[0].View(); F.rbNtC = p->rb[1].View(); F.tex.target = p->rptTarget.p; F.tex.neighbor = p->rptNeighbor.p;
     F.finalRGBA = p->finalRGBA.p; F.sampleSet = p->rptSampleSet.p;
     RptParams& prm = F.prm;
@@ -1384,10 +1413,11 @@ static int RenderIndirect(zr_pass* p, hipStream_t s, const zr_frame_constants* c
     if (rrPossible) HIP_TRY(hipMemsetAsync(p->groupMax.p, 0, (size_t)rounds * numGroups * sizeof(uint32_t), s));
     const uint32_t tilesX = (p->w + 15) / 16, tilesY = (p->h + 15) / 16;
     const GBuf gbv = gb->View();
-    const bool tex = sc->view.tex.count != 0;      // kernels carry ray differentials only when there is a texture heap
+    const SceneView scv = FrameView(sc, cb);
+    const bool tex = scv.tex.count != 0;      // kernels carry ray differentials only when there is a texture heap
     if (tex) { int r; if ((r = p->q[0].AllocTex((size_t)p->w * p->h)) || (r = p->q[1].AllocTex((size_t)p->w * p->h))) return r; }
     TimerBegin(p, s, "pt_init");
-    hipLaunchKernelGGL(tex ? k_pt_init<true> : k_pt_init<false>, dim3(tilesX * tilesY), dim3(kBlock), 0, s, sc->view, *cb, gbv, prm, p->finalRGBA.p, p->firstBOP.p,
+    hipLaunchKernelGGL(tex ? k_pt_init<true> : k_pt_init<false>, dim3(tilesX * tilesY), dim3(kBlock), 0, s, scv, *cb, gbv, prm, p->finalRGBA.p, p->firstBOP.p,
         p->q[0].View(), Ctr(0, 0), Ctr(2, 0), (uint32_t)((size_t)p->w * p->h), tilesX);
     TimerEnd(p, s);
     const size_t cap = (size_t)p->w * p->h;
@@ -1399,17 +1429,17 @@ static int RenderIndirect(zr_pass* p, hipStream_t s, const zr_frame_constants* c
     {
         const PathQueue qin = p->q[r & 1].View(), qout = p->q[(r + 1) & 1].View();
         TimerBegin(p, s, "trace");
-        if (traceMode == 0) hipLaunchKernelGGL(k_trace_simple, dim3(gridTraceSimple), dim3(kBlock), 0, s, sc->view, qin, Ctr(2, r), (uint32_t)cap, p->counters.p);
-        else hipLaunchKernelGGL(k_trace, dim3(gridTrace), dim3(kBlock), 0, s, sc->view, qin, Ctr(2, r), (uint32_t)cap, Ctr(1, r), p->counters.p);
+        if (traceMode == 0) hipLaunchKernelGGL(k_trace_simple, dim3(gridTraceSimple), dim3(kBlock), 0, s, scv, qin, Ctr(2, r), (uint32_t)cap, p->counters.p);
+        else hipLaunchKernelGGL(k_trace, dim3(gridTrace), dim3(kBlock), 0, s, scv, qin, Ctr(2, r), (uint32_t)cap, Ctr(1, r), p->counters.p);
         TimerEnd(p, s);
         TimerBegin(p, s, "pt_shade");
-        hipLaunchKernelGGL(tex ? k_pt_shade_tex : k_pt_shade, dim3(gridShade), dim3(kBlock), 0, s, sc->view, *cb, prm, qin, Ctr(0, r), qout, Ctr(0, r + 1), Ctr(2, r + 1), (uint32_t)cap,
+        hipLaunchKernelGGL(tex ? k_pt_shade_tex : k_pt_shade, dim3(gridShade), dim3(kBlock), 0, s, scv, *cb, prm, qin, Ctr(0, r), qout, Ctr(0, r + 1), Ctr(2, r + 1), (uint32_t)cap,
             p->finalRGBA.p, p->firstBOP.p, p->groupMax.p + (size_t)r * numGroups);
         TimerEnd(p, s);
         if (rrPossible && r >= 2)
         {
             TimerBegin(p, s, "pt_rr");
-            hipLaunchKernelGGL(tex ? k_pt_rr<true> : k_pt_rr<false>, dim3(gridShade), dim3(kBlock), 0, s, sc->view, prm, qout, Ctr(0, r + 1), Ctr(2, r + 1), (uint32_t)cap, p->groupMax.p + (size_t)r * numGroups);
+            hipLaunchKernelGGL(tex ? k_pt_rr<true> : k_pt_rr<false>, dim3(gridShade), dim3(kBlock), 0, s, scv, prm, qout, Ctr(0, r + 1), Ctr(2, r + 1), (uint32_t)cap, p->groupMax.p + (size_t)r * numGroups);
             TimerEnd(p, s);
         }
     }
@@ -1472,6 +1502,9 @@ static int RenderCompositing(zr_pass* p, hipStream_t s, const zr_frame_constants
 int zr_pass_set_owned_rect(zr_pass* p, uint32_t x0, uint32_t y0, uint32_t w, uint32_t h)
 {
     if (!p) return Fail(ZR_ERR_INVALID_ARG, "null pass");
+    if ((w == 0) != (h == 0)) return Fail(ZR_ERR_INVALID_ARG, "owned rect: width and height must both be 0 (whole tile) or both be positive");
+    if (w && ((x0 & 31u) || (y0 & 31u))) return Fail(ZR_ERR_INVALID_ARG, "owned rect origin must be 32-pixel aligned");
+    if (w && p->initialized && (w > p->w || h > p->h)) return Fail(ZR_ERR_INVALID_ARG, "owned rect %ux%u larger than the pass %ux%u", w, h, p->w, p->h);
     p->own[0] = x0; p->own[1] = y0; p->own[2] = w; p->own[3] = h;
     return ZR_OK;
 }
@@ -1558,8 +1591,6 @@ int zr_pass_render_stage(zr_pass* p, void* stream, const zr_frame_constants* cb,
             if (sc->maxTex[k] >= 0 && (uint64_t)off[k] + (uint64_t)sc->maxTex[k] >= sc->view.tex.count)
                 return Fail(ZR_ERR_INVALID_ARG, "texture table %d: offset %u + index %lld lies outside the scene's %u textures", k, off[k], (long long)sc->maxTex[k], sc->view.tex.count);
     }
-    sc->view.baseColorMapsOffset = cb->base_color_maps_desc_heap_offset; sc->view.normalMapsOffset = cb->normal_maps_desc_heap_offset;
-    sc->view.mrMapsOffset = cb->metallic_roughness_maps_desc_heap_offset; sc->view.emissiveMapsOffset = cb->emissive_maps_desc_heap_offset;
     switch (p->kind)
     {
     case ZR_PASS_GBUFFER: return (stages & ZR_STAGE_TEMPORAL) ? RenderGBuffer(p, s, cb, sc, gb) : ZR_OK;
@@ -1768,7 +1799,7 @@ int zr_trace_closest(const zr_scene* sc, void* stream, const float* d_rays, uint
     if (n == 0) return ZR_OK;
     HIP_TRY(hipSetDevice(sc->device));
     const uint32_t grid = std::min<uint32_t>((n + kBlock - 1) / kBlock, 8192u);
-    hipLaunchKernelGGL(k_trace_rays, dim3(grid), dim3(kBlock), 0, (hipStream_t)stream, sc->view, (const F4*)d_rays, n, mask, (U4*)d_hits);
+    hipLaunchKernelGGL(k_trace_rays, dim3(grid), dim3(kBlock), 0, (hipStream_t)stream, FrameView(sc, nullptr), (const F4*)d_rays, n, mask, (U4*)d_hits);
     HIP_TRY(hipGetLastError());
     return ZR_OK;
 }
@@ -1778,7 +1809,7 @@ int zr_trace_any(const zr_scene* sc, void* stream, const float* d_rays, uint32_t
     if (n == 0) return ZR_OK;
     HIP_TRY(hipSetDevice(sc->device));
     const uint32_t grid = std::min<uint32_t>((n + kBlock - 1) / kBlock, 8192u);
-    hipLaunchKernelGGL(k_trace_rays_any, dim3(grid), dim3(kBlock), 0, (hipStream_t)stream, sc->view, (const F4*)d_rays, n, mask, d_occ);
+    hipLaunchKernelGGL(k_trace_rays_any, dim3(grid), dim3(kBlock), 0, (hipStream_t)stream, FrameView(sc, nullptr), (const F4*)d_rays, n, mask, d_occ);
     HIP_TRY(hipGetLastError());
     return ZR_OK;
 }

@@ -206,11 +206,31 @@ void GBufferRT::Init(FrameContext* ctx) { InitRenderPass(ZR_PASS_GBUFFER, ctx, 0
 void GBufferRT::OnWindowResized() { ZR_CHECK(zr_pass_resize(m_pass, m_ctx->renderWidth, m_ctx->renderHeight)); }
 void GBufferRT::Render(Core::CommandList& cl) { ZR_CHECK(zr_pass_render(m_pass, cl.Stream(), &m_ctx->frameConstants, m_ctx->scene, m_ctx->gbuffer)); }
 
-void PreLighting::Init(FrameContext* ctx) { InitRenderPass(ZR_PASS_PRELIGHTING, ctx, 0); }
+void PreLighting::Init(FrameContext* ctx) { InitRenderPass(ZR_PASS_PRELIGHTING, ctx, 0); ZR_CHECK(zr_params_default(&m_params)); }
+void PreLighting::SetLightPresamplingParams(int minToEnable, int numSampleSets, int sampleSetSize)
+{
+    // PreLighting::Update (PreLighting.cpp:289-297): presampling is used iff the scene has >= minToEnable emissive triangles
+    m_minPresample = minToEnable;
+    const bool on = numSampleSets > 0 && sampleSetSize > 0 && (int)m_ctx->frameConstants.num_emissive_triangles >= minToEnable;
+    m_params.presampling = on ? 1u : 0u;
+    m_params.num_sample_sets = (uint32_t)numSampleSets; m_params.sample_set_size = (uint32_t)sampleSetSize;
+    if (!on) m_params.use_lvg = 0;
+    ZR_CHECK(zr_pass_set_params(m_pass, &m_params));
+}
+void PreLighting::SetLightVoxelGridParams(bool enable, uint32_t dimX, uint32_t dimY, uint32_t dimZ, float extX, float extY, float extZ, float offsetY)
+{
+    m_params.use_lvg = (enable && m_params.presampling) ? 1u : 0u;
+    m_params.lvg_grid_dim = dimX | (dimY << 10) | (dimZ << 20);
+    m_params.lvg_extents[0] = extX; m_params.lvg_extents[1] = extY; m_params.lvg_extents[2] = extZ;
+    m_params.lvg_offset_y = offsetY;
+    ZR_CHECK(zr_pass_set_params(m_pass, &m_params));
+}
 void PreLighting::Render(Core::CommandList& cl)
 {
-    // the alias table only changes when the emissive set changes (EmissiveTriangleAliasTable::Update, PreLighting.cpp:455-510)
-    if (m_aliasReady) return;
+    // The alias table only changes when the emissive set changes (EmissiveTriangleAliasTable::Update, PreLighting.cpp:455-510):
+    // the library skips that part itself once the scene holds a table.  K3 presampling and the K4 voxel grid are seeded by
+    // FrameNum and run every frame (PreLighting.cpp:299-441), so the pass is only skipped when neither is on.
+    if (m_aliasReady && !m_params.presampling && !m_params.use_lvg) return;
     ZR_CHECK(zr_pass_render(m_pass, cl.Stream(), &m_ctx->frameConstants, m_ctx->scene, nullptr));
     m_aliasReady = true;
 }
@@ -390,7 +410,15 @@ int zrh_graph_selftest(char* out, int outLen)
 // Renders `n` consecutive frames (cbs[i] = cbFrameConstants of frame i) through the graph exactly as the reference's
 // frame loop does (PathTracer.cpp:474-552: register passes / resources, declare inputs / outputs, Build, submit, fence)
 // and copies the FINAL plane of the last frame.  integrator: 0 = PATH_TRACING, 2 = ReSTIR_PT.
+int zrh_render_sequence3(const zr_scene_desc* desc, const zr_frame_constants* cbs, uint32_t n, uint32_t w, uint32_t h, int integrator, float* finalOut, float* directOut,
+    int presampleSets, int presampleSize);
 int zrh_render_sequence2(const zr_scene_desc* desc, const zr_frame_constants* cbs, uint32_t n, uint32_t w, uint32_t h, int integrator, float* finalOut, float* directOut)
+{ return zrh_render_sequence3(desc, cbs, n, w, h, integrator, finalOut, directOut, 0, 0); }
+
+// ... with light presampling (K3) when presampleSets > 0: PreLighting regenerates the sets every frame and the lighting passes
+// read them (DefaultRenderer.cpp:257-272: the three SetLightPresamplingParams calls of the reference's settings callback)
+int zrh_render_sequence3(const zr_scene_desc* desc, const zr_frame_constants* cbs, uint32_t n, uint32_t w, uint32_t h, int integrator, float* finalOut, float* directOut,
+    int presampleSets, int presampleSize)
 {
     RenderPass::FrameContext ctx;
     ctx.device = 0; ctx.renderWidth = w; ctx.renderHeight = h;
@@ -400,6 +428,13 @@ int zrh_render_sequence2(const zr_scene_desc* desc, const zr_frame_constants* cb
         RenderPass::GBufferRT gb; RenderPass::PreLighting pre; RenderPass::IndirectLighting ind; RenderPass::DirectLighting di;
         gb.Init(&ctx); pre.Init(&ctx); ind.Init(&ctx, (RenderPass::IndirectLighting::INTEGRATOR)integrator);
         if (directOut) di.Init(&ctx);
+        if (presampleSets > 0)
+        {
+            ctx.frameConstants = cbs[0];
+            pre.SetLightPresamplingParams(0, presampleSets, presampleSize);
+            ind.SetLightPresamplingParams(pre.IsPresamplingEnabled(), presampleSets, presampleSize);
+            if (directOut) di.SetLightPresamplingParams(pre.IsPresamplingEnabled(), presampleSets, presampleSize);
+        }
         Core::RenderGraph g;
         enum : uint64_t { R_GBUF = 1, R_ALIAS, R_IND, R_DI };
         for (uint32_t f = 0; f < n; f++)

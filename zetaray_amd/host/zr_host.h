@@ -170,10 +170,15 @@ namespace RenderPass {
     {
         void Init(FrameContext* ctx);
         void OnWindowResized() {}
-        void SetLightPresamplingParams(int minToEnable, int numSampleSets, int sampleSetSize) { m_minPresample = minToEnable; m_numSets = numSampleSets; m_setSize = sampleSetSize; }
+        // PreLighting.h:36-52: presampling switches on once the scene holds at least `minToEnable` emissive triangles
+        void SetLightPresamplingParams(int minToEnable, int numSampleSets, int sampleSetSize);
+        // PreLighting.h:53-58 (dims / extents / y offset of the light voxel grid; needs presampling)
+        void SetLightVoxelGridParams(bool enable, uint32_t dimX, uint32_t dimY, uint32_t dimZ, float extX, float extY, float extZ, float offsetY);
+        bool IsPresamplingEnabled() const { return m_params.presampling != 0; }
         void Render(Core::CommandList& cmdList);
     private:
-        int m_minPresample = 0, m_numSets = 0, m_setSize = 0;
+        zr_params m_params{};
+        int m_minPresample = 0;
         bool m_aliasReady = false;
     };
 
