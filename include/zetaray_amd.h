@@ -188,6 +188,11 @@ typedef struct zr_counters {
 int         zr_abi_version(void);
 const char* zr_last_error(void);
 int         zr_device_count(int* count);
+/* Self-description of the wire formats of zr_wire.h for binding generators and layout checks: one line per struct ("Name size") and per
+   field ("Name.Field offset size"), spelled with the REFERENCE's struct / field names (Vertex.h, RtCommon.h, Material.h, FrameConstants.h).
+   The test-suite compares this text with offsetof() of the reference's own headers compiled in place (oracle/_ref, tests/test_ref_pins.py).
+   Returns the number of bytes written (excluding the terminating 0), or -(required size) when `cap` is too small. */
+int         zr_wire_layout(char* buf, size_t cap);
 
 /* ---- scene: device copies of VB/IB/MeshInstance/Material/Emissive/AliasTable + BVH ---- */
 int zr_scene_create(int device, const zr_scene_desc* desc, zr_scene** out);

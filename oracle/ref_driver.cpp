@@ -40,3 +40,57 @@ void zref_unorm4_from_normalized(const float* q4, uint16_t* out, uint64_t n)
 }
 uintptr_t zref_align_phase(const float* p) { return ((32 - (reinterpret_cast<uintptr_t>(p) & 31)) & 31) / 4; }
 }
+
+// ---- layout pins: offsetof / sizeof of the C++ side of the reference's shared C++/HLSL headers, compiled in place ----
+#include <RayTracing/RtCommon.h>
+#include <Core/Material.h>
+#include <Core/Vertex.h>
+#include <../ZetaRenderPass/Common/FrameConstants.h>
+#include <cstdio>
+#include <string>
+
+extern "C" int zref_layout(char* out, int cap)
+{
+    std::string s;
+    char line[160];
+#define ZREF_FIELD(T, f) do { std::snprintf(line, sizeof(line), #T "." #f " %zu %zu\n", offsetof(T, f), sizeof(((T*)0)->f)); s += line; } while (0)
+#define ZREF_SIZE(T) do { std::snprintf(line, sizeof(line), #T " %zu\n", sizeof(T)); s += line; } while (0)
+    using namespace ZetaRay;
+    using Core::Vertex;
+    ZREF_SIZE(Vertex); ZREF_FIELD(Vertex, Position); ZREF_FIELD(Vertex, TexUV); ZREF_FIELD(Vertex, Normal); ZREF_FIELD(Vertex, Tangent);
+    using RT::MeshInstance;
+    ZREF_SIZE(MeshInstance); ZREF_FIELD(MeshInstance, BaseVtxOffset); ZREF_FIELD(MeshInstance, BaseIdxOffset); ZREF_FIELD(MeshInstance, Rotation);
+    ZREF_FIELD(MeshInstance, Scale); ZREF_FIELD(MeshInstance, MatIdx); ZREF_FIELD(MeshInstance, BaseEmissiveTriOffset); ZREF_FIELD(MeshInstance, Translation);
+    ZREF_FIELD(MeshInstance, PrevRotation); ZREF_FIELD(MeshInstance, PrevScale); ZREF_FIELD(MeshInstance, dTranslation); ZREF_FIELD(MeshInstance, BaseColorTex);
+    ZREF_FIELD(MeshInstance, AlphaFactor_Cutoff);
+    using RT::EmissiveTriangle;
+    ZREF_SIZE(EmissiveTriangle); ZREF_FIELD(EmissiveTriangle, Vtx0); ZREF_FIELD(EmissiveTriangle, V0V1); ZREF_FIELD(EmissiveTriangle, V0V2);
+    ZREF_FIELD(EmissiveTriangle, EdgeLengths); ZREF_FIELD(EmissiveTriangle, ID); ZREF_FIELD(EmissiveTriangle, PackedA); ZREF_FIELD(EmissiveTriangle, PackedB);
+    ZREF_FIELD(EmissiveTriangle, UV0); ZREF_FIELD(EmissiveTriangle, UV1); ZREF_FIELD(EmissiveTriangle, UV2);
+    using RT::EmissiveLumenAliasTableEntry;
+    ZREF_SIZE(EmissiveLumenAliasTableEntry); ZREF_FIELD(EmissiveLumenAliasTableEntry, CachedP_Orig); ZREF_FIELD(EmissiveLumenAliasTableEntry, CachedP_Alias);
+    ZREF_FIELD(EmissiveLumenAliasTableEntry, P_Curr); ZREF_FIELD(EmissiveLumenAliasTableEntry, Alias);
+    using RT::PresampledEmissiveTriangle;
+    ZREF_SIZE(PresampledEmissiveTriangle); ZREF_FIELD(PresampledEmissiveTriangle, pos); ZREF_FIELD(PresampledEmissiveTriangle, normal); ZREF_FIELD(PresampledEmissiveTriangle, pdf);
+    ZREF_FIELD(PresampledEmissiveTriangle, ID); ZREF_FIELD(PresampledEmissiveTriangle, idx); ZREF_FIELD(PresampledEmissiveTriangle, bary); ZREF_FIELD(PresampledEmissiveTriangle, le);
+    ZREF_FIELD(PresampledEmissiveTriangle, twoSided);
+    using RT::VoxelSample;
+    ZREF_SIZE(VoxelSample); ZREF_FIELD(VoxelSample, pos); ZREF_FIELD(VoxelSample, normal); ZREF_FIELD(VoxelSample, pdf); ZREF_FIELD(VoxelSample, ID); ZREF_FIELD(VoxelSample, le);
+    ZREF_FIELD(VoxelSample, twoSided);
+    ZREF_SIZE(Material); ZREF_FIELD(Material, BaseColorFactor); ZREF_FIELD(Material, BaseColorTex_Subsurf_CoatWeight); ZREF_FIELD(Material, NormalTex_TrDepth);
+    ZREF_FIELD(Material, MRTex_SpecRoughness_CoatRoughness); ZREF_FIELD(Material, EmissiveFactor_NormalScale); ZREF_FIELD(Material, EmissiveStrength_IOR);
+    ZREF_FIELD(Material, EmissiveTex_AlphaCutoff_CoatIOR); ZREF_FIELD(Material, CoatColor_Flags);
+    ZREF_SIZE(cbFrameConstants);
+#define ZREF_CB(f) ZREF_FIELD(cbFrameConstants, f)
+    ZREF_CB(CurrView); ZREF_CB(PrevView); ZREF_CB(CurrViewInv); ZREF_CB(PrevViewInv); ZREF_CB(CurrViewProj); ZREF_CB(PrevViewProj); ZREF_CB(CameraPos); ZREF_CB(CameraNear);
+    ZREF_CB(AspectRatio); ZREF_CB(PixelSpreadAngle); ZREF_CB(TanHalfFOV); ZREF_CB(dt); ZREF_CB(FrameNum); ZREF_CB(CurrGBufferDescHeapOffset); ZREF_CB(PrevGBufferDescHeapOffset);
+    ZREF_CB(BaseColorMapsDescHeapOffset); ZREF_CB(NormalMapsDescHeapOffset); ZREF_CB(MetallicRoughnessMapsDescHeapOffset); ZREF_CB(EmissiveMapsDescHeapOffset);
+    ZREF_CB(EnvMapDescHeapOffset); ZREF_CB(RenderWidth); ZREF_CB(RenderHeight); ZREF_CB(DisplayWidth); ZREF_CB(DisplayHeight); ZREF_CB(CurrCameraJitter); ZREF_CB(PrevCameraJitter);
+    ZREF_CB(PlanetRadius); ZREF_CB(SunCosAngularRadius); ZREF_CB(SunSinAngularRadius); ZREF_CB(pad); ZREF_CB(SunDir); ZREF_CB(SunIlluminance); ZREF_CB(RayleighSigmaSColor);
+    ZREF_CB(RayleighSigmaSScale); ZREF_CB(OzoneSigmaAColor); ZREF_CB(OzoneSigmaAScale); ZREF_CB(MieSigmaS); ZREF_CB(MieSigmaA); ZREF_CB(AtmosphereAltitude); ZREF_CB(g);
+    ZREF_CB(NumFramesCameraStatic); ZREF_CB(CameraStatic); ZREF_CB(Accumulate); ZREF_CB(SunMoved); ZREF_CB(CameraRayUVGradsScale); ZREF_CB(MipBias);
+    ZREF_CB(OneDivNumEmissiveTriangles); ZREF_CB(NumEmissiveTriangles); ZREF_CB(FocusDepth); ZREF_CB(LensRadius); ZREF_CB(DoF); ZREF_CB(pad2);
+    if ((int)s.size() + 1 > cap) return -(int)s.size() - 1;
+    std::memcpy(out, s.c_str(), s.size() + 1);
+    return (int)s.size();
+}

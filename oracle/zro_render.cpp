@@ -767,6 +767,7 @@ static void RenderPathTracer(const Scene& sc, const zr_frame_constants& g, GBVie
 #include "zro_rdi.h"
 #include "zro_rgi.h"
 #include "zro_sdi.h"
+#include "zro_kat.h"
 
 //--------------------------------------------------------------------------------------
 // C entry points (ctypes)
@@ -1261,5 +1262,12 @@ void zro_kat_bsdf(const zro_scene* h, const float* in /* n x 16 */, float* out /
         o[11] = BSDF::BSDFSamplerPdf(nrm, s, wi, BSDF::NoOp(), rng2);
     }
 }
+
+// function-level probes shared with the reference build and the HIP stage functions (zro_kat.h)
+void zro_kat2_sampling(const float* in, float* out, uint32_t n) { KAT::Sampling_(in, out, n); }
+void zro_kat2_math(const float* in, float* out, uint32_t n) { KAT::Math_(in, out, n); }
+void zro_kat2_rt(const float* in, float* out, uint32_t n) { KAT::RT_(in, out, n); }
+void zro_kat2_bsdf(const uint16_t* rho, const uint32_t* rho_dim, const float* in, float* out, uint32_t n)
+{ RhoLUT lut; lut.data = rho; lut.dim[0] = rho_dim[0]; lut.dim[1] = rho_dim[1]; lut.dim[2] = rho_dim[2]; KAT::BSDF_(&lut, in, out, n); }
 
 } // extern "C"

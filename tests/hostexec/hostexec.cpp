@@ -22,6 +22,7 @@ static const uint16_t kRdiSampleSet[64] = {
 #include "../../zetaray_amd/csrc/zr_rdi_sample_set.inc"
 };
 
+#include "hx_kat.h"
 using namespace zr;
 
 struct HxScene
@@ -615,4 +616,10 @@ int zhx_sdi_read_plane(const HxSdi* R, int plane, void* out)
     else std::memcpy(out, R->target.data(), R->target.size() * sizeof(F4));
     return 0;
 }
+// function-level probes shared with the reference build and the oracle (hx_kat.h)
+void zhx_kat_sampling(const float* in, float* out, uint32_t n) { hxkat::Sampling_(in, out, n); }
+void zhx_kat_math(const float* in, float* out, uint32_t n) { hxkat::Math_(in, out, n); }
+void zhx_kat_rt(const float* in, float* out, uint32_t n) { hxkat::RT_(in, out, n); }
+void zhx_kat_bsdf(const uint16_t* rho, const uint32_t* rho_dim, const float* in, float* out, uint32_t n) { hxkat::BSDF_(rho, rho_dim, in, out, n); }
+
 } // extern "C"

@@ -794,6 +794,68 @@ int zr_scene_create(int device, const zr_scene_desc* d, zr_scene** out)
     return ZR_OK;
 }
 
+int zr_wire_layout(char* buf, size_t cap)
+{
+    std::string s;
+    char line[160];
+#define ZR_L_SIZE(name, T) do { snprintf(line, sizeof(line), name " %zu\n", sizeof(T)); s += line; } while (0)
+#define ZR_L_FIELD(name, T, f) do { snprintf(line, sizeof(line), name " %zu %zu\n", offsetof(T, f), sizeof(((T*)0)->f)); s += line; } while (0)
+    ZR_L_SIZE("Vertex", zr_vertex); ZR_L_FIELD("Vertex.Position", zr_vertex, pos); ZR_L_FIELD("Vertex.TexUV", zr_vertex, uv);
+    ZR_L_FIELD("Vertex.Normal", zr_vertex, normal); ZR_L_FIELD("Vertex.Tangent", zr_vertex, tangent);
+    ZR_L_SIZE("MeshInstance", zr_mesh_instance);
+    ZR_L_FIELD("MeshInstance.BaseVtxOffset", zr_mesh_instance, base_vtx_offset); ZR_L_FIELD("MeshInstance.BaseIdxOffset", zr_mesh_instance, base_idx_offset);
+    ZR_L_FIELD("MeshInstance.Rotation", zr_mesh_instance, rotation); ZR_L_FIELD("MeshInstance.Scale", zr_mesh_instance, scale);
+    ZR_L_FIELD("MeshInstance.MatIdx", zr_mesh_instance, mat_idx); ZR_L_FIELD("MeshInstance.BaseEmissiveTriOffset", zr_mesh_instance, base_emissive_tri_offset);
+    ZR_L_FIELD("MeshInstance.Translation", zr_mesh_instance, translation); ZR_L_FIELD("MeshInstance.PrevRotation", zr_mesh_instance, prev_rotation);
+    ZR_L_FIELD("MeshInstance.PrevScale", zr_mesh_instance, prev_scale); ZR_L_FIELD("MeshInstance.dTranslation", zr_mesh_instance, d_translation);
+    ZR_L_FIELD("MeshInstance.BaseColorTex", zr_mesh_instance, base_color_tex); ZR_L_FIELD("MeshInstance.AlphaFactor_Cutoff", zr_mesh_instance, alpha_factor_cutoff);
+    ZR_L_SIZE("EmissiveTriangle", zr_emissive_triangle);
+    ZR_L_FIELD("EmissiveTriangle.Vtx0", zr_emissive_triangle, vtx0); ZR_L_FIELD("EmissiveTriangle.V0V1", zr_emissive_triangle, v0v1);
+    ZR_L_FIELD("EmissiveTriangle.V0V2", zr_emissive_triangle, v0v2); ZR_L_FIELD("EmissiveTriangle.EdgeLengths", zr_emissive_triangle, edge_lengths);
+    ZR_L_FIELD("EmissiveTriangle.ID", zr_emissive_triangle, id); ZR_L_FIELD("EmissiveTriangle.PackedA", zr_emissive_triangle, packed_a);
+    ZR_L_FIELD("EmissiveTriangle.PackedB", zr_emissive_triangle, packed_b); ZR_L_FIELD("EmissiveTriangle.UV0", zr_emissive_triangle, uv0);
+    ZR_L_FIELD("EmissiveTriangle.UV1", zr_emissive_triangle, uv1); ZR_L_FIELD("EmissiveTriangle.UV2", zr_emissive_triangle, uv2);
+    ZR_L_SIZE("EmissiveLumenAliasTableEntry", zr_alias_entry);
+    ZR_L_FIELD("EmissiveLumenAliasTableEntry.CachedP_Orig", zr_alias_entry, cached_p_orig); ZR_L_FIELD("EmissiveLumenAliasTableEntry.CachedP_Alias", zr_alias_entry, cached_p_alias);
+    ZR_L_FIELD("EmissiveLumenAliasTableEntry.P_Curr", zr_alias_entry, p_curr); ZR_L_FIELD("EmissiveLumenAliasTableEntry.Alias", zr_alias_entry, alias);
+    ZR_L_SIZE("PresampledEmissiveTriangle", zr_presampled_tri);
+    ZR_L_FIELD("PresampledEmissiveTriangle.pos", zr_presampled_tri, pos); ZR_L_FIELD("PresampledEmissiveTriangle.normal", zr_presampled_tri, normal);
+    ZR_L_FIELD("PresampledEmissiveTriangle.pdf", zr_presampled_tri, pdf); ZR_L_FIELD("PresampledEmissiveTriangle.ID", zr_presampled_tri, id);
+    ZR_L_FIELD("PresampledEmissiveTriangle.idx", zr_presampled_tri, idx); ZR_L_FIELD("PresampledEmissiveTriangle.bary", zr_presampled_tri, bary);
+    ZR_L_FIELD("PresampledEmissiveTriangle.le", zr_presampled_tri, le); ZR_L_FIELD("PresampledEmissiveTriangle.twoSided", zr_presampled_tri, two_sided);
+    ZR_L_SIZE("VoxelSample", zr_voxel_sample);
+    ZR_L_FIELD("VoxelSample.pos", zr_voxel_sample, pos); ZR_L_FIELD("VoxelSample.normal", zr_voxel_sample, normal); ZR_L_FIELD("VoxelSample.pdf", zr_voxel_sample, pdf);
+    ZR_L_FIELD("VoxelSample.ID", zr_voxel_sample, id); ZR_L_FIELD("VoxelSample.le", zr_voxel_sample, le); ZR_L_FIELD("VoxelSample.twoSided", zr_voxel_sample, two_sided);
+    ZR_L_SIZE("Material", zr_material);
+    ZR_L_FIELD("Material.BaseColorFactor", zr_material, base_color_factor); ZR_L_FIELD("Material.BaseColorTex_Subsurf_CoatWeight", zr_material, base_color_tex_subsurf_coat_weight);
+    ZR_L_FIELD("Material.NormalTex_TrDepth", zr_material, normal_tex_tr_depth); ZR_L_FIELD("Material.MRTex_SpecRoughness_CoatRoughness", zr_material, mr_tex_spec_roughness_coat_roughness);
+    ZR_L_FIELD("Material.EmissiveFactor_NormalScale", zr_material, emissive_factor_normal_scale); ZR_L_FIELD("Material.EmissiveStrength_IOR", zr_material, emissive_strength_ior);
+    ZR_L_FIELD("Material.EmissiveTex_AlphaCutoff_CoatIOR", zr_material, emissive_tex_alpha_cutoff_coat_ior); ZR_L_FIELD("Material.CoatColor_Flags", zr_material, coat_color_flags);
+    ZR_L_SIZE("cbFrameConstants", zr_frame_constants);
+#define ZR_L_CB(ref, f) ZR_L_FIELD("cbFrameConstants." ref, zr_frame_constants, f)
+    ZR_L_CB("CurrView", curr_view); ZR_L_CB("PrevView", prev_view); ZR_L_CB("CurrViewInv", curr_view_inv); ZR_L_CB("PrevViewInv", prev_view_inv);
+    ZR_L_CB("CurrViewProj", curr_view_proj); ZR_L_CB("PrevViewProj", prev_view_proj); ZR_L_CB("CameraPos", camera_pos); ZR_L_CB("CameraNear", camera_near);
+    ZR_L_CB("AspectRatio", aspect_ratio); ZR_L_CB("PixelSpreadAngle", pixel_spread_angle); ZR_L_CB("TanHalfFOV", tan_half_fov); ZR_L_CB("dt", dt);
+    ZR_L_CB("FrameNum", frame_num); ZR_L_CB("CurrGBufferDescHeapOffset", curr_gbuffer_desc_heap_offset); ZR_L_CB("PrevGBufferDescHeapOffset", prev_gbuffer_desc_heap_offset);
+    ZR_L_CB("BaseColorMapsDescHeapOffset", base_color_maps_desc_heap_offset); ZR_L_CB("NormalMapsDescHeapOffset", normal_maps_desc_heap_offset);
+    ZR_L_CB("MetallicRoughnessMapsDescHeapOffset", metallic_roughness_maps_desc_heap_offset); ZR_L_CB("EmissiveMapsDescHeapOffset", emissive_maps_desc_heap_offset);
+    ZR_L_CB("EnvMapDescHeapOffset", env_map_desc_heap_offset); ZR_L_CB("RenderWidth", render_width); ZR_L_CB("RenderHeight", render_height);
+    ZR_L_CB("DisplayWidth", display_width); ZR_L_CB("DisplayHeight", display_height); ZR_L_CB("CurrCameraJitter", curr_camera_jitter); ZR_L_CB("PrevCameraJitter", prev_camera_jitter);
+    ZR_L_CB("PlanetRadius", planet_radius); ZR_L_CB("SunCosAngularRadius", sun_cos_angular_radius); ZR_L_CB("SunSinAngularRadius", sun_sin_angular_radius); ZR_L_CB("pad", pad);
+    ZR_L_CB("SunDir", sun_dir); ZR_L_CB("SunIlluminance", sun_illuminance); ZR_L_CB("RayleighSigmaSColor", rayleigh_sigma_s_color); ZR_L_CB("RayleighSigmaSScale", rayleigh_sigma_s_scale);
+    ZR_L_CB("OzoneSigmaAColor", ozone_sigma_a_color); ZR_L_CB("OzoneSigmaAScale", ozone_sigma_a_scale); ZR_L_CB("MieSigmaS", mie_sigma_s); ZR_L_CB("MieSigmaA", mie_sigma_a);
+    ZR_L_CB("AtmosphereAltitude", atmosphere_altitude); ZR_L_CB("g", g); ZR_L_CB("NumFramesCameraStatic", num_frames_camera_static); ZR_L_CB("CameraStatic", camera_static);
+    ZR_L_CB("Accumulate", accumulate); ZR_L_CB("SunMoved", sun_moved); ZR_L_CB("CameraRayUVGradsScale", camera_ray_uv_grads_scale); ZR_L_CB("MipBias", mip_bias);
+    ZR_L_CB("OneDivNumEmissiveTriangles", one_div_num_emissive_triangles); ZR_L_CB("NumEmissiveTriangles", num_emissive_triangles); ZR_L_CB("FocusDepth", focus_depth);
+    ZR_L_CB("LensRadius", lens_radius); ZR_L_CB("DoF", dof); ZR_L_CB("pad2", pad2);
+#undef ZR_L_CB
+#undef ZR_L_FIELD
+#undef ZR_L_SIZE
+    if (!buf || s.size() + 1 > cap) return -(int)(s.size() + 1);
+    memcpy(buf, s.c_str(), s.size() + 1);
+    return (int)s.size();
+}
+
 int zr_scene_destroy(zr_scene* s) { delete s; return ZR_OK; }
 
 int zr_scene_set_alias_table(zr_scene* s, const zr_alias_entry* e, uint32_t n)
