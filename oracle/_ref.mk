@@ -9,10 +9,34 @@
 REF ?= /root/reference
 CXX ?= g++
 FLAGS := -std=c++20 -O2 -mavx2 -mfma -mf16c -fPIC -w -include ref_shim.h -I$(REF)/Source/ZetaCore -I$(REF)/Source -I$(REF)/External -DNDEBUG
-HLSL_FLAGS := -std=c++17 -O2 -ffp-contract=off -fno-fast-math -mavx2 -mfma -mf16c -fPIC -fpermissive -w -Iref_hlsl -I_ref/gen
-HLSL_ROOTS := ZetaRenderPass/Common/BSDFSampling.hlsli ZetaRenderPass/Common/RT.hlsli ZetaRenderPass/Common/GBuffers.hlsli ZetaRenderPass/Common/FrameConstants.h
+# The shader code is compiled with clang++ (the ROCm toolchain's) and -ftrivial-auto-var-init=zero: HLSL leaves locals such as
+# `Reconnection ret;` partly unset (Shift.hlsli:16-36 never sets x_k_in_motion / lobes / ID) and later READS them
+# (ReSTIR_PT_Reconnect_StC.hlsl:275); on the GPU an undefined value is 0 in practice, and 0 is what the ABI defines for them.
+HLSL_CXX ?= /opt/rocm/lib/llvm/bin/clang++
+HLSL_FLAGS := -std=c++17 -O2 -ffp-contract=off -fno-fast-math -mavx2 -mfma -mf16c -fPIC -w -ftrivial-auto-var-init=zero -Iref_hlsl -I_ref/gen
+HLSL_ROOTS := ZetaRenderPass/Common/BSDFSampling.hlsli ZetaRenderPass/Common/RT.hlsli ZetaRenderPass/Common/GBuffers.hlsli ZetaRenderPass/Common/FrameConstants.h \
+    ZetaRenderPass/GBuffer/GBufferRT_Inline.hlsl ZetaRenderPass/GBuffer/GBufferRT_Common.h \
+    ZetaRenderPass/IndirectLighting/PathTracer/PathTracer.hlsl ZetaRenderPass/IndirectLighting/IndirectLighting_Common.h \
+    $(addprefix ZetaRenderPass/IndirectLighting/ReSTIR_PT/,ReSTIR_PT_PathTrace.hlsl ReSTIR_PT_Replay.hlsl ReSTIR_PT_Reconnect_CtT.hlsl \
+        ReSTIR_PT_Reconnect_TtC.hlsl ReSTIR_PT_Reconnect_CtS.hlsl ReSTIR_PT_Reconnect_StC.hlsl ReSTIR_PT_SpatialSearch.hlsl)
 
-all: _ref/libzref.so _ref/libzref_hlsl.so
+# the reference's shader PASSES compiled as C++ (one shared object per shader permutation, like the reference's .cso files):
+#   _ref/libzref_k1.so                      GBufferRT_Inline.hlsl
+#   _ref/libzref_k9_{e0,e1,e1p}.so          PathTracer.hlsl with NEE_EMISSIVE = 0 / 1 / 1 + USE_PRESAMPLED_SETS (PathTracer, _WoPS, _WPS)
+#   _ref/libzref_rpt_{e0,e1,e1p}.so         ReSTIR PT: the 10 shaders of Variants/*.hlsl per NEE permutation + the restated host sequence (ref_rpt_host.cpp)
+PASS_LIBS := _ref/libzref_k1.so _ref/libzref_k9_e0.so _ref/libzref_k9_e1.so _ref/libzref_k9_e1p.so _ref/libzref_rpt_e0.so _ref/libzref_rpt_e1.so _ref/libzref_rpt_e1p.so
+PASS_HDRS := ref_hlsl/ref_pass_common.h ref_hlsl/hlsl_shim.h ref_hlsl/hlsl_resources.h ref_hlsl/hlsl_rt.h ref_hlsl/hlsl_group.h zro_scene.h
+
+all: _ref/libzref.so _ref/libzref_hlsl.so $(PASS_LIBS)
+
+_ref/libzref_k1.so: _ref/gen/.stamp ref_hlsl/ref_pass_gbuffer.cpp $(PASS_HDRS)
+	$(HLSL_CXX) $(HLSL_FLAGS) -shared -o $@ ref_hlsl/ref_pass_gbuffer.cpp
+_ref/libzref_k9_e0.so: _ref/gen/.stamp ref_hlsl/ref_pass_pathtracer.cpp $(PASS_HDRS)
+	$(HLSL_CXX) $(HLSL_FLAGS) -DNEE_EMISSIVE=0 -shared -o $@ ref_hlsl/ref_pass_pathtracer.cpp
+_ref/libzref_k9_e1.so: _ref/gen/.stamp ref_hlsl/ref_pass_pathtracer.cpp $(PASS_HDRS)
+	$(HLSL_CXX) $(HLSL_FLAGS) -DNEE_EMISSIVE=1 -shared -o $@ ref_hlsl/ref_pass_pathtracer.cpp
+_ref/libzref_k9_e1p.so: _ref/gen/.stamp ref_hlsl/ref_pass_pathtracer.cpp $(PASS_HDRS)
+	$(HLSL_CXX) $(HLSL_FLAGS) -DNEE_EMISSIVE=1 -DUSE_PRESAMPLED_SETS -shared -o $@ ref_hlsl/ref_pass_pathtracer.cpp
 
 _ref/libzref.so: ref_driver.cpp ref_shim.h
 	mkdir -p _ref
@@ -24,4 +48,37 @@ _ref/gen/.stamp: ref_hlsl/hlsl2cpp.py
 	touch $@
 
 _ref/libzref_hlsl.so: _ref/gen/.stamp ref_hlsl/ref_hlsl_driver.cpp ref_hlsl/hlsl_shim.h ref_hlsl/hlsl_resources.h zro_kat_layout.h
-	$(CXX) $(HLSL_FLAGS) -shared -o $@ ref_hlsl/ref_hlsl_driver.cpp
+	$(HLSL_CXX) $(HLSL_FLAGS) -shared -o $@ ref_hlsl/ref_hlsl_driver.cpp
+
+# ---- ReSTIR PT: one object per shader permutation (private namespace through -Dhlsl=...), linked with the host sequence
+RPT := ZetaRenderPass/IndirectLighting/ReSTIR_PT
+RPT_CB := -include ZetaRenderPass/IndirectLighting/IndirectLighting_Common.h
+# $(call rpt_obj,<perm tag>,<shader tag>,<file>,<g_local type>,<has scene>,<has lights>,<permutation macros>)
+define rpt_obj
+_ref/obj/rpt_$(1)_$(2).o: _ref/gen/.stamp ref_hlsl/ref_pass_shader.cpp ref_hlsl/ref_dispatch.h $(PASS_HDRS)
+	mkdir -p _ref/obj
+	$(HLSL_CXX) $(HLSL_FLAGS) -fvisibility=hidden -c -o $$@ ref_hlsl/ref_pass_shader.cpp -Dhlsl=hlsl_rpt_$(2) '-DZR_SHADER="$(RPT)/$(3)"' \
+	    -DZR_ENTRY=zrefp_shader_rpt_$(2) -DZR_LOCAL_CB=$(4) -DZR_HAS_SCENE=$(5) -DZR_HAS_LIGHTS=$(6) $(7)
+RPT_OBJS_$(1) += _ref/obj/rpt_$(1)_$(2).o
+endef
+# $(call rpt_perm,<perm tag>,<NEE_EMISSIVE>,<extra path-trace macros>)
+define rpt_perm
+$(call rpt_obj,$(1),pathtrace,ReSTIR_PT_PathTrace.hlsl,cb_ReSTIR_PT_PathTrace,1,$(2),-DNEE_EMISSIVE=$(2) $(3))
+$(call rpt_obj,$(1),replay_ctt,ReSTIR_PT_Replay.hlsl,cb_ReSTIR_PT_Reuse,1,0,-DNEE_EMISSIVE=$(2))
+$(call rpt_obj,$(1),replay_ttc,ReSTIR_PT_Replay.hlsl,cb_ReSTIR_PT_Reuse,1,0,-DNEE_EMISSIVE=$(2) -DTEMPORAL_TO_CURRENT)
+$(call rpt_obj,$(1),replay_cts,ReSTIR_PT_Replay.hlsl,cb_ReSTIR_PT_Reuse,1,0,-DNEE_EMISSIVE=$(2) -DCURRENT_TO_SPATIAL)
+$(call rpt_obj,$(1),replay_stc,ReSTIR_PT_Replay.hlsl,cb_ReSTIR_PT_Reuse,1,0,-DNEE_EMISSIVE=$(2) -DSPATIAL_TO_CURRENT)
+$(call rpt_obj,$(1),reconnect_ctt,ReSTIR_PT_Reconnect_CtT.hlsl,cb_ReSTIR_PT_Reuse,1,0,-DNEE_EMISSIVE=$(2))
+$(call rpt_obj,$(1),reconnect_ttc,ReSTIR_PT_Reconnect_TtC.hlsl,cb_ReSTIR_PT_Reuse,1,0,-DNEE_EMISSIVE=$(2))
+$(call rpt_obj,$(1),reconnect_cts,ReSTIR_PT_Reconnect_CtS.hlsl,cb_ReSTIR_PT_Reuse,1,0,-DNEE_EMISSIVE=$(2))
+$(call rpt_obj,$(1),reconnect_stc,ReSTIR_PT_Reconnect_StC.hlsl,cb_ReSTIR_PT_Reuse,1,0,-DNEE_EMISSIVE=$(2))
+$(call rpt_obj,$(1),spatial_search,ReSTIR_PT_SpatialSearch.hlsl,cb_ReSTIR_PT_SpatialSearch,0,0,-DNEE_EMISSIVE=$(2))
+_ref/obj/rpt_$(1)_host.o: _ref/gen/.stamp ref_hlsl/ref_rpt_host.cpp ref_hlsl/ref_dispatch.h $(PASS_HDRS)
+	mkdir -p _ref/obj
+	$(HLSL_CXX) $(HLSL_FLAGS) -c -o $$@ ref_hlsl/ref_rpt_host.cpp
+_ref/libzref_rpt_$(1).so: $$(RPT_OBJS_$(1)) _ref/obj/rpt_$(1)_host.o
+	$(HLSL_CXX) -shared -o $$@ $$(RPT_OBJS_$(1)) _ref/obj/rpt_$(1)_host.o
+endef
+$(eval $(call rpt_perm,e0,0,))
+$(eval $(call rpt_perm,e1,1,))
+$(eval $(call rpt_perm,e1p,1,-DUSE_PRESAMPLED_SETS))

@@ -125,9 +125,30 @@ def fix_static_const_members(code):
     return "".join(out)
 
 
+MAIN_RE = re.compile(r"\[\s*numthreads\s*\(([^\]]*)\)\s*\]\s*void\s+main\s*\(([^)]*)\)", re.S)
+SEM_TO_ARG = {"SV_DispatchThreadID": "zr_DTid", "SV_GroupID": "zr_Gid", "SV_GroupThreadID": "zr_GTid", "SV_GroupIndex": "zr_Gidx"}
+
+
+def entry_point_wrapper(code):
+    """for a compute shader: `zr_numthreads` (the [numthreads] attribute) and `zr_main_dispatch(DTid, Gid, GTid, Gidx)`, which forwards the
+    system values main() asks for through its parameter semantics (they are stripped from the signature further down)"""
+    m = MAIN_RE.search(code)
+    if not m:
+        return ""
+    dims = [d.strip() for d in m.group(1).split(",")]
+    args = []
+    for prm in m.group(2).split(","):
+        sem = prm.split(":")[-1].strip()
+        args.append(SEM_TO_ARG[sem])
+    return ("\nstatic const uint zr_numthreads[3] = {%s, %s, %s};\n"
+            "static inline void zr_main_dispatch(uint3 zr_DTid, uint3 zr_Gid, uint3 zr_GTid, uint zr_Gidx) { main(%s); }\n"
+            % (dims[0], dims[1], dims[2], ", ".join(args)))
+
+
 def translate(src, relpath, special):
     bare = strip_comments_keep_layout(src)
     code = bare
+    wrapper = entry_point_wrapper(code)
     code = code.replace("__cplusplus", "__ZR_REF_NEVER_DEFINED__")
     code = ATTR.sub("", code)
     code = REGISTER.sub("", code)
@@ -142,6 +163,12 @@ def translate(src, relpath, special):
         prev = code
         code = OUTPARAM.sub(r"\1\2& \3", code)
     code = INPARAM.sub(r"\1", code)
+    # half literals: 1.0h -> half(1.0f)
+    code = re.sub(r"(?<![\w.])(\d+\.\d*|\d+)h\b", r"half(\1f)", code)
+    # integer-literal swizzle: 0.xx -> int2(0)
+    code = re.sub(r"(?<![\w.])(\d+)\.(x{2,4})\b", lambda m: "int%d(%s)" % (len(m.group(2)), m.group(1)), code)
+    # scalar-literal swizzle, unsuffixed: 1.0.xxx -> float3(1.0f)
+    code = re.sub(r"(?<![\w.])(\d+\.\d*)\.(x{2,4}|r{2,4})\b", lambda m: "float%d(%sf)" % (len(m.group(2)), m.group(1)), code)
     code = suffix_float_literals(code)
     # scalar-literal swizzle: 1.0f.xxx -> float3(1.0f)
     code = re.sub(r"(?<![\w.])(\d[\w.]*f)\.(x{2,4}|r{2,4})\b", lambda m: "float%d(%s)" % (len(m.group(2)), m.group(1)), code)
@@ -151,7 +178,7 @@ def translate(src, relpath, special):
     code = fix_static_const_members(code)
     for pat, rep in special.get(os.path.basename(relpath), []) + special.get("*", []):
         code, k = re.subn(pat, rep, code)
-    return code
+    return code + wrapper
 
 
 # File-specific lexical fixes (pattern, replacement): places where HLSL and C++ disagree on something the generic rules cannot see.
@@ -165,7 +192,45 @@ SPECIAL = {
         # OffsetRayRTG: `int3 of_i = int_scale * geometricNormal;` -- HLSL converts float3 -> int3 implicitly (truncation toward zero)
         (r"int3 of_i = int_scale \* geometricNormal;", "int3 of_i = int3(int_scale * geometricNormal);"),
     ],
+    "GBufferRT_Inline.hlsl": [
+        # uint2 swizzle passed to an int2 parameter (HLSL converts silently; a C++ proxy cannot convert to two vector types)
+        (r"GBufferRT::UVDifferentials\(DTid\.xy,", "GBufferRT::UVDifferentials(int2(DTid.xy),"),
+    ],
+    "HLSLCompat.h": [
+        # member functions marked CONST in the shared headers are const on the C++ side; the HLSL branch drops the keyword, C++ needs it
+        (r"#define CONST\s*\n", "#define CONST const\n"),
+    ],
+    "Material.h": [
+        # the one getter the reference forgot to mark CONST (it is called on `const Material` values in RayQuery.hlsli)
+        (r"half_ GetTransmissionDepth\(\)", "half_ GetTransmissionDepth() const"),
+    ],
+    "RayQuery.hlsli": [
+        # Visibility_Segment, APPROXIMATE_EMISSIVE_SHADOW_RAY branch: hand the light's ID to the query, which implements the ABI's
+        # order-independent definition of the approximate segment (hlsl_rt.h: triangles carrying that ID are not occluders)
+        (r"(ray\.TMax = Math::PrevFloat32\(rayT \* 0\.999f - Math::NextFloat32\(ray\.TMin\)\);\s*ray\.Direction = wi;)",
+         r"\1 g_rqIgnoreID = triID; g_rqHasIgnoreID = true;"),
+        # `cond ? half : 0`: HLSL converts the literal to half; C++ cannot pick between half and int
+        (r"\? mat\.GetTransmissionDepth\(\) : 0;", "? mat.GetTransmissionDepth() : half(0);"),
+        (r"\? \(half\)mat\.GetSubsurface\(\) : 0;", "? (half)mat.GetSubsurface() : half(0);"),
+    ],
+    "Reservoir.hlsli": [
+        # `.x` on a scalar (legal HLSL): give the scalar a 1-component vector type
+        (r"float inF = g_inF\[DTid\]\.x;", "float1 inF = g_inF[DTid].x;"),
+        (r"void UnpackMetadataX\(uint metadata\)", "void UnpackMetadataX(uint1 metadata)"),
+    ],
+    "ReSTIR_PT_SpatialSearch.hlsl": [
+        (r"const int2 samplePosSS = round\(float2\(DTid\) \+ rotated\);", "const int2 samplePosSS = int2(round(float2(DTid) + rotated));"),
+    ],
+    "LightVoxelGrid.hlsli": [
+        # SignNotZero<T> on an int3 argument: HLSL converts the float3 result to int3 and back; the values are +-1 either way
+        (r"Math::SignNotZero\(voxelIdxCamSpace\)", "Math::SignNotZero(float3(voxelIdxCamSpace))"),
+    ],
     "*": [
+        # implicit float2 -> int2 (truncation) and int swizzle -> uint3 argument in the temporal reprojection code
+        (r"int2 prevPixel = prevUV \* renderDim;", "int2 prevPixel = int2(prevUV * renderDim);"),
+        (r"RNG::PCG3d\(prevPixel\.xyx\)", "RNG::PCG3d(uint3(prevPixel.xyx))"),
+        # `out uint2 swizzledGid` receives a uint16_t2 variable: HLSL converts on the way out, a C++ reference cannot
+        (r"\buint16_t2 swizzledGid;", "uint2 swizzledGid;"),
         # HLSL `groupshared T x[N];` at file scope: one copy per thread group -> per-thread storage owned by the group runner
         (r"\bgroupshared\b", "ZR_GROUPSHARED"),
     ],

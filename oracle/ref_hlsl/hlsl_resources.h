@@ -179,6 +179,10 @@ struct SamplerState
     }
 };
 
+// SamplerDescriptorHeap[i]: the drivers number the samplers like SamplerState::Kind
+struct SamplerHeapRef { SamplerState operator[](uint32_t i) const { SamplerState s; s.kind = (int)i; return s; } };
+static const SamplerHeapRef SamplerDescriptorHeap;
+
 struct HeapHandle { TexStorage* s; };
 struct DescriptorHeap
 {
@@ -190,6 +194,11 @@ static thread_local DescriptorHeap* g_heapPtr = nullptr;
 struct DescriptorHeapRef { HeapHandle operator[](uint32_t i) const { return (*g_heapPtr)[i]; } };
 static const DescriptorHeapRef ResourceDescriptorHeap;
 
+// see RWTexture2D below: the one pending read-modify-write proxy of this thread
+struct PendingRW { void (*flush)(void*) = nullptr; void* obj = nullptr; };
+static thread_local PendingRW g_pendingRW;
+static inline void FlushPendingRW() { if (g_pendingRW.flush) { void (*f)(void*) = g_pendingRW.flush; g_pendingRW.flush = nullptr; f(g_pendingRW.obj); } }
+
 template<class T> struct Texture2D
 {
     TexStorage* s = nullptr;
@@ -197,6 +206,7 @@ template<class T> struct Texture2D
     Texture2D(HeapHandle h) : s(h.s) {}
     T LoadPx(uint32_t x, uint32_t y) const
     {
+        FlushPendingRW();
         float f[4]; uint32_t u[4];
         if (x >= s->w || y >= s->h) { f[0] = f[1] = f[2] = f[3] = 0.0f; u[0] = u[1] = u[2] = u[3] = 0u; return Lanes<T>::get(f, u); }   // out-of-bounds loads return 0
         LoadRaw(*s, (size_t)y * s->w + x, f, u);
@@ -213,6 +223,7 @@ template<class T> struct Texture2D
     // ---- filtered sampling
     T Bilinear(float u, float v, bool wrap) const
     {
+        FlushPendingRW();
         // texel centres at (i + 0.5) / N, fp32 weights, lerp as a + t (b - a); wrap or clamp addressing
         const float W = (float)s->w, H = (float)s->h;
         if (wrap) { u = zr_tex_wrap(u); v = zr_tex_wrap(v); }
@@ -272,22 +283,33 @@ template<class T> struct Texture2D
     }
 };
 
-// RWTexture2D<T>::operator[] -> a reference proxy: reads as T (so swizzles work), assignment encodes into the plane's format
+// RWTexture2D<T>::operator[] -> an lvalue proxy: reads as T (so swizzles work); whole-element assignment and partial writes through a
+// swizzle (`g_out[px].rgb = c`, GBufferRT.hlsli:120; `g_outA[px].x = v`, Reservoir.hlsli:354) both land in the plane.  The proxy lives in
+// per-thread storage and encodes its value back when it changed; at most one proxy is pending, and every resource access, fiber switch
+// and dispatch end flushes it first (FlushPendingRW), so no reader ever sees a stale element.
+
 template<class T, bool IsClass = std::is_class<T>::value && !std::is_same<T, half>::value> struct RWRef;
 template<class T> struct RWRef<T, true> : T
 {
-    TexStorage* s; size_t idx; bool ok;
-    RWRef(TexStorage* st, size_t i, bool inBounds, const T& v) : T(v), s(st), idx(i), ok(inBounds) {}
-    RWRef& operator=(const T& v) { T::operator=(v); if (ok) { float f[4] = {0, 0, 0, 0}; uint32_t u[4] = {0, 0, 0, 0}; Lanes<T>::put(v, f, u); StoreRaw(*s, idx, f, u); } return *this; }
-    RWRef& operator=(const RWRef& o) { return *this = (const T&)o; }
+    TexStorage* s = nullptr; size_t idx = 0; bool ok = false; T orig;
+    void Bind(TexStorage* st, size_t i, bool inBounds, const T& v) { T::operator=(v); s = st; idx = i; ok = inBounds; orig = v; }
+    void Store(const T& v) { float f[4] = {0, 0, 0, 0}; uint32_t u[4] = {0, 0, 0, 0}; Lanes<T>::put(v, f, u); StoreRaw(*s, idx, f, u); }
+    static void FlushFn(void* p)
+    {
+        RWRef* r = (RWRef*)p; const T& cur = *r;
+        if (r->ok && memcmp(&cur, &r->orig, sizeof(T)) != 0) { r->Store(cur); r->orig = cur; }
+    }
+    RWRef& operator=(const T& v) { T::operator=(v); if (ok) Store(v); orig = v; return *this; }     // a whole-element store always writes
+    RWRef& operator=(const RWRef& o) { const T v = (const T&)o; return *this = v; }
 };
 template<class T> struct RWRef<T, false>
 {
-    TexStorage* s; size_t idx; bool ok; T val;
-    RWRef(TexStorage* st, size_t i, bool inBounds, const T& v) : s(st), idx(i), ok(inBounds), val(v) {}
+    TexStorage* s = nullptr; size_t idx = 0; bool ok = false; T val;
+    void Bind(TexStorage* st, size_t i, bool inBounds, const T& v) { s = st; idx = i; ok = inBounds; val = v; }
+    static void FlushFn(void*) {}
     operator T() const { return val; }
     RWRef& operator=(const T& v) { val = v; if (ok) { float f[4] = {0, 0, 0, 0}; uint32_t u[4] = {0, 0, 0, 0}; Lanes<T>::put(v, f, u); StoreRaw(*s, idx, f, u); } return *this; }
-    RWRef& operator=(const RWRef& o) { return *this = (T)o; }
+    RWRef& operator=(const RWRef& o) { const T v = o.val; return *this = v; }
     RWRef& operator+=(const T& v) { return *this = (T)(val + v); }
 };
 template<class T> struct RWTexture2D
@@ -295,18 +317,22 @@ template<class T> struct RWTexture2D
     TexStorage* s = nullptr;
     RWTexture2D() {}
     RWTexture2D(HeapHandle h) : s(h.s) {}
-    RWRef<T> At(uint32_t x, uint32_t y) const
+    RWRef<T>& At(uint32_t x, uint32_t y) const
     {
+        static thread_local RWRef<T> slot;
+        FlushPendingRW();
         float f[4] = {0, 0, 0, 0}; uint32_t u[4] = {0, 0, 0, 0};
         const bool ok = x < s->w && y < s->h;
         const size_t idx = ok ? (size_t)y * s->w + x : 0;
         if (ok) LoadRaw(*s, idx, f, u);
-        return RWRef<T>(s, idx, ok, Lanes<T>::get(f, u));
+        slot.Bind(s, idx, ok, Lanes<T>::get(f, u));
+        g_pendingRW.flush = &RWRef<T>::FlushFn; g_pendingRW.obj = &slot;
+        return slot;
     }
-    RWRef<T> operator[](const uint2& p) const { return At(p.x, p.y); }
-    RWRef<T> operator[](const int2& p) const { return At((uint32_t)p.x, (uint32_t)p.y); }
-    RWRef<T> operator[](const uint16_t2& p) const { return At(p.x, p.y); }
-    template<int M, int A, int B> RWRef<T> operator[](const Swz<uint32_t, M, A, B>& p) const { uint2 q = p; return At(q.x, q.y); }
+    RWRef<T>& operator[](const uint2& p) const { return At(p.x, p.y); }
+    RWRef<T>& operator[](const int2& p) const { return At((uint32_t)p.x, (uint32_t)p.y); }
+    RWRef<T>& operator[](const uint16_t2& p) const { return At(p.x, p.y); }
+    template<int M, int A, int B> RWRef<T>& operator[](const Swz<uint32_t, M, A, B>& p) const { uint2 q = p; return At(q.x, q.y); }
     void GetDimensions(uint32_t& w, uint32_t& h) const { w = s->w; h = s->h; }
 };
 

@@ -49,6 +49,11 @@ template<> struct implicit_vec_conv<int32_t, uint32_t> : std::true_type {};
 template<> struct implicit_vec_conv<uint32_t, int32_t> : std::true_type {};
 template<> struct implicit_vec_conv<uint16_t, uint32_t> : std::true_type {};
 template<> struct implicit_vec_conv<uint16_t, int32_t> : std::true_type {};
+template<> struct implicit_vec_conv<bool, int32_t> : std::true_type {};
+template<> struct implicit_vec_conv<bool, uint32_t> : std::true_type {};
+template<> struct implicit_vec_conv<uint32_t, float> : std::true_type {};      // integer -> float (DXC converts silently; used for pixel coordinates)
+template<> struct implicit_vec_conv<int32_t, float> : std::true_type {};
+template<> struct implicit_vec_conv<uint16_t, float> : std::true_type {};
 
 template<class T, int N, int... I> struct Swz
 {
@@ -177,6 +182,10 @@ HLSL_BITS(uint16_t2) HLSL_BITS(uint16_t3) HLSL_BITS(uint16_t4)
     inline V operator*(const V& a, const V& b) { V r; for (int i = 0; i < V::N; i++) r.d[i] = half((float)a.d[i] * (float)b.d[i]); return r; } \
     inline V operator/(const V& a, const V& b) { V r; for (int i = 0; i < V::N; i++) r.d[i] = half((float)a.d[i] / (float)b.d[i]); return r; }
 HLSL_HALF_ARITH(half2, bool2) HLSL_HALF_ARITH(half3, bool3) HLSL_HALF_ARITH(half4, bool4)
+// half vector (op) float scalar / float vector: promotes to floatN
+#define HLSL_HALF_MIX(V, F) \
+    HLSL_MIX1(V, F, float, F, +) HLSL_MIX1(V, F, float, F, -) HLSL_MIX1(V, F, float, F, *) HLSL_MIX1(V, F, float, F, /) \
+    HLSL_MIXV(V, F, +) HLSL_MIXV(V, F, -) HLSL_MIXV(V, F, *) HLSL_MIXV(V, F, /)
 // integer vector (op) scalar: an integer scalar keeps the vector's type, a float scalar / float vector promotes to floatN (what DXC does)
 #define HLSL_MIX1(V, F, S, R, op) \
     inline R operator op(const V& a, S b) { R r; for (int i = 0; i < V::N; i++) r.d[i] = (typename R::elem)a.d[i] op (typename R::elem)b; return r; } \
@@ -193,9 +202,12 @@ HLSL_HALF_ARITH(half2, bool2) HLSL_HALF_ARITH(half3, bool3) HLSL_HALF_ARITH(half
     HLSL_MIXV(V, F, +) HLSL_MIXV(V, F, -) HLSL_MIXV(V, F, *) HLSL_MIXV(V, F, /)
 #define HLSL_FSCALAR(V) HLSL_MIX1(V, V, float, V, +) HLSL_MIX1(V, V, float, V, -) HLSL_MIX1(V, V, float, V, *) HLSL_MIX1(V, V, float, V, /)
 HLSL_FSCALAR(float2) HLSL_FSCALAR(float3) HLSL_FSCALAR(float4)
+#define HLSL_HSCALAR(V) HLSL_MIX1(V, V, half, V, +) HLSL_MIX1(V, V, half, V, -) HLSL_MIX1(V, V, half, V, *) HLSL_MIX1(V, V, half, V, /)
+HLSL_HSCALAR(float2) HLSL_HSCALAR(float3) HLSL_HSCALAR(float4)
 HLSL_MIX(uint2, float2) HLSL_MIX(uint3, float3) HLSL_MIX(uint4, float4)
 HLSL_MIX(int2, float2) HLSL_MIX(int3, float3) HLSL_MIX(int4, float4)
 HLSL_MIX(uint16_t2, float2) HLSL_MIX(uint16_t3, float3) HLSL_MIX(uint16_t4, float4)
+HLSL_HALF_MIX(half2, float2) HLSL_HALF_MIX(half3, float3) HLSL_HALF_MIX(half4, float4)
 #define HLSL_BOOLV(V) \
     inline V operator!(const V& a) { V r; for (int i = 0; i < V::N; i++) r.d[i] = !a.d[i]; return r; } \
     inline V hlsl_and(const V& a, const V& b) { V r; for (int i = 0; i < V::N; i++) r.d[i] = a.d[i] && b.d[i]; return r; } \
@@ -261,10 +273,11 @@ inline uint reversebits(uint x) { uint r = 0; for (int i = 0; i < 32; i++) r |= 
 
 // min / max / clamp / select on scalars of mixed arithmetic types: the usual arithmetic conversions (what DXC applies);
 // floats compare with the HLSL / ABI NaN behaviour of zr_min / zr_max (a < b ? a : b)
-template<class A, class B> struct arith2 { typedef typename std::common_type<A, B>::type type; };
-template<> struct arith2<half, half> { typedef half type; };
-template<class B> struct arith2<half, B> { typedef float type; };
-template<class A> struct arith2<A, half> { typedef float type; };
+template<class A, class B, class = void> struct arith2 {};
+template<class A, class B> struct arith2<A, B, typename std::enable_if<std::is_arithmetic<A>::value && std::is_arithmetic<B>::value>::type> { typedef typename std::common_type<A, B>::type type; };
+template<> struct arith2<half, half, void> { typedef half type; };
+template<class B> struct arith2<half, B, typename std::enable_if<std::is_arithmetic<B>::value>::type> { typedef float type; };
+template<class A> struct arith2<A, half, typename std::enable_if<std::is_arithmetic<A>::value>::type> { typedef float type; };
 template<class T> struct is_scalar_t : std::integral_constant<bool, std::is_arithmetic<T>::value || std::is_same<T, half>::value> {};
 #define HLSL_SCALAR2(A, B) typename std::enable_if<is_scalar_t<A>::value && is_scalar_t<B>::value, typename arith2<A, B>::type>::type
 template<class A, class B> inline HLSL_SCALAR2(A, B) min(A a, B b) { typedef typename arith2<A, B>::type T; T x = (T)a, y = (T)b; return x < y ? x : y; }
@@ -310,6 +323,15 @@ template<int N> inline vec<uint16_t, N> asuint16(const vec<half, N>& h) { vec<ui
     inline bool any(const V& a) { bool r = false; for (int i = 0; i < V::N; i++) r = r || (a.d[i] != 0.0f); return r; } \
     inline bool all(const V& a) { bool r = true; for (int i = 0; i < V::N; i++) r = r && (a.d[i] != 0.0f); return r; }
 HLSL_FLOATV(float2, bool2, uint2, int2) HLSL_FLOATV(float3, bool3, uint3, int3) HLSL_FLOATV(float4, bool4, uint4, int4)
+// mad with scalar operands (a float or half scalar broadcasts)
+#define HLSL_MADS(V) \
+    inline V mad(const V& a, float b, const V& c) { V r; for (int i = 0; i < V::N; i++) r.d[i] = zr_fma(a.d[i], b, c.d[i]); return r; } \
+    inline V mad(float a, const V& b, const V& c) { V r; for (int i = 0; i < V::N; i++) r.d[i] = zr_fma(a, b.d[i], c.d[i]); return r; } \
+    inline V mad(const V& a, const V& b, float c) { V r; for (int i = 0; i < V::N; i++) r.d[i] = zr_fma(a.d[i], b.d[i], c); return r; } \
+    inline V mad(const V& a, float b, float c) { V r; for (int i = 0; i < V::N; i++) r.d[i] = zr_fma(a.d[i], b, c); return r; } \
+    inline V mad(float a, const V& b, float c) { V r; for (int i = 0; i < V::N; i++) r.d[i] = zr_fma(a, b.d[i], c); return r; } \
+    inline V mad(float a, float b, const V& c) { V r; for (int i = 0; i < V::N; i++) r.d[i] = zr_fma(a, b, c.d[i]); return r; }
+HLSL_MADS(float2) HLSL_MADS(float3) HLSL_MADS(float4)
 #define HLSL_INTV(V, B) \
     HLSL_MAP2(V, min) HLSL_MAP2(V, max) HLSL_MAP3(V, clamp) HLSL_MAP3(V, mad) \
     inline V select(const B& c, const V& a, const V& b) { V r; for (int i = 0; i < V::N; i++) r.d[i] = c.d[i] ? a.d[i] : b.d[i]; return r; } \

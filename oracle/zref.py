@@ -1,0 +1,127 @@
+"""ORACLE tooling -- test infrastructure only.
+
+ctypes wrappers over the REFERENCE's own shader passes compiled as C++ (oracle/_ref/libzref_k*.so, built by `make -C oracle -f _ref.mk`
+from /root/reference; see oracle/ref_hlsl/).  Only available where /root/reference exists (the build container): tests use it live
+there and fall back to the goldens it generated (tests/golden/ref_pass_*.npz, tools/make_ref_pass_goldens.py) elsewhere."""
+import ctypes as C
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+_libs = {}
+
+
+def available():
+    return os.path.exists(os.path.join(HERE, "_ref", "libzref_k1.so"))
+
+
+def _lib(name):
+    if name not in _libs:
+        L = C.CDLL(os.path.join(HERE, "_ref", f"libzref_{name}.so"))
+        L.zrefp_scene_create.restype = C.c_void_p
+        L.zrefp_scene_create.argtypes = [C.c_void_p, C.c_int]
+        L.zrefp_scene_destroy.argtypes = [C.c_void_p]
+        L.zrefp_scene_set_alias_table.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32]
+        L.zrefp_scene_set_sky_lut.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32]
+        L.zrefp_scene_set_sample_sets.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32]
+        _libs[name] = L
+    return _libs[name]
+
+
+class RefPass:
+    """one compiled shader permutation + its own copy of the scene"""
+
+    def __init__(self, name, scene, force_bvh=False):
+        self.L = _lib(name)
+        self._desc = scene.desc()
+        self.h = self.L.zrefp_scene_create(C.addressof(self._desc), int(force_bvh))
+        self._keep = []
+
+    def __del__(self):
+        try:
+            self.L.zrefp_scene_destroy(self.h)
+        except Exception:
+            pass
+
+    def set_alias_table(self, entries):
+        e = np.ascontiguousarray(entries)
+        self.L.zrefp_scene_set_alias_table(self.h, e.ctypes.data, len(e))
+
+    def set_sky_lut(self, texels):
+        t = np.ascontiguousarray(texels, np.uint32)
+        self.L.zrefp_scene_set_sky_lut(self.h, t.ctypes.data, t.shape[1], t.shape[0])
+
+    def set_sample_sets(self, sets, num_sets, set_size):
+        s = np.ascontiguousarray(sets)
+        self.L.zrefp_scene_set_sample_sets(self.h, s.ctypes.data, num_sets, set_size)
+
+
+class RefGBuffer(RefPass):
+    """K1: GBufferRT_Inline.hlsl"""
+
+    def __init__(self, scene, force_bvh=False):
+        super().__init__("k1", scene, force_bvh)
+        self.L.zrefp_gbuffer_render.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+
+    def render(self, cb):
+        from zetaray_amd import wire
+        w, h = int(cb["render_width"]), int(cb["render_height"])
+        arrays, planes = wire.alloc_gbuffer_planes(w, h)
+        cbb = np.ascontiguousarray(cb)
+        self.L.zrefp_gbuffer_render(self.h, cbb.ctypes.data, C.addressof(planes))
+        return arrays, planes
+
+
+class RefPathTracer(RefPass):
+    """K9: PathTracer.hlsl; the permutation follows the scene / params like IndirectLighting.h:251-300 picks the .cso"""
+
+    def __init__(self, scene, presampling=False, force_bvh=False):
+        name = "k9_e0" if len(scene.emissives) == 0 else ("k9_e1p" if presampling else "k9_e1")
+        super().__init__(name, scene, force_bvh)
+        self.L.zrefp_pathtrace_render.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+
+    def render(self, cb, gb_planes, params, final=None):
+        w, h = int(cb["render_width"]), int(cb["render_height"])
+        out = np.zeros((h, w, 4), np.float32) if final is None else np.ascontiguousarray(final.copy())
+        cbb = np.ascontiguousarray(cb)
+        self.L.zrefp_pathtrace_render(self.h, cbb.ctypes.data, C.addressof(gb_planes), C.addressof(params), out.ctypes.data)
+        return out
+
+
+class RefRestirPT(RefPass):
+    """K11 + K13-K16: the reference's ReSTIR PT shaders driven by the restated host sequence (oracle/ref_hlsl/ref_rpt_host.cpp)"""
+    PLANES = {"A": (0, np.uint8, 4), "B": (1, np.float32, 2), "C": (2, np.uint32, 4), "D": (3, np.uint32, 4), "E": (4, np.uint16, 1),
+              "F": (5, np.float32, 2), "G": (6, np.uint32, 2), "neighbor": (7, np.uint8, 2), "target": (8, np.float32, 4)}
+
+    def __init__(self, scene, w, h, presampling=False, force_bvh=False):
+        name = "rpt_e0" if len(scene.emissives) == 0 else ("rpt_e1p" if presampling else "rpt_e1")
+        super().__init__(name, scene, force_bvh)
+        L = self.L
+        L.zrefp_rpt_create.restype = C.c_void_p
+        L.zrefp_rpt_create.argtypes = [C.c_uint32, C.c_uint32]
+        L.zrefp_rpt_destroy.argtypes = [C.c_void_p]
+        L.zrefp_rpt_reset_temporal.argtypes = [C.c_void_p]
+        L.zrefp_rpt_render.argtypes = [C.c_void_p] * 7
+        L.zrefp_rpt_read_plane.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+        self.w, self.h_ = w, h
+        self.st = L.zrefp_rpt_create(w, h)
+        self.prev = None
+
+    def reset_temporal(self):
+        self.L.zrefp_rpt_reset_temporal(self.st)
+
+    def render(self, cb, params, gb):
+        """gb = (arrays, planes) of THIS frame's G-buffer; the previous frame's is remembered"""
+        out = np.zeros((self.h_, self.w, 4), np.float32)
+        cbb = np.ascontiguousarray(cb)
+        prev = C.addressof(self.prev[1]) if self.prev is not None else None
+        self.L.zrefp_rpt_render(self.h, self.st, cbb.ctypes.data, C.addressof(gb[1]), prev, C.addressof(params), out.ctypes.data)
+        self.prev = gb
+        return out
+
+    def plane(self, name, which=0):
+        idx, dt, ch = self.PLANES[name]
+        buf = np.zeros((self.h_, self.w, ch), dt)
+        self.L.zrefp_rpt_read_plane(self.st, which, idx, buf.ctypes.data)
+        return buf

@@ -1,0 +1,60 @@
+"""Generates tests/golden/ref_pass_*.npz: outputs of the REFERENCE's own shader passes compiled as C++ (oracle/_ref/libzref_k1.so,
+libzref_k9_*.so, libzref_rpt_*.so; `make -C oracle -f _ref.mk`) on the scenarios of tools/ref_pass_cases.py.
+
+    ref_pass_gbuffer.npz   K1 (GBufferRT_Inline.hlsl): the 10 G-buffer planes of frame 1 of every scene
+    ref_pass_<case>.npz    K9 (PathTracer.hlsl): FINAL of every frame; ReSTIR PT (K11, K13-K16): FINAL of every frame + the 7 reservoir planes
+                           and the spatial-neighbour plane after the last frame
+
+Inputs the reference computes elsewhere are taken from the already-pinned parts: the alias table (bit-exact vs the reference's own
+AliasTable_Build, tests/test_ref_pins.py), and K3 presampled sets / K17 sky LUT from the oracle (their building blocks are pinned in
+tests/test_ref_hlsl_pins.py).  The committed files let machines without /root/reference (the GPU box) compare the oracle AND the HIP
+product with the reference's outputs.  Run in the build container: python tools/make_ref_pass_goldens.py"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+import ref_pass_cases as RC  # noqa: E402
+from oracle import zref, zro  # noqa: E402
+from zetaray_amd import wire  # noqa: E402
+
+
+def prepare(ref, o, sc, cb, f, prm):
+    """scene-level inputs of frame f on the reference side"""
+    if len(sc.emissives) == 0:
+        ref.set_sky_lut(o.sky_lut(cb, 256, 128))
+    elif f == 1:
+        ref.set_alias_table(o.alias)
+    if prm.presampling:
+        ref.set_sample_sets(o.presample(f, prm.num_sample_sets, prm.sample_set_size), prm.num_sample_sets, prm.sample_set_size)
+
+
+def main():
+    gb_out = {}
+    for case in RC.CASES:
+        sc, force_bvh, integ, prm = RC.scene_and_params(case)
+        o = zro.OracleScene(sc, force_bvh=force_bvh)
+        k1 = zref.RefGBuffer(sc, force_bvh)
+        ref = (zref.RefPathTracer(sc, bool(prm.presampling), force_bvh) if integ == "pt" else
+               zref.RefRestirPT(sc, RC.W, RC.H, bool(prm.presampling), force_bvh))
+        res = {}
+        for f, cb in RC.frames_of(case):
+            prepare(ref, o, sc, cb, f, prm)
+            arrays, planes = k1.render(cb)
+            if f == 1:
+                for n, a in zip(wire.GB_PLANE_NAMES, arrays):
+                    gb_out[f"{case}_{n}"] = a.copy()
+            res[f"final_{f}"] = ref.render(cb, planes, prm) if integ == "pt" else ref.render(cb, prm, (arrays, planes))
+        if integ == "rpt":
+            for nm in RC.RPT_PLANES:
+                res["plane_" + nm] = ref.plane(nm)
+        np.savez_compressed(os.path.join(ROOT, "tests", "golden", f"ref_pass_{case}.npz"), **res)
+        print(case, {k: float(np.asarray(v, np.float64).mean()) for k, v in res.items() if k.startswith("final")})
+    np.savez_compressed(os.path.join(ROOT, "tests", "golden", "ref_pass_gbuffer.npz"), **gb_out)
+
+
+if __name__ == "__main__":
+    main()

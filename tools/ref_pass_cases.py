@@ -1,0 +1,69 @@
+"""The scenarios rendered by the REFERENCE's own shader passes (oracle/zref.py) for tests/golden/ref_pass_*.npz, shared by the generator
+(tools/make_ref_pass_goldens.py) and the tests that replay them on the oracle and on the GPU (tests/test_ref_passes.py)."""
+import os
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+W, H = 96, 64
+
+
+def _scene(kind):
+    from zetaray_amd import scene_io
+    if kind == "cornell_emissive":
+        return scene_io.load_npz(os.path.join(ROOT, "tests", "golden", "cornell_emissive.npz")), False, {}
+    if kind == "cornell":
+        return scene_io.load_npz(os.path.join(ROOT, "tests", "golden", "cornell.npz")), False, {}
+    if kind == "materials":           # metal / coat / glass / thin-walled instances, 150 lights
+        return scene_io.make_synthetic_scene(num_tris=3000, num_emissive=150, seed=11), True, dict(cam_pos=(0, 0, -3.5))
+    if kind == "materials_lights":    # the same geometry with 1500 lights (presampled sets)
+        return scene_io.make_synthetic_scene(num_tris=3000, num_emissive=1500, seed=11), True, dict(cam_pos=(0, 0, -3.5))
+    raise KeyError(kind)
+
+
+def _params(bounces=None, presample=None, flags_off=0):
+    from zetaray_amd import wire
+    p = wire.default_params()
+    if bounces:
+        p.max_non_tr_bounces, p.max_glossy_tr_bounces = bounces
+    if presample:
+        p.presampling, p.num_sample_sets, p.sample_set_size = 1, presample[0], presample[1]
+    p.flags &= ~flags_off
+    return p
+
+
+# name -> (scene kind, integrator, frames, params kwargs, moving camera?)
+CASES = {
+    "k9_cornell_emissive": ("cornell_emissive", "pt", 2, {}, False),
+    "k9_materials_rr": ("materials", "pt", 2, dict(bounces=(6, 8)), False),
+    "k9_presampled": ("materials_lights", "pt", 2, dict(presample=(32, 128)), False),
+    "k9_sun_sky": ("cornell", "pt", 2, {}, False),
+    "rpt_cornell_moving": ("cornell_emissive", "rpt", 4, {}, True),
+    "rpt_materials_rr": ("materials_lights", "rpt", 3, dict(bounces=(6, 8)), False),
+    "rpt_presampled": ("materials_lights", "rpt", 3, dict(presample=(32, 128)), False),
+    "rpt_sun_sky": ("cornell", "rpt", 3, {}, False),
+}
+RPT_PLANES = ("A", "B", "C", "D", "E", "F", "G", "neighbor")
+
+
+def frames_of(case):
+    """yields (frame number, cbFrameConstants) with the previous-frame camera chained like a renderer does"""
+    from zetaray_amd import scene_io
+    kind, _, n, _, moving = CASES[case]
+    sc, _, cam = _scene(kind)
+    prev = None
+    for f in range(1, n + 1):
+        kw = dict(cam)
+        if moving:
+            kw["cam_pos"] = (0.05 * f, 1.2, -4.043 + 0.02 * f)
+        cb = scene_io.make_frame_constants(W, H, frame_num=f, num_emissives=len(sc.emissives), **kw)
+        if prev is not None:
+            cb["prev_view"], cb["prev_view_inv"], cb["prev_camera_jitter"] = prev["curr_view"], prev["curr_view_inv"], prev["curr_camera_jitter"]
+        prev = cb.copy()
+        yield f, cb
+
+
+def scene_and_params(case):
+    kind, integ, n, pk, _ = CASES[case]
+    sc, force_bvh, _ = _scene(kind)
+    return sc, force_bvh, integ, _params(**pk)
