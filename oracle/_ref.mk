@@ -18,13 +18,17 @@ HLSL_ROOTS := ZetaRenderPass/Common/BSDFSampling.hlsli ZetaRenderPass/Common/RT.
     ZetaRenderPass/GBuffer/GBufferRT_Inline.hlsl ZetaRenderPass/GBuffer/GBufferRT_Common.h \
     ZetaRenderPass/IndirectLighting/PathTracer/PathTracer.hlsl ZetaRenderPass/IndirectLighting/IndirectLighting_Common.h \
     $(addprefix ZetaRenderPass/IndirectLighting/ReSTIR_PT/,ReSTIR_PT_PathTrace.hlsl ReSTIR_PT_Replay.hlsl ReSTIR_PT_Reconnect_CtT.hlsl \
-        ReSTIR_PT_Reconnect_TtC.hlsl ReSTIR_PT_Reconnect_CtS.hlsl ReSTIR_PT_Reconnect_StC.hlsl ReSTIR_PT_SpatialSearch.hlsl)
+        ReSTIR_PT_Reconnect_TtC.hlsl ReSTIR_PT_Reconnect_CtS.hlsl ReSTIR_PT_Reconnect_StC.hlsl ReSTIR_PT_SpatialSearch.hlsl) \
+    ZetaRenderPass/IndirectLighting/ReSTIR_GI/ReSTIR_GI.hlsl \
+    $(addprefix ZetaRenderPass/DirectLighting/,Emissive/ReSTIR_DI_Temporal.hlsl Emissive/ReSTIR_DI_Spatial.hlsl Emissive/DirectLighting_Common.h \
+        Sky/SkyDI_Temporal.hlsl Sky/SkyDI_Spatial.hlsl Sky/SkyDI_Common.h)
 
 # the reference's shader PASSES compiled as C++ (one shared object per shader permutation, like the reference's .cso files):
 #   _ref/libzref_k1.so                      GBufferRT_Inline.hlsl
 #   _ref/libzref_k9_{e0,e1,e1p}.so          PathTracer.hlsl with NEE_EMISSIVE = 0 / 1 / 1 + USE_PRESAMPLED_SETS (PathTracer, _WoPS, _WPS)
 #   _ref/libzref_rpt_{e0,e1,e1p}.so         ReSTIR PT: the 10 shaders of Variants/*.hlsl per NEE permutation + the restated host sequence (ref_rpt_host.cpp)
-PASS_LIBS := _ref/libzref_k1.so _ref/libzref_k9_e0.so _ref/libzref_k9_e1.so _ref/libzref_k9_e1p.so _ref/libzref_rpt_e0.so _ref/libzref_rpt_e1.so _ref/libzref_rpt_e1p.so
+PASS_LIBS := _ref/libzref_k1.so _ref/libzref_k9_e0.so _ref/libzref_k9_e1.so _ref/libzref_k9_e1p.so _ref/libzref_rpt_e0.so _ref/libzref_rpt_e1.so _ref/libzref_rpt_e1p.so \
+    _ref/libzref_gi_e0.so _ref/libzref_gi_e1.so _ref/libzref_gi_e1p.so _ref/libzref_di_e1.so _ref/libzref_di_e1p.so _ref/libzref_di_sky.so
 PASS_HDRS := ref_hlsl/ref_pass_common.h ref_hlsl/hlsl_shim.h ref_hlsl/hlsl_resources.h ref_hlsl/hlsl_rt.h ref_hlsl/hlsl_group.h zro_scene.h
 
 all: _ref/libzref.so _ref/libzref_hlsl.so $(PASS_LIBS)
@@ -82,3 +86,42 @@ endef
 $(eval $(call rpt_perm,e0,0,))
 $(eval $(call rpt_perm,e1,1,))
 $(eval $(call rpt_perm,e1p,1,-DUSE_PRESAMPLED_SETS))
+
+# ---- ReSTIR GI (K10): ReSTIR_GI.hlsl / Variants/ReSTIR_GI_WoPS.hlsl / ReSTIR_GI_WPS.hlsl + the restated host (ref_gi_host.cpp)
+# $(call gi_perm,<tag>,<NEE_EMISSIVE>,<extra macros>)
+define gi_perm
+_ref/obj/gi_$(1)_shader.o: _ref/gen/.stamp ref_hlsl/ref_pass_shader.cpp ref_hlsl/ref_dispatch.h $(PASS_HDRS)
+	mkdir -p _ref/obj
+	$(HLSL_CXX) $(HLSL_FLAGS) -fvisibility=hidden -c -o $$@ ref_hlsl/ref_pass_shader.cpp -Dhlsl=hlsl_gi '-DZR_SHADER="ZetaRenderPass/IndirectLighting/ReSTIR_GI/ReSTIR_GI.hlsl"' \
+	    -DZR_ENTRY=zrefp_shader_gi -DZR_LOCAL_CB=cb_ReSTIR_GI -DZR_HAS_SCENE=1 -DZR_HAS_LIGHTS=$(2) -DNEE_EMISSIVE=$(2) $(3)
+_ref/obj/gi_$(1)_host.o: _ref/gen/.stamp ref_hlsl/ref_gi_host.cpp ref_hlsl/ref_dispatch.h $(PASS_HDRS)
+	mkdir -p _ref/obj
+	$(HLSL_CXX) $(HLSL_FLAGS) -c -o $$@ ref_hlsl/ref_gi_host.cpp
+_ref/libzref_gi_$(1).so: _ref/obj/gi_$(1)_shader.o _ref/obj/gi_$(1)_host.o
+	$(HLSL_CXX) -shared -o $$@ _ref/obj/gi_$(1)_shader.o _ref/obj/gi_$(1)_host.o
+endef
+$(eval $(call gi_perm,e0,0,))
+$(eval $(call gi_perm,e1,1,))
+$(eval $(call gi_perm,e1p,1,-DUSE_PRESAMPLED_SETS))
+
+# ---- ReSTIR DI: emissive (K5 / K6: ReSTIR_DI_Temporal{,_WPS}.hlsl + ReSTIR_DI_Spatial.hlsl) and sun + sky (K7 / K8: SkyDI_Temporal.hlsl + SkyDI_Spatial.hlsl)
+DL := ZetaRenderPass/DirectLighting
+# $(call di_lib,<tag>,<sky 0/1>,<temporal file>,<spatial file>,<cb type>,<temporal globals mode>,<spatial globals mode>,<extra macros>)
+define di_lib
+_ref/obj/di_$(1)_temporal.o: _ref/gen/.stamp ref_hlsl/ref_pass_shader.cpp ref_hlsl/ref_dispatch.h $(PASS_HDRS)
+	mkdir -p _ref/obj
+	$(HLSL_CXX) $(HLSL_FLAGS) -fvisibility=hidden -c -o $$@ ref_hlsl/ref_pass_shader.cpp -Dhlsl=hlsl_di_t '-DZR_SHADER="$(DL)/$(3)"' \
+	    -DZR_ENTRY=zrefp_shader_di_temporal -DZR_LOCAL_CB=$(5) -DZR_HAS_SCENE=0 -DZR_HAS_LIGHTS=0 -DZR_DI_GLOBALS=$(6) $(8)
+_ref/obj/di_$(1)_spatial.o: _ref/gen/.stamp ref_hlsl/ref_pass_shader.cpp ref_hlsl/ref_dispatch.h $(PASS_HDRS)
+	mkdir -p _ref/obj
+	$(HLSL_CXX) $(HLSL_FLAGS) -fvisibility=hidden -c -o $$@ ref_hlsl/ref_pass_shader.cpp -Dhlsl=hlsl_di_s '-DZR_SHADER="$(DL)/$(4)"' \
+	    -DZR_ENTRY=zrefp_shader_di_spatial -DZR_LOCAL_CB=$(5) -DZR_HAS_SCENE=0 -DZR_HAS_LIGHTS=0 -DZR_DI_GLOBALS=$(7) $(8)
+_ref/obj/di_$(1)_host.o: _ref/gen/.stamp ref_hlsl/ref_di_host.cpp ref_hlsl/ref_dispatch.h $(PASS_HDRS)
+	mkdir -p _ref/obj
+	$(HLSL_CXX) $(HLSL_FLAGS) -DZR_DI_SKY=$(2) -c -o $$@ ref_hlsl/ref_di_host.cpp
+_ref/libzref_di_$(1).so: _ref/obj/di_$(1)_temporal.o _ref/obj/di_$(1)_spatial.o _ref/obj/di_$(1)_host.o
+	$(HLSL_CXX) -shared -o $$@ _ref/obj/di_$(1)_temporal.o _ref/obj/di_$(1)_spatial.o _ref/obj/di_$(1)_host.o
+endef
+$(eval $(call di_lib,e1,0,Emissive/ReSTIR_DI_Temporal.hlsl,Emissive/ReSTIR_DI_Spatial.hlsl,cb_ReSTIR_DI,1,2,))
+$(eval $(call di_lib,e1p,0,Emissive/ReSTIR_DI_Temporal.hlsl,Emissive/ReSTIR_DI_Spatial.hlsl,cb_ReSTIR_DI,1,2,-DUSE_PRESAMPLED_SETS))
+$(eval $(call di_lib,sky,1,Sky/SkyDI_Temporal.hlsl,Sky/SkyDI_Spatial.hlsl,cb_SkyDI,3,4,))

@@ -163,6 +163,8 @@ def translate(src, relpath, special):
         prev = code
         code = OUTPARAM.sub(r"\1\2& \3", code)
     code = INPARAM.sub(r"\1", code)
+    # macro-constant swizzle: FLT_MAX.xxx -> float3(FLT_MAX)
+    code = re.sub(r"\b([A-Z][A-Z0-9_]+)\.(x{2,4})\b", lambda m: "float%d(%s)" % (len(m.group(2)), m.group(1)), code)
     # half literals: 1.0h -> half(1.0f)
     code = re.sub(r"(?<![\w.])(\d+\.\d*|\d+)h\b", r"half(\1f)", code)
     # integer-literal swizzle: 0.xx -> int2(0)
@@ -229,6 +231,11 @@ SPECIAL = {
         # implicit float2 -> int2 (truncation) and int swizzle -> uint3 argument in the temporal reprojection code
         (r"int2 prevPixel = prevUV \* renderDim;", "int2 prevPixel = int2(prevUV * renderDim);"),
         (r"RNG::PCG3d\(prevPixel\.xyx\)", "RNG::PCG3d(uint3(prevPixel.xyx))"),
+        (r"int2 samplePosSS = prevPixel \+ \(i > 0\) \* offset;", "int2 samplePosSS = int2(float2(prevPixel) + (float)(i > 0) * offset);"),
+        (r"RNG::PCG3d\(samplePosSS\.xyx\)", "RNG::PCG3d(uint3(samplePosSS.xyx))"),
+        (r"RNG::PCG3d\(candidate\.posSS\.xyx\)", "RNG::PCG3d(uint3(candidate.posSS.xyx))"),
+        (r"const int2 posSS_i = round\(float2\(DTid\) \+ rotated\);", "const int2 posSS_i = int2(round(float2(DTid) + rotated));"),
+        (r"RNG::PCG3d\(posSS_i\.xyx\)", "RNG::PCG3d(uint3(posSS_i.xyx))"),
         # `out uint2 swizzledGid` receives a uint16_t2 variable: HLSL converts on the way out, a C++ reference cannot
         (r"\buint16_t2 swizzledGid;", "uint2 swizzledGid;"),
         # HLSL `groupshared T x[N];` at file scope: one copy per thread group -> per-thread storage owned by the group runner

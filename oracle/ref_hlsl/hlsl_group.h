@@ -23,6 +23,7 @@ struct GroupRunner
     {
         ucontext_t ctx; std::vector<char> stack; bool done = true; Scope waiting = NONE; bool runnable = false;
         uint32_t u[4] = {0, 0, 0, 0};           // this lane's operand of the pending cross-lane operation
+        int site = 0;                           // reconvergence rank of the operation the lane is parked at (see Run)
     };
     std::vector<Lane> lanes; ucontext_t sched; int cur = -1; int n = 0;
     // operands of the lanes of one wave at the last rendezvous (stable while the lanes consume them)
@@ -58,11 +59,17 @@ struct GroupRunner
                 bool all = true, any = false;
                 for (int i = w0; i < w1; i++) if (!lanes[i].done) { any = true; if (lanes[i].waiting != WAVE) all = false; }
                 if (!any || !all) continue;
+                // SIMT reconvergence: lanes parked at an operation inside a loop (the Russian-roulette WaveActiveMax of the bounce loops,
+                // rank 0) run on -- with exactly those lanes as the active mask -- while lanes that already left the loop wait at their
+                // operation after it (rank 1) until everyone has arrived, like a masked-off lane waits at the loop's exit on hardware
+                int rank = 1 << 30;
+                for (int i = w0; i < w1; i++) if (!lanes[i].done && lanes[i].site < rank) rank = lanes[i].site;
                 for (int i = w0; i < w1; i++)
                 {
-                    snapActive[i] = !lanes[i].done;
-                    for (int k = 0; k < 4; k++) snapU[4 * i + k] = lanes[i].done ? 0u : lanes[i].u[k];
-                    if (!lanes[i].done) { lanes[i].waiting = NONE; lanes[i].runnable = true; }
+                    const bool go = !lanes[i].done && lanes[i].site == rank;
+                    snapActive[i] = go;
+                    for (int k = 0; k < 4; k++) snapU[4 * i + k] = go ? lanes[i].u[k] : 0u;
+                    if (go) { lanes[i].waiting = NONE; lanes[i].runnable = true; }
                 }
                 released = true;
             }
@@ -89,10 +96,11 @@ static inline void DeviceMemoryBarrier() {}
 static inline void AllMemoryBarrierWithGroupSync() { GroupMemoryBarrierWithGroupSync(); }
 
 // park with a 4-dword operand; afterwards snapU / snapActive of this lane's wave hold every participant's operand
-static inline void WaveRendezvous(const uint32_t* u, int nwords)
+static inline void WaveRendezvous(const uint32_t* u, int nwords, int site = 1)
 {
     GroupRunner* g = GR();
     GroupRunner::Lane& L = g->lanes[g->cur];
+    L.site = site;
     for (int k = 0; k < 4; k++) L.u[k] = k < nwords ? u[k] : 0u;
     g->Park(GroupRunner::WAVE);
 }
@@ -126,7 +134,7 @@ static inline float3 WaveActiveSum(const float3& x) { return float3(WaveActiveSu
 static inline float WaveActiveMax(float x)
 {
     GroupRunner* g = GR(); if (!g) return x;
-    uint32_t u = zr_asuint(x); WaveRendezvous(&u, 1);
+    uint32_t u = zr_asuint(x); WaveRendezvous(&u, 1, 0);
     const int b = g->WaveBase(); bool first = true; float m = 0.0f;
     for (int i = 0; i < 64 && b + i < g->n; i++) if (g->snapActive[b + i]) { float v = zr_asfloat(g->snapU[4 * (b + i)]); m = first ? v : zr_max(m, v); first = false; }
     return m;

@@ -215,6 +215,7 @@ template<class T> struct Texture2D
     T operator[](const uint2& p) const { return LoadPx(p.x, p.y); }
     T operator[](const int2& p) const { return LoadPx((uint32_t)p.x, (uint32_t)p.y); }
     T operator[](const uint16_t2& p) const { return LoadPx(p.x, p.y); }
+    T operator[](const int16_t2& p) const { return LoadPx((uint32_t)(int32_t)p.x, (uint32_t)(int32_t)p.y); }
     template<int M, int A, int B> T operator[](const Swz<uint32_t, M, A, B>& p) const { uint2 q = p; return LoadPx(q.x, q.y); }
     template<int M, int A, int B> T operator[](const Swz<int32_t, M, A, B>& p) const { int2 q = p; return LoadPx((uint32_t)q.x, (uint32_t)q.y); }
     T Load(const int3& p) const { return LoadPx((uint32_t)p.x, (uint32_t)p.y); }

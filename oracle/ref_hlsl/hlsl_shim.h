@@ -38,6 +38,14 @@ struct half
 typedef half float16_t;
 typedef half min16float;
 
+// element casts: float -> integer follows the D3D rule for ftou / ftoi (D3D11.3 functional spec 22.13: the input is clamped to the target
+// range, NaN -> 0) -- what the hardware does and what the ABI's zr_f2u_sat / zr_f2i_sat define; everything else is the C++ conversion
+template<class T, class U> struct elem_cast { static T go(const U& u) { return (T)u; } };
+template<> struct elem_cast<uint32_t, float> { static uint32_t go(const float& f) { return zr_f2u_sat(f); } };
+template<> struct elem_cast<int32_t, float> { static int32_t go(const float& f) { return zr_f2i_sat(f); } };
+template<> struct elem_cast<uint16_t, float> { static uint16_t go(const float& f) { const uint32_t v = zr_f2u_sat(f); return (uint16_t)(v > 0xffffu ? 0xffffu : v); } };
+template<> struct elem_cast<int16_t, float> { static int16_t go(const float& f) { const int32_t v = zr_f2i_sat(f); return (int16_t)(v > 32767 ? 32767 : (v < -32768 ? -32768 : v)); } };
+
 // ------------------------------------------------------------------------------------------------ vectors with swizzles
 template<class T, int N> struct vec;
 
@@ -54,6 +62,9 @@ template<> struct implicit_vec_conv<bool, uint32_t> : std::true_type {};
 template<> struct implicit_vec_conv<uint32_t, float> : std::true_type {};      // integer -> float (DXC converts silently; used for pixel coordinates)
 template<> struct implicit_vec_conv<int32_t, float> : std::true_type {};
 template<> struct implicit_vec_conv<uint16_t, float> : std::true_type {};
+template<> struct implicit_vec_conv<int16_t, uint32_t> : std::true_type {};
+template<> struct implicit_vec_conv<int16_t, int32_t> : std::true_type {};
+template<> struct implicit_vec_conv<int16_t, float> : std::true_type {};
 
 template<class T, int N, int... I> struct Swz
 {
@@ -61,6 +72,8 @@ template<class T, int N, int... I> struct Swz
     static constexpr int K = sizeof...(I);
     typedef vec<T, K> V;
     operator V() const { return V(d[I]...); }
+    // a half swizzle promotes to a float vector
+    template<class T2 = T, class = typename std::enable_if<std::is_same<T2, half>::value>::type> operator vec<float, K>() const { return vec<float, K>((float)d[I]...); }
     Swz& operator=(const V& v) { const int idx[K] = {I...}; V t(v); for (int k = 0; k < K; k++) d[idx[k]] = t.d[k]; return *this; }
     Swz& operator=(const Swz& o) { return *this = (V)o; }
 #define HLSL_SWZ_COMPOUND(op) Swz& operator op##=(const V& v) { const int idx[K] = {I...}; V t(v); for (int k = 0; k < K; k++) d[idx[k]] op##= t.d[k]; return *this; }
@@ -77,13 +90,15 @@ template<class T, int N, int... I> struct Swz
     vec& operator=(const vec& o) { for (int i = 0; i < NN; i++) d[i] = o.d[i]; return *this; } \
     template<class U, class = typename std::enable_if<std::is_convertible<U, T>::value && !std::is_same<U, T>::value && std::is_arithmetic<U>::value>::type> \
     vec(U s) { for (int i = 0; i < NN; i++) d[i] = (T)s; } \
-    vec(T s) { for (int i = 0; i < NN; i++) d[i] = s; } \
+    /* scalar broadcast: implicit, except for half (a half scalar must not turn into a half vector inside scalar arithmetic) */ \
+    template<class T2 = T, class = typename std::enable_if<!std::is_same<T2, half>::value>::type> vec(T s) { for (int i = 0; i < NN; i++) d[i] = s; } \
+    template<class T2 = T, class = typename std::enable_if<std::is_same<T2, half>::value>::type, class = void> explicit vec(T s) { for (int i = 0; i < NN; i++) d[i] = s; } \
     template<class U, class = typename std::enable_if<!implicit_vec_conv<U, T>::value>::type> \
-    explicit vec(const vec<U, NN>& o) { for (int i = 0; i < NN; i++) d[i] = (T)o.d[i]; } \
+    explicit vec(const vec<U, NN>& o) { for (int i = 0; i < NN; i++) d[i] = elem_cast<T, U>::go(o.d[i]); } \
     template<class U, class = typename std::enable_if<implicit_vec_conv<U, T>::value>::type, class = void> \
     vec(const vec<U, NN>& o) { for (int i = 0; i < NN; i++) d[i] = (T)o.d[i]; }     /* promotions HLSL applies silently */ \
     template<class U, int M, int... J, class = typename std::enable_if<sizeof...(J) == NN && !std::is_same<U, T>::value>::type> \
-    explicit vec(const Swz<U, M, J...>& o) { vec<U, NN> t = o; for (int i = 0; i < NN; i++) d[i] = (T)t.d[i]; } \
+    explicit vec(const Swz<U, M, J...>& o) { vec<U, NN> t = o; for (int i = 0; i < NN; i++) d[i] = elem_cast<T, U>::go(t.d[i]); } \
     T& operator[](int i) { return d[i]; } \
     const T& operator[](int i) const { return d[i]; }
 
@@ -139,6 +154,9 @@ template<class T> struct vec<T, 4>
     vec(const vec<T, 2>& v, const vec<T, 2>& u) { d[0] = v.d[0]; d[1] = v.d[1]; d[2] = u.d[0]; d[3] = u.d[1]; }
     vec(T a_, T b_, const vec<T, 2>& u) { d[0] = a_; d[1] = b_; d[2] = u.d[0]; d[3] = u.d[1]; }
     vec(T a_, const vec<T, 2>& u, T e) { d[0] = a_; d[1] = u.d[0]; d[2] = u.d[1]; d[3] = e; }
+    // constructor-style casts with operands of another element type: half4(float3, half), float4(half3, float) ...
+    template<class U, class S, class = typename std::enable_if<!std::is_same<U, T>::value && (std::is_arithmetic<S>::value || std::is_same<S, half>::value)>::type>
+    vec(const vec<U, 3>& v, S e) { d[0] = (T)v.d[0]; d[1] = (T)v.d[1]; d[2] = (T)v.d[2]; d[3] = (T)e; }
 };
 
 #define HLSL_TYPEDEFS(T, name) typedef vec<T, 1> name##1; typedef vec<T, 2> name##2; typedef vec<T, 3> name##3; typedef vec<T, 4> name##4;

@@ -22,6 +22,27 @@ extern "C" void ZR_ENTRY(const ZrDispatch* d)
     memcpy(&hlsl::g_frame, d->frame_cb, sizeof(zr_frame_constants));
     if (d->local_cb_bytes != sizeof(hlsl::ZR_LOCAL_CB)) { std::fprintf(stderr, "%s: local constant buffer is %u B, shader expects %zu B\n", ZR_SHADER, d->local_cb_bytes, sizeof(hlsl::ZR_LOCAL_CB)); std::abort(); }
     memcpy(&hlsl::g_local, d->local_cb, sizeof(hlsl::ZR_LOCAL_CB));
+#ifdef ZR_DI_GLOBALS
+    // DirectLighting / SkyDI root signatures (DirectLighting.cpp:60-98, SkyDI.cpp:48-70): 1 = emissive temporal, 2 = emissive spatial,
+    // 3 = sky temporal, 4 = sky spatial
+    {
+        const zro::Scene& scPrev = d->prev_scene ? ((RefScene*)d->prev_scene)->sc : r->sc;
+        hlsl::g_bvh.scene = &r->sc;
+#if ZR_DI_GLOBALS == 1 || ZR_DI_GLOBALS == 3
+        hlsl::g_bvh_prev.scene = &scPrev;
+#endif
+#if ZR_DI_GLOBALS == 1 || ZR_DI_GLOBALS == 2
+        hlsl::g_emissives = StructuredBuffer<hlsl::RT::EmissiveTriangle>((const hlsl::RT::EmissiveTriangle*)r->sc.emissives.data(), (uint32_t)r->sc.emissives.size());
+        hlsl::g_frameMeshData = StructuredBuffer<hlsl::RT::MeshInstance>((const hlsl::RT::MeshInstance*)r->sc.instances.data(), (uint32_t)r->sc.instances.size());
+#endif
+#if ZR_DI_GLOBALS == 1
+        hlsl::g_aliasTable = StructuredBuffer<hlsl::RT::EmissiveLumenAliasTableEntry>((const hlsl::RT::EmissiveLumenAliasTableEntry*)r->sc.alias.data(), (uint32_t)r->sc.alias.size());
+#ifdef USE_PRESAMPLED_SETS
+        hlsl::g_sampleSets = StructuredBuffer<hlsl::RT::PresampledEmissiveTriangle>((const hlsl::RT::PresampledEmissiveTriangle*)r->sc.sampleSets.data(), (uint32_t)r->sc.sampleSets.size());
+#endif
+#endif
+    }
+#endif
 #if ZR_HAS_SCENE
     static_assert(sizeof(hlsl::RT::MeshInstance) == sizeof(zr_mesh_instance) && sizeof(hlsl::Vertex) == sizeof(zr_vertex) && sizeof(hlsl::Material) == sizeof(zr_material), "wire layouts");
     const zro::Scene& sc = d->use_prev_scene && d->prev_scene ? ((RefScene*)d->prev_scene)->sc : r->sc;

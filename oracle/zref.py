@@ -125,3 +125,65 @@ class RefRestirPT(RefPass):
         buf = np.zeros((self.h_, self.w, ch), dt)
         self.L.zrefp_rpt_read_plane(self.st, which, idx, buf.ctypes.data)
         return buf
+
+
+class RefRestirGI(RefPass):
+    """K10: ReSTIR_GI.hlsl + the restated host (oracle/ref_hlsl/ref_gi_host.cpp)"""
+    PLANES = {"A": (0, np.float32, 4), "B": (1, np.uint16, 4), "C": (2, np.float32, 4)}
+
+    def __init__(self, scene, w, h, presampling=False, force_bvh=False):
+        name = "gi_e0" if len(scene.emissives) == 0 else ("gi_e1p" if presampling else "gi_e1")
+        super().__init__(name, scene, force_bvh)
+        L = self.L
+        L.zrefp_gi_create.restype = C.c_void_p
+        L.zrefp_gi_create.argtypes = [C.c_uint32, C.c_uint32]
+        L.zrefp_gi_render.argtypes = [C.c_void_p] * 7
+        L.zrefp_gi_read_plane.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        self.w, self.h_ = w, h
+        self.st = L.zrefp_gi_create(w, h)
+        self.prev = None
+
+    def render(self, cb, params, gb):
+        out = np.zeros((self.h_, self.w, 4), np.float32)
+        cbb = np.ascontiguousarray(cb)
+        prev = C.addressof(self.prev[1]) if self.prev is not None else None
+        self.L.zrefp_gi_render(self.h, self.st, cbb.ctypes.data, C.addressof(gb[1]), prev, C.addressof(params), out.ctypes.data)
+        self.prev = gb
+        return out
+
+    def plane(self, name):
+        idx, dt, ch = self.PLANES[name]
+        buf = np.zeros((self.h_, self.w, ch), dt)
+        self.L.zrefp_gi_read_plane(self.st, idx, buf.ctypes.data)
+        return buf
+
+
+class RefDirect(RefPass):
+    """K5 / K6 (emissive ReSTIR DI) or K7 / K8 (sun + sky ReSTIR DI): the reference's DI shaders + restated host (oracle/ref_hlsl/ref_di_host.cpp)"""
+
+    def __init__(self, scene, w, h, sky=False, presampling=False, force_bvh=False):
+        super().__init__("di_sky" if sky else ("di_e1p" if presampling else "di_e1"), scene, force_bvh)
+        L = self.L
+        L.zrefp_di_create.restype = C.c_void_p
+        L.zrefp_di_create.argtypes = [C.c_uint32, C.c_uint32]
+        L.zrefp_di_render.argtypes = [C.c_void_p] * 7
+        L.zrefp_di_read_plane.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        self.w, self.h_, self.sky = w, h, sky
+        self.st = L.zrefp_di_create(w, h)
+        self.prev = None
+        self.PLANES = ({"A": (0, np.uint8, 1), "B": (1, np.uint16, 2), "C": (2, np.float32, 2), "target": (8, np.uint16, 4)} if sky else
+                       {"A": (0, np.uint32, 4), "B": (1, np.float32, 2), "target": (8, np.uint16, 4)})
+
+    def render(self, cb, params, gb):
+        out = np.zeros((self.h_, self.w, 4), np.float32)
+        cbb = np.ascontiguousarray(cb)
+        prev = C.addressof(self.prev[1]) if self.prev is not None else None
+        self.L.zrefp_di_render(self.h, self.st, cbb.ctypes.data, C.addressof(gb[1]), prev, C.addressof(params), out.ctypes.data)
+        self.prev = gb
+        return out
+
+    def plane(self, name):
+        idx, dt, ch = self.PLANES[name]
+        buf = np.zeros((self.h_, self.w, ch), dt)
+        self.L.zrefp_di_read_plane(self.st, idx, buf.ctypes.data)
+        return buf

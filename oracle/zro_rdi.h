@@ -475,7 +475,8 @@ static void Render(const Scene& sc, const zr_frame_constants& g, const zr_gbuffe
                 r.target = disoccluded ? -r.target : r.target;
                 float3 t = RPT::Sanitize3(r.target);
                 r.target = t;
-                st.target[4 * px] = t.x; st.target[4 * px + 1] = t.y; st.target[4 * px + 2] = t.z;
+                // the TARGET texture is R16G16B16A16_FLOAT (DirectLighting.h:71): the spatial pass reads fp16-rounded values
+                st.target[4 * px] = zr_round_f16(t.x); st.target[4 * px + 1] = zr_round_f16(t.y); st.target[4 * px + 2] = zr_round_f16(t.z);
             }
         }
         if (writeReservoirs) r.Write(curA, curB, px, prm.M_max);

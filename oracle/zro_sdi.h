@@ -471,7 +471,8 @@ static void Render(const Scene& sc, const zr_frame_constants& g, const zr_gbuffe
                 float3 t = r.target;                    // WriteTarget: Math::Sanitize (any NaN / inf -> the whole vector 0)
                 if (any_nan(t) || zr_isinf(t.x) || zr_isinf(t.y) || zr_isinf(t.z)) t = f3(0.0f);
                 r.target = t;
-                st.target[4 * px] = t.x; st.target[4 * px + 1] = t.y; st.target[4 * px + 2] = t.z;
+                // the TARGET texture is R16G16B16A16_FLOAT (SkyDI.h:61): the spatial pass reads fp16-rounded values
+                st.target[4 * px] = zr_round_f16(t.x); st.target[4 * px + 1] = zr_round_f16(t.y); st.target[4 * px + 2] = zr_round_f16(t.z);
             }
         }
         if (writeReservoirs) r.Write(curA, curB, curC, px, r.lightType == TYPE::SKY ? M_max_sky : M_max_sun);

@@ -1,7 +1,8 @@
 """Parity against the REFERENCE's own shader passes.
 
 tests/golden/ref_pass_*.npz hold what the reference's HLSL passes -- GBufferRT_Inline.hlsl (K1), PathTracer.hlsl (K9) and the ten ReSTIR PT
-shaders (K11, K13-K16) with the host sequence of IndirectLighting::RenderReSTIR_PT -- produce when compiled as C++ in place from
+shaders (K11, K13-K16) with the host sequence of IndirectLighting::RenderReSTIR_PT, ReSTIR_GI.hlsl (K10), ReSTIR_DI_Temporal / _Spatial.hlsl
+(K5 / K6) and SkyDI_Temporal / _Spatial.hlsl (K7 / K8) with their host sequences -- produce when compiled as C++ in place from
 /root/reference (oracle/ref_hlsl/, `make -C oracle -f _ref.mk`, tools/make_ref_pass_goldens.py) over the ABI's definitions of what the
 reference leaves to driver and hardware (traversal / intersection, transcendentals, texture filtering).
 
@@ -44,7 +45,7 @@ def test_oracle_reproduces_reference_passes(case):
     sc, force_bvh, integ, prm = RC.scene_and_params(case)
     g = _gold(case)
     o = zro.OracleScene(sc, force_bvh=force_bvh)
-    rpt = zro.OracleRPT(o, RC.W, RC.H) if integ == "rpt" else None
+    rpt = {"rpt": zro.OracleRPT, "gi": zro.OracleRGI, "di": zro.OracleRDI, "sdi": zro.OracleSDI}[integ](o, RC.W, RC.H) if integ != "pt" else None
     for f, cb in RC.frames_of(case):
         if len(sc.emissives) == 0:
             o.sky_lut(cb, 256, 128)
@@ -56,12 +57,11 @@ def test_oracle_reproduces_reference_passes(case):
                 assert _same(a, GB[f"{case}_{n}"]), f"K1 plane {n} differs from the reference shader's"
         got = o.pathtrace(cb, planes, prm)[0] if integ == "pt" else rpt.render(cb, prm, gb=(arrays, planes))
         assert _same(got, g[f"final_{f}"]), f"frame {f}: FINAL differs from the reference shaders'"
-    if integ == "rpt":
-        for nm in RC.RPT_PLANES:
-            a, b = rpt.plane(nm), g["plane_" + nm]
-            if nm == "A":
-                a, b = _plane_a(a), _plane_a(b)
-            assert _same(a, b), f"reservoir plane {nm} differs from the reference shaders'"
+    for nm in RC.PLANES[integ]:
+        a, b = rpt.plane(nm), g["plane_" + nm]
+        if nm == "A" and integ == "rpt":
+            a, b = _plane_a(a), _plane_a(b)
+        assert _same(a, b), f"reservoir plane {nm} differs from the reference shaders'"
 
 
 def _zref():
@@ -71,7 +71,7 @@ def _zref():
     return zref
 
 
-@pytest.mark.parametrize("case", ["k9_materials_rr", "rpt_cornell_moving", "rpt_sun_sky"])
+@pytest.mark.parametrize("case", ["k9_materials_rr", "rpt_cornell_moving", "rpt_sun_sky", "gi_materials_rr", "di_materials", "sdi_cornell_moving"])
 def test_live_reference_passes_match_stored_outputs(case):
     """re-runs the reference's compiled shaders: guards the stored files against a stale build"""
     zref = _zref()
@@ -82,7 +82,7 @@ def test_live_reference_passes_match_stored_outputs(case):
     g = _gold(case)
     o = zro.OracleScene(sc, force_bvh=force_bvh)
     k1 = zref.RefGBuffer(sc, force_bvh)
-    ref = (zref.RefPathTracer(sc, bool(prm.presampling), force_bvh) if integ == "pt" else zref.RefRestirPT(sc, RC.W, RC.H, bool(prm.presampling), force_bvh))
+    ref = M.make_ref(zref, sc, integ, prm, force_bvh)
     for f, cb in RC.frames_of(case):
         M.prepare(ref, o, sc, cb, f, prm)
         arrays, planes = k1.render(cb)
@@ -126,17 +126,27 @@ def test_hip_path_reproduces_reference_passes(case):
     from zetaray_amd import api
     sc, _, integ, prm = RC.scene_and_params(case)
     g = _gold(case)
-    r = api.Renderer(sc, RC.W, RC.H, params=prm, integrator=api.INTEGRATOR_RESTIR_PT if integ == "rpt" else api.INTEGRATOR_PATH_TRACING)
+    integrator = {"rpt": api.INTEGRATOR_RESTIR_PT, "gi": api.INTEGRATOR_RESTIR_GI}.get(integ, api.INTEGRATOR_PATH_TRACING)
+    if integ in ("di", "sdi"):
+        ip = wire.default_params()
+        ip.presampling, ip.num_sample_sets, ip.sample_set_size = prm.presampling, prm.num_sample_sets, prm.sample_set_size
+        r = api.Renderer(sc, RC.W, RC.H, params=ip)
+        p = r.enable_direct(prm) if integ == "di" else r.enable_sky_direct(prm)
+        r.skip_indirect = True
+        names = {"A": "di_A", "B": "di_B"} if integ == "di" else {"A": "sdi_A", "B": "sdi_B", "C": "sdi_C"}
+    else:
+        r = api.Renderer(sc, RC.W, RC.H, params=prm, integrator=integrator)
+        p = r.p_indirect
+        names = {n: n for n in RC.RPT_PLANES} if integ == "rpt" else {"A": "gi_A", "B": "gi_B", "C": "gi_C"}
     for f, cb in RC.frames_of(case):
         r.render_frame(cb)
         if f == 1:
             planes, _ = r.gbuffer.download()
             for n, a in zip(wire.GB_PLANE_NAMES, planes):
                 assert _same(a, GB[f"{case}_{n}"]), f"K1 plane {n} differs from the reference shader's"
-        assert _same(r.final(), g[f"final_{f}"]), f"frame {f}: FINAL differs from the reference shaders'"
-    if integ == "rpt":
-        for nm in RC.RPT_PLANES:
-            a, b = r.p_indirect.download_plane(nm), g["plane_" + nm]
-            if nm == "A":
-                a, b = _plane_a(a), _plane_a(b)
-            assert _same(a, b), f"reservoir plane {nm} differs from the reference shaders'"
+        assert _same(p.download(), g[f"final_{f}"]), f"frame {f}: FINAL differs from the reference shaders'"
+    for nm in RC.PLANES[integ]:
+        a, b = p.download_plane(names[nm]), g["plane_" + nm]
+        if nm == "A" and integ == "rpt":
+            a, b = _plane_a(a), _plane_a(b)
+        assert _same(a, b), f"reservoir plane {nm} differs from the reference shaders'"

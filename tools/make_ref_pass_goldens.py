@@ -2,8 +2,8 @@
 libzref_k9_*.so, libzref_rpt_*.so; `make -C oracle -f _ref.mk`) on the scenarios of tools/ref_pass_cases.py.
 
     ref_pass_gbuffer.npz   K1 (GBufferRT_Inline.hlsl): the 10 G-buffer planes of frame 1 of every scene
-    ref_pass_<case>.npz    K9 (PathTracer.hlsl): FINAL of every frame; ReSTIR PT (K11, K13-K16): FINAL of every frame + the 7 reservoir planes
-                           and the spatial-neighbour plane after the last frame
+    ref_pass_<case>.npz    K9 (PathTracer.hlsl): FINAL of every frame; ReSTIR PT (K11, K13-K16), ReSTIR GI (K10), ReSTIR DI (K5 / K6) and
+                           sun + sky DI (K7 / K8): FINAL of every frame + the persistent reservoir planes after the last frame
 
 Inputs the reference computes elsewhere are taken from the already-pinned parts: the alias table (bit-exact vs the reference's own
 AliasTable_Build, tests/test_ref_pins.py), and K3 presampled sets / K17 sky LUT from the oracle (their building blocks are pinned in
@@ -32,14 +32,24 @@ def prepare(ref, o, sc, cb, f, prm):
         ref.set_sample_sets(o.presample(f, prm.num_sample_sets, prm.sample_set_size), prm.num_sample_sets, prm.sample_set_size)
 
 
+def make_ref(zref, sc, integ, prm, force_bvh):
+    ps = bool(prm.presampling)
+    if integ == "pt":
+        return zref.RefPathTracer(sc, ps, force_bvh)
+    if integ == "rpt":
+        return zref.RefRestirPT(sc, RC.W, RC.H, ps, force_bvh)
+    if integ == "gi":
+        return zref.RefRestirGI(sc, RC.W, RC.H, ps, force_bvh)
+    return zref.RefDirect(sc, RC.W, RC.H, sky=(integ == "sdi"), presampling=ps, force_bvh=force_bvh)
+
+
 def main():
     gb_out = {}
     for case in RC.CASES:
         sc, force_bvh, integ, prm = RC.scene_and_params(case)
         o = zro.OracleScene(sc, force_bvh=force_bvh)
         k1 = zref.RefGBuffer(sc, force_bvh)
-        ref = (zref.RefPathTracer(sc, bool(prm.presampling), force_bvh) if integ == "pt" else
-               zref.RefRestirPT(sc, RC.W, RC.H, bool(prm.presampling), force_bvh))
+        ref = make_ref(zref, sc, integ, prm, force_bvh)
         res = {}
         for f, cb in RC.frames_of(case):
             prepare(ref, o, sc, cb, f, prm)
@@ -48,9 +58,8 @@ def main():
                 for n, a in zip(wire.GB_PLANE_NAMES, arrays):
                     gb_out[f"{case}_{n}"] = a.copy()
             res[f"final_{f}"] = ref.render(cb, planes, prm) if integ == "pt" else ref.render(cb, prm, (arrays, planes))
-        if integ == "rpt":
-            for nm in RC.RPT_PLANES:
-                res["plane_" + nm] = ref.plane(nm)
+        for nm in RC.PLANES[integ]:
+            res["plane_" + nm] = ref.plane(nm)
         np.savez_compressed(os.path.join(ROOT, "tests", "golden", f"ref_pass_{case}.npz"), **res)
         print(case, {k: float(np.asarray(v, np.float64).mean()) for k, v in res.items() if k.startswith("final")})
     np.savez_compressed(os.path.join(ROOT, "tests", "golden", "ref_pass_gbuffer.npz"), **gb_out)

@@ -21,9 +21,9 @@ def _scene(kind):
     raise KeyError(kind)
 
 
-def _params(bounces=None, presample=None, flags_off=0):
+def _params(bounces=None, presample=None, flags_off=0, kind=None):
     from zetaray_amd import wire
-    p = wire.default_params()
+    p = wire.default_params_di() if kind == "di" else (wire.default_params_sky_di() if kind == "sdi" else wire.default_params())
     if bounces:
         p.max_non_tr_bounces, p.max_glossy_tr_bounces = bounces
     if presample:
@@ -42,8 +42,17 @@ CASES = {
     "rpt_materials_rr": ("materials_lights", "rpt", 3, dict(bounces=(6, 8)), False),
     "rpt_presampled": ("materials_lights", "rpt", 3, dict(presample=(32, 128)), False),
     "rpt_sun_sky": ("cornell", "rpt", 3, {}, False),
+    "gi_cornell_moving": ("cornell_emissive", "gi", 4, {}, True),
+    "gi_materials_rr": ("materials_lights", "gi", 3, dict(bounces=(6, 8)), False),
+    "gi_presampled": ("materials_lights", "gi", 3, dict(presample=(32, 128)), False),
+    "gi_sun_sky": ("cornell", "gi", 3, {}, False),
+    "di_cornell_moving": ("cornell_emissive", "di", 5, {}, True),
+    "di_materials": ("materials_lights", "di", 3, {}, False),
+    "di_presampled": ("materials_lights", "di", 3, dict(presample=(32, 128)), False),
+    "sdi_cornell_moving": ("cornell", "sdi", 5, {}, True),
 }
 RPT_PLANES = ("A", "B", "C", "D", "E", "F", "G", "neighbor")
+PLANES = {"rpt": RPT_PLANES, "gi": ("A", "B", "C"), "di": ("A", "B"), "sdi": ("A", "B", "C"), "pt": ()}
 
 
 def frames_of(case):
@@ -66,4 +75,4 @@ def frames_of(case):
 def scene_and_params(case):
     kind, integ, n, pk, _ = CASES[case]
     sc, force_bvh, _ = _scene(kind)
-    return sc, force_bvh, integ, _params(**pk)
+    return sc, force_bvh, integ, _params(kind=integ, **pk)

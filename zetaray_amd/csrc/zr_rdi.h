@@ -397,7 +397,8 @@ ZR_HD void TemporalPixel(const DiFrame& F, const zr_frame_constants& g, uint32_t
             bool disoccluded = !tc.valid && ((motionVec.x * motionVec.x + motionVec.y * motionVec.y) > 0);
             r.target = disoccluded ? -r.target : r.target;
             r.target = rpt::Sanitize3(r.target);
-            F.target[px] = f4(r.target, 0.0f);
+            // the reference's TARGET texture is R16G16B16A16_FLOAT (DirectLighting.h:71): the spatial pass reads fp16-rounded values
+            F.target[px] = f4(zr_round_f16(r.target.x), zr_round_f16(r.target.y), zr_round_f16(r.target.z), 0.0f);
         }
     }
     if (prm.writeReservoirs) r.Write(F.cur, px, prm.M_max);

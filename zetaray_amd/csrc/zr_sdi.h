@@ -353,7 +353,8 @@ ZR_HD void TemporalPixel(const SkyFrame& F, const zr_frame_constants& g, uint32_
         if (prm.doSpatial)
         {
             r.target = rpt::Sanitize3(r.target);
-            F.target[px] = f4(r.target, 0.0f);
+            // the reference's TARGET texture is R16G16B16A16_FLOAT (SkyDI.h:61): the spatial pass reads fp16-rounded values
+            F.target[px] = f4(zr_round_f16(r.target.x), zr_round_f16(r.target.y), zr_round_f16(r.target.z), 0.0f);
         }
     }
     if (prm.writeReservoirs) WriteReservoir(r, F.cur, px, r.lightType == LT_SKY ? prm.M_max_sky : prm.M_max_sun);
