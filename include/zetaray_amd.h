@@ -197,6 +197,13 @@ int         zr_wire_layout(char* buf, size_t cap);
 /* ---- scene: device copies of VB/IB/MeshInstance/Material/Emissive/AliasTable + BVH ---- */
 int zr_scene_create(int device, const zr_scene_desc* desc, zr_scene** out);
 int zr_scene_destroy(zr_scene* scene);
+/* Per-frame update of dynamic instances (TLAS::FillMeshInstanceData + the TLAS rebuild, RtAccelerationStructure.cpp:318-506, 708-787;
+ * what the reference publishes as RT_FRAME_MESH_INSTANCES_CURR / _PREV and RT_SCENE_BVH_CURR / _PREV): `instances` = the new
+ * MeshInstance records (the caller fills PrevRotation / PrevScale / dTranslation like the reference does), `instance_to_world` = the new
+ * exact object-to-world matrices (n x 12 floats).  The instance buffer and acceleration structure of the last frame become the
+ * "previous" ones that the CtT replay / reconnect passes of ReSTIR PT and the temporal shifts of the DI passes trace against.
+ * Host call between frames (waits for the device); n must equal the scene's instance count. */
+int zr_scene_update_instances(zr_scene* scene, const zr_mesh_instance* instances, const float* instance_to_world, uint32_t n);
 /* EmissiveTriangleAliasTable::Render (PreLighting.cpp:512-585): upload a host-built table ... */
 int zr_scene_set_alias_table(zr_scene* scene, const zr_alias_entry* entries, uint32_t n);
 /* ... or build it from per-triangle power exactly like PreLighting.cpp:27-158 (host side, bit-exact) */

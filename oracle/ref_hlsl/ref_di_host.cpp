@@ -93,7 +93,7 @@ int zrefp_di_render(RefScene* r, DiState* S, const zr_frame_constants* cb, const
     L.PrevReservoir_A_DescHeapIdx = Slot(c == 1 ? R0_SRV : R1_SRV);
     L.CurrReservoir_A_DescHeapIdx = Slot(c == 1 ? R1_UAV : R0_UAV);
     ZrDispatch d; memset(&d, 0, sizeof(d));
-    d.scene = r; d.heap = &H; d.frame_cb = &g; d.local_cb = &L; d.local_cb_bytes = sizeof(L); d.groups_x = dx; d.groups_y = dy;
+    d.scene = r; d.prev_scene = r->prevHolder.get(); d.heap = &H; d.frame_cb = &g; d.local_cb = &L; d.local_cb_bytes = sizeof(L); d.groups_x = dx; d.groups_y = dy;
     zrefp_shader_di_temporal(&d);
     if (doSpatial)
     {

@@ -2,6 +2,7 @@
 // Shared host side of the reference PASSES compiled as C++ (ref_pass_*.cpp): scene, descriptor heap, plane registration.
 #pragma once
 #include <vector>
+#include <memory>
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
@@ -25,6 +26,7 @@ struct RefScene
 {
     zro::Scene sc;
     DescriptorHeap heap;
+    std::unique_ptr<RefScene> prevHolder;      // the scene as it was before the last zrefp_scene_update_instances (RT_SCENE_BVH_PREV etc.)
 };
 
 static inline void BindPlane(DescriptorHeap& h, uint32_t slot, void* data, uint32_t w, uint32_t ht, int fmt)
@@ -71,6 +73,9 @@ static inline RefScene* SceneCreate(const zr_scene_desc* d, int force_bvh) { Ref
 #define ZREFP_SCENE_API \
     extern "C" refpass::RefScene* zrefp_scene_create(const zr_scene_desc* d, int force_bvh) { return refpass::SceneCreate(d, force_bvh); } \
     extern "C" void zrefp_scene_destroy(refpass::RefScene* r) { delete r; } \
+    extern "C" int zrefp_scene_update_instances(refpass::RefScene* r, const zr_mesh_instance* inst, const float* xf, uint32_t n) \
+    { if (n != r->sc.instances.size()) return -1; r->prevHolder.reset(new refpass::RefScene()); r->prevHolder->sc = r->sc; r->prevHolder->sc.prev = nullptr; \
+      r->sc.UpdateInstances(inst, xf, n); return 0; } \
     extern "C" void zrefp_scene_set_alias_table(refpass::RefScene* r, const zr_alias_entry* e, uint32_t n) { r->sc.alias.assign(e, e + n); } \
     extern "C" void zrefp_scene_set_sample_sets(refpass::RefScene* r, const zr_presampled_tri* e, uint32_t numSets, uint32_t setSize) \
     { r->sc.sampleSets.assign(e, e + (size_t)numSets * setSize); r->sc.sampleSetSize = setSize; } \

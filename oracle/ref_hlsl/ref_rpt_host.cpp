@@ -134,7 +134,7 @@ int zrefp_rpt_render(RefScene* r, RptState* S, const zr_frame_constants* cb, con
     if (!S->temporalValid) PT.Flags |= CB_IND_FLAGS::RESET_TEMPORAL_TEXTURES;
 
     ZrDispatch d; memset(&d, 0, sizeof(d));
-    d.scene = r; d.prev_scene = nullptr; d.heap = &H; d.frame_cb = &g;
+    d.scene = r; d.prev_scene = r->prevHolder.get(); d.heap = &H; d.frame_cb = &g;
     auto Run = [&](void (*shader)(const ZrDispatch*), const void* lcb, uint32_t bytes, uint32_t gx, uint32_t gy, bool prevAS) {
         d.local_cb = lcb; d.local_cb_bytes = bytes; d.groups_x = gx; d.groups_y = gy; d.use_prev_scene = prevAS ? 1 : 0; shader(&d); };
 

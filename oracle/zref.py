@@ -44,6 +44,12 @@ class RefPass:
         except Exception:
             pass
 
+    def update_instances(self, instances, instance_to_world):
+        """per-frame MeshInstance records + object-to-world matrices; the scene as it was becomes the previous one"""
+        self.L.zrefp_scene_update_instances.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32]
+        i, x = np.ascontiguousarray(instances), np.ascontiguousarray(instance_to_world, np.float32)
+        assert self.L.zrefp_scene_update_instances(self.h, i.ctypes.data, x.ctypes.data, len(i)) == 0
+
     def set_alias_table(self, entries):
         e = np.ascontiguousarray(entries)
         self.L.zrefp_scene_set_alias_table(self.h, e.ctypes.data, len(e))

@@ -113,6 +113,13 @@ class OracleScene:
             lib().zro_scene_destroy(self.h)
             self.h = None
 
+    def update_instances(self, instances, instance_to_world):
+        """zr_scene_update_instances on the oracle: new MeshInstance records + object-to-world matrices; the scene as it was becomes
+        the previous one (bound by the CtT passes of ReSTIR PT and the temporal shifts of the DI passes)"""
+        i, x = np.ascontiguousarray(instances), np.ascontiguousarray(instance_to_world, np.float32)
+        lib().zro_scene_update_instances.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32]
+        assert lib().zro_scene_update_instances(self.h, i.ctypes.data, x.ctypes.data, len(i)) == 0
+
     def latch_heap_offsets(self, cb):
         cbb = np.ascontiguousarray(cb)
         lib().zro_scene_latch_heap_offsets(self.h, cbb.ctypes.data)

@@ -253,7 +253,7 @@ static float OffsetPathTarget_CtT(const Scene& sc, const Reservoir& r_curr, Temp
     target_offset *= BSDF::Unified(candidate.surface).f;
     float targetLum_offset = Math::Luminance(target_offset);
     if (targetLum_offset > 0)
-        targetLum_offset *= RtRayQuery::Visibility_Segment(sc, true, candidate.pos, wi_offset, t_offset, candidate.normal, r_curr.lightID,
+        targetLum_offset *= RtRayQuery::Visibility_Segment(sc.Prev(), true, candidate.pos, wi_offset, t_offset, candidate.normal, r_curr.lightID,
             candidate.surface.Transmissive()) ? 1.0f : 0.0f;
     return targetLum_offset;
 }

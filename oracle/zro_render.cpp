@@ -16,6 +16,7 @@
 //       ReSTIR_GI/PathTracing.hlsli, ReSTIR_GI/ReSTIR_GI_NEE.hlsli, NEE.hlsli             (1-spp path tracer)
 // and the C entry points the tests bind with ctypes.
 #include <cstdio>
+#include <memory>
 #include <cstdlib>
 #include <chrono>
 #include "zro_scene.h"
@@ -898,7 +899,7 @@ static void Render(const float* signal, const float* depthPlane, const uint32_t*
 
 extern "C" {
 
-struct zro_scene { Scene s; };
+struct zro_scene { Scene s; std::unique_ptr<Scene> prevHolder; };
 
 zro_scene* zro_scene_create(const zr_scene_desc* d, int force_bvh)
 {
@@ -907,6 +908,16 @@ zro_scene* zro_scene_create(const zr_scene_desc* d, int force_bvh)
     return h;
 }
 void zro_scene_destroy(zro_scene* h) { delete h; }
+// zr_scene_update_instances: the scene as it was becomes the "previous" one the CtT / temporal-shift passes bind
+int zro_scene_update_instances(zro_scene* h, const zr_mesh_instance* instances, const float* instance_to_world, uint32_t n)
+{
+    if (n != h->s.instances.size()) return -1;
+    h->s.prev = nullptr;
+    h->prevHolder.reset(new Scene(h->s));
+    h->s.UpdateInstances(instances, instance_to_world, n);
+    h->s.prev = h->prevHolder.get();
+    return 0;
+}
 int zro_scene_num_tris(const zro_scene* h) { return (int)h->s.tris.size(); }
 
 int zro_kahan_sum(const float* data, uint64_t n, uint32_t align_phase, float* out)

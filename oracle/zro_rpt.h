@@ -1422,6 +1422,8 @@ static void TemporalPass(const Scene& sc, const zr_frame_constants& g, const GBu
     ReservoirPlanes& cur = st.reservoirs[st.currIdx];
     const ReservoirPlanes& prev = st.reservoirs[1 - st.currIdx];
     Globals gl; gl.sc = &sc; gl.frame = &g; gl.numEmissives = g.num_emissive_triangles; gl.alpha_min = prm.alpha_min; gl.maxNumBounces = 0;
+    // the CtT passes bind the PREVIOUS acceleration structure and mesh-instance buffer (IndirectLighting.cpp:465-471, 542-548)
+    Globals glPrev = gl; glPrev.sc = &sc.Prev();
     const uint32_t M_max = prm.m_max_temporal & 0xf;
 
     // ---- K13 Replay_CtT and Replay_TtC (ReSTIR_PT_Replay.hlsl:289-534); plane threshold 0.01 here
@@ -1435,6 +1437,7 @@ static void TemporalPass(const Scene& sc, const zr_frame_constants& g, const GBu
         TemporalPixel tp = FindTemporal(g, gb, gbPrev, x, y, ps, 0.01f, (size_t)-1);
         if (!tp.ok) continue;
         gl.maxNumBounces = flags.transmissive ? (int)prm.max_glossy_tr_bounces : (int)prm.max_non_tr_bounces;
+        glPrev.maxNumBounces = gl.maxNumBounces;
         const size_t pp = (size_t)tp.py * W + tp.px;
         if (variant == 0)
         {
@@ -1448,7 +1451,7 @@ static void TemporalPass(const Scene& sc, const zr_frame_constants& g, const GBu
                 float3 dpdx, dpdy;     // computed and discarded by the reference (ReSTIR_PT_Replay.hlsl:114-117)
                 rd.dpdx_dpdy(tp.prev.pos, tp.prev.normal, dpdx, dpdy);
                 rd.ComputeUVDifferentials(dpdx, dpdy, triDiffs.dpdu, triDiffs.dpdv);
-                OffsetPathContext ctx = Replay_kGt2(gl, false, tp.prev.pos, tp.prev.normal, tp.prev.eta_next, tp.prev.surface, rd, triDiffs, r_curr.rc);
+                OffsetPathContext ctx = Replay_kGt2(glPrev, false, tp.prev.pos, tp.prev.normal, tp.prev.eta_next, tp.prev.surface, rd, triDiffs, r_curr.rc);
                 ctx.Write(st.rbuffer[0], px, r_curr.rc.IsCase3());
             }
         }
@@ -1482,8 +1485,8 @@ static void TemporalPass(const Scene& sc, const zr_frame_constants& g, const GBu
         if (r_curr.w_sum != 0 && r_prev.M > 0 && !r_curr.rc.Empty())
         {
             r_curr.Load_Reconnection(cur, px, g.num_emissive_triangles != 0);
-            if (r_curr.rc.IsCase1() || r_curr.rc.IsCase2()) MoveXk(sc, r_curr.rc, true, false);
-            gl.maxNumBounces = flags.transmissive ? (int)prm.max_glossy_tr_bounces : (int)prm.max_non_tr_bounces;
+            if (r_curr.rc.IsCase1() || r_curr.rc.IsCase2()) MoveXk(*glPrev.sc, r_curr.rc, true, false);
+            glPrev.maxNumBounces = flags.transmissive ? (int)prm.max_glossy_tr_bounces : (int)prm.max_non_tr_bounces;
             Math::TriDifferentials triDiffs; RT::RayDifferentials rd = ZeroRD();
             triDiffs.dpdu = triDiffs.dpdv = triDiffs.dndu = triDiffs.dndv = f3(0.0f);
             if (r_curr.rc.k == 2)
@@ -1492,7 +1495,7 @@ static void TemporalPass(const Scene& sc, const zr_frame_constants& g, const GBu
                 triDiffs = LoadTriDiffs(gbPrev, pp);
                 rd = InitRD(pcam, tp.px, tp.py, tp.prev.lensSample, tp.prev.origin);
             }
-            OffsetPath shift = Shift2(gl, false, px, tp.prev.pos, tp.prev.normal, tp.prev.eta_next, tp.prev.surface, rd, triDiffs, r_curr.rc, st.rbuffer[0]);
+            OffsetPath shift = Shift2(glPrev, false, px, tp.prev.pos, tp.prev.normal, tp.prev.eta_next, tp.prev.surface, rd, triDiffs, r_curr.rc, st.rbuffer[0]);
             float target_prev = Math::Luminance(shift.target);
             if (target_prev > 0)
             {

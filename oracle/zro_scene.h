@@ -106,8 +106,12 @@ struct Scene
     std::vector<uint32_t> triOrder;      // BVH leaf order -> global triangle index
     bool bruteForce = true;
     mutable Counters counters;
+    // previous frame's scene (RT_SCENE_BVH_PREV + RT_FRAME_MESH_INSTANCES_PREV, RtAccelerationStructure.cpp:382-506): what the CtT passes of
+    // ReSTIR PT and the temporal shifts of the DI passes bind; null = nothing moved since the last frame
+    const Scene* prev = nullptr;
+    const Scene& Prev() const { return prev ? *prev : *this; }
 
-    void Build(const zr_scene_desc& d, bool forceBVH)
+    void Build(const zr_scene_desc& d, bool forceBVH_)
     {
         vertices.assign(d.vertices, d.vertices + d.num_vertices);
         indices.assign(d.indices, d.indices + d.num_indices);
@@ -124,6 +128,28 @@ struct Scene
         }
         tex.descs = texDescs.data(); tex.texels = texels.data(); tex.srgb = zr_srgb_to_linear_table; tex.count = (uint32_t)texDescs.size();
 
+        instMask.assign(d.instance_mask, d.instance_mask + d.num_instances);
+        instNumTris.assign(d.instance_num_tris, d.instance_num_tris + d.num_instances);
+        forceBVH = forceBVH_;
+        BuildTris(d.instance_to_world);
+    }
+    std::vector<uint8_t> instMask; std::vector<uint32_t> instNumTris; bool forceBVH = false;
+
+    // zr_scene_update_instances on the oracle side: new per-frame MeshInstance records + object-to-world matrices (the caller fills the
+    // Prev* fields like TLAS::FillMeshInstanceData does); world-space triangles and the BVH are rebuilt.  The caller keeps a copy of the scene
+    // as it was (`prev`) for the passes that bind the previous acceleration structure.
+    void UpdateInstances(const zr_mesh_instance* inst, const float* instance_to_world, uint32_t n)
+    {
+        instances.assign(inst, inst + n);
+        BuildTris(instance_to_world);
+    }
+
+    void BuildTris(const float* instance_to_world)
+    {
+        const struct { const zr_mesh_instance* instances; const float* instance_to_world; const uint32_t* indices; const zr_vertex* vertices;
+                       const uint32_t* instance_num_tris; const uint8_t* instance_mask; uint32_t num_instances; }
+            d = {instances.data(), instance_to_world, indices.data(), vertices.data(), instNumTris.data(), instMask.data(), (uint32_t)instances.size()};
+        const bool forceBVH_ = forceBVH;
         tris.clear();
         for (uint32_t i = 0; i < d.num_instances; i++)
         {
@@ -145,7 +171,7 @@ struct Scene
                 tris.push_back(t);
             }
         }
-        bruteForce = !forceBVH && tris.size() <= 256;
+        bruteForce = !forceBVH_ && tris.size() <= 256;
         if (!bruteForce) BuildBVH();
     }
 

@@ -241,7 +241,7 @@ static void TemporalResample(const Scene& sc, const zr_frame_constants& g, Tempo
             const float3 target_prev = le * BSDF::Unified(candidate.surface).f;
             targetLum_prev = Math::Luminance(target_prev);
             if (targetLum_prev > 0)      // g_bvh_prev: static scenes, same BVH
-                targetLum_prev *= RtRayQuery::Visibility_Ray(sc, candidate.pos, wi_offset, candidate.normal, candidate.surface.Transmissive()) ? 1.0f : 0.0f;
+                targetLum_prev *= RtRayQuery::Visibility_Ray(sc.Prev(), candidate.pos, wi_offset, candidate.normal, candidate.surface.Transmissive()) ? 1.0f : 0.0f;
         }
         const float numerator = (float)r.M * Math::Luminance(r.target);
         const float denom = numerator + (float)r_prev.M * targetLum_prev * jacobian;

@@ -29,7 +29,17 @@ struct HxScene
 {
     std::vector<zr_vertex> vertices; std::vector<uint32_t> indices; std::vector<zr_mesh_instance> instances;
     std::vector<zr_material> materials; std::vector<zr_emissive_triangle> emissives; std::vector<zr_alias_entry> alias;
-    std::vector<uint16_t> rho; BuiltBvh bvh; mutable SceneView view; std::vector<zr_texture_desc> texDescs; std::vector<uint8_t> texels; std::vector<zr_presampled_tri> sampleSets; std::vector<uint32_t> skyLut; std::vector<zr_voxel_sample> lvg;
+    std::vector<uint16_t> rho; BuiltBvh bvh; mutable SceneView view;
+    // zhx_scene_update_instances: last frame's instance buffer + BVH (what the CtT / temporal-shift stages bind)
+    std::vector<zr_mesh_instance> instancesPrev; BuiltBvh bvhPrev; bool hasPrev = false;
+    std::vector<uint8_t> mask; std::vector<uint32_t> numTris;
+    SceneView PrevView() const
+    {
+        SceneView v = view;
+        if (hasPrev) { v.instances = instancesPrev.data(); v.nodes = bvhPrev.nodes4.data(); v.tris = bvhPrev.tris.data(); v.triMeta = bvhPrev.meta.data();
+                       v.numNodes = (uint32_t)bvhPrev.nodes4.size(); v.numTris = (uint32_t)bvhPrev.tris.size(); }
+        return v;
+    } std::vector<zr_texture_desc> texDescs; std::vector<uint8_t> texels; std::vector<zr_presampled_tri> sampleSets; std::vector<uint32_t> skyLut; std::vector<zr_voxel_sample> lvg;
 };
 
 // the descriptor-table offsets of the frame constants, latched into the scene view like zr_pass_render does
@@ -86,6 +96,7 @@ HxScene* zhx_scene_create(const zr_scene_desc* d)
     s->rho.assign(d->rho_lut, d->rho_lut + (size_t)d->rho_dim[0] * d->rho_dim[1] * d->rho_dim[2]);
     BvhBuilder b;
     s->bvh = b.Build(*d);
+    s->mask.assign(d->instance_mask, d->instance_mask + d->num_instances); s->numTris.assign(d->instance_num_tris, d->instance_num_tris + d->num_instances);
     SceneView& v = s->view;
     v.vertices = s->vertices.data(); v.indices = s->indices.data(); v.instances = s->instances.data(); v.materials = s->materials.data();
     v.emissives = s->emissives.data(); v.alias = nullptr; v.sampleSets = nullptr; v.sampleSetSize = 0; v.nodes = s->bvh.nodes4.data(); v.tris = s->bvh.tris.data(); v.triMeta = s->bvh.meta.data();
@@ -94,6 +105,19 @@ HxScene* zhx_scene_create(const zr_scene_desc* d)
     if (d->num_textures) { s->texDescs.assign(d->textures, d->textures + d->num_textures); s->texels.assign(d->texels, d->texels + d->texel_bytes); }
     v.tex.descs = s->texDescs.data(); v.tex.texels = s->texels.data(); v.tex.srgb = zr_srgb_to_linear_table; v.tex.count = d->num_textures;
     return s;
+}
+void zhx_scene_update_instances(HxScene* s, const zr_mesh_instance* instances, const float* instance_to_world, uint32_t n)
+{
+    s->instancesPrev = s->instances; s->bvhPrev = s->bvh; s->hasPrev = true;
+    s->instances.assign(instances, instances + n);
+    zr_scene_desc d; memset(&d, 0, sizeof(d));
+    d.vertices = s->vertices.data(); d.num_vertices = (uint32_t)s->vertices.size(); d.indices = s->indices.data(); d.num_indices = (uint32_t)s->indices.size();
+    d.instances = s->instances.data(); d.num_instances = n; d.instance_to_world = instance_to_world; d.instance_mask = s->mask.data(); d.instance_num_tris = s->numTris.data();
+    BvhBuilder b;
+    s->bvh = b.Build(d);
+    SceneView& v = s->view;
+    v.instances = s->instances.data(); v.nodes = s->bvh.nodes4.data(); v.tris = s->bvh.tris.data(); v.triMeta = s->bvh.meta.data();
+    v.numNodes = (uint32_t)s->bvh.nodes4.size(); v.numTris = (uint32_t)s->bvh.tris.size();
 }
 void zhx_scene_destroy(HxScene* s) { delete s; }
 void zhx_scene_set_alias(HxScene* s, const zr_alias_entry* e, uint32_t n) { s->alias.assign(e, e + n); s->view.alias = s->alias.data(); }
@@ -293,7 +317,7 @@ void zhx_rpt_render_stage(const HxScene* s, HxRpt* R, const zr_frame_constants* 
     auto flush = [&]() { total[0] += cnt[0]; total[1] += cnt[1]; cnt[0] = cnt[1] = 0; };
     const zr_frame_constants& g = *cb;
     RptFrame F;
-    F.sc = s->view; F.gb = ViewOf(curr); F.gb.x0 = g_tile_x0; F.gb.y0 = g_tile_y0;
+    F.sc = s->view; F.scPrev = s->PrevView(); F.gb = ViewOf(curr); F.gb.x0 = g_tile_x0; F.gb.y0 = g_tile_y0;
     F.gbPrev = prev ? ViewOf(prev) : F.gb; F.gbPrev.x0 = g_tile_x0; F.gbPrev.y0 = g_tile_y0;
     F.ox0 = g_own[2] ? g_own[0] : F.gb.x0; F.oy0 = g_own[2] ? g_own[1] : F.gb.y0;
     F.ow = g_own[2] ? g_own[2] : F.gb.w; F.oh = g_own[2] ? g_own[3] : F.gb.h;
@@ -460,6 +484,7 @@ void zhx_rdi_render(const HxScene* s, HxRdi* R, const zr_frame_constants* cb, co
     const uint32_t W = g.render_width, H = g.render_height;
     DiFrame F;
     F.sc = s->view; F.gb = ViewOf(curr); F.gbPrev = prev ? ViewOf(prev) : F.gb;
+    F.scPrev = s->PrevView();
     F.ox0 = 0; F.oy0 = 0; F.ow = W; F.oh = H;
     F.cur.A = R->A[R->currIdx].data(); F.cur.B = R->B[R->currIdx].data();
     F.prev.A = R->A[1 - R->currIdx].data(); F.prev.B = R->B[1 - R->currIdx].data();
@@ -589,6 +614,7 @@ void zhx_sdi_render(const HxScene* s, HxSdi* R, const zr_frame_constants* cb, co
     const uint32_t W = g.render_width, H = g.render_height;
     SkyFrame F;
     F.sc = s->view; F.gb = ViewOf(curr); F.gbPrev = prev ? ViewOf(prev) : F.gb;
+    F.scPrev = s->PrevView();
     F.cur.A = R->A[R->currIdx].data(); F.cur.B = R->B[R->currIdx].data(); F.cur.C = R->C[R->currIdx].data();
     F.prev.A = R->A[1 - R->currIdx].data(); F.prev.B = R->B[1 - R->currIdx].data(); F.prev.C = R->C[1 - R->currIdx].data();
     F.target = R->target.data(); F.finalRGBA = finalRGBA;

@@ -77,6 +77,12 @@ class HostExecScene:
             lib().zhx_scene_destroy(self.h)
             self.h = None
 
+    def update_instances(self, instances, instance_to_world):
+        L = lib()
+        L.zhx_scene_update_instances.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32]
+        i, x = np.ascontiguousarray(instances), np.ascontiguousarray(instance_to_world, np.float32)
+        L.zhx_scene_update_instances(self.h, i.ctypes.data, x.ctypes.data, len(i))
+
     def bvh_info(self):
         a, b, c = C.c_uint32(), C.c_uint32(), C.c_uint32()
         lib().zhx_bvh_info(self.h, C.byref(a), C.byref(b), C.byref(c))

@@ -46,13 +46,16 @@ def test_oracle_reproduces_reference_passes(case):
     g = _gold(case)
     o = zro.OracleScene(sc, force_bvh=force_bvh)
     rpt = {"rpt": zro.OracleRPT, "gi": zro.OracleRGI, "di": zro.OracleRDI, "sdi": zro.OracleSDI}[integ](o, RC.W, RC.H) if integ != "pt" else None
+    anim = RC.Animator(sc) if case in RC.ANIMATED else None
     for f, cb in RC.frames_of(case):
+        if anim is not None and f >= 2:
+            o.update_instances(*anim.step(f))
         if len(sc.emissives) == 0:
             o.sky_lut(cb, 256, 128)
         if prm.presampling:
             o.presample(f, prm.num_sample_sets, prm.sample_set_size)
         arrays, planes = o.gbuffer(cb)
-        if f == 1:
+        if f == (3 if anim is not None else 1):
             for n, a in zip(wire.GB_PLANE_NAMES, arrays):
                 assert _same(a, GB[f"{case}_{n}"]), f"K1 plane {n} differs from the reference shader's"
         got = o.pathtrace(cb, planes, prm)[0] if integ == "pt" else rpt.render(cb, prm, gb=(arrays, planes))
@@ -71,7 +74,8 @@ def _zref():
     return zref
 
 
-@pytest.mark.parametrize("case", ["k9_materials_rr", "rpt_cornell_moving", "rpt_sun_sky", "gi_materials_rr", "di_materials", "sdi_cornell_moving"])
+@pytest.mark.parametrize("case", ["k9_materials_rr", "rpt_cornell_moving", "rpt_sun_sky", "gi_materials_rr", "di_materials", "sdi_cornell_moving",
+                                  "rpt_moving_instance", "di_moving_instance"])
 def test_live_reference_passes_match_stored_outputs(case):
     """re-runs the reference's compiled shaders: guards the stored files against a stale build"""
     zref = _zref()
@@ -83,7 +87,12 @@ def test_live_reference_passes_match_stored_outputs(case):
     o = zro.OracleScene(sc, force_bvh=force_bvh)
     k1 = zref.RefGBuffer(sc, force_bvh)
     ref = M.make_ref(zref, sc, integ, prm, force_bvh)
+    anim = RC.Animator(sc) if case in RC.ANIMATED else None
     for f, cb in RC.frames_of(case):
+        if anim is not None and f >= 2:
+            inst, xw = anim.step(f)
+            for q in (o, k1, ref):
+                q.update_instances(inst, xw)
         M.prepare(ref, o, sc, cb, f, prm)
         arrays, planes = k1.render(cb)
         got = ref.render(cb, planes, prm) if integ == "pt" else ref.render(cb, prm, (arrays, planes))
@@ -138,15 +147,48 @@ def test_hip_path_reproduces_reference_passes(case):
         r = api.Renderer(sc, RC.W, RC.H, params=prm, integrator=integrator)
         p = r.p_indirect
         names = {n: n for n in RC.RPT_PLANES} if integ == "rpt" else {"A": "gi_A", "B": "gi_B", "C": "gi_C"}
+    anim = RC.Animator(sc) if case in RC.ANIMATED else None
     for f, cb in RC.frames_of(case):
+        if anim is not None and f >= 2:
+            r.scene.update_instances(*anim.step(f))
         r.render_frame(cb)
-        if f == 1:
+        if f == (3 if anim is not None else 1):
             planes, _ = r.gbuffer.download()
             for n, a in zip(wire.GB_PLANE_NAMES, planes):
                 assert _same(a, GB[f"{case}_{n}"]), f"K1 plane {n} differs from the reference shader's"
         assert _same(p.download(), g[f"final_{f}"]), f"frame {f}: FINAL differs from the reference shaders'"
     for nm in RC.PLANES[integ]:
         a, b = p.download_plane(names[nm]), g["plane_" + nm]
+        if nm == "A" and integ == "rpt":
+            a, b = _plane_a(a), _plane_a(b)
+        assert _same(a, b), f"reservoir plane {nm} differs from the reference shaders'"
+
+
+# ------------------------------------------------------------------ the HIP stage functions, executed on the host, against the reference's outputs
+@pytest.mark.parametrize("case", ["rpt_cornell_moving", "rpt_moving_instance", "di_moving_instance", "sdi_moving_instance", "gi_cornell_moving", "rpt_sun_sky"])
+def test_hip_stage_functions_on_host_reproduce_reference_passes(case):
+    """the product's device code (zr_stages.h, zr_rpt.h, zr_rdi.h, zr_sdi.h, zr_rgi.h) compiled for the host by tests/hostexec and run serially:
+    catches a divergence from the reference's shaders without a GPU, incl. the dynamic-instance paths (previous BVH / mesh instances, MoveXk)"""
+    from oracle import zro
+    from tests.hostexec import zhx
+    sc, force_bvh, integ, prm = RC.scene_and_params(case)
+    g = _gold(case)
+    o = zro.OracleScene(sc, force_bvh=force_bvh)                 # only for the scene-level inputs (alias table, presampled sets, sky LUT)
+    hx = zhx.HostExecScene(sc, alias=o.alias if len(sc.emissives) else None)
+    run = {"rpt": zhx.HostExecRPT, "gi": zhx.HostExecRGI, "di": zhx.HostExecRDI, "sdi": zhx.HostExecSDI}[integ](hx, RC.W, RC.H)
+    anim = RC.Animator(sc) if case in RC.ANIMATED else None
+    for f, cb in RC.frames_of(case):
+        if anim is not None and f >= 2:
+            hx.update_instances(*anim.step(f))
+        if len(sc.emissives) == 0:
+            hx.sky_lut(cb, 256, 128)
+        gb = hx.gbuffer(cb)
+        if f == (3 if anim is not None else 1):
+            for n, a in zip(wire.GB_PLANE_NAMES, gb[0]):
+                assert _same(a, GB[f"{case}_{n}"]), f"K1 plane {n} differs from the reference shader's"
+        assert _same(run.render(cb, prm, gb=gb), g[f"final_{f}"]), f"frame {f}: FINAL differs from the reference shaders'"
+    for nm in RC.PLANES[integ]:
+        a, b = run.plane(nm), g["plane_" + nm]
         if nm == "A" and integ == "rpt":
             a, b = _plane_a(a), _plane_a(b)
         assert _same(a, b), f"reservoir plane {nm} differs from the reference shaders'"

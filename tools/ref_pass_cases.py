@@ -50,9 +50,41 @@ CASES = {
     "di_materials": ("materials_lights", "di", 3, {}, False),
     "di_presampled": ("materials_lights", "di", 3, dict(presample=(32, 128)), False),
     "sdi_cornell_moving": ("cornell", "sdi", 5, {}, True),
+    # dynamic instance: the tall box slides and turns during frames 2-4 and rests afterwards (zr_scene_update_instances: previous
+    # acceleration structure + mesh instances bound by the CtT passes / temporal shifts, MoveXk, x_k_in_motion)
+    "rpt_moving_instance": ("cornell_emissive", "rpt", 6, {}, False),
+    "di_moving_instance": ("cornell_emissive", "di", 6, {}, False),
+    "sdi_moving_instance": ("cornell", "sdi", 5, {}, False),
 }
+ANIMATED = {"rpt_moving_instance", "di_moving_instance", "sdi_moving_instance"}
 RPT_PLANES = ("A", "B", "C", "D", "E", "F", "G", "neighbor")
 PLANES = {"rpt": RPT_PLANES, "gi": ("A", "B", "C"), "di": ("A", "B"), "sdi": ("A", "B", "C"), "pt": ()}
+
+
+def animated_instance(sc):
+    """index of the instance the *_moving_instance cases animate: the largest non-emissive mesh that is not a wall (a box)"""
+    import numpy as _np
+    from zetaray_amd import wire as _w
+    cand = [i for i in range(len(sc.instances)) if sc.instance_mask[i] == _w.SUBGROUP_NON_EMISSIVE and sc.instance_num_tris[i] >= 10]
+    return cand[-1]
+
+
+class Animator:
+    """per-frame instance updates of an animated case: call step(f) before rendering frame f >= 2; returns (instances, instance_to_world)"""
+
+    def __init__(self, sc):
+        import math
+        self.sc, self.idx, self.xf, self.math = sc, animated_instance(sc), {}, math
+        self.t0 = sc.instances["translation"][self.idx].copy()
+
+    def step(self, f):
+        from zetaray_amd import scene_io
+        m = self.math
+        if 2 <= f <= 4:
+            t = self.t0 + np.array([0.06 * (f - 1), 0.0, 0.03 * (f - 1)], np.float32)
+            a = 0.15 * (f - 1)
+            return scene_io.move_instance(self.sc, self.idx, translation=t, rotation=np.array([0, m.sin(a / 2), 0, m.cos(a / 2)], np.float32), xform_of=self.xf)
+        return scene_io.move_instance(self.sc, self.idx, xform_of=self.xf)
 
 
 def frames_of(case):

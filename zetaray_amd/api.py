@@ -33,7 +33,7 @@ RPT_OUTPUTS = {"A": (1, np.uint32, 1), "B": (2, np.float32, 2), "C": (3, np.uint
                "ntc_A": (14, np.uint16, 4), "ntc_B": (15, np.uint32, 4), "ntc_C": (16, np.uint32, 4), "ntc_D": (17, np.uint16, 1)}
 
 EXPORTS = [
-    "zr_abi_version", "zr_last_error", "zr_device_count", "zr_wire_layout", "zr_scene_create", "zr_scene_destroy",
+    "zr_abi_version", "zr_last_error", "zr_device_count", "zr_wire_layout", "zr_scene_create", "zr_scene_destroy", "zr_scene_update_instances",
     "zr_scene_set_alias_table", "zr_alias_table_build", "zr_scene_get_alias_table", "zr_scene_get_light_voxel_grid", "zr_scene_bvh_info",
     "zr_gbuffer_create", "zr_gbuffer_destroy", "zr_gbuffer_set_tile_origin", "zr_gbuffer_download", "zr_gbuffer_device_plane",
     "zr_params_default", "zr_pass_create", "zr_pass_init", "zr_pass_resize", "zr_pass_reset_temporal",
@@ -137,6 +137,13 @@ class Scene:
         self._desc = scene.desc()
         self.h = C.c_void_p()
         _check(lib().zr_scene_create(device, C.addressof(self._desc), C.byref(self.h)))
+
+    def update_instances(self, instances, instance_to_world):
+        """per-frame MeshInstance records + object-to-world matrices; last frame's instance buffer and BVH become the previous ones"""
+        L = lib()
+        L.zr_scene_update_instances.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32]
+        i, x = np.ascontiguousarray(instances), np.ascontiguousarray(instance_to_world, np.float32)
+        _check(L.zr_scene_update_instances(self.h, i.ctypes.data, x.ctypes.data, len(i)))
 
     def set_alias_table(self, entries):
         entries = np.ascontiguousarray(entries)

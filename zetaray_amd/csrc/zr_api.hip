@@ -441,6 +441,10 @@ struct zr_scene
     DevBuf<zr_presampled_tri> sampleSets; uint32_t numSampleSets = 0;      // K3 output, refreshed by every PRELIGHTING render
     DevBuf<zr_voxel_sample> lvg;                                           // K4 output, rebuilt by every PRELIGHTING render when use_lvg
     std::vector<zr_alias_entry> aliasHost;
+    // dynamic instances (zr_scene_update_instances): host copies of what a BVH rebuild needs, and the previous frame's instance buffer + BVH
+    std::vector<zr_vertex> hVertices; std::vector<uint32_t> hIndices; std::vector<uint8_t> hMask; std::vector<uint32_t> hNumTris;
+    DevBuf<zr_mesh_instance> instancesPrev; DevBuf<Bvh4Node> nodesPrev; DevBuf<BvhTri> trisPrev; DevBuf<TriMeta> metaPrev;
+    uint32_t numNodesPrev = 0, numTrisPrev = 0; bool hasPrev = false;
     // `view` is what kernels receive by value.  Passes of one dependency level may record concurrently from several host threads
     // (RenderGraph.cpp:442-541) while Sky / PreLighting publish scene-owned state (sky LUT, alias table, presampled sets, LVG):
     // every reader takes a private copy through FrameView() and every writer updates `view` under `mtx`.
@@ -460,6 +464,19 @@ static SceneView FrameView(const zr_scene* sc, const zr_frame_constants* cb)
     {
         v.baseColorMapsOffset = cb->base_color_maps_desc_heap_offset; v.normalMapsOffset = cb->normal_maps_desc_heap_offset;
         v.mrMapsOffset = cb->metallic_roughness_maps_desc_heap_offset; v.emissiveMapsOffset = cb->emissive_maps_desc_heap_offset;
+    }
+    return v;
+}
+// ... and as the passes that bind the PREVIOUS acceleration structure and mesh-instance buffer see it (RT_SCENE_BVH_PREV /
+// RT_FRAME_MESH_INSTANCES_PREV: CtT replay / reconnect of ReSTIR PT, the temporal shifts of the DI passes); == FrameView while nothing moved
+static SceneView FrameViewPrev(const zr_scene* sc, const zr_frame_constants* cb)
+{
+    SceneView v = FrameView(sc, cb);
+    std::lock_guard<std::mutex> lock(sc->mtx);
+    if (sc->hasPrev)
+    {
+        v.instances = sc->instancesPrev.p; v.nodes = sc->nodesPrev.p; v.tris = sc->trisPrev.p; v.triMeta = sc->metaPrev.p;
+        v.numNodes = sc->numNodesPrev; v.numTris = sc->numTrisPrev;
     }
     return v;
 }
@@ -790,7 +807,40 @@ int zr_scene_create(int device, const zr_scene_desc* d, zr_scene** out)
         if (d->instances[i].base_color_tex != ZR_INVALID_TEX && (int64_t)d->instances[i].base_color_tex > s->maxTex[0]) s->maxTex[0] = d->instances[i].base_color_tex;
     for (uint32_t i = 0; i < d->num_emissives; i++)
     { const uint32_t t = d->emissives[i].packed_b & 0xffffu; if (t != ZR_INVALID_TEX && (int64_t)t > s->maxTex[3]) s->maxTex[3] = t; }
+    s->hVertices.assign(d->vertices, d->vertices + d->num_vertices); s->hIndices.assign(d->indices, d->indices + d->num_indices);
+    s->hMask.assign(d->instance_mask, d->instance_mask + d->num_instances); s->hNumTris.assign(d->instance_num_tris, d->instance_num_tris + d->num_instances);
     *out = s;
+    return ZR_OK;
+}
+
+// TLAS / instance-buffer update of a frame (RtAccelerationStructure.cpp:382-506, 708-787): the current instance buffer and acceleration
+// structure become the previous ones, the new ones are built from the new object-to-world matrices.  This version rebuilds the BVH on
+// the host (binned SAH, like zr_scene_create) and waits for the device first; a device-side refit is the planned replacement.
+int zr_scene_update_instances(zr_scene* s, const zr_mesh_instance* instances, const float* instance_to_world, uint32_t n)
+{
+    if (!s || !instances || !instance_to_world) return Fail(ZR_ERR_INVALID_ARG, "zr_scene_update_instances: null argument");
+    if (n != s->instances.n) return Fail(ZR_ERR_INVALID_ARG, "zr_scene_update_instances: %u instances, the scene has %zu", n, s->instances.n);
+    HIP_TRY(hipSetDevice(s->device));
+    zr_scene_desc d; memset(&d, 0, sizeof(d));
+    d.vertices = s->hVertices.data(); d.num_vertices = (uint32_t)s->hVertices.size(); d.indices = s->hIndices.data(); d.num_indices = (uint32_t)s->hIndices.size();
+    d.instances = instances; d.num_instances = n; d.instance_to_world = instance_to_world; d.instance_mask = s->hMask.data(); d.instance_num_tris = s->hNumTris.data();
+    BvhBuilder builder;
+    BuiltBvh bvh = builder.Build(d);
+    if (bvh.stackNeed + 1 > (uint32_t)kTravStack) return Fail(ZR_ERR_UNSUPPORTED, "BVH needs %u traversal stack entries (limit %d)", bvh.stackNeed, kTravStack - 1);
+    HIP_TRY(hipDeviceSynchronize());           // kernels of earlier frames may still read the buffers that change roles below
+    std::lock_guard<std::mutex> lock(s->mtx);
+    std::swap(s->instances.p, s->instancesPrev.p); std::swap(s->instances.n, s->instancesPrev.n);
+    std::swap(s->nodes.p, s->nodesPrev.p); std::swap(s->nodes.n, s->nodesPrev.n);
+    std::swap(s->tris.p, s->trisPrev.p); std::swap(s->tris.n, s->trisPrev.n);
+    std::swap(s->meta.p, s->metaPrev.p); std::swap(s->meta.n, s->metaPrev.n);
+    s->numNodesPrev = s->view.numNodes; s->numTrisPrev = s->view.numTris; s->hasPrev = true;
+    int r;
+    if ((r = s->instances.Upload(instances, n)) || (r = s->nodes.Upload(bvh.nodes4.data(), bvh.nodes4.size())) ||
+        (r = s->tris.Upload(bvh.tris.data(), bvh.tris.size())) || (r = s->meta.Upload(bvh.meta.data(), bvh.meta.size()))) return r;
+    SceneView& v = s->view;
+    v.instances = s->instances.p; v.nodes = s->nodes.p; v.tris = s->tris.p; v.triMeta = s->meta.p;
+    v.numNodes = (uint32_t)bvh.nodes4.size(); v.numTris = (uint32_t)bvh.tris.size();
+    if (bvh.maxDepth > s->maxDepth) s->maxDepth = bvh.maxDepth;
     return ZR_OK;
 }
 
@@ -1245,6 +1295,7 @@ static int RenderDirectEmissive(zr_pass* p, hipStream_t s, const zr_frame_consta
         return Fail(ZR_ERR_NOT_INITIALIZED, "presampled light sets missing or of another size: render the PRELIGHTING pass with the same presampling params first");
     DiFrame F;
     F.sc = FrameView(sc, cb); F.gb = gb->View(); F.gbPrev = gb->PrevView();
+    F.scPrev = FrameViewPrev(sc, cb);
     if (int orc = ResolveOwnedRect(p, gb, cb, &F.ox0, &F.oy0, &F.ow, &F.oh)) return orc;
     F.cur.A = p->diA[p->currIdx].p; F.cur.B = p->diB[p->currIdx].p; F.prev.A = p->diA[1 - p->currIdx].p; F.prev.B = p->diB[1 - p->currIdx].p;
     F.target = p->diTarget.p; F.finalRGBA = p->finalRGBA.p; F.sampleSet = p->diSampleSet.p;
@@ -1286,6 +1337,7 @@ static int RenderDirectSky(zr_pass* p, hipStream_t s, const zr_frame_constants* 
     const zr_params& ip = p->params;
     SkyFrame F;
     F.sc = FrameView(sc, cb); F.gb = gb->View(); F.gbPrev = gb->PrevView();
+    F.scPrev = FrameViewPrev(sc, cb);
     if (int orc = ResolveOwnedRect(p, gb, cb, &F.ox0, &F.oy0, &F.ow, &F.oh)) return orc;
     F.cur.A = p->skyA[p->currIdx].p; F.cur.B = p->skyB[p->currIdx].p; F.cur.C = p->skyC[p->currIdx].p;
     F.prev.A = p->skyA[1 - p->currIdx].p; F.prev.B = p->skyB[1 - p->currIdx].p; F.prev.C = p->skyC[1 - p->currIdx].p;
@@ -1356,6 +1408,7 @@ static int RenderReSTIR_PT(zr_pass* p, hipStream_t s, const zr_frame_constants* 
     using namespace rpt;
     RptFrame F;
     F.sc = FrameView(sc, cb); F.gb = gb->View(); F.gbPrev = gb->PrevView();
+    F.scPrev = FrameViewPrev(sc, cb);
     if (int orc = ResolveOwnedRect(p, gb, cb, &F.ox0, &F.oy0, &F.ow, &F.oh)) return orc;
     F.rbCtN = p->rb[0].View(); F.rbNtC = p->rb[1].View(); F.tex.target = p->rptTarget.p; F.tex.neighbor = p->rptNeighbor.p;
     F.finalRGBA = p->finalRGBA.p; F.sampleSet = p->rptSampleSet.p;

@@ -135,6 +135,7 @@ struct DiParams { uint32_t flags, M_max, numSampleSets, accumulate, doTemporal, 
 struct DiFrame
 {
     SceneView sc; GBuf gb, gbPrev; DiPlanes cur, prev; F4* target; float* finalRGBA; const uint16_t* sampleSet; DiParams prm;
+    SceneView scPrev;        // previous frame's acceleration structure (g_bvh_prev, ReSTIR_DI_Temporal.hlsl:17)
     uint32_t ox0, oy0, ow, oh;
     ZR_HDM bool Owns(uint32_t x, uint32_t y) const { return x >= ox0 && y >= oy0 && x < ox0 + ow && y < oy0 + oh; }
 };
@@ -276,7 +277,11 @@ ZR_HD float OffsetPathTarget_CtT(const Globals& gl, const Reservoir& r_curr, con
     V3 target = r_curr.le * dwdA;
     target = target * Unified(gl.sc->rho, surface).f;
     float lum = Luminance(target);
-    if (lum > 0) lum *= VisibilitySegmentApprox(gl, candidate.pos, wi, t, candidate.normal, r_curr.lightID, surface.Transmissive()) ? 1.0f : 0.0f;
+    if (lum > 0)
+    {
+        Globals gp = gl; if (gl.scPrev) gp.sc = gl.scPrev;       // g_bvh_prev (Resampling.hlsli:134-200)
+        lum *= VisibilitySegmentApprox(gp, candidate.pos, wi, t, candidate.normal, r_curr.lightID, surface.Transmissive()) ? 1.0f : 0.0f;
+    }
     return lum;
 }
 ZR_HD V3 OffsetPathTarget_TtC(const Globals& gl, const Reservoir& r_prev, V3 pos, V3 normal, Surface surface)
@@ -349,7 +354,7 @@ ZR_HD V3 EmissiveColor(const GBuf& gb, size_t px)
 
 ZR_HD Globals MakeGlobals(const DiFrame& F, const zr_frame_constants& g, TravStack stack, uint32_t* cnt)
 {
-    Globals gl; gl.sc = &F.sc; gl.frame = &g; gl.emissive = g.num_emissive_triangles != 0; gl.numEmissives = g.num_emissive_triangles; gl.alpha_min = 0; gl.stack = stack; gl.cnt = cnt; gl.maxNumBounces = 1;
+    Globals gl; gl.sc = &F.sc; gl.scPrev = &F.scPrev; gl.frame = &g; gl.emissive = g.num_emissive_triangles != 0; gl.numEmissives = g.num_emissive_triangles; gl.alpha_min = 0; gl.stack = stack; gl.cnt = cnt; gl.maxNumBounces = 1;
     gl.presampled = false; gl.sampleSetIdx = 0;
     return gl;
 }

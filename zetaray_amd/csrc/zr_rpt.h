@@ -399,7 +399,9 @@ ZR_HD Reservoir Load_NonReconnection(const ResPlanes& p, size_t i)
 // cnt: this lane's ray counters {closest-hit queries, shadow / visibility queries} (never null)
 // emissive == false selects the NEE_EMISSIVE == 0 shader variants (sun + sky lighting): the kernels are instantiated per variant and set
 // it from a template constant, so the other variant's code folds away; frame = cbFrameConstants (sun, atmosphere)
-struct Globals { bool textured = false; const SceneView* sc; uint32_t numEmissives; int maxNumBounces; float alpha_min; TravStack stack; uint32_t* cnt; bool presampled; uint32_t sampleSetIdx;
+// scPrev: the previous frame's acceleration structure + mesh instances (RT_SCENE_BVH_PREV / RT_FRAME_MESH_INSTANCES_PREV), bound instead of
+// `sc` by the CtT passes of ReSTIR PT (IndirectLighting.cpp:465-471, 542-548) and by the temporal shifts of the DI passes (g_bvh_prev)
+struct Globals { bool textured = false; const SceneView* sc; const SceneView* scPrev = nullptr; uint32_t numEmissives; int maxNumBounces; float alpha_min; TravStack stack; uint32_t* cnt; bool presampled; uint32_t sampleSetIdx;
     const zr_frame_constants* frame; bool emissive; };
 
 // ---- ray queries (inline traversal)
@@ -1411,6 +1413,7 @@ ZR_HD_FLAT OffsetPath Shift2(const Globals& g, bool currFrame, size_t DTidIdx, V
 struct RptFrame
 {
     SceneView sc; GBuf gb, gbPrev; ResPlanes cur, prev;    // cur = this frame's reservoirs, prev = the other set
+    SceneView scPrev;                                      // the scene as it was last frame (== sc while nothing moves)
     RBuf rbCtN, rbNtC; RptTex tex; float* finalRGBA; const uint16_t* sampleSet; RptParams prm;
     // pixels this device is responsible for (global coordinates); the planes also hold an apron of neighbouring tiles'
     // pixels: G-buffer rendered locally, reservoirs received through the halo exchange
@@ -1420,7 +1423,7 @@ struct RptFrame
 
 ZR_HD Globals MakeGlobals(const RptFrame& F, const zr_frame_constants& g, bool transmissive, TravStack stack, uint32_t* cnt)
 {
-    Globals gl; gl.textured = F.prm.textured != 0; gl.sc = &F.sc; gl.frame = &g; gl.emissive = F.prm.emissive != 0; gl.numEmissives = g.num_emissive_triangles; gl.alpha_min = F.prm.alpha_min; gl.stack = stack; gl.cnt = cnt; gl.presampled = false; gl.sampleSetIdx = 0;
+    Globals gl; gl.textured = F.prm.textured != 0; gl.sc = &F.sc; gl.scPrev = &F.scPrev; gl.frame = &g; gl.emissive = F.prm.emissive != 0; gl.numEmissives = g.num_emissive_triangles; gl.alpha_min = F.prm.alpha_min; gl.stack = stack; gl.cnt = cnt; gl.presampled = false; gl.sampleSetIdx = 0;
     gl.maxNumBounces = transmissive ? (int)F.prm.maxGlossyTrBounces : (int)F.prm.maxNonTrBounces;
     return gl;
 }
@@ -1468,7 +1471,8 @@ ZR_HD_FLAT void ReplayTemporalPixel(const RptFrame& F, const zr_frame_constants&
         if (!r.rc.Empty() && (r.rc.k > 2))
         {
             r.Load_Reconnection(F.cur, px, F.prm.emissive != 0);
-            OffsetCtx ctx = Replay_kGt2(gl, false, tp.prev.pos, tp.prev.normal, tp.prev.eta_next, tp.prev.surface, r.rc,
+            Globals glP = gl; glP.sc = &F.scPrev;       // Replay_CtT binds the previous acceleration structure + mesh instances (IndirectLighting.cpp:465-471)
+            OffsetCtx ctx = Replay_kGt2(glP, false, tp.prev.pos, tp.prev.normal, tp.prev.eta_next, tp.prev.surface, r.rc,
                 MakePrimaryDiffs(PrevCamera(g), tp.px, tp.py, tp.prev, F.gbPrev, pp), true);
             WriteOffsetCtx(ctx, F.rbCtN, px, r.rc.IsCase3(), gl.textured);
         }
@@ -1532,8 +1536,10 @@ ZR_HD void ReconnectTemporalPixel(const RptFrame& F, const zr_frame_constants& g
         if (r_curr.w_sum != 0 && r_prev.M > 0 && !r_curr.rc.Empty())
         {
             r_curr.Load_Reconnection(F.cur, px, F.prm.emissive != 0);
-            if (r_curr.rc.IsCase1() || r_curr.rc.IsCase2()) MoveXk(F.sc, r_curr.rc, true, false);
-            OffsetPath shift = Shift2(gl, false, px, tp.prev.pos, tp.prev.normal, tp.prev.eta_next, tp.prev.surface, r_curr.rc, F.rbCtN,
+            // the CtT pass binds the previous acceleration structure and mesh instances
+            Globals glP = gl; glP.sc = &F.scPrev;
+            if (r_curr.rc.IsCase1() || r_curr.rc.IsCase2()) MoveXk(F.scPrev, r_curr.rc, true, false);
+            OffsetPath shift = Shift2(glP, false, px, tp.prev.pos, tp.prev.normal, tp.prev.eta_next, tp.prev.surface, r_curr.rc, F.rbCtN,
                 MakePrimaryDiffs(PrevCamera(g), tp.px, tp.py, tp.prev, F.gbPrev, pp));
             float target_prev = Luminance(shift.target);
             if (target_prev > 0)

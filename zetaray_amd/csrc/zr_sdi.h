@@ -114,10 +114,11 @@ struct SkyParams { uint32_t M_max_sky, M_max_sun, accumulate, doTemporal, doSpat
 struct SkyFrame
 {
     SceneView sc; GBuf gb, gbPrev; SkyPlanes cur, prev; F4* target; float* finalRGBA; SkyParams prm;
+    SceneView scPrev;        // previous frame's acceleration structure (g_bvh_prev, SkyDI_Temporal.hlsl:14)
     uint32_t ox0, oy0, ow, oh;       // owned rect (global pixels): the part of the planes this device shades (multi-GPU tile split)
     ZR_HDM bool Owns(uint32_t x, uint32_t y) const { return x >= ox0 && y >= oy0 && x < ox0 + ow && y < oy0 + oh; }
 };
-struct Ctx { const SceneView* sc; const zr_frame_constants* g; TravStack stack; uint32_t* cnt; };
+struct Ctx { const SceneView* sc; const zr_frame_constants* g; TravStack stack; uint32_t* cnt; const SceneView* scPrev = nullptr; };
 
 // RtRayQuery::Visibility_Ray, RayQuery.hlsli:302-334
 ZR_HD bool VisibilityRay(const Ctx& c, V3 origin, V3 wi, V3 normal, bool transmissive)
@@ -248,7 +249,8 @@ ZR_HD void TemporalResample(const Ctx& c, TemporalCandidate candidate, V3 pos, V
             const V3 target_prev = le * Unified(rho, candidate.surface).f;
             targetLum_prev = Luminance(target_prev);
             if (targetLum_prev > 0)
-                targetLum_prev *= VisibilityRay(c, candidate.pos, wi_offset, candidate.normal, candidate.surface.Transmissive()) ? 1.0f : 0.0f;
+                { Ctx cp = c; if (c.scPrev) cp.sc = c.scPrev;      // g_bvh_prev (Sky/Resampling.hlsli:142-183)
+                  targetLum_prev *= VisibilityRay(cp, candidate.pos, wi_offset, candidate.normal, candidate.surface.Transmissive()) ? 1.0f : 0.0f; }
         }
         const float numerator = (float)r.M * Luminance(r.target);
         const float denom = numerator + (float)r_prev.M * targetLum_prev * jacobian;
@@ -337,7 +339,7 @@ ZR_HD void TemporalPixel(const SkyFrame& F, const zr_frame_constants& g, uint32_
     PixelSurface ps = LoadPixelSurface(F.gb, cam, x, y, g.frame_num, px);
     uint32_t hx = y, hy = x, hz = x; zr_pcg3d(&hx, &hy, &hz);                 // RNG::PCG3d(DTid.yxx).yz
     Rng rng = Rng::Init(hy, hz, g.frame_num);
-    Ctx c; c.sc = &F.sc; c.g = &g; c.stack = stack; c.cnt = cnt;
+    Ctx c; c.sc = &F.sc; c.scPrev = &F.scPrev; c.g = &g; c.stack = stack; c.cnt = cnt;
     Reservoir r = RIS_InitialCandidates(c, prm.alpha_min, ps.pos, ps.normal, ps.surface, rng);
     if (prm.doTemporal)
     {
@@ -466,7 +468,7 @@ ZR_HD void SpatialPixel(const SkyFrame& F, const zr_frame_constants& g, uint32_t
     PixelSurface ps = LoadPixelSurface(F.gb, cam, x, y, g.frame_num, px);
     uint32_t hx = y, hy = x, hz = x; zr_pcg3d(&hx, &hy, &hz);
     Rng rng = Rng::Init(hy, hz, g.frame_num);
-    Ctx c; c.sc = &F.sc; c.g = &g; c.stack = stack; c.cnt = cnt;
+    Ctx c; c.sc = &F.sc; c.scPrev = &F.scPrev; c.g = &g; c.stack = stack; c.cnt = cnt;
     Reservoir r_c = LoadReservoir(F.cur, px);
     r_c.target = xyz(F.target[px]);
     const float u0 = rng.Uniform();

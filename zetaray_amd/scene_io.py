@@ -776,3 +776,34 @@ def set_texture_heap_offsets(cb, offs):
     cb["metallic_roughness_maps_desc_heap_offset"] = offs["metallic_roughness"]
     cb["emissive_maps_desc_heap_offset"] = offs["emissive"]
     return cb
+
+
+def move_instance(sc: Scene, idx, translation=None, rotation=None, scale=None, xform_of=None):
+    """Next frame of an animated scene, in place: instance `idx` gets a new TRS (glTF-convention-free: already in the renderer's space),
+    every instance's Prev* fields take the values it had this frame -- what TLAS::FillMeshInstanceData does per frame
+    (RtAccelerationStructure.cpp:318-380: PrevRotation / PrevScale = last frame's, dTranslation = half(T - T_prev)).
+    `xform_of[i]` remembers the unquantised (t, q, s) of instance i between calls.  Returns (instances, instance_to_world)."""
+    if xform_of is None:
+        xform_of = {}
+    inst = sc.instances
+    old_t = inst["translation"].copy()
+    inst["prev_rotation"] = inst["rotation"]
+    inst["prev_scale"] = inst["scale"]
+    inst["d_translation"] = 0            # half +0.0
+    if translation is not None or rotation is not None or scale is not None:
+        if idx not in xform_of:      # start from the instance's own (quantised) rotation and scale
+            q_init = inst["rotation"][idx].astype(np.float32) / np.float32(65535.0) * np.float32(2.0) - np.float32(1.0)
+            s_init = inst["scale"][idx].view(np.float16).astype(np.float32)
+            xform_of[idx] = (inst["translation"][idx].copy(), q_init, s_init)
+        t0, q0, s0 = xform_of[idx]
+        t = np.asarray(translation if translation is not None else t0, np.float32)
+        q = np.asarray(rotation if rotation is not None else q0, np.float32)
+        q = q / np.float32(np.sqrt(np.float32(np.dot(q, q))))
+        s = np.asarray(scale if scale is not None else s0, np.float32)
+        xform_of[idx] = (t, q, s)
+        inst["rotation"][idx] = np.rint((q * np.float32(0.5) + np.float32(0.5)) * np.float32(65535.0)).astype(np.uint16)
+        inst["scale"][idx] = f32_to_f16_bits(s)
+        inst["translation"][idx] = t
+        inst["d_translation"][idx] = f32_to_f16_bits(t - old_t[idx])
+        sc.instance_to_world[idx] = trs_matrix(t, q, s).astype(np.float32).reshape(12)
+    return sc.instances, sc.instance_to_world
