@@ -102,6 +102,42 @@ def cpu_baseline(scene_host, cb, max_rays=1_000_000, rpt_params=None):
                       f"{os.cpu_count()} logical cores); BVH traversal alone: {trace_only:.2f} Mrays/s"}
 
 
+def read_prof(api):
+    """Section counters of a -DZR_PROF build of the library (zr_dev_scene.h ProfScope): wave cycles per kernel and section, and the
+    vote statistics of the BVH traversal.  None for the product build, which has no such export."""
+    import ctypes as C
+    L = api.lib()
+    if not hasattr(L, "zr_debug_prof_read"):
+        return None
+    buf = (C.c_ulonglong * 256)()
+    L.zr_debug_prof_read.argtypes = [C.c_void_p]
+    if L.zr_debug_prof_read(buf) != 0:
+        return None
+    names = ["kernel", "trav", "trav_calls", "rays", "node_iters", "node_lanes", "tri_iters", "tri_lanes", "material", "nee", "bsdf",
+             "misc0", "misc1", "misc2", "misc3", "misc4"]
+    kernels = {0: "other", 1: "rpt_pathtrace", 2: "rpt_temporal", 3: "rpt_stc"}
+    res = {}
+    for k, kn in kernels.items():
+        v = {n: int(buf[16 * k + i]) for i, n in enumerate(names)}
+        if not any(v.values()):
+            continue
+        d = dict(v)
+        if v["kernel"]:
+            for n in ("trav", "material", "nee", "bsdf", "misc0", "misc1", "misc2", "misc3", "misc4"):
+                d[n + "_frac"] = round(v[n] / v["kernel"], 4)
+        it = v["node_iters"] + v["tri_iters"]
+        if it:
+            d["trav_lane_util"] = round((v["node_lanes"] + v["tri_lanes"]) / (64.0 * it), 4)
+            d["node_lane_util"] = round(v["node_lanes"] / (64.0 * max(1, v["node_iters"])), 4)
+            d["tri_lane_util"] = round(v["tri_lanes"] / (64.0 * max(1, v["tri_iters"])), 4)
+            d["nodes_per_ray"] = round(v["node_lanes"] / max(1, v["rays"]), 3)
+            d["tris_per_ray"] = round(v["tri_lanes"] / max(1, v["rays"]), 3)
+            d["iters_per_call"] = round(it / max(1, v["trav_calls"]), 2)
+            d["rays_per_call"] = round(v["rays"] / max(1, v["trav_calls"]), 2)
+        res[kn] = d
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -290,6 +326,9 @@ def main():
                 a = agg.setdefault(name, [0.0, 0])
                 a[0] += ms
                 a[1] += launches
+        prof = read_prof(api)      # only a -DZR_PROF measurement build exports the section counters (scripts/gpu_prof.sh)
+        if prof is not None:
+            out["prof"] = prof
         kern_rays = r.p_indirect.kernel_counters()
         di_rays = {}
         for q in di_passes:      # the DI passes' per-kernel ray counts over the same nfr frames
@@ -335,20 +374,36 @@ def main():
         frame_bytes = (BYTES_CLOSEST * (cc / nfr + W * H) + BYTES_SHADOW * (cs / nfr) + (47 + 38 + 16) * W * H)
         # measured HBM-side bytes per launch of that kernel: PMC passes (FETCH_SIZE x 2 x 1024 + WRITE_SIZE x 1024, MI355X_MICROARCH.md) of
         # exactly this command, collected by scripts/gpu_pmc.sh and committed under profiles/ (rocprofv3 cannot run inside the bench)
-        traffic, traffic_src = None, None
-        default_workload = (args.scene.endswith("cornell_emissive.npz") and rpt and not args.direct and not args.sky_direct and (W, H) == (1920, 1080))
-        pmc_file = os.path.join(ROOT, "profiles", "r01_pmc_traffic_rpt1080p.json")
-        if default_workload and os.path.exists(pmc_file):
+        traffic, traffic_src, valu = None, None, None
+        plain = not (args.direct or args.sky_direct or args.textured or args.di_only) and (W, H) == (1920, 1080)
+        scene_tag = ("cornell" if args.scene.endswith("cornell_emissive.npz") else
+                     "atrium" if (args.scene == "synthetic" and args.synthetic_layout == "atrium" and args.synthetic_tris == 262144
+                                  and args.synthetic_emissives == 100000) else None)
+        wl_tag = {"restir_pt": "rpt", "restir_gi": "gi", "pt": "pt"}[args.integrator]
+        pmc_rel = os.path.join("profiles", f"r02_pmc_{wl_tag}_{scene_tag}.json")
+        if plain and scene_tag and os.path.exists(os.path.join(ROOT, pmc_rel)):
             # kernel names as rocprofv3 prints them (template arguments: NEE_EMISSIVE, TEXTURED)
-            kmap = {"rpt_pathtrace": ["k_rpt_pathtrace<true>"], "rpt_reconnect_spatial": ["k_rpt_stc<true, false>", "k_rpt_stc<true>"],
-                    "rpt_reconnect_temporal": ["k_rpt_temporal<true, false>", "k_rpt_temporal<true>"], "gbuffer": ["k_gbuffer"]}
-            table = json.load(open(pmc_file))
-            rec = next((table[k] for k in kmap.get(dom, []) if k in table), None)
+            kmap = {"rpt_pathtrace": ["k_rpt_pathtrace<true>", "k_rpt_pathtrace_w4<true>"],
+                    "rpt_reconnect_spatial": ["k_rpt_stc<true, false>"], "rpt_reconnect_temporal": ["k_rpt_temporal<true, false>"],
+                    "gbuffer": ["k_gbuffer"], "rgi": ["k_rgi<false>"], "trace": ["k_trace_simple", "k_trace"], "pt_shade": ["k_pt_shade"]}
+            table = json.load(open(os.path.join(ROOT, pmc_rel)))
+            # the launch-count filter drops a kernel variant that only ran during warm-up
+            cands = [table[k] for k in kmap.get(dom, []) if k in table]
+            rec = max(cands, key=lambda r: r.get("launches_sampled", 0)) if cands else None
             if rec:
-                traffic, traffic_src = round(rec["traffic_bytes"]), "profiles/r01_pmc_traffic_rpt1080p.json"
-        out["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
-                           "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_unit": "bytes per launch",
+                traffic, traffic_src = round(rec["traffic_bytes"]), pmc_rel
+                if "valu" in rec:
+                    v = rec["valu"]
+                    valu = {"issue_frac": v["issue_frac"], "lane_util": v["lane_util"], "achieved_ginst_per_s": v["ginst_per_s"],
+                            "peak_ginst_per_s": v["peak_ginst_per_s"], "wait_frac": v.get("wait_frac"), "source": pmc_rel}
+        hbm_frac = achieved / HBM_PEAK_GBS
+        # which resource bounds the dominant kernel: the VALU issue slots when the PMC pass shows them busier than the HBM pipe
+        bound = "valu" if (valu is not None and valu["issue_frac"] > max(hbm_frac, (traffic or 0) / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS)) else "hbm"
+        out["roofline"] = {"bound": bound, "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
+                           "unit": "GB/s", "frac": round(hbm_frac, 5), "traffic": traffic, "traffic_unit": "bytes per launch",
                            "traffic_source": traffic_src, "algorithmic_bytes_per_launch": round(bytes_launch),
+                           "measured_traffic_GBs": (round(traffic / (avg_ms * 1e-3) / 1e9, 2) if traffic else None),
+                           "valu": valu,
                            "avg_launch_ms": round(avg_ms, 4), "launches_per_frame": launches / nfr,
                            "frame_model_GBs": round(frame_bytes / (ms_per_step * 1e-3) / 1e9, 2),
                            "kernel_ms_per_frame": {k: round(v[0] / nfr, 4) for k, v in agg.items()}}

@@ -456,10 +456,29 @@ struct zr_scene
 
 // The scene as one launch sees it: a private copy of the scene's view with the texture descriptor-table offsets of THIS frame's
 // constants (per-frame data in the reference, FrameConstants.h:31-34) -- nothing per-frame is latched on the shared scene.
+#ifdef ZR_PROF
+// measurement build only (scripts/gpu_prof.sh): 16 kernels x 16 wave-cycle / event counters, read and cleared by zr_debug_prof_read
+static unsigned long long* ProfBuffer()
+{
+    static unsigned long long* p = nullptr;
+    if (!p) { (void)hipMalloc(&p, 256 * sizeof(unsigned long long)); (void)hipMemset(p, 0, 256 * sizeof(unsigned long long)); }
+    return p;
+}
+extern "C" int zr_debug_prof_read(unsigned long long* out256)
+{
+    (void)hipDeviceSynchronize();
+    if (hipMemcpy(out256, ProfBuffer(), 256 * sizeof(unsigned long long), hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    (void)hipMemset(ProfBuffer(), 0, 256 * sizeof(unsigned long long));
+    return 0;
+}
+#endif
 static SceneView FrameView(const zr_scene* sc, const zr_frame_constants* cb)
 {
     std::lock_guard<std::mutex> lock(sc->mtx);
     SceneView v = sc->view;
+#ifdef ZR_PROF
+    v.prof = ProfBuffer();
+#endif
     if (cb)
     {
         v.baseColorMapsOffset = cb->base_color_maps_desc_heap_offset; v.normalMapsOffset = cb->normal_maps_desc_heap_offset;

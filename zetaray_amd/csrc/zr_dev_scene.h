@@ -63,7 +63,45 @@ struct SceneView
     uint32_t numEmissives;
     uint32_t numNodes;       // 0 => single leaf covering tris[0 .. numTris)
     uint32_t numTris;
+#ifdef ZR_PROF
+    unsigned long long* prof;     // -DZR_PROF builds only (scripts/gpu_prof.sh): wave-cycle counters per kernel / section
+#endif
 };
+
+// Section timers of the -DZR_PROF measurement build (scripts/gpu_prof.sh): wave cycles (s_memtime) between construction and
+// destruction, summed per wave in LDS (one lane, no atomics on the hot path) and flushed to sc.prof[16 * kernel + i] when
+// the kernel ends.  Empty in the product build.
+#if defined(ZR_PROF) && defined(__HIP_DEVICE_COMPILE__)
+__shared__ unsigned long long zrProfAcc[4 * 16];
+__device__ __forceinline__ void ProfAdd(int i, unsigned long long v)
+{
+    const unsigned long long m = __ballot(1);
+    if (__lane_id() == (uint32_t)(__ffsll((long long)m) - 1)) zrProfAcc[(threadIdx.x >> 6) * 16 + i] += v;
+}
+struct ProfScope
+{
+    int i; unsigned long long t0;
+    __device__ __forceinline__ ProfScope(int i_) : i(i_), t0(__builtin_readcyclecounter()) {}
+    __device__ __forceinline__ ~ProfScope() { ProfAdd(i, __builtin_readcyclecounter() - t0); }
+};
+struct ProfKernel
+{
+    unsigned long long* dst; unsigned long long t0;
+    __device__ __forceinline__ ProfKernel(unsigned long long* d) : dst(d), t0(__builtin_readcyclecounter())
+    { if ((threadIdx.x & 63u) < 16u) zrProfAcc[(threadIdx.x >> 6) * 16 + (threadIdx.x & 63u)] = 0; }
+    __device__ __forceinline__ ~ProfKernel()
+    {
+        ProfAdd(0, __builtin_readcyclecounter() - t0);
+        if ((threadIdx.x & 63u) < 16u) atomicAdd(dst + (threadIdx.x & 63u), zrProfAcc[(threadIdx.x >> 6) * 16 + (threadIdx.x & 63u)]);
+    }
+};
+#define ZR_PROF_SCOPE(i) ProfScope zrProfScope##i(i)
+#define ZR_PROF_KERNEL(sc, k) ProfKernel zrProfKernel((sc).prof + 16 * (k))
+#else
+#define ZR_PROF_SCOPE(i)
+#define ZR_PROF_KERNEL(sc, k)
+#endif
+enum { ZRP_KERNEL = 0, ZRP_TRAV, ZRP_TRAV_CALLS, ZRP_RAYS, ZRP_NODE_ITERS, ZRP_NODE_LANES, ZRP_TRI_ITERS, ZRP_TRI_LANES, ZRP_MATERIAL, ZRP_NEE, ZRP_BSDF, ZRP_MISC0, ZRP_MISC1, ZRP_MISC2, ZRP_MISC3, ZRP_MISC4 };
 
 struct RawHit { float t, u, v; uint32_t tri; };     // tri = global triangle index, kInvalidTri on miss
 
@@ -280,6 +318,11 @@ ZR_HD RawHit TraverseDyn(const SceneView& sc, V3 o, V3 d, float tmin, float tmax
     TravState s;
     TravInit(sc, s, o, d, tmin, tmax, mask, filterID, ignoreID);
 #ifdef __HIP_DEVICE_COMPILE__
+#ifdef ZR_PROF
+    ZR_PROF_SCOPE(ZRP_TRAV);
+    unsigned long long pNI = 0, pNL = 0, pTI = 0, pTL = 0;
+    ProfAdd(ZRP_TRAV_CALLS, 1); ProfAdd(ZRP_RAYS, __popcll(__ballot(1)));
+#endif
     TravLane L; L.triCur = 0; L.triEnd = 0; L.done = false;
     TravEnter(sc, s, L, s.cur);
     for (;;)
@@ -288,9 +331,15 @@ ZR_HD RawHit TraverseDyn(const SceneView& sc, V3 o, V3 d, float tmin, float tmax
         const bool atNode = !L.done && !atTri;
         const uint64_t mNode = __ballot(atNode), mTri = __ballot(atTri);
         if ((mNode | mTri) == 0) break;
+#ifdef ZR_PROF
+        if (__popcll(mNode) >= __popcll(mTri)) { pNI++; pNL += __popcll(mNode); } else { pTI++; pTL += __popcll(mTri); }
+#endif
         if (__popcll(mNode) >= __popcll(mTri)) { if (atNode) TravNodePhase(sc, s, L, stack); }
         else { if (atTri) TravTriPhase(sc, s, L, stack, anyHit, alphaTest); }
     }
+#ifdef ZR_PROF
+    ProfAdd(ZRP_NODE_ITERS, pNI); ProfAdd(ZRP_NODE_LANES, pNL); ProfAdd(ZRP_TRI_ITERS, pTI); ProfAdd(ZRP_TRI_LANES, pTL);
+#endif
 #else
     while (!TravStep(sc, s, stack, anyHit, alphaTest)) {}
 #endif

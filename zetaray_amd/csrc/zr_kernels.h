@@ -113,9 +113,10 @@ __device__ __forceinline__ void RptPathtraceBody(rpt::RptFrame& F, const zr_fram
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
     const uint32_t x = F.ox0 + tx * 16u + (lane & 15u), y = F.oy0 + ty * 16u + wave * 4u + (lane >> 4);
     ZR_TRAV_STACK(stack);
+    ZR_PROF_KERNEL(F.sc, 1);
     uint32_t cnt[2] = {0u, 0u};
     rpt::PTLane P;
-    rpt::PtInitLane(F.sc, g, F.gb, F.prm, F.Owns(x, y), x, y, F.finalRGBA, stack, cnt, P);
+    { ZR_PROF_SCOPE(ZRP_MISC0); rpt::PtInitLane(F.sc, g, F.gb, F.prm, F.Owns(x, y), x, y, F.finalRGBA, stack, cnt, P); }
     for (;;)
     {
         const bool any = __ballot(P.active) != 0;
@@ -126,9 +127,9 @@ __device__ __forceinline__ void RptPathtraceBody(rpt::RptFrame& F, const zr_fram
         {
             for (int s = 1; s < 64; s <<= 1) { uint32_t o = __shfl_xor(key, s); key = o > key ? o : key; }
         }
-        rpt::PtPhaseB(F.sc, F.prm, P, key);
+        { ZR_PROF_SCOPE(ZRP_MISC1); rpt::PtPhaseB(F.sc, F.prm, P, key); }
     }
-    rpt::PtFinishLane(F.gb, F.prm, F.cur, F.tex, F.finalRGBA, P);
+    { ZR_PROF_SCOPE(ZRP_MISC2); rpt::PtFinishLane(F.gb, F.prm, F.cur, F.tex, F.finalRGBA, P); }
     FlushRayCounters(counters, cnt);
 }
 template<bool EMISSIVE>
@@ -166,10 +167,25 @@ __global__ void __launch_bounds__(kBlock) k_rpt_light(rpt::RptFrame F, zr_frame_
         if (in) { rpt::SpatialSearchPixel(F, g, x, y); a = rpt::NeedsReplayCtS(F, x, y); b = rpt::NeedsReplayStC(F, x, y); }
     }
     const uint32_t pid = in ? (uint32_t)rpt::Pix(F.gb, x, y) : 0u;
-    const uint32_t sa = AllocSlotWave(counts + 0, a);
-    if (a) listA[sa] = pid;
-    const uint32_t sb = AllocSlotWave(counts + 1, b);
-    if (b) listB[sb] = pid;
+    // one atomic per block and list: with every wave appending (large scenes: most pixels carry k > 2 reservoirs) 65 k returning
+    // atomics on two neighbouring counters serialised in L2 and this trivial kernel took 0.54 ms (profiles/r02a_pmc_sq_rpt_atrium1080p.csv)
+    __shared__ uint32_t sCnt[2][kBlock / 64], sBase[2];
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    const uint64_t ma = __ballot(a), mb = __ballot(b);
+    if (lane == 0) { sCnt[0][wave] = (uint32_t)__popcll(ma); sCnt[1][wave] = (uint32_t)__popcll(mb); }
+    __syncthreads();
+    if (threadIdx.x < 2)
+    {
+        uint32_t total = 0;
+        for (int w = 0; w < kBlock / 64; w++) total += sCnt[threadIdx.x][w];
+        sBase[threadIdx.x] = total ? atomicAdd(counts + threadIdx.x, total) : 0u;
+    }
+    __syncthreads();
+    uint32_t oa = sBase[0], ob = sBase[1];
+    for (uint32_t w = 0; w < wave; w++) { oa += sCnt[0][w]; ob += sCnt[1][w]; }
+    const uint64_t below = (1ull << lane) - 1ull;
+    if (a) listA[oa + (uint32_t)__popcll(ma & below)] = pid;
+    if (b) listB[ob + (uint32_t)__popcll(mb & below)] = pid;
 }
 
 // K13 replays over a work list (device-side count, fixed grid, grid-stride): only pixels with k > 2 pay for the heavy kernel
@@ -199,6 +215,7 @@ __global__ void __launch_bounds__(kBlock) ZR_WAVES_TEMPORAL k_rpt_temporal(rpt::
     F.prm.emissive = EMISSIVE ? 1u : 0u; F.prm.textured = TEX ? 1u : 0u;
     uint32_t x, y; PixelOfThread(tilesX, F.ox0, F.oy0, &x, &y);
     ZR_TRAV_STACK(stack);
+    ZR_PROF_KERNEL(F.sc, 2);
     uint32_t cnt[2] = {0u, 0u};
     if (F.Owns(x, y)) rpt::ReconnectTemporalPixel(F, g, x, y, stack, cnt);
     FlushRayCounters(counters, cnt);
@@ -219,13 +236,16 @@ __global__ void __launch_bounds__(kBlock) ZR_WAVES_STC k_rpt_stc(rpt::RptFrame F
     uint32_t x, y; PixelOfThread(tilesX, F.ox0, F.oy0, &x, &y);
     ZR_TRAV_STACK(stack);
     uint32_t cnt[2] = {0u, 0u};
+    ZR_PROF_KERNEL(F.sc, 3);
     rpt::StcLane a;
     float v1, v2, v3, v4;
-    rpt::StcPhase0(F, g, x, y, a, v1, v2);
-    if (a.valid && a.hasN) rpt::ReconnectCtSPixel(F, g, x, y, stack, cnt);       // K16 CtS of this pixel (see zr_rpt.h)
+    { ZR_PROF_SCOPE(ZRP_MISC0); rpt::StcPhase0(F, g, x, y, a, v1, v2); }
+    { ZR_PROF_SCOPE(ZRP_MISC1);
+    if (a.valid && a.hasN) rpt::ReconnectCtSPixel(F, g, x, y, stack, cnt); }      // K16 CtS of this pixel (see zr_rpt.h)
     const float sum1 = WaveSumButterfly(v1), sum2 = WaveSumButterfly(v2);
     rpt::StcPhase1(F, g, a, sum1, v3);
     const float sum3 = WaveSumButterfly(v3);
+    ZR_PROF_SCOPE(ZRP_MISC2);
     rpt::StcPhase2(F, g, a, sum1, stack, cnt, v4);
     const float sum4 = WaveSumButterfly(v4);
     rpt::StcPhase3(F, g, a, sum2 + sum3 + sum4);

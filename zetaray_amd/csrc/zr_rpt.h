@@ -717,7 +717,8 @@ ZR_HD void EstimateDirectAndUpdateRC(const Globals& g, int pathVertex, V3 pos, c
     }
     BsdfSample nbs;
     int nextBounce = pathVertex - 1;
-    Direct ls_b = NEE_Bsdf(g, pos, hit.normal, surface, nextBounce, nbs, nextHit, rngReplay);
+    Direct ls_b;
+    { ZR_PROF_SCOPE(ZRP_MISC4); ls_b = NEE_Bsdf(g, pos, hit.normal, surface, nextBounce, nbs, nextHit, rngReplay); }
     if (nextHit.emissiveTriIdx != 0xffffffffu)
     {
         const V3 fOverPdf = throughput * ls_b.ld;
@@ -729,7 +730,8 @@ ZR_HD void EstimateDirectAndUpdateRC(const Globals& g, int pathVertex, V3 pos, c
     if (!IsSpecular(surface))
     {
         const uint32_t seed_nee = rngNEE.s;
-        Direct ls = NEE_Emissive(g, pos, hit.normal, surface, rngNEE);
+        Direct ls;
+        { ZR_PROF_SCOPE(ZRP_MISC3); ls = NEE_Emissive(g, pos, hit.normal, surface, rngNEE); }
         const V3 fOverPdf = throughput * ls.ld;
         li = li + fOverPdf;
         if (rc.IsCase2() || rc.IsCase3()) rc.Clear();
@@ -923,6 +925,9 @@ ZR_HD void PtPhaseA(const SceneView& sc, const zr_frame_constants& g, const RptP
     Globals gl; gl.sc = &sc; gl.frame = &g; gl.emissive = prm.emissive != 0; gl.numEmissives = g.num_emissive_triangles; gl.maxNumBounces = P.maxNumBounces; gl.alpha_min = prm.alpha_min; gl.stack = stack; gl.cnt = cnt;
     gl.presampled = prm.numSampleSets != 0; gl.sampleSetIdx = P.sampleSetIdx;
     P.pathVertex = P.bounce + 2;
+    V3 newPos;
+    {
+    ZR_PROF_SCOPE(ZRP_MATERIAL);
     if (prm.emissive)
     {
         // the BSDF ray of the previous vertex's NEE (ReSTIR_PT_PathTrace.hlsl:235-239)
@@ -932,7 +937,7 @@ ZR_HD void PtPhaseA(const SceneView& sc, const zr_frame_constants& g, const RptP
         else FillHit<false>(sc, P.nextHit.mesh, P.nextHit.prim, P.nextHit.bu, P.nextHit.bv, true, P.hit, true);
     }
     else if (!FindClosestID(gl, true, P.pos, P.normal, P.bs.wi, P.surface.Transmissive(), P.hit, prm.textured)) { P.active = false; return; }   // Hit::FindClosest<true, true>
-    V3 newPos = mad(P.hit.t, P.bs.wi, P.pos);
+    newPos = mad(P.hit.t, P.bs.wi, P.pos);
     float eta_mat;
     V4 uvGrads = v4(0, 0, 0, 0);
     if (prm.textured)
@@ -943,6 +948,7 @@ ZR_HD void PtPhaseA(const SceneView& sc, const zr_frame_constants& g, const RptP
     }
     if (!GetMaterialData(sc, -P.bs.wi, P.eta_curr, P.hit, P.surface, eta_mat, uvGrads, prm.textured)) { P.active = false; return; }
     P.eta_next = eta_mat;
+    }
     P.pos = newPos;
     P.normal = P.hit.normal;
     P.prevPdf = P.bs.pdf; P.prevLobe = P.bs.lobe;
@@ -953,8 +959,11 @@ ZR_HD void PtPhaseA(const SceneView& sc, const zr_frame_constants& g, const RptP
         P.tr = vexp(-P.hit.t * ext);
         P.throughput = P.throughput * P.tr;
     }
+    {
+    ZR_PROF_SCOPE(ZRP_NEE);
     EstimateDirectAndUpdateRC(gl, P.pathVertex, P.pos, P.hit, P.surface, P.prevHit, P.throughput, P.throughput_k, P.li, P.bs, P.nextHit, P.rc, P.r,
         P.rngThread, P.rngReplay);
+    }
     if (P.bounce >= (P.maxNumBounces - 1)) { P.active = false; return; }
     if (P.rc.IsCase2() || P.rc.IsCase3()) P.rc.Clear();
     P.bounce++;
