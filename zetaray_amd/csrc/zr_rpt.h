@@ -1798,7 +1798,9 @@ ZR_HD void ReconnectCtSPixel(const RptFrame& F, const zr_frame_constants& g, uin
 // K16 Reconnect_StC (ReSTIR_PT_Reconnect_StC.hlsl:112-352), cut at its four WaveActiveSum points.
 struct StcLane
 {
-    bool valid, hasN, spatialEmpty, resample, changed; size_t px, sp; Reservoir r_curr, r_spatial; PixelSurface ps; uint32_t M_max, M_new; GFlags flags;
+    // (kept small across the heavy calls: the pixel's surface is rebuilt inside phase 2 and r_curr is loaded after the CtS shift, so
+    // neither is live -- i.e. spilled -- across ReconnectCtSPixel; CtS writes only the *other* reservoir set's w_sum)
+    bool valid, hasN, spatialEmpty, resample, changed; size_t px, sp; Reservoir r_curr, r_spatial; uint32_t M_max, M_new; GFlags flags;
     uint32_t x, y; float w_sum_loaded;
 };
 ZR_HD void StcCopyToNextFrame(const RptFrame& F, size_t px, Reservoir& r, uint32_t M_max)
@@ -1818,22 +1820,20 @@ ZR_HD void StcPhase0(const RptFrame& F, const zr_frame_constants& g, uint32_t x,
     a.flags = DecodeFlags(F.gb.mr[a.px]);
     if (a.flags.invalid || a.flags.emissive) return;
     a.valid = true;
-    const Camera cam = CurrCamera(g);
-    a.ps = LoadPixelSurface(F.gb, cam, x, y, g.frame_num, a.px);
-    a.r_curr = Load_NonReconnection(F.cur, a.px);
-    a.w_sum_loaded = a.r_curr.w_sum;
-    a.r_curr.target = xyz(F.tex.target[a.px]);
+    a.w_sum_loaded = F.cur.B[2 * a.px];
     int sx, sy;
     a.hasN = NeighborOf(F, x, y, sx, sy);
     if (a.hasN) a.sp = Pix(F.gb, (uint32_t)sx, (uint32_t)sy);
-    s1 = a.r_curr.w_sum;
-    s2 = a.r_curr.w_sum * (a.hasN ? 0.0f : 1.0f);
+    s1 = a.w_sum_loaded;
+    s2 = a.w_sum_loaded * (a.hasN ? 0.0f : 1.0f);
 }
 // phase 1: lanes without a neighbour finish; the others load the spatial reservoir; contributes sum3
 ZR_HD void StcPhase1(const RptFrame& F, const zr_frame_constants& g, StcLane& a, float sum1, float& s3)
 {
     s3 = 0;
     if (!a.valid) return;
+    a.r_curr = Load_NonReconnection(F.cur, a.px);
+    a.r_curr.target = xyz(F.tex.target[a.px]);
     const float waveAvgExclusive = (sum1 - a.w_sum_loaded) / 64.0f;
     a.M_max = F.prm.M_max_spatial;
     a.M_max = !a.r_curr.rc.Empty() && a.r_curr.rc.lobe_k_min_1 == LOBE_GLOSSY_T ? umin(a.M_max, kMmaxXkTransmissive) : a.M_max;
@@ -1871,8 +1871,10 @@ ZR_HD void StcPhase2(const RptFrame& F, const zr_frame_constants& g, StcLane& a,
     a.r_spatial.rc.x_k_in_motion = false;
     a.r_spatial.Load_Reconnection(F.cur, a.sp, F.prm.emissive != 0);
     Globals gl = MakeGlobals(F, g, a.flags.transmissive, stack, cnt);
-    OffsetPath shift = Shift2(gl, true, a.px, a.ps.pos, a.ps.normal, a.ps.eta_next, a.ps.surface, a.r_spatial.rc, F.rbNtC,
-        MakePrimaryDiffs(CurrCamera(g), (int)a.x, (int)a.y, a.ps, F.gb, a.px));
+    const Camera cam = CurrCamera(g);
+    const PixelSurface ps = LoadPixelSurface(F.gb, cam, a.x, a.y, g.frame_num, a.px);
+    OffsetPath shift = Shift2(gl, true, a.px, ps.pos, ps.normal, ps.eta_next, ps.surface, a.r_spatial.rc, F.rbNtC,
+        MakePrimaryDiffs(cam, (int)a.x, (int)a.y, ps, F.gb, a.px));
     float targetLum_curr = Luminance(shift.target);
     float targetLum_spatial = a.r_spatial.W > 0 ? a.r_spatial.w_sum / a.r_spatial.W : 0;
     float jacobian = a.r_spatial.rc.partialJacobian > 0 ? shift.partialJacobian / a.r_spatial.rc.partialJacobian : 0;
