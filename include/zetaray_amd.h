@@ -69,7 +69,18 @@ typedef enum zr_pass_kind {
        motion-vector planes of the gbuffer passed to zr_pass_render.  Output: ZR_OUT_TAA, R16G16B16A16_FLOAT like the reference's
        two ping-pong targets (TAA.cpp:120-146); zr_params.taa_blend_weight = cbTAA.BlendWeight (default 0.1, TAA.h:72);
        zr_pass_reset_temporal = TemporalIsValid 0 for the next frame. */
-    ZR_PASS_TAA         = 7
+    ZR_PASS_TAA         = 7,
+    /* AutoExposure (RP/AutoExposure/AutoExposure.cpp:100-143): 256-bin log-luminance histogram of the image bound with
+       zr_pass_set_input(ZR_IN_POST_SIGNAL_F16 / _F32), then the bin-weighted mean, exponential adaptation over cbFrameConstants::dt and
+       the ISO-100 exposure.  zr_params.ae_*.  Outputs ZR_OUT_EXPOSURE (persistent across frames), ZR_OUT_AE_HISTOGRAM.
+       The pass size is the render size; zr_pass_render needs no gbuffer (pass NULL). */
+    ZR_PASS_AUTO_EXPOSURE = 8,
+    /* DisplayPass (RP/Display/Display.hlsl:41-77, DisplayOption::DEFAULT; Tonemap.hlsli): exposure x tone mapper over the image bound
+       with ZR_IN_POST_SIGNAL_*, point-sampled from render to display resolution.  The pass size is the DISPLAY size; the input has
+       cb.render_width x render_height texels.  zr_params.display_*; ZR_IN_DISPLAY_EXPOSURE = ZR_OUT_EXPOSURE of the auto-exposure pass;
+       the NEUTRAL tone mapper needs zr_pass_set_tonemap_lut.  Outputs ZR_OUT_DISPLAY (the pixel shader's float4) and
+       ZR_OUT_DISPLAY_SRGB8 (what the reference's R8G8B8A8_UNORM_SRGB back buffer stores). */
+    ZR_PASS_DISPLAY     = 9
 } zr_pass_kind;
 
 /* IndirectLighting::INTEGRATOR, reference IndirectLighting.h:40-46 */
@@ -114,7 +125,23 @@ typedef struct zr_params {
     float    lvg_extents[3];        /* voxel half extents; reference default (0.6, 0.45, 0.6) */
     float    lvg_offset_y;          /* 0.1 */
     float    taa_blend_weight;      /* ZR_PASS_TAA: cbTAA.BlendWeight, 0.1 */
+    /* ZR_PASS_AUTO_EXPOSURE: cbAutoExposureHist (AutoExposure_Common.h:11-21), defaults AutoExposure.h:73-81 */
+    float    ae_min_lum;            /* 5e-3 */
+    float    ae_max_lum;            /* 4.0 (LumRange = max - min) */
+    float    ae_lum_map_exp;        /* 0.5 */
+    float    ae_adaptation_rate;    /* 1.0 */
+    /* ZR_PASS_DISPLAY: cbDisplayPass (Display_Common.h:32-46), defaults Display.cpp:69-74 */
+    uint32_t display_tonemapper;    /* zr_tonemapper, NEUTRAL */
+    uint32_t display_auto_exposure; /* 1 */
+    float    display_saturation;    /* 1.0 (NEUTRAL, AgX_CUSTOM) */
+    float    display_agx_exp;       /* 1.0 (AgX_CUSTOM) */
 } zr_params;
+
+/* enum class Tonemapper, Display_Common.h:21-30 */
+typedef enum zr_tonemapper {
+    ZR_TONEMAP_NONE = 0, ZR_TONEMAP_NEUTRAL = 1, ZR_TONEMAP_AGX_DEFAULT = 2, ZR_TONEMAP_AGX_GOLDEN = 3, ZR_TONEMAP_AGX_PUNCHY = 4,
+    ZR_TONEMAP_AGX_CUSTOM = 5
+} zr_tonemapper;
 
 /* outputs, GetOutput(SHADER_OUT_RES) */
 typedef enum zr_output {
@@ -151,7 +178,13 @@ typedef enum zr_output {
     /* Sky (ZR_PASS_SKY) */
     ZR_OUT_SKY_LUT         = 40,   /* R11G11B10_FLOAT 4 B, LutWidth x LutHeight (Sky::SHADER_OUT_RES::SKY_VIEW_LUT) */
     /* TAA (ZR_PASS_TAA) */
-    ZR_OUT_TAA             = 41    /* RGBA16F 8 B: the anti-aliased image written by the last render (TAA::SHADER_OUT_RES::OUTPUT_A / _B) */
+    ZR_OUT_TAA             = 41,   /* RGBA16F 8 B: the anti-aliased image written by the last render (TAA::SHADER_OUT_RES::OUTPUT_A / _B) */
+    /* AutoExposure (ZR_PASS_AUTO_EXPOSURE) */
+    ZR_OUT_EXPOSURE        = 42,   /* RG32F 8 B, 1 x 1: exposure, adapted average luminance (AutoExposure::SHADER_OUT_RES::EXPOSURE) */
+    ZR_OUT_AE_HISTOGRAM    = 43,   /* R32_UINT, 256 x 1: the last frame's histogram (bin 0 = luminance <= 1e-4) */
+    /* Display (ZR_PASS_DISPLAY) */
+    ZR_OUT_DISPLAY         = 44,   /* RGBA32F 16 B: mainPS's return value (linear, before the back buffer's sRGB encode) */
+    ZR_OUT_DISPLAY_SRGB8   = 45    /* RGBA8 4 B: sRGB-encoded, as the reference's R8G8B8A8_UNORM_SRGB back buffer stores it */
 } zr_output;
 
 /* G-buffer planes (reference GBufferData::GBUFFER order and DXGI formats, DefaultRendererImpl.h:82-109) */
@@ -269,7 +302,16 @@ int zr_pass_download_output(const zr_pass* pass, int which, void* hip_stream, vo
 #define ZR_IN_INDIRECT    1
 #define ZR_IN_SKY_DI      2
 #define ZR_IN_TAA_SIGNAL  3   /* ZR_PASS_TAA: the RGBA32F image to anti-alias (TAA::SHADER_IN_RES::SIGNAL) */
-int zr_pass_set_input(zr_pass* pass, int which, const void* dev_rgba32f);
+/* ZR_PASS_AUTO_EXPOSURE / ZR_PASS_DISPLAY: the image to meter / display (AutoExposure::SHADER_IN_DESC::COMPOSITED,
+   DisplayPass::SetInput): either an RGBA16F plane (ZR_OUT_TAA) or an RGBA32F plane (ZR_OUT_FINAL of COMPOSITING; read rounded to half,
+   which is what the reference's R16G16B16A16_FLOAT composited texture holds).  Binding one clears the other. */
+#define ZR_IN_POST_SIGNAL_F16  4
+#define ZR_IN_POST_SIGNAL_F32  5
+#define ZR_IN_DISPLAY_EXPOSURE 6   /* ZR_PASS_DISPLAY: RG32F 1 x 1 (ZR_OUT_EXPOSURE) */
+int zr_pass_set_input(zr_pass* pass, int which, const void* dev_plane);
+/* ZR_PASS_DISPLAY: the Tony McMapface LUT of the NEUTRAL tone mapper, dim^3 R9G9B9E5_SHAREDEXP texels on the host (the payload of
+   Assets/LUT/tony_mc_mapface.dds, 48^3; shipped as zetaray_amd/assets/tony_mc_mapface_rgb9e5.bin).  Display.cpp:196-205. */
+int zr_pass_set_tonemap_lut(zr_pass* pass, const uint32_t* rgb9e5, uint32_t dim);
 /* ray counters accumulated since the last call (device -> host copy; synchronises the stream) */
 int zr_pass_read_counters(zr_pass* pass, void* hip_stream, zr_counters* out, int reset);
 /* the same counters split by the kernel that issued the queries (not reset; roofline bookkeeping of bench.py) */

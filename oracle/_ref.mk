@@ -21,14 +21,16 @@ HLSL_ROOTS := ZetaRenderPass/Common/BSDFSampling.hlsli ZetaRenderPass/Common/RT.
         ReSTIR_PT_Reconnect_TtC.hlsl ReSTIR_PT_Reconnect_CtS.hlsl ReSTIR_PT_Reconnect_StC.hlsl ReSTIR_PT_SpatialSearch.hlsl) \
     ZetaRenderPass/IndirectLighting/ReSTIR_GI/ReSTIR_GI.hlsl \
     $(addprefix ZetaRenderPass/DirectLighting/,Emissive/ReSTIR_DI_Temporal.hlsl Emissive/ReSTIR_DI_Spatial.hlsl Emissive/DirectLighting_Common.h \
-        Sky/SkyDI_Temporal.hlsl Sky/SkyDI_Spatial.hlsl Sky/SkyDI_Common.h)
+        Sky/SkyDI_Temporal.hlsl Sky/SkyDI_Spatial.hlsl Sky/SkyDI_Common.h) \
+    $(addprefix ZetaRenderPass/AutoExposure/,AutoExposure_Histogram.hlsl AutoExposure_WeightedAvg.hlsl AutoExposure_Common.h) \
+    ZetaRenderPass/Display/Display.hlsl ZetaRenderPass/Display/Display_Common.h
 
 # the reference's shader PASSES compiled as C++ (one shared object per shader permutation, like the reference's .cso files):
 #   _ref/libzref_k1.so                      GBufferRT_Inline.hlsl
 #   _ref/libzref_k9_{e0,e1,e1p}.so          PathTracer.hlsl with NEE_EMISSIVE = 0 / 1 / 1 + USE_PRESAMPLED_SETS (PathTracer, _WoPS, _WPS)
 #   _ref/libzref_rpt_{e0,e1,e1p}.so         ReSTIR PT: the 10 shaders of Variants/*.hlsl per NEE permutation + the restated host sequence (ref_rpt_host.cpp)
 PASS_LIBS := _ref/libzref_k1.so _ref/libzref_k9_e0.so _ref/libzref_k9_e1.so _ref/libzref_k9_e1p.so _ref/libzref_rpt_e0.so _ref/libzref_rpt_e1.so _ref/libzref_rpt_e1p.so \
-    _ref/libzref_gi_e0.so _ref/libzref_gi_e1.so _ref/libzref_gi_e1p.so _ref/libzref_di_e1.so _ref/libzref_di_e1p.so _ref/libzref_di_sky.so
+    _ref/libzref_gi_e0.so _ref/libzref_gi_e1.so _ref/libzref_gi_e1p.so _ref/libzref_di_e1.so _ref/libzref_di_e1p.so _ref/libzref_di_sky.so _ref/libzref_post.so
 PASS_HDRS := ref_hlsl/ref_pass_common.h ref_hlsl/hlsl_shim.h ref_hlsl/hlsl_resources.h ref_hlsl/hlsl_rt.h ref_hlsl/hlsl_group.h zro_scene.h
 
 all: _ref/libzref.so _ref/libzref_hlsl.so $(PASS_LIBS)
@@ -46,7 +48,7 @@ _ref/libzref.so: ref_driver.cpp ref_shim.h
 	mkdir -p _ref
 	$(CXX) $(FLAGS) -shared -o $@ $(REF)/Source/ZetaCore/Math/Common.cpp $(REF)/Source/ZetaCore/Math/Sampling.cpp ref_driver.cpp
 
-_ref/gen/.stamp: ref_hlsl/hlsl2cpp.py
+_ref/gen/.stamp: ref_hlsl/hlsl2cpp.py _ref.mk
 	mkdir -p _ref/gen
 	python3 ref_hlsl/hlsl2cpp.py $(REF)/Source _ref/gen $(HLSL_ROOTS)
 	touch $@
@@ -125,3 +127,22 @@ endef
 $(eval $(call di_lib,e1,0,Emissive/ReSTIR_DI_Temporal.hlsl,Emissive/ReSTIR_DI_Spatial.hlsl,cb_ReSTIR_DI,1,2,))
 $(eval $(call di_lib,e1p,0,Emissive/ReSTIR_DI_Temporal.hlsl,Emissive/ReSTIR_DI_Spatial.hlsl,cb_ReSTIR_DI,1,2,-DUSE_PRESAMPLED_SETS))
 $(eval $(call di_lib,sky,1,Sky/SkyDI_Temporal.hlsl,Sky/SkyDI_Spatial.hlsl,cb_SkyDI,3,4,))
+
+# ---- post stack: AutoExposure_Histogram.hlsl + AutoExposure_WeightedAvg.hlsl (compute; g_hist is a root UAV) and Display.hlsl (pixel shader)
+AE := ZetaRenderPass/AutoExposure
+_ref/obj/post_ae_hist.o: _ref/gen/.stamp ref_hlsl/ref_pass_shader.cpp ref_hlsl/ref_dispatch.h $(PASS_HDRS)
+	mkdir -p _ref/obj
+	$(HLSL_CXX) $(HLSL_FLAGS) -fvisibility=hidden -c -o $@ ref_hlsl/ref_pass_shader.cpp -Dhlsl=hlsl_ae_hist '-DZR_SHADER="$(AE)/AutoExposure_Histogram.hlsl"' \
+	    -DZR_ENTRY=zrefp_shader_ae_hist -DZR_LOCAL_CB=cbAutoExposureHist -DZR_HAS_SCENE=0 -DZR_HAS_LIGHTS=0 -DZR_ROOT_UAV=g_hist
+_ref/obj/post_ae_avg.o: _ref/gen/.stamp ref_hlsl/ref_pass_shader.cpp ref_hlsl/ref_dispatch.h $(PASS_HDRS)
+	mkdir -p _ref/obj
+	$(HLSL_CXX) $(HLSL_FLAGS) -fvisibility=hidden -c -o $@ ref_hlsl/ref_pass_shader.cpp -Dhlsl=hlsl_ae_avg '-DZR_SHADER="$(AE)/AutoExposure_WeightedAvg.hlsl"' \
+	    -DZR_ENTRY=zrefp_shader_ae_avg -DZR_LOCAL_CB=cbAutoExposureHist -DZR_HAS_SCENE=0 -DZR_HAS_LIGHTS=0 -DZR_ROOT_UAV=g_hist
+_ref/obj/post_display.o: _ref/gen/.stamp ref_hlsl/ref_pass_display.cpp ref_hlsl/ref_dispatch.h $(PASS_HDRS)
+	mkdir -p _ref/obj
+	$(HLSL_CXX) $(HLSL_FLAGS) -fvisibility=hidden -c -o $@ ref_hlsl/ref_pass_display.cpp -Dhlsl=hlsl_display
+_ref/obj/post_host.o: _ref/gen/.stamp ref_hlsl/ref_post_host.cpp ref_hlsl/ref_dispatch.h $(PASS_HDRS)
+	mkdir -p _ref/obj
+	$(HLSL_CXX) $(HLSL_FLAGS) -c -o $@ ref_hlsl/ref_post_host.cpp
+_ref/libzref_post.so: _ref/obj/post_ae_hist.o _ref/obj/post_ae_avg.o _ref/obj/post_display.o _ref/obj/post_host.o
+	$(HLSL_CXX) -shared -o $@ $^

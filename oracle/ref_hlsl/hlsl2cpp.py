@@ -186,6 +186,12 @@ def translate(src, relpath, special):
 # File-specific lexical fixes (pattern, replacement): places where HLSL and C++ disagree on something the generic rules cannot see.
 # Every entry keeps the arithmetic as written; it only resolves overloads / declarations the way DXC does.
 SPECIAL = {
+    "Display.hlsl": [
+        # vertex-to-pixel interpolant semantics of the VSOut struct members
+        (r"float4 PosSS : SV_Position;", "float4 PosSS;"), (r"float2 TexCoord : TEXCOORD;", "float2 TexCoord;"),
+        # Texture2D::operator[] with the float2 SV_Position (HLSL converts float2 -> uint2 implicitly; only the debug views read it)
+        (r"g_coat\[psin\.PosSS\.xy\]", "g_coat[uint2(psin.PosSS.xy)]"),
+    ],
     "StaticTextureSamplers.hlsli": [
         # static samplers are identified by name (RendererCore.cpp:450-545 defines filter / address mode per name)
         (r"SamplerState\s+(g_sam\w+)\s*;", r'static const SamplerState \1 = SamplerState::Named("\1");'),

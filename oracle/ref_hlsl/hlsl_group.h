@@ -128,6 +128,15 @@ static inline uint32_t WaveActiveSum(uint32_t x)
     return s;
 }
 static inline int WaveActiveSum(int x) { return (int)WaveActiveSum((uint32_t)x); }
+// WaveMatch: per lane, the mask of the wave's active lanes holding the same value (64 lanes: .x = lanes 0-31, .y = 32-63)
+static inline uint4 WaveMatch(uint32_t x)
+{
+    GroupRunner* g = GR(); if (!g) return uint4(1u, 0u, 0u, 0u);
+    WaveRendezvous(&x, 1);
+    uint32_t m[4] = {0, 0, 0, 0}; const int b = g->WaveBase();
+    for (int i = 0; i < 64 && b + i < g->n; i++) if (g->snapActive[b + i] && g->snapU[4 * (b + i)] == x) m[i >> 5] |= 1u << (i & 31);
+    return uint4(m[0], m[1], m[2], m[3]);
+}
 static inline uint32_t WaveActiveSum(bool x) { return WaveActiveSum((uint32_t)(x ? 1u : 0u)); }
 static inline uint16_t WaveActiveSum(uint16_t x) { return (uint16_t)WaveActiveSum((uint32_t)x); }
 static inline float3 WaveActiveSum(const float3& x) { return float3(WaveActiveSum(x.x), WaveActiveSum(x.y), WaveActiveSum(x.z)); }

@@ -19,7 +19,7 @@ enum TexFormat
     FMT_R16_UINT, FMT_RG16_UINT, FMT_RGBA16_UINT, FMT_R16_UNORM, FMT_RG16_UNORM, FMT_RG16_SNORM,
     FMT_R16_FLOAT, FMT_RG16_FLOAT, FMT_RGBA16_FLOAT,
     FMT_R32_UINT, FMT_RG32_UINT, FMT_RGBA32_UINT, FMT_R32_FLOAT, FMT_RG32_FLOAT, FMT_RGBA32_FLOAT,
-    FMT_R11G11B10_FLOAT,
+    FMT_R11G11B10_FLOAT, FMT_R9G9B9E5,
     FMT_MATERIAL_TEXTURE          // an entry of the scene's zr_tex_heap (decoded RGBA8 / RG8 texels with mips; sampled through zr_texture.h)
 };
 
@@ -38,7 +38,7 @@ static inline uint32_t FormatBytes(int f)
     case FMT_R8_UINT: case FMT_R8_UNORM: return 1;
     case FMT_RG8_UINT: case FMT_RG8_UNORM: case FMT_R16_UINT: case FMT_R16_UNORM: case FMT_R16_FLOAT: return 2;
     case FMT_RGBA8_UINT: case FMT_RGBA8_UNORM: case FMT_RG16_UINT: case FMT_RG16_UNORM: case FMT_RG16_SNORM: case FMT_RG16_FLOAT:
-    case FMT_R32_UINT: case FMT_R32_FLOAT: case FMT_R11G11B10_FLOAT: return 4;
+    case FMT_R32_UINT: case FMT_R32_FLOAT: case FMT_R11G11B10_FLOAT: case FMT_R9G9B9E5: return 4;
     case FMT_RGBA16_UINT: case FMT_RGBA16_FLOAT: case FMT_RG32_UINT: case FMT_RG32_FLOAT: return 8;
     case FMT_RGBA32_UINT: case FMT_RGBA32_FLOAT: return 16;
     default: return 0;
@@ -77,6 +77,13 @@ static inline void LoadRaw(const TexStorage& s, size_t idx, float f[4], uint32_t
     case FMT_RG32_FLOAT: memcpy(f, p, 8); break;
     case FMT_RGBA32_FLOAT: memcpy(f, p, 16); break;
     case FMT_R11G11B10_FLOAT: memcpy(w, p, 4); f[0] = zr_unpack_ufloat(w[0] & 0x7ffu, 6); f[1] = zr_unpack_ufloat((w[0] >> 11) & 0x7ffu, 6); f[2] = zr_unpack_ufloat(w[0] >> 22, 5); break;
+    case FMT_R9G9B9E5:       // shared exponent: mantissa * 2^(e - 15 - 9), exact in fp32
+    {
+        memcpy(w, p, 4);
+        const float sc = zr_asfloat((uint32_t)((int)(w[0] >> 27) - 15 - 9 + 127) << 23);
+        f[0] = (float)(w[0] & 0x1ffu) * sc; f[1] = (float)((w[0] >> 9) & 0x1ffu) * sc; f[2] = (float)((w[0] >> 18) & 0x1ffu) * sc;
+        break;
+    }
     default: break;
     }
 }
@@ -357,16 +364,32 @@ template<class T> struct Texture3D
             i0[a] = i < 0 ? 0 : (i > hi ? hi : i);
             i1[a] = (i + 1) < 0 ? 0 : ((i + 1) > hi ? hi : (i + 1));
         }
-        auto TX = [&](int x, int y, int z) { float f[4]; uint32_t u[4]; LoadRaw(*s, ((size_t)z * dim[1] + y) * dim[0] + x, f, u); return f[0]; };
-        float c00 = zr_lerp(TX(i0[0], i0[1], i0[2]), TX(i1[0], i0[1], i0[2]), fr[0]);
-        float c10 = zr_lerp(TX(i0[0], i1[1], i0[2]), TX(i1[0], i1[1], i0[2]), fr[0]);
-        float c01 = zr_lerp(TX(i0[0], i0[1], i1[2]), TX(i1[0], i0[1], i1[2]), fr[0]);
-        float c11 = zr_lerp(TX(i0[0], i1[1], i1[2]), TX(i1[0], i1[1], i1[2]), fr[0]);
-        float c0 = zr_lerp(c00, c10, fr[1]);
-        float c1 = zr_lerp(c01, c11, fr[1]);
-        float o[4] = {zr_lerp(c0, c1, fr[2]), 0, 0, 1}; uint32_t uu[4] = {0, 0, 0, 0};
+        float t[8][4]; uint32_t u[4];
+        for (int k = 0; k < 8; k++)
+        {
+            t[k][0] = t[k][1] = t[k][2] = 0.0f; t[k][3] = 1.0f;
+            LoadRaw(*s, ((size_t)((k & 4) ? i1[2] : i0[2]) * dim[1] + ((k & 2) ? i1[1] : i0[1])) * dim[0] + ((k & 1) ? i1[0] : i0[0]), t[k], u);
+        }
+        float o[4] = {0, 0, 0, 1}; uint32_t uu[4] = {0, 0, 0, 0};
+        for (int ch = 0; ch < 3; ch++)
+        {
+            const float c00 = zr_lerp(t[0][ch], t[1][ch], fr[0]), c10 = zr_lerp(t[2][ch], t[3][ch], fr[0]);
+            const float c01 = zr_lerp(t[4][ch], t[5][ch], fr[0]), c11 = zr_lerp(t[6][ch], t[7][ch], fr[0]);
+            o[ch] = zr_lerp(zr_lerp(c00, c10, fr[1]), zr_lerp(c01, c11, fr[1]), fr[2]);
+        }
         return Lanes<T>::get(o, uu);
     }
+};
+
+// RWByteAddressBuffer over host memory (atomics are plain read-modify-writes: the emulated group runs one lane at a time)
+struct RWByteAddressBuffer
+{
+    uint8_t* p = nullptr;
+    RWByteAddressBuffer() {}
+    explicit RWByteAddressBuffer(void* ptr) : p((uint8_t*)ptr) {}
+    uint Load(uint off) const { uint v; memcpy(&v, p + off, 4); return v; }
+    void Store(uint off, uint v) const { memcpy(p + off, &v, 4); }
+    void InterlockedAdd(uint off, uint v) const { Store(off, Load(off) + v); }
 };
 
 template<class T> struct StructuredBuffer

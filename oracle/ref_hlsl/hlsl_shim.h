@@ -359,6 +359,7 @@ HLSL_INTV(uint2, bool2) HLSL_INTV(uint3, bool3) HLSL_INTV(uint4, bool4) HLSL_INT
 HLSL_INTV(uint16_t2, bool2) HLSL_INTV(uint16_t3, bool3) HLSL_INTV(uint16_t4, bool4)
 HLSL_MAP1(int2, abs) HLSL_MAP1(int3, abs) HLSL_MAP1(int4, abs)
 HLSL_MAP1(uint2, countbits) HLSL_MAP1(uint3, countbits) HLSL_MAP1(uint4, countbits)
+HLSL_MAP1(uint2, firstbitlow) HLSL_MAP1(uint3, firstbitlow) HLSL_MAP1(uint4, firstbitlow)
 inline uint2 asuint(const uint2& a) { return a; }
 inline uint3 asuint(const uint3& a) { return a; }
 inline uint4 asuint(const uint4& a) { return a; }

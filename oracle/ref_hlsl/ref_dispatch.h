@@ -10,4 +10,5 @@ typedef struct ZrDispatch
     const void* frame_cb;     /* cbFrameConstants, 544 B */
     const void* local_cb; uint32_t local_cb_bytes;
     uint32_t groups_x, groups_y;
+    void* root_uav;           /* a root-descriptor UAV bound as a global (AutoExposure's g_hist : register(u0)), or null */
 } ZrDispatch;

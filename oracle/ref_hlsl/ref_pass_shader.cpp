@@ -22,6 +22,9 @@ extern "C" void ZR_ENTRY(const ZrDispatch* d)
     memcpy(&hlsl::g_frame, d->frame_cb, sizeof(zr_frame_constants));
     if (d->local_cb_bytes != sizeof(hlsl::ZR_LOCAL_CB)) { std::fprintf(stderr, "%s: local constant buffer is %u B, shader expects %zu B\n", ZR_SHADER, d->local_cb_bytes, sizeof(hlsl::ZR_LOCAL_CB)); std::abort(); }
     memcpy(&hlsl::g_local, d->local_cb, sizeof(hlsl::ZR_LOCAL_CB));
+#ifdef ZR_ROOT_UAV
+    hlsl::ZR_ROOT_UAV = RWByteAddressBuffer(d->root_uav);      // e.g. -DZR_ROOT_UAV=g_hist
+#endif
 #ifdef ZR_DI_GLOBALS
     // DirectLighting / SkyDI root signatures (DirectLighting.cpp:60-98, SkyDI.cpp:48-70): 1 = emissive temporal, 2 = emissive spatial,
     // 3 = sky temporal, 4 = sky spatial

@@ -193,3 +193,43 @@ class RefDirect(RefPass):
         buf = np.zeros((self.h_, self.w, ch), dt)
         self.L.zrefp_di_read_plane(self.st, idx, buf.ctypes.data)
         return buf
+
+
+class RefPost:
+    """AutoExposure_Histogram / AutoExposure_WeightedAvg / Display.hlsl (libzref_post.so: no scene)"""
+
+    def __init__(self):
+        self.L = C.CDLL(os.path.join(HERE, "_ref", "libzref_post.so"))
+        self.L.zrefp_auto_exposure.argtypes = [C.c_void_p, C.c_int, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        self.L.zrefp_display.argtypes = [C.c_void_p, C.c_int, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_float, C.c_float,
+                                         C.c_void_p, C.c_uint32, C.c_void_p]
+
+    @staticmethod
+    def _image(image):
+        a = np.ascontiguousarray(image)
+        assert a.ndim == 3 and a.shape[2] == 4 and a.dtype in (np.uint16, np.float32)
+        return a, int(a.dtype == np.uint16)
+
+    def auto_exposure(self, image, params, cb, exposure2=None):
+        a, is16 = self._image(image)
+        h, w = a.shape[:2]
+        prm4 = np.array([params.ae_min_lum, np.float32(params.ae_max_lum) - np.float32(params.ae_min_lum), params.ae_lum_map_exp, params.ae_adaptation_rate], np.float32)
+        hist = np.zeros(256, np.uint32)
+        e = np.zeros(2, np.float32) if exposure2 is None else np.array(exposure2, np.float32).copy()
+        cbb = np.ascontiguousarray(cb)
+        assert self.L.zrefp_auto_exposure(a.ctypes.data, is16, w, h, cbb.ctypes.data, prm4.ctypes.data, hist.ctypes.data, e.ctypes.data) == 0
+        return hist, e
+
+    def display(self, image, params, cb, exposure2=None, lut=None):
+        a, is16 = self._image(image)
+        rh, rw = a.shape[:2]
+        cbb = np.ascontiguousarray(cb)
+        dw, dh = int(cbb["display_width"]), int(cbb["display_height"])
+        out = np.zeros((dh, dw, 4), np.float32)
+        e = None if exposure2 is None else np.array(exposure2, np.float32).copy()
+        l = None if lut is None else np.ascontiguousarray(lut, np.uint32)
+        dim = 0 if l is None else int(round(l.size ** (1.0 / 3.0)))
+        assert self.L.zrefp_display(a.ctypes.data, is16, rw, rh, cbb.ctypes.data, None if e is None else e.ctypes.data, params.display_tonemapper,
+                                    params.display_auto_exposure, params.display_saturation, params.display_agx_exp,
+                                    None if l is None else l.ctypes.data, dim, out.ctypes.data) == 0
+        return out

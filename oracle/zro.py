@@ -398,6 +398,43 @@ def kat_unary(fn, x):
     return y
 
 
+def _post_image(image):
+    a = np.ascontiguousarray(image)
+    assert a.ndim == 3 and a.shape[2] == 4 and a.dtype in (np.uint16, np.float32), "image: (h, w, 4) u16 (RGBA16F bits) or f32"
+    return a, int(a.dtype == np.uint16)
+
+
+def auto_exposure(image, params, dt, exposure2=None):
+    """AutoExposure_Histogram.hlsl + AutoExposure_WeightedAvg.hlsl on an RGBA16F (u16 bits) or RGBA32F image.  `exposure2` = the
+    persistent (exposure, adapted luminance) texel from the previous frame (zeros on the first).  Returns (hist[256] u32, exposure2 f32[2])."""
+    a, is16 = _post_image(image)
+    h, w = a.shape[:2]
+    hist = np.zeros(256, np.uint32)
+    e = np.zeros(2, np.float32) if exposure2 is None else np.array(exposure2, np.float32).copy()
+    f = lib().zro_auto_exposure
+    f.argtypes = [C.c_void_p, C.c_int, C.c_uint32, C.c_uint32, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]
+    f(a.ctypes.data, is16, w, h, float(dt), C.addressof(params), hist.ctypes.data, e.ctypes.data)
+    return hist, e
+
+
+def display(image, params, display_size, exposure2=None, lut=None):
+    """Display.hlsl mainPS (DisplayOption::DEFAULT) over display_size = (dw, dh) pixels.  Returns (rgba f32 (dh, dw, 4), srgb8 u8 (dh, dw, 4))."""
+    a, is16 = _post_image(image)
+    rh, rw = a.shape[:2]
+    dw, dh = display_size
+    out = np.zeros((dh, dw, 4), np.float32)
+    srgb = np.zeros((dh, dw, 4), np.uint8)
+    e = None if exposure2 is None else np.ascontiguousarray(exposure2, np.float32)
+    l = None if lut is None else np.ascontiguousarray(lut, np.uint32)
+    dim = 0 if l is None else int(round(l.size ** (1.0 / 3.0)))
+    assert l is None or dim ** 3 == l.size
+    f = lib().zro_display
+    f.argtypes = [C.c_void_p, C.c_int, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
+    f(a.ctypes.data, is16, rw, rh, dw, dh, None if e is None else e.ctypes.data, C.addressof(params), None if l is None else l.ctypes.data, dim,
+      out.ctypes.data, srgb.ctypes.data)
+    return out, srgb
+
+
 def taa(signal_rgba, depth, motion, prev_out, blend_weight=0.1, temporal_valid=True):
     """TAA.hlsl on an RGBA32F signal (h, w, 4), depth (h, w) f32, motion (h, w) u32 (R16G16_SNORM), history (h, w, 4) f16 bits (u16);
     returns the new RGBA16F output as u16 (alpha = the history buffer's, untouched)."""

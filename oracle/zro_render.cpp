@@ -769,6 +769,7 @@ static void RenderPathTracer(const Scene& sc, const zr_frame_constants& g, GBVie
 #include "zro_rgi.h"
 #include "zro_sdi.h"
 #include "zro_kat.h"
+#include "zro_post.h"
 
 //--------------------------------------------------------------------------------------
 // C entry points (ctypes)
@@ -963,6 +964,35 @@ int zro_pathtrace_render(const zro_scene* h, const zr_frame_constants* cb, const
 int zro_taa(const float* signal_rgba, const float* depth, const uint32_t* motion, const uint16_t* prev_out, uint16_t* curr_out,
     uint32_t w, uint32_t h, float blend_weight, int temporal_valid)
 { TAA::Render(signal_rgba, depth, motion, prev_out, curr_out, (int)w, (int)h, blend_weight, temporal_valid != 0); return 0; }
+
+// AutoExposure (zro_post.h): histogram of an RGBA16F (is_f16) or RGBA32F image, then the 256-thread weighted average; exposure2 = the
+// persistent (exposure, adapted luminance) texel, read and written
+static Post::cbAutoExposureHist AeCb(const zr_params* prm)
+{ Post::cbAutoExposureHist cb; cb.MinLum = prm->ae_min_lum; cb.LumRange = prm->ae_max_lum - prm->ae_min_lum; cb.LumMapExp = prm->ae_lum_map_exp; cb.AdaptationRate = prm->ae_adaptation_rate; return cb; }
+int zro_auto_exposure(const void* image, int is_f16, uint32_t w, uint32_t h, float dt, const zr_params* prm, uint32_t* hist256, float* exposure2)
+{
+    Post::Image img{image, is_f16 != 0, w, h};
+    const Post::cbAutoExposureHist cb = AeCb(prm);
+    Post::Histogram(img, cb, hist256);
+    Post::WeightedAvg(hist256, w, h, dt, cb, exposure2);
+    return 0;
+}
+// Display.hlsl mainPS over dw x dh display pixels; out_rgba = the float4 return values, out_srgb8 = the back buffer's bytes (may be null)
+int zro_display(const void* image, int is_f16, uint32_t rw, uint32_t rh, uint32_t dw, uint32_t dh, const float* exposure2, const zr_params* prm,
+    const uint32_t* lut, uint32_t lut_dim, float* out_rgba, uint8_t* out_srgb8)
+{
+    Post::Image img{image, is_f16 != 0, rw, rh};
+    Post::cbDisplayPass cb; cb.Tonemapper = prm->display_tonemapper; cb.AutoExposure = prm->display_auto_exposure; cb.Saturation = prm->display_saturation; cb.AgXExp = prm->display_agx_exp;
+    Post::Lut l{lut, lut_dim};
+    for (uint32_t y = 0; y < dh; y++) for (uint32_t x = 0; x < dw; x++)
+    {
+        const float4 c = Post::mainPS(x, y, dw, dh, img, exposure2, cb, l);
+        const size_t i = (size_t)y * dw + x;
+        out_rgba[4 * i] = c.x; out_rgba[4 * i + 1] = c.y; out_rgba[4 * i + 2] = c.z; out_rgba[4 * i + 3] = c.w;
+        if (out_srgb8) { out_srgb8[4 * i] = (uint8_t)Post::LinearToSrgb8(c.x); out_srgb8[4 * i + 1] = (uint8_t)Post::LinearToSrgb8(c.y); out_srgb8[4 * i + 2] = (uint8_t)Post::LinearToSrgb8(c.z); out_srgb8[4 * i + 3] = 255; }
+    }
+    return 0;
+}
 
 // FireflyFilter.hlsl:33-123 on an RGBA32F image (Jacobi reading of the in-place filter, see include/zetaray_amd.h)
 int zro_firefly(const float* in_rgba, const float* depth, float* out_rgba, uint32_t w, uint32_t h)

@@ -185,3 +185,56 @@ def test_cpp_passes_render_post_chain():
         hist = zro.taa(signal, planes[7].reshape(h, w), planes[3].reshape(h, w), hist, 0.1, f > 0)
     assert np.array_equal(comp.view(np.uint32)[..., :3], signal.view(np.uint32)[..., :3])
     assert np.array_equal(taa[..., :3], hist[..., :3])
+
+
+@pytest.mark.gpu
+def test_cpp_passes_render_post_chain_to_display():
+    """... and on to the end of the frame: Compositing -> TAA -> AutoExposure -> Display (Tony McMapface) through the C++ mirror, 4 frames,
+    moving jittered camera.  The exposure texel, the display image and its sRGB8 back buffer == the oracle's chain, bit for bit."""
+    import os
+    from oracle import zro
+    from zetaray_amd import api
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sc = scene_io.load_npz(os.path.join(root, "tests", "golden", "cornell.npz"))
+    osc = zro.OracleScene(sc)
+    w, h, n = 80, 48, 4
+    cbl, prev = [], None
+    for f in range(1, n + 1):
+        cb = scene_io.make_frame_constants(w, h, frame_num=f, num_emissives=0, cam_pos=(0.04 * max(0, f - 2), 1.2, -4.043),
+                                           jitter=(0.2 * (f % 3 - 1), 0.2 * (f % 2 - 0.5)))
+        if prev is not None:
+            cb["prev_view"], cb["prev_view_inv"], cb["prev_camera_jitter"] = prev["curr_view"], prev["curr_view_inv"], prev["curr_camera_jitter"]
+        prev = cb.copy()
+        cbl.append(cb)
+    cbs = np.ascontiguousarray(np.stack(cbl))
+    desc = sc.desc()
+    out, dout, comp, disp = (np.zeros((h, w, 4), np.float32) for _ in range(4))
+    taa = np.zeros((h, w, 4), np.uint16)
+    srgb = np.zeros((h, w, 4), np.uint8)
+    exposure = np.zeros(2, np.float32)
+    lut = api.load_tonemap_lut()
+    L = _lib()
+    L.zrh_render_sequence_sky_display.argtypes = ([C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int] + [C.c_void_p] * 4 +
+                                                  [C.c_void_p, C.c_uint32, C.c_int] + [C.c_void_p] * 3)
+    assert L.zrh_render_sequence_sky_display(C.addressof(desc), cbs.ctypes.data, n, w, h, 2, out.ctypes.data, dout.ctypes.data, comp.ctypes.data, taa.ctypes.data,
+                                             lut.ctypes.data, 48, wire.TONEMAP_NEUTRAL, exposure.ctypes.data, disp.ctypes.data, srgb.ctypes.data) == 0
+    opt, osd = zro.OracleRPT(osc, w, h), zro.OracleSDI(osc, w, h)
+    hist = np.zeros((h, w, 4), np.uint16)
+    prm = wire.default_params()
+    e = np.zeros(2, np.float32)
+    for f in range(n):
+        osc.sky_lut(cbs[f], 256, 128)
+        ind = opt.render(cbs[f], wire.default_params())
+        sdi = osd.render(cbs[f], wire.default_params_sky_di())
+        planes, _keep = osc.gbuffer(cbs[f])
+        fl = planes[2].reshape(h, w) & 0xff
+        signal = np.zeros((h, w, 4), np.float32)
+        signal[..., :3] = sdi[..., :3] + ind[..., :3] * ((fl & 2) == 0)[..., None]
+        signal[(fl & 4) != 0] = 0
+        hist = zro.taa(signal, planes[7].reshape(h, w), planes[3].reshape(h, w), hist, 0.1, f > 0)
+        _, e = zro.auto_exposure(hist, prm, cbs[f]["dt"], e)
+    want, want_srgb = zro.display(hist, prm, (w, h), e, lut)
+    assert np.array_equal(taa[..., :3], hist[..., :3])
+    assert np.array_equal(exposure.view(np.uint32), e.view(np.uint32)) and exposure[0] > 0
+    assert np.array_equal(disp.view(np.uint32), want.view(np.uint32))
+    assert np.array_equal(srgb, want_srgb)

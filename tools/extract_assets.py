@@ -36,6 +36,13 @@ def main():
     pts = re.findall(r"half2\(([-0-9.e]+),\s*([-0-9.e]+)\)", txt)
     assert len(pts) == 32, len(pts)
     np.array(pts, dtype=np.float64).astype(np.float32).astype(np.float16).tofile(os.path.join(ROOT, "zetaray_amd/assets/rdi_sample_set_f16.bin"))
+    # Tony McMapface tone-mapping LUT (Assets/LUT/tony_mc_mapface.dds, MIT, https://github.com/h3r2tic/tony-mc-mapface): the 48^3
+    # R9G9B9E5_SHAREDEXP payload behind the DDS + DX10 headers
+    raw = open(os.path.join(REF, "Assets/LUT/tony_mc_mapface.dds"), "rb").read()
+    assert raw[:4] == b"DDS " and raw[84:88] == b"DX10"
+    h = struct.unpack("<31I", raw[4:128])
+    assert (h[2], h[3], h[5]) == (48, 48, 48) and struct.unpack("<I", raw[128:132])[0] == 67      # DXGI_FORMAT_R9G9B9E5_SHAREDEXP
+    open(os.path.join(ROOT, "zetaray_amd/assets/tony_mc_mapface_rgb9e5.bin"), "wb").write(raw[148:148 + 48 ** 3 * 4])
     import sys
     sys.path.insert(0, ROOT)
     from zetaray_amd import scene_io

@@ -15,8 +15,19 @@ from . import wire
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("ZETARAY_AMD_LIB", os.path.join(_HERE, "libzetaray_amd.so"))     # (override: compiler-variant experiments)
 
-PASS_GBUFFER, PASS_PRELIGHTING, PASS_DI_EMISSIVE, PASS_DI_SKY, PASS_INDIRECT, PASS_COMPOSITING, PASS_SKY, PASS_TAA = range(8)
+PASS_GBUFFER, PASS_PRELIGHTING, PASS_DI_EMISSIVE, PASS_DI_SKY, PASS_INDIRECT, PASS_COMPOSITING, PASS_SKY, PASS_TAA, PASS_AUTO_EXPOSURE, PASS_DISPLAY = range(10)
 IN_TAA_SIGNAL, OUT_TAA = 3, 41
+IN_POST_SIGNAL_F16, IN_POST_SIGNAL_F32, IN_DISPLAY_EXPOSURE = 4, 5, 6
+OUT_EXPOSURE, OUT_AE_HISTOGRAM, OUT_DISPLAY, OUT_DISPLAY_SRGB8 = 42, 43, 44, 45
+TONEMAP_LUT_PATH = os.path.join(_HERE, "assets", "tony_mc_mapface_rgb9e5.bin")
+
+
+def load_tonemap_lut():
+    """The Tony McMapface LUT of the NEUTRAL tone mapper: 48^3 R9G9B9E5_SHAREDEXP texels (tools/extract_assets.py)."""
+    lut = np.fromfile(TONEMAP_LUT_PATH, np.uint32)
+    assert lut.size == 48 ** 3, lut.size
+    return lut
+
 OUT_SKY_LUT = 40
 IN_EMISSIVE_DI, IN_INDIRECT, IN_SKY_DI = range(3)
 INTEGRATOR_PATH_TRACING, INTEGRATOR_RESTIR_GI, INTEGRATOR_RESTIR_PT = range(3)
@@ -41,6 +52,7 @@ EXPORTS = [
     "zr_pass_read_counters", "zr_pass_read_kernel_counters", "zr_pass_enable_timing", "zr_pass_get_timings", "zr_selftest_half_conversions", "zr_pass_destroy",
     "zr_trace_closest", "zr_trace_any",
     "zr_pass_set_owned_rect", "zr_pass_render_stage", "zr_pass_halo_pack", "zr_pass_halo_unpack", "zr_pass_halo_bytes_per_pixel", "zr_pass_set_input",
+    "zr_pass_set_tonemap_lut",
 ]
 STAGE_TEMPORAL, STAGE_SPATIAL, STAGE_ALL = 1, 2, 3
 HALO_POST_TEMPORAL, HALO_FINAL = 0, 1
@@ -98,6 +110,7 @@ def lib():
         L.zr_pass_read_counters.argtypes = [vp, vp, vp, i32]
         L.zr_pass_read_kernel_counters.argtypes = [vp, vp, u32, vp, vp, vp, vp]
         L.zr_pass_set_input.argtypes = [vp, i32, vp]
+        L.zr_pass_set_tonemap_lut.argtypes = [vp, vp, u32]
         L.zr_pass_set_owned_rect.argtypes = [vp, u32, u32, u32, u32]
         L.zr_pass_render_stage.argtypes = [vp, vp, vp, vp, vp, i32]
         L.zr_pass_halo_pack.argtypes = [vp, vp, vp, i32, u32, u32, u32, u32, vp, C.c_size_t]
@@ -234,6 +247,16 @@ class Pass:
 
     def set_input(self, which, dev_ptr):
         _check(lib().zr_pass_set_input(self.h, which, dev_ptr))
+
+    def set_tonemap_lut(self, lut=None):
+        lut = np.ascontiguousarray(load_tonemap_lut() if lut is None else lut, np.uint32)
+        dim = int(round(lut.size ** (1.0 / 3.0)))
+        _check(lib().zr_pass_set_tonemap_lut(self.h, lut.ctypes.data, dim))
+
+    def download_raw(self, which, dtype, shape, stream=None):
+        out = np.zeros(shape, dtype)
+        _check(lib().zr_pass_download_output(self.h, which, stream, out.ctypes.data, out.nbytes))
+        return out
 
     def set_owned_rect(self, x0, y0, w, h):
         _check(lib().zr_pass_set_owned_rect(self.h, x0, y0, w, h))

@@ -20,6 +20,7 @@
 #include "zr_rgi.h"
 #include "zr_bvh.h"
 #include "zr_taa.h"
+#include "zr_post.h"
 #include "../../include/zr_srgb_table.h"
 
 // 512 x half2 spatial-search points (generated from zetaray_amd/assets/rpt_sample_set_f16.bin by the Makefile)
@@ -227,6 +228,52 @@ __global__ void __launch_bounds__(256) k_taa(taa::TaaFrame F)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < F.w * F.h) taa::TaaPixel(F, i % F.w, i / F.w);
+}
+
+// AutoExposure_Histogram.hlsl: per-block LDS histogram (256 bins = 256 threads), one global atomic per non-empty bin and block.
+// in16 / in32: exactly one is non-null (RGBA16F plane, or RGBA32F read rounded to half).  HBM-bound: 8 (16) B read per pixel.
+__global__ void __launch_bounds__(256) k_ae_histogram(const uint16_t* in16, const F4* in32, uint32_t n, post::AeParams prm, uint32_t* hist)
+{
+    __shared__ uint32_t bins[post::kHistBins];
+    bins[threadIdx.x] = 0;
+    __syncthreads();
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
+    {
+        const V3 c = in16 ? post::LoadHalf3(in16, i) : post::HalfRounded(in32[i]);
+        atomicAdd(&bins[post::AeBin(c, prm)], 1u);
+    }
+    __syncthreads();
+    if (bins[threadIdx.x]) atomicAdd(hist + threadIdx.x, bins[threadIdx.x]);
+}
+// AutoExposure_WeightedAvg.hlsl: one 256-thread group = 4 waves of 64; WaveActiveSum = the ABI's xor butterfly
+__global__ void __launch_bounds__(256) k_ae_resolve(const uint32_t* hist, uint32_t numPixels, float dt, post::AeParams prm, float* exposure)
+{
+    const uint32_t gidx = threadIdx.x;
+    float val = post::AeBinValue(gidx, gidx == 0 ? 0u : hist[gidx]);
+    val = WaveSumButterfly(val);
+    __shared__ float waveSum[4];
+    if ((gidx & 63u) == 0) waveSum[gidx >> 6] = val;
+    __syncthreads();
+    float mean = gidx < 4 ? waveSum[gidx] : 0.0f;
+    mean = WaveSumButterfly(mean);
+    if (gidx == 0) post::AeResolve(mean, numPixels - hist[0], dt, prm, exposure);
+}
+// Display.hlsl mainPS: one thread per display pixel; point-clamp fetch of the render-resolution image
+__global__ void __launch_bounds__(256) k_display(const uint16_t* in16, const F4* in32, uint32_t rw, uint32_t rh, uint32_t dw, uint32_t dh,
+    const float* exposure, post::DisplayParams prm, post::Lut3D lut, F4* out, uint32_t* outSrgb)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= dw * dh) return;
+    const uint32_t x = i % dw, y = i / dw;
+    const float u = ((float)x + 0.5f) / (float)dw, v = ((float)y + 0.5f) / (float)dh;
+    int sx = (int)zr_floor(u * (float)rw), sy = (int)zr_floor(v * (float)rh);
+    sx = sx < 0 ? 0 : (sx > (int)rw - 1 ? (int)rw - 1 : sx); sy = sy < 0 ? 0 : (sy > (int)rh - 1 ? (int)rh - 1 : sy);
+    const size_t sp = (size_t)sy * rw + sx;
+    // Texture2D<float4> on the composited texture: the stored (half) values
+    const V3 c = in16 ? post::LoadHalf3(in16, sp) : post::HalfRounded(in32[sp]);
+    const V3 d = post::DisplayPixel(c, (prm.autoExposure && exposure) ? exposure[0] : 1.0f, prm, lut);
+    out[i] = f4(d, 1.0f);
+    outSrgb[i] = post::LinearToSrgb8(d.x) | (post::LinearToSrgb8(d.y) << 8) | (post::LinearToSrgb8(d.z) << 16) | 0xff000000u;
 }
 
 // self-test of zr_detmath.h's half conversions (instruction path vs portable path), see zr_selftest_half_conversions
@@ -606,6 +653,10 @@ struct zr_pass
     bool temporalValid = false, doTemporal = false, doSpatial = false; int currIdx = 0;
     const F4* compIn[4] = {nullptr, nullptr, nullptr, nullptr};     // COMPOSITING inputs (emissive DI, indirect, sky DI); [3] = TAA signal
     DevBuf<uint16_t> taaOut[2]; int taaIdx = 0;            // TAA: ping-pong RGBA16F outputs; taaIdx = the one written last
+    // AUTO_EXPOSURE / DISPLAY
+    const uint16_t* postIn16 = nullptr; const F4* postIn32 = nullptr; const float* exposureIn = nullptr;
+    DevBuf<uint32_t> aeHist; DevBuf<float> aeExposure;
+    DevBuf<uint32_t> tonemapLut; uint32_t tonemapLutDim = 0; DevBuf<F4> displayOut; DevBuf<uint32_t> displaySrgb;
     uint32_t own[4] = {0, 0, 0, 0};                // owned rect (global pixels); w == 0 -> the whole G-buffer rect
     // PRELIGHTING
     DevBuf<float> power;
@@ -754,6 +805,8 @@ int zr_params_default(zr_params* p)
     p->alpha_min = 0.175f * 0.175f; p->presampling = 0; p->num_sample_sets = 128; p->sample_set_size = 512;
     // light voxel grid: off; VOXEL_GRID_DIM (32, 8, 40), VOXEL_EXTENTS (0.6, 0.45, 0.6), y offset 0.1 (DefaultRendererImpl.h:42-43, 73-77)
     p->taa_blend_weight = 0.1f;      // TAA.h:72
+    p->ae_min_lum = 5e-3f; p->ae_max_lum = 4.0f; p->ae_lum_map_exp = 0.5f; p->ae_adaptation_rate = 1.0f;      // AutoExposure.h:73-81
+    p->display_tonemapper = ZR_TONEMAP_NEUTRAL; p->display_auto_exposure = 1; p->display_saturation = 1.0f; p->display_agx_exp = 1.0f;   // Display.cpp:69-74
     p->use_lvg = 0; p->lvg_grid_dim = 32u | (8u << 10) | (40u << 20);
     p->lvg_extents[0] = 0.6f; p->lvg_extents[1] = 0.45f; p->lvg_extents[2] = 0.6f; p->lvg_offset_y = 0.1f;
     return ZR_OK;
@@ -1015,7 +1068,7 @@ int zr_gbuffer_device_plane(const zr_gbuffer* g, int plane, void** dev)
 int zr_pass_create(int kind, int device, zr_pass** out)
 {
     if (!out) return Fail(ZR_ERR_INVALID_ARG, "null out");
-    if (kind < ZR_PASS_GBUFFER || kind > ZR_PASS_TAA) return Fail(ZR_ERR_INVALID_ARG, "unknown pass kind %d", kind);
+    if (kind < ZR_PASS_GBUFFER || kind > ZR_PASS_DISPLAY) return Fail(ZR_ERR_INVALID_ARG, "unknown pass kind %d", kind);
     int r = RequireDevice(device);
     if (r) return r;
     zr_pass* p = new (std::nothrow) zr_pass();
@@ -1047,6 +1100,18 @@ static int AllocPass(zr_pass* p)
         const size_t n = (size_t)p->w * p->h * 4;
         for (int k = 0; k < 2; k++) { if ((r = p->taaOut[k].Alloc(n))) return r; HIP_TRY(hipMemset(p->taaOut[k].p, 0, n * sizeof(uint16_t))); }
         p->taaIdx = 0; p->temporalValid = false;
+    }
+    if (p->kind == ZR_PASS_AUTO_EXPOSURE)
+    {
+        if ((r = p->aeHist.Alloc(post::kHistBins)) || (r = p->aeExposure.Alloc(2))) return r;
+        HIP_TRY(hipMemset(p->aeHist.p, 0, post::kHistBins * sizeof(uint32_t)));
+        HIP_TRY(hipMemset(p->aeExposure.p, 0, 2 * sizeof(float)));      // TEXTURE_FLAGS::INIT_TO_ZERO, AutoExposure.cpp:150-155
+    }
+    if (p->kind == ZR_PASS_DISPLAY)
+    {
+        const size_t cap = (size_t)p->w * p->h;
+        if ((r = p->displayOut.Alloc(cap)) || (r = p->displaySrgb.Alloc(cap))) return r;
+        HIP_TRY(hipMemset(p->displayOut.p, 0, cap * sizeof(F4))); HIP_TRY(hipMemset(p->displaySrgb.p, 0, cap * 4));
     }
     if (p->kind == ZR_PASS_COMPOSITING)
     {
@@ -1587,10 +1652,69 @@ int zr_pass_render(zr_pass* p, void* stream, const zr_frame_constants* cb, const
 int zr_pass_set_input(zr_pass* p, int which, const void* dev)
 {
     if (p && p->kind == ZR_PASS_TAA && which == ZR_IN_TAA_SIGNAL) { p->compIn[3] = (const F4*)dev; return ZR_OK; }
+    if (p && (p->kind == ZR_PASS_AUTO_EXPOSURE || p->kind == ZR_PASS_DISPLAY))
+    {
+        if (which == ZR_IN_POST_SIGNAL_F16) { p->postIn16 = (const uint16_t*)dev; p->postIn32 = nullptr; return ZR_OK; }
+        if (which == ZR_IN_POST_SIGNAL_F32) { p->postIn32 = (const F4*)dev; p->postIn16 = nullptr; return ZR_OK; }
+        if (which == ZR_IN_DISPLAY_EXPOSURE && p->kind == ZR_PASS_DISPLAY) { p->exposureIn = (const float*)dev; return ZR_OK; }
+        return Fail(ZR_ERR_INVALID_ARG, "zr_pass_set_input: bad input id for an AUTO_EXPOSURE / DISPLAY pass");
+    }
     if (!p || p->kind != ZR_PASS_COMPOSITING || which < 0 || which > 2) return Fail(ZR_ERR_INVALID_ARG, "zr_pass_set_input: not a COMPOSITING / TAA pass or bad input id");
     p->compIn[which] = (const F4*)dev;
     return ZR_OK;
 }
+extern "C" int zr_pass_set_tonemap_lut(zr_pass* p, const uint32_t* rgb9e5, uint32_t dim)
+{
+    if (!p || p->kind != ZR_PASS_DISPLAY || !rgb9e5 || dim == 0 || dim > 256) return Fail(ZR_ERR_INVALID_ARG, "zr_pass_set_tonemap_lut: needs a DISPLAY pass and a dim^3 LUT");
+    HIP_TRY(hipSetDevice(p->device));
+    const size_t n = (size_t)dim * dim * dim;
+    int r; if ((r = p->tonemapLut.Alloc(n))) return r;
+    HIP_TRY(hipMemcpy(p->tonemapLut.p, rgb9e5, n * sizeof(uint32_t), hipMemcpyHostToDevice));
+    p->tonemapLutDim = dim;
+    return ZR_OK;
+}
+
+static post::AeParams AeParamsOf(const zr_params& ip)
+{ post::AeParams a; a.minLum = ip.ae_min_lum; a.lumRange = ip.ae_max_lum - ip.ae_min_lum; a.lumMapExp = ip.ae_lum_map_exp; a.adaptationRate = ip.ae_adaptation_rate; return a; }
+
+// AutoExposure::Render (AutoExposure.cpp:100-143): clear the histogram, HISTOGRAM over the image, WEIGHTED_AVG in one group
+static int RenderAutoExposure(zr_pass* p, hipStream_t s, const zr_frame_constants* cb)
+{
+    if (cb->render_width != p->w || cb->render_height != p->h) return Fail(ZR_ERR_INVALID_ARG, "AUTO_EXPOSURE: frame constants / pass size mismatch");
+    if (!p->postIn16 && !p->postIn32) return Fail(ZR_ERR_NOT_INITIALIZED, "AUTO_EXPOSURE: no input bound (zr_pass_set_input(ZR_IN_POST_SIGNAL_*))");
+    const uint32_t n = p->w * p->h;
+    const post::AeParams prm = AeParamsOf(p->params);
+    HIP_TRY(hipMemsetAsync(p->aeHist.p, 0, post::kHistBins * sizeof(uint32_t), s));
+    TimerBegin(p, s, "ae_histogram");
+    const uint32_t grid = std::min<uint32_t>((n + 255) / 256, 2048u);
+    hipLaunchKernelGGL(k_ae_histogram, dim3(grid), dim3(256), 0, s, p->postIn16, p->postIn32, n, prm, p->aeHist.p);
+    TimerEnd(p, s);
+    TimerBegin(p, s, "ae_resolve");
+    hipLaunchKernelGGL(k_ae_resolve, dim3(1), dim3(256), 0, s, p->aeHist.p, n, cb->dt, prm, p->aeExposure.p);
+    TimerEnd(p, s);
+    HIP_TRY(hipGetLastError());
+    return ZR_OK;
+}
+// DisplayPass::Render (Display.cpp:188-260), the full-screen triangle of mainPS as one thread per display pixel
+static int RenderDisplay(zr_pass* p, hipStream_t s, const zr_frame_constants* cb)
+{
+    if (cb->display_width != p->w || cb->display_height != p->h) return Fail(ZR_ERR_INVALID_ARG, "DISPLAY: the pass size must be the display size of the frame constants");
+    if (!p->postIn16 && !p->postIn32) return Fail(ZR_ERR_NOT_INITIALIZED, "DISPLAY: no input bound (zr_pass_set_input(ZR_IN_POST_SIGNAL_*))");
+    const zr_params& ip = p->params;
+    if (ip.display_tonemapper >= post::TM_COUNT) return Fail(ZR_ERR_INVALID_ARG, "DISPLAY: unknown tone mapper %u", ip.display_tonemapper);
+    if (ip.display_tonemapper == ZR_TONEMAP_NEUTRAL && !p->tonemapLutDim) return Fail(ZR_ERR_NOT_INITIALIZED, "DISPLAY: the NEUTRAL tone mapper needs zr_pass_set_tonemap_lut");
+    if (ip.display_auto_exposure && !p->exposureIn) return Fail(ZR_ERR_NOT_INITIALIZED, "DISPLAY: auto exposure is on but no exposure bound (ZR_IN_DISPLAY_EXPOSURE)");
+    post::DisplayParams prm; prm.tonemapper = ip.display_tonemapper; prm.autoExposure = ip.display_auto_exposure; prm.saturation = ip.display_saturation; prm.agxExp = ip.display_agx_exp;
+    post::Lut3D lut; lut.data = p->tonemapLut.p; lut.dim = p->tonemapLutDim;
+    const uint32_t n = p->w * p->h;
+    TimerBegin(p, s, "display");
+    hipLaunchKernelGGL(k_display, dim3((n + 255) / 256), dim3(256), 0, s, p->postIn16, p->postIn32, cb->render_width, cb->render_height, p->w, p->h,
+        p->exposureIn, prm, lut, p->displayOut.p, p->displaySrgb.p);
+    TimerEnd(p, s);
+    HIP_TRY(hipGetLastError());
+    return ZR_OK;
+}
+
 // TAA::Render (TAA.cpp:75-118): reads the other output as history, then the roles swap
 static int RenderTAA(zr_pass* p, hipStream_t s, const zr_frame_constants* cb, zr_gbuffer* gb)
 {
@@ -1735,6 +1859,8 @@ int zr_pass_render_stage(zr_pass* p, void* stream, const zr_frame_constants* cb,
     case ZR_PASS_COMPOSITING: return (stages & ZR_STAGE_SPATIAL) ? RenderCompositing(p, s, cb, gb) : ZR_OK;
     case ZR_PASS_SKY: return (stages & ZR_STAGE_TEMPORAL) ? RenderSky(p, s, cb, const_cast<zr_scene*>(sc)) : ZR_OK;
     case ZR_PASS_TAA: return (stages & ZR_STAGE_SPATIAL) ? RenderTAA(p, s, cb, gb) : ZR_OK;
+    case ZR_PASS_AUTO_EXPOSURE: return (stages & ZR_STAGE_SPATIAL) ? RenderAutoExposure(p, s, cb) : ZR_OK;
+    case ZR_PASS_DISPLAY: return (stages & ZR_STAGE_SPATIAL) ? RenderDisplay(p, s, cb) : ZR_OK;
     default: return Fail(ZR_ERR_UNSUPPORTED, "pass kind %d not implemented", p->kind);
     }
 }
@@ -1751,6 +1877,18 @@ int zr_pass_get_output(const zr_pass* p, int which, void** dev, uint32_t* w, uin
         if (h) *h = p->h;
         if (bpp) *bpp = 4;
         return ZR_OK;
+    }
+    if (p->kind == ZR_PASS_AUTO_EXPOSURE)
+    {
+        if (which == ZR_OUT_EXPOSURE) { *dev = p->aeExposure.p; if (w) *w = 1; if (h) *h = 1; if (bpp) *bpp = 8; return ZR_OK; }
+        if (which == ZR_OUT_AE_HISTOGRAM) { *dev = p->aeHist.p; if (w) *w = post::kHistBins; if (h) *h = 1; if (bpp) *bpp = 4; return ZR_OK; }
+        return Fail(ZR_ERR_INVALID_ARG, "pass has no such output");
+    }
+    if (p->kind == ZR_PASS_DISPLAY)
+    {
+        if (which == ZR_OUT_DISPLAY) { *dev = p->displayOut.p; if (w) *w = p->w; if (h) *h = p->h; if (bpp) *bpp = 16; return ZR_OK; }
+        if (which == ZR_OUT_DISPLAY_SRGB8) { *dev = p->displaySrgb.p; if (w) *w = p->w; if (h) *h = p->h; if (bpp) *bpp = 4; return ZR_OK; }
+        return Fail(ZR_ERR_INVALID_ARG, "pass has no such output");
     }
     if (p->kind == ZR_PASS_TAA)
     {

@@ -323,6 +323,50 @@ void* TAA::GetOutput(SHADER_OUT_RES i) const
 }
 void TAA::Render(Core::CommandList& cl) { ZR_CHECK(zr_pass_render(m_pass, cl.Stream(), &m_ctx->frameConstants, m_ctx->scene, m_ctx->gbuffer)); }
 
+void AutoExposure::Init(FrameContext* ctx) { InitRenderPass(ZR_PASS_AUTO_EXPOSURE, ctx, 0); ZR_CHECK(zr_params_default(&m_params)); }
+void AutoExposure::OnWindowResized() { ZR_CHECK(zr_pass_resize(m_pass, m_ctx->renderWidth, m_ctx->renderHeight)); }
+void AutoExposure::SetDescriptor(SHADER_IN_DESC, const void* dev, bool rgba16f) { ZR_CHECK(zr_pass_set_input(m_pass, rgba16f ? ZR_IN_POST_SIGNAL_F16 : ZR_IN_POST_SIGNAL_F32, dev)); }
+void AutoExposure::SetMinLum(float v) { m_params.ae_min_lum = v; ZR_CHECK(zr_pass_set_params(m_pass, &m_params)); }
+void AutoExposure::SetMaxLum(float v) { m_params.ae_max_lum = v; ZR_CHECK(zr_pass_set_params(m_pass, &m_params)); }
+void AutoExposure::SetLumMapExp(float v) { m_params.ae_lum_map_exp = v; ZR_CHECK(zr_pass_set_params(m_pass, &m_params)); }
+void* AutoExposure::GetOutput(SHADER_OUT_RES i) const
+{
+    if (i >= SHADER_OUT_RES::COUNT) { std::fprintf(stderr, "Invalid shader output.\n"); std::abort(); }
+    void* dev = nullptr; uint32_t w, h, bpp;
+    ZR_CHECK(zr_pass_get_output(m_pass, ZR_OUT_EXPOSURE, &dev, &w, &h, &bpp));
+    return dev;
+}
+void AutoExposure::Render(Core::CommandList& cl) { ZR_CHECK(zr_pass_render(m_pass, cl.Stream(), &m_ctx->frameConstants, m_ctx->scene, nullptr)); }
+
+void DisplayPass::Init(FrameContext* ctx, uint32_t displayWidth, uint32_t displayHeight, const uint32_t* lut, uint32_t lutDim)
+{
+    m_ctx = ctx;
+    ZR_CHECK(zr_pass_create(ZR_PASS_DISPLAY, ctx->device, &m_pass));
+    ZR_CHECK(zr_pass_init(m_pass, displayWidth, displayHeight, 0));
+    m_initialized = true;
+    ZR_CHECK(zr_params_default(&m_params));
+    if (lut) ZR_CHECK(zr_pass_set_tonemap_lut(m_pass, lut, lutDim));
+    else { m_params.display_tonemapper = ZR_TONEMAP_AGX_DEFAULT; ZR_CHECK(zr_pass_set_params(m_pass, &m_params)); }     // NEUTRAL needs the LUT
+}
+void DisplayPass::SetGpuDescriptor(SHADER_IN_GPU_DESC i, const void* dev, bool rgba16f)
+{
+    if (i == SHADER_IN_GPU_DESC::COMPOSITED) ZR_CHECK(zr_pass_set_input(m_pass, rgba16f ? ZR_IN_POST_SIGNAL_F16 : ZR_IN_POST_SIGNAL_F32, dev));
+    else if (i == SHADER_IN_GPU_DESC::EXPOSURE) ZR_CHECK(zr_pass_set_input(m_pass, ZR_IN_DISPLAY_EXPOSURE, dev));
+    else { std::fprintf(stderr, "out-of-bound access.\n"); std::abort(); }
+}
+void DisplayPass::SetTonemapper(zr_tonemapper t) { m_params.display_tonemapper = (uint32_t)t; ZR_CHECK(zr_pass_set_params(m_pass, &m_params)); }
+void DisplayPass::SetAutoExposure(bool b) { m_params.display_auto_exposure = b ? 1u : 0u; ZR_CHECK(zr_pass_set_params(m_pass, &m_params)); }
+void DisplayPass::SetSaturation(float v) { m_params.display_saturation = v; ZR_CHECK(zr_pass_set_params(m_pass, &m_params)); }
+void DisplayPass::SetAgXExp(float v) { m_params.display_agx_exp = v; ZR_CHECK(zr_pass_set_params(m_pass, &m_params)); }
+void* DisplayPass::GetOutput(SHADER_OUT_RES i) const
+{
+    if (i >= SHADER_OUT_RES::COUNT) { std::fprintf(stderr, "Invalid shader output.\n"); std::abort(); }
+    void* dev = nullptr; uint32_t w, h, bpp;
+    ZR_CHECK(zr_pass_get_output(m_pass, i == SHADER_OUT_RES::BACK_BUFFER_LINEAR ? ZR_OUT_DISPLAY : ZR_OUT_DISPLAY_SRGB8, &dev, &w, &h, &bpp));
+    return dev;
+}
+void DisplayPass::Render(Core::CommandList& cl) { ZR_CHECK(zr_pass_render(m_pass, cl.Stream(), &m_ctx->frameConstants, m_ctx->scene, nullptr)); }
+
 void IndirectLighting::Init(FrameContext* ctx, INTEGRATOR method)
 {
     zr_params_default(&m_params);
@@ -469,17 +513,23 @@ int zrh_render_sequence3(const zr_scene_desc* desc, const zr_frame_constants* cb
 
 // The reference's default (sun + sky) frame: Sky -> GBuffer -> {SkyDI, Indirect} (PathTracer.cpp:165-181, 311-360, 474-552).
 // Copies the FINAL planes of the last frame: Indirect to `finalOut`, SkyDI to `skyDiOut`.
+int zrh_render_sequence_sky_display(const zr_scene_desc* desc, const zr_frame_constants* cbs, uint32_t n, uint32_t w, uint32_t h, int integrator, float* finalOut, float* skyDiOut,
+    float* compositedOut, uint16_t* taaOut, const uint32_t* lutRGB9E5, uint32_t lutDim, int tonemapper, float* exposureOut, float* displayOut, uint8_t* displaySrgbOut);
 int zrh_render_sequence_sky_post(const zr_scene_desc* desc, const zr_frame_constants* cbs, uint32_t n, uint32_t w, uint32_t h, int integrator, float* finalOut, float* skyDiOut,
-    float* compositedOut, uint16_t* taaOut);
+    float* compositedOut, uint16_t* taaOut)
+{ return zrh_render_sequence_sky_display(desc, cbs, n, w, h, integrator, finalOut, skyDiOut, compositedOut, taaOut, nullptr, 0, 0, nullptr, nullptr, nullptr); }
 int zrh_render_sequence_sky(const zr_scene_desc* desc, const zr_frame_constants* cbs, uint32_t n, uint32_t w, uint32_t h, int integrator, float* finalOut, float* skyDiOut)
 { return zrh_render_sequence_sky_post(desc, cbs, n, w, h, integrator, finalOut, skyDiOut, nullptr, nullptr); }
 
 // ... followed by Compositing -> TAA when compositedOut / taaOut are given (DefaultRenderer's post chain, Compositing.cpp / TAA.cpp):
 // compositedOut = RGBA32F of the last frame, taaOut = RGBA16F bits of the last frame
-int zrh_render_sequence_sky_post(const zr_scene_desc* desc, const zr_frame_constants* cbs, uint32_t n, uint32_t w, uint32_t h, int integrator, float* finalOut, float* skyDiOut,
-    float* compositedOut, uint16_t* taaOut)
+// ... and by AutoExposure -> Display on the TAA output when displayOut is given (DefaultRenderer.cpp: the last two nodes of the frame):
+// exposureOut = the (exposure, adapted luminance) texel, displayOut = RGBA32F, displaySrgbOut = RGBA8 of the last frame (display size = w x h)
+int zrh_render_sequence_sky_display(const zr_scene_desc* desc, const zr_frame_constants* cbs, uint32_t n, uint32_t w, uint32_t h, int integrator, float* finalOut, float* skyDiOut,
+    float* compositedOut, uint16_t* taaOut, const uint32_t* lutRGB9E5, uint32_t lutDim, int tonemapper, float* exposureOut, float* displayOut, uint8_t* displaySrgbOut)
 {
-    const bool post = compositedOut || taaOut;
+    const bool display = displayOut || displaySrgbOut || exposureOut;
+    const bool post = compositedOut || taaOut || display;
     RenderPass::FrameContext ctx;
     ctx.device = 0; ctx.renderWidth = w; ctx.renderHeight = h;
     ZR_CHECK(zr_scene_create(0, desc, &ctx.scene));
@@ -495,8 +545,21 @@ int zrh_render_sequence_sky_post(const zr_scene_desc* desc, const zr_frame_const
             comp.SetGpuDescriptor(RenderPass::Compositing::SHADER_IN_GPU_DESC::INDIRECT, ind.GetOutput(RenderPass::IndirectLighting::SHADER_OUT_RES::FINAL));
             taa.SetCPUDescriptor(RenderPass::TAA::SHADER_IN_CPU_DESC::SIGNAL, comp.GetOutput(RenderPass::Compositing::SHADER_OUT_RES::COMPOSITED));
         }
+        RenderPass::AutoExposure ae; RenderPass::DisplayPass disp;
+        // TAA ping-pongs its two targets: like DefaultRenderer's per-frame Update(), the consumers bind "the TAA target of this frame" when
+        // their node records, i.e. after the TAA node has run (they depend on R_TAA)
+        struct AeNode { RenderPass::AutoExposure* ae; RenderPass::TAA* taa; void Render(Core::CommandList& cl)
+            { ae->SetDescriptor(RenderPass::AutoExposure::SHADER_IN_DESC::COMPOSITED, taa->GetOutput(RenderPass::TAA::SHADER_OUT_RES::OUTPUT_A), true); ae->Render(cl); } } aeNode{&ae, &taa};
+        struct DispNode { RenderPass::DisplayPass* d; RenderPass::TAA* taa; void Render(Core::CommandList& cl)
+            { d->SetGpuDescriptor(RenderPass::DisplayPass::SHADER_IN_GPU_DESC::COMPOSITED, taa->GetOutput(RenderPass::TAA::SHADER_OUT_RES::OUTPUT_A), true); d->Render(cl); } } dispNode{&disp, &taa};
+        if (display)
+        {
+            ae.Init(&ctx); disp.Init(&ctx, w, h, lutRGB9E5, lutDim);
+            disp.SetTonemapper((zr_tonemapper)tonemapper);
+            disp.SetGpuDescriptor(RenderPass::DisplayPass::SHADER_IN_GPU_DESC::EXPOSURE, ae.GetOutput(RenderPass::AutoExposure::SHADER_OUT_RES::EXPOSURE));
+        }
         Core::RenderGraph g;
-        enum : uint64_t { R_LUT = 1, R_GBUF, R_IND, R_SDI, R_COMP, R_TAA };
+        enum : uint64_t { R_LUT = 1, R_GBUF, R_IND, R_SDI, R_COMP, R_TAA, R_EXPOSURE, R_BACKBUFFER };
         for (uint32_t f = 0; f < n; f++)
         {
             ctx.frameConstants = cbs[f];
@@ -516,6 +579,14 @@ int zrh_render_sequence_sky_post(const zr_scene_desc* desc, const zr_frame_const
                 g.RegisterResource(comp.GetOutput(RenderPass::Compositing::SHADER_OUT_RES::COMPOSITED), R_COMP);
                 g.RegisterResource(nullptr, R_TAA);       // ping-pong target: identified by its path id, like the reference's dummy resources
             }
+            Core::RenderNodeHandle hAe{}, hDisp{};
+            if (display)
+            {
+                hAe = g.RegisterRenderPass("AutoExposure", Core::RENDER_NODE_TYPE::COMPUTE, Core::MakeDelegate(&aeNode, &AeNode::Render));
+                hDisp = g.RegisterRenderPass("Display", Core::RENDER_NODE_TYPE::RENDER, Core::MakeDelegate(&dispNode, &DispNode::Render));
+                g.RegisterResource(ae.GetOutput(RenderPass::AutoExposure::SHADER_OUT_RES::EXPOSURE), R_EXPOSURE);
+                g.RegisterResource(disp.GetOutput(RenderPass::DisplayPass::SHADER_OUT_RES::BACK_BUFFER_LINEAR), R_BACKBUFFER);
+            }
             g.MoveToPostRegister();
             g.AddOutput(hSky, R_LUT, Core::STATE_UNORDERED_ACCESS);
             g.AddOutput(hGB, R_GBUF, Core::STATE_UNORDERED_ACCESS);
@@ -527,11 +598,19 @@ int zrh_render_sequence_sky_post(const zr_scene_desc* desc, const zr_frame_const
                 g.AddOutput(hComp, R_COMP, Core::STATE_UNORDERED_ACCESS);
                 g.AddInput(hTaa, R_COMP, Core::STATE_SHADER_READ); g.AddInput(hTaa, R_GBUF, Core::STATE_SHADER_READ); g.AddOutput(hTaa, R_TAA, Core::STATE_UNORDERED_ACCESS);
             }
+            if (display)
+            {
+                g.AddInput(hAe, R_TAA, Core::STATE_SHADER_READ); g.AddOutput(hAe, R_EXPOSURE, Core::STATE_UNORDERED_ACCESS);
+                g.AddInput(hDisp, R_TAA, Core::STATE_SHADER_READ); g.AddInput(hDisp, R_EXPOSURE, Core::STATE_SHADER_READ); g.AddOutput(hDisp, R_BACKBUFFER, Core::STATE_UNORDERED_ACCESS);
+            }
             Support::TaskSet ts;
             g.Build(ts);
             ts.Run(true);
             g.WaitForFrame();
         }
+        if (exposureOut && hipMemcpy(exposureOut, ae.GetOutput(RenderPass::AutoExposure::SHADER_OUT_RES::EXPOSURE), 8, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+        if (displayOut && hipMemcpy(displayOut, disp.GetOutput(RenderPass::DisplayPass::SHADER_OUT_RES::BACK_BUFFER_LINEAR), (size_t)w * h * 16, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+        if (displaySrgbOut && hipMemcpy(displaySrgbOut, disp.GetOutput(RenderPass::DisplayPass::SHADER_OUT_RES::BACK_BUFFER_SRGB8), (size_t)w * h * 4, hipMemcpyDeviceToHost) != hipSuccess) return -1;
         if (compositedOut && hipMemcpy(compositedOut, comp.GetOutput(RenderPass::Compositing::SHADER_OUT_RES::COMPOSITED), (size_t)w * h * 16, hipMemcpyDeviceToHost) != hipSuccess) return -1;
         if (taaOut && hipMemcpy(taaOut, taa.GetOutput(RenderPass::TAA::SHADER_OUT_RES::OUTPUT_A), (size_t)w * h * 8, hipMemcpyDeviceToHost) != hipSuccess) return -1;
         if (hipMemcpy(finalOut, ind.GetOutput(RenderPass::IndirectLighting::SHADER_OUT_RES::FINAL), (size_t)w * h * 16, hipMemcpyDeviceToHost) != hipSuccess) return -1;

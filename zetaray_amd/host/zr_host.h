@@ -247,6 +247,37 @@ namespace RenderPass {
         zr_params m_params{};
     };
 
+    // RP/AutoExposure/AutoExposure.h:21-100: luminance histogram + adapted exposure of the composited / anti-aliased image
+    struct AutoExposure final : public RenderPassBase
+    {
+        enum class SHADER_IN_DESC { COMPOSITED, COUNT };
+        enum class SHADER_OUT_RES { EXPOSURE, COUNT };
+        void Init(FrameContext* ctx);
+        void OnWindowResized();
+        // the image to meter: an RGBA16F plane (TAA output) or an RGBA32F plane (Compositing output)
+        void SetDescriptor(SHADER_IN_DESC i, const void* devicePlane, bool rgba16f);
+        void SetMinLum(float v); void SetMaxLum(float v); void SetLumMapExp(float v);      // params "Min Lum" / "Max Lum" / "Lum Map Exp", AutoExposure.cpp:64-87
+        void* GetOutput(SHADER_OUT_RES i) const;       // RG32F 1 x 1: exposure, adapted luminance
+        void Render(Core::CommandList& cmdList);
+    private:
+        zr_params m_params{};
+    };
+
+    // RP/Display/Display.h:35-153: exposure + tone mapping of the final image (DisplayOption::DEFAULT; picking / wireframe overlays are UI)
+    struct DisplayPass final : public RenderPassBase
+    {
+        enum class SHADER_IN_GPU_DESC { COMPOSITED, EXPOSURE, COUNT };
+        enum class SHADER_OUT_RES { BACK_BUFFER_LINEAR, BACK_BUFFER_SRGB8, COUNT };       // the reference renders into the swap chain's RTV
+        // display size = ctx.frameConstants.display_*; lutRGB9E5 = dim^3 texels of Assets/LUT/tony_mc_mapface.dds (Display.cpp:196-205), may be null
+        void Init(FrameContext* ctx, uint32_t displayWidth, uint32_t displayHeight, const uint32_t* lutRGB9E5, uint32_t lutDim);
+        void SetGpuDescriptor(SHADER_IN_GPU_DESC i, const void* devicePlane, bool rgba16f = false);
+        void SetTonemapper(zr_tonemapper t); void SetAutoExposure(bool b); void SetSaturation(float v); void SetAgXExp(float v);   // Display.cpp:565-619
+        void* GetOutput(SHADER_OUT_RES i) const;
+        void Render(Core::CommandList& cmdList);
+    private:
+        zr_params m_params{};
+    };
+
     struct IndirectLighting final : public RenderPassBase
     {
         enum class SHADER_OUT_RES { FINAL, COUNT };

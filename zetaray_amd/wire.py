@@ -101,7 +101,10 @@ class Params(C.Structure):
         ("m_max_temporal", C.c_uint32), ("m_max_spatial", C.c_uint32), ("alpha_min", C.c_float),
         ("presampling", C.c_uint32), ("num_sample_sets", C.c_uint32), ("sample_set_size", C.c_uint32),
         ("use_lvg", C.c_uint32), ("lvg_grid_dim", C.c_uint32), ("lvg_extents", C.c_float * 3), ("lvg_offset_y", C.c_float),
-        ("taa_blend_weight", C.c_float)]
+        ("taa_blend_weight", C.c_float),
+        ("ae_min_lum", C.c_float), ("ae_max_lum", C.c_float), ("ae_lum_map_exp", C.c_float), ("ae_adaptation_rate", C.c_float),
+        ("display_tonemapper", C.c_uint32), ("display_auto_exposure", C.c_uint32), ("display_saturation", C.c_float),
+        ("display_agx_exp", C.c_float)]
 
 
 class Counters(C.Structure):
@@ -136,7 +139,17 @@ def default_params() -> Params:
     p.lvg_extents[:] = (0.6, 0.45, 0.6)
     p.lvg_offset_y = 0.1
     p.taa_blend_weight = 0.1
+    set_post_defaults(p)
     return p
+
+
+TONEMAP_NONE, TONEMAP_NEUTRAL, TONEMAP_AGX_DEFAULT, TONEMAP_AGX_GOLDEN, TONEMAP_AGX_PUNCHY, TONEMAP_AGX_CUSTOM = range(6)
+
+
+def set_post_defaults(p):
+    """AutoExposure.h:73-81 and Display.cpp:69-74"""
+    p.ae_min_lum, p.ae_max_lum, p.ae_lum_map_exp, p.ae_adaptation_rate = 5e-3, 4.0, 0.5, 1.0
+    p.display_tonemapper, p.display_auto_exposure, p.display_saturation, p.display_agx_exp = TONEMAP_NEUTRAL, 1, 1.0, 1.0
 
 
 COMPOSIT_FIREFLY_FILTER = 1 << 10
