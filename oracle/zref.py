@@ -224,7 +224,7 @@ class RefPost:
         a, is16 = self._image(image)
         rh, rw = a.shape[:2]
         cbb = np.ascontiguousarray(cb)
-        dw, dh = int(cbb["display_width"]), int(cbb["display_height"])
+        dw, dh = int(np.asarray(cbb["display_width"]).reshape(-1)[0]), int(np.asarray(cbb["display_height"]).reshape(-1)[0])
         out = np.zeros((dh, dw, 4), np.float32)
         e = None if exposure2 is None else np.array(exposure2, np.float32).copy()
         l = None if lut is None else np.ascontiguousarray(lut, np.uint32)

@@ -398,6 +398,22 @@ def kat_unary(fn, x):
     return y
 
 
+def composite(scene, cb, mr_plane, sky_di=None, emissive_di=None, indirect=None, out=None):
+    """Compositing.hlsl main (in-scattering off).  mr_plane: the G-buffer's METALLIC_ROUGHNESS plane (h, w) u16 or (h, w, 2) u8; the DI / indirect
+    terms are (h, w, 4) f32 or None; `out` = the composited texture's previous content (alpha is kept).  Miss pixels show
+    Le_SkyWithSunDisk when a direct-lighting term is bound and the scene has a sky-view LUT."""
+    mr = np.ascontiguousarray(mr_plane)
+    h, w = mr.shape[:2]
+    mr8 = mr.view(np.uint8).reshape(h, w, 2)
+    planes = [None if p is None else np.ascontiguousarray(p, np.float32) for p in (sky_di, emissive_di, indirect)]
+    o = np.zeros((h, w, 4), np.float32) if out is None else np.ascontiguousarray(out, np.float32).copy()
+    cbb = np.ascontiguousarray(cb)
+    f = lib().zro_composite
+    f.argtypes = [C.c_void_p] * 7 + [C.c_uint32, C.c_uint32]
+    f(scene.h, cbb.ctypes.data, mr8.ctypes.data, *[None if p is None else p.ctypes.data for p in planes], o.ctypes.data, w, h)
+    return o
+
+
 def _post_image(image):
     a = np.ascontiguousarray(image)
     assert a.ndim == 3 and a.shape[2] == 4 and a.dtype in (np.uint16, np.float32), "image: (h, w, 4) u16 (RGBA16F bits) or f32"

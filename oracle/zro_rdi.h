@@ -4,7 +4,7 @@
 // zro_rdi.h: CPU restatement of ReSTIR DI for emissive lights (K5 / K6), USE_HALF_VECTOR_COPY_SHIFT == 0:
 //   DirectLighting/Emissive/ReSTIR_DI_Temporal.hlsl:29-390, ReSTIR_DI_Spatial.hlsl:24-192, Resampling.hlsli:10-521,
 //   PairwiseMIS.hlsli:11-231, Reservoir.hlsli:11-226, Util.hlsli:11-119, Params.hlsli; host order DirectLighting.cpp:166-296.
-// Pinned where the reference leaves it open: Le_SkyWithSunDisk for miss pixels = 0 (no sky model bound in this round);
+// Pinned where the reference leaves it open: Le_SkyWithSunDisk for miss pixels = 0 while the scene has no sky-view LUT;
 // ftou of a negative sample position = 0 (D3D rule); the spatial pass's WaveActiveSum runs over the 8x8 pixel group.
 #pragma once
 #include "zro_rpt.h"
@@ -441,8 +441,13 @@ static void Render(const Scene& sc, const zr_frame_constants& g, const zr_gbuffe
         float* o = finalRGBA + 4 * px;
         if (flags.invalid)
         {
-            // Le_SkyWithSunDisk pinned to 0 (no sky model bound): prev * (N > 1) + 0
-            if (accumulate) { const float k = g.num_frames_camera_static > 1 ? 1.0f : 0.0f; o[0] = o[0] * k + 0.0f; o[1] = o[1] * k + 0.0f; o[2] = o[2] * k + 0.0f; }
+            // ReSTIR_DI_Temporal.hlsl:274-286 (0 while no sky-view LUT is bound to the scene)
+            if (accumulate)
+            {
+                const float k = g.num_frames_camera_static > 1 ? 1.0f : 0.0f;
+                const float3 sky = sc.sky.data ? Light::Le_SkyWithSunDisk(x, y, g, sc.sky) : f3(0.0f);
+                o[0] = o[0] * k + sky.x; o[1] = o[1] * k + sky.y; o[2] = o[2] * k + sky.z;
+            }
             else { o[0] = o[1] = o[2] = 0; }
             continue;
         }

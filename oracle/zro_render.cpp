@@ -994,6 +994,36 @@ int zro_display(const void* image, int is_f16, uint32_t rw, uint32_t rh, uint32_
     return 0;
 }
 
+// Compositing.hlsl:30-125 (in-scattering off) over w x h pixels: mr = the G-buffer's METALLIC_ROUGHNESS plane (RG8_UNORM, 2 bytes / pixel);
+// sky_di / emissive_di / indirect: RGBA32F planes or null (the CB_COMPOSIT_FLAGS); out_rgba is read (alpha kept) and written
+int zro_composite(const zro_scene* h, const zr_frame_constants* cb, const uint8_t* mr, const float* sky_di, const float* emissive_di, const float* indirect,
+    float* out_rgba, uint32_t w, uint32_t ht)
+{
+    const zr_frame_constants& g_frame = *cb;
+    for (uint32_t y = 0; y < ht; y++) for (uint32_t x = 0; x < w; x++)
+    {
+        const size_t px = (size_t)y * w + x;
+        const RPT::GFlags flags = RPT::DecodeFlags((uint16_t)(mr[2 * px] | (mr[2 * px + 1] << 8)));      // GBuffer::DecodeMetallic of .x
+        float* o = out_rgba + 4 * px;
+        const bool accumulate = g_frame.accumulate && g_frame.camera_static;
+        if (flags.invalid && !accumulate)
+        {
+            const bool dirLighting = sky_di || emissive_di;
+            const float3 c = (dirLighting && h->s.sky.data) ? Light::Le_SkyWithSunDisk(x, y, g_frame, h->s.sky) : f3(0.0f);
+            o[0] = c.x; o[1] = c.y; o[2] = c.z;
+            continue;
+        }
+        const uint32_t numFramesAccumulated = accumulate ? g_frame.num_frames_camera_static : 1;
+        float3 color = f3(0.0f);
+        if (sky_di) color = f3(sky_di + 4 * px);
+        else if (emissive_di) color = color + f3(emissive_di + 4 * px);
+        if (indirect && !flags.emissive) color = color + f3(indirect + 4 * px);
+        color = color / (float)numFramesAccumulated;
+        o[0] = color.x; o[1] = color.y; o[2] = color.z;
+    }
+    return 0;
+}
+
 // FireflyFilter.hlsl:33-123 on an RGBA32F image (Jacobi reading of the in-place filter, see include/zetaray_amd.h)
 int zro_firefly(const float* in_rgba, const float* depth, float* out_rgba, uint32_t w, uint32_t h)
 {

@@ -393,20 +393,7 @@ struct State
     }
 };
 
-// Light::Le_SkyWithSunDisk, LightSource.hlsli:176-199
-static inline float3 Le_SkyWithSunDisk(const Scene& sc, const zr_frame_constants& g, uint32_t x, uint32_t y)
-{
-    const Camera cam = CurrCamera(g);
-    float3 wc = RT::GeneratePinholeCameraRay((int)x, (int)y, cam.renderDim, cam.aspect, cam.tanHalfFOV, cam.vbx, cam.vby, cam.vbz, cam.jitter);
-    float3 rayOrigin = f3(0.0f, 1e-1f, 0.0f);
-    rayOrigin.y += g.planet_radius;
-    float3 wTemp = wc;
-    wTemp.y = wTemp.y * g.sun_cos_angular_radius + zr_sqrt(1 - wc.y * wc.y) * g.sun_sin_angular_radius;
-    float t;
-    bool intersectedPlanet = Volume::IntersectRayPlanet(g.planet_radius, rayOrigin, wTemp, t);
-    if (dot(-wc, f3(g.sun_dir)) >= g.sun_cos_angular_radius && !intersectedPlanet) return f3(g.sun_illuminance);
-    return Light::Le_Sky(wc, sc.sky);
-}
+static inline float3 Le_SkyWithSunDisk(const Scene& sc, const zr_frame_constants& g, uint32_t x, uint32_t y) { return Light::Le_SkyWithSunDisk(x, y, g, sc.sky); }      // zro_sky.h
 
 // SkyDI::Render (SkyDI.cpp:135-259): K7 over all pixels, then K8
 static void Render(const Scene& sc, const zr_frame_constants& g, const zr_gbuffer_planes* gbCurr, const zr_gbuffer_planes* gbPrevPlanes,

@@ -174,5 +174,23 @@ static inline float3 Le_Sky(float3 wi, const SkyLUT& lut)
     return SampleSkyLUT(lut, uv);
 }
 
+// Light::Le_SkyWithSunDisk, LightSource.hlsli:176-199 (miss pixels of SkyDI, of the emissive DI pass and of Compositing)
+static inline float3 Le_SkyWithSunDisk(uint32_t DTid_x, uint32_t DTid_y, const zr_frame_constants& g_frame, const SkyLUT& envMap)
+{
+    float3 wc = RT::GeneratePinholeCameraRay((int)DTid_x, (int)DTid_y, f2((float)g_frame.render_width, (float)g_frame.render_height),
+        g_frame.aspect_ratio, g_frame.tan_half_fov, f3(g_frame.curr_view), f3(g_frame.curr_view + 4), f3(g_frame.curr_view + 8),
+        f2(g_frame.curr_camera_jitter[0], g_frame.curr_camera_jitter[1]));
+    float3 rayOrigin = f3(0, 1e-1f, 0);
+    rayOrigin.y += g_frame.planet_radius;
+    float3 wTemp = wc;
+    // cos(a - b) = cos a cos b + sin a sin b
+    wTemp.y = wTemp.y * g_frame.sun_cos_angular_radius + zr_sqrt(1 - wc.y * wc.y) * g_frame.sun_sin_angular_radius;
+    float t;
+    bool intersectedPlanet = Volume::IntersectRayPlanet(g_frame.planet_radius, rayOrigin, wTemp, t);
+    if (dot(-wc, f3(g_frame.sun_dir)) >= g_frame.sun_cos_angular_radius && !intersectedPlanet)
+        return f3(g_frame.sun_illuminance);
+    return Le_Sky(wc, envMap);
+}
+
 } // namespace Light
 } // namespace zro

@@ -900,3 +900,35 @@ def test_baseline_config1_goldens_on_gpu(api, scene_name, golden):
     got = r.final()
     assert np.array_equal(got.view(np.uint32), g["final"].view(np.uint32))
     assert tuple(r.p_indirect.read_counters()) == tuple(int(x) for x in g["counters"])
+
+
+def test_emissive_di_and_compositing_show_the_sky_behind_missing_geometry(api, cornell_emissive):
+    """ReSTIR_DI_Temporal.hlsl:274-286 and Compositing.hlsl:43-48: pixels without geometry take Light::Le_SkyWithSunDisk (sun disk or
+    sky-view LUT along the pixel's camera ray) once the scene has a sky-view LUT -- accumulated over static frames by the DI pass, written
+    directly by Compositing otherwise.  Emissive Cornell box at 16:9 (the box leaves side columns empty) with a ZR_PASS_SKY render."""
+    from oracle import zro
+    w, h = 128, 72
+    osc = zro.OracleScene(cornell_emissive)
+    r = api.Renderer(cornell_emissive, w, h, params=wire.default_params(), integrator=api.INTEGRATOR_RESTIR_PT)
+    prm = wire.default_params_di()
+    di = r.enable_direct(prm)
+    comp = r.enable_compositing()
+    r.p_sky = api.Pass(api.PASS_SKY, 256, 128)
+    odi, opt = zro.OracleRDI(osc, w, h), zro.OracleRPT(osc, w, h)
+    sun = np.array((0.05, -0.25, 0.97), np.float32)      # low sun in front of the camera: its disk lands in an empty side column or the sky does
+    for f in range(1, 4):
+        acc = f > 1      # frame 1: Compositing writes the sky; frames 2-3: the DI pass accumulates it
+        cb = _frame(cornell_emissive, w, h, f, accumulate=int(acc), camera_static=int(acc), num_frames_static=max(1, f - 1))
+        cb["sun_dir"] = sun / np.float32(np.linalg.norm(sun))
+        r.render_frame(cb)
+        osc.sky_lut(cb, 256, 128)
+        want_di = odi.render(cb, prm)
+        want_ind = opt.render(cb, wire.default_params())
+        got_di = di.download()
+        assert np.array_equal(got_di.view(np.uint32), want_di.view(np.uint32)), f"emissive DI, frame {f}"
+        planes, _keep = osc.gbuffer(cb)
+        want = zro.composite(osc, cb, planes[2].reshape(h, w), emissive_di=want_di, indirect=want_ind, out=None if f == 1 else want)
+        got = comp.download()
+        assert np.array_equal(got[..., :3].view(np.uint32), want[..., :3].view(np.uint32)), f"composited, frame {f}"
+        miss = ((planes[2].reshape(h, w) & 0xff) & 4) != 0
+        assert miss.any() and (got[miss][:, :3] > 0).all(), "sky must be visible where there is no geometry"

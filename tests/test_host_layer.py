@@ -177,11 +177,8 @@ def test_cpp_passes_render_post_chain():
         ind = opt.render(cbs[f], wire.default_params())
         sdi = osd.render(cbs[f], wire.default_params_sky_di())
         planes, _keep = osc.gbuffer(cbs[f])
-        # Compositing.hlsl:30-125 without accumulation: sky DI + indirect * !emissive, 0 for pixels without geometry
-        fl = planes[2].reshape(h, w) & 0xff
-        signal = np.zeros((h, w, 4), np.float32)
-        signal[..., :3] = sdi[..., :3] + ind[..., :3] * ((fl & 2) == 0)[..., None]
-        signal[(fl & 4) != 0] = 0
+        # Compositing.hlsl:30-125 without accumulation: sky DI + indirect * !emissive; pixels without geometry show the sky / sun disk
+        signal = zro.composite(osc, cbs[f], planes[2].reshape(h, w), sky_di=sdi, indirect=ind)
         hist = zro.taa(signal, planes[7].reshape(h, w), planes[3].reshape(h, w), hist, 0.1, f > 0)
     assert np.array_equal(comp.view(np.uint32)[..., :3], signal.view(np.uint32)[..., :3])
     assert np.array_equal(taa[..., :3], hist[..., :3])
@@ -227,10 +224,7 @@ def test_cpp_passes_render_post_chain_to_display():
         ind = opt.render(cbs[f], wire.default_params())
         sdi = osd.render(cbs[f], wire.default_params_sky_di())
         planes, _keep = osc.gbuffer(cbs[f])
-        fl = planes[2].reshape(h, w) & 0xff
-        signal = np.zeros((h, w, 4), np.float32)
-        signal[..., :3] = sdi[..., :3] + ind[..., :3] * ((fl & 2) == 0)[..., None]
-        signal[(fl & 4) != 0] = 0
+        signal = zro.composite(osc, cbs[f], planes[2].reshape(h, w), sky_di=sdi, indirect=ind)
         hist = zro.taa(signal, planes[7].reshape(h, w), planes[3].reshape(h, w), hist, 0.1, f > 0)
         _, e = zro.auto_exposure(hist, prm, cbs[f]["dt"], e)
     want, want_srgb = zro.display(hist, prm, (w, h), e, lut)

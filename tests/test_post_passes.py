@@ -16,6 +16,10 @@ from zetaray_amd import api  # noqa: E402
 GOLD = os.path.join(ROOT, "tests", "golden", "ref_post.npz")
 
 
+def _i(x):
+    return int(np.asarray(x).reshape(-1)[0])
+
+
 def bits(a):
     a = np.ascontiguousarray(a)
     return a.view(np.uint32) if a.dtype == np.float32 else a
@@ -57,7 +61,7 @@ def test_oracle_auto_exposure_reproduces_reference_shaders(case):
 def test_oracle_display_reproduces_reference_shader(case):
     gold = np.load(GOLD)
     name, img, prm, cb = display_inputs(case)
-    rgba, srgb = zro.display(img, prm, (int(cb["display_width"]), int(cb["display_height"])), pc.DISPLAY_EXPOSURE, api.load_tonemap_lut())
+    rgba, srgb = zro.display(img, prm, (_i(cb["display_width"]), _i(cb["display_height"])), pc.DISPLAY_EXPOSURE, api.load_tonemap_lut())
     assert_same(rgba, gold[f"{name}/rgba"], name)
     # the 8-bit back buffer: monotone in the linear value, 0 / 255 at the ends, NaN -> 0
     lin = rgba[..., :3]
@@ -84,7 +88,7 @@ def test_oracle_post_matches_reference_shaders_live():
             p2 = pc.params(tm, f != 2, 0.75, 1.2)
             cbd = pc.frame_constants(render=(160, 90), display=(200, 113) if f == 0 else None)
             want = ref.display(src, p2, cbd, e_ref, lut)
-            got, _ = zro.display(src, p2, (int(cbd["display_width"]), int(cbd["display_height"])), e_ref, lut)
+            got, _ = zro.display(src, p2, (_i(cbd["display_width"]), _i(cbd["display_height"])), e_ref, lut)
             assert_same(got, want, f"live display {tm} frame {f}")
 
 
@@ -130,7 +134,7 @@ def test_hip_display_reproduces_reference_shader(case, tiny_scene):
     import torch
     gold = np.load(GOLD)
     name, img, prm, cb = display_inputs(case)
-    dw, dh = int(cb["display_width"]), int(cb["display_height"])
+    dw, dh = _i(cb["display_width"]), _i(cb["display_height"])
     p = api.Pass(api.PASS_DISPLAY, dw, dh, params=prm)
     p.set_tonemap_lut()
     dev, exp = _upload(torch, img), _upload(torch, pc.DISPLAY_EXPOSURE)

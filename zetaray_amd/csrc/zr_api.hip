@@ -300,10 +300,11 @@ __global__ void __launch_bounds__(256) k_selftest_half(unsigned long long* bad)
 }
 
 // Compositing: pure streaming kernel (2 + 16 + 16 B read, 16 B written per pixel)
-__global__ void __launch_bounds__(256) k_composite(zr_frame_constants g, const uint16_t* mr, const F4* skyDI, const F4* emissiveDI, const F4* indirect, F4* out, uint32_t n)
+__global__ void __launch_bounds__(256) k_composite(zr_frame_constants g, const uint16_t* mr, const F4* skyDI, const F4* emissiveDI, const F4* indirect, F4* out, uint32_t n,
+    SkyLutView sky, uint32_t w)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) out[i] = CompositePixel(g, mr[i], skyDI, emissiveDI, indirect, i, out[i]);
+    if (i < n) out[i] = CompositePixel(g, mr[i], skyDI, emissiveDI, indirect, i, out[i], sky, i % w, i / w);
 }
 
 // Firefly filter (FireflyFilter.hlsl): a 3 x 3 stencil over RGBA32F + depth.  A block filters a 64 x 16 pixel tile, 4 pixels per thread;
@@ -1735,7 +1736,7 @@ static int RenderTAA(zr_pass* p, hipStream_t s, const zr_frame_constants* cb, zr
     return ZR_OK;
 }
 
-static int RenderCompositing(zr_pass* p, hipStream_t s, const zr_frame_constants* cb, zr_gbuffer* gb)
+static int RenderCompositing(zr_pass* p, hipStream_t s, const zr_frame_constants* cb, const zr_scene* sc, zr_gbuffer* gb)
 {
     if (!gb || gb->w != p->w || gb->h != p->h) return Fail(ZR_ERR_INVALID_ARG, "COMPOSITING needs a gbuffer of the pass size");
     const uint32_t n = p->w * p->h;
@@ -1744,7 +1745,7 @@ static int RenderCompositing(zr_pass* p, hipStream_t s, const zr_frame_constants
     const bool firefly = (p->params.flags & ZR_COMPOSIT_FIREFLY_FILTER) != 0;
     F4* composited = firefly ? p->firstBOP.p : (F4*)p->finalRGBA.p;
     hipLaunchKernelGGL(k_composite, dim3((n + 255) / 256), dim3(256), 0, s, *cb, (const uint16_t*)gb->Planes()[ZR_GB_METALLIC_ROUGHNESS].p, p->compIn[ZR_IN_SKY_DI],
-        p->compIn[ZR_IN_EMISSIVE_DI], p->compIn[ZR_IN_INDIRECT], composited, n);
+        p->compIn[ZR_IN_EMISSIVE_DI], p->compIn[ZR_IN_INDIRECT], composited, n, FrameView(sc, cb).sky, p->w);
     TimerEnd(p, s);
     if (firefly)
     {
@@ -1856,7 +1857,7 @@ int zr_pass_render_stage(zr_pass* p, void* stream, const zr_frame_constants* cb,
     case ZR_PASS_INDIRECT: return RenderIndirect(p, s, cb, sc, gb, stages);
     case ZR_PASS_DI_EMISSIVE: return RenderDirectEmissive(p, s, cb, sc, gb, stages);
     case ZR_PASS_DI_SKY: return RenderDirectSky(p, s, cb, sc, gb, stages);
-    case ZR_PASS_COMPOSITING: return (stages & ZR_STAGE_SPATIAL) ? RenderCompositing(p, s, cb, gb) : ZR_OK;
+    case ZR_PASS_COMPOSITING: return (stages & ZR_STAGE_SPATIAL) ? RenderCompositing(p, s, cb, sc, gb) : ZR_OK;
     case ZR_PASS_SKY: return (stages & ZR_STAGE_TEMPORAL) ? RenderSky(p, s, cb, const_cast<zr_scene*>(sc)) : ZR_OK;
     case ZR_PASS_TAA: return (stages & ZR_STAGE_SPATIAL) ? RenderTAA(p, s, cb, gb) : ZR_OK;
     case ZR_PASS_AUTO_EXPOSURE: return (stages & ZR_STAGE_SPATIAL) ? RenderAutoExposure(p, s, cb) : ZR_OK;

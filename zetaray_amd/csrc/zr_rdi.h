@@ -5,7 +5,7 @@
 // Resampling.hlsli:10-521, PairwiseMIS.hlsli:11-231, Reservoir.hlsli:11-226, Util.hlsli:11-119, Params.hlsli;
 // host order DirectLighting.cpp:166-296.  Persistent state in the reference's formats: two reservoir sets x (A RGBA32_UINT:
 // bary unorm2 | le half2 | le.z half + M << 16 | lightIdx, B RG32F: w_sum, W) = 24 B/px, target RGBA32F.
-// Pinned: Le_SkyWithSunDisk for miss pixels = 0 (no sky model bound in this round); ftou of a negative neighbour position
+// Pinned: Le_SkyWithSunDisk for miss pixels = 0 while the scene has no sky-view LUT (no ZR_PASS_SKY rendered yet); ftou of a negative neighbour position
 // = 0 (D3D rule); the spatial pass's WaveActiveSum(disoccluded) runs over the 8x8 pixel group = one wave64.
 #pragma once
 #include "zr_rpt.h"
@@ -368,8 +368,13 @@ ZR_HD void TemporalPixel(const DiFrame& F, const zr_frame_constants& g, uint32_t
     float* o = F.finalRGBA + 4 * px;
     if (flags.invalid)
     {
-        // Le_SkyWithSunDisk pinned to 0 (no sky model bound): prev * (N > 1) + 0
-        if (prm.accumulate) { const float k = g.num_frames_camera_static > 1 ? 1.0f : 0.0f; o[0] = o[0] * k + 0.0f; o[1] = o[1] * k + 0.0f; o[2] = o[2] * k + 0.0f; }
+        // ReSTIR_DI_Temporal.hlsl:274-286: prev * (N > 1) + Le_SkyWithSunDisk (0 while the scene has no sky-view LUT: no ZR_PASS_SKY rendered)
+        if (prm.accumulate)
+        {
+            const float k = g.num_frames_camera_static > 1 ? 1.0f : 0.0f;
+            const V3 sky = F.sc.sky.data ? Le_SkyWithSunDisk(F.sc.sky, g, x, y) : v3(0.0f);
+            o[0] = o[0] * k + sky.x; o[1] = o[1] * k + sky.y; o[2] = o[2] * k + sky.z;
+        }
         else { o[0] = 0; o[1] = 0; o[2] = 0; }
         return;
     }

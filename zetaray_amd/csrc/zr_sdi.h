@@ -295,20 +295,7 @@ ZR_HD void TemporalResample(const Ctx& c, TemporalCandidate candidate, V3 pos, V
     r.M = newM;
 }
 
-// Light::Le_SkyWithSunDisk, LightSource.hlsli:176-199
-ZR_HD V3 Le_SkyWithSunDisk(const SceneView& sc, const zr_frame_constants& g, uint32_t x, uint32_t y)
-{
-    const Camera cam = CurrCamera(g);
-    V3 wc = GeneratePinholeCameraRay((int)x, (int)y, cam.renderDim, cam.aspect, cam.tanHalfFOV, cam.vbx, cam.vby, cam.vbz, cam.jitter);
-    V3 rayOrigin = v3(0.0f, 1e-1f, 0.0f);
-    rayOrigin.y += g.planet_radius;
-    V3 wTemp = wc;
-    wTemp.y = wTemp.y * g.sun_cos_angular_radius + zr_sqrt(1 - wc.y * wc.y) * g.sun_sin_angular_radius;
-    float t;
-    bool intersectedPlanet = IntersectRayPlanet(g.planet_radius, rayOrigin, wTemp, t);
-    if (dot(-wc, v3p(g.sun_dir)) >= g.sun_cos_angular_radius && !intersectedPlanet) return v3(g.sun_illuminance);
-    return Le_Sky(wc, sc.sky);
-}
+ZR_HD V3 Le_SkyWithSunDisk(const SceneView& sc, const zr_frame_constants& g, uint32_t x, uint32_t y) { return zr::Le_SkyWithSunDisk(sc.sky, g, x, y); }      // zr_sky.h
 
 // K7: SkyDI_Temporal.hlsl main (:169-303) + InitialCandidatesAndTemporalReuse (:130-167) for one pixel
 ZR_HD void TemporalPixel(const SkyFrame& F, const zr_frame_constants& g, uint32_t x, uint32_t y, TravStack stack, uint32_t* cnt)

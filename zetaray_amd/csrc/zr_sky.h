@@ -149,4 +149,20 @@ ZR_HD V3 Le_Sky(V3 wi, const SkyLutView& lut)                // LightSource.hlsl
 // the target functor NEE_Sky hands to the lobe RIS (NEE.hlsli:68-84)
 struct SkyIncidentRadiance { SkyLutView lut; ZR_HDM V3 operator()(V3 w) const { return Le_Sky(w, lut); } };
 
+// Light::Le_SkyWithSunDisk, LightSource.hlsli:176-199: what a pixel without geometry shows -- the sun disk or the sky-view LUT along the
+// pixel's pinhole camera ray (used by SkyDI, by the emissive DI pass and by Compositing for miss pixels)
+ZR_HD V3 Le_SkyWithSunDisk(const SkyLutView& lut, const zr_frame_constants& g, uint32_t x, uint32_t y)
+{
+    V3 wc = GeneratePinholeCameraRay((int)x, (int)y, v2((float)g.render_width, (float)g.render_height), g.aspect_ratio, g.tan_half_fov,
+        Row3(g.curr_view, 0), Row3(g.curr_view, 1), Row3(g.curr_view, 2), v2(g.curr_camera_jitter[0], g.curr_camera_jitter[1]));
+    V3 rayOrigin = v3(0.0f, 1e-1f, 0.0f);
+    rayOrigin.y += g.planet_radius;
+    V3 wTemp = wc;
+    wTemp.y = wTemp.y * g.sun_cos_angular_radius + zr_sqrt(1 - wc.y * wc.y) * g.sun_sin_angular_radius;
+    float t;
+    bool intersectedPlanet = IntersectRayPlanet(g.planet_radius, rayOrigin, wTemp, t);
+    if (dot(-wc, v3p(g.sun_dir)) >= g.sun_cos_angular_radius && !intersectedPlanet) return v3(g.sun_illuminance);
+    return Le_Sky(wc, lut);
+}
+
 } // namespace zr

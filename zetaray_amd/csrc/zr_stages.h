@@ -930,12 +930,18 @@ ZR_HD zr_presampled_tri PresampleEmissive(const SceneView& sc, uint32_t i, uint3
     return s;
 }
 
-// Compositing.hlsl:30-125 for one pixel (in-scattering off; Le_SkyWithSunDisk of miss pixels pinned to 0: no sky model bound)
-ZR_HD F4 CompositePixel(const zr_frame_constants& g, uint16_t mrp, const F4* skyDI, const F4* emissiveDI, const F4* indirect, size_t px, F4 prevOut)
+// Compositing.hlsl:30-125 for one pixel (in-scattering off).  Miss pixels show Le_SkyWithSunDisk when a direct-lighting term is bound
+// (:43-48); `sky` = the scene's sky-view LUT (data == null -> 0: no ZR_PASS_SKY rendered)
+ZR_HD F4 CompositePixel(const zr_frame_constants& g, uint16_t mrp, const F4* skyDI, const F4* emissiveDI, const F4* indirect, size_t px, F4 prevOut,
+    const SkyLutView& sky, uint32_t x, uint32_t y)
 {
     const uint32_t fl = (uint32_t)zr_fma(zr_div255((float)(mrp & 0xff)), 255.0f, 0.5f);
     const bool accumulate = g.accumulate && g.camera_static;
-    if ((fl & ZR_GBUF_INVALID) && !accumulate) return f4(v3(0.0f), prevOut.w);
+    if ((fl & ZR_GBUF_INVALID) && !accumulate)
+    {
+        const bool dirLighting = skyDI || emissiveDI;
+        return f4((dirLighting && sky.data) ? Le_SkyWithSunDisk(sky, g, x, y) : v3(0.0f), prevOut.w);
+    }
     const uint32_t numFramesAccumulated = accumulate ? g.num_frames_camera_static : 1u;
     V3 color = v3(0.0f);
     if (skyDI) color = xyz(skyDI[px]);
