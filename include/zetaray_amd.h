@@ -135,6 +135,9 @@ typedef struct zr_params {
     uint32_t display_auto_exposure; /* 1 */
     float    display_saturation;    /* 1.0 (NEUTRAL, AgX_CUSTOM) */
     float    display_agx_exp;       /* 1.0 (AgX_CUSTOM) */
+    /* ZR_PASS_INDIRECT: enum class TEXTURE_FILTER (IndirectLighting_Common.h:69-77), the sampler of the material maps at path vertices
+       (cb_ReSTIR_*::TexFilterDescHeapIdx): ZR_TEX_FILTER_MIP0 / TRI_LINEAR / ANISOTROPIC_2X / ANISOTROPIC_4X / ANISOTROPIC_16X (zr_texture.h) */
+    uint32_t tex_filter;            /* ZR_TEX_FILTER_ANISOTROPIC_4X = 3 */
 } zr_params;
 
 /* enum class Tonemapper, Display_Common.h:21-30 */

@@ -121,9 +121,10 @@ ZR_HD void zr_tex_sample_level(const zr_tex_heap* T, uint32_t tex, float u, floa
     }
 }
 
-/* SampleGrad(g_samAnisotropicWrap, uv, ddx, ddy), MaxAnisotropy 4 */
-ZR_HD void zr_tex_sample_grad(const zr_tex_heap* T, uint32_t tex, float u, float v, float ddx_u, float ddx_v,
-                              float ddy_u, float ddy_v, float out[4])
+/* SampleGrad(sampler, uv, ddx, ddy) with an anisotropic sampler of MaxAnisotropy = max_aniso (1 = the trilinear sampler): N =
+   min(ceil(pmax / pmin), max_aniso) probes along the major axis at lod = log2(pmax / N) */
+ZR_HD void zr_tex_sample_grad_aniso(const zr_tex_heap* T, uint32_t tex, float u, float v, float ddx_u, float ddx_v,
+                                    float ddy_u, float ddy_v, int max_aniso, float out[4])
 {
     const zr_texture_desc* d = &T->descs[tex];
     const float w = (float)d->width, h = (float)d->height;
@@ -133,8 +134,9 @@ ZR_HD void zr_tex_sample_grad(const zr_tex_heap* T, uint32_t tex, float u, float
     float pmax = aMajor ? pa : pb;
     const float pmin = aMajor ? pb : pa;
     const float du = aMajor ? ddx_u : ddy_u, dv = aMajor ? ddx_v : ddy_v;
-    /* N = min(ceil(pmax / pmin), 4) without the division; NaN -> 4 */
-    const int n = !(pmax <= pmin) ? (!(pmax <= 2.0f * pmin) ? (!(pmax <= 3.0f * pmin) ? 4 : 3) : 2) : 1;
+    /* N = min(ceil(pmax / pmin), max_aniso) without the division; NaN -> max_aniso */
+    int n = 1;
+    for (int k = 1; k < max_aniso; k++) { if (!(pmax <= (float)k * pmin)) n = k + 1; else break; }
     pmax = zr_min(pmax, 1.0e30f);
     const float lod = pmax > 0.0f ? zr_log2(pmax / (float)n) : 0.0f;
     if (n == 1) { zr_tex_sample_level(T, tex, u, v, lod, out); return; }
@@ -147,6 +149,23 @@ ZR_HD void zr_tex_sample_grad(const zr_tex_heap* T, uint32_t tex, float u, float
         for (int k = 0; k < 4; k++) acc[k] = acc[k] + c[k];
     }
     for (int k = 0; k < 4; k++) out[k] = acc[k] / (float)n;
+}
+/* SampleGrad(g_samAnisotropicWrap_4x, uv, ddx, ddy): the default material sampler (TEXTURE_FILTER::ANISOTROPIC_4X) */
+ZR_HD void zr_tex_sample_grad(const zr_tex_heap* T, uint32_t tex, float u, float v, float ddx_u, float ddx_v,
+                              float ddy_u, float ddy_v, float out[4])
+{ zr_tex_sample_grad_aniso(T, tex, u, v, ddx_u, ddx_v, ddy_u, ddy_v, 4, out); }
+
+/* SampleGrad with the sampler that enum class TEXTURE_FILTER (IndirectLighting_Common.h:69-77) selects -- IndirectLighting.cpp:21-33 maps
+   it to the static samplers of RendererCore.cpp:450-553: MIP0 = g_samMip0 (trilinear, MaxLOD 0: always mip 0), TRI_LINEAR =
+   g_samLinearWrap (lod from the longer gradient), ANISOTROPIC_2X / _4X / _16X = the anisotropic samplers with that MaxAnisotropy */
+enum { ZR_TEX_FILTER_MIP0 = 0, ZR_TEX_FILTER_TRI_LINEAR = 1, ZR_TEX_FILTER_ANISOTROPIC_2X = 2, ZR_TEX_FILTER_ANISOTROPIC_4X = 3,
+       ZR_TEX_FILTER_ANISOTROPIC_16X = 4, ZR_TEX_FILTER_COUNT = 5 };
+ZR_HD void zr_tex_sample_grad_filter(const zr_tex_heap* T, uint32_t tex, uint32_t filter, float u, float v, float ddx_u, float ddx_v,
+                                     float ddy_u, float ddy_v, float out[4])
+{
+    if (filter == ZR_TEX_FILTER_MIP0) { zr_tex_sample_level(T, tex, u, v, 0.0f, out); return; }
+    const int max_aniso = filter == ZR_TEX_FILTER_TRI_LINEAR ? 1 : (filter == ZR_TEX_FILTER_ANISOTROPIC_2X ? 2 : (filter == ZR_TEX_FILTER_ANISOTROPIC_16X ? 16 : 4));
+    zr_tex_sample_grad_aniso(T, tex, u, v, ddx_u, ddx_v, ddy_u, ddy_v, max_aniso, out);
 }
 
 #endif /* ZR_TEXTURE_H */

@@ -276,17 +276,10 @@ template<class T> struct Texture2D
     T SampleGrad(const SamplerState& sam, const float2& uv, const float2& ddx, const float2& ddy) const
     {
         float o[4]; uint32_t uu[4] = {0, 0, 0, 0};
-        // the ABI builds ANISOTROPIC_4X (zr_texture.h); the linear sampler is the ddy = ddx degenerate case of the same recipe
-        const bool aniso = sam.kind == SamplerState::ANISO_WRAP || sam.kind == SamplerState::ANISO_WRAP_2X || sam.kind == SamplerState::ANISO_WRAP_4X;
-        if (aniso) zr_tex_sample_grad(s->heap, s->heapIdx, uv.x, uv.y, ddx.x, ddx.y, ddy.x, ddy.y, o);
-        else
-        {
-            const float ax = ddx.x * (float)s->heap->descs[s->heapIdx].width, ay = ddx.y * (float)s->heap->descs[s->heapIdx].height;
-            const float bx = ddy.x * (float)s->heap->descs[s->heapIdx].width, by = ddy.y * (float)s->heap->descs[s->heapIdx].height;
-            const float pa = zr_sqrt(ax * ax + ay * ay), pb = zr_sqrt(bx * bx + by * by);
-            float pmax = zr_min(pa >= pb ? pa : pb, 1.0e30f);
-            zr_tex_sample_level(s->heap, s->heapIdx, uv.x, uv.y, pmax > 0.0f ? zr_log2(pmax) : 0.0f, o);
-        }
+        // the ABI's software filtering (zr_texture.h): MaxAnisotropy per sampler (RendererCore.cpp:450-553), g_samMip0 clamps to mip 0
+        const uint32_t filter = sam.kind == SamplerState::MIP0 ? ZR_TEX_FILTER_MIP0 : (sam.kind == SamplerState::ANISO_WRAP ? ZR_TEX_FILTER_ANISOTROPIC_16X :
+            (sam.kind == SamplerState::ANISO_WRAP_2X ? ZR_TEX_FILTER_ANISOTROPIC_2X : (sam.kind == SamplerState::ANISO_WRAP_4X ? ZR_TEX_FILTER_ANISOTROPIC_4X : ZR_TEX_FILTER_TRI_LINEAR)));
+        zr_tex_sample_grad_filter(s->heap, s->heapIdx, filter, uv.x, uv.y, ddx.x, ddx.y, ddy.x, ddy.y, o);
         return Lanes<T>::get(o, uu);
     }
 };

@@ -61,7 +61,7 @@ int zrefp_gi_render(RefScene* r, GiState* S, const zr_frame_constants* cb, const
     L.DispatchDimX_NumGroupsInTile = ((RESTIR_GI_TEMPORAL_TILE_WIDTH * dy) << 16) | dx;
     L.SampleSetSize_NumSampleSets = prm->presampling ? ((prm->num_sample_sets << 16) | prm->sample_set_size) : 0u;
     L.M_max = prm->m_max_temporal; L.MaxNonTrBounces = prm->max_non_tr_bounces; L.MaxGlossyTrBounces = prm->max_glossy_tr_bounces;
-    L.TexFilterDescHeapIdx = SamplerState::ANISO_WRAP_4X;
+    L.TexFilterDescHeapIdx = EnumToSamplerIdx(prm->tex_filter);
     ZrDispatch d; memset(&d, 0, sizeof(d));
     d.scene = r; d.heap = &H; d.frame_cb = &g; d.local_cb = &L; d.local_cb_bytes = sizeof(L); d.groups_x = dx; d.groups_y = dy;
     zrefp_shader_gi(&d);

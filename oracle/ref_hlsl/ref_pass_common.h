@@ -29,6 +29,10 @@ struct RefScene
     std::unique_ptr<RefScene> prevHolder;      // the scene as it was before the last zrefp_scene_update_instances (RT_SCENE_BVH_PREV etc.)
 };
 
+// EnumToSamplerIdx, IndirectLighting.cpp:21-33: TEXTURE_FILTER (zr_params.tex_filter) -> static sampler index (RendererCore.cpp:547-555)
+static inline uint32_t EnumToSamplerIdx(uint32_t f)
+{ return f == 0 ? 0u : (f == 1 ? 3u : (f == 2 ? 6u : (f == 3 ? 7u : 5u))); }
+
 static inline void BindPlane(DescriptorHeap& h, uint32_t slot, void* data, uint32_t w, uint32_t ht, int fmt)
 { TexStorage& s = h.table[slot]; s.data = data; s.w = w; s.h = ht; s.d = 1; s.fmt = fmt; }
 

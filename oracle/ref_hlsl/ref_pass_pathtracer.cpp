@@ -37,6 +37,7 @@ extern "C" int zrefp_pathtrace_render(RefScene* r, const zr_frame_constants* cb,
     L.DispatchDimX_NumGroupsInTile = ((RESTIR_GI_TEMPORAL_TILE_WIDTH * dimY) << 16) | dimX;         // IndirectLighting.cpp:247-249
     L.SampleSetSize_NumSampleSets = prm->presampling ? ((prm->num_sample_sets << 16) | prm->sample_set_size) : 0u;   // IndirectLighting.cpp:153-165
     L.MaxNonTrBounces = prm->max_non_tr_bounces; L.MaxGlossyTrBounces = prm->max_glossy_tr_bounces; L.M_max = prm->m_max_temporal;
+    L.TexFilterDescHeapIdx = EnumToSamplerIdx(prm->tex_filter);      // IndirectLighting.cpp:21-33, 1565
     hlsl::g_bvh.scene = &r->sc;
     hlsl::g_frameMeshData = StructuredBuffer<hlsl::RT::MeshInstance>((const hlsl::RT::MeshInstance*)r->sc.instances.data(), (uint32_t)r->sc.instances.size());
     hlsl::g_vertices = StructuredBuffer<hlsl::Vertex>((const hlsl::Vertex*)r->sc.vertices.data(), (uint32_t)r->sc.vertices.size());

@@ -119,7 +119,7 @@ int zrefp_rpt_render(RefScene* r, RptState* S, const zr_frame_constants* cb, con
     // ---- constructor / parameter state: IndirectLighting.cpp:146-165
     cb_ReSTIR_PT_PathTrace& PT = S->cbPT; cb_ReSTIR_PT_Reuse& RU = S->cbReuse;
     memset(&PT, 0, sizeof(PT)); memset(&RU, 0, sizeof(RU));
-    const uint32_t texFilter = SamplerState::ANISO_WRAP_4X;                 // EnumToSamplerIdx(TEXTURE_FILTER::ANISOTROPIC_4X)
+    const uint32_t texFilter = EnumToSamplerIdx(prm->tex_filter);
     PT.Alpha_min = RU.Alpha_min = prm->alpha_min;
     PT.TexFilterDescHeapIdx = texFilter;
     PT.Packed = RU.Packed = prm->max_non_tr_bounces | (prm->max_glossy_tr_bounces << PACKED_INDEX::NUM_GLOSSY_BOUNCES) |

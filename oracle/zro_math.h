@@ -406,11 +406,12 @@ namespace Sampling {
 }
 
 namespace RT {
-    // RT.hlsli:233-241
+    // RT.hlsli:233-241.  The parameter is `uint2 pixel`: the ray differentials' auxiliary pixel int2(x, y - 1) (RT.hlsli:332, GBufferRT.hlsli:41)
+    // wraps to 4294967295 for the top row of the screen, and that is the value the float conversion sees
     static inline float3 GeneratePinholeCameraRay_CS(int px, int py, float2 renderDim, float aspectRatio,
         float tanHalfFOV, float2 jitter)
     {
-        float2 uv = {((float)px + 0.5f + jitter.x) / renderDim.x, ((float)py + 0.5f + jitter.y) / renderDim.y};
+        float2 uv = {((float)(uint32_t)px + 0.5f + jitter.x) / renderDim.x, ((float)(uint32_t)py + 0.5f + jitter.y) / renderDim.y};
         float2 ndc = Math::NDCFromUV(uv);
         return f3(ndc.x * aspectRatio * tanHalfFOV, ndc.y * tanHalfFOV, 1);
     }

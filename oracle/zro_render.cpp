@@ -336,14 +336,14 @@ static void RenderGBuffer(const Scene& sc, const zr_frame_constants& g, GBView g
         if (mat.GetBaseColorTex() != ZR_INVALID_TEX)
         {
             float c[4];
-            zr_tex_sample_grad(&sc.tex, g.base_color_maps_desc_heap_offset + mat.GetBaseColorTex(), uv.x, uv.y, grads.x, grads.y, grads.z, grads.w, c);
+            zr_tex_sample_grad_aniso(&sc.tex, g.base_color_maps_desc_heap_offset + mat.GetBaseColorTex(), uv.x, uv.y, grads.x, grads.y, grads.z, grads.w, 16, c);      // g_samAnisotropicWrap: MaxAnisotropy 16 (GBufferRT.hlsli:204-248, RendererCore.cpp:508-521)
             baseColor = baseColor * f3(c[0], c[1], c[2]);
         }
         // avoid normal mapping if tangent = (0, 0, 0), which results in NaN
         if (mat.GetNormalTex() != ZR_INVALID_TEX && zr_abs(dot(tangent, tangent)) > 1e-6f)
         {
             float c[4];
-            zr_tex_sample_grad(&sc.tex, g.normal_maps_desc_heap_offset + mat.GetNormalTex(), uv.x, uv.y, grads.x, grads.y, grads.z, grads.w, c);
+            zr_tex_sample_grad_aniso(&sc.tex, g.normal_maps_desc_heap_offset + mat.GetNormalTex(), uv.x, uv.y, grads.x, grads.y, grads.z, grads.w, 16, c);      // g_samAnisotropicWrap: MaxAnisotropy 16 (GBufferRT.hlsli:204-248, RendererCore.cpp:508-521)
             shadingNormal = Math::TangentSpaceToWorldSpace(f2(c[0], c[1]), tangent, normal, normalScale);
         }
         if (mat.DoubleSided() && dot(wo, normal) < 0) { shadingNormal = shadingNormal * -1.0f; dndu = dndu * -1.0f; dndv = dndv * -1.0f; }
@@ -357,7 +357,7 @@ static void RenderGBuffer(const Scene& sc, const zr_frame_constants& g, GBView g
         if (mat.GetMetallicRoughnessTex() != ZR_INVALID_TEX)
         {
             float c[4];
-            zr_tex_sample_grad(&sc.tex, g.metallic_roughness_maps_desc_heap_offset + mat.GetMetallicRoughnessTex(), uv.x, uv.y, grads.x, grads.y, grads.z, grads.w, c);
+            zr_tex_sample_grad_aniso(&sc.tex, g.metallic_roughness_maps_desc_heap_offset + mat.GetMetallicRoughnessTex(), uv.x, uv.y, grads.x, grads.y, grads.z, grads.w, 16, c);      // g_samAnisotropicWrap: MaxAnisotropy 16 (GBufferRT.hlsli:204-248, RendererCore.cpp:508-521)
             metallic *= c[0];
             roughness *= c[1];
         }
@@ -954,7 +954,7 @@ int zro_gbuffer_render(const zro_scene* h, const zr_frame_constants* cb, zr_gbuf
 int zro_pathtrace_render(const zro_scene* h, const zr_frame_constants* cb, const zr_gbuffer_planes* planes,
     const zr_params* prm, float* final_rgba, zr_counters* counters)
 {
-    h->s.counters = Counters(); h->s.LatchHeapOffsets(*cb);
+    h->s.counters = Counters(); h->s.LatchHeapOffsets(*cb); h->s.texFilter = prm->tex_filter;
     RenderPathTracer(h->s, *cb, GBView(planes), *prm, final_rgba);
     if (counters) { counters->n_closest = h->s.counters.n_closest; counters->n_shadow = h->s.counters.n_shadow; }
     return 0;
@@ -1138,7 +1138,7 @@ void zro_rpt_reset_temporal(zro_rpt* r) { r->st.temporalValid = false; }
 int zro_rpt_render(const zro_scene* h, zro_rpt* r, const zr_frame_constants* cb, const zr_gbuffer_planes* curr,
     const zr_gbuffer_planes* prev, const zr_params* prm, float* final_rgba, zr_counters* counters)
 {
-    h->s.counters = Counters(); h->s.LatchHeapOffsets(*cb);
+    h->s.counters = Counters(); h->s.LatchHeapOffsets(*cb); h->s.texFilter = prm->tex_filter;
     RPT::Render(h->s, *cb, curr, prev, *prm, r->st, final_rgba);
     if (counters) { counters->n_closest = h->s.counters.n_closest; counters->n_shadow = h->s.counters.n_shadow; }
     return 0;
@@ -1221,7 +1221,7 @@ void zro_rgi_reset_temporal(zro_rgi* r) { r->st.temporalValid = false; }
 int zro_rgi_render(const zro_scene* h, zro_rgi* r, const zr_frame_constants* cb, const zr_gbuffer_planes* curr, const zr_gbuffer_planes* prev,
     const zr_params* prm, float* final_rgba, zr_counters* counters)
 {
-    h->s.counters = Counters(); h->s.LatchHeapOffsets(*cb);
+    h->s.counters = Counters(); h->s.LatchHeapOffsets(*cb); h->s.texFilter = prm->tex_filter;
     RGI::Render(h->s, *cb, curr, prev, *prm, r->st, final_rgba);
     if (counters) { counters->n_closest = h->s.counters.n_closest; counters->n_shadow = h->s.counters.n_shadow; }
     return 0;

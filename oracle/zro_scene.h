@@ -96,8 +96,11 @@ struct Scene
     std::vector<uint8_t> texels;
     zr_tex_heap tex = {nullptr, nullptr, nullptr, 0};
     mutable uint32_t baseColorMapsOffset = 0, normalMapsOffset = 0, mrMapsOffset = 0, emissiveMapsOffset = 0;
+    // TEXTURE_FILTER of the indirect-lighting pass being rendered (cb_ReSTIR_*::TexFilterDescHeapIdx); the other passes use ANISOTROPIC_4X
+    mutable uint32_t texFilter = ZR_TEX_FILTER_ANISOTROPIC_4X;
     void LatchHeapOffsets(const zr_frame_constants& g) const
     {
+        texFilter = ZR_TEX_FILTER_ANISOTROPIC_4X;
         baseColorMapsOffset = g.base_color_maps_desc_heap_offset; normalMapsOffset = g.normal_maps_desc_heap_offset;
         mrMapsOffset = g.metallic_roughness_maps_desc_heap_offset; emissiveMapsOffset = g.emissive_maps_desc_heap_offset;
     }
@@ -511,7 +514,7 @@ static inline bool Visibility_Segment(const Scene& sc, bool approximate, float3 
 enum class TexSampler { Anisotropic, Isotropic };
 static inline void SampleMaterialTex(const Scene& sc, uint32_t tex, TexSampler ts, float2 uv, float4 g, float out[4])
 {
-    if (ts == TexSampler::Anisotropic) { zr_tex_sample_grad(&sc.tex, tex, uv.x, uv.y, g.x, g.y, g.z, g.w, out); return; }
+    if (ts == TexSampler::Anisotropic) { zr_tex_sample_grad_filter(&sc.tex, tex, sc.texFilter, uv.x, uv.y, g.x, g.y, g.z, g.w, out); return; }
     const zr_texture_desc& d = sc.tex.descs[tex];
     float mip = zr_log2(zr_max(g.x * (float)d.width, g.y * (float)d.height));
     zr_tex_sample_level(&sc.tex, tex, uv.x, uv.y, mip, out);

@@ -43,8 +43,10 @@ struct HxScene
 };
 
 // the descriptor-table offsets of the frame constants, latched into the scene view like zr_pass_render does
-static void Latch(const HxScene* s, const zr_frame_constants* cb)
+static void Latch(const HxScene* s, const zr_frame_constants* cb, const zr_params* indirectParams = nullptr)
 {
+    // the INDIRECT pass binds its TEXTURE_FILTER sampler; every other pass samples with ANISOTROPIC_4X (zr_api.hip FrameView)
+    s->view.texFilter = indirectParams ? indirectParams->tex_filter : (uint32_t)ZR_TEX_FILTER_ANISOTROPIC_4X;
     s->view.baseColorMapsOffset = cb->base_color_maps_desc_heap_offset; s->view.normalMapsOffset = cb->normal_maps_desc_heap_offset;
     s->view.mrMapsOffset = cb->metallic_roughness_maps_desc_heap_offset; s->view.emissiveMapsOffset = cb->emissive_maps_desc_heap_offset;
 }
@@ -200,7 +202,7 @@ void zhx_gbuffer(const HxScene* s, const zr_frame_constants* cb, zr_gbuffer_plan
 
 void zhx_pathtrace(const HxScene* s, const zr_frame_constants* cb, const zr_gbuffer_planes* planes, const zr_params* params,
     float* finalRGBA, zr_counters* counters)
-{ Latch(s, cb);
+{ Latch(s, cb, params);
     GBuf gb = ViewOf(planes);
     gb.x0 = g_tile_x0; gb.y0 = g_tile_y0;
     const uint32_t W = gb.w, H = gb.h;
@@ -311,7 +313,7 @@ void zhx_rpt_set_owned_rect(uint32_t x0, uint32_t y0, uint32_t w, uint32_t h) { 
 // The planes (`curr`, `prev`, reservoirs, finalRGBA) cover the extended tile whose origin zhx_set_tile_origin gave.
 void zhx_rpt_render_stage(const HxScene* s, HxRpt* R, const zr_frame_constants* cb, const zr_gbuffer_planes* curr, const zr_gbuffer_planes* prev,
     const zr_params* params, float* finalRGBA, zr_counters* counters, int stages)
-{ Latch(s, cb);
+{ Latch(s, cb, params);
     using namespace rpt;
     uint32_t cnt[2] = {0, 0}; uint64_t total[2] = {0, 0};
     auto flush = [&]() { total[0] += cnt[0]; total[1] += cnt[1]; cnt[0] = cnt[1] = 0; };
@@ -406,7 +408,7 @@ void zhx_rpt_render_stage(const HxScene* s, HxRpt* R, const zr_frame_constants* 
 }
 void zhx_rpt_render(const HxScene* s, HxRpt* R, const zr_frame_constants* cb, const zr_gbuffer_planes* curr, const zr_gbuffer_planes* prev,
     const zr_params* params, float* finalRGBA, zr_counters* counters)
-{ Latch(s, cb); zhx_rpt_render_stage(s, R, cb, curr, prev, params, finalRGBA, counters, 3); }
+{ Latch(s, cb, params); zhx_rpt_render_stage(s, R, cb, curr, prev, params, finalRGBA, counters, 3); }
 
 // which: 0 = the set the next frame reads as "previous", 1 = the other.  plane: 0..6 = A..G, 7 = target, 8 = neighbor
 int zhx_rpt_read_plane(const HxRpt* R, int which, int plane, void* out)
@@ -537,7 +539,7 @@ void zhx_rgi_destroy(HxRgi* r) { delete r; }
 void zhx_rgi_reset_temporal(HxRgi* r) { r->temporalValid = false; }
 void zhx_rgi_render(const HxScene* s, HxRgi* R, const zr_frame_constants* cb, const zr_gbuffer_planes* curr, const zr_gbuffer_planes* prev,
     const zr_params* params, float* finalRGBA, zr_counters* counters)
-{ Latch(s, cb);
+{ Latch(s, cb, params);
     using namespace rgi;
     uint32_t cnt[2] = {0, 0};
     const zr_frame_constants& g = *cb;

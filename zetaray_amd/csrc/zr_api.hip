@@ -532,6 +532,7 @@ static SceneView FrameView(const zr_scene* sc, const zr_frame_constants* cb)
         v.baseColorMapsOffset = cb->base_color_maps_desc_heap_offset; v.normalMapsOffset = cb->normal_maps_desc_heap_offset;
         v.mrMapsOffset = cb->metallic_roughness_maps_desc_heap_offset; v.emissiveMapsOffset = cb->emissive_maps_desc_heap_offset;
     }
+    v.texFilter = ZR_TEX_FILTER_ANISOTROPIC_4X;      // the INDIRECT pass overrides it with its zr_params.tex_filter
     return v;
 }
 // ... and as the passes that bind the PREVIOUS acceleration structure and mesh-instance buffer see it (RT_SCENE_BVH_PREV /
@@ -807,6 +808,7 @@ int zr_params_default(zr_params* p)
     // light voxel grid: off; VOXEL_GRID_DIM (32, 8, 40), VOXEL_EXTENTS (0.6, 0.45, 0.6), y offset 0.1 (DefaultRendererImpl.h:42-43, 73-77)
     p->taa_blend_weight = 0.1f;      // TAA.h:72
     p->ae_min_lum = 5e-3f; p->ae_max_lum = 4.0f; p->ae_lum_map_exp = 0.5f; p->ae_adaptation_rate = 1.0f;      // AutoExposure.h:73-81
+    p->tex_filter = ZR_TEX_FILTER_ANISOTROPIC_4X;      // IndirectLighting.h:243
     p->display_tonemapper = ZR_TONEMAP_NEUTRAL; p->display_auto_exposure = 1; p->display_saturation = 1.0f; p->display_agx_exp = 1.0f;   // Display.cpp:69-74
     p->use_lvg = 0; p->lvg_grid_dim = 32u | (8u << 10) | (40u << 20);
     p->lvg_extents[0] = 0.6f; p->lvg_extents[1] = 0.45f; p->lvg_extents[2] = 0.6f; p->lvg_offset_y = 0.1f;
@@ -1246,6 +1248,7 @@ int zr_pass_set_params(zr_pass* p, const zr_params* prm)
         return Fail(ZR_ERR_INVALID_ARG, "bounce counts must be in 1..15");
     if (prm->presampling && (prm->num_sample_sets == 0 || prm->sample_set_size == 0 || prm->num_sample_sets > 65535 || prm->sample_set_size > 65535))
         return Fail(ZR_ERR_INVALID_ARG, "presampling needs 1..65535 sample sets of 1..65535 samples");
+    if (prm->tex_filter >= ZR_TEX_FILTER_COUNT) return Fail(ZR_ERR_INVALID_ARG, "tex_filter must be a ZR_TEX_FILTER_* value");
     p->params = *prm;
     return ZR_OK;
 }
@@ -1461,6 +1464,7 @@ static int RenderReSTIR_GI(zr_pass* p, hipStream_t s, const zr_frame_constants* 
     const zr_params& ip = p->params;
     GiFrame F;
     F.sc = FrameView(sc, cb); F.gb = gb->View(); F.gbPrev = gb->PrevView();
+    F.sc.texFilter = ip.tex_filter;
     if (int orc = ResolveOwnedRect(p, gb, cb, &F.ox0, &F.oy0, &F.ow, &F.oh)) return orc;
     F.cur.A = p->giA[p->currIdx].p; F.cur.B = p->giB[p->currIdx].p; F.cur.C = p->giC[p->currIdx].p;
     F.prev.A = p->giA[1 - p->currIdx].p; F.prev.B = p->giB[1 - p->currIdx].p; F.prev.C = p->giC[1 - p->currIdx].p;
@@ -1494,6 +1498,7 @@ static int RenderReSTIR_PT(zr_pass* p, hipStream_t s, const zr_frame_constants* 
     RptFrame F;
     F.sc = FrameView(sc, cb); F.gb = gb->View(); F.gbPrev = gb->PrevView();
     F.scPrev = FrameViewPrev(sc, cb);
+    F.sc.texFilter = F.scPrev.texFilter = p->params.tex_filter;
     if (int orc = ResolveOwnedRect(p, gb, cb, &F.ox0, &F.oy0, &F.ow, &F.oh)) return orc;
     F.rbCtN = p->rb[0].View(); F.rbNtC = p->rb[1].View(); F.tex.target = p->rptTarget.p; F.tex.neighbor = p->rptNeighbor.p;
     F.finalRGBA = p->finalRGBA.p; F.sampleSet = p->rptSampleSet.p;
@@ -1613,7 +1618,8 @@ static int RenderIndirect(zr_pass* p, hipStream_t s, const zr_frame_constants* c
     if (rrPossible) HIP_TRY(hipMemsetAsync(p->groupMax.p, 0, (size_t)rounds * numGroups * sizeof(uint32_t), s));
     const uint32_t tilesX = (p->w + 15) / 16, tilesY = (p->h + 15) / 16;
     const GBuf gbv = gb->View();
-    const SceneView scv = FrameView(sc, cb);
+    SceneView scv = FrameView(sc, cb);
+    scv.texFilter = p->params.tex_filter;
     const bool tex = scv.tex.count != 0;      // kernels carry ray differentials only when there is a texture heap
     if (tex) { int r; if ((r = p->q[0].AllocTex((size_t)p->w * p->h)) || (r = p->q[1].AllocTex((size_t)p->w * p->h))) return r; }
     TimerBegin(p, s, "pt_init");

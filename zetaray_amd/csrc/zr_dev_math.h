@@ -315,9 +315,12 @@ ZR_HD V2 UniformSampleTriangle(V2 u)           // Sampling.hlsli:270-287
 }
 
 // ---- RT.hlsli ----
-ZR_HD V3 GeneratePinholeCameraRay_CS(int px, int py, V2 renderDim, float aspectRatio, float tanHalfFOV, V2 jitter)  // :233-241
+// :233-241.  The reference's parameter is `uint2 pixel`: the auxiliary pixel int2(x, y - 1) of the ray differentials (RT.hlsli:332,
+// GBufferRT.hlsli:41) wraps to 4294967295 on the top row of the screen -- the float conversion sees that value (found by the textured
+// reference-pass pins: the y-gradient of row 0 is huge there, so its texture fetches land on the coarsest mip)
+ZR_HD V3 GeneratePinholeCameraRay_CS(int px, int py, V2 renderDim, float aspectRatio, float tanHalfFOV, V2 jitter)
 {
-    V2 uv = v2(((float)px + 0.5f + jitter.x) / renderDim.x, ((float)py + 0.5f + jitter.y) / renderDim.y);
+    V2 uv = v2(((float)(uint32_t)px + 0.5f + jitter.x) / renderDim.x, ((float)(uint32_t)py + 0.5f + jitter.y) / renderDim.y);
     V2 ndc = NDCFromUV(uv);
     return v3(ndc.x * aspectRatio * tanHalfFOV, ndc.y * tanHalfFOV, 1);
 }

@@ -60,6 +60,7 @@ struct SceneView
     // constants (FrameConstants.h:31-34), latched from the cb of the zr_pass_render call that launches the kernel
     zr_tex_heap tex;
     uint32_t baseColorMapsOffset, normalMapsOffset, mrMapsOffset, emissiveMapsOffset;
+    uint32_t texFilter;      // zr_params.tex_filter of the pass that launches the kernel (cb_ReSTIR_*::TexFilterDescHeapIdx); ZR_TEX_FILTER_*
     uint32_t numEmissives;
     uint32_t numNodes;       // 0 => single leaf covering tris[0 .. numTris)
     uint32_t numTris;
@@ -417,12 +418,12 @@ ZR_HD void FillHit(const SceneView& sc, uint32_t meshIdx, uint32_t primIdx, floa
 }
 
 // GetMaterialData, RayQuery.hlsli:452-524 (texture maps not bound: factors only)
-// The two TexSampler policies of RayQuery.hlsli:408-450.  Anisotropic = SampleGrad(samp, uv, ddx, ddy) with the default
-// TEXTURE_FILTER::ANISOTROPIC_4X sampler (IndirectLighting.h:243); isotropic = SampleLevel(g_samLinearWrap, uv,
+// The two TexSampler policies of RayQuery.hlsli:408-450.  Anisotropic = SampleGrad(samp, uv, ddx, ddy) with the sampler the pass's
+// TEXTURE_FILTER selects (default ANISOTROPIC_4X, IndirectLighting.h:243; zr_texture.h); isotropic = SampleLevel(g_samLinearWrap, uv,
 // log2(max(dd.x * w, dd.y * h))) with dd = uv_grads.xy (the reconnection shift, Shift.hlsli:519).
 ZR_HD void SampleMaterialTex(const SceneView& sc, uint32_t tex, bool isotropic, V2 uv, V4 g, float out[4])
 {
-    if (!isotropic) { zr_tex_sample_grad(&sc.tex, tex, uv.x, uv.y, g.x, g.y, g.z, g.w, out); return; }
+    if (!isotropic) { zr_tex_sample_grad_filter(&sc.tex, tex, sc.texFilter, uv.x, uv.y, g.x, g.y, g.z, g.w, out); return; }
     const zr_texture_desc& d = sc.tex.descs[tex];
     const float mip = zr_log2(zr_max(g.x * (float)d.width, g.y * (float)d.height));
     zr_tex_sample_level(&sc.tex, tex, uv.x, uv.y, mip, out);

@@ -225,14 +225,14 @@ ZR_HD void GBufferPixel(const SceneView& sc, const zr_frame_constants& g, const 
     if (baseColorTex != ZR_INVALID_TEX)
     {
         float c[4];
-        zr_tex_sample_grad(&sc.tex, g.base_color_maps_desc_heap_offset + baseColorTex, uv.x, uv.y, grads.x, grads.y, grads.z, grads.w, c);
+        zr_tex_sample_grad_aniso(&sc.tex, g.base_color_maps_desc_heap_offset + baseColorTex, uv.x, uv.y, grads.x, grads.y, grads.z, grads.w, 16, c);      // g_samAnisotropicWrap: MaxAnisotropy 16 (GBufferRT.hlsli:204-248, RendererCore.cpp:508-521)
         baseColor = baseColor * v3(c[0], c[1], c[2]);
     }
     // avoid normal mapping if tangent = (0, 0, 0), which results in NaN
     if (normalTex != ZR_INVALID_TEX && zr_abs(dot(tangent, tangent)) > 1e-6f)
     {
         float c[4];
-        zr_tex_sample_grad(&sc.tex, g.normal_maps_desc_heap_offset + normalTex, uv.x, uv.y, grads.x, grads.y, grads.z, grads.w, c);
+        zr_tex_sample_grad_aniso(&sc.tex, g.normal_maps_desc_heap_offset + normalTex, uv.x, uv.y, grads.x, grads.y, grads.z, grads.w, 16, c);      // g_samAnisotropicWrap: MaxAnisotropy 16 (GBufferRT.hlsli:204-248, RendererCore.cpp:508-521)
         sn = TangentSpaceToWorldSpace(v2(c[0], c[1]), tangent, normal, zr_div255((float)(mat.emissive_factor_normal_scale >> 24)));
     }
     if (MatDoubleSided(mat) && dot(wo, normal) < 0) { sn = sn * -1.0f; dndu = dndu * -1.0f; dndv = dndv * -1.0f; }
@@ -246,7 +246,7 @@ ZR_HD void GBufferPixel(const SceneView& sc, const zr_frame_constants& g, const 
     if (mrTex != ZR_INVALID_TEX)
     {
         float c[4];
-        zr_tex_sample_grad(&sc.tex, g.metallic_roughness_maps_desc_heap_offset + mrTex, uv.x, uv.y, grads.x, grads.y, grads.z, grads.w, c);
+        zr_tex_sample_grad_aniso(&sc.tex, g.metallic_roughness_maps_desc_heap_offset + mrTex, uv.x, uv.y, grads.x, grads.y, grads.z, grads.w, 16, c);      // g_samAnisotropicWrap: MaxAnisotropy 16 (GBufferRT.hlsli:204-248, RendererCore.cpp:508-521)
         metallic *= c[0];
         roughness *= c[1];
     }

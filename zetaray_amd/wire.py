@@ -104,7 +104,7 @@ class Params(C.Structure):
         ("taa_blend_weight", C.c_float),
         ("ae_min_lum", C.c_float), ("ae_max_lum", C.c_float), ("ae_lum_map_exp", C.c_float), ("ae_adaptation_rate", C.c_float),
         ("display_tonemapper", C.c_uint32), ("display_auto_exposure", C.c_uint32), ("display_saturation", C.c_float),
-        ("display_agx_exp", C.c_float)]
+        ("display_agx_exp", C.c_float), ("tex_filter", C.c_uint32)]
 
 
 class Counters(C.Structure):
@@ -143,6 +143,7 @@ def default_params() -> Params:
     return p
 
 
+TEX_FILTER_MIP0, TEX_FILTER_TRI_LINEAR, TEX_FILTER_ANISOTROPIC_2X, TEX_FILTER_ANISOTROPIC_4X, TEX_FILTER_ANISOTROPIC_16X = range(5)
 TONEMAP_NONE, TONEMAP_NEUTRAL, TONEMAP_AGX_DEFAULT, TONEMAP_AGX_GOLDEN, TONEMAP_AGX_PUNCHY, TONEMAP_AGX_CUSTOM = range(6)
 
 
@@ -150,6 +151,7 @@ def set_post_defaults(p):
     """AutoExposure.h:73-81 and Display.cpp:69-74"""
     p.ae_min_lum, p.ae_max_lum, p.ae_lum_map_exp, p.ae_adaptation_rate = 5e-3, 4.0, 0.5, 1.0
     p.display_tonemapper, p.display_auto_exposure, p.display_saturation, p.display_agx_exp = TONEMAP_NEUTRAL, 1, 1.0, 1.0
+    p.tex_filter = TEX_FILTER_ANISOTROPIC_4X      # IndirectLighting.h:243
 
 
 COMPOSIT_FIREFLY_FILTER = 1 << 10
