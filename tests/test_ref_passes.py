@@ -44,7 +44,7 @@ def test_oracle_reproduces_reference_passes(case):
     from oracle import zro
     sc, force_bvh, integ, prm = RC.scene_and_params(case)
     g = _gold(case)
-    o = zro.OracleScene(sc, force_bvh=force_bvh)
+    o = zro.OracleScene(sc, force_bvh=force_bvh, cb=RC.first_cb(case))
     rpt = {"rpt": zro.OracleRPT, "gi": zro.OracleRGI, "di": zro.OracleRDI, "sdi": zro.OracleSDI}[integ](o, RC.W, RC.H) if integ != "pt" else None
     anim = RC.Animator(sc) if case in RC.ANIMATED else None
     for f, cb in RC.frames_of(case):
@@ -84,7 +84,7 @@ def test_live_reference_passes_match_stored_outputs(case):
     from oracle import zro
     sc, force_bvh, integ, prm = RC.scene_and_params(case)
     g = _gold(case)
-    o = zro.OracleScene(sc, force_bvh=force_bvh)
+    o = zro.OracleScene(sc, force_bvh=force_bvh, cb=RC.first_cb(case))
     k1 = zref.RefGBuffer(sc, force_bvh)
     ref = M.make_ref(zref, sc, integ, prm, force_bvh)
     anim = RC.Animator(sc) if case in RC.ANIMATED else None
@@ -173,7 +173,7 @@ def test_hip_stage_functions_on_host_reproduce_reference_passes(case):
     from tests.hostexec import zhx
     sc, force_bvh, integ, prm = RC.scene_and_params(case)
     g = _gold(case)
-    o = zro.OracleScene(sc, force_bvh=force_bvh)                 # only for the scene-level inputs (alias table, presampled sets, sky LUT)
+    o = zro.OracleScene(sc, force_bvh=force_bvh, cb=RC.first_cb(case))                 # only for the scene-level inputs (alias table, presampled sets, sky LUT)
     hx = zhx.HostExecScene(sc, alias=o.alias if len(sc.emissives) else None)
     run = {"rpt": zhx.HostExecRPT, "gi": zhx.HostExecRGI, "di": zhx.HostExecRDI, "sdi": zhx.HostExecSDI}[integ](hx, RC.W, RC.H)
     anim = RC.Animator(sc) if case in RC.ANIMATED else None

@@ -47,7 +47,7 @@ def main():
     gb_out = {}
     for case in RC.CASES:
         sc, force_bvh, integ, prm = RC.scene_and_params(case)
-        o = zro.OracleScene(sc, force_bvh=force_bvh)
+        o = zro.OracleScene(sc, force_bvh=force_bvh, cb=RC.first_cb(case))
         k1 = zref.RefGBuffer(sc, force_bvh)
         ref = make_ref(zref, sc, integ, prm, force_bvh)
         res = {}

@@ -125,6 +125,12 @@ def frames_of(case):
         yield f, cb
 
 
+def first_cb(case):
+    """frame 1's constants: what an OracleScene needs at construction to latch the texture-table offsets (the power estimate of textured
+    emissive triangles -- K2, hence the alias table -- samples the emissive maps through them)"""
+    return next(frames_of(case))[1]
+
+
 def scene_and_params(case):
     kind, integ, n, pk, _ = CASES[case]
     sc, force_bvh, _ = _scene(kind)
