@@ -41,6 +41,48 @@ void zref_unorm4_from_normalized(const float* q4, uint16_t* out, uint64_t n)
 uintptr_t zref_align_phase(const float* p) { return ((32 - (reinterpret_cast<uintptr_t>(p) & 31)) & 31) / 4; }
 }
 
+// ---- scene-ingestion pins: the reference's own transform math (Math/MatrixFuncs.h) and RT::EmissiveTriangle packing, for the C++ loader
+// (zetaray_amd/host/zr_scene_io.cpp).  Matrices cross this boundary as 4 x 3 row-vector matrices (rows 0-2 = basis images, row 3 = translation).
+#include <Math/MatrixFuncs.h>
+#include <RayTracing/RtCommon.h>
+extern "C" {
+// world = affineTransformation(s, q, t) x parent  (SceneCore.cpp:871-873)
+void zref_compose_world(const float* s3, const float* q4, const float* t3, const float* parent4x3, float* out4x3)
+{
+    using namespace ZetaRay::Math;
+    float3 s(s3[0], s3[1], s3[2]); float4 q(q4[0], q4[1], q4[2], q4[3]); float3 t(t3[0], t3[1], t3[2]);
+    v_float4x4 vLocal = affineTransformation(s, q, t);
+    float4x3 P;
+    for (int i = 0; i < 4; i++) P.m[i] = float3(parent4x3[3 * i], parent4x3[3 * i + 1], parent4x3[3 * i + 2]);
+    v_float4x4 vW = mul(vLocal, load4x3(P));
+    float4x3 W(store(vW));
+    for (int i = 0; i < 4; i++) { out4x3[3 * i] = W.m[i].x; out4x3[3 * i + 1] = W.m[i].y; out4x3[3 * i + 2] = W.m[i].z; }
+}
+// TLAS::FillMeshInstanceData (RtAccelerationStructure.cpp:318-357): decomposeSRT -> unorm4 rotation, half3 scale, translation
+void zref_fill_mesh_instance(const float* M4x3, float* s3, float* q4, float* t3, uint16_t* rot4, uint16_t* scale3)
+{
+    using namespace ZetaRay::Math;
+    float4x3 M;
+    for (int i = 0; i < 4; i++) M.m[i] = float3(M4x3[3 * i], M4x3[3 * i + 1], M4x3[3 * i + 2]);
+    v_float4x4 vM = load4x3(M);
+    float4a t, r, s;
+    decomposeSRT(vM, s, r, t);
+    s3[0] = s.x; s3[1] = s.y; s3[2] = s.z; q4[0] = r.x; q4[1] = r.y; q4[2] = r.z; q4[3] = r.w; t3[0] = t.x; t3[1] = t.y; t3[2] = t.z;
+    unorm4 u = unorm4::FromNormalized(r); rot4[0] = u.x; rot4[1] = u.y; rot4[2] = u.z; rot4[3] = u.w;
+    half3 h(s); scale3[0] = h.x; scale3[1] = h.y; scale3[2] = h.z;
+}
+// RT::EmissiveTriangle ctor (RtCommon.h:73-190); out = the 48-byte record
+void zref_emissive_triangle(const float* v0, const float* v1, const float* v2, const float* uv6, uint32_t factorRGB8, uint32_t tex, uint16_t strengthBits,
+    uint32_t triIdx, int doubleSided, void* out48)
+{
+    using namespace ZetaRay; using namespace ZetaRay::Math;
+    RT::EmissiveTriangle e(float3(v0[0], v0[1], v0[2]), float3(v1[0], v1[1], v1[2]), float3(v2[0], v2[1], v2[2]),
+        float2(uv6[0], uv6[1]), float2(uv6[2], uv6[3]), float2(uv6[4], uv6[5]), factorRGB8, tex, half::asfloat16(strengthBits), triIdx, doubleSided != 0);
+    static_assert(sizeof(e) == 48, "EmissiveTriangle size");
+    memcpy(out48, &e, 48);
+}
+}
+
 // ---- layout pins: offsetof / sizeof of the C++ side of the reference's shared C++/HLSL headers, compiled in place ----
 #include <RayTracing/RtCommon.h>
 #include <Core/Material.h>

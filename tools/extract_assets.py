@@ -52,6 +52,12 @@ def main():
         sc = scene_io.load_gltf(os.path.join(REF, "Assets/CornellBox", name + ".gltf"))
         scene_io.save_npz(sc, os.path.join(dst, name + ".npz"))
         print(name, "tris", sc.num_tris, "emissives", len(sc.emissives))
+    # cornell.gltf through the C++ loader (zetaray_amd/host/zr_scene_io.cpp): the same scene with the reference's real floor, the BC7
+    # checkerboard (Assets/CornellBox/compressed/checkerboard.dds, 1024^2, 11 mips) decoded into the texel heap
+    sc, offs = scene_io.load_gltf_native(os.path.join(REF, "Assets/CornellBox", "cornell.gltf"))
+    assert offs == dict(base_color=0, normal=1, metallic_roughness=1, emissive=1)
+    scene_io.save_npz(sc, os.path.join(dst, "cornell_textured.npz"))
+    print("cornell_textured: textures", len(sc.textures), "texel bytes", sc.texels.size)
     print("ok")
 
 

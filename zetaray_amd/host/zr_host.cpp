@@ -1,6 +1,7 @@
 // zr_host.cpp -- implementation of the RenderPass / RenderGraph mirror (see zr_host.h).  Plain C++ (g++), links
 // libzetaray_amd.so for the passes and libamdhip64 for streams/events (runtime API only; no kernels here).
 #include "zr_host.h"
+#include "zr_scene_io.h"
 #include <algorithm>
 #include <cstring>
 #include <future>
@@ -513,6 +514,18 @@ int zrh_render_sequence3(const zr_scene_desc* desc, const zr_frame_constants* cb
 
 // The reference's default (sun + sky) frame: Sky -> GBuffer -> {SkyDI, Indirect} (PathTracer.cpp:165-181, 311-360, 474-552).
 // Copies the FINAL planes of the last frame: Indirect to `finalOut`, SkyDI to `skyDiOut`.
+// Scene ingestion on the host (zr_scene_io.cpp) straight into a device scene: Model::glTF::Load + SceneCore + TLAS build of the reference
+// collapsed into one call.  tex_offsets4 = the descriptor-table offsets to put into cbFrameConstants (base colour, normal, MR, emissive).
+extern "C" int zrh_scene_create_from_gltf(int device, const char* path, const uint16_t* rho_lut, const uint32_t* rho_dim3, zr_scene** out, uint32_t* tex_offsets4)
+{
+    zrh_scene_data* data = nullptr;
+    if (zrh_gltf_load(path, rho_lut, rho_dim3, &data) != 0) { std::fprintf(stderr, "zrh_scene_create_from_gltf: %s\n", zrh_scene_io_last_error()); return -1; }
+    const int r = zr_scene_create(device, zrh_scene_data_desc(data), out);
+    if (tex_offsets4) zrh_scene_data_tex_offsets(data, tex_offsets4);
+    zrh_scene_data_destroy(data);
+    return r;
+}
+
 int zrh_render_sequence_sky_display(const zr_scene_desc* desc, const zr_frame_constants* cbs, uint32_t n, uint32_t w, uint32_t h, int integrator, float* finalOut, float* skyDiOut,
     float* compositedOut, uint16_t* taaOut, const uint32_t* lutRGB9E5, uint32_t lutDim, int tonemapper, float* exposureOut, float* displayOut, uint8_t* displaySrgbOut);
 int zrh_render_sequence_sky_post(const zr_scene_desc* desc, const zr_frame_constants* cbs, uint32_t n, uint32_t w, uint32_t h, int integrator, float* finalOut, float* skyDiOut,

@@ -1,0 +1,707 @@
+// zr_scene_io.cpp -- see zr_scene_io.h.  Plain C++17, no HIP, no third-party parser (the reference uses cgltf; the subset of glTF 2.0 it
+// consumes -- external buffers, TRS / matrix nodes, indexed triangle primitives, pbrMetallicRoughness + four KHR material extensions -- is
+// small enough for the JSON reader below).
+#include "zr_scene_io.h"
+#include "../../include/zr_detmath.h"
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <fstream>
+#include <map>
+#include <memory>
+#include <string>
+#include <vector>
+
+namespace {
+
+thread_local std::string g_err;
+struct Error { std::string what; };
+[[noreturn]] void Throw(const std::string& s) { throw Error{s}; }
+
+// ------------------------------------------------------------------------------------------------ JSON
+struct Json
+{
+    enum Kind { Null, Bool, Num, Str, Arr, Obj } kind = Null;
+    bool b = false; double num = 0; std::string str;
+    std::vector<Json> arr; std::vector<std::pair<std::string, Json>> obj;
+    const Json* Find(const char* k) const { for (auto& kv : obj) if (kv.first == k) return &kv.second; return nullptr; }
+    const Json& At(const char* k) const { const Json* j = Find(k); if (!j) Throw(std::string("glTF: missing key '") + k + "'"); return *j; }
+    double NumOr(const char* k, double d) const { const Json* j = Find(k); return (j && j->kind == Num) ? j->num : d; }
+    int IntOr(const char* k, int d) const { const Json* j = Find(k); return (j && j->kind == Num) ? (int)j->num : d; }
+    bool BoolOr(const char* k, bool d) const { const Json* j = Find(k); return (j && j->kind == Bool) ? j->b : d; }
+    std::string StrOr(const char* k, const char* d) const { const Json* j = Find(k); return (j && j->kind == Str) ? j->str : std::string(d); }
+    size_t Size() const { return kind == Arr ? arr.size() : 0; }
+};
+struct JsonParser
+{
+    const char* p; const char* end;
+    void Ws() { while (p < end && (*p == ' ' || *p == '\n' || *p == '\r' || *p == '\t')) p++; }
+    [[noreturn]] void Bad(const char* w) { Throw(std::string("JSON: ") + w); }
+    Json Value()
+    {
+        Ws(); if (p >= end) Bad("unexpected end");
+        Json j;
+        if (*p == '{')
+        {
+            j.kind = Json::Obj; p++; Ws();
+            if (p < end && *p == '}') { p++; return j; }
+            for (;;)
+            {
+                Ws(); if (p >= end || *p != '"') Bad("expected a key");
+                std::string k = String(); Ws();
+                if (p >= end || *p != ':') Bad("expected ':'");
+                p++;
+                j.obj.emplace_back(std::move(k), Value()); Ws();
+                if (p < end && *p == ',') { p++; continue; }
+                if (p < end && *p == '}') { p++; return j; }
+                Bad("expected ',' or '}'");
+            }
+        }
+        if (*p == '[')
+        {
+            j.kind = Json::Arr; p++; Ws();
+            if (p < end && *p == ']') { p++; return j; }
+            for (;;)
+            {
+                j.arr.push_back(Value()); Ws();
+                if (p < end && *p == ',') { p++; continue; }
+                if (p < end && *p == ']') { p++; return j; }
+                Bad("expected ',' or ']'");
+            }
+        }
+        if (*p == '"') { j.kind = Json::Str; j.str = String(); return j; }
+        if (!strncmp(p, "true", 4) && end - p >= 4) { j.kind = Json::Bool; j.b = true; p += 4; return j; }
+        if (!strncmp(p, "false", 5) && end - p >= 5) { j.kind = Json::Bool; j.b = false; p += 5; return j; }
+        if (!strncmp(p, "null", 4) && end - p >= 4) { p += 4; return j; }
+        char* e = nullptr; j.num = strtod(p, &e);
+        if (e == p) Bad("unexpected character");
+        j.kind = Json::Num; p = e; return j;
+    }
+    std::string String()
+    {
+        std::string s; p++;
+        while (p < end && *p != '"')
+        {
+            if (*p == '\\' && p + 1 < end)
+            {
+                p++;
+                switch (*p) { case 'n': s += '\n'; break; case 't': s += '\t'; break; case 'r': s += '\r'; break; case 'b': s += '\b'; break; case 'f': s += '\f'; break;
+                case 'u': { unsigned c = 0; if (end - p < 5) Bad("bad \\u escape"); sscanf(p + 1, "%4x", &c); p += 4; if (c < 0x80) s += (char)c; else if (c < 0x800) { s += (char)(0xc0 | (c >> 6)); s += (char)(0x80 | (c & 63)); } else { s += (char)(0xe0 | (c >> 12)); s += (char)(0x80 | ((c >> 6) & 63)); s += (char)(0x80 | (c & 63)); } break; }
+                default: s += *p; }
+                p++;
+            }
+            else s += *p++;
+        }
+        if (p >= end) Bad("unterminated string");
+        p++; return s;
+    }
+};
+
+std::vector<uint8_t> ReadFile(const std::string& path)
+{
+    std::ifstream f(path, std::ios::binary);
+    if (!f) Throw("cannot open " + path);
+    return std::vector<uint8_t>((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
+}
+std::string DirOf(const std::string& p) { size_t i = p.find_last_of('/'); return i == std::string::npos ? std::string(".") : p.substr(0, i); }
+
+// ------------------------------------------------------------------------------------------------ packing helpers (Material.h, Vector.h)
+uint32_t Unorm8(float f) { f = f < 0.0f ? 0.0f : (f > 1.0f ? 1.0f : f); return (uint32_t)(f * 255.0f + 0.5f); }
+uint32_t Rgb8(const float* c) { return Unorm8(c[0]) | (Unorm8(c[1]) << 8) | (Unorm8(c[2]) << 16); }      // Float3ToRGB8
+// Math::encode_octahedral (VectorFuncs.h:134-153) + unorm2::FromNormalized (Vector.h:626-647), in the SSE code's operation order:
+// |x| + |z| first, then + |y| (hadd_float3); the fold's sign comes from the INPUT component (v >= 0, so -0.0 counts as positive);
+// [-1, 1] -> [0, 1] is one fma; cvtps_epi32 rounds to nearest even
+void EncodeOct32(const float* n, uint16_t out[2])
+{
+    const float denom = (std::fabs(n[0]) + std::fabs(n[2])) + std::fabs(n[1]);
+    const float p[2] = {n[0] / denom, n[1] / denom};
+    for (int k = 0; k < 2; k++)
+    {
+        const float sgn = n[k] >= 0.0f ? 1.0f : -1.0f;
+        const float folded = (1.0f - std::fabs(p[1 - k])) * sgn;
+        const float enc = n[2] <= 0.0f ? folded : p[k];
+        out[k] = (uint16_t)std::nearbyintf(std::fma(enc, 0.5f, 0.5f) * 65535.0f);
+    }
+}
+
+struct MaterialDesc      // glTF::Asset::MaterialDesc defaults (Material.h:66-95 via pack below)
+{
+    float baseColor[4] = {1, 1, 1, 1}; float metallic = 1.0f, roughness = 1.0f, ior = 1.5f, transmission = 0.0f, subsurface = 0.0f;
+    float coatWeight = 0.0f, coatColor[3] = {0.8f, 0.8f, 0.8f}, coatRoughness = 0.0f, coatIor = 1.6f;
+    float emissiveFactor[3] = {0, 0, 0}; float emissiveStrength = 1.0f, normalScale = 1.0f, alphaCutoff = 0.5f; int alphaMode = 0;
+    bool doubleSided = false, thinWalled = false; float transmissionDepth = 0.0f;
+    uint32_t baseColorTex = 0xffff, normalTex = 0xffff, mrTex = 0xffff, emissiveTex = 0xffff;
+};
+// the setters of Material (Source/ZetaCore/Core/Material.h:66-260), as zetaray_amd/scene_io.py pack_material states them
+zr_material PackMaterial(const MaterialDesc& d)
+{
+    zr_material m; std::memset(&m, 0, sizeof(m));
+    m.base_color_factor = Rgb8(d.baseColor) | (Unorm8(d.baseColor[3]) << 24);
+    m.base_color_tex_subsurf_coat_weight = d.baseColorTex | (Unorm8(d.subsurface) << 16) | (Unorm8(d.coatWeight) << 24);
+    m.normal_tex_tr_depth = d.normalTex | ((uint32_t)zr_f32_to_f16(d.transmissionDepth) << 16);
+    m.mr_tex_spec_roughness_coat_roughness = d.mrTex | (Unorm8(d.roughness) << 16) | (Unorm8(d.coatRoughness) << 24);
+    m.emissive_factor_normal_scale = Rgb8(d.emissiveFactor) | (Unorm8(d.normalScale) << 24);
+    float iorN = (d.ior - 1.0f) / 1.5f; iorN = iorN < 0.0f ? 0.0f : (iorN > 1.0f ? 1.0f : iorN);
+    m.emissive_strength_ior = (uint32_t)zr_f32_to_f16(d.emissiveStrength) | ((uint32_t)(iorN * 65535.0f + 0.5f) << 16);
+    m.emissive_tex_alpha_cutoff_coat_ior = d.emissiveTex | (Unorm8(d.alphaCutoff) << 16) | (Unorm8((d.coatIor - 1.0f) / 1.5f) << 24);
+    uint32_t flags = Rgb8(d.coatColor);
+    if (d.metallic >= 0.9f) flags |= 1u << ZR_MAT_METALLIC_BIT;
+    if (d.doubleSided) flags |= 1u << ZR_MAT_DOUBLE_SIDED_BIT;
+    if (d.transmission >= 0.9f) flags |= 1u << ZR_MAT_TRANSMISSIVE_BIT;
+    flags |= ((uint32_t)d.alphaMode & 3u) << 27;
+    if (d.thinWalled) flags |= 1u << ZR_MAT_THIN_WALLED_BIT;
+    m.coat_color_flags = flags;
+    return m;
+}
+
+// ------------------------------------------------------------------------------------------------ transforms (Math/MatrixFuncs.h)
+// Row-vector 4 x 4 as the reference stores it: rows 0-2 = images of the basis vectors, row 3 = translation.  Only [i][0..2] is kept.
+struct Mat43 { float m[4][3]; };
+Mat43 FromToWorld(const float* M)       // 3 x 4 row-major, column-vector convention -> reference layout
+{ Mat43 r; for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) r.m[i][j] = M[4 * j + i]; for (int j = 0; j < 3; j++) r.m[3][j] = M[4 * j + 3]; return r; }
+void ToToWorld(const Mat43& r, float* M) { for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) M[4 * j + i] = r.m[i][j]; for (int j = 0; j < 3; j++) M[4 * j + 3] = r.m[3][j]; }
+
+// rotationMatFromQuat, MatrixFuncs.h:356-405 (operation order of the SSE code)
+void RotationMatFromQuat(const float q[4], float R[3][3])
+{
+    const float q1 = q[0], q2 = q[1], q3 = q[2], q4 = q[3];
+    const float q1s = q1 * q1, q2s = q2 * q2, q3s = q3 * q3;
+    const float d0 = std::fma(q1s + q3s, -2.0f, 1.0f), d1 = std::fma(q2s + q3s, -2.0f, 1.0f), d2 = std::fma(q1s + q2s, -2.0f, 1.0f);
+    const float q1q4 = (q1 * q4) * 2.0f, q2q4 = (q2 * q4) * 2.0f, q1q3 = (q3 * q1) * 2.0f, q3q4 = (q4 * q3) * 2.0f;
+    const float q1q2 = (q1 * q2) * 2.0f, q2q3 = (q2 * q3) * 2.0f;
+    R[0][0] = d1;          R[0][1] = q1q2 + q3q4; R[0][2] = q1q3 - q2q4;
+    R[1][0] = q1q2 - q3q4; R[1][1] = d0;          R[1][2] = q2q3 + q1q4;
+    R[2][0] = q1q3 + q2q4; R[2][1] = q2q3 - q1q4; R[2][2] = d2;
+}
+// affineTransformation(vS, vQ, vT), MatrixFuncs.h:488-503
+Mat43 AffineTransformation(const float s[3], const float q[4], const float t[3])
+{
+    float R[3][3]; RotationMatFromQuat(q, R);
+    Mat43 r;
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) r.m[i][j] = s[i] * R[i][j];
+    for (int j = 0; j < 3; j++) r.m[3][j] = t[j];
+    return r;
+}
+// mul(M1, M2), MatrixFuncs.h:114-163, for affine matrices (column 3 = (0, 0, 0, 1)): (a0 b0 + a1 b1) + (a2 b2 + a3 b3), fused as the AVX code
+Mat43 Mul(const Mat43& A, const Mat43& B)
+{
+    Mat43 C;
+    for (int i = 0; i < 4; i++)
+    {
+        const float a3 = i == 3 ? 1.0f : 0.0f;
+        for (int j = 0; j < 3; j++)
+        {
+            const float c2 = std::fma(A.m[i][1], B.m[1][j], A.m[i][0] * B.m[0][j]);
+            const float c6 = std::fma(a3, B.m[3][j], A.m[i][2] * B.m[2][j]);
+            C.m[i][j] = c2 + c6;
+        }
+    }
+    return C;
+}
+// decomposeSRT, MatrixFuncs.h:562-610 + quaternionFromRotationMat1, :410-437
+void DecomposeSRT(const Mat43& M, float s[3], float q[4], float t[3])
+{
+    for (int j = 0; j < 3; j++) t[j] = M.m[3][j];
+    float R[3][3];
+    for (int i = 0; i < 3; i++)
+    {
+        // diagonal of M M^T through mul(): (m0 m0 + m1 m1) + (m2 m2 + 0 0)
+        const float s2 = std::fma(M.m[i][1], M.m[i][1], M.m[i][0] * M.m[i][0]) + std::fma(0.0f, 0.0f, M.m[i][2] * M.m[i][2]);
+        s[i] = std::sqrt(s2);
+        const float inv = 1.0f / s[i];
+        for (int j = 0; j < 3; j++) R[i][j] = inv * M.m[i][j];
+    }
+    float tt[4], Q[4][4];
+    tt[0] = 1 + R[0][0] - R[1][1] - R[2][2];
+    tt[1] = 1 - R[0][0] + R[1][1] - R[2][2];
+    tt[2] = 1 - R[0][0] - R[1][1] + R[2][2];
+    tt[3] = 1 + R[0][0] + R[1][1] + R[2][2];
+    const float a = R[0][1] + R[1][0], b = R[2][0] + R[0][2], c = R[1][2] - R[2][1], d = R[1][2] + R[2][1], e = R[2][0] - R[0][2], f = R[0][1] - R[1][0];
+    const float q0[4] = {tt[0], a, b, c}, q1[4] = {a, tt[1], d, e}, q2[4] = {b, d, tt[2], f}, q3[4] = {c, e, f, tt[3]};
+    std::memcpy(Q[0], q0, 16); std::memcpy(Q[1], q1, 16); std::memcpy(Q[2], q2, 16); std::memcpy(Q[3], q3, 16);
+    const int i = (R[2][2] >= 0) * (2 + (R[0][0] >= -R[1][1])) + (R[2][2] < 0) * (R[1][1] >= R[0][0]);
+    const float k = 0.5f / std::sqrt(tt[i]);
+    for (int j = 0; j < 4; j++) q[j] = Q[i][j] * k;
+    // float4::normalize: _mm_dp_ps sums (x^2 + y^2) + (z^2 + w^2)
+    const float norm = std::sqrt((q[0] * q[0] + q[1] * q[1]) + (q[2] * q[2] + q[3] * q[3]));
+    const float inv = 1.0f / norm;
+    for (int j = 0; j < 4; j++) q[j] *= inv;
+}
+// unorm4::FromNormalized (Vector.h:745-769): fma(v, 0.5, 0.5) * 65535, round to nearest even
+uint16_t Unorm16FromNormalized(float v) { return (uint16_t)std::nearbyintf(std::fma(v, 0.5f, 0.5f) * 65535.0f); }
+
+void FillMeshInstance(const float* toWorld, zr_mesh_instance& I)
+{
+    float s[3], q[4], t[3];
+    DecomposeSRT(FromToWorld(toWorld), s, q, t);
+    for (int k = 0; k < 4; k++) I.rotation[k] = I.prev_rotation[k] = Unorm16FromNormalized(q[k]);
+    for (int k = 0; k < 3; k++) { I.scale[k] = I.prev_scale[k] = zr_f32_to_f16(s[k]); I.translation[k] = t[k]; I.d_translation[k] = zr_f32_to_f16(0.0f); }
+}
+
+// RT::EmissiveTriangle ctor + StoreVertices (RtCommon.h:73-190)
+void PackEmissiveTriangle(const float* v0, const float* v1, const float* v2, const float* uv, uint32_t factorRGB8, uint32_t tex, uint16_t strengthH,
+    uint32_t id, bool doubleSided, zr_emissive_triangle& e)
+{
+    std::memset(&e, 0, sizeof(e));
+    float e0[3], e1[3];
+    for (int k = 0; k < 3; k++) { e.vtx0[k] = v0[k]; e0[k] = v1[k] - v0[k]; e1[k] = v2[k] - v0[k]; }
+    const float l0 = std::sqrt((e0[0] * e0[0] + e0[1] * e0[1]) + (e0[2] * e0[2] + 0.0f)), l1 = std::sqrt((e1[0] * e1[0] + e1[1] * e1[1]) + (e1[2] * e1[2] + 0.0f));
+    const float n0[3] = {e0[0] / l0, e0[1] / l0, e0[2] / l0}, n1[3] = {e1[0] / l1, e1[1] / l1, e1[2] / l1};
+    EncodeOct32(n0, e.v0v1); EncodeOct32(n1, e.v0v2);
+    e.edge_lengths[0] = zr_f32_to_f16(l0); e.edge_lengths[1] = zr_f32_to_f16(l1);
+    e.id = id;
+    e.packed_a = (factorRGB8 & 0xffffffu) | (1u << 24) | (doubleSided ? (1u << 25) : 0u) | (((uint32_t)strengthH & 0xfu) << 28);
+    e.packed_b = (tex & 0xffffu) | ((uint32_t)strengthH << 16);
+    for (int k = 0; k < 2; k++) { e.uv0[k] = zr_f32_to_f16(uv[k]); e.uv1[k] = zr_f32_to_f16(uv[2 + k]); e.uv2[k] = zr_f32_to_f16(uv[4 + k]); }
+}
+
+// ------------------------------------------------------------------------------------------------ block decompression
+// BC7 (BPTC), the 8 modes of the D3D11 functional spec / Khronos data format spec section 18.3.
+const uint8_t kBc7Part2[64][16] = {
+ {0,0,1,1,0,0,1,1,0,0,1,1,0,0,1,1},{0,0,0,1,0,0,0,1,0,0,0,1,0,0,0,1},{0,1,1,1,0,1,1,1,0,1,1,1,0,1,1,1},{0,0,0,1,0,0,1,1,0,0,1,1,0,1,1,1},
+ {0,0,0,0,0,0,0,1,0,0,0,1,0,0,1,1},{0,0,1,1,0,1,1,1,0,1,1,1,1,1,1,1},{0,0,0,1,0,0,1,1,0,1,1,1,1,1,1,1},{0,0,0,0,0,0,0,1,0,0,1,1,0,1,1,1},
+ {0,0,0,0,0,0,0,0,0,0,0,1,0,0,1,1},{0,0,1,1,0,1,1,1,1,1,1,1,1,1,1,1},{0,0,0,0,0,0,0,1,0,1,1,1,1,1,1,1},{0,0,0,0,0,0,0,0,0,0,0,1,0,1,1,1},
+ {0,0,0,1,0,1,1,1,1,1,1,1,1,1,1,1},{0,0,0,0,0,0,0,0,1,1,1,1,1,1,1,1},{0,0,0,0,1,1,1,1,1,1,1,1,1,1,1,1},{0,0,0,0,0,0,0,0,0,0,0,0,1,1,1,1},
+ {0,0,0,0,1,0,0,0,1,1,1,0,1,1,1,1},{0,1,1,1,0,0,0,1,0,0,0,0,0,0,0,0},{0,0,0,0,0,0,0,0,1,0,0,0,1,1,1,0},{0,1,1,1,0,0,1,1,0,0,0,1,0,0,0,0},
+ {0,0,1,1,0,0,0,1,0,0,0,0,0,0,0,0},{0,0,0,0,1,0,0,0,1,1,0,0,1,1,1,0},{0,0,0,0,0,0,0,0,1,0,0,0,1,1,0,0},{0,1,1,1,0,0,1,1,0,0,1,1,0,0,0,1},
+ {0,0,1,1,0,0,0,1,0,0,0,1,0,0,0,0},{0,0,0,0,1,0,0,0,1,0,0,0,1,1,0,0},{0,1,1,0,0,1,1,0,0,1,1,0,0,1,1,0},{0,0,1,1,0,1,1,0,0,1,1,0,1,1,0,0},
+ {0,0,0,1,0,1,1,1,1,1,1,0,1,0,0,0},{0,0,0,0,1,1,1,1,1,1,1,1,0,0,0,0},{0,1,1,1,0,0,0,1,1,0,0,0,1,1,1,0},{0,0,1,1,1,0,0,1,1,0,0,1,1,1,0,0},
+ {0,1,0,1,0,1,0,1,0,1,0,1,0,1,0,1},{0,0,0,0,1,1,1,1,0,0,0,0,1,1,1,1},{0,1,0,1,1,0,1,0,0,1,0,1,1,0,1,0},{0,0,1,1,0,0,1,1,1,1,0,0,1,1,0,0},
+ {0,0,1,1,1,1,0,0,0,0,1,1,1,1,0,0},{0,1,0,1,0,1,0,1,1,0,1,0,1,0,1,0},{0,1,1,0,1,0,0,1,0,1,1,0,1,0,0,1},{0,1,0,1,1,0,1,0,1,0,1,0,0,1,0,1},
+ {0,1,1,1,0,0,1,1,1,1,0,0,1,1,1,0},{0,0,0,1,0,0,1,1,1,1,0,0,1,0,0,0},{0,0,1,1,0,0,1,0,0,1,0,0,1,1,0,0},{0,0,1,1,1,0,1,1,1,1,0,1,1,1,0,0},
+ {0,1,1,0,1,0,0,1,1,0,0,1,0,1,1,0},{0,0,1,1,1,1,0,0,1,1,0,0,0,0,1,1},{0,1,1,0,0,1,1,0,1,0,0,1,1,0,0,1},{0,0,0,0,0,1,1,0,0,1,1,0,0,0,0,0},
+ {0,1,0,0,1,1,1,0,0,1,0,0,0,0,0,0},{0,0,1,0,0,1,1,1,0,0,1,0,0,0,0,0},{0,0,0,0,0,0,1,0,0,1,1,1,0,0,1,0},{0,0,0,0,0,1,0,0,1,1,1,0,0,1,0,0},
+ {0,1,1,0,1,1,0,0,1,0,0,1,0,0,1,1},{0,0,1,1,0,1,1,0,1,1,0,0,1,0,0,1},{0,1,1,0,0,0,1,1,1,0,0,1,1,1,0,0},{0,0,1,1,1,0,0,1,1,1,0,0,0,1,1,0},
+ {0,1,1,0,1,1,0,0,1,1,0,0,1,0,0,1},{0,1,1,0,0,0,1,1,0,0,1,1,1,0,0,1},{0,1,1,1,1,1,1,0,1,0,0,0,0,0,0,1},{0,0,0,1,1,0,0,0,1,1,1,0,0,1,1,1},
+ {0,0,0,0,1,1,1,1,0,0,1,1,0,0,1,1},{0,0,1,1,0,0,1,1,1,1,1,1,0,0,0,0},{0,0,1,0,0,0,1,0,1,1,1,0,1,1,1,0},{0,1,0,0,0,1,0,0,0,1,1,1,0,1,1,1} };
+const uint8_t kBc7Part3[64][16] = {
+ {0,0,1,1,0,0,1,1,0,2,2,1,2,2,2,2},{0,0,0,1,0,0,1,1,2,2,1,1,2,2,2,1},{0,0,0,0,2,0,0,1,2,2,1,1,2,2,1,1},{0,2,2,2,0,0,2,2,0,0,1,1,0,1,1,1},
+ {0,0,0,0,0,0,0,0,1,1,2,2,1,1,2,2},{0,0,1,1,0,0,1,1,0,0,2,2,0,0,2,2},{0,0,2,2,0,0,2,2,1,1,1,1,1,1,1,1},{0,0,1,1,0,0,1,1,2,2,1,1,2,2,1,1},
+ {0,0,0,0,0,0,0,0,1,1,1,1,2,2,2,2},{0,0,0,0,1,1,1,1,1,1,1,1,2,2,2,2},{0,0,0,0,1,1,1,1,2,2,2,2,2,2,2,2},{0,0,1,2,0,0,1,2,0,0,1,2,0,0,1,2},
+ {0,1,1,2,0,1,1,2,0,1,1,2,0,1,1,2},{0,1,2,2,0,1,2,2,0,1,2,2,0,1,2,2},{0,0,1,1,0,1,1,2,1,1,2,2,1,2,2,2},{0,0,1,1,2,0,0,1,2,2,0,0,2,2,2,0},
+ {0,0,0,1,0,0,1,1,0,1,1,2,1,1,2,2},{0,1,1,1,0,0,1,1,2,0,0,1,2,2,0,0},{0,0,0,0,1,1,2,2,1,1,2,2,1,1,2,2},{0,0,2,2,0,0,2,2,0,0,2,2,1,1,1,1},
+ {0,1,1,1,0,1,1,1,0,2,2,2,0,2,2,2},{0,0,0,1,0,0,0,1,2,2,2,1,2,2,2,1},{0,0,0,0,0,0,1,1,0,1,2,2,0,1,2,2},{0,0,0,0,1,1,0,0,2,2,1,0,2,2,1,0},
+ {0,1,2,2,0,1,2,2,0,0,1,1,0,0,0,0},{0,0,1,2,0,0,1,2,1,1,2,2,2,2,2,2},{0,1,1,0,1,2,2,1,1,2,2,1,0,1,1,0},{0,0,0,0,0,1,1,0,1,2,2,1,1,2,2,1},
+ {0,0,2,2,1,1,0,2,1,1,0,2,0,0,2,2},{0,1,1,0,0,1,1,0,2,0,0,2,2,2,2,2},{0,0,1,1,0,1,2,2,0,1,2,2,0,0,1,1},{0,0,0,0,2,0,0,0,2,2,1,1,2,2,2,1},
+ {0,0,0,0,0,0,0,2,1,1,2,2,1,2,2,2},{0,2,2,2,0,0,2,2,0,0,1,2,0,0,1,1},{0,0,1,1,0,0,1,2,0,0,2,2,0,2,2,2},{0,1,2,0,0,1,2,0,0,1,2,0,0,1,2,0},
+ {0,0,0,0,1,1,1,1,2,2,2,2,0,0,0,0},{0,1,2,0,1,2,0,1,2,0,1,2,0,1,2,0},{0,1,2,0,2,0,1,2,1,2,0,1,0,1,2,0},{0,0,1,1,2,2,0,0,1,1,2,2,0,0,1,1},
+ {0,0,1,1,1,1,2,2,2,2,0,0,0,0,1,1},{0,1,0,1,0,1,0,1,2,2,2,2,2,2,2,2},{0,0,0,0,0,0,0,0,2,1,2,1,2,1,2,1},{0,0,2,2,1,1,2,2,0,0,2,2,1,1,2,2},
+ {0,0,2,2,0,0,1,1,0,0,2,2,0,0,1,1},{0,2,2,0,1,2,2,1,0,2,2,0,1,2,2,1},{0,1,0,1,2,2,2,2,2,2,2,2,0,1,0,1},{0,0,0,0,2,1,2,1,2,1,2,1,2,1,2,1},
+ {0,1,0,1,0,1,0,1,0,1,0,1,2,2,2,2},{0,2,2,2,0,1,1,1,0,2,2,2,0,1,1,1},{0,0,0,2,1,1,1,2,0,0,0,2,1,1,1,2},{0,0,0,0,2,1,1,2,2,1,1,2,2,1,1,2},
+ {0,2,2,2,0,1,1,1,0,1,1,1,0,2,2,2},{0,0,0,2,1,1,1,2,1,1,1,2,0,0,0,2},{0,1,1,0,0,1,1,0,0,1,1,0,2,2,2,2},{0,0,0,0,0,0,0,0,2,1,1,2,2,1,1,2},
+ {0,1,1,0,0,1,1,0,2,2,2,2,2,2,2,2},{0,0,2,2,0,0,1,1,0,0,1,1,0,0,2,2},{0,0,2,2,1,1,2,2,1,1,2,2,0,0,2,2},{0,0,0,0,0,0,0,0,0,0,0,0,2,1,1,2},
+ {0,0,0,2,0,0,0,1,0,0,0,2,0,0,0,1},{0,2,2,2,1,2,2,2,0,2,2,2,1,2,2,2},{0,1,0,1,2,2,2,2,2,2,2,2,2,2,2,2},{0,1,1,1,2,0,1,1,2,2,0,1,2,2,2,0} };
+const uint8_t kAnchor2[64] = {15,15,15,15,15,15,15,15,15,15,15,15,15,15,15,15,15,2,8,2,2,8,8,15,2,8,2,2,8,8,2,2,15,15,6,8,2,8,15,15,2,8,2,2,2,15,15,6,6,2,6,8,15,15,2,2,15,15,15,15,15,2,2,15};
+const uint8_t kAnchor3a[64] = {3,3,15,15,8,3,15,15,8,8,6,6,6,5,3,3,3,3,8,15,3,3,6,10,5,8,8,6,8,5,15,15,8,15,3,5,6,10,8,15,15,3,15,5,15,15,15,15,3,15,5,5,5,8,5,10,5,10,8,13,15,12,3,3};
+const uint8_t kAnchor3b[64] = {15,8,8,3,15,15,3,8,15,15,15,15,15,15,15,8,15,8,15,3,15,8,15,8,3,15,6,10,15,15,10,8,15,3,15,10,10,8,9,10,6,15,8,15,3,6,6,8,15,3,15,15,15,15,15,15,15,15,15,15,3,15,15,8};
+const uint8_t kW2[4] = {0, 21, 43, 64}, kW3[8] = {0, 9, 18, 27, 37, 46, 55, 64}, kW4[16] = {0, 4, 9, 13, 17, 21, 26, 30, 34, 38, 43, 47, 51, 55, 60, 64};
+struct Bits { const uint8_t* p; uint32_t pos = 0; uint32_t Get(uint32_t n) { uint32_t v = 0; for (uint32_t i = 0; i < n; i++, pos++) v |= (uint32_t)((p[pos >> 3] >> (pos & 7)) & 1u) << i; return v; } };
+uint8_t Interp(uint32_t a, uint32_t b, uint32_t w) { return (uint8_t)((a * (64 - w) + b * w + 32) >> 6); }
+void Bc7Block(const uint8_t* blk, uint8_t out[16][4])
+{
+    uint32_t mode = 0; while (mode < 8 && !((blk[0] >> mode) & 1)) mode++;
+    if (mode >= 8) { std::memset(out, 0, 64); return; }
+    static const uint8_t NS[8] = {3, 2, 3, 2, 1, 1, 1, 2}, PB[8] = {4, 6, 6, 6, 0, 0, 0, 6}, RB[8] = {0, 0, 0, 0, 2, 2, 0, 0}, ISB[8] = {0, 0, 0, 0, 1, 0, 0, 0};
+    static const uint8_t CB[8] = {4, 6, 5, 7, 5, 7, 7, 5}, AB[8] = {0, 0, 0, 0, 6, 8, 7, 5}, EPB[8] = {1, 0, 0, 1, 0, 0, 1, 1}, SPB[8] = {0, 1, 0, 0, 0, 0, 0, 0};
+    static const uint8_t IB[8] = {3, 3, 2, 2, 2, 2, 4, 2}, IB2[8] = {0, 0, 0, 0, 3, 2, 0, 0};
+    Bits bs{blk, mode + 1};
+    const uint32_t ns = NS[mode], part = bs.Get(PB[mode]), rot = bs.Get(RB[mode]), isel = bs.Get(ISB[mode]);
+    uint32_t ep[6][4];
+    for (int c = 0; c < 3; c++) for (uint32_t e = 0; e < 2 * ns; e++) ep[e][c] = bs.Get(CB[mode]);
+    for (uint32_t e = 0; e < 2 * ns; e++) ep[e][3] = AB[mode] ? bs.Get(AB[mode]) : 255u;
+    uint32_t cbits = CB[mode], abits = AB[mode];
+    if (EPB[mode]) { for (uint32_t e = 0; e < 2 * ns; e++) { const uint32_t pbit = bs.Get(1); for (int c = 0; c < 3; c++) ep[e][c] = (ep[e][c] << 1) | pbit; if (abits) ep[e][3] = (ep[e][3] << 1) | pbit; } cbits++; if (abits) abits++; }
+    else if (SPB[mode]) { for (uint32_t s = 0; s < ns; s++) { const uint32_t pbit = bs.Get(1); for (uint32_t e = 2 * s; e < 2 * s + 2; e++) for (int c = 0; c < 3; c++) ep[e][c] = (ep[e][c] << 1) | pbit; } cbits++; }
+    for (uint32_t e = 0; e < 2 * ns; e++)
+    {
+        for (int c = 0; c < 3; c++) { ep[e][c] <<= (8 - cbits); ep[e][c] |= ep[e][c] >> cbits; }
+        if (abits) { ep[e][3] <<= (8 - abits); ep[e][3] |= ep[e][3] >> abits; }
+    }
+    auto subsetOf = [&](int i) -> uint32_t { return ns == 1 ? 0u : (ns == 2 ? kBc7Part2[part][i] : kBc7Part3[part][i]); };
+    auto isAnchor = [&](int i) { if (i == 0) return true; if (ns == 2) return i == kAnchor2[part]; if (ns == 3) return i == kAnchor3a[part] || i == kAnchor3b[part]; return false; };
+    uint32_t idx[16], idx2[16];
+    for (int i = 0; i < 16; i++) idx[i] = bs.Get(IB[mode] - (isAnchor(i) ? 1u : 0u));
+    if (IB2[mode]) for (int i = 0; i < 16; i++) idx2[i] = bs.Get(IB2[mode] - (i == 0 ? 1u : 0u));
+    auto weight = [](uint32_t bits, uint32_t i) -> uint32_t { return bits == 2 ? kW2[i] : (bits == 3 ? kW3[i] : kW4[i]); };
+    for (int i = 0; i < 16; i++)
+    {
+        const uint32_t s = subsetOf(i);
+        uint32_t cw, aw;
+        if (IB2[mode]) { const uint32_t w1 = weight(IB[mode], idx[i]), w2 = weight(IB2[mode], idx2[i]); cw = isel ? w2 : w1; aw = isel ? w1 : w2; }
+        else cw = aw = weight(IB[mode], idx[i]);
+        uint8_t px[4];
+        for (int c = 0; c < 3; c++) px[c] = Interp(ep[2 * s][c], ep[2 * s + 1][c], cw);
+        px[3] = Interp(ep[2 * s][3], ep[2 * s + 1][3], aw);
+        if (rot) { const uint8_t t = px[3]; px[3] = px[rot - 1]; px[rot - 1] = t; }
+        std::memcpy(out[i], px, 4);
+    }
+}
+void Bc4Block(const uint8_t* b, uint8_t out[16])
+{
+    uint32_t r[8]; r[0] = b[0]; r[1] = b[1];
+    if (r[0] > r[1]) for (int i = 1; i < 7; i++) r[1 + i] = ((7 - i) * r[0] + i * r[1]) / 7;
+    else { for (int i = 1; i < 5; i++) r[1 + i] = ((5 - i) * r[0] + i * r[1]) / 5; r[6] = 0; r[7] = 255; }
+    uint64_t bits = 0; for (int i = 0; i < 6; i++) bits |= (uint64_t)b[2 + i] << (8 * i);
+    for (int i = 0; i < 16; i++) out[i] = (uint8_t)r[(bits >> (3 * i)) & 7];
+}
+
+// ------------------------------------------------------------------------------------------------ DDS -> texel heap entry
+struct Image { uint32_t w = 0, h = 0, mips = 0; int channels = 4; bool srgbFormat = false; std::vector<std::vector<uint8_t>> mip; };
+Image LoadDDS(const std::string& path)
+{
+    const std::vector<uint8_t> d = ReadFile(path);
+    if (d.size() < 128 || std::memcmp(d.data(), "DDS ", 4)) Throw(path + ": not a DDS file");
+    auto u32 = [&](size_t off) { uint32_t v; std::memcpy(&v, d.data() + off, 4); return v; };
+    Image img; img.h = u32(12); img.w = u32(16); img.mips = u32(28) ? u32(28) : 1;
+    size_t off = 128; uint32_t fmt = 0;
+    if (!std::memcmp(d.data() + 84, "DX10", 4)) { fmt = u32(128); off = 148; }
+    else if (!std::memcmp(d.data() + 84, "ATI2", 4) || !std::memcmp(d.data() + 84, "BC5U", 4)) fmt = 83;
+    else Throw(path + ": only DX10-header or BC5 DDS files are supported");
+    // DXGI_FORMAT: 28 / 29 RGBA8 (UNORM / sRGB), 83 BC5_UNORM, 98 / 99 BC7 (UNORM / sRGB)
+    if (fmt != 28 && fmt != 29 && fmt != 83 && fmt != 98 && fmt != 99) Throw(path + ": unsupported DXGI format " + std::to_string(fmt));
+    img.channels = fmt == 83 ? 2 : 4; img.srgbFormat = (fmt == 29 || fmt == 99);
+    uint32_t w = img.w, h = img.h;
+    for (uint32_t m = 0; m < img.mips; m++)
+    {
+        std::vector<uint8_t> px((size_t)w * h * img.channels);
+        const uint32_t bw = (w + 3) / 4, bh = (h + 3) / 4;
+        const size_t bytes = fmt == 28 || fmt == 29 ? (size_t)w * h * 4 : (size_t)bw * bh * 16;
+        if (off + bytes > d.size()) Throw(path + ": truncated");
+        if (fmt == 28 || fmt == 29) std::memcpy(px.data(), d.data() + off, bytes);
+        else if (fmt == 83) zrh_bc5_decode(d.data() + off, w, h, px.data());
+        else zrh_bc7_decode(d.data() + off, w, h, px.data());
+        img.mip.push_back(std::move(px));
+        off += bytes; w = w > 1 ? w >> 1 : 1; h = h > 1 ? h >> 1 : 1;
+    }
+    return img;
+}
+
+} // namespace
+
+struct zrh_scene_data
+{
+    std::vector<zr_vertex> vertices; std::vector<uint32_t> indices; std::vector<zr_mesh_instance> instances; std::vector<float> toWorld;
+    std::vector<uint8_t> mask; std::vector<uint32_t> numTris; std::vector<zr_material> materials; std::vector<zr_emissive_triangle> emissives;
+    std::vector<uint16_t> rho; uint32_t rhoDim[3] = {0, 0, 0};
+    std::vector<zr_texture_desc> textures; std::vector<uint8_t> texels; uint32_t texOffsets[4] = {0, 0, 0, 0};
+    zr_scene_desc desc;
+    void Finish()
+    {
+        std::memset(&desc, 0, sizeof(desc));
+        desc.vertices = vertices.data(); desc.num_vertices = (uint32_t)vertices.size(); desc.indices = indices.data(); desc.num_indices = (uint32_t)indices.size();
+        desc.instances = instances.data(); desc.num_instances = (uint32_t)instances.size(); desc.instance_to_world = toWorld.data();
+        desc.instance_mask = mask.data(); desc.instance_num_tris = numTris.data(); desc.materials = materials.data(); desc.num_materials = (uint32_t)materials.size();
+        desc.emissives = emissives.empty() ? nullptr : emissives.data(); desc.num_emissives = (uint32_t)emissives.size();
+        desc.rho_lut = rho.data(); for (int k = 0; k < 3; k++) desc.rho_dim[k] = rhoDim[k];
+        desc.textures = textures.empty() ? nullptr : textures.data(); desc.num_textures = (uint32_t)textures.size();
+        desc.texels = texels.empty() ? nullptr : texels.data(); desc.texel_bytes = texels.size();
+    }
+};
+
+namespace {
+
+struct Accessor { const uint8_t* base; size_t stride; int comp, ncomp; size_t count; bool normalized; };
+struct Gltf
+{
+    Json root; std::string dir; std::vector<std::vector<uint8_t>> buffers;
+    Accessor Acc(int idx) const
+    {
+        const Json& a = root.At("accessors").arr.at(idx);
+        const Json& bv = root.At("bufferViews").arr.at(a.At("bufferView").num);
+        const std::vector<uint8_t>& buf = buffers.at((size_t)bv.At("buffer").num);
+        Accessor r; r.comp = (int)a.At("componentType").num; r.count = (size_t)a.At("count").num; r.normalized = a.BoolOr("normalized", false);
+        const std::string t = a.At("type").str;
+        r.ncomp = t == "SCALAR" ? 1 : t == "VEC2" ? 2 : t == "VEC3" ? 3 : t == "VEC4" ? 4 : t == "MAT4" ? 16 : 0;
+        if (!r.ncomp) Throw("glTF: accessor type " + t + " is not supported");
+        const size_t csz = (r.comp == 5120 || r.comp == 5121) ? 1 : (r.comp == 5122 || r.comp == 5123) ? 2 : 4;
+        const size_t off = (size_t)bv.NumOr("byteOffset", 0) + (size_t)a.NumOr("byteOffset", 0);
+        r.stride = (size_t)bv.NumOr("byteStride", 0); if (!r.stride) r.stride = csz * r.ncomp;
+        if (off + (r.count ? (r.count - 1) * r.stride + csz * r.ncomp : 0) > buf.size()) Throw("glTF: accessor reads past its buffer");
+        r.base = buf.data() + off;
+        return r;
+    }
+    static float Comp(const Accessor& a, size_t i, int c)
+    {
+        const uint8_t* p = a.base + i * a.stride;
+        switch (a.comp)
+        {
+        case 5126: { float f; std::memcpy(&f, p + 4 * c, 4); return f; }
+        case 5121: { const float v = (float)p[c]; return a.normalized ? v / 255.0f : v; }
+        case 5123: { uint16_t u; std::memcpy(&u, p + 2 * c, 2); return a.normalized ? (float)u / 65535.0f : (float)u; }
+        case 5125: { uint32_t u; std::memcpy(&u, p + 4 * c, 4); return (float)u; }
+        case 5120: { const float v = (float)(int8_t)p[c]; return a.normalized ? std::fmax(v / 127.0f, -1.0f) : v; }
+        case 5122: { int16_t u; std::memcpy(&u, p + 2 * c, 2); return a.normalized ? std::fmax((float)u / 32767.0f, -1.0f) : (float)u; }
+        default: Throw("glTF: unsupported component type");
+        }
+    }
+    static uint32_t Index(const Accessor& a, size_t i)
+    {
+        const uint8_t* p = a.base + i * a.stride;
+        if (a.comp == 5121) return p[0];
+        if (a.comp == 5123) { uint16_t u; std::memcpy(&u, p, 2); return u; }
+        if (a.comp == 5125) { uint32_t u; std::memcpy(&u, p, 4); return u; }
+        Throw("glTF: index accessor must be unsigned");
+    }
+};
+
+struct MeshPrim { uint32_t vtx, idx, nidx; int mat; };
+
+void Load(const std::string& path, zrh_scene_data& sc)
+{
+    Gltf g;
+    { const std::vector<uint8_t> txt = ReadFile(path); JsonParser jp{(const char*)txt.data(), (const char*)txt.data() + txt.size()}; g.root = jp.Value(); }
+    g.dir = DirOf(path);
+    for (const Json& b : g.root.At("buffers").arr)
+    {
+        const std::string uri = b.StrOr("uri", "");
+        if (uri.empty() || !uri.compare(0, 5, "data:")) Throw("glTF: only external .bin buffers are supported");
+        g.buffers.push_back(ReadFile(g.dir + "/" + uri));
+    }
+    // ---- textures: one table per kind, heap = [base colour..., normal..., metallic-roughness..., emissive...] (the reference's four descriptor tables)
+    std::vector<int> table[4]; std::map<int, uint32_t> slot[4];
+    auto texSlot = [&](int kind, const Json* view) -> uint32_t {
+        if (!view) return 0xffffu;
+        const int texIdx = view->IntOr("index", -1); if (texIdx < 0) return 0xffffu;
+        const int image = g.root.At("textures").arr.at(texIdx).IntOr("source", -1); if (image < 0) Throw("glTF: textureView doesn't point to any image");
+        auto it = slot[kind].find(image); if (it != slot[kind].end()) return it->second;
+        const uint32_t s = (uint32_t)table[kind].size(); table[kind].push_back(image); slot[kind][image] = s; return s; };
+    // ---- materials (index 0 = the default material, glTF materials follow: MaterialIdx = glTF index + 1)
+    { MaterialDesc d; d.metallic = 0.0f; d.roughness = 0.3f; sc.materials.push_back(PackMaterial(d)); }
+    const Json* mats = g.root.Find("materials");
+    for (size_t mi = 0; mats && mi < mats->Size(); mi++)
+    {
+        const Json& m = mats->arr[mi];
+        MaterialDesc d;
+        static const Json kEmpty;
+        const Json& pbr = m.Find("pbrMetallicRoughness") ? *m.Find("pbrMetallicRoughness") : kEmpty;
+        const Json& ext = m.Find("extensions") ? *m.Find("extensions") : kEmpty;
+        if (const Json* f = pbr.Find("baseColorFactor")) for (int k = 0; k < 4; k++) d.baseColor[k] = (float)f->arr.at(k).num;
+        d.metallic = (float)pbr.NumOr("metallicFactor", 1.0); d.roughness = (float)pbr.NumOr("roughnessFactor", 1.0);
+        if (const Json* f = m.Find("emissiveFactor")) for (int k = 0; k < 3; k++) d.emissiveFactor[k] = (float)f->arr.at(k).num;
+        if (const Json* e = ext.Find("KHR_materials_emissive_strength")) d.emissiveStrength = (float)e->NumOr("emissiveStrength", 1.0);
+        if (const Json* e = ext.Find("KHR_materials_ior")) d.ior = (float)e->NumOr("ior", 1.5);
+        if (const Json* e = ext.Find("KHR_materials_transmission")) d.transmission = (float)e->NumOr("transmissionFactor", 0.0);
+        if (const Json* e = ext.Find("KHR_materials_clearcoat")) { d.coatWeight = (float)e->NumOr("clearcoatFactor", 0.0); d.coatRoughness = (float)e->NumOr("clearcoatRoughnessFactor", 0.0); }
+        d.alphaCutoff = (float)m.NumOr("alphaCutoff", 0.5);
+        const std::string am = m.StrOr("alphaMode", "OPAQUE"); d.alphaMode = am == "MASK" ? 1 : (am == "BLEND" ? 2 : 0);
+        d.doubleSided = m.BoolOr("doubleSided", false);
+        d.baseColorTex = texSlot(0, pbr.Find("baseColorTexture"));
+        if (const Json* nt = m.Find("normalTexture")) { d.normalTex = texSlot(1, nt); d.normalScale = (float)nt->NumOr("scale", 1.0); }
+        d.mrTex = texSlot(2, pbr.Find("metallicRoughnessTexture"));
+        d.emissiveTex = texSlot(3, m.Find("emissiveTexture"));
+        sc.materials.push_back(PackMaterial(d));
+    }
+    // decode the images into the texel heap
+    for (int kind = 0; kind < 4; kind++)
+    {
+        sc.texOffsets[kind] = (uint32_t)sc.textures.size();
+        for (int image : table[kind])
+        {
+            const std::string uri = g.root.At("images").arr.at(image).StrOr("uri", "");
+            if (uri.size() < 4 || uri.compare(uri.size() - 4, 4, ".dds")) Throw("glTF: image '" + uri + "': only .dds images are supported (the reference converts its assets with Tools/BCnCompressglTF)");
+            const Image img = LoadDDS(g.dir + "/" + uri);
+            const bool colour = (kind == 0 || kind == 3);
+            if (colour && img.channels != 4) Throw(uri + ": base colour / emissive maps must be 4-channel");
+            zr_texture_desc td; std::memset(&td, 0, sizeof(td));
+            while (sc.texels.size() & 3) sc.texels.push_back(0);
+            td.offset = sc.texels.size(); td.width = (uint16_t)img.w; td.height = (uint16_t)img.h; td.num_mips = (uint8_t)img.mips;
+            td.format = colour ? ZR_TEX_RGBA8_SRGB : ZR_TEX_RG8;
+            for (const auto& mp : img.mip)
+            {
+                if (!colour && img.channels == 4) { for (size_t i = 0; i < mp.size(); i += 4) { sc.texels.push_back(mp[i]); sc.texels.push_back(mp[i + 1]); } }      // RGBA8 normal / MR map: keep RG
+                else sc.texels.insert(sc.texels.end(), mp.begin(), mp.end());
+            }
+            sc.textures.push_back(td);
+        }
+    }
+    // ---- meshes: one entry per (mesh, primitive); RH -> LH: z flipped, winding swapped (glTF.cpp:163-236)
+    std::map<std::pair<int, int>, MeshPrim> prims;
+    const Json& meshes = g.root.At("meshes");
+    for (size_t mi = 0; mi < meshes.Size(); mi++)
+    {
+        const Json& plist = meshes.arr[mi].At("primitives");
+        for (size_t pi = 0; pi < plist.Size(); pi++)
+        {
+            const Json& prim = plist.arr[pi];
+            if (prim.IntOr("mode", 4) != 4) Throw("glTF: only triangle-list primitives are supported");
+            const Json& at = prim.At("attributes");
+            if (!at.Find("POSITION")) Throw("POSITION was not found in the vertex attributes.");
+            if (!at.Find("NORMAL")) Throw("NORMAL was not found in the vertex attributes.");
+            const Accessor pos = g.Acc((int)at.At("POSITION").num), nrm = g.Acc((int)at.At("NORMAL").num);
+            MeshPrim mp; mp.vtx = (uint32_t)sc.vertices.size(); mp.idx = (uint32_t)sc.indices.size(); mp.mat = prim.IntOr("material", -1);
+            const bool hasUV = at.Find("TEXCOORD_0") != nullptr, hasTan = hasUV && at.Find("TANGENT") != nullptr;
+            Accessor uv{}, tan{};
+            if (hasUV) uv = g.Acc((int)at.At("TEXCOORD_0").num);
+            if (hasTan) tan = g.Acc((int)at.At("TANGENT").num);
+            for (size_t v = 0; v < pos.count; v++)
+            {
+                zr_vertex vx; std::memset(&vx, 0, sizeof(vx));
+                const float n[3] = {Gltf::Comp(nrm, v, 0), Gltf::Comp(nrm, v, 1), Gltf::Comp(nrm, v, 2) * -1.0f};
+                vx.pos[0] = Gltf::Comp(pos, v, 0); vx.pos[1] = Gltf::Comp(pos, v, 1); vx.pos[2] = Gltf::Comp(pos, v, 2) * -1.0f;
+                EncodeOct32(n, vx.normal);
+                if (hasUV) { vx.uv[0] = Gltf::Comp(uv, v, 0); vx.uv[1] = Gltf::Comp(uv, v, 1); }
+                if (hasTan) { const float t[3] = {Gltf::Comp(tan, v, 0), Gltf::Comp(tan, v, 1), Gltf::Comp(tan, v, 2) * -1.0f}; EncodeOct32(t, vx.tangent); }
+                sc.vertices.push_back(vx);
+            }
+            if (!prim.Find("indices")) Throw("glTF: non-indexed primitives are not supported");
+            const Accessor ia = g.Acc((int)prim.At("indices").num);
+            if (ia.count % 3) Throw("glTF: index count is not a multiple of 3");
+            for (size_t t = 0; t < ia.count; t += 3) { sc.indices.push_back(Gltf::Index(ia, t)); sc.indices.push_back(Gltf::Index(ia, t + 2)); sc.indices.push_back(Gltf::Index(ia, t + 1)); }
+            mp.nidx = (uint32_t)ia.count;
+            prims[{(int)mi, (int)pi}] = mp;
+        }
+    }
+    // ---- nodes, depth first: world = local x parent (SceneCore.cpp:871-873); one instance per primitive
+    struct Em { uint32_t inst; MeshPrim mp; };
+    std::vector<Em> emissive;
+    const Json& nodes = g.root.At("nodes");
+    auto isEmissive = [&](int mat) {
+        if (mat < 0) return false;
+        const Json& m = mats->arr.at(mat);
+        float sum = 0; if (const Json* f = m.Find("emissiveFactor")) sum = (float)f->arr.at(0).num + (float)f->arr.at(1).num + (float)f->arr.at(2).num;
+        return sum > 0 || m.Find("emissiveTexture") != nullptr; };
+    Mat43 identity; std::memset(&identity, 0, sizeof(identity)); for (int i = 0; i < 3; i++) identity.m[i][i] = 1.0f;
+    struct Walker
+    {
+        Gltf& g; zrh_scene_data& sc; std::map<std::pair<int, int>, MeshPrim>& prims; std::vector<Em>& emissive; const Json& nodes; decltype(isEmissive)& isEm;
+        void Visit(int nidx, const Mat43& parent)
+        {
+            const Json& node = nodes.arr.at(nidx);
+            float s[3] = {1, 1, 1}, q[4] = {0, 0, 0, 1}, t[3] = {0, 0, 0};
+            if (const Json* m = node.Find("matrix"))
+            {
+                // column-major glTF matrix -> row-vector rows; RH -> LH (glTF.cpp:800-833), then decomposed like the reference's decomposeTRS
+                float M[16]; for (int k = 0; k < 16; k++) M[k] = (float)m->arr.at(k).num;
+                Mat43 r; for (int i = 0; i < 4; i++) for (int j = 0; j < 3; j++) r.m[i][j] = M[4 * i + j];
+                r.m[0][2] *= -1.0f; r.m[1][2] *= -1.0f; r.m[2][0] *= -1.0f; r.m[2][1] *= -1.0f; r.m[3][2] *= -1.0f;
+                DecomposeSRT(r, s, q, t);
+            }
+            else
+            {
+                if (const Json* a = node.Find("scale")) for (int k = 0; k < 3; k++) { s[k] = (float)a->arr.at(k).num; if (!(s[k] > 0)) Throw("Negative scale factors are not supported."); }
+                if (const Json* a = node.Find("translation")) { t[0] = (float)a->arr.at(0).num; t[1] = (float)a->arr.at(1).num; t[2] = (float)-a->arr.at(2).num; }
+                if (const Json* a = node.Find("rotation")) { q[0] = -(float)a->arr.at(0).num; q[1] = -(float)a->arr.at(1).num; q[2] = (float)a->arr.at(2).num; q[3] = (float)a->arr.at(3).num; }
+            }
+            const Mat43 world = Mul(AffineTransformation(s, q, t), parent);
+            const int mesh = node.IntOr("mesh", -1);
+            if (mesh >= 0)
+            {
+                const size_t np = g.root.At("meshes").arr.at(mesh).At("primitives").Size();
+                for (size_t pi = 0; pi < np; pi++)
+                {
+                    const MeshPrim& mp = prims.at({mesh, (int)pi});
+                    zr_mesh_instance I; std::memset(&I, 0, sizeof(I));
+                    float M[12]; ToToWorld(world, M);
+                    I.base_vtx_offset = mp.vtx; I.base_idx_offset = mp.idx; I.mat_idx = (uint16_t)(mp.mat + 1);
+                    FillMeshInstance(M, I);
+                    const zr_material& mat = sc.materials.at((size_t)mp.mat + 1);
+                    const uint32_t bct = mat.base_color_tex_subsurf_coat_weight & 0xffffu;
+                    I.base_color_tex = (uint16_t)bct;
+                    const float alpha = (float)((mat.base_color_factor >> 24) & 0xffu) / 255.0f, cutoff = (float)((mat.emissive_tex_alpha_cutoff_coat_ior >> 16) & 0xffu) / 255.0f;
+                    I.alpha_factor_cutoff = (uint16_t)(Unorm8(alpha) | (Unorm8(cutoff) << 8));
+                    I.base_emissive_tri_offset = 0xffffffffu;
+                    const bool em = isEm(mp.mat);
+                    const int alphaMode = (int)((mat.coat_color_flags >> 27) & 3u);
+                    sc.instances.push_back(I);
+                    sc.toWorld.insert(sc.toWorld.end(), M, M + 12);
+                    sc.mask.push_back((uint8_t)((em ? ZR_SUBGROUP_EMISSIVE : ZR_SUBGROUP_NON_EMISSIVE) | (alphaMode != 0 ? ZR_INSTANCE_NON_OPAQUE : 0u)));
+                    sc.numTris.push_back(mp.nidx / 3);
+                    if (em) emissive.push_back(Em{(uint32_t)sc.instances.size() - 1, mp});
+                }
+            }
+            if (const Json* ch = node.Find("children")) for (const Json& c : ch->arr) Visit((int)c.num, world);
+        }
+    } walker{g, sc, prims, emissive, nodes, isEmissive};
+    const Json& scenes = g.root.At("scenes");
+    const Json& scene = scenes.arr.at((size_t)g.root.IntOr("scene", 0));
+    for (const Json& n : scene.At("nodes").arr) walker.Visit((int)n.num, identity);
+    // ---- emissive triangles in world space (glTF.cpp:692-767, SceneCore.cpp:196-236): ID = PCG3d(instance, 0, triangle).x
+    for (const Em& em : emissive)
+    {
+        sc.instances[em.inst].base_emissive_tri_offset = (uint32_t)sc.emissives.size();
+        const zr_material& mat = sc.materials.at((size_t)em.mp.mat + 1);
+        const float* M = sc.toWorld.data() + 12 * (size_t)em.inst;
+        for (uint32_t p = 0; p < em.mp.nidx / 3; p++)
+        {
+            float pw[3][3], uv[6];
+            for (int k = 0; k < 3; k++)
+            {
+                const zr_vertex& v = sc.vertices[em.mp.vtx + sc.indices[em.mp.idx + 3 * p + k]];
+                for (int r = 0; r < 3; r++) pw[k][r] = ((M[4 * r] * v.pos[0] + M[4 * r + 1] * v.pos[1]) + M[4 * r + 2] * v.pos[2]) + M[4 * r + 3];
+                uv[2 * k] = v.uv[0]; uv[2 * k + 1] = v.uv[1];
+            }
+            uint32_t hx = em.inst, hy = 0, hz = p; zr_pcg3d(&hx, &hy, &hz);
+            zr_emissive_triangle e;
+            PackEmissiveTriangle(pw[0], pw[1], pw[2], uv, mat.emissive_factor_normal_scale & 0xffffffu, mat.emissive_tex_alpha_cutoff_coat_ior & 0xffffu,
+                (uint16_t)(mat.emissive_strength_ior & 0xffffu), hx, (mat.coat_color_flags & (1u << ZR_MAT_DOUBLE_SIDED_BIT)) != 0, e);
+            sc.emissives.push_back(e);
+        }
+    }
+}
+
+} // namespace
+
+extern "C" {
+
+const char* zrh_scene_io_last_error(void) { return g_err.c_str(); }
+
+int zrh_gltf_load(const char* path, const uint16_t* rho, const uint32_t* rhoDim, zrh_scene_data** out)
+{
+    if (!path || !out) { g_err = "null argument"; return -1; }
+    std::unique_ptr<zrh_scene_data> sc(new zrh_scene_data());
+    try { Load(path, *sc); }
+    catch (const Error& e) { g_err = e.what; return -1; }
+    catch (const std::exception& e) { g_err = std::string("glTF: malformed file (") + e.what() + ")"; return -1; }
+    if (rho && rhoDim) { const size_t n = (size_t)rhoDim[0] * rhoDim[1] * rhoDim[2]; sc->rho.assign(rho, rho + n); for (int k = 0; k < 3; k++) sc->rhoDim[k] = rhoDim[k]; }
+    sc->Finish();
+    *out = sc.release();
+    return 0;
+}
+const zr_scene_desc* zrh_scene_data_desc(const zrh_scene_data* s) { return s ? &s->desc : nullptr; }
+void zrh_scene_data_tex_offsets(const zrh_scene_data* s, uint32_t* out4) { for (int k = 0; k < 4; k++) out4[k] = s->texOffsets[k]; }
+void zrh_scene_data_destroy(zrh_scene_data* s) { delete s; }
+
+void zrh_decompose_srt(const float* M, float* s, float* q, float* t) { DecomposeSRT(FromToWorld(M), s, q, t); }
+void zrh_compose_world(const float* s, const float* q, const float* t, const float* parent, float* out)
+{
+    Mat43 P; std::memset(&P, 0, sizeof(P)); for (int i = 0; i < 3; i++) P.m[i][i] = 1.0f;
+    if (parent) P = FromToWorld(parent);
+    ToToWorld(Mul(AffineTransformation(s, q, t), P), out);
+}
+void zrh_fill_mesh_instance(const float* M, zr_mesh_instance* inst) { FillMeshInstance(M, *inst); }
+void zrh_pack_emissive_triangle(const float* v0, const float* v1, const float* v2, const float* uv6, uint32_t factor, uint32_t tex, uint16_t strength, uint32_t id,
+    int doubleSided, zr_emissive_triangle* out) { PackEmissiveTriangle(v0, v1, v2, uv6, factor, tex, strength, id, doubleSided != 0, *out); }
+
+int zrh_bc7_decode(const uint8_t* blocks, uint32_t w, uint32_t h, uint8_t* rgba)
+{
+    const uint32_t bw = (w + 3) / 4, bh = (h + 3) / 4;
+    for (uint32_t by = 0; by < bh; by++) for (uint32_t bx = 0; bx < bw; bx++)
+    {
+        uint8_t px[16][4];
+        Bc7Block(blocks + 16 * ((size_t)by * bw + bx), px);
+        for (int i = 0; i < 16; i++)
+        {
+            const uint32_t x = 4 * bx + (i & 3), y = 4 * by + (i >> 2);
+            if (x < w && y < h) std::memcpy(rgba + 4 * ((size_t)y * w + x), px[i], 4);
+        }
+    }
+    return 0;
+}
+int zrh_bc5_decode(const uint8_t* blocks, uint32_t w, uint32_t h, uint8_t* rg)
+{
+    const uint32_t bw = (w + 3) / 4, bh = (h + 3) / 4;
+    for (uint32_t by = 0; by < bh; by++) for (uint32_t bx = 0; bx < bw; bx++)
+    {
+        uint8_t r[16], g[16];
+        const uint8_t* b = blocks + 16 * ((size_t)by * bw + bx);
+        Bc4Block(b, r); Bc4Block(b + 8, g);
+        for (int i = 0; i < 16; i++)
+        {
+            const uint32_t x = 4 * bx + (i & 3), y = 4 * by + (i >> 2);
+            if (x < w && y < h) { rg[2 * ((size_t)y * w + x)] = r[i]; rg[2 * ((size_t)y * w + x) + 1] = g[i]; }
+        }
+    }
+    return 0;
+}
+
+}

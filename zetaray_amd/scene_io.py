@@ -47,11 +47,12 @@ def pcg3d(x, y, z):
 
 
 def encode_octahedral(n):
-    """Math::encode_octahedral + unorm2::FromNormalized (OctahedralVector.h:8-24, Vector.h:626-647)."""
+    """Math::encode_octahedral + unorm2::FromNormalized (VectorFuncs.h:134-153, Vector.h:626-647) in the SSE code's operation order: the
+    L1 norm is (|x| + |z|) + |y| (hadd_float3), the fold's sign is taken from the input component (v >= 0), round to nearest even."""
     n = np.asarray(n, dtype=np.float32).reshape(-1, 3)
-    denom = np.abs(n[:, 0]) + np.abs(n[:, 1]) + np.abs(n[:, 2])
+    denom = (np.abs(n[:, 0]) + np.abs(n[:, 2])) + np.abs(n[:, 1])
     p = n[:, :2] / denom[:, None]
-    sgn = np.where(np.signbit(p), np.float32(-1), np.float32(1)).astype(np.float32)
+    sgn = np.where(n[:, :2] >= 0, np.float32(1), np.float32(-1)).astype(np.float32)
     folded = (np.float32(1) - np.abs(p[:, ::-1])) * sgn
     enc = np.where((n[:, 2] <= 0)[:, None], folded, p).astype(np.float32)
     u = (enc * np.float32(0.5) + np.float32(0.5)) * np.float32(65535.0)
@@ -388,11 +389,66 @@ def load_gltf(path, rho=None) -> Scene:
     return sc
 
 
+def _sceneio_lib():
+    """zetaray_amd/libzetaray_sceneio.so: the C++ scene ingestion (zetaray_amd/host/zr_scene_io.cpp; no HIP dependency)"""
+    import ctypes as C
+    global _SCENEIO
+    if "_SCENEIO" not in globals() or _SCENEIO is None:
+        L = C.CDLL(os.path.join(os.path.dirname(os.path.abspath(__file__)), "libzetaray_sceneio.so"))
+        L.zrh_gltf_load.argtypes = [C.c_char_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.zrh_scene_io_last_error.restype = C.c_char_p
+        L.zrh_scene_data_desc.restype = C.POINTER(wire.SceneDesc)
+        L.zrh_scene_data_desc.argtypes = [C.c_void_p]
+        L.zrh_scene_data_tex_offsets.argtypes = [C.c_void_p, C.c_void_p]
+        L.zrh_scene_data_destroy.argtypes = [C.c_void_p]
+        _SCENEIO = L
+    return _SCENEIO
+
+
+def load_gltf_native(path, rho=None):
+    """glTF -> wire formats through the C++ loader (MeshInstance quantisation by decomposeSRT of the world matrix, node hierarchies, matrix
+    nodes, DDS material textures decoded to the texel heap).  Returns (Scene, texture-table offsets dict for set_texture_heap_offsets)."""
+    import ctypes as C
+    L = _sceneio_lib()
+    rho_data, rho_dim = load_rho_default() if rho is None else rho
+    rho_data = np.ascontiguousarray(rho_data, np.uint16)
+    dims = (C.c_uint32 * 3)(*rho_dim)
+    h = C.c_void_p()
+    if L.zrh_gltf_load(os.fsencode(path), rho_data.ctypes.data, dims, C.byref(h)) != 0:
+        raise RuntimeError(L.zrh_scene_io_last_error().decode())
+    try:
+        d = L.zrh_scene_data_desc(h).contents
+
+        def arr(ptr, n, dt):
+            if not ptr or n == 0:
+                return np.zeros(0, dt)
+            dt = np.dtype(dt)
+            return np.frombuffer(C.string_at(ptr, n * dt.itemsize), dt).copy()
+        sc = Scene()
+        sc.vertices = arr(d.vertices, d.num_vertices, wire.VERTEX)
+        sc.indices = arr(d.indices, d.num_indices, np.uint32)
+        sc.instances = arr(d.instances, d.num_instances, wire.MESH_INSTANCE)
+        sc.instance_to_world = arr(d.instance_to_world, d.num_instances * 12, np.float32).reshape(-1, 12)
+        sc.instance_mask = arr(d.instance_mask, d.num_instances, np.uint8)
+        sc.instance_num_tris = arr(d.instance_num_tris, d.num_instances, np.uint32)
+        sc.materials = arr(d.materials, d.num_materials, wire.MATERIAL)
+        sc.emissives = arr(d.emissives, d.num_emissives, wire.EMISSIVE_TRI)
+        sc.textures = arr(d.textures, d.num_textures, wire.TEXTURE_DESC)
+        sc.texels = arr(d.texels, d.texel_bytes, np.uint8)
+        sc.rho, sc.rho_dim = rho_data, tuple(rho_dim)
+        offs = (C.c_uint32 * 4)()
+        L.zrh_scene_data_tex_offsets(h, offs)
+        return sc, dict(base_color=offs[0], normal=offs[1], metallic_roughness=offs[2], emissive=offs[3])
+    finally:
+        L.zrh_scene_data_destroy(h)
+
+
 def save_npz(sc: Scene, path):
     """Wire-format fixture (tests/golden/*.npz); the rho LUT is not stored (it ships in zetaray_amd/assets)."""
     np.savez_compressed(path, vertices=sc.vertices, indices=sc.indices, instances=sc.instances,
                         instance_to_world=sc.instance_to_world, instance_mask=sc.instance_mask,
-                        instance_num_tris=sc.instance_num_tris, materials=sc.materials, emissives=sc.emissives)
+                        instance_num_tris=sc.instance_num_tris, materials=sc.materials, emissives=sc.emissives,
+                        **({"textures": sc.textures, "texels": sc.texels} if len(sc.textures) else {}))
 
 
 def load_npz(path) -> Scene:
@@ -406,6 +462,8 @@ def load_npz(path) -> Scene:
     sc.instance_num_tris = z["instance_num_tris"].astype(np.uint32)
     sc.materials = z["materials"].astype(wire.MATERIAL)
     sc.emissives = z["emissives"].astype(wire.EMISSIVE_TRI)
+    if "textures" in z.files:
+        sc.textures, sc.texels = z["textures"].astype(wire.TEXTURE_DESC), z["texels"].astype(np.uint8)
     sc.rho, sc.rho_dim = load_rho_default()
     return sc
 
