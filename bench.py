@@ -204,7 +204,10 @@ def main():
         # tile + a 32-px apron, and exchanges reservoir halos point-to-point over RCCL before the spatial stage and after
         # the frame (zetaray_amd/tiling.py); N = 1 degenerates to the plain renderer
         from zetaray_amd import tiling
-        tiled = tiling.TiledRestirPT(sc, W, H, world, rank, device=local_rank, params=prm, dist=dist, kind=args.integrator)
+        # N > 1: the halo exchange runs in C++ (libzetaray_host.so zr_halo.cpp: one pack kernel, grouped ncclSend / ncclRecv over RCCL on the
+        # pass's stream, one unpack kernel); ZR_HALO_TRANSPORT=torch_p2p selects the per-plane copies + torch.distributed P2P path
+        transport = os.environ.get("ZR_HALO_TRANSPORT", "rccl_cpp")
+        tiled = tiling.TiledRestirPT(sc, W, H, world, rank, device=local_rank, params=prm, dist=dist, kind=args.integrator, transport=transport)
         r = tiled.r
     else:
         r = api.Renderer(sc, tw, th, device=local_rank, params=prm, tile_origin=(x0, y0), integrator=api.INTEGRATOR_PATH_TRACING)
@@ -298,6 +301,7 @@ def main():
                        f", 32-px apron, RCCL p2p halo exchange of reservoir planes ({tiled.bpp} B/px): {tiled.halo_bytes} B sent per "
                        f"rank per exchange, {(1 if args.no_final_halo else 2) if rpt else (0 if args.no_final_halo else 1)} exchanges per frame"
                        if (tiled is not None and world > 1) else ""),
+                   "halo_transport": (tiled.transport if (tiled is not None and world > 1) else None),
                    "rays_per_frame": round((n_closest + n_shadow) / args.steps, 1),
                    "redundant_apron_primary_rays_per_frame": round(apron_rays / args.steps, 1),
                    "fps": round(1e3 / ms_per_step, 2)},

@@ -296,6 +296,15 @@ int zr_pass_halo_pack(zr_pass* pass, void* hip_stream, const zr_gbuffer* gbuffer
                       uint32_t width, uint32_t height, void* dev_dst, size_t bytes);
 int zr_pass_halo_unpack(zr_pass* pass, void* hip_stream, const zr_gbuffer* gbuffer, int which, uint32_t x0, uint32_t y0,
                         uint32_t width, uint32_t height, const void* dev_src, size_t bytes);
+/* Fused variant for the multi-device path: ONE kernel moves every reservoir plane of every rect between the planes and one device buffer
+   (send or receive buffer of all peers).  Rect i occupies [offset, offset + w * h * bytes_per_pixel) of the buffer, laid out like the block
+   zr_pass_halo_pack writes (planes back to back); offsets must be 16-byte aligned and w * h a multiple of 8. */
+#define ZR_HALO_MAX_RECTS 16
+typedef struct zr_halo_rect { uint32_t x0, y0, w, h; uint64_t offset; } zr_halo_rect;
+int zr_pass_halo_pack_all(zr_pass* pass, void* hip_stream, const zr_gbuffer* gbuffer, int which, const zr_halo_rect* rects, uint32_t num_rects,
+                          void* dev_buf, size_t bytes);
+int zr_pass_halo_unpack_all(zr_pass* pass, void* hip_stream, const zr_gbuffer* gbuffer, int which, const zr_halo_rect* rects, uint32_t num_rects,
+                            const void* dev_buf, size_t bytes);
 int zr_pass_get_output(const zr_pass* pass, int which, void** dev_ptr, uint32_t* width, uint32_t* height,
                        uint32_t* bytes_per_pixel);
 int zr_pass_download_output(const zr_pass* pass, int which, void* hip_stream, void* host_dst, size_t bytes);

@@ -932,3 +932,51 @@ def test_emissive_di_and_compositing_show_the_sky_behind_missing_geometry(api, c
         assert np.array_equal(got[..., :3].view(np.uint32), want[..., :3].view(np.uint32)), f"composited, frame {f}"
         miss = ((planes[2].reshape(h, w) & 0xff) & 4) != 0
         assert miss.any() and (got[miss][:, :3] > 0).all(), "sky must be visible where there is no geometry"
+
+
+def test_fused_halo_transfer_and_rccl_exchange_on_one_gpu(api, cornell_emissive):
+    """zr_pass_halo_pack_all / _unpack_all (one kernel for every plane x every rect) against the per-plane copy path, then the C++ HaloExchange
+    (libzetaray_host.so: pack kernel -> grouped ncclSend / ncclRecv over RCCL -> unpack kernel, nothing waits on the host) run by a world
+    of one rank that talks to itself: afterwards the reservoirs of the receiving strips equal those of the sending strips, plane by plane."""
+    import torch
+    from zetaray_amd import tiling
+    w, h = 256, 128
+    prm = wire.default_params()
+    r = api.Renderer(cornell_emissive, w, h, params=prm, integrator=api.INTEGRATOR_RESTIR_PT)
+    for f in (1, 2):
+        r.render_frame(_frame(cornell_emissive, w, h, f))
+    p = r.p_indirect
+    bpp = p.halo_bytes_per_pixel()
+    assert bpp == 62
+    rects = [(0, 0, 32, 128), (64, 32, 96, 64)]
+    # (1) fused pack == per-plane pack, block by block
+    offs, total = [], 0
+    for (x0, y0, rw, rh) in rects:
+        offs.append(total)
+        total += (rw * rh * bpp + 15) // 16 * 16
+    fused = torch.zeros(total, dtype=torch.uint8, device="cuda")
+    p.halo_all(r.gbuffer, api.HALO_FINAL, [(x0, y0, rw, rh, o) for (x0, y0, rw, rh), o in zip(rects, offs)], fused.data_ptr(), total, pack=True)
+    for (x0, y0, rw, rh), o in zip(rects, offs):
+        ref = torch.zeros(rw * rh * bpp, dtype=torch.uint8, device="cuda")
+        p.halo_pack(r.gbuffer, api.HALO_FINAL, (x0, y0, rw, rh), ref.data_ptr(), ref.numel())
+        torch.cuda.synchronize()
+        assert torch.equal(fused[o:o + ref.numel()], ref)
+    # (2) self-exchange through RCCL: the strip x 0..31 and the block (64..127, 32..95) are sent, and received at x 224..255 and (128..191, 64..127)
+    names = ["A", "B", "C", "D", "E", "F", "G"]
+    before = {n: p.download_plane(n) for n in names}
+    plan = [(0, (0, 0, 32, 128), (224, 0, 32, 128)), (0, (64, 32, 64, 64), (128, 64, 64, 64))]
+    nh = tiling.NativeHalo(p, r.gbuffer, 0, 1, 0, plan)
+    assert nh.send_bytes == (32 * 128 + 64 * 64) * bpp
+    nh.run(api.HALO_FINAL)
+    torch.cuda.synchronize()
+    after = {n: p.download_plane(n) for n in names}
+    nh.close()
+    for n in names:
+        a, b = before[n], after[n]
+        assert np.array_equal(b[0:128, 224:256], a[0:128, 0:32]), n
+        assert np.array_equal(b[64:128, 128:192], a[32:96, 64:128]), n
+        untouched = np.ones((h, w), bool)
+        untouched[0:128, 224:256] = False
+        untouched[64:128, 128:192] = False
+        assert np.array_equal(b[untouched], a[untouched]), n + ": pixels outside the receive rects changed"
+    assert any(before[n][0:128, 0:32].any() for n in names)

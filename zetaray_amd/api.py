@@ -52,7 +52,7 @@ EXPORTS = [
     "zr_pass_read_counters", "zr_pass_read_kernel_counters", "zr_pass_enable_timing", "zr_pass_get_timings", "zr_selftest_half_conversions", "zr_pass_destroy",
     "zr_trace_closest", "zr_trace_any",
     "zr_pass_set_owned_rect", "zr_pass_render_stage", "zr_pass_halo_pack", "zr_pass_halo_unpack", "zr_pass_halo_bytes_per_pixel", "zr_pass_set_input",
-    "zr_pass_set_tonemap_lut",
+    "zr_pass_set_tonemap_lut", "zr_pass_halo_pack_all", "zr_pass_halo_unpack_all",
 ]
 STAGE_TEMPORAL, STAGE_SPATIAL, STAGE_ALL = 1, 2, 3
 HALO_POST_TEMPORAL, HALO_FINAL = 0, 1
@@ -111,6 +111,8 @@ def lib():
         L.zr_pass_read_kernel_counters.argtypes = [vp, vp, u32, vp, vp, vp, vp]
         L.zr_pass_set_input.argtypes = [vp, i32, vp]
         L.zr_pass_set_tonemap_lut.argtypes = [vp, vp, u32]
+        L.zr_pass_halo_pack_all.argtypes = [vp, vp, vp, i32, vp, u32, vp, C.c_size_t]
+        L.zr_pass_halo_unpack_all.argtypes = [vp, vp, vp, i32, vp, u32, vp, C.c_size_t]
         L.zr_pass_set_owned_rect.argtypes = [vp, u32, u32, u32, u32]
         L.zr_pass_render_stage.argtypes = [vp, vp, vp, vp, vp, i32]
         L.zr_pass_halo_pack.argtypes = [vp, vp, vp, i32, u32, u32, u32, u32, vp, C.c_size_t]
@@ -263,6 +265,14 @@ class Pass:
 
     def halo_pack(self, gbuffer, which, rect, dev_ptr, nbytes, stream=None):
         _check(lib().zr_pass_halo_pack(self.h, stream, gbuffer.h, which, rect[0], rect[1], rect[2], rect[3], dev_ptr, nbytes))
+
+    def halo_all(self, gbuffer, which, rects, dev_ptr, nbytes, pack=True, stream=None):
+        """fused transfer: rects = [(x0, y0, w, h, byte offset into the buffer)]"""
+        class Rect(C.Structure):
+            _fields_ = [("x0", C.c_uint32), ("y0", C.c_uint32), ("w", C.c_uint32), ("h", C.c_uint32), ("offset", C.c_uint64)]
+        arr = (Rect * max(1, len(rects)))(*[Rect(*r) for r in rects])
+        f = lib().zr_pass_halo_pack_all if pack else lib().zr_pass_halo_unpack_all
+        _check(f(self.h, stream, gbuffer.h, which, arr, len(rects), dev_ptr, nbytes))
 
     def halo_bytes_per_pixel(self):
         b = C.c_uint32()

@@ -767,6 +767,42 @@ static void BuildAliasTableHost(std::vector<float>& probs, zr_alias_entry* table
 }
 
 // ------------------------------------------------------------------------------------------------ C-ABI
+// ---- fused halo transfer: every plane x every rect in ONE launch (the per-plane hipMemcpy2DAsync path above costs planes x peers copies:
+// 49 per exchange for ReSTIR PT on a 4 x 2 tile grid, each a few microseconds of launch latency for strips of a few hundred KB)
+struct HaloJob
+{
+    struct Plane { char* base; uint32_t bpp; } planes[8];
+    struct Rect { uint32_t first, w, h; uint32_t pad; uint64_t offset; } rects[ZR_HALO_MAX_RECTS];      // first = index of the rect's top-left pixel in the planes
+    uint32_t numPlanes, numRects, pitch;      // pitch = plane width in pixels
+    char* buf;
+};
+template<bool PACK> __global__ void __launch_bounds__(256) k_halo(HaloJob J)
+{
+    const HaloJob::Rect r = J.rects[blockIdx.y];
+    const uint32_t n = r.w * r.h;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
+    {
+        const size_t px = (size_t)r.first + (size_t)(i / r.w) * J.pitch + (i % r.w);
+        char* cursor = J.buf + r.offset;
+        for (uint32_t k = 0; k < J.numPlanes; k++)
+        {
+            const uint32_t bpp = J.planes[k].bpp;
+            char* a = J.planes[k].base + px * bpp;      // in the plane
+            char* b = cursor + (size_t)i * bpp;         // in the packed block (planes back to back, rows of the rect contiguous)
+            char* dst = PACK ? b : a; const char* src = PACK ? a : b;
+            switch (bpp)
+            {
+            case 16: *(uint4*)dst = *(const uint4*)src; break;
+            case 8: *(uint2*)dst = *(const uint2*)src; break;
+            case 4: *(uint32_t*)dst = *(const uint32_t*)src; break;
+            case 2: *(uint16_t*)dst = *(const uint16_t*)src; break;
+            default: *dst = *src; break;
+            }
+            cursor += (size_t)n * bpp;
+        }
+    }
+}
+
 extern "C" {
 
 int zr_abi_version(void) { return ZR_ABI_VERSION; }
@@ -1835,6 +1871,42 @@ static int HaloCopy(zr_pass* p, hipStream_t s, const zr_gbuffer* gb, int which, 
     }
     return ZR_OK;
 }
+static int HaloAll(zr_pass* p, hipStream_t s, const zr_gbuffer* gb, int which, const zr_halo_rect* rects, uint32_t n, void* buf, size_t bytes, bool pack)
+{
+    if (!p || !gb || (n && (!rects || !buf))) return Fail(ZR_ERR_INVALID_ARG, "null argument");
+    if (n > ZR_HALO_MAX_RECTS) return Fail(ZR_ERR_INVALID_ARG, "at most %d rects per fused halo transfer", ZR_HALO_MAX_RECTS);
+    HaloPlane planes[8]; size_t bpp = 0;
+    const int np = p->initialized ? HaloPlanes(p, which, planes, &bpp) : 0;
+    if (!np) return Fail(ZR_ERR_NOT_INITIALIZED, "pass has no reservoir planes to exchange (or is not initialised)");
+    if (!n) return ZR_OK;
+    HaloJob J; std::memset(&J, 0, sizeof(J));
+    J.numPlanes = (uint32_t)np; J.numRects = n; J.pitch = gb->w; J.buf = (char*)buf;
+    for (int i = 0; i < np; i++) { J.planes[i].base = (char*)planes[i].base; J.planes[i].bpp = (uint32_t)planes[i].bpp; }
+    uint32_t maxPx = 0;
+    for (uint32_t i = 0; i < n; i++)
+    {
+        const zr_halo_rect& r = rects[i];
+        if (r.x0 < gb->x0 || r.y0 < gb->y0 || r.x0 + r.w > gb->x0 + gb->w || r.y0 + r.h > gb->y0 + gb->h) return Fail(ZR_ERR_INVALID_ARG, "halo rect %u lies outside this device's planes", i);
+        const size_t blk = (size_t)r.w * r.h * bpp;
+        if ((r.offset & 15u) || r.offset + blk > bytes) return Fail(ZR_ERR_INVALID_ARG, "halo rect %u: block [%llu, +%zu) must be 16-byte aligned and inside the %zu-byte buffer", i, (unsigned long long)r.offset, blk, bytes);
+        // planes are copied with accesses of their own width: a block's plane sections start at sums of w * h * bpp_k (bpp 1 .. 16), which are
+        // aligned for every plane when w * h is a multiple of 8 -- strips of 32-px aligned tiles with a 32-px apron always are
+        if (((size_t)r.w * r.h) & 7u) return Fail(ZR_ERR_INVALID_ARG, "halo rect %u: w * h must be a multiple of 8 pixels", i);
+        J.rects[i].first = (r.y0 - gb->y0) * gb->w + (r.x0 - gb->x0); J.rects[i].w = r.w; J.rects[i].h = r.h; J.rects[i].offset = r.offset;
+        maxPx = std::max(maxPx, r.w * r.h);
+    }
+    HIP_TRY(hipSetDevice(p->device));
+    const dim3 grid(std::min<uint32_t>((maxPx + 255) / 256, 1024u), n);
+    if (pack) hipLaunchKernelGGL(k_halo<true>, grid, dim3(256), 0, s, J);
+    else hipLaunchKernelGGL(k_halo<false>, grid, dim3(256), 0, s, J);
+    HIP_TRY(hipGetLastError());
+    return ZR_OK;
+}
+int zr_pass_halo_pack_all(zr_pass* p, void* stream, const zr_gbuffer* gb, int which, const zr_halo_rect* rects, uint32_t n, void* dev_buf, size_t bytes)
+{ return HaloAll(p, (hipStream_t)stream, gb, which, rects, n, dev_buf, bytes, true); }
+int zr_pass_halo_unpack_all(zr_pass* p, void* stream, const zr_gbuffer* gb, int which, const zr_halo_rect* rects, uint32_t n, const void* dev_buf, size_t bytes)
+{ return HaloAll(p, (hipStream_t)stream, gb, which, rects, n, const_cast<void*>(dev_buf), bytes, false); }
+
 int zr_pass_halo_pack(zr_pass* p, void* stream, const zr_gbuffer* gb, int which, uint32_t x0, uint32_t y0, uint32_t w, uint32_t h, void* dev_dst, size_t bytes)
 { return HaloCopy(p, (hipStream_t)stream, gb, which, x0, y0, w, h, dev_dst, bytes, true); }
 int zr_pass_halo_unpack(zr_pass* p, void* stream, const zr_gbuffer* gb, int which, uint32_t x0, uint32_t y0, uint32_t w, uint32_t h, const void* dev_src, size_t bytes)

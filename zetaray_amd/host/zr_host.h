@@ -29,6 +29,21 @@
 
 #define ZR_CHECK(expr) do { int zr_rc_ = (expr); if (zr_rc_ != 0) { std::fprintf(stderr, "Check failed: %s -> %d: %s (%s:%d)\n", #expr, zr_rc_, zr_last_error(), __FILE__, __LINE__); std::abort(); } } while (0)
 
+// ---- multi-device transport (zr_halo.cpp), C linkage so that bench.py / tests can drive it through ctypes
+extern "C" {
+typedef struct zrh_comm zrh_comm;                     // one RCCL communicator (one rank of the tile split)
+typedef struct zrh_halo_exchange zrh_halo_exchange;   // send / receive buffers + the rect lists of one pass's exchange
+typedef struct zrh_halo_peer { int peer; uint32_t send_x0, send_y0, send_w, send_h, recv_x0, recv_y0, recv_w, recv_h; } zrh_halo_peer;
+const char* zrh_halo_last_error(void);
+int zrh_rccl_unique_id(uint8_t* out128);
+int zrh_comm_create(int device, int world, int rank, const uint8_t* id128, zrh_comm** out);
+void zrh_comm_destroy(zrh_comm* c);
+int zrh_halo_exchange_create(zr_pass* pass, zr_gbuffer* gb, zrh_comm* comm, const zrh_halo_peer* peers, uint32_t n, zrh_halo_exchange** out);
+void zrh_halo_exchange_destroy(zrh_halo_exchange* x);
+size_t zrh_halo_exchange_send_bytes(const zrh_halo_exchange* x);
+int zrh_halo_exchange_run(zrh_halo_exchange* x, void* hip_stream, int which);
+}
+
 namespace ZetaRayAMD {
 
 namespace Support {
@@ -276,6 +291,19 @@ namespace RenderPass {
         void Render(Core::CommandList& cmdList);
     private:
         zr_params m_params{};
+    };
+
+    // Multi-device only (not in the reference): the reservoir halo exchange of the screen-tile split as a graph node between the temporal and
+    // spatial stages of a pass (zr_halo.cpp: one pack kernel, grouped ncclSend / ncclRecv over RCCL, one unpack kernel, no host wait)
+    struct HaloExchange final
+    {
+        HaloExchange() = default;
+        HaloExchange(const HaloExchange&) = delete;
+        ~HaloExchange();
+        void Init(FrameContext* ctx, zr_pass* pass, zrh_comm* comm, const zrh_halo_peer* peers, uint32_t numPeers, int which /* ZR_HALO_* */);
+        void Render(Core::CommandList& cmdList);
+    private:
+        FrameContext* m_ctx = nullptr; zrh_halo_exchange* m_x = nullptr; int m_which = 0;
     };
 
     struct IndirectLighting final : public RenderPassBase

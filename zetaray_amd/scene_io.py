@@ -46,13 +46,18 @@ def pcg3d(x, y, z):
     return x, y, z
 
 
-def encode_octahedral(n):
+def encode_octahedral(n, sse_order=True):
     """Math::encode_octahedral + unorm2::FromNormalized (VectorFuncs.h:134-153, Vector.h:626-647) in the SSE code's operation order: the
-    L1 norm is (|x| + |z|) + |y| (hadd_float3), the fold's sign is taken from the input component (v >= 0), round to nearest even."""
+    L1 norm is (|x| + |z|) + |y| (hadd_float3), the fold's sign is taken from the input component (v >= 0), round to nearest even.
+    sse_order=False: the plain left-to-right statement ((|x| + |y|) + |z|, sign of the projected component) that the procedural test scenes
+    were generated with -- any valid encoding does for those, and keeping it keeps their committed goldens valid."""
     n = np.asarray(n, dtype=np.float32).reshape(-1, 3)
-    denom = (np.abs(n[:, 0]) + np.abs(n[:, 2])) + np.abs(n[:, 1])
+    if sse_order:
+        denom = (np.abs(n[:, 0]) + np.abs(n[:, 2])) + np.abs(n[:, 1])
+    else:
+        denom = np.abs(n[:, 0]) + np.abs(n[:, 1]) + np.abs(n[:, 2])
     p = n[:, :2] / denom[:, None]
-    sgn = np.where(n[:, :2] >= 0, np.float32(1), np.float32(-1)).astype(np.float32)
+    sgn = (np.where(n[:, :2] >= 0, np.float32(1), np.float32(-1)) if sse_order else np.where(np.signbit(p), np.float32(-1), np.float32(1))).astype(np.float32)
     folded = (np.float32(1) - np.abs(p[:, ::-1])) * sgn
     enc = np.where((n[:, 2] <= 0)[:, None], folded, p).astype(np.float32)
     u = (enc * np.float32(0.5) + np.float32(0.5)) * np.float32(65535.0)
@@ -656,7 +661,7 @@ def make_synthetic_scene(num_tris=262144, num_emissive=100000, seed=0x5EED, room
         T = len(P)
         v = np.zeros(T * 3, wire.VERTEX)
         v["pos"] = P.reshape(-1, 3).astype(np.float32)
-        v["normal"] = encode_octahedral(np.repeat(N, 3, axis=0))
+        v["normal"] = encode_octahedral(np.repeat(N, 3, axis=0), sse_order=False)
         v["uv"] = np.tile(np.array([[0, 0], [1, 0], [0, 1]], np.float32), (T, 1))
         inst = np.zeros((), wire.MESH_INSTANCE)
         inst["base_vtx_offset"] = sum(len(x) for x in verts)
@@ -727,8 +732,8 @@ def make_synthetic_scene(num_tris=262144, num_emissive=100000, seed=0x5EED, room
         l0 = np.sqrt((e0 * e0).sum(1, dtype=np.float32)).astype(np.float32)
         l1 = np.sqrt((e1 * e1).sum(1, dtype=np.float32)).astype(np.float32)
         ems["vtx0"] = P[:, 0]
-        ems["v0v1"] = encode_octahedral(e0 / l0[:, None])
-        ems["v0v2"] = encode_octahedral(e1 / l1[:, None])
+        ems["v0v1"] = encode_octahedral(e0 / l0[:, None], sse_order=False)
+        ems["v0v2"] = encode_octahedral(e1 / l1[:, None], sse_order=False)
         ems["edge_lengths"] = np.stack([f32_to_f16_bits(l0), f32_to_f16_bits(l1)], 1)
         M = 0xFFFFFFFF
         # vectorised PCG3d(geometryIndex = instance index, instanceID = 0, primIdx)
@@ -822,7 +827,7 @@ def add_test_textures(sc: Scene, seed=7, non_opaque_instance=2):
         P = v["pos"][b:b + n].reshape(-1, 3, 3)
         t = P[:, 1] - P[:, 0]
         t = t / np.maximum(np.linalg.norm(t, axis=1, keepdims=True), 1e-20)
-        v["tangent"][b:b + n] = encode_octahedral(np.repeat(t.astype(np.float32), 3, axis=0))
+        v["tangent"][b:b + n] = encode_octahedral(np.repeat(t.astype(np.float32), 3, axis=0), sse_order=False)
     sc.vertices = v
     return offs
 

@@ -71,7 +71,8 @@ class TiledRestirPT:
     one stage, final exchange only), "di" (ReSTIR DI emissive, 24 B/px) or "sky_di" (sun + sky ReSTIR DI, 13 B/px): the DI
     passes exchange once, between their temporal and spatial stages."""
 
-    def __init__(self, scene_host, width, height, world, rank, device=0, params=None, dist=None, kind="restir_pt", pass_params=None):
+    def __init__(self, scene_host, width, height, world, rank, device=0, params=None, dist=None, kind="restir_pt", pass_params=None,
+                 transport="torch_p2p"):
         import torch
         from . import api
         self.api, self.torch, self.dist = api, torch, dist
@@ -101,6 +102,13 @@ class TiledRestirPT:
             rb = torch.empty(recv[2] * recv[3] * self.bpp, dtype=torch.uint8, device=self.device) if recv else None
             self.bufs[peer] = (sb, rb)
         self.halo_bytes = sum((sb.numel() if sb is not None else 0) for sb, _ in self.bufs.values())
+        # transport="rccl_cpp": the C++ HaloExchange of libzetaray_host.so (zr_halo.cpp) -- one pack kernel, grouped ncclSend / ncclRecv issued
+        # from C++ on the pass's stream, one unpack kernel, no host wait -- instead of per-plane copies + torch.distributed P2P ops
+        self.transport = transport
+        self.native = None
+        if transport == "rccl_cpp" and world > 1:
+            self.native = NativeHalo(self.hp, self.r.gbuffer, device, world, rank, self.plan, dist)
+            self.halo_bytes = self.native.send_bytes
 
     def pack(self, which):
         """stage 1 of an exchange: copy my border strips into the per-peer send buffers (device-to-device, on the stream)"""
@@ -118,6 +126,9 @@ class TiledRestirPT:
 
     def exchange(self, which):
         if not self.plan:
+            return
+        if self.native is not None:
+            self.native.run(which)
             return
         dist = self.dist
         self.pack(which)
@@ -170,6 +181,64 @@ class TiledRestirPT:
         x0, y0, tw, th = self.tile
         ex0, ey0 = self.ext[0], self.ext[1]
         return self.tile, full[y0 - ey0:y0 - ey0 + th, x0 - ex0:x0 - ex0 + tw].copy()
+
+
+class NativeHalo:
+    """ctypes face of the C++ halo exchange (zetaray_amd/host/zr_halo.cpp).  The RCCL unique id is created on rank 0 and handed to the other
+    ranks through the process group that launched them (a 128-byte broadcast); world == 1 talks to itself (transport self-test)."""
+
+    def __init__(self, halo_pass, gbuffer, device, world, rank, plan, dist=None, unique_id=None):
+        import ctypes as C
+        import os
+        self.C = C
+        L = C.CDLL(os.path.join(os.path.dirname(os.path.abspath(__file__)), "libzetaray_host.so"))
+        L.zrh_halo_last_error.restype = C.c_char_p
+        L.zrh_comm_create.argtypes = [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+        L.zrh_comm_destroy.argtypes = [C.c_void_p]
+        L.zrh_halo_exchange_create.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]
+        L.zrh_halo_exchange_destroy.argtypes = [C.c_void_p]
+        L.zrh_halo_exchange_send_bytes.restype = C.c_size_t
+        L.zrh_halo_exchange_send_bytes.argtypes = [C.c_void_p]
+        L.zrh_halo_exchange_run.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+        self.L = L
+        idbuf = (C.c_uint8 * 128)()
+        if unique_id is not None:
+            C.memmove(idbuf, bytes(unique_id), 128)
+        else:
+            if rank == 0:
+                self._check(L.zrh_rccl_unique_id(idbuf))
+            if world > 1:
+                import torch
+                t = torch.tensor(list(bytes(idbuf)), dtype=torch.uint8, device=torch.device("cuda", device))
+                dist.broadcast(t, src=0)
+                C.memmove(idbuf, bytes(t.cpu().numpy().tobytes()), 128)
+        self.comm = C.c_void_p()
+        self._check(L.zrh_comm_create(device, world, rank, idbuf, C.byref(self.comm)))
+
+        class Peer(C.Structure):
+            _fields_ = [("peer", C.c_int)] + [(n, C.c_uint32) for n in ("send_x0", "send_y0", "send_w", "send_h", "recv_x0", "recv_y0", "recv_w", "recv_h")]
+        arr = (Peer * max(1, len(plan)))()
+        for i, (peer, send, recv) in enumerate(plan):
+            s, r = send or (0, 0, 0, 0), recv or (0, 0, 0, 0)
+            arr[i] = Peer(peer, s[0], s[1], s[2], s[3], r[0], r[1], r[2], r[3])
+        self.x = C.c_void_p()
+        self._check(L.zrh_halo_exchange_create(halo_pass.h, gbuffer.h, self.comm, arr, len(plan), C.byref(self.x)))
+        self.send_bytes = int(L.zrh_halo_exchange_send_bytes(self.x))
+
+    def _check(self, rc):
+        if rc != 0:
+            raise RuntimeError("halo exchange: " + self.L.zrh_halo_last_error().decode())
+
+    def run(self, which, stream=None):
+        self._check(self.L.zrh_halo_exchange_run(self.x, stream, which))
+
+    def close(self):
+        if self.x:
+            self.L.zrh_halo_exchange_destroy(self.x)
+            self.x = self.C.c_void_p()
+        if self.comm:
+            self.L.zrh_comm_destroy(self.comm)
+            self.comm = self.C.c_void_p()
 
 
 def exchange_in_process(ranks, which):
