@@ -107,8 +107,20 @@ class TiledRestirPT:
         self.transport = transport
         self.native = None
         if transport == "rccl_cpp" and world > 1:
-            self.native = NativeHalo(self.hp, self.r.gbuffer, device, world, rank, self.plan, dist)
-            self.halo_bytes = self.native.send_bytes
+            # every rank must take the same branch (communicator creation is collective): agree on success before using it
+            try:
+                native, ok = NativeHalo(self.hp, self.r.gbuffer, device, world, rank, self.plan, dist), 1
+            except Exception as e:      # e.g. no librccl.so next to this build: the torch.distributed P2P path still works
+                import sys
+                print(f"[zetaray_amd.tiling] rank {rank}: C++ RCCL halo exchange unavailable ({e}); using torch.distributed P2P", file=sys.stderr)
+                native, ok = None, 0
+            flag = torch.tensor([ok], dtype=torch.int32, device=self.device)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if int(flag.item()) == 1:
+                self.native = native
+                self.halo_bytes = self.native.send_bytes
+            else:
+                self.transport = "torch_p2p"
 
     def pack(self, which):
         """stage 1 of an exchange: copy my border strips into the per-peer send buffers (device-to-device, on the stream)"""
