@@ -217,13 +217,19 @@ class NativeHalo:
         if unique_id is not None:
             C.memmove(idbuf, bytes(unique_id), 128)
         else:
+            ok = 1
             if rank == 0:
-                self._check(L.zrh_rccl_unique_id(idbuf))
+                ok = 1 if L.zrh_rccl_unique_id(idbuf) == 0 else 0
             if world > 1:
+                # rank 0 always broadcasts (status byte + id), so that a failure there cannot leave the others waiting
                 import torch
-                t = torch.tensor(list(bytes(idbuf)), dtype=torch.uint8, device=torch.device("cuda", device))
+                t = torch.tensor([ok] + list(bytes(idbuf)), dtype=torch.uint8, device=torch.device("cuda", device))
                 dist.broadcast(t, src=0)
-                C.memmove(idbuf, bytes(t.cpu().numpy().tobytes()), 128)
+                raw = bytes(t.cpu().numpy().tobytes())
+                ok = raw[0]
+                C.memmove(idbuf, raw[1:], 128)
+            if not ok:
+                raise RuntimeError("halo exchange: " + (L.zrh_halo_last_error().decode() if rank == 0 else "rank 0 could not create the RCCL unique id"))
         self.comm = C.c_void_p()
         self._check(L.zrh_comm_create(device, world, rank, idbuf, C.byref(self.comm)))
 
