@@ -7,6 +7,7 @@
 // meshIdx = GeometryIndex() + InstanceID() and the primitive index within that mesh (RtAccelerationStructure.cpp:393-405).
 // Runs once per scene on the host; the device only ever sees the flat node / triangle arrays (zr_dev_scene.h).
 #pragma once
+#include <cstdlib>
 #include <vector>
 #include <algorithm>
 #include <cstring>
@@ -34,7 +35,21 @@ class BvhBuilder
 {
 public:
     static constexpr int kBins = 16;
-    static constexpr uint32_t kMaxLeaf = 4;
+    // Triangles per leaf.  Measured on MI355X (scripts/gpu_bvh.sh, 1080p): 4 -> 2 triangles cuts the triangle phase of the voted traversal (its lane
+    // utilisation is the lowest of the loop) for a few more inner nodes: atrium ReSTIR PT 22.05 -> 19.57 ms, K9 10.69 -> 9.89 ms, Cornell
+    // ReSTIR PT 2.51 -> 2.37 ms, ReSTIR GI 1.70 -> 1.51 ms; 1 and 3 are worse than 2, 8 much worse (25.5 ms), SAH leaf termination equals 2.
+    static constexpr uint32_t kMaxLeaf = 2;
+    static constexpr uint32_t kTinyScene = 8;      // up to this many triangles: one leaf, no nodes
+    // experiment knobs (scripts/gpu_bvh.sh): ZR_BVH_MAX_LEAF = 1..8 triangles per leaf; ZR_BVH_SAH_LEAF = node cost in triangle tests (> 0: a range of
+    // <= max-leaf triangles becomes a leaf when splitting it would not pay for the extra node)
+    uint32_t maxLeaf_ = kMaxLeaf; float nodeCost_ = 0.0f;
+    BvhBuilder()
+    {
+        if (const char* e = std::getenv("ZR_BVH_MAX_LEAF")) { const int v = std::atoi(e); if (v >= 1 && v <= 8) maxLeaf_ = (uint32_t)v; }
+        if (const char* e = std::getenv("ZR_BVH_SAH_LEAF")) nodeCost_ = (float)std::atof(e);
+        if (const char* e = std::getenv("ZR_BVH_SWEEP")) sweepBelow_ = (uint32_t)std::atoi(e);
+    }
+    uint32_t sweepBelow_ = 0;      // ranges of fewer triangles than this are split by an exact SAH sweep instead of 16 bins
 
     BuiltBvh Build(const zr_scene_desc& d)
     {
@@ -77,7 +92,7 @@ public:
             }
             bt_[i].gidx = i;
         }
-        if (N <= kMaxLeaf * 2)
+        if (N <= kTinyScene)
         {
             // tiny scene: a single leaf, no nodes
             out.tris = soup;
@@ -183,11 +198,34 @@ private:
     // splits [first, first+count) and returns the child reference (leaf or node index)
     uint32_t BuildChild(uint32_t first, uint32_t count, uint32_t depth)
     {
-        if (count <= kMaxLeaf) { out_->maxDepth = std::max(out_->maxDepth, depth); return MakeLeaf(first, count); }
+        if (count <= (nodeCost_ > 0 ? 1u : maxLeaf_) || (count <= maxLeaf_ && LeafIsCheaper(first, count))) { out_->maxDepth = std::max(out_->maxDepth, depth); return MakeLeaf(first, count); }
         uint32_t idx = (uint32_t)out_->nodes.size();
         out_->nodes.push_back(BvhNode());
         BuildInternal(idx, first, count, depth + 1);
         return idx;
+    }
+    // SAH leaf test for small ranges: cost(leaf) = count; cost(split) = nodeCost + sum over the best object split of area fraction x count
+    bool LeafIsCheaper(uint32_t first, uint32_t count)
+    {
+        if (!(nodeCost_ > 0) || count < 2) return count < 2;
+        float pmin[3], pmax[3]; Bounds(first, count, pmin, pmax);
+        const float parentArea = Area(pmin, pmax);
+        if (!(parentArea > 0)) return true;
+        float best = 3.402823466e+38f;
+        std::vector<BuildTri> tmp(bt_.begin() + first, bt_.begin() + first + count);
+        for (int axis = 0; axis < 3; axis++)
+        {
+            std::sort(tmp.begin(), tmp.end(), [axis](const BuildTri& a, const BuildTri& b) { return a.cent[axis] < b.cent[axis]; });
+            for (uint32_t k = 1; k < count; k++)
+            {
+                float lmin[3] = {3.402823466e+38f, 3.402823466e+38f, 3.402823466e+38f}, lmax[3] = {-3.402823466e+38f, -3.402823466e+38f, -3.402823466e+38f};
+                float rmin[3] = {3.402823466e+38f, 3.402823466e+38f, 3.402823466e+38f}, rmax[3] = {-3.402823466e+38f, -3.402823466e+38f, -3.402823466e+38f};
+                for (uint32_t i = 0; i < k; i++) Grow(lmin, lmax, tmp[i].bmin, tmp[i].bmax);
+                for (uint32_t i = k; i < count; i++) Grow(rmin, rmax, tmp[i].bmin, tmp[i].bmax);
+                best = std::min(best, (Area(lmin, lmax) * (float)k + Area(rmin, rmax) * (float)(count - k)) / parentArea);
+            }
+        }
+        return (float)count <= nodeCost_ + best;
     }
     void BuildInternal(uint32_t nodeIdx, uint32_t first, uint32_t count, uint32_t depth)
     {
@@ -223,7 +261,28 @@ private:
             }
         }
         uint32_t mid;
-        if (bestAxis < 0)
+        if (count < sweepBelow_ && bestAxis >= 0)
+        {
+            // exact sweep: every object split along every axis
+            float bestC = 3.402823466e+38f; int bAxis = -1; uint32_t bK = 0;
+            std::vector<float> rightArea(count);
+            for (int axis = 0; axis < 3; axis++)
+            {
+                std::sort(bt_.begin() + first, bt_.begin() + first + count, [axis](const BuildTri& a, const BuildTri& b) { return a.cent[axis] < b.cent[axis] || (a.cent[axis] == b.cent[axis] && a.gidx < b.gidx); });
+                float lo[3] = {3.402823466e+38f, 3.402823466e+38f, 3.402823466e+38f}, hi[3] = {-3.402823466e+38f, -3.402823466e+38f, -3.402823466e+38f};
+                for (uint32_t i = count; i-- > 1;) { Grow(lo, hi, bt_[first + i].bmin, bt_[first + i].bmax); rightArea[i] = Area(lo, hi); }
+                for (int r = 0; r < 3; r++) { lo[r] = 3.402823466e+38f; hi[r] = -3.402823466e+38f; }
+                for (uint32_t k = 1; k < count; k++)
+                {
+                    Grow(lo, hi, bt_[first + k - 1].bmin, bt_[first + k - 1].bmax);
+                    const float c = Area(lo, hi) * (float)k + rightArea[k] * (float)(count - k);
+                    if (c < bestC) { bestC = c; bAxis = axis; bK = k; }
+                }
+            }
+            std::sort(bt_.begin() + first, bt_.begin() + first + count, [bAxis](const BuildTri& a, const BuildTri& b) { return a.cent[bAxis] < b.cent[bAxis] || (a.cent[bAxis] == b.cent[bAxis] && a.gidx < b.gidx); });
+            mid = first + bK;
+        }
+        else if (bestAxis < 0)
         {
             // all centroids coincide: split by index
             mid = first + count / 2;

@@ -165,7 +165,17 @@ ZR_HD void IntersectLeaf(const SceneView& sc, uint32_t first, uint32_t count, V3
 // of that changes the result (closest hit + index tie-break / any hit are order independent, zr_intersect.h).
 static constexpr int kTravStack = 64;                     // entries; the host checks the built tree against it
 static constexpr int kTravStackWords = 2 * kTravStack;
-static constexpr int kTravLdsEntries = 8;                 // device: the first entries live in LDS, deeper ones in scratch
+#ifndef ZR_TRI_PHASE_WHOLE_LEAF
+#define ZR_TRI_PHASE_WHOLE_LEAF 1
+#endif
+#ifndef ZR_VOTE_WN
+#define ZR_VOTE_WN 1
+#define ZR_VOTE_WT 1
+#endif
+#ifndef ZR_TRAV_LDS_ENTRIES
+#define ZR_TRAV_LDS_ENTRIES 8
+#endif
+static constexpr int kTravLdsEntries = ZR_TRAV_LDS_ENTRIES;                 // device: the first entries live in LDS, deeper ones in scratch
 
 // One lane's traversal stack.  Device kernels keep the bottom kTravLdsEntries entries in LDS (entry e of lane l at
 // lds[e * stride + l]: conflict-free, and off the vector-memory path that the node / triangle fetches saturate) and the
@@ -243,11 +253,20 @@ ZR_HD uint32_t TravNode(const SceneView& sc, TravState& s, const TravStack& stac
     float t0, t1, t2, t3;
     // cull against the current best t (inclusive + widened, so equal-t candidates for the tie-break are visited)
 #define ZR_Q(w, k) ((float)(((w) >> (8 * (k))) & 0xffu))
-    // (all four slots are tested unconditionally -- an empty slot decodes to a harmless box -- to keep the phase branch-free)
-#define ZR_TRAV_BOX(k) { const int h = zr_ray_box_native(s.o.x, s.o.y, s.o.z, s.idx, s.idy, s.idz, \
-        zr_fma(ZR_Q(n.qlox, k), sx, n.ox), zr_fma(ZR_Q(n.qloy, k), sy, n.oy), zr_fma(ZR_Q(n.qloz, k), sz, n.oz), \
-        zr_fma(ZR_Q(n.qhix, k), sx, n.ox), zr_fma(ZR_Q(n.qhiy, k), sy, n.oy), zr_fma(ZR_Q(n.qhiz, k), sz, n.oz), \
-        s.tmin, s.best.t, &t##k); const bool ok = (h != 0) & (c##k != kEmptyChild); t##k = ok ? t##k : inf; c##k = ok ? c##k : kEmptyChild; }
+    // (all four slots are tested unconditionally -- an empty slot decodes to a harmless box -- to keep the phase branch-free.)
+    // Per axis the ray's direction sign says which quantised plane is the entry and which the exit, so the words are swapped once per node
+    // instead of taking min / max of the two plane distances per child: the same tn / tf as zr_ray_box_native, 18 fewer VALU ops per node.
+    const bool ngx = s.idx < 0.0f, ngy = s.idy < 0.0f, ngz = s.idz < 0.0f;
+    const uint32_t qnx = ngx ? n.qhix : n.qlox, qfx = ngx ? n.qlox : n.qhix;
+    const uint32_t qny = ngy ? n.qhiy : n.qloy, qfy = ngy ? n.qloy : n.qhiy;
+    const uint32_t qnz = ngz ? n.qhiz : n.qloz, qfz = ngz ? n.qloz : n.qhiz;
+    const float tfmax = s.best.t;
+#define ZR_TRAV_BOX(k) { \
+        const float nx = (zr_fma(ZR_Q(qnx, k), sx, n.ox) - s.o.x) * s.idx, ny = (zr_fma(ZR_Q(qny, k), sy, n.oy) - s.o.y) * s.idy, nz = (zr_fma(ZR_Q(qnz, k), sz, n.oz) - s.o.z) * s.idz; \
+        const float fx = (zr_fma(ZR_Q(qfx, k), sx, n.ox) - s.o.x) * s.idx, fy = (zr_fma(ZR_Q(qfy, k), sy, n.oy) - s.o.y) * s.idy, fz = (zr_fma(ZR_Q(qfz, k), sz, n.oz) - s.o.z) * s.idz; \
+        const float tn = __builtin_fmaxf(__builtin_fmaxf(nx, ny), __builtin_fmaxf(nz, s.tmin)); \
+        const float tf = __builtin_fminf(__builtin_fminf(fx, fy), __builtin_fminf(fz, tfmax)) * 1.0000003576278687f; \
+        const bool ok = (tn <= tf) & (c##k != kEmptyChild); t##k = ok ? tn : inf; c##k = ok ? c##k : kEmptyChild; }
     ZR_TRAV_BOX(0) ZR_TRAV_BOX(1) ZR_TRAV_BOX(2) ZR_TRAV_BOX(3)
 #undef ZR_TRAV_BOX
 #undef ZR_Q
@@ -306,6 +325,18 @@ ZR_HD void TravNodePhase(const SceneView& sc, TravState& s, TravLane& L, const T
 }
 ZR_HD void TravTriPhase(const SceneView& sc, TravState& s, TravLane& L, const TravStack& stack, bool anyHit, bool alphaTest = false)
 {
+#if ZR_TRI_PHASE_WHOLE_LEAF
+    // leaves hold at most two triangles (zr_bvh.h): both in one phase
+    if (L.triEnd - L.triCur <= 2u)
+    {
+        IntersectTri(sc, L.triCur, s.o, s.d, s.tmin, s.tmax, s.mask, s.best, s.filterID, s.ignoreID, alphaTest);
+        if (L.triCur + 1u < L.triEnd) IntersectTri(sc, L.triCur + 1u, s.o, s.d, s.tmin, s.tmax, s.mask, s.best, s.filterID, s.ignoreID, alphaTest);
+        L.triCur = L.triEnd;
+        if (anyHit && s.best.tri != kInvalidTri) L.done = true;
+        else TravPopEnter(sc, s, L, stack);
+        return;
+    }
+#endif
     IntersectTri(sc, L.triCur, s.o, s.d, s.tmin, s.tmax, s.mask, s.best, s.filterID, s.ignoreID, alphaTest);
     L.triCur++;
     if (anyHit && s.best.tri != kInvalidTri) { L.done = true; L.triCur = L.triEnd; }
@@ -333,9 +364,9 @@ ZR_HD RawHit TraverseDyn(const SceneView& sc, V3 o, V3 d, float tmin, float tmax
         const uint64_t mNode = __ballot(atNode), mTri = __ballot(atTri);
         if ((mNode | mTri) == 0) break;
 #ifdef ZR_PROF
-        if (__popcll(mNode) >= __popcll(mTri)) { pNI++; pNL += __popcll(mNode); } else { pTI++; pTL += __popcll(mTri); }
+        if (ZR_VOTE_WN * __popcll(mNode) >= ZR_VOTE_WT * __popcll(mTri)) { pNI++; pNL += __popcll(mNode); } else { pTI++; pTL += __popcll(mTri); }
 #endif
-        if (__popcll(mNode) >= __popcll(mTri)) { if (atNode) TravNodePhase(sc, s, L, stack); }
+        if (ZR_VOTE_WN * __popcll(mNode) >= ZR_VOTE_WT * __popcll(mTri)) { if (atNode) TravNodePhase(sc, s, L, stack); }
         else { if (atTri) TravTriPhase(sc, s, L, stack, anyHit, alphaTest); }
     }
 #ifdef ZR_PROF
