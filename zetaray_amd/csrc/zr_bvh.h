@@ -72,7 +72,7 @@ public:
                 }
                 BvhTri t;
                 for (int r = 0; r < 3; r++) { t.v0[r] = w[0][r]; t.e1[r] = w[1][r] - w[0][r]; t.e2[r] = w[2][r] - w[0][r]; }
-                t.gidx = (uint32_t)soup.size(); t.mask = d.instance_mask[i]; t.mesh = i;
+                t.gidx = (uint32_t)soup.size(); t.mask = d.instance_mask[i]; t.id = zr::TriID(i, p);
                 soup.push_back(t);
                 TriMeta m; m.mesh = i; m.prim = p;
                 out.meta.push_back(m);

@@ -31,7 +31,10 @@ struct Bvh4Node
     uint32_t qlox, qloy, qloz, qhix;
     uint32_t qhiy, qhiz, pad0, pad1;
 };
-struct BvhTri { float v0[3]; uint32_t gidx; float e1[3]; uint32_t mask; float e2[3]; uint32_t mesh; };
+// 48 B, three 16-byte loads.  mask = the instance's ZR_SUBGROUP_* / ZR_INSTANCE_NON_OPAQUE bits; id = the reference's hashed triangle ID
+// (TriID(mesh, prim)), stored so that rays which must ignore one triangle (approximate visibility segments) compare one word per candidate
+// instead of fetching TriMeta and hashing
+struct BvhTri { float v0[3]; uint32_t gidx; float e1[3]; uint32_t mask; float e2[3]; uint32_t id; };
 struct TriMeta { uint32_t mesh, prim; };
 
 static constexpr uint32_t kLeafBit = 0x80000000u;
@@ -140,7 +143,8 @@ ZR_HD void IntersectTri(const SceneView& sc, uint32_t i, V3 o, V3 d, float tmin,
 {
     const BvhTri T = sc.tris[i];
     if (!(T.mask & mask)) return;
-    if (filterID) { const TriMeta tm = sc.triMeta[T.gidx]; if (TriID(tm.mesh, tm.prim) == ignoreID) return; }
+    // (before the intersection test on purpose: behind it -- hits only -- every traversal kernel got 8-12 % slower on the atrium, measured A/B in one run)
+    if (filterID && T.id == ignoreID) return;
     float t, u, v;
     if (zr_ray_tri(o.x, o.y, o.z, d.x, d.y, d.z, T.v0[0], T.v0[1], T.v0[2], T.e1[0], T.e1[1], T.e1[2],
             T.e2[0], T.e2[1], T.e2[2], tmin, tmax, &t, &u, &v))
