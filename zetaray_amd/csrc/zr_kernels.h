@@ -18,11 +18,14 @@ static constexpr int kBlock = 256;
 // Occupancy targets of the register-heavy shading kernels, waves per SIMD (the compiler spills a little to reach them).
 // Measured on MI355X, Cornell 1080p / 380k-triangle atrium: k_rpt_pathtrace 2 -> 3 waves: 1.45 -> 1.21 ms /
 // 14.9 -> 11.8 ms (4 waves: 1.19 / 10.7 ms, but its ~300 B/lane of spills stream 3.4 GB through L2 per launch, PMC); k_rgi 2 -> 4: 2.19 -> 1.68 ms; k_rdi_* 2 -> 3: 0.72 -> 0.67, 0.39 -> 0.33 ms; k_sdi_spatial -> 4: 0.58 ->
-// 0.49 ms.  k_rpt_temporal, k_rpt_stc, k_pt_shade and k_sdi_temporal got slower with more waves and keep the default.
+// 0.49 ms.  k_rpt_stc, k_pt_shade and k_sdi_temporal got slower with more waves and keep the default.
+// Re-measured in round 2 after the traversal changes (2-triangle leaves, whole-leaf triangle phase): k_rpt_pathtrace 3 -> 4 waves 1.013 -> 1.000 ms
+// (5: 1.17), k_rpt_temporal default -> 4 waves 0.546 -> 0.536 ms / atrium 3.53 -> 3.27 ms (3: 0.57, 5: 0.70, 6: 0.82), k_rpt_stc 3 / 5 waves 0.77 / 0.72
+// against 0.64 at its natural 4, k_rgi 3 / 5 waves 1.37 / 1.45 against 1.30 at 4.
 #define ZR_WAVES(n) __attribute__((amdgpu_waves_per_eu(n, n)))
 #define ZR_WAVES_MIN(n) __attribute__((amdgpu_waves_per_eu(n)))
 #ifndef ZR_WAVES_PATHTRACE
-#define ZR_WAVES_PATHTRACE ZR_WAVES(3)
+#define ZR_WAVES_PATHTRACE ZR_WAVES(4)
 #endif
 #ifndef ZR_WAVES_RGI
 #define ZR_WAVES_RGI ZR_WAVES(4)
@@ -32,7 +35,7 @@ static constexpr int kBlock = 256;
 #define ZR_WAVES_SDI_S ZR_WAVES(4)
 #define ZR_WAVES_SDI_T
 #ifndef ZR_WAVES_TEMPORAL
-#define ZR_WAVES_TEMPORAL 
+#define ZR_WAVES_TEMPORAL ZR_WAVES(4)
 #endif
 #ifndef ZR_WAVES_STC
 #define ZR_WAVES_STC 
