@@ -467,7 +467,7 @@ ZR_HD Direct NEE_Bsdf(const Globals& g, V3 pos, V3 normal, const Surface& surfac
     const bool specular = IsSpecular(surface);
     const int numLightSamples = specular ? 0 : 1;
     bs = InitBsdfSample();
-    if (nextBounce <= g.maxNumBounces) bs = SampleBSDF(sc.rho, normal, surface, rng);
+    if (nextBounce <= g.maxNumBounces) { ZR_PROF_SCOPE(ZRP_BSDF); bs = SampleBSDF(sc.rho, normal, surface, rng); }
     const float wiPdf = bs.pdf;
     const V3 wi = bs.wi;
     const V3 f = bs.f;
@@ -548,7 +548,7 @@ ZR_HD Direct NEE_Emissive(const Globals& g, V3 pos, V3 normal, Surface surface, 
         float bsdfPdf = 0;
         if (dot(ld, ld) > 0)
         {
-            bsdfPdf = BSDFSamplerPdf(sc.rho, normal, surface, wi, rng);
+            { ZR_PROF_SCOPE(ZRP_NEE); bsdfPdf = BSDFSamplerPdf(sc.rho, normal, surface, wi, rng); }
             bsdfPdf *= dwdA;
         }
         ret.ld = PowerHeuristic(lightPdf, bsdfPdf, ld, 1.0f, 1.0f);
@@ -901,7 +901,8 @@ ZR_HD void PtInitLane(const SceneView& sc, const zr_frame_constants& g, const GB
     uint32_t sx = x, sy = y, sz = g.frame_num; zr_pcg3d(&sx, &sy, &sz);
     P.rngReplay = Rng::Seed(sx); P.rngThread = Rng::Seed(sy); P.seed_replay = sx;
     P.r = InitReservoir(); P.li = v3(0.0f);
-    BsdfSample bs = SampleBSDF(sc.rho, ps.normal, ps.surface, P.rngReplay);
+    BsdfSample bs;
+    { ZR_PROF_SCOPE(ZRP_BSDF); bs = SampleBSDF(sc.rho, ps.normal, ps.surface, P.rngReplay); }
     if (dot(bs.bsdfOverPdf, bs.bsdfOverPdf) == 0) return;
     if (prm.textured) P.rd = PrimaryRayDiffs(cam, (int)x, (int)y, ps, LoadTriDiffs(gb, px), bs.wi);
     P.sampleSetIdx = prm.emissive ? P.rngGroup.UniformUintBounded_Faster(prm.numSampleSets) : 0u;      // ReSTIR_PT_PathTrace.hlsl:406-408
@@ -959,11 +960,8 @@ ZR_HD void PtPhaseA(const SceneView& sc, const zr_frame_constants& g, const RptP
         P.tr = vexp(-P.hit.t * ext);
         P.throughput = P.throughput * P.tr;
     }
-    {
-    ZR_PROF_SCOPE(ZRP_NEE);
     EstimateDirectAndUpdateRC(gl, P.pathVertex, P.pos, P.hit, P.surface, P.prevHit, P.throughput, P.throughput_k, P.li, P.bs, P.nextHit, P.rc, P.r,
         P.rngThread, P.rngReplay);
-    }
     if (P.bounce >= (P.maxNumBounces - 1)) { P.active = false; return; }
     if (P.rc.IsCase2() || P.rc.IsCase3()) P.rc.Clear();
     P.bounce++;
