@@ -1,0 +1,40 @@
+"""Latency of zr_scene_update_instances on the BASELINE config-4 stand-in (262k-triangle atrium): device refit (default) next to the host rebuild
+(ZR_SCENE_UPDATE=rebuild), and the ReSTIR PT frame time on the refit / rebuilt tree after the largest non-emissive clutter instance moved.
+Prints one JSON line; scripts/gpu_refit.sh runs it once per mode.  GPU only."""
+import json, os, sys, time
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from zetaray_amd import api, scene_io, wire
+
+
+def main():
+    w, h = 1920, 1080
+    sc = scene_io.make_synthetic_scene(num_tris=262144, num_emissive=100000, layout="atrium")
+    prm = wire.default_params()
+    prm.presampling, prm.num_sample_sets, prm.sample_set_size = 1, 128, 512
+    r = api.Renderer(sc, w, h, params=prm, integrator=api.INTEGRATOR_RESTIR_PT)
+    cand = [i for i in range(1, len(sc.instances)) if sc.instance_mask[i] & wire.SUBGROUP_NON_EMISSIVE]
+    idx = max(cand, key=lambda i: int(sc.instance_num_tris[i]))
+    t0, xf = sc.instances["translation"][idx].copy(), {}
+    import torch
+    upd, frames = [], []
+    for f in range(1, 13):
+        if f >= 3:
+            k = f - 2
+            ang = 0.05 * k
+            q = np.array([0.0, np.sin(ang / 2), 0.0, np.cos(ang / 2)], np.float32)
+            scene_io.move_instance(sc, idx, translation=t0 + np.float32([0.02 * k, 0.0, 0.01 * k]), rotation=q, xform_of=xf)
+            torch.cuda.synchronize(); a = time.perf_counter()
+            r.scene.update_instances(sc.instances, sc.instance_to_world)
+            torch.cuda.synchronize(); upd.append((time.perf_counter() - a) * 1e3)
+        cb = scene_io.make_frame_constants(w, h, frame_num=f, num_emissives=len(sc.emissives), cam_pos=(0, 0, -3.5))
+        torch.cuda.synchronize(); a = time.perf_counter()
+        r.render_frame(cb)
+        torch.cuda.synchronize(); frames.append((time.perf_counter() - a) * 1e3)
+    print(json.dumps({"mode": os.environ.get("ZR_SCENE_UPDATE", "refit"), "instance": int(idx), "instance_tris": int(sc.instance_num_tris[idx]),
+                      "bvh": list(r.scene.bvh_info()), "update_ms": [round(x, 3) for x in upd], "update_ms_median": round(float(np.median(upd)), 3),
+                      "frame_ms_static": round(float(np.median(frames[:2])), 3), "frame_ms_moving": round(float(np.median(frames[4:])), 3)}))
+
+
+if __name__ == "__main__":
+    main()

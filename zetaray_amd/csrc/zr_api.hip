@@ -493,6 +493,8 @@ struct zr_scene
     std::vector<zr_vertex> hVertices; std::vector<uint32_t> hIndices; std::vector<uint8_t> hMask; std::vector<uint32_t> hNumTris;
     DevBuf<zr_mesh_instance> instancesPrev; DevBuf<Bvh4Node> nodesPrev; DevBuf<BvhTri> trisPrev; DevBuf<TriMeta> metaPrev;
     uint32_t numNodesPrev = 0, numTrisPrev = 0; bool hasPrev = false;
+    // device refit: node indices grouped by tree level (deepest level first) + the offsets of the groups, per-node float bounds, object-to-world matrices
+    DevBuf<uint32_t> levelNodes; std::vector<uint32_t> levelOffsets, hLevelOrder; DevBuf<float> nodeBounds, toWorld; bool refitReady = false;
     // `view` is what kernels receive by value.  Passes of one dependency level may record concurrently from several host threads
     // (RenderGraph.cpp:442-541) while Sky / PreLighting publish scene-owned state (sky LUT, alias table, presampled sets, LVG):
     // every reader takes a private copy through FrameView() and every writer updates `view` under `mtx`.
@@ -767,6 +769,89 @@ static void BuildAliasTableHost(std::vector<float>& probs, zr_alias_entry* table
 }
 
 // ------------------------------------------------------------------------------------------------ C-ABI
+// ---- device-side BVH refit (zr_scene_update_instances): the topology of the BVH4 stays, triangles are re-transformed and node boxes are
+// recomputed bottom-up, one launch per tree level (deepest first; levels are a few dozen at most and the nodes of a level are independent).
+// World-space triangles: the builder's expression (zr_bvh.h Build), so a refit scene traces the same triangles a rebuilt one would.
+__global__ void __launch_bounds__(256) k_refit_tris(BvhTri* tris, uint32_t n, const TriMeta* meta, const zr_mesh_instance* instances, const float* toWorld,
+    const zr_vertex* vertices, const uint32_t* indices)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    BvhTri t = tris[i];
+    const TriMeta tm = meta[t.gidx];
+    const zr_mesh_instance mi = instances[tm.mesh];
+    const float* M = toWorld + 12 * (size_t)tm.mesh;
+    float w[3][3];
+    for (int k = 0; k < 3; k++)
+    {
+        const uint32_t vi = indices[mi.base_idx_offset + 3 * tm.prim + k] + mi.base_vtx_offset;
+        const float* P = vertices[vi].pos;
+        for (int r = 0; r < 3; r++) w[k][r] = M[4 * r + 0] * P[0] + M[4 * r + 1] * P[1] + M[4 * r + 2] * P[2] + M[4 * r + 3];
+    }
+    for (int r = 0; r < 3; r++) { t.v0[r] = w[0][r]; t.e1[r] = w[1][r] - w[0][r]; t.e2[r] = w[2][r] - w[0][r]; }
+    tris[i] = t;
+}
+// bounds of leaf `c` (1-ulp padded like the builder's, since v0 + e1 is a rounded v1)
+__device__ __forceinline__ void LeafBounds(const BvhTri* tris, uint32_t c, float lo[3], float hi[3])
+{
+    const uint32_t first = (c & 0x7fffffffu) >> 3, count = (c & 7u) + 1u;
+    for (int r = 0; r < 3; r++) { lo[r] = 3.402823466e+38f; hi[r] = -3.402823466e+38f; }
+    for (uint32_t i = first; i < first + count; i++)
+    {
+        const BvhTri t = tris[i];
+        for (int r = 0; r < 3; r++)
+        {
+            const float a = t.v0[r], b = t.v0[r] + t.e1[r], cc = t.v0[r] + t.e2[r];
+            lo[r] = fminf(lo[r], zr::PrevFloat32(fminf(a, fminf(b, cc)))); hi[r] = fmaxf(hi[r], zr::NextFloat32(fmaxf(a, fmaxf(b, cc))));
+        }
+    }
+}
+// one level: node = levelNodes[i]; its inner children were finished by the previous (deeper) launch.  Quantisation = BvhBuilder::Collapse:
+// origin = the node's min corner, per-axis power-of-two scale whose 255 steps reach the max corner, child planes rounded outwards and verified
+// against the traversal's decode expression fma(q, scale, origin).
+__global__ void __launch_bounds__(64) k_refit_level(Bvh4Node* nodes, const uint32_t* levelNodes, uint32_t n, const BvhTri* tris, float* nodeBounds)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t ni = levelNodes[i];
+    Bvh4Node N = nodes[ni];
+    float clo[4][3], chi[4][3];
+    for (int c = 0; c < 4; c++)
+    {
+        const uint32_t ref = N.child[c];
+        if (ref == kEmptyChild) continue;
+        if (ref & kLeafBit) LeafBounds(tris, ref, clo[c], chi[c]);
+        else for (int r = 0; r < 3; r++) { clo[c][r] = nodeBounds[6 * (size_t)ref + r]; chi[c][r] = nodeBounds[6 * (size_t)ref + 3 + r]; }
+    }
+    float lo[3] = {3.402823466e+38f, 3.402823466e+38f, 3.402823466e+38f}, hi[3] = {-3.402823466e+38f, -3.402823466e+38f, -3.402823466e+38f};
+    for (int c = 0; c < 4; c++) if (N.child[c] != kEmptyChild) for (int r = 0; r < 3; r++) { lo[r] = fminf(lo[r], clo[c][r]); hi[r] = fmaxf(hi[r], chi[c][r]); }
+    uint32_t ex[3], qlo[3] = {0, 0, 0}, qhi[3] = {0, 0, 0};
+    for (int r = 0; r < 3; r++)
+    {
+        int e = 1;
+        const float ext = hi[r] - lo[r];
+        if (ext > 0) { int ee; (void)frexpf(ext / 255.0f, &ee); e = max(1, min(254, ee + 126 - 1)); }
+        while (e < 254 && !(fmaf(255.0f, zr_asfloat((uint32_t)e << 23), lo[r]) >= hi[r])) e++;
+        ex[r] = (uint32_t)e;
+        const float sc = zr_asfloat(ex[r] << 23);
+        for (int c = 0; c < 4; c++)
+        {
+            if (N.child[c] == kEmptyChild) continue;
+            int a = (int)floorf((clo[c][r] - lo[r]) / sc); a = max(0, min(255, a));
+            while (a > 0 && fmaf((float)a, sc, lo[r]) > clo[c][r]) a--;
+            int b = (int)ceilf((chi[c][r] - lo[r]) / sc); b = max(0, min(255, b));
+            while (b < 255 && fmaf((float)b, sc, lo[r]) < chi[c][r]) b++;
+            qlo[r] |= (uint32_t)a << (8 * c); qhi[r] |= (uint32_t)b << (8 * c);
+        }
+    }
+    N.ox = lo[0]; N.oy = lo[1]; N.oz = lo[2]; N.exps = ex[0] | (ex[1] << 8) | (ex[2] << 16);
+    N.qlox = qlo[0]; N.qloy = qlo[1]; N.qloz = qlo[2]; N.qhix = qhi[0]; N.qhiy = qhi[1]; N.qhiz = qhi[2];
+    nodes[ni] = N;
+    // what the parent sees: the box the quantised planes of the LARGEST child extent decode to would be looser; the exact union is enough,
+    // because the parent quantises it outwards again
+    for (int r = 0; r < 3; r++) { nodeBounds[6 * (size_t)ni + r] = lo[r]; nodeBounds[6 * (size_t)ni + 3 + r] = hi[r]; }
+}
+
 // ---- fused halo transfer: every plane x every rect in ONE launch (the per-plane hipMemcpy2DAsync path above costs planes x peers copies:
 // 49 per exchange for ReSTIR PT on a 4 x 2 tile grid, each a few microseconds of launch latency for strips of a few hundred KB)
 struct HaloJob
@@ -859,6 +944,22 @@ int zr_alias_table_build(const float* power, uint32_t n, uint32_t align_phase, z
     return ZR_OK;
 }
 
+// Tree levels of a BVH4 (root = node 0), deepest first: what the refit walks bottom-up
+static void BvhLevels(const std::vector<Bvh4Node>& nodes, std::vector<uint32_t>& order, std::vector<uint32_t>& offsets)
+{
+    order.clear(); offsets.clear();
+    if (nodes.empty()) return;
+    std::vector<std::vector<uint32_t>> levels(1, std::vector<uint32_t>(1, 0u));
+    for (size_t l = 0; l < levels.size(); l++)
+    {
+        std::vector<uint32_t> next;
+        for (uint32_t ni : levels[l]) for (int c = 0; c < 4; c++) { const uint32_t r = nodes[ni].child[c]; if (r != kEmptyChild && !(r & kLeafBit)) next.push_back(r); }
+        if (!next.empty()) levels.push_back(std::move(next));
+    }
+    for (size_t l = levels.size(); l-- > 0;) { offsets.push_back((uint32_t)order.size()); order.insert(order.end(), levels[l].begin(), levels[l].end()); }
+    offsets.push_back((uint32_t)order.size());
+}
+
 int zr_scene_create(int device, const zr_scene_desc* d, zr_scene** out)
 {
     if (!d || !out) return Fail(ZR_ERR_INVALID_ARG, "zr_scene_create: null argument");
@@ -920,38 +1021,78 @@ int zr_scene_create(int device, const zr_scene_desc* d, zr_scene** out)
     { const uint32_t t = d->emissives[i].packed_b & 0xffffu; if (t != ZR_INVALID_TEX && (int64_t)t > s->maxTex[3]) s->maxTex[3] = t; }
     s->hVertices.assign(d->vertices, d->vertices + d->num_vertices); s->hIndices.assign(d->indices, d->indices + d->num_indices);
     s->hMask.assign(d->instance_mask, d->instance_mask + d->num_instances); s->hNumTris.assign(d->instance_num_tris, d->instance_num_tris + d->num_instances);
+    BvhLevels(bvh.nodes4, s->hLevelOrder, s->levelOffsets);
+    if (!s->hLevelOrder.empty() && (r = s->levelNodes.Upload(s->hLevelOrder.data(), s->hLevelOrder.size()))) { delete s; return r; }
     *out = s;
     return ZR_OK;
 }
 
 // TLAS / instance-buffer update of a frame (RtAccelerationStructure.cpp:382-506, 708-787): the current instance buffer and acceleration
-// structure become the previous ones, the new ones are built from the new object-to-world matrices.  This version rebuilds the BVH on
-// the host (binned SAH, like zr_scene_create) and waits for the device first; a device-side refit is the planned replacement.
+// structure become the previous ones, the new ones follow the new object-to-world matrices.  Default: a **refit on the device** -- the BVH4 built
+// at zr_scene_create keeps its topology, k_refit_tris re-transforms the triangles and k_refit_level recomputes + re-quantises the node boxes
+// level by level (what a D3D12 TLAS / BLAS update with ALLOW_UPDATE does); ZR_SCENE_UPDATE=rebuild selects a full binned-SAH rebuild on the
+// host instead (better trees after large motion, three orders of magnitude slower).  Results do not depend on the tree (zr_intersect.h).
 int zr_scene_update_instances(zr_scene* s, const zr_mesh_instance* instances, const float* instance_to_world, uint32_t n)
 {
     if (!s || !instances || !instance_to_world) return Fail(ZR_ERR_INVALID_ARG, "zr_scene_update_instances: null argument");
     if (n != s->instances.n) return Fail(ZR_ERR_INVALID_ARG, "zr_scene_update_instances: %u instances, the scene has %zu", n, s->instances.n);
     HIP_TRY(hipSetDevice(s->device));
-    zr_scene_desc d; memset(&d, 0, sizeof(d));
-    d.vertices = s->hVertices.data(); d.num_vertices = (uint32_t)s->hVertices.size(); d.indices = s->hIndices.data(); d.num_indices = (uint32_t)s->hIndices.size();
-    d.instances = instances; d.num_instances = n; d.instance_to_world = instance_to_world; d.instance_mask = s->hMask.data(); d.instance_num_tris = s->hNumTris.data();
-    BvhBuilder builder;
-    BuiltBvh bvh = builder.Build(d);
-    if (bvh.stackNeed + 1 > (uint32_t)kTravStack) return Fail(ZR_ERR_UNSUPPORTED, "BVH needs %u traversal stack entries (limit %d)", bvh.stackNeed, kTravStack - 1);
-    HIP_TRY(hipDeviceSynchronize());           // kernels of earlier frames may still read the buffers that change roles below
-    std::lock_guard<std::mutex> lock(s->mtx);
-    std::swap(s->instances.p, s->instancesPrev.p); std::swap(s->instances.n, s->instancesPrev.n);
-    std::swap(s->nodes.p, s->nodesPrev.p); std::swap(s->nodes.n, s->nodesPrev.n);
-    std::swap(s->tris.p, s->trisPrev.p); std::swap(s->tris.n, s->trisPrev.n);
-    std::swap(s->meta.p, s->metaPrev.p); std::swap(s->meta.n, s->metaPrev.n);
-    s->numNodesPrev = s->view.numNodes; s->numTrisPrev = s->view.numTris; s->hasPrev = true;
+    const char* modeEnv = std::getenv("ZR_SCENE_UPDATE");
+    const bool rebuild = modeEnv && !std::strcmp(modeEnv, "rebuild");
     int r;
-    if ((r = s->instances.Upload(instances, n)) || (r = s->nodes.Upload(bvh.nodes4.data(), bvh.nodes4.size())) ||
-        (r = s->tris.Upload(bvh.tris.data(), bvh.tris.size())) || (r = s->meta.Upload(bvh.meta.data(), bvh.meta.size()))) return r;
+    if (rebuild)
+    {
+        zr_scene_desc d; memset(&d, 0, sizeof(d));
+        d.vertices = s->hVertices.data(); d.num_vertices = (uint32_t)s->hVertices.size(); d.indices = s->hIndices.data(); d.num_indices = (uint32_t)s->hIndices.size();
+        d.instances = instances; d.num_instances = n; d.instance_to_world = instance_to_world; d.instance_mask = s->hMask.data(); d.instance_num_tris = s->hNumTris.data();
+        BvhBuilder builder;
+        BuiltBvh bvh = builder.Build(d);
+        if (bvh.stackNeed + 1 > (uint32_t)kTravStack) return Fail(ZR_ERR_UNSUPPORTED, "BVH needs %u traversal stack entries (limit %d)", bvh.stackNeed, kTravStack - 1);
+        HIP_TRY(hipDeviceSynchronize());           // kernels of earlier frames may still read the buffers that change roles below
+        std::lock_guard<std::mutex> lock(s->mtx);
+        std::swap(s->instances.p, s->instancesPrev.p); std::swap(s->instances.n, s->instancesPrev.n);
+        std::swap(s->nodes.p, s->nodesPrev.p); std::swap(s->nodes.n, s->nodesPrev.n);
+        std::swap(s->tris.p, s->trisPrev.p); std::swap(s->tris.n, s->trisPrev.n);
+        std::swap(s->meta.p, s->metaPrev.p); std::swap(s->meta.n, s->metaPrev.n);
+        s->numNodesPrev = s->view.numNodes; s->numTrisPrev = s->view.numTris; s->hasPrev = true;
+        if ((r = s->instances.Upload(instances, n)) || (r = s->nodes.Upload(bvh.nodes4.data(), bvh.nodes4.size())) ||
+            (r = s->tris.Upload(bvh.tris.data(), bvh.tris.size())) || (r = s->meta.Upload(bvh.meta.data(), bvh.meta.size()))) return r;
+        SceneView& v = s->view;
+        v.instances = s->instances.p; v.nodes = s->nodes.p; v.tris = s->tris.p; v.triMeta = s->meta.p;
+        v.numNodes = (uint32_t)bvh.nodes4.size(); v.numTris = (uint32_t)bvh.tris.size();
+        if (bvh.maxDepth > s->maxDepth) s->maxDepth = bvh.maxDepth;
+        BvhLevels(bvh.nodes4, s->hLevelOrder, s->levelOffsets);
+        if ((r = s->levelNodes.Upload(s->hLevelOrder.data(), s->hLevelOrder.size()))) return r;
+        s->refitReady = false;      // the two buffer sets no longer share a topology
+        return ZR_OK;
+    }
+    HIP_TRY(hipDeviceSynchronize());               // kernels of earlier frames may still read the buffers that change roles below
+    std::lock_guard<std::mutex> lock(s->mtx);
+    const size_t nn = s->view.numNodes, nt = s->view.numTris;
+    if (!s->refitReady)
+    {
+        // both buffer sets must hold the same tree: duplicate the current one (once, or after a host rebuild)
+        if ((r = s->instancesPrev.Alloc(n)) || (nn && (r = s->nodesPrev.Alloc(nn))) || (r = s->trisPrev.Alloc(nt)) || (r = s->metaPrev.Alloc(s->meta.n)) ||
+            (nn && (r = s->nodeBounds.Alloc(6 * nn))) || (r = s->toWorld.Alloc(12 * (size_t)n))) return r;
+        HIP_TRY(hipMemcpy(s->instancesPrev.p, s->instances.p, n * sizeof(zr_mesh_instance), hipMemcpyDeviceToDevice));
+        if (nn) HIP_TRY(hipMemcpy(s->nodesPrev.p, s->nodes.p, nn * sizeof(Bvh4Node), hipMemcpyDeviceToDevice));
+        HIP_TRY(hipMemcpy(s->trisPrev.p, s->tris.p, nt * sizeof(BvhTri), hipMemcpyDeviceToDevice));
+        HIP_TRY(hipMemcpy(s->metaPrev.p, s->meta.p, s->meta.n * sizeof(TriMeta), hipMemcpyDeviceToDevice));
+        s->refitReady = true;
+    }
+    std::swap(s->instances.p, s->instancesPrev.p); std::swap(s->nodes.p, s->nodesPrev.p); std::swap(s->tris.p, s->trisPrev.p); std::swap(s->meta.p, s->metaPrev.p);
+    s->numNodesPrev = (uint32_t)nn; s->numTrisPrev = (uint32_t)nt; s->hasPrev = true;
+    HIP_TRY(hipMemcpy(s->instances.p, instances, n * sizeof(zr_mesh_instance), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(s->toWorld.p, instance_to_world, 12 * (size_t)n * sizeof(float), hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_refit_tris, dim3((uint32_t)((nt + 255) / 256)), dim3(256), 0, 0, s->tris.p, (uint32_t)nt, s->meta.p, s->instances.p, s->toWorld.p, s->vertices.p, s->indices.p);
+    for (size_t l = 0; l + 1 < s->levelOffsets.size(); l++)
+    {
+        const uint32_t first = s->levelOffsets[l], cnt = s->levelOffsets[l + 1] - first;
+        hipLaunchKernelGGL(k_refit_level, dim3((cnt + 63) / 64), dim3(64), 0, 0, s->nodes.p, s->levelNodes.p + first, cnt, s->tris.p, s->nodeBounds.p);
+    }
+    HIP_TRY(hipGetLastError());
     SceneView& v = s->view;
     v.instances = s->instances.p; v.nodes = s->nodes.p; v.tris = s->tris.p; v.triMeta = s->meta.p;
-    v.numNodes = (uint32_t)bvh.nodes4.size(); v.numTris = (uint32_t)bvh.tris.size();
-    if (bvh.maxDepth > s->maxDepth) s->maxDepth = bvh.maxDepth;
     return ZR_OK;
 }
 
