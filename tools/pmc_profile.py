@@ -24,7 +24,7 @@ def load(path):
     for line in open(path).read().splitlines()[1:]:
         # kernel names may contain commas (template arguments): split from the right
         name, ctr, launches, val, dur = line.rsplit(",", 4)
-        out.setdefault(name.replace("void ", ""), {})[ctr] = (float(val), int(launches), float(dur))
+        out.setdefault(name.strip('"').replace("void ", ""), {})[ctr] = (float(val), int(launches), float(dur))
     return out
 
 

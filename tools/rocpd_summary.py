@@ -7,7 +7,8 @@ import sys
 
 
 def short(name):
-    return name.split("(")[0]
+    n = name.split("(")[0]
+    return '"' + n + '"' if "," in n else n      # template argument lists contain commas
 
 
 def main():
