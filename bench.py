@@ -114,11 +114,11 @@ def read_prof(api):
     if L.zr_debug_prof_read(buf) != 0:
         return None
     names = ["kernel", "trav", "trav_calls", "rays", "node_iters", "node_lanes", "tri_iters", "tri_lanes", "material", "nee", "bsdf",
-             "misc0", "misc1", "misc2", "misc3", "misc4"]
+             "misc0", "misc1", "misc2", "misc3", "misc4", "steals", "steal_pairs"]
     kernels = {0: "other", 1: "rpt_pathtrace", 2: "rpt_temporal", 3: "rpt_stc"}
     res = {}
     for k, kn in kernels.items():
-        v = {n: int(buf[16 * k + i]) for i, n in enumerate(names)}
+        v = {n: int(buf[32 * k + i]) for i, n in enumerate(names)}
         if not any(v.values()):
             continue
         d = dict(v)
@@ -134,6 +134,8 @@ def read_prof(api):
             d["tris_per_ray"] = round(v["tri_lanes"] / max(1, v["rays"]), 3)
             d["iters_per_call"] = round(it / max(1, v["trav_calls"]), 2)
             d["rays_per_call"] = round(v["rays"] / max(1, v["trav_calls"]), 2)
+            d["steals_per_call"] = round(v["steals"] / max(1, v["trav_calls"]), 3)
+            d["pairs_per_steal"] = round(v["steal_pairs"] / max(1, v["steals"]), 2)
         res[kn] = d
     return res
 

@@ -507,7 +507,7 @@ struct zr_scene
 // The scene as one launch sees it: a private copy of the scene's view with the texture descriptor-table offsets of THIS frame's
 // constants (per-frame data in the reference, FrameConstants.h:31-34) -- nothing per-frame is latched on the shared scene.
 #ifdef ZR_PROF
-// measurement build only (scripts/gpu_prof.sh): 16 kernels x 16 wave-cycle / event counters, read and cleared by zr_debug_prof_read
+// measurement build only (scripts/gpu_prof.sh): 8 kernels x 32 wave-cycle / event counters, read and cleared by zr_debug_prof_read
 static unsigned long long* ProfBuffer()
 {
     static unsigned long long* p = nullptr;

@@ -73,14 +73,14 @@ struct SceneView
 };
 
 // Section timers of the -DZR_PROF measurement build (scripts/gpu_prof.sh): wave cycles (s_memtime) between construction and
-// destruction, summed per wave in LDS (one lane, no atomics on the hot path) and flushed to sc.prof[16 * kernel + i] when
+// destruction, summed per wave in LDS (one lane, no atomics on the hot path) and flushed to sc.prof[32 * kernel + i] when
 // the kernel ends.  Empty in the product build.
 #if defined(ZR_PROF) && defined(__HIP_DEVICE_COMPILE__)
-__shared__ unsigned long long zrProfAcc[4 * 16];
+__shared__ unsigned long long zrProfAcc[4 * 32];
 __device__ __forceinline__ void ProfAdd(int i, unsigned long long v)
 {
     const unsigned long long m = __ballot(1);
-    if (__lane_id() == (uint32_t)(__ffsll((long long)m) - 1)) zrProfAcc[(threadIdx.x >> 6) * 16 + i] += v;
+    if (__lane_id() == (uint32_t)(__ffsll((long long)m) - 1)) zrProfAcc[(threadIdx.x >> 6) * 32 + i] += v;
 }
 struct ProfScope
 {
@@ -92,20 +92,20 @@ struct ProfKernel
 {
     unsigned long long* dst; unsigned long long t0;
     __device__ __forceinline__ ProfKernel(unsigned long long* d) : dst(d), t0(__builtin_readcyclecounter())
-    { if ((threadIdx.x & 63u) < 16u) zrProfAcc[(threadIdx.x >> 6) * 16 + (threadIdx.x & 63u)] = 0; }
+    { if ((threadIdx.x & 63u) < 32u) zrProfAcc[(threadIdx.x >> 6) * 32 + (threadIdx.x & 63u)] = 0; }
     __device__ __forceinline__ ~ProfKernel()
     {
         ProfAdd(0, __builtin_readcyclecounter() - t0);
-        if ((threadIdx.x & 63u) < 16u) atomicAdd(dst + (threadIdx.x & 63u), zrProfAcc[(threadIdx.x >> 6) * 16 + (threadIdx.x & 63u)]);
+        if ((threadIdx.x & 63u) < 32u) atomicAdd(dst + (threadIdx.x & 63u), zrProfAcc[(threadIdx.x >> 6) * 32 + (threadIdx.x & 63u)]);
     }
 };
 #define ZR_PROF_SCOPE(i) ProfScope zrProfScope##i(i)
-#define ZR_PROF_KERNEL(sc, k) ProfKernel zrProfKernel((sc).prof + 16 * (k))
+#define ZR_PROF_KERNEL(sc, k) ProfKernel zrProfKernel((sc).prof + 32 * (k))
 #else
 #define ZR_PROF_SCOPE(i)
 #define ZR_PROF_KERNEL(sc, k)
 #endif
-enum { ZRP_KERNEL = 0, ZRP_TRAV, ZRP_TRAV_CALLS, ZRP_RAYS, ZRP_NODE_ITERS, ZRP_NODE_LANES, ZRP_TRI_ITERS, ZRP_TRI_LANES, ZRP_MATERIAL, ZRP_NEE, ZRP_BSDF, ZRP_MISC0, ZRP_MISC1, ZRP_MISC2, ZRP_MISC3, ZRP_MISC4 };
+enum { ZRP_KERNEL = 0, ZRP_TRAV, ZRP_TRAV_CALLS, ZRP_RAYS, ZRP_NODE_ITERS, ZRP_NODE_LANES, ZRP_TRI_ITERS, ZRP_TRI_LANES, ZRP_MATERIAL, ZRP_NEE, ZRP_BSDF, ZRP_MISC0, ZRP_MISC1, ZRP_MISC2, ZRP_MISC3, ZRP_MISC4, ZRP_STEALS, ZRP_STEAL_PAIRS };
 
 struct RawHit { float t, u, v; uint32_t tri; };     // tri = global triangle index, kInvalidTri on miss
 
@@ -179,6 +179,21 @@ static constexpr int kTravStackWords = 2 * kTravStack;
 #ifndef ZR_TRAV_LDS_ENTRIES
 #define ZR_TRAV_LDS_ENTRIES 8
 #endif
+// intra-wave work stealing inside Traverse (see TraverseDyn): idle lanes take the top stack entry of busy lanes.  Bit-exact (the GPU parity
+// suite passes with it) and 23 % fewer vote iterations per call, but SLOWER on every workload measured (ReSTIR PT Cornell
+// 2.28 -> 2.65 ms, atrium 17.8 -> 20.7 ms, K9 trace 5.19 -> 5.44 ms), so it is compiled out; -DZR_STEAL=1 builds it (scripts/gpu_steal.sh).
+#ifndef ZR_STEAL
+#define ZR_STEAL 0
+#endif
+#ifndef ZR_STEAL_MIN_IDLE
+#define ZR_STEAL_MIN_IDLE 16
+#endif
+#ifndef ZR_STEAL_MIN_PAIRS
+#define ZR_STEAL_MIN_PAIRS 2
+#endif
+#ifndef ZR_STEAL_COOLDOWN
+#define ZR_STEAL_COOLDOWN 1
+#endif
 static constexpr int kTravLdsEntries = ZR_TRAV_LDS_ENTRIES;                 // device: the first entries live in LDS, deeper ones in scratch
 
 // One lane's traversal stack.  Device kernels keep the bottom kTravLdsEntries entries in LDS (entry e of lane l at
@@ -192,7 +207,9 @@ struct StackEntry { uint32_t child; float t; };
 #define ZR_LDS_AS
 #define ZR_PRIVATE_AS
 #endif
-struct TravStack { ZR_LDS_AS StackEntry* lds; uint32_t stride; ZR_PRIVATE_AS StackEntry* mem; };
+// `aux` (device, ZR_STEAL): this wave's work-stealing region in LDS -- 64 x u64 merge keys, 64 x (t, u, v) payloads, 64 x u32 donor lanes
+struct TravStack { ZR_LDS_AS StackEntry* lds; uint32_t stride; ZR_PRIVATE_AS StackEntry* mem; uint32_t* aux = nullptr; };
+static constexpr uint32_t kStealAuxWords = 64 * 2 + 64 * 3 + 64;
 
 // (member-wise accesses: copying a whole StackEntry through an address-space-qualified pointer would go through a generic
 // pointer, and ROCm 7.2's gfx950 backend rejects the aperture check it emits for that cast)
@@ -347,6 +364,32 @@ ZR_HD void TravTriPhase(const SceneView& sc, TravState& s, TravLane& L, const Tr
     else if (L.triCur == L.triEnd) TravPopEnter(sc, s, L, stack);
 }
 
+#if ZR_STEAL
+#define ZR_STEAL_ANYHIT anyH
+#else
+#define ZR_STEAL_ANYHIT anyHit
+#endif
+#if defined(__HIP_DEVICE_COMPILE__) && ZR_STEAL
+// ---- intra-wave work stealing.  A Traverse call ends when the slowest ray of the wave ends; measured a call runs 2 x the vote
+// iterations its average ray needs and a third of the lanes work per iteration.  So lanes whose ray is finished take over pending subtrees of
+// the lanes still busy: the donor hands over the TOP entry of its stack (in LDS, where any lane can read it) together with a copy of the ray, both
+// go on independently, and the pieces of one ray are merged through a 64-bit LDS atomic min on (t, global triangle index) -- the closest hit
+// with the ABI's index tie-break is exactly that minimum, and any-hit is "some piece hit", so the result cannot depend on who traced what.
+// (t, u, v) of the winning piece travel beside the key: a piece writes them iff its key is the slot's key after its atomic (the LDS executes a
+// wave's instructions in order; equal keys mean the same triangle and the same ray, hence the same u, v).
+__device__ __forceinline__ unsigned long long StealKey(const RawHit& b)
+{ return ((unsigned long long)zr_asuint(b.t + 0.0f) << 32) | b.tri; }      // + 0: -0 and +0 compare equal in IntersectTri, so they must tie here too
+__device__ __forceinline__ void StealPublish(const TravStack& st, uint32_t owner, const RawHit& b)
+{
+    if (b.tri == kInvalidTri) return;
+    unsigned long long* keys = (unsigned long long*)st.aux;
+    const unsigned long long key = StealKey(b);
+    atomicMin(&keys[owner], key);
+    if (((volatile unsigned long long*)keys)[owner] == key)
+    { float* pl = (float*)(st.aux + 128) + 3 * owner; pl[0] = b.t; pl[1] = b.u; pl[2] = b.v; }
+}
+#endif
+
 // alphaTest (primary rays): candidates on ZR_INSTANCE_NON_OPAQUE geometry must pass TestOpacity
 ZR_HD RawHit TraverseDyn(const SceneView& sc, V3 o, V3 d, float tmin, float tmax, uint32_t mask, const TravStack& stack, bool anyHit,
     bool filterID = false, uint32_t ignoreID = 0, bool alphaTest = false)
@@ -356,25 +399,98 @@ ZR_HD RawHit TraverseDyn(const SceneView& sc, V3 o, V3 d, float tmin, float tmax
 #ifdef __HIP_DEVICE_COMPILE__
 #ifdef ZR_PROF
     ZR_PROF_SCOPE(ZRP_TRAV);
-    unsigned long long pNI = 0, pNL = 0, pTI = 0, pTL = 0;
+    unsigned long long pNI = 0, pNL = 0, pTI = 0, pTL = 0, pST = 0, pSP = 0;
     ProfAdd(ZRP_TRAV_CALLS, 1); ProfAdd(ZRP_RAYS, __popcll(__ballot(1)));
 #endif
     TravLane L; L.triCur = 0; L.triEnd = 0; L.done = false;
     TravEnter(sc, s, L, s.cur);
+#if ZR_STEAL
+    const uint32_t lane = __lane_id();
+    uint32_t owner = lane;          // whose ray this lane is working on
+    bool pub = true;                // false: this lane holds an unpublished piece of `owner`'s ray
+    bool stolen = false;            // wave-uniform: some piece changed lanes in this call
+    int cool = 0;                   // wave-uniform
+    bool anyH = anyHit;             // of the ray this lane works on (a wave of k_trace_simple mixes closest-hit and any-hit rays)
+#endif
     for (;;)
     {
         const bool atTri = L.triCur < L.triEnd;
         const bool atNode = !L.done && !atTri;
         const uint64_t mNode = __ballot(atNode), mTri = __ballot(atTri);
         if ((mNode | mTri) == 0) break;
+#if ZR_STEAL
+        if (cool > 0) cool--;
+        else
+        {
+            const uint64_t mIdle = __ballot(L.done);
+            if (__popcll(mIdle) >= ZR_STEAL_MIN_IDLE)
+            {
+                const bool canGive = !L.done && s.sp >= 1 && s.sp <= kTravLdsEntries;
+                const uint64_t mDon = __ballot(canGive);
+                const uint32_t nPairs = (uint32_t)min(__popcll(mIdle), __popcll(mDon));
+                if (nPairs >= ZR_STEAL_MIN_PAIRS)
+                {
+                    unsigned long long* keys = (unsigned long long*)stack.aux;
+                    uint32_t* pairLane = stack.aux + 128 + 192;
+                    if (!stolen) { keys[lane] = ~0ull; stolen = true; pub = false; }
+                    const uint64_t lt = (1ull << lane) - 1ull;
+                    const uint32_t rI = (uint32_t)__popcll(mIdle & lt), rD = (uint32_t)__popcll(mDon & lt);
+                    const bool give = canGive && rD < nPairs, take = L.done && rI < nPairs;
+                    if (give) pairLane[rD] = lane;
+                    // the piece this lane finished goes to its owner's slot before the lane's state is overwritten
+                    if (take && !pub) StealPublish(stack, owner, s.best);
+                    const int src = take ? (int)((volatile uint32_t*)pairLane)[rI] : (int)lane;
+                    const float ox = __shfl(s.o.x, src), oy = __shfl(s.o.y, src), oz = __shfl(s.o.z, src);
+                    const float dx = __shfl(s.d.x, src), dy = __shfl(s.d.y, src), dz = __shfl(s.d.z, src);
+                    const float tmn = __shfl(s.tmin, src), bt = __shfl(s.best.t, src);
+                    const uint32_t msk = __shfl(s.mask, src), ign = __shfl(s.ignoreID, src), own = __shfl(owner, src);
+                    const int dsp = __shfl(s.sp, src);
+                    const int flg = __shfl((int)s.filterID | ((int)anyH << 1) | ((int)(s.best.tri != kInvalidTri) << 2), src);
+                    if (take)
+                    {
+                        // the piece starts without a hit of its own; the donor's current best t bounds it (hits beyond it cannot win the merge;
+                        // zr_ray_tri accepts t < tmax, and an equal-t hit with a smaller index must still get through)
+                        TravInit(sc, s, v3(ox, oy, oz), v3(dx, dy, dz), tmn, (flg & 4) ? NextFloat32(bt) : bt, msk, (flg & 1) != 0, ign);
+                        anyH = (flg & 2) != 0; owner = own; pub = false;
+                        const ZR_LDS_AS StackEntry* e = stack.lds + (uint32_t)(dsp - 1) * stack.stride + (src - (int)lane);
+                        const uint32_t c = e->child; const float et = e->t;
+                        L.triCur = 0; L.triEnd = 0;
+                        if (et <= bt * 1.0000003576278687f) { L.done = false; TravEnter(sc, s, L, c); }
+                    }
+                    if (give) s.sp--;
+                    // any-hit rays: a piece that hit ends the whole ray
+                    if (anyH && !L.done && !take && ((volatile unsigned long long*)keys)[owner] != ~0ull) { L.done = true; L.triCur = L.triEnd; }
+                    cool = ZR_STEAL_COOLDOWN;
+#ifdef ZR_PROF
+                    pST++; pSP += nPairs;
+#endif
+                    continue;
+                }
+            }
+        }
+#endif
 #ifdef ZR_PROF
         if (ZR_VOTE_WN * __popcll(mNode) >= ZR_VOTE_WT * __popcll(mTri)) { pNI++; pNL += __popcll(mNode); } else { pTI++; pTL += __popcll(mTri); }
 #endif
         if (ZR_VOTE_WN * __popcll(mNode) >= ZR_VOTE_WT * __popcll(mTri)) { if (atNode) TravNodePhase(sc, s, L, stack); }
-        else { if (atTri) TravTriPhase(sc, s, L, stack, anyHit, alphaTest); }
+        else { if (atTri) TravTriPhase(sc, s, L, stack, ZR_STEAL_ANYHIT, alphaTest); }
     }
+#if ZR_STEAL
+    if (stolen)
+    {
+        if (!pub) StealPublish(stack, owner, s.best);
+        const unsigned long long key = ((volatile unsigned long long*)stack.aux)[lane];
+        if (key == ~0ull) { s.best.t = tmax; s.best.u = 0; s.best.v = 0; s.best.tri = kInvalidTri; }
+        else
+        {
+            const volatile float* pl = (volatile float*)(stack.aux + 128) + 3 * lane;
+            s.best.t = pl[0]; s.best.u = pl[1]; s.best.v = pl[2]; s.best.tri = (uint32_t)(key & 0xffffffffull);
+        }
+    }
+#endif
 #ifdef ZR_PROF
     ProfAdd(ZRP_NODE_ITERS, pNI); ProfAdd(ZRP_NODE_LANES, pNL); ProfAdd(ZRP_TRI_ITERS, pTI); ProfAdd(ZRP_TRI_LANES, pTL);
+    ProfAdd(ZRP_STEALS, pST); ProfAdd(ZRP_STEAL_PAIRS, pSP);
 #endif
 #else
     while (!TravStep(sc, s, stack, anyHit, alphaTest)) {}

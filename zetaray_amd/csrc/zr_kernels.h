@@ -41,10 +41,12 @@ static constexpr int kBlock = 256;
 #define ZR_WAVES_STC 
 #endif
 static constexpr uint32_t kCounterStride = 64;     // queue counters live 256 B apart: their atomics spread over L2 channels
-// this lane's traversal stack: kTravLdsEntries entries in LDS (16 KB per 256-lane block at 8 entries), the rest in scratch
+// this lane's traversal stack: kTravLdsEntries entries in LDS (16 KB per 256-lane block at 8 entries; + 6 KB for the work-stealing slots, zr_dev_scene.h), the rest in scratch
 #define ZR_TRAV_STACK(name) \
     __shared__ StackEntry name##Lds[kTravLdsEntries * kBlock]; StackEntry name##Mem[kTravStack - kTravLdsEntries]; \
-    TravStack name; name.lds = (ZR_LDS_AS StackEntry*)name##Lds + threadIdx.x; name.stride = kBlock; name.mem = (ZR_PRIVATE_AS StackEntry*)name##Mem
+    __shared__ __attribute__((aligned(8))) uint32_t name##Aux[ZR_STEAL ? kStealAuxWords * (kBlock / 64) : 2]; \
+    TravStack name; name.lds = (ZR_LDS_AS StackEntry*)name##Lds + threadIdx.x; name.stride = kBlock; name.mem = (ZR_PRIVATE_AS StackEntry*)name##Mem; \
+    name.aux = name##Aux + (ZR_STEAL ? kStealAuxWords * (threadIdx.x / 64) : 0)
 
 // one atomic per wave: lanes that `want` a slot get consecutive indices
 __device__ __forceinline__ uint32_t AllocSlotWave(uint32_t* counter, bool want)
