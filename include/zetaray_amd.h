@@ -165,6 +165,11 @@ typedef enum zr_output {
        and neighbour-to-current, planes A (RGBA16F 8 B), B (RGBA32_UINT), C (RGBA32_UINT), D (R16_UINT) */
     ZR_OUT_RPT_RBUF_CTN_A  = 10, ZR_OUT_RPT_RBUF_CTN_B = 11, ZR_OUT_RPT_RBUF_CTN_C = 12, ZR_OUT_RPT_RBUF_CTN_D = 13,
     ZR_OUT_RPT_RBUF_NTC_A  = 14, ZR_OUT_RPT_RBUF_NTC_B = 15, ZR_OUT_RPT_RBUF_NTC_C = 16, ZR_OUT_RPT_RBUF_NTC_D = 17,
+    /* K12 thread maps (ReSTIR_PT_Sort.hlsl; Util.hlsli:20-42), R16_UINT 2 B: x offset + 31 | (y offset + 31) << 7 | error << 15 of the pixel
+       the thread at this position shifts; CtN = Sort_CtT then Sort_CtS, NtC = Sort_TtC then Sort_StC (DESC_TABLE_RPT::THREAD_MAP_*).
+       Built under ZR_IND_SORT_TEMPORAL / ZR_IND_SORT_SPATIAL; wave order inside a bucket = wave index (the shader leaves it to the
+       arrival order of an LDS atomic). */
+    ZR_OUT_RPT_THREAD_MAP_CTN = 18, ZR_OUT_RPT_THREAD_MAP_NTC = 19,
     /* ReSTIR DI (ZR_PASS_DI_EMISSIVE) persistent state written by the last frame (Reservoir.hlsli:150-213) */
     ZR_OUT_RDI_RESERVOIR_A = 20,   /* RGBA32_UINT 16 B: bary unorm2, le.xy half2, le.z half | M << 16, lightIdx */
     ZR_OUT_RDI_RESERVOIR_B = 21,   /* RG32F        8 B: w_sum, W */

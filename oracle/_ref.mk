@@ -18,7 +18,7 @@ HLSL_ROOTS := ZetaRenderPass/Common/BSDFSampling.hlsli ZetaRenderPass/Common/RT.
     ZetaRenderPass/GBuffer/GBufferRT_Inline.hlsl ZetaRenderPass/GBuffer/GBufferRT_Common.h \
     ZetaRenderPass/IndirectLighting/PathTracer/PathTracer.hlsl ZetaRenderPass/IndirectLighting/IndirectLighting_Common.h \
     $(addprefix ZetaRenderPass/IndirectLighting/ReSTIR_PT/,ReSTIR_PT_PathTrace.hlsl ReSTIR_PT_Replay.hlsl ReSTIR_PT_Reconnect_CtT.hlsl \
-        ReSTIR_PT_Reconnect_TtC.hlsl ReSTIR_PT_Reconnect_CtS.hlsl ReSTIR_PT_Reconnect_StC.hlsl ReSTIR_PT_SpatialSearch.hlsl) \
+        ReSTIR_PT_Reconnect_TtC.hlsl ReSTIR_PT_Reconnect_CtS.hlsl ReSTIR_PT_Reconnect_StC.hlsl ReSTIR_PT_SpatialSearch.hlsl ReSTIR_PT_Sort.hlsl) \
     ZetaRenderPass/IndirectLighting/ReSTIR_GI/ReSTIR_GI.hlsl \
     $(addprefix ZetaRenderPass/DirectLighting/,Emissive/ReSTIR_DI_Temporal.hlsl Emissive/ReSTIR_DI_Spatial.hlsl Emissive/DirectLighting_Common.h \
         Sky/SkyDI_Temporal.hlsl Sky/SkyDI_Spatial.hlsl Sky/SkyDI_Common.h) \
@@ -79,6 +79,10 @@ $(call rpt_obj,$(1),reconnect_ttc,ReSTIR_PT_Reconnect_TtC.hlsl,cb_ReSTIR_PT_Reus
 $(call rpt_obj,$(1),reconnect_cts,ReSTIR_PT_Reconnect_CtS.hlsl,cb_ReSTIR_PT_Reuse,1,0,-DNEE_EMISSIVE=$(2))
 $(call rpt_obj,$(1),reconnect_stc,ReSTIR_PT_Reconnect_StC.hlsl,cb_ReSTIR_PT_Reuse,1,0,-DNEE_EMISSIVE=$(2))
 $(call rpt_obj,$(1),spatial_search,ReSTIR_PT_SpatialSearch.hlsl,cb_ReSTIR_PT_SpatialSearch,0,0,-DNEE_EMISSIVE=$(2))
+$(call rpt_obj,$(1),sort_ctt,ReSTIR_PT_Sort.hlsl,cb_ReSTIR_PT_Sort,0,0,-DNEE_EMISSIVE=$(2))
+$(call rpt_obj,$(1),sort_ttc,ReSTIR_PT_Sort.hlsl,cb_ReSTIR_PT_Sort,0,0,-DNEE_EMISSIVE=$(2) -DTEMPORAL_TO_CURRENT)
+$(call rpt_obj,$(1),sort_cts,ReSTIR_PT_Sort.hlsl,cb_ReSTIR_PT_Sort,0,0,-DNEE_EMISSIVE=$(2) -DCURRENT_TO_SPATIAL)
+$(call rpt_obj,$(1),sort_stc,ReSTIR_PT_Sort.hlsl,cb_ReSTIR_PT_Sort,0,0,-DNEE_EMISSIVE=$(2) -DSPATIAL_TO_CURRENT)
 _ref/obj/rpt_$(1)_host.o: _ref/gen/.stamp ref_hlsl/ref_rpt_host.cpp ref_hlsl/ref_dispatch.h $(PASS_HDRS)
 	mkdir -p _ref/obj
 	$(HLSL_CXX) $(HLSL_FLAGS) -c -o $$@ ref_hlsl/ref_rpt_host.cpp

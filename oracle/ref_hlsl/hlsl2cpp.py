@@ -186,6 +186,14 @@ def translate(src, relpath, special):
 # File-specific lexical fixes (pattern, replacement): places where HLSL and C++ disagree on something the generic rules cannot see.
 # Every entry keeps the arithmetic as written; it only resolves overloads / declarations the way DXC does.
 SPECIAL = {
+    "ReSTIR_PT_Sort.hlsl": [
+        # 16-bit group dimensions multiplied with 32-bit IDs (HLSL promotes; the C++ vector templates do not mix element types)
+        (r"const uint16_t2 GroupDim = uint16_t2\(", "const uint2 GroupDim = uint2("),
+        # cast of the enum array to a vector
+        # float2 -> int2 (HLSL converts implicitly, truncating)
+        (r"neighborPixel = prevUV \* renderDim;", "neighborPixel = int2(prevUV * renderDim);"),
+        (r"uint4 result = \(uint4\)error;", "uint4 result = uint4((uint)error[0], (uint)error[1], (uint)error[2], (uint)error[3]);"),
+    ],
     "Display.hlsl": [
         # vertex-to-pixel interpolant semantics of the VSOut struct members
         (r"float4 PosSS : SV_Position;", "float4 PosSS;"), (r"float2 TexCoord : TEXCOORD;", "float2 TexCoord;"),

@@ -373,6 +373,8 @@ inline float3 refract(const float3& i, const float3& n, float eta)
     return eta * i - (eta * ndoti + zr_sqrt(k)) * n;
 }
 inline float dot(float a, float b) { return a * b; }
+// dot(1, bool4): the number of set components (ReSTIR_PT_Sort.hlsl counts the 2 x 2 pixels of a thread per bucket this way)
+inline uint32_t dot(int a, const vec<bool, 4>& b) { return (uint32_t)a * ((uint32_t)b.d[0] + (uint32_t)b.d[1] + (uint32_t)b.d[2] + (uint32_t)b.d[3]); }
 // select(bool vector, half vector ...)
 inline half2 select(const bool2& c, const half2& a, const half2& b) { half2 r; for (int i = 0; i < 2; i++) r.d[i] = c.d[i] ? a.d[i] : b.d[i]; return r; }
 inline half3 select(const bool3& c, const half3& a, const half3& b) { half3 r; for (int i = 0; i < 3; i++) r.d[i] = c.d[i] ? a.d[i] : b.d[i]; return r; }

@@ -3,9 +3,11 @@
 // ReSTIR PT (K11, K13-K16) from the reference's own shaders compiled as C++ (ref_pass_shader.cpp, one object per shader permutation),
 // driven by a restatement of the reference's HOST code: IndirectLighting::RenderReSTIR_PT / ReSTIR_PT_Temporal / ReSTIR_PT_Spatial
 // (Source/ZetaRenderPass/IndirectLighting/IndirectLighting.cpp:370-1025) -- constant buffers, descriptor indices (the layout of
-// DESC_TABLE_RPT, IndirectLighting.h:167-230), dispatch sizes and order, the ping-pong of the two reservoir sets.  The thread-sort passes
-// (K12) are scheduling only and stay off (CB_IND_FLAGS::SORT_*), so a "wave" is the 64 consecutive threads of a thread group, which is what
-// the ABI pins wave intrinsics to.  Built per NEE permutation: libzref_rpt_{e0,e1,e1p}.so.
+// DESC_TABLE_RPT, IndirectLighting.h:167-230), dispatch sizes and order, the ping-pong of the two reservoir sets.  A "wave" is the 64
+// consecutive threads of a thread group, which is what the ABI pins wave intrinsics to.  The thread-sort passes (K12,
+// ReSTIR_PT_Sort.hlsl x 4) run as in the reference: the temporal pair always, the spatial pair under CB_IND_FLAGS::SORT_SPATIAL; the replay and
+// reconnect shaders consume the maps when zr_params.flags carries SORT_TEMPORAL / SORT_SPATIAL.  The group runner steps the waves of a group
+// in order, so the LDS InterlockedAdd of the sort (whose arrival order is unspecified on a GPU) resolves in wave order -- the order the ABI fixes.  Built per NEE permutation: libzref_rpt_{e0,e1,e1p}.so.
 #include "ref_pass_common.h"
 #include "ref_dispatch.h"
 
@@ -23,6 +25,8 @@ void zrefp_shader_rpt_replay_cts(const ZrDispatch*); void zrefp_shader_rpt_repla
 void zrefp_shader_rpt_reconnect_ctt(const ZrDispatch*); void zrefp_shader_rpt_reconnect_ttc(const ZrDispatch*);
 void zrefp_shader_rpt_reconnect_cts(const ZrDispatch*); void zrefp_shader_rpt_reconnect_stc(const ZrDispatch*);
 void zrefp_shader_rpt_spatial_search(const ZrDispatch*);
+void zrefp_shader_rpt_sort_ctt(const ZrDispatch*); void zrefp_shader_rpt_sort_ttc(const ZrDispatch*);
+void zrefp_shader_rpt_sort_cts(const ZrDispatch*); void zrefp_shader_rpt_sort_stc(const ZrDispatch*);
 }
 
 namespace {
@@ -82,6 +86,7 @@ int zrefp_rpt_read_plane(const RptState* S, int which, int plane, void* out)
     if (plane == 7) { memcpy(out, S->neighbor.data(), S->neighbor.size()); return 0; }
     if (plane == 8) { memcpy(out, S->target.data(), S->target.size()); return 0; }
     if (plane == 9) { memcpy(out, S->finalRGBA.data(), S->finalRGBA.size()); return 0; }
+    if (plane == 10 || plane == 11) { memcpy(out, S->threadMap[plane - 10].data(), S->threadMap[plane - 10].size()); return 0; }      // CtN, NtC
     return -1;
 }
 
@@ -125,7 +130,9 @@ int zrefp_rpt_render(RefScene* r, RptState* S, const zr_frame_constants* cb, con
     PT.Packed = RU.Packed = prm->max_non_tr_bounces | (prm->max_glossy_tr_bounces << PACKED_INDEX::NUM_GLOSSY_BOUNCES) |
         ((prm->m_max_temporal & 0xf) << PACKED_INDEX::MAX_TEMPORAL_M) | ((prm->m_max_spatial & 0xf) << PACKED_INDEX::MAX_SPATIAL_M) | (texFilter << PACKED_INDEX::TEX_FILTER);
     const uint32_t userFlags = prm->flags & (CB_IND_FLAGS::STOCHASTIC_MULTI_BOUNCE | CB_IND_FLAGS::RUSSIAN_ROULETTE | CB_IND_FLAGS::BOILING_SUPPRESSION | CB_IND_FLAGS::PATH_REGULARIZATION);
-    PT.Flags = RU.Flags = userFlags;                                        // SORT_TEMPORAL / SORT_SPATIAL stay off (scheduling only)
+    PT.Flags = RU.Flags = userFlags;
+    PT.Flags |= prm->flags & CB_IND_FLAGS::SORT_TEMPORAL;                                            // IndirectLighting.cpp:162-164, 1552-1561
+    RU.Flags |= prm->flags & (CB_IND_FLAGS::SORT_TEMPORAL | CB_IND_FLAGS::SORT_SPATIAL);
     PT.SampleSetSize_NumSampleSets = prm->presampling ? ((prm->num_sample_sets << 16) | prm->sample_set_size) : 0u;
     PT.TargetDescHeapIdx = RU.TargetDescHeapIdx = Slot(TARGET_UAV);
     PT.Final = RU.FinalDescHeapIdx = Slot(FINAL_UAV);
@@ -158,6 +165,15 @@ int zrefp_rpt_render(RefScene* r, RptState* S, const zr_frame_constants* cb, con
         RU.Reservoir_A_DescHeapIdx = PT.Reservoir_A_DescHeapIdx;
         // ---- ReSTIR_PT_Temporal, IndirectLighting.cpp:370-596
         RU.Flags |= CB_IND_FLAGS::TEMPORAL_RESAMPLE;
+        {   // Sort - TtC, Sort - CtT (IndirectLighting.cpp:383-441; unconditional)
+            cb_ReSTIR_PT_Sort so; memset(&so, 0, sizeof(so));
+            so.DispatchDimX = CeilDiv(w, RESTIR_PT_SORT_GROUP_DIM_X * 2); so.DispatchDimY = CeilDiv(h, RESTIR_PT_SORT_GROUP_DIM_Y * 2);
+            so.Flags = RU.Flags;
+            so.Reservoir_A_DescHeapIdx = RU.PrevReservoir_A_DescHeapIdx; so.MapDescHeapIdx = Slot(THREAD_MAP_NtC_UAV);
+            Run(zrefp_shader_rpt_sort_ttc, &so, sizeof(so), so.DispatchDimX, so.DispatchDimY, false);
+            so.Reservoir_A_DescHeapIdx = PT.Reservoir_A_DescHeapIdx; so.MapDescHeapIdx = Slot(THREAD_MAP_CtN_UAV);
+            Run(zrefp_shader_rpt_sort_ctt, &so, sizeof(so), so.DispatchDimX, so.DispatchDimY, false);
+        }
         const uint32_t rx = CeilDiv(w, RESTIR_PT_REPLAY_GROUP_DIM_X), ry = CeilDiv(h, RESTIR_PT_REPLAY_GROUP_DIM_Y);
         RU.RBufferA_CtN_DescHeapIdx = Slot(RBUFFER_A_CtN_UAV); RU.RBufferA_NtC_DescHeapIdx = Slot(RBUFFER_A_NtC_UAV);
         Run(zrefp_shader_rpt_replay_ctt, &RU, sizeof(RU), rx, ry, true);
@@ -181,6 +197,16 @@ int zrefp_rpt_render(RefScene* r, RptState* S, const zr_frame_constants* cb, con
             Run(zrefp_shader_rpt_spatial_search, &ss, sizeof(ss), dx, dy, false);
         }
         S->currTemporalIdx = 1 - S->currTemporalIdx;
+        if (RU.Flags & CB_IND_FLAGS::SORT_SPATIAL)      // Sort - CtS, Sort - StC (IndirectLighting.cpp:690-742)
+        {
+            cb_ReSTIR_PT_Sort so; memset(&so, 0, sizeof(so));
+            so.DispatchDimX = CeilDiv(w, RESTIR_PT_SORT_GROUP_DIM_X * 2); so.DispatchDimY = CeilDiv(h, RESTIR_PT_SORT_GROUP_DIM_Y * 2);
+            so.Flags = RU.Flags; so.Reservoir_A_DescHeapIdx = RU.Reservoir_A_DescHeapIdx;
+            so.MapDescHeapIdx = Slot(THREAD_MAP_CtN_UAV);
+            Run(zrefp_shader_rpt_sort_cts, &so, sizeof(so), so.DispatchDimX, so.DispatchDimY, false);
+            so.SpatialNeighborHeapIdx = Slot(SPATIAL_NEIGHBOR_SRV); so.MapDescHeapIdx = Slot(THREAD_MAP_NtC_UAV);
+            Run(zrefp_shader_rpt_sort_stc, &so, sizeof(so), so.DispatchDimX, so.DispatchDimY, false);
+        }
         const uint32_t rx = CeilDiv(w, RESTIR_PT_REPLAY_GROUP_DIM_X), ry = CeilDiv(h, RESTIR_PT_REPLAY_GROUP_DIM_Y);
         RU.RBufferA_CtN_DescHeapIdx = Slot(RBUFFER_A_CtN_UAV); RU.RBufferA_NtC_DescHeapIdx = Slot(RBUFFER_A_NtC_UAV);
         Run(zrefp_shader_rpt_replay_cts, &RU, sizeof(RU), rx, ry, false);

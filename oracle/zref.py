@@ -98,7 +98,8 @@ class RefPathTracer(RefPass):
 class RefRestirPT(RefPass):
     """K11 + K13-K16: the reference's ReSTIR PT shaders driven by the restated host sequence (oracle/ref_hlsl/ref_rpt_host.cpp)"""
     PLANES = {"A": (0, np.uint8, 4), "B": (1, np.float32, 2), "C": (2, np.uint32, 4), "D": (3, np.uint32, 4), "E": (4, np.uint16, 1),
-              "F": (5, np.float32, 2), "G": (6, np.uint32, 2), "neighbor": (7, np.uint8, 2), "target": (8, np.float32, 4)}
+              "F": (5, np.float32, 2), "G": (6, np.uint32, 2), "neighbor": (7, np.uint8, 2), "target": (8, np.float32, 4),
+              "map_ctn": (10, np.uint16, 1), "map_ntc": (11, np.uint16, 1)}      # K12 thread maps (ReSTIR_PT_Sort.hlsl)
 
     def __init__(self, scene, w, h, presampling=False, force_bvh=False):
         name = "rpt_e0" if len(scene.emissives) == 0 else ("rpt_e1p" if presampling else "rpt_e1")

@@ -215,7 +215,7 @@ class OracleRPT:
     """Stateful ReSTIR PT renderer of the oracle (zro_rpt.h).  render() keeps the previous frame's G-buffer alive."""
     PLANES = {"A": (0, np.uint32, 1), "B": (1, np.float32, 2), "C": (2, np.uint32, 4), "D": (3, np.uint32, 4),
               "E": (4, np.uint16, 1), "F": (5, np.float32, 2), "G": (6, np.uint32, 2), "target": (7, np.float32, 4),
-              "neighbor": (8, np.uint8, 2)}
+              "neighbor": (8, np.uint8, 2), "map_ctn": (10, np.uint16, 1), "map_ntc": (11, np.uint16, 1)}
 
     def __init__(self, oscene, w, h):
         from zetaray_amd import scene_io

@@ -1161,6 +1161,8 @@ int zro_rpt_read_plane(const zro_rpt* r, int which, int plane, void* out)
     case 6: return cp(p.G.data(), p.G.size() * 4);
     case 7: return cp(r->st.target.data(), r->st.target.size() * 4);
     case 8: return cp(r->st.neighbor.data(), r->st.neighbor.size());
+    case 10: return cp(r->st.threadMap[0].data(), r->st.threadMap[0].size() * 2);      // K12 thread maps: CtN, NtC
+    case 11: return cp(r->st.threadMap[1].data(), r->st.threadMap[1].size() * 2);
     }
     return 1;
 }

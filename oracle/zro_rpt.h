@@ -1224,6 +1224,7 @@ struct State
     RBuffer rbuffer[2];                    // [0] = CtN, [1] = NtC
     std::vector<float> target;             // RGBA32F (xyz)
     std::vector<uint8_t> neighbor;         // RG8_UINT
+    std::vector<uint16_t> threadMap[2];    // R16_UINT: [0] = CtN, [1] = NtC (K12, ReSTIR_PT_Sort.hlsl)
     std::vector<uint16_t> sampleSet;       // 512 x half2 (SampleSet.hlsli)
     bool temporalValid = false;
     int currIdx = 0;
@@ -1232,7 +1233,7 @@ struct State
         w = w_; h = h_; size_t n = (size_t)w * h;
         for (auto& r : reservoirs) r.Resize(n);
         for (auto& r : rbuffer) r.Resize(n);
-        target.assign(4 * n, 0); neighbor.assign(2 * n, 0);
+        target.assign(4 * n, 0); neighbor.assign(2 * n, 0); threadMap[0].assign(n, 0); threadMap[1].assign(n, 0);
         temporalValid = false; currIdx = 0;
     }
 };
@@ -1413,6 +1414,104 @@ static TemporalPixel FindTemporal(const zr_frame_constants& g, const GBufRead& g
     return t;
 }
 
+// ---- K12 ReSTIR_PT_Sort.hlsl:99-368 (+ FindNeighbor :23-64, WriteOutput :72-93, Util.hlsli:20-42 EncodeSorted / DecodeSorted).
+// One 16 x 16 thread group per 32 x 32 pixel tile, every thread owns a 2 x 2 quad; pixels are bucketed by the reconnection depth of the reservoir
+// their shift reads (k = 2, 3, 4, >= 5, skip) and the map stores, at the position of the thread that will process a pixel, the pixel's offset
+// (6 + 6 bits, biased by 31) and an error bit.  The shader orders the waves of a group by the arrival of an LDS InterlockedAdd, which a GPU
+// leaves unspecified; the ABI fixes wave order = wave index, so inside a bucket pixels are in (thread, quad slot) order.
+enum SortVariant { SORT_CtT = 0, SORT_TtC = 1, SORT_CtS = 2, SORT_StC = 3 };
+static const uint32_t SE_SUCCESS = 0, SE_INVALID_PIXEL = 1, SE_NOT_FOUND = 2, SE_EMPTY = 4;      // Shift.hlsli:8-14
+static inline void EncodeSorted(uint32_t x, uint32_t y, uint32_t mx, uint32_t my, uint32_t W, std::vector<uint16_t>& map, uint32_t error)
+{
+    const uint32_t dx = (uint32_t)((int)x - (int)mx + 31), dy = (uint32_t)((int)y - (int)my + 31);
+    map[(size_t)my * W + mx] = (uint16_t)(dx | (dy << 7) | ((error > 0 ? 1u : 0u) << 15));
+}
+static inline void DecodeSorted(uint32_t x, uint32_t y, uint32_t W, const std::vector<uint16_t>& map, int& ox, int& oy, bool& error)
+{
+    const uint32_t e = map[(size_t)y * W + x];
+    error = (e & (1u << 15)) != 0;
+    ox = (int)x + (int)(e & 0x3f) - 31; oy = (int)y + (int)((e >> 7) & 0x3f) - 31;
+}
+// metaA: the A plane the variant reads reservoir metadata from; neighbor: K15's output (StC only)
+static void SortPass(SortVariant variant, const zr_frame_constants& g, const GBufRead& gb, bool spatialResample,
+    const std::vector<uint32_t>& metaA, const std::vector<uint8_t>& neighbor, std::vector<uint16_t>& map)
+{
+    const uint32_t W = g.render_width, H = g.render_height;
+    const uint32_t dimX = (W + 31) / 32, dimY = (H + 31) / 32;
+    struct Px { uint32_t x, y, gtx, gty, result; };
+    std::vector<Px> bucket[5], all;
+    for (uint32_t gy = 0; gy < dimY; gy++) for (uint32_t gx = 0; gx < dimX; gx++)
+    {
+        for (auto& b : bucket) b.clear();
+        all.clear();
+        const bool againstEdge = (gx == dimX - 1) || (gy == dimY - 1);
+        const bool lastGroup = (gx == dimX - 1) && (gy == dimY - 1);
+        for (uint32_t gidx = 0; gidx < 256; gidx++) for (uint32_t i = 0; i < 4; i++)
+        {
+            Px p; p.gtx = (gidx & 15) * 2 + (i & 1); p.gty = (gidx >> 4) * 2 + (i >> 1);
+            p.x = gx * 32 + p.gtx; p.y = gy * 32 + p.gty;
+            // FindNeighbor
+            uint32_t err = SE_SUCCESS; int nx = 0, ny = 0;
+            if (p.x >= W || p.y >= H) err = SE_INVALID_PIXEL;
+            else
+            {
+                const size_t px = (size_t)p.y * W + p.x;
+                const GFlags flags = DecodeFlags(gb.mr[px]);
+                if (flags.invalid || flags.emissive) err = SE_INVALID_PIXEL;
+                else if (variant == SORT_TtC)
+                {
+                    const float2 renderDim = {(float)W, (float)H};
+                    const float2 motionVec = DecodeMotion(gb.motion[px]);
+                    const float2 currUV = {((float)p.x + 0.5f) / renderDim.x, ((float)p.y + 0.5f) / renderDim.y};
+                    const float2 prevUV = currUV - motionVec;
+                    nx = (int)(prevUV.x * renderDim.x); ny = (int)(prevUV.y * renderDim.y);
+                    if (prevUV.x < 0.0f || prevUV.y < 0.0f || prevUV.x > 1.0f || prevUV.y > 1.0f) err = SE_NOT_FOUND;
+                }
+                else if (variant == SORT_StC)
+                {
+                    const uint32_t ox = neighbor[2 * px], oy = neighbor[2 * px + 1];
+                    if (ox == 255) err = SE_NOT_FOUND;
+                    nx = (int)ox - 32 + (int)p.x; ny = (int)oy - 32 + (int)p.y;
+                }
+            }
+            bool skip = err != SE_SUCCESS;
+            uint32_t result = err, k = Reconnection::EMPTY;
+            if (err == SE_SUCCESS)
+            {
+                const bool fromNeighbor = variant == SORT_TtC || variant == SORT_StC;
+                const int rx = fromNeighbor ? nx : (int)p.x, ry = fromNeighbor ? ny : (int)p.y;
+                // out-of-bounds texture loads return 0 (k field 0 = reconnection at k = 2)
+                const uint32_t a = (rx >= 0 && ry >= 0 && rx < (int)W && ry < (int)H) ? metaA[(size_t)ry * W + rx] : 0u;
+                const uint32_t kk = a & 0xf;
+                k = kk == Reconnection::EMPTY ? kk : kk + 2;
+            }
+            if (k == Reconnection::EMPTY) { result |= SE_EMPTY; skip = true; }
+            bool edgeCase = false;
+            if (skip && againstEdge && p.x < W && p.y < H) { result = SE_SUCCESS; skip = false; edgeCase = true; }
+            p.result = result;
+            all.push_back(p);
+            if (!skip && k == 2) bucket[0].push_back(p);
+            else if (!skip && k == 3) bucket[1].push_back(p);
+            else if (!skip && k == 4) bucket[2].push_back(p);
+            else if (!skip && (k >= 5 || edgeCase)) bucket[3].push_back(p);
+            else if (skip) bucket[4].push_back(p);
+        }
+        auto write = [&](const Px& p, uint32_t mgx, uint32_t mgy)
+        {
+            if (gx == dimX - 1 && gy != dimY - 1) std::swap(mgx, mgy);
+            const uint32_t mx = gx * 32 + mgx, my = gy * 32 + mgy;
+            uint32_t error;
+            if (variant == SORT_TtC) error = p.result & (spatialResample ? (SE_INVALID_PIXEL | SE_NOT_FOUND) : SE_INVALID_PIXEL);
+            else if (variant == SORT_StC) error = p.result & SE_INVALID_PIXEL;
+            else error = p.result & (SE_INVALID_PIXEL | SE_EMPTY);
+            if (mx < W && my < H) EncodeSorted(p.x, p.y, mx, my, W, map, error);
+        };
+        if (lastGroup) { for (const Px& p : all) write(p, p.gtx, p.gty); continue; }      // one-to-one mapping for the very last thread group
+        uint32_t idx = 0;
+        for (auto& b : bucket) for (const Px& p : b) { write(p, idx & 31u, idx >> 5); idx++; }
+    }
+}
+
 static void TemporalPass(const Scene& sc, const zr_frame_constants& g, const GBufRead& gb, const GBufRead& gbPrev, const zr_params& prm, State& st,
     bool doSpatial, float* finalRGBA)
 {
@@ -1425,6 +1524,11 @@ static void TemporalPass(const Scene& sc, const zr_frame_constants& g, const GBu
     // the CtT passes bind the PREVIOUS acceleration structure and mesh-instance buffer (IndirectLighting.cpp:465-471, 542-548)
     Globals glPrev = gl; glPrev.sc = &sc.Prev();
     const uint32_t M_max = prm.m_max_temporal & 0xf;
+
+    // ---- K12 Sort_TtC, Sort_CtT (IndirectLighting.cpp:383-441: dispatched whether or not SORT_TEMPORAL is set).  The temporal reconnect passes
+    // have no wave operations, so which thread shifts which pixel (what the maps say) cannot change their results; the maps are outputs here.
+    SortPass(SORT_TtC, g, gb, doSpatial, prev.A, st.neighbor, st.threadMap[1]);
+    SortPass(SORT_CtT, g, gb, doSpatial, cur.A, st.neighbor, st.threadMap[0]);
 
     // ---- K13 Replay_CtT and Replay_TtC (ReSTIR_PT_Replay.hlsl:289-534); plane threshold 0.01 here
     for (int variant = 0; variant < 2; variant++)
@@ -1643,6 +1747,13 @@ static void SpatialPass(const Scene& sc, const zr_frame_constants& g, const GBuf
     const ReservoirPlanes& in = st.reservoirs[st.currIdx];
     ReservoirPlanes& out = st.reservoirs[1 - st.currIdx];
     st.currIdx = 1 - st.currIdx;
+    // ---- K12 Sort_CtS, Sort_StC (IndirectLighting.cpp:690-742)
+    const bool sortSpatial = (prm.flags & ZR_IND_SORT_SPATIAL) != 0;
+    if (sortSpatial)
+    {
+        SortPass(SORT_CtS, g, gb, true, in.A, st.neighbor, st.threadMap[0]);
+        SortPass(SORT_StC, g, gb, true, in.A, st.neighbor, st.threadMap[1]);
+    }
 
     auto neighborOf = [&](uint32_t x, uint32_t y, int& sx, int& sy) {
         const size_t px = (size_t)y * W + x;
@@ -1743,9 +1854,16 @@ static void SpatialPass(const Scene& sc, const zr_frame_constants& g, const GBuf
         for (uint32_t l = 0; l < 64; l++)
         {
             Lane& a = L[l]; a.valid = a.hasN = a.spatialEmpty = a.resample = false;
-            const uint32_t x = gx * 8 + (l & 7), y = gy * 8 + (l >> 3);
+            uint32_t x = gx * 8 + (l & 7), y = gy * 8 + (l >> 3);
             a.x = x; a.y = y;
             if (x >= W || y >= H) continue;
+            if (sortSpatial)      // ReSTIR_PT_Reconnect_StC.hlsl:133-140: the thread shifts the pixel the NtC map assigns to its position
+            {
+                int mx, my; bool error;
+                DecodeSorted(x, y, W, st.threadMap[1], mx, my, error);
+                if (error) continue;
+                x = (uint32_t)mx; y = (uint32_t)my; a.x = x; a.y = y;
+            }
             a.px = (size_t)y * W + x;
             a.flags = DecodeFlags(gb.mr[a.px]);
             if (a.flags.invalid || a.flags.emissive) continue;

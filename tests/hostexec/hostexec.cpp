@@ -285,6 +285,7 @@ void zhx_trace_any(const HxScene* s, const float* rays, uint32_t n, uint32_t mas
 struct HxRpt
 {
     uint32_t w = 0, h = 0; bool temporalValid = false, doTemporal = false, doSpatial = false; int currIdx = 0;
+    std::vector<uint16_t> map[2];      // K12 thread maps (CtN, NtC)
     struct Planes { std::vector<uint32_t> A, G; std::vector<float> B, F; std::vector<U4> C, D; std::vector<uint16_t> E;
         void Resize(size_t n) { A.assign(n, 0); B.assign(2 * n, 0); C.assign(n, U4{0, 0, 0, 0}); D.assign(n, U4{0, 0, 0, 0}); E.assign(n, 0); F.assign(2 * n, 0); G.assign(2 * n, 0); }
         rpt::ResPlanes View() { rpt::ResPlanes p; p.A = A.data(); p.B = B.data(); p.C = C.data(); p.D = D.data(); p.E = E.data(); p.F = F.data(); p.G = G.data(); return p; } } res[2];
@@ -335,6 +336,36 @@ void zhx_rpt_render_stage(const HxScene* s, HxRpt* R, const zr_frame_constants* 
     prm.M_max_temporal = params->m_max_temporal & 0xf; prm.M_max_spatial = params->m_max_spatial & 0xf; prm.alpha_min = params->alpha_min;
     prm.emissive = g.num_emissive_triangles ? 1u : 0u;
     prm.textured = s->view.tex.count ? 1u : 0u;
+    prm.temporalMap = 0; prm.sortTemporal = (params->flags & ZR_IND_SORT_TEMPORAL) ? 1u : 0u; prm.sortSpatial = (params->flags & ZR_IND_SORT_SPATIAL) ? 1u : 0u;
+    R->map[0].resize((size_t)F.gb.w * F.gb.h); R->map[1].resize((size_t)F.gb.w * F.gb.h);
+    F.mapCtN = R->map[0].data(); F.mapNtC = R->map[1].data();
+    // K12 on the host: the kernel's bucket order (wave, lane, quad slot) is plain thread order when the group runs serially
+    auto sortPass = [&](int variant, uint16_t* map)
+    {
+        const uint32_t W = g.render_width, H = g.render_height, dimX = (W + 31) / 32, dimY = (H + 31) / 32;
+        struct Px { uint32_t x, y, gtx, gty, res; };
+        std::vector<Px> bucket[5];
+        for (uint32_t gy = F.oy0 / 32; gy < (F.oy0 + F.oh + 31) / 32; gy++) for (uint32_t gx = F.ox0 / 32; gx < (F.ox0 + F.ow + 31) / 32; gx++)
+        {
+            for (auto& b : bucket) b.clear();
+            const bool againstEdge = gx == dimX - 1 || gy == dimY - 1, lastGroup = gx == dimX - 1 && gy == dimY - 1;
+            auto write = [&](const Px& q, uint32_t mgx, uint32_t mgy)
+            {
+                if (gx == dimX - 1 && gy != dimY - 1) std::swap(mgx, mgy);
+                const uint32_t mx = gx * 32 + mgx, my = gy * 32 + mgy;
+                if (mx < W && my < H && InPlanes(F.gb, (int)mx, (int)my))
+                    map[Pix(F.gb, mx, my)] = EncodeSorted(q.x, q.y, mx, my, SortErrorBits(variant, q.res, prm.doSpatial != 0));
+            };
+            for (uint32_t gidx = 0; gidx < 256; gidx++) for (uint32_t i = 0; i < 4; i++)
+            {
+                Px q; q.gtx = (gidx & 15) * 2 + (i & 1); q.gty = (gidx >> 4) * 2 + (i >> 1); q.x = gx * 32 + q.gtx; q.y = gy * 32 + q.gty;
+                const uint32_t c = SortClassify(F, g, variant, q.x, q.y, againstEdge, q.res);
+                if (lastGroup) write(q, q.gtx, q.gty); else bucket[c].push_back(q);
+            }
+            uint32_t idx = 0;
+            for (auto& b : bucket) for (const Px& q : b) { write(q, idx & 31u, idx >> 5); idx++; }
+        }
+    };
     if (stages & 1)
     {
         R->doTemporal = (params->flags & ZR_IND_TEMPORAL_RESAMPLE) && R->temporalValid && prev;
@@ -371,6 +402,7 @@ void zhx_rpt_render_stage(const HxScene* s, HxRpt* R, const zr_frame_constants* 
         }
         if (prm.doTemporal)
         {
+            sortPass(RPT_SORT_TTC, F.mapNtC); sortPass(RPT_SORT_CTT, F.mapCtN);      // unconditional, like the reference
             for (int v = 0; v < 2; v++) for (uint32_t y = Y0; y < Y1; y++) for (uint32_t x = X0; x < X1; x++) { ReplayTemporalPixel(F, g, v, x, y, stack, cnt); flush(); }
             for (uint32_t y = Y0; y < Y1; y++) for (uint32_t x = X0; x < X1; x++) { ReconnectTemporalPixel(F, g, x, y, stack, cnt); flush(); }
         }
@@ -378,6 +410,7 @@ void zhx_rpt_render_stage(const HxScene* s, HxRpt* R, const zr_frame_constants* 
     if ((stages & 2) && prm.doSpatial)
     {
         for (uint32_t y = Y0; y < Y1; y++) for (uint32_t x = X0; x < X1; x++) SpatialSearchPixel(F, g, x, y);
+        if (prm.sortSpatial) { sortPass(RPT_SORT_CTS, F.mapCtN); sortPass(RPT_SORT_STC, F.mapNtC); }
         for (int v = 0; v < 2; v++) for (uint32_t y = Y0; y < Y1; y++) for (uint32_t x = X0; x < X1; x++) { ReplaySpatialPixel(F, g, v, x, y, stack, cnt); flush(); }
         std::vector<StcLane> L(64);
         float v1[64], v2[64], v3[64], v4[64];
@@ -385,7 +418,9 @@ void zhx_rpt_render_stage(const HxScene* s, HxRpt* R, const zr_frame_constants* 
         {
             for (uint32_t l = 0; l < 64; l++)
             {
-                StcPhase0(F, g, gx * 8 + (l & 7), gy * 8 + (l >> 3), L[l], v1[l], v2[l]);
+                uint32_t x = gx * 8 + (l & 7), y = gy * 8 + (l >> 3);
+                if (prm.sortSpatial && F.Owns(x, y) && !DecodeSorted(F.mapNtC[Pix(F.gb, x, y)], x, y)) x = 0xffffffffu;      // k_rpt_stc
+                StcPhase0(F, g, x, y, L[l], v1[l], v2[l]);
                 if (L[l].valid && L[l].hasN) ReconnectCtSPixel(F, g, L[l].x, L[l].y, stack, cnt);
             }
             const float sum1 = ButterflySum64(v1), sum2 = ButterflySum64(v2);
@@ -426,6 +461,7 @@ int zhx_rpt_read_plane(const HxRpt* R, int which, int plane, void* out)
     case 6: return cp(p.G.data(), p.G.size() * 4);
     case 7: return cp(R->target.data(), R->target.size() * 16);
     case 8: return cp(R->neighbor.data(), R->neighbor.size());
+    case 18: case 19: return cp(R->map[plane - 18].data(), R->map[plane - 18].size() * 2);
     }
     if (plane >= 10 && plane <= 17)
     {

@@ -189,7 +189,7 @@ class HostExecRPT:
     """ReSTIR PT through the HIP stage functions, serially (mirror of oracle.zro.OracleRPT)."""
     PLANES = {"A": (0, np.uint32, 1), "B": (1, np.float32, 2), "C": (2, np.uint32, 4), "D": (3, np.uint32, 4),
               "E": (4, np.uint16, 1), "F": (5, np.float32, 2), "G": (6, np.uint32, 2), "target": (7, np.float32, 4),
-              "neighbor": (8, np.uint8, 2),
+              "neighbor": (8, np.uint8, 2), "map_ctn": (18, np.uint16, 1), "map_ntc": (19, np.uint16, 1),
               "ctn_A": (10, np.uint16, 4), "ctn_B": (11, np.uint32, 4), "ctn_C": (12, np.uint32, 4), "ctn_D": (13, np.uint16, 1),
               "ntc_A": (14, np.uint16, 4), "ntc_B": (15, np.uint32, 4), "ntc_C": (16, np.uint32, 4), "ntc_D": (17, np.uint16, 1)}
 

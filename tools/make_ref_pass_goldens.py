@@ -44,8 +44,13 @@ def make_ref(zref, sc, integ, prm, force_bvh):
 
 
 def main():
-    gb_out = {}
+    # optional arguments: case-name prefixes to (re)generate; the other cases' files and G-buffer entries are kept
+    only = sys.argv[1:]
+    gb_path = os.path.join(ROOT, "tests", "golden", "ref_pass_gbuffer.npz")
+    gb_out = dict(np.load(gb_path)) if only and os.path.exists(gb_path) else {}
     for case in RC.CASES:
+        if only and not any(case.startswith(o) for o in only):
+            continue
         sc, force_bvh, integ, prm = RC.scene_and_params(case)
         o = zro.OracleScene(sc, force_bvh=force_bvh, cb=RC.first_cb(case))
         k1 = zref.RefGBuffer(sc, force_bvh)
@@ -67,7 +72,7 @@ def main():
             res["plane_" + nm] = ref.plane(nm)
         np.savez_compressed(os.path.join(ROOT, "tests", "golden", f"ref_pass_{case}.npz"), **res)
         print(case, {k: float(np.asarray(v, np.float64).mean()) for k, v in res.items() if k.startswith("final")})
-    np.savez_compressed(os.path.join(ROOT, "tests", "golden", "ref_pass_gbuffer.npz"), **gb_out)
+    np.savez_compressed(gb_path, **gb_out)
 
 
 if __name__ == "__main__":

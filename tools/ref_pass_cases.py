@@ -53,6 +53,9 @@ CASES = {
     "rpt_materials_rr": ("materials_lights", "rpt", 3, dict(bounces=(6, 8)), False),
     "rpt_presampled": ("materials_lights", "rpt", 3, dict(presample=(32, 128)), False),
     "rpt_sun_sky": ("cornell", "rpt", 3, {}, False),
+    # CB_IND_FLAGS::SORT_TEMPORAL / SORT_SPATIAL off: Reconnect_StC's waves are the 8 x 8 screen blocks (every other ReSTIR PT case runs the
+    # reference's default, sorted)
+    "rpt_unsorted": ("materials_lights", "rpt", 3, dict(flags_off=(1 << 6) | (1 << 7)), False),
     "gi_cornell_moving": ("cornell_emissive", "gi", 4, {}, True),
     "gi_materials_rr": ("materials_lights", "gi", 3, dict(bounces=(6, 8)), False),
     "gi_presampled": ("materials_lights", "gi", 3, dict(presample=(32, 128)), False),
@@ -76,7 +79,7 @@ CASES = {
     "sdi_moving_instance": ("cornell", "sdi", 5, {}, False),
 }
 ANIMATED = {"rpt_moving_instance", "di_moving_instance", "sdi_moving_instance"}
-RPT_PLANES = ("A", "B", "C", "D", "E", "F", "G", "neighbor")
+RPT_PLANES = ("A", "B", "C", "D", "E", "F", "G", "neighbor", "map_ctn", "map_ntc")      # + the K12 thread maps of the last frame
 PLANES = {"rpt": RPT_PLANES, "gi": ("A", "B", "C"), "di": ("A", "B"), "sdi": ("A", "B", "C"), "pt": ()}
 
 

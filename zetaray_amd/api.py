@@ -37,7 +37,7 @@ RPT_OUTPUTS_EXTRA = {"taa": (41, np.uint16, 4), "sky_lut": (40, np.uint32, 1), "
                      "sdi_target": (27, np.float32, 4)}
 RPT_OUTPUTS = {"A": (1, np.uint32, 1), "B": (2, np.float32, 2), "C": (3, np.uint32, 4), "D": (4, np.uint32, 4),
                "E": (5, np.uint16, 1), "F": (6, np.float32, 2), "G": (7, np.uint32, 2), "target": (8, np.float32, 4),
-               "neighbor": (9, np.uint8, 2),
+               "neighbor": (9, np.uint8, 2), "map_ctn": (18, np.uint16, 1), "map_ntc": (19, np.uint16, 1),
                "ctn_A": (10, np.uint16, 4), "ctn_B": (11, np.uint32, 4), "ctn_C": (12, np.uint32, 4), "ctn_D": (13, np.uint16, 1),
                "gi_A": (30, np.float32, 4), "gi_B": (31, np.uint16, 4), "gi_C": (32, np.float32, 4),
                "di_A": (20, np.uint32, 4), "di_B": (21, np.float32, 2), "di_target": (22, np.float32, 4),

@@ -648,6 +648,7 @@ struct zr_pass
         rpt::RBuf View() const { rpt::RBuf v; v.A = A.p; v.B = B.p; v.C = C.p; v.D = D.p; return v; }
     } rb[2];
     DevBuf<F4> rptTarget; DevBuf<uint8_t> rptNeighbor; DevBuf<uint16_t> rptSampleSet;
+    DevBuf<uint16_t> rptMap[2];      // K12 thread maps: [0] CtN, [1] NtC
     DevBuf<uint32_t> rptLists, rptListCounts;      // 4 replay work lists (pixel ids) + their device-side counts
     // DI_EMISSIVE: two reservoir sets (A RGBA32_UINT, B RG32F), target, sample set
     DevBuf<U4> diA[2]; DevBuf<float> diB[2]; DevBuf<F4> diTarget; DevBuf<uint16_t> diSampleSet;
@@ -1371,6 +1372,7 @@ static int AllocPass(zr_pass* p)
             if ((r = p->rptTarget.Alloc(cap))) return r;
             if ((r = p->rptNeighbor.Alloc(2 * cap))) return r;
             HIP_TRY(hipMemset(p->rptTarget.p, 0, cap * 16)); HIP_TRY(hipMemset(p->rptNeighbor.p, 0, cap * 2));
+            for (auto& m : p->rptMap) { if ((r = m.Alloc(cap))) return r; HIP_TRY(hipMemset(m.p, 0, cap * 2)); }
             if ((r = p->rptSampleSet.Upload(kRptSampleSet, 1024))) return r;
             if ((r = p->rptLists.Alloc(4 * cap))) return r;
             if ((r = p->rptListCounts.Alloc(4))) return r;
@@ -1679,6 +1681,7 @@ static int RenderReSTIR_PT(zr_pass* p, hipStream_t s, const zr_frame_constants* 
     if (int orc = ResolveOwnedRect(p, gb, cb, &F.ox0, &F.oy0, &F.ow, &F.oh)) return orc;
     F.rbCtN = p->rb[0].View(); F.rbNtC = p->rb[1].View(); F.tex.target = p->rptTarget.p; F.tex.neighbor = p->rptNeighbor.p;
     F.finalRGBA = p->finalRGBA.p; F.sampleSet = p->rptSampleSet.p;
+    F.mapCtN = p->rptMap[0].p; F.mapNtC = p->rptMap[1].p;
     RptParams& prm = F.prm;
     const zr_params& ip = p->params;
     const bool havePrevGBuffer = gb->numRendered >= 2;
@@ -1690,6 +1693,11 @@ static int RenderReSTIR_PT(zr_pass* p, hipStream_t s, const zr_frame_constants* 
     prm.M_max_temporal = ip.m_max_temporal & 0xf; prm.M_max_spatial = ip.m_max_spatial & 0xf; prm.alpha_min = ip.alpha_min;
     prm.emissive = cb->num_emissive_triangles ? 1u : 0u;
     prm.textured = sc->view.tex.count ? 1u : 0u;
+    prm.sortTemporal = (ip.flags & ZR_IND_SORT_TEMPORAL) ? 1u : 0u; prm.sortSpatial = (ip.flags & ZR_IND_SORT_SPATIAL) ? 1u : 0u;
+    // the CtN map (current reservoirs bucketed by k) schedules the fused CtT + TtC kernel: 0.540 -> 0.495 ms Cornell, 3.27 -> 3.16 ms atrium at
+    // 1080p; the NtC map does not pay (0.546 / 3.34).  ZR_TEMPORAL_MAP = 0 / 1 / 2 overrides (scripts/gpu_sortmap.sh)
+    static const uint32_t temporalMapEnv = [] { const char* e = getenv("ZR_TEMPORAL_MAP"); return e ? (uint32_t)atoi(e) : 1u; }();
+    prm.temporalMap = prm.sortTemporal ? temporalMapEnv : 0u;
     if (stages & ZR_STAGE_TEMPORAL)
     {
         p->doTemporal = (ip.flags & ZR_IND_TEMPORAL_RESAMPLE) && p->temporalValid && havePrevGBuffer;
@@ -1701,13 +1709,15 @@ static int RenderReSTIR_PT(zr_pass* p, hipStream_t s, const zr_frame_constants* 
     F.cur = p->res[p->currIdx].View(); F.prev = p->res[1 - p->currIdx].View();
     const uint32_t tilesX = (F.ow + 15) / 16, tilesY = (F.oh + 15) / 16;
     const dim3 grid(tilesX * tilesY), block(kBlock);
+    const uint32_t sortTilesX = (F.ow + 31) / 32;
+    const dim3 gridSort(sortTilesX * ((F.oh + 31) / 32));
     // work lists for the replay passes: [0] CtT, [1] TtC, [2] CtS, [3] StC (plane-local pixel ids, device-side counts)
     uint32_t* listCnt = p->rptListCounts.p;
     const size_t cap = (size_t)p->w * p->h;
     uint32_t* lists[4] = {p->rptLists.p, p->rptLists.p + cap, p->rptLists.p + 2 * cap, p->rptLists.p + 3 * cap};
     const dim3 gridList((uint32_t)std::min<size_t>((cap + kBlock - 1) / kBlock, 1024));
     unsigned long long* ctr = p->counters.p;
-#define RPT_TIMED(name, launch) do { TimerBegin(p, s, name); launch; TimerEnd(p, s); } while (0)
+#define RPT_TIMED(name, ...) do { TimerBegin(p, s, name); __VA_ARGS__; TimerEnd(p, s); } while (0)
     // the NEE_EMISSIVE permutation of a kernel (the reference compiles separate shaders, IndirectLighting.h:251-300)
     const bool emissiveVariant = prm.emissive != 0;
     // (ZR_LARGE_SCENE_NODES: test hook, lets the parity tests run the large-scene kernel build on their small scenes)
@@ -1731,6 +1741,10 @@ static int RenderReSTIR_PT(zr_pass* p, hipStream_t s, const zr_frame_constants* 
         TimerEnd(p, s);
         if (prm.doTemporal)
         {
+            // K12 Sort_TtC / Sort_CtT (IndirectLighting.cpp:383-441: dispatched whether or not SORT_TEMPORAL is set).  The temporal reconnect
+            // passes have no wave operations, so these two maps cannot change a result; they are outputs (ZR_OUT_RPT_THREAD_MAP_*)
+            RPT_TIMED("rpt_sort_temporal", hipLaunchKernelGGL(k_rpt_sort<rpt::RPT_SORT_TTC>, gridSort, dim3(256), 0, s, F, *cb, sortTilesX, F.ox0 / 32u, F.oy0 / 32u, F.mapNtC);
+                hipLaunchKernelGGL(k_rpt_sort<rpt::RPT_SORT_CTT>, gridSort, dim3(256), 0, s, F, *cb, sortTilesX, F.ox0 / 32u, F.oy0 / 32u, F.mapCtN));
             RPT_TIMED("rpt_classify_temporal", hipLaunchKernelGGL(k_rpt_light<0>, grid, block, 0, s, F, *cb, tilesX, lists[0], lists[1], listCnt + 0));
             RPT_TIMED("rpt_replay_ctt", RPT_LAUNCH_PE(k_rpt_replay, RPT_REPLAY_CTT, gridList, block, 0, s, F, *cb, lists[0], listCnt + 0, ctr + 2 * 2));
             RPT_TIMED("rpt_replay_ttc", RPT_LAUNCH_PE(k_rpt_replay, RPT_REPLAY_TTC, gridList, block, 0, s, F, *cb, lists[1], listCnt + 1, ctr + 2 * 3));
@@ -1740,6 +1754,13 @@ static int RenderReSTIR_PT(zr_pass* p, hipStream_t s, const zr_frame_constants* 
     if ((stages & ZR_STAGE_SPATIAL) && prm.doSpatial)
     {
         RPT_TIMED("rpt_spatial_search", hipLaunchKernelGGL(k_rpt_light<1>, grid, block, 0, s, F, *cb, tilesX, lists[2], lists[3], listCnt + 2));
+        // K12 Sort_CtS / Sort_StC (IndirectLighting.cpp:690-742): the NtC map decides which pixels share a wave in Reconnect_StC, i.e. the
+        // population of its boiling-suppression averages
+        if (prm.sortSpatial)
+        {
+            RPT_TIMED("rpt_sort_spatial", hipLaunchKernelGGL(k_rpt_sort<rpt::RPT_SORT_CTS>, gridSort, dim3(256), 0, s, F, *cb, sortTilesX, F.ox0 / 32u, F.oy0 / 32u, F.mapCtN);
+                hipLaunchKernelGGL(k_rpt_sort<rpt::RPT_SORT_STC>, gridSort, dim3(256), 0, s, F, *cb, sortTilesX, F.ox0 / 32u, F.oy0 / 32u, F.mapNtC));
+        }
         RPT_TIMED("rpt_replay_cts", RPT_LAUNCH_PE(k_rpt_replay, RPT_REPLAY_CTS, gridList, block, 0, s, F, *cb, lists[2], listCnt + 2, ctr + 2 * 5));
         RPT_TIMED("rpt_replay_stc", RPT_LAUNCH_PE(k_rpt_replay, RPT_REPLAY_STC, gridList, block, 0, s, F, *cb, lists[3], listCnt + 3, ctr + 2 * 6));
         RPT_TIMED("rpt_reconnect_spatial", RPT_LAUNCH_E(k_rpt_stc, grid, block, 0, s, F, *cb, tilesX, ctr + 2 * 7));
@@ -2178,6 +2199,8 @@ int zr_pass_get_output(const zr_pass* p, int which, void** dev, uint32_t* w, uin
         default: *dev = B.D.p; bytes = 2; break;
         }
     }
+    else if ((which == ZR_OUT_RPT_THREAD_MAP_CTN || which == ZR_OUT_RPT_THREAD_MAP_NTC) && p->integrator == ZR_INTEGRATOR_RESTIR_PT)
+    { *dev = p->rptMap[which - ZR_OUT_RPT_THREAD_MAP_CTN].p; bytes = 2; }
     else if (which >= ZR_OUT_RPT_RESERVOIR_A && which <= ZR_OUT_RPT_NEIGHBOR && p->integrator == ZR_INTEGRATOR_RESTIR_PT)
     {
         const zr_pass::ResStorage& R = p->res[1 - p->currIdx];      // the set the next frame reads as "previous"

@@ -213,12 +213,72 @@ __global__ void __launch_bounds__(kBlock) k_rpt_replay(rpt::RptFrame F, zr_frame
     if (n) FlushRayCounters(counters, cnt);
 }
 
+// K12 (ReSTIR_PT_Sort.hlsl:99-368): one 256-thread block per 32 x 32 pixel tile, thread = 2 x 2 quad, wave w = threads 64 w .. 64 w + 63 of the
+// group (SV_GroupIndex order).  Buckets by reconnection depth; inside a bucket: wave, then lane, then quad slot.  The shader takes the wave
+// order from the arrival of an LDS InterlockedAdd (unspecified); the ABI fixes it to the wave index, which is what a prefix over per-wave
+// counts gives without atomics.  tile0 / tilesX: the 32 x 32 tiles of the owned rect, in render-target tile coordinates.
+template<int VARIANT>
+__global__ void __launch_bounds__(256) k_rpt_sort(rpt::RptFrame F, zr_frame_constants g, uint32_t tilesX, uint32_t tile0x, uint32_t tile0y, uint16_t* map)
+{
+    const uint32_t W = g.render_width, H = g.render_height, dimX = (W + 31u) / 32u, dimY = (H + 31u) / 32u;
+    const uint32_t gx = tile0x + blockIdx.x % tilesX, gy = tile0y + blockIdx.x / tilesX;
+    const uint32_t gidx = threadIdx.x, wave = gidx >> 6, lane = gidx & 63u;
+    const bool againstEdge = gx == dimX - 1u || gy == dimY - 1u, lastGroup = gx == dimX - 1u && gy == dimY - 1u;
+    uint32_t cls[4], res[4], px[4], py[4], gtx[4], gty[4];
+    for (int i = 0; i < 4; i++)
+    {
+        gtx[i] = (gidx & 15u) * 2u + (uint32_t)(i & 1); gty[i] = (gidx >> 4) * 2u + (uint32_t)(i >> 1);
+        px[i] = gx * 32u + gtx[i]; py[i] = gy * 32u + gty[i];
+        cls[i] = rpt::SortClassify(F, g, VARIANT, px[i], py[i], againstEdge, res[i]);
+    }
+    // per bucket: this wave's count and this lane's exclusive prefix (WaveActiveSum / WavePrefixSum of dot(1, flags))
+    __shared__ uint32_t sCnt[4][5];
+    const uint64_t lt = (1ull << lane) - 1ull;
+    uint32_t lanePrefix[5];
+    for (uint32_t c = 0; c < 5u; c++)
+    {
+        uint32_t n = 0, pre = 0;
+        for (int i = 0; i < 4; i++) { const uint64_t m = __ballot(cls[i] == c); n += (uint32_t)__popcll(m); pre += (uint32_t)__popcll(m & lt); }
+        lanePrefix[c] = pre;
+        if (lane == 0) sCnt[wave][c] = n;
+    }
+    __syncthreads();
+    uint32_t base[5], run = 0;
+    for (uint32_t c = 0; c < 5u; c++)
+    {
+        uint32_t before = 0, total = 0;
+        for (uint32_t w = 0; w < 4u; w++) { const uint32_t n = sCnt[w][c]; total += n; if (w < wave) before += n; }
+        base[c] = run + before; run += total;
+    }
+    const bool spatialResample = F.prm.doSpatial != 0;
+    for (int i = 0; i < 4; i++)
+    {
+        uint32_t mgx = gtx[i], mgy = gty[i];
+        if (!lastGroup)      // (the very last group maps one to one)
+        {
+            uint32_t in2x2 = 0;
+            for (int j = 0; j < i; j++) in2x2 += cls[j] == cls[i] ? 1u : 0u;
+            uint32_t b = base[4], lp = lanePrefix[4];      // (selects, not indexed register arrays)
+            for (uint32_t c = 0; c < 4u; c++) if (cls[i] == c) { b = base[c]; lp = lanePrefix[c]; }
+            const uint32_t idx = b + lp + in2x2;
+            mgx = idx & 31u; mgy = idx >> 5;
+        }
+        if (gx == dimX - 1u && gy != dimY - 1u) { const uint32_t t = mgx; mgx = mgy; mgy = t; }      // transposed at the right image boundary
+        const uint32_t mx = gx * 32u + mgx, my = gy * 32u + mgy;
+        if (mx < W && my < H && rpt::InPlanes(F.gb, (int)mx, (int)my))
+            map[rpt::Pix(F.gb, mx, my)] = rpt::EncodeSorted(px[i], py[i], mx, my, rpt::SortErrorBits(VARIANT, res[i], spatialResample));
+    }
+}
+
 // K14: CtT + TtC fused per pixel (zr_rpt.h ReconnectTemporalPixel)
 template<bool EMISSIVE, bool TEX>
 __global__ void __launch_bounds__(kBlock) ZR_WAVES_TEMPORAL k_rpt_temporal(rpt::RptFrame F, zr_frame_constants g, uint32_t tilesX, unsigned long long* counters)
 {
     F.prm.emissive = EMISSIVE ? 1u : 0u; F.prm.textured = TEX ? 1u : 0u;
     uint32_t x, y; PixelOfThread(tilesX, F.ox0, F.oy0, &x, &y);
+    // SORT_TEMPORAL: threads take their pixel from a K12 map, which puts reservoirs of equal reconnection depth into the same wave.  Scheduling
+    // only (no wave operation in CtT / TtC); the error bit is ignored because the fused kernel runs both shifts of a pixel
+    if (F.prm.temporalMap && F.Owns(x, y)) { const uint16_t e = (F.prm.temporalMap == 1u ? F.mapCtN : F.mapNtC)[rpt::Pix(F.gb, x, y)]; rpt::DecodeSorted(e & 0x7fffu, x, y); }
     ZR_TRAV_STACK(stack);
     ZR_PROF_KERNEL(F.sc, 2);
     uint32_t cnt[2] = {0u, 0u};
@@ -239,6 +299,9 @@ __global__ void __launch_bounds__(kBlock) ZR_WAVES_STC k_rpt_stc(rpt::RptFrame F
 {
     F.prm.emissive = EMISSIVE ? 1u : 0u; F.prm.textured = TEX ? 1u : 0u;
     uint32_t x, y; PixelOfThread(tilesX, F.ox0, F.oy0, &x, &y);
+    // SORT_SPATIAL (ReSTIR_PT_Reconnect_StC.hlsl:133-140): the thread at (x, y) shifts the pixel the NtC map assigns to its position, so the
+    // four wave sums below run over the 64 pixels K12 put together (error bit: nothing to do -- the lane stays in the wave, contributing 0)
+    if (F.prm.sortSpatial && F.Owns(x, y) && !rpt::DecodeSorted(F.mapNtC[rpt::Pix(F.gb, x, y)], x, y)) x = 0xffffffffu;
     ZR_TRAV_STACK(stack);
     uint32_t cnt[2] = {0u, 0u};
     ZR_PROF_KERNEL(F.sc, 3);

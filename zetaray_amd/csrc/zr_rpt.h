@@ -878,6 +878,8 @@ struct RptParams
     uint32_t doTemporal, doSpatial, writeReservoirs;
     uint32_t emissive;      // NEE_EMISSIVE: the scene has emissive triangles (else sun + sky)
     uint32_t textured;      // the scene has a texture heap: carry ray differentials, sample base-colour / metallic-roughness maps
+    uint32_t sortTemporal, sortSpatial;      // CB_IND_FLAGS::SORT_TEMPORAL / SORT_SPATIAL: K12 thread maps are built and consumed
+    uint32_t temporalMap;                    // which map schedules the fused CtT + TtC kernel: 0 none, 1 CtN, 2 NtC
 };
 
 // main() prologue + RIS_InitialCandidates up to the first FindClosest (ReSTIR_PT_PathTrace.hlsl:360-530, 194-236)
@@ -1422,6 +1424,7 @@ struct RptFrame
     SceneView sc; GBuf gb, gbPrev; ResPlanes cur, prev;    // cur = this frame's reservoirs, prev = the other set
     SceneView scPrev;                                      // the scene as it was last frame (== sc while nothing moves)
     RBuf rbCtN, rbNtC; RptTex tex; float* finalRGBA; const uint16_t* sampleSet; RptParams prm;
+    uint16_t* mapCtN; uint16_t* mapNtC;                    // K12 thread maps (R16_UINT, plane layout)
     // pixels this device is responsible for (global coordinates); the planes also hold an apron of neighbouring tiles'
     // pixels: G-buffer rendered locally, reservoirs received through the halo exchange
     uint32_t ox0, oy0, ow, oh;
@@ -1794,6 +1797,78 @@ ZR_HD void ReconnectCtSPixel(const RptFrame& F, const zr_frame_constants& g, uin
 }
 
 // K16 Reconnect_StC (ReSTIR_PT_Reconnect_StC.hlsl:112-352), cut at its four WaveActiveSum points.
+// ---- K12 thread maps (ReSTIR_PT_Sort.hlsl; Util.hlsli:20-42 EncodeSorted / DecodeSorted): the entry at a thread's position holds the offset of
+// the pixel that thread shifts (6 + 6 bits biased by 31, inside the 32 x 32 tile) and an error bit (nothing to do for this thread)
+enum { RPT_SORT_CTT = 0, RPT_SORT_TTC = 1, RPT_SORT_CTS = 2, RPT_SORT_STC = 3 };
+static constexpr uint32_t kSeInvalidPixel = 1, kSeNotFound = 2, kSeEmpty = 4;      // RPT_Util::SHIFT_ERROR, Shift.hlsli:8-14
+ZR_HD uint16_t EncodeSorted(uint32_t x, uint32_t y, uint32_t mx, uint32_t my, uint32_t error)
+{ return (uint16_t)(((uint32_t)((int)x - (int)mx + 31)) | (((uint32_t)((int)y - (int)my + 31)) << 7) | ((error ? 1u : 0u) << 15)); }
+// false: the map says this thread has no pixel
+ZR_HD bool DecodeSorted(uint16_t e, uint32_t& x, uint32_t& y)
+{
+    if (e & 0x8000u) return false;
+    x = (uint32_t)((int)x + (int)(e & 0x3fu) - 31); y = (uint32_t)((int)y + (int)((e >> 7) & 0x3fu) - 31);
+    return true;
+}
+// One pixel of the sort: FindNeighbor + the reservoir metadata the variant buckets by (ReSTIR_PT_Sort.hlsl:23-64, 139-226).
+// Returns the bucket (0..3 = k == 2, 3, 4, >= 5 / edge case; 4 = skip) and the SHIFT_ERROR bits in `result`.
+ZR_HD uint32_t SortClassify(const RptFrame& F, const zr_frame_constants& g, int variant, uint32_t x, uint32_t y, bool againstEdge, uint32_t& result)
+{
+    const uint32_t W = g.render_width, H = g.render_height;
+    uint32_t err = 0; int nx = 0, ny = 0;
+    if (x >= W || y >= H || !InPlanes(F.gb, (int)x, (int)y)) err = kSeInvalidPixel;
+    else
+    {
+        const size_t px = Pix(F.gb, x, y);
+        const GFlags flags = DecodeFlags(F.gb.mr[px]);
+        if (flags.invalid || flags.emissive) err = kSeInvalidPixel;
+        else if (variant == RPT_SORT_TTC)
+        {
+            const V2 motionVec = DecodeMotion(F.gb.motion[px]);
+            const float rw = (float)W, rh = (float)H;
+            const float pu = ((float)x + 0.5f) / rw - motionVec.x, pv = ((float)y + 0.5f) / rh - motionVec.y;
+            nx = (int)(pu * rw); ny = (int)(pv * rh);
+            if (pu < 0.0f || pv < 0.0f || pu > 1.0f || pv > 1.0f) err = kSeNotFound;
+        }
+        else if (variant == RPT_SORT_STC)
+        {
+            const uint32_t ox = F.tex.neighbor[2 * px], oy = F.tex.neighbor[2 * px + 1];
+            if (ox == 255u) err = kSeNotFound;
+            nx = (int)ox - kNeighborOffset + (int)x; ny = (int)oy - kNeighborOffset + (int)y;
+        }
+    }
+    bool skip = err != 0;
+    result = err;
+    uint32_t k = Reconnection::EMPTY;
+    if (err == 0)
+    {
+        const bool fromNeighbor = variant == RPT_SORT_TTC || variant == RPT_SORT_STC;
+        const int rx = fromNeighbor ? nx : (int)x, ry = fromNeighbor ? ny : (int)y;
+        // a load outside the render target returns 0 (k field 0 = reconnection at k = 2); outside this device's planes (a temporal
+        // neighbour beyond the apron of a screen tile) the same -- the temporal maps only schedule, they cannot change results
+        uint32_t a = 0;
+        if (rx >= 0 && ry >= 0 && rx < (int)W && ry < (int)H && InPlanes(F.gb, rx, ry))
+            a = (variant == RPT_SORT_TTC ? F.prev.A : F.cur.A)[Pix(F.gb, (uint32_t)rx, (uint32_t)ry)];
+        const uint32_t kk = a & 0xfu;
+        k = kk == Reconnection::EMPTY ? kk : kk + 2u;
+    }
+    if (k == Reconnection::EMPTY) { result |= kSeEmpty; skip = true; }
+    // valid threads of groups at the right / bottom image boundary must not end up outside the screen (ReSTIR_PT_Sort.hlsl:203-219):
+    // they join the k >= 5 bucket (their k is EMPTY = 15 here) with the error cleared
+    if (skip && againstEdge && x < W && y < H) { result = 0; skip = false; }
+    if (skip) return 4u;
+    if (k == 2u) return 0u;
+    if (k == 3u) return 1u;
+    if (k == 4u) return 2u;
+    return 3u;      // k >= 5 or the edge case
+}
+ZR_HD uint32_t SortErrorBits(int variant, uint32_t result, bool spatialResample)
+{
+    if (variant == RPT_SORT_TTC) return result & (spatialResample ? (kSeInvalidPixel | kSeNotFound) : kSeInvalidPixel);
+    if (variant == RPT_SORT_STC) return result & kSeInvalidPixel;
+    return result & (kSeInvalidPixel | kSeEmpty);
+}
+
 struct StcLane
 {
     // (kept small across the heavy calls: the pixel's surface is rebuilt inside phase 2 and r_curr is loaded after the CtS shift, so
