@@ -160,7 +160,7 @@ def test_tile_split_on_gpu(api, cornell_emissive, oracle_emissive):
     assert np.array_equal(img.view(np.uint32), want.view(np.uint32))
 
 
-RPT_PLANES = ("A", "B", "C", "D", "E", "F", "G", "neighbor")
+RPT_PLANES = ("A", "B", "C", "D", "E", "F", "G", "neighbor", "map_ctn", "map_ntc")      # reservoirs, K15 neighbour, K12 thread maps
 
 
 def _rpt_compare(api, scene, oscene, w, h, prm, frames, cam=None, reset_at=None):
@@ -193,6 +193,37 @@ def test_restir_pt_bit_exact(api, cornell_emissive, oracle_emissive, w, h):
     radiance and the persistent reservoir planes bit-exact vs the oracle."""
     got = _rpt_compare(api, cornell_emissive, oracle_emissive, w, h, wire.default_params(), 4, reset_at=4)
     assert got[..., :3].max() > 0
+
+
+def test_restir_pt_thread_sort_on_partial_tiles(api, cornell_emissive, oracle_emissive):
+    """K12 at 150 x 90 (partial 32 x 32 tiles on the right and bottom boundaries: the transposed right-boundary groups, the one-to-one last
+    group, in-image pixels of boundary groups in the k >= 5 bucket) with a camera that starts moving at frame 3: both thread maps, the
+    sorted Reconnect_StC waves (boiling suppression over the pixels K12 put together) and everything downstream equal the oracle's, which
+    equals the reference's own Sort + reconnect shaders (tests/test_ref_passes.py live pin); then the same with the sort flags off."""
+    from oracle import zro
+    w, h = 150, 90
+    for flags_off in (0, wire.IND_SORT_TEMPORAL | wire.IND_SORT_SPATIAL):
+        prm = wire.default_params()
+        prm.flags &= ~flags_off
+        r = api.Renderer(cornell_emissive, w, h, params=prm, integrator=api.INTEGRATOR_RESTIR_PT)
+        o = zro.OracleRPT(oracle_emissive, w, h)
+        prev = None
+        for f in range(1, 5):
+            cb = _frame(cornell_emissive, w, h, f, cam_pos=(0.07 * max(0, f - 2), 1.2, -4.043))
+            if prev is not None:
+                cb["prev_view"], cb["prev_view_inv"], cb["prev_camera_jitter"] = prev["curr_view"], prev["curr_view_inv"], prev["curr_camera_jitter"]
+            prev = cb.copy()
+            r.render_frame(cb)
+            want = o.render(cb, prm)
+            assert np.array_equal(r.final().view(np.uint32), want.view(np.uint32)), f"frame {f} (flags_off {flags_off})"
+            for nm in RPT_PLANES:
+                a, b = r.p_indirect.download_plane(nm), o.plane(nm)
+                if nm == "A":
+                    a, b = a & 0xffffff, b & 0xffffff
+                assert np.array_equal(a.view(np.uint8), b.view(np.uint8)), f"frame {f}: plane {nm} (flags_off {flags_off})"
+        m = r.p_indirect.download_plane("map_ntc").reshape(h, w)
+        if not flags_off:
+            assert int(((m & 0x7fff) != (31 | (31 << 7))).sum()) > 1000      # the spatial sort really permuted pixels
 
 
 def test_restir_pt_materials_and_rr_on_gpu(api):

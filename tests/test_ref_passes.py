@@ -100,12 +100,13 @@ def test_live_reference_passes_match_stored_outputs(case):
 
 
 def test_live_reference_restir_pt_larger_frame():
-    """live only: 160 x 96, 5 frames, camera that starts moving at frame 3, reference shaders vs oracle incl. every reservoir plane"""
+    """live only: 150 x 90 (partial 32 x 32 sort tiles on both boundaries), 5 frames, camera that starts moving at frame 3, reference shaders
+    (incl. the four ReSTIR_PT_Sort dispatches and the map-driven reconnect passes) vs oracle incl. every reservoir plane and both thread maps"""
     zref = _zref()
     from oracle import zro
     from zetaray_amd import scene_io
     sc = scene_io.load_npz(os.path.join(ROOT, "tests", "golden", "cornell_emissive.npz"))
-    w, h = 160, 96
+    w, h = 150, 90
     o = zro.OracleScene(sc)
     k1, ref, orpt = zref.RefGBuffer(sc), zref.RefRestirPT(sc, w, h), zro.OracleRPT(o, w, h)
     ref.set_alias_table(o.alias)
