@@ -443,11 +443,11 @@ __global__ void __launch_bounds__(kBlock) ZR_WAVES_RDI_S k_rdi_spatial(rdi::DiFr
 // K10: one 8x8 pixel group per wave, bounce loop in lockstep around the Russian-roulette wave max, then temporal resampling
 // and the boiling-suppression wave sum (zr_rgi.h)
 template<bool TEX>
-__global__ void __launch_bounds__(kBlock) ZR_WAVES_RGI k_rgi(rgi::GiFrame F, zr_frame_constants g, uint32_t tilesX, unsigned long long* counters)
+__global__ void __launch_bounds__(kRgiBlock) ZR_WAVES_RGI k_rgi(rgi::GiFrame F, zr_frame_constants g, uint32_t tilesX, unsigned long long* counters)
 {
     F.prm.textured = TEX;
-    uint32_t x, y; PixelOfThread(tilesX, F.ox0, F.oy0, &x, &y);
-    ZR_TRAV_STACK(stack);
+    uint32_t x, y; PixelOfThreadB<kRgiBlock>(tilesX, F.ox0, F.oy0, &x, &y);
+    ZR_TRAV_STACK_B(stack, kRgiBlock);
     uint32_t cnt[2] = {0u, 0u};
     rgi::Lane P;
     rgi::InitLane(F, g, x, y, stack, cnt, P);
@@ -1660,7 +1660,7 @@ static int RenderReSTIR_GI(zr_pass* p, hipStream_t s, const zr_frame_constants* 
     if (prm.useLVG && !sc->view.lvg) return Fail(ZR_ERR_NOT_INITIALIZED, "light voxel grid missing: render the PRELIGHTING pass with use_lvg first");
     const uint32_t tilesX = (F.ow + 15) / 16, tilesY = (F.oh + 15) / 16;
     TimerBegin(p, s, "rgi");
-    hipLaunchKernelGGL(sc->view.tex.count ? k_rgi<true> : k_rgi<false>, dim3(tilesX * tilesY), dim3(kBlock), 0, s, F, *cb, tilesX, p->counters.p + 2 * 10);
+    hipLaunchKernelGGL(sc->view.tex.count ? k_rgi<true> : k_rgi<false>, dim3(tilesX * tilesY * (256 / kRgiBlock)), dim3(kRgiBlock), 0, s, F, *cb, tilesX, p->counters.p + 2 * 10);
     TimerEnd(p, s);
     HIP_TRY(hipGetLastError());
     p->temporalValid = true;
@@ -1709,6 +1709,7 @@ static int RenderReSTIR_PT(zr_pass* p, hipStream_t s, const zr_frame_constants* 
     F.cur = p->res[p->currIdx].View(); F.prev = p->res[1 - p->currIdx].View();
     const uint32_t tilesX = (F.ow + 15) / 16, tilesY = (F.oh + 15) / 16;
     const dim3 grid(tilesX * tilesY), block(kBlock);
+    const dim3 gridRpt(tilesX * tilesY * (256 / kRptBlock)), blockRpt(kRptBlock);      // K11 (zr_kernels.h kRptBlock)
     const uint32_t sortTilesX = (F.ow + 31) / 32;
     const dim3 gridSort(sortTilesX * ((F.oh + 31) / 32));
     // work lists for the replay passes: [0] CtT, [1] TtC, [2] CtS, [3] StC (plane-local pixel ids, device-side counts)
@@ -1734,10 +1735,10 @@ static int RenderReSTIR_PT(zr_pass* p, hipStream_t s, const zr_frame_constants* 
     {
         HIP_TRY(hipMemsetAsync(listCnt, 0, 4 * sizeof(uint32_t), s));
         TimerBegin(p, s, "rpt_pathtrace");
-        if (texVariant) { if (emissiveVariant) hipLaunchKernelGGL(k_rpt_pathtrace_tex<true>, grid, block, 0, s, F, *cb, tilesX, ctr + 2 * 1); else hipLaunchKernelGGL(k_rpt_pathtrace_tex<false>, grid, block, 0, s, F, *cb, tilesX, ctr + 2 * 1); }
+        if (texVariant) { if (emissiveVariant) hipLaunchKernelGGL(k_rpt_pathtrace_tex<true>, gridRpt, blockRpt, 0, s, F, *cb, tilesX, ctr + 2 * 1); else hipLaunchKernelGGL(k_rpt_pathtrace_tex<false>, gridRpt, blockRpt, 0, s, F, *cb, tilesX, ctr + 2 * 1); }
         else if (sc->view.numNodes >= largeSceneNodes)     // BVH beyond the caches: the 4-wave build of K11 (zr_kernels.h)
-        { if (emissiveVariant) hipLaunchKernelGGL(k_rpt_pathtrace_w4<true>, grid, block, 0, s, F, *cb, tilesX, ctr + 2 * 1); else hipLaunchKernelGGL(k_rpt_pathtrace_w4<false>, grid, block, 0, s, F, *cb, tilesX, ctr + 2 * 1); }
-        else { if (emissiveVariant) hipLaunchKernelGGL(k_rpt_pathtrace<true>, grid, block, 0, s, F, *cb, tilesX, ctr + 2 * 1); else hipLaunchKernelGGL(k_rpt_pathtrace<false>, grid, block, 0, s, F, *cb, tilesX, ctr + 2 * 1); }
+        { if (emissiveVariant) hipLaunchKernelGGL(k_rpt_pathtrace_w4<true>, gridRpt, blockRpt, 0, s, F, *cb, tilesX, ctr + 2 * 1); else hipLaunchKernelGGL(k_rpt_pathtrace_w4<false>, gridRpt, blockRpt, 0, s, F, *cb, tilesX, ctr + 2 * 1); }
+        else { if (emissiveVariant) hipLaunchKernelGGL(k_rpt_pathtrace<true>, gridRpt, blockRpt, 0, s, F, *cb, tilesX, ctr + 2 * 1); else hipLaunchKernelGGL(k_rpt_pathtrace<false>, gridRpt, blockRpt, 0, s, F, *cb, tilesX, ctr + 2 * 1); }
         TimerEnd(p, s);
         if (prm.doTemporal)
         {

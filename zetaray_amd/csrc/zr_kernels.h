@@ -15,6 +15,14 @@ using namespace zr;
 
 // ------------------------------------------------------------------------------------------------ device helpers
 static constexpr int kBlock = 256;
+// threads per block of K11 (k_rpt_pathtrace*): 64 = one block per wave of the 16 x 16 tile.  A block's registers and LDS are released when its
+// slowest wave ends, and the waves of K11 run for very different times (path lengths): one-wave blocks measured 1.006 -> 0.947 ms (Cornell) and
+// 8.34 -> 8.01 ms (atrium) at 1080p.  K14 / K16 do the same work in every wave and are 2 - 5 % slower that way (0.492 -> 0.518 ms), so they keep
+// 256 (scripts/gpu_block.sh; -DZR_RPT_BLOCK=256 restores one block per tile).
+#ifndef ZR_RPT_BLOCK
+#define ZR_RPT_BLOCK 64
+#endif
+static constexpr int kRptBlock = ZR_RPT_BLOCK;
 // Occupancy targets of the register-heavy shading kernels, waves per SIMD (the compiler spills a little to reach them).
 // Measured on MI355X, Cornell 1080p / 380k-triangle atrium: k_rpt_pathtrace 2 -> 3 waves: 1.45 -> 1.21 ms /
 // 14.9 -> 11.8 ms (4 waves: 1.19 / 10.7 ms, but its ~300 B/lane of spills stream 3.4 GB through L2 per launch, PMC); k_rgi 2 -> 4: 2.19 -> 1.68 ms; k_rdi_* 2 -> 3: 0.72 -> 0.67, 0.39 -> 0.33 ms; k_sdi_spatial -> 4: 0.58 ->
@@ -42,11 +50,12 @@ static constexpr int kBlock = 256;
 #endif
 static constexpr uint32_t kCounterStride = 64;     // queue counters live 256 B apart: their atomics spread over L2 channels
 // this lane's traversal stack: kTravLdsEntries entries in LDS (16 KB per 256-lane block at 8 entries; + 6 KB for the work-stealing slots, zr_dev_scene.h), the rest in scratch
-#define ZR_TRAV_STACK(name) \
-    __shared__ StackEntry name##Lds[kTravLdsEntries * kBlock]; StackEntry name##Mem[kTravStack - kTravLdsEntries]; \
-    __shared__ __attribute__((aligned(8))) uint32_t name##Aux[ZR_STEAL ? kStealAuxWords * (kBlock / 64) : 2]; \
-    TravStack name; name.lds = (ZR_LDS_AS StackEntry*)name##Lds + threadIdx.x; name.stride = kBlock; name.mem = (ZR_PRIVATE_AS StackEntry*)name##Mem; \
+#define ZR_TRAV_STACK_B(name, B) \
+    __shared__ StackEntry name##Lds[kTravLdsEntries * (B)]; StackEntry name##Mem[kTravStack - kTravLdsEntries]; \
+    __shared__ __attribute__((aligned(8))) uint32_t name##Aux[ZR_STEAL ? kStealAuxWords * ((B) / 64) : 2]; \
+    TravStack name; name.lds = (ZR_LDS_AS StackEntry*)name##Lds + threadIdx.x; name.stride = (B); name.mem = (ZR_PRIVATE_AS StackEntry*)name##Mem; \
     name.aux = name##Aux + (ZR_STEAL ? kStealAuxWords * (threadIdx.x / 64) : 0)
+#define ZR_TRAV_STACK(name) ZR_TRAV_STACK_B(name, kBlock)
 
 // one atomic per wave: lanes that `want` a slot get consecutive indices
 __device__ __forceinline__ uint32_t AllocSlotWave(uint32_t* counter, bool want)
@@ -94,6 +103,28 @@ __device__ __forceinline__ void PixelOfThread(uint32_t tilesX, uint32_t x0, uint
     *y = y0 + ty * 16u + (wave >> 1) * 8u + (lane >> 3);
 }
 
+// K11 / K10: (tile, wave of the tile, lane) of this thread for either block size (256: block = tile, 64: block = one wave of the tile)
+template<int B>
+__device__ __forceinline__ void TileWaveLaneB(uint32_t* tile, uint32_t* wave, uint32_t* lane)
+{
+    if (B == 256) { *tile = blockIdx.x; *wave = threadIdx.x >> 6; *lane = threadIdx.x & 63u; }
+    else { *tile = blockIdx.x >> 2; *wave = blockIdx.x & 3u; *lane = threadIdx.x; }
+}
+__device__ __forceinline__ void RptTileWaveLane(uint32_t* tile, uint32_t* wave, uint32_t* lane) { TileWaveLaneB<kRptBlock>(tile, wave, lane); }
+// PixelOfThread for either block size
+template<int B>
+__device__ __forceinline__ void PixelOfThreadB(uint32_t tilesX, uint32_t x0, uint32_t y0, uint32_t* x, uint32_t* y)
+{
+    uint32_t tile, wave, lane; TileWaveLaneB<B>(&tile, &wave, &lane);
+    const uint32_t tx = tile % tilesX, ty = tile / tilesX;
+    *x = x0 + tx * 16u + (wave & 1u) * 8u + (lane & 7u);
+    *y = y0 + ty * 16u + (wave >> 1) * 8u + (lane >> 3);
+}
+#ifndef ZR_RGI_BLOCK
+#define ZR_RGI_BLOCK 64
+#endif
+static constexpr int kRgiBlock = ZR_RGI_BLOCK;      // K10 (k_rgi), same trade as kRptBlock: 1.298 -> 1.262 ms Cornell, 10.01 -> 9.57 ms atrium
+
 // ------------------------------------------------------------------------------------------------ ReSTIR PT kernels
 // per-lane ray counters -> one atomic pair per wave (all 64 lanes must call this)
 __device__ __forceinline__ void FlushRayCounters(unsigned long long* counters, const uint32_t* cnt)
@@ -114,10 +145,10 @@ template<bool EMISSIVE, bool TEX>
 __device__ __forceinline__ void RptPathtraceBody(rpt::RptFrame& F, const zr_frame_constants& g, uint32_t tilesX, unsigned long long* counters)
 {
     F.prm.emissive = EMISSIVE ? 1u : 0u; F.prm.textured = TEX ? 1u : 0u;
-    const uint32_t tile = blockIdx.x, tx = tile % tilesX, ty = tile / tilesX;
-    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    uint32_t tile, wave, lane; RptTileWaveLane(&tile, &wave, &lane);
+    const uint32_t tx = tile % tilesX, ty = tile / tilesX;
     const uint32_t x = F.ox0 + tx * 16u + (lane & 15u), y = F.oy0 + ty * 16u + wave * 4u + (lane >> 4);
-    ZR_TRAV_STACK(stack);
+    ZR_TRAV_STACK_B(stack, kRptBlock);
     ZR_PROF_KERNEL(F.sc, 1);
     uint32_t cnt[2] = {0u, 0u};
     rpt::PTLane P;
@@ -138,20 +169,20 @@ __device__ __forceinline__ void RptPathtraceBody(rpt::RptFrame& F, const zr_fram
     FlushRayCounters(counters, cnt);
 }
 template<bool EMISSIVE>
-__global__ void __launch_bounds__(kBlock) ZR_WAVES_PATHTRACE k_rpt_pathtrace(rpt::RptFrame F, zr_frame_constants g, uint32_t tilesX, unsigned long long* counters)
+__global__ void __launch_bounds__(kRptBlock) ZR_WAVES_PATHTRACE k_rpt_pathtrace(rpt::RptFrame F, zr_frame_constants g, uint32_t tilesX, unsigned long long* counters)
 { RptPathtraceBody<EMISSIVE, false>(F, g, tilesX, counters); }
 // The same kernel at 4 waves per SIMD (128 VGPRs, more spills): used for scenes whose BVH does not fit the caches, where the inline
 // traversal is latency-bound and the extra wave hides more than the spills cost (380 k-triangle atrium: 11.7 -> 10.6 ms; on the
 // 58-triangle Cornell box both take 1.16 ms, and the 3-wave build moves 5x less spill traffic, so small scenes keep it).
 template<bool EMISSIVE>
-__global__ void __launch_bounds__(kBlock) ZR_WAVES(4) k_rpt_pathtrace_w4(rpt::RptFrame F, zr_frame_constants g, uint32_t tilesX, unsigned long long* counters)
+__global__ void __launch_bounds__(kRptBlock) ZR_WAVES(4) k_rpt_pathtrace_w4(rpt::RptFrame F, zr_frame_constants g, uint32_t tilesX, unsigned long long* counters)
 { RptPathtraceBody<EMISSIVE, false>(F, g, tilesX, counters); }
 // The TEXTURED permutation keeps the compiler's default occupancy: forced to 3 waves (amdgpu_waves_per_eu(3, 3): ~150 spilled
 // VGPRs), ROCm 7.2's clang miscompiles the <sun + sky, textured> instance -- the y / z components of the reconnection radiance
 // rc.L of case-1 samples are written as 0 in ~70 % of the pixels (-O2 and -fno-vectorize change nothing, dropping the attribute
 // does; found by tests/test_gpu_parity.py::test_textured_integrators_on_gpu).
 template<bool EMISSIVE>
-__global__ void __launch_bounds__(kBlock) k_rpt_pathtrace_tex(rpt::RptFrame F, zr_frame_constants g, uint32_t tilesX, unsigned long long* counters)
+__global__ void __launch_bounds__(kRptBlock) k_rpt_pathtrace_tex(rpt::RptFrame F, zr_frame_constants g, uint32_t tilesX, unsigned long long* counters)
 { RptPathtraceBody<EMISSIVE, true>(F, g, tilesX, counters); }
 
 enum RptPixelPass { RPT_REPLAY_CTT = 0, RPT_REPLAY_TTC, RPT_RECONNECT_TEMPORAL, RPT_SPATIAL_SEARCH, RPT_REPLAY_CTS, RPT_REPLAY_STC };
