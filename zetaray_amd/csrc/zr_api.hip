@@ -394,19 +394,22 @@ __global__ void __launch_bounds__(kBlock) k_trace_rays_any(SceneView sc, const F
 }
 
 // ------------------------------------------------------------------------------------------------ sun + sky ReSTIR DI kernels
+// threads per block (see kRptBlock in zr_kernels.h; scripts/gpu_block3.sh): one-wave blocks pay for the emissive DI kernels (K5 0.580 -> 0.568 ms
+// Cornell, 5.42 -> 5.12 ms atrium; K6 0.258 -> 0.241 / 2.99 -> 2.61 ms), not for the sun + sky ones (K7 / K8 within +-0.6 %)
+static constexpr int kSdiBlock = 256, kDiBlock = 64;
 // K7: initial candidates (sun, cosine-sky, BSDF-sky) + temporal reuse; K8: pairwise-MIS spatial reuse.  One thread per pixel.
-__global__ void __launch_bounds__(kBlock) ZR_WAVES_SDI_T k_sdi_temporal(sdi::SkyFrame F, zr_frame_constants g, uint32_t tilesX, unsigned long long* counters)
+__global__ void __launch_bounds__(kSdiBlock) ZR_WAVES_SDI_T k_sdi_temporal(sdi::SkyFrame F, zr_frame_constants g, uint32_t tilesX, unsigned long long* counters)
 {
-    uint32_t x, y; PixelOfThread(tilesX, F.ox0, F.oy0, &x, &y);
-    ZR_TRAV_STACK(stack);
+    uint32_t x, y; PixelOfThreadB<kSdiBlock>(tilesX, F.ox0, F.oy0, &x, &y);
+    ZR_TRAV_STACK_B(stack, kSdiBlock);
     uint32_t cnt[2] = {0u, 0u};
     if (F.Owns(x, y)) sdi::TemporalPixel(F, g, x, y, stack, cnt);
     FlushRayCounters(counters, cnt);
 }
-__global__ void __launch_bounds__(kBlock) ZR_WAVES_SDI_S k_sdi_spatial(sdi::SkyFrame F, zr_frame_constants g, uint32_t tilesX, unsigned long long* counters)
+__global__ void __launch_bounds__(kSdiBlock) ZR_WAVES_SDI_S k_sdi_spatial(sdi::SkyFrame F, zr_frame_constants g, uint32_t tilesX, unsigned long long* counters)
 {
-    uint32_t x, y; PixelOfThread(tilesX, F.ox0, F.oy0, &x, &y);
-    ZR_TRAV_STACK(stack);
+    uint32_t x, y; PixelOfThreadB<kSdiBlock>(tilesX, F.ox0, F.oy0, &x, &y);
+    ZR_TRAV_STACK_B(stack, kSdiBlock);
     uint32_t cnt[2] = {0u, 0u};
     if (F.Owns(x, y)) sdi::SpatialPixel(F, g, x, y, stack, cnt);
     FlushRayCounters(counters, cnt);
@@ -418,19 +421,19 @@ static const uint16_t kRdiSampleSet[64] = {
 };
 
 // K5: initial candidates + temporal reuse, one thread per pixel (8x8 quadrant per wave, like the reference's thread group)
-__global__ void __launch_bounds__(kBlock) ZR_WAVES_RDI_T k_rdi_temporal(rdi::DiFrame F, zr_frame_constants g, uint32_t tilesX, unsigned long long* counters)
+__global__ void __launch_bounds__(kDiBlock) ZR_WAVES_RDI_T k_rdi_temporal(rdi::DiFrame F, zr_frame_constants g, uint32_t tilesX, unsigned long long* counters)
 {
-    uint32_t x, y; PixelOfThread(tilesX, F.ox0, F.oy0, &x, &y);
-    ZR_TRAV_STACK(stack);
+    uint32_t x, y; PixelOfThreadB<kDiBlock>(tilesX, F.ox0, F.oy0, &x, &y);
+    ZR_TRAV_STACK_B(stack, kDiBlock);
     uint32_t cnt[2] = {0u, 0u};
     if (F.Owns(x, y)) rdi::TemporalPixel(F, g, x, y, stack, cnt);
     FlushRayCounters(counters, cnt);
 }
 // K6: spatial reuse with pairwise MIS; WaveActiveSum(disoccluded) = popcount of a ballot over the 8x8 group
-__global__ void __launch_bounds__(kBlock) ZR_WAVES_RDI_S k_rdi_spatial(rdi::DiFrame F, zr_frame_constants g, uint32_t tilesX, unsigned long long* counters)
+__global__ void __launch_bounds__(kDiBlock) ZR_WAVES_RDI_S k_rdi_spatial(rdi::DiFrame F, zr_frame_constants g, uint32_t tilesX, unsigned long long* counters)
 {
-    uint32_t x, y; PixelOfThread(tilesX, F.ox0, F.oy0, &x, &y);
-    ZR_TRAV_STACK(stack);
+    uint32_t x, y; PixelOfThreadB<kDiBlock>(tilesX, F.ox0, F.oy0, &x, &y);
+    ZR_TRAV_STACK_B(stack, kDiBlock);
     uint32_t cnt[2] = {0u, 0u};
     rdi::SpatialLane a;
     rdi::SpatialPhase0(F, g, x, y, a);
@@ -1577,14 +1580,14 @@ static int RenderDirectEmissive(zr_pass* p, hipStream_t s, const zr_frame_consta
     if (stages & ZR_STAGE_TEMPORAL)
     {
         TimerBegin(p, s, "rdi_temporal");
-        hipLaunchKernelGGL(k_rdi_temporal, grid, block, 0, s, F, *cb, tilesX, p->counters.p + 2 * 8);
+        hipLaunchKernelGGL(k_rdi_temporal, dim3(grid.x * (256 / kDiBlock)), dim3(kDiBlock), 0, s, F, *cb, tilesX, p->counters.p + 2 * 8);
         TimerEnd(p, s);
     }
     if (!(stages & ZR_STAGE_SPATIAL)) { HIP_TRY(hipGetLastError()); return ZR_OK; }
     if (prm.doSpatial)
     {
         TimerBegin(p, s, "rdi_spatial");
-        hipLaunchKernelGGL(k_rdi_spatial, grid, block, 0, s, F, *cb, tilesX, p->counters.p + 2 * 9);
+        hipLaunchKernelGGL(k_rdi_spatial, dim3(grid.x * (256 / kDiBlock)), dim3(kDiBlock), 0, s, F, *cb, tilesX, p->counters.p + 2 * 9);
         TimerEnd(p, s);
     }
     HIP_TRY(hipGetLastError());
@@ -1620,14 +1623,14 @@ static int RenderDirectSky(zr_pass* p, hipStream_t s, const zr_frame_constants* 
     if (stages & ZR_STAGE_TEMPORAL)
     {
         TimerBegin(p, s, "sdi_temporal");
-        hipLaunchKernelGGL(k_sdi_temporal, grid, block, 0, s, F, *cb, tilesX, p->counters.p + 2 * 11);
+        hipLaunchKernelGGL(k_sdi_temporal, dim3(grid.x * (256 / kSdiBlock)), dim3(kSdiBlock), 0, s, F, *cb, tilesX, p->counters.p + 2 * 11);
         TimerEnd(p, s);
     }
     if (!(stages & ZR_STAGE_SPATIAL)) { HIP_TRY(hipGetLastError()); return ZR_OK; }
     if (prm.doSpatial)
     {
         TimerBegin(p, s, "sdi_spatial");
-        hipLaunchKernelGGL(k_sdi_spatial, grid, block, 0, s, F, *cb, tilesX, p->counters.p + 2 * 12);
+        hipLaunchKernelGGL(k_sdi_spatial, dim3(grid.x * (256 / kSdiBlock)), dim3(kSdiBlock), 0, s, F, *cb, tilesX, p->counters.p + 2 * 12);
         TimerEnd(p, s);
     }
     HIP_TRY(hipGetLastError());
