@@ -177,12 +177,16 @@ __global__ void __launch_bounds__(kRptBlock) ZR_WAVES_PATHTRACE k_rpt_pathtrace(
 template<bool EMISSIVE>
 __global__ void __launch_bounds__(kRptBlock) ZR_WAVES(4) k_rpt_pathtrace_w4(rpt::RptFrame F, zr_frame_constants g, uint32_t tilesX, unsigned long long* counters)
 { RptPathtraceBody<EMISSIVE, false>(F, g, tilesX, counters); }
-// The TEXTURED permutation keeps the compiler's default occupancy: forced to 3 waves (amdgpu_waves_per_eu(3, 3): ~150 spilled
-// VGPRs), ROCm 7.2's clang miscompiles the <sun + sky, textured> instance -- the y / z components of the reconnection radiance
-// rc.L of case-1 samples are written as 0 in ~70 % of the pixels (-O2 and -fno-vectorize change nothing, dropping the attribute
-// does; found by tests/test_gpu_parity.py::test_textured_integrators_on_gpu).
+// The TEXTURED permutation at 4 waves per SIMD as well: 11.99 -> 10.28 ms on the textured atrium (2 waves by default, 255 VGPRs; a minimum of
+// 3 gives 10.74).  Round 1 found that forcing it to exactly 3 waves (amdgpu_waves_per_eu(3, 3): ~150 spilled VGPRs) makes ROCm 7.2's clang
+// miscompile the <sun + sky, textured> instance -- the y / z components of the reconnection radiance rc.L of case-1 samples were written as
+// 0 in ~70 % of the pixels; the (4, 4) build passes the same 15 textured parity tests that caught it
+// (tests/test_gpu_parity.py::test_textured_integrators_on_gpu, the *_textured reference-pass cases; scripts/gpu_tex.sh).
+#ifndef ZR_WAVES_PATHTRACE_TEX
+#define ZR_WAVES_PATHTRACE_TEX ZR_WAVES(4)
+#endif
 template<bool EMISSIVE>
-__global__ void __launch_bounds__(kRptBlock) k_rpt_pathtrace_tex(rpt::RptFrame F, zr_frame_constants g, uint32_t tilesX, unsigned long long* counters)
+__global__ void __launch_bounds__(kRptBlock) ZR_WAVES_PATHTRACE_TEX k_rpt_pathtrace_tex(rpt::RptFrame F, zr_frame_constants g, uint32_t tilesX, unsigned long long* counters)
 { RptPathtraceBody<EMISSIVE, true>(F, g, tilesX, counters); }
 
 enum RptPixelPass { RPT_REPLAY_CTT = 0, RPT_REPLAY_TTC, RPT_RECONNECT_TEMPORAL, RPT_SPATIAL_SEARCH, RPT_REPLAY_CTS, RPT_REPLAY_STC };
