@@ -1685,6 +1685,9 @@ static int RenderReSTIR_PT(zr_pass* p, hipStream_t s, const zr_frame_constants* 
     F.rbCtN = p->rb[0].View(); F.rbNtC = p->rb[1].View(); F.tex.target = p->rptTarget.p; F.tex.neighbor = p->rptNeighbor.p;
     F.finalRGBA = p->finalRGBA.p; F.sampleSet = p->rptSampleSet.p;
     F.mapCtN = p->rptMap[0].p; F.mapNtC = p->rptMap[1].p;
+    // K12 sorts whole 32 x 32 tiles: an owned rect may end inside one only where the render target ends
+    if (((F.ox0 + F.ow) & 31u) && F.ox0 + F.ow != cb->render_width) return Fail(ZR_ERR_INVALID_ARG, "ReSTIR PT: the owned rect must end on a 32-pixel boundary or at the right edge of the render target");
+    if (((F.oy0 + F.oh) & 31u) && F.oy0 + F.oh != cb->render_height) return Fail(ZR_ERR_INVALID_ARG, "ReSTIR PT: the owned rect must end on a 32-pixel boundary or at the bottom edge of the render target");
     RptParams& prm = F.prm;
     const zr_params& ip = p->params;
     const bool havePrevGBuffer = gb->numRendered >= 2;
