@@ -291,3 +291,35 @@ def test_presampled_light_sets(synthetic_small):
     p0 = wire.default_params()
     want0, _ = o.pathtrace(cb, planes, p0)
     assert not np.array_equal(want0, want)
+
+
+def test_thread_sort_maps_are_tile_permutations(oracle_emissive, cornell_emissive):
+    """K12 (ReSTIR_PT_Sort.hlsl) properties that hold for any input: inside the render target every thread-map entry decodes to a pixel of the
+    same 32 x 32 tile, every pixel is assigned to exactly one thread (no pixel lost or processed twice at the partial boundary tiles), pixels
+    flagged invalid carry the error bit, and the oracle and the host-executed HIP stage functions produce the same maps."""
+    from oracle import zro
+    from tests.hostexec import zhx
+    w, h = 150, 90
+    prm = wire.default_params()
+    o = zro.OracleRPT(oracle_emissive, w, h)
+    hx = zhx.HostExecScene(cornell_emissive, alias=oracle_emissive.alias)
+    hr = zhx.HostExecRPT(hx, w, h)
+    prev = None
+    for f in range(1, 4):
+        cb = scene_io.make_frame_constants(w, h, frame_num=f, num_emissives=len(cornell_emissive.emissives), cam_pos=(0.07 * max(0, f - 1), 1.2, -4.043))
+        if prev is not None:
+            cb["prev_view"], cb["prev_view_inv"], cb["prev_camera_jitter"] = prev["curr_view"], prev["curr_view_inv"], prev["curr_camera_jitter"]
+        prev = cb.copy()
+        a = o.render(cb, prm)
+        b = hr.render(cb, prm, gb=hx.gbuffer(cb))
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), f"frame {f}"
+    ys, xs = np.mgrid[0:h, 0:w]
+    for name in ("map_ctn", "map_ntc"):
+        m = o.plane(name).reshape(h, w).astype(np.int64)
+        assert np.array_equal(m, hr.plane(name).reshape(h, w)), name
+        px, py = xs + (m & 0x3f) - 31, ys + ((m >> 7) & 0x3f) - 31
+        assert ((px >= 0) & (px < w) & (py >= 0) & (py < h)).all(), name
+        assert np.array_equal(px // 32, xs // 32) and np.array_equal(py // 32, ys // 32), f"{name}: a pixel left its tile"
+        assert len(np.unique(py * w + px)) == w * h, f"{name}: not a permutation"
+    # the spatial maps of the last frame really sort: a third of the positions at least point elsewhere
+    assert ((o.plane("map_ntc").reshape(h, w) & 0x7fff) != (31 | (31 << 7))).mean() > 0.3
