@@ -1750,11 +1750,9 @@ static int RenderReSTIR_PT(zr_pass* p, hipStream_t s, const zr_frame_constants* 
         {
             // K12 Sort_TtC / Sort_CtT (IndirectLighting.cpp:383-441: dispatched whether or not SORT_TEMPORAL is set).  The temporal reconnect
             // passes have no wave operations, so these two maps cannot change a result; they are outputs (ZR_OUT_RPT_THREAD_MAP_*)
-            RPT_TIMED("rpt_sort_temporal", hipLaunchKernelGGL(k_rpt_sort<rpt::RPT_SORT_TTC>, gridSort, dim3(256), 0, s, F, *cb, sortTilesX, F.ox0 / 32u, F.oy0 / 32u, F.mapNtC);
-                hipLaunchKernelGGL(k_rpt_sort<rpt::RPT_SORT_CTT>, gridSort, dim3(256), 0, s, F, *cb, sortTilesX, F.ox0 / 32u, F.oy0 / 32u, F.mapCtN));
+            RPT_TIMED("rpt_sort_temporal", hipLaunchKernelGGL((k_rpt_sort<rpt::RPT_SORT_TTC, rpt::RPT_SORT_CTT>), dim3(gridSort.x * 2), dim3(256), 0, s, F, *cb, sortTilesX, F.ox0 / 32u, F.oy0 / 32u, F.mapNtC, F.mapCtN));
             RPT_TIMED("rpt_classify_temporal", hipLaunchKernelGGL(k_rpt_light<0>, grid, block, 0, s, F, *cb, tilesX, lists[0], lists[1], listCnt + 0));
-            RPT_TIMED("rpt_replay_ctt", RPT_LAUNCH_PE(k_rpt_replay, RPT_REPLAY_CTT, gridList, block, 0, s, F, *cb, lists[0], listCnt + 0, ctr + 2 * 2));
-            RPT_TIMED("rpt_replay_ttc", RPT_LAUNCH_PE(k_rpt_replay, RPT_REPLAY_TTC, gridList, block, 0, s, F, *cb, lists[1], listCnt + 1, ctr + 2 * 3));
+            RPT_TIMED("rpt_replay_temporal", RPT_LAUNCH_PE(k_rpt_replay, RPT_REPLAY_CTT, dim3(gridList.x * 2), block, 0, s, F, *cb, lists[0], lists[1], listCnt + 0, ctr + 2 * 2));
             RPT_TIMED("rpt_reconnect_temporal", RPT_LAUNCH_E(k_rpt_temporal, grid, block, 0, s, F, *cb, tilesX, ctr + 2 * 4));
         }
     }
@@ -1765,11 +1763,9 @@ static int RenderReSTIR_PT(zr_pass* p, hipStream_t s, const zr_frame_constants* 
         // population of its boiling-suppression averages
         if (prm.sortSpatial)
         {
-            RPT_TIMED("rpt_sort_spatial", hipLaunchKernelGGL(k_rpt_sort<rpt::RPT_SORT_CTS>, gridSort, dim3(256), 0, s, F, *cb, sortTilesX, F.ox0 / 32u, F.oy0 / 32u, F.mapCtN);
-                hipLaunchKernelGGL(k_rpt_sort<rpt::RPT_SORT_STC>, gridSort, dim3(256), 0, s, F, *cb, sortTilesX, F.ox0 / 32u, F.oy0 / 32u, F.mapNtC));
+            RPT_TIMED("rpt_sort_spatial", hipLaunchKernelGGL((k_rpt_sort<rpt::RPT_SORT_CTS, rpt::RPT_SORT_STC>), dim3(gridSort.x * 2), dim3(256), 0, s, F, *cb, sortTilesX, F.ox0 / 32u, F.oy0 / 32u, F.mapCtN, F.mapNtC));
         }
-        RPT_TIMED("rpt_replay_cts", RPT_LAUNCH_PE(k_rpt_replay, RPT_REPLAY_CTS, gridList, block, 0, s, F, *cb, lists[2], listCnt + 2, ctr + 2 * 5));
-        RPT_TIMED("rpt_replay_stc", RPT_LAUNCH_PE(k_rpt_replay, RPT_REPLAY_STC, gridList, block, 0, s, F, *cb, lists[3], listCnt + 3, ctr + 2 * 6));
+        RPT_TIMED("rpt_replay_spatial", RPT_LAUNCH_PE(k_rpt_replay, RPT_REPLAY_CTS, dim3(gridList.x * 2), block, 0, s, F, *cb, lists[2], lists[3], listCnt + 2, ctr + 2 * 5));
         RPT_TIMED("rpt_reconnect_spatial", RPT_LAUNCH_E(k_rpt_stc, grid, block, 0, s, F, *cb, tilesX, ctr + 2 * 7));
     }
 #undef RPT_TIMED

@@ -228,16 +228,15 @@ __global__ void __launch_bounds__(kBlock) k_rpt_light(rpt::RptFrame F, zr_frame_
     if (b) listB[ob + (uint32_t)__popcll(mb & below)] = pid;
 }
 
-// K13 replays over a work list (device-side count, fixed grid, grid-stride): only pixels with k > 2 pay for the heavy kernel
+// K13 replays over work lists (device-side counts, fixed grid, grid-stride): only pixels with k > 2 pay for the heavy kernel.  One launch runs the
+// two replays of a stage (CtT + TtC, CtS + StC: independent -- each writes its own r-buffer): the first half of the grid walks list A with
+// PASS_A, the second half list B with PASS_A + 1, each specialisation compiled for its pass.
 template<int PASS, bool EMISSIVE, bool TEX>
-__global__ void __launch_bounds__(kBlock) k_rpt_replay(rpt::RptFrame F, zr_frame_constants g, const uint32_t* list, const uint32_t* count,
-    unsigned long long* counters)
+__device__ __forceinline__ void RptReplayList(rpt::RptFrame& F, const zr_frame_constants& g, const uint32_t* list, uint32_t n, unsigned long long* counters,
+    uint32_t block, uint32_t numBlocks, const TravStack& stack)
 {
-    F.prm.emissive = EMISSIVE ? 1u : 0u; F.prm.textured = TEX ? 1u : 0u;
-    ZR_TRAV_STACK(stack);
     uint32_t cnt[2] = {0u, 0u};
-    const uint32_t n = *count;
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
+    for (uint32_t i = block * blockDim.x + threadIdx.x; i < n; i += numBlocks * blockDim.x)
     {
         const uint32_t pid = list[i], x = F.gb.x0 + pid % F.gb.w, y = F.gb.y0 + pid / F.gb.w;
         if (PASS == RPT_REPLAY_CTT) rpt::ReplayTemporalPixel(F, g, 0, x, y, stack, cnt);
@@ -247,16 +246,27 @@ __global__ void __launch_bounds__(kBlock) k_rpt_replay(rpt::RptFrame F, zr_frame
     }
     if (n) FlushRayCounters(counters, cnt);
 }
+template<int PASS_A, bool EMISSIVE, bool TEX>
+__global__ void __launch_bounds__(kBlock) k_rpt_replay(rpt::RptFrame F, zr_frame_constants g, const uint32_t* listA, const uint32_t* listB, const uint32_t* counts,
+    unsigned long long* counters)
+{
+    F.prm.emissive = EMISSIVE ? 1u : 0u; F.prm.textured = TEX ? 1u : 0u;
+    ZR_TRAV_STACK(stack);
+    const uint32_t half = gridDim.x / 2u;
+    // (counters: the per-kernel slots of the two passes are neighbours, zr_api.hip kCounterNames)
+    if (blockIdx.x < half) RptReplayList<PASS_A, EMISSIVE, TEX>(F, g, listA, counts[0], counters, blockIdx.x, half, stack);
+    else RptReplayList<PASS_A + 1, EMISSIVE, TEX>(F, g, listB, counts[1], counters + 2, blockIdx.x - half, half, stack);
+}
 
 // K12 (ReSTIR_PT_Sort.hlsl:99-368): one 256-thread block per 32 x 32 pixel tile, thread = 2 x 2 quad, wave w = threads 64 w .. 64 w + 63 of the
 // group (SV_GroupIndex order).  Buckets by reconnection depth; inside a bucket: wave, then lane, then quad slot.  The shader takes the wave
 // order from the arrival of an LDS InterlockedAdd (unspecified); the ABI fixes it to the wave index, which is what a prefix over per-wave
 // counts gives without atomics.  tile0 / tilesX: the 32 x 32 tiles of the owned rect, in render-target tile coordinates.
 template<int VARIANT>
-__global__ void __launch_bounds__(256) k_rpt_sort(rpt::RptFrame F, zr_frame_constants g, uint32_t tilesX, uint32_t tile0x, uint32_t tile0y, uint16_t* map)
+__device__ __forceinline__ void RptSortTile(const rpt::RptFrame& F, const zr_frame_constants& g, uint32_t tile, uint32_t tilesX, uint32_t tile0x, uint32_t tile0y, uint16_t* map)
 {
     const uint32_t W = g.render_width, H = g.render_height, dimX = (W + 31u) / 32u, dimY = (H + 31u) / 32u;
-    const uint32_t gx = tile0x + blockIdx.x % tilesX, gy = tile0y + blockIdx.x / tilesX;
+    const uint32_t gx = tile0x + tile % tilesX, gy = tile0y + tile / tilesX;
     const uint32_t gidx = threadIdx.x, wave = gidx >> 6, lane = gidx & 63u;
     const bool againstEdge = gx == dimX - 1u || gy == dimY - 1u, lastGroup = gx == dimX - 1u && gy == dimY - 1u;
     uint32_t cls[4], res[4], px[4], py[4], gtx[4], gty[4];
@@ -303,6 +313,15 @@ __global__ void __launch_bounds__(256) k_rpt_sort(rpt::RptFrame F, zr_frame_cons
         if (mx < W && my < H && rpt::InPlanes(F.gb, (int)mx, (int)my))
             map[rpt::Pix(F.gb, mx, my)] = rpt::EncodeSorted(px[i], py[i], mx, my, rpt::SortErrorBits(VARIANT, res[i], spatialResample));
     }
+}
+
+// one launch sorts a stage's two maps (Sort_TtC + Sort_CtT, Sort_CtS + Sort_StC): first half of the grid = variant VA into mapA, second half = VB into mapB
+template<int VA, int VB>
+__global__ void __launch_bounds__(256) k_rpt_sort(rpt::RptFrame F, zr_frame_constants g, uint32_t tilesX, uint32_t tile0x, uint32_t tile0y, uint16_t* mapA, uint16_t* mapB)
+{
+    const uint32_t half = gridDim.x / 2u;
+    if (blockIdx.x < half) RptSortTile<VA>(F, g, blockIdx.x, tilesX, tile0x, tile0y, mapA);
+    else RptSortTile<VB>(F, g, blockIdx.x - half, tilesX, tile0x, tile0y, mapB);
 }
 
 // K14: CtT + TtC fused per pixel (zr_rpt.h ReconnectTemporalPixel)
@@ -359,7 +378,7 @@ __global__ void __launch_bounds__(kBlock) ZR_WAVES_STC k_rpt_stc(rpt::RptFrame F
 // ------------------------------------------------------------------------------------------------ translation-unit split
 // ZR_RPT_GROUP_A / _B(X): X = `template` in the TU that owns the group, `extern template` everywhere else
 #define ZR_RPT_ARGS_TILE (rpt::RptFrame, zr_frame_constants, uint32_t, unsigned long long*)
-#define ZR_RPT_ARGS_LIST (rpt::RptFrame, zr_frame_constants, const uint32_t*, const uint32_t*, unsigned long long*)
+#define ZR_RPT_ARGS_LIST (rpt::RptFrame, zr_frame_constants, const uint32_t*, const uint32_t*, const uint32_t*, unsigned long long*)
 #define ZR_RPT_GROUP_A(X) \
     X __global__ void k_rpt_pathtrace<true> ZR_RPT_ARGS_TILE; X __global__ void k_rpt_pathtrace<false> ZR_RPT_ARGS_TILE; \
     X __global__ void k_rpt_pathtrace_w4<true> ZR_RPT_ARGS_TILE; X __global__ void k_rpt_pathtrace_w4<false> ZR_RPT_ARGS_TILE; \
@@ -370,6 +389,6 @@ __global__ void __launch_bounds__(kBlock) ZR_WAVES_STC k_rpt_stc(rpt::RptFrame F
     X __global__ void k_rpt_replay<PASS, true, true> ZR_RPT_ARGS_LIST; X __global__ void k_rpt_replay<PASS, true, false> ZR_RPT_ARGS_LIST; \
     X __global__ void k_rpt_replay<PASS, false, true> ZR_RPT_ARGS_LIST; X __global__ void k_rpt_replay<PASS, false, false> ZR_RPT_ARGS_LIST;
 #define ZR_RPT_GROUP_B(X) \
-    ZR_RPT_REPLAY4(X, RPT_REPLAY_CTT) ZR_RPT_REPLAY4(X, RPT_REPLAY_TTC) ZR_RPT_REPLAY4(X, RPT_REPLAY_CTS) ZR_RPT_REPLAY4(X, RPT_REPLAY_STC) \
+    ZR_RPT_REPLAY4(X, RPT_REPLAY_CTT) ZR_RPT_REPLAY4(X, RPT_REPLAY_CTS) \
     X __global__ void k_rpt_stc<true, true> ZR_RPT_ARGS_TILE; X __global__ void k_rpt_stc<true, false> ZR_RPT_ARGS_TILE; \
     X __global__ void k_rpt_stc<false, true> ZR_RPT_ARGS_TILE; X __global__ void k_rpt_stc<false, false> ZR_RPT_ARGS_TILE;
