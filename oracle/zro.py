@@ -11,7 +11,11 @@ _LIB = None
 
 
 def build():
-    subprocess.check_call(["make", "-s", "-C", _HERE, "libzro.so"])
+    # (one process at a time: pytest-xdist workers would otherwise relink the library while another worker loads it)
+    import fcntl
+    with open(os.path.join(_HERE, ".build.lock"), "w") as lk:
+        fcntl.flock(lk, fcntl.LOCK_EX)
+        subprocess.check_call(["make", "-s", "-C", _HERE, "libzro.so"])
 
 
 def lib():

@@ -12,8 +12,12 @@ _LIB = None
 def lib():
     global _LIB
     if _LIB is None:
-        subprocess.check_call(["make", "-s", "-C", _HERE, "libzhx.so"])
-        L = C.CDLL(os.path.join(_HERE, "libzhx.so"))
+        # (one process at a time: pytest-xdist workers would otherwise relink the library while another worker loads it)
+        import fcntl
+        with open(os.path.join(_HERE, ".build.lock"), "w") as lk:
+            fcntl.flock(lk, fcntl.LOCK_EX)
+            subprocess.check_call(["make", "-s", "-C", _HERE, "libzhx.so"])
+            L = C.CDLL(os.path.join(_HERE, "libzhx.so"))
         L.zhx_scene_create.restype = C.c_void_p
         L.zhx_scene_create.argtypes = [C.c_void_p]
         L.zhx_scene_destroy.argtypes = [C.c_void_p]
