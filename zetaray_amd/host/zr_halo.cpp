@@ -31,7 +31,9 @@ struct Rccl
     bool Load(std::string& err)
     {
         if (so) return true;
-        for (const char* name : {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"}) { so = dlopen(name, RTLD_NOW | RTLD_GLOBAL); if (so) break; }
+        // the instance the process already uses (torch.distributed's) first: two RCCL copies in one process would each run their own bootstrap
+        for (const char* name : {"librccl.so.1", "librccl.so"}) { so = dlopen(name, RTLD_NOW | RTLD_NOLOAD); if (so) break; }
+        if (!so) for (const char* name : {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"}) { so = dlopen(name, RTLD_NOW | RTLD_GLOBAL); if (so) break; }
         if (!so) { err = std::string("cannot load librccl.so: ") + dlerror(); return false; }
 #define ZR_SYM(field, sym) field = (decltype(field))dlsym(so, sym); if (!field) { err = std::string("librccl.so lacks ") + sym; return false; }
         ZR_SYM(GetUniqueId, "ncclGetUniqueId") ZR_SYM(CommInitRank, "ncclCommInitRank") ZR_SYM(CommDestroy, "ncclCommDestroy")
