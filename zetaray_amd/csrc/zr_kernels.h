@@ -197,7 +197,7 @@ __global__ void __launch_bounds__(kBlock) k_rpt_light(rpt::RptFrame F, zr_frame_
 {
     uint32_t x, y; PixelOfThread(tilesX, F.ox0, F.oy0, &x, &y);
     const bool in = F.Owns(x, y);
-    bool a = false, b = false;
+    uint32_t a = 0, b = 0;      // replay class of this pixel for list A / B (0 = not on the list; zr_rpt.h ReplayClass)
     if (PASS == 0)          // temporal work lists: pixels whose current / temporal reservoir needs a replay (k > 2)
     {
         if (in) { a = rpt::NeedsReplayCtT(F, x, y); b = rpt::NeedsReplayTtC(F, g, x, y); }
@@ -208,24 +208,35 @@ __global__ void __launch_bounds__(kBlock) k_rpt_light(rpt::RptFrame F, zr_frame_
     }
     const uint32_t pid = in ? (uint32_t)rpt::Pix(F.gb, x, y) : 0u;
     // one atomic per block and list: with every wave appending (large scenes: most pixels carry k > 2 reservoirs) 65 k returning
-    // atomics on two neighbouring counters serialised in L2 and this trivial kernel took 0.54 ms (profiles/r02a_pmc_sq_rpt_atrium1080p.csv)
-    __shared__ uint32_t sCnt[2][kBlock / 64], sBase[2];
+    // atomics on two neighbouring counters serialised in L2 and this trivial kernel took 0.54 ms (profiles/r02a_pmc_sq_rpt_atrium1080p.csv).
+    // Inside the block's chunk of a list the entries are ordered by replay class (k = 3, 4, >= 5 -- K12's buckets), so that the 64 lanes of a
+    // replay wave mostly walk paths of the same length; which thread replays which pixel has no effect on the result.
+    __shared__ uint32_t sCnt[2][3][kBlock / 64], sBase[2];
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
-    const uint64_t ma = __ballot(a), mb = __ballot(b);
-    if (lane == 0) { sCnt[0][wave] = (uint32_t)__popcll(ma); sCnt[1][wave] = (uint32_t)__popcll(mb); }
+    uint64_t ma[3], mb[3];
+    for (uint32_t c = 0; c < 3u; c++)
+    {
+        ma[c] = __ballot(a == c + 1u); mb[c] = __ballot(b == c + 1u);
+        if (lane == 0) { sCnt[0][c][wave] = (uint32_t)__popcll(ma[c]); sCnt[1][c][wave] = (uint32_t)__popcll(mb[c]); }
+    }
     __syncthreads();
     if (threadIdx.x < 2)
     {
         uint32_t total = 0;
-        for (int w = 0; w < kBlock / 64; w++) total += sCnt[threadIdx.x][w];
+        for (int c = 0; c < 3; c++) for (int w = 0; w < kBlock / 64; w++) total += sCnt[threadIdx.x][c][w];
         sBase[threadIdx.x] = total ? atomicAdd(counts + threadIdx.x, total) : 0u;
     }
     __syncthreads();
-    uint32_t oa = sBase[0], ob = sBase[1];
-    for (uint32_t w = 0; w < wave; w++) { oa += sCnt[0][w]; ob += sCnt[1][w]; }
     const uint64_t below = (1ull << lane) - 1ull;
-    if (a) listA[oa + (uint32_t)__popcll(ma & below)] = pid;
-    if (b) listB[ob + (uint32_t)__popcll(mb & below)] = pid;
+    uint32_t oa = sBase[0], ob = sBase[1];
+    for (uint32_t c = 0; c < 3u; c++)
+    {
+        uint32_t ta = 0, tb = 0, wa = 0, wb = 0;      // bucket totals of the block, and of the waves before this one
+        for (uint32_t w = 0; w < (uint32_t)(kBlock / 64); w++) { const uint32_t na = sCnt[0][c][w], nb = sCnt[1][c][w]; ta += na; tb += nb; if (w < wave) { wa += na; wb += nb; } }
+        if (a == c + 1u) listA[oa + wa + (uint32_t)__popcll(ma[c] & below)] = pid;
+        if (b == c + 1u) listB[ob + wb + (uint32_t)__popcll(mb[c] & below)] = pid;
+        oa += ta; ob += tb;
+    }
 }
 
 // K13 replays over work lists (device-side counts, fixed grid, grid-stride): only pixels with k > 2 pay for the heavy kernel.  One launch runs the

@@ -1611,16 +1611,18 @@ ZR_HD void ReconnectTemporalPixel(const RptFrame& F, const zr_frame_constants& g
     if (!doSpatial) WriteOutputColor(g, F.finalRGBA, px, r_curr.target * r_curr.W);
 }
 
-// cheap predicates for the replay work lists (supersets of the pixels the replay passes act on; the passes re-check)
-ZR_HD bool NeedsReplayCtT(const RptFrame& F, uint32_t x, uint32_t y)
+// cheap predicates for the replay work lists (supersets of the pixels the replay passes act on; the passes re-check).  They return the replay
+// class of the reservoir's stored k - 2: 0 = no replay (empty or k = 2), 1 / 2 / 3 = k == 3 / k == 4 / k >= 5 -- the buckets of K12, by which
+// k_rpt_light orders the entries of a block so that the lanes of a replay wave walk paths of equal length
+ZR_HD uint32_t ReplayClass(uint32_t a) { const uint32_t k = a & 0xfu; return (k == Reconnection::EMPTY || k == 0u) ? 0u : (k < 3u ? k : 3u); }
+ZR_HD uint32_t NeedsReplayCtT(const RptFrame& F, uint32_t x, uint32_t y)
 {
     const size_t px = Pix(F.gb, x, y);
     GFlags flags = DecodeFlags(F.gb.mr[px]);
-    if (flags.invalid || flags.emissive) return false;
-    const uint32_t k = F.cur.A[px] & 0xf;
-    return k != Reconnection::EMPTY && k > 0;           // stored k - 2 > 0
+    if (flags.invalid || flags.emissive) return 0u;
+    return ReplayClass(F.cur.A[px]);
 }
-ZR_HD bool NeedsReplayTtC(const RptFrame& F, const zr_frame_constants& g, uint32_t x, uint32_t y)
+ZR_HD uint32_t NeedsReplayTtC(const RptFrame& F, const zr_frame_constants& g, uint32_t x, uint32_t y)
 {
     const size_t px = Pix(F.gb, x, y);
     GFlags flags = DecodeFlags(F.gb.mr[px]);
@@ -1631,8 +1633,7 @@ ZR_HD bool NeedsReplayTtC(const RptFrame& F, const zr_frame_constants& g, uint32
     if (prevUV.x < 0 || prevUV.y < 0 || prevUV.x > 1 || prevUV.y > 1) return false;
     const int ppx = (int)(prevUV.x * renderDim.x), ppy = (int)(prevUV.y * renderDim.y);
     if (ppx >= (int)g.render_width || ppy >= (int)g.render_height || !InPlanes(F.gb, ppx, ppy)) return false;
-    const uint32_t k = F.prev.A[Pix(F.gb, (uint32_t)ppx, (uint32_t)ppy)] & 0xf;
-    return k != Reconnection::EMPTY && k > 0;
+    return ReplayClass(F.prev.A[Pix(F.gb, (uint32_t)ppx, (uint32_t)ppy)]);
 }
 
 // Math::WorldPosFromScreenSpace, Math.hlsli:205-216
@@ -1743,24 +1744,22 @@ ZR_HD_FLAT void ReplaySpatialPixel(const RptFrame& F, const zr_frame_constants& 
     }
 }
 
-ZR_HD bool NeedsReplayCtS(const RptFrame& F, uint32_t x, uint32_t y)
+ZR_HD uint32_t NeedsReplayCtS(const RptFrame& F, uint32_t x, uint32_t y)
 {
     const size_t px = Pix(F.gb, x, y);
     GFlags flags = DecodeFlags(F.gb.mr[px]);
     if (flags.invalid || flags.emissive) return false;
     if (F.tex.neighbor[2 * px] == 255) return false;
-    const uint32_t k = F.cur.A[px] & 0xf;
-    return k != Reconnection::EMPTY && k > 0;
+    return ReplayClass(F.cur.A[px]);
 }
-ZR_HD bool NeedsReplayStC(const RptFrame& F, uint32_t x, uint32_t y)
+ZR_HD uint32_t NeedsReplayStC(const RptFrame& F, uint32_t x, uint32_t y)
 {
     const size_t px = Pix(F.gb, x, y);
     GFlags flags = DecodeFlags(F.gb.mr[px]);
     if (flags.invalid || flags.emissive) return false;
     int sx, sy;
     if (!NeighborOf(F, x, y, sx, sy)) return false;
-    const uint32_t k = F.cur.A[Pix(F.gb, (uint32_t)sx, (uint32_t)sy)] & 0xf;
-    return k != Reconnection::EMPTY && k > 0;
+    return ReplayClass(F.cur.A[Pix(F.gb, (uint32_t)sx, (uint32_t)sy)]);
 }
 
 // K16 Reconnect_CtS (ReSTIR_PT_Reconnect_CtS.hlsl:149-230).  Like CtT/TtC it only touches this pixel's entries (reads the
