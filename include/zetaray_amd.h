@@ -245,6 +245,13 @@ int zr_scene_destroy(zr_scene* scene);
  * "previous" ones that the CtT replay / reconnect passes of ReSTIR PT and the temporal shifts of the DI passes trace against.
  * Host call between frames (waits for the device); n must equal the scene's instance count. */
 int zr_scene_update_instances(zr_scene* scene, const zr_mesh_instance* instances, const float* instance_to_world, uint32_t n);
+/* Emissive triangles of instances that moved (SceneCore::UpdateEmissivePositions, SceneCore.cpp:913-955, then EmissiveBuffer::UpdateTriPositions'
+ * upload of [minIdx, maxIdx)): replaces `count` records of the scene's emissive buffer from index `first`.  The caller re-derives them like the
+ * reference's CPU side does -- decode the object-space record, transform, re-encode (zrh_emissive_to_world, zetaray_amd/host/zr_scene_io.h).
+ * Like the reference, moving a light does not re-estimate powers or rebuild the alias table (that happens when emissive MATERIALS change,
+ * PreLighting.cpp:266); presampled sets and the light voxel grid pick the new positions up on the next PRELIGHTING render.
+ * Host call between frames (waits for the device). */
+int zr_scene_update_emissives(zr_scene* scene, const zr_emissive_triangle* triangles, uint32_t first, uint32_t count);
 /* EmissiveTriangleAliasTable::Render (PreLighting.cpp:512-585): upload a host-built table ... */
 int zr_scene_set_alias_table(zr_scene* scene, const zr_alias_entry* entries, uint32_t n);
 /* ... or build it from per-triangle power exactly like PreLighting.cpp:27-158 (host side, bit-exact) */

@@ -81,6 +81,21 @@ void zref_emissive_triangle(const float* v0, const float* v1, const float* v2, c
     static_assert(sizeof(e) == 48, "EmissiveTriangle size");
     memcpy(out48, &e, 48);
 }
+// SceneCore::UpdateEmissivePositions / the first-frame emissive transform (SceneCore.cpp:196-236, 913-955): LoadVertices (decode the 16-bit
+// octahedral edges and half lengths) -> mul(toWorld, v) -> StoreVertices (re-encode).  M4x3: row-vector matrix as above.
+void zref_emissive_to_world(const void* in48, const float* M4x3, void* out48)
+{
+    using namespace ZetaRay; using namespace ZetaRay::Math;
+    RT::EmissiveTriangle e; memcpy(&e, in48, 48);
+    float4x3 M;
+    for (int i = 0; i < 4; i++) M.m[i] = float3(M4x3[3 * i], M4x3[3 * i + 1], M4x3[3 * i + 2]);
+    const v_float4x4 vW = load4x3(M);
+    __m128 v0, v1, v2;
+    e.LoadVertices(v0, v1, v2);
+    v0 = mul(vW, v0); v1 = mul(vW, v1); v2 = mul(vW, v2);
+    e.StoreVertices(v0, v1, v2);
+    memcpy(out48, &e, 48);
+}
 }
 
 // ---- layout pins: offsetof / sizeof of the C++ side of the reference's shared C++/HLSL headers, compiled in place ----

@@ -124,6 +124,12 @@ class OracleScene:
         lib().zro_scene_update_instances.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32]
         assert lib().zro_scene_update_instances(self.h, i.ctypes.data, x.ctypes.data, len(i)) == 0
 
+    def update_emissives(self, triangles, first=0):
+        """zr_scene_update_emissives on the oracle"""
+        t = np.ascontiguousarray(triangles)
+        lib().zro_scene_update_emissives.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32]
+        assert lib().zro_scene_update_emissives(self.h, t.ctypes.data, first, len(t)) == 0
+
     def latch_heap_offsets(self, cb):
         cbb = np.ascontiguousarray(cb)
         lib().zro_scene_latch_heap_offsets(self.h, cbb.ctypes.data)

@@ -919,6 +919,14 @@ int zro_scene_update_instances(zro_scene* h, const zr_mesh_instance* instances, 
     h->s.prev = h->prevHolder.get();
     return 0;
 }
+// zr_scene_update_emissives: there is one emissive buffer (the reference's too) -- the previous-frame scene view sees the new records as well
+int zro_scene_update_emissives(zro_scene* h, const zr_emissive_triangle* tris, uint32_t first, uint32_t count)
+{
+    if ((size_t)first + count > h->s.emissives.size()) return -1;
+    std::copy(tris, tris + count, h->s.emissives.begin() + first);
+    if (h->prevHolder) std::copy(tris, tris + count, h->prevHolder->emissives.begin() + first);
+    return 0;
+}
 int zro_scene_num_tris(const zro_scene* h) { return (int)h->s.tris.size(); }
 
 int zro_kahan_sum(const float* data, uint64_t n, uint32_t align_phase, float* out)

@@ -116,6 +116,36 @@ def test_emissive_triangle_packing_matches_reference_code():
         assert p.tobytes() == a.tobytes(), it
 
 
+@pytest.mark.skipif(not os.path.exists(ZREF), reason="needs oracle/_ref/libzref.so (built from /root/reference)")
+def test_emissive_world_transform_matches_reference_code():
+    """zrh_emissive_to_world (decode the 16-bit octahedral edges + half lengths, transform, re-encode: what SceneCore does to every emissive
+    triangle of a transformed instance on the first frame and to moving ones every frame) against the reference's own
+    EmissiveTriangle::LoadVertices -> mul(toWorld, v) -> StoreVertices, 8000 random triangles x random rotations / scales / translations."""
+    R, L = C.CDLL(ZREF), sio()
+    for f in (R.zref_emissive_to_world, L.zrh_emissive_to_world):
+        f.argtypes = [C.c_void_p] * 3
+    L.zrh_pack_emissive_triangle.argtypes = [C.c_void_p] * 4 + [C.c_uint32, C.c_uint32, C.c_uint16, C.c_uint32, C.c_int, C.c_void_p]
+    rng = np.random.default_rng(21)
+    for it in range(8000):
+        v = (rng.normal(size=(3, 3)) * rng.choice([0.01, 0.3, 2.0, 30.0])).astype(np.float32)
+        if it % 7 == 0:
+            v[1] = v[0] + np.float32([rng.normal(), 0, 0])
+        v0, v1, v2 = (np.ascontiguousarray(x) for x in v)
+        uv = rng.random(6).astype(np.float32)
+        e = np.zeros(1, wire.EMISSIVE_TRI)
+        L.zrh_pack_emissive_triangle(v0.ctypes.data, v1.ctypes.data, v2.ctypes.data, uv.ctypes.data, 0x804020, 0xffff, 0x4000, it, 1, e.ctypes.data)
+        q, _ = np.linalg.qr(rng.normal(size=(3, 3)))
+        M = np.zeros((3, 4), np.float32)
+        M[:, :3] = (q @ np.diag(rng.uniform(0.1, 3, 3))).astype(np.float32) if it % 11 else np.diag(rng.uniform(0.1, 3, 3)).astype(np.float32)
+        M[:, 3] = (rng.normal(size=3) * 5).astype(np.float32)
+        M4x3 = np.ascontiguousarray(np.vstack([M[:, :3].T, M[:, 3][None, :]]).astype(np.float32))      # the reference's row-vector layout
+        a, b = np.zeros(1, wire.EMISSIVE_TRI), np.zeros(1, wire.EMISSIVE_TRI)
+        L.zrh_emissive_to_world(e.ctypes.data, M.ctypes.data, a.ctypes.data)
+        R.zref_emissive_to_world(e.ctypes.data, M4x3.ctypes.data, b.ctypes.data)
+        assert a.tobytes() == b.tobytes(), (it, a, b)
+        assert scene_io.emissive_to_world(e, M).tobytes() == a.tobytes()
+
+
 @pytest.mark.skipif(not os.path.exists(REF_GLTF), reason="the reference's assets are not on this machine")
 @pytest.mark.parametrize("name", ["cornell", "cornell_emissive"])
 def test_native_loader_matches_python_loader_on_the_cornell_scenes(name):

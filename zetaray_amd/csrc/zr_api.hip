@@ -1036,6 +1036,16 @@ int zr_scene_create(int device, const zr_scene_desc* d, zr_scene** out)
 // at zr_scene_create keeps its topology, k_refit_tris re-transforms the triangles and k_refit_level recomputes + re-quantises the node boxes
 // level by level (what a D3D12 TLAS / BLAS update with ALLOW_UPDATE does); ZR_SCENE_UPDATE=rebuild selects a full binned-SAH rebuild on the
 // host instead (better trees after large motion, three orders of magnitude slower).  Results do not depend on the tree (zr_intersect.h).
+int zr_scene_update_emissives(zr_scene* s, const zr_emissive_triangle* triangles, uint32_t first, uint32_t count)
+{
+    if (!s || (!triangles && count)) return Fail(ZR_ERR_INVALID_ARG, "zr_scene_update_emissives: null argument");
+    if ((uint64_t)first + count > s->emissives.n) return Fail(ZR_ERR_INVALID_ARG, "zr_scene_update_emissives: [%u, %u) exceeds the scene's %zu emissive triangles", first, first + count, s->emissives.n);
+    if (!count) return ZR_OK;
+    HIP_TRY(hipSetDevice(s->device));
+    HIP_TRY(hipDeviceSynchronize());           // kernels of earlier frames may still sample the old records
+    HIP_TRY(hipMemcpy(s->emissives.p + first, triangles, (size_t)count * sizeof(zr_emissive_triangle), hipMemcpyHostToDevice));
+    return ZR_OK;
+}
 int zr_scene_update_instances(zr_scene* s, const zr_mesh_instance* instances, const float* instance_to_world, uint32_t n)
 {
     if (!s || !instances || !instance_to_world) return Fail(ZR_ERR_INVALID_ARG, "zr_scene_update_instances: null argument");

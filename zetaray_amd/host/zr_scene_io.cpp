@@ -238,17 +238,59 @@ void FillMeshInstance(const float* toWorld, zr_mesh_instance& I)
     for (int k = 0; k < 3; k++) { I.scale[k] = I.prev_scale[k] = zr_f32_to_f16(s[k]); I.translation[k] = t[k]; I.d_translation[k] = zr_f32_to_f16(0.0f); }
 }
 
-// RT::EmissiveTriangle ctor + StoreVertices (RtCommon.h:73-190)
-void PackEmissiveTriangle(const float* v0, const float* v1, const float* v2, const float* uv, uint32_t factorRGB8, uint32_t tex, uint16_t strengthH,
-    uint32_t id, bool doubleSided, zr_emissive_triangle& e)
+// RT::EmissiveTriangle::StoreVertices (RtCommon.h:141-198): vertex 0 + the two edges as 16-bit octahedral directions and half lengths
+void StoreEmissiveVertices(zr_emissive_triangle& e, const float* v0, const float* v1, const float* v2)
 {
-    std::memset(&e, 0, sizeof(e));
     float e0[3], e1[3];
     for (int k = 0; k < 3; k++) { e.vtx0[k] = v0[k]; e0[k] = v1[k] - v0[k]; e1[k] = v2[k] - v0[k]; }
     const float l0 = std::sqrt((e0[0] * e0[0] + e0[1] * e0[1]) + (e0[2] * e0[2] + 0.0f)), l1 = std::sqrt((e1[0] * e1[0] + e1[1] * e1[1]) + (e1[2] * e1[2] + 0.0f));
     const float n0[3] = {e0[0] / l0, e0[1] / l0, e0[2] / l0}, n1[3] = {e1[0] / l1, e1[1] / l1, e1[2] / l1};
     EncodeOct32(n0, e.v0v1); EncodeOct32(n1, e.v0v2);
     e.edge_lengths[0] = zr_f32_to_f16(l0); e.edge_lengths[1] = zr_f32_to_f16(l1);
+}
+// RT::EmissiveTriangle::DecodeVertices (RtCommon.h:200-234) with Math::decode_octahedral (VectorFuncs.h:155-174) and normalize (:64-70: dpps sums
+// (x^2 + y^2) + (z^2 + 0)), in the SSE code's operation order
+void DecodeEmissiveVertices(const zr_emissive_triangle& e, float* v0, float* v1, float* v2)
+{
+    const uint16_t enc[4] = {e.v0v1[0], e.v0v1[1], e.v0v2[0], e.v0v2[1]};
+    float u[4];
+    for (int k = 0; k < 4; k++) u[k] = std::fma((float)(int32_t)enc[k] / 65535.0f, 2.0f, -1.0f);
+    const float len[2] = {zr_f16_to_f32(e.edge_lengths[0]), zr_f16_to_f32(e.edge_lengths[1])};
+    float* out[2] = {v1, v2};
+    for (int j = 0; j < 2; j++)
+    {
+        const float ux = u[2 * j], uy = u[2 * j + 1];
+        const float z = 1.0f - (std::fabs(ux) + std::fabs(uy));
+        const float nz = 0.0f - z, posT = nz < 0.0f ? 0.0f : (nz > 1.0f ? 1.0f : nz), negT = 0.0f - posT;      // saturate(negate(z)), negate
+        const float dx = ux + (ux >= 0.0f ? negT : posT), dy = uy + (uy >= 0.0f ? negT : posT);
+        const float n = std::sqrt((dx * dx + dy * dy) + (z * z + 0.0f));
+        const float d[3] = {dx / n, dy / n, z / n};
+        for (int k = 0; k < 3; k++) out[j][k] = std::fma(d[k], len[j], e.vtx0[k]);
+    }
+    for (int k = 0; k < 3; k++) v0[k] = e.vtx0[k];
+}
+// mul(v_float4x4, __m128) (MatrixFuncs.h:93-112) of a point (w = 1) with a 3 x 4 object-to-world matrix (column-vector convention, zr_scene_desc)
+void MulPoint(const float* M, const float* v, float* out)
+{
+    for (int r = 0; r < 3; r++) out[r] = std::fma(1.0f, M[4 * r + 3], std::fma(v[2], M[4 * r + 2], std::fma(v[1], M[4 * r + 1], v[0] * M[4 * r])));
+}
+// the emissive-triangle transform of SceneCore (SceneCore.cpp:196-236 on the first frame, UpdateEmissivePositions :913-955 for moving instances):
+// decode the stored (object-space) triangle, transform its vertices, encode again -- every other field is kept
+void EmissiveToWorld(const zr_emissive_triangle& in, const float* M, zr_emissive_triangle& out)
+{
+    float v0[3], v1[3], v2[3], w0[3], w1[3], w2[3];
+    DecodeEmissiveVertices(in, v0, v1, v2);
+    MulPoint(M, v0, w0); MulPoint(M, v1, w1); MulPoint(M, v2, w2);
+    out = in;
+    StoreEmissiveVertices(out, w0, w1, w2);
+}
+
+// RT::EmissiveTriangle ctor + StoreVertices (RtCommon.h:73-190)
+void PackEmissiveTriangle(const float* v0, const float* v1, const float* v2, const float* uv, uint32_t factorRGB8, uint32_t tex, uint16_t strengthH,
+    uint32_t id, bool doubleSided, zr_emissive_triangle& e)
+{
+    std::memset(&e, 0, sizeof(e));
+    StoreEmissiveVertices(e, v0, v1, v2);
     e.id = id;
     e.packed_a = (factorRGB8 & 0xffffffu) | (1u << 24) | (doubleSided ? (1u << 25) : 0u) | (((uint32_t)strengthH & 0xfu) << 28);
     e.packed_b = (tex & 0xffffu) | ((uint32_t)strengthH << 16);
@@ -381,7 +423,7 @@ Image LoadDDS(const std::string& path)
 struct zrh_scene_data
 {
     std::vector<zr_vertex> vertices; std::vector<uint32_t> indices; std::vector<zr_mesh_instance> instances; std::vector<float> toWorld;
-    std::vector<uint8_t> mask; std::vector<uint32_t> numTris; std::vector<zr_material> materials; std::vector<zr_emissive_triangle> emissives;
+    std::vector<uint8_t> mask; std::vector<uint32_t> numTris; std::vector<zr_material> materials; std::vector<zr_emissive_triangle> emissives, emissivesInitial;
     std::vector<uint16_t> rho; uint32_t rhoDim[3] = {0, 0, 0};
     std::vector<zr_texture_desc> textures; std::vector<uint8_t> texels; uint32_t texOffsets[4] = {0, 0, 0, 0};
     zr_scene_desc desc;
@@ -623,17 +665,23 @@ void Load(const std::string& path, zrh_scene_data& sc)
         const float* M = sc.toWorld.data() + 12 * (size_t)em.inst;
         for (uint32_t p = 0; p < em.mp.nidx / 3; p++)
         {
-            float pw[3][3], uv[6];
+            float po[3][3], uv[6];
             for (int k = 0; k < 3; k++)
             {
                 const zr_vertex& v = sc.vertices[em.mp.vtx + sc.indices[em.mp.idx + 3 * p + k]];
-                for (int r = 0; r < 3; r++) pw[k][r] = ((M[4 * r] * v.pos[0] + M[4 * r + 1] * v.pos[1]) + M[4 * r + 2] * v.pos[2]) + M[4 * r + 3];
+                for (int r = 0; r < 3; r++) po[k][r] = v.pos[r];
                 uv[2 * k] = v.uv[0]; uv[2 * k + 1] = v.uv[1];
             }
             uint32_t hx = em.inst, hy = 0, hz = p; zr_pcg3d(&hx, &hy, &hz);
+            // the reference packs the triangle in OBJECT space when it loads the mesh (glTF.cpp:692-767) and SceneCore then decodes, transforms and
+            // re-encodes it unless the instance's world matrix is the identity (SceneCore.cpp:196-236); the object-space record is kept for
+            // zrh_emissive_to_world when the instance moves (UpdateEmissivePositions)
             zr_emissive_triangle e;
-            PackEmissiveTriangle(pw[0], pw[1], pw[2], uv, mat.emissive_factor_normal_scale & 0xffffffu, mat.emissive_tex_alpha_cutoff_coat_ior & 0xffffu,
+            PackEmissiveTriangle(po[0], po[1], po[2], uv, mat.emissive_factor_normal_scale & 0xffffffu, mat.emissive_tex_alpha_cutoff_coat_ior & 0xffffu,
                 (uint16_t)(mat.emissive_strength_ior & 0xffffu), hx, (mat.coat_color_flags & (1u << ZR_MAT_DOUBLE_SIDED_BIT)) != 0, e);
+            sc.emissivesInitial.push_back(e);
+            static const float kIdentity[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0};
+            if (std::memcmp(M, kIdentity, sizeof(kIdentity)) != 0) { zr_emissive_triangle w; EmissiveToWorld(e, M, w); e = w; }
             sc.emissives.push_back(e);
         }
     }
@@ -669,6 +717,8 @@ void zrh_compose_world(const float* s, const float* q, const float* t, const flo
     ToToWorld(Mul(AffineTransformation(s, q, t), P), out);
 }
 void zrh_fill_mesh_instance(const float* M, zr_mesh_instance* inst) { FillMeshInstance(M, *inst); }
+void zrh_emissive_to_world(const zr_emissive_triangle* in, const float* to_world_3x4, zr_emissive_triangle* out) { zr_emissive_triangle t; EmissiveToWorld(*in, to_world_3x4, t); *out = t; }
+const zr_emissive_triangle* zrh_scene_data_initial_emissives(const zrh_scene_data* s) { return s && !s->emissivesInitial.empty() ? s->emissivesInitial.data() : nullptr; }
 void zrh_pack_emissive_triangle(const float* v0, const float* v1, const float* v2, const float* uv6, uint32_t factor, uint32_t tex, uint16_t strength, uint32_t id,
     int doubleSided, zr_emissive_triangle* out) { PackEmissiveTriangle(v0, v1, v2, uv6, factor, tex, strength, id, doubleSided != 0, *out); }
 

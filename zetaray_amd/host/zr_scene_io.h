@@ -37,6 +37,12 @@ void zrh_fill_mesh_instance(const float* to_world_3x4, zr_mesh_instance* inst);
 // RT::EmissiveTriangle(v0, v1, v2, uv0..2, factor RGB8, texture, half strength bits, id, double sided)
 void zrh_pack_emissive_triangle(const float* v0, const float* v1, const float* v2, const float* uv6, uint32_t factor_rgb8, uint32_t tex,
                                 uint16_t strength_half, uint32_t id, int double_sided, zr_emissive_triangle* out);
+// SceneCore's emissive transform (SceneCore.cpp:196-236, UpdateEmissivePositions :913-955): decode the triangle's vertices (16-bit octahedral edge
+// directions, half lengths), transform them by the 3 x 4 object-to-world matrix, encode again; every other field is kept.  Per frame, for a moving
+// emissive instance: out[t] = zrh_emissive_to_world(initial[t], new matrix) for its triangles, then zr_scene_update_emissives (zetaray_amd.h)
+void zrh_emissive_to_world(const zr_emissive_triangle* in, const float* to_world_3x4, zr_emissive_triangle* out);
+// the object-space records of the scene's emissive triangles as loaded (same order as zr_scene_desc.emissives; ID already hashed)
+const zr_emissive_triangle* zrh_scene_data_initial_emissives(const zrh_scene_data* s);
 // BC7 / BC5 block decompression: w x h texels (multiples of 4 not required) -> RGBA8 / RG8 rows top-down
 int zrh_bc7_decode(const uint8_t* blocks, uint32_t w, uint32_t h, uint8_t* rgba8);
 int zrh_bc5_decode(const uint8_t* blocks, uint32_t w, uint32_t h, uint8_t* rg8);

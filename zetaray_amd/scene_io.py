@@ -377,7 +377,9 @@ def load_gltf(path, rho=None) -> Scene:
         tri_idx = sc.indices[info["idx"]:info["idx"] + info["nidx"]].reshape(-1, 3)
         for prim, (i0, i1, i2) in enumerate(tri_idx):
             vs = [sc.vertices[info["vtx"] + i] for i in (i0, i1, i2)]
-            pw = [(M[:, :3] @ v["pos"].astype(np.float32) + M[:, 3]).astype(np.float32) for v in vs]
+            # packed in OBJECT space at load, then decoded, transformed and re-encoded unless the instance sits at the identity
+            # (glTF.cpp:692-767, SceneCore.cpp:196-236; emissive_to_world)
+            pw = [v["pos"].astype(np.float32) for v in vs]
             ems.append(pack_emissive_triangle(
                 pw[0], pw[1], pw[2], [v["uv"] for v in vs],
                 factor_rgb8=int(matp["emissive_factor_normal_scale"]) & 0xFFFFFF,
@@ -386,12 +388,41 @@ def load_gltf(path, rho=None) -> Scene:
                 tri_id=pcg3d(inst_idx, 0, prim)[0],
                 double_sided=bool(int(matp["coat_color_flags"]) & (1 << 25))))
     sc.emissives = np.array(ems, dtype=wire.EMISSIVE_TRI) if ems else np.zeros(0, wire.EMISSIVE_TRI)
+    sc.emissives_initial = sc.emissives.copy()      # object space: what move_emissive_instance transforms
+    for inst_idx, info, M in emissive_tris:
+        M = np.ascontiguousarray(M, np.float32)
+        if not np.array_equal(M, np.eye(3, 4, dtype=np.float32)):
+            b, n = int(sc.instances[inst_idx]["base_emissive_tri_offset"]), info["nidx"] // 3
+            sc.emissives[b:b + n] = emissive_to_world(sc.emissives_initial[b:b + n], M)
 
     if rho is None:
         sc.rho, sc.rho_dim = load_rho_default()
     else:
         sc.rho, sc.rho_dim = rho
     return sc
+
+
+def emissive_to_world(tris, to_world_3x4):
+    """SceneCore's emissive transform (SceneCore.cpp:196-236, UpdateEmissivePositions :913-955) through the C++ restatement pinned to the reference's
+    own LoadVertices / mul / StoreVertices (tests/test_scene_io.py): decode -> transform -> re-encode each record of `tris`"""
+    import ctypes as C
+    L = _sceneio_lib()
+    tris = np.ascontiguousarray(tris, wire.EMISSIVE_TRI)
+    out = np.zeros_like(tris)
+    M = np.ascontiguousarray(to_world_3x4, np.float32).reshape(12)
+    for i in range(len(tris)):
+        L.zrh_emissive_to_world(C.c_void_p(tris[i:i + 1].ctypes.data), C.c_void_p(M.ctypes.data), C.c_void_p(out[i:i + 1].ctypes.data))
+    return out
+
+
+def move_emissive_instance(sc, idx, **kw):
+    """move_instance for an emissive instance: also re-derives its world-space EmissiveTriangle records from the object-space ones (needs
+    sc.emissives_initial: the glTF loaders provide it).  Returns (instances, instance_to_world, first emissive triangle, the new records)."""
+    inst, xw = move_instance(sc, idx, **kw)
+    b, n = int(sc.instances[idx]["base_emissive_tri_offset"]), int(sc.instance_num_tris[idx])
+    assert b != 0xFFFFFFFF, "not an emissive instance"
+    sc.emissives[b:b + n] = emissive_to_world(sc.emissives_initial[b:b + n], sc.instance_to_world[idx])
+    return inst, xw, b, sc.emissives[b:b + n]
 
 
 def _sceneio_lib():
@@ -406,6 +437,7 @@ def _sceneio_lib():
         L.zrh_scene_data_desc.argtypes = [C.c_void_p]
         L.zrh_scene_data_tex_offsets.argtypes = [C.c_void_p, C.c_void_p]
         L.zrh_scene_data_destroy.argtypes = [C.c_void_p]
+        L.zrh_emissive_to_world.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         _SCENEIO = L
     return _SCENEIO
 
@@ -453,7 +485,8 @@ def save_npz(sc: Scene, path):
     np.savez_compressed(path, vertices=sc.vertices, indices=sc.indices, instances=sc.instances,
                         instance_to_world=sc.instance_to_world, instance_mask=sc.instance_mask,
                         instance_num_tris=sc.instance_num_tris, materials=sc.materials, emissives=sc.emissives,
-                        **({"textures": sc.textures, "texels": sc.texels} if len(sc.textures) else {}))
+                        **({"textures": sc.textures, "texels": sc.texels} if len(sc.textures) else {}),
+                        **({"emissives_initial": sc.emissives_initial} if getattr(sc, "emissives_initial", None) is not None else {}))
 
 
 def load_npz(path) -> Scene:
@@ -469,6 +502,8 @@ def load_npz(path) -> Scene:
     sc.emissives = z["emissives"].astype(wire.EMISSIVE_TRI)
     if "textures" in z.files:
         sc.textures, sc.texels = z["textures"].astype(wire.TEXTURE_DESC), z["texels"].astype(np.uint8)
+    if "emissives_initial" in z.files:      # object-space records, for move_emissive_instance
+        sc.emissives_initial = z["emissives_initial"].astype(wire.EMISSIVE_TRI)
     sc.rho, sc.rho_dim = load_rho_default()
     return sc
 
