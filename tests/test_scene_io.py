@@ -376,3 +376,134 @@ def test_cornell_with_the_reference_floor_texture_on_gpu():
             for n, x, y in zip(wire.GB_PLANE_NAMES, planes, oplanes):
                 assert np.array_equal(np.asarray(x).view(np.uint8).reshape(-1), np.asarray(y).view(np.uint8).reshape(-1)), n
     assert got[..., :3].max() > 0
+
+
+@pytest.mark.skipif(not os.path.exists(ZREF), reason="needs oracle/_ref/libzref.so (built from /root/reference)")
+def test_per_frame_scene_maintenance_matches_reference_code(tmp_path):
+    """zrh_scene_data_begin_frame / _set_instance_world (the C++ host's per-frame scene update) against the reference's own code: MeshInstance
+    records = TLAS::FillMeshInstanceData's !staticMesh branch (decomposeSRT of the current and the previous world matrix, dTranslation =
+    half3(t - t_prev)), the moved light's EmissiveTriangle records = LoadVertices -> mul -> StoreVertices of the object-space ones; instances
+    that do not move turn static (Prev* = current, dTranslation = 0)."""
+    path, g, pos = _write_gltf(tmp_path)
+    L, R = sio(), C.CDLL(ZREF)
+    L.zrh_scene_data_begin_frame.argtypes = [C.c_void_p]
+    L.zrh_scene_data_set_instance_world.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p]
+    L.zrh_scene_data_dirty_emissives.argtypes = [C.c_void_p] * 3
+    L.zrh_scene_data_initial_emissives.restype = C.c_void_p
+    L.zrh_scene_data_initial_emissives.argtypes = [C.c_void_p]
+    R.zref_fill_mesh_instance.argtypes = [C.c_void_p] * 6
+    R.zref_emissive_to_world.argtypes = [C.c_void_p] * 3
+    rho, dim = scene_io.load_rho_default()
+    rho = np.ascontiguousarray(rho, np.uint16)
+    h = C.c_void_p()
+    assert L.zrh_gltf_load(os.fsencode(path), rho.ctypes.data, (C.c_uint32 * 3)(*dim), C.byref(h)) == 0
+    d = L.zrh_scene_data_desc(h).contents
+    n, ne = d.num_instances, d.num_emissives
+    inst = np.ctypeslib.as_array(C.cast(d.instances, C.POINTER(C.c_uint8)), (n * wire.MESH_INSTANCE.itemsize,)).view(wire.MESH_INSTANCE)
+    world = np.ctypeslib.as_array(C.cast(d.instance_to_world, C.POINTER(C.c_float)), (n, 12))
+    ems = np.ctypeslib.as_array(C.cast(d.emissives, C.POINTER(C.c_uint8)), (ne * 48,)).view(wire.EMISSIVE_TRI)
+    init = np.ctypeslib.as_array(C.cast(L.zrh_scene_data_initial_emissives(h), C.POINTER(C.c_uint8)), (ne * 48,)).view(wire.EMISSIVE_TRI).copy()
+    light = [i for i in range(n) if inst["base_emissive_tri_offset"][i] != 0xFFFFFFFF][0]
+    plain = [i for i in range(n) if i != light][0]
+    rng = np.random.default_rng(3)
+
+    def ref_srt(M):      # the reference's decomposition + quantisation of a 3 x 4 column-vector matrix
+        M4x3 = np.ascontiguousarray(np.vstack([M.reshape(3, 4)[:, :3].T, M.reshape(3, 4)[:, 3][None, :]]).astype(np.float32))
+        s3, q4, t3, rot, scl = np.zeros(3, np.float32), np.zeros(4, np.float32), np.zeros(3, np.float32), np.zeros(4, np.uint16), np.zeros(3, np.uint16)
+        R.zref_fill_mesh_instance(M4x3.ctypes.data, s3.ctypes.data, q4.ctypes.data, t3.ctypes.data, rot.ctypes.data, scl.ctypes.data)
+        return t3, rot, scl, M4x3
+
+    for frame in range(4):
+        before_world, before_inst = world.copy(), inst.copy()
+        L.zrh_scene_data_begin_frame(h)
+        moved = {}
+        for i in ((light, plain) if frame < 3 else (plain,)):      # last frame: the light rests
+            a = rng.uniform(-0.6, 0.6)
+            Rm = np.array([[np.cos(a), 0, np.sin(a)], [0, 1, 0], [-np.sin(a), 0, np.cos(a)]]) @ np.diag([rng.uniform(0.5, 2)] * 3)
+            M = np.zeros((3, 4), np.float32); M[:, :3] = Rm.astype(np.float32); M[:, 3] = rng.uniform(-3, 3, 3).astype(np.float32)
+            assert L.zrh_scene_data_set_instance_world(h, i, M.ctypes.data) == 0
+            moved[i] = M
+        for i in range(n):
+            if i in moved:
+                t, rot, scl, M4x3 = ref_srt(moved[i])
+                tp, rotp, sclp, _ = ref_srt(before_world[i])
+                assert np.array_equal(world[i], moved[i].reshape(12))
+                assert np.array_equal(inst["rotation"][i], rot) and np.array_equal(inst["scale"][i], scl) and np.array_equal(inst["translation"][i].view(np.uint32), t.view(np.uint32))
+                assert np.array_equal(inst["prev_rotation"][i], rotp) and np.array_equal(inst["prev_scale"][i], sclp)
+                assert np.array_equal(inst["d_translation"][i], (t - tp).astype(np.float16).view(np.uint16)), (frame, i)
+            else:
+                assert np.array_equal(inst["rotation"][i], before_inst["rotation"][i]) and np.array_equal(inst["prev_rotation"][i], inst["rotation"][i])
+                assert np.array_equal(inst["prev_scale"][i], inst["scale"][i]) and not inst["d_translation"][i].any()
+        first, count = C.c_uint32(), C.c_uint32()
+        L.zrh_scene_data_dirty_emissives(h, C.byref(first), C.byref(count))
+        if light in moved:
+            b, k = int(inst["base_emissive_tri_offset"][light]), int(C.cast(d.instance_num_tris, C.POINTER(C.c_uint32))[light])
+            assert (first.value, count.value) == (b, k)
+            M4x3 = ref_srt(moved[light])[3]
+            for j in range(b, b + k):
+                want = np.zeros(1, wire.EMISSIVE_TRI)
+                R.zref_emissive_to_world(init[j:j + 1].ctypes.data, M4x3.ctypes.data, want.ctypes.data)
+                assert ems[j:j + 1].tobytes() == want.tobytes(), (frame, j)
+        else:
+            assert count.value == 0
+    L.zrh_scene_data_destroy(h)
+
+
+@pytest.mark.gpu
+def test_cpp_scene_maintenance_drives_the_device_scene(tmp_path):
+    """The C++ host's whole dynamic-scene path on the GPU: zrh_gltf_load -> per frame zrh_scene_data_begin_frame / _set_instance_world (a light-carrying
+    instance and a plain one move) -> zrh_scene_apply_updates (zr_scene_update_emissives + zr_scene_update_instances: device refit, previous BVH kept)
+    -> ReSTIR PT + ReSTIR DI.  The oracle is fed the same records; radiance of both bit-exact over 4 frames."""
+    from oracle import zro
+    from zetaray_amd import api
+    path, g, pos = _write_gltf(tmp_path)
+    sc, _ = scene_io.load_gltf_native(path)
+    L = sio()
+    H = C.CDLL(os.path.join(ROOT, "zetaray_amd", "libzetaray_host.so"))
+    H.zrh_scene_apply_updates.argtypes = [C.c_void_p, C.c_void_p]
+    L.zrh_scene_data_begin_frame.argtypes = [C.c_void_p]
+    L.zrh_scene_data_set_instance_world.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p]
+    rho, dim = scene_io.load_rho_default()
+    rho = np.ascontiguousarray(rho, np.uint16)
+    h = C.c_void_p()
+    assert L.zrh_gltf_load(os.fsencode(path), rho.ctypes.data, (C.c_uint32 * 3)(*dim), C.byref(h)) == 0
+    d = L.zrh_scene_data_desc(h).contents
+    n, ne = d.num_instances, d.num_emissives
+    inst = np.ctypeslib.as_array(C.cast(d.instances, C.POINTER(C.c_uint8)), (n * wire.MESH_INSTANCE.itemsize,)).view(wire.MESH_INSTANCE)
+    world = np.ctypeslib.as_array(C.cast(d.instance_to_world, C.POINTER(C.c_float)), (n, 12))
+    ems = np.ctypeslib.as_array(C.cast(d.emissives, C.POINTER(C.c_uint8)), (ne * 48,)).view(wire.EMISSIVE_TRI)
+    light = [i for i in range(n) if inst["base_emissive_tri_offset"][i] != 0xFFFFFFFF][0]
+    plain = [i for i in range(n) if i != light][0]
+    w, hgt = 96, 64
+    prm = wire.default_params()
+    dprm = wire.default_params_di()
+    r = api.Renderer(sc, w, hgt, params=prm, integrator=api.INTEGRATOR_RESTIR_PT)
+    di = r.enable_direct(dprm)      # ReSTIR DI: the moved light's records decide every pixel of it
+    osc = zro.OracleScene(sc)
+    opt, odi = zro.OracleRPT(osc, w, hgt), zro.OracleRDI(osc, w, hgt)
+    base = {i: world[i].reshape(3, 4).copy() for i in (light, plain)}
+    prev, lit = None, 0.0
+    for f in range(1, 5):
+        if f >= 2:
+            L.zrh_scene_data_begin_frame(h)
+            for i in (light, plain):
+                M = base[i].copy()
+                M[:, 3] += np.float32([0.1 * (f - 1), 0.05 * (f - 1) * (1 if i == light else -1), 0.0])
+                assert L.zrh_scene_data_set_instance_world(h, i, np.ascontiguousarray(M).ctypes.data) == 0
+            assert H.zrh_scene_apply_updates(r.scene.h, h) == 0
+            osc.update_emissives(ems.copy(), 0)
+            osc.update_instances(inst.copy(), world.copy())
+        # camera between the light (above) and the plain quad, looking down at the quad
+        c = base[plain][:, 3]
+        cb = scene_io.make_frame_constants(w, hgt, frame_num=f, num_emissives=ne, cam_pos=(float(c[0]), float(c[1]) + 3.0, float(c[2])), view_dir=(0, -1, 0), up=(0, 0, 1))
+        if prev is not None:
+            cb["prev_view"], cb["prev_view_inv"], cb["prev_camera_jitter"] = prev["curr_view"], prev["curr_view_inv"], prev["curr_camera_jitter"]
+        prev = cb.copy()
+        r.render_frame(cb)
+        want, want_di = opt.render(cb, prm), odi.render(cb, dprm)
+        assert np.array_equal(r.final().view(np.uint32), want.view(np.uint32)), f"frame {f}: ReSTIR PT"
+        got = di.download()
+        assert np.array_equal(got.view(np.uint32), want_di.view(np.uint32)), f"frame {f}: ReSTIR DI"
+        lit = max(lit, float(got[..., :3].max()))
+    assert lit > 0      # the quad under the light is lit
+    L.zrh_scene_data_destroy(h)

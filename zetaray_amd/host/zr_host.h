@@ -42,6 +42,13 @@ int zrh_halo_exchange_create(zr_pass* pass, zr_gbuffer* gb, zrh_comm* comm, cons
 void zrh_halo_exchange_destroy(zrh_halo_exchange* x);
 size_t zrh_halo_exchange_send_bytes(const zrh_halo_exchange* x);
 int zrh_halo_exchange_run(zrh_halo_exchange* x, void* hip_stream, int which);
+// ---- scene ingestion + per-frame maintenance on the host (zr_scene_io.h) handed to the device scene
+struct zrh_scene_data;
+// Model::glTF::Load + SceneCore + TLAS build in one call; tex_offsets4 = the four descriptor-table offsets for cbFrameConstants
+int zrh_scene_create_from_gltf(int device, const char* path, const uint16_t* rho_lut, const uint32_t* rho_dim3, zr_scene** out, uint32_t* tex_offsets4);
+// per frame: upload what zrh_scene_data_begin_frame / zrh_scene_data_set_instance_world changed -- the moved lights' records
+// (zr_scene_update_emissives), then the instance buffer + matrices (zr_scene_update_instances)
+int zrh_scene_apply_updates(zr_scene* scene, const struct zrh_scene_data* data);
 }
 
 namespace ZetaRayAMD {

@@ -426,6 +426,7 @@ struct zrh_scene_data
     std::vector<uint8_t> mask; std::vector<uint32_t> numTris; std::vector<zr_material> materials; std::vector<zr_emissive_triangle> emissives, emissivesInitial;
     std::vector<uint16_t> rho; uint32_t rhoDim[3] = {0, 0, 0};
     std::vector<zr_texture_desc> textures; std::vector<uint8_t> texels; uint32_t texOffsets[4] = {0, 0, 0, 0};
+    std::vector<float> prevWorld; uint32_t dirtyFirst = 0xffffffffu, dirtyEnd = 0;      // per-frame maintenance (zrh_scene_data_begin_frame / _set_instance_world)
     zr_scene_desc desc;
     void Finish()
     {
@@ -717,6 +718,46 @@ void zrh_compose_world(const float* s, const float* q, const float* t, const flo
     ToToWorld(Mul(AffineTransformation(s, q, t), P), out);
 }
 void zrh_fill_mesh_instance(const float* M, zr_mesh_instance* inst) { FillMeshInstance(M, *inst); }
+// ---- per-frame scene maintenance: what SceneCore::Update / TLAS::FillMeshInstanceData do for dynamic instances
+void zrh_scene_data_begin_frame(zrh_scene_data* s)
+{
+    if (!s) return;
+    s->prevWorld = s->toWorld;
+    for (zr_mesh_instance& I : s->instances)      // an instance that does not move this frame: Prev* = current, dTranslation = 0
+    {
+        for (int k = 0; k < 4; k++) I.prev_rotation[k] = I.rotation[k];
+        for (int k = 0; k < 3; k++) { I.prev_scale[k] = I.scale[k]; I.d_translation[k] = zr_f32_to_f16(0.0f); }
+    }
+    s->dirtyFirst = 0xffffffffu; s->dirtyEnd = 0;
+}
+int zrh_scene_data_set_instance_world(zrh_scene_data* s, uint32_t inst, const float* world)
+{
+    if (!s || !world || inst >= s->instances.size()) { g_err = "zrh_scene_data_set_instance_world: bad argument"; return -1; }
+    if (s->prevWorld.size() != s->toWorld.size()) s->prevWorld = s->toWorld;
+    zr_mesh_instance& I = s->instances[inst];
+    // TLAS::FillMeshInstanceData, !staticMesh branch (RtAccelerationStructure.cpp:318-380): current and previous S / R / T by decomposeSRT of the two
+    // world matrices, dTranslation = half3(t - t_prev)
+    float sc[3], q[4], t[3], sp[3], qp[4], tp[3];
+    DecomposeSRT(FromToWorld(world), sc, q, t);
+    DecomposeSRT(FromToWorld(s->prevWorld.data() + 12 * (size_t)inst), sp, qp, tp);
+    for (int k = 0; k < 4; k++) { I.rotation[k] = Unorm16FromNormalized(q[k]); I.prev_rotation[k] = Unorm16FromNormalized(qp[k]); }
+    for (int k = 0; k < 3; k++)
+    { I.scale[k] = zr_f32_to_f16(sc[k]); I.prev_scale[k] = zr_f32_to_f16(sp[k]); I.translation[k] = t[k]; I.d_translation[k] = zr_f32_to_f16(t[k] - tp[k]); }
+    std::memcpy(s->toWorld.data() + 12 * (size_t)inst, world, 12 * sizeof(float));
+    // SceneCore::UpdateEmissivePositions for an instance that carries lights
+    if (I.base_emissive_tri_offset != 0xffffffffu && !s->emissivesInitial.empty())
+    {
+        const uint32_t b = I.base_emissive_tri_offset, n = s->numTris[inst];
+        for (uint32_t k = b; k < b + n; k++) EmissiveToWorld(s->emissivesInitial[k], world, s->emissives[k]);
+        s->dirtyFirst = std::min(s->dirtyFirst, b); s->dirtyEnd = std::max(s->dirtyEnd, b + n);
+    }
+    return 0;
+}
+void zrh_scene_data_dirty_emissives(const zrh_scene_data* s, uint32_t* first, uint32_t* count)
+{
+    const bool any = s && s->dirtyEnd > s->dirtyFirst;
+    *first = any ? s->dirtyFirst : 0u; *count = any ? s->dirtyEnd - s->dirtyFirst : 0u;
+}
 void zrh_emissive_to_world(const zr_emissive_triangle* in, const float* to_world_3x4, zr_emissive_triangle* out) { zr_emissive_triangle t; EmissiveToWorld(*in, to_world_3x4, t); *out = t; }
 const zr_emissive_triangle* zrh_scene_data_initial_emissives(const zrh_scene_data* s) { return s && !s->emissivesInitial.empty() ? s->emissivesInitial.data() : nullptr; }
 void zrh_pack_emissive_triangle(const float* v0, const float* v1, const float* v2, const float* uv6, uint32_t factor, uint32_t tex, uint16_t strength, uint32_t id,

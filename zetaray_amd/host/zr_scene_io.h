@@ -27,6 +27,16 @@ const zr_scene_desc* zrh_scene_data_desc(const zrh_scene_data* s);
 void zrh_scene_data_tex_offsets(const zrh_scene_data* s, uint32_t* out4);
 void zrh_scene_data_destroy(zrh_scene_data* s);
 
+// ---- per-frame maintenance of a loaded scene (SceneCore::Update + TLAS::FillMeshInstanceData for dynamic instances, RtAccelerationStructure.cpp:318-380;
+// SceneCore::UpdateEmissivePositions, SceneCore.cpp:913-955).  Per frame: begin_frame (this frame's matrices become the previous ones, every record
+// turns static: Prev* = current, dTranslation = 0), set_instance_world for each instance that moves (current + previous S / R / T by decomposeSRT,
+// dTranslation = half3(t - t_prev); the EmissiveTriangle records of a light-carrying instance re-derived from the object-space ones), then hand
+// zrh_scene_data_desc's instances / instance_to_world and the dirty emissive range to zr_scene_update_emissives / zr_scene_update_instances
+// (zrh_scene_apply_updates in zr_host.h does both calls).
+void zrh_scene_data_begin_frame(zrh_scene_data* s);
+int zrh_scene_data_set_instance_world(zrh_scene_data* s, uint32_t instance, const float* world_3x4);
+void zrh_scene_data_dirty_emissives(const zrh_scene_data* s, uint32_t* first, uint32_t* count);
+
 // ---- building blocks, exported for the parity pins (tests/test_scene_io.py) ----
 // decomposeSRT + quaternionFromRotationMat1 of a 3 x 4 row-major object-to-world matrix (column-vector convention, zr_scene_desc.instance_to_world)
 void zrh_decompose_srt(const float* to_world_3x4, float* scale3, float* quat4, float* translation3);
