@@ -80,6 +80,9 @@ static inline RefScene* SceneCreate(const zr_scene_desc* d, int force_bvh) { Ref
     extern "C" int zrefp_scene_update_instances(refpass::RefScene* r, const zr_mesh_instance* inst, const float* xf, uint32_t n) \
     { if (n != r->sc.instances.size()) return -1; r->prevHolder.reset(new refpass::RefScene()); r->prevHolder->sc = r->sc; r->prevHolder->sc.prev = nullptr; \
       r->sc.UpdateInstances(inst, xf, n); return 0; } \
+    extern "C" int zrefp_scene_update_emissives(refpass::RefScene* r, const zr_emissive_triangle* t, uint32_t first, uint32_t count) \
+    { if ((size_t)first + count > r->sc.emissives.size()) return -1; std::copy(t, t + count, r->sc.emissives.begin() + first); \
+      if (r->prevHolder) std::copy(t, t + count, r->prevHolder->sc.emissives.begin() + first); return 0; } \
     extern "C" void zrefp_scene_set_alias_table(refpass::RefScene* r, const zr_alias_entry* e, uint32_t n) { r->sc.alias.assign(e, e + n); } \
     extern "C" void zrefp_scene_set_sample_sets(refpass::RefScene* r, const zr_presampled_tri* e, uint32_t numSets, uint32_t setSize) \
     { r->sc.sampleSets.assign(e, e + (size_t)numSets * setSize); r->sc.sampleSetSize = setSize; } \

@@ -50,6 +50,12 @@ class RefPass:
         i, x = np.ascontiguousarray(instances), np.ascontiguousarray(instance_to_world, np.float32)
         assert self.L.zrefp_scene_update_instances(self.h, i.ctypes.data, x.ctypes.data, len(i)) == 0
 
+    def update_emissives(self, triangles, first=0):
+        """new EmissiveTriangle records of instances that moved (one emissive buffer: the previous-frame scene view sees them too)"""
+        self.L.zrefp_scene_update_emissives.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32]
+        t = np.ascontiguousarray(triangles)
+        assert self.L.zrefp_scene_update_emissives(self.h, t.ctypes.data, first, len(t)) == 0
+
     def set_alias_table(self, entries):
         e = np.ascontiguousarray(entries)
         self.L.zrefp_scene_set_alias_table(self.h, e.ctypes.data, len(e))

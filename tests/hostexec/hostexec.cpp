@@ -108,6 +108,9 @@ HxScene* zhx_scene_create(const zr_scene_desc* d)
     v.tex.descs = s->texDescs.data(); v.tex.texels = s->texels.data(); v.tex.srgb = zr_srgb_to_linear_table; v.tex.count = d->num_textures;
     return s;
 }
+// zr_scene_update_emissives (the view points into the vector, whose size does not change)
+void zhx_scene_update_emissives(HxScene* s, const zr_emissive_triangle* tris, uint32_t first, uint32_t count)
+{ std::copy(tris, tris + count, s->emissives.begin() + first); }
 void zhx_scene_update_instances(HxScene* s, const zr_mesh_instance* instances, const float* instance_to_world, uint32_t n)
 {
     s->instancesPrev = s->instances; s->bvhPrev = s->bvh; s->hasPrev = true;

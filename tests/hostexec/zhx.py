@@ -87,6 +87,12 @@ class HostExecScene:
         i, x = np.ascontiguousarray(instances), np.ascontiguousarray(instance_to_world, np.float32)
         L.zhx_scene_update_instances(self.h, i.ctypes.data, x.ctypes.data, len(i))
 
+    def update_emissives(self, triangles, first=0):
+        L = lib()
+        L.zhx_scene_update_emissives.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32]
+        t = np.ascontiguousarray(triangles)
+        L.zhx_scene_update_emissives(self.h, t.ctypes.data, first, len(t))
+
     def bvh_info(self):
         a, b, c = C.c_uint32(), C.c_uint32(), C.c_uint32()
         lib().zhx_bvh_info(self.h, C.byref(a), C.byref(b), C.byref(c))

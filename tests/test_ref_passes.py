@@ -46,10 +46,10 @@ def test_oracle_reproduces_reference_passes(case):
     g = _gold(case)
     o = zro.OracleScene(sc, force_bvh=force_bvh, cb=RC.first_cb(case))
     rpt = {"rpt": zro.OracleRPT, "gi": zro.OracleRGI, "di": zro.OracleRDI, "sdi": zro.OracleSDI}[integ](o, RC.W, RC.H) if integ != "pt" else None
-    anim = RC.Animator(sc) if case in RC.ANIMATED else None
+    anim = RC.Animator(sc, light=case in RC.MOVING_LIGHT) if case in RC.ANIMATED else None
     for f, cb in RC.frames_of(case):
         if anim is not None and f >= 2:
-            o.update_instances(*anim.step(f))
+            anim.apply(f, o)
         if len(sc.emissives) == 0:
             o.sky_lut(cb, 256, 128)
         if prm.presampling:
@@ -87,12 +87,10 @@ def test_live_reference_passes_match_stored_outputs(case):
     o = zro.OracleScene(sc, force_bvh=force_bvh, cb=RC.first_cb(case))
     k1 = zref.RefGBuffer(sc, force_bvh)
     ref = M.make_ref(zref, sc, integ, prm, force_bvh)
-    anim = RC.Animator(sc) if case in RC.ANIMATED else None
+    anim = RC.Animator(sc, light=case in RC.MOVING_LIGHT) if case in RC.ANIMATED else None
     for f, cb in RC.frames_of(case):
         if anim is not None and f >= 2:
-            inst, xw = anim.step(f)
-            for q in (o, k1, ref):
-                q.update_instances(inst, xw)
+            anim.apply(f, o, k1, ref)
         M.prepare(ref, o, sc, cb, f, prm)
         arrays, planes = k1.render(cb)
         got = ref.render(cb, planes, prm) if integ == "pt" else ref.render(cb, prm, (arrays, planes))
@@ -148,10 +146,10 @@ def test_hip_path_reproduces_reference_passes(case):
         r = api.Renderer(sc, RC.W, RC.H, params=prm, integrator=integrator)
         p = r.p_indirect
         names = {n: n for n in RC.RPT_PLANES} if integ == "rpt" else {"A": "gi_A", "B": "gi_B", "C": "gi_C"}
-    anim = RC.Animator(sc) if case in RC.ANIMATED else None
+    anim = RC.Animator(sc, light=case in RC.MOVING_LIGHT) if case in RC.ANIMATED else None
     for f, cb in RC.frames_of(case):
         if anim is not None and f >= 2:
-            r.scene.update_instances(*anim.step(f))
+            anim.apply(f, r.scene)
         r.render_frame(cb)
         if f == (3 if anim is not None else 1):
             planes, _ = r.gbuffer.download()
@@ -166,7 +164,8 @@ def test_hip_path_reproduces_reference_passes(case):
 
 
 # ------------------------------------------------------------------ the HIP stage functions, executed on the host, against the reference's outputs
-@pytest.mark.parametrize("case", ["rpt_cornell_moving", "rpt_moving_instance", "di_moving_instance", "sdi_moving_instance", "gi_cornell_moving", "rpt_sun_sky"])
+@pytest.mark.parametrize("case", ["rpt_cornell_moving", "rpt_moving_instance", "di_moving_instance", "sdi_moving_instance", "gi_cornell_moving", "rpt_sun_sky",
+                                  "rpt_moving_light", "di_moving_light"])
 def test_hip_stage_functions_on_host_reproduce_reference_passes(case):
     """the product's device code (zr_stages.h, zr_rpt.h, zr_rdi.h, zr_sdi.h, zr_rgi.h) compiled for the host by tests/hostexec and run serially:
     catches a divergence from the reference's shaders without a GPU, incl. the dynamic-instance paths (previous BVH / mesh instances, MoveXk)"""
@@ -177,10 +176,10 @@ def test_hip_stage_functions_on_host_reproduce_reference_passes(case):
     o = zro.OracleScene(sc, force_bvh=force_bvh, cb=RC.first_cb(case))                 # only for the scene-level inputs (alias table, presampled sets, sky LUT)
     hx = zhx.HostExecScene(sc, alias=o.alias if len(sc.emissives) else None)
     run = {"rpt": zhx.HostExecRPT, "gi": zhx.HostExecRGI, "di": zhx.HostExecRDI, "sdi": zhx.HostExecSDI}[integ](hx, RC.W, RC.H)
-    anim = RC.Animator(sc) if case in RC.ANIMATED else None
+    anim = RC.Animator(sc, light=case in RC.MOVING_LIGHT) if case in RC.ANIMATED else None
     for f, cb in RC.frames_of(case):
         if anim is not None and f >= 2:
-            hx.update_instances(*anim.step(f))
+            anim.apply(f, hx)
         if len(sc.emissives) == 0:
             hx.sky_lut(cb, 256, 128)
         gb = hx.gbuffer(cb)

@@ -56,12 +56,10 @@ def main():
         k1 = zref.RefGBuffer(sc, force_bvh)
         ref = make_ref(zref, sc, integ, prm, force_bvh)
         res = {}
-        anim = RC.Animator(sc) if case in RC.ANIMATED else None
+        anim = RC.Animator(sc, light=case in RC.MOVING_LIGHT) if case in RC.ANIMATED else None
         for f, cb in RC.frames_of(case):
             if anim is not None and f >= 2:
-                inst, xw = anim.step(f)
-                for q in (o, k1, ref):
-                    q.update_instances(inst, xw)
+                anim.apply(f, o, k1, ref)
             prepare(ref, o, sc, cb, f, prm)
             arrays, planes = k1.render(cb)
             if f == (3 if anim is not None else 1):          # animated cases: the G-buffer of a frame in motion (motion vectors, prev transform)

@@ -75,10 +75,14 @@ CASES = {
     "k9_textured_aniso16": ("textured", "pt", 1, dict(tex_filter=4), False),
     "k9_textured_sky": ("textured_sky", "pt", 1, {}, False),
     "rpt_moving_instance": ("cornell_emissive", "rpt", 6, {}, False),
+    # the light quad itself moves (SceneCore::UpdateEmissivePositions): reconnections onto a moving light, light samples reused across frames
+    "rpt_moving_light": ("cornell_emissive", "rpt", 5, {}, False),
+    "di_moving_light": ("cornell_emissive", "di", 5, {}, False),
     "di_moving_instance": ("cornell_emissive", "di", 6, {}, False),
     "sdi_moving_instance": ("cornell", "sdi", 5, {}, False),
 }
-ANIMATED = {"rpt_moving_instance", "di_moving_instance", "sdi_moving_instance"}
+ANIMATED = {"rpt_moving_instance", "di_moving_instance", "sdi_moving_instance", "rpt_moving_light", "di_moving_light"}
+MOVING_LIGHT = {"rpt_moving_light", "di_moving_light"}
 RPT_PLANES = ("A", "B", "C", "D", "E", "F", "G", "neighbor", "map_ctn", "map_ntc")      # + the K12 thread maps of the last frame
 PLANES = {"rpt": RPT_PLANES, "gi": ("A", "B", "C"), "di": ("A", "B"), "sdi": ("A", "B", "C"), "pt": ()}
 
@@ -91,12 +95,18 @@ def animated_instance(sc):
     return cand[-1]
 
 
+def light_instance(sc):
+    """the instance that carries the emissive triangles (the Cornell box's light quad)"""
+    return [i for i in range(len(sc.instances)) if sc.instances["base_emissive_tri_offset"][i] != 0xFFFFFFFF][0]
+
+
 class Animator:
     """per-frame instance updates of an animated case: call step(f) before rendering frame f >= 2; returns (instances, instance_to_world)"""
 
-    def __init__(self, sc):
+    def __init__(self, sc, light=False):
         import math
-        self.sc, self.idx, self.xf, self.math = sc, animated_instance(sc), {}, math
+        self.sc, self.idx, self.xf, self.math, self.light = sc, (light_instance(sc) if light else animated_instance(sc)), {}, math, light
+        self.emissive_update = None      # (first, records) of the last step when the light moves
         self.t0 = sc.instances["translation"][self.idx].copy()
 
     def step(self, f):
@@ -105,8 +115,22 @@ class Animator:
         if 2 <= f <= 4:
             t = self.t0 + np.array([0.06 * (f - 1), 0.0, 0.03 * (f - 1)], np.float32)
             a = 0.15 * (f - 1)
-            return scene_io.move_instance(self.sc, self.idx, translation=t, rotation=np.array([0, m.sin(a / 2), 0, m.cos(a / 2)], np.float32), xform_of=self.xf)
+            q = np.array([0, m.sin(a / 2), 0, m.cos(a / 2)], np.float32)
+            if self.light:
+                inst, xw, first, tris = scene_io.move_emissive_instance(self.sc, self.idx, translation=t, rotation=q, xform_of=self.xf)
+                self.emissive_update = (first, tris.copy())
+                return inst, xw
+            return scene_io.move_instance(self.sc, self.idx, translation=t, rotation=q, xform_of=self.xf)
+        self.emissive_update = None
         return scene_io.move_instance(self.sc, self.idx, xform_of=self.xf)
+
+    def apply(self, f, *scenes):
+        """step(f) + hand the updates to every scene object (update_emissives before update_instances)"""
+        inst, xw = self.step(f)
+        for q in scenes:
+            if self.emissive_update is not None:
+                q.update_emissives(self.emissive_update[1], self.emissive_update[0])
+            q.update_instances(inst, xw)
 
 
 def frames_of(case):
