@@ -35,6 +35,9 @@ static constexpr int kRptBlock = ZR_RPT_BLOCK;
 #ifndef ZR_WAVES_PATHTRACE
 #define ZR_WAVES_PATHTRACE ZR_WAVES(4)
 #endif
+#ifndef ZR_WAVES_PATHTRACE_LARGE
+#define ZR_WAVES_PATHTRACE_LARGE ZR_WAVES(4)      // k_rpt_pathtrace_w4: scenes whose BVH does not fit the caches
+#endif
 #ifndef ZR_WAVES_RGI
 #define ZR_WAVES_RGI ZR_WAVES(4)
 #endif
@@ -175,15 +178,16 @@ __global__ void __launch_bounds__(kRptBlock) ZR_WAVES_PATHTRACE k_rpt_pathtrace(
 // traversal is latency-bound and the extra wave hides more than the spills cost (380 k-triangle atrium: 11.7 -> 10.6 ms; on the
 // 58-triangle Cornell box both take 1.16 ms, and the 3-wave build moves 5x less spill traffic, so small scenes keep it).
 template<bool EMISSIVE>
-__global__ void __launch_bounds__(kRptBlock) ZR_WAVES(4) k_rpt_pathtrace_w4(rpt::RptFrame F, zr_frame_constants g, uint32_t tilesX, unsigned long long* counters)
+__global__ void __launch_bounds__(kRptBlock) ZR_WAVES_PATHTRACE_LARGE k_rpt_pathtrace_w4(rpt::RptFrame F, zr_frame_constants g, uint32_t tilesX, unsigned long long* counters)
 { RptPathtraceBody<EMISSIVE, false>(F, g, tilesX, counters); }
-// The TEXTURED permutation at 4 waves per SIMD as well: 11.99 -> 10.28 ms on the textured atrium (2 waves by default, 255 VGPRs; a minimum of
-// 3 gives 10.74).  Round 1 found that forcing it to exactly 3 waves (amdgpu_waves_per_eu(3, 3): ~150 spilled VGPRs) makes ROCm 7.2's clang
-// miscompile the <sun + sky, textured> instance -- the y / z components of the reconnection radiance rc.L of case-1 samples were written as
-// 0 in ~70 % of the pixels; the (4, 4) build passes the same 15 textured parity tests that caught it
-// (tests/test_gpu_parity.py::test_textured_integrators_on_gpu, the *_textured reference-pass cases; scripts/gpu_tex.sh).
+// The TEXTURED permutation at 6 waves per SIMD: its dependent texel gathers are latency that more waves hide -- textured atrium 11.99 ms at the
+// compiler's 2 waves (255 VGPRs), 10.74 at >= 3, 10.28 at 4, 10.11 at 5, **9.36 at 6**, 9.69 at 7, 9.96 at 8 (scripts/gpu_tex.sh, gpu_waves.sh); the
+// untextured large-scene build stays at 4 (5: 8.49, 6: 8.35 against 8.02 ms).  Round 1 found that forcing it to exactly 3 waves
+// (amdgpu_waves_per_eu(3, 3): ~150 spilled VGPRs) makes ROCm 7.2's clang miscompile the <sun + sky, textured> instance -- the y / z components
+// of the reconnection radiance rc.L of case-1 samples were written as 0 in ~70 % of the pixels; the builds above all pass the 15 textured parity
+// tests that caught it (tests/test_gpu_parity.py::test_textured_integrators_on_gpu, the *_textured reference-pass cases).
 #ifndef ZR_WAVES_PATHTRACE_TEX
-#define ZR_WAVES_PATHTRACE_TEX ZR_WAVES(4)
+#define ZR_WAVES_PATHTRACE_TEX ZR_WAVES(6)
 #endif
 template<bool EMISSIVE>
 __global__ void __launch_bounds__(kRptBlock) ZR_WAVES_PATHTRACE_TEX k_rpt_pathtrace_tex(rpt::RptFrame F, zr_frame_constants g, uint32_t tilesX, unsigned long long* counters)
