@@ -204,7 +204,10 @@ __global__ void __launch_bounds__(kBlock) k_pt_shade(SceneView sc, zr_frame_cons
 { PtShadeBody<false>(sc, g, prm, in, inCount, out, outCount, outRays, cap, finalRGBA, firstBOP, groupMax); }
 // textured permutation: 258 VGPRs by default = 1 wave per SIMD; asking for 2 costs 2 registers and takes the atrium's shade
 // stage from 8.6 to 5.6 ms per frame (the same request on the untextured kernel, 246 VGPRs, made it 10 % slower -- not applied)
-__global__ void __launch_bounds__(kBlock) ZR_WAVES_MIN(2) k_pt_shade_tex(SceneView sc, zr_frame_constants g, PtParams prm, PathQueue in, const uint32_t* inCount,
+#ifndef ZR_WAVES_PT_SHADE_TEX
+#define ZR_WAVES_PT_SHADE_TEX ZR_WAVES_MIN(2)
+#endif
+__global__ void __launch_bounds__(kBlock) ZR_WAVES_PT_SHADE_TEX k_pt_shade_tex(SceneView sc, zr_frame_constants g, PtParams prm, PathQueue in, const uint32_t* inCount,
     PathQueue out, uint32_t* outCount, uint32_t* outRays, uint32_t cap, float* finalRGBA, const F4* firstBOP, uint32_t* groupMax)
 { PtShadeBody<true>(sc, g, prm, in, inCount, out, outCount, outRays, cap, finalRGBA, firstBOP, groupMax); }
 
@@ -445,32 +448,37 @@ __global__ void __launch_bounds__(kDiBlock) ZR_WAVES_RDI_S k_rdi_spatial(rdi::Di
 // ------------------------------------------------------------------------------------------------ ReSTIR GI kernel
 // K10: one 8x8 pixel group per wave, bounce loop in lockstep around the Russian-roulette wave max, then temporal resampling
 // and the boiling-suppression wave sum (zr_rgi.h)
-template<bool TEX>
-__global__ void __launch_bounds__(kRgiBlock) ZR_WAVES_RGI k_rgi(rgi::GiFrame F, zr_frame_constants g, uint32_t tilesX, unsigned long long* counters)
-{
-    F.prm.textured = TEX;
-    uint32_t x, y; PixelOfThreadB<kRgiBlock>(tilesX, F.ox0, F.oy0, &x, &y);
-    ZR_TRAV_STACK_B(stack, kRgiBlock);
-    uint32_t cnt[2] = {0u, 0u};
-    rgi::Lane P;
-    rgi::InitLane(F, g, x, y, stack, cnt, P);
-    for (;;)
-    {
-        const bool any = __ballot(P.active) != 0;
-        rgi::PhaseA(F, g, stack, cnt, P);
-        if (!any) break;
-        uint32_t key = rgi::RRKey(P);
-        if (__ballot(key != 0) != 0)
-        {
-            for (int s = 1; s < 64; s <<= 1) { uint32_t o = __shfl_xor(key, s); key = o > key ? o : key; }
-        }
-        rgi::PhaseB(F, g, stack, cnt, P, key);
-    }
-    const float w = rgi::FinishAndResample(F, g, stack, cnt, P);
-    const float waveSum = WaveSumButterfly(w);
-    rgi::SuppressAndWrite(F, P, waveSum);
+// (the kernel body as a macro: routing both kernels through one inline function taking the frame by reference cost the untextured one 4 %)
+#define ZR_RGI_KERNEL_BODY(TEX) \
+    F.prm.textured = TEX; \
+    uint32_t x, y; PixelOfThreadB<kRgiBlock>(tilesX, F.ox0, F.oy0, &x, &y); \
+    ZR_TRAV_STACK_B(stack, kRgiBlock); \
+    uint32_t cnt[2] = {0u, 0u}; \
+    rgi::Lane P; \
+    rgi::InitLane(F, g, x, y, stack, cnt, P); \
+    for (;;) \
+    { \
+        const bool any = __ballot(P.active) != 0; \
+        rgi::PhaseA(F, g, stack, cnt, P); \
+        if (!any) break; \
+        uint32_t key = rgi::RRKey(P); \
+        if (__ballot(key != 0) != 0) \
+        { \
+            for (int s = 1; s < 64; s <<= 1) { uint32_t o = __shfl_xor(key, s); key = o > key ? o : key; } \
+        } \
+        rgi::PhaseB(F, g, stack, cnt, P, key); \
+    } \
+    const float w = rgi::FinishAndResample(F, g, stack, cnt, P); \
+    const float waveSum = WaveSumButterfly(w); \
+    rgi::SuppressAndWrite(F, P, waveSum); \
     FlushRayCounters(counters, cnt);
-}
+__global__ void __launch_bounds__(kRgiBlock) ZR_WAVES_RGI k_rgi(rgi::GiFrame F, zr_frame_constants g, uint32_t tilesX, unsigned long long* counters)
+{ ZR_RGI_KERNEL_BODY(false) }
+// the TEXTURED permutation hides its texel-gather latency with more waves, like K11's (textured atrium: 12.12 ms at 4 waves, 11.42 at 5, 10.96 at 6;
+// the untextured kernel is best at 4; scripts/gpu_waves2.sh)
+__global__ void __launch_bounds__(kRgiBlock) ZR_WAVES(6) k_rgi_tex(rgi::GiFrame F, zr_frame_constants g, uint32_t tilesX, unsigned long long* counters)
+{ ZR_RGI_KERNEL_BODY(true) }
+#undef ZR_RGI_KERNEL_BODY
 
 // ------------------------------------------------------------------------------------------------ host objects
 template<typename T> struct DevBuf
@@ -1673,7 +1681,7 @@ static int RenderReSTIR_GI(zr_pass* p, hipStream_t s, const zr_frame_constants* 
     if (prm.useLVG && !sc->view.lvg) return Fail(ZR_ERR_NOT_INITIALIZED, "light voxel grid missing: render the PRELIGHTING pass with use_lvg first");
     const uint32_t tilesX = (F.ow + 15) / 16, tilesY = (F.oh + 15) / 16;
     TimerBegin(p, s, "rgi");
-    hipLaunchKernelGGL(sc->view.tex.count ? k_rgi<true> : k_rgi<false>, dim3(tilesX * tilesY * (256 / kRgiBlock)), dim3(kRgiBlock), 0, s, F, *cb, tilesX, p->counters.p + 2 * 10);
+    hipLaunchKernelGGL(sc->view.tex.count ? k_rgi_tex : k_rgi, dim3(tilesX * tilesY * (256 / kRgiBlock)), dim3(kRgiBlock), 0, s, F, *cb, tilesX, p->counters.p + 2 * 10);
     TimerEnd(p, s);
     HIP_TRY(hipGetLastError());
     p->temporalValid = true;
