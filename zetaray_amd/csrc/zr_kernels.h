@@ -29,7 +29,9 @@ static constexpr int kRptBlock = ZR_RPT_BLOCK;
 // 0.49 ms.  k_rpt_stc, k_pt_shade and k_sdi_temporal got slower with more waves and keep the default.
 // Re-measured in round 2 after the traversal changes (2-triangle leaves, whole-leaf triangle phase): k_rpt_pathtrace 3 -> 4 waves 1.013 -> 1.000 ms
 // (5: 1.17), k_rpt_temporal default -> 4 waves 0.546 -> 0.536 ms / atrium 3.53 -> 3.27 ms (3: 0.57, 5: 0.70, 6: 0.82), k_rpt_stc 3 / 5 waves 0.77 / 0.72
-// against 0.64 at its natural 4, k_rgi 3 / 5 waves 1.37 / 1.45 against 1.30 at 4.
+// against 0.64 at its natural 4, k_rgi 3 / 5 waves 1.37 / 1.45 against 1.30 at 4.  The TEXTURED permutations of the path-tracing kernels want more (K11 6,
+// k_rgi_tex 6: texel-gather latency); the reconnect kernels do not even there (textured atrium, 5 / 6 waves: temporal 3.92 / 4.06 against 3.62 ms, K16
+// 2.93 / 3.48 against 2.82), nor does the textured K9 shade kernel (4 / 6 waves: 6.0 / 8.7 against 5.2 ms at >= 2).
 #define ZR_WAVES(n) __attribute__((amdgpu_waves_per_eu(n, n)))
 #define ZR_WAVES_MIN(n) __attribute__((amdgpu_waves_per_eu(n)))
 #ifndef ZR_WAVES_PATHTRACE
