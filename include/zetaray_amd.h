@@ -252,6 +252,10 @@ int zr_scene_update_instances(zr_scene* scene, const zr_mesh_instance* instances
  * PreLighting.cpp:266); presampled sets and the light voxel grid pick the new positions up on the next PRELIGHTING render.
  * Host call between frames (waits for the device). */
 int zr_scene_update_emissives(zr_scene* scene, const zr_emissive_triangle* triangles, uint32_t first, uint32_t count);
+/* Emissive MATERIALS changed (SceneCore::UpdateEmissiveMaterial: factor / strength rewritten in the records handed to zr_scene_update_emissives;
+ * Scene::AreEmissiveMaterialsStale, PreLighting.cpp:266): drops the alias table, so that the next ZR_PASS_PRELIGHTING render re-estimates the
+ * triangle powers (K2) and rebuilds it. */
+int zr_scene_invalidate_alias_table(zr_scene* scene);
 /* EmissiveTriangleAliasTable::Render (PreLighting.cpp:512-585): upload a host-built table ... */
 int zr_scene_set_alias_table(zr_scene* scene, const zr_alias_entry* entries, uint32_t n);
 /* ... or build it from per-triangle power exactly like PreLighting.cpp:27-158 (host side, bit-exact) */

@@ -143,6 +143,12 @@ class OracleScene:
                             C.c_uint32(len(uv)), out.ctypes.data_as(C.c_void_p))
         return out
 
+    def rebuild_alias_table(self):
+        """emissive materials changed (zr_scene_invalidate_alias_table + the next PRELIGHTING render): K2 + the alias-table build again"""
+        self.power = self.estimate_power()
+        self.alias = alias_table_build(self.power)
+        lib().zro_scene_set_alias_table(self.h, self.alias.ctypes.data, len(self.alias))
+
     def estimate_power(self):
         out = np.zeros(len(self.scene.emissives), np.float32)
         lib().zro_estimate_power(self.h, out.ctypes.data)

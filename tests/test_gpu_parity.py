@@ -1097,3 +1097,36 @@ def test_moving_light_on_gpu(api):
                 a_, b_ = a_ & 0xffffff, b_ & 0xffffff
             assert np.array_equal(a_.view(np.uint8), b_.view(np.uint8)), f"frame {f}: reservoir plane {nm}"
     assert not np.array_equal(before.view(np.uint8), sc.emissives.view(np.uint8))      # the light really moved
+
+
+def test_emissive_material_change_rebuilds_the_alias_table(api):
+    """SceneCore::UpdateEmissiveMaterial + PreLighting's stale-materials path (PreLighting.cpp:266): one of the Cornell light's two triangles gets
+    8 x its strength at frame 3 (zr_scene_update_emissives with the rewritten record, zr_scene_invalidate_alias_table); the next PRELIGHTING render
+    re-estimates the powers (K2) and rebuilds the table -- alias table, ReSTIR DI and ReSTIR PT equal the oracle's before and after."""
+    from oracle import zro
+    sc = scene_io.load_npz(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "cornell_emissive.npz"))
+    w, h = 96, 64
+    prm, dprm = wire.default_params(), wire.default_params_di()
+    r = api.Renderer(sc, w, h, params=prm, integrator=api.INTEGRATOR_RESTIR_PT)
+    di = r.enable_direct(dprm)
+    osc = zro.OracleScene(sc)
+    opt, odi = zro.OracleRPT(osc, w, h), zro.OracleRDI(osc, w, h)
+    tables = []
+    for f in range(1, 5):
+        if f == 3:
+            e = sc.emissives[0:1].copy()
+            s_old = np.uint16(int(e["packed_b"][0]) >> 16).view(np.float16)
+            s_new = int(np.float16(np.float32(s_old) * np.float32(8.0)).view(np.uint16))
+            e["packed_b"] = (int(e["packed_b"][0]) & 0xFFFF) | (s_new << 16)
+            e["packed_a"] = (int(e["packed_a"][0]) & 0x0FFFFFFF) | ((s_new & 0xF) << 28)
+            sc.emissives[0:1] = e
+            r.scene.update_emissives(e, 0); r.invalidate_alias_table()
+            osc.update_emissives(e, 0); osc.rebuild_alias_table()
+        cb = _frame(sc, w, h, f)
+        r.render_frame(cb)
+        tables.append(r.scene.get_alias_table().copy())
+        assert np.array_equal(tables[-1].view(np.uint8), np.asarray(osc.alias).view(np.uint8)), f"frame {f}: alias table"
+        want, want_di = opt.render(cb, prm), odi.render(cb, dprm)
+        assert np.array_equal(r.final().view(np.uint32), want.view(np.uint32)), f"frame {f}: ReSTIR PT"
+        assert np.array_equal(di.download().view(np.uint32), want_di.view(np.uint32)), f"frame {f}: ReSTIR DI"
+    assert np.array_equal(tables[0].view(np.uint8), tables[1].view(np.uint8)) and not np.array_equal(tables[1].view(np.uint8), tables[2].view(np.uint8))

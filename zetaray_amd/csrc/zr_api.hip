@@ -1054,6 +1054,15 @@ int zr_scene_update_emissives(zr_scene* s, const zr_emissive_triangle* triangles
     HIP_TRY(hipMemcpy(s->emissives.p + first, triangles, (size_t)count * sizeof(zr_emissive_triangle), hipMemcpyHostToDevice));
     return ZR_OK;
 }
+int zr_scene_invalidate_alias_table(zr_scene* s)
+{
+    if (!s) return Fail(ZR_ERR_INVALID_ARG, "zr_scene_invalidate_alias_table: null argument");
+    HIP_TRY(hipSetDevice(s->device));
+    HIP_TRY(hipDeviceSynchronize());           // kernels of earlier frames may still sample through the table
+    std::lock_guard<std::mutex> lock(s->mtx);
+    s->view.alias = nullptr; s->aliasHost.clear();
+    return ZR_OK;
+}
 int zr_scene_update_instances(zr_scene* s, const zr_mesh_instance* instances, const float* instance_to_world, uint32_t n)
 {
     if (!s || !instances || !instance_to_world) return Fail(ZR_ERR_INVALID_ARG, "zr_scene_update_instances: null argument");
@@ -1525,8 +1534,8 @@ static int RenderPreLightingInner(zr_pass* p, hipStream_t s, const zr_frame_cons
 {
     const uint32_t n = sc->view.numEmissives;
     if (n == 0) return ZR_OK;
-    // the alias table is built once per emissive set (EmissiveTriangleAliasTable is only re-run when emissives change);
-    // zr_scene_set_alias_table(…, 0 entries) or a new scene forces a rebuild
+    // the alias table is built once per emissive set (EmissiveTriangleAliasTable is only re-run when emissive materials change):
+    // zr_scene_invalidate_alias_table or a new scene forces a rebuild
     if (sc->view.alias) return p->params.presampling ? RenderPresample(p, s, cb, sc) : ZR_OK;
     int r = p->power.Alloc(n);
     if (r) return r;
