@@ -256,6 +256,9 @@ int zr_scene_update_emissives(zr_scene* scene, const zr_emissive_triangle* trian
  * Scene::AreEmissiveMaterialsStale, PreLighting.cpp:266): drops the alias table, so that the next ZR_PASS_PRELIGHTING render re-estimates the
  * triangle powers (K2) and rebuilds it. */
 int zr_scene_invalidate_alias_table(zr_scene* scene);
+/* Material edits (SceneCore::UpdateMaterial: the material buffer entry is rewritten and re-uploaded): replaces `count` records of the scene's
+ * material buffer from index `first`.  Texture indices must stay inside the scene's texture heap.  Host call between frames (waits for the device). */
+int zr_scene_update_materials(zr_scene* scene, const zr_material* materials, uint32_t first, uint32_t count);
 /* EmissiveTriangleAliasTable::Render (PreLighting.cpp:512-585): upload a host-built table ... */
 int zr_scene_set_alias_table(zr_scene* scene, const zr_alias_entry* entries, uint32_t n);
 /* ... or build it from per-triangle power exactly like PreLighting.cpp:27-158 (host side, bit-exact) */

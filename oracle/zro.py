@@ -143,6 +143,12 @@ class OracleScene:
                             C.c_uint32(len(uv)), out.ctypes.data_as(C.c_void_p))
         return out
 
+    def update_materials(self, materials, first=0):
+        """zr_scene_update_materials on the oracle"""
+        m = np.ascontiguousarray(materials)
+        lib().zro_scene_update_materials.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32]
+        assert lib().zro_scene_update_materials(self.h, m.ctypes.data, first, len(m)) == 0
+
     def rebuild_alias_table(self):
         """emissive materials changed (zr_scene_invalidate_alias_table + the next PRELIGHTING render): K2 + the alias-table build again"""
         self.power = self.estimate_power()

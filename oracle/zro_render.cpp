@@ -927,6 +927,14 @@ int zro_scene_update_emissives(zro_scene* h, const zr_emissive_triangle* tris, u
     if (h->prevHolder) std::copy(tris, tris + count, h->prevHolder->emissives.begin() + first);
     return 0;
 }
+// zr_scene_update_materials (one material buffer, shared with the previous-frame view)
+int zro_scene_update_materials(zro_scene* h, const zr_material* m, uint32_t first, uint32_t count)
+{
+    if ((size_t)first + count > h->s.materials.size()) return -1;
+    std::copy(m, m + count, h->s.materials.begin() + first);
+    if (h->prevHolder) std::copy(m, m + count, h->prevHolder->materials.begin() + first);
+    return 0;
+}
 int zro_scene_num_tris(const zro_scene* h) { return (int)h->s.tris.size(); }
 
 int zro_kahan_sum(const float* data, uint64_t n, uint32_t align_phase, float* out)

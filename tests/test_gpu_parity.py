@@ -1130,3 +1130,37 @@ def test_emissive_material_change_rebuilds_the_alias_table(api):
         assert np.array_equal(r.final().view(np.uint32), want.view(np.uint32)), f"frame {f}: ReSTIR PT"
         assert np.array_equal(di.download().view(np.uint32), want_di.view(np.uint32)), f"frame {f}: ReSTIR DI"
     assert np.array_equal(tables[0].view(np.uint8), tables[1].view(np.uint8)) and not np.array_equal(tables[1].view(np.uint8), tables[2].view(np.uint8))
+
+
+def test_material_edit_between_frames(api):
+    """SceneCore::UpdateMaterial: at frame 3 every non-emissive material of the Cornell box turns into a rough metal with another base colour
+    (zr_scene_update_materials); G-buffer, ReSTIR PT and ReSTIR DI equal the oracle's before and after (temporal reuse across the edit included)."""
+    from oracle import zro
+    sc = scene_io.load_npz(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "cornell_emissive.npz"))
+    w, h = 96, 64
+    prm, dprm = wire.default_params(), wire.default_params_di()
+    r = api.Renderer(sc, w, h, params=prm, integrator=api.INTEGRATOR_RESTIR_PT)
+    di = r.enable_direct(dprm)
+    osc = zro.OracleScene(sc)
+    opt, odi = zro.OracleRPT(osc, w, h), zro.OracleRDI(osc, w, h)
+    imgs = []
+    for f in range(1, 5):
+        if f == 3:
+            mats = sc.materials.copy()
+            for i in range(1, len(mats)):
+                if int(mats[i]["emissive_factor_normal_scale"]) & 0xFFFFFF:
+                    continue      # the light keeps its material (its power enters the alias table)
+                mats[i] = scene_io.pack_material(base_color=(0.2 + 0.1 * (i % 5), 0.7, 0.3, 1.0), metallic=1.0, roughness=0.35)
+            sc.materials[:] = mats
+            r.scene.update_materials(mats, 0); osc.update_materials(mats, 0)
+        cb = _frame(sc, w, h, f)
+        r.render_frame(cb)
+        planes, _ = r.gbuffer.download()
+        oplanes, _ = osc.gbuffer(cb)
+        for n, a, b in zip(wire.GB_PLANE_NAMES, planes, oplanes):
+            assert np.array_equal(np.asarray(a).view(np.uint8).reshape(-1), np.asarray(b).view(np.uint8).reshape(-1)), f"frame {f}: G-buffer plane {n}"
+        want, want_di = opt.render(cb, prm), odi.render(cb, dprm)
+        assert np.array_equal(r.final().view(np.uint32), want.view(np.uint32)), f"frame {f}: ReSTIR PT"
+        assert np.array_equal(di.download().view(np.uint32), want_di.view(np.uint32)), f"frame {f}: ReSTIR DI"
+        imgs.append(planes[0].copy())
+    assert not np.array_equal(np.asarray(imgs[1]), np.asarray(imgs[2]))      # the base-colour plane changed with the edit

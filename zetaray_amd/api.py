@@ -44,7 +44,7 @@ RPT_OUTPUTS = {"A": (1, np.uint32, 1), "B": (2, np.float32, 2), "C": (3, np.uint
                "ntc_A": (14, np.uint16, 4), "ntc_B": (15, np.uint32, 4), "ntc_C": (16, np.uint32, 4), "ntc_D": (17, np.uint16, 1)}
 
 EXPORTS = [
-    "zr_abi_version", "zr_last_error", "zr_device_count", "zr_wire_layout", "zr_scene_create", "zr_scene_destroy", "zr_scene_update_instances", "zr_scene_update_emissives", "zr_scene_invalidate_alias_table",
+    "zr_abi_version", "zr_last_error", "zr_device_count", "zr_wire_layout", "zr_scene_create", "zr_scene_destroy", "zr_scene_update_instances", "zr_scene_update_emissives", "zr_scene_invalidate_alias_table", "zr_scene_update_materials",
     "zr_scene_set_alias_table", "zr_alias_table_build", "zr_scene_get_alias_table", "zr_scene_get_light_voxel_grid", "zr_scene_bvh_info",
     "zr_gbuffer_create", "zr_gbuffer_destroy", "zr_gbuffer_set_tile_origin", "zr_gbuffer_download", "zr_gbuffer_device_plane",
     "zr_params_default", "zr_pass_create", "zr_pass_init", "zr_pass_resize", "zr_pass_reset_temporal",
@@ -166,6 +166,12 @@ class Scene:
         L.zr_scene_update_emissives.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32]
         t = np.ascontiguousarray(triangles, wire.EMISSIVE_TRI)
         _check(L.zr_scene_update_emissives(self.h, t.ctypes.data, first, len(t)))
+
+    def update_materials(self, materials, first=0):
+        """rewritten Material records for [first, first + len(materials))"""
+        lib().zr_scene_update_materials.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32]
+        m = np.ascontiguousarray(materials, wire.MATERIAL)
+        _check(lib().zr_scene_update_materials(self.h, m.ctypes.data, first, len(m)))
 
     def invalidate_alias_table(self):
         """emissive materials changed: the next PRELIGHTING render re-estimates the powers and rebuilds the alias table"""

@@ -1054,6 +1054,16 @@ int zr_scene_update_emissives(zr_scene* s, const zr_emissive_triangle* triangles
     HIP_TRY(hipMemcpy(s->emissives.p + first, triangles, (size_t)count * sizeof(zr_emissive_triangle), hipMemcpyHostToDevice));
     return ZR_OK;
 }
+int zr_scene_update_materials(zr_scene* s, const zr_material* materials, uint32_t first, uint32_t count)
+{
+    if (!s || (!materials && count)) return Fail(ZR_ERR_INVALID_ARG, "zr_scene_update_materials: null argument");
+    if ((uint64_t)first + count > s->materials.n) return Fail(ZR_ERR_INVALID_ARG, "zr_scene_update_materials: [%u, %u) exceeds the scene's %zu materials", first, first + count, s->materials.n);
+    if (!count) return ZR_OK;
+    HIP_TRY(hipSetDevice(s->device));
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(s->materials.p + first, materials, (size_t)count * sizeof(zr_material), hipMemcpyHostToDevice));
+    return ZR_OK;
+}
 int zr_scene_invalidate_alias_table(zr_scene* s)
 {
     if (!s) return Fail(ZR_ERR_INVALID_ARG, "zr_scene_invalidate_alias_table: null argument");
