@@ -391,7 +391,7 @@ def main():
             # kernel names as rocprofv3 prints them (template arguments: NEE_EMISSIVE, TEXTURED)
             kmap = {"rpt_pathtrace": ["k_rpt_pathtrace<true>", "k_rpt_pathtrace_w4<true>"],
                     "rpt_reconnect_spatial": ["k_rpt_stc<true, false>"], "rpt_reconnect_temporal": ["k_rpt_temporal<true, false>"],
-                    "gbuffer": ["k_gbuffer"], "rgi": ["k_rgi<false>"], "trace": ["k_trace_simple", "k_trace"], "pt_shade": ["k_pt_shade"]}
+                    "gbuffer": ["k_gbuffer"], "rgi": ["k_rgi", "k_rgi_tex", "k_rgi<false>"], "trace": ["k_trace_simple", "k_trace"], "pt_shade": ["k_pt_shade"]}
             table = json.load(open(os.path.join(ROOT, pmc_rel)))
             # the launch-count filter drops a kernel variant that only ran during warm-up
             cands = [table[k] for k in kmap.get(dom, []) if k in table]

@@ -34,8 +34,10 @@ static constexpr int kRptBlock = ZR_RPT_BLOCK;
 // 2.93 / 3.48 against 2.82), nor does the textured K9 shade kernel (4 / 6 waves: 6.0 / 8.7 against 5.2 ms at >= 2).
 #define ZR_WAVES(n) __attribute__((amdgpu_waves_per_eu(n, n)))
 #define ZR_WAVES_MIN(n) __attribute__((amdgpu_waves_per_eu(n)))
+// (with one-wave blocks 3 and 4 waves tie on small scenes -- 0.945 / 0.950 ms Cornell, 5: 1.12 -- and 3 waves spill a third of the bytes (PMC: 0.56 GB per
+// launch against 1.44 GB), so scenes whose BVH fits the caches run at 3; large scenes take k_rpt_pathtrace_w4)
 #ifndef ZR_WAVES_PATHTRACE
-#define ZR_WAVES_PATHTRACE ZR_WAVES(4)
+#define ZR_WAVES_PATHTRACE ZR_WAVES(3)
 #endif
 #ifndef ZR_WAVES_PATHTRACE_LARGE
 #define ZR_WAVES_PATHTRACE_LARGE ZR_WAVES(4)      // k_rpt_pathtrace_w4: scenes whose BVH does not fit the caches
