@@ -16,7 +16,8 @@ namespace hlsl {
 
 struct GroupRunner
 {
-    static constexpr int kWave = 64;
+    int kWave = 64;                          // lanes per wave: 64 (wave64 hardware) unless the shader pins [WaveSize(32)] (EstimateTriEmissivePower.hlsl)
+    bool sumAscending = false;               // float WaveActiveSum in ascending lane order instead of the xor butterfly (the ABI's definition for K2)
     static constexpr size_t kStack = 1 << 20;
     enum Scope { NONE, WAVE, GROUP };
     struct Lane
@@ -88,8 +89,8 @@ struct GroupRunner
 };
 
 static inline GroupRunner* GR() { return GroupRunner::Current(); }
-static inline uint32_t WaveGetLaneCount() { return GroupRunner::kWave; }
-static inline uint32_t WaveGetLaneIndex() { GroupRunner* g = GR(); return g ? (uint32_t)(g->cur % GroupRunner::kWave) : 0u; }
+static inline uint32_t WaveGetLaneCount() { GroupRunner* g = GR(); return g ? (uint32_t)g->kWave : 64u; }
+static inline uint32_t WaveGetLaneIndex() { GroupRunner* g = GR(); return g ? (uint32_t)(g->cur % g->kWave) : 0u; }
 static inline void GroupMemoryBarrierWithGroupSync() { if (GroupRunner* g = GR()) g->Park(GroupRunner::GROUP); }
 static inline void GroupMemoryBarrier() {}
 static inline void DeviceMemoryBarrier() {}
@@ -116,7 +117,8 @@ static inline float WaveActiveSum(float x)
     GroupRunner* g = GR(); if (!g) return x;
     uint32_t u = zr_asuint(x); WaveRendezvous(&u, 1);
     float v[64]; const int b = g->WaveBase();
-    for (int i = 0; i < 64; i++) v[i] = (b + i < g->n && g->snapActive[b + i]) ? zr_asfloat(g->snapU[4 * (b + i)]) : 0.0f;
+    for (int i = 0; i < 64; i++) v[i] = (i < g->kWave && b + i < g->n && g->snapActive[b + i]) ? zr_asfloat(g->snapU[4 * (b + i)]) : 0.0f;
+    if (g->sumAscending) { float acc = 0.0f; for (int i = 0; i < g->kWave; i++) acc += v[i]; return acc; }
     return ButterflySum64(v);
 }
 static inline uint32_t WaveActiveSum(uint32_t x)
@@ -124,7 +126,7 @@ static inline uint32_t WaveActiveSum(uint32_t x)
     GroupRunner* g = GR(); if (!g) return x;
     WaveRendezvous(&x, 1);
     uint32_t s = 0; const int b = g->WaveBase();
-    for (int i = 0; i < 64 && b + i < g->n; i++) if (g->snapActive[b + i]) s += g->snapU[4 * (b + i)];
+    for (int i = 0; i < g->kWave && b + i < g->n; i++) if (g->snapActive[b + i]) s += g->snapU[4 * (b + i)];
     return s;
 }
 static inline int WaveActiveSum(int x) { return (int)WaveActiveSum((uint32_t)x); }
@@ -134,7 +136,7 @@ static inline uint4 WaveMatch(uint32_t x)
     GroupRunner* g = GR(); if (!g) return uint4(1u, 0u, 0u, 0u);
     WaveRendezvous(&x, 1);
     uint32_t m[4] = {0, 0, 0, 0}; const int b = g->WaveBase();
-    for (int i = 0; i < 64 && b + i < g->n; i++) if (g->snapActive[b + i] && g->snapU[4 * (b + i)] == x) m[i >> 5] |= 1u << (i & 31);
+    for (int i = 0; i < g->kWave && b + i < g->n; i++) if (g->snapActive[b + i] && g->snapU[4 * (b + i)] == x) m[i >> 5] |= 1u << (i & 31);
     return uint4(m[0], m[1], m[2], m[3]);
 }
 static inline uint32_t WaveActiveSum(bool x) { return WaveActiveSum((uint32_t)(x ? 1u : 0u)); }
@@ -145,7 +147,7 @@ static inline float WaveActiveMax(float x)
     GroupRunner* g = GR(); if (!g) return x;
     uint32_t u = zr_asuint(x); WaveRendezvous(&u, 1, 0);
     const int b = g->WaveBase(); bool first = true; float m = 0.0f;
-    for (int i = 0; i < 64 && b + i < g->n; i++) if (g->snapActive[b + i]) { float v = zr_asfloat(g->snapU[4 * (b + i)]); m = first ? v : zr_max(m, v); first = false; }
+    for (int i = 0; i < g->kWave && b + i < g->n; i++) if (g->snapActive[b + i]) { float v = zr_asfloat(g->snapU[4 * (b + i)]); m = first ? v : zr_max(m, v); first = false; }
     return m;
 }
 static inline uint32_t WaveActiveMax(uint32_t x)
@@ -153,7 +155,7 @@ static inline uint32_t WaveActiveMax(uint32_t x)
     GroupRunner* g = GR(); if (!g) return x;
     WaveRendezvous(&x, 1);
     const int b = g->WaveBase(); uint32_t m = 0;
-    for (int i = 0; i < 64 && b + i < g->n; i++) if (g->snapActive[b + i]) m = g->snapU[4 * (b + i)] > m ? g->snapU[4 * (b + i)] : m;
+    for (int i = 0; i < g->kWave && b + i < g->n; i++) if (g->snapActive[b + i]) m = g->snapU[4 * (b + i)] > m ? g->snapU[4 * (b + i)] : m;
     return m;
 }
 static inline bool WaveActiveAnyTrue(bool x) { return WaveActiveSum((uint32_t)(x ? 1u : 0u)) != 0; }
@@ -175,7 +177,7 @@ static inline bool WaveIsFirstLane()
     GroupRunner* g = GR(); if (!g) return true;
     uint32_t z = 0; WaveRendezvous(&z, 1);
     const int b = g->WaveBase();
-    for (int i = 0; i < 64 && b + i < g->n; i++) if (g->snapActive[b + i]) return b + i == g->cur;
+    for (int i = 0; i < g->kWave && b + i < g->n; i++) if (g->snapActive[b + i]) return b + i == g->cur;
     return true;
 }
 template<class T> static inline T WaveReadLaneAt(T x, uint32_t lane)
@@ -190,7 +192,7 @@ template<class T> static inline T WaveReadLaneFirst(T x)
     GroupRunner* g = GR(); if (!g) return x;
     uint32_t u[4] = {0, 0, 0, 0}; memcpy(u, &x, sizeof(T)); WaveRendezvous(u, 4);
     const int b = g->WaveBase();
-    for (int i = 0; i < 64 && b + i < g->n; i++) if (g->snapActive[b + i]) { T r; memcpy(&r, &g->snapU[4 * (b + i)], sizeof(T)); return r; }
+    for (int i = 0; i < g->kWave && b + i < g->n; i++) if (g->snapActive[b + i]) { T r; memcpy(&r, &g->snapU[4 * (b + i)], sizeof(T)); return r; }
     return x;
 }
 // atomics on groupshared / UAV memory: lanes of a group are fibers of one OS thread, so plain read-modify-write is atomic here
