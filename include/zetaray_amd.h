@@ -266,6 +266,8 @@ int zr_alias_table_build(const float* power, uint32_t n, uint32_t align_phase, z
 int zr_scene_get_alias_table(const zr_scene* scene, zr_alias_entry* out_entries, uint32_t n);
 /* K4 output (PreLighting::GetLightVoxelGrid, GlobalResource::LIGHT_VOXEL_GRID): dim.x * dim.y * dim.z * 64 samples, voxel-major */
 int zr_scene_get_light_voxel_grid(const zr_scene* scene, void* hip_stream, zr_voxel_sample* out_samples, uint32_t n);
+/* K3 output (GlobalResource::PRESAMPLED_EMISSIVE_SETS, PreLighting.cpp:300-315): num_sample_sets * sample_set_size records of the last PRELIGHTING render */
+int zr_scene_get_presampled_sets(const zr_scene* scene, void* hip_stream, zr_presampled_tri* out_samples, uint32_t n);
 /* BVH introspection for tests / the CPU baseline */
 int zr_scene_bvh_info(const zr_scene* scene, uint32_t* num_nodes, uint32_t* num_tris, uint32_t* max_depth);
 

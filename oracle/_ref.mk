@@ -23,14 +23,17 @@ HLSL_ROOTS := ZetaRenderPass/Common/BSDFSampling.hlsli ZetaRenderPass/Common/RT.
     $(addprefix ZetaRenderPass/DirectLighting/,Emissive/ReSTIR_DI_Temporal.hlsl Emissive/ReSTIR_DI_Spatial.hlsl Emissive/DirectLighting_Common.h \
         Sky/SkyDI_Temporal.hlsl Sky/SkyDI_Spatial.hlsl Sky/SkyDI_Common.h) \
     $(addprefix ZetaRenderPass/AutoExposure/,AutoExposure_Histogram.hlsl AutoExposure_WeightedAvg.hlsl AutoExposure_Common.h) \
-    ZetaRenderPass/Display/Display.hlsl ZetaRenderPass/Display/Display_Common.h
+    ZetaRenderPass/Display/Display.hlsl ZetaRenderPass/Display/Display_Common.h \
+    $(addprefix ZetaRenderPass/PreLighting/,EstimateTriEmissivePower.hlsl PresampleEmissives.hlsl BuildLightVoxelGrid.hlsl PreLighting_Common.h) \
+    ZetaRenderPass/Sky/SkyViewLUT.hlsl ZetaRenderPass/Sky/Sky_Common.h \
+    $(addprefix ZetaRenderPass/Compositing/,Compositing.hlsl FireflyFilter.hlsl Compositing_Common.h) ZetaRenderPass/TAA/TAA.hlsl ZetaRenderPass/TAA/TAA_Common.h
 
 # the reference's shader PASSES compiled as C++ (one shared object per shader permutation, like the reference's .cso files):
 #   _ref/libzref_k1.so                      GBufferRT_Inline.hlsl
 #   _ref/libzref_k9_{e0,e1,e1p}.so          PathTracer.hlsl with NEE_EMISSIVE = 0 / 1 / 1 + USE_PRESAMPLED_SETS (PathTracer, _WoPS, _WPS)
 #   _ref/libzref_rpt_{e0,e1,e1p}.so         ReSTIR PT: the 10 shaders of Variants/*.hlsl per NEE permutation + the restated host sequence (ref_rpt_host.cpp)
 PASS_LIBS := _ref/libzref_k1.so _ref/libzref_k9_e0.so _ref/libzref_k9_e1.so _ref/libzref_k9_e1p.so _ref/libzref_rpt_e0.so _ref/libzref_rpt_e1.so _ref/libzref_rpt_e1p.so \
-    _ref/libzref_gi_e0.so _ref/libzref_gi_e1.so _ref/libzref_gi_e1p.so _ref/libzref_di_e1.so _ref/libzref_di_e1p.so _ref/libzref_di_sky.so _ref/libzref_post.so
+    _ref/libzref_gi_e0.so _ref/libzref_gi_e1.so _ref/libzref_gi_e1p.so _ref/libzref_di_e1.so _ref/libzref_di_e1p.so _ref/libzref_di_sky.so _ref/libzref_post.so _ref/libzref_aux.so _ref/libzref_gi_e1l.so
 PASS_HDRS := ref_hlsl/ref_pass_common.h ref_hlsl/hlsl_shim.h ref_hlsl/hlsl_resources.h ref_hlsl/hlsl_rt.h ref_hlsl/hlsl_group.h zro_scene.h
 
 all: _ref/libzref.so _ref/libzref_hlsl.so $(PASS_LIBS)
@@ -109,6 +112,8 @@ endef
 $(eval $(call gi_perm,e0,0,))
 $(eval $(call gi_perm,e1,1,))
 $(eval $(call gi_perm,e1p,1,-DUSE_PRESAMPLED_SETS))
+# Variants/ReSTIR_GI_LVG.hlsl: presampled sets + the light voxel grid (g_lvg : register(t8))
+$(eval $(call gi_perm,e1l,1,-DUSE_PRESAMPLED_SETS -DUSE_LVG))
 
 # ---- ReSTIR DI: emissive (K5 / K6: ReSTIR_DI_Temporal{,_WPS}.hlsl + ReSTIR_DI_Spatial.hlsl) and sun + sky (K7 / K8: SkyDI_Temporal.hlsl + SkyDI_Spatial.hlsl)
 DL := ZetaRenderPass/DirectLighting
@@ -149,4 +154,26 @@ _ref/obj/post_host.o: _ref/gen/.stamp ref_hlsl/ref_post_host.cpp ref_hlsl/ref_di
 	mkdir -p _ref/obj
 	$(HLSL_CXX) $(HLSL_FLAGS) -c -o $@ ref_hlsl/ref_post_host.cpp
 _ref/libzref_post.so: _ref/obj/post_ae_hist.o _ref/obj/post_ae_avg.o _ref/obj/post_display.o _ref/obj/post_host.o
+	$(HLSL_CXX) -shared -o $@ $^
+
+# ---- auxiliary passes: PreLighting (K2 / K3 / K4), SkyViewLUT (K17), Compositing + FireflyFilter, TAA -- ref_pass_aux.cpp per shader + ref_aux_host.cpp
+RP := ZetaRenderPass
+# $(call aux_obj,<tag>,<ZR_AUX>,<file>,<extra macros>)
+define aux_obj
+_ref/obj/aux_$(1).o: _ref/gen/.stamp ref_hlsl/ref_pass_aux.cpp ref_hlsl/ref_dispatch.h $(PASS_HDRS)
+	mkdir -p _ref/obj
+	$(HLSL_CXX) $(HLSL_FLAGS) -fvisibility=hidden -c -o $$@ ref_hlsl/ref_pass_aux.cpp -Dhlsl=hlsl_aux_$(1) '-DZR_SHADER="$(RP)/$(3)"' -DZR_ENTRY=zrefp_shader_$(1) -DZR_AUX=$(2) $(4)
+AUX_OBJS += _ref/obj/aux_$(1).o
+endef
+$(eval $(call aux_obj,estimate_power,1,PreLighting/EstimateTriEmissivePower.hlsl,))
+$(eval $(call aux_obj,presample,2,PreLighting/PresampleEmissives.hlsl,-DZR_LOCAL_CB=cbPresampling))
+$(eval $(call aux_obj,build_lvg,3,PreLighting/BuildLightVoxelGrid.hlsl,-DZR_LOCAL_CB=cbLVG))
+$(eval $(call aux_obj,sky_lut,4,Sky/SkyViewLUT.hlsl,-DZR_LOCAL_CB=cbSky))
+$(eval $(call aux_obj,compositing,5,Compositing/Compositing.hlsl,-DZR_LOCAL_CB=cbCompositing))
+$(eval $(call aux_obj,firefly,6,Compositing/FireflyFilter.hlsl,-DZR_LOCAL_CB=cbFireflyFilter))
+$(eval $(call aux_obj,taa,7,TAA/TAA.hlsl,-DZR_LOCAL_CB=cbTAA))
+_ref/obj/aux_host.o: _ref/gen/.stamp ref_hlsl/ref_aux_host.cpp ref_hlsl/ref_dispatch.h $(PASS_HDRS)
+	mkdir -p _ref/obj
+	$(HLSL_CXX) $(HLSL_FLAGS) -c -o $@ ref_hlsl/ref_aux_host.cpp
+_ref/libzref_aux.so: $(AUX_OBJS) _ref/obj/aux_host.o
 	$(HLSL_CXX) -shared -o $@ $^

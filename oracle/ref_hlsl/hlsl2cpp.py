@@ -237,6 +237,19 @@ SPECIAL = {
     "ReSTIR_PT_SpatialSearch.hlsl": [
         (r"const int2 samplePosSS = round\(float2\(DTid\) \+ rotated\);", "const int2 samplePosSS = int2(round(float2(DTid) + rotated));"),
     ],
+    "FireflyFilter.hlsl": [
+        # int2 compared with uint2: HLSL converts the signed side to unsigned (a negative address is "beyond" the image)
+        (r"any\(addr >= renderDim\)", "any(uint2(addr) >= renderDim)"),
+        # uint2 swizzles passed to float2 / int2 parameters
+        (r"Math::WorldPosFromScreenSpace\(DTid\.xy,", "Math::WorldPosFromScreenSpace(float2(DTid.xy),"),
+        (r"FilterFirefly\(g_composited, color, DTid\.xy, GTid\.xy,", "FilterFirefly(g_composited, color, int2(DTid.xy), int2(GTid.xy),"),
+    ],
+    "TAA.hlsl": [
+        (r"int2 closestDepthAddress = [^;]*;", "int2 closestDepthAddress = int2(0);"),
+        # uint2 + int2 (HLSL: unsigned arithmetic, then back to int2 -- the same bits)
+        (r"DTid\.xy \+ int2\(i, j\)", "int2(DTid.xy) + int2(i, j)"),
+        (r"DTid\.xy \+ closestDepthAddress", "int2(DTid.xy) + closestDepthAddress"),
+    ],
     "LightVoxelGrid.hlsli": [
         # SignNotZero<T> on an int3 argument: HLSL converts the float3 result to int3 and back; the values are +-1 either way
         (r"Math::SignNotZero\(voxelIdxCamSpace\)", "Math::SignNotZero(float3(voxelIdxCamSpace))"),

@@ -26,6 +26,7 @@ enum TexFormat
 struct TexStorage
 {
     void* data = nullptr;
+    const void* readData = nullptr;     // when set, loads come from this snapshot and stores go to `data` (race-free in-place passes: FireflyFilter.hlsl)
     uint32_t w = 0, h = 0, d = 1;
     int fmt = FMT_UNKNOWN;
     const zr_tex_heap* heap = nullptr; uint32_t heapIdx = 0;     // FMT_MATERIAL_TEXTURE
@@ -50,7 +51,7 @@ static inline bool FormatIsUint(int f)
 // raw element -> 4 lanes (floats or uints, by format class); missing channels read (0, 0, 0, 1) like D3D
 static inline void LoadRaw(const TexStorage& s, size_t idx, float f[4], uint32_t u[4])
 {
-    const uint8_t* p = (const uint8_t*)s.data + idx * FormatBytes(s.fmt);
+    const uint8_t* p = (const uint8_t*)(s.readData ? s.readData : s.data) + idx * FormatBytes(s.fmt);
     f[0] = f[1] = f[2] = 0.0f; f[3] = 1.0f; u[0] = u[1] = u[2] = 0u; u[3] = 1u;
     uint16_t h[4]; uint32_t w[4];
     switch (s.fmt)

@@ -11,4 +11,7 @@ typedef struct ZrDispatch
     const void* local_cb; uint32_t local_cb_bytes;
     uint32_t groups_x, groups_y;
     void* root_uav;           /* a root-descriptor UAV bound as a global (AutoExposure's g_hist : register(u0)), or null */
+    /* ref_pass_aux.cpp (PreLighting / Sky / Compositing / TAA shaders): root SRV / UAV buffers by role, element counts, z extent of the dispatch */
+    void* buf[4]; uint32_t buf_count[4];
+    uint32_t groups_z;        /* 0 = 1 */
 } ZrDispatch;

@@ -62,6 +62,13 @@ int zrefp_gi_render(RefScene* r, GiState* S, const zr_frame_constants* cb, const
     L.SampleSetSize_NumSampleSets = prm->presampling ? ((prm->num_sample_sets << 16) | prm->sample_set_size) : 0u;
     L.M_max = prm->m_max_temporal; L.MaxNonTrBounces = prm->max_non_tr_bounces; L.MaxGlossyTrBounces = prm->max_glossy_tr_bounces;
     L.TexFilterDescHeapIdx = EnumToSamplerIdx(prm->tex_filter);
+    if (prm->use_lvg)
+    {   // IndirectLighting::SetLightVoxelGridParams, IndirectLighting.h:88-102: dimensions packed 16 + 16 | 32, extents + y offset as four halfs
+        const uint32_t dx_ = prm->lvg_grid_dim & 1023u, dy_ = (prm->lvg_grid_dim >> 10) & 1023u, dz_ = (prm->lvg_grid_dim >> 20) & 1023u;
+        L.GridDim_xy = (dy_ << 16) | dx_; L.GridDim_z = dz_;
+        const uint32_t ex = zr_f32_to_f16(prm->lvg_extents[0]), ey = zr_f32_to_f16(prm->lvg_extents[1]), ez = zr_f32_to_f16(prm->lvg_extents[2]), oy = zr_f32_to_f16(prm->lvg_offset_y);
+        L.Extents_xy = (ey << 16) | ex; L.Extents_z_Offset_y = (oy << 16) | ez;
+    }
     ZrDispatch d; memset(&d, 0, sizeof(d));
     d.scene = r; d.heap = &H; d.frame_cb = &g; d.local_cb = &L; d.local_cb_bytes = sizeof(L); d.groups_x = dx; d.groups_y = dy;
     zrefp_shader_gi(&d);

@@ -86,5 +86,7 @@ static inline RefScene* SceneCreate(const zr_scene_desc* d, int force_bvh) { Ref
     extern "C" void zrefp_scene_set_alias_table(refpass::RefScene* r, const zr_alias_entry* e, uint32_t n) { r->sc.alias.assign(e, e + n); } \
     extern "C" void zrefp_scene_set_sample_sets(refpass::RefScene* r, const zr_presampled_tri* e, uint32_t numSets, uint32_t setSize) \
     { r->sc.sampleSets.assign(e, e + (size_t)numSets * setSize); r->sc.sampleSetSize = setSize; } \
+    extern "C" void zrefp_scene_set_lvg(refpass::RefScene* r, const zr_voxel_sample* v, const uint32_t* dim, const float* extents, float offsetY) \
+    { r->sc.lvgData.assign(v, v + (size_t)dim[0] * dim[1] * dim[2] * 64); for (int a = 0; a < 3; a++) { r->sc.lvgDim[a] = dim[a]; r->sc.lvgExtents[a] = extents[a]; } r->sc.lvgOffsetY = offsetY; } \
     extern "C" void zrefp_scene_set_sky_lut(refpass::RefScene* r, const uint32_t* texels, uint32_t w, uint32_t h) \
     { r->sc.skyData.assign(texels, texels + (size_t)w * h); r->sc.sky.data = r->sc.skyData.data(); r->sc.sky.w = w; r->sc.sky.h = h; }

@@ -61,6 +61,11 @@ extern "C" void ZR_ENTRY(const ZrDispatch* d)
     hlsl::g_aliasTable = StructuredBuffer<hlsl::RT::EmissiveLumenAliasTableEntry>((const hlsl::RT::EmissiveLumenAliasTableEntry*)r->sc.alias.data(), (uint32_t)r->sc.alias.size());
     hlsl::g_sampleSets = StructuredBuffer<hlsl::RT::PresampledEmissiveTriangle>((const hlsl::RT::PresampledEmissiveTriangle*)r->sc.sampleSets.data(), (uint32_t)r->sc.sampleSets.size());
 #endif
+#ifdef USE_LVG
+    // Variants/ReSTIR_GI_LVG.hlsl: g_lvg : register(t8), the grid PreLighting built this frame (IndirectLighting.cpp:344-351)
+    static_assert(sizeof(hlsl::RT::VoxelSample) == sizeof(zr_voxel_sample), "VoxelSample layout");
+    hlsl::g_lvg = StructuredBuffer<hlsl::RT::VoxelSample>((const hlsl::RT::VoxelSample*)r->sc.lvgData.data(), (uint32_t)r->sc.lvgData.size());
+#endif
     Dispatch(d->groups_x, d->groups_y, hlsl::zr_numthreads[0], hlsl::zr_numthreads[1], true,
         [](uint3 DTid, uint3 Gid, uint3 GTid, uint32_t Gidx) { hlsl::zr_main_dispatch(DTid, Gid, GTid, Gidx); });
 }

@@ -34,6 +34,7 @@ class RefPass:
 
     def __init__(self, name, scene, force_bvh=False):
         self.L = _lib(name)
+        self._scene = scene
         self._desc = scene.desc()
         self.h = self.L.zrefp_scene_create(C.addressof(self._desc), int(force_bvh))
         self._keep = []
@@ -63,6 +64,12 @@ class RefPass:
     def set_sky_lut(self, texels):
         t = np.ascontiguousarray(texels, np.uint32)
         self.L.zrefp_scene_set_sky_lut(self.h, t.ctypes.data, t.shape[1], t.shape[0])
+
+    def set_lvg(self, grid, dim, extents, offset_y):
+        """K4's output (BuildLightVoxelGrid.hlsl) for the USE_LVG permutation of ReSTIR GI"""
+        self.L.zrefp_scene_set_lvg.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float]
+        g, d, e = np.ascontiguousarray(grid), np.array(dim, np.uint32), np.array(extents, np.float32)
+        self.L.zrefp_scene_set_lvg(self.h, g.ctypes.data, d.ctypes.data, e.ctypes.data, float(offset_y))
 
     def set_sample_sets(self, sets, num_sets, set_size):
         s = np.ascontiguousarray(sets)
@@ -144,8 +151,8 @@ class RefRestirGI(RefPass):
     """K10: ReSTIR_GI.hlsl + the restated host (oracle/ref_hlsl/ref_gi_host.cpp)"""
     PLANES = {"A": (0, np.float32, 4), "B": (1, np.uint16, 4), "C": (2, np.float32, 4)}
 
-    def __init__(self, scene, w, h, presampling=False, force_bvh=False):
-        name = "gi_e0" if len(scene.emissives) == 0 else ("gi_e1p" if presampling else "gi_e1")
+    def __init__(self, scene, w, h, presampling=False, force_bvh=False, lvg=False):
+        name = "gi_e0" if len(scene.emissives) == 0 else (("gi_e1l" if lvg else "gi_e1p") if presampling else "gi_e1")
         super().__init__(name, scene, force_bvh)
         L = self.L
         L.zrefp_gi_create.restype = C.c_void_p
@@ -239,4 +246,83 @@ class RefPost:
         assert self.L.zrefp_display(a.ctypes.data, is16, rw, rh, cbb.ctypes.data, None if e is None else e.ctypes.data, params.display_tonemapper,
                                     params.display_auto_exposure, params.display_saturation, params.display_agx_exp,
                                     None if l is None else l.ctypes.data, dim, out.ctypes.data) == 0
+        return out
+
+
+class RefAux(RefPass):
+    """The reference's auxiliary shaders (libzref_aux.so): PreLighting K2 / K3 / K4 with a scene; SkyViewLUT (K17), Compositing +
+    FireflyFilter and TAA.  `scene` may be None for the passes that need none (sky_lut, taa)."""
+
+    def __init__(self, scene=None, force_bvh=False):
+        if scene is not None:
+            super().__init__("aux", scene, force_bvh)
+        else:
+            self.L, self.h = _lib("aux"), None
+        L = self.L
+        vp, u32 = C.c_void_p, C.c_uint32
+        L.zrefp_estimate_power.argtypes = [vp, vp, vp, vp]
+        L.zrefp_presample.argtypes = [vp, vp, u32, u32, vp]
+        L.zrefp_build_lvg.argtypes = [vp, vp, vp, vp, C.c_float, vp]
+        L.zrefp_sky_lut.argtypes = [vp, u32, u32, vp]
+        L.zrefp_composite.argtypes = [vp, vp, vp, vp, vp, vp, u32, C.c_int, vp]
+        L.zrefp_taa.argtypes = [vp, vp, vp, vp, vp, vp, u32, u32, C.c_float, C.c_int]
+
+    def __del__(self):
+        if self.h is not None:
+            super().__del__()
+
+    @staticmethod
+    def halton_table():
+        """the 64 Halton(2, 3) points of PreLighting::Init (PreLighting.cpp:236-243) from the reference's own Halton (libzref.so)"""
+        L = C.CDLL(os.path.join(HERE, "_ref", "libzref.so"))
+        L.zref_halton.restype = C.c_float
+        L.zref_halton.argtypes = [C.c_int, C.c_int]
+        return np.array([[L.zref_halton(i + 1, 2), L.zref_halton(i + 1, 3)] for i in range(64)], np.float32)
+
+    def estimate_power(self, cb):
+        out = np.zeros(len(self._desc_scene().emissives), np.float32)
+        cbb, hal = np.ascontiguousarray(cb), self.halton_table()
+        assert self.L.zrefp_estimate_power(self.h, cbb.ctypes.data, hal.ctypes.data, out.ctypes.data) == 0
+        return out
+
+    def _desc_scene(self):
+        return self._scene
+
+    def presample(self, cb, num_sets, set_size):
+        from zetaray_amd import wire
+        out = np.zeros(num_sets * set_size, wire.PRESAMPLED_TRI)
+        cbb = np.ascontiguousarray(cb)
+        assert self.L.zrefp_presample(self.h, cbb.ctypes.data, num_sets, set_size, out.ctypes.data) == 0
+        return out
+
+    def build_lvg(self, cb, dim, extents, offset_y):
+        from zetaray_amd import wire
+        d, e = np.array(dim, np.uint32), np.array(extents, np.float32)
+        out = np.zeros((int(d[2]), int(d[1]), int(d[0]), 64), wire.VOXEL_SAMPLE)
+        cbb = np.ascontiguousarray(cb)
+        assert self.L.zrefp_build_lvg(self.h, cbb.ctypes.data, d.ctypes.data, e.ctypes.data, float(offset_y), out.ctypes.data) == 0
+        return out
+
+    def sky_lut(self, cb, w=256, h=128):
+        out = np.zeros((h, w), np.uint32)
+        cbb = np.ascontiguousarray(cb)
+        assert self.L.zrefp_sky_lut(cbb.ctypes.data, w, h, out.ctypes.data) == 0
+        return out
+
+    def composite(self, cb, gb_planes, sky_di=None, emissive_di=None, indirect=None, flags=0, firefly=False, out=None):
+        """gb_planes: the zr_gbuffer_planes struct of this frame; inputs (h, w, 4) f32 or None; flags = CB_COMPOSIT_FLAGS"""
+        w, h = gb_planes.width, gb_planes.height
+        ins = [None if p is None else np.ascontiguousarray(p, np.float32) for p in (sky_di, emissive_di, indirect)]
+        o = np.zeros((h, w, 4), np.float32) if out is None else np.ascontiguousarray(out, np.float32).copy()
+        cbb = np.ascontiguousarray(cb)
+        assert self.L.zrefp_composite(self.h, cbb.ctypes.data, C.addressof(gb_planes), *[None if p is None else p.ctypes.data for p in ins], flags, int(firefly), o.ctypes.data) == 0
+        return o
+
+    def taa(self, cb, signal, depth, motion, prev_out, blend_weight=0.1, temporal_valid=True):
+        sig = np.ascontiguousarray(signal, np.float32)
+        h, w = sig.shape[:2]
+        d, m, prev = np.ascontiguousarray(depth, np.float32), np.ascontiguousarray(motion, np.uint32), np.ascontiguousarray(prev_out, np.uint16)
+        out = np.zeros((h, w, 4), np.uint16)
+        cbb = np.ascontiguousarray(cb)
+        assert self.L.zrefp_taa(cbb.ctypes.data, sig.ctypes.data, d.ctypes.data, m.ctypes.data, prev.ctypes.data, out.ctypes.data, w, h, float(blend_weight), int(bool(temporal_valid))) == 0
         return out

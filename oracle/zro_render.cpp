@@ -846,7 +846,7 @@ static void Render(const float* signal, const float* depthPlane, const uint32_t*
     int W, int H, float blendWeight, bool temporalIsValid)
 {
     auto Signal = [&](int x, int y) { const float* c = signal + 4 * ((size_t)y * W + x);
-        return f3(zr_round_f16(c[0]), zr_round_f16(c[1]), zr_round_f16(c[2])); };      // the reference's input is R16G16B16A16_FLOAT
+        return f3(c[0], c[1], c[2]); };      // the reference's input is Compositing's R32G32B32A32_FLOAT texture (Compositing.h:96, PostProcessor.cpp:158)
     auto Store = [&](int x, int y, float3 c) { uint16_t* o = currOut + 4 * ((size_t)y * W + x);
         o[0] = zr_f32_to_f16(c.x); o[1] = zr_f32_to_f16(c.y); o[2] = zr_f32_to_f16(c.z); };
     Tex16 prev{prevOut, W, H};

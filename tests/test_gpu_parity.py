@@ -847,6 +847,92 @@ def test_baseline_config_cornell_1080p_restir_pt_bit_exact(api, cornell_emissive
     assert got[..., :3].max() > 0
 
 
+def _chain(cb, prev):
+    if prev is not None:
+        cb["prev_view"], cb["prev_view_inv"], cb["prev_camera_jitter"] = prev["curr_view"], prev["curr_view_inv"], prev["curr_camera_jitter"]
+    return cb
+
+
+def test_baseline_config2_cornell_1080p_restir_di_emissive_bit_exact(api, cornell_emissive, oracle_emissive):
+    """BASELINE config 2 (emissive half): Cornell (emissive) 1920 x 1080, ReSTIR DI K5 + K6, frames 1-3 with the camera moving on frame 3,
+    FULL frame vs the oracle, tolerance 0: radiance, both reservoir planes + target, ray counters (DirectLighting.cpp:100-190)."""
+    from oracle import zro
+    w, h = 1920, 1080
+    prm = wire.default_params_di()
+    r = api.Renderer(cornell_emissive, w, h, params=wire.default_params())
+    r.skip_indirect = True
+    di = r.enable_direct(prm)
+    o = zro.OracleRDI(oracle_emissive, w, h)
+    prev = None
+    for f in range(1, 4):
+        cb = _chain(_frame(cornell_emissive, w, h, f, cam_pos=(0.06 * max(0, f - 2), 1.2, -4.043)), prev)
+        prev = cb.copy()
+        di.read_counters(reset=True)
+        r.render_frame(cb)
+        got = di.download()
+        want = o.render(cb, prm)
+        mism = int((got.view(np.uint32) != want.view(np.uint32)).any(axis=2).sum())
+        assert mism == 0, f"frame {f}: {mism} of {w * h} pixels differ"
+        assert di.read_counters() == o.counters
+        for nm, onm in (("di_A", "A"), ("di_B", "B"), ("di_target", "target")):
+            assert np.array_equal(di.download_plane(nm).view(np.uint8), o.plane(onm).view(np.uint8)), f"frame {f}: DI plane {onm}"
+    assert got[..., :3].max() > 0
+
+
+def test_baseline_config2_cornell_1080p_sky_di_bit_exact(api, cornell_sky):
+    """BASELINE config 2 (sun + sky half, the reference's default Cornell box): 1920 x 1080 SkyDI K7 + K8, frames 1-3, camera moving on
+    frame 3, FULL frame vs the oracle, tolerance 0: radiance, the four reservoir planes, ray counters (SkyDI.cpp:72-180)."""
+    from oracle import zro
+    w, h = 1920, 1080
+    osc = zro.OracleScene(cornell_sky)
+    prm = wire.default_params_sky_di()
+    r = api.Renderer(cornell_sky, w, h, params=wire.default_params())
+    r.skip_indirect = True
+    di = r.enable_sky_direct(prm)
+    o = zro.OracleSDI(osc, w, h)
+    prev = None
+    for f in range(1, 4):
+        cb = _chain(scene_io.make_frame_constants(w, h, frame_num=f, num_emissives=0, cam_pos=(0.06 * max(0, f - 2), 1.2, -4.043)), prev)
+        prev = cb.copy()
+        di.read_counters(reset=True)
+        r.render_frame(cb)
+        got = di.download()
+        osc.sky_lut(cb, 256, 128)
+        want = o.render(cb, prm)
+        mism = int((got.view(np.uint32) != want.view(np.uint32)).any(axis=2).sum())
+        assert mism == 0, f"frame {f}: {mism} of {w * h} pixels differ"
+        assert di.read_counters() == o.counters
+        for nm, onm in (("sdi_A", "A"), ("sdi_B", "B"), ("sdi_C", "C"), ("sdi_target", "target")):
+            assert np.array_equal(di.download_plane(nm).view(np.uint8), o.plane(onm).view(np.uint8)), f"frame {f}: sky DI plane {onm}"
+    assert got[..., :3].max() > 0
+
+
+def test_baseline_config3_cornell_1080p_restir_gi_bit_exact(api, cornell_emissive, oracle_emissive):
+    """BASELINE config 3: Cornell (emissive) 1920 x 1080, ReSTIR GI with 3 non-transmissive bounces, temporal resampling, M_max 10
+    (IndirectLighting.cpp:277-368), frames 1-3, camera moving on frame 3, FULL frame vs the oracle, tolerance 0: radiance, the three
+    reservoir planes, ray counters."""
+    from oracle import zro
+    w, h = 1920, 1080
+    prm = wire.default_params()
+    assert prm.max_non_tr_bounces == 3 and prm.m_max_temporal == 10
+    r = api.Renderer(cornell_emissive, w, h, params=prm, integrator=api.INTEGRATOR_RESTIR_GI)
+    o = zro.OracleRGI(oracle_emissive, w, h)
+    prev = None
+    for f in range(1, 4):
+        cb = _chain(_frame(cornell_emissive, w, h, f, cam_pos=(0.05 * max(0, f - 2), 1.2, -4.043)), prev)
+        prev = cb.copy()
+        r.p_indirect.read_counters(reset=True)
+        r.render_frame(cb)
+        got = r.final()
+        want = o.render(cb, prm)
+        mism = int((got.view(np.uint32) != want.view(np.uint32)).any(axis=2).sum())
+        assert mism == 0, f"frame {f}: {mism} of {w * h} pixels differ"
+        assert r.p_indirect.read_counters() == o.counters
+        for nm, onm in (("gi_A", "A"), ("gi_B", "B"), ("gi_C", "C")):
+            assert np.array_equal(r.p_indirect.download_plane(nm).view(np.uint8), o.plane(onm).view(np.uint8)), f"frame {f}: GI plane {onm}"
+    assert got[..., :3].max() > 0
+
+
 @pytest.fixture(scope="module")
 def atrium():
     """BASELINE config 4's scene class (bench.py --scene synthetic): 380 588 triangles of which 100 000 emissive"""

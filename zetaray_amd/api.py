@@ -45,7 +45,7 @@ RPT_OUTPUTS = {"A": (1, np.uint32, 1), "B": (2, np.float32, 2), "C": (3, np.uint
 
 EXPORTS = [
     "zr_abi_version", "zr_last_error", "zr_device_count", "zr_wire_layout", "zr_scene_create", "zr_scene_destroy", "zr_scene_update_instances", "zr_scene_update_emissives", "zr_scene_invalidate_alias_table", "zr_scene_update_materials",
-    "zr_scene_set_alias_table", "zr_alias_table_build", "zr_scene_get_alias_table", "zr_scene_get_light_voxel_grid", "zr_scene_bvh_info",
+    "zr_scene_set_alias_table", "zr_alias_table_build", "zr_scene_get_alias_table", "zr_scene_get_light_voxel_grid", "zr_scene_get_presampled_sets", "zr_scene_bvh_info",
     "zr_gbuffer_create", "zr_gbuffer_destroy", "zr_gbuffer_set_tile_origin", "zr_gbuffer_download", "zr_gbuffer_device_plane",
     "zr_params_default", "zr_pass_create", "zr_pass_init", "zr_pass_resize", "zr_pass_reset_temporal",
     "zr_pass_set_params", "zr_pass_render", "zr_pass_get_output", "zr_pass_download_output",
@@ -92,6 +92,7 @@ def lib():
         L.zr_alias_table_build.argtypes = [vp, u32, u32, vp]
         L.zr_scene_get_alias_table.argtypes = [vp, vp, u32]
         L.zr_scene_get_light_voxel_grid.argtypes = [vp, vp, vp, u32]
+        L.zr_scene_get_presampled_sets.argtypes = [vp, vp, vp, u32]
         L.zr_scene_bvh_info.argtypes = [vp, vp, vp, vp]
         L.zr_gbuffer_create.argtypes = [i32, u32, u32, vp]
         L.zr_gbuffer_destroy.argtypes = [vp]
@@ -190,6 +191,11 @@ class Scene:
     def get_light_voxel_grid(self, dim, stream=None):
         out = np.zeros((dim[2], dim[1], dim[0], 64), wire.VOXEL_SAMPLE)
         _check(lib().zr_scene_get_light_voxel_grid(self.h, stream, out.ctypes.data, out.size))
+        return out
+
+    def get_presampled_sets(self, num_sets, set_size, stream=None):
+        out = np.zeros(num_sets * set_size, wire.PRESAMPLED_TRI)
+        _check(lib().zr_scene_get_presampled_sets(self.h, stream, out.ctypes.data, len(out)))
         return out
 
     def bvh_info(self):

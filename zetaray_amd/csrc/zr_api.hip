@@ -1233,6 +1233,17 @@ int zr_scene_get_light_voxel_grid(const zr_scene* s, void* stream, zr_voxel_samp
     return ZR_OK;
 }
 
+int zr_scene_get_presampled_sets(const zr_scene* s, void* stream, zr_presampled_tri* out, uint32_t n)
+{
+    if (!s || !out) return Fail(ZR_ERR_INVALID_ARG, "null argument");
+    if (!s->view.sampleSets) return Fail(ZR_ERR_NOT_INITIALIZED, "no presampled light sets: render the PRELIGHTING pass with presampling first");
+    if (n != s->sampleSets.n) return Fail(ZR_ERR_INVALID_ARG, "the presampled sets hold %zu samples", s->sampleSets.n);
+    HIP_TRY(hipSetDevice(s->device));
+    HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+    HIP_TRY(hipMemcpy(out, s->sampleSets.p, (size_t)n * sizeof(zr_presampled_tri), hipMemcpyDeviceToHost));
+    return ZR_OK;
+}
+
 int zr_scene_bvh_info(const zr_scene* s, uint32_t* num_nodes, uint32_t* num_tris, uint32_t* max_depth)
 {
     if (!s) return Fail(ZR_ERR_INVALID_ARG, "null scene");

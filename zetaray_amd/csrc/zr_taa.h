@@ -47,8 +47,9 @@ ZR_HD V3 ClipAABB(V3 aabbMin, V3 aabbMax, V3 histSample)      // TAA.hlsl:49-64
 
 ZR_HD V3 LoadSignal(const TaaFrame& F, int x, int y)
 {
+    // the signal is Compositing's output, R32G32B32A32_FLOAT (Compositing.h:96; bound as TAA's input at PostProcessor.cpp:158): read as stored
     const F4 c = F.signal[(size_t)y * F.w + x];
-    return v3(zr_round_f16(c.x), zr_round_f16(c.y), zr_round_f16(c.z));
+    return v3(c.x, c.y, c.z);
 }
 ZR_HD V3 LoadHistoryTexel(const TaaFrame& F, int x, int y)
 {
