@@ -252,6 +252,18 @@ int zr_scene_update_instances(zr_scene* scene, const zr_mesh_instance* instances
  * PreLighting.cpp:266); presampled sets and the light voxel grid pick the new positions up on the next PRELIGHTING render.
  * Host call between frames (waits for the device). */
 int zr_scene_update_emissives(zr_scene* scene, const zr_emissive_triangle* triangles, uint32_t first, uint32_t count);
+/* Stream-ordered forms of the three updates above and of zr_scene_set_alias_table -- what the reference does when it records the instance /
+ * TLAS update and the buffer uploads on the frame's command list (RtAccelerationStructure.cpp:708-789, SceneCore.cpp:913-955,
+ * PreLighting.cpp:556-575): everything is ENQUEUED on `hip_stream` (host records are copied into a pinned staging ring first, so the
+ * caller's arrays may be reused at once) and the call returns without waiting for the device.  Ordering against zr_pass_render is the
+ * stream's; renders enqueued on OTHER streams are ordered by events inside the library (a render waits for the last update, an update
+ * waits for the last render of every stream that used the scene), so no host synchronisation is needed in either direction.  The plain
+ * forms are `_async` on the null stream followed by hipDeviceSynchronize().  (ZR_SCENE_UPDATE=rebuild, the host BVH rebuild, stays
+ * host-synchronous by construction.) */
+int zr_scene_update_instances_async(zr_scene* scene, void* hip_stream, const zr_mesh_instance* instances, const float* instance_to_world, uint32_t n);
+int zr_scene_update_emissives_async(zr_scene* scene, void* hip_stream, const zr_emissive_triangle* triangles, uint32_t first, uint32_t count);
+int zr_scene_update_materials_async(zr_scene* scene, void* hip_stream, const zr_material* materials, uint32_t first, uint32_t count);
+int zr_scene_set_alias_table_async(zr_scene* scene, void* hip_stream, const zr_alias_entry* entries, uint32_t n);
 /* Emissive MATERIALS changed (SceneCore::UpdateEmissiveMaterial: factor / strength rewritten in the records handed to zr_scene_update_emissives;
  * Scene::AreEmissiveMaterialsStale, PreLighting.cpp:266): drops the alias table, so that the next ZR_PASS_PRELIGHTING render re-estimates the
  * triangle powers (K2) and rebuilds it. */

@@ -1185,6 +1185,59 @@ def test_moving_light_on_gpu(api):
     assert not np.array_equal(before.view(np.uint8), sc.emissives.view(np.uint8))      # the light really moved
 
 
+def test_stream_ordered_scene_updates_across_streams(api):
+    """zr_scene_update_instances_async / _emissives_async: the moving light of the test above, but every update is ENQUEUED on one non-blocking
+    stream and every frame rendered on another, six frames back to back without a host synchronisation in between (the library orders the two
+    streams with events: a render waits for the last update, an update for the last render of each stream).  Afterwards every frame's ReSTIR PT
+    and ReSTIR DI image -- copied out on the render stream -- equals the oracle's."""
+    import torch
+    from oracle import zro
+    sc = scene_io.load_npz(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "cornell_emissive.npz"))
+    w, h = 128, 96
+    prm, dprm = wire.default_params(), wire.default_params_di()
+    r = api.Renderer(sc, w, h, params=prm, integrator=api.INTEGRATOR_RESTIR_PT)
+    di = r.enable_direct(dprm)
+    osc = zro.OracleScene(sc)
+    opt, odi = zro.OracleRPT(osc, w, h), zro.OracleRDI(osc, w, h)
+    idx = [i for i in range(len(sc.instances)) if sc.instances["base_emissive_tri_offset"][i] != 0xFFFFFFFF][0]
+    t0, xf = sc.instances["translation"][idx].copy(), {}
+    s_upd, s_ren = torch.cuda.Stream(), torch.cuda.Stream()
+    frames, wants, prev = [], [], None
+    nbytes = w * h * 16
+    import ctypes as C
+    hip = C.CDLL("libamdhip64.so")
+    hip.hipMemcpyAsync.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]
+    for f in range(1, 7):
+        if f >= 2:
+            a = 0.2 * (f - 1)
+            inst, xw, first, tris = scene_io.move_emissive_instance(sc, idx, translation=t0 + np.float32([0.05 * (f - 1), -0.02 * (f - 1), 0.03 * (f - 1)]),
+                                                                     rotation=np.array([0.0, np.sin(a / 2), 0.0, np.cos(a / 2)], np.float32), xform_of=xf)
+            r.scene.update_emissives(tris, first, stream=s_upd.cuda_stream)
+            r.scene.update_instances(inst, xw, stream=s_upd.cuda_stream)
+            tris[:] = 0; inst = None          # the caller's arrays may be reused at once (pinned staging ring)
+            inst2, xw2, first2, tris2 = scene_io.move_emissive_instance(sc, idx, translation=t0 + np.float32([0.05 * (f - 1), -0.02 * (f - 1), 0.03 * (f - 1)]),
+                                                                        rotation=np.array([0.0, np.sin(a / 2), 0.0, np.cos(a / 2)], np.float32), xform_of=xf)
+            osc.update_emissives(tris2, first2); osc.update_instances(inst2, xw2)
+        cb = _frame(sc, w, h, f)
+        if prev is not None:
+            cb["prev_view"], cb["prev_view_inv"], cb["prev_camera_jitter"] = prev["curr_view"], prev["curr_view_inv"], prev["curr_camera_jitter"]
+        prev = cb.copy()
+        r.render_frame(cb, stream=s_ren.cuda_stream)
+        # snapshot both images on the render stream (device-to-device, stream-ordered)
+        snap = torch.zeros(2 * nbytes, dtype=torch.uint8, device="cuda")
+        torch.cuda.current_stream().synchronize()          # the allocation's fill, not the renders
+        pt_ptr, di_ptr = r.p_indirect.output_ptr()[0], di.output_ptr()[0]      # (output planes are allocated by the first render)
+        assert hip.hipMemcpyAsync(snap.data_ptr(), pt_ptr, nbytes, 3, s_ren.cuda_stream) == 0
+        assert hip.hipMemcpyAsync(snap.data_ptr() + nbytes, di_ptr, nbytes, 3, s_ren.cuda_stream) == 0
+        frames.append(snap)
+        wants.append((opt.render(cb, prm), odi.render(cb, dprm)))
+    torch.cuda.synchronize()
+    for f, (snap, (want, want_di)) in enumerate(zip(frames, wants), 1):
+        got = snap.cpu().numpy().view(np.float32).reshape(2, h, w, 4)
+        assert np.array_equal(got[0].view(np.uint32), want.view(np.uint32)), f"frame {f}: ReSTIR PT"
+        assert np.array_equal(got[1].view(np.uint32), want_di.view(np.uint32)), f"frame {f}: ReSTIR DI"
+
+
 def test_emissive_material_change_rebuilds_the_alias_table(api):
     """SceneCore::UpdateEmissiveMaterial + PreLighting's stale-materials path (PreLighting.cpp:266): one of the Cornell light's two triangles gets
     8 x its strength at frame 3 (zr_scene_update_emissives with the rewritten record, zr_scene_invalidate_alias_table); the next PRELIGHTING render

@@ -45,6 +45,7 @@ RPT_OUTPUTS = {"A": (1, np.uint32, 1), "B": (2, np.float32, 2), "C": (3, np.uint
 
 EXPORTS = [
     "zr_abi_version", "zr_last_error", "zr_device_count", "zr_wire_layout", "zr_scene_create", "zr_scene_destroy", "zr_scene_update_instances", "zr_scene_update_emissives", "zr_scene_invalidate_alias_table", "zr_scene_update_materials",
+    "zr_scene_update_instances_async", "zr_scene_update_emissives_async", "zr_scene_update_materials_async", "zr_scene_set_alias_table_async",
     "zr_scene_set_alias_table", "zr_alias_table_build", "zr_scene_get_alias_table", "zr_scene_get_light_voxel_grid", "zr_scene_get_presampled_sets", "zr_scene_bvh_info",
     "zr_gbuffer_create", "zr_gbuffer_destroy", "zr_gbuffer_set_tile_origin", "zr_gbuffer_download", "zr_gbuffer_device_plane",
     "zr_params_default", "zr_pass_create", "zr_pass_init", "zr_pass_resize", "zr_pass_reset_temporal",
@@ -154,25 +155,39 @@ class Scene:
         self.h = C.c_void_p()
         _check(lib().zr_scene_create(device, C.addressof(self._desc), C.byref(self.h)))
 
-    def update_instances(self, instances, instance_to_world):
-        """per-frame MeshInstance records + object-to-world matrices; last frame's instance buffer and BVH become the previous ones"""
+    def update_instances(self, instances, instance_to_world, stream=False):
+        """per-frame MeshInstance records + object-to-world matrices; last frame's instance buffer and BVH become the previous ones.
+        stream=False: host-synchronous; a stream handle (or None = the null stream): enqueued, no host wait (zr_scene_update_instances_async)"""
         L = lib()
-        L.zr_scene_update_instances.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32]
         i, x = np.ascontiguousarray(instances), np.ascontiguousarray(instance_to_world, np.float32)
-        _check(L.zr_scene_update_instances(self.h, i.ctypes.data, x.ctypes.data, len(i)))
+        if stream is False:
+            L.zr_scene_update_instances.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32]
+            _check(L.zr_scene_update_instances(self.h, i.ctypes.data, x.ctypes.data, len(i)))
+        else:
+            L.zr_scene_update_instances_async.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32]
+            _check(L.zr_scene_update_instances_async(self.h, stream, i.ctypes.data, x.ctypes.data, len(i)))
 
-    def update_emissives(self, triangles, first=0):
+    def update_emissives(self, triangles, first=0, stream=False):
         """new EmissiveTriangle records for [first, first + len(triangles)) (instances that carry lights moved)"""
         L = lib()
-        L.zr_scene_update_emissives.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32]
         t = np.ascontiguousarray(triangles, wire.EMISSIVE_TRI)
-        _check(L.zr_scene_update_emissives(self.h, t.ctypes.data, first, len(t)))
+        if stream is False:
+            L.zr_scene_update_emissives.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32]
+            _check(L.zr_scene_update_emissives(self.h, t.ctypes.data, first, len(t)))
+        else:
+            L.zr_scene_update_emissives_async.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32]
+            _check(L.zr_scene_update_emissives_async(self.h, stream, t.ctypes.data, first, len(t)))
 
-    def update_materials(self, materials, first=0):
+    def update_materials(self, materials, first=0, stream=False):
         """rewritten Material records for [first, first + len(materials))"""
-        lib().zr_scene_update_materials.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32]
+        L = lib()
         m = np.ascontiguousarray(materials, wire.MATERIAL)
-        _check(lib().zr_scene_update_materials(self.h, m.ctypes.data, first, len(m)))
+        if stream is False:
+            L.zr_scene_update_materials.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32]
+            _check(L.zr_scene_update_materials(self.h, m.ctypes.data, first, len(m)))
+        else:
+            L.zr_scene_update_materials_async.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32]
+            _check(L.zr_scene_update_materials_async(self.h, stream, m.ctypes.data, first, len(m)))
 
     def invalidate_alias_table(self):
         """emissive materials changed: the next PRELIGHTING render re-estimates the powers and rebuilds the alias table"""

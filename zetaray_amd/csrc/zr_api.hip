@@ -513,7 +513,75 @@ struct zr_scene
     mutable std::mutex mtx;
     int64_t maxTex[4] = {-1, -1, -1, -1};     // largest tex16 used per table (base colour, normal, metallic-roughness, emissive)
     uint32_t maxDepth = 0;
+    // ---- stream-ordered updates (zr_scene_update_*_async; RtAccelerationStructure.cpp:708-789 records them on the frame's command list).
+    // Host records travel through a ring of pinned staging buffers (a slot is reused only after its copy has run); `updated` is recorded
+    // behind every update and waited for by renders on OTHER streams; `users` holds, per stream that rendered with this scene, an event
+    // recorded behind its last render, which an update on another stream waits for before it overwrites what those renders read.
+    struct StageSlot { void* host = nullptr; size_t cap = 0; hipEvent_t ev = nullptr; bool pending = false; };
+    StageSlot stage[4]; int stageNext = 0;
+    hipEvent_t updated = nullptr; hipStream_t updatedOn = nullptr; bool hasUpdate = false;
+    std::vector<std::pair<hipStream_t, hipEvent_t>> users;
+    ~zr_scene()
+    {
+        for (StageSlot& t : stage) { if (t.ev) (void)hipEventDestroy(t.ev); if (t.host) (void)hipHostFree(t.host); }
+        if (updated) (void)hipEventDestroy(updated);
+        for (auto& u : users) (void)hipEventDestroy(u.second);
+    }
 };
+
+// a pinned staging buffer of >= bytes whose previous transfer (if any) has completed; the caller fills it, enqueues its copy on `st`
+// and calls StageCommit
+static int StageAcquire(zr_scene* s, size_t bytes, zr_scene::StageSlot** out)
+{
+    zr_scene::StageSlot& t = s->stage[s->stageNext];
+    s->stageNext = (s->stageNext + 1) % 4;
+    if (t.pending) { HIP_TRY(hipEventSynchronize(t.ev)); t.pending = false; }      // only blocks when the host runs > 4 updates ahead of the device
+    if (!t.ev) HIP_TRY(hipEventCreateWithFlags(&t.ev, hipEventDisableTiming));
+    if (t.cap < bytes)
+    {
+        if (t.host) { (void)hipHostFree(t.host); t.host = nullptr; t.cap = 0; }
+        hipError_t e = hipHostMalloc(&t.host, bytes, hipHostMallocDefault);
+        if (e != hipSuccess) { t.host = nullptr; return Fail(ZR_ERR_OOM, "hipHostMalloc(%zu B) failed: %s", bytes, hipGetErrorString(e)); }
+        t.cap = bytes;
+    }
+    *out = &t;
+    return ZR_OK;
+}
+static int StageCommit(zr_scene::StageSlot* t, hipStream_t st) { HIP_TRY(hipEventRecord(t->ev, st)); t->pending = true; return ZR_OK; }
+// an update on `st` must not overwrite what renders enqueued on other streams still read
+static int SceneWaitUsers(zr_scene* s, hipStream_t st)
+{
+    std::lock_guard<std::mutex> lock(s->mtx);
+    for (auto& u : s->users) if (u.first != st) HIP_TRY(hipStreamWaitEvent(st, u.second, 0));
+    return ZR_OK;
+}
+static int SceneMarkUpdated(zr_scene* s, hipStream_t st)
+{
+    std::lock_guard<std::mutex> lock(s->mtx);
+    if (!s->updated) HIP_TRY(hipEventCreateWithFlags(&s->updated, hipEventDisableTiming));
+    HIP_TRY(hipEventRecord(s->updated, st));
+    s->updatedOn = st; s->hasUpdate = true;
+    return ZR_OK;
+}
+// a render on `st`: behind the last update if that ran on another stream ...
+static int SceneAcquireForRender(const zr_scene* sc, hipStream_t st)
+{
+    std::lock_guard<std::mutex> lock(sc->mtx);
+    if (sc->hasUpdate && sc->updatedOn != st) HIP_TRY(hipStreamWaitEvent(st, sc->updated, 0));
+    return ZR_OK;
+}
+// ... and remembered as a user of the scene's buffers (only once the scene has ever been updated: static scenes pay nothing)
+static int SceneReleaseAfterRender(const zr_scene* scc, hipStream_t st)
+{
+    zr_scene* sc = const_cast<zr_scene*>(scc);
+    std::lock_guard<std::mutex> lock(sc->mtx);
+    if (!sc->hasUpdate) return ZR_OK;
+    for (auto& u : sc->users) if (u.first == st) { HIP_TRY(hipEventRecord(u.second, st)); return ZR_OK; }
+    hipEvent_t ev; HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    sc->users.emplace_back(st, ev);
+    HIP_TRY(hipEventRecord(ev, st));
+    return ZR_OK;
+}
 
 // The scene as one launch sees it: a private copy of the scene's view with the texture descriptor-table offsets of THIS frame's
 // constants (per-frame data in the reference, FrameConstants.h:31-34) -- nothing per-frame is latched on the shared scene.
@@ -1044,43 +1112,79 @@ int zr_scene_create(int device, const zr_scene_desc* d, zr_scene** out)
 // at zr_scene_create keeps its topology, k_refit_tris re-transforms the triangles and k_refit_level recomputes + re-quantises the node boxes
 // level by level (what a D3D12 TLAS / BLAS update with ALLOW_UPDATE does); ZR_SCENE_UPDATE=rebuild selects a full binned-SAH rebuild on the
 // host instead (better trees after large motion, three orders of magnitude slower).  Results do not depend on the tree (zr_intersect.h).
-int zr_scene_update_emissives(zr_scene* s, const zr_emissive_triangle* triangles, uint32_t first, uint32_t count)
+// Texture indices of updated records raise the per-table maxima the descriptor-table bounds check of zr_pass_render relies on
+static void RaiseMaxTex(zr_scene* s, int table, uint32_t tex) { if (tex != ZR_INVALID_TEX && (int64_t)tex > s->maxTex[table]) s->maxTex[table] = tex; }
+
+int zr_scene_update_emissives_async(zr_scene* s, void* stream, const zr_emissive_triangle* triangles, uint32_t first, uint32_t count)
 {
     if (!s || (!triangles && count)) return Fail(ZR_ERR_INVALID_ARG, "zr_scene_update_emissives: null argument");
     if ((uint64_t)first + count > s->emissives.n) return Fail(ZR_ERR_INVALID_ARG, "zr_scene_update_emissives: [%u, %u) exceeds the scene's %zu emissive triangles", first, first + count, s->emissives.n);
     if (!count) return ZR_OK;
     HIP_TRY(hipSetDevice(s->device));
-    HIP_TRY(hipDeviceSynchronize());           // kernels of earlier frames may still sample the old records
-    HIP_TRY(hipMemcpy(s->emissives.p + first, triangles, (size_t)count * sizeof(zr_emissive_triangle), hipMemcpyHostToDevice));
-    return ZR_OK;
+    hipStream_t st = (hipStream_t)stream;
+    int r; zr_scene::StageSlot* t;
+    if ((r = StageAcquire(s, (size_t)count * sizeof(zr_emissive_triangle), &t))) return r;
+    memcpy(t->host, triangles, (size_t)count * sizeof(zr_emissive_triangle));
+    for (uint32_t i = 0; i < count; i++) RaiseMaxTex(s, 3, triangles[i].packed_b & 0xffffu);
+    if ((r = SceneWaitUsers(s, st))) return r;          // kernels of earlier frames on other streams may still sample the old records
+    HIP_TRY(hipMemcpyAsync(s->emissives.p + first, t->host, (size_t)count * sizeof(zr_emissive_triangle), hipMemcpyHostToDevice, st));
+    if ((r = StageCommit(t, st))) return r;
+    return SceneMarkUpdated(s, st);
 }
-int zr_scene_update_materials(zr_scene* s, const zr_material* materials, uint32_t first, uint32_t count)
+int zr_scene_update_materials_async(zr_scene* s, void* stream, const zr_material* materials, uint32_t first, uint32_t count)
 {
     if (!s || (!materials && count)) return Fail(ZR_ERR_INVALID_ARG, "zr_scene_update_materials: null argument");
     if ((uint64_t)first + count > s->materials.n) return Fail(ZR_ERR_INVALID_ARG, "zr_scene_update_materials: [%u, %u) exceeds the scene's %zu materials", first, first + count, s->materials.n);
     if (!count) return ZR_OK;
     HIP_TRY(hipSetDevice(s->device));
+    hipStream_t st = (hipStream_t)stream;
+    int r; zr_scene::StageSlot* t;
+    if ((r = StageAcquire(s, (size_t)count * sizeof(zr_material), &t))) return r;
+    memcpy(t->host, materials, (size_t)count * sizeof(zr_material));
+    for (uint32_t i = 0; i < count; i++)
+    {   // Material.h:268-427: base colour / normal / metallic-roughness / emissive texture ids (16 bits each)
+        RaiseMaxTex(s, 0, materials[i].base_color_tex_subsurf_coat_weight & 0xffffu); RaiseMaxTex(s, 1, materials[i].normal_tex_tr_depth & 0xffffu);
+        RaiseMaxTex(s, 2, materials[i].mr_tex_spec_roughness_coat_roughness & 0xffffu); RaiseMaxTex(s, 3, materials[i].emissive_tex_alpha_cutoff_coat_ior & 0xffffu);
+    }
+    if ((r = SceneWaitUsers(s, st))) return r;
+    HIP_TRY(hipMemcpyAsync(s->materials.p + first, t->host, (size_t)count * sizeof(zr_material), hipMemcpyHostToDevice, st));
+    if ((r = StageCommit(t, st))) return r;
+    return SceneMarkUpdated(s, st);
+}
+// the original host-synchronous entry points: the update on the null stream, then wait for it (errors of the copies / refit kernels surface here)
+int zr_scene_update_emissives(zr_scene* s, const zr_emissive_triangle* triangles, uint32_t first, uint32_t count)
+{
+    int r = zr_scene_update_emissives_async(s, nullptr, triangles, first, count);
+    if (r || !count) return r;
     HIP_TRY(hipDeviceSynchronize());
-    HIP_TRY(hipMemcpy(s->materials.p + first, materials, (size_t)count * sizeof(zr_material), hipMemcpyHostToDevice));
+    return ZR_OK;
+}
+int zr_scene_update_materials(zr_scene* s, const zr_material* materials, uint32_t first, uint32_t count)
+{
+    int r = zr_scene_update_materials_async(s, nullptr, materials, first, count);
+    if (r || !count) return r;
+    HIP_TRY(hipDeviceSynchronize());
     return ZR_OK;
 }
 int zr_scene_invalidate_alias_table(zr_scene* s)
 {
     if (!s) return Fail(ZR_ERR_INVALID_ARG, "zr_scene_invalidate_alias_table: null argument");
-    HIP_TRY(hipSetDevice(s->device));
-    HIP_TRY(hipDeviceSynchronize());           // kernels of earlier frames may still sample through the table
+    // kernels of earlier frames keep sampling the old table through the pointer they were launched with; the device buffer is only
+    // rewritten by zr_scene_set_alias_table, which orders itself behind them
     std::lock_guard<std::mutex> lock(s->mtx);
     s->view.alias = nullptr; s->aliasHost.clear();
     return ZR_OK;
 }
-int zr_scene_update_instances(zr_scene* s, const zr_mesh_instance* instances, const float* instance_to_world, uint32_t n)
+int zr_scene_update_instances_async(zr_scene* s, void* stream, const zr_mesh_instance* instances, const float* instance_to_world, uint32_t n)
 {
     if (!s || !instances || !instance_to_world) return Fail(ZR_ERR_INVALID_ARG, "zr_scene_update_instances: null argument");
     if (n != s->instances.n) return Fail(ZR_ERR_INVALID_ARG, "zr_scene_update_instances: %u instances, the scene has %zu", n, s->instances.n);
     HIP_TRY(hipSetDevice(s->device));
+    hipStream_t st = (hipStream_t)stream;
     const char* modeEnv = std::getenv("ZR_SCENE_UPDATE");
     const bool rebuild = modeEnv && !std::strcmp(modeEnv, "rebuild");
     int r;
+    for (uint32_t i = 0; i < n; i++) RaiseMaxTex(s, 0, instances[i].base_color_tex);
     if (rebuild)
     {
         zr_scene_desc d; memset(&d, 0, sizeof(d));
@@ -1089,7 +1193,7 @@ int zr_scene_update_instances(zr_scene* s, const zr_mesh_instance* instances, co
         BvhBuilder builder;
         BuiltBvh bvh = builder.Build(d);
         if (bvh.stackNeed + 1 > (uint32_t)kTravStack) return Fail(ZR_ERR_UNSUPPORTED, "BVH needs %u traversal stack entries (limit %d)", bvh.stackNeed, kTravStack - 1);
-        HIP_TRY(hipDeviceSynchronize());           // kernels of earlier frames may still read the buffers that change roles below
+        HIP_TRY(hipDeviceSynchronize());           // the host rebuild reallocates: a host-synchronous path by construction (ZR_SCENE_UPDATE=rebuild)
         std::lock_guard<std::mutex> lock(s->mtx);
         std::swap(s->instances.p, s->instancesPrev.p); std::swap(s->instances.n, s->instancesPrev.n);
         std::swap(s->nodes.p, s->nodesPrev.p); std::swap(s->nodes.n, s->nodesPrev.n);
@@ -1107,33 +1211,50 @@ int zr_scene_update_instances(zr_scene* s, const zr_mesh_instance* instances, co
         s->refitReady = false;      // the two buffer sets no longer share a topology
         return ZR_OK;
     }
-    HIP_TRY(hipDeviceSynchronize());               // kernels of earlier frames may still read the buffers that change roles below
-    std::lock_guard<std::mutex> lock(s->mtx);
+    // ---- refit on the device, stream-ordered: nothing below waits on the host (the staging ring aside, when the host runs far ahead)
     const size_t nn = s->view.numNodes, nt = s->view.numTris;
+    const size_t instBytes = (size_t)n * sizeof(zr_mesh_instance), xfBytes = 12 * (size_t)n * sizeof(float);
+    zr_scene::StageSlot* t;
+    if ((r = StageAcquire(s, instBytes + xfBytes, &t))) return r;
+    memcpy(t->host, instances, instBytes); memcpy((char*)t->host + instBytes, instance_to_world, xfBytes);
+    if ((r = SceneWaitUsers(s, st))) return r;         // renders of earlier frames on other streams still read the buffers that change roles below
+    std::lock_guard<std::mutex> lock(s->mtx);
     if (!s->refitReady)
     {
         // both buffer sets must hold the same tree: duplicate the current one (once, or after a host rebuild)
         if ((r = s->instancesPrev.Alloc(n)) || (nn && (r = s->nodesPrev.Alloc(nn))) || (r = s->trisPrev.Alloc(nt)) || (r = s->metaPrev.Alloc(s->meta.n)) ||
             (nn && (r = s->nodeBounds.Alloc(6 * nn))) || (r = s->toWorld.Alloc(12 * (size_t)n))) return r;
-        HIP_TRY(hipMemcpy(s->instancesPrev.p, s->instances.p, n * sizeof(zr_mesh_instance), hipMemcpyDeviceToDevice));
-        if (nn) HIP_TRY(hipMemcpy(s->nodesPrev.p, s->nodes.p, nn * sizeof(Bvh4Node), hipMemcpyDeviceToDevice));
-        HIP_TRY(hipMemcpy(s->trisPrev.p, s->tris.p, nt * sizeof(BvhTri), hipMemcpyDeviceToDevice));
-        HIP_TRY(hipMemcpy(s->metaPrev.p, s->meta.p, s->meta.n * sizeof(TriMeta), hipMemcpyDeviceToDevice));
+        HIP_TRY(hipMemcpyAsync(s->instancesPrev.p, s->instances.p, instBytes, hipMemcpyDeviceToDevice, st));
+        if (nn) HIP_TRY(hipMemcpyAsync(s->nodesPrev.p, s->nodes.p, nn * sizeof(Bvh4Node), hipMemcpyDeviceToDevice, st));
+        HIP_TRY(hipMemcpyAsync(s->trisPrev.p, s->tris.p, nt * sizeof(BvhTri), hipMemcpyDeviceToDevice, st));
+        HIP_TRY(hipMemcpyAsync(s->metaPrev.p, s->meta.p, s->meta.n * sizeof(TriMeta), hipMemcpyDeviceToDevice, st));
         s->refitReady = true;
     }
     std::swap(s->instances.p, s->instancesPrev.p); std::swap(s->nodes.p, s->nodesPrev.p); std::swap(s->tris.p, s->trisPrev.p); std::swap(s->meta.p, s->metaPrev.p);
     s->numNodesPrev = (uint32_t)nn; s->numTrisPrev = (uint32_t)nt; s->hasPrev = true;
-    HIP_TRY(hipMemcpy(s->instances.p, instances, n * sizeof(zr_mesh_instance), hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(s->toWorld.p, instance_to_world, 12 * (size_t)n * sizeof(float), hipMemcpyHostToDevice));
-    hipLaunchKernelGGL(k_refit_tris, dim3((uint32_t)((nt + 255) / 256)), dim3(256), 0, 0, s->tris.p, (uint32_t)nt, s->meta.p, s->instances.p, s->toWorld.p, s->vertices.p, s->indices.p);
+    HIP_TRY(hipMemcpyAsync(s->instances.p, t->host, instBytes, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(s->toWorld.p, (char*)t->host + instBytes, xfBytes, hipMemcpyHostToDevice, st));
+    if ((r = StageCommit(t, st))) return r;
+    hipLaunchKernelGGL(k_refit_tris, dim3((uint32_t)((nt + 255) / 256)), dim3(256), 0, st, s->tris.p, (uint32_t)nt, s->meta.p, s->instances.p, s->toWorld.p, s->vertices.p, s->indices.p);
     for (size_t l = 0; l + 1 < s->levelOffsets.size(); l++)
     {
         const uint32_t first = s->levelOffsets[l], cnt = s->levelOffsets[l + 1] - first;
-        hipLaunchKernelGGL(k_refit_level, dim3((cnt + 63) / 64), dim3(64), 0, 0, s->nodes.p, s->levelNodes.p + first, cnt, s->tris.p, s->nodeBounds.p);
+        hipLaunchKernelGGL(k_refit_level, dim3((cnt + 63) / 64), dim3(64), 0, st, s->nodes.p, s->levelNodes.p + first, cnt, s->tris.p, s->nodeBounds.p);
     }
     HIP_TRY(hipGetLastError());
     SceneView& v = s->view;
     v.instances = s->instances.p; v.nodes = s->nodes.p; v.tris = s->tris.p; v.triMeta = s->meta.p;
+    if (!s->updated) HIP_TRY(hipEventCreateWithFlags(&s->updated, hipEventDisableTiming));
+    HIP_TRY(hipEventRecord(s->updated, st));
+    s->updatedOn = st; s->hasUpdate = true;
+    return ZR_OK;
+}
+// host-synchronous form: the update on the null stream, then wait for the copies and the refit kernels (their errors surface here)
+int zr_scene_update_instances(zr_scene* s, const zr_mesh_instance* instances, const float* instance_to_world, uint32_t n)
+{
+    int r = zr_scene_update_instances_async(s, nullptr, instances, instance_to_world, n);
+    if (r) return r;
+    HIP_TRY(hipDeviceSynchronize());
     return ZR_OK;
 }
 
@@ -1201,16 +1322,31 @@ int zr_wire_layout(char* buf, size_t cap)
 
 int zr_scene_destroy(zr_scene* s) { delete s; return ZR_OK; }
 
-int zr_scene_set_alias_table(zr_scene* s, const zr_alias_entry* e, uint32_t n)
+int zr_scene_set_alias_table_async(zr_scene* s, void* stream, const zr_alias_entry* e, uint32_t n)
 {
     if (!s || !e) return Fail(ZR_ERR_INVALID_ARG, "zr_scene_set_alias_table: null argument");
     if (n != s->view.numEmissives) return Fail(ZR_ERR_INVALID_ARG, "alias table size %u != number of emissive triangles %u", n, s->view.numEmissives);
     HIP_TRY(hipSetDevice(s->device));
-    int r = s->alias.Upload(e, n);
+    hipStream_t st = (hipStream_t)stream;
+    int r; zr_scene::StageSlot* t;
+    if (s->alias.n != n && (r = s->alias.Alloc(n))) return r;      // (re)allocation only when the light count changed: hipFree waits for the device
+    if ((r = StageAcquire(s, (size_t)n * sizeof(zr_alias_entry), &t))) return r;
+    memcpy(t->host, e, (size_t)n * sizeof(zr_alias_entry));
+    if ((r = SceneWaitUsers(s, st))) return r;          // renders of earlier frames on other streams may still draw from the old table
+    HIP_TRY(hipMemcpyAsync(s->alias.p, t->host, (size_t)n * sizeof(zr_alias_entry), hipMemcpyHostToDevice, st));
+    if ((r = StageCommit(t, st))) return r;
+    {
+        std::lock_guard<std::mutex> lock(s->mtx);
+        s->aliasHost.assign(e, e + n);
+        s->view.alias = s->alias.p;
+    }
+    return SceneMarkUpdated(s, st);
+}
+int zr_scene_set_alias_table(zr_scene* s, const zr_alias_entry* e, uint32_t n)
+{
+    int r = zr_scene_set_alias_table_async(s, nullptr, e, n);
     if (r) return r;
-    std::lock_guard<std::mutex> lock(s->mtx);
-    s->aliasHost.assign(e, e + n);
-    s->view.alias = s->alias.p;
+    HIP_TRY(hipDeviceSynchronize());
     return ZR_OK;
 }
 
@@ -1570,7 +1706,7 @@ static int RenderPreLightingInner(zr_pass* p, hipStream_t s, const zr_frame_cons
     HIP_TRY(hipStreamSynchronize(s));
     std::vector<zr_alias_entry> table(n);
     BuildAliasTableHost(power, table.data(), 0);
-    if ((r = zr_scene_set_alias_table(sc, table.data(), n))) return r;
+    if ((r = zr_scene_set_alias_table_async(sc, s, table.data(), n))) return r;      // the upload is ordered on the pass stream, ahead of the sampling kernels
     return p->params.presampling ? RenderPresample(p, s, cb, sc) : ZR_OK;
 }
 
@@ -2125,7 +2261,20 @@ int zr_pass_halo_pack(zr_pass* p, void* stream, const zr_gbuffer* gb, int which,
 int zr_pass_halo_unpack(zr_pass* p, void* stream, const zr_gbuffer* gb, int which, uint32_t x0, uint32_t y0, uint32_t w, uint32_t h, const void* dev_src, size_t bytes)
 { return HaloCopy(p, (hipStream_t)stream, gb, which, x0, y0, w, h, const_cast<void*>(dev_src), bytes, false); }
 
+static int RenderStageInner(zr_pass* p, void* stream, const zr_frame_constants* cb, const zr_scene* sc, zr_gbuffer* gb, int stages);
 int zr_pass_render_stage(zr_pass* p, void* stream, const zr_frame_constants* cb, const zr_scene* sc, zr_gbuffer* gb, int stages)
+{
+    if (!p || !cb || !sc) return Fail(ZR_ERR_INVALID_ARG, "zr_pass_render: null argument");
+    // stream-ordered scene updates: wait (on the device) for an update enqueued on another stream, and leave an event behind this
+    // render for the next update to wait for.  Both are no-ops until the scene has been updated once.
+    HIP_TRY(hipSetDevice(p->device));
+    int r = SceneAcquireForRender(sc, (hipStream_t)stream);
+    if (r) return r;
+    r = RenderStageInner(p, stream, cb, sc, gb, stages);
+    if (r) return r;
+    return SceneReleaseAfterRender(sc, (hipStream_t)stream);
+}
+static int RenderStageInner(zr_pass* p, void* stream, const zr_frame_constants* cb, const zr_scene* sc, zr_gbuffer* gb, int stages)
 {
     if (!p || !cb || !sc) return Fail(ZR_ERR_INVALID_ARG, "zr_pass_render: null argument");
     if (!(stages & ZR_STAGE_ALL)) return Fail(ZR_ERR_INVALID_ARG, "no stage selected");

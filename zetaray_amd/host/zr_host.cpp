@@ -528,15 +528,18 @@ extern "C" int zrh_scene_create_from_gltf(int device, const char* path, const ui
 
 // Per-frame hand-over of a host-maintained scene (zr_scene_io.h: begin_frame / set_instance_world) to the device scene: the moved lights' records,
 // then the instance buffer + matrices (TLAS update: refit on the device, previous structure kept for the passes that bind it).
-extern "C" int zrh_scene_apply_updates(zr_scene* scene, const zrh_scene_data* data)
+// Stream-ordered (zr_scene_update_*_async): enqueued on `stream` like the reference records the TLAS update and the emissive upload on the
+// frame's command list; renders the graph issues on its own (non-blocking) streams are ordered behind it by the library's events.
+extern "C" int zrh_scene_apply_updates_on(zr_scene* scene, const zrh_scene_data* data, void* stream)
 {
     if (!scene || !data) return -1;
     const zr_scene_desc* d = zrh_scene_data_desc(data);
     uint32_t first = 0, count = 0;
     zrh_scene_data_dirty_emissives(data, &first, &count);
-    if (count) { const int r = zr_scene_update_emissives(scene, d->emissives + first, first, count); if (r) return r; }
-    return zr_scene_update_instances(scene, d->instances, d->instance_to_world, d->num_instances);
+    if (count) { const int r = zr_scene_update_emissives_async(scene, stream, d->emissives + first, first, count); if (r) return r; }
+    return zr_scene_update_instances_async(scene, stream, d->instances, d->instance_to_world, d->num_instances);
 }
+extern "C" int zrh_scene_apply_updates(zr_scene* scene, const zrh_scene_data* data) { return zrh_scene_apply_updates_on(scene, data, nullptr); }
 
 int zrh_render_sequence_sky_display(const zr_scene_desc* desc, const zr_frame_constants* cbs, uint32_t n, uint32_t w, uint32_t h, int integrator, float* finalOut, float* skyDiOut,
     float* compositedOut, uint16_t* taaOut, const uint32_t* lutRGB9E5, uint32_t lutDim, int tonemapper, float* exposureOut, float* displayOut, uint8_t* displaySrgbOut);

@@ -48,7 +48,8 @@ struct zrh_scene_data;
 int zrh_scene_create_from_gltf(int device, const char* path, const uint16_t* rho_lut, const uint32_t* rho_dim3, zr_scene** out, uint32_t* tex_offsets4);
 // per frame: upload what zrh_scene_data_begin_frame / zrh_scene_data_set_instance_world changed -- the moved lights' records
 // (zr_scene_update_emissives), then the instance buffer + matrices (zr_scene_update_instances)
-int zrh_scene_apply_updates(zr_scene* scene, const struct zrh_scene_data* data);
+int zrh_scene_apply_updates(zr_scene* scene, const struct zrh_scene_data* data);                       /* enqueued on the null stream, no host wait */
+int zrh_scene_apply_updates_on(zr_scene* scene, const struct zrh_scene_data* data, void* hip_stream); /* enqueued on `hip_stream` */
 }
 
 namespace ZetaRayAMD {
