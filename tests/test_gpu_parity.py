@@ -1205,19 +1205,20 @@ def test_stream_ordered_scene_updates_across_streams(api):
     frames, wants, prev = [], [], None
     nbytes = w * h * 16
     import ctypes as C
-    hip = C.CDLL("libamdhip64.so")
+    # the HIP runtime this process already uses (a second copy loaded by name would not know torch's streams)
+    hip_path = next(l.split()[-1] for l in open("/proc/self/maps") if "libamdhip64" in l)
+    hip = C.CDLL(hip_path)
     hip.hipMemcpyAsync.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]
     for f in range(1, 7):
         if f >= 2:
             a = 0.2 * (f - 1)
             inst, xw, first, tris = scene_io.move_emissive_instance(sc, idx, translation=t0 + np.float32([0.05 * (f - 1), -0.02 * (f - 1), 0.03 * (f - 1)]),
                                                                      rotation=np.array([0.0, np.sin(a / 2), 0.0, np.cos(a / 2)], np.float32), xform_of=xf)
-            r.scene.update_emissives(tris, first, stream=s_upd.cuda_stream)
-            r.scene.update_instances(inst, xw, stream=s_upd.cuda_stream)
-            tris[:] = 0; inst = None          # the caller's arrays may be reused at once (pinned staging ring)
-            inst2, xw2, first2, tris2 = scene_io.move_emissive_instance(sc, idx, translation=t0 + np.float32([0.05 * (f - 1), -0.02 * (f - 1), 0.03 * (f - 1)]),
-                                                                        rotation=np.array([0.0, np.sin(a / 2), 0.0, np.cos(a / 2)], np.float32), xform_of=xf)
-            osc.update_emissives(tris2, first2); osc.update_instances(inst2, xw2)
+            t_dev, i_dev, x_dev = tris.copy(), inst.copy(), np.array(xw, np.float32).copy()
+            r.scene.update_emissives(t_dev, first, stream=s_upd.cuda_stream)
+            r.scene.update_instances(i_dev, x_dev, stream=s_upd.cuda_stream)
+            t_dev.view(np.uint8)[:] = 0xff; i_dev.view(np.uint8)[:] = 0xff; x_dev[:] = 0      # the caller's arrays may be reused at once (pinned staging ring)
+            osc.update_emissives(tris, first); osc.update_instances(inst, xw)
         cb = _frame(sc, w, h, f)
         if prev is not None:
             cb["prev_view"], cb["prev_view_inv"], cb["prev_camera_jitter"] = prev["curr_view"], prev["curr_view_inv"], prev["curr_camera_jitter"]
@@ -1230,7 +1231,7 @@ def test_stream_ordered_scene_updates_across_streams(api):
         assert hip.hipMemcpyAsync(snap.data_ptr(), pt_ptr, nbytes, 3, s_ren.cuda_stream) == 0
         assert hip.hipMemcpyAsync(snap.data_ptr() + nbytes, di_ptr, nbytes, 3, s_ren.cuda_stream) == 0
         frames.append(snap)
-        wants.append((opt.render(cb, prm), odi.render(cb, dprm)))
+        wants.append((opt.render(cb, prm).copy(), odi.render(cb, dprm).copy()))
     torch.cuda.synchronize()
     for f, (snap, (want, want_di)) in enumerate(zip(frames, wants), 1):
         got = snap.cpu().numpy().view(np.float32).reshape(2, h, w, 4)

@@ -54,6 +54,7 @@ static int RequireDevice(int device)
 // the ReSTIR PT kernels are compiled in zr_tu_rpt_a.hip / zr_tu_rpt_b.hip (see zr_kernels.h)
 ZR_RPT_GROUP_A(extern template)
 ZR_RPT_GROUP_B(extern template)
+ZR_RPT_GROUP_C(extern template)
 
 __global__ void __launch_bounds__(kBlock) k_gbuffer(SceneView sc, zr_frame_constants g, GBuf gb, uint32_t tilesX)
 {
@@ -1103,6 +1104,8 @@ int zr_scene_create(int device, const zr_scene_desc* d, zr_scene** out)
     s->hMask.assign(d->instance_mask, d->instance_mask + d->num_instances); s->hNumTris.assign(d->instance_num_tris, d->instance_num_tris + d->num_instances);
     BvhLevels(bvh.nodes4, s->hLevelOrder, s->levelOffsets);
     if (!s->hLevelOrder.empty() && (r = s->levelNodes.Upload(s->hLevelOrder.data(), s->hLevelOrder.size()))) { delete s; return r; }
+    // uploads from pageable memory return once staged; renders on non-blocking streams must not start before the DMA has landed
+    { hipError_t e = hipDeviceSynchronize(); if (e != hipSuccess) { delete s; return Fail(ZR_ERR_HIP, "hipDeviceSynchronize failed: %s", hipGetErrorString(e)); } }
     *out = s;
     return ZR_OK;
 }
@@ -1404,6 +1407,7 @@ int zr_gbuffer_create(int device, uint32_t w, uint32_t h, zr_gbuffer** out)
         hipError_t e = hipMemset(g->planeSets[k][i].p, 0, g->planeSets[k][i].n);
         if (e != hipSuccess) { delete g; return Fail(ZR_ERR_HIP, "hipMemset failed: %s", hipGetErrorString(e)); }
     }
+    { hipError_t e = hipDeviceSynchronize(); if (e != hipSuccess) { delete g; return Fail(ZR_ERR_HIP, "hipDeviceSynchronize failed: %s", hipGetErrorString(e)); } }   // see zr_pass_init
     *out = g;
     return ZR_OK;
 }
@@ -1578,6 +1582,8 @@ int zr_pass_init(zr_pass* p, uint32_t w, uint32_t h, int integrator)
     p->w = w; p->h = h; p->integrator = integrator;
     int r = AllocPass(p);
     if (r) return r;
+    // the clears above are null-stream work and asynchronous to the host; a first render on a non-blocking stream must not overtake them
+    HIP_TRY(hipDeviceSynchronize());
     p->initialized = true;
     return ZR_OK;
 }
@@ -1595,6 +1601,7 @@ int zr_pass_reset_temporal(zr_pass* p)
     if (p->kind == ZR_PASS_INDIRECT) HIP_TRY(hipMemset(p->finalRGBA.p, 0, p->finalRGBA.n * sizeof(float)));
     p->temporalValid = false;       // IndirectLighting::ResetTemporal -> RESET_TEMPORAL_TEXTURES next frame
     if (p->kind == ZR_PASS_DI_EMISSIVE || p->kind == ZR_PASS_DI_SKY) { HIP_TRY(hipMemset(p->finalRGBA.p, 0, p->finalRGBA.n * sizeof(float))); p->currIdx = 0; }   // DirectLighting.cpp:159-164, SkyDI.cpp:128-133
+    HIP_TRY(hipDeviceSynchronize());      // a host call between frames: renders on non-blocking streams must see the cleared plane
     return ZR_OK;
 }
 int zr_pass_set_params(zr_pass* p, const zr_params* prm)
@@ -1925,7 +1932,15 @@ static int RenderReSTIR_PT(zr_pass* p, hipStream_t s, const zr_frame_constants* 
     {
         HIP_TRY(hipMemsetAsync(listCnt, 0, 4 * sizeof(uint32_t), s));
         TimerBegin(p, s, "rpt_pathtrace");
-        if (texVariant) { if (emissiveVariant) hipLaunchKernelGGL(k_rpt_pathtrace_tex<true>, gridRpt, blockRpt, 0, s, F, *cb, tilesX, ctr + 2 * 1); else hipLaunchKernelGGL(k_rpt_pathtrace_tex<false>, gridRpt, blockRpt, 0, s, F, *cb, tilesX, ctr + 2 * 1); }
+        // ZR_K11=pool: K11 with block-pooled traces (k_rpt_pathtrace_coop, zr_kernels.h; emissive untextured permutation); ZR_K11=inline: the megakernel
+        static const int k11Mode = [] { const char* e = getenv("ZR_K11"); return e && !strcmp(e, "inline") ? 0 : (e && !strcmp(e, "pool") ? 1 : ZR_K11_DEFAULT); }();
+        if (k11Mode == 1 && emissiveVariant && !texVariant)
+        {
+            const dim3 gridCoop(tilesX * tilesY), blockCoop(kCoopBlock);
+            if (sc->view.numNodes >= largeSceneNodes) hipLaunchKernelGGL(k_rpt_pathtrace_coop_w4<false>, gridCoop, blockCoop, 0, s, F, *cb, tilesX, ctr + 2 * 1);
+            else hipLaunchKernelGGL(k_rpt_pathtrace_coop<false>, gridCoop, blockCoop, 0, s, F, *cb, tilesX, ctr + 2 * 1);
+        }
+        else if (texVariant) { if (emissiveVariant) hipLaunchKernelGGL(k_rpt_pathtrace_tex<true>, gridRpt, blockRpt, 0, s, F, *cb, tilesX, ctr + 2 * 1); else hipLaunchKernelGGL(k_rpt_pathtrace_tex<false>, gridRpt, blockRpt, 0, s, F, *cb, tilesX, ctr + 2 * 1); }
         else if (sc->view.numNodes >= largeSceneNodes)     // BVH beyond the caches: the 4-wave build of K11 (zr_kernels.h)
         { if (emissiveVariant) hipLaunchKernelGGL(k_rpt_pathtrace_w4<true>, gridRpt, blockRpt, 0, s, F, *cb, tilesX, ctr + 2 * 1); else hipLaunchKernelGGL(k_rpt_pathtrace_w4<false>, gridRpt, blockRpt, 0, s, F, *cb, tilesX, ctr + 2 * 1); }
         else { if (emissiveVariant) hipLaunchKernelGGL(k_rpt_pathtrace<true>, gridRpt, blockRpt, 0, s, F, *cb, tilesX, ctr + 2 * 1); else hipLaunchKernelGGL(k_rpt_pathtrace<false>, gridRpt, blockRpt, 0, s, F, *cb, tilesX, ctr + 2 * 1); }
@@ -2445,7 +2460,7 @@ int zr_pass_read_counters(zr_pass* p, void* stream, zr_counters* out, int reset)
         HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
         HIP_TRY(hipMemcpy(c, p->counters.p, sizeof(c), hipMemcpyDeviceToHost));
         for (int i = 0; i < kCounterSlots; i++) { out->n_closest += c[2 * i]; out->n_shadow += c[2 * i + 1]; }
-        if (reset) HIP_TRY(hipMemset(p->counters.p, 0, sizeof(c)));
+        if (reset) { HIP_TRY(hipMemsetAsync(p->counters.p, 0, sizeof(c), (hipStream_t)stream)); HIP_TRY(hipStreamSynchronize((hipStream_t)stream)); }
     }
     if (reset) { p->hostCounters.n_closest = 0; p->hostCounters.n_shadow = 0; }
     return ZR_OK;

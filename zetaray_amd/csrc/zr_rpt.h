@@ -404,22 +404,40 @@ ZR_HD Reservoir Load_NonReconnection(const ResPlanes& p, size_t i)
 struct Globals { bool textured = false; const SceneView* sc; const SceneView* scPrev = nullptr; uint32_t numEmissives; int maxNumBounces; float alpha_min; TravStack stack; uint32_t* cnt; bool presampled; uint32_t sampleSetIdx;
     const zr_frame_constants* frame; bool emissive; };
 
-// ---- ray queries (inline traversal)
+// ---- ray queries.  Every query is "build the ray" -> traverse -> "read the hit"; the halves are separate functions so that a kernel can
+// run the traversal somewhere else than the calling lane (the block-cooperative ray pool of zr_kernels.h: BlockTrace).  want == false: the
+// query ends without a ray (the reference's early-outs).
+struct TraceReq { bool want; V3 o, d; float tmin, tmax; uint32_t mask; bool anyHit, filterID; uint32_t ignoreID; };
+ZR_HD TraceReq NoTraceReq() { TraceReq q; q.want = false; q.o = v3(0.0f); q.d = v3(0.0f); q.tmin = 0; q.tmax = 0; q.mask = 0; q.anyHit = false; q.filterID = false; q.ignoreID = 0; return q; }
+ZR_HD RawHit NoRawHit() { RawHit h; h.t = 0; h.u = 0; h.v = 0; h.tri = kInvalidTri; return h; }
+ZR_HD RawHit TraceInline(const SceneView& sc, const TraceReq& q, const TravStack& stack)
+{ return q.want ? TraverseDyn(sc, q.o, q.d, q.tmin, q.tmax, q.mask, stack, q.anyHit, q.filterID, q.ignoreID) : NoRawHit(); }
+
 struct HitEm { bool hit; float t; uint32_t mesh, prim, emissiveTriIdx; float bu, bv; };
 // Hit_Emissive::FindClosest, RayQuery.hlsli:146-207
-ZR_HD HitEm FindClosestEm(const Globals& g, V3 pos, V3 normal, V3 wi, bool transmissive)
+ZR_HD TraceReq ClosestEmReq(uint32_t* cnt, V3 pos, V3 normal, V3 wi, bool transmissive)
+{
+    TraceReq q = NoTraceReq();
+    F4 ro, rd;
+    if (!MakeClosestRay(pos, normal, wi, transmissive, true, &ro, &rd)) return q;
+    cnt[0]++;
+    q.want = true; q.o = xyz(ro); q.d = xyz(rd); q.tmin = ro.w; q.tmax = rd.w; q.mask = ZR_SUBGROUP_ALL;
+    return q;
+}
+ZR_HD HitEm ClosestEmResult(const SceneView& sc, const TraceReq& q, const RawHit& h)
 {
     HitEm r; r.hit = false; r.emissiveTriIdx = 0xffffffffu; r.t = 0; r.mesh = 0; r.prim = 0; r.bu = 0; r.bv = 0;
-    F4 ro, rd;
-    if (!MakeClosestRay(pos, normal, wi, transmissive, true, &ro, &rd)) return r;
-    g.cnt[0]++;
-    RawHit h = Traverse<false>(*g.sc, xyz(ro), xyz(rd), ro.w, rd.w, ZR_SUBGROUP_ALL, g.stack);
-    if (h.tri == kInvalidTri) return r;
-    const TriMeta tm = g.sc->triMeta[h.tri];
+    if (!q.want || h.tri == kInvalidTri) return r;
+    const TriMeta tm = sc.triMeta[h.tri];
     r.hit = true; r.t = h.t; r.bu = h.u; r.bv = h.v; r.mesh = tm.mesh; r.prim = tm.prim;
-    const uint32_t base = g.sc->instances[tm.mesh].base_emissive_tri_offset;
+    const uint32_t base = sc.instances[tm.mesh].base_emissive_tri_offset;
     if (base != 0xffffffffu) r.emissiveTriIdx = base + tm.prim;
     return r;
+}
+ZR_HD HitEm FindClosestEm(const Globals& g, V3 pos, V3 normal, V3 wi, bool transmissive)
+{
+    const TraceReq q = ClosestEmReq(g.cnt, pos, normal, wi, transmissive);
+    return ClosestEmResult(*g.sc, q, TraceInline(*g.sc, q, g.stack));
 }
 // Hit::FindClosest<ID = true>, RayQuery.hlsli:15-144
 ZR_HD bool FindClosestID(const Globals& g, bool currFrame, V3 pos, V3 normal, V3 wi, bool transmissive, HitInfo& hit, bool wantDiffs = false)
@@ -435,43 +453,53 @@ ZR_HD bool FindClosestID(const Globals& g, bool currFrame, V3 pos, V3 normal, V3
     else FillHit<false>(*g.sc, tm.mesh, tm.prim, h.u, h.v, true, hit, currFrame);
     return true;
 }
-// Visibility_Segment with APPROXIMATE_EMISSIVE_SHADOW_RAY == 1 (RayQuery.hlsli:337-406)
-ZR_HD bool VisibilitySegmentApprox(const Globals& g, V3 origin, V3 wi, float rayT, V3 normal, uint32_t triID, bool transmissive)
+// Visibility_Segment with APPROXIMATE_EMISSIVE_SHADOW_RAY == 1 (RayQuery.hlsli:337-406); visible iff the ray was emitted and hit nothing
+ZR_HD TraceReq SegmentApproxReq(uint32_t* cnt, V3 origin, V3 wi, float rayT, V3 normal, uint32_t triID, bool transmissive)
 {
-    if (triID == 0xffffffffu) return false;
-    if (rayT < 1e-6f) return false;
+    TraceReq q = NoTraceReq();
+    if (triID == 0xffffffffu) return q;
+    if (rayT < 1e-6f) return q;
     float ndotwi = dot(normal, wi);
-    if (ndotwi == 0) return false;
+    if (ndotwi == 0) return q;
     if (ndotwi < 0)
     {
         if (transmissive) normal = normal * -1.0f;
-        else return false;
+        else return q;
     }
     const V3 o = OffsetRayRTG(origin, normal);
     const float tminv = 3e-6f;
     const float tmax = PrevFloat32(rayT * 0.999f - NextFloat32(tminv));
-    g.cnt[1]++;
+    cnt[1]++;
     // "first accepted hit, visible iff its ID is the target's" (RayQuery.hlsli:372-405) depends on the traversal order; pinned
     // order-independently: triangles carrying the target's ID are not occluders, any other hit in the shortened segment is
-    RawHit h = Traverse<true>(*g.sc, o, wi, tminv, tmax, ZR_SUBGROUP_NON_EMISSIVE, g.stack, true, triID);
-    return h.tri == kInvalidTri;
+    q.want = true; q.o = o; q.d = wi; q.tmin = tminv; q.tmax = tmax; q.mask = ZR_SUBGROUP_NON_EMISSIVE; q.anyHit = true; q.filterID = true; q.ignoreID = triID;
+    return q;
+}
+ZR_HD bool SegmentVisible(const TraceReq& q, const RawHit& h) { return q.want && h.tri == kInvalidTri; }
+ZR_HD bool VisibilitySegmentApprox(const Globals& g, V3 origin, V3 wi, float rayT, V3 normal, uint32_t triID, bool transmissive)
+{
+    const TraceReq q = SegmentApproxReq(g.cnt, origin, wi, rayT, normal, triID, transmissive);
+    return SegmentVisible(q, TraceInline(*g.sc, q, g.stack));
 }
 
 ZR_HD bool IsSpecular(const Surface& s) { return s.GlossSpecular() && (s.metallic || s.specTr) && (!s.Coated() || s.CoatSpecular()); }
 
-// ReSTIR_PT_NEE.hlsli:134-207
-ZR_HD Direct NEE_Bsdf(const Globals& g, V3 pos, V3 normal, const Surface& surface, int nextBounce, BsdfSample& bs, HitEm& hitInfo, Rng& rng)
+// ReSTIR_PT_NEE.hlsli:134-207, cut at its FindClosest: the BSDF sample ...
+ZR_HD void NEE_Bsdf_Pre(const Globals& g, V3 normal, const Surface& surface, int nextBounce, BsdfSample& bs, Rng& rng)
+{
+    bs = InitBsdfSample();
+    if (nextBounce <= g.maxNumBounces) { ZR_PROF_SCOPE(ZRP_BSDF); bs = SampleBSDF(g.sc->rho, normal, surface, rng); }
+}
+// ... and what its ray found
+ZR_HD Direct NEE_Bsdf_Post(const Globals& g, V3 pos, const Surface& surface, int nextBounce, BsdfSample& bs, const HitEm& hitInfo)
 {
     const SceneView& sc = *g.sc;
     Direct ret = InitDirect();
     const bool specular = IsSpecular(surface);
     const int numLightSamples = specular ? 0 : 1;
-    bs = InitBsdfSample();
-    if (nextBounce <= g.maxNumBounces) { ZR_PROF_SCOPE(ZRP_BSDF); bs = SampleBSDF(sc.rho, normal, surface, rng); }
     const float wiPdf = bs.pdf;
     const V3 wi = bs.wi;
     const V3 f = bs.f;
-    hitInfo = FindClosestEm(g, pos, normal, wi, surface.Transmissive());
     if (hitInfo.emissiveTriIdx != 0xffffffffu)
     {
         const zr_emissive_triangle em = sc.emissives[hitInfo.emissiveTriIdx];
@@ -498,13 +526,21 @@ ZR_HD Direct NEE_Bsdf(const Globals& g, V3 pos, V3 normal, const Surface& surfac
     if (nextBounce >= g.maxNumBounces) bs.bsdfOverPdf = v3(0.0f);
     return ret;
 }
+ZR_HD Direct NEE_Bsdf(const Globals& g, V3 pos, V3 normal, const Surface& surface, int nextBounce, BsdfSample& bs, HitEm& hitInfo, Rng& rng)
+{
+    NEE_Bsdf_Pre(g, normal, surface, nextBounce, bs, rng);
+    hitInfo = FindClosestEm(g, pos, normal, bs.wi, surface.Transmissive());
+    return NEE_Bsdf_Post(g, pos, surface, nextBounce, bs, hitInfo);
+}
 
-// ReSTIR_PT_NEE.hlsli:209-284 (alias-table branch)
-ZR_HD Direct NEE_Emissive(const Globals& g, V3 pos, V3 normal, Surface surface, Rng& rng)
+// ReSTIR_PT_NEE.hlsli:209-284 (alias-table branch), cut at its Visibility_Segment: the light sample and its unshadowed contribution ...
+struct NeeEmState { Direct ret; Surface surface; V3 ld, le, ln, lpos, wi; float lightPdf, t, dwdA; uint32_t lightID; bool twoSided, facing; };
+ZR_HD TraceReq NEE_Emissive_Pre(const Globals& g, V3 pos, V3 normal, const Surface& surfaceIn, Rng& rng, NeeEmState& S)
 {
     const SceneView& sc = *g.sc;
-    Direct ret = InitDirect();
-    ret.lt = LT_EMISSIVE; ret.lobe = LOBE_ALL;
+    S.surface = surfaceIn;
+    S.ret = InitDirect();
+    S.ret.lt = LT_EMISSIVE; S.ret.lobe = LOBE_ALL;
     V3 lpos, ln, le; float lightPdf; uint32_t lightID; bool twoSided;
     if (g.presampled)       // USE_PRESAMPLED_SETS, ReSTIR_PT_NEE.hlsli:217-236
     {
@@ -538,24 +574,39 @@ ZR_HD Direct NEE_Emissive(const Globals& g, V3 pos, V3 normal, Surface surface, 
     }
     const float t = length(lpos - pos);
     const V3 wi = (lpos - pos) / t;
-    if ((dot(ln, -wi) > 0) && (t > 0))
+    S.lpos = lpos; S.ln = ln; S.le = le; S.lightPdf = lightPdf; S.lightID = lightID; S.twoSided = twoSided; S.t = t; S.wi = wi;
+    S.facing = (dot(ln, -wi) > 0) && (t > 0);
+    S.ld = v3(0.0f); S.dwdA = 0;
+    if (!S.facing) return NoTraceReq();
+    S.dwdA = zr_saturate(dot(ln, -wi)) / (t * t);
+    S.surface.SetWi(wi, normal);
+    S.ld = le * Unified(sc.rho, S.surface).f * S.dwdA;
+    if (!(dot(S.ld, S.ld) > 0)) return NoTraceReq();
+    return SegmentApproxReq(g.cnt, pos, wi, t, normal, lightID, S.surface.Transmissive());
+}
+// ... and the rest once the segment's visibility is known (`visible` is only read when the unshadowed contribution was non-zero)
+ZR_HD Direct NEE_Emissive_Post(const Globals& g, V3 normal, NeeEmState& S, bool visible, Rng& rng)
+{
+    if (!S.facing) return S.ret;
+    V3 ld = S.ld;
+    if (dot(ld, ld) > 0) ld = ld * (visible ? 1.0f : 0.0f);
+    float bsdfPdf = 0;
+    if (dot(ld, ld) > 0)
     {
-        const float dwdA = zr_saturate(dot(ln, -wi)) / (t * t);
-        surface.SetWi(wi, normal);
-        V3 ld = le * Unified(sc.rho, surface).f * dwdA;
-        if (dot(ld, ld) > 0)
-            ld = ld * (VisibilitySegmentApprox(g, pos, wi, t, normal, lightID, surface.Transmissive()) ? 1.0f : 0.0f);
-        float bsdfPdf = 0;
-        if (dot(ld, ld) > 0)
-        {
-            { ZR_PROF_SCOPE(ZRP_NEE); bsdfPdf = BSDFSamplerPdf(sc.rho, normal, surface, wi, rng); }
-            bsdfPdf *= dwdA;
-        }
-        ret.ld = PowerHeuristic(lightPdf, bsdfPdf, ld, 1.0f, 1.0f);
-        ret.le = le; ret.wi = wi; ret.pdf_solidAngle = lightPdf / dwdA; ret.dwdA = dwdA; ret.ID = lightID;
-        ret.pos = lpos; ret.normal = ln; ret.pdf_light = lightPdf; ret.twoSided = twoSided;
+        { ZR_PROF_SCOPE(ZRP_NEE); bsdfPdf = BSDFSamplerPdf(g.sc->rho, normal, S.surface, S.wi, rng); }
+        bsdfPdf *= S.dwdA;
     }
+    Direct& ret = S.ret;
+    ret.ld = PowerHeuristic(S.lightPdf, bsdfPdf, ld, 1.0f, 1.0f);
+    ret.le = S.le; ret.wi = S.wi; ret.pdf_solidAngle = S.lightPdf / S.dwdA; ret.dwdA = S.dwdA; ret.ID = S.lightID;
+    ret.pos = S.lpos; ret.normal = S.ln; ret.pdf_light = S.lightPdf; ret.twoSided = S.twoSided;
     return ret;
+}
+ZR_HD Direct NEE_Emissive(const Globals& g, V3 pos, V3 normal, const Surface& surface, Rng& rng)
+{
+    NeeEmState S;
+    const TraceReq q = NEE_Emissive_Pre(g, pos, normal, surface, rng, S);
+    return NEE_Emissive_Post(g, normal, S, SegmentVisible(q, TraceInline(*g.sc, q, g.stack)), rng);
 }
 
 // ReSTIR_PT_NEE.hlsli:306-391
@@ -742,6 +793,54 @@ ZR_HD void EstimateDirectAndUpdateRC(const Globals& g, int pathVertex, V3 pos, c
     bs = nbs;
 }
 
+// EstimateDirectAndUpdateRC<true> (ReSTIR_PT_PathTrace.hlsl:77-170) cut at its two BVH queries -- the BSDF ray of NEE_Bsdf and the light
+// segment of NEE_Emissive -- for kernels that trace elsewhere (zr_kernels.h: RptPathtraceBodyCoop).  Same statements in the same order as
+// the function above; `M` carries what lives across the cuts.
+struct PtMid { BsdfSample nbs; NeeEmState nee; bool doNee; uint32_t seed_nee; TraceReq q1, q2; };
+ZR_HD void EstimateDirectEm_Pre(const Globals& g, int pathVertex, V3 pos, const HitInfo& hit, const Surface& surface, Rng& rngReplay, PtMid& M)
+{
+    const int nextBounce = pathVertex - 1;
+    NEE_Bsdf_Pre(g, hit.normal, surface, nextBounce, M.nbs, rngReplay);
+    M.q1 = ClosestEmReq(g.cnt, pos, hit.normal, M.nbs.wi, surface.Transmissive());
+}
+ZR_HD void EstimateDirectEm_Mid(const Globals& g, int pathVertex, V3 pos, const HitInfo& hit, const Surface& surface, const PrevHit& prevHit,
+    V3 throughput, V3 throughput_k, V3& li, HitEm& nextHit, Reconnection& rc, Reservoir& r, Rng& rngNEE, PtMid& M, const RawHit& h1)
+{
+    const int nextBounce = pathVertex - 1;
+    nextHit = ClosestEmResult(*g.sc, M.q1, h1);
+    const Direct ls_b = NEE_Bsdf_Post(g, pos, surface, nextBounce, M.nbs, nextHit);
+    if (nextHit.emissiveTriIdx != 0xffffffffu)
+    {
+        const V3 fOverPdf = throughput * ls_b.ld;
+        li = li + fOverPdf;
+        rc.L = RoundHalf3(ls_b.ld * throughput_k);
+        MaybeSetCase2OrCase3(g, pathVertex, pos, hit.normal, hit.t, hit.ID, hit.meshIdx, surface, prevHit, ls_b, 0, rc);
+        r.Update(Luminance(fOverPdf), fOverPdf, rc, rngNEE);
+    }
+    M.doNee = !IsSpecular(surface);
+    M.q2 = NoTraceReq();
+    if (M.doNee)
+    {
+        M.seed_nee = rngNEE.s;
+        M.q2 = NEE_Emissive_Pre(g, pos, hit.normal, surface, rngNEE, M.nee);
+    }
+}
+ZR_HD void EstimateDirectEm_Post(const Globals& g, int pathVertex, V3 pos, const HitInfo& hit, const Surface& surface, const PrevHit& prevHit,
+    V3 throughput, V3 throughput_k, V3& li, BsdfSample& bs, Reconnection& rc, Reservoir& r, Rng& rngNEE, PtMid& M, const RawHit& h2)
+{
+    if (M.doNee)
+    {
+        const Direct ls = NEE_Emissive_Post(g, hit.normal, M.nee, SegmentVisible(M.q2, h2), rngNEE);
+        const V3 fOverPdf = throughput * ls.ld;
+        li = li + fOverPdf;
+        if (rc.IsCase2() || rc.IsCase3()) rc.Clear();
+        rc.L = RoundHalf3(ls.ld * throughput_k);
+        MaybeSetCase2OrCase3(g, pathVertex, pos, hit.normal, hit.t, hit.ID, hit.meshIdx, surface, prevHit, ls, M.seed_nee, rc);
+        r.Update(Luminance(fOverPdf), fOverPdf, rc, rngNEE);
+    }
+    bs = M.nbs;
+}
+
 // ---- G-buffer reads
 struct GFlags { bool metallic, transmissive, emissive, invalid, trDepthGt0, subsurface, coated; };
 ZR_HD GFlags DecodeFlags(uint16_t mrp)
@@ -882,10 +981,18 @@ struct RptParams
     uint32_t temporalMap;                    // which map schedules the fused CtT + TtC kernel: 0 none, 1 CtN, 2 NtC
 };
 
-// main() prologue + RIS_InitialCandidates up to the first FindClosest (ReSTIR_PT_PathTrace.hlsl:360-530, 194-236)
-ZR_HD void PtInitLane(const SceneView& sc, const zr_frame_constants& g, const GBuf& gb, const RptParams& prm, bool owned, uint32_t x, uint32_t y,
-    float* finalRGBA, TravStack stack, uint32_t* cnt, PTLane& P)
+ZR_HD Globals PtGlobals(const SceneView& sc, const zr_frame_constants& g, const RptParams& prm, const TravStack& stack, uint32_t* cnt, int maxNumBounces, uint32_t sampleSetIdx)
 {
+    Globals gl; gl.sc = &sc; gl.frame = &g; gl.emissive = prm.emissive != 0; gl.numEmissives = g.num_emissive_triangles; gl.maxNumBounces = maxNumBounces; gl.alpha_min = prm.alpha_min; gl.stack = stack; gl.cnt = cnt;
+    gl.presampled = prm.numSampleSets != 0; gl.sampleSetIdx = sampleSetIdx;
+    return gl;
+}
+// main() prologue + RIS_InitialCandidates up to the first FindClosest (ReSTIR_PT_PathTrace.hlsl:360-530, 194-236); q0 = that query
+// (emissive variant only: the sun + sky variant traces at the top of PtPhaseA)
+ZR_HD void PtInitLane_Pre(const SceneView& sc, const zr_frame_constants& g, const GBuf& gb, const RptParams& prm, bool owned, uint32_t x, uint32_t y,
+    float* finalRGBA, uint32_t* cnt, PTLane& P, TraceReq& q0)
+{
+    q0 = NoTraceReq();
     P.active = false; P.atRR = false; P.valid = false; P.x = x; P.y = y;
     if (!owned) return;
     const size_t px = Pix(gb, x, y);
@@ -915,31 +1022,102 @@ ZR_HD void PtInitLane(const SceneView& sc, const zr_frame_constants& g, const GB
     P.throughput_k = v3(1.0f);
     P.inMedium = P.eta_curr != kEtaAir;
     P.pos = ps.pos; P.normal = ps.normal; P.surface = ps.surface; P.bs = bs; P.eta_next = ps.eta_next;
-    Globals gl; gl.sc = &sc; gl.frame = &g; gl.emissive = prm.emissive != 0; gl.numEmissives = g.num_emissive_triangles; gl.maxNumBounces = P.maxNumBounces; gl.alpha_min = prm.alpha_min; gl.stack = stack; gl.cnt = cnt;
-    gl.presampled = prm.numSampleSets != 0; gl.sampleSetIdx = P.sampleSetIdx;
-    if (prm.emissive) P.nextHit = FindClosestEm(gl, ps.pos, ps.normal, bs.wi, ps.surface.Transmissive());
+    if (prm.emissive) q0 = ClosestEmReq(cnt, ps.pos, ps.normal, bs.wi, ps.surface.Transmissive());
     P.active = true;
 }
+ZR_HD void PtInitLane_Post(const SceneView& sc, const RptParams& prm, PTLane& P, const TraceReq& q0, const RawHit& h0)
+{ if (P.active && prm.emissive) P.nextHit = ClosestEmResult(sc, q0, h0); }
+ZR_HD void PtInitLane(const SceneView& sc, const zr_frame_constants& g, const GBuf& gb, const RptParams& prm, bool owned, uint32_t x, uint32_t y,
+    float* finalRGBA, TravStack stack, uint32_t* cnt, PTLane& P)
+{
+    TraceReq q0;
+    PtInitLane_Pre(sc, g, gb, prm, owned, x, y, finalRGBA, cnt, P, q0);
+    PtInitLane_Post(sc, prm, P, q0, TraceInline(sc, q0, stack));
+}
 
-ZR_HD void PtPhaseA(const SceneView& sc, const zr_frame_constants& g, const RptParams& prm, TravStack stack, uint32_t* cnt, PTLane& P)
+// PtPhaseA of the emissive variant, cut at its two BVH queries (M.q1 after _Pre, M.q2 after _Mid)
+ZR_HD void PtPhaseA_Pre(const SceneView& sc, const zr_frame_constants& g, const RptParams& prm, uint32_t* cnt, PTLane& P, PtMid& M)
 {
     P.atRR = false;
+    M.q1 = NoTraceReq(); M.q2 = NoTraceReq(); M.doNee = false;
     if (!P.active) return;
-    Globals gl; gl.sc = &sc; gl.frame = &g; gl.emissive = prm.emissive != 0; gl.numEmissives = g.num_emissive_triangles; gl.maxNumBounces = P.maxNumBounces; gl.alpha_min = prm.alpha_min; gl.stack = stack; gl.cnt = cnt;
-    gl.presampled = prm.numSampleSets != 0; gl.sampleSetIdx = P.sampleSetIdx;
+    TravStack noStack; noStack.lds = nullptr; noStack.stride = 0; noStack.mem = nullptr;
+    const Globals gl = PtGlobals(sc, g, prm, noStack, cnt, P.maxNumBounces, P.sampleSetIdx);
     P.pathVertex = P.bounce + 2;
     V3 newPos;
     {
     ZR_PROF_SCOPE(ZRP_MATERIAL);
-    if (prm.emissive)
+    // the BSDF ray of the previous vertex's NEE (ReSTIR_PT_PathTrace.hlsl:235-239)
+    if (!P.nextHit.hit) { P.active = false; return; }
+    P.hit.t = P.nextHit.t;
+    if (prm.textured) FillHit<true>(sc, P.nextHit.mesh, P.nextHit.prim, P.nextHit.bu, P.nextHit.bv, true, P.hit, true);
+    else FillHit<false>(sc, P.nextHit.mesh, P.nextHit.prim, P.nextHit.bu, P.nextHit.bv, true, P.hit, true);
+    newPos = mad(P.hit.t, P.bs.wi, P.pos);
+    float eta_mat;
+    V4 uvGrads = v4(0, 0, 0, 0);
+    if (prm.textured)
     {
-        // the BSDF ray of the previous vertex's NEE (ReSTIR_PT_PathTrace.hlsl:235-239)
-        if (!P.nextHit.hit) { P.active = false; return; }
-        P.hit.t = P.nextHit.t;
-        if (prm.textured) FillHit<true>(sc, P.nextHit.mesh, P.nextHit.prim, P.nextHit.bu, P.nextHit.bv, true, P.hit, true);
-        else FillHit<false>(sc, P.nextHit.mesh, P.nextHit.prim, P.nextHit.bu, P.nextHit.bv, true, P.hit, true);
+        P.rd.dpdx_dpdy(newPos, P.hit.normal, P.dpdx, P.dpdy);
+        P.rd.ComputeUVDifferentials(P.dpdx, P.dpdy, P.hit.dpdu, P.hit.dpdv);
+        uvGrads = P.rd.uv_grads;
     }
-    else if (!FindClosestID(gl, true, P.pos, P.normal, P.bs.wi, P.surface.Transmissive(), P.hit, prm.textured)) { P.active = false; return; }   // Hit::FindClosest<true, true>
+    if (!GetMaterialData(sc, -P.bs.wi, P.eta_curr, P.hit, P.surface, eta_mat, uvGrads, prm.textured)) { P.active = false; return; }
+    P.eta_next = eta_mat;
+    }
+    P.pos = newPos;
+    P.normal = P.hit.normal;
+    P.prevPdf = P.bs.pdf; P.prevLobe = P.bs.lobe;
+    P.tr = v3(1.0f);
+    if (P.inMedium && (P.surface.trDepth > 0))
+    {
+        V3 ext = -vlog(P.surface.base) / P.surface.trDepth;
+        P.tr = vexp(-P.hit.t * ext);
+        P.throughput = P.throughput * P.tr;
+    }
+    EstimateDirectEm_Pre(gl, P.pathVertex, P.pos, P.hit, P.surface, P.rngReplay, M);
+}
+// `live`: the lane went through _Pre without leaving the path (P.active may only be cleared by _Post's bookkeeping)
+ZR_HD void PtPhaseA_Mid(const SceneView& sc, const zr_frame_constants& g, const RptParams& prm, uint32_t* cnt, PTLane& P, PtMid& M, const RawHit& h1)
+{
+    if (!P.active) return;
+    TravStack noStack; noStack.lds = nullptr; noStack.stride = 0; noStack.mem = nullptr;
+    const Globals gl = PtGlobals(sc, g, prm, noStack, cnt, P.maxNumBounces, P.sampleSetIdx);
+    ZR_PROF_SCOPE(ZRP_MISC4);
+    EstimateDirectEm_Mid(gl, P.pathVertex, P.pos, P.hit, P.surface, P.prevHit, P.throughput, P.throughput_k, P.li, P.nextHit, P.rc, P.r, P.rngThread, M, h1);
+}
+ZR_HD void PtPhaseA_Post(const SceneView& sc, const zr_frame_constants& g, const RptParams& prm, uint32_t* cnt, PTLane& P, PtMid& M, const RawHit& h2)
+{
+    if (!P.active) return;
+    TravStack noStack; noStack.lds = nullptr; noStack.stride = 0; noStack.mem = nullptr;
+    const Globals gl = PtGlobals(sc, g, prm, noStack, cnt, P.maxNumBounces, P.sampleSetIdx);
+    { ZR_PROF_SCOPE(ZRP_MISC3);
+    EstimateDirectEm_Post(gl, P.pathVertex, P.pos, P.hit, P.surface, P.prevHit, P.throughput, P.throughput_k, P.li, P.bs, P.rc, P.r, P.rngThread, M, h2); }
+    if (P.bounce >= (P.maxNumBounces - 1)) { P.active = false; return; }
+    if (P.rc.IsCase2() || P.rc.IsCase3()) P.rc.Clear();
+    P.bounce++;
+    P.atRR = prm.russianRoulette && (P.bounce >= 3);
+}
+
+ZR_HD void PtPhaseA(const SceneView& sc, const zr_frame_constants& g, const RptParams& prm, TravStack stack, uint32_t* cnt, PTLane& P)
+{
+    if (prm.emissive)
+    {   // the cut form with its queries traced in place: one statement sequence for the megakernel, the host executor and the cooperative kernel
+        PtMid M;
+        PtPhaseA_Pre(sc, g, prm, cnt, P, M);
+        const RawHit h1 = TraceInline(sc, M.q1, stack);
+        PtPhaseA_Mid(sc, g, prm, cnt, P, M, h1);
+        const RawHit h2 = TraceInline(sc, M.q2, stack);
+        PtPhaseA_Post(sc, g, prm, cnt, P, M, h2);
+        return;
+    }
+    P.atRR = false;
+    if (!P.active) return;
+    Globals gl = PtGlobals(sc, g, prm, stack, cnt, P.maxNumBounces, P.sampleSetIdx);
+    P.pathVertex = P.bounce + 2;
+    V3 newPos;
+    {
+    ZR_PROF_SCOPE(ZRP_MATERIAL);
+    if (!FindClosestID(gl, true, P.pos, P.normal, P.bs.wi, P.surface.Transmissive(), P.hit, prm.textured)) { P.active = false; return; }   // Hit::FindClosest<true, true>
     newPos = mad(P.hit.t, P.bs.wi, P.pos);
     float eta_mat;
     V4 uvGrads = v4(0, 0, 0, 0);
