@@ -47,6 +47,29 @@ RPT_PIXEL_BYTES = {
 
 from zetaray_amd.tiling import tile_grid, tile_rect  # noqa: E402  (shared with the tests and the tiled renderer)
 
+_CORNELL_SKY = os.path.join(ROOT, "tests", "golden", "cornell.npz")
+# --config presets: BASELINE.json "configs"  -> the flags below
+CONFIGS = {
+    "2a": ("config 2, emissive half: Cornell (emissive) 1080p, ReSTIR DI only (K5/K6)", dict(direct=True, di_only=True, integrator="pt")),
+    "2b": ("config 2, sun + sky half: the reference's default Cornell box 1080p, SkyDI only (K7/K8)", dict(scene=_CORNELL_SKY, sky_direct=True, di_only=True, integrator="pt")),
+    "3": ("config 3: Cornell (emissive) 1080p ReSTIR GI, 3 bounces, temporal reuse", dict(integrator="restir_gi")),
+    "4": ("config 4 on one GPU: 380k-triangle / 100k-light atrium 1080p ReSTIR PT", dict(scene="synthetic", steps=32, warmup=8)),
+    "4k": ("config 5 without the denoise pass: the atrium at 3840x2160 ReSTIR PT", dict(scene="synthetic", width=3840, height=2160, steps=16, warmup=4)),
+    "pt": ("K9 unidirectional path tracer on the Cornell box (config 1's integrator at 1080p)", dict(integrator="pt")),
+}
+
+
+def source_hash():
+    """identifies the kernel sources a profile was taken with: sha1 over zetaray_amd/csrc + include (profiles/*.json carry it; a
+    roofline.traffic / valu block is only reported from a profile whose hash matches the sources of the library being benchmarked)"""
+    import glob
+    import hashlib
+    h = hashlib.sha1()
+    for f in sorted(glob.glob(os.path.join(ROOT, "zetaray_amd", "csrc", "*.h*")) + glob.glob(os.path.join(ROOT, "include", "*.h"))):
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
 
 def cpu_baseline(scene_host, cb, max_rays=1_000_000, rpt_params=None):
     """Single-thread CPU traversal (oracle BVH2 + ABI intersection) over primary + diffuse-bounce rays of this frame."""
@@ -163,7 +186,18 @@ def main():
     ap.add_argument("--di-only", action="store_true", help="skip the indirect pass: BASELINE config 1 (ReSTIR DI only)")
     ap.add_argument("--integrator", choices=["restir_pt", "restir_gi", "pt"], default="restir_pt",
                     help="restir_pt = K11-K16 (BASELINE metric); pt = K9 unidirectional path tracer")
+    ap.add_argument("--config", choices=sorted(CONFIGS), default=None,
+                    help="BASELINE.json configuration presets (same JSON line; the default without --config is the metric's own configuration, "
+                         "Cornell (emissive) 1920x1080 ReSTIR PT): " + "; ".join(f"{k} = {v[0]}" for k, v in sorted(CONFIGS.items())))
+    ap.add_argument("--settle", type=int, default=None,
+                    help="untimed frames rendered BEFORE the warm-up so that the temporal reservoirs have reached their M caps whatever --warmup is "
+                         "(default: 32 for the ReSTIR integrators, 0 otherwise)")
     args = ap.parse_args()
+    if args.config:
+        for k, v in CONFIGS[args.config][1].items():
+            if k in ("steps", "warmup") and getattr(args, k) != ap.get_default(k):
+                continue        # an explicit --steps / --warmup wins over the preset's
+            setattr(args, k, v)
 
     import torch
     from zetaray_amd import api, scene_io, wire
@@ -193,7 +227,7 @@ def main():
             scene_name += ", textured (base colour / normal / metallic-roughness / emissive maps, alpha-tested instance)"
     else:
         sc = scene_io.load_npz(args.scene)
-        scene_name = f"Cornell Box ({os.path.basename(args.scene)[:-4]}: {sc.num_tris} triangles, {len(sc.emissives)} emissive)"
+        scene_name = f"Cornell Box ({os.path.basename(args.scene)[:-4]}: {sc.num_tris} triangles, {len(sc.emissives)} emissive" + (", sun + sky" if len(sc.emissives) == 0 else "") + ")"
     prm = wire.default_params()
     if args.scene == "synthetic":
         # the reference turns light presampling on above a light-count threshold (PreLighting.cpp:289-297)
@@ -211,6 +245,29 @@ def main():
         transport = os.environ.get("ZR_HALO_TRANSPORT", "rccl_cpp")
         tiled = tiling.TiledRestirPT(sc, W, H, world, rank, device=local_rank, params=prm, dist=dist, kind=args.integrator, transport=transport)
         r = tiled.r
+        layout_kind = "equal-area grid"
+        if world > 1 and rpt and os.environ.get("ZR_TILE_LAYOUT", "cost") == "cost":
+            # cost-balanced split: a few frames on the equal-area grid with the per-cell ray counters on, every rank contributes the cells of
+            # its own tile, and all ranks cut the frame by the same kd-split on the summed map (tiling.balanced_layout)
+            r.p_indirect.enable_cost_map(True)
+            for i in range(12):
+                cbp = scene_io.make_frame_constants(W, H, frame_num=1 + i, num_emissives=len(sc.emissives), **cam)
+                tiled.render_frame(cbp, exchange_final=not args.no_final_halo)
+            torch.cuda.synchronize()
+            cost = torch.tensor(tiled.owned_cost_cells(), dtype=torch.float64, device="cuda")
+            dist.all_reduce(cost, op=dist.ReduceOp.SUM)
+            layout = tiling.choose_layout(W, H, world, cost.cpu().numpy())
+            r.p_indirect.enable_cost_map(False)
+            if layout is not None:
+                if tiled.native is not None:
+                    tiled.native.close()
+                del tiled, r
+                tiled = tiling.TiledRestirPT(sc, W, H, world, rank, device=local_rank, params=prm, dist=dist, kind=args.integrator, transport=transport, layout=layout)
+                r = tiled.r
+                layout_kind = "cost-balanced kd-split on the per-cell GPU time of 12 probe frames: " + str([list(t) for t in layout])
+            else:
+                layout_kind = "equal-area grid (the probe frames' cost map predicts < 15 % gain from re-balancing)"
+        x0, y0, tw, th = tiled.tile
     else:
         r = api.Renderer(sc, tw, th, device=local_rank, params=prm, tile_origin=(x0, y0), integrator=api.INTEGRATOR_PATH_TRACING)
 
@@ -242,8 +299,13 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for i in range(args.warmup):
+    # steady state first: the ray count per frame grows until the temporal reservoirs sit at their M caps (7.98 M rays / frame after 5
+    # frames against 8.74 M after 64 on the Cornell box), so a short --warmup must not change the reported rate
+    settle = args.settle if args.settle is not None else (32 if (rpt or args.integrator == "restir_gi" or di_passes) else 0)
+    for i in range(settle):
         frame(1 + i)
+    for i in range(args.warmup):
+        frame(1 + settle + i)
     barrier()
     r.p_gbuffer.read_counters(reset=True)
     r.p_indirect.read_counters(reset=True)
@@ -252,7 +314,7 @@ def main():
     barrier()
     t0 = time.perf_counter()
     for i in range(args.steps):
-        frame(1 + args.warmup + i)
+        frame(1 + settle + args.warmup + i)
     barrier()
     dt = time.perf_counter() - t0
 
@@ -299,11 +361,12 @@ def main():
                                (f"{scene_name} {W}x{H}, G-buffer + 1-spp "
                                 f"path tracer (K1+K9, NEE+MIS, 3 non-transmissive bounces, static camera)"),
                    "integrator": ("" if args.di_only else args.integrator) + ("+restir_di" if args.direct else "") + ("+sky_di" if args.sky_direct else ""),
-                   "parallelism": f"screen tiles {tile_grid(world)}" + (
+                   "parallelism": f"screen tiles {tile_grid(world)}" + (f" ({layout_kind})" if (tiled is not None and world > 1 and rpt) else "") + (
                        f", 32-px apron, RCCL p2p halo exchange of reservoir planes ({tiled.bpp} B/px): {tiled.halo_bytes} B sent per "
                        f"rank per exchange, {(1 if args.no_final_halo else 2) if rpt else (0 if args.no_final_halo else 1)} exchanges per frame"
                        if (tiled is not None and world > 1) else ""),
                    "halo_transport": (tiled.transport if (tiled is not None and world > 1) else None),
+                   "preset": args.config, "settle_frames": settle,
                    "rays_per_frame": round((n_closest + n_shadow) / args.steps, 1),
                    "redundant_apron_primary_rays_per_frame": round(apron_rays / args.steps, 1),
                    "fps": round(1e3 / ms_per_step, 2)},
@@ -381,33 +444,34 @@ def main():
         # measured HBM-side bytes per launch of that kernel: PMC passes (FETCH_SIZE x 2 x 1024 + WRITE_SIZE x 1024, MI355X_MICROARCH.md) of
         # exactly this command, collected by scripts/gpu_pmc.sh and committed under profiles/ (rocprofv3 cannot run inside the bench)
         traffic, traffic_src, valu = None, None, None
-        plain = not (args.direct or args.sky_direct or args.textured or args.di_only) and (W, H) == (1920, 1080)
+        plain = not (args.direct or args.sky_direct or args.textured or args.di_only)
         scene_tag = ("cornell" if args.scene.endswith("cornell_emissive.npz") else
                      "atrium" if (args.scene == "synthetic" and args.synthetic_layout == "atrium" and args.synthetic_tris == 262144
                                   and args.synthetic_emissives == 100000) else None)
-        wl_tag = {"restir_pt": "rpt", "restir_gi": "gi", "pt": "pt"}[args.integrator]
-        pmc_rel = os.path.join("profiles", f"r02_pmc_{wl_tag}_{scene_tag}.json")
+        wl_tag = {"restir_pt": "rpt", "restir_gi": "gi", "pt": "pt"}[args.integrator] + ("" if (W, H) == (1920, 1080) else f"_{W}x{H}")
+        pmc_rel = os.path.join("profiles", f"r03_pmc_{wl_tag}_{scene_tag}.json")
         if plain and scene_tag and os.path.exists(os.path.join(ROOT, pmc_rel)):
-            # kernel names as rocprofv3 prints them (template arguments: NEE_EMISSIVE, TEXTURED)
-            kmap = {"rpt_pathtrace": ["k_rpt_pathtrace<true>", "k_rpt_pathtrace_w4<true>"],
-                    "rpt_reconnect_spatial": ["k_rpt_stc<true, false>"], "rpt_reconnect_temporal": ["k_rpt_temporal<true, false>"],
-                    "gbuffer": ["k_gbuffer"], "rgi": ["k_rgi", "k_rgi_tex", "k_rgi<false>"], "trace": ["k_trace_simple", "k_trace"], "pt_shade": ["k_pt_shade"]}
             table = json.load(open(os.path.join(ROOT, pmc_rel)))
-            # the launch-count filter drops a kernel variant that only ran during warm-up
-            cands = [table[k] for k in kmap.get(dom, []) if k in table]
-            rec = max(cands, key=lambda r: r.get("launches_sampled", 0)) if cands else None
-            if rec:
-                traffic, traffic_src = round(rec["traffic_bytes"]), pmc_rel
-                if "valu" in rec:
-                    v = rec["valu"]
-                    valu = {"issue_frac": v["issue_frac"], "lane_util": v["lane_util"], "achieved_ginst_per_s": v["ginst_per_s"],
-                            "peak_ginst_per_s": v["peak_ginst_per_s"], "wait_frac": v.get("wait_frac"), "source": pmc_rel}
+            # only a profile of THESE kernel sources describes the library that was just timed
+            if table.get("_meta", {}).get("source_hash") == source_hash():
+                # kernel names as rocprofv3 prints them (template arguments: NEE_EMISSIVE, TEXTURED)
+                kmap = {"rpt_pathtrace": ["k_rpt_pathtrace<true>", "k_rpt_pathtrace_w4<true>", "k_rpt_pathtrace_coop<false>", "k_rpt_pathtrace_coop_w4<false>"],
+                        "rpt_reconnect_spatial": ["k_rpt_stc<true, false>"], "rpt_reconnect_temporal": ["k_rpt_temporal<true, false>"],
+                        "gbuffer": ["k_gbuffer"], "rgi": ["k_rgi", "k_rgi_tex", "k_rgi<false>"], "trace": ["k_trace_simple", "k_trace"], "pt_shade": ["k_pt_shade"]}
+                # the launch-count filter drops a kernel variant that only ran during warm-up
+                cands = [table[k] for k in kmap.get(dom, []) if k in table]
+                rec = max(cands, key=lambda r: r.get("launches_sampled", 0)) if cands else None
+                if rec:
+                    traffic, traffic_src = round(rec["traffic_bytes"]), pmc_rel
+                    if "valu" in rec:
+                        valu = dict(rec["valu"], source=pmc_rel)
         hbm_frac = achieved / HBM_PEAK_GBS
         # which resource bounds the dominant kernel: the VALU issue slots when the PMC pass shows them busier than the HBM pipe
-        bound = "valu" if (valu is not None and valu["issue_frac"] > max(hbm_frac, (traffic or 0) / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS)) else "hbm"
+        bound = "valu" if (valu is not None and valu.get("busy_frac", 0) > max(hbm_frac, (traffic or 0) / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS)) else "hbm"
         out["roofline"] = {"bound": bound, "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
                            "unit": "GB/s", "frac": round(hbm_frac, 5), "traffic": traffic, "traffic_unit": "bytes per launch",
                            "traffic_source": traffic_src, "algorithmic_bytes_per_launch": round(bytes_launch),
+                           "traffic_over_algorithmic": (round(traffic / bytes_launch, 3) if (traffic and bytes_launch) else None),
                            "measured_traffic_GBs": (round(traffic / (avg_ms * 1e-3) / 1e9, 2) if traffic else None),
                            "valu": valu,
                            "avg_launch_ms": round(avg_ms, 4), "launches_per_frame": launches / nfr,

@@ -33,7 +33,9 @@
 extern "C" {
 #endif
 
-#define ZR_ABI_VERSION 1
+/* 2: zr_params grew (ae_*, display_*, tex_filter); stream-ordered zr_scene_*_async entry points; zr_scene_get_presampled_sets.
+ * A caller built against another version must not pass its zr_params to zr_pass_set_params: check zr_abi_version() first. */
+#define ZR_ABI_VERSION 2
 
 typedef enum zr_status {
     ZR_OK = 0,
@@ -243,7 +245,10 @@ int zr_scene_destroy(zr_scene* scene);
  * MeshInstance records (the caller fills PrevRotation / PrevScale / dTranslation like the reference does), `instance_to_world` = the new
  * exact object-to-world matrices (n x 12 floats).  The instance buffer and acceleration structure of the last frame become the
  * "previous" ones that the CtT replay / reconnect passes of ReSTIR PT and the temporal shifts of the DI passes trace against.
- * Host call between frames (waits for the device); n must equal the scene's instance count. */
+ * Host call between frames (waits for the device); n must equal the scene's instance count.
+ * Once a scene has been updated, call this every frame -- also with unchanged records on frames where nothing moves -- like the reference
+ * rebuilds its instance buffer every frame (RtAccelerationStructure.cpp:382-506): the "previous" buffers are whatever was current before the
+ * LAST call, so skipping static frames would leave the temporal passes with a stale previous scene. */
 int zr_scene_update_instances(zr_scene* scene, const zr_mesh_instance* instances, const float* instance_to_world, uint32_t n);
 /* Emissive triangles of instances that moved (SceneCore::UpdateEmissivePositions, SceneCore.cpp:913-955, then EmissiveBuffer::UpdateTriPositions'
  * upload of [minIdx, maxIdx)): replaces `count` records of the scene's emissive buffer from index `first`.  The caller re-derives them like the
@@ -359,6 +364,11 @@ int zr_pass_set_input(zr_pass* pass, int which, const void* dev_plane);
 int zr_pass_set_tonemap_lut(zr_pass* pass, const uint32_t* rgb9e5, uint32_t dim);
 /* ray counters accumulated since the last call (device -> host copy; synchronises the stream) */
 int zr_pass_read_counters(zr_pass* pass, void* hip_stream, zr_counters* out, int reset);
+/* ReSTIR PT: GPU time per 32 x 32-pixel cell of the pass's planes ((w + 31) / 32 + 1 by (h + 31) / 32 + 1 cells, cell (0, 0) at the plane origin): the summed
+ * lifetimes, in units of 16 shader cycles, of the waves of K11 / K14 / K16 that worked on the cell since the last reset: the load signal of the cost-balanced screen split over N devices (tiling.balanced_layout).  No
+ * reference counterpart (the reference renders on one GPU).  Costs one atomic per wave while enabled. */
+int zr_pass_enable_cost_map(zr_pass* pass, int enable);
+int zr_pass_read_cost_map(zr_pass* pass, void* hip_stream, uint32_t* out_cells, uint32_t cells_w, uint32_t cells_h, int reset);
 /* the same counters split by the kernel that issued the queries (not reset; roofline bookkeeping of bench.py) */
 int zr_pass_read_kernel_counters(zr_pass* pass, void* hip_stream, uint32_t max_entries, const char** names,
                                  uint64_t* n_closest, uint64_t* n_shadow, uint32_t* count);

@@ -295,6 +295,52 @@ def test_restir_pt_tile_split_with_halo_exchange_on_gpu(api, cornell_emissive, o
         assert mism == 0, f"frame {f}: {mism} pixels differ"
 
 
+def test_restir_pt_cost_balanced_tile_split_on_gpu(api, cornell_emissive, oracle_emissive):
+    """The cost-balanced screen split: per-cell ray counters of a full-frame probe (zr_pass_read_cost_map) -> tiling.balanced_layout (kd-split,
+    6 ranks: an uneven count, tiles of different sizes) -> the same halo protocol.  The cost map (wave lifetimes of K11 / K14 / K16 per cell) is denser where the
+    box is, the six tiles' costs are balanced, and the stitched radiance is still bit-identical to the full-frame oracle with a moving camera."""
+    from oracle import zro
+    from zetaray_amd import tiling
+    w, h, world = 416, 288, 6
+    prm = wire.default_params()
+    probe = tiling.TiledRestirPT(cornell_emissive, w, h, 1, 0, params=prm)
+    probe.r.p_indirect.enable_cost_map(True)
+    for f in range(1, 5):
+        probe.render_frame(_frame(cornell_emissive, w, h, f))
+    cost = probe.owned_cost_cells()
+    assert cost.shape == ((h + 31) // 32, (w + 31) // 32) and cost.min() > 0            # every cell's waves report their lifetime
+    gw = cost.shape[1]
+    assert cost[:, gw // 2 - 2:gw // 2 + 2].mean() > 2 * cost[:, :2].mean()              # the box in the middle costs more than the empty sides
+    layout = tiling.balanced_layout(w, h, world, cost)
+    assert sum(t[2] * t[3] for t in layout) == w * h and all(t[0] % 32 == 0 and t[1] % 32 == 0 for t in layout)
+    shares = np.array([cost[t[1] // 32:(t[1] + t[3] + 31) // 32, t[0] // 32:(t[0] + t[2] + 31) // 32].sum() for t in layout]) / cost.sum()
+    eq = np.array([cost[t[1] // 32:(t[1] + t[3] + 31) // 32, t[0] // 32:(t[0] + t[2] + 31) // 32].sum()
+                   for t in [tiling.tile_rect(w, h, 4, r) for r in range(4)]]) / cost.sum()
+    assert shares.max() * world < 1.6, shares            # no tile carries more than 1.6 x its fair share (cells are coarse at this size)
+    del probe
+    ranks = [tiling.TiledRestirPT(cornell_emissive, w, h, world, r, params=prm, layout=layout) for r in range(world)]
+    o = zro.OracleRPT(oracle_emissive, w, h)
+    prev = None
+    for f in range(1, 5):
+        cb = _frame(cornell_emissive, w, h, f, cam_pos=(0.05 * f, 1.2, -4.043 + 0.02 * f))
+        if prev is not None:
+            cb["prev_view"], cb["prev_view_inv"], cb["prev_camera_jitter"] = prev["curr_view"], prev["curr_view_inv"], prev["curr_camera_jitter"]
+        prev = cb.copy()
+        for r in ranks:
+            r.stage_temporal(cb)
+        tiling.exchange_in_process(ranks, api.HALO_POST_TEMPORAL)
+        for r in ranks:
+            r.stage_spatial(cb)
+        tiling.exchange_in_process(ranks, api.HALO_FINAL)
+        want = o.render(cb, prm)
+        img = np.zeros_like(want)
+        for r in ranks:
+            (x0, y0, tw, th), t = r.final_tile()
+            img[y0:y0 + th, x0:x0 + tw] = t
+        mism = int((img.view(np.uint32) != want.view(np.uint32)).any(axis=2).sum())
+        assert mism == 0, f"frame {f}: {mism} pixels differ"
+
+
 def test_presampled_light_sets_on_gpu(api):
     """K3 on the GPU + the presampled NEE branches of K9 and K11 (PreLighting regenerates the sets every frame)."""
     from oracle import zro
@@ -1142,6 +1188,55 @@ def test_device_refit_of_a_large_dynamic_scene(api):
             assert np.array_equal(np.asarray(a).view(np.uint8).reshape(-1), np.asarray(b).view(np.uint8).reshape(-1)), f"frame {f}: G-buffer plane {n}"
         assert np.array_equal(r.final().view(np.uint32), want.view(np.uint32)), f"frame {f}"
     assert r.p_indirect.read_counters() is not None
+
+
+def test_device_built_bvh_traces_identically(api, monkeypatch):
+    """ZR_BVH_BUILD=device: the acceleration structure is built on the GPU (LBVH: Morton sort + breadth-first 4-wide topology + per-level boxes,
+    zr_tu_bvh.hip).  Query results do not depend on the tree, so 20 000 closest-hit rays against the oracle's own BVH2 and a ReSTIR PT sequence with
+    materials / Russian roulette stay bit-exact; then the tree is REBUILT on the device every frame for a moving instance (ZR_SCENE_UPDATE=rebuild)."""
+    from oracle import zro
+    monkeypatch.setenv("ZR_BVH_BUILD", "device")
+    sc = scene_io.make_synthetic_scene(num_tris=3000, num_emissive=150, seed=11)
+    osc = zro.OracleScene(sc, force_bvh=True)
+    handle = api.Scene(sc)
+    nodes, tris, depth = handle.bvh_info()
+    assert nodes > 300 and tris == sc.num_tris and 4 <= depth <= 20, (nodes, tris, depth)
+    import torch
+    rng = np.random.default_rng(5)
+    n = 20000
+    o = rng.uniform(-2.5, 2.5, (n, 3)); d = rng.normal(size=(n, 3)); d /= np.linalg.norm(d, axis=1, keepdims=True)
+    rays = np.concatenate([o, np.full((n, 1), 1e-4), d, np.full((n, 1), 3.0e38)], 1).astype(np.float32)
+    d_rays = torch.from_numpy(rays).cuda()
+    d_hits = torch.zeros((n, 4), dtype=torch.int32, device="cuda")
+    api._check(api.lib().zr_trace_closest(handle.h, None, d_rays.data_ptr(), n, 3, d_hits.data_ptr()))
+    torch.cuda.synchronize()
+    assert np.array_equal(d_hits.cpu().numpy().view(np.uint32), osc.trace_closest(rays))
+    handle.close()
+    prm = wire.default_params()
+    prm.max_non_tr_bounces, prm.max_glossy_tr_bounces = 6, 8
+    _rpt_compare(api, sc, osc, 96, 64, prm, 3, cam=dict(cam_pos=(0, 0, -3.5)))
+    # per-frame rebuild of a moving instance
+    monkeypatch.setenv("ZR_SCENE_UPDATE", "rebuild")
+    w, h = 96, 64
+    prm = wire.default_params()
+    r = api.Renderer(sc, w, h, params=prm, integrator=api.INTEGRATOR_RESTIR_PT)
+    opt = zro.OracleRPT(osc, w, h)
+    cand = [i for i in range(1, len(sc.instances)) if sc.instance_mask[i] & wire.SUBGROUP_NON_EMISSIVE]
+    idx = max(cand, key=lambda i: int(sc.instance_num_tris[i]))
+    t0, xf = sc.instances["translation"][idx].copy(), {}
+    prev = None
+    for f in range(1, 5):
+        if f >= 2:
+            ang = 0.12 * (f - 1)
+            scene_io.move_instance(sc, idx, translation=t0 + np.float32([0.08 * (f - 1), 0.03 * (f - 1), -0.05 * (f - 1)]),
+                                   rotation=np.array([0.0, np.sin(ang / 2), 0.0, np.cos(ang / 2)], np.float32), xform_of=xf)
+            r.scene.update_instances(sc.instances, sc.instance_to_world)
+            osc.update_instances(sc.instances, sc.instance_to_world)
+        cb = _chain(_frame(sc, w, h, f, cam_pos=(0, 0, -3.5)), prev)
+        prev = cb.copy()
+        r.render_frame(cb)
+        want = opt.render(cb, prm)
+        assert np.array_equal(r.final().view(np.uint32), want.view(np.uint32)), f"frame {f} (device rebuild)"
 
 
 def test_moving_light_on_gpu(api):

@@ -80,3 +80,33 @@ def test_tile_rects_cover_the_frame():
             assert x0 % 32 == 0 and y0 % 32 == 0 and tw > 0 and th > 0
             cover[y0:y0 + th, x0:x0 + tw] += 1
         assert (cover == 1).all()
+
+
+def test_balanced_layout_partitions_the_frame():
+    """tiling.balanced_layout: n 32-px-aligned rects that tile the frame, balanced cost, symmetric halo plans (both sides of an exchange
+    derive the same strips), for even and odd rank counts and for a map with empty regions (the Cornell box at 16:9)"""
+    import numpy as np
+    from zetaray_amd import tiling
+    W, H = 1920, 1080
+    gh, gw = (H + 31) // 32, (W + 31) // 32
+    rng = np.random.default_rng(3)
+    cost = np.zeros((gh, gw))
+    cost[:, 14:46] = 1.0 + rng.random((gh, 32))
+    cost[8:26, 24:36] *= 4.0
+    for n in (2, 3, 4, 6, 8):
+        L = tiling.balanced_layout(W, H, n, cost)
+        cover = np.zeros((H, W), np.int32)
+        for x0, y0, tw, th in L:
+            assert x0 % 32 == 0 and y0 % 32 == 0 and tw >= 64 and th >= 64
+            cover[y0:y0 + th, x0:x0 + tw] += 1
+        assert (cover == 1).all()
+        share = np.array([cost[y0 // 32:(y0 + th + 31) // 32, x0 // 32:(x0 + tw + 31) // 32].sum() for x0, y0, tw, th in L]) / cost.sum()
+        assert share.max() * n < 1.25, (n, share)
+        eq = np.array([cost[y0 // 32:(y0 + th + 31) // 32, x0 // 32:(x0 + tw + 31) // 32].sum()
+                       for x0, y0, tw, th in [tiling.tile_rect(W, H, n, r) for r in range(n)]]) / cost.sum() if n in (2, 4, 8) else None
+        if eq is not None and n == 8:
+            assert share.max() < eq.max()          # better than the equal-area grid on this map
+        for r in range(n):
+            for peer, send, recv in tiling.halo_plan(W, H, n, r, layout=L):
+                back = [(s2, r2) for p, s2, r2 in tiling.halo_plan(W, H, n, peer, layout=L) if p == r]
+                assert back and back[0] == (recv, send)

@@ -215,6 +215,41 @@ def _write_gltf(tmp_path):
     return str(p), g, pos
 
 
+def test_native_loader_rejects_malformed_files(tmp_path):
+    """untrusted input: out-of-range vertex indices, short attribute accessors, a material index beyond the array, a node cycle and a JSON
+    file that ends inside a number are errors, never out-of-bounds reads; KHR_materials_emissive_strength alone makes a
+    primitive emissive like glTF.cpp:405-410"""
+    import copy
+    path, g, _ = _write_gltf(tmp_path)
+
+    def load(mut, name, blob=None):
+        g2 = copy.deepcopy(g)
+        mut(g2)
+        q = tmp_path / name
+        q.write_text(json.dumps(g2) if blob is None else blob)
+        return scene_io.load_gltf_native(str(q))
+
+    def bad_index(g2):      # index 7 with 4 vertices
+        idx = np.array([0, 1, 7, 0, 2, 3], np.uint16)
+        blob = (tmp_path / "quad.bin").read_bytes()[:128] + idx.tobytes()
+        (tmp_path / "quad_bad.bin").write_bytes(blob)
+        g2["buffers"][0]["uri"] = "quad_bad.bin"
+    for mut, name in ((bad_index, "bad_index.gltf"),
+                      (lambda g2: g2["accessors"][1].update(count=3), "short_normals.gltf"),
+                      (lambda g2: g2["meshes"][0]["primitives"][0].update(material=9), "bad_material.gltf"),
+                      (lambda g2: g2["nodes"][1].update(children=[0]), "cycle.gltf")):
+        with pytest.raises(Exception):
+            load(mut, name)
+    with pytest.raises(Exception):
+        load(lambda g2: None, "truncated.gltf", blob=json.dumps(g)[:-40] + "12")
+    # emissive strength without a factor or a texture: still an emissive primitive
+    def strength_only(g2):
+        g2["materials"][0]["extensions"] = {"KHR_materials_emissive_strength": {"emissiveStrength": 3.0}}
+    sc, _ = load(strength_only, "strength_only.gltf")
+    base, _ = scene_io.load_gltf_native(path)
+    assert len(sc.emissives) == len(base.emissives) + 2
+
+
 def test_native_loader_on_a_synthetic_hierarchy(tmp_path):
     path, g, pos = _write_gltf(tmp_path)
     sc, offs = scene_io.load_gltf_native(path)

@@ -51,6 +51,7 @@ static int RequireDevice(int device)
 }
 
 #include "zr_kernels.h"
+#include "zr_bvh_device.h"
 // the ReSTIR PT kernels are compiled in zr_tu_rpt_a.hip / zr_tu_rpt_b.hip (see zr_kernels.h)
 ZR_RPT_GROUP_A(extern template)
 ZR_RPT_GROUP_B(extern template)
@@ -507,6 +508,8 @@ struct zr_scene
     uint32_t numNodesPrev = 0, numTrisPrev = 0; bool hasPrev = false;
     // device refit: node indices grouped by tree level (deepest level first) + the offsets of the groups, per-node float bounds, object-to-world matrices
     DevBuf<uint32_t> levelNodes; std::vector<uint32_t> levelOffsets, hLevelOrder; DevBuf<float> nodeBounds, toWorld; bool refitReady = false;
+    // device-side BVH build (zr_tu_bvh.hip): instance masks on the device, scratch buffers kept between builds
+    DevBuf<uint8_t> dMask; DeviceBvhScratch bvhScratch; bool deviceBuilt = false;
     // `view` is what kernels receive by value.  Passes of one dependency level may record concurrently from several host threads
     // (RenderGraph.cpp:442-541) while Sky / PreLighting publish scene-owned state (sky LUT, alias table, presampled sets, LVG):
     // every reader takes a private copy through FrameView() and every writer updates `view` under `mtx`.
@@ -729,6 +732,7 @@ struct zr_pass
     } rb[2];
     DevBuf<F4> rptTarget; DevBuf<uint8_t> rptNeighbor; DevBuf<uint16_t> rptSampleSet;
     DevBuf<uint16_t> rptMap[2];      // K12 thread maps: [0] CtN, [1] NtC
+    DevBuf<uint32_t> costMap; bool costOn = false;      // rays per 32 x 32-px cell (zr_pass_enable_cost_map)
     DevBuf<uint32_t> rptLists, rptListCounts;      // 4 replay work lists (pixel ids) + their device-side counts
     // DI_EMISSIVE: two reservoir sets (A RGBA32_UINT, B RG32F), target, sample set
     DevBuf<U4> diA[2]; DevBuf<float> diB[2]; DevBuf<F4> diTarget; DevBuf<uint16_t> diSampleSet;
@@ -1041,6 +1045,44 @@ static void BvhLevels(const std::vector<Bvh4Node>& nodes, std::vector<uint32_t>&
     offsets.push_back((uint32_t)order.size());
 }
 
+// Builds the CURRENT acceleration structure on the device from the scene's current instance buffer + object-to-world matrices (both already
+// on the device, or enqueued on `st`): LBVH topology (zr_tu_bvh.hip), then the level-by-level box computation + quantisation of the refit.
+// Host-synchronous (the level structure comes back).  The node / triangle buffers are grown to the build's capacity on first use.
+static int DeviceRebuild(zr_scene* s, hipStream_t st)
+{
+    const uint32_t nt = (uint32_t)s->meta.n;
+    int r;
+    if (s->nodes.n < nt || s->tris.n < nt || s->nodeBounds.n < 6 * (size_t)nt)
+    {
+        HIP_TRY(hipDeviceSynchronize());
+        if (s->nodes.n < nt && (r = s->nodes.Alloc(nt))) return r;
+        if (s->tris.n < nt && (r = s->tris.Alloc(nt))) return r;
+        if (s->nodeBounds.n < 6 * (size_t)nt && (r = s->nodeBounds.Alloc(6 * (size_t)nt))) return r;
+    }
+    if (!s->dMask.p && (r = s->dMask.Upload(s->hMask.data(), s->hMask.size()))) return r;
+    DeviceBvhInputs in; in.numTris = nt; in.meta = s->meta.p; in.instances = s->instances.p; in.toWorld = s->toWorld.p; in.vertices = s->vertices.p;
+    in.indices = s->indices.p; in.instanceMask = s->dMask.p;
+    DeviceBvhOutputs out; out.tris = s->tris.p; out.nodes = s->nodes.p; out.nodeCap = (uint32_t)s->nodes.n;
+    std::string err;
+    if (DeviceBuildBvh4(st, s->bvhScratch, in, out, err)) return Fail(ZR_ERR_HIP, "device BVH build: %s", err.c_str());
+    if (out.stackNeed + 1 > (uint32_t)kTravStack) return Fail(ZR_ERR_UNSUPPORTED, "device-built BVH has %u levels: needs %u traversal stack entries (limit %d); use the host builder", out.numLevels, out.stackNeed, kTravStack - 1);
+    s->hLevelOrder = out.levelOrder; s->levelOffsets = out.levelOffsets;
+    if (s->levelNodes.n < s->hLevelOrder.size()) { HIP_TRY(hipStreamSynchronize(st)); if ((r = s->levelNodes.Alloc(nt))) return r; }
+    HIP_TRY(hipMemcpyAsync(s->levelNodes.p, s->hLevelOrder.data(), s->hLevelOrder.size() * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+    for (size_t l = 0; l + 1 < s->levelOffsets.size(); l++)
+    {
+        const uint32_t first = s->levelOffsets[l], cnt = s->levelOffsets[l + 1] - first;
+        hipLaunchKernelGGL(k_refit_level, dim3((cnt + 63) / 64), dim3(64), 0, st, s->nodes.p, s->levelNodes.p + first, cnt, s->tris.p, s->nodeBounds.p);
+    }
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(st));          // hLevelOrder is pageable: its copy must have been staged and the kernels' errors seen
+    SceneView& v = s->view;
+    v.nodes = s->nodes.p; v.tris = s->tris.p; v.numNodes = out.numNodes; v.numTris = nt;
+    if (out.numLevels > s->maxDepth) s->maxDepth = out.numLevels;
+    s->deviceBuilt = true;
+    return ZR_OK;
+}
+
 int zr_scene_create(int device, const zr_scene_desc* d, zr_scene** out)
 {
     if (!d || !out) return Fail(ZR_ERR_INVALID_ARG, "zr_scene_create: null argument");
@@ -1051,8 +1093,22 @@ int zr_scene_create(int device, const zr_scene_desc* d, zr_scene** out)
     zr_scene* s = new (std::nothrow) zr_scene();
     if (!s) return Fail(ZR_ERR_OOM, "out of host memory");
     s->device = device;
-    BvhBuilder builder;
-    BuiltBvh bvh = builder.Build(*d);
+    // ZR_BVH_BUILD=device: the acceleration structure is built on the GPU (LBVH, zr_tu_bvh.hip) instead of by the host's binned-SAH builder
+    uint64_t totalTris = 0;
+    for (uint32_t i = 0; i < d->num_instances; i++) totalTris += d->instance_num_tris[i];
+    const char* buildEnv = std::getenv("ZR_BVH_BUILD");
+    const bool deviceBuild = buildEnv && !std::strcmp(buildEnv, "device") && totalTris > BvhBuilder::kTinyScene;
+    BuiltBvh bvh;
+    if (deviceBuild)
+    {   // only the global-order (mesh, primitive) table is made on the host; geometry never passes through it
+        bvh.meta.reserve((size_t)totalTris);
+        for (uint32_t i = 0; i < d->num_instances; i++) for (uint32_t p = 0; p < d->instance_num_tris[i]; p++) { TriMeta m; m.mesh = i; m.prim = p; bvh.meta.push_back(m); }
+    }
+    else
+    {
+        BvhBuilder builder;
+        bvh = builder.Build(*d);
+    }
     if (bvh.stackNeed + 1 > (uint32_t)kTravStack) { delete s; return Fail(ZR_ERR_UNSUPPORTED, "BVH needs %u traversal stack entries (limit %d)", bvh.stackNeed, kTravStack - 1); }
     s->maxDepth = bvh.maxDepth;
 #define UP(buf, ptr, cnt) if ((r = s->buf.Upload(ptr, cnt))) { delete s; return r; }
@@ -1104,6 +1160,10 @@ int zr_scene_create(int device, const zr_scene_desc* d, zr_scene** out)
     s->hMask.assign(d->instance_mask, d->instance_mask + d->num_instances); s->hNumTris.assign(d->instance_num_tris, d->instance_num_tris + d->num_instances);
     BvhLevels(bvh.nodes4, s->hLevelOrder, s->levelOffsets);
     if (!s->hLevelOrder.empty() && (r = s->levelNodes.Upload(s->hLevelOrder.data(), s->hLevelOrder.size()))) { delete s; return r; }
+    if (deviceBuild)
+    {
+        if ((r = s->toWorld.Upload(d->instance_to_world, 12 * (size_t)d->num_instances)) || (r = DeviceRebuild(s, nullptr))) { delete s; return r; }
+    }
     // uploads from pageable memory return once staged; renders on non-blocking streams must not start before the DMA has landed
     { hipError_t e = hipDeviceSynchronize(); if (e != hipSuccess) { delete s; return Fail(ZR_ERR_HIP, "hipDeviceSynchronize failed: %s", hipGetErrorString(e)); } }
     *out = s;
@@ -1185,10 +1245,34 @@ int zr_scene_update_instances_async(zr_scene* s, void* stream, const zr_mesh_ins
     HIP_TRY(hipSetDevice(s->device));
     hipStream_t st = (hipStream_t)stream;
     const char* modeEnv = std::getenv("ZR_SCENE_UPDATE");
-    const bool rebuild = modeEnv && !std::strcmp(modeEnv, "rebuild");
+    bool rebuild = modeEnv && !std::strcmp(modeEnv, "rebuild");
     int r;
     for (uint32_t i = 0; i < n; i++) RaiseMaxTex(s, 0, instances[i].base_color_tex);
-    if (rebuild)
+    const bool rebuildHost = modeEnv && !std::strcmp(modeEnv, "rebuild_host");
+    if (rebuild && s->meta.n > BvhBuilder::kTinyScene)
+    {
+        // ---- a NEW tree on the device (ZR_SCENE_UPDATE=rebuild): LBVH over the moved triangles, ~1 ms for the 380k-triangle atrium against 192 ms
+        // for the host's binned-SAH rebuild (ZR_SCENE_UPDATE=rebuild_host); what the reference's per-frame TLAS rebuild is (RtAccelerationStructure.cpp:708-789)
+        const size_t nt = s->meta.n;
+        HIP_TRY(hipDeviceSynchronize());           // buffers change roles and may be reallocated below: a host-synchronous path
+        std::lock_guard<std::mutex> lock(s->mtx);
+        if ((r = (s->instancesPrev.n == n ? ZR_OK : s->instancesPrev.Alloc(n))) || (s->nodesPrev.n < nt && (r = s->nodesPrev.Alloc(nt))) ||
+            (s->trisPrev.n < nt && (r = s->trisPrev.Alloc(nt))) || (s->metaPrev.n != s->meta.n && (r = s->metaPrev.Alloc(s->meta.n))) ||
+            (s->toWorld.n != 12 * (size_t)n && (r = s->toWorld.Alloc(12 * (size_t)n)))) return r;
+        if (!s->hasPrev && !s->refitReady) HIP_TRY(hipMemcpy(s->metaPrev.p, s->meta.p, s->meta.n * sizeof(TriMeta), hipMemcpyDeviceToDevice));
+        std::swap(s->instances.p, s->instancesPrev.p); std::swap(s->instances.n, s->instancesPrev.n);
+        std::swap(s->nodes.p, s->nodesPrev.p); std::swap(s->nodes.n, s->nodesPrev.n);
+        std::swap(s->tris.p, s->trisPrev.p); std::swap(s->tris.n, s->trisPrev.n);
+        std::swap(s->meta.p, s->metaPrev.p); std::swap(s->meta.n, s->metaPrev.n);
+        s->numNodesPrev = s->view.numNodes; s->numTrisPrev = s->view.numTris; s->hasPrev = true;
+        HIP_TRY(hipMemcpy(s->instances.p, instances, (size_t)n * sizeof(zr_mesh_instance), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(s->toWorld.p, instance_to_world, 12 * (size_t)n * sizeof(float), hipMemcpyHostToDevice));
+        s->view.instances = s->instances.p; s->view.triMeta = s->meta.p;
+        if ((r = DeviceRebuild(s, st))) return r;
+        s->refitReady = false;      // the two buffer sets no longer share a topology
+        return ZR_OK;
+    }
+    if (rebuild || rebuildHost)
     {
         zr_scene_desc d; memset(&d, 0, sizeof(d));
         d.vertices = s->hVertices.data(); d.num_vertices = (uint32_t)s->hVertices.size(); d.indices = s->hIndices.data(); d.num_indices = (uint32_t)s->hIndices.size();
@@ -1564,6 +1648,7 @@ static int AllocPass(zr_pass* p)
             if ((r = p->rptNeighbor.Alloc(2 * cap))) return r;
             HIP_TRY(hipMemset(p->rptTarget.p, 0, cap * 16)); HIP_TRY(hipMemset(p->rptNeighbor.p, 0, cap * 2));
             for (auto& m : p->rptMap) { if ((r = m.Alloc(cap))) return r; HIP_TRY(hipMemset(m.p, 0, cap * 2)); }
+            { const size_t cells = (size_t)((p->w + 31u) / 32u + 1u) * ((p->h + 31u) / 32u + 1u); if ((r = p->costMap.Alloc(cells))) return r; HIP_TRY(hipMemset(p->costMap.p, 0, cells * 4)); }
             if ((r = p->rptSampleSet.Upload(kRptSampleSet, 1024))) return r;
             if ((r = p->rptLists.Alloc(4 * cap))) return r;
             if ((r = p->rptListCounts.Alloc(4))) return r;
@@ -1876,6 +1961,7 @@ static int RenderReSTIR_PT(zr_pass* p, hipStream_t s, const zr_frame_constants* 
     F.rbCtN = p->rb[0].View(); F.rbNtC = p->rb[1].View(); F.tex.target = p->rptTarget.p; F.tex.neighbor = p->rptNeighbor.p;
     F.finalRGBA = p->finalRGBA.p; F.sampleSet = p->rptSampleSet.p;
     F.mapCtN = p->rptMap[0].p; F.mapNtC = p->rptMap[1].p;
+    F.costMap = p->costOn ? p->costMap.p : nullptr; F.costW = (p->w + 31u) / 32u + 1u;
     // K12 sorts whole 32 x 32 tiles: an owned rect may end inside one only where the render target ends
     if (((F.ox0 + F.ow) & 31u) && F.ox0 + F.ow != cb->render_width) return Fail(ZR_ERR_INVALID_ARG, "ReSTIR PT: the owned rect must end on a 32-pixel boundary or at the right edge of the render target");
     if (((F.oy0 + F.oh) & 31u) && F.oy0 + F.oh != cb->render_height) return Fail(ZR_ERR_INVALID_ARG, "ReSTIR PT: the owned rect must end on a 32-pixel boundary or at the bottom edge of the render target");
@@ -2447,6 +2533,26 @@ int zr_pass_download_output(const zr_pass* p, int which, void* stream, void* dst
     HIP_TRY(hipSetDevice(p->device));
     HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
     HIP_TRY(hipMemcpy(dst, dev, bytes, hipMemcpyDeviceToHost));
+    return ZR_OK;
+}
+// Cost map of a ReSTIR PT pass: wave lifetimes (shader cycles / 16) of K11 / K14 / K16 per 32 x 32-px cell of the pass's planes (cell (0, 0) at the
+// plane origin) since the last reset -- the load signal of the cost-balanced screen split (zetaray_amd/tiling.py balanced_layout).  One atomic per wave while enabled.
+int zr_pass_enable_cost_map(zr_pass* p, int enable)
+{
+    if (!p || !p->initialized) return Fail(ZR_ERR_NOT_INITIALIZED, "pass not initialised");
+    if (p->kind != ZR_PASS_INDIRECT || p->integrator != ZR_INTEGRATOR_RESTIR_PT) return Fail(ZR_ERR_UNSUPPORTED, "the cost map is an output of the ReSTIR PT pass");
+    p->costOn = enable != 0;
+    return ZR_OK;
+}
+int zr_pass_read_cost_map(zr_pass* p, void* stream, uint32_t* out, uint32_t cells_w, uint32_t cells_h, int reset)
+{
+    if (!p || !out || !p->initialized) return Fail(ZR_ERR_INVALID_ARG, "zr_pass_read_cost_map: bad argument");
+    const uint32_t cw = (p->w + 31u) / 32u + 1u, ch = (p->h + 31u) / 32u + 1u;
+    if (!p->costMap.p || cells_w != cw || cells_h != ch) return Fail(ZR_ERR_INVALID_ARG, "the cost map is %u x %u cells", cw, ch);
+    HIP_TRY(hipSetDevice(p->device));
+    HIP_TRY(hipMemcpyAsync(out, p->costMap.p, (size_t)cw * ch * 4, hipMemcpyDeviceToHost, (hipStream_t)stream));
+    if (reset) HIP_TRY(hipMemsetAsync(p->costMap.p, 0, (size_t)cw * ch * 4, (hipStream_t)stream));
+    HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
     return ZR_OK;
 }
 int zr_pass_read_counters(zr_pass* p, void* stream, zr_counters* out, int reset)

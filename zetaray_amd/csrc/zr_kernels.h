@@ -145,12 +145,33 @@ __device__ __forceinline__ void FlushRayCounters(unsigned long long* counters, c
     }
 }
 
+// the wave's LIFETIME (shader cycles / 16, from t0 = the cycle counter at kernel entry) also goes to the cost-map cell of its pixels: ray counts
+// turned out to be a poor load signal (rays of a dense region cost several times those of an open one: the ray-balanced 8-way split of the
+// atrium had a 4.1 ms tile against 3.6 ms for the equal-area grid), time is the thing to balance.  All 64 lanes call this; (x, y): any pixel
+// of the wave -- a wave's pixels share a 32 x 32 cell (16 x 4 / 8 x 8 groups of 32-aligned tiles, or one K12 sort tile).
+__device__ __forceinline__ void FlushRayCountersCost(const rpt::RptFrame& F, unsigned long long* counters, const uint32_t* cnt, uint32_t x, uint32_t y, bool inFrame,
+    unsigned long long t0)
+{
+    if (F.costMap != nullptr)
+    {
+        const uint64_t m = __ballot(inFrame);
+        if (m != 0)
+        {
+            const int leader = __ffsll((long long)m) - 1;
+            const unsigned long long dt = (__builtin_readcyclecounter() - t0) >> 4;
+            if ((int)__lane_id() == leader) atomicAdd(&F.costMap[((y - F.gb.y0) >> 5) * F.costW + ((x - F.gb.x0) >> 5)], (uint32_t)(dt > 0xffffffull ? 0xffffffull : dt));
+        }
+    }
+    FlushRayCounters(counters, cnt);
+}
+
 // K11: block = 16x16 pixels, wave w = rows 4w..4w+3 (a 16x4 block: the RR "wave" of the ABI, zr_rpt.h header)
 // EMISSIVE: the NEE_EMISSIVE shader permutation (emissive triangles vs sun + sky); a template constant so the other variant folds away
 // TEX: the scene has a texture heap (ray differentials carried, material maps sampled); likewise a template constant
 template<bool EMISSIVE, bool TEX>
 __device__ __forceinline__ void RptPathtraceBody(rpt::RptFrame& F, const zr_frame_constants& g, uint32_t tilesX, unsigned long long* counters)
 {
+    const unsigned long long t0 = __builtin_readcyclecounter();
     F.prm.emissive = EMISSIVE ? 1u : 0u; F.prm.textured = TEX ? 1u : 0u;
     uint32_t tile, wave, lane; RptTileWaveLane(&tile, &wave, &lane);
     const uint32_t tx = tile % tilesX, ty = tile / tilesX;
@@ -159,11 +180,11 @@ __device__ __forceinline__ void RptPathtraceBody(rpt::RptFrame& F, const zr_fram
     ZR_PROF_KERNEL(F.sc, 1);
     uint32_t cnt[2] = {0u, 0u};
     rpt::PTLane P;
-    { ZR_PROF_SCOPE(ZRP_MISC0); rpt::PtInitLane(F.sc, g, F.gb, F.prm, F.Owns(x, y), x, y, F.finalRGBA, stack, cnt, P); }
+    { ZR_PROF_SCOPE(ZRP_MISC0); rpt::PtInitLane_Fused(F.sc, g, F.gb, F.prm, F.Owns(x, y), x, y, F.finalRGBA, stack, cnt, P); }
     for (;;)
     {
         const bool any = __ballot(P.active) != 0;
-        rpt::PtPhaseA(F.sc, g, F.prm, stack, cnt, P);
+        rpt::PtPhaseA_Fused(F.sc, g, F.prm, stack, cnt, P);
         if (!any) break;
         uint32_t key = rpt::PtRRKey(P);
         if (__ballot(key != 0) != 0)
@@ -173,7 +194,7 @@ __device__ __forceinline__ void RptPathtraceBody(rpt::RptFrame& F, const zr_fram
         { ZR_PROF_SCOPE(ZRP_MISC1); rpt::PtPhaseB(F.sc, F.prm, P, key); }
     }
     { ZR_PROF_SCOPE(ZRP_MISC2); rpt::PtFinishLane(F.gb, F.prm, F.cur, F.tex, F.finalRGBA, P); }
-    FlushRayCounters(counters, cnt);
+    FlushRayCountersCost(F, counters, cnt, x, y, F.Owns(x, y), t0);
 }
 template<bool EMISSIVE>
 __global__ void __launch_bounds__(kRptBlock) ZR_WAVES_PATHTRACE k_rpt_pathtrace(rpt::RptFrame F, zr_frame_constants g, uint32_t tilesX, unsigned long long* counters)
@@ -336,6 +357,7 @@ static constexpr int kCoopBlock = 256;
 template<bool TEX>
 __device__ __forceinline__ void RptPathtraceBodyCoop(rpt::RptFrame& F, const zr_frame_constants& g, uint32_t tilesX, unsigned long long* counters)
 {
+    const unsigned long long t0 = __builtin_readcyclecounter();
     F.prm.emissive = 1u; F.prm.textured = TEX ? 1u : 0u;
     const uint32_t tile = blockIdx.x, wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
     const uint32_t tx = tile % tilesX, ty = tile / tilesX;
@@ -368,7 +390,7 @@ __device__ __forceinline__ void RptPathtraceBodyCoop(rpt::RptFrame& F, const zr_
         rpt::PtPhaseB(F.sc, F.prm, P, key);
     }
     rpt::PtFinishLane(F.gb, F.prm, F.cur, F.tex, F.finalRGBA, P);
-    FlushRayCounters(counters, cnt);
+    FlushRayCountersCost(F, counters, cnt, x, y, F.Owns(x, y), t0);
 }
 #ifndef ZR_WAVES_PATHTRACE_COOP
 #define ZR_WAVES_PATHTRACE_COOP ZR_WAVES(3)
@@ -530,6 +552,7 @@ __global__ void __launch_bounds__(256) k_rpt_sort(rpt::RptFrame F, zr_frame_cons
 template<bool EMISSIVE, bool TEX>
 __global__ void __launch_bounds__(kBlock) ZR_WAVES_TEMPORAL k_rpt_temporal(rpt::RptFrame F, zr_frame_constants g, uint32_t tilesX, unsigned long long* counters)
 {
+    const unsigned long long t0 = __builtin_readcyclecounter();
     F.prm.emissive = EMISSIVE ? 1u : 0u; F.prm.textured = TEX ? 1u : 0u;
     uint32_t x, y; PixelOfThread(tilesX, F.ox0, F.oy0, &x, &y);
     // SORT_TEMPORAL: threads take their pixel from a K12 map, which puts reservoirs of equal reconnection depth into the same wave.  Scheduling
@@ -539,7 +562,7 @@ __global__ void __launch_bounds__(kBlock) ZR_WAVES_TEMPORAL k_rpt_temporal(rpt::
     ZR_PROF_KERNEL(F.sc, 2);
     uint32_t cnt[2] = {0u, 0u};
     if (F.Owns(x, y)) rpt::ReconnectTemporalPixel(F, g, x, y, stack, cnt);
-    FlushRayCounters(counters, cnt);
+    FlushRayCountersCost(F, counters, cnt, x, y, F.Owns(x, y), t0);
 }
 
 // canonical wave sum of the ABI: xor butterfly, strides 1..32 (zr_rpt.h ButterflySum64 is the host statement of it)
@@ -553,6 +576,7 @@ __device__ __forceinline__ float WaveSumButterfly(float v)
 template<bool EMISSIVE, bool TEX>
 __global__ void __launch_bounds__(kBlock) ZR_WAVES_STC k_rpt_stc(rpt::RptFrame F, zr_frame_constants g, uint32_t tilesX, unsigned long long* counters)
 {
+    const unsigned long long t0 = __builtin_readcyclecounter();
     F.prm.emissive = EMISSIVE ? 1u : 0u; F.prm.textured = TEX ? 1u : 0u;
     uint32_t x, y; PixelOfThread(tilesX, F.ox0, F.oy0, &x, &y);
     // SORT_SPATIAL (ReSTIR_PT_Reconnect_StC.hlsl:133-140): the thread at (x, y) shifts the pixel the NtC map assigns to its position, so the
@@ -573,7 +597,7 @@ __global__ void __launch_bounds__(kBlock) ZR_WAVES_STC k_rpt_stc(rpt::RptFrame F
     rpt::StcPhase2(F, g, a, sum1, stack, cnt, v4);
     const float sum4 = WaveSumButterfly(v4);
     rpt::StcPhase3(F, g, a, sum2 + sum3 + sum4);
-    FlushRayCounters(counters, cnt);
+    FlushRayCountersCost(F, counters, cnt, x, y, x != 0xffffffffu && F.Owns(x, y), t0);
 }
 
 

@@ -410,8 +410,11 @@ struct Globals { bool textured = false; const SceneView* sc; const SceneView* sc
 struct TraceReq { bool want; V3 o, d; float tmin, tmax; uint32_t mask; bool anyHit, filterID; uint32_t ignoreID; };
 ZR_HD TraceReq NoTraceReq() { TraceReq q; q.want = false; q.o = v3(0.0f); q.d = v3(0.0f); q.tmin = 0; q.tmax = 0; q.mask = 0; q.anyHit = false; q.filterID = false; q.ignoreID = 0; return q; }
 ZR_HD RawHit NoRawHit() { RawHit h; h.t = 0; h.u = 0; h.v = 0; h.tri = kInvalidTri; return h; }
+// the query kind is a compile-time constant where the query is traced in place (the flags of `q` are for pools that mix kinds):
+// AnyHit / FilterID = false, false for the closest-hit queries, true, true for the approximate light segment
+template<bool AnyHit, bool FilterID>
 ZR_HD RawHit TraceInline(const SceneView& sc, const TraceReq& q, const TravStack& stack)
-{ return q.want ? TraverseDyn(sc, q.o, q.d, q.tmin, q.tmax, q.mask, stack, q.anyHit, q.filterID, q.ignoreID) : NoRawHit(); }
+{ return q.want ? TraverseDyn(sc, q.o, q.d, q.tmin, q.tmax, AnyHit ? (uint32_t)ZR_SUBGROUP_NON_EMISSIVE : (uint32_t)ZR_SUBGROUP_ALL, stack, AnyHit, FilterID, q.ignoreID) : NoRawHit(); }
 
 struct HitEm { bool hit; float t; uint32_t mesh, prim, emissiveTriIdx; float bu, bv; };
 // Hit_Emissive::FindClosest, RayQuery.hlsli:146-207
@@ -437,7 +440,7 @@ ZR_HD HitEm ClosestEmResult(const SceneView& sc, const TraceReq& q, const RawHit
 ZR_HD HitEm FindClosestEm(const Globals& g, V3 pos, V3 normal, V3 wi, bool transmissive)
 {
     const TraceReq q = ClosestEmReq(g.cnt, pos, normal, wi, transmissive);
-    return ClosestEmResult(*g.sc, q, TraceInline(*g.sc, q, g.stack));
+    return ClosestEmResult(*g.sc, q, TraceInline<false, false>(*g.sc, q, g.stack));
 }
 // Hit::FindClosest<ID = true>, RayQuery.hlsli:15-144
 ZR_HD bool FindClosestID(const Globals& g, bool currFrame, V3 pos, V3 normal, V3 wi, bool transmissive, HitInfo& hit, bool wantDiffs = false)
@@ -479,7 +482,7 @@ ZR_HD bool SegmentVisible(const TraceReq& q, const RawHit& h) { return q.want &&
 ZR_HD bool VisibilitySegmentApprox(const Globals& g, V3 origin, V3 wi, float rayT, V3 normal, uint32_t triID, bool transmissive)
 {
     const TraceReq q = SegmentApproxReq(g.cnt, origin, wi, rayT, normal, triID, transmissive);
-    return SegmentVisible(q, TraceInline(*g.sc, q, g.stack));
+    return SegmentVisible(q, TraceInline<true, true>(*g.sc, q, g.stack));
 }
 
 ZR_HD bool IsSpecular(const Surface& s) { return s.GlossSpecular() && (s.metallic || s.specTr) && (!s.Coated() || s.CoatSpecular()); }
@@ -606,8 +609,152 @@ ZR_HD Direct NEE_Emissive(const Globals& g, V3 pos, V3 normal, const Surface& su
 {
     NeeEmState S;
     const TraceReq q = NEE_Emissive_Pre(g, pos, normal, surface, rng, S);
-    return NEE_Emissive_Post(g, normal, S, SegmentVisible(q, TraceInline(*g.sc, q, g.stack)), rng);
+    return NEE_Emissive_Post(g, normal, S, SegmentVisible(q, TraceInline<true, true>(*g.sc, q, g.stack)), rng);
 }
+
+// ---- the same queries and NEE functions in their FUSED form (one function, traversal in the middle): what the inline megakernel
+// k_rpt_pathtrace compiles.  Statement for statement the cut forms above (the GPU parity tests run both: ZR_K11=inline / pool, and the host
+// executor runs the cut forms); kept because the cut costs the megakernel registers -- +38 % spill traffic, K11 +3 % on the Cornell box and
+// +9 % on the atrium (profiles/r03_*).
+// Hit_Emissive::FindClosest, RayQuery.hlsli:146-207
+ZR_HD HitEm FindClosestEm_Fused(const Globals& g, V3 pos, V3 normal, V3 wi, bool transmissive)
+{
+    HitEm r; r.hit = false; r.emissiveTriIdx = 0xffffffffu; r.t = 0; r.mesh = 0; r.prim = 0; r.bu = 0; r.bv = 0;
+    F4 ro, rd;
+    if (!MakeClosestRay(pos, normal, wi, transmissive, true, &ro, &rd)) return r;
+    g.cnt[0]++;
+    RawHit h = Traverse<false>(*g.sc, xyz(ro), xyz(rd), ro.w, rd.w, ZR_SUBGROUP_ALL, g.stack);
+    if (h.tri == kInvalidTri) return r;
+    const TriMeta tm = g.sc->triMeta[h.tri];
+    r.hit = true; r.t = h.t; r.bu = h.u; r.bv = h.v; r.mesh = tm.mesh; r.prim = tm.prim;
+    const uint32_t base = g.sc->instances[tm.mesh].base_emissive_tri_offset;
+    if (base != 0xffffffffu) r.emissiveTriIdx = base + tm.prim;
+    return r;
+}
+
+// Visibility_Segment with APPROXIMATE_EMISSIVE_SHADOW_RAY == 1 (RayQuery.hlsli:337-406)
+ZR_HD bool VisibilitySegmentApprox_Fused(const Globals& g, V3 origin, V3 wi, float rayT, V3 normal, uint32_t triID, bool transmissive)
+{
+    if (triID == 0xffffffffu) return false;
+    if (rayT < 1e-6f) return false;
+    float ndotwi = dot(normal, wi);
+    if (ndotwi == 0) return false;
+    if (ndotwi < 0)
+    {
+        if (transmissive) normal = normal * -1.0f;
+        else return false;
+    }
+    const V3 o = OffsetRayRTG(origin, normal);
+    const float tminv = 3e-6f;
+    const float tmax = PrevFloat32(rayT * 0.999f - NextFloat32(tminv));
+    g.cnt[1]++;
+    // "first accepted hit, visible iff its ID is the target's" (RayQuery.hlsli:372-405) depends on the traversal order; pinned
+    // order-independently: triangles carrying the target's ID are not occluders, any other hit in the shortened segment is
+    RawHit h = Traverse<true>(*g.sc, o, wi, tminv, tmax, ZR_SUBGROUP_NON_EMISSIVE, g.stack, true, triID);
+    return h.tri == kInvalidTri;
+}
+
+
+// ReSTIR_PT_NEE.hlsli:134-207
+ZR_HD Direct NEE_Bsdf_Fused(const Globals& g, V3 pos, V3 normal, const Surface& surface, int nextBounce, BsdfSample& bs, HitEm& hitInfo, Rng& rng)
+{
+    const SceneView& sc = *g.sc;
+    Direct ret = InitDirect();
+    const bool specular = IsSpecular(surface);
+    const int numLightSamples = specular ? 0 : 1;
+    bs = InitBsdfSample();
+    if (nextBounce <= g.maxNumBounces) { ZR_PROF_SCOPE(ZRP_BSDF); bs = SampleBSDF(sc.rho, normal, surface, rng); }
+    const float wiPdf = bs.pdf;
+    const V3 wi = bs.wi;
+    const V3 f = bs.f;
+    hitInfo = FindClosestEm_Fused(g, pos, normal, wi, surface.Transmissive());
+    if (hitInfo.emissiveTriIdx != 0xffffffffu)
+    {
+        const zr_emissive_triangle em = sc.emissives[hitInfo.emissiveTriIdx];
+        const V3 le = EmLe(sc, em, v2(hitInfo.bu, hitInfo.bv));
+        const V3 vtx0 = v3p(em.vtx0), vtx1 = EmV1(em), vtx2 = EmV2(em);
+        V3 ln = cross(vtx1 - vtx0, vtx2 - vtx0);
+        float twoArea = length(ln);
+        ln = dot(ln, ln) == 0 ? v3(0.0f) : ln / twoArea;
+        ln = EmDoubleSided(em) && (dot(-wi, ln) < 0) ? -ln : ln;
+        float lightPdf = 0;
+        if (!specular)
+        {
+            const float lightSourcePdf = numLightSamples > 0 ? sc.alias[hitInfo.emissiveTriIdx].cached_p_orig : 0;
+            lightPdf = twoArea > 0 ? lightSourcePdf * (2.0f / twoArea) : 0;
+        }
+        float dwdA = zr_saturate(dot(ln, -wi)) / (hitInfo.t * hitInfo.t);
+        float wiPdf_area = wiPdf * dwdA;
+        V3 ld = le * f * dwdA;
+        ret.ld = specular ? (wiPdf_area > 0 ? ld / wiPdf_area : v3(0.0f)) : PowerHeuristic(wiPdf_area, lightPdf, ld, 1.0f, 1.0f);
+        ret.le = le; ret.wi = wi; ret.pdf_solidAngle = wiPdf; ret.dwdA = dwdA; ret.ID = em.id;
+        ret.pos = mad(hitInfo.t, wi, pos); ret.normal = ln; ret.pdf_light = lightPdf; ret.lobe = bs.lobe;
+        ret.lt = LT_EMISSIVE; ret.twoSided = EmDoubleSided(em);
+    }
+    if (nextBounce >= g.maxNumBounces) bs.bsdfOverPdf = v3(0.0f);
+    return ret;
+}
+
+
+// ReSTIR_PT_NEE.hlsli:209-284 (alias-table branch)
+ZR_HD Direct NEE_Emissive_Fused(const Globals& g, V3 pos, V3 normal, Surface surface, Rng& rng)
+{
+    const SceneView& sc = *g.sc;
+    Direct ret = InitDirect();
+    ret.lt = LT_EMISSIVE; ret.lobe = LOBE_ALL;
+    V3 lpos, ln, le; float lightPdf; uint32_t lightID; bool twoSided;
+    if (g.presampled)       // USE_PRESAMPLED_SETS, ReSTIR_PT_NEE.hlsli:217-236
+    {
+        PresampledLight pl = SamplePresampledSet(sc, g.sampleSetIdx, pos, rng);
+        lpos = pl.pos; ln = pl.normal; le = pl.le; lightPdf = pl.pdf; lightID = pl.ID; twoSided = pl.twoSided;
+        rng.Uniform(); rng.Uniform(); rng.Uniform();       // "deterministic RNG state regardless of USE_PRESAMPLED_SETS"
+    }
+    else
+    {
+        // Light::AliasTableSample::get, LightSource.hlsli:72-98
+        uint32_t u0 = rng.UniformUintBounded(g.numEmissives);
+        const zr_alias_entry ae = sc.alias[u0];
+        uint32_t lidx; float lpdfSrc;
+        if (rng.Uniform() < ae.p_curr) { lpdfSrc = ae.cached_p_orig; lidx = u0; }
+        else { lpdfSrc = ae.cached_p_alias; lidx = ae.alias; }
+        const zr_emissive_triangle em = sc.emissives[lidx];
+        // Light::EmissiveTriSample::get, LightSource.hlsli:109-137
+        V2 u = rng.Uniform2D();
+        V2 bary = UniformSampleTriangle(u);
+        const V3 vtx0 = v3p(em.vtx0), vtx1 = EmV1(em), vtx2 = EmV2(em);
+        lpos = (1.0f - bary.x - bary.y) * vtx0 + bary.x * vtx1 + bary.y * vtx2;
+        ln = cross(vtx1 - vtx0, vtx2 - vtx0);
+        bool normalIs0 = dot(ln, ln) == 0;
+        float twoArea = length(ln);
+        float lpdfPos = normalIs0 ? 0.0f : 2.0f / twoArea;
+        ln = normalIs0 ? ln : ln / twoArea;
+        ln = EmDoubleSided(em) && dot(pos - lpos, ln) < 0 ? -ln : ln;
+        le = EmLe(sc, em, bary);
+        lightPdf = lpdfSrc * lpdfPos;
+        lightID = em.id; twoSided = EmDoubleSided(em);
+    }
+    const float t = length(lpos - pos);
+    const V3 wi = (lpos - pos) / t;
+    if ((dot(ln, -wi) > 0) && (t > 0))
+    {
+        const float dwdA = zr_saturate(dot(ln, -wi)) / (t * t);
+        surface.SetWi(wi, normal);
+        V3 ld = le * Unified(sc.rho, surface).f * dwdA;
+        if (dot(ld, ld) > 0)
+            ld = ld * (VisibilitySegmentApprox_Fused(g, pos, wi, t, normal, lightID, surface.Transmissive()) ? 1.0f : 0.0f);
+        float bsdfPdf = 0;
+        if (dot(ld, ld) > 0)
+        {
+            { ZR_PROF_SCOPE(ZRP_NEE); bsdfPdf = BSDFSamplerPdf(sc.rho, normal, surface, wi, rng); }
+            bsdfPdf *= dwdA;
+        }
+        ret.ld = PowerHeuristic(lightPdf, bsdfPdf, ld, 1.0f, 1.0f);
+        ret.le = le; ret.wi = wi; ret.pdf_solidAngle = lightPdf / dwdA; ret.dwdA = dwdA; ret.ID = lightID;
+        ret.pos = lpos; ret.normal = ln; ret.pdf_light = lightPdf; ret.twoSided = twoSided;
+    }
+    return ret;
+}
+
 
 // ReSTIR_PT_NEE.hlsli:306-391
 ZR_HD Direct EvalDirect_Case2(const Globals& g, V3 normal, Surface surface, V3 wi, V3 le, float dwdA, float lightPdf, uint32_t lobe,
@@ -792,6 +939,49 @@ ZR_HD void EstimateDirectAndUpdateRC(const Globals& g, int pathVertex, V3 pos, c
     }
     bs = nbs;
 }
+
+// fused form (see NEE_Bsdf_Fused)
+ZR_HD void EstimateDirectAndUpdateRC_Fused(const Globals& g, int pathVertex, V3 pos, const HitInfo& hit, const Surface& surface, const PrevHit& prevHit,
+    V3 throughput, V3 throughput_k, V3& li, BsdfSample& bs, HitEm& nextHit, Reconnection& rc, Reservoir& r, Rng& rngNEE, Rng& rngReplay)
+{
+    if (!g.emissive)      // EstimateDirectAndUpdateRC<false>, ReSTIR_PT_PathTrace.hlsl:172-191
+    {
+        const uint32_t seed_nee = rngNEE.s;
+        Direct ls = NEE_NonEmissive(g, pos, hit.normal, surface, rngNEE);
+        const V3 fOverPdf = throughput * ls.ld;
+        li = li + fOverPdf;
+        rc.L = RoundHalf3(ls.ld * throughput_k);
+        MaybeSetCase2OrCase3(g, pathVertex, pos, hit.normal, hit.t, hit.ID, hit.meshIdx, surface, prevHit, ls, seed_nee, rc);
+        r.Update(Luminance(fOverPdf), fOverPdf, rc, rngNEE);
+        return;
+    }
+    BsdfSample nbs;
+    int nextBounce = pathVertex - 1;
+    Direct ls_b;
+    { ZR_PROF_SCOPE(ZRP_MISC4); ls_b = NEE_Bsdf_Fused(g, pos, hit.normal, surface, nextBounce, nbs, nextHit, rngReplay); }
+    if (nextHit.emissiveTriIdx != 0xffffffffu)
+    {
+        const V3 fOverPdf = throughput * ls_b.ld;
+        li = li + fOverPdf;
+        rc.L = RoundHalf3(ls_b.ld * throughput_k);
+        MaybeSetCase2OrCase3(g, pathVertex, pos, hit.normal, hit.t, hit.ID, hit.meshIdx, surface, prevHit, ls_b, 0, rc);
+        r.Update(Luminance(fOverPdf), fOverPdf, rc, rngNEE);
+    }
+    if (!IsSpecular(surface))
+    {
+        const uint32_t seed_nee = rngNEE.s;
+        Direct ls;
+        { ZR_PROF_SCOPE(ZRP_MISC3); ls = NEE_Emissive_Fused(g, pos, hit.normal, surface, rngNEE); }
+        const V3 fOverPdf = throughput * ls.ld;
+        li = li + fOverPdf;
+        if (rc.IsCase2() || rc.IsCase3()) rc.Clear();
+        rc.L = RoundHalf3(ls.ld * throughput_k);
+        MaybeSetCase2OrCase3(g, pathVertex, pos, hit.normal, hit.t, hit.ID, hit.meshIdx, surface, prevHit, ls, seed_nee, rc);
+        r.Update(Luminance(fOverPdf), fOverPdf, rc, rngNEE);
+    }
+    bs = nbs;
+}
+
 
 // EstimateDirectAndUpdateRC<true> (ReSTIR_PT_PathTrace.hlsl:77-170) cut at its two BVH queries -- the BSDF ray of NEE_Bsdf and the light
 // segment of NEE_Emissive -- for kernels that trace elsewhere (zr_kernels.h: RptPathtraceBodyCoop).  Same statements in the same order as
@@ -1032,7 +1222,7 @@ ZR_HD void PtInitLane(const SceneView& sc, const zr_frame_constants& g, const GB
 {
     TraceReq q0;
     PtInitLane_Pre(sc, g, gb, prm, owned, x, y, finalRGBA, cnt, P, q0);
-    PtInitLane_Post(sc, prm, P, q0, TraceInline(sc, q0, stack));
+    PtInitLane_Post(sc, prm, P, q0, TraceInline<false, false>(sc, q0, stack));
 }
 
 // PtPhaseA of the emissive variant, cut at its two BVH queries (M.q1 after _Pre, M.q2 after _Mid)
@@ -1104,9 +1294,9 @@ ZR_HD void PtPhaseA(const SceneView& sc, const zr_frame_constants& g, const RptP
     {   // the cut form with its queries traced in place: one statement sequence for the megakernel, the host executor and the cooperative kernel
         PtMid M;
         PtPhaseA_Pre(sc, g, prm, cnt, P, M);
-        const RawHit h1 = TraceInline(sc, M.q1, stack);
+        const RawHit h1 = TraceInline<false, false>(sc, M.q1, stack);
         PtPhaseA_Mid(sc, g, prm, cnt, P, M, h1);
-        const RawHit h2 = TraceInline(sc, M.q2, stack);
+        const RawHit h2 = TraceInline<true, true>(sc, M.q2, stack);
         PtPhaseA_Post(sc, g, prm, cnt, P, M, h2);
         return;
     }
@@ -1147,6 +1337,96 @@ ZR_HD void PtPhaseA(const SceneView& sc, const zr_frame_constants& g, const RptP
     P.bounce++;
     P.atRR = prm.russianRoulette && (P.bounce >= 3);
 }
+
+// fused forms for the inline megakernel (see NEE_Bsdf_Fused)
+// main() prologue + RIS_InitialCandidates up to the first FindClosest (ReSTIR_PT_PathTrace.hlsl:360-530, 194-236)
+ZR_HD void PtInitLane_Fused(const SceneView& sc, const zr_frame_constants& g, const GBuf& gb, const RptParams& prm, bool owned, uint32_t x, uint32_t y,
+    float* finalRGBA, TravStack stack, uint32_t* cnt, PTLane& P)
+{
+    P.active = false; P.atRR = false; P.valid = false; P.x = x; P.y = y;
+    if (!owned) return;
+    const size_t px = Pix(gb, x, y);
+    GFlags flags = DecodeFlags(gb.mr[px]);
+    if (flags.invalid || flags.emissive)
+    {
+        if (!prm.accumulate) { float* o = finalRGBA + 4 * px; o[0] = 0; o[1] = 0; o[2] = 0; }
+        return;
+    }
+    P.valid = true;
+    const Camera cam = CurrCamera(g);
+    PixelSurface ps = LoadPixelSurface(gb, cam, x, y, g.frame_num, px);
+    P.maxNumBounces = ps.surface.specTr ? (int)prm.maxGlossyTrBounces : (int)prm.maxNonTrBounces;
+    { uint32_t a = x / 16, b = y / 8, c = g.frame_num, d = 1; zr_pcg4d(&a, &b, &c, &d); P.rngGroup = Rng::Seed(a); }
+    uint32_t sx = x, sy = y, sz = g.frame_num; zr_pcg3d(&sx, &sy, &sz);
+    P.rngReplay = Rng::Seed(sx); P.rngThread = Rng::Seed(sy); P.seed_replay = sx;
+    P.r = InitReservoir(); P.li = v3(0.0f);
+    BsdfSample bs;
+    { ZR_PROF_SCOPE(ZRP_BSDF); bs = SampleBSDF(sc.rho, ps.normal, ps.surface, P.rngReplay); }
+    if (dot(bs.bsdfOverPdf, bs.bsdfOverPdf) == 0) return;
+    if (prm.textured) P.rd = PrimaryRayDiffs(cam, (int)x, (int)y, ps, LoadTriDiffs(gb, px), bs.wi);
+    P.sampleSetIdx = prm.emissive ? P.rngGroup.UniformUintBounded_Faster(prm.numSampleSets) : 0u;      // ReSTIR_PT_PathTrace.hlsl:406-408
+    P.rc = InitReconnection();
+    P.bounce = 0; P.throughput = bs.bsdfOverPdf;
+    P.prevHit.alpha_lobe = LobeAlpha(ps.surface, bs.lobe); P.prevHit.lobe = bs.lobe; P.prevHit.wi = bs.wi; P.prevHit.pdf = bs.pdf;
+    P.eta_curr = dot(ps.normal, bs.wi) < 0 ? ps.eta_next : kEtaAir;
+    P.throughput_k = v3(1.0f);
+    P.inMedium = P.eta_curr != kEtaAir;
+    P.pos = ps.pos; P.normal = ps.normal; P.surface = ps.surface; P.bs = bs; P.eta_next = ps.eta_next;
+    Globals gl; gl.sc = &sc; gl.frame = &g; gl.emissive = prm.emissive != 0; gl.numEmissives = g.num_emissive_triangles; gl.maxNumBounces = P.maxNumBounces; gl.alpha_min = prm.alpha_min; gl.stack = stack; gl.cnt = cnt;
+    gl.presampled = prm.numSampleSets != 0; gl.sampleSetIdx = P.sampleSetIdx;
+    if (prm.emissive) P.nextHit = FindClosestEm_Fused(gl, ps.pos, ps.normal, bs.wi, ps.surface.Transmissive());
+    P.active = true;
+}
+
+ZR_HD void PtPhaseA_Fused(const SceneView& sc, const zr_frame_constants& g, const RptParams& prm, TravStack stack, uint32_t* cnt, PTLane& P)
+{
+    P.atRR = false;
+    if (!P.active) return;
+    Globals gl; gl.sc = &sc; gl.frame = &g; gl.emissive = prm.emissive != 0; gl.numEmissives = g.num_emissive_triangles; gl.maxNumBounces = P.maxNumBounces; gl.alpha_min = prm.alpha_min; gl.stack = stack; gl.cnt = cnt;
+    gl.presampled = prm.numSampleSets != 0; gl.sampleSetIdx = P.sampleSetIdx;
+    P.pathVertex = P.bounce + 2;
+    V3 newPos;
+    {
+    ZR_PROF_SCOPE(ZRP_MATERIAL);
+    if (prm.emissive)
+    {
+        // the BSDF ray of the previous vertex's NEE (ReSTIR_PT_PathTrace.hlsl:235-239)
+        if (!P.nextHit.hit) { P.active = false; return; }
+        P.hit.t = P.nextHit.t;
+        if (prm.textured) FillHit<true>(sc, P.nextHit.mesh, P.nextHit.prim, P.nextHit.bu, P.nextHit.bv, true, P.hit, true);
+        else FillHit<false>(sc, P.nextHit.mesh, P.nextHit.prim, P.nextHit.bu, P.nextHit.bv, true, P.hit, true);
+    }
+    else if (!FindClosestID(gl, true, P.pos, P.normal, P.bs.wi, P.surface.Transmissive(), P.hit, prm.textured)) { P.active = false; return; }   // Hit::FindClosest<true, true>
+    newPos = mad(P.hit.t, P.bs.wi, P.pos);
+    float eta_mat;
+    V4 uvGrads = v4(0, 0, 0, 0);
+    if (prm.textured)
+    {
+        P.rd.dpdx_dpdy(newPos, P.hit.normal, P.dpdx, P.dpdy);
+        P.rd.ComputeUVDifferentials(P.dpdx, P.dpdy, P.hit.dpdu, P.hit.dpdv);
+        uvGrads = P.rd.uv_grads;
+    }
+    if (!GetMaterialData(sc, -P.bs.wi, P.eta_curr, P.hit, P.surface, eta_mat, uvGrads, prm.textured)) { P.active = false; return; }
+    P.eta_next = eta_mat;
+    }
+    P.pos = newPos;
+    P.normal = P.hit.normal;
+    P.prevPdf = P.bs.pdf; P.prevLobe = P.bs.lobe;
+    P.tr = v3(1.0f);
+    if (P.inMedium && (P.surface.trDepth > 0))
+    {
+        V3 ext = -vlog(P.surface.base) / P.surface.trDepth;
+        P.tr = vexp(-P.hit.t * ext);
+        P.throughput = P.throughput * P.tr;
+    }
+    EstimateDirectAndUpdateRC_Fused(gl, P.pathVertex, P.pos, P.hit, P.surface, P.prevHit, P.throughput, P.throughput_k, P.li, P.bs, P.nextHit, P.rc, P.r,
+        P.rngThread, P.rngReplay);
+    if (P.bounce >= (P.maxNumBounces - 1)) { P.active = false; return; }
+    if (P.rc.IsCase2() || P.rc.IsCase3()) P.rc.Clear();
+    P.bounce++;
+    P.atRR = prm.russianRoulette && (P.bounce >= 3);
+}
+
 
 // bit pattern a lane contributes to the wave max (luminance of a non-negative throughput; NaN / negative -> 0)
 ZR_HD uint32_t PtRRKey(const PTLane& P)
@@ -1607,6 +1887,9 @@ struct RptFrame
     // pixels: G-buffer rendered locally, reservoirs received through the halo exchange
     uint32_t ox0, oy0, ow, oh;
     ZR_HDM bool Owns(uint32_t x, uint32_t y) const { return x >= ox0 && y >= oy0 && x < ox0 + ow && y < oy0 + oh; }
+    // GPU time per 32 x 32-pixel cell of the planes (cell (0, 0) at the plane origin gb.x0, gb.y0): wave lifetimes of K11 / K14 / K16, one
+    // atomic per wave: what the cost-balanced tile split of the multi-GPU path is computed from (tiling.balanced_layout); null = off
+    uint32_t* costMap; uint32_t costW;
 };
 
 ZR_HD Globals MakeGlobals(const RptFrame& F, const zr_frame_constants& g, bool transmissive, TravStack stack, uint32_t* cnt)

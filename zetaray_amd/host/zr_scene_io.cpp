@@ -395,6 +395,9 @@ Image LoadDDS(const std::string& path)
     if (d.size() < 128 || std::memcmp(d.data(), "DDS ", 4)) Throw(path + ": not a DDS file");
     auto u32 = [&](size_t off) { uint32_t v; std::memcpy(&v, d.data() + off, 4); return v; };
     Image img; img.h = u32(12); img.w = u32(16); img.mips = u32(28) ? u32(28) : 1;
+    // zr_texture_desc stores 16-bit dimensions and an 8-bit mip count; a full chain of a 65535-texel side has 16 levels
+    if (img.w == 0 || img.h == 0 || img.w > 65535u || img.h > 65535u) Throw(path + ": texture dimensions must be in [1, 65535]");
+    if (img.mips > 16u) Throw(path + ": more than 16 mip levels");
     size_t off = 128; uint32_t fmt = 0;
     if (!std::memcmp(d.data() + 84, "DX10", 4)) { fmt = u32(128); off = 148; }
     else if (!std::memcmp(d.data() + 84, "ATI2", 4) || !std::memcmp(d.data() + 84, "BC5U", 4)) fmt = 83;
@@ -492,7 +495,10 @@ struct MeshPrim { uint32_t vtx, idx, nidx; int mat; };
 void Load(const std::string& path, zrh_scene_data& sc)
 {
     Gltf g;
-    { const std::vector<uint8_t> txt = ReadFile(path); JsonParser jp{(const char*)txt.data(), (const char*)txt.data() + txt.size()}; g.root = jp.Value(); }
+    {   // the parser's strtod / strncmp look ahead: give them a NUL-terminated buffer (`end` stays at the last byte of the file)
+        std::vector<uint8_t> txt = ReadFile(path); txt.push_back(0);
+        JsonParser jp{(const char*)txt.data(), (const char*)txt.data() + txt.size() - 1}; g.root = jp.Value();
+    }
     g.dir = DirOf(path);
     for (const Json& b : g.root.At("buffers").arr)
     {
@@ -576,6 +582,11 @@ void Load(const std::string& path, zrh_scene_data& sc)
             Accessor uv{}, tan{};
             if (hasUV) uv = g.Acc((int)at.At("TEXCOORD_0").num);
             if (hasTan) tan = g.Acc((int)at.At("TANGENT").num);
+            // every attribute is read for pos.count vertices: each accessor must hold that many elements
+            if (nrm.count < pos.count || (hasUV && uv.count < pos.count) || (hasTan && tan.count < pos.count))
+                Throw("glTF: NORMAL / TEXCOORD_0 / TANGENT accessor shorter than POSITION");
+            const int numMats = mats ? (int)mats->Size() : 0;
+            if (mp.mat >= numMats) Throw("glTF: primitive names material " + std::to_string(mp.mat) + " but the file has " + std::to_string(numMats));
             for (size_t v = 0; v < pos.count; v++)
             {
                 zr_vertex vx; std::memset(&vx, 0, sizeof(vx));
@@ -589,7 +600,13 @@ void Load(const std::string& path, zrh_scene_data& sc)
             if (!prim.Find("indices")) Throw("glTF: non-indexed primitives are not supported");
             const Accessor ia = g.Acc((int)prim.At("indices").num);
             if (ia.count % 3) Throw("glTF: index count is not a multiple of 3");
-            for (size_t t = 0; t < ia.count; t += 3) { sc.indices.push_back(Gltf::Index(ia, t)); sc.indices.push_back(Gltf::Index(ia, t + 2)); sc.indices.push_back(Gltf::Index(ia, t + 1)); }
+            for (size_t t = 0; t < ia.count; t += 3)
+            {
+                const uint32_t i0 = Gltf::Index(ia, t), i1 = Gltf::Index(ia, t + 2), i2 = Gltf::Index(ia, t + 1);
+                // an index beyond the primitive's vertices would read past the vertex buffer on the host and on the device (BVH build, refit)
+                if (i0 >= pos.count || i1 >= pos.count || i2 >= pos.count) Throw("glTF: vertex index out of range");
+                sc.indices.push_back(i0); sc.indices.push_back(i1); sc.indices.push_back(i2);
+            }
             mp.nidx = (uint32_t)ia.count;
             prims[{(int)mi, (int)pi}] = mp;
         }
@@ -599,16 +616,25 @@ void Load(const std::string& path, zrh_scene_data& sc)
     std::vector<Em> emissive;
     const Json& nodes = g.root.At("nodes");
     auto isEmissive = [&](int mat) {
-        if (mat < 0) return false;
+        if (mat < 0 || !mats) return false;
         const Json& m = mats->arr.at(mat);
         float sum = 0; if (const Json* f = m.Find("emissiveFactor")) sum = (float)f->arr.at(0).num + (float)f->arr.at(1).num + (float)f->arr.at(2).num;
-        return sum > 0 || m.Find("emissiveTexture") != nullptr; };
+        // glTF.cpp:405-410: factor sum > 0 OR KHR_materials_emissive_strength present OR an emissive texture
+        bool hasStrength = false;
+        if (const Json* ext = m.Find("extensions")) hasStrength = ext->Find("KHR_materials_emissive_strength") != nullptr;
+        return sum > 0 || hasStrength || m.Find("emissiveTexture") != nullptr; };
     Mat43 identity; std::memset(&identity, 0, sizeof(identity)); for (int i = 0; i < 3; i++) identity.m[i][i] = 1.0f;
     struct Walker
     {
         Gltf& g; zrh_scene_data& sc; std::map<std::pair<int, int>, MeshPrim>& prims; std::vector<Em>& emissive; const Json& nodes; decltype(isEmissive)& isEm;
+        std::vector<uint8_t> onPath;
         void Visit(int nidx, const Mat43& parent)
         {
+            if (nidx < 0 || (size_t)nidx >= nodes.arr.size()) Throw("glTF: node index out of range");
+            if (onPath.empty()) onPath.assign(nodes.arr.size(), 0);
+            if (onPath[nidx]) Throw("glTF: the node hierarchy has a cycle");
+            onPath[nidx] = 1;
+            struct Leave { std::vector<uint8_t>& v; int i; ~Leave() { v[i] = 0; } } leave{onPath, nidx};
             const Json& node = nodes.arr.at(nidx);
             float s[3] = {1, 1, 1}, q[4] = {0, 0, 0, 1}, t[3] = {0, 0, 0};
             if (const Json* m = node.Find("matrix"))
@@ -654,7 +680,7 @@ void Load(const std::string& path, zrh_scene_data& sc)
             }
             if (const Json* ch = node.Find("children")) for (const Json& c : ch->arr) Visit((int)c.num, world);
         }
-    } walker{g, sc, prims, emissive, nodes, isEmissive};
+    } walker{g, sc, prims, emissive, nodes, isEmissive, {}};
     const Json& scenes = g.root.At("scenes");
     const Json& scene = scenes.arr.at((size_t)g.root.IntOr("scene", 0));
     for (const Json& n : scene.At("nodes").arr) walker.Visit((int)n.num, identity);

@@ -17,8 +17,12 @@ def tile_grid(n):
     return {1: (1, 1), 2: (2, 1), 4: (2, 2), 8: (4, 2)}[n]
 
 
-def tile_rect(w, h, n, rank):
-    """(x0, y0, tw, th) of rank's tile: 32-px aligned boundaries."""
+def tile_rect(w, h, n, rank, layout=None):
+    """(x0, y0, tw, th) of rank's tile: 32-px aligned boundaries.  layout: the n rects of a cost-balanced split (balanced_layout), else the
+    equal-area grid."""
+    if layout is not None:
+        assert len(layout) == n
+        return tuple(int(v) for v in layout[rank])
     gx, gy = tile_grid(n)
     tx, ty = rank % gx, rank // gx
 
@@ -29,6 +33,69 @@ def tile_rect(w, h, n, rank):
     x0, tw = split(w, gx, tx)
     y0, th = split(h, gy, ty)
     return x0, y0, tw, th
+
+
+def balanced_layout(w, h, n, cost, min_cells=2):
+    """n 32-px-aligned rects that tile the w x h frame with (nearly) equal COST: `cost` is a (ceil(h / 32), ceil(w / 32)) array of work per
+    32 x 32-px cell (zr_pass_read_cost_map: rays per cell of the previous frames).  Recursive kd-split: a region that has to feed k ranks
+    is cut -- along the axis and at the cell boundary where the two sides' cost shares come closest to floor(k / 2) : ceil(k / 2) -- until
+    every region feeds one rank.  Deterministic (every rank computes the same layout from the same map); a tile is at least `min_cells`
+    cells wide and high so that the 32-px apron of its neighbours never spans a whole tile."""
+    cost = np.asarray(cost, np.float64)
+    gh, gw = (h + 31) // 32, (w + 31) // 32
+    assert cost.shape == (gh, gw), (cost.shape, (gh, gw))
+    cost = cost + cost.sum() * 1e-6 / cost.size + 1e-9          # empty regions still split by area
+    out = []
+
+    def rec(cx0, cy0, cx1, cy1, k):
+        if k == 1:
+            x0, y0 = cx0 * 32, cy0 * 32
+            out.append((x0, y0, min(w, cx1 * 32) - x0, min(h, cy1 * 32) - y0))
+            return
+        k1 = k // 2
+        want = k1 / k
+        region = cost[cy0:cy1, cx0:cx1]
+        total = region.sum()
+        best = None
+        for axis in (0, 1):             # 0: cut in x, 1: cut in y
+            prof = np.cumsum(region.sum(axis=0 if axis == 0 else 1))
+            length = len(prof)
+            lo, hi = min_cells * k1, length - min_cells * (k - k1)         # each side keeps room for its ranks
+            if hi < lo:
+                continue
+            for c in range(max(1, lo), min(length - 1, hi) + 1):
+                err = abs(prof[c - 1] / total - want)
+                # prefer the cut with the better balance; ties: the cut through the longer axis (squarer tiles, shorter borders)
+                key = (round(err, 9), -(length))
+                if best is None or key < best[0]:
+                    best = (key, axis, c)
+        assert best is not None, "region too small to split"
+        _, axis, c = best
+        if axis == 0:
+            rec(cx0, cy0, cx0 + c, cy1, k1); rec(cx0 + c, cy0, cx1, cy1, k - k1)
+        else:
+            rec(cx0, cy0, cx1, cy0 + c, k1); rec(cx0, cy0 + c, cx1, cy1, k - k1)
+    rec(0, 0, gw, gh, n)
+    return out
+
+
+def cost_share(cost, rect):
+    x0, y0, tw, th = rect
+    return float(np.asarray(cost)[y0 // 32:(y0 + th + 31) // 32, x0 // 32:(x0 + tw + 31) // 32].sum())
+
+
+def choose_layout(w, h, n, cost, min_gain=1.15):
+    """The cost-balanced layout if it is predicted to beat the equal-area grid by at least `min_gain` in the costliest tile, else None (= the
+    grid).  Measured on the MI355X (profiles/r03_tile_balance.jsonl): on the Cornell box at 16:9, whose sides are empty, the kd-split brings the
+    slowest of 8 tiles from 0.83 to 0.72 ms; on the uniformly dense atrium the grid is already within 8 % of perfect balance and unequal tile shapes
+    only add apron and tail (3.60 -> 3.89 ms), so the grid stays."""
+    total = float(np.asarray(cost).sum())
+    if total <= 0 or n == 1:
+        return None
+    grid = max(cost_share(cost, tile_rect(w, h, n, r)) for r in range(n))
+    lay = balanced_layout(w, h, n, cost)
+    bal = max(cost_share(cost, t) for t in lay)
+    return lay if grid > min_gain * bal else None
 
 
 def extended_rect(w, h, rect, apron=APRON):
@@ -46,16 +113,16 @@ def intersect(a, b):
     return x0, y0, x1 - x0, y1 - y0
 
 
-def halo_plan(w, h, n, rank, apron=APRON):
+def halo_plan(w, h, n, rank, apron=APRON, layout=None):
     """[(peer, send_rect, recv_rect)]: send = my tile inside the peer's extended rect, recv = the peer's tile inside mine
     (global pixel coordinates).  Symmetric by construction, so both sides agree on sizes without a handshake."""
-    mine = tile_rect(w, h, n, rank)
+    mine = tile_rect(w, h, n, rank, layout)
     mine_ext = extended_rect(w, h, mine, apron)
     plan = []
     for peer in range(n):
         if peer == rank:
             continue
-        theirs = tile_rect(w, h, n, peer)
+        theirs = tile_rect(w, h, n, peer, layout)
         send = intersect(mine, extended_rect(w, h, theirs, apron))
         recv = intersect(theirs, mine_ext)
         if send is not None or recv is not None:
@@ -72,15 +139,16 @@ class TiledRestirPT:
     passes exchange once, between their temporal and spatial stages."""
 
     def __init__(self, scene_host, width, height, world, rank, device=0, params=None, dist=None, kind="restir_pt", pass_params=None,
-                 transport="torch_p2p"):
+                 transport="torch_p2p", layout=None):
         import torch
         from . import api
         self.api, self.torch, self.dist = api, torch, dist
         self.kind = kind
         self.W, self.H, self.world, self.rank = width, height, world, rank
-        self.tile = tile_rect(width, height, world, rank)
+        self.layout = layout
+        self.tile = tile_rect(width, height, world, rank, layout)
         self.ext = extended_rect(width, height, self.tile) if world > 1 else self.tile
-        self.plan = halo_plan(width, height, world, rank) if world > 1 else []
+        self.plan = halo_plan(width, height, world, rank, layout=layout) if world > 1 else []
         ex0, ey0, ew, eh = self.ext
         integ = {"restir_pt": api.INTEGRATOR_RESTIR_PT, "restir_gi": api.INTEGRATOR_RESTIR_GI}.get(kind, api.INTEGRATOR_PATH_TRACING)
         self.r = api.Renderer(scene_host, ew, eh, device=device, params=params, integrator=integ, tile_origin=(ex0, ey0))
@@ -186,6 +254,18 @@ class TiledRestirPT:
         self.stage_spatial(cb)
         if final and exchange_final:
             self.exchange(self.api.HALO_FINAL)
+
+    def owned_cost_cells(self):
+        """this rank's contribution to the frame's cost map: (ceil(H / 32), ceil(W / 32)) float64, rays per cell of the OWNED tile since the
+        last call (zero elsewhere); summing the ranks' arrays gives the whole frame's map"""
+        gh, gw = (self.H + 31) // 32, (self.W + 31) // 32
+        out = np.zeros((gh, gw), np.float64)
+        cm = self.r.p_indirect.read_cost_map(reset=True)
+        ex0, ey0 = self.ext[0] // 32, self.ext[1] // 32
+        x0, y0, tw, th = self.tile
+        c0x, c0y, c1x, c1y = x0 // 32, y0 // 32, (x0 + tw + 31) // 32, (y0 + th + 31) // 32
+        out[c0y:c1y, c0x:c1x] = cm[c0y - ey0:c1y - ey0, c0x - ex0:c1x - ex0]
+        return out
 
     def final_tile(self):
         """(tile rect, RGBA32F array of the owned tile)"""
