@@ -273,6 +273,10 @@ int zr_scene_set_alias_table_async(zr_scene* scene, void* hip_stream, const zr_a
  * Scene::AreEmissiveMaterialsStale, PreLighting.cpp:266): drops the alias table, so that the next ZR_PASS_PRELIGHTING render re-estimates the
  * triangle powers (K2) and rebuilds it. */
 int zr_scene_invalidate_alias_table(zr_scene* scene);
+/* ... or, like the reference's steady state (PreLighting.cpp:527-540: the table is rebuilt when the read-back fence has passed, the old one is sampled
+ * until then): PRELIGHTING renders only ENQUEUE -- K2 + an asynchronous read-back on the first, the host build + upload once the read-back has
+ * landed (checked without waiting) -- so the new table takes effect a frame or two later and no render call blocks. */
+int zr_scene_invalidate_alias_table_deferred(zr_scene* scene);
 /* Material edits (SceneCore::UpdateMaterial: the material buffer entry is rewritten and re-uploaded): replaces `count` records of the scene's
  * material buffer from index `first`.  Texture indices must stay inside the scene's texture heap.  Host call between frames (waits for the device). */
 int zr_scene_update_materials(zr_scene* scene, const zr_material* materials, uint32_t first, uint32_t count);

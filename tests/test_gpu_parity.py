@@ -1367,6 +1367,44 @@ def test_emissive_material_change_rebuilds_the_alias_table(api):
     assert np.array_equal(tables[0].view(np.uint8), tables[1].view(np.uint8)) and not np.array_equal(tables[1].view(np.uint8), tables[2].view(np.uint8))
 
 
+def test_deferred_alias_table_rebuild_never_blocks(api):
+    """zr_scene_invalidate_alias_table_deferred (the reference's steady state, PreLighting.cpp:527-540): after an emissive-material change the OLD
+    table keeps being sampled -- the frame rendered right after the change equals the oracle with the new light record and the old table -- and the
+    rebuilt table arrives without any render call waiting: once the read-back has landed (a device synchronisation between
+    the frames stands in for time) the next PRELIGHTING render uploads the rebuilt table, and every frame equals the oracle run with the same schedule."""
+    import torch
+    from oracle import zro
+    sc = scene_io.load_npz(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "cornell_emissive.npz"))
+    w, h = 96, 64
+    prm = wire.default_params()
+    r = api.Renderer(sc, w, h, params=prm, integrator=api.INTEGRATOR_RESTIR_PT)
+    osc = zro.OracleScene(sc)
+    opt = zro.OracleRPT(osc, w, h)
+    old_table = None
+    for f in range(1, 8):
+        if f == 3:
+            e = sc.emissives[0:1].copy()
+            s_old = np.uint16(int(e["packed_b"][0]) >> 16).view(np.float16)
+            s_new = int(np.float16(np.float32(s_old) * np.float32(8.0)).view(np.uint16))
+            e["packed_b"] = (int(e["packed_b"][0]) & 0xFFFF) | (s_new << 16)
+            e["packed_a"] = (int(e["packed_a"][0]) & 0x0FFFFFFF) | ((s_new & 0xF) << 28)
+            sc.emissives[0:1] = e
+            old_table = r.scene.get_alias_table().copy()
+            r.scene.update_emissives(e, 0); r.invalidate_alias_table(deferred=True)
+            osc.update_emissives(e, 0)                       # the oracle keeps its old table for now
+        if f == 4:
+            osc.rebuild_alias_table()        # frame 3 started the read-back and the device went idle: frame 4's PRELIGHTING render picks it up
+        cb = _frame(sc, w, h, f)
+        r.render_frame(cb)
+        torch.cuda.synchronize()             # (stands in for time passing; no render call above waited for the device)
+        want = opt.render(cb, prm)
+        assert np.array_equal(r.final().view(np.uint32), want.view(np.uint32)), f"frame {f}"
+        if f == 3:
+            assert np.array_equal(r.scene.get_alias_table().view(np.uint8), old_table.view(np.uint8)), "frame 3 still samples the old table"
+    assert np.array_equal(r.scene.get_alias_table().view(np.uint8), np.asarray(osc.alias).view(np.uint8))
+    assert not np.array_equal(old_table.view(np.uint8), np.asarray(osc.alias).view(np.uint8))
+
+
 def test_material_edit_between_frames(api):
     """SceneCore::UpdateMaterial: at frame 3 every non-emissive material of the Cornell box turns into a rough metal with another base colour
     (zr_scene_update_materials); G-buffer, ReSTIR PT and ReSTIR DI equal the oracle's before and after (temporal reuse across the edit included)."""

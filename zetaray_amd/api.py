@@ -45,7 +45,7 @@ RPT_OUTPUTS = {"A": (1, np.uint32, 1), "B": (2, np.float32, 2), "C": (3, np.uint
 
 EXPORTS = [
     "zr_abi_version", "zr_last_error", "zr_device_count", "zr_wire_layout", "zr_scene_create", "zr_scene_destroy", "zr_scene_update_instances", "zr_scene_update_emissives", "zr_scene_invalidate_alias_table", "zr_scene_update_materials",
-    "zr_scene_update_instances_async", "zr_scene_update_emissives_async", "zr_scene_update_materials_async", "zr_scene_set_alias_table_async",
+    "zr_scene_invalidate_alias_table_deferred", "zr_scene_update_instances_async", "zr_scene_update_emissives_async", "zr_scene_update_materials_async", "zr_scene_set_alias_table_async",
     "zr_scene_set_alias_table", "zr_alias_table_build", "zr_scene_get_alias_table", "zr_scene_get_light_voxel_grid", "zr_scene_get_presampled_sets", "zr_scene_bvh_info", "zr_pass_enable_cost_map", "zr_pass_read_cost_map",
     "zr_gbuffer_create", "zr_gbuffer_destroy", "zr_gbuffer_set_tile_origin", "zr_gbuffer_download", "zr_gbuffer_device_plane",
     "zr_params_default", "zr_pass_create", "zr_pass_init", "zr_pass_resize", "zr_pass_reset_temporal",
@@ -188,6 +188,11 @@ class Scene:
         else:
             L.zr_scene_update_materials_async.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32]
             _check(L.zr_scene_update_materials_async(self.h, stream, m.ctypes.data, first, len(m)))
+
+    def invalidate_alias_table_deferred(self):
+        """the reference's steady-state form: the old table is sampled until the rebuilt one has been uploaded; no render call waits"""
+        lib().zr_scene_invalidate_alias_table_deferred.argtypes = [C.c_void_p]
+        _check(lib().zr_scene_invalidate_alias_table_deferred(self.h))
 
     def invalidate_alias_table(self):
         """emissive materials changed: the next PRELIGHTING render re-estimates the powers and rebuilds the alias table"""
@@ -461,8 +466,13 @@ class Renderer:
         self._bind_post_inputs()
         return self.p_direct
 
-    def invalidate_alias_table(self):
-        """emissive materials changed (records already handed to scene.update_emissives): PRELIGHTING re-estimates powers + rebuilds the table"""
+    def invalidate_alias_table(self, deferred=False):
+        """emissive materials changed (records already handed to scene.update_emissives): PRELIGHTING re-estimates powers + rebuilds the table.
+        deferred: the reference's steady-state form -- the old table is sampled until the new one has arrived, no render call waits"""
+        if deferred:
+            self.scene.invalidate_alias_table_deferred()
+            self._alias_poll = 8          # PRELIGHTING renders for the next frames: the first starts the read-back, a later one picks it up
+            return
         self.scene.invalidate_alias_table()
         self._alias_ready = False
 
@@ -482,9 +492,10 @@ class Renderer:
         self._bind_post_inputs()
         self.render_sky(cb, stream)
         self.p_gbuffer.render(cb, self.scene, self.gbuffer, stream)
-        if not self._alias_ready or self._presampling:      # presampled light sets are regenerated every frame (K3)
+        if not self._alias_ready or self._presampling or getattr(self, "_alias_poll", 0) > 0:      # presampled light sets are regenerated every frame (K3)
             self.p_prelight.render(cb, self.scene, None, stream)
             self._alias_ready = True
+            self._alias_poll = max(0, getattr(self, "_alias_poll", 0) - 1)
         if self.p_direct is not None:
             self.p_direct.render(cb, self.scene, self.gbuffer, stream)
         if self.p_sky_direct is not None:

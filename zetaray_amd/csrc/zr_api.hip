@@ -510,6 +510,7 @@ struct zr_scene
     DevBuf<uint32_t> levelNodes; std::vector<uint32_t> levelOffsets, hLevelOrder; DevBuf<float> nodeBounds, toWorld; bool refitReady = false;
     // device-side BVH build (zr_tu_bvh.hip): instance masks on the device, scratch buffers kept between builds
     DevBuf<uint8_t> dMask; DeviceBvhScratch bvhScratch; bool deviceBuilt = false;
+    bool aliasStale = false;      // zr_scene_invalidate_alias_table_deferred: the old table stays bound until the rebuilt one has been uploaded
     // `view` is what kernels receive by value.  Passes of one dependency level may record concurrently from several host threads
     // (RenderGraph.cpp:442-541) while Sky / PreLighting publish scene-owned state (sky LUT, alias table, presampled sets, LVG):
     // every reader takes a private copy through FrameView() and every writer updates `view` under `mtx`.
@@ -749,6 +750,8 @@ struct zr_pass
     uint32_t own[4] = {0, 0, 0, 0};                // owned rect (global pixels); w == 0 -> the whole G-buffer rect
     // PRELIGHTING
     DevBuf<float> power;
+    // deferred alias-table rebuild (zr_scene_invalidate_alias_table_deferred): K2's powers are read back into pinned memory behind an event
+    float* powerHost = nullptr; size_t powerHostCap = 0; hipEvent_t powerEv = nullptr; bool powerPending = false;
     // timing
     bool timing = false;
     struct Timer { const char* name; hipEvent_t a, b; bool used; };
@@ -1236,6 +1239,16 @@ int zr_scene_invalidate_alias_table(zr_scene* s)
     // rewritten by zr_scene_set_alias_table, which orders itself behind them
     std::lock_guard<std::mutex> lock(s->mtx);
     s->view.alias = nullptr; s->aliasHost.clear();
+    return ZR_OK;
+}
+// The reference's steady-state behaviour (EmissiveTriangleAliasTable::Render, PreLighting.cpp:527-540: "fence hasn't passed, returning ..."): the
+// old table keeps being sampled until the re-estimated powers have come back and the new table has been uploaded -- a frame or two later --
+// and no render call ever waits for the device.  zr_scene_invalidate_alias_table is the deterministic form (new table in the very next frame).
+int zr_scene_invalidate_alias_table_deferred(zr_scene* s)
+{
+    if (!s) return Fail(ZR_ERR_INVALID_ARG, "zr_scene_invalidate_alias_table_deferred: null argument");
+    std::lock_guard<std::mutex> lock(s->mtx);
+    if (s->view.alias) s->aliasStale = true;      // without a table there is nothing to keep: the next PRELIGHTING render builds one (first-frame path)
     return ZR_OK;
 }
 int zr_scene_update_instances_async(zr_scene* s, void* stream, const zr_mesh_instance* instances, const float* instance_to_world, uint32_t n)
@@ -1785,6 +1798,34 @@ static int RenderPreLightingInner(zr_pass* p, hipStream_t s, const zr_frame_cons
     if (n == 0) return ZR_OK;
     // the alias table is built once per emissive set (EmissiveTriangleAliasTable is only re-run when emissive materials change):
     // zr_scene_invalidate_alias_table or a new scene forces a rebuild
+    if (sc->view.alias && sc->aliasStale)
+    {
+        // deferred rebuild: (1) nothing in flight -> estimate the powers and start their read-back; (2) read-back finished -> build on the host and
+        // enqueue the upload; either way this call only enqueues, and the bound table stays valid for this frame's sampling
+        int r;
+        if (!p->powerPending)
+        {
+            if (p->power.n != n && (r = p->power.Alloc(n))) return r;
+            if (p->powerHostCap < n) { if (p->powerHost) (void)hipHostFree(p->powerHost); p->powerHost = nullptr; HIP_TRY(hipHostMalloc((void**)&p->powerHost, n * sizeof(float), hipHostMallocDefault)); p->powerHostCap = n; }
+            if (!p->powerEv) HIP_TRY(hipEventCreateWithFlags(&p->powerEv, hipEventDisableTiming));
+            hipLaunchKernelGGL(k_estimate_power, dim3((n + 255) / 256), dim3(256), 0, s, FrameView(sc, cb), n, p->power.p);
+            HIP_TRY(hipGetLastError());
+            HIP_TRY(hipMemcpyAsync(p->powerHost, p->power.p, n * sizeof(float), hipMemcpyDeviceToHost, s));
+            HIP_TRY(hipEventRecord(p->powerEv, s));
+            p->powerPending = true;
+        }
+        else if (hipEventQuery(p->powerEv) == hipSuccess)
+        {
+            std::vector<float> power(p->powerHost, p->powerHost + n);
+            std::vector<zr_alias_entry> table(n);
+            BuildAliasTableHost(power, table.data(), 0);
+            if ((r = zr_scene_set_alias_table_async(sc, s, table.data(), n))) return r;
+            p->powerPending = false;
+            std::lock_guard<std::mutex> lock(sc->mtx);
+            sc->aliasStale = false;
+        }
+        return p->params.presampling ? RenderPresample(p, s, cb, sc) : ZR_OK;
+    }
     if (sc->view.alias) return p->params.presampling ? RenderPresample(p, s, cb, sc) : ZR_OK;
     int r = p->power.Alloc(n);
     if (r) return r;
@@ -2043,7 +2084,10 @@ static int RenderReSTIR_PT(zr_pass* p, hipStream_t s, const zr_frame_constants* 
     }
     if ((stages & ZR_STAGE_SPATIAL) && prm.doSpatial)
     {
-        RPT_TIMED("rpt_spatial_search", hipLaunchKernelGGL(k_rpt_light<1>, grid, block, 0, s, F, *cb, tilesX, lists[2], lists[3], listCnt + 2));
+        // ZR_SEARCH=tile: the LDS-tiled K15 (k_rpt_light<2>), kept for the A/B of DESIGN's N3 row -- measured slower than the plain gathers
+        static const bool searchTile = [] { const char* e = getenv("ZR_SEARCH"); return e && !strcmp(e, "tile"); }();
+        if (searchTile) RPT_TIMED("rpt_spatial_search", hipLaunchKernelGGL(k_rpt_light<2>, grid, block, 0, s, F, *cb, tilesX, lists[2], lists[3], listCnt + 2));
+        else RPT_TIMED("rpt_spatial_search", hipLaunchKernelGGL(k_rpt_light<1>, grid, block, 0, s, F, *cb, tilesX, lists[2], lists[3], listCnt + 2));
         // K12 Sort_CtS / Sort_StC (IndirectLighting.cpp:690-742): the NtC map decides which pixels share a wave in Reconnect_StC, i.e. the
         // population of its boiling-suppression averages
         if (prm.sortSpatial)
@@ -2625,6 +2669,8 @@ int zr_pass_destroy(zr_pass* p)
     if (!p) return ZR_OK;
     (void)hipSetDevice(p->device);
     for (auto& t : p->timers) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); }
+    if (p->powerEv) (void)hipEventDestroy(p->powerEv);
+    if (p->powerHost) (void)hipHostFree(p->powerHost);
     delete p;
     return ZR_OK;
 }

@@ -417,7 +417,30 @@ __global__ void __launch_bounds__(kBlock) k_rpt_light(rpt::RptFrame F, zr_frame_
     }
     else                    // K15 spatial search, then the spatial work lists
     {
-        if (in) { rpt::SpatialSearchPixel(F, g, x, y); a = rpt::NeedsReplayCtS(F, x, y); b = rpt::NeedsReplayStC(F, x, y); }
+        if (PASS == 2)
+        {
+            // N3 experiment (north_star: "LDS-staged reservoir tiles for the spatial-reuse stencil"): the 46 x 46 texels (mr, depth, normal: 10 B)
+            // the 16 x 16 block's searches can touch (radius 15) staged in LDS first; same arithmetic, candidates read from the tile
+            constexpr int R = rpt::kSearchRadius, T = 16 + 2 * R;
+            __shared__ uint16_t tMr[T * T]; __shared__ float tDepth[T * T]; __shared__ uint32_t tNormal[T * T];
+            const uint32_t tile = blockIdx.x, tx0 = F.ox0 + (tile % tilesX) * 16u, ty0 = F.oy0 + (tile / tilesX) * 16u;
+            for (uint32_t i = threadIdx.x; i < (uint32_t)(T * T); i += kBlock)
+            {
+                const int gx = (int)tx0 - R + (int)(i % T), gy = (int)ty0 - R + (int)(i / T);
+                const bool ok = gx >= 0 && gy >= 0 && gx < (int)g.render_width && gy < (int)g.render_height && rpt::InPlanes(F.gb, gx, gy);
+                const size_t sp = ok ? rpt::Pix(F.gb, (uint32_t)gx, (uint32_t)gy) : 0;
+                tMr[i] = ok ? F.gb.mr[sp] : (uint16_t)0; tDepth[i] = ok ? F.gb.depth[sp] : 0.0f; tNormal[i] = ok ? F.gb.normal[sp] : 0u;
+            }
+            __syncthreads();
+            struct TileFetch
+            {
+                const uint16_t* mr; const float* depth; const uint32_t* normal; int x0, y0;
+                __device__ void operator()(int sx, int sy, uint16_t& m, float& d, uint32_t& n) const
+                { const int i = (sy - y0) * T + (sx - x0); m = mr[i]; d = depth[i]; n = normal[i]; }
+            } tf{tMr, tDepth, tNormal, (int)tx0 - R, (int)ty0 - R};
+            if (in) { rpt::SpatialSearchPixelT(F, g, x, y, tf); a = rpt::NeedsReplayCtS(F, x, y); b = rpt::NeedsReplayStC(F, x, y); }
+        }
+        else if (in) { rpt::SpatialSearchPixel(F, g, x, y); a = rpt::NeedsReplayCtS(F, x, y); b = rpt::NeedsReplayStC(F, x, y); }
     }
     const uint32_t pid = in ? (uint32_t)rpt::Pix(F.gb, x, y) : 0u;
     // one atomic per block and list: with every wave appending (large scenes: most pixels carry k > 2 reservoirs) 65 k returning

@@ -2108,8 +2108,16 @@ ZR_HD V3 WorldPosSS(float px, float py, V2 renderDim, float z_view, float tanHal
               viewInv[8] * d.x + viewInv[9] * d.y + viewInv[10] * d.z + viewInv[11]);
 }
 
-// K15 SpatialSearch (ReSTIR_PT_SpatialSearch.hlsl:21-146)
-ZR_HD void SpatialSearchPixel(const RptFrame& F, const zr_frame_constants& g, uint32_t x, uint32_t y)
+// How K15 reads a candidate's G-buffer texels: straight from the planes ...
+struct PlaneFetch
+{
+    const GBuf* gb;
+    ZR_HDM void operator()(int sx, int sy, uint16_t& mr, float& depth, uint32_t& normal) const
+    { const size_t sp = Pix(*gb, (uint32_t)sx, (uint32_t)sy); mr = gb->mr[sp]; depth = gb->depth[sp]; normal = gb->normal[sp]; }
+};
+// K15 SpatialSearch (ReSTIR_PT_SpatialSearch.hlsl:21-146); Fetch: see PlaneFetch (zr_kernels.h has the LDS-tile variant measured for DESIGN's N3 row)
+template<typename Fetch>
+ZR_HD void SpatialSearchPixelT(const RptFrame& F, const zr_frame_constants& g, uint32_t x, uint32_t y, const Fetch& fetch)
 {
     const GBuf& gb = F.gb;
     const uint32_t W = g.render_width, H = g.render_height;
@@ -2140,15 +2148,15 @@ ZR_HD void SpatialSearchPixel(const RptFrame& F, const zr_frame_constants& g, ui
         if (sxp < 0 || syp < 0 || sxp >= (int)W || syp >= (int)H) continue;
         if (sxp == (int)x && syp == (int)y) continue;
         if (!InPlanes(gb, sxp, syp)) continue;      // cannot happen with an apron >= the search radius
-        const size_t sp = Pix(gb, (uint32_t)sxp, (uint32_t)syp);
-        const uint16_t smr = gb.mr[sp];
+        uint16_t smr; float sdepth; uint32_t snormal;
+        fetch(sxp, syp, smr, sdepth, snormal);
         GFlags sf = DecodeFlags(smr);
         if (sf.invalid || sf.emissive) continue;
         if (flags.metallic != sf.metallic) continue;
         if (flags.transmissive != sf.transmissive) continue;
         if (zr_abs(RoughnessOf(smr) - roughness) > kMaxRoughDiffSpatial) continue;
-        const V3 samplePos = WorldPosSS((float)sxp, (float)syp, renderDim, gb.depth[sp], g.tan_half_fov, g.aspect_ratio, g.curr_view_inv, jitter);
-        const V3 sampleNormal = DecodeOct32u(gb.normal[sp]);
+        const V3 samplePos = WorldPosSS((float)sxp, (float)syp, renderDim, sdepth, g.tan_half_fov, g.aspect_ratio, g.curr_view_inv, jitter);
+        const V3 sampleNormal = DecodeOct32u(snormal);
         float planeDist = zr_abs(dot(normal, samplePos - pos));
         if (!(planeDist <= 0.01f * viewDepth)) continue;
         if (dot(sampleNormal, normal) < kMinNormalSimSpatial) continue;
@@ -2158,6 +2166,9 @@ ZR_HD void SpatialSearchPixel(const RptFrame& F, const zr_frame_constants& g, ui
     if (nx == 0xffff) { F.tex.neighbor[2 * px] = 255; F.tex.neighbor[2 * px + 1] = 255; }
     else { F.tex.neighbor[2 * px] = (uint8_t)(nx - (int)x + kNeighborOffset); F.tex.neighbor[2 * px + 1] = (uint8_t)(ny - (int)y + kNeighborOffset); }
 }
+
+ZR_HD void SpatialSearchPixel(const RptFrame& F, const zr_frame_constants& g, uint32_t x, uint32_t y)
+{ PlaneFetch f; f.gb = &F.gb; SpatialSearchPixelT(F, g, x, y, f); }
 
 ZR_HD bool NeighborOf(const RptFrame& F, uint32_t x, uint32_t y, int& sx, int& sy)
 {
