@@ -82,6 +82,9 @@ __global__ void __launch_bounds__(kBlock) k_trace_simple(SceneView sc, PathQueue
 {
     const uint32_t nC = rayCount[0], nM = rayCount[kCounterStride], total = nC + nM + rayCount[2 * kCounterStride];
     ZR_TRAV_STACK(stack);
+#ifdef ZR_NODE_CACHE_MORE
+    ZR_NODE_CACHE_FILL(stack, sc, kBlock);
+#endif
     for (uint32_t base = blockIdx.x * kBlock; base < total; base += gridDim.x * kBlock)
     {
         const uint32_t j = base + threadIdx.x;
@@ -451,10 +454,16 @@ __global__ void __launch_bounds__(kDiBlock) ZR_WAVES_RDI_S k_rdi_spatial(rdi::Di
 // K10: one 8x8 pixel group per wave, bounce loop in lockstep around the Russian-roulette wave max, then temporal resampling
 // and the boiling-suppression wave sum (zr_rgi.h)
 // (the kernel body as a macro: routing both kernels through one inline function taking the frame by reference cost the untextured one 4 %)
+#ifdef ZR_NODE_CACHE_MORE
+#define ZR_RGI_NODE_CACHE ZR_NODE_CACHE_FILL(stack, F.sc, kRgiBlock);
+#else
+#define ZR_RGI_NODE_CACHE
+#endif
 #define ZR_RGI_KERNEL_BODY(TEX) \
     F.prm.textured = TEX; \
     uint32_t x, y; PixelOfThreadB<kRgiBlock>(tilesX, F.ox0, F.oy0, &x, &y); \
     ZR_TRAV_STACK_B(stack, kRgiBlock); \
+    ZR_RGI_NODE_CACHE \
     uint32_t cnt[2] = {0u, 0u}; \
     rgi::Lane P; \
     rgi::InitLane(F, g, x, y, stack, cnt, P); \

@@ -106,7 +106,34 @@ public:
         BuildInternal(0, 0, N, 1);
         out.nodes4.reserve(out.nodes.size() / 2 + 1);
         Collapse(0, out.stackNeed);
+        ReorderBreadthFirst(out.nodes4);
         return out;
+    }
+
+    // Numbers the TOP of the tree breadth-first: the first kTopNodes nodes (five levels of a full 4-wide tree) are the root, then level by level
+    // -- what every ray visits becomes one contiguous prefix (the optional LDS node cache of the kernels copies exactly that prefix); all other
+    // nodes keep their depth-first order behind it, so subtrees stay contiguous.  Results and the stack bound do not depend on node numbers.
+    static constexpr size_t kTopNodes = 341;
+    static void ReorderBreadthFirst(std::vector<Bvh4Node>& nodes)
+    {
+        if (nodes.empty()) return;
+        std::vector<uint32_t> order; order.reserve(nodes.size());
+        std::vector<uint8_t> placed(nodes.size(), 0);
+        order.push_back(0u); placed[0] = 1;
+        for (size_t i = 0; i < order.size() && order.size() < kTopNodes; i++)
+            for (int c = 0; c < 4 && order.size() < kTopNodes; c++)
+            { const uint32_t r = nodes[order[i]].child[c]; if (r != kEmptyChild && !(r & kLeafBit)) { order.push_back(r); placed[r] = 1; } }
+        for (uint32_t i = 0; i < (uint32_t)nodes.size(); i++) if (!placed[i]) order.push_back(i);
+        std::vector<uint32_t> newIdx(nodes.size(), 0u);
+        for (size_t i = 0; i < order.size(); i++) newIdx[order[i]] = (uint32_t)i;
+        std::vector<Bvh4Node> out(order.size());
+        for (size_t i = 0; i < order.size(); i++)
+        {
+            Bvh4Node n = nodes[order[i]];
+            for (int c = 0; c < 4; c++) if (n.child[c] != kEmptyChild && !(n.child[c] & kLeafBit)) n.child[c] = newIdx[n.child[c]];
+            out[i] = n;
+        }
+        nodes.swap(out);
     }
 
 private:

@@ -208,7 +208,17 @@ struct StackEntry { uint32_t child; float t; };
 #define ZR_PRIVATE_AS
 #endif
 // `aux` (device, ZR_STEAL): this wave's work-stealing region in LDS -- 64 x u64 merge keys, 64 x (t, u, v) payloads, 64 x u32 donor lanes
-struct TravStack { ZR_LDS_AS StackEntry* lds; uint32_t stride; ZR_PRIVATE_AS StackEntry* mem; uint32_t* aux = nullptr; };
+// `cache` (device, -DZR_NODE_CACHE=N): the first N nodes of the tree -- its top levels, nodes are numbered breadth-first -- copied into LDS by the
+// block (north_star's "LDS-staged node cache"); measured, DESIGN 5.7
+// Measured (MI355X, 1080p, N = 64 = 4 KB per block; scripts/gpu_r03_k11.sh with a -DZR_NODE_CACHE=64 build of every kernel): K11 on the 380k-triangle
+// atrium 8.37 -> 7.63 ms; the reconnect kernels get slower with it (K14 3.30 -> 3.43 ms, Cornell 0.508 -> 0.538 ms: their traversals are a quarter
+// of the kernel and the fill + the extra branch cost more than the top-level hits save); Cornell's tree has fewer than N nodes.  So only the
+// large-scene K11 (k_rpt_pathtrace_w4) fills it; kernels that do not fill keep cache == nullptr, a compile-time constant that folds the branch away.
+#ifndef ZR_NODE_CACHE
+#define ZR_NODE_CACHE 64
+#endif
+struct alignas(16) NodeQuad { uint32_t x, y, z, w; };
+struct TravStack { ZR_LDS_AS StackEntry* lds; uint32_t stride; ZR_PRIVATE_AS StackEntry* mem; uint32_t* aux = nullptr; const ZR_LDS_AS NodeQuad* cache = nullptr; };
 static constexpr uint32_t kStealAuxWords = 64 * 2 + 64 * 3 + 64;
 
 // (member-wise accesses: copying a whole StackEntry through an address-space-qualified pointer would go through a generic
@@ -267,7 +277,22 @@ ZR_HD bool TravPop(TravState& s, const TravStack& stack)
 // inner node s.cur: tests the 4 child boxes, pushes the far hits and returns the nearest one (kEmptyChild: none hit)
 ZR_HD uint32_t TravNode(const SceneView& sc, TravState& s, const TravStack& stack)
 {
+#if ZR_NODE_CACHE && defined(__HIP_DEVICE_COMPILE__)
+    Bvh4Node n;
+    if (stack.cache != nullptr && s.cur < (uint32_t)ZR_NODE_CACHE)
+    {
+        const ZR_LDS_AS NodeQuad* c = stack.cache + 4u * s.cur;
+        NodeQuad a, b, cc, d;
+        a.x = c[0].x; a.y = c[0].y; a.z = c[0].z; a.w = c[0].w; b.x = c[1].x; b.y = c[1].y; b.z = c[1].z; b.w = c[1].w;
+        cc.x = c[2].x; cc.y = c[2].y; cc.z = c[2].z; cc.w = c[2].w; d.x = c[3].x; d.y = c[3].y; d.z = c[3].z; d.w = c[3].w;
+        n.ox = zr_asfloat(a.x); n.oy = zr_asfloat(a.y); n.oz = zr_asfloat(a.z); n.exps = a.w;
+        n.child[0] = b.x; n.child[1] = b.y; n.child[2] = b.z; n.child[3] = b.w;
+        n.qlox = cc.x; n.qloy = cc.y; n.qloz = cc.z; n.qhix = cc.w; n.qhiy = d.x; n.qhiz = d.y; n.pad0 = 0; n.pad1 = 0;
+    }
+    else n = sc.nodes[s.cur];
+#else
     const Bvh4Node n = sc.nodes[s.cur];
+#endif
     const float inf = zr_asfloat(0x7f800000u);
     const float sx = zr_asfloat((n.exps & 0xffu) << 23), sy = zr_asfloat(((n.exps >> 8) & 0xffu) << 23), sz = zr_asfloat(((n.exps >> 16) & 0xffu) << 23);
     uint32_t c0 = n.child[0], c1 = n.child[1], c2 = n.child[2], c3 = n.child[3];

@@ -63,6 +63,16 @@ static constexpr uint32_t kCounterStride = 64;     // queue counters live 256 B 
     TravStack name; name.lds = (ZR_LDS_AS StackEntry*)name##Lds + threadIdx.x; name.stride = (B); name.mem = (ZR_PRIVATE_AS StackEntry*)name##Mem; \
     name.aux = name##Aux + (ZR_STEAL ? kStealAuxWords * (threadIdx.x / 64) : 0)
 #define ZR_TRAV_STACK(name) ZR_TRAV_STACK_B(name, kBlock)
+// -DZR_NODE_CACHE=N: the block copies the first N nodes (the top levels: breadth-first numbering) into LDS once; TravNode reads those from there
+#if ZR_NODE_CACHE
+#define ZR_NODE_CACHE_FILL(name, scene, B) \
+    __shared__ uint4 name##NodeCache[4 * ZR_NODE_CACHE]; \
+    { const uint32_t nc_ = (scene).numNodes < (uint32_t)ZR_NODE_CACHE ? (scene).numNodes : (uint32_t)ZR_NODE_CACHE; \
+      for (uint32_t i_ = threadIdx.x; i_ < 4u * nc_; i_ += (B)) name##NodeCache[i_] = ((const uint4*)(scene).nodes)[i_]; \
+      __syncthreads(); name.cache = nc_ == (uint32_t)ZR_NODE_CACHE ? (const ZR_LDS_AS NodeQuad*)name##NodeCache : nullptr; }
+#else
+#define ZR_NODE_CACHE_FILL(name, scene, B)
+#endif
 
 // one atomic per wave: lanes that `want` a slot get consecutive indices
 __device__ __forceinline__ uint32_t AllocSlotWave(uint32_t* counter, bool want)
@@ -168,7 +178,7 @@ __device__ __forceinline__ void FlushRayCountersCost(const rpt::RptFrame& F, uns
 // K11: block = 16x16 pixels, wave w = rows 4w..4w+3 (a 16x4 block: the RR "wave" of the ABI, zr_rpt.h header)
 // EMISSIVE: the NEE_EMISSIVE shader permutation (emissive triangles vs sun + sky); a template constant so the other variant folds away
 // TEX: the scene has a texture heap (ray differentials carried, material maps sampled); likewise a template constant
-template<bool EMISSIVE, bool TEX>
+template<bool EMISSIVE, bool TEX, bool NODE_CACHE = false>
 __device__ __forceinline__ void RptPathtraceBody(rpt::RptFrame& F, const zr_frame_constants& g, uint32_t tilesX, unsigned long long* counters)
 {
     const unsigned long long t0 = __builtin_readcyclecounter();
@@ -177,6 +187,7 @@ __device__ __forceinline__ void RptPathtraceBody(rpt::RptFrame& F, const zr_fram
     const uint32_t tx = tile % tilesX, ty = tile / tilesX;
     const uint32_t x = F.ox0 + tx * 16u + (lane & 15u), y = F.oy0 + ty * 16u + wave * 4u + (lane >> 4);
     ZR_TRAV_STACK_B(stack, kRptBlock);
+    if (NODE_CACHE) { ZR_NODE_CACHE_FILL(stack, F.sc, kRptBlock); }      // the tree's top 64 nodes in LDS (large scenes: 8.37 -> 7.63 ms on the atrium)
     ZR_PROF_KERNEL(F.sc, 1);
     uint32_t cnt[2] = {0u, 0u};
     rpt::PTLane P;
@@ -204,7 +215,7 @@ __global__ void __launch_bounds__(kRptBlock) ZR_WAVES_PATHTRACE k_rpt_pathtrace(
 // 58-triangle Cornell box both take 1.16 ms, and the 3-wave build moves 5x less spill traffic, so small scenes keep it).
 template<bool EMISSIVE>
 __global__ void __launch_bounds__(kRptBlock) ZR_WAVES_PATHTRACE_LARGE k_rpt_pathtrace_w4(rpt::RptFrame F, zr_frame_constants g, uint32_t tilesX, unsigned long long* counters)
-{ RptPathtraceBody<EMISSIVE, false>(F, g, tilesX, counters); }
+{ RptPathtraceBody<EMISSIVE, false, true>(F, g, tilesX, counters); }
 // The TEXTURED permutation at 6 waves per SIMD: its dependent texel gathers are latency that more waves hide -- textured atrium 11.99 ms at the
 // compiler's 2 waves (255 VGPRs), 10.74 at >= 3, 10.28 at 4, 10.11 at 5, **9.36 at 6**, 9.69 at 7, 9.96 at 8 (scripts/gpu_tex.sh, gpu_waves.sh); the
 // untextured large-scene build stays at 4 (5: 8.49, 6: 8.35 against 8.02 ms).  Round 1 found that forcing it to exactly 3 waves
@@ -499,6 +510,9 @@ __global__ void __launch_bounds__(kBlock) k_rpt_replay(rpt::RptFrame F, zr_frame
 {
     F.prm.emissive = EMISSIVE ? 1u : 0u; F.prm.textured = TEX ? 1u : 0u;
     ZR_TRAV_STACK(stack);
+#ifdef ZR_NODE_CACHE_MORE
+    ZR_NODE_CACHE_FILL(stack, F.sc, kBlock);
+#endif
     const uint32_t half = gridDim.x / 2u;
     // (counters: the per-kernel slots of the two passes are neighbours, zr_api.hip kCounterNames)
     if (blockIdx.x < half) RptReplayList<PASS_A, EMISSIVE, TEX>(F, g, listA, counts[0], counters, blockIdx.x, half, stack);
