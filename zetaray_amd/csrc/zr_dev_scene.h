@@ -210,12 +210,14 @@ struct StackEntry { uint32_t child; float t; };
 // `aux` (device, ZR_STEAL): this wave's work-stealing region in LDS -- 64 x u64 merge keys, 64 x (t, u, v) payloads, 64 x u32 donor lanes
 // `cache` (device, -DZR_NODE_CACHE=N): the first N nodes of the tree -- its top levels, nodes are numbered breadth-first -- copied into LDS by the
 // block (north_star's "LDS-staged node cache"); measured, DESIGN 5.7
-// Measured (MI355X, 1080p, N = 64 = 4 KB per block; scripts/gpu_r03_k11.sh with a -DZR_NODE_CACHE=64 build of every kernel): K11 on the 380k-triangle
+// Measured (MI355X, 1080p, N = 64 = 4 KB per block, later 32; scripts/gpu_r03_k11.sh with a -DZR_NODE_CACHE=64 build of every kernel): K11 on the 380k-triangle
 // atrium 8.37 -> 7.63 ms; the reconnect kernels get slower with it (K14 3.30 -> 3.43 ms, Cornell 0.508 -> 0.538 ms: their traversals are a quarter
 // of the kernel and the fill + the extra branch cost more than the top-level hits save); Cornell's tree has fewer than N nodes.  So only the
 // large-scene K11 (k_rpt_pathtrace_w4) fills it; kernels that do not fill keep cache == nullptr, a compile-time constant that folds the branch away.
+// (size: 32 nodes = the top three levels measure like 64 -- 7.64 / 7.62 ms; 128 nodes cost K11 occupancy through LDS: 10.2 ms; one 256-node cache
+// per 256-thread block: 7.94 ms)
 #ifndef ZR_NODE_CACHE
-#define ZR_NODE_CACHE 64
+#define ZR_NODE_CACHE 32
 #endif
 struct alignas(16) NodeQuad { uint32_t x, y, z, w; };
 struct TravStack { ZR_LDS_AS StackEntry* lds; uint32_t stride; ZR_PRIVATE_AS StackEntry* mem; uint32_t* aux = nullptr; const ZR_LDS_AS NodeQuad* cache = nullptr; };

@@ -187,7 +187,7 @@ __device__ __forceinline__ void RptPathtraceBody(rpt::RptFrame& F, const zr_fram
     const uint32_t tx = tile % tilesX, ty = tile / tilesX;
     const uint32_t x = F.ox0 + tx * 16u + (lane & 15u), y = F.oy0 + ty * 16u + wave * 4u + (lane >> 4);
     ZR_TRAV_STACK_B(stack, kRptBlock);
-    if (NODE_CACHE) { ZR_NODE_CACHE_FILL(stack, F.sc, kRptBlock); }      // the tree's top 64 nodes in LDS (large scenes: 8.37 -> 7.63 ms on the atrium)
+    if (NODE_CACHE) { ZR_NODE_CACHE_FILL(stack, F.sc, kRptBlock); }      // the tree's top ZR_NODE_CACHE nodes in LDS (large scenes: 8.37 -> 7.63 ms on the atrium)
     ZR_PROF_KERNEL(F.sc, 1);
     uint32_t cnt[2] = {0u, 0u};
     rpt::PTLane P;
