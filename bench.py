@@ -45,6 +45,12 @@ RPT_PIXEL_BYTES = {
 }
 
 
+# the denoise pass (zr_svgf.h), algorithmic bytes per pixel and launch: temporal = signal 16 + depth / normal / motion 12 + previous depth / normal 8 +
+# history colour 16 + moments 8 in, accumulated 16 + moments 8 + guide 16 out; variance = 16 + 8 + 16 in, 16 out; one a-trous iteration = colour 16
+# + guide 16 in, 16 out (the 24 neighbour taps are re-reads of what other pixels load once: cache hits in the model)
+DENOISE_PIXEL_BYTES = {"denoise_temporal": 60 + 40, "denoise_variance": 40 + 16, "denoise_atrous": 32 + 16}
+
+
 from zetaray_amd.tiling import tile_grid, tile_rect  # noqa: E402  (shared with the tests and the tiled renderer)
 
 _CORNELL_SKY = os.path.join(ROOT, "tests", "golden", "cornell.npz")
@@ -55,6 +61,8 @@ CONFIGS = {
     "3": ("config 3: Cornell (emissive) 1080p ReSTIR GI, 3 bounces, temporal reuse", dict(integrator="restir_gi")),
     "4": ("config 4 on one GPU: 380k-triangle / 100k-light atrium 1080p ReSTIR PT", dict(scene="synthetic", steps=32, warmup=8)),
     "4k": ("config 5 without the denoise pass: the atrium at 3840x2160 ReSTIR PT", dict(scene="synthetic", width=3840, height=2160, steps=16, warmup=4)),
+    "5": ("config 5 on one GPU: the atrium at 3840x2160, ReSTIR PT + the denoise pass (spatiotemporal variance-guided filter, 5 a-trous iterations)",
+          dict(scene="synthetic", width=3840, height=2160, steps=16, warmup=4, denoise=True)),
     "pt": ("K9 unidirectional path tracer on the Cornell box (config 1's integrator at 1080p)", dict(integrator="pt")),
 }
 
@@ -171,6 +179,7 @@ def main():
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--denoise", action="store_true", help="add the denoise pass (ZR_PASS_DENOISE) on the indirect image (one GPU)")
     ap.add_argument("--scene", default=os.path.join(ROOT, "tests", "golden", "cornell_emissive.npz"),
                     help="wire-format .npz, or 'synthetic' = the procedural Sponza-class scene of BASELINE config 4 "
                          "(262144 triangles + 100000 emissive triangles, presampled light sets on)")
@@ -209,10 +218,19 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if os.environ.get("ZR_BENCH_SHARED_GPU") == "1":
+            # test rig for a box with one GPU (tests/test_gpu_parity.py): every rank renders on device 0, the ranks talk over gloo and the halo
+            # strips go through the host -- the orchestration (probe frames, cost-balanced re-tiling, timing protocol) is the multi-GPU one
+            local_rank = 0
+            os.environ["ZR_HALO_TRANSPORT"] = "torch_p2p"
+            torch.cuda.set_device(0)
+            dist.init_process_group("gloo")
+        else:
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     torch.cuda.set_device(local_rank)
+    cdev = "cpu" if (dist is not None and dist.get_backend() == "gloo") else "cuda"      # where the few scalars of the timing protocol are reduced
 
     W, H = args.width, args.height
     cam = {}
@@ -254,7 +272,7 @@ def main():
                 cbp = scene_io.make_frame_constants(W, H, frame_num=1 + i, num_emissives=len(sc.emissives), **cam)
                 tiled.render_frame(cbp, exchange_final=not args.no_final_halo)
             torch.cuda.synchronize()
-            cost = torch.tensor(tiled.owned_cost_cells(), dtype=torch.float64, device="cuda")
+            cost = torch.tensor(tiled.owned_cost_cells(), dtype=torch.float64, device=cdev)
             dist.all_reduce(cost, op=dist.ReduceOp.SUM)
             layout = tiling.choose_layout(W, H, world, cost.cpu().numpy())
             r.p_indirect.enable_cost_map(False)
@@ -284,6 +302,10 @@ def main():
         assert world == 1 and not rpt and (args.direct or args.sky_direct), "--di-only needs --integrator pt and a DI pass"
         r.skip_indirect = True
     di_passes = [q for q in (r.p_direct, r.p_sky_direct) if q is not None]
+    p_denoise = None
+    if args.denoise:
+        assert world == 1 and not args.di_only, "--denoise: one GPU (the a-trous stencil reaches 62 px, beyond the tiles' 32-px apron), on an indirect integrator"
+        p_denoise = r.enable_denoise()
 
     def frame(i):
         cb = scene_io.make_frame_constants(W, H, frame_num=i, num_emissives=len(sc.emissives), **cam)
@@ -291,6 +313,9 @@ def main():
             scene_io.set_texture_heap_offsets(cb, tex_offsets)
         if tiled is not None:
             tiled.render_frame(cb, exchange_final=not args.no_final_halo)
+            if p_denoise is not None:      # (Renderer.render_frame runs it itself)
+                p_denoise.set_input(api.IN_DENOISE_SIGNAL, r.p_indirect.output_ptr()[0])
+                p_denoise.render(cb, r.scene, r.gbuffer)
         else:
             r.render_frame(cb)
 
@@ -332,13 +357,13 @@ def main():
     rays = np.array([c1[0] - apron_rays + c2[0] + c3[0], c1[1] + c2[1] + c3[1]], np.float64)
     tmax = dt
     if dist is not None:
-        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        tt = torch.tensor([dt], dtype=torch.float64, device=cdev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         tmax = float(tt.item())
-        rr = torch.tensor(rays, dtype=torch.float64, device="cuda")
+        rr = torch.tensor(rays, dtype=torch.float64, device=cdev)
         dist.all_reduce(rr, op=dist.ReduceOp.SUM)
         rays = rr.cpu().numpy()
-        ar = torch.tensor([float(apron_rays)], dtype=torch.float64, device="cuda")
+        ar = torch.tensor([float(apron_rays)], dtype=torch.float64, device=cdev)
         dist.all_reduce(ar, op=dist.ReduceOp.SUM)
         apron_rays = float(ar.item())
     n_closest, n_shadow = float(rays[0]), float(rays[1])
@@ -355,7 +380,8 @@ def main():
                                 f"initial candidates, temporal + pairwise-MIS spatial reuse, static camera)") if args.di_only else
                                (f"{scene_name} {W}x{H}, G-buffer + ReSTIR PT "
                                 f"(K1 + K11-K16: initial candidates, temporal + spatial reconnection reuse, boiling "
-                                f"suppression; 3 non-transmissive / 4 glossy-transmissive bounces, static camera)") if rpt else
+                                f"suppression; 3 non-transmissive / 4 glossy-transmissive bounces, static camera)"
+                                + (" + denoise pass (temporal accumulation, variance estimate, 5 a-trous iterations)" if args.denoise else "")) if rpt else
                                (f"{scene_name} {W}x{H}, G-buffer + ReSTIR GI (K1+K10, "
                                 f"3 bounces, temporal reuse, static camera)") if args.integrator == "restir_gi" else
                                (f"{scene_name} {W}x{H}, G-buffer + 1-spp "
@@ -372,6 +398,11 @@ def main():
                    "fps": round(1e3 / ms_per_step, 2)},
     }
 
+    if os.environ.get("ZR_K11") == "trip" and rpt and world == 1:
+        # diagnostic build of K11: path state stored + reloaded at every bounce boundary
+        a, b, wds = r.p_indirect.debug_trip_stats()
+        out["config"]["k11_state_round_trip"] = {"alive_lanes_at_bounce_boundaries": a, "lane_slots": b, "alive_frac": round(a / max(b, 1), 4),
+                                                 "state_bytes_per_path": 4 * wds}
     if rank == 0 and world == 1:
         # ---- roofline of the dominant kernel: hipEvent timing inside the library over a few timed frames
         r.p_gbuffer.enable_timing(True)
@@ -380,6 +411,8 @@ def main():
             r.p_sky.enable_timing(True)
         for q in di_passes:
             q.enable_timing(True)
+        if p_denoise is not None:
+            p_denoise.enable_timing(True)
         agg = {}
         nfr = 8
         r.p_indirect.read_counters(reset=True)
@@ -389,7 +422,7 @@ def main():
             frame(1000 + i)
             torch.cuda.synchronize()
             tm = {**r.p_gbuffer.timings(), **({} if args.di_only else r.p_indirect.timings())}
-            for q in di_passes + ([r.p_sky] if r.p_sky is not None else []):
+            for q in di_passes + ([r.p_sky] if r.p_sky is not None else []) + ([p_denoise] if p_denoise is not None else []):
                 tm.update(q.timings())
             for name, (ms, launches) in tm.items():
                 a = agg.setdefault(name, [0.0, 0])
@@ -437,6 +470,8 @@ def main():
             bytes_launch = (BYTES_CLOSEST * kcc + BYTES_SHADOW * kcs) / launches + (27 * 3 + 2 * 13 + 32) * W * H
         elif dom == "gbuffer":
             bytes_launch = (BYTES_CLOSEST + 47) * W * H
+        elif dom.startswith("denoise_"):
+            bytes_launch = DENOISE_PIXEL_BYTES[dom] * W * H
         else:
             bytes_launch = 0.0
         achieved = bytes_launch / (avg_ms * 1e-3) / 1e9

@@ -82,7 +82,15 @@ typedef enum zr_pass_kind {
        cb.render_width x render_height texels.  zr_params.display_*; ZR_IN_DISPLAY_EXPOSURE = ZR_OUT_EXPOSURE of the auto-exposure pass;
        the NEUTRAL tone mapper needs zr_pass_set_tonemap_lut.  Outputs ZR_OUT_DISPLAY (the pixel shader's float4) and
        ZR_OUT_DISPLAY_SRGB8 (what the reference's R8G8B8A8_UNORM_SRGB back buffer stores). */
-    ZR_PASS_DISPLAY     = 9
+    ZR_PASS_DISPLAY     = 9,
+    /* Denoise: a spatiotemporal variance-guided filter (after Schied et al. 2017) over a noisy radiance image -- temporal accumulation of colour and
+       luminance moments along the G-buffer's motion vectors, a variance estimate, zr_params.svgf_iterations a-trous iterations with depth / normal /
+       luminance edge stopping.  NO REFERENCE COUNTERPART (the reference presents ReSTIR PT through TAA / FSR2): the pass exists for BASELINE.json's
+       config 5 ("ReSTIR PT + SVGF denoise tile pass" at 3840 x 2160) and its arithmetic is defined by this library (zetaray_amd/csrc/zr_svgf.h;
+       restated in oracle/zro_svgf.h).  Input: an RGBA32F image bound with zr_pass_set_input(ZR_IN_DENOISE_SIGNAL) -- e.g. the INDIRECT pass's
+       FINAL -- plus the depth / normal / motion planes of the gbuffer passed to zr_pass_render and the same gbuffer's previous-frame planes.
+       Output ZR_OUT_DENOISED; zr_pass_reset_temporal drops the history. */
+    ZR_PASS_DENOISE     = 10
 } zr_pass_kind;
 
 /* IndirectLighting::INTEGRATOR, reference IndirectLighting.h:40-46 */
@@ -140,6 +148,13 @@ typedef struct zr_params {
     /* ZR_PASS_INDIRECT: enum class TEXTURE_FILTER (IndirectLighting_Common.h:69-77), the sampler of the material maps at path vertices
        (cb_ReSTIR_*::TexFilterDescHeapIdx): ZR_TEX_FILTER_MIP0 / TRI_LINEAR / ANISOTROPIC_2X / ANISOTROPIC_4X / ANISOTROPIC_16X (zr_texture.h) */
     uint32_t tex_filter;            /* ZR_TEX_FILTER_ANISOTROPIC_4X = 3 */
+    /* ZR_PASS_DENOISE (no reference counterpart; zr_svgf.h) */
+    float    svgf_alpha;            /* 0.2: floor of the colour blend factor (1 / history length above it) */
+    float    svgf_alpha_moments;    /* 0.2: the same for the luminance moments */
+    float    svgf_sigma_l;          /* 4.0: luminance edge-stopping, in standard deviations */
+    float    svgf_sigma_z;          /* 1.0: depth edge-stopping, in units of the pixel's screen-space depth slope */
+    uint32_t svgf_normal_power_log2;/* 7: normal weight = max(0, n . n_q) ^ (2 ^ 7) */
+    uint32_t svgf_iterations;       /* 5 a-trous iterations (steps 1, 2, 4, 8, 16); 0..8 */
 } zr_params;
 
 /* enum class Tonemapper, Display_Common.h:21-30 */
@@ -194,7 +209,11 @@ typedef enum zr_output {
     ZR_OUT_AE_HISTOGRAM    = 43,   /* R32_UINT, 256 x 1: the last frame's histogram (bin 0 = luminance <= 1e-4) */
     /* Display (ZR_PASS_DISPLAY) */
     ZR_OUT_DISPLAY         = 44,   /* RGBA32F 16 B: mainPS's return value (linear, before the back buffer's sRGB encode) */
-    ZR_OUT_DISPLAY_SRGB8   = 45    /* RGBA8 4 B: sRGB-encoded, as the reference's R8G8B8A8_UNORM_SRGB back buffer stores it */
+    ZR_OUT_DISPLAY_SRGB8   = 45,   /* RGBA8 4 B: sRGB-encoded, as the reference's R8G8B8A8_UNORM_SRGB back buffer stores it */
+    /* Denoise (ZR_PASS_DENOISE) */
+    ZR_OUT_DENOISED        = 46,   /* RGBA32F 16 B: filtered radiance, a = its variance estimate */
+    ZR_OUT_DENOISE_HISTORY = 47,   /* RGBA32F 16 B: colour history the next frame accumulates into (rgb after the first a-trous iteration), a = history length */
+    ZR_OUT_DENOISE_MOMENTS = 48    /* RG32F    8 B: accumulated first / second luminance moments */
 } zr_output;
 
 /* G-buffer planes (reference GBufferData::GBUFFER order and DXGI formats, DefaultRendererImpl.h:82-109) */
@@ -362,6 +381,7 @@ int zr_pass_download_output(const zr_pass* pass, int which, void* hip_stream, vo
 #define ZR_IN_POST_SIGNAL_F16  4
 #define ZR_IN_POST_SIGNAL_F32  5
 #define ZR_IN_DISPLAY_EXPOSURE 6   /* ZR_PASS_DISPLAY: RG32F 1 x 1 (ZR_OUT_EXPOSURE) */
+#define ZR_IN_DENOISE_SIGNAL   7   /* ZR_PASS_DENOISE: the RGBA32F image to filter */
 int zr_pass_set_input(zr_pass* pass, int which, const void* dev_plane);
 /* ZR_PASS_DISPLAY: the Tony McMapface LUT of the NEUTRAL tone mapper, dim^3 R9G9B9E5_SHAREDEXP texels on the host (the payload of
    Assets/LUT/tony_mc_mapface.dds, 48^3; shipped as zetaray_amd/assets/tony_mc_mapface_rgb9e5.bin).  Display.cpp:196-205. */
@@ -373,6 +393,10 @@ int zr_pass_read_counters(zr_pass* pass, void* hip_stream, zr_counters* out, int
  * reference counterpart (the reference renders on one GPU).  Costs one atomic per wave while enabled. */
 int zr_pass_enable_cost_map(zr_pass* pass, int enable);
 int zr_pass_read_cost_map(zr_pass* pass, void* hip_stream, uint32_t* out_cells, uint32_t cells_w, uint32_t cells_h, int reset);
+/* diagnostic, ReSTIR PT with ZR_K11=trip in the environment: K11 stores and reloads each live path's state through SoA planes at every bounce
+ * boundary -- the traffic a per-bounce relaunch with path compaction would have to move.  out = {lanes alive at the boundaries, lane slots of the waves
+ * that passed them, 32-bit words per path state}.  Waits for the device.  No reference counterpart. */
+int zr_pass_debug_trip_stats(zr_pass* pass, uint64_t out[3]);
 /* the same counters split by the kernel that issued the queries (not reset; roofline bookkeeping of bench.py) */
 int zr_pass_read_kernel_counters(zr_pass* pass, void* hip_stream, uint32_t max_entries, const char** names,
                                  uint64_t* n_closest, uint64_t* n_shadow, uint32_t* count);

@@ -473,6 +473,28 @@ def display(image, params, display_size, exposure2=None, lut=None):
     return out, srgb
 
 
+SVGF_DEFAULTS = dict(alpha=0.2, alpha_moments=0.2, sigma_l=4.0, sigma_z=1.0, normal_power_log2=7, iterations=5)
+
+
+def svgf(signal_rgba, depth, normal, motion, prev_depth, prev_normal, hist_color, hist_moments, temporal_valid=True, **kw):
+    """the denoise pass (zro_svgf.h; no reference counterpart) on one frame: signal (h, w, 4) f32, depth (h, w) f32, normal / motion (h, w) u32 (G-buffer
+    planes), the previous frame's depth / normal, history colour (h, w, 4) f32 (rgb + length) and moments (h, w, 2) f32.
+    Returns (out (h, w, 4) rgb + variance, new history colour, new history moments)."""
+    prm = dict(SVGF_DEFAULTS, **kw)
+    sig = np.ascontiguousarray(signal_rgba, np.float32)
+    h, w = sig.shape[:2]
+    d = np.ascontiguousarray(depth, np.float32); n = np.ascontiguousarray(normal, np.uint32); m = np.ascontiguousarray(motion, np.uint32)
+    pd = np.ascontiguousarray(prev_depth, np.float32); pn = np.ascontiguousarray(prev_normal, np.uint32)
+    hc = np.array(hist_color, np.float32, copy=True).reshape(h, w, 4); hm = np.array(hist_moments, np.float32, copy=True).reshape(h, w, 2)
+    out = np.zeros((h, w, 4), np.float32)
+    p4 = np.array([prm["alpha"], prm["alpha_moments"], prm["sigma_l"], prm["sigma_z"]], np.float32)
+    f = lib().zro_svgf
+    f.argtypes = [C.c_void_p] * 8 + [C.c_int, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p]
+    f(sig.ctypes.data, d.ctypes.data, n.ctypes.data, m.ctypes.data, pd.ctypes.data, pn.ctypes.data, hc.ctypes.data, hm.ctypes.data,
+      int(bool(temporal_valid)), p4.ctypes.data, int(prm["normal_power_log2"]), int(prm["iterations"]), w, h, out.ctypes.data)
+    return out, hc, hm
+
+
 def taa(signal_rgba, depth, motion, prev_out, blend_weight=0.1, temporal_valid=True):
     """TAA.hlsl on an RGBA32F signal (h, w, 4), depth (h, w) f32, motion (h, w) u32 (R16G16_SNORM), history (h, w, 4) f16 bits (u16);
     returns the new RGBA16F output as u16 (alpha = the history buffer's, untouched)."""

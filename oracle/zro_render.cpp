@@ -770,6 +770,7 @@ static void RenderPathTracer(const Scene& sc, const zr_frame_constants& g, GBVie
 #include "zro_sdi.h"
 #include "zro_kat.h"
 #include "zro_post.h"
+#include "zro_svgf.h"
 
 //--------------------------------------------------------------------------------------
 // C entry points (ctypes)
@@ -980,6 +981,17 @@ int zro_pathtrace_render(const zro_scene* h, const zr_frame_constants* cb, const
 int zro_taa(const float* signal_rgba, const float* depth, const uint32_t* motion, const uint16_t* prev_out, uint16_t* curr_out,
     uint32_t w, uint32_t h, float blend_weight, int temporal_valid)
 { TAA::Render(signal_rgba, depth, motion, prev_out, curr_out, (int)w, (int)h, blend_weight, temporal_valid != 0); return 0; }
+
+// Denoise pass (zro_svgf.h; no reference counterpart): one frame.  hist_color (RGBA32F: rgb + history length) / hist_moments (2 floats per pixel)
+// hold the previous frame's history on entry and this frame's on return; out = RGBA32F (rgb + variance).  params = {alpha, alpha_moments,
+// sigma_l, sigma_z}, normal_power_log2, iterations
+int zro_svgf(const float* signal_rgba, const float* depth, const uint32_t* normal, const uint32_t* motion, const float* prev_depth, const uint32_t* prev_normal,
+    float* hist_color, float* hist_moments, int temporal_valid, const float* params4, uint32_t normal_power_log2, uint32_t iterations, uint32_t w, uint32_t h, float* out)
+{
+    SVGF::Params prm = {params4[0], params4[1], params4[2], params4[3], normal_power_log2, iterations};
+    SVGF::Frame(signal_rgba, depth, normal, motion, prev_depth, prev_normal, hist_color, hist_moments, temporal_valid != 0, prm, (int)w, (int)h, out);
+    return 0;
+}
 
 // AutoExposure (zro_post.h): histogram of an RGBA16F (is_f16) or RGBA32F image, then the 256-thread weighted average; exposure2 = the
 // persistent (exposure, adapted luminance) texel, read and written

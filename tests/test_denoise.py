@@ -1,0 +1,195 @@
+"""The denoise pass (ZR_PASS_DENOISE; spatiotemporal variance-guided filter, BASELINE config 5).  NO REFERENCE COUNTERPART: the pass is defined by
+the specification in zetaray_amd/csrc/zr_svgf.h, the oracle (oracle/zro_svgf.h) restates it independently -- parity is "unpinned" by construction.
+
+CPU: properties of the oracle that the specification implies (what a filter of this kind must do).  GPU: the HIP pass == the oracle, bit for bit,
+on rendered frames (ReSTIR PT, moving camera, history reset) and on synthetic planes with depth / normal edges and misses."""
+import os
+
+import numpy as np
+import pytest
+
+from zetaray_amd import scene_io, wire
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+FLT_MAX = np.float32(3.4028234663852886e38)
+
+
+def _oct32(n):
+    """oct32 bits of unit normals (h, w, 3), by the oracle's own encoder convention: (x, y) of the octahedral map as two unorm16"""
+    n = n / np.abs(n).sum(-1, keepdims=True)
+    x, y = n[..., 0].copy(), n[..., 1].copy()
+    neg = n[..., 2] < 0
+    ox = (1 - np.abs(y)) * np.where(x >= 0, 1.0, -1.0)
+    oy = (1 - np.abs(x)) * np.where(y >= 0, 1.0, -1.0)
+    x[neg], y[neg] = ox[neg], oy[neg]
+    u = np.clip(np.round((x * 0.5 + 0.5) * 65535.0), 0, 65535).astype(np.uint32)
+    v = np.clip(np.round((y * 0.5 + 0.5) * 65535.0), 0, 65535).astype(np.uint32)
+    return u | (v << 16)
+
+
+def _planes(h, w, rng, split=True, miss=True):
+    """a synthetic G-buffer: two planes at different depths / orientations meeting at a vertical edge, a tilted floor, a block of misses"""
+    yy, xx = np.mgrid[0:h, 0:w].astype(np.float32)
+    depth = (4.0 + 0.01 * xx + 0.02 * yy).astype(np.float32)
+    nrm = np.zeros((h, w, 3), np.float32)
+    nrm[...] = (0.0, 0.0, -1.0)
+    if split:
+        right = xx >= w // 2
+        depth[right] = (7.0 + 0.015 * yy[right]).astype(np.float32)
+        nrm[right] = (-0.6, 0.0, -0.8)
+    if miss:
+        depth[: h // 5, : w // 4] = FLT_MAX
+    return depth, _oct32(nrm)
+
+
+def test_oracle_constant_image_is_a_fixed_point():
+    from oracle import zro
+    h, w = 24, 40
+    rng = np.random.default_rng(1)
+    depth, normal = _planes(h, w, rng)
+    sig = np.zeros((h, w, 4), np.float32)
+    sig[..., :3] = (0.25, 0.5, 0.125)
+    motion = np.zeros((h, w), np.uint32)
+    hc, hm = np.zeros((h, w, 4), np.float32), np.zeros((h, w, 2), np.float32)
+    for f in range(3):
+        out, hc, hm = zro.svgf(sig, depth, normal, motion, depth, normal, hc, hm, temporal_valid=f > 0)
+        assert np.allclose(out[..., :3], sig[..., :3], rtol=0, atol=2e-7), f
+        assert np.all(out[..., 3] <= 1e-9)
+        valid = depth != FLT_MAX
+        assert np.all(hc[..., 3][valid] == f + 1) and np.all(hc[..., 3][~valid] == 1)
+
+
+def test_oracle_reduces_noise_and_keeps_edges():
+    from oracle import zro
+    h, w = 48, 64
+    rng = np.random.default_rng(2)
+    depth, normal = _planes(h, w, rng, miss=False)
+    left = np.arange(w)[None, :] < w // 2
+    mean = np.where(left[..., None], np.float32(1.0), np.float32(0.1)) * np.ones((h, w, 3), np.float32)
+    motion = np.zeros((h, w), np.uint32)
+    hc, hm = np.zeros((h, w, 4), np.float32), np.zeros((h, w, 2), np.float32)
+    errs = []
+    for f in range(6):
+        sig = np.zeros((h, w, 4), np.float32)
+        sig[..., :3] = mean * rng.uniform(0.0, 2.0, (h, w, 1)).astype(np.float32)
+        out, hc, hm = zro.svgf(sig, depth, normal, motion, depth, normal, hc, hm, temporal_valid=f > 0)
+        errs.append((float(np.abs(sig[..., :3] - mean).mean()), float(np.abs(out[..., :3] - mean).mean())))
+    # the filtered image is much closer to the mean than the input, more so as history accumulates
+    assert errs[0][1] < 0.35 * errs[0][0] and errs[-1][1] < 0.12 * errs[-1][0], errs
+    # nothing crosses the geometric edge: both sides stay inside their own input range (left [0, 2], right [0, 0.2])
+    assert out[:, w // 2:, :3].max() <= 0.2 + 1e-6 and out[:, : w // 2, :3].min() >= 0.0
+    assert np.abs(out[:, w // 2 + 2:, 0].mean() - 0.1) < 0.02 and np.abs(out[:, : w // 2 - 2, 0].mean() - 1.0) < 0.2
+    # the variance estimate shrinks with every a-trous iteration
+    v = [zro.svgf(sig, depth, normal, motion, depth, normal, np.zeros_like(hc), np.zeros_like(hm), temporal_valid=False, iterations=k)[0][..., 3].mean() for k in (0, 1, 3, 5)]
+    assert v[0] > v[1] > v[2] > v[3] > 0, v
+
+
+def test_oracle_history_follows_motion_and_rejects_disocclusion():
+    from oracle import zro
+    h, w = 32, 48
+    rng = np.random.default_rng(3)
+    depth, normal = _planes(h, w, rng, split=False, miss=False)
+    base = rng.uniform(0.2, 1.0, (h, w, 3)).astype(np.float32)
+    sig = np.zeros((h, w, 4), np.float32)
+    sig[..., :3] = base
+    zero = np.zeros((h, w), np.uint32)
+    hc, hm = np.zeros((h, w, 4), np.float32), np.zeros((h, w, 2), np.float32)
+    _, hc, hm = zro.svgf(sig, depth, normal, zero, depth, normal, hc, hm, temporal_valid=False, iterations=0)
+    # the image moved 2 px to the right: motion = currUV - prevUV = +2 / w in x (R16G16_SNORM), history found at x - 2
+    mv = np.uint32(int(round(2.0 / w * 32767.0)) & 0xffff)
+    motion = np.full((h, w), mv, np.uint32)
+    sig2 = np.zeros_like(sig)
+    sig2[:, 2:, :3] = base[:, :-2]
+    sig2[:, :2, :3] = base[:, :2]
+    depth2 = depth.copy()
+    depth2[:, 2:] = depth[:, :-2]
+    _, hc2, _ = zro.svgf(sig2, depth2, normal, motion, depth, normal, hc, hm, temporal_valid=True, iterations=0)
+    assert np.all(hc2[:, 3:-1, 3] == 2.0)            # history followed the motion vector
+    assert np.all(hc2[:, 0, 3] == 1.0)               # reprojected from outside the image: no history
+    # a depth jump of more than 10 % is a disocclusion
+    _, hc3, _ = zro.svgf(sig, depth * np.float32(1.5), normal, zero, depth, normal, hc, hm, temporal_valid=True, iterations=0)
+    assert np.all(hc3[..., 3] == 1.0)
+    # misses pass through untouched and never enter a neighbour's sum
+    d4 = depth.copy()
+    d4[10:14, 10:14] = FLT_MAX
+    s4 = sig.copy()
+    s4[10:14, 10:14, :3] = 1000.0
+    out4, _, _ = zro.svgf(s4, d4, normal, zero, d4, normal, np.zeros_like(hc), np.zeros_like(hm), temporal_valid=False)
+    assert np.all(out4[10:14, 10:14, :3] == 1000.0) and out4[..., :3][d4 != FLT_MAX].max() <= 1.0 + 1e-6
+
+
+@pytest.mark.gpu
+def test_denoise_pass_matches_oracle_on_rendered_frames(api, cornell_emissive):
+    """ReSTIR PT on the Cornell box, moving camera, 6 frames with a history reset: the pass's output, colour history and moments == the oracle's
+    on the same signal and G-buffer planes, every frame, tolerance 0."""
+    from oracle import zro
+    w, h = 200, 120
+    r = api.Renderer(cornell_emissive, w, h, params=wire.default_params(), integrator=api.INTEGRATOR_RESTIR_PT)
+    dn = r.enable_denoise()
+    hc, hm = np.zeros((h, w, 4), np.float32), np.zeros((h, w, 2), np.float32)
+    prev, prev_planes = None, None
+    for f in range(1, 7):
+        cb = scene_io.make_frame_constants(w, h, frame_num=f, num_emissives=len(cornell_emissive.emissives), cam_pos=(0.04 * max(0, f - 2), 1.2, -4.043))
+        if prev is not None:
+            cb["prev_view"], cb["prev_view_inv"] = prev["curr_view"], prev["curr_view_inv"]
+        prev = cb.copy()
+        if f == 5:
+            dn.reset_temporal()
+        r.render_frame(cb)
+        signal = r.p_indirect.download()
+        planes, _ = r.gbuffer.download()
+        depth, normal, motion = planes[7].reshape(h, w), planes[1].reshape(h, w), planes[3].reshape(h, w)
+        pd, pn = (depth, normal) if prev_planes is None else prev_planes
+        want, hc, hm = zro.svgf(signal, depth, normal, motion, pd, pn, hc, hm, temporal_valid=f not in (1, 5))
+        prev_planes = (depth.copy(), normal.copy())
+        got = dn.download_plane("denoised")
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), f"frame {f}: {int((got.view(np.uint32) != want.view(np.uint32)).any(-1).sum())} pixels differ"
+        assert np.array_equal(dn.download_plane("denoise_history").view(np.uint32), hc.view(np.uint32)), f"frame {f}: history"
+        assert np.array_equal(dn.download_plane("denoise_moments").view(np.uint32), hm.view(np.uint32)), f"frame {f}: moments"
+    hit = depth != FLT_MAX
+    noisy = signal[..., :3][hit]
+    assert got[..., :3][hit].std() < noisy.std() and got[..., 3].max() > 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("iterations", [0, 1, 5, 8])
+def test_denoise_pass_iteration_counts(api, cornell_emissive, iterations):
+    from oracle import zro
+    w, h = 96, 64
+    prm = wire.default_params()
+    prm.svgf_iterations = iterations
+    prm.svgf_sigma_l, prm.svgf_normal_power_log2, prm.svgf_alpha = 2.0, 5, 0.1
+    r = api.Renderer(cornell_emissive, w, h, params=wire.default_params(), integrator=api.INTEGRATOR_RESTIR_PT)
+    dn = r.enable_denoise(prm)
+    hc, hm = np.zeros((h, w, 4), np.float32), np.zeros((h, w, 2), np.float32)
+    prev_planes = None
+    for f in range(1, 4):
+        cb = scene_io.make_frame_constants(w, h, frame_num=f, num_emissives=len(cornell_emissive.emissives))
+        r.render_frame(cb)
+        planes, _ = r.gbuffer.download()
+        depth, normal, motion = planes[7].reshape(h, w), planes[1].reshape(h, w), planes[3].reshape(h, w)
+        pd, pn = (depth, normal) if prev_planes is None else prev_planes
+        want, hc, hm = zro.svgf(r.p_indirect.download(), depth, normal, motion, pd, pn, hc, hm, temporal_valid=f > 1, iterations=iterations, sigma_l=2.0,
+                                normal_power_log2=5, alpha=0.1)
+        prev_planes = (depth.copy(), normal.copy())
+        assert np.array_equal(dn.download_plane("denoised").view(np.uint32), want.view(np.uint32)), f"frame {f}"
+        assert np.array_equal(dn.download_plane("denoise_history").view(np.uint32), hc.view(np.uint32)), f"frame {f}: history"
+
+
+@pytest.mark.gpu
+def test_denoise_pass_at_3840x2160_is_deterministic_and_smooths(api, cornell_emissive):
+    """BASELINE config 5's resolution: two independent renderers produce the same bits; the filtered image has a fraction of the input's
+    pixel-to-pixel variation inside surfaces."""
+    w, h = 3840, 2160
+    outs = []
+    for k in range(2):
+        r = api.Renderer(cornell_emissive, w, h, params=wire.default_params(), integrator=api.INTEGRATOR_RESTIR_PT)
+        dn = r.enable_denoise()
+        for f in range(1, 4):
+            r.render_frame(scene_io.make_frame_constants(w, h, frame_num=f, num_emissives=len(cornell_emissive.emissives)))
+        outs.append((dn.download_plane("denoised"), r.p_indirect.download()))
+        r.close() if hasattr(r, "close") else None
+    assert np.array_equal(outs[0][0].view(np.uint32), outs[1][0].view(np.uint32))
+    got, sig = outs[0]
+    inner = (slice(900, 1200), slice(1700, 2100))
+    assert np.abs(np.diff(got[inner][..., 1], axis=1)).mean() < 0.2 * np.abs(np.diff(sig[inner][..., 1], axis=1)).mean()

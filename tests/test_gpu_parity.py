@@ -1437,3 +1437,35 @@ def test_material_edit_between_frames(api):
         assert np.array_equal(di.download().view(np.uint32), want_di.view(np.uint32)), f"frame {f}: ReSTIR DI"
         imgs.append(planes[0].copy())
     assert not np.array_equal(np.asarray(imgs[1]), np.asarray(imgs[2]))      # the base-colour plane changed with the edit
+
+
+def test_bench_multi_rank_protocol_on_one_gpu():
+    """`bench.py --gpus 2` and `--gpus 4` end to end on a box with ONE GPU: the ranks are real processes launched by torch.distributed.run exactly as the
+    driver launches them, but share device 0 and talk over gloo (ZR_BENCH_SHARED_GPU=1, halo strips staged through the host).  What runs is the
+    multi-GPU orchestration -- tile split, halo plan, probe frames with the cost map, choose_layout + re-tiling, barrier / max-over-ranks timing,
+    whole-job ray count -- everything except RCCL itself (exercised by test_fused_halo_transfer_and_rccl_exchange_on_one_gpu)."""
+    import json
+    import subprocess
+    import sys
+    env = dict(os.environ, ZR_BENCH_SHARED_GPU="1", MASTER_ADDR="127.0.0.1")
+    singles = []
+    for n, port, settle in ((1, 0, 4), (1, 0, 16), (2, 29631, 4), (4, 29632, 4)):
+        cmd = [sys.executable, os.path.join(ROOT, "bench.py")] if n == 1 else \
+            [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1", "--master-port", str(port),
+             os.path.join(ROOT, "bench.py")]
+        cmd += ["--gpus", str(n), "--steps", "4", "--warmup", "2", "--settle", str(settle), "--width", "512", "--height", "288", "--no-cpu-baseline"]
+        res = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
+        assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
+        lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
+        assert len(lines) == 1, res.stdout[-2000:]
+        d = json.loads(lines[0])
+        assert d["n_gpus"] == n and d["steps"] == 4 and d["value"] > 0 and d["scaling"] == "strong"
+        if n == 1:
+            singles.append(d["config"]["rays_per_frame"])
+            continue
+        assert "screen tiles" in d["config"]["parallelism"] and ("cost-balanced" in d["config"]["parallelism"] or "equal-area" in d["config"]["parallelism"])
+        # The same frames are traced whatever the split, so the whole-job ray count per frame is the single-device one with equally aged
+        # reservoirs: 4 settle frames when the probe's cost map made the ranks re-tile (fresh passes), 12 probe + 4 settle frames when they kept
+        # the grid.  (Equal frame numbers give bit-identical frames, hence equal counts; the probe frames shift the numbering in the second case.)
+        rel = min(abs(d["config"]["rays_per_frame"] / s1 - 1) for s1 in singles)
+        assert rel < 0.03, (d["config"]["rays_per_frame"], singles, d["config"]["parallelism"])

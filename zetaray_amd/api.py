@@ -15,10 +15,11 @@ from . import wire
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("ZETARAY_AMD_LIB", os.path.join(_HERE, "libzetaray_amd.so"))     # (override: compiler-variant experiments)
 
-PASS_GBUFFER, PASS_PRELIGHTING, PASS_DI_EMISSIVE, PASS_DI_SKY, PASS_INDIRECT, PASS_COMPOSITING, PASS_SKY, PASS_TAA, PASS_AUTO_EXPOSURE, PASS_DISPLAY = range(10)
+PASS_GBUFFER, PASS_PRELIGHTING, PASS_DI_EMISSIVE, PASS_DI_SKY, PASS_INDIRECT, PASS_COMPOSITING, PASS_SKY, PASS_TAA, PASS_AUTO_EXPOSURE, PASS_DISPLAY, PASS_DENOISE = range(11)
 IN_TAA_SIGNAL, OUT_TAA = 3, 41
 IN_POST_SIGNAL_F16, IN_POST_SIGNAL_F32, IN_DISPLAY_EXPOSURE = 4, 5, 6
 OUT_EXPOSURE, OUT_AE_HISTOGRAM, OUT_DISPLAY, OUT_DISPLAY_SRGB8 = 42, 43, 44, 45
+IN_DENOISE_SIGNAL, OUT_DENOISED, OUT_DENOISE_HISTORY, OUT_DENOISE_MOMENTS = 7, 46, 47, 48
 TONEMAP_LUT_PATH = os.path.join(_HERE, "assets", "tony_mc_mapface_rgb9e5.bin")
 
 
@@ -33,7 +34,8 @@ IN_EMISSIVE_DI, IN_INDIRECT, IN_SKY_DI = range(3)
 INTEGRATOR_PATH_TRACING, INTEGRATOR_RESTIR_GI, INTEGRATOR_RESTIR_PT = range(3)
 OUT_FINAL = 0
 # ReSTIR PT persistent state (zr_output): name -> (id, dtype, channels)
-RPT_OUTPUTS_EXTRA = {"taa": (41, np.uint16, 4), "sky_lut": (40, np.uint32, 1), "sdi_A": (24, np.uint8, 1), "sdi_B": (25, np.uint16, 2), "sdi_C": (26, np.float32, 2),
+RPT_OUTPUTS_EXTRA = {"denoised": (46, np.float32, 4), "denoise_history": (47, np.float32, 4), "denoise_moments": (48, np.float32, 2),
+                     "taa": (41, np.uint16, 4), "sky_lut": (40, np.uint32, 1), "sdi_A": (24, np.uint8, 1), "sdi_B": (25, np.uint16, 2), "sdi_C": (26, np.float32, 2),
                      "sdi_target": (27, np.float32, 4)}
 RPT_OUTPUTS = {"A": (1, np.uint32, 1), "B": (2, np.float32, 2), "C": (3, np.uint32, 4), "D": (4, np.uint32, 4),
                "E": (5, np.uint16, 1), "F": (6, np.float32, 2), "G": (7, np.uint32, 2), "target": (8, np.float32, 4),
@@ -356,6 +358,13 @@ class Pass:
         _check(lib().zr_pass_read_cost_map(self.h, stream, out.ctypes.data, cw, ch, int(reset)))
         return out
 
+    def debug_trip_stats(self):
+        """ZR_K11=trip diagnostic: (lanes alive at K11's bounce boundaries, lane slots of the waves that passed them, 32-bit words per path state)"""
+        out = (C.c_uint64 * 3)()
+        lib().zr_pass_debug_trip_stats.argtypes = [C.c_void_p, C.c_void_p]
+        _check(lib().zr_pass_debug_trip_stats(self.h, out))
+        return int(out[0]), int(out[1]), int(out[2])
+
     def read_counters(self, reset=True, stream=None):
         c = wire.Counters()
         _check(lib().zr_pass_read_counters(self.h, stream, C.addressof(c), int(reset)))
@@ -441,6 +450,14 @@ class Renderer:
         if getattr(self, "p_taa", None) is not None:
             self.p_taa.set_input(IN_TAA_SIGNAL, self.p_composit.output_ptr()[0])
 
+    def enable_denoise(self, params=None, device=0):
+        """add the denoise pass (ZR_PASS_DENOISE: spatiotemporal variance-guided filter; no reference counterpart) on the indirect pass's FINAL image;
+        it renders after the lighting passes, before Compositing reads anything (Compositing keeps reading the unfiltered planes).  Read the
+        result with p_denoise.download_plane("denoised") (RGBA32F: rgb + variance)."""
+        self.p_denoise = Pass(PASS_DENOISE, self.p_indirect.w, self.p_indirect.h_, device=device, params=params or wire.default_params())
+        self.p_denoise.set_input(IN_DENOISE_SIGNAL, self.p_indirect.output_ptr()[0])
+        return self.p_denoise
+
     def enable_taa(self, blend_weight=0.1, device=0):
         """add the TAA pass on the composited image (adds the Compositing pass if it is not there yet); read it with
         p_taa.download_plane("taa") (RGBA16F bits)"""
@@ -502,6 +519,9 @@ class Renderer:
             self.p_sky_direct.render(cb, self.scene, self.gbuffer, stream)
         if not self.skip_indirect:
             self.p_indirect.render(cb, self.scene, self.gbuffer, stream)
+        if getattr(self, "p_denoise", None) is not None:
+            self.p_denoise.set_input(IN_DENOISE_SIGNAL, self.p_indirect.output_ptr()[0])
+            self.p_denoise.render(cb, self.scene, self.gbuffer, stream)
         if self.p_composit is not None:
             self.p_composit.render(cb, self.scene, self.gbuffer, stream)
         if getattr(self, "p_taa", None) is not None:

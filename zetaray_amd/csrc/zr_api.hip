@@ -20,6 +20,7 @@
 #include "zr_rgi.h"
 #include "zr_bvh.h"
 #include "zr_taa.h"
+#include "zr_svgf.h"
 #include "zr_post.h"
 #include "../../include/zr_srgb_table.h"
 
@@ -237,6 +238,15 @@ __global__ void __launch_bounds__(256) k_taa(taa::TaaFrame F)
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < F.w * F.h) taa::TaaPixel(F, i % F.w, i / F.w);
 }
+
+// Denoise pass (zr_svgf.h): blocks of 32 x 8 pixels, one thread per pixel.  All three kernels are gathers over planes of 16-byte texels that the
+// L2 serves after the first touch (5 x 5 taps of colour + guide per a-trous iteration): HBM-bound, 32 B read + 16 B written per pixel and
+// iteration algorithmically.
+__device__ __forceinline__ bool SvgfPixel(uint32_t w, uint32_t h, int* x, int* y)
+{ *x = (int)(blockIdx.x * 32u + (threadIdx.x & 31u)); *y = (int)(blockIdx.y * 8u + (threadIdx.x >> 5)); return *x < (int)w && *y < (int)h; }
+__global__ void __launch_bounds__(256) k_svgf_temporal(svgf::SvgfFrame F) { int x, y; if (SvgfPixel(F.w, F.h, &x, &y)) svgf::TemporalPixel(F, x, y); }
+__global__ void __launch_bounds__(256) k_svgf_variance(svgf::FilterFrame F) { int x, y; if (SvgfPixel(F.w, F.h, &x, &y)) svgf::VariancePixel(F, x, y); }
+__global__ void __launch_bounds__(256) k_svgf_atrous(svgf::FilterFrame F) { int x, y; if (SvgfPixel(F.w, F.h, &x, &y)) svgf::AtrousPixel(F, x, y); }
 
 // AutoExposure_Histogram.hlsl: per-block LDS histogram (256 bins = 256 threads), one global atomic per non-empty bin and block.
 // in16 / in32: exactly one is non-null (RGBA16F plane, or RGBA32F read rounded to half).  HBM-bound: 8 (16) B read per pixel.
@@ -479,6 +489,7 @@ __global__ void __launch_bounds__(kDiBlock) ZR_WAVES_RDI_S k_rdi_spatial(rdi::Di
         } \
         rgi::PhaseB(F, g, stack, cnt, P, key); \
     } \
+    rgi::ReloadPrimary(F, g, P); \
     const float w = rgi::FinishAndResample(F, g, stack, cnt, P); \
     const float waveSum = WaveSumButterfly(w); \
     rgi::SuppressAndWrite(F, P, waveSum); \
@@ -742,6 +753,8 @@ struct zr_pass
     } rb[2];
     DevBuf<F4> rptTarget; DevBuf<uint8_t> rptNeighbor; DevBuf<uint16_t> rptSampleSet;
     DevBuf<uint16_t> rptMap[2];      // K12 thread maps: [0] CtN, [1] NtC
+    DevBuf<uint32_t> trip; DevBuf<unsigned long long> tripStats;      // ZR_K11=trip diagnostic
+    DevBuf<uint32_t> carry[2], carryCount;                             // K11 with per-bounce compaction: path-state planes (ping-pong), alive counts
     DevBuf<uint32_t> costMap; bool costOn = false;      // rays per 32 x 32-px cell (zr_pass_enable_cost_map)
     DevBuf<uint32_t> rptLists, rptListCounts;      // 4 replay work lists (pixel ids) + their device-side counts
     // DI_EMISSIVE: two reservoir sets (A RGBA32_UINT, B RG32F), target, sample set
@@ -751,6 +764,7 @@ struct zr_pass
     DevBuf<F4> giA[2], giC[2]; DevBuf<uint16_t> giB[2];
     bool temporalValid = false, doTemporal = false, doSpatial = false; int currIdx = 0;
     const F4* compIn[4] = {nullptr, nullptr, nullptr, nullptr};     // COMPOSITING inputs (emissive DI, indirect, sky DI); [3] = TAA signal
+    DevBuf<F4> svgfHist, svgfAccum, svgfPing, svgfPong; DevBuf<float> svgfMoments[2]; DevBuf<U4> svgfGuide; int svgfMomIdx = 0; const F4* svgfOut = nullptr;      // DENOISE
     DevBuf<uint16_t> taaOut[2]; int taaIdx = 0;            // TAA: ping-pong RGBA16F outputs; taaIdx = the one written last
     // AUTO_EXPOSURE / DISPLAY
     const uint16_t* postIn16 = nullptr; const F4* postIn32 = nullptr; const float* exposureIn = nullptr;
@@ -1546,7 +1560,7 @@ int zr_gbuffer_device_plane(const zr_gbuffer* g, int plane, void** dev)
 int zr_pass_create(int kind, int device, zr_pass** out)
 {
     if (!out) return Fail(ZR_ERR_INVALID_ARG, "null out");
-    if (kind < ZR_PASS_GBUFFER || kind > ZR_PASS_DISPLAY) return Fail(ZR_ERR_INVALID_ARG, "unknown pass kind %d", kind);
+    if (kind < ZR_PASS_GBUFFER || kind > ZR_PASS_DENOISE) return Fail(ZR_ERR_INVALID_ARG, "unknown pass kind %d", kind);
     int r = RequireDevice(device);
     if (r) return r;
     zr_pass* p = new (std::nothrow) zr_pass();
@@ -1578,6 +1592,14 @@ static int AllocPass(zr_pass* p)
         const size_t n = (size_t)p->w * p->h * 4;
         for (int k = 0; k < 2; k++) { if ((r = p->taaOut[k].Alloc(n))) return r; HIP_TRY(hipMemset(p->taaOut[k].p, 0, n * sizeof(uint16_t))); }
         p->taaIdx = 0; p->temporalValid = false;
+    }
+    if (p->kind == ZR_PASS_DENOISE)
+    {
+        const size_t n = (size_t)p->w * p->h;
+        if ((r = p->svgfHist.Alloc(n)) || (r = p->svgfAccum.Alloc(n)) || (r = p->svgfPing.Alloc(n)) || (r = p->svgfPong.Alloc(n)) || (r = p->svgfGuide.Alloc(n))) return r;
+        for (int k = 0; k < 2; k++) { if ((r = p->svgfMoments[k].Alloc(2 * n))) return r; HIP_TRY(hipMemset(p->svgfMoments[k].p, 0, 2 * n * sizeof(float))); }
+        HIP_TRY(hipMemset(p->svgfHist.p, 0, n * sizeof(F4))); HIP_TRY(hipMemset(p->svgfPing.p, 0, n * sizeof(F4))); HIP_TRY(hipMemset(p->svgfPong.p, 0, n * sizeof(F4)));
+        p->svgfMomIdx = 0; p->svgfOut = p->svgfPing.p; p->temporalValid = false;
     }
     if (p->kind == ZR_PASS_AUTO_EXPOSURE)
     {
@@ -2012,6 +2034,8 @@ static int RenderReSTIR_PT(zr_pass* p, hipStream_t s, const zr_frame_constants* 
     F.finalRGBA = p->finalRGBA.p; F.sampleSet = p->rptSampleSet.p;
     F.mapCtN = p->rptMap[0].p; F.mapNtC = p->rptMap[1].p;
     F.costMap = p->costOn ? p->costMap.p : nullptr; F.costW = (p->w + 31u) / 32u + 1u;
+    F.trip = nullptr; F.tripStats = nullptr; F.tripStride = 0;
+    F.carryOut = nullptr; F.carryIn = nullptr; F.carryCount = nullptr; F.carryCap = 0; F.carryBounce = 0;
     // K12 sorts whole 32 x 32 tiles: an owned rect may end inside one only where the render target ends
     if (((F.ox0 + F.ow) & 31u) && F.ox0 + F.ow != cb->render_width) return Fail(ZR_ERR_INVALID_ARG, "ReSTIR PT: the owned rect must end on a 32-pixel boundary or at the right edge of the render target");
     if (((F.oy0 + F.oh) & 31u) && F.oy0 + F.oh != cb->render_height) return Fail(ZR_ERR_INVALID_ARG, "ReSTIR PT: the owned rect must end on a 32-pixel boundary or at the bottom edge of the render target");
@@ -2069,12 +2093,38 @@ static int RenderReSTIR_PT(zr_pass* p, hipStream_t s, const zr_frame_constants* 
         HIP_TRY(hipMemsetAsync(listCnt, 0, 4 * sizeof(uint32_t), s));
         TimerBegin(p, s, "rpt_pathtrace");
         // ZR_K11=pool: K11 with block-pooled traces (k_rpt_pathtrace_coop, zr_kernels.h; emissive untextured permutation); ZR_K11=inline: the megakernel
-        static const int k11Mode = [] { const char* e = getenv("ZR_K11"); return e && !strcmp(e, "inline") ? 0 : (e && !strcmp(e, "pool") ? 1 : ZR_K11_DEFAULT); }();
+        static const int k11Mode = [] { const char* e = getenv("ZR_K11"); return e && !strcmp(e, "inline") ? 0 : (e && !strcmp(e, "pool") ? 1 : (e && !strcmp(e, "trip") ? 2 : (e && !strcmp(e, "compact") ? 3 : ZR_K11_DEFAULT))); }();
         if (k11Mode == 1 && emissiveVariant && !texVariant)
         {
             const dim3 gridCoop(tilesX * tilesY), blockCoop(kCoopBlock);
             if (sc->view.numNodes >= largeSceneNodes) hipLaunchKernelGGL(k_rpt_pathtrace_coop_w4<false>, gridCoop, blockCoop, 0, s, F, *cb, tilesX, ctr + 2 * 1);
             else hipLaunchKernelGGL(k_rpt_pathtrace_coop<false>, gridCoop, blockCoop, 0, s, F, *cb, tilesX, ctr + 2 * 1);
+        }
+        else if (k11Mode == 3 && !texVariant)
+        {   // a kernel per bounce, live paths compacted in between (zr_kernels.h: k_rpt_pt_first / k_rpt_pt_next)
+            const size_t cap = (size_t)F.gb.w * F.gb.h;
+            if (p->carry[0].n != cap * rpt::kPtCarryWords) { int rr; for (int k = 0; k < 2; k++) if ((rr = p->carry[k].Alloc(cap * rpt::kPtCarryWords))) return rr; if ((rr = p->carryCount.Alloc(16))) return rr; }
+            HIP_TRY(hipMemsetAsync(p->carryCount.p, 0, 16 * sizeof(uint32_t), s));
+            uint32_t maxB = prm.maxNonTrBounces > prm.maxGlossyTrBounces ? prm.maxNonTrBounces : prm.maxGlossyTrBounces;
+            if (prm.russianRoulette && maxB > 3u) maxB = 3u;      // paths that go further are traced by whole tiles inside k_rpt_pt_first
+            F.carryCap = cap; F.carryCount = p->carryCount.p; F.carryBounce = 0; F.carryOut = p->carry[0].p; F.carryIn = nullptr;
+            if (emissiveVariant) hipLaunchKernelGGL(k_rpt_pt_first<true>, gridRpt, blockRpt, 0, s, F, *cb, tilesX, ctr + 2 * 1);
+            else hipLaunchKernelGGL(k_rpt_pt_first<false>, gridRpt, blockRpt, 0, s, F, *cb, tilesX, ctr + 2 * 1);
+            const dim3 gridNext((uint32_t)((cap + kRptBlock - 1) / kRptBlock));
+            for (uint32_t b = 1; b + 1 <= maxB && b < 15u; b++)
+            {
+                F.carryBounce = b; F.carryIn = p->carry[(b - 1) & 1].p; F.carryOut = p->carry[b & 1].p;
+                if (emissiveVariant) hipLaunchKernelGGL(k_rpt_pt_next<true>, gridNext, blockRpt, 0, s, F, *cb, tilesX, ctr + 2 * 1);
+                else hipLaunchKernelGGL(k_rpt_pt_next<false>, gridNext, blockRpt, 0, s, F, *cb, tilesX, ctr + 2 * 1);
+            }
+        }
+        else if (k11Mode == 2 && emissiveVariant && !texVariant)
+        {   // diagnostic: the megakernel with a path-state round trip through SoA planes at every bounce boundary (zr_kernels.h)
+            const size_t stride = (size_t)F.gb.w * F.gb.h;
+            if (!p->trip.p) { int rr; if ((rr = p->trip.Alloc(stride * 192u))) return rr; if ((rr = p->tripStats.Alloc(4))) return rr; HIP_TRY(hipMemsetAsync(p->tripStats.p, 0, 32, s)); }
+            F.trip = p->trip.p; F.tripStats = p->tripStats.p; F.tripStride = stride;
+            if (sc->view.numNodes >= largeSceneNodes) hipLaunchKernelGGL(k_rpt_pathtrace_trip_w4<false>, gridRpt, blockRpt, 0, s, F, *cb, tilesX, ctr + 2 * 1);
+            else hipLaunchKernelGGL(k_rpt_pathtrace_trip<false>, gridRpt, blockRpt, 0, s, F, *cb, tilesX, ctr + 2 * 1);
         }
         else if (texVariant) { if (emissiveVariant) hipLaunchKernelGGL(k_rpt_pathtrace_tex<true>, gridRpt, blockRpt, 0, s, F, *cb, tilesX, ctr + 2 * 1); else hipLaunchKernelGGL(k_rpt_pathtrace_tex<false>, gridRpt, blockRpt, 0, s, F, *cb, tilesX, ctr + 2 * 1); }
         else if (sc->view.numNodes >= largeSceneNodes)     // BVH beyond the caches: the 4-wave build of K11 (zr_kernels.h)
@@ -2198,6 +2248,7 @@ int zr_pass_render(zr_pass* p, void* stream, const zr_frame_constants* cb, const
 int zr_pass_set_input(zr_pass* p, int which, const void* dev)
 {
     if (p && p->kind == ZR_PASS_TAA && which == ZR_IN_TAA_SIGNAL) { p->compIn[3] = (const F4*)dev; return ZR_OK; }
+    if (p && p->kind == ZR_PASS_DENOISE && which == ZR_IN_DENOISE_SIGNAL) { p->compIn[3] = (const F4*)dev; return ZR_OK; }
     if (p && (p->kind == ZR_PASS_AUTO_EXPOSURE || p->kind == ZR_PASS_DISPLAY))
     {
         if (which == ZR_IN_POST_SIGNAL_F16) { p->postIn16 = (const uint16_t*)dev; p->postIn32 = nullptr; return ZR_OK; }
@@ -2278,6 +2329,47 @@ static int RenderTAA(zr_pass* p, hipStream_t s, const zr_frame_constants* cb, zr
     TimerEnd(p, s);
     HIP_TRY(hipGetLastError());
     p->taaIdx = curr; p->temporalValid = true;
+    return ZR_OK;
+}
+
+// Denoise pass: temporal accumulation -> variance estimate -> a-trous iterations (zr_svgf.h; no reference counterpart)
+static int RenderDenoise(zr_pass* p, hipStream_t s, const zr_frame_constants* cb, zr_gbuffer* gb)
+{
+    if (!gb || gb->w != p->w || gb->h != p->h) return Fail(ZR_ERR_INVALID_ARG, "DENOISE needs a gbuffer of the pass size");
+    if (cb->render_width != p->w || cb->render_height != p->h) return Fail(ZR_ERR_INVALID_ARG, "DENOISE: frame constants / pass size mismatch");
+    if (!p->compIn[3]) return Fail(ZR_ERR_NOT_INITIALIZED, "DENOISE: no input bound (zr_pass_set_input(ZR_IN_DENOISE_SIGNAL))");
+    const zr_params& prm = p->params;
+    if (prm.svgf_iterations > 8u || prm.svgf_normal_power_log2 > 16u) return Fail(ZR_ERR_INVALID_ARG, "DENOISE: svgf_iterations must be <= 8, svgf_normal_power_log2 <= 16");
+    const GBuf cur = gb->View(), prev = gb->PrevView();
+    const int mi = p->svgfMomIdx;
+    svgf::SvgfParams sp; sp.alpha = prm.svgf_alpha; sp.alphaMoments = prm.svgf_alpha_moments; sp.sigmaL = prm.svgf_sigma_l; sp.sigmaZ = prm.svgf_sigma_z;
+    sp.normalPowerLog2 = prm.svgf_normal_power_log2; sp.iterations = prm.svgf_iterations;
+    svgf::SvgfFrame T;
+    T.signal = p->compIn[3]; T.depth = cur.depth; T.normal = cur.normal; T.motion = cur.motion; T.prevDepth = prev.depth; T.prevNormal = prev.normal;
+    T.histColor = p->svgfHist.p; T.histMoments = p->svgfMoments[mi].p; T.accum = p->svgfAccum.p; T.moments = p->svgfMoments[mi ^ 1].p; T.guide = p->svgfGuide.p;
+    T.w = p->w; T.h = p->h; T.temporalValid = (p->temporalValid && gb->numRendered >= 2) ? 1u : 0u; T.prm = sp;
+    const dim3 grid((p->w + 31u) / 32u, (p->h + 7u) / 8u), block(256);
+    TimerBegin(p, s, "denoise_temporal");
+    hipLaunchKernelGGL(k_svgf_temporal, grid, block, 0, s, T);
+    TimerEnd(p, s);
+    svgf::FilterFrame V;
+    V.src = p->svgfAccum.p; V.moments = p->svgfMoments[mi ^ 1].p; V.guide = p->svgfGuide.p; V.dst = p->svgfPing.p; V.lenSrc = p->svgfAccum.p;
+    V.history = sp.iterations == 0 ? p->svgfHist.p : nullptr; V.w = p->w; V.h = p->h; V.step = 1; V.prm = sp;
+    TimerBegin(p, s, "denoise_variance");
+    hipLaunchKernelGGL(k_svgf_variance, grid, block, 0, s, V);
+    TimerEnd(p, s);
+    F4* src = p->svgfPing.p; F4* dst = p->svgfPong.p;
+    TimerBegin(p, s, "denoise_atrous");
+    for (uint32_t it = 0; it < sp.iterations; it++)
+    {
+        svgf::FilterFrame A = V;
+        A.src = src; A.dst = dst; A.moments = nullptr; A.step = 1u << it; A.history = it == 0 ? p->svgfHist.p : nullptr;
+        hipLaunchKernelGGL(k_svgf_atrous, grid, block, 0, s, A);
+        F4* t = src; src = dst; dst = t;
+    }
+    TimerEnd(p, s);
+    HIP_TRY(hipGetLastError());
+    p->svgfOut = src; p->svgfMomIdx = mi ^ 1; p->temporalValid = true;
     return ZR_OK;
 }
 
@@ -2456,6 +2548,7 @@ static int RenderStageInner(zr_pass* p, void* stream, const zr_frame_constants* 
     case ZR_PASS_TAA: return (stages & ZR_STAGE_SPATIAL) ? RenderTAA(p, s, cb, gb) : ZR_OK;
     case ZR_PASS_AUTO_EXPOSURE: return (stages & ZR_STAGE_SPATIAL) ? RenderAutoExposure(p, s, cb) : ZR_OK;
     case ZR_PASS_DISPLAY: return (stages & ZR_STAGE_SPATIAL) ? RenderDisplay(p, s, cb) : ZR_OK;
+    case ZR_PASS_DENOISE: return (stages & ZR_STAGE_SPATIAL) ? RenderDenoise(p, s, cb, gb) : ZR_OK;
     default: return Fail(ZR_ERR_UNSUPPORTED, "pass kind %d not implemented", p->kind);
     }
 }
@@ -2483,6 +2576,15 @@ int zr_pass_get_output(const zr_pass* p, int which, void** dev, uint32_t* w, uin
     {
         if (which == ZR_OUT_DISPLAY) { *dev = p->displayOut.p; if (w) *w = p->w; if (h) *h = p->h; if (bpp) *bpp = 16; return ZR_OK; }
         if (which == ZR_OUT_DISPLAY_SRGB8) { *dev = p->displaySrgb.p; if (w) *w = p->w; if (h) *h = p->h; if (bpp) *bpp = 4; return ZR_OK; }
+        return Fail(ZR_ERR_INVALID_ARG, "pass has no such output");
+    }
+    if (p->kind == ZR_PASS_DENOISE)
+    {
+        if (w) *w = p->w;
+        if (h) *h = p->h;
+        if (which == ZR_OUT_DENOISED) { *dev = (void*)p->svgfOut; if (bpp) *bpp = 16; return ZR_OK; }
+        if (which == ZR_OUT_DENOISE_HISTORY) { *dev = p->svgfHist.p; if (bpp) *bpp = 16; return ZR_OK; }
+        if (which == ZR_OUT_DENOISE_MOMENTS) { *dev = p->svgfMoments[p->svgfMomIdx].p; if (bpp) *bpp = 8; return ZR_OK; }
         return Fail(ZR_ERR_INVALID_ARG, "pass has no such output");
     }
     if (p->kind == ZR_PASS_TAA)
@@ -2595,6 +2697,17 @@ int zr_pass_enable_cost_map(zr_pass* p, int enable)
     if (!p || !p->initialized) return Fail(ZR_ERR_NOT_INITIALIZED, "pass not initialised");
     if (p->kind != ZR_PASS_INDIRECT || p->integrator != ZR_INTEGRATOR_RESTIR_PT) return Fail(ZR_ERR_UNSUPPORTED, "the cost map is an output of the ReSTIR PT pass");
     p->costOn = enable != 0;
+    return ZR_OK;
+}
+int zr_pass_debug_trip_stats(zr_pass* p, uint64_t out[3])
+{
+    if (!p || !out) return Fail(ZR_ERR_INVALID_ARG, "null argument");
+    out[0] = out[1] = out[2] = 0;
+    if (!p->tripStats.p) return ZR_OK;
+    HIP_TRY(hipDeviceSynchronize());
+    unsigned long long h[4];
+    HIP_TRY(hipMemcpy(h, p->tripStats.p, 32, hipMemcpyDeviceToHost));
+    out[0] = h[0]; out[1] = h[1]; out[2] = h[2];
     return ZR_OK;
 }
 int zr_pass_read_cost_map(zr_pass* p, void* stream, uint32_t* out, uint32_t cells_w, uint32_t cells_h, int reset)

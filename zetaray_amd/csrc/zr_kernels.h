@@ -229,6 +229,173 @@ template<bool EMISSIVE>
 __global__ void __launch_bounds__(kRptBlock) ZR_WAVES_PATHTRACE_TEX k_rpt_pathtrace_tex(rpt::RptFrame F, zr_frame_constants g, uint32_t tilesX, unsigned long long* counters)
 { RptPathtraceBody<EMISSIVE, true>(F, g, tilesX, counters); }
 
+// ------------------------------------------------------------------------------------------------ K11 with per-bounce path compaction (round 3)
+// On scenes where paths end early (Cornell box: open front, paths that reach the light) the megakernel's waves run every bounce with the lanes
+// of the paths that are still alive -- 35 % of them on average at the bounce boundaries of the Cornell frame (zr_pass_debug_trip_stats), 95 % on
+// the atrium.  Here a bounce is a kernel: k_rpt_pt_first runs the prologue and the first bounce for every pixel in 16 x 4 tiles like the
+// megakernel, then the paths still alive move into consecutive slots of SoA planes (84 words = 336 B per path, rpt::PtCarry; slots come from a
+// wave-aggregated atomic, so a wave's paths sit side by side and the stores coalesce); k_rpt_pt_next runs one more bounce over slots
+// 0 .. count - 1 with full waves and compacts again; a path that ends writes its reservoir (PtFinishLane) from wherever it is.  Per-pixel
+// arithmetic is the megakernel's, statement for statement, so the results are bit-identical; tiles whose paths can reach Russian roulette (a
+// maximum over the 16 x 4 tile) stay whole, see k_rpt_pt_first.
+template<bool EMISSIVE>
+__device__ __forceinline__ void PtBounceAndCompact(rpt::RptFrame& F, const zr_frame_constants& g, const TravStack& stack, uint32_t* cnt, rpt::PTLane& P)
+{
+    rpt::PtPhaseA_Fused(F.sc, g, F.prm, stack, cnt, P);
+    rpt::PtPhaseB(F.sc, F.prm, P, 0u);
+    const bool alive = P.active;
+    const uint32_t slot = AllocSlotWave(F.carryCount + F.carryBounce, alive);
+    if (alive)
+    {
+        rpt::PtCarryStore st; st.p = F.carryOut + slot; st.stride = F.carryCap;
+        rpt::PtCarry(st, P);
+    }
+    else rpt::PtFinishLane(F.gb, F.prm, F.cur, F.tex, F.finalRGBA, P);
+}
+template<bool EMISSIVE>
+__global__ void __launch_bounds__(kRptBlock) ZR_WAVES_PATHTRACE k_rpt_pt_first(rpt::RptFrame F, zr_frame_constants g, uint32_t tilesX, unsigned long long* counters)
+{
+    const unsigned long long t0 = __builtin_readcyclecounter();
+    F.prm.emissive = EMISSIVE ? 1u : 0u; F.prm.textured = 0u;
+    uint32_t tile, wave, lane; RptTileWaveLane(&tile, &wave, &lane);
+    const uint32_t tx = tile % tilesX, ty = tile / tilesX;
+    const uint32_t x = F.ox0 + tx * 16u + (lane & 15u), y = F.oy0 + ty * 16u + wave * 4u + (lane >> 4);
+    ZR_TRAV_STACK_B(stack, kRptBlock);
+    uint32_t cnt[2] = {0u, 0u};
+    rpt::PTLane P;
+    rpt::PtInitLane_Fused(F.sc, g, F.gb, F.prm, F.Owns(x, y), x, y, F.finalRGBA, stack, cnt, P);
+    // Russian roulette starts at the fourth bounce, which only paths with maxNumBounces >= 4 reach (glossy-transmissive primary hits), and its
+    // survival probability is the maximum over the tile's lanes that are at it: a tile with such a pixel runs the megakernel's loop as a whole
+    if (F.prm.russianRoulette && __ballot(P.valid && P.maxNumBounces >= 4) != 0)
+    {
+        for (;;)
+        {
+            const bool any = __ballot(P.active) != 0;
+            rpt::PtPhaseA_Fused(F.sc, g, F.prm, stack, cnt, P);
+            if (!any) break;
+            uint32_t key = rpt::PtRRKey(P);
+            if (__ballot(key != 0) != 0)
+            {
+                for (int s = 1; s < 64; s <<= 1) { uint32_t o = __shfl_xor(key, s); key = o > key ? o : key; }
+            }
+            rpt::PtPhaseB(F.sc, F.prm, P, key);
+        }
+        rpt::PtFinishLane(F.gb, F.prm, F.cur, F.tex, F.finalRGBA, P);
+    }
+    else if (__ballot(P.valid) != 0) PtBounceAndCompact<EMISSIVE>(F, g, stack, cnt, P);
+    FlushRayCountersCost(F, counters, cnt, x, y, F.Owns(x, y), t0);
+}
+template<bool EMISSIVE>
+__global__ void __launch_bounds__(kRptBlock) ZR_WAVES_PATHTRACE k_rpt_pt_next(rpt::RptFrame F, zr_frame_constants g, uint32_t tilesX, unsigned long long* counters)
+{
+    const unsigned long long t0 = __builtin_readcyclecounter();
+    F.prm.emissive = EMISSIVE ? 1u : 0u; F.prm.textured = 0u;
+    const uint32_t n = F.carryCount[F.carryBounce - 1u];
+    const uint32_t slot = blockIdx.x * kRptBlock + threadIdx.x;
+    if (blockIdx.x * kRptBlock >= n) return;
+    ZR_TRAV_STACK_B(stack, kRptBlock);
+    uint32_t cnt[2] = {0u, 0u};
+    rpt::PTLane P;
+    P.valid = false; P.active = false; P.atRR = false; P.x = 0; P.y = 0;
+    if (slot < n)
+    {
+        rpt::PtCarryLoad ld; ld.p = F.carryIn + slot; ld.stride = F.carryCap;
+        rpt::PtCarry(ld, P);
+    }
+    PtBounceAndCompact<EMISSIVE>(F, g, stack, cnt, P);
+    FlushRayCountersCost(F, counters, cnt, P.x, P.y, P.valid, t0);
+}
+
+// ------------------------------------------------------------------------------------------------ path-state round trip (round 3 diagnostic)
+// What a per-bounce relaunch of K11 (paths compacted between bounces, state in SoA planes) would have to move: the same megakernel, but at every
+// bounce boundary each live path stores its state -- everything PtPhaseA / PtPhaseB / PtFinishLane read later -- into [word][pixel] planes and
+// loads it back (a compiler barrier in between, so nothing is forwarded in registers).  No relaunch, no compaction, perfectly coalesced: the
+// LOWER bound of that design's overhead, measured instead of estimated.  It also counts the lanes alive at each boundary, i.e. what compaction
+// could win back.  Results are unchanged (the state that comes back is the state that went out).  ZR_K11=trip, emissive untextured permutation.
+template<class T> __device__ __forceinline__ void TripStore(const T& v, uint32_t*& p, size_t stride, uint32_t& words)
+{
+    constexpr int n = (int)((sizeof(T) + 3) / 4);
+    uint32_t w[n];
+    for (int i = 0; i < n; i++) w[i] = 0;
+    __builtin_memcpy(w, &v, sizeof(T));
+#pragma unroll
+    for (int i = 0; i < n; i++) p[(size_t)i * stride] = w[i];
+    p += (size_t)n * stride; words += n;
+}
+template<class T> __device__ __forceinline__ void TripLoad(T& v, const uint32_t*& p, size_t stride)
+{
+    constexpr int n = (int)((sizeof(T) + 3) / 4);
+    uint32_t w[n];
+#pragma unroll
+    for (int i = 0; i < n; i++) w[i] = p[(size_t)i * stride];
+    __builtin_memcpy(&v, w, sizeof(T));
+    p += (size_t)n * stride;
+}
+// the state live across a bounce boundary of the untextured emissive kernel (rd / dpdx / dpdy are the textured permutation's)
+#define ZR_TRIP_FIELDS(X) X(P.pos) X(P.normal) X(P.surface) X(P.bs) X(P.rngReplay) X(P.rngThread) X(P.rngGroup) X(P.rc) X(P.r) X(P.li) X(P.throughput) \
+    X(P.throughput_k) X(P.bounce) X(P.prevHit) X(P.eta_curr) X(P.eta_next) X(P.inMedium) X(P.nextHit) X(P.seed_replay) X(P.sampleSetIdx) X(P.maxNumBounces) \
+    X(P.hit) X(P.tr) X(P.prevPdf) X(P.prevLobe) X(P.pathVertex)
+template<bool NODE_CACHE>
+__device__ __forceinline__ void RptPathtraceBodyTrip(rpt::RptFrame& F, const zr_frame_constants& g, uint32_t tilesX, unsigned long long* counters)
+{
+    const unsigned long long t0 = __builtin_readcyclecounter();
+    F.prm.emissive = 1u; F.prm.textured = 0u;
+    uint32_t tile, wave, lane; RptTileWaveLane(&tile, &wave, &lane);
+    const uint32_t tx = tile % tilesX, ty = tile / tilesX;
+    const uint32_t x = F.ox0 + tx * 16u + (lane & 15u), y = F.oy0 + ty * 16u + wave * 4u + (lane >> 4);
+    ZR_TRAV_STACK_B(stack, kRptBlock);
+    if (NODE_CACHE) { ZR_NODE_CACHE_FILL(stack, F.sc, kRptBlock); }
+    uint32_t cnt[2] = {0u, 0u};
+    rpt::PTLane P;
+    rpt::PtInitLane_Fused(F.sc, g, F.gb, F.prm, F.Owns(x, y), x, y, F.finalRGBA, stack, cnt, P);
+    uint32_t alive = 0, slots = 0, words = 0;
+    for (;;)
+    {
+        const bool any = __ballot(P.active) != 0;
+        rpt::PtPhaseA_Fused(F.sc, g, F.prm, stack, cnt, P);
+        if (!any) break;
+        uint32_t key = rpt::PtRRKey(P);
+        if (__ballot(key != 0) != 0)
+        {
+            for (int s = 1; s < 64; s <<= 1) { uint32_t o = __shfl_xor(key, s); key = o > key ? o : key; }
+        }
+        rpt::PtPhaseB(F.sc, F.prm, P, key);
+        // ---- the bounce boundary
+        const uint64_t live = __ballot(P.active);
+        if (live != 0) { alive += (uint32_t)__popcll((unsigned long long)live); slots += 64u; }
+        if (P.active)
+        {
+            const size_t px = rpt::Pix(F.gb, x, y);
+            uint32_t* o = F.trip + px; words = 0;
+#define ZR_TRIP_ST(f) TripStore(f, o, F.tripStride, words);
+            ZR_TRIP_FIELDS(ZR_TRIP_ST)
+#undef ZR_TRIP_ST
+        }
+        __asm__ volatile("" ::: "memory");
+        if (P.active)
+        {
+            const size_t px = rpt::Pix(F.gb, x, y);
+            const uint32_t* i = F.trip + px;
+#define ZR_TRIP_LD(f) TripLoad(f, i, F.tripStride);
+            ZR_TRIP_FIELDS(ZR_TRIP_LD)
+#undef ZR_TRIP_LD
+        }
+    }
+    rpt::PtFinishLane(F.gb, F.prm, F.cur, F.tex, F.finalRGBA, P);
+    if (lane == 0 && slots != 0)
+    {
+        atomicAdd(F.tripStats + 0, (unsigned long long)alive); atomicAdd(F.tripStats + 1, (unsigned long long)slots);
+    }
+    if (words != 0) F.tripStats[2] = words;
+    FlushRayCountersCost(F, counters, cnt, x, y, F.Owns(x, y), t0);
+}
+template<bool UNUSED>
+__global__ void __launch_bounds__(kRptBlock) ZR_WAVES_PATHTRACE k_rpt_pathtrace_trip(rpt::RptFrame F, zr_frame_constants g, uint32_t tilesX, unsigned long long* counters)
+{ RptPathtraceBodyTrip<false>(F, g, tilesX, counters); }
+template<bool UNUSED>
+__global__ void __launch_bounds__(kRptBlock) ZR_WAVES_PATHTRACE_LARGE k_rpt_pathtrace_trip_w4(rpt::RptFrame F, zr_frame_constants g, uint32_t tilesX, unsigned long long* counters)
+{ RptPathtraceBodyTrip<true>(F, g, tilesX, counters); }
+
 // ------------------------------------------------------------------------------------------------ block-cooperative ray pool (round 3)
 // The inline traversals of K11 ran at 23 % lane utilisation (section profile): a query is entered by the 29 of 64 lanes whose
 // shading branch needs it, and the call lasts until its slowest ray is done (10.5 vote iterations for rays that need 5.2 steps).  Here the
@@ -649,7 +816,10 @@ __global__ void __launch_bounds__(kBlock) ZR_WAVES_STC k_rpt_stc(rpt::RptFrame F
     X __global__ void k_rpt_temporal<true, true> ZR_RPT_ARGS_TILE; X __global__ void k_rpt_temporal<true, false> ZR_RPT_ARGS_TILE; \
     X __global__ void k_rpt_temporal<false, true> ZR_RPT_ARGS_TILE; X __global__ void k_rpt_temporal<false, false> ZR_RPT_ARGS_TILE;
 #define ZR_RPT_GROUP_C(X) \
-    X __global__ void k_rpt_pathtrace_coop<false> ZR_RPT_ARGS_TILE; X __global__ void k_rpt_pathtrace_coop_w4<false> ZR_RPT_ARGS_TILE;
+    X __global__ void k_rpt_pathtrace_coop<false> ZR_RPT_ARGS_TILE; X __global__ void k_rpt_pathtrace_coop_w4<false> ZR_RPT_ARGS_TILE; \
+    X __global__ void k_rpt_pathtrace_trip<false> ZR_RPT_ARGS_TILE; X __global__ void k_rpt_pathtrace_trip_w4<false> ZR_RPT_ARGS_TILE; \
+    X __global__ void k_rpt_pt_first<true> ZR_RPT_ARGS_TILE; X __global__ void k_rpt_pt_first<false> ZR_RPT_ARGS_TILE; \
+    X __global__ void k_rpt_pt_next<true> ZR_RPT_ARGS_TILE; X __global__ void k_rpt_pt_next<false> ZR_RPT_ARGS_TILE;
 #define ZR_RPT_REPLAY4(X, PASS) \
     X __global__ void k_rpt_replay<PASS, true, true> ZR_RPT_ARGS_LIST; X __global__ void k_rpt_replay<PASS, true, false> ZR_RPT_ARGS_LIST; \
     X __global__ void k_rpt_replay<PASS, false, true> ZR_RPT_ARGS_LIST; X __global__ void k_rpt_replay<PASS, false, false> ZR_RPT_ARGS_LIST;

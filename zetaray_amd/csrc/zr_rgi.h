@@ -282,6 +282,49 @@ ZR_HD bool TraceContinuation(const Globals& gl, V3 pos, V3 normal, V3 wi, bool t
 }
 
 // ReSTIR_GI.hlsl main prologue + EstimateIndirectLighting / RIS_InitialCandidates up to the PathTrace call
+// the primary hit of pixel (x, y) as the G-buffer holds it: position, normal, material -> P.pos / normal / roughness / ior / z_view / surface.
+// -DZR_RGI_REMAT=1 calls it AGAIN after the path loop instead of keeping ~45 registers of primary-hit state live across it (none of it is
+// touched while the path is traced; the 128-VGPR kernel spills it).  Measured (scripts/gpu_r03_trip.sh, Cornell 1080p): k_rgi 1.282 ms without,
+// 1.295 ms with; HBM-side traffic 2.21 -> 2.32 GB per launch -- the register allocator spills something else instead, nothing gained.  Off.
+ZR_HD void LoadPrimary(const GiFrame& F, const zr_frame_constants& g, uint32_t x, uint32_t y, size_t px, Lane& P, V2& lens, V3& origin)
+{
+    const uint16_t mrp = F.gb.mr[px];
+    const GFlags flags = DecodeFlags(mrp);
+    const Camera cam = CurrCamera(g);
+    P.z_view = F.gb.depth[px];
+    lens = v2(0, 0);
+    if (cam.dof)
+    {
+        uint32_t hx = x, hy = y, hz = x; zr_pcg3d(&hx, &hy, &hz);
+        Rng rr = Rng::Init(hz, hy, g.frame_num);
+        lens = UniformSampleDiskConcentric(rr.Uniform2D());
+        lens = lens * cam.lensRadius;
+    }
+    origin = cam.origin;
+    P.pos = rpt::WorldPosSS2(cam, (float)x, (float)y, P.z_view, lens, origin);
+    P.normal = DecodeOct32u(F.gb.normal[px]);
+    const V3 baseColor = UnpackRGB8(F.gb.baseColor[px]);
+    P.roughness = RoughnessOf(mrp);
+    P.ior = kDefaultEtaMat;
+    if (flags.transmissive) P.ior = DecodeIOR(zr_div255((float)F.gb.ior[px]));
+    const V3 wo = normalize(origin - P.pos);
+    P.surface = InitSurface(P.normal, wo, flags.metallic, P.roughness, baseColor, kEtaAir, P.ior, flags.transmissive, 0.0f, 0.0f, 0.0f, v3(0.0f), 0.0f, kDefaultEtaCoat);
+}
+#ifndef ZR_RGI_REMAT
+#define ZR_RGI_REMAT 0
+#endif
+// after the path loop: the primary hit again, through addresses the compiler cannot connect to the first load
+ZR_HD void ReloadPrimary(const GiFrame& F, const zr_frame_constants& g, Lane& P)
+{
+#if ZR_RGI_REMAT && defined(__HIP_DEVICE_COMPILE__)
+    if (!P.valid) return;
+    uint32_t x = P.x, y = P.y; uint32_t pxl = (uint32_t)P.px;
+    __asm__ volatile("" : "+v"(x), "+v"(y), "+v"(pxl));
+    V2 lens; V3 origin;
+    LoadPrimary(F, g, x, y, (size_t)pxl, P, lens, origin);
+#endif
+}
+
 ZR_HD void InitLane(const GiFrame& F, const zr_frame_constants& g, uint32_t x, uint32_t y, TravStack stack, uint32_t* cnt, Lane& P)
 {
     const GiParams& prm = F.prm;
@@ -297,24 +340,8 @@ ZR_HD void InitLane(const GiFrame& F, const zr_frame_constants& g, uint32_t x, u
     }
     P.valid = true;
     const Camera cam = CurrCamera(g);
-    P.z_view = F.gb.depth[P.px];
-    V2 lens = v2(0, 0);
-    if (cam.dof)
-    {
-        uint32_t hx = x, hy = y, hz = x; zr_pcg3d(&hx, &hy, &hz);
-        Rng rr = Rng::Init(hz, hy, g.frame_num);
-        lens = UniformSampleDiskConcentric(rr.Uniform2D());
-        lens = lens * cam.lensRadius;
-    }
-    V3 origin = cam.origin;
-    P.pos = rpt::WorldPosSS2(cam, (float)x, (float)y, P.z_view, lens, origin);
-    P.normal = DecodeOct32u(F.gb.normal[P.px]);
-    const V3 baseColor = UnpackRGB8(F.gb.baseColor[P.px]);
-    P.roughness = RoughnessOf(mrp);
-    P.ior = kDefaultEtaMat;
-    if (flags.transmissive) P.ior = DecodeIOR(zr_div255((float)F.gb.ior[P.px]));
-    const V3 wo = normalize(origin - P.pos);
-    P.surface = InitSurface(P.normal, wo, flags.metallic, P.roughness, baseColor, kEtaAir, P.ior, flags.transmissive, 0.0f, 0.0f, 0.0f, v3(0.0f), 0.0f, kDefaultEtaCoat);
+    V2 lens; V3 origin;
+    LoadPrimary(F, g, x, y, P.px, P, lens, origin);
     P.rngGroup = Rng::Init((x >> 3) ^ 61u, (y >> 3) ^ 61u, g.frame_num);
     P.rngThread = Rng::Init(x ^ 511u, y ^ 31u, g.frame_num);
     P.maxNumBounces = flags.transmissive ? (int)prm.maxGlossyTrBounces : (int)prm.maxNonTrBounces;

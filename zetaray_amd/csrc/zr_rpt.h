@@ -1468,6 +1468,64 @@ ZR_HD void PtPhaseB(const SceneView& sc, const RptParams& prm, PTLane& P, uint32
     if (prm.textured) P.rd.UpdateRays(P.pos, P.normal, P.bs.wi, P.surface.wo, P.hit.dndu, P.hit.dndv, P.dpdx, P.dpdy, transmitted, P.surface.eta);
 }
 
+// ---- the path state that lives across a bounce boundary (after PtPhaseB, before the next PtPhaseA) of the untextured kernels, as 32-bit
+// words: what K11 with per-bounce path compaction (zr_kernels.h: k_rpt_pt_first / k_rpt_pt_next) moves through its SoA planes.  Everything
+// else in PTLane is either recomputed by PtPhaseA before it is read (surface, hit, tr, prevPdf / prevLobe, pathVertex, eta_next, atRR) or dead.
+// One function enumerates the fields for both directions: V::f / u / i move a float / uint32_t / int, V::Store says which way.
+static constexpr uint32_t kPtCarryWords = 84;
+template<class V> ZR_HD void PtCarryRc(V& v, Reconnection& rc)
+{
+    v.f(rc.x_k.x); v.f(rc.x_k.y); v.f(rc.x_k.z); v.u(rc.ID); v.u(rc.meshIdx); v.f(rc.partialJacobian); v.f(rc.w.x); v.f(rc.w.y); v.f(rc.w.z);
+    v.f(rc.lightPdf); v.u(rc.seed_replay); v.u(rc.seed_nee); v.f(rc.dwdA); v.f(rc.L.x); v.f(rc.L.y); v.f(rc.L.z);
+    uint32_t m = 0;
+    if (V::Store) m = (rc.k & 0xffu) | ((rc.lobe_k_min_1 & 0xfu) << 8) | ((rc.lobe_k & 0xfu) << 12) | ((rc.lt_k & 0xfu) << 16) | ((rc.lt_k_plus_1 & 0xfu) << 20) | ((rc.x_k_in_motion ? 1u : 0u) << 24);
+    v.u(m);
+    if (!V::Store) { rc.k = m & 0xffu; rc.lobe_k_min_1 = (m >> 8) & 0xfu; rc.lobe_k = (m >> 12) & 0xfu; rc.lt_k = (m >> 16) & 0xfu; rc.lt_k_plus_1 = (m >> 20) & 0xfu; rc.x_k_in_motion = ((m >> 24) & 1u) != 0; }
+}
+template<class V> ZR_HD void PtCarry(V& v, PTLane& P)
+{
+    uint32_t pix = 0, flags = 0;
+    if (V::Store)
+    {
+        pix = P.x | (P.y << 16);
+        flags = (P.inMedium ? 1u : 0u) | (P.nextHit.hit ? 2u : 0u) | (P.surface.Transmissive() ? 4u : 0u) | ((uint32_t)P.bounce << 8) | ((uint32_t)P.maxNumBounces << 16);
+    }
+    v.u(pix); v.u(flags);
+    if (!V::Store)
+    {
+        P.x = pix & 0xffffu; P.y = pix >> 16; P.valid = true; P.active = true; P.atRR = false;
+        P.inMedium = (flags & 1u) != 0; P.nextHit.hit = (flags & 2u) != 0; P.bounce = (int)((flags >> 8) & 0xffu); P.maxNumBounces = (int)(flags >> 16);
+        // (the sun + sky variant traces its continuation ray at the top of PtPhaseA and only asks the old surface whether it transmits)
+        P.surface.specTr = (flags & 4u) != 0; P.surface.subsurface = 0.0f;
+    }
+    v.f(P.pos.x); v.f(P.pos.y); v.f(P.pos.z); v.f(P.normal.x); v.f(P.normal.y); v.f(P.normal.z);
+    v.f(P.bs.wi.x); v.f(P.bs.wi.y); v.f(P.bs.wi.z); v.f(P.bs.pdf); v.u(P.bs.lobe);
+    v.u(P.rngReplay.s); v.u(P.rngThread.s); v.u(P.rngGroup.s);
+    PtCarryRc(v, P.rc);
+    v.f(P.r.w_sum); v.f(P.r.target.x); v.f(P.r.target.y); v.f(P.r.target.z); v.u(P.r.M);
+    PtCarryRc(v, P.r.rc);
+    v.f(P.li.x); v.f(P.li.y); v.f(P.li.z); v.f(P.throughput.x); v.f(P.throughput.y); v.f(P.throughput.z);
+    v.f(P.throughput_k.x); v.f(P.throughput_k.y); v.f(P.throughput_k.z);
+    v.f(P.prevHit.alpha_lobe); v.f(P.prevHit.wi.x); v.f(P.prevHit.wi.y); v.f(P.prevHit.wi.z); v.f(P.prevHit.pdf); v.u(P.prevHit.lobe);
+    v.f(P.eta_curr);
+    v.f(P.nextHit.t); v.u(P.nextHit.mesh); v.u(P.nextHit.prim); v.f(P.nextHit.bu); v.f(P.nextHit.bv);
+    v.u(P.seed_replay); v.u(P.sampleSetIdx);
+}
+struct PtCarryStore
+{
+    static constexpr bool Store = true;
+    uint32_t* p; size_t stride; uint32_t n = 0;
+    ZR_HDM void f(float& x) { *p = zr_asuint(x); p += stride; n++; }
+    ZR_HDM void u(uint32_t& x) { *p = x; p += stride; n++; }
+};
+struct PtCarryLoad
+{
+    static constexpr bool Store = false;
+    const uint32_t* p; size_t stride; uint32_t n = 0;
+    ZR_HDM void f(float& x) { x = zr_asfloat(*p); p += stride; n++; }
+    ZR_HDM void u(uint32_t& x) { x = *p; p += stride; n++; }
+};
+
 struct RptTex   // per-pass auxiliary planes
 {
     F4* target;          // RGBA32F (xyz)
@@ -1890,6 +1948,12 @@ struct RptFrame
     // GPU time per 32 x 32-pixel cell of the planes (cell (0, 0) at the plane origin gb.x0, gb.y0): wave lifetimes of K11 / K14 / K16, one
     // atomic per wave: what the cost-balanced tile split of the multi-GPU path is computed from (tiling.balanced_layout); null = off
     uint32_t* costMap; uint32_t costW;
+    // diagnostic (ZR_K11=trip, zr_kernels.h: k_rpt_pathtrace_trip): SoA planes the path state makes a round trip through at every bounce boundary
+    // + {alive lanes, lane slots, words per path} of the waves that pass the boundary
+    uint32_t* trip; unsigned long long* tripStats; size_t tripStride;
+    // K11 with per-bounce path compaction: path state planes [word][slot] written by one bounce's kernel and read by the next (ping-pong),
+    // carryCount[b] = paths alive after bounce b (their slots are 0 .. count - 1), carryCap = slots per plane
+    uint32_t* carryOut; const uint32_t* carryIn; uint32_t* carryCount; size_t carryCap; uint32_t carryBounce;
 };
 
 ZR_HD Globals MakeGlobals(const RptFrame& F, const zr_frame_constants& g, bool transmissive, TravStack stack, uint32_t* cnt)

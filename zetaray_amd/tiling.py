@@ -212,6 +212,24 @@ class TiledRestirPT:
             return
         dist = self.dist
         self.pack(which)
+        if dist.get_backend() == "gloo":
+            # test rig (bench.py with ZR_BENCH_SHARED_GPU=1: several ranks on one device, no RCCL between them): strips staged through the host
+            self.torch.cuda.synchronize()
+            reqs, landed = [], []
+            for peer, send, recv in self.plan:
+                sb, rb = self.bufs[peer]
+                if send:
+                    reqs.append(dist.isend(sb.cpu(), peer))
+                if recv:
+                    hb = self.torch.empty(rb.numel(), dtype=self.torch.uint8)
+                    reqs.append(dist.irecv(hb, peer))
+                    landed.append((rb, hb))
+            for req in reqs:
+                req.wait()
+            for rb, hb in landed:
+                rb.copy_(hb)
+            self.unpack(which)
+            return
         ops = []
         for peer, send, recv in self.plan:
             sb, rb = self.bufs[peer]

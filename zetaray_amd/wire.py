@@ -104,7 +104,9 @@ class Params(C.Structure):
         ("taa_blend_weight", C.c_float),
         ("ae_min_lum", C.c_float), ("ae_max_lum", C.c_float), ("ae_lum_map_exp", C.c_float), ("ae_adaptation_rate", C.c_float),
         ("display_tonemapper", C.c_uint32), ("display_auto_exposure", C.c_uint32), ("display_saturation", C.c_float),
-        ("display_agx_exp", C.c_float), ("tex_filter", C.c_uint32)]
+        ("display_agx_exp", C.c_float), ("tex_filter", C.c_uint32),
+        ("svgf_alpha", C.c_float), ("svgf_alpha_moments", C.c_float), ("svgf_sigma_l", C.c_float), ("svgf_sigma_z", C.c_float),
+        ("svgf_normal_power_log2", C.c_uint32), ("svgf_iterations", C.c_uint32)]
 
 
 class Counters(C.Structure):
@@ -152,6 +154,8 @@ def set_post_defaults(p):
     p.ae_min_lum, p.ae_max_lum, p.ae_lum_map_exp, p.ae_adaptation_rate = 5e-3, 4.0, 0.5, 1.0
     p.display_tonemapper, p.display_auto_exposure, p.display_saturation, p.display_agx_exp = TONEMAP_NEUTRAL, 1, 1.0, 1.0
     p.tex_filter = TEX_FILTER_ANISOTROPIC_4X      # IndirectLighting.h:243
+    # ZR_PASS_DENOISE (no reference counterpart)
+    p.svgf_alpha, p.svgf_alpha_moments, p.svgf_sigma_l, p.svgf_sigma_z, p.svgf_normal_power_log2, p.svgf_iterations = 0.2, 0.2, 4.0, 1.0, 7, 5
 
 
 COMPOSIT_FIREFLY_FILTER = 1 << 10
