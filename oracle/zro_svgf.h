@@ -143,7 +143,7 @@ static inline void Variance(const float* accum, const float* moments, const std:
             else if (length >= 4.0f) var = zr_max(0.0f, m2 - m1 * m1);
             else
             {
-                const float phiZ = prm.sigmaZ * zr_max(c0.fw, 1e-8f);
+                const float rcpPhiZ = 1.0f / (prm.sigmaZ * zr_max(c0.fw, 1e-8f));
                 float ws = 1.0f;
                 for (int dy = -3; dy <= 3; dy++)
                     for (int dx = -3; dx <= 3; dx++)
@@ -153,7 +153,8 @@ static inline void Variance(const float* accum, const float* moments, const std:
                         if (qx < 0 || qy < 0 || qx >= W || qy >= H) continue;
                         const size_t j = (size_t)qy * W + qx;
                         if (Miss(g[j].z)) continue;
-                        const float wz = zr_abs(c0.z - g[j].z) / (phiZ * zr_sqrt((float)(dx * dx + dy * dy)));
+                        const float rcpDist = 1.0f / zr_sqrt((float)(dx * dx + dy * dy));
+                        const float wz = zr_abs(c0.z - g[j].z) * (rcpPhiZ * rcpDist);
                         const float w = zr_exp(0.0f - wz) * PowNormal(c0.n, g[j].n, prm.normalPowerLog2);
                         col = col + w * f3(accum[4 * j], accum[4 * j + 1], accum[4 * j + 2]);
                         m1 += w * moments[2 * j]; m2 += w * moments[2 * j + 1];
@@ -187,8 +188,8 @@ static inline void Atrous(const float* src, const std::vector<Guide>& g, const P
                         const float k = (dx == 0 ? 0.5f : 0.25f) * (dy == 0 ? 0.5f : 0.25f);
                         blurred += k * src[4 * ((size_t)qy * W + qx) + 3];
                     }
-                const float phiL = prm.sigmaL * zr_sqrt(zr_max(0.0f, blurred)) + 1e-4f;
-                const float phiZ = prm.sigmaZ * zr_max(c0.fw, 1e-8f) * (float)step;
+                const float rcpPhiL = 1.0f / (prm.sigmaL * zr_sqrt(zr_max(0.0f, blurred)) + 1e-4f);
+                const float rcpPhiZ = 1.0f / (prm.sigmaZ * zr_max(c0.fw, 1e-8f) * (float)step);
                 const float lum = Math::Luminance(col);
                 float ws = 1.0f;
                 for (int dy = -2; dy <= 2; dy++)
@@ -201,8 +202,9 @@ static inline void Atrous(const float* src, const std::vector<Guide>& g, const P
                         if (Miss(g[j].z)) continue;
                         const float3 cq = f3(src[4 * j], src[4 * j + 1], src[4 * j + 2]);
                         const float h = kB3[dx < 0 ? -dx : dx] * kB3[dy < 0 ? -dy : dy];
-                        const float wl = zr_abs(lum - Math::Luminance(cq)) / phiL;
-                        const float wz = zr_abs(c0.z - g[j].z) / (phiZ * zr_sqrt((float)(dx * dx + dy * dy)));
+                        const float wl = zr_abs(lum - Math::Luminance(cq)) * rcpPhiL;
+                        const float rcpDist = 1.0f / zr_sqrt((float)(dx * dx + dy * dy));
+                        const float wz = zr_abs(c0.z - g[j].z) * (rcpPhiZ * rcpDist);
                         const float w = (h * zr_exp((0.0f - wl) - wz)) * PowNormal(c0.n, g[j].n, prm.normalPowerLog2);
                         col = col + w * cq;
                         var += (w * w) * src[4 * j + 3];

@@ -14,6 +14,7 @@
 #include "../../zetaray_amd/csrc/zr_rdi.h"
 #include "../../zetaray_amd/csrc/zr_rgi.h"
 #include "../../zetaray_amd/csrc/zr_taa.h"
+#include "../../zetaray_amd/csrc/zr_svgf.h"
 
 static const uint16_t kRptSampleSet[1024] = {
 #include "../../zetaray_amd/csrc/zr_rpt_sample_set.inc"
@@ -185,6 +186,30 @@ void zhx_taa(const float* signal, const float* depth, const uint32_t* motion, co
     taa::TaaFrame F; F.signal = (const F4*)signal; F.depth = depth; F.motion = motion; F.prevOut = prevOut; F.currOut = currOut; F.w = w; F.h = h;
     F.blendWeight = blendWeight; F.temporalIsValid = temporalValid ? 1u : 0u;
     for (uint32_t y = 0; y < h; y++) for (uint32_t x = 0; x < w; x++) taa::TaaPixel(F, x, y);
+}
+// the denoise pass's stage functions (zr_svgf.h) over a whole frame, in the order RenderDenoise launches them; hist_color / hist_moments in and out
+void zhx_svgf(const float* signal, const float* depth, const uint32_t* normal, const uint32_t* motion, const float* prevDepth, const uint32_t* prevNormal,
+    float* histColor, float* histMoments, int temporalValid, const float* params4, uint32_t normalPowerLog2, uint32_t iterations, uint32_t w, uint32_t h, float* out)
+{
+    const size_t n = (size_t)w * h;
+    std::vector<F4> accum(n), guide(n), ping(n), pong(n); std::vector<float> moments(2 * n), fw(n);
+    svgf::SvgfParams sp; sp.alpha = params4[0]; sp.alphaMoments = params4[1]; sp.sigmaL = params4[2]; sp.sigmaZ = params4[3]; sp.normalPowerLog2 = normalPowerLog2; sp.iterations = iterations;
+    svgf::SvgfFrame T; T.signal = (const F4*)signal; T.depth = depth; T.normal = normal; T.motion = motion; T.prevDepth = prevDepth; T.prevNormal = prevNormal;
+    T.histColor = (const F4*)histColor; T.histMoments = histMoments; T.accum = accum.data(); T.moments = moments.data(); T.guide = guide.data(); T.guideFw = fw.data();
+    T.w = w; T.h = h; T.temporalValid = temporalValid ? 1u : 0u; T.prm = sp;
+    for (uint32_t y = 0; y < h; y++) for (uint32_t x = 0; x < w; x++) svgf::TemporalPixel(T, (int)x, (int)y);
+    svgf::FilterFrame V; V.src = accum.data(); V.moments = moments.data(); V.guide = guide.data(); V.guideFw = fw.data(); V.dst = ping.data(); V.lenSrc = accum.data();
+    V.history = iterations == 0 ? (F4*)histColor : nullptr; V.w = w; V.h = h; V.step = 1; V.prm = sp;
+    for (uint32_t y = 0; y < h; y++) for (uint32_t x = 0; x < w; x++) svgf::VariancePixel(V, (int)x, (int)y);
+    F4* src = ping.data(); F4* dst = pong.data();
+    for (uint32_t it = 0; it < iterations; it++)
+    {
+        svgf::FilterFrame A = V; A.src = src; A.dst = dst; A.moments = nullptr; A.step = 1u << it; A.history = it == 0 ? (F4*)histColor : nullptr;
+        for (uint32_t y = 0; y < h; y++) for (uint32_t x = 0; x < w; x++) svgf::AtrousPixel(A, (int)x, (int)y);
+        F4* t = src; src = dst; dst = t;
+    }
+    memcpy(histMoments, moments.data(), 2 * n * sizeof(float));
+    memcpy(out, src, n * sizeof(F4));
 }
 void zhx_latch_heap_offsets(const HxScene* s, const zr_frame_constants* cb) { Latch(s, cb); }
 void zhx_estimate_power(const HxScene* s, float* out) { for (size_t i = 0; i < s->emissives.size(); i++) out[i] = EstimateTriPower(s->view, s->emissives[i]); }

@@ -377,6 +377,23 @@ class HostExecRGI:
         return out
 
 
+def svgf(signal_rgba, depth, normal, motion, prev_depth, prev_normal, hist_color, hist_moments, temporal_valid=True, alpha=0.2, alpha_moments=0.2,
+         sigma_l=4.0, sigma_z=1.0, normal_power_log2=7, iterations=5):
+    """the denoise pass's HIP stage functions (zr_svgf.h) run serially on the host; same interface as oracle.zro.svgf"""
+    sig = np.ascontiguousarray(signal_rgba, np.float32)
+    h, w = sig.shape[:2]
+    d = np.ascontiguousarray(depth, np.float32); n = np.ascontiguousarray(normal, np.uint32); m = np.ascontiguousarray(motion, np.uint32)
+    pd = np.ascontiguousarray(prev_depth, np.float32); pn = np.ascontiguousarray(prev_normal, np.uint32)
+    hc = np.array(hist_color, np.float32, copy=True).reshape(h, w, 4); hm = np.array(hist_moments, np.float32, copy=True).reshape(h, w, 2)
+    out = np.zeros((h, w, 4), np.float32)
+    p4 = np.array([alpha, alpha_moments, sigma_l, sigma_z], np.float32)
+    f = lib().zhx_svgf
+    f.argtypes = [C.c_void_p] * 8 + [C.c_int, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p]
+    f(sig.ctypes.data, d.ctypes.data, n.ctypes.data, m.ctypes.data, pd.ctypes.data, pn.ctypes.data, hc.ctypes.data, hm.ctypes.data,
+      int(bool(temporal_valid)), p4.ctypes.data, int(normal_power_log2), int(iterations), w, h, out.ctypes.data)
+    return out, hc, hm
+
+
 def taa(signal_rgba, depth, motion, prev_out, blend_weight=0.1, temporal_valid=True):
     """TAA.hlsl on an RGBA32F signal (h, w, 4), depth (h, w) f32, motion (h, w) u32 (R16G16_SNORM), history (h, w, 4) f16 bits (u16);
     returns the new RGBA16F output as u16 (alpha = the history buffer's, untouched)."""

@@ -14,6 +14,13 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 FLT_MAX = np.float32(3.4028234663852886e38)
 
 
+@pytest.fixture(scope="module")
+def api():
+    from zetaray_amd import api
+    assert api.device_count() >= 1, "no HIP device visible"
+    return api
+
+
 def _oct32(n):
     """oct32 bits of unit normals (h, w, 3), by the oracle's own encoder convention: (x, y) of the octahedral map as two unorm16"""
     n = n / np.abs(n).sum(-1, keepdims=True)
@@ -116,6 +123,33 @@ def test_oracle_history_follows_motion_and_rejects_disocclusion():
     s4[10:14, 10:14, :3] = 1000.0
     out4, _, _ = zro.svgf(s4, d4, normal, zero, d4, normal, np.zeros_like(hc), np.zeros_like(hm), temporal_valid=False)
     assert np.all(out4[10:14, 10:14, :3] == 1000.0) and out4[..., :3][d4 != FLT_MAX].max() <= 1.0 + 1e-6
+
+
+@pytest.mark.parametrize("iterations", [0, 2, 5])
+def test_hip_stage_functions_match_oracle_on_the_host(iterations):
+    """the HIP pass's stage functions (zr_svgf.h), run serially by the host executor, == the oracle's independent restatement, bit for bit: noisy
+    frames over a G-buffer with a depth / normal edge and misses, a sideways motion of 1.5 px per frame, a history reset, NaNs in the signal"""
+    from oracle import zro
+    from tests.hostexec import zhx
+    h, w = 40, 56
+    rng = np.random.default_rng(7)
+    depth, normal = _planes(h, w, rng)
+    mv = np.uint32(int(round(1.5 / w * 32767.0)) & 0xffff) | (np.uint32(int(round(-0.5 / h * 32767.0)) & 0xffff) << np.uint32(16))
+    state = [(np.zeros((h, w, 4), np.float32), np.zeros((h, w, 2), np.float32)) for _ in range(2)]
+    for f in range(5):
+        sig = np.zeros((h, w, 4), np.float32)
+        sig[..., :3] = rng.uniform(0.0, 3.0, (h, w, 3)).astype(np.float32) * np.where(np.arange(w)[None, :, None] < w // 2, 1.0, 0.2).astype(np.float32)
+        if f == 2:
+            sig[5, 7, 1] = np.nan
+        motion = np.full((h, w), mv if f >= 2 else 0, np.uint32)
+        valid = f not in (0, 3)
+        kw = dict(temporal_valid=valid, iterations=iterations, sigma_l=3.0, normal_power_log2=6)
+        a = zro.svgf(sig, depth, normal, motion, depth, normal, *state[0], **kw)
+        b = zhx.svgf(sig, depth, normal, motion, depth, normal, *state[1], **kw)
+        for name, x, y in zip(("output", "history", "moments"), a, b):
+            assert np.array_equal(x.view(np.uint32), y.view(np.uint32)), f"frame {f}: {name}: {int((x.view(np.uint32) != y.view(np.uint32)).sum())} words differ"
+        state = [(a[1], a[2]), (b[1], b[2])]
+    assert np.isfinite(a[0]).all() and a[1][..., 3].max() >= 2
 
 
 @pytest.mark.gpu

@@ -8,7 +8,7 @@
 // in oracle/zro_svgf.h, which the tests compare bit for bit): parity "unpinned" by construction, DESIGN.md section 5.13.
 //
 // Definition (fp32, operations in the order written, -ffp-contract=off, zr_exp of zr_detmath.h; pixel p = (x, y), W x H image):
-//   guide(p)     = (z, fw, n): z = linear depth of the G-buffer (FLT_MAX = miss), n = oct32 normal bits, fw = max(|z(x+1, y) - z|, |z(x, y+1) - z|)
+//   guide(p)     = (z, fw, n): z = linear depth of the G-buffer (FLT_MAX = miss), n = the decoded oct32 normal, fw = max(|z(x+1, y) - z|, |z(x, y+1) - z|)
 //                  with the neighbour replaced by the one on the other side at the last column / row and differences to a miss counted as 0
 //   temporal(p)  : c = signal.rgb (NaN -> 0), l = Luminance(c).  History position q = (uv - motion) * (W, H) - 0.5 with uv = (p + 0.5) / (W, H);
 //                  the four texels around q with bilinear weights, a texel usable when inside the image, not a miss in the previous G-buffer,
@@ -17,11 +17,11 @@
 //                  a_c = max(alpha, 1 / length'), a_m = max(alpha_moments, 1 / length'), accumulated = hist + a * (new - hist).
 //                  No usable history (or a miss, or temporal_valid == 0): accumulated = new, length' = 1.
 //   variance(p)  : length' >= 4: max(0, m2 - m1 * m1), colour unchanged.  Else the 7 x 7 neighbourhood with weights
-//                  w = exp(0 - wz) * wn (centre 1), wz = |z - zq| / (sigma_z * max(fw, 1e-8) * sqrt(dx^2 + dy^2)), wn as below:
+//                  w = exp(0 - wz) * wn (centre 1), wz = |z - zq| * ((1 / (sigma_z * max(fw, 1e-8))) * (1 / sqrt(dx^2 + dy^2))), wn as below:
 //                  colour = sum(w c) / sum(w), moments likewise, variance = max(0, m2 - m1 * m1) * (4 / length').
 //   atrous_i(p)  : step s = 2^i; v3 = 3 x 3 binomial of the variance (1/4, 1/8, 1/16), phi_l = sigma_l * sqrt(max(0, v3)) + 1e-4,
 //                  phi_z = sigma_z * max(fw, 1e-8) * s; taps q = p + s * (dx, dy), dx, dy in -2..2 except (0, 0), inside the image, not a miss:
-//                  w = h(dx) h(dy) * exp(0 - wl - wz) * wn, h = {1, 2/3, 1/6}[|d|], wl = |l - lq| / phi_l, wz = |z - zq| / (phi_z * sqrt(dx^2 + dy^2)),
+//                  w = h(dx) h(dy) * exp(0 - wl - wz) * wn, h = {1, 2/3, 1/6}[|d|], wl = |l - lq| * (1 / phi_l), wz = |z - zq| * ((1 / phi_z) * (1 / sqrt(dx^2 + dy^2))),
 //                  wn = max(0, dot(n, nq)) raised to 2^normal_power_log2 by repeated squaring.
 //                  colour' = (c + sum w cq) / (1 + sum w), variance' = (v + sum w^2 vq) / (1 + sum w)^2.  Miss pixels pass through.
 //                  The colour after iteration 0 (or after the variance stage when there are no iterations) is the next frame's colour history.
@@ -40,15 +40,15 @@ struct SvgfFrame
     const float* prevDepth; const uint32_t* prevNormal;      // the previous frame's
     const F4* histColor; const float* histMoments;           // previous frame: rgb + history length; (m1, m2) per pixel
     F4* accum; float* moments;                               // this frame's accumulated colour + length, moments (become the history)
-    U4* guide;                                               // z bits, fw bits, oct32 normal, 0
+    F4* guide; float* guideFw;                               // (n.x, n.y, n.z, z) that every tap reads; fw, which only the centre needs
     uint32_t w, h, temporalValid;
     SvgfParams prm;
 };
 
 ZR_HD V3 Sanitize3Z(V3 c) { return any_nan(c) ? v3(0.0f) : c; }
 
-// guide plane of pixel (x, y)
-ZR_HD U4 MakeGuide(const float* depth, const uint32_t* normal, int x, int y, int W, int H)
+// guide planes of pixel (x, y)
+ZR_HD void MakeGuide(const float* depth, const uint32_t* normal, int x, int y, int W, int H, F4* guide, float* guideFw)
 {
     const size_t i = (size_t)y * W + x;
     const float z = depth[i];
@@ -61,8 +61,8 @@ ZR_HD U4 MakeGuide(const float* depth, const uint32_t* normal, int x, int y, int
         if (yn >= 0) { const float zn = depth[(size_t)yn * W + x]; if (zn != ZR_FLT_MAX) dy = zr_abs(zn - z); }
         fw = zr_max(dx, dy);
     }
-    U4 g; g.x = zr_asuint(z); g.y = zr_asuint(fw); g.z = normal[i]; g.w = 0u;
-    return g;
+    guide[i] = f4(DecodeOct32u(normal[i]), z);
+    guideFw[i] = fw;
 }
 
 ZR_HD float NormalWeight(V3 n, V3 nq, uint32_t powerLog2)
@@ -87,7 +87,7 @@ ZR_HD void TemporalPixel(const SvgfFrame& F, int x, int y)
 {
     const int W = (int)F.w, H = (int)F.h;
     const size_t i = (size_t)y * W + x;
-    F.guide[i] = MakeGuide(F.depth, F.normal, x, y, W, H);
+    MakeGuide(F.depth, F.normal, x, y, W, H, F.guide, F.guideFw);
     const F4 s = F.signal[i];
     const V3 c = Sanitize3Z(v3(s.x, s.y, s.z));
     const float l = Luminance(c);
@@ -148,7 +148,7 @@ struct FilterFrame
 {
     const F4* src;            // rgb + variance (a-trous) / rgb + history length (variance stage)
     const float* moments;     // variance stage only
-    const U4* guide;
+    const F4* guide; const float* guideFw;
     F4* dst;                  // rgb + variance
     F4* history;              // != null: the filtered rgb also goes here with the history length of `lenSrc` (colour history of the next frame)
     const F4* lenSrc;
@@ -162,8 +162,8 @@ ZR_HD void VariancePixel(const FilterFrame& F, int x, int y)
     const int W = (int)F.w, H = (int)F.h;
     const size_t i = (size_t)y * W + x;
     const F4 a = F.src[i];
-    const U4 g = F.guide[i];
-    const float z = zr_asfloat(g.x), len = a.w;
+    const F4 g = F.guide[i];
+    const float z = g.w, len = a.w;
     V3 c = v3(a.x, a.y, a.z);
     float m1 = F.moments[2 * i], m2 = F.moments[2 * i + 1];
     float var;
@@ -171,8 +171,8 @@ ZR_HD void VariancePixel(const FilterFrame& F, int x, int y)
     else if (len >= 4.0f) var = zr_max(0.0f, m2 - m1 * m1);
     else
     {
-        const V3 n = DecodeOct32u(g.z);
-        const float phiZ = F.prm.sigmaZ * zr_max(zr_asfloat(g.y), 1e-8f);
+        const V3 n = v3(g.x, g.y, g.z);
+        const float invPhiZ = 1.0f / (F.prm.sigmaZ * zr_max(F.guideFw[i], 1e-8f));
         float wsum = 1.0f;
         for (int dy = -3; dy <= 3; dy++)
             for (int dx = -3; dx <= 3; dx++)
@@ -181,11 +181,11 @@ ZR_HD void VariancePixel(const FilterFrame& F, int x, int y)
                 const int qx = x + dx, qy = y + dy;
                 if (qx < 0 || qy < 0 || qx >= W || qy >= H) continue;
                 const size_t j = (size_t)qy * W + qx;
-                const U4 gq = F.guide[j];
-                const float zq = zr_asfloat(gq.x);
+                const F4 gq = F.guide[j];
+                const float zq = gq.w;
                 if (zq == ZR_FLT_MAX) continue;
-                const float wz = zr_abs(z - zq) / (phiZ * zr_sqrt((float)(dx * dx + dy * dy)));
-                const float wgt = zr_exp(0.0f - wz) * NormalWeight(n, DecodeOct32u(gq.z), F.prm.normalPowerLog2);
+                const float wz = zr_abs(z - zq) * (invPhiZ * (1.0f / zr_sqrt((float)(dx * dx + dy * dy))));
+                const float wgt = zr_exp(0.0f - wz) * NormalWeight(n, v3(gq.x, gq.y, gq.z), F.prm.normalPowerLog2);
                 const F4 q = F.src[j];
                 c = c + wgt * v3(q.x, q.y, q.z);
                 m1 += wgt * F.moments[2 * j]; m2 += wgt * F.moments[2 * j + 1];
@@ -198,14 +198,23 @@ ZR_HD void VariancePixel(const FilterFrame& F, int x, int y)
     if (F.history) F.history[i] = f4(c, len);
 }
 
+// where an a-trous iteration reads its taps from: the planes, or a tile of them staged in LDS (zr_api.hip: k_svgf_atrous_lds)
+struct PlaneTaps
+{
+    const F4* src; const F4* guide; int W;
+    ZR_HDM F4 Src(int x, int y) const { return src[(size_t)y * W + x]; }
+    ZR_HDM F4 Guide(int x, int y) const { return guide[(size_t)y * W + x]; }
+};
+
 // one a-trous iteration
-ZR_HD void AtrousPixel(const FilterFrame& F, int x, int y)
+template<class Taps>
+ZR_HD void AtrousPixelT(const FilterFrame& F, int x, int y, const Taps& taps)
 {
     const int W = (int)F.w, H = (int)F.h, s = (int)F.step;
     const size_t i = (size_t)y * W + x;
-    const F4 a = F.src[i];
-    const U4 g = F.guide[i];
-    const float z = zr_asfloat(g.x);
+    const F4 a = taps.Src(x, y);
+    const F4 g = taps.Guide(x, y);
+    const float z = g.w;
     V3 c = v3(a.x, a.y, a.z); float var = a.w;
     if (z != ZR_FLT_MAX)
     {
@@ -216,11 +225,11 @@ ZR_HD void AtrousPixel(const FilterFrame& F, int x, int y)
             {
                 const int qx = x + dx < 0 ? 0 : (x + dx >= W ? W - 1 : x + dx), qy = y + dy < 0 ? 0 : (y + dy >= H ? H - 1 : y + dy);
                 const float k = (dx == 0 ? 0.5f : 0.25f) * (dy == 0 ? 0.5f : 0.25f);
-                v3x3 += k * F.src[(size_t)qy * W + qx].w;
+                v3x3 += k * taps.Src(qx, qy).w;
             }
-        const float phiL = F.prm.sigmaL * zr_sqrt(zr_max(0.0f, v3x3)) + 1e-4f;
-        const float phiZ = F.prm.sigmaZ * zr_max(zr_asfloat(g.y), 1e-8f) * (float)s;
-        const V3 n = DecodeOct32u(g.z);
+        const float invPhiL = 1.0f / (F.prm.sigmaL * zr_sqrt(zr_max(0.0f, v3x3)) + 1e-4f);
+        const float invPhiZ = 1.0f / (F.prm.sigmaZ * zr_max(F.guideFw[i], 1e-8f) * (float)s);
+        const V3 n = v3(g.x, g.y, g.z);
         const float l = Luminance(c);
         float wsum = 1.0f;
         for (int dy = -2; dy <= 2; dy++)
@@ -229,17 +238,16 @@ ZR_HD void AtrousPixel(const FilterFrame& F, int x, int y)
                 if (dx == 0 && dy == 0) continue;
                 const int qx = x + dx * s, qy = y + dy * s;
                 if (qx < 0 || qy < 0 || qx >= W || qy >= H) continue;
-                const size_t j = (size_t)qy * W + qx;
-                const U4 gq = F.guide[j];
-                const float zq = zr_asfloat(gq.x);
+                const F4 gq = taps.Guide(qx, qy);
+                const float zq = gq.w;
                 if (zq == ZR_FLT_MAX) continue;
-                const F4 q = F.src[j];
+                const F4 q = taps.Src(qx, qy);
                 const V3 cq = v3(q.x, q.y, q.z);
                 const int ax = dx < 0 ? -dx : dx, ay = dy < 0 ? -dy : dy;
                 const float hx = ax == 0 ? 1.0f : (ax == 1 ? 2.0f / 3.0f : 1.0f / 6.0f), hy = ay == 0 ? 1.0f : (ay == 1 ? 2.0f / 3.0f : 1.0f / 6.0f);
-                const float wl = zr_abs(l - Luminance(cq)) / phiL;
-                const float wz = zr_abs(z - zq) / (phiZ * zr_sqrt((float)(dx * dx + dy * dy)));
-                const float wgt = ((hx * hy) * zr_exp((0.0f - wl) - wz)) * NormalWeight(n, DecodeOct32u(gq.z), F.prm.normalPowerLog2);
+                const float wl = zr_abs(l - Luminance(cq)) * invPhiL;
+                const float wz = zr_abs(z - zq) * (invPhiZ * (1.0f / zr_sqrt((float)(dx * dx + dy * dy))));
+                const float wgt = ((hx * hy) * zr_exp((0.0f - wl) - wz)) * NormalWeight(n, v3(gq.x, gq.y, gq.z), F.prm.normalPowerLog2);
                 c = c + wgt * cq;
                 var += (wgt * wgt) * q.w;
                 wsum += wgt;
@@ -250,6 +258,8 @@ ZR_HD void AtrousPixel(const FilterFrame& F, int x, int y)
     F.dst[i] = f4(c, var);
     if (F.history) F.history[i] = f4(c, F.lenSrc[i].w);
 }
+ZR_HD void AtrousPixel(const FilterFrame& F, int x, int y)
+{ PlaneTaps t; t.src = F.src; t.guide = F.guide; t.W = (int)F.w; AtrousPixelT(F, x, y, t); }
 
 } // namespace svgf
 } // namespace zr
