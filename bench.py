@@ -399,10 +399,9 @@ def main():
     }
 
     if os.environ.get("ZR_K11") == "trip" and rpt and world == 1:
-        # diagnostic build of K11: path state stored + reloaded at every bounce boundary
+        # diagnostic build of K11: lanes alive at its bounce boundaries; the timings of this run mean nothing
         a, b, wds = r.p_indirect.debug_trip_stats()
-        out["config"]["k11_state_round_trip"] = {"alive_lanes_at_bounce_boundaries": a, "lane_slots": b, "alive_frac": round(a / max(b, 1), 4),
-                                                 "state_bytes_per_path": 4 * wds}
+        out["config"]["k11_bounce_boundaries"] = {"alive_lanes": a, "lane_slots": b, "alive_frac": round(a / max(b, 1), 4), "carried_state_bytes_per_path": 4 * wds}
     if rank == 0 and world == 1:
         # ---- roofline of the dominant kernel: hipEvent timing inside the library over a few timed frames
         r.p_gbuffer.enable_timing(True)

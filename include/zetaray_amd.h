@@ -393,9 +393,9 @@ int zr_pass_read_counters(zr_pass* pass, void* hip_stream, zr_counters* out, int
  * reference counterpart (the reference renders on one GPU).  Costs one atomic per wave while enabled. */
 int zr_pass_enable_cost_map(zr_pass* pass, int enable);
 int zr_pass_read_cost_map(zr_pass* pass, void* hip_stream, uint32_t* out_cells, uint32_t cells_w, uint32_t cells_h, int reset);
-/* diagnostic, ReSTIR PT with ZR_K11=trip in the environment: K11 stores and reloads each live path's state through SoA planes at every bounce
- * boundary -- the traffic a per-bounce relaunch with path compaction would have to move.  out = {lanes alive at the boundaries, lane slots of the waves
- * that passed them, 32-bit words per path state}.  Waits for the device.  No reference counterpart. */
+/* diagnostic, ReSTIR PT with ZR_K11=trip in the environment: K11 counts the lanes alive at its bounce boundaries -- what compaction between
+ * bounces could win back.  out = {lanes alive at the boundaries, lane slots of the waves that passed them, 32-bit words of path state carried across a
+ * boundary}, accumulated since the pass was created.  Waits for the device.  No reference counterpart. */
 int zr_pass_debug_trip_stats(zr_pass* pass, uint64_t out[3]);
 /* the same counters split by the kernel that issued the queries (not reset; roofline bookkeeping of bench.py) */
 int zr_pass_read_kernel_counters(zr_pass* pass, void* hip_stream, uint32_t max_entries, const char** names,

@@ -2,7 +2,7 @@
 # of both (FETCH_SIZE / WRITE_SIZE passes); then the k_rgi primary-hit rematerialisation A/B (libzr_rgi_noremat.so = without)
 R=$GRAFT_REPO_ROOT
 cd $R
-P='import sys,json; d=json.loads(sys.stdin.read()); k=d["roofline"]["kernel_ms_per_frame"]; print(json.dumps({"ms": d["ms_per_step"], "k": {a: b for a, b in k.items() if b > 0.3}, "trip": d["config"].get("k11_state_round_trip")}))'
+P='import sys,json; d=json.loads(sys.stdin.read()); k=d["roofline"]["kernel_ms_per_frame"]; print(json.dumps({"ms": d["ms_per_step"], "k": {a: b for a, b in k.items() if b > 0.3}, "trip": d["config"].get("k11_bounce_boundaries")}))'
 for mode in inline trip; do
   for a in "" "--config 4"; do
     echo "== K11 $mode $a"; ZR_K11=$mode timeout 600 python bench.py --gpus 1 --steps 32 --warmup 8 --settle 16 --no-cpu-baseline $a 2>&1 | tail -1 | python -c "$P"

@@ -233,7 +233,7 @@ __global__ void __launch_bounds__(kRptBlock) ZR_WAVES_PATHTRACE_TEX k_rpt_pathtr
 // On scenes where paths end early (Cornell box: open front, paths that reach the light) the megakernel's waves run every bounce with the lanes
 // of the paths that are still alive -- 35 % of them on average at the bounce boundaries of the Cornell frame (zr_pass_debug_trip_stats), 95 % on
 // the atrium.  Here a bounce is a kernel: k_rpt_pt_first runs the prologue and the first bounce for every pixel in 16 x 4 tiles like the
-// megakernel, then the paths still alive move into consecutive slots of SoA planes (84 words = 336 B per path, rpt::PtCarry; slots come from a
+// megakernel, then the paths still alive move into consecutive slots of SoA planes (78 words = 312 B per path, rpt::PtCarry; slots come from a
 // wave-aggregated atomic, so a wave's paths sit side by side and the stores coalesce); k_rpt_pt_next runs one more bounce over slots
 // 0 .. count - 1 with full waves and compacts again; a path that ends writes its reservoir (PtFinishLane) from wherever it is.  Per-pixel
 // arithmetic is the megakernel's, statement for statement, so the results are bit-identical; tiles whose paths can reach Russian roulette (a
@@ -306,35 +306,12 @@ __global__ void __launch_bounds__(kRptBlock) ZR_WAVES_PATHTRACE k_rpt_pt_next(rp
     FlushRayCountersCost(F, counters, cnt, P.x, P.y, P.valid, t0);
 }
 
-// ------------------------------------------------------------------------------------------------ path-state round trip (round 3 diagnostic)
-// What a per-bounce relaunch of K11 (paths compacted between bounces, state in SoA planes) would have to move: the same megakernel, but at every
-// bounce boundary each live path stores its state -- everything PtPhaseA / PtPhaseB / PtFinishLane read later -- into [word][pixel] planes and
-// loads it back (a compiler barrier in between, so nothing is forwarded in registers).  No relaunch, no compaction, perfectly coalesced: the
-// LOWER bound of that design's overhead, measured instead of estimated.  It also counts the lanes alive at each boundary, i.e. what compaction
-// could win back.  Results are unchanged (the state that comes back is the state that went out).  ZR_K11=trip, emissive untextured permutation.
-template<class T> __device__ __forceinline__ void TripStore(const T& v, uint32_t*& p, size_t stride, uint32_t& words)
-{
-    constexpr int n = (int)((sizeof(T) + 3) / 4);
-    uint32_t w[n];
-    for (int i = 0; i < n; i++) w[i] = 0;
-    __builtin_memcpy(w, &v, sizeof(T));
-#pragma unroll
-    for (int i = 0; i < n; i++) p[(size_t)i * stride] = w[i];
-    p += (size_t)n * stride; words += n;
-}
-template<class T> __device__ __forceinline__ void TripLoad(T& v, const uint32_t*& p, size_t stride)
-{
-    constexpr int n = (int)((sizeof(T) + 3) / 4);
-    uint32_t w[n];
-#pragma unroll
-    for (int i = 0; i < n; i++) w[i] = p[(size_t)i * stride];
-    __builtin_memcpy(&v, w, sizeof(T));
-    p += (size_t)n * stride;
-}
-// the state live across a bounce boundary of the untextured emissive kernel (rd / dpdx / dpdy are the textured permutation's)
-#define ZR_TRIP_FIELDS(X) X(P.pos) X(P.normal) X(P.surface) X(P.bs) X(P.rngReplay) X(P.rngThread) X(P.rngGroup) X(P.rc) X(P.r) X(P.li) X(P.throughput) \
-    X(P.throughput_k) X(P.bounce) X(P.prevHit) X(P.eta_curr) X(P.eta_next) X(P.inMedium) X(P.nextHit) X(P.seed_replay) X(P.sampleSetIdx) X(P.maxNumBounces) \
-    X(P.hit) X(P.tr) X(P.prevPdf) X(P.prevLobe) X(P.pathVertex)
+// ------------------------------------------------------------------------------------------------ alive-lane diagnostic (round 3)
+// The megakernel with counters at its bounce boundaries: lanes alive / lane slots of the waves that pass a boundary (zr_pass_debug_trip_stats) --
+// what compaction between bounces could win back: 0.35 on the Cornell frame, 0.95 on the atrium.  It also sends the carried state (rpt::PtCarry)
+// through memory and back at each boundary; results are unchanged, but the kernel's TIME means nothing: in the middle of the loop the 78 carried
+// words all become live at one point and go through scratch (624 -> 1232 B per lane, 0.95 -> 2.6 ms).  What carrying the state really costs is
+// measured by the kernels above.  ZR_K11=trip, emissive untextured permutation.
 template<bool NODE_CACHE>
 __device__ __forceinline__ void RptPathtraceBodyTrip(rpt::RptFrame& F, const zr_frame_constants& g, uint32_t tilesX, unsigned long long* counters)
 {
@@ -365,20 +342,15 @@ __device__ __forceinline__ void RptPathtraceBodyTrip(rpt::RptFrame& F, const zr_
         if (live != 0) { alive += (uint32_t)__popcll((unsigned long long)live); slots += 64u; }
         if (P.active)
         {
-            const size_t px = rpt::Pix(F.gb, x, y);
-            uint32_t* o = F.trip + px; words = 0;
-#define ZR_TRIP_ST(f) TripStore(f, o, F.tripStride, words);
-            ZR_TRIP_FIELDS(ZR_TRIP_ST)
-#undef ZR_TRIP_ST
+            rpt::PtCarryStore st; st.p = F.trip + rpt::Pix(F.gb, x, y); st.stride = F.tripStride;
+            rpt::PtCarry(st, P);
+            words = st.n;
         }
         __asm__ volatile("" ::: "memory");
         if (P.active)
         {
-            const size_t px = rpt::Pix(F.gb, x, y);
-            const uint32_t* i = F.trip + px;
-#define ZR_TRIP_LD(f) TripLoad(f, i, F.tripStride);
-            ZR_TRIP_FIELDS(ZR_TRIP_LD)
-#undef ZR_TRIP_LD
+            rpt::PtCarryLoad ld; ld.p = F.trip + rpt::Pix(F.gb, x, y); ld.stride = F.tripStride;
+            rpt::PtCarry(ld, P);
         }
     }
     rpt::PtFinishLane(F.gb, F.prm, F.cur, F.tex, F.finalRGBA, P);

@@ -1472,7 +1472,7 @@ ZR_HD void PtPhaseB(const SceneView& sc, const RptParams& prm, PTLane& P, uint32
 // words: what K11 with per-bounce path compaction (zr_kernels.h: k_rpt_pt_first / k_rpt_pt_next) moves through its SoA planes.  Everything
 // else in PTLane is either recomputed by PtPhaseA before it is read (surface, hit, tr, prevPdf / prevLobe, pathVertex, eta_next, atRR) or dead.
 // One function enumerates the fields for both directions: V::f / u / i move a float / uint32_t / int, V::Store says which way.
-static constexpr uint32_t kPtCarryWords = 84;
+static constexpr uint32_t kPtCarryWords = 78;
 template<class V> ZR_HD void PtCarryRc(V& v, Reconnection& rc)
 {
     v.f(rc.x_k.x); v.f(rc.x_k.y); v.f(rc.x_k.z); v.u(rc.ID); v.u(rc.meshIdx); v.f(rc.partialJacobian); v.f(rc.w.x); v.f(rc.w.y); v.f(rc.w.z);
@@ -1948,8 +1948,8 @@ struct RptFrame
     // GPU time per 32 x 32-pixel cell of the planes (cell (0, 0) at the plane origin gb.x0, gb.y0): wave lifetimes of K11 / K14 / K16, one
     // atomic per wave: what the cost-balanced tile split of the multi-GPU path is computed from (tiling.balanced_layout); null = off
     uint32_t* costMap; uint32_t costW;
-    // diagnostic (ZR_K11=trip, zr_kernels.h: k_rpt_pathtrace_trip): SoA planes the path state makes a round trip through at every bounce boundary
-    // + {alive lanes, lane slots, words per path} of the waves that pass the boundary
+    // diagnostic (ZR_K11=trip, zr_kernels.h: k_rpt_pathtrace_trip): {alive lanes, lane slots, words per path} of the waves that pass a bounce
+    // boundary, and the planes the carried state is sent through there
     uint32_t* trip; unsigned long long* tripStats; size_t tripStride;
     // K11 with per-bounce path compaction: path state planes [word][slot] written by one bounce's kernel and read by the next (ping-pong),
     // carryCount[b] = paths alive after bounce b (their slots are 0 .. count - 1), carryCap = slots per plane
