@@ -474,6 +474,9 @@ def main():
         else:
             bytes_launch = 0.0
         achieved = bytes_launch / (avg_ms * 1e-3) / 1e9
+        plane_px = (RPT_PIXEL_BYTES.get(dom) if dom.startswith("rpt_") else (23 + 2 * 40 + 27 + 16) if dom == "rgi" else (27 * 3 + 2 * 13 + 32) if dom in ("sdi_temporal", "sdi_spatial", "rdi_temporal", "rdi_spatial") else
+                    47 if dom == "gbuffer" else DENOISE_PIXEL_BYTES.get(dom))
+        plane_bytes = round(plane_px * W * H) if plane_px else None
         frame_bytes = (BYTES_CLOSEST * (cc / nfr + W * H) + BYTES_SHADOW * (cs / nfr) + (47 + 38 + 16) * W * H)
         # measured HBM-side bytes per launch of that kernel: PMC passes (FETCH_SIZE x 2 x 1024 + WRITE_SIZE x 1024, MI355X_MICROARCH.md) of
         # exactly this command, collected by scripts/gpu_pmc.sh and committed under profiles/ (rocprofv3 cannot run inside the bench)
@@ -506,6 +509,9 @@ def main():
                            "unit": "GB/s", "frac": round(hbm_frac, 5), "traffic": traffic, "traffic_unit": "bytes per launch",
                            "traffic_source": traffic_src, "algorithmic_bytes_per_launch": round(bytes_launch),
                            "traffic_over_algorithmic": (round(traffic / bytes_launch, 3) if (traffic and bytes_launch) else None),
+                           # against the planes alone (what the pass must read / write per pixel; the per-ray record bytes of SURVEY 8(d) never
+                           # leave the registers of a megakernel): everything above ~1 is scene data that missed the caches + scratch spills
+                           "plane_bytes_per_launch": plane_bytes, "traffic_over_plane_bytes": (round(traffic / plane_bytes, 3) if (traffic and plane_bytes) else None),
                            "measured_traffic_GBs": (round(traffic / (avg_ms * 1e-3) / 1e9, 2) if traffic else None),
                            "valu": valu,
                            "avg_launch_ms": round(avg_ms, 4), "launches_per_frame": launches / nfr,

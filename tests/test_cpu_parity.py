@@ -323,3 +323,22 @@ def test_thread_sort_maps_are_tile_permutations(oracle_emissive, cornell_emissiv
         assert len(np.unique(py * w + px)) == w * h, f"{name}: not a permutation"
     # the spatial maps of the last frame really sort: a third of the positions at least point elsewhere
     assert ((o.plane("map_ntc").reshape(h, w) & 0x7fff) != (31 | (31 << 7))).mean() > 0.3
+
+
+def test_c_and_python_parameter_defaults_agree():
+    """zr_params_default (what zr_pass_create and the C++ host start from) == wire.default_params(), field by field -- including the blocks of
+    the post and denoise passes"""
+    import ctypes as C
+    from zetaray_amd import api, wire
+    c = wire.Params()
+    L = api.lib()
+    L.zr_params_default.argtypes = [C.c_void_p]
+    assert L.zr_params_default(C.byref(c)) == 0
+    p = wire.default_params()
+    for name, _ in wire.Params._fields_:
+        a, b = getattr(c, name), getattr(p, name)
+        if hasattr(a, "__len__"):
+            a, b = list(a), list(b)
+        if name in ("lvg_grid_dim", "lvg_extents", "lvg_offset_y", "use_lvg"):
+            continue      # the light voxel grid block is filled in by the caller that turns it on (DefaultRendererImpl.h:73-77)
+        assert a == b or (isinstance(a, float) and abs(a - b) <= 1e-7 * abs(b)), (name, a, b)

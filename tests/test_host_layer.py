@@ -232,3 +232,29 @@ def test_cpp_passes_render_post_chain_to_display():
     assert np.array_equal(exposure.view(np.uint32), e.view(np.uint32)) and exposure[0] > 0
     assert np.array_equal(disp.view(np.uint32), want.view(np.uint32))
     assert np.array_equal(srgb, want_srgb)
+
+
+@pytest.mark.gpu
+def test_cpp_denoise_node_in_the_render_graph(cornell_emissive, oracle_emissive):
+    """The C++ mirror's Denoise node (no reference counterpart; RenderPass-shaped like the others) scheduled after IndirectLighting by the
+    RenderGraph, 4 frames of ReSTIR PT: its output == the oracle's denoise pass run on the oracle's ReSTIR PT frames and G-buffers."""
+    from oracle import zro
+    w, h, n, iters = 96, 64, 4, 3
+    cbs = np.ascontiguousarray(np.stack([scene_io.make_frame_constants(w, h, frame_num=f, num_emissives=len(cornell_emissive.emissives)) for f in range(1, n + 1)]))
+    desc = cornell_emissive.desc()
+    final, den = np.zeros((h, w, 4), np.float32), np.zeros((h, w, 4), np.float32)
+    L = _lib()
+    L.zrh_render_sequence_denoise.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]
+    assert L.zrh_render_sequence_denoise(C.addressof(desc), cbs.ctypes.data, n, w, h, iters, final.ctypes.data, den.ctypes.data) == 0
+    o = zro.OracleRPT(oracle_emissive, w, h)
+    hc, hm = np.zeros((h, w, 4), np.float32), np.zeros((h, w, 2), np.float32)
+    prev = None
+    for f in range(n):
+        sig = o.render(cbs[f], wire.default_params()).copy()
+        planes, _keep = oracle_emissive.gbuffer(cbs[f])
+        depth, normal, motion = planes[7].reshape(h, w).copy(), planes[1].reshape(h, w).copy(), planes[3].reshape(h, w).copy()
+        pd, pn = (depth, normal) if prev is None else prev
+        want, hc, hm = zro.svgf(sig, depth, normal, motion, pd, pn, hc, hm, temporal_valid=f > 0, iterations=iters)
+        prev = (depth, normal)
+    assert np.array_equal(final.view(np.uint32), sig.view(np.uint32))
+    assert np.array_equal(den.view(np.uint32), want.view(np.uint32))

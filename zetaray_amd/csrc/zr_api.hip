@@ -1068,6 +1068,7 @@ int zr_params_default(zr_params* p)
     p->taa_blend_weight = 0.1f;      // TAA.h:72
     p->ae_min_lum = 5e-3f; p->ae_max_lum = 4.0f; p->ae_lum_map_exp = 0.5f; p->ae_adaptation_rate = 1.0f;      // AutoExposure.h:73-81
     p->tex_filter = ZR_TEX_FILTER_ANISOTROPIC_4X;      // IndirectLighting.h:243
+    p->svgf_alpha = 0.2f; p->svgf_alpha_moments = 0.2f; p->svgf_sigma_l = 4.0f; p->svgf_sigma_z = 1.0f; p->svgf_normal_power_log2 = 7; p->svgf_iterations = 5;   // ZR_PASS_DENOISE (zr_svgf.h)
     p->display_tonemapper = ZR_TONEMAP_NEUTRAL; p->display_auto_exposure = 1; p->display_saturation = 1.0f; p->display_agx_exp = 1.0f;   // Display.cpp:69-74
     p->use_lvg = 0; p->lvg_grid_dim = 32u | (8u << 10) | (40u << 20);
     p->lvg_extents[0] = 0.6f; p->lvg_extents[1] = 0.45f; p->lvg_extents[2] = 0.6f; p->lvg_offset_y = 0.1f;

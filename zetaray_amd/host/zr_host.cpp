@@ -324,6 +324,22 @@ void* TAA::GetOutput(SHADER_OUT_RES i) const
 }
 void TAA::Render(Core::CommandList& cl) { ZR_CHECK(zr_pass_render(m_pass, cl.Stream(), &m_ctx->frameConstants, m_ctx->scene, m_ctx->gbuffer)); }
 
+void Denoise::Init(FrameContext* ctx) { InitRenderPass(ZR_PASS_DENOISE, ctx, 0); ZR_CHECK(zr_params_default(&m_params)); }
+void Denoise::OnWindowResized() { ZR_CHECK(zr_pass_resize(m_pass, m_ctx->renderWidth, m_ctx->renderHeight)); }
+void Denoise::SetCPUDescriptor(SHADER_IN_CPU_DESC, const void* dev) { ZR_CHECK(zr_pass_set_input(m_pass, ZR_IN_DENOISE_SIGNAL, dev)); }
+void Denoise::SetIterations(uint32_t n) { m_params.svgf_iterations = n; ZR_CHECK(zr_pass_set_params(m_pass, &m_params)); }
+void Denoise::SetSigmas(float l, float z, uint32_t nlog2)
+{ m_params.svgf_sigma_l = l; m_params.svgf_sigma_z = z; m_params.svgf_normal_power_log2 = nlog2; ZR_CHECK(zr_pass_set_params(m_pass, &m_params)); }
+void Denoise::ResetTemporal() { ZR_CHECK(zr_pass_reset_temporal(m_pass)); }
+void* Denoise::GetOutput(SHADER_OUT_RES i) const
+{
+    if (i >= SHADER_OUT_RES::COUNT) { std::fprintf(stderr, "Invalid shader output.\n"); std::abort(); }
+    void* dev = nullptr; uint32_t w, h, bpp;
+    ZR_CHECK(zr_pass_get_output(m_pass, ZR_OUT_DENOISED, &dev, &w, &h, &bpp));
+    return dev;
+}
+void Denoise::Render(Core::CommandList& cl) { ZR_CHECK(zr_pass_render(m_pass, cl.Stream(), &m_ctx->frameConstants, m_ctx->scene, m_ctx->gbuffer)); }
+
 void AutoExposure::Init(FrameContext* ctx) { InitRenderPass(ZR_PASS_AUTO_EXPOSURE, ctx, 0); ZR_CHECK(zr_params_default(&m_params)); }
 void AutoExposure::OnWindowResized() { ZR_CHECK(zr_pass_resize(m_pass, m_ctx->renderWidth, m_ctx->renderHeight)); }
 void AutoExposure::SetDescriptor(SHADER_IN_DESC, const void* dev, bool rgba16f) { ZR_CHECK(zr_pass_set_input(m_pass, rgba16f ? ZR_IN_POST_SIGNAL_F16 : ZR_IN_POST_SIGNAL_F32, dev)); }
@@ -643,6 +659,51 @@ int zrh_render_sequence_sky_display(const zr_scene_desc* desc, const zr_frame_co
         if (taaOut && hipMemcpy(taaOut, taa.GetOutput(RenderPass::TAA::SHADER_OUT_RES::OUTPUT_A), (size_t)w * h * 8, hipMemcpyDeviceToHost) != hipSuccess) return -1;
         if (hipMemcpy(finalOut, ind.GetOutput(RenderPass::IndirectLighting::SHADER_OUT_RES::FINAL), (size_t)w * h * 16, hipMemcpyDeviceToHost) != hipSuccess) return -1;
         if (skyDiOut && hipMemcpy(skyDiOut, sdi.GetOutput(RenderPass::SkyDI::SHADER_OUT_RES::DENOISED), (size_t)w * h * 16, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    }
+    zr_gbuffer_destroy(ctx.gbuffer);
+    zr_scene_destroy(ctx.scene);
+    return 0;
+}
+
+// GBuffer -> PreLighting -> IndirectLighting (ReSTIR PT) -> Denoise through the RenderGraph, n frames; finalOut = the indirect pass's FINAL and
+// denoisedOut = the Denoise node's output (RGBA32F: rgb + variance) of the last frame
+int zrh_render_sequence_denoise(const zr_scene_desc* desc, const zr_frame_constants* cbs, uint32_t n, uint32_t w, uint32_t h, uint32_t iterations, float* finalOut,
+    float* denoisedOut)
+{
+    RenderPass::FrameContext ctx;
+    ctx.device = 0; ctx.renderWidth = w; ctx.renderHeight = h;
+    ZR_CHECK(zr_scene_create(0, desc, &ctx.scene));
+    ZR_CHECK(zr_gbuffer_create(0, w, h, &ctx.gbuffer));
+    {
+        RenderPass::GBufferRT gb; RenderPass::PreLighting pre; RenderPass::IndirectLighting ind; RenderPass::Denoise dn;
+        gb.Init(&ctx); pre.Init(&ctx); ind.Init(&ctx, RenderPass::IndirectLighting::INTEGRATOR::ReSTIR_PT); dn.Init(&ctx);
+        dn.SetIterations(iterations);
+        dn.SetCPUDescriptor(RenderPass::Denoise::SHADER_IN_CPU_DESC::SIGNAL, ind.GetOutput(RenderPass::IndirectLighting::SHADER_OUT_RES::FINAL));
+        Core::RenderGraph g;
+        enum : uint64_t { R_GBUF = 1, R_LIGHTS, R_IND, R_DENOISED };
+        for (uint32_t f = 0; f < n; f++)
+        {
+            ctx.frameConstants = cbs[f];
+            g.BeginFrame();
+            auto hGB = g.RegisterRenderPass("GBuffer", Core::RENDER_NODE_TYPE::COMPUTE, Core::MakeDelegate(&gb, &RenderPass::GBufferRT::Render));
+            auto hPre = g.RegisterRenderPass("PreLighting", Core::RENDER_NODE_TYPE::COMPUTE, Core::MakeDelegate(&pre, &RenderPass::PreLighting::Render));
+            auto hInd = g.RegisterRenderPass("Indirect", Core::RENDER_NODE_TYPE::COMPUTE, Core::MakeDelegate(&ind, &RenderPass::IndirectLighting::Render));
+            auto hDn = g.RegisterRenderPass("Denoise", Core::RENDER_NODE_TYPE::COMPUTE, Core::MakeDelegate(&dn, &RenderPass::Denoise::Render));
+            g.RegisterResource(nullptr, R_GBUF); g.RegisterResource(nullptr, R_LIGHTS);
+            g.RegisterResource(ind.GetOutput(RenderPass::IndirectLighting::SHADER_OUT_RES::FINAL), R_IND);
+            g.RegisterResource(nullptr, R_DENOISED);      // ping-pong target, identified by its path id
+            g.MoveToPostRegister();
+            g.AddOutput(hGB, R_GBUF, Core::STATE_UNORDERED_ACCESS);
+            g.AddOutput(hPre, R_LIGHTS, Core::STATE_UNORDERED_ACCESS);
+            g.AddInput(hInd, R_GBUF, Core::STATE_SHADER_READ); g.AddInput(hInd, R_LIGHTS, Core::STATE_SHADER_READ); g.AddOutput(hInd, R_IND, Core::STATE_UNORDERED_ACCESS);
+            g.AddInput(hDn, R_IND, Core::STATE_SHADER_READ); g.AddInput(hDn, R_GBUF, Core::STATE_SHADER_READ); g.AddOutput(hDn, R_DENOISED, Core::STATE_UNORDERED_ACCESS);
+            Support::TaskSet ts;
+            g.Build(ts);
+            ts.Run(true);
+            g.WaitForFrame();
+        }
+        if (hipMemcpy(finalOut, ind.GetOutput(RenderPass::IndirectLighting::SHADER_OUT_RES::FINAL), (size_t)w * h * 16, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+        if (hipMemcpy(denoisedOut, dn.GetOutput(RenderPass::Denoise::SHADER_OUT_RES::DENOISED), (size_t)w * h * 16, hipMemcpyDeviceToHost) != hipSuccess) return -1;
     }
     zr_gbuffer_destroy(ctx.gbuffer);
     zr_scene_destroy(ctx.scene);

@@ -270,6 +270,25 @@ namespace RenderPass {
         zr_params m_params{};
     };
 
+    // Denoise: NO reference counterpart (the reference has no denoiser; BASELINE config 5 asks for one).  Shaped like the reference's other post
+    // nodes so that a RenderGraph can schedule it between IndirectLighting and Compositing: input = the indirect pass's radiance, output = the
+    // filtered radiance (rgb + variance).  zetaray_amd/csrc/zr_svgf.h defines the filter.
+    struct Denoise final : public RenderPassBase
+    {
+        enum class SHADER_IN_CPU_DESC { SIGNAL, COUNT };
+        enum class SHADER_OUT_RES { DENOISED, COUNT };
+        void Init(FrameContext* ctx);
+        void OnWindowResized();
+        void SetCPUDescriptor(SHADER_IN_CPU_DESC i, const void* devicePlane);       // RGBA32F signal
+        void SetIterations(uint32_t n);                                              // a-trous iterations, 0..8 (default 5)
+        void SetSigmas(float luminance, float depth, uint32_t normalPowerLog2);
+        void ResetTemporal();
+        void* GetOutput(SHADER_OUT_RES i) const;
+        void Render(Core::CommandList& cmdList);
+    private:
+        zr_params m_params{};
+    };
+
     // RP/AutoExposure/AutoExposure.h:21-100: luminance histogram + adapted exposure of the composited / anti-aliased image
     struct AutoExposure final : public RenderPassBase
     {
