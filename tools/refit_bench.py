@@ -17,10 +17,13 @@ def main():
     idx = max(cand, key=lambda i: int(sc.instance_num_tris[i]))
     t0, xf = sc.instances["translation"][idx].copy(), {}
     import torch
-    upd, frames = [], []
-    for f in range(1, 13):
-        if f >= 3:
-            k = f - 2
+    upd, frames, kern = [], [], {"static": {}, "moving": {}}
+    n_static, n_moving = 24, 16
+    r.p_gbuffer.enable_timing(True); r.p_indirect.enable_timing(True)
+    for f in range(1, n_static + n_moving + 1):
+        moving = f > n_static
+        if moving:
+            k = f - n_static
             ang = 0.05 * k
             q = np.array([0.0, np.sin(ang / 2), 0.0, np.cos(ang / 2)], np.float32)
             scene_io.move_instance(sc, idx, translation=t0 + np.float32([0.02 * k, 0.0, 0.01 * k]), rotation=q, xform_of=xf)
@@ -31,9 +34,14 @@ def main():
         torch.cuda.synchronize(); a = time.perf_counter()
         r.render_frame(cb)
         torch.cuda.synchronize(); frames.append((time.perf_counter() - a) * 1e3)
+        if (not moving and f > 12) or (moving and f > n_static + 4):      # steady state of either phase
+            for name, (ms, launches) in {**r.p_gbuffer.timings(), **r.p_indirect.timings()}.items():
+                kern["moving" if moving else "static"].setdefault(name, []).append(ms)
+    kms = {ph: {k: round(float(np.mean(v)), 3) for k, v in d.items() if np.mean(v) > 0.05} for ph, d in kern.items()}
     print(json.dumps({"mode": os.environ.get("ZR_SCENE_UPDATE", "refit"), "instance": int(idx), "instance_tris": int(sc.instance_num_tris[idx]),
                       "bvh": list(r.scene.bvh_info()), "update_ms": [round(x, 3) for x in upd], "update_ms_median": round(float(np.median(upd)), 3),
-                      "frame_ms_static": round(float(np.median(frames[:2])), 3), "frame_ms_moving": round(float(np.median(frames[4:])), 3)}))
+                      "frame_ms_static": round(float(np.median(frames[12:n_static])), 3), "frame_ms_moving": round(float(np.median(frames[n_static + 4:])), 3),
+                      "kernel_ms_static": kms["static"], "kernel_ms_moving": kms["moving"]}))
 
 
 if __name__ == "__main__":

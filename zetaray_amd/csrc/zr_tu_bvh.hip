@@ -1,8 +1,8 @@
 // zr_tu_bvh.hip -- the acceleration-structure BUILD on the device (round 3).
 //
 // The reference builds its BLAS / TLAS with D3D12 driver calls on the GPU (RtAccelerationStructure.cpp:121-200 StaticBLAS::Rebuild, :708-789
-// TLAS::Render).  Here: a linear BVH over the world-space triangles of all instances -- 30-bit Morton code of the triangle centroid with the
-// global triangle index as the low 32 key bits (unique keys: no duplicate handling), one 64-bit radix sort (hipCUB / rocPRIM), a breadth-first
+// TLAS::Render).  Here: a linear BVH over the world-space triangles of all instances -- Morton code of the triangle centroid (15 - 21 bits per axis, k_bvh_keys) with the
+// global triangle index as the low ceil(log2 n) key bits (unique keys: no duplicate handling), one 64-bit radix sort (hipCUB / rocPRIM), a breadth-first
 // construction of the 4-wide tree straight from the sorted keys (a node = a key range; it is cut up to three times at the highest differing
 // key bit, largest piece first, into 2 - 4 children; ranges of <= 2 triangles become leaves), and the per-level box computation + 8-bit
 // quantisation that the refit already has (k_refit_level, zr_api.hip), bottom-up.  Breadth-first node allocation makes the nodes of a level
@@ -61,17 +61,16 @@ __global__ void __launch_bounds__(256) k_bvh_tris(BvhTri* out, uint32_t n, const
     }
 }
 
-__device__ __forceinline__ uint32_t Expand10(uint32_t v)
-{
-    v &= 0x3ffu; v = (v | (v << 16)) & 0x030000ffu; v = (v | (v << 8)) & 0x0300f00fu; v = (v | (v << 4)) & 0x030c30c3u; v = (v | (v << 2)) & 0x09249249u;
-    return v;
-}
-__global__ void __launch_bounds__(256) k_bvh_keys(const BvhTri* tris, uint32_t n, const uint32_t* sceneBounds, unsigned long long* keys)
+// key = Morton code of the centroid (B bits per axis, x the most significant of each triple) << idxBits | triangle index.  The index only needs
+// ceil(log2 n) bits, the code gets the rest: B = min(21, (64 - idxBits) / 3) -- 15 bits per axis for the 380 k-triangle atrium instead of the 10 of a
+// 32-bit code, so clustered geometry is separated by position rather than by index order.
+__global__ void __launch_bounds__(256) k_bvh_keys(const BvhTri* tris, uint32_t n, const uint32_t* sceneBounds, unsigned long long* keys, uint32_t idxBits)
 {
     const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= n) return;
     const BvhTri t = tris[g];
-    uint32_t q[3];
+    const uint32_t B = (64u - idxBits) / 3u < 21u ? (64u - idxBits) / 3u : 21u;
+    unsigned long long q[3];
     for (int r = 0; r < 3; r++)
     {
         const float lo = OrderedFloat(sceneBounds[r]), hi = OrderedFloat(sceneBounds[3 + r]);
@@ -80,15 +79,19 @@ __global__ void __launch_bounds__(256) k_bvh_keys(const BvhTri* tris, uint32_t n
         const float ext = hi - lo;
         float u = ext > 0 ? (c - lo) / ext : 0.0f;
         u = fminf(fmaxf(u, 0.0f), 1.0f);
-        q[r] = min(1023u, (uint32_t)(u * 1024.0f));
+        const unsigned long long cells = 1ull << B;
+        const unsigned long long v = (unsigned long long)((double)u * (double)cells);
+        q[r] = v < cells ? v : cells - 1ull;
     }
-    const uint32_t m = (Expand10(q[0]) << 2) | (Expand10(q[1]) << 1) | Expand10(q[2]);
-    keys[g] = ((unsigned long long)m << 32) | g;
+    unsigned long long m = 0;
+    for (uint32_t bit = 0; bit < B; bit++)
+        m |= (((q[0] >> bit) & 1ull) << (3u * bit + 2u)) | (((q[1] >> bit) & 1ull) << (3u * bit + 1u)) | (((q[2] >> bit) & 1ull) << (3u * bit));
+    keys[g] = (m << idxBits) | g;
 }
-__global__ void __launch_bounds__(256) k_bvh_emit(const BvhTri* byGlobal, const unsigned long long* keys, uint32_t n, BvhTri* sorted)
+__global__ void __launch_bounds__(256) k_bvh_emit(const BvhTri* byGlobal, const unsigned long long* keys, uint32_t n, BvhTri* sorted, uint32_t idxBits)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) sorted[i] = byGlobal[(uint32_t)(keys[i] & 0xffffffffull)];
+    if (i < n) sorted[i] = byGlobal[(uint32_t)(keys[i] & ((1ull << idxBits) - 1ull))];
 }
 
 // Karras' split of a sorted key range [a, b), b - a >= 2: the position where the highest differing bit flips.  Left = [a, s), right = [s, b).
@@ -197,9 +200,10 @@ int DeviceBuildBvh4(hipStream_t st, DeviceBvhScratch& S, const DeviceBvhInputs& 
     uint32_t* bounds = ctl + kCtlCount + 1;
     const dim3 grid((n + 255) / 256), block(256);
     hipLaunchKernelGGL(k_bvh_tris, grid, block, 0, st, (BvhTri*)I.byGlobal, n, in.meta, in.instances, in.toWorld, in.vertices, in.indices, in.instanceMask, bounds);
-    hipLaunchKernelGGL(k_bvh_keys, grid, block, 0, st, (const BvhTri*)I.byGlobal, n, bounds, (unsigned long long*)I.keys[0]);
+    uint32_t idxBits = 1; while ((1ull << idxBits) < n) idxBits++;
+    hipLaunchKernelGGL(k_bvh_keys, grid, block, 0, st, (const BvhTri*)I.byGlobal, n, bounds, (unsigned long long*)I.keys[0], idxBits);
     BVH_TRY(hipcub::DeviceRadixSort::SortKeys(I.sortTemp, I.sortBytes, (const unsigned long long*)I.keys[0], (unsigned long long*)I.keys[1], (int)n, 0, 64, st));
-    hipLaunchKernelGGL(k_bvh_emit, grid, block, 0, st, (const BvhTri*)I.byGlobal, (const unsigned long long*)I.keys[1], n, out.tris);
+    hipLaunchKernelGGL(k_bvh_emit, grid, block, 0, st, (const BvhTri*)I.byGlobal, (const unsigned long long*)I.keys[1], n, out.tris, idxBits);
     // the root covers every key; levels until one comes out empty (checked on the host afterwards: the launches are unconditional)
     const uint2 rootRange = make_uint2(0u, n);
     BVH_TRY(hipMemcpyAsync(I.ranges, &rootRange, sizeof(rootRange), hipMemcpyHostToDevice, st));
