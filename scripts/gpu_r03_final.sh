@@ -12,5 +12,5 @@ for c in default 2a 2b 3 pt 4 4k 5; do
 import json; d=json.load(open('gpurun_out/r03_bench_$c.json')); r=d['roofline']
 print('$c', d['ms_per_step'], 'ms', d['value'], 'Mrays/s', 'dom', r['kernel'], r['avg_launch_ms'], 'frac', r['frac'], 'bound', r['bound'], 'traffic', r['traffic'], 'x plane', r.get('traffic_over_plane_bytes'), 'valu', (r['valu'] or {}).get('busy_frac'))"
 done
-timeout 1400 python -m pytest tests -q -m gpu 2>&1 | tail -4
+timeout 1400 python -m pytest tests -q -m gpu 2>&1 | grep -E "passed|failed|error" | tail -3
 timeout 600 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2
