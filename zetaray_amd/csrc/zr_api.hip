@@ -1723,7 +1723,7 @@ static int AllocPass(zr_pass* p)
             { const size_t cells = (size_t)((p->w + 31u) / 32u + 1u) * ((p->h + 31u) / 32u + 1u); if ((r = p->costMap.Alloc(cells))) return r; HIP_TRY(hipMemset(p->costMap.p, 0, cells * 4)); }
             if ((r = p->rptSampleSet.Upload(kRptSampleSet, 1024))) return r;
             if ((r = p->rptLists.Alloc(4 * cap))) return r;
-            if ((r = p->rptListCounts.Alloc(4))) return r;
+            if ((r = p->rptListCounts.Alloc(8))) return r;      // 4 counts + 4 cursors (k_rpt_replay pulls its work dynamically)
             p->temporalValid = false; p->currIdx = 0;
         }
     }
@@ -2102,6 +2102,7 @@ static int RenderReSTIR_PT(zr_pass* p, hipStream_t s, const zr_frame_constants* 
     const size_t cap = (size_t)p->w * p->h;
     uint32_t* lists[4] = {p->rptLists.p, p->rptLists.p + cap, p->rptLists.p + 2 * cap, p->rptLists.p + 3 * cap};
     const dim3 gridList((uint32_t)std::min<size_t>((cap + kBlock - 1) / kBlock, 1024));
+    const dim3 gridReplay((uint32_t)std::min<size_t>((cap + kBlock - 1) / kBlock, kReplayPersistentBlocks));      // the temporal replays pull their work (zr_kernels.h)
     unsigned long long* ctr = p->counters.p;
 #define RPT_TIMED(name, ...) do { TimerBegin(p, s, name); __VA_ARGS__; TimerEnd(p, s); } while (0)
     // the NEE_EMISSIVE permutation of a kernel (the reference compiles separate shaders, IndirectLighting.h:251-300)
@@ -2118,7 +2119,7 @@ static int RenderReSTIR_PT(zr_pass* p, hipStream_t s, const zr_frame_constants* 
         else { if (texVariant) hipLaunchKernelGGL((kern<PASS, false, true>), __VA_ARGS__); else hipLaunchKernelGGL((kern<PASS, false, false>), __VA_ARGS__); } } while (0)
     if (stages & ZR_STAGE_TEMPORAL)
     {
-        HIP_TRY(hipMemsetAsync(listCnt, 0, 4 * sizeof(uint32_t), s));
+        HIP_TRY(hipMemsetAsync(listCnt, 0, 8 * sizeof(uint32_t), s));
         TimerBegin(p, s, "rpt_pathtrace");
         // ZR_K11=pool: K11 with block-pooled traces (k_rpt_pathtrace_coop, zr_kernels.h; emissive untextured permutation); ZR_K11=inline: the megakernel
         static const int k11Mode = [] { const char* e = getenv("ZR_K11"); return e && !strcmp(e, "inline") ? 0 : (e && !strcmp(e, "pool") ? 1 : (e && !strcmp(e, "trip") ? 2 : (e && !strcmp(e, "compact") ? 3 : ZR_K11_DEFAULT))); }();
@@ -2149,7 +2150,7 @@ static int RenderReSTIR_PT(zr_pass* p, hipStream_t s, const zr_frame_constants* 
         else if (k11Mode == 2 && emissiveVariant && !texVariant)
         {   // diagnostic: the megakernel with a path-state round trip through SoA planes at every bounce boundary (zr_kernels.h)
             const size_t stride = (size_t)F.gb.w * F.gb.h;
-            if (!p->trip.p) { int rr; if ((rr = p->trip.Alloc(stride * 192u))) return rr; if ((rr = p->tripStats.Alloc(4))) return rr; HIP_TRY(hipMemsetAsync(p->tripStats.p, 0, 32, s)); }
+            if (!p->trip.p) { int rr; if ((rr = p->trip.Alloc(stride * rpt::kPtCarryWords))) return rr; if ((rr = p->tripStats.Alloc(4))) return rr; HIP_TRY(hipMemsetAsync(p->tripStats.p, 0, 32, s)); }
             F.trip = p->trip.p; F.tripStats = p->tripStats.p; F.tripStride = stride;
             if (sc->view.numNodes >= largeSceneNodes) hipLaunchKernelGGL(k_rpt_pathtrace_trip_w4<false>, gridRpt, blockRpt, 0, s, F, *cb, tilesX, ctr + 2 * 1);
             else hipLaunchKernelGGL(k_rpt_pathtrace_trip<false>, gridRpt, blockRpt, 0, s, F, *cb, tilesX, ctr + 2 * 1);
@@ -2165,7 +2166,7 @@ static int RenderReSTIR_PT(zr_pass* p, hipStream_t s, const zr_frame_constants* 
             // passes have no wave operations, so these two maps cannot change a result; they are outputs (ZR_OUT_RPT_THREAD_MAP_*)
             RPT_TIMED("rpt_sort_temporal", hipLaunchKernelGGL((k_rpt_sort<rpt::RPT_SORT_TTC, rpt::RPT_SORT_CTT>), dim3(gridSort.x * 2), dim3(256), 0, s, F, *cb, sortTilesX, F.ox0 / 32u, F.oy0 / 32u, F.mapNtC, F.mapCtN));
             RPT_TIMED("rpt_classify_temporal", hipLaunchKernelGGL(k_rpt_light<0>, grid, block, 0, s, F, *cb, tilesX, lists[0], lists[1], listCnt + 0));
-            RPT_TIMED("rpt_replay_temporal", RPT_LAUNCH_PE(k_rpt_replay, RPT_REPLAY_CTT, dim3(gridList.x * 2), block, 0, s, F, *cb, lists[0], lists[1], listCnt + 0, ctr + 2 * 2));
+            RPT_TIMED("rpt_replay_temporal", RPT_LAUNCH_PE(k_rpt_replay, RPT_REPLAY_CTT, gridReplay, block, 0, s, F, *cb, lists[0], lists[1], listCnt + 0, ctr + 2 * 2));
             RPT_TIMED("rpt_reconnect_temporal", RPT_LAUNCH_E(k_rpt_temporal, grid, block, 0, s, F, *cb, tilesX, ctr + 2 * 4));
         }
     }

@@ -628,23 +628,49 @@ __global__ void __launch_bounds__(kBlock) k_rpt_light(rpt::RptFrame F, zr_frame_
 // K13 replays over work lists (device-side counts, fixed grid, grid-stride): only pixels with k > 2 pay for the heavy kernel.  One launch runs the
 // two replays of a stage (CtT + TtC, CtS + StC: independent -- each writes its own r-buffer): the first half of the grid walks list A with
 // PASS_A, the second half list B with PASS_A + 1, each specialisation compiled for its pass.
+// K13: the replay passes run over work lists (pixels whose reservoir holds a path with k > 2).  A path's replay costs anything between a few
+// hundred instructions and two full bounces, so a static split of a list over the blocks leaves the kernel waiting for its unluckiest block
+// (atrium: 1.99 of 3 resident waves per SIMD on average, PMC).  DYNAMIC: a persistent grid (as many waves as are resident at once) in which
+// every wave pulls the next 128 entries from a cursor next to the list's count -- one returning atomic per wave and chunk -- first from list A
+// until it is empty, then from list B.  Which wave replays a pixel has no influence on the result.  Measured (scripts/gpu_r03_replay.sh,
+// atrium): the temporal replays 1.27 -> 1.19 ms at 1080p, 4.14 -> 3.46 ms at 3840 x 2160; the spatial replays get SLOWER that way (0.88 -> 1.03 ms at
+// 1080p, unchanged at 4K) and keep the static split; with 64-entry chunks and a 2048-block grid the cursor itself was the bottleneck (16 k
+// returning atomics on one word: + 0.5 ms on the Cornell frame, whose lists are nearly empty).
 template<int PASS, bool EMISSIVE, bool TEX>
-__device__ __forceinline__ void RptReplayList(rpt::RptFrame& F, const zr_frame_constants& g, const uint32_t* list, uint32_t n, unsigned long long* counters,
-    uint32_t block, uint32_t numBlocks, const TravStack& stack)
+__device__ __forceinline__ void RptReplayPixel(rpt::RptFrame& F, const zr_frame_constants& g, uint32_t pid, const TravStack& stack, uint32_t* cnt)
+{
+    const uint32_t x = F.gb.x0 + pid % F.gb.w, y = F.gb.y0 + pid / F.gb.w;
+    if (PASS == RPT_REPLAY_CTT) rpt::ReplayTemporalPixel(F, g, 0, x, y, stack, cnt);
+    else if (PASS == RPT_REPLAY_TTC) rpt::ReplayTemporalPixel(F, g, 1, x, y, stack, cnt);
+    else if (PASS == RPT_REPLAY_CTS) rpt::ReplaySpatialPixel(F, g, 0, x, y, stack, cnt);
+    else rpt::ReplaySpatialPixel(F, g, 1, x, y, stack, cnt);
+}
+template<int PASS, bool EMISSIVE, bool TEX, bool DYNAMIC>
+__device__ __forceinline__ void RptReplayList(rpt::RptFrame& F, const zr_frame_constants& g, const uint32_t* list, uint32_t n, uint32_t* cursor,
+    unsigned long long* counters, uint32_t block, uint32_t numBlocks, const TravStack& stack)
 {
     uint32_t cnt[2] = {0u, 0u};
-    for (uint32_t i = block * blockDim.x + threadIdx.x; i < n; i += numBlocks * blockDim.x)
+    if (DYNAMIC)
     {
-        const uint32_t pid = list[i], x = F.gb.x0 + pid % F.gb.w, y = F.gb.y0 + pid / F.gb.w;
-        if (PASS == RPT_REPLAY_CTT) rpt::ReplayTemporalPixel(F, g, 0, x, y, stack, cnt);
-        else if (PASS == RPT_REPLAY_TTC) rpt::ReplayTemporalPixel(F, g, 1, x, y, stack, cnt);
-        else if (PASS == RPT_REPLAY_CTS) rpt::ReplaySpatialPixel(F, g, 0, x, y, stack, cnt);
-        else rpt::ReplaySpatialPixel(F, g, 1, x, y, stack, cnt);
+        const uint32_t lane = threadIdx.x & 63u;
+        for (; n != 0;)
+        {
+            uint32_t base = 0;
+            if (lane == 0) base = atomicAdd(cursor, 128u);
+            base = __shfl(base, 0);
+            if (base >= n) break;
+            if (base + lane < n) RptReplayPixel<PASS, EMISSIVE, TEX>(F, g, list[base + lane], stack, cnt);
+            if (base + 64u + lane < n) RptReplayPixel<PASS, EMISSIVE, TEX>(F, g, list[base + 64u + lane], stack, cnt);
+        }
     }
+    else
+        for (uint32_t i = block * blockDim.x + threadIdx.x; i < n; i += numBlocks * blockDim.x) RptReplayPixel<PASS, EMISSIVE, TEX>(F, g, list[i], stack, cnt);
     if (n) FlushRayCounters(counters, cnt);
 }
+static constexpr uint32_t kReplayPersistentBlocks = 768;      // 3 resident waves per SIMD x 1024 SIMDs / 4 waves per block
+// counts: {entries of list A, entries of list B}; counts[4], counts[5]: the two cursors (zeroed with the counts)
 template<int PASS_A, bool EMISSIVE, bool TEX>
-__global__ void __launch_bounds__(kBlock) k_rpt_replay(rpt::RptFrame F, zr_frame_constants g, const uint32_t* listA, const uint32_t* listB, const uint32_t* counts,
+__global__ void __launch_bounds__(kBlock) k_rpt_replay(rpt::RptFrame F, zr_frame_constants g, const uint32_t* listA, const uint32_t* listB, uint32_t* counts,
     unsigned long long* counters)
 {
     F.prm.emissive = EMISSIVE ? 1u : 0u; F.prm.textured = TEX ? 1u : 0u;
@@ -652,10 +678,18 @@ __global__ void __launch_bounds__(kBlock) k_rpt_replay(rpt::RptFrame F, zr_frame
 #ifdef ZR_NODE_CACHE_MORE
     ZR_NODE_CACHE_FILL(stack, F.sc, kBlock);
 #endif
-    const uint32_t half = gridDim.x / 2u;
     // (counters: the per-kernel slots of the two passes are neighbours, zr_api.hip kCounterNames)
-    if (blockIdx.x < half) RptReplayList<PASS_A, EMISSIVE, TEX>(F, g, listA, counts[0], counters, blockIdx.x, half, stack);
-    else RptReplayList<PASS_A + 1, EMISSIVE, TEX>(F, g, listB, counts[1], counters + 2, blockIdx.x - half, half, stack);
+    if (PASS_A == RPT_REPLAY_CTT)
+    {
+        RptReplayList<PASS_A, EMISSIVE, TEX, true>(F, g, listA, counts[0], counts + 4, counters, 0, 0, stack);
+        RptReplayList<PASS_A + 1, EMISSIVE, TEX, true>(F, g, listB, counts[1], counts + 5, counters + 2, 0, 0, stack);
+    }
+    else
+    {
+        const uint32_t half = gridDim.x / 2u;
+        if (blockIdx.x < half) RptReplayList<PASS_A, EMISSIVE, TEX, false>(F, g, listA, counts[0], nullptr, counters, blockIdx.x, half, stack);
+        else RptReplayList<PASS_A + 1, EMISSIVE, TEX, false>(F, g, listB, counts[1], nullptr, counters + 2, blockIdx.x - half, half, stack);
+    }
 }
 
 // K12 (ReSTIR_PT_Sort.hlsl:99-368): one 256-thread block per 32 x 32 pixel tile, thread = 2 x 2 quad, wave w = threads 64 w .. 64 w + 63 of the
@@ -780,7 +814,7 @@ __global__ void __launch_bounds__(kBlock) ZR_WAVES_STC k_rpt_stc(rpt::RptFrame F
 // ------------------------------------------------------------------------------------------------ translation-unit split
 // ZR_RPT_GROUP_A / _B(X): X = `template` in the TU that owns the group, `extern template` everywhere else
 #define ZR_RPT_ARGS_TILE (rpt::RptFrame, zr_frame_constants, uint32_t, unsigned long long*)
-#define ZR_RPT_ARGS_LIST (rpt::RptFrame, zr_frame_constants, const uint32_t*, const uint32_t*, const uint32_t*, unsigned long long*)
+#define ZR_RPT_ARGS_LIST (rpt::RptFrame, zr_frame_constants, const uint32_t*, const uint32_t*, uint32_t*, unsigned long long*)
 #define ZR_RPT_GROUP_A(X) \
     X __global__ void k_rpt_pathtrace<true> ZR_RPT_ARGS_TILE; X __global__ void k_rpt_pathtrace<false> ZR_RPT_ARGS_TILE; \
     X __global__ void k_rpt_pathtrace_w4<true> ZR_RPT_ARGS_TILE; X __global__ void k_rpt_pathtrace_w4<false> ZR_RPT_ARGS_TILE; \
