@@ -18,7 +18,7 @@ for wl in ${WORKLOADS:-rpt_cornell rpt_atrium gi_cornell}; do
   case $wl in
     rpt_cornell) ARGS="";;
     rpt_atrium) ARGS="--config 4";;
-    rpt_3840x2160_atrium) ARGS="--config 4k";;
+    rpt_3840x2160_atrium) ARGS="--config 5";;      # (config 5 = 4k + the denoise pass: one profile serves both presets)
     gi_cornell) ARGS="--config 3";;
     gi_atrium) ARGS="--integrator restir_gi --scene synthetic";;
     pt_cornell) ARGS="--config pt";;
