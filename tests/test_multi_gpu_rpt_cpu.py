@@ -25,7 +25,7 @@ def _frames(scene_io, sc, w, h, n):
     return cbs
 
 
-def _worker(rank, world, port, w, h, nframes, out_path):
+def _worker(rank, world, port, w, h, nframes, out_path, layout=None):
     sys.path.insert(0, ROOT)
     import torch
     import torch.distributed as dist
@@ -38,9 +38,9 @@ def _worker(rank, world, port, w, h, nframes, out_path):
     sc = scene_io.load_npz(os.path.join(ROOT, "tests", "golden", "cornell_emissive.npz"))
     o = zro.OracleScene(sc)
     hx = zhx.HostExecScene(sc, o.alias)
-    tile = tiling.tile_rect(w, h, world, rank)
+    tile = tiling.tile_rect(w, h, world, rank, layout)
     ext = tiling.extended_rect(w, h, tile)
-    plan = tiling.halo_plan(w, h, world, rank)
+    plan = tiling.halo_plan(w, h, world, rank, layout=layout)
     r = zhx.HostExecRPT(hx, ext[2], ext[3], ext=ext, owned=tile)
     prm = wire.default_params()
 
@@ -80,7 +80,13 @@ def _worker(rank, world, port, w, h, nframes, out_path):
     dist.destroy_process_group()
 
 
-def test_restir_pt_tile_split_with_halo_exchange_is_bit_identical(tmp_path):
+import pytest
+
+
+@pytest.mark.parametrize("layout", [None, [(0, 0, 96, 64), (96, 0, 32, 64)]], ids=["equal-area grid", "uneven cost-balanced style split"])
+def test_restir_pt_tile_split_with_halo_exchange_is_bit_identical(tmp_path, layout):
+    """layout None: tiling.tile_rect's grid; the second case is the kind of split tiling.balanced_layout produces (32-px-aligned tiles of
+    different sizes): the halo plan and the stitched result must not depend on the tiles being equal"""
     import torch.multiprocessing as mp
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -88,7 +94,7 @@ def test_restir_pt_tile_split_with_halo_exchange_is_bit_identical(tmp_path):
     s.close()
     w, h, nframes, world = 128, 64, 4, 2
     out = str(tmp_path / "rank")
-    mp.spawn(_worker, args=(world, port, w, h, nframes, out), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, port, w, h, nframes, out, layout), nprocs=world, join=True)
     sys.path.insert(0, ROOT)
     from oracle import zro
     from zetaray_amd import scene_io, wire
@@ -118,14 +124,17 @@ def test_halo_plan_is_symmetric_and_covers_the_apron():
     sys.path.insert(0, ROOT)
     from zetaray_amd import tiling
     W, H = 1920, 1080
-    for n in (2, 4, 8):
+    rng = np.random.default_rng(5)
+    blob = np.fromfunction(lambda y, x: np.exp(-((x - 20) ** 2 + (y - 12) ** 2) / 90.0), ((H + 31) // 32, (W + 31) // 32))
+    layouts = [(n, None) for n in (2, 4, 8)] + [(n, tiling.balanced_layout(W, H, n, blob + 0.01 * rng.random(blob.shape))) for n in (3, 6, 8)]
+    for n, layout in layouts:
         for r in range(n):
-            tile = tiling.tile_rect(W, H, n, r)
+            tile = tiling.tile_rect(W, H, n, r, layout)
             ext = tiling.extended_rect(W, H, tile)
             cover = np.zeros((H, W), np.int32)
             cover[tile[1]:tile[1] + tile[3], tile[0]:tile[0] + tile[2]] = 1
-            for peer, send, recv in tiling.halo_plan(W, H, n, r):
-                back = [(s2, r2) for p2, s2, r2 in tiling.halo_plan(W, H, n, peer) if p2 == r][0]
+            for peer, send, recv in tiling.halo_plan(W, H, n, r, layout=layout):
+                back = [(s2, r2) for p2, s2, r2 in tiling.halo_plan(W, H, n, peer, layout=layout) if p2 == r][0]
                 assert back == (recv, send)
                 if recv:
                     cover[recv[1]:recv[1] + recv[3], recv[0]:recv[0] + recv[2]] += 1
