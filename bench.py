@@ -337,11 +337,13 @@ def main():
     for q in di_passes:
         q.read_counters(reset=True)
     barrier()
+    exch0 = tiled.exchanges_done if tiled is not None else 0
     t0 = time.perf_counter()
     for i in range(args.steps):
         frame(1 + settle + args.warmup + i)
     barrier()
     dt = time.perf_counter() - t0
+    exch_per_frame = ((tiled.exchanges_done - exch0) / args.steps) if tiled is not None else 0.0
 
     c1 = r.p_gbuffer.read_counters(reset=True)
     c2 = r.p_indirect.read_counters(reset=True)
@@ -389,7 +391,7 @@ def main():
                    "integrator": ("" if args.di_only else args.integrator) + ("+restir_di" if args.direct else "") + ("+sky_di" if args.sky_direct else ""),
                    "parallelism": f"screen tiles {tile_grid(world)}" + (f" ({layout_kind})" if (tiled is not None and world > 1 and rpt) else "") + (
                        f", 32-px apron, RCCL p2p halo exchange of reservoir planes ({tiled.bpp} B/px): {tiled.halo_bytes} B sent per "
-                       f"rank per exchange, {(1 if args.no_final_halo else 2) if rpt else (0 if args.no_final_halo else 1)} exchanges per frame"
+                       f"rank per exchange, {exch_per_frame:g} exchanges per frame (the previous frame's final reservoirs are fetched only by frames whose reprojection can cross a tile border: not while camera and scene stand still)"
                        if (tiled is not None and world > 1) else ""),
                    "halo_transport": (tiled.transport if (tiled is not None and world > 1) else None),
                    "preset": args.config, "settle_frames": settle,

@@ -1522,3 +1522,32 @@ def test_bench_two_ranks_over_rccl_when_two_gpus_are_visible():
     assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
     d = json.loads([l for l in res.stdout.splitlines() if l.startswith("{")][0])
     assert d["n_gpus"] == 2 and d["value"] > 0 and d["config"]["halo_transport"] == "rccl_cpp", d["config"]
+
+
+def test_final_halo_is_exchanged_only_by_frames_that_read_it(api, cornell_emissive, oracle_emissive):
+    """TiledRestirPT.render_frame's exchange policy (tiling.render_frame_in_process is the same policy for tile objects in one process): the
+    FINAL halo moves at the start of the frame that reprojects across tiles -- moving camera: two exchanges per frame, unmoved camera and
+    scene: one -- and the stitched image stays bit-identical to the full-frame oracle through moving -> static -> moving -> moved-light frames."""
+    from oracle import zro
+    from zetaray_amd import tiling
+    w, h, world = 200, 120, 4
+    prm = wire.default_params()
+    ranks = [tiling.TiledRestirPT(cornell_emissive, w, h, world, r, params=prm) for r in range(world)]
+    o = zro.OracleRPT(oracle_emissive, w, h)
+    cams = [(0.05, 1.2, -4.02), (0.10, 1.2, -4.00), (0.10, 1.2, -4.00), (0.10, 1.2, -4.00), (0.16, 1.2, -3.98), (0.16, 1.2, -3.98)]
+    prev, counts = None, []
+    for f, cam in enumerate(cams, 1):
+        cb = _frame(cornell_emissive, w, h, f, cam_pos=cam)
+        if prev is not None:
+            cb["prev_view"], cb["prev_view_inv"], cb["prev_camera_jitter"] = prev["curr_view"], prev["curr_view_inv"], prev["curr_camera_jitter"]
+        prev = cb.copy()
+        counts.append(tiling.render_frame_in_process(ranks, cb))
+        want = o.render(cb, prm)
+        img = np.zeros_like(want)
+        for r in ranks:
+            (x0, y0, tw, th), t = r.final_tile()
+            img[y0:y0 + th, x0:x0 + tw] = t
+        mism = int((img.view(np.uint32) != want.view(np.uint32)).any(axis=2).sum())
+        assert mism == 0, f"frame {f}: {mism} pixels differ"
+    # frame 1: nothing to fetch yet; 2, 5: the camera moved; 3, 4, 6: it did not
+    assert counts == [1, 2, 1, 1, 2, 1], counts

@@ -155,12 +155,14 @@ class Scene:
         self.host = scene
         self._desc = scene.desc()
         self.h = C.c_void_p()
+        self.version = 0      # bumped by every update_*: lets a caller see whether anything moved since it last looked (tiling.TiledRestirPT)
         _check(lib().zr_scene_create(device, C.addressof(self._desc), C.byref(self.h)))
 
     def update_instances(self, instances, instance_to_world, stream=False):
         """per-frame MeshInstance records + object-to-world matrices; last frame's instance buffer and BVH become the previous ones.
         stream=False: host-synchronous; a stream handle (or None = the null stream): enqueued, no host wait (zr_scene_update_instances_async)"""
         L = lib()
+        self.version += 1
         i, x = np.ascontiguousarray(instances), np.ascontiguousarray(instance_to_world, np.float32)
         if stream is False:
             L.zr_scene_update_instances.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32]
@@ -172,6 +174,7 @@ class Scene:
     def update_emissives(self, triangles, first=0, stream=False):
         """new EmissiveTriangle records for [first, first + len(triangles)) (instances that carry lights moved)"""
         L = lib()
+        self.version += 1
         t = np.ascontiguousarray(triangles, wire.EMISSIVE_TRI)
         if stream is False:
             L.zr_scene_update_emissives.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32]
@@ -183,6 +186,7 @@ class Scene:
     def update_materials(self, materials, first=0, stream=False):
         """rewritten Material records for [first, first + len(materials))"""
         L = lib()
+        self.version += 1
         m = np.ascontiguousarray(materials, wire.MATERIAL)
         if stream is False:
             L.zr_scene_update_materials.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32]

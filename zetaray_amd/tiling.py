@@ -174,6 +174,9 @@ class TiledRestirPT:
         # from C++ on the pass's stream, one unpack kernel, no host wait -- instead of per-plane copies + torch.distributed P2P ops
         self.transport = transport
         self.native = None
+        self._frames_rendered = 0
+        self._scene_version_seen = self.r.scene.version
+        self.exchanges_done = 0      # (statistics: how many halo exchanges this object has run)
         if transport == "rccl_cpp" and world > 1:
             # every rank must take the same branch (communicator creation is collective): agree on success before using it
             try:
@@ -207,6 +210,7 @@ class TiledRestirPT:
     def exchange(self, which):
         if not self.plan:
             return
+        self.exchanges_done += 1
         if self.native is not None:
             self.native.run(which)
             return
@@ -263,15 +267,29 @@ class TiledRestirPT:
     # which exchanges a frame of this kind needs: (post-temporal, final)
     EXCHANGES = {"restir_pt": (True, True), "restir_gi": (False, True), "di": (True, False), "sky_di": (True, False)}
 
+    def history_crosses_tiles(self, cb):
+        """Can this frame's temporal stage read a previous-frame reservoir that belongs to another tile?  ReSTIR PT reads exactly the reprojected
+        pixel (FindTemporal), so with an unmoved camera (same view, same jitter) and an unchanged scene every pixel reads its own history and
+        the apron's previous reservoirs are never touched.  The other passes pick temporal candidates in a neighbourhood: always yes."""
+        if self.kind != "restir_pt":
+            return True
+        same_cam = (np.array_equal(cb["curr_view"], cb["prev_view"]) and np.array_equal(cb["curr_camera_jitter"], cb["prev_camera_jitter"]))
+        return not (same_cam and self.r.scene.version == self._scene_version_seen)
+
     def render_frame(self, cb, exchange_final=True):
-        """exchange_final=False skips the post-frame exchange: valid for a static camera (reprojection stays in the tile)"""
+        """One frame of this rank's tile.  The FINAL halo (the reservoirs the temporal stage reads as "previous" in the apron) is exchanged at the
+        START of the frame that needs it rather than at the end of the frame that produced it -- the planes are the same (nothing renders in
+        between), and a frame whose reprojection cannot leave its tile (history_crosses_tiles) skips the exchange altogether: one exchange per
+        frame instead of two while nothing moves.  exchange_final=False never exchanges it (the caller vouches for a static view)."""
         post, final = self.EXCHANGES[self.kind]
+        if final and exchange_final and self._frames_rendered > 0 and self.history_crosses_tiles(cb):
+            self.exchange(self.api.HALO_FINAL)
         self.stage_temporal(cb)
         if post:
             self.exchange(self.api.HALO_POST_TEMPORAL)
         self.stage_spatial(cb)
-        if final and exchange_final:
-            self.exchange(self.api.HALO_FINAL)
+        self._frames_rendered += 1
+        self._scene_version_seen = self.r.scene.version
 
     def owned_cost_cells(self):
         """this rank's contribution to the frame's cost map: (ceil(H / 32), ceil(W / 32)) float64, rays per cell of the OWNED tile since the
@@ -355,6 +373,25 @@ class NativeHalo:
         if self.comm:
             self.L.zrh_comm_destroy(self.comm)
             self.comm = self.C.c_void_p()
+
+
+def render_frame_in_process(ranks, cb, exchange_final=True):
+    """TiledRestirPT.render_frame for tile objects that live in ONE process (the single-GPU tests): the same exchange policy, the halos moved by
+    exchange_in_process.  Returns the number of exchanges the frame took."""
+    api = ranks[0].api
+    post, final = ranks[0].EXCHANGES[ranks[0].kind]
+    n = 0
+    if final and exchange_final and ranks[0]._frames_rendered > 0 and ranks[0].history_crosses_tiles(cb):
+        exchange_in_process(ranks, api.HALO_FINAL); n += 1
+    for r in ranks:
+        r.stage_temporal(cb)
+    if post:
+        exchange_in_process(ranks, api.HALO_POST_TEMPORAL); n += 1
+    for r in ranks:
+        r.stage_spatial(cb)
+        r._frames_rendered += 1
+        r._scene_version_seen = r.r.scene.version
+    return n
 
 
 def exchange_in_process(ranks, which):
