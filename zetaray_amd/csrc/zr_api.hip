@@ -2047,9 +2047,18 @@ static int RenderReSTIR_GI(zr_pass* p, hipStream_t s, const zr_frame_constants* 
     return ZR_OK;
 }
 
-// IndirectLighting::RenderReSTIR_PT (IndirectLighting.cpp:877-1004) + the Render() tail (:1006-1025).
-// stages: ZR_STAGE_TEMPORAL = K11 + temporal passes, ZR_STAGE_SPATIAL = spatial passes + end-of-frame bookkeeping; a
-// multi-GPU host exchanges reservoir halos between the two (and after the second).
+// K11 is launched as one-wave blocks, and a wave lives for the whole path: a grid of a few thousand waves runs in ROUNDS of as many waves as are
+// resident at once -- 3072 for the 3-wave build, 4096 for the 4-wave build.  A 480 x 544 tile of the 8-way screen split is 4080 waves: one round and
+// a third of a second one at 3 waves per SIMD, exactly one at 4.  Measured per tile of the Cornell frame (scripts/gpu_r03_rounds.sh): the busiest
+// 8-way tiles 0.365 -> 0.31 ms with the 4-wave build (slowest tile of the split 0.82 -> 0.76 ms); with two rounds or more the per-wave cost of the
+// 4-wave build (the kernel is VALU-bound: a wave shares its SIMD with one more) eats the saving -- the 4-way split's tiles (8160 waves) get 4 - 17 %
+// slower, the 2-way split's do not care -- so only the one-round case switches.
+static bool FewerRoundsAtFourWaves(uint32_t waves)
+{
+    static const bool off = [] { const char* e = getenv("ZR_K11_ROUNDS"); return e && !strcmp(e, "0"); }();      // (A/B switch)
+    return !off && waves > 3072u && waves <= 4096u;
+}
+
 static int RenderReSTIR_PT(zr_pass* p, hipStream_t s, const zr_frame_constants* cb, const zr_scene* sc, zr_gbuffer* gb, int stages)
 {
     using namespace rpt;
@@ -2156,7 +2165,7 @@ static int RenderReSTIR_PT(zr_pass* p, hipStream_t s, const zr_frame_constants* 
             else hipLaunchKernelGGL(k_rpt_pathtrace_trip<false>, gridRpt, blockRpt, 0, s, F, *cb, tilesX, ctr + 2 * 1);
         }
         else if (texVariant) { if (emissiveVariant) hipLaunchKernelGGL(k_rpt_pathtrace_tex<true>, gridRpt, blockRpt, 0, s, F, *cb, tilesX, ctr + 2 * 1); else hipLaunchKernelGGL(k_rpt_pathtrace_tex<false>, gridRpt, blockRpt, 0, s, F, *cb, tilesX, ctr + 2 * 1); }
-        else if (sc->view.numNodes >= largeSceneNodes)     // BVH beyond the caches: the 4-wave build of K11 (zr_kernels.h)
+        else if (sc->view.numNodes >= largeSceneNodes || FewerRoundsAtFourWaves(gridRpt.x))     // BVH beyond the caches, or a small grid: the 4-wave build of K11 (zr_kernels.h)
         { if (emissiveVariant) hipLaunchKernelGGL(k_rpt_pathtrace_w4<true>, gridRpt, blockRpt, 0, s, F, *cb, tilesX, ctr + 2 * 1); else hipLaunchKernelGGL(k_rpt_pathtrace_w4<false>, gridRpt, blockRpt, 0, s, F, *cb, tilesX, ctr + 2 * 1); }
         else { if (emissiveVariant) hipLaunchKernelGGL(k_rpt_pathtrace<true>, gridRpt, blockRpt, 0, s, F, *cb, tilesX, ctr + 2 * 1); else hipLaunchKernelGGL(k_rpt_pathtrace<false>, gridRpt, blockRpt, 0, s, F, *cb, tilesX, ctr + 2 * 1); }
         TimerEnd(p, s);
