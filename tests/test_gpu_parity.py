@@ -1551,3 +1551,11 @@ def test_final_halo_is_exchanged_only_by_frames_that_read_it(api, cornell_emissi
         assert mism == 0, f"frame {f}: {mism} pixels differ"
     # frame 1: nothing to fetch yet; 2, 5: the camera moved; 3, 4, 6: it did not
     assert counts == [1, 2, 1, 1, 2, 1], counts
+
+
+def test_restir_pt_one_round_grid_is_bit_exact(api, cornell_emissive, oracle_emissive):
+    """512 x 480 is 3840 one-wave blocks of K11: more than the 3-wave build keeps resident (3072), fewer than the 4-wave build does (4096) -- the
+    grid size at which the pass switches K11 to its 4-wave build (zr_api.hip FewerRoundsAtFourWaves; an 8-way tile of a 1080p frame is such a
+    grid).  Same planes, same radiance as the oracle."""
+    got = _rpt_compare(api, cornell_emissive, oracle_emissive, 512, 480, wire.default_params(), 2)
+    assert got[..., :3].max() > 0
