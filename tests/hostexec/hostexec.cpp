@@ -24,7 +24,11 @@ static const uint16_t kRdiSampleSet[64] = {
 };
 
 #include "hx_kat.h"
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
 using namespace zr;
+static bool g_k11_carry = false;      // zhx_set_k11_carry: K11 emulation sends live paths through rpt::PtCarry at every bounce boundary
 
 struct HxScene
 {
@@ -211,6 +215,7 @@ void zhx_svgf(const float* signal, const float* depth, const uint32_t* normal, c
     memcpy(histMoments, moments.data(), 2 * n * sizeof(float));
     memcpy(out, src, n * sizeof(F4));
 }
+void zhx_set_k11_carry(int on) { g_k11_carry = on != 0; }
 void zhx_latch_heap_offsets(const HxScene* s, const zr_frame_constants* cb) { Latch(s, cb); }
 void zhx_estimate_power(const HxScene* s, float* out) { for (size_t i = 0; i < s->emissives.size(); i++) out[i] = EstimateTriPower(s->view, s->emissives[i]); }
 
@@ -424,6 +429,20 @@ void zhx_rpt_render_stage(const HxScene* s, HxRpt* R, const zr_frame_constants* 
                 uint32_t bits = 0;
                 for (uint32_t l = 0; l < 64; l++) { uint32_t b = PtRRKey(lanes[l]); bits = b > bits ? b : bits; }
                 for (uint32_t l = 0; l < 64; l++) PtPhaseB(F.sc, prm, lanes[l], bits);
+                if (g_k11_carry)
+                {   // the bounce boundary of the compacting kernels (zr_kernels.h k_rpt_pt_first / _next): a live path continues from NOTHING but the
+                    // words rpt::PtCarry moves -- stored from this lane, loaded into a lane whose every other byte is poison
+                    for (uint32_t l = 0; l < 64; l++)
+                    {
+                        if (!lanes[l].active) continue;
+                        uint32_t words[kPtCarryWords + 8];
+                        PtCarryStore st; st.p = words; st.stride = 1; PtCarry(st, lanes[l]);
+                        if (st.n != kPtCarryWords) { std::fprintf(stderr, "PtCarry moves %u words, kPtCarryWords says %u\n", st.n, kPtCarryWords); std::abort(); }
+                        PTLane fresh; std::memset((void*)&fresh, 0xCD, sizeof(fresh));
+                        PtCarryLoad ld; ld.p = words; ld.stride = 1; PtCarry(ld, fresh);
+                        lanes[l] = fresh;
+                    }
+                }
             }
             for (uint32_t l = 0; l < 64; l++) PtFinishLane(F.gb, prm, F.cur, F.tex, finalRGBA, lanes[l]);
             flush();

@@ -377,6 +377,11 @@ class HostExecRGI:
         return out
 
 
+def set_k11_carry(on):
+    """K11 emulation: at every bounce boundary a live path is rebuilt from the words rpt::PtCarry moves (what the compacting kernels carry) and nothing else"""
+    lib().zhx_set_k11_carry(int(bool(on)))
+
+
 def svgf(signal_rgba, depth, normal, motion, prev_depth, prev_normal, hist_color, hist_moments, temporal_valid=True, alpha=0.2, alpha_moments=0.2,
          sigma_l=4.0, sigma_z=1.0, normal_power_log2=7, iterations=5):
     """the denoise pass's HIP stage functions (zr_svgf.h) run serially on the host; same interface as oracle.zro.svgf"""

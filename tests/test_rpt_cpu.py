@@ -106,6 +106,29 @@ def test_rpt_all_material_classes(synthetic_small, nb, gb):
     assert any(k > 2 for k, _ in ks) and {c for _, c in ks} == {1, 2, 3}, ks
 
 
+@pytest.mark.parametrize("nb,gb", [(3, 4), (6, 8)])
+def test_k11_carried_state_is_all_a_path_needs(synthetic_small, cornell_emissive, oracle_emissive, hx_emissive, nb, gb):
+    """K11 with per-bounce path compaction (zr_kernels.h k_rpt_pt_first / k_rpt_pt_next, ZR_K11=compact) moves a live path between kernels as the
+    78 words rpt::PtCarry enumerates.  Here the host executor rebuilds every live path from exactly those words at every bounce boundary -- the rest
+    of the lane state is poison -- on the material scene (metal, coat, glass, thin walls, Russian roulette with (6, 8) bounces) and on the Cornell
+    box: radiance and all reservoir planes still equal the oracle's."""
+    sc, osc, hx = synthetic_small
+    w, h = 64, 48
+    prm = wire.default_params()
+    prm.max_non_tr_bounces, prm.max_glossy_tr_bounces = nb, gb
+    zhx.set_k11_carry(True)
+    try:
+        for scene, oscene, hxs, cam in ((sc, osc, hx, dict(cam_pos=(0, 0, -3.5))), (cornell_emissive, oracle_emissive, hx_emissive, {})):
+            o, x = zro.OracleRPT(oscene, w, h), zhx.HostExecRPT(hxs, w, h)
+            for f in range(1, 4):
+                cb = _cb(scene, w, h, f, **cam)
+                a, b = o.render(cb, prm), x.render(cb, prm)
+                assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), f"frame {f}"
+                _assert_same_state(o, x, f)
+    finally:
+        zhx.set_k11_carry(False)
+
+
 def test_rpt_initial_candidates_unbiased_vs_k9(cornell_emissive, oracle_emissive):
     """Without reuse K11 is a path tracer with a different RNG layout: its mean converges to K9's (pins the oracle's
     NEE / MIS / throughput bookkeeping against the independently pinned K9 restatement)."""
@@ -145,8 +168,9 @@ def test_rpt_self_shift_identity(synthetic_small):
     assert np.median(np.abs(jr - 1)) < 1e-3 and np.quantile(np.abs(jr - 1), 0.85) < 0.03
 
 
+@pytest.mark.parametrize("carry", [False, True], ids=["", "state carried through PtCarry at bounce boundaries"])
 @pytest.mark.parametrize("kind", ["cornell", "glossy"])
-def test_rpt_sun_sky_bit_exact(kind):
+def test_rpt_sun_sky_bit_exact(kind, carry):
     """NEE_EMISSIVE == 0 variants of K11-K16: no emissive triangles; NEE_NonEmissive (one RIS over sun / cosine-sky / BSDF-sky with
     Le_Sky as the lobe-RIS target), case-2 / case-3 reconnections to SUN / SKY, EstimateDirect_y_k_min_1 in the shifts, the
     partial (component-wise) reservoir plane writes of the non-emissive Write<>: radiance, all 7 planes, counters; moving camera."""
@@ -164,6 +188,7 @@ def test_rpt_sun_sky_bit_exact(kind):
     prm = wire.default_params()
     o, x = zro.OracleRPT(osc, w, h), zhx.HostExecRPT(hx, w, h)
     prev = None
+    zhx.set_k11_carry(carry)      # (the sun + sky variant traces its continuation ray at the top of PtPhaseA: the carried normal / transmissive flag)
     for f in range(1, 6):
         cb = sio.make_frame_constants(w, h, frame_num=f, num_emissives=0, cam_pos=(cam0[0] + 0.05 * max(0, f - 3), cam0[1], cam0[2]))
         if sun is not None:
@@ -180,6 +205,7 @@ def test_rpt_sun_sky_bit_exact(kind):
         for nm in "ABCDEFG":
             assert np.array_equal(o.plane(nm).view(np.uint8), x.plane(nm).view(np.uint8)), f"frame {f}: plane {nm} differs"
         assert o.counters == x.counters
+    zhx.set_k11_carry(False)
     assert a[..., :3].max() > 0
     A = o.plane("A")[..., 0]
     assert (((A >> 16) & 3) != 0).any()          # some reservoirs reconnect into the sun / sky (case 2)
