@@ -233,7 +233,10 @@ __global__ void __launch_bounds__(kBlock) k_pt_rr(SceneView sc, PtParams prm, Pa
 // TAA: one thread per pixel; 9 signal + 9 depth reads from a 3 x 3 neighbourhood that the L2 serves after the first touch, 9 bilinear
 // history fetches (36 half4 texels) around the reprojected position, one half4 store: HBM-bound (16 + 4 + 4 + 8 B read, 8 B written per
 // pixel algorithmically)
-__global__ void __launch_bounds__(256) k_taa(taa::TaaFrame F)
+#ifndef ZR_WAVES_TAA
+#define ZR_WAVES_TAA
+#endif
+__global__ void __launch_bounds__(256) ZR_WAVES_TAA k_taa(taa::TaaFrame F)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < F.w * F.h) taa::TaaPixel(F, i % F.w, i / F.w);

@@ -53,8 +53,10 @@ ZR_HD V3 LoadSignal(const TaaFrame& F, int x, int y)
 }
 ZR_HD V3 LoadHistoryTexel(const TaaFrame& F, int x, int y)
 {
-    const uint16_t* p = F.prevOut + 4 * ((size_t)y * F.w + x);
-    return v3(zr_f16_to_f32(p[0]), zr_f16_to_f32(p[1]), zr_f16_to_f32(p[2]));
+    // one 8-byte load per RGBA16F texel (the Catmull-Rom fetch reads 36 of them per pixel: three 2-byte loads each made TAA load-issue bound)
+    uint64_t t;
+    __builtin_memcpy(&t, F.prevOut + 4 * ((size_t)y * F.w + x), 8);
+    return v3(zr_f16_to_f32((uint16_t)(t & 0xffffu)), zr_f16_to_f32((uint16_t)((t >> 16) & 0xffffu)), zr_f16_to_f32((uint16_t)((t >> 32) & 0xffffu)));
 }
 // SampleLevel(g_samLinearClamp, uv, 0) on the history
 ZR_HD V3 SampleHistory(const TaaFrame& F, float u, float v)
