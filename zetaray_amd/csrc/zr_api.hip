@@ -2114,6 +2114,7 @@ static int RenderReSTIR_PT(zr_pass* p, hipStream_t s, const zr_frame_constants* 
     const size_t cap = (size_t)p->w * p->h;
     uint32_t* lists[4] = {p->rptLists.p, p->rptLists.p + cap, p->rptLists.p + 2 * cap, p->rptLists.p + 3 * cap};
     const dim3 gridList((uint32_t)std::min<size_t>((cap + kBlock - 1) / kBlock, 1024));
+    const dim3 gridLight((tilesX * tilesY + kLightTilesPerBlock - 1u) / kLightTilesPerBlock), gridSearch((tilesX * tilesY + kSearchTilesPerBlock - 1u) / kSearchTilesPerBlock);      // k_rpt_light<0> / <1>: several tiles per block
     const dim3 gridReplay((uint32_t)std::min<size_t>((cap + kBlock - 1) / kBlock, kReplayPersistentBlocks));      // the temporal replays pull their work (zr_kernels.h)
     unsigned long long* ctr = p->counters.p;
 #define RPT_TIMED(name, ...) do { TimerBegin(p, s, name); __VA_ARGS__; TimerEnd(p, s); } while (0)
@@ -2177,7 +2178,7 @@ static int RenderReSTIR_PT(zr_pass* p, hipStream_t s, const zr_frame_constants* 
             // K12 Sort_TtC / Sort_CtT (IndirectLighting.cpp:383-441: dispatched whether or not SORT_TEMPORAL is set).  The temporal reconnect
             // passes have no wave operations, so these two maps cannot change a result; they are outputs (ZR_OUT_RPT_THREAD_MAP_*)
             RPT_TIMED("rpt_sort_temporal", hipLaunchKernelGGL((k_rpt_sort<rpt::RPT_SORT_TTC, rpt::RPT_SORT_CTT>), dim3(gridSort.x * 2), dim3(256), 0, s, F, *cb, sortTilesX, F.ox0 / 32u, F.oy0 / 32u, F.mapNtC, F.mapCtN));
-            RPT_TIMED("rpt_classify_temporal", hipLaunchKernelGGL(k_rpt_light<0>, grid, block, 0, s, F, *cb, tilesX, lists[0], lists[1], listCnt + 0));
+            RPT_TIMED("rpt_classify_temporal", hipLaunchKernelGGL(k_rpt_light<0>, gridLight, block, 0, s, F, *cb, tilesX, lists[0], lists[1], listCnt + 0));
             RPT_TIMED("rpt_replay_temporal", RPT_LAUNCH_PE(k_rpt_replay, RPT_REPLAY_CTT, gridReplay, block, 0, s, F, *cb, lists[0], lists[1], listCnt + 0, ctr + 2 * 2));
             RPT_TIMED("rpt_reconnect_temporal", RPT_LAUNCH_E(k_rpt_temporal, grid, block, 0, s, F, *cb, tilesX, ctr + 2 * 4));
         }
@@ -2187,7 +2188,7 @@ static int RenderReSTIR_PT(zr_pass* p, hipStream_t s, const zr_frame_constants* 
         // ZR_SEARCH=tile: the LDS-tiled K15 (k_rpt_light<2>), kept for the A/B of DESIGN's N3 row -- measured slower than the plain gathers
         static const bool searchTile = [] { const char* e = getenv("ZR_SEARCH"); return e && !strcmp(e, "tile"); }();
         if (searchTile) RPT_TIMED("rpt_spatial_search", hipLaunchKernelGGL(k_rpt_light<2>, grid, block, 0, s, F, *cb, tilesX, lists[2], lists[3], listCnt + 2));
-        else RPT_TIMED("rpt_spatial_search", hipLaunchKernelGGL(k_rpt_light<1>, grid, block, 0, s, F, *cb, tilesX, lists[2], lists[3], listCnt + 2));
+        else RPT_TIMED("rpt_spatial_search", hipLaunchKernelGGL(k_rpt_light<1>, gridSearch, block, 0, s, F, *cb, tilesX, lists[2], lists[3], listCnt + 2));
         // K12 Sort_CtS / Sort_StC (IndirectLighting.cpp:690-742): the NtC map decides which pixels share a wave in Reconnect_StC, i.e. the
         // population of its boiling-suppression averages
         if (prm.sortSpatial)

@@ -555,74 +555,88 @@ __global__ void __launch_bounds__(kCoopBlock) ZR_WAVES(4) k_rpt_pathtrace_coop_w
 enum RptPixelPass { RPT_REPLAY_CTT = 0, RPT_REPLAY_TTC, RPT_RECONNECT_TEMPORAL, RPT_SPATIAL_SEARCH, RPT_REPLAY_CTS, RPT_REPLAY_STC };
 
 // light per-pixel kernels (no traversal, no scratch)
+// tiles per block of the light per-pixel kernels.  They end in ONE returning atomic per block and work list, and both list counters live in one cache
+// line: with a tile per block the 2 x 8160 atomics of a 1080p frame were the whole kernel (0.093 ms on the atrium for 29 MB of plane reads -- the
+// ~88 dequeues per microsecond one word sustains, MI355X_MICROARCH.md).  Four tiles per block: a quarter of the atomics.
+// (the search kernel does real work per pixel -- three dependent candidate gathers -- and is latency-bound rather than atomic-bound: two tiles)
+static constexpr uint32_t kLightTilesPerBlock = 4, kSearchTilesPerBlock = 2;
 template<int PASS>
 __global__ void __launch_bounds__(kBlock) k_rpt_light(rpt::RptFrame F, zr_frame_constants g, uint32_t tilesX, uint32_t* listA, uint32_t* listB, uint32_t* counts)
 {
-    uint32_t x, y; PixelOfThread(tilesX, F.ox0, F.oy0, &x, &y);
-    const bool in = F.Owns(x, y);
-    uint32_t a = 0, b = 0;      // replay class of this pixel for list A / B (0 = not on the list; zr_rpt.h ReplayClass)
-    if (PASS == 0)          // temporal work lists: pixels whose current / temporal reservoir needs a replay (k > 2)
-    {
-        if (in) { a = rpt::NeedsReplayCtT(F, x, y); b = rpt::NeedsReplayTtC(F, g, x, y); }
-    }
-    else                    // K15 spatial search, then the spatial work lists
-    {
-        if (PASS == 2)
-        {
-            // N3 experiment (north_star: "LDS-staged reservoir tiles for the spatial-reuse stencil"): the 46 x 46 texels (mr, depth, normal: 10 B)
-            // the 16 x 16 block's searches can touch (radius 15) staged in LDS first; same arithmetic, candidates read from the tile
-            constexpr int R = rpt::kSearchRadius, T = 16 + 2 * R;
-            __shared__ uint16_t tMr[T * T]; __shared__ float tDepth[T * T]; __shared__ uint32_t tNormal[T * T];
-            const uint32_t tile = blockIdx.x, tx0 = F.ox0 + (tile % tilesX) * 16u, ty0 = F.oy0 + (tile / tilesX) * 16u;
-            for (uint32_t i = threadIdx.x; i < (uint32_t)(T * T); i += kBlock)
-            {
-                const int gx = (int)tx0 - R + (int)(i % T), gy = (int)ty0 - R + (int)(i / T);
-                const bool ok = gx >= 0 && gy >= 0 && gx < (int)g.render_width && gy < (int)g.render_height && rpt::InPlanes(F.gb, gx, gy);
-                const size_t sp = ok ? rpt::Pix(F.gb, (uint32_t)gx, (uint32_t)gy) : 0;
-                tMr[i] = ok ? F.gb.mr[sp] : (uint16_t)0; tDepth[i] = ok ? F.gb.depth[sp] : 0.0f; tNormal[i] = ok ? F.gb.normal[sp] : 0u;
-            }
-            __syncthreads();
-            struct TileFetch
-            {
-                const uint16_t* mr; const float* depth; const uint32_t* normal; int x0, y0;
-                __device__ void operator()(int sx, int sy, uint16_t& m, float& d, uint32_t& n) const
-                { const int i = (sy - y0) * T + (sx - x0); m = mr[i]; d = depth[i]; n = normal[i]; }
-            } tf{tMr, tDepth, tNormal, (int)tx0 - R, (int)ty0 - R};
-            if (in) { rpt::SpatialSearchPixelT(F, g, x, y, tf); a = rpt::NeedsReplayCtS(F, x, y); b = rpt::NeedsReplayStC(F, x, y); }
-        }
-        else if (in) { rpt::SpatialSearchPixel(F, g, x, y); a = rpt::NeedsReplayCtS(F, x, y); b = rpt::NeedsReplayStC(F, x, y); }
-    }
-    const uint32_t pid = in ? (uint32_t)rpt::Pix(F.gb, x, y) : 0u;
-    // one atomic per block and list: with every wave appending (large scenes: most pixels carry k > 2 reservoirs) 65 k returning
-    // atomics on two neighbouring counters serialised in L2 and this trivial kernel took 0.54 ms (profiles/r02a_pmc_sq_rpt_atrium1080p.csv).
-    // Inside the block's chunk of a list the entries are ordered by replay class (k = 3, 4, >= 5 -- K12's buckets), so that the 64 lanes of a
-    // replay wave mostly walk paths of the same length; which thread replays which pixel has no effect on the result.
-    __shared__ uint32_t sCnt[2][3][kBlock / 64], sBase[2];
+    constexpr uint32_t TPB = PASS == 0 ? kLightTilesPerBlock : (PASS == 1 ? kSearchTilesPerBlock : 1u);      // (the LDS-tile experiment stages one tile's neighbourhood)
+    constexpr uint32_t VW = TPB * (uint32_t)(kBlock / 64);             // "virtual waves" of the block: (tile, wave) pairs, in that order
+    const uint32_t numTiles = tilesX * ((F.oh + 15u) / 16u);
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
-    uint64_t ma[3], mb[3];
-    for (uint32_t c = 0; c < 3u; c++)
+    uint32_t a[TPB], b[TPB], pid[TPB];      // replay class of this thread's pixel of tile t for list A / B (0 = not on the list; zr_rpt.h ReplayClass)
+    __shared__ uint32_t sCnt[2][3][VW], sBase[2];
+    for (uint32_t t = 0; t < TPB; t++)
     {
-        ma[c] = __ballot(a == c + 1u); mb[c] = __ballot(b == c + 1u);
-        if (lane == 0) { sCnt[0][c][wave] = (uint32_t)__popcll(ma[c]); sCnt[1][c][wave] = (uint32_t)__popcll(mb[c]); }
+        const uint32_t tile = blockIdx.x * TPB + t;
+        const uint32_t tx = tile % tilesX, ty = tile / tilesX;
+        const uint32_t x = F.ox0 + tx * 16u + (wave & 1u) * 8u + (lane & 7u), y = F.oy0 + ty * 16u + (wave >> 1) * 8u + (lane >> 3);
+        const bool in = tile < numTiles && F.Owns(x, y);
+        a[t] = 0; b[t] = 0;
+        if (PASS == 0)          // temporal work lists: pixels whose current / temporal reservoir needs a replay (k > 2)
+        {
+            if (in) { a[t] = rpt::NeedsReplayCtT(F, x, y); b[t] = rpt::NeedsReplayTtC(F, g, x, y); }
+        }
+        else                    // K15 spatial search, then the spatial work lists
+        {
+            if (PASS == 2)
+            {
+                // N3 experiment (north_star: "LDS-staged reservoir tiles for the spatial-reuse stencil"): the 46 x 46 texels (mr, depth, normal: 10 B)
+                // the 16 x 16 block's searches can touch (radius 15) staged in LDS first; same arithmetic, candidates read from the tile
+                constexpr int R = rpt::kSearchRadius, T = 16 + 2 * R;
+                __shared__ uint16_t tMr[T * T]; __shared__ float tDepth[T * T]; __shared__ uint32_t tNormal[T * T];
+                const uint32_t tx0 = F.ox0 + tx * 16u, ty0 = F.oy0 + ty * 16u;
+                for (uint32_t i = threadIdx.x; i < (uint32_t)(T * T); i += kBlock)
+                {
+                    const int gx = (int)tx0 - R + (int)(i % T), gy = (int)ty0 - R + (int)(i / T);
+                    const bool ok = gx >= 0 && gy >= 0 && gx < (int)g.render_width && gy < (int)g.render_height && rpt::InPlanes(F.gb, gx, gy);
+                    const size_t sp = ok ? rpt::Pix(F.gb, (uint32_t)gx, (uint32_t)gy) : 0;
+                    tMr[i] = ok ? F.gb.mr[sp] : (uint16_t)0; tDepth[i] = ok ? F.gb.depth[sp] : 0.0f; tNormal[i] = ok ? F.gb.normal[sp] : 0u;
+                }
+                __syncthreads();
+                struct TileFetch
+                {
+                    const uint16_t* mr; const float* depth; const uint32_t* normal; int x0, y0;
+                    __device__ void operator()(int sx, int sy, uint16_t& m, float& d, uint32_t& n) const
+                    { const int i = (sy - y0) * T + (sx - x0); m = mr[i]; d = depth[i]; n = normal[i]; }
+                } tf{tMr, tDepth, tNormal, (int)tx0 - R, (int)ty0 - R};
+                if (in) { rpt::SpatialSearchPixelT(F, g, x, y, tf); a[t] = rpt::NeedsReplayCtS(F, x, y); b[t] = rpt::NeedsReplayStC(F, x, y); }
+            }
+            else if (in) { rpt::SpatialSearchPixel(F, g, x, y); a[t] = rpt::NeedsReplayCtS(F, x, y); b[t] = rpt::NeedsReplayStC(F, x, y); }
+        }
+        pid[t] = in ? (uint32_t)rpt::Pix(F.gb, x, y) : 0u;
+        for (uint32_t c = 0; c < 3u; c++)
+        {
+            const uint64_t ma = __ballot(a[t] == c + 1u), mb = __ballot(b[t] == c + 1u);
+            if (lane == 0) { sCnt[0][c][t * (kBlock / 64) + wave] = (uint32_t)__popcll(ma); sCnt[1][c][t * (kBlock / 64) + wave] = (uint32_t)__popcll(mb); }
+        }
     }
+    // one atomic per block and list (see kLightTilesPerBlock).  Inside the block's chunk of a list the entries are ordered by replay class
+    // (k = 3, 4, >= 5 -- K12's buckets), so that the 64 lanes of a replay wave mostly walk paths of the same length; which thread replays which
+    // pixel has no effect on the result.
     __syncthreads();
     if (threadIdx.x < 2)
     {
         uint32_t total = 0;
-        for (int c = 0; c < 3; c++) for (int w = 0; w < kBlock / 64; w++) total += sCnt[threadIdx.x][c][w];
+        for (uint32_t c = 0; c < 3u; c++) for (uint32_t w = 0; w < VW; w++) total += sCnt[threadIdx.x][c][w];
         sBase[threadIdx.x] = total ? atomicAdd(counts + threadIdx.x, total) : 0u;
     }
     __syncthreads();
     const uint64_t below = (1ull << lane) - 1ull;
     uint32_t oa = sBase[0], ob = sBase[1];
     for (uint32_t c = 0; c < 3u; c++)
-    {
-        uint32_t ta = 0, tb = 0, wa = 0, wb = 0;      // bucket totals of the block, and of the waves before this one
-        for (uint32_t w = 0; w < (uint32_t)(kBlock / 64); w++) { const uint32_t na = sCnt[0][c][w], nb = sCnt[1][c][w]; ta += na; tb += nb; if (w < wave) { wa += na; wb += nb; } }
-        if (a == c + 1u) listA[oa + wa + (uint32_t)__popcll(ma[c] & below)] = pid;
-        if (b == c + 1u) listB[ob + wb + (uint32_t)__popcll(mb[c] & below)] = pid;
-        oa += ta; ob += tb;
-    }
+        for (uint32_t t = 0; t < TPB; t++)
+        {
+            const uint64_t ma = __ballot(a[t] == c + 1u), mb = __ballot(b[t] == c + 1u);
+            uint32_t wa = 0, wb = 0, ta = 0, tb = 0;      // entries of this (class, tile) before this wave, and in all of its waves
+            for (uint32_t w = 0; w < (uint32_t)(kBlock / 64); w++) { const uint32_t na = sCnt[0][c][t * (kBlock / 64) + w], nb = sCnt[1][c][t * (kBlock / 64) + w]; ta += na; tb += nb; if (w < wave) { wa += na; wb += nb; } }
+            if (a[t] == c + 1u) listA[oa + wa + (uint32_t)__popcll(ma & below)] = pid[t];
+            if (b[t] == c + 1u) listB[ob + wb + (uint32_t)__popcll(mb & below)] = pid[t];
+            oa += ta; ob += tb;
+        }
 }
 
 // K13 replays over work lists (device-side counts, fixed grid, grid-stride): only pixels with k > 2 pay for the heavy kernel.  One launch runs the
