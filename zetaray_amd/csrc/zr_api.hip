@@ -73,9 +73,8 @@ __global__ void __launch_bounds__(kBlock) k_pt_init(SceneView sc, zr_frame_const
     uint32_t x, y; PixelOfThread(tilesX, gb.x0, gb.y0, &x, &y);
     PathOut po; po.alive = false;
     if (x < gb.x0 + gb.w && y < gb.y0 + gb.h) PtInitPixel(sc, g, gb, prm, x, y, finalRGBA, firstBOP, po, TEX);
-    const uint32_t slot = AllocSlotWave(outCount, po.alive);
+    const uint32_t slot = AllocPathAndRaysBlock(outCount, out.rayList, cap, outRays, po.alive, po.alive && po.rayC_d.w >= 0, po.alive && po.rayM_d.w >= 0, po.alive && po.rayS_d.w >= 0);
     if (po.alive) WritePath(out, slot, po, TEX);
-    AppendRays(out.rayList, cap, outRays, slot, po.alive && po.rayC_d.w >= 0, po.alive && po.rayM_d.w >= 0, po.alive && po.rayS_d.w >= 0);
 }
 
 // trace stage, run-to-completion variant (default): grid-stride over the queue's compacted ray list
@@ -200,9 +199,8 @@ __device__ __forceinline__ void PtShadeBody(const SceneView& sc, const zr_frame_
         const uint32_t i = base + threadIdx.x;
         PathOut po; po.alive = false;
         if (i < n) PtShadePath(sc, g, prm, in, i, finalRGBA, firstBOP, groupMax, po, TEX);
-        const uint32_t slot = AllocSlotWave(outCount, po.alive);
+        const uint32_t slot = AllocPathAndRaysBlock(outCount, out.rayList, cap, outRays, po.alive, po.alive && po.rayC_d.w >= 0, po.alive && po.rayM_d.w >= 0, po.alive && po.rayS_d.w >= 0);
         if (po.alive) WritePath(out, slot, po, TEX);
-        AppendRays(out.rayList, cap, outRays, slot, po.alive && po.rayC_d.w >= 0, po.alive && po.rayM_d.w >= 0, po.alive && po.rayS_d.w >= 0);
     }
 }
 __global__ void __launch_bounds__(kBlock) k_pt_shade(SceneView sc, zr_frame_constants g, PtParams prm, PathQueue in, const uint32_t* inCount,
@@ -226,7 +224,7 @@ __global__ void __launch_bounds__(kBlock) k_pt_rr(SceneView sc, PtParams prm, Pa
     {
         const uint32_t i = base + threadIdx.x;
         const bool cont = i < n && PtRussianRoulette(sc, prm, q, i, groupMax, TEX);
-        AppendRays(q.rayList, cap, rays, i, cont, false, false);
+        AllocPathAndRaysBlock(nullptr, q.rayList, cap, rays, false, cont, false, false, true, i);
     }
 }
 

@@ -96,6 +96,47 @@ __device__ __forceinline__ void AppendRays(uint32_t* rayList, uint32_t cap, uint
     if (m) rayList[cap + s1] = slot;
     if (sh) rayList[2 * cap + s2] = slot;
 }
+// The same allocations for a whole 256-thread block: ONE returning atomic per counter and block instead of one per wave.  A word sustains ~88
+// returning atomics per microsecond (MI355X_MICROARCH.md); a 1080p stage of K9 is 32 640 waves, i.e. 0.37 ms of atomics per counter when every
+// wave allocates -- k_pt_init took 0.25 ms for work that needs a third of that.  want[k]: this lane wants a slot of counter k (k = 0: the path
+// queue, 1 - 3: the C / M / S ray lists; counters[k] may be null = unused).  All threads of the block must call this (two barriers inside).
+__device__ __forceinline__ void AllocSlotsBlock(uint32_t* const counters[4], const bool want[4], uint32_t slot[4])
+{
+    __shared__ uint32_t sCnt[4][kBlock / 64], sBase[4];
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    uint64_t m[4];
+    for (int k = 0; k < 4; k++) { m[k] = __ballot(want[k]); if (lane == 0) sCnt[k][wave] = (uint32_t)__popcll(m[k]); }
+    __syncthreads();
+    if (threadIdx.x < 4)
+    {
+        uint32_t total = 0;
+        for (int w = 0; w < kBlock / 64; w++) total += sCnt[threadIdx.x][w];
+        sBase[threadIdx.x] = (total && counters[threadIdx.x]) ? atomicAdd(counters[threadIdx.x], total) : 0u;
+    }
+    __syncthreads();
+    const uint64_t below = (1ull << lane) - 1ull;
+    for (int k = 0; k < 4; k++)
+    {
+        uint32_t before = 0;
+        for (uint32_t w = 0; w < wave; w++) before += sCnt[k][w];
+        slot[k] = sBase[k] + before + (uint32_t)__popcll(m[k] & below);
+    }
+    __syncthreads();      // (the next call of a grid-stride loop rewrites sCnt)
+}
+// path slot + ray-list entries of one wavefront stage through AllocSlotsBlock; returns the path's slot in the queue
+__device__ __forceinline__ uint32_t AllocPathAndRaysBlock(uint32_t* outCount, uint32_t* rayList, uint32_t cap, uint32_t* rayCount, bool alive, bool c, bool m, bool sh,
+    bool haveSlot = false, uint32_t givenSlot = 0)
+{
+    uint32_t* const ctr[4] = {haveSlot ? nullptr : outCount, rayCount, rayCount + kCounterStride, rayCount + 2 * kCounterStride};
+    const bool want[4] = {!haveSlot && alive, c, m, sh};
+    uint32_t s[4];
+    AllocSlotsBlock(ctr, want, s);
+    const uint32_t slot = haveSlot ? givenSlot : s[0];
+    if (c) rayList[s[1]] = slot;
+    if (m) rayList[cap + s[2]] = slot;
+    if (sh) rayList[2 * cap + s[3]] = slot;
+    return slot;
+}
 // entry j of the concatenation (C rays, M rays, S rays) of a queue's ray lists -> type, slot
 __device__ __forceinline__ void RayOfIndex(const uint32_t* rayList, uint32_t cap, uint32_t nC, uint32_t nM, uint32_t j, uint32_t& type, uint32_t& slot)
 {
