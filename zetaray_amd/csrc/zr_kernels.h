@@ -187,6 +187,9 @@ static constexpr int kRgiBlock = ZR_RGI_BLOCK;      // K10 (k_rgi), same trade a
 // per-lane ray counters -> one atomic pair per wave (all 64 lanes must call this)
 __device__ __forceinline__ void FlushRayCounters(unsigned long long* counters, const uint32_t* cnt)
 {
+#ifdef ZR_NO_RAY_COUNTERS      // (measurement build: what the per-wave counter atomics cost)
+    return;
+#endif
     uint32_t a = cnt[0], b = cnt[1];
     for (int s = 1; s < 64; s <<= 1) { a += __shfl_xor(a, s); b += __shfl_xor(b, s); }
     if (__lane_id() == 0)
