@@ -215,6 +215,19 @@ void zhx_svgf(const float* signal, const float* depth, const uint32_t* normal, c
     memcpy(histMoments, moments.data(), 2 * n * sizeof(float));
     memcpy(out, src, n * sizeof(F4));
 }
+// FNV-1a over the built tree: the 4-wide nodes, the triangles in leaf order, the stack bound (what the device would be given)
+uint64_t zhx_bvh_digest(const HxScene* s, uint32_t* numNodes, uint32_t* numTris, uint32_t* stackNeed)
+{
+    uint64_t h = 1469598103934665603ull;
+    auto eat = [&](const void* p, size_t n) { const uint8_t* b = (const uint8_t*)p; for (size_t i = 0; i < n; i++) { h ^= b[i]; h *= 1099511628211ull; } };
+    eat(s->bvh.nodes4.data(), s->bvh.nodes4.size() * sizeof(Bvh4Node));
+    eat(s->bvh.tris.data(), s->bvh.tris.size() * sizeof(BvhTri));
+    eat(&s->bvh.stackNeed, 4);
+    if (numNodes) *numNodes = (uint32_t)s->bvh.nodes4.size();
+    if (numTris) *numTris = (uint32_t)s->bvh.tris.size();
+    if (stackNeed) *stackNeed = s->bvh.stackNeed;
+    return h;
+}
 void zhx_set_k11_carry(int on) { g_k11_carry = on != 0; }
 void zhx_latch_heap_offsets(const HxScene* s, const zr_frame_constants* cb) { Latch(s, cb); }
 void zhx_estimate_power(const HxScene* s, float* out) { for (size_t i = 0; i < s->emissives.size(); i++) out[i] = EstimateTriPower(s->view, s->emissives[i]); }

@@ -81,6 +81,14 @@ class HostExecScene:
             lib().zhx_scene_destroy(self.h)
             self.h = None
 
+    def bvh_digest(self):
+        """(FNV-1a over the built 4-wide nodes + leaf-ordered triangles + stack bound, nodes, triangles, stack bound)"""
+        L = lib()
+        L.zhx_bvh_digest.restype = C.c_uint64
+        L.zhx_bvh_digest.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        n, t, st = C.c_uint32(), C.c_uint32(), C.c_uint32()
+        return int(L.zhx_bvh_digest(self.h, C.byref(n), C.byref(t), C.byref(st))), n.value, t.value, st.value
+
     def update_instances(self, instances, instance_to_world):
         L = lib()
         L.zhx_scene_update_instances.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32]

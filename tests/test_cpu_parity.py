@@ -342,3 +342,23 @@ def test_c_and_python_parameter_defaults_agree():
         if name in ("lvg_grid_dim", "lvg_extents", "lvg_offset_y", "use_lvg"):
             continue      # the light voxel grid block is filled in by the caller that turns it on (DefaultRendererImpl.h:73-77)
         assert a == b or (isinstance(a, float) and abs(a - b) <= 1e-7 * abs(b)), (name, a, b)
+
+
+def test_host_bvh_build_is_independent_of_its_thread_count():
+    """the forked SAH build (zr_bvh.h, ZR_BVH_THREADS): same 4-wide nodes, same leaf-ordered triangles, same stack bound for 1, 3 and 8 threads"""
+    import os
+    from tests.hostexec import zhx
+    from zetaray_amd import scene_io
+    sc = scene_io.make_synthetic_scene(num_tris=60000, num_emissive=2000, seed=3)
+    old = os.environ.get("ZR_BVH_THREADS")
+    try:
+        digests = []
+        for nt in ("1", "3", "8"):
+            os.environ["ZR_BVH_THREADS"] = nt
+            digests.append(zhx.HostExecScene(sc).bvh_digest())
+    finally:
+        if old is None:
+            os.environ.pop("ZR_BVH_THREADS", None)
+        else:
+            os.environ["ZR_BVH_THREADS"] = old
+    assert len(set(digests)) == 1 and digests[0][1] > 1000, digests
