@@ -227,3 +227,22 @@ def test_denoise_pass_at_3840x2160_is_deterministic_and_smooths(api, cornell_emi
     got, sig = outs[0]
     inner = (slice(900, 1200), slice(1700, 2100))
     assert np.abs(np.diff(got[inner][..., 1], axis=1)).mean() < 0.2 * np.abs(np.diff(sig[inner][..., 1], axis=1)).mean()
+
+
+def test_specification_vectors():
+    """tests/golden/denoise_spec.npz (tools/make_denoise_golden.py): the pass has no reference to pin it, these vectors are what keeps its definition
+    from drifting -- the oracle and the host-executed HIP stage functions both reproduce them bit for bit."""
+    from oracle import zro
+    from tests.hostexec import zhx
+    from tools.make_denoise_golden import inputs
+    gold = np.load(os.path.join(ROOT, "tests", "golden", "denoise_spec.npz"))
+    depth, normal, frames, kw = inputs()
+    assert np.array_equal(depth, gold["depth"]) and np.array_equal(normal, gold["normal"])
+    h, w = depth.shape
+    for impl in (zro.svgf, zhx.svgf):
+        hc, hm = np.zeros((h, w, 4), np.float32), np.zeros((h, w, 2), np.float32)
+        for f, (sig, motion, valid) in enumerate(frames):
+            assert np.array_equal(sig.view(np.uint32), gold[f"signal{f}"].view(np.uint32)) and np.array_equal(motion, gold[f"motion{f}"])
+            o, hc, hm = impl(sig, depth, normal, motion, depth, normal, hc, hm, temporal_valid=valid, **kw)
+            for name, got in (("out", o), ("hist", hc), ("mom", hm)):
+                assert np.array_equal(got.view(np.uint32), gold[f"{name}{f}"].view(np.uint32)), f"{impl.__module__}: frame {f}: {name}"
