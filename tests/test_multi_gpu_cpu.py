@@ -110,3 +110,18 @@ def test_balanced_layout_partitions_the_frame():
             for peer, send, recv in tiling.halo_plan(W, H, n, r, layout=L):
                 back = [(s2, r2) for p, s2, r2 in tiling.halo_plan(W, H, n, peer, layout=L) if p == r]
                 assert back and back[0] == (recv, send)
+
+
+def test_final_halo_policy_decision():
+    """tiling.frame_reads_history_across_tiles: the post-frame reservoir halo is only needed by a ReSTIR PT frame whose camera or scene moved"""
+    from zetaray_amd import scene_io, tiling
+    a = scene_io.make_frame_constants(256, 128, frame_num=3, num_emissives=2)
+    assert not tiling.frame_reads_history_across_tiles("restir_pt", a, False)
+    assert tiling.frame_reads_history_across_tiles("restir_pt", a, True)                     # an instance, a light or a material changed
+    assert tiling.frame_reads_history_across_tiles("restir_gi", a, False)                    # GI draws temporal candidates from a neighbourhood
+    b = scene_io.make_frame_constants(256, 128, frame_num=4, num_emissives=2, cam_pos=(0.1, 1.2, -4.0))
+    b["prev_view"], b["prev_view_inv"] = a["curr_view"], a["curr_view_inv"]
+    assert tiling.frame_reads_history_across_tiles("restir_pt", b, False)                    # the camera moved
+    c = scene_io.make_frame_constants(256, 128, frame_num=5, num_emissives=2, jitter=(0.25, -0.25))
+    c["prev_camera_jitter"] = np.float32([0.0, 0.0])
+    assert tiling.frame_reads_history_across_tiles("restir_pt", c, False)                    # only the jitter changed: still a different reprojection

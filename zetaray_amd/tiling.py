@@ -130,6 +130,15 @@ def halo_plan(w, h, n, rank, apron=APRON, layout=None):
     return plan
 
 
+def frame_reads_history_across_tiles(kind, cb, scene_changed):
+    """Can this frame's temporal stage read a previous-frame reservoir that belongs to another tile?  ReSTIR PT reads exactly the reprojected
+    pixel (FindTemporal), so with an unmoved camera (same view, same jitter) and an unchanged scene every pixel reads its own history and the
+    apron's previous reservoirs are never touched.  The other passes pick temporal candidates in a neighbourhood: always yes."""
+    if kind != "restir_pt" or scene_changed:
+        return True
+    return not (np.array_equal(cb["curr_view"], cb["prev_view"]) and np.array_equal(cb["curr_camera_jitter"], cb["prev_camera_jitter"]))
+
+
 class TiledRestirPT:
     """One rank of a tile-split renderer on a GPU: G-buffer + PreLighting + the pass with cross-pixel reuse (two stages) with
     the halo exchange in between, through torch.distributed P2P (backend nccl == RCCL over xGMI on ROCm).
@@ -268,13 +277,7 @@ class TiledRestirPT:
     EXCHANGES = {"restir_pt": (True, True), "restir_gi": (False, True), "di": (True, False), "sky_di": (True, False)}
 
     def history_crosses_tiles(self, cb):
-        """Can this frame's temporal stage read a previous-frame reservoir that belongs to another tile?  ReSTIR PT reads exactly the reprojected
-        pixel (FindTemporal), so with an unmoved camera (same view, same jitter) and an unchanged scene every pixel reads its own history and
-        the apron's previous reservoirs are never touched.  The other passes pick temporal candidates in a neighbourhood: always yes."""
-        if self.kind != "restir_pt":
-            return True
-        same_cam = (np.array_equal(cb["curr_view"], cb["prev_view"]) and np.array_equal(cb["curr_camera_jitter"], cb["prev_camera_jitter"]))
-        return not (same_cam and self.r.scene.version == self._scene_version_seen)
+        return frame_reads_history_across_tiles(self.kind, cb, self.r.scene.version != self._scene_version_seen)
 
     def render_frame(self, cb, exchange_final=True):
         """One frame of this rank's tile.  The FINAL halo (the reservoirs the temporal stage reads as "previous" in the apron) is exchanged at the
