@@ -246,3 +246,52 @@ def test_specification_vectors():
             o, hc, hm = impl(sig, depth, normal, motion, depth, normal, hc, hm, temporal_valid=valid, **kw)
             for name, got in (("out", o), ("hist", hc), ("mom", hm)):
                 assert np.array_equal(got.view(np.uint32), gold[f"{name}{f}"].view(np.uint32)), f"{impl.__module__}: frame {f}: {name}"
+
+
+@pytest.mark.parametrize("h,w", [(1, 1), (2, 3), (9, 33), (5, 70)])
+def test_ragged_and_degenerate_images(h, w):
+    """sizes below the filter footprint, nothing but misses, nothing but NaN: the oracle and the host-executed stage functions agree bit for bit and
+    stay finite; a frame of misses passes its signal through"""
+    from oracle import zro
+    from tests.hostexec import zhx
+    rng = np.random.default_rng(h * 131 + w)
+    depth = rng.uniform(2.0, 9.0, (h, w)).astype(np.float32)
+    normal = _oct32(rng.normal(size=(h, w, 3)).astype(np.float32) + np.float32([0, 0, -3]))
+    motion = np.zeros((h, w), np.uint32)
+    cases = {"plain": (depth, rng.uniform(0, 2, (h, w, 4)).astype(np.float32)),
+             "all misses": (np.full((h, w), FLT_MAX, np.float32), rng.uniform(0, 2, (h, w, 4)).astype(np.float32)),
+             "all NaN": (depth, np.full((h, w, 4), np.nan, np.float32))}
+    for name, (d, sig) in cases.items():
+        sa = [(np.zeros((h, w, 4), np.float32), np.zeros((h, w, 2), np.float32)) for _ in range(2)]
+        for f in range(3):
+            a = zro.svgf(sig, d, normal, motion, d, normal, *sa[0], temporal_valid=f > 0)
+            b = zhx.svgf(sig, d, normal, motion, d, normal, *sa[1], temporal_valid=f > 0)
+            for x, y in zip(a, b):
+                assert np.array_equal(x.view(np.uint32), y.view(np.uint32)), (name, f)
+            sa = [(a[1], a[2]), (b[1], b[2])]
+            assert np.isfinite(a[0]).all(), (name, f)
+        if name == "all misses":
+            assert np.array_equal(a[0][..., :3], sig[..., :3]) and np.all(a[0][..., 3] == 0)
+        if name == "all NaN":
+            assert np.all(a[0][..., :3] == 0)
+
+
+@pytest.mark.gpu
+def test_denoise_pass_on_an_image_smaller_than_its_footprint(api, cornell_emissive):
+    """40 x 24: every a-trous iteration from step 4 on reaches past the image on all sides, the 32 x 8 blocks are partial in x, the LDS tiles of
+    steps 1 and 2 hang over every border -- still the oracle's bits."""
+    from oracle import zro
+    w, h = 40, 24
+    r = api.Renderer(cornell_emissive, w, h, params=wire.default_params(), integrator=api.INTEGRATOR_RESTIR_PT)
+    dn = r.enable_denoise()
+    hc, hm = np.zeros((h, w, 4), np.float32), np.zeros((h, w, 2), np.float32)
+    prev_planes = None
+    for f in range(1, 4):
+        r.render_frame(scene_io.make_frame_constants(w, h, frame_num=f, num_emissives=len(cornell_emissive.emissives)))
+        planes, _ = r.gbuffer.download()
+        depth, normal, motion = planes[7].reshape(h, w), planes[1].reshape(h, w), planes[3].reshape(h, w)
+        pd, pn = (depth, normal) if prev_planes is None else prev_planes
+        want, hc, hm = zro.svgf(r.p_indirect.download(), depth, normal, motion, pd, pn, hc, hm, temporal_valid=f > 1)
+        prev_planes = (depth.copy(), normal.copy())
+        assert np.array_equal(dn.download_plane("denoised").view(np.uint32), want.view(np.uint32)), f"frame {f}"
+        assert np.array_equal(dn.download_plane("denoise_history").view(np.uint32), hc.view(np.uint32)), f"frame {f}: history"
