@@ -1559,3 +1559,21 @@ def test_restir_pt_one_round_grid_is_bit_exact(api, cornell_emissive, oracle_emi
     grid).  Same planes, same radiance as the oracle."""
     got = _rpt_compare(api, cornell_emissive, oracle_emissive, 512, 480, wire.default_params(), 2)
     assert got[..., :3].max() > 0
+
+
+def test_frames_without_any_geometry_on_gpu(api, cornell_emissive, oracle_emissive):
+    """Every primary ray misses (the camera looks straight up from outside the box): ReSTIR PT, ReSTIR GI and the K9 path tracer over three frames
+    -- work lists empty, every wave of every kernel idle after its first test -- still equal the oracle, with zero radiance and only primary rays."""
+    from oracle import zro
+    w, h = 208, 96
+    prm = wire.default_params()
+    cam = dict(view_dir=(0, 1, 0), up=(0, 0, 1))
+    got = _rpt_compare(api, cornell_emissive, oracle_emissive, w, h, prm, 3, cam=cam)
+    assert not got[..., :3].any()
+    for integ in (api.INTEGRATOR_RESTIR_GI, api.INTEGRATOR_PATH_TRACING):
+        r = api.Renderer(cornell_emissive, w, h, params=prm, integrator=integ)
+        for f in range(1, 4):
+            r.render_frame(_frame(cornell_emissive, w, h, f, **cam))
+        assert not r.final()[..., :3].any()
+        n_closest, n_shadow = r.p_indirect.read_counters()
+        assert n_shadow == 0 and n_closest == 0, (integ, n_closest, n_shadow)

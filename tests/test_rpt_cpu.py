@@ -209,3 +209,17 @@ def test_rpt_sun_sky_bit_exact(kind, carry):
     assert a[..., :3].max() > 0
     A = o.plane("A")[..., 0]
     assert (((A >> 16) & 3) != 0).any()          # some reservoirs reconnect into the sun / sky (case 2)
+
+
+def test_frames_without_any_geometry(cornell_emissive, oracle_emissive, hx_emissive):
+    """the camera looks straight up from outside the box: every primary ray misses.  ReSTIR PT (3 frames, so the temporal and spatial stages run over nothing but
+    invalid pixels) == the oracle, nothing but the primary rays is traced and the radiance is zero."""
+    w, h = 48, 32
+    prm = wire.default_params()
+    o, x = zro.OracleRPT(oracle_emissive, w, h), zhx.HostExecRPT(hx_emissive, w, h)
+    for f in range(1, 4):
+        cb = _cb(cornell_emissive, w, h, f, view_dir=(0, 1, 0), up=(0, 0, 1))      # straight up from outside the box
+        a, b = o.render(cb, prm), x.render(cb, prm)
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), f"frame {f}"
+        _assert_same_state(o, x, f)
+        assert not a[..., :3].any()
