@@ -1577,3 +1577,23 @@ def test_frames_without_any_geometry_on_gpu(api, cornell_emissive, oracle_emissi
         assert not r.final()[..., :3].any()
         n_closest, n_shadow = r.p_indirect.read_counters()
         assert n_shadow == 0 and n_closest == 0, (integ, n_closest, n_shadow)
+
+
+def test_scene_without_bvh_nodes_on_gpu(api, cornell_emissive):
+    """Six triangles (a wall, the light, a wall of the Cornell box): BvhBuilder emits no nodes and the kernels traverse the single leaf that holds
+    everything (kWholeSceneLeaf).  G-buffer, ReSTIR PT (planes included) and the K9 path tracer == the oracle."""
+    from oracle import zro
+    from tests.test_rpt_cpu import _six_triangle_scene
+    sc = _six_triangle_scene(cornell_emissive)
+    osc = zro.OracleScene(sc)
+    w, h = 200, 120
+    prm = wire.default_params()
+    got = _rpt_compare(api, sc, osc, w, h, prm, 3)
+    assert (got[..., :3].sum(-1) > 0).sum() > 200
+    r = api.Renderer(sc, w, h, params=prm)
+    assert r.scene.bvh_info()[0] == 0
+    cb = _frame(sc, w, h, 1)
+    r.render_frame(cb)
+    _, planes = osc.gbuffer(cb)
+    want, _ = osc.pathtrace(cb, planes, prm)
+    assert np.array_equal(r.final().view(np.uint32), want.view(np.uint32))

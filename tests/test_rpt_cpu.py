@@ -223,3 +223,39 @@ def test_frames_without_any_geometry(cornell_emissive, oracle_emissive, hx_emiss
         assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), f"frame {f}"
         _assert_same_state(o, x, f)
         assert not a[..., :3].any()
+
+
+def _six_triangle_scene(cornell_emissive):
+    """three quads of the Cornell box -- a wall, the light, another wall: 6 triangles, below BvhBuilder::kTinyScene, so the scene has NO nodes and every
+    query runs against the single leaf that holds all triangles (zr_dev_scene.h kWholeSceneLeaf)"""
+    import copy
+    keep = [1, 6, 7]
+    s2 = copy.copy(cornell_emissive)
+    s2.instances = cornell_emissive.instances[keep].copy()
+    s2.instance_to_world = cornell_emissive.instance_to_world[keep].copy()
+    s2.instance_mask = cornell_emissive.instance_mask[keep].copy()
+    s2.instance_num_tris = cornell_emissive.instance_num_tris[keep].copy()
+    em = cornell_emissive.emissives.copy()
+    for p in range(len(em)):
+        em[p]["id"] = scene_io.pcg3d(keep.index(6), 0, p)[0]      # the light is instance 1 of this scene: its triangles' IDs hash the new index
+    s2.emissives = em
+    s2._desc = None
+    return s2
+
+
+def test_scene_without_bvh_nodes(cornell_emissive):
+    """a 6-triangle scene (no BVH nodes: one leaf over everything): G-buffer and three ReSTIR PT frames, host-executed HIP stage functions == oracle"""
+    sc = _six_triangle_scene(cornell_emissive)
+    assert sc.num_tris == 6
+    osc = zro.OracleScene(sc)
+    hx = zhx.HostExecScene(sc, osc.alias)
+    assert hx.bvh_digest()[1] == 0          # no nodes
+    w, h = 64, 48
+    prm = wire.default_params()
+    o, x = zro.OracleRPT(osc, w, h), zhx.HostExecRPT(hx, w, h)
+    for f in range(1, 4):
+        cb = _cb(sc, w, h, f)
+        a, b = o.render(cb, prm), x.render(cb, prm)
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), f"frame {f}"
+        _assert_same_state(o, x, f)
+    assert (a[..., :3].sum(-1) > 0).sum() > 50
