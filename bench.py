@@ -42,6 +42,12 @@ RPT_PIXEL_BYTES = {
     "rpt_reconnect_spatial": 2 + 2 * 27 + 3 * 62 + 16 + 2 * 42 + 62 + 16,   # CtS + StC fused
     "rpt_spatial_search": 4 * 14 + 2 + 8,
     "rpt_classify_temporal": 2 + 4 + 8,
+    # replay passes (both directions in one launch): per listed pixel the reservoir (62) + G-buffer planes (27) in, one r-buffer (42) out --
+    # an upper bound per pixel of the frame, the lists hold a subset; sort: plane A's k / flags (4) in, two u16 maps out
+    "rpt_replay_temporal": 2 * (62 + 27 + 42),
+    "rpt_replay_spatial": 2 * (62 + 27 + 42),
+    "rpt_sort_temporal": 2 * 4 + 2 * 2,
+    "rpt_sort_spatial": 2 * 4 + 2 * 2,
 }
 
 
@@ -79,7 +85,7 @@ def source_hash():
     return h.hexdigest()[:16]
 
 
-def cpu_baseline(scene_host, cb, max_rays=1_000_000, rpt_params=None):
+def cpu_baseline(scene_host, cb, max_rays=1_000_000, rpt_params=None, sample=(2, 8)):
     """Single-thread CPU traversal (oracle BVH2 + ABI intersection) over primary + diffuse-bounce rays of this frame."""
     from oracle import zro
     o = zro.OracleScene(scene_host, force_bvh=True)
@@ -115,21 +121,24 @@ def cpu_baseline(scene_host, cb, max_rays=1_000_000, rpt_params=None):
         return {"value": round(reps * len(rays) / tot / 1e6, 4), "unit": "Mrays/s", "cores": 1, "kind": "port",
                 "sample": f"{reps} x {len(rays)} closest-hit rays (random primary + diffuse bounce) of the same frame, oracle BVH2, "
                           f"{tot:.1f} s, host has {os.cpu_count()} logical cores"}
-    # the whole workload on a bounded sample: the oracle's G-buffer + ReSTIR PT (same parameters) at half resolution for 8 frames
-    # (temporal + spatial reuse active from frame 2), one thread; rays = the oracle's own ray counters
+    # the whole workload on a bounded sample: the oracle's G-buffer + ReSTIR PT (same parameters) at reduced resolution for a few frames
+    # (temporal + spatial reuse active from frame 2), one thread; rays = the oracle's own ray counters.  Cornell: half resolution x 8 frames
+    # (~12 s); the atrium: quarter resolution x 4 frames (~25 s)
     import time
-    from zetaray_amd import scene_io
-    sw, sh = max(64, w // 2), max(36, h // 2)
+    div, nframes = sample
+    sw, sh = max(64, w // div), max(36, h // div)
     orpt = zro.OracleRPT(o, sw, sh)
     rays_total, t0 = 0, time.perf_counter()
-    for f in range(1, 9):
+    for f in range(1, nframes + 1):
         cbs = cb.copy()
         cbs["render_width"], cbs["render_height"], cbs["frame_num"] = sw, sh, f
+        if rpt_params.presampling:
+            o.presample(f, int(rpt_params.num_sample_sets), int(rpt_params.sample_set_size))      # K3, the light sets this frame's NEE draws from
         orpt.render(cbs, rpt_params)
         rays_total += sum(orpt.counters)
     dt_rpt = time.perf_counter() - t0
     return {"value": round(rays_total / dt_rpt / 1e6, 4), "unit": "Mrays/s", "cores": 1, "kind": "port",
-            "sample": f"oracle G-buffer + ReSTIR PT, {sw}x{sh} x 8 frames ({rays_total} rays, {dt_rpt:.1f} s, 1 thread of "
+            "sample": f"oracle G-buffer + ReSTIR PT, {sw}x{sh} x {nframes} frames ({rays_total} rays, {dt_rpt:.1f} s, 1 thread of "
                       f"{os.cpu_count()} logical cores); BVH traversal alone: {trace_only:.2f} Mrays/s"}
 
 
@@ -171,67 +180,13 @@ def read_prof(api):
     return res
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=256)
-    ap.add_argument("--warmup", type=int, default=64)
-    ap.add_argument("--width", type=int, default=1920)
-    ap.add_argument("--height", type=int, default=1080)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--denoise", action="store_true", help="add the denoise pass (ZR_PASS_DENOISE) on the indirect image (one GPU)")
-    ap.add_argument("--scene", default=os.path.join(ROOT, "tests", "golden", "cornell_emissive.npz"),
-                    help="wire-format .npz, or 'synthetic' = the procedural Sponza-class scene of BASELINE config 4 "
-                         "(262144 triangles + 100000 emissive triangles, presampled light sets on)")
-    ap.add_argument("--synthetic-tris", type=int, default=262144)
-    ap.add_argument("--synthetic-layout", choices=["atrium", "soup"], default="atrium")
-    ap.add_argument("--synthetic-emissives", type=int, default=100000)
-    ap.add_argument("--no-final-halo", action="store_true",
-                    help="skip the post-frame halo exchange (exact for a static camera, which this bench uses)")
-    ap.add_argument("--direct", action="store_true", help="also run the ReSTIR DI (emissive) pass every frame (N = 1)")
-    ap.add_argument("--sky-direct", action="store_true", help="also run the sun + sky ReSTIR DI pass (K7/K8) every frame (N = 1)")
-    ap.add_argument("--textured", action="store_true",
-                    help="bind the procedural test texture set to the synthetic scene (TEXTURED kernel permutations: ray differentials, material maps)")
-    ap.add_argument("--di-only", action="store_true", help="skip the indirect pass: BASELINE config 1 (ReSTIR DI only)")
-    ap.add_argument("--integrator", choices=["restir_pt", "restir_gi", "pt"], default="restir_pt",
-                    help="restir_pt = K11-K16 (BASELINE metric); pt = K9 unidirectional path tracer")
-    ap.add_argument("--config", choices=sorted(CONFIGS), default=None,
-                    help="BASELINE.json configuration presets (same JSON line; the default without --config is the metric's own configuration, "
-                         "Cornell (emissive) 1920x1080 ReSTIR PT): " + "; ".join(f"{k} = {v[0]}" for k, v in sorted(CONFIGS.items())))
-    ap.add_argument("--settle", type=int, default=None,
-                    help="untimed frames rendered BEFORE the warm-up so that the temporal reservoirs have reached their M caps whatever --warmup is "
-                         "(default: 32 for the ReSTIR integrators, 0 otherwise)")
-    args = ap.parse_args()
-    if args.config:
-        for k, v in CONFIGS[args.config][1].items():
-            if k in ("steps", "warmup") and getattr(args, k) != ap.get_default(k):
-                continue        # an explicit --steps / --warmup wins over the preset's
-            setattr(args, k, v)
-
+def measure(args, ctx):
+    """One workload end to end on the devices of this job: scene + passes resident in HBM, settle + warm-up frames, the timed region of
+    args.steps frames (barrier + torch.cuda.synchronize() on both sides, max over ranks), then -- rank 0, N = 1 -- the roofline block of the
+    dominant kernel (hipEvent timing inside the library) and the CPU baseline.  Returns the JSON line as a dict."""
     import torch
     from zetaray_amd import api, scene_io, wire
-
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if os.environ.get("ZR_BENCH_SHARED_GPU") == "1":
-            # test rig for a box with one GPU (tests/test_gpu_parity.py): every rank renders on device 0, the ranks talk over gloo and the halo
-            # strips go through the host -- the orchestration (probe frames, cost-balanced re-tiling, timing protocol) is the multi-GPU one
-            local_rank = 0
-            os.environ["ZR_HALO_TRANSPORT"] = "torch_p2p"
-            torch.cuda.set_device(0)
-            dist.init_process_group("gloo")
-        else:
-            torch.cuda.set_device(local_rank)
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
-    torch.cuda.set_device(local_rank)
-    cdev = "cpu" if (dist is not None and dist.get_backend() == "gloo") else "cuda"      # where the few scalars of the timing protocol are reduced
-
+    world, rank, local_rank, dist, cdev = ctx["world"], ctx["rank"], ctx["local_rank"], ctx["dist"], ctx["cdev"]
     W, H = args.width, args.height
     cam = {}
     tex_offsets = None
@@ -394,7 +349,7 @@ def main():
                        f"rank per exchange, {exch_per_frame:g} exchanges per frame (the previous frame's final reservoirs are fetched only by frames whose reprojection can cross a tile border: not while camera and scene stand still)"
                        if (tiled is not None and world > 1) else ""),
                    "halo_transport": (tiled.transport if (tiled is not None and world > 1) else None),
-                   "preset": args.config, "settle_frames": settle,
+                   "preset": args.config, "settle_frames": settle, "arith": args.arith, "library": os.path.basename(api.LIB_PATH),
                    "rays_per_frame": round((n_closest + n_shadow) / args.steps, 1),
                    "redundant_apron_primary_rays_per_frame": round(apron_rays / args.steps, 1),
                    "fps": round(1e3 / ms_per_step, 2)},
@@ -474,7 +429,10 @@ def main():
         elif dom.startswith("denoise_"):
             bytes_launch = DENOISE_PIXEL_BYTES[dom] * W * H
         else:
-            bytes_launch = 0.0
+            raise RuntimeError(f"bench.py has no algorithmic-bytes model for the dominant kernel '{dom}' (timed kernels: {sorted(agg)}): "
+                               f"add it to the byte tables instead of reporting a roofline of 0")
+        if dom.startswith("rpt_") and dom not in RPT_PIXEL_BYTES:
+            raise RuntimeError(f"bench.py: ReSTIR PT kernel '{dom}' is missing from RPT_PIXEL_BYTES")
         achieved = bytes_launch / (avg_ms * 1e-3) / 1e9
         plane_px = (RPT_PIXEL_BYTES.get(dom) if dom.startswith("rpt_") else (23 + 2 * 40 + 27 + 16) if dom == "rgi" else (27 * 3 + 2 * 13 + 32) if dom in ("sdi_temporal", "sdi_spatial", "rdi_temporal", "rdi_spatial") else
                     47 if dom == "gbuffer" else DENOISE_PIXEL_BYTES.get(dom))
@@ -488,8 +446,9 @@ def main():
                      "atrium" if (args.scene == "synthetic" and args.synthetic_layout == "atrium" and args.synthetic_tris == 262144
                                   and args.synthetic_emissives == 100000) else None)
         wl_tag = {"restir_pt": "rpt", "restir_gi": "gi", "pt": "pt"}[args.integrator] + ("" if (W, H) == (1920, 1080) else f"_{W}x{H}")
-        pmc_rel = os.path.join("profiles", f"r03_pmc_{wl_tag}_{scene_tag}.json")
-        if plain and scene_tag and os.path.exists(os.path.join(ROOT, pmc_rel)):
+        pmc_rel = next((q for q in (os.path.join("profiles", f"{rnd}_pmc_{wl_tag}_{scene_tag}.json") for rnd in ("r04", "r03"))
+                        if os.path.exists(os.path.join(ROOT, q))), "")
+        if plain and scene_tag and pmc_rel:
             table = json.load(open(os.path.join(ROOT, pmc_rel)))
             # only a profile of THESE kernel sources describes the library that was just timed
             if table.get("_meta", {}).get("source_hash") == source_hash():
@@ -523,7 +482,98 @@ def main():
             cbf = scene_io.make_frame_constants(W, H, frame_num=1, num_emissives=len(sc.emissives), **cam)
             if tex_offsets is not None:
                 scene_io.set_texture_heap_offsets(cbf, tex_offsets)
-            out["cpu_baseline"] = cpu_baseline(sc, cbf, rpt_params=prm if (rpt and args.scene != "synthetic") else None)
+            out["cpu_baseline"] = cpu_baseline(sc, cbf, rpt_params=prm if rpt else None, max_rays=1_000_000 if args.scene != "synthetic" else 200_000,
+                                               sample=(2, 8) if args.scene != "synthetic" else (4, 4))
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=256)
+    ap.add_argument("--warmup", type=int, default=64)
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--arith", choices=["contract", "fast"], default="contract",
+                    help="contract = libzetaray_amd.so, the bit-exact arithmetic contract of include/zr_detmath.h (the product default, what every parity test "
+                         "loads); fast = libzetaray_amd_fast.so, the tolerance-mode build of the same sources (hardware rcp / rsq / exp / log / sin / cos, "
+                         "contracted FMAs; parity = tests/test_fast_arith.py).  A fast line says so in config.arith and is never the default.")
+    ap.add_argument("--no-extra-workloads", action="store_true",
+                    help="the default line also measures BASELINE config 4 (atrium 1080p ReSTIR PT) in the same process as extra_workloads[0]; this skips it")
+    ap.add_argument("--denoise", action="store_true", help="add the denoise pass (ZR_PASS_DENOISE) on the indirect image (one GPU)")
+    ap.add_argument("--scene", default=os.path.join(ROOT, "tests", "golden", "cornell_emissive.npz"),
+                    help="wire-format .npz, or 'synthetic' = the procedural Sponza-class scene of BASELINE config 4 "
+                         "(262144 triangles + 100000 emissive triangles, presampled light sets on)")
+    ap.add_argument("--synthetic-tris", type=int, default=262144)
+    ap.add_argument("--synthetic-layout", choices=["atrium", "soup"], default="atrium")
+    ap.add_argument("--synthetic-emissives", type=int, default=100000)
+    ap.add_argument("--no-final-halo", action="store_true",
+                    help="skip the post-frame halo exchange (exact for a static camera, which this bench uses)")
+    ap.add_argument("--direct", action="store_true", help="also run the ReSTIR DI (emissive) pass every frame (N = 1)")
+    ap.add_argument("--sky-direct", action="store_true", help="also run the sun + sky ReSTIR DI pass (K7/K8) every frame (N = 1)")
+    ap.add_argument("--textured", action="store_true",
+                    help="bind the procedural test texture set to the synthetic scene (TEXTURED kernel permutations: ray differentials, material maps)")
+    ap.add_argument("--di-only", action="store_true", help="skip the indirect pass: BASELINE config 1 (ReSTIR DI only)")
+    ap.add_argument("--integrator", choices=["restir_pt", "restir_gi", "pt"], default="restir_pt",
+                    help="restir_pt = K11-K16 (BASELINE metric); pt = K9 unidirectional path tracer")
+    ap.add_argument("--config", choices=sorted(CONFIGS), default=None,
+                    help="BASELINE.json configuration presets (same JSON line; the default without --config is the metric's own configuration, "
+                         "Cornell (emissive) 1920x1080 ReSTIR PT): " + "; ".join(f"{k} = {v[0]}" for k, v in sorted(CONFIGS.items())))
+    ap.add_argument("--settle", type=int, default=None,
+                    help="untimed frames rendered BEFORE the warm-up so that the temporal reservoirs have reached their M caps whatever --warmup is "
+                         "(default: 32 for the ReSTIR integrators, 0 otherwise)")
+    args = ap.parse_args()
+    if args.config:
+        for k, v in CONFIGS[args.config][1].items():
+            if k in ("steps", "warmup") and getattr(args, k) != ap.get_default(k):
+                continue        # an explicit --steps / --warmup wins over the preset's
+            setattr(args, k, v)
+
+    if args.arith == "fast":
+        os.environ["ZETARAY_AMD_LIB"] = os.path.join(ROOT, "zetaray_amd", "libzetaray_amd_fast.so")      # read by zetaray_amd/api.py at import
+    import torch
+    from zetaray_amd import api, scene_io, wire
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if os.environ.get("ZR_BENCH_SHARED_GPU") == "1":
+            # test rig for a box with one GPU (tests/test_gpu_parity.py): every rank renders on device 0, the ranks talk over gloo and the halo
+            # strips go through the host -- the orchestration (probe frames, cost-balanced re-tiling, timing protocol) is the multi-GPU one
+            local_rank = 0
+            os.environ["ZR_HALO_TRANSPORT"] = "torch_p2p"
+            torch.cuda.set_device(0)
+            dist.init_process_group("gloo")
+        else:
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    torch.cuda.set_device(local_rank)
+    cdev = "cpu" if (dist is not None and dist.get_backend() == "gloo") else "cuda"      # where the few scalars of the timing protocol are reduced
+
+    ctx = dict(world=world, rank=rank, local_rank=local_rank, dist=dist, cdev=cdev)
+    out = measure(args, ctx)
+    default_line = (args.config is None and world == 1 and args.scene.endswith("cornell_emissive.npz") and args.integrator == "restir_pt"
+                    and (args.width, args.height) == (1920, 1080) and not (args.direct or args.sky_direct or args.denoise or args.di_only or args.textured))
+    if default_line and not args.no_extra_workloads:
+        # the driver runs `bench.py --gpus 1`: `value` stays the metric's own configuration (Cornell), and BASELINE config 4's scene -- the
+        # 380k-triangle / 100k-light atrium at 1080p -- is measured in the same process with its own roofline and CPU baseline
+        extra = []
+        for preset in ("4",):
+            a2 = argparse.Namespace(**vars(args))
+            a2.config = preset
+            for k, v in CONFIGS[preset][1].items():
+                setattr(a2, k, v)
+            o2 = measure(a2, ctx)
+            extra.append({"preset": preset, "workload": o2["config"]["workload"], "ms_per_step": o2["ms_per_step"], "value": o2["value"], "unit": o2["unit"],
+                          "steps": o2["steps"], "warmup": o2["warmup"], "rays_per_frame": o2["config"]["rays_per_frame"], "fps": o2["config"]["fps"],
+                          "roofline": o2.get("roofline"), "cpu_baseline": o2.get("cpu_baseline")})
+        out["extra_workloads"] = extra
     if rank == 0:
         print(json.dumps(out))
     if dist is not None:

@@ -35,7 +35,7 @@ extern "C" {
 
 /* 2: zr_params grew (ae_*, display_*, tex_filter); stream-ordered zr_scene_*_async entry points; zr_scene_get_presampled_sets.
  * A caller built against another version must not pass its zr_params to zr_pass_set_params: check zr_abi_version() first. */
-#define ZR_ABI_VERSION 2
+#define ZR_ABI_VERSION 3
 
 typedef enum zr_status {
     ZR_OK = 0,
@@ -155,6 +155,12 @@ typedef struct zr_params {
     float    svgf_sigma_z;          /* 1.0: depth edge-stopping, in units of the pixel's screen-space depth slope */
     uint32_t svgf_normal_power_log2;/* 7: normal weight = max(0, n . n_q) ^ (2 ^ 7) */
     uint32_t svgf_iterations;       /* 5 a-trous iterations (steps 1, 2, 4, 8, 16); 0..8 */
+    /* ZR_PASS_INDIRECT, ReSTIR PT (ABI version 3): IndirectLighting::m_numSpatialPasses ("#Spatial Passes", range 0..2, IndirectLighting.cpp:1240,
+       default 1 IndirectLighting.h:392).  0: no spatial reuse (the temporal pass writes the frame's radiance); 2: the host loop of
+       IndirectLighting.cpp:616-621, 860-870 -- a second search / sort / replay / reconnect round whose inputs are the first round's outputs
+       (reservoir sets swapped), the target plane not rewritten in between (ReSTIR_PT_Reconnect_StC.hlsl:328-346).  One-device only for 2:
+       the tile split exchanges no halo between the rounds (ZR_ERR_UNSUPPORTED from zr_pass_render_stage). */
+    uint32_t num_spatial_passes;    /* 1 */
 } zr_params;
 
 /* enum class Tonemapper, Display_Common.h:21-30 */

@@ -150,7 +150,8 @@ int zrefp_rpt_render(RefScene* r, RptState* S, const zr_frame_constants* cb, con
     const uint32_t srvAIdx = c == 1 ? RESERVOIR_0_A_SRV : RESERVOIR_1_A_SRV;
     const uint32_t uavAIdx = c == 1 ? RESERVOIR_1_A_UAV : RESERVOIR_0_A_UAV;
     const bool doTemporal = (prm->flags & CB_IND_FLAGS::TEMPORAL_RESAMPLE) && S->temporalValid;
-    const bool doSpatial = (prm->flags & CB_IND_FLAGS::SPATIAL_RESAMPLE) && doTemporal;       // m_numSpatialPasses = 1 (IndirectLighting.h:392)
+    const uint32_t numSpatialPasses = prm->num_spatial_passes > 2u ? 2u : prm->num_spatial_passes;      // m_numSpatialPasses, 0..2 (IndirectLighting.cpp:1240)
+    const bool doSpatial = (prm->flags & CB_IND_FLAGS::SPATIAL_RESAMPLE) && (numSpatialPasses > 0) && doTemporal;       // IndirectLighting.cpp:905-906
     {
         const uint32_t dx = CeilDiv(w, RESTIR_PT_PATH_TRACE_GROUP_DIM_X), dy = CeilDiv(h, RESTIR_PT_PATH_TRACE_GROUP_DIM_Y);
         if (doTemporal) PT.Flags |= CB_IND_FLAGS::TEMPORAL_RESAMPLE;
@@ -185,9 +186,10 @@ int zrefp_rpt_render(RefScene* r, RptState* S, const zr_frame_constants* cb, con
         Run(zrefp_shader_rpt_reconnect_ttc, &RU, sizeof(RU), tx, ty, false);
     }
     if (doSpatial)
+    for (uint32_t pass = 0; pass < numSpatialPasses; pass++)
     {
-        // ---- ReSTIR_PT_Spatial, IndirectLighting.cpp:598-875 (one pass)
-        RU.Packed = (RU.Packed & ~0xf000u) | ((1u << 14) | (0u << 12));
+        // ---- ReSTIR_PT_Spatial, IndirectLighting.cpp:598-875: for (pass < m_numSpatialPasses)
+        RU.Packed = (RU.Packed & ~0xf000u) | ((numSpatialPasses << 14) | (pass << 12));
         {
             const uint32_t dx = CeilDiv(w, RESTIR_PT_SPATIAL_SEARCH_GROUP_DIM_X), dy = CeilDiv(h, RESTIR_PT_SPATIAL_SEARCH_GROUP_DIM_Y);
             cb_ReSTIR_PT_SpatialSearch ss; memset(&ss, 0, sizeof(ss));
@@ -216,6 +218,8 @@ int zrefp_rpt_render(RefScene* r, RptState* S, const zr_frame_constants* cb, con
         RU.DispatchDimX_NumGroupsInTile = ((RESTIR_PT_TILE_WIDTH * sy) << 16) | sx;
         Run(zrefp_shader_rpt_reconnect_cts, &RU, sizeof(RU), sx, sy, false);
         Run(zrefp_shader_rpt_reconnect_stc, &RU, sizeof(RU), sx, sy, false);
+        // Prepare for next iteration, IndirectLighting.cpp:860-870: swap input and output reservoirs
+        if (pass == 0 && numSpatialPasses == 2u) std::swap(RU.PrevReservoir_A_DescHeapIdx, RU.Reservoir_A_DescHeapIdx);
     }
     // ---- Render() tail, IndirectLighting.cpp:1021-1024
     S->temporalValid = true;

@@ -1969,12 +1969,14 @@ static void Render(const Scene& sc, const zr_frame_constants& g, const zr_gbuffe
 {
     GBufRead gb(gbCurr);
     const bool doTemporal = (prm.flags & ZR_IND_TEMPORAL_RESAMPLE) && st.temporalValid && gbPrev != nullptr;
-    const bool doSpatial = (prm.flags & ZR_IND_SPATIAL_RESAMPLE) && doTemporal;
+    const bool doSpatial = (prm.flags & ZR_IND_SPATIAL_RESAMPLE) && doTemporal && prm.num_spatial_passes > 0;      // IndirectLighting.cpp:906
     // reservoirs are written when temporal resampling is on for this frame or when the temporal textures were just reset
     const bool writeReservoirs = doTemporal || !st.temporalValid;
     PathTracePass(sc, g, gb, prm, st, doTemporal, writeReservoirs, finalRGBA);
     if (doTemporal) { GBufRead gp(gbPrev); TemporalPass(sc, g, gb, gp, prm, st, doSpatial, finalRGBA); }
-    if (doSpatial) SpatialPass(sc, g, gb, prm, st, finalRGBA);
+    // for (pass < m_numSpatialPasses), IndirectLighting.cpp:616-875: every round searches again, swaps inputs and outputs (SpatialPass flips
+    // st.currIdx, :682-688) and leaves the target plane alone (ReSTIR_PT_Reconnect_StC.hlsl:328-346: numPasses = 1 is hard-coded in the shader)
+    if (doSpatial) for (uint32_t pass = 0; pass < prm.num_spatial_passes && pass < 2u; pass++) SpatialPass(sc, g, gb, prm, st, finalRGBA);
     st.temporalValid = true;
     st.currIdx = 1 - st.currIdx;
 }

@@ -415,8 +415,9 @@ void zhx_rpt_render_stage(const HxScene* s, HxRpt* R, const zr_frame_constants* 
     if (stages & 1)
     {
         R->doTemporal = (params->flags & ZR_IND_TEMPORAL_RESAMPLE) && R->temporalValid && prev;
-        R->doSpatial = (params->flags & ZR_IND_SPATIAL_RESAMPLE) && R->doTemporal;
+        R->doSpatial = (params->flags & ZR_IND_SPATIAL_RESAMPLE) && R->doTemporal && params->num_spatial_passes > 0;
     }
+    const uint32_t numSpatialPasses = params->num_spatial_passes > 2u ? 2u : params->num_spatial_passes;
     prm.doTemporal = R->doTemporal ? 1u : 0u;
     prm.doSpatial = R->doSpatial ? 1u : 0u;
     prm.writeReservoirs = (prm.doTemporal || !R->temporalValid) ? 1u : 0u;
@@ -468,6 +469,7 @@ void zhx_rpt_render_stage(const HxScene* s, HxRpt* R, const zr_frame_constants* 
         }
     }
     if ((stages & 2) && prm.doSpatial)
+    for (uint32_t spass = 0; spass < numSpatialPasses; spass++)
     {
         for (uint32_t y = Y0; y < Y1; y++) for (uint32_t x = X0; x < X1; x++) SpatialSearchPixel(F, g, x, y);
         if (prm.sortSpatial) { sortPass(RPT_SORT_CTS, F.mapCtN); sortPass(RPT_SORT_STC, F.mapNtC); }
@@ -490,13 +492,14 @@ void zhx_rpt_render_stage(const HxScene* s, HxRpt* R, const zr_frame_constants* 
             const float sum4 = ButterflySum64(v4);
             for (uint32_t l = 0; l < 64; l++) StcPhase3(F, g, L[l], sum2 + sum3 + sum4);
         }
+        if (spass == 0 && numSpatialPasses == 2u) std::swap(F.cur, F.prev);      // the round's outputs are the next round's inputs
     }
     flush();
     if (counters) { counters->n_closest = total[0]; counters->n_shadow = total[1]; }
     if (stages & 2)
     {
         // spatial wrote the other set, which becomes "current" (IndirectLighting.cpp:609-612, 682-685); Render() flips again
-        if (prm.doSpatial) R->currIdx = 1 - R->currIdx;
+        if (prm.doSpatial && (numSpatialPasses & 1u)) R->currIdx = 1 - R->currIdx;      // one flip per round
         R->temporalValid = true;
         R->currIdx = 1 - R->currIdx;
     }

@@ -199,7 +199,7 @@ def test_abi_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(L, name), f"libzetaray_amd.so does not export {name}"
     assert declared == set(api.EXPORTS)
-    assert L.zr_abi_version() == 2
+    assert L.zr_abi_version() == 3
 
 
 def test_no_device_is_a_loud_error(cornell_emissive):

@@ -1,0 +1,65 @@
+"""The tolerance-mode arithmetic build (libzetaray_amd_fast.so: include/zr_detmath.h ZR_ARITH_FAST -- hardware rcp / rsq / sqrt / exp / log /
+sin / cos, contracted FMAs, 2.5-ulp divide) against the oracle, at the bar BASELINE.json's north_star states for radiance: a per-pixel L2
+tolerance on the accumulated image, integer reservoir state (light picks, k, lobes, M) equal wherever no decision flipped.
+
+The contract build (libzetaray_amd.so) stays the default and the only library the bit-exact tests load; this file is the only one that loads
+the fast build, in a subprocess (tools/fast_arith_check.py), because the library is chosen at load time."""
+import ctypes
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+FAST_LIB = os.path.join(ROOT, "zetaray_amd", "libzetaray_amd_fast.so")
+
+# Stated tolerances (measured values on MI355X are recorded in DESIGN.md section 6.4 and profiles/r04_fast_arith_parity.json):
+ACCUM_FRAMES = 256
+ACCUM_REL_L2_TOL = 0.02            # relative L2 of the 256-frame accumulated ReSTIR PT image against the oracle's
+ACCUM_PX_ABOVE_5PCT_TOL = 0.02     # share of pixels whose own relative error of the accumulated radiance exceeds 5 %
+FRAME1_INT_STATE_MIN_SHARE = 0.98  # share of pixels whose frame-1 integer reservoir state equals the oracle's
+FRAME1_DI_LIGHT_MIN_SHARE = 0.98   # share of pixels whose frame-1 ReSTIR DI light pick (lightIdx) and M equal the oracle's
+
+
+def test_fast_library_exports_the_same_abi():
+    """not gpu: the tolerance-mode library is the same C-ABI (every symbol the contract library exports), so it is a drop-in selected at load time"""
+    from zetaray_amd import api
+    if not os.path.exists(FAST_LIB):
+        pytest.skip("libzetaray_amd_fast.so not built (make -C zetaray_amd/csrc fast)")
+    L = ctypes.CDLL(FAST_LIB)
+    missing = [s for s in api.EXPORTS if not hasattr(L, s)]
+    assert not missing, missing
+    assert L.zr_abi_version() == ctypes.CDLL(api.LIB_PATH).zr_abi_version()
+
+
+@pytest.fixture(scope="module")
+def fast_report():
+    assert os.path.exists(FAST_LIB), "libzetaray_amd_fast.so is missing: __graft_entry__.build() builds it"
+    env = dict(os.environ, ZETARAY_AMD_LIB=FAST_LIB)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fast_arith_check.py"), "--frames", str(ACCUM_FRAMES)],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-2000:]
+    rep = json.loads(p.stdout.strip().splitlines()[-1])
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    json.dump(rep, open(os.path.join(ROOT, "gpurun_out", "fast_arith_parity.json"), "w"), indent=1)
+    return rep
+
+
+@pytest.mark.gpu
+def test_fast_arith_accumulated_radiance_within_tolerance(fast_report):
+    r = fast_report
+    assert r["lib"] == "libzetaray_amd_fast.so" and r["frames"] == ACCUM_FRAMES
+    assert r["rpt_accum_rel_l2"] <= ACCUM_REL_L2_TOL, r
+    assert r["rpt_accum_px_share_above_5pct"] <= ACCUM_PX_ABOVE_5PCT_TOL, r
+    m = r["rpt_accum_mean_radiance"]
+    assert abs(m["fast"] - m["oracle"]) <= 0.005 * m["oracle"], m      # no bias: the image means agree to 0.5 %
+
+
+@pytest.mark.gpu
+def test_fast_arith_frame1_integer_state(fast_report):
+    r = fast_report
+    assert r["rpt_frame1_integer_state_equal_share"] >= FRAME1_INT_STATE_MIN_SHARE, r
+    assert r["rdi_frame1_lightIdx_equal_share"] >= FRAME1_DI_LIGHT_MIN_SHARE, r
+    assert r["rdi_frame1_M_equal_share"] >= FRAME1_DI_LIGHT_MIN_SHARE, r

@@ -30,7 +30,7 @@ def _scene(kind):
 TEX_OFFSETS = {}      # scene kind -> the four descriptor-table offsets of its texture heap (cbFrameConstants::*MapsDescHeapOffset)
 
 
-def _params(bounces=None, presample=None, flags_off=0, kind=None, tex_filter=None):
+def _params(bounces=None, presample=None, flags_off=0, kind=None, tex_filter=None, spatial_passes=None):
     from zetaray_amd import wire
     p = wire.default_params_di() if kind == "di" else (wire.default_params_sky_di() if kind == "sdi" else wire.default_params())
     if bounces:
@@ -40,6 +40,8 @@ def _params(bounces=None, presample=None, flags_off=0, kind=None, tex_filter=Non
     p.flags &= ~flags_off
     if tex_filter is not None:
         p.tex_filter = tex_filter
+    if spatial_passes is not None:
+        p.num_spatial_passes = spatial_passes
     return p
 
 
@@ -56,6 +58,11 @@ CASES = {
     # CB_IND_FLAGS::SORT_TEMPORAL / SORT_SPATIAL off: Reconnect_StC's waves are the 8 x 8 screen blocks (every other ReSTIR PT case runs the
     # reference's default, sorted)
     "rpt_unsorted": ("materials_lights", "rpt", 3, dict(flags_off=(1 << 6) | (1 << 7)), False),
+    # m_numSpatialPasses = 2 / 0 (IndirectLighting.cpp:616-621, 860-870, 906): the second search / sort / replay / reconnect round on swapped
+    # reservoir sets; no spatial reuse at all (the temporal pass writes the radiance)
+    "rpt_two_spatial": ("cornell_emissive", "rpt", 4, dict(spatial_passes=2), True),
+    "rpt_two_spatial_materials": ("materials_lights", "rpt", 3, dict(spatial_passes=2, bounces=(6, 8)), False),
+    "rpt_no_spatial": ("materials_lights", "rpt", 3, dict(spatial_passes=0), False),
     "gi_cornell_moving": ("cornell_emissive", "gi", 4, {}, True),
     "gi_materials_rr": ("materials_lights", "gi", 3, dict(bounces=(6, 8)), False),
     "gi_presampled": ("materials_lights", "gi", 3, dict(presample=(32, 128)), False),

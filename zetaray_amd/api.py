@@ -156,7 +156,19 @@ class Scene:
         self._desc = scene.desc()
         self.h = C.c_void_p()
         self.version = 0      # bumped by every update_*: lets a caller see whether anything moved since it last looked (tiling.TiledRestirPT)
+        # do the instance records now on the device describe motion (prev transform != current)?  They keep doing so in every later frame until
+        # the host uploads records at rest, whether or not update_instances is called again -- the G-buffer's motion vectors come from them
+        self.instances_in_motion = self._records_in_motion(getattr(scene, "instances", None))
         _check(lib().zr_scene_create(device, C.addressof(self._desc), C.byref(self.h)))
+
+    @staticmethod
+    def _records_in_motion(instances):
+        """MeshInstance records (wire.MESH_INSTANCE) whose previous transform differs from the current one: dTranslation (half3) non-zero, or
+        PrevRotation / PrevScale != Rotation / Scale (RtCommon.h:47-64)"""
+        if instances is None or len(instances) == 0:
+            return False
+        i = np.asarray(instances)
+        return bool(((i["d_translation"] & 0x7fff) != 0).any() or (i["prev_rotation"] != i["rotation"]).any() or (i["prev_scale"] != i["scale"]).any())
 
     def update_instances(self, instances, instance_to_world, stream=False):
         """per-frame MeshInstance records + object-to-world matrices; last frame's instance buffer and BVH become the previous ones.
@@ -164,6 +176,7 @@ class Scene:
         L = lib()
         self.version += 1
         i, x = np.ascontiguousarray(instances), np.ascontiguousarray(instance_to_world, np.float32)
+        self.instances_in_motion = self._records_in_motion(i)
         if stream is False:
             L.zr_scene_update_instances.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32]
             _check(L.zr_scene_update_instances(self.h, i.ctypes.data, x.ctypes.data, len(i)))

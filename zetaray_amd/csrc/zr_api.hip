@@ -1070,6 +1070,7 @@ int zr_params_default(zr_params* p)
     p->ae_min_lum = 5e-3f; p->ae_max_lum = 4.0f; p->ae_lum_map_exp = 0.5f; p->ae_adaptation_rate = 1.0f;      // AutoExposure.h:73-81
     p->tex_filter = ZR_TEX_FILTER_ANISOTROPIC_4X;      // IndirectLighting.h:243
     p->svgf_alpha = 0.2f; p->svgf_alpha_moments = 0.2f; p->svgf_sigma_l = 4.0f; p->svgf_sigma_z = 1.0f; p->svgf_normal_power_log2 = 7; p->svgf_iterations = 5;   // ZR_PASS_DENOISE (zr_svgf.h)
+    p->num_spatial_passes = 1;        // IndirectLighting.h:392
     p->display_tonemapper = ZR_TONEMAP_NEUTRAL; p->display_auto_exposure = 1; p->display_saturation = 1.0f; p->display_agx_exp = 1.0f;   // Display.cpp:69-74
     p->use_lvg = 0; p->lvg_grid_dim = 32u | (8u << 10) | (40u << 20);
     p->lvg_extents[0] = 0.6f; p->lvg_extents[1] = 0.45f; p->lvg_extents[2] = 0.6f; p->lvg_offset_y = 0.1f;
@@ -2096,8 +2097,13 @@ static int RenderReSTIR_PT(zr_pass* p, hipStream_t s, const zr_frame_constants* 
     if (stages & ZR_STAGE_TEMPORAL)
     {
         p->doTemporal = (ip.flags & ZR_IND_TEMPORAL_RESAMPLE) && p->temporalValid && havePrevGBuffer;
-        p->doSpatial = (ip.flags & ZR_IND_SPATIAL_RESAMPLE) && p->doTemporal;
+        p->doSpatial = (ip.flags & ZR_IND_SPATIAL_RESAMPLE) && p->doTemporal && ip.num_spatial_passes > 0;      // IndirectLighting.cpp:906
     }
+    // m_numSpatialPasses (IndirectLighting.cpp:616-621, 1240): 0..2
+    if (ip.num_spatial_passes > 2u) return Fail(ZR_ERR_INVALID_ARG, "ReSTIR PT: num_spatial_passes must be 0, 1 or 2");
+    const uint32_t numSpatialPasses = ip.num_spatial_passes;
+    // the second round reads the first round's outputs at neighbouring pixels: a tile would need a third halo exchange between the rounds
+    if (numSpatialPasses == 2u && stages != ZR_STAGE_ALL) return Fail(ZR_ERR_UNSUPPORTED, "ReSTIR PT: num_spatial_passes = 2 is not available in staged (tile-split) rendering");
     prm.doTemporal = p->doTemporal ? 1u : 0u;
     prm.doSpatial = p->doSpatial ? 1u : 0u;
     prm.writeReservoirs = (prm.doTemporal || !p->temporalValid) ? 1u : 0u;
@@ -2182,19 +2188,24 @@ static int RenderReSTIR_PT(zr_pass* p, hipStream_t s, const zr_frame_constants* 
         }
     }
     if ((stages & ZR_STAGE_SPATIAL) && prm.doSpatial)
+    for (uint32_t spass = 0; spass < numSpatialPasses; spass++)
     {
+        // replay work lists + their device-side counts of this round: {2, 3} for the first, {6, 7} for the second (zeroed at the start of the frame)
+        uint32_t* const sCnt = listCnt + (spass == 0 ? 2 : 6);
         // ZR_SEARCH=tile: the LDS-tiled K15 (k_rpt_light<2>), kept for the A/B of DESIGN's N3 row -- measured slower than the plain gathers
         static const bool searchTile = [] { const char* e = getenv("ZR_SEARCH"); return e && !strcmp(e, "tile"); }();
-        if (searchTile) RPT_TIMED("rpt_spatial_search", hipLaunchKernelGGL(k_rpt_light<2>, grid, block, 0, s, F, *cb, tilesX, lists[2], lists[3], listCnt + 2));
-        else RPT_TIMED("rpt_spatial_search", hipLaunchKernelGGL(k_rpt_light<1>, gridSearch, block, 0, s, F, *cb, tilesX, lists[2], lists[3], listCnt + 2));
+        if (searchTile) RPT_TIMED("rpt_spatial_search", hipLaunchKernelGGL(k_rpt_light<2>, grid, block, 0, s, F, *cb, tilesX, lists[2], lists[3], sCnt));
+        else RPT_TIMED("rpt_spatial_search", hipLaunchKernelGGL(k_rpt_light<1>, gridSearch, block, 0, s, F, *cb, tilesX, lists[2], lists[3], sCnt));
         // K12 Sort_CtS / Sort_StC (IndirectLighting.cpp:690-742): the NtC map decides which pixels share a wave in Reconnect_StC, i.e. the
         // population of its boiling-suppression averages
         if (prm.sortSpatial)
         {
             RPT_TIMED("rpt_sort_spatial", hipLaunchKernelGGL((k_rpt_sort<rpt::RPT_SORT_CTS, rpt::RPT_SORT_STC>), dim3(gridSort.x * 2), dim3(256), 0, s, F, *cb, sortTilesX, F.ox0 / 32u, F.oy0 / 32u, F.mapCtN, F.mapNtC));
         }
-        RPT_TIMED("rpt_replay_spatial", RPT_LAUNCH_PE(k_rpt_replay, RPT_REPLAY_CTS, dim3(gridList.x * 2), block, 0, s, F, *cb, lists[2], lists[3], listCnt + 2, ctr + 2 * 5));
+        RPT_TIMED("rpt_replay_spatial", RPT_LAUNCH_PE(k_rpt_replay, RPT_REPLAY_CTS, dim3(gridList.x * 2), block, 0, s, F, *cb, lists[2], lists[3], sCnt, ctr + 2 * 5));
         RPT_TIMED("rpt_reconnect_spatial", RPT_LAUNCH_E(k_rpt_stc, grid, block, 0, s, F, *cb, tilesX, ctr + 2 * 7));
+        // "Prepare for next iteration": the round's outputs become the next round's inputs (IndirectLighting.cpp:860-870: std::swap(inputs, outputs))
+        if (spass == 0 && numSpatialPasses == 2u) { const ResPlanes t = F.cur; F.cur = F.prev; F.prev = t; }
     }
 #undef RPT_TIMED
 #undef RPT_LAUNCH_E
@@ -2204,7 +2215,7 @@ static int RenderReSTIR_PT(zr_pass* p, hipStream_t s, const zr_frame_constants* 
     {
         // spatial read this frame's reservoirs and wrote the other set, which becomes "current"
         // (IndirectLighting.cpp:609-612, 682-685); Render() flips once more (:1018-1024)
-        if (prm.doSpatial) p->currIdx = 1 - p->currIdx;
+        if (prm.doSpatial && (numSpatialPasses & 1u)) p->currIdx = 1 - p->currIdx;      // one flip per round (IndirectLighting.cpp:688)
         p->temporalValid = true;
         p->currIdx = 1 - p->currIdx;
     }

@@ -130,11 +130,16 @@ def halo_plan(w, h, n, rank, apron=APRON, layout=None):
     return plan
 
 
-def frame_reads_history_across_tiles(kind, cb, scene_changed):
+def frame_reads_history_across_tiles(kind, cb, scene_changed, instances_in_motion=False):
     """Can this frame's temporal stage read a previous-frame reservoir that belongs to another tile?  ReSTIR PT reads exactly the reprojected
-    pixel (FindTemporal), so with an unmoved camera (same view, same jitter) and an unchanged scene every pixel reads its own history and the
-    apron's previous reservoirs are never touched.  The other passes pick temporal candidates in a neighbourhood: always yes."""
-    if kind != "restir_pt" or scene_changed:
+    pixel (FindTemporal), so with an unmoved camera (same view, same jitter), an unchanged scene AND a G-buffer whose motion vectors are all
+    zero every pixel reads its own history and the apron's previous reservoirs are never touched.  The motion vector comes from the actual
+    primary hit (zr_stages.h: GBuffer motion): with a thin-lens camera (cb.dof) the hit lies off the pinhole ray the reprojection assumes, and
+    instance records that still carry a previous transform different from the current one (no new update_instances call is needed for that)
+    move their pixels too -- both mean "yes".  The other passes pick temporal candidates in a neighbourhood: always yes."""
+    if kind != "restir_pt" or scene_changed or instances_in_motion:
+        return True
+    if int(cb["dof"]) != 0:
         return True
     return not (np.array_equal(cb["curr_view"], cb["prev_view"]) and np.array_equal(cb["curr_camera_jitter"], cb["prev_camera_jitter"]))
 
@@ -277,7 +282,7 @@ class TiledRestirPT:
     EXCHANGES = {"restir_pt": (True, True), "restir_gi": (False, True), "di": (True, False), "sky_di": (True, False)}
 
     def history_crosses_tiles(self, cb):
-        return frame_reads_history_across_tiles(self.kind, cb, self.r.scene.version != self._scene_version_seen)
+        return frame_reads_history_across_tiles(self.kind, cb, self.r.scene.version != self._scene_version_seen, self.r.scene.instances_in_motion)
 
     def render_frame(self, cb, exchange_final=True):
         """One frame of this rank's tile.  The FINAL halo (the reservoirs the temporal stage reads as "previous" in the apron) is exchanged at the

@@ -106,7 +106,7 @@ class Params(C.Structure):
         ("display_tonemapper", C.c_uint32), ("display_auto_exposure", C.c_uint32), ("display_saturation", C.c_float),
         ("display_agx_exp", C.c_float), ("tex_filter", C.c_uint32),
         ("svgf_alpha", C.c_float), ("svgf_alpha_moments", C.c_float), ("svgf_sigma_l", C.c_float), ("svgf_sigma_z", C.c_float),
-        ("svgf_normal_power_log2", C.c_uint32), ("svgf_iterations", C.c_uint32)]
+        ("svgf_normal_power_log2", C.c_uint32), ("svgf_iterations", C.c_uint32), ("num_spatial_passes", C.c_uint32)]
 
 
 class Counters(C.Structure):
@@ -156,6 +156,7 @@ def set_post_defaults(p):
     p.tex_filter = TEX_FILTER_ANISOTROPIC_4X      # IndirectLighting.h:243
     # ZR_PASS_DENOISE (no reference counterpart)
     p.svgf_alpha, p.svgf_alpha_moments, p.svgf_sigma_l, p.svgf_sigma_z, p.svgf_normal_power_log2, p.svgf_iterations = 0.2, 0.2, 4.0, 1.0, 7, 5
+    p.num_spatial_passes = 1          # IndirectLighting.h:392
 
 
 COMPOSIT_FIREFLY_FILTER = 1 << 10
