@@ -396,7 +396,11 @@ int zr_pass_set_tonemap_lut(zr_pass* pass, const uint32_t* rgb9e5, uint32_t dim)
 int zr_pass_read_counters(zr_pass* pass, void* hip_stream, zr_counters* out, int reset);
 /* ReSTIR PT: GPU time per 32 x 32-pixel cell of the pass's planes ((w + 31) / 32 + 1 by (h + 31) / 32 + 1 cells, cell (0, 0) at the plane origin): the summed
  * lifetimes, in units of 16 shader cycles, of the waves of K11 / K14 / K16 that worked on the cell since the last reset: the load signal of the cost-balanced screen split over N devices (tiling.balanced_layout).  No
- * reference counterpart (the reference renders on one GPU).  Costs one atomic per wave while enabled. */
+ * reference counterpart (the reference renders on one GPU).  Costs one atomic per wave while enabled.
+ * enable = ZR_COST_MAP_RAYS (2): the cells count the BVH queries issued for their pixels by every kernel of the pass instead (a diagnostic: the
+ * per-window ray counts of the at-size parity tests, tests/test_gpu_parity.py::test_atrium_*_windows_*). */
+#define ZR_COST_MAP_TIME 1
+#define ZR_COST_MAP_RAYS 2
 int zr_pass_enable_cost_map(zr_pass* pass, int enable);
 int zr_pass_read_cost_map(zr_pass* pass, void* hip_stream, uint32_t* out_cells, uint32_t cells_w, uint32_t cells_h, int reset);
 /* diagnostic, ReSTIR PT with ZR_K11=trip in the environment: K11 counts the lanes alive at its bounce boundaries -- what compaction between

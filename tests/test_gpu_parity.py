@@ -1047,6 +1047,71 @@ def test_baseline_config_atrium_path_tracer_and_gi_bit_exact(api, atrium):
         assert np.array_equal(rg.final().view(np.uint32), wantg.view(np.uint32)), f"ReSTIR GI frame {f}"
 
 
+# ---- at-size parity for BASELINE configs 4 and 5 without a full CPU frame: scattered windows of the full-resolution atrium (tests/window_parity.py)
+class _GpuFullFrame:
+    """the full-resolution frame on the device, staged like a tile of the multi-GPU split: what tests/window_parity.py compares the windows with"""
+
+    def __init__(self, api, sc, W, H, prm):
+        self.api = api
+        self.r = api.Renderer(sc, W, H, params=prm, integrator=api.INTEGRATOR_RESTIR_PT)
+        self.p = self.r.p_indirect
+        self.p.enable_cost_map(2)      # ZR_COST_MAP_RAYS
+
+    def stage1(self, cb):
+        r = self.r
+        r.p_gbuffer.render(cb, r.scene, r.gbuffer)
+        r.p_prelight.render(cb, r.scene, None)
+        self.p.read_cost_map(reset=True)
+        self.p.render_stage(cb, r.scene, r.gbuffer, self.api.STAGE_TEMPORAL)
+
+    def stage2(self, cb):
+        self.p.render_stage(cb, self.r.scene, self.r.gbuffer, self.api.STAGE_SPATIAL)
+        full_a = self.p.download_plane("A")
+        assert not (full_a >> 24).any(), "plane A, byte 3: the library never writes it (zero since zr_pass_init)"
+        return self.r.final(), self.p.read_cost_map(reset=True)
+
+    def rect_planes(self, which, rect):
+        """the reservoir planes of `rect` (global pixel coordinates) of set `which` (1 = post-temporal, between the stages; 0 = final) as the library
+        packs them for a neighbouring device (zr_pass_halo_pack): plane after plane, each a dense w x h block"""
+        import torch
+        from tests.window_parity import HALO_PLANES
+        n = rect[2] * rect[3]
+        buf = torch.empty(n * 62, dtype=torch.uint8, device="cuda")
+        self.p.halo_pack(self.r.gbuffer, self.api.HALO_POST_TEMPORAL if which == 1 else self.api.HALO_FINAL, rect, buf.data_ptr(), buf.numel())
+        torch.cuda.synchronize()
+        host, out, off = buf.cpu().numpy(), {}, 0
+        for name, dt, ch, nbytes in HALO_PLANES:
+            out[name] = host[off:off + n * nbytes].view(dt).reshape(rect[3], rect[2], ch).copy()
+            off += n * nbytes
+        assert off == host.size
+        return out
+
+
+def _atrium_windows_parity(api, atrium, W, H, windows, frames=3):
+    from tests.window_parity import windows_parity
+    sc, o = atrium
+    prm = wire.default_params()
+    prm.presampling, prm.num_sample_sets, prm.sample_set_size = 1, 128, 512
+    cams = [(0.0, 0, -3.5)] * (frames - 1) + [(0.04, 0, -3.5)]      # the camera starts moving at the last frame: its temporal stage reprojects into the apron
+    rays = windows_parity(_GpuFullFrame(api, sc, W, H, prm), sc, o.alias, W, H, windows, prm, cams)
+    assert rays > 0
+
+
+def test_atrium_1080p_windows_restir_pt_bit_exact(api, atrium):
+    """BASELINE config 4 at its quoted size: the 380k-triangle / 100k-light atrium at 1920 x 1080, ReSTIR PT, 3 frames, eight scattered 64 x 64
+    windows (one in the frame's corner, one ending in the partial 32 x 32 sort tile at the bottom edge: 1080 = 33 x 32 + 24)."""
+    windows = [(0, 0, 64, 64), (960, 512, 64, 64), (1856, 0, 64, 64), (320, 256, 64, 64), (1408, 768, 64, 64), (640, 1024, 64, 56), (1856, 1024, 64, 56),
+               (1152, 128, 64, 64)]
+    _atrium_windows_parity(api, atrium, 1920, 1080, windows)
+
+
+def test_atrium_2160p_windows_restir_pt_bit_exact(api, atrium):
+    """BASELINE config 5's resolution: the atrium at 3840 x 2160, ReSTIR PT, 3 frames, four windows incl. one on the partial sort tiles of the
+    bottom edge (2160 = 67 x 32 + 16) and one in the far corner."""
+    windows = [(1920, 1056, 64, 64), (512, 320, 64, 64), (3008, 2112, 64, 48), (3776, 2112, 64, 48)]
+    _atrium_windows_parity(api, atrium, 3840, 2160, windows)
+
+
 @pytest.mark.parametrize("scene_name,golden", [("cornell.npz", "config1_cornell_256.npz"), ("cornell_emissive.npz", "config1_cornell_emissive_256.npz")])
 def test_baseline_config1_goldens_on_gpu(api, scene_name, golden):
     """BASELINE config 1 (256 x 256, K9, 1 spp, frame 1, jitter off, default sun) against the COMMITTED fixtures of tests/golden/

@@ -259,3 +259,45 @@ def test_scene_without_bvh_nodes(cornell_emissive):
         assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), f"frame {f}"
         _assert_same_state(o, x, f)
     assert (a[..., :3].sum(-1) > 0).sum() > 50
+
+
+def test_window_parity_machinery_against_a_full_frame_host_executor(cornell_emissive, oracle_emissive):
+    """CPU dry run of tests/window_parity.py (the at-size GPU tests of the 1080p / 2160p atrium): the full frame is played by a full-frame host
+    executor instead of the GPU -- staged the same way, its rects cut out of its planes instead of zr_pass_halo_pack -- and the full-frame image it
+    produces is the oracle's.  Windows in a corner, in the interior, and on the partial 32 x 32 tiles of the bottom edge; moving camera."""
+    from oracle import zro
+    from tests.hostexec import zhx
+    from tests.window_parity import HALO_PLANES, windows_parity
+    W, H = 160, 120
+    prm = wire.default_params()
+
+    class Full:
+        def __init__(self):
+            self.hx = zhx.HostExecScene(cornell_emissive, oracle_emissive.alias)
+            self.r = zhx.HostExecRPT(self.hx, W, H)
+
+        def stage1(self, cb):
+            self.r.render_stage(cb, prm, 1)
+
+        def stage2(self, cb):
+            return self.r.render_stage(cb, prm, 2).copy(), None
+
+        def rect_planes(self, which, rect):
+            x, y, w, h = rect
+            return {name: self.r.plane(name, which)[y:y + h, x:x + w].copy() for name, _, _, _ in HALO_PLANES}
+
+    full = Full()
+    cams = [(0.0, 1.2, -4.043), (0.0, 1.2, -4.043), (0.05, 1.2, -4.02), (0.1, 1.2, -4.0)]
+    rays = windows_parity(full, cornell_emissive, oracle_emissive.alias, W, H, [(0, 0, 64, 64), (64, 32, 64, 32), (96, 96, 64, 24)], prm, cams)
+    assert rays > 0
+    # ... and that full frame is the oracle's
+    o = zro.OracleRPT(oracle_emissive, W, H)
+    from zetaray_amd import scene_io
+    prev = None
+    for f, cam in enumerate(cams, 1):
+        cb = scene_io.make_frame_constants(W, H, frame_num=f, num_emissives=len(cornell_emissive.emissives), cam_pos=cam)
+        if prev is not None:
+            cb["prev_view"], cb["prev_view_inv"], cb["prev_camera_jitter"] = prev["curr_view"], prev["curr_view_inv"], prev["curr_camera_jitter"]
+        prev = cb.copy()
+        want = o.render(cb, prm)
+    assert np.array_equal(full.r.final.view(np.uint32), want.view(np.uint32))

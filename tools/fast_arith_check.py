@@ -29,7 +29,7 @@ def main():
     os.environ.setdefault("ZETARAY_AMD_LIB", os.path.join(ROOT, "zetaray_amd", "libzetaray_amd_fast.so"))
     from zetaray_amd import api, scene_io, wire
     from oracle import zro
-    assert api.LIB_PATH.endswith("libzetaray_amd_fast.so"), api.LIB_PATH
+    assert os.path.basename(api.LIB_PATH).startswith("libzetaray_amd_fast"), api.LIB_PATH
     sc = scene_io.load_npz(os.path.join(ROOT, "tests", "golden", "cornell_emissive.npz"))
     w, h = args.width, args.height
     prm = wire.default_params()

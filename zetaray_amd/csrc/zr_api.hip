@@ -605,7 +605,14 @@ static int StageCommit(zr_scene::StageSlot* t, hipStream_t st) { HIP_TRY(hipEven
 static int SceneWaitUsers(zr_scene* s, hipStream_t st)
 {
     std::lock_guard<std::mutex> lock(s->mtx);
+    // the FIRST update of a scene: renders have not recorded user events yet (SceneReleaseAfterRender starts doing so once hasUpdate is set, so
+    // that static scenes pay nothing), and kernels of earlier frames on non-blocking streams may still read the buffers this update overwrites
+    // in place -- wait for the device once.  (Not legal inside a stream capture: capture a scene's update path only after its first update.)
+    if (!s->hasUpdate) HIP_TRY(hipDeviceSynchronize());
     for (auto& u : s->users) if (u.first != st) HIP_TRY(hipStreamWaitEvent(st, u.second, 0));
+    // ... and updates on different streams are ordered against each other: this one runs behind the previous one (a render on `st` then only has
+    // to wait for the latest update, which is what SceneAcquireForRender does)
+    if (s->hasUpdate && s->updated && s->updatedOn != st) HIP_TRY(hipStreamWaitEvent(st, s->updated, 0));
     return ZR_OK;
 }
 static int SceneMarkUpdated(zr_scene* s, hipStream_t st)
@@ -783,7 +790,7 @@ struct zr_pass
     DevBuf<uint16_t> rptMap[2];      // K12 thread maps: [0] CtN, [1] NtC
     DevBuf<uint32_t> trip; DevBuf<unsigned long long> tripStats;      // ZR_K11=trip diagnostic
     DevBuf<uint32_t> carry[2], carryCount;                             // K11 with per-bounce compaction: path-state planes (ping-pong), alive counts
-    DevBuf<uint32_t> costMap; bool costOn = false;      // rays per 32 x 32-px cell (zr_pass_enable_cost_map)
+    DevBuf<uint32_t> costMap; bool costOn = false, costRays = false;      // rays per 32 x 32-px cell (zr_pass_enable_cost_map)
     DevBuf<uint32_t> rptLists, rptListCounts;      // 4 replay work lists (pixel ids) + their device-side counts
     // DI_EMISSIVE: two reservoir sets (A RGBA32_UINT, B RG32F), target, sample set
     DevBuf<U4> diA[2]; DevBuf<float> diB[2]; DevBuf<F4> diTarget; DevBuf<uint16_t> diSampleSet;
@@ -1322,6 +1329,10 @@ int zr_scene_update_instances_async(zr_scene* s, void* stream, const zr_mesh_ins
         const size_t nt = s->meta.n;
         HIP_TRY(hipDeviceSynchronize());           // buffers change roles and may be reallocated below: a host-synchronous path
         std::lock_guard<std::mutex> lock(s->mtx);
+        // everything the failure path below must put back: a build that fails (allocation, a tree deeper than the traversal stack) must not leave
+        // view.nodes / view.tris pointing at buffers that were just demoted to "previous" next to the NEW instance records
+        const SceneView viewBefore = s->view;
+        const uint32_t numNodesPrevBefore = s->numNodesPrev, numTrisPrevBefore = s->numTrisPrev;
         if ((r = (s->instancesPrev.n == n ? ZR_OK : s->instancesPrev.Alloc(n))) || (s->nodesPrev.n < nt && (r = s->nodesPrev.Alloc(nt))) ||
             (s->trisPrev.n < nt && (r = s->trisPrev.Alloc(nt))) || (s->metaPrev.n != s->meta.n && (r = s->metaPrev.Alloc(s->meta.n))) ||
             (s->toWorld.n != 12 * (size_t)n && (r = s->toWorld.Alloc(12 * (size_t)n)))) return r;
@@ -1334,7 +1345,18 @@ int zr_scene_update_instances_async(zr_scene* s, void* stream, const zr_mesh_ins
         HIP_TRY(hipMemcpy(s->instances.p, instances, (size_t)n * sizeof(zr_mesh_instance), hipMemcpyHostToDevice));
         HIP_TRY(hipMemcpy(s->toWorld.p, instance_to_world, 12 * (size_t)n * sizeof(float), hipMemcpyHostToDevice));
         s->view.instances = s->instances.p; s->view.triMeta = s->meta.p;
-        if ((r = DeviceRebuild(s, st))) return r;
+        if ((r = DeviceRebuild(s, st)))
+        {
+            // roll back: the buffers take their old roles again and the scene renders as before the call.  The "previous" set was used as the build
+            // target, so there is no previous structure any more (hasPrev = false: the CtT / temporal passes bind the current one, as in frame 1).
+            (void)hipDeviceSynchronize();
+            std::swap(s->instances.p, s->instancesPrev.p); std::swap(s->instances.n, s->instancesPrev.n);
+            std::swap(s->nodes.p, s->nodesPrev.p); std::swap(s->nodes.n, s->nodesPrev.n);
+            std::swap(s->tris.p, s->trisPrev.p); std::swap(s->tris.n, s->trisPrev.n);
+            std::swap(s->meta.p, s->metaPrev.p); std::swap(s->meta.n, s->metaPrev.n);
+            s->view = viewBefore; s->numNodesPrev = numNodesPrevBefore; s->numTrisPrev = numTrisPrevBefore; s->hasPrev = false;
+            return r;
+        }
         s->refitReady = false;      // the two buffer sets no longer share a topology
         return ZR_OK;
     }
@@ -2072,7 +2094,7 @@ static int RenderReSTIR_PT(zr_pass* p, hipStream_t s, const zr_frame_constants* 
     F.rbCtN = p->rb[0].View(); F.rbNtC = p->rb[1].View(); F.tex.target = p->rptTarget.p; F.tex.neighbor = p->rptNeighbor.p;
     F.finalRGBA = p->finalRGBA.p; F.sampleSet = p->rptSampleSet.p;
     F.mapCtN = p->rptMap[0].p; F.mapNtC = p->rptMap[1].p;
-    F.costMap = p->costOn ? p->costMap.p : nullptr; F.costW = (p->w + 31u) / 32u + 1u;
+    F.costMap = p->costOn ? p->costMap.p : nullptr; F.costW = (p->w + 31u) / 32u + 1u; F.costMode = p->costRays ? 1u : 0u;
     F.trip = nullptr; F.tripStats = nullptr; F.tripStride = 0;
     F.carryOut = nullptr; F.carryIn = nullptr; F.carryCount = nullptr; F.carryCap = 0; F.carryBounce = 0;
     // K12 sorts whole 32 x 32 tiles: an owned rect may end inside one only where the render target ends
@@ -2754,6 +2776,7 @@ int zr_pass_enable_cost_map(zr_pass* p, int enable)
     if (!p || !p->initialized) return Fail(ZR_ERR_NOT_INITIALIZED, "pass not initialised");
     if (p->kind != ZR_PASS_INDIRECT || p->integrator != ZR_INTEGRATOR_RESTIR_PT) return Fail(ZR_ERR_UNSUPPORTED, "the cost map is an output of the ReSTIR PT pass");
     p->costOn = enable != 0;
+    p->costRays = enable == ZR_COST_MAP_RAYS;
     return ZR_OK;
 }
 int zr_pass_debug_trip_stats(zr_pass* p, uint64_t out[3])

@@ -212,8 +212,14 @@ __device__ __forceinline__ void FlushRayCountersCost(const rpt::RptFrame& F, uns
         if (m != 0)
         {
             const int leader = __ffsll((long long)m) - 1;
-            const unsigned long long dt = (__builtin_readcyclecounter() - t0) >> 4;
-            if ((int)__lane_id() == leader) atomicAdd(&F.costMap[((y - F.gb.y0) >> 5) * F.costW + ((x - F.gb.x0) >> 5)], (uint32_t)(dt > 0xffffffull ? 0xffffffull : dt));
+            unsigned long long dt = (__builtin_readcyclecounter() - t0) >> 4;
+            if (F.costMode)
+            {   // ray mode: the wave's queries (lanes outside the frame issued none)
+                uint32_t r = cnt[0] + cnt[1];
+                for (int s = 1; s < 64; s <<= 1) r += __shfl_xor(r, s);
+                dt = r;
+            }
+            if ((int)__lane_id() == leader && dt) atomicAdd(&F.costMap[((y - F.gb.y0) >> 5) * F.costW + ((x - F.gb.x0) >> 5)], (uint32_t)(dt > 0xffffffull ? 0xffffffull : dt));
         }
     }
     FlushRayCounters(counters, cnt);
@@ -698,10 +704,13 @@ template<int PASS, bool EMISSIVE, bool TEX>
 __device__ __forceinline__ void RptReplayPixel(rpt::RptFrame& F, const zr_frame_constants& g, uint32_t pid, const TravStack& stack, uint32_t* cnt)
 {
     const uint32_t x = F.gb.x0 + pid % F.gb.w, y = F.gb.y0 + pid / F.gb.w;
+    const uint32_t before = cnt[0] + cnt[1];
     if (PASS == RPT_REPLAY_CTT) rpt::ReplayTemporalPixel(F, g, 0, x, y, stack, cnt);
     else if (PASS == RPT_REPLAY_TTC) rpt::ReplayTemporalPixel(F, g, 1, x, y, stack, cnt);
     else if (PASS == RPT_REPLAY_CTS) rpt::ReplaySpatialPixel(F, g, 0, x, y, stack, cnt);
     else rpt::ReplaySpatialPixel(F, g, 1, x, y, stack, cnt);
+    // ray-mode cost map (diagnostic): the lanes of a replay wave come from anywhere in the frame, so every lane adds to its own pixel's cell
+    if (F.costMap != nullptr && F.costMode && cnt[0] + cnt[1] != before) atomicAdd(&F.costMap[((y - F.gb.y0) >> 5) * F.costW + ((x - F.gb.x0) >> 5)], cnt[0] + cnt[1] - before);
 }
 template<int PASS, bool EMISSIVE, bool TEX, bool DYNAMIC>
 __device__ __forceinline__ void RptReplayList(rpt::RptFrame& F, const zr_frame_constants& g, const uint32_t* list, uint32_t n, uint32_t* cursor,

@@ -1947,7 +1947,9 @@ struct RptFrame
     ZR_HDM bool Owns(uint32_t x, uint32_t y) const { return x >= ox0 && y >= oy0 && x < ox0 + ow && y < oy0 + oh; }
     // GPU time per 32 x 32-pixel cell of the planes (cell (0, 0) at the plane origin gb.x0, gb.y0): wave lifetimes of K11 / K14 / K16, one
     // atomic per wave: what the cost-balanced tile split of the multi-GPU path is computed from (tiling.balanced_layout); null = off
-    uint32_t* costMap; uint32_t costW;
+    // costMode 1 (ZR_COST_MAP_RAYS): the cells accumulate the BVH queries (closest + any-hit) issued for their pixels by EVERY kernel of the pass
+    // instead -- the per-window ray counts the at-size parity tests compare with the host executor's
+    uint32_t* costMap; uint32_t costW; uint32_t costMode;
     // diagnostic (ZR_K11=trip, zr_kernels.h: k_rpt_pathtrace_trip): {alive lanes, lane slots, words per path} of the waves that pass a bounce
     // boundary, and the planes the carried state is sent through there
     uint32_t* trip; unsigned long long* tripStats; size_t tripStride;
