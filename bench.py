@@ -259,18 +259,17 @@ def measure(args, ctx):
     di_passes = [q for q in (r.p_direct, r.p_sky_direct) if q is not None]
     p_denoise = None
     if args.denoise:
-        assert world == 1 and not args.di_only, "--denoise: one GPU (the a-trous stencil reaches 62 px, beyond the tiles' 32-px apron), on an indirect integrator"
-        p_denoise = r.enable_denoise()
+        # N > 1: every rank filters its tile + apron and trades halos between the steps whose stencil would outrun the apron (tiling.denoise_schedule:
+        # 3 exchanges per frame for the default 5 a-trous iterations); the stitched result equals one device's (tests/test_denoise_tiles_cpu.py, test_denoise.py)
+        assert not args.di_only, "--denoise filters the indirect integrator's image"
+        p_denoise = tiled.enable_denoise() if tiled is not None else r.enable_denoise()
 
     def frame(i):
         cb = scene_io.make_frame_constants(W, H, frame_num=i, num_emissives=len(sc.emissives), **cam)
         if tex_offsets is not None:
             scene_io.set_texture_heap_offsets(cb, tex_offsets)
         if tiled is not None:
-            tiled.render_frame(cb, exchange_final=not args.no_final_halo)
-            if p_denoise is not None:      # (Renderer.render_frame runs it itself)
-                p_denoise.set_input(api.IN_DENOISE_SIGNAL, r.p_indirect.output_ptr()[0])
-                p_denoise.render(cb, r.scene, r.gbuffer)
+            tiled.render_frame(cb, exchange_final=not args.no_final_halo)      # (runs the denoise schedule too when the pass is enabled)
         else:
             r.render_frame(cb)
 
@@ -501,7 +500,7 @@ def main():
                          "contracted FMAs; parity = tests/test_fast_arith.py).  A fast line says so in config.arith and is never the default.")
     ap.add_argument("--no-extra-workloads", action="store_true",
                     help="the default line also measures BASELINE config 4 (atrium 1080p ReSTIR PT) in the same process as extra_workloads[0]; this skips it")
-    ap.add_argument("--denoise", action="store_true", help="add the denoise pass (ZR_PASS_DENOISE) on the indirect image (one GPU)")
+    ap.add_argument("--denoise", action="store_true", help="add the denoise pass (ZR_PASS_DENOISE) on the indirect image (tile-split like the integrator for N > 1)")
     ap.add_argument("--scene", default=os.path.join(ROOT, "tests", "golden", "cornell_emissive.npz"),
                     help="wire-format .npz, or 'synthetic' = the procedural Sponza-class scene of BASELINE config 4 "
                          "(262144 triangles + 100000 emissive triangles, presampled light sets on)")

@@ -348,8 +348,21 @@ int zr_pass_render(zr_pass* pass, void* hip_stream, const zr_frame_constants* cb
 #define ZR_STAGE_TEMPORAL 1
 #define ZR_STAGE_SPATIAL  2
 #define ZR_STAGE_ALL      3
+/* ZR_PASS_DENOISE only: the steps of the pass one by one (zr_pass_render_stage; ZR_STAGE_SPATIAL / ZR_STAGE_ALL = all of them).  A device of the tile
+   split runs them in groups with a halo exchange wherever the next step's stencil would reach beyond what is still exact in its 32-px apron
+   (reach: variance 3 px, a-trous iteration i 2 * 2^i px; zetaray_amd/tiling.py denoise_schedule): exchange ZR_HALO_DENOISE_INPUT, TEMPORAL + VARIANCE +
+   ATROUS(0..2), exchange ZR_HALO_DENOISE_ITER, ATROUS(3), exchange ZR_HALO_DENOISE_ITER, ATROUS(4) for the default five iterations. */
+#define ZR_STAGE_DENOISE_TEMPORAL  (1 << 8)
+#define ZR_STAGE_DENOISE_VARIANCE  (1 << 9)
+#define ZR_STAGE_DENOISE_ATROUS(i) (1u << (10 + (i)))      /* i = 0 .. svgf_iterations - 1 (<= 8) */
+#define ZR_STAGE_DENOISE_MASK      0x3ff00
 #define ZR_HALO_POST_TEMPORAL 0   /* valid between the two stages of a frame */
 #define ZR_HALO_FINAL         1   /* valid after the frame: the set the next frame reads as "previous" */
+/* ZR_PASS_DENOISE: what a tile needs from its neighbours before the temporal step -- this frame's input signal (the RGBA32F plane bound as
+   ZR_IN_DENOISE_SIGNAL: the indirect pass shades owned pixels only) + the colour / length history (RGBA32F) + the moment history (RG32F), 40 B per
+   pixel -- and between a-trous iterations: the iteration's current colour + variance plane (RGBA32F, 16 B per pixel) */
+#define ZR_HALO_DENOISE_INPUT 2
+#define ZR_HALO_DENOISE_ITER  3
 #define ZR_HALO_BYTES_PER_PIXEL 62  /* planes A..G back to back: 4 + 8 + 16 + 16 + 2 + 8 + 8, each row-major over the rect */
 int zr_pass_set_owned_rect(zr_pass* pass, uint32_t x0, uint32_t y0, uint32_t width, uint32_t height);   /* global pixels; width 0 = whole tile */
 /* The same protocol for the other passes with cross-pixel reuse (SURVEY 8(e) "Collective"): bytes per pixel of a halo transfer =

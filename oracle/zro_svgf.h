@@ -1,9 +1,11 @@
 // zro_svgf.h -- ORACLE (test infrastructure only): CPU restatement of the denoise pass (ZR_PASS_DENOISE), whole-image loops.
 //
 // PARITY UNPINNED: the reference has no denoiser, so there is no reference code to follow or to pin against.  The pass is defined by the
-// written specification at the top of zetaray_amd/csrc/zr_svgf.h (after Schied et al., "Spatiotemporal Variance-Guided Filtering", HPG 2017);
-// this file restates that specification independently of the HIP stage functions -- image-level passes over plain arrays, its own helper
-// structure -- with the same fp32 operations in the same order, so the two can be compared bit for bit (tests/test_denoise.py).
+// written specification at the top of zetaray_amd/csrc/zr_svgf.h (after Schied et al., "Spatiotemporal Variance-Guided Filtering", HPG 2017;
+// DEFINITION VERSION 2: compact-support falloff E(x) = max(0, 1 - x / 16)^16, written fused multiply-adds, predicated taps, one reciprocal per
+// pixel, sanitised + clamped signal); this file restates that specification independently of the HIP stage functions -- image-level passes over
+// plain arrays, its own helper structure, full frames only (the product's tile windows are compared against THIS full frame) -- with the same fp32
+// operations in the same order, so the two can be compared bit for bit (tests/test_denoise.py).
 #pragma once
 #include "zro_math.h"
 #include "zro_rpt.h"      // RPT::DecodeMotion
@@ -19,6 +21,18 @@ struct Guide { float z, fw; float3 n; };
 
 static inline float3 NormalOf(uint32_t bits) { const uint16_t e[2] = {(uint16_t)(bits & 0xffffu), (uint16_t)(bits >> 16)}; return Math::DecodeOct32(e); }
 static inline bool Miss(float z) { return z == ZR_FLT_MAX; }
+static inline bool IsFinite(float v) { return !zr_isnan(v) && !zr_isinf(v); }
+// Lum(c) = fma(0.2126, c.x, fma(0.7152, c.y, 0.0722 * c.z))
+static inline float Lum(float3 c) { const float b = 0.0722f * c.z; const float gb = zr_fma(0.7152f, c.y, b); return zr_fma(0.2126f, c.x, gb); }
+// E(x) = max(0, 1 - x / 16)^16
+static inline float E16(float x)
+{
+    const float lin = zr_fma(x, -0.0625f, 1.0f);
+    const float t1 = zr_max(0.0f, lin);
+    const float t2 = t1 * t1, t4 = t2 * t2, t8 = t4 * t4;
+    return t8 * t8;
+}
+static inline int ClampI(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 
 static inline std::vector<Guide> BuildGuide(const float* depth, const uint32_t* normal, int W, int H)
 {
@@ -41,9 +55,12 @@ static inline std::vector<Guide> BuildGuide(const float* depth, const uint32_t* 
     return g;
 }
 
+// Nw(n, nq) = max(0, fma(n.x, nq.x, fma(n.y, nq.y, n.z * nq.z)))^(2^log2)
 static inline float PowNormal(float3 a, float3 b, uint32_t log2)
 {
-    float d = zr_max(0.0f, dot(a, b));
+    const float zz = a.z * b.z;
+    const float yz = zr_fma(a.y, b.y, zz);
+    float d = zr_max(0.0f, zr_fma(a.x, b.x, yz));
     for (uint32_t k = 0; k < log2; k++) d = d * d;
     return d;
 }
@@ -56,7 +73,9 @@ static inline bool Usable(const History& h, int W, int H, int qx, int qy, float 
     const size_t j = (size_t)qy * W + qx;
     if (Miss(h.prevDepth[j])) return false;
     if (!(zr_abs(h.prevDepth[j] - z) <= 0.1f * z)) return false;
-    return dot(NormalOf(h.prevNormal[j]), n) >= 0.9f;
+    if (!(dot(NormalOf(h.prevNormal[j]), n) >= 0.9f)) return false;
+    for (int k = 0; k < 4; k++) if (!IsFinite(h.color[4 * j + k])) return false;
+    return IsFinite(h.moments[2 * j]) && IsFinite(h.moments[2 * j + 1]);
 }
 
 // signal RGBA32F; accum RGBA32F (rgb + history length); moments 2 floats per pixel
@@ -68,8 +87,9 @@ static inline void Temporal(const float* signal, const float* depth, const uint3
         {
             const size_t i = (size_t)y * W + x;
             float3 c = f3(signal[4 * i], signal[4 * i + 1], signal[4 * i + 2]);
-            if (zr_isnan(c.x) || zr_isnan(c.y) || zr_isnan(c.z)) c = f3(0.0f, 0.0f, 0.0f);
-            const float lum = Math::Luminance(c);
+            if (!IsFinite(c.x) || !IsFinite(c.y) || !IsFinite(c.z)) c = f3(0.0f, 0.0f, 0.0f);
+            else c = f3(zr_min(zr_max(c.x, -1.0e15f), 1.0e15f), zr_min(zr_max(c.y, -1.0e15f), 1.0e15f), zr_min(zr_max(c.z, -1.0e15f), 1.0e15f));
+            const float lum = Lum(c);
             float3 out = c; float m1 = lum, m2 = lum * lum, length = 1.0f;
             const float z = depth[i];
             if (!Miss(z) && temporalValid)
@@ -136,7 +156,7 @@ static inline void Variance(const float* accum, const float* moments, const std:
             const size_t i = (size_t)y * W + x;
             const Guide& c0 = g[i];
             const float length = accum[4 * i + 3];
-            float3 col = f3(accum[4 * i], accum[4 * i + 1], accum[4 * i + 2]);
+            float col[3] = {accum[4 * i], accum[4 * i + 1], accum[4 * i + 2]};
             float m1 = moments[2 * i], m2 = moments[2 * i + 1];
             float var;
             if (Miss(c0.z)) var = 0.0f;
@@ -150,20 +170,22 @@ static inline void Variance(const float* accum, const float* moments, const std:
                     {
                         if (dx == 0 && dy == 0) continue;
                         const int qx = x + dx, qy = y + dy;
-                        if (qx < 0 || qy < 0 || qx >= W || qy >= H) continue;
-                        const size_t j = (size_t)qy * W + qx;
-                        if (Miss(g[j].z)) continue;
+                        const bool inside = qx >= 0 && qy >= 0 && qx < W && qy < H;
+                        const size_t j = (size_t)ClampI(qy, 0, H - 1) * W + ClampI(qx, 0, W - 1);      // every tap is read (position clamped) ...
                         const float rcpDist = 1.0f / zr_sqrt((float)(dx * dx + dy * dy));
                         const float wz = zr_abs(c0.z - g[j].z) * (rcpPhiZ * rcpDist);
-                        const float w = zr_exp(0.0f - wz) * PowNormal(c0.n, g[j].n, prm.normalPowerLog2);
-                        col = col + w * f3(accum[4 * j], accum[4 * j + 1], accum[4 * j + 2]);
-                        m1 += w * moments[2 * j]; m2 += w * moments[2 * j + 1];
-                        ws += w;
+                        float w = E16(wz) * PowNormal(c0.n, g[j].n, prm.normalPowerLog2);
+                        if (!inside || Miss(g[j].z)) w = 0.0f;                                           // ... and weighted 0 when it does not count
+                        for (int k = 0; k < 3; k++) col[k] = zr_fma(w, accum[4 * j + k], col[k]);
+                        m1 = zr_fma(w, moments[2 * j], m1); m2 = zr_fma(w, moments[2 * j + 1], m2);
+                        ws = ws + w;
                     }
-                col = col / ws; m1 = m1 / ws; m2 = m2 / ws;
+                const float r = 1.0f / ws;
+                for (int k = 0; k < 3; k++) col[k] = col[k] * r;
+                m1 = m1 * r; m2 = m2 * r;
                 var = zr_max(0.0f, m2 - m1 * m1) * (4.0f / length);
             }
-            dst[4 * i] = col.x; dst[4 * i + 1] = col.y; dst[4 * i + 2] = col.z; dst[4 * i + 3] = var;
+            dst[4 * i] = col[0]; dst[4 * i + 1] = col[1]; dst[4 * i + 2] = col[2]; dst[4 * i + 3] = var;
         }
 }
 
@@ -175,7 +197,7 @@ static inline void Atrous(const float* src, const std::vector<Guide>& g, const P
         {
             const size_t i = (size_t)y * W + x;
             const Guide& c0 = g[i];
-            float3 col = f3(src[4 * i], src[4 * i + 1], src[4 * i + 2]);
+            float col[3] = {src[4 * i], src[4 * i + 1], src[4 * i + 2]};
             float var = src[4 * i + 3];
             if (!Miss(c0.z))
             {
@@ -183,37 +205,37 @@ static inline void Atrous(const float* src, const std::vector<Guide>& g, const P
                 for (int dy = -1; dy <= 1; dy++)
                     for (int dx = -1; dx <= 1; dx++)
                     {
-                        int qx = x + dx, qy = y + dy;
-                        qx = qx < 0 ? 0 : (qx > W - 1 ? W - 1 : qx); qy = qy < 0 ? 0 : (qy > H - 1 ? H - 1 : qy);
+                        const int qx = ClampI(x + dx, 0, W - 1), qy = ClampI(y + dy, 0, H - 1);
                         const float k = (dx == 0 ? 0.5f : 0.25f) * (dy == 0 ? 0.5f : 0.25f);
-                        blurred += k * src[4 * ((size_t)qy * W + qx) + 3];
+                        blurred = zr_fma(k, src[4 * ((size_t)qy * W + qx) + 3], blurred);
                     }
-                const float rcpPhiL = 1.0f / (prm.sigmaL * zr_sqrt(zr_max(0.0f, blurred)) + 1e-4f);
-                const float rcpPhiZ = 1.0f / (prm.sigmaZ * zr_max(c0.fw, 1e-8f) * (float)step);
-                const float lum = Math::Luminance(col);
+                const float rcpPhiL = 1.0f / zr_fma(prm.sigmaL, zr_sqrt(zr_max(0.0f, blurred)), 1e-4f);
+                const float rcpPhiZ = 1.0f / ((prm.sigmaZ * zr_max(c0.fw, 1e-8f)) * (float)step);
+                const float lum = Lum(f3(col[0], col[1], col[2]));
                 float ws = 1.0f;
                 for (int dy = -2; dy <= 2; dy++)
                     for (int dx = -2; dx <= 2; dx++)
                     {
                         if (dx == 0 && dy == 0) continue;
                         const int qx = x + dx * step, qy = y + dy * step;
-                        if (qx < 0 || qy < 0 || qx >= W || qy >= H) continue;
-                        const size_t j = (size_t)qy * W + qx;
-                        if (Miss(g[j].z)) continue;
+                        const bool inside = qx >= 0 && qy >= 0 && qx < W && qy < H;
+                        const size_t j = (size_t)ClampI(qy, 0, H - 1) * W + ClampI(qx, 0, W - 1);
                         const float3 cq = f3(src[4 * j], src[4 * j + 1], src[4 * j + 2]);
                         const float h = kB3[dx < 0 ? -dx : dx] * kB3[dy < 0 ? -dy : dy];
-                        const float wl = zr_abs(lum - Math::Luminance(cq)) * rcpPhiL;
+                        const float wl = zr_abs(lum - Lum(cq)) * rcpPhiL;
                         const float rcpDist = 1.0f / zr_sqrt((float)(dx * dx + dy * dy));
                         const float wz = zr_abs(c0.z - g[j].z) * (rcpPhiZ * rcpDist);
-                        const float w = (h * zr_exp((0.0f - wl) - wz)) * PowNormal(c0.n, g[j].n, prm.normalPowerLog2);
-                        col = col + w * cq;
-                        var += (w * w) * src[4 * j + 3];
-                        ws += w;
+                        float w = (h * E16(wl + wz)) * PowNormal(c0.n, g[j].n, prm.normalPowerLog2);
+                        if (!inside || Miss(g[j].z)) w = 0.0f;
+                        col[0] = zr_fma(w, cq.x, col[0]); col[1] = zr_fma(w, cq.y, col[1]); col[2] = zr_fma(w, cq.z, col[2]);
+                        var = zr_fma(w * w, src[4 * j + 3], var);
+                        ws = ws + w;
                     }
-                col = col / ws;
-                var = var / (ws * ws);
+                const float r = 1.0f / ws;
+                col[0] = col[0] * r; col[1] = col[1] * r; col[2] = col[2] * r;
+                var = var * (r * r);
             }
-            dst[4 * i] = col.x; dst[4 * i + 1] = col.y; dst[4 * i + 2] = col.z; dst[4 * i + 3] = var;
+            dst[4 * i] = col[0]; dst[4 * i + 1] = col[1]; dst[4 * i + 2] = col[2]; dst[4 * i + 3] = var;
         }
 }
 

@@ -28,6 +28,7 @@ static const uint16_t kRdiSampleSet[64] = {
 #include <cstdlib>
 #include <cstring>
 using namespace zr;
+static bool g_k11_park = false;       // zhx_set_k11_park: K11 keeps the reservoir's selected reconnection in a park outside the lane (zr_rpt.h RcPark)
 static bool g_k11_carry = false;      // zhx_set_k11_carry: K11 emulation sends live paths through rpt::PtCarry at every bounce boundary
 
 struct HxScene
@@ -191,29 +192,93 @@ void zhx_taa(const float* signal, const float* depth, const uint32_t* motion, co
     F.blendWeight = blendWeight; F.temporalIsValid = temporalValid ? 1u : 0u;
     for (uint32_t y = 0; y < h; y++) for (uint32_t x = 0; x < w; x++) taa::TaaPixel(F, x, y);
 }
-// the denoise pass's stage functions (zr_svgf.h) over a whole frame, in the order RenderDenoise launches them; hist_color / hist_moments in and out
+// the denoise pass's stage functions (zr_svgf.h) with the pass's state, over a WINDOW of the frame (the whole frame, or a tile + apron of the
+// multi-device split) and step by step (the ZR_STAGE_DENOISE_* bits of include/zetaray_amd.h), in the order RenderDenoise launches them
+struct HxSvgf
+{
+    svgf::Window win;
+    std::vector<F4> hist, accum, guide, ping, pong; std::vector<float> moments[2], fw;
+    int momIdx = 0; F4* cur = nullptr; const F4* out = nullptr;
+};
+HxSvgf* zhx_svgf_create(int ox, int oy, int pw, int ph, int W, int H)
+{
+    HxSvgf* S = new HxSvgf();
+    S->win.ox = ox; S->win.oy = oy; S->win.pw = pw; S->win.ph = ph; S->win.W = W; S->win.H = H;
+    const size_t n = (size_t)pw * ph;
+    S->hist.assign(n, F4{0, 0, 0, 0}); S->accum.assign(n, F4{0, 0, 0, 0}); S->guide.assign(n, F4{0, 0, 0, 0}); S->ping.assign(n, F4{0, 0, 0, 0}); S->pong.assign(n, F4{0, 0, 0, 0});
+    S->moments[0].assign(2 * n, 0.0f); S->moments[1].assign(2 * n, 0.0f); S->fw.assign(n, 0.0f);
+    S->cur = S->ping.data(); S->out = S->ping.data();
+    return S;
+}
+void zhx_svgf_destroy(HxSvgf* S) { delete S; }
+// planes are the window's (pw x ph); steps: ZR_STAGE_DENOISE_* bits
+void zhx_svgf_render(HxSvgf* S, const float* signal, const float* depth, const uint32_t* normal, const uint32_t* motion, const float* prevDepth, const uint32_t* prevNormal,
+    int temporalValid, const float* params4, uint32_t normalPowerLog2, uint32_t iterations, uint32_t steps)
+{
+    const svgf::Window& w = S->win;
+    const int mi = S->momIdx;
+    svgf::SvgfParams sp; sp.alpha = params4[0]; sp.alphaMoments = params4[1]; sp.sigmaL = params4[2]; sp.sigmaZ = params4[3]; sp.normalPowerLog2 = normalPowerLog2; sp.iterations = iterations;
+    if (steps & ZR_STAGE_DENOISE_TEMPORAL)
+    {
+        svgf::SvgfFrame T; T.signal = (const F4*)signal; T.depth = depth; T.normal = normal; T.motion = motion; T.prevDepth = prevDepth; T.prevNormal = prevNormal;
+        T.histColor = S->hist.data(); T.histMoments = S->moments[mi].data(); T.accum = S->accum.data(); T.moments = S->moments[mi ^ 1].data(); T.guide = S->guide.data(); T.guideFw = S->fw.data();
+        T.win = w; T.temporalValid = temporalValid ? 1u : 0u; T.prm = sp;
+        for (int y = w.oy; y < w.oy + w.ph; y++) for (int x = w.ox; x < w.ox + w.pw; x++) svgf::TemporalPixel(T, x, y);
+    }
+    svgf::FilterFrame V; V.src = S->accum.data(); V.moments = S->moments[mi ^ 1].data(); V.guide = S->guide.data(); V.guideFw = S->fw.data(); V.dst = S->ping.data(); V.lenSrc = S->accum.data();
+    V.history = iterations == 0 ? S->hist.data() : nullptr; V.win = w; V.step = 1; V.prm = sp;
+    if (steps & ZR_STAGE_DENOISE_VARIANCE)
+    {
+        for (int y = w.oy; y < w.oy + w.ph; y++) for (int x = w.ox; x < w.ox + w.pw; x++) svgf::VariancePixel(V, x, y);
+        S->cur = S->ping.data();
+    }
+    for (uint32_t it = 0; it < iterations; it++)
+    {
+        if (!(steps & ZR_STAGE_DENOISE_ATROUS(it))) continue;
+        F4* src = S->cur; F4* dst = src == S->ping.data() ? S->pong.data() : S->ping.data();
+        svgf::FilterFrame A = V; A.src = src; A.dst = dst; A.moments = nullptr; A.step = 1u << it; A.history = it == 0 ? S->hist.data() : nullptr;
+        // odd iterations through the unrolled form of the stencil, even ones through the row loop: both forms of zr_svgf.h run on the host
+        for (int y = w.oy; y < w.oy + w.ph; y++) for (int x = w.ox; x < w.ox + w.pw; x++)
+        {
+            svgf::PlaneTaps t; t.src = A.src; t.guide = A.guide; t.win = w;
+            if (normalPowerLog2 == 7u) { if (it & 1u) svgf::AtrousPixelT<7, false>(A, x, y, t); else svgf::AtrousPixelT<7, true>(A, x, y, t); }
+            else { if (it & 1u) svgf::AtrousPixelT<-1, false>(A, x, y, t); else svgf::AtrousPixelT<-1, true>(A, x, y, t); }
+        }
+        S->cur = dst;
+    }
+    const uint32_t last = iterations ? ZR_STAGE_DENOISE_ATROUS(iterations - 1u) : (uint32_t)ZR_STAGE_DENOISE_VARIANCE;
+    if (steps & last) { S->out = S->cur; S->momIdx = mi ^ 1; }
+}
+// which: 0 = colour history (4 floats), 1 = moment history (2 floats; the set the next temporal step reads), 2 = the plane the next a-trous iteration reads
+// (4 floats), 3 = the frame's output (4 floats)
+static float* SvgfPlane(HxSvgf* S, int which, int* ch)
+{
+    switch (which)
+    {
+    case 0: *ch = 4; return (float*)S->hist.data();
+    case 1: *ch = 2; return S->moments[S->momIdx].data();
+    case 2: *ch = 4; return (float*)S->cur;
+    default: *ch = 4; return (float*)S->out;
+    }
+}
+void zhx_svgf_read_plane(HxSvgf* S, int which, float* out) { int ch; const float* p = SvgfPlane(S, which, &ch); memcpy(out, p, (size_t)S->win.pw * S->win.ph * ch * sizeof(float)); }
+// copy the rect (x, y, w, h) (window-local texels) of the window-sized array `full` into the plane
+void zhx_svgf_write_plane_rect(HxSvgf* S, int which, const float* full, uint32_t x, uint32_t y, uint32_t w, uint32_t h)
+{
+    int ch; float* p = SvgfPlane(S, which, &ch);
+    for (uint32_t r = 0; r < h; r++) { const size_t o = ((size_t)(y + r) * S->win.pw + x) * ch; memcpy(p + o, full + o, (size_t)w * ch * sizeof(float)); }
+}
+// one full frame in one call (hist_color / hist_moments in and out): the interface of oracle zro_svgf
 void zhx_svgf(const float* signal, const float* depth, const uint32_t* normal, const uint32_t* motion, const float* prevDepth, const uint32_t* prevNormal,
     float* histColor, float* histMoments, int temporalValid, const float* params4, uint32_t normalPowerLog2, uint32_t iterations, uint32_t w, uint32_t h, float* out)
 {
+    HxSvgf* S = zhx_svgf_create(0, 0, (int)w, (int)h, (int)w, (int)h);
     const size_t n = (size_t)w * h;
-    std::vector<F4> accum(n), guide(n), ping(n), pong(n); std::vector<float> moments(2 * n), fw(n);
-    svgf::SvgfParams sp; sp.alpha = params4[0]; sp.alphaMoments = params4[1]; sp.sigmaL = params4[2]; sp.sigmaZ = params4[3]; sp.normalPowerLog2 = normalPowerLog2; sp.iterations = iterations;
-    svgf::SvgfFrame T; T.signal = (const F4*)signal; T.depth = depth; T.normal = normal; T.motion = motion; T.prevDepth = prevDepth; T.prevNormal = prevNormal;
-    T.histColor = (const F4*)histColor; T.histMoments = histMoments; T.accum = accum.data(); T.moments = moments.data(); T.guide = guide.data(); T.guideFw = fw.data();
-    T.w = w; T.h = h; T.temporalValid = temporalValid ? 1u : 0u; T.prm = sp;
-    for (uint32_t y = 0; y < h; y++) for (uint32_t x = 0; x < w; x++) svgf::TemporalPixel(T, (int)x, (int)y);
-    svgf::FilterFrame V; V.src = accum.data(); V.moments = moments.data(); V.guide = guide.data(); V.guideFw = fw.data(); V.dst = ping.data(); V.lenSrc = accum.data();
-    V.history = iterations == 0 ? (F4*)histColor : nullptr; V.w = w; V.h = h; V.step = 1; V.prm = sp;
-    for (uint32_t y = 0; y < h; y++) for (uint32_t x = 0; x < w; x++) svgf::VariancePixel(V, (int)x, (int)y);
-    F4* src = ping.data(); F4* dst = pong.data();
-    for (uint32_t it = 0; it < iterations; it++)
-    {
-        svgf::FilterFrame A = V; A.src = src; A.dst = dst; A.moments = nullptr; A.step = 1u << it; A.history = it == 0 ? (F4*)histColor : nullptr;
-        for (uint32_t y = 0; y < h; y++) for (uint32_t x = 0; x < w; x++) svgf::AtrousPixel(A, (int)x, (int)y);
-        F4* t = src; src = dst; dst = t;
-    }
-    memcpy(histMoments, moments.data(), 2 * n * sizeof(float));
-    memcpy(out, src, n * sizeof(F4));
+    memcpy(S->hist.data(), histColor, n * sizeof(F4)); memcpy(S->moments[0].data(), histMoments, 2 * n * sizeof(float));
+    zhx_svgf_render(S, signal, depth, normal, motion, prevDepth, prevNormal, temporalValid, params4, normalPowerLog2, iterations, ZR_STAGE_DENOISE_MASK);
+    memcpy(histColor, S->hist.data(), n * sizeof(F4)); memcpy(histMoments, S->moments[S->momIdx].data(), 2 * n * sizeof(float));
+    memcpy(out, S->out, n * sizeof(F4));
+    zhx_svgf_destroy(S);
 }
 // FNV-1a over the built tree: the 4-wide nodes, the triangles in leaf order, the stack bound (what the device would be given)
 uint64_t zhx_bvh_digest(const HxScene* s, uint32_t* numNodes, uint32_t* numTris, uint32_t* stackNeed)
@@ -229,6 +294,7 @@ uint64_t zhx_bvh_digest(const HxScene* s, uint32_t* numNodes, uint32_t* numTris,
     return h;
 }
 void zhx_set_k11_carry(int on) { g_k11_carry = on != 0; }
+void zhx_set_k11_park(int on) { g_k11_park = on != 0; }
 void zhx_latch_heap_offsets(const HxScene* s, const zr_frame_constants* cb) { Latch(s, cb); }
 void zhx_estimate_power(const HxScene* s, float* out) { for (size_t i = 0; i < s->emissives.size(); i++) out[i] = EstimateTriPower(s->view, s->emissives[i]); }
 
@@ -428,12 +494,15 @@ void zhx_rpt_render_stage(const HxScene* s, HxRpt* R, const zr_frame_constants* 
     {
         // K11: waves = 16x4 pixel blocks of the global grid
         std::vector<PTLane> lanes(64);
+        std::vector<uint32_t> parkWords(kRcParkWords * 64, 0xCDCDCDCDu);
         for (uint32_t by = Y0 / 4; by < (Y1 + 3) / 4; by++) for (uint32_t bx = X0 / 16; bx < (X1 + 15) / 16; bx++)
         {
             for (uint32_t l = 0; l < 64; l++)
             {
                 const uint32_t x = bx * 16 + (l & 15), y = by * 4 + (l >> 4);
                 PtInitLane(F.sc, g, F.gb, prm, F.Owns(x, y), x, y, finalRGBA, stack, cnt, lanes[l]);
+                // k_rpt_pathtrace_park (zr_rpt.h RcPark): the reservoir's selected reconnection parked outside the lane, [word][lane] like the LDS block
+                if (g_k11_park) { lanes[l].r.park.p = parkWords.data() + l; lanes[l].r.park.stride = 64; lanes[l].r.parked = false; }
             }
             for (;;)
             {
@@ -453,6 +522,7 @@ void zhx_rpt_render_stage(const HxScene* s, HxRpt* R, const zr_frame_constants* 
                         PtCarryStore st; st.p = words; st.stride = 1; PtCarry(st, lanes[l]);
                         if (st.n != kPtCarryWords) { std::fprintf(stderr, "PtCarry moves %u words, kPtCarryWords says %u\n", st.n, kPtCarryWords); std::abort(); }
                         PTLane fresh; std::memset((void*)&fresh, 0xCD, sizeof(fresh));
+                        fresh.r.park.p = nullptr; fresh.r.park.stride = 0; fresh.r.parked = false;      // (a default-constructed lane has no park: k_rpt_pt_next)
                         PtCarryLoad ld; ld.p = words; ld.stride = 1; PtCarry(ld, fresh);
                         lanes[l] = fresh;
                     }

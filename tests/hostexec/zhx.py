@@ -390,6 +390,11 @@ def set_k11_carry(on):
     lib().zhx_set_k11_carry(int(bool(on)))
 
 
+def set_k11_park(on):
+    """K11 emulation of k_rpt_pathtrace_park: the reservoir's selected reconnection lives in a [word][lane] park outside the lane (zr_rpt.h RcPark)"""
+    lib().zhx_set_k11_park(int(bool(on)))
+
+
 def svgf(signal_rgba, depth, normal, motion, prev_depth, prev_normal, hist_color, hist_moments, temporal_valid=True, alpha=0.2, alpha_moments=0.2,
          sigma_l=4.0, sigma_z=1.0, normal_power_log2=7, iterations=5):
     """the denoise pass's HIP stage functions (zr_svgf.h) run serially on the host; same interface as oracle.zro.svgf"""
@@ -405,6 +410,59 @@ def svgf(signal_rgba, depth, normal, motion, prev_depth, prev_normal, hist_color
     f(sig.ctypes.data, d.ctypes.data, n.ctypes.data, m.ctypes.data, pd.ctypes.data, pn.ctypes.data, hc.ctypes.data, hm.ctypes.data,
       int(bool(temporal_valid)), p4.ctypes.data, int(normal_power_log2), int(iterations), w, h, out.ctypes.data)
     return out, hc, hm
+
+
+STAGE_DENOISE_TEMPORAL, STAGE_DENOISE_VARIANCE, STAGE_DENOISE_MASK = 1 << 8, 1 << 9, 0x3ff00
+
+
+def stage_denoise_atrous(i):
+    return 1 << (10 + i)
+
+
+class HostExecDenoise:
+    """The denoise pass's HIP stage functions with the pass's state, over a window of the frame and step by step (what zr_pass_render_stage runs on a
+    device of the tile split): window = (x0, y0, w, h) of a frame (W, H); planes handed to render() are the window's."""
+    PLANES = {"history": (0, 4), "moments": (1, 2), "iter": (2, 4), "out": (3, 4)}
+
+    def __init__(self, W, H, window=None, **kw):
+        self.W, self.H = W, H
+        self.win = tuple(window) if window is not None else (0, 0, W, H)
+        self.prm = dict(alpha=0.2, alpha_moments=0.2, sigma_l=4.0, sigma_z=1.0, normal_power_log2=7, iterations=5)
+        self.prm.update(kw)
+        L = lib()
+        L.zhx_svgf_create.restype = C.c_void_p
+        L.zhx_svgf_create.argtypes = [C.c_int] * 6
+        self.h = C.c_void_p(L.zhx_svgf_create(self.win[0], self.win[1], self.win[2], self.win[3], W, H))
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib().zhx_svgf_destroy.argtypes = [C.c_void_p]
+            lib().zhx_svgf_destroy(self.h)
+            self.h = None
+
+    def render(self, signal, depth, normal, motion, prev_depth, prev_normal, temporal_valid=True, steps=STAGE_DENOISE_MASK):
+        ph, pw = self.win[3], self.win[2]
+        arrs = [np.ascontiguousarray(signal, np.float32).reshape(ph, pw, 4), np.ascontiguousarray(depth, np.float32).reshape(ph, pw),
+                np.ascontiguousarray(normal, np.uint32).reshape(ph, pw), np.ascontiguousarray(motion, np.uint32).reshape(ph, pw),
+                np.ascontiguousarray(prev_depth, np.float32).reshape(ph, pw), np.ascontiguousarray(prev_normal, np.uint32).reshape(ph, pw)]
+        p4 = np.array([self.prm["alpha"], self.prm["alpha_moments"], self.prm["sigma_l"], self.prm["sigma_z"]], np.float32)
+        f = lib().zhx_svgf_render
+        f.argtypes = [C.c_void_p] * 7 + [C.c_int, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32]
+        f(self.h, *[a.ctypes.data for a in arrs], int(bool(temporal_valid)), p4.ctypes.data, int(self.prm["normal_power_log2"]), int(self.prm["iterations"]), int(steps))
+
+    def plane(self, name):
+        which, ch = self.PLANES[name]
+        out = np.zeros((self.win[3], self.win[2], ch), np.float32)
+        lib().zhx_svgf_read_plane.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        lib().zhx_svgf_read_plane(self.h, which, out.ctypes.data)
+        return out
+
+    def write_plane_rect(self, name, full, rect_local):
+        which, ch = self.PLANES[name]
+        full = np.ascontiguousarray(full, np.float32)
+        assert full.shape == (self.win[3], self.win[2], ch), (full.shape, self.win)
+        lib().zhx_svgf_write_plane_rect.argtypes = [C.c_void_p, C.c_int, C.c_void_p] + [C.c_uint32] * 4
+        lib().zhx_svgf_write_plane_rect(self.h, which, full.ctypes.data, *[int(v) for v in rect_local])
 
 
 def taa(signal_rgba, depth, motion, prev_out, blend_weight=0.1, temporal_valid=True):

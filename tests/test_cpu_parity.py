@@ -219,7 +219,7 @@ def test_no_device_is_a_loud_error(cornell_emissive):
 def test_wire_struct_sizes():
     assert wire.VERTEX.itemsize == 28 and wire.MESH_INSTANCE.itemsize == 64 and wire.MATERIAL.itemsize == 32
     assert wire.EMISSIVE_TRI.itemsize == 48 and wire.ALIAS_ENTRY.itemsize == 16 and wire.FRAME_CONSTANTS.itemsize == 544
-    assert C.sizeof(wire.Params) == 124     # 64 + the auto-exposure (16 B) and display (16 B) blocks + tex_filter + the denoise block (24 B)
+    assert C.sizeof(wire.Params) == 128     # 64 + the auto-exposure (16 B) and display (16 B) blocks + tex_filter + the denoise block (24 B) + num_spatial_passes (ABI 3)
 
 
 # ------------------------------------------------------------------ Russian roulette + special materials

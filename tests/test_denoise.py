@@ -229,6 +229,43 @@ def test_denoise_pass_at_3840x2160_is_deterministic_and_smooths(api, cornell_emi
     assert np.abs(np.diff(got[inner][..., 1], axis=1)).mean() < 0.2 * np.abs(np.diff(sig[inner][..., 1], axis=1)).mean()
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("world,w,h", [(4, 200, 120), (8, 512, 288)])
+def test_denoise_on_tiles_equals_one_device(api, cornell_emissive, world, w, h):
+    """BASELINE config 5's "denoise tile pass": ReSTIR PT + the denoise pass on `world` screen tiles (TiledRestirPT objects in one process -- the
+    pack / unpack data path RCCL sees; tiling.denoise_schedule: three halo exchanges per frame for five a-trous iterations) against ONE device
+    rendering the whole frame, moving camera, a history reset: denoised output, colour history and moments of every owned tile bit-identical."""
+    from zetaray_amd import tiling
+    prm = wire.default_params()
+    one = api.Renderer(cornell_emissive, w, h, params=prm, integrator=api.INTEGRATOR_RESTIR_PT)
+    dn1 = one.enable_denoise()
+    ranks = [tiling.TiledRestirPT(cornell_emissive, w, h, world, r, params=prm) for r in range(world)]
+    for t in ranks:
+        t.enable_denoise()
+    prev, exchanges = None, []
+    for f in range(1, 6):
+        cb = scene_io.make_frame_constants(w, h, frame_num=f, num_emissives=len(cornell_emissive.emissives), cam_pos=(0.04 * max(0, f - 2), 1.2, -4.043))
+        if prev is not None:
+            cb["prev_view"], cb["prev_view_inv"], cb["prev_camera_jitter"] = prev["curr_view"], prev["curr_view_inv"], prev["curr_camera_jitter"]
+        prev = cb.copy()
+        if f == 4:
+            dn1.reset_temporal()
+            for t in ranks:
+                t.p_denoise.reset_temporal()
+        one.render_frame(cb)
+        exchanges.append(tiling.render_frame_in_process(ranks, cb))
+        want = {n: dn1.download_plane(n) for n in ("denoised", "denoise_history", "denoise_moments")}
+        for t in ranks:
+            (x0, y0, tw, th), _ = t.final_tile()
+            ex0, ey0 = t.ext[0], t.ext[1]
+            for n, full in want.items():
+                got = t.p_denoise.download_plane(n)[y0 - ey0:y0 - ey0 + th, x0 - ex0:x0 - ex0 + tw]
+                assert np.array_equal(np.ascontiguousarray(got).view(np.uint32), np.ascontiguousarray(full[y0:y0 + th, x0:x0 + tw]).view(np.uint32)), f"frame {f} rank {t.rank}: {n}"
+    # reservoir exchanges (1 or 2 per frame) + the denoise pass's three
+    assert all(e in (4, 5) for e in exchanges), exchanges
+    assert want["denoised"][..., :3].max() > 0
+
+
 def test_specification_vectors():
     """tests/golden/denoise_spec.npz (tools/make_denoise_golden.py): the pass has no reference to pin it, these vectors are what keeps its definition
     from drifting -- the oracle and the host-executed HIP stage functions both reproduce them bit for bit."""

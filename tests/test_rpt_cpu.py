@@ -129,6 +129,27 @@ def test_k11_carried_state_is_all_a_path_needs(synthetic_small, cornell_emissive
         zhx.set_k11_carry(False)
 
 
+def test_k11_with_the_selected_reconnection_parked(synthetic_small, cornell_emissive, oracle_emissive, hx_emissive):
+    """k_rpt_pathtrace_park (ZR_K11_PARK=1; zr_rpt.h RcPark): while a path is traced the reservoir's selected reconnection lives in a [word][lane]
+    park (LDS on the device) -- Reservoir::Update stores winners there, the epilogue reads the last one back.  The host executor runs K11 that way,
+    the lane's own copy never written: radiance and all reservoir planes still equal the oracle's, materials + Russian roulette and Cornell."""
+    sc, osc, hx = synthetic_small
+    w, h = 64, 48
+    prm = wire.default_params()
+    prm.max_non_tr_bounces, prm.max_glossy_tr_bounces = 6, 8
+    zhx.set_k11_park(True)
+    try:
+        for scene, oscene, hxs, cam in ((sc, osc, hx, dict(cam_pos=(0, 0, -3.5))), (cornell_emissive, oracle_emissive, hx_emissive, {})):
+            o, x = zro.OracleRPT(oscene, w, h), zhx.HostExecRPT(hxs, w, h)
+            for f in range(1, 4):
+                cb = _cb(scene, w, h, f, **cam)
+                a, b = o.render(cb, prm), x.render(cb, prm)
+                assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), f"frame {f}"
+                _assert_same_state(o, x, f)
+    finally:
+        zhx.set_k11_park(False)
+
+
 def test_rpt_initial_candidates_unbiased_vs_k9(cornell_emissive, oracle_emissive):
     """Without reuse K11 is a path tracer with a different RNG layout: its mean converges to K9's (pins the oracle's
     NEE / MIS / throughput bookkeeping against the independently pinned K9 restatement)."""

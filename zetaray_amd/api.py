@@ -59,6 +59,13 @@ EXPORTS = [
 ]
 STAGE_TEMPORAL, STAGE_SPATIAL, STAGE_ALL = 1, 2, 3
 HALO_POST_TEMPORAL, HALO_FINAL = 0, 1
+HALO_DENOISE_INPUT, HALO_DENOISE_ITER = 2, 3                  # ZR_PASS_DENOISE on tiles (tiling.denoise_schedule): 40 / 16 B per pixel
+STAGE_DENOISE_TEMPORAL, STAGE_DENOISE_VARIANCE, STAGE_DENOISE_MASK = 1 << 8, 1 << 9, 0x3ff00
+
+
+def stage_denoise_atrous(i):
+    return 1 << (10 + i)
+
 HALO_BYTES_PER_PIXEL = 62
 
 

@@ -240,40 +240,50 @@ __global__ void __launch_bounds__(256) ZR_WAVES_TAA k_taa(taa::TaaFrame F)
     if (i < F.w * F.h) taa::TaaPixel(F, i % F.w, i / F.w);
 }
 
-// Denoise pass (zr_svgf.h): blocks of 32 x 8 pixels, one thread per pixel.  All three kernels are gathers over planes of 16-byte texels that the
-// L2 serves after the first touch (5 x 5 taps of colour + guide per a-trous iteration): HBM-bound, 32 B read + 16 B written per pixel and
-// iteration algorithmically.
-__device__ __forceinline__ bool SvgfPixel(uint32_t w, uint32_t h, int* x, int* y)
-{ *x = (int)(blockIdx.x * 32u + (threadIdx.x & 31u)); *y = (int)(blockIdx.y * 8u + (threadIdx.x >> 5)); return *x < (int)w && *y < (int)h; }
-__global__ void __launch_bounds__(256) k_svgf_temporal(svgf::SvgfFrame F) { int x, y; if (SvgfPixel(F.w, F.h, &x, &y)) svgf::TemporalPixel(F, x, y); }
-__global__ void __launch_bounds__(256) k_svgf_variance(svgf::FilterFrame F) { int x, y; if (SvgfPixel(F.w, F.h, &x, &y)) svgf::VariancePixel(F, x, y); }
-__global__ void __launch_bounds__(256) k_svgf_atrous(svgf::FilterFrame F) { int x, y; if (SvgfPixel(F.w, F.h, &x, &y)) svgf::AtrousPixel(F, x, y); }
+// Denoise pass (zr_svgf.h): blocks of 32 x 8 pixels of the pass's planes (a window of the frame: the whole of it on one device, a tile + apron in
+// the multi-GPU split), one thread per pixel.  The a-trous kernel is VALU-bound (r04: ~1.6 k VALU instructions per pixel in definition 1, SIMD VALU
+// ~0.9 busy at 0.03 of the HBM roof): definition 2 of zr_svgf.h is what addresses that; the LDS tiles of the dense steps save the remaining tap latency.
+__device__ __forceinline__ bool SvgfPixel(const svgf::Window& w, int* x, int* y)
+{
+    const int lx = (int)(blockIdx.x * 32u + (threadIdx.x & 31u)), ly = (int)(blockIdx.y * 8u + (threadIdx.x >> 5));
+    *x = w.ox + lx; *y = w.oy + ly;
+    return lx < w.pw && ly < w.ph;
+}
+__global__ void __launch_bounds__(256) k_svgf_temporal(svgf::SvgfFrame F) { int x, y; if (SvgfPixel(F.win, &x, &y)) svgf::TemporalPixel(F, x, y); }
+// POW: svgf_normal_power_log2 as a compile-time constant (7, the default: the squarings unroll) or -1 (read from the parameters)
+template<int POW> __global__ void __launch_bounds__(256) k_svgf_variance(svgf::FilterFrame F) { int x, y; if (SvgfPixel(F.win, &x, &y)) svgf::VariancePixelT<POW>(F, x, y); }
+// ROWLOOP: zr_svgf.h AtrousPixelT -- false = the 24 taps unrolled (held to 128 VGPRs: 4 waves per SIMD), true = a loop over the tap rows (8 waves)
+template<int POW, bool ROWLOOP> __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) k_svgf_atrous(svgf::FilterFrame F)
+{ int x, y; if (SvgfPixel(F.win, &x, &y)) { svgf::PlaneTaps t; t.src = F.src; t.guide = F.guide; t.win = F.win; svgf::AtrousPixelT<POW, ROWLOOP>(F, x, y, t); } }
 // The same iteration with the block's (32 + 4 S) x (8 + 4 S) neighbourhood of both planes staged in LDS first (steps 1 and 2: 13.8 / 20.5 KB per block),
 // so that the 25 taps + the 3 x 3 variance blur are ds_read_b128 instead of cache hits.  Same stage function, same results.  The default for
-// steps 1 and 2 (RenderDenoise).
+// steps 1 and 2 (RenderDenoise).  Tap positions arrive clamped into the planes, which keeps them inside the tile (a clamped position is nearer to the block
+// than the unclamped one).
 struct LdsTaps
 {
     const ZR_LDS_AS F4* c; const ZR_LDS_AS F4* g; int x0, y0, tw;
-    __device__ __forceinline__ F4 Src(int x, int y) const { const ZR_LDS_AS F4* q = c + (y - y0) * tw + (x - x0); F4 r; r.x = q->x; r.y = q->y; r.z = q->z; r.w = q->w; return r; }
-    __device__ __forceinline__ F4 Guide(int x, int y) const { const ZR_LDS_AS F4* q = g + (y - y0) * tw + (x - x0); F4 r; r.x = q->x; r.y = q->y; r.z = q->z; r.w = q->w; return r; }
+    __device__ __forceinline__ int RowBase(int y) const { return (y - y0) * tw - x0; }
+    __device__ __forceinline__ F4 Src(int rb, int x) const { const ZR_LDS_AS F4* q = c + rb + x; F4 r; r.x = q->x; r.y = q->y; r.z = q->z; r.w = q->w; return r; }
+    __device__ __forceinline__ F4 Guide(int rb, int x) const { const ZR_LDS_AS F4* q = g + rb + x; F4 r; r.x = q->x; r.y = q->y; r.z = q->z; r.w = q->w; return r; }
 };
-template<int S>
-__global__ void __launch_bounds__(256) k_svgf_atrous_lds(svgf::FilterFrame F)
+template<int S, int POW, bool ROWLOOP>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) k_svgf_atrous_lds(svgf::FilterFrame F)
 {
     constexpr int TW = 32 + 4 * S, TH = 8 + 4 * S;
     __shared__ F4 sC[TW * TH];
     __shared__ F4 sG[TW * TH];
-    const int bx0 = (int)(blockIdx.x * 32u) - 2 * S, by0 = (int)(blockIdx.y * 8u) - 2 * S;
+    const svgf::Window& w = F.win;
+    const int bx0 = w.ox + (int)(blockIdx.x * 32u) - 2 * S, by0 = w.oy + (int)(blockIdx.y * 8u) - 2 * S;
     for (int t = (int)threadIdx.x; t < TW * TH; t += 256)
     {
         const int gx = bx0 + t % TW, gy = by0 + t / TW;
-        if (gx >= 0 && gy >= 0 && gx < (int)F.w && gy < (int)F.h) { const size_t j = (size_t)gy * F.w + gx; sC[t] = F.src[j]; sG[t] = F.guide[j]; }
+        if (w.InPlanes(gx, gy)) { const size_t j = w.Idx(gx, gy); sC[t] = F.src[j]; sG[t] = F.guide[j]; }
     }
     __syncthreads();
     int x, y;
-    if (!SvgfPixel(F.w, F.h, &x, &y)) return;
+    if (!SvgfPixel(w, &x, &y)) return;
     LdsTaps taps; taps.c = (const ZR_LDS_AS F4*)sC; taps.g = (const ZR_LDS_AS F4*)sG; taps.x0 = bx0; taps.y0 = by0; taps.tw = TW;
-    svgf::AtrousPixelT(F, x, y, taps);
+    svgf::AtrousPixelT<POW, ROWLOOP>(F, x, y, taps);
 }
 
 // AutoExposure_Histogram.hlsl: per-block LDS histogram (256 bins = 256 threads), one global atomic per non-empty bin and block.
@@ -799,7 +809,7 @@ struct zr_pass
     DevBuf<F4> giA[2], giC[2]; DevBuf<uint16_t> giB[2];
     bool temporalValid = false, doTemporal = false, doSpatial = false; int currIdx = 0;
     const F4* compIn[4] = {nullptr, nullptr, nullptr, nullptr};     // COMPOSITING inputs (emissive DI, indirect, sky DI); [3] = TAA signal
-    DevBuf<F4> svgfHist, svgfAccum, svgfPing, svgfPong; DevBuf<float> svgfMoments[2], svgfGuideFw; DevBuf<F4> svgfGuide; int svgfMomIdx = 0; const F4* svgfOut = nullptr;      // DENOISE
+    DevBuf<F4> svgfHist, svgfAccum, svgfPing, svgfPong; DevBuf<float> svgfMoments[2], svgfGuideFw; DevBuf<F4> svgfGuide; int svgfMomIdx = 0; const F4* svgfOut = nullptr; F4* svgfCur = nullptr; uint32_t svgfStepsDone = 0;      // DENOISE
     DevBuf<uint16_t> taaOut[2]; int taaIdx = 0;            // TAA: ping-pong RGBA16F outputs; taaIdx = the one written last
     // AUTO_EXPOSURE / DISPLAY
     const uint16_t* postIn16 = nullptr; const F4* postIn32 = nullptr; const float* exposureIn = nullptr;
@@ -1651,7 +1661,7 @@ static int AllocPass(zr_pass* p)
         if ((r = p->svgfHist.Alloc(n)) || (r = p->svgfAccum.Alloc(n)) || (r = p->svgfPing.Alloc(n)) || (r = p->svgfPong.Alloc(n)) || (r = p->svgfGuide.Alloc(n)) || (r = p->svgfGuideFw.Alloc(n))) return r;
         for (int k = 0; k < 2; k++) { if ((r = p->svgfMoments[k].Alloc(2 * n))) return r; HIP_TRY(hipMemset(p->svgfMoments[k].p, 0, 2 * n * sizeof(float))); }
         HIP_TRY(hipMemset(p->svgfHist.p, 0, n * sizeof(F4))); HIP_TRY(hipMemset(p->svgfPing.p, 0, n * sizeof(F4))); HIP_TRY(hipMemset(p->svgfPong.p, 0, n * sizeof(F4)));
-        p->svgfMomIdx = 0; p->svgfOut = p->svgfPing.p; p->temporalValid = false;
+        p->svgfMomIdx = 0; p->svgfOut = p->svgfPing.p; p->svgfCur = p->svgfPing.p; p->temporalValid = false;
     }
     if (p->kind == ZR_PASS_AUTO_EXPOSURE)
     {
@@ -2197,7 +2207,13 @@ static int RenderReSTIR_PT(zr_pass* p, hipStream_t s, const zr_frame_constants* 
         else if (texVariant) { if (emissiveVariant) hipLaunchKernelGGL(k_rpt_pathtrace_tex<true>, gridRpt, blockRpt, 0, s, F, *cb, tilesX, ctr + 2 * 1); else hipLaunchKernelGGL(k_rpt_pathtrace_tex<false>, gridRpt, blockRpt, 0, s, F, *cb, tilesX, ctr + 2 * 1); }
         else if (sc->view.numNodes >= largeSceneNodes || FewerRoundsAtFourWaves(gridRpt.x))     // BVH beyond the caches, or a small grid: the 4-wave build of K11 (zr_kernels.h)
         { if (emissiveVariant) hipLaunchKernelGGL(k_rpt_pathtrace_w4<true>, gridRpt, blockRpt, 0, s, F, *cb, tilesX, ctr + 2 * 1); else hipLaunchKernelGGL(k_rpt_pathtrace_w4<false>, gridRpt, blockRpt, 0, s, F, *cb, tilesX, ctr + 2 * 1); }
-        else { if (emissiveVariant) hipLaunchKernelGGL(k_rpt_pathtrace<true>, gridRpt, blockRpt, 0, s, F, *cb, tilesX, ctr + 2 * 1); else hipLaunchKernelGGL(k_rpt_pathtrace<false>, gridRpt, blockRpt, 0, s, F, *cb, tilesX, ctr + 2 * 1); }
+        else
+        {
+            // ZR_K11_PARK=1: the 3-wave build with the reservoir's selected reconnection in LDS (zr_rpt.h RcPark; measured in DESIGN 6.4)
+            static const bool park = [] { const char* e = getenv("ZR_K11_PARK"); return e ? atoi(e) != 0 : (ZR_K11_PARK_DEFAULT != 0); }();
+            if (park) { if (emissiveVariant) hipLaunchKernelGGL(k_rpt_pathtrace_park<true>, gridRpt, blockRpt, 0, s, F, *cb, tilesX, ctr + 2 * 1); else hipLaunchKernelGGL(k_rpt_pathtrace_park<false>, gridRpt, blockRpt, 0, s, F, *cb, tilesX, ctr + 2 * 1); }
+            else if (emissiveVariant) hipLaunchKernelGGL(k_rpt_pathtrace<true>, gridRpt, blockRpt, 0, s, F, *cb, tilesX, ctr + 2 * 1); else hipLaunchKernelGGL(k_rpt_pathtrace<false>, gridRpt, blockRpt, 0, s, F, *cb, tilesX, ctr + 2 * 1);
+        }
         TimerEnd(p, s);
         if (prm.doTemporal)
         {
@@ -2405,50 +2421,73 @@ static int RenderTAA(zr_pass* p, hipStream_t s, const zr_frame_constants* cb, zr
     return ZR_OK;
 }
 
-// Denoise pass: temporal accumulation -> variance estimate -> a-trous iterations (zr_svgf.h; no reference counterpart)
-static int RenderDenoise(zr_pass* p, hipStream_t s, const zr_frame_constants* cb, zr_gbuffer* gb)
+// Denoise pass: temporal accumulation -> variance estimate -> a-trous iterations (zr_svgf.h; no reference counterpart).
+// `steps`: which of them this call runs (ZR_STAGE_DENOISE_*; zr_pass_render = all).  A device of the tile split runs them in groups with halo
+// exchanges in between (zetaray_amd/tiling.py denoise_schedule): the planes then cover the tile + its apron, a window of the frame.
+static int RenderDenoise(zr_pass* p, hipStream_t s, const zr_frame_constants* cb, zr_gbuffer* gb, uint32_t steps)
 {
     if (!gb || gb->w != p->w || gb->h != p->h) return Fail(ZR_ERR_INVALID_ARG, "DENOISE needs a gbuffer of the pass size");
-    if (cb->render_width != p->w || cb->render_height != p->h) return Fail(ZR_ERR_INVALID_ARG, "DENOISE: frame constants / pass size mismatch");
-    if (!p->compIn[3]) return Fail(ZR_ERR_NOT_INITIALIZED, "DENOISE: no input bound (zr_pass_set_input(ZR_IN_DENOISE_SIGNAL))");
+    if (gb->x0 + gb->w > cb->render_width || gb->y0 + gb->h > cb->render_height) return Fail(ZR_ERR_INVALID_ARG, "DENOISE: the planes' window leaves the frame of the frame constants");
+    if (!p->compIn[3]) return Fail(ZR_ERR_NOT_INITIALIZED, "DENOISE: no input signal (zr_pass_set_input(pass, ZR_IN_DENOISE_SIGNAL, rgba32f))");
     const zr_params& prm = p->params;
     if (prm.svgf_iterations > 8u || prm.svgf_normal_power_log2 > 16u) return Fail(ZR_ERR_INVALID_ARG, "DENOISE: svgf_iterations must be <= 8, svgf_normal_power_log2 <= 16");
+    if (!(prm.svgf_sigma_z > 0.0f) || !(prm.svgf_sigma_l >= 0.0f) || !(prm.svgf_sigma_z < 1e30f) || !(prm.svgf_sigma_l < 1e30f)) return Fail(ZR_ERR_INVALID_ARG, "DENOISE: svgf_sigma_z must be positive, svgf_sigma_l non-negative, both finite");
     const GBuf cur = gb->View(), prev = gb->PrevView();
-    const int mi = p->svgfMomIdx;
     svgf::SvgfParams sp; sp.alpha = prm.svgf_alpha; sp.alphaMoments = prm.svgf_alpha_moments; sp.sigmaL = prm.svgf_sigma_l; sp.sigmaZ = prm.svgf_sigma_z;
     sp.normalPowerLog2 = prm.svgf_normal_power_log2; sp.iterations = prm.svgf_iterations;
-    svgf::SvgfFrame T;
-    T.signal = p->compIn[3]; T.depth = cur.depth; T.normal = cur.normal; T.motion = cur.motion; T.prevDepth = prev.depth; T.prevNormal = prev.normal;
-    T.histColor = p->svgfHist.p; T.histMoments = p->svgfMoments[mi].p; T.accum = p->svgfAccum.p; T.moments = p->svgfMoments[mi ^ 1].p; T.guide = p->svgfGuide.p; T.guideFw = p->svgfGuideFw.p;
-    T.w = p->w; T.h = p->h; T.temporalValid = (p->temporalValid && gb->numRendered >= 2) ? 1u : 0u; T.prm = sp;
+    svgf::Window win; win.ox = (int)gb->x0; win.oy = (int)gb->y0; win.pw = (int)p->w; win.ph = (int)p->h; win.W = (int)cb->render_width; win.H = (int)cb->render_height;
     const dim3 grid((p->w + 31u) / 32u, (p->h + 7u) / 8u), block(256);
-    TimerBegin(p, s, "denoise_temporal");
-    hipLaunchKernelGGL(k_svgf_temporal, grid, block, 0, s, T);
-    TimerEnd(p, s);
+    const bool pow7 = sp.normalPowerLog2 == 7u;
+    const int mi = p->svgfMomIdx;      // histMoments = [mi], this frame's = [mi ^ 1]; flipped when the frame's last step has run
+    if (steps & ZR_STAGE_DENOISE_TEMPORAL)
+    {
+        svgf::SvgfFrame T;
+        T.signal = p->compIn[3]; T.depth = cur.depth; T.normal = cur.normal; T.motion = cur.motion; T.prevDepth = prev.depth; T.prevNormal = prev.normal;
+        T.histColor = p->svgfHist.p; T.histMoments = p->svgfMoments[mi].p; T.accum = p->svgfAccum.p; T.moments = p->svgfMoments[mi ^ 1].p; T.guide = p->svgfGuide.p; T.guideFw = p->svgfGuideFw.p;
+        T.win = win; T.temporalValid = (p->temporalValid && gb->numRendered >= 2) ? 1u : 0u; T.prm = sp;
+        TimerBegin(p, s, "denoise_temporal");
+        hipLaunchKernelGGL(k_svgf_temporal, grid, block, 0, s, T);
+        TimerEnd(p, s);
+        p->svgfStepsDone = 0;
+    }
     svgf::FilterFrame V;
     V.src = p->svgfAccum.p; V.moments = p->svgfMoments[mi ^ 1].p; V.guide = p->svgfGuide.p; V.guideFw = p->svgfGuideFw.p; V.dst = p->svgfPing.p; V.lenSrc = p->svgfAccum.p;
-    V.history = sp.iterations == 0 ? p->svgfHist.p : nullptr; V.w = p->w; V.h = p->h; V.step = 1; V.prm = sp;
-    TimerBegin(p, s, "denoise_variance");
-    hipLaunchKernelGGL(k_svgf_variance, grid, block, 0, s, V);
-    TimerEnd(p, s);
-    F4* src = p->svgfPing.p; F4* dst = p->svgfPong.p;
-    TimerBegin(p, s, "denoise_atrous");
+    V.history = sp.iterations == 0 ? p->svgfHist.p : nullptr; V.win = win; V.step = 1; V.prm = sp;
+    if (steps & ZR_STAGE_DENOISE_VARIANCE)
+    {
+        TimerBegin(p, s, "denoise_variance");
+        if (pow7) hipLaunchKernelGGL(k_svgf_variance<7>, grid, block, 0, s, V); else hipLaunchKernelGGL(k_svgf_variance<-1>, grid, block, 0, s, V);
+        TimerEnd(p, s);
+        p->svgfCur = p->svgfPing.p;
+    }
+    bool timing = false;
     for (uint32_t it = 0; it < sp.iterations; it++)
     {
+        if (!(steps & ZR_STAGE_DENOISE_ATROUS(it))) continue;
+        if (!timing) { TimerBegin(p, s, "denoise_atrous"); timing = true; }
+        F4* src = p->svgfCur; F4* dst = src == p->svgfPing.p ? p->svgfPong.p : p->svgfPing.p;
         svgf::FilterFrame A = V;
         A.src = src; A.dst = dst; A.moments = nullptr; A.step = 1u << it; A.history = it == 0 ? p->svgfHist.p : nullptr;
         // LDS-staged tiles for the dense iterations (steps 1 and 2: atrium 3840 x 2160 0.528 -> 0.416 ms each); ZR_DENOISE=plain: every iteration from the
         // planes; ZR_DENOISE=lds4: step 4 from a 48 x 24 tile too (36.8 KB per block)
         static const int ldsSteps = [] { const char* e = getenv("ZR_DENOISE"); return e && !strcmp(e, "plain") ? 0 : (e && !strcmp(e, "lds4") ? 3 : 2); }();
-        if (it == 0 && ldsSteps >= 1) hipLaunchKernelGGL(k_svgf_atrous_lds<1>, grid, block, 0, s, A);
-        else if (it == 1 && ldsSteps >= 2) hipLaunchKernelGGL(k_svgf_atrous_lds<2>, grid, block, 0, s, A);
-        else if (it == 2 && ldsSteps >= 3) hipLaunchKernelGGL(k_svgf_atrous_lds<4>, grid, block, 0, s, A);
-        else hipLaunchKernelGGL(k_svgf_atrous, grid, block, 0, s, A);
-        F4* t = src; src = dst; dst = t;
+        // ZR_DENOISE_TAPS=row: the row-loop form of the tap stencil instead of the unrolled one (zr_svgf.h AtrousPixelT); a parameterised normal power
+        // (svgf_normal_power_log2 != 7) always takes the row loop
+        static const bool rowLoop = [] { const char* e = getenv("ZR_DENOISE_TAPS"); return e && !strcmp(e, "row"); }();
+#define ZR_SVGF_LAUNCH(K, ...) do { if (!pow7) hipLaunchKernelGGL((K<__VA_ARGS__ -1, true>), grid, block, 0, s, A); else if (rowLoop) hipLaunchKernelGGL((K<__VA_ARGS__ 7, true>), grid, block, 0, s, A); \
+            else hipLaunchKernelGGL((K<__VA_ARGS__ 7, false>), grid, block, 0, s, A); } while (0)
+        if (it == 0 && ldsSteps >= 1) ZR_SVGF_LAUNCH(k_svgf_atrous_lds, 1,);
+        else if (it == 1 && ldsSteps >= 2) ZR_SVGF_LAUNCH(k_svgf_atrous_lds, 2,);
+        else if (it == 2 && ldsSteps >= 3) ZR_SVGF_LAUNCH(k_svgf_atrous_lds, 4,);
+        else ZR_SVGF_LAUNCH(k_svgf_atrous,);
+#undef ZR_SVGF_LAUNCH
+        p->svgfCur = dst;
     }
-    TimerEnd(p, s);
+    if (timing) TimerEnd(p, s);
     HIP_TRY(hipGetLastError());
-    p->svgfOut = src; p->svgfMomIdx = mi ^ 1; p->temporalValid = true;
+    // the frame is complete when its last step has run: the last a-trous iteration, or the variance stage when there are none
+    const uint32_t last = sp.iterations ? ZR_STAGE_DENOISE_ATROUS(sp.iterations - 1u) : (uint32_t)ZR_STAGE_DENOISE_VARIANCE;
+    if (steps & last) { p->svgfOut = p->svgfCur; p->svgfMomIdx = mi ^ 1; p->temporalValid = true; }
     return ZR_OK;
 }
 
@@ -2509,6 +2548,14 @@ static int HaloPlanes(zr_pass* p, int which, HaloPlane* planes, size_t* bytesPer
     { planes[n++] = {p->giA[set].p, 16}; planes[n++] = {p->giB[set].p, 8}; planes[n++] = {p->giC[set].p, 16}; }
     else if (p->kind == ZR_PASS_DI_EMISSIVE) { planes[n++] = {p->diA[set].p, 16}; planes[n++] = {p->diB[set].p, 8}; }
     else if (p->kind == ZR_PASS_DI_SKY) { planes[n++] = {p->skyA[set].p, 1}; planes[n++] = {p->skyB[set].p, 4}; planes[n++] = {p->skyC[set].p, 8}; }
+    else if (p->kind == ZR_PASS_DENOISE)
+    {
+        // INPUT: what the temporal step of a tile reads in its apron -- this frame's signal (the bound input plane: its owner shaded it) and the
+        // history the previous frame left (colour + length, moments); ITER: the plane the next a-trous iteration reads
+        if (which == ZR_HALO_DENOISE_INPUT && p->compIn[3])
+        { planes[n++] = {(void*)p->compIn[3], 16}; planes[n++] = {p->svgfHist.p, 16}; planes[n++] = {p->svgfMoments[p->svgfMomIdx].p, 8}; }
+        else if (which == ZR_HALO_DENOISE_ITER) planes[n++] = {p->svgfCur, 16};
+    }
     size_t b = 0;
     for (int i = 0; i < n; i++) b += planes[i].bpp;
     *bytesPerPixel = b;
@@ -2518,6 +2565,7 @@ int zr_pass_halo_bytes_per_pixel(zr_pass* p, uint32_t* bytes)
 {
     if (!p || !bytes) return Fail(ZR_ERR_INVALID_ARG, "null argument");
     HaloPlane pl[8]; size_t b = 0;
+    if (p->initialized && p->kind == ZR_PASS_DENOISE) { *bytes = 40; return ZR_OK; }      // the larger of its two exchanges (ZR_HALO_DENOISE_INPUT; _ITER moves 16)
     if (!p->initialized || !HaloPlanes(p, ZR_HALO_FINAL, pl, &b)) return Fail(ZR_ERR_NOT_INITIALIZED, "pass has no reservoir planes to exchange (or is not initialised)");
     *bytes = (uint32_t)b;
     return ZR_OK;
@@ -2627,7 +2675,11 @@ static int RenderStageInner(zr_pass* p, void* stream, const zr_frame_constants* 
     case ZR_PASS_TAA: return (stages & ZR_STAGE_SPATIAL) ? RenderTAA(p, s, cb, gb) : ZR_OK;
     case ZR_PASS_AUTO_EXPOSURE: return (stages & ZR_STAGE_SPATIAL) ? RenderAutoExposure(p, s, cb) : ZR_OK;
     case ZR_PASS_DISPLAY: return (stages & ZR_STAGE_SPATIAL) ? RenderDisplay(p, s, cb) : ZR_OK;
-    case ZR_PASS_DENOISE: return (stages & ZR_STAGE_SPATIAL) ? RenderDenoise(p, s, cb, gb) : ZR_OK;
+    case ZR_PASS_DENOISE:
+    {   // ZR_STAGE_SPATIAL (what zr_pass_render passes): the whole pass; ZR_STAGE_DENOISE_* bits: the steps of a tile's schedule
+        const uint32_t steps = ((uint32_t)stages & ZR_STAGE_DENOISE_MASK) | ((stages & ZR_STAGE_SPATIAL) ? (uint32_t)ZR_STAGE_DENOISE_MASK : 0u);
+        return steps ? RenderDenoise(p, s, cb, gb, steps) : ZR_OK;
+    }
     default: return Fail(ZR_ERR_UNSUPPORTED, "pass kind %d not implemented", p->kind);
     }
 }

@@ -228,7 +228,8 @@ __device__ __forceinline__ void FlushRayCountersCost(const rpt::RptFrame& F, uns
 // K11: block = 16x16 pixels, wave w = rows 4w..4w+3 (a 16x4 block: the RR "wave" of the ABI, zr_rpt.h header)
 // EMISSIVE: the NEE_EMISSIVE shader permutation (emissive triangles vs sun + sky); a template constant so the other variant folds away
 // TEX: the scene has a texture heap (ray differentials carried, material maps sampled); likewise a template constant
-template<bool EMISSIVE, bool TEX, bool NODE_CACHE = false>
+// PARK: the reservoir's selected reconnection in LDS instead of registers / scratch (zr_rpt.h RcPark: 17 words x 64 lanes = 4.25 KB per one-wave block)
+template<bool EMISSIVE, bool TEX, bool NODE_CACHE = false, bool PARK = false>
 __device__ __forceinline__ void RptPathtraceBody(rpt::RptFrame& F, const zr_frame_constants& g, uint32_t tilesX, unsigned long long* counters)
 {
     const unsigned long long t0 = __builtin_readcyclecounter();
@@ -242,6 +243,8 @@ __device__ __forceinline__ void RptPathtraceBody(rpt::RptFrame& F, const zr_fram
     uint32_t cnt[2] = {0u, 0u};
     rpt::PTLane P;
     { ZR_PROF_SCOPE(ZRP_MISC0); rpt::PtInitLane_Fused(F.sc, g, F.gb, F.prm, F.Owns(x, y), x, y, F.finalRGBA, stack, cnt, P); }
+    __shared__ uint32_t rcParkLds[PARK ? rpt::kRcParkWords * kRptBlock : 1];
+    if (PARK) { P.r.park.p = (ZR_LDS_AS uint32_t*)rcParkLds + threadIdx.x; P.r.park.stride = kRptBlock; P.r.parked = false; }
     for (;;)
     {
         const bool any = __ballot(P.active) != 0;
@@ -260,6 +263,10 @@ __device__ __forceinline__ void RptPathtraceBody(rpt::RptFrame& F, const zr_fram
 template<bool EMISSIVE>
 __global__ void __launch_bounds__(kRptBlock) ZR_WAVES_PATHTRACE k_rpt_pathtrace(rpt::RptFrame F, zr_frame_constants g, uint32_t tilesX, unsigned long long* counters)
 { RptPathtraceBody<EMISSIVE, false>(F, g, tilesX, counters); }
+// the same with the reservoir's selected reconnection parked in LDS (ZR_K11_PARK=1; zr_rpt.h RcPark)
+template<bool EMISSIVE>
+__global__ void __launch_bounds__(kRptBlock) ZR_WAVES_PATHTRACE k_rpt_pathtrace_park(rpt::RptFrame F, zr_frame_constants g, uint32_t tilesX, unsigned long long* counters)
+{ RptPathtraceBody<EMISSIVE, false, false, true>(F, g, tilesX, counters); }
 // The same kernel at 4 waves per SIMD (128 VGPRs, more spills): used for scenes whose BVH does not fit the caches, where the inline
 // traversal is latency-bound and the extra wave hides more than the spills cost (380 k-triangle atrium: 11.7 -> 10.6 ms; on the
 // 58-triangle Cornell box both take 1.16 ms, and the 3-wave build moves 5x less spill traffic, so small scenes keep it).
@@ -551,6 +558,9 @@ __device__ __forceinline__ RawHit BlockTrace(const SceneView& sc, const rpt::Tra
 // K11 with pooled traces (emissive-NEE variant; zr_rpt.h: the stage functions cut at their BVH queries).  Block = the 16 x 16 tile, wave w =
 // rows 4w .. 4w+3 like k_rpt_pathtrace; the bounce loop runs until every wave of the block is done (finished waves keep tracing for the others).
 static constexpr int kCoopBlock = 256;
+#ifndef ZR_K11_PARK_DEFAULT
+#define ZR_K11_PARK_DEFAULT 0     // 1 = k_rpt_pathtrace_park (RcPark) for scenes that take the 3-wave build; ZR_K11_PARK=0|1 overrides at run time
+#endif
 #ifndef ZR_K11_DEFAULT
 #define ZR_K11_DEFAULT 0          // 0 = the inline megakernel, 1 = pooled traces; ZR_K11=inline|pool overrides at run time
 #endif
@@ -885,6 +895,7 @@ __global__ void __launch_bounds__(kBlock) ZR_WAVES_STC k_rpt_stc(rpt::RptFrame F
 #define ZR_RPT_GROUP_A(X) \
     X __global__ void k_rpt_pathtrace<true> ZR_RPT_ARGS_TILE; X __global__ void k_rpt_pathtrace<false> ZR_RPT_ARGS_TILE; \
     X __global__ void k_rpt_pathtrace_w4<true> ZR_RPT_ARGS_TILE; X __global__ void k_rpt_pathtrace_w4<false> ZR_RPT_ARGS_TILE; \
+    X __global__ void k_rpt_pathtrace_park<true> ZR_RPT_ARGS_TILE; X __global__ void k_rpt_pathtrace_park<false> ZR_RPT_ARGS_TILE; \
     X __global__ void k_rpt_pathtrace_tex<true> ZR_RPT_ARGS_TILE; X __global__ void k_rpt_pathtrace_tex<false> ZR_RPT_ARGS_TILE; \
     X __global__ void k_rpt_temporal<true, true> ZR_RPT_ARGS_TILE; X __global__ void k_rpt_temporal<true, false> ZR_RPT_ARGS_TILE; \
     X __global__ void k_rpt_temporal<false, true> ZR_RPT_ARGS_TILE; X __global__ void k_rpt_temporal<false, false> ZR_RPT_ARGS_TILE;

@@ -270,9 +270,37 @@ struct ResPlanes
     uint32_t* G;     // RG32_UINT
 };
 
+// K11: while a path is traced the reservoir's SELECTED reconnection is cold state -- written when a candidate wins the
+// resampling, read once in the epilogue -- 23 words that the register allocator otherwise spills to scratch.  With a park bound, Update stores a
+// winning candidate into it (17 words: the small integers share one) and the epilogue reads it back; the registers of Reservoir::rc are dead in
+// between.  p: this lane's first word, word k at p[k * stride] (LDS, [word][lane]: conflict-free); p == nullptr (every other user of Reservoir):
+// plain member copies, and the branch folds away.
+struct RcPark { ZR_LDS_AS uint32_t* p; uint32_t stride; };
+static constexpr uint32_t kRcParkWords = 17;
+ZR_HD void RcParkStore(const RcPark& k, const Reconnection& rc)
+{
+    const uint32_t s = k.stride;
+    k.p[0] = zr_asuint(rc.x_k.x); k.p[s] = zr_asuint(rc.x_k.y); k.p[2 * s] = zr_asuint(rc.x_k.z); k.p[3 * s] = rc.ID; k.p[4 * s] = rc.meshIdx;
+    k.p[5 * s] = zr_asuint(rc.partialJacobian); k.p[6 * s] = zr_asuint(rc.w.x); k.p[7 * s] = zr_asuint(rc.w.y); k.p[8 * s] = zr_asuint(rc.w.z);
+    k.p[9 * s] = zr_asuint(rc.lightPdf); k.p[10 * s] = rc.seed_replay; k.p[11 * s] = rc.seed_nee; k.p[12 * s] = zr_asuint(rc.dwdA);
+    k.p[13 * s] = zr_asuint(rc.L.x); k.p[14 * s] = zr_asuint(rc.L.y); k.p[15 * s] = zr_asuint(rc.L.z);
+    k.p[16 * s] = (rc.k & 0xffu) | (rc.lobe_k_min_1 << 8) | (rc.lobe_k << 12) | (rc.lt_k << 16) | (rc.lt_k_plus_1 << 20) | ((rc.x_k_in_motion ? 1u : 0u) << 24);
+}
+ZR_HD void RcParkLoad(const RcPark& k, Reconnection& rc)
+{
+    const uint32_t s = k.stride;
+    rc.x_k = v3(zr_asfloat(k.p[0]), zr_asfloat(k.p[s]), zr_asfloat(k.p[2 * s])); rc.ID = k.p[3 * s]; rc.meshIdx = k.p[4 * s];
+    rc.partialJacobian = zr_asfloat(k.p[5 * s]); rc.w = v3(zr_asfloat(k.p[6 * s]), zr_asfloat(k.p[7 * s]), zr_asfloat(k.p[8 * s]));
+    rc.lightPdf = zr_asfloat(k.p[9 * s]); rc.seed_replay = k.p[10 * s]; rc.seed_nee = k.p[11 * s]; rc.dwdA = zr_asfloat(k.p[12 * s]);
+    rc.L = v3(zr_asfloat(k.p[13 * s]), zr_asfloat(k.p[14 * s]), zr_asfloat(k.p[15 * s]));
+    const uint32_t m = k.p[16 * s];
+    rc.k = m & 0xffu; rc.lobe_k_min_1 = (m >> 8) & 0xfu; rc.lobe_k = (m >> 12) & 0xfu; rc.lt_k = (m >> 16) & 0xfu; rc.lt_k_plus_1 = (m >> 20) & 0xfu; rc.x_k_in_motion = ((m >> 24) & 1u) != 0;
+}
+
 struct Reservoir
 {
     float w_sum, W; V3 target; Reconnection rc; uint32_t M;
+    RcPark park = {nullptr, 0}; bool parked = false;      // K11 only (see RcPark): the selected reconnection lives at `park` once `parked`
     // Reservoir.hlsli:23-45
     ZR_HDM bool Update(float weight, V3 target_, const Reconnection& rc_, Rng& rng)
     {
@@ -280,7 +308,11 @@ struct Reservoir
         M += 1;
         if (weight == 0) return false;
         w_sum += weight;
-        if (rng.Uniform() < (weight / w_sum)) { rc = rc_; target = target_; return true; }
+        if (rng.Uniform() < (weight / w_sum))
+        {
+            if (park.p) { RcParkStore(park, rc_); parked = true; } else rc = rc_;
+            target = target_; return true;
+        }
         return false;
     }
     ZR_HDM void UnpackMetadata(uint32_t a)
@@ -1538,6 +1570,7 @@ ZR_HD void PtFinishLane(const GBuf& gb, const RptParams& prm, const ResPlanes& o
     if (!P.valid) return;
     const size_t px = Pix(gb, P.x, P.y);
     Reservoir& r = P.r;
+    if (r.park.p && r.parked) RcParkLoad(r.park, r.rc);      // K11 with the selected reconnection parked in LDS (RcPark)
     r.rc.seed_replay = P.seed_replay;
     float targetLum = Luminance(r.target);
     r.W = targetLum > 0 ? zr_max(r.w_sum / targetLum, 1.0f) : 0;

@@ -51,15 +51,31 @@ ZR_HD V3 LoadSignal(const TaaFrame& F, int x, int y)
     const F4 c = F.signal[(size_t)y * F.w + x];
     return v3(c.x, c.y, c.z);
 }
-ZR_HD V3 LoadHistoryTexel(const TaaFrame& F, int x, int y)
+// One 8-byte load per RGBA16F texel (the Catmull-Rom fetch reads 36 of them per pixel: three 2-byte loads each made TAA load-issue bound).
+// zr_f16_to_f32 special-cases Inf / NaN per value -- ~8 extra instructions each, 108 conversions per pixel: most of this kernel's VALU work
+// (profiles/r04b_post_sqA.csv: 1449 VALU instructions per pixel, the kernel VALU-bound at 0.08 of the HBM roof).  EXACT = false converts with plain
+// v_cvt_f32_f16 and ORs a "some value of this texel is Inf / NaN" bit into `special`: adding 0x0400 to an exponent field of all ones carries into the
+// field's top bit.  The caller re-runs the fetch with EXACT = true in the (practically never taken) case that the bit is set, so the result is
+// zr_f16_to_f32's for every input.
+template<bool EXACT>
+ZR_HD V3 LoadHistoryTexel(const TaaFrame& F, int x, int y, uint64_t& special)
 {
-    // one 8-byte load per RGBA16F texel (the Catmull-Rom fetch reads 36 of them per pixel: three 2-byte loads each made TAA load-issue bound)
     uint64_t t;
     __builtin_memcpy(&t, F.prevOut + 4 * ((size_t)y * F.w + x), 8);
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (!EXACT)
+    {
+        special |= (t & 0x00007c007c007c00ull) + 0x0000040004000400ull;
+        union { uint16_t u; _Float16 h; } a, b, c;
+        a.u = (uint16_t)(t & 0xffffu); b.u = (uint16_t)((t >> 16) & 0xffffu); c.u = (uint16_t)((t >> 32) & 0xffffu);
+        return v3((float)a.h, (float)b.h, (float)c.h);
+    }
+#endif
     return v3(zr_f16_to_f32((uint16_t)(t & 0xffffu)), zr_f16_to_f32((uint16_t)((t >> 16) & 0xffffu)), zr_f16_to_f32((uint16_t)((t >> 32) & 0xffffu)));
 }
 // SampleLevel(g_samLinearClamp, uv, 0) on the history
-ZR_HD V3 SampleHistory(const TaaFrame& F, float u, float v)
+template<bool EXACT>
+ZR_HD V3 SampleHistory(const TaaFrame& F, float u, float v, uint64_t& special)
 {
     const float x = u * (float)F.w - 0.5f, y = v * (float)F.h - 0.5f;
     const float fx = zr_floor(x), fy = zr_floor(y);
@@ -69,14 +85,15 @@ ZR_HD V3 SampleHistory(const TaaFrame& F, float u, float v)
     const int W1 = (int)F.w - 1, H1 = (int)F.h - 1;
     x0 = x0 < 0 ? 0 : (x0 > W1 ? W1 : x0); x1 = x1 < 0 ? 0 : (x1 > W1 ? W1 : x1);
     y0 = y0 < 0 ? 0 : (y0 > H1 ? H1 : y0); y1 = y1 < 0 ? 0 : (y1 > H1 ? H1 : y1);
-    const V3 c00 = LoadHistoryTexel(F, x0, y0), c10 = LoadHistoryTexel(F, x1, y0);
-    const V3 c01 = LoadHistoryTexel(F, x0, y1), c11 = LoadHistoryTexel(F, x1, y1);
+    const V3 c00 = LoadHistoryTexel<EXACT>(F, x0, y0, special), c10 = LoadHistoryTexel<EXACT>(F, x1, y0, special);
+    const V3 c01 = LoadHistoryTexel<EXACT>(F, x0, y1, special), c11 = LoadHistoryTexel<EXACT>(F, x1, y1, special);
     const V3 top = c00 + tx * (c10 - c00);
     const V3 bot = c01 + tx * (c11 - c01);
     return top + ty * (bot - top);
 }
 // Common::SampleTextureCatmullRom, Common.hlsli:63-105 (9 bilinear fetches)
-ZR_HD V3 SampleHistoryCatmullRom(const TaaFrame& F, V2 uv, V2 texSize)
+template<bool EXACT>
+ZR_HD V3 SampleHistoryCatmullRomT(const TaaFrame& F, V2 uv, V2 texSize, uint64_t& special)
 {
     const V2 samplePos = v2(uv.x * texSize.x, uv.y * texSize.y);
     const V2 texPos1 = v2(zr_floor(samplePos.x - 0.5f) + 0.5f, zr_floor(samplePos.y - 0.5f) + 0.5f);
@@ -94,16 +111,23 @@ ZR_HD V3 SampleHistoryCatmullRom(const TaaFrame& F, V2 uv, V2 texSize)
     texPos3 = v2(texPos3.x / texSize.x, texPos3.y / texSize.y);
     texPos12 = v2(texPos12.x / texSize.x, texPos12.y / texSize.y);
     V3 result = v3(0.0f);
-    result = result + SampleHistory(F, texPos0.x, texPos0.y) * w0.x * w0.y;
-    result = result + SampleHistory(F, texPos12.x, texPos0.y) * w12.x * w0.y;
-    result = result + SampleHistory(F, texPos3.x, texPos0.y) * w3.x * w0.y;
-    result = result + SampleHistory(F, texPos0.x, texPos12.y) * w0.x * w12.y;
-    result = result + SampleHistory(F, texPos12.x, texPos12.y) * w12.x * w12.y;
-    result = result + SampleHistory(F, texPos3.x, texPos12.y) * w3.x * w12.y;
-    result = result + SampleHistory(F, texPos0.x, texPos3.y) * w0.x * w3.y;
-    result = result + SampleHistory(F, texPos12.x, texPos3.y) * w12.x * w3.y;
-    result = result + SampleHistory(F, texPos3.x, texPos3.y) * w3.x * w3.y;
+    result = result + SampleHistory<EXACT>(F, texPos0.x, texPos0.y, special) * w0.x * w0.y;
+    result = result + SampleHistory<EXACT>(F, texPos12.x, texPos0.y, special) * w12.x * w0.y;
+    result = result + SampleHistory<EXACT>(F, texPos3.x, texPos0.y, special) * w3.x * w0.y;
+    result = result + SampleHistory<EXACT>(F, texPos0.x, texPos12.y, special) * w0.x * w12.y;
+    result = result + SampleHistory<EXACT>(F, texPos12.x, texPos12.y, special) * w12.x * w12.y;
+    result = result + SampleHistory<EXACT>(F, texPos3.x, texPos12.y, special) * w3.x * w12.y;
+    result = result + SampleHistory<EXACT>(F, texPos0.x, texPos3.y, special) * w0.x * w3.y;
+    result = result + SampleHistory<EXACT>(F, texPos12.x, texPos3.y, special) * w12.x * w3.y;
+    result = result + SampleHistory<EXACT>(F, texPos3.x, texPos3.y, special) * w3.x * w3.y;
     return result;
+}
+ZR_HD V3 SampleHistoryCatmullRom(const TaaFrame& F, V2 uv, V2 texSize)
+{
+    uint64_t special = 0;
+    V3 r = SampleHistoryCatmullRomT<false>(F, uv, texSize, special);
+    if (special & 0x0000800080008000ull) r = SampleHistoryCatmullRomT<true>(F, uv, texSize, special);      // an Inf / NaN among the 36 texels
+    return r;
 }
 
 ZR_HD void StoreRGB16F(const TaaFrame& F, uint32_t x, uint32_t y, V3 c)

@@ -89,11 +89,13 @@ void zrh_comm_destroy(zrh_comm* c) { if (c) { if (c->comm) g_rccl.CommDestroy(c-
 
 // peers[i]: the rank to talk to and the rects (global pixels; w == 0: nothing in that direction) it needs from us / we need from it --
 // tiling.halo_plan's rows.  Both sides derive the same sizes from the tile layout, so there is no handshake.
-int zrh_halo_exchange_create(zr_pass* pass, zr_gbuffer* gb, zrh_comm* comm, const zrh_halo_peer* peers, uint32_t n, zrh_halo_exchange** out)
+// bytes_per_pixel: what one exchange of this object moves per pixel; 0 = the pass's own figure (zr_pass_halo_bytes_per_pixel).  A pass with exchanges
+// of different sizes (ZR_PASS_DENOISE: ZR_HALO_DENOISE_INPUT 40 B, ZR_HALO_DENOISE_ITER 16 B) gets one object per size on one communicator.
+int zrh_halo_exchange_create_bpp(zr_pass* pass, zr_gbuffer* gb, zrh_comm* comm, const zrh_halo_peer* peers, uint32_t n, uint32_t bytes_per_pixel, zrh_halo_exchange** out)
 {
     if (!pass || !gb || !comm || !out || (n && !peers)) return FailHalo("zrh_halo_exchange_create: null argument");
-    uint32_t bpp = 0;
-    if (zr_pass_halo_bytes_per_pixel(pass, &bpp) != ZR_OK) return FailHalo(zr_last_error());
+    uint32_t bpp = bytes_per_pixel;
+    if (!bpp && zr_pass_halo_bytes_per_pixel(pass, &bpp) != ZR_OK) return FailHalo(zr_last_error());
     zrh_halo_exchange* x = new zrh_halo_exchange(); x->pass = pass; x->gb = gb; x->comm = comm;
     auto align16 = [](size_t v) { return (v + 15) & ~(size_t)15; };
     for (uint32_t i = 0; i < n; i++)
@@ -112,6 +114,8 @@ int zrh_halo_exchange_create(zr_pass* pass, zr_gbuffer* gb, zrh_comm* comm, cons
     *out = x;
     return 0;
 }
+int zrh_halo_exchange_create(zr_pass* pass, zr_gbuffer* gb, zrh_comm* comm, const zrh_halo_peer* peers, uint32_t n, zrh_halo_exchange** out)
+{ return zrh_halo_exchange_create_bpp(pass, gb, comm, peers, n, 0, out); }
 void zrh_halo_exchange_destroy(zrh_halo_exchange* x) { if (x) { if (x->sendBuf) (void)hipFree(x->sendBuf); if (x->recvBuf) (void)hipFree(x->recvBuf); delete x; } }
 size_t zrh_halo_exchange_send_bytes(const zrh_halo_exchange* x) { return x ? x->sendBytes : 0; }
 

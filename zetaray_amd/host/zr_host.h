@@ -39,6 +39,8 @@ int zrh_rccl_unique_id(uint8_t* out128);
 int zrh_comm_create(int device, int world, int rank, const uint8_t* id128, zrh_comm** out);
 void zrh_comm_destroy(zrh_comm* c);
 int zrh_halo_exchange_create(zr_pass* pass, zr_gbuffer* gb, zrh_comm* comm, const zrh_halo_peer* peers, uint32_t n, zrh_halo_exchange** out);
+/* the same with an explicit size per pixel (0 = the pass's own): ZR_PASS_DENOISE moves 40 B (ZR_HALO_DENOISE_INPUT) or 16 B (ZR_HALO_DENOISE_ITER) */
+int zrh_halo_exchange_create_bpp(zr_pass* pass, zr_gbuffer* gb, zrh_comm* comm, const zrh_halo_peer* peers, uint32_t n, uint32_t bytes_per_pixel, zrh_halo_exchange** out);
 void zrh_halo_exchange_destroy(zrh_halo_exchange* x);
 size_t zrh_halo_exchange_send_bytes(const zrh_halo_exchange* x);
 int zrh_halo_exchange_run(zrh_halo_exchange* x, void* hip_stream, int which);

@@ -130,6 +130,29 @@ def halo_plan(w, h, n, rank, apron=APRON, layout=None):
     return plan
 
 
+def denoise_schedule(iterations, apron=APRON):
+    """The denoise pass (ZR_PASS_DENOISE) on a tile + apron: which steps run between which halo exchanges so that every OWNED pixel equals the full
+    frame's.  A step computed on the window is exact `reach` pixels inside what its inputs were exact on: the variance stage reads 3 px around a
+    pixel, a-trous iteration i reads 2 * 2^i px (zr_svgf.h).  After an exchange the exchanged plane is exact on the whole apron again (its owners
+    computed it).  Returns [("exchange", which) | ("steps", mask), ...]; for the default 5 iterations: exchange INPUT (signal + history), temporal +
+    variance + a-trous 0..2 (32 - 3 - 2 - 4 - 8 = 15 px left), exchange ITER, a-trous 3 (16 px), exchange ITER, a-trous 4 (32 px)."""
+    from . import api
+    sched, steps = [("exchange", api.HALO_DENOISE_INPUT)], api.STAGE_DENOISE_TEMPORAL | api.STAGE_DENOISE_VARIANCE
+    margin = apron - 3
+    assert margin >= 0
+    for i in range(iterations):
+        need = 2 << i
+        if need > apron:
+            raise ValueError(f"denoise on tiles: a-trous iteration {i} reaches {need} px, beyond the {apron}-px apron (at most {apron.bit_length() - 1} iterations)")
+        if margin < need:
+            sched += [("steps", steps), ("exchange", api.HALO_DENOISE_ITER)]
+            steps, margin = 0, apron
+        steps |= api.stage_denoise_atrous(i)
+        margin -= need
+    sched.append(("steps", steps))
+    return sched
+
+
 def frame_reads_history_across_tiles(kind, cb, scene_changed, instances_in_motion=False):
     """Can this frame's temporal stage read a previous-frame reservoir that belongs to another tile?  ReSTIR PT reads exactly the reprojected
     pixel (FindTemporal), so with an unmoved camera (same view, same jitter), an unchanged scene AND a G-buffer whose motion vectors are all
@@ -207,28 +230,75 @@ class TiledRestirPT:
             else:
                 self.transport = "torch_p2p"
 
+    def _xfer(self, which):
+        """(pass, bytes per pixel) of an exchange: the reservoir exchanges belong to the halo pass, the ZR_HALO_DENOISE_* ones to the denoise pass"""
+        api = self.api
+        if which == api.HALO_DENOISE_INPUT:
+            return self.p_denoise, 40
+        if which == api.HALO_DENOISE_ITER:
+            return self.p_denoise, 16
+        return self.hp, self.bpp
+
     def pack(self, which):
         """stage 1 of an exchange: copy my border strips into the per-peer send buffers (device-to-device, on the stream)"""
+        hp, bpp = self._xfer(which)
         for peer, send, recv in self.plan:
             if send:
                 sb = self.bufs[peer][0]
-                self.hp.halo_pack(self.r.gbuffer, which, send, sb.data_ptr(), sb.numel())
+                hp.halo_pack(self.r.gbuffer, which, send, sb.data_ptr(), send[2] * send[3] * bpp)
 
     def unpack(self, which):
         """stage 3: scatter the received strips into my apron"""
+        hp, bpp = self._xfer(which)
         for peer, send, recv in self.plan:
             if recv:
                 rb = self.bufs[peer][1]
-                self.hp.halo_unpack(self.r.gbuffer, which, recv, rb.data_ptr(), rb.numel())
+                hp.halo_unpack(self.r.gbuffer, which, recv, rb.data_ptr(), recv[2] * recv[3] * bpp)
+
+    def enable_denoise(self, params=None):
+        """add the denoise pass on this tile: planes = tile + apron, steps and halo exchanges by denoise_schedule (every owned pixel == the full
+        frame's); read the result with denoised_tile()"""
+        from . import wire
+        prm = params if params is not None else wire.default_params()
+        self.p_denoise = self.r.enable_denoise(prm)
+        self.r.p_denoise = None          # (Renderer.render_frame must not run it in one go: render_frame below drives the schedule)
+        self._dn_sched = denoise_schedule(int(prm.svgf_iterations)) if self.world > 1 else [("steps", self.api.STAGE_DENOISE_MASK)]
+        if self.native is not None:
+            self.native_dn = {self.api.HALO_DENOISE_INPUT: NativeHalo(self.p_denoise, self.r.gbuffer, self.device.index, self.world, self.rank, self.plan, comm_of=self.native, bpp=40),
+                              self.api.HALO_DENOISE_ITER: NativeHalo(self.p_denoise, self.r.gbuffer, self.device.index, self.world, self.rank, self.plan, comm_of=self.native, bpp=16)}
+        return self.p_denoise
+
+    def denoise(self, cb, exchange=None):
+        """the denoise pass of this frame on the tile (after stage_spatial); exchange(which): how the halos move (default: this object's transport)"""
+        api = self.api
+        self.p_denoise.set_input(api.IN_DENOISE_SIGNAL, self.r.p_indirect.output_ptr()[0])
+        for kind, v in self._dn_sched:
+            if kind == "exchange":
+                (exchange or self.exchange)(v)
+            elif v:
+                self.p_denoise.render_stage(cb, self.r.scene, self.r.gbuffer, v)
+
+    def denoise_steps(self, cb, steps):
+        """one group of steps of the schedule (tile objects sharing a process: tiling.render_frame_in_process)"""
+        self.p_denoise.set_input(self.api.IN_DENOISE_SIGNAL, self.r.p_indirect.output_ptr()[0])
+        if steps:
+            self.p_denoise.render_stage(cb, self.r.scene, self.r.gbuffer, steps)
+
+    def denoised_tile(self):
+        full = self.p_denoise.download_plane("denoised")
+        x0, y0, tw, th = self.tile
+        ex0, ey0 = self.ext[0], self.ext[1]
+        return self.tile, full[y0 - ey0:y0 - ey0 + th, x0 - ex0:x0 - ex0 + tw].copy()
 
     def exchange(self, which):
         if not self.plan:
             return
         self.exchanges_done += 1
         if self.native is not None:
-            self.native.run(which)
+            (self.native_dn[which] if which in getattr(self, "native_dn", {}) else self.native).run(which)
             return
         dist = self.dist
+        hp, bpp = self._xfer(which)
         self.pack(which)
         if dist.get_backend() == "gloo":
             # test rig (bench.py with ZR_BENCH_SHARED_GPU=1: several ranks on one device, no RCCL between them): strips staged through the host
@@ -237,24 +307,24 @@ class TiledRestirPT:
             for peer, send, recv in self.plan:
                 sb, rb = self.bufs[peer]
                 if send:
-                    reqs.append(dist.isend(sb.cpu(), peer))
+                    reqs.append(dist.isend(sb[:send[2] * send[3] * bpp].cpu(), peer))
                 if recv:
-                    hb = self.torch.empty(rb.numel(), dtype=self.torch.uint8)
+                    hb = self.torch.empty(recv[2] * recv[3] * bpp, dtype=self.torch.uint8)
                     reqs.append(dist.irecv(hb, peer))
                     landed.append((rb, hb))
             for req in reqs:
                 req.wait()
             for rb, hb in landed:
-                rb.copy_(hb)
+                rb[:hb.numel()].copy_(hb)
             self.unpack(which)
             return
         ops = []
         for peer, send, recv in self.plan:
             sb, rb = self.bufs[peer]
             if send:
-                ops.append(dist.P2POp(dist.isend, sb, peer))
+                ops.append(dist.P2POp(dist.isend, sb[:send[2] * send[3] * bpp], peer))
             if recv:
-                ops.append(dist.P2POp(dist.irecv, rb, peer))
+                ops.append(dist.P2POp(dist.irecv, rb[:recv[2] * recv[3] * bpp], peer))
         for req in dist.batch_isend_irecv(ops):
             req.wait()
         self.unpack(which)
@@ -296,6 +366,8 @@ class TiledRestirPT:
         if post:
             self.exchange(self.api.HALO_POST_TEMPORAL)
         self.stage_spatial(cb)
+        if getattr(self, "p_denoise", None) is not None:
+            self.denoise(cb)
         self._frames_rendered += 1
         self._scene_version_seen = self.r.scene.version
 
@@ -323,7 +395,9 @@ class NativeHalo:
     """ctypes face of the C++ halo exchange (zetaray_amd/host/zr_halo.cpp).  The RCCL unique id is created on rank 0 and handed to the other
     ranks through the process group that launched them (a 128-byte broadcast); world == 1 talks to itself (transport self-test)."""
 
-    def __init__(self, halo_pass, gbuffer, device, world, rank, plan, dist=None, unique_id=None):
+    def __init__(self, halo_pass, gbuffer, device, world, rank, plan, dist=None, unique_id=None, comm_of=None, bpp=0):
+        """comm_of: another NativeHalo whose communicator this object shares (creating one is collective); bpp: bytes per pixel of this object's
+        exchanges when they differ from the pass's own figure (the denoise pass's two exchanges)"""
         import ctypes as C
         import os
         self.C = C
@@ -331,14 +405,17 @@ class NativeHalo:
         L.zrh_halo_last_error.restype = C.c_char_p
         L.zrh_comm_create.argtypes = [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
         L.zrh_comm_destroy.argtypes = [C.c_void_p]
-        L.zrh_halo_exchange_create.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]
+        L.zrh_halo_exchange_create_bpp.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]
         L.zrh_halo_exchange_destroy.argtypes = [C.c_void_p]
         L.zrh_halo_exchange_send_bytes.restype = C.c_size_t
         L.zrh_halo_exchange_send_bytes.argtypes = [C.c_void_p]
         L.zrh_halo_exchange_run.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
         self.L = L
+        self.owns_comm = comm_of is None
         idbuf = (C.c_uint8 * 128)()
-        if unique_id is not None:
+        if comm_of is not None:
+            pass
+        elif unique_id is not None:
             C.memmove(idbuf, bytes(unique_id), 128)
         else:
             ok = 1
@@ -354,8 +431,11 @@ class NativeHalo:
                 C.memmove(idbuf, raw[1:], 128)
             if not ok:
                 raise RuntimeError("halo exchange: " + (L.zrh_halo_last_error().decode() if rank == 0 else "rank 0 could not create the RCCL unique id"))
-        self.comm = C.c_void_p()
-        self._check(L.zrh_comm_create(device, world, rank, idbuf, C.byref(self.comm)))
+        if comm_of is not None:
+            self.comm = comm_of.comm
+        else:
+            self.comm = C.c_void_p()
+            self._check(L.zrh_comm_create(device, world, rank, idbuf, C.byref(self.comm)))
 
         class Peer(C.Structure):
             _fields_ = [("peer", C.c_int)] + [(n, C.c_uint32) for n in ("send_x0", "send_y0", "send_w", "send_h", "recv_x0", "recv_y0", "recv_w", "recv_h")]
@@ -364,7 +444,7 @@ class NativeHalo:
             s, r = send or (0, 0, 0, 0), recv or (0, 0, 0, 0)
             arr[i] = Peer(peer, s[0], s[1], s[2], s[3], r[0], r[1], r[2], r[3])
         self.x = C.c_void_p()
-        self._check(L.zrh_halo_exchange_create(halo_pass.h, gbuffer.h, self.comm, arr, len(plan), C.byref(self.x)))
+        self._check(L.zrh_halo_exchange_create_bpp(halo_pass.h, gbuffer.h, self.comm, arr, len(plan), int(bpp), C.byref(self.x)))
         self.send_bytes = int(L.zrh_halo_exchange_send_bytes(self.x))
 
     def _check(self, rc):
@@ -378,9 +458,9 @@ class NativeHalo:
         if self.x:
             self.L.zrh_halo_exchange_destroy(self.x)
             self.x = self.C.c_void_p()
-        if self.comm:
+        if self.comm and self.owns_comm:
             self.L.zrh_comm_destroy(self.comm)
-            self.comm = self.C.c_void_p()
+        self.comm = self.C.c_void_p()
 
 
 def render_frame_in_process(ranks, cb, exchange_final=True):
@@ -397,6 +477,16 @@ def render_frame_in_process(ranks, cb, exchange_final=True):
         exchange_in_process(ranks, api.HALO_POST_TEMPORAL); n += 1
     for r in ranks:
         r.stage_spatial(cb)
+    if getattr(ranks[0], "p_denoise", None) is not None:
+        # every tile runs the same schedule: the steps between two exchanges on every tile, then the exchange among them
+        for k, (kind, v) in enumerate(ranks[0]._dn_sched):
+            if kind == "exchange":
+                if len(ranks) > 1:
+                    exchange_in_process(ranks, v); n += 1
+            else:
+                for r in ranks:
+                    r.denoise_steps(cb, v)
+    for r in ranks:
         r._frames_rendered += 1
         r._scene_version_seen = r.r.scene.version
     return n
@@ -410,6 +500,6 @@ def exchange_in_process(ranks, which):
     for r in ranks:
         for peer, send, recv in r.plan:
             if recv:
-                r.bufs[peer][1].copy_(ranks[peer].bufs[r.rank][0])
+                r.bufs[peer][1].copy_(ranks[peer].bufs[r.rank][0])      # (whole buffers: the exchange's bytes are their head)
     for r in ranks:
         r.unpack(which)
