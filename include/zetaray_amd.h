@@ -291,6 +291,13 @@ int zr_scene_update_emissives(zr_scene* scene, const zr_emissive_triangle* trian
  * forms are `_async` on the null stream followed by hipDeviceSynchronize().  (ZR_SCENE_UPDATE=rebuild, the host BVH rebuild, stays
  * host-synchronous by construction.) */
 int zr_scene_update_instances_async(zr_scene* scene, void* hip_stream, const zr_mesh_instance* instances, const float* instance_to_world, uint32_t n);
+/* Background SAH rebuild for dynamic scenes (the reference rebuilds its TLAS every frame, RtAccelerationStructure.cpp:708-789; this library refits one
+   world-space tree, whose topology ages as instances move).  Enabled: an update that finds no build in flight snapshots the new transforms and starts
+   the host's SAH builder on a thread; the first update after it has finished uploads the new topology into the buffer set that becomes current and
+   refits it to that update's transforms -- stream-ordered, no render waits, results never depend on the tree.  stats: builds started / installed,
+   building = 0 idle, 1 building, 2 built and waiting for the next update.  ZR_SCENE_UPDATE=refit_sah turns it on for every scene of the process. */
+int zr_scene_set_background_rebuild(zr_scene* scene, int enable);
+int zr_scene_background_rebuild_stats(zr_scene* scene, uint64_t* started, uint64_t* installed, int* building);
 int zr_scene_update_emissives_async(zr_scene* scene, void* hip_stream, const zr_emissive_triangle* triangles, uint32_t first, uint32_t count);
 int zr_scene_update_materials_async(zr_scene* scene, void* hip_stream, const zr_material* materials, uint32_t first, uint32_t count);
 int zr_scene_set_alias_table_async(zr_scene* scene, void* hip_stream, const zr_alias_entry* entries, uint32_t n);

@@ -902,6 +902,16 @@ static void Render(const float* signal, const float* depthPlane, const uint32_t*
 extern "C" {
 
 struct zro_scene { Scene s; std::unique_ptr<Scene> prevHolder; };
+// ray counters of one pass render: queries against the CURRENT structure are tallied on the scene, queries against the PREVIOUS one (the CtT replay /
+// reconnect passes of ReSTIR PT and the temporal shifts of the DI passes, once instances have moved) on the previous scene object -- a frame's total
+// is their sum (round 4: the second term used to be dropped, which only showed in dynamic frames, where no test compared counters)
+static void ResetCounters(const zro_scene* h) { h->s.counters = Counters(); if (h->prevHolder) h->prevHolder->counters = Counters(); }
+static void ReadCounters(const zro_scene* h, zr_counters* c)
+{
+    if (!c) return;
+    c->n_closest = h->s.counters.n_closest; c->n_shadow = h->s.counters.n_shadow;
+    if (h->prevHolder) { c->n_closest += h->prevHolder->counters.n_closest; c->n_shadow += h->prevHolder->counters.n_shadow; }
+}
 
 zro_scene* zro_scene_create(const zr_scene_desc* d, int force_bvh)
 {
@@ -971,9 +981,9 @@ int zro_gbuffer_render(const zro_scene* h, const zr_frame_constants* cb, zr_gbuf
 int zro_pathtrace_render(const zro_scene* h, const zr_frame_constants* cb, const zr_gbuffer_planes* planes,
     const zr_params* prm, float* final_rgba, zr_counters* counters)
 {
-    h->s.counters = Counters(); h->s.LatchHeapOffsets(*cb); h->s.texFilter = prm->tex_filter;
+    ResetCounters(h); h->s.LatchHeapOffsets(*cb); h->s.texFilter = prm->tex_filter;
     RenderPathTracer(h->s, *cb, GBView(planes), *prm, final_rgba);
-    if (counters) { counters->n_closest = h->s.counters.n_closest; counters->n_shadow = h->s.counters.n_shadow; }
+    ReadCounters(h, counters);
     return 0;
 }
 
@@ -1166,9 +1176,9 @@ void zro_rpt_reset_temporal(zro_rpt* r) { r->st.temporalValid = false; }
 int zro_rpt_render(const zro_scene* h, zro_rpt* r, const zr_frame_constants* cb, const zr_gbuffer_planes* curr,
     const zr_gbuffer_planes* prev, const zr_params* prm, float* final_rgba, zr_counters* counters)
 {
-    h->s.counters = Counters(); h->s.LatchHeapOffsets(*cb); h->s.texFilter = prm->tex_filter;
+    ResetCounters(h); h->s.LatchHeapOffsets(*cb); h->s.texFilter = prm->tex_filter;
     RPT::Render(h->s, *cb, curr, prev, *prm, r->st, final_rgba);
-    if (counters) { counters->n_closest = h->s.counters.n_closest; counters->n_shadow = h->s.counters.n_shadow; }
+    ReadCounters(h, counters);
     return 0;
 }
 int zro_rpt_self_shift(const zro_scene* h, zro_rpt* r, const zr_frame_constants* cb, const zr_gbuffer_planes* curr, const zr_params* prm, int which, float* out)
@@ -1204,9 +1214,9 @@ void zro_rdi_reset_temporal(zro_rdi* r) { r->st.temporalValid = false; r->st.cur
 int zro_rdi_render(const zro_scene* h, zro_rdi* r, const zr_frame_constants* cb, const zr_gbuffer_planes* curr, const zr_gbuffer_planes* prev,
     const zr_params* prm, float* final_rgba, zr_counters* counters)
 {
-    h->s.counters = Counters(); h->s.LatchHeapOffsets(*cb);
+    ResetCounters(h); h->s.LatchHeapOffsets(*cb);
     RDI::Render(h->s, *cb, curr, prev, *prm, r->st, final_rgba);
-    if (counters) { counters->n_closest = h->s.counters.n_closest; counters->n_shadow = h->s.counters.n_shadow; }
+    ReadCounters(h, counters);
     return 0;
 }
 // plane 0 = reservoir A (4 x u32), 1 = B (2 x f32) of the set written by the last frame, 2 = target (4 x f32)
@@ -1227,9 +1237,9 @@ void zro_sdi_reset_temporal(zro_sdi* r) { r->st.temporalValid = false; r->st.cur
 int zro_sdi_render(const zro_scene* h, zro_sdi* r, const zr_frame_constants* cb, const zr_gbuffer_planes* curr, const zr_gbuffer_planes* prev,
     const zr_params* prm, float* final_rgba, zr_counters* counters)
 {
-    h->s.counters = Counters(); h->s.LatchHeapOffsets(*cb);
+    ResetCounters(h); h->s.LatchHeapOffsets(*cb);
     SDI::Render(h->s, *cb, curr, prev, *prm, r->st, final_rgba);
-    if (counters) { counters->n_closest = h->s.counters.n_closest; counters->n_shadow = h->s.counters.n_shadow; }
+    ReadCounters(h, counters);
     return 0;
 }
 // plane 0 = A (u8 metadata), 1 = B (2 x u16 oct32), 2 = C (2 x f32: w_sum, W) of the set written by the last frame, 3 = target (4 x f32)
@@ -1251,9 +1261,9 @@ void zro_rgi_reset_temporal(zro_rgi* r) { r->st.temporalValid = false; }
 int zro_rgi_render(const zro_scene* h, zro_rgi* r, const zr_frame_constants* cb, const zr_gbuffer_planes* curr, const zr_gbuffer_planes* prev,
     const zr_params* prm, float* final_rgba, zr_counters* counters)
 {
-    h->s.counters = Counters(); h->s.LatchHeapOffsets(*cb); h->s.texFilter = prm->tex_filter;
+    ResetCounters(h); h->s.LatchHeapOffsets(*cb); h->s.texFilter = prm->tex_filter;
     RGI::Render(h->s, *cb, curr, prev, *prm, r->st, final_rgba);
-    if (counters) { counters->n_closest = h->s.counters.n_closest; counters->n_shadow = h->s.counters.n_shadow; }
+    ReadCounters(h, counters);
     return 0;
 }
 // plane 0 = A (4 x f32: pos, ID bits), 1 = B (4 x f16: Lo, M), 2 = C (4 x f32: w_sum, W, normal oct32 bits, unused) of the last frame's set

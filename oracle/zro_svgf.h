@@ -2,8 +2,8 @@
 //
 // PARITY UNPINNED: the reference has no denoiser, so there is no reference code to follow or to pin against.  The pass is defined by the
 // written specification at the top of zetaray_amd/csrc/zr_svgf.h (after Schied et al., "Spatiotemporal Variance-Guided Filtering", HPG 2017;
-// DEFINITION VERSION 2: compact-support falloff E(x) = max(0, 1 - x / 16)^16, written fused multiply-adds, predicated taps, one reciprocal per
-// pixel, sanitised + clamped signal); this file restates that specification independently of the HIP stage functions -- image-level passes over
+// DEFINITION VERSION 3: compact-support falloff E(x) = max(0, 1 - x / 16)^16, written fused multiply-adds, predicated taps, one reciprocal per
+// pixel, sanitised + clamped signal, fp16 colour / normal in the planes between the stages); this file restates that specification independently of the HIP stage functions -- image-level passes over
 // plain arrays, its own helper structure, full frames only (the product's tile windows are compared against THIS full frame) -- with the same fp32
 // operations in the same order, so the two can be compared bit for bit (tests/test_denoise.py).
 #pragma once
@@ -33,6 +33,9 @@ static inline float E16(float x)
     return t8 * t8;
 }
 static inline int ClampI(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+// h(v): through fp16 (round to nearest even) and back -- the storage format of colour and normal between two filter stages
+static inline float AsHalf(float v) { return zr_f16_to_f32_portable(zr_f32_to_f16_portable(v)); }
+static inline void ColourThroughHalf(float* rgba, size_t n) { for (size_t i = 0; i < n; i++) for (int k = 0; k < 3; k++) rgba[4 * i + k] = AsHalf(rgba[4 * i + k]); }
 
 static inline std::vector<Guide> BuildGuide(const float* depth, const uint32_t* normal, int W, int H)
 {
@@ -43,6 +46,7 @@ static inline std::vector<Guide> BuildGuide(const float* depth, const uint32_t* 
             Guide& o = g[(size_t)y * W + x];
             o.z = depth[(size_t)y * W + x];
             o.n = NormalOf(normal[(size_t)y * W + x]);
+            o.n = f3(AsHalf(o.n.x), AsHalf(o.n.y), AsHalf(o.n.z));      // the guide normal is what an fp16 plane holds
             o.fw = 0.0f;
             if (Miss(o.z)) continue;
             float ddx = 0.0f, ddy = 0.0f;
@@ -73,9 +77,7 @@ static inline bool Usable(const History& h, int W, int H, int qx, int qy, float 
     const size_t j = (size_t)qy * W + qx;
     if (Miss(h.prevDepth[j])) return false;
     if (!(zr_abs(h.prevDepth[j] - z) <= 0.1f * z)) return false;
-    if (!(dot(NormalOf(h.prevNormal[j]), n) >= 0.9f)) return false;
-    for (int k = 0; k < 4; k++) if (!IsFinite(h.color[4 * j + k])) return false;
-    return IsFinite(h.moments[2 * j]) && IsFinite(h.moments[2 * j + 1]);
+    return dot(NormalOf(h.prevNormal[j]), n) >= 0.9f;
 }
 
 // signal RGBA32F; accum RGBA32F (rgb + history length); moments 2 floats per pixel
@@ -88,7 +90,7 @@ static inline void Temporal(const float* signal, const float* depth, const uint3
             const size_t i = (size_t)y * W + x;
             float3 c = f3(signal[4 * i], signal[4 * i + 1], signal[4 * i + 2]);
             if (!IsFinite(c.x) || !IsFinite(c.y) || !IsFinite(c.z)) c = f3(0.0f, 0.0f, 0.0f);
-            else c = f3(zr_min(zr_max(c.x, -1.0e15f), 1.0e15f), zr_min(zr_max(c.y, -1.0e15f), 1.0e15f), zr_min(zr_max(c.z, -1.0e15f), 1.0e15f));
+            else c = f3(zr_min(zr_max(c.x, -60000.0f), 60000.0f), zr_min(zr_max(c.y, -60000.0f), 60000.0f), zr_min(zr_max(c.z, -60000.0f), 60000.0f));
             const float lum = Lum(c);
             float3 out = c; float m1 = lum, m2 = lum * lum, length = 1.0f;
             const float z = depth[i];
@@ -132,7 +134,8 @@ static inline void Temporal(const float* signal, const float* depth, const uint3
                             }
                     }
                 }
-                if (ws > 0.01f)
+                const bool sumsFinite = IsFinite(hc.x) && IsFinite(hc.y) && IsFinite(hc.z) && IsFinite(hl) && IsFinite(h1) && IsFinite(h2);
+                if (ws > 0.01f && sumsFinite)
                 {
                     hc = hc / ws; h1 = h1 / ws; h2 = h2 / ws; hl = hl / ws;
                     length = zr_min(hl + 1.0f, 255.0f);
@@ -252,11 +255,13 @@ static inline void Frame(const float* signal, const float* depth, const uint32_t
     std::memcpy(histMoments, moments.data(), 2 * n * sizeof(float));
     auto feedback = [&](const float* filtered) { for (size_t i = 0; i < n; i++) { histColor[4 * i] = filtered[4 * i]; histColor[4 * i + 1] = filtered[4 * i + 1]; histColor[4 * i + 2] = filtered[4 * i + 2]; histColor[4 * i + 3] = accum[4 * i + 3]; } };
     if (prm.iterations == 0) feedback(a.data());
+    else ColourThroughHalf(a.data(), n);            // a stage's output that another stage reads is stored with fp16 colour; history and the last stage's stay fp32
     float* src = a.data(); float* dst = b.data();
     for (uint32_t it = 0; it < prm.iterations; it++)
     {
         Atrous(src, g, prm, W, H, 1 << it, dst);
         if (it == 0) feedback(dst);
+        if (it + 1 != prm.iterations) ColourThroughHalf(dst, n);
         float* t = src; src = dst; dst = t;
     }
     std::memcpy(out, src, 4 * n * sizeof(float));

@@ -197,7 +197,7 @@ void zhx_taa(const float* signal, const float* depth, const uint32_t* motion, co
 struct HxSvgf
 {
     svgf::Window win;
-    std::vector<F4> hist, accum, guide, ping, pong; std::vector<float> moments[2], fw;
+    std::vector<F4> hist, accum, guide, ping, pong; std::vector<float> moments[2], fw, gz;
     int momIdx = 0; F4* cur = nullptr; const F4* out = nullptr;
 };
 HxSvgf* zhx_svgf_create(int ox, int oy, int pw, int ph, int W, int H)
@@ -206,7 +206,7 @@ HxSvgf* zhx_svgf_create(int ox, int oy, int pw, int ph, int W, int H)
     S->win.ox = ox; S->win.oy = oy; S->win.pw = pw; S->win.ph = ph; S->win.W = W; S->win.H = H;
     const size_t n = (size_t)pw * ph;
     S->hist.assign(n, F4{0, 0, 0, 0}); S->accum.assign(n, F4{0, 0, 0, 0}); S->guide.assign(n, F4{0, 0, 0, 0}); S->ping.assign(n, F4{0, 0, 0, 0}); S->pong.assign(n, F4{0, 0, 0, 0});
-    S->moments[0].assign(2 * n, 0.0f); S->moments[1].assign(2 * n, 0.0f); S->fw.assign(n, 0.0f);
+    S->moments[0].assign(2 * n, 0.0f); S->moments[1].assign(2 * n, 0.0f); S->fw.assign(n, 0.0f); S->gz.assign(n, 0.0f);
     S->cur = S->ping.data(); S->out = S->ping.data();
     return S;
 }
@@ -221,12 +221,12 @@ void zhx_svgf_render(HxSvgf* S, const float* signal, const float* depth, const u
     if (steps & ZR_STAGE_DENOISE_TEMPORAL)
     {
         svgf::SvgfFrame T; T.signal = (const F4*)signal; T.depth = depth; T.normal = normal; T.motion = motion; T.prevDepth = prevDepth; T.prevNormal = prevNormal;
-        T.histColor = S->hist.data(); T.histMoments = S->moments[mi].data(); T.accum = S->accum.data(); T.moments = S->moments[mi ^ 1].data(); T.guide = S->guide.data(); T.guideFw = S->fw.data();
+        T.histColor = S->hist.data(); T.histMoments = S->moments[mi].data(); T.accum = S->accum.data(); T.moments = S->moments[mi ^ 1].data(); T.guide = S->guide.data(); T.guideFw = S->fw.data(); T.guideZ = S->gz.data();
         T.win = w; T.temporalValid = temporalValid ? 1u : 0u; T.prm = sp;
         for (int y = w.oy; y < w.oy + w.ph; y++) for (int x = w.ox; x < w.ox + w.pw; x++) svgf::TemporalPixel(T, x, y);
     }
-    svgf::FilterFrame V; V.src = S->accum.data(); V.moments = S->moments[mi ^ 1].data(); V.guide = S->guide.data(); V.guideFw = S->fw.data(); V.dst = S->ping.data(); V.lenSrc = S->accum.data();
-    V.history = iterations == 0 ? S->hist.data() : nullptr; V.win = w; V.step = 1; V.prm = sp;
+    svgf::FilterFrame V; V.src = S->accum.data(); V.moments = S->moments[mi ^ 1].data(); V.guide = S->guide.data(); V.guideFw = S->fw.data(); V.guideZ = S->gz.data(); V.dst = S->ping.data(); V.lenSrc = S->accum.data();
+    V.history = iterations == 0 ? S->hist.data() : nullptr; V.win = w; V.step = 1; V.prm = sp; V.dstPacked = iterations != 0;
     if (steps & ZR_STAGE_DENOISE_VARIANCE)
     {
         for (int y = w.oy; y < w.oy + w.ph; y++) for (int x = w.ox; x < w.ox + w.pw; x++) svgf::VariancePixel(V, x, y);
@@ -236,11 +236,11 @@ void zhx_svgf_render(HxSvgf* S, const float* signal, const float* depth, const u
     {
         if (!(steps & ZR_STAGE_DENOISE_ATROUS(it))) continue;
         F4* src = S->cur; F4* dst = src == S->ping.data() ? S->pong.data() : S->ping.data();
-        svgf::FilterFrame A = V; A.src = src; A.dst = dst; A.moments = nullptr; A.step = 1u << it; A.history = it == 0 ? S->hist.data() : nullptr;
+        svgf::FilterFrame A = V; A.src = src; A.dst = dst; A.moments = nullptr; A.step = 1u << it; A.history = it == 0 ? S->hist.data() : nullptr; A.dstPacked = it + 1u != iterations;
         // odd iterations through the unrolled form of the stencil, even ones through the row loop: both forms of zr_svgf.h run on the host
         for (int y = w.oy; y < w.oy + w.ph; y++) for (int x = w.ox; x < w.ox + w.pw; x++)
         {
-            svgf::PlaneTaps t; t.src = A.src; t.guide = A.guide; t.win = w;
+            svgf::PlaneTaps t; t.srcP = (const U4*)A.src; t.guideZ = A.guideZ; t.win = w;
             if (normalPowerLog2 == 7u) { if (it & 1u) svgf::AtrousPixelT<7, false>(A, x, y, t); else svgf::AtrousPixelT<7, true>(A, x, y, t); }
             else { if (it & 1u) svgf::AtrousPixelT<-1, false>(A, x, y, t); else svgf::AtrousPixelT<-1, true>(A, x, y, t); }
         }

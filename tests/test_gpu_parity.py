@@ -1255,6 +1255,55 @@ def test_device_refit_of_a_large_dynamic_scene(api):
     assert r.p_indirect.read_counters() is not None
 
 
+def test_background_sah_rebuild_keeps_dynamic_frames_bit_exact(api):
+    """zr_scene_set_background_rebuild: while instances move, the host's SAH builder runs on a thread on a snapshot of the
+    transforms and a later update_instances swaps its tree in -- topology from the snapshot, triangles and boxes refit to the update at hand; the
+    device refit covers every frame in between.  3000-triangle materials scene, three instances' worth of motion over 11 frames, an install every
+    second update (the test waits for the builder so that the schedule is deterministic): G-buffer, ReSTIR PT radiance, reservoir planes and ray
+    counters equal the oracle's every frame -- nothing depends on which tree a frame was traced through."""
+    import time
+    from oracle import zro
+    sc = scene_io.make_synthetic_scene(num_tris=3000, num_emissive=150, seed=11)
+    w, h = 96, 64
+    prm = wire.default_params()
+    r = api.Renderer(sc, w, h, params=prm, integrator=api.INTEGRATOR_RESTIR_PT)
+    r.scene.set_background_rebuild(True)
+    osc = zro.OracleScene(sc, force_bvh=True)
+    opt = zro.OracleRPT(osc, w, h)
+    cand = [i for i in range(1, len(sc.instances)) if sc.instance_mask[i] & wire.SUBGROUP_NON_EMISSIVE]
+    idx = max(cand, key=lambda i: int(sc.instance_num_tris[i]))
+    t0, xf = sc.instances["translation"][idx].copy(), {}
+    prev = None
+    for f in range(1, 12):
+        if f >= 2:
+            ang = 0.12 * (f - 1)
+            q = np.array([0.0, np.sin(ang / 2), 0.0, np.cos(ang / 2)], np.float32)
+            scene_io.move_instance(sc, idx, translation=t0 + np.float32([0.05 * (f - 1), 0.02 * (f - 1), -0.03 * (f - 1)]), rotation=q, xform_of=xf)
+            r.scene.update_instances(sc.instances, sc.instance_to_world)
+            osc.update_instances(sc.instances, sc.instance_to_world)
+            t_wait = time.perf_counter()
+            while r.scene.background_rebuild_stats()[2] == 1 and time.perf_counter() - t_wait < 20.0:
+                time.sleep(0.005)
+        cb = _chain(_frame(sc, w, h, f, cam_pos=(0, 0, -3.5)), prev)
+        prev = cb.copy()
+        r.p_indirect.read_counters(reset=True)
+        r.render_frame(cb)
+        want = opt.render(cb, prm)
+        planes, _ = r.gbuffer.download()
+        oplanes, _ = osc.gbuffer(cb)
+        for n, a, b in zip(wire.GB_PLANE_NAMES, planes, oplanes):
+            assert np.array_equal(np.asarray(a).view(np.uint8).reshape(-1), np.asarray(b).view(np.uint8).reshape(-1)), f"frame {f}: G-buffer plane {n}"
+        assert np.array_equal(r.final().view(np.uint32), want.view(np.uint32)), f"frame {f}"
+        assert r.p_indirect.read_counters() == opt.counters, f"frame {f}: ray counters"
+        for nm in ("A", "B", "C", "D", "E", "F", "G"):
+            a, b = r.p_indirect.download_plane(nm), opt.plane(nm)
+            if nm == "A":
+                a, b = a & 0xffffff, b & 0xffffff
+            assert np.array_equal(a.view(np.uint8), b.view(np.uint8)), f"frame {f}: reservoir plane {nm}"
+    started, installed, _ = r.scene.background_rebuild_stats()
+    assert started >= 3 and installed >= 3, (started, installed)
+
+
 def test_device_built_bvh_traces_identically(api, monkeypatch):
     """ZR_BVH_BUILD=device: the acceleration structure is built on the GPU (LBVH: Morton sort + breadth-first 4-wide topology + per-level boxes,
     zr_tu_bvh.hip).  Query results do not depend on the tree, so 20 000 closest-hit rays against the oracle's own BVH2 and a ReSTIR PT sequence with

@@ -18,7 +18,7 @@ def main():
     t0, xf = sc.instances["translation"][idx].copy(), {}
     import torch
     upd, frames, kern = [], [], {"static": {}, "moving": {}}
-    n_static, n_moving = 24, 16
+    n_static, n_moving = 24, int(os.environ.get("REFIT_MOVING_FRAMES", "16"))
     r.p_gbuffer.enable_timing(True); r.p_indirect.enable_timing(True)
     for f in range(1, n_static + n_moving + 1):
         moving = f > n_static
@@ -38,7 +38,7 @@ def main():
             for name, (ms, launches) in {**r.p_gbuffer.timings(), **r.p_indirect.timings()}.items():
                 kern["moving" if moving else "static"].setdefault(name, []).append(ms)
     kms = {ph: {k: round(float(np.mean(v)), 3) for k, v in d.items() if np.mean(v) > 0.05} for ph, d in kern.items()}
-    print(json.dumps({"mode": os.environ.get("ZR_SCENE_UPDATE", "refit"), "instance": int(idx), "instance_tris": int(sc.instance_num_tris[idx]),
+    print(json.dumps({"mode": os.environ.get("ZR_SCENE_UPDATE", "refit"), "background_rebuilds": list(r.scene.background_rebuild_stats()), "instance": int(idx), "instance_tris": int(sc.instance_num_tris[idx]),
                       "bvh": list(r.scene.bvh_info()), "update_ms": [round(x, 3) for x in upd], "update_ms_median": round(float(np.median(upd)), 3),
                       "frame_ms_static": round(float(np.median(frames[12:n_static])), 3), "frame_ms_moving": round(float(np.median(frames[n_static + 4:])), 3),
                       "kernel_ms_static": kms["static"], "kernel_ms_moving": kms["moving"]}))

@@ -47,6 +47,7 @@ RPT_OUTPUTS = {"A": (1, np.uint32, 1), "B": (2, np.float32, 2), "C": (3, np.uint
 
 EXPORTS = [
     "zr_abi_version", "zr_last_error", "zr_device_count", "zr_wire_layout", "zr_scene_create", "zr_scene_destroy", "zr_scene_update_instances", "zr_scene_update_emissives", "zr_scene_invalidate_alias_table", "zr_scene_update_materials",
+    "zr_scene_set_background_rebuild", "zr_scene_background_rebuild_stats",
     "zr_scene_invalidate_alias_table_deferred", "zr_scene_update_instances_async", "zr_scene_update_emissives_async", "zr_scene_update_materials_async", "zr_scene_set_alias_table_async",
     "zr_scene_set_alias_table", "zr_alias_table_build", "zr_scene_get_alias_table", "zr_scene_get_light_voxel_grid", "zr_scene_get_presampled_sets", "zr_scene_bvh_info", "zr_pass_enable_cost_map", "zr_pass_read_cost_map", "zr_pass_debug_trip_stats",
     "zr_gbuffer_create", "zr_gbuffer_destroy", "zr_gbuffer_set_tile_origin", "zr_gbuffer_download", "zr_gbuffer_device_plane",
@@ -190,6 +191,19 @@ class Scene:
         else:
             L.zr_scene_update_instances_async.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32]
             _check(L.zr_scene_update_instances_async(self.h, stream, i.ctypes.data, x.ctypes.data, len(i)))
+
+    def set_background_rebuild(self, on=True):
+        """dynamic scenes: rebuild the SAH tree on a host thread for the instances' current transforms and swap it in at a later update_instances
+        (zr_scene_set_background_rebuild); the device refit keeps running every frame in between"""
+        lib().zr_scene_set_background_rebuild.argtypes = [C.c_void_p, C.c_int]
+        _check(lib().zr_scene_set_background_rebuild(self.h, int(bool(on))))
+
+    def background_rebuild_stats(self):
+        """(builds started, builds installed, state: 0 idle / 1 building / 2 built, waiting for the next update)"""
+        a, b, st = C.c_uint64(), C.c_uint64(), C.c_int()
+        lib().zr_scene_background_rebuild_stats.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        _check(lib().zr_scene_background_rebuild_stats(self.h, C.byref(a), C.byref(b), C.byref(st)))
+        return a.value, b.value, st.value
 
     def update_emissives(self, triangles, first=0, stream=False):
         """new EmissiveTriangle records for [first, first + len(triangles)) (instances that carry lights moved)"""

@@ -254,17 +254,21 @@ __global__ void __launch_bounds__(256) k_svgf_temporal(svgf::SvgfFrame F) { int 
 template<int POW> __global__ void __launch_bounds__(256) k_svgf_variance(svgf::FilterFrame F) { int x, y; if (SvgfPixel(F.win, &x, &y)) svgf::VariancePixelT<POW>(F, x, y); }
 // ROWLOOP: zr_svgf.h AtrousPixelT -- false = the 24 taps unrolled (held to 128 VGPRs: 4 waves per SIMD), true = a loop over the tap rows (8 waves)
 template<int POW, bool ROWLOOP> __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) k_svgf_atrous(svgf::FilterFrame F)
-{ int x, y; if (SvgfPixel(F.win, &x, &y)) { svgf::PlaneTaps t; t.src = F.src; t.guide = F.guide; t.win = F.win; svgf::AtrousPixelT<POW, ROWLOOP>(F, x, y, t); } }
+{ int x, y; if (SvgfPixel(F.win, &x, &y)) { svgf::PlaneTaps t; t.srcP = (const U4*)F.src; t.guideZ = F.guideZ; t.win = F.win; svgf::AtrousPixelT<POW, ROWLOOP>(F, x, y, t); } }
 // The same iteration with the block's (32 + 4 S) x (8 + 4 S) neighbourhood of both planes staged in LDS first (steps 1 and 2: 13.8 / 20.5 KB per block),
 // so that the 25 taps + the 3 x 3 variance blur are ds_read_b128 instead of cache hits.  Same stage function, same results.  The default for
 // steps 1 and 2 (RenderDenoise).  Tap positions arrive clamped into the planes, which keeps them inside the tile (a clamped position is nearer to the block
 // than the unclamped one).
 struct LdsTaps
 {
-    const ZR_LDS_AS F4* c; const ZR_LDS_AS F4* g; int x0, y0, tw;
+    const ZR_LDS_AS F4* c; const ZR_LDS_AS F4* g; int x0, y0, tw;      // the tile holds the stage texels unpacked: (rgb, variance) and (n, z) in fp32
     __device__ __forceinline__ int RowBase(int y) const { return (y - y0) * tw - x0; }
-    __device__ __forceinline__ F4 Src(int rb, int x) const { const ZR_LDS_AS F4* q = c + rb + x; F4 r; r.x = q->x; r.y = q->y; r.z = q->z; r.w = q->w; return r; }
-    __device__ __forceinline__ F4 Guide(int rb, int x) const { const ZR_LDS_AS F4* q = g + rb + x; F4 r; r.x = q->x; r.y = q->y; r.z = q->z; r.w = q->w; return r; }
+    __device__ __forceinline__ void Load(int rb, int x, F4& gq, F4& q) const
+    {
+        const ZR_LDS_AS F4* a = c + rb + x; const ZR_LDS_AS F4* b = g + rb + x;
+        q.x = a->x; q.y = a->y; q.z = a->z; q.w = a->w; gq.x = b->x; gq.y = b->y; gq.z = b->z; gq.w = b->w;
+    }
+    __device__ __forceinline__ float Var(int rb, int x) const { return (c + rb + x)->w; }
 };
 template<int S, int POW, bool ROWLOOP>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) k_svgf_atrous_lds(svgf::FilterFrame F)
@@ -277,7 +281,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) k
     for (int t = (int)threadIdx.x; t < TW * TH; t += 256)
     {
         const int gx = bx0 + t % TW, gy = by0 + t / TW;
-        if (w.InPlanes(gx, gy)) { const size_t j = w.Idx(gx, gy); sC[t] = F.src[j]; sG[t] = F.guide[j]; }
+        if (w.InPlanes(gx, gy)) { const size_t j = w.Idx(gx, gy); F4 gq, q; svgf::UnpackStage(((const U4*)F.src)[j], F.guideZ[j], gq, q); sC[t] = q; sG[t] = gq; }
     }
     __syncthreads();
     int x, y;
@@ -584,8 +588,21 @@ struct zr_scene
     StageSlot stage[4]; int stageNext = 0;
     hipEvent_t updated = nullptr; hipStream_t updatedOn = nullptr; bool hasUpdate = false;
     std::vector<std::pair<hipStream_t, hipEvent_t>> users;
+    // ---- background SAH rebuild (zr_scene_set_background_rebuild; VERDICT r3 item 9, RtAccelerationStructure.cpp:708-789 rebuilds its TLAS every frame).
+    // The device refit keeps the topology of the last build, and a tree built for where the instances WERE gets worse the further they move.  With this
+    // on, an update that finds no build in flight snapshots the new transforms and starts the host's binned-SAH builder on a thread; the first update
+    // after it has finished uploads the new topology into the buffer set that is about to become current and refits THAT to the transforms of the
+    // update at hand.  No render waits, no result depends on the tree (include/zr_intersect.h's tie-break), the previous structure stays what it was.
+    struct Background
+    {
+        bool enabled = false; std::thread th; std::atomic<int> state{0};      // 0 idle, 1 building, 2 built
+        BuiltBvh bvh; std::vector<uint32_t> levelOrder, levelOffsets;
+        std::vector<zr_mesh_instance> inst; std::vector<float> xf;
+        uint32_t refitsSince = 0; uint64_t started = 0, installed = 0;
+    } bg;
     ~zr_scene()
     {
+        if (bg.th.joinable()) bg.th.join();
         for (StageSlot& t : stage) { if (t.ev) (void)hipEventDestroy(t.ev); if (t.host) (void)hipHostFree(t.host); }
         if (updated) (void)hipEventDestroy(updated);
         for (auto& u : users) (void)hipEventDestroy(u.second);
@@ -809,7 +826,7 @@ struct zr_pass
     DevBuf<F4> giA[2], giC[2]; DevBuf<uint16_t> giB[2];
     bool temporalValid = false, doTemporal = false, doSpatial = false; int currIdx = 0;
     const F4* compIn[4] = {nullptr, nullptr, nullptr, nullptr};     // COMPOSITING inputs (emissive DI, indirect, sky DI); [3] = TAA signal
-    DevBuf<F4> svgfHist, svgfAccum, svgfPing, svgfPong; DevBuf<float> svgfMoments[2], svgfGuideFw; DevBuf<F4> svgfGuide; int svgfMomIdx = 0; const F4* svgfOut = nullptr; F4* svgfCur = nullptr; uint32_t svgfStepsDone = 0;      // DENOISE
+    DevBuf<F4> svgfHist, svgfAccum, svgfPing, svgfPong; DevBuf<float> svgfMoments[2], svgfGuideFw, svgfGuideZ; DevBuf<F4> svgfGuide; int svgfMomIdx = 0; const F4* svgfOut = nullptr; F4* svgfCur = nullptr; uint32_t svgfStepsDone = 0;      // DENOISE
     DevBuf<uint16_t> taaOut[2]; int taaIdx = 0;            // TAA: ping-pong RGBA16F outputs; taaIdx = the one written last
     // AUTO_EXPOSURE / DISPLAY
     const uint16_t* postIn16 = nullptr; const F4* postIn32 = nullptr; const float* exposureIn = nullptr;
@@ -1229,6 +1246,7 @@ int zr_scene_create(int device, const zr_scene_desc* d, zr_scene** out)
         if (d->instances[i].base_color_tex != ZR_INVALID_TEX && (int64_t)d->instances[i].base_color_tex > s->maxTex[0]) s->maxTex[0] = d->instances[i].base_color_tex;
     for (uint32_t i = 0; i < d->num_emissives; i++)
     { const uint32_t t = d->emissives[i].packed_b & 0xffffu; if (t != ZR_INVALID_TEX && (int64_t)t > s->maxTex[3]) s->maxTex[3] = t; }
+    { const char* e = getenv("ZR_SCENE_UPDATE"); s->bg.enabled = e && !strcmp(e, "refit_sah"); }      // (zr_scene_set_background_rebuild for every scene of the process)
     s->hVertices.assign(d->vertices, d->vertices + d->num_vertices); s->hIndices.assign(d->indices, d->indices + d->num_indices);
     s->hMask.assign(d->instance_mask, d->instance_mask + d->num_instances); s->hNumTris.assign(d->instance_num_tris, d->instance_num_tris + d->num_instances);
     BvhLevels(bvh.nodes4, s->hLevelOrder, s->levelOffsets);
@@ -1397,6 +1415,33 @@ int zr_scene_update_instances_async(zr_scene* s, void* stream, const zr_mesh_ins
         return ZR_OK;
     }
     // ---- refit on the device, stream-ordered: nothing below waits on the host (the staging ring aside, when the host runs far ahead)
+    // background SAH rebuild: is a finished tree waiting to be installed by this update?
+    const bool install = s->bg.enabled && s->bg.state.load(std::memory_order_acquire) == 2 && s->bg.inst.size() == n &&
+                         s->bg.bvh.tris.size() == s->view.numTris && s->bg.bvh.stackNeed + 1 <= (uint32_t)kTravStack;
+    if (s->bg.enabled && s->bg.state.load(std::memory_order_acquire) == 2 && !install)
+    {   // a tree that cannot be used (the scene changed shape under it, or it is too deep for the traversal stack): drop it
+        if (s->bg.th.joinable()) s->bg.th.join();
+        s->bg.state.store(0);
+    }
+    if (install && s->bg.th.joinable()) s->bg.th.join();
+    if (s->bg.enabled)
+    {   // both buffer sets must be able to hold any topology over these triangles (a BVH4 over nt triangles has < nt nodes): grown once, with their contents
+        const size_t cap = s->view.numTris;
+        if (s->nodes.n < cap || (s->refitReady && s->nodesPrev.n < cap) || s->levelNodes.n < cap || s->nodeBounds.n < 6 * cap)
+        {
+            HIP_TRY(hipDeviceSynchronize());
+            auto grow = [&](auto& buf, size_t count, size_t keep) -> int {
+                if (buf.n >= count) return ZR_OK;
+                std::remove_reference_t<decltype(buf)> nb; int rr = nb.Alloc(count); if (rr) return rr;
+                if (keep && buf.p) HIP_TRY(hipMemcpy(nb.p, buf.p, keep * sizeof(*buf.p), hipMemcpyDeviceToDevice));
+                std::swap(buf.p, nb.p); std::swap(buf.n, nb.n);
+                return ZR_OK; };
+            std::lock_guard<std::mutex> lockGrow(s->mtx);
+            if ((r = grow(s->nodes, cap, s->view.numNodes)) || (s->nodesPrev.p && (r = grow(s->nodesPrev, cap, s->refitReady || s->hasPrev ? s->numNodesPrev : 0))) ||
+                (r = grow(s->levelNodes, cap, s->hLevelOrder.size())) || (r = grow(s->nodeBounds, 6 * cap, 0))) return r;
+            s->view.nodes = s->nodes.p;
+        }
+    }
     const size_t nn = s->view.numNodes, nt = s->view.numTris;
     const size_t instBytes = (size_t)n * sizeof(zr_mesh_instance), xfBytes = 12 * (size_t)n * sizeof(float);
     zr_scene::StageSlot* t;
@@ -1406,9 +1451,11 @@ int zr_scene_update_instances_async(zr_scene* s, void* stream, const zr_mesh_ins
     std::lock_guard<std::mutex> lock(s->mtx);
     if (!s->refitReady)
     {
-        // both buffer sets must hold the same tree: duplicate the current one (once, or after a host rebuild)
-        if ((r = s->instancesPrev.Alloc(n)) || (nn && (r = s->nodesPrev.Alloc(nn))) || (r = s->trisPrev.Alloc(nt)) || (r = s->metaPrev.Alloc(s->meta.n)) ||
-            (nn && (r = s->nodeBounds.Alloc(6 * nn))) || (r = s->toWorld.Alloc(12 * (size_t)n))) return r;
+        // both buffer sets must hold the same tree: duplicate the current one (once, or after a rebuild)
+        const size_t nodeCap = s->bg.enabled ? std::max(nn, nt) : nn;
+        if ((s->instancesPrev.n != n && (r = s->instancesPrev.Alloc(n))) || (nodeCap && s->nodesPrev.n < nodeCap && (r = s->nodesPrev.Alloc(nodeCap))) ||
+            (s->trisPrev.n != nt && (r = s->trisPrev.Alloc(nt))) || (s->metaPrev.n != s->meta.n && (r = s->metaPrev.Alloc(s->meta.n))) ||
+            (nodeCap && s->nodeBounds.n < 6 * nodeCap && (r = s->nodeBounds.Alloc(6 * nodeCap))) || (s->toWorld.n != 12 * (size_t)n && (r = s->toWorld.Alloc(12 * (size_t)n)))) return r;
         HIP_TRY(hipMemcpyAsync(s->instancesPrev.p, s->instances.p, instBytes, hipMemcpyDeviceToDevice, st));
         if (nn) HIP_TRY(hipMemcpyAsync(s->nodesPrev.p, s->nodes.p, nn * sizeof(Bvh4Node), hipMemcpyDeviceToDevice, st));
         HIP_TRY(hipMemcpyAsync(s->trisPrev.p, s->tris.p, nt * sizeof(BvhTri), hipMemcpyDeviceToDevice, st));
@@ -1420,6 +1467,31 @@ int zr_scene_update_instances_async(zr_scene* s, void* stream, const zr_mesh_ins
     HIP_TRY(hipMemcpyAsync(s->instances.p, t->host, instBytes, hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemcpyAsync(s->toWorld.p, (char*)t->host + instBytes, xfBytes, hipMemcpyHostToDevice, st));
     if ((r = StageCommit(t, st))) return r;
+    uint32_t numNodesNow = (uint32_t)nn;
+    if (install)
+    {
+        // the background build's topology goes into the set that has just become current (last frame's "previous": nobody needs it any more);
+        // its triangles and boxes are then computed for THIS update's transforms by the refit kernels below, like any other frame's
+        zr_scene::Background& B = s->bg;
+        // (the triangle array carries the tree's leaf order: BvhTri::gidx names the scene triangle a slot holds, and k_refit_tris re-transforms slot i
+        // from meta[gidx] -- meta itself is in scene order and does not change)
+        const size_t nodeBytes = B.bvh.nodes4.size() * sizeof(Bvh4Node), triBytes = B.bvh.tris.size() * sizeof(BvhTri), lvlBytes = B.levelOrder.size() * sizeof(uint32_t);
+        zr_scene::StageSlot* tb;
+        if ((r = StageAcquire(s, nodeBytes + triBytes + lvlBytes, &tb))) return r;
+        memcpy(tb->host, B.bvh.nodes4.data(), nodeBytes); memcpy((char*)tb->host + nodeBytes, B.bvh.tris.data(), triBytes); memcpy((char*)tb->host + nodeBytes + triBytes, B.levelOrder.data(), lvlBytes);
+        HIP_TRY(hipMemcpyAsync(s->nodes.p, tb->host, nodeBytes, hipMemcpyHostToDevice, st));
+        HIP_TRY(hipMemcpyAsync(s->tris.p, (char*)tb->host + nodeBytes, triBytes, hipMemcpyHostToDevice, st));
+        HIP_TRY(hipMemcpyAsync(s->levelNodes.p, (char*)tb->host + nodeBytes + triBytes, lvlBytes, hipMemcpyHostToDevice, st));
+        if ((r = StageCommit(tb, st))) return r;
+        s->hLevelOrder = B.levelOrder; s->levelOffsets = B.levelOffsets;
+        numNodesNow = (uint32_t)B.bvh.nodes4.size();
+        if (B.bvh.maxDepth > s->maxDepth) s->maxDepth = B.bvh.maxDepth;
+        s->refitReady = false;      // the two sets hold different topologies now: the next update duplicates this one first
+        s->deviceBuilt = false;
+        B.installed++; B.refitsSince = 0;
+        B.bvh = BuiltBvh(); B.state.store(0, std::memory_order_release);
+    }
+    else if (s->bg.enabled) s->bg.refitsSince++;
     hipLaunchKernelGGL(k_refit_tris, dim3((uint32_t)((nt + 255) / 256)), dim3(256), 0, st, s->tris.p, (uint32_t)nt, s->meta.p, s->instances.p, s->toWorld.p, s->vertices.p, s->indices.p);
     for (size_t l = 0; l + 1 < s->levelOffsets.size(); l++)
     {
@@ -1428,10 +1500,45 @@ int zr_scene_update_instances_async(zr_scene* s, void* stream, const zr_mesh_ins
     }
     HIP_TRY(hipGetLastError());
     SceneView& v = s->view;
-    v.instances = s->instances.p; v.nodes = s->nodes.p; v.tris = s->tris.p; v.triMeta = s->meta.p;
+    v.instances = s->instances.p; v.nodes = s->nodes.p; v.tris = s->tris.p; v.triMeta = s->meta.p; v.numNodes = numNodesNow;
     if (!s->updated) HIP_TRY(hipEventCreateWithFlags(&s->updated, hipEventDisableTiming));
     HIP_TRY(hipEventRecord(s->updated, st));
     s->updatedOn = st; s->hasUpdate = true;
+    if (s->bg.enabled && s->bg.state.load(std::memory_order_acquire) == 0 && s->bg.refitsSince >= 1 && s->meta.n > BvhBuilder::kTinyScene)
+    {
+        // start the next build on these transforms (host copies: the caller's arrays are only valid during the call)
+        zr_scene::Background& B = s->bg;
+        if (B.th.joinable()) B.th.join();
+        B.inst.assign(instances, instances + n); B.xf.assign(instance_to_world, instance_to_world + 12 * (size_t)n);
+        B.state.store(1, std::memory_order_release); B.started++;
+        zr_scene* sp = s;
+        B.th = std::thread([sp] {
+            zr_scene::Background& Q = sp->bg;
+            zr_scene_desc d; memset(&d, 0, sizeof(d));
+            d.vertices = sp->hVertices.data(); d.num_vertices = (uint32_t)sp->hVertices.size(); d.indices = sp->hIndices.data(); d.num_indices = (uint32_t)sp->hIndices.size();
+            d.instances = Q.inst.data(); d.num_instances = (uint32_t)Q.inst.size(); d.instance_to_world = Q.xf.data(); d.instance_mask = sp->hMask.data(); d.instance_num_tris = sp->hNumTris.data();
+            BvhBuilder builder;
+            Q.bvh = builder.Build(d);
+            BvhLevels(Q.bvh.nodes4, Q.levelOrder, Q.levelOffsets);
+            Q.state.store(2, std::memory_order_release);
+        });
+    }
+    return ZR_OK;
+}
+// A tree built for where the instances are NOW, in the background, swapped in by a later zr_scene_update_instances(_async) (see zr_scene::Background).
+int zr_scene_set_background_rebuild(zr_scene* s, int enable)
+{
+    if (!s) return Fail(ZR_ERR_INVALID_ARG, "zr_scene_set_background_rebuild: null scene");
+    std::lock_guard<std::mutex> lock(s->mtx);
+    s->bg.enabled = enable != 0;
+    return ZR_OK;
+}
+int zr_scene_background_rebuild_stats(zr_scene* s, uint64_t* started, uint64_t* installed, int* building)
+{
+    if (!s) return Fail(ZR_ERR_INVALID_ARG, "zr_scene_background_rebuild_stats: null scene");
+    if (started) *started = s->bg.started;
+    if (installed) *installed = s->bg.installed;
+    if (building) *building = s->bg.state.load(std::memory_order_acquire);
     return ZR_OK;
 }
 // host-synchronous form: the update on the null stream, then wait for the copies and the refit kernels (their errors surface here)
@@ -1658,7 +1765,7 @@ static int AllocPass(zr_pass* p)
     if (p->kind == ZR_PASS_DENOISE)
     {
         const size_t n = (size_t)p->w * p->h;
-        if ((r = p->svgfHist.Alloc(n)) || (r = p->svgfAccum.Alloc(n)) || (r = p->svgfPing.Alloc(n)) || (r = p->svgfPong.Alloc(n)) || (r = p->svgfGuide.Alloc(n)) || (r = p->svgfGuideFw.Alloc(n))) return r;
+        if ((r = p->svgfHist.Alloc(n)) || (r = p->svgfAccum.Alloc(n)) || (r = p->svgfPing.Alloc(n)) || (r = p->svgfPong.Alloc(n)) || (r = p->svgfGuide.Alloc(n)) || (r = p->svgfGuideFw.Alloc(n)) || (r = p->svgfGuideZ.Alloc(n))) return r;
         for (int k = 0; k < 2; k++) { if ((r = p->svgfMoments[k].Alloc(2 * n))) return r; HIP_TRY(hipMemset(p->svgfMoments[k].p, 0, 2 * n * sizeof(float))); }
         HIP_TRY(hipMemset(p->svgfHist.p, 0, n * sizeof(F4))); HIP_TRY(hipMemset(p->svgfPing.p, 0, n * sizeof(F4))); HIP_TRY(hipMemset(p->svgfPong.p, 0, n * sizeof(F4)));
         p->svgfMomIdx = 0; p->svgfOut = p->svgfPing.p; p->svgfCur = p->svgfPing.p; p->temporalValid = false;
@@ -2443,7 +2550,7 @@ static int RenderDenoise(zr_pass* p, hipStream_t s, const zr_frame_constants* cb
     {
         svgf::SvgfFrame T;
         T.signal = p->compIn[3]; T.depth = cur.depth; T.normal = cur.normal; T.motion = cur.motion; T.prevDepth = prev.depth; T.prevNormal = prev.normal;
-        T.histColor = p->svgfHist.p; T.histMoments = p->svgfMoments[mi].p; T.accum = p->svgfAccum.p; T.moments = p->svgfMoments[mi ^ 1].p; T.guide = p->svgfGuide.p; T.guideFw = p->svgfGuideFw.p;
+        T.histColor = p->svgfHist.p; T.histMoments = p->svgfMoments[mi].p; T.accum = p->svgfAccum.p; T.moments = p->svgfMoments[mi ^ 1].p; T.guide = p->svgfGuide.p; T.guideFw = p->svgfGuideFw.p; T.guideZ = p->svgfGuideZ.p;
         T.win = win; T.temporalValid = (p->temporalValid && gb->numRendered >= 2) ? 1u : 0u; T.prm = sp;
         TimerBegin(p, s, "denoise_temporal");
         hipLaunchKernelGGL(k_svgf_temporal, grid, block, 0, s, T);
@@ -2451,8 +2558,9 @@ static int RenderDenoise(zr_pass* p, hipStream_t s, const zr_frame_constants* cb
         p->svgfStepsDone = 0;
     }
     svgf::FilterFrame V;
-    V.src = p->svgfAccum.p; V.moments = p->svgfMoments[mi ^ 1].p; V.guide = p->svgfGuide.p; V.guideFw = p->svgfGuideFw.p; V.dst = p->svgfPing.p; V.lenSrc = p->svgfAccum.p;
+    V.src = p->svgfAccum.p; V.moments = p->svgfMoments[mi ^ 1].p; V.guide = p->svgfGuide.p; V.guideFw = p->svgfGuideFw.p; V.guideZ = p->svgfGuideZ.p; V.dst = p->svgfPing.p; V.lenSrc = p->svgfAccum.p;
     V.history = sp.iterations == 0 ? p->svgfHist.p : nullptr; V.win = win; V.step = 1; V.prm = sp;
+    V.dstPacked = sp.iterations != 0;      // the planes between two stages hold fp16 colour + normal (zr_svgf.h PackStage); the pass's last stage writes fp32
     if (steps & ZR_STAGE_DENOISE_VARIANCE)
     {
         TimerBegin(p, s, "denoise_variance");
@@ -2467,13 +2575,14 @@ static int RenderDenoise(zr_pass* p, hipStream_t s, const zr_frame_constants* cb
         if (!timing) { TimerBegin(p, s, "denoise_atrous"); timing = true; }
         F4* src = p->svgfCur; F4* dst = src == p->svgfPing.p ? p->svgfPong.p : p->svgfPing.p;
         svgf::FilterFrame A = V;
-        A.src = src; A.dst = dst; A.moments = nullptr; A.step = 1u << it; A.history = it == 0 ? p->svgfHist.p : nullptr;
-        // LDS-staged tiles for the dense iterations (steps 1 and 2: atrium 3840 x 2160 0.528 -> 0.416 ms each); ZR_DENOISE=plain: every iteration from the
-        // planes; ZR_DENOISE=lds4: step 4 from a 48 x 24 tile too (36.8 KB per block)
-        static const int ldsSteps = [] { const char* e = getenv("ZR_DENOISE"); return e && !strcmp(e, "plain") ? 0 : (e && !strcmp(e, "lds4") ? 3 : 2); }();
-        // ZR_DENOISE_TAPS=row: the row-loop form of the tap stencil instead of the unrolled one (zr_svgf.h AtrousPixelT); a parameterised normal power
-        // (svgf_normal_power_log2 != 7) always takes the row loop
-        static const bool rowLoop = [] { const char* e = getenv("ZR_DENOISE_TAPS"); return e && !strcmp(e, "row"); }();
+        A.src = src; A.dst = dst; A.moments = nullptr; A.step = 1u << it; A.history = it == 0 ? p->svgfHist.p : nullptr; A.dstPacked = it + 1u != sp.iterations;
+        // LDS-staged tiles for the dense iterations: steps 1, 2 and 4 (48 x 24 tile, 36.8 KB per block, for the last).  With definition 2 the iterations that
+        // read their taps from the planes are L1-bound (800 B of taps per pixel through 64 B / clk / CU: 0.24 ms at 3840 x 2160 against 0.14 - 0.15 ms from
+        // LDS, profiles/r04c_post_sqA.csv); steps 8 and 16 do not fit a tile.  ZR_DENOISE=plain: every iteration from the planes; ZR_DENOISE=lds2: steps 1 and 2 only
+        static const int ldsSteps = [] { const char* e = getenv("ZR_DENOISE"); return e && !strcmp(e, "plain") ? 0 : (e && !strcmp(e, "lds2") ? 2 : 3); }();
+        // the row-loop form of the tap stencil (zr_svgf.h AtrousPixelT) is the default: 5 iterations 0.978 ms against 1.006 ms for the fully unrolled form at
+        // 3840 x 2160 (profiles/r04c_post_chain*.jsonl), a fifth of the code; ZR_DENOISE_TAPS=unroll selects the other
+        static const bool rowLoop = [] { const char* e = getenv("ZR_DENOISE_TAPS"); return !(e && !strcmp(e, "unroll")); }();
 #define ZR_SVGF_LAUNCH(K, ...) do { if (!pow7) hipLaunchKernelGGL((K<__VA_ARGS__ -1, true>), grid, block, 0, s, A); else if (rowLoop) hipLaunchKernelGGL((K<__VA_ARGS__ 7, true>), grid, block, 0, s, A); \
             else hipLaunchKernelGGL((K<__VA_ARGS__ 7, false>), grid, block, 0, s, A); } while (0)
         if (it == 0 && ldsSteps >= 1) ZR_SVGF_LAUNCH(k_svgf_atrous_lds, 1,);
@@ -2650,12 +2759,12 @@ int zr_pass_render_stage(zr_pass* p, void* stream, const zr_frame_constants* cb,
 static int RenderStageInner(zr_pass* p, void* stream, const zr_frame_constants* cb, const zr_scene* sc, zr_gbuffer* gb, int stages)
 {
     if (!p || !cb || !sc) return Fail(ZR_ERR_INVALID_ARG, "zr_pass_render: null argument");
-    if (!(stages & ZR_STAGE_ALL)) return Fail(ZR_ERR_INVALID_ARG, "no stage selected");
+    if (!(stages & (ZR_STAGE_ALL | (p && p->kind == ZR_PASS_DENOISE ? ZR_STAGE_DENOISE_MASK : 0)))) return Fail(ZR_ERR_INVALID_ARG, "no stage selected");
     if (!p->initialized) return Fail(ZR_ERR_NOT_INITIALIZED, "pass not initialised (zr_pass_init)");
     if (sc->device != p->device || (gb && gb->device != p->device)) return Fail(ZR_ERR_INVALID_ARG, "scene / gbuffer / pass live on different devices");
     HIP_TRY(hipSetDevice(p->device));
     hipStream_t s = (hipStream_t)stream;
-    if (stages & ZR_STAGE_TEMPORAL) p->numTimers = 0;      // timings accumulate over the stages of one frame
+    if ((stages & ZR_STAGE_TEMPORAL) || (p->kind == ZR_PASS_DENOISE && (stages & (ZR_STAGE_SPATIAL | ZR_STAGE_DENOISE_TEMPORAL)))) p->numTimers = 0;      // timings accumulate over the stages of one frame
     {
         const uint32_t off[4] = { cb->base_color_maps_desc_heap_offset, cb->normal_maps_desc_heap_offset,
                                   cb->metallic_roughness_maps_desc_heap_offset, cb->emissive_maps_desc_heap_offset };

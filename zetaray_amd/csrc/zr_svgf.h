@@ -7,7 +7,7 @@
 // config 5 names "ReSTIR PT + SVGF denoise tile pass" at 3840 x 2160.  Its arithmetic is therefore DEFINED HERE (and restated independently
 // in oracle/zro_svgf.h, which the tests compare bit for bit): parity "unpinned" by construction, DESIGN.md section 5.13.
 //
-// DEFINITION, VERSION 2 (round 4).  What changed against version 1, and why: the a-trous kernel measured VALU-bound, not bandwidth-bound
+// DEFINITION, VERSION 3 (round 4; version 2 + item (6)).  What changed against version 1, and why: the a-trous kernel measured VALU-bound, not bandwidth-bound
 // (profiles/r04b_post_sq*.csv: 1622 VALU instructions per pixel and iteration, SIMD VALU ~0.9 busy, 0.03 of the HBM roof), two thirds of it the
 // Cephes exp, unfused multiply-adds and per-tap branches.  Version 2 keeps the filter (5 x 5 B3 taps, depth / normal / luminance edge stops,
 // variance propagation) and prices its arithmetic for the machine: (1) the edge-stopping falloff is the compact-support E(x) = max(0, 1 - x / 16)^16
@@ -15,19 +15,23 @@
 // sides, so HIP == oracle stays bit for bit) in the luminance, the dot products and every accumulation; (3) taps are PREDICATED, not skipped: every
 // tap position is clamped into the image, loaded, weighted, and its weight replaced by 0 when the tap is not usable -- no per-tap branch; (4) one
 // reciprocal per pixel instead of four divisions; (5) non-finite signal values are treated as 0 and the radiance is clamped to +-1e15, so every
-// value downstream is finite (0 x finite = 0 is what makes (3) exact) and an overflowed sample can no longer poison the history.
+// value downstream is finite (0 x finite = 0 is what makes (3) exact) and an overflowed sample can no longer poison the history;
+// (6) with (1) - (4) in place the iterations that gather their taps from the planes (steps 8 and 16; 4 without its LDS tile) are bound by the L1's 64 B per
+// clock and CU -- 25 taps x 32 B per pixel -- so the planes BETWEEN the stages hold what a tap needs in 20 B instead: colour and normal as fp16
+// (round to nearest even), variance and depth as fp32.  The history planes and the pass's output stay fp32: rounding happens between filter stages only.
 //
 // Definition (fp32, operations in the order written, -ffp-contract=off, fma(a, b, c) = zr_fma; pixel p = (x, y) in FRAME coordinates, W x H frame):
 //   Lum(c)       = fma(0.2126, c.x, fma(0.7152, c.y, 0.0722 * c.z))
 //   E(x)         = t^16, t = max(0, fma(x, -0.0625, 1)), by squaring four times
 //   Nw(n, nq)    = max(0, fma(n.x, nq.x, fma(n.y, nq.y, n.z * nq.z))) raised to 2^normal_power_log2 by repeated squaring
-//   guide(p)     = (n, z, fw): z = linear depth of the G-buffer (FLT_MAX = miss), n = the decoded oct32 normal, fw = max(|z(x+1, y) - z|, |z(x, y+1) - z|)
+//   h(v)         = v rounded to fp16 (round to nearest even) and back
+//   guide(p)     = (n, z, fw): z = linear depth of the G-buffer (FLT_MAX = miss), n = h(the decoded oct32 normal), fw = max(|z(x+1, y) - z|, |z(x, y+1) - z|)
 //                  with the neighbour replaced by the one on the other side at the last column / row and differences to a miss counted as 0
-//   temporal(p)  : c = signal.rgb, (0, 0, 0) if a component is not finite, then each component clamped to [-1e15, 1e15]; l = Lum(c).
+//   temporal(p)  : c = signal.rgb, (0, 0, 0) if a component is not finite, then each component clamped to [-60000, 60000] (fp16's range); l = Lum(c).
 //                  History position q = (uv - motion) * (W, H) - 0.5 with uv = (p + 0.5) / (W, H); the four texels around q with bilinear weights,
-//                  a texel usable when inside the image, not a miss in the previous G-buffer, |z_prev - z| <= 0.1 * z, dot(n_prev, n) >= 0.9 and its
-//                  colour, length and moments finite; if their weight sum is <= 0.01 the nine texels around round(q) are tried with weight 1 each.
-//                  Usable history: colour / moments / length = weighted means, length' = min(length + 1, 255),
+//                  a texel usable when inside the image, not a miss in the previous G-buffer, |z_prev - z| <= 0.1 * z and dot(n_prev, n) >= 0.9;
+//                  if their weight sum is <= 0.01 the nine texels around round(q) are tried with weight 1 each.
+//                  Usable history (weight sum > 0.01 and the weighted sums of colour, length and moments all finite): colour / moments / length = weighted means, length' = min(length + 1, 255),
 //                  a_c = max(alpha, 1 / length'), a_m = max(alpha_moments, 1 / length'), accumulated = hist + a * (new - hist).
 //                  No usable history (or a miss, or temporal_valid == 0): accumulated = new, length' = 1.   (unchanged from version 1 but for the sanitising)
 //   variance(p)  : length' >= 4: max(0, m2 - m1 * m1), colour unchanged.  Else the 7 x 7 neighbourhood, taps q = p + (dx, dy) != p in row order, position
@@ -41,6 +45,8 @@
 //                  wz = |z - zq| * (rz * (1 / sqrt(dx^2 + dy^2)));  c = fma(w, cq, c), var = fma(w * w, vq, var), ws = ws + w from 1;
 //                  r = 1 / ws: colour' = c * r, variance' = var * (r * r).  Miss pixels pass through.
 //                  The colour after iteration 0 (or after the variance stage when there are no iterations) is the next frame's colour history.
+//   between stages: the colour a later a-trous iteration reads (from the variance stage or the iteration before it) is h(colour); the colour history and
+//                  the output of the last stage are the fp32 values the stage computed.
 //
 // TILES: the planes of a pass may cover a window (ox, oy, pw, ph) of the frame -- a device's tile + its 32-px apron.  Every
 // formula above uses frame coordinates and frame dimensions; a position that leaves the window is clamped into it and the tap counted unusable.  A
@@ -72,7 +78,7 @@ struct SvgfFrame
     const float* prevDepth; const uint32_t* prevNormal;      // the previous frame's
     const F4* histColor; const float* histMoments;           // previous frame: rgb + history length; (m1, m2) per pixel
     F4* accum; float* moments;                               // this frame's accumulated colour + length, moments (become the history)
-    F4* guide; float* guideFw;                               // (n.x, n.y, n.z, z) that every tap reads; fw, which only the centre needs
+    F4* guide; float* guideFw; float* guideZ;               // (n.x, n.y, n.z, z): the variance stage's taps; fw, which only a stage's centre needs; z alone: the a-trous taps
     Window win; uint32_t temporalValid;
     SvgfParams prm;
 };
@@ -85,7 +91,37 @@ ZR_HD float Falloff(float x)
     t = t * t; t = t * t; t = t * t; t = t * t;
     return t;
 }
-ZR_HD float Clamp15(float x) { return zr_min(zr_max(x, -1.0e15f), 1.0e15f); }
+ZR_HD float Clamp15(float x) { return zr_min(zr_max(x, -60000.0f), 60000.0f); }      // (fp16's finite range: the planes between the stages hold fp16 colour)
+// fp16 <-> fp32 for values that are finite by construction (no Inf / NaN special cases): the conversion instructions on the device, the portable code on the host
+ZR_HD uint32_t HalfBits(float f)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    union { _Float16 h; uint16_t u; } c; c.h = (_Float16)f; return c.u;
+#else
+    return zr_f32_to_f16_portable(f);
+#endif
+}
+ZR_HD float HalfValue(uint32_t bits)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    union { _Float16 h; uint16_t u; } c; c.u = (uint16_t)bits; return (float)c.h;
+#else
+    return zr_f16_to_f32_portable((uint16_t)bits);
+#endif
+}
+ZR_HD float RoundHalf(float f) { return HalfValue(HalfBits(f)); }
+// the 16-byte texel of a plane between two filter stages: {h(r) | h(g) << 16, h(b) | h(n.x) << 16, h(n.y) | h(n.z) << 16, variance}
+ZR_HD U4 PackStage(V3 c, float var, V3 n)
+{
+    U4 p;
+    p.x = HalfBits(c.x) | (HalfBits(c.y) << 16); p.y = HalfBits(c.z) | (HalfBits(n.x) << 16); p.z = HalfBits(n.y) | (HalfBits(n.z) << 16); p.w = zr_asuint(var);
+    return p;
+}
+ZR_HD void UnpackStage(const U4& p, float z, F4& gq, F4& q)
+{
+    q = f4(v3(HalfValue(p.x & 0xffffu), HalfValue(p.x >> 16), HalfValue(p.y & 0xffffu)), zr_asfloat(p.w));
+    gq = f4(v3(HalfValue(p.y >> 16), HalfValue(p.z & 0xffffu), HalfValue(p.z >> 16)), z);
+}
 ZR_HD V3 SanitizeSignal(V3 c)
 {
     if (!(Finite(c.x) && Finite(c.y) && Finite(c.z))) return v3(0.0f);
@@ -93,7 +129,7 @@ ZR_HD V3 SanitizeSignal(V3 c)
 }
 
 // guide planes of pixel (x, y)
-ZR_HD void MakeGuide(const float* depth, const uint32_t* normal, int x, int y, const Window& w, F4* guide, float* guideFw)
+ZR_HD void MakeGuide(const float* depth, const uint32_t* normal, int x, int y, const Window& w, F4* guide, float* guideFw, float* guideZ)
 {
     const size_t i = w.Idx(x, y);
     const float z = depth[i];
@@ -106,8 +142,9 @@ ZR_HD void MakeGuide(const float* depth, const uint32_t* normal, int x, int y, c
         if (yn >= 0 && w.InPlanes(x, yn)) { const float zn = depth[w.Idx(x, yn)]; if (zn != ZR_FLT_MAX) dy = zr_abs(zn - z); }
         fw = zr_max(dx, dy);
     }
-    guide[i] = f4(DecodeOct32u(normal[i]), z);
-    guideFw[i] = fw;
+    const V3 n = DecodeOct32u(normal[i]);
+    guide[i] = f4(v3(RoundHalf(n.x), RoundHalf(n.y), RoundHalf(n.z)), z);
+    guideFw[i] = fw; guideZ[i] = z;
 }
 
 template<int POW>      // POW >= 0: the exponent's log2 as a compile-time constant (the default 7 unrolls); -1: prm.normalPowerLog2 at run time
@@ -127,16 +164,14 @@ ZR_HD bool HistoryUsable(const SvgfFrame& F, int qx, int qy, float z, V3 n)
     const float zp = F.prevDepth[j];
     if (zp == ZR_FLT_MAX) return false;
     if (!(zr_abs(zp - z) <= 0.1f * z)) return false;
-    if (!(dot(DecodeOct32u(F.prevNormal[j]), n) >= 0.9f)) return false;
-    const F4 h = F.histColor[j];
-    return Finite(h.x) && Finite(h.y) && Finite(h.z) && Finite(h.w) && Finite(F.histMoments[2 * j]) && Finite(F.histMoments[2 * j + 1]);
+    return dot(DecodeOct32u(F.prevNormal[j]), n) >= 0.9f;
 }
 
 ZR_HD void TemporalPixel(const SvgfFrame& F, int x, int y)
 {
     const int W = F.win.W, H = F.win.H;
     const size_t i = F.win.Idx(x, y);
-    MakeGuide(F.depth, F.normal, x, y, F.win, F.guide, F.guideFw);
+    MakeGuide(F.depth, F.normal, x, y, F.win, F.guide, F.guideFw, F.guideZ);
     const F4 s = F.signal[i];
     const V3 c = SanitizeSignal(v3(s.x, s.y, s.z));
     const float l = Lum(c);
@@ -180,7 +215,9 @@ ZR_HD void TemporalPixel(const SvgfFrame& F, int x, int y)
                     wsum += 1.0f;
                 }
         }
-        if (wsum > 0.01f)
+        // (a non-finite history value -- there is none unless the planes were corrupted from outside: the signal is sanitised -- makes the sums
+        // non-finite; such history counts as none instead of spreading)
+        if (wsum > 0.01f && Finite(hc.x) && Finite(hc.y) && Finite(hc.z) && Finite(hlen) && Finite(hm1) && Finite(hm2))
         {
             hc = hc / wsum; hm1 = hm1 / wsum; hm2 = hm2 / wsum; hlen = hlen / wsum;
             len = zr_min(hlen + 1.0f, 255.0f);
@@ -195,10 +232,11 @@ ZR_HD void TemporalPixel(const SvgfFrame& F, int x, int y)
 
 struct FilterFrame
 {
-    const F4* src;            // rgb + variance (a-trous) / rgb + history length (variance stage)
+    const F4* src;            // variance stage: rgb + history length (fp32); a-trous: the stage texels of PackStage, 16 B each, read through `srcP`
     const float* moments;     // variance stage only
-    const F4* guide; const float* guideFw;
-    F4* dst;                  // rgb + variance
+    const F4* guide; const float* guideFw; const float* guideZ;
+    F4* dst;                  // rgb + variance: fp32 when this is the pass's last stage, else stage texels (PackStage) written through `dstP`
+    bool dstPacked;
     F4* history;              // != null: the filtered rgb also goes here with the history length of `lenSrc` (colour history of the next frame)
     const F4* lenSrc;
     Window win; uint32_t step;
@@ -260,7 +298,7 @@ ZR_HD void VariancePixelT(const FilterFrame& F, int x, int y)
         c = v3(c.x * r, c.y * r, c.z * r); m1 = m1 * r; m2 = m2 * r;
         var = zr_max(0.0f, m2 - m1 * m1) * (4.0f / len);
     }
-    F.dst[i] = f4(c, var);
+    if (F.dstPacked) ((U4*)F.dst)[i] = PackStage(c, var, v3(g.x, g.y, g.z)); else F.dst[i] = f4(c, var);
     if (F.history) F.history[i] = f4(c, len);
 }
 ZR_HD void VariancePixel(const FilterFrame& F, int x, int y)
@@ -270,10 +308,10 @@ ZR_HD void VariancePixel(const FilterFrame& F, int x, int y)
 // (column, row) already clamped into the planes; an implementation turns a row into a base offset once (RowBase) and adds the column (At)
 struct PlaneTaps
 {
-    const F4* src; const F4* guide; Window win;
+    const U4* srcP; const float* guideZ; Window win;      // the stage texels (PackStage) + the depth plane: 20 B per tap
     ZR_HDM int RowBase(int y) const { return (y - win.oy) * win.pw - win.ox; }
-    ZR_HDM F4 Src(int rowBase, int x) const { return src[rowBase + x]; }
-    ZR_HDM F4 Guide(int rowBase, int x) const { return guide[rowBase + x]; }
+    ZR_HDM void Load(int rowBase, int x, F4& gq, F4& q) const { const U4 p = srcP[rowBase + x]; UnpackStage(p, guideZ[rowBase + x], gq, q); }
+    ZR_HDM float Var(int rowBase, int x) const { return zr_asfloat(srcP[rowBase + x].w); }
 };
 
 // B3 tap weights h(d) and 1 / sqrt(dx^2 + dy^2) of the 5 x 5 stencil as fp32 literals (= the correctly rounded 1.0f / sqrtf(n) the definition names;
@@ -310,8 +348,8 @@ ZR_HD void AtrousPixelT(const FilterFrame& F, int x, int y, const Taps& taps)
     const int s = (int)F.step;
     const size_t i = w.Idx(x, y);
     const int row0 = taps.RowBase(y);
-    const F4 a = taps.Src(row0, x);
-    const F4 g = taps.Guide(row0, x);
+    F4 a, g;
+    taps.Load(row0, x, g, a);
     const float z = g.w;
     AtrousAcc A; A.c = v3(a.x, a.y, a.z); A.var = a.w; A.wsum = 1.0f;
     if (z != ZR_FLT_MAX)
@@ -328,7 +366,7 @@ ZR_HD void AtrousPixelT(const FilterFrame& F, int x, int y, const Taps& taps)
                 for (int dx = -1; dx <= 1; dx++)
                 {
                     const float k = (dx == 0 ? 0.5f : 0.25f) * (dy == 0 ? 0.5f : 0.25f);
-                    v3x3 = zr_fma(k, (dx == 0 && dy == 0) ? a.w : taps.Src(rb, xs[dx + 1]).w, v3x3);
+                    v3x3 = zr_fma(k, (dx == 0 && dy == 0) ? a.w : taps.Var(rb, xs[dx + 1]), v3x3);
                 }
             }
         }
@@ -354,7 +392,9 @@ ZR_HD void AtrousPixelT(const FilterFrame& F, int x, int y, const Taps& taps)
                 {
                     if (dx == 0 && dy == 0) continue;
                     const int ax = dx < 0 ? -dx : dx;
-                    AtrousTap<POW>(A, taps.Guide(rb, cx[dx + 2]), taps.Src(rb, cx[dx + 2]), iny && inx[dx + 2], TapH(ax) * hy, TapRcpLen(ax, ay), l, z, n, rl, rz, F.prm.normalPowerLog2);
+                    F4 gq, q;
+                    taps.Load(rb, cx[dx + 2], gq, q);
+                    AtrousTap<POW>(A, gq, q, iny && inx[dx + 2], TapH(ax) * hy, TapRcpLen(ax, ay), l, z, n, rl, rz, F.prm.normalPowerLog2);
                 }
             }
         }
@@ -371,7 +411,9 @@ ZR_HD void AtrousPixelT(const FilterFrame& F, int x, int y, const Taps& taps)
                 {
                     if (dx == 0 && dy == 0) continue;
                     const int ax = dx < 0 ? -dx : dx;
-                    AtrousTap<POW>(A, taps.Guide(rb, cx[dx + 2]), taps.Src(rb, cx[dx + 2]), iny && inx[dx + 2], TapH(ax) * TapH(ay), TapRcpLen(ax, ay), l, z, n, rl, rz, F.prm.normalPowerLog2);
+                    F4 gq, q;
+                    taps.Load(rb, cx[dx + 2], gq, q);
+                    AtrousTap<POW>(A, gq, q, iny && inx[dx + 2], TapH(ax) * TapH(ay), TapRcpLen(ax, ay), l, z, n, rl, rz, F.prm.normalPowerLog2);
                 }
             }
         }
@@ -379,14 +421,14 @@ ZR_HD void AtrousPixelT(const FilterFrame& F, int x, int y, const Taps& taps)
         A.c = v3(A.c.x * r, A.c.y * r, A.c.z * r);
         A.var = A.var * (r * r);
     }
-    F.dst[i] = f4(A.c, A.var);
+    if (F.dstPacked) ((U4*)F.dst)[i] = PackStage(A.c, A.var, v3(g.x, g.y, g.z)); else F.dst[i] = f4(A.c, A.var);
     if (F.history) F.history[i] = f4(A.c, F.lenSrc[i].w);
 }
 template<class Taps>
 ZR_HD void AtrousPixelTaps(const FilterFrame& F, int x, int y, const Taps& taps)
 { if (F.prm.normalPowerLog2 == 7u) AtrousPixelT<7, true>(F, x, y, taps); else AtrousPixelT<-1, true>(F, x, y, taps); }
 ZR_HD void AtrousPixel(const FilterFrame& F, int x, int y)
-{ PlaneTaps t; t.src = F.src; t.guide = F.guide; t.win = F.win; AtrousPixelTaps(F, x, y, t); }
+{ PlaneTaps t; t.srcP = (const U4*)F.src; t.guideZ = F.guideZ; t.win = F.win; AtrousPixelTaps(F, x, y, t); }
 
 } // namespace svgf
 } // namespace zr
