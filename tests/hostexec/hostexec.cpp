@@ -217,11 +217,12 @@ void zhx_svgf_render(HxSvgf* S, const float* signal, const float* depth, const u
 {
     const svgf::Window& w = S->win;
     const int mi = S->momIdx;
+    if (steps & ZR_STAGE_DENOISE_TEMPORAL) memcpy(S->gz.data(), depth, S->gz.size() * sizeof(float));      // the a-trous taps read the G-buffer's depth plane (kept for the later steps of the frame)
     svgf::SvgfParams sp; sp.alpha = params4[0]; sp.alphaMoments = params4[1]; sp.sigmaL = params4[2]; sp.sigmaZ = params4[3]; sp.normalPowerLog2 = normalPowerLog2; sp.iterations = iterations;
     if (steps & ZR_STAGE_DENOISE_TEMPORAL)
     {
         svgf::SvgfFrame T; T.signal = (const F4*)signal; T.depth = depth; T.normal = normal; T.motion = motion; T.prevDepth = prevDepth; T.prevNormal = prevNormal;
-        T.histColor = S->hist.data(); T.histMoments = S->moments[mi].data(); T.accum = S->accum.data(); T.moments = S->moments[mi ^ 1].data(); T.guide = S->guide.data(); T.guideFw = S->fw.data(); T.guideZ = S->gz.data();
+        T.histColor = S->hist.data(); T.histMoments = S->moments[mi].data(); T.accum = S->accum.data(); T.moments = S->moments[mi ^ 1].data(); T.guide = S->guide.data(); T.guideFw = S->fw.data();
         T.win = w; T.temporalValid = temporalValid ? 1u : 0u; T.prm = sp;
         for (int y = w.oy; y < w.oy + w.ph; y++) for (int x = w.ox; x < w.ox + w.pw; x++) svgf::TemporalPixel(T, x, y);
     }

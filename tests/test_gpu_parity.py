@@ -853,6 +853,43 @@ def test_taa_on_gpu(api, cornell_emissive, oracle_emissive):
     assert got[..., :3].view(np.float16).astype(np.float32).max() > 0
 
 
+def test_taa_with_overflowing_and_nan_history_on_gpu(api, cornell_emissive):
+    """The TAA kernel converts its 36 history texels per pixel with plain v_cvt_f32_f16 and re-runs the exact path only when one of them holds an Inf or
+    a NaN (zr_taa.h LoadHistoryTexel<EXACT>).  Here the history really holds them: a synthetic signal with values beyond fp16's range (-> Inf in the RGBA16F
+    output, i.e. in the next frame's history), NaNs and Infs, over the Cornell box's G-buffer with a moving camera: every frame == the oracle's TAA.hlsl
+    restatement, bit for bit, and the special values are really there."""
+    import torch
+    from oracle import zro
+    w, h = 160, 96
+    prm = wire.default_params()
+    prm.taa_blend_weight = 0.1
+    r = api.Renderer(cornell_emissive, w, h, params=wire.default_params())
+    taa = api.Pass(api.PASS_TAA, w, h, params=prm)
+    rng = np.random.default_rng(17)
+    hist = np.zeros((h, w, 4), np.uint16)
+    prev, saw_special = None, 0
+    for f in range(1, 6):
+        cb = _chain(_frame(cornell_emissive, w, h, f, cam_pos=(0.04 * f, 1.2, -4.043)), prev)
+        prev = cb.copy()
+        r.p_gbuffer.render(cb, r.scene, r.gbuffer)
+        sig = np.zeros((h, w, 4), np.float32)
+        sig[..., :3] = rng.uniform(0.0, 2.0, (h, w, 3)).astype(np.float32)
+        hot = rng.random((h, w)) < 0.02
+        sig[hot, 0] = 3.0e5                      # beyond fp16: the stored output is +Inf
+        sig[rng.random((h, w)) < 0.005, 1] = np.nan
+        sig[rng.random((h, w)) < 0.005, 2] = np.inf
+        dev = torch.from_numpy(sig).cuda()
+        taa.set_input(api.IN_TAA_SIGNAL, dev.data_ptr())
+        taa.render(cb, r.scene, r.gbuffer)
+        planes, _ = r.gbuffer.download()
+        want = zro.taa(sig, planes[7].reshape(h, w), planes[3].reshape(h, w), hist, 0.1, f > 1)
+        got = taa.download_plane("taa")
+        assert np.array_equal(got[..., :3], want[..., :3]), f"frame {f}: {int((got[..., :3] != want[..., :3]).any(-1).sum())} pixels differ"
+        hist = got
+        saw_special += int(((got[..., :3] & 0x7c00) == 0x7c00).sum())
+    assert saw_special > 50
+
+
 def test_half_conversion_instructions_match_portable_code(api):
     """The kernels' fp32 <-> fp16 conversions use v_cvt_f16_f32 / v_cvt_f32_f16; on the device they must agree with the portable
     code (== the oracle's, pinned to the reference's half in test_ref_pins.py) for all 2^32 / 2^16 bit patterns."""

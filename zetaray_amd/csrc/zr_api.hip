@@ -826,7 +826,7 @@ struct zr_pass
     DevBuf<F4> giA[2], giC[2]; DevBuf<uint16_t> giB[2];
     bool temporalValid = false, doTemporal = false, doSpatial = false; int currIdx = 0;
     const F4* compIn[4] = {nullptr, nullptr, nullptr, nullptr};     // COMPOSITING inputs (emissive DI, indirect, sky DI); [3] = TAA signal
-    DevBuf<F4> svgfHist, svgfAccum, svgfPing, svgfPong; DevBuf<float> svgfMoments[2], svgfGuideFw, svgfGuideZ; DevBuf<F4> svgfGuide; int svgfMomIdx = 0; const F4* svgfOut = nullptr; F4* svgfCur = nullptr; uint32_t svgfStepsDone = 0;      // DENOISE
+    DevBuf<F4> svgfHist, svgfAccum, svgfPing, svgfPong; DevBuf<float> svgfMoments[2], svgfGuideFw; DevBuf<F4> svgfGuide; int svgfMomIdx = 0; const F4* svgfOut = nullptr; F4* svgfCur = nullptr; uint32_t svgfStepsDone = 0;      // DENOISE
     DevBuf<uint16_t> taaOut[2]; int taaIdx = 0;            // TAA: ping-pong RGBA16F outputs; taaIdx = the one written last
     // AUTO_EXPOSURE / DISPLAY
     const uint16_t* postIn16 = nullptr; const F4* postIn32 = nullptr; const float* exposureIn = nullptr;
@@ -1765,7 +1765,7 @@ static int AllocPass(zr_pass* p)
     if (p->kind == ZR_PASS_DENOISE)
     {
         const size_t n = (size_t)p->w * p->h;
-        if ((r = p->svgfHist.Alloc(n)) || (r = p->svgfAccum.Alloc(n)) || (r = p->svgfPing.Alloc(n)) || (r = p->svgfPong.Alloc(n)) || (r = p->svgfGuide.Alloc(n)) || (r = p->svgfGuideFw.Alloc(n)) || (r = p->svgfGuideZ.Alloc(n))) return r;
+        if ((r = p->svgfHist.Alloc(n)) || (r = p->svgfAccum.Alloc(n)) || (r = p->svgfPing.Alloc(n)) || (r = p->svgfPong.Alloc(n)) || (r = p->svgfGuide.Alloc(n)) || (r = p->svgfGuideFw.Alloc(n))) return r;
         for (int k = 0; k < 2; k++) { if ((r = p->svgfMoments[k].Alloc(2 * n))) return r; HIP_TRY(hipMemset(p->svgfMoments[k].p, 0, 2 * n * sizeof(float))); }
         HIP_TRY(hipMemset(p->svgfHist.p, 0, n * sizeof(F4))); HIP_TRY(hipMemset(p->svgfPing.p, 0, n * sizeof(F4))); HIP_TRY(hipMemset(p->svgfPong.p, 0, n * sizeof(F4)));
         p->svgfMomIdx = 0; p->svgfOut = p->svgfPing.p; p->svgfCur = p->svgfPing.p; p->temporalValid = false;
@@ -2550,7 +2550,7 @@ static int RenderDenoise(zr_pass* p, hipStream_t s, const zr_frame_constants* cb
     {
         svgf::SvgfFrame T;
         T.signal = p->compIn[3]; T.depth = cur.depth; T.normal = cur.normal; T.motion = cur.motion; T.prevDepth = prev.depth; T.prevNormal = prev.normal;
-        T.histColor = p->svgfHist.p; T.histMoments = p->svgfMoments[mi].p; T.accum = p->svgfAccum.p; T.moments = p->svgfMoments[mi ^ 1].p; T.guide = p->svgfGuide.p; T.guideFw = p->svgfGuideFw.p; T.guideZ = p->svgfGuideZ.p;
+        T.histColor = p->svgfHist.p; T.histMoments = p->svgfMoments[mi].p; T.accum = p->svgfAccum.p; T.moments = p->svgfMoments[mi ^ 1].p; T.guide = p->svgfGuide.p; T.guideFw = p->svgfGuideFw.p;
         T.win = win; T.temporalValid = (p->temporalValid && gb->numRendered >= 2) ? 1u : 0u; T.prm = sp;
         TimerBegin(p, s, "denoise_temporal");
         hipLaunchKernelGGL(k_svgf_temporal, grid, block, 0, s, T);
@@ -2558,7 +2558,7 @@ static int RenderDenoise(zr_pass* p, hipStream_t s, const zr_frame_constants* cb
         p->svgfStepsDone = 0;
     }
     svgf::FilterFrame V;
-    V.src = p->svgfAccum.p; V.moments = p->svgfMoments[mi ^ 1].p; V.guide = p->svgfGuide.p; V.guideFw = p->svgfGuideFw.p; V.guideZ = p->svgfGuideZ.p; V.dst = p->svgfPing.p; V.lenSrc = p->svgfAccum.p;
+    V.src = p->svgfAccum.p; V.moments = p->svgfMoments[mi ^ 1].p; V.guide = p->svgfGuide.p; V.guideFw = p->svgfGuideFw.p; V.guideZ = cur.depth; V.dst = p->svgfPing.p; V.lenSrc = p->svgfAccum.p;
     V.history = sp.iterations == 0 ? p->svgfHist.p : nullptr; V.win = win; V.step = 1; V.prm = sp;
     V.dstPacked = sp.iterations != 0;      // the planes between two stages hold fp16 colour + normal (zr_svgf.h PackStage); the pass's last stage writes fp32
     if (steps & ZR_STAGE_DENOISE_VARIANCE)

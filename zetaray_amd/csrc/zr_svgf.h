@@ -78,7 +78,7 @@ struct SvgfFrame
     const float* prevDepth; const uint32_t* prevNormal;      // the previous frame's
     const F4* histColor; const float* histMoments;           // previous frame: rgb + history length; (m1, m2) per pixel
     F4* accum; float* moments;                               // this frame's accumulated colour + length, moments (become the history)
-    F4* guide; float* guideFw; float* guideZ;               // (n.x, n.y, n.z, z): the variance stage's taps; fw, which only a stage's centre needs; z alone: the a-trous taps
+    F4* guide; float* guideFw;                               // (n.x, n.y, n.z, z): the variance stage's taps; fw, which only a stage's centre needs
     Window win; uint32_t temporalValid;
     SvgfParams prm;
 };
@@ -129,7 +129,7 @@ ZR_HD V3 SanitizeSignal(V3 c)
 }
 
 // guide planes of pixel (x, y)
-ZR_HD void MakeGuide(const float* depth, const uint32_t* normal, int x, int y, const Window& w, F4* guide, float* guideFw, float* guideZ)
+ZR_HD void MakeGuide(const float* depth, const uint32_t* normal, int x, int y, const Window& w, F4* guide, float* guideFw)
 {
     const size_t i = w.Idx(x, y);
     const float z = depth[i];
@@ -144,7 +144,7 @@ ZR_HD void MakeGuide(const float* depth, const uint32_t* normal, int x, int y, c
     }
     const V3 n = DecodeOct32u(normal[i]);
     guide[i] = f4(v3(RoundHalf(n.x), RoundHalf(n.y), RoundHalf(n.z)), z);
-    guideFw[i] = fw; guideZ[i] = z;
+    guideFw[i] = fw;
 }
 
 template<int POW>      // POW >= 0: the exponent's log2 as a compile-time constant (the default 7 unrolls); -1: prm.normalPowerLog2 at run time
@@ -171,7 +171,7 @@ ZR_HD void TemporalPixel(const SvgfFrame& F, int x, int y)
 {
     const int W = F.win.W, H = F.win.H;
     const size_t i = F.win.Idx(x, y);
-    MakeGuide(F.depth, F.normal, x, y, F.win, F.guide, F.guideFw, F.guideZ);
+    MakeGuide(F.depth, F.normal, x, y, F.win, F.guide, F.guideFw);
     const F4 s = F.signal[i];
     const V3 c = SanitizeSignal(v3(s.x, s.y, s.z));
     const float l = Lum(c);
@@ -234,7 +234,8 @@ struct FilterFrame
 {
     const F4* src;            // variance stage: rgb + history length (fp32); a-trous: the stage texels of PackStage, 16 B each, read through `srcP`
     const float* moments;     // variance stage only
-    const F4* guide; const float* guideFw; const float* guideZ;
+    const F4* guide; const float* guideFw;
+    const float* guideZ;      // the depth an a-trous tap reads next to its stage texel: the G-buffer's linear-depth plane itself
     F4* dst;                  // rgb + variance: fp32 when this is the pass's last stage, else stage texels (PackStage) written through `dstP`
     bool dstPacked;
     F4* history;              // != null: the filtered rgb also goes here with the history length of `lenSrc` (colour history of the next frame)
