@@ -158,8 +158,8 @@ typedef struct zr_params {
     /* ZR_PASS_INDIRECT, ReSTIR PT (ABI version 3): IndirectLighting::m_numSpatialPasses ("#Spatial Passes", range 0..2, IndirectLighting.cpp:1240,
        default 1 IndirectLighting.h:392).  0: no spatial reuse (the temporal pass writes the frame's radiance); 2: the host loop of
        IndirectLighting.cpp:616-621, 860-870 -- a second search / sort / replay / reconnect round whose inputs are the first round's outputs
-       (reservoir sets swapped), the target plane not rewritten in between (ReSTIR_PT_Reconnect_StC.hlsl:328-346).  One-device only for 2:
-       the tile split exchanges no halo between the rounds (ZR_ERR_UNSUPPORTED from zr_pass_render_stage). */
+       (reservoir sets swapped), the target plane not rewritten in between (ReSTIR_PT_Reconnect_StC.hlsl:328-346).  On tiles the second round is its own
+       stage behind one more halo exchange (ZR_STAGE_SPATIAL2). */
     uint32_t num_spatial_passes;    /* 1 */
 } zr_params;
 
@@ -355,6 +355,9 @@ int zr_pass_render(zr_pass* pass, void* hip_stream, const zr_frame_constants* cb
 #define ZR_STAGE_TEMPORAL 1
 #define ZR_STAGE_SPATIAL  2
 #define ZR_STAGE_ALL      3
+/* ReSTIR PT with zr_params.num_spatial_passes = 2 on tiles: the second search / sort / replay / reconnect round as its own stage, with one more exchange of
+   ZR_HALO_POST_TEMPORAL (the set the next stage reads) before it; zr_pass_render runs both rounds.  A no-op for every other pass / setting. */
+#define ZR_STAGE_SPATIAL2 4
 /* ZR_PASS_DENOISE only: the steps of the pass one by one (zr_pass_render_stage; ZR_STAGE_SPATIAL / ZR_STAGE_ALL = all of them).  A device of the tile
    split runs them in groups with a halo exchange wherever the next step's stencil would reach beyond what is still exact in its 32-px apron
    (reach: variance 3 px, a-trous iteration i 2 * 2^i px; zetaray_amd/tiling.py denoise_schedule): exchange ZR_HALO_DENOISE_INPUT, TEMPORAL + VARIANCE +

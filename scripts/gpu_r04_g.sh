@@ -1,4 +1,4 @@
-# Round-4 GPU visit G (closing set on the final kernel sources): the whole GPU suite, smoke(), post-chain timings, the r04 PMC profile set of the two
+# Round-4 closing set (run on the final kernel sources): the whole GPU suite, smoke(), post-chain timings, the r04 PMC profile set of the two
 # ReSTIR PT workloads (bench.py reports traffic / valu only from a profile whose source hash matches), every bench preset, the default line.
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out

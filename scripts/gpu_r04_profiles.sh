@@ -24,7 +24,8 @@ for wl in ${WORKLOADS:-rpt_cornell rpt_atrium gi_cornell}; do
     pt_cornell) ARGS="--config pt";;
     pt_atrium) ARGS="--integrator pt --scene synthetic";;
   esac
-  CMD="python $R/bench.py --gpus 1 --steps 6 --warmup 2 --settle 8 --no-cpu-baseline $ARGS"
+  # (--no-extra-workloads: the default line would otherwise render configs 4 and 5 in the same process, and their launches share kernel names with Cornell's)
+  CMD="python $R/bench.py --gpus 1 --steps 6 --warmup 2 --settle 8 --no-cpu-baseline --no-extra-workloads $ARGS"
   O=$R/gpurun_out/${TAG:-r04}_$wl
   pmc ${O}_fetch FETCH_SIZE $CMD; pmc ${O}_write WRITE_SIZE $CMD
   for p in A B C E; do eval CTR=\$SQ_$p; pmc ${O}_sq$p "$CTR" $CMD; done

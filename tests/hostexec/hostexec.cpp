@@ -197,7 +197,7 @@ void zhx_taa(const float* signal, const float* depth, const uint32_t* motion, co
 struct HxSvgf
 {
     svgf::Window win;
-    std::vector<F4> hist, accum, guide, ping, pong; std::vector<float> moments[2], fw, gz;
+    std::vector<F4> hist, accum, ping, pong; std::vector<svgf::GuideN> guide; std::vector<float> moments[2], fw, gz;
     int momIdx = 0; F4* cur = nullptr; const F4* out = nullptr;
 };
 HxSvgf* zhx_svgf_create(int ox, int oy, int pw, int ph, int W, int H)
@@ -205,7 +205,7 @@ HxSvgf* zhx_svgf_create(int ox, int oy, int pw, int ph, int W, int H)
     HxSvgf* S = new HxSvgf();
     S->win.ox = ox; S->win.oy = oy; S->win.pw = pw; S->win.ph = ph; S->win.W = W; S->win.H = H;
     const size_t n = (size_t)pw * ph;
-    S->hist.assign(n, F4{0, 0, 0, 0}); S->accum.assign(n, F4{0, 0, 0, 0}); S->guide.assign(n, F4{0, 0, 0, 0}); S->ping.assign(n, F4{0, 0, 0, 0}); S->pong.assign(n, F4{0, 0, 0, 0});
+    S->hist.assign(n, F4{0, 0, 0, 0}); S->accum.assign(n, F4{0, 0, 0, 0}); S->guide.assign(n, svgf::GuideN{0, 0}); S->ping.assign(n, F4{0, 0, 0, 0}); S->pong.assign(n, F4{0, 0, 0, 0});
     S->moments[0].assign(2 * n, 0.0f); S->moments[1].assign(2 * n, 0.0f); S->fw.assign(n, 0.0f); S->gz.assign(n, 0.0f);
     S->cur = S->ping.data(); S->out = S->ping.data();
     return S;
@@ -397,7 +397,7 @@ void zhx_trace_any(const HxScene* s, const float* rays, uint32_t n, uint32_t mas
 // ---------------------------------------------------------------- ReSTIR PT (zr_rpt.h) in program order
 struct HxRpt
 {
-    uint32_t w = 0, h = 0; bool temporalValid = false, doTemporal = false, doSpatial = false; int currIdx = 0;
+    uint32_t w = 0, h = 0; bool temporalValid = false, doTemporal = false, doSpatial = false, frameOpen = false; int currIdx = 0;
     std::vector<uint16_t> map[2];      // K12 thread maps (CtN, NtC)
     struct Planes { std::vector<uint32_t> A, G; std::vector<float> B, F; std::vector<U4> C, D; std::vector<uint16_t> E;
         void Resize(size_t n) { A.assign(n, 0); B.assign(2 * n, 0); C.assign(n, U4{0, 0, 0, 0}); D.assign(n, U4{0, 0, 0, 0}); E.assign(n, 0); F.assign(2 * n, 0); G.assign(2 * n, 0); }
@@ -539,9 +539,10 @@ void zhx_rpt_render_stage(const HxScene* s, HxRpt* R, const zr_frame_constants* 
             for (uint32_t y = Y0; y < Y1; y++) for (uint32_t x = X0; x < X1; x++) { ReconnectTemporalPixel(F, g, x, y, stack, cnt); flush(); }
         }
     }
-    if ((stages & 2) && prm.doSpatial)
-    for (uint32_t spass = 0; spass < numSpatialPasses; spass++)
+    for (uint32_t spass = 0; spass < numSpatialPasses && prm.doSpatial; spass++)
     {
+        if (!(stages & (spass == 0 ? 2 : 4))) continue;      // ZR_STAGE_SPATIAL / ZR_STAGE_SPATIAL2
+        F.cur = R->res[R->currIdx].View(); F.prev = R->res[1 - R->currIdx].View();      // a round reads the current set and writes the other, which becomes current
         for (uint32_t y = Y0; y < Y1; y++) for (uint32_t x = X0; x < X1; x++) SpatialSearchPixel(F, g, x, y);
         if (prm.sortSpatial) { sortPass(RPT_SORT_CTS, F.mapCtN); sortPass(RPT_SORT_STC, F.mapNtC); }
         for (int v = 0; v < 2; v++) for (uint32_t y = Y0; y < Y1; y++) for (uint32_t x = X0; x < X1; x++) { ReplaySpatialPixel(F, g, v, x, y, stack, cnt); flush(); }
@@ -563,16 +564,18 @@ void zhx_rpt_render_stage(const HxScene* s, HxRpt* R, const zr_frame_constants* 
             const float sum4 = ButterflySum64(v4);
             for (uint32_t l = 0; l < 64; l++) StcPhase3(F, g, L[l], sum2 + sum3 + sum4);
         }
-        if (spass == 0 && numSpatialPasses == 2u) std::swap(F.cur, F.prev);      // the round's outputs are the next round's inputs
+        R->currIdx = 1 - R->currIdx;      // one flip per round: the round's outputs are the next round's inputs
     }
     flush();
     if (counters) { counters->n_closest = total[0]; counters->n_shadow = total[1]; }
-    if (stages & 2)
+    if (stages & 1) R->frameOpen = true;
+    // the frame ends with its last stage (the second round when there is one this frame, else stage 2); Render() flips again
+    const bool lastStage = (prm.doSpatial && numSpatialPasses == 2u) ? (stages & 4) != 0 : (stages & 2) != 0;
+    if (lastStage && R->frameOpen)
     {
-        // spatial wrote the other set, which becomes "current" (IndirectLighting.cpp:609-612, 682-685); Render() flips again
-        if (prm.doSpatial && (numSpatialPasses & 1u)) R->currIdx = 1 - R->currIdx;      // one flip per round
         R->temporalValid = true;
         R->currIdx = 1 - R->currIdx;
+        R->frameOpen = false;
     }
 }
 void zhx_rpt_render(const HxScene* s, HxRpt* R, const zr_frame_constants* cb, const zr_gbuffer_planes* curr, const zr_gbuffer_planes* prev,

@@ -228,10 +228,10 @@ class HostExecRPT:
         lib().zhx_rpt_reset_temporal(self.r)
 
     def render(self, cb, params, gb=None):
-        return self.render_stage(cb, params, 3, gb)
+        return self.render_stage(cb, params, 7, gb)
 
     def render_stage(self, cb, params, stages, gb=None):
-        """stages: 1 = K11 + temporal, 2 = spatial + end of frame, 3 = both.  With ext=(x0, y0, w, h) the planes cover that
+        """stages: 1 = K11 + temporal, 2 = spatial (first round) + end of frame, 4 = the second spatial round (num_spatial_passes = 2), 7 = all.  With ext=(x0, y0, w, h) the planes cover that
         extended tile and `owned` is the rect this instance shades (multi-device split)."""
         from zetaray_amd import wire
         if stages & 1:
@@ -254,7 +254,8 @@ class HostExecRPT:
             L.zhx_rpt_set_owned_rect(0, 0, 0, 0)
         c = getattr(self, "counters", (0, 0)) if not (stages & 1) else (0, 0)
         self.counters = (c[0] + cnt.n_closest, c[1] + cnt.n_shadow)
-        if stages & 2:
+        last = 4 if (params.num_spatial_passes == 2 and (params.flags & 0x2)) else 2      # the stage after which the frame's G-buffer becomes "previous"
+        if stages & last:
             self.prev = gb
         return self.final
 

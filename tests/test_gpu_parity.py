@@ -1704,6 +1704,69 @@ def test_final_halo_is_exchanged_only_by_frames_that_read_it(api, cornell_emissi
     assert counts == [1, 2, 1, 1, 2, 1], counts
 
 
+def test_tile_split_with_a_thin_lens_camera_exchanges_the_final_halo(api, cornell_emissive, oracle_emissive):
+    """with cb.dof the primary hit lies off the pinhole ray the reprojection assumes, so the G-buffer's motion vectors are non-zero on a
+    perfectly static frame and the temporal stage reads neighbouring pixels' history across tile borders.  The exchange policy must therefore move the
+    FINAL halo every frame (two exchanges per frame from frame 2 on) although neither view, jitter nor scene change -- and the stitched image of four
+    tiles stays bit-identical to the full-frame oracle."""
+    from oracle import zro
+    from zetaray_amd import tiling
+    w, h, world = 200, 120, 4
+    prm = wire.default_params()
+    ranks = [tiling.TiledRestirPT(cornell_emissive, w, h, world, r, params=prm) for r in range(world)]
+    o = zro.OracleRPT(oracle_emissive, w, h)
+    prev, counts = None, []
+    for f in range(1, 5):
+        cb = _frame(cornell_emissive, w, h, f)
+        cb["dof"], cb["focus_depth"], cb["lens_radius"] = 1, 3.0, 0.08
+        cb = _chain(cb, prev)
+        prev = cb.copy()
+        counts.append(tiling.render_frame_in_process(ranks, cb))
+        want = o.render(cb, prm)
+        img = np.zeros_like(want)
+        for r in ranks:
+            (x0, y0, tw, th), t = r.final_tile()
+            img[y0:y0 + th, x0:x0 + tw] = t
+        mism = int((img.view(np.uint32) != want.view(np.uint32)).any(axis=2).sum())
+        assert mism == 0, f"frame {f}: {mism} pixels differ"
+    assert counts == [1, 2, 2, 2], counts
+
+
+def test_tile_split_with_two_spatial_rounds(api, cornell_emissive, oracle_emissive):
+    """num_spatial_passes = 2 on tiles: the second round reads the first round's outputs at neighbouring pixels, so it is its own stage
+    (ZR_STAGE_SPATIAL2) behind one more exchange of the set the next stage reads.  Four tile objects, moving camera: stitched radiance and reservoir
+    planes bit-identical to the full-frame oracle (which runs the reference's host loop), three exchanges per frame once reuse is on."""
+    from oracle import zro
+    from zetaray_amd import tiling
+    w, h, world = 200, 120, 4
+    prm = wire.default_params()
+    prm.num_spatial_passes = 2
+    ranks = [tiling.TiledRestirPT(cornell_emissive, w, h, world, r, params=prm) for r in range(world)]
+    o = zro.OracleRPT(oracle_emissive, w, h)
+    prev, counts = None, []
+    for f in range(1, 5):
+        cb = _chain(_frame(cornell_emissive, w, h, f, cam_pos=(0.04 * f, 1.2, -4.03)), prev)
+        prev = cb.copy()
+        counts.append(tiling.render_frame_in_process(ranks, cb))
+        want = o.render(cb, prm)
+        img = np.zeros_like(want)
+        planes = {nm: np.zeros_like(o.plane(nm)) for nm in ("A", "B", "C", "D", "E", "F", "G")}
+        for r in ranks:
+            (x0, y0, tw, th), t = r.final_tile()
+            img[y0:y0 + th, x0:x0 + tw] = t
+            ex0, ey0 = r.ext[0], r.ext[1]
+            for nm in planes:
+                planes[nm][y0:y0 + th, x0:x0 + tw] = r.r.p_indirect.download_plane(nm)[y0 - ey0:y0 - ey0 + th, x0 - ex0:x0 - ex0 + tw]
+        mism = int((img.view(np.uint32) != want.view(np.uint32)).any(axis=2).sum())
+        assert mism == 0, f"frame {f}: {mism} pixels differ"
+        for nm, got in planes.items():
+            a, b = got, o.plane(nm)
+            if nm == "A":
+                a, b = a & 0xffffff, b & 0xffffff
+            assert np.array_equal(a.view(np.uint8), b.view(np.uint8)), f"frame {f}: reservoir plane {nm}"
+    assert counts == [2, 3, 3, 3], counts
+
+
 def test_restir_pt_one_round_grid_is_bit_exact(api, cornell_emissive, oracle_emissive):
     """512 x 480 is 3840 one-wave blocks of K11: more than the 3-wave build keeps resident (3072), fewer than the 4-wave build does (4096) -- the
     grid size at which the pass switches K11 to its 4-wave build (zr_api.hip FewerRoundsAtFourWaves; an 8-way tile of a 1080p frame is such a

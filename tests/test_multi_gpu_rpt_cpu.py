@@ -25,7 +25,7 @@ def _frames(scene_io, sc, w, h, n):
     return cbs
 
 
-def _worker(rank, world, port, w, h, nframes, out_path, layout=None):
+def _worker(rank, world, port, w, h, nframes, out_path, layout=None, spatial_passes=1):
     sys.path.insert(0, ROOT)
     import torch
     import torch.distributed as dist
@@ -43,6 +43,7 @@ def _worker(rank, world, port, w, h, nframes, out_path, layout=None):
     plan = tiling.halo_plan(w, h, world, rank, layout=layout)
     r = zhx.HostExecRPT(hx, ext[2], ext[3], ext=ext, owned=tile)
     prm = wire.default_params()
+    prm.num_spatial_passes = spatial_passes
 
     def local(rect):
         return rect[0] - ext[0], rect[1] - ext[1], rect[2], rect[3]
@@ -70,6 +71,9 @@ def _worker(rank, world, port, w, h, nframes, out_path, layout=None):
         r.render_stage(cb, prm, 1)
         exchange(1)          # between the stages the post-temporal set is "which = 1"
         r.render_stage(cb, prm, 2)
+        if spatial_passes == 2:
+            exchange(1)      # the first round's outputs are the current set now: what the second round reads at neighbouring pixels
+            r.render_stage(cb, prm, 4)
         exchange(0)          # after the frame: the set the next frame reads as previous
     x, y, tw, th = local(tile)
     res = {"tile": np.array(tile), "final": r.final[y:y + th, x:x + tw].copy(), "rays": np.array(r.counters)}
@@ -83,8 +87,9 @@ def _worker(rank, world, port, w, h, nframes, out_path, layout=None):
 import pytest
 
 
-@pytest.mark.parametrize("layout", [None, [(0, 0, 96, 64), (96, 0, 32, 64)]], ids=["equal-area grid", "uneven cost-balanced style split"])
-def test_restir_pt_tile_split_with_halo_exchange_is_bit_identical(tmp_path, layout):
+@pytest.mark.parametrize("layout,spatial_passes", [(None, 1), ([(0, 0, 96, 64), (96, 0, 32, 64)], 1), (None, 2)],
+                         ids=["equal-area grid", "uneven cost-balanced style split", "two spatial rounds (a third exchange between them)"])
+def test_restir_pt_tile_split_with_halo_exchange_is_bit_identical(tmp_path, layout, spatial_passes):
     """layout None: tiling.tile_rect's grid; the second case is the kind of split tiling.balanced_layout produces (32-px-aligned tiles of
     different sizes): the halo plan and the stitched result must not depend on the tiles being equal"""
     import torch.multiprocessing as mp
@@ -94,7 +99,7 @@ def test_restir_pt_tile_split_with_halo_exchange_is_bit_identical(tmp_path, layo
     s.close()
     w, h, nframes, world = 128, 64, 4, 2
     out = str(tmp_path / "rank")
-    mp.spawn(_worker, args=(world, port, w, h, nframes, out, layout), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, port, w, h, nframes, out, layout, spatial_passes), nprocs=world, join=True)
     sys.path.insert(0, ROOT)
     from oracle import zro
     from zetaray_amd import scene_io, wire
@@ -102,6 +107,7 @@ def test_restir_pt_tile_split_with_halo_exchange_is_bit_identical(tmp_path, layo
     o = zro.OracleScene(sc)
     ref = zro.OracleRPT(o, w, h)
     prm = wire.default_params()
+    prm.num_spatial_passes = spatial_passes
     rays = np.zeros(2, np.int64)
     for cb in _frames(scene_io, sc, w, h, nframes):
         want = ref.render(cb, prm)

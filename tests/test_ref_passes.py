@@ -165,7 +165,7 @@ def test_hip_path_reproduces_reference_passes(case):
 
 # ------------------------------------------------------------------ the HIP stage functions, executed on the host, against the reference's outputs
 @pytest.mark.parametrize("case", ["rpt_cornell_moving", "rpt_moving_instance", "di_moving_instance", "sdi_moving_instance", "gi_cornell_moving", "rpt_sun_sky",
-                                  "rpt_moving_light", "di_moving_light", "rpt_two_spatial", "rpt_two_spatial_materials", "rpt_no_spatial"])
+                                  "rpt_moving_light", "di_moving_light", "rpt_two_spatial", "rpt_two_spatial_materials", "rpt_no_spatial", "rpt_two_spatial_sun_sky"])
 def test_hip_stage_functions_on_host_reproduce_reference_passes(case):
     """the product's device code (zr_stages.h, zr_rpt.h, zr_rdi.h, zr_sdi.h, zr_rgi.h) compiled for the host by tests/hostexec and run serially:
     catches a divergence from the reference's shaders without a GPU, incl. the dynamic-instance paths (previous BVH / mesh instances, MoveXk)"""

@@ -63,6 +63,7 @@ CASES = {
     "rpt_two_spatial": ("cornell_emissive", "rpt", 4, dict(spatial_passes=2), True),
     "rpt_two_spatial_materials": ("materials_lights", "rpt", 3, dict(spatial_passes=2, bounces=(6, 8)), False),
     "rpt_no_spatial": ("materials_lights", "rpt", 3, dict(spatial_passes=0), False),
+    "rpt_two_spatial_sun_sky": ("cornell", "rpt", 3, dict(spatial_passes=2), False),      # the NEE_EMISSIVE == 0 permutation (component-wise reservoir writes) through two rounds
     "gi_cornell_moving": ("cornell_emissive", "gi", 4, {}, True),
     "gi_materials_rr": ("materials_lights", "gi", 3, dict(bounces=(6, 8)), False),
     "gi_presampled": ("materials_lights", "gi", 3, dict(presample=(32, 128)), False),

@@ -59,6 +59,7 @@ EXPORTS = [
     "zr_pass_set_tonemap_lut", "zr_pass_halo_pack_all", "zr_pass_halo_unpack_all",
 ]
 STAGE_TEMPORAL, STAGE_SPATIAL, STAGE_ALL = 1, 2, 3
+STAGE_SPATIAL2 = 4          # ReSTIR PT, num_spatial_passes = 2 on tiles: the second round, behind one more HALO_POST_TEMPORAL exchange
 HALO_POST_TEMPORAL, HALO_FINAL = 0, 1
 HALO_DENOISE_INPUT, HALO_DENOISE_ITER = 2, 3                  # ZR_PASS_DENOISE on tiles (tiling.denoise_schedule): 40 / 16 B per pixel
 STAGE_DENOISE_TEMPORAL, STAGE_DENOISE_VARIANCE, STAGE_DENOISE_MASK = 1 << 8, 1 << 9, 0x3ff00

@@ -817,6 +817,7 @@ struct zr_pass
     DevBuf<uint16_t> rptMap[2];      // K12 thread maps: [0] CtN, [1] NtC
     DevBuf<uint32_t> trip; DevBuf<unsigned long long> tripStats;      // ZR_K11=trip diagnostic
     DevBuf<uint32_t> carry[2], carryCount;                             // K11 with per-bounce compaction: path-state planes (ping-pong), alive counts
+    bool frameOpen = false;      // ReSTIR PT staged rendering: a frame's TEMPORAL stage has run, its last stage has not
     DevBuf<uint32_t> costMap; bool costOn = false, costRays = false;      // rays per 32 x 32-px cell (zr_pass_enable_cost_map)
     DevBuf<uint32_t> rptLists, rptListCounts;      // 4 replay work lists (pixel ids) + their device-side counts
     // DI_EMISSIVE: two reservoir sets (A RGBA32_UINT, B RG32F), target, sample set
@@ -826,7 +827,7 @@ struct zr_pass
     DevBuf<F4> giA[2], giC[2]; DevBuf<uint16_t> giB[2];
     bool temporalValid = false, doTemporal = false, doSpatial = false; int currIdx = 0;
     const F4* compIn[4] = {nullptr, nullptr, nullptr, nullptr};     // COMPOSITING inputs (emissive DI, indirect, sky DI); [3] = TAA signal
-    DevBuf<F4> svgfHist, svgfAccum, svgfPing, svgfPong; DevBuf<float> svgfMoments[2], svgfGuideFw; DevBuf<F4> svgfGuide; int svgfMomIdx = 0; const F4* svgfOut = nullptr; F4* svgfCur = nullptr; uint32_t svgfStepsDone = 0;      // DENOISE
+    DevBuf<F4> svgfHist, svgfAccum, svgfPing, svgfPong; DevBuf<float> svgfMoments[2], svgfGuideFw; DevBuf<svgf::GuideN> svgfGuide; int svgfMomIdx = 0; const F4* svgfOut = nullptr; F4* svgfCur = nullptr; uint32_t svgfStepsDone = 0;      // DENOISE
     DevBuf<uint16_t> taaOut[2]; int taaIdx = 0;            // TAA: ping-pong RGBA16F outputs; taaIdx = the one written last
     // AUTO_EXPOSURE / DISPLAY
     const uint16_t* postIn16 = nullptr; const F4* postIn32 = nullptr; const float* exposureIn = nullptr;
@@ -2241,8 +2242,8 @@ static int RenderReSTIR_PT(zr_pass* p, hipStream_t s, const zr_frame_constants* 
     // m_numSpatialPasses (IndirectLighting.cpp:616-621, 1240): 0..2
     if (ip.num_spatial_passes > 2u) return Fail(ZR_ERR_INVALID_ARG, "ReSTIR PT: num_spatial_passes must be 0, 1 or 2");
     const uint32_t numSpatialPasses = ip.num_spatial_passes;
-    // the second round reads the first round's outputs at neighbouring pixels: a tile would need a third halo exchange between the rounds
-    if (numSpatialPasses == 2u && stages != ZR_STAGE_ALL) return Fail(ZR_ERR_UNSUPPORTED, "ReSTIR PT: num_spatial_passes = 2 is not available in staged (tile-split) rendering");
+    // staged (tile-split) rendering with two rounds: ZR_STAGE_SPATIAL runs the first, ZR_STAGE_SPATIAL2 the second -- it reads the first round's outputs at
+    // neighbouring pixels, so the host exchanges ZR_HALO_POST_TEMPORAL (= the set the next stage reads: res[currIdx]) once more in between
     prm.doTemporal = p->doTemporal ? 1u : 0u;
     prm.doSpatial = p->doSpatial ? 1u : 0u;
     prm.writeReservoirs = (prm.doTemporal || !p->temporalValid) ? 1u : 0u;
@@ -2332,9 +2333,11 @@ static int RenderReSTIR_PT(zr_pass* p, hipStream_t s, const zr_frame_constants* 
             RPT_TIMED("rpt_reconnect_temporal", RPT_LAUNCH_E(k_rpt_temporal, grid, block, 0, s, F, *cb, tilesX, ctr + 2 * 4));
         }
     }
-    if ((stages & ZR_STAGE_SPATIAL) && prm.doSpatial)
-    for (uint32_t spass = 0; spass < numSpatialPasses; spass++)
+    for (uint32_t spass = 0; spass < numSpatialPasses && prm.doSpatial; spass++)
     {
+        if (!(stages & (spass == 0 ? ZR_STAGE_SPATIAL : ZR_STAGE_SPATIAL2))) continue;
+        // a round reads res[currIdx] and writes the other set, which then becomes "current" (IndirectLighting.cpp:609-612, 682-688: one flip per round)
+        F.cur = p->res[p->currIdx].View(); F.prev = p->res[1 - p->currIdx].View();
         // replay work lists + their device-side counts of this round: {2, 3} for the first, {6, 7} for the second (zeroed at the start of the frame)
         uint32_t* const sCnt = listCnt + (spass == 0 ? 2 : 6);
         // ZR_SEARCH=tile: the LDS-tiled K15 (k_rpt_light<2>), kept for the A/B of DESIGN's N3 row -- measured slower than the plain gathers
@@ -2349,20 +2352,21 @@ static int RenderReSTIR_PT(zr_pass* p, hipStream_t s, const zr_frame_constants* 
         }
         RPT_TIMED("rpt_replay_spatial", RPT_LAUNCH_PE(k_rpt_replay, RPT_REPLAY_CTS, dim3(gridList.x * 2), block, 0, s, F, *cb, lists[2], lists[3], sCnt, ctr + 2 * 5));
         RPT_TIMED("rpt_reconnect_spatial", RPT_LAUNCH_E(k_rpt_stc, grid, block, 0, s, F, *cb, tilesX, ctr + 2 * 7));
-        // "Prepare for next iteration": the round's outputs become the next round's inputs (IndirectLighting.cpp:860-870: std::swap(inputs, outputs))
-        if (spass == 0 && numSpatialPasses == 2u) { const ResPlanes t = F.cur; F.cur = F.prev; F.prev = t; }
+        // "Prepare for next iteration" (IndirectLighting.cpp:860-870: std::swap(inputs, outputs)) is the flip itself here: the next round starts from res[currIdx]
+        p->currIdx = 1 - p->currIdx;
     }
 #undef RPT_TIMED
 #undef RPT_LAUNCH_E
 #undef RPT_LAUNCH_PE
     HIP_TRY(hipGetLastError());
-    if (stages & ZR_STAGE_SPATIAL)
+    if (stages & ZR_STAGE_TEMPORAL) p->frameOpen = true;
+    // the frame ends with its last stage: the second round when there is one this frame, else ZR_STAGE_SPATIAL; Render() flips once more (:1018-1024)
+    const bool lastStage = (prm.doSpatial && numSpatialPasses == 2u) ? (stages & ZR_STAGE_SPATIAL2) != 0 : (stages & ZR_STAGE_SPATIAL) != 0;
+    if (lastStage && p->frameOpen)
     {
-        // spatial read this frame's reservoirs and wrote the other set, which becomes "current"
-        // (IndirectLighting.cpp:609-612, 682-685); Render() flips once more (:1018-1024)
-        if (prm.doSpatial && (numSpatialPasses & 1u)) p->currIdx = 1 - p->currIdx;      // one flip per round (IndirectLighting.cpp:688)
         p->temporalValid = true;
         p->currIdx = 1 - p->currIdx;
+        p->frameOpen = false;
     }
     return ZR_OK;
 }
@@ -2439,7 +2443,7 @@ static int RenderIndirect(zr_pass* p, hipStream_t s, const zr_frame_constants* c
 }
 
 int zr_pass_render(zr_pass* p, void* stream, const zr_frame_constants* cb, const zr_scene* sc, zr_gbuffer* gb)
-{ return zr_pass_render_stage(p, stream, cb, sc, gb, ZR_STAGE_ALL); }
+{ return zr_pass_render_stage(p, stream, cb, sc, gb, ZR_STAGE_ALL | ZR_STAGE_SPATIAL2); }
 
 int zr_pass_set_input(zr_pass* p, int which, const void* dev)
 {
@@ -2759,7 +2763,7 @@ int zr_pass_render_stage(zr_pass* p, void* stream, const zr_frame_constants* cb,
 static int RenderStageInner(zr_pass* p, void* stream, const zr_frame_constants* cb, const zr_scene* sc, zr_gbuffer* gb, int stages)
 {
     if (!p || !cb || !sc) return Fail(ZR_ERR_INVALID_ARG, "zr_pass_render: null argument");
-    if (!(stages & (ZR_STAGE_ALL | (p && p->kind == ZR_PASS_DENOISE ? ZR_STAGE_DENOISE_MASK : 0)))) return Fail(ZR_ERR_INVALID_ARG, "no stage selected");
+    if (!(stages & (ZR_STAGE_ALL | ZR_STAGE_SPATIAL2 | (p && p->kind == ZR_PASS_DENOISE ? ZR_STAGE_DENOISE_MASK : 0)))) return Fail(ZR_ERR_INVALID_ARG, "no stage selected");
     if (!p->initialized) return Fail(ZR_ERR_NOT_INITIALIZED, "pass not initialised (zr_pass_init)");
     if (sc->device != p->device || (gb && gb->device != p->device)) return Fail(ZR_ERR_INVALID_ARG, "scene / gbuffer / pass live on different devices");
     HIP_TRY(hipSetDevice(p->device));

@@ -71,6 +71,9 @@ struct Window
     ZR_HDM size_t Idx(int x, int y) const { return (size_t)(y - oy) * (size_t)pw + (size_t)(x - ox); }
 };
 
+// the guide normal of a pixel as the planes hold it: h(n.x) | h(n.y) << 16, h(n.z)
+struct GuideN { uint32_t xy, z; };
+
 struct SvgfFrame
 {
     const F4* signal;                                        // RGBA32F noisy radiance of this frame
@@ -78,7 +81,7 @@ struct SvgfFrame
     const float* prevDepth; const uint32_t* prevNormal;      // the previous frame's
     const F4* histColor; const float* histMoments;           // previous frame: rgb + history length; (m1, m2) per pixel
     F4* accum; float* moments;                               // this frame's accumulated colour + length, moments (become the history)
-    F4* guide; float* guideFw;                               // (n.x, n.y, n.z, z): the variance stage's taps; fw, which only a stage's centre needs
+    GuideN* guide; float* guideFw;                           // h(n) of every pixel (8 B: what the variance stage reads next to the depth plane); fw, which only a stage's centre needs
     Window win; uint32_t temporalValid;
     SvgfParams prm;
 };
@@ -129,7 +132,7 @@ ZR_HD V3 SanitizeSignal(V3 c)
 }
 
 // guide planes of pixel (x, y)
-ZR_HD void MakeGuide(const float* depth, const uint32_t* normal, int x, int y, const Window& w, F4* guide, float* guideFw)
+ZR_HD void MakeGuide(const float* depth, const uint32_t* normal, int x, int y, const Window& w, GuideN* guide, float* guideFw)
 {
     const size_t i = w.Idx(x, y);
     const float z = depth[i];
@@ -143,7 +146,8 @@ ZR_HD void MakeGuide(const float* depth, const uint32_t* normal, int x, int y, c
         fw = zr_max(dx, dy);
     }
     const V3 n = DecodeOct32u(normal[i]);
-    guide[i] = f4(v3(RoundHalf(n.x), RoundHalf(n.y), RoundHalf(n.z)), z);
+    GuideN gn; gn.xy = HalfBits(n.x) | (HalfBits(n.y) << 16); gn.z = HalfBits(n.z);
+    guide[i] = gn;
     guideFw[i] = fw;
 }
 
@@ -234,8 +238,8 @@ struct FilterFrame
 {
     const F4* src;            // variance stage: rgb + history length (fp32); a-trous: the stage texels of PackStage, 16 B each, read through `srcP`
     const float* moments;     // variance stage only
-    const F4* guide; const float* guideFw;
-    const float* guideZ;      // the depth an a-trous tap reads next to its stage texel: the G-buffer's linear-depth plane itself
+    const GuideN* guide; const float* guideFw;
+    const float* guideZ;      // the depth a tap reads next to its normal / stage texel: the G-buffer's linear-depth plane itself
     F4* dst;                  // rgb + variance: fp32 when this is the pass's last stage, else stage texels (PackStage) written through `dstP`
     bool dstPacked;
     F4* history;              // != null: the filtered rgb also goes here with the history length of `lenSrc` (colour history of the next frame)
@@ -243,6 +247,9 @@ struct FilterFrame
     Window win; uint32_t step;
     SvgfParams prm;
 };
+
+ZR_HD F4 LoadGuide(const GuideN* guide, const float* depth, size_t i)
+{ const GuideN gn = guide[i]; return f4(v3(HalfValue(gn.xy & 0xffffu), HalfValue(gn.xy >> 16), HalfValue(gn.z & 0xffffu)), depth[i]); }
 
 // 1 / sqrt(dx^2 + dy^2) for the 7 x 7 stencil of the variance stage: the correctly rounded 1.0f / sqrtf((float)n), n = 0 .. 18, as fp32 literals (the loops
 // are real loops there -- the stage's neighbourhood path only runs for pixels with a short history -- and a run-time sqrt + divide per tap would
@@ -261,7 +268,7 @@ ZR_HD void VariancePixelT(const FilterFrame& F, int x, int y)
     const Window& w = F.win;
     const size_t i = w.Idx(x, y);
     const F4 a = F.src[i];
-    const F4 g = F.guide[i];
+    const F4 g = LoadGuide(F.guide, F.guideZ, i);
     const float z = g.w, len = a.w;
     V3 c = v3(a.x, a.y, a.z);
     float m1 = F.moments[2 * i], m2 = F.moments[2 * i + 1];
@@ -284,7 +291,7 @@ ZR_HD void VariancePixelT(const FilterFrame& F, int x, int y)
                 const int qx = x + dx;
                 const bool in = iny && qx >= w.ox && qx < w.ox + w.pw;
                 const size_t j = row + (size_t)(w.ClampX(qx) - w.ox);
-                const F4 gq = F.guide[j];
+                const F4 gq = LoadGuide(F.guide, F.guideZ, j);
                 const float zq = gq.w;
                 const float wz = zr_abs(z - zq) * (rz * RcpLen(dx, dy));
                 const float wv = Falloff(wz) * NormalWeightT<POW>(n, v3(gq.x, gq.y, gq.z), F.prm.normalPowerLog2);

@@ -181,6 +181,9 @@ class TiledRestirPT:
         from . import api
         self.api, self.torch, self.dist = api, torch, dist
         self.kind = kind
+        # ReSTIR PT with two spatial rounds (IndirectLighting::m_numSpatialPasses = 2): the second round reads the first one's outputs at neighbouring
+        # pixels, so it is its own stage behind one more exchange of the set the next stage reads
+        self.two_spatial_rounds = kind == "restir_pt" and params is not None and int(params.num_spatial_passes) == 2
         self.W, self.H, self.world, self.rank = width, height, world, rank
         self.layout = layout
         self.tile = tile_rect(width, height, world, rank, layout)
@@ -348,6 +351,9 @@ class TiledRestirPT:
     def stage_spatial(self, cb):
         self.hp.render_stage(cb, self.r.scene, self.r.gbuffer, self.api.STAGE_SPATIAL)
 
+    def stage_spatial2(self, cb):
+        self.hp.render_stage(cb, self.r.scene, self.r.gbuffer, self.api.STAGE_SPATIAL2)
+
     # which exchanges a frame of this kind needs: (post-temporal, final)
     EXCHANGES = {"restir_pt": (True, True), "restir_gi": (False, True), "di": (True, False), "sky_di": (True, False)}
 
@@ -366,6 +372,9 @@ class TiledRestirPT:
         if post:
             self.exchange(self.api.HALO_POST_TEMPORAL)
         self.stage_spatial(cb)
+        if self.two_spatial_rounds:
+            self.exchange(self.api.HALO_POST_TEMPORAL)
+            self.stage_spatial2(cb)
         if getattr(self, "p_denoise", None) is not None:
             self.denoise(cb)
         self._frames_rendered += 1
@@ -477,6 +486,10 @@ def render_frame_in_process(ranks, cb, exchange_final=True):
         exchange_in_process(ranks, api.HALO_POST_TEMPORAL); n += 1
     for r in ranks:
         r.stage_spatial(cb)
+    if ranks[0].two_spatial_rounds:
+        exchange_in_process(ranks, api.HALO_POST_TEMPORAL); n += 1
+        for r in ranks:
+            r.stage_spatial2(cb)
     if getattr(ranks[0], "p_denoise", None) is not None:
         # every tile runs the same schedule: the steps between two exchanges on every tile, then the exchange among them
         for k, (kind, v) in enumerate(ranks[0]._dn_sched):
