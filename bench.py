@@ -51,10 +51,10 @@ RPT_PIXEL_BYTES = {
 }
 
 
-# the denoise pass (zr_svgf.h), algorithmic bytes per pixel and launch: temporal = signal 16 + depth / normal / motion 12 + previous depth / normal 8 +
-# history colour 16 + moments 8 in, accumulated 16 + moments 8 + guide 16 out; variance = 16 + 8 + 16 in, 16 out; one a-trous iteration = colour 16
-# + guide 16 in, 16 out (the 24 neighbour taps are re-reads of what other pixels load once: cache hits in the model)
-DENOISE_PIXEL_BYTES = {"denoise_temporal": 60 + 40, "denoise_variance": 40 + 16, "denoise_atrous": 32 + 16}
+# the denoise pass (zr_svgf.h, definition 3), algorithmic bytes per pixel and launch: temporal = signal 16 + depth / normal / motion 12 + previous depth / normal 8 +
+# history colour 16 + moments 8 in, accumulated 16 + moments 8 + guide normal 8 + depth slope 4 out; variance = accumulated 16 + moments 8 + guide normal 8 in, stage texel 16 out;
+# one a-trous iteration = stage texel 16 + depth 4 in, 16 out (the 24 neighbour taps are re-reads of what other pixels load once: cache hits in the model)
+DENOISE_PIXEL_BYTES = {"denoise_temporal": 60 + 36, "denoise_variance": 32 + 16, "denoise_atrous": 20 + 16}
 
 
 from zetaray_amd.tiling import tile_grid, tile_rect  # noqa: E402  (shared with the tests and the tiled renderer)

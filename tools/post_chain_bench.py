@@ -11,7 +11,7 @@ from zetaray_amd import api, scene_io, wire
 BYTES = {"compositing": 16 + 4 + 2 + 16,                 # indirect in, base colour + flags of the G-buffer, composited out (DI terms absent here)
          "firefly_filter": 16 + 16,                           # composited in, filtered out (5 x 5 taps from an LDS tile)
          "taa": 16 + 4 + 4 + 8 + 8,                    # signal, depth, motion, history in; RGBA16F out
-         "denoise_temporal": 60 + 40, "denoise_variance": 40 + 16, "denoise_atrous": 32 + 16}
+         "denoise_temporal": 60 + 36, "denoise_variance": 32 + 16, "denoise_atrous": 20 + 16}      # definition 3 of zr_svgf.h (bench.py DENOISE_PIXEL_BYTES)
 W, H = 3840, 2160
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sc = scene_io.load_npz(os.path.join(root, "tests", "golden", "cornell_emissive.npz"))
