@@ -39,6 +39,7 @@ struct HxScene
     // zhx_scene_update_instances: last frame's instance buffer + BVH (what the CtT / temporal-shift stages bind)
     std::vector<zr_mesh_instance> instancesPrev; BuiltBvh bvhPrev; bool hasPrev = false;
     std::vector<uint8_t> mask; std::vector<uint32_t> numTris;
+    std::vector<uint8_t> ownSubtree;      // zhx_scene_set_own_subtree: instances the next rebuild keeps in subtrees of their own (zr_bvh.h Build)
     SceneView PrevView() const
     {
         SceneView v = view;
@@ -125,11 +126,12 @@ void zhx_scene_update_instances(HxScene* s, const zr_mesh_instance* instances, c
     d.vertices = s->vertices.data(); d.num_vertices = (uint32_t)s->vertices.size(); d.indices = s->indices.data(); d.num_indices = (uint32_t)s->indices.size();
     d.instances = s->instances.data(); d.num_instances = n; d.instance_to_world = instance_to_world; d.instance_mask = s->mask.data(); d.instance_num_tris = s->numTris.data();
     BvhBuilder b;
-    s->bvh = b.Build(d);
+    s->bvh = b.Build(d, s->ownSubtree.size() == n ? s->ownSubtree.data() : nullptr);
     SceneView& v = s->view;
     v.instances = s->instances.data(); v.nodes = s->bvh.nodes4.data(); v.tris = s->bvh.tris.data(); v.triMeta = s->bvh.meta.data();
     v.numNodes = (uint32_t)s->bvh.nodes4.size(); v.numTris = (uint32_t)s->bvh.tris.size();
 }
+void zhx_scene_set_own_subtree(HxScene* s, const uint8_t* flags, uint32_t n) { s->ownSubtree.assign(flags, flags + n); }
 void zhx_scene_destroy(HxScene* s) { delete s; }
 void zhx_scene_set_alias(HxScene* s, const zr_alias_entry* e, uint32_t n) { s->alias.assign(e, e + n); s->view.alias = s->alias.data(); }
 void zhx_bvh_info(const HxScene* s, uint32_t* nodes, uint32_t* tris, uint32_t* depth)

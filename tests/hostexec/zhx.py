@@ -95,6 +95,13 @@ class HostExecScene:
         i, x = np.ascontiguousarray(instances), np.ascontiguousarray(instance_to_world, np.float32)
         L.zhx_scene_update_instances(self.h, i.ctypes.data, x.ctypes.data, len(i))
 
+    def set_own_subtree(self, flags):
+        """instances the next update_instances rebuild keeps in subtrees of their own (what the product's background rebuild does for instances that moved)"""
+        L = lib()
+        L.zhx_scene_set_own_subtree.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32]
+        f = np.ascontiguousarray(flags, np.uint8)
+        L.zhx_scene_set_own_subtree(self.h, f.ctypes.data, len(f))
+
     def update_emissives(self, triangles, first=0):
         L = lib()
         L.zhx_scene_update_emissives.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32]

@@ -322,3 +322,43 @@ def test_window_parity_machinery_against_a_full_frame_host_executor(cornell_emis
         prev = cb.copy()
         want = o.render(cb, prm)
     assert np.array_equal(full.r.final.view(np.uint32), want.view(np.uint32))
+
+
+def test_moved_instances_in_subtrees_of_their_own():
+    """zr_bvh.h Build(ownSubtree): what the product's background rebuild does once an instance has moved (the reference's static -> dynamic BLAS
+    conversion, SceneCore.cpp:1038) -- its triangles leave the common SAH tree for a subtree of their own, joined near the root.  Host-executed HIP
+    stage functions through such trees (one and two instances on their own, then every instance) == oracle over three frames of motion: hits do not
+    depend on the tree.  Each of the three trees differs from the common one and from the others."""
+    sc = scene_io.make_synthetic_scene(num_tris=3000, num_emissive=150, seed=11)
+    osc = zro.OracleScene(sc, force_bvh=True)
+    hx = zhx.HostExecScene(sc, osc.alias)
+    common = hx.bvh_digest()
+    w, h = 48, 32
+    prm = wire.default_params()
+    o, x = zro.OracleRPT(osc, w, h), zhx.HostExecRPT(hx, w, h)
+    cand = sorted((i for i in range(1, len(sc.instances)) if sc.instance_mask[i] & wire.SUBGROUP_NON_EMISSIVE), key=lambda i: -int(sc.instance_num_tris[i]))
+    t0, xf = {i: sc.instances["translation"][i].copy() for i in cand[:2]}, {}
+    own_sets = {2: cand[:1], 3: cand[:2], 4: range(len(sc.instances))}
+    prev, digests = None, set()
+    for f in range(1, 5):
+        if f >= 2:
+            for k, i in enumerate(cand[:2]):
+                ang = 0.1 * (f - 1) * (k + 1)
+                scene_io.move_instance(sc, i, translation=t0[i] + np.float32([0.05 * (f - 1), 0.02 * k, -0.03 * (f - 1)]),
+                                       rotation=np.array([0.0, np.sin(ang / 2), 0.0, np.cos(ang / 2)], np.float32), xform_of=xf)
+            own = np.zeros(len(sc.instances), np.uint8)
+            own[list(own_sets[f])] = 1
+            hx.set_own_subtree(own)
+            hx.update_instances(sc.instances, sc.instance_to_world)
+            osc.update_instances(sc.instances, sc.instance_to_world)
+            d = hx.bvh_digest()
+            assert d[2] == common[2] and d[0] != common[0]
+            digests.add(d[0])
+        cb = _cb(sc, w, h, f, cam_pos=(0, 0, -3.5))
+        if prev is not None:
+            cb["prev_view"], cb["prev_view_inv"], cb["prev_camera_jitter"] = prev["curr_view"], prev["curr_view_inv"], prev["curr_camera_jitter"]
+        prev = cb.copy()
+        a, b = o.render(cb, prm), x.render(cb, prm)
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), f"frame {f}"
+        _assert_same_state(o, x, f)
+    assert len(digests) == 3

@@ -593,16 +593,28 @@ struct zr_scene
     // on, an update that finds no build in flight snapshots the new transforms and starts the host's binned-SAH builder on a thread; the first update
     // after it has finished uploads the new topology into the buffer set that is about to become current and refits THAT to the transforms of the
     // update at hand.  No render waits, no result depends on the tree (include/zr_intersect.h's tie-break), the previous structure stays what it was.
+    // What the build thread hands over is the TOPOLOGY only, packed in pinned memory by the thread itself: [4 child references per node | the scene
+    // triangle each leaf slot holds | node ids level by level] -- 3.6 MB for the 380 k-triangle atrium, where whole node + triangle arrays are 24.8 MB.
+    // Everything else in a node (origin, scales, quantised planes) and in a triangle slot (vertices, mask, ID) is recomputed on the device for the
+    // transforms of the installing update (k_install_topology, then the refit kernels), so the installing update costs the host three async copies.
     struct Background
     {
         bool enabled = false; std::thread th; std::atomic<int> state{0};      // 0 idle, 1 building, 2 built
-        BuiltBvh bvh; std::vector<uint32_t> levelOrder, levelOffsets;
-        std::vector<zr_mesh_instance> inst; std::vector<float> xf;
+        std::vector<uint32_t> levelOffsets;
+        uint32_t numNodes = 0, numTris = 0, stackNeed = 0, maxDepth = 0; bool packed = false;
+        uint32_t* pkg = nullptr; size_t pkgCap = 0; hipEvent_t pkgCopied = nullptr; bool pkgInFlight = false;      // pkgCap in words
+        std::vector<zr_mesh_instance> inst; std::vector<float> xf; std::vector<uint8_t> own;
         uint32_t refitsSince = 0; uint64_t started = 0, installed = 0;
+        double buildMs = 0, packMs = 0;
     } bg;
+    DevBuf<uint32_t> bgDev;                      // device side of the package (children + slot triangles)
+    // instances whose transform has ever changed: the background build gives each a subtree of its own (zr_bvh.h Build, ownSubtree)
+    std::vector<float> hToWorld; std::vector<uint8_t> movedEver;
     ~zr_scene()
     {
         if (bg.th.joinable()) bg.th.join();
+        if (bg.pkg) (void)hipHostFree(bg.pkg);
+        if (bg.pkgCopied) (void)hipEventDestroy(bg.pkgCopied);
         for (StageSlot& t : stage) { if (t.ev) (void)hipEventDestroy(t.ev); if (t.host) (void)hipHostFree(t.host); }
         if (updated) (void)hipEventDestroy(updated);
         for (auto& u : users) (void)hipEventDestroy(u.second);
@@ -965,6 +977,28 @@ __global__ void __launch_bounds__(256) k_refit_tris(BvhTri* tris, uint32_t n, co
     for (int r = 0; r < 3; r++) { t.v0[r] = w[0][r]; t.e1[r] = w[1][r] - w[0][r]; t.e2[r] = w[2][r] - w[0][r]; }
     tris[i] = t;
 }
+// A tree built in the background arrives as topology only (zr_scene::Background): child references per node, scene triangle per leaf slot.  The
+// slot's constant words are the builder's (zr_bvh.h Build: mask of the instance, hashed triangle ID); vertices follow in k_refit_tris, boxes in k_refit_level.
+__global__ void __launch_bounds__(256) k_install_topology(Bvh4Node* nodes, const uint32_t* children, uint32_t numNodes, BvhTri* tris, const uint32_t* slotTri, uint32_t numTris,
+    const TriMeta* meta, const uint8_t* instanceMask)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < numNodes)
+    {
+        const uint4 c = ((const uint4*)children)[i];
+        Bvh4Node N; N.ox = N.oy = N.oz = 0.0f; N.exps = 0; N.child[0] = c.x; N.child[1] = c.y; N.child[2] = c.z; N.child[3] = c.w;
+        N.qlox = N.qloy = N.qloz = N.qhix = N.qhiy = N.qhiz = 0; N.pad0 = 0; N.pad1 = 0;
+        nodes[i] = N;
+    }
+    if (i < numTris)
+    {
+        const uint32_t g = slotTri[i];
+        const TriMeta tm = meta[g];
+        BvhTri t; for (int r = 0; r < 3; r++) { t.v0[r] = 0.0f; t.e1[r] = 0.0f; t.e2[r] = 0.0f; }
+        t.gidx = g; t.mask = instanceMask[tm.mesh]; t.id = TriID(tm.mesh, tm.prim);
+        tris[i] = t;
+    }
+}
 // bounds of leaf `c` (1-ulp padded like the builder's, since v0 + e1 is a rounded v1)
 __device__ __forceinline__ void LeafBounds(const BvhTri* tris, uint32_t c, float lo[3], float hi[3])
 {
@@ -1250,6 +1284,7 @@ int zr_scene_create(int device, const zr_scene_desc* d, zr_scene** out)
     { const char* e = getenv("ZR_SCENE_UPDATE"); s->bg.enabled = e && !strcmp(e, "refit_sah"); }      // (zr_scene_set_background_rebuild for every scene of the process)
     s->hVertices.assign(d->vertices, d->vertices + d->num_vertices); s->hIndices.assign(d->indices, d->indices + d->num_indices);
     s->hMask.assign(d->instance_mask, d->instance_mask + d->num_instances); s->hNumTris.assign(d->instance_num_tris, d->instance_num_tris + d->num_instances);
+    s->hToWorld.assign(d->instance_to_world, d->instance_to_world + 12 * (size_t)d->num_instances); s->movedEver.assign(d->num_instances, 0);
     BvhLevels(bvh.nodes4, s->hLevelOrder, s->levelOffsets);
     if (!s->hLevelOrder.empty() && (r = s->levelNodes.Upload(s->hLevelOrder.data(), s->hLevelOrder.size()))) { delete s; return r; }
     if (deviceBuild)
@@ -1350,6 +1385,9 @@ int zr_scene_update_instances_async(zr_scene* s, void* stream, const zr_mesh_ins
     bool rebuild = modeEnv && !std::strcmp(modeEnv, "rebuild");
     int r;
     for (uint32_t i = 0; i < n; i++) RaiseMaxTex(s, 0, instances[i].base_color_tex);
+    for (uint32_t i = 0; i < n; i++)      // the reference's static -> dynamic conversion of an instance that starts to move (SceneCore.cpp:1038)
+        if (std::memcmp(s->hToWorld.data() + 12 * (size_t)i, instance_to_world + 12 * (size_t)i, 12 * sizeof(float))) s->movedEver[i] = 1;
+    std::memcpy(s->hToWorld.data(), instance_to_world, 12 * (size_t)n * sizeof(float));
     const bool rebuildHost = modeEnv && !std::strcmp(modeEnv, "rebuild_host");
     if (rebuild && s->meta.n > BvhBuilder::kTinyScene)
     {
@@ -1417,8 +1455,8 @@ int zr_scene_update_instances_async(zr_scene* s, void* stream, const zr_mesh_ins
     }
     // ---- refit on the device, stream-ordered: nothing below waits on the host (the staging ring aside, when the host runs far ahead)
     // background SAH rebuild: is a finished tree waiting to be installed by this update?
-    const bool install = s->bg.enabled && s->bg.state.load(std::memory_order_acquire) == 2 && s->bg.inst.size() == n &&
-                         s->bg.bvh.tris.size() == s->view.numTris && s->bg.bvh.stackNeed + 1 <= (uint32_t)kTravStack;
+    const bool install = s->bg.enabled && s->bg.state.load(std::memory_order_acquire) == 2 && s->bg.packed && s->bg.inst.size() == n &&
+                         s->bg.numTris == s->view.numTris && s->bg.stackNeed + 1 <= (uint32_t)kTravStack;
     if (s->bg.enabled && s->bg.state.load(std::memory_order_acquire) == 2 && !install)
     {   // a tree that cannot be used (the scene changed shape under it, or it is too deep for the traversal stack): drop it
         if (s->bg.th.joinable()) s->bg.th.join();
@@ -1428,9 +1466,11 @@ int zr_scene_update_instances_async(zr_scene* s, void* stream, const zr_mesh_ins
     if (s->bg.enabled)
     {   // both buffer sets must be able to hold any topology over these triangles (a BVH4 over nt triangles has < nt nodes): grown once, with their contents
         const size_t cap = s->view.numTris;
-        if (s->nodes.n < cap || (s->refitReady && s->nodesPrev.n < cap) || s->levelNodes.n < cap || s->nodeBounds.n < 6 * cap)
+        if (s->nodes.n < cap || (s->refitReady && s->nodesPrev.n < cap) || s->levelNodes.n < cap || s->nodeBounds.n < 6 * cap || s->bgDev.n < 5 * cap || !s->dMask.p)
         {
             HIP_TRY(hipDeviceSynchronize());
+            if (!s->dMask.p && (r = s->dMask.Upload(s->hMask.data(), s->hMask.size()))) return r;
+            if (s->bgDev.n < 5 * cap && (r = s->bgDev.Alloc(5 * cap))) return r;      // 4 child words per node (< cap nodes) + one word per triangle slot
             auto grow = [&](auto& buf, size_t count, size_t keep) -> int {
                 if (buf.n >= count) return ZR_OK;
                 std::remove_reference_t<decltype(buf)> nb; int rr = nb.Alloc(count); if (rr) return rr;
@@ -1474,23 +1514,20 @@ int zr_scene_update_instances_async(zr_scene* s, void* stream, const zr_mesh_ins
         // the background build's topology goes into the set that has just become current (last frame's "previous": nobody needs it any more);
         // its triangles and boxes are then computed for THIS update's transforms by the refit kernels below, like any other frame's
         zr_scene::Background& B = s->bg;
-        // (the triangle array carries the tree's leaf order: BvhTri::gidx names the scene triangle a slot holds, and k_refit_tris re-transforms slot i
-        // from meta[gidx] -- meta itself is in scene order and does not change)
-        const size_t nodeBytes = B.bvh.nodes4.size() * sizeof(Bvh4Node), triBytes = B.bvh.tris.size() * sizeof(BvhTri), lvlBytes = B.levelOrder.size() * sizeof(uint32_t);
-        zr_scene::StageSlot* tb;
-        if ((r = StageAcquire(s, nodeBytes + triBytes + lvlBytes, &tb))) return r;
-        memcpy(tb->host, B.bvh.nodes4.data(), nodeBytes); memcpy((char*)tb->host + nodeBytes, B.bvh.tris.data(), triBytes); memcpy((char*)tb->host + nodeBytes + triBytes, B.levelOrder.data(), lvlBytes);
-        HIP_TRY(hipMemcpyAsync(s->nodes.p, tb->host, nodeBytes, hipMemcpyHostToDevice, st));
-        HIP_TRY(hipMemcpyAsync(s->tris.p, (char*)tb->host + nodeBytes, triBytes, hipMemcpyHostToDevice, st));
-        HIP_TRY(hipMemcpyAsync(s->levelNodes.p, (char*)tb->host + nodeBytes + triBytes, lvlBytes, hipMemcpyHostToDevice, st));
-        if ((r = StageCommit(tb, st))) return r;
-        s->hLevelOrder = B.levelOrder; s->levelOffsets = B.levelOffsets;
-        numNodesNow = (uint32_t)B.bvh.nodes4.size();
-        if (B.bvh.maxDepth > s->maxDepth) s->maxDepth = B.bvh.maxDepth;
+        const size_t devWords = 4 * (size_t)B.numNodes + B.numTris;
+        if (!B.pkgCopied) HIP_TRY(hipEventCreateWithFlags(&B.pkgCopied, hipEventDisableTiming));
+        HIP_TRY(hipMemcpyAsync(s->bgDev.p, B.pkg, devWords * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+        HIP_TRY(hipMemcpyAsync(s->levelNodes.p, B.pkg + devWords, (size_t)B.numNodes * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+        HIP_TRY(hipEventRecord(B.pkgCopied, st)); B.pkgInFlight = true;      // the next build's thread waits for it before it overwrites the package
+        hipLaunchKernelGGL(k_install_topology, dim3((uint32_t)((std::max<size_t>(B.numNodes, B.numTris) + 255) / 256)), dim3(256), 0, st,
+            s->nodes.p, s->bgDev.p, B.numNodes, s->tris.p, s->bgDev.p + 4 * (size_t)B.numNodes, B.numTris, s->meta.p, s->dMask.p);
+        s->hLevelOrder.assign(B.pkg + devWords, B.pkg + devWords + B.numNodes); s->levelOffsets = B.levelOffsets;
+        numNodesNow = B.numNodes;
+        if (B.maxDepth > s->maxDepth) s->maxDepth = B.maxDepth;
         s->refitReady = false;      // the two sets hold different topologies now: the next update duplicates this one first
         s->deviceBuilt = false;
         B.installed++; B.refitsSince = 0;
-        B.bvh = BuiltBvh(); B.state.store(0, std::memory_order_release);
+        B.state.store(0, std::memory_order_release);
     }
     else if (s->bg.enabled) s->bg.refitsSince++;
     hipLaunchKernelGGL(k_refit_tris, dim3((uint32_t)((nt + 255) / 256)), dim3(256), 0, st, s->tris.p, (uint32_t)nt, s->meta.p, s->instances.p, s->toWorld.p, s->vertices.p, s->indices.p);
@@ -1511,16 +1548,47 @@ int zr_scene_update_instances_async(zr_scene* s, void* stream, const zr_mesh_ins
         zr_scene::Background& B = s->bg;
         if (B.th.joinable()) B.th.join();
         B.inst.assign(instances, instances + n); B.xf.assign(instance_to_world, instance_to_world + 12 * (size_t)n);
+        { const char* e = std::getenv("ZR_BVH_GROUP"); if (e && !std::strcmp(e, "0")) B.own.clear(); else B.own = s->movedEver; }
         B.state.store(1, std::memory_order_release); B.started++;
         zr_scene* sp = s;
         B.th = std::thread([sp] {
             zr_scene::Background& Q = sp->bg;
+            const auto t0 = std::chrono::steady_clock::now();
             zr_scene_desc d; memset(&d, 0, sizeof(d));
             d.vertices = sp->hVertices.data(); d.num_vertices = (uint32_t)sp->hVertices.size(); d.indices = sp->hIndices.data(); d.num_indices = (uint32_t)sp->hIndices.size();
             d.instances = Q.inst.data(); d.num_instances = (uint32_t)Q.inst.size(); d.instance_to_world = Q.xf.data(); d.instance_mask = sp->hMask.data(); d.instance_num_tris = sp->hNumTris.data();
             BvhBuilder builder;
-            Q.bvh = builder.Build(d);
-            BvhLevels(Q.bvh.nodes4, Q.levelOrder, Q.levelOffsets);
+            BuiltBvh bvh = builder.Build(d, Q.own.empty() ? nullptr : Q.own.data());
+            std::vector<uint32_t> levelOrder;
+            BvhLevels(bvh.nodes4, levelOrder, Q.levelOffsets);
+            const auto t1 = std::chrono::steady_clock::now();
+            // pack the topology into pinned memory (this thread's time, not the installing update's)
+            const size_t nn = bvh.nodes4.size(), nt = bvh.tris.size(), words = 5 * nn + nt;
+            Q.packed = false;
+            if (hipSetDevice(sp->device) == hipSuccess)
+            {
+                if (Q.pkgInFlight) { (void)hipEventSynchronize(Q.pkgCopied); Q.pkgInFlight = false; }      // the previous package's copies have left the buffer
+                if (Q.pkgCap < words)
+                {
+                    if (Q.pkg) { (void)hipHostFree(Q.pkg); Q.pkg = nullptr; Q.pkgCap = 0; }
+                    void* h = nullptr;
+                    if (hipHostMalloc(&h, (words + words / 8) * sizeof(uint32_t), hipHostMallocDefault) == hipSuccess) { Q.pkg = (uint32_t*)h; Q.pkgCap = words + words / 8; }
+                    else (void)hipGetLastError();
+                }
+                if (Q.pkg)
+                {
+                    uint32_t* w = Q.pkg;
+                    for (size_t i = 0; i < nn; i++) for (int c = 0; c < 4; c++) *w++ = bvh.nodes4[i].child[c];
+                    for (size_t i = 0; i < nt; i++) *w++ = bvh.tris[i].gidx;
+                    std::memcpy(w, levelOrder.data(), nn * sizeof(uint32_t));
+                    Q.packed = true;
+                }
+            }
+            Q.numNodes = (uint32_t)nn; Q.numTris = (uint32_t)nt; Q.stackNeed = bvh.stackNeed; Q.maxDepth = bvh.maxDepth;
+            Q.buildMs = std::chrono::duration<double, std::milli>(t1 - t0).count();
+            Q.packMs = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t1).count();
+            if (std::getenv("ZR_BVH_TIMING"))
+                std::fprintf(stderr, "[zr_scene] background tree: %zu nodes over %zu triangles, build %.1f ms, package (%.1f MB pinned) %.1f ms\n", nn, nt, Q.buildMs, words * 4e-6, Q.packMs);
             Q.state.store(2, std::memory_order_release);
         });
     }

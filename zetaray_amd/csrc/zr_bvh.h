@@ -63,7 +63,13 @@ public:
     int threads_ = 1;
     uint32_t sweepBelow_ = 0;      // ranges of fewer triangles than this are split by an exact SAH sweep instead of 16 bins
 
-    BuiltBvh Build(const zr_scene_desc& d)
+    // ownSubtree (optional, one byte per instance): instances flagged here are kept out of the common SAH tree and get a subtree of their own, joined
+    // to the rest near the root -- the flat-tree form of the reference's TLAS over one static BLAS and one BLAS per dynamic instance
+    // (RtAccelerationStructure.cpp:121 StaticBLAS::Rebuild, :807 TLAS::BuildDynamicBLASes, :1484 TLAS::RebuildTLAS; an instance that starts to move is
+    // converted by SceneCore::ConvertInstanceDynamic, SceneCore.cpp:1038, and TLAS::UpdateFrameMeshInstances_StaticToDynamic, :508).  A rigid motion of such an instance then moves a subtree of triangles that
+    // belong together: the device refit (zr_api.hip k_refit_level) keeps its boxes tight, where the same motion inside a common tree inflates every
+    // node that mixes the mover's triangles with static ones.  Closest hits and any-hit answers do not depend on the tree, so results are unchanged.
+    BuiltBvh Build(const zr_scene_desc& d, const uint8_t* ownSubtree = nullptr)
     {
         BuiltBvh out;
         // ---- flatten instances -> world-space triangles (global order = instance order, then primitive order)
@@ -116,7 +122,10 @@ public:
         soup_ = &soup; out_ = &out;
         nodeCount_.store(1); maxDepth_.store(0); spare_.store(threads_ - 1);
         const auto t0 = std::chrono::steady_clock::now();
-        BuildInternal(0, 0, N, 1);
+        std::vector<Group> groups;
+        if (ownSubtree) MakeGroups(d, ownSubtree, groups);
+        if (groups.size() >= 2) BuildGroups(groups.data(), (uint32_t)groups.size(), 0, 1);
+        else BuildInternal(0, 0, N, 1);
         const auto t1 = std::chrono::steady_clock::now();
         out.nodes.resize(nodeCount_.load());
         out.maxDepth = maxDepth_.load();
@@ -216,6 +225,67 @@ private:
     }
 
     static float ScaleOf(uint32_t biasedExp) { uint32_t u = biasedExp << 23; float f; std::memcpy(&f, &u, 4); return f; }
+
+    // ---- instances with a subtree of their own (Build's ownSubtree)
+    struct Group { uint32_t first, count, order; float bmin[3], bmax[3]; };
+    // bt_ arrives in scene order (instance by instance); rearranged to [all triangles of unflagged instances | flagged instance | flagged instance ...]
+    void MakeGroups(const zr_scene_desc& d, const uint8_t* own, std::vector<Group>& groups)
+    {
+        std::vector<BuildTri> re; re.reserve(bt_.size());
+        std::vector<uint32_t> base(d.num_instances + 1, 0u);
+        for (uint32_t i = 0; i < d.num_instances; i++) base[i + 1] = base[i] + d.instance_num_tris[i];
+        auto add = [&](uint32_t first) {
+            const uint32_t count = (uint32_t)re.size() - first;
+            if (!count) return;
+            Group g; g.first = first; g.count = count; g.order = (uint32_t)groups.size();
+            for (int r = 0; r < 3; r++) { g.bmin[r] = 3.402823466e+38f; g.bmax[r] = -3.402823466e+38f; }
+            for (uint32_t k = first; k < first + count; k++) Grow(g.bmin, g.bmax, re[k].bmin, re[k].bmax);
+            groups.push_back(g); };
+        for (uint32_t i = 0; i < d.num_instances; i++) if (!own[i]) re.insert(re.end(), bt_.begin() + base[i], bt_.begin() + base[i + 1]);
+        add(0);
+        for (uint32_t i = 0; i < d.num_instances; i++)
+            if (own[i]) { const uint32_t first = (uint32_t)re.size(); re.insert(re.end(), bt_.begin() + base[i], bt_.begin() + base[i + 1]); add(first); }
+        bt_.swap(re);
+    }
+    uint32_t GroupChild(Group* g, uint32_t n, uint32_t depth)
+    {
+        if (n == 1) return BuildChild(g[0].first, g[0].count, depth);
+        const uint32_t idx = nodeCount_.fetch_add(1);
+        BuildGroups(g, n, idx, depth + 1);
+        return idx;
+    }
+    // the tree ABOVE the groups: exact SAH sweep over the groups' boxes along each axis, a group weighing its triangle count (there are few groups)
+    void BuildGroups(Group* g, uint32_t n, uint32_t nodeIdx, uint32_t depth)
+    {
+        float bestC = 3.402823466e+38f; int bAxis = 0; uint32_t bK = n / 2;
+        std::vector<float> rightArea(n); std::vector<uint32_t> rightN(n);
+        auto byAxis = [](int axis) { return [axis](const Group& a, const Group& b) {
+            const float ca = a.bmin[axis] + a.bmax[axis], cb = b.bmin[axis] + b.bmax[axis]; return ca < cb || (ca == cb && a.order < b.order); }; };
+        for (int axis = 0; axis < 3; axis++)
+        {
+            std::sort(g, g + n, byAxis(axis));
+            float lo[3] = {3.402823466e+38f, 3.402823466e+38f, 3.402823466e+38f}, hi[3] = {-3.402823466e+38f, -3.402823466e+38f, -3.402823466e+38f};
+            uint32_t cnt = 0;
+            for (uint32_t i = n; i-- > 1;) { Grow(lo, hi, g[i].bmin, g[i].bmax); cnt += g[i].count; rightArea[i] = Area(lo, hi); rightN[i] = cnt; }
+            for (int r = 0; r < 3; r++) { lo[r] = 3.402823466e+38f; hi[r] = -3.402823466e+38f; }
+            cnt = 0;
+            for (uint32_t k = 1; k < n; k++)
+            {
+                Grow(lo, hi, g[k - 1].bmin, g[k - 1].bmax); cnt += g[k - 1].count;
+                const float c = Area(lo, hi) * (float)cnt + rightArea[k] * (float)rightN[k];
+                if (c < bestC) { bestC = c; bAxis = axis; bK = k; }
+            }
+        }
+        std::sort(g, g + n, byAxis(bAxis));
+        float lmin[3], lmax[3], rmin[3], rmax[3];
+        for (int r = 0; r < 3; r++) { lmin[r] = rmin[r] = 3.402823466e+38f; lmax[r] = rmax[r] = -3.402823466e+38f; }
+        for (uint32_t i = 0; i < bK; i++) Grow(lmin, lmax, g[i].bmin, g[i].bmax);
+        for (uint32_t i = bK; i < n; i++) Grow(rmin, rmax, g[i].bmin, g[i].bmax);
+        const uint32_t l = GroupChild(g, bK, depth), r = GroupChild(g + bK, n - bK, depth);
+        BvhNode& nd = out_->nodes[nodeIdx];
+        for (int k = 0; k < 3; k++) { nd.lmin[k] = lmin[k]; nd.lmax[k] = lmax[k]; nd.rmin[k] = rmin[k]; nd.rmax[k] = rmax[k]; }
+        nd.left = l; nd.right = r; nd.pad0 = 0; nd.pad1 = 0;
+    }
 
     std::vector<BuildTri> bt_;
     const std::vector<BvhTri>* soup_ = nullptr;
