@@ -1600,17 +1600,19 @@ def test_bench_multi_rank_protocol_on_one_gpu():
     import sys
     env = dict(os.environ, ZR_BENCH_SHARED_GPU="1", MASTER_ADDR="127.0.0.1")
     singles = []
-    for n, port, settle in ((1, 0, 4), (1, 0, 16), (2, 29631, 4), (4, 29632, 4)):
+    # (the last run adds the denoise pass: BASELINE config 5's shape on two ranks -- the three denoise halo exchanges of tiling.denoise_schedule per frame)
+    for n, port, settle, more in ((1, 0, 4, []), (1, 0, 16, []), (2, 29631, 4, []), (4, 29632, 4, []), (2, 29633, 4, ["--denoise"])):
         cmd = [sys.executable, os.path.join(ROOT, "bench.py")] if n == 1 else \
             [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1", "--master-port", str(port),
              os.path.join(ROOT, "bench.py")]
-        cmd += ["--gpus", str(n), "--steps", "4", "--warmup", "2", "--settle", str(settle), "--width", "512", "--height", "288", "--no-cpu-baseline"]
+        cmd += ["--gpus", str(n), "--steps", "4", "--warmup", "2", "--settle", str(settle), "--width", "512", "--height", "288", "--no-cpu-baseline"] + more
         res = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
         assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
         lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
         assert len(lines) == 1, res.stdout[-2000:]
         d = json.loads(lines[0])
         assert d["n_gpus"] == n and d["steps"] == 4 and d["value"] > 0 and d["scaling"] == "strong"
+        assert ("denoise pass" in d["config"]["workload"]) == bool(more)
         if n == 1:
             singles.append(d["config"]["rays_per_frame"])
             continue

@@ -840,17 +840,24 @@ __global__ void __launch_bounds__(256) k_rpt_sort(rpt::RptFrame F, zr_frame_cons
     else RptSortTile<VB>(F, g, blockIdx.x - half, tilesX, tile0x, tile0y, mapB);
 }
 
+// Block size of the two reconnect kernels (K14, K16): nothing in them is shared between the waves of a block, so a 16 x 16 tile can be one
+// 256-thread block or four one-wave blocks (the trade of kRptBlock: a block's registers and LDS are only released when its slowest wave ends).
+#ifndef ZR_RECON_BLOCK
+#define ZR_RECON_BLOCK 256
+#endif
+static constexpr int kReconBlock = ZR_RECON_BLOCK;
+
 // K14: CtT + TtC fused per pixel (zr_rpt.h ReconnectTemporalPixel)
 template<bool EMISSIVE, bool TEX>
-__global__ void __launch_bounds__(kBlock) ZR_WAVES_TEMPORAL k_rpt_temporal(rpt::RptFrame F, zr_frame_constants g, uint32_t tilesX, unsigned long long* counters)
+__global__ void __launch_bounds__(kReconBlock) ZR_WAVES_TEMPORAL k_rpt_temporal(rpt::RptFrame F, zr_frame_constants g, uint32_t tilesX, unsigned long long* counters)
 {
     const unsigned long long t0 = __builtin_readcyclecounter();
     F.prm.emissive = EMISSIVE ? 1u : 0u; F.prm.textured = TEX ? 1u : 0u;
-    uint32_t x, y; PixelOfThread(tilesX, F.ox0, F.oy0, &x, &y);
+    uint32_t x, y; PixelOfThreadB<kReconBlock>(tilesX, F.ox0, F.oy0, &x, &y);
     // SORT_TEMPORAL: threads take their pixel from a K12 map, which puts reservoirs of equal reconnection depth into the same wave.  Scheduling
     // only (no wave operation in CtT / TtC); the error bit is ignored because the fused kernel runs both shifts of a pixel
     if (F.prm.temporalMap && F.Owns(x, y)) { const uint16_t e = (F.prm.temporalMap == 1u ? F.mapCtN : F.mapNtC)[rpt::Pix(F.gb, x, y)]; rpt::DecodeSorted(e & 0x7fffu, x, y); }
-    ZR_TRAV_STACK(stack);
+    ZR_TRAV_STACK_B(stack, kReconBlock);
     ZR_PROF_KERNEL(F.sc, 2);
     uint32_t cnt[2] = {0u, 0u};
     if (F.Owns(x, y)) rpt::ReconnectTemporalPixel(F, g, x, y, stack, cnt);
@@ -866,15 +873,15 @@ __device__ __forceinline__ float WaveSumButterfly(float v)
 
 // K16 CtS + StC: wave = 8x8 pixel group; every lane of the wave walks all four phases (absent lanes contribute 0)
 template<bool EMISSIVE, bool TEX>
-__global__ void __launch_bounds__(kBlock) ZR_WAVES_STC k_rpt_stc(rpt::RptFrame F, zr_frame_constants g, uint32_t tilesX, unsigned long long* counters)
+__global__ void __launch_bounds__(kReconBlock) ZR_WAVES_STC k_rpt_stc(rpt::RptFrame F, zr_frame_constants g, uint32_t tilesX, unsigned long long* counters)
 {
     const unsigned long long t0 = __builtin_readcyclecounter();
     F.prm.emissive = EMISSIVE ? 1u : 0u; F.prm.textured = TEX ? 1u : 0u;
-    uint32_t x, y; PixelOfThread(tilesX, F.ox0, F.oy0, &x, &y);
+    uint32_t x, y; PixelOfThreadB<kReconBlock>(tilesX, F.ox0, F.oy0, &x, &y);
     // SORT_SPATIAL (ReSTIR_PT_Reconnect_StC.hlsl:133-140): the thread at (x, y) shifts the pixel the NtC map assigns to its position, so the
     // four wave sums below run over the 64 pixels K12 put together (error bit: nothing to do -- the lane stays in the wave, contributing 0)
     if (F.prm.sortSpatial && F.Owns(x, y) && !rpt::DecodeSorted(F.mapNtC[rpt::Pix(F.gb, x, y)], x, y)) x = 0xffffffffu;
-    ZR_TRAV_STACK(stack);
+    ZR_TRAV_STACK_B(stack, kReconBlock);
     uint32_t cnt[2] = {0u, 0u};
     ZR_PROF_KERNEL(F.sc, 3);
     rpt::StcLane a;
