@@ -258,3 +258,48 @@ def test_cpp_denoise_node_in_the_render_graph(cornell_emissive, oracle_emissive)
         prev = (depth, normal)
     assert np.array_equal(final.view(np.uint32), sig.view(np.uint32))
     assert np.array_equal(den.view(np.uint32), want.view(np.uint32))
+
+
+@pytest.mark.gpu
+def test_cpp_passes_take_the_reference_ui_parameters(cornell_emissive, oracle_emissive):
+    """The knobs the reference's settings UI turns (IndirectLighting.cpp:1468-1600 and DirectLighting.cpp:374-410 *Callback members) as setters of the
+    C++ mirror: a ReSTIR PT + ReSTIR DI run with nearly every one of them off its default -- 2 / 3 bounces, no Russian roulette, TWO spatial rounds,
+    M_max 6 / 5, temporal sort off, boiling suppression off, path regularisation on, Alpha_min 0.2 (stored squared); DI with M_max 12, no extra
+    disocclusion samples, deterministic spatial, Alpha_min 0.1 -- equals the oracle run with the same parameter block, bit for bit, after 4 frames
+    with a moving camera."""
+    from oracle import zro
+    w, h, n = 80, 48, 4
+    cbs = np.ascontiguousarray(np.stack([scene_io.make_frame_constants(w, h, frame_num=f, num_emissives=len(cornell_emissive.emissives), cam_pos=(0.02 * f, 1.2, -4.043))
+                                         for f in range(1, n + 1)]))
+    for f in range(1, n):
+        cbs[f]["prev_view"], cbs[f]["prev_view_inv"], cbs[f]["prev_camera_jitter"] = cbs[f - 1]["curr_view"], cbs[f - 1]["curr_view_inv"], cbs[f - 1]["curr_camera_jitter"]
+
+    class Tuning(C.Structure):
+        _fields_ = [(k, C.c_int) for k in ("max_non_tr", "max_glossy_tr", "stochastic_multibounce", "russian_roulette", "temporal", "spatial_passes", "m_max_t", "m_max_s",
+                                           "sort_temporal", "sort_spatial", "boiling_suppression", "path_regularization")] + [("alpha_min", C.c_float)] + \
+                   [(k, C.c_int) for k in ("di_temporal", "di_spatial", "di_m_max", "di_extra_disocclusion", "di_stochastic_spatial")] + [("di_alpha_min", C.c_float)]
+    t = Tuning(2, 3, -1, 0, 1, 2, 6, 5, 0, 1, 0, 1, 0.2, 1, 1, 12, 0, 0, 0.1)
+    prm = wire.default_params()
+    prm.max_non_tr_bounces, prm.max_glossy_tr_bounces, prm.m_max_temporal, prm.m_max_spatial, prm.num_spatial_passes = 2, 3, 6, 5, 2
+    prm.flags = wire.IND_TEMPORAL_RESAMPLE | wire.IND_SPATIAL_RESAMPLE | wire.IND_PATH_REGULARIZATION | wire.IND_SORT_SPATIAL
+    prm.alpha_min = float(np.float32(0.2) * np.float32(0.2))
+    dip = wire.default_params_di()
+    dip.flags = wire.IND_TEMPORAL_RESAMPLE | wire.IND_SPATIAL_RESAMPLE
+    dip.m_max_temporal = 12
+    dip.alpha_min = float(np.float32(0.1) * np.float32(0.1))
+    desc = cornell_emissive.desc()
+    out, dout = np.zeros((h, w, 4), np.float32), np.zeros((h, w, 4), np.float32)
+    L = _lib()
+    L.zrh_render_sequence_tuned.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+    assert L.zrh_render_sequence_tuned(C.addressof(desc), cbs.ctypes.data, n, w, h, 2, C.byref(t), out.ctypes.data, dout.ctypes.data) == 0
+    o, odi = zro.OracleRPT(oracle_emissive, w, h), zro.OracleRDI(oracle_emissive, w, h)
+    for f in range(n):
+        want = o.render(cbs[f], prm)
+        dwant = odi.render(cbs[f], dip)
+    assert np.array_equal(out.view(np.uint32), want.view(np.uint32))
+    assert np.array_equal(dout.view(np.uint32), dwant.view(np.uint32))
+    # ... and the defaults are not what was just rendered (the knobs did something)
+    o2 = zro.OracleRPT(oracle_emissive, w, h)
+    for f in range(n):
+        plain = o2.render(cbs[f], wire.default_params())
+    assert not np.array_equal(plain.view(np.uint32), want.view(np.uint32))

@@ -251,6 +251,17 @@ void DirectLighting::SetLightPresamplingParams(bool enable, int numSampleSets, i
     m_params.presampling = enable ? 1u : 0u; m_params.num_sample_sets = (uint32_t)numSampleSets; m_params.sample_set_size = (uint32_t)sampleSetSize;
     ZR_CHECK(zr_pass_set_params(m_pass, &m_params));
 }
+void DirectLighting::SetFlag(uint32_t bit, bool on)
+{
+    m_params.flags = on ? (m_params.flags | bit) : (m_params.flags & ~bit);
+    ZR_CHECK(zr_pass_set_params(m_pass, &m_params));
+}
+void DirectLighting::SetTemporalResampling(bool b) { SetFlag(ZR_IND_TEMPORAL_RESAMPLE, b); }
+void DirectLighting::SetSpatialResampling(bool b) { SetFlag(ZR_IND_SPATIAL_RESAMPLE, b); }
+void DirectLighting::SetMaxTemporalM(int m) { m_params.m_max_temporal = (uint32_t)m; ZR_CHECK(zr_pass_set_params(m_pass, &m_params)); }
+void DirectLighting::SetExtraSamplesDisocclusion(bool b) { SetFlag(ZR_DI_EXTRA_DISOCCLUSION_SAMPLING, b); }
+void DirectLighting::SetStochasticSpatial(bool b) { SetFlag(ZR_DI_STOCHASTIC_SPATIAL, b); }
+void DirectLighting::SetAlphaMin(float a) { m_params.alpha_min = a * a; ZR_CHECK(zr_pass_set_params(m_pass, &m_params)); }
 void* DirectLighting::GetOutput(SHADER_OUT_RES i) const
 {
     if (i != SHADER_OUT_RES::FINAL) { std::fprintf(stderr, "Invalid shader output.\n"); std::abort(); }
@@ -277,7 +288,23 @@ void* Sky::GetOutput(SHADER_OUT_RES i) const
 }
 void Sky::Render(Core::CommandList& cl) { ZR_CHECK(zr_pass_render(m_pass, cl.Stream(), &m_ctx->frameConstants, m_ctx->scene, nullptr)); }
 
-void SkyDI::Init(FrameContext* ctx) { InitRenderPass(ZR_PASS_DI_SKY, ctx, 0); }       // library defaults = SkyDI.cpp:81-82
+void SkyDI::Init(FrameContext* ctx)
+{
+    InitRenderPass(ZR_PASS_DI_SKY, ctx, 0);       // library defaults = SkyDI.cpp:81-82; a copy to edit (sky M_max = m_max_temporal, sun M_max = m_max_spatial)
+    zr_params_default(&m_params);
+    m_params.flags = ZR_IND_TEMPORAL_RESAMPLE | ZR_IND_SPATIAL_RESAMPLE;
+    m_params.m_max_temporal = 15; m_params.m_max_spatial = 3; m_params.alpha_min = 0.35f * 0.35f;
+}
+void SkyDI::SetFlag(uint32_t bit, bool on)
+{
+    m_params.flags = on ? (m_params.flags | bit) : (m_params.flags & ~bit);
+    ZR_CHECK(zr_pass_set_params(m_pass, &m_params));
+}
+void SkyDI::SetTemporalResampling(bool b) { SetFlag(ZR_IND_TEMPORAL_RESAMPLE, b); }
+void SkyDI::SetSpatialResampling(bool b) { SetFlag(ZR_IND_SPATIAL_RESAMPLE, b); }
+void SkyDI::SetMaxMSky(int m) { m_params.m_max_temporal = (uint32_t)m; ZR_CHECK(zr_pass_set_params(m_pass, &m_params)); }
+void SkyDI::SetMaxMSun(int m) { m_params.m_max_spatial = (uint32_t)m; ZR_CHECK(zr_pass_set_params(m_pass, &m_params)); }
+void SkyDI::SetAlphaMin(float a) { m_params.alpha_min = a * a; ZR_CHECK(zr_pass_set_params(m_pass, &m_params)); }
 void SkyDI::OnWindowResized() { ZR_CHECK(zr_pass_resize(m_pass, m_ctx->renderWidth, m_ctx->renderHeight)); }
 void SkyDI::ResetTemporal() { ZR_CHECK(zr_pass_reset_temporal(m_pass)); }
 void* SkyDI::GetOutput(SHADER_OUT_RES i) const
@@ -293,9 +320,19 @@ void Compositing::Init(FrameContext* ctx) { InitRenderPass(ZR_PASS_COMPOSITING, 
 void Compositing::OnWindowResized() { ZR_CHECK(zr_pass_resize(m_pass, m_ctx->renderWidth, m_ctx->renderHeight)); }
 void Compositing::SetGpuDescriptor(SHADER_IN_GPU_DESC i, const void* dev)
 {
-    const int which = i == SHADER_IN_GPU_DESC::SKY_DI ? ZR_IN_SKY_DI : (i == SHADER_IN_GPU_DESC::EMISSIVE_DI ? ZR_IN_EMISSIVE_DI : ZR_IN_INDIRECT);
-    ZR_CHECK(zr_pass_set_input(m_pass, which, dev));
+    if (i >= SHADER_IN_GPU_DESC::COUNT) { std::fprintf(stderr, "Invalid shader input.\n"); std::abort(); }
+    m_desc[(int)i] = dev;
+    Rebind();
 }
+// an input that is switched off is unbound in the library (which composes the planes that are bound); the descriptor is remembered
+void Compositing::Rebind()
+{
+    ZR_CHECK(zr_pass_set_input(m_pass, ZR_IN_SKY_DI, m_direct ? m_desc[(int)SHADER_IN_GPU_DESC::SKY_DI] : nullptr));
+    ZR_CHECK(zr_pass_set_input(m_pass, ZR_IN_EMISSIVE_DI, m_direct ? m_desc[(int)SHADER_IN_GPU_DESC::EMISSIVE_DI] : nullptr));
+    ZR_CHECK(zr_pass_set_input(m_pass, ZR_IN_INDIRECT, m_indirect ? m_desc[(int)SHADER_IN_GPU_DESC::INDIRECT] : nullptr));
+}
+void Compositing::SetDirectEnablement(bool b) { m_direct = b; Rebind(); }
+void Compositing::SetIndirectEnablement(bool b) { m_indirect = b; Rebind(); }
 void Compositing::SetFireflyFilterEnablement(bool b)
 {
     m_params.flags = b ? (m_params.flags | ZR_COMPOSIT_FIREFLY_FILTER) : (m_params.flags & ~(uint32_t)ZR_COMPOSIT_FIREFLY_FILTER);
@@ -407,6 +444,38 @@ void IndirectLighting::SetMaxBounces(int nonTr, int glossyTr)
     m_params.max_non_tr_bounces = (uint32_t)nonTr; m_params.max_glossy_tr_bounces = (uint32_t)glossyTr;
     ZR_CHECK(zr_pass_set_params(m_pass, &m_params));
 }
+void IndirectLighting::SetLightVoxelGridParams(bool enabled, uint32_t dimX, uint32_t dimY, uint32_t dimZ, float extX, float extY, float extZ, float offsetY)
+{
+    if (enabled && !(dimX > 0 && dimY > 0 && dimZ > 0 && extX > 0 && extY > 0 && extZ > 0)) { std::fprintf(stderr, "LVG is enabled, but the dimension is invalid.\n"); std::abort(); }
+    if (enabled && !m_params.presampling) { std::fprintf(stderr, "LVG can't be used while light presampling is disabled.\n"); std::abort(); }      // IndirectLighting.h:93
+    m_params.use_lvg = enabled ? 1u : 0u; m_params.lvg_grid_dim = dimX | (dimY << 10) | (dimZ << 20);
+    m_params.lvg_extents[0] = extX; m_params.lvg_extents[1] = extY; m_params.lvg_extents[2] = extZ; m_params.lvg_offset_y = offsetY;
+    ZR_CHECK(zr_pass_set_params(m_pass, &m_params));
+}
+void IndirectLighting::SetFlag(uint32_t bit, bool on)
+{
+    m_params.flags = on ? (m_params.flags | bit) : (m_params.flags & ~bit);
+    ZR_CHECK(zr_pass_set_params(m_pass, &m_params));
+}
+void IndirectLighting::SetMaxNonTrBounces(int n) { m_params.max_non_tr_bounces = (uint32_t)n; ZR_CHECK(zr_pass_set_params(m_pass, &m_params)); }
+void IndirectLighting::SetMaxGlossyTrBounces(int n) { m_params.max_glossy_tr_bounces = (uint32_t)n; ZR_CHECK(zr_pass_set_params(m_pass, &m_params)); }
+void IndirectLighting::SetStochasticMultibounce(bool b) { SetFlag(ZR_IND_STOCHASTIC_MULTI_BOUNCE, b); }
+void IndirectLighting::SetRussianRoulette(bool b) { SetFlag(ZR_IND_RUSSIAN_ROULETTE, b); }
+void IndirectLighting::SetTemporalResampling(bool b) { SetFlag(ZR_IND_TEMPORAL_RESAMPLE, b); }
+// m_numSpatialPasses (IndirectLighting.cpp:1514-1518): doSpatial = (m_numSpatialPasses > 0) && doTemporal (:906)
+void IndirectLighting::SetSpatialResampling(int numPasses)
+{
+    m_params.num_spatial_passes = (uint32_t)numPasses;
+    SetFlag(ZR_IND_SPATIAL_RESAMPLE, numPasses > 0);
+}
+void IndirectLighting::SetM_maxT(int m) { m_params.m_max_temporal = (uint32_t)m; ZR_CHECK(zr_pass_set_params(m_pass, &m_params)); }
+void IndirectLighting::SetM_maxS(int m) { m_params.m_max_spatial = (uint32_t)m; ZR_CHECK(zr_pass_set_params(m_pass, &m_params)); }
+void IndirectLighting::SetSortTemporal(bool b) { SetFlag(ZR_IND_SORT_TEMPORAL, b); }
+void IndirectLighting::SetSortSpatial(bool b) { SetFlag(ZR_IND_SORT_SPATIAL, b); }
+void IndirectLighting::SetTexFilter(uint32_t f) { m_params.tex_filter = f; ZR_CHECK(zr_pass_set_params(m_pass, &m_params)); }
+void IndirectLighting::SetBoilingSuppression(bool b) { SetFlag(ZR_IND_BOILING_SUPPRESSION, b); }
+void IndirectLighting::SetPathRegularization(bool b) { SetFlag(ZR_IND_PATH_REGULARIZATION, b); }
+void IndirectLighting::SetAlphaMin(float a) { m_params.alpha_min = a * a; ZR_CHECK(zr_pass_set_params(m_pass, &m_params)); }
 void* IndirectLighting::GetOutput(SHADER_OUT_RES i) const
 {
     if (i != SHADER_OUT_RES::FINAL) { std::fprintf(stderr, "Invalid shader output.\n"); std::abort(); }
@@ -473,6 +542,24 @@ int zrh_graph_selftest(char* out, int outLen)
 // and copies the FINAL plane of the last frame.  integrator: 0 = PATH_TRACING, 2 = ReSTIR_PT.
 int zrh_render_sequence3(const zr_scene_desc* desc, const zr_frame_constants* cbs, uint32_t n, uint32_t w, uint32_t h, int integrator, float* finalOut, float* directOut,
     int presampleSets, int presampleSize);
+// the reference's UI parameters of the two lighting passes as one record (tests): every field < 0 leaves the pass's default alone
+struct zrh_tuning
+{
+    int max_non_tr, max_glossy_tr, stochastic_multibounce, russian_roulette, temporal, spatial_passes, m_max_t, m_max_s, sort_temporal, sort_spatial, boiling_suppression,
+        path_regularization;
+    float alpha_min;
+    int di_temporal, di_spatial, di_m_max, di_extra_disocclusion, di_stochastic_spatial;
+    float di_alpha_min;
+};
+static const zrh_tuning* g_tuning = nullptr;
+int zrh_render_sequence_tuned(const zr_scene_desc* desc, const zr_frame_constants* cbs, uint32_t n, uint32_t w, uint32_t h, int integrator, const zrh_tuning* t,
+    float* finalOut, float* directOut)
+{
+    g_tuning = t;
+    const int r = zrh_render_sequence3(desc, cbs, n, w, h, integrator, finalOut, directOut, 0, 0);
+    g_tuning = nullptr;
+    return r;
+}
 int zrh_render_sequence2(const zr_scene_desc* desc, const zr_frame_constants* cbs, uint32_t n, uint32_t w, uint32_t h, int integrator, float* finalOut, float* directOut)
 { return zrh_render_sequence3(desc, cbs, n, w, h, integrator, finalOut, directOut, 0, 0); }
 
@@ -495,6 +582,31 @@ int zrh_render_sequence3(const zr_scene_desc* desc, const zr_frame_constants* cb
             pre.SetLightPresamplingParams(0, presampleSets, presampleSize);
             ind.SetLightPresamplingParams(pre.IsPresamplingEnabled(), presampleSets, presampleSize);
             if (directOut) di.SetLightPresamplingParams(pre.IsPresamplingEnabled(), presampleSets, presampleSize);
+        }
+        if (const zrh_tuning* t = g_tuning)
+        {   // what the reference's settings UI does between frames: one callback per knob (IndirectLighting.cpp:1468-1600, DirectLighting.cpp:374-410)
+            if (t->max_non_tr >= 0) ind.SetMaxNonTrBounces(t->max_non_tr);
+            if (t->max_glossy_tr >= 0) ind.SetMaxGlossyTrBounces(t->max_glossy_tr);
+            if (t->stochastic_multibounce >= 0) ind.SetStochasticMultibounce(t->stochastic_multibounce != 0);
+            if (t->russian_roulette >= 0) ind.SetRussianRoulette(t->russian_roulette != 0);
+            if (t->temporal >= 0) ind.SetTemporalResampling(t->temporal != 0);
+            if (t->spatial_passes >= 0) ind.SetSpatialResampling(t->spatial_passes);
+            if (t->m_max_t >= 0) ind.SetM_maxT(t->m_max_t);
+            if (t->m_max_s >= 0) ind.SetM_maxS(t->m_max_s);
+            if (t->sort_temporal >= 0) ind.SetSortTemporal(t->sort_temporal != 0);
+            if (t->sort_spatial >= 0) ind.SetSortSpatial(t->sort_spatial != 0);
+            if (t->boiling_suppression >= 0) ind.SetBoilingSuppression(t->boiling_suppression != 0);
+            if (t->path_regularization >= 0) ind.SetPathRegularization(t->path_regularization != 0);
+            if (t->alpha_min >= 0) ind.SetAlphaMin(t->alpha_min);
+            if (directOut)
+            {
+                if (t->di_temporal >= 0) di.SetTemporalResampling(t->di_temporal != 0);
+                if (t->di_spatial >= 0) di.SetSpatialResampling(t->di_spatial != 0);
+                if (t->di_m_max >= 0) di.SetMaxTemporalM(t->di_m_max);
+                if (t->di_extra_disocclusion >= 0) di.SetExtraSamplesDisocclusion(t->di_extra_disocclusion != 0);
+                if (t->di_stochastic_spatial >= 0) di.SetStochasticSpatial(t->di_stochastic_spatial != 0);
+                if (t->di_alpha_min >= 0) di.SetAlphaMin(t->di_alpha_min);
+            }
         }
         Core::RenderGraph g;
         enum : uint64_t { R_GBUF = 1, R_ALIAS, R_IND, R_DI };

@@ -215,9 +215,18 @@ namespace RenderPass {
         void OnWindowResized();
         void ResetTemporal();
         void SetLightPresamplingParams(bool enable, int numSampleSets, int sampleSetSize);
+        // The reference's UI parameters of this pass ("Temporal Resample", "Spatial Resample", "M_max", "Extra Sampling (Disocclusion)", "Stochastic
+        // Spatial", "Alpha_min (Lobe Selection)": registered in DirectLighting::Init, delivered to DirectLighting.cpp:374-410 *Callback) as plain setters
+        void SetTemporalResampling(bool b);
+        void SetSpatialResampling(bool b);
+        void SetMaxTemporalM(int m);                      // 1..30
+        void SetExtraSamplesDisocclusion(bool b);
+        void SetStochasticSpatial(bool b);
+        void SetAlphaMin(float alphaMin);                 // the constant buffer holds its square (DirectLighting.cpp:404-408)
         void* GetOutput(SHADER_OUT_RES i) const;
         void Render(Core::CommandList& cmdList);
     private:
+        void SetFlag(uint32_t bit, bool on);
         zr_params m_params{};
     };
 
@@ -237,8 +246,17 @@ namespace RenderPass {
         void Init(FrameContext* ctx);
         void OnWindowResized();
         void ResetTemporal();
+        // UI parameters (SkyDI.cpp:350-379): "Temporal Resample", "Spatial Resample", "M_max (Sky)", "M_max (Sun)", "Alpha_min (Lobe Selection)"
+        void SetTemporalResampling(bool b);
+        void SetSpatialResampling(bool b);
+        void SetMaxMSky(int m);                           // 1..15
+        void SetMaxMSun(int m);                           // 1..15
+        void SetAlphaMin(float alphaMin);                 // stored squared
         void* GetOutput(SHADER_OUT_RES i) const;
         void Render(Core::CommandList& cmdList);
+    private:
+        void SetFlag(uint32_t bit, bool on);
+        zr_params m_params{};
     };
 
     // RP/Compositing/Compositing.h:19-115: (sky DI | emissive DI) + indirect, optional firefly filter
@@ -250,10 +268,16 @@ namespace RenderPass {
         void OnWindowResized();
         void SetGpuDescriptor(SHADER_IN_GPU_DESC i, const void* devicePlane);       // RGBA32F FINAL plane of the producing pass
         void SetFireflyFilterEnablement(bool b);
+        // "Direct" / "Indirect" toggles of the settings UI (Compositing.cpp:166-179: they clear the CB_COMPOSIT_FLAGS bit of the input; the descriptor stays bound)
+        void SetDirectEnablement(bool b);
+        void SetIndirectEnablement(bool b);
         void* GetOutput(SHADER_OUT_RES i) const;
         void Render(Core::CommandList& cmdList);
     private:
+        void Rebind();
         zr_params m_params{};
+        const void* m_desc[3] = {nullptr, nullptr, nullptr};      // by SHADER_IN_GPU_DESC
+        bool m_direct = true, m_indirect = true;
     };
 
     // RP/TAA/TAA.h:20-80: temporal anti-aliasing of the composited image
@@ -344,11 +368,31 @@ namespace RenderPass {
         void ResetTemporal();
         void SetMethod(INTEGRATOR method);
         void SetLightPresamplingParams(bool enable, int numSampleSets, int sampleSetSize);
+        // IndirectLighting.h:83-98 (ReSTIR GI samples lights from the grid on bounces > 0; needs presampling)
+        void SetLightVoxelGridParams(bool enabled, uint32_t dimX, uint32_t dimY, uint32_t dimZ, float extX, float extY, float extZ, float offsetY);
         void SetMaxBounces(int nonTr, int glossyTr);
+        // The reference's UI parameters of this pass, registered with App::AddParam in SwitchToReSTIR_PT / SwitchToReSTIR_GI / SwitchToPathTracer
+        // (IndirectLighting.cpp:1027-1275, 1321-1414) and delivered to the *Callback members (IndirectLighting.cpp:1468-1600): the same knobs as plain setters
+        void SetMaxNonTrBounces(int n);                   // "Max Non-Transmissive Bounces", 1..8
+        void SetMaxGlossyTrBounces(int n);                // "Max Glossy Transmissive Bounces", 1..8
+        void SetStochasticMultibounce(bool b);            // ReSTIR GI / path tracer
+        void SetRussianRoulette(bool b);
+        void SetTemporalResampling(bool b);
+        void SetSpatialResampling(int numPasses);         // "Spatial Resample", 0..2 (m_numSpatialPasses)
+        void SetM_maxT(int m);                            // "M_max (Temporal)", 1..15
+        void SetM_maxS(int m);                            // "M_max (Spatial)", 1..15
+        void SetSortTemporal(bool b);
+        void SetSortSpatial(bool b);
+        void SetTexFilter(uint32_t zrTexFilter);          // ZR_TEX_FILTER_* (enum class TEXTURE_FILTER, IndirectLighting_Common.h:69-77)
+        void SetBoilingSuppression(bool b);
+        void SetPathRegularization(bool b);
+        void SetAlphaMin(float alphaMin);                 // "Alpha_min (Reconnection)"; the constant buffers hold its square (IndirectLighting.cpp:1593-1600)
+        const zr_params& Params() const { return m_params; }
         // device pointer of the FINAL plane (RGBA32F)
         void* GetOutput(SHADER_OUT_RES i) const;
         void Render(Core::CommandList& cmdList);
     private:
+        void SetFlag(uint32_t bit, bool on);
         zr_params m_params{};
     };
 }
