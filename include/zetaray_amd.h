@@ -340,6 +340,13 @@ int zr_pass_create(int kind, int device, zr_pass** out);
 int zr_pass_init(zr_pass* pass, uint32_t width, uint32_t height, int integrator);
 int zr_pass_resize(zr_pass* pass, uint32_t width, uint32_t height);   /* OnWindowResized + ResetTemporal */
 int zr_pass_reset_temporal(zr_pass* pass);
+/* GBUFFER pass: GBufferRT::PickPixel / ClearPick / GetPickReadbackBuffer (GBuffer/GBufferRT.h:36-46).  While a pick is pending every GBUFFER render writes
+   the mesh index (GeometryIndex + InstanceID: the index of the instance record) under pixel (x, y) of the render target, UINT32_MAX when the primary ray
+   misses (GBufferRT_Inline.hlsl:241-242); on a screen tile only the pass whose tile holds the pixel writes.  zr_pass_read_pick copies the value back on
+   `stream` and waits for it; ZR_ERR_NOT_INITIALIZED when no render has covered the pixel since zr_pass_pick_pixel. */
+int zr_pass_pick_pixel(zr_pass* pass, uint32_t x, uint32_t y);
+int zr_pass_clear_pick(zr_pass* pass);
+int zr_pass_read_pick(zr_pass* pass, void* stream, uint32_t* mesh_idx);
 int zr_pass_set_params(zr_pass* pass, const zr_params* params);
 /* Render(CommandList&): enqueue only.  cb = the 544-byte cbFrameConstants of this frame (host pointer, copied). */
 int zr_pass_render(zr_pass* pass, void* hip_stream, const zr_frame_constants* cb, const zr_scene* scene,

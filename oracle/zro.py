@@ -206,6 +206,18 @@ class OracleScene:
         lib().zro_gbuffer_render(self.h, cbb.ctypes.data, C.addressof(planes))
         return arrays, planes
 
+    def pick(self, cb, x, y):
+        """GBufferRT::PickPixel(x, y) + a G-buffer render: the mesh index under the pixel, 0xffffffff on a miss (GBufferRT_Inline.hlsl:241-242)"""
+        from zetaray_amd import wire
+        w, h = int(cb["render_width"]), int(cb["render_height"])
+        arrays, planes = wire.alloc_gbuffer_planes(w, h)
+        cbb = np.ascontiguousarray(cb)
+        out = C.c_uint32(0xfffffffe)
+        L = lib()
+        L.zro_gbuffer_render_pick.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]
+        L.zro_gbuffer_render_pick(self.h, cbb.ctypes.data, C.addressof(planes), int(x), int(y), C.byref(out))
+        return int(out.value)
+
     def pathtrace(self, cb, gb_planes, params, final=None):
         from zetaray_amd import wire
         w, h = int(cb["render_width"]), int(cb["render_height"])

@@ -210,7 +210,8 @@ static float4 UVDifferentials(int px, int py, float3 origin, float3 dir, bool th
 //--------------------------------------------------------------------------------------
 // K1: G-buffer (GBufferRT_Inline.hlsl:204-287, TracePrimaryHit :72-198, GBufferRT.hlsli:102-282)
 //--------------------------------------------------------------------------------------
-static void RenderGBuffer(const Scene& sc, const zr_frame_constants& g, GBView gb)
+// pick (optional): GBufferRT::PickPixel's pixel -> *pick = hitMeshIdx, UINT32_MAX on a miss (GBufferRT_Inline.hlsl:241-242)
+static void RenderGBuffer(const Scene& sc, const zr_frame_constants& g, GBView gb, uint32_t pickX = 0xffffu, uint32_t pickY = 0xffffu, uint32_t* pick = nullptr)
 {
     BSDF::g_rho = &sc.rhoLUT;
     const float2 renderDim = {(float)g.render_width, (float)g.render_height};
@@ -239,6 +240,7 @@ static void RenderGBuffer(const Scene& sc, const zr_frame_constants& g, GBView g
 
         sc.counters.n_closest++;
         Scene::RawHit h = sc.Trace(rayOrigin, rayDir, 0.0f, ZR_FLT_MAX, ZR_SUBGROUP_ALL, false, false, 0, /*alphaTest*/ true);
+        if (pick && x == pickX && y == pickY) *pick = h.hit ? sc.tris[h.tri].mesh_idx : 0xffffffffu;
 
         if (!h.hit)
         {
@@ -977,6 +979,9 @@ int zro_scene_latch_heap_offsets(const zro_scene* h, const zr_frame_constants* c
 
 int zro_gbuffer_render(const zro_scene* h, const zr_frame_constants* cb, zr_gbuffer_planes* planes)
 { h->s.LatchHeapOffsets(*cb); RenderGBuffer(h->s, *cb, GBView(planes)); return 0; }
+// ... with GBufferRT::PickPixel(x, y) pending
+int zro_gbuffer_render_pick(const zro_scene* h, const zr_frame_constants* cb, zr_gbuffer_planes* planes, uint32_t x, uint32_t y, uint32_t* mesh_idx)
+{ h->s.LatchHeapOffsets(*cb); RenderGBuffer(h->s, *cb, GBView(planes), x, y, mesh_idx); return 0; }
 
 int zro_pathtrace_render(const zro_scene* h, const zr_frame_constants* cb, const zr_gbuffer_planes* planes,
     const zr_params* prm, float* final_rgba, zr_counters* counters)

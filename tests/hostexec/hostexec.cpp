@@ -305,6 +305,10 @@ static uint32_t g_tile_x0 = 0, g_tile_y0 = 0;
 // screen-tile origin for the next zhx_gbuffer / zhx_pathtrace calls (planes then have the tile's size)
 void zhx_set_tile_origin(uint32_t x0, uint32_t y0) { g_tile_x0 = x0; g_tile_y0 = y0; }
 
+static uint32_t g_pick_xy = 0xffffffffu, g_picked = 0xfffffffeu;
+// GBufferRT::PickPixel for the next zhx_gbuffer calls (x = 0xffff: none); zhx_picked = what the last one wrote
+void zhx_pick_pixel(uint32_t x, uint32_t y) { g_pick_xy = x | (y << 16); }
+uint32_t zhx_picked() { return g_picked; }
 void zhx_gbuffer(const HxScene* s, const zr_frame_constants* cb, zr_gbuffer_planes* planes)
 { Latch(s, cb);
     GBuf gb = ViewOf(planes);
@@ -312,7 +316,7 @@ void zhx_gbuffer(const HxScene* s, const zr_frame_constants* cb, zr_gbuffer_plan
     zr::StackEntry stackMem[zr::kTravStack]; zr::TravStack stack; stack.lds = nullptr; stack.stride = 0; stack.mem = stackMem;
     for (uint32_t y = gb.y0; y < gb.y0 + gb.h; y++)
         for (uint32_t x = gb.x0; x < gb.x0 + gb.w; x++)
-            GBufferPixel(s->view, *cb, gb, x, y, stack, nullptr);
+            GBufferPixel(s->view, *cb, gb, x, y, stack, nullptr, (x | (y << 16)) == g_pick_xy ? &g_picked : nullptr);
 }
 
 void zhx_pathtrace(const HxScene* s, const zr_frame_constants* cb, const zr_gbuffer_planes* planes, const zr_params* params,

@@ -179,6 +179,16 @@ class HostExecScene:
         lib().zhx_set_tile_origin(0, 0)
         return arrays, planes
 
+    def pick(self, cb, x, y, tile=None):
+        """GBufferRT::PickPixel(x, y) + a G-buffer render through the product's stage function"""
+        L = lib()
+        L.zhx_pick_pixel.argtypes = [C.c_uint32, C.c_uint32]
+        L.zhx_picked.restype = C.c_uint32
+        L.zhx_pick_pixel(int(x), int(y))
+        self.gbuffer(cb, tile)
+        L.zhx_pick_pixel(0xffff, 0xffff)
+        return int(L.zhx_picked())
+
     def pathtrace(self, cb, planes, params, final=None, tile=None):
         from zetaray_amd import wire
         x0, y0, w, h = tile if tile else (0, 0, int(cb["render_width"]), int(cb["render_height"]))

@@ -1813,3 +1813,53 @@ def test_scene_without_bvh_nodes_on_gpu(api, cornell_emissive):
     _, planes = osc.gbuffer(cb)
     want, _ = osc.pathtrace(cb, planes, prm)
     assert np.array_equal(r.final().view(np.uint32), want.view(np.uint32))
+
+
+def test_pick_pixel_reports_the_mesh_under_the_cursor(api, cornell_emissive, oracle_emissive):
+    """zr_pass_pick_pixel / zr_pass_read_pick / zr_pass_clear_pick = GBufferRT::PickPixel, the pick read-back buffer, ClearPick (GBufferRT.h:36-46;
+    GBufferRT_Inline.hlsl:241-242 writes hitMeshIdx or UINT32_MAX).  Cornell box and the 3000-triangle materials scene: picked mesh == the oracle's for a
+    grid of pixels, a miss reads UINT32_MAX, on a screen tile the pixel is named in render-target coordinates (and a tile that does not hold it has
+    nothing to read), the G-buffer planes are what they are without a pick, and after ClearPick the pass stops writing."""
+    from oracle import zro
+    w, h = 160, 96
+    for sc, osc, cam in ((cornell_emissive, oracle_emissive, {}), (None, None, dict(cam_pos=(0, 0, -3.5)))):
+        if sc is None:
+            sc = scene_io.make_synthetic_scene(num_tris=3000, num_emissive=150, seed=11)
+            osc = zro.OracleScene(sc, force_bvh=True)
+        r = api.Renderer(sc, w, h, params=wire.default_params(), integrator=api.INTEGRATOR_RESTIR_PT)
+        cb = _frame(sc, w, h, 2, **cam)
+        seen = set()
+        for y in range(3, h, 13):
+            for x in range(2, w, 17):
+                r.p_gbuffer.pick_pixel(x, y)
+                r.p_gbuffer.render(cb, r.scene, r.gbuffer)
+                got, want = r.p_gbuffer.read_pick(), osc.pick(cb, x, y)
+                assert got == want, (x, y, got, want)
+                seen.add(got)
+        assert len(seen - {0xffffffff}) >= 5
+        planes, _ = r.gbuffer.download()
+        oplanes, _ = osc.gbuffer(cb)
+        for n, a, b in zip(wire.GB_PLANE_NAMES, planes, oplanes):
+            assert np.array_equal(np.asarray(a).view(np.uint8).reshape(-1), np.asarray(b).view(np.uint8).reshape(-1)), n
+        r.p_gbuffer.clear_pick()
+    # a miss
+    cb_out = _frame(cornell_emissive, w, h, 2, cam_pos=(0.0, 1.0, -30.0), view_dir=(0, 0, -1))
+    r = api.Renderer(cornell_emissive, w, h, params=wire.default_params(), integrator=api.INTEGRATOR_RESTIR_PT)
+    r.p_gbuffer.pick_pixel(7, 9)
+    r.p_gbuffer.render(cb_out, r.scene, r.gbuffer)
+    assert r.p_gbuffer.read_pick() == 0xffffffff == oracle_emissive.pick(cb_out, 7, 9)
+    # ClearPick: a later render over another view does not overwrite the value
+    r.p_gbuffer.clear_pick()
+    cb = _frame(cornell_emissive, w, h, 2)
+    r.p_gbuffer.render(cb, r.scene, r.gbuffer)
+    assert r.p_gbuffer.read_pick() == 0xffffffff
+    # screen tile: render-target coordinates; a tile that does not hold the pixel reports that nothing was written
+    tile = (64, 32, 96, 64)
+    rt = api.Renderer(cornell_emissive, tile[2], tile[3], params=wire.default_params(), integrator=api.INTEGRATOR_RESTIR_PT, tile_origin=tile[:2])
+    rt.p_gbuffer.pick_pixel(100, 60)
+    rt.p_gbuffer.render(cb, rt.scene, rt.gbuffer)
+    assert rt.p_gbuffer.read_pick() == oracle_emissive.pick(cb, 100, 60)
+    rt.p_gbuffer.pick_pixel(10, 10)
+    rt.p_gbuffer.render(cb, rt.scene, rt.gbuffer)
+    with pytest.raises(RuntimeError):
+        rt.p_gbuffer.read_pick()

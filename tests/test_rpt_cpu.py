@@ -362,3 +362,28 @@ def test_moved_instances_in_subtrees_of_their_own():
         assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), f"frame {f}"
         _assert_same_state(o, x, f)
     assert len(digests) == 3
+
+
+def test_picked_pixel_reports_the_mesh_under_it(cornell_emissive, oracle_emissive, hx_emissive):
+    """GBufferRT::PickPixel (GBufferRT.h:36-46, GBufferRT_Inline.hlsl:241-242: g_pick[0] = hitMeshIdx, UINT32_MAX on a miss): the product's K1 stage
+    function on the host == the oracle for a grid of pixels of the Cornell box (walls, boxes, the light, the open front's misses), on a screen tile
+    too; the G-buffer itself is unchanged by a pending pick."""
+    w, h = 96, 64
+    cb = _cb(cornell_emissive, w, h, 3)
+    seen = set()
+    for y in range(2, h, 9):
+        for x in range(1, w, 11):
+            a, b = oracle_emissive.pick(cb, x, y), hx_emissive.pick(cb, x, y)
+            assert a == b, (x, y, a, b)
+            seen.add(a)
+    assert len(seen - {0xffffffff}) >= 5 and max(seen - {0xffffffff}) < len(cornell_emissive.instances)      # several instances
+    # a camera outside the box looking away: every primary ray misses
+    cb_out = _cb(cornell_emissive, w, h, 3, cam_pos=(0.0, 1.0, -30.0), view_dir=(0, 0, -1))
+    assert oracle_emissive.pick(cb_out, 5, 5) == hx_emissive.pick(cb_out, 5, 5) == 0xffffffff
+    # on a tile: the pixel is named in render-target coordinates
+    tile = (32, 32, 64, 32)
+    assert hx_emissive.pick(cb, 40, 50, tile=tile) == oracle_emissive.pick(cb, 40, 50)
+    pa, _ = hx_emissive.gbuffer(cb)
+    pb, _ = oracle_emissive.gbuffer(cb)
+    for n, a, b in zip(wire.GB_PLANE_NAMES, pa, pb):
+        assert np.array_equal(np.asarray(a).view(np.uint8).reshape(-1), np.asarray(b).view(np.uint8).reshape(-1)), n

@@ -51,7 +51,7 @@ EXPORTS = [
     "zr_scene_invalidate_alias_table_deferred", "zr_scene_update_instances_async", "zr_scene_update_emissives_async", "zr_scene_update_materials_async", "zr_scene_set_alias_table_async",
     "zr_scene_set_alias_table", "zr_alias_table_build", "zr_scene_get_alias_table", "zr_scene_get_light_voxel_grid", "zr_scene_get_presampled_sets", "zr_scene_bvh_info", "zr_pass_enable_cost_map", "zr_pass_read_cost_map", "zr_pass_debug_trip_stats",
     "zr_gbuffer_create", "zr_gbuffer_destroy", "zr_gbuffer_set_tile_origin", "zr_gbuffer_download", "zr_gbuffer_device_plane",
-    "zr_params_default", "zr_pass_create", "zr_pass_init", "zr_pass_resize", "zr_pass_reset_temporal",
+    "zr_params_default", "zr_pass_create", "zr_pass_init", "zr_pass_resize", "zr_pass_reset_temporal", "zr_pass_pick_pixel", "zr_pass_clear_pick", "zr_pass_read_pick",
     "zr_pass_set_params", "zr_pass_render", "zr_pass_get_output", "zr_pass_download_output",
     "zr_pass_read_counters", "zr_pass_read_kernel_counters", "zr_pass_enable_timing", "zr_pass_get_timings", "zr_selftest_half_conversions", "zr_pass_destroy",
     "zr_trace_closest", "zr_trace_any",
@@ -323,6 +323,25 @@ class Pass:
 
     def reset_temporal(self):
         _check(lib().zr_pass_reset_temporal(self.h))
+
+    # GBUFFER pass: GBufferRT::PickPixel / ClearPick / the pick read-back (GBufferRT.h:36-46)
+    def pick_pixel(self, x, y):
+        L = lib()
+        L.zr_pass_pick_pixel.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32]
+        _check(L.zr_pass_pick_pixel(self.h, int(x), int(y)))
+
+    def clear_pick(self):
+        L = lib()
+        L.zr_pass_clear_pick.argtypes = [C.c_void_p]
+        _check(L.zr_pass_clear_pick(self.h))
+
+    def read_pick(self, stream=None):
+        """mesh index written by the last G-buffer render over the picked pixel (0xffffffff: the primary ray missed)"""
+        L = lib()
+        L.zr_pass_read_pick.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        out = C.c_uint32(0)
+        _check(L.zr_pass_read_pick(self.h, stream, C.byref(out)))
+        return int(out.value)
 
     def render(self, cb, scene, gbuffer=None, stream=None):
         cbb = np.ascontiguousarray(cb)

@@ -58,12 +58,13 @@ ZR_RPT_GROUP_A(extern template)
 ZR_RPT_GROUP_B(extern template)
 ZR_RPT_GROUP_C(extern template)
 
-__global__ void __launch_bounds__(kBlock) k_gbuffer(SceneView sc, zr_frame_constants g, GBuf gb, uint32_t tilesX)
+// pickXY: x | y << 16 of the pixel to pick (render-target coordinates), 0xffffffff = none
+__global__ void __launch_bounds__(kBlock) k_gbuffer(SceneView sc, zr_frame_constants g, GBuf gb, uint32_t tilesX, uint32_t pickXY, uint32_t* pick)
 {
     uint32_t x, y; PixelOfThread(tilesX, gb.x0, gb.y0, &x, &y);
     if (x >= gb.x0 + gb.w || y >= gb.y0 + gb.h) return;
     ZR_TRAV_STACK(stack);
-    GBufferPixel(sc, g, gb, x, y, stack, nullptr);
+    GBufferPixel(sc, g, gb, x, y, stack, nullptr, (x | (y << 16)) == pickXY ? pick : nullptr);
 }
 
 template<bool TEX>
@@ -807,6 +808,8 @@ struct zr_pass
     DevBuf<float> finalRGBA; DevBuf<F4> firstBOP; DevBuf<uint32_t> counts; DevBuf<unsigned long long> counters;
     DevBuf<uint32_t> groupMax;      // kMaxRounds x (8x8 groups of the tile): RR reduction keys
     zr_counters hostCounters{0, 0};
+    // GBUFFER: GBufferRT::PickPixel (GBufferRT.h:36-46).  pickXY = x | y << 16, 0xffffffff = no pick pending; pickBuf[0] = the last picked mesh index
+    uint32_t pickXY = 0xffffffffu; DevBuf<uint32_t> pickBuf; bool pickWritten = false;
     // INDIRECT / ReSTIR PT: two reservoir sets (7 planes each), two r-buffers, target, spatial neighbour, sample set
     struct ResStorage
     {
@@ -2000,10 +2003,43 @@ static int RenderGBuffer(zr_pass* p, hipStream_t s, const zr_frame_constants* cb
     const uint32_t tilesX = (gb->w + 15) / 16, tilesY = (gb->h + 15) / 16;
     gb->cur ^= 1; gb->numRendered++;
     TimerBegin(p, s, "gbuffer");
-    hipLaunchKernelGGL(k_gbuffer, dim3(tilesX * tilesY), dim3(kBlock), 0, s, FrameView(sc, cb), *cb, gb->View(), tilesX);
+    uint32_t pickXY = 0xffffffffu;
+    if (p->pickXY != 0xffffffffu)
+    {
+        // a pending pick: only a G-buffer (tile) that holds the pixel writes
+        if (!p->pickBuf.p) { int r = p->pickBuf.Alloc(1); if (r) return r; }
+        const uint32_t px = p->pickXY & 0xffffu, py = p->pickXY >> 16;
+        if (px >= gb->x0 && px < gb->x0 + gb->w && py >= gb->y0 && py < gb->y0 + gb->h) { pickXY = p->pickXY; p->pickWritten = true; }
+    }
+    hipLaunchKernelGGL(k_gbuffer, dim3(tilesX * tilesY), dim3(kBlock), 0, s, FrameView(sc, cb), *cb, gb->View(), tilesX, pickXY, p->pickBuf.p);
     TimerEnd(p, s);
     HIP_TRY(hipGetLastError());
     p->hostCounters.n_closest += (uint64_t)gb->w * gb->h;
+    return ZR_OK;
+}
+
+// GBufferRT::PickPixel / ClearPick / GetPickReadbackBuffer (GBufferRT.h:36-46): every GBUFFER render while a pick is pending writes the mesh index under
+// the pixel (GBufferRT_Inline.hlsl:241-242: hitMeshIdx, UINT32_MAX on a miss)
+int zr_pass_pick_pixel(zr_pass* p, uint32_t x, uint32_t y)
+{
+    if (!p || p->kind != ZR_PASS_GBUFFER) return Fail(ZR_ERR_INVALID_ARG, "zr_pass_pick_pixel: needs a GBUFFER pass");
+    if (x >= 0xffffu || y >= 0xffffu) return Fail(ZR_ERR_INVALID_ARG, "zr_pass_pick_pixel: pixel (%u, %u) out of range", x, y);      // (UINT16_MAX is the reference's "no pick")
+    p->pickXY = x | (y << 16); p->pickWritten = false;
+    return ZR_OK;
+}
+int zr_pass_clear_pick(zr_pass* p)
+{
+    if (!p || p->kind != ZR_PASS_GBUFFER) return Fail(ZR_ERR_INVALID_ARG, "zr_pass_clear_pick: needs a GBUFFER pass");
+    p->pickXY = 0xffffffffu;
+    return ZR_OK;
+}
+int zr_pass_read_pick(zr_pass* p, void* stream, uint32_t* mesh_idx)
+{
+    if (!p || p->kind != ZR_PASS_GBUFFER || !mesh_idx) return Fail(ZR_ERR_INVALID_ARG, "zr_pass_read_pick: needs a GBUFFER pass and an output");
+    if (!p->pickWritten) return Fail(ZR_ERR_NOT_INITIALIZED, "zr_pass_read_pick: no G-buffer has been rendered over the picked pixel since zr_pass_pick_pixel");
+    HIP_TRY(hipSetDevice(p->device));
+    HIP_TRY(hipMemcpyAsync(mesh_idx, p->pickBuf.p, sizeof(uint32_t), hipMemcpyDeviceToHost, (hipStream_t)stream));
+    HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
     return ZR_OK;
 }
 

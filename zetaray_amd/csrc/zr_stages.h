@@ -114,8 +114,9 @@ ZR_HD V3 TangentSpaceToWorldSpace(V2 bumpNormal2, V3 tangent, V3 normal, float s
 
 // K1: one pixel of GBufferRT_Inline.hlsl main (:204-287) + TracePrimaryHit (:72-198) + GBufferRT.hlsli:102-282.
 // Primary rays are coherent, so traversal runs inline in this kernel (no queue round trip).
+// `picked` (the pixel GBufferRT::PickPixel named, else null): receives hitMeshIdx or UINT32_MAX (GBufferRT_Inline.hlsl:241-242)
 ZR_HD void GBufferPixel(const SceneView& sc, const zr_frame_constants& g, const GBuf& gb, uint32_t x, uint32_t y,
-    TravStack stack, uint64_t* nClosest)
+    TravStack stack, uint64_t* nClosest, uint32_t* picked = nullptr)
 {
     const uint32_t px = (y - gb.y0) * gb.w + (x - gb.x0);
     const V2 renderDim = v2((float)g.render_width, (float)g.render_height);
@@ -142,6 +143,7 @@ ZR_HD void GBufferPixel(const SceneView& sc, const zr_frame_constants& g, const 
 
     if (h.tri == kInvalidTri)
     {
+        if (picked) *picked = 0xffffffffu;
         gb.depth[px] = ZR_FLT_MAX;
         gb.mr[px] = (uint16_t)FloatToUNorm8(4.0f / 255.0f);
         V3 prevCam = v3(g.prev_view_inv[3], g.prev_view_inv[7], g.prev_view_inv[11]);
@@ -157,6 +159,7 @@ ZR_HD void GBufferPixel(const SceneView& sc, const zr_frame_constants& g, const 
     }
 
     const TriMeta tm = sc.triMeta[h.tri];
+    if (picked) *picked = tm.mesh;
     const zr_mesh_instance& md = sc.instances[tm.mesh];
     uint32_t tri = tm.prim * 3 + md.base_idx_offset;
     const zr_vertex& V0 = sc.vertices[sc.indices[tri] + md.base_vtx_offset];

@@ -205,6 +205,9 @@ void RenderPassBase::InitRenderPass(int kind, FrameContext* ctx, int integrator)
 
 void GBufferRT::Init(FrameContext* ctx) { InitRenderPass(ZR_PASS_GBUFFER, ctx, 0); }
 void GBufferRT::OnWindowResized() { ZR_CHECK(zr_pass_resize(m_pass, m_ctx->renderWidth, m_ctx->renderHeight)); }
+void GBufferRT::PickPixel(uint16_t x, uint16_t y) { ZR_CHECK(zr_pass_pick_pixel(m_pass, x, y)); m_pickPending = true; }
+void GBufferRT::ClearPick() { ZR_CHECK(zr_pass_clear_pick(m_pass)); m_pickPending = false; }
+uint32_t GBufferRT::ReadPick(void* stream) const { uint32_t v = 0xffffffffu; ZR_CHECK(zr_pass_read_pick(m_pass, stream, &v)); return v; }
 void GBufferRT::Render(Core::CommandList& cl) { ZR_CHECK(zr_pass_render(m_pass, cl.Stream(), &m_ctx->frameConstants, m_ctx->scene, m_ctx->gbuffer)); }
 
 void PreLighting::Init(FrameContext* ctx) { InitRenderPass(ZR_PASS_PRELIGHTING, ctx, 0); ZR_CHECK(zr_params_default(&m_params)); }

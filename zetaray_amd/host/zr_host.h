@@ -188,7 +188,16 @@ namespace RenderPass {
     {
         void Init(FrameContext* ctx);
         void OnWindowResized();
+        // GBufferRT.h:36-46: the next Render()s write the mesh index under the pixel into the pick buffer until ClearPick()
+        void PickPixel(uint16_t pixelX, uint16_t pixelY);
+        bool HasPendingPick() const { return m_pickPending; }
+        void ClearPick();
+        // the reference hands out its read-back buffer (GetPickReadbackBuffer) and the scene maps it a frame later; here: the value itself, after
+        // waiting for `stream` (UINT32_MAX = the primary ray missed)
+        uint32_t ReadPick(void* stream = nullptr) const;
         void Render(Core::CommandList& cmdList);
+    private:
+        bool m_pickPending = false;
     };
 
     struct PreLighting final : public RenderPassBase
