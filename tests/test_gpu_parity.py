@@ -1863,3 +1863,81 @@ def test_pick_pixel_reports_the_mesh_under_the_cursor(api, cornell_emissive, ora
     rt.p_gbuffer.render(cb, rt.scene, rt.gbuffer)
     with pytest.raises(RuntimeError):
         rt.p_gbuffer.read_pick()
+
+
+def test_background_rebuild_edge_cases(api, cornell_emissive):
+    """zr_scene_set_background_rebuild at its edges: (a) a scene of small instances in which every instance but one ends up with a subtree of its own (the boxes
+    and walls of the Cornell scene all move a little each frame; only the light is left for the common tree), installs waited for; (b) the switch turned off
+    while a build is in flight -- the finished tree is never installed and later updates keep refitting; (c) a scene below the builder's node
+    threshold never starts a build.  G-buffer and ReSTIR PT radiance == oracle on every frame."""
+    import copy
+    import time
+    from oracle import zro
+    w, h = 96, 64
+    prm = wire.default_params()
+
+    def wait_builder(scene):
+        t0 = time.perf_counter()
+        while scene.background_rebuild_stats()[2] == 1 and time.perf_counter() - t0 < 20.0:
+            time.sleep(0.005)
+
+    def run(sc, frames, mover, switch_off_at=None, cam=None):
+        r = api.Renderer(sc, w, h, params=prm, integrator=api.INTEGRATOR_RESTIR_PT)
+        r.scene.set_background_rebuild(True)
+        osc = zro.OracleScene(sc, force_bvh=True)
+        opt = zro.OracleRPT(osc, w, h)
+        prev, xf = None, {}
+        for f in range(1, frames + 1):
+            if f >= 2:
+                mover(sc, f, xf)
+                r.scene.update_instances(sc.instances, sc.instance_to_world)
+                osc.update_instances(sc.instances, sc.instance_to_world)
+                if switch_off_at is None or f < switch_off_at:
+                    wait_builder(r.scene)
+                if f == switch_off_at:
+                    r.scene.set_background_rebuild(False)
+            cb = _chain(_frame(sc, w, h, f, **(cam or {})), prev)
+            prev = cb.copy()
+            r.render_frame(cb)
+            want = opt.render(cb, prm)
+            planes, _ = r.gbuffer.download()
+            oplanes, _ = osc.gbuffer(cb)
+            for n, a, b in zip(wire.GB_PLANE_NAMES, planes, oplanes):
+                assert np.array_equal(np.asarray(a).view(np.uint8).reshape(-1), np.asarray(b).view(np.uint8).reshape(-1)), f"frame {f}: G-buffer plane {n}"
+            assert np.array_equal(r.final().view(np.uint32), want.view(np.uint32)), f"frame {f}"
+        wait_builder(r.scene)
+        return r.scene.background_rebuild_stats()
+
+    # (a) every instance of the Cornell scene moves (by a hair: the light's emissive records are not updated, so it keeps its place)
+    sc = copy.copy(cornell_emissive)
+    sc.instances, sc.instance_to_world, sc._desc = cornell_emissive.instances.copy(), cornell_emissive.instance_to_world.copy(), None
+    light = [i for i in range(len(sc.instances)) if not (sc.instance_mask[i] & wire.SUBGROUP_NON_EMISSIVE)]
+    t0 = sc.instances["translation"].copy()
+
+    def all_move(s, f, xf):
+        for i in range(len(s.instances)):
+            if i not in light:
+                scene_io.move_instance(s, i, translation=t0[i] + np.float32([0.002 * (f - 1) * ((i % 3) - 1), 0.0, 0.001 * (f - 1)]), xform_of=xf)
+    started, installed, _ = run(sc, 7, all_move)
+    assert started >= 2 and installed >= 2, (started, installed)
+
+    # (b) switched off while the builder runs: nothing more is installed, frames stay exact
+    sc = scene_io.make_synthetic_scene(num_tris=3000, num_emissive=150, seed=11)
+    cand = [i for i in range(1, len(sc.instances)) if sc.instance_mask[i] & wire.SUBGROUP_NON_EMISSIVE]
+    idx = max(cand, key=lambda i: int(sc.instance_num_tris[i]))
+    t1 = sc.instances["translation"][idx].copy()
+
+    def one_moves(s, f, xf):
+        scene_io.move_instance(s, idx, translation=t1 + np.float32([0.04 * (f - 1), 0.0, -0.02 * (f - 1)]), xform_of=xf)
+    started, installed, building = run(sc, 8, one_moves, switch_off_at=4, cam=dict(cam_pos=(0, 0, -3.5)))
+    assert building != 1 and installed <= started and installed <= 2, (started, installed, building)
+
+    # (c) six triangles: no nodes, nothing to build
+    from tests.test_rpt_cpu import _six_triangle_scene
+    sc = _six_triangle_scene(cornell_emissive)
+    t2 = sc.instances["translation"][0].copy()
+
+    def wall_moves(s, f, xf):
+        scene_io.move_instance(s, 0, translation=t2 + np.float32([0.0, 0.0, 0.01 * (f - 1)]), xform_of=xf)
+    started, installed, _ = run(sc, 4, wall_moves)
+    assert started == 0 and installed == 0
