@@ -1941,3 +1941,62 @@ def test_background_rebuild_edge_cases(api, cornell_emissive):
         scene_io.move_instance(s, 0, translation=t2 + np.float32([0.0, 0.0, 0.01 * (f - 1)]), xform_of=xf)
     started, installed, _ = run(sc, 4, wall_moves)
     assert started == 0 and installed == 0
+
+
+def test_argument_validation_sweep(api, cornell_emissive):
+    """Every misuse below must come back as a ZetaRayError with a message -- never a crash, a hang or a silent no-op -- and must leave the objects
+    usable: the frame rendered afterwards equals the one rendered before.  (The reference aborts through Check(); this ABI returns error codes)"""
+    import torch
+    w, h = 64, 64
+    prm = wire.default_params()
+    r = api.Renderer(cornell_emissive, w, h, params=prm, integrator=api.INTEGRATOR_RESTIR_PT)
+    cb = _frame(cornell_emissive, w, h, 1)
+    r.render_frame(cb)
+    before = r.final().copy()
+    E = api.ZetaRayError
+    buf = torch.zeros(1 << 16, dtype=torch.uint8, device="cuda")
+
+    def bad(fn, *a, **k):
+        with pytest.raises(E) as ei:
+            fn(*a, **k)
+        assert str(ei.value) and "error" in str(ei.value)
+
+    # scene updates: wrong counts / ranges
+    bad(r.scene.update_instances, cornell_emissive.instances[:-1], cornell_emissive.instance_to_world[:-1])
+    bad(r.scene.update_emissives, cornell_emissive.emissives, first=1)                                  # [1, n + 1) exceeds the scene's triangles
+    bad(r.scene.update_materials, cornell_emissive.materials, first=len(cornell_emissive.materials))
+    # passes: wrong kind for the call
+    bad(r.p_indirect.pick_pixel, 3, 3)
+    bad(r.p_gbuffer.pick_pixel, 0xffff, 1)
+    bad(r.p_gbuffer.read_pick)                                                                          # nothing picked yet
+    bad(r.p_indirect.render_stage, cb, r.scene, r.gbuffer, 0)                                           # no stage selected
+    bad(r.p_indirect.render_stage, cb, r.scene, r.gbuffer, api.STAGE_DENOISE_TEMPORAL)                  # a denoise step bit on the integrator
+    bad(r.p_indirect.set_input, 0, 0)                                                                   # not a compositing / post pass
+    bad(r.p_indirect.download_raw, 9999, np.float32, (h, w, 4))                                         # unknown output id
+    # parameters out of range
+    for field, value in (("max_non_tr_bounces", 0), ("max_glossy_tr_bounces", 99), ("m_max_temporal", 0), ("num_spatial_passes", 3), ("tex_filter", 17)):
+        p2 = wire.default_params()
+        setattr(p2, field, value)
+        bad(r.p_indirect.set_params, p2)
+    p2 = wire.default_params()
+    p2.presampling, p2.num_sample_sets = 1, 0
+    bad(r.p_indirect.set_params, p2)
+    # tiles: unaligned origin / owned rect, rects outside the pass, a transfer buffer that is too small
+    bad(r.p_indirect.set_owned_rect, 16, 0, 32, 32)
+    bad(r.p_indirect.set_owned_rect, 0, 0, 32, 0)
+    bad(r.p_indirect.set_owned_rect, 0, 0, 4096, 4096)
+    bad(r.p_indirect.halo_pack, r.gbuffer, api.HALO_POST_TEMPORAL, (48, 48, 32, 32), buf.data_ptr(), buf.numel())      # leaves the 64 x 64 pass
+    bad(r.p_indirect.halo_pack, r.gbuffer, api.HALO_POST_TEMPORAL, (0, 0, 32, 32), buf.data_ptr(), 16)                    # 32 x 32 x 62 B do not fit 16 B
+    bad(r.p_indirect.halo_pack, r.gbuffer, 77, (0, 0, 32, 32), buf.data_ptr(), buf.numel())                                # unknown halo set
+    bad(r.p_indirect.resize, 0, 16)
+    # a G-buffer of another size than the pass
+    gb2 = api.GBuffer(32, 32)
+    bad(r.p_indirect.render, _frame(cornell_emissive, w, h, 2), r.scene, gb2)
+    # ... and everything still works: frame 1 again on fresh temporal state equals the first render
+    r.p_indirect.reset_temporal()
+    r2 = api.Renderer(cornell_emissive, w, h, params=prm, integrator=api.INTEGRATOR_RESTIR_PT)
+    r2.render_frame(cb)
+    assert np.array_equal(r2.final().view(np.uint32), before.view(np.uint32))
+    r.p_gbuffer.render(cb, r.scene, r.gbuffer)
+    r.p_indirect.render(cb, r.scene, r.gbuffer)
+    assert np.array_equal(r.final().view(np.uint32), before.view(np.uint32))
