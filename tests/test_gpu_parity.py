@@ -2000,3 +2000,50 @@ def test_argument_validation_sweep(api, cornell_emissive):
     r.p_gbuffer.render(cb, r.scene, r.gbuffer)
     r.p_indirect.render(cb, r.scene, r.gbuffer)
     assert np.array_equal(r.final().view(np.uint32), before.view(np.uint32))
+
+
+def test_argument_validation_sweep_of_the_other_passes(api, cornell_emissive):
+    """The same for the post / direct-lighting passes and the scene object: unbound inputs, sizes that do not match, out-of-range parameters."""
+    w, h = 64, 64
+    E = api.ZetaRayError
+    r = api.Renderer(cornell_emissive, w, h, params=wire.default_params(), integrator=api.INTEGRATOR_RESTIR_PT)
+    cb = _frame(cornell_emissive, w, h, 1)
+    r.render_frame(cb)
+
+    def bad(fn, *a, **k):
+        with pytest.raises(E) as ei:
+            fn(*a, **k)
+        assert str(ei.value)
+
+    for kind in (api.PASS_TAA, api.PASS_DENOISE, api.PASS_AUTO_EXPOSURE, api.PASS_DISPLAY):
+        p = api.Pass(kind, w, h)
+        bad(p.render, cb, r.scene, r.gbuffer)                              # no input bound
+        bad(p.set_input, 99, r.p_indirect.output_ptr()[0])                 # unknown input id
+    dn = api.Pass(api.PASS_DENOISE, w, h)
+    for field, value in (("svgf_iterations", 9), ("svgf_normal_power_log2", 40)):
+        p2 = wire.default_params()
+        setattr(p2, field, value)
+        bad(dn.set_params, p2)
+    dn.set_input(api.IN_DENOISE_SIGNAL, r.p_indirect.output_ptr()[0])
+    gb2 = api.GBuffer(32, 32)
+    bad(dn.render, cb, r.scene, gb2)                                       # G-buffer of another size
+    comp = api.Pass(api.PASS_COMPOSITING, w, h)
+    bad(comp.render, cb, r.scene, gb2)
+    di = api.Pass(api.PASS_DI_EMISSIVE, w, h)
+    p2 = wire.default_params_di()
+    p2.m_max_temporal = 31
+    bad(di.set_params, p2)
+    sdi = api.Pass(api.PASS_DI_SKY, w, h)
+    p2 = wire.default_params_sky_di()
+    p2.m_max_spatial = 16
+    bad(sdi.set_params, p2)
+    # scene: an alias table of the wrong length, a voxel grid that was never built
+    bad(r.scene.set_alias_table, r.scene.get_alias_table()[:-1])
+    bad(r.scene.get_light_voxel_grid, (4, 4, 4))
+    bad(r.scene.get_presampled_sets, 4, 8)
+    # the renderer is unharmed
+    r2 = api.Renderer(cornell_emissive, w, h, params=wire.default_params(), integrator=api.INTEGRATOR_RESTIR_PT)
+    r2.render_frame(cb)
+    r.p_indirect.reset_temporal()
+    r.render_frame(cb)
+    assert np.array_equal(r.final().view(np.uint32), r2.final().view(np.uint32))

@@ -1992,6 +1992,8 @@ int zr_pass_set_params(zr_pass* p, const zr_params* prm)
     // the reservoir caps travel in 4-bit fields of cb_ReSTIR_PT_*::Packed (IndirectLighting.cpp:1260-1270: "M_max (Temporal)" 1..15, "M_max (Spatial)" 1..12)
     if (p->kind == ZR_PASS_INDIRECT && (prm->m_max_temporal < 1 || prm->m_max_temporal > 15 || prm->m_max_spatial < 1 || prm->m_max_spatial > 15))
         return Fail(ZR_ERR_INVALID_ARG, "indirect lighting: M_max (temporal %u, spatial %u) must be in 1..15", prm->m_max_temporal, prm->m_max_spatial);
+    if (p->kind == ZR_PASS_DENOISE && (prm->svgf_iterations > 8u || prm->svgf_normal_power_log2 > 16u))
+        return Fail(ZR_ERR_INVALID_ARG, "DENOISE: svgf_iterations must be <= 8, svgf_normal_power_log2 <= 16");
     if (p->kind == ZR_PASS_INDIRECT && prm->num_spatial_passes > 2u) return Fail(ZR_ERR_INVALID_ARG, "ReSTIR PT: num_spatial_passes must be 0, 1 or 2 (IndirectLighting.cpp:1238-1240)");
     if (prm->presampling && (prm->num_sample_sets == 0 || prm->sample_set_size == 0 || prm->num_sample_sets > 65535 || prm->sample_set_size > 65535))
         return Fail(ZR_ERR_INVALID_ARG, "presampling needs 1..65535 sample sets of 1..65535 samples");
