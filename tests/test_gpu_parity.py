@@ -2047,3 +2047,83 @@ def test_argument_validation_sweep_of_the_other_passes(api, cornell_emissive):
     r.p_indirect.reset_temporal()
     r.render_frame(cb)
     assert np.array_equal(r.final().view(np.uint32), r2.final().view(np.uint32))
+
+
+def test_distinct_handles_driven_from_concurrent_host_threads(api, cornell_emissive):
+    """The threading contract of the boundary (SURVEY 8(b): the reference records its passes on worker threads, nodes of one batch concurrently;
+    "distinct handles may be driven from distinct host threads concurrently; a single handle is externally serialised").  Three host threads,
+    each with a scene + G-buffer + passes of its own and its own non-blocking stream -- ReSTIR PT, ReSTIR GI and the path tracer, 5 frames with a
+    moving camera, creation and destruction inside the threads, three rounds -- produce what the same work produces on one thread.  Then the
+    reference's own concurrency: ONE scene and G-buffer, the DirectLighting and IndirectLighting passes of a frame enqueued from two threads on two streams."""
+    import threading
+    import torch
+    w, h, n = 96, 64, 5
+    sc_syn = scene_io.make_synthetic_scene(num_tris=3000, num_emissive=150, seed=11)
+    jobs = [(cornell_emissive, api.INTEGRATOR_RESTIR_PT, {}), (cornell_emissive, api.INTEGRATOR_RESTIR_GI, {}), (sc_syn, api.INTEGRATOR_PATH_TRACING, dict(cam_pos=(0, 0, -3.5)))]
+
+    def frames_of(sc, cam):
+        prev, out = None, []
+        for f in range(1, n + 1):
+            kw = dict(cam)
+            kw["cam_pos"] = tuple(np.float32(kw.get("cam_pos", (0.0, 1.2, -4.043))) + np.float32([0.02 * f, 0, 0]))
+            cb = _chain(_frame(sc, w, h, f, **kw), prev)
+            prev = cb.copy()
+            out.append(cb)
+        return out
+
+    def work(job, out, idx, use_stream):
+        sc, integ, cam = job
+        try:
+            st = torch.cuda.Stream() if use_stream else None
+            r = api.Renderer(sc, w, h, params=wire.default_params(), integrator=integ)
+            for cb in frames_of(sc, cam):
+                r.render_frame(cb, stream=st.cuda_stream if st is not None else None)
+            if st is not None:
+                st.synchronize()
+            out[idx] = r.final().copy()
+        except Exception as e:      # surfaced by the assert below
+            out[idx] = e
+
+    serial = [None] * len(jobs)
+    for i, j in enumerate(jobs):
+        work(j, serial, i, False)
+    assert all(isinstance(a, np.ndarray) for a in serial), serial
+    for rnd in range(3):
+        got = [None] * len(jobs)
+        ts = [threading.Thread(target=work, args=(j, got, i, True)) for i, j in enumerate(jobs)]
+        for t in ts:
+            t.start()
+        for t in ts:
+            t.join(120)
+        for i in range(len(jobs)):
+            assert isinstance(got[i], np.ndarray), (rnd, i, got[i])
+            assert np.array_equal(got[i].view(np.uint32), serial[i].view(np.uint32)), (rnd, i)
+
+    # one scene, one G-buffer, two passes of the same batch from two threads on two streams
+    def shared(concurrent):
+        r = api.Renderer(cornell_emissive, w, h, params=wire.default_params(), integrator=api.INTEGRATOR_RESTIR_PT)
+        r.enable_direct(wire.default_params_di())
+        sa, sb = torch.cuda.Stream(), torch.cuda.Stream()
+        errs = []
+        for cb in frames_of(cornell_emissive, {}):
+            r.p_gbuffer.render(cb, r.scene, r.gbuffer)
+            r.p_prelight.render(cb, r.scene, None)
+            torch.cuda.synchronize()
+
+            def go(p, st):
+                try:
+                    p.render(cb, r.scene, r.gbuffer, st.cuda_stream)
+                except Exception as e:
+                    errs.append(e)
+            if concurrent:
+                ta, tb = threading.Thread(target=go, args=(r.p_direct, sa)), threading.Thread(target=go, args=(r.p_indirect, sb))
+                ta.start(); tb.start(); ta.join(60); tb.join(60)
+            else:
+                go(r.p_direct, sa); go(r.p_indirect, sb)
+            torch.cuda.synchronize()
+        assert not errs, errs
+        return r.p_direct.download().copy(), r.final().copy()
+    d0, i0 = shared(False)
+    for rnd in range(2):
+        d1, i1 = shared(True)
+        assert np.array_equal(d0.view(np.uint32), d1.view(np.uint32)) and np.array_equal(i0.view(np.uint32), i1.view(np.uint32)), rnd
