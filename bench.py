@@ -346,7 +346,7 @@ def measure(args, ctx):
                    "parallelism": f"screen tiles {tile_grid(world)}" + (f" ({layout_kind})" if (tiled is not None and world > 1 and rpt) else "") + (
                        f", 32-px apron, RCCL p2p halo exchange of reservoir planes ({tiled.bpp} B/px): {tiled.halo_bytes} B sent per "
                        f"rank per exchange, {exch_per_frame:g} exchanges per frame (the previous frame's final reservoirs are fetched only by frames whose reprojection can cross a tile border: not while camera and scene stand still)"
-                       if (tiled is not None and world > 1) else ""),
+                       if (tiled is not None and world > 1) else "") + ("; every rank's FINAL tile stays on its device (no gather inside the timed region)" if world > 1 else ""),
                    "halo_transport": (tiled.transport if (tiled is not None and world > 1) else None),
                    "preset": args.config, "settle_frames": settle, "arith": args.arith, "library": os.path.basename(api.LIB_PATH),
                    "rays_per_frame": round((n_closest + n_shadow) / args.steps, 1),
