@@ -343,7 +343,7 @@ int zr_pass_reset_temporal(zr_pass* pass);
 /* GBUFFER pass: GBufferRT::PickPixel / ClearPick / GetPickReadbackBuffer (GBuffer/GBufferRT.h:36-46).  While a pick is pending every GBUFFER render writes
    the mesh index (GeometryIndex + InstanceID: the index of the instance record) under pixel (x, y) of the render target, UINT32_MAX when the primary ray
    misses (GBufferRT_Inline.hlsl:241-242); on a screen tile only the pass whose tile holds the pixel writes.  zr_pass_read_pick copies the value back on
-   `stream` and waits for it; ZR_ERR_NOT_INITIALIZED when no render has covered the pixel since zr_pass_pick_pixel. */
+   `stream` -- the stream the G-buffer was rendered on, or one ordered behind it -- and waits for it; ZR_ERR_NOT_INITIALIZED when no render has covered the pixel since zr_pass_pick_pixel. */
 int zr_pass_pick_pixel(zr_pass* pass, uint32_t x, uint32_t y);
 int zr_pass_clear_pick(zr_pass* pass);
 int zr_pass_read_pick(zr_pass* pass, void* stream, uint32_t* mesh_idx);
