@@ -30,7 +30,7 @@ def _scene(kind):
 TEX_OFFSETS = {}      # scene kind -> the four descriptor-table offsets of its texture heap (cbFrameConstants::*MapsDescHeapOffset)
 
 
-def _params(bounces=None, presample=None, flags_off=0, kind=None, tex_filter=None, spatial_passes=None):
+def _params(bounces=None, presample=None, flags_off=0, kind=None, tex_filter=None, spatial_passes=None, flags_on=0, m_max=None, alpha_min=None):
     from zetaray_amd import wire
     p = wire.default_params_di() if kind == "di" else (wire.default_params_sky_di() if kind == "sdi" else wire.default_params())
     if bounces:
@@ -38,6 +38,11 @@ def _params(bounces=None, presample=None, flags_off=0, kind=None, tex_filter=Non
     if presample:
         p.presampling, p.num_sample_sets, p.sample_set_size = 1, presample[0], presample[1]
     p.flags &= ~flags_off
+    p.flags |= flags_on
+    if m_max:
+        p.m_max_temporal, p.m_max_spatial = m_max
+    if alpha_min is not None:      # the settings UI's value; the constant buffers hold its square (IndirectLighting.cpp:1593-1600, DirectLighting.cpp:404-408)
+        p.alpha_min = float(np.float32(alpha_min) * np.float32(alpha_min))
     if tex_filter is not None:
         p.tex_filter = tex_filter
     if spatial_passes is not None:
@@ -64,6 +69,11 @@ CASES = {
     "rpt_two_spatial_materials": ("materials_lights", "rpt", 3, dict(spatial_passes=2, bounces=(6, 8)), False),
     "rpt_no_spatial": ("materials_lights", "rpt", 3, dict(spatial_passes=0), False),
     "rpt_two_spatial_sun_sky": ("cornell", "rpt", 3, dict(spatial_passes=2), False),      # the NEE_EMISSIVE == 0 permutation (component-wise reservoir writes) through two rounds
+    # the settings UI's knobs off their defaults (IndirectLighting.cpp:1468-1600 / DirectLighting.cpp:374-410 callbacks; the C++ mirror's setters): 2 / 3
+    # bounces, no Russian roulette, M_max 6 / 5, temporal sort off, boiling suppression off, path regularisation ON, Alpha_min 0.2; DI: M_max 12, no extra
+    # disocclusion samples, deterministic spatial neighbours, Alpha_min 0.1
+    "rpt_tuned": ("materials_lights", "rpt", 3, dict(bounces=(2, 3), m_max=(6, 5), alpha_min=0.2, flags_off=(1 << 3) | (1 << 4) | (1 << 6), flags_on=(1 << 5)), False),
+    "di_tuned": ("materials_lights", "di", 3, dict(m_max=(12, 20), alpha_min=0.1, flags_off=(1 << 8) | (1 << 9)), False),
     "gi_cornell_moving": ("cornell_emissive", "gi", 4, {}, True),
     "gi_materials_rr": ("materials_lights", "gi", 3, dict(bounces=(6, 8)), False),
     "gi_presampled": ("materials_lights", "gi", 3, dict(presample=(32, 128)), False),
