@@ -74,6 +74,9 @@ CASES = {
     # disocclusion samples, deterministic spatial neighbours, Alpha_min 0.1
     "rpt_tuned": ("materials_lights", "rpt", 3, dict(bounces=(2, 3), m_max=(6, 5), alpha_min=0.2, flags_off=(1 << 3) | (1 << 4) | (1 << 6), flags_on=(1 << 5)), False),
     "di_tuned": ("materials_lights", "di", 3, dict(m_max=(12, 20), alpha_min=0.1, flags_off=(1 << 8) | (1 << 9)), False),
+    # ReSTIR GI: CB_IND_FLAGS::STOCHASTIC_MULTI_BOUNCE on, boiling suppression off, M_max 6, 2 / 3 bounces; sun + sky DI: M_max (sky) 8, M_max (sun) 2, Alpha_min 0.2
+    "gi_tuned": ("materials_lights", "gi", 4, dict(bounces=(2, 3), m_max=(6, 8), flags_on=(1 << 2), flags_off=(1 << 4)), False),
+    "sdi_tuned": ("cornell", "sdi", 4, dict(m_max=(8, 2), alpha_min=0.2), True),
     "gi_cornell_moving": ("cornell_emissive", "gi", 4, {}, True),
     "gi_materials_rr": ("materials_lights", "gi", 3, dict(bounces=(6, 8)), False),
     "gi_presampled": ("materials_lights", "gi", 3, dict(presample=(32, 128)), False),
