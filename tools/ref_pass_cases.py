@@ -77,6 +77,10 @@ CASES = {
     # ReSTIR GI: CB_IND_FLAGS::STOCHASTIC_MULTI_BOUNCE on, boiling suppression off, M_max 6, 2 / 3 bounces; sun + sky DI: M_max (sky) 8, M_max (sun) 2, Alpha_min 0.2
     "gi_tuned": ("materials_lights", "gi", 4, dict(bounces=(2, 3), m_max=(6, 8), flags_on=(1 << 2), flags_off=(1 << 4)), False),
     "sdi_tuned": ("cornell", "sdi", 4, dict(m_max=(8, 2), alpha_min=0.2), True),
+    # depth of field (cbFrameConstants::DoF / LensRadius / FocusDepth; GBufferRT_Inline.hlsl:215-231: the primary ray leaves a lens sample, the depth plane
+    # holds t, the motion vector is non-zero on a still frame): K1 + ReSTIR PT with a moving camera, and the textured path tracer (CameraRayUVGradsScale)
+    "rpt_dof": ("cornell_emissive", "rpt", 3, {}, True),
+    "k9_textured_dof": ("textured", "pt", 2, {}, False),
     "gi_cornell_moving": ("cornell_emissive", "gi", 4, {}, True),
     "gi_materials_rr": ("materials_lights", "gi", 3, dict(bounces=(6, 8)), False),
     "gi_presampled": ("materials_lights", "gi", 3, dict(presample=(32, 128)), False),
@@ -102,6 +106,8 @@ CASES = {
     "di_moving_instance": ("cornell_emissive", "di", 6, {}, False),
     "sdi_moving_instance": ("cornell", "sdi", 5, {}, False),
 }
+# per-case edits of the frame constants
+CB_EDIT = {"rpt_dof": dict(dof=1, lens_radius=0.05, focus_depth=4.0), "k9_textured_dof": dict(dof=1, lens_radius=0.05, focus_depth=3.0, camera_ray_uv_grads_scale=0.75)}
 ANIMATED = {"rpt_moving_instance", "di_moving_instance", "sdi_moving_instance", "rpt_moving_light", "di_moving_light"}
 MOVING_LIGHT = {"rpt_moving_light", "di_moving_light"}
 RPT_PLANES = ("A", "B", "C", "D", "E", "F", "G", "neighbor", "map_ctn", "map_ntc")      # + the K12 thread maps of the last frame
@@ -167,6 +173,8 @@ def frames_of(case):
         cb = scene_io.make_frame_constants(W, H, frame_num=f, num_emissives=len(sc.emissives), **kw)
         if kind in TEX_OFFSETS:
             scene_io.set_texture_heap_offsets(cb, TEX_OFFSETS[kind])
+        for k, v in CB_EDIT.get(case, {}).items():
+            cb[k] = v
         if prev is not None:
             cb["prev_view"], cb["prev_view_inv"], cb["prev_camera_jitter"] = prev["curr_view"], prev["curr_view_inv"], prev["curr_camera_jitter"]
         prev = cb.copy()
