@@ -81,6 +81,11 @@ CASES = {
     # holds t, the motion vector is non-zero on a still frame): K1 + ReSTIR PT with a moving camera, and the textured path tracer (CameraRayUVGradsScale)
     "rpt_dof": ("cornell_emissive", "rpt", 3, {}, True),
     "k9_textured_dof": ("textured", "pt", 2, {}, False),
+    # frame accumulation (cbFrameConstants::Accumulate && CameraStatic, NumFramesCameraStatic: ReSTIR_PT/Util.hlsli:141-159, ReSTIR_DI_Temporal.hlsl:274-303,
+    # PathTracer.hlsl:205-211): FINAL sums the frames of a standing camera.  (ReSTIR PT and DI only: the path-tracer harness keeps no FINAL between frames;
+    # K9's accumulation is the linearity test of tests/test_gpu_parity.py)
+    "rpt_accumulate": ("cornell_emissive", "rpt", 4, {}, False),
+    "di_accumulate": ("cornell_emissive", "di", 4, {}, False),
     "gi_cornell_moving": ("cornell_emissive", "gi", 4, {}, True),
     "gi_materials_rr": ("materials_lights", "gi", 3, dict(bounces=(6, 8)), False),
     "gi_presampled": ("materials_lights", "gi", 3, dict(presample=(32, 128)), False),
@@ -108,6 +113,9 @@ CASES = {
 }
 # per-case edits of the frame constants
 CB_EDIT = {"rpt_dof": dict(dof=1, lens_radius=0.05, focus_depth=4.0), "k9_textured_dof": dict(dof=1, lens_radius=0.05, focus_depth=3.0, camera_ray_uv_grads_scale=0.75)}
+_ACC = lambda f: dict(accumulate=1, camera_static=1 if f > 1 else 0, num_frames_static=f - 1)      # noqa: E731
+# (the DI pass accumulates Le_SkyWithSunDisk at miss pixels, ReSTIR_DI_Temporal.hlsl:276-281, and an emissive-only scene binds no sky-view LUT: its camera stands inside the box)
+CB_KW = {"rpt_accumulate": _ACC, "di_accumulate": lambda f: dict(_ACC(f), cam_pos=(0.0, 1.0, -0.9))}      # per-case, per-frame arguments of make_frame_constants
 ANIMATED = {"rpt_moving_instance", "di_moving_instance", "sdi_moving_instance", "rpt_moving_light", "di_moving_light"}
 MOVING_LIGHT = {"rpt_moving_light", "di_moving_light"}
 RPT_PLANES = ("A", "B", "C", "D", "E", "F", "G", "neighbor", "map_ctn", "map_ntc")      # + the K12 thread maps of the last frame
@@ -170,6 +178,7 @@ def frames_of(case):
         kw = dict(cam)
         if moving:
             kw["cam_pos"] = (0.05 * f, 1.2, -4.043 + 0.02 * f)
+        kw.update(CB_KW[case](f) if case in CB_KW else {})
         cb = scene_io.make_frame_constants(W, H, frame_num=f, num_emissives=len(sc.emissives), **kw)
         if kind in TEX_OFFSETS:
             scene_io.set_texture_heap_offsets(cb, TEX_OFFSETS[kind])
