@@ -86,6 +86,13 @@ CASES = {
     # K9's accumulation is the linearity test of tests/test_gpu_parity.py)
     "rpt_accumulate": ("cornell_emissive", "rpt", 4, {}, False),
     "di_accumulate": ("cornell_emissive", "di", 4, {}, False),
+    # the "Temporal Resample" / "Spatial Resample" switches of every ReSTIR pass off (TemporalResamplingCallback / SpatialResamplingCallback of the four passes)
+    "di_no_spatial": ("cornell_emissive", "di", 3, dict(flags_off=(1 << 1)), True),
+    "di_no_reuse": ("materials_lights", "di", 3, dict(flags_off=(1 << 0) | (1 << 1)), False),
+    "sdi_no_spatial": ("cornell", "sdi", 3, dict(flags_off=(1 << 1)), True),
+    "sdi_no_reuse": ("cornell", "sdi", 2, dict(flags_off=(1 << 0) | (1 << 1)), False),
+    "rpt_no_reuse": ("cornell_emissive", "rpt", 3, dict(flags_off=(1 << 0)), True),
+    "gi_no_temporal": ("cornell_emissive", "gi", 3, dict(flags_off=(1 << 0)), True),
     "gi_cornell_moving": ("cornell_emissive", "gi", 4, {}, True),
     "gi_materials_rr": ("materials_lights", "gi", 3, dict(bounces=(6, 8)), False),
     "gi_presampled": ("materials_lights", "gi", 3, dict(presample=(32, 128)), False),
