@@ -93,6 +93,7 @@ CASES = {
     "sdi_no_reuse": ("cornell", "sdi", 2, dict(flags_off=(1 << 0) | (1 << 1)), False),
     "rpt_no_reuse": ("cornell_emissive", "rpt", 3, dict(flags_off=(1 << 0)), True),
     "gi_no_temporal": ("cornell_emissive", "gi", 3, dict(flags_off=(1 << 0)), True),
+    "di_textured": ("textured", "di", 3, {}, False),      # emissive maps in the light samples of K5 / K6 (Le_EmissiveTriangle's texture fetch), the G-buffer of a textured scene
     "gi_cornell_moving": ("cornell_emissive", "gi", 4, {}, True),
     "gi_materials_rr": ("materials_lights", "gi", 3, dict(bounces=(6, 8)), False),
     "gi_presampled": ("materials_lights", "gi", 3, dict(presample=(32, 128)), False),
