@@ -362,3 +362,22 @@ def test_host_bvh_build_is_independent_of_its_thread_count():
         else:
             os.environ["ZR_BVH_THREADS"] = old
     assert len(set(digests)) == 1 and digests[0][1] > 1000, digests
+
+
+@pytest.mark.parametrize("header", ["zetaray_amd.h", "zr_wire.h", "zr_detmath.h", "zr_intersect.h", "zr_texture.h", "zr_srgb_table.h"])
+def test_public_headers_are_plain_c(header, tmp_path):
+    """The boundary is a C ABI: every header under include/ compiles on its own as C99 (-pedantic, warnings are errors) and as C++17 -- what a
+    cgo / JNI / ctypes binding generator or the reference's C++ would feed on; no torch, HIP or C++ types in the signatures."""
+    import shutil
+    import subprocess
+    if shutil.which("gcc") is None or shutil.which("g++") is None:
+        pytest.skip("no host compiler")
+    inc = os.path.join(ROOT, "include")
+    src_c, src_cpp = tmp_path / "t.c", tmp_path / "t.cpp"
+    body = f'#include "{header}"\nint main(void) {{ return 0; }}\n'
+    src_c.write_text(body)
+    src_cpp.write_text(body)
+    for cmd in (["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-fsyntax-only", "-I", inc, str(src_c)],
+                ["g++", "-std=c++17", "-Wall", "-Wextra", "-Werror", "-Wno-unused-function", "-fsyntax-only", "-I", inc, str(src_cpp)]):
+        res = subprocess.run(cmd, capture_output=True, text=True, timeout=120)
+        assert res.returncode == 0, " ".join(cmd) + "\n" + res.stderr[-3000:]
