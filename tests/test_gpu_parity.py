@@ -1868,8 +1868,8 @@ def test_pick_pixel_reports_the_mesh_under_the_cursor(api, cornell_emissive, ora
 def test_background_rebuild_edge_cases(api, cornell_emissive):
     """zr_scene_set_background_rebuild at its edges: (a) a scene of small instances in which every instance but one ends up with a subtree of its own (the boxes
     and walls of the Cornell scene all move a little each frame; only the light is left for the common tree), installs waited for; (b) the switch turned off
-    while a build is in flight -- the finished tree is never installed and later updates keep refitting; (c) a scene below the builder's node
-    threshold never starts a build.  G-buffer and ReSTIR PT radiance == oracle on every frame."""
+    while a build is in flight -- the finished tree is never installed and later updates keep refitting; (b') updates that repeat the same matrices start no build once the resting pose has its tree; (c) a scene below the
+    builder's node threshold never starts a build.  G-buffer and ReSTIR PT radiance == oracle on every frame."""
     import copy
     import time
     from oracle import zro
@@ -1931,6 +1931,17 @@ def test_background_rebuild_edge_cases(api, cornell_emissive):
         scene_io.move_instance(s, idx, translation=t1 + np.float32([0.04 * (f - 1), 0.0, -0.02 * (f - 1)]), xform_of=xf)
     started, installed, building = run(sc, 8, one_moves, switch_off_at=4, cam=dict(cam_pos=(0, 0, -3.5)))
     assert building != 1 and installed <= started and installed <= 2, (started, installed, building)
+
+    # (b') the instance comes to rest after frame 3 while the host keeps handing over (the same) matrices every frame: one more build for the resting
+    # pose, then none
+    sc = scene_io.make_synthetic_scene(num_tris=3000, num_emissive=150, seed=11)
+    t1 = sc.instances["translation"][idx].copy()
+
+    def moves_then_rests(s, f, xf):
+        k = min(f, 3)
+        scene_io.move_instance(s, idx, translation=t1 + np.float32([0.04 * (k - 1), 0.0, -0.02 * (k - 1)]), xform_of=xf)
+    started, installed, building = run(sc, 9, moves_then_rests, cam=dict(cam_pos=(0, 0, -3.5)))
+    assert started == 2 and installed == 2 and building == 0, (started, installed, building)
 
     # (c) six triangles: no nodes, nothing to build
     from tests.test_rpt_cpu import _six_triangle_scene

@@ -606,6 +606,7 @@ struct zr_scene
         uint32_t* pkg = nullptr; size_t pkgCap = 0; hipEvent_t pkgCopied = nullptr; bool pkgInFlight = false;      // pkgCap in words
         std::vector<zr_mesh_instance> inst; std::vector<float> xf; std::vector<uint8_t> own;
         uint32_t refitsSince = 0; uint64_t started = 0, installed = 0;
+        bool movedSinceBuild = false;      // a transform changed since the last build was started: updates that repeat the same matrices start no build
         double buildMs = 0, packMs = 0;
     } bg;
     DevBuf<uint32_t> bgDev;                      // device side of the package (children + slot triangles)
@@ -1389,7 +1390,7 @@ int zr_scene_update_instances_async(zr_scene* s, void* stream, const zr_mesh_ins
     int r;
     for (uint32_t i = 0; i < n; i++) RaiseMaxTex(s, 0, instances[i].base_color_tex);
     for (uint32_t i = 0; i < n; i++)      // the reference's static -> dynamic conversion of an instance that starts to move (SceneCore.cpp:1038)
-        if (std::memcmp(s->hToWorld.data() + 12 * (size_t)i, instance_to_world + 12 * (size_t)i, 12 * sizeof(float))) s->movedEver[i] = 1;
+        if (std::memcmp(s->hToWorld.data() + 12 * (size_t)i, instance_to_world + 12 * (size_t)i, 12 * sizeof(float))) { s->movedEver[i] = 1; s->bg.movedSinceBuild = true; }
     std::memcpy(s->hToWorld.data(), instance_to_world, 12 * (size_t)n * sizeof(float));
     const bool rebuildHost = modeEnv && !std::strcmp(modeEnv, "rebuild_host");
     if (rebuild && s->meta.n > BvhBuilder::kTinyScene)
@@ -1545,10 +1546,11 @@ int zr_scene_update_instances_async(zr_scene* s, void* stream, const zr_mesh_ins
     if (!s->updated) HIP_TRY(hipEventCreateWithFlags(&s->updated, hipEventDisableTiming));
     HIP_TRY(hipEventRecord(s->updated, st));
     s->updatedOn = st; s->hasUpdate = true;
-    if (s->bg.enabled && s->bg.state.load(std::memory_order_acquire) == 0 && s->bg.refitsSince >= 1 && s->meta.n > BvhBuilder::kTinyScene)
+    if (s->bg.enabled && s->bg.state.load(std::memory_order_acquire) == 0 && s->bg.refitsSince >= 1 && s->bg.movedSinceBuild && s->meta.n > BvhBuilder::kTinyScene)
     {
         // start the next build on these transforms (host copies: the caller's arrays are only valid during the call)
         zr_scene::Background& B = s->bg;
+        B.movedSinceBuild = false;
         if (B.th.joinable()) B.th.join();
         B.inst.assign(instances, instances + n); B.xf.assign(instance_to_world, instance_to_world + 12 * (size_t)n);
         { const char* e = std::getenv("ZR_BVH_GROUP"); if (e && !std::strcmp(e, "0")) B.own.clear(); else B.own = s->movedEver; }
