@@ -1591,7 +1591,7 @@ def test_material_edit_between_frames(api):
 
 
 def test_bench_multi_rank_protocol_on_one_gpu():
-    """`bench.py --gpus 2` and `--gpus 4` end to end on a box with ONE GPU: the ranks are real processes launched by torch.distributed.run exactly as the
+    """`bench.py --gpus 2`, `--gpus 4` and `--gpus 8` end to end on a box with ONE GPU: the ranks are real processes launched by torch.distributed.run exactly as the
     driver launches them, but share device 0 and talk over gloo (ZR_BENCH_SHARED_GPU=1, halo strips staged through the host).  What runs is the
     multi-GPU orchestration -- tile split, halo plan, probe frames with the cost map, choose_layout + re-tiling, barrier / max-over-ranks timing,
     whole-job ray count -- everything except RCCL itself (exercised by test_fused_halo_transfer_and_rccl_exchange_on_one_gpu)."""
@@ -1601,7 +1601,7 @@ def test_bench_multi_rank_protocol_on_one_gpu():
     env = dict(os.environ, ZR_BENCH_SHARED_GPU="1", MASTER_ADDR="127.0.0.1")
     singles = []
     # (the last run adds the denoise pass: BASELINE config 5's shape on two ranks -- the three denoise halo exchanges of tiling.denoise_schedule per frame)
-    for n, port, settle, more in ((1, 0, 4, []), (1, 0, 16, []), (2, 29631, 4, []), (4, 29632, 4, []), (2, 29633, 4, ["--denoise"])):
+    for n, port, settle, more in ((1, 0, 4, []), (1, 0, 16, []), (2, 29631, 4, []), (4, 29632, 4, []), (8, 29634, 4, []), (2, 29633, 4, ["--denoise"])):
         cmd = [sys.executable, os.path.join(ROOT, "bench.py")] if n == 1 else \
             [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1", "--master-port", str(port),
              os.path.join(ROOT, "bench.py")]
