@@ -118,14 +118,16 @@ CASES = {
     "di_moving_light": ("cornell_emissive", "di", 5, {}, False),
     "di_moving_instance": ("cornell_emissive", "di", 6, {}, False),
     "sdi_moving_instance": ("cornell", "sdi", 5, {}, False),
+    "gi_moving_instance": ("cornell_emissive", "gi", 5, {}, False),      # ReSTIR GI's temporal pass over a moving box (previous instance buffer, motion vectors of the mover)
+    "gi_moving_light": ("cornell_emissive", "gi", 5, {}, False),
 }
 # per-case edits of the frame constants
 CB_EDIT = {"rpt_dof": dict(dof=1, lens_radius=0.05, focus_depth=4.0), "k9_textured_dof": dict(dof=1, lens_radius=0.05, focus_depth=3.0, camera_ray_uv_grads_scale=0.75)}
 _ACC = lambda f: dict(accumulate=1, camera_static=1 if f > 1 else 0, num_frames_static=f - 1)      # noqa: E731
 # (the DI pass accumulates Le_SkyWithSunDisk at miss pixels, ReSTIR_DI_Temporal.hlsl:276-281, and an emissive-only scene binds no sky-view LUT: its camera stands inside the box)
 CB_KW = {"rpt_accumulate": _ACC, "di_accumulate": lambda f: dict(_ACC(f), cam_pos=(0.0, 1.0, -0.9))}      # per-case, per-frame arguments of make_frame_constants
-ANIMATED = {"rpt_moving_instance", "di_moving_instance", "sdi_moving_instance", "rpt_moving_light", "di_moving_light"}
-MOVING_LIGHT = {"rpt_moving_light", "di_moving_light"}
+ANIMATED = {"rpt_moving_instance", "di_moving_instance", "sdi_moving_instance", "rpt_moving_light", "di_moving_light", "gi_moving_instance", "gi_moving_light"}
+MOVING_LIGHT = {"rpt_moving_light", "di_moving_light", "gi_moving_light"}
 RPT_PLANES = ("A", "B", "C", "D", "E", "F", "G", "neighbor", "map_ctn", "map_ntc")      # + the K12 thread maps of the last frame
 PLANES = {"rpt": RPT_PLANES, "gi": ("A", "B", "C"), "di": ("A", "B"), "sdi": ("A", "B", "C"), "pt": ()}
 
