@@ -15,7 +15,8 @@ ZREFP_SCENE_API
 extern "C" {
 
 // one frame of K1: DispatchThreads(RenderWidth x RenderHeight) of main(DTid); planes are zeroed first like the product / oracle define
-int zrefp_gbuffer_render(RefScene* r, const zr_frame_constants* cb, zr_gbuffer_planes* planes)
+// pick_x == 0xffff: no pick pending (GBufferRT.h:36-46); otherwise *picked receives what the shader wrote to g_pick[0] (GBufferRT_Inline.hlsl:241-242)
+int zrefp_gbuffer_render_pick(RefScene* r, const zr_frame_constants* cb, zr_gbuffer_planes* planes, uint32_t pick_x, uint32_t pick_y, uint32_t* picked)
 {
     static_assert(sizeof(hlsl::cbFrameConstants) == sizeof(zr_frame_constants), "cbFrameConstants layout");
     static_assert(sizeof(hlsl::RT::MeshInstance) == sizeof(zr_mesh_instance), "MeshInstance layout");
@@ -29,17 +30,20 @@ int zrefp_gbuffer_render(RefScene* r, const zr_frame_constants* cb, zr_gbuffer_p
     hlsl::g_frame.BaseColorMapsDescHeapOffset += SLOT_TEXTURES; hlsl::g_frame.NormalMapsDescHeapOffset += SLOT_TEXTURES;
     hlsl::g_frame.MetallicRoughnessMapsDescHeapOffset += SLOT_TEXTURES; hlsl::g_frame.EmissiveMapsDescHeapOffset += SLOT_TEXTURES;
     hlsl::g_local.UavTableDescHeapIdx = SLOT_GBUF_UAV;
-    hlsl::g_local.PickedPixelX = 0xffff; hlsl::g_local.PickedPixelY = 0xffff;
+    hlsl::g_local.PickedPixelX = (uint16_t)pick_x; hlsl::g_local.PickedPixelY = (uint16_t)pick_y;
     hlsl::g_bvh.scene = &r->sc;
     hlsl::g_frameMeshData = StructuredBuffer<hlsl::RT::MeshInstance>((const hlsl::RT::MeshInstance*)r->sc.instances.data(), (uint32_t)r->sc.instances.size());
     hlsl::g_sceneVertices = StructuredBuffer<hlsl::Vertex>((const hlsl::Vertex*)r->sc.vertices.data(), (uint32_t)r->sc.vertices.size());
     hlsl::g_sceneIndices = StructuredBuffer<hlsl::uint>(r->sc.indices.data(), (uint32_t)r->sc.indices.size());
     hlsl::g_materials = StructuredBuffer<hlsl::Material>((const hlsl::Material*)r->sc.materials.data(), (uint32_t)r->sc.materials.size());
-    static uint32_t pick[4]; hlsl::g_pick = RWStructuredBuffer<hlsl::uint>(pick, 4);
+    static uint32_t pick[4]; pick[0] = 0xfffffffeu; hlsl::g_pick = RWStructuredBuffer<hlsl::uint>(pick, 4);
     for (uint32_t y = 0; y < planes->height; y++)
         for (uint32_t x = 0; x < planes->width; x++)
         { hlsl::main(hlsl::uint3(x, y, 0)); FlushPendingRW(); }
+    if (picked) *picked = pick[0];
     return 0;
 }
+int zrefp_gbuffer_render(RefScene* r, const zr_frame_constants* cb, zr_gbuffer_planes* planes)
+{ return zrefp_gbuffer_render_pick(r, cb, planes, 0xffffu, 0xffffu, nullptr); }
 
 } // extern "C"

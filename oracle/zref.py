@@ -92,6 +92,18 @@ class RefGBuffer(RefPass):
         return arrays, planes
 
 
+    def pick(self, cb, x, y):
+        """GBufferRT::PickPixel(x, y) + one dispatch of the reference's K1: what the shader wrote to g_pick[0]"""
+        from zetaray_amd import wire
+        w, h = int(cb["render_width"]), int(cb["render_height"])
+        arrays, planes = wire.alloc_gbuffer_planes(w, h)
+        cbb = np.ascontiguousarray(cb)
+        out = C.c_uint32(0)
+        self.L.zrefp_gbuffer_render_pick.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]
+        self.L.zrefp_gbuffer_render_pick(self.h, cbb.ctypes.data, C.addressof(planes), int(x), int(y), C.byref(out))
+        return int(out.value)
+
+
 class RefPathTracer(RefPass):
     """K9: PathTracer.hlsl; the permutation follows the scene / params like IndirectLighting.h:251-300 picks the .cso"""
 

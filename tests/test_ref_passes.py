@@ -192,3 +192,29 @@ def test_hip_stage_functions_on_host_reproduce_reference_passes(case):
         if nm == "A" and integ == "rpt":
             a, b = _plane_a(a), _plane_a(b)
         assert _same(a, b), f"reservoir plane {nm} differs from the reference shaders'"
+
+
+@pytest.mark.parametrize("case", list(RC.PICK_CASES))
+def test_oracle_picks_what_the_reference_shader_picks(case):
+    """GBufferRT::PickPixel: the oracle's K1 reports the mesh the reference's GBufferRT_Inline.hlsl wrote to g_pick[0] (UINT32_MAX on a miss)"""
+    from oracle import zro
+    sc, force_bvh, _, _ = RC.scene_and_params(case)
+    o = zro.OracleScene(sc, force_bvh=force_bvh, cb=RC.first_cb(case))
+    cb = RC.first_cb(case)
+    rows = GB[f"pick_{case}"]
+    assert len(rows) == len(RC.PICK_PIXELS) and len(set(int(v) for v in rows[:, 2])) >= 3
+    for x, y, want in rows:
+        assert o.pick(cb, int(x), int(y)) == int(want), (int(x), int(y))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", list(RC.PICK_CASES))
+def test_hip_path_picks_what_the_reference_shader_picks(case):
+    from zetaray_amd import api
+    sc, _, _, prm = RC.scene_and_params(case)
+    r = api.Renderer(sc, RC.W, RC.H, params=prm)
+    cb = RC.first_cb(case)
+    for x, y, want in GB[f"pick_{case}"]:
+        r.p_gbuffer.pick_pixel(int(x), int(y))
+        r.p_gbuffer.render(cb, r.scene, r.gbuffer)
+        assert r.p_gbuffer.read_pick() == int(want), (int(x), int(y))

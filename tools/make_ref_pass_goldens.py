@@ -70,6 +70,15 @@ def main():
             res["plane_" + nm] = ref.plane(nm)
         np.savez_compressed(os.path.join(ROOT, "tests", "golden", f"ref_pass_{case}.npz"), **res)
         print(case, {k: float(np.asarray(v, np.float64).mean()) for k, v in res.items() if k.startswith("final")})
+    # GBufferRT::PickPixel: what the reference's K1 writes to g_pick[0] (hitMeshIdx, UINT32_MAX on a miss) for a grid of pixels of frame 1
+    for case in RC.PICK_CASES:
+        if only and not any(case.startswith(o) or o == "pick" for o in only):
+            continue
+        sc, force_bvh, _, _ = RC.scene_and_params(case)
+        k1 = zref.RefGBuffer(sc, force_bvh)
+        cb = RC.first_cb(case)
+        gb_out[f"pick_{case}"] = np.array([[x, y, k1.pick(cb, x, y)] for (x, y) in RC.PICK_PIXELS], np.uint32)
+        print("pick", case, sorted(set(int(v) for v in gb_out[f"pick_{case}"][:, 2])))
     np.savez_compressed(gb_path, **gb_out)
 
 

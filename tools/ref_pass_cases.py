@@ -132,6 +132,11 @@ RPT_PLANES = ("A", "B", "C", "D", "E", "F", "G", "neighbor", "map_ctn", "map_ntc
 PLANES = {"rpt": RPT_PLANES, "gi": ("A", "B", "C"), "di": ("A", "B"), "sdi": ("A", "B", "C"), "pt": ()}
 
 
+# GBufferRT::PickPixel (tests/golden/ref_pass_gbuffer.npz pick_<case>: rows of x, y, picked mesh): frame 1 of these cases, a grid over the W x H target
+PICK_CASES = ("rpt_cornell_moving", "rpt_materials_rr", "k9_sun_sky")
+PICK_PIXELS = [(x, y) for y in range(3, H, 12) for x in range(2, W, 13)]
+
+
 def animated_instance(sc):
     """index of the instance the *_moving_instance cases animate: the largest non-emissive mesh that is not a wall (a box)"""
     import numpy as _np
