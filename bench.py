@@ -483,6 +483,39 @@ def measure(args, ctx):
                 scene_io.set_texture_heap_offsets(cbf, tex_offsets)
             out["cpu_baseline"] = cpu_baseline(sc, cbf, rpt_params=prm if rpt else None, max_rays=1_000_000 if args.scene != "synthetic" else 200_000,
                                                sample=(2, 8) if args.scene != "synthetic" else (4, 4))
+    if world > 1 and tiled is not None and rpt:
+        # ---- N > 1: the fraction of the HBM roofline of the whole job (north_star: "at 1 / 2 / 4 / 8 GPUs ... as fraction of the HBM roofline").  Every rank
+        # times the metric's kernel (K11) on its tile with the library's hipEvents over a few frames; achieved = the ranks' algorithmic bytes per launch
+        # (per-ray model on the rays the kernel issued + the planes of the OWNED pixels) summed, over the slowest rank's launch time; peak = N x 8 TB/s.
+        dom = "rpt_pathtrace"
+        r.p_indirect.enable_timing(True)
+        r.p_indirect.read_counters(reset=True)
+        nfr, agg_ms, agg_n = 8, 0.0, 0
+        dist.barrier()
+        for i in range(nfr):
+            frame(1000 + i)
+            torch.cuda.synchronize()
+            ms, launches = r.p_indirect.timings().get(dom, (0.0, 0))
+            agg_ms += ms
+            agg_n += launches
+        kcc, kcs = r.p_indirect.kernel_counters().get(dom, (0, 0))
+        r.p_indirect.read_counters(reset=True)
+        r.p_indirect.enable_timing(False)
+        avg_ms = agg_ms / max(agg_n, 1)
+        bytes_launch = (BYTES_CLOSEST * kcc + BYTES_SHADOW * kcs) / max(agg_n, 1) + RPT_PIXEL_BYTES[dom] * tw * th
+        mine = torch.tensor([bytes_launch, avg_ms], dtype=torch.float64, device=cdev)
+        every = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(every, mine)
+        if rank == 0:
+            per = [(float(t[0]), float(t[1])) for t in every]
+            slowest = max(m for _, m in per)
+            achieved = sum(b for b, _ in per) / (slowest * 1e-3) / 1e9
+            out["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS * world, "unit": "GB/s",
+                               "frac": round(achieved / (HBM_PEAK_GBS * world), 5), "traffic": None,
+                               "per_rank_achieved_GBs": [round(b / (m * 1e-3) / 1e9, 2) if m > 0 else None for b, m in per],
+                               "per_rank_avg_launch_ms": [round(m, 4) for _, m in per],
+                               "note": "whole job: the ranks' algorithmic bytes per launch of the metric's kernel summed over the slowest rank's launch time, against N x the HBM peak; "
+                                       "traffic / VALU counters are collected at N = 1 (profiles/)"}
     return out
 
 

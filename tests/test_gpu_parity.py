@@ -1617,6 +1617,9 @@ def test_bench_multi_rank_protocol_on_one_gpu():
             singles.append(d["config"]["rays_per_frame"])
             continue
         assert "screen tiles" in d["config"]["parallelism"] and ("cost-balanced" in d["config"]["parallelism"] or "equal-area" in d["config"]["parallelism"])
+        # the whole-job roofline object of an N > 1 line: every rank's K11 timed on its tile, N x the HBM peak
+        rf = d["roofline"]
+        assert rf["kernel"] == "rpt_pathtrace" and rf["peak"] == 8000.0 * n and 0 < rf["frac"] < 1 and len(rf["per_rank_avg_launch_ms"]) == n and min(rf["per_rank_avg_launch_ms"]) > 0
         # The same frames are traced whatever the split, so the whole-job ray count per frame is the single-device one with equally aged
         # reservoirs: 4 settle frames when the probe's cost map made the ranks re-tile (fresh passes), 12 probe + 4 settle frames when they kept
         # the grid.  (Equal frame numbers give bit-identical frames, hence equal counts; the probe frames shift the numbering in the second case.)
