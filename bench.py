@@ -493,22 +493,25 @@ def measure(args, ctx):
         nfr, agg_ms, agg_n = 8, 0.0, 0
         dist.barrier()
         for i in range(nfr):
-            frame(1000 + i)
+            frame(1000 + i)      # (collective: every rank renders the same number of frames whatever its timers say)
             torch.cuda.synchronize()
             ms, launches = r.p_indirect.timings().get(dom, (0.0, 0))
             agg_ms += ms
             agg_n += launches
-        kcc, kcs = r.p_indirect.kernel_counters().get(dom, (0, 0))
-        r.p_indirect.read_counters(reset=True)
-        r.p_indirect.enable_timing(False)
-        avg_ms = agg_ms / max(agg_n, 1)
-        bytes_launch = (BYTES_CLOSEST * kcc + BYTES_SHADOW * kcs) / max(agg_n, 1) + RPT_PIXEL_BYTES[dom] * tw * th
+        try:      # a rank that cannot produce its share contributes zeros: the line must not die (or hang the others) over an annotation
+            kcc, kcs = r.p_indirect.kernel_counters().get(dom, (0, 0))
+            r.p_indirect.read_counters(reset=True)
+            r.p_indirect.enable_timing(False)
+            avg_ms = agg_ms / max(agg_n, 1)
+            bytes_launch = (BYTES_CLOSEST * kcc + BYTES_SHADOW * kcs) / max(agg_n, 1) + RPT_PIXEL_BYTES[dom] * tw * th
+        except Exception:
+            bytes_launch, avg_ms = 0.0, 0.0
         mine = torch.tensor([bytes_launch, avg_ms], dtype=torch.float64, device=cdev)
         every = [torch.zeros_like(mine) for _ in range(world)]
         dist.all_gather(every, mine)
         if rank == 0:
             per = [(float(t[0]), float(t[1])) for t in every]
-            slowest = max(m for _, m in per)
+            slowest = max(max(m for _, m in per), 1e-9)
             achieved = sum(b for b, _ in per) / (slowest * 1e-3) / 1e9
             out["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS * world, "unit": "GB/s",
                                "frac": round(achieved / (HBM_PEAK_GBS * world), 5), "traffic": None,
