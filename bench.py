@@ -565,6 +565,23 @@ def main():
                 continue        # an explicit --steps / --warmup wins over the preset's
             setattr(args, k, v)
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` without a launcher (the shape of the driver's N = 1 command): start the N ranks here -- one process per GPU
+        # under torch.distributed.run on the loopback address, exactly the command the contract names -- and pass rank 0's JSON line through.
+        # (Launched by torchrun / the driver, WORLD_SIZE is set and this branch is skipped.)
+        import socket
+        import subprocess
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        env = dict(os.environ)
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: RCCL needs it on this driver
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        if os.environ.get("ZR_BENCH_LAUNCH_ECHO") == "1":      # (tests on a box without GPUs: show the launch instead of performing it)
+            print(json.dumps({"launch": cmd}))
+            sys.exit(0)
+        sys.exit(subprocess.call(cmd, env=env))
     if args.arith == "fast":
         os.environ["ZETARAY_AMD_LIB"] = os.path.join(ROOT, "zetaray_amd", "libzetaray_amd_fast.so")      # read by zetaray_amd/api.py at import
     import torch

@@ -29,6 +29,7 @@ static const uint16_t kRdiSampleSet[64] = {
 #include <cstring>
 using namespace zr;
 static bool g_k11_park = false;       // zhx_set_k11_park: K11 keeps the reservoir's selected reconnection in a park outside the lane (zr_rpt.h RcPark)
+static bool g_k11_fused = false;      // zhx_set_k11_fused: K11 emulation runs the FUSED stage functions (PtInitLane_Fused / PtPhaseA_Fused: what k_rpt_pathtrace compiles) instead of the cut ones
 static bool g_k11_carry = false;      // zhx_set_k11_carry: K11 emulation sends live paths through rpt::PtCarry at every bounce boundary
 
 struct HxScene
@@ -297,6 +298,7 @@ uint64_t zhx_bvh_digest(const HxScene* s, uint32_t* numNodes, uint32_t* numTris,
     return h;
 }
 void zhx_set_k11_carry(int on) { g_k11_carry = on != 0; }
+void zhx_set_k11_fused(int on) { g_k11_fused = on != 0; }
 void zhx_set_k11_park(int on) { g_k11_park = on != 0; }
 void zhx_latch_heap_offsets(const HxScene* s, const zr_frame_constants* cb) { Latch(s, cb); }
 void zhx_estimate_power(const HxScene* s, float* out) { for (size_t i = 0; i < s->emissives.size(); i++) out[i] = EstimateTriPower(s->view, s->emissives[i]); }
@@ -507,14 +509,19 @@ void zhx_rpt_render_stage(const HxScene* s, HxRpt* R, const zr_frame_constants* 
             for (uint32_t l = 0; l < 64; l++)
             {
                 const uint32_t x = bx * 16 + (l & 15), y = by * 4 + (l >> 4);
-                PtInitLane(F.sc, g, F.gb, prm, F.Owns(x, y), x, y, finalRGBA, stack, cnt, lanes[l]);
+                if (g_k11_fused) PtInitLane_Fused(F.sc, g, F.gb, prm, F.Owns(x, y), x, y, finalRGBA, stack, cnt, lanes[l]);
+                else PtInitLane(F.sc, g, F.gb, prm, F.Owns(x, y), x, y, finalRGBA, stack, cnt, lanes[l]);
                 // k_rpt_pathtrace_park (zr_rpt.h RcPark): the reservoir's selected reconnection parked outside the lane, [word][lane] like the LDS block
                 if (g_k11_park) { lanes[l].r.park.p = parkWords.data() + l; lanes[l].r.park.stride = 64; lanes[l].r.parked = false; }
             }
             for (;;)
             {
                 bool any = false;
-                for (uint32_t l = 0; l < 64; l++) { if (lanes[l].active) any = true; PtPhaseA(F.sc, g, prm, stack, cnt, lanes[l]); }
+                for (uint32_t l = 0; l < 64; l++)
+                {
+                    if (lanes[l].active) any = true;
+                    if (g_k11_fused) PtPhaseA_Fused(F.sc, g, prm, stack, cnt, lanes[l]); else PtPhaseA(F.sc, g, prm, stack, cnt, lanes[l]);
+                }
                 if (!any) break;
                 uint32_t bits = 0;
                 for (uint32_t l = 0; l < 64; l++) { uint32_t b = PtRRKey(lanes[l]); bits = b > bits ? b : bits; }

@@ -408,6 +408,11 @@ def set_k11_carry(on):
     lib().zhx_set_k11_carry(int(bool(on)))
 
 
+def set_k11_fused(on):
+    """K11 emulation runs the fused stage functions (PtInitLane_Fused / PtPhaseA_Fused, the ones the inline megakernel compiles) instead of the cut ones"""
+    lib().zhx_set_k11_fused(int(bool(on)))
+
+
 def set_k11_park(on):
     """K11 emulation of k_rpt_pathtrace_park: the reservoir's selected reconnection lives in a [word][lane] park outside the lane (zr_rpt.h RcPark)"""
     lib().zhx_set_k11_park(int(bool(on)))

@@ -1602,7 +1602,10 @@ def test_bench_multi_rank_protocol_on_one_gpu():
     singles = []
     # (the last run adds the denoise pass: BASELINE config 5's shape on two ranks -- the three denoise halo exchanges of tiling.denoise_schedule per frame)
     for n, port, settle, more in ((1, 0, 4, []), (1, 0, 16, []), (2, 29631, 4, []), (4, 29632, 4, []), (8, 29634, 4, []), (2, 29633, 4, ["--denoise"])):
-        cmd = [sys.executable, os.path.join(ROOT, "bench.py")] if n == 1 else \
+        # n == 2 without --denoise is started as plain `python bench.py --gpus 2` (no launcher: bench.py starts its ranks itself, the shape of
+        # the driver's N = 1 command); the other N > 1 runs go through torch.distributed.run the way the driver launches them
+        self_launch = n == 2 and not more
+        cmd = [sys.executable, os.path.join(ROOT, "bench.py")] if (n == 1 or self_launch) else \
             [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1", "--master-port", str(port),
              os.path.join(ROOT, "bench.py")]
         cmd += ["--gpus", str(n), "--steps", "4", "--warmup", "2", "--settle", str(settle), "--width", "512", "--height", "288", "--no-cpu-baseline"] + more
@@ -1617,6 +1620,7 @@ def test_bench_multi_rank_protocol_on_one_gpu():
             singles.append(d["config"]["rays_per_frame"])
             continue
         assert "screen tiles" in d["config"]["parallelism"] and ("cost-balanced" in d["config"]["parallelism"] or "equal-area" in d["config"]["parallelism"])
+        assert d["config"]["halo_transport"] == "torch_p2p"      # (this rig; rccl_cpp on distinct devices: test_bench_two_ranks_over_rccl_when_two_gpus_are_visible)
         # the whole-job roofline object of an N > 1 line: every rank's K11 timed on its tile, N x the HBM peak
         rf = d["roofline"]
         assert rf["kernel"] == "rpt_pathtrace" and rf["peak"] == 8000.0 * n and 0 < rf["frac"] < 1 and len(rf["per_rank_avg_launch_ms"]) == n and min(rf["per_rank_avg_launch_ms"]) > 0

@@ -125,3 +125,43 @@ def test_final_halo_policy_decision():
     c = scene_io.make_frame_constants(256, 128, frame_num=5, num_emissives=2, jitter=(0.25, -0.25))
     c["prev_camera_jitter"] = np.float32([0.0, 0.0])
     assert tiling.frame_reads_history_across_tiles("restir_pt", c, False)                    # only the jitter changed: still a different reprojection
+
+
+def test_bench_starts_its_own_ranks_when_no_launcher_did():
+    """`python bench.py --gpus N` without WORLD_SIZE in the environment (the shape of the driver's N = 1 command) re-executes itself as N ranks under
+    torch.distributed.run on the loopback address instead of asserting; with WORLD_SIZE set (the driver's torchrun launch) it does not.  The launch
+    itself needs GPUs (tests/test_gpu_parity.py::test_bench_multi_rank_protocol_on_one_gpu runs it); here the command it would run is shown."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env["ZR_BENCH_LAUNCH_ECHO"] = "1"
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "3", "--warmup", "1"], env=env, capture_output=True, text=True, timeout=120)
+    assert res.returncode == 0, res.stderr[-2000:]
+    cmd = json.loads(res.stdout.strip().splitlines()[-1])["launch"]
+    assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"] and "--nproc-per-node=8" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and int(cmd[cmd.index("--master-port") + 1]) > 0
+    i = cmd.index(os.path.join(ROOT, "bench.py"))
+    assert cmd[i + 1:] == ["--gpus", "8", "--steps", "3", "--warmup", "1"]
+
+
+def test_tiled_denoise_pass_lives_on_the_tile_device():
+    """TiledRestirPT.enable_denoise must create the denoise pass on the rank's own device (like the direct-lighting passes), or every
+    rank with local_rank != 0 gets a pass on device 0 next to a scene and G-buffer on local_rank.  No GPU here: the renderer is a recorder."""
+    sys.path.insert(0, ROOT)
+    from zetaray_amd import tiling
+
+    class _Dev:
+        index = 3
+
+    class _Rec:
+        gbuffer = None
+        p_denoise = "set"
+
+        def enable_denoise(self, prm, device=0):
+            self.seen = device
+            return "pass"
+
+    t = tiling.TiledRestirPT.__new__(tiling.TiledRestirPT)
+    t.r, t.device, t.world, t.native = _Rec(), _Dev(), 1, None
+    t.api = type("A", (), {"STAGE_DENOISE_MASK": 0})
+    assert t.enable_denoise() == "pass" and t.r.seen == 3 and t.r.p_denoise is None

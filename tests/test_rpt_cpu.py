@@ -129,6 +129,29 @@ def test_k11_carried_state_is_all_a_path_needs(synthetic_small, cornell_emissive
         zhx.set_k11_carry(False)
 
 
+def test_k11_fused_stage_functions_equal_the_oracle(synthetic_small, cornell_emissive, oracle_emissive, hx_emissive):
+    """The inline megakernel k_rpt_pathtrace compiles the FUSED forms of the K11 stage functions (PtInitLane_Fused / PtPhaseA_Fused, traversal in the
+    middle of one function); the host executor normally runs the cut forms.  Here it runs the fused ones: radiance and all reservoir planes equal the
+    oracle's on the material scene (metal, coat, glass, thin walls, Russian roulette) and on the Cornell box -- so an edit that reaches only one of
+    the two forms (round 5: the wo-only BSDF terms prepared once per surface, the light direction's evaluation reused by the sampler pdf) shows here.
+    (The sun + sky variant: test_rpt_sun_sky_bit_exact[fused].)"""
+    sc, osc, hx = synthetic_small
+    w, h = 64, 48
+    prm = wire.default_params()
+    prm.max_non_tr_bounces, prm.max_glossy_tr_bounces = 6, 8
+    zhx.set_k11_fused(True)
+    try:
+        for scene, oscene, hxs, cam in ((sc, osc, hx, dict(cam_pos=(0, 0, -3.5))), (cornell_emissive, oracle_emissive, hx_emissive, {})):
+            o, x = zro.OracleRPT(oscene, w, h), zhx.HostExecRPT(hxs, w, h)
+            for f in range(1, 4):
+                cb = _cb(scene, w, h, f, **cam)
+                a, b = o.render(cb, prm), x.render(cb, prm)
+                assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), f"frame {f}"
+                _assert_same_state(o, x, f)
+    finally:
+        zhx.set_k11_fused(False)
+
+
 def test_k11_with_the_selected_reconnection_parked(synthetic_small, cornell_emissive, oracle_emissive, hx_emissive):
     """k_rpt_pathtrace_park (ZR_K11_PARK=1; zr_rpt.h RcPark): while a path is traced the reservoir's selected reconnection lives in a [word][lane]
     park (LDS on the device) -- Reservoir::Update stores winners there, the epilogue reads the last one back.  The host executor runs K11 that way,
@@ -189,7 +212,7 @@ def test_rpt_self_shift_identity(synthetic_small):
     assert np.median(np.abs(jr - 1)) < 1e-3 and np.quantile(np.abs(jr - 1), 0.85) < 0.03
 
 
-@pytest.mark.parametrize("carry", [False, True], ids=["", "state carried through PtCarry at bounce boundaries"])
+@pytest.mark.parametrize("carry", [False, True, "fused"], ids=["", "state carried through PtCarry at bounce boundaries", "fused"])
 @pytest.mark.parametrize("kind", ["cornell", "glossy"])
 def test_rpt_sun_sky_bit_exact(kind, carry):
     """NEE_EMISSIVE == 0 variants of K11-K16: no emissive triangles; NEE_NonEmissive (one RIS over sun / cosine-sky / BSDF-sky with
@@ -209,6 +232,8 @@ def test_rpt_sun_sky_bit_exact(kind, carry):
     prm = wire.default_params()
     o, x = zro.OracleRPT(osc, w, h), zhx.HostExecRPT(hx, w, h)
     prev = None
+    zhx.set_k11_fused(carry == "fused")      # the fused stage functions of the inline megakernel instead of the cut ones
+    carry = carry is True
     zhx.set_k11_carry(carry)      # (the sun + sky variant traces its continuation ray at the top of PtPhaseA: the carried normal / transmissive flag)
     for f in range(1, 6):
         cb = sio.make_frame_constants(w, h, frame_num=f, num_emissives=0, cam_pos=(cam0[0] + 0.05 * max(0, f - 3), cam0[1], cam0[2]))
@@ -226,7 +251,7 @@ def test_rpt_sun_sky_bit_exact(kind, carry):
         for nm in "ABCDEFG":
             assert np.array_equal(o.plane(nm).view(np.uint8), x.plane(nm).view(np.uint8)), f"frame {f}: plane {nm} differs"
         assert o.counters == x.counters
-    zhx.set_k11_carry(False)
+    zhx.set_k11_carry(False); zhx.set_k11_fused(False)
     assert a[..., :3].max() > 0
     A = o.plane("A")[..., 0]
     assert (((A >> 16) & 3) != 0).any()          # some reservoirs reconnect into the sun / sky (case 2)

@@ -112,11 +112,42 @@ ZR_HD V3 OrenNayar(bool multiScatter, V3 rho, float sigma, float ndotwo, float n
     }
     return ndotwi * (f + f_comp) * rho;
 }
+// OrenNayar on a prepared surface (Surface::woReady): sigma, A and the multi-scatter albedo term come in, everything else as above
+ZR_HD V3 OrenNayarPrepared(bool multiScatter, V3 rho, float sigma, float A, V3 rho_ms, float ndotwo, float ndotwi, float wodotwi, float g_wo)
+{
+    if (sigma == 0) return ZR_ONE_OVER_PI * ndotwi * rho;
+    float B = sigma * A;
+    float s_over_t = zr_fma(-ndotwi, ndotwo, wodotwi);
+    s_over_t = s_over_t > 0 ? s_over_t / zr_max(ndotwi, ndotwo) : s_over_t;
+    V3 f = v3(ZR_ONE_OVER_PI * zr_fma(B, s_over_t, A));
+    V3 f_comp = v3(0.0f);
+    if (multiScatter)
+    {
+        float E_wo = g_wo;
+        float E_wi = E_FON_approx(ndotwi, sigma);
+        f_comp = (1 - E_wo) * (1 - E_wi) * rho_ms;
+    }
+    return ndotwi * (f + f_comp) * rho;
+}
 ZR_HD V3 GGXMicrofacetBRDF(float alpha, float ndotwh, float ndotwo, float ndotwi, V3 fr, bool specular)   // :392-413
 {
     if (specular) return (ndotwh >= kMinNdotHSpecular ? 1.0f : 0.0f) * fr;
     float alphaSq = alpha * alpha;
     float f = GGX(ndotwh, alphaSq) * SmithG2_Opt(1.0f, alphaSq, ndotwi, ndotwo) * ndotwi;
+    return f * fr;
+}
+// SmithG2_Opt with the wo factor of denomWo prepared (Surface::c_smith_wo)
+ZR_HD float SmithG2_OptPrepared(float n, float alphaSq, float ndotwi, float ndotwo, float smith_wo)
+{
+    float denomWo = ndotwi * smith_wo;
+    float denomWi = ndotwo * zr_sqrt(zr_fma(zr_fma(-ndotwi, alphaSq, ndotwi), ndotwi, alphaSq));
+    return (0.5f * n) / (denomWo + denomWi);
+}
+ZR_HD V3 GGXMicrofacetBRDF_Prepared(float alpha, float ndotwh, float ndotwo, float ndotwi, V3 fr, bool specular, float smith_wo)
+{
+    if (specular) return (ndotwh >= kMinNdotHSpecular ? 1.0f : 0.0f) * fr;
+    float alphaSq = alpha * alpha;
+    float f = GGX(ndotwh, alphaSq) * SmithG2_OptPrepared(1.0f, alphaSq, ndotwi, ndotwo, smith_wo) * ndotwi;
     return f * fr;
 }
 ZR_HD float JacobianHalfVecToIncident_Tr(float eta, float whdotwo, float whdotwi)              // :420-427
@@ -131,6 +162,16 @@ ZR_HD float GGXMicrofacetBTDF(float alpha, float ndotwh, float ndotwo, float ndo
     if (specular) { float f = ndotwh >= kMinNdotHSpecular ? 1.0f : 0.0f; return f * (1 - fr); }
     float alphaSq = alpha * alpha;
     float f = GGX(ndotwh, alphaSq) * SmithG2_Opt(4.0f, alphaSq, ndotwi, ndotwo) * whdotwo;
+    f *= JacobianHalfVecToIncident_Tr(eta, whdotwo, whdotwi);
+    f *= ndotwi;
+    return f * (1 - fr);
+}
+ZR_HD float GGXMicrofacetBTDF_Prepared(float alpha, float ndotwh, float ndotwo, float ndotwi, float whdotwo, float whdotwi,
+    float eta, float fr, bool specular, float smith_wo)
+{
+    if (specular) { float f = ndotwh >= kMinNdotHSpecular ? 1.0f : 0.0f; return f * (1 - fr); }
+    float alphaSq = alpha * alpha;
+    float f = GGX(ndotwh, alphaSq) * SmithG2_OptPrepared(4.0f, alphaSq, ndotwi, ndotwo, smith_wo) * whdotwo;
     f *= JacobianHalfVecToIncident_Tr(eta, whdotwo, whdotwi);
     f *= ndotwi;
     return f * (1 - fr);
@@ -157,6 +198,11 @@ ZR_HD float GGXMicrofacetPdf(float alpha, float ndotwh, float ndotwo)           
     float alphaSq = alpha * alpha;
     return (GGX(ndotwh, alphaSq) * SmithG1(alphaSq, ndotwo)) / ndotwo;
 }
+ZR_HD float GGXMicrofacetPdf_Prepared(float alpha, float ndotwh, float ndotwo, float g1_wo)     // SmithG1(alpha^2, ndotwo) prepared (Surface::c_g1_wo)
+{
+    float alphaSq = alpha * alpha;
+    return (GGX(ndotwh, alphaSq) * g1_wo) / ndotwo;
+}
 
 // BSDF.hlsli:560-862
 struct Surface
@@ -169,6 +215,17 @@ struct Surface
     bool specTr, metallic, backfacing_wo, invalid, reflection;
     float trDepth, subsurface;      // half in the reference: always fp16-representable
     float coat_weight; V3 coat_color; float coat_alpha, coat_eta;
+    // Terms of the evaluation that depend on the outgoing direction and the material only -- not on wi.  The reference's BSDF::Unified recomputes
+    // them for every incident direction (BSDF.hlsli:1176-1266 is called 6 times per bounce on one ShadingData: two lobe candidates of SampleBSDF,
+    // the light sample, three of BSDFSamplerPdf); PrepareWo (below) evaluates them once per surface with the very expressions of the inline code, so
+    // every user gets bit-identical values.  woReady == false: not prepared, users evaluate inline (kernels that never call PrepareWo fold the test).
+    bool woReady;
+    float c_refl_g;      // GGXReflectance_Dielectric(rho, alpha, ndotwo, eta): the rho-LUT sample (8 texel loads + trilinear) of the gloss layer
+    float c_refl_c;      // ... of the coat: GGXReflectance_Dielectric(rho, coat_alpha, ndotwo, coat_eta)
+    float c_sigma, c_onA; V3 c_rho_ms;      // OrenNayar: sigma = sqrt(alpha), A = 1 / (1 + 0.2878 sigma), the multi-scatter albedo term
+    float c_eta_rel, c_f0;                  // Fresnel: 1 / eta, DielectricF0(eta)
+    float c_smith_wo;    // SmithG2_Opt: sqrt((ndotwo - ndotwo alpha^2) ndotwo + alpha^2), the factor of denomWo that does not depend on wi
+    float c_g1_wo;       // SmithG1(alpha^2, ndotwo)
 
     ZR_HDM bool ThinWalled() const { return subsurface > 0; }
     ZR_HDM bool Transmissive() const { return specTr || ThinWalled(); }
@@ -226,12 +283,13 @@ struct Surface
         SetWi(wi, n, wh);
         return wh;
     }
+    ZR_HDM float F0() const { return woReady ? c_f0 : DielectricF0(eta); }
     ZR_HDM V3 Fresnel(V3 fr0, bool* tir) const
     {
         float cosTheta_i = whdotwo;
         *tir = false;
         if (metallic) return FresnelSchlick(fr0, cosTheta_i);
-        float eta_rel = 1.0f / eta;
+        float eta_rel = woReady ? c_eta_rel : 1.0f / eta;
         float sinSq = zr_saturate(zr_fma(-cosTheta_i, cosTheta_i, 1.0f));
         float cosTSq = zr_fma(-eta_rel * eta_rel, sinSq, 1.0f);
         *tir = cosTSq <= 0;
@@ -240,7 +298,7 @@ struct Surface
     }
     ZR_HDM V3 Fresnel() const
     {
-        V3 fr0 = metallic ? base : v3(DielectricF0(eta));
+        V3 fr0 = metallic ? base : v3(F0());
         bool unused;
         return Fresnel(fr0, &unused);
     }
@@ -292,14 +350,59 @@ ZR_HD Surface InitSurface(V3 n, V3 wo, bool metallic, float roughness, V3 baseCo
     si.coat_alpha = coat_roughness * coat_roughness;
     si.coat_eta = eta_curr == kEtaAir ? eta_coat / kEtaAir : kEtaAir / eta_coat;
     si.ndotwi = 0; si.ndotwh = 0; si.whdotwi = 0; si.whdotwo = 0; si.wodotwi = 0; si.invalid = true; si.reflection = true;
+    si.woReady = false; si.c_refl_g = 0; si.c_refl_c = 0; si.c_sigma = 0; si.c_onA = 0; si.c_rho_ms = v3(0.0f); si.c_eta_rel = 0; si.c_f0 = 0; si.c_smith_wo = 0; si.c_g1_wo = 0;
     return si;
 }
+
+// The wo-only terms of a surface (see Surface): each one is the expression its inline user evaluates, on the same operands, in the same order.
+// Only the terms a later evaluation can reach are computed (a metal never reads the rho LUT, a specular gloss layer has no Smith terms, ...);
+// the others stay 0 and are never read, because the users test the same material flags.
+ZR_HD float OrenNayarA(float sigma) { return 1.0f / zr_fma(0.287793398f, sigma, 1.0f); }
+ZR_HD V3 OrenNayarRhoMs(V3 rho, float A, float B)
+{
+    float avgR = zr_fma(0.0724882111f, B, A);
+    float one_min = 1 - avgR;
+    float tmp = ZR_ONE_OVER_PI * (avgR / one_min);
+    V3 rho_ms = v3(tmp / zr_fma(-rho.x, one_min, 1.0f), tmp / zr_fma(-rho.y, one_min, 1.0f), tmp / zr_fma(-rho.z, one_min, 1.0f));
+    return rho_ms * rho;
+}
+ZR_HD float SmithWoTerm(float alphaSq, float ndotwo) { return zr_sqrt(zr_fma(zr_fma(-ndotwo, alphaSq, ndotwo), ndotwo, alphaSq)); }
+ZR_HD void PrepareWo(const RhoView& rho, Surface& s)
+{
+    const float alphaSq = s.alpha * s.alpha;
+    if (!s.metallic)
+    {
+        s.c_eta_rel = 1.0f / s.eta;
+        s.c_f0 = DielectricF0(s.eta);
+        if (!s.GlossSpecular()) s.c_refl_g = GGXReflectance_Dielectric(rho, s.alpha, s.ndotwo, s.eta);
+        if (!s.specTr)      // the diffuse slab: EvalDiffuse is only reached without specular transmission
+        {
+            s.c_sigma = zr_sqrt(s.alpha);
+            if (s.c_sigma != 0)
+            {
+                s.c_onA = OrenNayarA(s.c_sigma);
+                s.c_rho_ms = OrenNayarRhoMs(s.base, s.c_onA, s.c_sigma * s.c_onA);
+            }
+        }
+    }
+    if (s.Coated()) s.c_refl_c = GGXReflectance_Dielectric(rho, s.coat_alpha, s.ndotwo, s.coat_eta);
+    if (!s.GlossSpecular())
+    {
+        s.c_smith_wo = SmithWoTerm(alphaSq, s.ndotwo);
+        s.c_g1_wo = SmithG1(alphaSq, s.ndotwo);
+    }
+    s.woReady = true;
+}
+// the two LUT reads of a prepared / unprepared surface
+ZR_HD float ReflG(const RhoView& rho, const Surface& s) { return s.woReady ? s.c_refl_g : GGXReflectance_Dielectric(rho, s.alpha, s.ndotwo, s.eta); }
+ZR_HD float ReflC(const RhoView& rho, const Surface& s) { return s.woReady ? s.c_refl_c : GGXReflectance_Dielectric(rho, s.coat_alpha, s.ndotwo, s.coat_eta); }
 
 // ---- slabs, BSDF.hlsli:904-1152 ----
 ZR_HD V3 EvalDiffuse(bool eon, const Surface& s)
 {
     float k = s.subsurface == 0 ? 1 : s.subsurface * 0.5f;
-    V3 d = OrenNayar(eon, s.base, zr_sqrt(s.alpha), s.ndotwo, s.ndotwi, s.wodotwi, s.g_wo);
+    V3 d = s.woReady ? OrenNayarPrepared(eon, s.base, s.c_sigma, s.c_onA, s.c_rho_ms, s.ndotwo, s.ndotwi, s.wodotwi, s.g_wo)
+                     : OrenNayar(eon, s.base, zr_sqrt(s.alpha), s.ndotwo, s.ndotwi, s.wodotwi, s.g_wo);
     return k * d;
 }
 ZR_HD V3 SampleDiffuse(V3 n, V2 u, float* pdf)
@@ -309,7 +412,14 @@ ZR_HD V3 SampleDiffuse(V3 n, V2 u, float* pdf)
     return mad(l.x, onb.b1, mad(l.y, onb.b2, l.z * n));
 }
 ZR_HD float DiffusePdf(const Surface& s) { return s.ndotwi * ZR_ONE_OVER_PI; }
-ZR_HD V3 EvalGloss(const Surface& s, V3 fr) { return GGXMicrofacetBRDF(s.alpha, s.ndotwh, s.ndotwo, s.ndotwi, fr, s.GlossSpecular()); }
+ZR_HD V3 EvalGloss(const Surface& s, V3 fr)
+{
+    return s.woReady ? GGXMicrofacetBRDF_Prepared(s.alpha, s.ndotwh, s.ndotwo, s.ndotwi, fr, s.GlossSpecular(), s.c_smith_wo)
+                     : GGXMicrofacetBRDF(s.alpha, s.ndotwh, s.ndotwo, s.ndotwi, fr, s.GlossSpecular());
+}
+// GGXMicrofacetPdf of the gloss layer's half vector
+ZR_HD float GlossWhPdf(const Surface& s)
+{ return s.woReady && !s.GlossSpecular() ? GGXMicrofacetPdf_Prepared(s.alpha, s.ndotwh, s.ndotwo, s.c_g1_wo) : GGXMicrofacetPdf(s.alpha, s.ndotwh, s.ndotwo); }
 ZR_HD V3 SampleGloss(const Surface& s, V3 n, V2 u)
 {
     if (s.GlossSpecular()) return reflect(-s.wo, n);
@@ -318,10 +428,13 @@ ZR_HD V3 SampleGloss(const Surface& s, V3 n, V2 u)
 ZR_HD float GlossPdf(const Surface& s)
 {
     if (s.GlossSpecular()) return (s.ndotwh >= kMinNdotHSpecular) ? 1.0f : 0.0f;
-    return GGXMicrofacetPdf(s.alpha, s.ndotwh, s.ndotwo) / 4.0f;
+    return GlossWhPdf(s) / 4.0f;
 }
 ZR_HD float EvalTranslucentTr(const Surface& s, float fr)
-{ return GGXMicrofacetBTDF(s.alpha, s.ndotwh, s.ndotwo, s.ndotwi, s.whdotwo, s.whdotwi, s.eta, fr, s.GlossSpecular()); }
+{
+    return s.woReady ? GGXMicrofacetBTDF_Prepared(s.alpha, s.ndotwh, s.ndotwo, s.ndotwi, s.whdotwo, s.whdotwi, s.eta, fr, s.GlossSpecular(), s.c_smith_wo)
+                     : GGXMicrofacetBTDF(s.alpha, s.ndotwh, s.ndotwo, s.ndotwi, s.whdotwo, s.whdotwi, s.eta, fr, s.GlossSpecular());
+}
 ZR_HD float EvalCoat(const Surface& s, float Fr)
 { return s.coat_weight * GGXMicrofacetBRDF(s.coat_alpha, s.ndotwh, s.ndotwo, s.ndotwi, v3(Fr), s.CoatSpecular()).x; }
 ZR_HD V3 SampleCoat(const Surface& s, V3 n, V2 u)
@@ -342,7 +455,7 @@ ZR_HD V3 BaseWeight(const RhoView& rho, const Surface& s)
         float cosT;
         float Fr_coat = s.Fresnel_Coat(&cosT);
         if (cosT <= 0) return v3(0.0f);
-        float refl_c = s.CoatSpecular() ? Fr_coat : GGXReflectance_Dielectric(rho, s.coat_alpha, s.ndotwo, s.coat_eta);
+        float refl_c = s.CoatSpecular() ? Fr_coat : ReflC(rho, s);
         float c = 0.5f / cosT + 0.5f / s.whdotwo;
         V3 coat_tr = vexp(c * vlog(s.coat_color));
         bw = Lerp(v3(1.0f), (1 - refl_c) * coat_tr, s.coat_weight);
@@ -352,7 +465,7 @@ ZR_HD V3 BaseWeight(const RhoView& rho, const Surface& s)
 ZR_HD V3 TransmittanceToDielectricBaseTr(const RhoView& rho, const Surface& s)
 {
     V3 bw = BaseWeight(rho, s);
-    float refl_g = s.GlossSpecular() ? 0 : GGXReflectance_Dielectric(rho, s.alpha, s.ndotwo, s.eta);
+    float refl_g = s.GlossSpecular() ? 0 : ReflG(rho, s);
     return (1 - refl_g) * bw;
 }
 ZR_HD V3 DielectricBaseSpecularTr(const RhoView& rho, const Surface& s, float Fr_g)
@@ -366,7 +479,7 @@ ZR_HD V3 DielectricBaseDiffuseTr(const RhoView& rho, const Surface& s, float Fr_
 {
     if (s.invalid) return v3(0.0f);
     V3 bw = BaseWeight(rho, s);
-    float refl_g = s.GlossSpecular() ? Fr_g : GGXReflectance_Dielectric(rho, s.alpha, s.ndotwo, s.eta);
+    float refl_g = s.GlossSpecular() ? Fr_g : ReflG(rho, s);
     return (1 - refl_g) * EvalDiffuse(false, s) * bw;
 }
 
@@ -389,16 +502,16 @@ ZR_HD Eval Unified(const RhoView& rho, const Surface& s)
             ret.f = v3(EvalCoat(s, Fr_coat));
             if (tir_c) return ret;
         }
-        float refl_c = s.CoatSpecular() ? Fr_coat : GGXReflectance_Dielectric(rho, s.coat_alpha, s.ndotwo, s.coat_eta);
+        float refl_c = s.CoatSpecular() ? Fr_coat : ReflC(rho, s);
         float c = 1.0f / cosT;
         V3 coat_tr = vexp(c * vlog(s.coat_color));
         bw = Lerp(v3(1.0f), (1 - refl_c) * coat_tr, s.coat_weight);
     }
-    V3 fr0 = s.metallic ? s.base : v3(DielectricF0(s.eta));
+    V3 fr0 = s.metallic ? s.base : v3(s.F0());
     ret.Fr_g = s.Fresnel(fr0, &ret.tir);
     V3 glossyRefl = EvalGloss(s, ret.Fr_g);
     if (s.metallic || ret.tir) { ret.f = ret.f + bw * glossyRefl; return ret; }
-    float refl_g = s.GlossSpecular() ? ret.Fr_g.x : GGXReflectance_Dielectric(rho, s.alpha, s.ndotwo, s.eta);
+    float refl_g = s.GlossSpecular() ? ret.Fr_g.x : ReflG(rho, s);
     if (!s.specTr)
     {
         V3 diffuse = EvalDiffuse(true, s);
@@ -428,7 +541,7 @@ ZR_HD BsdfSample SampleBSDF_NoDiffuse(const RhoView& rho, V3 n, Surface s, V2 u_
     float pdf_base = 1;
     if (s.Coated())
     {
-        float refl_c = GGXReflectance_Dielectric(rho, s.coat_alpha, s.ndotwo, s.coat_eta);
+        float refl_c = ReflC(rho, s);
         float pdf_coat = refl_c * s.coat_weight;
         pdf_base = 1 - pdf_coat;
         if (u_wrs_0 < pdf_coat)
@@ -445,7 +558,7 @@ ZR_HD BsdfSample SampleBSDF_NoDiffuse(const RhoView& rho, V3 n, Surface s, V2 u_
     V3 wh = s.GlossSpecular() ? n : SampleGGXMicrofacet(s.wo, s.alpha, n, u_g);
     V3 wi_r = reflect(-s.wo, wh);
     s.SetWi_Refl(wi_r, n, wh);
-    float wh_pdf = GGXMicrofacetPdf(s.alpha, s.ndotwh, s.ndotwo);
+    float wh_pdf = GlossWhPdf(s);
     ret.wi = wi_r; ret.lobe = LOBE_GLOSSY_R;
     ret.pdf = s.GlossSpecular() ? 1 : wh_pdf / 4.0f;
     ret.pdf *= pdf_base;
@@ -566,12 +679,12 @@ ZR_HD float BSDFSamplerPdf_NoDiffuse(const RhoView& rho, V3 n, Surface s, V3 wi,
     float pdf_base = 1, pdf_c = 0;
     if (s.Coated())
     {
-        float refl_c = GGXReflectance_Dielectric(rho, s.coat_alpha, s.ndotwo, s.coat_eta);
+        float refl_c = ReflC(rho, s);
         float pdf_coat = refl_c * s.coat_weight;
         pdf_base = 1 - pdf_coat;
         if (s.reflection) pdf_c = CoatPdf(s) * pdf_coat;
     }
-    const float wh_pdf = GGXMicrofacetPdf(s.alpha, s.ndotwh, s.ndotwo);
+    const float wh_pdf = GlossWhPdf(s);
     if (s.metallic || !s.specTr)
     {
         float pdf_gr = s.GlossSpecular() ? (s.ndotwh >= kMinNdotHSpecular ? 1.0f : 0.0f) : wh_pdf / 4.0f;
@@ -601,14 +714,17 @@ ZR_HD float BSDFSamplerPdf_NoDiffuse(const RhoView& rho, V3 n, Surface s, V3 wi,
 }
 
 // BSDFSamplerPdf, BSDFSampling.hlsli:639-759
+// `haveZ`: the caller has already applied s.SetWi(wi_z, n) to `s` and evaluated f_z = Unified(rho, s).f -- every NEE function of the reference
+// evaluates the BSDF towards the light and then asks this function for the sampler's pdf of the same direction, which evaluates it again
+// (ReSTIR_PT_NEE.hlsli:262-275, 318-336); SetWi and Unified are pure functions of (s, wi_z, n), so reusing the caller's values is bit-identical.
 template<typename Func>
-ZR_HD float BSDFSamplerPdf(const RhoView& rho, V3 n, Surface s, V3 wi_z, Func func, Rng& rng)
+ZR_HD float BSDFSamplerPdf(const RhoView& rho, V3 n, Surface s, V3 wi_z, Func func, Rng& rng, bool haveZ = false, V3 f_z = v3(0.0f))
 {
     if (s.specTr) return BSDFSamplerPdf_NoDiffuse(rho, n, s, wi_z, func);
-    s.SetWi(wi_z, n);
+    if (!haveZ) s.SetWi(wi_z, n);
     if (!s.reflection && !s.ThinWalled()) return 0;
-    Eval ez = Unified(rho, s);
-    float targetLum = Luminance(ez.f * func(wi_z));
+    if (!haveZ) f_z = Unified(rho, s).f;
+    float targetLum = Luminance(f_z * func(wi_z));
     if (targetLum == 0) return 0;
 
     float w_sum_c, w_sum_g, w_sum_dr, w_sum_dt;
@@ -672,5 +788,7 @@ ZR_HD float BSDFSamplerPdf(const RhoView& rho, V3 n, Surface s, V3 wi_z, Func fu
 }
 ZR_HD float BSDFSamplerPdf_NoDiffuse(const RhoView& rho, V3 n, const Surface& s, V3 wi) { return BSDFSamplerPdf_NoDiffuse(rho, n, s, wi, NoOpTarget()); }
 ZR_HD float BSDFSamplerPdf(const RhoView& rho, V3 n, const Surface& s, V3 wi_z, Rng& rng) { return BSDFSamplerPdf(rho, n, s, wi_z, NoOpTarget(), rng); }
+// s: SetWi(wi_z, n) applied; f_z = Unified(rho, s).f
+ZR_HD float BSDFSamplerPdf_AtZ(const RhoView& rho, V3 n, const Surface& s, V3 wi_z, V3 f_z, Rng& rng) { return BSDFSamplerPdf(rho, n, s, wi_z, NoOpTarget(), rng, true, f_z); }
 
 } // namespace zr

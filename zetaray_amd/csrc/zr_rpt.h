@@ -139,7 +139,7 @@ ZR_HD SamplerEval EvalBSDFSampler_NoDiffuse(const RhoView& rho, V3 n, Surface s,
     ret.f = e.f * targetScale;
     if (s.Coated())
     {
-        float refl_c = GGXReflectance_Dielectric(rho, s.coat_alpha, s.ndotwo, s.coat_eta);
+        float refl_c = ReflC(rho, s);
         float pdf_coat = refl_c * s.coat_weight;
         pdf_base = 1 - pdf_coat;
         if (lobe == LOBE_COAT)
@@ -149,7 +149,7 @@ ZR_HD SamplerEval EvalBSDFSampler_NoDiffuse(const RhoView& rho, V3 n, Surface s,
             return ret;
         }
     }
-    const float wh_pdf = GGXMicrofacetPdf(s.alpha, s.ndotwh, s.ndotwo);
+    const float wh_pdf = GlossWhPdf(s);
     ret.pdf = !s.GlossSpecular() ? wh_pdf / 4.0f : (s.ndotwh >= kMinNdotHSpecular ? 1.0f : 0.0f);
     ret.pdf *= pdf_base;
     ret.bsdfOverPdf = ret.f / ret.pdf;
@@ -569,7 +569,7 @@ ZR_HD Direct NEE_Bsdf(const Globals& g, V3 pos, V3 normal, const Surface& surfac
 }
 
 // ReSTIR_PT_NEE.hlsli:209-284 (alias-table branch), cut at its Visibility_Segment: the light sample and its unshadowed contribution ...
-struct NeeEmState { Direct ret; Surface surface; V3 ld, le, ln, lpos, wi; float lightPdf, t, dwdA; uint32_t lightID; bool twoSided, facing; };
+struct NeeEmState { Direct ret; Surface surface; V3 ld, le, ln, lpos, wi, fz; float lightPdf, t, dwdA; uint32_t lightID; bool twoSided, facing; };      // fz: Unified(surface).f towards the light
 ZR_HD TraceReq NEE_Emissive_Pre(const Globals& g, V3 pos, V3 normal, const Surface& surfaceIn, Rng& rng, NeeEmState& S)
 {
     const SceneView& sc = *g.sc;
@@ -611,11 +611,12 @@ ZR_HD TraceReq NEE_Emissive_Pre(const Globals& g, V3 pos, V3 normal, const Surfa
     const V3 wi = (lpos - pos) / t;
     S.lpos = lpos; S.ln = ln; S.le = le; S.lightPdf = lightPdf; S.lightID = lightID; S.twoSided = twoSided; S.t = t; S.wi = wi;
     S.facing = (dot(ln, -wi) > 0) && (t > 0);
-    S.ld = v3(0.0f); S.dwdA = 0;
+    S.ld = v3(0.0f); S.dwdA = 0; S.fz = v3(0.0f);
     if (!S.facing) return NoTraceReq();
     S.dwdA = zr_saturate(dot(ln, -wi)) / (t * t);
     S.surface.SetWi(wi, normal);
-    S.ld = le * Unified(sc.rho, S.surface).f * S.dwdA;
+    S.fz = Unified(sc.rho, S.surface).f;
+    S.ld = le * S.fz * S.dwdA;
     if (!(dot(S.ld, S.ld) > 0)) return NoTraceReq();
     return SegmentApproxReq(g.cnt, pos, wi, t, normal, lightID, S.surface.Transmissive());
 }
@@ -628,7 +629,7 @@ ZR_HD Direct NEE_Emissive_Post(const Globals& g, V3 normal, NeeEmState& S, bool 
     float bsdfPdf = 0;
     if (dot(ld, ld) > 0)
     {
-        { ZR_PROF_SCOPE(ZRP_NEE); bsdfPdf = BSDFSamplerPdf(g.sc->rho, normal, S.surface, S.wi, rng); }
+        { ZR_PROF_SCOPE(ZRP_NEE); bsdfPdf = BSDFSamplerPdf_AtZ(g.sc->rho, normal, S.surface, S.wi, S.fz, rng); }
         bsdfPdf *= S.dwdA;
     }
     Direct& ret = S.ret;
@@ -771,13 +772,14 @@ ZR_HD Direct NEE_Emissive_Fused(const Globals& g, V3 pos, V3 normal, Surface sur
     {
         const float dwdA = zr_saturate(dot(ln, -wi)) / (t * t);
         surface.SetWi(wi, normal);
-        V3 ld = le * Unified(sc.rho, surface).f * dwdA;
+        const V3 fz = Unified(sc.rho, surface).f;
+        V3 ld = le * fz * dwdA;
         if (dot(ld, ld) > 0)
             ld = ld * (VisibilitySegmentApprox_Fused(g, pos, wi, t, normal, lightID, surface.Transmissive()) ? 1.0f : 0.0f);
         float bsdfPdf = 0;
         if (dot(ld, ld) > 0)
         {
-            { ZR_PROF_SCOPE(ZRP_NEE); bsdfPdf = BSDFSamplerPdf(sc.rho, normal, surface, wi, rng); }
+            { ZR_PROF_SCOPE(ZRP_NEE); bsdfPdf = BSDFSamplerPdf_AtZ(sc.rho, normal, surface, wi, fz, rng); }
             bsdfPdf *= dwdA;
         }
         ret.ld = PowerHeuristic(lightPdf, bsdfPdf, ld, 1.0f, 1.0f);
@@ -794,13 +796,14 @@ ZR_HD Direct EvalDirect_Case2(const Globals& g, V3 normal, Surface surface, V3 w
 {
     const RhoView& rho = g.sc->rho;
     surface.SetWi(wi, normal);
-    V3 ld = le * Unified(rho, surface).f * dwdA;
+    const V3 fz = Unified(rho, surface).f;
+    V3 ld = le * fz * dwdA;
     Direct ret = InitDirect();
     if (dot(ld, ld) == 0) return ret;
     if (lobe == LOBE_ALL)
     {
         rngNEE.Uniform(); rngNEE.Uniform(); rngNEE.Uniform(); rngNEE.Uniform();
-        float bsdfPdf = BSDFSamplerPdf(rho, normal, surface, wi, rngNEE);
+        float bsdfPdf = BSDFSamplerPdf_AtZ(rho, normal, surface, wi, fz, rngNEE);
         ret.ld = PowerHeuristic(lightPdf, bsdfPdf * dwdA, ld, 1.0f, 1.0f);
         ret.pdf_solidAngle = 1.0f;
     }
@@ -821,7 +824,8 @@ ZR_HD Direct EvalDirect_Case3(const Globals& g, V3 pos, V3 normal, Surface surfa
     float wiDotLN = dot(lightNormal, -wi);
     float dwdA = zr_abs(wiDotLN) / (t * t);
     surface.SetWi(wi, normal);
-    V3 ld = (wiDotLN > 0) || twoSided ? le * Unified(rho, surface).f * dwdA : v3(0.0f);
+    V3 fz = v3(0.0f), ld = v3(0.0f);
+    if ((wiDotLN > 0) || twoSided) { fz = Unified(rho, surface).f; ld = le * fz * dwdA; }
     if (dot(ld, ld) > 0)
         ld = ld * (VisibilitySegmentApprox(g, pos, wi, t, normal, lightID, surface.Transmissive()) ? 1.0f : 0.0f);
     Direct ret = InitDirect();
@@ -829,7 +833,7 @@ ZR_HD Direct EvalDirect_Case3(const Globals& g, V3 pos, V3 normal, Surface surfa
     if (lobe == LOBE_ALL)
     {
         rngNEE.Uniform(); rngNEE.Uniform(); rngNEE.Uniform(); rngNEE.Uniform();
-        float bsdfPdf = BSDFSamplerPdf(rho, normal, surface, wi, rngNEE);
+        float bsdfPdf = BSDFSamplerPdf_AtZ(rho, normal, surface, wi, fz, rngNEE);
         ret.ld = PowerHeuristic(lightPdf, bsdfPdf * dwdA, ld, 1.0f, 1.0f);
         ret.pdf_solidAngle = 1.0f;
     }
@@ -1227,6 +1231,7 @@ ZR_HD void PtInitLane_Pre(const SceneView& sc, const zr_frame_constants& g, cons
     P.valid = true;
     const Camera cam = CurrCamera(g);
     PixelSurface ps = LoadPixelSurface(gb, cam, x, y, g.frame_num, px);
+    PrepareWo(sc.rho, ps.surface);
     P.maxNumBounces = ps.surface.specTr ? (int)prm.maxGlossyTrBounces : (int)prm.maxNonTrBounces;
     { uint32_t a = x / 16, b = y / 8, c = g.frame_num, d = 1; zr_pcg4d(&a, &b, &c, &d); P.rngGroup = Rng::Seed(a); }
     uint32_t sx = x, sy = y, sz = g.frame_num; zr_pcg3d(&sx, &sy, &sz);
@@ -1284,6 +1289,7 @@ ZR_HD void PtPhaseA_Pre(const SceneView& sc, const zr_frame_constants& g, const 
         uvGrads = P.rd.uv_grads;
     }
     if (!GetMaterialData(sc, -P.bs.wi, P.eta_curr, P.hit, P.surface, eta_mat, uvGrads, prm.textured)) { P.active = false; return; }
+    PrepareWo(sc.rho, P.surface);      // six evaluations per bounce share the surface's wo-only terms (zr_dev_bsdf.h)
     P.eta_next = eta_mat;
     }
     P.pos = newPos;
@@ -1350,6 +1356,7 @@ ZR_HD void PtPhaseA(const SceneView& sc, const zr_frame_constants& g, const RptP
         uvGrads = P.rd.uv_grads;
     }
     if (!GetMaterialData(sc, -P.bs.wi, P.eta_curr, P.hit, P.surface, eta_mat, uvGrads, prm.textured)) { P.active = false; return; }
+    PrepareWo(sc.rho, P.surface);      // six evaluations per bounce share the surface's wo-only terms (zr_dev_bsdf.h)
     P.eta_next = eta_mat;
     }
     P.pos = newPos;
@@ -1387,6 +1394,7 @@ ZR_HD void PtInitLane_Fused(const SceneView& sc, const zr_frame_constants& g, co
     P.valid = true;
     const Camera cam = CurrCamera(g);
     PixelSurface ps = LoadPixelSurface(gb, cam, x, y, g.frame_num, px);
+    PrepareWo(sc.rho, ps.surface);
     P.maxNumBounces = ps.surface.specTr ? (int)prm.maxGlossyTrBounces : (int)prm.maxNonTrBounces;
     { uint32_t a = x / 16, b = y / 8, c = g.frame_num, d = 1; zr_pcg4d(&a, &b, &c, &d); P.rngGroup = Rng::Seed(a); }
     uint32_t sx = x, sy = y, sz = g.frame_num; zr_pcg3d(&sx, &sy, &sz);
@@ -1439,6 +1447,7 @@ ZR_HD void PtPhaseA_Fused(const SceneView& sc, const zr_frame_constants& g, cons
         uvGrads = P.rd.uv_grads;
     }
     if (!GetMaterialData(sc, -P.bs.wi, P.eta_curr, P.hit, P.surface, eta_mat, uvGrads, prm.textured)) { P.active = false; return; }
+    PrepareWo(sc.rho, P.surface);      // six evaluations per bounce share the surface's wo-only terms (zr_dev_bsdf.h)
     P.eta_next = eta_mat;
     }
     P.pos = newPos;
@@ -1728,6 +1737,7 @@ ZR_HD_FLAT void Replay(const Globals& g, bool currFrame, int numBounces, BsdfSam
             ctx.throughput = ctx.throughput * vexp(-hit.t * ext);
         }
         if (bounce >= numBounces) break;
+        PrepareWo(sc.rho, ctx.surface);
         bs = SampleBSDF(sc.rho, ctx.normal, ctx.surface, ctx.rngReplay);
         if (dot(bs.bsdfOverPdf, bs.bsdfOverPdf) == 0) { ctx.throughput = v3(0.0f); return; }
         const float alpha_lobe = LobeAlpha(ctx.surface, bs.lobe);
@@ -1756,6 +1766,7 @@ ZR_HD_FLAT OffsetCtx Replay_kGt2(const Globals& g, bool currFrame, V3 pos, V3 no
     ctx.pos = pos; ctx.normal = normal; ctx.surface = surface; ctx.rngReplay = Rng::Seed(rc.seed_replay);
     ctx.eta_curr = kEtaAir; ctx.eta_next = ior; ctx.throughput = v3(1.0f);
     const int numBounces = (int)rc.k - 2;
+    PrepareWo(g.sc->rho, ctx.surface);
     BsdfSample bs = SampleBSDF(g.sc->rho, ctx.normal, ctx.surface, ctx.rngReplay);
     if (dot(bs.bsdfOverPdf, bs.bsdfOverPdf) == 0) { ctx.throughput = v3(0.0f); return ctx; }
     if (g.textured)
@@ -1780,6 +1791,7 @@ ZR_HD_FLAT float StepPath(const Globals& g, bool currFrame, OffsetCtx& ctx, cons
     float alpha_k_min_1 = LobeAlpha(ctx.surface, rc.lobe_k_min_1);
     if (!CanReconnect(alpha_k_min_1, 1, rc.lobe_k_min_1, rc.lobe_k, g.alpha_min)) return 0;
     V3 w_k_min_1 = normalize(rc.x_k - ctx.pos);
+    PrepareWo(sc.rho, ctx.surface);      // y_{k-1}: the lobe candidates of EvalBSDFSampler share its wo-only terms
     SamplerEval e = EvalBSDFSampler(sc.rho, ctx.normal, ctx.surface, w_k_min_1, rc.lobe_k_min_1, ctx.rngReplay);
     if (dot(e.bsdfOverPdf, e.bsdfOverPdf) == 0) return 0;
     HitInfo hit;
@@ -1793,6 +1805,7 @@ ZR_HD_FLAT float StepPath(const Globals& g, bool currFrame, OffsetCtx& ctx, cons
     if (g.textured) { hit.dndu = v3(0.0f); hit.dndv = v3(0.0f); }     // (not fetched here; GetMaterialData may flip them)
     // RtRayQuery::IsotropicSampler with g_samLinearWrap (Shift.hlsli:519-521)
     if (!GetMaterialData(sc, -w_k_min_1, ctx.eta_curr, hit, ctx.surface, eta_mat, ctx.rd.uv_grads, g.textured, true)) return 0;
+    PrepareWo(sc.rho, ctx.surface);      // y_k: evaluated two to four times by the case-1 / case-2 branches of Shift2
     ctx.eta_next = eta_mat;
     if (inMedium && (ctx.surface.trDepth > 0))
     {
@@ -1925,6 +1938,7 @@ ZR_HD_FLAT OffsetPath Shift2(const Globals& g, bool currFrame, size_t DTidIdx, V
     {
         if (!IsLobeValid(ctx.surface, rc.lobe_k_min_1)) return ret;
         if (LobeAlpha(ctx.surface, rc.lobe_k_min_1) < g.alpha_min) return ret;
+        PrepareWo(g.sc->rho, ctx.surface);
     }
     Rng rngNEE = Rng::Seed(rc.seed_nee);
     if (!g.emissive)      // Shift2<Emissive = false>, Shift.hlsli:788-813

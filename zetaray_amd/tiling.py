@@ -263,7 +263,7 @@ class TiledRestirPT:
         frame's); read the result with denoised_tile()"""
         from . import wire
         prm = params if params is not None else wire.default_params()
-        self.p_denoise = self.r.enable_denoise(prm)
+        self.p_denoise = self.r.enable_denoise(prm, device=self.device.index)      # the tile's device, like enable_direct / enable_sky_direct above
         self.r.p_denoise = None          # (Renderer.render_frame must not run it in one go: render_frame below drives the schedule)
         self._dn_sched = denoise_schedule(int(prm.svgf_iterations)) if self.world > 1 else [("steps", self.api.STAGE_DENOISE_MASK)]
         if self.native is not None:
