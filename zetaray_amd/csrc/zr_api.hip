@@ -2363,7 +2363,8 @@ static int RenderReSTIR_PT(zr_pass* p, hipStream_t s, const zr_frame_constants* 
     const uint32_t tilesX = (F.ow + 15) / 16, tilesY = (F.oh + 15) / 16;
     const dim3 grid(tilesX * tilesY), block(kBlock);
     const dim3 gridRpt(tilesX * tilesY * (256 / kRptBlock)), blockRpt(kRptBlock);      // K11 (zr_kernels.h kRptBlock)
-    const dim3 gridRecon(tilesX * tilesY * (256 / kReconBlock)), blockRecon(kReconBlock);      // K14, K16 (zr_kernels.h kReconBlock)
+    const dim3 gridRecon(tilesX * tilesY * (256 / kReconBlock)), blockRecon(kReconBlock);      // K14 (zr_kernels.h kReconBlock)
+    const dim3 gridStc(tilesX * tilesY * (256 / kStcBlock)), blockStc(kStcBlock);                // K16 (zr_kernels.h kStcBlock)
     const uint32_t sortTilesX = (F.ow + 31) / 32;
     const dim3 gridSort(sortTilesX * ((F.oh + 31) / 32));
     // work lists for the replay passes: [0] CtT, [1] TtC, [2] CtS, [3] StC (plane-local pixel ids, device-side counts)
@@ -2464,7 +2465,7 @@ static int RenderReSTIR_PT(zr_pass* p, hipStream_t s, const zr_frame_constants* 
             RPT_TIMED("rpt_sort_spatial", hipLaunchKernelGGL((k_rpt_sort<rpt::RPT_SORT_CTS, rpt::RPT_SORT_STC>), dim3(gridSort.x * 2), dim3(256), 0, s, F, *cb, sortTilesX, F.ox0 / 32u, F.oy0 / 32u, F.mapCtN, F.mapNtC));
         }
         RPT_TIMED("rpt_replay_spatial", RPT_LAUNCH_PE(k_rpt_replay, RPT_REPLAY_CTS, dim3(gridList.x * 2), block, 0, s, F, *cb, lists[2], lists[3], sCnt, ctr + 2 * 5));
-        RPT_TIMED("rpt_reconnect_spatial", RPT_LAUNCH_E(k_rpt_stc, gridRecon, blockRecon, 0, s, F, *cb, tilesX, ctr + 2 * 7));
+        RPT_TIMED("rpt_reconnect_spatial", RPT_LAUNCH_E(k_rpt_stc, gridStc, blockStc, 0, s, F, *cb, tilesX, ctr + 2 * 7));
         // "Prepare for next iteration" (IndirectLighting.cpp:860-870: std::swap(inputs, outputs)) is the flip itself here: the next round starts from res[currIdx]
         p->currIdx = 1 - p->currIdx;
     }

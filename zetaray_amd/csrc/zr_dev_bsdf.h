@@ -112,7 +112,7 @@ ZR_HD V3 OrenNayar(bool multiScatter, V3 rho, float sigma, float ndotwo, float n
     }
     return ndotwi * (f + f_comp) * rho;
 }
-// OrenNayar on a prepared surface (Surface::woReady): sigma, A and the multi-scatter albedo term come in, everything else as above
+// OrenNayar on a prepared surface (Surface::woMask & WO_DIFFUSE): sigma, A and the multi-scatter albedo term come in, everything else as above
 ZR_HD V3 OrenNayarPrepared(bool multiScatter, V3 rho, float sigma, float A, V3 rho_ms, float ndotwo, float ndotwi, float wodotwi, float g_wo)
 {
     if (sigma == 0) return ZR_ONE_OVER_PI * ndotwi * rho;
@@ -218,8 +218,10 @@ struct Surface
     // Terms of the evaluation that depend on the outgoing direction and the material only -- not on wi.  The reference's BSDF::Unified recomputes
     // them for every incident direction (BSDF.hlsli:1176-1266 is called 6 times per bounce on one ShadingData: two lobe candidates of SampleBSDF,
     // the light sample, three of BSDFSamplerPdf); PrepareWo (below) evaluates them once per surface with the very expressions of the inline code, so
-    // every user gets bit-identical values.  woReady == false: not prepared, users evaluate inline (kernels that never call PrepareWo fold the test).
-    bool woReady;
+    // every user gets bit-identical values.  woMask: which groups are prepared (WO_*); users of a group that is not evaluate inline (kernels that
+    // never call PrepareWo fold the test).  Groups, because a prepared term is a live register while the surface is evaluated: K11, six evaluations
+    // per bounce, prepares everything; the reconnection shifts, two or three evaluations per surface at 128 VGPRs, choose (ZR_PREP_SHIFT, zr_rpt.h).
+    uint32_t woMask;
     float c_refl_g;      // GGXReflectance_Dielectric(rho, alpha, ndotwo, eta): the rho-LUT sample (8 texel loads + trilinear) of the gloss layer
     float c_refl_c;      // ... of the coat: GGXReflectance_Dielectric(rho, coat_alpha, ndotwo, coat_eta)
     float c_sigma, c_onA; V3 c_rho_ms;      // OrenNayar: sigma = sqrt(alpha), A = 1 / (1 + 0.2878 sigma), the multi-scatter albedo term
@@ -283,13 +285,13 @@ struct Surface
         SetWi(wi, n, wh);
         return wh;
     }
-    ZR_HDM float F0() const { return woReady ? c_f0 : DielectricF0(eta); }
+    ZR_HDM float F0() const { return (woMask & 4u) ? c_f0 : DielectricF0(eta); }
     ZR_HDM V3 Fresnel(V3 fr0, bool* tir) const
     {
         float cosTheta_i = whdotwo;
         *tir = false;
         if (metallic) return FresnelSchlick(fr0, cosTheta_i);
-        float eta_rel = woReady ? c_eta_rel : 1.0f / eta;
+        float eta_rel = (woMask & 4u) ? c_eta_rel : 1.0f / eta;
         float sinSq = zr_saturate(zr_fma(-cosTheta_i, cosTheta_i, 1.0f));
         float cosTSq = zr_fma(-eta_rel * eta_rel, sinSq, 1.0f);
         *tir = cosTSq <= 0;
@@ -350,7 +352,7 @@ ZR_HD Surface InitSurface(V3 n, V3 wo, bool metallic, float roughness, V3 baseCo
     si.coat_alpha = coat_roughness * coat_roughness;
     si.coat_eta = eta_curr == kEtaAir ? eta_coat / kEtaAir : kEtaAir / eta_coat;
     si.ndotwi = 0; si.ndotwh = 0; si.whdotwi = 0; si.whdotwo = 0; si.wodotwi = 0; si.invalid = true; si.reflection = true;
-    si.woReady = false; si.c_refl_g = 0; si.c_refl_c = 0; si.c_sigma = 0; si.c_onA = 0; si.c_rho_ms = v3(0.0f); si.c_eta_rel = 0; si.c_f0 = 0; si.c_smith_wo = 0; si.c_g1_wo = 0;
+    si.woMask = 0; si.c_refl_g = 0; si.c_refl_c = 0; si.c_sigma = 0; si.c_onA = 0; si.c_rho_ms = v3(0.0f); si.c_eta_rel = 0; si.c_f0 = 0; si.c_smith_wo = 0; si.c_g1_wo = 0;
     return si;
 }
 
@@ -367,15 +369,19 @@ ZR_HD V3 OrenNayarRhoMs(V3 rho, float A, float B)
     return rho_ms * rho;
 }
 ZR_HD float SmithWoTerm(float alphaSq, float ndotwo) { return zr_sqrt(zr_fma(zr_fma(-ndotwo, alphaSq, ndotwo), ndotwo, alphaSq)); }
-ZR_HD void PrepareWo(const RhoView& rho, Surface& s)
+enum : uint32_t { WO_LUT = 1u, WO_DIFFUSE = 2u, WO_FRESNEL = 4u, WO_SMITH = 8u, WO_ALL = 15u };
+ZR_HD void PrepareWo(const RhoView& rho, Surface& s, uint32_t groups = WO_ALL)
 {
     const float alphaSq = s.alpha * s.alpha;
     if (!s.metallic)
     {
-        s.c_eta_rel = 1.0f / s.eta;
-        s.c_f0 = DielectricF0(s.eta);
-        if (!s.GlossSpecular()) s.c_refl_g = GGXReflectance_Dielectric(rho, s.alpha, s.ndotwo, s.eta);
-        if (!s.specTr)      // the diffuse slab: EvalDiffuse is only reached without specular transmission
+        if (groups & WO_FRESNEL)
+        {
+            s.c_eta_rel = 1.0f / s.eta;
+            s.c_f0 = DielectricF0(s.eta);
+        }
+        if ((groups & WO_LUT) && !s.GlossSpecular()) s.c_refl_g = GGXReflectance_Dielectric(rho, s.alpha, s.ndotwo, s.eta);
+        if ((groups & WO_DIFFUSE) && !s.specTr)      // the diffuse slab: EvalDiffuse is only reached without specular transmission
         {
             s.c_sigma = zr_sqrt(s.alpha);
             if (s.c_sigma != 0)
@@ -385,23 +391,23 @@ ZR_HD void PrepareWo(const RhoView& rho, Surface& s)
             }
         }
     }
-    if (s.Coated()) s.c_refl_c = GGXReflectance_Dielectric(rho, s.coat_alpha, s.ndotwo, s.coat_eta);
-    if (!s.GlossSpecular())
+    if ((groups & WO_LUT) && s.Coated()) s.c_refl_c = GGXReflectance_Dielectric(rho, s.coat_alpha, s.ndotwo, s.coat_eta);
+    if ((groups & WO_SMITH) && !s.GlossSpecular())
     {
         s.c_smith_wo = SmithWoTerm(alphaSq, s.ndotwo);
         s.c_g1_wo = SmithG1(alphaSq, s.ndotwo);
     }
-    s.woReady = true;
+    s.woMask = groups;
 }
 // the two LUT reads of a prepared / unprepared surface
-ZR_HD float ReflG(const RhoView& rho, const Surface& s) { return s.woReady ? s.c_refl_g : GGXReflectance_Dielectric(rho, s.alpha, s.ndotwo, s.eta); }
-ZR_HD float ReflC(const RhoView& rho, const Surface& s) { return s.woReady ? s.c_refl_c : GGXReflectance_Dielectric(rho, s.coat_alpha, s.ndotwo, s.coat_eta); }
+ZR_HD float ReflG(const RhoView& rho, const Surface& s) { return (s.woMask & WO_LUT) ? s.c_refl_g : GGXReflectance_Dielectric(rho, s.alpha, s.ndotwo, s.eta); }
+ZR_HD float ReflC(const RhoView& rho, const Surface& s) { return (s.woMask & WO_LUT) ? s.c_refl_c : GGXReflectance_Dielectric(rho, s.coat_alpha, s.ndotwo, s.coat_eta); }
 
 // ---- slabs, BSDF.hlsli:904-1152 ----
 ZR_HD V3 EvalDiffuse(bool eon, const Surface& s)
 {
     float k = s.subsurface == 0 ? 1 : s.subsurface * 0.5f;
-    V3 d = s.woReady ? OrenNayarPrepared(eon, s.base, s.c_sigma, s.c_onA, s.c_rho_ms, s.ndotwo, s.ndotwi, s.wodotwi, s.g_wo)
+    V3 d = (s.woMask & 2u) ? OrenNayarPrepared(eon, s.base, s.c_sigma, s.c_onA, s.c_rho_ms, s.ndotwo, s.ndotwi, s.wodotwi, s.g_wo)
                      : OrenNayar(eon, s.base, zr_sqrt(s.alpha), s.ndotwo, s.ndotwi, s.wodotwi, s.g_wo);
     return k * d;
 }
@@ -414,12 +420,12 @@ ZR_HD V3 SampleDiffuse(V3 n, V2 u, float* pdf)
 ZR_HD float DiffusePdf(const Surface& s) { return s.ndotwi * ZR_ONE_OVER_PI; }
 ZR_HD V3 EvalGloss(const Surface& s, V3 fr)
 {
-    return s.woReady ? GGXMicrofacetBRDF_Prepared(s.alpha, s.ndotwh, s.ndotwo, s.ndotwi, fr, s.GlossSpecular(), s.c_smith_wo)
+    return (s.woMask & 8u) ? GGXMicrofacetBRDF_Prepared(s.alpha, s.ndotwh, s.ndotwo, s.ndotwi, fr, s.GlossSpecular(), s.c_smith_wo)
                      : GGXMicrofacetBRDF(s.alpha, s.ndotwh, s.ndotwo, s.ndotwi, fr, s.GlossSpecular());
 }
 // GGXMicrofacetPdf of the gloss layer's half vector
 ZR_HD float GlossWhPdf(const Surface& s)
-{ return s.woReady && !s.GlossSpecular() ? GGXMicrofacetPdf_Prepared(s.alpha, s.ndotwh, s.ndotwo, s.c_g1_wo) : GGXMicrofacetPdf(s.alpha, s.ndotwh, s.ndotwo); }
+{ return (s.woMask & 8u) && !s.GlossSpecular() ? GGXMicrofacetPdf_Prepared(s.alpha, s.ndotwh, s.ndotwo, s.c_g1_wo) : GGXMicrofacetPdf(s.alpha, s.ndotwh, s.ndotwo); }
 ZR_HD V3 SampleGloss(const Surface& s, V3 n, V2 u)
 {
     if (s.GlossSpecular()) return reflect(-s.wo, n);
@@ -432,7 +438,7 @@ ZR_HD float GlossPdf(const Surface& s)
 }
 ZR_HD float EvalTranslucentTr(const Surface& s, float fr)
 {
-    return s.woReady ? GGXMicrofacetBTDF_Prepared(s.alpha, s.ndotwh, s.ndotwo, s.ndotwi, s.whdotwo, s.whdotwi, s.eta, fr, s.GlossSpecular(), s.c_smith_wo)
+    return (s.woMask & 8u) ? GGXMicrofacetBTDF_Prepared(s.alpha, s.ndotwh, s.ndotwo, s.ndotwi, s.whdotwo, s.whdotwi, s.eta, fr, s.GlossSpecular(), s.c_smith_wo)
                      : GGXMicrofacetBTDF(s.alpha, s.ndotwh, s.ndotwo, s.ndotwi, s.whdotwo, s.whdotwi, s.eta, fr, s.GlossSpecular());
 }
 ZR_HD float EvalCoat(const Surface& s, float Fr)

@@ -138,10 +138,12 @@ ZR_HD bool TestOpacity(const SceneView& sc, uint32_t meshIdx, uint32_t primIdx, 
     return true;
 }
 
+struct TravStack;
+ZR_HD BvhTri FetchTri(const SceneView& sc, uint32_t i, const TravStack* st);
 ZR_HD void IntersectTri(const SceneView& sc, uint32_t i, V3 o, V3 d, float tmin, float tmax,
-    uint32_t mask, RawHit& best, bool filterID = false, uint32_t ignoreID = 0, bool alphaTest = false)
+    uint32_t mask, RawHit& best, bool filterID = false, uint32_t ignoreID = 0, bool alphaTest = false, const TravStack* st = nullptr)
 {
-    const BvhTri T = sc.tris[i];
+    const BvhTri T = FetchTri(sc, i, st);
     if (!(T.mask & mask)) return;
     // (before the intersection test on purpose: behind it -- hits only -- every traversal kernel got 8-12 % slower on the atrium, measured A/B in one run)
     if (filterID && T.id == ignoreID) return;
@@ -220,9 +222,27 @@ struct StackEntry { uint32_t child; float t; };
 #define ZR_NODE_CACHE 32
 #endif
 struct alignas(16) NodeQuad { uint32_t x, y, z, w; };
-struct TravStack { ZR_LDS_AS StackEntry* lds; uint32_t stride; ZR_PRIVATE_AS StackEntry* mem; uint32_t* aux = nullptr; const ZR_LDS_AS NodeQuad* cache = nullptr; };
+struct TravStack { ZR_LDS_AS StackEntry* lds; uint32_t stride; ZR_PRIVATE_AS StackEntry* mem; uint32_t* aux = nullptr; const ZR_LDS_AS NodeQuad* cache = nullptr;
+    uint32_t cacheNodes = 0;      // nodes 0 .. cacheNodes - 1 are in `cache` (<= ZR_NODE_CACHE; a scene with fewer nodes is cached whole)
+    const ZR_LDS_AS NodeQuad* triCache = nullptr; uint32_t cacheTris = 0; };     // leaf-order triangles 0 .. cacheTris - 1 (3 quads each) in LDS: tiny scenes
 static constexpr uint32_t kStealAuxWords = 64 * 2 + 64 * 3 + 64;
 
+// triangle i of the leaf order: from the block's LDS copy when the scene is cached whole (tiny scenes, ZR_SCENE_CACHE_FILL), else from HBM / L2
+ZR_HD BvhTri FetchTri(const SceneView& sc, uint32_t i, const TravStack* st)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (st != nullptr && st->triCache != nullptr && i < st->cacheTris)
+    {
+        const ZR_LDS_AS NodeQuad* c = st->triCache + 3u * i;
+        BvhTri T;
+        T.v0[0] = zr_asfloat(c[0].x); T.v0[1] = zr_asfloat(c[0].y); T.v0[2] = zr_asfloat(c[0].z); T.gidx = c[0].w;
+        T.e1[0] = zr_asfloat(c[1].x); T.e1[1] = zr_asfloat(c[1].y); T.e1[2] = zr_asfloat(c[1].z); T.mask = c[1].w;
+        T.e2[0] = zr_asfloat(c[2].x); T.e2[1] = zr_asfloat(c[2].y); T.e2[2] = zr_asfloat(c[2].z); T.id = c[2].w;
+        return T;
+    }
+#endif
+    return sc.tris[i];
+}
 // (member-wise accesses: copying a whole StackEntry through an address-space-qualified pointer would go through a generic
 // pointer, and ROCm 7.2's gfx950 backend rejects the aperture check it emits for that cast)
 ZR_HD void StackWrite(const TravStack& st, int e, uint32_t c, float t)
@@ -281,7 +301,7 @@ ZR_HD uint32_t TravNode(const SceneView& sc, TravState& s, const TravStack& stac
 {
 #if ZR_NODE_CACHE && defined(__HIP_DEVICE_COMPILE__)
     Bvh4Node n;
-    if (stack.cache != nullptr && s.cur < (uint32_t)ZR_NODE_CACHE)
+    if (stack.cache != nullptr && s.cur < stack.cacheNodes)
     {
         const ZR_LDS_AS NodeQuad* c = stack.cache + 4u * s.cur;
         NodeQuad a, b, cc, d;
@@ -377,15 +397,15 @@ ZR_HD void TravTriPhase(const SceneView& sc, TravState& s, TravLane& L, const Tr
     // leaves hold at most two triangles (zr_bvh.h): both in one phase
     if (L.triEnd - L.triCur <= 2u)
     {
-        IntersectTri(sc, L.triCur, s.o, s.d, s.tmin, s.tmax, s.mask, s.best, s.filterID, s.ignoreID, alphaTest);
-        if (L.triCur + 1u < L.triEnd) IntersectTri(sc, L.triCur + 1u, s.o, s.d, s.tmin, s.tmax, s.mask, s.best, s.filterID, s.ignoreID, alphaTest);
+        IntersectTri(sc, L.triCur, s.o, s.d, s.tmin, s.tmax, s.mask, s.best, s.filterID, s.ignoreID, alphaTest, &stack);
+        if (L.triCur + 1u < L.triEnd) IntersectTri(sc, L.triCur + 1u, s.o, s.d, s.tmin, s.tmax, s.mask, s.best, s.filterID, s.ignoreID, alphaTest, &stack);
         L.triCur = L.triEnd;
         if (anyHit && s.best.tri != kInvalidTri) L.done = true;
         else TravPopEnter(sc, s, L, stack);
         return;
     }
 #endif
-    IntersectTri(sc, L.triCur, s.o, s.d, s.tmin, s.tmax, s.mask, s.best, s.filterID, s.ignoreID, alphaTest);
+    IntersectTri(sc, L.triCur, s.o, s.d, s.tmin, s.tmax, s.mask, s.best, s.filterID, s.ignoreID, alphaTest, &stack);
     L.triCur++;
     if (anyHit && s.best.tri != kInvalidTri) { L.done = true; L.triCur = L.triEnd; }
     else if (L.triCur == L.triEnd) TravPopEnter(sc, s, L, stack);

@@ -36,6 +36,12 @@ static constexpr int kRptBlock = ZR_RPT_BLOCK;
 #define ZR_WAVES_MIN(n) __attribute__((amdgpu_waves_per_eu(n)))
 // (with one-wave blocks 3 and 4 waves tie on small scenes -- 0.945 / 0.950 ms Cornell, 5: 1.12 -- and 3 waves spill a third of the bytes (PMC: 0.56 GB per
 // launch against 1.44 GB), so scenes whose BVH fits the caches run at 3; large scenes take k_rpt_pathtrace_w4)
+#ifdef ZR_WAVES_PATHTRACE_N      // (numeric forms for `make variant EXTRA=-D...=4`, see ZR_WAVES_STC_N)
+#define ZR_WAVES_PATHTRACE ZR_WAVES(ZR_WAVES_PATHTRACE_N)
+#endif
+#ifdef ZR_WAVES_TEMPORAL_N
+#define ZR_WAVES_TEMPORAL ZR_WAVES(ZR_WAVES_TEMPORAL_N)
+#endif
 #ifndef ZR_WAVES_PATHTRACE
 #define ZR_WAVES_PATHTRACE ZR_WAVES(3)
 #endif
@@ -52,8 +58,13 @@ static constexpr int kRptBlock = ZR_RPT_BLOCK;
 #ifndef ZR_WAVES_TEMPORAL
 #define ZR_WAVES_TEMPORAL ZR_WAVES(4)
 #endif
+#ifdef ZR_WAVES_STC_N      // (numeric form for `make variant EXTRA=-DZR_WAVES_STC_N=4`: a parenthesised macro value does not survive make + sh quoting)
+#define ZR_WAVES_STC ZR_WAVES(ZR_WAVES_STC_N)
+#endif
+// (round 5: with the prepared wo-only terms in Surface the allocator's own choice for k_rpt_stc became 145 VGPRs = 3 waves: 0.686 ms against 0.657 at 4,
+// atrium 3.13 against 2.74 -- pinned to the 4 it chose before, profiles/r05_ab_*.json)
 #ifndef ZR_WAVES_STC
-#define ZR_WAVES_STC 
+#define ZR_WAVES_STC ZR_WAVES(4)
 #endif
 static constexpr uint32_t kCounterStride = 64;     // queue counters live 256 B apart: their atomics spread over L2 channels
 // this lane's traversal stack: kTravLdsEntries entries in LDS (16 KB per 256-lane block at 8 entries; + 6 KB for the work-stealing slots, zr_dev_scene.h), the rest in scratch
@@ -69,10 +80,28 @@ static constexpr uint32_t kCounterStride = 64;     // queue counters live 256 B 
     __shared__ uint4 name##NodeCache[4 * ZR_NODE_CACHE]; \
     { const uint32_t nc_ = (scene).numNodes < (uint32_t)ZR_NODE_CACHE ? (scene).numNodes : (uint32_t)ZR_NODE_CACHE; \
       for (uint32_t i_ = threadIdx.x; i_ < 4u * nc_; i_ += (B)) name##NodeCache[i_] = ((const uint4*)(scene).nodes)[i_]; \
-      __syncthreads(); name.cache = nc_ == (uint32_t)ZR_NODE_CACHE ? (const ZR_LDS_AS NodeQuad*)name##NodeCache : nullptr; }
+      __syncthreads(); name.cache = nc_ ? (const ZR_LDS_AS NodeQuad*)name##NodeCache : nullptr; name.cacheNodes = nc_; }
 #else
 #define ZR_NODE_CACHE_FILL(name, scene, B)
 #endif
+// Tiny scenes (Cornell class: <= kSceneCacheNodes nodes and <= kSceneCacheTris triangles, 2 + 4.5 KB): the block copies the WHOLE acceleration
+// structure into LDS once -- north_star's "LDS-staged node caches" taken to the scene that fits.  Every traversal iteration is a dependent
+// fetch; from LDS it returns in ~60 cycles instead of the ~250 of an L2 hit (the scene is L2- but not L1-resident: scratch and the planes
+// stream through the 32 KB L1), and the megakernels are latency-bound at 3 - 4 waves per SIMD.  The host picks the kernel
+// permutation per scene (zr_api.hip); larger scenes run the kernels without this code.
+#ifndef ZR_SCENE_LDS
+#define ZR_SCENE_LDS 0
+#endif
+static constexpr uint32_t kSceneCacheNodes = 32, kSceneCacheTris = 96;
+#define ZR_SCENE_CACHE_FILL(name, scene, B) \
+    __shared__ uint4 name##SceneCache[4 * kSceneCacheNodes + 3 * kSceneCacheTris]; \
+    { const uint32_t nn_ = (scene).numNodes, nt_ = (scene).numTris; \
+      if (nn_ <= kSceneCacheNodes && nt_ <= kSceneCacheTris) { \
+        for (uint32_t i_ = threadIdx.x; i_ < 4u * nn_; i_ += (B)) name##SceneCache[i_] = ((const uint4*)(scene).nodes)[i_]; \
+        for (uint32_t i_ = threadIdx.x; i_ < 3u * nt_; i_ += (B)) name##SceneCache[4 * kSceneCacheNodes + i_] = ((const uint4*)(scene).tris)[i_]; \
+        __syncthreads(); \
+        name.cache = nn_ ? (const ZR_LDS_AS NodeQuad*)name##SceneCache : nullptr; name.cacheNodes = nn_; \
+        name.triCache = (const ZR_LDS_AS NodeQuad*)name##SceneCache + 4 * kSceneCacheNodes; name.cacheTris = nt_; } }
 
 // one atomic per wave: lanes that `want` a slot get consecutive indices
 __device__ __forceinline__ uint32_t AllocSlotWave(uint32_t* counter, bool want)
@@ -239,6 +268,9 @@ __device__ __forceinline__ void RptPathtraceBody(rpt::RptFrame& F, const zr_fram
     const uint32_t x = F.ox0 + tx * 16u + (lane & 15u), y = F.oy0 + ty * 16u + wave * 4u + (lane >> 4);
     ZR_TRAV_STACK_B(stack, kRptBlock);
     if (NODE_CACHE) { ZR_NODE_CACHE_FILL(stack, F.sc, kRptBlock); }      // the tree's top ZR_NODE_CACHE nodes in LDS (large scenes: 8.37 -> 7.63 ms on the atrium)
+#if ZR_SCENE_LDS
+    else { ZR_SCENE_CACHE_FILL(stack, F.sc, kRptBlock); }                 // small scenes: all of it
+#endif
     ZR_PROF_KERNEL(F.sc, 1);
     uint32_t cnt[2] = {0u, 0u};
     rpt::PTLane P;
@@ -846,6 +878,18 @@ __global__ void __launch_bounds__(256) k_rpt_sort(rpt::RptFrame F, zr_frame_cons
 #define ZR_RECON_BLOCK 256
 #endif
 static constexpr int kReconBlock = ZR_RECON_BLOCK;
+// K16's own block size (ZR_STC_BLOCK, default = kReconBlock) and where its lane record lives.  rpt::StcLane -- two reservoirs with their
+// reconnections, ~110 words -- is indexed through merged stores (Makefile note), so it cannot be promoted to registers: as a local it is
+// scratch, i.e. it streams through L1 / L2 and every dirty line is written to HBM when the wave's scratch is recycled (k_rpt_stc moved
+// 2.1 GB per 1080p launch against 0.87 GB of planes, profiles/r05_pmc_rpt_cornell.json).  -DZR_STC_LDS=1 -DZR_STC_BLOCK=64 keeps it in LDS
+// instead (one-wave blocks: 64 x 440 B = 28 KB + the 4 KB stack, five blocks per CU).
+#ifndef ZR_STC_BLOCK
+#define ZR_STC_BLOCK ZR_RECON_BLOCK
+#endif
+#ifndef ZR_STC_LDS
+#define ZR_STC_LDS 0
+#endif
+static constexpr int kStcBlock = ZR_STC_BLOCK;
 
 // K14: CtT + TtC fused per pixel (zr_rpt.h ReconnectTemporalPixel)
 template<bool EMISSIVE, bool TEX>
@@ -858,6 +902,9 @@ __global__ void __launch_bounds__(kReconBlock) ZR_WAVES_TEMPORAL k_rpt_temporal(
     // only (no wave operation in CtT / TtC); the error bit is ignored because the fused kernel runs both shifts of a pixel
     if (F.prm.temporalMap && F.Owns(x, y)) { const uint16_t e = (F.prm.temporalMap == 1u ? F.mapCtN : F.mapNtC)[rpt::Pix(F.gb, x, y)]; rpt::DecodeSorted(e & 0x7fffu, x, y); }
     ZR_TRAV_STACK_B(stack, kReconBlock);
+#if ZR_SCENE_LDS
+    ZR_SCENE_CACHE_FILL(stack, F.sc, kReconBlock);
+#endif
     ZR_PROF_KERNEL(F.sc, 2);
     uint32_t cnt[2] = {0u, 0u};
     if (F.Owns(x, y)) rpt::ReconnectTemporalPixel(F, g, x, y, stack, cnt);
@@ -873,18 +920,28 @@ __device__ __forceinline__ float WaveSumButterfly(float v)
 
 // K16 CtS + StC: wave = 8x8 pixel group; every lane of the wave walks all four phases (absent lanes contribute 0)
 template<bool EMISSIVE, bool TEX>
-__global__ void __launch_bounds__(kReconBlock) ZR_WAVES_STC k_rpt_stc(rpt::RptFrame F, zr_frame_constants g, uint32_t tilesX, unsigned long long* counters)
+__global__ void __launch_bounds__(kStcBlock) ZR_WAVES_STC k_rpt_stc(rpt::RptFrame F, zr_frame_constants g, uint32_t tilesX, unsigned long long* counters)
 {
     const unsigned long long t0 = __builtin_readcyclecounter();
     F.prm.emissive = EMISSIVE ? 1u : 0u; F.prm.textured = TEX ? 1u : 0u;
-    uint32_t x, y; PixelOfThreadB<kReconBlock>(tilesX, F.ox0, F.oy0, &x, &y);
+    uint32_t x, y; PixelOfThreadB<kStcBlock>(tilesX, F.ox0, F.oy0, &x, &y);
     // SORT_SPATIAL (ReSTIR_PT_Reconnect_StC.hlsl:133-140): the thread at (x, y) shifts the pixel the NtC map assigns to its position, so the
     // four wave sums below run over the 64 pixels K12 put together (error bit: nothing to do -- the lane stays in the wave, contributing 0)
     if (F.prm.sortSpatial && F.Owns(x, y) && !rpt::DecodeSorted(F.mapNtC[rpt::Pix(F.gb, x, y)], x, y)) x = 0xffffffffu;
-    ZR_TRAV_STACK_B(stack, kReconBlock);
+    ZR_TRAV_STACK_B(stack, kStcBlock);
+#if ZR_SCENE_LDS
+    ZR_SCENE_CACHE_FILL(stack, F.sc, kStcBlock);
+#endif
     uint32_t cnt[2] = {0u, 0u};
     ZR_PROF_KERNEL(F.sc, 3);
+#if ZR_STC_LDS
+    // (raw words: a __shared__ object may not have initialisers, and StcLane's reservoirs carry default member initialisers)
+    __shared__ __attribute__((aligned(16))) uint32_t stcLaneLds[kStcBlock * ((sizeof(rpt::StcLane) + 15) / 16 * 4)];
+    rpt::StcLane& a = *reinterpret_cast<rpt::StcLane*>(stcLaneLds + threadIdx.x * ((sizeof(rpt::StcLane) + 15) / 16 * 4));
+    a.r_curr.park.p = nullptr; a.r_curr.park.stride = 0; a.r_curr.parked = false; a.r_spatial.park.p = nullptr; a.r_spatial.park.stride = 0; a.r_spatial.parked = false;
+#else
     rpt::StcLane a;
+#endif
     float v1, v2, v3, v4;
     { ZR_PROF_SCOPE(ZRP_MISC0); rpt::StcPhase0(F, g, x, y, a, v1, v2); }
     { ZR_PROF_SCOPE(ZRP_MISC1);

@@ -310,6 +310,11 @@ ZR_HD void LoadPrimary(const GiFrame& F, const zr_frame_constants& g, uint32_t x
     const V3 wo = normalize(origin - P.pos);
     P.surface = InitSurface(P.normal, wo, flags.metallic, P.roughness, baseColor, kEtaAir, P.ior, flags.transmissive, 0.0f, 0.0f, 0.0f, v3(0.0f), 0.0f, kDefaultEtaCoat);
 }
+// wo-only term groups (zr_dev_bsdf.h WO_*) K10 prepares on the surfaces of its path
+#ifndef ZR_PREP_RGI
+#define ZR_PREP_RGI 1
+#endif
+static constexpr uint32_t kPrepRgi = ZR_PREP_RGI;
 #ifndef ZR_RGI_REMAT
 #define ZR_RGI_REMAT 0
 #endif
@@ -349,7 +354,11 @@ ZR_HD void InitLane(const GiFrame& F, const zr_frame_constants& g, uint32_t x, u
         P.maxNumBounces = P.rngGroup.Uniform() < 0.5f ? 1 : P.maxNumBounces;
     P.sampleSetIdx = P.rngGroup.UniformUintBounded_Faster(prm.numSampleSets);
     P.r = InitReservoir();
-    P.firstSample = SampleBSDF(F.sc.rho, P.normal, P.surface, P.rngThread);
+    {   // the lobe candidates of the first sample share the primary surface's wo-only terms; a copy, so that they are not live across the path loop
+        Surface sp = P.surface;
+        if (kPrepRgi) PrepareWo(F.sc.rho, sp, kPrepRgi);
+        P.firstSample = SampleBSDF(F.sc.rho, P.normal, sp, P.rngThread);
+    }
     if (P.firstSample.pdf == 0) return;
     if (prm.textured)
     {
@@ -390,6 +399,7 @@ ZR_HD void PhaseA(const GiFrame& F, const zr_frame_constants& g, TravStack stack
         uvGrads = P.rd.uv_grads;
     }
     if (!GetMaterialData(F.sc, -P.bs.wi, P.eta_curr, P.hit, P.psurface, eta_mat, uvGrads, F.prm.textured)) { P.active = false; return; }
+    if (kPrepRgi) PrepareWo(F.sc.rho, P.psurface, kPrepRgi);      // the vertex is evaluated three to five times (NEE, its MIS sampler, the continuation's lobes)
     P.eta_next = eta_mat;
     // RGI_Util::NEE (NEE_EMISSIVE == 1, USE_MIS == 1, MIS_ALL_BOUNCES == 0)
     V3 ld;

@@ -26,6 +26,17 @@ static constexpr float kMaxRoughDiffSpatial = 0.05f;
 static constexpr float kMinNormalSimSpatial = 0.9f;
 static constexpr uint32_t kMmaxXkTransmissive = 4, kMmaxXkInMotion = 4;
 static constexpr int kNeighborOffset = 32;
+// which wo-only term groups (zr_dev_bsdf.h WO_*) the reconnection shifts and replays prepare on the surfaces they evaluate two to four times.
+// K11 prepares all of them (six evaluations per bounce); the shift kernels run at 128 VGPRs, where every prepared term is a register taken
+// from the evaluation that follows -- measured on MI355X (profiles/r05_ab_*.json)
+#ifndef ZR_PREP_SHIFT
+#define ZR_PREP_SHIFT 1
+#endif
+static constexpr uint32_t kPrepShift = ZR_PREP_SHIFT;
+#ifndef ZR_PREP_K11
+#define ZR_PREP_K11 15
+#endif
+static constexpr uint32_t kPrepK11 = ZR_PREP_K11;
 static constexpr int kSearchRadius = 15;
 enum LT : uint32_t { LT_NONE = 0, LT_SUN = 1, LT_SKY = 2, LT_EMISSIVE = 3 };
 
@@ -1231,7 +1242,7 @@ ZR_HD void PtInitLane_Pre(const SceneView& sc, const zr_frame_constants& g, cons
     P.valid = true;
     const Camera cam = CurrCamera(g);
     PixelSurface ps = LoadPixelSurface(gb, cam, x, y, g.frame_num, px);
-    PrepareWo(sc.rho, ps.surface);
+    PrepareWo(sc.rho, ps.surface, kPrepK11);
     P.maxNumBounces = ps.surface.specTr ? (int)prm.maxGlossyTrBounces : (int)prm.maxNonTrBounces;
     { uint32_t a = x / 16, b = y / 8, c = g.frame_num, d = 1; zr_pcg4d(&a, &b, &c, &d); P.rngGroup = Rng::Seed(a); }
     uint32_t sx = x, sy = y, sz = g.frame_num; zr_pcg3d(&sx, &sy, &sz);
@@ -1289,7 +1300,7 @@ ZR_HD void PtPhaseA_Pre(const SceneView& sc, const zr_frame_constants& g, const 
         uvGrads = P.rd.uv_grads;
     }
     if (!GetMaterialData(sc, -P.bs.wi, P.eta_curr, P.hit, P.surface, eta_mat, uvGrads, prm.textured)) { P.active = false; return; }
-    PrepareWo(sc.rho, P.surface);      // six evaluations per bounce share the surface's wo-only terms (zr_dev_bsdf.h)
+    PrepareWo(sc.rho, P.surface, kPrepK11);      // six evaluations per bounce share the surface's wo-only terms (zr_dev_bsdf.h)
     P.eta_next = eta_mat;
     }
     P.pos = newPos;
@@ -1356,7 +1367,7 @@ ZR_HD void PtPhaseA(const SceneView& sc, const zr_frame_constants& g, const RptP
         uvGrads = P.rd.uv_grads;
     }
     if (!GetMaterialData(sc, -P.bs.wi, P.eta_curr, P.hit, P.surface, eta_mat, uvGrads, prm.textured)) { P.active = false; return; }
-    PrepareWo(sc.rho, P.surface);      // six evaluations per bounce share the surface's wo-only terms (zr_dev_bsdf.h)
+    PrepareWo(sc.rho, P.surface, kPrepK11);      // six evaluations per bounce share the surface's wo-only terms (zr_dev_bsdf.h)
     P.eta_next = eta_mat;
     }
     P.pos = newPos;
@@ -1394,7 +1405,7 @@ ZR_HD void PtInitLane_Fused(const SceneView& sc, const zr_frame_constants& g, co
     P.valid = true;
     const Camera cam = CurrCamera(g);
     PixelSurface ps = LoadPixelSurface(gb, cam, x, y, g.frame_num, px);
-    PrepareWo(sc.rho, ps.surface);
+    PrepareWo(sc.rho, ps.surface, kPrepK11);
     P.maxNumBounces = ps.surface.specTr ? (int)prm.maxGlossyTrBounces : (int)prm.maxNonTrBounces;
     { uint32_t a = x / 16, b = y / 8, c = g.frame_num, d = 1; zr_pcg4d(&a, &b, &c, &d); P.rngGroup = Rng::Seed(a); }
     uint32_t sx = x, sy = y, sz = g.frame_num; zr_pcg3d(&sx, &sy, &sz);
@@ -1447,7 +1458,7 @@ ZR_HD void PtPhaseA_Fused(const SceneView& sc, const zr_frame_constants& g, cons
         uvGrads = P.rd.uv_grads;
     }
     if (!GetMaterialData(sc, -P.bs.wi, P.eta_curr, P.hit, P.surface, eta_mat, uvGrads, prm.textured)) { P.active = false; return; }
-    PrepareWo(sc.rho, P.surface);      // six evaluations per bounce share the surface's wo-only terms (zr_dev_bsdf.h)
+    PrepareWo(sc.rho, P.surface, kPrepK11);      // six evaluations per bounce share the surface's wo-only terms (zr_dev_bsdf.h)
     P.eta_next = eta_mat;
     }
     P.pos = newPos;
@@ -1737,7 +1748,7 @@ ZR_HD_FLAT void Replay(const Globals& g, bool currFrame, int numBounces, BsdfSam
             ctx.throughput = ctx.throughput * vexp(-hit.t * ext);
         }
         if (bounce >= numBounces) break;
-        PrepareWo(sc.rho, ctx.surface);
+        if (kPrepShift) PrepareWo(sc.rho, ctx.surface, kPrepShift);
         bs = SampleBSDF(sc.rho, ctx.normal, ctx.surface, ctx.rngReplay);
         if (dot(bs.bsdfOverPdf, bs.bsdfOverPdf) == 0) { ctx.throughput = v3(0.0f); return; }
         const float alpha_lobe = LobeAlpha(ctx.surface, bs.lobe);
@@ -1766,7 +1777,7 @@ ZR_HD_FLAT OffsetCtx Replay_kGt2(const Globals& g, bool currFrame, V3 pos, V3 no
     ctx.pos = pos; ctx.normal = normal; ctx.surface = surface; ctx.rngReplay = Rng::Seed(rc.seed_replay);
     ctx.eta_curr = kEtaAir; ctx.eta_next = ior; ctx.throughput = v3(1.0f);
     const int numBounces = (int)rc.k - 2;
-    PrepareWo(g.sc->rho, ctx.surface);
+    if (kPrepShift) PrepareWo(g.sc->rho, ctx.surface, kPrepShift);
     BsdfSample bs = SampleBSDF(g.sc->rho, ctx.normal, ctx.surface, ctx.rngReplay);
     if (dot(bs.bsdfOverPdf, bs.bsdfOverPdf) == 0) { ctx.throughput = v3(0.0f); return ctx; }
     if (g.textured)
@@ -1791,8 +1802,12 @@ ZR_HD_FLAT float StepPath(const Globals& g, bool currFrame, OffsetCtx& ctx, cons
     float alpha_k_min_1 = LobeAlpha(ctx.surface, rc.lobe_k_min_1);
     if (!CanReconnect(alpha_k_min_1, 1, rc.lobe_k_min_1, rc.lobe_k, g.alpha_min)) return 0;
     V3 w_k_min_1 = normalize(rc.x_k - ctx.pos);
-    PrepareWo(sc.rho, ctx.surface);      // y_{k-1}: the lobe candidates of EvalBSDFSampler share its wo-only terms
-    SamplerEval e = EvalBSDFSampler(sc.rho, ctx.normal, ctx.surface, w_k_min_1, rc.lobe_k_min_1, ctx.rngReplay);
+    SamplerEval e;
+    {
+    ZR_PROF_SCOPE(ZRP_BSDF);      // (-DZR_PROF builds: the evaluation at y_{k-1})
+    if (kPrepShift) PrepareWo(sc.rho, ctx.surface, kPrepShift);      // y_{k-1}: the lobe candidates of EvalBSDFSampler share its wo-only terms
+    e = EvalBSDFSampler(sc.rho, ctx.normal, ctx.surface, w_k_min_1, rc.lobe_k_min_1, ctx.rngReplay);
+    }
     if (dot(e.bsdfOverPdf, e.bsdfOverPdf) == 0) return 0;
     HitInfo hit;
     if (!FindClosestID(g, currFrame, ctx.pos, ctx.normal, w_k_min_1, ctx.surface.Transmissive(), hit)) return 0;
@@ -1804,8 +1819,9 @@ ZR_HD_FLAT float StepPath(const Globals& g, bool currFrame, OffsetCtx& ctx, cons
     float eta_mat;
     if (g.textured) { hit.dndu = v3(0.0f); hit.dndv = v3(0.0f); }     // (not fetched here; GetMaterialData may flip them)
     // RtRayQuery::IsotropicSampler with g_samLinearWrap (Shift.hlsli:519-521)
-    if (!GetMaterialData(sc, -w_k_min_1, ctx.eta_curr, hit, ctx.surface, eta_mat, ctx.rd.uv_grads, g.textured, true)) return 0;
-    PrepareWo(sc.rho, ctx.surface);      // y_k: evaluated two to four times by the case-1 / case-2 branches of Shift2
+    { ZR_PROF_SCOPE(ZRP_MATERIAL);
+    if (!GetMaterialData(sc, -w_k_min_1, ctx.eta_curr, hit, ctx.surface, eta_mat, ctx.rd.uv_grads, g.textured, true)) return 0; }
+    if (kPrepShift) PrepareWo(sc.rho, ctx.surface, kPrepShift);      // y_k: evaluated two to four times by the case-1 / case-2 branches of Shift2
     ctx.eta_next = eta_mat;
     if (inMedium && (ctx.surface.trDepth > 0))
     {
@@ -1927,6 +1943,7 @@ ZR_HD_FLAT OffsetPath Shift2(const Globals& g, bool currFrame, size_t DTidIdx, V
         if (ret.partialJacobian == 0) return ret;
         if (rc.IsCase1())
         {
+            ZR_PROF_SCOPE(ZRP_NEE);      // (-DZR_PROF builds: ZRP_NEE = the evaluation at y_k, all three cases)
             SamplerEval e = EvalBSDFSampler(g.sc->rho, ctx.normal, ctx.surface, rc.w, rc.lobe_k, ctx.rngReplay);
             ctx.throughput = ctx.throughput * e.bsdfOverPdf;
             ret.target = ctx.throughput * rc.L;
@@ -1938,7 +1955,7 @@ ZR_HD_FLAT OffsetPath Shift2(const Globals& g, bool currFrame, size_t DTidIdx, V
     {
         if (!IsLobeValid(ctx.surface, rc.lobe_k_min_1)) return ret;
         if (LobeAlpha(ctx.surface, rc.lobe_k_min_1) < g.alpha_min) return ret;
-        PrepareWo(g.sc->rho, ctx.surface);
+        if (kPrepShift) PrepareWo(g.sc->rho, ctx.surface, kPrepShift);
     }
     Rng rngNEE = Rng::Seed(rc.seed_nee);
     if (!g.emissive)      // Shift2<Emissive = false>, Shift.hlsli:788-813
@@ -1960,6 +1977,7 @@ ZR_HD_FLAT OffsetPath Shift2(const Globals& g, bool currFrame, size_t DTidIdx, V
         }
         return ret;
     }
+    ZR_PROF_SCOPE(ZRP_NEE);
     if (rc.IsCase2())
     {
         Direct ls = EvalDirect_Case2(g, ctx.normal, ctx.surface, rc.w, rc.L, rc.dwdA, rc.lightPdf, rc.lobe_k, ctx.rngReplay, rngNEE);
@@ -2106,9 +2124,13 @@ ZR_HD void ReconnectTemporalPixel(const RptFrame& F, const zr_frame_constants& g
     if (flags.invalid || flags.emissive) return;
     const bool doSpatial = F.prm.doSpatial;
     const Camera cam = CurrCamera(g);
-    PixelSurface ps = LoadPixelSurface(F.gb, cam, x, y, g.frame_num, px);
+    PixelSurface ps; TemporalPixel tp;
+    {
+    ZR_PROF_SCOPE(ZRP_MISC4);      // (-DZR_PROF builds: the two pixel surfaces)
+    ps = LoadPixelSurface(F.gb, cam, x, y, g.frame_num, px);
     // CtT reads the previous G-buffer's coat plane at DTid (ReSTIR_PT_Reconnect_CtT.hlsl:80), TtC at prevPixel
-    TemporalPixel tp = FindTemporal(F, g, x, y, ps, kMaxPlaneDistReuse, true);
+    tp = FindTemporal(F, g, x, y, ps, kMaxPlaneDistReuse, true);
+    }
     Globals gl = MakeGlobals(F, g, flags.transmissive, stack, cnt);
     const size_t pp = Pix(F.gb, (uint32_t)tp.px, (uint32_t)tp.py);
 

@@ -506,6 +506,7 @@ ZR_HD void PtInitPixel(const SceneView& sc, const zr_frame_constants& g, const G
     const uint32_t maxB = f_tr ? prm.maxGlossyTrBounces : prm.maxNonTrBounces;
     const uint32_t sampleSetIdx = rngGroup.UniformUintBounded_Faster(prm.numSampleSets);     // one group-RNG draw, always
 
+    PrepareWo(sc.rho, surface);
     BsdfSample bs = SampleBSDF(sc.rho, normal, surface, rngThread);
     F4 ro, rd;
     bool ok = bs.pdf != 0;
@@ -672,6 +673,7 @@ ZR_HD void PtShadePath(const SceneView& sc, const zr_frame_constants& g, const P
     else FillHit<false>(sc, tm.mesh, tm.prim, zr_asfloat(hc.y), zr_asfloat(hc.z), false, hit);
     Surface surface; float eta_mat;
     if (!GetMaterialData(sc, -wiC, eta_curr, hit, surface, eta_mat, uvGrads, tex)) { WriteFinal(finalRGBA, pid, li, fb, prm.accumulate); return; }
+    PrepareWo(sc.rho, surface);      // six evaluations of this vertex follow (NEE, its sampler pdf, the continuation's lobes): their wo-only terms once
     const float eta_next = eta_curr == kEtaAir ? eta_mat : kEtaAir;    // as computed inside GetMaterialData
     if (tex) { out.t[4] = f4(hit.normal, surface.eta); out.t[5] = f4(surface.wo, 0.0f); out.t[6] = f4(dpdx, 0.0f); out.t[7] = f4(dpdy, 0.0f); }
 
@@ -742,7 +744,8 @@ ZR_HD void PtShadePath(const SceneView& sc, const zr_frame_constants& g, const P
             {
                 const float dwdA = zr_saturate(dot(ln, -wi)) / (tl * tl);
                 surface.SetWi(wi, n);
-                le = le * (Unified(sc.rho, surface).f * dwdA);
+                const V3 fz = Unified(sc.rho, surface).f;
+                le = le * (fz * dwdA);
                 bool occludedEarly = false;
                 if (dot(le, le) > 0)
                 {
@@ -751,7 +754,7 @@ ZR_HD void PtShadePath(const SceneView& sc, const zr_frame_constants& g, const P
                     { out.rayS_o = ro; out.rayS_d = rd; out.sLightID = lightID; nflags |= PF_S_RAY; }
                     else occludedEarly = true;
                 }
-                float bsdfPdf = BSDFSamplerPdf(sc.rho, n, surface, wi, rngT);
+                float bsdfPdf = BSDFSamplerPdf_AtZ(sc.rho, n, surface, wi, fz, rngT);      // (the light direction's SetWi + Unified above, not evaluated again)
                 bsdfPdf *= dwdA;
                 if (occludedEarly) le = le * 0.0f;
                 ldLight = ldLight + PowerHeuristic(lightPdf, bsdfPdf, le, (float)numLightSamples, 1.0f);
