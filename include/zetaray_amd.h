@@ -295,7 +295,11 @@ int zr_scene_update_instances_async(zr_scene* scene, void* hip_stream, const zr_
    world-space tree, whose topology ages as instances move).  Enabled: an update that finds no build in flight snapshots the new transforms and starts
    the host's SAH builder on a thread; the first update after it has finished uploads the new topology into the buffer set that becomes current and
    refits it to that update's transforms -- stream-ordered, no render waits, results never depend on the tree.  stats: builds started / installed,
-   building = 0 idle, 1 building, 2 built and waiting for the next update.  ZR_SCENE_UPDATE=refit_sah turns it on for every scene of the process. */
+   building = 0 idle, 1 building, 2 built and waiting for the next update.  ZR_SCENE_UPDATE=refit_sah turns it on for every scene of the process.
+   Threading: zr_scene_set_background_rebuild and the update calls of ONE scene must come from one thread at a time (the pass-level contract: a scene
+   has one owner); zr_scene_background_rebuild_stats may be called from any thread.  Stream capture: the FIRST in-place update of a scene waits for
+   the device once (it cannot know which earlier renders read the buffers it is about to rewrite), so it must not be recorded into a hipGraph
+   capture; later updates only enqueue. */
 int zr_scene_set_background_rebuild(zr_scene* scene, int enable);
 int zr_scene_background_rebuild_stats(zr_scene* scene, uint64_t* started, uint64_t* installed, int* building);
 int zr_scene_update_emissives_async(zr_scene* scene, void* hip_stream, const zr_emissive_triangle* triangles, uint32_t first, uint32_t count);
@@ -437,6 +441,9 @@ int zr_pass_read_cost_map(zr_pass* pass, void* hip_stream, uint32_t* out_cells, 
  * bounces could win back.  out = {lanes alive at the boundaries, lane slots of the waves that passed them, 32-bit words of path state carried across a
  * boundary}, accumulated since the pass was created.  Waits for the device.  No reference counterpart. */
 int zr_pass_debug_trip_stats(zr_pass* pass, uint64_t out[3]);
+/* test hook: the node count from which the ReSTIR PT pass launches K11's large-scene instantiation (4 waves per SIMD + the top of the tree in LDS;
+ * default 16384 nodes = 1 MB) -- lets the parity tests run that instantiation on their small scenes.  0 restores the default.  Process-wide. */
+int zr_debug_set_large_scene_nodes(uint32_t num_nodes);
 /* the same counters split by the kernel that issued the queries (not reset; roofline bookkeeping of bench.py) */
 int zr_pass_read_kernel_counters(zr_pass* pass, void* hip_stream, uint32_t max_entries, const char** names,
                                  uint64_t* n_closest, uint64_t* n_shadow, uint32_t* count);

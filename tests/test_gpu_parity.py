@@ -901,24 +901,19 @@ def test_half_conversion_instructions_match_portable_code(api):
     assert (a.value, b.value) == (0, 0)
 
 
-def test_restir_pt_large_scene_kernel_build_on_gpu():
-    """K11 has a second build for scenes whose BVH exceeds the caches (4 waves per SIMD, zr_kernels.h); ZR_LARGE_SCENE_NODES=1 selects it
-    for the small test scene, in a fresh process (the threshold is read once): same bit-exact comparison as the materials / RR test."""
-    import subprocess
-    import sys
-    code = (
-        "import sys; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
-        "from oracle import zro\n"
-        "from zetaray_amd import api, scene_io, wire\n"
-        "import test_gpu_parity as T\n"
-        "sc = scene_io.make_synthetic_scene(num_tris=3000, num_emissive=1500, seed=11)\n"
-        "o = zro.OracleScene(sc, force_bvh=True)\n"
-        "prm = wire.default_params(); prm.max_non_tr_bounces, prm.max_glossy_tr_bounces = 6, 8\n"
-        "T._rpt_compare(api, sc, o, 96, 64, prm, 3, cam=dict(cam_pos=(0, 0, -3.5)))\n"
-        "print('LARGE_OK')\n") % (ROOT, os.path.join(ROOT, "tests"))
-    env = dict(os.environ, ZR_LARGE_SCENE_NODES="1")
-    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
-    assert r.returncode == 0 and "LARGE_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+def test_restir_pt_large_scene_kernel_build_on_gpu(api):
+    """K11 has a second build for scenes whose BVH exceeds the caches (4 waves per SIMD + the top of the tree in LDS, zr_kernels.h);
+    zr_debug_set_large_scene_nodes(1) selects it for the small test scene: same bit-exact comparison as the materials / RR test."""
+    from oracle import zro
+    sc = scene_io.make_synthetic_scene(num_tris=3000, num_emissive=1500, seed=11)
+    o = zro.OracleScene(sc, force_bvh=True)
+    prm = wire.default_params()
+    prm.max_non_tr_bounces, prm.max_glossy_tr_bounces = 6, 8
+    assert api.lib().zr_debug_set_large_scene_nodes(1) == 0
+    try:
+        _rpt_compare(api, sc, o, 96, 64, prm, 3, cam=dict(cam_pos=(0, 0, -3.5)))
+    finally:
+        api.lib().zr_debug_set_large_scene_nodes(0)
 
 
 # ------------------------------------------------------------------ parity on the BASELINE configurations (SURVEY.md 8(d))
@@ -1026,14 +1021,13 @@ def atrium():
 
 def test_baseline_config_atrium_restir_pt_bit_exact(api, atrium):
     """The 380k-triangle / 100k-light atrium with the presampled light sets the reference would use (128 x 512, PreLighting.cpp:289-297)
-    at 480 x 270 for 3 frames, ZR_LARGE_SCENE_NODES at its default: the BVH has >= 16k nodes, so the 4-wave build of K11
+    at 480 x 270 for 3 frames, the large-scene threshold at its default: the BVH has >= 16k nodes, so the 4-wave build of K11
     (k_rpt_pathtrace_w4) and traversal stacks deeper than the 8 LDS entries really run.  Radiance, reservoir planes, counters: tolerance 0."""
     sc, o = atrium
     handle = api.Scene(sc)
     nodes, tris, depth = handle.bvh_info()
     handle.close()
     assert nodes >= 16384 and tris == sc.num_tris, (nodes, tris)
-    assert int(os.environ.get("ZR_LARGE_SCENE_NODES", "16384")) == 16384, "this test must run with the default large-scene threshold"
     prm = wire.default_params()
     prm.presampling, prm.num_sample_sets, prm.sample_set_size = 1, 128, 512
     w, h = 480, 270
@@ -1653,14 +1647,17 @@ print("DIGEST", hh.hexdigest())
 
 @pytest.mark.parametrize("scene", ["cornell_emissive.npz", "cornell.npz"])
 def test_k11_kernel_variants_produce_identical_frames(scene):
-    """K11 has three selectable forms (ZR_K11, read once per process): the inline megakernel (default), block-pooled traces (`pool`, emissive
+    """The experiments build (libzetaray_amd_exp.so) has three selectable forms of K11 (ZR_K11, read once per process): the inline megakernel (the product's), block-pooled traces (`pool`, emissive
     permutation) and a kernel per bounce with path compaction (`compact`).  Four ReSTIR PT frames with a moving camera: radiance and every
     reservoir plane hash to the same digest under each."""
     import subprocess
     import sys
+    exp = os.path.join(ROOT, "zetaray_amd", "libzetaray_amd_exp.so")
+    if not os.path.exists(exp):
+        pytest.skip("the K11 forms other than the inline megakernel exist only in the experiments build (make -C zetaray_amd/csrc experiments)")
     digests = {}
     for mode in ("inline", "compact", "pool"):
-        res = subprocess.run([sys.executable, "-c", _VARIANT_SNIPPET, ROOT, scene], env=dict(os.environ, ZR_K11=mode), capture_output=True, text=True, timeout=600)
+        res = subprocess.run([sys.executable, "-c", _VARIANT_SNIPPET, ROOT, scene], env=dict(os.environ, ZR_K11=mode, ZETARAY_AMD_LIB=exp), capture_output=True, text=True, timeout=600)
         assert res.returncode == 0, res.stdout[-1000:] + res.stderr[-3000:]
         digests[mode] = [l for l in res.stdout.splitlines() if l.startswith("DIGEST")][0]
     assert len(set(digests.values())) == 1, digests

@@ -1,5 +1,5 @@
 """per-kernel GPU time of each rank's tile of the 8-way split (one device, tiles rendered in turn, halos exchanged in process): where a small tile's
-time goes.  python scripts/tile_kernels.py [--scene synthetic]"""
+time goes.  python tools/tile_kernels.py [--scene synthetic]"""
 import argparse, json, os, sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

@@ -52,11 +52,21 @@ static int RequireDevice(int device)
 }
 
 #include "zr_kernels.h"
+
+// A/B switches of the measurement builds.  The product library has none: each reads as its default.  `make experiments` (-DZR_EXPERIMENTS ->
+// libzetaray_amd_exp.so) turns them into environment variables read once per process.
+#ifdef ZR_EXPERIMENTS
+#define ZR_EXP_ENV(name) std::getenv(name)
+#else
+#define ZR_EXP_ENV(name) ((const char*)nullptr)
+#endif
 #include "zr_bvh_device.h"
 // the ReSTIR PT kernels are compiled in zr_tu_rpt_a.hip / zr_tu_rpt_b.hip (see zr_kernels.h)
 ZR_RPT_GROUP_A(extern template)
 ZR_RPT_GROUP_B(extern template)
+#ifdef ZR_EXPERIMENTS
 ZR_RPT_GROUP_C(extern template)
+#endif
 
 // pickXY: x | y << 16 of the pixel to pick (render-target coordinates), 0xffffffff = none
 __global__ void __launch_bounds__(kBlock) k_gbuffer(SceneView sc, zr_frame_constants g, GBuf gb, uint32_t tilesX, uint32_t pickXY, uint32_t* pick)
@@ -605,7 +615,7 @@ struct zr_scene
         uint32_t numNodes = 0, numTris = 0, stackNeed = 0, maxDepth = 0; bool packed = false;
         uint32_t* pkg = nullptr; size_t pkgCap = 0; hipEvent_t pkgCopied = nullptr; bool pkgInFlight = false;      // pkgCap in words
         std::vector<zr_mesh_instance> inst; std::vector<float> xf; std::vector<uint8_t> own;
-        uint32_t refitsSince = 0; uint64_t started = 0, installed = 0;
+        uint32_t refitsSince = 0; std::atomic<uint64_t> started{0}, installed{0};      // (atomic: zr_scene_background_rebuild_stats may read them from another thread)
         bool movedSinceBuild = false;      // a transform changed since the last build was started: updates that repeat the same matrices start no build
         double buildMs = 0, packMs = 0;
     } bg;
@@ -789,7 +799,9 @@ struct QueueStorage
     }
 };
 
+static constexpr uint32_t kRptListWords = 12;      // replay work-list counts + cursors of the ReSTIR PT pass (layout: where the buffer is allocated)
 static constexpr uint32_t kLargeSceneNodes = 16384;     // BVH4 nodes (64 B each): 1 MB of nodes and up counts as "does not fit the caches"
+static std::atomic<uint32_t> g_largeSceneNodes{kLargeSceneNodes};      // zr_debug_set_large_scene_nodes
 static constexpr int kMaxRounds = 16;
 static constexpr int kMaxTimers = 64;
 // ray-counter slots (pairs of u64 on the device): 0 = wavefront path tracer, 1.. = ReSTIR PT kernels in launch order
@@ -1553,7 +1565,7 @@ int zr_scene_update_instances_async(zr_scene* s, void* stream, const zr_mesh_ins
         B.movedSinceBuild = false;
         if (B.th.joinable()) B.th.join();
         B.inst.assign(instances, instances + n); B.xf.assign(instance_to_world, instance_to_world + 12 * (size_t)n);
-        { const char* e = std::getenv("ZR_BVH_GROUP"); if (e && !std::strcmp(e, "0")) B.own.clear(); else B.own = s->movedEver; }
+        { const char* e = ZR_EXP_ENV("ZR_BVH_GROUP"); if (e && !std::strcmp(e, "0")) B.own.clear(); else B.own = s->movedEver; }
         B.state.store(1, std::memory_order_release); B.started++;
         zr_scene* sp = s;
         B.th = std::thread([sp] {
@@ -1592,7 +1604,7 @@ int zr_scene_update_instances_async(zr_scene* s, void* stream, const zr_mesh_ins
             Q.numNodes = (uint32_t)nn; Q.numTris = (uint32_t)nt; Q.stackNeed = bvh.stackNeed; Q.maxDepth = bvh.maxDepth;
             Q.buildMs = std::chrono::duration<double, std::milli>(t1 - t0).count();
             Q.packMs = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t1).count();
-            if (std::getenv("ZR_BVH_TIMING"))
+            if (ZR_EXP_ENV("ZR_BVH_TIMING"))
                 std::fprintf(stderr, "[zr_scene] background tree: %zu nodes over %zu triangles, build %.1f ms, package (%.1f MB pinned) %.1f ms\n", nn, nt, Q.buildMs, words * 4e-6, Q.packMs);
             Q.state.store(2, std::memory_order_release);
         });
@@ -1610,8 +1622,8 @@ int zr_scene_set_background_rebuild(zr_scene* s, int enable)
 int zr_scene_background_rebuild_stats(zr_scene* s, uint64_t* started, uint64_t* installed, int* building)
 {
     if (!s) return Fail(ZR_ERR_INVALID_ARG, "zr_scene_background_rebuild_stats: null scene");
-    if (started) *started = s->bg.started;
-    if (installed) *installed = s->bg.installed;
+    if (started) *started = s->bg.started.load(std::memory_order_relaxed);
+    if (installed) *installed = s->bg.installed.load(std::memory_order_relaxed);
     if (building) *building = s->bg.state.load(std::memory_order_acquire);
     return ZR_OK;
 }
@@ -1938,7 +1950,10 @@ static int AllocPass(zr_pass* p)
             { const size_t cells = (size_t)((p->w + 31u) / 32u + 1u) * ((p->h + 31u) / 32u + 1u); if ((r = p->costMap.Alloc(cells))) return r; HIP_TRY(hipMemset(p->costMap.p, 0, cells * 4)); }
             if ((r = p->rptSampleSet.Upload(kRptSampleSet, 1024))) return r;
             if ((r = p->rptLists.Alloc(4 * cap))) return r;
-            if ((r = p->rptListCounts.Alloc(8))) return r;      // 4 counts + 4 cursors (k_rpt_replay pulls its work dynamically)
+            // word layout (kRptListWords): [0, 1] temporal counts, [2, 3] first spatial round, [4, 5] the temporal replays' cursors (counts + 4 / + 5 of
+            // base 0: the only DYNAMIC replay), [6, 7] second spatial round, [8 .. 11] = base 6's cursor slots -- unused (the spatial replays split
+            // their lists statically) but allocated and zeroed, so that no base ever reaches past the buffer
+            if ((r = p->rptListCounts.Alloc(kRptListWords))) return r;
             p->temporalValid = false; p->currIdx = 0;
         }
     }
@@ -2309,7 +2324,7 @@ static int RenderReSTIR_GI(zr_pass* p, hipStream_t s, const zr_frame_constants* 
 // slower, the 2-way split's do not care -- so only the one-round case switches.
 static bool FewerRoundsAtFourWaves(uint32_t waves)
 {
-    static const bool off = [] { const char* e = getenv("ZR_K11_ROUNDS"); return e && !strcmp(e, "0"); }();      // (A/B switch)
+    static const bool off = [] { const char* e = ZR_EXP_ENV("ZR_K11_ROUNDS"); return e && !strcmp(e, "0"); }();      // (A/B switch)
     return !off && waves > 3072u && waves <= 4096u;
 }
 
@@ -2344,7 +2359,7 @@ static int RenderReSTIR_PT(zr_pass* p, hipStream_t s, const zr_frame_constants* 
     prm.sortTemporal = (ip.flags & ZR_IND_SORT_TEMPORAL) ? 1u : 0u; prm.sortSpatial = (ip.flags & ZR_IND_SORT_SPATIAL) ? 1u : 0u;
     // the CtN map (current reservoirs bucketed by k) schedules the fused CtT + TtC kernel: 0.540 -> 0.495 ms Cornell, 3.27 -> 3.16 ms atrium at
     // 1080p; the NtC map does not pay (0.546 / 3.34).  ZR_TEMPORAL_MAP = 0 / 1 / 2 overrides (scripts/gpu_sortmap.sh)
-    static const uint32_t temporalMapEnv = [] { const char* e = getenv("ZR_TEMPORAL_MAP"); return e ? (uint32_t)atoi(e) : 1u; }();
+    static const uint32_t temporalMapEnv = [] { const char* e = ZR_EXP_ENV("ZR_TEMPORAL_MAP"); return e ? (uint32_t)atoi(e) : 1u; }();
     prm.temporalMap = prm.sortTemporal ? temporalMapEnv : 0u;
     if (stages & ZR_STAGE_TEMPORAL)
     {
@@ -2378,8 +2393,8 @@ static int RenderReSTIR_PT(zr_pass* p, hipStream_t s, const zr_frame_constants* 
 #define RPT_TIMED(name, ...) do { TimerBegin(p, s, name); __VA_ARGS__; TimerEnd(p, s); } while (0)
     // the NEE_EMISSIVE permutation of a kernel (the reference compiles separate shaders, IndirectLighting.h:251-300)
     const bool emissiveVariant = prm.emissive != 0;
-    // (ZR_LARGE_SCENE_NODES: test hook, lets the parity tests run the large-scene kernel build on their small scenes)
-    static const uint32_t largeSceneNodes = [] { const char* e = getenv("ZR_LARGE_SCENE_NODES"); return e ? (uint32_t)atoi(e) : kLargeSceneNodes; }();
+    // (zr_debug_set_large_scene_nodes: test hook, lets the parity tests run the large-scene kernel build on their small scenes)
+    const uint32_t largeSceneNodes = g_largeSceneNodes.load(std::memory_order_relaxed);
     // ... and the TEXTURED permutation (this ABI's: untextured scenes carry no ray differentials)
     const bool texVariant = prm.textured != 0;
 #define RPT_LAUNCH_E(kern, ...) do { \
@@ -2390,10 +2405,13 @@ static int RenderReSTIR_PT(zr_pass* p, hipStream_t s, const zr_frame_constants* 
         else { if (texVariant) hipLaunchKernelGGL((kern<PASS, false, true>), __VA_ARGS__); else hipLaunchKernelGGL((kern<PASS, false, false>), __VA_ARGS__); } } while (0)
     if (stages & ZR_STAGE_TEMPORAL)
     {
-        HIP_TRY(hipMemsetAsync(listCnt, 0, 8 * sizeof(uint32_t), s));
+        HIP_TRY(hipMemsetAsync(listCnt, 0, kRptListWords * sizeof(uint32_t), s));
         TimerBegin(p, s, "rpt_pathtrace");
-        // ZR_K11=pool: K11 with block-pooled traces (k_rpt_pathtrace_coop, zr_kernels.h; emissive untextured permutation); ZR_K11=inline: the megakernel
+#ifdef ZR_EXPERIMENTS
+        // (experiments build, zr_kernels_exp.h) ZR_K11=pool: K11 with block-pooled traces (k_rpt_pathtrace_coop; emissive untextured permutation);
+        // compact: a kernel per bounce; trip: the alive-lane diagnostic; ZR_K11=inline: the megakernel
         static const int k11Mode = [] { const char* e = getenv("ZR_K11"); return e && !strcmp(e, "inline") ? 0 : (e && !strcmp(e, "pool") ? 1 : (e && !strcmp(e, "trip") ? 2 : (e && !strcmp(e, "compact") ? 3 : ZR_K11_DEFAULT))); }();
+        static const bool park = [] { const char* e = getenv("ZR_K11_PARK"); return e ? atoi(e) != 0 : (ZR_K11_PARK_DEFAULT != 0); }();      // the 3-wave build with the reservoir's selected reconnection in LDS (zr_rpt.h RcPark)
         if (k11Mode == 1 && emissiveVariant && !texVariant)
         {
             const dim3 gridCoop(tilesX * tilesY), blockCoop(kCoopBlock);
@@ -2426,16 +2444,14 @@ static int RenderReSTIR_PT(zr_pass* p, hipStream_t s, const zr_frame_constants* 
             if (sc->view.numNodes >= largeSceneNodes) hipLaunchKernelGGL(k_rpt_pathtrace_trip_w4<false>, gridRpt, blockRpt, 0, s, F, *cb, tilesX, ctr + 2 * 1);
             else hipLaunchKernelGGL(k_rpt_pathtrace_trip<false>, gridRpt, blockRpt, 0, s, F, *cb, tilesX, ctr + 2 * 1);
         }
-        else if (texVariant) { if (emissiveVariant) hipLaunchKernelGGL(k_rpt_pathtrace_tex<true>, gridRpt, blockRpt, 0, s, F, *cb, tilesX, ctr + 2 * 1); else hipLaunchKernelGGL(k_rpt_pathtrace_tex<false>, gridRpt, blockRpt, 0, s, F, *cb, tilesX, ctr + 2 * 1); }
+        else if (k11Mode == 0 && park && !texVariant && !(sc->view.numNodes >= largeSceneNodes || FewerRoundsAtFourWaves(gridRpt.x)))
+        { if (emissiveVariant) hipLaunchKernelGGL(k_rpt_pathtrace_park<true>, gridRpt, blockRpt, 0, s, F, *cb, tilesX, ctr + 2 * 1); else hipLaunchKernelGGL(k_rpt_pathtrace_park<false>, gridRpt, blockRpt, 0, s, F, *cb, tilesX, ctr + 2 * 1); }
+        else
+#endif
+        if (texVariant) { if (emissiveVariant) hipLaunchKernelGGL(k_rpt_pathtrace_tex<true>, gridRpt, blockRpt, 0, s, F, *cb, tilesX, ctr + 2 * 1); else hipLaunchKernelGGL(k_rpt_pathtrace_tex<false>, gridRpt, blockRpt, 0, s, F, *cb, tilesX, ctr + 2 * 1); }
         else if (sc->view.numNodes >= largeSceneNodes || FewerRoundsAtFourWaves(gridRpt.x))     // BVH beyond the caches, or a small grid: the 4-wave build of K11 (zr_kernels.h)
         { if (emissiveVariant) hipLaunchKernelGGL(k_rpt_pathtrace_w4<true>, gridRpt, blockRpt, 0, s, F, *cb, tilesX, ctr + 2 * 1); else hipLaunchKernelGGL(k_rpt_pathtrace_w4<false>, gridRpt, blockRpt, 0, s, F, *cb, tilesX, ctr + 2 * 1); }
-        else
-        {
-            // ZR_K11_PARK=1: the 3-wave build with the reservoir's selected reconnection in LDS (zr_rpt.h RcPark; measured in DESIGN 6.4)
-            static const bool park = [] { const char* e = getenv("ZR_K11_PARK"); return e ? atoi(e) != 0 : (ZR_K11_PARK_DEFAULT != 0); }();
-            if (park) { if (emissiveVariant) hipLaunchKernelGGL(k_rpt_pathtrace_park<true>, gridRpt, blockRpt, 0, s, F, *cb, tilesX, ctr + 2 * 1); else hipLaunchKernelGGL(k_rpt_pathtrace_park<false>, gridRpt, blockRpt, 0, s, F, *cb, tilesX, ctr + 2 * 1); }
-            else if (emissiveVariant) hipLaunchKernelGGL(k_rpt_pathtrace<true>, gridRpt, blockRpt, 0, s, F, *cb, tilesX, ctr + 2 * 1); else hipLaunchKernelGGL(k_rpt_pathtrace<false>, gridRpt, blockRpt, 0, s, F, *cb, tilesX, ctr + 2 * 1);
-        }
+        else { if (emissiveVariant) hipLaunchKernelGGL(k_rpt_pathtrace<true>, gridRpt, blockRpt, 0, s, F, *cb, tilesX, ctr + 2 * 1); else hipLaunchKernelGGL(k_rpt_pathtrace<false>, gridRpt, blockRpt, 0, s, F, *cb, tilesX, ctr + 2 * 1); }
         TimerEnd(p, s);
         if (prm.doTemporal)
         {
@@ -2454,10 +2470,13 @@ static int RenderReSTIR_PT(zr_pass* p, hipStream_t s, const zr_frame_constants* 
         F.cur = p->res[p->currIdx].View(); F.prev = p->res[1 - p->currIdx].View();
         // replay work lists + their device-side counts of this round: {2, 3} for the first, {6, 7} for the second (zeroed at the start of the frame)
         uint32_t* const sCnt = listCnt + (spass == 0 ? 2 : 6);
+#ifdef ZR_EXPERIMENTS
         // ZR_SEARCH=tile: the LDS-tiled K15 (k_rpt_light<2>), kept for the A/B of DESIGN's N3 row -- measured slower than the plain gathers
         static const bool searchTile = [] { const char* e = getenv("ZR_SEARCH"); return e && !strcmp(e, "tile"); }();
         if (searchTile) RPT_TIMED("rpt_spatial_search", hipLaunchKernelGGL(k_rpt_light<2>, grid, block, 0, s, F, *cb, tilesX, lists[2], lists[3], sCnt));
-        else RPT_TIMED("rpt_spatial_search", hipLaunchKernelGGL(k_rpt_light<1>, gridSearch, block, 0, s, F, *cb, tilesX, lists[2], lists[3], sCnt));
+        else
+#endif
+        RPT_TIMED("rpt_spatial_search", hipLaunchKernelGGL(k_rpt_light<1>, gridSearch, block, 0, s, F, *cb, tilesX, lists[2], lists[3], sCnt));
         // K12 Sort_CtS / Sort_StC (IndirectLighting.cpp:690-742): the NtC map decides which pixels share a wave in Reconnect_StC, i.e. the
         // population of its boiling-suppression averages
         if (prm.sortSpatial)
@@ -2533,7 +2552,7 @@ static int RenderIndirect(zr_pass* p, hipStream_t s, const zr_frame_constants* c
     const uint32_t gridShade = (uint32_t)std::min<size_t>((cap + kBlock - 1) / kBlock, 4096);
     const uint32_t gridTrace = (uint32_t)std::min<size_t>((3 * cap + kBlock - 1) / kBlock, 2048);    // persistent: 256 CUs x 8 blocks
     const uint32_t gridTraceSimple = (uint32_t)std::min<size_t>((3 * cap + kBlock - 1) / kBlock, 8192);
-    static const int traceMode = [] { const char* e = getenv("ZR_TRACE_MODE"); return e ? atoi(e) : 0; }();
+    static const int traceMode = [] { const char* e = ZR_EXP_ENV("ZR_TRACE_MODE"); return e ? atoi(e) : 0; }();
     for (int r = 0; r < rounds; r++)
     {
         const PathQueue qin = p->q[r & 1].View(), qout = p->q[(r + 1) & 1].View();
@@ -2697,10 +2716,10 @@ static int RenderDenoise(zr_pass* p, hipStream_t s, const zr_frame_constants* cb
         // LDS-staged tiles for the dense iterations: steps 1, 2 and 4 (48 x 24 tile, 36.8 KB per block, for the last).  With definition 2 the iterations that
         // read their taps from the planes are L1-bound (800 B of taps per pixel through 64 B / clk / CU: 0.24 ms at 3840 x 2160 against 0.14 - 0.15 ms from
         // LDS, profiles/r04c_post_sqA.csv); steps 8 and 16 do not fit a tile.  ZR_DENOISE=plain: every iteration from the planes; ZR_DENOISE=lds2: steps 1 and 2 only
-        static const int ldsSteps = [] { const char* e = getenv("ZR_DENOISE"); return e && !strcmp(e, "plain") ? 0 : (e && !strcmp(e, "lds2") ? 2 : 3); }();
+        static const int ldsSteps = [] { const char* e = ZR_EXP_ENV("ZR_DENOISE"); return e && !strcmp(e, "plain") ? 0 : (e && !strcmp(e, "lds2") ? 2 : 3); }();
         // the row-loop form of the tap stencil (zr_svgf.h AtrousPixelT) is the default: 5 iterations 0.978 ms against 1.006 ms for the fully unrolled form at
         // 3840 x 2160 (profiles/r04c_post_chain*.jsonl), a fifth of the code; ZR_DENOISE_TAPS=unroll selects the other
-        static const bool rowLoop = [] { const char* e = getenv("ZR_DENOISE_TAPS"); return !(e && !strcmp(e, "unroll")); }();
+        static const bool rowLoop = [] { const char* e = ZR_EXP_ENV("ZR_DENOISE_TAPS"); return !(e && !strcmp(e, "unroll")); }();
 #define ZR_SVGF_LAUNCH(K, ...) do { if (!pow7) hipLaunchKernelGGL((K<__VA_ARGS__ -1, true>), grid, block, 0, s, A); else if (rowLoop) hipLaunchKernelGGL((K<__VA_ARGS__ 7, true>), grid, block, 0, s, A); \
             else hipLaunchKernelGGL((K<__VA_ARGS__ 7, false>), grid, block, 0, s, A); } while (0)
         if (it == 0 && ldsSteps >= 1) ZR_SVGF_LAUNCH(k_svgf_atrous_lds, 1,);
@@ -3058,6 +3077,7 @@ int zr_pass_enable_cost_map(zr_pass* p, int enable)
     p->costRays = enable == ZR_COST_MAP_RAYS;
     return ZR_OK;
 }
+int zr_debug_set_large_scene_nodes(uint32_t n) { g_largeSceneNodes.store(n ? n : kLargeSceneNodes, std::memory_order_relaxed); return ZR_OK; }
 int zr_pass_debug_trip_stats(zr_pass* p, uint64_t out[3])
 {
     if (!p || !out) return Fail(ZR_ERR_INVALID_ARG, "null argument");

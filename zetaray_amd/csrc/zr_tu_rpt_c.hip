@@ -1,3 +1,7 @@
-// zr_tu_rpt_c.hip -- translation unit of libzetaray_amd.so holding K11 with pooled traces (k_rpt_pathtrace_coop; see zr_kernels.h)
+// zr_tu_rpt_c.hip -- translation unit of the EXPERIMENTS build only (libzetaray_amd_exp.so, `make experiments`): K11's park / compact / trip / pool
+// forms (zr_kernels_exp.h)
 #include "zr_kernels.h"
+#ifndef ZR_EXPERIMENTS
+#error "zr_tu_rpt_c.hip belongs to the experiments build (-DZR_EXPERIMENTS)"
+#endif
 ZR_RPT_GROUP_C(template)
