@@ -294,6 +294,99 @@ class OracleRPT:
         return out
 
 
+class OracleRPTWindows:
+    """The oracle's ReSTIR PT on scattered windows of ONE full-size frame (at-size parity, tests/window_parity.py): full-size planes and global pixel
+    coordinates -- the oracle's passes unchanged but for the rectangle their loops visit (zro_rpt.h g_active) -- G-buffer rendered on window + apron,
+    K11 / temporal / spatial stages on the owned window, the apron's reservoirs written in by the caller from the frame under test.  window(i) gives
+    the per-window view with the interface of tests.hostexec.zhx.HostExecRPT (render_stage, plane, write_plane_rect, counters)."""
+    HALO = {"A": (0, np.uint32, 1), "B": (1, np.float32, 2), "C": (2, np.uint32, 4), "D": (3, np.uint32, 4), "E": (4, np.uint16, 1), "F": (5, np.float32, 2), "G": (6, np.uint32, 2)}
+
+    def __init__(self, oscene, W, H, windows):
+        """windows: [(own, ext)], own / ext = (x0, y0, w, h) in frame coordinates, pairwise disjoint ext"""
+        from zetaray_amd import scene_io, wire
+        self.osc, self.W, self.H, self.windows = oscene, W, H, list(windows)
+        self.sample_set = scene_io.load_rpt_sample_set()
+        self.r = lib().zro_rpt_create(W, H, self.sample_set.ctypes.data)
+        self.gb = [wire.alloc_gbuffer_planes(W, H), wire.alloc_gbuffer_planes(W, H)]
+        self.gbi, self.frame_gb, self.have_prev = 0, None, False
+        self.final = np.zeros((H, W, 4), np.float32)
+        self.counters = [(0, 0)] * len(self.windows)
+        # the physical reservoir set holding a window's post-temporal (between its stages) / final (after its stage 2) reservoirs: the windows share one
+        # state and only the last window of a sweep commits the end-of-frame set flips, so the logical names are resolved here
+        self.set_of = [[0, 0] for _ in self.windows]      # [window][which]: which = 1 post-temporal, 0 final
+        L = lib()
+        L.zro_gbuffer_render_rect.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p] + [C.c_uint32] * 4
+        L.zro_rpt_render_stage.argtypes = [C.c_void_p] * 8 + [C.c_int, C.c_void_p, C.c_int]
+        L.zro_rpt_curr_idx.argtypes = [C.c_void_p]
+        L.zro_rpt_rw_plane_rect.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p] + [C.c_uint32] * 7 + [C.c_int]
+
+    def __del__(self):
+        if getattr(self, "r", None):
+            lib().zro_rpt_destroy(self.r)
+            self.r = None
+
+    def _stage(self, i, cb, params, stage):
+        from zetaray_amd import wire
+        own, ext = self.windows[i]
+        cbb = np.ascontiguousarray(cb)
+        key = int(cb["frame_num"])
+        if stage == 1:
+            if self.frame_gb != key:      # first window of a new frame: the planes of the last frame become "previous"
+                if self.frame_gb is not None:
+                    self.gbi, self.have_prev = 1 - self.gbi, True
+                self.frame_gb = key
+            lib().zro_gbuffer_render_rect(self.osc.h, cbb.ctypes.data, C.addressof(self.gb[self.gbi][1]), ext[0], ext[1], ext[0] + ext[2], ext[1] + ext[3])
+        prev = C.addressof(self.gb[1 - self.gbi][1]) if self.have_prev else None
+        rect = (C.c_uint32 * 4)(own[0], own[1], own[0] + own[2], own[1] + own[3])
+        cnt = wire.Counters()
+        commit = 1 if (stage == 2 and i == len(self.windows) - 1) else 0
+        before = lib().zro_rpt_curr_idx(self.r)
+        after = lib().zro_rpt_render_stage(self.osc.h, self.r, cbb.ctypes.data, C.addressof(self.gb[self.gbi][1]), prev, C.addressof(params),
+                                           self.final.ctypes.data, C.addressof(cnt), stage, rect, commit)
+        if stage == 1:
+            self.set_of[i][1] = before          # K11 and the temporal passes write the current set
+        else:
+            self.set_of[i][0] = 1 - after       # "the set the next frame reads as previous" once the flips are committed
+        c = self.counters[i] if stage == 2 else (0, 0)
+        self.counters[i] = (c[0] + cnt.n_closest, c[1] + cnt.n_shadow)
+
+    def _rw(self, i, name, which, buf, rect_local, write):
+        own, ext = self.windows[i]
+        idx, dt, ch = self.HALO[name]
+        x, y, w, h = rect_local
+        lib().zro_rpt_rw_plane_rect(self.r, 2 + self.set_of[i][which], idx, buf.ctypes.data, ext[0], ext[1], ext[2], ext[0] + x, ext[1] + y, w, h, write)
+
+    def window(self, i):
+        return _OracleWindow(self, i)
+
+
+class _OracleWindow:
+    def __init__(self, parent, i):
+        self.p, self.i = parent, i
+        self.own, self.ext = parent.windows[i]
+
+    @property
+    def counters(self):
+        return self.p.counters[self.i]
+
+    def render_stage(self, cb, params, stage):
+        """stage 1 = G-buffer on window + apron, K11 + temporal on the window; 2 = spatial + end of frame (the LAST window of the sweep commits it).
+        Returns the full-size radiance array cropped to the extended rect."""
+        self.p._stage(self.i, cb, params, stage)
+        e = self.ext
+        return self.p.final[e[1]:e[1] + e[3], e[0]:e[0] + e[2]]
+
+    def plane(self, name, which=0):
+        idx, dt, ch = self.p.HALO[name]
+        out = np.zeros((self.ext[3], self.ext[2], ch), dt)
+        self.p._rw(self.i, name, which, out, (0, 0, self.ext[2], self.ext[3]), 0)
+        return out
+
+    def write_plane_rect(self, name, which, full, rect_local):
+        idx, dt, ch = self.p.HALO[name]
+        self.p._rw(self.i, name, which, np.ascontiguousarray(full, dt), rect_local, 1)
+
+
 class OracleRDI:
     """Stateful ReSTIR DI (emissive) renderer of the oracle (zro_rdi.h)."""
     PLANES = {"A": (0, np.uint32, 4), "B": (1, np.float32, 2), "target": (2, np.float32, 4)}

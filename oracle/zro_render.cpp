@@ -211,6 +211,9 @@ static float4 UVDifferentials(int px, int py, float3 origin, float3 dir, bool th
 // K1: G-buffer (GBufferRT_Inline.hlsl:204-287, TracePrimaryHit :72-198, GBufferRT.hlsli:102-282)
 //--------------------------------------------------------------------------------------
 // pick (optional): GBufferRT::PickPixel's pixel -> *pick = hitMeshIdx, UINT32_MAX on a miss (GBufferRT_Inline.hlsl:241-242)
+// (g_gbRect: the pixels a call renders, x0 y0 x1 y1 -- everything by default; zro_gbuffer_render_rect renders a window of a full-size frame for the
+// at-size parity tests, tests/window_parity.py)
+static uint32_t g_gbRect[4] = {0u, 0u, 0xffffffffu, 0xffffffffu};
 static void RenderGBuffer(const Scene& sc, const zr_frame_constants& g, GBView gb, uint32_t pickX = 0xffffu, uint32_t pickY = 0xffffu, uint32_t* pick = nullptr)
 {
     BSDF::g_rho = &sc.rhoLUT;
@@ -221,6 +224,7 @@ static void RenderGBuffer(const Scene& sc, const zr_frame_constants& g, GBView g
     for (uint32_t y = 0; y < g.render_height; y++)
     for (uint32_t x = 0; x < g.render_width; x++)
     {
+        if (x < g_gbRect[0] || y < g_gbRect[1] || x >= g_gbRect[2] || y >= g_gbRect[3]) continue;
         const size_t px = (size_t)y * g.render_width + x;
         float2 lensSample = {0, 0};
         float3 rayDirCS = RT::GeneratePinholeCameraRay_CS((int)x, (int)y, renderDim, g.aspect_ratio, g.tan_half_fov, jitter);
@@ -979,6 +983,15 @@ int zro_scene_latch_heap_offsets(const zro_scene* h, const zr_frame_constants* c
 
 int zro_gbuffer_render(const zro_scene* h, const zr_frame_constants* cb, zr_gbuffer_planes* planes)
 { h->s.LatchHeapOffsets(*cb); RenderGBuffer(h->s, *cb, GBView(planes)); return 0; }
+// ... only the pixels of [x0, x1) x [y0, y1) of the full-size planes (the other pixels keep what the planes held)
+int zro_gbuffer_render_rect(const zro_scene* h, const zr_frame_constants* cb, zr_gbuffer_planes* planes, uint32_t x0, uint32_t y0, uint32_t x1, uint32_t y1)
+{
+    h->s.LatchHeapOffsets(*cb);
+    g_gbRect[0] = x0; g_gbRect[1] = y0; g_gbRect[2] = x1; g_gbRect[3] = y1;
+    RenderGBuffer(h->s, *cb, GBView(planes));
+    g_gbRect[0] = 0; g_gbRect[1] = 0; g_gbRect[2] = 0xffffffffu; g_gbRect[3] = 0xffffffffu;
+    return 0;
+}
 // ... with GBufferRT::PickPixel(x, y) pending
 int zro_gbuffer_render_pick(const zro_scene* h, const zr_frame_constants* cb, zr_gbuffer_planes* planes, uint32_t x, uint32_t y, uint32_t* mesh_idx)
 { h->s.LatchHeapOffsets(*cb); RenderGBuffer(h->s, *cb, GBView(planes), x, y, mesh_idx); return 0; }
@@ -1184,6 +1197,47 @@ int zro_rpt_render(const zro_scene* h, zro_rpt* r, const zr_frame_constants* cb,
     ResetCounters(h); h->s.LatchHeapOffsets(*cb); h->s.texFilter = prm->tex_filter;
     RPT::Render(h->s, *cb, curr, prev, *prm, r->st, final_rgba);
     ReadCounters(h, counters);
+    return 0;
+}
+// One stage of a frame over the pixels of rect = {x0, y0, x1, y1} of a full-size frame (zro_rpt.h RenderStage; at-size parity tests).  Several
+// disjoint windows share one state: every window but the last of a stage-2 sweep passes commit = 0, which takes back the end-of-frame bookkeeping
+// (the set flips, temporalValid) so that the next window runs the same sequence on its own pixels.
+int zro_rpt_render_stage(const zro_scene* h, zro_rpt* r, const zr_frame_constants* cb, const zr_gbuffer_planes* curr, const zr_gbuffer_planes* prev,
+    const zr_params* prm, float* final_rgba, zr_counters* counters, int stage, const uint32_t* rect, int commit)
+{
+    ResetCounters(h); h->s.LatchHeapOffsets(*cb); h->s.texFilter = prm->tex_filter;
+    const int currIdx = r->st.currIdx; const bool valid = r->st.temporalValid;
+    RPT::RenderStage(h->s, *cb, curr, prev, *prm, r->st, final_rgba, stage, rect);
+    const int after = r->st.currIdx;      // (returned: where the sets stand once the stage is committed -- the caller addresses them physically meanwhile)
+    if (!commit) { r->st.currIdx = currIdx; r->st.temporalValid = valid; }
+    ReadCounters(h, counters);
+    return after;
+}
+int zro_rpt_curr_idx(const zro_rpt* r) { return r->st.currIdx; }
+// reads (write = 0) or writes rect {x, y, w, h} (global pixel coordinates) of a plane from / into `buf`, a row-major array of buf_w pixels per row
+// whose first pixel is (bx0, by0).  which / plane: as zro_rpt_read_plane (planes 0..6 only); which = 2 / 3: reservoir set 0 / 1, whatever is current
+int zro_rpt_rw_plane_rect(zro_rpt* r, int which, int plane, void* buf, uint32_t bx0, uint32_t by0, uint32_t buf_w, uint32_t x, uint32_t y, uint32_t w, uint32_t hgt, int write)
+{
+    RPT::ReservoirPlanes& p = r->st.reservoirs[which >= 2 ? which - 2 : (which == 0 ? 1 - r->st.currIdx : r->st.currIdx)];
+    uint8_t* base; size_t bpp;
+    switch (plane)
+    {
+    case 0: base = (uint8_t*)p.A.data(); bpp = 4; break;
+    case 1: base = (uint8_t*)p.B.data(); bpp = 8; break;
+    case 2: base = (uint8_t*)p.C.data(); bpp = 16; break;
+    case 3: base = (uint8_t*)p.D.data(); bpp = 16; break;
+    case 4: base = (uint8_t*)p.E.data(); bpp = 2; break;
+    case 5: base = (uint8_t*)p.F.data(); bpp = 8; break;
+    case 6: base = (uint8_t*)p.G.data(); bpp = 8; break;
+    default: return 1;
+    }
+    const size_t W = r->st.w;
+    for (uint32_t j = 0; j < hgt; j++)
+    {
+        uint8_t* pl = base + ((size_t)(y + j) * W + x) * bpp;
+        uint8_t* bf = (uint8_t*)buf + ((size_t)(y + j - by0) * buf_w + (x - bx0)) * bpp;
+        if (write) std::memcpy(pl, bf, (size_t)w * bpp); else std::memcpy(bf, pl, (size_t)w * bpp);
+    }
     return 0;
 }
 int zro_rpt_self_shift(const zro_scene* h, zro_rpt* r, const zr_frame_constants* cb, const zr_gbuffer_planes* curr, const zr_params* prm, int which, float* out)

@@ -1238,6 +1238,14 @@ struct State
     }
 };
 
+// Active rectangle of the passes below: the per-pixel / per-group loops visit only pixels inside it (default: everything).  It exists for the
+// at-size parity tests (tests/window_parity.py): a full-resolution frame is compared on scattered windows, so the oracle renders a window + apron of
+// a full-size frame -- global pixel coordinates, full-size planes, nothing else changes -- with the apron's reservoirs written in from the frame under
+// test, the way the host executor is driven.  The rectangle is aligned to 32 pixels (or ends at the frame's edge), so the 16 x 4 path-tracing waves,
+// the 8 x 8 groups of Reconnect_StC and the 32 x 32 sort tiles are inside or outside as a whole.
+struct ActiveRect { uint32_t x0 = 0, y0 = 0, x1 = 0xffffffffu, y1 = 0xffffffffu; bool Has(uint32_t x, uint32_t y) const { return x >= x0 && y >= y0 && x < x1 && y < y1; } };
+static ActiveRect g_active;
+
 // Util.hlsli:141-159
 static void WriteOutputColor(const zr_frame_constants& g, float* finalRGBA, size_t px, float3 li)
 {
@@ -1268,6 +1276,7 @@ static void PathTracePass(const Scene& sc, const zr_frame_constants& g, const GB
     for (uint32_t by = 0; by < (H + 3) / 4; by++)
     for (uint32_t bx = 0; bx < (W + 15) / 16; bx++)
     {
+        if (!g_active.Has(bx * 16, by * 4)) continue;
         Globals gl[64];
         for (uint32_t l = 0; l < 64; l++)
         {
@@ -1442,6 +1451,7 @@ static void SortPass(SortVariant variant, const zr_frame_constants& g, const GBu
     std::vector<Px> bucket[5], all;
     for (uint32_t gy = 0; gy < dimY; gy++) for (uint32_t gx = 0; gx < dimX; gx++)
     {
+        if (!g_active.Has(gx * 32, gy * 32)) continue;
         for (auto& b : bucket) b.clear();
         all.clear();
         const bool againstEdge = (gx == dimX - 1) || (gy == dimY - 1);
@@ -1534,6 +1544,7 @@ static void TemporalPass(const Scene& sc, const zr_frame_constants& g, const GBu
     for (int variant = 0; variant < 2; variant++)
     for (uint32_t y = 0; y < H; y++) for (uint32_t x = 0; x < W; x++)
     {
+        if (!g_active.Has(x, y)) continue;
         const size_t px = (size_t)y * W + x;
         GFlags flags = DecodeFlags(gb.mr[px]);
         if (flags.invalid || flags.emissive) continue;
@@ -1576,6 +1587,7 @@ static void TemporalPass(const Scene& sc, const zr_frame_constants& g, const GBu
     // ---- K14 Reconnect_CtT (ReSTIR_PT_Reconnect_CtT.hlsl:130-292)
     for (uint32_t y = 0; y < H; y++) for (uint32_t x = 0; x < W; x++)
     {
+        if (!g_active.Has(x, y)) continue;
         const size_t px = (size_t)y * W + x;
         GFlags flags = DecodeFlags(gb.mr[px]);
         if (flags.invalid || flags.emissive) continue;
@@ -1615,6 +1627,7 @@ static void TemporalPass(const Scene& sc, const zr_frame_constants& g, const GBu
     // ---- K14 Reconnect_TtC (ReSTIR_PT_Reconnect_TtC.hlsl:124-390)
     for (uint32_t y = 0; y < H; y++) for (uint32_t x = 0; x < W; x++)
     {
+        if (!g_active.Has(x, y)) continue;
         const size_t px = (size_t)y * W + x;
         GFlags flags = DecodeFlags(gb.mr[px]);
         if (flags.invalid || flags.emissive) continue;
@@ -1698,6 +1711,7 @@ static void SpatialPass(const Scene& sc, const zr_frame_constants& g, const GBuf
     // ---- K15 SpatialSearch (ReSTIR_PT_SpatialSearch.hlsl:21-146)
     for (uint32_t y = 0; y < H; y++) for (uint32_t x = 0; x < W; x++)
     {
+        if (!g_active.Has(x, y)) continue;
         const size_t px = (size_t)y * W + x;
         GFlags flags = DecodeFlags(gb.mr[px]);
         if (flags.invalid || flags.emissive) continue;
@@ -1765,6 +1779,7 @@ static void SpatialPass(const Scene& sc, const zr_frame_constants& g, const GBuf
     for (int variant = 0; variant < 2; variant++)
     for (uint32_t y = 0; y < H; y++) for (uint32_t x = 0; x < W; x++)
     {
+        if (!g_active.Has(x, y)) continue;
         const size_t px = (size_t)y * W + x;
         GFlags flags = DecodeFlags(gb.mr[px]);
         if (flags.invalid || flags.emissive) continue;
@@ -1805,6 +1820,7 @@ static void SpatialPass(const Scene& sc, const zr_frame_constants& g, const GBuf
     // ---- K16 Reconnect_CtS (ReSTIR_PT_Reconnect_CtS.hlsl:149-230)
     for (uint32_t y = 0; y < H; y++) for (uint32_t x = 0; x < W; x++)
     {
+        if (!g_active.Has(x, y)) continue;
         const size_t px = (size_t)y * W + x;
         int sx, sy;
         if (!neighborOf(x, y, sx, sy)) continue;
@@ -1848,6 +1864,7 @@ static void SpatialPass(const Scene& sc, const zr_frame_constants& g, const GBuf
     std::vector<Lane> L(64);
     for (uint32_t gy = 0; gy < (H + 7) / 8; gy++) for (uint32_t gx = 0; gx < (W + 7) / 8; gx++)
     {
+        if (!g_active.Has(gx * 8, gy * 8)) continue;
         // WaveActiveSum #1 / #2: lanes that passed the invalid/emissive early-out
         float v1[64], v2[64], v3[64], v4[64];
         for (uint32_t l = 0; l < 64; l++) v1[l] = v2[l] = v3[l] = v4[l] = 0.0f;
@@ -1981,6 +1998,30 @@ static void Render(const Scene& sc, const zr_frame_constants& g, const zr_gbuffe
     st.currIdx = 1 - st.currIdx;
 }
 
+// The same frame in two steps over `rect` (x0, y0, x1, y1) of a full-size frame: stage 1 = K11 + the temporal passes, stage 2 = the spatial rounds +
+// the end-of-frame bookkeeping.  Between the two the caller may overwrite reservoirs outside the rectangle's owned part (zro_rpt_write_plane_rect).
+static void RenderStage(const Scene& sc, const zr_frame_constants& g, const zr_gbuffer_planes* gbCurr, const zr_gbuffer_planes* gbPrev, const zr_params& prm,
+    State& st, float* finalRGBA, int stage, const uint32_t rect[4])
+{
+    GBufRead gb(gbCurr);
+    const bool doTemporal = (prm.flags & ZR_IND_TEMPORAL_RESAMPLE) && st.temporalValid && gbPrev != nullptr;
+    const bool doSpatial = (prm.flags & ZR_IND_SPATIAL_RESAMPLE) && doTemporal && prm.num_spatial_passes > 0;
+    const bool writeReservoirs = doTemporal || !st.temporalValid;
+    g_active.x0 = rect[0]; g_active.y0 = rect[1]; g_active.x1 = rect[2]; g_active.y1 = rect[3];
+    if (stage == 1)
+    {
+        PathTracePass(sc, g, gb, prm, st, doTemporal, writeReservoirs, finalRGBA);
+        if (doTemporal) { GBufRead gp(gbPrev); TemporalPass(sc, g, gb, gp, prm, st, doSpatial, finalRGBA); }
+    }
+    else
+    {
+        if (doSpatial) for (uint32_t pass = 0; pass < prm.num_spatial_passes && pass < 2u; pass++) SpatialPass(sc, g, gb, prm, st, finalRGBA);
+        st.temporalValid = true;
+        st.currIdx = 1 - st.currIdx;
+    }
+    g_active = ActiveRect();
+}
+
 // debug / property test: shift every pixel's current reservoir sample onto its own pixel.  For a correct shift the
 // offset path equals the base path: target ratio ~= 1 (L is stored in fp16) and Jacobian == 1.
 // out: 6 floats per pixel (lum(shift.target), w_sum / W, shift.partialJacobian, rc.partialJacobian, k, case)
@@ -1995,6 +2036,7 @@ static void SelfShift(const Scene& sc, const zr_frame_constants& g, const zr_gbu
     Globals gl; gl.sc = &sc; gl.frame = &g; gl.numEmissives = g.num_emissive_triangles; gl.alpha_min = prm.alpha_min;
     for (uint32_t y = 0; y < H; y++) for (uint32_t x = 0; x < W; x++)
     {
+        if (!g_active.Has(x, y)) continue;
         const size_t px = (size_t)y * W + x;
         float* o = out + 6 * px; for (int i = 0; i < 6; i++) o[i] = 0;
         GFlags flags = DecodeFlags(gb.mr[px]);

@@ -1124,7 +1124,8 @@ def _atrium_windows_parity(api, atrium, W, H, windows, frames=3):
     prm = wire.default_params()
     prm.presampling, prm.num_sample_sets, prm.sample_set_size = 1, 128, 512
     cams = [(0.0, 0, -3.5)] * (frames - 1) + [(0.04, 0, -3.5)]      # the camera starts moving at the last frame: its temporal stage reprojects into the apron
-    rays = windows_parity(_GpuFullFrame(api, sc, W, H, prm), sc, o.alias, W, H, windows, prm, cams)
+    # oracle=o: the windows are rendered by the oracle too (zro.OracleRPTWindows) -- GPU == host-executed stage functions == oracle at the quoted size
+    rays = windows_parity(_GpuFullFrame(api, sc, W, H, prm), sc, o.alias, W, H, windows, prm, cams, oracle=o)
     assert rays > 0
 
 

@@ -334,7 +334,9 @@ def test_window_parity_machinery_against_a_full_frame_host_executor(cornell_emis
 
     full = Full()
     cams = [(0.0, 1.2, -4.043), (0.0, 1.2, -4.043), (0.05, 1.2, -4.02), (0.1, 1.2, -4.0)]
-    rays = windows_parity(full, cornell_emissive, oracle_emissive.alias, W, H, [(0, 0, 64, 64), (64, 32, 64, 32), (96, 96, 64, 24)], prm, cams)
+    # oracle=...: the oracle renders the same windows (oracle/zro_rpt.h restricted to a rectangle of the full-size frame, zro.OracleRPTWindows) and
+    # is compared with the full frame as well -- the machinery the GPU tests of the 1080p / 2160p atrium use against the GPU's frame
+    rays = windows_parity(full, cornell_emissive, oracle_emissive.alias, W, H, [(0, 0, 64, 64), (64, 32, 64, 32), (96, 96, 64, 24)], prm, cams, oracle=oracle_emissive)
     assert rays > 0
     # ... and that full frame is the oracle's
     o = zro.OracleRPT(oracle_emissive, W, H)
