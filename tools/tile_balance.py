@@ -16,6 +16,9 @@ def main():
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--layout", choices=["equal", "cost"], default="equal",
                     help="cost: the kd-split of tiling.balanced_layout on the per-cell ray counts of 12 full-frame probe frames")
+    ap.add_argument("--halves", action="store_true",
+                    help="VERDICT r4 item 3(c): every device's tile of the equal-area split cut in two (32-px aligned, the longer side), the halves rendered "
+                         "CONCURRENTLY on two streams -- one round of waves lasts as long as its slowest wave, a second independent half fills the slots its tail leaves idle")
     a = ap.parse_args()
     W, H = a.width, a.height
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -43,6 +46,43 @@ def main():
         torch.cuda.synchronize()
         full_ms = (time.perf_counter() - t0) / 8 * 1e3
         del probe
+    if a.halves:
+        halves = []
+        for r in range(a.world):
+            x0, y0, tw, th = tiling.tile_rect(W, H, a.world, r, layout)
+            if th >= tw:
+                c = max(64, min(th - 64, (th // 2 + 31) // 32 * 32))
+                halves += [(x0, y0, tw, c), (x0, y0 + c, tw, th - c)]
+            else:
+                c = max(64, min(tw - 64, (tw // 2 + 31) // 32 * 32))
+                halves += [(x0, y0, c, th), (x0 + c, y0, tw - c, th)]
+        tiles = [tiling.TiledRestirPT(sc, W, H, 2 * a.world, r, params=prm, layout=halves) for r in range(2 * a.world)]
+        streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+        t = np.zeros((a.world, 2))
+        n = 0
+        for f in range(1, a.frames + 1):
+            cb = scene_io.make_frame_constants(W, H, frame_num=f, num_emissives=len(sc.emissives), **cam)
+            for d in range(a.world):
+                torch.cuda.synchronize(); t0 = time.perf_counter()
+                for k in range(2):
+                    tiles[2 * d + k].stage_temporal(cb, streams[k].cuda_stream)
+                torch.cuda.synchronize()
+                if f > 3:
+                    t[d, 0] += time.perf_counter() - t0
+            tiling.exchange_in_process(tiles, api.HALO_POST_TEMPORAL)
+            for d in range(a.world):
+                torch.cuda.synchronize(); t0 = time.perf_counter()
+                for k in range(2):
+                    tiles[2 * d + k].stage_spatial(cb, streams[k].cuda_stream)
+                torch.cuda.synchronize()
+                if f > 3:
+                    t[d, 1] += time.perf_counter() - t0
+            tiling.exchange_in_process(tiles, api.HALO_FINAL)
+            n += f > 3
+        ms = t.sum(axis=1) / n * 1e3
+        print(json.dumps({"scene": a.scene, "world": a.world, "size": [W, H], "layout": "halves on two streams", "tile_ms": [round(float(x), 3) for x in ms], "rects": halves,
+                          "max_ms": round(float(ms.max()), 3), "mean_ms": round(float(ms.mean()), 3), "sum_ms": round(float(ms.sum()), 3)}))
+        return
     ranks = [tiling.TiledRestirPT(sc, W, H, a.world, r, params=prm, layout=layout) for r in range(a.world)]
     t = np.zeros((a.world, 2))
     n = 0

@@ -15,6 +15,11 @@ namespace rdi {
 
 using rpt::Pix; using rpt::GFlags; using rpt::DecodeFlags; using rpt::RoughnessOf; using rpt::DecodeMotion; using rpt::Camera;
 using rpt::CurrCamera; using rpt::PrevCamera; using rpt::PixelSurface; using rpt::LoadPixelSurface; using rpt::LoadPixelSurfaceEx;
+// wo-only term groups (zr_dev_bsdf.h WO_*) the direct-lighting kernels prepare on the pixel's surface: the rho-LUT read (group 1), as in the shifts
+#ifndef ZR_PREP_DI
+#define ZR_PREP_DI 1
+#endif
+static constexpr uint32_t kPrepDi = ZR_PREP_DI;
 using rpt::Globals; using rpt::VisibilitySegmentApprox; using rpt::IsSpecular;
 
 static constexpr int kNumLightCandidates = 3;
@@ -387,6 +392,7 @@ ZR_HD void TemporalPixel(const DiFrame& F, const zr_frame_constants& g, uint32_t
     }
     const Camera cam = CurrCamera(g);
     PixelSurface ps = LoadPixelSurface(F.gb, cam, x, y, g.frame_num, px);
+    if (kPrepDi) PrepareWo(F.sc.rho, ps.surface, kPrepDi);      // the pixel's surface is evaluated once per light candidate and per temporal target
     const uint32_t dispX = (g.render_width + 7) / 8, dispY = (g.render_height + 7) / 8;
     uint32_t ugx, ugy; UnswizzleGid(x / 8, y / 8, dispX, dispY, ugx, ugy);
     Rng rng_group = Rng::Init(ugx, ugy, g.frame_num);
@@ -503,6 +509,7 @@ ZR_HD void SpatialPhase0(const DiFrame& F, const zr_frame_constants& g, uint32_t
     a.active = true;
     const Camera cam = CurrCamera(g);
     a.ps = LoadPixelSurface(F.gb, cam, x, y, g.frame_num, a.px);
+    if (kPrepDi) PrepareWo(F.sc.rho, a.ps.surface, kPrepDi);      // ... once per spatial neighbour
     Reservoir r = LoadReservoir(F.cur, a.px);
     if (r.lightIdx != 0xffffffffu)
     {

@@ -324,6 +324,7 @@ ZR_HD void TemporalPixel(const SkyFrame& F, const zr_frame_constants& g, uint32_
     }
     const Camera cam = CurrCamera(g);
     PixelSurface ps = LoadPixelSurface(F.gb, cam, x, y, g.frame_num, px);
+    if (rdi::kPrepDi) PrepareWo(F.sc.rho, ps.surface, rdi::kPrepDi);
     uint32_t hx = y, hy = x, hz = x; zr_pcg3d(&hx, &hy, &hz);                 // RNG::PCG3d(DTid.yxx).yz
     Rng rng = Rng::Init(hy, hz, g.frame_num);
     Ctx c; c.sc = &F.sc; c.scPrev = &F.scPrev; c.g = &g; c.stack = stack; c.cnt = cnt;
@@ -453,6 +454,7 @@ ZR_HD void SpatialPixel(const SkyFrame& F, const zr_frame_constants& g, uint32_t
     const uint32_t W = g.render_width, H = g.render_height;
     const Camera cam = CurrCamera(g);
     PixelSurface ps = LoadPixelSurface(F.gb, cam, x, y, g.frame_num, px);
+    if (rdi::kPrepDi) PrepareWo(F.sc.rho, ps.surface, rdi::kPrepDi);
     uint32_t hx = y, hy = x, hz = x; zr_pcg3d(&hx, &hy, &hz);
     Rng rng = Rng::Init(hy, hz, g.frame_num);
     Ctx c; c.sc = &F.sc; c.scPrev = &F.scPrev; c.g = &g; c.stack = stack; c.cnt = cnt;

@@ -332,24 +332,25 @@ class TiledRestirPT:
             req.wait()
         self.unpack(which)
 
-    def stage_temporal(self, cb):
+    def stage_temporal(self, cb, stream=None):
+        """stream: a hipStream_t (integer handle) -- several tile objects of one device may run on streams of their own (tools/tile_balance.py --halves)"""
         api, r = self.api, self.r
-        r.render_sky(cb)
-        r.p_gbuffer.render(cb, r.scene, r.gbuffer)
+        r.render_sky(cb, stream)
+        r.p_gbuffer.render(cb, r.scene, r.gbuffer, stream)
         if len(r.scene_host.emissives) and (not r._alias_ready or r._presampling):
-            r.p_prelight.render(cb, r.scene, None)
+            r.p_prelight.render(cb, r.scene, None, stream)
             r._alias_ready = True
         if self.kind in ("di", "sky_di"):
-            self.hp.render_stage(cb, r.scene, r.gbuffer, api.STAGE_TEMPORAL)
+            self.hp.render_stage(cb, r.scene, r.gbuffer, api.STAGE_TEMPORAL, stream)
             return
         if r.p_direct is not None:
-            r.p_direct.render(cb, r.scene, r.gbuffer)
+            r.p_direct.render(cb, r.scene, r.gbuffer, stream)
         if r.p_sky_direct is not None:
-            r.p_sky_direct.render(cb, r.scene, r.gbuffer)
-        r.p_indirect.render_stage(cb, r.scene, r.gbuffer, api.STAGE_TEMPORAL)
+            r.p_sky_direct.render(cb, r.scene, r.gbuffer, stream)
+        r.p_indirect.render_stage(cb, r.scene, r.gbuffer, api.STAGE_TEMPORAL, stream)
 
-    def stage_spatial(self, cb):
-        self.hp.render_stage(cb, self.r.scene, self.r.gbuffer, self.api.STAGE_SPATIAL)
+    def stage_spatial(self, cb, stream=None):
+        self.hp.render_stage(cb, self.r.scene, self.r.gbuffer, self.api.STAGE_SPATIAL, stream)
 
     def stage_spatial2(self, cb):
         self.hp.render_stage(cb, self.r.scene, self.r.gbuffer, self.api.STAGE_SPATIAL2)
