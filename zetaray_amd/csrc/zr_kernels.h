@@ -195,6 +195,7 @@ template<int B>
 __device__ __forceinline__ void TileWaveLaneB(uint32_t* tile, uint32_t* wave, uint32_t* lane)
 {
     if (B == 256) { *tile = blockIdx.x; *wave = threadIdx.x >> 6; *lane = threadIdx.x & 63u; }
+    else if (B == 128) { *tile = blockIdx.x >> 1; *wave = ((blockIdx.x & 1u) << 1) | (threadIdx.x >> 6); *lane = threadIdx.x & 63u; }      // two waves: half a tile
     else { *tile = blockIdx.x >> 2; *wave = blockIdx.x & 3u; *lane = threadIdx.x; }
 }
 __device__ __forceinline__ void RptTileWaveLane(uint32_t* tile, uint32_t* wave, uint32_t* lane) { TileWaveLaneB<kRptBlock>(tile, wave, lane); }
