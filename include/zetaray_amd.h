@@ -444,6 +444,10 @@ int zr_pass_debug_trip_stats(zr_pass* pass, uint64_t out[3]);
 /* test hook: the node count from which the ReSTIR PT pass launches K11's large-scene instantiation (4 waves per SIMD + the top of the tree in LDS;
  * default 16384 nodes = 1 MB) -- lets the parity tests run that instantiation on their small scenes.  0 restores the default.  Process-wide. */
 int zr_debug_set_large_scene_nodes(uint32_t num_nodes);
+/* test hook: the deepest tree the DEVICE builder (ZR_BVH_BUILD=device, ZR_SCENE_UPDATE=rebuild) may produce, in levels.  The default, 21, is what a
+ * lane's traversal stack holds (3 entries per level of 64); a node whose key range could not fit below the cap if cut unevenly is cut into four
+ * equal parts instead (zr_tu_bvh.hip).  2 .. 21, anything else restores the default.  Process-wide; no reference counterpart. */
+int zr_debug_set_bvh_depth_cap(uint32_t levels);
 /* the same counters split by the kernel that issued the queries (not reset; roofline bookkeeping of bench.py) */
 int zr_pass_read_kernel_counters(zr_pass* pass, void* hip_stream, uint32_t max_entries, const char** names,
                                  uint64_t* n_closest, uint64_t* n_shadow, uint32_t* count);

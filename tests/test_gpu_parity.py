@@ -1385,6 +1385,41 @@ def test_device_built_bvh_traces_identically(api, monkeypatch):
         assert np.array_equal(r.final().view(np.uint32), want.view(np.uint32)), f"frame {f} (device rebuild)"
 
 
+def test_device_bvh_build_respects_the_depth_cap(api, monkeypatch):
+    """The device builder never produces a tree deeper than the traversal stack can take (21 levels): a node whose key range could not fit below
+    the cap if it were cut at a Morton bit is cut into four equal parts (zr_tu_bvh.hip; before round 5 a deeper tree was an error).  A cascade deep
+    enough to reach level 21 needs > 60 key bits of structure, so the test lowers the cap instead (zr_debug_set_bvh_depth_cap): the 3000-triangle
+    scene, whose LBVH is naturally ~10 levels deep, built with a cap of 7 -- the balanced cuts take over from level 1 or 2 on -- must come out at
+    <= 7 levels, with every triangle in it (20 000 closest-hit rays == the oracle's BVH2) and a bit-exact ReSTIR PT sequence."""
+    from oracle import zro
+    import torch
+    monkeypatch.setenv("ZR_BVH_BUILD", "device")
+    sc = scene_io.make_synthetic_scene(num_tris=3000, num_emissive=150, seed=11)
+    osc = zro.OracleScene(sc, force_bvh=True)
+    natural = api.Scene(sc)
+    _, _, depth0 = natural.bvh_info()
+    natural.close()
+    assert api.lib().zr_debug_set_bvh_depth_cap(7) == 0
+    try:
+        handle = api.Scene(sc)
+        nodes, tris, depth = handle.bvh_info()
+        assert tris == sc.num_tris and depth <= 7 < depth0, (nodes, tris, depth, depth0)
+        rng = np.random.default_rng(6)
+        n = 20000
+        o = rng.uniform(-2.5, 2.5, (n, 3)); d = rng.normal(size=(n, 3)); d /= np.linalg.norm(d, axis=1, keepdims=True)
+        rays = np.concatenate([o, np.full((n, 1), 1e-4), d, np.full((n, 1), 3.0e38)], 1).astype(np.float32)
+        d_rays = torch.from_numpy(rays).cuda()
+        d_hits = torch.zeros((n, 4), dtype=torch.int32, device="cuda")
+        api._check(api.lib().zr_trace_closest(handle.h, None, d_rays.data_ptr(), n, 3, d_hits.data_ptr()))
+        torch.cuda.synchronize()
+        assert np.array_equal(d_hits.cpu().numpy().view(np.uint32), osc.trace_closest(rays))
+        handle.close()
+        prm = wire.default_params()
+        _rpt_compare(api, sc, osc, 96, 64, prm, 2, cam=dict(cam_pos=(0, 0, -3.5)))
+    finally:
+        api.lib().zr_debug_set_bvh_depth_cap(0)
+
+
 def test_moving_light_on_gpu(api):
     """zr_scene_update_emissives: the Cornell box's light quad translates and turns over frames 2-5 (its EmissiveTriangle records re-derived from the
     object-space ones like SceneCore::UpdateEmissivePositions does -- decode, transform, re-encode, pinned to the reference's code in

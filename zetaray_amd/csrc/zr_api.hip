@@ -3077,6 +3077,7 @@ int zr_pass_enable_cost_map(zr_pass* p, int enable)
     p->costRays = enable == ZR_COST_MAP_RAYS;
     return ZR_OK;
 }
+int zr_debug_set_bvh_depth_cap(uint32_t levels) { DeviceBvhSetDepthCap(levels); return ZR_OK; }
 int zr_debug_set_large_scene_nodes(uint32_t n) { g_largeSceneNodes.store(n ? n : kLargeSceneNodes, std::memory_order_relaxed); return ZR_OK; }
 int zr_pass_debug_trip_stats(zr_pass* p, uint64_t out[3])
 {

@@ -30,5 +30,7 @@ struct DeviceBvhScratch
 };
 // enqueues the build on `st` and waits for it (the level structure comes back to the host); 0 = ok, else `err` says why
 int DeviceBuildBvh4(hipStream_t st, DeviceBvhScratch& scratch, const DeviceBvhInputs& in, DeviceBvhOutputs& out, std::string& err);
+// test hook: the deepest tree the builder may produce, in levels (2 .. 21; anything else restores the default 21 = what the traversal stack holds)
+void DeviceBvhSetDepthCap(uint32_t levels);
 
 } // namespace zr

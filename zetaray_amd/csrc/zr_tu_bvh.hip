@@ -113,7 +113,16 @@ __device__ __forceinline__ uint32_t FindSplit(const unsigned long long* keys, ui
 // one tree level: nodes [ctl[level], ctl[level + 1]) each cut their key range into 2 - 4 children; inner children get the next free node ids
 // (so the next level is contiguous too).  ctl[0 .. kMaxLevels + 1] = level starts, ctl[kCtlCount] = node counter.
 constexpr uint32_t kMaxLevels = 62, kCtlCount = 64, kMaxLeafTris = 2;
-__global__ void __launch_bounds__(64) k_bvh_level(const unsigned long long* keys, uint2* ranges, Bvh4Node* nodes, uint32_t* ctl, uint32_t level, uint32_t cap)
+// Depth cap.  An ordered traversal pushes at most three entries per level, and a lane's stack holds kTravStack = 64: a tree may have 21 levels
+// (node levels 0 .. kLastLevel).  Morton cuts alone do not promise that -- a geometric cascade of clusters spends one 4-wide level per three key
+// bits (21 levels for 63 bits) before the clusters themselves are divided -- and a deeper tree used to be rejected (missing 4).  A
+// node whose range could no longer fit below the cap if it were cut unevenly is cut into four equal parts of its (Morton-ordered) range instead:
+// need(c) = levels a balanced subtree over c triangles occupies; a Morton child is never larger than its parent, so `level + need(count) >
+// kLastLevel` is the last moment to switch, and from there every level is balanced (need drops by one per level).  Any n <= 2 * 4^20 fits.
+constexpr uint32_t kLastLevel = 20;
+static uint32_t g_lastLevel = kLastLevel;      // (zr_debug_set_bvh_depth_cap: the parity tests lower it to run the balanced cuts on an ordinary scene)
+__device__ __forceinline__ uint32_t BalancedLevels(uint32_t c) { uint32_t n = 0; while (c > kMaxLeafTris) { c = (c + 3u) >> 2; n++; } return n; }
+__global__ void __launch_bounds__(64) k_bvh_level(const unsigned long long* keys, uint2* ranges, Bvh4Node* nodes, uint32_t* ctl, uint32_t level, uint32_t cap, uint32_t lastLevel)
 {
     const uint32_t start = ctl[level], end = ctl[level + 1];
     for (uint32_t node = start + blockIdx.x * blockDim.x + threadIdx.x; ; node += gridDim.x * blockDim.x)
@@ -124,7 +133,17 @@ __global__ void __launch_bounds__(64) k_bvh_level(const unsigned long long* keys
         {
             const uint2 rg = ranges[node];
             sa[0] = rg.x; sb[0] = rg.y; k = 1;
-            while (k < 4)
+            const uint32_t cnt = rg.y - rg.x;
+            if (level + BalancedLevels(cnt) > lastLevel)
+            {   // equal parts (the depth cap above); parts are never empty: cnt > kMaxLeafTris >= 2, and 4 parts of >= 3 triangles ...
+                k = 0;
+                for (uint32_t i = 0; i < 4u; i++)
+                {
+                    const uint32_t a = rg.x + (uint32_t)(((unsigned long long)cnt * i) >> 2), b = rg.x + (uint32_t)(((unsigned long long)cnt * (i + 1u)) >> 2);
+                    if (b > a) { sa[k] = a; sb[k] = b; k++; }      // ... (3 triangles: one part stays empty and is skipped)
+                }
+            }
+            else while (k < 4)
             {
                 int pick = -1; uint32_t best = kMaxLeafTris;
                 for (int i = 0; i < k; i++) { const uint32_t c = sb[i] - sa[i]; if (c > best) { best = c; pick = i; } }
@@ -175,6 +194,7 @@ DeviceBvhScratch::~DeviceBvhScratch() { delete impl; }
 
 #define BVH_TRY(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { err = hipGetErrorString(e_); return -1; } } while (0)
 
+void DeviceBvhSetDepthCap(uint32_t levels) { g_lastLevel = (levels >= 2u && levels <= kLastLevel + 1u) ? levels - 1u : kLastLevel; }
 int DeviceBuildBvh4(hipStream_t st, DeviceBvhScratch& S, const DeviceBvhInputs& in, DeviceBvhOutputs& out, std::string& err)
 {
     const uint32_t n = in.numTris;
@@ -210,7 +230,7 @@ int DeviceBuildBvh4(hipStream_t st, DeviceBvhScratch& S, const DeviceBvhInputs& 
     for (uint32_t l = 0; l < kMaxLevels; l++)
     {
         // a level of a tree over n keys has at most n / 3 + 1 inner nodes; 256 blocks of one wave grid-stride over whatever there is
-        hipLaunchKernelGGL(k_bvh_level, dim3(512), dim3(64), 0, st, (const unsigned long long*)I.keys[1], (uint2*)I.ranges, out.nodes, ctl, l, out.nodeCap);
+        hipLaunchKernelGGL(k_bvh_level, dim3(512), dim3(64), 0, st, (const unsigned long long*)I.keys[1], (uint2*)I.ranges, out.nodes, ctl, l, out.nodeCap, g_lastLevel);
         hipLaunchKernelGGL(k_bvh_close, dim3(1), dim3(1), 0, st, ctl, l);
         if (l >= 7 && (l & 3u) == 3u)
         {   // peek every fourth level from level 7 on: stop launching once the tree has ended
