@@ -5,7 +5,9 @@
 //   zr_api.hip       host side (C-ABI) + the K1 / K9 / K10 / DI / sky / pre-lighting kernels; the ReSTIR PT kernels are only
 //                    *declared* there (extern template below) and launched through their host stubs
 //   zr_tu_rpt_a.hip  explicit instantiations of K11 (k_rpt_pathtrace, k_rpt_pathtrace_tex) and K14 (k_rpt_temporal)
-//   zr_tu_rpt_b.hip  explicit instantiations of K13 (k_rpt_replay) and K16 (k_rpt_stc)
+//   zr_tu_rpt_b.hip  explicit instantiations of K13 (k_rpt_replay)
+//   zr_tu_rpt_d.hip  explicit instantiations of K16 (k_rpt_stc)
+//   zr_tu_di.hip     K5 - K8 and K10 (zr_kernels_di.h)
 #pragma once
 #include <hip/hip_runtime.h>
 #include "zr_stages.h"
@@ -653,6 +655,7 @@ __global__ void __launch_bounds__(kStcBlock) ZR_WAVES_STC k_rpt_stc(rpt::RptFram
     X __global__ void k_rpt_replay<PASS, true, true> ZR_RPT_ARGS_LIST; X __global__ void k_rpt_replay<PASS, true, false> ZR_RPT_ARGS_LIST; \
     X __global__ void k_rpt_replay<PASS, false, true> ZR_RPT_ARGS_LIST; X __global__ void k_rpt_replay<PASS, false, false> ZR_RPT_ARGS_LIST;
 #define ZR_RPT_GROUP_B(X) \
-    ZR_RPT_REPLAY4(X, RPT_REPLAY_CTT) ZR_RPT_REPLAY4(X, RPT_REPLAY_CTS) \
+    ZR_RPT_REPLAY4(X, RPT_REPLAY_CTT) ZR_RPT_REPLAY4(X, RPT_REPLAY_CTS)
+#define ZR_RPT_GROUP_D(X) \
     X __global__ void k_rpt_stc<true, true> ZR_RPT_ARGS_TILE; X __global__ void k_rpt_stc<true, false> ZR_RPT_ARGS_TILE; \
     X __global__ void k_rpt_stc<false, true> ZR_RPT_ARGS_TILE; X __global__ void k_rpt_stc<false, false> ZR_RPT_ARGS_TILE;
