@@ -381,3 +381,20 @@ def test_public_headers_are_plain_c(header, tmp_path):
                 ["g++", "-std=c++17", "-Wall", "-Wextra", "-Werror", "-Wno-unused-function", "-fsyntax-only", "-I", inc, str(src_cpp)]):
         res = subprocess.run(cmd, capture_output=True, text=True, timeout=120)
         assert res.returncode == 0, " ".join(cmd) + "\n" + res.stderr[-3000:]
+
+
+def test_clean_checkout_has_every_build_prerequisite(tmp_path):
+    """the generated sample-set tables (zr_*_sample_set.inc) are git-ignored prerequisites; their generator rules once went missing and stale
+    files in the builder's tree hid it.  A tree made of nothing but the tracked files must be able to plan every build (`make -n`): the product library,
+    the tolerance-mode and experiments builds, the host executor and the oracle."""
+    import shutil
+    import subprocess
+    if not os.path.isdir(os.path.join(ROOT, ".git")) or shutil.which("git") is None:
+        pytest.skip("not a git checkout (the GPU box gets a snapshot without .git)")
+    co = tmp_path / "co"
+    co.mkdir()
+    ar = subprocess.run(["git", "-C", ROOT, "archive", "HEAD"], capture_output=True, check=True)
+    subprocess.run(["tar", "-x", "-C", str(co)], input=ar.stdout, check=True)
+    for sub, target in (("zetaray_amd/csrc", []), ("zetaray_amd/csrc", ["fast"]), ("zetaray_amd/csrc", ["experiments"]), ("tests/hostexec", []), ("oracle", [])):
+        r = subprocess.run(["make", "-n", "-C", str(co / sub)] + target, capture_output=True, text=True)
+        assert r.returncode == 0, f"{sub} {target}: {r.stderr[-800:]}"
