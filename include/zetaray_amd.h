@@ -448,6 +448,12 @@ int zr_debug_set_large_scene_nodes(uint32_t num_nodes);
  * lane's traversal stack holds (3 entries per level of 64); a node whose key range could not fit below the cap if cut unevenly is cut into four
  * equal parts instead (zr_tu_bvh.hip).  2 .. 21, anything else restores the default.  Process-wide; no reference counterpart. */
 int zr_debug_set_bvh_depth_cap(uint32_t levels);
+/* test hook: 0 = scenes of the plain material class (every material an opaque, uncoated, non-metallic dielectric; no texture heap) render with the
+ * general kernels like every other scene; 1 (default) = they render with the PLAIN permutations of the ReSTIR PT kernels, which have no code for the
+ * other lobes.  Results are identical either way (tests/test_gpu_parity.py::test_material_class_kernels_change_nothing).  Process-wide. */
+int zr_debug_set_material_class_kernels(int enable);
+/* the material class zr_scene_create / zr_scene_update_materials currently derive from the scene's material table: 1 = plain, 0 = general. */
+int zr_scene_material_class(const zr_scene* scene, uint32_t* out_class);
 /* the same counters split by the kernel that issued the queries (not reset; roofline bookkeeping of bench.py) */
 int zr_pass_read_kernel_counters(zr_pass* pass, void* hip_stream, uint32_t max_entries, const char** names,
                                  uint64_t* n_closest, uint64_t* n_shadow, uint32_t* count);

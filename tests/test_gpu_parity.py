@@ -916,6 +916,42 @@ def test_restir_pt_large_scene_kernel_build_on_gpu(api):
         api.lib().zr_debug_set_large_scene_nodes(0)
 
 
+def test_material_class_kernels_change_nothing(api, cornell_emissive, oracle_emissive, cornell_sky):
+    """K11 / K14 / K16 (and K9, K5 - K8, K10) have a second permutation for scenes of the plain material class (no metal, transmission, thin wall, coat or texture in
+    the whole material table: the Cornell boxes), compiled without the code of those lobes.  The other ReSTIR PT tests of this file run it on
+    the Cornell box by default; here the same box renders with the general kernels (zr_debug_set_material_class_kernels(0)), with the PLAIN
+    large-scene instantiation of K11, and with sun + sky lighting through the general kernels: all bit-exact against the oracle, hence
+    identical to each other.  A scene with one metallic material is of the general class."""
+    from oracle import zro
+    L = api.lib()
+    assert api.Scene(cornell_emissive).material_class() == 1 and api.Scene(cornell_sky).material_class() == 1
+    assert api.Scene(scene_io.make_synthetic_scene(num_tris=300, num_emissive=100, seed=3)).material_class() == 0
+    try:
+        for enable, large in ((0, 0), (1, 1), (0, 1)):
+            assert L.zr_debug_set_material_class_kernels(enable) == 0 and L.zr_debug_set_large_scene_nodes(1 if large else 0) == 0
+            _rpt_compare(api, cornell_emissive, oracle_emissive, 200, 120, wire.default_params(), 4)
+        assert L.zr_debug_set_material_class_kernels(0) == 0 and L.zr_debug_set_large_scene_nodes(0) == 0
+        w, h = 96, 64
+        osc = zro.OracleScene(cornell_sky)
+        r = api.Renderer(cornell_sky, w, h, params=wire.default_params(), integrator=api.INTEGRATOR_RESTIR_PT)
+        o = zro.OracleRPT(osc, w, h)
+        for f in range(1, 4):
+            cb = scene_io.make_frame_constants(w, h, frame_num=f, num_emissives=0, cam_pos=(0.0, 1.2, -4.043))
+            r.render_frame(cb)
+            osc.sky_lut(cb, 256, 128)
+            want = o.render(cb, wire.default_params())
+            assert np.array_equal(r.final().view(np.uint32), want.view(np.uint32)), f"sun + sky, general kernels, frame {f}"
+        # K9, K5 / K6, K7 / K8 and K10 have the permutation too: their Cornell tests above ran it; here the general kernels on the same scenes
+        test_path_tracer_bit_exact(api, cornell_emissive, oracle_emissive, 160, 96, 7)
+        test_path_tracer_sun_sky_bit_exact(api, cornell_sky, 200, 120, 4)
+        test_restir_di_bit_exact(api, cornell_emissive, oracle_emissive, 72, 48)
+        test_sky_di_bit_exact(api, cornell_sky, "cornell", 72, 48)
+        test_restir_gi_bit_exact(api, cornell_emissive, oracle_emissive)
+        test_restir_gi_sun_sky_bit_exact(api, cornell_sky)
+    finally:
+        L.zr_debug_set_material_class_kernels(1); L.zr_debug_set_large_scene_nodes(0)
+
+
 # ------------------------------------------------------------------ parity on the BASELINE configurations (SURVEY.md 8(d))
 def test_baseline_config_cornell_1080p_restir_pt_bit_exact(api, cornell_emissive, oracle_emissive):
     """The bench workload itself: Cornell (emissive) 1920 x 1080, ReSTIR PT defaults (3 / 4 bounces, temporal + spatial reuse, boiling
@@ -1606,7 +1642,9 @@ def test_material_edit_between_frames(api):
                     continue      # the light keeps its material (its power enters the alias table)
                 mats[i] = scene_io.pack_material(base_color=(0.2 + 0.1 * (i % 5), 0.7, 0.3, 1.0), metallic=1.0, roughness=0.35)
             sc.materials[:] = mats
+            assert r.scene.material_class() == 1      # frames 1-2 ran the PLAIN kernel permutations ...
             r.scene.update_materials(mats, 0); osc.update_materials(mats, 0)
+            assert r.scene.material_class() == 0      # ... frames 3-4 the general ones, over the same reservoirs
         cb = _frame(sc, w, h, f)
         r.render_frame(cb)
         planes, _ = r.gbuffer.download()

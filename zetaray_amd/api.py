@@ -49,7 +49,7 @@ EXPORTS = [
     "zr_abi_version", "zr_last_error", "zr_device_count", "zr_wire_layout", "zr_scene_create", "zr_scene_destroy", "zr_scene_update_instances", "zr_scene_update_emissives", "zr_scene_invalidate_alias_table", "zr_scene_update_materials",
     "zr_scene_set_background_rebuild", "zr_scene_background_rebuild_stats",
     "zr_scene_invalidate_alias_table_deferred", "zr_scene_update_instances_async", "zr_scene_update_emissives_async", "zr_scene_update_materials_async", "zr_scene_set_alias_table_async",
-    "zr_scene_set_alias_table", "zr_alias_table_build", "zr_scene_get_alias_table", "zr_scene_get_light_voxel_grid", "zr_scene_get_presampled_sets", "zr_scene_bvh_info", "zr_pass_enable_cost_map", "zr_pass_read_cost_map", "zr_pass_debug_trip_stats", "zr_debug_set_large_scene_nodes", "zr_debug_set_bvh_depth_cap",
+    "zr_scene_set_alias_table", "zr_alias_table_build", "zr_scene_get_alias_table", "zr_scene_get_light_voxel_grid", "zr_scene_get_presampled_sets", "zr_scene_bvh_info", "zr_pass_enable_cost_map", "zr_pass_read_cost_map", "zr_pass_debug_trip_stats", "zr_debug_set_large_scene_nodes", "zr_debug_set_bvh_depth_cap", "zr_debug_set_material_class_kernels", "zr_scene_material_class",
     "zr_gbuffer_create", "zr_gbuffer_destroy", "zr_gbuffer_set_tile_origin", "zr_gbuffer_download", "zr_gbuffer_device_plane",
     "zr_params_default", "zr_pass_create", "zr_pass_init", "zr_pass_resize", "zr_pass_reset_temporal", "zr_pass_pick_pixel", "zr_pass_clear_pick", "zr_pass_read_pick",
     "zr_pass_set_params", "zr_pass_render", "zr_pass_get_output", "zr_pass_download_output",
@@ -229,6 +229,13 @@ class Scene:
         else:
             L.zr_scene_update_materials_async.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32]
             _check(L.zr_scene_update_materials_async(self.h, stream, m.ctypes.data, first, len(m)))
+
+    def material_class(self):
+        """1 when every material is an opaque, uncoated, non-metallic dielectric and the scene has no textures (the PLAIN kernel permutations), else 0"""
+        out = C.c_uint32()
+        lib().zr_scene_material_class.argtypes = [C.c_void_p, C.c_void_p]
+        _check(lib().zr_scene_material_class(self.h, C.byref(out)))
+        return out.value
 
     def invalidate_alias_table_deferred(self):
         """the reference's steady-state form: the old table is sampled until the rebuilt one has been uploaded; no render call waits"""

@@ -64,7 +64,9 @@ static int RequireDevice(int device)
 // the ReSTIR PT kernels are compiled in zr_tu_rpt_a.hip / zr_tu_rpt_b.hip (see zr_kernels.h)
 ZR_RPT_GROUP_A(extern template)
 ZR_RPT_GROUP_B(extern template)
+ZR_RPT_GROUP_F(extern template)
 ZR_RPT_GROUP_D(extern template)
+ZR_RPT_GROUP_E(extern template)
 #ifdef ZR_EXPERIMENTS
 ZR_RPT_GROUP_C(extern template)
 #endif
@@ -78,10 +80,12 @@ __global__ void __launch_bounds__(kBlock) k_gbuffer(SceneView sc, zr_frame_const
     GBufferPixel(sc, g, gb, x, y, stack, nullptr, (x | (y << 16)) == pickXY ? pick : nullptr);
 }
 
-template<bool TEX>
+// (PLAIN: the material-class permutation of the K9 stages, like K11's -- zr_rpt.h SetMaterialClass)
+template<bool TEX, bool PLAIN>
 __global__ void __launch_bounds__(kBlock) k_pt_init(SceneView sc, zr_frame_constants g, GBuf gb, PtParams prm, float* finalRGBA,
     F4* firstBOP, PathQueue out, uint32_t* outCount, uint32_t* outRays, uint32_t cap, uint32_t tilesX)
 {
+    sc.plain = PLAIN; gb.plain = PLAIN;
     uint32_t x, y; PixelOfThread(tilesX, gb.x0, gb.y0, &x, &y);
     PathOut po; po.alive = false;
     if (x < gb.x0 + gb.w && y < gb.y0 + gb.h) PtInitPixel(sc, g, gb, prm, x, y, finalRGBA, firstBOP, po, TEX);
@@ -215,9 +219,10 @@ __device__ __forceinline__ void PtShadeBody(const SceneView& sc, const zr_frame_
         if (po.alive) WritePath(out, slot, po, TEX);
     }
 }
+template<bool PLAIN>
 __global__ void __launch_bounds__(kBlock) k_pt_shade(SceneView sc, zr_frame_constants g, PtParams prm, PathQueue in, const uint32_t* inCount,
     PathQueue out, uint32_t* outCount, uint32_t* outRays, uint32_t cap, float* finalRGBA, const F4* firstBOP, uint32_t* groupMax)
-{ PtShadeBody<false>(sc, g, prm, in, inCount, out, outCount, outRays, cap, finalRGBA, firstBOP, groupMax); }
+{ sc.plain = PLAIN; PtShadeBody<false>(sc, g, prm, in, inCount, out, outCount, outRays, cap, finalRGBA, firstBOP, groupMax); }
 // textured permutation: 258 VGPRs by default = 1 wave per SIMD; asking for 2 costs 2 registers and takes the atrium's shade
 // stage from 8.6 to 5.6 ms per frame (the same request on the untextured kernel, 246 VGPRs, made it 10 % slower -- not applied)
 #ifndef ZR_WAVES_PT_SHADE_TEX
@@ -470,6 +475,8 @@ __global__ void __launch_bounds__(kBlock) k_trace_rays_any(SceneView sc, const F
 // threads per block (see kRptBlock in zr_kernels.h): one-wave blocks pay for the emissive DI kernels (K5 0.580 -> 0.568 ms
 // Cornell, 5.42 -> 5.12 ms atrium; K6 0.258 -> 0.241 / 2.99 -> 2.61 ms), not for the sun + sky ones (K7 / K8 within +-0.6 %)
 #include "zr_kernels_di.h"
+ZR_DI_GROUP(extern template, false)
+ZR_DI_GROUP(extern template, true)
 static const uint16_t kRdiSampleSet[64] = {
 #include "zr_rdi_sample_set.inc"
 };
@@ -489,6 +496,9 @@ struct zr_scene
     int device = 0;
     DevBuf<zr_vertex> vertices; DevBuf<uint32_t> indices; DevBuf<zr_mesh_instance> instances; DevBuf<zr_material> materials;
     DevBuf<zr_emissive_triangle> emissives; DevBuf<zr_alias_entry> alias; DevBuf<Bvh4Node> nodes; DevBuf<BvhTri> tris;
+    // material class (SceneView::plain): host copy of the material table + "every material is an opaque uncoated non-metallic dielectric"; kept current by
+    // zr_scene_create / zr_scene_update_materials on the calling thread, read by zr_pass_render when it picks a kernel permutation
+    std::vector<zr_material> hMaterials; std::atomic<bool> plainMaterials{false};
     DevBuf<TriMeta> meta; DevBuf<uint16_t> rho;
     DevBuf<zr_texture_desc> texDescs; DevBuf<uint8_t> texels; DevBuf<float> srgb;   // material texture heap (zr_texture.h)
     DevBuf<zr_presampled_tri> sampleSets; uint32_t numSampleSets = 0;      // K3 output, refreshed by every PRELIGHTING render
@@ -720,7 +730,10 @@ struct QueueStorage
 
 static constexpr uint32_t kRptListWords = 12;      // replay work-list counts + cursors of the ReSTIR PT pass (layout: where the buffer is allocated)
 static constexpr uint32_t kLargeSceneNodes = 16384;     // BVH4 nodes (64 B each): 1 MB of nodes and up counts as "does not fit the caches"
-static std::atomic<uint32_t> g_largeSceneNodes{kLargeSceneNodes};      // zr_debug_set_large_scene_nodes
+static std::atomic<uint32_t> g_largeSceneNodes{kLargeSceneNodes};
+static std::atomic<bool> g_materialClassKernels{true};      // zr_debug_set_material_class_kernels: plain scenes run the PLAIN kernel permutations
+// the PLAIN kernel permutations apply: the scene's material table is of the plain class (and has no texture heap)
+static bool PlainClass(const zr_scene* sc) { return sc->plainMaterials.load(std::memory_order_relaxed) && g_materialClassKernels.load(std::memory_order_relaxed); }
 static constexpr int kMaxRounds = 16;
 static constexpr int kMaxTimers = 64;
 // ray-counter slots (pairs of u64 on the device): 0 = wavefront path tracer, 1.. = ReSTIR PT kernels in launch order
@@ -1143,6 +1156,13 @@ static int DeviceRebuild(zr_scene* s, hipStream_t st)
     return ZR_OK;
 }
 
+// SceneView::plain: no material of the table is metallic, transmissive, thin-walled or coated (the fields GetMaterialData turns into those lobes, Material.h:268-427)
+static bool MaterialsArePlain(const std::vector<zr_material>& m)
+{
+    const uint32_t lobes = (1u << ZR_MAT_METALLIC_BIT) | (1u << ZR_MAT_TRANSMISSIVE_BIT) | (1u << ZR_MAT_THIN_WALLED_BIT);
+    for (const zr_material& x : m) if ((x.coat_color_flags & lobes) || ((x.base_color_tex_subsurf_coat_weight >> 24) & 0xffu)) return false;
+    return !m.empty();
+}
 int zr_scene_create(int device, const zr_scene_desc* d, zr_scene** out)
 {
     if (!d || !out) return Fail(ZR_ERR_INVALID_ARG, "zr_scene_create: null argument");
@@ -1202,6 +1222,8 @@ int zr_scene_create(int device, const zr_scene_desc* d, zr_scene** out)
     v.emissives = s->emissives.p; v.alias = nullptr; v.sampleSets = nullptr; v.sampleSetSize = 0; v.nodes = s->nodes.p; v.tris = s->tris.p; v.triMeta = s->meta.p;
     v.rho.data = s->rho.p; v.rho.dx = d->rho_dim[0]; v.rho.dy = d->rho_dim[1]; v.rho.dz = d->rho_dim[2];
     v.numEmissives = d->num_emissives; v.numNodes = (uint32_t)bvh.nodes4.size(); v.numTris = (uint32_t)bvh.tris.size();
+    s->hMaterials.assign(d->materials, d->materials + d->num_materials);
+    s->plainMaterials = MaterialsArePlain(s->hMaterials) && d->num_textures == 0;
     v.tex.descs = s->texDescs.p; v.tex.texels = s->texels.p; v.tex.srgb = s->srgb.p; v.tex.count = d->num_textures;
     // largest tex16 per descriptor table, so that zr_pass_render can reject frame constants whose table offsets would
     // send a texture fetch outside the heap
@@ -1272,6 +1294,8 @@ int zr_scene_update_materials_async(zr_scene* s, void* stream, const zr_material
         RaiseMaxTex(s, 2, materials[i].mr_tex_spec_roughness_coat_roughness & 0xffffu); RaiseMaxTex(s, 3, materials[i].emissive_tex_alpha_cutoff_coat_ior & 0xffffu);
     }
     if ((r = SceneWaitUsers(s, st))) return r;
+    std::copy(materials, materials + count, s->hMaterials.begin() + first);
+    s->plainMaterials = MaterialsArePlain(s->hMaterials) && s->view.tex.count == 0;
     HIP_TRY(hipMemcpyAsync(s->materials.p + first, t->host, (size_t)count * sizeof(zr_material), hipMemcpyHostToDevice, st));
     if ((r = StageCommit(t, st))) return r;
     return SceneMarkUpdated(s, st);
@@ -2141,17 +2165,18 @@ static int RenderDirectEmissive(zr_pass* p, hipStream_t s, const zr_frame_consta
     prm.writeReservoirs = (prm.doTemporal || !p->temporalValid) ? 1u : 0u;
     const uint32_t tilesX = (F.ow + 15) / 16, tilesY = (F.oh + 15) / 16;
     const dim3 grid(tilesX * tilesY), block(kBlock);
+    const bool plainDi = PlainClass(sc);
     if (stages & ZR_STAGE_TEMPORAL)
     {
         TimerBegin(p, s, "rdi_temporal");
-        hipLaunchKernelGGL(k_rdi_temporal, dim3(grid.x * (256 / kDiBlock)), dim3(kDiBlock), 0, s, F, *cb, tilesX, p->counters.p + 2 * 8);
+        hipLaunchKernelGGL(plainDi ? k_rdi_temporal<true> : k_rdi_temporal<false>, dim3(grid.x * (256 / kDiBlock)), dim3(kDiBlock), 0, s, F, *cb, tilesX, p->counters.p + 2 * 8);
         TimerEnd(p, s);
     }
     if (!(stages & ZR_STAGE_SPATIAL)) { HIP_TRY(hipGetLastError()); return ZR_OK; }
     if (prm.doSpatial)
     {
         TimerBegin(p, s, "rdi_spatial");
-        hipLaunchKernelGGL(k_rdi_spatial, dim3(grid.x * (256 / kDiBlock)), dim3(kDiBlock), 0, s, F, *cb, tilesX, p->counters.p + 2 * 9);
+        hipLaunchKernelGGL(plainDi ? k_rdi_spatial<true> : k_rdi_spatial<false>, dim3(grid.x * (256 / kDiBlock)), dim3(kDiBlock), 0, s, F, *cb, tilesX, p->counters.p + 2 * 9);
         TimerEnd(p, s);
     }
     HIP_TRY(hipGetLastError());
@@ -2184,17 +2209,18 @@ static int RenderDirectSky(zr_pass* p, hipStream_t s, const zr_frame_constants* 
     prm.writeReservoirs = (prm.doTemporal || !p->temporalValid) ? 1u : 0u;
     const uint32_t tilesX = (F.ow + 15) / 16, tilesY = (F.oh + 15) / 16;
     const dim3 grid(tilesX * tilesY), block(kBlock);
+    const bool plainDi = PlainClass(sc);
     if (stages & ZR_STAGE_TEMPORAL)
     {
         TimerBegin(p, s, "sdi_temporal");
-        hipLaunchKernelGGL(k_sdi_temporal, dim3(grid.x * (256 / kSdiBlock)), dim3(kSdiBlock), 0, s, F, *cb, tilesX, p->counters.p + 2 * 11);
+        hipLaunchKernelGGL(plainDi ? k_sdi_temporal<true> : k_sdi_temporal<false>, dim3(grid.x * (256 / kSdiBlock)), dim3(kSdiBlock), 0, s, F, *cb, tilesX, p->counters.p + 2 * 11);
         TimerEnd(p, s);
     }
     if (!(stages & ZR_STAGE_SPATIAL)) { HIP_TRY(hipGetLastError()); return ZR_OK; }
     if (prm.doSpatial)
     {
         TimerBegin(p, s, "sdi_spatial");
-        hipLaunchKernelGGL(k_sdi_spatial, dim3(grid.x * (256 / kSdiBlock)), dim3(kSdiBlock), 0, s, F, *cb, tilesX, p->counters.p + 2 * 12);
+        hipLaunchKernelGGL(plainDi ? k_sdi_spatial<true> : k_sdi_spatial<false>, dim3(grid.x * (256 / kSdiBlock)), dim3(kSdiBlock), 0, s, F, *cb, tilesX, p->counters.p + 2 * 12);
         TimerEnd(p, s);
     }
     HIP_TRY(hipGetLastError());
@@ -2227,7 +2253,7 @@ static int RenderReSTIR_GI(zr_pass* p, hipStream_t s, const zr_frame_constants* 
     if (prm.useLVG && !sc->view.lvg) return Fail(ZR_ERR_NOT_INITIALIZED, "light voxel grid missing: render the PRELIGHTING pass with use_lvg first");
     const uint32_t tilesX = (F.ow + 15) / 16, tilesY = (F.oh + 15) / 16;
     TimerBegin(p, s, "rgi");
-    hipLaunchKernelGGL(sc->view.tex.count ? k_rgi_tex : k_rgi, dim3(tilesX * tilesY * (256 / kRgiBlock)), dim3(kRgiBlock), 0, s, F, *cb, tilesX, p->counters.p + 2 * 10);
+    hipLaunchKernelGGL(sc->view.tex.count ? k_rgi_tex : PlainClass(sc) ? k_rgi<true> : k_rgi<false>, dim3(tilesX * tilesY * (256 / kRgiBlock)), dim3(kRgiBlock), 0, s, F, *cb, tilesX, p->counters.p + 2 * 10);
     TimerEnd(p, s);
     HIP_TRY(hipGetLastError());
     p->temporalValid = true;
@@ -2316,9 +2342,12 @@ static int RenderReSTIR_PT(zr_pass* p, hipStream_t s, const zr_frame_constants* 
     const uint32_t largeSceneNodes = g_largeSceneNodes.load(std::memory_order_relaxed);
     // ... and the TEXTURED permutation (this ABI's: untextured scenes carry no ray differentials)
     const bool texVariant = prm.textured != 0;
+    // ... and the material-class permutation (zr_kernels.h PLAIN): scenes of opaque uncoated non-metallic dielectrics without a texture heap run kernels that have no code for the other lobes
+    const bool plainVariant = PlainClass(sc) && !texVariant;
 #define RPT_LAUNCH_E(kern, ...) do { \
-        if (emissiveVariant) { if (texVariant) hipLaunchKernelGGL((kern<true, true>), __VA_ARGS__); else hipLaunchKernelGGL((kern<true, false>), __VA_ARGS__); } \
-        else { if (texVariant) hipLaunchKernelGGL((kern<false, true>), __VA_ARGS__); else hipLaunchKernelGGL((kern<false, false>), __VA_ARGS__); } } while (0)
+        if (plainVariant) { if (emissiveVariant) hipLaunchKernelGGL((kern<true, false, true>), __VA_ARGS__); else hipLaunchKernelGGL((kern<false, false, true>), __VA_ARGS__); } \
+        else if (emissiveVariant) { if (texVariant) hipLaunchKernelGGL((kern<true, true, false>), __VA_ARGS__); else hipLaunchKernelGGL((kern<true, false, false>), __VA_ARGS__); } \
+        else { if (texVariant) hipLaunchKernelGGL((kern<false, true, false>), __VA_ARGS__); else hipLaunchKernelGGL((kern<false, false, false>), __VA_ARGS__); } } while (0)
 #define RPT_LAUNCH_PE(kern, PASS, ...) do { \
         if (emissiveVariant) { if (texVariant) hipLaunchKernelGGL((kern<PASS, true, true>), __VA_ARGS__); else hipLaunchKernelGGL((kern<PASS, true, false>), __VA_ARGS__); } \
         else { if (texVariant) hipLaunchKernelGGL((kern<PASS, false, true>), __VA_ARGS__); else hipLaunchKernelGGL((kern<PASS, false, false>), __VA_ARGS__); } } while (0)
@@ -2369,8 +2398,15 @@ static int RenderReSTIR_PT(zr_pass* p, hipStream_t s, const zr_frame_constants* 
 #endif
         if (texVariant) { if (emissiveVariant) hipLaunchKernelGGL(k_rpt_pathtrace_tex<true>, gridRpt, blockRpt, 0, s, F, *cb, tilesX, ctr + 2 * 1); else hipLaunchKernelGGL(k_rpt_pathtrace_tex<false>, gridRpt, blockRpt, 0, s, F, *cb, tilesX, ctr + 2 * 1); }
         else if (sc->view.numNodes >= largeSceneNodes || FewerRoundsAtFourWaves(gridRpt.x))     // BVH beyond the caches, or a small grid: the 4-wave build of K11 (zr_kernels.h)
-        { if (emissiveVariant) hipLaunchKernelGGL(k_rpt_pathtrace_w4<true>, gridRpt, blockRpt, 0, s, F, *cb, tilesX, ctr + 2 * 1); else hipLaunchKernelGGL(k_rpt_pathtrace_w4<false>, gridRpt, blockRpt, 0, s, F, *cb, tilesX, ctr + 2 * 1); }
-        else { if (emissiveVariant) hipLaunchKernelGGL(k_rpt_pathtrace<true>, gridRpt, blockRpt, 0, s, F, *cb, tilesX, ctr + 2 * 1); else hipLaunchKernelGGL(k_rpt_pathtrace<false>, gridRpt, blockRpt, 0, s, F, *cb, tilesX, ctr + 2 * 1); }
+        {
+            if (plainVariant) { if (emissiveVariant) hipLaunchKernelGGL((k_rpt_pathtrace_w4<true, true>), gridRpt, blockRpt, 0, s, F, *cb, tilesX, ctr + 2 * 1); else hipLaunchKernelGGL((k_rpt_pathtrace_w4<false, true>), gridRpt, blockRpt, 0, s, F, *cb, tilesX, ctr + 2 * 1); }
+            else if (emissiveVariant) hipLaunchKernelGGL((k_rpt_pathtrace_w4<true, false>), gridRpt, blockRpt, 0, s, F, *cb, tilesX, ctr + 2 * 1); else hipLaunchKernelGGL((k_rpt_pathtrace_w4<false, false>), gridRpt, blockRpt, 0, s, F, *cb, tilesX, ctr + 2 * 1);
+        }
+        else
+        {
+            if (plainVariant) { if (emissiveVariant) hipLaunchKernelGGL((k_rpt_pathtrace<true, true>), gridRpt, blockRpt, 0, s, F, *cb, tilesX, ctr + 2 * 1); else hipLaunchKernelGGL((k_rpt_pathtrace<false, true>), gridRpt, blockRpt, 0, s, F, *cb, tilesX, ctr + 2 * 1); }
+            else if (emissiveVariant) hipLaunchKernelGGL((k_rpt_pathtrace<true, false>), gridRpt, blockRpt, 0, s, F, *cb, tilesX, ctr + 2 * 1); else hipLaunchKernelGGL((k_rpt_pathtrace<false, false>), gridRpt, blockRpt, 0, s, F, *cb, tilesX, ctr + 2 * 1);
+        }
         TimerEnd(p, s);
         if (prm.doTemporal)
         {
@@ -2462,9 +2498,10 @@ static int RenderIndirect(zr_pass* p, hipStream_t s, const zr_frame_constants* c
     SceneView scv = FrameView(sc, cb);
     scv.texFilter = p->params.tex_filter;
     const bool tex = scv.tex.count != 0;      // kernels carry ray differentials only when there is a texture heap
+    const bool plainPt = PlainClass(sc);
     if (tex) { int r; if ((r = p->q[0].AllocTex((size_t)p->w * p->h)) || (r = p->q[1].AllocTex((size_t)p->w * p->h))) return r; }
     TimerBegin(p, s, "pt_init");
-    hipLaunchKernelGGL(tex ? k_pt_init<true> : k_pt_init<false>, dim3(tilesX * tilesY), dim3(kBlock), 0, s, scv, *cb, gbv, prm, p->finalRGBA.p, p->firstBOP.p,
+    hipLaunchKernelGGL((tex ? k_pt_init<true, false> : plainPt ? k_pt_init<false, true> : k_pt_init<false, false>), dim3(tilesX * tilesY), dim3(kBlock), 0, s, scv, *cb, gbv, prm, p->finalRGBA.p, p->firstBOP.p,
         p->q[0].View(), Ctr(0, 0), Ctr(2, 0), (uint32_t)((size_t)p->w * p->h), tilesX);
     TimerEnd(p, s);
     const size_t cap = (size_t)p->w * p->h;
@@ -2480,7 +2517,7 @@ static int RenderIndirect(zr_pass* p, hipStream_t s, const zr_frame_constants* c
         else hipLaunchKernelGGL(k_trace, dim3(gridTrace), dim3(kBlock), 0, s, scv, qin, Ctr(2, r), (uint32_t)cap, Ctr(1, r), p->counters.p);
         TimerEnd(p, s);
         TimerBegin(p, s, "pt_shade");
-        hipLaunchKernelGGL(tex ? k_pt_shade_tex : k_pt_shade, dim3(gridShade), dim3(kBlock), 0, s, scv, *cb, prm, qin, Ctr(0, r), qout, Ctr(0, r + 1), Ctr(2, r + 1), (uint32_t)cap,
+        hipLaunchKernelGGL(tex ? k_pt_shade_tex : plainPt ? k_pt_shade<true> : k_pt_shade<false>, dim3(gridShade), dim3(kBlock), 0, s, scv, *cb, prm, qin, Ctr(0, r), qout, Ctr(0, r + 1), Ctr(2, r + 1), (uint32_t)cap,
             p->finalRGBA.p, p->firstBOP.p, p->groupMax.p + (size_t)r * numGroups);
         TimerEnd(p, s);
         if (rrPossible && r >= 2)
@@ -2996,6 +3033,13 @@ int zr_pass_enable_cost_map(zr_pass* p, int enable)
     p->costRays = enable == ZR_COST_MAP_RAYS;
     return ZR_OK;
 }
+int zr_scene_material_class(const zr_scene* s, uint32_t* out)
+{
+    if (!s || !out) return Fail(ZR_ERR_INVALID_ARG, "zr_scene_material_class: null argument");
+    *out = s->plainMaterials.load() ? 1u : 0u;
+    return ZR_OK;
+}
+int zr_debug_set_material_class_kernels(int enable) { g_materialClassKernels.store(enable != 0, std::memory_order_relaxed); return ZR_OK; }
 int zr_debug_set_bvh_depth_cap(uint32_t levels) { DeviceBvhSetDepthCap(levels); return ZR_OK; }
 int zr_debug_set_large_scene_nodes(uint32_t n) { g_largeSceneNodes.store(n ? n : kLargeSceneNodes, std::memory_order_relaxed); return ZR_OK; }
 int zr_pass_debug_trip_stats(zr_pass* p, uint64_t out[3])

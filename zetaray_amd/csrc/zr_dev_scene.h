@@ -65,6 +65,9 @@ struct SceneView
     uint32_t baseColorMapsOffset, normalMapsOffset, mrMapsOffset, emissiveMapsOffset;
     uint32_t texFilter;      // zr_params.tex_filter of the pass that launches the kernel (cb_ReSTIR_*::TexFilterDescHeapIdx); ZR_TEX_FILTER_*
     uint32_t numEmissives;
+    // material class of the scene: every material is an opaque, uncoated, non-metallic dielectric and there is no texture heap (zr_api.hip ScenePlain).  The
+    // host sets it; kernels of the PLAIN permutation overwrite it with their template constant, so that InitSurface(…, plain) folds (zr_dev_bsdf.h)
+    uint32_t plain;
     uint32_t numNodes;       // 0 => single leaf covering tris[0 .. numTris)
     uint32_t numTris;
 #ifdef ZR_PROF
@@ -669,7 +672,7 @@ ZR_HD bool GetMaterialData(const SceneView& sc, V3 wo, float eta_curr, HitInfo& 
     float eta_next = eta_curr == kEtaAir ? eta : kEtaAir;
     float subsurface = MatThinWalled(mat) ? zr_round_f16(MatSubsurface(mat)) : 0;
     surface = InitSurface(hit.normal, wo, metallic >= kMinMetalnessMetal, roughness, baseColor, eta_curr, eta_next, tr, trDepth,
-        subsurface, MatCoatWeight(mat), UnpackRGB8(mat.coat_color_flags), MatCoatRoughness(mat), MatCoatIOR(mat));
+        subsurface, MatCoatWeight(mat), UnpackRGB8(mat.coat_color_flags), MatCoatRoughness(mat), MatCoatIOR(mat), sc.plain != 0);
     return true;
 }
 

@@ -38,18 +38,40 @@ static constexpr int kRptBlock = ZR_RPT_BLOCK;
 #define ZR_WAVES_MIN(n) __attribute__((amdgpu_waves_per_eu(n)))
 // (with one-wave blocks 3 and 4 waves tie on small scenes -- 0.945 / 0.950 ms Cornell, 5: 1.12 -- and 3 waves spill a third of the bytes (PMC: 0.56 GB per
 // launch against 1.44 GB), so scenes whose BVH fits the caches run at 3; large scenes take k_rpt_pathtrace_w4)
-#ifdef ZR_WAVES_PATHTRACE_N      // (numeric forms for `make variant EXTRA=-D...=4`, see ZR_WAVES_STC_N)
-#define ZR_WAVES_PATHTRACE ZR_WAVES(ZR_WAVES_PATHTRACE_N)
+// Occupancy targets as numbers (`make variant EXTRA=-DZR_WAVES_STC_N=3`: a parenthesised macro value does not survive make + sh quoting).
+// The PLAIN permutations (material-class kernels, zr_tu_rpt_e.hip) have their own: a third of the code, other register needs.
+#ifndef ZR_WAVES_PATHTRACE_N
+#define ZR_WAVES_PATHTRACE_N 3
 #endif
-#ifdef ZR_WAVES_TEMPORAL_N
-#define ZR_WAVES_TEMPORAL ZR_WAVES(ZR_WAVES_TEMPORAL_N)
+#ifndef ZR_WAVES_PATHTRACE_LARGE_N
+#define ZR_WAVES_PATHTRACE_LARGE_N 4      // k_rpt_pathtrace_w4: scenes whose BVH does not fit the caches
 #endif
-#ifndef ZR_WAVES_PATHTRACE
-#define ZR_WAVES_PATHTRACE ZR_WAVES(3)
+#ifndef ZR_WAVES_TEMPORAL_N
+#define ZR_WAVES_TEMPORAL_N 4
 #endif
-#ifndef ZR_WAVES_PATHTRACE_LARGE
-#define ZR_WAVES_PATHTRACE_LARGE ZR_WAVES(4)      // k_rpt_pathtrace_w4: scenes whose BVH does not fit the caches
+// (round 5: with the prepared wo-only terms in Surface the allocator's own choice for k_rpt_stc became 145 VGPRs = 3 waves: 0.686 ms against 0.657 at 4,
+// atrium 3.13 against 2.74 -- pinned to the 4 it chose before, profiles/r05_ab_*.json)
+#ifndef ZR_WAVES_STC_N
+#define ZR_WAVES_STC_N 4
 #endif
+#ifndef ZR_WAVES_PATHTRACE_PLAIN_N
+#define ZR_WAVES_PATHTRACE_PLAIN_N 4      // (Cornell: 0.753 ms at 3, 0.726 at 4, 0.911 at 2)
+#endif
+#ifndef ZR_WAVES_PATHTRACE_LARGE_PLAIN_N
+#define ZR_WAVES_PATHTRACE_LARGE_PLAIN_N 4
+#endif
+#ifndef ZR_WAVES_TEMPORAL_PLAIN_N
+#define ZR_WAVES_TEMPORAL_PLAIN_N 4
+#endif
+#ifndef ZR_WAVES_STC_PLAIN_N
+#define ZR_WAVES_STC_PLAIN_N 4
+#endif
+// (the attribute's arguments may depend on a template parameter)
+#define ZR_WAVES_SEL(plain, nPlain, n) __attribute__((amdgpu_waves_per_eu((plain) ? (nPlain) : (n), (plain) ? (nPlain) : (n))))
+#define ZR_WAVES_PATHTRACE ZR_WAVES_SEL(PLAIN, ZR_WAVES_PATHTRACE_PLAIN_N, ZR_WAVES_PATHTRACE_N)
+#define ZR_WAVES_PATHTRACE_LARGE ZR_WAVES_SEL(PLAIN, ZR_WAVES_PATHTRACE_LARGE_PLAIN_N, ZR_WAVES_PATHTRACE_LARGE_N)
+#define ZR_WAVES_TEMPORAL ZR_WAVES_SEL(PLAIN, ZR_WAVES_TEMPORAL_PLAIN_N, ZR_WAVES_TEMPORAL_N)
+#define ZR_WAVES_STC ZR_WAVES_SEL(PLAIN, ZR_WAVES_STC_PLAIN_N, ZR_WAVES_STC_N)
 #ifndef ZR_WAVES_RGI
 #define ZR_WAVES_RGI ZR_WAVES(4)
 #endif
@@ -57,17 +79,6 @@ static constexpr int kRptBlock = ZR_RPT_BLOCK;
 #define ZR_WAVES_RDI_S ZR_WAVES(3)
 #define ZR_WAVES_SDI_S ZR_WAVES(4)
 #define ZR_WAVES_SDI_T
-#ifndef ZR_WAVES_TEMPORAL
-#define ZR_WAVES_TEMPORAL ZR_WAVES(4)
-#endif
-#ifdef ZR_WAVES_STC_N      // (numeric form for `make variant EXTRA=-DZR_WAVES_STC_N=4`: a parenthesised macro value does not survive make + sh quoting)
-#define ZR_WAVES_STC ZR_WAVES(ZR_WAVES_STC_N)
-#endif
-// (round 5: with the prepared wo-only terms in Surface the allocator's own choice for k_rpt_stc became 145 VGPRs = 3 waves: 0.686 ms against 0.657 at 4,
-// atrium 3.13 against 2.74 -- pinned to the 4 it chose before, profiles/r05_ab_*.json)
-#ifndef ZR_WAVES_STC
-#define ZR_WAVES_STC ZR_WAVES(4)
-#endif
 static constexpr uint32_t kCounterStride = 64;     // queue counters live 256 B apart: their atomics spread over L2 channels
 // this lane's traversal stack: kTravLdsEntries entries in LDS (16 KB per 256-lane block at 8 entries; + 6 KB for the work-stealing slots, zr_dev_scene.h), the rest in scratch
 #define ZR_TRAV_STACK_B(name, B) \
@@ -261,11 +272,14 @@ __device__ __forceinline__ void FlushRayCountersCost(const rpt::RptFrame& F, uns
 // EMISSIVE: the NEE_EMISSIVE shader permutation (emissive triangles vs sun + sky); a template constant so the other variant folds away
 // TEX: the scene has a texture heap (ray differentials carried, material maps sampled); likewise a template constant
 // PARK: the reservoir's selected reconnection in LDS instead of registers / scratch (zr_rpt.h RcPark: 17 words x 64 lanes = 4.25 KB per one-wave block)
-template<bool EMISSIVE, bool TEX, bool NODE_CACHE = false, bool PARK = false>
+// PLAIN: the scene's material class (SceneView::plain: opaque uncoated non-metallic dielectrics only); likewise a template constant -- the kernel then has
+// no code for the other lobes (24 283 -> 9 529 VALU instructions; Cornell 1080p 0.853 -> 0.77 ms).  The host launches it only for such scenes.
+template<bool EMISSIVE, bool TEX, bool NODE_CACHE = false, bool PARK = false, bool PLAIN = false>
 __device__ __forceinline__ void RptPathtraceBody(rpt::RptFrame& F, const zr_frame_constants& g, uint32_t tilesX, unsigned long long* counters)
 {
     const unsigned long long t0 = __builtin_readcyclecounter();
     F.prm.emissive = EMISSIVE ? 1u : 0u; F.prm.textured = TEX ? 1u : 0u;
+    rpt::SetMaterialClass(F, PLAIN);
     uint32_t tile, wave, lane; RptTileWaveLane(&tile, &wave, &lane);
     const uint32_t tx = tile % tilesX, ty = tile / tilesX;
     const uint32_t x = F.ox0 + tx * 16u + (lane & 15u), y = F.oy0 + ty * 16u + wave * 4u + (lane >> 4);
@@ -295,15 +309,15 @@ __device__ __forceinline__ void RptPathtraceBody(rpt::RptFrame& F, const zr_fram
     { ZR_PROF_SCOPE(ZRP_MISC2); rpt::PtFinishLane(F.gb, F.prm, F.cur, F.tex, F.finalRGBA, P); }
     FlushRayCountersCost(F, counters, cnt, x, y, F.Owns(x, y), t0);
 }
-template<bool EMISSIVE>
+template<bool EMISSIVE, bool PLAIN = false>
 __global__ void __launch_bounds__(kRptBlock) ZR_WAVES_PATHTRACE k_rpt_pathtrace(rpt::RptFrame F, zr_frame_constants g, uint32_t tilesX, unsigned long long* counters)
-{ RptPathtraceBody<EMISSIVE, false>(F, g, tilesX, counters); }
+{ RptPathtraceBody<EMISSIVE, false, false, false, PLAIN>(F, g, tilesX, counters); }
 // The same kernel at 4 waves per SIMD (128 VGPRs, more spills): used for scenes whose BVH does not fit the caches, where the inline
 // traversal is latency-bound and the extra wave hides more than the spills cost (380 k-triangle atrium: 11.7 -> 10.6 ms; on the
 // 58-triangle Cornell box both take 1.16 ms, and the 3-wave build moves 5x less spill traffic, so small scenes keep it).
-template<bool EMISSIVE>
+template<bool EMISSIVE, bool PLAIN = false>
 __global__ void __launch_bounds__(kRptBlock) ZR_WAVES_PATHTRACE_LARGE k_rpt_pathtrace_w4(rpt::RptFrame F, zr_frame_constants g, uint32_t tilesX, unsigned long long* counters)
-{ RptPathtraceBody<EMISSIVE, false, true>(F, g, tilesX, counters); }
+{ RptPathtraceBody<EMISSIVE, false, true, false, PLAIN>(F, g, tilesX, counters); }
 // The TEXTURED permutation at 6 waves per SIMD: its dependent texel gathers are latency that more waves hide -- textured atrium 11.99 ms at the
 // compiler's 2 waves (255 VGPRs), 10.74 at >= 3, 10.28 at 4, 10.11 at 5, **9.36 at 6**, 9.69 at 7, 9.96 at 8 (scripts/gpu_tex.sh, gpu_waves.sh); the
 // untextured large-scene build stays at 4 (5: 8.49, 6: 8.35 against 8.02 ms).  Round 1 found that forcing it to exactly 3 waves
@@ -569,11 +583,12 @@ static constexpr int kReconBlock = ZR_RECON_BLOCK;
 static constexpr int kStcBlock = ZR_STC_BLOCK;
 
 // K14: CtT + TtC fused per pixel (zr_rpt.h ReconnectTemporalPixel)
-template<bool EMISSIVE, bool TEX>
+template<bool EMISSIVE, bool TEX, bool PLAIN = false>
 __global__ void __launch_bounds__(kReconBlock) ZR_WAVES_TEMPORAL k_rpt_temporal(rpt::RptFrame F, zr_frame_constants g, uint32_t tilesX, unsigned long long* counters)
 {
     const unsigned long long t0 = __builtin_readcyclecounter();
     F.prm.emissive = EMISSIVE ? 1u : 0u; F.prm.textured = TEX ? 1u : 0u;
+    rpt::SetMaterialClass(F, PLAIN);
     uint32_t x, y; PixelOfThreadB<kReconBlock>(tilesX, F.ox0, F.oy0, &x, &y);
     // SORT_TEMPORAL: threads take their pixel from a K12 map, which puts reservoirs of equal reconnection depth into the same wave.  Scheduling
     // only (no wave operation in CtT / TtC); the error bit is ignored because the fused kernel runs both shifts of a pixel
@@ -596,11 +611,12 @@ __device__ __forceinline__ float WaveSumButterfly(float v)
 }
 
 // K16 CtS + StC: wave = 8x8 pixel group; every lane of the wave walks all four phases (absent lanes contribute 0)
-template<bool EMISSIVE, bool TEX>
+template<bool EMISSIVE, bool TEX, bool PLAIN = false>
 __global__ void __launch_bounds__(kStcBlock) ZR_WAVES_STC k_rpt_stc(rpt::RptFrame F, zr_frame_constants g, uint32_t tilesX, unsigned long long* counters)
 {
     const unsigned long long t0 = __builtin_readcyclecounter();
     F.prm.emissive = EMISSIVE ? 1u : 0u; F.prm.textured = TEX ? 1u : 0u;
+    rpt::SetMaterialClass(F, PLAIN);
     uint32_t x, y; PixelOfThreadB<kStcBlock>(tilesX, F.ox0, F.oy0, &x, &y);
     // SORT_SPATIAL (ReSTIR_PT_Reconnect_StC.hlsl:133-140): the thread at (x, y) shifts the pixel the NtC map assigns to its position, so the
     // four wave sums below run over the 64 pixels K12 put together (error bit: nothing to do -- the lane stays in the wave, contributing 0)
@@ -639,11 +655,18 @@ __global__ void __launch_bounds__(kStcBlock) ZR_WAVES_STC k_rpt_stc(rpt::RptFram
 #define ZR_RPT_ARGS_TILE (rpt::RptFrame, zr_frame_constants, uint32_t, unsigned long long*)
 #define ZR_RPT_ARGS_LIST (rpt::RptFrame, zr_frame_constants, const uint32_t*, const uint32_t*, uint32_t*, unsigned long long*)
 #define ZR_RPT_GROUP_A(X) \
-    X __global__ void k_rpt_pathtrace<true> ZR_RPT_ARGS_TILE; X __global__ void k_rpt_pathtrace<false> ZR_RPT_ARGS_TILE; \
-    X __global__ void k_rpt_pathtrace_w4<true> ZR_RPT_ARGS_TILE; X __global__ void k_rpt_pathtrace_w4<false> ZR_RPT_ARGS_TILE; \
+    X __global__ void k_rpt_pathtrace<true, false> ZR_RPT_ARGS_TILE; X __global__ void k_rpt_pathtrace<false, false> ZR_RPT_ARGS_TILE; \
+    X __global__ void k_rpt_pathtrace_w4<true, false> ZR_RPT_ARGS_TILE; X __global__ void k_rpt_pathtrace_w4<false, false> ZR_RPT_ARGS_TILE; \
     X __global__ void k_rpt_pathtrace_tex<true> ZR_RPT_ARGS_TILE; X __global__ void k_rpt_pathtrace_tex<false> ZR_RPT_ARGS_TILE; \
-    X __global__ void k_rpt_temporal<true, true> ZR_RPT_ARGS_TILE; X __global__ void k_rpt_temporal<true, false> ZR_RPT_ARGS_TILE; \
-    X __global__ void k_rpt_temporal<false, true> ZR_RPT_ARGS_TILE; X __global__ void k_rpt_temporal<false, false> ZR_RPT_ARGS_TILE;
+    X __global__ void k_rpt_temporal<true, true, false> ZR_RPT_ARGS_TILE; X __global__ void k_rpt_temporal<true, false, false> ZR_RPT_ARGS_TILE; \
+    X __global__ void k_rpt_temporal<false, true, false> ZR_RPT_ARGS_TILE; X __global__ void k_rpt_temporal<false, false, false> ZR_RPT_ARGS_TILE;
+// the material-class permutation (PLAIN = true: a scene whose material table has no metal, no transmission, no thin wall, no coat and no texture):
+// zr_tu_rpt_e.hip
+#define ZR_RPT_GROUP_E(X) \
+    X __global__ void k_rpt_pathtrace<true, true> ZR_RPT_ARGS_TILE; X __global__ void k_rpt_pathtrace<false, true> ZR_RPT_ARGS_TILE; \
+    X __global__ void k_rpt_pathtrace_w4<true, true> ZR_RPT_ARGS_TILE; X __global__ void k_rpt_pathtrace_w4<false, true> ZR_RPT_ARGS_TILE; \
+    X __global__ void k_rpt_temporal<true, false, true> ZR_RPT_ARGS_TILE; X __global__ void k_rpt_temporal<false, false, true> ZR_RPT_ARGS_TILE; \
+    X __global__ void k_rpt_stc<true, false, true> ZR_RPT_ARGS_TILE; X __global__ void k_rpt_stc<false, false, true> ZR_RPT_ARGS_TILE;
 // (experiments build only: zr_tu_rpt_c.hip)
 #define ZR_RPT_GROUP_C(X) \
     X __global__ void k_rpt_pathtrace_park<true> ZR_RPT_ARGS_TILE; X __global__ void k_rpt_pathtrace_park<false> ZR_RPT_ARGS_TILE; \
@@ -654,8 +677,8 @@ __global__ void __launch_bounds__(kStcBlock) ZR_WAVES_STC k_rpt_stc(rpt::RptFram
 #define ZR_RPT_REPLAY4(X, PASS) \
     X __global__ void k_rpt_replay<PASS, true, true> ZR_RPT_ARGS_LIST; X __global__ void k_rpt_replay<PASS, true, false> ZR_RPT_ARGS_LIST; \
     X __global__ void k_rpt_replay<PASS, false, true> ZR_RPT_ARGS_LIST; X __global__ void k_rpt_replay<PASS, false, false> ZR_RPT_ARGS_LIST;
-#define ZR_RPT_GROUP_B(X) \
-    ZR_RPT_REPLAY4(X, RPT_REPLAY_CTT) ZR_RPT_REPLAY4(X, RPT_REPLAY_CTS)
+#define ZR_RPT_GROUP_B(X) ZR_RPT_REPLAY4(X, RPT_REPLAY_CTT)
+#define ZR_RPT_GROUP_F(X) ZR_RPT_REPLAY4(X, RPT_REPLAY_CTS)
 #define ZR_RPT_GROUP_D(X) \
-    X __global__ void k_rpt_stc<true, true> ZR_RPT_ARGS_TILE; X __global__ void k_rpt_stc<true, false> ZR_RPT_ARGS_TILE; \
-    X __global__ void k_rpt_stc<false, true> ZR_RPT_ARGS_TILE; X __global__ void k_rpt_stc<false, false> ZR_RPT_ARGS_TILE;
+    X __global__ void k_rpt_stc<true, true, false> ZR_RPT_ARGS_TILE; X __global__ void k_rpt_stc<true, false, false> ZR_RPT_ARGS_TILE; \
+    X __global__ void k_rpt_stc<false, true, false> ZR_RPT_ARGS_TILE; X __global__ void k_rpt_stc<false, false, false> ZR_RPT_ARGS_TILE;

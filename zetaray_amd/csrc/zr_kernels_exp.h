@@ -6,7 +6,7 @@
 #pragma once
 // the same with the reservoir's selected reconnection parked in LDS (ZR_K11_PARK=1; zr_rpt.h RcPark)
 template<bool EMISSIVE>
-__global__ void __launch_bounds__(kRptBlock) ZR_WAVES_PATHTRACE k_rpt_pathtrace_park(rpt::RptFrame F, zr_frame_constants g, uint32_t tilesX, unsigned long long* counters)
+__global__ void __launch_bounds__(kRptBlock) ZR_WAVES(ZR_WAVES_PATHTRACE_N) k_rpt_pathtrace_park(rpt::RptFrame F, zr_frame_constants g, uint32_t tilesX, unsigned long long* counters)
 { RptPathtraceBody<EMISSIVE, false, false, true>(F, g, tilesX, counters); }
 
 // ------------------------------------------------------------------------------------------------ K11 with per-bounce path compaction (round 3)
@@ -33,7 +33,7 @@ __device__ __forceinline__ void PtBounceAndCompact(rpt::RptFrame& F, const zr_fr
     else rpt::PtFinishLane(F.gb, F.prm, F.cur, F.tex, F.finalRGBA, P);
 }
 template<bool EMISSIVE>
-__global__ void __launch_bounds__(kRptBlock) ZR_WAVES_PATHTRACE k_rpt_pt_first(rpt::RptFrame F, zr_frame_constants g, uint32_t tilesX, unsigned long long* counters)
+__global__ void __launch_bounds__(kRptBlock) ZR_WAVES(ZR_WAVES_PATHTRACE_N) k_rpt_pt_first(rpt::RptFrame F, zr_frame_constants g, uint32_t tilesX, unsigned long long* counters)
 {
     const unsigned long long t0 = __builtin_readcyclecounter();
     F.prm.emissive = EMISSIVE ? 1u : 0u; F.prm.textured = 0u;
@@ -66,7 +66,7 @@ __global__ void __launch_bounds__(kRptBlock) ZR_WAVES_PATHTRACE k_rpt_pt_first(r
     FlushRayCountersCost(F, counters, cnt, x, y, F.Owns(x, y), t0);
 }
 template<bool EMISSIVE>
-__global__ void __launch_bounds__(kRptBlock) ZR_WAVES_PATHTRACE k_rpt_pt_next(rpt::RptFrame F, zr_frame_constants g, uint32_t tilesX, unsigned long long* counters)
+__global__ void __launch_bounds__(kRptBlock) ZR_WAVES(ZR_WAVES_PATHTRACE_N) k_rpt_pt_next(rpt::RptFrame F, zr_frame_constants g, uint32_t tilesX, unsigned long long* counters)
 {
     const unsigned long long t0 = __builtin_readcyclecounter();
     F.prm.emissive = EMISSIVE ? 1u : 0u; F.prm.textured = 0u;
@@ -142,10 +142,10 @@ __device__ __forceinline__ void RptPathtraceBodyTrip(rpt::RptFrame& F, const zr_
     FlushRayCountersCost(F, counters, cnt, x, y, F.Owns(x, y), t0);
 }
 template<bool UNUSED>
-__global__ void __launch_bounds__(kRptBlock) ZR_WAVES_PATHTRACE k_rpt_pathtrace_trip(rpt::RptFrame F, zr_frame_constants g, uint32_t tilesX, unsigned long long* counters)
+__global__ void __launch_bounds__(kRptBlock) ZR_WAVES(ZR_WAVES_PATHTRACE_N) k_rpt_pathtrace_trip(rpt::RptFrame F, zr_frame_constants g, uint32_t tilesX, unsigned long long* counters)
 { RptPathtraceBodyTrip<false>(F, g, tilesX, counters); }
 template<bool UNUSED>
-__global__ void __launch_bounds__(kRptBlock) ZR_WAVES_PATHTRACE_LARGE k_rpt_pathtrace_trip_w4(rpt::RptFrame F, zr_frame_constants g, uint32_t tilesX, unsigned long long* counters)
+__global__ void __launch_bounds__(kRptBlock) ZR_WAVES(ZR_WAVES_PATHTRACE_LARGE_N) k_rpt_pathtrace_trip_w4(rpt::RptFrame F, zr_frame_constants g, uint32_t tilesX, unsigned long long* counters)
 { RptPathtraceBodyTrip<true>(F, g, tilesX, counters); }
 
 // ------------------------------------------------------------------------------------------------ block-cooperative ray pool (round 3)

@@ -306,9 +306,9 @@ ZR_HD void LoadPrimary(const GiFrame& F, const zr_frame_constants& g, uint32_t x
     const V3 baseColor = UnpackRGB8(F.gb.baseColor[px]);
     P.roughness = RoughnessOf(mrp);
     P.ior = kDefaultEtaMat;
-    if (flags.transmissive) P.ior = DecodeIOR(zr_div255((float)F.gb.ior[px]));
+    if (flags.transmissive && !F.gb.plain) P.ior = DecodeIOR(zr_div255((float)F.gb.ior[px]));
     const V3 wo = normalize(origin - P.pos);
-    P.surface = InitSurface(P.normal, wo, flags.metallic, P.roughness, baseColor, kEtaAir, P.ior, flags.transmissive, 0.0f, 0.0f, 0.0f, v3(0.0f), 0.0f, kDefaultEtaCoat);
+    P.surface = InitSurface(P.normal, wo, flags.metallic, P.roughness, baseColor, kEtaAir, P.ior, flags.transmissive, 0.0f, 0.0f, 0.0f, v3(0.0f), 0.0f, kDefaultEtaCoat, F.gb.plain != 0);
 }
 // wo-only term groups (zr_dev_bsdf.h WO_*) K10 prepares on the surfaces of its path
 #ifndef ZR_PREP_RGI
@@ -536,7 +536,7 @@ ZR_HD float TargetLumAtTemporalPixel(const Globals& gl, const GiFrame& F, const 
     }
     const V3 wo_prev = normalize(camPos_prev - c.posW);
     Surface surface_prev = InitSurface(c.normal, wo_prev, c.metallic, c.roughness, baseColor_prev, kEtaAir, c.eta_next, c.transmissive, 0.0f, 0.0f, 0.0f,
-        v3(0.0f), 0.0f, kDefaultEtaCoat);
+        v3(0.0f), 0.0f, kDefaultEtaCoat, F.gbPrev.plain != 0);
     surface_prev.SetWi(wi, c.normal);
     const V3 target_prev = r_curr.Lo * Unified(gl.sc->rho, surface_prev).f;
     const float targetLum_prev = Luminance(target_prev);

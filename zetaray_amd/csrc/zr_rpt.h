@@ -33,6 +33,12 @@ static constexpr int kNeighborOffset = 32;
 #define ZR_PREP_SHIFT 1
 #endif
 static constexpr uint32_t kPrepShift = ZR_PREP_SHIFT;
+// ... and in the PLAIN permutations, whose lanes have the registers for every group (Cornell: temporal 0.405 -> 0.397 ms, spatial 0.593 -> 0.579, profiles/r05_ab_summary.md visit 13)
+#ifndef ZR_PREP_SHIFT_PLAIN
+#define ZR_PREP_SHIFT_PLAIN 15
+#endif
+static constexpr uint32_t kPrepShiftPlain = ZR_PREP_SHIFT_PLAIN;
+ZR_HD uint32_t PrepShiftGroups(uint32_t plain) { return plain ? kPrepShiftPlain : kPrepShift; }
 #ifndef ZR_PREP_K11
 #define ZR_PREP_K11 15
 #endif
@@ -1144,6 +1150,7 @@ ZR_HD PixelSurface LoadPixelSurfaceEx(const GBuf& gb, const Camera& cam, uint32_
     const size_t px = Pix(gb, x, y);
     const uint16_t mrp = gb.mr[px];
     ps.flags = DecodeFlags(mrp); ps.roughness = RoughnessOf(mrp); ps.z = gb.depth[px];
+    if (gb.plain) { ps.flags.metallic = false; ps.flags.transmissive = false; ps.flags.trDepthGt0 = false; ps.flags.subsurface = false; ps.flags.coated = false; }      // what the planes of a plain scene hold (zr_dev_bsdf.h InitSurface)
     V2 lens = v2(0, 0);
     if (cam.dof)
     {
@@ -1172,7 +1179,7 @@ ZR_HD PixelSurface LoadPixelSurfaceEx(const GBuf& gb, const Camera& cam, uint32_
     }
     const V3 wo = normalize(origin - ps.pos);
     ps.surface = InitSurface(ps.normal, wo, ps.flags.metallic, ps.roughness, baseColor, kEtaAir, ps.eta_next, ps.flags.transmissive,
-        (useTrDepth && ps.flags.trDepthGt0) ? 1.0f : 0.0f, subsurface, coat_weight, coat_color, coat_roughness, coat_ior);
+        (useTrDepth && ps.flags.trDepthGt0) ? 1.0f : 0.0f, subsurface, coat_weight, coat_color, coat_roughness, coat_ior, gb.plain != 0);
     ps.lens = lens; ps.origin = origin;
     return ps;
 }
@@ -1620,6 +1627,7 @@ struct RBuf
     uint16_t* A;   // RGBA16F (throughput, max uv grad)
     U4* B; U4* C;  // RGBA32_UINT
     uint16_t* D;   // R16_UINT
+    uint32_t plain = 0;      // as GBuf::plain, for the surfaces rebuilt from the r-buffer
 };
 struct OffsetCtx { V3 throughput, pos, normal; Surface surface; float eta_curr, eta_next; Rng rngReplay; RayDiffs rd; };   // rd: textured scenes only
 ZR_HD OffsetCtx InitOffsetCtx()
@@ -1645,6 +1653,7 @@ ZR_HD OffsetCtx LoadOffsetCtx(const RBuf& rb, size_t i, bool isCase3 = false, bo
     float roughness = zr_div255((float)(c.z & 0xff));
     V3 baseColor = UnpackRGB8(c.y & 0xffffff);
     uint32_t flags = c.y >> 24;
+    if (rb.plain) flags = 0;
     bool metallic = flags & 0x1, specTr = (flags & 0x4) == 0x4;
     float trDepth = (flags & 0x8) == 0x8 ? 1.0f : 0.0f;
     bool coated = (flags & 0x10) == 0x10;
@@ -1660,7 +1669,7 @@ ZR_HD OffsetCtx LoadOffsetCtx(const RBuf& rb, size_t i, bool isCase3 = false, bo
         coat_ior = zr_fma(zr_div255((float)((d_w >> 8) & 0xff)), 1.5f, 1.0f);
     }
     ctx.surface = InitSurface(ctx.normal, wo, metallic, roughness, baseColor, ctx.eta_curr, eta_next, specTr, trDepth, zr_round_f16(subsurface),
-        coat_weight, coat_color, coat_roughness, coat_ior);
+        coat_weight, coat_color, coat_roughness, coat_ior, rb.plain != 0);
     return ctx;
 }
 ZR_HD void WriteOffsetCtx(const OffsetCtx& ctx, const RBuf& rb, size_t i, bool isCase3, bool tex = false)
@@ -1748,7 +1757,7 @@ ZR_HD_FLAT void Replay(const Globals& g, bool currFrame, int numBounces, BsdfSam
             ctx.throughput = ctx.throughput * vexp(-hit.t * ext);
         }
         if (bounce >= numBounces) break;
-        if (kPrepShift) PrepareWo(sc.rho, ctx.surface, kPrepShift);
+        if (PrepShiftGroups(sc.plain)) PrepareWo(sc.rho, ctx.surface, PrepShiftGroups(sc.plain));
         bs = SampleBSDF(sc.rho, ctx.normal, ctx.surface, ctx.rngReplay);
         if (dot(bs.bsdfOverPdf, bs.bsdfOverPdf) == 0) { ctx.throughput = v3(0.0f); return; }
         const float alpha_lobe = LobeAlpha(ctx.surface, bs.lobe);
@@ -1777,7 +1786,7 @@ ZR_HD_FLAT OffsetCtx Replay_kGt2(const Globals& g, bool currFrame, V3 pos, V3 no
     ctx.pos = pos; ctx.normal = normal; ctx.surface = surface; ctx.rngReplay = Rng::Seed(rc.seed_replay);
     ctx.eta_curr = kEtaAir; ctx.eta_next = ior; ctx.throughput = v3(1.0f);
     const int numBounces = (int)rc.k - 2;
-    if (kPrepShift) PrepareWo(g.sc->rho, ctx.surface, kPrepShift);
+    if (PrepShiftGroups(g.sc->plain)) PrepareWo(g.sc->rho, ctx.surface, PrepShiftGroups(g.sc->plain));
     BsdfSample bs = SampleBSDF(g.sc->rho, ctx.normal, ctx.surface, ctx.rngReplay);
     if (dot(bs.bsdfOverPdf, bs.bsdfOverPdf) == 0) { ctx.throughput = v3(0.0f); return ctx; }
     if (g.textured)
@@ -1805,7 +1814,7 @@ ZR_HD_FLAT float StepPath(const Globals& g, bool currFrame, OffsetCtx& ctx, cons
     SamplerEval e;
     {
     ZR_PROF_SCOPE(ZRP_BSDF);      // (-DZR_PROF builds: the evaluation at y_{k-1})
-    if (kPrepShift) PrepareWo(sc.rho, ctx.surface, kPrepShift);      // y_{k-1}: the lobe candidates of EvalBSDFSampler share its wo-only terms
+    if (PrepShiftGroups(sc.plain)) PrepareWo(sc.rho, ctx.surface, PrepShiftGroups(sc.plain));      // y_{k-1}: the lobe candidates of EvalBSDFSampler share its wo-only terms
     e = EvalBSDFSampler(sc.rho, ctx.normal, ctx.surface, w_k_min_1, rc.lobe_k_min_1, ctx.rngReplay);
     }
     if (dot(e.bsdfOverPdf, e.bsdfOverPdf) == 0) return 0;
@@ -1821,7 +1830,7 @@ ZR_HD_FLAT float StepPath(const Globals& g, bool currFrame, OffsetCtx& ctx, cons
     // RtRayQuery::IsotropicSampler with g_samLinearWrap (Shift.hlsli:519-521)
     { ZR_PROF_SCOPE(ZRP_MATERIAL);
     if (!GetMaterialData(sc, -w_k_min_1, ctx.eta_curr, hit, ctx.surface, eta_mat, ctx.rd.uv_grads, g.textured, true)) return 0; }
-    if (kPrepShift) PrepareWo(sc.rho, ctx.surface, kPrepShift);      // y_k: evaluated two to four times by the case-1 / case-2 branches of Shift2
+    if (PrepShiftGroups(sc.plain)) PrepareWo(sc.rho, ctx.surface, PrepShiftGroups(sc.plain));      // y_k: evaluated two to four times by the case-1 / case-2 branches of Shift2
     ctx.eta_next = eta_mat;
     if (inMedium && (ctx.surface.trDepth > 0))
     {
@@ -1955,7 +1964,7 @@ ZR_HD_FLAT OffsetPath Shift2(const Globals& g, bool currFrame, size_t DTidIdx, V
     {
         if (!IsLobeValid(ctx.surface, rc.lobe_k_min_1)) return ret;
         if (LobeAlpha(ctx.surface, rc.lobe_k_min_1) < g.alpha_min) return ret;
-        if (kPrepShift) PrepareWo(g.sc->rho, ctx.surface, kPrepShift);
+        if (PrepShiftGroups(g.sc->plain)) PrepareWo(g.sc->rho, ctx.surface, PrepShiftGroups(g.sc->plain));
     }
     Rng rngNEE = Rng::Seed(rc.seed_nee);
     if (!g.emissive)      // Shift2<Emissive = false>, Shift.hlsli:788-813
@@ -2023,6 +2032,10 @@ struct RptFrame
     uint32_t* carryOut; const uint32_t* carryIn; uint32_t* carryCount; size_t carryCap; uint32_t carryBounce;
 };
 
+// the PLAIN permutation of a kernel writes its template constant into every structure a surface is rebuilt from (scene, G-buffers, r-buffers): the
+// material class then is a compile-time fact in InitSurface, LoadPixelSurfaceEx and LoadOffsetCtx, and the metal / transmission / thin-wall / coat code folds away
+ZR_HD void SetMaterialClass(RptFrame& F, bool plain)
+{ const uint32_t p = plain ? 1u : 0u; F.sc.plain = p; F.scPrev.plain = p; F.gb.plain = p; F.gbPrev.plain = p; F.rbCtN.plain = p; F.rbNtC.plain = p; }
 ZR_HD Globals MakeGlobals(const RptFrame& F, const zr_frame_constants& g, bool transmissive, TravStack stack, uint32_t* cnt)
 {
     Globals gl; gl.textured = F.prm.textured != 0; gl.sc = &F.sc; gl.scPrev = &F.scPrev; gl.frame = &g; gl.emissive = F.prm.emissive != 0; gl.numEmissives = g.num_emissive_triangles; gl.alpha_min = F.prm.alpha_min; gl.stack = stack; gl.cnt = cnt; gl.presampled = false; gl.sampleSetIdx = 0;

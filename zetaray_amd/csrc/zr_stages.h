@@ -35,6 +35,7 @@ struct GBuf
     uint32_t w, h, x0, y0;
     uint32_t* baseColor; uint32_t* normal; uint16_t* mr; uint32_t* motion; uint32_t* emissive; uint8_t* ior;
     uint16_t* coat; float* depth; uint32_t* triA; uint32_t* triB;
+    uint32_t plain = 0;      // the scene's material class (SceneView::plain) for the surfaces rebuilt from these planes: set by the PLAIN kernel permutations only
 };
 
 ZR_HD float EncodeMetallic(float metalness, bool tr, V3 emissive, float trDepth, float subsurface, float coat_weight)  // GBuffers.hlsli:52-68
@@ -457,7 +458,8 @@ ZR_HD void PtInitPixel(const SceneView& sc, const zr_frame_constants& g, const G
         if (!prm.accumulate) { float* o = finalRGBA + 4 * (size_t)pid; o[0] = 0; o[1] = 0; o[2] = 0; }
         return;
     }
-    const bool f_tr = fl & ZR_GBUF_TRANSMISSIVE, f_trDepth = fl & ZR_GBUF_TRDEPTH_GT0, f_metal = fl & ZR_GBUF_METALLIC;
+    // (gb.plain: the scene's material class, a compile-time constant in the PLAIN kernel permutations -- these flags then are known to be clear)
+    const bool f_tr = !gb.plain && (fl & ZR_GBUF_TRANSMISSIVE), f_trDepth = !gb.plain && (fl & ZR_GBUF_TRDEPTH_GT0), f_metal = !gb.plain && (fl & ZR_GBUF_METALLIC);
     const V2 renderDim = v2((float)g.render_width, (float)g.render_height);
     const V2 jitter = v2(g.curr_camera_jitter[0], g.curr_camera_jitter[1]);
     const V3 vbx = Row3(g.curr_view, 0), vby = Row3(g.curr_view, 1), vbz = Row3(g.curr_view, 2);
@@ -499,7 +501,7 @@ ZR_HD void PtInitPixel(const SceneView& sc, const zr_frame_constants& g, const G
     if (f_tr) eta_next = DecodeIOR(zr_div255((float)gb.ior[pid]));
     const V3 wo = normalize(origin - pos);
     Surface surface = InitSurface(normal, wo, f_metal, mr_y, baseColor, eta_curr, eta_next, f_tr, f_trDepth ? 1.0f : 0.0f,
-        0.0f, 0.0f, v3(0.0f), 0.0f, kDefaultEtaCoat);
+        0.0f, 0.0f, v3(0.0f), 0.0f, kDefaultEtaCoat, gb.plain != 0);
 
     Rng rngGroup = Rng::Init((x >> 3) ^ 61u, (y >> 3) ^ 61u, g.frame_num);
     Rng rngThread = Rng::Init(x ^ 511u, y ^ 31u, g.frame_num);

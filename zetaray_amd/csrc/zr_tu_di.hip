@@ -1,91 +1,6 @@
 // zr_tu_di.hip -- translation unit of libzetaray_amd.so holding the direct-lighting kernels (K5 / K6 emissive ReSTIR DI, K7 / K8 sun + sky ReSTIR DI) and
-// the ReSTIR GI kernel (K10); prototypes and block sizes in zr_kernels_di.h, launches in zr_api.hip
+// the ReSTIR GI kernel (K10) of the general material class + the TEXTURED K10; definitions in zr_kernels_di.h, launches in zr_api.hip
 #include "zr_kernels_di.h"
-
-// ------------------------------------------------------------------------------------------------ sun + sky ReSTIR DI kernels
-// threads per block (see kRptBlock in zr_kernels.h; scripts/gpu_block3.sh): one-wave blocks pay for the emissive DI kernels (K5 0.580 -> 0.568 ms
-// Cornell, 5.42 -> 5.12 ms atrium; K6 0.258 -> 0.241 / 2.99 -> 2.61 ms), not for the sun + sky ones (K7 / K8 within +-0.6 %)
-// K7: initial candidates (sun, cosine-sky, BSDF-sky) + temporal reuse; K8: pairwise-MIS spatial reuse.  One thread per pixel.
-__global__ void __launch_bounds__(kSdiBlock) ZR_WAVES_SDI_T k_sdi_temporal(sdi::SkyFrame F, zr_frame_constants g, uint32_t tilesX, unsigned long long* counters)
-{
-    uint32_t x, y; PixelOfThreadB<kSdiBlock>(tilesX, F.ox0, F.oy0, &x, &y);
-    ZR_TRAV_STACK_B(stack, kSdiBlock);
-    uint32_t cnt[2] = {0u, 0u};
-    if (F.Owns(x, y)) sdi::TemporalPixel(F, g, x, y, stack, cnt);
-    FlushRayCounters(counters, cnt);
-}
-__global__ void __launch_bounds__(kSdiBlock) ZR_WAVES_SDI_S k_sdi_spatial(sdi::SkyFrame F, zr_frame_constants g, uint32_t tilesX, unsigned long long* counters)
-{
-    uint32_t x, y; PixelOfThreadB<kSdiBlock>(tilesX, F.ox0, F.oy0, &x, &y);
-    ZR_TRAV_STACK_B(stack, kSdiBlock);
-    uint32_t cnt[2] = {0u, 0u};
-    if (F.Owns(x, y)) sdi::SpatialPixel(F, g, x, y, stack, cnt);
-    FlushRayCounters(counters, cnt);
-}
-
-// ------------------------------------------------------------------------------------------------ ReSTIR DI kernels
-
-// K5: initial candidates + temporal reuse, one thread per pixel (8x8 quadrant per wave, like the reference's thread group)
-__global__ void __launch_bounds__(kDiBlock) ZR_WAVES_RDI_T k_rdi_temporal(rdi::DiFrame F, zr_frame_constants g, uint32_t tilesX, unsigned long long* counters)
-{
-    uint32_t x, y; PixelOfThreadB<kDiBlock>(tilesX, F.ox0, F.oy0, &x, &y);
-    ZR_TRAV_STACK_B(stack, kDiBlock);
-    uint32_t cnt[2] = {0u, 0u};
-    if (F.Owns(x, y)) rdi::TemporalPixel(F, g, x, y, stack, cnt);
-    FlushRayCounters(counters, cnt);
-}
-// K6: spatial reuse with pairwise MIS; WaveActiveSum(disoccluded) = popcount of a ballot over the 8x8 group
-__global__ void __launch_bounds__(kDiBlock) ZR_WAVES_RDI_S k_rdi_spatial(rdi::DiFrame F, zr_frame_constants g, uint32_t tilesX, unsigned long long* counters)
-{
-    uint32_t x, y; PixelOfThreadB<kDiBlock>(tilesX, F.ox0, F.oy0, &x, &y);
-    ZR_TRAV_STACK_B(stack, kDiBlock);
-    uint32_t cnt[2] = {0u, 0u};
-    rdi::SpatialLane a;
-    rdi::SpatialPhase0(F, g, x, y, a);
-    const uint32_t waveDisoccluded = (uint32_t)__popcll(__ballot(a.disoccluded));
-    rdi::SpatialPhase1(F, g, a, waveDisoccluded, stack, cnt);
-    FlushRayCounters(counters, cnt);
-}
-
-// ------------------------------------------------------------------------------------------------ ReSTIR GI kernel
-// K10: one 8x8 pixel group per wave, bounce loop in lockstep around the Russian-roulette wave max, then temporal resampling
-// and the boiling-suppression wave sum (zr_rgi.h)
-// (the kernel body as a macro: routing both kernels through one inline function taking the frame by reference cost the untextured one 4 %)
-#ifdef ZR_NODE_CACHE_MORE
-#define ZR_RGI_NODE_CACHE ZR_NODE_CACHE_FILL(stack, F.sc, kRgiBlock);
-#else
-#define ZR_RGI_NODE_CACHE
-#endif
-#define ZR_RGI_KERNEL_BODY(TEX) \
-    F.prm.textured = TEX; \
-    uint32_t x, y; PixelOfThreadB<kRgiBlock>(tilesX, F.ox0, F.oy0, &x, &y); \
-    ZR_TRAV_STACK_B(stack, kRgiBlock); \
-    ZR_RGI_NODE_CACHE \
-    uint32_t cnt[2] = {0u, 0u}; \
-    rgi::Lane P; \
-    rgi::InitLane(F, g, x, y, stack, cnt, P); \
-    for (;;) \
-    { \
-        const bool any = __ballot(P.active) != 0; \
-        rgi::PhaseA(F, g, stack, cnt, P); \
-        if (!any) break; \
-        uint32_t key = rgi::RRKey(P); \
-        if (__ballot(key != 0) != 0) \
-        { \
-            for (int s = 1; s < 64; s <<= 1) { uint32_t o = __shfl_xor(key, s); key = o > key ? o : key; } \
-        } \
-        rgi::PhaseB(F, g, stack, cnt, P, key); \
-    } \
-    rgi::ReloadPrimary(F, g, P); \
-    const float w = rgi::FinishAndResample(F, g, stack, cnt, P); \
-    const float waveSum = WaveSumButterfly(w); \
-    rgi::SuppressAndWrite(F, P, waveSum); \
-    FlushRayCounters(counters, cnt);
-__global__ void __launch_bounds__(kRgiBlock) ZR_WAVES_RGI k_rgi(rgi::GiFrame F, zr_frame_constants g, uint32_t tilesX, unsigned long long* counters)
-{ ZR_RGI_KERNEL_BODY(false) }
-// the TEXTURED permutation hides its texel-gather latency with more waves, like K11's (textured atrium: 12.12 ms at 4 waves, 11.42 at 5, 10.96 at 6;
-// the untextured kernel is best at 4; scripts/gpu_waves2.sh)
+ZR_DI_GROUP(template, false)
 __global__ void __launch_bounds__(kRgiBlock) ZR_WAVES(6) k_rgi_tex(rgi::GiFrame F, zr_frame_constants g, uint32_t tilesX, unsigned long long* counters)
-{ ZR_RGI_KERNEL_BODY(true) }
-#undef ZR_RGI_KERNEL_BODY
-
+{ ZR_RGI_KERNEL_BODY(true, false) }
