@@ -28,10 +28,12 @@
 #define ZR_HD __host__ __device__ inline __attribute__((always_inline))
 #define ZR_HDM __host__ __device__ __attribute__((always_inline))          /* member functions */
 #define ZR_HD_FLAT ZR_HD
+#define ZR_UNROLL _Pragma("unroll")      /* full unrolling: two-slot arrays indexed by the loop counter become registers */
 #else
 #define ZR_HD static inline
 #define ZR_HDM
 #define ZR_HD_FLAT static inline
+#define ZR_UNROLL
 #endif
 
 #define ZR_PI              3.141592654f

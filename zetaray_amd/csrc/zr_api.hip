@@ -61,12 +61,8 @@ static int RequireDevice(int device)
 #define ZR_EXP_ENV(name) ((const char*)nullptr)
 #endif
 #include "zr_bvh_device.h"
-// the ReSTIR PT kernels are compiled in zr_tu_rpt_a.hip / zr_tu_rpt_b.hip (see zr_kernels.h)
-ZR_RPT_GROUP_A(extern template)
-ZR_RPT_GROUP_B(extern template)
-ZR_RPT_GROUP_F(extern template)
-ZR_RPT_GROUP_D(extern template)
-ZR_RPT_GROUP_E(extern template)
+// the ReSTIR PT kernels are compiled in zr_tu_rpt_[a-i].hip (see zr_kernels.h)
+ZR_RPT_GROUPS_PRODUCT(extern template)
 #ifdef ZR_EXPERIMENTS
 ZR_RPT_GROUP_C(extern template)
 #endif
@@ -230,12 +226,13 @@ __global__ void __launch_bounds__(kBlock) k_pt_shade(SceneView sc, zr_frame_cons
 #endif
 __global__ void __launch_bounds__(kBlock) ZR_WAVES_PT_SHADE_TEX k_pt_shade_tex(SceneView sc, zr_frame_constants g, PtParams prm, PathQueue in, const uint32_t* inCount,
     PathQueue out, uint32_t* outCount, uint32_t* outRays, uint32_t cap, float* finalRGBA, const F4* firstBOP, uint32_t* groupMax)
-{ PtShadeBody<true>(sc, g, prm, in, inCount, out, outCount, outRays, cap, finalRGBA, firstBOP, groupMax); }
+{ sc.plain = 0; PtShadeBody<true>(sc, g, prm, in, inCount, out, outCount, outRays, cap, finalRGBA, firstBOP, groupMax); }
 
 // Russian-roulette stage: finishes the vertices PtShadePath parked (only launched for rounds in which RR can trigger)
 template<bool TEX>
 __global__ void __launch_bounds__(kBlock) k_pt_rr(SceneView sc, PtParams prm, PathQueue q, const uint32_t* count, uint32_t* rays, uint32_t cap, const uint32_t* groupMax)
 {
+    sc.plain = 0;
     const uint32_t n = *count;
     for (uint32_t base = blockIdx.x * kBlock; base < n; base += gridDim.x * kBlock)
     {

@@ -479,6 +479,7 @@ __global__ void __launch_bounds__(kBlock) k_rpt_replay(rpt::RptFrame F, zr_frame
     unsigned long long* counters)
 {
     F.prm.emissive = EMISSIVE ? 1u : 0u; F.prm.textured = TEX ? 1u : 0u;
+    rpt::SetMaterialClass(F, false);      // (no PLAIN permutation of the replays: the class must still be a constant, or both forms of everything it selects are compiled in)
     ZR_TRAV_STACK(stack);
 #ifdef ZR_NODE_CACHE_MORE
     ZR_NODE_CACHE_FILL(stack, F.sc, kBlock);
@@ -634,6 +635,10 @@ __global__ void __launch_bounds__(kStcBlock) ZR_WAVES_STC k_rpt_stc(rpt::RptFram
     a.r_curr.park.p = nullptr; a.r_curr.park.stride = 0; a.r_curr.parked = false; a.r_spatial.park.p = nullptr; a.r_spatial.park.stride = 0; a.r_spatial.parked = false;
 #else
     rpt::StcLane a;
+    // The general permutation keeps the lane's two reservoirs (304 B) as an object in scratch memory: split into registers they cost it 160 - 220 spilled
+    // VGPRs at its 128 (atrium: 2.72 -> 2.85 ms), whereas the PLAIN permutation, a third of the code, gains from the split (Cornell: 0.578 -> 0.539 ms).
+    // The empty asm takes the object's address, which is what keeps it whole.
+    if (!PLAIN) asm volatile("" :: "v"(&a) : "memory");
 #endif
     float v1, v2, v3, v4;
     { ZR_PROF_SCOPE(ZRP_MISC0); rpt::StcPhase0(F, g, x, y, a, v1, v2); }
@@ -651,17 +656,26 @@ __global__ void __launch_bounds__(kStcBlock) ZR_WAVES_STC k_rpt_stc(rpt::RptFram
 
 
 // ------------------------------------------------------------------------------------------------ translation-unit split
-// ZR_RPT_GROUP_A / _B(X): X = `template` in the TU that owns the group, `extern template` everywhere else
+// ZR_RPT_GROUP_*(X): X = `template` in the TU that owns the group (zr_tu_rpt_<letter>.hip), `extern template` everywhere else.  The groups are cut for
+// the build's wall clock (8 jobs): roughly equal compile times, no group above a minute.
 #define ZR_RPT_ARGS_TILE (rpt::RptFrame, zr_frame_constants, uint32_t, unsigned long long*)
 #define ZR_RPT_ARGS_LIST (rpt::RptFrame, zr_frame_constants, const uint32_t*, const uint32_t*, uint32_t*, unsigned long long*)
+// K11, untextured
 #define ZR_RPT_GROUP_A(X) \
     X __global__ void k_rpt_pathtrace<true, false> ZR_RPT_ARGS_TILE; X __global__ void k_rpt_pathtrace<false, false> ZR_RPT_ARGS_TILE; \
-    X __global__ void k_rpt_pathtrace_w4<true, false> ZR_RPT_ARGS_TILE; X __global__ void k_rpt_pathtrace_w4<false, false> ZR_RPT_ARGS_TILE; \
+    X __global__ void k_rpt_pathtrace_w4<true, false> ZR_RPT_ARGS_TILE; X __global__ void k_rpt_pathtrace_w4<false, false> ZR_RPT_ARGS_TILE;
+// K11 + K14, textured
+#define ZR_RPT_GROUP_G(X) \
     X __global__ void k_rpt_pathtrace_tex<true> ZR_RPT_ARGS_TILE; X __global__ void k_rpt_pathtrace_tex<false> ZR_RPT_ARGS_TILE; \
-    X __global__ void k_rpt_temporal<true, true, false> ZR_RPT_ARGS_TILE; X __global__ void k_rpt_temporal<true, false, false> ZR_RPT_ARGS_TILE; \
-    X __global__ void k_rpt_temporal<false, true, false> ZR_RPT_ARGS_TILE; X __global__ void k_rpt_temporal<false, false, false> ZR_RPT_ARGS_TILE;
-// the material-class permutation (PLAIN = true: a scene whose material table has no metal, no transmission, no thin wall, no coat and no texture):
-// zr_tu_rpt_e.hip
+    X __global__ void k_rpt_temporal<true, true, false> ZR_RPT_ARGS_TILE; X __global__ void k_rpt_temporal<false, true, false> ZR_RPT_ARGS_TILE;
+// K14 + K16, untextured
+#define ZR_RPT_GROUP_H(X) \
+    X __global__ void k_rpt_temporal<true, false, false> ZR_RPT_ARGS_TILE; X __global__ void k_rpt_temporal<false, false, false> ZR_RPT_ARGS_TILE; \
+    X __global__ void k_rpt_stc<true, false, false> ZR_RPT_ARGS_TILE; X __global__ void k_rpt_stc<false, false, false> ZR_RPT_ARGS_TILE;
+// K16, textured
+#define ZR_RPT_GROUP_D(X) \
+    X __global__ void k_rpt_stc<true, true, false> ZR_RPT_ARGS_TILE; X __global__ void k_rpt_stc<false, true, false> ZR_RPT_ARGS_TILE;
+// the material-class permutation (PLAIN = true: a scene whose material table has no metal, no transmission, no thin wall, no coat and no texture)
 #define ZR_RPT_GROUP_E(X) \
     X __global__ void k_rpt_pathtrace<true, true> ZR_RPT_ARGS_TILE; X __global__ void k_rpt_pathtrace<false, true> ZR_RPT_ARGS_TILE; \
     X __global__ void k_rpt_pathtrace_w4<true, true> ZR_RPT_ARGS_TILE; X __global__ void k_rpt_pathtrace_w4<false, true> ZR_RPT_ARGS_TILE; \
@@ -674,11 +688,12 @@ __global__ void __launch_bounds__(kStcBlock) ZR_WAVES_STC k_rpt_stc(rpt::RptFram
     X __global__ void k_rpt_pathtrace_trip<false> ZR_RPT_ARGS_TILE; X __global__ void k_rpt_pathtrace_trip_w4<false> ZR_RPT_ARGS_TILE; \
     X __global__ void k_rpt_pt_first<true> ZR_RPT_ARGS_TILE; X __global__ void k_rpt_pt_first<false> ZR_RPT_ARGS_TILE; \
     X __global__ void k_rpt_pt_next<true> ZR_RPT_ARGS_TILE; X __global__ void k_rpt_pt_next<false> ZR_RPT_ARGS_TILE;
-#define ZR_RPT_REPLAY4(X, PASS) \
-    X __global__ void k_rpt_replay<PASS, true, true> ZR_RPT_ARGS_LIST; X __global__ void k_rpt_replay<PASS, true, false> ZR_RPT_ARGS_LIST; \
-    X __global__ void k_rpt_replay<PASS, false, true> ZR_RPT_ARGS_LIST; X __global__ void k_rpt_replay<PASS, false, false> ZR_RPT_ARGS_LIST;
-#define ZR_RPT_GROUP_B(X) ZR_RPT_REPLAY4(X, RPT_REPLAY_CTT)
-#define ZR_RPT_GROUP_F(X) ZR_RPT_REPLAY4(X, RPT_REPLAY_CTS)
-#define ZR_RPT_GROUP_D(X) \
-    X __global__ void k_rpt_stc<true, true, false> ZR_RPT_ARGS_TILE; X __global__ void k_rpt_stc<true, false, false> ZR_RPT_ARGS_TILE; \
-    X __global__ void k_rpt_stc<false, true, false> ZR_RPT_ARGS_TILE; X __global__ void k_rpt_stc<false, false, false> ZR_RPT_ARGS_TILE;
+// K13: the temporal pass's replays, emissive (B) / sun + sky (I) lighting; the spatial pass's (F)
+#define ZR_RPT_GROUP_B(X) \
+    X __global__ void k_rpt_replay<RPT_REPLAY_CTT, true, true> ZR_RPT_ARGS_LIST; X __global__ void k_rpt_replay<RPT_REPLAY_CTT, true, false> ZR_RPT_ARGS_LIST;
+#define ZR_RPT_GROUP_I(X) \
+    X __global__ void k_rpt_replay<RPT_REPLAY_CTT, false, true> ZR_RPT_ARGS_LIST; X __global__ void k_rpt_replay<RPT_REPLAY_CTT, false, false> ZR_RPT_ARGS_LIST;
+#define ZR_RPT_GROUP_F(X) \
+    X __global__ void k_rpt_replay<RPT_REPLAY_CTS, true, true> ZR_RPT_ARGS_LIST; X __global__ void k_rpt_replay<RPT_REPLAY_CTS, true, false> ZR_RPT_ARGS_LIST; \
+    X __global__ void k_rpt_replay<RPT_REPLAY_CTS, false, true> ZR_RPT_ARGS_LIST; X __global__ void k_rpt_replay<RPT_REPLAY_CTS, false, false> ZR_RPT_ARGS_LIST;
+#define ZR_RPT_GROUPS_PRODUCT(X) ZR_RPT_GROUP_A(X) ZR_RPT_GROUP_B(X) ZR_RPT_GROUP_D(X) ZR_RPT_GROUP_E(X) ZR_RPT_GROUP_F(X) ZR_RPT_GROUP_G(X) ZR_RPT_GROUP_H(X) ZR_RPT_GROUP_I(X)

@@ -36,7 +36,7 @@ template<bool EMISSIVE>
 __global__ void __launch_bounds__(kRptBlock) ZR_WAVES(ZR_WAVES_PATHTRACE_N) k_rpt_pt_first(rpt::RptFrame F, zr_frame_constants g, uint32_t tilesX, unsigned long long* counters)
 {
     const unsigned long long t0 = __builtin_readcyclecounter();
-    F.prm.emissive = EMISSIVE ? 1u : 0u; F.prm.textured = 0u;
+    F.prm.emissive = EMISSIVE ? 1u : 0u; F.prm.textured = 0u; rpt::SetMaterialClass(F, false);
     uint32_t tile, wave, lane; RptTileWaveLane(&tile, &wave, &lane);
     const uint32_t tx = tile % tilesX, ty = tile / tilesX;
     const uint32_t x = F.ox0 + tx * 16u + (lane & 15u), y = F.oy0 + ty * 16u + wave * 4u + (lane >> 4);
@@ -69,7 +69,7 @@ template<bool EMISSIVE>
 __global__ void __launch_bounds__(kRptBlock) ZR_WAVES(ZR_WAVES_PATHTRACE_N) k_rpt_pt_next(rpt::RptFrame F, zr_frame_constants g, uint32_t tilesX, unsigned long long* counters)
 {
     const unsigned long long t0 = __builtin_readcyclecounter();
-    F.prm.emissive = EMISSIVE ? 1u : 0u; F.prm.textured = 0u;
+    F.prm.emissive = EMISSIVE ? 1u : 0u; F.prm.textured = 0u; rpt::SetMaterialClass(F, false);
     const uint32_t n = F.carryCount[F.carryBounce - 1u];
     const uint32_t slot = blockIdx.x * kRptBlock + threadIdx.x;
     if (blockIdx.x * kRptBlock >= n) return;
@@ -96,7 +96,7 @@ template<bool NODE_CACHE>
 __device__ __forceinline__ void RptPathtraceBodyTrip(rpt::RptFrame& F, const zr_frame_constants& g, uint32_t tilesX, unsigned long long* counters)
 {
     const unsigned long long t0 = __builtin_readcyclecounter();
-    F.prm.emissive = 1u; F.prm.textured = 0u;
+    F.prm.emissive = 1u; F.prm.textured = 0u; rpt::SetMaterialClass(F, false);
     uint32_t tile, wave, lane; RptTileWaveLane(&tile, &wave, &lane);
     const uint32_t tx = tile % tilesX, ty = tile / tilesX;
     const uint32_t x = F.ox0 + tx * 16u + (lane & 15u), y = F.oy0 + ty * 16u + wave * 4u + (lane >> 4);
@@ -291,7 +291,7 @@ template<bool TEX>
 __device__ __forceinline__ void RptPathtraceBodyCoop(rpt::RptFrame& F, const zr_frame_constants& g, uint32_t tilesX, unsigned long long* counters)
 {
     const unsigned long long t0 = __builtin_readcyclecounter();
-    F.prm.emissive = 1u; F.prm.textured = TEX ? 1u : 0u;
+    F.prm.emissive = 1u; F.prm.textured = TEX ? 1u : 0u; rpt::SetMaterialClass(F, false);
     const uint32_t tile = blockIdx.x, wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
     const uint32_t tx = tile % tilesX, ty = tile / tilesX;
     const uint32_t x = F.ox0 + tx * 16u + (lane & 15u), y = F.oy0 + ty * 16u + wave * 4u + (lane >> 4);

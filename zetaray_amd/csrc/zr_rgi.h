@@ -497,17 +497,20 @@ ZR_HD void FindTemporalCandidate(const GiFrame& F, const zr_frame_constants& g, 
         if (!(zr_abs(dot(normal, prevPos - posW)) <= tolerance * viewZ)) continue;
         const V3 prevNormal = DecodeOct32u(sp == (size_t)-1 ? 0u : F.gbPrev.normal[sp]);
         const float prevRough = RoughnessOf(mrp);
-        valid[curr] = dot(prevNormal, normal) > 0.1f;
-        if (roughness < 0.5f) valid[curr] = valid[curr] && (zr_abs(prevRough - roughness) < 0.15f);
+        // (the candidate in locals, then stored to a slot chosen by a branch: indexing the two-slot arrays with `curr` keeps them in scratch memory)
+        bool ok = dot(prevNormal, normal) > 0.1f;
+        if (roughness < 0.5f) ok = ok && (zr_abs(prevRough - roughness) < 0.15f);
         float prevEta_mat = kDefaultEtaMat;
         if (pf.transmissive) prevEta_mat = DecodeIOR(zr_div255((float)(sp == (size_t)-1 ? 0 : F.gbPrev.ior[sp])));
-        valid[curr] = valid[curr] && (pf.transmissive == transmissive);
-        valid[curr] = g.dof ? true : valid[curr];
-        if (valid[curr])
+        ok = ok && (pf.transmissive == transmissive);
+        ok = g.dof ? true : ok;
+        if (curr == 0) valid[0] = ok; else valid[1] = ok;
+        if (ok)
         {
-            TemporalSampleData& d = data[curr];
+            TemporalSampleData d;
             d.px = sx; d.py = sy; d.posW = prevPos; d.normal = prevNormal; d.metallic = pf.metallic; d.roughness = prevRough;
             d.transmissive = pf.transmissive; d.eta_next = prevEta_mat;
+            if (curr == 0) data[0] = d; else data[1] = d;
             curr++;
             if (curr == 2) break;
         }
@@ -599,7 +602,7 @@ ZR_HD void TemporalResample2(const Globals& gl, const GiFrame& F, const zr_frame
 {
     uint32_t M_new = r.M;
     Reservoir r_prev[2]; size_t sp[2];
-    for (int k = 0; k < 2; k++)
+    ZR_UNROLL for (int k = 0; k < 2; k++)
     {
         sp[k] = Texel(F.gbPrev, c[k].px, c[k].py, g.render_width, g.render_height);
         r_prev[k] = PartialRead_Reuse(F.prev, sp[k]);
@@ -610,7 +613,7 @@ ZR_HD void TemporalResample2(const Globals& gl, const GiFrame& F, const zr_frame
         float denom = p_curr;
         if (Luminance(r.Lo) > 1e-5f)
         {
-            for (int p = 0; p < 2; p++)
+            ZR_UNROLL for (int p = 0; p < 2; p++)
             {
                 if (r_prev[p].M == 0) continue;
                 float targetLum_prev = TargetLumAtTemporalPixel(gl, F, g, r, c[p], p != 0);
@@ -621,7 +624,7 @@ ZR_HD void TemporalResample2(const Globals& gl, const GiFrame& F, const zr_frame
         const float m_curr = denom == 0 ? 0 : p_curr / denom;
         r.w_sum *= m_curr;
     }
-    for (int i = 0; i < 2; i++)
+    ZR_UNROLL for (int i = 0; i < 2; i++)
     {
         V3 wi = r_prev[i].pos - posW;
         float t = (wi.x == 0 && wi.y == 0 && wi.z == 0) ? 0 : length(wi);

@@ -1,3 +1,3 @@
-// zr_tu_rpt_b.hip -- translation unit of libzetaray_amd.so holding the K13 replay kernels of the temporal pass (current -> temporal neighbour; the spatial pass: zr_tu_rpt_f.hip; see zr_kernels.h)
+// zr_tu_rpt_b.hip -- translation unit of libzetaray_amd.so holding the K13 replay kernels of the temporal pass, emissive lighting (ZR_RPT_GROUP_B, zr_kernels.h)
 #include "zr_kernels.h"
 ZR_RPT_GROUP_B(template)
