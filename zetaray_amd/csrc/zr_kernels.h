@@ -637,8 +637,7 @@ __global__ void __launch_bounds__(kStcBlock) ZR_WAVES_STC k_rpt_stc(rpt::RptFram
     rpt::StcLane a;
     // The general permutation keeps the lane's two reservoirs (304 B) as an object in scratch memory: split into registers they cost it 160 - 220 spilled
     // VGPRs at its 128 (atrium: 2.72 -> 2.85 ms), whereas the PLAIN permutation, a third of the code, gains from the split (Cornell: 0.578 -> 0.539 ms).
-    // The empty asm takes the object's address, which is what keeps it whole.
-    if (!PLAIN) asm volatile("" :: "v"(&a) : "memory");
+    if (!PLAIN) ZR_KEEP_IN_MEMORY(a);
 #endif
     float v1, v2, v3, v4;
     { ZR_PROF_SCOPE(ZRP_MISC0); rpt::StcPhase0(F, g, x, y, a, v1, v2); }

@@ -29,6 +29,16 @@ static constexpr int kNeighborOffset = 32;
 // which wo-only term groups (zr_dev_bsdf.h WO_*) the reconnection shifts and replays prepare on the surfaces they evaluate two to four times.
 // K11 prepares all of them (six evaluations per bounce); the shift kernels run at 128 VGPRs, where every prepared term is a register taken
 // from the evaluation that follows -- measured on MI355X (profiles/r05_ab_*.json)
+// ZR_KEEP_IN_MEMORY(obj): the empty asm takes the object's address, which keeps it a whole object in scratch memory instead of a set of registers.
+// For state that is live across a heavy call but not used by it, in a kernel that spills anyway, the memory object is the cheaper spill (K16, zr_kernels.h).
+#if defined(__HIP_DEVICE_COMPILE__)
+#define ZR_KEEP_IN_MEMORY(obj) asm volatile("" :: "v"(&(obj)) : "memory")
+#else
+#define ZR_KEEP_IN_MEMORY(obj) ((void)0)
+#endif
+#ifndef ZR_PIN_TEMPORAL      // (A/B: 1 = the pixel's surface, 2 = the temporal neighbour's, in the general K14)
+#define ZR_PIN_TEMPORAL 0
+#endif
 #ifndef ZR_RC_MERGED_STORES
 #define ZR_RC_MERGED_STORES 0
 #endif
@@ -2159,6 +2169,8 @@ ZR_HD void ReconnectTemporalPixel(const RptFrame& F, const zr_frame_constants& g
     const bool doSpatial = F.prm.doSpatial;
     const Camera cam = CurrCamera(g);
     PixelSurface ps; TemporalPixel tp;
+    if ((ZR_PIN_TEMPORAL & 1) && !F.sc.plain) ZR_KEEP_IN_MEMORY(ps);
+    if ((ZR_PIN_TEMPORAL & 2) && !F.sc.plain) ZR_KEEP_IN_MEMORY(tp);
     {
     ZR_PROF_SCOPE(ZRP_MISC4);      // (-DZR_PROF builds: the two pixel surfaces)
     ps = LoadPixelSurface(F.gb, cam, x, y, g.frame_num, px);
