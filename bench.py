@@ -451,12 +451,13 @@ def measure(args, ctx):
             table = json.load(open(os.path.join(ROOT, pmc_rel)))
             # only a profile of THESE kernel sources describes the library that was just timed
             if table.get("_meta", {}).get("source_hash") == source_hash():
-                # kernel names as rocprofv3 prints them (template arguments: NEE_EMISSIVE, TEXTURED)
-                kmap = {"rpt_pathtrace": ["k_rpt_pathtrace<true>", "k_rpt_pathtrace_w4<true>", "k_rpt_pathtrace_coop<false>", "k_rpt_pathtrace_coop_w4<false>"],
-                        "rpt_reconnect_spatial": ["k_rpt_stc<true, false>"], "rpt_reconnect_temporal": ["k_rpt_temporal<true, false>"],
-                        "gbuffer": ["k_gbuffer"], "rgi": ["k_rgi", "k_rgi_tex", "k_rgi<false>"], "trace": ["k_trace_simple", "k_trace"], "pt_shade": ["k_pt_shade"]}
-                # the launch-count filter drops a kernel variant that only ran during warm-up
-                cands = [table[k] for k in kmap.get(dom, []) if k in table]
+                # kernel names as rocprofv3 prints them carry their template arguments (NEE_EMISSIVE, TEXTURED, PLAIN: k_rpt_pathtrace<true, true>, k_rgi<true>, ...):
+                # every permutation of the stage's kernel is a candidate ...
+                kmap = {"rpt_pathtrace": ["k_rpt_pathtrace", "k_rpt_pathtrace_w4", "k_rpt_pathtrace_tex", "k_rpt_pathtrace_coop", "k_rpt_pathtrace_coop_w4"],
+                        "rpt_reconnect_spatial": ["k_rpt_stc"], "rpt_reconnect_temporal": ["k_rpt_temporal"],
+                        "gbuffer": ["k_gbuffer"], "rgi": ["k_rgi", "k_rgi_tex"], "trace": ["k_trace_simple", "k_trace"], "pt_shade": ["k_pt_shade", "k_pt_shade_tex"]}
+                # ... and the launch-count filter drops a permutation that only ran during warm-up
+                cands = [rec_ for k, rec_ in table.items() if k != "_meta" and k.split("<")[0] in kmap.get(dom, [])]
                 rec = max(cands, key=lambda r: r.get("launches_sampled", 0)) if cands else None
                 if rec:
                     traffic, traffic_src = round(rec["traffic_bytes"]), pmc_rel
