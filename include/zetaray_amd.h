@@ -452,7 +452,10 @@ int zr_debug_set_bvh_depth_cap(uint32_t levels);
  * general kernels like every other scene; 1 (default) = they render with the PLAIN permutations of the ReSTIR PT kernels, which have no code for the
  * other lobes.  Results are identical either way (tests/test_gpu_parity.py::test_material_class_kernels_change_nothing).  Process-wide. */
 int zr_debug_set_material_class_kernels(int enable);
-/* the material class zr_scene_create / zr_scene_update_materials currently derive from the scene's material table: 1 = plain, 0 = general. */
+/* the material class zr_scene_create / zr_scene_update_materials currently derive from the scene's material table: 1 = plain, 0 = general.
+ * The lighting passes render a plain scene with the PLAIN kernel permutations once both plane sets of the G-buffer they are given were rendered (by the
+ * GBUFFER pass) while the scene was plain; an engine that fills the planes itself through zr_gbuffer_device_plane must keep their flags (metallic,
+ * transmissive, coated, ...) consistent with the material table, as the GBUFFER pass does. */
 int zr_scene_material_class(const zr_scene* scene, uint32_t* out_class);
 /* the same counters split by the kernel that issued the queries (not reset; roofline bookkeeping of bench.py) */
 int zr_pass_read_kernel_counters(zr_pass* pass, void* hip_stream, uint32_t max_entries, const char** names,

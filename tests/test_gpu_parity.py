@@ -1624,7 +1624,8 @@ def test_deferred_alias_table_rebuild_never_blocks(api):
 
 def test_material_edit_between_frames(api):
     """SceneCore::UpdateMaterial: at frame 3 every non-emissive material of the Cornell box turns into a rough metal with another base colour
-    (zr_scene_update_materials); G-buffer, ReSTIR PT and ReSTIR DI equal the oracle's before and after (temporal reuse across the edit included)."""
+    (zr_scene_update_materials), at frame 5 the original materials return; G-buffer, ReSTIR PT and ReSTIR DI equal the oracle's before and after
+    (temporal reuse across the edits included; the material class goes plain -> general -> plain, the kernels PLAIN -> general at frame 3 -> PLAIN at frame 6)."""
     from oracle import zro
     sc = scene_io.load_npz(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "cornell_emissive.npz"))
     w, h = 96, 64
@@ -1634,13 +1635,25 @@ def test_material_edit_between_frames(api):
     osc = zro.OracleScene(sc)
     opt, odi = zro.OracleRPT(osc, w, h), zro.OracleRDI(osc, w, h)
     imgs = []
-    for f in range(1, 5):
+    original = sc.materials.copy()
+    for f in range(1, 8):
+        if f == 5:
+            # ... and back: the scene is of the plain class again, but frame 5's temporal reuse reads frame 4's G-buffer, whose pixels carry the metals' flags --
+            # the pass keeps the general kernels for that frame (zr_gbuffer tracks the class each plane set was rendered under) and returns to the PLAIN ones at frame 6
+            sc.materials[:] = original
+            r.scene.update_materials(original, 0); osc.update_materials(original, 0)
+            assert r.scene.material_class() == 1
         if f == 3:
             mats = sc.materials.copy()
             for i in range(1, len(mats)):
                 if int(mats[i]["emissive_factor_normal_scale"]) & 0xFFFFFF:
                     continue      # the light keeps its material (its power enters the alias table)
-                mats[i] = scene_io.pack_material(base_color=(0.2 + 0.1 * (i % 5), 0.7, 0.3, 1.0), metallic=1.0, roughness=0.35)
+                if i % 2:
+                    mats[i] = scene_io.pack_material(base_color=(0.2 + 0.1 * (i % 5), 0.7, 0.3, 1.0), metallic=1.0, roughness=0.35)
+                else:
+                    # the metal bit alone, roughness kept: the temporal passes' similarity tests (roughness, transmission) still accept the pixel across the edit,
+                    # so the frames after each edit shift samples onto surfaces of the OTHER material class (what the G-buffer's class tracking is for)
+                    mats[i]["coat_color_flags"] |= np.uint32(1 << 24)
             sc.materials[:] = mats
             assert r.scene.material_class() == 1      # frames 1-2 ran the PLAIN kernel permutations ...
             r.scene.update_materials(mats, 0); osc.update_materials(mats, 0)

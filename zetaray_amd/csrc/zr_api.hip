@@ -674,6 +674,9 @@ struct zr_gbuffer
     // `cur`; the other set is the previous frame's G-buffer that the temporal passes of ReSTIR read
     DevBuf<uint8_t> planeSets[2][ZR_GB_COUNT];
     int cur = 0; uint64_t numRendered = 0;
+    // the scene's material class (zr_scene::plainMaterials) at the time each plane set was rendered: the PLAIN kernel permutations take a pixel's flags as known,
+    // so both the current and the previous frame's planes must come from a plain material table (a scene that BECAME plain renders one more frame with the general kernels)
+    bool plainAt[2] = {true, true};
     DevBuf<uint8_t>* Planes() { return planeSets[cur]; }
     const DevBuf<uint8_t>* Planes() const { return planeSets[cur]; }
     GBuf View() const { return ViewOf(cur); }
@@ -730,7 +733,8 @@ static constexpr uint32_t kLargeSceneNodes = 16384;     // BVH4 nodes (64 B each
 static std::atomic<uint32_t> g_largeSceneNodes{kLargeSceneNodes};
 static std::atomic<bool> g_materialClassKernels{true};      // zr_debug_set_material_class_kernels: plain scenes run the PLAIN kernel permutations
 // the PLAIN kernel permutations apply: the scene's material table is of the plain class (and has no texture heap)
-static bool PlainClass(const zr_scene* sc) { return sc->plainMaterials.load(std::memory_order_relaxed) && g_materialClassKernels.load(std::memory_order_relaxed); }
+static bool PlainClass(const zr_scene* sc, const zr_gbuffer* gb)
+{ return sc->plainMaterials.load(std::memory_order_relaxed) && gb->plainAt[0] && gb->plainAt[1] && g_materialClassKernels.load(std::memory_order_relaxed); }
 static constexpr int kMaxRounds = 16;
 static constexpr int kMaxTimers = 64;
 // ray-counter slots (pairs of u64 on the device): 0 = wavefront path tracer, 1.. = ReSTIR PT kernels in launch order
@@ -1965,6 +1969,7 @@ static int RenderGBuffer(zr_pass* p, hipStream_t s, const zr_frame_constants* cb
     if (gb->x0 + gb->w > cb->render_width || gb->y0 + gb->h > cb->render_height) return Fail(ZR_ERR_INVALID_ARG, "gbuffer tile lies outside the render target of the frame constants");
     const uint32_t tilesX = (gb->w + 15) / 16, tilesY = (gb->h + 15) / 16;
     gb->cur ^= 1; gb->numRendered++;
+    gb->plainAt[gb->cur] = sc->plainMaterials.load(std::memory_order_relaxed);
     TimerBegin(p, s, "gbuffer");
     uint32_t pickXY = 0xffffffffu;
     if (p->pickXY != 0xffffffffu)
@@ -2162,7 +2167,7 @@ static int RenderDirectEmissive(zr_pass* p, hipStream_t s, const zr_frame_consta
     prm.writeReservoirs = (prm.doTemporal || !p->temporalValid) ? 1u : 0u;
     const uint32_t tilesX = (F.ow + 15) / 16, tilesY = (F.oh + 15) / 16;
     const dim3 grid(tilesX * tilesY), block(kBlock);
-    const bool plainDi = PlainClass(sc);
+    const bool plainDi = PlainClass(sc, gb);
     if (stages & ZR_STAGE_TEMPORAL)
     {
         TimerBegin(p, s, "rdi_temporal");
@@ -2206,7 +2211,7 @@ static int RenderDirectSky(zr_pass* p, hipStream_t s, const zr_frame_constants* 
     prm.writeReservoirs = (prm.doTemporal || !p->temporalValid) ? 1u : 0u;
     const uint32_t tilesX = (F.ow + 15) / 16, tilesY = (F.oh + 15) / 16;
     const dim3 grid(tilesX * tilesY), block(kBlock);
-    const bool plainDi = PlainClass(sc);
+    const bool plainDi = PlainClass(sc, gb);
     if (stages & ZR_STAGE_TEMPORAL)
     {
         TimerBegin(p, s, "sdi_temporal");
@@ -2250,7 +2255,7 @@ static int RenderReSTIR_GI(zr_pass* p, hipStream_t s, const zr_frame_constants* 
     if (prm.useLVG && !sc->view.lvg) return Fail(ZR_ERR_NOT_INITIALIZED, "light voxel grid missing: render the PRELIGHTING pass with use_lvg first");
     const uint32_t tilesX = (F.ow + 15) / 16, tilesY = (F.oh + 15) / 16;
     TimerBegin(p, s, "rgi");
-    hipLaunchKernelGGL(sc->view.tex.count ? k_rgi_tex : PlainClass(sc) ? k_rgi<true> : k_rgi<false>, dim3(tilesX * tilesY * (256 / kRgiBlock)), dim3(kRgiBlock), 0, s, F, *cb, tilesX, p->counters.p + 2 * 10);
+    hipLaunchKernelGGL(sc->view.tex.count ? k_rgi_tex : PlainClass(sc, gb) ? k_rgi<true> : k_rgi<false>, dim3(tilesX * tilesY * (256 / kRgiBlock)), dim3(kRgiBlock), 0, s, F, *cb, tilesX, p->counters.p + 2 * 10);
     TimerEnd(p, s);
     HIP_TRY(hipGetLastError());
     p->temporalValid = true;
@@ -2340,7 +2345,7 @@ static int RenderReSTIR_PT(zr_pass* p, hipStream_t s, const zr_frame_constants* 
     // ... and the TEXTURED permutation (this ABI's: untextured scenes carry no ray differentials)
     const bool texVariant = prm.textured != 0;
     // ... and the material-class permutation (zr_kernels.h PLAIN): scenes of opaque uncoated non-metallic dielectrics without a texture heap run kernels that have no code for the other lobes
-    const bool plainVariant = PlainClass(sc) && !texVariant;
+    const bool plainVariant = PlainClass(sc, gb) && !texVariant;
 #define RPT_LAUNCH_E(kern, ...) do { \
         if (plainVariant) { if (emissiveVariant) hipLaunchKernelGGL((kern<true, false, true>), __VA_ARGS__); else hipLaunchKernelGGL((kern<false, false, true>), __VA_ARGS__); } \
         else if (emissiveVariant) { if (texVariant) hipLaunchKernelGGL((kern<true, true, false>), __VA_ARGS__); else hipLaunchKernelGGL((kern<true, false, false>), __VA_ARGS__); } \
@@ -2495,7 +2500,7 @@ static int RenderIndirect(zr_pass* p, hipStream_t s, const zr_frame_constants* c
     SceneView scv = FrameView(sc, cb);
     scv.texFilter = p->params.tex_filter;
     const bool tex = scv.tex.count != 0;      // kernels carry ray differentials only when there is a texture heap
-    const bool plainPt = PlainClass(sc);
+    const bool plainPt = PlainClass(sc, gb);
     if (tex) { int r; if ((r = p->q[0].AllocTex((size_t)p->w * p->h)) || (r = p->q[1].AllocTex((size_t)p->w * p->h))) return r; }
     TimerBegin(p, s, "pt_init");
     hipLaunchKernelGGL((tex ? k_pt_init<true, false> : plainPt ? k_pt_init<false, true> : k_pt_init<false, false>), dim3(tilesX * tilesY), dim3(kBlock), 0, s, scv, *cb, gbv, prm, p->finalRGBA.p, p->firstBOP.p,

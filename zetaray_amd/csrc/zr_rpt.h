@@ -39,9 +39,6 @@ static constexpr int kNeighborOffset = 32;
 #ifndef ZR_PIN_TEMPORAL      // (A/B: 1 = the pixel's surface, 2 = the temporal neighbour's, in the general K14)
 #define ZR_PIN_TEMPORAL 0
 #endif
-#ifndef ZR_RC_MERGED_STORES
-#define ZR_RC_MERGED_STORES 0
-#endif
 #ifndef ZR_PREP_SHIFT
 #define ZR_PREP_SHIFT 1
 #endif
@@ -357,13 +354,6 @@ struct Reservoir
         rc.x_k_in_motion = (mz >> 2) != 0;
         M = mx >> 4;
     }
-#if ZR_RC_MERGED_STORES      // (A/B: the form the compiler turns into stores through a selected address)
-#define ZR_RC_SET(field, value) rc.field = (value)
-#define ZR_RC_COMMIT (void)meshIdx_, (void)seed_nee_
-#else
-#define ZR_RC_SET(field, value) field##_ = (value)
-#define ZR_RC_COMMIT rc.meshIdx = meshIdx_, rc.seed_nee = seed_nee_
-#endif
     // LoadCase1/2/3<Emissive> (Reservoir.hlsli:47-139)
     ZR_HDM void Load_Reconnection(const ResPlanes& p, size_t i, bool emissive)
     {
@@ -377,31 +367,31 @@ struct Reservoir
             if (rc.IsCase2())
             {
                 rc.x_k = v3(zr_asfloat(c.w), zr_asfloat(d.x), zr_asfloat(d.y));
-                if (rc.lt_k_plus_1 == LT_SKY) { rc.w = DecodeOct32u(d.z); ZR_RC_SET(seed_nee, d.w); }
-                ZR_RC_SET(meshIdx, p.G[2 * i + 1]);
+                if (rc.lt_k_plus_1 == LT_SKY) { rc.w = DecodeOct32u(d.z); seed_nee_ = d.w; }
+                meshIdx_ = p.G[2 * i + 1];
             }
-            else if (rc.lt_k == LT_SKY) { rc.w = DecodeOct32u(d.z); ZR_RC_SET(seed_nee, d.w); }
-            ZR_RC_COMMIT;
+            else if (rc.lt_k == LT_SKY) { rc.w = DecodeOct32u(d.z); seed_nee_ = d.w; }
+            rc.meshIdx = meshIdx_; rc.seed_nee = seed_nee_;
             return;
         }
         rc.seed_replay = c.y; rc.ID = c.z;
         rc.x_k = v3(zr_asfloat(c.w), zr_asfloat(d.x), zr_asfloat(d.y));
         rc.w = DecodeOct32u(d.z);
         rc.L = v3(zr_f16_to_f32((uint16_t)(d.w & 0xffff)), zr_f16_to_f32((uint16_t)(d.w >> 16)), zr_f16_to_f32(p.E[i]));
-        if (rc.IsCase1()) { rc.partialJacobian = zr_asfloat(c.x); ZR_RC_SET(meshIdx, p.G[2 * i + 1]); }
+        if (rc.IsCase1()) { rc.partialJacobian = zr_asfloat(c.x); meshIdx_ = p.G[2 * i + 1]; }
         else if (rc.IsCase2())
         {
             rc.partialJacobian = zr_asfloat(c.x);
             rc.lightPdf = p.F[2 * i]; rc.dwdA = p.F[2 * i + 1];
-            ZR_RC_SET(seed_nee, p.G[2 * i]); ZR_RC_SET(meshIdx, p.G[2 * i + 1]);
+            seed_nee_ = p.G[2 * i]; meshIdx_ = p.G[2 * i + 1];
         }
         else
         {
             rc.partialJacobian = rc.lobe_k_min_1 == LOBE_ALL ? 1.0f : zr_asfloat(c.x);
             rc.lightPdf = p.F[2 * i];
-            ZR_RC_SET(seed_nee, c.x);
+            seed_nee_ = c.x;
         }
-        ZR_RC_COMMIT;
+        rc.meshIdx = meshIdx_; rc.seed_nee = seed_nee_;
     }
     static ZR_HDM uint32_t PackA_x(const Reconnection& rc, uint32_t m)
     { uint32_t k = rc.Empty() ? rc.k : (rc.k > 2 ? rc.k : 2) - 2; return k | (m << 4); }
@@ -1996,12 +1986,8 @@ ZR_HD_FLAT OffsetPath Shift2(const Globals& g, bool currFrame, size_t DTidIdx, V
     {
         const uint32_t lt = rc.IsCase2() ? rc.lt_k_plus_1 : rc.lt_k;
         // (both fields read, then selected: a load through a selected ADDRESS keeps a whole reservoir in scratch memory -- SROA gives up on the object)
-#if ZR_RC_MERGED_STORES
-        const uint32_t lobe = rc.IsCase2() ? rc.lobe_k : rc.lobe_k_min_1;
-#else
         const uint32_t lobe_a = rc.lobe_k, lobe_b = rc.lobe_k_min_1;
         const uint32_t lobe = rc.IsCase2() ? lobe_a : lobe_b;
-#endif
         float pdf;
         const V3 target = EstimateDirect_y_k_min_1(g, ctx, lt, rc.w, lobe, rngNEE, pdf);
         ret.target = ctx.throughput * target;
