@@ -85,6 +85,71 @@ def source_hash():
     return h.hexdigest()[:16]
 
 
+_SMI_SNIPPET = r"""
+import json, sys
+out = {}
+try:
+    import amdsmi as A
+    A.amdsmi_init()
+    hs = A.amdsmi_get_processor_handles()
+    h = hs[min(int(sys.argv[1]), len(hs) - 1)]
+    def grab(name, fn):
+        try:
+            v = fn()
+            out[name] = v if isinstance(v, (int, float, str, list, dict, type(None))) else str(v)
+        except Exception as e:
+            out[name] = "n/a: " + type(e).__name__
+    grab("sclk", lambda: A.amdsmi_get_clock_info(h, A.AmdSmiClkType.SYS))
+    grab("mclk", lambda: A.amdsmi_get_clock_info(h, A.AmdSmiClkType.MEM))
+    grab("fclk", lambda: A.amdsmi_get_clock_info(h, A.AmdSmiClkType.DF))
+    grab("socclk", lambda: A.amdsmi_get_clock_info(h, A.AmdSmiClkType.SOC))
+    grab("power_cap", lambda: A.amdsmi_get_power_cap_info(h))
+    grab("power", lambda: A.amdsmi_get_power_info(h))
+    grab("perf_level", lambda: A.amdsmi_get_gpu_perf_level(h))
+    grab("memory_partition", lambda: A.amdsmi_get_gpu_memory_partition(h))
+    grab("compute_partition", lambda: A.amdsmi_get_gpu_compute_partition(h))
+    grab("activity", lambda: A.amdsmi_get_gpu_activity(h))
+    A.amdsmi_shut_down()
+except Exception as e:
+    out["error"] = repr(e)[:200]
+print(json.dumps(out, default=str))
+"""
+
+
+def device_state(api, device, min_ms=60.0):
+    """What the device of this process delivers right now: static properties + the copy / FMA / shader-clock probes of zr_device_probe_run (measured here,
+    before the timed region) + what amdsmi reports about clocks, power cap and partition modes (a child process with a timeout: the bench line must
+    not depend on the management library being usable by an ordinary user).  VERDICT r5: the same command ran 18 % apart on two boxes of the pool."""
+    import ctypes as C
+    import subprocess
+
+    class Probe(C.Structure):
+        _fields_ = [("name", C.c_char * 64), ("arch", C.c_char * 32), ("compute_units", C.c_uint32), ("clock_khz_max", C.c_uint32),
+                    ("mem_clock_khz_max", C.c_uint32), ("mem_bus_bits", C.c_uint32), ("l2_bytes", C.c_uint32), ("wall_clock_khz", C.c_uint32),
+                    ("hbm_bytes", C.c_uint64), ("copy_GBs", C.c_float), ("copy_ms", C.c_float), ("fma_tflops", C.c_float), ("fma_ms", C.c_float),
+                    ("sclk_mhz_under_load", C.c_float)]
+    L = api.lib()
+    pr = Probe()
+    L.zr_device_probe_run.argtypes = [C.c_int, C.c_float, C.c_void_p]
+    rc = L.zr_device_probe_run(int(device), float(min_ms), C.byref(pr))
+    if rc != 0:
+        return {"error": L.zr_last_error().decode(errors="replace")}
+    st = {"name": pr.name.decode(errors="replace"), "arch": pr.arch.decode(errors="replace"), "compute_units": pr.compute_units,
+          "clock_mhz_max": pr.clock_khz_max / 1e3, "mem_clock_mhz_max": pr.mem_clock_khz_max / 1e3, "mem_bus_bits": pr.mem_bus_bits,
+          "l2_MiB": round(pr.l2_bytes / 2**20, 2), "hbm_GiB": round(pr.hbm_bytes / 2**30, 1),
+          "probe_copy_GBs": round(pr.copy_GBs, 1), "probe_copy_ms": round(pr.copy_ms, 1),
+          "probe_fma_tflops": round(pr.fma_tflops, 2), "probe_fma_ms": round(pr.fma_ms, 1),
+          "probe_sclk_mhz_under_load": round(pr.sclk_mhz_under_load, 1),
+          "probe_note": "copy = device-to-device hipMemcpyAsync of 512 MiB, read + written bytes per second; fma = fp32 v_fma_f32 issue rate with 8 waves per SIMD on "
+                        "every CU (2 flops per FMA); sclk = shader-clock counter over the 100 MHz wall clock inside the FMA kernel"}
+    try:
+        cp = subprocess.run([sys.executable, "-c", _SMI_SNIPPET, str(device)], capture_output=True, text=True, timeout=30)
+        st["smi"] = json.loads(cp.stdout.strip().splitlines()[-1])
+    except Exception as e:
+        st["smi"] = {"error": repr(e)[:200]}
+    return st
+
+
 def cpu_baseline(scene_host, cb, max_rays=1_000_000, rpt_params=None, sample=(2, 8)):
     """Single-thread CPU traversal (oracle BVH2 + ABI intersection) over primary + diffuse-bounce rays of this frame."""
     from oracle import zro
@@ -241,20 +306,34 @@ def measure(args, ctx):
             else:
                 layout_kind = "equal-area grid (the probe frames' cost map predicts < 15 % gain from re-balancing)"
         x0, y0, tw, th = tiled.tile
+    elif args.di_only and world > 1:
+        # BASELINE config 2 on N devices: the DI pass is the pass whose reservoirs cross tile borders (TEMPORAL stage -> exchange ZR_HALO_POST_TEMPORAL -> SPATIAL
+        # stage, 24 / 13 B per pixel; tiling.TiledRestirPT kind "di" / "sky_di", tests/test_gpu_parity.py::test_tile_split_with_halo_exchange_other_passes_on_gpu)
+        from zetaray_amd import tiling
+        assert not rpt and (args.direct != args.sky_direct), "--di-only with N > 1 takes exactly one of --direct / --sky-direct"
+        transport = os.environ.get("ZR_HALO_TRANSPORT", "rccl_cpp")
+        if args.direct:
+            dip = wire.default_params_di()
+            dip.presampling, dip.num_sample_sets, dip.sample_set_size = prm.presampling, prm.num_sample_sets, prm.sample_set_size
+        else:
+            dip = wire.default_params_sky_di()
+        tiled = tiling.TiledRestirPT(sc, W, H, world, rank, device=local_rank, params=prm, dist=dist, kind="di" if args.direct else "sky_di", pass_params=dip, transport=transport)
+        r = tiled.r
+        x0, y0, tw, th = tiled.tile
     else:
         r = api.Renderer(sc, tw, th, device=local_rank, params=prm, tile_origin=(x0, y0), integrator=api.INTEGRATOR_PATH_TRACING)
 
-    if args.direct:
-        assert world == 1, "--direct: the DI pass has no tile split yet"
+    if args.direct and r.p_direct is None:
+        assert world == 1, "--direct next to an indirect integrator has no tile split (only --di-only shards the DI pass)"
         dip = wire.default_params_di()
         dip.presampling, dip.num_sample_sets, dip.sample_set_size = prm.presampling, prm.num_sample_sets, prm.sample_set_size
         r.enable_direct(dip, device=local_rank)
 
-    if args.sky_direct:
-        assert world == 1, "--sky-direct: the sky DI pass has no tile split yet"
+    if args.sky_direct and r.p_sky_direct is None:
+        assert world == 1, "--sky-direct next to an indirect integrator has no tile split (only --di-only shards the DI pass)"
         r.enable_sky_direct(wire.default_params_sky_di(), device=local_rank)
     if args.di_only:
-        assert world == 1 and not rpt and (args.direct or args.sky_direct), "--di-only needs --integrator pt and a DI pass"
+        assert not rpt and (args.direct or args.sky_direct), "--di-only needs --integrator pt and a DI pass"
         r.skip_indirect = True
     di_passes = [q for q in (r.p_direct, r.p_sky_direct) if q is not None]
     p_denoise = None
@@ -281,8 +360,30 @@ def measure(args, ctx):
     # steady state first: the ray count per frame grows until the temporal reservoirs sit at their M caps (7.98 M rays / frame after 5
     # frames against 8.74 M after 64 on the Cornell box), so a short --warmup must not change the reported rate
     settle = args.settle if args.settle is not None else (32 if (rpt or args.integrator == "restir_gi" or di_passes) else 0)
+    # the device as it is right now, measured before anything is timed (every rank probes its own device; rank 0's block goes on the line as `device_state`,
+    # N > 1 adds one summary row per rank)
+    dev_state = device_state(api, local_rank) if not args.no_device_state else None
+    barrier()
+    t_s = time.perf_counter()
     for i in range(settle):
         frame(1 + i)
+    barrier()
+    t_settle = time.perf_counter() - t_s
+    # clock ramp: real frames of this workload until >= args.ramp_s seconds of them have run back to back (a 44 ms timed region after 80 ms of
+    # warm-up measures the governor as much as the code).  Every rank renders the same number of frames (the halo exchange is collective).
+    ramp = 0
+    if args.ramp_s > 0:
+        per_frame = t_settle / settle if settle else None
+        if per_frame is None:
+            barrier(); t_s = time.perf_counter(); frame(1 + settle); barrier(); per_frame = time.perf_counter() - t_s
+        ramp = int(min(4000, max(0, np.ceil(args.ramp_s / max(per_frame, 1e-5)))))
+        if dist is not None:
+            tr = torch.tensor([ramp], dtype=torch.int64, device=cdev)
+            dist.all_reduce(tr, op=dist.ReduceOp.MAX)
+            ramp = int(tr.item())
+        for i in range(ramp):
+            frame(1 + settle + i)
+    settle += ramp
     for i in range(args.warmup):
         frame(1 + settle + i)
     barrier()
@@ -348,12 +449,46 @@ def measure(args, ctx):
                        f"rank per exchange, {exch_per_frame:g} exchanges per frame (the previous frame's final reservoirs are fetched only by frames whose reprojection can cross a tile border: not while camera and scene stand still)"
                        if (tiled is not None and world > 1) else "") + ("; every rank's FINAL tile stays on its device (no gather inside the timed region)" if world > 1 else ""),
                    "halo_transport": (tiled.transport if (tiled is not None and world > 1) else None),
-                   "preset": args.config, "settle_frames": settle, "arith": args.arith, "library": os.path.basename(api.LIB_PATH),
+                   "preset": args.config, "settle_frames": settle - ramp, "ramp_frames": ramp, "arith": args.arith, "library": os.path.basename(api.LIB_PATH),
+                   # which permutation of the ReSTIR kernels this scene ran (zr_kernels.h PLAIN: scenes whose material table has no metal, transmission, thin
+                   # wall, coat or texture run kernels without code for those lobes; one such material anywhere and the frame runs the general kernels)
+                   "kernel_class": ("plain" if (r.scene.material_class() == 1 and not args.textured and args.kernel_class != "general") else "general"),
                    "rays_per_frame": round((n_closest + n_shadow) / args.steps, 1),
                    "redundant_apron_primary_rays_per_frame": round(apron_rays / args.steps, 1),
                    "fps": round(1e3 / ms_per_step, 2)},
     }
 
+    if dev_state is not None:
+        out["device_state"] = dev_state
+        if dist is not None:
+            # first contact with a multi-GPU node: one row per rank -- device index, name, the three probes -- so that a slow or misplaced rank is visible in the line
+            row = {"rank": rank, "device": local_rank, "name": dev_state.get("name"), "copy_GBs": dev_state.get("probe_copy_GBs"), "fma_tflops": dev_state.get("probe_fma_tflops"),
+                   "sclk_mhz": dev_state.get("probe_sclk_mhz_under_load"), "error": dev_state.get("error")}
+            rows = [None] * world
+            dist.all_gather_object(rows, row)
+            out["device_state"]["ranks"] = rows
+    if world == 1 and (rpt or args.integrator == "restir_gi") and out["config"]["kernel_class"] == "plain" and not args.no_general_kernels:
+        # the same frames on the GENERAL kernel permutations (zr_debug_set_material_class_kernels(0): what this scene would run with one glass sphere in it),
+        # same protocol: a few frames to settle, then args.steps frames between two barriers.  Results are identical (test_material_class_kernels_change_nothing)
+        L = api.lib()
+        L.zr_debug_set_material_class_kernels(0)
+        try:
+            for i in range(max(args.warmup, 8)):
+                frame(3000 + i)
+            barrier()
+            t1 = time.perf_counter()
+            for i in range(args.steps):
+                frame(3100 + i)
+            barrier()
+            out["general_kernels"] = {"kernel_class": "general", "ms_per_step": round((time.perf_counter() - t1) / args.steps * 1e3, 4), "steps": args.steps,
+                                      "note": "the same scene and frames with the material-class permutations switched off (zr_debug_set_material_class_kernels(0)); bit-identical output"}
+        finally:
+            L.zr_debug_set_material_class_kernels(1)
+        for i in range(4):      # back on the PLAIN kernels before the per-kernel timing below
+            frame(3200 + i)
+        barrier()
+        r.p_gbuffer.read_counters(reset=True)
+        r.p_indirect.read_counters(reset=True)
     if os.environ.get("ZR_K11") == "trip" and rpt and world == 1:
         # diagnostic build of K11: lanes alive at its bounce boundaries; the timings of this run mean nothing
         a, b, wds = r.p_indirect.debug_trip_stats()
@@ -477,13 +612,41 @@ def measure(args, ctx):
                            "valu": valu,
                            "avg_launch_ms": round(avg_ms, 4), "launches_per_frame": launches / nfr,
                            "frame_model_GBs": round(frame_bytes / (ms_per_step * 1e-3) / 1e9, 2),
-                           "kernel_ms_per_frame": {k: round(v[0] / nfr, 4) for k, v in agg.items()}}
+                           "kernel_ms_per_frame": {k: round(v[0] / nfr, 4) for k, v in agg.items()},
+                           "kernel_ms_note": f"hipEvent pairs around every launch over {nfr} frames rendered one at a time AFTER the timed region; the events and the per-frame "
+                                             "synchronisation make that pass a few per cent slower than the untimed frames ms_per_step is measured on, so the sum may exceed it"}
         if not args.no_cpu_baseline:
             cbf = scene_io.make_frame_constants(W, H, frame_num=1, num_emissives=len(sc.emissives), **cam)
             if tex_offsets is not None:
                 scene_io.set_texture_heap_offsets(cbf, tex_offsets)
             out["cpu_baseline"] = cpu_baseline(sc, cbf, rpt_params=prm if rpt else None, max_rays=1_000_000 if args.scene != "synthetic" else 200_000,
                                                sample=(2, 8) if args.scene != "synthetic" else (4, 4))
+    if world > 1 and tiled is not None:
+        # ---- first contact with a multi-GPU node (a run nobody can debug afterwards): every rank reports where it ran, what it sends and how long ONE halo
+        # exchange takes on its own (8 back-to-back exchanges of the planes as they stand -- idempotent -- between two barriers)
+        post, _final = tiled.EXCHANGES[tiled.kind]
+        which = api.HALO_POST_TEMPORAL if post else api.HALO_FINAL
+        exch_ms, exch_err = None, None
+        try:
+            barrier()
+            t1 = time.perf_counter()
+            for _ in range(8):
+                tiled.exchange(which)
+            barrier()
+            exch_ms = round((time.perf_counter() - t1) / 8 * 1e3, 4)
+            tiled.exchanges_done -= 8
+        except Exception as e:      # the line must not die over an annotation
+            exch_err = repr(e)[:200]
+        try:
+            rccl = ".".join(str(v) for v in torch.cuda.nccl.version()) if dist.get_backend() == "nccl" else None
+        except Exception:
+            rccl = None
+        row = {"rank": rank, "device": local_rank, "tile": list(tiled.tile), "halo_bytes_sent_per_exchange": int(tiled.halo_bytes), "halo_bytes_per_pixel": int(tiled.bpp),
+               "peers": len(tiled.plan), "transport": tiled.transport, "exchange_ms": exch_ms, "exchange_error": exch_err}
+        rows = [None] * world
+        dist.all_gather_object(rows, row)
+        out["multi_gpu"] = {"backend": dist.get_backend(), "rccl_version": rccl, "communicator_size": dist.get_world_size(), "exchanges_per_frame": exch_per_frame,
+                            "halo_pass": tiled.kind, "ranks": rows}
     if world > 1 and tiled is not None and rpt:
         # ---- N > 1: the fraction of the HBM roofline of the whole job (north_star: "at 1 / 2 / 4 / 8 GPUs ... as fraction of the HBM roofline").  Every rank
         # times the metric's kernel (K11) on its tile with the library's hipEvents over a few frames; achieved = the ranks' algorithmic bytes per launch
@@ -556,6 +719,12 @@ def main():
     ap.add_argument("--config", choices=sorted(CONFIGS), default=None,
                     help="BASELINE.json configuration presets (same JSON line; the default without --config is the metric's own configuration, "
                          "Cornell (emissive) 1920x1080 ReSTIR PT): " + "; ".join(f"{k} = {v[0]}" for k, v in sorted(CONFIGS.items())))
+    ap.add_argument("--ramp-s", type=float, default=0.6,
+                    help="seconds of back-to-back frames of the workload rendered before --warmup so that the device's clocks have ramped (0 = none)")
+    ap.add_argument("--no-device-state", action="store_true", help="skip the device_state block (zr_device_probe_run + amdsmi)")
+    ap.add_argument("--no-general-kernels", action="store_true", help="skip the general-kernel timing of a plain-class scene (general_kernels)")
+    ap.add_argument("--kernel-class", choices=["auto", "general"], default="auto",
+                    help="general = run a plain-class scene on the general kernel permutations (zr_debug_set_material_class_kernels(0)) for the whole run")
     ap.add_argument("--settle", type=int, default=None,
                     help="untimed frames rendered BEFORE the warm-up so that the temporal reservoirs have reached their M caps whatever --warmup is "
                          "(default: 32 for the ReSTIR integrators, 0 otherwise)")
@@ -610,6 +779,8 @@ def main():
     cdev = "cpu" if (dist is not None and dist.get_backend() == "gloo") else "cuda"      # where the few scalars of the timing protocol are reduced
 
     ctx = dict(world=world, rank=rank, local_rank=local_rank, dist=dist, cdev=cdev)
+    if args.kernel_class == "general":
+        api.lib().zr_debug_set_material_class_kernels(0)
     out = measure(args, ctx)
     default_line = (args.config is None and world == 1 and args.scene.endswith("cornell_emissive.npz") and args.integrator == "restir_pt"
                     and (args.width, args.height) == (1920, 1080) and not (args.direct or args.sky_direct or args.denoise or args.di_only or args.textured))
@@ -641,7 +812,7 @@ def main():
         if os.path.exists(fast_lib):
             import subprocess
             try:
-                cp = subprocess.run([sys.executable, os.path.abspath(__file__), "--arith", "fast", "--no-extra-workloads", "--no-cpu-baseline",
+                cp = subprocess.run([sys.executable, os.path.abspath(__file__), "--arith", "fast", "--no-extra-workloads", "--no-cpu-baseline", "--no-device-state", "--no-general-kernels",
                                      "--steps", str(args.steps), "--warmup", str(args.warmup)], capture_output=True, text=True, timeout=600)
                 o3 = json.loads([l for l in cp.stdout.splitlines() if l.startswith("{")][-1])
                 out["tolerance_mode"] = {"arith": "fast", "library": o3["config"]["library"], "ms_per_step": o3["ms_per_step"], "value": o3["value"], "unit": o3["unit"],

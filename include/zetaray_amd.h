@@ -256,6 +256,20 @@ typedef struct zr_counters {
 int         zr_abi_version(void);
 const char* zr_last_error(void);
 int         zr_device_count(int* count);
+/* What the device delivers right now, measured on it (round 6; no reference counterpart -- the reference reads adapter properties through DXGI,
+   Source/ZetaCore/Core/Device.cpp, and never times the adapter): static properties + three probes of >= min_ms milliseconds each (<= 0: 50 ms):
+   a device-to-device copy (HBM side, read + written bytes per second), an fp32 FMA issue-rate kernel that fills every SIMD (VALU side), and the shader
+   clock the probe's waves actually ran at (shader-clock counter over the constant-rate wall clock).  bench.py prints it as `device_state` before its
+   timed region, so that a frame time can be told apart from the box it was measured on.  Waits for the device; ~0.2 s. */
+typedef struct zr_device_probe {
+    char     name[64], arch[32];
+    uint32_t compute_units, clock_khz_max, mem_clock_khz_max, mem_bus_bits, l2_bytes, wall_clock_khz;
+    uint64_t hbm_bytes;
+    float    copy_GBs, copy_ms;              /* device-to-device copy: (read + written) GB/s, device time spent */
+    float    fma_tflops, fma_ms;             /* fp32 FMA rate over all CUs (2 flops per FMA), device time spent */
+    float    sclk_mhz_under_load;            /* shader clock during the FMA probe */
+} zr_device_probe;
+int         zr_device_probe_run(int device, float min_ms, zr_device_probe* out);
 /* Self-description of the wire formats of zr_wire.h for binding generators and layout checks: one line per struct ("Name size") and per
    field ("Name.Field offset size"), spelled with the REFERENCE's struct / field names (Vertex.h, RtCommon.h, Material.h, FrameConstants.h).
    The test-suite compares this text with offsetof() of the reference's own headers compiled in place (oracle/_ref, tests/test_ref_pins.py).
@@ -369,6 +383,14 @@ int zr_pass_render(zr_pass* pass, void* hip_stream, const zr_frame_constants* cb
 /* ReSTIR PT with zr_params.num_spatial_passes = 2 on tiles: the second search / sort / replay / reconnect round as its own stage, with one more exchange of
    ZR_HALO_POST_TEMPORAL (the set the next stage reads) before it; zr_pass_render runs both rounds.  A no-op for every other pass / setting. */
 #define ZR_STAGE_SPATIAL2 4
+/* ReSTIR PT: the TEMPORAL stage in its two halves (ZR_STAGE_TEMPORAL == both; other passes ignore the bits).
+     ZR_STAGE_CANDIDATES      K11 alone: this frame's initial candidates (ReSTIR_PT_PathTrace.hlsl).  Reads only this frame's G-buffer and the scene;
+                              writes the "current" reservoir set and the target plane.
+     ZR_STAGE_TEMPORAL_REUSE  K12 - K14: Sort_TtC / Sort_CtT, the replays, the temporal reconnection (IndirectLighting.cpp:383-596).
+   They are what a renderer puts on two queues to software-pipeline consecutive frames (zr_pass_set_frame_overlap below), the way the reference
+   overlaps work between its direct and its async-compute queue (Source/ZetaCore/Core/RenderGraph.cpp:442-541). */
+#define ZR_STAGE_CANDIDATES     8
+#define ZR_STAGE_TEMPORAL_REUSE 16
 /* ZR_PASS_DENOISE only: the steps of the pass one by one (zr_pass_render_stage; ZR_STAGE_SPATIAL / ZR_STAGE_ALL = all of them).  A device of the tile
    split runs them in groups with a halo exchange wherever the next step's stencil would reach beyond what is still exact in its 32-px apron
    (reach: variance 3 px, a-trous iteration i 2 * 2^i px; zetaray_amd/tiling.py denoise_schedule): exchange ZR_HALO_DENOISE_INPUT, TEMPORAL + VARIANCE +
@@ -386,6 +408,22 @@ int zr_pass_render(zr_pass* pass, void* hip_stream, const zr_frame_constants* cb
 #define ZR_HALO_DENOISE_ITER  3
 #define ZR_HALO_BYTES_PER_PIXEL 62  /* planes A..G back to back: 4 + 8 + 16 + 16 + 2 + 8 + 8, each row-major over the rect */
 int zr_pass_set_owned_rect(zr_pass* pass, uint32_t x0, uint32_t y0, uint32_t width, uint32_t height);   /* global pixels; width 0 = whole tile */
+/* Frame overlap (round 6): K1 + K11 of frame N + 1 beside K15 / K12 / K13 / K16 of frame N.
+   K11's candidates depend on nothing but G-buffer(N + 1), so with enable = 1 the ReSTIR PT pass keeps a THIRD reservoir set, a second target plane and
+   a second FINAL plane, and its stages may be enqueued on two streams:
+       stream A:  GBUFFER(N + 1), PRELIGHTING(N + 1), INDIRECT stage ZR_STAGE_CANDIDATES(N + 1)
+       stream B:  INDIRECT stages ZR_STAGE_TEMPORAL_REUSE | ZR_STAGE_SPATIAL [| ZR_STAGE_SPATIAL2](N + 1), then whatever consumes the frame
+   in exactly that host order, frame after frame.  The library orders them with events: CANDIDATES(N + 1) waits for the temporal reuse of frame N (the last
+   reader of the planes it recycles), TEMPORAL_REUSE(N + 1) waits for CANDIDATES(N + 1); the G-buffer given here is tracked -- a GBUFFER render waits for
+   the passes still reading the plane set it is about to overwrite, a pass on another stream waits for the GBUFFER render.  Results do not depend on
+   the streams (one stream for everything is the plain order) nor on the switch: tests/test_gpu_parity.py::test_frame_overlap_changes_nothing.
+   Outputs: zr_pass_get_output(ZR_OUT_FINAL / ZR_OUT_RPT_*) address the planes of the last frame whose final stage has been enqueued; re-query them every
+   frame (ZR_OUT_FINAL alternates between two planes unless the frame accumulates).  Only the ReSTIR PT integrator; call between frames.
+   zr_pass_frame_overlap_stream: a non-blocking stream owned by the pass, for callers without streams of their own ("stream A"). */
+int zr_pass_set_frame_overlap(zr_pass* pass, zr_gbuffer* gbuffer, int enable);
+int zr_pass_frame_overlap_stream(zr_pass* pass, void** hip_stream);
+/* hipDeviceSynchronize for callers that hold no HIP runtime of their own (bindings through ctypes / cgo) */
+int zr_device_synchronize(int device);
 /* The same protocol for the other passes with cross-pixel reuse (SURVEY 8(e) "Collective"): bytes per pixel of a halo transfer =
    the pass's reservoir planes back to back: ReSTIR PT 62, ReSTIR GI 40 (A, B, C), ReSTIR DI emissive 24 (A, B), sun + sky DI 13.
    DI passes: TEMPORAL stage -> exchange ZR_HALO_POST_TEMPORAL -> SPATIAL stage (the exchanged set is also the one the next

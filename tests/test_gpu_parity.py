@@ -1682,24 +1682,42 @@ def test_bench_multi_rank_protocol_on_one_gpu():
     env = dict(os.environ, ZR_BENCH_SHARED_GPU="1", MASTER_ADDR="127.0.0.1")
     singles = []
     # (the last run adds the denoise pass: BASELINE config 5's shape on two ranks -- the three denoise halo exchanges of tiling.denoise_schedule per frame)
-    for n, port, settle, more in ((1, 0, 4, []), (1, 0, 16, []), (2, 29631, 4, []), (4, 29632, 4, []), (8, 29634, 4, []), (2, 29633, 4, ["--denoise"])):
+    # ... and BASELINE config 2 (the DI passes alone, sharded as the pass whose reservoirs cross tile borders: `--config 2a / 2b --gpus 2`)
+    for n, port, settle, more in ((1, 0, 4, []), (1, 0, 16, []), (2, 29631, 4, []), (4, 29632, 4, []), (8, 29634, 4, []), (2, 29633, 4, ["--denoise"]),
+                                  (2, 29635, 4, ["--config", "2a"]), (2, 29636, 4, ["--config", "2b"]), (8, 29637, 4, ["--denoise"])):
         # n == 2 without --denoise is started as plain `python bench.py --gpus 2` (no launcher: bench.py starts its ranks itself, the shape of
         # the driver's N = 1 command); the other N > 1 runs go through torch.distributed.run the way the driver launches them
         self_launch = n == 2 and not more
         cmd = [sys.executable, os.path.join(ROOT, "bench.py")] if (n == 1 or self_launch) else \
             [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1", "--master-port", str(port),
              os.path.join(ROOT, "bench.py")]
-        cmd += ["--gpus", str(n), "--steps", "4", "--warmup", "2", "--settle", str(settle), "--width", "512", "--height", "288", "--no-cpu-baseline"] + more
+        cmd += ["--gpus", str(n), "--steps", "4", "--warmup", "2", "--settle", str(settle), "--ramp-s", "0", "--no-general-kernels", "--width", "512", "--height", "288", "--no-cpu-baseline"] + more
         res = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
         assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
         lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
         assert len(lines) == 1, res.stdout[-2000:]
         d = json.loads(lines[0])
         assert d["n_gpus"] == n and d["steps"] == 4 and d["value"] > 0 and d["scaling"] == "strong"
-        assert ("denoise pass" in d["config"]["workload"]) == bool(more)
+        assert ("denoise pass" in d["config"]["workload"]) == ("--denoise" in more)
+        # the device as the process found it: the probes ran and say something
+        ds = d["device_state"]
+        assert ds["compute_units"] > 0 and ds["probe_copy_GBs"] > 100 and ds["probe_fma_tflops"] > 1 and ds["probe_sclk_mhz_under_load"] > 100, ds
         if n == 1:
+            assert d["config"]["kernel_class"] == "plain" and "multi_gpu" not in d
             singles.append(d["config"]["rays_per_frame"])
             continue
+        # first-contact block of an N > 1 line: one row per rank with its device, tile, halo bytes and the time of one exchange; per-rank probe rows
+        mg = d["multi_gpu"]
+        assert mg["communicator_size"] == n and len(mg["ranks"]) == n and sorted(q["rank"] for q in mg["ranks"]) == list(range(n)), mg
+        assert all(q["exchange_error"] is None and q["exchange_ms"] > 0 and q["halo_bytes_sent_per_exchange"] > 0 and q["peers"] >= 1 and q["transport"] == "torch_p2p" for q in mg["ranks"]), mg
+        assert mg["exchanges_per_frame"] >= 1 and len(ds["ranks"]) == n and all(q["copy_GBs"] > 100 for q in ds["ranks"]), (mg, ds["ranks"])
+        if "--config" in more:
+            # config 2 on two ranks: the DI pass is the halo pass (24 / 13 B per pixel, one exchange per frame), every rank counted rays
+            assert mg["halo_pass"] == ("di" if more[1] == "2a" else "sky_di") and mg["ranks"][0]["halo_bytes_per_pixel"] == (24 if more[1] == "2a" else 13), mg
+            assert mg["exchanges_per_frame"] == 1 and d["config"]["integrator"] in ("+restir_di", "+sky_di"), d["config"]
+            continue
+        if "--denoise" in more:
+            assert mg["exchanges_per_frame"] >= 4, mg      # post-temporal + the three denoise exchanges of tiling.denoise_schedule
         assert "screen tiles" in d["config"]["parallelism"] and ("cost-balanced" in d["config"]["parallelism"] or "equal-area" in d["config"]["parallelism"])
         assert d["config"]["halo_transport"] == "torch_p2p"      # (this rig; rccl_cpp on distinct devices: test_bench_two_ranks_over_rccl_when_two_gpus_are_visible)
         # the whole-job roofline object of an N > 1 line: every rank's K11 timed on its tile, N x the HBM peak

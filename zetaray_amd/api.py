@@ -46,7 +46,7 @@ RPT_OUTPUTS = {"A": (1, np.uint32, 1), "B": (2, np.float32, 2), "C": (3, np.uint
                "ntc_A": (14, np.uint16, 4), "ntc_B": (15, np.uint32, 4), "ntc_C": (16, np.uint32, 4), "ntc_D": (17, np.uint16, 1)}
 
 EXPORTS = [
-    "zr_abi_version", "zr_last_error", "zr_device_count", "zr_wire_layout", "zr_scene_create", "zr_scene_destroy", "zr_scene_update_instances", "zr_scene_update_emissives", "zr_scene_invalidate_alias_table", "zr_scene_update_materials",
+    "zr_abi_version", "zr_last_error", "zr_device_count", "zr_device_probe_run", "zr_wire_layout", "zr_scene_create", "zr_scene_destroy", "zr_scene_update_instances", "zr_scene_update_emissives", "zr_scene_invalidate_alias_table", "zr_scene_update_materials",
     "zr_scene_set_background_rebuild", "zr_scene_background_rebuild_stats",
     "zr_scene_invalidate_alias_table_deferred", "zr_scene_update_instances_async", "zr_scene_update_emissives_async", "zr_scene_update_materials_async", "zr_scene_set_alias_table_async",
     "zr_scene_set_alias_table", "zr_alias_table_build", "zr_scene_get_alias_table", "zr_scene_get_light_voxel_grid", "zr_scene_get_presampled_sets", "zr_scene_bvh_info", "zr_pass_enable_cost_map", "zr_pass_read_cost_map", "zr_pass_debug_trip_stats", "zr_debug_set_large_scene_nodes", "zr_debug_set_bvh_depth_cap", "zr_debug_set_material_class_kernels", "zr_scene_material_class",
@@ -57,9 +57,11 @@ EXPORTS = [
     "zr_trace_closest", "zr_trace_any",
     "zr_pass_set_owned_rect", "zr_pass_render_stage", "zr_pass_halo_pack", "zr_pass_halo_unpack", "zr_pass_halo_bytes_per_pixel", "zr_pass_set_input",
     "zr_pass_set_tonemap_lut", "zr_pass_halo_pack_all", "zr_pass_halo_unpack_all",
+    "zr_pass_set_frame_overlap", "zr_pass_frame_overlap_stream", "zr_device_synchronize",
 ]
 STAGE_TEMPORAL, STAGE_SPATIAL, STAGE_ALL = 1, 2, 3
 STAGE_SPATIAL2 = 4          # ReSTIR PT, num_spatial_passes = 2 on tiles: the second round, behind one more HALO_POST_TEMPORAL exchange
+STAGE_CANDIDATES, STAGE_TEMPORAL_REUSE = 8, 16      # ReSTIR PT: the TEMPORAL stage in its two halves (K11 / K12-K14): what frame overlap puts on two streams
 HALO_POST_TEMPORAL, HALO_FINAL = 0, 1
 HALO_DENOISE_INPUT, HALO_DENOISE_ITER = 2, 3                  # ZR_PASS_DENOISE on tiles (tiling.denoise_schedule): 40 / 16 B per pixel
 STAGE_DENOISE_TEMPORAL, STAGE_DENOISE_VARIANCE, STAGE_DENOISE_MASK = 1 << 8, 1 << 9, 0x3ff00
@@ -134,6 +136,9 @@ def lib():
         L.zr_pass_enable_timing.argtypes = [vp, i32]
         L.zr_pass_get_timings.argtypes = [vp, u32, vp, vp, vp, vp]
         L.zr_pass_destroy.argtypes = [vp]
+        L.zr_pass_set_frame_overlap.argtypes = [vp, vp, i32]
+        L.zr_pass_frame_overlap_stream.argtypes = [vp, vp]
+        L.zr_device_synchronize.argtypes = [i32]
         L.zr_trace_closest.argtypes = [vp, vp, vp, u32, u32, vp]
         L.zr_trace_any.argtypes = [vp, vp, vp, u32, u32, vp]
         _LIB = L
@@ -361,6 +366,17 @@ class Pass:
     def set_input(self, which, dev_ptr):
         _check(lib().zr_pass_set_input(self.h, which, dev_ptr))
 
+    def set_frame_overlap(self, gbuffer, on=True):
+        """ReSTIR PT: keep a third reservoir set + second target / FINAL planes so that this frame's CANDIDATES stage may run beside the previous frame's
+        reuse stages on another stream (zetaray_amd.h zr_pass_set_frame_overlap); the G-buffer becomes stream-tracked"""
+        _check(lib().zr_pass_set_frame_overlap(self.h, gbuffer.h, int(on)))
+
+    def frame_overlap_stream(self):
+        """the pass-owned non-blocking stream for the GBUFFER / PRELIGHTING / CANDIDATES half of an overlapped frame (a hipStream_t as an integer)"""
+        st = C.c_void_p()
+        _check(lib().zr_pass_frame_overlap_stream(self.h, C.byref(st)))
+        return st.value
+
     def set_tonemap_lut(self, lut=None):
         lut = np.ascontiguousarray(load_tonemap_lut() if lut is None else lut, np.uint32)
         dim = int(round(lut.size ** (1.0 / 3.0)))
@@ -492,6 +508,19 @@ class Renderer:
         self.skip_indirect = False
         self.p_composit = None        # Compositing: enable_compositing()
         self._alias_ready = False
+        self._overlap_stream = None   # frame overlap: enable_frame_overlap()
+        self._device = device
+
+    def enable_frame_overlap(self, on=True):
+        """Software-pipeline consecutive ReSTIR PT frames on two streams: the G-buffer, PreLighting and K11 of frame N + 1 go to a stream of the pass's
+        own and run beside the search / sort / replay / reconnect kernels of frame N (the reference overlaps its direct and async-compute queues the same
+        way, RenderGraph.cpp:442-541).  Bit-identical frames; throughput goes up, the latency of one frame does not go down.  Indirect (ReSTIR PT) + denoise
+        only: the DI passes, Compositing and TAA keep single-buffered outputs that the next frame's first half would overwrite under their consumers."""
+        assert self.p_direct is None and self.p_sky_direct is None and self.p_composit is None and getattr(self, "p_taa", None) is None, \
+            "frame overlap covers GBuffer + PreLighting + Indirect (ReSTIR PT) [+ denoise]"
+        _check(lib().zr_device_synchronize(self._device))
+        self.p_indirect.set_frame_overlap(self.gbuffer, on)
+        self._overlap_stream = self.p_indirect.frame_overlap_stream() if on else None
 
     def enable_compositing(self, device=0, firefly_filter=False):
         """add the Compositing pass: (DI + indirect * !emissive) / NumFramesCameraStatic, optionally followed by the firefly filter"""
@@ -571,6 +600,8 @@ class Renderer:
             self._sky_key = key
 
     def render_frame(self, cb, stream=None):
+        if self._overlap_stream is not None:
+            return self._render_frame_overlapped(cb, stream)
         self._bind_post_inputs()
         self.render_sky(cb, stream)
         self.p_gbuffer.render(cb, self.scene, self.gbuffer, stream)
@@ -591,6 +622,33 @@ class Renderer:
             self.p_composit.render(cb, self.scene, self.gbuffer, stream)
         if getattr(self, "p_taa", None) is not None:
             self.p_taa.render(cb, self.scene, self.gbuffer, stream)
+
+    def _render_frame_overlapped(self, cb, stream=None):
+        """render_frame with frame overlap on: first half on the pass's stream, second half on `stream` (zetaray_amd.h zr_pass_set_frame_overlap)"""
+        a = self._overlap_stream
+        assert self.p_direct is None and self.p_sky_direct is None and self.p_composit is None and not self.skip_indirect
+        if self.p_sky is not None:
+            key = b"".join(np.asarray(cb[f]).tobytes() for f in self._SKY_FIELDS)
+            if key != getattr(self, "_sky_key", None):
+                # K17 rewrites the sky-view LUT that kernels of BOTH halves sample: a rare event (sun / atmosphere edits), ordered the blunt way
+                _check(lib().zr_device_synchronize(self._device))
+                self.p_sky.render(cb, self.scene, None, stream)
+                _check(lib().zr_device_synchronize(self._device))
+                self._sky_key = key
+        self.p_gbuffer.render(cb, self.scene, self.gbuffer, a)
+        if not self._alias_ready or self._presampling or getattr(self, "_alias_poll", 0) > 0:
+            if not self._alias_ready:
+                _check(lib().zr_device_synchronize(self._device))      # the alias table's first build is read by both halves
+            self.p_prelight.render(cb, self.scene, None, a)          # (K3's presampled sets are read by K11 alone: same stream)
+            if not self._alias_ready:
+                _check(lib().zr_device_synchronize(self._device))
+            self._alias_ready = True
+            self._alias_poll = max(0, getattr(self, "_alias_poll", 0) - 1)
+        self.p_indirect.render_stage(cb, self.scene, self.gbuffer, STAGE_CANDIDATES, a)
+        self.p_indirect.render_stage(cb, self.scene, self.gbuffer, STAGE_TEMPORAL_REUSE | STAGE_SPATIAL | STAGE_SPATIAL2, stream)
+        if getattr(self, "p_denoise", None) is not None:
+            self.p_denoise.set_input(IN_DENOISE_SIGNAL, self.p_indirect.output_ptr()[0])
+            self.p_denoise.render(cb, self.scene, self.gbuffer, stream)
 
     def final(self):
         return self.p_indirect.download()

@@ -61,6 +61,7 @@ static int RequireDevice(int device)
 #define ZR_EXP_ENV(name) ((const char*)nullptr)
 #endif
 #include "zr_bvh_device.h"
+namespace zr { int DeviceProbeRun(int device, float min_ms, zr_device_probe* out, std::string& err); }      // zr_tu_probe.hip
 // the ReSTIR PT kernels are compiled in zr_tu_rpt_[a-i].hip (see zr_kernels.h)
 ZR_RPT_GROUPS_PRODUCT(extern template)
 #ifdef ZR_EXPERIMENTS
@@ -677,6 +678,13 @@ struct zr_gbuffer
     // the scene's material class (zr_scene::plainMaterials) at the time each plane set was rendered: the PLAIN kernel permutations take a pixel's flags as known,
     // so both the current and the previous frame's planes must come from a plain material table (a scene that BECAME plain renders one more frame with the general kernels)
     bool plainAt[2] = {true, true};
+    // stream tracking (zr_pass_set_frame_overlap): with the passes of a frame spread over two streams, a GBUFFER render must not overwrite a plane set
+    // that a pass on another stream still reads, and a pass on another stream must not read a set before its GBUFFER render has finished
+    bool tracked = false;
+    hipEvent_t evWritten = nullptr; hipStream_t writer = nullptr; bool hasWrite = false;
+    struct Reader { hipStream_t st; hipEvent_t ev; };
+    std::vector<Reader> readers[2];      // per plane set: the last read of every stream that has read it
+    ~zr_gbuffer() { if (evWritten) (void)hipEventDestroy(evWritten); for (auto& v : readers) for (auto& r : v) (void)hipEventDestroy(r.ev); }
     DevBuf<uint8_t>* Planes() { return planeSets[cur]; }
     const DevBuf<uint8_t>* Planes() const { return planeSets[cur]; }
     GBuf View() const { return ViewOf(cur); }
@@ -693,6 +701,39 @@ struct zr_gbuffer
         return g;
     }
 };
+
+// tracked G-buffers: `s` has finished reading plane set `set` at this point of its queue
+static int GBufferMarkRead(zr_gbuffer* gb, int set, hipStream_t s)
+{
+    if (!gb || !gb->tracked) return ZR_OK;
+    for (auto& r : gb->readers[set]) if (r.st == s) { HIP_TRY(hipEventRecord(r.ev, s)); return ZR_OK; }
+    hipEvent_t ev; HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    gb->readers[set].push_back({s, ev});
+    HIP_TRY(hipEventRecord(ev, s));
+    return ZR_OK;
+}
+// ... a pass on `s` is about to read the current planes: behind their GBUFFER render if that ran on another stream
+static int GBufferAcquireRead(zr_gbuffer* gb, hipStream_t s)
+{
+    if (!gb || !gb->tracked || !gb->hasWrite || gb->writer == s) return ZR_OK;
+    HIP_TRY(hipStreamWaitEvent(s, gb->evWritten, 0));
+    return ZR_OK;
+}
+// ... the GBUFFER pass on `s` is about to overwrite plane set `set`: behind every other stream's last read of it
+static int GBufferAcquireWrite(zr_gbuffer* gb, int set, hipStream_t s)
+{
+    if (!gb->tracked) return ZR_OK;
+    for (auto& r : gb->readers[set]) if (r.st != s) HIP_TRY(hipStreamWaitEvent(s, r.ev, 0));
+    return ZR_OK;
+}
+static int GBufferMarkWritten(zr_gbuffer* gb, hipStream_t s)
+{
+    if (!gb->tracked) return ZR_OK;
+    if (!gb->evWritten) HIP_TRY(hipEventCreateWithFlags(&gb->evWritten, hipEventDisableTiming));
+    HIP_TRY(hipEventRecord(gb->evWritten, s));
+    gb->writer = s; gb->hasWrite = true;
+    return ZR_OK;
+}
 
 struct QueueStorage
 {
@@ -767,14 +808,27 @@ struct zr_pass
             return ZR_OK;
         }
         rpt::ResPlanes View() const { rpt::ResPlanes v; v.A = A.p; v.B = B.p; v.C = C.p; v.D = D.p; v.E = E.p; v.F = F.p; v.G = G.p; return v; }
-    } res[2];
+    } res[3];      // [2]: allocated by zr_pass_set_frame_overlap (the set K11 of the next frame writes while this frame's reuse passes read the other two)
     struct RBufStorage
     {
         DevBuf<uint16_t> A, D; DevBuf<U4> B, C;
         int Alloc(size_t n) { int r; if ((r = A.Alloc(4 * n)) || (r = B.Alloc(n)) || (r = C.Alloc(n)) || (r = D.Alloc(n))) return r; return ZR_OK; }
         rpt::RBuf View() const { rpt::RBuf v; v.A = A.p; v.B = B.p; v.C = C.p; v.D = D.p; return v; }
     } rb[2];
-    DevBuf<F4> rptTarget; DevBuf<uint8_t> rptNeighbor; DevBuf<uint16_t> rptSampleSet;
+    DevBuf<F4> rptTarget, rptTargetAlt; DevBuf<uint8_t> rptNeighbor; DevBuf<uint16_t> rptSampleSet;
+    // Frame overlap (zr_pass_set_frame_overlap).  rptSet: which storage plays the two roles currIdx flips between ([0], [1]) and which one is free ([2]);
+    // the CANDIDATES stage of an overlapped frame writes the free set and hands the set it replaces back.  tgtIdx / finIdx: the target / FINAL plane of
+    // the frame whose CANDIDATES stage ran last; finOut: the FINAL plane of the last frame whose final stage has been enqueued (zr_pass_get_output)
+    bool overlap = false; int rptSet[3] = {0, 1, 2}; int tgtIdx = 0, finIdx = 0, finOut = 0;
+    DevBuf<float> finalAlt;
+    hipStream_t overlapStream = nullptr;                     // "stream A" for callers without streams of their own
+    hipEvent_t evCand = nullptr, evTemporal = nullptr;       // K11 of the open frame done (on candStream) / K14 of the last frame done (on reuseStream)
+    hipStream_t candStream = nullptr, reuseStream = nullptr; bool haveCand = false, haveTemporal = false;
+    zr_pass::ResStorage& RptCur() { return res[rptSet[currIdx]]; }
+    zr_pass::ResStorage& RptOth() { return res[rptSet[1 - currIdx]]; }
+    const zr_pass::ResStorage& RptOth() const { return res[rptSet[1 - currIdx]]; }
+    F4* Target() const { return tgtIdx ? rptTargetAlt.p : rptTarget.p; }
+    float* Final(int i) const { return i ? finalAlt.p : finalRGBA.p; }
     DevBuf<uint16_t> rptMap[2];      // K12 thread maps: [0] CtN, [1] NtC
     DevBuf<uint32_t> trip; DevBuf<unsigned long long> tripStats;      // ZR_K11=trip diagnostic
     DevBuf<uint32_t> carry[2], carryCount;                             // K11 with per-bounce compaction: path-state planes (ping-pong), alive counts
@@ -1056,6 +1110,15 @@ int zr_device_count(int* count)
     int n = 0;
     hipError_t e = hipGetDeviceCount(&n);
     *count = (e == hipSuccess) ? n : 0;
+    return ZR_OK;
+}
+
+int zr_device_probe_run(int device, float min_ms, zr_device_probe* out)
+{
+    if (!out) return Fail(ZR_ERR_INVALID_ARG, "out is null");
+    if (int r = RequireDevice(device)) return r;
+    std::string err;
+    if (zr::DeviceProbeRun(device, min_ms, out, err)) return Fail(ZR_ERR_HIP, "zr_device_probe_run: %s", err.c_str());
     return ZR_OK;
 }
 
@@ -1782,6 +1845,18 @@ int zr_pass_create(int kind, int device, zr_pass** out)
     return ZR_OK;
 }
 
+// the planes frame overlap adds to a ReSTIR PT pass (zr_pass_set_frame_overlap): a third reservoir set, a second target plane, a second FINAL plane
+static int AllocOverlapPlanes(zr_pass* p)
+{
+    const size_t cap = (size_t)p->w * p->h;
+    int r;
+    zr_pass::ResStorage& R = p->res[2];
+    if ((r = R.Alloc(cap)) || (r = p->rptTargetAlt.Alloc(cap)) || (r = p->finalAlt.Alloc(cap * 4))) return r;
+    HIP_TRY(hipMemset(R.A.p, 0, cap * 4)); HIP_TRY(hipMemset(R.B.p, 0, cap * 8)); HIP_TRY(hipMemset(R.C.p, 0, cap * 16));
+    HIP_TRY(hipMemset(R.D.p, 0, cap * 16)); HIP_TRY(hipMemset(R.E.p, 0, cap * 2)); HIP_TRY(hipMemset(R.F.p, 0, cap * 8)); HIP_TRY(hipMemset(R.G.p, 0, cap * 8));
+    HIP_TRY(hipMemset(p->rptTargetAlt.p, 0, cap * 16)); HIP_TRY(hipMemset(p->finalAlt.p, 0, cap * 4 * sizeof(float)));
+    return ZR_OK;
+}
 static int AllocPass(zr_pass* p)
 {
     int r;
@@ -1894,6 +1969,8 @@ static int AllocPass(zr_pass* p)
             { const size_t cells = (size_t)((p->w + 31u) / 32u + 1u) * ((p->h + 31u) / 32u + 1u); if ((r = p->costMap.Alloc(cells))) return r; HIP_TRY(hipMemset(p->costMap.p, 0, cells * 4)); }
             if ((r = p->rptSampleSet.Upload(kRptSampleSet, 1024))) return r;
             if ((r = p->rptLists.Alloc(4 * cap))) return r;
+            p->rptSet[0] = 0; p->rptSet[1] = 1; p->rptSet[2] = 2; p->tgtIdx = 0; p->finIdx = 0; p->finOut = 0; p->frameOpen = false; p->haveCand = false; p->haveTemporal = false;
+            if (p->overlap) { if ((r = AllocOverlapPlanes(p))) return r; }
             // word layout (kRptListWords): [0, 1] temporal counts, [2, 3] first spatial round, [4, 5] the temporal replays' cursors (counts + 4 / + 5 of
             // base 0: the only DYNAMIC replay), [6, 7] second spatial round, [8 .. 11] = base 6's cursor slots -- unused (the spatial replays split
             // their lists statically) but allocated and zeroed, so that no base ever reaches past the buffer
@@ -1929,7 +2006,7 @@ int zr_pass_reset_temporal(zr_pass* p)
     if (!p) return Fail(ZR_ERR_INVALID_ARG, "null pass");
     if (!p->initialized) return Fail(ZR_ERR_NOT_INITIALIZED, "pass not initialised");
     HIP_TRY(hipSetDevice(p->device));
-    if (p->kind == ZR_PASS_INDIRECT) HIP_TRY(hipMemset(p->finalRGBA.p, 0, p->finalRGBA.n * sizeof(float)));
+    if (p->kind == ZR_PASS_INDIRECT) { HIP_TRY(hipDeviceSynchronize()); HIP_TRY(hipMemset(p->finalRGBA.p, 0, p->finalRGBA.n * sizeof(float))); if (p->finalAlt.p) HIP_TRY(hipMemset(p->finalAlt.p, 0, p->finalAlt.n * sizeof(float))); }
     p->temporalValid = false;       // IndirectLighting::ResetTemporal -> RESET_TEMPORAL_TEXTURES next frame
     if (p->kind == ZR_PASS_DI_EMISSIVE || p->kind == ZR_PASS_DI_SKY) { HIP_TRY(hipMemset(p->finalRGBA.p, 0, p->finalRGBA.n * sizeof(float))); p->currIdx = 0; }   // DirectLighting.cpp:159-164, SkyDI.cpp:128-133
     HIP_TRY(hipDeviceSynchronize());      // a host call between frames: renders on non-blocking streams must see the cleared plane
@@ -1968,6 +2045,7 @@ static int RenderGBuffer(zr_pass* p, hipStream_t s, const zr_frame_constants* cb
     if (!gb) return Fail(ZR_ERR_INVALID_ARG, "GBUFFER pass needs a gbuffer");
     if (gb->x0 + gb->w > cb->render_width || gb->y0 + gb->h > cb->render_height) return Fail(ZR_ERR_INVALID_ARG, "gbuffer tile lies outside the render target of the frame constants");
     const uint32_t tilesX = (gb->w + 15) / 16, tilesY = (gb->h + 15) / 16;
+    if (int wr = GBufferAcquireWrite(gb, gb->cur ^ 1, s)) return wr;      // (tracked G-buffers: the set about to be overwritten may still be read on another stream)
     gb->cur ^= 1; gb->numRendered++;
     gb->plainAt[gb->cur] = sc->plainMaterials.load(std::memory_order_relaxed);
     TimerBegin(p, s, "gbuffer");
@@ -1983,7 +2061,7 @@ static int RenderGBuffer(zr_pass* p, hipStream_t s, const zr_frame_constants* cb
     TimerEnd(p, s);
     HIP_TRY(hipGetLastError());
     p->hostCounters.n_closest += (uint64_t)gb->w * gb->h;
-    return ZR_OK;
+    return GBufferMarkWritten(gb, s);
 }
 
 // GBufferRT::PickPixel / ClearPick / GetPickReadbackBuffer (GBufferRT.h:36-46): every GBUFFER render while a pick is pending writes the mesh index under
@@ -2278,13 +2356,27 @@ static bool FewerRoundsAtFourWaves(uint32_t waves)
 static int RenderReSTIR_PT(zr_pass* p, hipStream_t s, const zr_frame_constants* cb, const zr_scene* sc, zr_gbuffer* gb, int stages)
 {
     using namespace rpt;
+    // the TEMPORAL stage in its two halves (zetaray_amd.h): K11 alone / K12 - K14
+    const bool stageCand = (stages & (ZR_STAGE_TEMPORAL | ZR_STAGE_CANDIDATES)) != 0, stageReuseT = (stages & (ZR_STAGE_TEMPORAL | ZR_STAGE_TEMPORAL_REUSE)) != 0;
+    if (stageCand && p->overlap)
+    {
+        if (p->frameOpen) return Fail(ZR_ERR_INVALID_ARG, "ReSTIR PT with frame overlap: the previous frame's last stage has not been enqueued (stage order: CANDIDATES, TEMPORAL_REUSE, SPATIAL[, SPATIAL2])");
+        // Frame overlap: this frame's K11 runs beside the previous frame's reuse passes, which still read the two sets in play and that frame's target
+        // plane -- so it writes the free set (which takes the "current" role; the set it replaces is free from here on) and the other target / FINAL
+        // plane, behind the previous frame's temporal reuse: the last kernel that read what is recycled here (K16 of the frame before it precedes that
+        // K14 on its stream) and the last reader of the G-buffer set this frame's GBUFFER render overwrote.
+        std::swap(p->rptSet[p->currIdx], p->rptSet[2]);
+        p->tgtIdx ^= 1;
+        if (!(cb->accumulate && cb->camera_static)) p->finIdx ^= 1;      // (an accumulating frame adds to the plane the frames before it wrote)
+        if (p->haveTemporal && p->reuseStream != s) HIP_TRY(hipStreamWaitEvent(s, p->evTemporal, 0));
+    }
     RptFrame F;
     F.sc = FrameView(sc, cb); F.gb = gb->View(); F.gbPrev = gb->PrevView();
     F.scPrev = FrameViewPrev(sc, cb);
     F.sc.texFilter = F.scPrev.texFilter = p->params.tex_filter;
     if (int orc = ResolveOwnedRect(p, gb, cb, &F.ox0, &F.oy0, &F.ow, &F.oh)) return orc;
-    F.rbCtN = p->rb[0].View(); F.rbNtC = p->rb[1].View(); F.tex.target = p->rptTarget.p; F.tex.neighbor = p->rptNeighbor.p;
-    F.finalRGBA = p->finalRGBA.p; F.sampleSet = p->rptSampleSet.p;
+    F.rbCtN = p->rb[0].View(); F.rbNtC = p->rb[1].View(); F.tex.target = p->Target(); F.tex.neighbor = p->rptNeighbor.p;
+    F.finalRGBA = p->Final(p->finIdx); F.sampleSet = p->rptSampleSet.p;
     F.mapCtN = p->rptMap[0].p; F.mapNtC = p->rptMap[1].p;
     F.costMap = p->costOn ? p->costMap.p : nullptr; F.costW = (p->w + 31u) / 32u + 1u; F.costMode = p->costRays ? 1u : 0u;
     F.trip = nullptr; F.tripStats = nullptr; F.tripStride = 0;
@@ -2308,7 +2400,7 @@ static int RenderReSTIR_PT(zr_pass* p, hipStream_t s, const zr_frame_constants* 
     // 1080p; the NtC map does not pay (0.546 / 3.34).  ZR_TEMPORAL_MAP = 0 / 1 / 2 overrides (scripts/gpu_sortmap.sh)
     static const uint32_t temporalMapEnv = [] { const char* e = ZR_EXP_ENV("ZR_TEMPORAL_MAP"); return e ? (uint32_t)atoi(e) : 1u; }();
     prm.temporalMap = prm.sortTemporal ? temporalMapEnv : 0u;
-    if (stages & ZR_STAGE_TEMPORAL)
+    if (stageCand)
     {
         p->doTemporal = (ip.flags & ZR_IND_TEMPORAL_RESAMPLE) && p->temporalValid && havePrevGBuffer;
         p->doSpatial = (ip.flags & ZR_IND_SPATIAL_RESAMPLE) && p->doTemporal && ip.num_spatial_passes > 0;      // IndirectLighting.cpp:906
@@ -2321,7 +2413,7 @@ static int RenderReSTIR_PT(zr_pass* p, hipStream_t s, const zr_frame_constants* 
     prm.doTemporal = p->doTemporal ? 1u : 0u;
     prm.doSpatial = p->doSpatial ? 1u : 0u;
     prm.writeReservoirs = (prm.doTemporal || !p->temporalValid) ? 1u : 0u;
-    F.cur = p->res[p->currIdx].View(); F.prev = p->res[1 - p->currIdx].View();
+    F.cur = p->RptCur().View(); F.prev = p->RptOth().View();
     const uint32_t tilesX = (F.ow + 15) / 16, tilesY = (F.oh + 15) / 16;
     const dim3 grid(tilesX * tilesY), block(kBlock);
     const dim3 gridRpt(tilesX * tilesY * (256 / kRptBlock)), blockRpt(kRptBlock);      // K11 (zr_kernels.h kRptBlock)
@@ -2353,9 +2445,9 @@ static int RenderReSTIR_PT(zr_pass* p, hipStream_t s, const zr_frame_constants* 
 #define RPT_LAUNCH_PE(kern, PASS, ...) do { \
         if (emissiveVariant) { if (texVariant) hipLaunchKernelGGL((kern<PASS, true, true>), __VA_ARGS__); else hipLaunchKernelGGL((kern<PASS, true, false>), __VA_ARGS__); } \
         else { if (texVariant) hipLaunchKernelGGL((kern<PASS, false, true>), __VA_ARGS__); else hipLaunchKernelGGL((kern<PASS, false, false>), __VA_ARGS__); } } while (0)
-    if (stages & ZR_STAGE_TEMPORAL)
+    if (stageCand)
     {
-        HIP_TRY(hipMemsetAsync(listCnt, 0, kRptListWords * sizeof(uint32_t), s));
+        if (int ar = GBufferAcquireRead(gb, s)) return ar;
         TimerBegin(p, s, "rpt_pathtrace");
 #ifdef ZR_EXPERIMENTS
         // (experiments build, zr_kernels_exp.h) ZR_K11=pool: K11 with block-pooled traces (k_rpt_pathtrace_coop; emissive untextured permutation);
@@ -2410,6 +2502,13 @@ static int RenderReSTIR_PT(zr_pass* p, hipStream_t s, const zr_frame_constants* 
             else if (emissiveVariant) hipLaunchKernelGGL((k_rpt_pathtrace<true, false>), gridRpt, blockRpt, 0, s, F, *cb, tilesX, ctr + 2 * 1); else hipLaunchKernelGGL((k_rpt_pathtrace<false, false>), gridRpt, blockRpt, 0, s, F, *cb, tilesX, ctr + 2 * 1);
         }
         TimerEnd(p, s);
+        if (p->overlap) { HIP_TRY(hipEventRecord(p->evCand, s)); p->candStream = s; p->haveCand = true; }
+    }
+    if (stageReuseT)
+    {
+        if (p->overlap && p->haveCand && p->candStream != s) HIP_TRY(hipStreamWaitEvent(s, p->evCand, 0));      // (K11, and with it the GBUFFER render before it on that stream)
+        else if (int ar = GBufferAcquireRead(gb, s)) return ar;
+        HIP_TRY(hipMemsetAsync(listCnt, 0, kRptListWords * sizeof(uint32_t), s));      // (the work lists are the reuse passes' alone: K11 of the next frame may already run)
         if (prm.doTemporal)
         {
             // K12 Sort_TtC / Sort_CtT (IndirectLighting.cpp:383-441: dispatched whether or not SORT_TEMPORAL is set).  The temporal reconnect
@@ -2419,12 +2518,15 @@ static int RenderReSTIR_PT(zr_pass* p, hipStream_t s, const zr_frame_constants* 
             RPT_TIMED("rpt_replay_temporal", RPT_LAUNCH_PE(k_rpt_replay, RPT_REPLAY_CTT, gridReplay, block, 0, s, F, *cb, lists[0], lists[1], listCnt + 0, ctr + 2 * 2));
             RPT_TIMED("rpt_reconnect_temporal", RPT_LAUNCH_E(k_rpt_temporal, gridRecon, blockRecon, 0, s, F, *cb, tilesX, ctr + 2 * 4));
         }
+        // nothing after this point reads the PREVIOUS frame's G-buffer, its final reservoirs or scene (the spatial passes read this frame's only)
+        if (p->overlap) { HIP_TRY(hipEventRecord(p->evTemporal, s)); p->reuseStream = s; p->haveTemporal = true; }
+        if (int mr = GBufferMarkRead(gb, gb->cur ^ 1, s)) return mr;
     }
     for (uint32_t spass = 0; spass < numSpatialPasses && prm.doSpatial; spass++)
     {
         if (!(stages & (spass == 0 ? ZR_STAGE_SPATIAL : ZR_STAGE_SPATIAL2))) continue;
         // a round reads res[currIdx] and writes the other set, which then becomes "current" (IndirectLighting.cpp:609-612, 682-688: one flip per round)
-        F.cur = p->res[p->currIdx].View(); F.prev = p->res[1 - p->currIdx].View();
+        F.cur = p->RptCur().View(); F.prev = p->RptOth().View();
         // replay work lists + their device-side counts of this round: {2, 3} for the first, {6, 7} for the second (zeroed at the start of the frame)
         uint32_t* const sCnt = listCnt + (spass == 0 ? 2 : 6);
 #ifdef ZR_EXPERIMENTS
@@ -2449,7 +2551,7 @@ static int RenderReSTIR_PT(zr_pass* p, hipStream_t s, const zr_frame_constants* 
 #undef RPT_LAUNCH_E
 #undef RPT_LAUNCH_PE
     HIP_TRY(hipGetLastError());
-    if (stages & ZR_STAGE_TEMPORAL) p->frameOpen = true;
+    if (stageCand) p->frameOpen = true;
     // the frame ends with its last stage: the second round when there is one this frame, else ZR_STAGE_SPATIAL; Render() flips once more (:1018-1024)
     const bool lastStage = (prm.doSpatial && numSpatialPasses == 2u) ? (stages & ZR_STAGE_SPATIAL2) != 0 : (stages & ZR_STAGE_SPATIAL) != 0;
     if (lastStage && p->frameOpen)
@@ -2457,6 +2559,8 @@ static int RenderReSTIR_PT(zr_pass* p, hipStream_t s, const zr_frame_constants* 
         p->temporalValid = true;
         p->currIdx = 1 - p->currIdx;
         p->frameOpen = false;
+        p->finOut = p->finIdx;
+        if (int mr = GBufferMarkRead(gb, gb->cur, s)) return mr;
     }
     return ZR_OK;
 }
@@ -2717,6 +2821,40 @@ static int RenderCompositing(zr_pass* p, hipStream_t s, const zr_frame_constants
     return ZR_OK;
 }
 
+int zr_device_synchronize(int device)
+{
+    if (int r = RequireDevice(device)) return r;
+    HIP_TRY(hipDeviceSynchronize());
+    return ZR_OK;
+}
+int zr_pass_set_frame_overlap(zr_pass* p, zr_gbuffer* gb, int enable)
+{
+    if (!p || !gb) return Fail(ZR_ERR_INVALID_ARG, "zr_pass_set_frame_overlap: null argument");
+    if (!p->initialized) return Fail(ZR_ERR_NOT_INITIALIZED, "pass not initialised");
+    if (p->kind != ZR_PASS_INDIRECT || p->integrator != ZR_INTEGRATOR_RESTIR_PT) return Fail(ZR_ERR_UNSUPPORTED, "frame overlap is a mode of the ReSTIR PT pass");
+    if (p->frameOpen) return Fail(ZR_ERR_INVALID_ARG, "zr_pass_set_frame_overlap: call between frames (a frame's last stage has not been enqueued)");
+    if (gb->device != p->device) return Fail(ZR_ERR_INVALID_ARG, "gbuffer / pass live on different devices");
+    HIP_TRY(hipSetDevice(p->device));
+    HIP_TRY(hipDeviceSynchronize());      // (a host call between frames; the planes allocated below are cleared on the null stream)
+    if (enable && !p->res[2].A.p) { if (int r = AllocOverlapPlanes(p)) return r; HIP_TRY(hipDeviceSynchronize()); }
+    if (enable && !p->evCand)
+    {
+        HIP_TRY(hipEventCreateWithFlags(&p->evCand, hipEventDisableTiming)); HIP_TRY(hipEventCreateWithFlags(&p->evTemporal, hipEventDisableTiming));
+        HIP_TRY(hipStreamCreateWithFlags(&p->overlapStream, hipStreamNonBlocking));
+    }
+    // switching off keeps the plane roles as they stand (the set last written as FINAL stays the one the next frame reads); FINAL goes on in the plane it is in
+    p->overlap = enable != 0; p->haveCand = false; p->haveTemporal = false;
+    gb->tracked = enable != 0;
+    if (!enable) { gb->hasWrite = false; for (auto& v : gb->readers) { for (auto& r : v) (void)hipEventDestroy(r.ev); v.clear(); } }
+    return ZR_OK;
+}
+int zr_pass_frame_overlap_stream(zr_pass* p, void** stream)
+{
+    if (!p || !stream) return Fail(ZR_ERR_INVALID_ARG, "null argument");
+    if (!p->overlapStream) return Fail(ZR_ERR_NOT_INITIALIZED, "frame overlap has never been enabled on this pass (zr_pass_set_frame_overlap)");
+    *stream = (void*)p->overlapStream;
+    return ZR_OK;
+}
 int zr_pass_set_owned_rect(zr_pass* p, uint32_t x0, uint32_t y0, uint32_t w, uint32_t h)
 {
     if (!p) return Fail(ZR_ERR_INVALID_ARG, "null pass");
@@ -2732,7 +2870,7 @@ static zr_pass::ResStorage* HaloSet(zr_pass* p, int which)
 {
     // between the stages of a frame the post-temporal reservoirs are res[currIdx]; after the frame the set the next
     // frame reads as "previous" is res[1 - currIdx]
-    return &p->res[which == ZR_HALO_POST_TEMPORAL ? p->currIdx : 1 - p->currIdx];
+    return &p->res[p->rptSet[which == ZR_HALO_POST_TEMPORAL ? p->currIdx : 1 - p->currIdx]];
 }
 struct HaloPlane { void* base; size_t bpp; };
 // the planes a halo transfer of this pass moves, and their bytes per pixel
@@ -2744,7 +2882,7 @@ static int HaloPlanes(zr_pass* p, int which, HaloPlane* planes, size_t* bytesPer
     int n = 0;
     if (p->kind == ZR_PASS_INDIRECT && p->integrator == ZR_INTEGRATOR_RESTIR_PT)
     {
-        zr_pass::ResStorage* R = &p->res[set];
+        zr_pass::ResStorage* R = &p->res[p->rptSet[set]];
         const HaloPlane pl[7] = {{R->A.p, 4}, {R->B.p, 8}, {R->C.p, 16}, {R->D.p, 16}, {R->E.p, 2}, {R->F.p, 8}, {R->G.p, 8}};
         for (auto& q : pl) planes[n++] = q;
     }
@@ -2847,19 +2985,25 @@ int zr_pass_render_stage(zr_pass* p, void* stream, const zr_frame_constants* cb,
     HIP_TRY(hipSetDevice(p->device));
     int r = SceneAcquireForRender(sc, (hipStream_t)stream);
     if (r) return r;
+    // tracked G-buffers (zr_pass_set_frame_overlap): the ReSTIR PT pass orders its stages itself, finer than a whole call; every other reader waits for
+    // the planes' GBUFFER render when that ran on another stream and leaves an event behind its reads of both plane sets
+    const bool rptPass = p->kind == ZR_PASS_INDIRECT && p->integrator == ZR_INTEGRATOR_RESTIR_PT;
+    const bool trackedReader = gb && gb->tracked && p->kind != ZR_PASS_GBUFFER && !rptPass;
+    if (trackedReader) { if ((r = GBufferAcquireRead(gb, (hipStream_t)stream))) return r; }
     r = RenderStageInner(p, stream, cb, sc, gb, stages);
     if (r) return r;
+    if (trackedReader) { if ((r = GBufferMarkRead(gb, 0, (hipStream_t)stream)) || (r = GBufferMarkRead(gb, 1, (hipStream_t)stream))) return r; }
     return SceneReleaseAfterRender(sc, (hipStream_t)stream);
 }
 static int RenderStageInner(zr_pass* p, void* stream, const zr_frame_constants* cb, const zr_scene* sc, zr_gbuffer* gb, int stages)
 {
     if (!p || !cb || !sc) return Fail(ZR_ERR_INVALID_ARG, "zr_pass_render: null argument");
-    if (!(stages & (ZR_STAGE_ALL | ZR_STAGE_SPATIAL2 | (p && p->kind == ZR_PASS_DENOISE ? ZR_STAGE_DENOISE_MASK : 0)))) return Fail(ZR_ERR_INVALID_ARG, "no stage selected");
+    if (!(stages & (ZR_STAGE_ALL | ZR_STAGE_SPATIAL2 | ZR_STAGE_CANDIDATES | ZR_STAGE_TEMPORAL_REUSE | (p && p->kind == ZR_PASS_DENOISE ? ZR_STAGE_DENOISE_MASK : 0)))) return Fail(ZR_ERR_INVALID_ARG, "no stage selected");
     if (!p->initialized) return Fail(ZR_ERR_NOT_INITIALIZED, "pass not initialised (zr_pass_init)");
     if (sc->device != p->device || (gb && gb->device != p->device)) return Fail(ZR_ERR_INVALID_ARG, "scene / gbuffer / pass live on different devices");
     HIP_TRY(hipSetDevice(p->device));
     hipStream_t s = (hipStream_t)stream;
-    if ((stages & ZR_STAGE_TEMPORAL) || (p->kind == ZR_PASS_DENOISE && (stages & (ZR_STAGE_SPATIAL | ZR_STAGE_DENOISE_TEMPORAL)))) p->numTimers = 0;      // timings accumulate over the stages of one frame
+    if ((stages & (ZR_STAGE_TEMPORAL | ZR_STAGE_CANDIDATES)) || (p->kind == ZR_PASS_DENOISE && (stages & (ZR_STAGE_SPATIAL | ZR_STAGE_DENOISE_TEMPORAL)))) p->numTimers = 0;      // timings accumulate over the stages of one frame
     {
         const uint32_t off[4] = { cb->base_color_maps_desc_heap_offset, cb->normal_maps_desc_heap_offset,
                                   cb->metallic_roughness_maps_desc_heap_offset, cb->emissive_maps_desc_heap_offset };
@@ -2971,7 +3115,7 @@ int zr_pass_get_output(const zr_pass* p, int which, void** dev, uint32_t* w, uin
     }
     if (p->kind != ZR_PASS_INDIRECT) return Fail(ZR_ERR_INVALID_ARG, "pass has no such output");
     uint32_t bytes = 16;
-    if (which == ZR_OUT_FINAL) *dev = p->finalRGBA.p;
+    if (which == ZR_OUT_FINAL) *dev = p->Final(p->finOut);
     else if (which >= ZR_OUT_RGI_RESERVOIR_A && which <= ZR_OUT_RGI_RESERVOIR_C && p->integrator == ZR_INTEGRATOR_RESTIR_GI)
     {
         const int last = 1 - p->currIdx;
@@ -2994,7 +3138,7 @@ int zr_pass_get_output(const zr_pass* p, int which, void** dev, uint32_t* w, uin
     { *dev = p->rptMap[which - ZR_OUT_RPT_THREAD_MAP_CTN].p; bytes = 2; }
     else if (which >= ZR_OUT_RPT_RESERVOIR_A && which <= ZR_OUT_RPT_NEIGHBOR && p->integrator == ZR_INTEGRATOR_RESTIR_PT)
     {
-        const zr_pass::ResStorage& R = p->res[1 - p->currIdx];      // the set the next frame reads as "previous"
+        const zr_pass::ResStorage& R = p->RptOth();      // the set the next frame reads as "previous"
         switch (which)
         {
         case ZR_OUT_RPT_RESERVOIR_A: *dev = R.A.p; bytes = 4; break;
@@ -3004,7 +3148,7 @@ int zr_pass_get_output(const zr_pass* p, int which, void** dev, uint32_t* w, uin
         case ZR_OUT_RPT_RESERVOIR_E: *dev = R.E.p; bytes = 2; break;
         case ZR_OUT_RPT_RESERVOIR_F: *dev = R.F.p; bytes = 8; break;
         case ZR_OUT_RPT_RESERVOIR_G: *dev = R.G.p; bytes = 8; break;
-        case ZR_OUT_RPT_TARGET: *dev = p->rptTarget.p; bytes = 16; break;
+        case ZR_OUT_RPT_TARGET: *dev = p->Target(); bytes = 16; break;
         default: *dev = p->rptNeighbor.p; bytes = 2; break;
         }
     }
@@ -3075,6 +3219,7 @@ int zr_pass_read_counters(zr_pass* p, void* stream, zr_counters* out, int reset)
     {
         unsigned long long c[2 * kCounterSlots];
         HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+        if (p->haveCand) HIP_TRY(hipStreamSynchronize(p->candStream));      // (frame overlap: K11 may have run on another stream)
         HIP_TRY(hipMemcpy(c, p->counters.p, sizeof(c), hipMemcpyDeviceToHost));
         for (int i = 0; i < kCounterSlots; i++) { out->n_closest += c[2 * i]; out->n_shadow += c[2 * i + 1]; }
         if (reset) { HIP_TRY(hipMemsetAsync(p->counters.p, 0, sizeof(c), (hipStream_t)stream)); HIP_TRY(hipStreamSynchronize((hipStream_t)stream)); }
@@ -3090,6 +3235,7 @@ int zr_pass_read_kernel_counters(zr_pass* p, void* stream, uint32_t max_entries,
     HIP_TRY(hipSetDevice(p->device));
     unsigned long long c[2 * kCounterSlots];
     HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+    if (p->haveCand) HIP_TRY(hipStreamSynchronize(p->candStream));
     HIP_TRY(hipMemcpy(c, p->counters.p, sizeof(c), hipMemcpyDeviceToHost));
     uint32_t n = 0;
     for (int i = 0; i < kCounterSlots && n < max_entries; i++)
@@ -3138,6 +3284,9 @@ int zr_pass_destroy(zr_pass* p)
     for (auto& t : p->timers) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); }
     if (p->powerEv) (void)hipEventDestroy(p->powerEv);
     if (p->powerHost) (void)hipHostFree(p->powerHost);
+    if (p->overlapStream) { (void)hipStreamSynchronize(p->overlapStream); (void)hipStreamDestroy(p->overlapStream); }
+    if (p->evCand) (void)hipEventDestroy(p->evCand);
+    if (p->evTemporal) (void)hipEventDestroy(p->evTemporal);
     delete p;
     return ZR_OK;
 }
