@@ -336,12 +336,17 @@ def measure(args, ctx):
         assert not rpt and (args.direct or args.sky_direct), "--di-only needs --integrator pt and a DI pass"
         r.skip_indirect = True
     di_passes = [q for q in (r.p_direct, r.p_sky_direct) if q is not None]
+    overlap = bool(args.frame_overlap) and rpt and not di_passes
     p_denoise = None
     if args.denoise:
         # N > 1: every rank filters its tile + apron and trades halos between the steps whose stencil would outrun the apron (tiling.denoise_schedule:
         # 3 exchanges per frame for the default 5 a-trous iterations); the stitched result equals one device's (tests/test_denoise_tiles_cpu.py, test_denoise.py)
         assert not args.di_only, "--denoise filters the indirect integrator's image"
         p_denoise = tiled.enable_denoise() if tiled is not None else r.enable_denoise()
+    if overlap:
+        # consecutive frames software-pipelined on two streams (zetaray_amd.h zr_pass_set_frame_overlap): K1 + K11 of frame N + 1 beside K15 / K12 / K13 / K16 of
+        # frame N.  Bit-identical frames (test_frame_overlap_changes_nothing); ms_per_step is then a THROUGHPUT, the latency of one frame is frame_ms_median
+        (tiled if tiled is not None else r).enable_frame_overlap(True)
 
     def frame(i):
         cb = scene_io.make_frame_constants(W, H, frame_num=i, num_emissives=len(sc.emissives), **cam)
@@ -452,6 +457,7 @@ def measure(args, ctx):
                    "preset": args.config, "settle_frames": settle - ramp, "ramp_frames": ramp, "arith": args.arith, "library": os.path.basename(api.LIB_PATH),
                    # which permutation of the ReSTIR kernels this scene ran (zr_kernels.h PLAIN: scenes whose material table has no metal, transmission, thin
                    # wall, coat or texture run kernels without code for those lobes; one such material anywhere and the frame runs the general kernels)
+                   "frame_overlap": overlap,
                    "kernel_class": ("plain" if (r.scene.material_class() == 1 and not args.textured and args.kernel_class != "general") else "general"),
                    "rays_per_frame": round((n_closest + n_shadow) / args.steps, 1),
                    "redundant_apron_primary_rays_per_frame": round(apron_rays / args.steps, 1),
@@ -493,6 +499,22 @@ def measure(args, ctx):
         # diagnostic build of K11: lanes alive at its bounce boundaries; the timings of this run mean nothing
         a, b, wds = r.p_indirect.debug_trip_stats()
         out["config"]["k11_bounce_boundaries"] = {"alive_lanes": a, "lane_slots": b, "alive_frac": round(a / max(b, 1), 4), "carried_state_bytes_per_path": 4 * wds}
+    if overlap and world == 1:
+        # what follows times kernels and single frames one at a time: the plain order on one stream (kernel times under overlap are the times of two kernels sharing the device).
+        # Before that, the same protocol once more with the switch off: the pair (overlapped, plain) goes on the line
+        barrier()
+        (tiled if tiled is not None else r).enable_frame_overlap(False)
+        for i in range(max(args.warmup, 8)):
+            frame(2500 + i)
+        barrier()
+        t1 = time.perf_counter()
+        for i in range(args.steps):
+            frame(2600 + i)
+        barrier()
+        out["frame_overlap_off"] = {"ms_per_step": round((time.perf_counter() - t1) / args.steps * 1e3, 4), "steps": args.steps,
+                                    "note": "the same frames in the plain order on one stream (zr_pass_set_frame_overlap(0)); bit-identical output"}
+        r.p_gbuffer.read_counters(reset=True)
+        r.p_indirect.read_counters(reset=True)
     if rank == 0 and world == 1:
         # ---- roofline of the dominant kernel: hipEvent timing inside the library over a few timed frames
         r.p_gbuffer.enable_timing(True)
@@ -725,6 +747,8 @@ def main():
     ap.add_argument("--no-general-kernels", action="store_true", help="skip the general-kernel timing of a plain-class scene (general_kernels)")
     ap.add_argument("--kernel-class", choices=["auto", "general"], default="auto",
                     help="general = run a plain-class scene on the general kernel permutations (zr_debug_set_material_class_kernels(0)) for the whole run")
+    ap.add_argument("--frame-overlap", type=int, choices=[0, 1], default=0,
+                    help="1 = software-pipeline consecutive ReSTIR PT frames on two streams (K1 + K11 of frame N + 1 beside the reuse passes of frame N; bit-identical frames)")
     ap.add_argument("--settle", type=int, default=None,
                     help="untimed frames rendered BEFORE the warm-up so that the temporal reservoirs have reached their M caps whatever --warmup is "
                          "(default: 32 for the ReSTIR integrators, 0 otherwise)")

@@ -163,12 +163,21 @@ def test_tile_split_on_gpu(api, cornell_emissive, oracle_emissive):
 RPT_PLANES = ("A", "B", "C", "D", "E", "F", "G", "neighbor", "map_ctn", "map_ntc")      # reservoirs, K15 neighbour, K12 thread maps
 
 
-def _rpt_compare(api, scene, oscene, w, h, prm, frames, cam=None, reset_at=None):
+def _rpt_compare(api, scene, oscene, w, h, prm, frames, cam=None, reset_at=None, overlap=False, cam_of_frame=None):
     from oracle import zro
     r = api.Renderer(scene, w, h, params=prm, integrator=api.INTEGRATOR_RESTIR_PT)
+    if overlap:
+        r.enable_frame_overlap()
     o = zro.OracleRPT(oscene, w, h)
+    prev = None
     for f in range(1, frames + 1):
-        cb = _frame(scene, w, h, f, **(cam or {}))
+        cb = _frame(scene, w, h, f, **(cam_of_frame(f) if cam_of_frame else (cam or {})))
+        if cam_of_frame is not None:
+            if prev is not None:
+                cb["prev_view"], cb["prev_view_inv"], cb["prev_camera_jitter"] = prev["curr_view"], prev["curr_view_inv"], prev["curr_camera_jitter"]
+            prev = cb.copy()
+        if prm.presampling:
+            oscene.presample(f, int(prm.num_sample_sets), int(prm.sample_set_size))
         if reset_at == f:
             r.p_indirect.reset_temporal(); o.reset_temporal()
         r.p_indirect.read_counters(reset=True)
@@ -193,6 +202,67 @@ def test_restir_pt_bit_exact(api, cornell_emissive, oracle_emissive, w, h):
     radiance and the persistent reservoir planes bit-exact vs the oracle."""
     got = _rpt_compare(api, cornell_emissive, oracle_emissive, w, h, wire.default_params(), 4, reset_at=4)
     assert got[..., :3].max() > 0
+
+
+def _overlap_digest(api, scene, w, h, prm, frames, overlap, cam_of_frame=None, denoise=False, toggle_at=()):
+    """sha1 per frame over FINAL, every reservoir plane, the target plane (and the denoised image) of a ReSTIR PT sequence"""
+    import hashlib
+    r = api.Renderer(scene, w, h, params=prm, integrator=api.INTEGRATOR_RESTIR_PT)
+    if denoise:
+        r.enable_denoise()
+    if overlap:
+        r.enable_frame_overlap()
+    out, prev = [], None
+    for f in range(1, frames + 1):
+        if f in toggle_at:
+            overlap = not overlap
+            r.enable_frame_overlap(overlap)
+        cb = _frame(scene, w, h, f, **(cam_of_frame(f) if cam_of_frame else {}))
+        if prev is not None:
+            cb["prev_view"], cb["prev_view_inv"], cb["prev_camera_jitter"] = prev["curr_view"], prev["curr_view_inv"], prev["curr_camera_jitter"]
+        prev = cb.copy()
+        r.render_frame(cb)
+        hh = hashlib.sha1(r.final().tobytes())
+        for nm in ("B", "C", "D", "E", "F", "G", "target"):
+            hh.update(r.p_indirect.download_plane(nm).tobytes())
+        hh.update((r.p_indirect.download_plane("A") & 0xffffff).tobytes())
+        if denoise:
+            hh.update(r.p_denoise.download_plane("denoised").tobytes())
+        out.append(hh.hexdigest())
+    return out, r.p_indirect.read_counters()
+
+
+def test_frame_overlap_changes_nothing(api, cornell_emissive, oracle_emissive, cornell_sky):
+    """Frame overlap (zr_pass_set_frame_overlap: the G-buffer, PreLighting and K11 of frame N + 1 on a second stream beside K15 / K12 / K13 / K16 of frame N, a
+    third reservoir set, second target / FINAL planes, event-ordered stages) against the oracle and against the plain order:
+      * small frames vs the CPU oracle with the switch on: moving camera + a temporal reset, num_spatial_passes 0 / 1 / 2, sun + sky lighting (the sky LUT is
+        rendered before either half), a materials scene with presampled light sets (K3 every frame on the first half's stream);
+      * 1920 x 1080, where the two halves really run side by side (each alone fills the device): 6 frames with the camera moving from frame 4, every plane
+        of every frame hashes to the digest of the plain order; the same with the denoise pass consuming each frame, and with the switch flipped on and
+        off in the middle of the sequence (the plane roles carry over); ray counters identical."""
+    from oracle import zro
+    cam = lambda f: dict(cam_pos=(0.05 * max(0, f - 2), 1.2, -4.043))
+    _rpt_compare(api, cornell_emissive, oracle_emissive, 200, 120, wire.default_params(), 5, reset_at=4, overlap=True, cam_of_frame=cam)
+    for nsp in (0, 2):
+        prm = wire.default_params()
+        prm.num_spatial_passes = nsp
+        _rpt_compare(api, cornell_emissive, oracle_emissive, 96, 64, prm, 4, overlap=True, cam_of_frame=cam)
+    _rpt_compare(api, cornell_sky, zro.OracleScene(cornell_sky), 96, 64, wire.default_params(), 3, overlap=True, cam=dict(cam_pos=(0.0, 1.2, -4.043)))
+    sc = scene_io.make_synthetic_scene(num_tris=3000, num_emissive=1500, seed=11)
+    prm = wire.default_params()
+    prm.presampling, prm.num_sample_sets, prm.sample_set_size = 1, 16, 64
+    _rpt_compare(api, sc, zro.OracleScene(sc, force_bvh=True), 96, 64, prm, 3, overlap=True, cam=dict(cam_pos=(0, 0, -3.5)))
+    # at size: overlapped == plain, frame by frame
+    w, h = 1920, 1080
+    cam = lambda f: dict(cam_pos=(0.02 * max(0, f - 3), 1.2, -4.043))
+    ref = {}
+    for dn in (False, True):
+        plain, c0 = _overlap_digest(api, cornell_emissive, w, h, wire.default_params(), 6, False, cam, denoise=dn)
+        over, c1 = _overlap_digest(api, cornell_emissive, w, h, wire.default_params(), 6, True, cam, denoise=dn)
+        assert plain == over and c0 == c1, (dn, [a == b for a, b in zip(plain, over)], c0, c1)
+        ref[dn] = (plain, c0)
+    mixed, c2 = _overlap_digest(api, cornell_emissive, w, h, wire.default_params(), 6, False, cam, toggle_at=(3, 5))
+    assert mixed == ref[False][0] and c2 == ref[False][1], [a == b for a, b in zip(mixed, ref[False][0])]
 
 
 def test_restir_pt_thread_sort_on_partial_tiles(api, cornell_emissive, oracle_emissive):

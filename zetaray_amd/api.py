@@ -623,10 +623,9 @@ class Renderer:
         if getattr(self, "p_taa", None) is not None:
             self.p_taa.render(cb, self.scene, self.gbuffer, stream)
 
-    def _render_frame_overlapped(self, cb, stream=None):
-        """render_frame with frame overlap on: first half on the pass's stream, second half on `stream` (zetaray_amd.h zr_pass_set_frame_overlap)"""
+    def _first_half(self, cb, stream, prelight):
+        """the half of an overlapped frame that goes to the pass's own stream: [sky LUT,] G-buffer, PreLighting, K11 (zetaray_amd.h zr_pass_set_frame_overlap)"""
         a = self._overlap_stream
-        assert self.p_direct is None and self.p_sky_direct is None and self.p_composit is None and not self.skip_indirect
         if self.p_sky is not None:
             key = b"".join(np.asarray(cb[f]).tobytes() for f in self._SKY_FIELDS)
             if key != getattr(self, "_sky_key", None):
@@ -636,7 +635,7 @@ class Renderer:
                 _check(lib().zr_device_synchronize(self._device))
                 self._sky_key = key
         self.p_gbuffer.render(cb, self.scene, self.gbuffer, a)
-        if not self._alias_ready or self._presampling or getattr(self, "_alias_poll", 0) > 0:
+        if prelight:
             if not self._alias_ready:
                 _check(lib().zr_device_synchronize(self._device))      # the alias table's first build is read by both halves
             self.p_prelight.render(cb, self.scene, None, a)          # (K3's presampled sets are read by K11 alone: same stream)
@@ -645,6 +644,11 @@ class Renderer:
             self._alias_ready = True
             self._alias_poll = max(0, getattr(self, "_alias_poll", 0) - 1)
         self.p_indirect.render_stage(cb, self.scene, self.gbuffer, STAGE_CANDIDATES, a)
+
+    def _render_frame_overlapped(self, cb, stream=None):
+        """render_frame with frame overlap on: first half on the pass's stream, second half on `stream`"""
+        assert self.p_direct is None and self.p_sky_direct is None and self.p_composit is None and not self.skip_indirect
+        self._first_half(cb, stream, not self._alias_ready or self._presampling or getattr(self, "_alias_poll", 0) > 0)
         self.p_indirect.render_stage(cb, self.scene, self.gbuffer, STAGE_TEMPORAL_REUSE | STAGE_SPATIAL | STAGE_SPATIAL2, stream)
         if getattr(self, "p_denoise", None) is not None:
             self.p_denoise.set_input(IN_DENOISE_SIGNAL, self.p_indirect.output_ptr()[0])

@@ -335,6 +335,13 @@ class TiledRestirPT:
     def stage_temporal(self, cb, stream=None):
         """stream: a hipStream_t (integer handle) -- several tile objects of one device may run on streams of their own (tools/tile_balance.py --halves)"""
         api, r = self.api, self.r
+        if r._overlap_stream is not None:
+            # frame overlap (api.Renderer.enable_frame_overlap): G-buffer, PreLighting and K11 on the pass's own stream -- beside the previous frame's halo
+            # exchange and spatial stage, which are still in `stream`'s queue -- and the temporal reuse behind them on `stream`
+            assert self.kind == "restir_pt" and r.p_direct is None and r.p_sky_direct is None
+            r._first_half(cb, stream, bool(len(r.scene_host.emissives) and (not r._alias_ready or r._presampling)))
+            r.p_indirect.render_stage(cb, r.scene, r.gbuffer, api.STAGE_TEMPORAL_REUSE, stream)
+            return
         r.render_sky(cb, stream)
         r.p_gbuffer.render(cb, r.scene, r.gbuffer, stream)
         if len(r.scene_host.emissives) and (not r._alias_ready or r._presampling):
@@ -348,6 +355,11 @@ class TiledRestirPT:
         if r.p_sky_direct is not None:
             r.p_sky_direct.render(cb, r.scene, r.gbuffer, stream)
         r.p_indirect.render_stage(cb, r.scene, r.gbuffer, api.STAGE_TEMPORAL, stream)
+
+    def enable_frame_overlap(self, on=True):
+        """software-pipeline consecutive frames of this tile on two streams (api.Renderer.enable_frame_overlap); the stages and exchanges keep their order"""
+        assert self.kind == "restir_pt"
+        self.r.enable_frame_overlap(on)
 
     def stage_spatial(self, cb, stream=None):
         self.hp.render_stage(cb, self.r.scene, self.r.gbuffer, self.api.STAGE_SPATIAL, stream)
