@@ -540,7 +540,7 @@ def measure(args, ctx):
                 a = agg.setdefault(name, [0.0, 0])
                 a[0] += ms
                 a[1] += launches
-        prof = read_prof(api)      # only a -DZR_PROF measurement build exports the section counters (scripts/gpu_prof.sh)
+        prof = read_prof(api)      # only a -DZR_PROF measurement build exports the section counters (scripts/gpu.sh prof)
         if prof is not None:
             out["prof"] = prof
         kern_rays = r.p_indirect.kernel_counters()
@@ -595,7 +595,7 @@ def measure(args, ctx):
         plane_bytes = round(plane_px * W * H) if plane_px else None
         frame_bytes = (BYTES_CLOSEST * (cc / nfr + W * H) + BYTES_SHADOW * (cs / nfr) + (47 + 38 + 16) * W * H)
         # measured HBM-side bytes per launch of that kernel: PMC passes (FETCH_SIZE x 2 x 1024 + WRITE_SIZE x 1024, MI355X_MICROARCH.md) of
-        # exactly this command, collected by scripts/gpu_pmc.sh and committed under profiles/ (rocprofv3 cannot run inside the bench)
+        # exactly this command, collected by scripts/gpu.sh profiles and committed under profiles/ (rocprofv3 cannot run inside the bench)
         traffic, traffic_src, valu = None, None, None
         plain = not (args.direct or args.sky_direct or args.textured or args.di_only)
         scene_tag = ("cornell" if args.scene.endswith("cornell_emissive.npz") else

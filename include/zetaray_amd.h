@@ -419,7 +419,14 @@ int zr_pass_set_owned_rect(zr_pass* pass, uint32_t x0, uint32_t y0, uint32_t wid
    the streams (one stream for everything is the plain order) nor on the switch: tests/test_gpu_parity.py::test_frame_overlap_changes_nothing.
    Outputs: zr_pass_get_output(ZR_OUT_FINAL / ZR_OUT_RPT_*) address the planes of the last frame whose final stage has been enqueued; re-query them every
    frame (ZR_OUT_FINAL alternates between two planes unless the frame accumulates).  Only the ReSTIR PT integrator; call between frames.
-   zr_pass_frame_overlap_stream: a non-blocking stream owned by the pass, for callers without streams of their own ("stream A"). */
+   zr_pass_frame_overlap_stream: a non-blocking stream owned by the pass, for callers without streams of their own ("stream A").
+   enable = ZR_FRAME_OVERLAP (1): the product mode.  The passes update reservoir records in place and write only the components a record's case uses
+   (Reservoir.hlsli:283-456), so the UNUSED bytes of a record -- never read by any pass -- are whatever the set held before: with three sets in
+   rotation that is another frame's leftovers than in the plain order.  Every used byte, FINAL and the ray counters are identical.
+   enable = ZR_FRAME_OVERLAP_CARRY (2): additionally copies the replaced set and target plane into the set that takes their place before K11 (one
+   streaming kernel, 156 B per pixel): every byte of every plane then equals the plain order's -- what the parity tests compare with the oracle. */
+#define ZR_FRAME_OVERLAP       1
+#define ZR_FRAME_OVERLAP_CARRY 2
 int zr_pass_set_frame_overlap(zr_pass* pass, zr_gbuffer* gbuffer, int enable);
 int zr_pass_frame_overlap_stream(zr_pass* pass, void** hip_stream);
 /* hipDeviceSynchronize for callers that hold no HIP runtime of their own (bindings through ctypes / cgo) */
@@ -491,9 +498,11 @@ int zr_debug_set_bvh_depth_cap(uint32_t levels);
  * other lobes.  Results are identical either way (tests/test_gpu_parity.py::test_material_class_kernels_change_nothing).  Process-wide. */
 int zr_debug_set_material_class_kernels(int enable);
 /* the material class zr_scene_create / zr_scene_update_materials currently derive from the scene's material table: 1 = plain, 0 = general.
- * The lighting passes render a plain scene with the PLAIN kernel permutations once both plane sets of the G-buffer they are given were rendered (by the
- * GBUFFER pass) while the scene was plain; an engine that fills the planes itself through zr_gbuffer_device_plane must keep their flags (metallic,
- * transmissive, coated, ...) consistent with the material table, as the GBUFFER pass does. */
+ * The lighting passes render a plain scene with the PLAIN kernel permutations when the plane sets of the G-buffer they read were rendered by the GBUFFER
+ * pass FROM THAT SCENE while it was plain (the current set; the previous one too from the second render on).  A G-buffer no GBUFFER pass has rendered --
+ * planes an engine filled itself through zr_gbuffer_device_plane -- or one rendered from another scene runs the general kernels: its flags (metallic,
+ * transmissive, coated, ...) are not the library's to vouch for.  (An engine that OVERWRITES planes of a rendered set must keep them consistent with
+ * the material table, as the halo exchange of the tile split does: it moves planes the GBUFFER pass of a neighbouring device rendered from the same scene.) */
 int zr_scene_material_class(const zr_scene* scene, uint32_t* out_class);
 /* the same counters split by the kernel that issued the queries (not reset; roofline bookkeeping of bench.py) */
 int zr_pass_read_kernel_counters(zr_pass* pass, void* hip_stream, uint32_t max_entries, const char** names,

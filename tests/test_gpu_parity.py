@@ -167,7 +167,7 @@ def _rpt_compare(api, scene, oscene, w, h, prm, frames, cam=None, reset_at=None,
     from oracle import zro
     r = api.Renderer(scene, w, h, params=prm, integrator=api.INTEGRATOR_RESTIR_PT)
     if overlap:
-        r.enable_frame_overlap()
+        r.enable_frame_overlap(True, carry=True)      # (carry: the unused bytes of the reservoir records too, so whole planes compare equal)
     o = zro.OracleRPT(oscene, w, h)
     prev = None
     for f in range(1, frames + 1):
@@ -178,6 +178,8 @@ def _rpt_compare(api, scene, oscene, w, h, prm, frames, cam=None, reset_at=None,
             prev = cb.copy()
         if prm.presampling:
             oscene.presample(f, int(prm.num_sample_sets), int(prm.sample_set_size))
+        if len(scene.emissives) == 0:
+            oscene.sky_lut(cb, 256, 128)      # sun + sky lighting samples the sky-view LUT (K17)
         if reset_at == f:
             r.p_indirect.reset_temporal(); o.reset_temporal()
         r.p_indirect.read_counters(reset=True)
@@ -204,32 +206,33 @@ def test_restir_pt_bit_exact(api, cornell_emissive, oracle_emissive, w, h):
     assert got[..., :3].max() > 0
 
 
-def _overlap_digest(api, scene, w, h, prm, frames, overlap, cam_of_frame=None, denoise=False, toggle_at=()):
-    """sha1 per frame over FINAL, every reservoir plane, the target plane (and the denoised image) of a ReSTIR PT sequence"""
+def _overlap_digest(api, scene, w, h, prm, frames, overlap, cam_of_frame=None, denoise=False, toggle_at=(), carry=True):
+    """sha1 per frame over FINAL, every reservoir plane, the target plane (and the denoised image) of a ReSTIR PT sequence; and over FINAL alone"""
     import hashlib
     r = api.Renderer(scene, w, h, params=prm, integrator=api.INTEGRATOR_RESTIR_PT)
     if denoise:
         r.enable_denoise()
     if overlap:
-        r.enable_frame_overlap()
-    out, prev = [], None
+        r.enable_frame_overlap(True, carry)
+    out, fin, prev = [], [], None
     for f in range(1, frames + 1):
         if f in toggle_at:
             overlap = not overlap
-            r.enable_frame_overlap(overlap)
+            r.enable_frame_overlap(overlap, carry)
         cb = _frame(scene, w, h, f, **(cam_of_frame(f) if cam_of_frame else {}))
         if prev is not None:
             cb["prev_view"], cb["prev_view_inv"], cb["prev_camera_jitter"] = prev["curr_view"], prev["curr_view_inv"], prev["curr_camera_jitter"]
         prev = cb.copy()
         r.render_frame(cb)
         hh = hashlib.sha1(r.final().tobytes())
+        fin.append(hh.hexdigest())
         for nm in ("B", "C", "D", "E", "F", "G", "target"):
             hh.update(r.p_indirect.download_plane(nm).tobytes())
         hh.update((r.p_indirect.download_plane("A") & 0xffffff).tobytes())
         if denoise:
             hh.update(r.p_denoise.download_plane("denoised").tobytes())
         out.append(hh.hexdigest())
-    return out, r.p_indirect.read_counters()
+    return out, fin, r.p_indirect.read_counters()
 
 
 def test_frame_overlap_changes_nothing(api, cornell_emissive, oracle_emissive, cornell_sky):
@@ -239,7 +242,9 @@ def test_frame_overlap_changes_nothing(api, cornell_emissive, oracle_emissive, c
         rendered before either half), a materials scene with presampled light sets (K3 every frame on the first half's stream);
       * 1920 x 1080, where the two halves really run side by side (each alone fills the device): 6 frames with the camera moving from frame 4, every plane
         of every frame hashes to the digest of the plain order; the same with the denoise pass consuming each frame, and with the switch flipped on and
-        off in the middle of the sequence (the plane roles carry over); ray counters identical."""
+        off in the middle of the sequence (the plane roles carry over); ray counters identical.
+    These run ZR_FRAME_OVERLAP_CARRY (whole planes comparable).  The product mode leaves the UNUSED bytes of the reservoir records to the rotation of the three
+    sets: its FINAL image and ray counters over 12 frames equal the plain order's."""
     from oracle import zro
     cam = lambda f: dict(cam_pos=(0.05 * max(0, f - 2), 1.2, -4.043))
     _rpt_compare(api, cornell_emissive, oracle_emissive, 200, 120, wire.default_params(), 5, reset_at=4, overlap=True, cam_of_frame=cam)
@@ -257,12 +262,17 @@ def test_frame_overlap_changes_nothing(api, cornell_emissive, oracle_emissive, c
     cam = lambda f: dict(cam_pos=(0.02 * max(0, f - 3), 1.2, -4.043))
     ref = {}
     for dn in (False, True):
-        plain, c0 = _overlap_digest(api, cornell_emissive, w, h, wire.default_params(), 6, False, cam, denoise=dn)
-        over, c1 = _overlap_digest(api, cornell_emissive, w, h, wire.default_params(), 6, True, cam, denoise=dn)
+        plain, fin0, c0 = _overlap_digest(api, cornell_emissive, w, h, wire.default_params(), 6, False, cam, denoise=dn)
+        over, _, c1 = _overlap_digest(api, cornell_emissive, w, h, wire.default_params(), 6, True, cam, denoise=dn)
         assert plain == over and c0 == c1, (dn, [a == b for a, b in zip(plain, over)], c0, c1)
-        ref[dn] = (plain, c0)
-    mixed, c2 = _overlap_digest(api, cornell_emissive, w, h, wire.default_params(), 6, False, cam, toggle_at=(3, 5))
-    assert mixed == ref[False][0] and c2 == ref[False][1], [a == b for a, b in zip(mixed, ref[False][0])]
+        ref[dn] = (plain, fin0, c0)
+    mixed, _, c2 = _overlap_digest(api, cornell_emissive, w, h, wire.default_params(), 6, False, cam, toggle_at=(3, 5))
+    assert mixed == ref[False][0] and c2 == ref[False][2], [a == b for a, b in zip(mixed, ref[False][0])]
+    # the product mode (no carry): the bytes a reservoir record does not use may differ, nothing else -- FINAL of every frame and the ray counters are the plain order's
+    # (a used byte that differed would change a later frame's radiance: the reservoirs of frame N are the temporal and spatial inputs of frames N + 1 ...)
+    plain12, fin12, c12 = _overlap_digest(api, cornell_emissive, w, h, wire.default_params(), 12, False, cam)
+    _, finp, cp = _overlap_digest(api, cornell_emissive, w, h, wire.default_params(), 12, True, cam, carry=False)
+    assert finp == fin12 and cp == c12, ([a == b for a, b in zip(finp, fin12)], cp, c12)
 
 
 def test_restir_pt_thread_sort_on_partial_tiles(api, cornell_emissive, oracle_emissive):

@@ -303,3 +303,57 @@ def test_cpp_passes_take_the_reference_ui_parameters(cornell_emissive, oracle_em
     for f in range(n):
         plain = o2.render(cbs[f], wire.default_params())
     assert not np.array_equal(plain.view(np.uint32), want.view(np.uint32))
+
+
+@pytest.mark.gpu
+def test_cpp_indirect_pass_as_two_graph_nodes_overlaps_frames(cornell_emissive, oracle_emissive):
+    """IndirectLighting::SetFrameOverlap + RenderCandidates / RenderReuse: the ReSTIR PT pass as two nodes of the C++ RenderGraph -- GBuffer, PreLighting and
+    Indirect.Candidates on the async-compute queue, Indirect.Reuse on the direct queue -- with the frames of the sequence submitted back to back (one wait at
+    the end).  5 frames, camera moving from frame 3: FINAL of the last frame == the oracle (carry and product mode), == the single-node graph; the graph's
+    batches show the two halves; the same at 1280 x 720 (where the halves really run side by side) against the single-node graph, with light presampling on
+    a materials scene."""
+    from oracle import zro
+    L = _lib()
+    L.zrh_render_sequence_overlap.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_char_p, C.c_int]
+
+    def cbs_of(sc, w, h, n, cam0):
+        out, prev = [], None
+        for f in range(1, n + 1):
+            cb = scene_io.make_frame_constants(w, h, frame_num=f, num_emissives=len(sc.emissives), cam_pos=(cam0[0] + 0.04 * max(0, f - 2), cam0[1], cam0[2]))
+            if prev is not None:
+                cb["prev_view"], cb["prev_view_inv"], cb["prev_camera_jitter"] = prev["curr_view"], prev["curr_view_inv"], prev["curr_camera_jitter"]
+            prev = cb.copy()
+            out.append(cb)
+        return np.ascontiguousarray(np.stack(out))
+
+    def run(sc, cbs, w, h, mode, sets=0, size=0):
+        desc = sc.desc()
+        out = np.zeros((h, w, 4), np.float32)
+        buf = C.create_string_buffer(512)
+        assert L.zrh_render_sequence_overlap(C.addressof(desc), cbs.ctypes.data, len(cbs), w, h, mode, out.ctypes.data, sets, size, buf, 512) == 0
+        return out, buf.value.decode()
+
+    w, h, n = 96, 64, 5
+    cbs = cbs_of(cornell_emissive, w, h, n, (0.0, 1.2, -4.043))
+    o = zro.OracleRPT(oracle_emissive, w, h)
+    prm = wire.default_params()
+    for f in range(n):
+        want = o.render(cbs[f], prm)
+    for mode in (0, 1, 2):
+        got, batches = run(cornell_emissive, cbs, w, h, mode)
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), f"overlap mode {mode}"
+        b = [set(x.split(",")) for x in batches.split("|")]
+        if mode:
+            assert b == [{"GBuffer", "PreLighting"}, {"Indirect.Candidates"}, {"Indirect.Reuse"}], batches
+        else:
+            assert b == [{"GBuffer", "PreLighting"}, {"Indirect"}], batches
+    # at a size where each half fills the device, and with PreLighting's K3 regenerating the light sets every frame on the first half's queue
+    w, h, n = 1280, 720, 6
+    sc = scene_io.make_synthetic_scene(num_tris=3000, num_emissive=1500, seed=11)
+    for scene, cam0, sets, size in ((cornell_emissive, (0.0, 1.2, -4.043), 0, 0), (sc, (0.0, 0.0, -3.5), 16, 64)):
+        cbs = cbs_of(scene, w, h, n, cam0)
+        plain, _ = run(scene, cbs, w, h, 0, sets, size)
+        for mode in (1, 2):
+            got, _ = run(scene, cbs, w, h, mode, sets, size)
+            assert np.array_equal(got.view(np.uint32), plain.view(np.uint32)), (mode, sets)
+        assert plain[..., :3].max() > 0

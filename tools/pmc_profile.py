@@ -1,4 +1,4 @@
-"""profiles/<name>.json <- the per-kernel summaries of separate rocprofv3 --pmc passes of one bench.py command (scripts/gpu_r03_profiles.sh):
+"""profiles/<name>.json <- the per-kernel summaries of separate rocprofv3 --pmc passes of one bench.py command (scripts/gpu.sh profiles):
 FETCH_SIZE, WRITE_SIZE and the SQ passes A (waves / cycles / waits), B (active cycles per instruction type), C (instruction counts),
 E (VALU classes).  Per kernel and launch:
 

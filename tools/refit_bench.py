@@ -1,6 +1,6 @@
 """Latency of zr_scene_update_instances on the BASELINE config-4 stand-in (262k-triangle atrium): device refit (default) next to the host rebuild
 (ZR_SCENE_UPDATE=rebuild), and the ReSTIR PT frame time on the refit / rebuilt tree after the largest non-emissive clutter instance moved.
-Prints one JSON line; scripts/gpu_refit.sh runs it once per mode.  GPU only."""
+Prints one JSON line; scripts/gpu_refit.sh [rounds 1-4: git history up to 31e92fa; today scripts/gpu.sh ab] runs it once per mode.  GPU only."""
 import json, os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

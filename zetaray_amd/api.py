@@ -366,10 +366,10 @@ class Pass:
     def set_input(self, which, dev_ptr):
         _check(lib().zr_pass_set_input(self.h, which, dev_ptr))
 
-    def set_frame_overlap(self, gbuffer, on=True):
+    def set_frame_overlap(self, gbuffer, on=1):
         """ReSTIR PT: keep a third reservoir set + second target / FINAL planes so that this frame's CANDIDATES stage may run beside the previous frame's
         reuse stages on another stream (zetaray_amd.h zr_pass_set_frame_overlap); the G-buffer becomes stream-tracked"""
-        _check(lib().zr_pass_set_frame_overlap(self.h, gbuffer.h, int(on)))
+        _check(lib().zr_pass_set_frame_overlap(self.h, gbuffer.h, int(on)))      # 0 off, 1 = ZR_FRAME_OVERLAP, 2 = ZR_FRAME_OVERLAP_CARRY
 
     def frame_overlap_stream(self):
         """the pass-owned non-blocking stream for the GBUFFER / PRELIGHTING / CANDIDATES half of an overlapped frame (a hipStream_t as an integer)"""
@@ -511,15 +511,17 @@ class Renderer:
         self._overlap_stream = None   # frame overlap: enable_frame_overlap()
         self._device = device
 
-    def enable_frame_overlap(self, on=True):
-        """Software-pipeline consecutive ReSTIR PT frames on two streams: the G-buffer, PreLighting and K11 of frame N + 1 go to a stream of the pass's
+    def enable_frame_overlap(self, on=True, carry=False):
+        """(carry: ZR_FRAME_OVERLAP_CARRY -- the unused bytes of the reservoir records are carried over too, so every plane equals the plain order's byte
+        for byte: what the parity tests compare with the oracle; costs one streaming copy per frame)
+        Software-pipeline consecutive ReSTIR PT frames on two streams: the G-buffer, PreLighting and K11 of frame N + 1 go to a stream of the pass's
         own and run beside the search / sort / replay / reconnect kernels of frame N (the reference overlaps its direct and async-compute queues the same
         way, RenderGraph.cpp:442-541).  Bit-identical frames; throughput goes up, the latency of one frame does not go down.  Indirect (ReSTIR PT) + denoise
         only: the DI passes, Compositing and TAA keep single-buffered outputs that the next frame's first half would overwrite under their consumers."""
         assert self.p_direct is None and self.p_sky_direct is None and self.p_composit is None and getattr(self, "p_taa", None) is None, \
             "frame overlap covers GBuffer + PreLighting + Indirect (ReSTIR PT) [+ denoise]"
         _check(lib().zr_device_synchronize(self._device))
-        self.p_indirect.set_frame_overlap(self.gbuffer, on)
+        self.p_indirect.set_frame_overlap(self.gbuffer, (2 if carry else 1) if on else 0)
         self._overlap_stream = self.p_indirect.frame_overlap_stream() if on else None
 
     def enable_compositing(self, device=0, firefly_filter=False):

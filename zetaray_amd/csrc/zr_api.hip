@@ -497,6 +497,8 @@ struct zr_scene
     // material class (SceneView::plain): host copy of the material table + "every material is an opaque uncoated non-metallic dielectric"; kept current by
     // zr_scene_create / zr_scene_update_materials on the calling thread, read by zr_pass_render when it picks a kernel permutation
     std::vector<zr_material> hMaterials; std::atomic<bool> plainMaterials{false};
+    // identity of this scene for the G-buffers rendered from it (zr_gbuffer::sceneAt): never reused, unlike an address
+    uint64_t uid = [] { static std::atomic<uint64_t> next{1}; return next.fetch_add(1); }();
     DevBuf<TriMeta> meta; DevBuf<uint16_t> rho;
     DevBuf<zr_texture_desc> texDescs; DevBuf<uint8_t> texels; DevBuf<float> srgb;   // material texture heap (zr_texture.h)
     DevBuf<zr_presampled_tri> sampleSets; uint32_t numSampleSets = 0;      // K3 output, refreshed by every PRELIGHTING render
@@ -624,7 +626,7 @@ static int SceneReleaseAfterRender(const zr_scene* scc, hipStream_t st)
 // The scene as one launch sees it: a private copy of the scene's view with the texture descriptor-table offsets of THIS frame's
 // constants (per-frame data in the reference, FrameConstants.h:31-34) -- nothing per-frame is latched on the shared scene.
 #ifdef ZR_PROF
-// measurement build only (scripts/gpu_prof.sh): 8 kernels x 32 wave-cycle / event counters, read and cleared by zr_debug_prof_read
+// measurement build only (scripts/gpu.sh prof): 8 kernels x 32 wave-cycle / event counters, read and cleared by zr_debug_prof_read
 static unsigned long long* ProfBuffer()
 {
     static unsigned long long* p = nullptr;
@@ -678,6 +680,9 @@ struct zr_gbuffer
     // the scene's material class (zr_scene::plainMaterials) at the time each plane set was rendered: the PLAIN kernel permutations take a pixel's flags as known,
     // so both the current and the previous frame's planes must come from a plain material table (a scene that BECAME plain renders one more frame with the general kernels)
     bool plainAt[2] = {true, true};
+    // ... and WHICH scene rendered it (zr_scene::uid; 0 = never rendered by a GBUFFER pass): planes an engine filled itself through zr_gbuffer_device_plane, or
+    // rendered from another scene than the lighting pass is given, carry flags the lighting pass cannot vouch for -- they run the general kernels
+    uint64_t sceneAt[2] = {0, 0};
     // stream tracking (zr_pass_set_frame_overlap): with the passes of a frame spread over two streams, a GBUFFER render must not overwrite a plane set
     // that a pass on another stream still reads, and a pass on another stream must not read a set before its GBUFFER render has finished
     bool tracked = false;
@@ -775,7 +780,14 @@ static std::atomic<uint32_t> g_largeSceneNodes{kLargeSceneNodes};
 static std::atomic<bool> g_materialClassKernels{true};      // zr_debug_set_material_class_kernels: plain scenes run the PLAIN kernel permutations
 // the PLAIN kernel permutations apply: the scene's material table is of the plain class (and has no texture heap)
 static bool PlainClass(const zr_scene* sc, const zr_gbuffer* gb)
-{ return sc->plainMaterials.load(std::memory_order_relaxed) && gb->plainAt[0] && gb->plainAt[1] && g_materialClassKernels.load(std::memory_order_relaxed); }
+{
+    if (!sc->plainMaterials.load(std::memory_order_relaxed) || !g_materialClassKernels.load(std::memory_order_relaxed)) return false;
+    const int c = gb->cur;
+    if (!(gb->plainAt[c] && gb->sceneAt[c] == sc->uid)) return false;
+    // the other set is the previous frame's G-buffer; nothing reads it before the second GBUFFER render (havePrevGBuffer)
+    if (gb->numRendered >= 2 && !(gb->plainAt[c ^ 1] && gb->sceneAt[c ^ 1] == sc->uid)) return false;
+    return true;
+}
 static constexpr int kMaxRounds = 16;
 static constexpr int kMaxTimers = 64;
 // ray-counter slots (pairs of u64 on the device): 0 = wavefront path tracer, 1.. = ReSTIR PT kernels in launch order
@@ -819,7 +831,7 @@ struct zr_pass
     // Frame overlap (zr_pass_set_frame_overlap).  rptSet: which storage plays the two roles currIdx flips between ([0], [1]) and which one is free ([2]);
     // the CANDIDATES stage of an overlapped frame writes the free set and hands the set it replaces back.  tgtIdx / finIdx: the target / FINAL plane of
     // the frame whose CANDIDATES stage ran last; finOut: the FINAL plane of the last frame whose final stage has been enqueued (zr_pass_get_output)
-    bool overlap = false; int rptSet[3] = {0, 1, 2}; int tgtIdx = 0, finIdx = 0, finOut = 0;
+    bool overlap = false, overlapCarry = false; int rptSet[3] = {0, 1, 2}; int tgtIdx = 0, finIdx = 0, finOut = 0;
     DevBuf<float> finalAlt;
     hipStream_t overlapStream = nullptr;                     // "stream A" for callers without streams of their own
     hipEvent_t evCand = nullptr, evTemporal = nullptr;       // K11 of the open frame done (on candStream) / K14 of the last frame done (on reuseStream)
@@ -2047,7 +2059,7 @@ static int RenderGBuffer(zr_pass* p, hipStream_t s, const zr_frame_constants* cb
     const uint32_t tilesX = (gb->w + 15) / 16, tilesY = (gb->h + 15) / 16;
     if (int wr = GBufferAcquireWrite(gb, gb->cur ^ 1, s)) return wr;      // (tracked G-buffers: the set about to be overwritten may still be read on another stream)
     gb->cur ^= 1; gb->numRendered++;
-    gb->plainAt[gb->cur] = sc->plainMaterials.load(std::memory_order_relaxed);
+    gb->plainAt[gb->cur] = sc->plainMaterials.load(std::memory_order_relaxed); gb->sceneAt[gb->cur] = sc->uid;
     TimerBegin(p, s, "gbuffer");
     uint32_t pickXY = 0xffffffffu;
     if (p->pickXY != 0xffffffffu)
@@ -2343,10 +2355,20 @@ static int RenderReSTIR_GI(zr_pass* p, hipStream_t s, const zr_frame_constants* 
 
 // K11 is launched as one-wave blocks, and a wave lives for the whole path: a grid of a few thousand waves runs in ROUNDS of as many waves as are
 // resident at once -- 3072 for the 3-wave build, 4096 for the 4-wave build.  A 480 x 544 tile of the 8-way screen split is 4080 waves: one round and
-// a third of a second one at 3 waves per SIMD, exactly one at 4.  Measured per tile of the Cornell frame (scripts/gpu_r03_rounds.sh): the busiest
+// a third of a second one at 3 waves per SIMD, exactly one at 4.  Measured per tile of the Cornell frame (scripts/gpu_r03_rounds.sh [rounds 1-4: git history up to 31e92fa; today scripts/gpu.sh ab]): the busiest
 // 8-way tiles 0.365 -> 0.31 ms with the 4-wave build (slowest tile of the split 0.82 -> 0.76 ms); with two rounds or more the per-wave cost of the
 // 4-wave build (the kernel is VALU-bound: a wave shares its SIMD with one more) eats the saving -- the 4-way split's tiles (8160 waves) get 4 - 17 %
 // slower, the 2-way split's do not care -- so only the one-round case switches.
+// frame overlap, carry mode: every plane of reservoir set `src` (+ its target plane) into `dst`, pixel by pixel (62 + 16 B read and written per pixel)
+__global__ void __launch_bounds__(256) k_rpt_carry(rpt::ResPlanes dst, rpt::ResPlanes src, F4* tdst, const F4* tsrc, size_t n)
+{
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+    {
+        dst.A[i] = src.A[i]; dst.B[2 * i] = src.B[2 * i]; dst.B[2 * i + 1] = src.B[2 * i + 1]; dst.C[i] = src.C[i]; dst.D[i] = src.D[i]; dst.E[i] = src.E[i];
+        dst.F[2 * i] = src.F[2 * i]; dst.F[2 * i + 1] = src.F[2 * i + 1]; dst.G[2 * i] = src.G[2 * i]; dst.G[2 * i + 1] = src.G[2 * i + 1];
+        tdst[i] = tsrc[i];
+    }
+}
 static bool FewerRoundsAtFourWaves(uint32_t waves)
 {
     static const bool off = [] { const char* e = ZR_EXP_ENV("ZR_K11_ROUNDS"); return e && !strcmp(e, "0"); }();      // (A/B switch)
@@ -2357,6 +2379,7 @@ static int RenderReSTIR_PT(zr_pass* p, hipStream_t s, const zr_frame_constants* 
 {
     using namespace rpt;
     // the TEMPORAL stage in its two halves (zetaray_amd.h): K11 alone / K12 - K14
+    const zr_pass::ResStorage* carryFrom = nullptr;
     const bool stageCand = (stages & (ZR_STAGE_TEMPORAL | ZR_STAGE_CANDIDATES)) != 0, stageReuseT = (stages & (ZR_STAGE_TEMPORAL | ZR_STAGE_TEMPORAL_REUSE)) != 0;
     if (stageCand && p->overlap)
     {
@@ -2367,6 +2390,7 @@ static int RenderReSTIR_PT(zr_pass* p, hipStream_t s, const zr_frame_constants* 
         // K14 on its stream) and the last reader of the G-buffer set this frame's GBUFFER render overwrote.
         std::swap(p->rptSet[p->currIdx], p->rptSet[2]);
         p->tgtIdx ^= 1;
+        carryFrom = p->overlapCarry ? &p->res[p->rptSet[2]] : nullptr;
         if (!(cb->accumulate && cb->camera_static)) p->finIdx ^= 1;      // (an accumulating frame adds to the plane the frames before it wrote)
         if (p->haveTemporal && p->reuseStream != s) HIP_TRY(hipStreamWaitEvent(s, p->evTemporal, 0));
     }
@@ -2397,7 +2421,7 @@ static int RenderReSTIR_PT(zr_pass* p, hipStream_t s, const zr_frame_constants* 
     prm.textured = sc->view.tex.count ? 1u : 0u;
     prm.sortTemporal = (ip.flags & ZR_IND_SORT_TEMPORAL) ? 1u : 0u; prm.sortSpatial = (ip.flags & ZR_IND_SORT_SPATIAL) ? 1u : 0u;
     // the CtN map (current reservoirs bucketed by k) schedules the fused CtT + TtC kernel: 0.540 -> 0.495 ms Cornell, 3.27 -> 3.16 ms atrium at
-    // 1080p; the NtC map does not pay (0.546 / 3.34).  ZR_TEMPORAL_MAP = 0 / 1 / 2 overrides (scripts/gpu_sortmap.sh)
+    // 1080p; the NtC map does not pay (0.546 / 3.34).  ZR_TEMPORAL_MAP = 0 / 1 / 2 overrides (scripts/gpu_sortmap.sh [rounds 1-4: git history up to 31e92fa; today scripts/gpu.sh ab])
     static const uint32_t temporalMapEnv = [] { const char* e = ZR_EXP_ENV("ZR_TEMPORAL_MAP"); return e ? (uint32_t)atoi(e) : 1u; }();
     prm.temporalMap = prm.sortTemporal ? temporalMapEnv : 0u;
     if (stageCand)
@@ -2448,6 +2472,15 @@ static int RenderReSTIR_PT(zr_pass* p, hipStream_t s, const zr_frame_constants* 
     if (stageCand)
     {
         if (int ar = GBufferAcquireRead(gb, s)) return ar;
+        if (carryFrom)
+        {
+            // ZR_FRAME_OVERLAP_CARRY: K11 and the passes behind it update reservoir records in place (Reservoir.hlsli:283-456 writes the components a record's case
+            // uses), so the bytes a record does NOT use are whatever the set held before -- in the plain order the set K11 wrote last frame, here the free set.
+            // Copying the replaced set (and target plane) into the one that takes its place makes every byte of every plane equal to the plain order's.
+            const size_t n = (size_t)p->w * p->h;
+            RPT_TIMED("rpt_overlap_carry", hipLaunchKernelGGL(k_rpt_carry, dim3((uint32_t)std::min<size_t>((n + 255) / 256, 4096)), dim3(256), 0, s, F.cur, carryFrom->View(), p->Target(),
+                (const F4*)(p->tgtIdx ? p->rptTarget.p : p->rptTargetAlt.p), n));
+        }
         TimerBegin(p, s, "rpt_pathtrace");
 #ifdef ZR_EXPERIMENTS
         // (experiments build, zr_kernels_exp.h) ZR_K11=pool: K11 with block-pooled traces (k_rpt_pathtrace_coop; emissive untextured permutation);
@@ -2843,7 +2876,7 @@ int zr_pass_set_frame_overlap(zr_pass* p, zr_gbuffer* gb, int enable)
         HIP_TRY(hipStreamCreateWithFlags(&p->overlapStream, hipStreamNonBlocking));
     }
     // switching off keeps the plane roles as they stand (the set last written as FINAL stays the one the next frame reads); FINAL goes on in the plane it is in
-    p->overlap = enable != 0; p->haveCand = false; p->haveTemporal = false;
+    p->overlap = enable != 0; p->overlapCarry = enable == ZR_FRAME_OVERLAP_CARRY; p->haveCand = false; p->haveTemporal = false;
     gb->tracked = enable != 0;
     if (!enable) { gb->hasWrite = false; for (auto& v : gb->readers) { for (auto& r : v) (void)hipEventDestroy(r.ev); v.clear(); } }
     return ZR_OK;

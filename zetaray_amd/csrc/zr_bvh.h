@@ -39,12 +39,12 @@ class BvhBuilder
 {
 public:
     static constexpr int kBins = 16;
-    // Triangles per leaf.  Measured on MI355X (scripts/gpu_bvh.sh, 1080p): 4 -> 2 triangles cuts the triangle phase of the voted traversal (its lane
+    // Triangles per leaf.  Measured on MI355X (scripts/gpu_bvh.sh [rounds 1-4: git history up to 31e92fa; today scripts/gpu.sh ab], 1080p): 4 -> 2 triangles cuts the triangle phase of the voted traversal (its lane
     // utilisation is the lowest of the loop) for a few more inner nodes: atrium ReSTIR PT 22.05 -> 19.57 ms, K9 10.69 -> 9.89 ms, Cornell
     // ReSTIR PT 2.51 -> 2.37 ms, ReSTIR GI 1.70 -> 1.51 ms; 1 and 3 are worse than 2, 8 much worse (25.5 ms), SAH leaf termination equals 2.
     static constexpr uint32_t kMaxLeaf = 2;
     static constexpr uint32_t kTinyScene = 8;      // up to this many triangles: one leaf, no nodes
-    // experiment knobs (scripts/gpu_bvh.sh): ZR_BVH_MAX_LEAF = 1..8 triangles per leaf; ZR_BVH_SAH_LEAF = node cost in triangle tests (> 0: a range of
+    // experiment knobs (scripts/gpu_bvh.sh [rounds 1-4: git history up to 31e92fa; today scripts/gpu.sh ab]): ZR_BVH_MAX_LEAF = 1..8 triangles per leaf; ZR_BVH_SAH_LEAF = node cost in triangle tests (> 0: a range of
     // <= max-leaf triangles becomes a leaf when splitting it would not pay for the extra node)
     uint32_t maxLeaf_ = kMaxLeaf; float nodeCost_ = 0.0f;
     BvhBuilder()

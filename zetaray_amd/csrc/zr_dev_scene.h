@@ -65,17 +65,18 @@ struct SceneView
     uint32_t baseColorMapsOffset, normalMapsOffset, mrMapsOffset, emissiveMapsOffset;
     uint32_t texFilter;      // zr_params.tex_filter of the pass that launches the kernel (cb_ReSTIR_*::TexFilterDescHeapIdx); ZR_TEX_FILTER_*
     uint32_t numEmissives;
-    // material class of the scene: every material is an opaque, uncoated, non-metallic dielectric and there is no texture heap (zr_api.hip ScenePlain).  The
-    // host sets it; kernels of the PLAIN permutation overwrite it with their template constant, so that InitSurface(…, plain) folds (zr_dev_bsdf.h)
+    // material class of the scene: every material is an opaque, uncoated, non-metallic dielectric and there is no texture heap (zr_api.hip MaterialsArePlain).
+    // The host leaves it 0; kernels of the PLAIN permutation -- which the host launches only for such scenes, zr_api.hip PlainClass -- overwrite it with their
+    // template constant, so that InitSurface(..., plain) folds (zr_dev_bsdf.h).  The host executor of the tests sets it through zhx_set_material_class.
     uint32_t plain;
     uint32_t numNodes;       // 0 => single leaf covering tris[0 .. numTris)
     uint32_t numTris;
 #ifdef ZR_PROF
-    unsigned long long* prof;     // -DZR_PROF builds only (scripts/gpu_prof.sh): wave-cycle counters per kernel / section
+    unsigned long long* prof;     // -DZR_PROF builds only (scripts/gpu.sh prof): wave-cycle counters per kernel / section
 #endif
 };
 
-// Section timers of the -DZR_PROF measurement build (scripts/gpu_prof.sh): wave cycles (s_memtime) between construction and
+// Section timers of the -DZR_PROF measurement build (scripts/gpu.sh prof): wave cycles (s_memtime) between construction and
 // destruction, summed per wave in LDS (one lane, no atomics on the hot path) and flushed to sc.prof[32 * kernel + i] when
 // the kernel ends.  Empty in the product build.
 #if defined(ZR_PROF) && defined(__HIP_DEVICE_COMPILE__)
@@ -186,7 +187,7 @@ static constexpr int kTravStackWords = 2 * kTravStack;
 #endif
 // intra-wave work stealing inside Traverse (see TraverseDyn): idle lanes take the top stack entry of busy lanes.  Bit-exact (the GPU parity
 // suite passes with it) and 23 % fewer vote iterations per call, but SLOWER on every workload measured (ReSTIR PT Cornell
-// 2.28 -> 2.65 ms, atrium 17.8 -> 20.7 ms, K9 trace 5.19 -> 5.44 ms), so it is compiled out; -DZR_STEAL=1 builds it (scripts/gpu_steal.sh).
+// 2.28 -> 2.65 ms, atrium 17.8 -> 20.7 ms, K9 trace 5.19 -> 5.44 ms), so it is compiled out; -DZR_STEAL=1 builds it (scripts/gpu_steal.sh [rounds 1-4: git history up to 31e92fa; today scripts/gpu.sh ab]).
 #ifndef ZR_STEAL
 #define ZR_STEAL 0
 #endif
@@ -215,7 +216,7 @@ struct StackEntry { uint32_t child; float t; };
 // `aux` (device, ZR_STEAL): this wave's work-stealing region in LDS -- 64 x u64 merge keys, 64 x (t, u, v) payloads, 64 x u32 donor lanes
 // `cache` (device, -DZR_NODE_CACHE=N): the first N nodes of the tree -- its top levels, nodes are numbered breadth-first -- copied into LDS by the
 // block (north_star's "LDS-staged node cache"); measured, DESIGN 5.7
-// Measured (MI355X, 1080p, N = 64 = 4 KB per block, later 32; scripts/gpu_r03_k11.sh with a -DZR_NODE_CACHE=64 build of every kernel): K11 on the 380k-triangle
+// Measured (MI355X, 1080p, N = 64 = 4 KB per block, later 32; scripts/gpu_r03_k11.sh [rounds 1-4: git history up to 31e92fa; today scripts/gpu.sh ab] with a -DZR_NODE_CACHE=64 build of every kernel): K11 on the 380k-triangle
 // atrium 8.37 -> 7.63 ms; the reconnect kernels get slower with it (K14 3.30 -> 3.43 ms, Cornell 0.508 -> 0.538 ms: their traversals are a quarter
 // of the kernel and the fill + the extra branch cost more than the top-level hits save); Cornell's tree has fewer than N nodes.  So only the
 // large-scene K11 (k_rpt_pathtrace_w4) fills it; kernels that do not fill keep cache == nullptr, a compile-time constant that folds the branch away.

@@ -20,7 +20,7 @@ static constexpr int kBlock = 256;
 // threads per block of K11 (k_rpt_pathtrace*): 64 = one block per wave of the 16 x 16 tile.  A block's registers and LDS are released when its
 // slowest wave ends, and the waves of K11 run for very different times (path lengths): one-wave blocks measured 1.006 -> 0.947 ms (Cornell) and
 // 8.34 -> 8.01 ms (atrium) at 1080p.  K14 / K16 do the same work in every wave and are 2 - 5 % slower that way (0.492 -> 0.518 ms), so they keep
-// 256 (scripts/gpu_block.sh; -DZR_RPT_BLOCK=256 restores one block per tile).
+// 256 (scripts/gpu_block.sh [rounds 1-4: git history up to 31e92fa; today scripts/gpu.sh ab]; -DZR_RPT_BLOCK=256 restores one block per tile).
 #ifndef ZR_RPT_BLOCK
 #define ZR_RPT_BLOCK 64
 #endif
@@ -319,7 +319,7 @@ template<bool EMISSIVE, bool PLAIN = false>
 __global__ void __launch_bounds__(kRptBlock) ZR_WAVES_PATHTRACE_LARGE k_rpt_pathtrace_w4(rpt::RptFrame F, zr_frame_constants g, uint32_t tilesX, unsigned long long* counters)
 { RptPathtraceBody<EMISSIVE, false, true, false, PLAIN>(F, g, tilesX, counters); }
 // The TEXTURED permutation at 6 waves per SIMD: its dependent texel gathers are latency that more waves hide -- textured atrium 11.99 ms at the
-// compiler's 2 waves (255 VGPRs), 10.74 at >= 3, 10.28 at 4, 10.11 at 5, **9.36 at 6**, 9.69 at 7, 9.96 at 8 (scripts/gpu_tex.sh, gpu_waves.sh); the
+// compiler's 2 waves (255 VGPRs), 10.74 at >= 3, 10.28 at 4, 10.11 at 5, **9.36 at 6**, 9.69 at 7, 9.96 at 8 (scripts/gpu_tex.sh [rounds 1-4: git history up to 31e92fa; today scripts/gpu.sh ab], gpu_waves.sh); the
 // untextured large-scene build stays at 4 (5: 8.49, 6: 8.35 against 8.02 ms).  Round 1 found that forcing it to exactly 3 waves
 // (amdgpu_waves_per_eu(3, 3): ~150 spilled VGPRs) makes ROCm 7.2's clang miscompile the <sun + sky, textured> instance -- the y / z components
 // of the reconnection radiance rc.L of case-1 samples were written as 0 in ~70 % of the pixels; the builds above all pass the 15 textured parity
@@ -429,7 +429,7 @@ __global__ void __launch_bounds__(kBlock) k_rpt_light(rpt::RptFrame F, zr_frame_
 // hundred instructions and two full bounces, so a static split of a list over the blocks leaves the kernel waiting for its unluckiest block
 // (atrium: 1.99 of 3 resident waves per SIMD on average, PMC).  DYNAMIC: a persistent grid (as many waves as are resident at once) in which
 // every wave pulls the next 128 entries from a cursor next to the list's count -- one returning atomic per wave and chunk -- first from list A
-// until it is empty, then from list B.  Which wave replays a pixel has no influence on the result.  Measured (scripts/gpu_r03_replay.sh,
+// until it is empty, then from list B.  Which wave replays a pixel has no influence on the result.  Measured (scripts/gpu_r03_replay.sh [rounds 1-4: git history up to 31e92fa; today scripts/gpu.sh ab],
 // atrium): the temporal replays 1.27 -> 1.19 ms at 1080p, 4.14 -> 3.46 ms at 3840 x 2160; the spatial replays get SLOWER that way (0.88 -> 1.03 ms at
 // 1080p, unchanged at 4K) and keep the static split; with 64-entry chunks and a 2048-block grid the cursor itself was the bottleneck (16 k
 // returning atomics on one word: + 0.5 ms on the Cornell frame, whose lists are nearly empty).

@@ -12,7 +12,7 @@ template<class Frame> __device__ __forceinline__ void SetMaterialClassDi(Frame& 
 __device__ __forceinline__ void SetMaterialClassGi(rgi::GiFrame& F, bool plain) { F.sc.plain = plain; F.gb.plain = plain; F.gbPrev.plain = plain; }
 
 // ------------------------------------------------------------------------------------------------ sun + sky ReSTIR DI kernels
-// threads per block (see kRptBlock in zr_kernels.h; scripts/gpu_block3.sh): one-wave blocks pay for the emissive DI kernels (K5 0.580 -> 0.568 ms
+// threads per block (see kRptBlock in zr_kernels.h; scripts/gpu_block3.sh [rounds 1-4: git history up to 31e92fa; today scripts/gpu.sh ab]): one-wave blocks pay for the emissive DI kernels (K5 0.580 -> 0.568 ms
 // Cornell, 5.42 -> 5.12 ms atrium; K6 0.258 -> 0.241 / 2.99 -> 2.61 ms), not for the sun + sky ones (K7 / K8 within +-0.6 %)
 // K7: initial candidates (sun, cosine-sky, BSDF-sky) + temporal reuse; K8: pairwise-MIS spatial reuse.  One thread per pixel.
 template<bool PLAIN>
@@ -102,7 +102,7 @@ template<bool PLAIN>
 __global__ void __launch_bounds__(kRgiBlock) ZR_WAVES_RGI k_rgi(rgi::GiFrame F, zr_frame_constants g, uint32_t tilesX, unsigned long long* counters)
 { ZR_RGI_KERNEL_BODY(false, PLAIN) }
 // the TEXTURED permutation hides its texel-gather latency with more waves, like K11's (textured atrium: 12.12 ms at 4 waves, 11.42 at 5, 10.96 at 6;
-// the untextured kernel is best at 4; scripts/gpu_waves2.sh)
+// the untextured kernel is best at 4; scripts/gpu_waves2.sh [rounds 1-4: git history up to 31e92fa; today scripts/gpu.sh ab])
 __global__ void k_rgi_tex(rgi::GiFrame F, zr_frame_constants g, uint32_t tilesX, unsigned long long* counters);
 
 // X = `template` in the TU that owns the group, `extern template` everywhere else (like ZR_RPT_GROUP_*)

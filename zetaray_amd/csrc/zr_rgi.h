@@ -284,7 +284,7 @@ ZR_HD bool TraceContinuation(const Globals& gl, V3 pos, V3 normal, V3 wi, bool t
 // ReSTIR_GI.hlsl main prologue + EstimateIndirectLighting / RIS_InitialCandidates up to the PathTrace call
 // the primary hit of pixel (x, y) as the G-buffer holds it: position, normal, material -> P.pos / normal / roughness / ior / z_view / surface.
 // -DZR_RGI_REMAT=1 calls it AGAIN after the path loop instead of keeping ~45 registers of primary-hit state live across it (none of it is
-// touched while the path is traced; the 128-VGPR kernel spills it).  Measured (scripts/gpu_r03_trip.sh, Cornell 1080p): k_rgi 1.282 ms without,
+// touched while the path is traced; the 128-VGPR kernel spills it).  Measured (scripts/gpu_r03_trip.sh [rounds 1-4: git history up to 31e92fa; today scripts/gpu.sh ab], Cornell 1080p): k_rgi 1.282 ms without,
 // 1.295 ms with; HBM-side traffic 2.21 -> 2.32 GB per launch -- the register allocator spills something else instead, nothing gained.  Off.
 ZR_HD void LoadPrimary(const GiFrame& F, const zr_frame_constants& g, uint32_t x, uint32_t y, size_t px, Lane& P, V2& lens, V3& origin)
 {

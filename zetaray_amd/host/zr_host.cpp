@@ -487,6 +487,12 @@ void* IndirectLighting::GetOutput(SHADER_OUT_RES i) const
     return dev;
 }
 void IndirectLighting::Render(Core::CommandList& cl) { ZR_CHECK(zr_pass_render(m_pass, cl.Stream(), &m_ctx->frameConstants, m_ctx->scene, m_ctx->gbuffer)); }
+void IndirectLighting::SetFrameOverlap(bool enable, bool carry)
+{ ZR_CHECK(zr_pass_set_frame_overlap(m_pass, m_ctx->gbuffer, enable ? (carry ? ZR_FRAME_OVERLAP_CARRY : ZR_FRAME_OVERLAP) : 0)); }
+void IndirectLighting::RenderCandidates(Core::CommandList& cl)
+{ ZR_CHECK(zr_pass_render_stage(m_pass, cl.Stream(), &m_ctx->frameConstants, m_ctx->scene, m_ctx->gbuffer, ZR_STAGE_CANDIDATES)); }
+void IndirectLighting::RenderReuse(Core::CommandList& cl)
+{ ZR_CHECK(zr_pass_render_stage(m_pass, cl.Stream(), &m_ctx->frameConstants, m_ctx->scene, m_ctx->gbuffer, ZR_STAGE_TEMPORAL_REUSE | ZR_STAGE_SPATIAL | ZR_STAGE_SPATIAL2)); }
 
 } // namespace RenderPass
 } // namespace ZetaRayAMD
@@ -637,6 +643,73 @@ int zrh_render_sequence3(const zr_scene_desc* desc, const zr_frame_constants* cb
         }
         if (hipMemcpy(finalOut, ind.GetOutput(RenderPass::IndirectLighting::SHADER_OUT_RES::FINAL), (size_t)w * h * 16, hipMemcpyDeviceToHost) != hipSuccess) return -1;
         if (directOut && hipMemcpy(directOut, di.GetOutput(RenderPass::DirectLighting::SHADER_OUT_RES::FINAL), (size_t)w * h * 16, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    }
+    zr_gbuffer_destroy(ctx.gbuffer);
+    zr_scene_destroy(ctx.scene);
+    return 0;
+}
+
+// A ReSTIR PT sequence with the indirect pass as two graph nodes on two queues (IndirectLighting::SetFrameOverlap): GBufferRT, PreLighting and
+// Indirect.Candidates are ASYNC_COMPUTE nodes, Indirect.Reuse a COMPUTE node; the frames are submitted back to back and only the last one is waited for,
+// so the first half of frame N + 1 runs beside the second half of frame N.  overlapMode 0 = the plain single-node form of zrh_render_sequence3 (for the
+// comparison), 1 = ZR_FRAME_OVERLAP, 2 = ZR_FRAME_OVERLAP_CARRY.  Copies FINAL of the last frame; batchesOut (optional): the graph's batches of the last frame.
+int zrh_render_sequence_overlap(const zr_scene_desc* desc, const zr_frame_constants* cbs, uint32_t n, uint32_t w, uint32_t h, int overlapMode, float* finalOut,
+    int presampleSets, int presampleSize, char* batchesOut, int batchesCap)
+{
+    RenderPass::FrameContext ctx;
+    ctx.device = 0; ctx.renderWidth = w; ctx.renderHeight = h;
+    ZR_CHECK(zr_scene_create(0, desc, &ctx.scene));
+    ZR_CHECK(zr_gbuffer_create(0, w, h, &ctx.gbuffer));
+    {
+        RenderPass::GBufferRT gb; RenderPass::PreLighting pre; RenderPass::IndirectLighting ind;
+        gb.Init(&ctx); pre.Init(&ctx); ind.Init(&ctx, RenderPass::IndirectLighting::INTEGRATOR::ReSTIR_PT);
+        if (presampleSets > 0)
+        {
+            ctx.frameConstants = cbs[0];
+            pre.SetLightPresamplingParams(0, presampleSets, presampleSize);
+            ind.SetLightPresamplingParams(pre.IsPresamplingEnabled(), presampleSets, presampleSize);
+        }
+        if (overlapMode) ind.SetFrameOverlap(true, overlapMode == 2);
+        Core::RenderGraph g;
+        enum : uint64_t { R_GBUF = 1, R_ALIAS, R_CAND, R_IND };
+        for (uint32_t f = 0; f < n; f++)
+        {
+            ctx.frameConstants = cbs[f];
+            g.BeginFrame();
+            const auto first = overlapMode ? Core::RENDER_NODE_TYPE::ASYNC_COMPUTE : Core::RENDER_NODE_TYPE::COMPUTE;
+            auto hGB = g.RegisterRenderPass("GBuffer", first, Core::MakeDelegate(&gb, &RenderPass::GBufferRT::Render));
+            auto hPre = g.RegisterRenderPass("PreLighting", Core::RENDER_NODE_TYPE::ASYNC_COMPUTE, Core::MakeDelegate(&pre, &RenderPass::PreLighting::Render));
+            Core::RenderNodeHandle hCand, hInd;
+            if (overlapMode)
+            {
+                hCand = g.RegisterRenderPass("Indirect.Candidates", Core::RENDER_NODE_TYPE::ASYNC_COMPUTE, Core::MakeDelegate(&ind, &RenderPass::IndirectLighting::RenderCandidates));
+                hInd = g.RegisterRenderPass("Indirect.Reuse", Core::RENDER_NODE_TYPE::COMPUTE, Core::MakeDelegate(&ind, &RenderPass::IndirectLighting::RenderReuse));
+            }
+            else hInd = g.RegisterRenderPass("Indirect", Core::RENDER_NODE_TYPE::COMPUTE, Core::MakeDelegate(&ind, &RenderPass::IndirectLighting::Render));
+            g.RegisterResource(nullptr, R_GBUF); g.RegisterResource(nullptr, R_ALIAS); g.RegisterResource(nullptr, R_CAND); g.RegisterResource(nullptr, R_IND);
+            g.MoveToPostRegister();
+            g.AddOutput(hGB, R_GBUF, Core::STATE_UNORDERED_ACCESS);
+            g.AddOutput(hPre, R_ALIAS, Core::STATE_UNORDERED_ACCESS);
+            if (overlapMode)
+            {
+                g.AddInput(hCand, R_GBUF, Core::STATE_SHADER_READ); g.AddInput(hCand, R_ALIAS, Core::STATE_SHADER_READ); g.AddOutput(hCand, R_CAND, Core::STATE_UNORDERED_ACCESS);
+                g.AddInput(hInd, R_CAND, Core::STATE_SHADER_READ); g.AddInput(hInd, R_GBUF, Core::STATE_SHADER_READ);
+            }
+            else { g.AddInput(hInd, R_GBUF, Core::STATE_SHADER_READ); g.AddInput(hInd, R_ALIAS, Core::STATE_SHADER_READ); }
+            g.AddOutput(hInd, R_IND, Core::STATE_UNORDERED_ACCESS);
+            Support::TaskSet ts;
+            g.Build(ts);
+            ts.Run(true);
+            // the alias table's first build (frame 0) is read by both halves of every later frame: one wait, like the reference's first-frame upload fence
+            if (!overlapMode || f == 0 || f + 1 == n) g.WaitForFrame();
+        }
+        if (batchesOut && batchesCap > 0)
+        {
+            std::string txt;
+            for (size_t b = 0; b < g.Batches().size(); b++) { if (b) txt += "|"; for (size_t k = 0; k < g.Batches()[b].size(); k++) { if (k) txt += ","; txt += g.Batches()[b][k]; } }
+            std::snprintf(batchesOut, (size_t)batchesCap, "%s", txt.c_str());
+        }
+        if (hipMemcpy(finalOut, ind.GetOutput(RenderPass::IndirectLighting::SHADER_OUT_RES::FINAL), (size_t)w * h * 16, hipMemcpyDeviceToHost) != hipSuccess) return -1;
     }
     zr_gbuffer_destroy(ctx.gbuffer);
     zr_scene_destroy(ctx.scene);

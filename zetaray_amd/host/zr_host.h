@@ -400,6 +400,14 @@ namespace RenderPass {
         // device pointer of the FINAL plane (RGBA32F)
         void* GetOutput(SHADER_OUT_RES i) const;
         void Render(Core::CommandList& cmdList);
+        // Frame overlap (ReSTIR PT; zetaray_amd.h zr_pass_set_frame_overlap): the pass as TWO graph nodes.  RenderCandidates (K11: this frame's initial candidates)
+        // is registered as an ASYNC_COMPUTE node next to GBufferRT and PreLighting, RenderReuse (K12 - K16) as a COMPUTE node that consumes it -- the reference
+        // overlaps work between its direct and async-compute queues the same way (Core/RenderGraph.cpp:442-541).  With the frames of a sequence submitted back
+        // to back (no WaitForFrame in between) K1 + K11 of frame N + 1 run beside the search / sort / replay / reconnect kernels of frame N; the library
+        // orders what crosses frames with events of its own.  GetOutput(FINAL) must be re-queried every frame (two planes alternate).
+        void SetFrameOverlap(bool enable, bool carryUnusedBytes = false);
+        void RenderCandidates(Core::CommandList& cmdList);
+        void RenderReuse(Core::CommandList& cmdList);
     private:
         void SetFlag(uint32_t bit, bool on);
         zr_params m_params{};

@@ -356,10 +356,10 @@ class TiledRestirPT:
             r.p_sky_direct.render(cb, r.scene, r.gbuffer, stream)
         r.p_indirect.render_stage(cb, r.scene, r.gbuffer, api.STAGE_TEMPORAL, stream)
 
-    def enable_frame_overlap(self, on=True):
+    def enable_frame_overlap(self, on=True, carry=False):
         """software-pipeline consecutive frames of this tile on two streams (api.Renderer.enable_frame_overlap); the stages and exchanges keep their order"""
         assert self.kind == "restir_pt"
-        self.r.enable_frame_overlap(on)
+        self.r.enable_frame_overlap(on, carry)
 
     def stage_spatial(self, cb, stream=None):
         self.hp.render_stage(cb, self.r.scene, self.r.gbuffer, self.api.STAGE_SPATIAL, stream)
