@@ -30,6 +30,7 @@ static const uint16_t kRdiSampleSet[64] = {
 using namespace zr;
 static bool g_k11_park = false;       // zhx_set_k11_park: K11 keeps the reservoir's selected reconnection in a park outside the lane (zr_rpt.h RcPark)
 static bool g_k11_fused = false;      // zhx_set_k11_fused: K11 emulation runs the FUSED stage functions (PtInitLane_Fused / PtPhaseA_Fused: what k_rpt_pathtrace compiles) instead of the cut ones
+static bool g_plain = false;          // zhx_set_material_class: run the ReSTIR PT stage functions the way the PLAIN kernel permutations do (rpt::SetMaterialClass(F, true))
 static bool g_k11_carry = false;      // zhx_set_k11_carry: K11 emulation sends live paths through rpt::PtCarry at every bounce boundary
 
 struct HxScene
@@ -300,6 +301,9 @@ uint64_t zhx_bvh_digest(const HxScene* s, uint32_t* numNodes, uint32_t* numTris,
 void zhx_set_k11_carry(int on) { g_k11_carry = on != 0; }
 void zhx_set_k11_fused(int on) { g_k11_fused = on != 0; }
 void zhx_set_k11_park(int on) { g_k11_park = on != 0; }
+// the material class as the PLAIN kernel permutations see it (zr_kernels.h: SceneView::plain, GBuf::plain, RBuf::plain all 1): only legal for scenes whose
+// material table IS plain (zr_api.hip MaterialsArePlain) -- the caller's responsibility here as it is the host's in the product
+void zhx_set_material_class(int plain) { g_plain = plain != 0; }
 void zhx_latch_heap_offsets(const HxScene* s, const zr_frame_constants* cb) { Latch(s, cb); }
 void zhx_estimate_power(const HxScene* s, float* out) { for (size_t i = 0; i < s->emissives.size(); i++) out[i] = EstimateTriPower(s->view, s->emissives[i]); }
 
@@ -448,6 +452,7 @@ void zhx_rpt_render_stage(const HxScene* s, HxRpt* R, const zr_frame_constants* 
     const uint32_t X0 = F.ox0, Y0 = F.oy0, X1 = F.ox0 + F.ow, Y1 = F.oy0 + F.oh;
     F.rbCtN = R->rb[0].View(); F.rbNtC = R->rb[1].View(); F.tex.target = R->target.data(); F.tex.neighbor = R->neighbor.data();
     F.finalRGBA = finalRGBA; F.sampleSet = kRptSampleSet;
+    SetMaterialClass(F, g_plain);
     RptParams& prm = F.prm;
     prm.maxNonTrBounces = params->max_non_tr_bounces; prm.maxGlossyTrBounces = params->max_glossy_tr_bounces;
     prm.russianRoulette = (params->flags & ZR_IND_RUSSIAN_ROULETTE) ? 1u : 0u;

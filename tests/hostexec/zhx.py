@@ -413,6 +413,11 @@ def set_k11_fused(on):
     lib().zhx_set_k11_fused(int(bool(on)))
 
 
+def set_material_class(plain):
+    """the ReSTIR PT stage functions as the PLAIN kernel permutations run them (SceneView / GBuf / RBuf::plain = 1); only for scenes whose materials are plain"""
+    lib().zhx_set_material_class(int(bool(plain)))
+
+
 def set_k11_park(on):
     """K11 emulation of k_rpt_pathtrace_park: the reservoir's selected reconnection lives in a [word][lane] park outside the lane (zr_rpt.h RcPark)"""
     lib().zhx_set_k11_park(int(bool(on)))

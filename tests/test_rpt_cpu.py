@@ -152,6 +152,35 @@ def test_k11_fused_stage_functions_equal_the_oracle(synthetic_small, cornell_emi
         zhx.set_k11_fused(False)
 
 
+def test_plain_material_class_changes_nothing_on_plain_scenes(cornell_emissive, oracle_emissive, hx_emissive):
+    """The PLAIN kernel permutations (zr_kernels.h) set SceneView / GBuf / RBuf::plain = 1, which folds the metal / transmission / thin-wall / coat code out of
+    InitSurface, LoadPixelSurfaceEx and LoadOffsetCtx.  On the device that path is only compared GPU == oracle; here the host executor runs the same stage
+    functions with the class set (cut and fused forms of K11) on the Cornell box, emissive and sun + sky -- scenes of the plain class: radiance and every reservoir
+    plane equal the oracle's, i.e. the general path's."""
+    from zetaray_amd import scene_io
+    import os
+    w, h = 64, 48
+    prm = wire.default_params()
+    sky = scene_io.load_npz(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "cornell.npz"))
+    osky = zro.OracleScene(sky)
+    hsky = zhx.HostExecScene(sky)
+    zhx.set_material_class(True)
+    try:
+        for fused in (False, True):
+            zhx.set_k11_fused(fused)
+            for scene, oscene, hxs in ((cornell_emissive, oracle_emissive, hx_emissive), (sky, osky, hsky)):
+                o, x = zro.OracleRPT(oscene, w, h), zhx.HostExecRPT(hxs, w, h)
+                for f in range(1, 4):
+                    cb = _cb(scene, w, h, f, cam_pos=(0.04 * max(0, f - 2), 1.2, -4.043))
+                    if len(scene.emissives) == 0:
+                        oscene.sky_lut(cb, 256, 128); hxs.sky_lut(cb, 256, 128)
+                    a, b = o.render(cb, prm), x.render(cb, prm)
+                    assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), f"frame {f} (fused {fused})"
+                    _assert_same_state(o, x, f)
+    finally:
+        zhx.set_material_class(False); zhx.set_k11_fused(False)
+
+
 def test_k11_with_the_selected_reconnection_parked(synthetic_small, cornell_emissive, oracle_emissive, hx_emissive):
     """k_rpt_pathtrace_park (ZR_K11_PARK=1; zr_rpt.h RcPark): while a path is traced the reservoir's selected reconnection lives in a [word][lane]
     park (LDS on the device) -- Reservoir::Update stores winners there, the epilogue reads the last one back.  The host executor runs K11 that way,

@@ -19,6 +19,9 @@ def main():
     ap.add_argument("--halves", action="store_true",
                     help="VERDICT r4 item 3(c): every device's tile of the equal-area split cut in two (32-px aligned, the longer side), the halves rendered "
                          "CONCURRENTLY on two streams -- one round of waves lasts as long as its slowest wave, a second independent half fills the slots its tail leaves idle")
+    ap.add_argument("--overlap", action="store_true",
+                    help="VERDICT r5 item 2: per tile, the THROUGHPUT of its own frames rendered back to back (no wait between the stages or frames; aprons as the lockstep "
+                         "warm-up frames left them) in the plain order and with frame overlap (K1 + K11 of frame N + 1 on a second stream beside the spatial stage of frame N)")
     a = ap.parse_args()
     W, H = a.width, a.height
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -45,6 +48,22 @@ def main():
             probe.render_frame(scene_io.make_frame_constants(W, H, frame_num=f, num_emissives=len(sc.emissives), **cam))
         torch.cuda.synchronize()
         full_ms = (time.perf_counter() - t0) / 8 * 1e3
+        del probe
+    full_ov = None
+    if a.overlap:
+        # the single-device frame the tiles are compared with: plain and overlapped, 16 frames back to back after 12 to settle
+        probe = tiling.TiledRestirPT(sc, W, H, 1, 0, params=prm)
+        res = []
+        for mode in (0, 1):
+            probe.enable_frame_overlap(bool(mode))
+            for rep in range(2):
+                torch.cuda.synchronize(); t0 = time.perf_counter()
+                for f in range(16):
+                    probe.render_frame(scene_io.make_frame_constants(W, H, frame_num=100 + (2 * mode + rep) * 16 + f, num_emissives=len(sc.emissives), **cam))
+                torch.cuda.synchronize()
+                dt = (time.perf_counter() - t0) / 16 * 1e3
+            res.append(dt)
+        full_ms, full_ov = res
         del probe
     if a.halves:
         halves = []
@@ -104,6 +123,36 @@ def main():
         tiling.exchange_in_process(ranks, api.HALO_FINAL)
         n += f > 3
     ms = (t.sum(axis=1) / n * 1e3)
+    if a.overlap:
+        # every tile alone, M frames back to back: plain order, then overlapped (the kernels of an 8-way tile are ONE round of workgroups each: the plain order
+        # pays every kernel's tail, the overlapped one fills it with the other half's workgroups)
+        M = 24
+        thr = np.zeros((a.world, 2))
+        # one second stream for all tile objects of this process: HIP multiplexes a process's streams onto a handful of hardware queues, and with a stream per
+        # tile object (8 here; a real rank has one) some tile's "second" stream lands on the queue of the null stream and overlaps nothing
+        shared = torch.cuda.Stream()
+        for i, r in enumerate(ranks):
+            for mode in (0, 1):
+                r.enable_frame_overlap(bool(mode))
+                if mode:
+                    r.r._overlap_stream = shared.cuda_stream
+                for rep in range(2):      # (first repetition: warm-up)
+                    torch.cuda.synchronize(); t0 = time.perf_counter()
+                    for k in range(M):
+                        cb = scene_io.make_frame_constants(W, H, frame_num=a.frames + 1 + (2 * mode + rep) * M + k, num_emissives=len(sc.emissives), **cam)
+                        r.stage_temporal(cb)
+                        r.stage_spatial(cb)
+                    torch.cuda.synchronize()
+                    thr[i, mode] = (time.perf_counter() - t0) / M * 1e3
+            r.enable_frame_overlap(False)
+        print(json.dumps({"scene": a.scene, "world": a.world, "size": [W, H], "layout": a.layout, "single_device_frame_ms": round(full_ms, 3), "single_device_frame_ms_overlapped": round(full_ov, 3),
+                          "slowest_tile_bound_plain": round(full_ms / float(thr[:, 0].max()), 2), "slowest_tile_bound_overlapped": round(full_ms / float(thr[:, 1].max()), 2),
+                          "slowest_tile_bound_overlapped_vs_overlapped_single": round(full_ov / float(thr[:, 1].max()), 2),
+                          "tile_ms_stage_by_stage": [round(float(x), 3) for x in ms], "rects": [tiling.tile_rect(W, H, a.world, r, layout) for r in range(a.world)],
+                          "tile_ms_back_to_back_plain": [round(float(x), 3) for x in thr[:, 0]], "tile_ms_back_to_back_overlapped": [round(float(x), 3) for x in thr[:, 1]],
+                          "max_ms_plain": round(float(thr[:, 0].max()), 3), "max_ms_overlapped": round(float(thr[:, 1].max()), 3),
+                          "sum_ms_plain": round(float(thr[:, 0].sum()), 3), "sum_ms_overlapped": round(float(thr[:, 1].sum()), 3)}))
+        return
     print(json.dumps({"scene": a.scene, "world": a.world, "size": [W, H], "layout": a.layout, "layout_chosen": ("kd-split" if layout is not None else "grid"), "single_device_frame_ms": (round(full_ms, 3) if full_ms else None),
                       "tile_ms": [round(float(x), 3) for x in ms], "rects": [tiling.tile_rect(W, H, a.world, r, layout) for r in range(a.world)],
                       "max_ms": round(float(ms.max()), 3), "mean_ms": round(float(ms.mean()), 3), "sum_ms": round(float(ms.sum()), 3)}))

@@ -675,25 +675,29 @@ struct zr_gbuffer
     int device = 0; uint32_t w = 0, h = 0, x0 = 0, y0 = 0;
     // double-buffered like the reference's GBufferData (DefaultRendererImpl.h:80-130): every GBUFFER pass render flips
     // `cur`; the other set is the previous frame's G-buffer that the temporal passes of ReSTIR read
-    DevBuf<uint8_t> planeSets[2][ZR_GB_COUNT];
-    int cur = 0; uint64_t numRendered = 0;
+    // (a third set once the G-buffer is stream-tracked, zr_pass_set_frame_overlap: the GBUFFER render of frame N + 2 then runs while the temporal passes of
+    // frame N + 1 still read the sets of frames N + 1 and N)
+    DevBuf<uint8_t> planeSets[3][ZR_GB_COUNT];
+    int cur = 0, numSets = 2; uint64_t numRendered = 0;
+    int Next() const { return (cur + 1) % numSets; }
+    int Prev() const { return (cur + numSets - 1) % numSets; }
     // the scene's material class (zr_scene::plainMaterials) at the time each plane set was rendered: the PLAIN kernel permutations take a pixel's flags as known,
     // so both the current and the previous frame's planes must come from a plain material table (a scene that BECAME plain renders one more frame with the general kernels)
-    bool plainAt[2] = {true, true};
+    bool plainAt[3] = {true, true, true};
     // ... and WHICH scene rendered it (zr_scene::uid; 0 = never rendered by a GBUFFER pass): planes an engine filled itself through zr_gbuffer_device_plane, or
     // rendered from another scene than the lighting pass is given, carry flags the lighting pass cannot vouch for -- they run the general kernels
-    uint64_t sceneAt[2] = {0, 0};
+    uint64_t sceneAt[3] = {0, 0, 0};
     // stream tracking (zr_pass_set_frame_overlap): with the passes of a frame spread over two streams, a GBUFFER render must not overwrite a plane set
     // that a pass on another stream still reads, and a pass on another stream must not read a set before its GBUFFER render has finished
     bool tracked = false;
     hipEvent_t evWritten = nullptr; hipStream_t writer = nullptr; bool hasWrite = false;
     struct Reader { hipStream_t st; hipEvent_t ev; };
-    std::vector<Reader> readers[2];      // per plane set: the last read of every stream that has read it
+    std::vector<Reader> readers[3];      // per plane set: the last read of every stream that has read it
     ~zr_gbuffer() { if (evWritten) (void)hipEventDestroy(evWritten); for (auto& v : readers) for (auto& r : v) (void)hipEventDestroy(r.ev); }
     DevBuf<uint8_t>* Planes() { return planeSets[cur]; }
     const DevBuf<uint8_t>* Planes() const { return planeSets[cur]; }
     GBuf View() const { return ViewOf(cur); }
-    GBuf PrevView() const { return ViewOf(cur ^ 1); }
+    GBuf PrevView() const { return ViewOf(Prev()); }
     GBuf ViewOf(int which) const
     {
         const DevBuf<uint8_t>* planes = planeSets[which];
@@ -785,7 +789,7 @@ static bool PlainClass(const zr_scene* sc, const zr_gbuffer* gb)
     const int c = gb->cur;
     if (!(gb->plainAt[c] && gb->sceneAt[c] == sc->uid)) return false;
     // the other set is the previous frame's G-buffer; nothing reads it before the second GBUFFER render (havePrevGBuffer)
-    if (gb->numRendered >= 2 && !(gb->plainAt[c ^ 1] && gb->sceneAt[c ^ 1] == sc->uid)) return false;
+    if (gb->numRendered >= 2 && !(gb->plainAt[gb->Prev()] && gb->sceneAt[gb->Prev()] == sc->uid)) return false;
     return true;
 }
 static constexpr int kMaxRounds = 16;
@@ -832,7 +836,9 @@ struct zr_pass
     // the CANDIDATES stage of an overlapped frame writes the free set and hands the set it replaces back.  tgtIdx / finIdx: the target / FINAL plane of
     // the frame whose CANDIDATES stage ran last; finOut: the FINAL plane of the last frame whose final stage has been enqueued (zr_pass_get_output)
     bool overlap = false, overlapCarry = false; int rptSet[3] = {0, 1, 2}; int tgtIdx = 0, finIdx = 0, finOut = 0;
-    DevBuf<float> finalAlt;
+    DevBuf<float> finalAlt, finalAlt2;      // FINAL rotates over three planes: K11 of frame N + 2 (which clears the pixels without a surface) may run while frame N's is still being consumed
+    // the last stage of the frame before the previous one done (depth-2 pipelining, product mode): evDone[k & 1] is recorded when frame k closes
+    hipEvent_t evDone[2] = {nullptr, nullptr}; bool haveDone[2] = {false, false}; hipStream_t doneStream[2] = {nullptr, nullptr}; uint64_t ovFrame = 0;
     hipStream_t overlapStream = nullptr;                     // "stream A" for callers without streams of their own
     hipEvent_t evCand = nullptr, evTemporal = nullptr;       // K11 of the open frame done (on candStream) / K14 of the last frame done (on reuseStream)
     hipStream_t candStream = nullptr, reuseStream = nullptr; bool haveCand = false, haveTemporal = false;
@@ -840,7 +846,7 @@ struct zr_pass
     zr_pass::ResStorage& RptOth() { return res[rptSet[1 - currIdx]]; }
     const zr_pass::ResStorage& RptOth() const { return res[rptSet[1 - currIdx]]; }
     F4* Target() const { return tgtIdx ? rptTargetAlt.p : rptTarget.p; }
-    float* Final(int i) const { return i ? finalAlt.p : finalRGBA.p; }
+    float* Final(int i) const { return i == 0 ? finalRGBA.p : (i == 1 ? finalAlt.p : finalAlt2.p); }
     DevBuf<uint16_t> rptMap[2];      // K12 thread maps: [0] CtN, [1] NtC
     DevBuf<uint32_t> trip; DevBuf<unsigned long long> tripStats;      // ZR_K11=trip diagnostic
     DevBuf<uint32_t> carry[2], carryCount;                             // K11 with per-bounce compaction: path-state planes (ping-pong), alive counts
@@ -1863,10 +1869,10 @@ static int AllocOverlapPlanes(zr_pass* p)
     const size_t cap = (size_t)p->w * p->h;
     int r;
     zr_pass::ResStorage& R = p->res[2];
-    if ((r = R.Alloc(cap)) || (r = p->rptTargetAlt.Alloc(cap)) || (r = p->finalAlt.Alloc(cap * 4))) return r;
+    if ((r = R.Alloc(cap)) || (r = p->rptTargetAlt.Alloc(cap)) || (r = p->finalAlt.Alloc(cap * 4)) || (r = p->finalAlt2.Alloc(cap * 4))) return r;
     HIP_TRY(hipMemset(R.A.p, 0, cap * 4)); HIP_TRY(hipMemset(R.B.p, 0, cap * 8)); HIP_TRY(hipMemset(R.C.p, 0, cap * 16));
     HIP_TRY(hipMemset(R.D.p, 0, cap * 16)); HIP_TRY(hipMemset(R.E.p, 0, cap * 2)); HIP_TRY(hipMemset(R.F.p, 0, cap * 8)); HIP_TRY(hipMemset(R.G.p, 0, cap * 8));
-    HIP_TRY(hipMemset(p->rptTargetAlt.p, 0, cap * 16)); HIP_TRY(hipMemset(p->finalAlt.p, 0, cap * 4 * sizeof(float)));
+    HIP_TRY(hipMemset(p->rptTargetAlt.p, 0, cap * 16)); HIP_TRY(hipMemset(p->finalAlt.p, 0, cap * 4 * sizeof(float))); HIP_TRY(hipMemset(p->finalAlt2.p, 0, cap * 4 * sizeof(float)));
     return ZR_OK;
 }
 static int AllocPass(zr_pass* p)
@@ -1981,7 +1987,7 @@ static int AllocPass(zr_pass* p)
             { const size_t cells = (size_t)((p->w + 31u) / 32u + 1u) * ((p->h + 31u) / 32u + 1u); if ((r = p->costMap.Alloc(cells))) return r; HIP_TRY(hipMemset(p->costMap.p, 0, cells * 4)); }
             if ((r = p->rptSampleSet.Upload(kRptSampleSet, 1024))) return r;
             if ((r = p->rptLists.Alloc(4 * cap))) return r;
-            p->rptSet[0] = 0; p->rptSet[1] = 1; p->rptSet[2] = 2; p->tgtIdx = 0; p->finIdx = 0; p->finOut = 0; p->frameOpen = false; p->haveCand = false; p->haveTemporal = false;
+            p->rptSet[0] = 0; p->rptSet[1] = 1; p->rptSet[2] = 2; p->tgtIdx = 0; p->finIdx = 0; p->finOut = 0; p->frameOpen = false; p->haveCand = false; p->haveTemporal = false; p->haveDone[0] = p->haveDone[1] = false;
             if (p->overlap) { if ((r = AllocOverlapPlanes(p))) return r; }
             // word layout (kRptListWords): [0, 1] temporal counts, [2, 3] first spatial round, [4, 5] the temporal replays' cursors (counts + 4 / + 5 of
             // base 0: the only DYNAMIC replay), [6, 7] second spatial round, [8 .. 11] = base 6's cursor slots -- unused (the spatial replays split
@@ -2018,7 +2024,7 @@ int zr_pass_reset_temporal(zr_pass* p)
     if (!p) return Fail(ZR_ERR_INVALID_ARG, "null pass");
     if (!p->initialized) return Fail(ZR_ERR_NOT_INITIALIZED, "pass not initialised");
     HIP_TRY(hipSetDevice(p->device));
-    if (p->kind == ZR_PASS_INDIRECT) { HIP_TRY(hipDeviceSynchronize()); HIP_TRY(hipMemset(p->finalRGBA.p, 0, p->finalRGBA.n * sizeof(float))); if (p->finalAlt.p) HIP_TRY(hipMemset(p->finalAlt.p, 0, p->finalAlt.n * sizeof(float))); }
+    if (p->kind == ZR_PASS_INDIRECT) { HIP_TRY(hipDeviceSynchronize()); HIP_TRY(hipMemset(p->finalRGBA.p, 0, p->finalRGBA.n * sizeof(float))); if (p->finalAlt.p) { HIP_TRY(hipMemset(p->finalAlt.p, 0, p->finalAlt.n * sizeof(float))); HIP_TRY(hipMemset(p->finalAlt2.p, 0, p->finalAlt2.n * sizeof(float))); } }
     p->temporalValid = false;       // IndirectLighting::ResetTemporal -> RESET_TEMPORAL_TEXTURES next frame
     if (p->kind == ZR_PASS_DI_EMISSIVE || p->kind == ZR_PASS_DI_SKY) { HIP_TRY(hipMemset(p->finalRGBA.p, 0, p->finalRGBA.n * sizeof(float))); p->currIdx = 0; }   // DirectLighting.cpp:159-164, SkyDI.cpp:128-133
     HIP_TRY(hipDeviceSynchronize());      // a host call between frames: renders on non-blocking streams must see the cleared plane
@@ -2057,8 +2063,8 @@ static int RenderGBuffer(zr_pass* p, hipStream_t s, const zr_frame_constants* cb
     if (!gb) return Fail(ZR_ERR_INVALID_ARG, "GBUFFER pass needs a gbuffer");
     if (gb->x0 + gb->w > cb->render_width || gb->y0 + gb->h > cb->render_height) return Fail(ZR_ERR_INVALID_ARG, "gbuffer tile lies outside the render target of the frame constants");
     const uint32_t tilesX = (gb->w + 15) / 16, tilesY = (gb->h + 15) / 16;
-    if (int wr = GBufferAcquireWrite(gb, gb->cur ^ 1, s)) return wr;      // (tracked G-buffers: the set about to be overwritten may still be read on another stream)
-    gb->cur ^= 1; gb->numRendered++;
+    if (int wr = GBufferAcquireWrite(gb, gb->Next(), s)) return wr;      // (tracked G-buffers: the set about to be overwritten may still be read on another stream)
+    gb->cur = gb->Next(); gb->numRendered++;
     gb->plainAt[gb->cur] = sc->plainMaterials.load(std::memory_order_relaxed); gb->sceneAt[gb->cur] = sc->uid;
     TimerBegin(p, s, "gbuffer");
     uint32_t pickXY = 0xffffffffu;
@@ -2391,8 +2397,18 @@ static int RenderReSTIR_PT(zr_pass* p, hipStream_t s, const zr_frame_constants* 
         std::swap(p->rptSet[p->currIdx], p->rptSet[2]);
         p->tgtIdx ^= 1;
         carryFrom = p->overlapCarry ? &p->res[p->rptSet[2]] : nullptr;
-        if (!(cb->accumulate && cb->camera_static)) p->finIdx ^= 1;      // (an accumulating frame adds to the plane the frames before it wrote)
-        if (p->haveTemporal && p->reuseStream != s) HIP_TRY(hipStreamWaitEvent(s, p->evTemporal, 0));
+        if (!(cb->accumulate && cb->camera_static)) p->finIdx = (p->finIdx + 1) % 3;      // (an accumulating frame adds to the plane the frames before it wrote)
+        if (p->overlapCarry)
+        {   // carry mode copies the replaced set, whose last writer is the previous frame's K14: one frame of overlap (beside that frame's spatial stage)
+            if (p->haveTemporal && p->reuseStream != s) HIP_TRY(hipStreamWaitEvent(s, p->evTemporal, 0));
+        }
+        else
+        {   // product mode: what this stage recycles -- the free reservoir set and this parity's target plane -- was last touched by the frame BEFORE the
+            // previous one (its spatial stage read them), and the G-buffer has a third plane set: two frames of overlap, the first half of frame N + 2 also
+            // runs beside the temporal reuse of frame N + 1
+            const int k = (int)(p->ovFrame & 1);
+            if (p->haveDone[k] && p->doneStream[k] != s) HIP_TRY(hipStreamWaitEvent(s, p->evDone[k], 0));
+        }
     }
     RptFrame F;
     F.sc = FrameView(sc, cb); F.gb = gb->View(); F.gbPrev = gb->PrevView();
@@ -2553,7 +2569,7 @@ static int RenderReSTIR_PT(zr_pass* p, hipStream_t s, const zr_frame_constants* 
         }
         // nothing after this point reads the PREVIOUS frame's G-buffer, its final reservoirs or scene (the spatial passes read this frame's only)
         if (p->overlap) { HIP_TRY(hipEventRecord(p->evTemporal, s)); p->reuseStream = s; p->haveTemporal = true; }
-        if (int mr = GBufferMarkRead(gb, gb->cur ^ 1, s)) return mr;
+        if (int mr = GBufferMarkRead(gb, gb->Prev(), s)) return mr;
     }
     for (uint32_t spass = 0; spass < numSpatialPasses && prm.doSpatial; spass++)
     {
@@ -2593,6 +2609,7 @@ static int RenderReSTIR_PT(zr_pass* p, hipStream_t s, const zr_frame_constants* 
         p->currIdx = 1 - p->currIdx;
         p->frameOpen = false;
         p->finOut = p->finIdx;
+        if (p->overlap) { const int k = (int)(p->ovFrame & 1); HIP_TRY(hipEventRecord(p->evDone[k], s)); p->haveDone[k] = true; p->doneStream[k] = s; p->ovFrame++; }
         if (int mr = GBufferMarkRead(gb, gb->cur, s)) return mr;
     }
     return ZR_OK;
@@ -2873,10 +2890,22 @@ int zr_pass_set_frame_overlap(zr_pass* p, zr_gbuffer* gb, int enable)
     if (enable && !p->evCand)
     {
         HIP_TRY(hipEventCreateWithFlags(&p->evCand, hipEventDisableTiming)); HIP_TRY(hipEventCreateWithFlags(&p->evTemporal, hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&p->evDone[0], hipEventDisableTiming)); HIP_TRY(hipEventCreateWithFlags(&p->evDone[1], hipEventDisableTiming));
         HIP_TRY(hipStreamCreateWithFlags(&p->overlapStream, hipStreamNonBlocking));
     }
     // switching off keeps the plane roles as they stand (the set last written as FINAL stays the one the next frame reads); FINAL goes on in the plane it is in
-    p->overlap = enable != 0; p->overlapCarry = enable == ZR_FRAME_OVERLAP_CARRY; p->haveCand = false; p->haveTemporal = false;
+    p->overlap = enable != 0; p->overlapCarry = enable == ZR_FRAME_OVERLAP_CARRY; p->haveCand = false; p->haveTemporal = false; p->haveDone[0] = p->haveDone[1] = false;
+    if (enable && gb->numSets == 2)
+    {   // the third plane set (never given back: the sets' roles rotate)
+        for (int i = 0; i < ZR_GB_COUNT; i++)
+        {
+            if (int r = gb->planeSets[2][i].Alloc((size_t)gb->w * gb->h * ZR_GB_PLANE_BYTES[i])) return r;
+            HIP_TRY(hipMemset(gb->planeSets[2][i].p, 0, gb->planeSets[2][i].n));
+        }
+        HIP_TRY(hipDeviceSynchronize());
+        // sets 0 / 1 hold the last two frames; the rotation continues from the current one: cur = 0 -> next 1 (two frames old), cur = 1 -> next 2 (fresh)
+        gb->numSets = 3;
+    }
     gb->tracked = enable != 0;
     if (!enable) { gb->hasWrite = false; for (auto& v : gb->readers) { for (auto& r : v) (void)hipEventDestroy(r.ev); v.clear(); } }
     return ZR_OK;
@@ -3025,7 +3054,7 @@ int zr_pass_render_stage(zr_pass* p, void* stream, const zr_frame_constants* cb,
     if (trackedReader) { if ((r = GBufferAcquireRead(gb, (hipStream_t)stream))) return r; }
     r = RenderStageInner(p, stream, cb, sc, gb, stages);
     if (r) return r;
-    if (trackedReader) { if ((r = GBufferMarkRead(gb, 0, (hipStream_t)stream)) || (r = GBufferMarkRead(gb, 1, (hipStream_t)stream))) return r; }
+    if (trackedReader) { if ((r = GBufferMarkRead(gb, gb->cur, (hipStream_t)stream)) || (r = GBufferMarkRead(gb, gb->Prev(), (hipStream_t)stream))) return r; }
     return SceneReleaseAfterRender(sc, (hipStream_t)stream);
 }
 static int RenderStageInner(zr_pass* p, void* stream, const zr_frame_constants* cb, const zr_scene* sc, zr_gbuffer* gb, int stages)
@@ -3320,6 +3349,7 @@ int zr_pass_destroy(zr_pass* p)
     if (p->overlapStream) { (void)hipStreamSynchronize(p->overlapStream); (void)hipStreamDestroy(p->overlapStream); }
     if (p->evCand) (void)hipEventDestroy(p->evCand);
     if (p->evTemporal) (void)hipEventDestroy(p->evTemporal);
+    for (auto& e : p->evDone) if (e) (void)hipEventDestroy(e);
     delete p;
     return ZR_OK;
 }
