@@ -674,6 +674,9 @@ def measure(args, ctx):
         # times the metric's kernel (K11) on its tile with the library's hipEvents over a few frames; achieved = the ranks' algorithmic bytes per launch
         # (per-ray model on the rays the kernel issued + the planes of the OWNED pixels) summed, over the slowest rank's launch time; peak = N x 8 TB/s.
         dom = "rpt_pathtrace"
+        if overlap:
+            barrier()
+            tiled.enable_frame_overlap(False)      # a kernel's own time: the plain order (under overlap it shares the device with the other half's kernels)
         r.p_indirect.enable_timing(True)
         r.p_indirect.read_counters(reset=True)
         nfr, agg_ms, agg_n = 8, 0.0, 0
@@ -747,8 +750,10 @@ def main():
     ap.add_argument("--no-general-kernels", action="store_true", help="skip the general-kernel timing of a plain-class scene (general_kernels)")
     ap.add_argument("--kernel-class", choices=["auto", "general"], default="auto",
                     help="general = run a plain-class scene on the general kernel permutations (zr_debug_set_material_class_kernels(0)) for the whole run")
-    ap.add_argument("--frame-overlap", type=int, choices=[0, 1], default=0,
-                    help="1 = software-pipeline consecutive ReSTIR PT frames on two streams (K1 + K11 of frame N + 1 beside the reuse passes of frame N; bit-identical frames)")
+    ap.add_argument("--frame-overlap", type=int, choices=[0, 1], default=1,
+                    help="1 (default) = consecutive ReSTIR PT frames software-pipelined on two streams: the G-buffer and K11 of frames N + 1 / N + 2 beside the reuse passes of frame N "
+                         "(zetaray_amd.h zr_pass_set_frame_overlap; bit-identical frames) -- ms_per_step is then the frame THROUGHPUT, config.frame_ms_median the latency of one "
+                         "frame rendered alone, and frame_overlap_off carries the plain order's ms_per_step; 0 = the plain order on one stream")
     ap.add_argument("--settle", type=int, default=None,
                     help="untimed frames rendered BEFORE the warm-up so that the temporal reservoirs have reached their M caps whatever --warmup is "
                          "(default: 32 for the ReSTIR integrators, 0 otherwise)")

@@ -344,15 +344,21 @@ def test_restir_pt_full_resolution_properties(api, cornell_emissive):
     assert hf(imgs[0]) < 0.85 * hf(base)
 
 
-def test_restir_pt_tile_split_with_halo_exchange_on_gpu(api, cornell_emissive, oracle_emissive):
+@pytest.mark.parametrize("overlap", [False, True])
+def test_restir_pt_tile_split_with_halo_exchange_on_gpu(api, cornell_emissive, oracle_emissive, overlap):
     """4 tiles (2x2) of one frame sequence on one device: each tile object renders its tile + apron, halos move through
     zr_pass_halo_pack / unpack (the buffers RCCL would carry); stitched radiance == the full-frame oracle, moving camera.  200 x 120:
-    tile boundaries at 128 / 64, partial 32 x 32 sort tiles on the right and bottom image boundaries (K12's edge rules under tiling)."""
+    tile boundaries at 128 / 64, partial 32 x 32 sort tiles on the right and bottom image boundaries (K12's edge rules under tiling).
+    overlap: every tile with frame overlap on (its G-buffer, PreLighting and K11 on a stream of its own, beside the previous frame's exchange and
+    spatial stage: what bench.py runs on N devices)."""
     from oracle import zro
     from zetaray_amd import tiling
     w, h, world = 200, 120, 4
     prm = wire.default_params()
     ranks = [tiling.TiledRestirPT(cornell_emissive, w, h, world, r, params=prm) for r in range(world)]
+    if overlap:
+        for r in ranks:
+            r.enable_frame_overlap(True)
     o = zro.OracleRPT(oracle_emissive, w, h)
     prev = None
     for f in range(1, 5):

@@ -40,7 +40,9 @@ def main():
     kms = {ph: {k: round(float(np.mean(v)), 3) for k, v in d.items() if np.mean(v) > 0.05} for ph, d in kern.items()}
     print(json.dumps({"mode": os.environ.get("ZR_SCENE_UPDATE", "refit"), "background_rebuilds": list(r.scene.background_rebuild_stats()), "instance": int(idx), "instance_tris": int(sc.instance_num_tris[idx]),
                       "bvh": list(r.scene.bvh_info()), "update_ms": [round(x, 3) for x in upd], "update_ms_median": round(float(np.median(upd)), 3), "update_ms_mean": round(float(np.mean(upd[4:])), 3),
-                      "group": os.environ.get("ZR_BVH_GROUP", "1"), "frame_ms_moving_series": [round(x, 2) for x in frames[n_static:]],
+                      # ZR_BVH_GROUP (and every other A/B switch) is read by the EXPERIMENTS build only (libzetaray_amd_exp.so, ZR_EXP_ENV); the product library groups always
+                      "library": os.path.basename(api.LIB_PATH),
+                      "group": (os.environ.get("ZR_BVH_GROUP", "1") if os.path.basename(api.LIB_PATH) == "libzetaray_amd_exp.so" else "1 (product library: the ZR_BVH_GROUP switch exists in libzetaray_amd_exp.so only)"), "frame_ms_moving_series": [round(x, 2) for x in frames[n_static:]],
                       "frame_ms_static": round(float(np.median(frames[12:n_static])), 3), "frame_ms_moving": round(float(np.median(frames[n_static + 4:])), 3),
                       "kernel_ms_static": kms["static"], "kernel_ms_moving": kms["moving"]}))
 
