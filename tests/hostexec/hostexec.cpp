@@ -394,6 +394,74 @@ void zhx_trace_closest(const HxScene* s, const float* rays, uint32_t n, uint32_t
         hits[4 * i] = h.x; hits[4 * i + 1] = h.y; hits[4 * i + 2] = h.z; hits[4 * i + 3] = h.w;
     }
 }
+// the built tree's topology for inspection (tools/bvh_quality.py --dump): 4 child words per wide node
+void zhx_bvh_children(const HxScene* s, uint32_t* out) { for (size_t i = 0; i < s->bvh.nodes4.size(); i++) for (int c = 0; c < 4; c++) out[4 * i + c] = s->bvh.nodes4[i].child[c]; }
+// tree quality (tools/bvh_quality.py): the ordered stack traversal of zr_dev_scene.h over `rays` with its steps counted -- out = {inner nodes visited (4 box tests each),
+// leaves visited, triangles tested, hits}; any_hit: stop at the first hit (shadow rays)
+void zhx_trace_stats(const HxScene* s, const float* rays, uint32_t n, uint32_t mask, int any_hit, uint64_t* out)
+{
+    zr::StackEntry stackMem[zr::kTravStack]; zr::TravStack stack; stack.lds = nullptr; stack.stride = 0; stack.mem = stackMem;
+    uint64_t nodes = 0, leaves = 0, tris = 0, hits = 0;
+    for (uint32_t i = 0; i < n; i++)
+    {
+        TravState st;
+        TravInit(s->view, st, v3(rays[8 * i], rays[8 * i + 1], rays[8 * i + 2]), v3(rays[8 * i + 4], rays[8 * i + 5], rays[8 * i + 6]), rays[8 * i + 3], rays[8 * i + 7], mask, false, 0);
+        for (;;)
+        {
+            if (st.cur & kLeafBit) { leaves++; tris += st.cur == kWholeSceneLeaf ? s->view.numTris : (st.cur & 7u) + 1u; } else nodes++;
+            if (TravStep(s->view, st, stack, any_hit != 0)) break;
+        }
+        hits += st.best.tri != kInvalidTri;
+    }
+    out[0] = nodes; out[1] = leaves; out[2] = tris; out[3] = hits;
+}
+// The device's VOTED scheduling of the same state machine (zr_dev_scene.h TraverseDyn, device branch) replayed on the host: consecutive groups of 64 rays are
+// "waves"; every iteration the lanes still traversing vote for the inner-node phase or the leaf phase and the wave runs the one with more takers.  What a
+// traversal call costs a wave is its ITERATIONS, not its rays' own steps (the section profiler: 10.5 iterations per call for rays that need 3.8 + 1.4), and
+// that depends on the tree's shape -- depth, how alike the rays' step counts are -- in ways the per-ray counts do not show.  out = {node iterations, leaf
+// iterations, lanes in node iterations, lanes in leaf iterations, calls}.  active (optional, one byte per ray): lanes that issue a ray (a wave's idle lanes).
+void zhx_trace_vote_stats(const HxScene* s, const float* rays, const uint8_t* active, uint32_t n, uint32_t mask, int any_hit, uint64_t* out)
+{
+    uint64_t nodeIt = 0, triIt = 0, nodeLanes = 0, triLanes = 0, calls = 0;
+    std::vector<zr::StackEntry> stackMem((size_t)64 * zr::kTravStack);
+    for (uint32_t base = 0; base < n; base += 64)
+    {
+        const uint32_t cnt = std::min(64u, n - base);
+        TravState st[64]; TravLane L[64]; zr::TravStack stack[64]; bool live[64];
+        bool any = false;
+        for (uint32_t l = 0; l < cnt; l++)
+        {
+            const uint32_t i = base + l;
+            live[l] = !active || active[i];
+            stack[l].lds = nullptr; stack[l].stride = 0; stack[l].mem = stackMem.data() + (size_t)l * zr::kTravStack;
+            L[l].triCur = 0; L[l].triEnd = 0; L[l].done = !live[l];
+            if (!live[l]) continue;
+            any = true;
+            TravInit(s->view, st[l], v3(rays[8 * i], rays[8 * i + 1], rays[8 * i + 2]), v3(rays[8 * i + 4], rays[8 * i + 5], rays[8 * i + 6]), rays[8 * i + 3], rays[8 * i + 7], mask, false, 0);
+            TravEnter(s->view, st[l], L[l], st[l].cur);
+        }
+        if (!any) continue;
+        calls++;
+        for (;;)
+        {
+            uint32_t nNode = 0, nTri = 0;
+            for (uint32_t l = 0; l < cnt; l++) { const bool atTri = L[l].triCur < L[l].triEnd; nTri += atTri; nNode += !L[l].done && !atTri; }
+            if (nNode + nTri == 0) break;
+            static const int wn = std::getenv("ZHX_VOTE_WN") ? std::atoi(std::getenv("ZHX_VOTE_WN")) : ZR_VOTE_WN, wt = std::getenv("ZHX_VOTE_WT") ? std::atoi(std::getenv("ZHX_VOTE_WT")) : ZR_VOTE_WT;
+            if ((uint32_t)wn * nNode >= (uint32_t)wt * nTri)
+            {
+                nodeIt++; nodeLanes += nNode;
+                for (uint32_t l = 0; l < cnt; l++) if (!L[l].done && !(L[l].triCur < L[l].triEnd)) TravNodePhase(s->view, st[l], L[l], stack[l]);
+            }
+            else
+            {
+                triIt++; triLanes += nTri;
+                for (uint32_t l = 0; l < cnt; l++) if (L[l].triCur < L[l].triEnd) TravTriPhase(s->view, st[l], L[l], stack[l], any_hit != 0);
+            }
+        }
+    }
+    out[0] = nodeIt; out[1] = triIt; out[2] = nodeLanes; out[3] = triLanes; out[4] = calls;
+}
 void zhx_trace_any(const HxScene* s, const float* rays, uint32_t n, uint32_t mask, uint32_t* occ)
 {
     zr::StackEntry stackMem[zr::kTravStack]; zr::TravStack stack; stack.lds = nullptr; stack.stride = 0; stack.mem = stackMem;

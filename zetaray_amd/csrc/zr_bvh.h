@@ -52,6 +52,9 @@ public:
         if (const char* e = std::getenv("ZR_BVH_MAX_LEAF")) { const int v = std::atoi(e); if (v >= 1 && v <= 8) maxLeaf_ = (uint32_t)v; }
         if (const char* e = std::getenv("ZR_BVH_SAH_LEAF")) nodeCost_ = (float)std::atof(e);
         if (const char* e = std::getenv("ZR_BVH_SWEEP")) sweepBelow_ = (uint32_t)std::atoi(e);
+        if (const char* e = std::getenv("ZR_BVH_COLLAPSE")) optimalCollapse_ = std::strcmp(e, "greedy") != 0;
+        if (const char* e = std::getenv("ZR_BVH_SPLIT")) medianBelow_ = !std::strcmp(e, "median") ? 0xffffffffu : (uint32_t)std::atoi(e);
+        if (const char* e = std::getenv("ZR_BVH_CNODE")) { const float v = (float)std::atof(e); if (v > 0) collapseNodeCost_ = v; }
         // the top of the recursion forks: a range keeps one half and hands the other to a new thread while threads are left (ZR_BVH_THREADS, default
         // = hardware threads, at most 16).  Every range's split depends only on its own triangles, leaves land at their range's position and the
         // BVH2 node numbers only matter as references, so the collapsed tree is the same bit for bit whatever the schedule (380 k-triangle atrium:
@@ -62,6 +65,14 @@ public:
     }
     int threads_ = 1;
     uint32_t sweepBelow_ = 0;      // ranges of fewer triangles than this are split by an exact SAH sweep instead of 16 bins
+    // BVH2 -> BVH4: which descendants of a binary node become the (up to four) children of its wide node.  true: the SAH-optimal choice for the given binary
+    // tree by dynamic programming (Ylitie, Karras, Laine 2017, "Efficient Incoherent Ray Traversal on GPUs Through Compressed Wide BVHs", section 4.1);
+    // false (ZR_BVH_COLLAPSE=greedy): rounds 1 - 5's rule -- open the inner child of largest area until there are four.  The greedy rule leaves the bottom of the
+    // tree half empty (a 4-triangle range is a node with two 2-triangle leaves and two empty slots: 99.7 k nodes, 2.9 children per node on the 380 k-triangle
+    // atrium); measured per ray by tools/bvh_quality.py and in the kernels by the section profiler.  collapseNodeCost_: one node visit (4 box
+    // tests, sort, pushes: ~190 VALU instructions) in units of one triangle test (~65).  Results never depend on the tree (zr_intersect.h).
+    bool optimalCollapse_ = true; float collapseNodeCost_ = 3.0f;
+    uint32_t medianBelow_ = 0;      // (experiment, ZR_BVH_SPLIT=median | N: ranges of fewer than N triangles are split at the object median of the widest centroid axis)
 
     // ownSubtree (optional, one byte per instance): instances flagged here are kept out of the common SAH tree and get a subtree of their own, joined
     // to the rest near the root -- the flat-tree form of the reference's TLAS over one static BLAS and one BLAS per dynamic instance
@@ -130,7 +141,9 @@ public:
         out.nodes.resize(nodeCount_.load());
         out.maxDepth = maxDepth_.load();
         out.nodes4.reserve(out.nodes.size() / 2 + 1);
+        if (optimalCollapse_) PlanCollapse();
         Collapse(0, out.stackNeed);
+        plan_.clear(); plan_.shrink_to_fit();
         ReorderBreadthFirst(out.nodes4);
         if (std::getenv("ZR_BVH_TIMING"))
             std::fprintf(stderr, "[zr_bvh] %u triangles, %d threads: SAH build %.1f ms, collapse + reorder %.1f ms\n", N, threads_,
@@ -168,23 +181,97 @@ private:
     // BVH2 -> BVH4: start from a node's two children and keep replacing the inner child of largest surface area by its
     // own two children until there are four (or only leaves are left).  Returns the new node's index; `need` receives the
     // stack entries a traversal below this node can hold at once.
+    struct C { uint32_t ref; float lo[3], hi[3]; };
+    // ---- the optimal collapse.  For a binary node x, cost[i - 1] = the least SAH cost of x's subtree when it may occupy up to i child slots of the wide node above it:
+    //   i = 1: x is a wide node itself: area(x) * cNode + min over k of cost(left, k) + cost(right, 4 - k);
+    //   i > 1: either fewer slots (cost i - 1), or x is dissolved and its children share the slots: min over k of cost(left, k) + cost(right, i - k).
+    // A leaf costs area * triangles whatever it is given.  split[i - 1] remembers the choice (0: "as with i - 1 slots", else k = the left child's share).
+    struct Plan { float cost[4]; uint8_t split[4]; };
+    std::vector<Plan> plan_;
+    float LeafCost(uint32_t ref, const float lo[3], const float hi[3]) const { return Area(lo, hi) * (float)((ref & 7u) + 1u); }
+    float PlanCost(uint32_t ref, const float lo[3], const float hi[3], int slots) const
+    { return (ref & kLeafBit) ? LeafCost(ref, lo, hi) : plan_[ref].cost[slots - 1]; }
+    void PlanNode(uint32_t x, const float lo[3], const float hi[3])
+    {
+        const BvhNode& n = out_->nodes[x];
+        if (!(n.left & kLeafBit)) PlanNode(n.left, n.lmin, n.lmax);
+        if (!(n.right & kLeafBit)) PlanNode(n.right, n.rmin, n.rmax);
+        Plan& P = plan_[x];
+        float best = 3.402823466e+38f; int bk = 1;
+        for (int k = 1; k <= 3; k++)
+        {
+            const float c = PlanCost(n.left, n.lmin, n.lmax, k) + PlanCost(n.right, n.rmin, n.rmax, 4 - k);
+            if (c < best) { best = c; bk = k; }
+        }
+        P.cost[0] = Area(lo, hi) * collapseNodeCost_ + best; P.split[0] = (uint8_t)bk;
+        for (int i = 2; i <= 4; i++)
+        {
+            float bi = P.cost[i - 2]; int bs = 0;
+            for (int k = 1; k < i; k++)
+            {
+                const float c = PlanCost(n.left, n.lmin, n.lmax, k) + PlanCost(n.right, n.rmin, n.rmax, i - k);
+                if (c < bi) { bi = c; bs = k; }
+            }
+            P.cost[i - 1] = bi; P.split[i - 1] = (uint8_t)bs;
+        }
+    }
+    void PlanCollapse()
+    {
+        plan_.assign(out_->nodes.size(), Plan());
+        const BvhNode& n = out_->nodes[0];
+        float lo[3], hi[3];
+        for (int r = 0; r < 3; r++) { lo[r] = std::min(n.lmin[r], n.rmin[r]); hi[r] = std::max(n.lmax[r], n.rmax[r]); }
+        PlanNode(0, lo, hi);
+    }
+    // the children of wide node x according to the plan: x's two children share four slots
+    void Resolve(uint32_t ref, const float lo[3], const float hi[3], int slots, C* c, int& k)
+    {
+        if (!(ref & kLeafBit))
+        {
+            while (slots > 1 && plan_[ref].split[slots - 1] == 0) slots--;
+            if (slots > 1)
+            {
+                const BvhNode& n = out_->nodes[ref];
+                const int kl = plan_[ref].split[slots - 1];
+                Resolve(n.left, n.lmin, n.lmax, kl, c, k);
+                Resolve(n.right, n.rmin, n.rmax, slots - kl, c, k);
+                return;
+            }
+        }
+        c[k].ref = ref;
+        for (int r = 0; r < 3; r++) { c[k].lo[r] = lo[r]; c[k].hi[r] = hi[r]; }
+        k++;
+    }
+    void GatherPlanned(uint32_t x, C* c, int& k)
+    {
+        const BvhNode& n = out_->nodes[x];
+        const int kl = plan_[x].split[0];
+        k = 0;
+        Resolve(n.left, n.lmin, n.lmax, kl, c, k);
+        Resolve(n.right, n.rmin, n.rmax, 4 - kl, c, k);
+    }
     uint32_t Collapse(uint32_t node2, uint32_t& need)
     {
-        struct C { uint32_t ref; float lo[3], hi[3]; } c[4];
-        const BvhNode& n = out_->nodes[node2];
-        int k = 2;
-        c[0].ref = n.left; c[1].ref = n.right;
-        for (int r = 0; r < 3; r++) { c[0].lo[r] = n.lmin[r]; c[0].hi[r] = n.lmax[r]; c[1].lo[r] = n.rmin[r]; c[1].hi[r] = n.rmax[r]; }
-        while (k < 4)
+        C c[4];
+        int k = 0;
+        if (optimalCollapse_) GatherPlanned(node2, c, k);
+        else
         {
-            int pick = -1; float bestA = -1.0f;
-            for (int i = 0; i < k; i++)
-                if (!(c[i].ref & kLeafBit)) { float a = Area(c[i].lo, c[i].hi); if (a > bestA) { bestA = a; pick = i; } }
-            if (pick < 0) break;
-            const BvhNode& m = out_->nodes[c[pick].ref];
-            c[pick].ref = m.left; c[k].ref = m.right;
-            for (int r = 0; r < 3; r++) { c[pick].lo[r] = m.lmin[r]; c[pick].hi[r] = m.lmax[r]; c[k].lo[r] = m.rmin[r]; c[k].hi[r] = m.rmax[r]; }
-            k++;
+            const BvhNode& n = out_->nodes[node2];
+            k = 2;
+            c[0].ref = n.left; c[1].ref = n.right;
+            for (int r = 0; r < 3; r++) { c[0].lo[r] = n.lmin[r]; c[0].hi[r] = n.lmax[r]; c[1].lo[r] = n.rmin[r]; c[1].hi[r] = n.rmax[r]; }
+            while (k < 4)
+            {
+                int pick = -1; float bestA = -1.0f;
+                for (int i = 0; i < k; i++)
+                    if (!(c[i].ref & kLeafBit)) { float a = Area(c[i].lo, c[i].hi); if (a > bestA) { bestA = a; pick = i; } }
+                if (pick < 0) break;
+                const BvhNode& m = out_->nodes[c[pick].ref];
+                c[pick].ref = m.left; c[k].ref = m.right;
+                for (int r = 0; r < 3; r++) { c[pick].lo[r] = m.lmin[r]; c[pick].hi[r] = m.lmax[r]; c[k].lo[r] = m.rmin[r]; c[k].hi[r] = m.rmax[r]; }
+                k++;
+            }
         }
         const uint32_t idx = (uint32_t)out_->nodes4.size();
         out_->nodes4.push_back(Bvh4Node());
@@ -379,7 +466,15 @@ private:
             }
         }
         uint32_t mid;
-        if (count < sweepBelow_ && bestAxis >= 0)
+        if (count < medianBelow_ && bestAxis >= 0)
+        {
+            int ax = 0; float we = -1.0f;
+            for (int r = 0; r < 3; r++) if (cmax[r] - cmin[r] > we) { we = cmax[r] - cmin[r]; ax = r; }
+            std::sort(bt_.begin() + first, bt_.begin() + first + count, [ax](const BuildTri& a, const BuildTri& b) { return a.cent[ax] < b.cent[ax] || (a.cent[ax] == b.cent[ax] && a.gidx < b.gidx); });
+            uint32_t half = count / 2; if ((half & 1u) && half + 1 < count) half++;      // even halves: leaves of two
+            mid = first + half;
+        }
+        else if (count < sweepBelow_ && bestAxis >= 0)
         {
             // exact sweep: every object split along every axis
             float bestC = 3.402823466e+38f; int bAxis = -1; uint32_t bK = 0;

@@ -228,7 +228,12 @@ struct StackEntry { uint32_t child; float t; };
 struct alignas(16) NodeQuad { uint32_t x, y, z, w; };
 struct TravStack { ZR_LDS_AS StackEntry* lds; uint32_t stride; ZR_PRIVATE_AS StackEntry* mem; uint32_t* aux = nullptr; const ZR_LDS_AS NodeQuad* cache = nullptr;
     uint32_t cacheNodes = 0;      // nodes 0 .. cacheNodes - 1 are in `cache` (<= ZR_NODE_CACHE; a scene with fewer nodes is cached whole)
-    const ZR_LDS_AS NodeQuad* triCache = nullptr; uint32_t cacheTris = 0; };     // leaf-order triangles 0 .. cacheTris - 1 (3 quads each) in LDS: tiny scenes
+    const ZR_LDS_AS NodeQuad* triCache = nullptr; uint32_t cacheTris = 0;       // leaf-order triangles 0 .. cacheTris - 1 (3 quads each) in LDS: tiny scenes
+    // weight of a lane waiting at a leaf in the phase vote of TraverseDyn (a lane waiting at an inner node weighs ZR_VOTE_WN = 1): 1 = plain majority.  The spatial
+    // reconnect kernel sets 2 -- its dense calls (60 of 64 lanes issue a ray) finish sooner when the leaf phase runs as soon as a third of the lanes wait for it:
+    // k_rpt_stc 0.509 -> 0.490 ms on the Cornell frame, 2.68 -> 2.62 ms on the atrium; K11's sparse calls get SLOWER that way (atrium 7.12 -> 8.8 ms) and keep 1
+    // (profiles/r06i_ab_vote_weights.txt; tools/bvh_quality.py replays the schedule on the host)
+    uint32_t voteTri = ZR_VOTE_WT; };
 static constexpr uint32_t kStealAuxWords = 64 * 2 + 64 * 3 + 64;
 
 // triangle i of the leaf order: from the block's LDS copy when the scene is cached whole (tiny scenes, ZR_SCENE_CACHE_FILL), else from HBM / L2
@@ -521,9 +526,9 @@ ZR_HD RawHit TraverseDyn(const SceneView& sc, V3 o, V3 d, float tmin, float tmax
         }
 #endif
 #ifdef ZR_PROF
-        if (ZR_VOTE_WN * __popcll(mNode) >= ZR_VOTE_WT * __popcll(mTri)) { pNI++; pNL += __popcll(mNode); } else { pTI++; pTL += __popcll(mTri); }
+        if (ZR_VOTE_WN * __popcll(mNode) >= (int)stack.voteTri * __popcll(mTri)) { pNI++; pNL += __popcll(mNode); } else { pTI++; pTL += __popcll(mTri); }
 #endif
-        if (ZR_VOTE_WN * __popcll(mNode) >= ZR_VOTE_WT * __popcll(mTri)) { if (atNode) TravNodePhase(sc, s, L, stack); }
+        if (ZR_VOTE_WN * __popcll(mNode) >= (int)stack.voteTri * __popcll(mTri)) { if (atNode) TravNodePhase(sc, s, L, stack); }
         else { if (atTri) TravTriPhase(sc, s, L, stack, ZR_STEAL_ANYHIT, alphaTest); }
     }
 #if ZR_STEAL

@@ -582,6 +582,9 @@ static constexpr int kReconBlock = ZR_RECON_BLOCK;
 #define ZR_STC_LDS 0
 #endif
 static constexpr int kStcBlock = ZR_STC_BLOCK;
+#ifndef ZR_VOTE_WT_STC
+#define ZR_VOTE_WT_STC 2
+#endif
 
 // K14: CtT + TtC fused per pixel (zr_rpt.h ReconnectTemporalPixel)
 template<bool EMISSIVE, bool TEX, bool PLAIN = false>
@@ -623,6 +626,7 @@ __global__ void __launch_bounds__(kStcBlock) ZR_WAVES_STC k_rpt_stc(rpt::RptFram
     // four wave sums below run over the 64 pixels K12 put together (error bit: nothing to do -- the lane stays in the wave, contributing 0)
     if (F.prm.sortSpatial && F.Owns(x, y) && !rpt::DecodeSorted(F.mapNtC[rpt::Pix(F.gb, x, y)], x, y)) x = 0xffffffffu;
     ZR_TRAV_STACK_B(stack, kStcBlock);
+    stack.voteTri = ZR_VOTE_WT_STC;      // (zr_dev_scene.h TravStack::voteTri)
 #if ZR_SCENE_LDS
     ZR_SCENE_CACHE_FILL(stack, F.sc, kStcBlock);
 #endif
