@@ -602,7 +602,7 @@ def measure(args, ctx):
                      "atrium" if (args.scene == "synthetic" and args.synthetic_layout == "atrium" and args.synthetic_tris == 262144
                                   and args.synthetic_emissives == 100000) else None)
         wl_tag = {"restir_pt": "rpt", "restir_gi": "gi", "pt": "pt"}[args.integrator] + ("" if (W, H) == (1920, 1080) else f"_{W}x{H}")
-        pmc_rel = next((q for q in (os.path.join("profiles", f"{rnd}_pmc_{wl_tag}_{scene_tag}.json") for rnd in ("r05", "r04", "r03"))
+        pmc_rel = next((q for q in (os.path.join("profiles", f"{rnd}_pmc_{wl_tag}_{scene_tag}.json") for rnd in ("r06", "r05", "r04", "r03"))
                         if os.path.exists(os.path.join(ROOT, q))), "")
         if plain and scene_tag and pmc_rel:
             table = json.load(open(os.path.join(ROOT, pmc_rel)))

@@ -1,7 +1,7 @@
 #!/bin/bash
 # One runner for every GPU visit (replaces the per-visit gpu_r0N_*.sh scripts of rounds 1 - 4).  Runs ON the GPU box, from the repository root:
 #   gpurun --timeout 900 -- 'bash scripts/gpu.sh ab base "" stc4 ; bash scripts/gpu.sh suite'
-# Tasks (TAG=r05 by default; everything lands in gpurun_out/${TAG}_*, copy what should be judged into profiles/):
+# Tasks (TAG=r06 by default; everything lands in gpurun_out/${TAG}_*, copy what should be judged into profiles/):
 #   ab LIB...          A/B of library builds: for each name ("" or "default" = libzetaray_amd.so, X = libzetaray_amd_X.so) the bench lines of the
 #                      workloads in WORKLOADS (default "cornell atrium"), then one table of frame + kernel times
 #   suite [PYTEST_ARGS] the -m gpu parity suite (+ smoke)
@@ -11,7 +11,7 @@
 #   stats [ARGS]       one rocprofv3 --kernel-trace --stats run of bench.py ARGS -> ${TAG}_kernel_stats.csv
 #   tiles              tools/tile_balance.py on Cornell + atrium (per-tile times of the 8-way split on one device)
 #   prof LIB           section profiler (-DZR_PROF build LIB) on Cornell + atrium -> ${TAG}_section_profile_*.json
-R=${GRAFT_REPO_ROOT:-$PWD}; TAG=${TAG:-r05}; OUT=$R/gpurun_out; mkdir -p $OUT
+R=${GRAFT_REPO_ROOT:-$PWD}; TAG=${TAG:-r06}; OUT=$R/gpurun_out; mkdir -p $OUT
 task=$1; shift
 libpath() { case "$1" in ""|default) echo "";; *) echo "$R/zetaray_amd/libzetaray_amd_$1.so";; esac; }
 wl_args() { case $1 in
@@ -53,7 +53,7 @@ bench)
   ;;
 stats)
   cd /tmp && export TMPDIR=/tmp; rm -rf /tmp/st_d
-  timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/st_d -- python $R/bench.py --gpus 1 --steps 16 --warmup 4 --settle 8 --no-cpu-baseline --no-extra-workloads "$@" > $OUT/${TAG}_stats.log 2>&1
+  timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/st_d -- python $R/bench.py --gpus 1 --steps 16 --warmup 4 --settle 8 --ramp-s 0 --no-device-state --no-general-kernels --no-cpu-baseline --no-extra-workloads "$@" > $OUT/${TAG}_stats.log 2>&1
   python $R/tools/rocpd_summary.py stats $(find /tmp/st_d -name "*results.db" | head -1) $OUT/${TAG}_kernel_stats.csv | head -25
   ;;
 profiles)
@@ -70,7 +70,8 @@ profiles)
     rm -rf ${O}_d; }
   for wl in ${WORKLOADS:-rpt_cornell rpt_atrium gi_cornell}; do
     # (--no-extra-workloads: the default line would otherwise render configs 4 and 5 in the same process, and their launches share kernel names with Cornell's)
-    CMD="python $R/bench.py --gpus 1 --steps 6 --warmup 2 --settle 8 --no-cpu-baseline --no-extra-workloads $(wl_args $wl)"
+    # (--frame-overlap 0: a kernel's counters and duration alone on the device; --ramp-s 0: the counter passes serialise the kernels, nothing to ramp)
+    CMD="python $R/bench.py --gpus 1 --steps 6 --warmup 2 --settle 8 --ramp-s 0 --frame-overlap 0 --no-device-state --no-general-kernels --no-cpu-baseline --no-extra-workloads $(wl_args $wl)"
     O=$OUT/${TAG}_$wl
     pmc ${O}_fetch FETCH_SIZE $CMD; pmc ${O}_write WRITE_SIZE $CMD
     for p in ${SQ_SETS:-A B C E}; do eval CTR=\$SQ_$p; pmc ${O}_sq$p "$CTR" $CMD; done
@@ -94,7 +95,7 @@ prof)
   cd $R; export ZETARAY_AMD_LIB=$(libpath "$1")
   P='import sys,json; d=json.loads(sys.stdin.read()); print(json.dumps({"ms": d["ms_per_step"], "kernels": d["roofline"]["kernel_ms_per_frame"], "prof": d.get("prof")}, indent=1))'
   for wl in ${WORKLOADS:-cornell atrium}; do
-    timeout 600 python bench.py --gpus 1 --steps 16 --warmup 4 --no-cpu-baseline --no-extra-workloads $(wl_args $wl) 2> $OUT/${TAG}_prof_err.log | tail -1 | python -c "$P" > $OUT/${TAG}_section_profile_$wl.json || tail -5 $OUT/${TAG}_prof_err.log
+    timeout 600 python bench.py --gpus 1 --steps 16 --warmup 4 --frame-overlap 0 --no-device-state --no-general-kernels --no-cpu-baseline --no-extra-workloads $(wl_args $wl) 2> $OUT/${TAG}_prof_err.log | tail -1 | python -c "$P" > $OUT/${TAG}_section_profile_$wl.json || tail -5 $OUT/${TAG}_prof_err.log
   done
   ;;
 *) echo "unknown task $task"; exit 2;;

@@ -306,7 +306,12 @@ ZR_HD bool TravPop(TravState& s, const TravStack& stack)
     const uint32_t cc = sw ? c##a : c##b; c##a = sw ? c##b : c##a; c##b = cc; }
 
 // inner node s.cur: tests the 4 child boxes, pushes the far hits and returns the nearest one (kEmptyChild: none hit)
-ZR_HD uint32_t TravNode(const SceneView& sc, TravState& s, const TravStack& stack)
+// unordered (any-hit rays, -DZR_ANYHIT_UNSORTED=1): the children need no near-to-far order -- "some hit" is order-free and the entry-distance cull of TravPop never
+// triggers (best.t stays tmax until the ray ends) -- so the sorting network is skipped: the first child hit is visited, the others pushed
+#ifndef ZR_ANYHIT_UNSORTED
+#define ZR_ANYHIT_UNSORTED 0
+#endif
+ZR_HD uint32_t TravNode(const SceneView& sc, TravState& s, const TravStack& stack, bool unordered = false)
 {
 #if ZR_NODE_CACHE && defined(__HIP_DEVICE_COMPILE__)
     Bvh4Node n;
@@ -347,6 +352,16 @@ ZR_HD uint32_t TravNode(const SceneView& sc, TravState& s, const TravStack& stac
     ZR_TRAV_BOX(0) ZR_TRAV_BOX(1) ZR_TRAV_BOX(2) ZR_TRAV_BOX(3)
 #undef ZR_TRAV_BOX
 #undef ZR_Q
+#if ZR_ANYHIT_UNSORTED
+    if (unordered)
+    {
+        uint32_t next = c0;
+        if (c1 != kEmptyChild) { if (next != kEmptyChild) StackWrite(stack, s.sp++, c1, t1); else next = c1; }
+        if (c2 != kEmptyChild) { if (next != kEmptyChild) StackWrite(stack, s.sp++, c2, t2); else next = c2; }
+        if (c3 != kEmptyChild) { if (next != kEmptyChild) StackWrite(stack, s.sp++, c3, t3); else next = c3; }
+        return next;
+    }
+#endif
     // sorting network: near to far, misses (t = inf) last
     ZR_TRAV_CSWAP(0, 1) ZR_TRAV_CSWAP(2, 3) ZR_TRAV_CSWAP(0, 2) ZR_TRAV_CSWAP(1, 3) ZR_TRAV_CSWAP(1, 2)
     if (c3 != kEmptyChild) StackWrite(stack, s.sp++, c3, t3);
@@ -394,9 +409,9 @@ ZR_HD void TravPopEnter(const SceneView& sc, TravState& s, TravLane& L, const Tr
     if (TravPop(s, stack)) TravEnter(sc, s, L, s.cur);
     else L.done = true;
 }
-ZR_HD void TravNodePhase(const SceneView& sc, TravState& s, TravLane& L, const TravStack& stack)
+ZR_HD void TravNodePhase(const SceneView& sc, TravState& s, TravLane& L, const TravStack& stack, bool unordered = false)
 {
-    const uint32_t next = TravNode(sc, s, stack);
+    const uint32_t next = TravNode(sc, s, stack, unordered);
     if (next == kEmptyChild) TravPopEnter(sc, s, L, stack);
     else TravEnter(sc, s, L, next);
 }
@@ -528,7 +543,7 @@ ZR_HD RawHit TraverseDyn(const SceneView& sc, V3 o, V3 d, float tmin, float tmax
 #ifdef ZR_PROF
         if (ZR_VOTE_WN * __popcll(mNode) >= (int)stack.voteTri * __popcll(mTri)) { pNI++; pNL += __popcll(mNode); } else { pTI++; pTL += __popcll(mTri); }
 #endif
-        if (ZR_VOTE_WN * __popcll(mNode) >= (int)stack.voteTri * __popcll(mTri)) { if (atNode) TravNodePhase(sc, s, L, stack); }
+        if (ZR_VOTE_WN * __popcll(mNode) >= (int)stack.voteTri * __popcll(mTri)) { if (atNode) TravNodePhase(sc, s, L, stack, ZR_STEAL_ANYHIT); }
         else { if (atTri) TravTriPhase(sc, s, L, stack, ZR_STEAL_ANYHIT, alphaTest); }
     }
 #if ZR_STEAL
