@@ -7,6 +7,7 @@ construction (ZR_BVH_*), so each variant runs in a process of its own:
 
     python tools/bvh_quality.py [--scene synthetic|cornell] [--rays 200000]          one JSON line
     python tools/bvh_quality.py --sweep                                              the table of variants (children processes)
+    python tools/bvh_quality.py --scene cornell --dump                               the wide tree itself
 """
 import argparse, ctypes as C, json, os, subprocess, sys, time
 import numpy as np
@@ -146,7 +147,32 @@ def main():
     ap.add_argument("--rays", type=int, default=100000)
     ap.add_argument("--waves", type=int, default=400, help="16 x 4 pixel blocks whose rays are replayed through the voted schedule")
     ap.add_argument("--sweep", action="store_true")
+    ap.add_argument("--dump", action="store_true", help="print the wide tree (small scenes): N<i> = inner node, L<n> = leaf of n triangles, - = empty slot")
     a = ap.parse_args()
+    if a.dump:
+        from zetaray_amd import scene_io
+        from tests.hostexec import zhx
+        sc = (scene_io.make_synthetic_scene(num_tris=262144, num_emissive=100000, layout="atrium") if a.scene == "synthetic"
+              else scene_io.load_npz(os.path.join(ROOT, "tests", "golden", "cornell_emissive.npz")))
+        hx = zhx.HostExecScene(sc)
+        _, nn, nt, st = hx.bvh_digest()
+        ch = np.zeros((nn, 4), np.uint32)
+        zhx.lib().zhx_bvh_children.argtypes = [C.c_void_p, C.c_void_p]
+        zhx.lib().zhx_bvh_children(hx.h, ch.ctypes.data)
+
+        def show(i, d):
+            print("  " * d + f"node {i}: " + " ".join("-" if c == 0xFFFFFFFF else (f"L{(c & 7) + 1}" if c & 0x80000000 else f"N{c}") for c in ch[i]))
+            if d < 6:
+                for c in ch[i]:
+                    if c != 0xFFFFFFFF and not (c & 0x80000000):
+                        show(int(c), d + 1)
+        if nn <= 200:
+            show(0, 0)
+        flat = ch.ravel()
+        leaf = (flat != 0xFFFFFFFF) & ((flat & 0x80000000) != 0)
+        print(json.dumps({"nodes": nn, "tris": nt, "stack_need": st, "leaves": int(leaf.sum()), "leaf_sizes": np.bincount((flat[leaf] & 7) + 1).tolist(),
+                          "children_per_node": round(float((flat != 0xFFFFFFFF).sum()) / max(nn, 1), 3)}))
+        return
     if a.sweep:
         variants = [{}, {"ZR_BVH_SWEEP": "1000000000"}, {"ZR_BVH_MAX_LEAF": "4"}, {"ZR_BVH_SAH_LEAF": "1.0"}] + [dict(kv.split("=") for kv in v.split(",")) for v in os.environ.get("ZR_BVH_VARIANTS", "").split(";") if v]
         for v in variants:
