@@ -275,6 +275,26 @@ def test_frame_overlap_changes_nothing(api, cornell_emissive, oracle_emissive, c
     assert finp == fin12 and cp == c12, ([a == b for a, b in zip(finp, fin12)], cp, c12)
 
 
+def test_frame_overlap_needs_its_tracked_gbuffer(api, cornell_emissive):
+    """Two frames in flight need the G-buffer's third plane set and stream tracking, which zr_pass_set_frame_overlap gives to the G-buffer it is handed: a frame rendered
+    from ANOTHER G-buffer (a renderer that replaced it on a resize and forgot) fails loudly instead of racing; handing the new one over makes it work."""
+    w, h = 96, 64
+    r = api.Renderer(cornell_emissive, w, h, params=wire.default_params(), integrator=api.INTEGRATOR_RESTIR_PT)
+    r.enable_frame_overlap(True)
+    for f in (1, 2):
+        r.render_frame(_frame(cornell_emissive, w, h, f))
+    other = api.GBuffer(w, h)
+    cb = _frame(cornell_emissive, w, h, 3)
+    r.p_gbuffer.render(cb, r.scene, other)
+    with pytest.raises(api.ZetaRayError):
+        r.p_indirect.render_stage(cb, r.scene, other, api.STAGE_CANDIDATES)
+    r.gbuffer = other
+    r.enable_frame_overlap(True)
+    for f in (3, 4, 5):
+        r.render_frame(_frame(cornell_emissive, w, h, f))
+    assert np.isfinite(r.final()).all() and r.final()[..., :3].max() > 0
+
+
 def test_restir_pt_thread_sort_on_partial_tiles(api, cornell_emissive, oracle_emissive):
     """K12 at 150 x 90 (partial 32 x 32 tiles on the right and bottom boundaries: the transposed right-boundary groups, the one-to-one last
     group, in-image pixels of boundary groups in the k >= 5 bucket) with a camera that starts moving at frame 3: both thread maps, the

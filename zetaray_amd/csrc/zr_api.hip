@@ -2389,6 +2389,9 @@ static int RenderReSTIR_PT(zr_pass* p, hipStream_t s, const zr_frame_constants* 
     const bool stageCand = (stages & (ZR_STAGE_TEMPORAL | ZR_STAGE_CANDIDATES)) != 0, stageReuseT = (stages & (ZR_STAGE_TEMPORAL | ZR_STAGE_TEMPORAL_REUSE)) != 0;
     if (stageCand && p->overlap)
     {
+        // two frames in flight need the G-buffer's third plane set and its stream tracking: both belong to the G-buffer handed to zr_pass_set_frame_overlap (a renderer
+        // that replaces its G-buffer -- a resize -- hands the new one over again)
+        if (!gb->tracked || gb->numSets < 3) return Fail(ZR_ERR_INVALID_ARG, "ReSTIR PT with frame overlap: this G-buffer is not the one given to zr_pass_set_frame_overlap (call it again with the new G-buffer)");
         if (p->frameOpen) return Fail(ZR_ERR_INVALID_ARG, "ReSTIR PT with frame overlap: the previous frame's last stage has not been enqueued (stage order: CANDIDATES, TEMPORAL_REUSE, SPATIAL[, SPATIAL2])");
         // Frame overlap: this frame's K11 runs beside the previous frame's reuse passes, which still read the two sets in play and that frame's target
         // plane -- so it writes the free set (which takes the "current" role; the set it replaces is free from here on) and the other target / FINAL
