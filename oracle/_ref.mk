@@ -33,7 +33,7 @@ HLSL_ROOTS := ZetaRenderPass/Common/BSDFSampling.hlsli ZetaRenderPass/Common/RT.
 #   _ref/libzref_k9_{e0,e1,e1p}.so          PathTracer.hlsl with NEE_EMISSIVE = 0 / 1 / 1 + USE_PRESAMPLED_SETS (PathTracer, _WoPS, _WPS)
 #   _ref/libzref_rpt_{e0,e1,e1p}.so         ReSTIR PT: the 10 shaders of Variants/*.hlsl per NEE permutation + the restated host sequence (ref_rpt_host.cpp)
 PASS_LIBS := _ref/libzref_k1.so _ref/libzref_k9_e0.so _ref/libzref_k9_e1.so _ref/libzref_k9_e1p.so _ref/libzref_rpt_e0.so _ref/libzref_rpt_e1.so _ref/libzref_rpt_e1p.so \
-    _ref/libzref_gi_e0.so _ref/libzref_gi_e1.so _ref/libzref_gi_e1p.so _ref/libzref_di_e1.so _ref/libzref_di_e1p.so _ref/libzref_di_sky.so _ref/libzref_post.so _ref/libzref_aux.so _ref/libzref_gi_e1l.so
+    _ref/libzref_gi_e0.so _ref/libzref_gi_e1.so _ref/libzref_gi_e1p.so _ref/libzref_di_e1.so _ref/libzref_di_e1p.so _ref/libzref_di_e1h.so _ref/libzref_di_sky.so _ref/libzref_post.so _ref/libzref_aux.so _ref/libzref_gi_e1l.so
 PASS_HDRS := ref_hlsl/ref_pass_common.h ref_hlsl/hlsl_shim.h ref_hlsl/hlsl_resources.h ref_hlsl/hlsl_rt.h ref_hlsl/hlsl_group.h zro_scene.h
 
 all: _ref/libzref.so _ref/libzref_hlsl.so $(PASS_LIBS)
@@ -135,6 +135,8 @@ _ref/libzref_di_$(1).so: _ref/obj/di_$(1)_temporal.o _ref/obj/di_$(1)_spatial.o 
 endef
 $(eval $(call di_lib,e1,0,Emissive/ReSTIR_DI_Temporal.hlsl,Emissive/ReSTIR_DI_Spatial.hlsl,cb_ReSTIR_DI,1,2,))
 $(eval $(call di_lib,e1p,0,Emissive/ReSTIR_DI_Temporal.hlsl,Emissive/ReSTIR_DI_Spatial.hlsl,cb_ReSTIR_DI,1,2,-DUSE_PRESAMPLED_SETS))
+# (round 6) the emissive DI shaders with the reference's half-vector copy shift compiled in (Params.hlsli: USE_HALF_VECTOR_COPY_SHIFT, 0 in the reference's tree)
+$(eval $(call di_lib,e1h,0,Emissive/ReSTIR_DI_Temporal.hlsl,Emissive/ReSTIR_DI_Spatial.hlsl,cb_ReSTIR_DI,1,2,-DUSE_HALF_VECTOR_COPY_SHIFT=1))
 $(eval $(call di_lib,sky,1,Sky/SkyDI_Temporal.hlsl,Sky/SkyDI_Spatial.hlsl,cb_SkyDI,3,4,))
 
 # ---- post stack: AutoExposure_Histogram.hlsl + AutoExposure_WeightedAvg.hlsl (compute; g_hist is a root UAV) and Display.hlsl (pixel shader)

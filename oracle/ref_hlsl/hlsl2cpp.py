@@ -229,6 +229,11 @@ SPECIAL = {
         (r"\? mat\.GetTransmissionDepth\(\) : 0;", "? mat.GetTransmissionDepth() : half(0);"),
         (r"\? \(half\)mat\.GetSubsurface\(\) : 0;", "? (half)mat.GetSubsurface() : half(0);"),
     ],
+    "Params.hlsli": [
+        # DirectLighting/Emissive/Params.hlsli: the reference's compile-time switch of the emissive ReSTIR DI half-vector copy shift, 0 in the file.  Guarded so that the
+        # `e1h` permutation of _ref.mk can compile the shaders with the switch at 1 (-DUSE_HALF_VECTOR_COPY_SHIFT=1) -- what a maintainer does by editing the 0
+        (r"#define USE_HALF_VECTOR_COPY_SHIFT 0", "#ifndef USE_HALF_VECTOR_COPY_SHIFT\n#define USE_HALF_VECTOR_COPY_SHIFT 0\n#endif"),
+    ],
     "Reservoir.hlsli": [
         # `.x` on a scalar (legal HLSL): give the scalar a 1-component vector type
         (r"float inF = g_inF\[DTid\]\.x;", "float1 inF = g_inF[DTid].x;"),
