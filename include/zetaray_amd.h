@@ -112,6 +112,11 @@ typedef enum zr_integrator {
 /* ReSTIR DI (ZR_PASS_DI_EMISSIVE) reads TEMPORAL_RESAMPLE / SPATIAL_RESAMPLE above plus (CB_RDI_FLAGS, DirectLighting_Common.h:13-20): */
 #define ZR_DI_STOCHASTIC_SPATIAL          (1u << 8)
 #define ZR_DI_EXTRA_DISOCCLUSION_SAMPLING (1u << 9)
+/* ... and the reference's COMPILE-time switch USE_HALF_VECTOR_COPY_SHIFT (DirectLighting/Emissive/Params.hlsli:12; 0 in the reference's tree) as a run-time flag: BSDF-sampled
+   candidates of lobes narrower than alpha_min are reused by copying their half vector in the shading frame and re-tracing the reflected ray (Reservoir.hlsli:56-119, 156-184;
+   Resampling.hlsli:138-274; PairwiseMIS.hlsli:60-170); reservoir plane A then carries the flag and lobe in its metadata bits 5..8 and the oct-encoded half vector in
+   place of the barycentrics.  Off by default, like the reference.  Pinned against the reference's shaders compiled with the macro at 1 (tests/golden/ref_pass_di_half_vector*.npz). */
+#define ZR_DI_HALF_VECTOR_COPY_SHIFT      (1u << 11)
 /* Compositing (ZR_PASS_COMPOSITING): run the firefly filter on the composited image (Compositing::SetFireflyFilterEnablement,
    RP/Compositing/FireflyFilter.hlsl).  Pinned: every pixel reads the unfiltered image (the reference filters its UAV in place). */
 #define ZR_COMPOSIT_FIREFLY_FILTER        (1u << 10)

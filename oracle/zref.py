@@ -193,8 +193,10 @@ class RefRestirGI(RefPass):
 class RefDirect(RefPass):
     """K5 / K6 (emissive ReSTIR DI) or K7 / K8 (sun + sky ReSTIR DI): the reference's DI shaders + restated host (oracle/ref_hlsl/ref_di_host.cpp)"""
 
-    def __init__(self, scene, w, h, sky=False, presampling=False, force_bvh=False):
-        super().__init__("di_sky" if sky else ("di_e1p" if presampling else "di_e1"), scene, force_bvh)
+    def __init__(self, scene, w, h, sky=False, presampling=False, force_bvh=False, half_vec=False):
+        # half_vec: the emissive DI shaders compiled with USE_HALF_VECTOR_COPY_SHIFT = 1 (libzref_di_e1h.so; the reference's tree has 0)
+        assert not (half_vec and (sky or presampling))
+        super().__init__("di_sky" if sky else ("di_e1h" if half_vec else ("di_e1p" if presampling else "di_e1")), scene, force_bvh)
         L = self.L
         L.zrefp_di_create.restype = C.c_void_p
         L.zrefp_di_create.argtypes = [C.c_uint32, C.c_uint32]

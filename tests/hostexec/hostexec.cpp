@@ -756,6 +756,7 @@ void zhx_rdi_render(const HxScene* s, HxRdi* R, const zr_frame_constants* cb, co
     prm.doTemporal = (R->temporalValid && (params->flags & ZR_IND_TEMPORAL_RESAMPLE) && prev) ? 1u : 0u;
     prm.doSpatial = (prm.doTemporal && (params->flags & ZR_IND_SPATIAL_RESAMPLE)) ? 1u : 0u;
     prm.writeReservoirs = (prm.doTemporal || !R->temporalValid) ? 1u : 0u;
+    prm.halfVec = (params->flags & ZR_DI_HALF_VECTOR_COPY_SHIFT) ? 1u : 0u; prm.alpha_min = params->alpha_min;
     zr::StackEntry stackMem[zr::kTravStack]; zr::TravStack stack; stack.lds = nullptr; stack.stride = 0; stack.mem = stackMem;
     for (uint32_t y = 0; y < H; y++) for (uint32_t x = 0; x < W; x++) TemporalPixel(F, g, x, y, stack, cnt);
     if (prm.doSpatial)

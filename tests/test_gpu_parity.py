@@ -523,6 +523,38 @@ def test_restir_di_materials_presampled_on_gpu(api):
         assert np.array_equal(di.download().view(np.uint32), want.view(np.uint32)), f"frame {f}"
 
 
+@pytest.mark.parametrize("alpha_min", [0.25, 0.8])
+def test_restir_di_half_vector_copy_shift_on_gpu(api, alpha_min):
+    """USE_HALF_VECTOR_COPY_SHIFT (ReSTIR_DI/Params.hlsli:12) through the C-ABI: glossy lobes below alpha_min keep their half vector across temporal
+    and spatial reuse (Resampling.hlsli:130-317, PairwiseMIS.hlsli:37-214); radiance, reservoir planes (incl. the oct-encoded half vector and lobe bits)
+    and ray counters against the oracle, which is pinned on the reference's shaders compiled with the switch on (tests/test_ref_passes.py di_half_vector*)."""
+    from oracle import zro
+    sc = scene_io.make_synthetic_scene(num_tris=3000, num_emissive=1500, seed=11)
+    o = zro.OracleScene(sc, force_bvh=True)
+    w, h = 160, 96
+    prm = wire.default_params_di()
+    prm.flags |= wire.DI_HALF_VECTOR_COPY_SHIFT
+    prm.alpha_min = alpha_min
+    r = api.Renderer(sc, w, h, params=wire.default_params())
+    di = r.enable_direct(prm)
+    odi = zro.OracleRDI(o, w, h)
+    prev, shifted = None, 0
+    for f in range(1, 6):
+        cb = _frame(sc, w, h, f, cam_pos=(0.04 * max(0, f - 2), 0.01 * max(0, f - 2), -3.5))
+        if prev is not None:
+            cb["prev_view"], cb["prev_view_inv"], cb["prev_camera_jitter"] = prev["curr_view"], prev["curr_view_inv"], prev["curr_camera_jitter"]
+        prev = cb.copy()
+        di.read_counters(reset=True)
+        r.render_frame(cb)
+        want = odi.render(cb, prm)
+        assert np.array_equal(di.download().view(np.uint32), want.view(np.uint32)), f"frame {f}"
+        assert di.read_counters() == odi.counters
+        for nm, onm in (("di_A", "A"), ("di_B", "B"), ("di_target", "target")):
+            assert np.array_equal(di.download_plane(nm).view(np.uint8), odi.plane(onm).view(np.uint8)), f"frame {f}: DI plane {onm}"
+        shifted += int(((odi.plane("A").view(np.uint32).reshape(-1, 4)[:, 2] >> 21) & 1).sum())      # metadata (A.z >> 16) bit 5 = the reservoir carries a half vector
+    assert shifted > 0, "no reservoir used the half-vector shift: the case does not exercise it"
+
+
 def test_restir_gi_bit_exact(api, cornell_emissive, oracle_emissive):
     """K10 (ReSTIR GI) through the C-ABI, 5 frames, camera moving from frame 3: radiance, reservoir planes, ray counters."""
     from oracle import zro

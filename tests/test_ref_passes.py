@@ -75,7 +75,7 @@ def _zref():
 
 
 @pytest.mark.parametrize("case", ["k9_materials_rr", "rpt_cornell_moving", "rpt_sun_sky", "gi_materials_rr", "di_materials", "sdi_cornell_moving",
-                                  "rpt_moving_instance", "di_moving_instance", "rpt_two_spatial", "rpt_no_spatial"])
+                                  "rpt_moving_instance", "di_moving_instance", "rpt_two_spatial", "rpt_no_spatial", "di_half_vector", "di_half_vector_static"])
 def test_live_reference_passes_match_stored_outputs(case):
     """re-runs the reference's compiled shaders: guards the stored files against a stale build"""
     zref = _zref()
@@ -165,7 +165,8 @@ def test_hip_path_reproduces_reference_passes(case):
 
 # ------------------------------------------------------------------ the HIP stage functions, executed on the host, against the reference's outputs
 @pytest.mark.parametrize("case", ["rpt_cornell_moving", "rpt_moving_instance", "di_moving_instance", "sdi_moving_instance", "gi_cornell_moving", "rpt_sun_sky",
-                                  "rpt_moving_light", "di_moving_light", "rpt_two_spatial", "rpt_two_spatial_materials", "rpt_no_spatial", "rpt_two_spatial_sun_sky"])
+                                  "rpt_moving_light", "di_moving_light", "rpt_two_spatial", "rpt_two_spatial_materials", "rpt_no_spatial", "rpt_two_spatial_sun_sky",
+                                  "di_half_vector", "di_half_vector_static", "di_materials"])
 def test_hip_stage_functions_on_host_reproduce_reference_passes(case):
     """the product's device code (zr_stages.h, zr_rpt.h, zr_rdi.h, zr_sdi.h, zr_rgi.h) compiled for the host by tests/hostexec and run serially:
     catches a divergence from the reference's shaders without a GPU, incl. the dynamic-instance paths (previous BVH / mesh instances, MoveXk)"""

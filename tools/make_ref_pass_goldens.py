@@ -40,7 +40,7 @@ def make_ref(zref, sc, integ, prm, force_bvh):
         return zref.RefRestirPT(sc, RC.W, RC.H, ps, force_bvh)
     if integ == "gi":
         return zref.RefRestirGI(sc, RC.W, RC.H, ps, force_bvh)
-    return zref.RefDirect(sc, RC.W, RC.H, sky=(integ == "sdi"), presampling=ps, force_bvh=force_bvh)
+    return zref.RefDirect(sc, RC.W, RC.H, sky=(integ == "sdi"), presampling=ps, force_bvh=force_bvh, half_vec=(integ == "di" and bool(prm.flags & wire.DI_HALF_VECTOR_COPY_SHIFT)))
 
 
 def main():

@@ -99,6 +99,10 @@ CASES = {
     "gi_presampled": ("materials_lights", "gi", 3, dict(presample=(32, 128)), False),
     "gi_sun_sky": ("cornell", "gi", 3, {}, False),
     "di_cornell_moving": ("cornell_emissive", "di", 5, {}, True),
+    # (round 6) the reference's USE_HALF_VECTOR_COPY_SHIFT = 1 build of the emissive DI shaders (Params.hlsli:12; 0 in its tree): Alpha_min 0.8 / 0.6 (far above what a renderer would use: coverage) makes the metal (roughness
+    # 0.35), glossy (0.15 - 0.25) and coat lobes of the materials scene reuse by half-vector copy; moving camera (temporal Jacobians), spatial pairwise MIS
+    "di_half_vector": ("materials_lights", "di", 4, dict(flags_on=(1 << 11), alpha_min=0.8), False),      # (camera path: CB_KW below)
+    "di_half_vector_static": ("materials_lights", "di", 3, dict(flags_on=(1 << 11), alpha_min=0.6, m_max=(12, 20)), False),
     "di_materials": ("materials_lights", "di", 3, {}, False),
     "di_presampled": ("materials_lights", "di", 3, dict(presample=(32, 128)), False),
     "sdi_cornell_moving": ("cornell", "sdi", 5, {}, True),
@@ -125,7 +129,8 @@ CASES = {
 CB_EDIT = {"rpt_dof": dict(dof=1, lens_radius=0.05, focus_depth=4.0), "k9_textured_dof": dict(dof=1, lens_radius=0.05, focus_depth=3.0, camera_ray_uv_grads_scale=0.75)}
 _ACC = lambda f: dict(accumulate=1, camera_static=1 if f > 1 else 0, num_frames_static=f - 1)      # noqa: E731
 # (the DI pass accumulates Le_SkyWithSunDisk at miss pixels, ReSTIR_DI_Temporal.hlsl:276-281, and an emissive-only scene binds no sky-view LUT: its camera stands inside the box)
-CB_KW = {"rpt_accumulate": _ACC, "di_accumulate": lambda f: dict(_ACC(f), cam_pos=(0.0, 1.0, -0.9))}      # per-case, per-frame arguments of make_frame_constants
+CB_KW = {"rpt_accumulate": _ACC, "di_accumulate": lambda f: dict(_ACC(f), cam_pos=(0.0, 1.0, -0.9)),
+         "di_half_vector": lambda f: dict(cam_pos=(0.04 * max(0, f - 2), 0.01 * max(0, f - 2), -3.5))}      # per-case, per-frame arguments of make_frame_constants
 ANIMATED = {"rpt_moving_instance", "di_moving_instance", "sdi_moving_instance", "rpt_moving_light", "di_moving_light", "gi_moving_instance", "gi_moving_light"}
 MOVING_LIGHT = {"rpt_moving_light", "di_moving_light", "gi_moving_light"}
 RPT_PLANES = ("A", "B", "C", "D", "E", "F", "G", "neighbor", "map_ctn", "map_ntc")      # + the K12 thread maps of the last frame

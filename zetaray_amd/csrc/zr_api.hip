@@ -2261,20 +2261,22 @@ static int RenderDirectEmissive(zr_pass* p, hipStream_t s, const zr_frame_consta
     prm.doTemporal = (p->temporalValid && (ip.flags & ZR_IND_TEMPORAL_RESAMPLE) && gb->numRendered >= 2) ? 1u : 0u;
     prm.doSpatial = (prm.doTemporal && (ip.flags & ZR_IND_SPATIAL_RESAMPLE)) ? 1u : 0u;
     prm.writeReservoirs = (prm.doTemporal || !p->temporalValid) ? 1u : 0u;
+    const bool hvs = (ip.flags & ZR_DI_HALF_VECTOR_COPY_SHIFT) != 0;      // USE_HALF_VECTOR_COPY_SHIFT (ReSTIR_DI/Params.hlsli:12): its own kernel instantiations
+    prm.halfVec = hvs ? 1u : 0u; prm.alpha_min = ip.alpha_min;
     const uint32_t tilesX = (F.ow + 15) / 16, tilesY = (F.oh + 15) / 16;
     const dim3 grid(tilesX * tilesY), block(kBlock);
     const bool plainDi = PlainClass(sc, gb);
     if (stages & ZR_STAGE_TEMPORAL)
     {
         TimerBegin(p, s, "rdi_temporal");
-        hipLaunchKernelGGL(plainDi ? k_rdi_temporal<true> : k_rdi_temporal<false>, dim3(grid.x * (256 / kDiBlock)), dim3(kDiBlock), 0, s, F, *cb, tilesX, p->counters.p + 2 * 8);
+        hipLaunchKernelGGL(hvs ? (plainDi ? k_rdi_temporal<true, true> : k_rdi_temporal<false, true>) : (plainDi ? k_rdi_temporal<true, false> : k_rdi_temporal<false, false>), dim3(grid.x * (256 / kDiBlock)), dim3(kDiBlock), 0, s, F, *cb, tilesX, p->counters.p + 2 * 8);
         TimerEnd(p, s);
     }
     if (!(stages & ZR_STAGE_SPATIAL)) { HIP_TRY(hipGetLastError()); return ZR_OK; }
     if (prm.doSpatial)
     {
         TimerBegin(p, s, "rdi_spatial");
-        hipLaunchKernelGGL(plainDi ? k_rdi_spatial<true> : k_rdi_spatial<false>, dim3(grid.x * (256 / kDiBlock)), dim3(kDiBlock), 0, s, F, *cb, tilesX, p->counters.p + 2 * 9);
+        hipLaunchKernelGGL(hvs ? (plainDi ? k_rdi_spatial<true, true> : k_rdi_spatial<false, true>) : (plainDi ? k_rdi_spatial<true, false> : k_rdi_spatial<false, false>), dim3(grid.x * (256 / kDiBlock)), dim3(kDiBlock), 0, s, F, *cb, tilesX, p->counters.p + 2 * 9);
         TimerEnd(p, s);
     }
     HIP_TRY(hipGetLastError());

@@ -38,10 +38,12 @@ __global__ void __launch_bounds__(kSdiBlock) ZR_WAVES_SDI_S k_sdi_spatial(sdi::S
 
 // ------------------------------------------------------------------------------------------------ ReSTIR DI kernels
 // K5: initial candidates + temporal reuse, one thread per pixel (8x8 quadrant per wave, like the reference's thread group)
-template<bool PLAIN>
+// HVS: USE_HALF_VECTOR_COPY_SHIFT (ReSTIR_DI/Params.hlsli:12) as a compile-time fact, so the default build keeps the code it had before the shift existed
+template<bool PLAIN, bool HVS>
 __global__ void __launch_bounds__(kDiBlock) ZR_WAVES_RDI_T k_rdi_temporal(rdi::DiFrame F, zr_frame_constants g, uint32_t tilesX, unsigned long long* counters)
 {
     SetMaterialClassDi(F, PLAIN);
+    F.prm.halfVec = HVS ? 1u : 0u;
     uint32_t x, y; PixelOfThreadB<kDiBlock>(tilesX, F.ox0, F.oy0, &x, &y);
     ZR_TRAV_STACK_B(stack, kDiBlock);
     uint32_t cnt[2] = {0u, 0u};
@@ -49,10 +51,11 @@ __global__ void __launch_bounds__(kDiBlock) ZR_WAVES_RDI_T k_rdi_temporal(rdi::D
     FlushRayCounters(counters, cnt);
 }
 // K6: spatial reuse with pairwise MIS; WaveActiveSum(disoccluded) = popcount of a ballot over the 8x8 group
-template<bool PLAIN>
+template<bool PLAIN, bool HVS>
 __global__ void __launch_bounds__(kDiBlock) ZR_WAVES_RDI_S k_rdi_spatial(rdi::DiFrame F, zr_frame_constants g, uint32_t tilesX, unsigned long long* counters)
 {
     SetMaterialClassDi(F, PLAIN);
+    F.prm.halfVec = HVS ? 1u : 0u;
     uint32_t x, y; PixelOfThreadB<kDiBlock>(tilesX, F.ox0, F.oy0, &x, &y);
     ZR_TRAV_STACK_B(stack, kDiBlock);
     uint32_t cnt[2] = {0u, 0u};
@@ -109,5 +112,6 @@ __global__ void k_rgi_tex(rgi::GiFrame F, zr_frame_constants g, uint32_t tilesX,
 #define ZR_DI_ARGS(Frame) (Frame, zr_frame_constants, uint32_t, unsigned long long*)
 #define ZR_DI_GROUP(X, PLAIN) \
     X __global__ void k_sdi_temporal<PLAIN> ZR_DI_ARGS(sdi::SkyFrame); X __global__ void k_sdi_spatial<PLAIN> ZR_DI_ARGS(sdi::SkyFrame); \
-    X __global__ void k_rdi_temporal<PLAIN> ZR_DI_ARGS(rdi::DiFrame); X __global__ void k_rdi_spatial<PLAIN> ZR_DI_ARGS(rdi::DiFrame); \
+    X __global__ void k_rdi_temporal<PLAIN, false> ZR_DI_ARGS(rdi::DiFrame); X __global__ void k_rdi_spatial<PLAIN, false> ZR_DI_ARGS(rdi::DiFrame); \
+    X __global__ void k_rdi_temporal<PLAIN, true> ZR_DI_ARGS(rdi::DiFrame); X __global__ void k_rdi_spatial<PLAIN, true> ZR_DI_ARGS(rdi::DiFrame); \
     X __global__ void k_rgi<PLAIN> ZR_DI_ARGS(rgi::GiFrame);

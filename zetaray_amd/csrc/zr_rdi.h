@@ -1,5 +1,6 @@
-// zr_rdi.h -- per-pixel stage functions of ReSTIR DI for emissive lights (K5 temporal, K6 spatial),
-// USE_HALF_VECTOR_COPY_SHIFT == 0.
+// zr_rdi.h -- per-pixel stage functions of ReSTIR DI for emissive lights (K5 temporal, K6 spatial).  The reference's compile-time switch
+// USE_HALF_VECTOR_COPY_SHIFT (Params.hlsli:12, 0 in its tree) is DiParams::halfVec here: a template constant of the kernels (zr_kernels_di.h HVS), selected by
+// ZR_DI_HALF_VECTOR_COPY_SHIFT; the permutation without it folds every line of the shift away.
 //
 // Reference (Source/ZetaRenderPass/DirectLighting/Emissive/): ReSTIR_DI_Temporal.hlsl:29-390, ReSTIR_DI_Spatial.hlsl:24-192,
 // Resampling.hlsli:10-521, PairwiseMIS.hlsli:11-231, Reservoir.hlsli:11-226, Util.hlsli:11-119, Params.hlsli;
@@ -20,7 +21,10 @@ using rpt::CurrCamera; using rpt::PrevCamera; using rpt::PixelSurface; using rpt
 #define ZR_PREP_DI 1
 #endif
 static constexpr uint32_t kPrepDi = ZR_PREP_DI;
-using rpt::Globals; using rpt::VisibilitySegmentApprox; using rpt::IsSpecular;
+using rpt::Globals; using rpt::VisibilitySegmentApprox; using rpt::IsSpecular; using rpt::IsLobeValid; using rpt::LobeAlpha;
+// Math.hlsli:308-322
+ZR_HD V3 WorldToTangentFrame(V3 normal, V3 w) { ONB o = BuildONB(normal); return v3(dot(o.b1, w), dot(o.b2, w), dot(normal, w)); }
+ZR_HD V3 FromTangentFrameToWorld(V3 normal, V3 wl) { ONB o = BuildONB(normal); return wl.x * o.b1 + wl.y * o.b2 + wl.z * normal; }
 
 static constexpr int kNumLightCandidates = 3;
 static constexpr int kMinSpatial = 1, kExtraSpatial = 1, kMaxSpatial = 4;
@@ -33,20 +37,59 @@ struct Reservoir
 {
     float w_sum, W; V3 le; uint32_t lightIdx; V2 bary; uint32_t M;
     V3 target; uint32_t lightID; V3 lightPos, lightNormal; bool doubleSided;
+    // half-vector copy shift (Reservoir.hlsli:56-119, 203-212): the selected sample came from a lobe narrower than alpha_min; it is reused by copying its half vector
+    // in the shading frame (wh_local) and re-tracing the reflected ray; partialJacobian = |wh . wo| where it was drawn; lobe = LOBE_* (LOBE_ALL for light samples)
+    bool halfVectorCopyShift; uint32_t lobe; V3 wh_local; float partialJacobian;
     ZR_HDM bool Update(float weight, V3 le_, uint32_t lightIdx_, V2 bary_, Rng& rng)
     {
         if (zr_isnan(weight)) return false;
         M += 1;
         if (weight == 0) return false;
         w_sum += weight;
-        if (rng.Uniform() < (weight / w_sum)) { le = le_; lightIdx = lightIdx_; bary = bary_; return true; }
+        if (rng.Uniform() < (weight / w_sum)) { le = le_; lightIdx = lightIdx_; bary = bary_; halfVectorCopyShift = false; lobe = LOBE_ALL; return true; }
         return false;
     }
-    ZR_HDM void Write(const DiPlanes& p, size_t i, uint32_t M_max) const
+    // a BSDF-sampled candidate (Reservoir.hlsli:56-91)
+    ZR_HDM bool Update(float weight, bool halfVecShift, V3 wi, V3 wo, V3 normal, uint32_t lb, V3 le_, uint32_t lightIdx_, V2 bary_, Rng& rng)
+    {
+        if (zr_isnan(weight)) return false;
+        M += 1;
+        if (weight == 0) return false;
+        w_sum += weight;
+        if (rng.Uniform() < (weight / w_sum))
+        {
+            le = le_; lightIdx = lightIdx_; bary = bary_; halfVectorCopyShift = halfVecShift; lobe = lb;
+            if (halfVecShift)
+            {
+                V3 wh = normalize(wo + wi);
+                wh_local = WorldToTangentFrame(normal, wh);
+                partialJacobian = zr_abs(dot(wh, wo));
+            }
+            return true;
+        }
+        return false;
+    }
+    // a reused sample (Reservoir.hlsli:93-119)
+    ZR_HDM bool Update(float weight, bool halfVecShift, V3 wh, float whdotwo, uint32_t lb, V3 le_, uint32_t lightIdx_, V2 bary_, Rng& rng)
+    {
+        if (zr_isnan(weight)) return false;
+        M += 1;
+        if (weight == 0) return false;
+        w_sum += weight;
+        if (rng.Uniform() < (weight / w_sum))
+        { le = le_; lightIdx = lightIdx_; bary = bary_; halfVectorCopyShift = halfVecShift; lobe = lb; wh_local = wh; partialJacobian = whdotwo; return true; }
+        return false;
+    }
+    ZR_HDM void Write(const DiPlanes& p, size_t i, uint32_t M_max, bool halfVec = false) const
     {
         uint32_t lx = zr_f32_to_f16(le.x), ly = zr_f32_to_f16(le.y), lz = zr_f32_to_f16(le.z);
         uint32_t M_capped = (M & 0xffffu) < M_max ? (M & 0xffffu) : M_max;
         uint32_t bx = FloatToUNorm16(bary.x), by = FloatToUNorm16(bary.y);
+        if (halfVec)
+        {   // Reservoir.hlsli:177-184: metadata bit 5 = the flag, bits 6..8 = the lobe; the oct-encoded half vector takes the barycentrics' place
+            M_capped |= ((halfVectorCopyShift ? 1u : 0u) << 5) | ((lobe > LOBE_ALL ? (uint32_t)LOBE_ALL : lobe) << 6);
+            if (halfVectorCopyShift) { const V2 e = EncodeUnitVector(wh_local); bx = FloatToUNorm16(e.x); by = FloatToUNorm16(e.y); }
+        }
         U4 a; a.x = (by << 16) | bx; a.y = (ly << 16) | lx; a.z = (M_capped << 16) | lz; a.w = lightIdx;
         p.A[i] = a;
         p.B[2 * i] = w_sum; p.B[2 * i + 1] = W;
@@ -56,9 +99,10 @@ ZR_HD Reservoir InitReservoir()
 {
     Reservoir r; r.le = v3(0.0f); r.M = 0; r.w_sum = 0; r.W = 0; r.lightIdx = 0xffffffffu; r.bary = v2(0, 0);
     r.target = v3(0.0f); r.lightID = 0xffffffffu; r.lightPos = v3(0.0f); r.lightNormal = v3(0.0f); r.doubleSided = false;
+    r.halfVectorCopyShift = false; r.lobe = LOBE_ALL; r.wh_local = v3(0.0f); r.partialJacobian = 1;      // (wh_local: not initialised by the reference's Init(); only read behind the flag)
     return r;
 }
-ZR_HD Reservoir LoadReservoir(const DiPlanes& p, size_t i)
+ZR_HD Reservoir LoadReservoir(const DiPlanes& p, size_t i, bool halfVec = false)
 {
     const U4 a = p.A[i];
     Reservoir r = InitReservoir();
@@ -67,6 +111,14 @@ ZR_HD Reservoir LoadReservoir(const DiPlanes& p, size_t i)
     r.le = v3(zr_f16_to_f32((uint16_t)(a.y & 0xffff)), zr_f16_to_f32((uint16_t)(a.y >> 16)), zr_f16_to_f32((uint16_t)(a.z & 0xffff)));
     r.lightIdx = a.w;
     r.bary = v2(zr_div65535((float)(a.x & 0xffff)), zr_div65535((float)(a.x >> 16)));
+    if (halfVec)
+    {   // Reservoir.hlsli:156-160: A.x is read both as the barycentrics and as the oct-encoded half vector
+        const uint32_t metadata = a.z >> 16;
+        r.halfVectorCopyShift = ((metadata >> 5) & 0x1u) != 0;
+        const uint32_t lv = (metadata >> 6) & 0x7u;
+        r.lobe = lv > (uint32_t)LOBE_ALL ? (uint32_t)LOBE_ALL : lv;
+        r.wh_local = DecodeOct32u(a.x);
+    }
     return r;
 }
 
@@ -135,7 +187,7 @@ ZR_HD BsdfSample SampleBSDF_NoDiffuseRng(const RhoView& rho, V3 n, const Surface
     return SampleBSDF_NoDiffuse(rho, n, s, u_c, u_g, u0, u1);
 }
 
-struct DiParams { uint32_t flags, M_max, numSampleSets, accumulate, doTemporal, doSpatial, writeReservoirs; };
+struct DiParams { uint32_t flags, M_max, numSampleSets, accumulate, doTemporal, doSpatial, writeReservoirs, halfVec; float alpha_min; };
 
 struct DiFrame
 {
@@ -144,6 +196,37 @@ struct DiFrame
     uint32_t ox0, oy0, ow, oh;
     ZR_HDM bool Owns(uint32_t x, uint32_t y) const { return x >= ox0 && y >= oy0 && x < ox0 + ow && y < oy0 + oh; }
 };
+
+// Reservoir.hlsli:216-225
+ZR_HD bool IsShiftInvertible(const DiParams& prm, const Reservoir& r_base, const Surface& surface_offset)
+{
+    if (!prm.halfVec) return true;
+    return !r_base.halfVectorCopyShift || (IsLobeValid(surface_offset, r_base.lobe) && (LobeAlpha(surface_offset, r_base.lobe) <= prm.alpha_min));
+}
+// the half-vector copy shift's offset path (Resampling.hlsli:146-179, 220-252; PairwiseMIS.hlsli:72-102, 140-168): the copied half vector's reflection is traced from the
+// offset surface; target = Le * dwdA of the light it lands on (0 when it lands on the light's back).  false: nothing emissive was hit.  `surface` gets wi = the traced
+// direction whenever a light was hit.
+ZR_HD bool HalfVectorOffsetTarget(const Globals& gl, V3 pos, V3 normal, Surface& surface, V3 wh, V3& target)
+{
+    const SceneView& sc = *gl.sc;
+    const V3 wi_offset = reflect(-surface.wo, wh);
+    BSDFHitInfo hitInfo = FindClosestHit(gl, pos, normal, wi_offset, surface.Transmissive());
+    if (!hitInfo.hit) return false;
+    const zr_emissive_triangle em = sc.emissives[hitInfo.emissiveTriIdx];
+    const V3 le = EmLe(sc, em, hitInfo.bary);
+    const V3 vtx0 = v3p(em.vtx0), vtx1 = EmV1(em), vtx2 = EmV2(em);
+    V3 lightNormal = cross(vtx1 - vtx0, vtx2 - vtx0);
+    float twoArea = length(lightNormal);
+    lightNormal = dot(lightNormal, lightNormal) == 0 ? v3(0.0f) : lightNormal / twoArea;
+    lightNormal = EmDoubleSided(em) && dot(-wi_offset, lightNormal) < 0 ? -lightNormal : lightNormal;
+    if (dot(-wi_offset, lightNormal) > 0)
+    {
+        float dwdA = zr_saturate(dot(lightNormal, -wi_offset)) / (hitInfo.t * hitInfo.t);
+        target = le * dwdA;
+    }
+    surface.SetWi(wi_offset, normal);
+    return true;
+}
 
 // ReSTIR_DI_Temporal.hlsl:29-203
 ZR_HD Reservoir RIS_InitialCandidates(const Globals& gl, const zr_frame_constants& g, const DiParams& prm, V3 pos, V3 normal, Surface surface,
@@ -157,6 +240,7 @@ ZR_HD Reservoir RIS_InitialCandidates(const Globals& gl, const zr_frame_constant
         BsdfSample bs = SampleBSDF_NoDiffuseRng(sc.rho, normal, surface, rng);
         V3 wi = bs.wi;
         float pdf_w = bs.pdf;
+        const bool useHalfVecShift = prm.halfVec ? (LobeAlpha(surface, bs.lobe) <= prm.alpha_min) : false;      // ReSTIR_DI_Temporal.hlsl:45-50
         BSDFHitInfo hitInfo = FindClosestHit(gl, pos, normal, wi, surface.Transmissive());
         float w_b = 0; V3 le = v3(0.0f), lightNormal = v3(0.0f), target = v3(0.0f); uint32_t emissiveID = 0xffffffffu; bool doubleSided = false;
         if (hitInfo.hit)
@@ -183,7 +267,8 @@ ZR_HD Reservoir RIS_InitialCandidates(const Globals& gl, const zr_frame_constant
                 w_b = m_i * Luminance(target);
             }
         }
-        if (r.Update(w_b, le, hitInfo.emissiveTriIdx, hitInfo.bary, rng))
+        if (prm.halfVec ? r.Update(w_b, useHalfVecShift, wi, surface.wo, normal, bs.lobe, le, hitInfo.emissiveTriIdx, hitInfo.bary, rng)
+                        : r.Update(w_b, le, hitInfo.emissiveTriIdx, hitInfo.bary, rng))
         { r.target = target; r.lightID = emissiveID; r.lightPos = hitInfo.lightPos; r.lightNormal = lightNormal; r.doubleSided = doubleSided; }
     }
     for (int s_l = 0; s_l < numLightSamples; s_l++)
@@ -267,37 +352,63 @@ ZR_HD TemporalCandidate FindTemporalCandidate(const DiFrame& F, const zr_frame_c
 }
 
 // Resampling.hlsli:138-285 (no half-vector shift)
-ZR_HD float OffsetPathTarget_CtT(const Globals& gl, const Reservoir& r_curr, const TemporalCandidate& candidate)
+ZR_HD float OffsetPathTarget_CtT(const Globals& gl, const DiParams& prm, const Reservoir& r_curr, const TemporalCandidate& candidate, V3 wh)
 {
     Surface surface = candidate.surface;
-    V3 wi = r_curr.lightPos - candidate.pos;
+    if (!IsShiftInvertible(prm, r_curr, surface)) return 0;
+    V3 target = v3(0.0f);
+    V3 wi = v3(0.0f);
+    float t = 0;
+    if (prm.halfVec && r_curr.halfVectorCopyShift)
+    {
+        Globals gp = gl; if (gl.scPrev) gp.sc = gl.scPrev;       // g_bvh_prev
+        if (!HalfVectorOffsetTarget(gp, candidate.pos, candidate.normal, surface, wh, target)) return 0;
+    }
+    else
+    {
+    wi = r_curr.lightPos - candidate.pos;
     const bool isZero = dot(wi, wi) == 0;
-    float t = isZero ? 0 : length(wi);
+    t = isZero ? 0 : length(wi);
     wi = isZero ? wi : wi / t;
     surface.SetWi(wi, candidate.normal);
     V3 ln = r_curr.lightNormal;
     if (r_curr.doubleSided && dot(-wi, ln) < 0) ln = -ln;
     float cosThetaPrime = zr_saturate(dot(ln, -wi));
     const float dwdA = isZero ? 0 : cosThetaPrime / (t * t);
-    V3 target = r_curr.le * dwdA;
+    target = r_curr.le * dwdA;
+    }
     target = target * Unified(gl.sc->rho, surface).f;
     float lum = Luminance(target);
-    if (lum > 0)
+    if (!(prm.halfVec && r_curr.halfVectorCopyShift) && lum > 0)
     {
         Globals gp = gl; if (gl.scPrev) gp.sc = gl.scPrev;       // g_bvh_prev (Resampling.hlsli:134-200)
         lum *= VisibilitySegmentApprox(gp, candidate.pos, wi, t, candidate.normal, r_curr.lightID, surface.Transmissive()) ? 1.0f : 0.0f;
     }
     return lum;
 }
-ZR_HD V3 OffsetPathTarget_TtC(const Globals& gl, const Reservoir& r_prev, V3 pos, V3 normal, Surface surface)
+ZR_HD V3 OffsetPathTarget_TtC(const Globals& gl, const DiParams& prm, const Reservoir& r_prev, V3 pos, V3 normal, Surface surface, V3 wh)
 {
-    EmissiveData e = InitEmissiveData(*gl.sc, r_prev.lightIdx, r_prev.bary);
-    SetSurfacePos(e, pos);
-    float dwdA_ = dWdA(e);
-    surface.SetWi(e.wi, normal);
-    V3 target = r_prev.le * dwdA_;
+    if (!IsShiftInvertible(prm, r_prev, surface)) return v3(0.0f);
+    V3 target = v3(0.0f);
+    V3 wi_offset = v3(0.0f);
+    float t_offset = 0;
+    uint32_t lightID = 0xffffffffu;
+    if (prm.halfVec && r_prev.halfVectorCopyShift)
+    {
+        if (!HalfVectorOffsetTarget(gl, pos, normal, surface, wh, target)) return v3(0.0f);
+    }
+    else
+    {
+        EmissiveData e = InitEmissiveData(*gl.sc, r_prev.lightIdx, r_prev.bary);
+        SetSurfacePos(e, pos);
+        wi_offset = e.wi; t_offset = e.t; lightID = e.ID;
+        float dwdA_ = dWdA(e);
+        surface.SetWi(e.wi, normal);
+        target = r_prev.le * dwdA_;
+    }
     target = target * Unified(gl.sc->rho, surface).f;
-    if (dot(target, target) > 0) target = target * (VisibilitySegmentApprox(gl, pos, e.wi, e.t, normal, e.ID, surface.Transmissive()) ? 1.0f : 0.0f);
+    if (!(prm.halfVec && r_prev.halfVectorCopyShift) && dot(target, target) > 0)
+        target = target * (VisibilitySegmentApprox(gl, pos, wi_offset, t_offset, normal, lightID, surface.Transmissive()) ? 1.0f : 0.0f);
     return target;
 }
 
@@ -305,28 +416,48 @@ ZR_HD V3 OffsetPathTarget_TtC(const Globals& gl, const Reservoir& r_prev, V3 pos
 ZR_HD void TemporalResample1(const Globals& gl, const DiFrame& F, V3 pos, V3 normal, const Surface& surface, const TemporalCandidate& candidate,
     Reservoir& r_curr, Rng& rng)
 {
-    Reservoir r_prev = LoadReservoir(F.prev, Pix(F.gb, (uint32_t)candidate.px, (uint32_t)candidate.py));
+    const DiParams& prm = F.prm;
+    Reservoir r_prev = LoadReservoir(F.prev, Pix(F.gb, (uint32_t)candidate.px, (uint32_t)candidate.py), prm.halfVec != 0);
     const uint32_t newM = (r_curr.M + r_prev.M) & 0xffffu;
     if (r_curr.w_sum != 0)
     {
-        float targetLum_prev = OffsetPathTarget_CtT(gl, r_curr, candidate);
+        float jacobian = 1; V3 wh_prev = v3(0.0f);
+        if (prm.halfVec)
+        {
+            wh_prev = FromTangentFrameToWorld(candidate.normal, r_curr.wh_local);
+            float whdotwo = zr_abs(dot(candidate.surface.wo, wh_prev));
+            jacobian = r_curr.partialJacobian == 0 ? 0 : whdotwo / r_curr.partialJacobian;
+            jacobian = r_curr.halfVectorCopyShift ? jacobian : 1;
+        }
+        float targetLum_prev = OffsetPathTarget_CtT(gl, prm, r_curr, candidate, wh_prev);
         const float numerator = (float)r_curr.M * Luminance(r_curr.target);
-        const float denom = numerator + (float)r_prev.M * targetLum_prev * 1.0f;
+        const float denom = numerator + (float)r_prev.M * targetLum_prev * jacobian;
         const float m_curr = denom > 0 ? numerator / denom : 0;
         r_curr.w_sum *= m_curr;
     }
     if (r_prev.lightIdx != 0xffffffffu)
     {
-        const V3 target_curr = OffsetPathTarget_TtC(gl, r_prev, pos, normal, surface);
+        float jacobian = 1, whdotwo_curr = 0; V3 wh_curr = v3(0.0f);
+        if (prm.halfVec)
+        {
+            wh_curr = FromTangentFrameToWorld(normal, r_prev.wh_local);
+            V3 wh_prev = FromTangentFrameToWorld(candidate.normal, r_prev.wh_local);
+            float whdotwo_prev = zr_abs(dot(candidate.surface.wo, wh_prev));
+            whdotwo_curr = zr_abs(dot(surface.wo, wh_curr));
+            jacobian = whdotwo_prev > 0 ? whdotwo_curr / whdotwo_prev : 0;
+            jacobian = r_prev.halfVectorCopyShift ? jacobian : 1;
+        }
+        const V3 target_curr = OffsetPathTarget_TtC(gl, prm, r_prev, pos, normal, surface, wh_curr);
         const float targetLum_curr = Luminance(target_curr);
         if (targetLum_curr > 0)
         {
             const float targetLum_prev = r_prev.W > 0 ? r_prev.w_sum / r_prev.W : 0;
             const float numerator = (float)r_prev.M * targetLum_prev;
-            const float denom = numerator / 1.0f + (float)r_curr.M * targetLum_curr;
+            const float denom = numerator / jacobian + (float)r_curr.M * targetLum_curr;
             const float m_prev = denom > 0 ? numerator / denom : 0;
             const float w_prev = m_prev * targetLum_curr * r_prev.W;
-            if (r_curr.Update(w_prev, r_prev.le, r_prev.lightIdx, r_prev.bary, rng)) r_curr.target = target_curr;
+            if (prm.halfVec ? r_curr.Update(w_prev, r_prev.halfVectorCopyShift, r_prev.wh_local, whdotwo_curr, r_prev.lobe, r_prev.le, r_prev.lightIdx, r_prev.bary, rng)
+                            : r_curr.Update(w_prev, r_prev.le, r_prev.lightIdx, r_prev.bary, rng)) r_curr.target = target_curr;
         }
     }
     float targetLum = Luminance(r_curr.target);
@@ -417,7 +548,7 @@ ZR_HD void TemporalPixel(const DiFrame& F, const zr_frame_constants& g, uint32_t
             F.target[px] = f4(zr_round_f16(r.target.x), zr_round_f16(r.target.y), zr_round_f16(r.target.z), 0.0f);
         }
     }
-    if (prm.writeReservoirs) r.Write(F.cur, px, prm.M_max);
+    if (prm.writeReservoirs) r.Write(F.cur, px, prm.M_max, prm.halfVec != 0);
     if (!prm.doSpatial || !prm.doTemporal) WriteFinal(g, F.finalRGBA, px, r.target * r.W);
 }
 
@@ -437,7 +568,7 @@ ZR_HD void Update_m_c(PairwiseMIS& p, const Reservoir& r_c, const Reservoir& r_i
     const float denom = numerator + ((float)r_c.M / (float)p.k) * p_c_y_c;
     p.m_c += 1 - (numerator / denom);
 }
-ZR_HD void Stream(PairwiseMIS& p, const Globals& gl, const Reservoir& r_c, V3 pos_c, V3 normal_c, Surface surface_c, const Reservoir& r_i, V3 pos_i,
+ZR_HD void Stream(PairwiseMIS& p, const Globals& gl, const DiParams& prm, const Reservoir& r_c, V3 pos_c, V3 normal_c, Surface surface_c, const Reservoir& r_i, V3 pos_i,
     V3 normal_i, Surface surface_i, Rng& rng)
 {
     const RhoView& rho = gl.sc->rho;
@@ -445,6 +576,22 @@ ZR_HD void Stream(PairwiseMIS& p, const Globals& gl, const Reservoir& r_c, V3 po
     float m_i = 0;
     if (r_i.lightIdx != 0xffffffffu)
     {
+        float jacobian_i_to_c = 0;
+        if (IsShiftInvertible(prm, r_i, surface_c))
+        {
+            jacobian_i_to_c = 1; V3 wh_c = v3(0.0f);
+            if (prm.halfVec)
+            {
+                wh_c = FromTangentFrameToWorld(normal_c, r_i.wh_local);
+                V3 wh_i = FromTangentFrameToWorld(normal_i, r_i.wh_local);
+                float whdotwo_i = zr_abs(dot(surface_i.wo, wh_i));
+                float whdotwo_c = zr_abs(dot(surface_c.wo, wh_c));
+                jacobian_i_to_c = whdotwo_i > 0 ? whdotwo_c / whdotwo_i : 0;
+                jacobian_i_to_c = r_c.halfVectorCopyShift ? jacobian_i_to_c : 1;      // (sic: r_c, PairwiseMIS.hlsli:70)
+            }
+            if (prm.halfVec && r_i.halfVectorCopyShift) (void)HalfVectorOffsetTarget(gl, pos_c, normal_c, surface_c, wh_c, target_c_y_i);
+            else
+            {
         EmissiveData e = InitEmissiveData(*gl.sc, r_i.lightIdx, r_i.bary);
         SetSurfacePos(e, pos_c);
         float dwdA_ = dWdA(e);
@@ -452,13 +599,32 @@ ZR_HD void Stream(PairwiseMIS& p, const Globals& gl, const Reservoir& r_c, V3 po
         target_c_y_i = r_i.le * dwdA_;
         if (dot(target_c_y_i, target_c_y_i) > 0)
             target_c_y_i = target_c_y_i * (VisibilitySegmentApprox(gl, pos_c, e.wi, e.t, normal_c, e.ID, surface_c.Transmissive()) ? 1.0f : 0.0f);
+            }
         target_c_y_i = target_c_y_i * Unified(rho, surface_c).f;
-        m_i = Compute_m_i(p, r_c, r_i, Luminance(target_c_y_i), 1.0f);
+        }
+        m_i = Compute_m_i(p, r_c, r_i, Luminance(target_c_y_i), jacobian_i_to_c);
     }
     float jacobian_c_to_i = 0;
     if (r_c.lightIdx != 0xffffffffu)
     {
-        jacobian_c_to_i = 1;
+        bool invertible = IsShiftInvertible(prm, r_c, surface_i);
+        V3 wh_i = v3(0.0f);
+        if (invertible)
+        {
+            jacobian_c_to_i = 1;
+            if (prm.halfVec)
+            {
+                wh_i = FromTangentFrameToWorld(normal_i, r_c.wh_local);
+                V3 wh_c = FromTangentFrameToWorld(normal_c, r_c.wh_local);
+                float whdotwo_i = zr_abs(dot(surface_i.wo, wh_i));
+                float whdotwo_c = zr_abs(dot(surface_c.wo, wh_c));
+                jacobian_c_to_i = whdotwo_c == 0 ? 0 : whdotwo_i / whdotwo_c;
+                jacobian_c_to_i = r_c.halfVectorCopyShift ? jacobian_c_to_i : 1;
+            }
+        }
+        if (invertible && prm.halfVec && r_i.halfVectorCopyShift) (void)HalfVectorOffsetTarget(gl, pos_i, normal_i, surface_i, wh_i, target_i_y_c);      // (sic: r_i, PairwiseMIS.hlsli:141)
+        else if (invertible)
+        {
         V3 wi_i = r_c.lightPos - pos_i;
         const bool isZero = dot(wi_i, wi_i) == 0;
         float t_i = isZero ? 0 : length(wi_i);
@@ -470,20 +636,23 @@ ZR_HD void Stream(PairwiseMIS& p, const Globals& gl, const Reservoir& r_c, V3 po
         target_i_y_c = r_c.le * dwdA_;
         if (dot(target_i_y_c, target_i_y_c) > 0)
             target_i_y_c = target_i_y_c * (VisibilitySegmentApprox(gl, pos_i, wi_i, t_i, normal_i, r_c.lightID, surface_i.Transmissive()) ? 1.0f : 0.0f);
+        }
         target_i_y_c = target_i_y_c * Unified(rho, surface_i).f;
     }
     Update_m_c(p, r_c, r_i, Luminance(target_i_y_c), jacobian_c_to_i);
     if (r_i.lightIdx != 0xffffffffu)
     {
         const float w_i = m_i * Luminance(target_c_y_i) * r_i.W;
-        if (p.r_s.Update(w_i, r_i.le, r_i.lightIdx, r_i.bary, rng)) p.r_s.target = target_c_y_i;
+        if (prm.halfVec ? p.r_s.Update(w_i, r_i.halfVectorCopyShift, r_i.wh_local, 0.0f /*unused*/, r_i.lobe, r_i.le, r_i.lightIdx, r_i.bary, rng)
+                        : p.r_s.Update(w_i, r_i.le, r_i.lightIdx, r_i.bary, rng)) p.r_s.target = target_c_y_i;
     }
     p.M_s += r_i.M;
 }
-ZR_HD void End(PairwiseMIS& p, const Reservoir& r_c, Rng& rng)
+ZR_HD void End(PairwiseMIS& p, const DiParams& prm, const Reservoir& r_c, Rng& rng)
 {
     const float w_c = p.m_c * r_c.w_sum;
-    if (p.r_s.Update(w_c, r_c.le, r_c.lightIdx, r_c.bary, rng)) p.r_s.target = r_c.target;
+    if (prm.halfVec ? p.r_s.Update(w_c, r_c.halfVectorCopyShift, r_c.wh_local, 0.0f /*unused*/, r_c.lobe, r_c.le, r_c.lightIdx, r_c.bary, rng)
+                    : p.r_s.Update(w_c, r_c.le, r_c.lightIdx, r_c.bary, rng)) p.r_s.target = r_c.target;
     p.r_s.M = p.M_s & 0xffffu;
     const float targetLum = Luminance(p.r_s.target);
     p.r_s.W = targetLum > 0 ? p.r_s.w_sum / (targetLum * (float)(1 + p.k)) : 0;
@@ -510,7 +679,7 @@ ZR_HD void SpatialPhase0(const DiFrame& F, const zr_frame_constants& g, uint32_t
     const Camera cam = CurrCamera(g);
     a.ps = LoadPixelSurface(F.gb, cam, x, y, g.frame_num, a.px);
     if (kPrepDi) PrepareWo(F.sc.rho, a.ps.surface, kPrepDi);      // ... once per spatial neighbour
-    Reservoir r = LoadReservoir(F.cur, a.px);
+    Reservoir r = LoadReservoir(F.cur, a.px, F.prm.halfVec != 0);
     if (r.lightIdx != 0xffffffffu)
     {
         EmissiveData e = InitEmissiveData(F.sc, r.lightIdx, r.bary);
@@ -569,10 +738,10 @@ ZR_HD void SpatialPhase1(const DiFrame& F, const zr_frame_constants& g, SpatialL
         const size_t sp = Pix(F.gb, candX[i], candY[i]);
         // the neighbour's surface is built with transmission depth = false (Resampling.hlsli:505-508)
         PixelSurface pi = LoadPixelSurfaceEx(F.gb, cam, candX[i], candY[i], g.frame_num, sp, false);
-        Reservoir r_spatial = LoadReservoir(F.cur, sp);
-        Stream(pw, gl, a.r, a.ps.pos, a.ps.normal, a.ps.surface, r_spatial, pi.pos, pi.normal, pi.surface, rng);
+        Reservoir r_spatial = LoadReservoir(F.cur, sp, prm.halfVec != 0);
+        Stream(pw, gl, prm, a.r, a.ps.pos, a.ps.normal, a.ps.surface, r_spatial, pi.pos, pi.normal, pi.surface, rng);
     }
-    End(pw, a.r, rng);
+    End(pw, prm, a.r, rng);
     WriteFinal(g, F.finalRGBA, a.px, pw.r_s.target * pw.r_s.W);
 }
 

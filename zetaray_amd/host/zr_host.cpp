@@ -265,6 +265,7 @@ void DirectLighting::SetMaxTemporalM(int m) { m_params.m_max_temporal = (uint32_
 void DirectLighting::SetExtraSamplesDisocclusion(bool b) { SetFlag(ZR_DI_EXTRA_DISOCCLUSION_SAMPLING, b); }
 void DirectLighting::SetStochasticSpatial(bool b) { SetFlag(ZR_DI_STOCHASTIC_SPATIAL, b); }
 void DirectLighting::SetAlphaMin(float a) { m_params.alpha_min = a * a; ZR_CHECK(zr_pass_set_params(m_pass, &m_params)); }
+void DirectLighting::SetHalfVectorCopyShift(bool b) { SetFlag(ZR_DI_HALF_VECTOR_COPY_SHIFT, b); }
 void* DirectLighting::GetOutput(SHADER_OUT_RES i) const
 {
     if (i != SHADER_OUT_RES::FINAL) { std::fprintf(stderr, "Invalid shader output.\n"); std::abort(); }

@@ -232,6 +232,7 @@ namespace RenderPass {
         void SetExtraSamplesDisocclusion(bool b);
         void SetStochasticSpatial(bool b);
         void SetAlphaMin(float alphaMin);                 // the constant buffer holds its square (DirectLighting.cpp:404-408)
+        void SetHalfVectorCopyShift(bool b);              // USE_HALF_VECTOR_COPY_SHIFT (Emissive/Params.hlsli:12): a compile-time switch in the reference (0 in its tree), a flag here
         void* GetOutput(SHADER_OUT_RES i) const;
         void Render(Core::CommandList& cmdList);
     private:

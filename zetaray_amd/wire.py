@@ -162,6 +162,7 @@ def set_post_defaults(p):
 COMPOSIT_FIREFLY_FILTER = 1 << 10
 DI_STOCHASTIC_SPATIAL = 1 << 8
 DI_EXTRA_DISOCCLUSION_SAMPLING = 1 << 9
+DI_HALF_VECTOR_COPY_SHIFT = 1 << 11      # the reference's compile-time USE_HALF_VECTOR_COPY_SHIFT (Emissive/Params.hlsli:12) as a run-time flag of the emissive DI pass
 
 
 def default_params_sky_di():
