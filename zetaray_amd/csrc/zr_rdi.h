@@ -366,16 +366,16 @@ ZR_HD float OffsetPathTarget_CtT(const Globals& gl, const DiParams& prm, const R
     }
     else
     {
-    wi = r_curr.lightPos - candidate.pos;
-    const bool isZero = dot(wi, wi) == 0;
-    t = isZero ? 0 : length(wi);
-    wi = isZero ? wi : wi / t;
-    surface.SetWi(wi, candidate.normal);
-    V3 ln = r_curr.lightNormal;
-    if (r_curr.doubleSided && dot(-wi, ln) < 0) ln = -ln;
-    float cosThetaPrime = zr_saturate(dot(ln, -wi));
-    const float dwdA = isZero ? 0 : cosThetaPrime / (t * t);
-    target = r_curr.le * dwdA;
+        wi = r_curr.lightPos - candidate.pos;
+        const bool isZero = dot(wi, wi) == 0;
+        t = isZero ? 0 : length(wi);
+        wi = isZero ? wi : wi / t;
+        surface.SetWi(wi, candidate.normal);
+        V3 ln = r_curr.lightNormal;
+        if (r_curr.doubleSided && dot(-wi, ln) < 0) ln = -ln;
+        float cosThetaPrime = zr_saturate(dot(ln, -wi));
+        const float dwdA = isZero ? 0 : cosThetaPrime / (t * t);
+        target = r_curr.le * dwdA;
     }
     target = target * Unified(gl.sc->rho, surface).f;
     float lum = Luminance(target);
@@ -592,15 +592,15 @@ ZR_HD void Stream(PairwiseMIS& p, const Globals& gl, const DiParams& prm, const 
             if (prm.halfVec && r_i.halfVectorCopyShift) (void)HalfVectorOffsetTarget(gl, pos_c, normal_c, surface_c, wh_c, target_c_y_i);
             else
             {
-        EmissiveData e = InitEmissiveData(*gl.sc, r_i.lightIdx, r_i.bary);
-        SetSurfacePos(e, pos_c);
-        float dwdA_ = dWdA(e);
-        surface_c.SetWi(e.wi, normal_c);
-        target_c_y_i = r_i.le * dwdA_;
-        if (dot(target_c_y_i, target_c_y_i) > 0)
-            target_c_y_i = target_c_y_i * (VisibilitySegmentApprox(gl, pos_c, e.wi, e.t, normal_c, e.ID, surface_c.Transmissive()) ? 1.0f : 0.0f);
+                EmissiveData e = InitEmissiveData(*gl.sc, r_i.lightIdx, r_i.bary);
+                SetSurfacePos(e, pos_c);
+                float dwdA_ = dWdA(e);
+                surface_c.SetWi(e.wi, normal_c);
+                target_c_y_i = r_i.le * dwdA_;
+                if (dot(target_c_y_i, target_c_y_i) > 0)
+                    target_c_y_i = target_c_y_i * (VisibilitySegmentApprox(gl, pos_c, e.wi, e.t, normal_c, e.ID, surface_c.Transmissive()) ? 1.0f : 0.0f);
             }
-        target_c_y_i = target_c_y_i * Unified(rho, surface_c).f;
+            target_c_y_i = target_c_y_i * Unified(rho, surface_c).f;
         }
         m_i = Compute_m_i(p, r_c, r_i, Luminance(target_c_y_i), jacobian_i_to_c);
     }
@@ -625,17 +625,17 @@ ZR_HD void Stream(PairwiseMIS& p, const Globals& gl, const DiParams& prm, const 
         if (invertible && prm.halfVec && r_i.halfVectorCopyShift) (void)HalfVectorOffsetTarget(gl, pos_i, normal_i, surface_i, wh_i, target_i_y_c);      // (sic: r_i, PairwiseMIS.hlsli:141)
         else if (invertible)
         {
-        V3 wi_i = r_c.lightPos - pos_i;
-        const bool isZero = dot(wi_i, wi_i) == 0;
-        float t_i = isZero ? 0 : length(wi_i);
-        wi_i = isZero ? v3(0.0f) : wi_i / t_i;
-        surface_i.SetWi(wi_i, normal_i);
-        const V3 ln = dot(r_c.lightNormal, -wi_i) < 0 && r_c.doubleSided ? -r_c.lightNormal : r_c.lightNormal;
-        const float cosThetaPrime = zr_saturate(dot(ln, -wi_i));
-        const float dwdA_ = isZero ? 0 : cosThetaPrime / (t_i * t_i);
-        target_i_y_c = r_c.le * dwdA_;
-        if (dot(target_i_y_c, target_i_y_c) > 0)
-            target_i_y_c = target_i_y_c * (VisibilitySegmentApprox(gl, pos_i, wi_i, t_i, normal_i, r_c.lightID, surface_i.Transmissive()) ? 1.0f : 0.0f);
+            V3 wi_i = r_c.lightPos - pos_i;
+            const bool isZero = dot(wi_i, wi_i) == 0;
+            float t_i = isZero ? 0 : length(wi_i);
+            wi_i = isZero ? v3(0.0f) : wi_i / t_i;
+            surface_i.SetWi(wi_i, normal_i);
+            const V3 ln = dot(r_c.lightNormal, -wi_i) < 0 && r_c.doubleSided ? -r_c.lightNormal : r_c.lightNormal;
+            const float cosThetaPrime = zr_saturate(dot(ln, -wi_i));
+            const float dwdA_ = isZero ? 0 : cosThetaPrime / (t_i * t_i);
+            target_i_y_c = r_c.le * dwdA_;
+            if (dot(target_i_y_c, target_i_y_c) > 0)
+                target_i_y_c = target_i_y_c * (VisibilitySegmentApprox(gl, pos_i, wi_i, t_i, normal_i, r_c.lightID, surface_i.Transmissive()) ? 1.0f : 0.0f);
         }
         target_i_y_c = target_i_y_c * Unified(rho, surface_i).f;
     }
