@@ -1418,6 +1418,34 @@ def test_fused_halo_transfer_and_rccl_exchange_on_one_gpu(api, cornell_emissive)
     assert any(before[n][0:128, 0:32].any() for n in names)
 
 
+@pytest.mark.parametrize("kind", ["restir_pt", "di"])
+def test_halo_exchange_before_the_first_frame(api, cornell_emissive, kind):
+    """TiledRestirPT's first-contact exchange (tiling.py: one exchange through the C++ RCCL node right after it is created, so that a transport that
+    cannot work on this node is replaced before a frame depends on it) runs on a pass that has not rendered yet: the planes exist, the exchange
+    succeeds and moves zeros, and the frames rendered afterwards are the ones a pass without that exchange renders."""
+    import hashlib
+    import torch
+    from zetaray_amd import tiling
+    w, h = 256, 128
+    ip = wire.default_params()
+    digests = []
+    for trial in (False, True):
+        r = api.Renderer(cornell_emissive, w, h, params=ip, integrator=api.INTEGRATOR_RESTIR_PT if kind == "restir_pt" else api.INTEGRATOR_PATH_TRACING)
+        p = r.p_indirect
+        if kind == "di":
+            p = r.enable_direct(wire.default_params_di())
+            r.skip_indirect = True
+        if trial:
+            nh = tiling.NativeHalo(p, r.gbuffer, 0, 1, 0, [(0, (0, 0, 32, 128), (224, 0, 32, 128))])
+            nh.run(api.HALO_POST_TEMPORAL)
+            torch.cuda.synchronize()
+            nh.close()
+        for f in (1, 2, 3):
+            r.render_frame(_frame(cornell_emissive, w, h, f))
+        digests.append(hashlib.sha1((p.download() if kind == "di" else r.final()).tobytes()).hexdigest())
+    assert digests[0] == digests[1]
+
+
 def test_device_refit_of_a_large_dynamic_scene(api):
     """zr_scene_update_instances refits the BVH on the device (triangles re-transformed, node boxes re-quantised level by level).  3000-triangle
     materials scene, three instances moving / rotating / scaling over 4 frames: G-buffer, ReSTIR PT radiance, reservoir planes and ray counters equal

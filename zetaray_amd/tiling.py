@@ -228,10 +228,30 @@ class TiledRestirPT:
             flag = torch.tensor([ok], dtype=torch.int32, device=self.device)
             dist.all_reduce(flag, op=dist.ReduceOp.MIN)
             if int(flag.item()) == 1:
+                # first contact: ONE exchange of the planes as they stand (idempotent; nothing has rendered yet) before anything depends on the transport --
+                # an error code from RCCL at run time (a peer-access or IPC refusal only a real multi-GPU node can produce) sends EVERY rank to the
+                # torch.distributed path instead of ending the run in the first timed frame
+                try:
+                    post, _final = self.EXCHANGES[self.kind]
+                    native.run(self.api.HALO_POST_TEMPORAL if post else self.api.HALO_FINAL)
+                    torch.cuda.synchronize(self.device)
+                    ok = 1
+                except Exception as e:
+                    import sys
+                    print(f"[zetaray_amd.tiling] rank {rank}: the C++ RCCL halo exchange failed its first exchange ({e}); using torch.distributed P2P", file=sys.stderr)
+                    ok = 0
+                flag = torch.tensor([ok], dtype=torch.int32, device=self.device)
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if int(flag.item()) == 1:
                 self.native = native
                 self.halo_bytes = self.native.send_bytes
             else:
                 self.transport = "torch_p2p"
+                if native is not None:
+                    try:
+                        native.close()
+                    except Exception:
+                        pass
 
     def _xfer(self, which):
         """(pass, bytes per pixel) of an exchange: the reservoir exchanges belong to the halo pass, the ZR_HALO_DENOISE_* ones to the denoise pass"""
