@@ -1105,12 +1105,17 @@ def _chain(cb, prev):
     return cb
 
 
-def test_baseline_config2_cornell_1080p_restir_di_emissive_bit_exact(api, cornell_emissive, oracle_emissive):
+@pytest.mark.parametrize("half_vector", [False, True])
+def test_baseline_config2_cornell_1080p_restir_di_emissive_bit_exact(api, cornell_emissive, oracle_emissive, half_vector):
     """BASELINE config 2 (emissive half): Cornell (emissive) 1920 x 1080, ReSTIR DI K5 + K6, frames 1-3 with the camera moving on frame 3,
-    FULL frame vs the oracle, tolerance 0: radiance, both reservoir planes + target, ray counters (DirectLighting.cpp:100-190)."""
+    FULL frame vs the oracle, tolerance 0: radiance, both reservoir planes + target, ray counters (DirectLighting.cpp:100-190).
+    half_vector: the same with USE_HALF_VECTOR_COPY_SHIFT on (alpha_min 1: the boxes' rough gloss lobes qualify whenever a BSDF-sampled candidate wins)."""
     from oracle import zro
     w, h = 1920, 1080
     prm = wire.default_params_di()
+    if half_vector:
+        prm.flags |= wire.DI_HALF_VECTOR_COPY_SHIFT
+        prm.alpha_min = 1.0
     r = api.Renderer(cornell_emissive, w, h, params=wire.default_params())
     r.skip_indirect = True
     di = r.enable_direct(prm)
@@ -1129,6 +1134,8 @@ def test_baseline_config2_cornell_1080p_restir_di_emissive_bit_exact(api, cornel
         for nm, onm in (("di_A", "A"), ("di_B", "B"), ("di_target", "target")):
             assert np.array_equal(di.download_plane(nm).view(np.uint8), o.plane(onm).view(np.uint8)), f"frame {f}: DI plane {onm}"
     assert got[..., :3].max() > 0
+    if half_vector:
+        assert int(((o.plane("A").view(np.uint32).reshape(-1, 4)[:, 2] >> 21) & 1).sum()) > 0, "no reservoir carries a half vector: the case does not exercise the shift"
 
 
 def test_baseline_config2_cornell_1080p_sky_di_bit_exact(api, cornell_sky):
