@@ -84,14 +84,20 @@ def cost_share(cost, rect):
     return float(np.asarray(cost)[y0 // 32:(y0 + th + 31) // 32, x0 // 32:(x0 + tw + 31) // 32].sum())
 
 
-def choose_layout(w, h, n, cost, min_gain=1.15):
+def choose_layout(w, h, n, cost, min_gain=1.15, uniform=0.3):
     """The cost-balanced layout if it is predicted to beat the equal-area grid by at least `min_gain` in the costliest tile, else None (= the
     grid).  Measured on the MI355X (profiles/r03_tile_balance.jsonl): on the Cornell box at 16:9, whose sides are empty, the kd-split brings the
     slowest of 8 tiles from 0.83 to 0.72 ms; on the uniformly dense atrium the grid is already within 8 % of perfect balance and unequal tile shapes
-    only add apron and tail (3.60 -> 3.89 ms), so the grid stays."""
+    only add apron and tail (3.60 -> 3.89 ms), so the grid stays.  uniform (round 6, tools/tile_balance.py --uniform, profiles/r06u_tile_uniform_term.txt): 0.2 - 0.4 brings
+    the slowest of 8 Cornell tiles from 0.47 to 0.41 ms (bound 3.66 x -> 4.2 x with frame overlap), changes nothing for 2 / 4 tiles or the atrium."""
     total = float(np.asarray(cost).sum())
     if total <= 0 or n == 1:
         return None
+    if uniform > 0:
+        # the cost map holds the wave lifetimes of K11 / K14 / K16; the kernels that cost the same for every pixel whatever it shows (K1, the sorts, the
+        # neighbour search) are a uniform term on top: `uniform` x the map's mean per cell
+        cost = np.asarray(cost, np.float64)
+        cost = cost + uniform * total / cost.size
     grid = max(cost_share(cost, tile_rect(w, h, n, r)) for r in range(n))
     lay = balanced_layout(w, h, n, cost)
     bal = max(cost_share(cost, t) for t in lay)
