@@ -17,6 +17,7 @@ def main():
     ap.add_argument("--layout", choices=["equal", "cost"], default="equal",
                     help="cost: the kd-split of tiling.balanced_layout on the per-cell ray counts of 12 full-frame probe frames")
     ap.add_argument("--uniform", type=float, default=None, help="tiling.choose_layout's per-pixel term (default: the library's)")
+    ap.add_argument("--min-gain", type=float, default=None, help="tiling.choose_layout's threshold for leaving the equal-area grid (default: the library's 1.15)")
     ap.add_argument("--halves", action="store_true",
                     help="VERDICT r4 item 3(c): every device's tile of the equal-area split cut in two (32-px aligned, the longer side), the halves rendered "
                          "CONCURRENTLY on two streams -- one round of waves lasts as long as its slowest wave, a second independent half fills the slots its tail leaves idle")
@@ -42,7 +43,7 @@ def main():
         for f in range(1, 13):
             probe.render_frame(scene_io.make_frame_constants(W, H, frame_num=f, num_emissives=len(sc.emissives), **cam))
         torch.cuda.synchronize()
-        layout = tiling.choose_layout(W, H, a.world, probe.owned_cost_cells(), **({} if a.uniform is None else dict(uniform=a.uniform)))
+        layout = tiling.choose_layout(W, H, a.world, probe.owned_cost_cells(), **({} if a.uniform is None else dict(uniform=a.uniform)), **({} if a.min_gain is None else dict(min_gain=a.min_gain)))
         probe.r.p_indirect.enable_cost_map(False)
         t0 = time.perf_counter()
         for f in range(13, 21):
