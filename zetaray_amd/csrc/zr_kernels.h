@@ -472,10 +472,16 @@ __device__ __forceinline__ void RptReplayList(rpt::RptFrame& F, const zr_frame_c
         for (uint32_t i = block * blockDim.x + threadIdx.x; i < n; i += numBlocks * blockDim.x) RptReplayPixel<PASS, EMISSIVE, TEX>(F, g, list[i], stack, cnt);
     if (n) FlushRayCounters(counters, cnt);
 }
-static constexpr uint32_t kReplayPersistentBlocks = 768;      // 3 resident waves per SIMD x 1024 SIMDs / 4 waves per block
+// the replay kernels wait for memory with their VALUs idle 30 - 40 % of the time (profiles/r06_pmc_rpt_atrium.json), so they take the spills of 128 VGPRs for a fourth
+// wave per SIMD: atrium temporal replays 1.155 -> 1.02 ms (3 waves, 144 VGPRs, 768 blocks before), frame 14.7 -> 14.35 ms; 5 waves: 1.15 (profiles/r06v_ab_replay_waves.txt)
+#ifndef ZR_WAVES_REPLAY_N
+#define ZR_WAVES_REPLAY_N 4
+#endif
+#define ZR_WAVES_REPLAY __attribute__((amdgpu_waves_per_eu(ZR_WAVES_REPLAY_N, ZR_WAVES_REPLAY_N)))
+static constexpr uint32_t kReplayPersistentBlocks = 256u * ZR_WAVES_REPLAY_N;      // what is resident at once: N waves per SIMD x 1024 SIMDs / 4 waves per block
 // counts: {entries of list A, entries of list B}; counts[4], counts[5]: the two cursors (zeroed with the counts)
 template<int PASS_A, bool EMISSIVE, bool TEX>
-__global__ void __launch_bounds__(kBlock) k_rpt_replay(rpt::RptFrame F, zr_frame_constants g, const uint32_t* listA, const uint32_t* listB, uint32_t* counts,
+__global__ void __launch_bounds__(kBlock) ZR_WAVES_REPLAY k_rpt_replay(rpt::RptFrame F, zr_frame_constants g, const uint32_t* listA, const uint32_t* listB, uint32_t* counts,
     unsigned long long* counters)
 {
     F.prm.emissive = EMISSIVE ? 1u : 0u; F.prm.textured = TEX ? 1u : 0u;
