@@ -275,6 +275,96 @@ def test_frame_overlap_changes_nothing(api, cornell_emissive, oracle_emissive, c
     assert finp == fin12 and cp == c12, ([a == b for a, b in zip(finp, fin12)], cp, c12)
 
 
+def _back_to_back(api, scene, w, h, prm, frames, mode, cam_of_frame, mover=None, light=None):
+    """`frames` ReSTIR PT frames submitted WITHOUT a host wait in between (what bench.py times; the digests of _overlap_digest wait for every frame, so there
+    the two halves of consecutive frames never actually share the device), optionally with an instance moved before every frame from the third on;
+    mode: None = plain order, "carry" / "product" = zr_pass_set_frame_overlap.  Returns the digest of the last frame's planes, of its FINAL alone, the ray counters."""
+    import hashlib
+    import copy
+    sc = copy.copy(scene)       # the arrays the sequence rewrites are this run's own (the fixture is shared)
+    sc.instances, sc.instance_to_world, sc.emissives = scene.instances.copy(), scene.instance_to_world.copy(), scene.emissives.copy()
+    r = api.Renderer(sc, w, h, params=prm, integrator=api.INTEGRATOR_RESTIR_PT)
+    if mode is not None:
+        r.enable_frame_overlap(True, mode == "carry")
+    prev, xf = None, {}
+    t0 = sc.instances["translation"][mover].copy() if mover is not None else None
+    l0 = sc.instances["translation"][light].copy() if light is not None else None
+    for f in range(1, frames + 1):
+        if mover is not None and f >= 3:
+            ang = 0.05 * (f - 2)
+            scene_io.move_instance(sc, mover, translation=t0 + np.float32([0.03 * (f - 2), 0.01 * (f - 2), -0.02 * (f - 2)]),
+                                   rotation=np.array([0.0, np.sin(ang / 2), 0.0, np.cos(ang / 2)], np.float32), xform_of=xf)
+            r.scene.update_instances(sc.instances, sc.instance_to_world)
+        if light is not None and f >= 3:
+            a = 0.05 * (f - 2)
+            inst, xw, first, tris = scene_io.move_emissive_instance(sc, light, translation=l0 + np.float32([0.02 * (f - 2), -0.01 * (f - 2), 0.015 * (f - 2)]),
+                                                                     rotation=np.array([0.0, np.sin(a / 2), 0.0, np.cos(a / 2)], np.float32), xform_of=xf)
+            r.scene.update_emissives(tris, first); r.scene.update_instances(inst, xw)
+            if f % 4 == 0:
+                r.invalidate_alias_table()       # the next PRELIGHTING render rebuilds it (on the first half's stream under overlap)
+        cb = _frame(sc, w, h, f, **cam_of_frame(f))
+        if prev is not None:
+            cb["prev_view"], cb["prev_view_inv"], cb["prev_camera_jitter"] = prev["curr_view"], prev["curr_view_inv"], prev["curr_camera_jitter"]
+        prev = cb.copy()
+        r.render_frame(cb)
+    fin = r.final()
+    hh = hashlib.sha1(fin.tobytes())
+    for nm in ("B", "C", "D", "E", "F", "G", "target"):
+        hh.update(r.p_indirect.download_plane(nm).tobytes())
+    hh.update((r.p_indirect.download_plane("A") & 0xffffff).tobytes())
+    return hh.hexdigest(), hashlib.sha1(fin.tobytes()).hexdigest(), r.p_indirect.read_counters()
+
+
+def test_frame_overlap_back_to_back_frames(api, cornell_emissive):
+    """Frames in flight for real: 24 frames of the 1920 x 1080 Cornell box with a moving camera, and 16 of a 3000-triangle materials scene whose largest
+    instance moves every frame (zr_scene_update_instances between the frames: the refit and the previous-structure swap are ordered against BOTH streams),
+    submitted without a host wait.  Carry mode: every plane of the last frame equals the plain order's; product mode: its FINAL and the ray counters do.
+    The same with the Cornell box's light moving (zr_scene_update_emissives + _instances before every frame, the alias table invalidated every fourth).
+    Two or three runs of each overlapped sequence, so that a race has more than one chance to show."""
+    w, h = 1920, 1080
+    cam = lambda f: dict(cam_pos=(0.01 * max(0, f - 3), 1.2, -4.043))
+    plain = _back_to_back(api, cornell_emissive, w, h, wire.default_params(), 24, None, cam)
+    for rep in range(3):
+        carry = _back_to_back(api, cornell_emissive, w, h, wire.default_params(), 24, "carry", cam)
+        assert carry == plain, (rep, carry, plain)
+        prod = _back_to_back(api, cornell_emissive, w, h, wire.default_params(), 24, "product", cam)
+        assert prod[1:] == plain[1:], (rep, prod, plain)
+    sc = scene_io.make_synthetic_scene(num_tris=3000, num_emissive=150, seed=11)
+    cand = [i for i in range(1, len(sc.instances)) if sc.instance_mask[i] & wire.SUBGROUP_NON_EMISSIVE]
+    idx = max(cand, key=lambda i: int(sc.instance_num_tris[i]))
+    cam2 = lambda f: dict(cam_pos=(0.005 * max(0, f - 3), 0, -3.5))
+    plain = _back_to_back(api, sc, w, h, wire.default_params(), 16, None, cam2, mover=idx)
+    for rep in range(3):
+        carry = _back_to_back(api, sc, w, h, wire.default_params(), 16, "carry", cam2, mover=idx)
+        assert carry == plain, ("moving instance", rep, carry, plain)
+        prod = _back_to_back(api, sc, w, h, wire.default_params(), 16, "product", cam2, mover=idx)
+        assert prod[1:] == plain[1:], ("moving instance", rep, prod, plain)
+    # bench.py's own path (a TiledRestirPT of one rank: stage_temporal + stage_spatial per frame) in the product mode
+    import hashlib
+    from zetaray_amd import tiling
+    plain = _back_to_back(api, cornell_emissive, w, h, wire.default_params(), 24, None, cam)
+    for rep in range(2):
+        t = tiling.TiledRestirPT(cornell_emissive, w, h, 1, 0, params=wire.default_params())
+        t.enable_frame_overlap(True)
+        prev = None
+        for f in range(1, 25):
+            cb = _frame(cornell_emissive, w, h, f, **cam(f))
+            if prev is not None:
+                cb["prev_view"], cb["prev_view_inv"], cb["prev_camera_jitter"] = prev["curr_view"], prev["curr_view_inv"], prev["curr_camera_jitter"]
+            prev = cb.copy()
+            t.render_frame(cb)
+        assert (hashlib.sha1(t.r.final().tobytes()).hexdigest(), t.r.p_indirect.read_counters()) == plain[1:], ("tiled, one rank", rep)
+        del t
+    # a moving light: emissive records + its instance updated before every frame, the alias table rebuilt every fourth
+    lidx = [i for i in range(len(cornell_emissive.instances)) if cornell_emissive.instances["base_emissive_tri_offset"][i] != 0xFFFFFFFF][0]
+    plain = _back_to_back(api, cornell_emissive, w, h, wire.default_params(), 16, None, cam, light=lidx)
+    for rep in range(2):
+        carry = _back_to_back(api, cornell_emissive, w, h, wire.default_params(), 16, "carry", cam, light=lidx)
+        assert carry == plain, ("moving light", rep, carry, plain)
+        prod = _back_to_back(api, cornell_emissive, w, h, wire.default_params(), 16, "product", cam, light=lidx)
+        assert prod[1:] == plain[1:], ("moving light", rep, prod, plain)
+
+
 def test_frame_overlap_needs_its_tracked_gbuffer(api, cornell_emissive):
     """Two frames in flight need the G-buffer's third plane set and stream tracking, which zr_pass_set_frame_overlap gives to the G-buffer it is handed: a frame rendered
     from ANOTHER G-buffer (a renderer that replaced it on a resize and forgot) fails loudly instead of racing; handing the new one over makes it work."""
