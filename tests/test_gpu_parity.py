@@ -355,6 +355,24 @@ def test_frame_overlap_back_to_back_frames(api, cornell_emissive):
             t.render_frame(cb)
         assert (hashlib.sha1(t.r.final().tobytes()).hexdigest(), t.r.p_indirect.read_counters()) == plain[1:], ("tiled, one rank", rep)
         del t
+    # ... and of four ranks' tile objects on this one device with every halo exchange in between (no host wait anywhere): the stitched FINAL of frame 12
+    ref12 = _back_to_back(api, cornell_emissive, w, h, wire.default_params(), 12, None, cam)
+    ranks = [tiling.TiledRestirPT(cornell_emissive, w, h, 4, k, params=wire.default_params()) for k in range(4)]
+    for t in ranks:
+        t.enable_frame_overlap(True)
+    prev = None
+    for f in range(1, 13):
+        cb = _frame(cornell_emissive, w, h, f, **cam(f))
+        if prev is not None:
+            cb["prev_view"], cb["prev_view_inv"], cb["prev_camera_jitter"] = prev["curr_view"], prev["curr_view_inv"], prev["curr_camera_jitter"]
+        prev = cb.copy()
+        tiling.render_frame_in_process(ranks, cb)
+    img = np.zeros((h, w, 4), np.float32)
+    for t in ranks:
+        (x0, y0, tw, th), tile = t.final_tile()
+        img[y0:y0 + th, x0:x0 + tw] = tile
+    assert hashlib.sha1(img.tobytes()).hexdigest() == ref12[1], "four tiles, overlapped, back to back"
+    del ranks
     # a moving light: emissive records + its instance updated before every frame, the alias table rebuilt every fourth
     lidx = [i for i in range(len(cornell_emissive.instances)) if cornell_emissive.instances["base_emissive_tri_offset"][i] != 0xFFFFFFFF][0]
     plain = _back_to_back(api, cornell_emissive, w, h, wire.default_params(), 16, None, cam, light=lidx)
