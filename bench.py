@@ -604,6 +604,12 @@ def measure(args, ctx):
         wl_tag = {"restir_pt": "rpt", "restir_gi": "gi", "pt": "pt"}[args.integrator] + ("" if (W, H) == (1920, 1080) else f"_{W}x{H}")
         pmc_rel = next((q for q in (os.path.join("profiles", f"{rnd}_pmc_{wl_tag}_{scene_tag}.json") for rnd in ("r06", "r05", "r04", "r03"))
                         if os.path.exists(os.path.join(ROOT, q))), "")
+        # BASELINE config 2's halves (--config 2a / 2b: the DI pass alone on its own Cornell scene at 1080p) have profiles of their own
+        di_cfg = args.di_only and not args.textured and (W, H) == (1920, 1080) and os.path.basename(args.scene) in ("cornell_emissive.npz", "cornell.npz")
+        if di_cfg:
+            plain, scene_tag = True, "cornell"
+            pmc_rel = os.path.join("profiles", "r06_pmc_2a.json" if args.direct else "r06_pmc_2b.json")
+            pmc_rel = pmc_rel if os.path.exists(os.path.join(ROOT, pmc_rel)) else ""
         if plain and scene_tag and pmc_rel:
             table = json.load(open(os.path.join(ROOT, pmc_rel)))
             # only a profile of THESE kernel sources describes the library that was just timed
@@ -612,7 +618,8 @@ def measure(args, ctx):
                 # every permutation of the stage's kernel is a candidate ...
                 kmap = {"rpt_pathtrace": ["k_rpt_pathtrace", "k_rpt_pathtrace_w4", "k_rpt_pathtrace_tex", "k_rpt_pathtrace_coop", "k_rpt_pathtrace_coop_w4"],
                         "rpt_reconnect_spatial": ["k_rpt_stc"], "rpt_reconnect_temporal": ["k_rpt_temporal"],
-                        "gbuffer": ["k_gbuffer"], "rgi": ["k_rgi", "k_rgi_tex"], "trace": ["k_trace_simple", "k_trace"], "pt_shade": ["k_pt_shade", "k_pt_shade_tex"]}
+                        "gbuffer": ["k_gbuffer"], "rgi": ["k_rgi", "k_rgi_tex"], "trace": ["k_trace_simple", "k_trace"], "pt_shade": ["k_pt_shade", "k_pt_shade_tex"],
+                        "rdi_temporal": ["k_rdi_temporal"], "rdi_spatial": ["k_rdi_spatial"], "sdi_temporal": ["k_sdi_temporal"], "sdi_spatial": ["k_sdi_spatial"]}
                 # ... and the launch-count filter drops a permutation that only ran during warm-up
                 cands = [rec_ for k, rec_ in table.items() if k != "_meta" and k.split("<")[0] in kmap.get(dom, [])]
                 rec = max(cands, key=lambda r: r.get("launches_sampled", 0)) if cands else None
