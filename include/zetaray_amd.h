@@ -491,8 +491,9 @@ int zr_pass_read_cost_map(zr_pass* pass, void* hip_stream, uint32_t* out_cells, 
  * bounces could win back.  out = {lanes alive at the boundaries, lane slots of the waves that passed them, 32-bit words of path state carried across a
  * boundary}, accumulated since the pass was created.  Waits for the device.  No reference counterpart. */
 int zr_pass_debug_trip_stats(zr_pass* pass, uint64_t out[3]);
-/* test hook: the node count from which the ReSTIR PT pass launches K11's large-scene instantiation (4 waves per SIMD + the top of the tree in LDS;
- * default 16384 nodes = 1 MB) -- lets the parity tests run that instantiation on their small scenes.  0 restores the default.  Process-wide. */
+/* test hook: the node count from which the ReSTIR PT pass launches K11's node-cached instantiation (4 waves per SIMD + the top of the tree in LDS).  Default 1: every
+ * scene with a tree (measured faster at every size in round 6; rounds 3 - 5: 16384 nodes = 1 MB) -- a huge count (0x7FFFFFFF) lets the parity tests run the other instantiation.
+ * 0 restores the default.  Process-wide. */
 int zr_debug_set_large_scene_nodes(uint32_t num_nodes);
 /* test hook: the deepest tree the DEVICE builder (ZR_BVH_BUILD=device, ZR_SCENE_UPDATE=rebuild) may produce, in levels.  The default, 21, is what a
  * lane's traversal stack holds (3 entries per level of 64); a node whose key range could not fit below the cap if cut unevenly is cut into four

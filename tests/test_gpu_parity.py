@@ -1147,15 +1147,16 @@ def test_half_conversion_instructions_match_portable_code(api):
     assert (a.value, b.value) == (0, 0)
 
 
-def test_restir_pt_large_scene_kernel_build_on_gpu(api):
-    """K11 has a second build for scenes whose BVH exceeds the caches (4 waves per SIMD + the top of the tree in LDS, zr_kernels.h);
-    zr_debug_set_large_scene_nodes(1) selects it for the small test scene: same bit-exact comparison as the materials / RR test."""
+def test_restir_pt_uncached_kernel_build_on_gpu(api):
+    """K11 has two builds: 4 waves per SIMD + the top of the tree in LDS (the default for every scene with a tree since round 6: every other ReSTIR PT test runs it) and
+    the one without the node cache (3 waves for the general material class); zr_debug_set_large_scene_nodes(0x7FFFFFFF) selects the latter: same bit-exact
+    comparison as the materials / RR test."""
     from oracle import zro
     sc = scene_io.make_synthetic_scene(num_tris=3000, num_emissive=1500, seed=11)
     o = zro.OracleScene(sc, force_bvh=True)
     prm = wire.default_params()
     prm.max_non_tr_bounces, prm.max_glossy_tr_bounces = 6, 8
-    assert api.lib().zr_debug_set_large_scene_nodes(1) == 0
+    assert api.lib().zr_debug_set_large_scene_nodes(0x7FFFFFFF) == 0
     try:
         _rpt_compare(api, sc, o, 96, 64, prm, 3, cam=dict(cam_pos=(0, 0, -3.5)))
     finally:
@@ -1165,8 +1166,8 @@ def test_restir_pt_large_scene_kernel_build_on_gpu(api):
 def test_material_class_kernels_change_nothing(api, cornell_emissive, oracle_emissive, cornell_sky):
     """K11 / K14 / K16 (and K9, K5 - K8, K10) have a second permutation for scenes of the plain material class (no metal, transmission, thin wall, coat or texture in
     the whole material table: the Cornell boxes), compiled without the code of those lobes.  The other ReSTIR PT tests of this file run it on
-    the Cornell box by default; here the same box renders with the general kernels (zr_debug_set_material_class_kernels(0)), with the PLAIN
-    large-scene instantiation of K11, and with sun + sky lighting through the general kernels: all bit-exact against the oracle, hence
+    the Cornell box by default; here the same box renders with the general kernels (zr_debug_set_material_class_kernels(0)) in both instantiations of K11 (with and
+    without the LDS node cache), with the PLAIN node-cached one, and with sun + sky lighting through the general kernels: all bit-exact against the oracle, hence
     identical to each other.  A scene with one metallic material is of the general class."""
     from oracle import zro
     L = api.lib()
@@ -1174,7 +1175,7 @@ def test_material_class_kernels_change_nothing(api, cornell_emissive, oracle_emi
     assert api.Scene(scene_io.make_synthetic_scene(num_tris=300, num_emissive=100, seed=3)).material_class() == 0
     try:
         for enable, large in ((0, 0), (1, 1), (0, 1)):
-            assert L.zr_debug_set_material_class_kernels(enable) == 0 and L.zr_debug_set_large_scene_nodes(1 if large else 0) == 0
+            assert L.zr_debug_set_material_class_kernels(enable) == 0 and L.zr_debug_set_large_scene_nodes(1 if large else 0x7FFFFFFF) == 0
             _rpt_compare(api, cornell_emissive, oracle_emissive, 200, 120, wire.default_params(), 4)
         assert L.zr_debug_set_material_class_kernels(0) == 0 and L.zr_debug_set_large_scene_nodes(0) == 0
         w, h = 96, 64

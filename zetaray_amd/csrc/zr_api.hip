@@ -779,7 +779,11 @@ struct QueueStorage
 };
 
 static constexpr uint32_t kRptListWords = 12;      // replay work-list counts + cursors of the ReSTIR PT pass (layout: where the buffer is allocated)
-static constexpr uint32_t kLargeSceneNodes = 16384;     // BVH4 nodes (64 B each): 1 MB of nodes and up counts as "does not fit the caches"
+// the node count from which K11 runs as k_rpt_pathtrace_w4 (4 waves per SIMD + the top 32 nodes of the tree in LDS).  Rounds 3 - 5: 16384 (1 MB of nodes = "does not fit
+// the caches"; smaller scenes tied).  Round 6, re-measured on the collapsed trees (profiles/r06w_ab_k11_node_cache_small_scenes.txt): the cached build wins at every size --
+// Cornell PLAIN K11 0.699 -> 0.679 ms (its 13 nodes are all in LDS), general Cornell 0.817 -> 0.803, sun + sky 0.899 -> 0.874, a 20 k-triangle scene 5.69 -> 5.26 -- so every
+// scene that has a tree takes it; the other instantiation stays selectable (zr_debug_set_large_scene_nodes) and covered by the parity tests.
+static constexpr uint32_t kLargeSceneNodes = 1;
 static std::atomic<uint32_t> g_largeSceneNodes{kLargeSceneNodes};
 static std::atomic<bool> g_materialClassKernels{true};      // zr_debug_set_material_class_kernels: plain scenes run the PLAIN kernel permutations
 // the PLAIN kernel permutations apply: the scene's material table is of the plain class (and has no texture heap)

@@ -38,6 +38,7 @@ static constexpr int kRptBlock = ZR_RPT_BLOCK;
 #define ZR_WAVES_MIN(n) __attribute__((amdgpu_waves_per_eu(n)))
 // (with one-wave blocks 3 and 4 waves tie on small scenes -- 0.945 / 0.950 ms Cornell, 5: 1.12 -- and 3 waves spill a third of the bytes (PMC: 0.56 GB per
 // launch against 1.44 GB), so scenes whose BVH fits the caches run at 3; large scenes take k_rpt_pathtrace_w4)
+// (round 6: on the collapsed trees k_rpt_pathtrace_w4 -- 4 waves + the LDS node cache -- wins at every scene size and is what the host launches, zr_api.hip kLargeSceneNodes)
 // Occupancy targets as numbers (`make variant EXTRA=-DZR_WAVES_STC_N=3`: a parenthesised macro value does not survive make + sh quoting).
 // The PLAIN permutations (material-class kernels, zr_tu_rpt_e.hip) have their own: a third of the code, other register needs.
 #ifndef ZR_WAVES_PATHTRACE_N
@@ -314,7 +315,7 @@ __global__ void __launch_bounds__(kRptBlock) ZR_WAVES_PATHTRACE k_rpt_pathtrace(
 { RptPathtraceBody<EMISSIVE, false, false, false, PLAIN>(F, g, tilesX, counters); }
 // The same kernel at 4 waves per SIMD (128 VGPRs, more spills): used for scenes whose BVH does not fit the caches, where the inline
 // traversal is latency-bound and the extra wave hides more than the spills cost (380 k-triangle atrium: 11.7 -> 10.6 ms; on the
-// 58-triangle Cornell box both take 1.16 ms, and the 3-wave build moves 5x less spill traffic, so small scenes keep it).
+// 58-triangle Cornell box both took 1.16 ms in round 3; round 6: 0.817 -> 0.803 general, 0.699 -> 0.679 PLAIN, whose tree is then all in LDS -- every scene takes it).
 template<bool EMISSIVE, bool PLAIN = false>
 __global__ void __launch_bounds__(kRptBlock) ZR_WAVES_PATHTRACE_LARGE k_rpt_pathtrace_w4(rpt::RptFrame F, zr_frame_constants g, uint32_t tilesX, unsigned long long* counters)
 { RptPathtraceBody<EMISSIVE, false, true, false, PLAIN>(F, g, tilesX, counters); }
